@@ -1,0 +1,251 @@
+"""ctypes front-end of the CPU oracle (oracle/ss_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (seekstorm_amd) must never import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+
+OP_AND, OP_OR = 0, 1
+RT_COUNT, RT_TOPK, RT_TOPKCOUNT = 0, 1, 2
+CT_ARRAY, CT_BITMAP, CT_RLE = 1, 2, 3
+
+u8p = C.POINTER(C.c_uint8)
+u16p = C.POINTER(C.c_uint16)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+f32p = C.POINTER(C.c_float)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        build()
+    L = C.CDLL(_LIB)
+    L.so_int_to_byte4.restype = C.c_uint8
+    L.so_int_to_byte4.argtypes = [C.c_uint32]
+    L.so_byte4_to_int.restype = C.c_uint32
+    L.so_byte4_to_int.argtypes = [C.c_uint8]
+    L.so_avgdl.restype = C.c_float
+    L.so_avgdl.argtypes = [C.c_uint64, C.c_uint64]
+    L.so_bm25_component_cache.argtypes = [C.c_float, f32p]
+    L.so_idf.restype = C.c_float
+    L.so_idf.argtypes = [C.c_uint64, C.c_uint64]
+    L.so_bm25_term.restype = C.c_float
+    L.so_bm25_term.argtypes = [C.c_float, C.c_uint32, C.c_float]
+    L.so_splitmix64.restype = C.c_uint64
+    L.so_splitmix64.argtypes = [C.c_uint64]
+    L.so_h.restype = C.c_uint64
+    L.so_h.argtypes = [C.c_uint64] * 3
+    L.so_lex_doclen.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, u8p, u8p]
+    L.so_lex_term_postings.restype = C.c_uint64
+    L.so_lex_term_postings.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, u32p, u16p, C.c_uint64]
+    L.so_vec_gen.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, f32p]
+    L.so_shard_build.restype = C.c_void_p
+    L.so_shard_build.argtypes = [C.c_uint64, u8p, C.c_uint32, u64p, u32p, u16p]
+    L.so_shard_free.argtypes = [C.c_void_p]
+    L.so_shard_avgdl.restype = C.c_float
+    L.so_shard_avgdl.argtypes = [C.c_void_p]
+    L.so_shard_posting_count.restype = C.c_uint64
+    L.so_shard_posting_count.argtypes = [C.c_void_p, C.c_uint32]
+    L.so_shard_container.restype = C.c_int
+    L.so_shard_container.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, u32p, u32p, f32p]
+    L.so_shard_decode_block.restype = C.c_uint32
+    L.so_shard_decode_block.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, u16p]
+    for fn in (L.so_search_lex, L.so_search_lex_exhaustive):
+        fn.restype = C.c_uint32
+    L.so_search_lex.argtypes = [C.c_void_p, C.c_uint32, u32p, C.c_int, C.c_uint32, C.c_int, u32p, f32p, u64p]
+    L.so_search_lex_exhaustive.argtypes = [C.c_void_p, C.c_uint32, u32p, C.c_int, C.c_uint32, u32p, f32p, u64p]
+    L.so_query_stats.argtypes = [C.c_void_p, C.c_uint32, u32p, u64p, u64p]
+    L.so_normalize_f32.argtypes = [f32p, C.c_uint32]
+    L.so_dot_f32.restype = C.c_float
+    L.so_dot_f32.argtypes = [f32p, f32p, C.c_uint32]
+    L.so_dot_f32_lanes8.restype = C.c_float
+    L.so_dot_f32_lanes8.argtypes = [f32p, f32p, C.c_uint32]
+    L.so_vec_search.restype = C.c_uint32
+    L.so_vec_search.argtypes = [f32p, C.c_uint64, C.c_uint32, u32p, f32p, C.c_uint32, C.c_float, C.c_int,
+                                u32p, f32p, u64p, u64p]
+    L.so_vector_score_field.restype = C.c_float
+    L.so_vector_score_field.argtypes = [C.c_float]
+    L.so_threshold_raw.restype = C.c_float
+    L.so_threshold_raw.argtypes = [C.c_float]
+    L.so_merge.restype = C.c_uint32
+    L.so_merge.argtypes = [C.c_int, u64p, f32p, C.c_uint32, u64p, f32p, C.c_uint32, C.c_uint32, C.c_uint32,
+                           u64p, f32p, u8p]
+    _lib = L
+    return L
+
+
+# ---------------------------------------------------------------- synthetic corpora
+LEX_SEED = 0x5EEC5701
+VEC_SEED = 0xC051AE01
+VECQ_SEED = 0xC051AE02
+N_VOCAB = 4096
+
+
+def len_table():
+    """1024 log-normal quantiles of doc length, clamp [8,2000], as SmallFloat bytes."""
+    from statistics import NormalDist
+    nd = NormalDist()
+    L = lib()
+    out = np.zeros(1024, np.uint8)
+    for i in range(1024):
+        z = nd.inv_cdf((i + 0.5) / 1024.0)
+        ln = int(round(np.exp(np.log(120.0) + 0.6 * z)))
+        ln = min(max(ln, 8), 2000)
+        out[i] = L.so_int_to_byte4(ln)
+    return out
+
+
+def term_thresholds(n_vocab=N_VOCAB):
+    """df_t/N log-uniform in [0.05%, 20%] by term index, as 32-bit compare thresholds."""
+    t = np.arange(n_vocab, dtype=np.float64)
+    frac = 0.0005 * (0.2 / 0.0005) ** (t / max(n_vocab - 1, 1))
+    return np.minimum(np.floor(frac * 2.0 ** 32), 2.0 ** 32 - 1).astype(np.uint32)
+
+
+def lex_doclen(n_docs, seed=LEX_SEED):
+    tab = len_table()
+    out = np.empty(n_docs, np.uint8)
+    lib().so_lex_doclen(seed, 0, n_docs, _p(tab, u8p), _p(out, u8p))
+    return out
+
+
+def lex_term(term, thresh32, n_docs, seed=LEX_SEED):
+    L = lib()
+    n = L.so_lex_term_postings(seed, term, int(thresh32), n_docs, None, None, 0)
+    docs = np.empty(n, np.uint32)
+    tfs = np.empty(n, np.uint16)
+    L.so_lex_term_postings(seed, term, int(thresh32), n_docs, _p(docs, u32p), _p(tfs, u16p), n)
+    return docs, tfs
+
+
+def lex_corpus(n_docs, terms, seed=LEX_SEED, thresholds=None):
+    """Decoded postings (CSR) of the given vocabulary term ids; CSR row i <-> terms[i]."""
+    th = term_thresholds() if thresholds is None else thresholds
+    offs = [0]
+    dl, tl = [], []
+    for t in terms:
+        d, f = lex_term(int(t), th[int(t)], n_docs, seed)
+        dl.append(d)
+        tl.append(f)
+        offs.append(offs[-1] + len(d))
+    docs = np.concatenate(dl) if dl else np.zeros(0, np.uint32)
+    tfs = np.concatenate(tl) if tl else np.zeros(0, np.uint16)
+    return np.asarray(offs, np.uint64), docs.astype(np.uint32), tfs.astype(np.uint16)
+
+
+def vec_gen(seed, r0, n, dim, normalize=True):
+    out = np.empty((n, dim), np.float32)
+    lib().so_vec_gen(seed, r0, n, dim, 1 if normalize else 0, _p(out, f32p))
+    return out
+
+
+# ---------------------------------------------------------------- shard wrapper
+class Shard:
+    def __init__(self, n_docs, doclen, offs, docs, tfs):
+        self.n_docs = int(n_docs)
+        self.doclen = np.ascontiguousarray(doclen, np.uint8)
+        self.offs = np.ascontiguousarray(offs, np.uint64)
+        self.docs = np.ascontiguousarray(docs, np.uint32)
+        self.tfs = np.ascontiguousarray(tfs, np.uint16)
+        self.n_terms = len(self.offs) - 1
+        self.h = lib().so_shard_build(self.n_docs, _p(self.doclen, u8p), self.n_terms, _p(self.offs, u64p),
+                                      _p(self.docs, u32p), _p(self.tfs, u16p))
+
+    def __del__(self):
+        try:
+            lib().so_shard_free(self.h)
+        except Exception:
+            pass
+
+    @property
+    def avgdl(self):
+        return lib().so_shard_avgdl(self.h)
+
+    def df(self, t):
+        return lib().so_shard_posting_count(self.h, t)
+
+    def container(self, t, bo):
+        bid, cnt, mp = C.c_uint32(), C.c_uint32(), C.c_float()
+        ct = lib().so_shard_container(self.h, t, bo, C.byref(bid), C.byref(cnt), C.byref(mp))
+        return ct, bid.value, cnt.value, mp.value
+
+    def decode_block(self, t, bo):
+        out = np.empty(65536, np.uint16)
+        n = lib().so_shard_decode_block(self.h, t, bo, _p(out, u16p))
+        return out[:n].copy()
+
+    def _search(self, fn, terms, op, k, rt=None):
+        q = np.ascontiguousarray(terms, np.uint32)
+        od = np.empty(max(k, 1), np.uint32)
+        os_ = np.empty(max(k, 1), np.float32)
+        tot = C.c_uint64()
+        if rt is None:
+            n = fn(self.h, len(q), _p(q, u32p), op, k, _p(od, u32p), _p(os_, f32p), C.byref(tot))
+        else:
+            n = fn(self.h, len(q), _p(q, u32p), op, k, rt, _p(od, u32p), _p(os_, f32p), C.byref(tot))
+        return od[:n].copy(), os_[:n].copy(), tot.value
+
+    def search(self, terms, op, k, rt=RT_TOPKCOUNT):
+        return self._search(lib().so_search_lex, terms, op, k, rt)
+
+    def search_exhaustive(self, terms, op, k):
+        return self._search(lib().so_search_lex_exhaustive, terms, op, k)
+
+    def stats(self, terms):
+        q = np.ascontiguousarray(terms, np.uint32)
+        a, b = C.c_uint64(), C.c_uint64()
+        lib().so_query_stats(self.h, len(q), _p(q, u32p), C.byref(a), C.byref(b))
+        return a.value, b.value
+
+
+def vec_search(rows, query, k, row_doc_ids=None, threshold_raw=-3.4028234663852886e38, simd_order=True):
+    rows = np.ascontiguousarray(rows, np.float32)
+    query = np.ascontiguousarray(query, np.float32)
+    rd = None if row_doc_ids is None else np.ascontiguousarray(row_doc_ids, np.uint32)
+    od = np.empty(max(k, 1), np.uint32)
+    os_ = np.empty(max(k, 1), np.float32)
+    tot, obs = C.c_uint64(), C.c_uint64()
+    n = lib().so_vec_search(_p(rows, f32p), rows.shape[0], rows.shape[1], _p(rd, u32p), _p(query, f32p), k,
+                            threshold_raw, 1 if simd_order else 0, _p(od, u32p), _p(os_, f32p),
+                            C.byref(tot), C.byref(obs))
+    return od[:n].copy(), os_[:n].copy(), tot.value, obs.value
+
+
+def normalize(v):
+    v = np.ascontiguousarray(v, np.float32).copy()
+    lib().so_normalize_f32(_p(v, f32p), v.shape[-1])
+    return v
+
+
+def merge(mode, lex=None, vec=None, offset=0, length=10):
+    ld = np.ascontiguousarray(lex[0] if lex else [], np.uint64)
+    ls = np.ascontiguousarray(lex[1] if lex else [], np.float32)
+    vd = np.ascontiguousarray(vec[0] if vec else [], np.uint64)
+    vs = np.ascontiguousarray(vec[1] if vec else [], np.float32)
+    od = np.empty(max(length, 1), np.uint64)
+    os_ = np.empty(max(length, 1), np.float32)
+    src = np.empty(max(length, 1), np.uint8)
+    n = lib().so_merge(mode, _p(ld, u64p), _p(ls, f32p), len(ld), _p(vd, u64p), _p(vs, f32p), len(vd), offset,
+                       length, _p(od, u64p), _p(os_, f32p), _p(src, u8p))
+    return od[:n].copy(), os_[:n].copy(), src[:n].copy()

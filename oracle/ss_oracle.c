@@ -1,0 +1,695 @@
+/*
+ * ss_oracle.c -- CPU restatement of SeekStorm's query hot path (see ss_oracle.h header note).
+ * TEST INFRASTRUCTURE ONLY; never linked into the product.  Plain C11, no dependencies.
+ * Citations are file:line under /root/reference/seekstorm/src.
+ */
+#include "ss_oracle.h"
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ SmallFloat */
+/* index.rs:4237-4251 int_to_byte4 (NUM_FREE_VALUES = 24, index.rs:4232) */
+uint8_t so_int_to_byte4(uint32_t i) {
+  if (i < 24u) return (uint8_t)i;
+  uint32_t ii = i - 24u;
+  uint32_t num_bits = ii ? 32u - (uint32_t)__builtin_clz(ii) : 0u;
+  if (num_bits < 4u) return (uint8_t)(24u + ii);
+  uint32_t shift = num_bits - 4u;
+  return (uint8_t)(24u + (((ii >> shift) & 0x07u) | ((shift + 1u) << 3)));
+}
+/* index.rs:4255-4268 byte4_to_int */
+uint32_t so_byte4_to_int(uint8_t b) {
+  if (b < 24u) return b;
+  uint32_t i = (uint32_t)b - 24u, bits = i & 7u, shift = i >> 3;
+  if (shift == 0) return 24u + bits;
+  return 24u + ((bits | 8u) << (shift - 1u));
+}
+/* commit.rs:318-319: positions_sum_normalized as f32 / indexed_doc_count as f32 */
+float so_avgdl(uint64_t positions_sum_normalized, uint64_t indexed_doc_count) {
+  return (float)positions_sum_normalized / (float)indexed_doc_count;
+}
+/* commit.rs:321-325 */
+void so_bm25_component_cache(float avgdl, float* out) {
+  for (int i = 0; i < 256; i++) {
+    float q = (float)so_byte4_to_int((uint8_t)i) / avgdl;
+    out[i] = SO_K * (1.0f - SO_B + SO_B * q);
+  }
+}
+/* search.rs:3225-3230: (((N - n + 0.5) / (n + 0.5)) + 1.0).ln(), all f32 */
+float so_idf(uint64_t N, uint64_t n) {
+  float Nf = (float)N, nf = (float)n;
+  return logf(((Nf - nf + 0.5f) / (nf + 0.5f)) + 1.0f);
+}
+/* add_result.rs:1445-1447: idf * ((tf * (K + 1.0) / (tf + comp)) + SIGMA) */
+float so_bm25_term(float idf, uint32_t tf, float comp) {
+  float t = (float)tf;
+  return idf * ((t * (SO_K + 1.0f) / (t + comp)) + SO_SIGMA);
+}
+
+/* ------------------------------------------------------------------ generator */
+uint64_t so_splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  uint64_t z = x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+uint64_t so_h(uint64_t seed, uint64_t a, uint64_t b) {
+  return so_splitmix64(seed ^ (a * 0x9E3779B97F4A7C15ull) ^ (b * 0xC2B2AE3D27D4EB4Full));
+}
+void so_lex_doclen(uint64_t seed, uint64_t d0, uint64_t n, const uint8_t* tab, uint8_t* out) {
+  for (uint64_t i = 0; i < n; i++) out[i] = tab[so_h(seed, 0, d0 + i) >> 54];
+}
+uint64_t so_lex_term_postings(uint64_t seed, uint32_t term, uint32_t thresh32, uint64_t n_docs,
+                              uint32_t* out_docs, uint16_t* out_tfs, uint64_t cap) {
+  uint64_t c = 0;
+  for (uint64_t d = 0; d < n_docs; d++) {
+    uint64_t hv = so_h(seed, (uint64_t)term + 1u, d);
+    if ((uint32_t)(hv >> 32) < thresh32) {
+      if (out_docs && c < cap) {
+        uint32_t lo = (uint32_t)hv | 0x80000000u;
+        out_docs[c] = (uint32_t)d;
+        out_tfs[c] = (uint16_t)(1u + (uint32_t)__builtin_ctz(lo));
+      }
+      c++;
+    }
+  }
+  return c;
+}
+/* vector_similarity.rs:70-74 normalize_f32: norm = sqrt(sum x*x) (sequential), factor = 1/norm */
+void so_normalize_f32(float* v, uint32_t dim) {
+  volatile float s = 0.0f; /* volatile: forbid reassociation/FMA contraction, keep the reference's order */
+  for (uint32_t i = 0; i < dim; i++) {
+    volatile float p = v[i] * v[i];
+    s = s + p;
+  }
+  float f = 1.0f / sqrtf(s);
+  for (uint32_t i = 0; i < dim; i++) v[i] *= f;
+}
+void so_vec_gen(uint64_t seed, uint64_t r0, uint64_t n, uint32_t dim, int normalize, float* out) {
+  for (uint64_t r = 0; r < n; r++) {
+    float* row = out + r * dim;
+    for (uint32_t c = 0; c < dim; c++) {
+      int32_t iv = (int32_t)(uint32_t)(so_h(seed, r0 + r, c) >> 32);
+      row[c] = (float)iv * 4.656612873077392578125e-10f; /* 2^-31 */
+    }
+    if (normalize) so_normalize_f32(row, dim);
+  }
+}
+
+/* ------------------------------------------------------------------ shard model */
+typedef struct {
+  uint32_t block_id;
+  uint32_t count; /* postings in block (reference stores count-1 as u16, index.rs:786) */
+  int ctype;
+  float max_part; /* idf-less block max (index.rs:2938 get_max_score, compress_postinglist.rs:529-555) */
+  uint8_t* cont;  /* container bytes */
+  uint32_t cont_bytes;
+  const uint16_t* tf; /* decoded tf by rank (stands in for the position-pointer decode, add_result.rs:2036) */
+} so_blk;
+typedef struct {
+  uint64_t posting_count;
+  uint32_t n_blocks;
+  so_blk* blocks;
+} so_term;
+struct so_shard {
+  uint64_t n_docs;
+  uint32_t n_level_blocks;
+  uint8_t* doclen;
+  float avgdl;
+  float comp[256];
+  uint32_t n_terms;
+  so_term* terms;
+  uint64_t* off;   /* raw CSR copy for the exhaustive ground truth */
+  uint32_t* docs;
+  uint16_t* tfs;
+};
+
+static inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+static inline void wr16(uint8_t* p, uint16_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
+
+/* compress_postinglist.rs:256-332 chooser + 694 (array) / 759 (bitmap) / 832 (rle) writers */
+static void encode_block(so_blk* b, const uint32_t* docs, uint32_t n) {
+  uint32_t runs = 1;
+  for (uint32_t i = 1; i < n; i++)
+    if ((docs[i] & 0xFFFFu) != (docs[i - 1] & 0xFFFFu) + 1u) runs++;
+  /* rle writer abandons when completed runs (= runs-1 at the end) reach the threshold:
+   * threshold = count/2 if count < 4096 else 2048 (delta disabled, compress_postinglist.rs:242) */
+  uint32_t thr = (n < 4096u) ? (n / 2u) : 2048u;
+  int rle = (thr > 0u) && (runs - 1u < thr);
+  if (rle) {
+    b->ctype = SO_CT_RLE;
+    b->cont_bytes = 2u + runs * 4u;
+    b->cont = (uint8_t*)malloc(b->cont_bytes);
+    wr16(b->cont, (uint16_t)runs);
+    uint32_t r = 0, start = docs[0] & 0xFFFFu, len = 0;
+    for (uint32_t i = 1; i < n; i++) {
+      uint32_t d = docs[i] & 0xFFFFu;
+      if (d == (docs[i - 1] & 0xFFFFu) + 1u) len++;
+      else {
+        wr16(b->cont + 2 + r * 4, (uint16_t)start);
+        wr16(b->cont + 4 + r * 4, (uint16_t)len);
+        r++; start = d; len = 0;
+      }
+    }
+    wr16(b->cont + 2 + r * 4, (uint16_t)start);
+    wr16(b->cont + 4 + r * 4, (uint16_t)len);
+  } else if (n < 4096u) {
+    b->ctype = SO_CT_ARRAY;
+    b->cont_bytes = n * 2u;
+    b->cont = (uint8_t*)malloc(b->cont_bytes);
+    for (uint32_t i = 0; i < n; i++) wr16(b->cont + 2 * i, (uint16_t)(docs[i] & 0xFFFFu));
+  } else {
+    b->ctype = SO_CT_BITMAP;
+    b->cont_bytes = 8192u;
+    b->cont = (uint8_t*)calloc(8192u, 1);
+    for (uint32_t i = 0; i < n; i++) {
+      uint32_t d = docs[i] & 0xFFFFu; /* bit d <-> byte d>>3 bit d&7: compress_postinglist.rs:818-823 */
+      b->cont[d >> 3] |= (uint8_t)(1u << (d & 7u));
+    }
+  }
+}
+
+static uint32_t decode_block(const so_blk* b, uint16_t* out) {
+  uint32_t n = 0;
+  if (b->ctype == SO_CT_ARRAY) {
+    for (uint32_t i = 0; i < b->count; i++) out[n++] = rd16(b->cont + 2 * i);
+  } else if (b->ctype == SO_CT_BITMAP) {
+    for (uint32_t w = 0; w < 1024; w++) {
+      uint64_t x;
+      memcpy(&x, b->cont + 8 * w, 8);
+      while (x) { /* intersection.rs:33-108 tzcnt / blsr iteration */
+        out[n++] = (uint16_t)(w * 64u + (uint32_t)__builtin_ctzll(x));
+        x &= x - 1;
+      }
+    }
+  } else {
+    uint32_t runs = rd16(b->cont);
+    for (uint32_t r = 0; r < runs; r++) {
+      uint32_t s = rd16(b->cont + 2 + 4 * r), l = rd16(b->cont + 4 + 4 * r);
+      for (uint32_t j = 0; j <= l; j++) out[n++] = (uint16_t)(s + j); /* 0..=runlength, single.rs:235 */
+    }
+  }
+  return n;
+}
+
+so_shard* so_shard_build(uint64_t n_docs, const uint8_t* doclen, uint32_t n_terms, const uint64_t* off,
+                         const uint32_t* docs, const uint16_t* tfs) {
+  so_shard* s = (so_shard*)calloc(1, sizeof(so_shard));
+  s->n_docs = n_docs;
+  s->n_level_blocks = (uint32_t)((n_docs + SO_BLOCK - 1) / SO_BLOCK);
+  s->doclen = (uint8_t*)calloc((size_t)s->n_level_blocks * SO_BLOCK, 1);
+  memcpy(s->doclen, doclen, n_docs);
+  uint64_t psum = 0;
+  for (uint64_t d = 0; d < n_docs; d++) psum += so_byte4_to_int(doclen[d]);
+  s->avgdl = so_avgdl(psum, n_docs);
+  so_bm25_component_cache(s->avgdl, s->comp);
+  s->n_terms = n_terms;
+  s->terms = (so_term*)calloc(n_terms, sizeof(so_term));
+  uint64_t total = off[n_terms];
+  s->off = (uint64_t*)malloc((n_terms + 1) * sizeof(uint64_t));
+  memcpy(s->off, off, (n_terms + 1) * sizeof(uint64_t));
+  s->docs = (uint32_t*)malloc((total ? total : 1) * sizeof(uint32_t));
+  s->tfs = (uint16_t*)malloc((total ? total : 1) * sizeof(uint16_t));
+  memcpy(s->docs, docs, total * sizeof(uint32_t));
+  memcpy(s->tfs, tfs, total * sizeof(uint16_t));
+  for (uint32_t t = 0; t < n_terms; t++) {
+    so_term* T = &s->terms[t];
+    uint64_t b0 = off[t], b1 = off[t + 1];
+    T->posting_count = b1 - b0;
+    uint32_t nb = 0;
+    for (uint64_t i = b0; i < b1; i++)
+      if (i == b0 || (docs[i] >> 16) != (docs[i - 1] >> 16)) nb++;
+    T->n_blocks = nb;
+    T->blocks = (so_blk*)calloc(nb ? nb : 1, sizeof(so_blk));
+    uint32_t bi = 0;
+    for (uint64_t i = b0; i < b1;) {
+      uint64_t j = i;
+      while (j < b1 && (docs[j] >> 16) == (docs[i] >> 16)) j++;
+      so_blk* b = &T->blocks[bi++];
+      b->block_id = docs[i] >> 16;
+      b->count = (uint32_t)(j - i);
+      b->tf = s->tfs + i;
+      encode_block(b, docs + i, b->count);
+      float mx = 0.0f;
+      for (uint64_t p = i; p < j; p++) {
+        float v = so_bm25_term(1.0f, tfs[p], s->comp[doclen[docs[p]]]);
+        if (v > mx) mx = v;
+      }
+      b->max_part = mx;
+      i = j;
+    }
+  }
+  return s;
+}
+void so_shard_free(so_shard* s) {
+  if (!s) return;
+  for (uint32_t t = 0; t < s->n_terms; t++) {
+    for (uint32_t b = 0; b < s->terms[t].n_blocks; b++) free(s->terms[t].blocks[b].cont);
+    free(s->terms[t].blocks);
+  }
+  free(s->terms); free(s->doclen); free(s->off); free(s->docs); free(s->tfs); free(s);
+}
+float so_shard_avgdl(const so_shard* s) { return s->avgdl; }
+uint64_t so_shard_posting_count(const so_shard* s, uint32_t t) { return t < s->n_terms ? s->terms[t].posting_count : 0; }
+int so_shard_container(const so_shard* s, uint32_t t, uint32_t bo, uint32_t* bid, uint32_t* cnt, float* mp) {
+  if (t >= s->n_terms || bo >= s->terms[t].n_blocks) return 0;
+  const so_blk* b = &s->terms[t].blocks[bo];
+  if (bid) *bid = b->block_id;
+  if (cnt) *cnt = b->count;
+  if (mp) *mp = b->max_part;
+  return b->ctype;
+}
+uint32_t so_shard_decode_block(const so_shard* s, uint32_t t, uint32_t bo, uint16_t* out) {
+  if (t >= s->n_terms || bo >= s->terms[t].n_blocks) return 0;
+  return decode_block(&s->terms[t].blocks[bo], out);
+}
+
+/* ------------------------------------------------------------------ min-heap (min_heap.rs:45-53, 1193-1259) */
+typedef struct { uint32_t doc; float score; } so_res;
+typedef struct { so_res* e; uint32_t n, k; } so_heap;
+static void heap_up(so_heap* h, uint32_t i) {
+  while (i > 0) {
+    uint32_t p = (i - 1) / 2;
+    if (h->e[i].score < h->e[p].score) { so_res t = h->e[i]; h->e[i] = h->e[p]; h->e[p] = t; i = p; }
+    else break;
+  }
+}
+static void heap_down(so_heap* h, uint32_t i) {
+  for (;;) {
+    uint32_t l = 2 * i + 1, r = l + 1, m = i;
+    if (l < h->n && h->e[l].score < h->e[m].score) m = l;
+    if (r < h->n && h->e[r].score < h->e[m].score) m = r;
+    if (m == i) break;
+    so_res t = h->e[i]; h->e[i] = h->e[m]; h->e[m] = t; i = m;
+  }
+}
+/* add_topk without docid_hashset: admit while not full, else only if score > root (STRICT, min_heap.rs:1250) */
+static int heap_add_topk(so_heap* h, uint32_t doc, float score) {
+  if (h->k == 0) return 0;
+  if (h->n < h->k) { h->e[h->n].doc = doc; h->e[h->n].score = score; h->n++; heap_up(h, h->n - 1); return 1; }
+  if (score > h->e[0].score) { h->e[0].doc = doc; h->e[0].score = score; heap_down(h, 0); return 1; }
+  return 0;
+}
+static int heap_full(const so_heap* h) { return h->n >= h->k; }
+/* search.rs:3565-3593: stable sort of the heap array by score desc */
+static uint32_t heap_drain(so_heap* h, uint32_t* od, float* os) {
+  for (uint32_t i = 1; i < h->n; i++) { /* insertion sort = stable */
+    so_res x = h->e[i]; uint32_t j = i;
+    while (j > 0 && h->e[j - 1].score < x.score) { h->e[j] = h->e[j - 1]; j--; }
+    h->e[j] = x;
+  }
+  for (uint32_t i = 0; i < h->n; i++) { od[i] = h->e[i].doc; os[i] = h->e[i].score; }
+  return h->n;
+}
+
+/* ------------------------------------------------------------------ container cursors (intersection.rs:112-2013) */
+typedef struct {
+  const so_blk* b;
+  float idf;
+  uint32_t pos;      /* array: index cursor; rle: run cursor */
+  uint32_t rle_rank; /* rle: postings before run `pos` */
+  uint32_t rank;     /* rank (p_docid) of the last successful lookup */
+} so_cur;
+
+/* membership + rank of doc id d (ascending probes).  Array: galloping, intersection.rs:352-362.
+ * Bitmap: bit test + popcount rank, intersection.rs:772-794.  Rle: run walk, intersection.rs:934-. */
+static int cur_find(so_cur* c, uint32_t d) {
+  const so_blk* b = c->b;
+  if (b->ctype == SO_CT_ARRAY) {
+    uint32_t n = b->count, p = c->pos;
+    if (p >= n) return 0;
+    if (rd16(b->cont + 2 * p) < d) {
+      uint32_t bound = 2;
+      while (p + bound < n && rd16(b->cont + 2 * (p + bound)) < d) { p += bound; bound <<= 1; }
+      uint32_t hi = p + bound < n ? p + bound : n - 1;
+      uint32_t lo = p;
+      while (lo < hi) { /* first index with value >= d in (p, hi] */
+        uint32_t mid = (lo + hi) / 2;
+        if (rd16(b->cont + 2 * mid) < d) lo = mid + 1; else hi = mid;
+      }
+      p = lo;
+    }
+    c->pos = p;
+    if (p < n && rd16(b->cont + 2 * p) == d) { c->rank = p; return 1; }
+    return 0;
+  } else if (b->ctype == SO_CT_BITMAP) {
+    if (!((b->cont[d >> 3] >> (d & 7u)) & 1u)) return 0;
+    uint32_t w = d >> 6, r = 0;
+    for (uint32_t i = 0; i < w; i++) { uint64_t x; memcpy(&x, b->cont + 8 * i, 8); r += (uint32_t)__builtin_popcountll(x); }
+    uint64_t x; memcpy(&x, b->cont + 8 * w, 8);
+    uint32_t bit = d & 63u;
+    if (bit) r += (uint32_t)__builtin_popcountll(x & ((1ull << bit) - 1ull));
+    c->rank = r;
+    return 1;
+  } else {
+    uint32_t runs = rd16(b->cont);
+    while (c->pos < runs) {
+      uint32_t s = rd16(b->cont + 2 + 4 * c->pos), l = rd16(b->cont + 4 + 4 * c->pos);
+      if (d > s + l) { c->rle_rank += l + 1; c->pos++; continue; }
+      if (d < s) return 0;
+      c->rank = c->rle_rank + (d - s);
+      return 1;
+    }
+    return 0;
+  }
+}
+
+typedef struct { uint32_t ord[32]; float score; uint32_t block_id; uint32_t present; } so_bm;
+static int bm_cmp(const void* a, const void* b) {
+  const so_bm* x = (const so_bm*)a; const so_bm* y = (const so_bm*)b;
+  if (x->score > y->score) return -1;
+  if (x->score < y->score) return 1;
+  return (x->block_id > y->block_id) - (x->block_id < y->block_id);
+}
+
+/* intersection_blockid (intersection.rs:2023-2301) + intersection_docid (112-447) +
+ * add_result_multiterm_singlefield (add_result.rs:3418-3706, no filters / no phrase) */
+static void search_and(const so_shard* s, uint32_t nq, const uint32_t* qt, const float* idf, int rt,
+                       so_heap* heap, uint64_t* total) {
+  uint32_t ptr[32] = {0};
+  uint32_t nbm = 0, cap = 0;
+  for (uint32_t t = 0; t < nq; t++) if (t == 0 || s->terms[qt[t]].n_blocks < cap) cap = s->terms[qt[t]].n_blocks;
+  so_bm* bms = (so_bm*)malloc((cap ? cap : 1) * sizeof(so_bm));
+  /* block-id merge, intersection.rs:2058-2222 */
+  for (;;) {
+    int done = 0; uint32_t mx = 0;
+    for (uint32_t t = 0; t < nq; t++) {
+      const so_term* T = &s->terms[qt[t]];
+      if (ptr[t] >= T->n_blocks) { done = 1; break; }
+      if (T->blocks[ptr[t]].block_id > mx) mx = T->blocks[ptr[t]].block_id;
+    }
+    if (done) break;
+    int all = 1;
+    for (uint32_t t = 0; t < nq; t++) {
+      const so_term* T = &s->terms[qt[t]];
+      while (ptr[t] < T->n_blocks && T->blocks[ptr[t]].block_id < mx) ptr[t]++;
+      if (ptr[t] >= T->n_blocks) { done = 1; break; }
+      if (T->blocks[ptr[t]].block_id != mx) all = 0;
+    }
+    if (done) break;
+    if (!all) continue;
+    so_bm* m = &bms[nbm++];
+    m->block_id = mx; m->score = 0.0f;
+    for (uint32_t t = 0; t < nq; t++) { /* block_score = sum max_block_score, intersection.rs:2090-2097 */
+      m->ord[t] = ptr[t];
+      m->score += idf[t] * s->terms[qt[t]].blocks[ptr[t]].max_part;
+      ptr[t]++;
+    }
+  }
+  if (rt != SO_RT_COUNT) qsort(bms, nbm, sizeof(so_bm), bm_cmp); /* intersection.rs:2225 */
+  uint16_t* first = (uint16_t*)malloc(65536 * sizeof(uint16_t));
+  for (uint32_t bi = 0; bi < nbm; bi++) {
+    so_bm* m = &bms[bi];
+    if (rt == SO_RT_TOPK && heap_full(heap) && heap->k > 0 && m->score <= heap->e[0].score) break; /* 2227-2233 */
+    /* term order: non-bitmap first, then by block posting count asc (intersection.rs:258-273) */
+    uint32_t order[32];
+    for (uint32_t t = 0; t < nq; t++) order[t] = t;
+    for (uint32_t i = 1; i < nq; i++) {
+      uint32_t x = order[i]; uint32_t j = i;
+      for (; j > 0; j--) {
+        const so_blk* a = &s->terms[qt[order[j - 1]]].blocks[m->ord[order[j - 1]]];
+        const so_blk* b = &s->terms[qt[x]].blocks[m->ord[x]];
+        int abm = a->ctype == SO_CT_BITMAP, bbm = b->ctype == SO_CT_BITMAP;
+        int gt = (abm != bbm) ? (abm > bbm) : (a->count > b->count);
+        if (!gt) break;
+        order[j] = order[j - 1];
+      }
+      order[j] = x;
+    }
+    so_cur cur[32];
+    for (uint32_t i = 0; i < nq; i++) {
+      uint32_t t = order[i];
+      cur[i].b = &s->terms[qt[t]].blocks[m->ord[t]];
+      cur[i].idf = idf[t]; cur[i].pos = 0; cur[i].rle_rank = 0; cur[i].rank = 0;
+    }
+    uint32_t n0 = decode_block(cur[0].b, first);
+    for (uint32_t p0 = 0; p0 < n0; p0++) {
+      uint32_t d = first[p0];
+      int ok = 1;
+      for (uint32_t i = 1; i < nq && ok; i++) ok = cur_find(&cur[i], d);
+      if (!ok) continue;
+      cur[0].rank = p0;
+      uint32_t docid = (m->block_id << 16) | d;
+      /* add_result.rs:3503-3537 */
+      if (rt == SO_RT_COUNT) { (*total)++; continue; }
+      if (heap_full(heap) && heap->k > 0 && m->score <= heap->e[0].score) {
+        if (rt == SO_RT_TOPKCOUNT) (*total)++;
+        continue;
+      }
+      float comp = s->comp[s->doclen[docid]];
+      float bm25 = 0.0f; /* add_result.rs:1435-1449, terms in current query_list order */
+      for (uint32_t i = 0; i < nq; i++) bm25 += so_bm25_term(cur[i].idf, cur[i].b->tf[cur[i].rank], comp);
+      (*total)++;
+      heap_add_topk(heap, docid, bm25);
+    }
+  }
+  free(first); free(bms);
+}
+
+/* union_blockid / union_docid / union_scan_8|32 structure (union.rs:265, 32, 403-805).  The reference
+ * answers 2..10-term OR by sub-query decomposition (union.rs:1168-1479) whose net result is the exact
+ * top-k of the union under full BM25 over matched terms; this table scan is the
+ * reference's own formulation of the same result (used there for >10 terms / counts). */
+static void search_or(const so_shard* s, uint32_t nq, const uint32_t* qt, const float* idf, int rt,
+                      so_heap* heap, uint64_t* total) {
+  uint32_t ptr[32] = {0};
+  uint32_t cap = 0, nbm = 0;
+  for (uint32_t t = 0; t < nq; t++) cap += s->terms[qt[t]].n_blocks;
+  so_bm* bms = (so_bm*)malloc((cap ? cap : 1) * sizeof(so_bm));
+  for (;;) { /* union of block ids */
+    uint32_t mn = 0xFFFFFFFFu;
+    for (uint32_t t = 0; t < nq; t++) {
+      const so_term* T = &s->terms[qt[t]];
+      if (ptr[t] < T->n_blocks && T->blocks[ptr[t]].block_id < mn) mn = T->blocks[ptr[t]].block_id;
+    }
+    if (mn == 0xFFFFFFFFu) break;
+    so_bm* m = &bms[nbm++];
+    m->block_id = mn; m->score = 0.0f; m->present = 0;
+    for (uint32_t t = 0; t < nq; t++) {
+      const so_term* T = &s->terms[qt[t]];
+      if (ptr[t] < T->n_blocks && T->blocks[ptr[t]].block_id == mn) {
+        m->ord[t] = ptr[t]; m->present |= 1u << t;
+        m->score += idf[t] * T->blocks[ptr[t]].max_part;
+        ptr[t]++;
+      }
+    }
+  }
+  if (rt != SO_RT_COUNT) qsort(bms, nbm, sizeof(so_bm), bm_cmp);
+  uint32_t* table = (uint32_t*)malloc(65536 * sizeof(uint32_t));
+  uint16_t* tmp = (uint16_t*)malloc(65536 * sizeof(uint16_t));
+  float* mstab = nq <= 10 ? (float*)malloc(((size_t)1 << nq) * sizeof(float)) : NULL;
+  for (uint32_t bi = 0; bi < nbm; bi++) {
+    so_bm* m = &bms[bi];
+    int block_skip = heap_full(heap) && heap->k > 0 && m->score <= heap->e[0].score;
+    if (rt == SO_RT_TOPK && block_skip) break;
+    memset(table, 0, 65536 * sizeof(uint32_t));
+    for (uint32_t t = 0; t < nq; t++) { /* union.rs:418-481 scatter term bit */
+      if (!(m->present & (1u << t))) continue;
+      uint32_t n = decode_block(&s->terms[qt[t]].blocks[m->ord[t]], tmp);
+      for (uint32_t i = 0; i < n; i++) table[tmp[i]] |= 1u << t;
+    }
+    if (mstab) /* union.rs:538-546 */
+      for (uint32_t i = 0; i < (1u << nq); i++) {
+        float v = 0.0f;
+        for (uint32_t j = 0; j < nq; j++)
+          if ((i >> j) & 1u) v += (m->present & (1u << j)) ? idf[j] * s->terms[qt[j]].blocks[m->ord[j]].max_part : 0.0f;
+        mstab[i] = v;
+      }
+    uint32_t rank[32] = {0};
+    for (uint32_t d = 0; d < 65536; d++) { /* union.rs:553-592 */
+      uint32_t bits = table[d];
+      if (!bits) continue;
+      (*total)++;
+      if (!block_skip && rt != SO_RT_COUNT) {
+        float bound;
+        if (mstab) bound = mstab[bits];
+        else { bound = 0.0f; for (uint32_t j = 0; j < nq; j++) if ((bits >> j) & 1u) bound += idf[j] * s->terms[qt[j]].blocks[m->ord[j]].max_part; }
+        if (!heap_full(heap) || bound > heap->e[0].score) {
+          uint32_t docid = (m->block_id << 16) | d;
+          float comp = s->comp[s->doclen[docid]];
+          float bm25 = 0.0f;
+          for (uint32_t j = 0; j < nq; j++) /* add_result.rs:1444-1446 skips terms with bm25_flag=false */
+            if ((bits >> j) & 1u) bm25 += so_bm25_term(idf[j], s->terms[qt[j]].blocks[m->ord[j]].tf[rank[j]], comp);
+          heap_add_topk(heap, docid, bm25);
+        }
+      }
+      for (uint32_t j = 0; j < nq; j++) rank[j] += (bits >> j) & 1u;
+    }
+  }
+  free(mstab); free(tmp); free(table); free(bms);
+}
+
+uint32_t so_search_lex(const so_shard* s, uint32_t nq, const uint32_t* qt, int op, uint32_t k, int rt,
+                       uint32_t* od, float* os, uint64_t* total) {
+  uint64_t tot = 0;
+  if (nq == 0 || nq > 32) { if (total) *total = 0; return 0; }
+  float idf[32];
+  for (uint32_t t = 0; t < nq; t++) {
+    if (qt[t] >= s->n_terms) { if (total) *total = 0; return 0; }
+    idf[t] = so_idf(s->n_docs, s->terms[qt[t]].posting_count);
+  }
+  /* search.rs:2527-2541: heap size min(offset+length, indexed_doc_count) */
+  uint32_t kk = k; if ((uint64_t)kk > s->n_docs) kk = (uint32_t)s->n_docs;
+  if (rt == SO_RT_COUNT) kk = 0;
+  so_heap heap; heap.n = 0; heap.k = kk; heap.e = (so_res*)malloc((kk ? kk : 1) * sizeof(so_res));
+  if (op == SO_OP_AND || nq == 1) search_and(s, nq, qt, idf, rt, &heap, &tot);
+  else search_or(s, nq, qt, idf, rt, &heap, &tot);
+  uint32_t n = heap_drain(&heap, od, os);
+  free(heap.e);
+  if (total) *total = tot;
+  return n;
+}
+
+typedef struct { float score; uint32_t doc; } so_sd;
+static int sd_cmp(const void* a, const void* b) {
+  const so_sd* x = (const so_sd*)a; const so_sd* y = (const so_sd*)b;
+  if (x->score > y->score) return -1;
+  if (x->score < y->score) return 1;
+  return (x->doc > y->doc) - (x->doc < y->doc);
+}
+uint32_t so_search_lex_exhaustive(const so_shard* s, uint32_t nq, const uint32_t* qt, int op, uint32_t k,
+                                  uint32_t* od, float* os, uint64_t* total) {
+  float* sc = (float*)calloc(s->n_docs ? s->n_docs : 1, sizeof(float));
+  uint8_t* cnt = (uint8_t*)calloc(s->n_docs ? s->n_docs : 1, 1);
+  for (uint32_t t = 0; t < nq; t++) {
+    float idf = so_idf(s->n_docs, s->terms[qt[t]].posting_count);
+    for (uint64_t i = s->off[qt[t]]; i < s->off[qt[t] + 1]; i++) {
+      uint32_t d = s->docs[i];
+      sc[d] += so_bm25_term(idf, s->tfs[i], s->comp[s->doclen[d]]);
+      cnt[d]++;
+    }
+  }
+  uint64_t m = 0;
+  for (uint64_t d = 0; d < s->n_docs; d++) if (op == SO_OP_AND ? cnt[d] == nq : cnt[d] > 0) m++;
+  so_sd* v = (so_sd*)malloc((m ? m : 1) * sizeof(so_sd));
+  uint64_t j = 0;
+  for (uint64_t d = 0; d < s->n_docs; d++)
+    if (op == SO_OP_AND ? cnt[d] == nq : cnt[d] > 0) { v[j].score = sc[d]; v[j].doc = (uint32_t)d; j++; }
+  qsort(v, m, sizeof(so_sd), sd_cmp);
+  uint32_t n = (uint32_t)(m < k ? m : k);
+  for (uint32_t i = 0; i < n; i++) { od[i] = v[i].doc; os[i] = v[i].score; }
+  if (total) *total = m;
+  free(v); free(cnt); free(sc);
+  return n;
+}
+void so_query_stats(const so_shard* s, uint32_t nq, const uint32_t* qt, uint64_t* sum_df, uint64_t* sum_blocks) {
+  uint64_t a = 0, b = 0;
+  for (uint32_t t = 0; t < nq; t++) { a += s->terms[qt[t]].posting_count; b += s->terms[qt[t]].n_blocks; }
+  if (sum_df) *sum_df = a;
+  if (sum_blocks) *sum_blocks = b;
+}
+
+/* ------------------------------------------------------------------ vector path */
+/* vector_similarity.rs:1006-1008: a.iter().zip(b).map(|(x,y)| x*y).sum()  (sequential) */
+float so_dot_f32(const float* a, const float* b, uint32_t dim) {
+  float s = 0.0f;
+  for (uint32_t i = 0; i < dim; i++) s += a[i] * b[i];
+  return s;
+}
+/* vector_similarity.rs:1118-1142: 8 fmadd lanes over dim/8 steps, then the 8 lanes summed in order */
+float so_dot_f32_lanes8(const float* q, const float* e, uint32_t dim) {
+  float l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t steps = dim / 8;
+  for (uint32_t i = 0; i < steps; i++)
+    for (int j = 0; j < 8; j++) l[j] = __builtin_fmaf(q[i * 8 + j], e[i * 8 + j], l[j]);
+  float s = 0.0f;
+  for (int j = 0; j < 8; j++) s += l[j];
+  return s;
+}
+float so_vector_score_field(float dot) { return ((dot * (1.0f / 16129.0f)) + 1.0f) * 0.5f; }
+/* vector.rs:388-397 (Dot/Cosine arm): ((t*2)-1) / SIMILARITY_NORMALIZATION_64_I8 */
+float so_threshold_raw(float t) { return ((t * 2.0f) - 1.0f) / (1.0f / 16129.0f); }
+
+typedef struct { uint32_t doc; float score; } so_item;
+uint32_t so_vec_search(const float* rows, uint64_t n_rows, uint32_t dim, const uint32_t* row_doc, const float* q,
+                       uint32_t k, float thr, int simd_order, uint32_t* od, float* os, uint64_t* out_total,
+                       uint64_t* out_observed) {
+  /* TopK::new / push, vector.rs:366-496 */
+  so_item* items = (so_item*)malloc((k ? k : 1) * sizeof(so_item));
+  for (uint32_t i = 0; i < k; i++) { items[i].doc = 0; items[i].score = -FLT_MAX; }
+  uint32_t len = 0; uint64_t total = 0, observed = 0; float lowest = -FLT_MAX;
+  for (uint64_t r = 0; r < n_rows; r++) {
+    const float* e = rows + r * dim;
+    float score = simd_order ? so_dot_f32_lanes8(q, e, dim) : so_dot_f32(q, e, dim);
+    uint32_t doc = row_doc ? row_doc[r] : (uint32_t)r;
+    observed++;
+    if (score < thr || (len == k && score <= lowest)) continue;
+    total++;
+    if (len < k) {
+      int dup = 0;
+      for (uint32_t i = 0; i < len; i++) if (items[i].doc == doc) { if (score > items[i].score) items[i].score = score; dup = 1; break; }
+      if (!dup) { items[len].doc = doc; items[len].score = score; len++; }
+      continue;
+    }
+    uint32_t min_i = 0; float min_v = items[0].score; int dup = 0;
+    for (uint32_t i = 0; i < len; i++) {
+      if (items[i].doc == doc) { if (score > items[i].score) items[i].score = score; dup = 1; break; }
+      if (items[i].score < min_v) { min_v = items[i].score; min_i = i; }
+    }
+    if (dup) continue;
+    if (score > min_v) { lowest = min_v; items[min_i].doc = doc; items[min_i].score = score; }
+  }
+  for (uint32_t i = 1; i < len; i++) { /* vector.rs:1472 sort desc (stable) */
+    so_item x = items[i]; uint32_t j = i;
+    while (j > 0 && items[j - 1].score < x.score) { items[j] = items[j - 1]; j--; }
+    items[j] = x;
+  }
+  for (uint32_t i = 0; i < len; i++) { od[i] = items[i].doc; os[i] = items[i].score; }
+  if (out_total) *out_total = total;
+  if (out_observed) *out_observed = observed;
+  free(items);
+  return len;
+}
+
+/* ------------------------------------------------------------------ merge / RRF */
+typedef struct { uint64_t doc; float score; uint8_t src; uint32_t seq; } so_m;
+static int m_cmp_desc_stable(const void* a, const void* b) {
+  const so_m* x = (const so_m*)a; const so_m* y = (const so_m*)b;
+  if (x->score > y->score) return -1;
+  if (x->score < y->score) return 1;
+  return (x->seq > y->seq) - (x->seq < y->seq);
+}
+static int m_cmp_desc_doc(const void* a, const void* b) {
+  const so_m* x = (const so_m*)a; const so_m* y = (const so_m*)b;
+  if (x->score > y->score) return -1;
+  if (x->score < y->score) return 1;
+  return (x->doc > y->doc) - (x->doc < y->doc);
+}
+uint32_t so_merge(int mode, const uint64_t* ld, const float* ls, uint32_t nl, const uint64_t* vd, const float* vs,
+                  uint32_t nv, uint32_t offset, uint32_t length, uint64_t* od, float* os, uint8_t* osrc) {
+  uint32_t cap = nl + nv + 1, n = 0;
+  so_m* out = (so_m*)malloc(cap * sizeof(so_m));
+  if (mode == 0) { for (uint32_t i = 0; i < nl; i++) { out[n].doc = ld[i]; out[n].score = ls[i]; out[n].src = 0; out[n].seq = n; n++; } }
+  else if (mode == 1) { for (uint32_t i = 0; i < nv; i++) { out[n].doc = vd[i]; out[n].score = vs[i]; out[n].src = 1; out[n].seq = n; n++; } }
+  else { /* search.rs:1962-2035: k = 0.6, 0-based rank over the cross-shard concatenation sorted desc */
+    so_m* L = (so_m*)malloc((nl + 1) * sizeof(so_m));
+    so_m* V = (so_m*)malloc((nv + 1) * sizeof(so_m));
+    for (uint32_t i = 0; i < nl; i++) { L[i].doc = ld[i]; L[i].score = ls[i]; L[i].seq = i; }
+    for (uint32_t i = 0; i < nv; i++) { V[i].doc = vd[i]; V[i].score = vs[i]; V[i].seq = i; }
+    qsort(L, nl, sizeof(so_m), m_cmp_desc_stable);
+    qsort(V, nv, sizeof(so_m), m_cmp_desc_stable);
+    const float kk = 0.6f;
+    for (uint32_t i = 0; i < nl; i++) { /* insert: a later duplicate doc id overwrites (AHashMap::insert) */
+      uint32_t j = 0; for (; j < n; j++) if (out[j].doc == L[i].doc) break;
+      out[j].doc = L[i].doc; out[j].score = 1.0f / (kk + (float)i); out[j].src = 0; out[j].seq = j;
+      if (j == n) n++;
+    }
+    for (uint32_t i = 0; i < nv; i++) {
+      float r = 1.0f / (kk + (float)i);
+      uint32_t j = 0; for (; j < n; j++) if (out[j].doc == V[i].doc) break;
+      if (j < n) { out[j].score += r; out[j].src = 2; }
+      else { out[n].doc = V[i].doc; out[n].score = r; out[n].src = 1; out[n].seq = n; n++; }
+    }
+    free(L); free(V);
+  }
+  /* search.rs:2103-2105 stable sort by score desc; lexical/vector keep concatenation order on ties,
+   * hybrid order on ties is hash order in the reference -> doc id asc here (deterministic) */
+  qsort(out, n, sizeof(so_m), mode == 2 ? m_cmp_desc_doc : m_cmp_desc_stable);
+  uint32_t w = 0;
+  for (uint32_t i = offset; i < n && w < length; i++, w++) { od[w] = out[i].doc; os[w] = out[i].score; if (osrc) osrc[w] = out[i].src; }
+  free(out);
+  return w;
+}

@@ -1,0 +1,113 @@
+/*
+ * ss_oracle.h -- CPU restatement ("oracle") of SeekStorm's query hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only
+ * as the checker / reported CPU baseline.  The product (seekstorm_amd/) never links it.
+ *
+ * Parity status: the reference (Rust, ~50 un-vendored crates, no Cargo.lock, no toolchain
+ * in this image) cannot be built here, and its own tests pin only result COUNTS
+ * (tests/test.rs:150-208, 676-744).  This restatement is therefore pinned by
+ *   (1) those count assertions, re-enacted in tests/test_oracle_kat.py,
+ *   (2) the formula KATs of SURVEY.md section 8(c) (SmallFloat, idf, BM25, RRF),
+ *   (3) an independent naive numpy restatement (oracle/naive.py) that must agree.
+ * Score/rank parity against the real Rust binary is "parity unpinned" (see DESIGN.md).
+ *
+ * Every function cites the reference file:line (relative to /root/reference/seekstorm/src)
+ * it follows.
+ */
+#ifndef SS_ORACLE_H
+#define SS_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- scoring constants: add_result.rs:20-22 ---- */
+#define SO_K 1.2f
+#define SO_B 0.75f
+#define SO_SIGMA 0.0f
+#define SO_BLOCK 65536u /* ROARING_BLOCK_SIZE index.rs:115 */
+
+/* ---- SmallFloat: index.rs:4237-4279 ---- */
+uint8_t so_int_to_byte4(uint32_t i);
+uint32_t so_byte4_to_int(uint8_t b);
+
+/* bm25_component_cache: commit.rs:318-325 (same at index.rs:3786-3792) */
+float so_avgdl(uint64_t positions_sum_normalized, uint64_t indexed_doc_count);
+void so_bm25_component_cache(float avgdl, float* out256);
+/* idf: search.rs:3225-3230 */
+float so_idf(uint64_t indexed_doc_count, uint64_t posting_count);
+/* one term of get_bm25f_multiterm_singlefield: add_result.rs:1444-1449 */
+float so_bm25_term(float idf, uint32_t tf, float comp);
+
+/* ---- synthetic corpus generator (integer-exact variant) ---- */
+uint64_t so_splitmix64(uint64_t x);
+uint64_t so_h(uint64_t seed, uint64_t a, uint64_t b);
+/* doc-length bytes for docs [d0, d0+n): len_table1024 holds SmallFloat bytes per quantile */
+void so_lex_doclen(uint64_t seed, uint64_t d0, uint64_t n, const uint8_t* len_table1024, uint8_t* out);
+/* postings of term t over docs [0,n_docs): posting present iff (h(seed,t+1,d)>>32) < thresh32;
+ * tf = 1 + min(ctz(low32), 31).  Returns the count; out arrays may be NULL to count only. */
+uint64_t so_lex_term_postings(uint64_t seed, uint32_t term, uint32_t thresh32, uint64_t n_docs,
+                              uint32_t* out_docs, uint16_t* out_tfs, uint64_t cap);
+/* vector rows [r0,r0+n) x dim, uniform(-1,1) then normalize_f32 semantics */
+void so_vec_gen(uint64_t seed, uint64_t r0, uint64_t n, uint32_t dim, int normalize, float* out);
+
+/* ---- lexical shard model (index.rs:770-860, compress_postinglist.rs:240-332) ---- */
+typedef struct so_shard so_shard;
+enum { SO_CT_ARRAY = 1, SO_CT_BITMAP = 2, SO_CT_RLE = 3 };
+enum { SO_OP_AND = 0, SO_OP_OR = 1 };
+enum { SO_RT_COUNT = 0, SO_RT_TOPK = 1, SO_RT_TOPKCOUNT = 2 };
+
+/* Build a shard from decoded postings (CSR by term; doc ids shard-local, ascending per term).
+ * Containers are chosen per 65536-doc block by the reference rule. */
+so_shard* so_shard_build(uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t n_terms,
+                         const uint64_t* term_offsets, const uint32_t* doc_ids, const uint16_t* tfs);
+void so_shard_free(so_shard*);
+float so_shard_avgdl(const so_shard*);
+uint64_t so_shard_posting_count(const so_shard*, uint32_t term);
+/* container kind chosen for (term, block ordinal); returns 0 if out of range */
+int so_shard_container(const so_shard*, uint32_t term, uint32_t block_ordinal, uint32_t* block_id,
+                       uint32_t* count, float* max_block_part);
+/* decode a container back to doc ids (tests the three formats round-trip) */
+uint32_t so_shard_decode_block(const so_shard*, uint32_t term, uint32_t block_ordinal, uint16_t* out);
+
+/* search_lexical_shard dispatch (search.rs:3374-3560) restricted to single-field AND / OR,
+ * Topk / TopkCount / Count, no filters.  Results sorted by score desc (search.rs:3565-3593).
+ * out_* sized k; returns number of results. */
+uint32_t so_search_lex(const so_shard*, uint32_t n_q_terms, const uint32_t* q_terms, int op, uint32_t k,
+                       int result_type, uint32_t* out_doc, float* out_score, uint64_t* out_total);
+/* brute-force ground truth (independent code path): exhaustive scoring + exact top-k by
+ * (score desc, doc asc); also returns the exact match count. */
+uint32_t so_search_lex_exhaustive(const so_shard*, uint32_t n_q_terms, const uint32_t* q_terms, int op,
+                                  uint32_t k, uint32_t* out_doc, float* out_score, uint64_t* out_total);
+/* statistics for the roofline's algorithmic bytes: sum df, #blocks touched */
+void so_query_stats(const so_shard*, uint32_t n_q_terms, const uint32_t* q_terms, uint64_t* sum_df,
+                    uint64_t* sum_blocks);
+
+/* ---- vector path (vector.rs:356-497, 1202-1515; vector_similarity.rs:70-74,1006-1008,1118-1142) ---- */
+void so_normalize_f32(float* v, uint32_t dim);
+float so_dot_f32(const float* a, const float* b, uint32_t dim);       /* scalar order  */
+float so_dot_f32_lanes8(const float* q, const float* e, uint32_t dim); /* dot_f32_avx2 order */
+/* search_vector_shard, AnnMode::All, F32 dot/cosine.  row_doc_ids may be NULL (= row index).
+ * threshold_raw: compared as `score < threshold_raw` (pass -FLT_MAX for none).  Returns count. */
+uint32_t so_vec_search(const float* rows, uint64_t n_rows, uint32_t dim, const uint32_t* row_doc_ids,
+                       const float* query, uint32_t k, float threshold_raw, int simd_order,
+                       uint32_t* out_doc, float* out_score, uint64_t* out_total, uint64_t* out_observed);
+/* vector_score field: vector.rs:1495-1499 */
+float so_vector_score_field(float dot);
+/* TopK threshold transform: vector.rs:388-397 */
+float so_threshold_raw(float similarity_threshold);
+
+/* ---- fusion / merge (search.rs:1669-1673, 1875-2035, 2098-2119) ---- */
+/* lists are concatenations over shards of per-shard top-(offset+length); ids already global.
+ * mode 0 = lexical only, 1 = vector only, 2 = hybrid RRF(k=0.6).  Output sorted desc, offset
+ * dropped, truncated to length.  Ties broken by doc id asc (reference: hash order). */
+uint32_t so_merge(int mode, const uint64_t* lex_doc, const float* lex_score, uint32_t n_lex,
+                  const uint64_t* vec_doc, const float* vec_score, uint32_t n_vec, uint32_t offset,
+                  uint32_t length, uint64_t* out_doc, float* out_score, uint8_t* out_source);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

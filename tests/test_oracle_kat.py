@@ -1,0 +1,205 @@
+"""Pins the CPU oracle: formula KATs, the reference's own count assertions
+(tests/test.rs:150-208, 676-744 re-enacted on hand-built postings), container round-trips,
+and agreement with the independent naive numpy restatement."""
+import numpy as np
+import pytest
+
+from oracle import naive
+from oracle import oracle as O
+
+
+def test_smallfloat_kats():
+    L = O.lib()
+    for i in range(40):
+        assert L.so_int_to_byte4(i) == i  # 0..39 -> identity
+    # SURVEY 8c derived KATs
+    assert L.so_int_to_byte4(100) == 57 and L.so_byte4_to_int(57) == 96
+    assert L.so_int_to_byte4(1000) == 87 and L.so_byte4_to_int(87) == 984
+    assert L.so_int_to_byte4(65535) == 135 and L.so_byte4_to_int(135) == 61464
+    assert L.so_byte4_to_int(100) == 3096
+    assert L.so_byte4_to_int(200) == 16777240
+    assert L.so_byte4_to_int(255) == 2013265944
+    # round trip is monotone and idempotent; both restatements agree everywhere
+    for b in range(256):
+        v = L.so_byte4_to_int(b)
+        assert v == naive.byte4_to_int(b)
+        assert L.so_int_to_byte4(v) == b
+    for i in list(range(0, 5000)) + [65535, 10 ** 6, 2 ** 31]:
+        assert L.so_int_to_byte4(i) == naive.int_to_byte4(i)
+
+
+def test_bm25_kat():
+    L = O.lib()
+    idf = L.so_idf(1_000_000, 1000)
+    assert abs(idf - 6.9072566) < 1e-5
+    comp = np.zeros(256, np.float32)
+    L.so_bm25_component_cache(np.float32(120.5), comp.ctypes.data_as(O.f32p))
+    b = L.so_int_to_byte4(100)
+    assert abs(comp[b] - 1.0170125) < 1e-6
+    s = L.so_bm25_term(idf, 3, float(comp[b]))
+    assert abs(s - 11.348706) < 1e-4
+    assert np.allclose(comp, naive.component_cache(np.float32(120.5)), rtol=1e-7)
+    assert abs(float(naive.idf(1_000_000, 1000)) - idf) < 1e-6
+
+
+def test_rrf_kat():
+    d, s, src = O.merge(2, lex=([10, 11, 12], [3.0, 2.0, 1.0]), vec=([20, 21, 22], [0.9, 0.8, 0.7]), length=6)
+    assert np.allclose(sorted(s, reverse=True)[:6:2], [1.6666666, 0.625, 0.3846154], rtol=1e-6)
+    # doc in both lists -> sum, source Hybrid (search.rs:1995-2008)
+    d, s, src = O.merge(2, lex=([5, 6], [2.0, 1.0]), vec=([6, 7], [0.5, 0.4]), length=3)
+    assert list(d) == [6, 5, 7]
+    assert np.isclose(s[0], 1.0 / 1.6 + 1.0 / 0.6, rtol=1e-6) and src[0] == 2
+    nd, ns = naive.rrf([5, 6], [6, 7], 3)
+    assert nd == list(d) and np.allclose(ns, s, rtol=1e-6)
+
+
+def _mini_index():
+    """4-doc fixture shaped like tests/test.rs:96-148: term ids 0='test', 1='body2'."""
+    # docs 0..3; 'test' occurs in docs 1 and 2; 'body2' in doc 1 only
+    doclen = np.array([O.lib().so_int_to_byte4(x) for x in (3, 4, 4, 3)], np.uint8)
+    offs = np.array([0, 2, 3], np.uint64)
+    docs = np.array([1, 2, 1], np.uint32)
+    tfs = np.array([1, 1, 1], np.uint16)
+    return O.Shard(4, doclen, offs, docs, tfs)
+
+
+def test_reference_count_pins():
+    sh = _mini_index()
+    # tests/test.rs:150-177  "+body2 +test" -> results.len()==1, result_count_total==1
+    d, s, tot = sh.search([1, 0], O.OP_AND, 10, O.RT_TOPKCOUNT)
+    assert len(d) == 1 and tot == 1 and d[0] == 1
+    # tests/test.rs:181-208  "test" union Count -> result_count_total == 2
+    d, s, tot = sh.search([0], O.OP_OR, 10, O.RT_COUNT)
+    assert len(d) == 0 and tot == 2
+    d, s, tot = sh.search([0, 1], O.OP_OR, 10, O.RT_TOPKCOUNT)
+    assert tot == 2 and set(d) == {1, 2} and d[0] == 1
+
+
+def test_reference_vector_count_pin():
+    # tests/test.rs:676-744: 3 vectors, k=10 -> 3 hits (TopK with len < k returns everything)
+    rows = O.vec_gen(7, 0, 3, 128)
+    d, s, tot, obs = O.vec_search(rows, rows[1], 10)
+    assert len(d) == 3 and tot == 3 and obs == 3 and d[0] == 1 and abs(s[0] - 1.0) < 1e-5
+    assert all(s[i] >= s[i + 1] for i in range(len(s) - 1))
+
+
+def test_dot_generators_match_reference_tolerance():
+    # vector_similarity.rs:3012-3037 deterministic generator; |simd - scalar| < 1e-3 on 128-d
+    i = np.arange(128, dtype=np.float32)
+    a = (np.sin(0.137 * i) / 2 + np.cos(0.013 * i) / 2).astype(np.float32)
+    b = (np.sin(0.137 * (i + 7)) / 2 + np.cos(0.013 * (i + 7)) / 2).astype(np.float32)
+    L = O.lib()
+    s0 = L.so_dot_f32(a.ctypes.data_as(O.f32p), b.ctypes.data_as(O.f32p), 128)
+    s1 = L.so_dot_f32_lanes8(a.ctypes.data_as(O.f32p), b.ctypes.data_as(O.f32p), 128)
+    assert abs(s0 - s1) < 1e-3
+    assert abs(s0 - float(a.astype(np.float64) @ b.astype(np.float64))) < 1e-3
+    n = O.normalize(a)
+    assert abs(float((n.astype(np.float64) ** 2).sum()) - 1.0) < 1e-5  # vector_similarity.rs:3103-3112
+
+
+def test_vector_score_field_and_threshold():
+    L = O.lib()
+    assert abs(L.so_vector_score_field(1.0) - ((1.0 / 16129.0) + 1.0) / 2.0) < 1e-7
+    assert abs(L.so_threshold_raw(0.7) - ((0.7 * 2 - 1) * 16129.0)) < 1e-2
+
+
+def _corpus(n_docs, terms, seed=O.LEX_SEED):
+    dl = O.lex_doclen(n_docs, seed)
+    offs, docs, tfs = O.lex_corpus(n_docs, terms, seed)
+    return dl, offs, docs, tfs
+
+
+def test_container_chooser_and_roundtrip():
+    n_docs = 200_000
+    # df 0.05% (array), ~4% (array), ~20% (bitmap)
+    terms = [0, 3000, 4095]
+    dl, offs, docs, tfs = _corpus(n_docs, terms)
+    # plus a hand-made run-heavy term -> RLE
+    run_docs = np.concatenate([np.arange(100, 400), np.arange(70000, 70800)]).astype(np.uint32)
+    offs = np.append(offs, offs[-1] + len(run_docs)).astype(np.uint64)
+    docs = np.concatenate([docs, run_docs])
+    tfs = np.concatenate([tfs, np.ones(len(run_docs), np.uint16)])
+    sh = O.Shard(n_docs, dl, offs, docs, tfs)
+    kinds = set()
+    for t in range(4):
+        d = docs[int(offs[t]):int(offs[t + 1])]
+        bo = 0
+        for blk in np.unique(d >> 16):
+            ct, bid, cnt, mp = sh.container(t, bo)
+            exp = (d[(d >> 16) == blk] & 0xFFFF).astype(np.uint16)
+            assert bid == blk and cnt == len(exp)
+            runs = 1 + int((np.diff(exp.astype(np.int64)) != 1).sum())
+            thr = cnt // 2 if cnt < 4096 else 2048
+            want = O.CT_RLE if (thr > 0 and runs - 1 < thr) else (O.CT_ARRAY if cnt < 4096 else O.CT_BITMAP)
+            assert ct == want
+            kinds.add(ct)
+            assert np.array_equal(sh.decode_block(t, bo), exp)
+            bo += 1
+    assert kinds == {O.CT_ARRAY, O.CT_BITMAP, O.CT_RLE}
+
+
+@pytest.mark.parametrize("op", [O.OP_AND, O.OP_OR])
+@pytest.mark.parametrize("terms", [[4000, 3500], [4095, 4000, 3000], [2000, 4095], [1000]])
+def test_oracle_vs_exhaustive_vs_naive(op, terms):
+    n_docs = 150_000
+    dl, offs, docs, tfs = _corpus(n_docs, terms)
+    sh = O.Shard(n_docs, dl, offs, docs, tfs)
+    q = list(range(len(terms)))
+    k = 10
+    d1, s1, tot1 = sh.search(q, op, k, O.RT_TOPKCOUNT)
+    d2, s2, tot2 = sh.search_exhaustive(q, op, k)
+    post = [(docs[int(offs[i]):int(offs[i + 1])], tfs[int(offs[i]):int(offs[i + 1])]) for i in q]
+    ids, sc = naive.bm25_scores(n_docs, dl, post, op == O.OP_AND or len(terms) == 1)
+    d3, s3 = naive.topk(ids, sc, k)
+    eff_and = op == O.OP_AND or len(terms) == 1
+    assert tot2 == len(ids)
+    assert tot1 == tot2  # TopkCount is exact (intersection.rs:2227-2233, add_result.rs:3522-3536)
+    assert len(d1) == len(d2) == len(d3) == min(k, len(ids))
+    # scores agree within 1e-4 relative; sets agree outside the tie band of the k-th score
+    assert np.allclose(s1, s2, rtol=1e-4) and np.allclose(s2, s3, rtol=1e-4)
+    if len(s2):
+        kth = s2[-1]
+        strict = lambda d, s: {int(x) for x, y in zip(d, s) if y > kth * (1 + 1e-4)}
+        assert strict(d1, s1) == strict(d2, s2) == strict(d3, s3)
+    if eff_and:
+        # bit-exact doc-id set of the conjunction: ask for everything
+        dall, sall, tall = sh.search(q, O.OP_AND, len(ids) + 5, O.RT_TOPKCOUNT)
+        assert set(map(int, dall)) == set(map(int, ids)) and tall == len(ids)
+    # Topk (with early termination) returns the same ranking as TopkCount
+    d4, s4, _ = sh.search(q, op, k, O.RT_TOPK)
+    assert np.allclose(s4, s1, rtol=1e-6)
+
+
+def test_vector_oracle_vs_naive():
+    rows = O.vec_gen(O.VEC_SEED, 0, 5000, 64)
+    qs = O.vec_gen(O.VECQ_SEED, 0, 4, 64)
+    for q in qs:
+        d, s, tot, obs = O.vec_search(rows, q, 100)
+        nd, ns = naive.cosine_topk(rows, q, 100)
+        assert obs == 5000 and len(d) == 100
+        assert np.allclose(s, ns, rtol=1e-4, atol=1e-6)
+        kth = ns[-1]
+        assert {int(x) for x, y in zip(d, s) if y > kth + 1e-5} == {int(x) for x, y in zip(nd, ns) if y > kth + 1e-5}
+
+
+def test_vector_dedup_semantics():
+    # vector.rs:441-452,462-473: several records of one doc -> one result with the max score
+    rows = O.vec_gen(3, 0, 50, 32)
+    docs = (np.arange(50) // 2).astype(np.uint32)
+    d, s, tot, obs = O.vec_search(rows, rows[10], 10, row_doc_ids=docs)
+    assert len(set(map(int, d))) == len(d) and d[0] == 5
+    full = rows @ rows[10]
+    for doc, sc in zip(d, s):
+        assert abs(sc - full[docs == doc].max()) < 1e-5
+
+
+def test_generator_is_stable():
+    # golden values of the counter-based generator (guards CPU<->GPU agreement of the hash)
+    L = O.lib()
+    assert L.so_splitmix64(0) == 0xE220A8397B1DCDAF
+    assert L.so_h(O.LEX_SEED, 1, 2) == L.so_h(O.LEX_SEED, 1, 2)
+    g = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "generator.npz"))
+    d, t = O.lex_term(4000, O.term_thresholds()[4000], 50_000)
+    assert np.array_equal(d[:64], g["lex_docs"]) and np.array_equal(t[:64], g["lex_tfs"])
+    assert np.array_equal(O.lex_doclen(4096)[:256], g["doclen"])
+    assert np.array_equal(O.vec_gen(O.VEC_SEED, 5, 2, 16), g["vec"])
