@@ -1,0 +1,137 @@
+/*
+ * seekstorm_hip.h -- C ABI of the MI355X-native SeekStorm query hot path.
+ *
+ * This is the drop-in boundary.  The reference (Rust crate `seekstorm`) has NO FFI / plugin
+ * interface; the seams this ABI replaces are the two per-shard executors and the cross-shard
+ * merge (citations relative to /root/reference/seekstorm/src):
+ *
+ *   ss_bm25_search   <- the dispatch block of search_lexical_shard, search.rs:3374-3560
+ *                       (single_blockid / union_docid_2|3 / union_blockid / intersection_blockid)
+ *                       inputs already resolved by the host: term -> posting list, idf (search.rs:3225-3230)
+ *   ss_vec_search    <- SearchVectorShard::search_vector_shard, vector.rs:1105-1115 / 1202-1515
+ *                       (AnnMode::All, F32 dot/cosine; query already normalised, search.rs:1464-1475)
+ *   ss_*_upload      <- (re)build of the device image at the end of open_shard (index.rs:3796)
+ *                       and after each commit (commit.rs:142-148)
+ *   ss_merge_results <- cross-shard gather + RRF + sort/offset/length, search.rs:1875-2119
+ *
+ * Conventions (mirroring the reference's search path, search.rs:2461-2463 / vector.rs:1222-1224):
+ *   - every function returns 0 on success or a negative SS_E* code; never throws, never aborts;
+ *   - results come back sorted by score descending, per-shard LOCAL doc ids, caller-owned buffers;
+ *   - unused result slots hold doc id SS_NO_DOC and score 0;
+ *   - per-shard request size is offset+length with offset 0 (search.rs:1658-1659): `k` below;
+ *   - thread-safe: concurrent calls on one handle are serialised internally; destroy must not race.
+ * Plain C types only: no torch / HIP types in any signature (streams cross as void*).
+ */
+#ifndef SEEKSTORM_HIP_H
+#define SEEKSTORM_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS_ABI_VERSION 1
+#define SS_NO_DOC 0xFFFFFFFFu
+#define SS_MAX_QUERY_TERMS 10 /* union_docid_3 handles <= 10 terms, union.rs:1308 */
+#define SS_MAX_K 1024
+#define SS_VEC_BATCH 64 /* queries scanned per pass over the matrix */
+
+enum {
+  SS_OK = 0,
+  SS_EINVAL = -1,   /* bad argument */
+  SS_ENOMEM = -2,   /* device or host allocation failed */
+  SS_EDEVICE = -3,  /* HIP runtime error (no device, launch failure, ...) */
+  SS_ENOTSUP = -4,  /* valid request outside the implemented scope */
+  SS_ESTATE = -5    /* image not uploaded yet */
+};
+
+/* QueryType (search.rs:59) restricted to the two set operations; ResultType (search.rs:168) */
+enum { SS_OP_INTERSECTION = 0, SS_OP_UNION = 1 };
+enum { SS_RT_COUNT = 0, SS_RT_TOPK = 1, SS_RT_TOPKCOUNT = 2 };
+/* SearchMode (search.rs:73) for ss_merge_results */
+enum { SS_MODE_LEXICAL = 0, SS_MODE_VECTOR = 1, SS_MODE_HYBRID = 2 };
+/* ResultSource (min_heap.rs:17-40) */
+enum { SS_SRC_LEXICAL = 0, SS_SRC_VECTOR = 1, SS_SRC_HYBRID = 2 };
+
+typedef struct ss_shard ss_shard; /* opaque: the HBM image of ONE shard on ONE device */
+
+int ss_abi_version(void);
+const char* ss_strerror(int code);
+int ss_device_count(int* out);
+int ss_shard_create(int device, ss_shard** out);
+int ss_shard_destroy(ss_shard* s);
+/* block until all work queued on the shard's stream is done */
+int ss_shard_sync(ss_shard* s);
+
+/* ------------------------------------------------------------------ BM25 image
+ * Host passes DECODED postings (CSR by term, shard-local doc ids ascending per term, tf = positions_count
+ * of the single indexed field) and the per-doc SmallFloat length bytes (index.rs:5397); the library builds
+ * the HBM image (sub-block CSR of packed postings, bm25_component_cache per commit.rs:318-325). */
+int ss_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t n_terms,
+                   const uint64_t* term_offsets, const uint32_t* doc_ids, const uint16_t* tfs);
+/* Device-side synthetic corpus (bench/test utility; generator = oracle so_lex_*):
+ * posting (t,d) iff (h(seed,t+1,d)>>32) < thresh32[t]; bit-identical to ss_bm25_upload of the same corpus. */
+int ss_bm25_synth(ss_shard* s, uint64_t seed, uint64_t n_docs, uint32_t n_terms, const uint32_t* thresh32,
+                  const uint8_t* len_table1024);
+int ss_bm25_info(ss_shard* s, uint64_t* n_docs, float* avgdl, uint32_t* n_terms, uint64_t* n_postings);
+/* posting_count per term (the df the host needs for idf, search.rs:3225-3230) */
+int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df_out);
+
+typedef struct {
+  uint32_t n_terms;                  /* 1..SS_MAX_QUERY_TERMS unique terms */
+  uint32_t op;                       /* SS_OP_* */
+  uint32_t term[SS_MAX_QUERY_TERMS]; /* term index into the uploaded vocabulary */
+  float idf[SS_MAX_QUERY_TERMS];     /* host-computed, search.rs:3225-3230 */
+} ss_bm25_query;
+
+/* Batched BM25 search.  Outputs: out_doc/out_score [n_queries*k], out_count [n_queries] (= results.len()),
+ * out_total [n_queries] (= result_count_total: exact match count for Count/TopkCount). */
+int ss_bm25_search(ss_shard* s, uint32_t n_queries, const ss_bm25_query* queries, uint32_t k,
+                   uint32_t result_type, uint32_t* out_doc, float* out_score, uint32_t* out_count,
+                   uint64_t* out_total);
+/* Same, everything device-resident and asynchronous on `stream` (a hipStream_t passed as void*;
+ * NULL = the shard's own stream).  d_queries is a device array of ss_bm25_query that the caller has validated
+ * (term < n_terms, unique terms, idf > 0).  ops_mask: bit 0 set if any query is an intersection of > 1 terms
+ * (selects the kernel variant that carries match counters), bit 1 set if any query is a union. */
+int ss_bm25_search_dev(ss_shard* s, uint32_t n_queries, const ss_bm25_query* d_queries, uint32_t k,
+                       uint32_t result_type, uint32_t ops_mask, uint32_t* d_out_doc, float* d_out_score,
+                       uint32_t* d_out_count, uint64_t* d_out_total, void* stream);
+
+/* ------------------------------------------------------------------ vector image
+ * rows: row-major [n_rows x dim] f32, already L2-normalised for cosine (vector.rs:585-596); the uploader of
+ * a real vector.bin strips the 24-byte VectorHeader (vector.rs:62-73).  row_doc_ids may be NULL (= row index);
+ * several records per doc (vector.rs:441-452 dedup) are rejected with SS_ENOTSUP for now. */
+int ss_vec_upload(ss_shard* s, uint64_t n_rows, uint32_t dim, const float* rows, const uint32_t* row_doc_ids);
+/* Device-side synthetic matrix (generator = oracle so_vec_gen, uniform(-1,1) then normalize_f32). */
+int ss_vec_synth(ss_shard* s, uint64_t seed, uint64_t n_rows, uint32_t dim);
+int ss_vec_info(ss_shard* s, uint64_t* n_rows, uint32_t* dim);
+/* copy rows [r0, r0+n) back to the host (test accessor) */
+int ss_vec_read_rows(ss_shard* s, uint64_t r0, uint64_t n, float* out);
+
+/* Batched brute-force scan (AnnMode::All).  queries: [n_queries x dim] f32 normalised.  threshold_raw is
+ * compared as `score < threshold_raw -> reject` (vector.rs:423; pass -FLT_MAX for none).
+ * out_total = number of rows that passed the running top-k filter (vector.rs:429 counts accepted pushes;
+ * order-dependent in the reference, an upper bound here; exact when n_rows <= k). */
+int ss_vec_search(ss_shard* s, uint32_t n_queries, const float* queries, uint32_t k, float threshold_raw,
+                  uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total);
+int ss_vec_search_dev(ss_shard* s, uint32_t n_queries, const float* d_queries, uint32_t k, float threshold_raw,
+                      uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total,
+                      void* stream);
+
+/* ------------------------------------------------------------------ cross-shard merge + RRF (host side)
+ * Inputs are the concatenation over shards of per-shard top-(offset+length) lists with GLOBAL ids
+ * (global = local*S + shard, search.rs:1671).  Hybrid = RRF k=0.6, 0-based ranks (search.rs:1962-2035).
+ * Returns the number of results written (<= length) or a negative code. */
+int ss_merge_results(int mode, const uint64_t* lex_doc, const float* lex_score, uint32_t n_lex,
+                     const uint64_t* vec_doc, const float* vec_score, uint32_t n_vec, uint32_t offset,
+                     uint32_t length, uint64_t* out_doc, float* out_score, uint8_t* out_source);
+
+/* ------------------------------------------------------------------ measurement hooks
+ * When enabled the library brackets every launch of the dominant kernels with HIP events on the stream
+ * the kernel is launched on and accumulates (launches, milliseconds).  kernel: 0 = bm25 scan, 1 = vector scan. */
+int ss_profile_enable(ss_shard* s, int on);
+int ss_profile_read(ss_shard* s, int kernel, uint64_t* launches, double* total_ms, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,13 @@
+"""seekstorm_amd -- MI355X-native implementation of SeekStorm's query hot path.
+
+BM25 posting-list union/intersection with exact top-k, dense-vector brute-force cosine/dot top-k, RRF hybrid fusion
+and cross-shard top-k merge, as hand-written HIP kernels for gfx950 behind a C ABI (include/seekstorm_hip.h).
+This package is the host-side mirror of the reference's search interface on top of that ABI.
+There is no CPU fallback: without the built HIP library and a GPU every search call raises.
+"""
+from ._native import LIB_PATH, SeekStormHipError, lib  # noqa: F401
+from .search import (Index, QueryType, Result, ResultObject, ResultSource, ResultType, SearchMode, Shard,  # noqa: F401
+                     idf_f32, merge_results, normalize_f32, threshold_raw)
+
+__all__ = ["Index", "Shard", "QueryType", "ResultType", "SearchMode", "ResultSource", "Result", "ResultObject",
+           "merge_results", "normalize_f32", "idf_f32", "threshold_raw", "lib", "LIB_PATH", "SeekStormHipError"]

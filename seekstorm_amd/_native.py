@@ -1,0 +1,100 @@
+"""ctypes binding of libseekstorm_hip.so (the C ABI in include/seekstorm_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or no MI355X is visible, the calls fail loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libseekstorm_hip.so")
+
+SS_NO_DOC = 0xFFFFFFFF
+SS_MAX_QUERY_TERMS = 10
+SS_MAX_K = 1024
+SS_VEC_BATCH = 64
+OP_INTERSECTION, OP_UNION = 0, 1
+RT_COUNT, RT_TOPK, RT_TOPKCOUNT = 0, 1, 2
+MODE_LEXICAL, MODE_VECTOR, MODE_HYBRID = 0, 1, 2
+SRC_LEXICAL, SRC_VECTOR, SRC_HYBRID = 0, 1, 2
+FLT_MIN_NEG = -3.4028234663852886e38
+
+u8p = C.POINTER(C.c_uint8)
+u16p = C.POINTER(C.c_uint16)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+f32p = C.POINTER(C.c_float)
+
+
+class Bm25Query(C.Structure):
+    _fields_ = [("n_terms", C.c_uint32), ("op", C.c_uint32), ("term", C.c_uint32 * SS_MAX_QUERY_TERMS),
+                ("idf", C.c_float * SS_MAX_QUERY_TERMS)]
+
+
+BM25_QUERY_DTYPE = np.dtype([("n_terms", np.uint32), ("op", np.uint32), ("term", np.uint32, (SS_MAX_QUERY_TERMS,)),
+                             ("idf", np.float32, (SS_MAX_QUERY_TERMS,))])
+assert BM25_QUERY_DTYPE.itemsize == C.sizeof(Bm25Query)
+
+# every symbol include/seekstorm_hip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("ss_abi_version", C.c_int, []),
+    ("ss_strerror", C.c_char_p, [C.c_int]),
+    ("ss_device_count", C.c_int, [C.POINTER(C.c_int)]),
+    ("ss_shard_create", C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    ("ss_shard_destroy", C.c_int, [C.c_void_p]),
+    ("ss_shard_sync", C.c_int, [C.c_void_p]),
+    ("ss_bm25_upload", C.c_int, [C.c_void_p, C.c_uint64, u8p, C.c_uint32, u64p, u32p, u16p]),
+    ("ss_bm25_synth", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, u32p, u8p]),
+    ("ss_bm25_info", C.c_int, [C.c_void_p, u64p, f32p, u32p, u64p]),
+    ("ss_bm25_term_df", C.c_int, [C.c_void_p, C.c_uint32, u32p, u64p]),
+    ("ss_bm25_search", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, u32p, f32p, u32p, u64p]),
+    ("ss_bm25_search_dev", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("ss_vec_upload", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, f32p, u32p]),
+    ("ss_vec_synth", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32]),
+    ("ss_vec_info", C.c_int, [C.c_void_p, u64p, u32p]),
+    ("ss_vec_read_rows", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, f32p]),
+    ("ss_vec_search", C.c_int, [C.c_void_p, C.c_uint32, f32p, C.c_uint32, C.c_float, u32p, f32p, u32p, u64p]),
+    ("ss_vec_search_dev", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("ss_merge_results", C.c_int, [C.c_int, u64p, f32p, C.c_uint32, u64p, f32p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                   u64p, f32p, u8p]),
+    ("ss_profile_enable", C.c_int, [C.c_void_p, C.c_int]),
+    ("ss_profile_read", C.c_int, [C.c_void_p, C.c_int, u64p, C.POINTER(C.c_double), C.c_int]),
+]
+
+_lib = None
+
+
+class SeekStormHipError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = lib().ss_strerror(code).decode() if _lib is not None else "?"
+        super().__init__(f"{where}: {msg} (code {code})")
+
+
+def lib():
+    """Load the HIP library.  Raises if it has not been built (python -m seekstorm_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python seekstorm_amd/build.py` (hipcc, gfx950). "
+                               "There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code, where):
+    if code < 0:
+        raise SeekStormHipError(code, where)
+    return code
+
+
+def ptr(a, t):
+    return None if a is None else a.ctypes.data_as(t)

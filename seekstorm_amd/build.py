@@ -1,0 +1,53 @@
+"""Builds libseekstorm_hip.so (gfx950) in-tree with hipcc.  No CPU fallback is ever built."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT_DIR = os.path.join(HERE, "lib")
+LIB = os.path.join(OUT_DIR, "libseekstorm_hip.so")
+SOURCES = ["ss_api.hip", "vec_scan.hip", "bm25.hip", "synth.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
+
+
+def _newer(dst, srcs):
+    if not os.path.exists(dst):
+        return False
+    t = os.path.getmtime(dst)
+    return all(os.path.getmtime(s) <= t for s in srcs)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    deps = [os.path.join(CSRC, "ss_common.h"), os.path.join(HERE, "..", "include", "seekstorm_hip.h")]
+    objs = []
+    jobs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(OUT_DIR, src.replace(".hip", ".o"))
+        objs.append(op)
+        if force or not _newer(op, [sp] + deps):
+            jobs.append([HIPCC] + FLAGS + ["-c", sp, "-o", op])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for err in ex.map(run, jobs):
+            if verbose and err:
+                print(err)
+    if jobs or not os.path.exists(LIB):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs + ["-Wl,-rpath,/opt/rocm/lib"])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,438 @@
+// C ABI of the MI355X-native SeekStorm query hot path (see include/seekstorm_hip.h for the contract and the
+// reference seams each entry point replaces).  Host-side plumbing only; the kernels live in vec_scan.hip / bm25.hip.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <unordered_map>
+
+#include "ss_common.h"
+
+#define SS_TRY(x)          \
+  do {                     \
+    int _rc = (x);         \
+    if (_rc) return _rc;   \
+  } while (0)
+
+extern "C" {
+
+int ss_abi_version(void) { return SS_ABI_VERSION; }
+
+const char* ss_strerror(int code) {
+  switch (code) {
+    case SS_OK: return "ok";
+    case SS_EINVAL: return "invalid argument";
+    case SS_ENOMEM: return "out of memory";
+    case SS_EDEVICE: return "HIP device/runtime error";
+    case SS_ENOTSUP: return "not supported by the MI355X hot path (see DESIGN.md)";
+    case SS_ESTATE: return "image not uploaded";
+    default: return "unknown error";
+  }
+}
+
+int ss_device_count(int* out) {
+  if (!out) return SS_EINVAL;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { *out = 0; return SS_EDEVICE; }
+  *out = n;
+  return SS_OK;
+}
+
+int ss_shard_create(int device, ss_shard** out) {
+  if (!out) return SS_EINVAL;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SS_EDEVICE;  // fail loudly: no CPU fallback exists
+  if (device < 0 || device >= n) return SS_EINVAL;
+  SS_HIP(hipSetDevice(device));
+  ss_shard* s = new (std::nothrow) ss_shard();
+  if (!s) return SS_ENOMEM;
+  s->device = device;
+  if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return SS_EDEVICE; }
+  *out = s;
+  return SS_OK;
+}
+
+static void free_vec(ss_shard* s) {
+  void* ptrs[] = {s->d_X, s->d_row_doc, s->d_Qf, s->d_vstate, s->d_cand};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  s->d_X = nullptr; s->d_row_doc = nullptr; s->d_Qf = nullptr; s->d_vstate = nullptr; s->d_cand = nullptr;
+  s->n_rows = s->n_rows_pad = 0; s->dim = s->dim_pad = 0;
+}
+static void free_bm25(ss_shard* s) {
+  void* ptrs[] = {s->d_post, s->d_term_base, s->d_sub_off, s->d_comp};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  s->d_post = nullptr; s->d_term_base = nullptr; s->d_sub_off = nullptr; s->d_comp = nullptr;
+  s->bm_n_docs = 0; s->bm_n_terms = 0; s->bm_n_sub = 0; s->bm_n_post = 0;
+  s->h_term_base.clear();
+}
+
+int ss_shard_destroy(ss_shard* s) {
+  if (!s) return SS_EINVAL;
+  (void)hipSetDevice(s->device);
+  (void)hipStreamSynchronize(s->stream);
+  free_vec(s);
+  free_bm25(s);
+  void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_part};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (int kx = 0; kx < 2; kx++)
+    for (auto& pr : s->prof.pending[kx]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  (void)hipStreamDestroy(s->stream);
+  delete s;
+  return SS_OK;
+}
+
+int ss_shard_sync(ss_shard* s) {
+  if (!s) return SS_EINVAL;
+  SS_HIP(hipSetDevice(s->device));
+  SS_HIP(hipStreamSynchronize(s->stream));
+  return SS_OK;
+}
+
+// ------------------------------------------------------------------ staging helpers
+static int ensure_out(ss_shard* s, size_t nq, size_t k) {
+  size_t need = nq * std::max<size_t>(k, 1);
+  if (need <= s->out_cap && nq <= s->q_cap) return SS_OK;
+  void* ptrs[] = {s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  s->d_out_doc = nullptr; s->d_out_score = nullptr; s->d_out_count = nullptr; s->d_out_total = nullptr;
+  s->out_cap = 0; s->q_cap = 0;
+  SS_HIP(hipMalloc(&s->d_out_doc, need * sizeof(uint32_t)));
+  SS_HIP(hipMalloc(&s->d_out_score, need * sizeof(float)));
+  SS_HIP(hipMalloc(&s->d_out_count, nq * sizeof(uint32_t)));
+  SS_HIP(hipMalloc(&s->d_out_total, nq * sizeof(uint64_t)));
+  s->out_cap = need; s->q_cap = nq;
+  return SS_OK;
+}
+
+// ------------------------------------------------------------------ BM25
+int ss_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen, uint32_t n_terms, const uint64_t* offs,
+                   const uint32_t* docs, const uint16_t* tfs) {
+  if (!s || !doclen || !offs || n_docs == 0 || n_terms == 0) return SS_EINVAL;
+  if (offs[n_terms] && (!docs || !tfs)) return SS_EINVAL;
+  if (n_docs > 0xFFFFFFFFull) return SS_ENOTSUP;
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  SS_HIP(hipStreamSynchronize(s->stream));
+  free_bm25(s);
+  s->bm_n_docs = n_docs;
+  s->bm_n_terms = n_terms;
+  s->bm_n_sub = (uint32_t)((n_docs + BM_SUB - 1) >> BM_SUB_LOG2);
+  int rc = ssi_bm25_build_from_host(s, doclen, offs, docs, tfs);
+  if (rc) free_bm25(s);
+  return rc;
+}
+
+int ss_bm25_synth(ss_shard* s, uint64_t seed, uint64_t n_docs, uint32_t n_terms, const uint32_t* thresh32,
+                  const uint8_t* len_table1024) {
+  if (!s || !thresh32 || !len_table1024 || n_docs == 0 || n_terms == 0) return SS_EINVAL;
+  if (n_docs > 0xFFFFFFFFull) return SS_ENOTSUP;
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  SS_HIP(hipStreamSynchronize(s->stream));
+  free_bm25(s);
+  s->bm_n_docs = n_docs;
+  s->bm_n_terms = n_terms;
+  s->bm_n_sub = (uint32_t)((n_docs + BM_SUB - 1) >> BM_SUB_LOG2);
+  uint32_t* d_th = nullptr;
+  uint8_t* d_tab = nullptr;
+  SS_HIP(hipMalloc(&d_th, (size_t)n_terms * sizeof(uint32_t)));
+  SS_HIP(hipMalloc(&d_tab, 1024));
+  SS_HIP(hipMemcpy(d_th, thresh32, (size_t)n_terms * sizeof(uint32_t), hipMemcpyHostToDevice));
+  SS_HIP(hipMemcpy(d_tab, len_table1024, 1024, hipMemcpyHostToDevice));
+  int rc = ssi_bm25_synth(s, seed, d_th, d_tab, s->stream);
+  (void)hipFree(d_th);
+  (void)hipFree(d_tab);
+  if (rc) free_bm25(s);
+  return rc;
+}
+
+int ss_bm25_info(ss_shard* s, uint64_t* n_docs, float* avgdl, uint32_t* n_terms, uint64_t* n_postings) {
+  if (!s) return SS_EINVAL;
+  if (!s->d_post) return SS_ESTATE;
+  if (n_docs) *n_docs = s->bm_n_docs;
+  if (avgdl) *avgdl = s->bm_avgdl;
+  if (n_terms) *n_terms = s->bm_n_terms;
+  if (n_postings) *n_postings = s->bm_n_post;
+  return SS_OK;
+}
+
+int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df_out) {
+  if (!s || !terms || !df_out) return SS_EINVAL;
+  if (!s->d_post) return SS_ESTATE;
+  for (uint32_t i = 0; i < n; i++) {
+    if (terms[i] >= s->bm_n_terms) return SS_EINVAL;
+    df_out[i] = s->h_term_base[terms[i] + 1] - s->h_term_base[terms[i]];
+  }
+  return SS_OK;
+}
+
+static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q, bool* has_and) {
+  *has_and = false;
+  for (uint32_t i = 0; i < nq; i++) {
+    if (q[i].n_terms == 0 || q[i].n_terms > SS_MAX_QUERY_TERMS) return SS_EINVAL;
+    if (q[i].op != SS_OP_INTERSECTION && q[i].op != SS_OP_UNION) return SS_EINVAL;
+    for (uint32_t t = 0; t < q[i].n_terms; t++) {
+      if (q[i].term[t] >= s->bm_n_terms) return SS_EINVAL;
+      if (!(q[i].idf[t] > 0.0f)) return SS_EINVAL;
+      for (uint32_t u = 0; u < t; u++)
+        if (q[i].term[u] == q[i].term[t]) return SS_EINVAL;  // unique terms only (search.rs:3023 unique_terms)
+    }
+    if (q[i].op == SS_OP_INTERSECTION && q[i].n_terms > 1) *has_and = true;
+  }
+  return SS_OK;
+}
+
+int ss_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k, uint32_t rt, uint32_t* out_doc,
+                   float* out_score, uint32_t* out_count, uint64_t* out_total) {
+  if (!s || !q || !out_count || !out_total) return SS_EINVAL;
+  if (rt > SS_RT_TOPKCOUNT) return SS_EINVAL;
+  if (rt != SS_RT_COUNT && (k == 0 || k > SS_MAX_K || !out_doc || !out_score)) return SS_EINVAL;
+  if (!s->d_post) return SS_ESTATE;
+  if (nq == 0) return SS_OK;
+  bool has_and = false;
+  SS_TRY(check_queries(s, nq, q, &has_and));
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  const uint32_t kk = rt == SS_RT_COUNT ? 0 : k;
+  SS_TRY(ensure_out(s, nq, std::max<uint32_t>(kk, 1)));
+  if ((size_t)nq * sizeof(ss_bm25_query) > s->bq_cap) {
+    if (s->d_bq) (void)hipFree(s->d_bq);
+    s->d_bq = nullptr; s->bq_cap = 0;
+    SS_HIP(hipMalloc(&s->d_bq, (size_t)nq * sizeof(ss_bm25_query)));
+    s->bq_cap = (size_t)nq * sizeof(ss_bm25_query);
+  }
+  SS_HIP(hipMemcpyAsync(s->d_bq, q, (size_t)nq * sizeof(ss_bm25_query), hipMemcpyHostToDevice, s->stream));
+  SS_TRY(ssi_bm25_search(s, nq, (const ss_bm25_query*)s->d_bq, kk, rt, s->d_out_doc, s->d_out_score, s->d_out_count,
+                         s->d_out_total, has_and, s->stream));
+  if (kk) {
+    SS_HIP(hipMemcpyAsync(out_doc, s->d_out_doc, (size_t)nq * kk * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    SS_HIP(hipMemcpyAsync(out_score, s->d_out_score, (size_t)nq * kk * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+  }
+  SS_HIP(hipMemcpyAsync(out_count, s->d_out_count, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+  SS_HIP(hipMemcpyAsync(out_total, s->d_out_total, (size_t)nq * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
+  SS_HIP(hipStreamSynchronize(s->stream));
+  return SS_OK;
+}
+
+int ss_bm25_search_dev(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t ops_mask,
+                       uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total,
+                       void* stream) {
+  if (!s || !d_q || !d_out_count || !d_out_total) return SS_EINVAL;
+  if (rt > SS_RT_TOPKCOUNT) return SS_EINVAL;
+  if (rt != SS_RT_COUNT && (k == 0 || k > SS_MAX_K || !d_out_doc || !d_out_score)) return SS_EINVAL;
+  if (!s->d_post) return SS_ESTATE;
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  hipStream_t st = stream ? (hipStream_t)stream : s->stream;
+  return ssi_bm25_search(s, nq, d_q, rt == SS_RT_COUNT ? 0 : k, rt, d_out_doc, d_out_score, d_out_count, d_out_total,
+                         (ops_mask & 1u) != 0, st);
+}
+
+// ------------------------------------------------------------------ vectors
+static int vec_alloc(ss_shard* s, uint64_t n_rows, uint32_t dim) {
+  free_vec(s);
+  s->n_rows = n_rows;
+  s->dim = dim;
+  s->dim_pad = (dim + VS_KC - 1) / VS_KC * VS_KC;
+  s->n_rows_pad = (n_rows + VS_TR - 1) / VS_TR * VS_TR;
+  const size_t bytes = (size_t)s->n_rows_pad * s->dim_pad * sizeof(float);
+  SS_HIP(hipMalloc(&s->d_X, bytes));
+  if (s->dim_pad != dim) SS_HIP(hipMemsetAsync(s->d_X, 0, bytes, s->stream));
+  else if (s->n_rows_pad != n_rows)
+    SS_HIP(hipMemsetAsync(s->d_X + (size_t)n_rows * s->dim_pad, 0, (size_t)(s->n_rows_pad - n_rows) * s->dim_pad * sizeof(float),
+                          s->stream));
+  return SS_OK;
+}
+
+int ss_vec_upload(ss_shard* s, uint64_t n_rows, uint32_t dim, const float* rows, const uint32_t* row_doc_ids) {
+  if (!s || !rows || n_rows == 0 || dim == 0) return SS_EINVAL;
+  if (n_rows > 0xFFFFFFFEull) return SS_ENOTSUP;
+  if (row_doc_ids) {  // several records per doc (vector.rs:441-452) are not handled on device yet
+    std::vector<uint32_t> tmp(row_doc_ids, row_doc_ids + n_rows);
+    std::sort(tmp.begin(), tmp.end());
+    if (std::adjacent_find(tmp.begin(), tmp.end()) != tmp.end()) return SS_ENOTSUP;
+  }
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  SS_HIP(hipStreamSynchronize(s->stream));
+  int rc = vec_alloc(s, n_rows, dim);
+  if (rc) { free_vec(s); return rc; }
+  SS_HIP(hipMemcpy2DAsync(s->d_X, (size_t)s->dim_pad * sizeof(float), rows, (size_t)dim * sizeof(float),
+                          (size_t)dim * sizeof(float), n_rows, hipMemcpyHostToDevice, s->stream));
+  if (row_doc_ids) {
+    SS_HIP(hipMalloc(&s->d_row_doc, n_rows * sizeof(uint32_t)));
+    SS_HIP(hipMemcpyAsync(s->d_row_doc, row_doc_ids, n_rows * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+  }
+  SS_HIP(hipStreamSynchronize(s->stream));
+  return ssi_vec_alloc_ws(s);
+}
+
+int ss_vec_synth(ss_shard* s, uint64_t seed, uint64_t n_rows, uint32_t dim) {
+  if (!s || n_rows == 0 || dim == 0) return SS_EINVAL;
+  if (n_rows > 0xFFFFFFFEull) return SS_ENOTSUP;
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  SS_HIP(hipStreamSynchronize(s->stream));
+  int rc = vec_alloc(s, n_rows, dim);
+  if (rc) { free_vec(s); return rc; }
+  SS_TRY(ssi_vec_synth(s, seed, s->stream));
+  SS_HIP(hipStreamSynchronize(s->stream));
+  return ssi_vec_alloc_ws(s);
+}
+
+int ss_vec_info(ss_shard* s, uint64_t* n_rows, uint32_t* dim) {
+  if (!s) return SS_EINVAL;
+  if (!s->d_X) return SS_ESTATE;
+  if (n_rows) *n_rows = s->n_rows;
+  if (dim) *dim = s->dim;
+  return SS_OK;
+}
+
+int ss_vec_read_rows(ss_shard* s, uint64_t r0, uint64_t n, float* out) {
+  if (!s || !out) return SS_EINVAL;
+  if (!s->d_X) return SS_ESTATE;
+  if (r0 + n > s->n_rows) return SS_EINVAL;
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  SS_HIP(hipStreamSynchronize(s->stream));
+  SS_HIP(hipMemcpy2D(out, (size_t)s->dim * sizeof(float), s->d_X + r0 * s->dim_pad, (size_t)s->dim_pad * sizeof(float),
+                     (size_t)s->dim * sizeof(float), n, hipMemcpyDeviceToHost));
+  return SS_OK;
+}
+
+int ss_vec_search(ss_shard* s, uint32_t nq, const float* queries, uint32_t k, float thr, uint32_t* out_doc,
+                  float* out_score, uint32_t* out_count, uint64_t* out_total) {
+  if (!s || !queries || !out_doc || !out_score || !out_count || !out_total) return SS_EINVAL;
+  if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
+  if (!s->d_X) return SS_ESTATE;
+  if (nq == 0) return SS_OK;
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  SS_TRY(ensure_out(s, nq, k));
+  float* d_q = nullptr;
+  SS_HIP(hipMalloc(&d_q, (size_t)nq * s->dim * sizeof(float)));
+  int rc = SS_OK;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    if (hipMemcpyAsync(d_q, queries, (size_t)nq * s->dim * sizeof(float), hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = SS_EDEVICE; break; }
+    rc = ssi_vec_search(s, nq, d_q, k, thr, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->stream,
+                        attempt == 1);
+    if (rc) break;
+    if (hipMemcpyAsync(out_count, s->d_out_count, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+        hipStreamSynchronize(s->stream) != hipSuccess) { rc = SS_EDEVICE; break; }
+    bool ovf = false;
+    for (uint32_t i = 0; i < nq; i++) ovf |= out_count[i] == 0xFFFFFFFFu;
+    if (!ovf) break;
+    if (attempt == 1) { rc = SS_EDEVICE; break; }  // cannot overflow in safe mode
+  }
+  if (rc == SS_OK) {
+    if (hipMemcpy(out_doc, s->d_out_doc, (size_t)nq * k * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(out_score, s->d_out_score, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(out_total, s->d_out_total, (size_t)nq * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess)
+      rc = SS_EDEVICE;
+  }
+  (void)hipFree(d_q);
+  return rc;
+}
+
+int ss_vec_search_dev(ss_shard* s, uint32_t nq, const float* d_queries, uint32_t k, float thr, uint32_t* d_out_doc,
+                      float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, void* stream) {
+  if (!s || !d_queries || !d_out_doc || !d_out_score || !d_out_count || !d_out_total) return SS_EINVAL;
+  if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
+  if (!s->d_X) return SS_ESTATE;
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  hipStream_t st = stream ? (hipStream_t)stream : s->stream;
+  return ssi_vec_search(s, nq, d_queries, k, thr, d_out_doc, d_out_score, d_out_count, d_out_total, st, false);
+}
+
+// ------------------------------------------------------------------ cross-shard merge + RRF (search.rs:1875-2119)
+int ss_merge_results(int mode, const uint64_t* lex_doc, const float* lex_score, uint32_t n_lex, const uint64_t* vec_doc,
+                     const float* vec_score, uint32_t n_vec, uint32_t offset, uint32_t length, uint64_t* out_doc,
+                     float* out_score, uint8_t* out_source) {
+  if (mode < SS_MODE_LEXICAL || mode > SS_MODE_HYBRID) return SS_EINVAL;
+  if ((n_lex && (!lex_doc || !lex_score)) || (n_vec && (!vec_doc || !vec_score))) return SS_EINVAL;
+  if (length && (!out_doc || !out_score)) return SS_EINVAL;
+  struct R { uint64_t doc; float score; uint8_t src; };
+  std::vector<R> res;
+  auto by_score_desc = [](const R& a, const R& b) { return a.score > b.score; };
+  if (mode == SS_MODE_LEXICAL) {
+    for (uint32_t i = 0; i < n_lex; i++) res.push_back({lex_doc[i], lex_score[i], SS_SRC_LEXICAL});
+  } else if (mode == SS_MODE_VECTOR) {
+    for (uint32_t i = 0; i < n_vec; i++) res.push_back({vec_doc[i], vec_score[i], SS_SRC_VECTOR});
+  } else {
+    // reciprocal rank fusion, k = 0.6, 0-based ranks over the score-sorted concatenation (search.rs:1962-2035)
+    std::vector<R> L, V;
+    for (uint32_t i = 0; i < n_lex; i++) L.push_back({lex_doc[i], lex_score[i], SS_SRC_LEXICAL});
+    for (uint32_t i = 0; i < n_vec; i++) V.push_back({vec_doc[i], vec_score[i], SS_SRC_VECTOR});
+    std::stable_sort(L.begin(), L.end(), by_score_desc);
+    std::stable_sort(V.begin(), V.end(), by_score_desc);
+    std::unordered_map<uint64_t, size_t> at;
+    for (size_t i = 0; i < L.size(); i++) {
+      float r = 1.0f / (0.6f + (float)i);
+      auto it = at.find(L[i].doc);
+      if (it == at.end()) { at.emplace(L[i].doc, res.size()); res.push_back({L[i].doc, r, SS_SRC_LEXICAL}); }
+      else res[it->second].score = r;  // AHashMap::insert overwrites
+    }
+    for (size_t i = 0; i < V.size(); i++) {
+      float r = 1.0f / (0.6f + (float)i);
+      auto it = at.find(V[i].doc);
+      if (it == at.end()) { at.emplace(V[i].doc, res.size()); res.push_back({V[i].doc, r, SS_SRC_VECTOR}); }
+      else { res[it->second].score += r; res[it->second].src = SS_SRC_HYBRID; }
+    }
+    // the reference leaves equal RRF scores in hash order (search.rs:2034); we fix doc id ascending
+    std::sort(res.begin(), res.end(), [](const R& a, const R& b) { return a.doc < b.doc; });
+  }
+  std::stable_sort(res.begin(), res.end(), by_score_desc);  // search.rs:2103-2105
+  uint32_t w = 0;
+  for (size_t i = offset; i < res.size() && w < length; i++, w++) {
+    out_doc[w] = res[i].doc;
+    out_score[w] = res[i].score;
+    if (out_source) out_source[w] = res[i].src;
+  }
+  return (int)w;
+}
+
+// ------------------------------------------------------------------ measurement hooks
+int ss_profile_enable(ss_shard* s, int on) {
+  if (!s) return SS_EINVAL;
+  std::lock_guard<std::mutex> g(s->mu);
+  s->prof.on = on != 0;
+  return SS_OK;
+}
+
+int ss_profile_read(ss_shard* s, int kernel, uint64_t* launches, double* total_ms, int reset) {
+  if (!s || kernel < 0 || kernel > 1) return SS_EINVAL;
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  for (auto& pr : s->prof.pending[kernel]) {
+    SS_HIP(hipEventSynchronize(pr.second));
+    float ms = 0.f;
+    SS_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+    s->prof.ms[kernel] += ms;
+    s->prof.launches[kernel] += 1;
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  s->prof.pending[kernel].clear();
+  if (launches) *launches = s->prof.launches[kernel];
+  if (total_ms) *total_ms = s->prof.ms[kernel];
+  if (reset) { s->prof.launches[kernel] = 0; s->prof.ms[kernel] = 0.0; }
+  return SS_OK;
+}
+
+}  // extern "C"
+
+void ssi_prof_begin(ss_shard* s, int kernel, hipStream_t st, hipEvent_t* e0, hipEvent_t* e1) {
+  (void)kernel;
+  *e0 = nullptr; *e1 = nullptr;
+  if (!s->prof.on) return;
+  if (hipEventCreate(e0) != hipSuccess || hipEventCreate(e1) != hipSuccess) { *e0 = *e1 = nullptr; return; }
+  (void)hipEventRecord(*e0, st);
+}
+void ssi_prof_end(ss_shard* s, int kernel, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+  if (!e0 || !e1) return;
+  (void)hipEventRecord(e1, st);
+  s->prof.pending[kernel].emplace_back(e0, e1);
+}

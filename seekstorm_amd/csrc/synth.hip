@@ -1,0 +1,235 @@
+// HBM image builders: (a) from host arrays (ss_bm25_upload), (b) device-side synthetic corpora whose
+// counter-based generator is bit-identical to the CPU oracle's (oracle/ss_oracle.c so_lex_* / so_vec_gen), so a
+// 10M-doc / 10M x 768 corpus never crosses PCIe and the oracle can still regenerate any slice of it.
+#include "ss_common.h"
+
+#include <cmath>
+#include <cstring>
+
+typedef unsigned long long u64;
+
+__host__ __device__ inline u64 ss_splitmix64(u64 x) {
+  x += 0x9E3779B97F4A7C15ull;
+  u64 z = x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__host__ __device__ inline u64 ss_h(u64 seed, u64 a, u64 b) {
+  return ss_splitmix64(seed ^ (a * 0x9E3779B97F4A7C15ull) ^ (b * 0xC2B2AE3D27D4EB4Full));
+}
+// SmallFloat decode, index.rs:4255-4268
+__host__ __device__ inline uint32_t ss_byte4_to_int(uint32_t b) {
+  if (b < 24u) return b;
+  uint32_t i = b - 24u, bits = i & 7u, shift = i >> 3;
+  return shift == 0 ? 24u + bits : 24u + ((bits | 8u) << (shift - 1u));
+}
+
+// ---------------------------------------------------------------- vectors
+// one thread per row: uniform(-1,1) from the hash, then normalize_f32 semantics (vector_similarity.rs:70-74):
+// sequential sum of squares (unfused), factor = 1/sqrt(sum), multiply.
+__global__ void vec_synth_kernel(float* __restrict__ X, u64 seed, u64 n_rows, uint32_t dim, uint32_t dim_pad) {
+  u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  float* row = X + r * dim_pad;
+  float s = 0.f;
+  for (uint32_t c = 0; c < dim; c++) {
+    int iv = (int)(uint32_t)(ss_h(seed, r, c) >> 32);
+    float v = __fmul_rn((float)iv, 4.656612873077392578125e-10f);
+    s = __fadd_rn(s, __fmul_rn(v, v));
+  }
+  float f = __fdiv_rn(1.0f, __fsqrt_rn(s));
+  for (uint32_t c = 0; c < dim; c++) {
+    int iv = (int)(uint32_t)(ss_h(seed, r, c) >> 32);
+    row[c] = __fmul_rn(__fmul_rn((float)iv, 4.656612873077392578125e-10f), f);
+  }
+}
+
+int ssi_vec_synth(ss_shard* s, uint64_t seed, hipStream_t st) {
+  u64 n = s->n_rows;
+  uint32_t grid = (uint32_t)((n + 255) / 256);
+  vec_synth_kernel<<<grid, 256, 0, st>>>(s->d_X, seed, n, s->dim, s->dim_pad);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
+// ---------------------------------------------------------------- BM25 image from host arrays
+static void fill_comp(float avgdl, float* comp) {  // commit.rs:321-325
+  for (int i = 0; i < 256; i++) {
+    float q = (float)ss_byte4_to_int((uint32_t)i) / avgdl;
+    comp[i] = 1.2f * (1.0f - 0.75f + 0.75f * q);
+  }
+}
+
+static int alloc_image(ss_shard* s, u64 n_post) {
+  const size_t rows = (size_t)s->bm_n_terms * (s->bm_n_sub + 1);
+  SS_HIP(hipMalloc(&s->d_post, (n_post + 256) * sizeof(uint32_t)));
+  SS_HIP(hipMemset(s->d_post + n_post, 0, 256 * sizeof(uint32_t)));
+  SS_HIP(hipMalloc(&s->d_term_base, ((size_t)s->bm_n_terms + 1) * sizeof(u64)));
+  SS_HIP(hipMalloc(&s->d_sub_off, (rows ? rows : 1) * sizeof(uint32_t)));
+  SS_HIP(hipMalloc(&s->d_comp, 256 * sizeof(float)));
+  return SS_OK;
+}
+
+int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t* offs, const uint32_t* docs,
+                             const uint16_t* tfs) {
+  const uint32_t nt = s->bm_n_terms, ns = s->bm_n_sub;
+  const u64 n_post = offs[nt];
+  u64 psum = 0;
+  for (u64 d = 0; d < s->bm_n_docs; d++) psum += ss_byte4_to_int(doclen[d]);
+  s->bm_avgdl = (float)psum / (float)s->bm_n_docs;  // commit.rs:318-319
+  float comp[256];
+  fill_comp(s->bm_avgdl, comp);
+  std::vector<uint32_t> post(n_post ? n_post : 1);
+  std::vector<uint32_t> sub((size_t)nt * (ns + 1));
+  for (uint32_t t = 0; t < nt; t++) {
+    uint32_t* row = sub.data() + (size_t)t * (ns + 1);
+    u64 i = offs[t];
+    for (uint32_t sb = 0; sb <= ns; sb++) {
+      u64 lim = (u64)sb << BM_SUB_LOG2;
+      while (i < offs[t + 1] && docs[i] < lim) i++;
+      if (i - offs[t] > 0xFFFFFFFFull) return SS_ENOTSUP;
+      row[sb] = (uint32_t)(i - offs[t]);
+    }
+    for (u64 j = offs[t]; j < offs[t + 1]; j++) {
+      if (docs[j] >= s->bm_n_docs) return SS_EINVAL;
+      if (j > offs[t] && docs[j] <= docs[j - 1]) return SS_EINVAL;
+      if (tfs[j] == 0) return SS_EINVAL;
+      if (tfs[j] > BM_TF_MAX) return SS_ENOTSUP;
+      post[j] = bm_pack(docs[j] & (BM_SUB - 1), doclen[docs[j]], tfs[j]);
+    }
+  }
+  s->bm_n_post = n_post;
+  int rc = alloc_image(s, n_post);
+  if (rc) return rc;
+  SS_HIP(hipMemcpy(s->d_post, post.data(), n_post * sizeof(uint32_t), hipMemcpyHostToDevice));
+  SS_HIP(hipMemcpy(s->d_term_base, offs, ((size_t)nt + 1) * sizeof(u64), hipMemcpyHostToDevice));
+  SS_HIP(hipMemcpy(s->d_sub_off, sub.data(), sub.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  SS_HIP(hipMemcpy(s->d_comp, comp, sizeof(comp), hipMemcpyHostToDevice));
+  s->h_term_base.assign(offs, offs + nt + 1);
+  return SS_OK;
+}
+
+// ---------------------------------------------------------------- BM25 synthetic image, generated on device
+__global__ void lex_doclen_kernel(uint8_t* __restrict__ doclen, u64 seed, u64 n_docs, const uint8_t* __restrict__ tab,
+                                  u64* __restrict__ psum) {
+  u64 d = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 v = 0;
+  if (d < n_docs) {
+    uint8_t b = tab[ss_h(seed, 0, d) >> 54];
+    doclen[d] = b;
+    v = ss_byte4_to_int(b);
+  }
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(psum, v);
+}
+
+// one wave per (term, sub-block): count / fill postings in ascending doc order
+template <bool FILL>
+__global__ void lex_gen_kernel(u64 seed, u64 n_docs, uint32_t n_terms, uint32_t n_sub, const uint32_t* __restrict__ thresh,
+                               const uint8_t* __restrict__ doclen, uint32_t* __restrict__ sub_cnt /*[nt][ns+1]*/,
+                               const u64* __restrict__ term_base, uint32_t* __restrict__ post) {
+  const int lane = threadIdx.x & 63;
+  const u64 gw = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const u64 total = (u64)n_terms * n_sub;
+  if (gw >= total) return;
+  const uint32_t t = (uint32_t)(gw / n_sub), sb = (uint32_t)(gw % n_sub);
+  const uint32_t th = thresh[t];
+  const u64 d0 = (u64)sb << BM_SUB_LOG2;
+  uint32_t run = 0;
+  u64 base = 0;
+  if (FILL) base = term_base[t] + sub_cnt[(size_t)t * (n_sub + 1) + sb];
+  for (int i = 0; i < BM_SUB / 64; i++) {
+    u64 d = d0 + (u64)i * 64 + lane;
+    u64 hv = ss_h(seed, (u64)t + 1, d);
+    bool present = d < n_docs && (uint32_t)(hv >> 32) < th;
+    u64 m = __ballot(present);
+    if (FILL && present) {
+      uint32_t pos = run + __popcll(m & ((1ull << lane) - 1ull));
+      uint32_t lo = (uint32_t)hv | 0x80000000u;
+      uint32_t tf = 1u + (uint32_t)__builtin_ctz(lo);
+      post[base + pos] = bm_pack((uint32_t)(d & (BM_SUB - 1)), doclen[d], tf);
+    }
+    run += __popcll(m);
+  }
+  if (!FILL && lane == 0) sub_cnt[(size_t)t * (n_sub + 1) + sb + 1] = run;  // shifted by one for the exclusive scan
+}
+
+// per term: in-place inclusive scan of row[1..ns] (row[0] = 0) -> exclusive offsets; writes the term total
+__global__ void lex_scan_rows_kernel(uint32_t* __restrict__ sub, uint32_t n_sub, u64* __restrict__ term_tot) {
+  const uint32_t t = blockIdx.x;
+  uint32_t* row = sub + (size_t)t * (n_sub + 1);
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) { carry = 0; row[0] = 0; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (uint32_t b0 = 1; b0 <= n_sub; b0 += blockDim.x) {
+    uint32_t i = b0 + threadIdx.x;
+    uint32_t v = i <= n_sub ? row[i] : 0;
+    uint32_t x = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      uint32_t y = __shfl_up(x, o);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    uint32_t pre = carry;
+    for (int j = 0; j < w; j++) pre += wsum[j];
+    if (i <= n_sub) row[i] = pre + x;
+    __syncthreads();
+    if (threadIdx.x == blockDim.x - 1) carry = pre + x;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) term_tot[t] = carry;
+}
+
+__global__ void lex_scan_terms_kernel(const u64* __restrict__ tot, u64* __restrict__ base, uint32_t n_terms) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    u64 a = 0;
+    for (uint32_t t = 0; t < n_terms; t++) { base[t] = a; a += tot[t]; }
+    base[n_terms] = a;
+  }
+}
+
+int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const uint8_t* d_lentab, hipStream_t st) {
+  const uint32_t nt = s->bm_n_terms, ns = s->bm_n_sub;
+  const u64 nd = s->bm_n_docs;
+  uint8_t* d_doclen = nullptr;
+  u64* d_psum = nullptr;
+  u64* d_tot = nullptr;
+  SS_HIP(hipMalloc(&d_doclen, nd));
+  SS_HIP(hipMalloc(&d_psum, sizeof(u64)));
+  SS_HIP(hipMalloc(&d_tot, (size_t)nt * sizeof(u64)));
+  SS_HIP(hipMemsetAsync(d_psum, 0, sizeof(u64), st));
+  lex_doclen_kernel<<<(uint32_t)((nd + 255) / 256), 256, 0, st>>>(d_doclen, seed, nd, d_lentab, d_psum);
+  const size_t rows = (size_t)nt * (ns + 1);
+  SS_HIP(hipMalloc(&s->d_sub_off, rows * sizeof(uint32_t)));
+  SS_HIP(hipMalloc(&s->d_term_base, ((size_t)nt + 1) * sizeof(u64)));
+  SS_HIP(hipMalloc(&s->d_comp, 256 * sizeof(float)));
+  const u64 waves = (u64)nt * ns;
+  const uint32_t grid = (uint32_t)((waves + 3) / 4);
+  lex_gen_kernel<false><<<grid, 256, 0, st>>>(seed, nd, nt, ns, d_thresh, d_doclen, s->d_sub_off, nullptr, nullptr);
+  lex_scan_rows_kernel<<<nt, 1024, 0, st>>>(s->d_sub_off, ns, d_tot);
+  lex_scan_terms_kernel<<<1, 64, 0, st>>>(d_tot, (u64*)s->d_term_base, nt);
+  SS_HIP(hipStreamSynchronize(st));
+  s->h_term_base.resize((size_t)nt + 1);
+  SS_HIP(hipMemcpy(s->h_term_base.data(), s->d_term_base, ((size_t)nt + 1) * sizeof(u64), hipMemcpyDeviceToHost));
+  u64 psum = 0;
+  SS_HIP(hipMemcpy(&psum, d_psum, sizeof(u64), hipMemcpyDeviceToHost));
+  s->bm_n_post = s->h_term_base[nt];
+  s->bm_avgdl = (float)psum / (float)nd;
+  float comp[256];
+  fill_comp(s->bm_avgdl, comp);
+  SS_HIP(hipMemcpy(s->d_comp, comp, sizeof(comp), hipMemcpyHostToDevice));
+  SS_HIP(hipMalloc(&s->d_post, (s->bm_n_post + 256) * sizeof(uint32_t)));
+  SS_HIP(hipMemsetAsync(s->d_post + s->bm_n_post, 0, 256 * sizeof(uint32_t), st));
+  lex_gen_kernel<true><<<grid, 256, 0, st>>>(seed, nd, nt, ns, d_thresh, d_doclen, s->d_sub_off,
+                                             (const u64*)s->d_term_base, s->d_post);
+  SS_HIP(hipStreamSynchronize(st));
+  (void)hipFree(d_doclen);
+  (void)hipFree(d_psum);
+  (void)hipFree(d_tot);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}

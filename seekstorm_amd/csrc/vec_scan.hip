@@ -1,0 +1,336 @@
+// Dense-vector brute-force scan (AnnMode::All, F32 dot / cosine) for gfx950.
+//
+// Replaces search_vector_shard's hot loop (vector.rs:1397-1466: read_record -> dot_f32_avx2 ->
+// TopK::push) for a batch of up to 64 queries per pass over the matrix.
+//
+//   scores[N x 64] = X[N x dim] . Q^T  computed with v_mfma_f32_32x32x2_f32 (exact f32 fma chain),
+//   never materialised: each wave holds a 32-row x 64-query accumulator tile, compares it in
+//   registers against the per-query running threshold tau (the current k-th best score) and appends
+//   the rare survivors to a per-query candidate buffer.  A tiny "refine" kernel between geometrically
+//   growing row chunks re-selects the exact top-k and raises tau (TopK::push semantics, vector.rs:410-496:
+//   strict '>' against the current minimum; ties keep the earlier row).
+//
+// Data movement: X streams HBM -> LDS with global_load_lds_dwordx4 in full 128-byte lines (8 lanes per
+// row-line, XOR-swizzled on the SOURCE piece so ds_read_b128 of the MFMA A fragments is conflict-free);
+// Q is pre-permuted into MFMA B-fragment order once per batch and re-streamed from L2 per K-chunk.
+// 3-stage LDS ring, counted vmcnt, one raw s_barrier per K-chunk, persistent across tiles.
+#include "ss_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+struct VState {
+  float tau[64];
+  uint32_t cnt[64];
+  uint32_t kept[64];
+  uint32_t ovf;
+  uint32_t pad[63];
+  unsigned long long total[64];
+};
+
+__device__ __forceinline__ uint32_t f2ord(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+  uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+  return __uint_as_float(u);
+}
+// larger key = better: (score desc, row asc)
+__device__ __forceinline__ unsigned long long mk_key(float s, uint32_t row) {
+  return ((unsigned long long)f2ord(s) << 32) | (unsigned long long)(0xFFFFFFFFu - row);
+}
+
+// ---------------------------------------------------------------- Q -> MFMA B-fragment order
+// Qf[kc][nt(2)][t(4)][lane(64)][j(4)] = Q[q = nt*32 + (lane&31)][k = kc*32 + (2t + (lane>>5))*4 + j]
+__global__ void vec_qprep_kernel(const float* __restrict__ Q, uint32_t nq, uint32_t dim, float* __restrict__ Qf) {
+  const uint32_t kc = blockIdx.x;
+  for (uint32_t e = threadIdx.x; e < 2048; e += blockDim.x) {
+    uint32_t j = e & 3, lane = (e >> 2) & 63, t = (e >> 8) & 3, nt = e >> 10;
+    uint32_t q = nt * 32 + (lane & 31);
+    uint32_t k = kc * 32 + (2 * t + (lane >> 5)) * 4 + j;
+    Qf[(size_t)kc * 2048 + e] = (q < nq && k < dim) ? Q[(size_t)q * dim + k] : 0.0f;
+  }
+}
+
+__global__ void vec_init_kernel(VState* st, float tau_init) {
+  int i = threadIdx.x;
+  if (i < 64) {
+    st->tau[i] = tau_init;
+    st->cnt[i] = 0;
+    st->kept[i] = 0;
+    st->total[i] = 0ull;
+  }
+  if (i == 0) st->ovf = 0;
+}
+
+// ---------------------------------------------------------------- the scan
+__global__ void __launch_bounds__(VS_WAVES * 64, 2)
+vec_scan_kernel(const float* __restrict__ X, uint32_t dim_pad, unsigned long long n_rows,
+                const float* __restrict__ Qf, uint32_t nch, uint32_t tile0, uint32_t ntiles, VState* __restrict__ st,
+                unsigned long long* __restrict__ cand) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // per-launch constants: my two queries' thresholds (tau only changes between launches)
+  float tau0 = st->tau[lane & 31];
+  float tau1 = st->tau[32 + (lane & 31)];
+  if (st->ovf) return;
+  // pin the thresholds in registers NOW: a compiler-placed wait at their first use (the per-tile epilogue)
+  // would be a vmcnt(0) that drains the LDS-DMA ring once per tile
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(tau0), "+v"(tau1)::"memory");
+
+  // tiles of this workgroup: tile0 + blockIdx.x + i * gridDim.x
+  const uint32_t first = blockIdx.x;
+  if (first >= ntiles) return;
+  const uint32_t my_tiles = (ntiles - first + gridDim.x - 1) / gridDim.x;
+  const uint32_t G = my_tiles * nch;
+
+  // ---- producer addressing (global -> LDS, 16 B per lane, 8 lanes per 128-B row line)
+  uint32_t xsrc[4];  // float offset of my piece inside the tile's chunk, per issue i
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    uint32_t rl = 32u * w + 8u * i + (lane >> 3);     // row inside tile
+    uint32_t f = (rl >> 1) & 7u;                      // swizzle key (conflict-free ds_read_b128)
+    uint32_t piece = (uint32_t)(lane & 7) ^ f;        // logical 16-B piece fetched into physical slot lane&7
+    xsrc[i] = rl * dim_pad + piece * 4u;
+  }
+  const size_t tile_stride = (size_t)VS_TR * dim_pad;  // floats per tile
+
+  // ---- consumer addressing
+  uint32_t aoff[4];
+  {
+    uint32_t rw = 32u * w + (lane & 31);
+    uint32_t f = (rw >> 1) & 7u;
+#pragma unroll
+    for (int t = 0; t < 4; t++) aoff[t] = rw * 128u + (((2u * t + (lane >> 5)) ^ f) << 4);
+  }
+  const uint32_t boff = VS_XS + lane * 16u;
+
+  uint32_t i_tile = 0, i_kc = 0, i_stage = 0;  // issue cursor
+  auto issue = [&]() {
+    const float* xt = X + (size_t)(tile0 + first + (size_t)i_tile * gridDim.x) * tile_stride + i_kc * VS_KC;
+    char* sb = smem + i_stage * VS_STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      __builtin_amdgcn_global_load_lds(GPTR(xt + xsrc[i]), LPTR(sb + (32 * w + 8 * i) * 128), 16, 0, 0);
+    const float* qs = Qf + (size_t)i_kc * 2048 + lane * 4;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+      __builtin_amdgcn_global_load_lds(GPTR(qs + (2 * w + i) * 256), LPTR(sb + VS_XS + (2 * w + i) * 1024), 16, 0, 0);
+    if (++i_kc == nch) { i_kc = 0; ++i_tile; }
+    if (++i_stage == VS_STAGES) i_stage = 0;
+  };
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+  issue();
+  if (G > 1) issue();
+
+  uint32_t c_tile = 0, c_kc = 0, c_stage = 0;  // consume cursor
+  for (uint32_t g = 0; g < G; ++g) {
+    // my own 6 LDS-DMA pieces of chunk g have landed (chunk g+1's 6 may still be in flight)
+    if (g + 1 < G) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // everyone's pieces landed; everyone finished reading stage (g-1)%3
+    if (g + 2 < G) issue();        // refill the stage consumed in iteration g-1
+
+    const char* sb = smem + c_stage * VS_STAGE;
+    f32x4 xa[4], qb0[4], qb1[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      xa[t] = *(const f32x4*)(sb + aoff[t]);
+      qb0[t] = *(const f32x4*)(sb + boff + t * 1024);
+      qb1[t] = *(const f32x4*)(sb + boff + (4 + t) * 1024);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[t][j], qb0[t][j], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[t][j], qb1[t][j], acc1, 0, 0, 0);
+      }
+    }
+
+    if (++c_kc == nch) {
+      // ---- fused top-k filter: lane owns query (lane&31)+{0,32}, 16 rows per accumulator
+      const unsigned long long row_base =
+          (unsigned long long)(tile0 + first + (unsigned long long)c_tile * gridDim.x) * VS_TR + 32u * w + 4u * (lane >> 5);
+      float m0 = acc0[0], m1 = acc1[0];
+#pragma unroll
+      for (int r = 1; r < 16; r++) { m0 = fmaxf(m0, acc0[r]); m1 = fmaxf(m1, acc1[r]); }
+      if (m0 > tau0) {
+        const uint32_t q = lane & 31;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          unsigned long long row = row_base + (r & 3) + 8 * (r >> 2);
+          if (acc0[r] > tau0 && row < n_rows) {
+            uint32_t slot = atomicAdd(&st->cnt[q], 1u);
+            if (slot < VS_CAP) cand[(size_t)q * VS_CAP + slot] = mk_key(acc0[r], (uint32_t)row);
+          }
+        }
+      }
+      if (m1 > tau1) {
+        const uint32_t q = 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          unsigned long long row = row_base + (r & 3) + 8 * (r >> 2);
+          if (acc1[r] > tau1 && row < n_rows) {
+            uint32_t slot = atomicAdd(&st->cnt[q], 1u);
+            if (slot < VS_CAP) cand[(size_t)q * VS_CAP + slot] = mk_key(acc1[r], (uint32_t)row);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
+      c_kc = 0;
+      ++c_tile;
+    }
+    if (++c_stage == VS_STAGES) c_stage = 0;
+  }
+}
+
+// ---------------------------------------------------------------- refine: exact top-k of the candidates, raise tau
+// One workgroup per query.  Sorts the (<= VS_CAP) candidate keys descending in LDS (bitonic), keeps the best k
+// at the front of the buffer, sets tau = k-th best score (TopK::push admits only score > current minimum).
+__global__ void __launch_bounds__(1024) vec_refine_kernel(VState* __restrict__ st, unsigned long long* __restrict__ cand,
+                                                         uint32_t k) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* keys = (unsigned long long*)smem;
+  const uint32_t q = blockIdx.x;
+  const uint32_t raw = st->cnt[q];
+  const uint32_t kept = st->kept[q];
+  if (raw == kept) return;  // nothing new since the last refine
+  if (raw > VS_CAP) {
+    if (threadIdx.x == 0) st->ovf = 1;  // candidate buffer overflow: host re-runs the batch in safe mode
+    return;
+  }
+  const uint32_t n = raw;
+  uint32_t np = 64;
+  while (np < n) np <<= 1;
+  unsigned long long* base = cand + (size_t)q * VS_CAP;
+  for (uint32_t i = threadIdx.x; i < np; i += blockDim.x) keys[i] = i < n ? base[i] : 0ull;
+  __syncthreads();
+  for (uint32_t size = 2; size <= np; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      for (uint32_t i = threadIdx.x; i < (np >> 1); i += blockDim.x) {
+        uint32_t lo = 2 * i - (i & (stride - 1));
+        uint32_t hi = lo + stride;
+        bool desc = ((lo & size) == 0);
+        unsigned long long a = keys[lo], b = keys[hi];
+        if ((a < b) == desc) { keys[lo] = b; keys[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  const uint32_t keep = n < k ? n : k;
+  for (uint32_t i = threadIdx.x; i < keep; i += blockDim.x) base[i] = keys[i];
+  if (threadIdx.x == 0) {
+    st->total[q] += (unsigned long long)(n - kept);
+    st->cnt[q] = keep;
+    st->kept[q] = keep;
+    if (n >= k && k > 0) st->tau[q] = ord2f((uint32_t)(keys[k - 1] >> 32));
+  }
+}
+
+__global__ void vec_final_kernel(const VState* __restrict__ st, const unsigned long long* __restrict__ cand,
+                                 const uint32_t* __restrict__ row_doc, uint32_t nq, uint32_t k,
+                                 uint32_t* __restrict__ out_doc, float* __restrict__ out_score,
+                                 uint32_t* __restrict__ out_count, unsigned long long* __restrict__ out_total) {
+  const uint32_t q = blockIdx.x;
+  if (q >= nq) return;
+  const uint32_t n = st->cnt[q] < k ? st->cnt[q] : k;
+  for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
+    uint32_t doc = SS_NO_DOC;
+    float sc = 0.f;
+    if (i < n) {
+      unsigned long long key = cand[(size_t)q * VS_CAP + i];
+      uint32_t row = 0xFFFFFFFFu - (uint32_t)key;
+      doc = row_doc ? row_doc[row] : row;
+      sc = ord2f((uint32_t)(key >> 32));
+    }
+    out_doc[(size_t)q * k + i] = doc;
+    out_score[(size_t)q * k + i] = sc;
+  }
+  if (threadIdx.x == 0) {
+    out_count[q] = st->ovf ? 0xFFFFFFFFu : n;
+    out_total[q] = st->total[q];
+  }
+}
+
+// ---------------------------------------------------------------- host side
+int ssi_vec_alloc_ws(ss_shard* s) {
+  if (!s->d_Qf) {
+    const uint32_t nch = s->dim_pad / VS_KC;
+    SS_HIP(hipMalloc(&s->d_Qf, (size_t)nch * 2048 * sizeof(float)));
+  }
+  if (!s->d_vstate) SS_HIP(hipMalloc(&s->d_vstate, sizeof(VState)));
+  if (!s->d_cand) SS_HIP(hipMalloc(&s->d_cand, (size_t)64 * VS_CAP * sizeof(unsigned long long)));
+  static bool attr_done = false;
+  if (!attr_done) {
+    SS_HIP(hipFuncSetAttribute((const void*)vec_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, VS_LDS));
+    SS_HIP(hipFuncSetAttribute((const void*)vec_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               VS_CAP * sizeof(unsigned long long)));
+    attr_done = true;
+  }
+  return SS_OK;
+}
+
+int ssi_vec_search(ss_shard* s, uint32_t nq, const float* d_queries, uint32_t k, float thr, uint32_t* d_out_doc,
+                   float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, hipStream_t st, bool safe_mode) {
+  if (!s->d_X) return SS_ESTATE;
+  if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
+  int rc = ssi_vec_alloc_ws(s);
+  if (rc) return rc;
+  const uint32_t nch = s->dim_pad / VS_KC;
+  const uint32_t T = (uint32_t)(s->n_rows_pad / VS_TR);
+  VState* vst = (VState*)s->d_vstate;
+  unsigned long long* cand = (unsigned long long*)s->d_cand;
+  // `score < threshold -> reject` (vector.rs:423)  ==  admit score > nextafter(threshold, -inf)
+  const float tau_init = (thr <= -3.4028234663852886e38f) ? -INFINITY : nextafterf(thr, -INFINITY);
+
+  // chunk schedule (data independent): first chunk small (everything is a candidate), then geometric growth
+  // so that the expected number of survivors per chunk stays ~ k * growth << VS_CAP.
+  std::vector<uint32_t> chunks;
+  if (safe_mode) {
+    uint32_t step = (VS_CAP - k) / VS_TR;
+    for (uint32_t d = 0; d < T; d += step) chunks.push_back(std::min(step, T - d));
+  } else {
+    double growth = std::max(1.5, std::min(4.0, (double)(VS_CAP - k) / (2.0 * k)));
+    uint32_t done = std::min<uint32_t>(T, VS_FIRST_TILES);
+    chunks.push_back(done);
+    while (done < T) {
+      uint32_t c = (uint32_t)std::min<double>((double)(T - done), std::max(1.0, done * growth));
+      chunks.push_back(c);
+      done += c;
+    }
+  }
+
+  for (uint32_t g0 = 0; g0 < nq; g0 += SS_VEC_BATCH) {
+    const uint32_t nb = std::min<uint32_t>(SS_VEC_BATCH, nq - g0);
+    vec_qprep_kernel<<<nch, 512, 0, st>>>(d_queries + (size_t)g0 * s->dim, nb, s->dim, s->d_Qf);
+    vec_init_kernel<<<1, 64, 0, st>>>(vst, tau_init);
+    uint32_t tile0 = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ssi_prof_begin(s, 1, st, &e0, &e1);
+    for (uint32_t c : chunks) {
+      uint32_t grid = std::min<uint32_t>(c, 512);
+      vec_scan_kernel<<<grid, VS_WAVES * 64, VS_LDS, st>>>(s->d_X, s->dim_pad, (unsigned long long)s->n_rows, s->d_Qf,
+                                                           nch, tile0, c, vst, cand);
+      vec_refine_kernel<<<SS_VEC_BATCH, 1024, VS_CAP * sizeof(unsigned long long), st>>>(vst, cand, k);
+      tile0 += c;
+    }
+    ssi_prof_end(s, 1, st, e0, e1);
+    vec_final_kernel<<<nb, 128, 0, st>>>(vst, cand, s->d_row_doc, nb, k, d_out_doc + (size_t)g0 * k,
+                                         d_out_score + (size_t)g0 * k, d_out_count + g0,
+                                         (unsigned long long*)d_out_total + g0);
+  }
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}

@@ -1,0 +1,312 @@
+"""Host-side mirror of the reference's search interface for the query hot path.
+
+Names, argument meaning and error behaviour follow the `seekstorm` crate (citations relative to
+/root/reference/seekstorm/src):
+
+  QueryType / ResultType / SearchMode / ResultSource / Result / ResultObject   search.rs:59,168,73,186; min_heap.rs:17-40
+  Shard.search_lexical_shard     <- SearchLexicalShard::search_lexical_shard     search.rs:2427-2442
+  Shard.search_vector_shard      <- SearchVectorShard::search_vector_shard       vector.rs:1105-1115
+  Index.search                   <- <IndexArc as Search>::search                 search.rs:1134-1150, 1154-2131
+
+Out of scope by SURVEY.md section 8 (stays in the Rust host): tokenizer / term hashing, so a query is a list of
+resolved term ids instead of a query string; facets, filters, highlights, query rewriting.
+
+All compute goes through the C ABI (seekstorm_amd/_native.py -> libseekstorm_hip.so).  Like the reference's search
+path, a failing shard degrades to an empty ResultObject (search.rs:2461-2463, vector.rs:1222-1224) unless
+`strict=True` is passed, in which case the C-ABI error is raised.
+"""
+import ctypes as C
+import enum
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _native as N
+
+
+class QueryType(enum.IntEnum):  # search.rs:59
+    Union = N.OP_UNION
+    Intersection = N.OP_INTERSECTION
+
+
+class ResultType(enum.IntEnum):  # search.rs:168
+    Count = N.RT_COUNT
+    Topk = N.RT_TOPK
+    TopkCount = N.RT_TOPKCOUNT
+
+
+class SearchMode(enum.IntEnum):  # search.rs:73
+    Lexical = N.MODE_LEXICAL
+    Vector = N.MODE_VECTOR
+    Hybrid = N.MODE_HYBRID
+
+
+class ResultSource(enum.IntEnum):  # min_heap.rs
+    Lexical = N.SRC_LEXICAL
+    Vector = N.SRC_VECTOR
+    Hybrid = N.SRC_HYBRID
+
+
+@dataclass
+class Result:  # min_heap.rs:17-40 (fields of the hot path)
+    doc_id: int
+    score: float
+    source: ResultSource = ResultSource.Lexical
+
+
+@dataclass
+class ResultObject:  # search.rs:186-213
+    results: List[Result] = field(default_factory=list)
+    result_count: int = 0
+    result_count_total: int = 0
+    observed_vector_count: int = 0
+
+
+SIMILARITY_NORMALIZATION_64_I8 = np.float32(1.0) / np.float32(16129.0)  # vector.rs:29
+
+
+def normalize_f32(v):
+    """vector_similarity.rs:70-74 (query-side normalisation, search.rs:1464-1475)."""
+    v = np.ascontiguousarray(v, np.float32)
+    s = np.float32(0.0)
+    for x in v:  # sequential f32 sum like the reference
+        s = np.float32(s + np.float32(x * x))
+    return (v * (np.float32(1.0) / np.sqrt(s, dtype=np.float32))).astype(np.float32)
+
+
+def idf_f32(indexed_doc_count, posting_count):
+    """search.rs:3225-3230, all f32."""
+    Nf, nf = np.float32(indexed_doc_count), np.float32(posting_count)
+    return np.float32(np.log(((Nf - nf + np.float32(0.5)) / (nf + np.float32(0.5))) + np.float32(1.0), dtype=np.float32))
+
+
+def threshold_raw(similarity_threshold):
+    """TopK::new, vector.rs:388-397 (Dot/Cosine arm)."""
+    if similarity_threshold is None:
+        return N.FLT_MIN_NEG
+    return float(((np.float32(similarity_threshold) * np.float32(2.0)) - np.float32(1.0)) / SIMILARITY_NORMALIZATION_64_I8)
+
+
+class Shard:
+    """One shard image on one MI355X (opaque ss_shard handle)."""
+
+    def __init__(self, device=0, shard_id=0):
+        self.device = device
+        self.shard_id = shard_id
+        h = C.c_void_p()
+        N.check(N.lib().ss_shard_create(device, C.byref(h)), "ss_shard_create")
+        self._h = h
+        self._df_cache = {}
+        self.indexed_doc_count = 0
+        self.vector_count = 0
+        self.dim = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            N.lib().ss_shard_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- image (re)build: end of open_shard (index.rs:3796) / after commit (commit.rs:142-148)
+    def upload_lexical(self, n_docs, doclen_bytes, term_offsets, doc_ids, tfs):
+        dl = np.ascontiguousarray(doclen_bytes, np.uint8)
+        off = np.ascontiguousarray(term_offsets, np.uint64)
+        d = np.ascontiguousarray(doc_ids, np.uint32)
+        t = np.ascontiguousarray(tfs, np.uint16)
+        N.check(N.lib().ss_bm25_upload(self._h, int(n_docs), N.ptr(dl, N.u8p), len(off) - 1, N.ptr(off, N.u64p),
+                                       N.ptr(d, N.u32p), N.ptr(t, N.u16p)), "ss_bm25_upload")
+        self.indexed_doc_count = int(n_docs)
+        self._df_cache.clear()
+
+    def synth_lexical(self, seed, n_docs, thresh32, len_table1024):
+        th = np.ascontiguousarray(thresh32, np.uint32)
+        tab = np.ascontiguousarray(len_table1024, np.uint8)
+        assert tab.size == 1024
+        N.check(N.lib().ss_bm25_synth(self._h, int(seed), int(n_docs), len(th), N.ptr(th, N.u32p), N.ptr(tab, N.u8p)),
+                "ss_bm25_synth")
+        self.indexed_doc_count = int(n_docs)
+        self._df_cache.clear()
+
+    def upload_vectors(self, rows, row_doc_ids=None):
+        r = np.ascontiguousarray(rows, np.float32)
+        ids = None if row_doc_ids is None else np.ascontiguousarray(row_doc_ids, np.uint32)
+        N.check(N.lib().ss_vec_upload(self._h, r.shape[0], r.shape[1], N.ptr(r, N.f32p), N.ptr(ids, N.u32p)), "ss_vec_upload")
+        self.vector_count, self.dim = r.shape
+
+    def synth_vectors(self, seed, n_rows, dim):
+        N.check(N.lib().ss_vec_synth(self._h, int(seed), int(n_rows), int(dim)), "ss_vec_synth")
+        self.vector_count, self.dim = int(n_rows), int(dim)
+
+    def read_rows(self, r0, n):
+        out = np.empty((n, self.dim), np.float32)
+        N.check(N.lib().ss_vec_read_rows(self._h, int(r0), int(n), N.ptr(out, N.f32p)), "ss_vec_read_rows")
+        return out
+
+    def lexical_info(self):
+        nd, av, nt, npost = C.c_uint64(), C.c_float(), C.c_uint32(), C.c_uint64()
+        N.check(N.lib().ss_bm25_info(self._h, C.byref(nd), C.byref(av), C.byref(nt), C.byref(npost)), "ss_bm25_info")
+        return dict(n_docs=nd.value, avgdl=av.value, n_terms=nt.value, n_postings=npost.value)
+
+    def posting_count(self, terms):
+        terms = np.ascontiguousarray(terms, np.uint32)
+        out = np.empty(len(terms), np.uint64)
+        N.check(N.lib().ss_bm25_term_df(self._h, len(terms), N.ptr(terms, N.u32p), N.ptr(out, N.u64p)), "ss_bm25_term_df")
+        return out
+
+    # ---- query construction: term resolution + idf stay on the host (search.rs:3066-3358)
+    def make_queries(self, term_lists: Sequence[Sequence[int]], query_types):
+        nq = len(term_lists)
+        if isinstance(query_types, (int, QueryType)):
+            query_types = [query_types] * nq
+        q = np.zeros(nq, N.BM25_QUERY_DTYPE)
+        flat = np.fromiter((t for tl in term_lists for t in tl), np.uint32)
+        uniq = np.unique(flat)
+        missing = [int(t) for t in uniq if int(t) not in self._df_cache]
+        if missing:
+            for t, df in zip(missing, self.posting_count(missing)):
+                self._df_cache[t] = int(df)
+        for i, (tl, qt) in enumerate(zip(term_lists, query_types)):
+            tl = list(dict.fromkeys(int(t) for t in tl))  # unique_terms, search.rs:3023
+            if not 1 <= len(tl) <= N.SS_MAX_QUERY_TERMS:
+                raise ValueError("1..10 unique terms per query")
+            q["n_terms"][i] = len(tl)
+            q["op"][i] = int(qt)
+            for j, t in enumerate(tl):
+                q["term"][i, j] = t
+                q["idf"][i, j] = idf_f32(self.indexed_doc_count, self._df_cache[t])
+        return q
+
+    # ---- batched executors (one C-ABI call per batch)
+    def search_lexical_batch(self, queries, k, result_type=ResultType.TopkCount):
+        nq = len(queries)
+        kk = max(int(k), 1)
+        doc = np.full((nq, kk), N.SS_NO_DOC, np.uint32)
+        score = np.zeros((nq, kk), np.float32)
+        cnt = np.zeros(nq, np.uint32)
+        tot = np.zeros(nq, np.uint64)
+        N.check(N.lib().ss_bm25_search(self._h, nq, queries.ctypes.data_as(C.c_void_p), int(k), int(result_type),
+                                       N.ptr(doc, N.u32p), N.ptr(score, N.f32p), N.ptr(cnt, N.u32p), N.ptr(tot, N.u64p)),
+                "ss_bm25_search")
+        return doc, score, cnt, tot
+
+    def search_vector_batch(self, query_vectors, k, similarity_threshold=None):
+        qv = np.ascontiguousarray(query_vectors, np.float32)
+        if qv.ndim == 1:
+            qv = qv[None, :]
+        if qv.shape[1] != self.dim:
+            raise ValueError("query dimension mismatch")
+        nq = qv.shape[0]
+        doc = np.full((nq, k), N.SS_NO_DOC, np.uint32)
+        score = np.zeros((nq, k), np.float32)
+        cnt = np.zeros(nq, np.uint32)
+        tot = np.zeros(nq, np.uint64)
+        N.check(N.lib().ss_vec_search(self._h, nq, N.ptr(qv, N.f32p), int(k), threshold_raw(similarity_threshold),
+                                      N.ptr(doc, N.u32p), N.ptr(score, N.f32p), N.ptr(cnt, N.u32p), N.ptr(tot, N.u64p)),
+                "ss_vec_search")
+        return doc, score, cnt, tot
+
+    # ---- the reference's per-shard seams (one query)
+    def search_lexical_shard(self, query_terms, query_type_default=QueryType.Union, offset=0, length=10,
+                             result_type=ResultType.TopkCount, strict=False) -> ResultObject:
+        ro = ResultObject()
+        try:
+            q = self.make_queries([query_terms], query_type_default)
+            doc, score, cnt, tot = self.search_lexical_batch(q, offset + length, result_type)
+        except Exception:
+            if strict:
+                raise
+            return ro
+        n = int(cnt[0])
+        ro.results = [Result(int(d), float(s), ResultSource.Lexical) for d, s in zip(doc[0, :n], score[0, :n])][offset:]
+        ro.result_count = len(ro.results)
+        ro.result_count_total = int(tot[0])
+        return ro
+
+    def search_vector_shard(self, query_vector, length=10, similarity_threshold=None, strict=False) -> ResultObject:
+        ro = ResultObject()
+        try:
+            doc, score, cnt, tot = self.search_vector_batch(query_vector, length, similarity_threshold)
+        except Exception:
+            if strict:
+                raise
+            return ro
+        n = int(cnt[0])
+        ro.results = [Result(int(d), float(s), ResultSource.Vector) for d, s in zip(doc[0, :n], score[0, :n])]
+        ro.result_count = n
+        ro.result_count_total = int(tot[0])
+        ro.observed_vector_count = self.vector_count  # AnnMode::All observes every record (vector.rs:421)
+        return ro
+
+    # ---- measurement hooks
+    def profile(self, on=True):
+        N.check(N.lib().ss_profile_enable(self._h, 1 if on else 0), "ss_profile_enable")
+
+    def profile_read(self, kernel, reset=True):
+        n, ms = C.c_uint64(), C.c_double()
+        N.check(N.lib().ss_profile_read(self._h, kernel, C.byref(n), C.byref(ms), 1 if reset else 0), "ss_profile_read")
+        return n.value, ms.value
+
+
+def merge_results(mode, lex=None, vec=None, offset=0, length=10):
+    """search.rs:1875-2119 on GLOBAL ids: concat over shards, RRF for Hybrid, sort desc, offset, truncate."""
+    ld = np.ascontiguousarray(lex[0] if lex is not None else [], np.uint64)
+    ls = np.ascontiguousarray(lex[1] if lex is not None else [], np.float32)
+    vd = np.ascontiguousarray(vec[0] if vec is not None else [], np.uint64)
+    vs = np.ascontiguousarray(vec[1] if vec is not None else [], np.float32)
+    L = max(int(length), 1)
+    od = np.empty(L, np.uint64)
+    os_ = np.empty(L, np.float32)
+    src = np.empty(L, np.uint8)
+    n = N.check(N.lib().ss_merge_results(int(mode), N.ptr(ld, N.u64p), N.ptr(ls, N.f32p), len(ld), N.ptr(vd, N.u64p),
+                                         N.ptr(vs, N.f32p), len(vd), int(offset), int(length), N.ptr(od, N.u64p),
+                                         N.ptr(os_, N.f32p), N.ptr(src, N.u8p)), "ss_merge_results")
+    return od[:n].copy(), os_[:n].copy(), src[:n].copy()
+
+
+class Index:
+    """In-process multi-shard index: doc g lives in shard g % S with local id g // S (index.rs:5284)."""
+
+    def __init__(self, shards: Sequence[Shard]):
+        self.shards = list(shards)
+
+    @property
+    def shard_number(self):
+        return len(self.shards)
+
+    def search(self, query_terms: Optional[Sequence[int]] = None, query_vector=None,
+               query_type_default=QueryType.Union, search_mode=SearchMode.Lexical, offset=0, length=10,
+               result_type=ResultType.TopkCount, similarity_threshold=None, normalize_query=True,
+               strict=False) -> ResultObject:
+        S = self.shard_number
+        ro = ResultObject()
+        want_lex = search_mode in (SearchMode.Lexical, SearchMode.Hybrid) and query_terms
+        want_vec = search_mode in (SearchMode.Vector, SearchMode.Hybrid) and query_vector is not None
+        if want_vec and normalize_query:
+            query_vector = normalize_f32(query_vector)  # search.rs:1464-1475 (Cosine, external inference)
+        lex_d, lex_s, vec_d, vec_s = [], [], [], []
+        for sh in self.shards:  # search.rs:1637-1743: each shard asked for (offset 0, length offset+length)
+            lt = vt = 0
+            if want_lex:
+                r = sh.search_lexical_shard(query_terms, query_type_default, 0, offset + length, result_type, strict)
+                lex_d += [x.doc_id * S + sh.shard_id for x in r.results]  # search.rs:1671
+                lex_s += [x.score for x in r.results]
+                lt = r.result_count_total
+            if want_vec:
+                r = sh.search_vector_shard(query_vector, offset + length, similarity_threshold, strict)
+                vec_d += [x.doc_id * S + sh.shard_id for x in r.results]  # search.rs:1693
+                vec_s += [x.score for x in r.results]
+                vt = r.result_count_total
+                ro.observed_vector_count += r.observed_vector_count
+            # search.rs:1884,1899 sum; Hybrid: max(lexical, vector) per shard (search.rs:1919-1921)
+            ro.result_count_total += max(lt, vt) if search_mode == SearchMode.Hybrid else (lt + vt)
+        if result_type != ResultType.Count:
+            d, s, src = merge_results(search_mode, (lex_d, lex_s), (vec_d, vec_s), offset, length)
+            ro.results = [Result(int(a), float(b), ResultSource(int(c))) for a, b, c in zip(d, s, src)]
+        ro.result_count = len(ro.results)
+        return ro

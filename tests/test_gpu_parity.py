@@ -1,0 +1,285 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same seeded
+inputs.  Bar: bit-exact doc-id sets / counts for integer work, scores within 1e-4 relative (north_star)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4  # north_star tolerance for BM25 / cosine scores
+
+
+@pytest.fixture(scope="module")
+def S():
+    import seekstorm_amd
+    return seekstorm_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def _check_topk(doc, score, cnt, od, os_, abs_tol=0.0):
+    """rows sorted desc; scores within REL of the oracle's; identical id sets outside the tie band of the k-th."""
+    n = int(cnt)
+    assert n == len(od)
+    d, s = doc[:n], score[:n]
+    assert np.all(s[:-1] >= s[1:])
+    assert np.all(doc[n:] == 0xFFFFFFFF)
+    assert len(set(map(int, d))) == n
+    assert np.allclose(s, os_, rtol=REL, atol=abs_tol)
+    if n:
+        band = abs(float(os_[-1])) * REL + abs_tol
+        strict = lambda dd, ss: {int(x) for x, y in zip(dd, ss) if y > os_[-1] + band}
+        assert strict(d, s) == strict(od, os_)
+
+
+# ------------------------------------------------------------------ vector path
+@pytest.mark.parametrize("n_rows,dim,nq,k", [(20000, 768, 64, 100), (4099, 100, 3, 10), (130, 64, 65, 100), (50, 32, 2, 100)])
+def test_vector_parity(S, O, n_rows, dim, nq, k):
+    rows = O.vec_gen(O.VEC_SEED, 0, n_rows, dim)
+    qs = O.vec_gen(O.VECQ_SEED, 0, nq, dim)
+    sh = S.Shard(0)
+    sh.upload_vectors(rows)
+    doc, score, cnt, tot = sh.search_vector_batch(qs, k)
+    for i in range(nq):
+        od, os_, otot, oobs = O.vec_search(rows, qs[i], k)
+        _check_topk(doc[i], score[i], cnt[i], od, os_, abs_tol=2e-6)
+        assert tot[i] >= cnt[i]
+        if n_rows <= k:
+            assert tot[i] == otot == n_rows  # tests/test.rs:676-744 shape: fewer rows than k -> all returned
+    sh.close()
+
+
+def test_vector_self_query_and_row_ids(S, O):
+    rows = O.vec_gen(11, 0, 3000, 128)
+    ids = (np.arange(3000, dtype=np.uint32) * 7 + 3).astype(np.uint32)  # unique external doc ids
+    sh = S.Shard(0)
+    sh.upload_vectors(rows, ids)
+    doc, score, cnt, tot = sh.search_vector_batch(rows[[5, 1234, 2999]], 10)
+    assert list(doc[:, 0]) == [ids[5], ids[1234], ids[2999]]
+    assert np.allclose(score[:, 0], 1.0, atol=1e-5)
+    # several records per doc is outside the implemented scope and must be refused loudly, not mis-answered
+    with pytest.raises(S.SeekStormHipError):
+        sh.upload_vectors(rows, np.zeros(3000, np.uint32))
+    sh.close()
+
+
+def test_vector_threshold(S, O):
+    rows = O.vec_gen(5, 0, 5000, 64)
+    q = O.vec_gen(6, 0, 1, 64)[0]
+    full = rows @ q
+    thr_raw = float(np.sort(full)[-20])  # exactly 20 rows have score >= thr_raw
+    sh = S.Shard(0)
+    sh.upload_vectors(rows)
+    import ctypes as C
+    from seekstorm_amd import _native as N
+    k = 100
+    doc = np.zeros(k, np.uint32); sc = np.zeros(k, np.float32); cnt = np.zeros(1, np.uint32); tot = np.zeros(1, np.uint64)
+    N.check(N.lib().ss_vec_search(sh._h, 1, N.ptr(np.ascontiguousarray(q[None]), N.f32p), k, thr_raw, N.ptr(doc, N.u32p),
+                                  N.ptr(sc, N.f32p), N.ptr(cnt, N.u32p), N.ptr(tot, N.u64p)), "ss_vec_search")
+    od, os_, _, _ = O.vec_search(rows, q, k, threshold_raw=thr_raw)
+    assert 18 <= len(od) <= 22
+    _check_topk(doc, sc, cnt[0], od, os_, abs_tol=2e-6)
+    sh.close()
+
+
+def test_vector_candidate_overflow_falls_back_exactly(S, O):
+    """Adversarial order: every later row beats all earlier ones, so every row is a candidate and the fast
+    schedule overflows its candidate buffer; the library must re-run in safe mode and still be exact."""
+    n, dim = 40000, 32
+    th = np.linspace(1.2, 0.0, n).astype(np.float64)
+    rows = np.zeros((n, dim), np.float32)
+    rows[:, 0] = np.cos(th)
+    rows[:, 1] = np.sin(th)
+    q = np.zeros(dim, np.float32)
+    q[0] = 1.0
+    sh = S.Shard(0)
+    sh.upload_vectors(rows)
+    doc, score, cnt, tot = sh.search_vector_batch(q, 100)
+    od, os_, _, _ = O.vec_search(rows, q, 100)
+    _check_topk(doc[0], score[0], cnt[0], od, os_, abs_tol=2e-6)
+    sh.close()
+
+
+def test_vector_synth_matches_oracle_generator(S, O):
+    sh = S.Shard(0)
+    sh.synth_vectors(O.VEC_SEED, 1000, 96)
+    got = sh.read_rows(0, 1000)
+    want = O.vec_gen(O.VEC_SEED, 0, 1000, 96)
+    assert np.allclose(got, want, rtol=0, atol=1e-7)
+    assert np.mean(got == want) > 0.99
+    sh.close()
+
+
+# ------------------------------------------------------------------ BM25 path
+VOC = [0, 1500, 2500, 3000, 3300, 3600, 3800, 3900, 4000, 4050, 4095]  # df from 0.05% to 20%
+
+
+@pytest.fixture(scope="module")
+def lex(S, O):
+    n_docs = 300_000
+    dl = O.lex_doclen(n_docs)
+    offs, docs, tfs = O.lex_corpus(n_docs, VOC)
+    osh = O.Shard(n_docs, dl, offs, docs, tfs)
+    sh = S.Shard(0)
+    sh.upload_lexical(n_docs, dl, offs, docs, tfs)
+    yield sh, osh, n_docs
+    sh.close()
+
+
+def test_bm25_image_stats(S, O, lex):
+    sh, osh, n_docs = lex
+    info = sh.lexical_info()
+    assert info["n_docs"] == n_docs and info["n_terms"] == len(VOC)
+    assert abs(info["avgdl"] - osh.avgdl) <= 1e-6 * osh.avgdl
+    df = sh.posting_count(np.arange(len(VOC)))
+    assert [int(x) for x in df] == [osh.df(t) for t in range(len(VOC))]
+
+
+QUERIES = [[10], [0], [10, 9], [9, 5], [10, 8, 3], [7, 6, 5], [1, 0], [10, 9, 8, 7], [2, 10], [4, 3, 2, 1, 0],
+           [10, 9, 8, 7, 6, 5, 4, 3, 2, 1]]
+
+
+@pytest.mark.parametrize("op", ["Union", "Intersection"])
+@pytest.mark.parametrize("k", [10, 100, 200])
+def test_bm25_parity(S, O, lex, op, k):
+    sh, osh, n_docs = lex
+    qt = getattr(S.QueryType, op)
+    oop = O.OP_OR if op == "Union" else O.OP_AND
+    q = sh.make_queries(QUERIES, qt)
+    doc, score, cnt, tot = sh.search_lexical_batch(q, k, S.ResultType.TopkCount)
+    for i, terms in enumerate(QUERIES):
+        od, os_, otot = osh.search_exhaustive(terms, oop, k)
+        assert int(tot[i]) == otot, (terms, op)  # exact result_count_total
+        _check_topk(doc[i], score[i], cnt[i], od, os_)
+        # and the reference-structured oracle (block-max pruned, containers) agrees too
+        od2, os2, otot2 = osh.search(terms, oop, k, O.RT_TOPKCOUNT)
+        assert otot2 == otot
+        assert np.allclose(os2, score[i][:len(os2)], rtol=REL)
+
+
+def test_bm25_intersection_doc_sets_bit_exact(S, O, lex):
+    """north_star: bit-exact doc-id sets for conjunctive intersection (ask for every match)."""
+    sh, osh, n_docs = lex
+    terms_list = [[7, 6], [8, 5, 2], [10, 4, 3], [9, 1]]
+    q = sh.make_queries(terms_list, S.QueryType.Intersection)
+    doc, score, cnt, tot = sh.search_lexical_batch(q, 1024, S.ResultType.TopkCount)
+    for i, terms in enumerate(terms_list):
+        od, os_, otot = osh.search_exhaustive(terms, O.OP_AND, 1024)
+        assert otot <= 1024, "fixture must fit in k"
+        assert int(tot[i]) == otot == int(cnt[i])
+        assert set(map(int, doc[i][:cnt[i]])) == set(map(int, od))
+
+
+def test_bm25_count_and_mixed_batch(S, O, lex):
+    sh, osh, n_docs = lex
+    terms_list = [[10, 9], [10, 9], [5], [6, 2]]
+    types = [S.QueryType.Union, S.QueryType.Intersection, S.QueryType.Union, S.QueryType.Intersection]
+    q = sh.make_queries(terms_list, types)
+    doc, score, cnt, tot = sh.search_lexical_batch(q, 10, S.ResultType.Count)
+    for i, (terms, t) in enumerate(zip(terms_list, types)):
+        _, _, otot = osh.search_exhaustive(terms, O.OP_OR if t == S.QueryType.Union else O.OP_AND, 1)
+        assert int(tot[i]) == otot and cnt[i] == 0
+    doc, score, cnt, tot = sh.search_lexical_batch(q, 10, S.ResultType.Topk)
+    for i, (terms, t) in enumerate(zip(terms_list, types)):
+        od, os_, _ = osh.search_exhaustive(terms, O.OP_OR if t == S.QueryType.Union else O.OP_AND, 10)
+        _check_topk(doc[i], score[i], cnt[i], od, os_)
+
+
+def test_bm25_large_batch_is_deterministic(S, O, lex):
+    sh, osh, n_docs = lex
+    rng = np.random.default_rng(3)
+    tl = [list(rng.choice(len(VOC), size=3, replace=False)) for _ in range(700)]
+    q = sh.make_queries(tl, S.QueryType.Union)
+    a = sh.search_lexical_batch(q, 10)
+    b = sh.search_lexical_batch(q, 10)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    for i in (0, 123, 699):
+        od, os_, otot = osh.search_exhaustive(tl[i], O.OP_OR, 10)
+        assert int(a[3][i]) == otot
+        _check_topk(a[0][i], a[1][i], a[2][i], od, os_)
+
+
+def test_bm25_synth_image_equals_uploaded_image(S, O):
+    """the device-side generator must produce the corpus the oracle generates on the host"""
+    n_docs, nt = 70_000, 16
+    th = O.term_thresholds(nt)
+    tab = O.len_table()
+    a = S.Shard(0)
+    a.synth_lexical(O.LEX_SEED, n_docs, th, tab)
+    dl = O.lex_doclen(n_docs)
+    offs, docs, tfs = O.lex_corpus(n_docs, list(range(nt)), thresholds=th)
+    b = S.Shard(0)
+    b.upload_lexical(n_docs, dl, offs, docs, tfs)
+    ia, ib = a.lexical_info(), b.lexical_info()
+    assert ia == ib
+    assert np.array_equal(a.posting_count(np.arange(nt)), b.posting_count(np.arange(nt)))
+    tl = [[15, 14, 9], [13, 2], [15], [12, 11, 10, 3]]
+    for qt in (S.QueryType.Union, S.QueryType.Intersection):
+        ra = a.search_lexical_batch(a.make_queries(tl, qt), 10)
+        rb = b.search_lexical_batch(b.make_queries(tl, qt), 10)
+        for x, y in zip(ra, rb):
+            assert np.array_equal(x, y)
+    a.close(); b.close()
+
+
+def test_abi_rejects_bad_input_without_crashing(S, O, lex):
+    sh, osh, n_docs = lex
+    q = sh.make_queries([[1, 2]], S.QueryType.Union)
+    q["term"][0, 0] = 10_000  # out of vocabulary
+    with pytest.raises(S.SeekStormHipError):
+        sh.search_lexical_batch(q, 10)
+    empty = S.Shard(0)
+    assert empty.search_lexical_shard([1]).result_count == 0  # degrades to empty like search.rs:2461-2463
+    with pytest.raises(S.SeekStormHipError):
+        empty.search_lexical_shard([1], strict=True)
+    assert empty.search_vector_shard(np.ones(8, np.float32)).result_count == 0
+    empty.close()
+
+
+# ------------------------------------------------------------------ planner: shards, hybrid RRF
+def test_index_two_shards_hybrid_matches_oracle(S, O):
+    n_docs, dim, S_n = 40_000, 64, 2
+    voc = [3000, 3600, 4000]
+    dl = O.lex_doclen(n_docs)
+    offs, docs, tfs = O.lex_corpus(n_docs, voc)
+    rows = O.vec_gen(O.VEC_SEED, 0, n_docs, dim)
+    qv = O.vec_gen(O.VECQ_SEED, 0, 1, dim, normalize=False)[0] * 3.0  # un-normalised on purpose
+    shards, oshards, orows = [], [], []
+    for sid in range(S_n):  # doc g -> shard g % S, local id g // S (index.rs:5284)
+        sel = np.arange(sid, n_docs, S_n)
+        o2, d2, t2 = [0], [], []
+        for t in range(len(voc)):
+            d = docs[int(offs[t]):int(offs[t + 1])]
+            f = tfs[int(offs[t]):int(offs[t + 1])]
+            m = (d % S_n) == sid
+            d2.append(d[m] // S_n); t2.append(f[m]); o2.append(o2[-1] + int(m.sum()))
+        d2 = np.concatenate(d2).astype(np.uint32); t2 = np.concatenate(t2)
+        sh = S.Shard(0, shard_id=sid)
+        sh.upload_lexical(len(sel), dl[sel], np.asarray(o2, np.uint64), d2, t2)
+        sh.upload_vectors(rows[sel])
+        shards.append(sh)
+        oshards.append(O.Shard(len(sel), dl[sel], np.asarray(o2, np.uint64), d2, t2))
+        orows.append(rows[sel])
+    idx = S.Index(shards)
+    k = 20
+    qn = O.normalize(qv)
+    lex_d, lex_s, vec_d, vec_s = [], [], [], []
+    for sid in range(S_n):
+        od, os_, _ = oshards[sid].search_exhaustive([0, 1, 2], O.OP_OR, k)
+        lex_d += [int(x) * S_n + sid for x in od]; lex_s += list(os_)
+        vd, vs, _, _ = O.vec_search(orows[sid], qn, k)
+        vec_d += [int(x) * S_n + sid for x in vd]; vec_s += list(vs)
+    for mode, omode in ((S.SearchMode.Lexical, 0), (S.SearchMode.Vector, 1), (S.SearchMode.Hybrid, 2)):
+        ro = idx.search([0, 1, 2], qv, S.QueryType.Union, mode, 0, k, strict=True)
+        od, os_, osrc = O.merge(omode, (lex_d, lex_s), (vec_d, vec_s), 0, k)
+        assert ro.result_count == len(od) == k
+        got_s = np.array([r.score for r in ro.results], np.float32)
+        assert np.allclose(got_s, os_, rtol=REL, atol=2e-6)
+        band = abs(float(os_[-1])) * REL + 2e-6
+        assert {r.doc_id for r in ro.results if r.score > os_[-1] + band} == {int(x) for x, y in zip(od, os_) if y > os_[-1] + band}
+    for sh in shards:
+        sh.close()
