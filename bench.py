@@ -1,0 +1,331 @@
+#!/usr/bin/env python3
+"""bench.py -- SeekStorm query hot path on MI355X.
+
+Primary workload (BASELINE.json configs[1], "C2"): 10M synthetic docs, 3-term OR, BM25 top-10, one shard per GPU.
+A "step" = one batch of 1000 resolved queries through ss_bm25_search_dev (queries and outputs resident in HBM).
+Secondary workload (configs[2], "C3"), reported in the same JSON line under "vector": 10M x 768 f32, batch-64 cosine
+top-100 brute force through ss_vec_search_dev.
+
+Multi-GPU (weak scaling): one process per GPU, one 10M-doc / 10M-row shard per rank, every rank answers
+the same query batch on its shard, one RCCL all-gather of the per-shard top-k, ss_topk_merge_dev on every rank.
+`value` counts shard-queries (queries x shards scanned) per second so that it is the whole-job aggregate;
+`global_qps` is the rate of merged answers over the N-times larger corpus.
+
+  python bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: FP32 matrix peak
+
+
+def pct(a, p):
+    a = sorted(a)
+    return a[min(len(a) - 1, int(round(p / 100.0 * (len(a) - 1))))] if a else None
+
+
+def band_terms(th, lo, hi):
+    frac = th.astype(np.float64) / 2.0 ** 32
+    return np.nonzero((frac >= lo) & (frac < hi))[0]
+
+
+def make_c2_queries(O, n_queries, seed=1234):
+    """3 distinct terms, one from each df band [0.5-2%], [2-5%], [5-15%]."""
+    th = O.term_thresholds()
+    bands = [band_terms(th, 0.005, 0.02), band_terms(th, 0.02, 0.05), band_terms(th, 0.05, 0.15)]
+    rng = np.random.default_rng(seed)
+    return [[int(rng.choice(b)) for b in bands] for _ in range(n_queries)], th
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="all", choices=["all", "bm25", "vec"])
+    ap.add_argument("--docs", type=int, default=10_000_000)
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--queries", type=int, default=1000)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch  # first: the HIP runtime torch loads is then shared with libseekstorm_hip.so
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import seekstorm_amd as S
+    from seekstorm_amd import _native as N
+    L = S.lib()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # an explicit (non-null) stream: the C ABI treats a NULL stream as "the shard's own stream", and the RCCL
+    # all-gather must be ordered after the search kernels on ONE stream
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    sptr = C.c_void_p(stream.cuda_stream)
+    assert sptr.value, "expected a non-null HIP stream handle"
+    sh = S.Shard(local_rank, shard_id=rank)
+    out = {}
+
+    def timed(step_fn, steps, warmup):
+        for _ in range(warmup):
+            step_fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    def latencies(step_fn, n):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for a, b in ev:
+            a.record(stream)
+            step_fn()
+            b.record(stream)
+            torch.cuda.synchronize()
+        return [a.elapsed_time(b) for a, b in ev]
+
+    # ------------------------------------------------------------------ BM25 (primary)
+    bm = None
+    if args.workload in ("all", "bm25"):
+        from oracle import oracle as O  # query set + thresholds come from the generator module (host constants only)
+        k = 10
+        term_lists, th = make_c2_queries(O, args.queries)
+        tab = O.len_table()
+        t0 = time.perf_counter()
+        sh.synth_lexical(O.LEX_SEED ^ (rank * 0x9E3779B1), args.docs, th, tab)
+        build_s = time.perf_counter() - t0
+        info = sh.lexical_info()
+        q_np = sh.make_queries(term_lists, S.QueryType.Union)
+        nq = len(q_np)
+        q_dev = torch.from_numpy(q_np.view(np.uint8).reshape(nq, -1).copy()).to(dev)
+        o_doc = torch.empty((nq, k), dtype=torch.int32, device=dev)
+        o_score = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        o_cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
+        o_tot = torch.empty((nq,), dtype=torch.int64, device=dev)
+        if world > 1:
+            g_doc = torch.empty((world, nq, k), dtype=torch.int32, device=dev)
+            g_score = torch.empty((world, nq, k), dtype=torch.float32, device=dev)
+            g_cnt = torch.empty((world, nq), dtype=torch.int32, device=dev)
+            m_doc = torch.empty((nq, k), dtype=torch.int64, device=dev)
+            m_score = torch.empty((nq, k), dtype=torch.float32, device=dev)
+            m_cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
+
+        def bm_step(n=nq):
+            N.check(L.ss_bm25_search_dev(sh._h, n, q_dev.data_ptr(), k, N.RT_TOPK, 2, o_doc.data_ptr(), o_score.data_ptr(),
+                                         o_cnt.data_ptr(), o_tot.data_ptr(), sptr), "ss_bm25_search_dev")
+            if world > 1:
+                dist.all_gather_into_tensor(g_doc, o_doc)
+                dist.all_gather_into_tensor(g_score, o_score)
+                dist.all_gather_into_tensor(g_cnt, o_cnt)
+                N.check(L.ss_topk_merge_dev(local_rank, n, world, k, g_doc.data_ptr(), g_score.data_ptr(), g_cnt.data_ptr(),
+                                            m_doc.data_ptr(), m_score.data_ptr(), m_cnt.data_ptr(), sptr), "ss_topk_merge_dev")
+
+        sh.profile(True)
+        bm_step()
+        torch.cuda.synchronize()
+        sh.profile_read(0, reset=True)
+        dt = timed(bm_step, args.steps, args.warmup)
+        launches, kms = sh.profile_read(0, reset=True)
+        sh.profile(False)
+        # algorithmic bytes: sum_t df_t*(2B id + 1B tf) + 1B per scored candidate + 4B per (term, block) + 8B*k
+        tot = o_tot.cpu().numpy().astype(np.int64)
+        uniq = sorted({t for tl in term_lists for t in tl})
+        dfm = dict(zip(uniq, (int(x) for x in sh.posting_count(uniq))))
+        n_blocks = (args.docs + 65535) // 65536
+        bytes_q = np.array([sum(dfm[t] for t in tl) * 3 + int(tot[i]) + 4 * n_blocks * len(tl) + 8 * k
+                            for i, tl in enumerate(term_lists)], np.float64)
+        bytes_launch = float(bytes_q.sum())
+        avg_ms = kms / max(launches, 1)
+        ach = bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        lat_batch = latencies(bm_step, 12)
+        lat_one = latencies(lambda: bm_step(1), 60)
+        bm = dict(qps=nq * args.steps / dt, ms_per_step=dt / args.steps * 1e3, build_s=build_s, info=info,
+                  roofline={"bound": "hbm", "kernel": "bm25_scan_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": bytes_launch,
+                            "avg_launch_ms": avg_ms, "launches": int(launches)},
+                  latency_ms={"batch_p50": pct(lat_batch, 50), "batch_p99": pct(lat_batch, 99),
+                              "single_query_p50": pct(lat_one, 50), "single_query_p99": pct(lat_one, 99)},
+                  mean_bytes_per_query=float(bytes_q.mean()), mean_union=float(tot.mean()))
+        # correctness guard inside the bench: sorted, k results, counts sane
+        sc = o_score.cpu().numpy()
+        assert np.all(sc[:, :-1] >= sc[:, 1:]) and np.all(o_cnt.cpu().numpy() == k)
+
+        if rank == 0 and world == 1 and not args.no_cpu:
+            # cpu_baseline: the oracle (reference-structured C port: containers, block-max pruned table scan) on the
+            # host cores, bounded sample of the same query set on the same corpus (terms regenerated on the host)
+            from concurrent.futures import ThreadPoolExecutor
+            ns = 12
+            sample = term_lists[:ns]
+            voc = sorted({t for tl in sample for t in tl})
+            dl = O.lex_doclen(args.docs, O.LEX_SEED)
+            offs, docs, tfs = O.lex_corpus(args.docs, voc, O.LEX_SEED)
+            osh = O.Shard(args.docs, dl, offs, docs, tfs)
+            remap = {t: i for i, t in enumerate(voc)}
+            qs = [[remap[t] for t in tl] for tl in sample]
+            cores = min(os.cpu_count() or 1, 32)
+            od, os_, _ = osh.search(qs[0], O.OP_OR, k, O.RT_TOPK)  # parity spot check GPU vs oracle on query 0
+            assert np.allclose(os_, sc[0][:len(os_)], rtol=1e-4), "bench parity spot check failed"
+            done = 0
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(cores) as ex:
+                while time.perf_counter() - t0 < args.cpu_seconds:
+                    list(ex.map(lambda q: osh.search(q, O.OP_OR, k, O.RT_TOPK), qs * max(1, cores // ns + 1)))
+                    done += len(qs) * max(1, cores // ns + 1)
+            el = time.perf_counter() - t0
+            bm["cpu_baseline"] = {"value": done / el, "unit": "queries/s", "cores": cores, "kind": "port",
+                                  "sample": f"{ns} of the {nq} C2 queries repeated for {el:.1f}s on the same {args.docs}-doc "
+                                            f"corpus, {cores} threads, oracle/ss_oracle.c so_search_lex (OR, Topk, k=10)"}
+            del osh
+
+    # ------------------------------------------------------------------ vector (secondary)
+    vec = None
+    if args.workload in ("all", "vec"):
+        from oracle import oracle as O
+        kv, B = 100, 64
+        t0 = time.perf_counter()
+        sh.synth_vectors(O.VEC_SEED ^ (rank * 0x9E3779B1), args.rows, args.dim)
+        vbuild = time.perf_counter() - t0
+        qv = torch.from_numpy(O.vec_gen(O.VECQ_SEED, 0, B, args.dim)).to(dev)
+        v_doc = torch.empty((B, kv), dtype=torch.int32, device=dev)
+        v_score = torch.empty((B, kv), dtype=torch.float32, device=dev)
+        v_cnt = torch.empty((B,), dtype=torch.int32, device=dev)
+        v_tot = torch.empty((B,), dtype=torch.int64, device=dev)
+        if world > 1:
+            gv_doc = torch.empty((world, B, kv), dtype=torch.int32, device=dev)
+            gv_score = torch.empty((world, B, kv), dtype=torch.float32, device=dev)
+            gv_cnt = torch.empty((world, B), dtype=torch.int32, device=dev)
+            mv_doc = torch.empty((B, kv), dtype=torch.int64, device=dev)
+            mv_score = torch.empty((B, kv), dtype=torch.float32, device=dev)
+            mv_cnt = torch.empty((B,), dtype=torch.int32, device=dev)
+
+        def vec_step(n=B):
+            N.check(L.ss_vec_search_dev(sh._h, n, qv.data_ptr(), kv, N.FLT_MIN_NEG, v_doc.data_ptr(), v_score.data_ptr(),
+                                        v_cnt.data_ptr(), v_tot.data_ptr(), sptr), "ss_vec_search_dev")
+            if world > 1:
+                dist.all_gather_into_tensor(gv_doc, v_doc)
+                dist.all_gather_into_tensor(gv_score, v_score)
+                dist.all_gather_into_tensor(gv_cnt, v_cnt)
+                N.check(L.ss_topk_merge_dev(local_rank, n, world, kv, gv_doc.data_ptr(), gv_score.data_ptr(), gv_cnt.data_ptr(),
+                                            mv_doc.data_ptr(), mv_score.data_ptr(), mv_cnt.data_ptr(), sptr), "ss_topk_merge_dev")
+
+        sh.profile(True)
+        vec_step()
+        torch.cuda.synchronize()
+        sh.profile_read(1, reset=True)
+        vsteps = max(4, args.steps // 2)
+        dtv = timed(vec_step, vsteps, min(args.warmup, 2))
+        launches, kms = sh.profile_read(1, reset=True)
+        sh.profile(False)
+        cnt = v_cnt.cpu().numpy()
+        assert np.all(cnt.astype(np.int64) == min(kv, args.rows)), "vector candidate overflow or short result in bench"
+        flops = 2.0 * args.dim * args.rows * B  # per pass (2*dim*N per query)
+        avg_ms = kms / max(launches, 1)
+        ach = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        lat = latencies(vec_step, 8)
+        vec = dict(qps=B * vsteps / dtv, ms_per_step=dtv / vsteps * 1e3, build_s=vbuild,
+                   roofline={"bound": "mfma", "kernel": "vec_scan_kernel (+refine, all row chunks of one pass)", "achieved": ach,
+                             "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
+                             "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": 4.0 * args.dim * args.rows,
+                             "hbm_GBs": 4.0 * args.dim * args.rows / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
+                             "avg_launch_ms": avg_ms, "launches": int(launches)},
+                   latency_ms={"batch64_p50": pct(lat, 50), "batch64_p99": pct(lat, 99)})
+        # property checks at full size: sorted, and the scores really are dot products of the returned rows
+        vs = v_score.cpu().numpy()
+        assert np.all(vs[:, :-1] >= vs[:, 1:])
+        ids = v_doc.cpu().numpy()
+        r0 = sh.read_rows(int(ids[0, 0]), 1)[0]
+        assert abs(float(r0 @ qv[0].cpu().numpy()) - float(vs[0, 0])) < 1e-4
+        if rank == 0 and world == 1 and not args.no_cpu:
+            from concurrent.futures import ThreadPoolExecutor
+            M = min(args.rows, 200_000)
+            rows = O.vec_gen(O.VEC_SEED, 0, M, args.dim)
+            qh = qv.cpu().numpy()
+            cores = min(os.cpu_count() or 1, 32)
+            od, os_, _, _ = O.vec_search(rows, qh[0], kv)
+            done = 0
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(cores) as ex:
+                while time.perf_counter() - t0 < args.cpu_seconds:
+                    list(ex.map(lambda q: O.vec_search(rows, q, kv), [qh[i % B] for i in range(cores)]))
+                    done += cores
+            el = time.perf_counter() - t0
+            scale = args.rows / M
+            vec["cpu_baseline"] = {"value": done / el / scale, "unit": "queries/s", "cores": cores, "kind": "port",
+                                   "sample": f"{done} cosine top-100 scans of the first {M} rows in {el:.1f}s, {cores} threads, "
+                                             f"oracle so_vec_search (dot_f32_avx2 order, TopK::push); rate divided by {scale:.0f} "
+                                             f"(linear scan) to {args.rows} rows"}
+
+    # ------------------------------------------------------------------ report
+    if rank == 0:
+        prim = bm if bm is not None else vec
+        is_bm = bm is not None
+        line = {
+            "metric": "queries/sec" + (" (BM25 3-term OR top-10)" if is_bm else " (cosine top-100, batch 64)"),
+            "value": prim["qps"] * world,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps if is_bm else max(4, args.steps // 2),
+            "warmup": args.warmup,
+            "ms_per_step": prim["ms_per_step"],
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": ({"workload": "C2: 10M synthetic docs, 3-term OR BM25 top-10, one shard per GPU", "docs_per_shard": args.docs,
+                        "queries_per_step": args.queries, "k": 10, "vocabulary": 4096, "result_type": "Topk",
+                        "value_counts": "queries x shards scanned (one 10M-doc shard per GPU)"} if is_bm else
+                       {"workload": "C3: 10M x 768 f32, batch-64 cosine top-100 brute force", "rows_per_shard": args.rows,
+                        "dim": args.dim, "batch": 64, "k": 100}),
+            "global_qps": prim["qps"],
+            "roofline": prim["roofline"],
+            "cpu_baseline": prim.get("cpu_baseline"),
+            "latency_ms": prim["latency_ms"],
+        }
+        if is_bm:
+            line["bm25"] = {"build_s": bm["build_s"], "postings": int(bm["info"]["n_postings"]), "avgdl": bm["info"]["avgdl"],
+                            "mean_algorithmic_bytes_per_query": bm["mean_bytes_per_query"], "mean_union_size": bm["mean_union"]}
+        if vec is not None and is_bm:
+            line["vector"] = {"metric": "queries/sec (cosine top-100, 10M x 768 f32, batch 64)", "value": vec["qps"] * world,
+                              "global_qps": vec["qps"], "ms_per_step": vec["ms_per_step"], "roofline": vec["roofline"],
+                              "cpu_baseline": vec.get("cpu_baseline"), "latency_ms": vec["latency_ms"], "build_s": vec["build_s"],
+                              "rows_per_shard": args.rows, "dim": args.dim}
+        print(json.dumps(line), flush=True)
+    sh.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

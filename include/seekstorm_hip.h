@@ -125,6 +125,14 @@ int ss_merge_results(int mode, const uint64_t* lex_doc, const float* lex_score, 
                      const uint64_t* vec_doc, const float* vec_score, uint32_t n_vec, uint32_t offset,
                      uint32_t length, uint64_t* out_doc, float* out_score, uint8_t* out_source);
 
+/* Device-side variant for the multi-GPU path: per-shard top-k lists of a whole query batch, laid out
+ * [n_shards][n_queries][k] exactly as an RCCL all-gather of the ss_*_search_dev outputs leaves them, are merged
+ * per query into global ids (local*S + shard), sorted by score desc (ties: shard order, as the reference's stable
+ * sort of the concatenation).  Unused slots: doc = UINT64_MAX.  n_shards*k <= 8192. */
+int ss_topk_merge_dev(int device, uint32_t n_queries, uint32_t n_shards, uint32_t k, const uint32_t* d_doc,
+                      const float* d_score, const uint32_t* d_count, uint64_t* d_out_doc, float* d_out_score,
+                      uint32_t* d_out_count, void* stream);
+
 /* ------------------------------------------------------------------ measurement hooks
  * When enabled the library brackets every launch of the dominant kernels with HIP events on the stream
  * the kernel is launched on and accumulates (launches, milliseconds).  kernel: 0 = bm25 scan, 1 = vector scan. */
