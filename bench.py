@@ -142,7 +142,7 @@ def main():
             m_cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
 
         def bm_step(n=nq):
-            N.check(L.ss_bm25_search_dev(sh._h, n, q_dev.data_ptr(), k, N.RT_TOPK, 2, o_doc.data_ptr(), o_score.data_ptr(),
+            N.check(L.ss_bm25_search_dev(sh._h, n, q_dev.data_ptr(), k, N.RT_TOPK, 2 | (3 << 8), o_doc.data_ptr(), o_score.data_ptr(),
                                          o_cnt.data_ptr(), o_tot.data_ptr(), sptr), "ss_bm25_search_dev")
             if world > 1:
                 dist.all_gather_into_tensor(g_doc, o_doc)

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(OUT_DIR, "libseekstorm_hip.so")
-SOURCES = ["ss_api.hip", "vec_scan.hip", "bm25.hip", "synth.hip", "merge.hip"]
+SOURCES = ["ss_api.hip", "vec_scan.hip", "bm25.hip", "synth.hip", "merge.hip", "bm25_fast.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
 
@@ -22,7 +22,7 @@ def _newer(dst, srcs):
 
 def build(force=False, verbose=False):
     os.makedirs(OUT_DIR, exist_ok=True)
-    deps = [os.path.join(CSRC, "ss_common.h"), os.path.join(HERE, "..", "include", "seekstorm_hip.h")]
+    deps = [os.path.join(CSRC, "ss_common.h"), os.path.join(CSRC, "bm25_dev.h"), os.path.join(HERE, "..", "include", "seekstorm_hip.h")]
     objs = []
     jobs = []
     for src in SOURCES:
@@ -40,7 +40,7 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
         return r.stderr
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         for err in ex.map(run, jobs):
             if verbose and err:
                 print(err)

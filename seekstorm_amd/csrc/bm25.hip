@@ -17,158 +17,23 @@
 //            register-held sorted top-k (strict '>' admission against the current k-th, ties -> lower doc id).
 // Partition-local top-k lists are merged by a small bitonic kernel.  Integer / irregular work: no MFMA; the bound is
 // HBM bandwidth (4 B per posting + CSR offsets).
-#include "ss_common.h"
+#include "bm25_dev.h"
 
-constexpr int BM_RC = 12;            // posting chunks (256 postings each) in flight per wave and round
-constexpr float BM_K1P = 2.2f;       // K + 1.0 (add_result.rs:20)
-
-struct BmParams {
-  const uint32_t* post;
-  const unsigned long long* term_base;
-  const uint32_t* sub_off;
-  const float* comp;
-  const ss_bm25_query* q;
-  unsigned long long* part_keys;   // [nq][P][KS]
-  unsigned long long* total;       // [nq] exact match counts
-  uint32_t n_sub, n_terms, nq, P, k;
-};
-
-typedef unsigned long long u64;
-
-__device__ __forceinline__ u64 shfl64(u64 v, int src) {
-  uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)(v >> 32), src);
-  return ((u64)hi << 32) | lo;
-}
-__device__ __forceinline__ u64 shflx64(u64 v, int m) {
-  uint32_t lo = __shfl_xor((uint32_t)v, m), hi = __shfl_xor((uint32_t)(v >> 32), m);
-  return ((u64)hi << 32) | lo;
-}
-__device__ __forceinline__ u64 rdlane64(u64 v, int l) {
-  uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, l), hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), l);
-  return ((u64)hi << 32) | lo;
-}
-// full bitonic sort of one key per lane, descending by lane index
-__device__ __forceinline__ u64 wave_sort_desc(u64 x, int lane) {
-#pragma unroll
-  for (int k2 = 2; k2 <= 64; k2 <<= 1) {
-#pragma unroll
-    for (int j = k2 >> 1; j > 0; j >>= 1) {
-      u64 p = shflx64(x, j);
-      bool up = (lane & k2) == 0;  // this block sorts descending
-      bool lower = (lane & j) == 0;
-      bool keep_max = (lower == up);
-      x = keep_max ? (x > p ? x : p) : (x < p ? x : p);
-    }
-  }
-  return x;
-}
-// sort a bitonic sequence descending
-__device__ __forceinline__ u64 wave_bitonic_merge_desc(u64 x, int lane) {
-#pragma unroll
-  for (int j = 32; j > 0; j >>= 1) {
-    u64 p = shflx64(x, j);
-    bool lower = (lane & j) == 0;
-    x = lower ? (x > p ? x : p) : (x < p ? x : p);
-  }
-  return x;
-}
-
-// Wave-resident sorted top-k: rank r*64+lane lives in keys[r] of `lane`; 0 = empty.  The list is only touched on
-// the (rare) candidate path, which is kept out of line so the unrolled posting loops stay small.
-template <int KPL>
-__device__ __forceinline__ u64 topk_finish(u64 (&keys)[KPL], uint32_t k, int lane) {
-#pragma unroll
-  for (int r = 0; r < KPL; r++)
-    if ((uint32_t)(r * 64 + lane) >= k) keys[r] = 0ull;
-  const uint32_t kr = (k - 1) >> 6, kl = (k - 1) & 63;
-  u64 w = 0ull;
-#pragma unroll
-  for (int r = 0; r < KPL; r++)
-    if ((uint32_t)r == kr) w = rdlane64(keys[r], kl);
-  return w;  // key at rank k-1 (0 while not full): admission threshold, strict '>'
-}
-// insert one (wave-uniform) key
-template <int KPL>
-__device__ __forceinline__ u64 topk_insert1(u64 (&keys)[KPL], u64 key, uint32_t k, int lane) {
-  uint32_t pos = 0;
-#pragma unroll
-  for (int r = 0; r < KPL; r++) pos += __popcll(__ballot(keys[r] > key));
-  u64 carry = key;
-  bool active = false;
-#pragma unroll
-  for (int r = 0; r < KPL; r++) {
-    if (!active && pos < (uint32_t)(64 * (r + 1))) {
-      active = true;
-      pos -= 64 * r;
-    } else if (active) {
-      pos = 0;
-    }
-    if (active) {
-      u64 out = rdlane64(keys[r], 63);
-      u64 up = shfl64(keys[r], lane > 0 ? lane - 1 : 0);
-      keys[r] = (uint32_t)lane < pos ? keys[r] : ((uint32_t)lane == pos ? carry : up);
-      carry = out;
-    }
-  }
-  return topk_finish<KPL>(keys, k, lane);
-}
-// merge 64 new keys (one per lane, 0 = none)
-template <int KPL>
-__device__ __forceinline__ u64 topk_merge64(u64 (&keys)[KPL], u64 nk, uint32_t k, int lane) {
-  u64 c = wave_sort_desc(nk, lane);
-#pragma unroll
-  for (int r = 0; r < KPL; r++) {
-    u64 crev = shfl64(c, 63 - lane);
-    u64 hi = keys[r] > crev ? keys[r] : crev;
-    u64 lo = keys[r] > crev ? crev : keys[r];
-    keys[r] = wave_bitonic_merge_desc(hi, lane);
-    if (r + 1 < KPL) c = wave_bitonic_merge_desc(lo, lane);
-  }
-  return topk_finish<KPL>(keys, k, lane);
-}
-// offer up to 4 candidate keys per lane (0 = none); returns the new admission threshold
-template <int KPL>
-__device__ __attribute__((noinline)) u64 topk_offer(u64 (&keys)[KPL], u64 k0, u64 k1, u64 k2, u64 k3, u64 worst,
-                                                    uint32_t k) {
-  const int lane = __lane_id();
-  for (;;) {
-    u64 a = k0 > k1 ? k0 : k1, b = k2 > k3 ? k2 : k3;
-    u64 mk = a > b ? a : b;  // this lane's best remaining candidate
-    bool cand = mk > worst;
-    u64 m = __ballot(cand);
-    if (m == 0) break;
-    if (__popcll(m) > 6) {
-      worst = topk_merge64<KPL>(keys, cand ? mk : 0ull, k, lane);
-    } else {
-      while (m) {
-        int l = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        u64 kk = rdlane64(mk, l);
-        if (kk > worst) worst = topk_insert1<KPL>(keys, kk, k, lane);
-      }
-    }
-    if (cand) {  // consumed (inserted or rejected against a threshold that only rises)
-      if (k0 == mk) k0 = 0;
-      else if (k1 == mk) k1 = 0;
-      else if (k2 == mk) k2 = 0;
-      else k3 = 0;
-    }
-  }
-  return worst;
-}
 
 template <bool HAS_AND, int KPL>
-__global__ void __launch_bounds__(HAS_AND ? 192 : 256) bm25_scan_kernel(BmParams p) {
+__global__ void __launch_bounds__(HAS_AND ? 384 : 512) bm25_scan_kernel(BmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int WAVES = HAS_AND ? 3 : 4;
+  constexpr int WAVES = HAS_AND ? 6 : 8;
   constexpr int WAVE_LDS = BM_SUB * 4 + (HAS_AND ? BM_SUB : 0);
   float* comp = (float*)smem;
+  float* wlut = comp + 256;  // wlut[(tf<<8)|len] = tf*(K+1)/(tf+comp[len]) for tf < 16
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float* acc = (float*)(smem + 1024 + w * WAVE_LDS);
-  uint32_t* cntw = (uint32_t*)(smem + 1024 + w * WAVE_LDS + BM_SUB * 4);
+  char* wbase = smem + BM_LUT_BYTES + w * WAVE_LDS;
+  float* acc = (float*)wbase;
+  uint32_t* cntw = (uint32_t*)(wbase + BM_SUB * 4);
 
-  for (int i = tid; i < 256; i += WAVES * 64) comp[i] = p.comp[i];
+  for (int i = tid; i < 256 + 4096; i += WAVES * 64) comp[i] = p.comp[i];
   for (int i = lane; i < BM_SUB; i += 64) acc[i] = 0.f;
   if (HAS_AND)
     for (int i = lane; i < BM_SUB / 4; i += 64) cntw[i] = 0u;
@@ -178,6 +43,7 @@ __global__ void __launch_bounds__(HAS_AND ? 192 : 256) bm25_scan_kernel(BmParams
   const uint32_t A = p.nq * p.P;
   const uint32_t row_len = p.n_sub + 1;
   const uint32_t k = p.k;
+  const bool count_mode = p.count != 0;
 
   for (uint32_t a = blockIdx.x * WAVES + w; a < A; a += total_waves) {
     const uint32_t qi = a % p.nq, part = a / p.nq;
@@ -205,107 +71,159 @@ __global__ void __launch_bounds__(HAS_AND ? 192 : 256) bm25_scan_kernel(BmParams
     u64 worst = 0ull;
     u64 matched = 0;
 
-    for (uint32_t s = s_begin; s < s_end; ++s) {
-      uint32_t b = 0, e = 0;
-      if ((uint32_t)lane < nt) {
-        b = p.sub_off[rowoff + s];
-        e = p.sub_off[rowoff + s + 1];
+    // sub-block boundaries of my term (lane < nt), rolling window; indices past s_end clamp -> empty items
+    // (every lane loads -- lanes >= nt read row 0 -- so the load is unconditional and hipcc can count it)
+    auto bnd = [&](uint32_t j) -> uint32_t { return p.sub_off[rowoff + (j < s_end ? j : s_end)]; };
+
+    // issue the loads of one round (chunks c0 .. c0+cpt-1 of every term) of the item [b, b+len) into v[].
+    // Always exactly BM_RC loads: inactive slots / lanes read the first posting (one cached line) so that the
+    // compiler sees a fixed number of outstanding loads and emits COUNTED vmcnt waits -- the next item's loads
+    // then stay in flight while the current item is processed.
+    auto issue_loads = [&](uint4(&v)[BM_RC], uint32_t b, uint32_t len, uint32_t c0) {
+      const u64 abs0 = tbase + b;
+      uint32_t t = 0, c = c0;
+#pragma unroll
+      for (int j = 0; j < BM_RC; j++) {
+        const uint32_t lj = __builtin_amdgcn_readlane(len, t);
+        const u64 bj = rdlane64(abs0, t);
+        const uint32_t lead = (uint32_t)bj & 3u;  // 16-byte aligned loads; leading elements masked in phase 1
+        const uint32_t vs = c << 8;
+        const bool on = ((uint32_t)j < used) && (vs + (uint32_t)lane * 4 < lead + lj);
+        const uint32_t* src = on ? (p.post + (bj - lead) + vs + lane * 4) : p.post;
+        v[j] = *(const uint4*)src;
+        if (++t == nt) { t = 0; ++c; }
       }
-      const uint32_t len = e - b;
-      const u64 pb = tbase + b;
-      uint32_t maxlen = 0;
+    };
+
+    // phase 1 on the registers of one round: acc[doc] += idf * wlut[tf,len]   (add_result.rs:1445-1447)
+    auto phase1 = [&](uint4(&v)[BM_RC], uint32_t b, uint32_t len, uint32_t c0) {
+      const u64 abs0 = tbase + b;
+      uint32_t t = 0, c = c0;
+#pragma unroll
+      for (int j = 0; j < BM_RC; j++) {
+        if ((uint32_t)j < used) {
+          const uint32_t lj = __builtin_amdgcn_readlane(len, t);
+          const uint32_t lead = __builtin_amdgcn_readlane((uint32_t)abs0, t) & 3u;
+          const float idf = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(idf_l), t));
+          const uint32_t vs = c << 8;
+          if (vs < lead + lj) {
+            const uint32_t i0 = vs + (uint32_t)lane * 4 - lead;  // index inside the term's span (wraps if before it)
+            const uint32_t pv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+            // Plain (non-atomic) read-modify-write: the 256 postings of a chunk belong to ONE term, so their docs are
+            // distinct, and the tile is private to this wave whose LDS operations execute in order.  (LDS float
+            // atomics measured ~3 clk per lane here; a gather + scatter is an order of magnitude cheaper.)
+            bool valid[4];
+            float old[4], wgt[4];
+            uint32_t cold[4];
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+              const uint32_t pp = pv[x];
+              valid[x] = (i0 + x) < lj;
+              const uint32_t doc = valid[x] ? (pp & 0xFFFu) : 0u;
+              old[x] = acc[doc];
+              wgt[x] = wlut[valid[x] ? ((pp >> 13) & 0xFFFu) : 0u];
+              if (HAS_AND && is_and) cold[x] = ((const uint8_t*)cntw)[doc];
+            }
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+              const uint32_t pp = pv[x];
+              if (valid[x]) {
+                float wp = wgt[x];
+                if (pp >> 25) {  // tf >= 16: outside the table (rare)
+                  float tf = (float)(pp >> 21);
+                  wp = tf * BM_K1P * __builtin_amdgcn_rcpf(tf + comp[(pp >> 13) & 0xFFu]);
+                }
+                acc[pp & 0xFFFu] = old[x] + idf * wp;
+                if (HAS_AND && is_and) ((uint8_t*)cntw)[pp & 0xFFFu] = (uint8_t)(cold[x] + 1u);
+              }
+            }
+          }
+          if (++t == nt) { t = 0; ++c; }
+        }
+      }
+    };
+
+    // phase 2: dense scan of the 4096-entry tile (16 x ds_read_b128 per lane), clear it, collect matches.
+    // doc = (i*64 + lane)*4 + e; for intersections byte e of cntw[i*64+lane] counts the terms that hit doc.
+    auto phase2 = [&](uint32_t doc_base) {
+      const float worst_sc = __uint_as_float((uint32_t)(worst >> 32));
+      float wsc = worst_sc;
+#pragma unroll 4
+      for (int i = 0; i < BM_SUB / 256; i++) {
+        const int slot = i * 64 + lane;
+        float4 x = *(const float4*)(acc + slot * 4);
+        *(float4*)(acc + slot * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool h0 = x.x != 0.f, h1 = x.y != 0.f, h2 = x.z != 0.f, h3 = x.w != 0.f;
+        if (HAS_AND && is_and) {
+          uint32_t cw = cntw[slot];
+          cntw[slot] = 0u;
+          h0 = (cw & 0xFFu) == nt;
+          h1 = ((cw >> 8) & 0xFFu) == nt;
+          h2 = ((cw >> 16) & 0xFFu) == nt;
+          h3 = (cw >> 24) == nt;
+          if (!h0) x.x = 0.f;
+          if (!h1) x.y = 0.f;
+          if (!h2) x.z = 0.f;
+          if (!h3) x.w = 0.f;
+        }
+        if (count_mode)
+          matched += __popcll(__ballot(h0)) + __popcll(__ballot(h1)) + __popcll(__ballot(h2)) + __popcll(__ballot(h3));
+        if (k) {
+          const float m = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
+          if (__ballot(m > 0.f && m >= wsc)) {  // rare once the list is warm
+            const uint32_t d0 = doc_base + slot * 4;
+            u64 k0 = ((u64)__float_as_uint(x.x) << 32) | (u64)(0xFFFFFFFFu - d0);
+            u64 k1 = ((u64)__float_as_uint(x.y) << 32) | (u64)(0xFFFFFFFFu - (d0 + 1));
+            u64 k2 = ((u64)__float_as_uint(x.z) << 32) | (u64)(0xFFFFFFFFu - (d0 + 2));
+            u64 k3 = ((u64)__float_as_uint(x.w) << 32) | (u64)(0xFFFFFFFFu - (d0 + 3));
+            k0 = (x.x > 0.f && k0 > worst) ? k0 : 0ull;
+            k1 = (x.y > 0.f && k1 > worst) ? k1 : 0ull;
+            k2 = (x.z > 0.f && k2 > worst) ? k2 : 0ull;
+            k3 = (x.w > 0.f && k3 > worst) ? k3 : 0ull;
+            if (__ballot((k0 | k1 | k2 | k3) != 0ull)) {
+              worst = topk_offer<KPL>(topk, k0, k1, k2, k3, worst, k);
+              wsc = __uint_as_float((uint32_t)(worst >> 32));
+            }
+          }
+        }
+      }
+    };
+
+    // rounds needed by an item: max over terms of ceil((lead + len) / 256)
+    auto rounds_of = [&](uint32_t b, uint32_t len) -> uint32_t {
+      const uint32_t lead = ((uint32_t)(tbase + b)) & 3u;
+      const uint32_t nch = len ? ((lead + len + 255) >> 8) : 0;
+      uint32_t mx = 0;
       for (uint32_t t = 0; t < nt; ++t) {
-        uint32_t l = __builtin_amdgcn_readlane(len, t);
-        maxlen = l > maxlen ? l : maxlen;
+        uint32_t n = __builtin_amdgcn_readlane(nch, t);
+        mx = n > mx ? n : mx;
       }
-      if (maxlen == 0) continue;
-      const uint32_t maxc = (maxlen + 255) >> 8;
-      const uint32_t doc_base = s << BM_SUB_LOG2;
+      return mx;
+    };
 
-      uint4 v[BM_RC];
-      uint32_t nv[BM_RC];
-      float idfj[BM_RC];
+    uint4 vA[BM_RC], vB[BM_RC];
+    uint32_t B0 = bnd(s_begin), B1 = bnd(s_begin + 1), B2 = bnd(s_begin + 2);
+    issue_loads(vA, B0, B1 - B0, 0);
 
-      // PH: 1 = accumulate, 2 = collect (reload), 3 = both on the same registers
-      auto round = [&](uint32_t c0, int PH) {
-        uint32_t t = 0, c = c0;
-#pragma unroll
-        for (int j = 0; j < BM_RC; j++) {
-          nv[j] = 0;
-          if ((uint32_t)j < used) {
-            uint32_t lj = __builtin_amdgcn_readlane(len, t);
-            uint32_t start = c << 8;
-            if (start < lj) {
-              uint32_t n = lj - start;
-              nv[j] = n > 256 ? 256 : n;
-              idfj[j] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(idf_l), t));
-              u64 base = rdlane64(pb, t) + start;
-              if ((uint32_t)lane * 4 < nv[j]) v[j] = *(const uint4*)(p.post + base + lane * 4);
-            }
-            if (++t == nt) { t = 0; ++c; }
-          }
+    // one item: prefetch the boundary 3 ahead and the postings of the next item, then process the current one
+    auto body = [&](uint4(&cur)[BM_RC], uint4(&nxt)[BM_RC], uint32_t s) {
+      const uint32_t B3 = bnd(s + 3);
+      issue_loads(nxt, B1, B2 - B1, 0);
+      const uint32_t len = B1 - B0;
+      const uint32_t maxc = rounds_of(B0, len);
+      if (maxc) {
+        for (uint32_t c0 = 0; c0 < maxc; c0 += cpt) {
+          if (c0) issue_loads(cur, B0, len, c0);  // oversized item: rounds after the prefetched one load synchronously
+          phase1(cur, B0, len, c0);
         }
-        if (PH & 1) {
-#pragma unroll
-          for (int j = 0; j < BM_RC; j++) {
-            if (nv[j]) {
-              const uint32_t pv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
-#pragma unroll
-              for (int x = 0; x < 4; x++) {
-                if ((uint32_t)lane * 4 + x < nv[j]) {
-                  uint32_t doc = pv[x] & 0x1FFFu;
-                  float tf = (float)(pv[x] >> 21);
-                  float cmp = comp[(pv[x] >> 13) & 0xFFu];
-                  // idf * (tf*(K+1) / (tf + comp))   add_result.rs:1447 (SIGMA = 0)
-                  float wgt = idfj[j] * (tf * BM_K1P * __builtin_amdgcn_rcpf(tf + cmp));
-                  __hip_atomic_fetch_add(&acc[doc], wgt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                  if (HAS_AND && is_and)
-                    __hip_atomic_fetch_add(&cntw[doc >> 2], 1u << ((doc & 3) * 8), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
-                }
-              }
-            }
-          }
-        }
-        if (PH & 2) {
-#pragma unroll
-          for (int j = 0; j < BM_RC; j++) {
-            if (nv[j]) {
-              const uint32_t pv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
-              u64 ck[4];
-              bool any_c = false;
-#pragma unroll
-              for (int x = 0; x < 4; x++) {
-                const uint32_t doc = pv[x] & 0x1FFFu;
-                float sc = 0.f;
-                bool hit = false;
-                if ((uint32_t)lane * 4 + x < nv[j]) {
-                  sc = __hip_atomic_exchange(&acc[doc], 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                  hit = sc != 0.f;
-                  if (HAS_AND && is_and) {
-                    uint32_t sh = (doc & 3) * 8;
-                    uint32_t old = __hip_atomic_fetch_and(&cntw[doc >> 2], ~(0xFFu << sh), __ATOMIC_RELAXED,
-                                                          __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    hit = hit && (((old >> sh) & 0xFFu) == nt);
-                  }
-                }
-                matched += __popcll(__ballot(hit));
-                u64 key = ((u64)__float_as_uint(sc) << 32) | (u64)(0xFFFFFFFFu - (doc_base + doc));
-                ck[x] = (hit && key > worst) ? key : 0ull;
-                any_c |= ck[x] != 0ull;
-              }
-              if (k && __ballot(any_c)) worst = topk_offer<KPL>(topk, ck[0], ck[1], ck[2], ck[3], worst, k);
-            }
-          }
-        }
-      };
-
-      if (maxc <= cpt) {
-        round(0, 3);
-      } else {
-        for (uint32_t c0 = 0; c0 < maxc; c0 += cpt) round(c0, 1);
-        for (uint32_t c0 = 0; c0 < maxc; c0 += cpt) round(c0, 2);
+        phase2(s << BM_SUB_LOG2);
       }
+      B0 = B1; B1 = B2; B2 = B3;
+    };
+    for (uint32_t s = s_begin; s < s_end; s += 2) {
+      body(vA, vB, s);
+      if (s + 1 < s_end) body(vB, vA, s + 1);
+      else break;
     }
 
     // publish the partition-local list and the exact match count
@@ -380,8 +298,8 @@ __global__ void bm25_final_kernel(const u64* __restrict__ keys, const u64* __res
 // ---------------------------------------------------------------- host side
 template <bool HAS_AND, int KPL>
 static int launch_scan(const BmParams& p, uint32_t grid, hipStream_t st) {
-  constexpr int WAVES = HAS_AND ? 3 : 4;
-  constexpr int lds = 1024 + WAVES * (BM_SUB * 4 + (HAS_AND ? BM_SUB : 0));
+  constexpr int WAVES = HAS_AND ? 6 : 8;
+  constexpr int lds = BM_LUT_BYTES + WAVES * (BM_SUB * 4 + (HAS_AND ? BM_SUB : 0));
   static bool done = false;
   if (!done) {
     SS_HIP(hipFuncSetAttribute((const void*)bm25_scan_kernel<HAS_AND, KPL>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -393,7 +311,7 @@ static int launch_scan(const BmParams& p, uint32_t grid, hipStream_t st) {
 }
 
 int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t* d_out_doc,
-                    float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, hipStream_t st) {
+                    float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, uint32_t nt_max, hipStream_t st) {
   if (!s->d_post) return SS_ESTATE;
   if (nq == 0) return SS_OK;
   if (k > SS_MAX_K) return SS_EINVAL;
@@ -430,9 +348,10 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   p.nq = nq;
   p.P = P;
   p.k = k;
+  p.count = (rt == SS_RT_TOPK) ? 0u : 1u;  // Topk: result_count_total is not required to be exact
   const uint32_t A = nq * P;
-  const int waves_per_wg = has_and ? 3 : 4;
-  uint32_t grid = std::min<uint32_t>((A + waves_per_wg - 1) / waves_per_wg, 512);
+  const int waves_per_wg = has_and ? 6 : 8;
+  uint32_t grid = std::min<uint32_t>((A + waves_per_wg - 1) / waves_per_wg, 256);
 
   hipEvent_t e0 = nullptr, e1 = nullptr;
   ssi_prof_begin(s, 0, st, &e0, &e1);
@@ -444,7 +363,10 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
     case 4: rc = launch_scan<AND_, 4>(p, grid, st); break; \
     default: rc = launch_scan<AND_, 16>(p, grid, st); break; \
   }
-  if (has_and) { SS_LAUNCH(true) } else { SS_LAUNCH(false) }
+  rc = ssi_bm25_launch_fast(p, nt_max, has_and, KPL, st);  // NT-specialised kernels for <= 4 terms, k <= 128
+  if (rc == SS_ENOTSUP) {
+    if (has_and) { SS_LAUNCH(true) } else { SS_LAUNCH(false) }
+  }
 #undef SS_LAUNCH
   ssi_prof_end(s, 0, st, e0, e1);
   if (rc) return rc;

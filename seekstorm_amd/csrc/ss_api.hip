@@ -168,8 +168,9 @@ int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df
   return SS_OK;
 }
 
-static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q, bool* has_and) {
+static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q, bool* has_and, uint32_t* nt_max) {
   *has_and = false;
+  *nt_max = 0;
   for (uint32_t i = 0; i < nq; i++) {
     if (q[i].n_terms == 0 || q[i].n_terms > SS_MAX_QUERY_TERMS) return SS_EINVAL;
     if (q[i].op != SS_OP_INTERSECTION && q[i].op != SS_OP_UNION) return SS_EINVAL;
@@ -180,6 +181,7 @@ static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q,
         if (q[i].term[u] == q[i].term[t]) return SS_EINVAL;  // unique terms only (search.rs:3023 unique_terms)
     }
     if (q[i].op == SS_OP_INTERSECTION && q[i].n_terms > 1) *has_and = true;
+    *nt_max = std::max(*nt_max, q[i].n_terms);
   }
   return SS_OK;
 }
@@ -192,7 +194,8 @@ int ss_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k,
   if (!s->d_post) return SS_ESTATE;
   if (nq == 0) return SS_OK;
   bool has_and = false;
-  SS_TRY(check_queries(s, nq, q, &has_and));
+  uint32_t nt_max = 0;
+  SS_TRY(check_queries(s, nq, q, &has_and, &nt_max));
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   const uint32_t kk = rt == SS_RT_COUNT ? 0 : k;
@@ -205,7 +208,7 @@ int ss_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k,
   }
   SS_HIP(hipMemcpyAsync(s->d_bq, q, (size_t)nq * sizeof(ss_bm25_query), hipMemcpyHostToDevice, s->stream));
   SS_TRY(ssi_bm25_search(s, nq, (const ss_bm25_query*)s->d_bq, kk, rt, s->d_out_doc, s->d_out_score, s->d_out_count,
-                         s->d_out_total, has_and, s->stream));
+                         s->d_out_total, has_and, nt_max, s->stream));
   if (kk) {
     SS_HIP(hipMemcpyAsync(out_doc, s->d_out_doc, (size_t)nq * kk * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     SS_HIP(hipMemcpyAsync(out_score, s->d_out_score, (size_t)nq * kk * sizeof(float), hipMemcpyDeviceToHost, s->stream));
@@ -227,7 +230,7 @@ int ss_bm25_search_dev(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint3
   SS_HIP(hipSetDevice(s->device));
   hipStream_t st = stream ? (hipStream_t)stream : s->stream;
   return ssi_bm25_search(s, nq, d_q, rt == SS_RT_COUNT ? 0 : k, rt, d_out_doc, d_out_score, d_out_count, d_out_total,
-                         (ops_mask & 1u) != 0, st);
+                         (ops_mask & 1u) != 0, (ops_mask >> 8) & 0xFFu ? (ops_mask >> 8) & 0xFFu : SS_MAX_QUERY_TERMS, st);
 }
 
 // ------------------------------------------------------------------ vectors

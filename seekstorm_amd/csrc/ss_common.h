@@ -85,7 +85,7 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const float* d_queries, uint32_t k,
 int ssi_vec_alloc_ws(ss_shard* s);
 // ---- implemented in bm25.hip
 int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t* d_out_doc,
-                    float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, hipStream_t st);
+                    float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, uint32_t nt_max, hipStream_t st);
 // ---- implemented in synth.hip
 int ssi_vec_synth(ss_shard* s, uint64_t seed, hipStream_t st);
 int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const uint8_t* d_lentab, hipStream_t st);

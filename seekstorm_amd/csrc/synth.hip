@@ -54,12 +54,20 @@ int ssi_vec_synth(ss_shard* s, uint64_t seed, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------- BM25 image from host arrays
-static void fill_comp(float avgdl, float* comp) {  // commit.rs:321-325
+// comp[0..255] = bm25_component_cache (commit.rs:321-325); comp[256 + (tf<<8|len)] = tf*(K+1)/(tf+comp[len]) for
+// tf < 16 (add_result.rs:1445-1447 without the idf factor): the table the scan kernel indexes with posting bits.
+static void fill_comp(float avgdl, float* comp) {
   for (int i = 0; i < 256; i++) {
     float q = (float)ss_byte4_to_int((uint32_t)i) / avgdl;
     comp[i] = 1.2f * (1.0f - 0.75f + 0.75f * q);
   }
+  for (int tf = 0; tf < 16; tf++)
+    for (int l = 0; l < 256; l++) {
+      float t = (float)tf;
+      comp[256 + (tf << 8) + l] = tf ? (t * (1.2f + 1.0f) / (t + comp[l])) : 0.0f;
+    }
 }
+constexpr int SS_COMP_N = 256 + 4096;
 
 static int alloc_image(ss_shard* s, u64 n_post) {
   const size_t rows = (size_t)s->bm_n_terms * (s->bm_n_sub + 1);
@@ -67,7 +75,7 @@ static int alloc_image(ss_shard* s, u64 n_post) {
   SS_HIP(hipMemset(s->d_post + n_post, 0, 256 * sizeof(uint32_t)));
   SS_HIP(hipMalloc(&s->d_term_base, ((size_t)s->bm_n_terms + 1) * sizeof(u64)));
   SS_HIP(hipMalloc(&s->d_sub_off, (rows ? rows : 1) * sizeof(uint32_t)));
-  SS_HIP(hipMalloc(&s->d_comp, 256 * sizeof(float)));
+  SS_HIP(hipMalloc(&s->d_comp, SS_COMP_N * sizeof(float)));
   return SS_OK;
 }
 
@@ -78,7 +86,7 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
   u64 psum = 0;
   for (u64 d = 0; d < s->bm_n_docs; d++) psum += ss_byte4_to_int(doclen[d]);
   s->bm_avgdl = (float)psum / (float)s->bm_n_docs;  // commit.rs:318-319
-  float comp[256];
+  float comp[SS_COMP_N];
   fill_comp(s->bm_avgdl, comp);
   std::vector<uint32_t> post(n_post ? n_post : 1);
   std::vector<uint32_t> sub((size_t)nt * (ns + 1));
@@ -206,7 +214,7 @@ int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const u
   const size_t rows = (size_t)nt * (ns + 1);
   SS_HIP(hipMalloc(&s->d_sub_off, rows * sizeof(uint32_t)));
   SS_HIP(hipMalloc(&s->d_term_base, ((size_t)nt + 1) * sizeof(u64)));
-  SS_HIP(hipMalloc(&s->d_comp, 256 * sizeof(float)));
+  SS_HIP(hipMalloc(&s->d_comp, SS_COMP_N * sizeof(float)));
   const u64 waves = (u64)nt * ns;
   const uint32_t grid = (uint32_t)((waves + 3) / 4);
   lex_gen_kernel<false><<<grid, 256, 0, st>>>(seed, nd, nt, ns, d_thresh, d_doclen, s->d_sub_off, nullptr, nullptr);
@@ -219,7 +227,7 @@ int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const u
   SS_HIP(hipMemcpy(&psum, d_psum, sizeof(u64), hipMemcpyDeviceToHost));
   s->bm_n_post = s->h_term_base[nt];
   s->bm_avgdl = (float)psum / (float)nd;
-  float comp[256];
+  float comp[SS_COMP_N];
   fill_comp(s->bm_avgdl, comp);
   SS_HIP(hipMemcpy(s->d_comp, comp, sizeof(comp), hipMemcpyHostToDevice));
   SS_HIP(hipMalloc(&s->d_post, (s->bm_n_post + 256) * sizeof(uint32_t)));
