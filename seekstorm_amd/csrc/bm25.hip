@@ -21,9 +21,9 @@
 
 
 template <bool HAS_AND, int KPL>
-__global__ void __launch_bounds__(HAS_AND ? 384 : 512) bm25_scan_kernel(BmParams p) {
+__global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) bm25_scan_kernel(BmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int WAVES = HAS_AND ? 6 : 8;
+  constexpr int WAVES = HAS_AND ? BM_WAVES_AND : BM_WAVES_OR;
   constexpr int WAVE_LDS = BM_SUB * 4 + (HAS_AND ? BM_SUB : 0);
   float* comp = (float*)smem;
   float* wlut = comp + 256;  // wlut[(tf<<8)|len] = tf*(K+1)/(tf+comp[len]) for tf < 16
@@ -298,7 +298,7 @@ __global__ void bm25_final_kernel(const u64* __restrict__ keys, const u64* __res
 // ---------------------------------------------------------------- host side
 template <bool HAS_AND, int KPL>
 static int launch_scan(const BmParams& p, uint32_t grid, hipStream_t st) {
-  constexpr int WAVES = HAS_AND ? 6 : 8;
+  constexpr int WAVES = HAS_AND ? BM_WAVES_AND : BM_WAVES_OR;
   constexpr int lds = BM_LUT_BYTES + WAVES * (BM_SUB * 4 + (HAS_AND ? BM_SUB : 0));
   static bool done = false;
   if (!done) {
@@ -320,7 +320,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   const int KPL = kk <= 64 ? 1 : kk <= 128 ? 2 : kk <= 256 ? 4 : 16;
   const uint32_t KS = 64 * KPL;
   // partitions per query: enough assignments to load-balance ~2048 resident waves
-  uint32_t P = (8192 + nq - 1) / nq;
+  uint32_t P = (4u * 256u * BM_WAVES_OR + nq - 1) / nq;
   P = std::max<uint32_t>(1, std::min<uint32_t>(P, s->bm_n_sub));
   const size_t need = (size_t)nq * P * KS * 2 + nq;  // two ping-pong merge buffers + totals
   if (need > s->part_cap) {
@@ -350,7 +350,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   p.k = k;
   p.count = (rt == SS_RT_TOPK) ? 0u : 1u;  // Topk: result_count_total is not required to be exact
   const uint32_t A = nq * P;
-  const int waves_per_wg = has_and ? 6 : 8;
+  const int waves_per_wg = has_and ? BM_WAVES_AND : BM_WAVES_OR;
   uint32_t grid = std::min<uint32_t>((A + waves_per_wg - 1) / waves_per_wg, 256);
 
   hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -12,9 +12,9 @@ template <int NT> struct FastCfg { static constexpr int CPT = NT <= 2 ? 4 : 3; s
 constexpr int BM_WAVE_ACC = BM_SUB * 4 + 256;  // accumulator tile + 64 per-lane dump slots
 
 template <int NT, bool HAS_AND, int KPL>
-__global__ void __launch_bounds__(HAS_AND ? 384 : 512) bm25_scan_fast_kernel(BmParams p) {
+__global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) bm25_scan_fast_kernel(BmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int WAVES = HAS_AND ? 6 : 8;
+  constexpr int WAVES = HAS_AND ? BM_WAVES_AND : BM_WAVES_OR;
   constexpr int CPT = FastCfg<NT>::CPT;
   constexpr int RC = FastCfg<NT>::RC;
   constexpr int WAVE_LDS = BM_WAVE_ACC + (HAS_AND ? BM_SUB : 0);
@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(HAS_AND ? 384 : 512) bm25_scan_fast_kernel(BmP
 
 template <int NT, bool HAS_AND, int KPL>
 static int launch_fast(const BmParams& p, hipStream_t st) {
-  constexpr int WAVES = HAS_AND ? 6 : 8;
+  constexpr int WAVES = HAS_AND ? BM_WAVES_AND : BM_WAVES_OR;
   constexpr int lds = BM_LUT_BYTES + WAVES * (BM_WAVE_ACC + (HAS_AND ? BM_SUB : 0));
   static bool done = false;
   if (!done) {
