@@ -29,6 +29,15 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: FP32 matrix peak
 
 
+def pmc_traffic(kind):
+    """HBM bytes per launch from the committed PMC run (profiles/pmc_traffic.json, produced by tools/pmc_summary.py
+    from separate rocprofv3 --pmc passes of this same command); None if the file is absent."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[kind]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def pct(a, p):
     a = sorted(a)
     return a[min(len(a) - 1, int(round(p / 100.0 * (len(a) - 1))))] if a else None
@@ -89,7 +98,8 @@ def main():
     sptr = C.c_void_p(stream.cuda_stream)
     assert sptr.value, "expected a non-null HIP stream handle"
     sh = S.Shard(local_rank, shard_id=rank)
-    out = {}
+    from seekstorm_amd import distributed as D
+    merged = {}
 
     def timed(step_fn, steps, warmup):
         for _ in range(warmup):
@@ -133,33 +143,28 @@ def main():
         o_score = torch.empty((nq, k), dtype=torch.float32, device=dev)
         o_cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
         o_tot = torch.empty((nq,), dtype=torch.int64, device=dev)
-        if world > 1:
-            g_doc = torch.empty((world, nq, k), dtype=torch.int32, device=dev)
-            g_score = torch.empty((world, nq, k), dtype=torch.float32, device=dev)
-            g_cnt = torch.empty((world, nq), dtype=torch.int32, device=dev)
-            m_doc = torch.empty((nq, k), dtype=torch.int64, device=dev)
-            m_score = torch.empty((nq, k), dtype=torch.float32, device=dev)
-            m_cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
-
         def bm_step(n=nq):
             N.check(L.ss_bm25_search_dev(sh._h, n, q_dev.data_ptr(), k, N.RT_TOPK, 2 | (3 << 8), o_doc.data_ptr(), o_score.data_ptr(),
                                          o_cnt.data_ptr(), o_tot.data_ptr(), sptr), "ss_bm25_search_dev")
-            if world > 1:
-                dist.all_gather_into_tensor(g_doc, o_doc)
-                dist.all_gather_into_tensor(g_score, o_score)
-                dist.all_gather_into_tensor(g_cnt, o_cnt)
-                N.check(L.ss_topk_merge_dev(local_rank, n, world, k, g_doc.data_ptr(), g_score.data_ptr(), g_cnt.data_ptr(),
-                                            m_doc.data_ptr(), m_score.data_ptr(), m_cnt.data_ptr(), sptr), "ss_topk_merge_dev")
+            if world > 1:  # one all-gather of the per-shard top-k over RCCL, identical merge on every rank
+                g = D.all_gather_topk(o_doc[:n], o_score[:n], o_cnt[:n])
+                merged["bm25"] = D.merge_gathered_device(*g, sptr, local_rank)
 
+        # exact union sizes for the roofline's "1 B per scored candidate" term: one untimed TopkCount pass
+        N.check(L.ss_bm25_search_dev(sh._h, nq, q_dev.data_ptr(), k, N.RT_TOPKCOUNT, 2 | (3 << 8), o_doc.data_ptr(),
+                                     o_score.data_ptr(), o_cnt.data_ptr(), o_tot.data_ptr(), sptr), "ss_bm25_search_dev")
+        torch.cuda.synchronize()
+        tot = o_tot.cpu().numpy().astype(np.int64)
+        ref_scores = o_score.cpu().numpy().copy()
         sh.profile(True)
         bm_step()
         torch.cuda.synchronize()
+        assert np.array_equal(ref_scores, o_score.cpu().numpy()), "Topk and TopkCount rankings differ"
         sh.profile_read(0, reset=True)
         dt = timed(bm_step, args.steps, args.warmup)
         launches, kms = sh.profile_read(0, reset=True)
         sh.profile(False)
         # algorithmic bytes: sum_t df_t*(2B id + 1B tf) + 1B per scored candidate + 4B per (term, block) + 8B*k
-        tot = o_tot.cpu().numpy().astype(np.int64)
         uniq = sorted({t for tl in term_lists for t in tl})
         dfm = dict(zip(uniq, (int(x) for x in sh.posting_count(uniq))))
         n_blocks = (args.docs + 65535) // 65536
@@ -171,8 +176,8 @@ def main():
         lat_batch = latencies(bm_step, 12)
         lat_one = latencies(lambda: bm_step(1), 60)
         bm = dict(qps=nq * args.steps / dt, ms_per_step=dt / args.steps * 1e3, build_s=build_s, info=info,
-                  roofline={"bound": "hbm", "kernel": "bm25_scan_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": bytes_launch,
+                  roofline={"bound": "hbm", "kernel": "bm25_scan_fast_kernel<3,false,1>", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("bm25"), "algorithmic_bytes_per_launch": bytes_launch,
                             "avg_launch_ms": avg_ms, "launches": int(launches)},
                   latency_ms={"batch_p50": pct(lat_batch, 50), "batch_p99": pct(lat_batch, 99),
                               "single_query_p50": pct(lat_one, 50), "single_query_p99": pct(lat_one, 99)},
@@ -221,23 +226,12 @@ def main():
         v_score = torch.empty((B, kv), dtype=torch.float32, device=dev)
         v_cnt = torch.empty((B,), dtype=torch.int32, device=dev)
         v_tot = torch.empty((B,), dtype=torch.int64, device=dev)
-        if world > 1:
-            gv_doc = torch.empty((world, B, kv), dtype=torch.int32, device=dev)
-            gv_score = torch.empty((world, B, kv), dtype=torch.float32, device=dev)
-            gv_cnt = torch.empty((world, B), dtype=torch.int32, device=dev)
-            mv_doc = torch.empty((B, kv), dtype=torch.int64, device=dev)
-            mv_score = torch.empty((B, kv), dtype=torch.float32, device=dev)
-            mv_cnt = torch.empty((B,), dtype=torch.int32, device=dev)
-
         def vec_step(n=B):
             N.check(L.ss_vec_search_dev(sh._h, n, qv.data_ptr(), kv, N.FLT_MIN_NEG, v_doc.data_ptr(), v_score.data_ptr(),
                                         v_cnt.data_ptr(), v_tot.data_ptr(), sptr), "ss_vec_search_dev")
             if world > 1:
-                dist.all_gather_into_tensor(gv_doc, v_doc)
-                dist.all_gather_into_tensor(gv_score, v_score)
-                dist.all_gather_into_tensor(gv_cnt, v_cnt)
-                N.check(L.ss_topk_merge_dev(local_rank, n, world, kv, gv_doc.data_ptr(), gv_score.data_ptr(), gv_cnt.data_ptr(),
-                                            mv_doc.data_ptr(), mv_score.data_ptr(), mv_cnt.data_ptr(), sptr), "ss_topk_merge_dev")
+                g = D.all_gather_topk(v_doc[:n], v_score[:n], v_cnt[:n])
+                merged["vec"] = D.merge_gathered_device(*g, sptr, local_rank)
 
         sh.profile(True)
         vec_step()
@@ -255,7 +249,7 @@ def main():
         lat = latencies(vec_step, 8)
         vec = dict(qps=B * vsteps / dtv, ms_per_step=dtv / vsteps * 1e3, build_s=vbuild,
                    roofline={"bound": "mfma", "kernel": "vec_scan_kernel (+refine, all row chunks of one pass)", "achieved": ach,
-                             "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
+                             "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": pmc_traffic("vector"),
                              "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": 4.0 * args.dim * args.rows,
                              "hbm_GBs": 4.0 * args.dim * args.rows / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
                              "avg_launch_ms": avg_ms, "launches": int(launches)},

@@ -1,0 +1,83 @@
+"""Multi-process (one process per GPU) leg of the search planner: index shards partition across ranks
+(doc g -> shard g % S, local id g // S, index.rs:5284); every rank answers the query batch on its shard and ONE
+all-gather of the per-shard top-(offset+length) lists replaces the reference's await-all-JoinHandles + Vec::append
+(search.rs:1875-1917); the merge (sort desc, offset, truncate -- search.rs:2098-2119; RRF for Hybrid,
+search.rs:1962-2035) then runs identically on every rank.
+
+Backends: `nccl` (= RCCL over xGMI) with device tensors and ss_topk_merge_dev on the GPU box; `gloo` with host tensors
+and ss_merge_results, used by the CPU tests (world_size 2).  Payload per rank is n_queries * k * 8 bytes: latency-,
+not bandwidth-bound, so a single one-shot all-gather per list is used (no bucketing, no ring tuning).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _native as N
+from .search import SearchMode, merge_results
+
+
+def all_gather_topk(doc: torch.Tensor, score: torch.Tensor, count: torch.Tensor):
+    """doc/score: [nq, k] of this rank's shard (local ids, sorted desc); count: [nq].  Returns [S, nq, k] x2, [S, nq]."""
+    world = dist.get_world_size()
+
+    def gather(x):
+        x = x.contiguous()
+        # concatenated output form: accepted by both RCCL and gloo; viewed as [S, ...] afterwards
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x)
+        return out.view((world,) + tuple(x.shape))
+
+    g_doc, g_score, g_cnt = gather(doc), gather(score), gather(count)
+    return g_doc, g_score, g_cnt
+
+
+def merge_gathered_host(g_doc, g_score, g_cnt, offset, length, mode=SearchMode.Lexical):
+    """Host merge of gathered single-mode lists -> per query (global ids, scores).  Shard of list s is rank s."""
+    S, nq, k = g_doc.shape
+    gd = g_doc.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    gs = g_score.cpu().numpy()
+    gc = g_cnt.cpu().numpy().astype(np.int64)
+    out = []
+    for q in range(nq):
+        ids, sc = [], []
+        for s in range(S):
+            n = int(gc[s, q])
+            ids += [int(x) * S + s for x in gd[s, q, :n]]  # search.rs:1671
+            sc += [float(x) for x in gs[s, q, :n]]
+        lists = (ids, sc)
+        if mode == SearchMode.Vector:
+            out.append(merge_results(SearchMode.Vector, None, lists, offset, length)[:2])
+        else:
+            out.append(merge_results(SearchMode.Lexical, lists, None, offset, length)[:2])
+    return out
+
+
+def merge_gathered_hybrid_host(lex, vec, offset, length):
+    """lex / vec: (g_doc, g_score, g_cnt) triples gathered separately; RRF over the cross-shard concatenations."""
+    S, nq, _ = lex[0].shape
+    res = []
+    for q in range(nq):
+        parts = []
+        for g_doc, g_score, g_cnt in (lex, vec):
+            gd = g_doc.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+            gs = g_score.cpu().numpy()
+            gc = g_cnt.cpu().numpy().astype(np.int64)
+            ids, sc = [], []
+            for s in range(S):
+                n = int(gc[s, q])
+                ids += [int(x) * S + s for x in gd[s, q, :n]]
+                sc += [float(x) for x in gs[s, q, :n]]
+            parts.append((ids, sc))
+        res.append(merge_results(SearchMode.Hybrid, parts[0], parts[1], offset, length))
+    return res
+
+
+def merge_gathered_device(g_doc, g_score, g_cnt, stream_ptr, device_index):
+    """ss_topk_merge_dev on the gathered device tensors; returns (global ids int64 [nq,k], scores, counts)."""
+    S, nq, k = g_doc.shape
+    m_doc = torch.empty((nq, k), dtype=torch.int64, device=g_doc.device)
+    m_score = torch.empty((nq, k), dtype=torch.float32, device=g_doc.device)
+    m_cnt = torch.empty((nq,), dtype=torch.int32, device=g_doc.device)
+    N.check(N.lib().ss_topk_merge_dev(device_index, nq, S, k, g_doc.data_ptr(), g_score.data_ptr(), g_cnt.data_ptr(),
+                                      m_doc.data_ptr(), m_score.data_ptr(), m_cnt.data_ptr(), stream_ptr), "ss_topk_merge_dev")
+    return m_doc, m_score, m_cnt

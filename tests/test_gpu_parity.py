@@ -284,3 +284,29 @@ def test_index_two_shards_hybrid_matches_oracle(S, O):
         assert {r.doc_id for r in ro.results if r.score > os_[-1] + band} == {int(x) for x, y in zip(od, os_) if y > os_[-1] + band}
     for sh in shards:
         sh.close()
+
+
+def test_device_merge_matches_host_merge(S, O):
+    """ss_topk_merge_dev (used after the RCCL all-gather) == ss_merge_results on the same gathered lists"""
+    import ctypes as C
+    import torch
+    from seekstorm_amd import distributed as D
+    rng = np.random.default_rng(5)
+    Sn, nq, k = 4, 9, 100
+    doc = np.stack([np.stack([rng.choice(100000, k, replace=False) for _ in range(nq)]) for _ in range(Sn)]).astype(np.int32)
+    score = np.sort(rng.standard_normal((Sn, nq, k)).astype(np.float32), axis=2)[:, :, ::-1].copy()  # negative scores too
+    cnt = rng.integers(0, k + 1, (Sn, nq)).astype(np.int32)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        g = [torch.from_numpy(x).to(dev) for x in (doc, score, cnt)]
+        m_doc, m_score, m_cnt = D.merge_gathered_device(*g, C.c_void_p(st.cuda_stream), 0)
+        st.synchronize()
+    host = D.merge_gathered_host(torch.from_numpy(doc), torch.from_numpy(score), torch.from_numpy(cnt), 0, k, S.SearchMode.Vector)
+    md, ms, mc = m_doc.cpu().numpy(), m_score.cpu().numpy(), m_cnt.cpu().numpy()
+    for q in range(nq):
+        hd, hs = host[q]
+        n = int(mc[q])
+        assert n == len(hd) == min(k, int(cnt[:, q].sum()))
+        assert np.array_equal(md[q, :n].astype(np.uint64), hd) and np.array_equal(ms[q, :n], hs)
+        assert np.all(md[q, n:] == -1)

@@ -1,0 +1,174 @@
+"""CPU-side tests (-m "not gpu"): the C-ABI library loads and exports every symbol include/seekstorm_hip.h declares,
+the host-side planner logic (merge / RRF / idf / normalisation / error behaviour) agrees with the oracle, and the
+multi-process gather + merge path is exercised with gloo, world_size 2.  No GPU compute is called here."""
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes as C
+    from seekstorm_amd import _native as N
+    hdr = open(os.path.join(ROOT, "include", "seekstorm_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(ss_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 20
+    L = C.CDLL(N.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in seekstorm_hip.h but not exported"
+    bound = {s[0] for s in N.SYMBOLS}
+    assert set(declared) == bound, (set(declared) ^ bound)
+    assert N.lib().ss_abi_version() == 1
+    assert N.lib().ss_strerror(-4).decode().startswith("not supported")
+
+
+def test_struct_layout_matches_header():
+    import ctypes as C
+    from seekstorm_amd import _native as N
+    assert C.sizeof(N.Bm25Query) == 4 + 4 + 4 * 10 + 4 * 10
+    assert N.BM25_QUERY_DTYPE.fields["term"][1] == 8 and N.BM25_QUERY_DTYPE.fields["idf"][1] == 48
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import ctypes as C
+    import seekstorm_amd as S
+    n = C.c_int(-1)
+    rc = S.lib().ss_device_count(C.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(S.SeekStormHipError):
+        S.Shard(0)
+
+
+def test_product_sources_do_not_reference_oracle_code():
+    pkg = os.path.join(ROOT, "seekstorm_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "ss_oracle.h" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_merge_results_matches_oracle(mode):
+    import seekstorm_amd as S
+    from oracle import oracle as O
+    rng = np.random.default_rng(7 + mode)
+    for trial in range(20):
+        nl, nv = int(rng.integers(0, 40)), int(rng.integers(0, 40))
+        ld = rng.choice(200, nl, replace=False).astype(np.uint64)
+        vd = rng.choice(200, nv, replace=False).astype(np.uint64)
+        ls = np.sort(rng.random(nl).astype(np.float32) * 10)[::-1].copy()
+        vs = np.sort(rng.random(nv).astype(np.float32))[::-1].copy()
+        off, length = int(rng.integers(0, 5)), int(rng.integers(1, 30))
+        d, s, src = S.merge_results(mode, (ld, ls), (vd, vs), off, length)
+        od, os_, osrc = O.merge(mode, (ld, ls), (vd, vs), off, length)
+        assert np.array_equal(d, od) and np.allclose(s, os_, rtol=1e-6) and np.array_equal(src, osrc)
+
+
+def test_rrf_semantics():
+    import seekstorm_amd as S
+    # search.rs:1962-2035: k = 0.6, ranks from 0; doc in both lists sums and becomes Hybrid
+    d, s, src = S.merge_results(S.SearchMode.Hybrid, ([10, 11, 12], [3.0, 2.0, 1.0]), ([11, 20], [0.9, 0.8]), 0, 10)
+    assert list(d) == [11, 10, 20, 12]
+    assert np.allclose(s, [1 / 1.6 + 1 / 0.6, 1 / 0.6, 1 / 1.6, 1 / 2.6], rtol=1e-6)
+    assert list(src) == [S.ResultSource.Hybrid, S.ResultSource.Lexical, S.ResultSource.Vector, S.ResultSource.Lexical]
+    # offset / length applied after the merge (search.rs:2109-2119)
+    d2, _, _ = S.merge_results(S.SearchMode.Hybrid, ([10, 11, 12], [3.0, 2.0, 1.0]), ([11, 20], [0.9, 0.8]), 1, 2)
+    assert list(d2) == [10, 20]
+
+
+def test_host_scalars_match_oracle():
+    import seekstorm_amd as S
+    from oracle import oracle as O
+    L = O.lib()
+    for N_, n in [(1_000_000, 1000), (10_000_000, 125_000), (300_000, 60_000), (4, 2)]:
+        assert abs(float(S.idf_f32(N_, n)) - L.so_idf(N_, n)) <= 2e-7 * max(1.0, L.so_idf(N_, n))
+    v = O.vec_gen(3, 0, 1, 768, normalize=False)[0]
+    assert np.allclose(S.normalize_f32(v), O.normalize(v), rtol=0, atol=1e-7)
+    assert abs(S.threshold_raw(0.7) - L.so_threshold_raw(0.7)) < 1e-2
+    assert S.threshold_raw(None) < -3e38
+
+
+# ------------------------------------------------------------------ world_size-2 gloo: gather + merge == single-process merge
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, nq, k, seed, q):
+    import torch
+    import torch.distributed as dist
+    from seekstorm_amd import distributed as D
+    from seekstorm_amd.search import SearchMode
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lists = _fake_shard_lists(world, nq, k, seed)
+    lex, vec = lists[rank]
+    out = {}
+    for name, (doc, score, cnt), mode in (("lex", lex, SearchMode.Lexical), ("vec", vec, SearchMode.Vector)):
+        g = D.all_gather_topk(torch.from_numpy(doc), torch.from_numpy(score), torch.from_numpy(cnt))
+        out[name] = D.merge_gathered_host(*g, 0, k, mode)
+        out[name + "_g"] = g
+    out["hyb"] = D.merge_gathered_hybrid_host(out.pop("lex_g"), out.pop("vec_g"), 0, k)
+    q.put((rank, {kk: [(np.asarray(a).tolist(), np.asarray(b).tolist()) for a, b, *_ in v] for kk, v in out.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _fake_shard_lists(world, nq, k, seed):
+    """deterministic per-shard top-k lists (sorted desc, ragged counts) for both modes"""
+    rng = np.random.default_rng(seed)
+    res = []
+    for s in range(world):
+        per = []
+        for scale in (10.0, 1.0):
+            doc = np.stack([rng.choice(5000, k, replace=False) for _ in range(nq)]).astype(np.int32)
+            score = np.sort(rng.random((nq, k)).astype(np.float32) * scale, axis=1)[:, ::-1].copy()
+            cnt = rng.integers(k // 2, k + 1, nq).astype(np.int32)
+            per.append((doc, score, cnt))
+        res.append(tuple(per))
+    return res
+
+
+def test_two_process_gloo_gather_merge_equals_single_process():
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    world, nq, k, seed = 2, 5, 16, 99
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nq, k, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    lists = _fake_shard_lists(world, nq, k, seed)
+    assert got[0] == got[1]  # identical merge on every rank
+    for qi in range(nq):
+        cat = {}
+        for mi, name in enumerate(("lex", "vec")):
+            ids, sc = [], []
+            for s in range(world):
+                doc, score, cnt = lists[s][mi]
+                n = int(cnt[qi])
+                ids += [int(x) * world + s for x in doc[qi, :n]]
+                sc += [float(x) for x in score[qi, :n]]
+            cat[name] = (ids, sc)
+            od, os_, _ = O.merge(mi, cat[name], cat[name], 0, k) if mi == 0 else O.merge(1, None, cat[name], 0, k)
+            gd, gs = got[0][name][qi]
+            assert gd == [int(x) for x in od] and np.allclose(gs, os_, rtol=1e-6)
+        od, os_, _ = O.merge(2, cat["lex"], cat["vec"], 0, k)
+        gd, gs = got[0]["hyb"][qi]
+        assert gd == [int(x) for x in od] and np.allclose(gs, os_, rtol=1e-6)
