@@ -83,6 +83,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: run `python seekstorm_amd/build.py` (hipcc, gfx950). "
                                "There is no CPU fallback.")
+        # One HIP runtime per process: torch bundles its own libamdhip64 (requested by file name, SONAME
+        # libamdhip64.so.7); ours asks for the SONAME.  Loaded first, torch's copy satisfies both; loaded second it
+        # becomes a second runtime that finds no device ("No HIP GPUs are available").  torch is plumbing here
+        # (buffers, streams, torch.distributed) and optional: without it the ROCm copy is used.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)
