@@ -2,10 +2,12 @@
 #pragma once
 #include "ss_common.h"
 
-constexpr int BM_RC = 12;            // posting chunks (256 postings each) in flight per wave and round
 constexpr float BM_K1P = 2.2f;       // K + 1.0 (add_result.rs:20)
-// LDS layout per workgroup: [comp 256 f32][wlut 4096 f32][per wave: acc 4096 f32 (+64 dump slots) (+ 4096 match-count bytes)]
+// LDS layout per workgroup: [comp 256 f32][wlut 4096 f32][per wave: BM_WAVE_ACC (+ BM_WAVE_CNT) bytes, ss_common.h]
 constexpr int BM_LUT_BYTES = (256 + 4096) * 4;
+constexpr int BM_RSRC_FLAGS = 0x00020000;  // raw buffer descriptor word 3: 32-bit data format
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct BmParams {
   const uint32_t* post;
@@ -143,5 +145,127 @@ __device__ __attribute__((noinline)) u64 topk_offer(u64 (&keys)[KPL], u64 k0, u6
 }
 
 
-// NT-specialised scan kernels (bm25_fast.hip); returns SS_ENOTSUP if there is no instantiation for (nt_max, KPL)
-int ssi_bm25_launch_fast(const BmParams& p, uint32_t nt_max, bool has_and, int KPL, hipStream_t st);
+// ---------------------------------------------------------------- LDS access by byte offset
+// (integer offsets instead of pointers: the compiler folds the constant part into the DS instruction's offset field
+// and needs no address arithmetic on a generic pointer)
+typedef __attribute__((address_space(3))) float bm_lds_f32;
+typedef __attribute__((address_space(3))) uint32_t bm_lds_u32;
+typedef __attribute__((address_space(3))) uint8_t bm_lds_u8;
+typedef __attribute__((address_space(3))) f32x4 bm_lds_f32x4;
+__device__ __forceinline__ float lds_ldf(uint32_t off) { return *(bm_lds_f32*)(uintptr_t)off; }
+__device__ __forceinline__ void lds_stf(uint32_t off, float v) { *(bm_lds_f32*)(uintptr_t)off = v; }
+__device__ __forceinline__ uint32_t lds_ld32(uint32_t off) { return *(bm_lds_u32*)(uintptr_t)off; }
+__device__ __forceinline__ void lds_st32(uint32_t off, uint32_t v) { *(bm_lds_u32*)(uintptr_t)off = v; }
+__device__ __forceinline__ uint32_t lds_ld8(uint32_t off) { return *(bm_lds_u8*)(uintptr_t)off; }
+__device__ __forceinline__ void lds_st8(uint32_t off, uint32_t v) { *(bm_lds_u8*)(uintptr_t)off = (uint8_t)v; }
+__device__ __forceinline__ f32x4 lds_ldf4(uint32_t off) { return *(bm_lds_f32x4*)(uintptr_t)off; }
+__device__ __forceinline__ void lds_stf4(uint32_t off, f32x4 v) { *(bm_lds_f32x4*)(uintptr_t)off = v; }
+
+// Per-wave LDS addresses (bytes): accb + 4*field (field 0 = dump), tile = accb + 4 (16-byte aligned), match counters
+// cnt + field (AND only), lut = weight table base.
+struct BmLds {
+  uint32_t lut, comp, accb, tile, cnt, cntw;
+};
+
+// tf >= 16 lies outside the weight table: tf*(K+1)/(tf + comp[len]) computed directly (rare, kept out of line)
+__device__ __attribute__((noinline)) f32x4 bm_big_tf_weights(u32x4 pv, f32x4 wp, uint32_t comp_off) {
+#pragma unroll
+  for (int x = 0; x < 4; x++) {
+    if (pv[x] & BM_BIG_TF_MASK) {
+      const float tf = (float)bm_tf(pv[x]);
+      wp[x] = tf * BM_K1P * __builtin_amdgcn_rcpf(tf + lds_ldf(comp_off + bm_len(pv[x]) * 4u));
+    }
+  }
+  return wp;
+}
+
+// One 256-posting chunk (4 per lane) of ONE term: acc[doc] += idf * wlut[tf,len]   (add_result.rs:1445-1447).
+// Plain gather / scatter: the docs of one term are distinct and the tile is private to the wave, whose LDS operations
+// execute in order.  NULL postings (padding, out-of-range lanes) add 0 to the dump slot.  Returns max of the new scores.
+template <bool HAS_AND>
+__device__ __forceinline__ float bm_chunk(const u32x4 q, float idf, const BmLds& L, bool is_and, float mx) {
+  const uint32_t pv[4] = {q.x, q.y, q.z, q.w};
+  uint32_t ao[4], co[4], cold[4];
+  float old[4], wp[4];
+#pragma unroll
+  for (int x = 0; x < 4; x++) {
+    ao[x] = (pv[x] & 0x7FFCu) + L.accb;
+    old[x] = lds_ldf(ao[x]);
+    wp[x] = lds_ldf(((pv[x] >> 16) & 0x3FFCu) + L.lut);
+    if (HAS_AND && is_and) {
+      co[x] = ((pv[x] & 0x7FFCu) >> 2) + L.cnt;
+      cold[x] = lds_ld8(co[x]);
+    }
+  }
+  if (__ballot(((pv[0] | pv[1]) | (pv[2] | pv[3])) & BM_BIG_TF_MASK)) {  // some tf >= 16 (rare)
+    const f32x4 fx = bm_big_tf_weights(q, f32x4{wp[0], wp[1], wp[2], wp[3]}, L.comp);
+    wp[0] = fx.x; wp[1] = fx.y; wp[2] = fx.z; wp[3] = fx.w;
+  }
+#pragma unroll
+  for (int x = 0; x < 4; x++) {
+    const float nw = old[x] + idf * wp[x];
+    lds_stf(ao[x], nw);
+    mx = fmaxf(mx, nw);
+    if (HAS_AND && is_and) lds_st8(co[x], cold[x] + 1u);
+  }
+  return mx;
+}
+
+template <bool HAS_AND>
+__device__ __forceinline__ void bm_clear_tile(const BmLds& L, bool is_and, int lane) {
+#pragma unroll
+  for (int i = 0; i < BM_SUB / 256; i++) {
+    lds_stf4(L.tile + (i * 64 + lane) * 16, f32x4{0.f, 0.f, 0.f, 0.f});
+    if (HAS_AND && is_and) lds_st32(L.cntw + (i * 64 + lane) * 4, 0u);
+  }
+}
+
+// dense scan of the tile (only when some doc may enter the list, or exact counts are wanted): clears it, counts
+// matches (union: any term, intersection: all terms) and offers survivors to the wave-resident top-k
+template <bool HAS_AND, int KPL>
+__device__ __forceinline__ void bm_scan_tile(const BmLds& L, bool is_and, uint32_t nt, int lane, uint32_t doc_base,
+                                             bool count_mode, uint32_t k, u64 (&topk)[KPL], u64& worst, float& wsc,
+                                             u64& matched) {
+#pragma unroll 2
+  for (int i = 0; i < BM_SUB / 256; i++) {
+    const int slot = i * 64 + lane;
+    f32x4 x = lds_ldf4(L.tile + slot * 16);
+    lds_stf4(L.tile + slot * 16, f32x4{0.f, 0.f, 0.f, 0.f});
+    bool h0 = x.x != 0.f, h1 = x.y != 0.f, h2 = x.z != 0.f, h3 = x.w != 0.f;
+    if (HAS_AND && is_and) {
+      const uint32_t cw = lds_ld32(L.cntw + slot * 4);
+      lds_st32(L.cntw + slot * 4, 0u);
+      h0 = (cw & 0xFFu) == nt;
+      h1 = ((cw >> 8) & 0xFFu) == nt;
+      h2 = ((cw >> 16) & 0xFFu) == nt;
+      h3 = (cw >> 24) == nt;
+      if (!h0) x.x = 0.f;
+      if (!h1) x.y = 0.f;
+      if (!h2) x.z = 0.f;
+      if (!h3) x.w = 0.f;
+    }
+    if (count_mode)
+      matched += __popcll(__ballot(h0)) + __popcll(__ballot(h1)) + __popcll(__ballot(h2)) + __popcll(__ballot(h3));
+    if (k) {
+      const float m = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
+      if (__ballot(m > 0.f && m >= wsc)) {
+        const uint32_t d0 = doc_base + slot * 4;
+        u64 k0 = ((u64)__float_as_uint(x.x) << 32) | (u64)(0xFFFFFFFFu - d0);
+        u64 k1 = ((u64)__float_as_uint(x.y) << 32) | (u64)(0xFFFFFFFFu - (d0 + 1));
+        u64 k2 = ((u64)__float_as_uint(x.z) << 32) | (u64)(0xFFFFFFFFu - (d0 + 2));
+        u64 k3 = ((u64)__float_as_uint(x.w) << 32) | (u64)(0xFFFFFFFFu - (d0 + 3));
+        k0 = (x.x > 0.f && k0 > worst) ? k0 : 0ull;
+        k1 = (x.y > 0.f && k1 > worst) ? k1 : 0ull;
+        k2 = (x.z > 0.f && k2 > worst) ? k2 : 0ull;
+        k3 = (x.w > 0.f && k3 > worst) ? k3 : 0ull;
+        if (__ballot((k0 | k1 | k2 | k3) != 0ull)) {
+          worst = topk_offer<KPL>(topk, k0, k1, k2, k3, worst, k);
+          if (worst) wsc = __uint_as_float((uint32_t)(worst >> 32));
+        }
+      }
+    }
+  }
+}
+
+// scan kernels (bm25_fast.hip): NT-specialised for <= 4 terms and k <= 128, grouped generic kernel otherwise
+int ssi_bm25_launch_scan(const BmParams& p, uint32_t nt_max, bool has_and, int KPL, hipStream_t st);

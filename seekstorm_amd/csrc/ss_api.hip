@@ -65,7 +65,7 @@ static void free_bm25(ss_shard* s) {
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->d_post = nullptr; s->d_term_base = nullptr; s->d_sub_off = nullptr; s->d_comp = nullptr;
   s->bm_n_docs = 0; s->bm_n_terms = 0; s->bm_n_sub = 0; s->bm_n_post = 0;
-  s->h_term_base.clear();
+  s->h_df.clear(); s->bm_n_post_pad = 0;
 }
 
 int ss_shard_destroy(ss_shard* s) {
@@ -163,7 +163,7 @@ int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df
   if (!s->d_post) return SS_ESTATE;
   for (uint32_t i = 0; i < n; i++) {
     if (terms[i] >= s->bm_n_terms) return SS_EINVAL;
-    df_out[i] = s->h_term_base[terms[i] + 1] - s->h_term_base[terms[i]];
+    df_out[i] = s->h_df[terms[i]];
   }
   return SS_OK;
 }

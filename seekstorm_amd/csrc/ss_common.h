@@ -26,11 +26,26 @@ constexpr int BM_SUB_LOG2 = 12;             // docs per sub-block = 4096 = one w
 constexpr int BM_SUB = 1 << BM_SUB_LOG2;
 constexpr int BM_WAVES_OR = 8 << (12 - BM_SUB_LOG2);   // waves per workgroup (one workgroup per CU), union-only kernels
 constexpr int BM_WAVES_AND = 6 << (12 - BM_SUB_LOG2);  // kernels that also carry match counters
-constexpr uint32_t BM_TF_MAX = 2046;        // 11-bit tf field, 2047 reserved
-// packed posting: bits 0..12 doc-in-sub-block (13 bits), 13..20 SmallFloat length byte, 21..31 tf
+constexpr uint32_t BM_TF_MAX = 511;         // 9-bit tf field
+// Packed posting (one dword).  Laid out so that the two LDS byte offsets the scan needs are single AND / shift+AND
+// extractions and everything else rides in the bits they mask off:
+//   bits  2..14  doc field = doc-in-sub-block + 1 (1..4096)            -> p & 0x7FFC        = 4 * field (accumulator)
+//   bits 18..25  SmallFloat length byte, bits 26..29 tf & 15           -> (p >> 16) & 0x3FFC = 4 * ((tf & 15) << 8 | len)
+//   bit 15, bits 16..17, bits 30..31 = tf bits 4, 5..6, 7..8 (non-zero only when tf >= 16: weight computed, not looked up)
+// The all-zero dword is the NULL posting (segment padding, and what an out-of-range buffer load returns): its doc
+// field addresses the dump slot in front of a wave's accumulator tile and its table weight (tf = 0) is 0.
+constexpr uint32_t BM_BIG_TF_MASK = 0xC0038000u;
 __host__ __device__ inline uint32_t bm_pack(uint32_t doc_in_sub, uint32_t len_byte, uint32_t tf) {
-  return (doc_in_sub & 0x1FFFu) | ((len_byte & 0xFFu) << 13) | (tf << 21);
+  return (((doc_in_sub + 1u) & 0x1FFFu) << 2) | (((tf >> 4) & 1u) << 15) | (((tf >> 5) & 3u) << 16) |
+         ((len_byte & 0xFFu) << 18) | ((tf & 15u) << 26) | (((tf >> 7) & 3u) << 30);
 }
+__host__ __device__ inline uint32_t bm_tf(uint32_t p) {
+  return ((p >> 26) & 15u) | (((p >> 15) & 1u) << 4) | (((p >> 16) & 3u) << 5) | ((p >> 30) << 7);
+}
+__host__ __device__ inline uint32_t bm_len(uint32_t p) { return (p >> 18) & 0xFFu; }
+// per-wave LDS: [12 B pad][dump f32][tile BM_SUB f32] (+ [3 B pad][dump u8][BM_SUB u8 match counters])
+constexpr int BM_WAVE_ACC = 16 + BM_SUB * 4;
+constexpr int BM_WAVE_CNT = 16 + BM_SUB;  // counters of doc d at byte 4 + d; the dump counter at byte 3
 
 struct ss_prof {
   bool on = false;
@@ -63,11 +78,13 @@ struct ss_shard {
   uint32_t bm_n_terms = 0, bm_n_sub = 0;
   uint64_t bm_n_post = 0;
   float bm_avgdl = 0.f;
-  uint32_t* d_post = nullptr;     // packed postings, ordered (term, doc)
-  uint64_t* d_term_base = nullptr; // [n_terms+1] first posting of each term
-  uint32_t* d_sub_off = nullptr;   // [n_terms][n_sub+1] offsets relative to term base
-  float* d_comp = nullptr;         // bm25_component_cache[256]
-  std::vector<uint64_t> h_term_base;
+  uint64_t bm_n_post_pad = 0;     // dwords in d_post (segments padded to 16 bytes)
+  uint32_t* d_post = nullptr;     // packed postings, ordered (term, sub-block, doc); every (term, sub-block) segment
+                                  // starts 16-byte aligned and is zero-padded (NULL postings) to a multiple of 16 bytes
+  uint64_t* d_term_base = nullptr; // [n_terms+1] first 16-byte unit of each term
+  uint32_t* d_sub_off = nullptr;   // [n_terms][n_sub+1] segment boundaries in 16-byte units relative to the term base
+  float* d_comp = nullptr;         // bm25_component_cache[256] + wlut[4096]
+  std::vector<uint64_t> h_df;      // posting_count per term (the df the host needs for idf)
   // bm25 workspace
   void* d_bq = nullptr; size_t bq_cap = 0;       // staged queries
   uint64_t* d_part = nullptr; size_t part_cap = 0; // partition-local top-k keys

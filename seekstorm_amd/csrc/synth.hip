@@ -69,52 +69,75 @@ static void fill_comp(float avgdl, float* comp) {
 }
 constexpr int SS_COMP_N = 256 + 4096;
 
-static int alloc_image(ss_shard* s, u64 n_post) {
-  const size_t rows = (size_t)s->bm_n_terms * (s->bm_n_sub + 1);
-  SS_HIP(hipMalloc(&s->d_post, (n_post + 256) * sizeof(uint32_t)));
-  SS_HIP(hipMemset(s->d_post + n_post, 0, 256 * sizeof(uint32_t)));
-  SS_HIP(hipMalloc(&s->d_term_base, ((size_t)s->bm_n_terms + 1) * sizeof(u64)));
-  SS_HIP(hipMalloc(&s->d_sub_off, (rows ? rows : 1) * sizeof(uint32_t)));
-  SS_HIP(hipMalloc(&s->d_comp, SS_COMP_N * sizeof(float)));
+// segments are padded to 16 bytes; the image ends with 1 KB of NULL postings so that a whole-wave load of the last
+// unit never leaves the allocation
+static int alloc_post(ss_shard* s, u64 n_units) {
+  s->bm_n_post_pad = n_units * 4;
+  SS_HIP(hipMalloc(&s->d_post, (s->bm_n_post_pad + 256) * sizeof(uint32_t)));
+  SS_HIP(hipMemset(s->d_post + s->bm_n_post_pad, 0, 256 * sizeof(uint32_t)));
   return SS_OK;
 }
 
 int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t* offs, const uint32_t* docs,
                              const uint16_t* tfs) {
   const uint32_t nt = s->bm_n_terms, ns = s->bm_n_sub;
-  const u64 n_post = offs[nt];
   u64 psum = 0;
   for (u64 d = 0; d < s->bm_n_docs; d++) psum += ss_byte4_to_int(doclen[d]);
   s->bm_avgdl = (float)psum / (float)s->bm_n_docs;  // commit.rs:318-319
   float comp[SS_COMP_N];
   fill_comp(s->bm_avgdl, comp);
-  std::vector<uint32_t> post(n_post ? n_post : 1);
+  // pass 1: validate, segment boundaries in 16-byte units (4 postings, zero padded) relative to the term base
   std::vector<uint32_t> sub((size_t)nt * (ns + 1));
+  std::vector<u64> tbase((size_t)nt + 1);
+  s->h_df.assign(nt, 0);
+  u64 units = 0;
   for (uint32_t t = 0; t < nt; t++) {
+    if (offs[t + 1] < offs[t]) return SS_EINVAL;
+    tbase[t] = units;
+    s->h_df[t] = offs[t + 1] - offs[t];
     uint32_t* row = sub.data() + (size_t)t * (ns + 1);
-    u64 i = offs[t];
-    for (uint32_t sb = 0; sb <= ns; sb++) {
-      u64 lim = (u64)sb << BM_SUB_LOG2;
+    u64 i = offs[t], u = 0;
+    for (uint32_t sb = 0; sb < ns; sb++) {
+      row[sb] = (uint32_t)u;
+      const u64 lim = ((u64)sb + 1) << BM_SUB_LOG2;
+      const u64 i0 = i;
       while (i < offs[t + 1] && docs[i] < lim) i++;
-      if (i - offs[t] > 0xFFFFFFFFull) return SS_ENOTSUP;
-      row[sb] = (uint32_t)(i - offs[t]);
+      u += (i - i0 + 3) >> 2;
+      if (u >= (1ull << 28)) return SS_ENOTSUP;  // a term's segment offsets must stay below 4 GB
     }
-    for (u64 j = offs[t]; j < offs[t + 1]; j++) {
-      if (docs[j] >= s->bm_n_docs) return SS_EINVAL;
-      if (j > offs[t] && docs[j] <= docs[j - 1]) return SS_EINVAL;
-      if (tfs[j] == 0) return SS_EINVAL;
-      if (tfs[j] > BM_TF_MAX) return SS_ENOTSUP;
-      post[j] = bm_pack(docs[j] & (BM_SUB - 1), doclen[docs[j]], tfs[j]);
+    row[ns] = (uint32_t)u;
+    if (i != offs[t + 1]) return SS_EINVAL;  // doc id >= n_docs
+    units += u;
+  }
+  tbase[nt] = units;
+  std::vector<uint32_t> post(units ? units * 4 : 4, 0u);
+  for (uint32_t t = 0; t < nt; t++) {
+    const uint32_t* row = sub.data() + (size_t)t * (ns + 1);
+    u64 j = offs[t];
+    for (uint32_t sb = 0; sb < ns; sb++) {
+      const u64 lim = ((u64)sb + 1) << BM_SUB_LOG2;
+      u64 w = (tbase[t] + row[sb]) * 4;
+      for (; j < offs[t + 1] && docs[j] < lim; j++, w++) {
+        if (docs[j] >= s->bm_n_docs) return SS_EINVAL;
+        if (j > offs[t] && docs[j] <= docs[j - 1]) return SS_EINVAL;
+        if (tfs[j] == 0) return SS_EINVAL;
+        if (tfs[j] > BM_TF_MAX) return SS_ENOTSUP;
+        post[w] = bm_pack(docs[j] & (BM_SUB - 1), doclen[docs[j]], tfs[j]);
+      }
     }
   }
-  s->bm_n_post = n_post;
-  int rc = alloc_image(s, n_post);
+  s->bm_n_post = offs[nt];
+  const size_t rows = (size_t)nt * (ns + 1);
+  int rc = alloc_post(s, units);
   if (rc) return rc;
-  SS_HIP(hipMemcpy(s->d_post, post.data(), n_post * sizeof(uint32_t), hipMemcpyHostToDevice));
-  SS_HIP(hipMemcpy(s->d_term_base, offs, ((size_t)nt + 1) * sizeof(u64), hipMemcpyHostToDevice));
+  SS_HIP(hipMalloc(&s->d_term_base, ((size_t)nt + 1) * sizeof(u64)));
+  SS_HIP(hipMalloc(&s->d_sub_off, (rows + ns + 1) * sizeof(uint32_t)));  // + one all-zero row (absent terms)
+  SS_HIP(hipMemset(s->d_sub_off + rows, 0, ((size_t)ns + 1) * sizeof(uint32_t)));
+  SS_HIP(hipMalloc(&s->d_comp, SS_COMP_N * sizeof(float)));
+  if (units) SS_HIP(hipMemcpy(s->d_post, post.data(), units * 4 * sizeof(uint32_t), hipMemcpyHostToDevice));
+  SS_HIP(hipMemcpy(s->d_term_base, tbase.data(), ((size_t)nt + 1) * sizeof(u64), hipMemcpyHostToDevice));
   SS_HIP(hipMemcpy(s->d_sub_off, sub.data(), sub.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   SS_HIP(hipMemcpy(s->d_comp, comp, sizeof(comp), hipMemcpyHostToDevice));
-  s->h_term_base.assign(offs, offs + nt + 1);
   return SS_OK;
 }
 
@@ -132,11 +155,12 @@ __global__ void lex_doclen_kernel(uint8_t* __restrict__ doclen, u64 seed, u64 n_
   if ((threadIdx.x & 63) == 0 && v) atomicAdd(psum, v);
 }
 
-// one wave per (term, sub-block): count / fill postings in ascending doc order
+// one wave per (term, sub-block): count / fill postings in ascending doc order.
+// !FILL: sub[t][sb+1] = padded units (for the exclusive scan), cnt[t] += postings.  FILL: postings + zero padding.
 template <bool FILL>
 __global__ void lex_gen_kernel(u64 seed, u64 n_docs, uint32_t n_terms, uint32_t n_sub, const uint32_t* __restrict__ thresh,
-                               const uint8_t* __restrict__ doclen, uint32_t* __restrict__ sub_cnt /*[nt][ns+1]*/,
-                               const u64* __restrict__ term_base, uint32_t* __restrict__ post) {
+                               const uint8_t* __restrict__ doclen, uint32_t* __restrict__ sub /*[nt][ns+1]*/,
+                               const u64* __restrict__ term_base, uint32_t* __restrict__ post, u64* __restrict__ df) {
   const int lane = threadIdx.x & 63;
   const u64 gw = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const u64 total = (u64)n_terms * n_sub;
@@ -146,7 +170,7 @@ __global__ void lex_gen_kernel(u64 seed, u64 n_docs, uint32_t n_terms, uint32_t 
   const u64 d0 = (u64)sb << BM_SUB_LOG2;
   uint32_t run = 0;
   u64 base = 0;
-  if (FILL) base = term_base[t] + sub_cnt[(size_t)t * (n_sub + 1) + sb];
+  if (FILL) base = (term_base[t] + sub[(size_t)t * (n_sub + 1) + sb]) * 4;
   for (int i = 0; i < BM_SUB / 64; i++) {
     u64 d = d0 + (u64)i * 64 + lane;
     u64 hv = ss_h(seed, (u64)t + 1, d);
@@ -160,7 +184,12 @@ __global__ void lex_gen_kernel(u64 seed, u64 n_docs, uint32_t n_terms, uint32_t 
     }
     run += __popcll(m);
   }
-  if (!FILL && lane == 0) sub_cnt[(size_t)t * (n_sub + 1) + sb + 1] = run;  // shifted by one for the exclusive scan
+  if (FILL) {
+    if ((uint32_t)lane < ((4u - (run & 3u)) & 3u)) post[base + run + lane] = 0u;  // NULL padding
+  } else if (lane == 0) {
+    sub[(size_t)t * (n_sub + 1) + sb + 1] = (run + 3u) >> 2;  // shifted by one for the exclusive scan
+    if (run) atomicAdd(&df[t], (u64)run);
+  }
 }
 
 // per term: in-place inclusive scan of row[1..ns] (row[0] = 0) -> exclusive offsets; writes the term total
@@ -206,38 +235,50 @@ int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const u
   uint8_t* d_doclen = nullptr;
   u64* d_psum = nullptr;
   u64* d_tot = nullptr;
+  u64* d_df = nullptr;
   SS_HIP(hipMalloc(&d_doclen, nd));
   SS_HIP(hipMalloc(&d_psum, sizeof(u64)));
   SS_HIP(hipMalloc(&d_tot, (size_t)nt * sizeof(u64)));
+  SS_HIP(hipMalloc(&d_df, (size_t)nt * sizeof(u64)));
   SS_HIP(hipMemsetAsync(d_psum, 0, sizeof(u64), st));
+  SS_HIP(hipMemsetAsync(d_df, 0, (size_t)nt * sizeof(u64), st));
   lex_doclen_kernel<<<(uint32_t)((nd + 255) / 256), 256, 0, st>>>(d_doclen, seed, nd, d_lentab, d_psum);
   const size_t rows = (size_t)nt * (ns + 1);
-  SS_HIP(hipMalloc(&s->d_sub_off, rows * sizeof(uint32_t)));
+  SS_HIP(hipMalloc(&s->d_sub_off, (rows + ns + 1) * sizeof(uint32_t)));  // + one all-zero row (absent terms)
+  SS_HIP(hipMemsetAsync(s->d_sub_off + rows, 0, ((size_t)ns + 1) * sizeof(uint32_t), st));
   SS_HIP(hipMalloc(&s->d_term_base, ((size_t)nt + 1) * sizeof(u64)));
   SS_HIP(hipMalloc(&s->d_comp, SS_COMP_N * sizeof(float)));
   const u64 waves = (u64)nt * ns;
   const uint32_t grid = (uint32_t)((waves + 3) / 4);
-  lex_gen_kernel<false><<<grid, 256, 0, st>>>(seed, nd, nt, ns, d_thresh, d_doclen, s->d_sub_off, nullptr, nullptr);
+  lex_gen_kernel<false><<<grid, 256, 0, st>>>(seed, nd, nt, ns, d_thresh, d_doclen, s->d_sub_off, nullptr, nullptr, d_df);
   lex_scan_rows_kernel<<<nt, 1024, 0, st>>>(s->d_sub_off, ns, d_tot);
   lex_scan_terms_kernel<<<1, 64, 0, st>>>(d_tot, (u64*)s->d_term_base, nt);
   SS_HIP(hipStreamSynchronize(st));
-  s->h_term_base.resize((size_t)nt + 1);
-  SS_HIP(hipMemcpy(s->h_term_base.data(), s->d_term_base, ((size_t)nt + 1) * sizeof(u64), hipMemcpyDeviceToHost));
-  u64 psum = 0;
+  std::vector<u64> tot(nt);
+  s->h_df.resize(nt);
+  SS_HIP(hipMemcpy(tot.data(), d_tot, (size_t)nt * sizeof(u64), hipMemcpyDeviceToHost));
+  SS_HIP(hipMemcpy(s->h_df.data(), d_df, (size_t)nt * sizeof(u64), hipMemcpyDeviceToHost));
+  u64 units = 0, psum = 0, npost = 0;
+  for (uint32_t t = 0; t < nt; t++) {
+    if (tot[t] >= (1ull << 28)) return SS_ENOTSUP;  // a term's segment offsets must stay below 4 GB
+    units += tot[t];
+    npost += s->h_df[t];
+  }
   SS_HIP(hipMemcpy(&psum, d_psum, sizeof(u64), hipMemcpyDeviceToHost));
-  s->bm_n_post = s->h_term_base[nt];
+  s->bm_n_post = npost;
   s->bm_avgdl = (float)psum / (float)nd;
   float comp[SS_COMP_N];
   fill_comp(s->bm_avgdl, comp);
   SS_HIP(hipMemcpy(s->d_comp, comp, sizeof(comp), hipMemcpyHostToDevice));
-  SS_HIP(hipMalloc(&s->d_post, (s->bm_n_post + 256) * sizeof(uint32_t)));
-  SS_HIP(hipMemsetAsync(s->d_post + s->bm_n_post, 0, 256 * sizeof(uint32_t), st));
+  int rc = alloc_post(s, units);
+  if (rc) return rc;
   lex_gen_kernel<true><<<grid, 256, 0, st>>>(seed, nd, nt, ns, d_thresh, d_doclen, s->d_sub_off,
-                                             (const u64*)s->d_term_base, s->d_post);
+                                             (const u64*)s->d_term_base, s->d_post, nullptr);
   SS_HIP(hipStreamSynchronize(st));
   (void)hipFree(d_doclen);
   (void)hipFree(d_psum);
   (void)hipFree(d_tot);
+  (void)hipFree(d_df);
   SS_HIP(hipGetLastError());
   return SS_OK;
 }
