@@ -115,7 +115,7 @@ __device__ __forceinline__ u64 topk_merge64(u64 (&keys)[KPL], u64 nk, uint32_t k
 }
 // offer up to 4 candidate keys per lane (0 = none); returns the new admission threshold
 template <int KPL>
-__device__ __attribute__((noinline)) u64 topk_offer(u64 (&keys)[KPL], u64 k0, u64 k1, u64 k2, u64 k3, u64 worst,
+__device__ __forceinline__ u64 topk_offer(u64 (&keys)[KPL], u64 k0, u64 k1, u64 k2, u64 k3, u64 worst,
                                                     uint32_t k) {
   const int lane = __lane_id();
   for (;;) {
@@ -220,51 +220,64 @@ __device__ __forceinline__ void bm_clear_tile(const BmLds& L, bool is_and, int l
   }
 }
 
-// dense scan of the tile (only when some doc may enter the list, or exact counts are wanted): clears it, counts
-// matches (union: any term, intersection: all terms) and offers survivors to the wave-resident top-k
+// Wave-resident result state of one (query, partition) assignment
+template <int KPL>
+struct BmTop {
+  u64 keys[KPL];   // sorted top-k, rank r*64+lane in keys[r]
+  u64 worst;       // key at rank k-1 (0 while the list is not full)
+  float wsc;       // its score (-1 while not full): the trigger threshold of the item loop
+  u64 matched;     // exact match count (Count / TopkCount)
+};
+
+// Dense scan of the tile (only when some doc may enter the list, or exact counts are wanted): clears it, counts
+// matches (union: any term, intersection: all terms) and offers survivors to the wave-resident top-k.  Kept OUT OF
+// LINE: its ballots / lane loops need many scalar registers, and inlined into the item loop they push the loop's own
+// scalar state (descriptors, boundaries) into spill lanes.  State crosses the call in registers (by value).
 template <bool HAS_AND, int KPL>
-__device__ __forceinline__ void bm_scan_tile(const BmLds& L, bool is_and, uint32_t nt, int lane, uint32_t doc_base,
-                                             bool count_mode, uint32_t k, u64 (&topk)[KPL], u64& worst, float& wsc,
-                                             u64& matched) {
+__device__ __attribute__((noinline)) BmTop<KPL> bm_scan_tile(BmTop<KPL> T, uint32_t tile, uint32_t cntw, uint32_t nt_and,
+                                                             uint32_t doc_base, uint32_t count_mode, uint32_t k) {
+  const int lane = __lane_id();
+  const bool is_and = HAS_AND && nt_and != 0;  // nt_and = number of terms of an intersection, 0 for a union
 #pragma unroll 2
   for (int i = 0; i < BM_SUB / 256; i++) {
     const int slot = i * 64 + lane;
-    f32x4 x = lds_ldf4(L.tile + slot * 16);
-    lds_stf4(L.tile + slot * 16, f32x4{0.f, 0.f, 0.f, 0.f});
+    f32x4 x = lds_ldf4(tile + slot * 16);
+    lds_stf4(tile + slot * 16, f32x4{0.f, 0.f, 0.f, 0.f});
     bool h0 = x.x != 0.f, h1 = x.y != 0.f, h2 = x.z != 0.f, h3 = x.w != 0.f;
     if (HAS_AND && is_and) {
-      const uint32_t cw = lds_ld32(L.cntw + slot * 4);
-      lds_st32(L.cntw + slot * 4, 0u);
-      h0 = (cw & 0xFFu) == nt;
-      h1 = ((cw >> 8) & 0xFFu) == nt;
-      h2 = ((cw >> 16) & 0xFFu) == nt;
-      h3 = (cw >> 24) == nt;
+      const uint32_t cw = lds_ld32(cntw + slot * 4);
+      lds_st32(cntw + slot * 4, 0u);
+      h0 = (cw & 0xFFu) == nt_and;
+      h1 = ((cw >> 8) & 0xFFu) == nt_and;
+      h2 = ((cw >> 16) & 0xFFu) == nt_and;
+      h3 = (cw >> 24) == nt_and;
       if (!h0) x.x = 0.f;
       if (!h1) x.y = 0.f;
       if (!h2) x.z = 0.f;
       if (!h3) x.w = 0.f;
     }
     if (count_mode)
-      matched += __popcll(__ballot(h0)) + __popcll(__ballot(h1)) + __popcll(__ballot(h2)) + __popcll(__ballot(h3));
+      T.matched += __popcll(__ballot(h0)) + __popcll(__ballot(h1)) + __popcll(__ballot(h2)) + __popcll(__ballot(h3));
     if (k) {
       const float m = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
-      if (__ballot(m > 0.f && m >= wsc)) {
+      if (__ballot(m > 0.f && m >= T.wsc)) {
         const uint32_t d0 = doc_base + slot * 4;
         u64 k0 = ((u64)__float_as_uint(x.x) << 32) | (u64)(0xFFFFFFFFu - d0);
         u64 k1 = ((u64)__float_as_uint(x.y) << 32) | (u64)(0xFFFFFFFFu - (d0 + 1));
         u64 k2 = ((u64)__float_as_uint(x.z) << 32) | (u64)(0xFFFFFFFFu - (d0 + 2));
         u64 k3 = ((u64)__float_as_uint(x.w) << 32) | (u64)(0xFFFFFFFFu - (d0 + 3));
-        k0 = (x.x > 0.f && k0 > worst) ? k0 : 0ull;
-        k1 = (x.y > 0.f && k1 > worst) ? k1 : 0ull;
-        k2 = (x.z > 0.f && k2 > worst) ? k2 : 0ull;
-        k3 = (x.w > 0.f && k3 > worst) ? k3 : 0ull;
+        k0 = (x.x > 0.f && k0 > T.worst) ? k0 : 0ull;
+        k1 = (x.y > 0.f && k1 > T.worst) ? k1 : 0ull;
+        k2 = (x.z > 0.f && k2 > T.worst) ? k2 : 0ull;
+        k3 = (x.w > 0.f && k3 > T.worst) ? k3 : 0ull;
         if (__ballot((k0 | k1 | k2 | k3) != 0ull)) {
-          worst = topk_offer<KPL>(topk, k0, k1, k2, k3, worst, k);
-          if (worst) wsc = __uint_as_float((uint32_t)(worst >> 32));
+          T.worst = topk_offer<KPL>(T.keys, k0, k1, k2, k3, T.worst, k);
+          if (T.worst) T.wsc = __uint_as_float((uint32_t)(T.worst >> 32));
         }
       }
     }
   }
+  return T;
 }
 
 // scan kernels (bm25_fast.hip): NT-specialised for <= 4 terms and k <= 128, grouped generic kernel otherwise

@@ -65,52 +65,52 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
     const ss_bm25_query* __restrict__ Q = qs + qi;
     const uint32_t nt = Q->n_terms;
     const bool is_and = HAS_AND && (Q->op == SS_OP_INTERSECTION) && nt > 1;
-    // per-term scalars; terms >= nt use the all-zero row n_terms of sub_off: their segments have zero length
-    uint32_t row[NT];
+    // Per-term state in scalar registers: descriptor base, idf and a rolling window of three segment boundaries.
+    // The boundaries themselves are fetched 64 at a time into vector registers (lane i = sub-block s0 + i, one
+    // coalesced load per term every BLK items) and picked with v_readlane, so the item loop carries no scalar loads,
+    // no 64-bit address arithmetic and no pending boundary load across its back edge.  Terms >= nt use the all-zero
+    // row n_terms of sub_off: their segments have zero length.
+    constexpr uint32_t BLK = 62;  // items per boundary block: item i needs boundaries i, i+1 and (for the prefetch) i+2
     const uint32_t* tptr[NT];
+    const uint32_t* rowp[NT];
     float idf[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) {
       const bool have = (uint32_t)t < nt;
       const uint32_t term = have ? Q->term[t] : n_terms;
       idf[t] = have ? Q->idf[t] : 0.f;
-      row[t] = term * row_len;
       tptr[t] = post + term_base[term] * 4ull;
+      rowp[t] = sub_off + (size_t)term * row_len;
     }
     const uint32_t s_begin = (uint32_t)(((u64)n_sub * part) / P);
     const uint32_t s_end = (uint32_t)(((u64)n_sub * (part + 1)) / P);
 
-    u64 topk[KPL];
+    BmTop<KPL> T;
 #pragma unroll
-    for (int r = 0; r < KPL; r++) topk[r] = 0ull;
-    u64 worst = 0ull;
-    float wsc = -1.0f;  // score of the current k-th best (-1 while the list is not full): trigger threshold
-    u64 matched = 0;
-
-    // segment boundaries, 16-byte units relative to the term base; uniform address -> scalar load
-    auto bnd = [&](int t, uint32_t j) -> uint32_t { return sub_off[row[t] + (j < s_end ? j : s_end)]; };
+    for (int r = 0; r < KPL; r++) T.keys[r] = 0ull;
+    T.worst = 0ull;
+    T.wsc = -1.0f;
+    T.matched = 0;
+    const uint32_t nt_and = is_and ? nt : 0u;
 
     // RC loads per item; lanes (and whole chunks) past the segment end are out of range: zeros, no memory access
     auto issue_loads = [&](u32x4(&v)[RC], const uint32_t (&b0)[NT], const uint32_t (&b1)[NT]) {
 #pragma unroll
       for (int t = 0; t < NT; t++) {
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[t], 0, (int)(b1[t] << 4), BM_RSRC_FLAGS);
-        const int soff = (int)(b0[t] << 4);
 #pragma unroll
-        for (int c = 0; c < CPT; c++) v[t * CPT + c] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + c * 1024, soff, 0);
+        for (int c = 0; c < CPT; c++)
+          v[t * CPT + c] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + c * 1024, (int)(b0[t] << 4), 0);
       }
     };
 
     u32x4 vA[RC], vB[RC];
     uint32_t B0[NT], B1[NT], B2[NT];
-#pragma unroll
-    for (int t = 0; t < NT; t++) { B0[t] = bnd(t, s_begin); B1[t] = bnd(t, s_begin + 1); B2[t] = bnd(t, s_begin + 2); }
-    issue_loads(vA, B0, B1);
+    uint32_t vbnd[NT];  // boundaries s0 .. s0+63 of term t, one per lane (indices past s_end clamp: empty items)
 
-    auto body = [&](u32x4(&cur)[RC], u32x4(&nxt)[RC], uint32_t s) {
-      uint32_t B3[NT];
+    auto body = [&](u32x4(&cur)[RC], u32x4(&nxt)[RC], uint32_t s, uint32_t i) {
 #pragma unroll
-      for (int t = 0; t < NT; t++) B3[t] = bnd(t, s + 3);
+      for (int t = 0; t < NT; t++) B2[t] = __builtin_amdgcn_readlane(vbnd[t], i + 2);
       issue_loads(nxt, B1, B2);
       uint32_t maxn = 0;
 #pragma unroll
@@ -134,24 +134,38 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
             }
           }
         }
-        if (count_mode || (k && __ballot(mx >= wsc)))
-          bm_scan_tile<HAS_AND, KPL>(L, is_and, nt, lane, s << BM_SUB_LOG2, count_mode, k, topk, worst, wsc, matched);
+        if (count_mode || (k && __ballot(mx >= T.wsc)))
+          T = bm_scan_tile<HAS_AND, KPL>(T, L.tile, L.cntw, nt_and, s << BM_SUB_LOG2, count_mode, k);
         else
           bm_clear_tile<HAS_AND>(L, is_and, lane);
       }
 #pragma unroll
-      for (int t = 0; t < NT; t++) { B0[t] = B1[t]; B1[t] = B2[t]; B2[t] = B3[t]; }
+      for (int t = 0; t < NT; t++) { B0[t] = B1[t]; B1[t] = B2[t]; }
     };
-    for (uint32_t s = s_begin; s < s_end; s += 2) {
-      body(vA, vB, s);
-      if (s + 1 < s_end) body(vB, vA, s + 1);
-      else break;
+
+    for (uint32_t s0 = s_begin; s0 < s_end; s0 += BLK) {
+      const uint32_t j = s0 + (uint32_t)lane;
+#pragma unroll
+      for (int t = 0; t < NT; t++) vbnd[t] = rowp[t][j < s_end ? j : s_end];
+      // re-derived in EVERY block (same values as the rolled ones): the first use of the freshly loaded boundary
+      // registers, and with it their vmcnt wait, sits here and not at the top of the item loop
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        B0[t] = __builtin_amdgcn_readlane(vbnd[t], 0);
+        B1[t] = __builtin_amdgcn_readlane(vbnd[t], 1);
+      }
+      if (s0 == s_begin) issue_loads(vA, B0, B1);
+      const uint32_t cnt = min(BLK, s_end - s0);  // BLK is even: every block starts on the vA buffer
+      for (uint32_t i = 0; i < cnt; i += 2) {
+        body(vA, vB, s0 + i, i);
+        if (i + 1 < cnt) body(vB, vA, s0 + i + 1, i + 1);
+      }
     }
 
     u64* out = part_keys + ((size_t)qi * P + part) * (64 * KPL);
 #pragma unroll
-    for (int r = 0; r < KPL; r++) out[r * 64 + lane] = topk[r];
-    if (lane == 0 && matched) atomicAdd(&total[qi], matched);
+    for (int r = 0; r < KPL; r++) out[r * 64 + lane] = T.keys[r];
+    if (lane == 0 && T.matched) atomicAdd(&total[qi], T.matched);
   }
 }
 
@@ -177,12 +191,13 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
     const bool is_and = HAS_AND && (Q->op == SS_OP_INTERSECTION) && nt > 1;
     const uint32_t s_begin = (uint32_t)(((u64)n_sub * part) / P);
     const uint32_t s_end = (uint32_t)(((u64)n_sub * (part + 1)) / P);
-    u64 topk[KPL];
+    BmTop<KPL> T;
 #pragma unroll
-    for (int r = 0; r < KPL; r++) topk[r] = 0ull;
-    u64 worst = 0ull;
-    float wsc = -1.0f;
-    u64 matched = 0;
+    for (int r = 0; r < KPL; r++) T.keys[r] = 0ull;
+    T.worst = 0ull;
+    T.wsc = -1.0f;
+    T.matched = 0;
+    const uint32_t nt_and = is_and ? nt : 0u;
 
     for (uint32_t s = s_begin; s < s_end; s++) {
       float mx = 0.f;
@@ -222,16 +237,16 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
         }
       }
       if (any) {
-        if (count_mode || (k && __ballot(mx >= wsc)))
-          bm_scan_tile<HAS_AND, KPL>(L, is_and, nt, lane, s << BM_SUB_LOG2, count_mode, k, topk, worst, wsc, matched);
+        if (count_mode || (k && __ballot(mx >= T.wsc)))
+          T = bm_scan_tile<HAS_AND, KPL>(T, L.tile, L.cntw, nt_and, s << BM_SUB_LOG2, count_mode, k);
         else
           bm_clear_tile<HAS_AND>(L, is_and, lane);
       }
     }
     u64* out = part_keys + ((size_t)qi * P + part) * (64 * KPL);
 #pragma unroll
-    for (int r = 0; r < KPL; r++) out[r * 64 + lane] = topk[r];
-    if (lane == 0 && matched) atomicAdd(&total[qi], matched);
+    for (int r = 0; r < KPL; r++) out[r * 64 + lane] = T.keys[r];
+    if (lane == 0 && T.matched) atomicAdd(&total[qi], T.matched);
   }
 }
 
