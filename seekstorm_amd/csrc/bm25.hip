@@ -79,7 +79,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   // partitions per query: enough assignments to load-balance ~2048 resident waves
   uint32_t P = (4u * 256u * BM_WAVES_OR + nq - 1) / nq;
   P = std::max<uint32_t>(1, std::min<uint32_t>(P, s->bm_n_sub));
-  const size_t need = (size_t)nq * P * KS * 2 + nq;  // two ping-pong merge buffers + totals
+  const size_t need = (size_t)nq * P * KS * 2 + nq + (nq + 1) / 2;  // two ping-pong merge buffers + totals + tau
   if (need > s->part_cap) {
     if (s->d_part) (void)hipFree(s->d_part);
     s->d_part = nullptr;
@@ -90,7 +90,8 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   u64* bufA = (u64*)s->d_part;
   u64* bufB = bufA + (size_t)nq * P * KS;
   u64* total = bufB + (size_t)nq * P * KS;
-  SS_HIP(hipMemsetAsync(total, 0, nq * sizeof(u64), st));
+  uint32_t* tau = (uint32_t*)(total + nq);
+  SS_HIP(hipMemsetAsync(total, 0, nq * sizeof(u64) + (size_t)((nq + 1) / 2) * sizeof(u64), st));
 
   BmParams p;
   p.post = s->d_post;
@@ -100,6 +101,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   p.q = d_q;
   p.part_keys = bufA;
   p.total = total;
+  p.tau = tau;
   p.n_sub = s->bm_n_sub;
   p.n_terms = s->bm_n_terms;
   p.nq = nq;

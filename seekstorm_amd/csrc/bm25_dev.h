@@ -17,6 +17,7 @@ struct BmParams {
   const ss_bm25_query* q;
   unsigned long long* part_keys;   // [nq][P][KS]
   unsigned long long* total;       // [nq] exact match counts
+  uint32_t* tau;                   // [nq] shared admission threshold: bits of the best k-th score any partition holds
   uint32_t n_sub, n_terms, nq, P, k, count;
 };
 
@@ -235,7 +236,11 @@ struct BmTop {
 // scalar state (descriptors, boundaries) into spill lanes.  State crosses the call in registers (by value).
 template <bool HAS_AND, int KPL>
 __device__ __attribute__((noinline)) BmTop<KPL> bm_scan_tile(BmTop<KPL> T, uint32_t tile, uint32_t cntw, uint32_t nt_and,
-                                                             uint32_t doc_base, uint32_t count_mode, uint32_t k) {
+                                                             uint32_t doc_base, uint32_t count_mode, uint32_t k, float thr,
+                                                             uint32_t* tau_q) {
+  // thr = max(own k-th best score, the k-th best score some other partition of the query already holds): a doc
+  // below it cannot be in the query's top-k.  Equal scores stay admissible (the final merge breaks ties by doc id).
+  const float wsc_in = T.wsc;
   const int lane = __lane_id();
   const bool is_and = HAS_AND && nt_and != 0;  // nt_and = number of terms of an intersection, 0 for a union
 #pragma unroll 2
@@ -260,23 +265,28 @@ __device__ __attribute__((noinline)) BmTop<KPL> bm_scan_tile(BmTop<KPL> T, uint3
       T.matched += __popcll(__ballot(h0)) + __popcll(__ballot(h1)) + __popcll(__ballot(h2)) + __popcll(__ballot(h3));
     if (k) {
       const float m = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
-      if (__ballot(m > 0.f && m >= T.wsc)) {
+      if (__ballot(m > 0.f && m >= thr)) {
         const uint32_t d0 = doc_base + slot * 4;
         u64 k0 = ((u64)__float_as_uint(x.x) << 32) | (u64)(0xFFFFFFFFu - d0);
         u64 k1 = ((u64)__float_as_uint(x.y) << 32) | (u64)(0xFFFFFFFFu - (d0 + 1));
         u64 k2 = ((u64)__float_as_uint(x.z) << 32) | (u64)(0xFFFFFFFFu - (d0 + 2));
         u64 k3 = ((u64)__float_as_uint(x.w) << 32) | (u64)(0xFFFFFFFFu - (d0 + 3));
-        k0 = (x.x > 0.f && k0 > T.worst) ? k0 : 0ull;
-        k1 = (x.y > 0.f && k1 > T.worst) ? k1 : 0ull;
-        k2 = (x.z > 0.f && k2 > T.worst) ? k2 : 0ull;
-        k3 = (x.w > 0.f && k3 > T.worst) ? k3 : 0ull;
+        k0 = (x.x > 0.f && x.x >= thr && k0 > T.worst) ? k0 : 0ull;
+        k1 = (x.y > 0.f && x.y >= thr && k1 > T.worst) ? k1 : 0ull;
+        k2 = (x.z > 0.f && x.z >= thr && k2 > T.worst) ? k2 : 0ull;
+        k3 = (x.w > 0.f && x.w >= thr && k3 > T.worst) ? k3 : 0ull;
         if (__ballot((k0 | k1 | k2 | k3) != 0ull)) {
           T.worst = topk_offer<KPL>(T.keys, k0, k1, k2, k3, T.worst, k);
-          if (T.worst) T.wsc = __uint_as_float((uint32_t)(T.worst >> 32));
+          if (T.worst) {
+            T.wsc = __uint_as_float((uint32_t)(T.worst >> 32));
+            thr = fmaxf(thr, T.wsc);
+          }
         }
       }
     }
   }
+  // publish a raised k-th best score (scores are positive floats: their bit patterns order like unsigned integers)
+  if (tau_q && T.wsc > wsc_in && lane == 0) atomicMax(tau_q, __float_as_uint(T.wsc));
   return T;
 }
 

@@ -21,7 +21,8 @@ template <int NT> struct FastCfg { static constexpr int CPT = NT <= 2 ? 4 : 3; s
 #define BM_KERNEL_ARGS                                                                                              \
   const uint32_t *__restrict__ post, const unsigned long long *__restrict__ term_base,                             \
       const uint32_t *__restrict__ sub_off, const float *__restrict__ comp_g, const ss_bm25_query *__restrict__ qs, \
-      unsigned long long *__restrict__ part_keys, unsigned long long *__restrict__ total, uint32_t n_sub,           \
+      unsigned long long *__restrict__ part_keys, unsigned long long *__restrict__ total, uint32_t *tau,            \
+      uint32_t n_sub,                                                                                               \
       uint32_t n_terms, uint32_t nq, uint32_t P, uint32_t k, uint32_t count
 
 template <bool HAS_AND>
@@ -108,7 +109,10 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
     uint32_t B0[NT], B1[NT], B2[NT];
     uint32_t vbnd[NT];  // boundaries s0 .. s0+63 of term t, one per lane (indices past s_end clamp: empty items)
 
+    uint32_t* tau_q = tau + qi;
     auto body = [&](u32x4(&cur)[RC], u32x4(&nxt)[RC], uint32_t s, uint32_t i) {
+      // the query's shared threshold, refreshed every item (issued ahead of the posting loads: in-order return)
+      const uint32_t tau_bits = __hip_atomic_load(tau_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
       for (int t = 0; t < NT; t++) B2[t] = __builtin_amdgcn_readlane(vbnd[t], i + 2);
       issue_loads(nxt, B1, B2);
@@ -134,8 +138,9 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
             }
           }
         }
-        if (count_mode || (k && __ballot(mx >= T.wsc)))
-          T = bm_scan_tile<HAS_AND, KPL>(T, L.tile, L.cntw, nt_and, s << BM_SUB_LOG2, count_mode, k);
+        const float thr = fmaxf(T.wsc, __uint_as_float(tau_bits));
+        if (count_mode || (k && __ballot(mx >= thr)))
+          T = bm_scan_tile<HAS_AND, KPL>(T, L.tile, L.cntw, nt_and, s << BM_SUB_LOG2, count_mode, k, thr, tau_q);
         else
           bm_clear_tile<HAS_AND>(L, is_and, lane);
       }
@@ -238,7 +243,7 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
       }
       if (any) {
         if (count_mode || (k && __ballot(mx >= T.wsc)))
-          T = bm_scan_tile<HAS_AND, KPL>(T, L.tile, L.cntw, nt_and, s << BM_SUB_LOG2, count_mode, k);
+          T = bm_scan_tile<HAS_AND, KPL>(T, L.tile, L.cntw, nt_and, s << BM_SUB_LOG2, count_mode, k, T.wsc, nullptr);
         else
           bm_clear_tile<HAS_AND>(L, is_and, lane);
       }
@@ -251,7 +256,7 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
 }
 
 #define BM_PASS_ARGS                                                                                                 \
-  p.post, p.term_base, p.sub_off, p.comp, p.q, p.part_keys, p.total, p.n_sub, p.n_terms, p.nq, p.P, p.k, p.count
+  p.post, p.term_base, p.sub_off, p.comp, p.q, p.part_keys, p.total, p.tau, p.n_sub, p.n_terms, p.nq, p.P, p.k, p.count
 
 template <int NT, bool HAS_AND, int KPL>
 static int launch_fast(const BmParams& p, hipStream_t st) {
