@@ -119,7 +119,54 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
       uint32_t maxn = 0;
 #pragma unroll
       for (int t = 0; t < NT; t++) maxn = max(maxn, B1[t] - B0[t]);
-      if (maxn) {
+      const uint32_t nlast = B1[NT - 1] - B0[NT - 1];
+      if (!HAS_AND && nlast != 0 && maxn <= (uint32_t)CPT * 64u) {
+        // Fused-clear path (unions, no oversized segment).  The LAST term is only gathered: its new scores stay in
+        // registers until the trigger is known.  No trigger (the common case): the tile is never read again, so the
+        // last term's docs get 0 instead of their score and the earlier terms' docs are zeroed through the
+        // addresses kept from their scatter -- 4-byte stores to the touched entries instead of a 16 KB dense clear.
+        float mx = 0.f;
+        uint32_t ao[(NT > 1 ? NT - 1 : 1) * CPT][4];
+#pragma unroll
+        for (int t = 0; t + 1 < NT; t++) {
+          const uint32_t n16 = B1[t] - B0[t];
+#pragma unroll
+          for (int c = 0; c < CPT; c++)
+            if ((uint32_t)c * 64u < n16) mx = bm_chunk_keep(cur[t * CPT + c], idf[t], L, mx, ao[t * CPT + c]);
+        }
+        uint32_t aoL[CPT][4];
+        float nwL[CPT][4];
+#pragma unroll
+        for (int c = 0; c < CPT; c++)
+          if ((uint32_t)c * 64u < nlast) mx = bm_chunk_read(cur[(NT - 1) * CPT + c], idf[NT - 1], L, mx, aoL[c], nwL[c]);
+        const float thr = fmaxf(T.wsc, __uint_as_float(tau_bits));
+        if (count_mode || (k && __ballot(mx >= thr))) {
+#pragma unroll
+          for (int c = 0; c < CPT; c++)
+            if ((uint32_t)c * 64u < nlast) {
+#pragma unroll
+              for (int x = 0; x < 4; x++) lds_stf(aoL[c][x], nwL[c][x]);
+            }
+          T = bm_scan_tile<HAS_AND, KPL>(T, L.tile, L.cntw, nt_and, s << BM_SUB_LOG2, count_mode, k, thr, tau_q);
+        } else {
+#pragma unroll
+          for (int c = 0; c < CPT; c++)
+            if ((uint32_t)c * 64u < nlast) {
+#pragma unroll
+              for (int x = 0; x < 4; x++) lds_stf(aoL[c][x], 0.f);
+            }
+#pragma unroll
+          for (int t = 0; t + 1 < NT; t++) {
+            const uint32_t n16 = B1[t] - B0[t];
+#pragma unroll
+            for (int c = 0; c < CPT; c++)
+              if ((uint32_t)c * 64u < n16) {
+#pragma unroll
+                for (int x = 0; x < 4; x++) lds_stf(ao[t * CPT + c][x], 0.f);
+              }
+          }
+        }
+      } else if (maxn) {
         float mx = 0.f;  // running maximum of the scores written in this item
 #pragma unroll
         for (int t = 0; t < NT; t++) {

@@ -30,19 +30,22 @@ constexpr uint32_t BM_TF_MAX = 511;         // 9-bit tf field
 // Packed posting (one dword).  Laid out so that the two LDS byte offsets the scan needs are single AND / shift+AND
 // extractions and everything else rides in the bits they mask off:
 //   bits  2..14  doc field = doc-in-sub-block + 1 (1..4096)            -> p & 0x7FFC        = 4 * field (accumulator)
-//   bits 18..25  SmallFloat length byte, bits 26..29 tf & 15           -> (p >> 16) & 0x3FFC = 4 * ((tf & 15) << 8 | len)
+//   bits 18..25  LUT column, bits 26..29 tf & 15                       -> (p >> 16) & 0x3FFC = 4 * ((tf & 15) << 8 | col)
+//                col = (len + 7 * (tf & 15)) & 255: rows of the weight table are rotated against each other so that
+//                equal lengths with different tf (the common case inside one wave) fall into different LDS banks
 //   bit 15, bits 16..17, bits 30..31 = tf bits 4, 5..6, 7..8 (non-zero only when tf >= 16: weight computed, not looked up)
 // The all-zero dword is the NULL posting (segment padding, and what an out-of-range buffer load returns): its doc
 // field addresses the dump slot in front of a wave's accumulator tile and its table weight (tf = 0) is 0.
 constexpr uint32_t BM_BIG_TF_MASK = 0xC0038000u;
+__host__ __device__ inline uint32_t bm_lut_col(uint32_t len_byte, uint32_t tf) { return (len_byte + 7u * (tf & 15u)) & 0xFFu; }
 __host__ __device__ inline uint32_t bm_pack(uint32_t doc_in_sub, uint32_t len_byte, uint32_t tf) {
   return (((doc_in_sub + 1u) & 0x1FFFu) << 2) | (((tf >> 4) & 1u) << 15) | (((tf >> 5) & 3u) << 16) |
-         ((len_byte & 0xFFu) << 18) | ((tf & 15u) << 26) | (((tf >> 7) & 3u) << 30);
+         (bm_lut_col(len_byte, tf) << 18) | ((tf & 15u) << 26) | (((tf >> 7) & 3u) << 30);
 }
 __host__ __device__ inline uint32_t bm_tf(uint32_t p) {
   return ((p >> 26) & 15u) | (((p >> 15) & 1u) << 4) | (((p >> 16) & 3u) << 5) | ((p >> 30) << 7);
 }
-__host__ __device__ inline uint32_t bm_len(uint32_t p) { return (p >> 18) & 0xFFu; }
+__host__ __device__ inline uint32_t bm_len(uint32_t p) { return (((p >> 18) & 0xFFu) - 7u * ((p >> 26) & 15u)) & 0xFFu; }
 // per-wave LDS: [12 B pad][dump f32][tile BM_SUB f32] (+ [3 B pad][dump u8][BM_SUB u8 match counters])
 constexpr int BM_WAVE_ACC = 16 + BM_SUB * 4;
 constexpr int BM_WAVE_CNT = 16 + BM_SUB;  // counters of doc d at byte 4 + d; the dump counter at byte 3

@@ -64,7 +64,7 @@ static void fill_comp(float avgdl, float* comp) {
   for (int tf = 0; tf < 16; tf++)
     for (int l = 0; l < 256; l++) {
       float t = (float)tf;
-      comp[256 + (tf << 8) + l] = tf ? (t * (1.2f + 1.0f) / (t + comp[l])) : 0.0f;
+      comp[256 + (tf << 8) + bm_lut_col((uint32_t)l, (uint32_t)tf)] = tf ? (t * (1.2f + 1.0f) / (t + comp[l])) : 0.0f;
     }
 }
 constexpr int SS_COMP_N = 256 + 4096;
