@@ -212,25 +212,22 @@ __device__ __forceinline__ float bm_chunk(const u32x4 q, float idf, const BmLds&
   return mx;
 }
 
-// Union-only variants used by the fused-clear path of the item loop (bm25_fast.hip):
-// bm_chunk_keep = bm_chunk that also hands back the four accumulator addresses it touched;
-// bm_chunk_read = the gather half only: new scores stay in registers, nothing is written yet.
-__device__ __forceinline__ float bm_chunk_keep(const u32x4 q, float idf, const BmLds& L, float mx, uint32_t (&ao)[4]) {
+// ---- chunk flavours of the fused item path (unions, items without tf >= 16 postings; bm25_fast.hip):
+//   first : the tile is still all zero for this term's docs -> score = idf * w, scattered without a read
+//   keep  : gather / add / scatter, addresses handed back
+//   read  : gather / add only, the new scores stay in registers (last term: scattered or zeroed once the trigger is known)
+// At most 8 LDS reads are in flight per chunk (the LDS counter has 4 bits).
+__device__ __forceinline__ float bm_chunk_first(const u32x4 q, float idf, const BmLds& L, float mx, uint32_t (&ao)[4]) {
   const uint32_t pv[4] = {q.x, q.y, q.z, q.w};
-  float old[4], wp[4];
+  float w[4];
 #pragma unroll
   for (int x = 0; x < 4; x++) {
     ao[x] = (pv[x] & 0x7FFCu) + L.accb;
-    old[x] = lds_ldf(ao[x]);
-    wp[x] = lds_ldf(((pv[x] >> 16) & 0x3FFCu) + L.lut);
-  }
-  if (__ballot(((pv[0] | pv[1]) | (pv[2] | pv[3])) & BM_BIG_TF_MASK)) {
-    const f32x4 fx = bm_big_tf_weights(q, f32x4{wp[0], wp[1], wp[2], wp[3]}, L.comp);
-    wp[0] = fx.x; wp[1] = fx.y; wp[2] = fx.z; wp[3] = fx.w;
+    w[x] = lds_ldf(((pv[x] >> 16) & 0x3FFCu) + L.lut);
   }
 #pragma unroll
   for (int x = 0; x < 4; x++) {
-    const float nw = old[x] + idf * wp[x];
+    const float nw = idf * w[x];
     lds_stf(ao[x], nw);
     mx = fmaxf(mx, nw);
   }
@@ -246,15 +243,18 @@ __device__ __forceinline__ float bm_chunk_read(const u32x4 q, float idf, const B
     old[x] = lds_ldf(ao[x]);
     wp[x] = lds_ldf(((pv[x] >> 16) & 0x3FFCu) + L.lut);
   }
-  if (__ballot(((pv[0] | pv[1]) | (pv[2] | pv[3])) & BM_BIG_TF_MASK)) {
-    const f32x4 fx = bm_big_tf_weights(q, f32x4{wp[0], wp[1], wp[2], wp[3]}, L.comp);
-    wp[0] = fx.x; wp[1] = fx.y; wp[2] = fx.z; wp[3] = fx.w;
-  }
 #pragma unroll
   for (int x = 0; x < 4; x++) {
     nw[x] = old[x] + idf * wp[x];
     mx = fmaxf(mx, nw[x]);
   }
+  return mx;
+}
+__device__ __forceinline__ float bm_chunk_keep(const u32x4 q, float idf, const BmLds& L, float mx, uint32_t (&ao)[4]) {
+  float nw[4];
+  mx = bm_chunk_read(q, idf, L, mx, ao, nw);
+#pragma unroll
+  for (int x = 0; x < 4; x++) lds_stf(ao[x], nw[x]);
   return mx;
 }
 

@@ -119,12 +119,18 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
       uint32_t maxn = 0;
 #pragma unroll
       for (int t = 0; t < NT; t++) maxn = max(maxn, B1[t] - B0[t]);
+      // Postings with tf >= 16 need a computed weight (bm_big_tf_weights): such items (rare) take the general path, so
+      // that the fused path is free of calls and data-dependent branches.
+      uint32_t anyb = 0;
+#pragma unroll
+      for (int i = 0; i < RC; i++) anyb |= (cur[i].x | cur[i].y) | (cur[i].z | cur[i].w);
       const uint32_t nlast = B1[NT - 1] - B0[NT - 1];
-      if (!HAS_AND && nlast != 0 && maxn <= (uint32_t)CPT * 64u) {
-        // Fused-clear path (unions, no oversized segment).  The LAST term is only gathered: its new scores stay in
-        // registers until the trigger is known.  No trigger (the common case): the tile is never read again, so the
-        // last term's docs get 0 instead of their score and the earlier terms' docs are zeroed through the
-        // addresses kept from their scatter -- 4-byte stores to the touched entries instead of a 16 KB dense clear.
+      if (!HAS_AND && nlast != 0 && maxn <= (uint32_t)CPT * 64u && __ballot(anyb & BM_BIG_TF_MASK) == 0) {
+        // Fused path (unions, last term present, no oversized segment).  The tile is all zero when an item starts:
+        // the first term is a pure scatter, middle terms gather / add / scatter, and the LAST term is only gathered --
+        // its new scores stay in registers until the trigger is known.  No trigger (the common case): the tile is never
+        // read again, so every touched entry is zeroed through the addresses kept in registers (4-byte stores instead
+        // of a 16 KB dense clear).  Trigger: the last term's scores are scattered and the tile is scanned.
         float mx = 0.f;
         uint32_t ao[(NT > 1 ? NT - 1 : 1) * CPT][4];
 #pragma unroll
@@ -132,7 +138,10 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
           const uint32_t n16 = B1[t] - B0[t];
 #pragma unroll
           for (int c = 0; c < CPT; c++)
-            if ((uint32_t)c * 64u < n16) mx = bm_chunk_keep(cur[t * CPT + c], idf[t], L, mx, ao[t * CPT + c]);
+            if ((uint32_t)c * 64u < n16) {
+              if (t == 0) mx = bm_chunk_first(cur[t * CPT + c], idf[t], L, mx, ao[t * CPT + c]);
+              else mx = bm_chunk_keep(cur[t * CPT + c], idf[t], L, mx, ao[t * CPT + c]);
+            }
         }
         uint32_t aoL[CPT][4];
         float nwL[CPT][4];
