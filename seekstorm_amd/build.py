@@ -46,7 +46,29 @@ def build(force=False, verbose=False):
                 print(err)
     if jobs or not os.path.exists(LIB):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs + ["-Wl,-rpath,/opt/rocm/lib"])
+    build_host(force or bool(jobs), verbose)
     return LIB
+
+
+HOST_DIR = os.path.join(HERE, "host")
+HOST_LIB = os.path.join(OUT_DIR, "libseekstorm_host.so")
+HOST_SOURCES = ["seekstorm_host.cpp", "host_capi.cpp"]
+
+
+def build_host(force=False, verbose=False):
+    """C++ host mirror of the reference's search interface (planner, merge, batch coalescer) above the C ABI."""
+    srcs = [os.path.join(HOST_DIR, f) for f in HOST_SOURCES]
+    deps = srcs + [os.path.join(HOST_DIR, "seekstorm_host.hpp"), os.path.join(HERE, "..", "include", "seekstorm_hip.h")]
+    if not force and _newer(HOST_LIB, deps):
+        return HOST_LIB
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread", "-o", HOST_LIB] + srcs + \
+          ["-L" + OUT_DIR, "-lseekstorm_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("g++ failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    return HOST_LIB
 
 
 if __name__ == "__main__":

@@ -1,0 +1,103 @@
+// Flat C shim over the C++ host mirror (seekstorm_host.hpp) so that the parity tests can drive it through ctypes.
+// Test plumbing only: a C++ application links seekstorm_host.hpp directly.
+#include <cstring>
+
+#include "seekstorm_host.hpp"
+
+using namespace seekstorm;
+
+struct ssh_index {
+  std::vector<std::shared_ptr<Shard>> shards;
+  std::unique_ptr<Index> index;
+  std::vector<std::unique_ptr<VectorBatchCoalescer>> coalescers;
+};
+
+static int write_out(const ResultObject& ro, uint32_t cap, uint64_t* out_doc, float* out_score, uint8_t* out_source,
+                     float* out_lexical, float* out_vector, uint64_t* out_meta /* [4] */) {
+  const uint32_t n = (uint32_t)std::min<size_t>(cap, ro.results.size());
+  for (uint32_t i = 0; i < n; i++) {
+    out_doc[i] = ro.results[i].doc_id;
+    out_score[i] = ro.results[i].score;
+    if (out_source) out_source[i] = (uint8_t)ro.results[i].source;
+    if (out_lexical) out_lexical[i] = ro.results[i].lexical_score;
+    if (out_vector) out_vector[i] = ro.results[i].vector_score;
+  }
+  if (out_meta) {
+    out_meta[0] = ro.result_count;
+    out_meta[1] = ro.result_count_total;
+    out_meta[2] = ro.observed_vector_count;
+    out_meta[3] = (uint64_t)(int64_t)ro.last_error;
+  }
+  return (int)n;
+}
+
+extern "C" {
+
+float ssh_idf(uint64_t n_docs, uint64_t posting_count) { return idf(n_docs, posting_count); }
+void ssh_normalize_f32(float* v, uint64_t n) { normalize_f32(v, (size_t)n); }
+float ssh_threshold_raw(float similarity_threshold) { return threshold_raw(&similarity_threshold); }
+float ssh_vector_score(float raw) { return vector_score_of(raw); }
+
+ssh_index* ssh_index_create(int n_shards, const int* devices) {
+  ssh_index* ix = new ssh_index();
+  for (int i = 0; i < n_shards; i++) ix->shards.push_back(std::make_shared<Shard>(devices ? devices[i] : 0, (uint32_t)i));
+  ix->index.reset(new Index(ix->shards));
+  return ix;
+}
+void ssh_index_destroy(ssh_index* ix) { delete ix; }
+int ssh_shard_ok(ssh_index* ix, int shard) { return ix->shards[shard]->ok() ? 1 : 0; }
+int ssh_shard_create_error(ssh_index* ix, int shard) { return ix->shards[shard]->create_error(); }
+
+int ssh_upload_lexical(ssh_index* ix, int shard, uint64_t n_docs, const uint8_t* doclen, uint32_t n_terms, const uint64_t* offs,
+                       const uint32_t* docs, const uint16_t* tfs) {
+  return ix->shards[shard]->upload_lexical(n_docs, doclen, n_terms, offs, docs, tfs);
+}
+int ssh_upload_vectors(ssh_index* ix, int shard, uint64_t n_rows, uint32_t dim, const float* rows, const uint32_t* ids) {
+  return ix->shards[shard]->upload_vectors(n_rows, dim, rows, ids);
+}
+
+// Index::search; returns the number of results written (<= cap)
+int ssh_search(ssh_index* ix, const uint32_t* terms, uint32_t n_terms, const float* query_vector, uint32_t query_type,
+               int search_mode, uint32_t offset, uint32_t length, uint32_t result_type, int has_threshold, float threshold,
+               int normalize_query, uint32_t cap, uint64_t* out_doc, float* out_score, uint8_t* out_source,
+               float* out_lexical, float* out_vector, uint64_t* out_meta) {
+  std::vector<uint32_t> t(terms, terms + n_terms);
+  ResultObject ro = ix->index->search(t, query_vector, (QueryType)query_type, (SearchMode)search_mode, offset, length,
+                                      (ResultType)result_type, has_threshold ? &threshold : nullptr, normalize_query != 0);
+  return write_out(ro, cap, out_doc, out_score, out_source, out_lexical, out_vector, out_meta);
+}
+
+// per-shard seams
+int ssh_search_lexical_shard(ssh_index* ix, int shard, const uint32_t* terms, uint32_t n_terms, uint32_t query_type,
+                             uint32_t offset, uint32_t length, uint32_t result_type, uint32_t cap, uint64_t* out_doc,
+                             float* out_score, uint64_t* out_meta) {
+  std::vector<uint32_t> t(terms, terms + n_terms);
+  ResultObject ro = ix->shards[shard]->search_lexical_shard(t, (QueryType)query_type, offset, length, (ResultType)result_type);
+  return write_out(ro, cap, out_doc, out_score, nullptr, nullptr, nullptr, out_meta);
+}
+
+// n concurrent single-query vector searches through a VectorBatchCoalescer (one submitting thread per query);
+// out arrays are [n][length]; returns the number of device batches used
+int ssh_coalesced_vector_search(ssh_index* ix, int shard, uint32_t n, const float* queries, uint32_t length,
+                                uint32_t max_batch, uint32_t max_wait_us, uint64_t* out_doc, float* out_score,
+                                uint32_t* out_count) {
+  Shard& sh = *ix->shards[shard];
+  VectorBatchCoalescer co(ix->shards[shard], max_batch, max_wait_us);
+  const uint32_t dim = sh.dim();
+  std::vector<std::future<ResultObject>> fut(n);
+  std::vector<std::thread> th;
+  for (uint32_t i = 0; i < n; i++)
+    th.emplace_back([&, i] { fut[i] = co.submit(std::vector<float>(queries + (size_t)i * dim, queries + (size_t)(i + 1) * dim), length, nullptr); });
+  for (auto& t : th) t.join();
+  for (uint32_t i = 0; i < n; i++) {
+    ResultObject ro = fut[i].get();
+    out_count[i] = (uint32_t)ro.results.size();
+    for (size_t j = 0; j < ro.results.size() && j < length; j++) {
+      out_doc[(size_t)i * length + j] = ro.results[j].doc_id;
+      out_score[(size_t)i * length + j] = ro.results[j].score;
+    }
+  }
+  return (int)co.batches_submitted();
+}
+
+}  // extern "C"

@@ -1,0 +1,331 @@
+// C++ host mirror of the reference's search interface for the query hot path (see seekstorm_host.hpp).
+#include "seekstorm_host.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+namespace seekstorm {
+
+// ------------------------------------------------------------------ scalar pieces
+float idf(uint64_t indexed_doc_count, uint64_t posting_count) {
+  // search.rs:3225-3230: (((N - n + 0.5) / (n + 0.5)) + 1).ln(), every operand f32
+  const float N = (float)indexed_doc_count, n = (float)posting_count;
+  return std::log(((N - n + 0.5f) / (n + 0.5f)) + 1.0f);
+}
+
+void normalize_f32(float* v, size_t n) {
+  // vector_similarity.rs:70-74: sequential f32 sum of squares, then multiply by 1 / sqrt(sum)
+  float s = 0.f;
+  for (size_t i = 0; i < n; i++) s += v[i] * v[i];
+  const float f = 1.0f / std::sqrt(s);
+  for (size_t i = 0; i < n; i++) v[i] *= f;
+}
+
+static const float kSimilarityNormalization64I8 = 1.0f / 16129.0f;  // vector.rs:29
+
+float threshold_raw(const float* similarity_threshold) {
+  if (!similarity_threshold) return -3.4028234663852886e38f;
+  return ((*similarity_threshold * 2.0f) - 1.0f) / kSimilarityNormalization64I8;  // vector.rs:388-397
+}
+
+float vector_score_of(float raw_dot) { return ((raw_dot * kSimilarityNormalization64I8) + 1.0f) / 2.0f; }  // vector.rs:1495-1499
+
+// ------------------------------------------------------------------ Shard
+Shard::Shard(int device, uint32_t shard_id) : shard_id_(shard_id) {
+  create_rc_ = ss_shard_create(device, &h_);
+  if (create_rc_ != SS_OK) h_ = nullptr;
+}
+
+Shard::~Shard() {
+  if (h_) ss_shard_destroy(h_);
+}
+
+int Shard::upload_lexical(uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t n_terms, const uint64_t* term_offsets,
+                          const uint32_t* doc_ids, const uint16_t* tfs) {
+  if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
+  const int rc = ss_bm25_upload(h_, n_docs, doclen_bytes, n_terms, term_offsets, doc_ids, tfs);
+  n_docs_ = rc == SS_OK ? n_docs : 0;
+  return rc;
+}
+
+int Shard::upload_vectors(uint64_t n_rows, uint32_t dim, const float* rows, const uint32_t* row_doc_ids) {
+  if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
+  const int rc = ss_vec_upload(h_, n_rows, dim, rows, row_doc_ids);
+  n_rows_ = rc == SS_OK ? n_rows : 0;
+  dim_ = rc == SS_OK ? dim : 0;
+  return rc;
+}
+
+int Shard::synth_lexical(uint64_t seed, uint64_t n_docs, uint32_t n_terms, const uint32_t* thresh32,
+                         const uint8_t* len_table1024) {
+  if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
+  const int rc = ss_bm25_synth(h_, seed, n_docs, n_terms, thresh32, len_table1024);
+  n_docs_ = rc == SS_OK ? n_docs : 0;
+  return rc;
+}
+
+int Shard::synth_vectors(uint64_t seed, uint64_t n_rows, uint32_t dim) {
+  if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
+  const int rc = ss_vec_synth(h_, seed, n_rows, dim);
+  n_rows_ = rc == SS_OK ? n_rows : 0;
+  dim_ = rc == SS_OK ? dim : 0;
+  return rc;
+}
+
+int Shard::make_query(const std::vector<uint32_t>& terms, QueryType qt, ss_bm25_query* out) {
+  if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
+  std::vector<uint32_t> uniq;  // unique_terms in first-seen order (search.rs:3023)
+  for (uint32_t t : terms)
+    if (std::find(uniq.begin(), uniq.end(), t) == uniq.end()) uniq.push_back(t);
+  if (uniq.empty() || uniq.size() > SS_MAX_QUERY_TERMS) return SS_EINVAL;
+  uint64_t df[SS_MAX_QUERY_TERMS];
+  const int rc = ss_bm25_term_df(h_, (uint32_t)uniq.size(), uniq.data(), df);
+  if (rc != SS_OK) return rc;
+  std::memset(out, 0, sizeof(*out));
+  out->n_terms = (uint32_t)uniq.size();
+  out->op = (uint32_t)qt;
+  for (size_t i = 0; i < uniq.size(); i++) {
+    out->term[i] = uniq[i];
+    out->idf[i] = idf(n_docs_, df[i]);
+  }
+  return SS_OK;
+}
+
+std::vector<ResultObject> Shard::search_lexical_batch(const std::vector<ss_bm25_query>& queries, size_t k,
+                                                      ResultType result_type) {
+  const size_t nq = queries.size();
+  std::vector<ResultObject> out(nq);
+  if (nq == 0) return out;
+  const size_t kk = std::max<size_t>(k, 1);
+  std::vector<uint32_t> doc(nq * kk), cnt(nq);
+  std::vector<float> score(nq * kk);
+  std::vector<uint64_t> tot(nq);
+  const int rc = h_ ? ss_bm25_search(h_, (uint32_t)nq, queries.data(), (uint32_t)k, (uint32_t)result_type, doc.data(),
+                                     score.data(), cnt.data(), tot.data())
+                    : (create_rc_ ? create_rc_ : SS_ESTATE);
+  for (size_t q = 0; q < nq; q++) {
+    ResultObject& ro = out[q];
+    if (rc != SS_OK) { ro.last_error = rc; continue; }  // degrade to empty (search.rs:2461-2463)
+    const size_t n = result_type == ResultType::Count ? 0 : cnt[q];
+    ro.results.resize(n);
+    for (size_t i = 0; i < n; i++) {
+      Result& r = ro.results[i];
+      r.doc_id = doc[q * kk + i];
+      r.score = score[q * kk + i];
+      r.lexical_score = r.score;
+      r.shard_id = shard_id_;
+      r.level_id = (uint32_t)(r.doc_id >> 16);  // 65 536-doc levels (index.rs:115)
+      r.source = ResultSource::Lexical;
+    }
+    ro.result_count = n;
+    ro.result_count_total = tot[q];
+  }
+  return out;
+}
+
+std::vector<ResultObject> Shard::search_vector_batch(const float* query_vectors, size_t n_queries, size_t k,
+                                                     const float* similarity_threshold) {
+  std::vector<ResultObject> out(n_queries);
+  if (n_queries == 0) return out;
+  const size_t kk = std::max<size_t>(k, 1);
+  std::vector<uint32_t> doc(n_queries * kk), cnt(n_queries);
+  std::vector<float> score(n_queries * kk);
+  std::vector<uint64_t> tot(n_queries);
+  const int rc = h_ ? ss_vec_search(h_, (uint32_t)n_queries, query_vectors, (uint32_t)k, threshold_raw(similarity_threshold),
+                                    doc.data(), score.data(), cnt.data(), tot.data())
+                    : (create_rc_ ? create_rc_ : SS_ESTATE);
+  for (size_t q = 0; q < n_queries; q++) {
+    ResultObject& ro = out[q];
+    if (rc != SS_OK) { ro.last_error = rc; continue; }  // degrade to empty (vector.rs:1222-1224)
+    const size_t n = cnt[q];
+    ro.results.resize(n);
+    for (size_t i = 0; i < n; i++) {
+      Result& r = ro.results[i];
+      r.doc_id = doc[q * kk + i];
+      r.score = score[q * kk + i];              // raw dot (vector.rs:1474-1506)
+      r.vector_score = vector_score_of(r.score);
+      r.shard_id = shard_id_;
+      r.level_id = (uint32_t)(r.doc_id >> 16);
+      r.source = ResultSource::Vector;
+    }
+    ro.result_count = n;
+    ro.result_count_total = tot[q];
+    ro.observed_vector_count = n_rows_;  // AnnMode::All observes every record (vector.rs:421)
+    ro.observed_cluster_count = 1;
+  }
+  return out;
+}
+
+ResultObject Shard::search_lexical_shard(const std::vector<uint32_t>& query_terms, QueryType query_type_default, size_t offset,
+                                         size_t length, ResultType result_type) {
+  ss_bm25_query q;
+  const int rc = make_query(query_terms, query_type_default, &q);
+  if (rc != SS_OK) {
+    ResultObject ro;
+    ro.last_error = rc;
+    return ro;
+  }
+  ResultObject ro = std::move(search_lexical_batch({q}, offset + length, result_type)[0]);
+  if (offset) {  // drain offset (search.rs:3585-3593)
+    ro.results.erase(ro.results.begin(), ro.results.begin() + std::min(offset, ro.results.size()));
+    ro.result_count = ro.results.size();
+  }
+  return ro;
+}
+
+ResultObject Shard::search_vector_shard(const float* query_vector, size_t length, const float* similarity_threshold) {
+  if (!query_vector) return ResultObject();
+  return std::move(search_vector_batch(query_vector, 1, length, similarity_threshold)[0]);
+}
+
+// ------------------------------------------------------------------ Index::search
+ResultObject Index::search(const std::vector<uint32_t>& query_terms, const float* query_vector, QueryType query_type_default,
+                           SearchMode search_mode, size_t offset, size_t length, ResultType result_type,
+                           const float* similarity_threshold, bool normalize_query) {
+  ResultObject ro;
+  const size_t S = shards_.size();
+  if (S == 0) return ro;
+  const bool want_lex = (search_mode == SearchMode::Lexical || search_mode == SearchMode::Hybrid) && !query_terms.empty();
+  const bool want_vec = (search_mode == SearchMode::Vector || search_mode == SearchMode::Hybrid) && query_vector != nullptr;
+  std::vector<float> qv;
+  if (want_vec) {
+    qv.assign(query_vector, query_vector + shards_[0]->dim());
+    if (normalize_query) normalize_f32(qv.data(), qv.size());  // search.rs:1464-1475
+  }
+  // one host thread per shard; lexical then vector sequentially inside the task for Hybrid (search.rs:1698-1740)
+  std::vector<ResultObject> lex(S), vec(S);
+  auto task = [&](size_t i) {
+    Shard& sh = *shards_[i];
+    if (want_lex) lex[i] = sh.search_lexical_shard(query_terms, query_type_default, 0, offset + length, result_type);
+    if (want_vec && qv.size() == sh.dim()) vec[i] = sh.search_vector_shard(qv.data(), offset + length, similarity_threshold);
+  };
+  if (S == 1) {
+    task(0);  // shard_number == 1: called directly, no spawn (search.rs:1434)
+  } else {
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < S; i++) th.emplace_back(task, i);
+    for (auto& t : th) t.join();
+  }
+  std::vector<uint64_t> ld, vd;
+  std::vector<float> ls, vs;
+  for (size_t i = 0; i < S; i++) {
+    const uint64_t sid = shards_[i]->shard_id();
+    for (const Result& r : lex[i].results) { ld.push_back(r.doc_id * S + sid); ls.push_back(r.score); }  // search.rs:1671
+    for (const Result& r : vec[i].results) { vd.push_back(r.doc_id * S + sid); vs.push_back(r.score); }  // search.rs:1693
+    const uint64_t lt = lex[i].result_count_total, vt = vec[i].result_count_total;
+    ro.result_count_total += search_mode == SearchMode::Hybrid ? std::max(lt, vt) : (lt + vt);  // search.rs:1884-1921
+    ro.observed_vector_count += vec[i].observed_vector_count;
+    ro.observed_cluster_count += vec[i].observed_cluster_count;
+    if (lex[i].last_error) ro.last_error = lex[i].last_error;
+    if (vec[i].last_error) ro.last_error = vec[i].last_error;
+  }
+  if (result_type != ResultType::Count && length > 0) {
+    std::vector<uint64_t> od(length);
+    std::vector<float> os(length);
+    std::vector<uint8_t> src(length);
+    const int n = ss_merge_results((int)search_mode, ld.data(), ls.data(), (uint32_t)ld.size(), vd.data(), vs.data(),
+                                   (uint32_t)vd.size(), (uint32_t)offset, (uint32_t)length, od.data(), os.data(), src.data());
+    if (n < 0) {
+      ro.last_error = n;
+    } else {
+      ro.results.resize((size_t)n);
+      for (int i = 0; i < n; i++) {
+        Result& r = ro.results[i];
+        r.doc_id = od[i];
+        r.score = os[i];
+        r.source = (ResultSource)src[i];
+        r.shard_id = (uint32_t)(od[i] % S);
+        r.level_id = (uint32_t)((od[i] / S) >> 16);
+        // per-list component scores of a fused result (min_heap.rs:17-40)
+        for (size_t j = 0; j < ld.size(); j++)
+          if (ld[j] == od[i]) { r.lexical_score = ls[j]; break; }
+        for (size_t j = 0; j < vd.size(); j++)
+          if (vd[j] == od[i]) { r.vector_score = vector_score_of(vs[j]); break; }
+      }
+    }
+  }
+  ro.result_count = ro.results.size();
+  return ro;
+}
+
+// ------------------------------------------------------------------ VectorBatchCoalescer
+VectorBatchCoalescer::VectorBatchCoalescer(std::shared_ptr<Shard> shard, size_t max_batch, unsigned max_wait_us)
+    : shard_(std::move(shard)), max_batch_(std::max<size_t>(1, max_batch)), max_wait_us_(max_wait_us) {
+  worker_ = std::thread([this] { run(); });
+}
+
+VectorBatchCoalescer::~VectorBatchCoalescer() {
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    stop_ = true;
+  }
+  cv_.notify_all();
+  worker_.join();
+}
+
+std::future<ResultObject> VectorBatchCoalescer::submit(std::vector<float> query_vector, size_t length,
+                                                       const float* similarity_threshold) {
+  auto r = std::make_unique<Req>();
+  r->q = std::move(query_vector);
+  r->length = length;
+  r->has_thr = similarity_threshold != nullptr;
+  r->thr = similarity_threshold ? *similarity_threshold : 0.f;
+  std::future<ResultObject> f = r->done.get_future();
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    queue_.push_back(std::move(r));
+  }
+  cv_.notify_all();
+  return f;
+}
+
+void VectorBatchCoalescer::run() {
+  for (;;) {
+    std::vector<std::unique_ptr<Req>> batch;
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_.wait(lk, [this] { return stop_ || !queue_.empty(); });
+      if (queue_.empty()) {
+        if (stop_) return;
+        continue;
+      }
+      // give late arrivals a moment: wait until the batch is full or max_wait_us has elapsed
+      const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(max_wait_us_);
+      cv_.wait_until(lk, deadline, [this] { return stop_ || queue_.size() >= max_batch_; });
+      // one batch = the longest prefix with the same threshold and dimension, at most max_batch requests
+      size_t n = 1;
+      while (n < queue_.size() && n < max_batch_ && queue_[n]->has_thr == queue_[0]->has_thr &&
+             queue_[n]->thr == queue_[0]->thr && queue_[n]->q.size() == queue_[0]->q.size())
+        n++;
+      for (size_t i = 0; i < n; i++) batch.push_back(std::move(queue_[i]));
+      queue_.erase(queue_.begin(), queue_.begin() + n);
+      batches_++;
+      queries_ += n;
+    }
+    const size_t dim = batch[0]->q.size();
+    size_t k = 0;
+    for (auto& r : batch) k = std::max(k, r->length);
+    std::vector<ResultObject> res;
+    if (dim == shard_->dim() && k > 0) {
+      std::vector<float> flat(batch.size() * dim);
+      for (size_t i = 0; i < batch.size(); i++) std::memcpy(&flat[i * dim], batch[i]->q.data(), dim * sizeof(float));
+      const float thr = batch[0]->thr;
+      res = shard_->search_vector_batch(flat.data(), batch.size(), k, batch[0]->has_thr ? &thr : nullptr);
+    } else {
+      res.resize(batch.size());
+      for (auto& r : res) r.last_error = SS_EINVAL;
+    }
+    for (size_t i = 0; i < batch.size(); i++) {
+      ResultObject& ro = res[i];
+      if (ro.results.size() > batch[i]->length) {  // a batch runs at the largest k of its members
+        ro.results.resize(batch[i]->length);
+        ro.result_count = ro.results.size();
+      }
+      batch[i]->done.set_value(std::move(ro));
+    }
+  }
+}
+
+}  // namespace seekstorm

@@ -1,0 +1,162 @@
+// C++ host side of the MI355X query hot path: the planner / merge layer that sits ABOVE the C ABI
+// (include/seekstorm_hip.h), mirroring the `seekstorm` crate's interface for this path.  The reference is Rust; this
+// image has no Rust toolchain, so the host mirror is C++ (INTEGRATION.md shows the Rust binding).  Citations are
+// relative to /root/reference/seekstorm/src.
+//
+//   QueryType / ResultType / SearchMode / ResultSource      search.rs:59, 168, 73; min_heap.rs:17-40
+//   Result / ResultObject                                   min_heap.rs:17-40 (feature `vb`), search.rs:186-213
+//   Shard::search_lexical_shard                             search.rs:2427-2442 (dispatch block 3374-3560 -> ss_bm25_search)
+//   Shard::search_vector_shard                              vector.rs:1105-1115 (-> ss_vec_search)
+//   Index::search                                           <IndexArc as Search>::search, search.rs:1134-1150 / 1154-2131
+//   BatchCoalescer                                          new: the reference has no batched entry point (one query per
+//                                                           request, http_server.rs:218-289); concurrent callers are
+//                                                           coalesced into one C-ABI batch per device pass
+//
+// No compute happens here: every score, set operation, top-k and merge is behind the C ABI.  Like the reference's
+// search path (search.rs:2461-2463, vector.rs:1222-1224) a failing shard degrades to an empty ResultObject; the
+// C-ABI code is kept in `last_error` for diagnosis.  Out of scope (stays in the Rust host):
+// tokenizer / term hashing -- a lexical query arrives as resolved term ids -- facets, filters, query rewriting.
+#pragma once
+#include <stdint.h>
+
+#include <condition_variable>
+#include <future>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "../../include/seekstorm_hip.h"
+
+namespace seekstorm {
+
+enum class QueryType : uint32_t { Union = SS_OP_UNION, Intersection = SS_OP_INTERSECTION };      // search.rs:59
+enum class ResultType : uint32_t { Count = SS_RT_COUNT, Topk = SS_RT_TOPK, TopkCount = SS_RT_TOPKCOUNT };  // search.rs:168
+enum class SearchMode : int { Lexical = SS_MODE_LEXICAL, Vector = SS_MODE_VECTOR, Hybrid = SS_MODE_HYBRID };  // search.rs:73
+enum class ResultSource : uint8_t { Lexical = SS_SRC_LEXICAL, Vector = SS_SRC_VECTOR, Hybrid = SS_SRC_HYBRID };
+
+// min_heap.rs:17-40 with the default feature `vb`
+struct Result {
+  uint64_t doc_id = 0;  // usize: shard-local from the per-shard executors, global (local * S + shard) from Index::search
+  float score = 0.f;
+  uint32_t field_id = 0, chunk_id = 0, level_id = 0, shard_id = 0, cluster_id = 0;
+  float cluster_score = 0.f, vector_score = 0.f, lexical_score = 0.f;
+  ResultSource source = ResultSource::Lexical;
+};
+
+// search.rs:186-213 (fields of this path)
+struct ResultObject {
+  std::vector<Result> results;
+  uint64_t result_count = 0;        // = results.len()
+  uint64_t result_count_total = 0;  // exact match count for Count / TopkCount; accepted pushes for vectors
+  uint64_t observed_vector_count = 0;
+  uint64_t observed_cluster_count = 0;
+  int last_error = 0;               // SS_OK or the C-ABI code that emptied this object
+};
+
+// ---- host-side scalar pieces of the reference algorithm
+float idf(uint64_t indexed_doc_count, uint64_t posting_count);  // search.rs:3225-3230, all f32
+void normalize_f32(float* v, size_t n);                         // vector_similarity.rs:70-74 (search.rs:1464-1475)
+float threshold_raw(const float* similarity_threshold);         // TopK::new, vector.rs:388-397; nullptr = none
+float vector_score_of(float raw_dot);                           // vector.rs:1495-1499: ((dot / 16129) + 1) / 2
+
+// One shard image on one MI355X.
+class Shard {
+ public:
+  Shard(int device, uint32_t shard_id);  // failure (no device, no library) leaves an unusable shard: searches return empty
+  ~Shard();
+  Shard(const Shard&) = delete;
+  Shard& operator=(const Shard&) = delete;
+
+  bool ok() const { return h_ != nullptr; }
+  int create_error() const { return create_rc_; }
+  ss_shard* handle() const { return h_; }
+  uint32_t shard_id() const { return shard_id_; }
+
+  // (re)build of the device image: end of open_shard (index.rs:3796) / after a commit (commit.rs:142-148)
+  int upload_lexical(uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t n_terms, const uint64_t* term_offsets,
+                     const uint32_t* doc_ids, const uint16_t* tfs);
+  int upload_vectors(uint64_t n_rows, uint32_t dim, const float* rows, const uint32_t* row_doc_ids);
+  int synth_lexical(uint64_t seed, uint64_t n_docs, uint32_t n_terms, const uint32_t* thresh32, const uint8_t* len_table1024);
+  int synth_vectors(uint64_t seed, uint64_t n_rows, uint32_t dim);
+
+  uint64_t indexed_doc_count() const { return n_docs_; }
+  uint64_t vector_count() const { return n_rows_; }
+  uint32_t dim() const { return dim_; }
+
+  // term resolution result -> device query (idf from shard-local N and posting_count, search.rs:3225-3230)
+  int make_query(const std::vector<uint32_t>& terms, QueryType qt, ss_bm25_query* out);
+
+  // the reference's per-shard seams (one query)
+  ResultObject search_lexical_shard(const std::vector<uint32_t>& query_terms, QueryType query_type_default, size_t offset,
+                                    size_t length, ResultType result_type);
+  ResultObject search_vector_shard(const float* query_vector /* normalised, dim() floats */, size_t length,
+                                   const float* similarity_threshold);
+  // batched forms used by the coalescer (results sorted by score desc, shard-local ids)
+  std::vector<ResultObject> search_lexical_batch(const std::vector<ss_bm25_query>& queries, size_t k, ResultType result_type);
+  std::vector<ResultObject> search_vector_batch(const float* query_vectors, size_t n_queries, size_t k,
+                                                const float* similarity_threshold);
+
+ private:
+  ss_shard* h_ = nullptr;
+  uint32_t shard_id_ = 0;
+  int create_rc_ = SS_OK;
+  uint64_t n_docs_ = 0, n_rows_ = 0;
+  uint32_t dim_ = 0;
+};
+
+// In-process multi-shard index: doc g lives in shard g % S with local id g / S (index.rs:5284).
+class Index {
+ public:
+  explicit Index(std::vector<std::shared_ptr<Shard>> shards) : shards_(std::move(shards)) {}
+  size_t shard_number() const { return shards_.size(); }
+  Shard& shard(size_t i) { return *shards_[i]; }
+
+  // <IndexArc as Search>::search for this path.  query_terms: resolved term ids (empty = no lexical part);
+  // query_vector: dim floats or nullptr; Cosine with external inference -> normalised here when normalize_query.
+  // One host thread per shard (the reference spawns one task per shard, search.rs:1637-1743); each shard is asked for
+  // (offset 0, length offset+length) (search.rs:1658-1659); ids become local * S + shard (search.rs:1671);
+  // totals are summed, Hybrid takes max(lexical, vector) per shard (search.rs:1919-1921); merge / RRF / sort /
+  // offset / truncate through ss_merge_results (search.rs:1875-2119).
+  ResultObject search(const std::vector<uint32_t>& query_terms, const float* query_vector, QueryType query_type_default,
+                      SearchMode search_mode, size_t offset, size_t length, ResultType result_type,
+                      const float* similarity_threshold = nullptr, bool normalize_query = true);
+
+ private:
+  std::vector<std::shared_ptr<Shard>> shards_;
+};
+
+// Coalesces concurrent single-query vector searches on ONE shard into device batches: a caller enqueues its query
+// and blocks on a future; a worker thread submits whatever has arrived (up to max_batch, after at most max_wait_us
+// since the first queued request) as one ss_vec_search call.  All requests of a batch share k = the largest requested
+// length (each result list is cut back to its own length) and must share the similarity threshold (requests with a
+// different threshold start a new batch).
+class VectorBatchCoalescer {
+ public:
+  VectorBatchCoalescer(std::shared_ptr<Shard> shard, size_t max_batch = SS_VEC_BATCH, unsigned max_wait_us = 200);
+  ~VectorBatchCoalescer();
+  std::future<ResultObject> submit(std::vector<float> query_vector, size_t length, const float* similarity_threshold);
+  uint64_t batches_submitted() const { return batches_; }
+  uint64_t queries_submitted() const { return queries_; }
+
+ private:
+  struct Req {
+    std::vector<float> q;
+    size_t length;
+    bool has_thr;
+    float thr;
+    std::promise<ResultObject> done;
+  };
+  void run();
+  std::shared_ptr<Shard> shard_;
+  size_t max_batch_;
+  unsigned max_wait_us_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::vector<std::unique_ptr<Req>> queue_;
+  bool stop_ = false;
+  uint64_t batches_ = 0, queries_ = 0;
+  std::thread worker_;
+};
+
+}  // namespace seekstorm

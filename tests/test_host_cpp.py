@@ -1,0 +1,178 @@
+"""The C++ host mirror of the reference's search interface (seekstorm_amd/host): planner, per-shard seams, merge and
+the batch coalescer, driven through the flat C shim host_capi.cpp.  CPU part: library loads, scalar pieces equal the
+oracle, a host without a GPU degrades to empty results with the C-ABI error kept.  GPU part (-m gpu): Index::search
+over two shards (lexical / vector / hybrid) against the oracle's merge, and coalesced concurrent vector searches."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST_LIB = os.path.join(ROOT, "seekstorm_amd", "lib", "libseekstorm_host.so")
+REL = 1e-4
+
+u8p, u16p, u32p, u64p, f32p = (C.POINTER(t) for t in (C.c_uint8, C.c_uint16, C.c_uint32, C.c_uint64, C.c_float))
+
+
+def P(a, t):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+@pytest.fixture(scope="module")
+def H():
+    from seekstorm_amd import _native as N
+    N.lib()  # loads torch's HIP runtime first, then libseekstorm_hip.so (one runtime per process)
+    if not os.path.exists(HOST_LIB):
+        from seekstorm_amd import build as B
+        B.build_host()
+    L = C.CDLL(HOST_LIB)
+    L.ssh_idf.restype = C.c_float
+    L.ssh_idf.argtypes = [C.c_uint64, C.c_uint64]
+    L.ssh_normalize_f32.argtypes = [f32p, C.c_uint64]
+    L.ssh_threshold_raw.restype = C.c_float
+    L.ssh_threshold_raw.argtypes = [C.c_float]
+    L.ssh_vector_score.restype = C.c_float
+    L.ssh_vector_score.argtypes = [C.c_float]
+    L.ssh_index_create.restype = C.c_void_p
+    L.ssh_index_create.argtypes = [C.c_int, C.POINTER(C.c_int)]
+    L.ssh_index_destroy.argtypes = [C.c_void_p]
+    L.ssh_shard_ok.argtypes = [C.c_void_p, C.c_int]
+    L.ssh_shard_create_error.argtypes = [C.c_void_p, C.c_int]
+    L.ssh_upload_lexical.argtypes = [C.c_void_p, C.c_int, C.c_uint64, u8p, C.c_uint32, u64p, u32p, u16p]
+    L.ssh_upload_vectors.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, f32p, u32p]
+    L.ssh_search.argtypes = [C.c_void_p, u32p, C.c_uint32, f32p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
+                             C.c_int, C.c_float, C.c_int, C.c_uint32, u64p, f32p, u8p, f32p, f32p, u64p]
+    L.ssh_search_lexical_shard.argtypes = [C.c_void_p, C.c_int, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                           C.c_uint32, C.c_uint32, u64p, f32p, u64p]
+    L.ssh_coalesced_vector_search.argtypes = [C.c_void_p, C.c_int, C.c_uint32, f32p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                              u64p, f32p, u32p]
+    return L
+
+
+def _search(L, ix, terms, qv, qt, mode, offset, length, rt=2, thr=None, normalize=True):
+    t = np.ascontiguousarray(terms, np.uint32)
+    cap = max(length, 1)
+    doc = np.zeros(cap, np.uint64); sc = np.zeros(cap, np.float32); src = np.zeros(cap, np.uint8)
+    ls = np.zeros(cap, np.float32); vs = np.zeros(cap, np.float32); meta = np.zeros(4, np.uint64)
+    q = None if qv is None else np.ascontiguousarray(qv, np.float32)
+    n = L.ssh_search(ix, P(t, u32p), len(t), P(q, f32p), qt, mode, offset, length, rt, 0 if thr is None else 1,
+                     0.0 if thr is None else float(thr), 1 if normalize else 0, cap, P(doc, u64p), P(sc, f32p), P(src, u8p),
+                     P(ls, f32p), P(vs, f32p), P(meta, u64p))
+    return doc[:n], sc[:n], src[:n], ls[:n], vs[:n], meta
+
+
+# ------------------------------------------------------------------ CPU
+def test_host_scalars_match_oracle(H):
+    from oracle import oracle as O
+    OL = O.lib()
+    for N_, n in ((1_000_000, 1000), (10, 3), (40_000, 39_999), (7, 7)):
+        assert H.ssh_idf(N_, n) == OL.so_idf(N_, n)
+    assert abs(H.ssh_idf(1_000_000, 1000) - 6.9072566) < 1e-6  # SURVEY 8c KAT
+    v = (np.sin(0.137 * np.arange(128)) / 2 + np.cos(0.013 * np.arange(128)) / 2).astype(np.float32)  # make_f32, vector_similarity.rs:3012
+    a = v.copy()
+    H.ssh_normalize_f32(P(a, f32p), len(a))
+    assert np.allclose(a, O.normalize(v), rtol=0, atol=1e-7) and abs(float(np.dot(a, a)) - 1.0) < 1e-5
+    assert H.ssh_threshold_raw(0.7) == np.float32((np.float32(0.7) * np.float32(2) - np.float32(1)) / (np.float32(1) / np.float32(16129)))
+    assert abs(H.ssh_vector_score(16129.0) - 1.0) < 1e-6 and abs(H.ssh_vector_score(0.0) - 0.5) < 1e-7
+
+
+def test_host_without_gpu_degrades_to_empty(H):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu tests")
+    ix = H.ssh_index_create(2, None)
+    try:
+        assert H.ssh_shard_ok(ix, 0) == 0 and H.ssh_shard_create_error(ix, 0) == -3  # SS_EDEVICE, no CPU fallback
+        d, s, src, _, _, meta = _search(H, ix, [1, 2], np.ones(8, np.float32), 1, 2, 0, 10)
+        assert len(d) == 0 and meta[0] == 0 and meta[1] == 0
+        assert np.int64(meta[3]) == -3  # the C-ABI code that emptied the result is kept (search.rs:2461-2463 degrade)
+    finally:
+        H.ssh_index_destroy(ix)
+
+
+# ------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_cpp_index_two_shards_matches_oracle(H):
+    from oracle import oracle as O
+    n_docs, dim, S_n = 40_000, 64, 2
+    voc = [3000, 3600, 4000]
+    dl = O.lex_doclen(n_docs)
+    offs, docs, tfs = O.lex_corpus(n_docs, voc)
+    rows = O.vec_gen(O.VEC_SEED, 0, n_docs, dim)
+    qv = O.vec_gen(O.VECQ_SEED, 0, 1, dim, normalize=False)[0] * 3.0
+    dev = (C.c_int * S_n)(0, 0)
+    ix = H.ssh_index_create(S_n, dev)
+    oshards, orows = [], []
+    try:
+        for sid in range(S_n):  # doc g -> shard g % S, local id g // S (index.rs:5284)
+            sel = np.arange(sid, n_docs, S_n)
+            o2, d2, t2 = [0], [], []
+            for t in range(len(voc)):
+                d = docs[int(offs[t]):int(offs[t + 1])]
+                f = tfs[int(offs[t]):int(offs[t + 1])]
+                m = (d % S_n) == sid
+                d2.append(d[m] // S_n); t2.append(f[m]); o2.append(o2[-1] + int(m.sum()))
+            d2 = np.concatenate(d2).astype(np.uint32); t2 = np.concatenate(t2).astype(np.uint16)
+            o2 = np.asarray(o2, np.uint64)
+            dls = np.ascontiguousarray(dl[sel])
+            r = np.ascontiguousarray(rows[sel])
+            assert H.ssh_shard_ok(ix, sid) == 1
+            assert H.ssh_upload_lexical(ix, sid, len(sel), P(dls, u8p), len(voc), P(o2, u64p), P(d2, u32p), P(t2, u16p)) == 0
+            assert H.ssh_upload_vectors(ix, sid, len(sel), dim, P(r, f32p), None) == 0
+            oshards.append(O.Shard(len(sel), dls, o2, d2, t2))
+            orows.append(r)
+        k = 20
+        qn = O.normalize(qv)
+        lex_d, lex_s, vec_d, vec_s, lex_tot = [], [], [], [], 0
+        for sid in range(S_n):
+            od, os_, otot = oshards[sid].search_exhaustive([0, 1, 2], O.OP_OR, k)
+            lex_d += [int(x) * S_n + sid for x in od]; lex_s += list(os_); lex_tot += otot
+            vd, vs, _, _ = O.vec_search(orows[sid], qn, k)
+            vec_d += [int(x) * S_n + sid for x in vd]; vec_s += list(vs)
+        for mode in (0, 1, 2):  # Lexical, Vector, Hybrid
+            d, s, src, ls, vsc, meta = _search(H, ix, [0, 1, 2], qv, 1, mode, 0, k)
+            od, os_, osrc = O.merge(mode, (lex_d, lex_s), (vec_d, vec_s), 0, k)
+            assert len(d) == len(od) == k and meta[0] == k and np.int64(meta[3]) == 0
+            assert np.allclose(s, os_, rtol=REL, atol=2e-6)
+            band = abs(float(os_[-1])) * REL + 2e-6
+            assert {int(x) for x, y in zip(d, s) if y > os_[-1] + band} == {int(x) for x, y in zip(od, os_) if y > os_[-1] + band}
+            if mode == 0:
+                assert meta[1] == lex_tot and np.all(src == 0) and np.allclose(ls, s)
+            if mode == 1:
+                assert meta[2] == n_docs and np.all(src == 1)  # AnnMode::All observes every record
+                assert np.allclose(vsc, (s / np.float32(16129.0) + 1) / 2, rtol=1e-6)
+            if mode == 2:
+                assert set(src.tolist()) <= {0, 1, 2}
+        # offset / length are applied after the merge (search.rs:2109-2119)
+        d0, s0, *_ = _search(H, ix, [0, 1, 2], None, 1, 0, 0, 12)
+        d1, s1, *_ = _search(H, ix, [0, 1, 2], None, 1, 0, 5, 7)
+        assert np.array_equal(d0[5:12], d1) and np.array_equal(s0[5:12], s1)
+        # the per-shard seam drains its own offset (search.rs:3585-3593)
+        doc = np.zeros(10, np.uint64); sc = np.zeros(10, np.float32); meta = np.zeros(4, np.uint64)
+        n = H.ssh_search_lexical_shard(ix, 0, P(np.array([1, 2], np.uint32), u32p), 2, 0, 3, 7, 2, 10, P(doc, u64p), P(sc, f32p), P(meta, u64p))
+        od, os_, otot = oshards[0].search_exhaustive([1, 2], O.OP_AND, 10)
+        assert n == min(7, max(0, len(od) - 3)) and meta[1] == otot
+        assert np.allclose(sc[:n], os_[3:3 + n], rtol=REL)
+    finally:
+        H.ssh_index_destroy(ix)
+
+
+@pytest.mark.gpu
+def test_cpp_coalescer_batches_concurrent_queries(H):
+    from oracle import oracle as O
+    n_rows, dim, nq, k = 6000, 96, 40, 10
+    rows = O.vec_gen(21, 0, n_rows, dim)
+    qs = O.vec_gen(22, 0, nq, dim)
+    ix = H.ssh_index_create(1, None)
+    try:
+        assert H.ssh_upload_vectors(ix, 0, n_rows, dim, P(rows, f32p), None) == 0
+        doc = np.zeros((nq, k), np.uint64); sc = np.zeros((nq, k), np.float32); cnt = np.zeros(nq, np.uint32)
+        batches = H.ssh_coalesced_vector_search(ix, 0, nq, P(qs, f32p), k, 64, 20000, P(doc, u64p), P(sc, f32p), P(cnt, u32p))
+        assert 1 <= batches < nq  # concurrent callers share device passes
+        for i in range(nq):
+            od, os_, _, _ = O.vec_search(rows, qs[i], k)
+            assert cnt[i] == k and np.allclose(sc[i], os_, rtol=REL, atol=2e-6)
+            assert set(map(int, doc[i][:5])) <= set(map(int, od))
+    finally:
+        H.ssh_index_destroy(ix)
