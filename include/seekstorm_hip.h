@@ -99,8 +99,9 @@ int ss_bm25_search_dev(ss_shard* s, uint32_t n_queries, const ss_bm25_query* d_q
 
 /* ------------------------------------------------------------------ vector image
  * rows: row-major [n_rows x dim] f32, already L2-normalised for cosine (vector.rs:585-596); the uploader of
- * a real vector.bin strips the 24-byte VectorHeader (vector.rs:62-73).  row_doc_ids may be NULL (= row index);
- * several records per doc (vector.rs:441-452 dedup) are rejected with SS_ENOTSUP for now. */
+ * a real vector.bin strips the 24-byte VectorHeader (vector.rs:62-73).  row_doc_ids may be NULL (= row index).
+ * Several records may share a doc id (one per indexed field x chunk, vector.rs:561-576): the search then returns each
+ * doc once with its best record's score, as TopK::push does (vector.rs:441-452, 462-473). */
 int ss_vec_upload(ss_shard* s, uint64_t n_rows, uint32_t dim, const float* rows, const uint32_t* row_doc_ids);
 /* Device-side synthetic matrix (generator = oracle so_vec_gen, uniform(-1,1) then normalize_f32). */
 int ss_vec_synth(ss_shard* s, uint64_t seed, uint64_t n_rows, uint32_t dim);

@@ -58,7 +58,7 @@ static void free_vec(ss_shard* s) {
   void* ptrs[] = {s->d_X, s->d_row_doc, s->d_Qf, s->d_vstate, s->d_cand};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->d_X = nullptr; s->d_row_doc = nullptr; s->d_Qf = nullptr; s->d_vstate = nullptr; s->d_cand = nullptr;
-  s->n_rows = s->n_rows_pad = 0; s->dim = s->dim_pad = 0;
+  s->n_rows = s->n_rows_pad = 0; s->dim = s->dim_pad = 0; s->vec_multi_record = false;
 }
 static void free_bm25(ss_shard* s) {
   void* ptrs[] = {s->d_post, s->d_term_base, s->d_sub_off, s->d_comp};
@@ -252,10 +252,12 @@ static int vec_alloc(ss_shard* s, uint64_t n_rows, uint32_t dim) {
 int ss_vec_upload(ss_shard* s, uint64_t n_rows, uint32_t dim, const float* rows, const uint32_t* row_doc_ids) {
   if (!s || !rows || n_rows == 0 || dim == 0) return SS_EINVAL;
   if (n_rows > 0xFFFFFFFEull) return SS_ENOTSUP;
-  if (row_doc_ids) {  // several records per doc (vector.rs:441-452) are not handled on device yet
+  bool multi = false;
+  if (row_doc_ids) {  // several records per doc (one per field x chunk, vector.rs:561-576) -> dedup in the refine kernel
     std::vector<uint32_t> tmp(row_doc_ids, row_doc_ids + n_rows);
     std::sort(tmp.begin(), tmp.end());
-    if (std::adjacent_find(tmp.begin(), tmp.end()) != tmp.end()) return SS_ENOTSUP;
+    multi = std::adjacent_find(tmp.begin(), tmp.end()) != tmp.end();
+    if (!tmp.empty() && tmp.back() == SS_NO_DOC) return SS_EINVAL;
   }
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
@@ -264,6 +266,7 @@ int ss_vec_upload(ss_shard* s, uint64_t n_rows, uint32_t dim, const float* rows,
   if (rc) { free_vec(s); return rc; }
   SS_HIP(hipMemcpy2DAsync(s->d_X, (size_t)s->dim_pad * sizeof(float), rows, (size_t)dim * sizeof(float),
                           (size_t)dim * sizeof(float), n_rows, hipMemcpyHostToDevice, s->stream));
+  s->vec_multi_record = multi;
   if (row_doc_ids) {
     SS_HIP(hipMalloc(&s->d_row_doc, n_rows * sizeof(uint32_t)));
     SS_HIP(hipMemcpyAsync(s->d_row_doc, row_doc_ids, n_rows * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));

@@ -64,6 +64,7 @@ struct ss_shard {
   // ---- vector image
   float* d_X = nullptr;          // [n_rows_pad][dim_pad]
   uint32_t* d_row_doc = nullptr; // optional row -> doc id
+  bool vec_multi_record = false; // several records per doc: TopK::push dedup (vector.rs:441-452) in the refine kernel
   uint64_t n_rows = 0, n_rows_pad = 0;
   uint32_t dim = 0, dim_pad = 0;
   // vector workspace (one 64-query batch in flight per shard)

@@ -199,10 +199,36 @@ vec_scan_kernel(const float* __restrict__ X, uint32_t dim_pad, unsigned long lon
 // ---------------------------------------------------------------- refine: exact top-k of the candidates, raise tau
 // One workgroup per query.  Sorts the (<= VS_CAP) candidate keys descending in LDS (bitonic), keeps the best k
 // at the front of the buffer, sets tau = k-th best score (TopK::push admits only score > current minimum).
+// With several records per doc (one per indexed field x chunk, vector.rs:561-576) TopK::push keeps ONE entry per doc
+// holding its best score (vector.rs:441-452, 462-473): candidates are first sorted by (doc, key desc), every entry
+// but the first of a doc is dropped, then the survivors are sorted by key.
+__device__ __forceinline__ void vr_bitonic(unsigned long long* keys, uint32_t* docs, uint32_t np, bool by_doc) {
+  for (uint32_t size = 2; size <= np; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      for (uint32_t i = threadIdx.x; i < (np >> 1); i += blockDim.x) {
+        uint32_t lo = 2 * i - (i & (stride - 1));
+        uint32_t hi = lo + stride;
+        bool desc = ((lo & size) == 0);
+        unsigned long long a = keys[lo], b = keys[hi];
+        bool a_before_b;  // order: by_doc ? (doc asc, key desc) : (key desc)
+        if (by_doc) {
+          uint32_t da = docs[lo], db = docs[hi];
+          a_before_b = da != db ? da < db : a > b;
+          if (a_before_b != desc && !(da == db && a == b)) { keys[lo] = b; keys[hi] = a; docs[lo] = db; docs[hi] = da; }
+        } else {
+          if ((a < b) == desc) { keys[lo] = b; keys[hi] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 __global__ void __launch_bounds__(1024) vec_refine_kernel(VState* __restrict__ st, unsigned long long* __restrict__ cand,
-                                                         uint32_t k) {
+                                                         uint32_t k, const uint32_t* __restrict__ row_doc /* non-null: dedup */) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long* keys = (unsigned long long*)smem;
+  uint32_t* docs = (uint32_t*)(smem + VS_CAP * sizeof(unsigned long long));
   const uint32_t q = blockIdx.x;
   const uint32_t raw = st->cnt[q];
   const uint32_t kept = st->kept[q];
@@ -215,27 +241,39 @@ __global__ void __launch_bounds__(1024) vec_refine_kernel(VState* __restrict__ s
   uint32_t np = 64;
   while (np < n) np <<= 1;
   unsigned long long* base = cand + (size_t)q * VS_CAP;
-  for (uint32_t i = threadIdx.x; i < np; i += blockDim.x) keys[i] = i < n ? base[i] : 0ull;
-  __syncthreads();
-  for (uint32_t size = 2; size <= np; size <<= 1) {
-    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-      for (uint32_t i = threadIdx.x; i < (np >> 1); i += blockDim.x) {
-        uint32_t lo = 2 * i - (i & (stride - 1));
-        uint32_t hi = lo + stride;
-        bool desc = ((lo & size) == 0);
-        unsigned long long a = keys[lo], b = keys[hi];
-        if ((a < b) == desc) { keys[lo] = b; keys[hi] = a; }
-      }
-      __syncthreads();
-    }
+  for (uint32_t i = threadIdx.x; i < np; i += blockDim.x) {
+    const unsigned long long key = i < n ? base[i] : 0ull;
+    keys[i] = key;
+    if (row_doc) docs[i] = key ? row_doc[0xFFFFFFFFu - (uint32_t)key] : 0xFFFFFFFFu;  // empty slots sort last
   }
-  const uint32_t keep = n < k ? n : k;
+  __syncthreads();
+  if (row_doc) {
+    vr_bitonic(keys, docs, np, true);
+    // (doc asc, key desc): an entry whose predecessor has the same doc is a worse record of that doc
+    unsigned long long mine[8];
+    for (uint32_t j = 0, i = threadIdx.x; i < np; i += blockDim.x, j++)
+      mine[j] = (i > 0 && keys[i] && docs[i] == docs[i - 1]) ? 0ull : keys[i];
+    __syncthreads();
+    for (uint32_t j = 0, i = threadIdx.x; i < np; i += blockDim.x, j++) keys[i] = mine[j];
+    __syncthreads();
+  }
+  vr_bitonic(keys, docs, np, false);
+  // number of live entries after the dedup
+  __shared__ uint32_t live;
+  if (threadIdx.x == 0) live = 0;
+  __syncthreads();
+  uint32_t cnt = 0;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) cnt += keys[i] != 0ull;
+  if (cnt) atomicAdd(&live, cnt);
+  __syncthreads();
+  const uint32_t nl = live;
+  const uint32_t keep = nl < k ? nl : k;
   for (uint32_t i = threadIdx.x; i < keep; i += blockDim.x) base[i] = keys[i];
   if (threadIdx.x == 0) {
     st->total[q] += (unsigned long long)(n - kept);
     st->cnt[q] = keep;
     st->kept[q] = keep;
-    if (n >= k && k > 0) st->tau[q] = ord2f((uint32_t)(keys[k - 1] >> 32));
+    if (nl >= k && k > 0) st->tau[q] = ord2f((uint32_t)(keys[k - 1] >> 32));
   }
 }
 
@@ -276,7 +314,7 @@ int ssi_vec_alloc_ws(ss_shard* s) {
   if (!attr_done) {
     SS_HIP(hipFuncSetAttribute((const void*)vec_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, VS_LDS));
     SS_HIP(hipFuncSetAttribute((const void*)vec_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               VS_CAP * sizeof(unsigned long long)));
+                               VS_CAP * (sizeof(unsigned long long) + sizeof(uint32_t))));
     attr_done = true;
   }
   return SS_OK;
@@ -323,7 +361,8 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const float* d_queries, uint32_t k,
       uint32_t grid = std::min<uint32_t>(c, 512);
       vec_scan_kernel<<<grid, VS_WAVES * 64, VS_LDS, st>>>(s->d_X, s->dim_pad, (unsigned long long)s->n_rows, s->d_Qf,
                                                            nch, tile0, c, vst, cand);
-      vec_refine_kernel<<<SS_VEC_BATCH, 1024, VS_CAP * sizeof(unsigned long long), st>>>(vst, cand, k);
+      vec_refine_kernel<<<SS_VEC_BATCH, 1024, VS_CAP * (sizeof(unsigned long long) + sizeof(uint32_t)), st>>>(
+          vst, cand, k, s->vec_multi_record ? s->d_row_doc : nullptr);
       tile0 += c;
     }
     ssi_prof_end(s, 1, st, e0, e1);

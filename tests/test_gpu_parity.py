@@ -61,9 +61,34 @@ def test_vector_self_query_and_row_ids(S, O):
     doc, score, cnt, tot = sh.search_vector_batch(rows[[5, 1234, 2999]], 10)
     assert list(doc[:, 0]) == [ids[5], ids[1234], ids[2999]]
     assert np.allclose(score[:, 0], 1.0, atol=1e-5)
-    # several records per doc is outside the implemented scope and must be refused loudly, not mis-answered
-    with pytest.raises(S.SeekStormHipError):
-        sh.upload_vectors(rows, np.zeros(3000, np.uint32))
+    sh.close()
+
+
+@pytest.mark.parametrize("n_rows,n_docs,k", [(6000, 1500, 100), (3000, 40, 100), (5000, 5000, 10)])
+def test_vector_multi_record_docs_dedup(S, O, n_rows, n_docs, k):
+    """several records per doc (one per field x chunk, vector.rs:561-576): each doc once, with its best score
+    (TopK::push dedup, vector.rs:441-452 / 462-473)"""
+    dim = 64
+    rows = O.vec_gen(31, 0, n_rows, dim)
+    rng = np.random.default_rng(7)
+    ids = rng.integers(0, n_docs, n_rows).astype(np.uint32) if n_docs < n_rows else rng.permutation(n_rows).astype(np.uint32)
+    qs = O.vec_gen(32, 0, 5, dim)
+    sh = S.Shard(0)
+    sh.upload_vectors(rows, ids)
+    doc, score, cnt, tot = sh.search_vector_batch(qs, k)
+    for i in range(len(qs)):
+        od, os_, _, _ = O.vec_search(rows, qs[i], k, row_doc_ids=ids)
+        full = rows @ qs[i]
+        best = {}
+        for r in range(n_rows):  # independent statement of the semantics: per-doc maximum, then top-k
+            d = int(ids[r])
+            best[d] = max(best.get(d, -2.0), float(full[r]))
+        exp = sorted(best.values(), reverse=True)[:k]
+        n = int(cnt[i])
+        assert n == len(od) == min(k, len(best))
+        assert len(set(map(int, doc[i][:n]))) == n  # every doc once
+        assert np.allclose(score[i][:n], exp, rtol=REL, atol=2e-6)
+        _check_topk(doc[i], score[i], cnt[i], od, os_, abs_tol=2e-6)
     sh.close()
 
 
