@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 --pmc databases collected by `tools/collect_pmc.sh` into profiles/<tag>_pmc_summary.md and
-profiles/pmc_traffic.json (HBM bytes per launch of the dominant kernels, corrected as MI355X_MICROARCH.md section
-HBM prescribes: FETCH_SIZE/WRITE_SIZE are in KiB and FETCH_SIZE reports exactly half of a wide coalesced read on
-gfx950 -> bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024).
-Usage: python tools/pmc_summary.py <gpurun_out dir> <tag> <full_bm25_launches> <vec_passes>"""
+"""Turns the rocprofv3 --pmc databases collected by `tools/collect_pmc.sh all <tag>` (separate passes per counter group:
+fetch, write, sqA, sqB, sqC -- never combined with API tracing) into profiles/<tag>_pmc_summary.md and
+profiles/pmc_traffic.json.
+
+HBM bytes follow MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are KiB, and on gfx950 FETCH_SIZE reports
+exactly half of a wide coalesced read -> bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  BM25 figures are per FULL launch
+(the dispatches with the largest grid: 1000-query batches; single-query latency probes are excluded); vector figures
+are per 64-query pass (7 row-chunk launches of vec_scan_kernel).
+Usage: python tools/pmc_summary.py <gpurun_out dir> <tag>"""
 import json
 import os
 import sqlite3
@@ -11,54 +15,80 @@ import sys
 from collections import defaultdict
 
 
-def totals(db, pat):
+def load(db, pat):
+    """-> {dispatch_id: {'grid': g, 'dur': ns, counter: value}} for kernels whose name contains pat"""
     cur = sqlite3.connect(db).cursor()
-    cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
-    ix = {c: i for i, c in enumerate(cols)}
-    kn = "kernel_name" if "kernel_name" in ix else "name"
-    agg = defaultdict(float)
-    disp = set()
-    for r in cur.execute("select * from counters_collection"):
-        if pat in r[ix[kn]]:
-            agg[r[ix["counter_name"]]] += float(r[ix["value"]])
-            disp.add(r[ix["dispatch_id"]])
-    return dict(agg), len(disp)
+    out = defaultdict(dict)
+    for did, name, grid, dur, cn, val in cur.execute(
+            "select dispatch_id, kernel_name, grid_size, duration, counter_name, value from counters_collection"):
+        if pat in name:
+            d = out[did]
+            d["grid"], d["dur"] = grid, dur
+            d[cn] = d.get(cn, 0.0) + float(val)
+    return out
 
 
 def main():
-    d, tag, n_bm, n_vec = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
-    out = {}
-    lines = [f"# PMC summary ({tag})", "",
-             "rocprofv3 --pmc <counters> --kernel-trace -- python bench.py --no-cpu --steps 4 --warmup 1 (separate passes per counter group).",
-             f"Per-launch figures divide the kernel totals by the number of full-size launches in that run "
-             f"({n_bm} BM25 batches of 1000 queries; {n_vec} vector passes of 64 queries = 7 row-chunk launches each); "
-             "the 60 single-query latency probes add < 0.4 % to the BM25 totals.", ""]
-    for kern, pat, n in (("bm25", "bm25_scan", n_bm), ("vector", "vec_scan_kernel", n_vec)):
-        f, _ = totals(os.path.join(d, "pmc_FETCH_SIZE", "x_results.db"), pat)
-        w, _ = totals(os.path.join(d, "pmc_WRITE_SIZE", "x_results.db"), pat)
-        s, nd = totals(os.path.join(d, "pmc_SQ_VALU_MFMA_BUSY_CYCLES", "x_results.db"), pat)
-        fetch = f.get("FETCH_SIZE", 0.0)
-        write = w.get("WRITE_SIZE", 0.0)
-        hbm = (2.0 * fetch + write) * 1024.0 / n
-        out[kern] = {"hbm_bytes_per_launch": hbm, "fetch_size_kib_total": fetch, "write_size_kib_total": write, "launches": n}
-        lines += [f"## {kern}: `{pat}`", "",
-                  f"- FETCH_SIZE total {fetch:.4g} KiB, WRITE_SIZE total {write:.4g} KiB over {n} full launches",
-                  f"- HBM traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / {n} = **{hbm / 1e9:.3f} GB**"]
-        gui = f.get("GRBM_GUI_ACTIVE", 0.0)
-        if gui:
-            lines.append(f"- GRBM_GUI_ACTIVE total {gui:.4g} (summed over the 8 XCDs) -> {gui / 8 / n:.4g} shader cycles per launch")
-            out[kern]["cycles_per_launch"] = gui / 8 / n
-        for c in sorted(s):
-            lines.append(f"- {c}: total {s[c]:.4g}, per launch {s[c] / n:.4g}")
-        if s.get("SQ_VALU_MFMA_BUSY_CYCLES") and gui:
-            util = s["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * gui / 8)
+    d, tag = sys.argv[1], sys.argv[2]
+    db = lambda g: os.path.join(d, f"pmc_{tag}_{g}", "x_results.db")
+    out, lines = {}, [f"# PMC summary ({tag})", "",
+                      "`rocprofv3 --pmc <group> --kernel-trace -- python bench.py --workload all --no-cpu --steps 4 --warmup 1`, "
+                      "one run per counter group (tools/collect_pmc.sh).  SQ_* wave counters are in quad-cycles "
+                      "(MI355X_MICROARCH.md); GRBM_GUI_ACTIVE is summed over the 8 XCDs.", ""]
+    for kern, pat in (("bm25", "bm25_scan_fast_kernel"), ("vector", "vec_scan_kernel")):
+        groups = {g: load(db(g), pat) for g in ("fetch", "write", "sqA", "sqB", "sqC") if os.path.exists(db(g))}
+
+        def sel(g):
+            rows = list(groups[g].values())
+            if kern == "bm25":
+                gmax = max(r["grid"] for r in rows)
+                rows = [r for r in rows if r["grid"] == gmax]
+                return rows, len(rows)
+            return rows, max(1, len(rows) // 7)
+
+        def tot(g, c):
+            rows, n = sel(g)
+            return sum(r.get(c, 0.0) for r in rows), n
+
+        fetch, n = tot("fetch", "FETCH_SIZE")
+        write, nw = tot("write", "WRITE_SIZE")
+        gui, _ = tot("fetch", "GRBM_GUI_ACTIVE")
+        hbm = (2.0 * fetch / n + write / nw) * 1024.0
+        rows, _ = sel("fetch")
+        dur_ms = sum(r["dur"] for r in rows) / n / 1e6
+        unit = "full launch (1000 queries)" if kern == "bm25" else "64-query pass (7 launches)"
+        out[kern] = {"hbm_bytes_per_launch": hbm, "fetch_size_kib_total": fetch, "write_size_kib_total": write,
+                     "launches": n, "cycles_per_launch": gui / 8 / n, "kernel_ms_per_launch_profiled": dur_ms}
+        lines += [f"## {kern}: `{pat}` -- per {unit}, {n} of them", "",
+                  f"- FETCH_SIZE {fetch / n:.4g} KiB, WRITE_SIZE {write / nw:.4g} KiB -> HBM traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 = "
+                  f"**{hbm / 1e9:.3f} GB**",
+                  f"- kernel time under the profiler {dur_ms:.3f} ms; GRBM_GUI_ACTIVE / 8 = {gui / 8 / n:.4g} shader cycles "
+                  f"(effective clock {gui / 8 / n / dur_ms / 1e6:.2f} GHz)"]
+        cu_cycles = gui / 8 / n * 256
+        vals = {}
+        for g in ("sqA", "sqB", "sqC"):
+            if g not in groups:
+                continue
+            rows, ng = sel(g)
+            names = sorted({c for r in rows for c in r if c not in ("grid", "dur")})
+            for c in names:
+                vals[c] = sum(r.get(c, 0.0) for r in rows) / ng
+        for c in sorted(vals):
+            if c != "GRBM_GUI_ACTIVE":
+                lines.append(f"- {c}: {vals[c]:.4g}")
+        if vals.get("SQ_WAVE_CYCLES"):
+            wc = vals["SQ_WAVE_CYCLES"]
+            lines.append(f"- wave-time split: issuing {100 * vals.get('SQ_ACTIVE_INST_ANY', 0) / wc:.0f} %, waiting on s_waitcnt / barrier "
+                         f"{100 * vals.get('SQ_WAIT_ANY', 0) / wc:.0f} %, issue-stalled {100 * vals.get('SQ_WAIT_INST_ANY', 0) / wc:.0f} %")
+        if vals.get("SQ_LDS_IDX_ACTIVE"):
+            lines.append(f"- LDS busy {100 * vals['SQ_LDS_IDX_ACTIVE'] / cu_cycles:.0f} % of CU cycles, of which bank conflicts "
+                         f"{100 * vals.get('SQ_LDS_BANK_CONFLICT', 0) / vals['SQ_LDS_IDX_ACTIVE']:.0f} %")
+            out[kern]["lds_busy"] = vals["SQ_LDS_IDX_ACTIVE"] / cu_cycles
+        if vals.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+            util = vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * gui / 8 / n)
             out[kern]["mfma_util"] = util
             lines.append(f"- **MFMA utilisation** = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x shader cycles) = **{100 * util:.1f} %** "
-                         "(busy cycles = 64 per v_mfma_f32_32x32x2_f32)")
-        if s.get("SQ_WAVE_CYCLES"):
-            wc = s["SQ_WAVE_CYCLES"]
-            lines.append(f"- wave-time split: active {100 * s.get('SQ_ACTIVE_INST_ANY', 0) / wc:.0f} %, s_waitcnt/barrier wait "
-                         f"{100 * s.get('SQ_WAIT_ANY', 0) / wc:.0f} %, issue stall {100 * s.get('SQ_WAIT_INST_ANY', 0) / wc:.0f} %")
+                         "(64 busy cycles per v_mfma_f32_32x32x2_f32)")
         lines.append("")
     os.makedirs("profiles", exist_ok=True)
     open(os.path.join("profiles", f"{tag}_pmc_summary.md"), "w").write("\n".join(lines) + "\n")
