@@ -73,6 +73,13 @@ int ss_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen_bytes, ui
 int ss_bm25_synth(ss_shard* s, uint64_t seed, uint64_t n_docs, uint32_t n_terms, const uint32_t* thresh32,
                   const uint8_t* len_table1024);
 int ss_bm25_info(ss_shard* s, uint64_t* n_docs, float* avgdl, uint32_t* n_terms, uint64_t* n_postings);
+/* Search strategy.  AUTO: top-k of unions without exact counts (SS_RT_TOPK) and all intersections take the PRUNED path
+ * (the reference's block-max / sub-query pruning, intersection.rs:2224-2233, union.rs:1355-1405, as MaxScore over a
+ * probe index: only essential / shortest lists are read); everything else, and every request when the probe index
+ * did not fit in device memory, takes the EXHAUSTIVE scan.  Both return identical results.  SS_BM25_PRUNED fails with
+ * SS_ENOTSUP where pruning cannot serve the request (exact union counts, > 4 terms, k > 128). */
+enum { SS_BM25_AUTO = 0, SS_BM25_EXHAUSTIVE = 1, SS_BM25_PRUNED = 2 };
+int ss_bm25_set_strategy(ss_shard* s, int strategy);
 /* posting_count per term (the df the host needs for idf, search.rs:3225-3230) */
 int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df_out);
 

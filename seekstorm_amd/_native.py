@@ -15,6 +15,7 @@ SS_MAX_QUERY_TERMS = 10
 SS_MAX_K = 1024
 SS_VEC_BATCH = 64
 OP_INTERSECTION, OP_UNION = 0, 1
+BM25_AUTO, BM25_EXHAUSTIVE, BM25_PRUNED = 0, 1, 2
 RT_COUNT, RT_TOPK, RT_TOPKCOUNT = 0, 1, 2
 MODE_LEXICAL, MODE_VECTOR, MODE_HYBRID = 0, 1, 2
 SRC_LEXICAL, SRC_VECTOR, SRC_HYBRID = 0, 1, 2
@@ -48,6 +49,7 @@ SYMBOLS = [
     ("ss_bm25_synth", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, u32p, u8p]),
     ("ss_bm25_info", C.c_int, [C.c_void_p, u64p, f32p, u32p, u64p]),
     ("ss_bm25_term_df", C.c_int, [C.c_void_p, C.c_uint32, u32p, u64p]),
+    ("ss_bm25_set_strategy", C.c_int, [C.c_void_p, C.c_int]),
     ("ss_bm25_search", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, u32p, f32p, u32p, u64p]),
     ("ss_bm25_search_dev", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

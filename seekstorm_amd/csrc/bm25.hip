@@ -68,7 +68,8 @@ __global__ void bm25_final_kernel(const u64* __restrict__ keys, const u64* __res
 
 // ---------------------------------------------------------------- host side
 int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t* d_out_doc,
-                    float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, uint32_t nt_max, hipStream_t st) {
+                    float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, bool has_or,
+                    uint32_t nt_max, hipStream_t st) {
   if (!s->d_post) return SS_ESTATE;
   if (nq == 0) return SS_OK;
   if (k > SS_MAX_K) return SS_EINVAL;
@@ -110,7 +111,16 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   p.count = (rt == SS_RT_TOPK) ? 0u : 1u;  // Topk: result_count_total is not required to be exact
   hipEvent_t e0 = nullptr, e1 = nullptr;
   ssi_prof_begin(s, 0, st, &e0, &e1);
-  const int rc = ssi_bm25_launch_scan(p, nt_max, has_and, KPL, st);
+  // Strategy.  Pruned (probe index, bm25_probe.hip): top-k of unions without exact counts, and intersections with any
+  // result type -- it reads only the essential / shortest lists.  Exhaustive (bm25_fast.hip): everything else (exact
+  // union counts need every posting), and whenever the probe index is absent or SS_BM25_EXHAUSTIVE is selected.
+  int rc = SS_ENOTSUP;
+  const bool prunable = s->bm_strategy != SS_BM25_EXHAUSTIVE && (!has_or || rt == SS_RT_TOPK);
+  if (prunable) rc = ssi_bm25_launch_probe(p, s->d_probe, s->d_umax, nt_max, KPL, st);
+  if (rc == SS_ENOTSUP) {
+    if (s->bm_strategy == SS_BM25_PRUNED) return SS_ENOTSUP;
+    rc = ssi_bm25_launch_scan(p, nt_max, has_and, KPL, st);
+  }
   ssi_prof_end(s, 0, st, e0, e1);
   if (rc) return rc;
 

@@ -1,0 +1,269 @@
+// BM25 top-k with MaxScore-style pruning over a probe index (no accumulator tile): the gfx950 counterpart of the
+// reference's "touch as few postings as possible" strategy -- block-max ordered intersection (intersection.rs:2023-2301),
+// sub-query decomposition of unions guarded by list maxima (union.rs:1308-1479: a subset is only evaluated if the sum of
+// its max_list_score can beat the heap minimum) -- restated for a wave:
+//
+//   * terms are ordered by their score upper bound U_t = idf_t * max weight of the list (index.rs:3239 max_list_score);
+//   * with thr = the k-th best score known for the query (own list or any other partition's, shared through tau[]), the
+//     longest suffix of terms whose U sums to less than thr is NON-ESSENTIAL: a doc made only of them cannot enter the
+//     top-k.  Only the posting streams of essential terms are read ("drivers"), 64 consecutive postings per load, one per
+//     lane, regardless of sub-block boundaries (each lane derives its sub-block from the stream position);
+//   * every other term is PROBED for the driver's doc: one 16-byte record {64 doc bits, index of their first posting}
+//     tells membership and position, and only on a hit is that term's posting fetched for its weight.  Probing stops as
+//     soon as partial score + remaining upper bounds < thr.  A doc present in several essential terms is evaluated by
+//     the first; driver streams run one after the other (largest U first), so by the time the second stream would
+//     start the threshold has usually made it non-essential and it is skipped altogether;
+//   * intersections use the shortest list as the only driver and require a hit in every other term; their exact match
+//     count is the number of surviving drivers, so Count / TopkCount need no exhaustive pass either.
+//
+// Scores are combined in query-term order with the same fma chain as the exhaustive kernels, so both produce bit-identical
+// scores.  One wave per (query, partition); no LDS beyond the weight table; G chunks are evaluated together so that
+// their gathers are in flight at the same time.
+#include <type_traits>
+
+#include "bm25_dev.h"
+
+constexpr int PB_WAVES = 4;
+
+
+template <int KPL>
+__device__ __attribute__((noinline)) BmTop<KPL> bm_offer_lane_keys(BmTop<KPL> T, u64 key, uint32_t k, uint32_t* tau_q) {
+  const float wsc_in = T.wsc;
+  T.worst = topk_offer<KPL>(T.keys, key, 0ull, 0ull, 0ull, T.worst, k);
+  if (T.worst) T.wsc = __uint_as_float((uint32_t)(T.worst >> 32));
+  if (tau_q && T.wsc > wsc_in && __lane_id() == 0) atomicMax(tau_q, __float_as_uint(T.wsc));
+  return T;
+}
+
+// weight of one posting: table for tf < 16, formula above
+__device__ __forceinline__ float pb_weight(uint32_t p) {
+  float w = lds_ldf(((p >> 16) & 0x3FFCu) + 1024u);
+  if (p & BM_BIG_TF_MASK) {
+    const float tf = (float)bm_tf(p);
+    w = tf * BM_K1P * __builtin_amdgcn_rcpf(tf + lds_ldf(bm_len(p) * 4u));
+  }
+  return w;
+}
+
+template <int NT, int KPL>
+__global__ void __launch_bounds__(PB_WAVES * 64) bm25_probe_kernel(
+    const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base, const uint32_t* __restrict__ sub_off,
+    const float* __restrict__ comp_g, const uint4* __restrict__ probe, const float* __restrict__ umax,
+    const ss_bm25_query* __restrict__ qs, unsigned long long* __restrict__ part_keys, unsigned long long* __restrict__ total,
+    uint32_t* tau, uint32_t n_sub, uint32_t n_terms, uint32_t nq, uint32_t P, uint32_t k, uint32_t count) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 256 + 4096; i += PB_WAVES * 64) ((float*)smem)[i] = comp_g[i];
+  __syncthreads();
+
+  const uint32_t a = blockIdx.x * PB_WAVES + w;
+  if (a >= nq * P) return;
+  const uint32_t qi = a % nq, part = a / nq;
+  const ss_bm25_query* __restrict__ Q = qs + qi;
+  const uint32_t nt = Q->n_terms;
+  const bool is_and = (Q->op == SS_OP_INTERSECTION) && nt > 1;
+  const uint32_t row_len = n_sub + 1;
+
+  // per-term state in PROCESSING order (sorted below); qpos = position in the query (order of the score sum)
+  const uint32_t* tptr[NT];
+  const uint32_t* rowp[NT];
+  const uint4* prow[NT];
+  float idf[NT], U[NT];
+  uint32_t qpos[NT];
+  unsigned long long size[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    const bool have = (uint32_t)t < nt;
+    const uint32_t term = have ? Q->term[t] : n_terms;
+    idf[t] = have ? Q->idf[t] : 0.f;
+    U[t] = idf[t] * umax[term] * 1.000002f;  // upper bound of idf * w over the list (rcp-approximated weights included)
+    qpos[t] = t;
+    tptr[t] = post + term_base[term] * 4ull;
+    rowp[t] = sub_off + (size_t)term * row_len;
+    prow[t] = probe + (size_t)term * n_sub * (BM_SUB / 64);
+    size[t] = have ? term_base[term + 1] - term_base[term] : ~0ull;
+  }
+  // sort: unions by U descending (absent terms have U = 0: last), intersections by list size ascending (absent: last)
+  auto cswap = [&](int x, int y) {
+    const bool sw = is_and ? (size[y] < size[x]) : (U[y] > U[x]);
+    if (sw) {
+      { auto t_ = tptr[x]; tptr[x] = tptr[y]; tptr[y] = t_; }
+      { auto t_ = rowp[x]; rowp[x] = rowp[y]; rowp[y] = t_; }
+      { auto t_ = prow[x]; prow[x] = prow[y]; prow[y] = t_; }
+      { float t_ = idf[x]; idf[x] = idf[y]; idf[y] = t_; }
+      { float t_ = U[x]; U[x] = U[y]; U[y] = t_; }
+      { uint32_t t_ = qpos[x]; qpos[x] = qpos[y]; qpos[y] = t_; }
+      { auto t_ = size[x]; size[x] = size[y]; size[y] = t_; }
+    }
+  };
+  if (NT == 2) { cswap(0, 1); }
+  if (NT == 3) { cswap(0, 1); cswap(1, 2); cswap(0, 1); }
+  if (NT == 4) { cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2); }
+  float SU[NT + 1];  // SU[j] = sum of U[j..]
+  SU[NT] = 0.f;
+#pragma unroll
+  for (int j = NT - 1; j >= 0; j--) SU[j] = SU[j + 1] + U[j];
+
+  const uint32_t s_begin = (uint32_t)(((u64)n_sub * part) / P);
+  const uint32_t s_end = (uint32_t)(((u64)n_sub * (part + 1)) / P);
+  BmTop<KPL> T;
+#pragma unroll
+  for (int r = 0; r < KPL; r++) T.keys[r] = 0ull;
+  T.worst = 0ull;
+  T.wsc = -1.0f;
+  T.matched = 0;
+  uint32_t* tau_q = tau + qi;
+  const int lane4 = lane * 4;
+  constexpr int G = 4;  // chunks (64 driver postings each) evaluated together: their gathers overlap
+
+  // score in QUERY order with the exhaustive kernels' fma chain (bit-identical results)
+  auto combine = [&](const float (&wv)[NT], uint32_t pres) -> float {
+    float score = 0.f;
+#pragma unroll
+    for (uint32_t qp = 0; qp < (uint32_t)NT; qp++) {
+#pragma unroll
+      for (int t = 0; t < NT; t++)
+        if (qpos[t] == qp && (pres >> t) & 1u) score = fmaf(idf[t], wv[t], score);
+    }
+    return score;
+  };
+
+  // one driver stream: the postings of processing term J inside this partition's sub-block range
+  auto stream = [&](auto Jc) {
+    constexpr int J = decltype(Jc)::value;
+    const uint32_t x_begin = rowp[J][s_begin] * 4u, x_end = rowp[J][s_end] * 4u;  // dword range of the stream
+    if (x_begin == x_end) return;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[J], 0, (int)(x_end * 4u), BM_RSRC_FLAGS);
+    // sub-block boundaries of the driver (dword offsets), 64 per block load: lane i = sub-block blk0 + i
+    uint32_t blk0 = s_begin;
+    uint32_t vb = rowp[J][min(blk0 + (uint32_t)lane, s_end)] * 4u;
+    auto bnd = [&](uint32_t s) -> uint32_t {  // s in [blk0, blk0 + 64), uniform
+      return __builtin_amdgcn_readlane(vb, s - blk0);
+    };
+    uint32_t s_cur = s_begin;  // sub-block containing the stream position x (bnd(s_cur) <= x)
+    for (uint32_t x = x_begin; x < x_end; x += 64u * G) {
+      const float thr = fmaxf(T.wsc, __uint_as_float(__hip_atomic_load(tau_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+      if (!is_and && J > 0 && k && SU[J] < thr * 0.99999f) return;  // this and all later terms are non-essential now
+      uint32_t pg[G], tile[G];
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        pg[g] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane4 + g * 256, (int)(x * 4u), 0);
+        tile[g] = s_cur;
+      }
+      // each lane's sub-block: count the boundaries at or before its stream position
+      const uint32_t x_hi = min(x + 64u * G, x_end);
+      for (;;) {
+        if (s_cur + 1u - blk0 >= 64u) {  // next boundary lies outside the loaded block
+          blk0 = s_cur;
+          vb = rowp[J][min(blk0 + (uint32_t)lane, s_end)] * 4u;
+        }
+        if (s_cur + 1u > s_end) break;
+        const uint32_t b = bnd(s_cur + 1u);
+        if (b >= x_hi) break;
+        s_cur++;
+#pragma unroll
+        for (int g = 0; g < G; g++) tile[g] += (x + 64u * g + (uint32_t)lane) >= b ? 1u : 0u;
+      }
+      uint32_t dg[G], pres[G];
+      bool alive[G];
+      float wv[G][NT], known[G];
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        alive[g] = pg[g] != 0u;
+        dg[g] = ((pg[g] >> 2) & 0x1FFFu) - 1u;  // doc inside its sub-block
+        pres[g] = 1u << J;
+#pragma unroll
+        for (int t = 0; t < NT; t++) wv[g][t] = 0.f;
+        wv[g][J] = alive[g] ? pb_weight(pg[g]) : 0.f;
+        known[g] = idf[J] * wv[g][J];
+      }
+      float rest = SU[0] - U[J];
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        if (t == J || (uint32_t)t >= nt) continue;
+        bool any = false;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+          if (!is_and && k) alive[g] = alive[g] && (known[g] + rest) >= thr * 0.99999f;
+          any |= __ballot(alive[g]) != 0ull;
+        }
+        if (!any) break;
+        rest -= U[t];
+        uint4 rec[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+          rec[g] = make_uint4(0, 0, 0, 0);
+          if (alive[g]) rec[g] = prow[t][(size_t)tile[g] * (BM_SUB / 64) + (dg[g] >> 6)];
+        }
+        uint32_t pt[G];
+        bool hit[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+          const u64 bits = ((u64)rec[g].y << 32) | rec[g].x;
+          hit[g] = alive[g] && ((bits >> (dg[g] & 63u)) & 1ull);
+          if (is_and) alive[g] = hit[g];
+          else if (t < J && hit[g]) { alive[g] = false; hit[g] = false; }  // evaluated in the earlier term's stream
+          pt[g] = 0u;
+          if (hit[g]) pt[g] = tptr[t][rec[g].z + (uint32_t)__popcll(bits & ((1ull << (dg[g] & 63u)) - 1ull))];
+        }
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+          if (hit[g]) {
+            wv[g][t] = pb_weight(pt[g]);
+            pres[g] |= 1u << t;
+            known[g] += idf[t] * wv[g][t];
+          }
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        if (__ballot(alive[g]) == 0ull) continue;
+        if (count && is_and) T.matched += __popcll(__ballot(alive[g]));
+        if (k) {
+          const float score = combine(wv[g], pres[g]);
+          const bool cand = alive[g] && score >= thr && score > 0.f;
+          if (__ballot(cand)) {
+            const u64 key = cand ? (((u64)__float_as_uint(score) << 32) | (u64)(0xFFFFFFFFu - ((tile[g] << BM_SUB_LOG2) + dg[g]))) : 0ull;
+            const u64 key2 = key > T.worst ? key : 0ull;
+            if (__ballot(key2 != 0ull)) T = bm_offer_lane_keys<KPL>(T, key2, k, tau_q);
+          }
+        }
+      }
+    }
+  };
+  // drivers: unions -> every term in upper-bound order (a stream ends as soon as its term is non-essential);
+  // intersections -> the shortest list only
+  stream(std::integral_constant<int, 0>{});
+  if (!is_and) {
+    if (NT > 1 && nt > 1) stream(std::integral_constant<int, (NT > 1 ? 1 : 0)>{});
+    if (NT > 2 && nt > 2) stream(std::integral_constant<int, (NT > 2 ? 2 : 0)>{});
+    if (NT > 3 && nt > 3) stream(std::integral_constant<int, (NT > 3 ? 3 : 0)>{});
+  }
+
+  u64* out = part_keys + ((size_t)qi * P + part) * (64 * KPL);
+#pragma unroll
+  for (int r = 0; r < KPL; r++) out[r * 64 + lane] = T.keys[r];
+  if (lane == 0 && T.matched) atomicAdd(&total[qi], T.matched);
+}
+
+template <int NT, int KPL>
+static int launch_probe(const BmParams& p, const uint4* probe, const float* umax, hipStream_t st) {
+  const uint32_t A = p.nq * p.P;
+  bm25_probe_kernel<NT, KPL><<<(A + PB_WAVES - 1) / PB_WAVES, PB_WAVES * 64, BM_LUT_BYTES, st>>>(
+      p.post, p.term_base, p.sub_off, p.comp, probe, umax, p.q, p.part_keys, p.total, p.tau, p.n_sub, p.n_terms, p.nq, p.P, p.k,
+      p.count);
+  return SS_OK;
+}
+
+// returns SS_ENOTSUP when there is no instantiation for (nt_max, KPL): the caller falls back to the exhaustive kernels
+int ssi_bm25_launch_probe(const BmParams& p, const uint4* probe, const float* umax, uint32_t nt_max, int KPL, hipStream_t st) {
+  if (!probe || !umax || nt_max == 0 || nt_max > 4 || (KPL != 1 && KPL != 2)) return SS_ENOTSUP;
+  const int NT = nt_max <= 2 ? 2 : (int)nt_max;
+#define SS_P(NT_, KPL_) \
+  if (NT == NT_ && KPL == KPL_) return launch_probe<NT_, KPL_>(p, probe, umax, st);
+  SS_P(2, 1) SS_P(3, 1) SS_P(4, 1) SS_P(2, 2) SS_P(3, 2) SS_P(4, 2)
+#undef SS_P
+  return SS_ENOTSUP;
+}

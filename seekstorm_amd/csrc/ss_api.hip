@@ -61,9 +61,10 @@ static void free_vec(ss_shard* s) {
   s->n_rows = s->n_rows_pad = 0; s->dim = s->dim_pad = 0; s->vec_multi_record = false;
 }
 static void free_bm25(ss_shard* s) {
-  void* ptrs[] = {s->d_post, s->d_term_base, s->d_sub_off, s->d_comp};
+  void* ptrs[] = {s->d_post, s->d_term_base, s->d_sub_off, s->d_comp, s->d_probe, s->d_umax};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->d_post = nullptr; s->d_term_base = nullptr; s->d_sub_off = nullptr; s->d_comp = nullptr;
+  s->d_probe = nullptr; s->d_umax = nullptr;
   s->bm_n_docs = 0; s->bm_n_terms = 0; s->bm_n_sub = 0; s->bm_n_post = 0;
   s->h_df.clear(); s->bm_n_post_pad = 0;
 }
@@ -148,6 +149,13 @@ int ss_bm25_synth(ss_shard* s, uint64_t seed, uint64_t n_docs, uint32_t n_terms,
   return rc;
 }
 
+int ss_bm25_set_strategy(ss_shard* s, int strategy) {
+  if (!s || strategy < SS_BM25_AUTO || strategy > SS_BM25_PRUNED) return SS_EINVAL;
+  std::lock_guard<std::mutex> g(s->mu);
+  s->bm_strategy = strategy;
+  return SS_OK;
+}
+
 int ss_bm25_info(ss_shard* s, uint64_t* n_docs, float* avgdl, uint32_t* n_terms, uint64_t* n_postings) {
   if (!s) return SS_EINVAL;
   if (!s->d_post) return SS_ESTATE;
@@ -168,8 +176,9 @@ int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df
   return SS_OK;
 }
 
-static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q, bool* has_and, uint32_t* nt_max) {
+static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q, bool* has_and, bool* has_or, uint32_t* nt_max) {
   *has_and = false;
+  *has_or = false;
   *nt_max = 0;
   for (uint32_t i = 0; i < nq; i++) {
     if (q[i].n_terms == 0 || q[i].n_terms > SS_MAX_QUERY_TERMS) return SS_EINVAL;
@@ -181,6 +190,7 @@ static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q,
         if (q[i].term[u] == q[i].term[t]) return SS_EINVAL;  // unique terms only (search.rs:3023 unique_terms)
     }
     if (q[i].op == SS_OP_INTERSECTION && q[i].n_terms > 1) *has_and = true;
+    else *has_or = true;
     *nt_max = std::max(*nt_max, q[i].n_terms);
   }
   return SS_OK;
@@ -193,9 +203,9 @@ int ss_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k,
   if (rt != SS_RT_COUNT && (k == 0 || k > SS_MAX_K || !out_doc || !out_score)) return SS_EINVAL;
   if (!s->d_post) return SS_ESTATE;
   if (nq == 0) return SS_OK;
-  bool has_and = false;
+  bool has_and = false, has_or = false;
   uint32_t nt_max = 0;
-  SS_TRY(check_queries(s, nq, q, &has_and, &nt_max));
+  SS_TRY(check_queries(s, nq, q, &has_and, &has_or, &nt_max));
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   const uint32_t kk = rt == SS_RT_COUNT ? 0 : k;
@@ -208,7 +218,7 @@ int ss_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k,
   }
   SS_HIP(hipMemcpyAsync(s->d_bq, q, (size_t)nq * sizeof(ss_bm25_query), hipMemcpyHostToDevice, s->stream));
   SS_TRY(ssi_bm25_search(s, nq, (const ss_bm25_query*)s->d_bq, kk, rt, s->d_out_doc, s->d_out_score, s->d_out_count,
-                         s->d_out_total, has_and, nt_max, s->stream));
+                         s->d_out_total, has_and, has_or, nt_max, s->stream));
   if (kk) {
     SS_HIP(hipMemcpyAsync(out_doc, s->d_out_doc, (size_t)nq * kk * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     SS_HIP(hipMemcpyAsync(out_score, s->d_out_score, (size_t)nq * kk * sizeof(float), hipMemcpyDeviceToHost, s->stream));
@@ -230,7 +240,8 @@ int ss_bm25_search_dev(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint3
   SS_HIP(hipSetDevice(s->device));
   hipStream_t st = stream ? (hipStream_t)stream : s->stream;
   return ssi_bm25_search(s, nq, d_q, rt == SS_RT_COUNT ? 0 : k, rt, d_out_doc, d_out_score, d_out_count, d_out_total,
-                         (ops_mask & 1u) != 0, (ops_mask >> 8) & 0xFFu ? (ops_mask >> 8) & 0xFFu : SS_MAX_QUERY_TERMS, st);
+                         (ops_mask & 1u) != 0, (ops_mask & 2u) != 0 || (ops_mask & 3u) == 0,
+                         (ops_mask >> 8) & 0xFFu ? (ops_mask >> 8) & 0xFFu : SS_MAX_QUERY_TERMS, st);
 }
 
 // ------------------------------------------------------------------ vectors

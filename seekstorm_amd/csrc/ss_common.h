@@ -89,6 +89,11 @@ struct ss_shard {
   uint32_t* d_sub_off = nullptr;   // [n_terms][n_sub+1] segment boundaries in 16-byte units relative to the term base
   float* d_comp = nullptr;         // bm25_component_cache[256] + wlut[4096]
   std::vector<uint64_t> h_df;      // posting_count per term (the df the host needs for idf)
+  // probe index (membership + rank of a doc in a term's segment without reading the segment): one 16-byte record
+  // {u64 bits of 64 docs, u32 index (inside the term's posting array) of their first posting} per (term, sub-block, 64-doc group)
+  uint4* d_probe = nullptr;        // [n_terms + 1][n_sub][BM_SUB / 64]; row n_terms is all zero (absent terms)
+  int bm_strategy = SS_BM25_AUTO;  // ss_bm25_set_strategy
+  float* d_umax = nullptr;         // [n_terms + 1] largest weight tf*(K+1)/(tf+comp[len]) of the term (max_list_score / idf)
   // bm25 workspace
   void* d_bq = nullptr; size_t bq_cap = 0;       // staged queries
   uint64_t* d_part = nullptr; size_t part_cap = 0; // partition-local top-k keys
@@ -109,7 +114,8 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const float* d_queries, uint32_t k,
 int ssi_vec_alloc_ws(ss_shard* s);
 // ---- implemented in bm25.hip
 int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t* d_out_doc,
-                    float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, uint32_t nt_max, hipStream_t st);
+                    float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, bool has_or,
+                    uint32_t nt_max, hipStream_t st);
 // ---- implemented in synth.hip
 int ssi_vec_synth(ss_shard* s, uint64_t seed, hipStream_t st);
 int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const uint8_t* d_lentab, hipStream_t st);

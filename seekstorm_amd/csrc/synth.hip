@@ -78,6 +78,25 @@ static int alloc_post(ss_shard* s, u64 n_units) {
   return SS_OK;
 }
 
+// Probe index + per-term weight maxima.  Skipped (d_probe stays null: searches then always scan exhaustively) when it
+// would not fit beside the postings.
+constexpr int BM_GROUPS = BM_SUB / 64;
+static int alloc_probe(ss_shard* s) {
+  const size_t recs = ((size_t)s->bm_n_terms + 1) * s->bm_n_sub * BM_GROUPS;
+  SS_HIP(hipMalloc(&s->d_umax, ((size_t)s->bm_n_terms + 1) * sizeof(float)));
+  SS_HIP(hipMemset(s->d_umax, 0, ((size_t)s->bm_n_terms + 1) * sizeof(float)));
+  size_t free_b = 0, total_b = 0;
+  SS_HIP(hipMemGetInfo(&free_b, &total_b));
+  if (recs * sizeof(uint4) > free_b / 2) return SS_OK;
+  SS_HIP(hipMalloc(&s->d_probe, recs * sizeof(uint4)));
+  SS_HIP(hipMemset(s->d_probe, 0, recs * sizeof(uint4)));
+  return SS_OK;
+}
+__host__ __device__ inline float bm_weight_of(uint32_t tf, uint32_t len_byte, const float* comp) {
+  // the weight the scan kernels use for this posting: table for tf < 16, formula above (bm_big_tf_weights)
+  return tf < 16u ? comp[256 + (tf << 8) + bm_lut_col(len_byte, tf)] : (float)tf * 2.2f / ((float)tf + comp[len_byte]);
+}
+
 int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t* offs, const uint32_t* docs,
                              const uint16_t* tfs) {
   const uint32_t nt = s->bm_n_terms, ns = s->bm_n_sub;
@@ -138,6 +157,32 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
   SS_HIP(hipMemcpy(s->d_term_base, tbase.data(), ((size_t)nt + 1) * sizeof(u64), hipMemcpyHostToDevice));
   SS_HIP(hipMemcpy(s->d_sub_off, sub.data(), sub.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   SS_HIP(hipMemcpy(s->d_comp, comp, sizeof(comp), hipMemcpyHostToDevice));
+  rc = alloc_probe(s);
+  if (rc) return rc;
+  std::vector<float> umax((size_t)nt + 1, 0.f);
+  std::vector<uint4> probe;
+  if (s->d_probe) probe.assign((size_t)nt * ns * BM_GROUPS, make_uint4(0, 0, 0, 0));
+  for (uint32_t t = 0; t < nt; t++) {
+    for (u64 j = offs[t]; j < offs[t + 1]; j++) {
+      umax[t] = std::max(umax[t], bm_weight_of(tfs[j], doclen[docs[j]], comp));
+      if (!s->d_probe) continue;
+      const uint32_t sb = docs[j] >> BM_SUB_LOG2, d = docs[j] & (BM_SUB - 1);
+      uint4* row = probe.data() + ((size_t)t * ns + sb) * BM_GROUPS;
+      const uint32_t g = d >> 6, b = d & 63;
+      if (b < 32) row[g].x |= 1u << b; else row[g].y |= 1u << (b - 32);
+    }
+  }
+  for (size_t r = 0; r < probe.size(); r += BM_GROUPS) {  // z = index (inside the term) of the group's first posting
+    const size_t t = (r / BM_GROUPS) / ns, sb = (r / BM_GROUPS) % ns;
+    uint32_t run = sub[t * (ns + 1) + sb] * 4u;
+    for (int g = 0; g < BM_GROUPS; g++) {
+      probe[r + g].z = run;
+      run += (uint32_t)__builtin_popcount(probe[r + g].x) + (uint32_t)__builtin_popcount(probe[r + g].y);
+    }
+  }
+  SS_HIP(hipMemcpy(s->d_umax, umax.data(), umax.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (s->d_probe && !probe.empty())
+    SS_HIP(hipMemcpy(s->d_probe, probe.data(), probe.size() * sizeof(uint4), hipMemcpyHostToDevice));
   return SS_OK;
 }
 
@@ -160,7 +205,8 @@ __global__ void lex_doclen_kernel(uint8_t* __restrict__ doclen, u64 seed, u64 n_
 template <bool FILL>
 __global__ void lex_gen_kernel(u64 seed, u64 n_docs, uint32_t n_terms, uint32_t n_sub, const uint32_t* __restrict__ thresh,
                                const uint8_t* __restrict__ doclen, uint32_t* __restrict__ sub /*[nt][ns+1]*/,
-                               const u64* __restrict__ term_base, uint32_t* __restrict__ post, u64* __restrict__ df) {
+                               const u64* __restrict__ term_base, uint32_t* __restrict__ post, u64* __restrict__ df,
+                               uint4* __restrict__ probe, uint32_t* __restrict__ umax_bits, const float* __restrict__ comp) {
   const int lane = threadIdx.x & 63;
   const u64 gw = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const u64 total = (u64)n_terms * n_sub;
@@ -170,6 +216,7 @@ __global__ void lex_gen_kernel(u64 seed, u64 n_docs, uint32_t n_terms, uint32_t 
   const u64 d0 = (u64)sb << BM_SUB_LOG2;
   uint32_t run = 0;
   u64 base = 0;
+  float wmax = 0.f;
   if (FILL) base = (term_base[t] + sub[(size_t)t * (n_sub + 1) + sb]) * 4;
   for (int i = 0; i < BM_SUB / 64; i++) {
     u64 d = d0 + (u64)i * 64 + lane;
@@ -181,10 +228,16 @@ __global__ void lex_gen_kernel(u64 seed, u64 n_docs, uint32_t n_terms, uint32_t 
       uint32_t lo = (uint32_t)hv | 0x80000000u;
       uint32_t tf = 1u + (uint32_t)__builtin_ctz(lo);
       post[base + pos] = bm_pack((uint32_t)(d & (BM_SUB - 1)), doclen[d], tf);
+      wmax = fmaxf(wmax, bm_weight_of(tf, doclen[d], comp));
     }
+    if (FILL && probe && lane == 0)
+      probe[((size_t)t * n_sub + sb) * (BM_SUB / 64) + i] =
+          make_uint4((uint32_t)m, (uint32_t)(m >> 32), sub[(size_t)t * (n_sub + 1) + sb] * 4u + run, 0u);
     run += __popcll(m);
   }
   if (FILL) {
+    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+    if (lane == 0 && wmax > 0.f) atomicMax(&umax_bits[t], __float_as_uint(wmax));  // positive floats order like their bits
     if ((uint32_t)lane < ((4u - (run & 3u)) & 3u)) post[base + run + lane] = 0u;  // NULL padding
   } else if (lane == 0) {
     sub[(size_t)t * (n_sub + 1) + sb + 1] = (run + 3u) >> 2;  // shifted by one for the exclusive scan
@@ -250,7 +303,8 @@ int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const u
   SS_HIP(hipMalloc(&s->d_comp, SS_COMP_N * sizeof(float)));
   const u64 waves = (u64)nt * ns;
   const uint32_t grid = (uint32_t)((waves + 3) / 4);
-  lex_gen_kernel<false><<<grid, 256, 0, st>>>(seed, nd, nt, ns, d_thresh, d_doclen, s->d_sub_off, nullptr, nullptr, d_df);
+  lex_gen_kernel<false><<<grid, 256, 0, st>>>(seed, nd, nt, ns, d_thresh, d_doclen, s->d_sub_off, nullptr, nullptr, d_df,
+                                              nullptr, nullptr, nullptr);
   lex_scan_rows_kernel<<<nt, 1024, 0, st>>>(s->d_sub_off, ns, d_tot);
   lex_scan_terms_kernel<<<1, 64, 0, st>>>(d_tot, (u64*)s->d_term_base, nt);
   SS_HIP(hipStreamSynchronize(st));
@@ -272,8 +326,11 @@ int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const u
   SS_HIP(hipMemcpy(s->d_comp, comp, sizeof(comp), hipMemcpyHostToDevice));
   int rc = alloc_post(s, units);
   if (rc) return rc;
+  rc = alloc_probe(s);
+  if (rc) return rc;
   lex_gen_kernel<true><<<grid, 256, 0, st>>>(seed, nd, nt, ns, d_thresh, d_doclen, s->d_sub_off,
-                                             (const u64*)s->d_term_base, s->d_post, nullptr);
+                                             (const u64*)s->d_term_base, s->d_post, nullptr, s->d_probe,
+                                             (uint32_t*)s->d_umax, s->d_comp);
   SS_HIP(hipStreamSynchronize(st));
   (void)hipFree(d_doclen);
   (void)hipFree(d_psum);

@@ -148,6 +148,10 @@ class Shard:
         N.check(N.lib().ss_vec_read_rows(self._h, int(r0), int(n), N.ptr(out, N.f32p)), "ss_vec_read_rows")
         return out
 
+    def set_strategy(self, strategy):
+        """N.BM25_AUTO / BM25_EXHAUSTIVE / BM25_PRUNED (ss_bm25_set_strategy); both strategies return identical results"""
+        N.check(N.lib().ss_bm25_set_strategy(self._h, int(strategy)), "ss_bm25_set_strategy")
+
     def lexical_info(self):
         nd, av, nt, npost = C.c_uint64(), C.c_float(), C.c_uint32(), C.c_uint64()
         N.check(N.lib().ss_bm25_info(self._h, C.byref(nd), C.byref(av), C.byref(nt), C.byref(npost)), "ss_bm25_info")

@@ -19,6 +19,6 @@ for g in ${3:-sqA sqB sqC fetch write}; do
   ( cd /tmp && timeout 600 rocprofv3 --pmc ${G[$g]} --kernel-trace -d $OLDPWD/$d -o x -- python $OLDPWD/bench.py --workload $WL --no-cpu --steps 4 --warmup 1 > $OLDPWD/$d.log 2>&1 )
   db=$(find $d -name "*results.db" | head -1)
   echo "=== group $g ($db)" >> $OUT
-  python tools/rocpd_pmc.py $db scan >> $OUT 2>&1
+  python tools/rocpd_pmc.py $db >> $OUT 2>&1
 done
 tail -3 gpurun_out/pmc_${TAG}_sqA.log >> $OUT
