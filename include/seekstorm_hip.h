@@ -98,7 +98,7 @@ int ss_bm25_search(ss_shard* s, uint32_t n_queries, const ss_bm25_query* queries
 /* Same, everything device-resident and asynchronous on `stream` (a hipStream_t passed as void*;
  * NULL = the shard's own stream).  d_queries is a device array of ss_bm25_query that the caller has validated
  * (term < n_terms, unique terms, idf > 0).  ops_mask: bit 0 set if any query is an intersection of > 1 terms
- * (selects the kernel variant that carries match counters), bit 1 set if any query is a union; bits 8..15 = the
+ * (selects the kernel variant that carries match counters), bit 1 set if any query is a union of > 1 terms; bits 8..15 = the
  * largest n_terms in the batch (0 = unknown: the generic 10-term kernel is used). */
 int ss_bm25_search_dev(ss_shard* s, uint32_t n_queries, const ss_bm25_query* d_queries, uint32_t k,
                        uint32_t result_type, uint32_t ops_mask, uint32_t* d_out_doc, float* d_out_score,

@@ -176,6 +176,8 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
           }
         }
       } else if (maxn) {
+        // general path: every term completely (prefetched chunks, then the rest of an oversized segment loaded
+        // synchronously) before the next one, so that a doc's score is always summed in query-term order
         float mx = 0.f;  // running maximum of the scores written in this item
 #pragma unroll
         for (int t = 0; t < NT; t++) {
@@ -183,10 +185,7 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
 #pragma unroll
           for (int c = 0; c < CPT; c++)
             if ((uint32_t)c * 64u < n16) mx = bm_chunk<HAS_AND>(cur[t * CPT + c], idf[t], L, is_and, mx);
-        }
-        if (maxn > (uint32_t)CPT * 64u) {  // oversized segments (df above ~CPT/16 of the docs): rest loaded synchronously
-#pragma unroll
-          for (int t = 0; t < NT; t++) {
+          if (n16 > (uint32_t)CPT * 64u) {  // df above ~CPT/16 of the docs
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[t], 0, (int)(B1[t] << 4), BM_RSRC_FLAGS);
             for (uint32_t u = B0[t] + CPT * 64u; u < B1[t]; u += 64u) {
               const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0);

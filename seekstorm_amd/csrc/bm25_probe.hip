@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64) bm25_probe_kernel(
 #pragma unroll
       for (int g = 0; g < G; g++) {
         if (__ballot(alive[g]) == 0ull) continue;
-        if (count && is_and) T.matched += __popcll(__ballot(alive[g]));
+        if (count && (is_and || nt == 1)) T.matched += __popcll(__ballot(alive[g]));
         if (k) {
           const float score = combine(wv[g], pres[g]);
           const bool cand = alive[g] && score >= thr && score > 0.f;

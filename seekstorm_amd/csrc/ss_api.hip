@@ -190,7 +190,7 @@ static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q,
         if (q[i].term[u] == q[i].term[t]) return SS_EINVAL;  // unique terms only (search.rs:3023 unique_terms)
     }
     if (q[i].op == SS_OP_INTERSECTION && q[i].n_terms > 1) *has_and = true;
-    else *has_or = true;
+    else if (q[i].n_terms > 1) *has_or = true;  // a single-term query is both: its exact count is its posting count
     *nt_max = std::max(*nt_max, q[i].n_terms);
   }
   return SS_OK;

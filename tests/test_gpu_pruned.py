@@ -1,0 +1,126 @@
+"""Pruned (MaxScore over the probe index) vs exhaustive BM25 strategy, through the C ABI: both must return IDENTICAL
+results -- same doc ids, bit-identical scores, same exact counts -- and agree with the CPU oracle.  Corpora are built to
+stress what pruning can get wrong: ties at the k-th score, tf >= 16 postings (weights outside the table), very sparse and
+very dense terms, single-term queries, k larger than the match count, many partitions per query."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def S():
+    import seekstorm_amd
+    return seekstorm_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def _corpus(O, n_docs, dfs, seed, tie_heavy=False, big_tf=False):
+    rng = np.random.default_rng(seed)
+    if tie_heavy:  # few distinct lengths and tf = 1 almost everywhere: large groups of equal scores
+        lens = rng.choice([40, 41, 120], n_docs)
+    else:
+        lens = np.clip(np.round(np.exp(np.log(120) + 0.6 * rng.standard_normal(n_docs))), 8, 2000).astype(np.int64)
+    dl = np.array([O.lib().so_int_to_byte4(int(x)) for x in np.unique(lens)], np.uint8)
+    lut = dict(zip(np.unique(lens).tolist(), dl.tolist()))
+    doclen = np.array([lut[int(x)] for x in lens], np.uint8)
+    offs, docs, tfs = [0], [], []
+    for df in dfs:
+        n = max(1, int(round(df * n_docs)))
+        d = np.sort(rng.choice(n_docs, n, replace=False)).astype(np.uint32)
+        if tie_heavy:
+            tf = np.where(rng.random(n) < 0.97, 1, 2).astype(np.uint16)
+        else:
+            tf = (1 + rng.geometric(0.55, n) - 1).clip(1, 400).astype(np.uint16)
+            if big_tf:
+                m = rng.random(n) < 0.03
+                tf[m] = rng.integers(16, 400, int(m.sum())).astype(np.uint16)
+        docs.append(d); tfs.append(tf); offs.append(offs[-1] + n)
+    return doclen, np.asarray(offs, np.uint64), np.concatenate(docs), np.concatenate(tfs)
+
+
+def _run(S, sh, queries, k, rt, strategy):
+    from seekstorm_amd import _native as N
+    sh.set_strategy(strategy)
+    out = sh.search_lexical_batch(queries, k, rt)
+    sh.set_strategy(N.BM25_AUTO)
+    return out
+
+
+@pytest.mark.parametrize("tie_heavy,big_tf", [(False, False), (True, False), (False, True)])
+def test_pruned_equals_exhaustive_and_oracle(S, O, tie_heavy, big_tf):
+    from seekstorm_amd import _native as N
+    n_docs = 150_000
+    dfs = [0.0004, 0.002, 0.008, 0.02, 0.05, 0.11, 0.3, 0.62, 0.013, 0.004, 0.035, 0.0009]
+    dl, offs, docs, tfs = _corpus(O, n_docs, dfs, 5 + tie_heavy + 2 * big_tf, tie_heavy, big_tf)
+    sh = S.Shard(0)
+    sh.upload_lexical(n_docs, dl, offs, docs, tfs)
+    osh = O.Shard(n_docs, dl, offs, docs, tfs)
+    rng = np.random.default_rng(99)
+    term_lists = [[int(x) for x in rng.choice(len(dfs), int(rng.integers(1, 5)), replace=False)] for _ in range(60)]
+    term_lists += [[0], [7], [6, 7], [0, 11], [5, 6, 7], [0, 1, 2, 3]]
+    for qt, op in ((S.QueryType.Union, O.OP_OR), (S.QueryType.Intersection, O.OP_AND)):
+        q = sh.make_queries(term_lists, qt)
+        for k in (1, 10, 100):
+            # top-k: pruned == exhaustive, bit for bit
+            pd, ps, pc, _ = _run(S, sh, q, k, S.ResultType.Topk, N.BM25_PRUNED)
+            ed, es, ec, _ = _run(S, sh, q, k, S.ResultType.Topk, N.BM25_EXHAUSTIVE)
+            assert np.array_equal(pc, ec)
+            assert np.array_equal(ps, es), f"{qt} k={k}: scores differ"
+            assert np.array_equal(pd, ed), f"{qt} k={k}: doc ids differ"
+            # and against the oracle (scores within tolerance, identical sets outside the tie band)
+            for i in (0, 7, 23, len(term_lists) - 1, len(term_lists) - 4):
+                od, os_, otot = osh.search_exhaustive(term_lists[i], op, k)
+                n = int(pc[i])
+                assert n == len(od)
+                assert np.allclose(ps[i][:n], os_, rtol=REL)
+                if n:
+                    band = abs(float(os_[-1])) * REL
+                    assert {int(x) for x, y in zip(pd[i][:n], ps[i][:n]) if y > os_[-1] + band} == \
+                           {int(x) for x, y in zip(od, os_) if y > os_[-1] + band}
+        if qt == S.QueryType.Intersection:  # exact counts of intersections come from the pruned path too
+            for rt in (S.ResultType.TopkCount, S.ResultType.Count):
+                pd, ps, pc, pt = _run(S, sh, q, 10, rt, N.BM25_PRUNED)
+                ed, es, ec, et = _run(S, sh, q, 10, rt, N.BM25_EXHAUSTIVE)
+                assert np.array_equal(pt, et) and np.array_equal(pc, ec)
+                if rt == S.ResultType.TopkCount:
+                    assert np.array_equal(ps, es) and np.array_equal(pd, ed)
+                for i in (1, 30, len(term_lists) - 2):
+                    _, _, otot = osh.search_exhaustive(term_lists[i], op, 10)
+                    assert int(pt[i]) == otot
+    # exact union counts cannot be pruned: the explicit PRUNED strategy refuses, AUTO falls back to the scan
+    q = sh.make_queries(term_lists[:4], S.QueryType.Union)
+    with pytest.raises(S.SeekStormHipError):
+        _run(S, sh, q, 10, S.ResultType.TopkCount, N.BM25_PRUNED)
+    ad, as_, ac, at = _run(S, sh, q, 10, S.ResultType.TopkCount, N.BM25_AUTO)
+    for i in range(4):
+        assert int(at[i]) == osh.search_exhaustive(term_lists[i], O.OP_OR, 10)[2]
+    sh.close()
+
+
+def test_pruned_many_partitions_and_small_shards(S, O):
+    """few queries -> one sub-block per partition; shards smaller than a sub-block; k larger than the match count"""
+    from seekstorm_amd import _native as N
+    for n_docs in (100, 5000, 70_000):
+        dfs = [0.01, 0.05, 0.2, 0.5]
+        dl, offs, docs, tfs = _corpus(O, n_docs, dfs, 3)
+        sh = S.Shard(0)
+        sh.upload_lexical(n_docs, dl, offs, docs, tfs)
+        osh = O.Shard(n_docs, dl, offs, docs, tfs)
+        tl = [[0, 1, 2], [3, 0], [1]]
+        for qt, op in ((S.QueryType.Union, O.OP_OR), (S.QueryType.Intersection, O.OP_AND)):
+            q = sh.make_queries(tl, qt)
+            for k in (10, 128):
+                pd, ps, pc, _ = _run(S, sh, q, k, S.ResultType.Topk, N.BM25_PRUNED)
+                ed, es, ec, _ = _run(S, sh, q, k, S.ResultType.Topk, N.BM25_EXHAUSTIVE)
+                assert np.array_equal(pc, ec) and np.array_equal(ps, es) and np.array_equal(pd, ed)
+                for i in range(len(tl)):
+                    od, os_, _ = osh.search_exhaustive(tl[i], op, k)
+                    assert int(pc[i]) == len(od) and np.allclose(ps[i][:len(od)], os_, rtol=REL)
+        sh.close()
