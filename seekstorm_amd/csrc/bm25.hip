@@ -2,6 +2,8 @@
 // kernels live in bm25_fast.hip (shared device code: bm25_dev.h).  Reference seam replaced: the dispatch block of
 // search_lexical_shard (search.rs:3374-3560) down to MinHeap::add_topk (min_heap.rs:1193) and the final
 // sort-by-score-descending of the heap array (search.rs:3565-3593).
+#include <cstdlib>
+
 #include "bm25_dev.h"
 
 
@@ -77,8 +79,19 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   const uint32_t kk = k ? k : 1;
   const int KPL = kk <= 64 ? 1 : kk <= 128 ? 2 : kk <= 256 ? 4 : 16;
   const uint32_t KS = 64 * KPL;
-  // partitions per query: enough assignments to load-balance ~2048 resident waves
-  uint32_t P = (4u * 256u * BM_WAVES_OR + nq - 1) / nq;
+  // Strategy.  Pruned (probe index, bm25_probe.hip): top-k of unions without exact counts, and intersections with any
+  // result type -- it reads only the essential / shortest lists.  Exhaustive (bm25_fast.hip): everything else (exact
+  // union counts need every posting), and whenever the probe index is absent or SS_BM25_EXHAUSTIVE is selected.
+  const bool pruned = s->bm_strategy != SS_BM25_EXHAUSTIVE && (!has_or || rt == SS_RT_TOPK) && s->d_probe && s->d_umax &&
+                      nt_max >= 1 && nt_max <= 4 && KPL <= 2;
+  if (!pruned && s->bm_strategy == SS_BM25_PRUNED) return SS_ENOTSUP;
+  // Partitions per query (one wave each).  The grid is a whole number of "rounds" of resident waves: a partially
+  // filled last round costs its full duration (measured on C2: 550K q/s at 1.95 rounds vs 477K at 2.44).  Exhaustive
+  // scan: 2048 resident waves (LDS-bound), ~2 rounds; pruned: 6144 resident waves, ~4 rounds of shorter assignments
+  // balance its more uneven work (driver streams differ 4x in length between queries).
+  const uint32_t resident = pruned ? 6144u : 2048u, rounds = pruned ? 4u : 2u;
+  uint32_t P = (rounds * resident) / nq;
+  if (const char* e = getenv("SS_BM25_P")) P = (uint32_t)atoi(e);  // tuning override
   P = std::max<uint32_t>(1, std::min<uint32_t>(P, s->bm_n_sub));
   const size_t need = (size_t)nq * P * KS * 2 + nq + (nq + 1) / 2;  // two ping-pong merge buffers + totals + tau
   if (need > s->part_cap) {
@@ -111,16 +124,8 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   p.count = (rt == SS_RT_TOPK) ? 0u : 1u;  // Topk: result_count_total is not required to be exact
   hipEvent_t e0 = nullptr, e1 = nullptr;
   ssi_prof_begin(s, 0, st, &e0, &e1);
-  // Strategy.  Pruned (probe index, bm25_probe.hip): top-k of unions without exact counts, and intersections with any
-  // result type -- it reads only the essential / shortest lists.  Exhaustive (bm25_fast.hip): everything else (exact
-  // union counts need every posting), and whenever the probe index is absent or SS_BM25_EXHAUSTIVE is selected.
-  int rc = SS_ENOTSUP;
-  const bool prunable = s->bm_strategy != SS_BM25_EXHAUSTIVE && (!has_or || rt == SS_RT_TOPK);
-  if (prunable) rc = ssi_bm25_launch_probe(p, s->d_probe, s->d_umax, nt_max, KPL, st);
-  if (rc == SS_ENOTSUP) {
-    if (s->bm_strategy == SS_BM25_PRUNED) return SS_ENOTSUP;
-    rc = ssi_bm25_launch_scan(p, nt_max, has_and, KPL, st);
-  }
+  const int rc = pruned ? ssi_bm25_launch_probe(p, s->d_probe, s->d_umax, nt_max, KPL, st)
+                        : ssi_bm25_launch_scan(p, nt_max, has_and, KPL, st);
   ssi_prof_end(s, 0, st, e0, e1);
   if (rc) return rc;
 

@@ -46,7 +46,7 @@ __device__ __forceinline__ float pb_weight(uint32_t p) {
 }
 
 template <int NT, int KPL>
-__global__ void __launch_bounds__(PB_WAVES * 64) bm25_probe_kernel(
+__global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
     const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base, const uint32_t* __restrict__ sub_off,
     const float* __restrict__ comp_g, const uint4* __restrict__ probe, const float* __restrict__ umax,
     const ss_bm25_query* __restrict__ qs, unsigned long long* __restrict__ part_keys, unsigned long long* __restrict__ total,

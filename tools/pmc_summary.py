@@ -35,12 +35,14 @@ def main():
                       "`rocprofv3 --pmc <group> --kernel-trace -- python bench.py --workload all --no-cpu --steps 4 --warmup 1`, "
                       "one run per counter group (tools/collect_pmc.sh).  SQ_* wave counters are in quad-cycles "
                       "(MI355X_MICROARCH.md); GRBM_GUI_ACTIVE is summed over the 8 XCDs.", ""]
-    for kern, pat in (("bm25", "bm25_scan_fast_kernel"), ("vector", "vec_scan_kernel")):
+    for kern, pat in (("bm25", "bm25_scan_fast_kernel"), ("bm25_pruned", "bm25_probe_kernel"), ("vector", "vec_scan_kernel")):
         groups = {g: load(db(g), pat) for g in ("fetch", "write", "sqA", "sqB", "sqC") if os.path.exists(db(g))}
+        if not groups.get("fetch"):
+            continue
 
         def sel(g):
             rows = list(groups[g].values())
-            if kern == "bm25":
+            if kern.startswith("bm25"):
                 gmax = max(r["grid"] for r in rows)
                 rows = [r for r in rows if r["grid"] == gmax]
                 return rows, len(rows)
@@ -56,7 +58,7 @@ def main():
         hbm = (2.0 * fetch / n + write / nw) * 1024.0
         rows, _ = sel("fetch")
         dur_ms = sum(r["dur"] for r in rows) / n / 1e6
-        unit = "full launch (1000 queries)" if kern == "bm25" else "64-query pass (7 launches)"
+        unit = "full launch (1000 queries)" if kern.startswith("bm25") else "64-query pass (7 launches)"
         out[kern] = {"hbm_bytes_per_launch": hbm, "fetch_size_kib_total": fetch, "write_size_kib_total": write,
                      "launches": n, "cycles_per_launch": gui / 8 / n, "kernel_ms_per_launch_profiled": dur_ms}
         lines += [f"## {kern}: `{pat}` -- per {unit}, {n} of them", "",
