@@ -81,15 +81,17 @@ static int alloc_post(ss_shard* s, u64 n_units) {
 // Probe index + per-term weight maxima.  Skipped (d_probe stays null: searches then always scan exhaustively) when it
 // would not fit beside the postings.
 constexpr int BM_GROUPS = BM_SUB / 64;
-static int alloc_probe(ss_shard* s) {
-  const size_t recs = ((size_t)s->bm_n_terms + 1) * s->bm_n_sub * BM_GROUPS;
+static int alloc_probe(ss_shard* s, hipStream_t st) {
+  // Everything the builders do not overwrite is cleared ON THE BUILD STREAM: the shard stream is non-blocking, so a
+  // null-stream hipMemset is not ordered against the generator kernels that follow and could wipe what they wrote.
+  const size_t rows = (size_t)s->bm_n_terms * s->bm_n_sub * BM_GROUPS, zero_row = (size_t)s->bm_n_sub * BM_GROUPS;
   SS_HIP(hipMalloc(&s->d_umax, ((size_t)s->bm_n_terms + 1) * sizeof(float)));
-  SS_HIP(hipMemset(s->d_umax, 0, ((size_t)s->bm_n_terms + 1) * sizeof(float)));
+  SS_HIP(hipMemsetAsync(s->d_umax, 0, ((size_t)s->bm_n_terms + 1) * sizeof(float), st));
   size_t free_b = 0, total_b = 0;
   SS_HIP(hipMemGetInfo(&free_b, &total_b));
-  if (recs * sizeof(uint4) > free_b / 2) return SS_OK;
-  SS_HIP(hipMalloc(&s->d_probe, recs * sizeof(uint4)));
-  SS_HIP(hipMemset(s->d_probe, 0, recs * sizeof(uint4)));
+  if ((rows + zero_row) * sizeof(uint4) > free_b / 2) return SS_OK;
+  SS_HIP(hipMalloc(&s->d_probe, (rows + zero_row) * sizeof(uint4)));
+  SS_HIP(hipMemsetAsync(s->d_probe + rows, 0, zero_row * sizeof(uint4), st));  // row n_terms: absent terms
   return SS_OK;
 }
 __host__ __device__ inline float bm_weight_of(uint32_t tf, uint32_t len_byte, const float* comp) {
@@ -157,8 +159,9 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
   SS_HIP(hipMemcpy(s->d_term_base, tbase.data(), ((size_t)nt + 1) * sizeof(u64), hipMemcpyHostToDevice));
   SS_HIP(hipMemcpy(s->d_sub_off, sub.data(), sub.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   SS_HIP(hipMemcpy(s->d_comp, comp, sizeof(comp), hipMemcpyHostToDevice));
-  rc = alloc_probe(s);
+  rc = alloc_probe(s, s->stream);
   if (rc) return rc;
+  SS_HIP(hipStreamSynchronize(s->stream));
   std::vector<float> umax((size_t)nt + 1, 0.f);
   std::vector<uint4> probe;
   if (s->d_probe) probe.assign((size_t)nt * ns * BM_GROUPS, make_uint4(0, 0, 0, 0));
@@ -326,7 +329,7 @@ int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const u
   SS_HIP(hipMemcpy(s->d_comp, comp, sizeof(comp), hipMemcpyHostToDevice));
   int rc = alloc_post(s, units);
   if (rc) return rc;
-  rc = alloc_probe(s);
+  rc = alloc_probe(s, st);
   if (rc) return rc;
   lex_gen_kernel<true><<<grid, 256, 0, st>>>(seed, nd, nt, ns, d_thresh, d_doclen, s->d_sub_off,
                                              (const u64*)s->d_term_base, s->d_post, nullptr, s->d_probe,

@@ -124,3 +124,23 @@ def test_pruned_many_partitions_and_small_shards(S, O):
                     od, os_, _ = osh.search_exhaustive(tl[i], op, k)
                     assert int(pc[i]) == len(od) and np.allclose(ps[i][:len(od)], os_, rtol=REL)
         sh.close()
+
+
+def test_pruned_is_repeatable_on_a_generated_corpus(S, O):
+    """the pruned path shares thresholds between concurrently running partitions (atomics): whatever the interleaving,
+    every run must reproduce the exhaustive answer exactly"""
+    from seekstorm_amd import _native as N
+    n_docs = 1_500_000
+    th = O.term_thresholds(256)
+    sh = S.Shard(0)
+    sh.synth_lexical(O.LEX_SEED, n_docs, th, O.len_table())
+    rng = np.random.default_rng(4)
+    tl = [[int(x) for x in rng.choice(256, 3, replace=False)] for _ in range(200)]
+    q = sh.make_queries(tl, S.QueryType.Union)
+    ed, es, ec, _ = _run(S, sh, q, 10, S.ResultType.Topk, N.BM25_EXHAUSTIVE)
+    for rep in range(12):
+        sub = q[: 200 - 7 * rep]  # different batch sizes -> different partition counts and interleavings
+        pd, ps, pc, _ = _run(S, sh, sub, 10, S.ResultType.Topk, N.BM25_PRUNED)
+        n = len(sub)
+        assert np.array_equal(ps, es[:n]) and np.array_equal(pd, ed[:n]) and np.array_equal(pc, ec[:n]), f"run {rep}"
+    sh.close()
