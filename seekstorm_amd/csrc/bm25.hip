@@ -116,6 +116,9 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   p.part_keys = bufA;
   p.total = total;
   p.tau = tau;
+  p.exc_off = (const unsigned long long*)s->d_exc_off;
+  p.exc_doc = s->d_exc_doc;
+  p.exc_tf = s->d_exc_tf;
   p.n_sub = s->bm_n_sub;
   p.n_terms = s->bm_n_terms;
   p.nq = nq;
@@ -130,11 +133,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   if (rc) return rc;
 
   // merge tree over the P partition lists
-  static bool mattr = false;
-  if (!mattr) {
-    SS_HIP(hipFuncSetAttribute((const void*)bm25_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
-    mattr = true;
-  }
+  SS_SET_MAX_LDS(bm25_merge_kernel, 8192 * 8);
   uint32_t lists = P;
   u64 *src = bufA, *dst = bufB;
   const uint32_t group = 8192 / KS;

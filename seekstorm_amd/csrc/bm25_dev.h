@@ -18,6 +18,9 @@ struct BmParams {
   unsigned long long* part_keys;   // [nq][P][KS]
   unsigned long long* total;       // [nq] exact match counts
   uint32_t* tau;                   // [nq] shared admission threshold: bits of the best k-th score any partition holds
+  const unsigned long long* exc_off;  // exception lists: postings whose tf does not fit the 9-bit field
+  const uint32_t* exc_doc;
+  const uint32_t* exc_tf;
   uint32_t n_sub, n_terms, nq, P, k, count;
 };
 
@@ -168,12 +171,29 @@ struct BmLds {
   uint32_t lut, comp, accb, tile, cnt, cntw;
 };
 
-// tf >= 16 lies outside the weight table: tf*(K+1)/(tf + comp[len]) computed directly (rare, kept out of line)
-__device__ __attribute__((noinline)) f32x4 bm_big_tf_weights(u32x4 pv, f32x4 wp, uint32_t comp_off) {
+// Exception lists (tf >= 511): exact tf of (term, doc) by binary search.  Cold path.
+struct BmExc {
+  const unsigned long long* off;
+  const uint32_t* doc;
+  const uint32_t* tf;
+};
+__device__ __attribute__((noinline)) float bm_exact_tf(BmExc X, uint32_t term, uint32_t doc) {
+  unsigned long long lo = X.off[term], hi = X.off[term + 1];
+  while (lo < hi) {
+    const unsigned long long mid = (lo + hi) >> 1;
+    if (X.doc[mid] < doc) lo = mid + 1; else hi = mid;
+  }
+  return (float)X.tf[lo];  // present by construction of the image
+}
+// tf >= 16 lies outside the weight table: tf*(K+1)/(tf + comp[len]) computed directly (rare, kept out of line).
+// doc0 = shard-local id of doc field 1 of the sub-block.
+__device__ __attribute__((noinline)) f32x4 bm_big_tf_weights(u32x4 pv, f32x4 wp, uint32_t comp_off, BmExc X, uint32_t term,
+                                                             uint32_t doc0) {
 #pragma unroll
   for (int x = 0; x < 4; x++) {
     if (pv[x] & BM_BIG_TF_MASK) {
-      const float tf = (float)bm_tf(pv[x]);
+      float tf = (float)bm_tf(pv[x]);
+      if (bm_tf(pv[x]) == BM_TF_ESC) tf = bm_exact_tf(X, term, doc0 + ((pv[x] >> 2) & 0x1FFFu) - 1u);
       wp[x] = tf * BM_K1P * __builtin_amdgcn_rcpf(tf + lds_ldf(comp_off + bm_len(pv[x]) * 4u));
     }
   }
@@ -184,7 +204,8 @@ __device__ __attribute__((noinline)) f32x4 bm_big_tf_weights(u32x4 pv, f32x4 wp,
 // Plain gather / scatter: the docs of one term are distinct and the tile is private to the wave, whose LDS operations
 // execute in order.  NULL postings (padding, out-of-range lanes) add 0 to the dump slot.  Returns max of the new scores.
 template <bool HAS_AND>
-__device__ __forceinline__ float bm_chunk(const u32x4 q, float idf, const BmLds& L, bool is_and, float mx) {
+__device__ __forceinline__ float bm_chunk(const u32x4 q, float idf, const BmLds& L, bool is_and, float mx, BmExc X, uint32_t term,
+                                          uint32_t doc0) {
   const uint32_t pv[4] = {q.x, q.y, q.z, q.w};
   uint32_t ao[4], co[4], cold[4];
   float old[4], wp[4];
@@ -199,7 +220,7 @@ __device__ __forceinline__ float bm_chunk(const u32x4 q, float idf, const BmLds&
     }
   }
   if (__ballot(((pv[0] | pv[1]) | (pv[2] | pv[3])) & BM_BIG_TF_MASK)) {  // some tf >= 16 (rare)
-    const f32x4 fx = bm_big_tf_weights(q, f32x4{wp[0], wp[1], wp[2], wp[3]}, L.comp);
+    const f32x4 fx = bm_big_tf_weights(q, f32x4{wp[0], wp[1], wp[2], wp[3]}, L.comp, X, term, doc0);
     wp[0] = fx.x; wp[1] = fx.y; wp[2] = fx.z; wp[3] = fx.w;
   }
 #pragma unroll

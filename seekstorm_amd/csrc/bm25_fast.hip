@@ -22,7 +22,8 @@ template <int NT> struct FastCfg { static constexpr int CPT = NT <= 2 ? 4 : 3; s
   const uint32_t *__restrict__ post, const unsigned long long *__restrict__ term_base,                             \
       const uint32_t *__restrict__ sub_off, const float *__restrict__ comp_g, const ss_bm25_query *__restrict__ qs, \
       unsigned long long *__restrict__ part_keys, unsigned long long *__restrict__ total, uint32_t *tau,            \
-      uint32_t n_sub,                                                                                               \
+      const unsigned long long *__restrict__ exc_off, const uint32_t *__restrict__ exc_doc,                         \
+      const uint32_t *__restrict__ exc_tf, uint32_t n_sub,                                                          \
       uint32_t n_terms, uint32_t nq, uint32_t P, uint32_t k, uint32_t count
 
 template <bool HAS_AND>
@@ -75,10 +76,13 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
     const uint32_t* tptr[NT];
     const uint32_t* rowp[NT];
     float idf[NT];
+    uint32_t tid_[NT];
+    const BmExc X{exc_off, exc_doc, exc_tf};
 #pragma unroll
     for (int t = 0; t < NT; t++) {
       const bool have = (uint32_t)t < nt;
       const uint32_t term = have ? Q->term[t] : n_terms;
+      tid_[t] = term;
       idf[t] = have ? Q->idf[t] : 0.f;
       tptr[t] = post + term_base[term] * 4ull;
       rowp[t] = sub_off + (size_t)term * row_len;
@@ -184,12 +188,12 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
           const uint32_t n16 = B1[t] - B0[t];
 #pragma unroll
           for (int c = 0; c < CPT; c++)
-            if ((uint32_t)c * 64u < n16) mx = bm_chunk<HAS_AND>(cur[t * CPT + c], idf[t], L, is_and, mx);
+            if ((uint32_t)c * 64u < n16) mx = bm_chunk<HAS_AND>(cur[t * CPT + c], idf[t], L, is_and, mx, X, tid_[t], s << BM_SUB_LOG2);
           if (n16 > (uint32_t)CPT * 64u) {  // df above ~CPT/16 of the docs
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[t], 0, (int)(B1[t] << 4), BM_RSRC_FLAGS);
             for (uint32_t u = B0[t] + CPT * 64u; u < B1[t]; u += 64u) {
               const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0);
-              mx = bm_chunk<HAS_AND>(q, idf[t], L, is_and, mx);
+              mx = bm_chunk<HAS_AND>(q, idf[t], L, is_and, mx, X, tid_[t], s << BM_SUB_LOG2);
             }
           }
         }
@@ -267,10 +271,13 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
         uint32_t b0[G], b1[G];
         float idf[G];
         const uint32_t* tp[G];
+        uint32_t tid_[G];
+        const BmExc X{exc_off, exc_doc, exc_tf};
 #pragma unroll
         for (int t = 0; t < G; t++) {
           const bool have = g0 + t < nt;
           const uint32_t term = have ? Q->term[have ? g0 + t : 0] : n_terms;
+          tid_[t] = term;
           idf[t] = have ? Q->idf[have ? g0 + t : 0] : 0.f;
           tp[t] = post + term_base[term] * 4ull;
           b0[t] = sub_off[term * row_len + s];
@@ -286,12 +293,12 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
           any |= n16 != 0;
 #pragma unroll
           for (int c = 0; c < CPT; c++)
-            if ((uint32_t)c * 64u < n16) mx = bm_chunk<HAS_AND>(v[t * CPT + c], idf[t], L, is_and, mx);
+            if ((uint32_t)c * 64u < n16) mx = bm_chunk<HAS_AND>(v[t * CPT + c], idf[t], L, is_and, mx, X, tid_[t], s << BM_SUB_LOG2);
           if (n16 > (uint32_t)CPT * 64u) {
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tp[t], 0, (int)(b1[t] << 4), BM_RSRC_FLAGS);
             for (uint32_t u = b0[t] + CPT * 64u; u < b1[t]; u += 64u) {
               const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0);
-              mx = bm_chunk<HAS_AND>(q, idf[t], L, is_and, mx);
+              mx = bm_chunk<HAS_AND>(q, idf[t], L, is_and, mx, X, tid_[t], s << BM_SUB_LOG2);
             }
           }
         }
@@ -311,18 +318,13 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
 }
 
 #define BM_PASS_ARGS                                                                                                 \
-  p.post, p.term_base, p.sub_off, p.comp, p.q, p.part_keys, p.total, p.tau, p.n_sub, p.n_terms, p.nq, p.P, p.k, p.count
+  p.post, p.term_base, p.sub_off, p.comp, p.q, p.part_keys, p.total, p.tau, p.exc_off, p.exc_doc, p.exc_tf, p.n_sub, p.n_terms, p.nq, p.P, p.k, p.count
 
 template <int NT, bool HAS_AND, int KPL>
 static int launch_fast(const BmParams& p, hipStream_t st) {
   constexpr int WAVES = HAS_AND ? BM_WAVES_AND : BM_WAVES_OR;
   constexpr int lds = BM_LUT_BYTES + WAVES * (BM_WAVE_ACC + (HAS_AND ? BM_WAVE_CNT : 0));
-  static bool done = false;
-  if (!done) {
-    SS_HIP(hipFuncSetAttribute((const void*)bm25_scan_fast_kernel<NT, HAS_AND, KPL>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    done = true;
-  }
+  SS_SET_MAX_LDS((bm25_scan_fast_kernel<NT, HAS_AND, KPL>), lds);
   const uint32_t A = p.nq * p.P;
   bm25_scan_fast_kernel<NT, HAS_AND, KPL><<<(A + WAVES - 1) / WAVES, WAVES * 64, lds, st>>>(BM_PASS_ARGS);
   return SS_OK;
@@ -332,12 +334,7 @@ template <bool HAS_AND, int KPL>
 static int launch_group(const BmParams& p, hipStream_t st) {
   constexpr int WAVES = HAS_AND ? BM_WAVES_AND : BM_WAVES_OR;
   constexpr int lds = BM_LUT_BYTES + WAVES * (BM_WAVE_ACC + (HAS_AND ? BM_WAVE_CNT : 0));
-  static bool done = false;
-  if (!done) {
-    SS_HIP(hipFuncSetAttribute((const void*)bm25_scan_group_kernel<HAS_AND, KPL>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    done = true;
-  }
+  SS_SET_MAX_LDS((bm25_scan_group_kernel<HAS_AND, KPL>), lds);
   const uint32_t A = p.nq * p.P;
   const uint32_t grid = std::min<uint32_t>((A + WAVES - 1) / WAVES, 256);
   bm25_scan_group_kernel<HAS_AND, KPL><<<grid, WAVES * 64, lds, st>>>(BM_PASS_ARGS);

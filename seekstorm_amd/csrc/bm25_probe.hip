@@ -35,11 +35,12 @@ __device__ __attribute__((noinline)) BmTop<KPL> bm_offer_lane_keys(BmTop<KPL> T,
   return T;
 }
 
-// weight of one posting: table for tf < 16, formula above
-__device__ __forceinline__ float pb_weight(uint32_t p) {
+// weight of one posting: table for tf < 16, formula above (exact tf from the exception list when the field is saturated)
+__device__ __forceinline__ float pb_weight(uint32_t p, const BmExc& X, uint32_t term, uint32_t doc) {
   float w = lds_ldf(((p >> 16) & 0x3FFCu) + 1024u);
   if (p & BM_BIG_TF_MASK) {
-    const float tf = (float)bm_tf(p);
+    float tf = (float)bm_tf(p);
+    if (bm_tf(p) == BM_TF_ESC) tf = bm_exact_tf(X, term, doc);
     w = tf * BM_K1P * __builtin_amdgcn_rcpf(tf + lds_ldf(bm_len(p) * 4u));
   }
   return w;
@@ -50,7 +51,8 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
     const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base, const uint32_t* __restrict__ sub_off,
     const float* __restrict__ comp_g, const uint4* __restrict__ probe, const float* __restrict__ umax,
     const ss_bm25_query* __restrict__ qs, unsigned long long* __restrict__ part_keys, unsigned long long* __restrict__ total,
-    uint32_t* tau, uint32_t n_sub, uint32_t n_terms, uint32_t nq, uint32_t P, uint32_t k, uint32_t count) {
+    uint32_t* tau, const unsigned long long* __restrict__ exc_off, const uint32_t* __restrict__ exc_doc,
+    const uint32_t* __restrict__ exc_tf, uint32_t n_sub, uint32_t n_terms, uint32_t nq, uint32_t P, uint32_t k, uint32_t count) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
   const int tid = threadIdx.x, lane = tid & 63;
@@ -71,7 +73,8 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
   const uint32_t* rowp[NT];
   const uint4* prow[NT];
   float idf[NT], U[NT];
-  uint32_t qpos[NT];
+  uint32_t qpos[NT], tid_[NT];
+  const BmExc X{exc_off, exc_doc, exc_tf};
   unsigned long long size[NT];
 #pragma unroll
   for (int t = 0; t < NT; t++) {
@@ -80,6 +83,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
     idf[t] = have ? Q->idf[t] : 0.f;
     U[t] = idf[t] * umax[term] * 1.000002f;  // upper bound of idf * w over the list (rcp-approximated weights included)
     qpos[t] = t;
+    tid_[t] = term;
     tptr[t] = post + term_base[term] * 4ull;
     rowp[t] = sub_off + (size_t)term * row_len;
     prow[t] = probe + (size_t)term * n_sub * (BM_SUB / 64);
@@ -95,6 +99,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
       { float t_ = idf[x]; idf[x] = idf[y]; idf[y] = t_; }
       { float t_ = U[x]; U[x] = U[y]; U[y] = t_; }
       { uint32_t t_ = qpos[x]; qpos[x] = qpos[y]; qpos[y] = t_; }
+      { uint32_t t_ = tid_[x]; tid_[x] = tid_[y]; tid_[y] = t_; }
       { auto t_ = size[x]; size[x] = size[y]; size[y] = t_; }
     }
   };
@@ -176,7 +181,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
         pres[g] = 1u << J;
 #pragma unroll
         for (int t = 0; t < NT; t++) wv[g][t] = 0.f;
-        wv[g][J] = alive[g] ? pb_weight(pg[g]) : 0.f;
+        wv[g][J] = alive[g] ? pb_weight(pg[g], X, tid_[J], (tile[g] << BM_SUB_LOG2) + dg[g]) : 0.f;
         known[g] = idf[J] * wv[g][J];
       }
       float rest = SU[0] - U[J];
@@ -211,7 +216,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
 #pragma unroll
         for (int g = 0; g < G; g++) {
           if (hit[g]) {
-            wv[g][t] = pb_weight(pt[g]);
+            wv[g][t] = pb_weight(pt[g], X, tid_[t], (tile[g] << BM_SUB_LOG2) + dg[g]);
             pres[g] |= 1u << t;
             known[g] += idf[t] * wv[g][t];
           }
@@ -252,7 +257,7 @@ template <int NT, int KPL>
 static int launch_probe(const BmParams& p, const uint4* probe, const float* umax, hipStream_t st) {
   const uint32_t A = p.nq * p.P;
   bm25_probe_kernel<NT, KPL><<<(A + PB_WAVES - 1) / PB_WAVES, PB_WAVES * 64, BM_LUT_BYTES, st>>>(
-      p.post, p.term_base, p.sub_off, p.comp, probe, umax, p.q, p.part_keys, p.total, p.tau, p.n_sub, p.n_terms, p.nq, p.P, p.k,
+      p.post, p.term_base, p.sub_off, p.comp, probe, umax, p.q, p.part_keys, p.total, p.tau, p.exc_off, p.exc_doc, p.exc_tf, p.n_sub, p.n_terms, p.nq, p.P, p.k,
       p.count);
   return SS_OK;
 }

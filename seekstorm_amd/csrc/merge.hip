@@ -77,11 +77,7 @@ extern "C" int ss_topk_merge_dev(int device, uint32_t n_queries, uint32_t n_shar
   SS_HIP(hipSetDevice(device));
   uint32_t np = 64;
   while (np < n_shards * k) np <<= 1;
-  static bool attr = false;
-  if (!attr) {
-    SS_HIP(hipFuncSetAttribute((const void*)topk_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
-    attr = true;
-  }
+  SS_SET_MAX_LDS(topk_merge_kernel, 8192 * 8);
   topk_merge_kernel<<<n_queries, 256, np * sizeof(u64), (hipStream_t)stream>>>(n_queries, n_shards, k, d_doc, d_score, d_count,
                                                                               (u64*)d_out_doc, d_out_score, d_out_count);
   SS_HIP(hipGetLastError());

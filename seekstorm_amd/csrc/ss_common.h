@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -26,14 +27,15 @@ constexpr int BM_SUB_LOG2 = 12;             // docs per sub-block = 4096 = one w
 constexpr int BM_SUB = 1 << BM_SUB_LOG2;
 constexpr int BM_WAVES_OR = 8 << (12 - BM_SUB_LOG2);   // waves per workgroup (one workgroup per CU), union-only kernels
 constexpr int BM_WAVES_AND = 6 << (12 - BM_SUB_LOG2);  // kernels that also carry match counters
-constexpr uint32_t BM_TF_MAX = 511;         // 9-bit tf field
+constexpr uint32_t BM_TF_ESC = 511;         // 9-bit tf field; 511 = "the exact tf (>= 511) is in the term's exception list"
 // Packed posting (one dword).  Laid out so that the two LDS byte offsets the scan needs are single AND / shift+AND
 // extractions and everything else rides in the bits they mask off:
 //   bits  2..14  doc field = doc-in-sub-block + 1 (1..4096)            -> p & 0x7FFC        = 4 * field (accumulator)
 //   bits 18..25  LUT column, bits 26..29 tf & 15                       -> (p >> 16) & 0x3FFC = 4 * ((tf & 15) << 8 | col)
 //                col = (len + 7 * (tf & 15)) & 255: rows of the weight table are rotated against each other so that
 //                equal lengths with different tf (the common case inside one wave) fall into different LDS banks
-//   bit 15, bits 16..17, bits 30..31 = tf bits 4, 5..6, 7..8 (non-zero only when tf >= 16: weight computed, not looked up)
+//   bit 15, bits 16..17, bits 30..31 = tf bits 4, 5..6, 7..8 (non-zero only when tf >= 16: weight computed, not looked up);
+//                tf >= 511 is stored as 511 and its exact value kept in a per-term exception list (doc, tf) sorted by doc
 // The all-zero dword is the NULL posting (segment padding, and what an out-of-range buffer load returns): its doc
 // field addresses the dump slot in front of a wave's accumulator tile and its table weight (tf = 0) is 0.
 constexpr uint32_t BM_BIG_TF_MASK = 0xC0038000u;
@@ -93,6 +95,9 @@ struct ss_shard {
   // {u64 bits of 64 docs, u32 index (inside the term's posting array) of their first posting} per (term, sub-block, 64-doc group)
   uint4* d_probe = nullptr;        // [n_terms + 1][n_sub][BM_SUB / 64]; row n_terms is all zero (absent terms)
   int bm_strategy = SS_BM25_AUTO;  // ss_bm25_set_strategy
+  uint64_t* d_exc_off = nullptr;   // [n_terms + 2] CSR of the exception lists (postings with tf >= 511)
+  uint32_t* d_exc_doc = nullptr;   // shard-local doc ids, ascending per term
+  uint32_t* d_exc_tf = nullptr;    // exact tf
   float* d_umax = nullptr;         // [n_terms + 1] largest weight tf*(K+1)/(tf+comp[len]) of the term (max_list_score / idf)
   // bm25 workspace
   void* d_bq = nullptr; size_t bq_cap = 0;       // staged queries
@@ -100,6 +105,20 @@ struct ss_shard {
   uint64_t* d_ptotal = nullptr;                   // per (query, partition) match counts
   ss_prof prof;
 };
+
+// Opt-in to more than 64 KB of dynamic LDS is a per-device function attribute: set it once per (kernel, device) --
+// one process may hold shards on several GPUs (C++ host Index), and concurrent searches may race to be first.
+#define SS_SET_MAX_LDS(kernel_fn, bytes)                                                            \
+  do {                                                                                              \
+    static std::atomic<uint32_t> _done_mask{0};                                                     \
+    int _dev = 0;                                                                                   \
+    SS_HIP(hipGetDevice(&_dev));                                                                    \
+    const uint32_t _bit = 1u << (_dev & 31);                                                        \
+    if (!(_done_mask.load(std::memory_order_acquire) & _bit)) {                                     \
+      SS_HIP(hipFuncSetAttribute((const void*)(kernel_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes))); \
+      _done_mask.fetch_or(_bit, std::memory_order_release);                                         \
+    }                                                                                               \
+  } while (0)
 
 // error helper
 #define SS_HIP(x)                                   \

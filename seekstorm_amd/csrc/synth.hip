@@ -99,6 +99,21 @@ __host__ __device__ inline float bm_weight_of(uint32_t tf, uint32_t len_byte, co
   return tf < 16u ? comp[256 + (tf << 8) + bm_lut_col(len_byte, tf)] : (float)tf * 2.2f / ((float)tf + comp[len_byte]);
 }
 
+// exception lists: CSR by term of (doc, exact tf) for the postings whose tf saturates the 9-bit field
+static int upload_exceptions(ss_shard* s, const std::vector<u64>& off, const std::vector<uint32_t>& doc,
+                             const std::vector<uint32_t>& tf) {
+  const size_t n = doc.size();
+  SS_HIP(hipMalloc(&s->d_exc_off, off.size() * sizeof(u64)));
+  SS_HIP(hipMalloc(&s->d_exc_doc, (n + 1) * sizeof(uint32_t)));
+  SS_HIP(hipMalloc(&s->d_exc_tf, (n + 1) * sizeof(uint32_t)));
+  SS_HIP(hipMemcpy(s->d_exc_off, off.data(), off.size() * sizeof(u64), hipMemcpyHostToDevice));
+  if (n) {
+    SS_HIP(hipMemcpy(s->d_exc_doc, doc.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    SS_HIP(hipMemcpy(s->d_exc_tf, tf.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  return SS_OK;
+}
+
 int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t* offs, const uint32_t* docs,
                              const uint16_t* tfs) {
   const uint32_t nt = s->bm_n_terms, ns = s->bm_n_sub;
@@ -132,7 +147,10 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
   }
   tbase[nt] = units;
   std::vector<uint32_t> post(units ? units * 4 : 4, 0u);
+  std::vector<u64> exc_off((size_t)nt + 2, 0);
+  std::vector<uint32_t> exc_doc, exc_tf;
   for (uint32_t t = 0; t < nt; t++) {
+    exc_off[t] = exc_doc.size();
     const uint32_t* row = sub.data() + (size_t)t * (ns + 1);
     u64 j = offs[t];
     for (uint32_t sb = 0; sb < ns; sb++) {
@@ -142,14 +160,18 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
         if (docs[j] >= s->bm_n_docs) return SS_EINVAL;
         if (j > offs[t] && docs[j] <= docs[j - 1]) return SS_EINVAL;
         if (tfs[j] == 0) return SS_EINVAL;
-        if (tfs[j] > BM_TF_MAX) return SS_ENOTSUP;
-        post[w] = bm_pack(docs[j] & (BM_SUB - 1), doclen[docs[j]], tfs[j]);
+        const uint32_t tf = tfs[j];
+        if (tf >= BM_TF_ESC) { exc_doc.push_back(docs[j]); exc_tf.push_back(tf); }  // exact value kept in the exception list
+        post[w] = bm_pack(docs[j] & (BM_SUB - 1), doclen[docs[j]], tf < BM_TF_ESC ? tf : BM_TF_ESC);
       }
     }
   }
+  exc_off[nt] = exc_off[nt + 1] = exc_doc.size();
   s->bm_n_post = offs[nt];
   const size_t rows = (size_t)nt * (ns + 1);
   int rc = alloc_post(s, units);
+  if (rc) return rc;
+  rc = upload_exceptions(s, exc_off, exc_doc, exc_tf);
   if (rc) return rc;
   SS_HIP(hipMalloc(&s->d_term_base, ((size_t)nt + 1) * sizeof(u64)));
   SS_HIP(hipMalloc(&s->d_sub_off, (rows + ns + 1) * sizeof(uint32_t)));  // + one all-zero row (absent terms)
@@ -328,6 +350,8 @@ int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const u
   fill_comp(s->bm_avgdl, comp);
   SS_HIP(hipMemcpy(s->d_comp, comp, sizeof(comp), hipMemcpyHostToDevice));
   int rc = alloc_post(s, units);
+  if (rc) return rc;
+  rc = upload_exceptions(s, std::vector<u64>((size_t)nt + 2, 0), {}, {});  // generated tf <= 32: no exceptions
   if (rc) return rc;
   rc = alloc_probe(s, st);
   if (rc) return rc;

@@ -310,13 +310,8 @@ int ssi_vec_alloc_ws(ss_shard* s) {
   }
   if (!s->d_vstate) SS_HIP(hipMalloc(&s->d_vstate, sizeof(VState)));
   if (!s->d_cand) SS_HIP(hipMalloc(&s->d_cand, (size_t)64 * VS_CAP * sizeof(unsigned long long)));
-  static bool attr_done = false;
-  if (!attr_done) {
-    SS_HIP(hipFuncSetAttribute((const void*)vec_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, VS_LDS));
-    SS_HIP(hipFuncSetAttribute((const void*)vec_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               VS_CAP * (sizeof(unsigned long long) + sizeof(uint32_t))));
-    attr_done = true;
-  }
+  SS_SET_MAX_LDS(vec_scan_kernel, VS_LDS);
+  SS_SET_MAX_LDS(vec_refine_kernel, VS_CAP * (sizeof(unsigned long long) + sizeof(uint32_t)));
   return SS_OK;
 }
 

@@ -37,10 +37,13 @@ def _corpus(O, n_docs, dfs, seed, tie_heavy=False, big_tf=False):
         if tie_heavy:
             tf = np.where(rng.random(n) < 0.97, 1, 2).astype(np.uint16)
         else:
-            tf = (1 + rng.geometric(0.55, n) - 1).clip(1, 400).astype(np.uint16)
+            tf = rng.geometric(0.55, n).clip(1, 400).astype(np.uint16)
             if big_tf:
                 m = rng.random(n) < 0.03
                 tf[m] = rng.integers(16, 400, int(m.sum())).astype(np.uint16)
+            if big_tf == 2:  # tf beyond the 9-bit posting field: exact values come from the exception lists
+                m = rng.random(n) < 0.01
+                tf[m] = rng.choice([510, 511, 512, 3000, 65535], int(m.sum())).astype(np.uint16)
         docs.append(d); tfs.append(tf); offs.append(offs[-1] + n)
     return doclen, np.asarray(offs, np.uint64), np.concatenate(docs), np.concatenate(tfs)
 
@@ -53,7 +56,7 @@ def _run(S, sh, queries, k, rt, strategy):
     return out
 
 
-@pytest.mark.parametrize("tie_heavy,big_tf", [(False, False), (True, False), (False, True)])
+@pytest.mark.parametrize("tie_heavy,big_tf", [(False, 0), (True, 0), (False, 1), (False, 2)])
 def test_pruned_equals_exhaustive_and_oracle(S, O, tie_heavy, big_tf):
     from seekstorm_amd import _native as N
     n_docs = 150_000
