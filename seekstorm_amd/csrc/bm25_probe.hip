@@ -23,7 +23,8 @@
 
 #include "bm25_dev.h"
 
-constexpr int PB_WAVES = 4;
+constexpr int PB_WAVES = 8;
+constexpr int PB_QCAP = 320;  // survivor queue entries per wave: < 64 left over + one group of 4 x 64 pushed
 
 
 template <int KPL>
@@ -135,11 +136,82 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
     return score;
   };
 
+  auto offer = [&](bool cand, float score, uint32_t doc) {
+    if (__ballot(cand)) {
+      const u64 key = cand ? (((u64)__float_as_uint(score) << 32) | (u64)(0xFFFFFFFFu - doc)) : 0ull;
+      const u64 key2 = key > T.worst ? key : 0ull;
+      if (__ballot(key2 != 0ull)) T = bm_offer_lane_keys<KPL>(T, key2, k, tau_q);
+    }
+  };
+  auto cur_thr = [&]() -> float {
+    return fmaxf(T.wsc, __uint_as_float(__hip_atomic_load(tau_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+  };
+
+  // Survivor queue (LDS, private to the wave): candidates that passed the DENSE stage -- driver posting weighed, first
+  // other term probed -- wait here until 64 of them can take the SPARSE stage together (posting fetch of the probed
+  // term, remaining probes, score).  After the first probe only a few percent of the lanes are still alive; without
+  // the queue every later gather round trip would be paid for a handful of lanes.
+  constexpr uint32_t QCAP = PB_QCAP;
+  const uint32_t q_doc = BM_LUT_BYTES + (uint32_t)w * (QCAP * 12u), q_w0 = q_doc + QCAP * 4u, q_pos = q_w0 + QCAP * 4u;
+  uint32_t qn = 0;
+
   // one driver stream: the postings of processing term J inside this partition's sub-block range
   auto stream = [&](auto Jc) {
     constexpr int J = decltype(Jc)::value;
+    constexpr int A = J == 0 ? 1 : 0;  // the first other term in probe order
     const uint32_t x_begin = rowp[J][s_begin] * 4u, x_end = rowp[J][s_end] * 4u;  // dword range of the stream
     if (x_begin == x_end) return;
+
+    // ---- sparse stage: the LAST n queue entries (n <= 64), one per lane
+    auto drain = [&](uint32_t n) {
+      const float thr = cur_thr();
+      bool alive = (uint32_t)lane < n;
+      const uint32_t qb = (qn - n + (uint32_t)lane) * 4u;
+      const uint32_t doc = alive ? lds_ld32(q_doc + qb) : 0u;
+      const uint32_t pos = alive ? lds_ld32(q_pos + qb) : 0xFFFFFFFFu;
+      const uint32_t tile = doc >> BM_SUB_LOG2, d = doc & (BM_SUB - 1);
+      float wv[NT];
+#pragma unroll
+      for (int t = 0; t < NT; t++) wv[t] = 0.f;
+      wv[J] = alive ? lds_ldf(q_w0 + qb) : 0.f;
+      uint32_t pres = 1u << J;
+      float known = idf[J] * wv[J];
+      if (alive && pos != 0xFFFFFFFFu) {  // hit in term A: now fetch its posting
+        const uint32_t pa = tptr[A][pos];
+        wv[A] = pb_weight(pa, X, tid_[A], doc);
+        pres |= 1u << A;
+        known += idf[A] * wv[A];
+      }
+      float rest = SU[0] - U[J] - ((uint32_t)A < nt ? U[A] : 0.f);
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        if (t == J || t == A || (uint32_t)t >= nt) continue;
+        if (!is_and && k) alive = alive && (known + rest) >= thr * 0.99999f;
+        if (__ballot(alive) == 0ull) break;
+        rest -= U[t];
+        uint4 rec = make_uint4(0, 0, 0, 0);
+        if (alive) rec = prow[t][(size_t)tile * (BM_SUB / 64) + (d >> 6)];
+        const u64 bits = ((u64)rec.y << 32) | rec.x;
+        bool hit = alive && ((bits >> (d & 63u)) & 1ull);
+        if (is_and) alive = hit;
+        else if (t < J && hit) { alive = false; hit = false; }  // evaluated in the earlier term's stream
+        if (hit) {
+          const uint32_t pt = tptr[t][rec.z + (uint32_t)__popcll(bits & ((1ull << (d & 63u)) - 1ull))];
+          wv[t] = pb_weight(pt, X, tid_[t], doc);
+          pres |= 1u << t;
+          known += idf[t] * wv[t];
+        }
+      }
+      if (__ballot(alive)) {
+        if (count && is_and) T.matched += __popcll(__ballot(alive));
+        if (k) {
+          const float score = combine(wv, pres);
+          offer(alive && score >= thr && score > 0.f, score, doc);
+        }
+      }
+      qn -= n;
+    };
+
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[J], 0, (int)(x_end * 4u), BM_RSRC_FLAGS);
     // sub-block boundaries of the driver (dword offsets), 64 per block load: lane i = sub-block blk0 + i
     uint32_t blk0 = s_begin;
@@ -148,14 +220,21 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
       return __builtin_amdgcn_readlane(vb, s - blk0);
     };
     uint32_t s_cur = s_begin;  // sub-block containing the stream position x (bnd(s_cur) <= x)
+    uint32_t pn[G];            // driver postings of the NEXT group (prefetched)
+#pragma unroll
+    for (int g = 0; g < G; g++) pn[g] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane4 + g * 256, (int)(x_begin * 4u), 0);
     for (uint32_t x = x_begin; x < x_end; x += 64u * G) {
-      const float thr = fmaxf(T.wsc, __uint_as_float(__hip_atomic_load(tau_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
-      if (!is_and && J > 0 && k && SU[J] < thr * 0.99999f) return;  // this and all later terms are non-essential now
+      const float thr = cur_thr();
+      if (!is_and && J > 0 && k && SU[J] < thr * 0.99999f) break;  // this and all later terms are non-essential now
       uint32_t pg[G], tile[G];
 #pragma unroll
       for (int g = 0; g < G; g++) {
-        pg[g] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane4 + g * 256, (int)(x * 4u), 0);
+        pg[g] = pn[g];
         tile[g] = s_cur;
+      }
+      if (x + 64u * G < x_end) {
+#pragma unroll
+        for (int g = 0; g < G; g++) pn[g] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane4 + g * 256, (int)((x + 64u * G) * 4u), 0);
       }
       // each lane's sub-block: count the boundaries at or before its stream position
       const uint32_t x_hi = min(x + 64u * G, x_end);
@@ -171,72 +250,60 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
 #pragma unroll
         for (int g = 0; g < G; g++) tile[g] += (x + 64u * g + (uint32_t)lane) >= b ? 1u : 0u;
       }
-      uint32_t dg[G], pres[G];
+      // ---- dense stage: weigh the driver posting, probe the first other term
+      uint32_t dg[G];
       bool alive[G];
-      float wv[G][NT], known[G];
+      float w0[G];
 #pragma unroll
       for (int g = 0; g < G; g++) {
         alive[g] = pg[g] != 0u;
         dg[g] = ((pg[g] >> 2) & 0x1FFFu) - 1u;  // doc inside its sub-block
-        pres[g] = 1u << J;
-#pragma unroll
-        for (int t = 0; t < NT; t++) wv[g][t] = 0.f;
-        wv[g][J] = alive[g] ? pb_weight(pg[g], X, tid_[J], (tile[g] << BM_SUB_LOG2) + dg[g]) : 0.f;
-        known[g] = idf[J] * wv[g][J];
+        w0[g] = alive[g] ? pb_weight(pg[g], X, tid_[J], (tile[g] << BM_SUB_LOG2) + dg[g]) : 0.f;
       }
-      float rest = SU[0] - U[J];
-#pragma unroll
-      for (int t = 0; t < NT; t++) {
-        if (t == J || (uint32_t)t >= nt) continue;
-        bool any = false;
+      if (nt == 1) {  // single-term query: the driver posting is the whole score
 #pragma unroll
         for (int g = 0; g < G; g++) {
-          if (!is_and && k) alive[g] = alive[g] && (known[g] + rest) >= thr * 0.99999f;
-          any |= __ballot(alive[g]) != 0ull;
-        }
-        if (!any) break;
-        rest -= U[t];
-        uint4 rec[G];
-#pragma unroll
-        for (int g = 0; g < G; g++) {
-          rec[g] = make_uint4(0, 0, 0, 0);
-          if (alive[g]) rec[g] = prow[t][(size_t)tile[g] * (BM_SUB / 64) + (dg[g] >> 6)];
-        }
-        uint32_t pt[G];
-        bool hit[G];
-#pragma unroll
-        for (int g = 0; g < G; g++) {
-          const u64 bits = ((u64)rec[g].y << 32) | rec[g].x;
-          hit[g] = alive[g] && ((bits >> (dg[g] & 63u)) & 1ull);
-          if (is_and) alive[g] = hit[g];
-          else if (t < J && hit[g]) { alive[g] = false; hit[g] = false; }  // evaluated in the earlier term's stream
-          pt[g] = 0u;
-          if (hit[g]) pt[g] = tptr[t][rec[g].z + (uint32_t)__popcll(bits & ((1ull << (dg[g] & 63u)) - 1ull))];
-        }
-#pragma unroll
-        for (int g = 0; g < G; g++) {
-          if (hit[g]) {
-            wv[g][t] = pb_weight(pt[g], X, tid_[t], (tile[g] << BM_SUB_LOG2) + dg[g]);
-            pres[g] |= 1u << t;
-            known[g] += idf[t] * wv[g][t];
+          if (__ballot(alive[g]) == 0ull) continue;
+          if (count) T.matched += __popcll(__ballot(alive[g]));
+          if (k) {
+            const float score = fmaf(idf[J], w0[g], 0.f);
+            offer(alive[g] && score >= thr && score > 0.f, score, (tile[g] << BM_SUB_LOG2) + dg[g]);
           }
         }
+        continue;
+      }
+      const float rest0 = SU[0] - U[J];
+      uint4 rec[G];
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        if (!is_and && k) alive[g] = alive[g] && (idf[J] * w0[g] + rest0) >= thr * 0.99999f;
+        rec[g] = make_uint4(0, 0, 0, 0);
+        if (alive[g]) rec[g] = prow[A][(size_t)tile[g] * (BM_SUB / 64) + (dg[g] >> 6)];
       }
 #pragma unroll
       for (int g = 0; g < G; g++) {
-        if (__ballot(alive[g]) == 0ull) continue;
-        if (count && (is_and || nt == 1)) T.matched += __popcll(__ballot(alive[g]));
-        if (k) {
-          const float score = combine(wv[g], pres[g]);
-          const bool cand = alive[g] && score >= thr && score > 0.f;
-          if (__ballot(cand)) {
-            const u64 key = cand ? (((u64)__float_as_uint(score) << 32) | (u64)(0xFFFFFFFFu - ((tile[g] << BM_SUB_LOG2) + dg[g]))) : 0ull;
-            const u64 key2 = key > T.worst ? key : 0ull;
-            if (__ballot(key2 != 0ull)) T = bm_offer_lane_keys<KPL>(T, key2, k, tau_q);
+        const u64 bits = ((u64)rec[g].y << 32) | rec[g].x;
+        bool hit = alive[g] && ((bits >> (dg[g] & 63u)) & 1ull);
+        uint32_t pos = 0xFFFFFFFFu;
+        if (is_and) alive[g] = hit;
+        else if (A < J && hit) { alive[g] = false; hit = false; }  // evaluated in the earlier term's stream
+        else if (!hit && k) alive[g] = alive[g] && (idf[J] * w0[g] + rest0 - U[A]) >= thr * 0.99999f;
+        if (hit) pos = rec[g].z + (uint32_t)__popcll(bits & ((1ull << (dg[g] & 63u)) - 1ull));
+        // push the survivors of this chunk
+        const u64 m = __ballot(alive[g]);
+        if (m) {
+          if (alive[g]) {
+            const uint32_t at = qn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            lds_st32(q_doc + at * 4u, (tile[g] << BM_SUB_LOG2) + dg[g]);
+            lds_stf(q_w0 + at * 4u, w0[g]);
+            lds_st32(q_pos + at * 4u, pos);
           }
+          qn += (uint32_t)__popcll(m);
         }
       }
+      while (qn >= 64u) drain(64u);
     }
+    if (qn) drain(qn);
   };
   // drivers: unions -> every term in upper-bound order (a stream ends as soon as its term is non-essential);
   // intersections -> the shortest list only
@@ -256,7 +323,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
 template <int NT, int KPL>
 static int launch_probe(const BmParams& p, const uint4* probe, const float* umax, hipStream_t st) {
   const uint32_t A = p.nq * p.P;
-  bm25_probe_kernel<NT, KPL><<<(A + PB_WAVES - 1) / PB_WAVES, PB_WAVES * 64, BM_LUT_BYTES, st>>>(
+  bm25_probe_kernel<NT, KPL><<<(A + PB_WAVES - 1) / PB_WAVES, PB_WAVES * 64, BM_LUT_BYTES + PB_WAVES * PB_QCAP * 12, st>>>(
       p.post, p.term_base, p.sub_off, p.comp, probe, umax, p.q, p.part_keys, p.total, p.tau, p.exc_off, p.exc_doc, p.exc_tf, p.n_sub, p.n_terms, p.nq, p.P, p.k,
       p.count);
   return SS_OK;
