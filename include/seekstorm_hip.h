@@ -68,6 +68,22 @@ int ss_shard_sync(ss_shard* s);
  * the HBM image (sub-block CSR of packed postings, bm25_component_cache per commit.rs:318-325). */
 int ss_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t n_terms,
                    const uint64_t* term_offsets, const uint32_t* doc_ids, const uint16_t* tfs);
+/* Same image from the reference's own in-RAM block format (first step of SURVEY section 8 f-1): one ss_ref_block per
+ * (term, 65 536-doc block) = BlockObjectIndex (index.rs:781-789) + the key-body byte array of the segment the posting
+ * list lives in (index.rs:991-995).  Doc-id containers (Array / Bitmap / Rle, compress_postinglist.rs:694-946) and the
+ * rank/position pointers (tf = positions_count, add_result.rs:2036-2197) are decoded on the host.  Single indexed
+ * field, SingleTerm keys; blocks of a term ascending by block_id. */
+typedef struct {
+  uint32_t block_id;                 /* docs block_id * 65536 + local */
+  uint32_t compression_type_pointer; /* CompressionType << 30 | rank_position_pointer_range */
+  uint16_t posting_count_m1;         /* posting_count - 1, as stored */
+  uint16_t pointer_pivot_p_docid;    /* ranks below it have 2-byte pointers, the others 3-byte */
+  const uint8_t* byte_array;         /* key bodies of the segment */
+  uint64_t byte_array_len;
+} ss_ref_block;
+int ss_ref_decode_block(const ss_ref_block* block, uint16_t* docs_out /*[65536]*/, uint16_t* tfs_out /*[65536]*/);
+int ss_bm25_upload_ref_blocks(ss_shard* s, uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t n_terms,
+                              const uint64_t* term_block_offsets /*[n_terms+1]*/, const ss_ref_block* blocks);
 /* Device-side synthetic corpus (bench/test utility; generator = oracle so_lex_*):
  * posting (t,d) iff (h(seed,t+1,d)>>32) < thresh32[t]; bit-identical to ss_bm25_upload of the same corpus. */
 int ss_bm25_synth(ss_shard* s, uint64_t seed, uint64_t n_docs, uint32_t n_terms, const uint32_t* thresh32,

@@ -1,0 +1,156 @@
+"""TEST INFRASTRUCTURE ONLY (see oracle/README): writer of the reference's in-RAM posting-list block format, restated
+from the reference's indexing path so that the product's reader (seekstorm_amd/csrc/ref_format.hip) can be checked
+against byte arrays laid out exactly as a SeekStorm segment holds them.  Parity unpinned: no Rust toolchain in this image
+to produce the bytes with the reference itself; every function cites the lines it follows.
+
+Single indexed field, NgramType::SingleTerm keys.
+
+    posting record (index_posting.rs:40-66, 445-471, 568-660, 846-873; compress_postinglist.rs:948-976)
+    key body layout  (compress_postinglist.rs:415-525 docid_iterator, 694-946 container writers)
+    chooser          (compress_postinglist.rs:242-332; Delta disabled)
+"""
+import numpy as np
+
+CT_DELTA, CT_ARRAY, CT_BITMAP, CT_RLE = 0, 1, 2, 3  # index.rs:838-843
+STOP = 0x80
+
+
+def _bits(v):
+    return int(v).bit_length()
+
+
+def vint(v):
+    """write_field_vec / compress_positions single-field VINT: most significant 7-bit group first, stop bit on the last
+    byte (index_posting.rs:858-873)"""
+    if v < 128:
+        return bytes([v | STOP])
+    if v < 16384:
+        return bytes([v >> 7, (v & 0x7F) | STOP])
+    assert v < 2097152
+    return bytes([v >> 14, (v >> 7) & 0x7F, (v & 0x7F) | STOP])
+
+
+def position_vint(d):
+    """compress_positions (compress_postinglist.rs:948-976); note the >> 13 of the three-byte form is the reference's"""
+    if d < 128:
+        return bytes([d | STOP])
+    if d < 16384:
+        return bytes([(d >> 7) & 0x7F, (d & 0x7F) | STOP])
+    return bytes([(d >> 13) & 0x7F, (d >> 7) & 0x7F, (d & 0x7F) | STOP])
+
+
+def delta_positions(positions):
+    """index_posting.rs:55-64: first position absolute, then gap - 1"""
+    out, prev = [], 0
+    for i, p in enumerate(positions):
+        out.append(p if i == 0 else p - prev - 1)
+        prev = p
+    return out
+
+
+def embeddable(deltas, pointer_size):
+    """index_posting.rs:447-471 (indexed_field_vec.len() == 1)"""
+    n = len(deltas)
+    b = [_bits(x) for x in deltas]
+    if pointer_size == 2:
+        return (n == 1 and b[0] <= 14) or (n == 2 and b[0] <= 7 and b[1] <= 7)
+    return ((n == 1 and b[0] <= 21) or (n == 2 and b[0] <= 10 and b[1] <= 11) or
+            (n == 3 and max(b) <= 7) or (n == 4 and max(b[:3]) <= 5 and b[3] <= 6))
+
+
+def embed(deltas, pointer_size):
+    """index_posting.rs:592-640: positions packed into the pointer itself"""
+    n = len(deltas)
+    remaining = pointer_size * 8 - (0 if pointer_size == 2 else 1) - 2
+    data = 0
+    for i, d in enumerate(deltas):
+        w = remaining // (n - i)
+        remaining -= w
+        data = (data << w) | d
+    if pointer_size == 2:
+        return bytes([data & 0xFF, ((data >> 8) | 0x80 | ((n - 1) << 6)) & 0xFF])
+    return bytes([data & 0xFF, (data >> 8) & 0xFF, ((data >> 16) | 0x80 | ((n - 1) << 5)) & 0xFF])
+
+
+def container(local_docs):
+    """(compression type, bytes): chooser compress_postinglist.rs:256-332, writers :694 / :759 / :832"""
+    d = np.asarray(local_docs, np.int64)
+    n = len(d)
+    runs = 1 + int(np.count_nonzero(np.diff(d) != 1))
+    thr = n // 2 if n < 4096 else 2048
+    if thr > 0 and runs - 1 < thr:
+        starts = np.concatenate(([0], np.nonzero(np.diff(d) != 1)[0] + 1))
+        ends = np.concatenate((starts[1:], [n]))
+        out = bytearray(int(runs).to_bytes(2, "little"))
+        for s, e in zip(starts, ends):
+            out += int(d[s]).to_bytes(2, "little") + int(e - s - 1).to_bytes(2, "little")
+        return CT_RLE, bytes(out)
+    if n < 4096:
+        return CT_ARRAY, d.astype("<u2").tobytes()
+    bm = np.zeros(8192, np.uint8)
+    np.bitwise_or.at(bm, d >> 3, (1 << (d & 7)).astype(np.uint8))
+    return CT_BITMAP, bm.tobytes()
+
+
+def encode_key_body(local_docs, positions_per_doc, base=0, positions_limit=32768):
+    """One posting list of one block -> (body bytes, compression_type_pointer, posting_count, pointer_pivot_p_docid).
+    `base` = offset of the body inside the segment's byte array (the previous keys' bodies).  positions_limit is the
+    reference's 32 768 (index_posting.rs:193, 579-587); tests lower it to reach 3-byte pointers with small inputs."""
+    n = len(local_docs)
+    assert n == len(positions_per_doc) and 1 <= n <= 65536
+    size_positions = 0
+    pivot = 0
+    pointers, records = [], []
+    three = False
+    for rank, pos in enumerate(positions_per_doc):
+        deltas = delta_positions(pos)
+        # index_posting.rs:193-199
+        if not three and size_positions < positions_limit and rank < 65535:
+            pivot = rank + 1
+            psize = 2
+        else:
+            psize = 3
+            three = True
+        if embeddable(deltas, psize):
+            pointers.append(embed(deltas, psize))
+            continue
+        rec = vint(len(pos)) + b"".join(position_vint(x) for x in deltas)
+        if psize == 2 and size_positions + len(rec) >= positions_limit:  # index_posting.rs:579-587
+            psize, pivot, three = 3, rank, True
+        size_positions += len(rec)
+        records.append(rec)
+        # compress_postinglist.rs:473-515: the pointer is the cumulative size = distance back from the pointer range
+        if psize == 2:
+            assert size_positions < 32768
+            pointers.append(bytes([size_positions & 255, (size_positions >> 8) & 127]))
+        else:
+            assert size_positions < (1 << 23)
+            pointers.append(bytes([size_positions & 255, (size_positions >> 8) & 255, (size_positions >> 16) & 127]))
+    ctype, cont = container(local_docs)
+    body = b"".join(reversed(records)) + b"".join(pointers) + cont
+    rng = base + size_positions
+    assert rng < (1 << 30)
+    return body, (ctype << 30) | rng, n, pivot
+
+
+def random_positions(rng, tf, max_gap=40):
+    """ascending u16 positions"""
+    max_gap = max(1, min(max_gap, 65536 // tf))
+    gaps = rng.integers(0, max_gap, size=tf)
+    pos = np.cumsum(gaps + 1) - 1
+    assert pos[-1] < 65536
+    return [int(x) for x in pos]
+
+
+def encode_term(docs, tfs, rng, base_bytes=b"", positions_limit=32768, max_gap=40):
+    """Whole posting list -> list of (block_id, compression_type_pointer, posting_count, pivot, byte_array); every block's
+    byte array begins with `base_bytes` (standing for other keys' bodies in the same segment)."""
+    docs = np.asarray(docs, np.int64)
+    out = []
+    bid = docs >> 16
+    for b in np.unique(bid):
+        sel = np.nonzero(bid == b)[0]
+        pos = [random_positions(rng, int(tfs[i]), max_gap) for i in sel]
+        body, ctp, cnt, pivot = encode_key_body(docs[sel] & 0xFFFF, pos, len(base_bytes), positions_limit)
+        out.append((int(b), ctp, cnt, pivot, base_bytes + body))
+    return out

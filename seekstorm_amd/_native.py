@@ -33,6 +33,11 @@ class Bm25Query(C.Structure):
                 ("idf", C.c_float * SS_MAX_QUERY_TERMS)]
 
 
+class RefBlock(C.Structure):  # ss_ref_block
+    _fields_ = [("block_id", C.c_uint32), ("compression_type_pointer", C.c_uint32), ("posting_count_m1", C.c_uint16),
+                ("pointer_pivot_p_docid", C.c_uint16), ("byte_array", C.c_void_p), ("byte_array_len", C.c_uint64)]
+
+
 BM25_QUERY_DTYPE = np.dtype([("n_terms", np.uint32), ("op", np.uint32), ("term", np.uint32, (SS_MAX_QUERY_TERMS,)),
                              ("idf", np.float32, (SS_MAX_QUERY_TERMS,))])
 assert BM25_QUERY_DTYPE.itemsize == C.sizeof(Bm25Query)
@@ -46,6 +51,8 @@ SYMBOLS = [
     ("ss_shard_destroy", C.c_int, [C.c_void_p]),
     ("ss_shard_sync", C.c_int, [C.c_void_p]),
     ("ss_bm25_upload", C.c_int, [C.c_void_p, C.c_uint64, u8p, C.c_uint32, u64p, u32p, u16p]),
+    ("ss_ref_decode_block", C.c_int, [C.c_void_p, u16p, u16p]),
+    ("ss_bm25_upload_ref_blocks", C.c_int, [C.c_void_p, C.c_uint64, u8p, C.c_uint32, u64p, C.c_void_p]),
     ("ss_bm25_synth", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, u32p, u8p]),
     ("ss_bm25_info", C.c_int, [C.c_void_p, u64p, f32p, u32p, u64p]),
     ("ss_bm25_term_df", C.c_int, [C.c_void_p, C.c_uint32, u32p, u64p]),

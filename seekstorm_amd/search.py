@@ -124,6 +124,24 @@ class Shard:
         self.indexed_doc_count = int(n_docs)
         self._df_cache.clear()
 
+    def upload_ref_blocks(self, n_docs, doclen_bytes, term_blocks):
+        """term_blocks: per term a list of (block_id, compression_type_pointer, posting_count, pointer_pivot_p_docid,
+        key_body_bytes) in the reference's in-RAM format (ss_bm25_upload_ref_blocks)"""
+        dl = np.ascontiguousarray(doclen_bytes, np.uint8)
+        flat = [b for tb in term_blocks for b in tb]
+        arr = (N.RefBlock * max(len(flat), 1))()
+        keep = []
+        for i, (bid, ctp, cnt, pivot, body) in enumerate(flat):
+            buf = np.frombuffer(bytes(body), np.uint8).copy()
+            keep.append(buf)
+            arr[i] = N.RefBlock(bid, ctp, cnt - 1, pivot, buf.ctypes.data, len(buf))
+        offs = np.zeros(len(term_blocks) + 1, np.uint64)
+        offs[1:] = np.cumsum([len(tb) for tb in term_blocks])
+        N.check(N.lib().ss_bm25_upload_ref_blocks(self._h, int(n_docs), N.ptr(dl, N.u8p), len(term_blocks), N.ptr(offs, N.u64p),
+                                                  C.cast(arr, C.c_void_p)), "ss_bm25_upload_ref_blocks")
+        self.indexed_doc_count = int(n_docs)
+        self._df_cache.clear()
+
     def synth_lexical(self, seed, n_docs, thresh32, len_table1024):
         th = np.ascontiguousarray(thresh32, np.uint32)
         tab = np.ascontiguousarray(len_table1024, np.uint8)
