@@ -84,6 +84,25 @@ typedef struct {
 int ss_ref_decode_block(const ss_ref_block* block, uint16_t* docs_out /*[65536]*/, uint16_t* tfs_out /*[65536]*/);
 int ss_bm25_upload_ref_blocks(ss_shard* s, uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t n_terms,
                               const uint64_t* term_block_offsets /*[n_terms+1]*/, const ss_ref_block* blocks);
+/* ... and from a shard's index.bin as it lies on disk / in the mmap (writer commit.rs:264-369 and
+ * 467-552, reader index.rs:3263-3740).  ss_index_bin_open only walks the levels, segment head tables and key heads
+ * (host, no device needed) and borrows `bytes`, which must outlive the handle.  Term id = rank of the key_hash among
+ * the SingleTerm keys, ascending: the Rust side keeps translating term -> key_hash (ahash / gxhash stay in Rust) and
+ * binary-searches ss_index_bin_term_keys.  N-gram keys are counted and skipped; more than one indexed field (BM25F)
+ * is SS_ENOTSUP at decode time.  indexed_field_count / key_head_size (20 | 22 | 23, index.rs:2806-2812) come from
+ * schema.json / index.json; segment_number_bits is 11 for every index opened by the reference (index.rs:3285). */
+typedef struct ss_index_bin ss_index_bin;
+int ss_index_bin_open(const uint8_t* bytes, uint64_t len, uint32_t indexed_field_count, uint32_t key_head_size,
+                      uint32_t segment_number_bits, ss_index_bin** out);
+int ss_index_bin_close(ss_index_bin* ix);
+int ss_index_bin_info(const ss_index_bin* ix, uint64_t* n_docs, uint64_t* positions_sum_normalized, uint32_t* n_levels,
+                      uint32_t* n_terms, uint32_t* n_ngram_keys_skipped);
+int ss_index_bin_term_keys(const ss_index_bin* ix, uint64_t* keys_out /*[n_terms], ascending*/);
+/* decoded postings of one term (tooling / tests); SS_EINVAL with *n_out = needed capacity when cap is too small */
+int ss_index_bin_term_postings(const ss_index_bin* ix, uint32_t term, uint64_t cap, uint32_t* docs_out, uint16_t* tfs_out,
+                               uint64_t* n_out);
+int ss_bm25_upload_index_bin(ss_shard* s, const ss_index_bin* ix);
+
 /* Device-side synthetic corpus (bench/test utility; generator = oracle so_lex_*):
  * posting (t,d) iff (h(seed,t+1,d)>>32) < thresh32[t]; bit-identical to ss_bm25_upload of the same corpus. */
 int ss_bm25_synth(ss_shard* s, uint64_t seed, uint64_t n_docs, uint32_t n_terms, const uint32_t* thresh32,
@@ -127,6 +146,9 @@ int ss_bm25_search_dev(ss_shard* s, uint32_t n_queries, const ss_bm25_query* d_q
  * doc once with its best record's score, as TopK::push does (vector.rs:441-452, 462-473). */
 int ss_vec_upload(ss_shard* s, uint64_t n_rows, uint32_t dim, const float* rows, const uint32_t* row_doc_ids);
 /* Device-side synthetic matrix (generator = oracle so_vec_gen, uniform(-1,1) then normalize_f32). */
+/* Rows straight from a shard's vector.bin (writer vector.rs:1066-1094): per level u32 cluster_count + child counts,
+ * then 24-byte VectorHeader + dim x f32 records; doc id = (level << 16) | header.doc_id (vector.rs:1448).  f32 only. */
+int ss_vec_upload_vector_bin(ss_shard* s, const uint8_t* bytes, uint64_t len, uint32_t dim);
 int ss_vec_synth(ss_shard* s, uint64_t seed, uint64_t n_rows, uint32_t dim);
 int ss_vec_info(ss_shard* s, uint64_t* n_rows, uint32_t* dim);
 /* copy rows [r0, r0+n) back to the host (test accessor) */

@@ -154,3 +154,87 @@ def encode_term(docs, tfs, rng, base_bytes=b"", positions_limit=32768, max_gap=4
         body, ctp, cnt, pivot = encode_key_body(docs[sel] & 0xFFFF, pos, len(base_bytes), positions_limit)
         out.append((int(b), ctp, cnt, pivot, base_bytes + body))
     return out
+
+
+# ------------------------------------------------------------------------------------------------ index.bin / vector.bin
+def write_index_bin(n_docs, doclen_bytes, terms, rng, segment_number_bits=11, key_head_size=20, ngram_keys=(),
+                    positions_sum=None, positions_limit=32768):
+    """index.bin of one shard with one indexed field (commit.rs:264-369 level writer, 467-552 commit_segment,
+    compress_postinglist.rs:339-409 key head).  terms: list of (key_hash with low 3 bits 0, docs ascending, tfs).
+    ngram_keys: key hashes with NgramType bits set, written as 1-posting keys the reader has to skip.
+    Segment of a key = (key_hash >> 40) & mask here (the reference uses hash32(term) & mask, tokenizer.rs:660 -- a
+    different hash of the same term; readers never rely on it).  max_docid / max_p_docid (a-12 block-max posting) hold
+    the highest-tf posting: the device image derives its own bounds, no reader under test uses them."""
+    from . import oracle as O
+    nseg = 1 << segment_number_bits
+    dlc = np.array([O.lib().so_byte4_to_int(b) for b in range(256)], np.uint64)  # DOCUMENT_LENGTH_COMPRESSION
+    dl = np.zeros(((n_docs + 65535) >> 16) << 16, np.uint8)
+    dl[:n_docs] = doclen_bytes
+    out = bytearray()
+    out += (6).to_bytes(2, "little") + (1).to_bytes(2, "little")
+    psum_cum = 0
+    n_levels = (n_docs + 65535) >> 16
+    per_term_blocks = []
+    for key, docs, tfs in terms:
+        assert key & 7 == 0
+        per_term_blocks.append({b[0]: b for b in encode_term(docs, tfs, rng, positions_limit=positions_limit)})
+    for level in range(n_levels):
+        if level == 0:
+            out += (0).to_bytes(2, "little")  # longest_field_id
+        out += dl[level << 16:(level + 1) << 16].tobytes()
+        docs_cum = min(n_docs, (level + 1) << 16)
+        psum_cum += int(dlc[dl[level << 16:docs_cum]].sum())
+        out += docs_cum.to_bytes(8, "little")
+        out += (psum_cum if positions_sum is None or level + 1 < n_levels else positions_sum).to_bytes(8, "little")
+        segs = [[] for _ in range(nseg)]
+        for (key, _, _), blocks in zip(terms, per_term_blocks):
+            if level in blocks:
+                segs[(key >> 40) & (nseg - 1)].append((key, blocks[level]))
+        if level == 0:
+            for key in ngram_keys:
+                assert key & 7
+                segs[(key >> 40) & (nseg - 1)].append((key, None))
+        heads_tbl = bytearray()
+        payload = bytearray()
+        for seg in segs:
+            seg.sort(key=lambda e: e[0])
+            heads, bodies = bytearray(), bytearray()
+            for key, blk in seg:
+                if blk is None:  # n-gram key: one posting, doc 0, layout irrelevant to a reader that skips it
+                    body, ctp, cnt, pivot = encode_key_body([0], [[1]], base=len(bodies))
+                    maxd = maxp = 0
+                else:
+                    # re-base the body behind the previous keys' bodies: the pointer is relative to the key-body slice
+                    _, ctp0, cnt, pivot, raw = blk
+                    body = raw
+                    ctp = (ctp0 & 0xC0000000) | ((ctp0 & 0x3FFFFFFF) + len(bodies))
+                    maxp, maxd = 0, 0
+                h = bytearray(key.to_bytes(8, "little") + (cnt - 1).to_bytes(2, "little") + maxd.to_bytes(2, "little") +
+                              maxp.to_bytes(2, "little"))
+                h += bytes(key_head_size - 20)  # n-gram df bytes (22 / 23 byte heads)
+                h += pivot.to_bytes(2, "little") + ctp.to_bytes(4, "little")
+                assert len(h) == key_head_size
+                heads += h
+                bodies += body
+            heads_tbl += (len(heads) + len(bodies)).to_bytes(4, "little") + len(seg).to_bytes(4, "little")
+            payload += heads + bodies
+        out += heads_tbl + payload
+    return bytes(out)
+
+
+def write_vector_bin(levels, dim):
+    """vector.bin (vector.rs:1066-1094).  levels: per level a list of clusters, each a list of (doc_id u16, field_id,
+    chunk_id, vector f32[dim]); header = packed VectorHeader (vector.rs:62-73): u16 doc_id, u32 field_id, u32 chunk_id,
+    f32 scale, f32 norm, i16 zero_point, i32 sum_q."""
+    import struct
+    out = bytearray()
+    for clusters in levels:
+        out += len(clusters).to_bytes(4, "little")
+        for c in clusters:
+            out += len(c).to_bytes(4, "little")
+        for c in clusters:
+            for doc_id, field_id, chunk_id, v in c:
+                v = np.asarray(v, "<f4")
+                assert v.shape == (dim,)
+                out += struct.pack("<HIIffhi", doc_id, field_id, chunk_id, 1.0, 1.0, 0, 0) + v.tobytes()
+    return bytes(out)

@@ -53,6 +53,12 @@ SYMBOLS = [
     ("ss_bm25_upload", C.c_int, [C.c_void_p, C.c_uint64, u8p, C.c_uint32, u64p, u32p, u16p]),
     ("ss_ref_decode_block", C.c_int, [C.c_void_p, u16p, u16p]),
     ("ss_bm25_upload_ref_blocks", C.c_int, [C.c_void_p, C.c_uint64, u8p, C.c_uint32, u64p, C.c_void_p]),
+    ("ss_index_bin_open", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("ss_index_bin_close", C.c_int, [C.c_void_p]),
+    ("ss_index_bin_info", C.c_int, [C.c_void_p, u64p, u64p, u32p, u32p, u32p]),
+    ("ss_index_bin_term_keys", C.c_int, [C.c_void_p, u64p]),
+    ("ss_index_bin_term_postings", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, u32p, u16p, u64p]),
+    ("ss_bm25_upload_index_bin", C.c_int, [C.c_void_p, C.c_void_p]),
     ("ss_bm25_synth", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, u32p, u8p]),
     ("ss_bm25_info", C.c_int, [C.c_void_p, u64p, f32p, u32p, u64p]),
     ("ss_bm25_term_df", C.c_int, [C.c_void_p, C.c_uint32, u32p, u64p]),
@@ -61,6 +67,7 @@ SYMBOLS = [
     ("ss_bm25_search_dev", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("ss_vec_upload", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, f32p, u32p]),
+    ("ss_vec_upload_vector_bin", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]),
     ("ss_vec_synth", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32]),
     ("ss_vec_info", C.c_int, [C.c_void_p, u64p, u32p]),
     ("ss_vec_read_rows", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, f32p]),

@@ -12,7 +12,9 @@
 // embedded pointers carry the count in their top bits, the others point backwards into the VINT area whose first
 // value is the count (read_singlefield_value, add_result.rs:2584-2606).  N-gram keys (extra tf values before the
 // count) and multi-field postings are outside this reader: SS_ENOTSUP.
+#include <algorithm>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #include "ss_common.h"
@@ -145,4 +147,181 @@ extern "C" int ss_bm25_upload_ref_blocks(ss_shard* s, uint64_t n_docs, const uin
   }
   offs[n_terms] = docs.size();
   return ss_bm25_upload(s, n_docs, doclen_bytes, n_terms, offs.data(), docs.data(), tfs.data());
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// index.bin walker (writer commit.rs:264-369 + commit_segment 467-552, reader index.rs:3263-3740)
+//
+//   u16 major (= 6), u16 minor                                                         index.rs:103-107, 2839-2853
+//   per level (one 65 536-doc block id, shared by all keys):
+//     [u16 longest_field_id]   first level only                                        commit.rs:264-274
+//     indexed_field_count x [u8; 65536] length bytes                                   commit.rs:276-281
+//     u64 indexed_doc_count (cumulative), u64 positions_sum_normalized (cumulative)    commit.rs:298-311
+//     segment_number1 x (u32 block_length, u32 key_count)                              commit.rs:313-316, 355-363
+//     per segment: key_count heads of key_head_size bytes, ascending key_hash, then the key bodies
+//   key head (compress_postinglist.rs:339-409): u64 key_hash @0 (low 3 bits = NgramType), u16 posting_count - 1 @8,
+//     u16 max_docid @10, u16 max_p_docid @12, n-gram df bytes @14.., u16 pointer_pivot_p_docid @size-6,
+//     u32 compression_type_pointer @size-4
+struct ss_index_bin {
+  const uint8_t* bytes = nullptr;
+  uint64_t len = 0;
+  uint32_t n_fields = 1, key_head_size = 20, seg_bits = 11;
+  uint64_t n_docs = 0, positions_sum = 0;
+  uint32_t n_ngram_keys = 0;
+  uint16_t longest_field_id = 0;
+  std::vector<const uint8_t*> doclen;  // per level: indexed_field_count arrays of 65 536 bytes
+  struct Blk {
+    uint64_t key;
+    ss_ref_block b;
+  };
+  std::vector<Blk> blocks;             // sorted by (key, block_id)
+  std::vector<uint64_t> keys;          // ascending; term id = index
+  std::vector<uint64_t> term_block_off;
+};
+
+namespace {
+inline uint64_t rd64(const uint8_t* p) { uint64_t v; std::memcpy(&v, p, 8); return v; }
+inline uint32_t rd32(const uint8_t* p) { uint32_t v; std::memcpy(&v, p, 4); return v; }
+}  // namespace
+
+extern "C" int ss_index_bin_open(const uint8_t* bytes, uint64_t len, uint32_t indexed_field_count, uint32_t key_head_size,
+                                 uint32_t segment_number_bits, ss_index_bin** out) {
+  if (!bytes || !out || len < 4 || indexed_field_count == 0 || segment_number_bits > 16) return SS_EINVAL;
+  if (key_head_size != 20 && key_head_size != 22 && key_head_size != 23) return SS_EINVAL;  // index.rs:2806-2812
+  if (rd16(bytes) != 6u) return SS_ENOTSUP;  // INDEX_FORMAT_VERSION_MAJOR
+  std::unique_ptr<ss_index_bin> ix(new ss_index_bin);
+  ix->bytes = bytes; ix->len = len;
+  ix->n_fields = indexed_field_count; ix->key_head_size = key_head_size; ix->seg_bits = segment_number_bits;
+  const uint64_t nseg = 1ull << segment_number_bits;
+  uint64_t pos = 4;
+  uint32_t level = 0;
+  while (pos < len) {
+    if (level == 0) {
+      if (pos + 2 > len) return SS_EINVAL;
+      ix->longest_field_id = (uint16_t)rd16(bytes + pos);
+      pos += 2;
+    }
+    const uint64_t fixed = (uint64_t)indexed_field_count * 65536u + 16u + nseg * 8u;
+    if (pos + fixed > len) return SS_EINVAL;
+    ix->doclen.push_back(bytes + pos);
+    pos += (uint64_t)indexed_field_count * 65536u;
+    const uint64_t docs = rd64(bytes + pos), psum = rd64(bytes + pos + 8);
+    if (docs < ix->n_docs || docs > ((uint64_t)level + 1) * 65536u || docs <= (uint64_t)level * 65536u) return SS_EINVAL;
+    ix->n_docs = docs; ix->positions_sum = psum;
+    pos += 16;
+    const uint8_t* heads = bytes + pos;
+    pos += nseg * 8u;
+    for (uint64_t k0 = 0; k0 < nseg; k0++) {
+      const uint64_t block_length = rd32(heads + 8 * k0), key_count = rd32(heads + 8 * k0 + 4);
+      const uint64_t head_bytes = key_count * key_head_size;
+      if (head_bytes > block_length || pos + block_length > len) return SS_EINVAL;
+      const uint8_t* body = bytes + pos + head_bytes;
+      const uint64_t body_len = block_length - head_bytes;
+      uint64_t prev = 0;
+      for (uint64_t i = 0; i < key_count; i++) {
+        const uint8_t* h = bytes + pos + i * key_head_size;
+        const uint64_t key = rd64(h);
+        if (i && key <= prev) return SS_EINVAL;  // heads are binary-searched by key_hash (search.rs:2310-2357)
+        prev = key;
+        if (key & 7u) { ix->n_ngram_keys++; continue; }  // NgramType != SingleTerm (index.rs:1854-1872)
+        ss_index_bin::Blk e;
+        e.key = key;
+        e.b.block_id = level;
+        e.b.posting_count_m1 = (uint16_t)rd16(h + 8);
+        e.b.pointer_pivot_p_docid = (uint16_t)rd16(h + key_head_size - 6);
+        e.b.compression_type_pointer = rd32(h + key_head_size - 4);
+        e.b.byte_array = body;
+        e.b.byte_array_len = body_len;
+        ix->blocks.push_back(e);
+      }
+      pos += block_length;
+    }
+    level++;
+  }
+  std::stable_sort(ix->blocks.begin(), ix->blocks.end(),
+                   [](const ss_index_bin::Blk& a, const ss_index_bin::Blk& b) { return a.key < b.key; });  // levels stay ascending
+  for (size_t i = 0; i < ix->blocks.size(); i++) {
+    if (i == 0 || ix->blocks[i].key != ix->blocks[i - 1].key) {
+      ix->keys.push_back(ix->blocks[i].key);
+      ix->term_block_off.push_back(i);
+    }
+  }
+  ix->term_block_off.push_back(ix->blocks.size());
+  *out = ix.release();
+  return SS_OK;
+}
+
+extern "C" int ss_index_bin_close(ss_index_bin* ix) {
+  delete ix;
+  return SS_OK;
+}
+
+extern "C" int ss_index_bin_info(const ss_index_bin* ix, uint64_t* n_docs, uint64_t* positions_sum, uint32_t* n_levels,
+                                 uint32_t* n_terms, uint32_t* n_ngram_keys_skipped) {
+  if (!ix) return SS_EINVAL;
+  if (n_docs) *n_docs = ix->n_docs;
+  if (positions_sum) *positions_sum = ix->positions_sum;
+  if (n_levels) *n_levels = (uint32_t)ix->doclen.size();
+  if (n_terms) *n_terms = (uint32_t)ix->keys.size();
+  if (n_ngram_keys_skipped) *n_ngram_keys_skipped = ix->n_ngram_keys;
+  return SS_OK;
+}
+
+extern "C" int ss_index_bin_term_keys(const ss_index_bin* ix, uint64_t* keys_out) {
+  if (!ix || !keys_out) return SS_EINVAL;
+  std::memcpy(keys_out, ix->keys.data(), ix->keys.size() * sizeof(uint64_t));
+  return SS_OK;
+}
+
+namespace {
+// decoded postings of one term appended to docs / tfs
+int index_bin_term(const ss_index_bin* ix, uint32_t term, std::vector<uint32_t>& docs, std::vector<uint16_t>& tfs,
+                   uint16_t* d16, uint16_t* t16) {
+  if (ix->n_fields != 1) return SS_ENOTSUP;  // BM25F field vectors: SURVEY section 8 f-2
+  for (uint64_t bi = ix->term_block_off[term]; bi < ix->term_block_off[term + 1]; bi++) {
+    const ss_ref_block& b = ix->blocks[bi].b;
+    const int n = ss_ref_decode_block(&b, d16, t16);
+    if (n < 0) return n;
+    for (int i = 0; i < n; i++) {
+      const uint64_t doc = ((uint64_t)b.block_id << 16) | d16[i];
+      if (doc >= ix->n_docs) return SS_EINVAL;
+      docs.push_back((uint32_t)doc);
+      tfs.push_back(t16[i]);
+    }
+  }
+  return SS_OK;
+}
+}  // namespace
+
+extern "C" int ss_index_bin_term_postings(const ss_index_bin* ix, uint32_t term, uint64_t cap, uint32_t* docs_out,
+                                          uint16_t* tfs_out, uint64_t* n_out) {
+  if (!ix || term >= ix->keys.size() || !n_out) return SS_EINVAL;
+  std::vector<uint32_t> docs;
+  std::vector<uint16_t> tfs, d16(65536), t16(65536);
+  const int rc = index_bin_term(ix, term, docs, tfs, d16.data(), t16.data());
+  if (rc) return rc;
+  *n_out = docs.size();
+  if (docs.size() > cap) return SS_EINVAL;  // *n_out tells the needed capacity
+  if (docs_out) std::memcpy(docs_out, docs.data(), docs.size() * 4);
+  if (tfs_out) std::memcpy(tfs_out, tfs.data(), tfs.size() * 2);
+  return SS_OK;
+}
+
+extern "C" int ss_bm25_upload_index_bin(ss_shard* s, const ss_index_bin* ix) {
+  if (!s || !ix) return SS_EINVAL;
+  if (ix->keys.empty() || ix->n_docs == 0) return SS_EINVAL;
+  std::vector<uint64_t> offs(ix->keys.size() + 1, 0);
+  std::vector<uint32_t> docs;
+  std::vector<uint16_t> tfs, d16(65536), t16(65536);
+  for (uint32_t t = 0; t < ix->keys.size(); t++) {
+    offs[t] = docs.size();
+    const int rc = index_bin_term(ix, t, docs, tfs, d16.data(), t16.data());
+    if (rc) return rc;
+  }
+  offs[ix->keys.size()] = docs.size();
+  std::vector<uint8_t> doclen(ix->doclen.size() * 65536u);
+  for (size_t l = 0; l < ix->doclen.size(); l++) std::memcpy(doclen.data() + l * 65536u, ix->doclen[l], 65536u);  // field 0
+  // avgdl = positions_sum_normalized / indexed_doc_count as the reference's reader computes it (index.rs:3480-3482)
+  return ssi_bm25_upload(s, ix->n_docs, doclen.data(), (uint32_t)ix->keys.size(), offs.data(), docs.data(), tfs.data(),
+                         ix->positions_sum);
 }

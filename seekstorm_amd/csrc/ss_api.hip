@@ -110,6 +110,13 @@ static int ensure_out(ss_shard* s, size_t nq, size_t k) {
 // ------------------------------------------------------------------ BM25
 int ss_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen, uint32_t n_terms, const uint64_t* offs,
                    const uint32_t* docs, const uint16_t* tfs) {
+  return ssi_bm25_upload(s, n_docs, doclen, n_terms, offs, docs, tfs, 0);
+}
+
+}  // extern "C"
+
+int ssi_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen, uint32_t n_terms, const uint64_t* offs,
+                    const uint32_t* docs, const uint16_t* tfs, uint64_t positions_sum) {
   if (!s || !doclen || !offs || n_docs == 0 || n_terms == 0) return SS_EINVAL;
   if (offs[n_terms] && (!docs || !tfs)) return SS_EINVAL;
   if (n_docs > 0xFFFFFFFFull) return SS_ENOTSUP;
@@ -120,10 +127,12 @@ int ss_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen, uint32_t
   s->bm_n_docs = n_docs;
   s->bm_n_terms = n_terms;
   s->bm_n_sub = (uint32_t)((n_docs + BM_SUB - 1) >> BM_SUB_LOG2);
-  int rc = ssi_bm25_build_from_host(s, doclen, offs, docs, tfs);
+  int rc = ssi_bm25_build_from_host(s, doclen, offs, docs, tfs, positions_sum);
   if (rc) free_bm25(s);
   return rc;
 }
+
+extern "C" {
 
 int ss_bm25_synth(ss_shard* s, uint64_t seed, uint64_t n_docs, uint32_t n_terms, const uint32_t* thresh32,
                   const uint8_t* len_table1024) {
@@ -282,6 +291,64 @@ int ss_vec_upload(ss_shard* s, uint64_t n_rows, uint32_t dim, const float* rows,
     SS_HIP(hipMalloc(&s->d_row_doc, n_rows * sizeof(uint32_t)));
     SS_HIP(hipMemcpyAsync(s->d_row_doc, row_doc_ids, n_rows * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
   }
+  SS_HIP(hipStreamSynchronize(s->stream));
+  return ssi_vec_alloc_ws(s);
+}
+
+// vector.bin (writer vector.rs:1066-1094, reader 1279-1298): per level u32 cluster_count, cluster_count x u32 child_count,
+// then the records cluster after cluster, each a packed 24-byte VectorHeader (u16 doc_id first, vector.rs:62-73) + dim x f32.
+// Shard-local doc id of a record = (level << 16) | doc_id (vector.rs:1448).  The payloads go to HBM straight from the
+// file bytes with a strided copy per level; AnnMode::All visits every cluster, so the cluster structure is not kept.
+int ss_vec_upload_vector_bin(ss_shard* s, const uint8_t* bytes, uint64_t len, uint32_t dim) {
+  if (!s || !bytes || dim == 0) return SS_EINVAL;
+  const uint64_t rec = 24u + (uint64_t)dim * 4u;
+  struct Lvl { uint64_t first, n; };
+  std::vector<Lvl> levels;
+  std::vector<uint32_t> ids;
+  uint64_t pos = 0;
+  while (pos < len) {
+    if (pos + 4 > len) return SS_EINVAL;
+    uint32_t clusters;
+    memcpy(&clusters, bytes + pos, 4);
+    pos += 4;
+    if (pos + (uint64_t)clusters * 4u > len) return SS_EINVAL;
+    uint64_t n = 0;
+    for (uint32_t c = 0; c < clusters; c++) {
+      uint32_t child;
+      memcpy(&child, bytes + pos + 4ull * c, 4);
+      n += child;
+    }
+    pos += (uint64_t)clusters * 4u;
+    if (n > (len - pos) / rec || levels.size() >= 65536u) return SS_EINVAL;
+    for (uint64_t r = 0; r < n; r++) {
+      uint16_t d;
+      memcpy(&d, bytes + pos + r * rec, 2);
+      ids.push_back((uint32_t)(levels.size() << 16) | d);
+    }
+    levels.push_back({pos, n});
+    pos += n * rec;
+  }
+  const uint64_t n_rows = ids.size();
+  if (n_rows == 0) return SS_EINVAL;
+  if (n_rows > 0xFFFFFFFEull) return SS_ENOTSUP;
+  std::vector<uint32_t> tmp(ids);
+  std::sort(tmp.begin(), tmp.end());
+  const bool multi = std::adjacent_find(tmp.begin(), tmp.end()) != tmp.end();
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  SS_HIP(hipStreamSynchronize(s->stream));
+  int rc = vec_alloc(s, n_rows, dim);
+  if (rc) { free_vec(s); return rc; }
+  uint64_t row = 0;
+  for (const Lvl& l : levels) {
+    if (l.n == 0) continue;
+    SS_HIP(hipMemcpy2DAsync(s->d_X + row * s->dim_pad, (size_t)s->dim_pad * sizeof(float), bytes + l.first + 24u, rec,
+                            (size_t)dim * sizeof(float), l.n, hipMemcpyHostToDevice, s->stream));
+    row += l.n;
+  }
+  s->vec_multi_record = multi;
+  SS_HIP(hipMalloc(&s->d_row_doc, n_rows * sizeof(uint32_t)));
+  SS_HIP(hipMemcpyAsync(s->d_row_doc, ids.data(), n_rows * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
   SS_HIP(hipStreamSynchronize(s->stream));
   return ssi_vec_alloc_ws(s);
 }

@@ -138,7 +138,10 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
 // ---- implemented in synth.hip
 int ssi_vec_synth(ss_shard* s, uint64_t seed, hipStream_t st);
 int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const uint8_t* d_lentab, hipStream_t st);
+// positions_sum = 0: avgdl from the decoded length bytes; else the reference's stored positions_sum_normalized (index.rs:3480)
 int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t* offs, const uint32_t* docs,
-                             const uint16_t* tfs);
+                             const uint16_t* tfs, uint64_t positions_sum);
+int ssi_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen, uint32_t n_terms, const uint64_t* offs,
+                    const uint32_t* docs, const uint16_t* tfs, uint64_t positions_sum);
 void ssi_prof_begin(ss_shard* s, int kernel, hipStream_t st, hipEvent_t* e0, hipEvent_t* e1);
 void ssi_prof_end(ss_shard* s, int kernel, hipStream_t st, hipEvent_t e0, hipEvent_t e1);

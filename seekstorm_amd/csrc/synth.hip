@@ -115,10 +115,12 @@ static int upload_exceptions(ss_shard* s, const std::vector<u64>& off, const std
 }
 
 int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t* offs, const uint32_t* docs,
-                             const uint16_t* tfs) {
+                             const uint16_t* tfs, uint64_t positions_sum) {
   const uint32_t nt = s->bm_n_terms, ns = s->bm_n_sub;
   u64 psum = 0;
-  for (u64 d = 0; d < s->bm_n_docs; d++) psum += ss_byte4_to_int(doclen[d]);
+  if (positions_sum) psum = positions_sum;
+  else
+    for (u64 d = 0; d < s->bm_n_docs; d++) psum += ss_byte4_to_int(doclen[d]);
   s->bm_avgdl = (float)psum / (float)s->bm_n_docs;  // commit.rs:318-319
   float comp[SS_COMP_N];
   fill_comp(s->bm_avgdl, comp);

@@ -88,6 +88,49 @@ def threshold_raw(similarity_threshold):
     return float(((np.float32(similarity_threshold) * np.float32(2.0)) - np.float32(1.0)) / SIMILARITY_NORMALIZATION_64_I8)
 
 
+class IndexBin:
+    """Parsed view of a shard's index.bin (ss_index_bin_*; host only -- works without a GPU).  Term id = rank of the
+    key_hash among the SingleTerm keys; `term_of_key` is the lookup the Rust side does after hashing the term."""
+
+    def __init__(self, data, indexed_field_count=1, key_head_size=20, segment_number_bits=11):
+        self._buf = np.frombuffer(bytes(data), np.uint8).copy()  # the handle borrows these bytes
+        h = C.c_void_p()
+        N.check(N.lib().ss_index_bin_open(self._buf.ctypes.data, len(self._buf), indexed_field_count, key_head_size,
+                                          segment_number_bits, C.byref(h)), "ss_index_bin_open")
+        self._h = h
+        nd, ps = C.c_uint64(), C.c_uint64()
+        nl, nt, ng = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        N.check(N.lib().ss_index_bin_info(h, C.byref(nd), C.byref(ps), C.byref(nl), C.byref(nt), C.byref(ng)), "ss_index_bin_info")
+        self.indexed_doc_count, self.positions_sum_normalized = nd.value, ps.value
+        self.level_count, self.term_count, self.ngram_keys_skipped = nl.value, nt.value, ng.value
+        self.term_keys = np.zeros(self.term_count, np.uint64)
+        if self.term_count:
+            N.check(N.lib().ss_index_bin_term_keys(h, N.ptr(self.term_keys, N.u64p)), "ss_index_bin_term_keys")
+
+    def term_of_key(self, key_hash):
+        i = int(np.searchsorted(self.term_keys, np.uint64(key_hash)))
+        return i if i < self.term_count and int(self.term_keys[i]) == int(key_hash) else None
+
+    def postings(self, term):
+        n = C.c_uint64()
+        N.lib().ss_index_bin_term_postings(self._h, term, 0, None, None, C.byref(n))
+        docs, tfs = np.zeros(n.value, np.uint32), np.zeros(n.value, np.uint16)
+        N.check(N.lib().ss_index_bin_term_postings(self._h, term, n.value, N.ptr(docs, N.u32p), N.ptr(tfs, N.u16p), C.byref(n)),
+                "ss_index_bin_term_postings")
+        return docs, tfs
+
+    def close(self):
+        if self._h:
+            N.lib().ss_index_bin_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Shard:
     """One shard image on one MI355X (opaque ss_shard handle)."""
 
@@ -141,6 +184,18 @@ class Shard:
                                                   C.cast(arr, C.c_void_p)), "ss_bm25_upload_ref_blocks")
         self.indexed_doc_count = int(n_docs)
         self._df_cache.clear()
+
+    def upload_index_bin(self, ix: "IndexBin"):
+        N.check(N.lib().ss_bm25_upload_index_bin(self._h, ix._h), "ss_bm25_upload_index_bin")
+        self.indexed_doc_count = int(ix.indexed_doc_count)
+        self._df_cache.clear()
+
+    def upload_vector_bin(self, data, dim):
+        buf = np.frombuffer(bytes(data), np.uint8)
+        N.check(N.lib().ss_vec_upload_vector_bin(self._h, buf.ctypes.data, len(buf), int(dim)), "ss_vec_upload_vector_bin")
+        n, d = C.c_uint64(), C.c_uint32()
+        N.check(N.lib().ss_vec_info(self._h, C.byref(n), C.byref(d)), "ss_vec_info")
+        self.vector_count, self.dim = n.value, d.value
 
     def synth_lexical(self, seed, n_docs, thresh32, len_table1024):
         th = np.ascontiguousarray(thresh32, np.uint32)

@@ -123,3 +123,91 @@ def test_upload_ref_blocks_equals_csr_upload():
         assert np.allclose(ra[1][0][:ra[2][0]], os_, rtol=1e-4)
     a.close()
     b.close()
+
+
+# ------------------------------------------------------------------------------------------------ index.bin / vector.bin
+def _corpus(rng, n_docs, dfs):
+    from oracle import oracle as O
+    dl = O.lex_doclen(n_docs)
+    lists = []
+    for df in dfs:
+        docs = np.sort(rng.choice(n_docs, size=df, replace=False)).astype(np.uint32)
+        tfs = np.minimum(rng.geometric(0.45, size=df), 600).astype(np.uint16)
+        lists.append((docs, tfs))
+    keys = sorted(int(k) & ~7 for k in rng.integers(1 << 40, 1 << 63, size=len(dfs), dtype=np.int64))
+    assert len(set(keys)) == len(keys)
+    perm = rng.permutation(len(dfs))  # key order != the order the lists were made in
+    terms = [(keys[i], *lists[perm[i]]) for i in range(len(dfs))]
+    return dl, terms
+
+
+@pytest.mark.parametrize("head,bits", [(20, 11), (22, 4), (23, 4)])
+def test_index_bin_walk(head, bits):
+    rng = np.random.default_rng(head)
+    n_docs = 150_000  # 3 levels, the last incomplete
+    dl, terms = _corpus(rng, n_docs, [40_000, 3_000, 17, 90_000, 1])
+    ngram = [int(k) | 1 for k in rng.integers(1 << 40, 1 << 63, size=3, dtype=np.int64)] if head != 20 else []
+    data = RF.write_index_bin(n_docs, dl, terms, rng, segment_number_bits=bits, key_head_size=head, ngram_keys=ngram)
+    ix = S.IndexBin(data, 1, head, bits)
+    assert ix.indexed_doc_count == n_docs and ix.level_count == 3 and ix.term_count == len(terms)
+    assert ix.ngram_keys_skipped == len(ngram)
+    assert [int(k) for k in ix.term_keys] == [t[0] for t in terms]
+    for t, (key, docs, tfs) in enumerate(terms):
+        assert ix.term_of_key(key) == t
+        d, f = ix.postings(t)
+        assert np.array_equal(d, docs) and np.array_equal(f, tfs)
+    assert ix.term_of_key(terms[0][0] + 8) is None
+    ix.close()
+
+
+def test_index_bin_rejects_garbage():
+    rng = np.random.default_rng(3)
+    dl, terms = _corpus(rng, 70_000, [500, 9])
+    data = RF.write_index_bin(70_000, dl, terms, rng, segment_number_bits=3)
+    for bad in (data[:len(data) - 5], b"\x05\x00\x01\x00" + data[4:], data[:3]):
+        with pytest.raises(S.SeekStormHipError):
+            S.IndexBin(bad, 1, 20, 3)
+    empty = S.IndexBin(data[:4], 1, 20, 3)  # a freshly created index: header only (index.rs:2839-2853)
+    assert empty.level_count == 0 and empty.term_count == 0
+    with pytest.raises(S.SeekStormHipError):
+        S.IndexBin(data, 1, 21, 3)
+
+
+@pytest.mark.gpu
+def test_upload_index_bin_and_vector_bin_answer_like_the_arrays():
+    from oracle import oracle as O
+    rng = np.random.default_rng(21)
+    n_docs = 140_000
+    dl, terms = _corpus(rng, n_docs, [60_000, 9_000, 700, 30_000])
+    data = RF.write_index_bin(n_docs, dl, terms, rng)  # the reference's 2048 segments
+    ix = S.IndexBin(data)
+    a, b = S.Shard(0), S.Shard(0)
+    a.upload_index_bin(ix)
+    offs = np.zeros(len(terms) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(t[1]) for t in terms])
+    alld, allt = np.concatenate([t[1] for t in terms]), np.concatenate([t[2] for t in terms])
+    b.upload_lexical(n_docs, dl, offs, alld, allt)
+    osh = O.Shard(n_docs, dl, offs, alld, allt)
+    assert a.lexical_info() == b.lexical_info()
+    for qt, op, q in ((S.QueryType.Union, O.OP_OR, [0, 1, 2]), (S.QueryType.Intersection, O.OP_AND, [0, 3]),
+                      (S.QueryType.Union, O.OP_OR, [3, 1])):
+        ra = a.search_lexical_batch(a.make_queries([q], qt), 10)
+        rb_ = b.search_lexical_batch(b.make_queries([q], qt), 10)
+        for x, y in zip(ra, rb_):
+            assert np.array_equal(x, y)
+        od, os_, otot = osh.search_exhaustive(q, op, 10)
+        assert int(ra[3][0]) == otot and np.allclose(ra[1][0][:ra[2][0]], os_, rtol=1e-4)
+    # vector.bin: 2 levels, clustered records, several records per doc in level 1
+    dim = 64
+    rows = O.vec_gen(O.VEC_SEED, 0, 700, dim)
+    recs = [(int(i % 300), 0, int(i // 300), rows[i]) for i in range(700)]
+    levels = [[recs[0:120], recs[120:300]], [recs[300:301], recs[301:650], recs[650:700]]]
+    ids = np.array([(0 << 16) | r[0] for r in recs[:300]] + [(1 << 16) | r[0] for r in recs[300:]], np.uint32)
+    a.upload_vector_bin(RF.write_vector_bin(levels, dim), dim)
+    b.upload_vectors(rows, ids)
+    qs = O.vec_gen(O.VECQ_SEED, 0, 5, dim)
+    for x, y in zip(a.search_vector_batch(qs, 20), b.search_vector_batch(qs, 20)):
+        assert np.array_equal(x, y)
+    assert np.array_equal(a.read_rows(0, 700), rows)
+    a.close()
+    b.close()
