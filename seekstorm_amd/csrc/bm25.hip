@@ -127,7 +127,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   p.count = (rt == SS_RT_TOPK) ? 0u : 1u;  // Topk: result_count_total is not required to be exact
   hipEvent_t e0 = nullptr, e1 = nullptr;
   ssi_prof_begin(s, 0, st, &e0, &e1);
-  const int rc = pruned ? ssi_bm25_launch_probe(p, s->d_probe, s->d_umax, nt_max, KPL, st)
+  const int rc = pruned ? ssi_bm25_launch_probe(p, s->d_probe, s->d_probe_z, s->d_umax, nt_max, KPL, st)
                         : ssi_bm25_launch_scan(p, nt_max, has_and, KPL, st);
   ssi_prof_end(s, 0, st, e0, e1);
   if (rc) return rc;

@@ -50,7 +50,8 @@ __device__ __forceinline__ float pb_weight(uint32_t p, const BmExc& X, uint32_t 
 template <int NT, int KPL>
 __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
     const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base, const uint32_t* __restrict__ sub_off,
-    const float* __restrict__ comp_g, const uint4* __restrict__ probe, const float* __restrict__ umax,
+    const float* __restrict__ comp_g, const uint2* __restrict__ probe, const uint32_t* __restrict__ probe_z,
+    const float* __restrict__ umax,
     const ss_bm25_query* __restrict__ qs, unsigned long long* __restrict__ part_keys, unsigned long long* __restrict__ total,
     uint32_t* tau, const unsigned long long* __restrict__ exc_off, const uint32_t* __restrict__ exc_doc,
     const uint32_t* __restrict__ exc_tf, uint32_t n_sub, uint32_t n_terms, uint32_t nq, uint32_t P, uint32_t k, uint32_t count) {
@@ -72,7 +73,8 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
   // per-term state in PROCESSING order (sorted below); qpos = position in the query (order of the score sum)
   const uint32_t* tptr[NT];
   const uint32_t* rowp[NT];
-  const uint4* prow[NT];
+  const uint2* prow[NT];   // 64 doc bits per group
+  const uint32_t* zrow[NT];  // index of the group's first posting (fetched on hits only)
   float idf[NT], U[NT];
   uint32_t qpos[NT], tid_[NT];
   const BmExc X{exc_off, exc_doc, exc_tf};
@@ -88,6 +90,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
     tptr[t] = post + term_base[term] * 4ull;
     rowp[t] = sub_off + (size_t)term * row_len;
     prow[t] = probe + (size_t)term * n_sub * (BM_SUB / 64);
+    zrow[t] = probe_z + (size_t)term * n_sub * (BM_SUB / 64);
     size[t] = have ? term_base[term + 1] - term_base[term] : ~0ull;
   }
   // sort: unions by U descending (absent terms have U = 0: last), intersections by list size ascending (absent: last)
@@ -97,6 +100,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
       { auto t_ = tptr[x]; tptr[x] = tptr[y]; tptr[y] = t_; }
       { auto t_ = rowp[x]; rowp[x] = rowp[y]; rowp[y] = t_; }
       { auto t_ = prow[x]; prow[x] = prow[y]; prow[y] = t_; }
+      { auto t_ = zrow[x]; zrow[x] = zrow[y]; zrow[y] = t_; }
       { float t_ = idf[x]; idf[x] = idf[y]; idf[y] = t_; }
       { float t_ = U[x]; U[x] = U[y]; U[y] = t_; }
       { uint32_t t_ = qpos[x]; qpos[x] = qpos[y]; qpos[y] = t_; }
@@ -176,30 +180,53 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
       wv[J] = alive ? lds_ldf(q_w0 + qb) : 0.f;
       uint32_t pres = 1u << J;
       float known = idf[J] * wv[J];
-      if (alive && pos != 0xFFFFFFFFu) {  // hit in term A: now fetch its posting
-        const uint32_t pa = tptr[A][pos];
+      // round 1: z of the A hit, and (speculatively: these are the few survivors) the bits of every remaining term
+      const size_t gidx = (size_t)tile * (BM_SUB / 64) + (d >> 6);
+      const bool hit_a = alive && pos != 0xFFFFFFFFu;  // pos = rank inside the group
+      uint32_t za = 0u;
+      if (hit_a) za = zrow[A][gidx];
+      uint2 rb[NT];
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        rb[t] = make_uint2(0u, 0u);
+        if (t == J || t == A || (uint32_t)t >= nt) continue;
+        if (alive) rb[t] = prow[t][gidx];
+      }
+      // round 2: the A posting, z of the other hits
+      uint32_t pa = 0u;
+      if (hit_a) pa = tptr[A][za + pos];
+      bool hit[NT];
+      uint32_t zt[NT], rk[NT];
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        hit[t] = false; zt[t] = 0u; rk[t] = 0u;
+        if (t == J || t == A || (uint32_t)t >= nt) continue;
+        const u64 bits = ((u64)rb[t].y << 32) | rb[t].x;
+        hit[t] = alive && ((bits >> (d & 63u)) & 1ull);
+        if (is_and) alive = hit[t];
+        else if (t < J && hit[t]) { alive = false; }  // evaluated in the earlier term's stream
+        rk[t] = (uint32_t)__popcll(bits & ((1ull << (d & 63u)) - 1ull));
+      }
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        hit[t] = hit[t] && alive;
+        if (hit[t]) zt[t] = zrow[t][gidx];
+      }
+      if (hit_a) {
         wv[A] = pb_weight(pa, X, tid_[A], doc);
         pres |= 1u << A;
         known += idf[A] * wv[A];
       }
+      // round 3: postings of the other hits (skipped when the bounds already rule the doc out)
       float rest = SU[0] - U[J] - ((uint32_t)A < nt ? U[A] : 0.f);
+      if (!is_and && k) alive = alive && (known + rest) >= thr * 0.99999f;
 #pragma unroll
       for (int t = 0; t < NT; t++) {
         if (t == J || t == A || (uint32_t)t >= nt) continue;
-        if (!is_and && k) alive = alive && (known + rest) >= thr * 0.99999f;
-        if (__ballot(alive) == 0ull) break;
-        rest -= U[t];
-        uint4 rec = make_uint4(0, 0, 0, 0);
-        if (alive) rec = prow[t][(size_t)tile * (BM_SUB / 64) + (d >> 6)];
-        const u64 bits = ((u64)rec.y << 32) | rec.x;
-        bool hit = alive && ((bits >> (d & 63u)) & 1ull);
-        if (is_and) alive = hit;
-        else if (t < J && hit) { alive = false; hit = false; }  // evaluated in the earlier term's stream
-        if (hit) {
-          const uint32_t pt = tptr[t][rec.z + (uint32_t)__popcll(bits & ((1ull << (d & 63u)) - 1ull))];
+        if (hit[t] && alive) {
+          const uint32_t pt = tptr[t][zt[t] + rk[t]];
           wv[t] = pb_weight(pt, X, tid_[t], doc);
           pres |= 1u << t;
-          known += idf[t] * wv[t];
         }
       }
       if (__ballot(alive)) {
@@ -273,11 +300,11 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
         continue;
       }
       const float rest0 = SU[0] - U[J];
-      uint4 rec[G];
+      uint2 rec[G];
 #pragma unroll
       for (int g = 0; g < G; g++) {
         if (!is_and && k) alive[g] = alive[g] && (idf[J] * w0[g] + rest0) >= thr * 0.99999f;
-        rec[g] = make_uint4(0, 0, 0, 0);
+        rec[g] = make_uint2(0u, 0u);
         if (alive[g]) rec[g] = prow[A][(size_t)tile[g] * (BM_SUB / 64) + (dg[g] >> 6)];
       }
 #pragma unroll
@@ -288,7 +315,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
         if (is_and) alive[g] = hit;
         else if (A < J && hit) { alive[g] = false; hit = false; }  // evaluated in the earlier term's stream
         else if (!hit && k) alive[g] = alive[g] && (idf[J] * w0[g] + rest0 - U[A]) >= thr * 0.99999f;
-        if (hit) pos = rec[g].z + (uint32_t)__popcll(bits & ((1ull << (dg[g] & 63u)) - 1ull));
+        if (hit) pos = (uint32_t)__popcll(bits & ((1ull << (dg[g] & 63u)) - 1ull));  // rank inside the group
         // push the survivors of this chunk
         const u64 m = __ballot(alive[g]);
         if (m) {
@@ -321,20 +348,21 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
 }
 
 template <int NT, int KPL>
-static int launch_probe(const BmParams& p, const uint4* probe, const float* umax, hipStream_t st) {
+static int launch_probe(const BmParams& p, const uint2* probe, const uint32_t* probe_z, const float* umax, hipStream_t st) {
   const uint32_t A = p.nq * p.P;
   bm25_probe_kernel<NT, KPL><<<(A + PB_WAVES - 1) / PB_WAVES, PB_WAVES * 64, BM_LUT_BYTES + PB_WAVES * PB_QCAP * 12, st>>>(
-      p.post, p.term_base, p.sub_off, p.comp, probe, umax, p.q, p.part_keys, p.total, p.tau, p.exc_off, p.exc_doc, p.exc_tf, p.n_sub, p.n_terms, p.nq, p.P, p.k,
+      p.post, p.term_base, p.sub_off, p.comp, probe, probe_z, umax, p.q, p.part_keys, p.total, p.tau, p.exc_off, p.exc_doc, p.exc_tf, p.n_sub, p.n_terms, p.nq, p.P, p.k,
       p.count);
   return SS_OK;
 }
 
 // returns SS_ENOTSUP when there is no instantiation for (nt_max, KPL): the caller falls back to the exhaustive kernels
-int ssi_bm25_launch_probe(const BmParams& p, const uint4* probe, const float* umax, uint32_t nt_max, int KPL, hipStream_t st) {
-  if (!probe || !umax || nt_max == 0 || nt_max > 4 || (KPL != 1 && KPL != 2)) return SS_ENOTSUP;
+int ssi_bm25_launch_probe(const BmParams& p, const uint2* probe, const uint32_t* probe_z, const float* umax, uint32_t nt_max, int KPL,
+                          hipStream_t st) {
+  if (!probe || !probe_z || !umax || nt_max == 0 || nt_max > 4 || (KPL != 1 && KPL != 2)) return SS_ENOTSUP;
   const int NT = nt_max <= 2 ? 2 : (int)nt_max;
 #define SS_P(NT_, KPL_) \
-  if (NT == NT_ && KPL == KPL_) return launch_probe<NT_, KPL_>(p, probe, umax, st);
+  if (NT == NT_ && KPL == KPL_) return launch_probe<NT_, KPL_>(p, probe, probe_z, umax, st);
   SS_P(2, 1) SS_P(3, 1) SS_P(4, 1) SS_P(2, 2) SS_P(3, 2) SS_P(4, 2)
 #undef SS_P
   return SS_ENOTSUP;

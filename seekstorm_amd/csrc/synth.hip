@@ -89,9 +89,11 @@ static int alloc_probe(ss_shard* s, hipStream_t st) {
   SS_HIP(hipMemsetAsync(s->d_umax, 0, ((size_t)s->bm_n_terms + 1) * sizeof(float), st));
   size_t free_b = 0, total_b = 0;
   SS_HIP(hipMemGetInfo(&free_b, &total_b));
-  if ((rows + zero_row) * sizeof(uint4) > free_b / 2) return SS_OK;
-  SS_HIP(hipMalloc(&s->d_probe, (rows + zero_row) * sizeof(uint4)));
-  SS_HIP(hipMemsetAsync(s->d_probe + rows, 0, zero_row * sizeof(uint4), st));  // row n_terms: absent terms
+  if ((rows + zero_row) * (sizeof(uint2) + sizeof(uint32_t)) > free_b / 2) return SS_OK;
+  SS_HIP(hipMalloc(&s->d_probe, (rows + zero_row) * sizeof(uint2)));
+  SS_HIP(hipMalloc(&s->d_probe_z, (rows + zero_row) * sizeof(uint32_t)));
+  SS_HIP(hipMemsetAsync(s->d_probe + rows, 0, zero_row * sizeof(uint2), st));  // row n_terms: absent terms
+  SS_HIP(hipMemsetAsync(s->d_probe_z + rows, 0, zero_row * sizeof(uint32_t), st));
   return SS_OK;
 }
 __host__ __device__ inline float bm_weight_of(uint32_t tf, uint32_t len_byte, const float* comp) {
@@ -187,14 +189,16 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
   if (rc) return rc;
   SS_HIP(hipStreamSynchronize(s->stream));
   std::vector<float> umax((size_t)nt + 1, 0.f);
-  std::vector<uint4> probe;
-  if (s->d_probe) probe.assign((size_t)nt * ns * BM_GROUPS, make_uint4(0, 0, 0, 0));
+  std::vector<uint2> probe;
+  std::vector<uint32_t> probe_z;
+  if (s->d_probe) probe.assign((size_t)nt * ns * BM_GROUPS, make_uint2(0, 0));
+  probe_z.assign(probe.size(), 0u);
   for (uint32_t t = 0; t < nt; t++) {
     for (u64 j = offs[t]; j < offs[t + 1]; j++) {
       umax[t] = std::max(umax[t], bm_weight_of(tfs[j], doclen[docs[j]], comp));
       if (!s->d_probe) continue;
       const uint32_t sb = docs[j] >> BM_SUB_LOG2, d = docs[j] & (BM_SUB - 1);
-      uint4* row = probe.data() + ((size_t)t * ns + sb) * BM_GROUPS;
+      uint2* row = probe.data() + ((size_t)t * ns + sb) * BM_GROUPS;
       const uint32_t g = d >> 6, b = d & 63;
       if (b < 32) row[g].x |= 1u << b; else row[g].y |= 1u << (b - 32);
     }
@@ -203,13 +207,16 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
     const size_t t = (r / BM_GROUPS) / ns, sb = (r / BM_GROUPS) % ns;
     uint32_t run = sub[t * (ns + 1) + sb] * 4u;
     for (int g = 0; g < BM_GROUPS; g++) {
-      probe[r + g].z = run;
+      probe_z[r + g] = run;
       run += (uint32_t)__builtin_popcount(probe[r + g].x) + (uint32_t)__builtin_popcount(probe[r + g].y);
     }
   }
   SS_HIP(hipMemcpy(s->d_umax, umax.data(), umax.size() * sizeof(float), hipMemcpyHostToDevice));
   if (s->d_probe && !probe.empty())
-    SS_HIP(hipMemcpy(s->d_probe, probe.data(), probe.size() * sizeof(uint4), hipMemcpyHostToDevice));
+  {
+    SS_HIP(hipMemcpy(s->d_probe, probe.data(), probe.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    SS_HIP(hipMemcpy(s->d_probe_z, probe_z.data(), probe_z.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
   return SS_OK;
 }
 
@@ -233,7 +240,7 @@ template <bool FILL>
 __global__ void lex_gen_kernel(u64 seed, u64 n_docs, uint32_t n_terms, uint32_t n_sub, const uint32_t* __restrict__ thresh,
                                const uint8_t* __restrict__ doclen, uint32_t* __restrict__ sub /*[nt][ns+1]*/,
                                const u64* __restrict__ term_base, uint32_t* __restrict__ post, u64* __restrict__ df,
-                               uint4* __restrict__ probe, uint32_t* __restrict__ umax_bits, const float* __restrict__ comp) {
+                               uint2* __restrict__ probe, uint32_t* __restrict__ probe_z, uint32_t* __restrict__ umax_bits, const float* __restrict__ comp) {
   const int lane = threadIdx.x & 63;
   const u64 gw = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const u64 total = (u64)n_terms * n_sub;
@@ -257,9 +264,11 @@ __global__ void lex_gen_kernel(u64 seed, u64 n_docs, uint32_t n_terms, uint32_t 
       post[base + pos] = bm_pack((uint32_t)(d & (BM_SUB - 1)), doclen[d], tf);
       wmax = fmaxf(wmax, bm_weight_of(tf, doclen[d], comp));
     }
-    if (FILL && probe && lane == 0)
-      probe[((size_t)t * n_sub + sb) * (BM_SUB / 64) + i] =
-          make_uint4((uint32_t)m, (uint32_t)(m >> 32), sub[(size_t)t * (n_sub + 1) + sb] * 4u + run, 0u);
+    if (FILL && probe && lane == 0) {
+      const size_t gi = ((size_t)t * n_sub + sb) * (BM_SUB / 64) + i;
+      probe[gi] = make_uint2((uint32_t)m, (uint32_t)(m >> 32));
+      probe_z[gi] = sub[(size_t)t * (n_sub + 1) + sb] * 4u + run;
+    }
     run += __popcll(m);
   }
   if (FILL) {
@@ -331,7 +340,7 @@ int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const u
   const u64 waves = (u64)nt * ns;
   const uint32_t grid = (uint32_t)((waves + 3) / 4);
   lex_gen_kernel<false><<<grid, 256, 0, st>>>(seed, nd, nt, ns, d_thresh, d_doclen, s->d_sub_off, nullptr, nullptr, d_df,
-                                              nullptr, nullptr, nullptr);
+                                              nullptr, nullptr, nullptr, nullptr);
   lex_scan_rows_kernel<<<nt, 1024, 0, st>>>(s->d_sub_off, ns, d_tot);
   lex_scan_terms_kernel<<<1, 64, 0, st>>>(d_tot, (u64*)s->d_term_base, nt);
   SS_HIP(hipStreamSynchronize(st));
@@ -358,7 +367,7 @@ int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const u
   rc = alloc_probe(s, st);
   if (rc) return rc;
   lex_gen_kernel<true><<<grid, 256, 0, st>>>(seed, nd, nt, ns, d_thresh, d_doclen, s->d_sub_off,
-                                             (const u64*)s->d_term_base, s->d_post, nullptr, s->d_probe,
+                                             (const u64*)s->d_term_base, s->d_post, nullptr, s->d_probe, s->d_probe_z,
                                              (uint32_t*)s->d_umax, s->d_comp);
   SS_HIP(hipStreamSynchronize(st));
   (void)hipFree(d_doclen);
