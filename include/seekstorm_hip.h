@@ -68,6 +68,12 @@ int ss_shard_sync(ss_shard* s);
  * the HBM image (sub-block CSR of packed postings, bm25_component_cache per commit.rs:318-325). */
 int ss_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t n_terms,
                    const uint64_t* term_offsets, const uint32_t* doc_ids, const uint16_t* tfs);
+/* Tombstones = the shard's delete_hashset (index.rs:1594): shard-local doc ids, as delete.bin stores them (a plain
+ * stream of u64, index.rs:3798-3809 -- the file's bytes can be passed as they are) or as delete_document adds them
+ * (index.rs:5110).  The call replaces the set (n = 0 clears it); it applies to lexical and vector searches alike: a
+ * deleted doc is skipped before it counts or ranks (add_result.rs:3435, union.rs:975, vector.rs:1450-1452). */
+int ss_set_deleted(ss_shard* s, const uint64_t* doc_ids, uint64_t n);
+
 /* Same image from the reference's own in-RAM block format (first step of SURVEY section 8 f-1): one ss_ref_block per
  * (term, 65 536-doc block) = BlockObjectIndex (index.rs:781-789) + the key-body byte array of the segment the posting
  * list lives in (index.rs:991-995).  Doc-id containers (Array / Bitmap / Rle, compress_postinglist.rs:694-946) and the

@@ -84,6 +84,10 @@ def lib():
     L.so_vec_search.restype = C.c_uint32
     L.so_vec_search.argtypes = [f32p, C.c_uint64, C.c_uint32, u32p, f32p, C.c_uint32, C.c_float, C.c_int,
                                 u32p, f32p, u64p, u64p]
+    L.so_vec_search_del.restype = C.c_uint32
+    L.so_vec_search_del.argtypes = [f32p, C.c_uint64, C.c_uint32, u32p, f32p, C.c_uint32, C.c_float, C.c_int, u64p,
+                                    C.c_uint64, u32p, f32p, u64p, u64p]
+    L.so_shard_set_deleted.argtypes = [C.c_void_p, u64p, C.c_uint64]
     L.so_vector_score_field.restype = C.c_float
     L.so_vector_score_field.argtypes = [C.c_float]
     L.so_threshold_raw.restype = C.c_float
@@ -172,6 +176,10 @@ class Shard:
         self.h = lib().so_shard_build(self.n_docs, _p(self.doclen, u8p), self.n_terms, _p(self.offs, u64p),
                                       _p(self.docs, u32p), _p(self.tfs, u16p))
 
+    def set_deleted(self, doc_ids):
+        ids = np.ascontiguousarray(doc_ids, np.uint64)
+        lib().so_shard_set_deleted(self.h, _p(ids, u64p) if len(ids) else None, len(ids))
+
     def __del__(self):
         try:
             lib().so_shard_free(self.h)
@@ -219,16 +227,17 @@ class Shard:
         return a.value, b.value
 
 
-def vec_search(rows, query, k, row_doc_ids=None, threshold_raw=-3.4028234663852886e38, simd_order=True):
+def vec_search(rows, query, k, row_doc_ids=None, threshold_raw=-3.4028234663852886e38, simd_order=True, deleted=None):
     rows = np.ascontiguousarray(rows, np.float32)
     query = np.ascontiguousarray(query, np.float32)
     rd = None if row_doc_ids is None else np.ascontiguousarray(row_doc_ids, np.uint32)
     od = np.empty(max(k, 1), np.uint32)
     os_ = np.empty(max(k, 1), np.float32)
     tot, obs = C.c_uint64(), C.c_uint64()
-    n = lib().so_vec_search(_p(rows, f32p), rows.shape[0], rows.shape[1], _p(rd, u32p), _p(query, f32p), k,
-                            threshold_raw, 1 if simd_order else 0, _p(od, u32p), _p(os_, f32p),
-                            C.byref(tot), C.byref(obs))
+    dl = np.unique(np.ascontiguousarray([] if deleted is None else deleted, np.uint64))  # sorted
+    n = lib().so_vec_search_del(_p(rows, f32p), rows.shape[0], rows.shape[1], _p(rd, u32p), _p(query, f32p), k,
+                                threshold_raw, 1 if simd_order else 0, _p(dl, u64p) if len(dl) else None, len(dl),
+                                _p(od, u32p), _p(os_, f32p), C.byref(tot), C.byref(obs))
     return od[:n].copy(), os_[:n].copy(), tot.value, obs.value
 
 

@@ -122,6 +122,7 @@ struct so_shard {
   float comp[256];
   uint32_t n_terms;
   so_term* terms;
+  uint8_t* deleted; /* delete_hashset (index.rs:1594) as a byte per doc, NULL = empty */
   uint64_t* off;   /* raw CSR copy for the exhaustive ground truth */
   uint32_t* docs;
   uint16_t* tfs;
@@ -250,7 +251,15 @@ void so_shard_free(so_shard* s) {
     for (uint32_t b = 0; b < s->terms[t].n_blocks; b++) free(s->terms[t].blocks[b].cont);
     free(s->terms[t].blocks);
   }
-  free(s->terms); free(s->doclen); free(s->off); free(s->docs); free(s->tfs); free(s);
+  free(s->terms); free(s->doclen); free(s->off); free(s->docs); free(s->tfs); free(s->deleted); free(s);
+}
+/* delete_hashset: index.rs:1594, filled from delete.bin (index.rs:3798-3809) / delete_document (index.rs:5110) */
+void so_shard_set_deleted(so_shard* s, const uint64_t* doc_ids, uint64_t n) {
+  free(s->deleted);
+  s->deleted = NULL;
+  if (!n) return;
+  s->deleted = (uint8_t*)calloc((size_t)s->n_level_blocks * SO_BLOCK, 1);
+  for (uint64_t i = 0; i < n; i++) if (doc_ids[i] < (uint64_t)s->n_level_blocks * SO_BLOCK) s->deleted[doc_ids[i]] = 1;
 }
 float so_shard_avgdl(const so_shard* s) { return s->avgdl; }
 uint64_t so_shard_posting_count(const so_shard* s, uint32_t t) { return t < s->n_terms ? s->terms[t].posting_count : 0; }
@@ -433,6 +442,7 @@ static void search_and(const so_shard* s, uint32_t nq, const uint32_t* qt, const
       if (!ok) continue;
       cur[0].rank = p0;
       uint32_t docid = (m->block_id << 16) | d;
+      if (s->deleted && s->deleted[docid]) continue; /* add_result.rs:3435: first thing add_result does */
       /* add_result.rs:3503-3537 */
       if (rt == SO_RT_COUNT) { (*total)++; continue; }
       if (heap_full(heap) && heap->k > 0 && m->score <= heap->e[0].score) {
@@ -502,8 +512,10 @@ static void search_or(const so_shard* s, uint32_t nq, const uint32_t* qt, const 
     for (uint32_t d = 0; d < 65536; d++) { /* union.rs:553-592 */
       uint32_t bits = table[d];
       if (!bits) continue;
-      (*total)++;
-      if (!block_skip && rt != SO_RT_COUNT) {
+      /* union.rs:975-: union_count clears deleted docs; add_result.rs:3435 skips them (ranks still advance) */
+      int gone = s->deleted && s->deleted[((uint64_t)m->block_id << 16) | d];
+      if (!gone) (*total)++;
+      if (!gone && !block_skip && rt != SO_RT_COUNT) {
         float bound;
         if (mstab) bound = mstab[bits];
         else { bound = 0.0f; for (uint32_t j = 0; j < nq; j++) if ((bits >> j) & 1u) bound += idf[j] * s->terms[qt[j]].blocks[m->ord[j]].max_part; }
@@ -562,6 +574,8 @@ uint32_t so_search_lex_exhaustive(const so_shard* s, uint32_t nq, const uint32_t
       cnt[d]++;
     }
   }
+  if (s->deleted)
+    for (uint64_t d = 0; d < s->n_docs; d++) if (s->deleted[d]) cnt[d] = 0;
   uint64_t m = 0;
   for (uint64_t d = 0; d < s->n_docs; d++) if (op == SO_OP_AND ? cnt[d] == nq : cnt[d] > 0) m++;
   so_sd* v = (so_sd*)malloc((m ? m : 1) * sizeof(so_sd));
@@ -607,6 +621,11 @@ typedef struct { uint32_t doc; float score; } so_item;
 uint32_t so_vec_search(const float* rows, uint64_t n_rows, uint32_t dim, const uint32_t* row_doc, const float* q,
                        uint32_t k, float thr, int simd_order, uint32_t* od, float* os, uint64_t* out_total,
                        uint64_t* out_observed) {
+  return so_vec_search_del(rows, n_rows, dim, row_doc, q, k, thr, simd_order, NULL, 0, od, os, out_total, out_observed);
+}
+uint32_t so_vec_search_del(const float* rows, uint64_t n_rows, uint32_t dim, const uint32_t* row_doc, const float* q,
+                           uint32_t k, float thr, int simd_order, const uint64_t* deleted_sorted, uint64_t n_deleted,
+                           uint32_t* od, float* os, uint64_t* out_total, uint64_t* out_observed) {
   /* TopK::new / push, vector.rs:366-496 */
   so_item* items = (so_item*)malloc((k ? k : 1) * sizeof(so_item));
   for (uint32_t i = 0; i < k; i++) { items[i].doc = 0; items[i].score = -FLT_MAX; }
@@ -616,6 +635,11 @@ uint32_t so_vec_search(const float* rows, uint64_t n_rows, uint32_t dim, const u
     float score = simd_order ? so_dot_f32_lanes8(q, e, dim) : so_dot_f32(q, e, dim);
     uint32_t doc = row_doc ? row_doc[r] : (uint32_t)r;
     observed++;
+    if (n_deleted) { /* vector.rs:1450-1452: scored, then not pushed */
+      uint64_t lo = 0, hi = n_deleted;
+      while (lo < hi) { uint64_t mid = (lo + hi) / 2; if (deleted_sorted[mid] < doc) lo = mid + 1; else hi = mid; }
+      if (lo < n_deleted && deleted_sorted[lo] == doc) continue;
+    }
     if (score < thr || (len == k && score <= lowest)) continue;
     total++;
     if (len < k) {

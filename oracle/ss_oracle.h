@@ -64,6 +64,8 @@ enum { SO_RT_COUNT = 0, SO_RT_TOPK = 1, SO_RT_TOPKCOUNT = 2 };
 so_shard* so_shard_build(uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t n_terms,
                          const uint64_t* term_offsets, const uint32_t* doc_ids, const uint16_t* tfs);
 void so_shard_free(so_shard*);
+/* delete_hashset of the shard (index.rs:1594): replaces the set; searches skip these docs (add_result.rs:3435) */
+void so_shard_set_deleted(so_shard*, const uint64_t* doc_ids, uint64_t n);
 float so_shard_avgdl(const so_shard*);
 uint64_t so_shard_posting_count(const so_shard*, uint32_t term);
 /* container kind chosen for (term, block ordinal); returns 0 if out of range */
@@ -94,6 +96,11 @@ float so_dot_f32_lanes8(const float* q, const float* e, uint32_t dim); /* dot_f3
 uint32_t so_vec_search(const float* rows, uint64_t n_rows, uint32_t dim, const uint32_t* row_doc_ids,
                        const float* query, uint32_t k, float threshold_raw, int simd_order,
                        uint32_t* out_doc, float* out_score, uint64_t* out_total, uint64_t* out_observed);
+/* same with a delete_hashset (ascending doc ids): a deleted record is scored but not pushed, vector.rs:1450-1452 */
+uint32_t so_vec_search_del(const float* rows, uint64_t n_rows, uint32_t dim, const uint32_t* row_doc_ids,
+                           const float* query, uint32_t k, float threshold_raw, int simd_order,
+                           const uint64_t* deleted_sorted, uint64_t n_deleted, uint32_t* out_doc, float* out_score,
+                           uint64_t* out_total, uint64_t* out_observed);
 /* vector_score field: vector.rs:1495-1499 */
 float so_vector_score_field(float dot);
 /* TopK threshold transform: vector.rs:388-397 */

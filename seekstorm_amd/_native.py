@@ -50,6 +50,7 @@ SYMBOLS = [
     ("ss_shard_create", C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     ("ss_shard_destroy", C.c_int, [C.c_void_p]),
     ("ss_shard_sync", C.c_int, [C.c_void_p]),
+    ("ss_set_deleted", C.c_int, [C.c_void_p, u64p, C.c_uint64]),
     ("ss_bm25_upload", C.c_int, [C.c_void_p, C.c_uint64, u8p, C.c_uint32, u64p, u32p, u16p]),
     ("ss_ref_decode_block", C.c_int, [C.c_void_p, u16p, u16p]),
     ("ss_bm25_upload_ref_blocks", C.c_int, [C.c_void_p, C.c_uint64, u8p, C.c_uint32, u64p, C.c_void_p]),

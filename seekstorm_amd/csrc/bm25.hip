@@ -119,6 +119,8 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   p.exc_off = (const unsigned long long*)s->d_exc_off;
   p.exc_doc = s->d_exc_doc;
   p.exc_tf = s->d_exc_tf;
+  p.del = s->n_deleted ? s->d_deleted : nullptr;
+  p.del_words = (uint32_t)s->deleted_words;
   p.n_sub = s->bm_n_sub;
   p.n_terms = s->bm_n_terms;
   p.nq = nq;

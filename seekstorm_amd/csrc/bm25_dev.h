@@ -21,6 +21,8 @@ struct BmParams {
   const unsigned long long* exc_off;  // exception lists: postings whose tf does not fit the 9-bit field
   const uint32_t* exc_doc;
   const uint32_t* exc_tf;
+  const uint32_t* del;             // tombstone bitmap (bit doc & 31 of word doc >> 5), null = no deleted docs
+  uint32_t del_words;
   uint32_t n_sub, n_terms, nq, P, k, count;
 };
 
@@ -304,25 +306,44 @@ struct BmTop {
 template <bool HAS_AND, int KPL>
 __device__ __attribute__((noinline)) BmTop<KPL> bm_scan_tile(BmTop<KPL> T, uint32_t tile, uint32_t cntw, uint32_t nt_and,
                                                              uint32_t doc_base, uint32_t count_mode, uint32_t k, float thr,
-                                                             uint32_t* tau_q) {
+                                                             uint32_t* tau_q, const uint32_t* __restrict__ del,
+                                                             uint32_t del_words) {
   // thr = max(own k-th best score, the k-th best score some other partition of the query already holds): a doc
   // below it cannot be in the query's top-k.  Equal scores stay admissible (the final merge breaks ties by doc id).
   const float wsc_in = T.wsc;
   const int lane = __lane_id();
   const bool is_and = HAS_AND && nt_and != 0;  // nt_and = number of terms of an intersection, 0 for a union
+  // tombstones of this sub-block (128 words): lane l keeps words l and 64 + l; iteration i needs word 8 i + lane / 8.
+  // A deleted doc neither counts nor ranks (add_result.rs:3435, union.rs:975).
+  uint32_t dw0 = 0u, dw1 = 0u;
+  if (del) {
+    const uint32_t wb = doc_base >> 5;
+    if (wb + (uint32_t)lane < del_words) dw0 = del[wb + lane];
+    if (wb + 64u + (uint32_t)lane < del_words) dw1 = del[wb + 64u + lane];
+  }
+  const bool any_del = del && __ballot((dw0 | dw1) != 0u);
 #pragma unroll 2
   for (int i = 0; i < BM_SUB / 256; i++) {
     const int slot = i * 64 + lane;
     f32x4 x = lds_ldf4(tile + slot * 16);
     lds_stf4(tile + slot * 16, f32x4{0.f, 0.f, 0.f, 0.f});
+    uint32_t nib = 0u;  // tombstone bits of this lane's four docs
+    if (any_del) {
+      const uint32_t wsel = __shfl(i < 8 ? dw0 : dw1, (i * 8 + (lane >> 3)) & 63);
+      nib = (wsel >> ((lane & 7) * 4)) & 15u;
+      if (nib & 1u) x.x = 0.f;
+      if (nib & 2u) x.y = 0.f;
+      if (nib & 4u) x.z = 0.f;
+      if (nib & 8u) x.w = 0.f;
+    }
     bool h0 = x.x != 0.f, h1 = x.y != 0.f, h2 = x.z != 0.f, h3 = x.w != 0.f;
     if (HAS_AND && is_and) {
       const uint32_t cw = lds_ld32(cntw + slot * 4);
       lds_st32(cntw + slot * 4, 0u);
-      h0 = (cw & 0xFFu) == nt_and;
-      h1 = ((cw >> 8) & 0xFFu) == nt_and;
-      h2 = ((cw >> 16) & 0xFFu) == nt_and;
-      h3 = (cw >> 24) == nt_and;
+      h0 = (cw & 0xFFu) == nt_and && !(nib & 1u);
+      h1 = ((cw >> 8) & 0xFFu) == nt_and && !(nib & 2u);
+      h2 = ((cw >> 16) & 0xFFu) == nt_and && !(nib & 4u);
+      h3 = (cw >> 24) == nt_and && !(nib & 8u);
       if (!h0) x.x = 0.f;
       if (!h1) x.y = 0.f;
       if (!h2) x.z = 0.f;

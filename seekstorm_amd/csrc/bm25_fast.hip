@@ -23,7 +23,7 @@ template <int NT> struct FastCfg { static constexpr int CPT = NT <= 2 ? 4 : 3; s
       const uint32_t *__restrict__ sub_off, const float *__restrict__ comp_g, const ss_bm25_query *__restrict__ qs, \
       unsigned long long *__restrict__ part_keys, unsigned long long *__restrict__ total, uint32_t *tau,            \
       const unsigned long long *__restrict__ exc_off, const uint32_t *__restrict__ exc_doc,                         \
-      const uint32_t *__restrict__ exc_tf, uint32_t n_sub,                                                          \
+      const uint32_t *__restrict__ exc_tf, const uint32_t *__restrict__ del, uint32_t del_words, uint32_t n_sub,    \
       uint32_t n_terms, uint32_t nq, uint32_t P, uint32_t k, uint32_t count
 
 template <bool HAS_AND>
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
 #pragma unroll
               for (int x = 0; x < 4; x++) lds_stf(aoL[c][x], nwL[c][x]);
             }
-          T = bm_scan_tile<HAS_AND, KPL>(T, L.tile, L.cntw, nt_and, s << BM_SUB_LOG2, count_mode, k, thr, tau_q);
+          T = bm_scan_tile<HAS_AND, KPL>(T, L.tile, L.cntw, nt_and, s << BM_SUB_LOG2, count_mode, k, thr, tau_q, del, del_words);
         } else {
 #pragma unroll
           for (int c = 0; c < CPT; c++)
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
         }
         const float thr = fmaxf(T.wsc, __uint_as_float(tau_bits));
         if (count_mode || (k && __ballot(mx >= thr)))
-          T = bm_scan_tile<HAS_AND, KPL>(T, L.tile, L.cntw, nt_and, s << BM_SUB_LOG2, count_mode, k, thr, tau_q);
+          T = bm_scan_tile<HAS_AND, KPL>(T, L.tile, L.cntw, nt_and, s << BM_SUB_LOG2, count_mode, k, thr, tau_q, del, del_words);
         else
           bm_clear_tile<HAS_AND>(L, is_and, lane);
       }
@@ -305,7 +305,7 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
       }
       if (any) {
         if (count_mode || (k && __ballot(mx >= T.wsc)))
-          T = bm_scan_tile<HAS_AND, KPL>(T, L.tile, L.cntw, nt_and, s << BM_SUB_LOG2, count_mode, k, T.wsc, nullptr);
+          T = bm_scan_tile<HAS_AND, KPL>(T, L.tile, L.cntw, nt_and, s << BM_SUB_LOG2, count_mode, k, T.wsc, nullptr, del, del_words);
         else
           bm_clear_tile<HAS_AND>(L, is_and, lane);
       }
@@ -318,7 +318,7 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
 }
 
 #define BM_PASS_ARGS                                                                                                 \
-  p.post, p.term_base, p.sub_off, p.comp, p.q, p.part_keys, p.total, p.tau, p.exc_off, p.exc_doc, p.exc_tf, p.n_sub, p.n_terms, p.nq, p.P, p.k, p.count
+  p.post, p.term_base, p.sub_off, p.comp, p.q, p.part_keys, p.total, p.tau, p.exc_off, p.exc_doc, p.exc_tf, p.del, p.del_words, p.n_sub, p.n_terms, p.nq, p.P, p.k, p.count
 
 template <int NT, bool HAS_AND, int KPL>
 static int launch_fast(const BmParams& p, hipStream_t st) {

@@ -54,7 +54,8 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
     const float* __restrict__ umax,
     const ss_bm25_query* __restrict__ qs, unsigned long long* __restrict__ part_keys, unsigned long long* __restrict__ total,
     uint32_t* tau, const unsigned long long* __restrict__ exc_off, const uint32_t* __restrict__ exc_doc,
-    const uint32_t* __restrict__ exc_tf, uint32_t n_sub, uint32_t n_terms, uint32_t nq, uint32_t P, uint32_t k, uint32_t count) {
+    const uint32_t* __restrict__ exc_tf, const uint32_t* __restrict__ del, uint32_t del_words, uint32_t n_sub, uint32_t n_terms,
+    uint32_t nq, uint32_t P, uint32_t k, uint32_t count) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
   const int tid = threadIdx.x, lane = tid & 63;
@@ -147,6 +148,12 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
       if (__ballot(key2 != 0ull)) T = bm_offer_lane_keys<KPL>(T, key2, k, tau_q);
     }
   };
+  // tombstone test (delete_hashset, add_result.rs:3435): only ever evaluated for the few lanes that still hold a candidate
+  auto is_deleted = [&](bool lanes, uint32_t doc) -> bool {
+    uint32_t wd = 0u;
+    if (lanes && (doc >> 5) < del_words) wd = del[doc >> 5];
+    return (wd >> (doc & 31u)) & 1u;
+  };
   auto cur_thr = [&]() -> float {
     return fmaxf(T.wsc, __uint_as_float(__hip_atomic_load(tau_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
   };
@@ -229,6 +236,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
           pres |= 1u << t;
         }
       }
+      if (del && __ballot(alive)) alive = alive && !is_deleted(alive, doc);
       if (__ballot(alive)) {
         if (count && is_and) T.matched += __popcll(__ballot(alive));
         if (k) {
@@ -291,10 +299,14 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
 #pragma unroll
         for (int g = 0; g < G; g++) {
           if (__ballot(alive[g]) == 0ull) continue;
+          const uint32_t doc1 = (tile[g] << BM_SUB_LOG2) + dg[g];
+          if (del && count) alive[g] = alive[g] && !is_deleted(alive[g], doc1);
           if (count) T.matched += __popcll(__ballot(alive[g]));
           if (k) {
             const float score = fmaf(idf[J], w0[g], 0.f);
-            offer(alive[g] && score >= thr && score > 0.f, score, (tile[g] << BM_SUB_LOG2) + dg[g]);
+            bool cand = alive[g] && score >= thr && score > 0.f;
+            if (del && !count && __ballot(cand)) cand = cand && !is_deleted(cand, doc1);
+            offer(cand, score, doc1);
           }
         }
         continue;
@@ -351,7 +363,7 @@ template <int NT, int KPL>
 static int launch_probe(const BmParams& p, const uint2* probe, const uint32_t* probe_z, const float* umax, hipStream_t st) {
   const uint32_t A = p.nq * p.P;
   bm25_probe_kernel<NT, KPL><<<(A + PB_WAVES - 1) / PB_WAVES, PB_WAVES * 64, BM_LUT_BYTES + PB_WAVES * PB_QCAP * 12, st>>>(
-      p.post, p.term_base, p.sub_off, p.comp, probe, probe_z, umax, p.q, p.part_keys, p.total, p.tau, p.exc_off, p.exc_doc, p.exc_tf, p.n_sub, p.n_terms, p.nq, p.P, p.k,
+      p.post, p.term_base, p.sub_off, p.comp, probe, probe_z, umax, p.q, p.part_keys, p.total, p.tau, p.exc_off, p.exc_doc, p.exc_tf, p.del, p.del_words, p.n_sub, p.n_terms, p.nq, p.P, p.k,
       p.count);
   return SS_OK;
 }

@@ -75,7 +75,7 @@ int ss_shard_destroy(ss_shard* s) {
   (void)hipStreamSynchronize(s->stream);
   free_vec(s);
   free_bm25(s);
-  void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_part};
+  void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_part, s->d_deleted};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int kx = 0; kx < 2; kx++)
     for (auto& pr : s->prof.pending[kx]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -156,6 +156,38 @@ int ss_bm25_synth(ss_shard* s, uint64_t seed, uint64_t n_docs, uint32_t n_terms,
   (void)hipFree(d_tab);
   if (rc) free_bm25(s);
   return rc;
+}
+
+// Tombstones: delete_hashset of the shard (index.rs:1594; filled from delete.bin, index.rs:3798-3809, and by
+// delete_document, index.rs:5110).  Replaces the whole set; n = 0 clears it.  Both search paths skip a deleted doc before
+// it counts or ranks (add_result.rs:3435, union.rs:975, vector.rs:1450).
+int ss_set_deleted(ss_shard* s, const uint64_t* doc_ids, uint64_t n) {
+  if (!s || (n && !doc_ids)) return SS_EINVAL;
+  uint64_t mx = 0;
+  for (uint64_t i = 0; i < n; i++) {
+    if (doc_ids[i] >= 0xFFFFFFFFull) return SS_EINVAL;
+    mx = std::max(mx, doc_ids[i]);
+  }
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  SS_HIP(hipStreamSynchronize(s->stream));
+  if (s->d_deleted) { (void)hipFree(s->d_deleted); s->d_deleted = nullptr; }
+  s->deleted_words = 0;
+  s->n_deleted = 0;
+  if (n == 0) return SS_OK;
+  std::vector<uint32_t> bits((size_t)(mx >> 5) + 1, 0u);
+  uint64_t distinct = 0;
+  for (uint64_t i = 0; i < n; i++) {
+    uint32_t& w = bits[(size_t)(doc_ids[i] >> 5)];
+    const uint32_t b = 1u << (doc_ids[i] & 31u);
+    distinct += !(w & b);
+    w |= b;
+  }
+  SS_HIP(hipMalloc(&s->d_deleted, bits.size() * sizeof(uint32_t)));
+  SS_HIP(hipMemcpy(s->d_deleted, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  s->deleted_words = bits.size();
+  s->n_deleted = distinct;
+  return SS_OK;
 }
 
 int ss_bm25_set_strategy(ss_shard* s, int strategy) {

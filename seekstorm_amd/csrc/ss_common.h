@@ -93,6 +93,8 @@ struct ss_shard {
   std::vector<uint64_t> h_df;      // posting_count per term (the df the host needs for idf)
   // probe index (membership + rank of a doc in a term's segment without reading the segment): one 16-byte record
   // {u64 bits of 64 docs, u32 index (inside the term's posting array) of their first posting} per (term, sub-block, 64-doc group)
+  uint32_t* d_deleted = nullptr;   // tombstone bitmap by shard-local doc id (delete.bin / delete_hashset), null = none
+  uint64_t deleted_words = 0, n_deleted = 0;
   uint2* d_probe = nullptr;        // [n_terms + 1][n_sub][BM_SUB / 64] 64 doc bits; row n_terms is all zero (absent terms)
   uint32_t* d_probe_z = nullptr;   // same shape: index inside the term of the group's first posting (read on hits only)
   int bm_strategy = SS_BM25_AUTO;  // ss_bm25_set_strategy

@@ -225,7 +225,9 @@ __device__ __forceinline__ void vr_bitonic(unsigned long long* keys, uint32_t* d
 }
 
 __global__ void __launch_bounds__(1024) vec_refine_kernel(VState* __restrict__ st, unsigned long long* __restrict__ cand,
-                                                         uint32_t k, const uint32_t* __restrict__ row_doc /* non-null: dedup */) {
+                                                         uint32_t k, const uint32_t* __restrict__ row_doc /* non-null: dedup */,
+                                                         const uint32_t* __restrict__ doc_map /* row -> doc, null = identity */,
+                                                         const uint32_t* __restrict__ del, uint32_t del_words) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long* keys = (unsigned long long*)smem;
   uint32_t* docs = (uint32_t*)(smem + VS_CAP * sizeof(unsigned long long));
@@ -241,8 +243,19 @@ __global__ void __launch_bounds__(1024) vec_refine_kernel(VState* __restrict__ s
   uint32_t np = 64;
   while (np < n) np <<= 1;
   unsigned long long* base = cand + (size_t)q * VS_CAP;
+  __shared__ uint32_t live, dropped;
+  if (threadIdx.x == 0) { live = 0; dropped = 0; }
+  __syncthreads();
   for (uint32_t i = threadIdx.x; i < np; i += blockDim.x) {
-    const unsigned long long key = i < n ? base[i] : 0ull;
+    unsigned long long key = i < n ? base[i] : 0ull;
+    if (del && key && i >= kept) {  // tombstones: the record was scored but is never pushed (vector.rs:1450-1452)
+      const uint32_t row = 0xFFFFFFFFu - (uint32_t)key;
+      const uint32_t doc = doc_map ? doc_map[row] : row;
+      if ((doc >> 5) < del_words && ((del[doc >> 5] >> (doc & 31u)) & 1u)) {
+        key = 0ull;
+        atomicAdd(&dropped, 1u);
+      }
+    }
     keys[i] = key;
     if (row_doc) docs[i] = key ? row_doc[0xFFFFFFFFu - (uint32_t)key] : 0xFFFFFFFFu;  // empty slots sort last
   }
@@ -259,9 +272,6 @@ __global__ void __launch_bounds__(1024) vec_refine_kernel(VState* __restrict__ s
   }
   vr_bitonic(keys, docs, np, false);
   // number of live entries after the dedup
-  __shared__ uint32_t live;
-  if (threadIdx.x == 0) live = 0;
-  __syncthreads();
   uint32_t cnt = 0;
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) cnt += keys[i] != 0ull;
   if (cnt) atomicAdd(&live, cnt);
@@ -270,7 +280,7 @@ __global__ void __launch_bounds__(1024) vec_refine_kernel(VState* __restrict__ s
   const uint32_t keep = nl < k ? nl : k;
   for (uint32_t i = threadIdx.x; i < keep; i += blockDim.x) base[i] = keys[i];
   if (threadIdx.x == 0) {
-    st->total[q] += (unsigned long long)(n - kept);
+    st->total[q] += (unsigned long long)(n - kept - dropped);
     st->cnt[q] = keep;
     st->kept[q] = keep;
     if (nl >= k && k > 0) st->tau[q] = ord2f((uint32_t)(keys[k - 1] >> 32));
@@ -357,7 +367,8 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const float* d_queries, uint32_t k,
       vec_scan_kernel<<<grid, VS_WAVES * 64, VS_LDS, st>>>(s->d_X, s->dim_pad, (unsigned long long)s->n_rows, s->d_Qf,
                                                            nch, tile0, c, vst, cand);
       vec_refine_kernel<<<SS_VEC_BATCH, 1024, VS_CAP * (sizeof(unsigned long long) + sizeof(uint32_t)), st>>>(
-          vst, cand, k, s->vec_multi_record ? s->d_row_doc : nullptr);
+          vst, cand, k, s->vec_multi_record ? s->d_row_doc : nullptr, s->d_row_doc, s->n_deleted ? s->d_deleted : nullptr,
+          (uint32_t)s->deleted_words);
       tile0 += c;
     }
     ssi_prof_end(s, 1, st, e0, e1);

@@ -58,6 +58,40 @@ int Shard::upload_vectors(uint64_t n_rows, uint32_t dim, const float* rows, cons
   return rc;
 }
 
+int Shard::open_index_bin(const uint8_t* bytes, uint64_t len, uint32_t key_head_size, std::vector<uint64_t>* term_keys) {
+  if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
+  ss_index_bin* ix = nullptr;
+  int rc = ss_index_bin_open(bytes, len, 1, key_head_size, 11, &ix);  // open_index always uses 2048 segments (index.rs:3285)
+  if (rc) return rc;
+  uint64_t n_docs = 0;
+  uint32_t n_terms = 0;
+  ss_index_bin_info(ix, &n_docs, nullptr, nullptr, &n_terms, nullptr);
+  if (term_keys) {
+    term_keys->assign(n_terms, 0);
+    if (n_terms) ss_index_bin_term_keys(ix, term_keys->data());
+  }
+  rc = ss_bm25_upload_index_bin(h_, ix);
+  ss_index_bin_close(ix);
+  n_docs_ = rc == SS_OK ? n_docs : 0;
+  return rc;
+}
+
+int Shard::open_vector_bin(const uint8_t* bytes, uint64_t len, uint32_t dim) {
+  if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
+  const int rc = ss_vec_upload_vector_bin(h_, bytes, len, dim);
+  uint64_t n = 0;
+  uint32_t d = 0;
+  if (rc == SS_OK) ss_vec_info(h_, &n, &d);
+  n_rows_ = n;
+  dim_ = d;
+  return rc;
+}
+
+int Shard::set_deleted(const uint64_t* doc_ids, uint64_t n) {
+  if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
+  return ss_set_deleted(h_, doc_ids, n);
+}
+
 int Shard::synth_lexical(uint64_t seed, uint64_t n_docs, uint32_t n_terms, const uint32_t* thresh32,
                          const uint8_t* len_table1024) {
   if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;

@@ -77,6 +77,11 @@ class Shard {
   int upload_lexical(uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t n_terms, const uint64_t* term_offsets,
                      const uint32_t* doc_ids, const uint16_t* tfs);
   int upload_vectors(uint64_t n_rows, uint32_t dim, const float* rows, const uint32_t* row_doc_ids);
+  // shard files as the reference writes them: index.bin (single indexed field), vector.bin (f32), delete.bin
+  int open_index_bin(const uint8_t* bytes, uint64_t len, uint32_t key_head_size, std::vector<uint64_t>* term_keys);
+  int open_vector_bin(const uint8_t* bytes, uint64_t len, uint32_t dim);
+  // delete_hashset (index.rs:1594): replaces the tombstone set; delete_document (index.rs:5110) re-sends it
+  int set_deleted(const uint64_t* doc_ids, uint64_t n);
   int synth_lexical(uint64_t seed, uint64_t n_docs, uint32_t n_terms, const uint32_t* thresh32, const uint8_t* len_table1024);
   int synth_vectors(uint64_t seed, uint64_t n_rows, uint32_t dim);
 

@@ -197,6 +197,13 @@ class Shard:
         N.check(N.lib().ss_vec_info(self._h, C.byref(n), C.byref(d)), "ss_vec_info")
         self.vector_count, self.dim = n.value, d.value
 
+    def set_deleted(self, doc_ids):
+        """delete_hashset of the shard (index.rs:1594): replaces the tombstone set; also takes delete.bin's bytes"""
+        if isinstance(doc_ids, (bytes, bytearray, memoryview)):
+            doc_ids = np.frombuffer(bytes(doc_ids), "<u8")
+        ids = np.ascontiguousarray(doc_ids, np.uint64)
+        N.check(N.lib().ss_set_deleted(self._h, N.ptr(ids, N.u64p) if len(ids) else None, len(ids)), "ss_set_deleted")
+
     def synth_lexical(self, seed, n_docs, thresh32, len_table1024):
         th = np.ascontiguousarray(thresh32, np.uint32)
         tab = np.ascontiguousarray(len_table1024, np.uint8)

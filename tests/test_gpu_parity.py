@@ -335,3 +335,68 @@ def test_device_merge_matches_host_merge(S, O):
         assert n == len(hd) == min(k, int(cnt[:, q].sum()))
         assert np.array_equal(md[q, :n].astype(np.uint64), hd) and np.array_equal(ms[q, :n], hs)
         assert np.all(md[q, n:] == -1)
+
+
+def test_deleted_docs_lexical_both_strategies(S, O, lex):
+    """delete_hashset (add_result.rs:3435, union.rs:975): a tombstoned doc neither counts nor ranks, in any result type,
+    under the exhaustive and the pruned strategy; clearing the set restores the answers."""
+    sh, osh, n_docs = lex
+    tl_all = [[10, 9, 8], [9, 5], [10], [7, 6, 5, 4], [10, 9, 8, 7, 6, 5]]
+    rng = np.random.default_rng(17)
+    try:
+        for qt, oop in ((S.QueryType.Union, O.OP_OR), (S.QueryType.Intersection, O.OP_AND)):
+            tl = tl_all
+            q = sh.make_queries(tl, qt)
+            base = sh.search_lexical_batch(q, 10)
+            gone = set(int(x) for x in rng.choice(n_docs, size=3000, replace=False))
+            for i in range(len(tl)):  # plus ranked docs of every query, first and middle
+                gone.update(int(d) for d in base[0][i][:base[2][i]][::3])
+            gone = sorted(gone)
+            sh.set_deleted(gone)
+            osh.set_deleted(gone)
+            for strat in (1, 2, 0):  # EXHAUSTIVE, PRUNED, AUTO
+                sh.set_strategy(strat)
+                tl = tl_all[:4] if strat == 2 else tl_all  # the pruned kernel serves <= 4 terms
+                q = sh.make_queries(tl, qt)
+                for rt in (S.ResultType.TopkCount, S.ResultType.Topk, S.ResultType.Count):
+                    if strat == 2 and rt != S.ResultType.Topk and qt == S.QueryType.Union:
+                        continue  # exact union counts are outside the pruned strategy (ENOTSUP by design)
+                    doc, score, cnt, tot = sh.search_lexical_batch(q, 10, rt)
+                    for i, terms in enumerate(tl):
+                        od, os_, otot = osh.search_exhaustive(terms, oop, 10)
+                        if rt != S.ResultType.Topk:
+                            assert int(tot[i]) == otot, (terms, qt, strat, rt)
+                        if rt != S.ResultType.Count:
+                            assert not set(map(int, doc[i][:cnt[i]])) & set(gone)
+                            _check_topk(doc[i], score[i], cnt[i], od, os_)
+            sh.set_strategy(0)
+            sh.set_deleted([])
+            osh.set_deleted([])
+            again = sh.search_lexical_batch(sh.make_queries(tl_all, qt), 10)
+            for x, y in zip(base, again):
+                assert np.array_equal(x, y)
+    finally:
+        sh.set_strategy(0)
+        sh.set_deleted([])
+        osh.set_deleted([])
+
+
+def test_deleted_docs_vector(S, O):
+    rows = O.vec_gen(O.VEC_SEED, 0, 6000, 96)
+    ids = (np.arange(6000) // 2).astype(np.uint32)  # two records per doc
+    qs = O.vec_gen(O.VECQ_SEED, 0, 6, 96)
+    sh = S.Shard(0)
+    sh.upload_vectors(rows, ids)
+    base = sh.search_vector_batch(qs, 50)
+    gone = sorted({int(d) for i in range(len(qs)) for d in base[0][i][:10:2]} | {1, 2999})
+    sh.set_deleted(np.array(gone, np.uint64).tobytes())  # delete.bin's layout: a stream of u64 (index.rs:3798-3809)
+    doc, score, cnt, tot = sh.search_vector_batch(qs, 50)
+    for i in range(len(qs)):
+        od, os_, _, _ = O.vec_search(rows, qs[i], 50, row_doc_ids=ids, deleted=gone)
+        assert cnt[i] == len(od) and not set(map(int, doc[i][:cnt[i]])) & set(gone)
+        assert np.allclose(score[i][:cnt[i]], os_, rtol=1e-4, atol=2e-6)
+        assert [int(x) for x in doc[i][:30]] == [int(x) for x in od[:30]]
+    sh.set_deleted([])
+    for x, y in zip(base, sh.search_vector_batch(qs, 50)):
+        assert np.array_equal(x, y)
+    sh.close()

@@ -203,3 +203,34 @@ def test_generator_is_stable():
     assert np.array_equal(d[:64], g["lex_docs"]) and np.array_equal(t[:64], g["lex_tfs"])
     assert np.array_equal(O.lex_doclen(4096)[:256], g["doclen"])
     assert np.array_equal(O.vec_gen(O.VEC_SEED, 5, 2, 16), g["vec"])
+
+
+def test_deleted_docs_neither_count_nor_rank():
+    # delete_hashset: add_result.rs:3435 (skipped before counting), union.rs:975 (cleared from the count bitmaps),
+    # vector.rs:1450-1452 (scored, not pushed)
+    n_docs = 150_000
+    terms = [4095, 4000, 3000]
+    dl, offs, docs, tfs = _corpus(n_docs, terms)
+    sh = O.Shard(n_docs, dl, offs, docs, tfs)
+    q = [0, 1, 2]
+    for op in (O.OP_OR, O.OP_AND):
+        d0, s0, tot0 = sh.search(q, op, 10, O.RT_TOPKCOUNT)
+        gone = [int(d0[0]), int(d0[3]), 7]  # two ranked docs + one arbitrary doc
+        member = lambda d: sum(d in docs[int(offs[i]):int(offs[i + 1])] for i in q)
+        matched_gone = sum((member(g) == 3) if op == O.OP_AND else (member(g) > 0) for g in gone)
+        sh.set_deleted(gone)
+        for fn in (lambda: sh.search(q, op, 10, O.RT_TOPKCOUNT), lambda: sh.search_exhaustive(q, op, 10)):
+            d1, s1, tot1 = fn()
+            assert tot1 == tot0 - matched_gone
+            assert not set(map(int, d1)) & set(gone)
+            keep = [i for i, d in enumerate(d0) if int(d) not in gone]
+            assert np.allclose(s1[:len(keep)], s0[keep], rtol=1e-6)  # the survivors move up, scores unchanged (idf keeps N, df)
+        assert sh.search(q, op, 0, O.RT_COUNT)[2] == tot0 - matched_gone
+        sh.set_deleted([])
+        assert sh.search(q, op, 10, O.RT_TOPKCOUNT)[2] == tot0
+    rows = O.vec_gen(O.VEC_SEED, 0, 3000, 64)
+    qv = O.vec_gen(O.VECQ_SEED, 0, 1, 64)[0]
+    d0, s0, tot0, obs0 = O.vec_search(rows, qv, 20)
+    d1, s1, tot1, obs1 = O.vec_search(rows, qv, 20, deleted=[int(d0[0]), int(d0[5])])
+    assert obs1 == obs0 == 3000 and int(d0[0]) not in d1 and int(d0[5]) not in d1
+    assert [int(x) for x in d1[:4]] == [int(x) for x in d0[1:5]]
