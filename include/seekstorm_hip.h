@@ -124,11 +124,15 @@ int ss_bm25_set_strategy(ss_shard* s, int strategy);
 /* posting_count per term (the df the host needs for idf, search.rs:3225-3230) */
 int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df_out);
 
+/* query_list + not_query_list of the dispatch block (search.rs:3374-3560).  NOT terms ("-term", not_query_list): a doc
+ * found in one of their posting lists neither counts nor ranks (add_result.rs:3440-3497).  They are stored after the
+ * n_terms query terms, their number in bits 8..15 of op:  op = SS_OP_* | SS_OP_NOT_TERMS(n);  n_terms + n <= 10. */
+#define SS_OP_NOT_TERMS(n) ((uint32_t)(n) << 8)
 typedef struct {
-  uint32_t n_terms;                  /* 1..SS_MAX_QUERY_TERMS unique terms */
-  uint32_t op;                       /* SS_OP_* */
-  uint32_t term[SS_MAX_QUERY_TERMS]; /* term index into the uploaded vocabulary */
-  float idf[SS_MAX_QUERY_TERMS];     /* host-computed, search.rs:3225-3230 */
+  uint32_t n_terms;                  /* 1..SS_MAX_QUERY_TERMS unique terms (scored; all required for an intersection) */
+  uint32_t op;                       /* SS_OP_* | SS_OP_NOT_TERMS(number of NOT terms) */
+  uint32_t term[SS_MAX_QUERY_TERMS]; /* term index into the uploaded vocabulary; query terms first, then the NOT terms */
+  float idf[SS_MAX_QUERY_TERMS];     /* host-computed, search.rs:3225-3230; entries of NOT terms are ignored */
 } ss_bm25_query;
 
 /* Batched BM25 search.  Outputs: out_doc/out_score [n_queries*k], out_count [n_queries] (= results.len()),
@@ -140,7 +144,8 @@ int ss_bm25_search(ss_shard* s, uint32_t n_queries, const ss_bm25_query* queries
  * NULL = the shard's own stream).  d_queries is a device array of ss_bm25_query that the caller has validated
  * (term < n_terms, unique terms, idf > 0).  ops_mask: bit 0 set if any query is an intersection of > 1 terms
  * (selects the kernel variant that carries match counters), bit 1 set if any query is a union of > 1 terms; bits 8..15 = the
- * largest n_terms in the batch (0 = unknown: the generic 10-term kernel is used). */
+ * largest n_terms + NOT terms in the batch (0 = unknown: the generic 10-term kernel is used); bits 16..23 = the largest
+ * n_terms alone (0 = same as bits 8..15, i.e. no NOT terms). */
 int ss_bm25_search_dev(ss_shard* s, uint32_t n_queries, const ss_bm25_query* d_queries, uint32_t k,
                        uint32_t result_type, uint32_t ops_mask, uint32_t* d_out_doc, float* d_out_score,
                        uint32_t* d_out_count, uint64_t* d_out_total, void* stream);

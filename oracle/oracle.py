@@ -71,7 +71,9 @@ def lib():
     L.so_shard_container.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, u32p, u32p, f32p]
     L.so_shard_decode_block.restype = C.c_uint32
     L.so_shard_decode_block.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, u16p]
-    for fn in (L.so_search_lex, L.so_search_lex_exhaustive):
+    L.so_search_lex_not.argtypes = [C.c_void_p, C.c_uint32, u32p, C.c_uint32, u32p, C.c_int, C.c_uint32, C.c_int, u32p, f32p, u64p]
+    L.so_search_lex_exhaustive_not.argtypes = [C.c_void_p, C.c_uint32, u32p, C.c_uint32, u32p, C.c_int, C.c_uint32, u32p, f32p, u64p]
+    for fn in (L.so_search_lex, L.so_search_lex_exhaustive, L.so_search_lex_not, L.so_search_lex_exhaustive_not):
         fn.restype = C.c_uint32
     L.so_search_lex.argtypes = [C.c_void_p, C.c_uint32, u32p, C.c_int, C.c_uint32, C.c_int, u32p, f32p, u64p]
     L.so_search_lex_exhaustive.argtypes = [C.c_void_p, C.c_uint32, u32p, C.c_int, C.c_uint32, u32p, f32p, u64p]
@@ -203,22 +205,24 @@ class Shard:
         n = lib().so_shard_decode_block(self.h, t, bo, _p(out, u16p))
         return out[:n].copy()
 
-    def _search(self, fn, terms, op, k, rt=None):
+    def _search(self, fn, terms, not_terms, op, k, rt=None):
         q = np.ascontiguousarray(terms, np.uint32)
+        nq = np.ascontiguousarray(not_terms, np.uint32)
         od = np.empty(max(k, 1), np.uint32)
         os_ = np.empty(max(k, 1), np.float32)
         tot = C.c_uint64()
+        head = (self.h, len(q), _p(q, u32p), len(nq), _p(nq, u32p) if len(nq) else None, op, k)
         if rt is None:
-            n = fn(self.h, len(q), _p(q, u32p), op, k, _p(od, u32p), _p(os_, f32p), C.byref(tot))
+            n = fn(*head, _p(od, u32p), _p(os_, f32p), C.byref(tot))
         else:
-            n = fn(self.h, len(q), _p(q, u32p), op, k, rt, _p(od, u32p), _p(os_, f32p), C.byref(tot))
+            n = fn(*head, rt, _p(od, u32p), _p(os_, f32p), C.byref(tot))
         return od[:n].copy(), os_[:n].copy(), tot.value
 
-    def search(self, terms, op, k, rt=RT_TOPKCOUNT):
-        return self._search(lib().so_search_lex, terms, op, k, rt)
+    def search(self, terms, op, k, rt=RT_TOPKCOUNT, not_terms=()):
+        return self._search(lib().so_search_lex_not, terms, not_terms, op, k, rt)
 
-    def search_exhaustive(self, terms, op, k):
-        return self._search(lib().so_search_lex_exhaustive, terms, op, k)
+    def search_exhaustive(self, terms, op, k, not_terms=()):
+        return self._search(lib().so_search_lex_exhaustive_not, terms, not_terms, op, k)
 
     def stats(self, terms):
         q = np.ascontiguousarray(terms, np.uint32)

@@ -377,7 +377,7 @@ static int bm_cmp(const void* a, const void* b) {
 /* intersection_blockid (intersection.rs:2023-2301) + intersection_docid (112-447) +
  * add_result_multiterm_singlefield (add_result.rs:3418-3706, no filters / no phrase) */
 static void search_and(const so_shard* s, uint32_t nq, const uint32_t* qt, const float* idf, int rt,
-                       so_heap* heap, uint64_t* total) {
+                       so_heap* heap, uint64_t* total, const uint8_t* gone) {
   uint32_t ptr[32] = {0};
   uint32_t nbm = 0, cap = 0;
   for (uint32_t t = 0; t < nq; t++) if (t == 0 || s->terms[qt[t]].n_blocks < cap) cap = s->terms[qt[t]].n_blocks;
@@ -442,7 +442,7 @@ static void search_and(const so_shard* s, uint32_t nq, const uint32_t* qt, const
       if (!ok) continue;
       cur[0].rank = p0;
       uint32_t docid = (m->block_id << 16) | d;
-      if (s->deleted && s->deleted[docid]) continue; /* add_result.rs:3435: first thing add_result does */
+      if (gone && gone[docid]) continue; /* add_result.rs:3435 delete_hashset, 3440-3497 not_query_list: first things add_result does */
       /* add_result.rs:3503-3537 */
       if (rt == SO_RT_COUNT) { (*total)++; continue; }
       if (heap_full(heap) && heap->k > 0 && m->score <= heap->e[0].score) {
@@ -464,7 +464,7 @@ static void search_and(const so_shard* s, uint32_t nq, const uint32_t* qt, const
  * top-k of the union under full BM25 over matched terms; this table scan is the
  * reference's own formulation of the same result (used there for >10 terms / counts). */
 static void search_or(const so_shard* s, uint32_t nq, const uint32_t* qt, const float* idf, int rt,
-                      so_heap* heap, uint64_t* total) {
+                      so_heap* heap, uint64_t* total, const uint8_t* gone) {
   uint32_t ptr[32] = {0};
   uint32_t cap = 0, nbm = 0;
   for (uint32_t t = 0; t < nq; t++) cap += s->terms[qt[t]].n_blocks;
@@ -513,9 +513,10 @@ static void search_or(const so_shard* s, uint32_t nq, const uint32_t* qt, const 
       uint32_t bits = table[d];
       if (!bits) continue;
       /* union.rs:975-: union_count clears deleted docs; add_result.rs:3435 skips them (ranks still advance) */
-      int gone = s->deleted && s->deleted[((uint64_t)m->block_id << 16) | d];
-      if (!gone) (*total)++;
-      if (!gone && !block_skip && rt != SO_RT_COUNT) {
+      /* ... and union.rs:483-530 zeroes the docs of NOT terms in the scatter table */
+      int out = gone && gone[((uint64_t)m->block_id << 16) | d];
+      if (!out) (*total)++;
+      if (!out && !block_skip && rt != SO_RT_COUNT) {
         float bound;
         if (mstab) bound = mstab[bits];
         else { bound = 0.0f; for (uint32_t j = 0; j < nq; j++) if ((bits >> j) & 1u) bound += idf[j] * s->terms[qt[j]].blocks[m->ord[j]].max_part; }
@@ -534,8 +535,24 @@ static void search_or(const so_shard* s, uint32_t nq, const uint32_t* qt, const 
   free(mstab); free(tmp); free(table); free(bms);
 }
 
+/* deleted docs + docs of the NOT terms as one byte map (NULL when there are none).  The reference walks the NOT lists
+ * with per-term cursors inside add_result (add_result.rs:3440-3497); the result is the same set difference. */
+static uint8_t* exclusion_map(const so_shard* s, uint32_t n_not, const uint32_t* not_terms) {
+  if (!s->deleted && !n_not) return NULL;
+  size_t n = (size_t)s->n_level_blocks * SO_BLOCK;
+  uint8_t* g = (uint8_t*)calloc(n, 1);
+  if (s->deleted) memcpy(g, s->deleted, n);
+  for (uint32_t j = 0; j < n_not; j++)
+    if (not_terms[j] < s->n_terms)
+      for (uint64_t i = s->off[not_terms[j]]; i < s->off[not_terms[j] + 1]; i++) g[s->docs[i]] = 1;
+  return g;
+}
 uint32_t so_search_lex(const so_shard* s, uint32_t nq, const uint32_t* qt, int op, uint32_t k, int rt,
                        uint32_t* od, float* os, uint64_t* total) {
+  return so_search_lex_not(s, nq, qt, 0, NULL, op, k, rt, od, os, total);
+}
+uint32_t so_search_lex_not(const so_shard* s, uint32_t nq, const uint32_t* qt, uint32_t n_not, const uint32_t* not_terms,
+                           int op, uint32_t k, int rt, uint32_t* od, float* os, uint64_t* total) {
   uint64_t tot = 0;
   if (nq == 0 || nq > 32) { if (total) *total = 0; return 0; }
   float idf[32];
@@ -547,9 +564,11 @@ uint32_t so_search_lex(const so_shard* s, uint32_t nq, const uint32_t* qt, int o
   uint32_t kk = k; if ((uint64_t)kk > s->n_docs) kk = (uint32_t)s->n_docs;
   if (rt == SO_RT_COUNT) kk = 0;
   so_heap heap; heap.n = 0; heap.k = kk; heap.e = (so_res*)malloc((kk ? kk : 1) * sizeof(so_res));
-  if (op == SO_OP_AND || nq == 1) search_and(s, nq, qt, idf, rt, &heap, &tot);
-  else search_or(s, nq, qt, idf, rt, &heap, &tot);
+  uint8_t* gone = exclusion_map(s, n_not, not_terms);
+  if (op == SO_OP_AND || nq == 1) search_and(s, nq, qt, idf, rt, &heap, &tot, gone);
+  else search_or(s, nq, qt, idf, rt, &heap, &tot, gone);
   uint32_t n = heap_drain(&heap, od, os);
+  free(gone);
   free(heap.e);
   if (total) *total = tot;
   return n;
@@ -564,6 +583,11 @@ static int sd_cmp(const void* a, const void* b) {
 }
 uint32_t so_search_lex_exhaustive(const so_shard* s, uint32_t nq, const uint32_t* qt, int op, uint32_t k,
                                   uint32_t* od, float* os, uint64_t* total) {
+  return so_search_lex_exhaustive_not(s, nq, qt, 0, NULL, op, k, od, os, total);
+}
+uint32_t so_search_lex_exhaustive_not(const so_shard* s, uint32_t nq, const uint32_t* qt, uint32_t n_not,
+                                      const uint32_t* not_terms, int op, uint32_t k, uint32_t* od, float* os,
+                                      uint64_t* total) {
   float* sc = (float*)calloc(s->n_docs ? s->n_docs : 1, sizeof(float));
   uint8_t* cnt = (uint8_t*)calloc(s->n_docs ? s->n_docs : 1, 1);
   for (uint32_t t = 0; t < nq; t++) {
@@ -574,8 +598,10 @@ uint32_t so_search_lex_exhaustive(const so_shard* s, uint32_t nq, const uint32_t
       cnt[d]++;
     }
   }
-  if (s->deleted)
-    for (uint64_t d = 0; d < s->n_docs; d++) if (s->deleted[d]) cnt[d] = 0;
+  uint8_t* gone = exclusion_map(s, n_not, not_terms);
+  if (gone)
+    for (uint64_t d = 0; d < s->n_docs; d++) if (gone[d]) cnt[d] = 0;
+  free(gone);
   uint64_t m = 0;
   for (uint64_t d = 0; d < s->n_docs; d++) if (op == SO_OP_AND ? cnt[d] == nq : cnt[d] > 0) m++;
   so_sd* v = (so_sd*)malloc((m ? m : 1) * sizeof(so_sd));

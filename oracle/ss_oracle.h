@@ -79,6 +79,13 @@ uint32_t so_shard_decode_block(const so_shard*, uint32_t term, uint32_t block_or
  * out_* sized k; returns number of results. */
 uint32_t so_search_lex(const so_shard*, uint32_t n_q_terms, const uint32_t* q_terms, int op, uint32_t k,
                        int result_type, uint32_t* out_doc, float* out_score, uint64_t* out_total);
+/* same with a not_query_list (the "-term" operands): a doc of a NOT list neither counts nor ranks, add_result.rs:3440-3497 */
+uint32_t so_search_lex_not(const so_shard*, uint32_t n_q_terms, const uint32_t* q_terms, uint32_t n_not,
+                           const uint32_t* not_terms, int op, uint32_t k, int result_type, uint32_t* out_doc,
+                           float* out_score, uint64_t* out_total);
+uint32_t so_search_lex_exhaustive_not(const so_shard*, uint32_t n_q_terms, const uint32_t* q_terms, uint32_t n_not,
+                                      const uint32_t* not_terms, int op, uint32_t k, uint32_t* out_doc, float* out_score,
+                                      uint64_t* out_total);
 /* brute-force ground truth (independent code path): exhaustive scoring + exact top-k by
  * (score desc, doc asc); also returns the exact match count. */
 uint32_t so_search_lex_exhaustive(const so_shard*, uint32_t n_q_terms, const uint32_t* q_terms, int op,

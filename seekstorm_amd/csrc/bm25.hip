@@ -71,7 +71,7 @@ __global__ void bm25_final_kernel(const u64* __restrict__ keys, const u64* __res
 // ---------------------------------------------------------------- host side
 int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t* d_out_doc,
                     float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, bool has_or,
-                    uint32_t nt_max, hipStream_t st) {
+                    uint32_t nt_max, uint32_t np_max, hipStream_t st) {
   if (!s->d_post) return SS_ESTATE;
   if (nq == 0) return SS_OK;
   if (k > SS_MAX_K) return SS_EINVAL;
@@ -83,7 +83,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   // result type -- it reads only the essential / shortest lists.  Exhaustive (bm25_fast.hip): everything else (exact
   // union counts need every posting), and whenever the probe index is absent or SS_BM25_EXHAUSTIVE is selected.
   const bool pruned = s->bm_strategy != SS_BM25_EXHAUSTIVE && (!has_or || rt == SS_RT_TOPK) && s->d_probe && s->d_umax &&
-                      nt_max >= 1 && nt_max <= 4 && KPL <= 2;
+                      np_max >= 1 && np_max <= 4 && KPL <= 2;  // NOT terms are probed outside the template
   if (!pruned && s->bm_strategy == SS_BM25_PRUNED) return SS_ENOTSUP;
   // Partitions per query (one wave each).  The grid is a whole number of "rounds" of resident waves: a partially
   // filled last round costs its full duration (measured on C2: 550K q/s at 1.95 rounds vs 477K at 2.44).  Exhaustive
@@ -129,7 +129,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   p.count = (rt == SS_RT_TOPK) ? 0u : 1u;  // Topk: result_count_total is not required to be exact
   hipEvent_t e0 = nullptr, e1 = nullptr;
   ssi_prof_begin(s, 0, st, &e0, &e1);
-  const int rc = pruned ? ssi_bm25_launch_probe(p, s->d_probe, s->d_probe_z, s->d_umax, nt_max, KPL, st)
+  const int rc = pruned ? ssi_bm25_launch_probe(p, s->d_probe, s->d_probe_z, s->d_umax, np_max, KPL, nt_max != np_max, st)
                         : ssi_bm25_launch_scan(p, nt_max, has_and, KPL, st);
   ssi_prof_end(s, 0, st, e0, e1);
   if (rc) return rc;

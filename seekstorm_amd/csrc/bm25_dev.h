@@ -336,14 +336,14 @@ __device__ __attribute__((noinline)) BmTop<KPL> bm_scan_tile(BmTop<KPL> T, uint3
       if (nib & 4u) x.z = 0.f;
       if (nib & 8u) x.w = 0.f;
     }
-    bool h0 = x.x != 0.f, h1 = x.y != 0.f, h2 = x.z != 0.f, h3 = x.w != 0.f;
+    bool h0 = x.x > 0.f, h1 = x.y > 0.f, h2 = x.z > 0.f, h3 = x.w > 0.f;  // a doc of a NOT list has a negative score
     if (HAS_AND && is_and) {
       const uint32_t cw = lds_ld32(cntw + slot * 4);
       lds_st32(cntw + slot * 4, 0u);
-      h0 = (cw & 0xFFu) == nt_and && !(nib & 1u);
-      h1 = ((cw >> 8) & 0xFFu) == nt_and && !(nib & 2u);
-      h2 = ((cw >> 16) & 0xFFu) == nt_and && !(nib & 4u);
-      h3 = (cw >> 24) == nt_and && !(nib & 8u);
+      h0 = h0 && (cw & 0xFFu) == nt_and;  // h: score > 0 (not deleted, in no NOT list)
+      h1 = h1 && ((cw >> 8) & 0xFFu) == nt_and;
+      h2 = h2 && ((cw >> 16) & 0xFFu) == nt_and;
+      h3 = h3 && (cw >> 24) == nt_and;
       if (!h0) x.x = 0.f;
       if (!h1) x.y = 0.f;
       if (!h2) x.z = 0.f;
@@ -381,4 +381,5 @@ __device__ __attribute__((noinline)) BmTop<KPL> bm_scan_tile(BmTop<KPL> T, uint3
 // scan kernels (bm25_fast.hip): NT-specialised for <= 4 terms and k <= 128, grouped generic kernel otherwise
 int ssi_bm25_launch_scan(const BmParams& p, uint32_t nt_max, bool has_and, int KPL, hipStream_t st);
 // pruned top-k over the probe index (bm25_probe.hip); SS_ENOTSUP if it cannot serve the request
-int ssi_bm25_launch_probe(const BmParams& p, const uint2* probe, const uint32_t* probe_z, const float* umax, uint32_t nt_max, int KPL, hipStream_t st);
+int ssi_bm25_launch_probe(const BmParams& p, const uint2* probe, const uint32_t* probe_z, const float* umax, uint32_t nt_max, int KPL,
+                          bool any_not, hipStream_t st);

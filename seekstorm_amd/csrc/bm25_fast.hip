@@ -65,8 +65,8 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
   if (a < nq * P) {
     const uint32_t qi = a % nq, part = a / nq;
     const ss_bm25_query* __restrict__ Q = qs + qi;
-    const uint32_t nt = Q->n_terms;
-    const bool is_and = HAS_AND && (Q->op == SS_OP_INTERSECTION) && nt > 1;
+    const uint32_t np = Q->n_terms, nt = np + bm_q_nnot(Q->op);  // positive terms, then the NOT terms
+    const bool is_and = HAS_AND && (bm_q_op(Q->op) == SS_OP_INTERSECTION) && np > 1;
     // Per-term state in scalar registers: descriptor base, idf and a rolling window of three segment boundaries.
     // The boundaries themselves are fetched 64 at a time into vector registers (lane i = sub-block s0 + i, one
     // coalesced load per term every BLK items) and picked with v_readlane, so the item loop carries no scalar loads,
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
       const bool have = (uint32_t)t < nt;
       const uint32_t term = have ? Q->term[t] : n_terms;
       tid_[t] = term;
-      idf[t] = have ? Q->idf[t] : 0.f;
+      idf[t] = have ? ((uint32_t)t < np ? Q->idf[t] : BM_NOT_IDF) : 0.f;
       tptr[t] = post + term_base[term] * 4ull;
       rowp[t] = sub_off + (size_t)term * row_len;
     }
@@ -96,7 +96,7 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
     T.worst = 0ull;
     T.wsc = -1.0f;
     T.matched = 0;
-    const uint32_t nt_and = is_and ? nt : 0u;
+    const uint32_t nt_and = is_and ? np : 0u;
 
     // RC loads per item; lanes (and whole chunks) past the segment end are out of range: zeros, no memory access
     auto issue_loads = [&](u32x4(&v)[RC], const uint32_t (&b0)[NT], const uint32_t (&b1)[NT]) {
@@ -188,12 +188,13 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
           const uint32_t n16 = B1[t] - B0[t];
 #pragma unroll
           for (int c = 0; c < CPT; c++)
-            if ((uint32_t)c * 64u < n16) mx = bm_chunk<HAS_AND>(cur[t * CPT + c], idf[t], L, is_and, mx, X, tid_[t], s << BM_SUB_LOG2);
+            if ((uint32_t)c * 64u < n16)
+              mx = bm_chunk<HAS_AND>(cur[t * CPT + c], idf[t], L, is_and && (uint32_t)t < np, mx, X, tid_[t], s << BM_SUB_LOG2);
           if (n16 > (uint32_t)CPT * 64u) {  // df above ~CPT/16 of the docs
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[t], 0, (int)(B1[t] << 4), BM_RSRC_FLAGS);
             for (uint32_t u = B0[t] + CPT * 64u; u < B1[t]; u += 64u) {
               const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0);
-              mx = bm_chunk<HAS_AND>(q, idf[t], L, is_and, mx, X, tid_[t], s << BM_SUB_LOG2);
+              mx = bm_chunk<HAS_AND>(q, idf[t], L, is_and && (uint32_t)t < np, mx, X, tid_[t], s << BM_SUB_LOG2);
             }
           }
         }
@@ -251,8 +252,8 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
   for (uint32_t a = blockIdx.x * WAVES + w; a < A; a += total_waves) {
     const uint32_t qi = a % nq, part = a / nq;
     const ss_bm25_query* __restrict__ Q = qs + qi;
-    const uint32_t nt = Q->n_terms;
-    const bool is_and = HAS_AND && (Q->op == SS_OP_INTERSECTION) && nt > 1;
+    const uint32_t np = Q->n_terms, nt = np + bm_q_nnot(Q->op);
+    const bool is_and = HAS_AND && (bm_q_op(Q->op) == SS_OP_INTERSECTION) && np > 1;
     const uint32_t s_begin = (uint32_t)(((u64)n_sub * part) / P);
     const uint32_t s_end = (uint32_t)(((u64)n_sub * (part + 1)) / P);
     BmTop<KPL> T;
@@ -261,7 +262,7 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
     T.worst = 0ull;
     T.wsc = -1.0f;
     T.matched = 0;
-    const uint32_t nt_and = is_and ? nt : 0u;
+    const uint32_t nt_and = is_and ? np : 0u;
 
     for (uint32_t s = s_begin; s < s_end; s++) {
       float mx = 0.f;
@@ -278,7 +279,7 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
           const bool have = g0 + t < nt;
           const uint32_t term = have ? Q->term[have ? g0 + t : 0] : n_terms;
           tid_[t] = term;
-          idf[t] = have ? Q->idf[have ? g0 + t : 0] : 0.f;
+          idf[t] = have ? (g0 + t < np ? Q->idf[have ? g0 + t : 0] : BM_NOT_IDF) : 0.f;
           tp[t] = post + term_base[term] * 4ull;
           b0[t] = sub_off[term * row_len + s];
           b1[t] = sub_off[term * row_len + s + 1];
@@ -293,12 +294,13 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
           any |= n16 != 0;
 #pragma unroll
           for (int c = 0; c < CPT; c++)
-            if ((uint32_t)c * 64u < n16) mx = bm_chunk<HAS_AND>(v[t * CPT + c], idf[t], L, is_and, mx, X, tid_[t], s << BM_SUB_LOG2);
+            if ((uint32_t)c * 64u < n16)
+              mx = bm_chunk<HAS_AND>(v[t * CPT + c], idf[t], L, is_and && g0 + t < np, mx, X, tid_[t], s << BM_SUB_LOG2);
           if (n16 > (uint32_t)CPT * 64u) {
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tp[t], 0, (int)(b1[t] << 4), BM_RSRC_FLAGS);
             for (uint32_t u = b0[t] + CPT * 64u; u < b1[t]; u += 64u) {
               const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0);
-              mx = bm_chunk<HAS_AND>(q, idf[t], L, is_and, mx, X, tid_[t], s << BM_SUB_LOG2);
+              mx = bm_chunk<HAS_AND>(q, idf[t], L, is_and && g0 + t < np, mx, X, tid_[t], s << BM_SUB_LOG2);
             }
           }
         }

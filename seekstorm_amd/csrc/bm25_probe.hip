@@ -47,7 +47,8 @@ __device__ __forceinline__ float pb_weight(uint32_t p, const BmExc& X, uint32_t 
   return w;
 }
 
-template <int NT, int KPL>
+// FILT: tombstones and / or NOT terms are present (a separate instantiation: the unfiltered kernel pays nothing for them)
+template <int NT, int KPL, bool FILT>
 __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
     const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base, const uint32_t* __restrict__ sub_off,
     const float* __restrict__ comp_g, const uint2* __restrict__ probe, const uint32_t* __restrict__ probe_z,
@@ -67,8 +68,8 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
   if (a >= nq * P) return;
   const uint32_t qi = a % nq, part = a / nq;
   const ss_bm25_query* __restrict__ Q = qs + qi;
-  const uint32_t nt = Q->n_terms;
-  const bool is_and = (Q->op == SS_OP_INTERSECTION) && nt > 1;
+  const uint32_t nt = Q->n_terms, n_not = FILT ? bm_q_nnot(Q->op) : 0u;  // NT covers the query terms; NOT terms are probed at the end
+  const bool is_and = (bm_q_op(Q->op) == SS_OP_INTERSECTION) && nt > 1;
   const uint32_t row_len = n_sub + 1;
 
   // per-term state in PROCESSING order (sorted below); qpos = position in the query (order of the score sum)
@@ -154,6 +155,19 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
     if (lanes && (doc >> 5) < del_words) wd = del[doc >> 5];
     return (wd >> (doc & 31u)) & 1u;
   };
+  // NOT terms (add_result.rs:3440-3497): a candidate found in one of their lists is dropped; evaluated like the
+  // tombstones, for the few lanes that still hold a candidate
+  auto in_not_list = [&](bool lanes, uint32_t doc) -> bool {
+    bool found = false;
+    for (uint32_t j = 0; j < n_not; j++) {
+      const uint32_t term = Q->term[nt + j];
+      uint2 r = make_uint2(0u, 0u);
+      if (lanes) r = probe[((size_t)term * n_sub + (doc >> BM_SUB_LOG2)) * (BM_SUB / 64) + ((doc & (BM_SUB - 1)) >> 6)];
+      const u64 bits = ((u64)r.y << 32) | r.x;
+      found = found || ((bits >> (doc & 63u)) & 1ull);
+    }
+    return found;
+  };
   auto cur_thr = [&]() -> float {
     return fmaxf(T.wsc, __uint_as_float(__hip_atomic_load(tau_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
   };
@@ -236,7 +250,9 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
           pres |= 1u << t;
         }
       }
-      if (del && __ballot(alive)) alive = alive && !is_deleted(alive, doc);
+      if (FILT && del && __ballot(alive)) alive = alive && !is_deleted(alive, doc);
+      if (FILT && n_not && !(count && is_and) && k) alive = alive && combine(wv, pres) >= thr;  // probe the NOT lists for real candidates only
+      if (FILT && n_not && __ballot(alive)) alive = alive && !in_not_list(alive, doc);
       if (__ballot(alive)) {
         if (count && is_and) T.matched += __popcll(__ballot(alive));
         if (k) {
@@ -300,12 +316,14 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
         for (int g = 0; g < G; g++) {
           if (__ballot(alive[g]) == 0ull) continue;
           const uint32_t doc1 = (tile[g] << BM_SUB_LOG2) + dg[g];
-          if (del && count) alive[g] = alive[g] && !is_deleted(alive[g], doc1);
+          if (FILT && del && count) alive[g] = alive[g] && !is_deleted(alive[g], doc1);
+          if (FILT && n_not && count) alive[g] = alive[g] && !in_not_list(alive[g], doc1);
           if (count) T.matched += __popcll(__ballot(alive[g]));
           if (k) {
             const float score = fmaf(idf[J], w0[g], 0.f);
             bool cand = alive[g] && score >= thr && score > 0.f;
-            if (del && !count && __ballot(cand)) cand = cand && !is_deleted(cand, doc1);
+            if (FILT && del && !count && __ballot(cand)) cand = cand && !is_deleted(cand, doc1);
+            if (FILT && n_not && !count && __ballot(cand)) cand = cand && !in_not_list(cand, doc1);
             offer(cand, score, doc1);
           }
         }
@@ -359,10 +377,10 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
   if (lane == 0 && T.matched) atomicAdd(&total[qi], T.matched);
 }
 
-template <int NT, int KPL>
+template <int NT, int KPL, bool FILT>
 static int launch_probe(const BmParams& p, const uint2* probe, const uint32_t* probe_z, const float* umax, hipStream_t st) {
   const uint32_t A = p.nq * p.P;
-  bm25_probe_kernel<NT, KPL><<<(A + PB_WAVES - 1) / PB_WAVES, PB_WAVES * 64, BM_LUT_BYTES + PB_WAVES * PB_QCAP * 12, st>>>(
+  bm25_probe_kernel<NT, KPL, FILT><<<(A + PB_WAVES - 1) / PB_WAVES, PB_WAVES * 64, BM_LUT_BYTES + PB_WAVES * PB_QCAP * 12, st>>>(
       p.post, p.term_base, p.sub_off, p.comp, probe, probe_z, umax, p.q, p.part_keys, p.total, p.tau, p.exc_off, p.exc_doc, p.exc_tf, p.del, p.del_words, p.n_sub, p.n_terms, p.nq, p.P, p.k,
       p.count);
   return SS_OK;
@@ -370,11 +388,13 @@ static int launch_probe(const BmParams& p, const uint2* probe, const uint32_t* p
 
 // returns SS_ENOTSUP when there is no instantiation for (nt_max, KPL): the caller falls back to the exhaustive kernels
 int ssi_bm25_launch_probe(const BmParams& p, const uint2* probe, const uint32_t* probe_z, const float* umax, uint32_t nt_max, int KPL,
-                          hipStream_t st) {
+                          bool any_not, hipStream_t st) {
   if (!probe || !probe_z || !umax || nt_max == 0 || nt_max > 4 || (KPL != 1 && KPL != 2)) return SS_ENOTSUP;
   const int NT = nt_max <= 2 ? 2 : (int)nt_max;
-#define SS_P(NT_, KPL_) \
-  if (NT == NT_ && KPL == KPL_) return launch_probe<NT_, KPL_>(p, probe, probe_z, umax, st);
+  const bool filt = any_not || p.del != nullptr;
+#define SS_P(NT_, KPL_)                                                                          \
+  if (NT == NT_ && KPL == KPL_)                                                                  \
+    return filt ? launch_probe<NT_, KPL_, true>(p, probe, probe_z, umax, st) : launch_probe<NT_, KPL_, false>(p, probe, probe_z, umax, st);
   SS_P(2, 1) SS_P(3, 1) SS_P(4, 1) SS_P(2, 2) SS_P(3, 2) SS_P(4, 2)
 #undef SS_P
   return SS_ENOTSUP;

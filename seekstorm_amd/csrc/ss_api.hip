@@ -217,22 +217,27 @@ int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df
   return SS_OK;
 }
 
-static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q, bool* has_and, bool* has_or, uint32_t* nt_max) {
+// nt_max: largest n_terms + NOT terms of the batch (what the scan kernels are specialised on); np_max: largest n_terms
+static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q, bool* has_and, bool* has_or, uint32_t* nt_max,
+                         uint32_t* np_max) {
   *has_and = false;
   *has_or = false;
   *nt_max = 0;
+  *np_max = 0;
   for (uint32_t i = 0; i < nq; i++) {
-    if (q[i].n_terms == 0 || q[i].n_terms > SS_MAX_QUERY_TERMS) return SS_EINVAL;
-    if (q[i].op != SS_OP_INTERSECTION && q[i].op != SS_OP_UNION) return SS_EINVAL;
-    for (uint32_t t = 0; t < q[i].n_terms; t++) {
+    const uint32_t op = bm_q_op(q[i].op), n_not = bm_q_nnot(q[i].op), all = q[i].n_terms + n_not;
+    if (q[i].n_terms == 0 || all > SS_MAX_QUERY_TERMS || (q[i].op >> 16)) return SS_EINVAL;
+    if (op != SS_OP_INTERSECTION && op != SS_OP_UNION) return SS_EINVAL;
+    for (uint32_t t = 0; t < all; t++) {
       if (q[i].term[t] >= s->bm_n_terms) return SS_EINVAL;
-      if (!(q[i].idf[t] > 0.0f)) return SS_EINVAL;
+      if (t < q[i].n_terms && !(q[i].idf[t] > 0.0f)) return SS_EINVAL;
       for (uint32_t u = 0; u < t; u++)
         if (q[i].term[u] == q[i].term[t]) return SS_EINVAL;  // unique terms only (search.rs:3023 unique_terms)
     }
-    if (q[i].op == SS_OP_INTERSECTION && q[i].n_terms > 1) *has_and = true;
+    if (op == SS_OP_INTERSECTION && q[i].n_terms > 1) *has_and = true;
     else if (q[i].n_terms > 1) *has_or = true;  // a single-term query is both: its exact count is its posting count
-    *nt_max = std::max(*nt_max, q[i].n_terms);
+    *nt_max = std::max(*nt_max, all);
+    *np_max = std::max(*np_max, q[i].n_terms);
   }
   return SS_OK;
 }
@@ -245,8 +250,8 @@ int ss_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k,
   if (!s->d_post) return SS_ESTATE;
   if (nq == 0) return SS_OK;
   bool has_and = false, has_or = false;
-  uint32_t nt_max = 0;
-  SS_TRY(check_queries(s, nq, q, &has_and, &has_or, &nt_max));
+  uint32_t nt_max = 0, np_max = 0;
+  SS_TRY(check_queries(s, nq, q, &has_and, &has_or, &nt_max, &np_max));
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   const uint32_t kk = rt == SS_RT_COUNT ? 0 : k;
@@ -259,7 +264,7 @@ int ss_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k,
   }
   SS_HIP(hipMemcpyAsync(s->d_bq, q, (size_t)nq * sizeof(ss_bm25_query), hipMemcpyHostToDevice, s->stream));
   SS_TRY(ssi_bm25_search(s, nq, (const ss_bm25_query*)s->d_bq, kk, rt, s->d_out_doc, s->d_out_score, s->d_out_count,
-                         s->d_out_total, has_and, has_or, nt_max, s->stream));
+                         s->d_out_total, has_and, has_or, nt_max, np_max, s->stream));
   if (kk) {
     SS_HIP(hipMemcpyAsync(out_doc, s->d_out_doc, (size_t)nq * kk * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     SS_HIP(hipMemcpyAsync(out_score, s->d_out_score, (size_t)nq * kk * sizeof(float), hipMemcpyDeviceToHost, s->stream));
@@ -282,7 +287,9 @@ int ss_bm25_search_dev(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint3
   hipStream_t st = stream ? (hipStream_t)stream : s->stream;
   return ssi_bm25_search(s, nq, d_q, rt == SS_RT_COUNT ? 0 : k, rt, d_out_doc, d_out_score, d_out_count, d_out_total,
                          (ops_mask & 1u) != 0, (ops_mask & 2u) != 0 || (ops_mask & 3u) == 0,
-                         (ops_mask >> 8) & 0xFFu ? (ops_mask >> 8) & 0xFFu : SS_MAX_QUERY_TERMS, st);
+                         (ops_mask >> 8) & 0xFFu ? (ops_mask >> 8) & 0xFFu : SS_MAX_QUERY_TERMS,
+                         (ops_mask >> 16) & 0xFFu ? (ops_mask >> 16) & 0xFFu
+                                                  : ((ops_mask >> 8) & 0xFFu ? (ops_mask >> 8) & 0xFFu : SS_MAX_QUERY_TERMS), st);
 }
 
 // ------------------------------------------------------------------ vectors

@@ -135,9 +135,16 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const float* d_queries, uint32_t k,
                    float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, hipStream_t st, bool safe_mode);
 int ssi_vec_alloc_ws(ss_shard* s);
 // ---- implemented in bm25.hip
+// ss_bm25_query::op = operator (bits 0-7) | number of NOT terms (bits 8-15); the NOT terms follow the n_terms query
+// terms in term[] (their idf entries are ignored).  A doc found in a NOT list neither counts nor ranks
+// (add_result.rs:3440-3497).  On the device a NOT term is a term with idf = BM_NOT_IDF: its docs' scores become hugely
+// negative, and only positive scores are candidates or counted.
+#define BM_NOT_IDF (-1.0e30f)
+__host__ __device__ inline uint32_t bm_q_op(uint32_t op) { return op & 0xFFu; }
+__host__ __device__ inline uint32_t bm_q_nnot(uint32_t op) { return (op >> 8) & 0xFFu; }
 int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t* d_out_doc,
                     float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, bool has_or,
-                    uint32_t nt_max, hipStream_t st);
+                    uint32_t nt_max, uint32_t np_max, hipStream_t st);
 // ---- implemented in synth.hip
 int ssi_vec_synth(ss_shard* s, uint64_t seed, hipStream_t st);
 int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const uint8_t* d_lentab, hipStream_t st);

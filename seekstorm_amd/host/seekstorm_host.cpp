@@ -108,22 +108,27 @@ int Shard::synth_vectors(uint64_t seed, uint64_t n_rows, uint32_t dim) {
   return rc;
 }
 
-int Shard::make_query(const std::vector<uint32_t>& terms, QueryType qt, ss_bm25_query* out) {
+int Shard::make_query(const std::vector<uint32_t>& terms, QueryType qt, ss_bm25_query* out,
+                      const std::vector<uint32_t>& not_terms) {
   if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
-  std::vector<uint32_t> uniq;  // unique_terms in first-seen order (search.rs:3023)
+  std::vector<uint32_t> uniq, nots;  // unique_terms in first-seen order (search.rs:3023)
   for (uint32_t t : terms)
     if (std::find(uniq.begin(), uniq.end(), t) == uniq.end()) uniq.push_back(t);
-  if (uniq.empty() || uniq.size() > SS_MAX_QUERY_TERMS) return SS_EINVAL;
+  for (uint32_t t : not_terms)  // not_query_list: the "-term" operands (add_result.rs:3440-3497)
+    if (std::find(uniq.begin(), uniq.end(), t) == uniq.end() && std::find(nots.begin(), nots.end(), t) == nots.end())
+      nots.push_back(t);
+  if (uniq.empty() || uniq.size() + nots.size() > SS_MAX_QUERY_TERMS) return SS_EINVAL;
   uint64_t df[SS_MAX_QUERY_TERMS];
   const int rc = ss_bm25_term_df(h_, (uint32_t)uniq.size(), uniq.data(), df);
   if (rc != SS_OK) return rc;
   std::memset(out, 0, sizeof(*out));
   out->n_terms = (uint32_t)uniq.size();
-  out->op = (uint32_t)qt;
+  out->op = (uint32_t)qt | SS_OP_NOT_TERMS(nots.size());
   for (size_t i = 0; i < uniq.size(); i++) {
     out->term[i] = uniq[i];
     out->idf[i] = idf(n_docs_, df[i]);
   }
+  for (size_t i = 0; i < nots.size(); i++) out->term[uniq.size() + i] = nots[i];
   return SS_OK;
 }
 

@@ -90,7 +90,8 @@ class Shard {
   uint32_t dim() const { return dim_; }
 
   // term resolution result -> device query (idf from shard-local N and posting_count, search.rs:3225-3230)
-  int make_query(const std::vector<uint32_t>& terms, QueryType qt, ss_bm25_query* out);
+  int make_query(const std::vector<uint32_t>& terms, QueryType qt, ss_bm25_query* out,
+                 const std::vector<uint32_t>& not_terms = {});
 
   // the reference's per-shard seams (one query)
   ResultObject search_lexical_shard(const std::vector<uint32_t>& query_terms, QueryType query_type_default, size_t offset,

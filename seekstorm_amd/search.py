@@ -244,26 +244,32 @@ class Shard:
         return out
 
     # ---- query construction: term resolution + idf stay on the host (search.rs:3066-3358)
-    def make_queries(self, term_lists: Sequence[Sequence[int]], query_types):
+    def make_queries(self, term_lists: Sequence[Sequence[int]], query_types, not_lists=None):
+        """query_list (+ not_query_list: the "-term" operands, add_result.rs:3440-3497) of each query -> ss_bm25_query"""
         nq = len(term_lists)
+        if not_lists is None:
+            not_lists = [()] * nq
         if isinstance(query_types, (int, QueryType)):
             query_types = [query_types] * nq
         q = np.zeros(nq, N.BM25_QUERY_DTYPE)
-        flat = np.fromiter((t for tl in term_lists for t in tl), np.uint32)
+        flat = np.fromiter((t for tl in list(term_lists) + list(not_lists) for t in tl), np.uint32)
         uniq = np.unique(flat)
         missing = [int(t) for t in uniq if int(t) not in self._df_cache]
         if missing:
             for t, df in zip(missing, self.posting_count(missing)):
                 self._df_cache[t] = int(df)
-        for i, (tl, qt) in enumerate(zip(term_lists, query_types)):
+        for i, (tl, qt, nl) in enumerate(zip(term_lists, query_types, not_lists)):
             tl = list(dict.fromkeys(int(t) for t in tl))  # unique_terms, search.rs:3023
-            if not 1 <= len(tl) <= N.SS_MAX_QUERY_TERMS:
-                raise ValueError("1..10 unique terms per query")
+            nl = [t for t in dict.fromkeys(int(t) for t in nl) if t not in tl]
+            if not 1 <= len(tl) or len(tl) + len(nl) > N.SS_MAX_QUERY_TERMS:
+                raise ValueError("1..10 unique terms per query (NOT terms included)")
             q["n_terms"][i] = len(tl)
-            q["op"][i] = int(qt)
+            q["op"][i] = int(qt) | (len(nl) << 8)
             for j, t in enumerate(tl):
                 q["term"][i, j] = t
                 q["idf"][i, j] = idf_f32(self.indexed_doc_count, self._df_cache[t])
+            for j, t in enumerate(nl):
+                q["term"][i, len(tl) + j] = t
         return q
 
     # ---- batched executors (one C-ABI call per batch)
@@ -297,10 +303,10 @@ class Shard:
 
     # ---- the reference's per-shard seams (one query)
     def search_lexical_shard(self, query_terms, query_type_default=QueryType.Union, offset=0, length=10,
-                             result_type=ResultType.TopkCount, strict=False) -> ResultObject:
+                             result_type=ResultType.TopkCount, strict=False, not_terms=()) -> ResultObject:
         ro = ResultObject()
         try:
-            q = self.make_queries([query_terms], query_type_default)
+            q = self.make_queries([query_terms], query_type_default, [not_terms])
             doc, score, cnt, tot = self.search_lexical_batch(q, offset + length, result_type)
         except Exception:
             if strict:

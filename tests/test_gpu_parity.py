@@ -400,3 +400,64 @@ def test_deleted_docs_vector(S, O):
     for x, y in zip(base, sh.search_vector_batch(qs, 50)):
         assert np.array_equal(x, y)
     sh.close()
+
+
+def test_not_terms_both_strategies(S, O, lex):
+    """not_query_list (add_result.rs:3440-3497): docs of a NOT list neither count nor rank; every result type, both
+    strategies, NT-specialised and grouped kernels, together with tombstones."""
+    sh, osh, n_docs = lex
+    cases = [([10, 9], [8]), ([10, 9, 8], [7]), ([10], [9]), ([7, 6], [10, 2]), ([5], [10, 9, 8]),
+             ([10, 9, 8, 7], [6, 5]), ([4, 3, 2, 1, 0], [10]), ([10, 9, 8], [7, 6, 5, 4, 3, 2, 1])]
+    try:
+        for qt, oop in ((S.QueryType.Union, O.OP_OR), (S.QueryType.Intersection, O.OP_AND)):
+            for strat in (1, 2, 0):
+                cs = [c for c in cases if len(c[0]) <= 4] if strat == 2 else cases
+                sh.set_strategy(strat)
+                q = sh.make_queries([c[0] for c in cs], qt, [c[1] for c in cs])
+                assert all(int(o) >> 8 == len(c[1]) for o, c in zip(q["op"], cs))
+                for rt in (S.ResultType.TopkCount, S.ResultType.Topk, S.ResultType.Count):
+                    if strat == 2 and rt != S.ResultType.Topk and qt == S.QueryType.Union:
+                        continue
+                    doc, score, cnt, tot = sh.search_lexical_batch(q, 10, rt)
+                    for i, (pos, neg) in enumerate(cs):
+                        od, os_, otot = osh.search_exhaustive(pos, oop, 10, not_terms=neg)
+                        if rt != S.ResultType.Topk:
+                            assert int(tot[i]) == otot, (pos, neg, qt, strat, rt)
+                        if rt != S.ResultType.Count:
+                            _check_topk(doc[i], score[i], cnt[i], od, os_)
+        # NOT terms + tombstones + a mixed batch (with and without NOT terms)
+        sh.set_strategy(0)
+        gone = list(range(0, n_docs, 97))
+        sh.set_deleted(gone)
+        osh.set_deleted(gone)
+        mixed = [([10, 9, 8], []), ([10, 9, 8], [7]), ([6], [5]), ([9, 3], [])]
+        for qt, oop in ((S.QueryType.Union, O.OP_OR), (S.QueryType.Intersection, O.OP_AND)):
+            q = sh.make_queries([c[0] for c in mixed], qt, [c[1] for c in mixed])
+            doc, score, cnt, tot = sh.search_lexical_batch(q, 10)
+            for i, (pos, neg) in enumerate(mixed):
+                od, os_, otot = osh.search_exhaustive(pos, oop, 10, not_terms=neg)
+                assert int(tot[i]) == otot
+                _check_topk(doc[i], score[i], cnt[i], od, os_)
+                od2, os2, otot2 = osh.search(pos, oop, 10, O.RT_TOPKCOUNT, not_terms=neg)  # reference-structured oracle
+                assert otot2 == otot and np.allclose(os2, os_, rtol=REL)
+    finally:
+        sh.set_strategy(0)
+        sh.set_deleted([])
+        osh.set_deleted([])
+
+
+def test_not_terms_abi_validation(S, O, lex):
+    sh, osh, n_docs = lex
+    q = sh.make_queries([[10, 9]], S.QueryType.Union, [[8]])
+    bad = q.copy()
+    bad["op"][0] = int(S.QueryType.Union) | (9 << 8)  # 2 + 9 > 10 terms
+    with pytest.raises(S.SeekStormHipError):
+        sh.search_lexical_batch(bad, 10)
+    bad = q.copy()
+    bad["term"][0, 2] = 10  # NOT term repeats a query term
+    with pytest.raises(S.SeekStormHipError):
+        sh.search_lexical_batch(bad, 10)
+    bad = q.copy()
+    bad["op"][0] = int(S.QueryType.Union) | (1 << 16)
+    with pytest.raises(S.SeekStormHipError):
+        sh.search_lexical_batch(bad, 10)

@@ -234,3 +234,24 @@ def test_deleted_docs_neither_count_nor_rank():
     d1, s1, tot1, obs1 = O.vec_search(rows, qv, 20, deleted=[int(d0[0]), int(d0[5])])
     assert obs1 == obs0 == 3000 and int(d0[0]) not in d1 and int(d0[5]) not in d1
     assert [int(x) for x in d1[:4]] == [int(x) for x in d0[1:5]]
+
+
+def test_not_terms_exclude_docs():
+    # not_query_list (add_result.rs:3440-3497; union.rs:483-530): set difference, applied before counting
+    n_docs = 150_000
+    terms = [4095, 4000, 3000, 3500]
+    dl, offs, docs, tfs = _corpus(n_docs, terms)
+    sh = O.Shard(n_docs, dl, offs, docs, tfs)
+    lists = [set(map(int, docs[int(offs[i]):int(offs[i + 1])])) for i in range(4)]
+    for op, pos, neg in ((O.OP_OR, [0, 1], [2]), (O.OP_AND, [0, 1], [3]), (O.OP_OR, [1], [0, 2]), (O.OP_AND, [0, 2], [1, 3])):
+        base = set.intersection(*[lists[i] for i in pos]) if op == O.OP_AND else set.union(*[lists[i] for i in pos])
+        want = base - set.union(*[lists[i] for i in neg])
+        d1, s1, t1 = sh.search(pos, op, 10, O.RT_TOPKCOUNT, not_terms=neg)
+        d2, s2, t2 = sh.search_exhaustive(pos, op, 10, not_terms=neg)
+        assert t1 == t2 == len(want)
+        assert set(map(int, d1)) <= want and set(map(int, d2)) <= want
+        assert np.allclose(s1, s2, rtol=1e-4)
+        # scores of the survivors are those of the query without NOT terms
+        dall, sall, _ = sh.search_exhaustive(pos, op, 2000)
+        keep = [(int(d), float(s)) for d, s in zip(dall, sall) if int(d) in want][:10]
+        assert [d for d, _ in keep] == [int(d) for d in d2][:len(keep)]
