@@ -150,7 +150,8 @@ def main():
                 g = D.all_gather_topk(o_doc[:n], o_score[:n], o_cnt[:n])
                 merged["bm25"] = D.merge_gathered_device(*g, sptr, local_rank)
 
-        # exact union sizes for the roofline's "1 B per scored candidate" term: one untimed TopkCount pass
+        # exact union sizes for the roofline's "1 B per scored candidate" term: one untimed TopkCount pass (exhaustive scan)
+        sh.set_strategy(N.BM25_EXHAUSTIVE)
         N.check(L.ss_bm25_search_dev(sh._h, nq, q_dev.data_ptr(), k, N.RT_TOPKCOUNT, 2 | (3 << 8), o_doc.data_ptr(),
                                      o_score.data_ptr(), o_cnt.data_ptr(), o_tot.data_ptr(), sptr), "ss_bm25_search_dev")
         torch.cuda.synchronize()
@@ -182,6 +183,22 @@ def main():
         # (2) the default strategy (AUTO): top-k unions take the pruned path (MaxScore over the probe index)
         qps, ms_step, avg_ms, launches = measure(N.BM25_AUTO, args.steps, args.warmup)
         dt = nq * args.steps / qps
+
+        # (3) ResultType::TopkCount, the reference server's default: pruned top-k + exact union counts (popcounts over the
+        # probe index's bit records) under AUTO, against the exhaustive scan that used to serve it
+        def tc_step():
+            N.check(L.ss_bm25_search_dev(sh._h, nq, q_dev.data_ptr(), k, N.RT_TOPKCOUNT, 2 | (3 << 8), o_doc.data_ptr(),
+                                         o_score.data_ptr(), o_cnt.data_ptr(), o_tot.data_ptr(), sptr), "ss_bm25_search_dev")
+        tc = {}
+        for name, strat in (("exhaustive", N.BM25_EXHAUSTIVE), ("auto", N.BM25_AUTO)):
+            sh.set_strategy(strat)
+            tc_step()
+            torch.cuda.synchronize()
+            assert np.array_equal(tot, o_tot.cpu().numpy().astype(np.int64)), "TopkCount totals differ between strategies"
+            assert np.array_equal(ref_scores, o_score.cpu().numpy())
+            d_ = timed(tc_step, max(4, args.steps // 2), min(args.warmup, 2))
+            tc[name] = {"value": nq * max(4, args.steps // 2) / d_, "unit": "queries/s", "ms_per_step": d_ / max(4, args.steps // 2) * 1e3}
+        sh.set_strategy(N.BM25_AUTO)
         ach = bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         ex_ach = bytes_launch / (ex_kms * 1e-3) / 1e9 if ex_kms > 0 else 0.0
         lat_batch = latencies(bm_step, 12)
@@ -199,6 +216,8 @@ def main():
                                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ex_ach / HBM_PEAK_GBS,
                                            "traffic": pmc_traffic("bm25"), "algorithmic_bytes_per_launch": bytes_launch,
                                            "avg_launch_ms": ex_kms, "launches": ex_n}},
+                  topk_count=dict(tc, note="same batch with ResultType::TopkCount (exact result_count_total, the reference server's "
+                                           "default): AUTO = pruned top-k + union counts from the probe index's bit records"),
                   latency_ms={"batch_p50": pct(lat_batch, 50), "batch_p99": pct(lat_batch, 99),
                               "single_query_p50": pct(lat_one, 50), "single_query_p99": pct(lat_one, 99)},
                   mean_bytes_per_query=float(bytes_q.mean()), mean_union=float(tot.mean()))
@@ -329,6 +348,7 @@ def main():
         }
         if is_bm:
             line["exhaustive"] = bm["exhaustive"]
+            line["topk_count"] = bm["topk_count"]
             line["bm25"] = {"build_s": bm["build_s"], "postings": int(bm["info"]["n_postings"]), "avgdl": bm["info"]["avgdl"],
                             "mean_algorithmic_bytes_per_query": bm["mean_bytes_per_query"], "mean_union_size": bm["mean_union"]}
         if vec is not None and is_bm:

@@ -114,11 +114,12 @@ int ss_bm25_upload_index_bin(ss_shard* s, const ss_index_bin* ix);
 int ss_bm25_synth(ss_shard* s, uint64_t seed, uint64_t n_docs, uint32_t n_terms, const uint32_t* thresh32,
                   const uint8_t* len_table1024);
 int ss_bm25_info(ss_shard* s, uint64_t* n_docs, float* avgdl, uint32_t* n_terms, uint64_t* n_postings);
-/* Search strategy.  AUTO: top-k of unions without exact counts (SS_RT_TOPK) and all intersections take the PRUNED path
- * (the reference's block-max / sub-query pruning, intersection.rs:2224-2233, union.rs:1355-1405, as MaxScore over a
- * probe index: only essential / shortest lists are read); everything else, and every request when the probe index
- * did not fit in device memory, takes the EXHAUSTIVE scan.  Both return identical results.  SS_BM25_PRUNED fails with
- * SS_ENOTSUP where pruning cannot serve the request (exact union counts, > 4 terms, k > 128). */
+/* Search strategy.  AUTO: requests with <= 4 scored terms and k <= 128 take the PRUNED path (the reference's block-max /
+ * sub-query pruning, intersection.rs:2224-2233, union.rs:1355-1405, as MaxScore over a probe index: only essential /
+ * shortest lists are read; exact union counts are popcounts over the index's bit records like union_count,
+ * union.rs:807-); everything else, and every request when the probe index did not fit in device memory, takes the
+ * EXHAUSTIVE scan.  Both return identical results.  SS_BM25_PRUNED fails with SS_ENOTSUP where pruning cannot serve
+ * the request (> 4 scored terms, k > 128, no probe index). */
 enum { SS_BM25_AUTO = 0, SS_BM25_EXHAUSTIVE = 1, SS_BM25_PRUNED = 2 };
 int ss_bm25_set_strategy(ss_shard* s, int strategy);
 /* posting_count per term (the df the host needs for idf, search.rs:3225-3230) */

@@ -79,10 +79,11 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   const uint32_t kk = k ? k : 1;
   const int KPL = kk <= 64 ? 1 : kk <= 128 ? 2 : kk <= 256 ? 4 : 16;
   const uint32_t KS = 64 * KPL;
-  // Strategy.  Pruned (probe index, bm25_probe.hip): top-k of unions without exact counts, and intersections with any
-  // result type -- it reads only the essential / shortest lists.  Exhaustive (bm25_fast.hip): everything else (exact
-  // union counts need every posting), and whenever the probe index is absent or SS_BM25_EXHAUSTIVE is selected.
-  const bool pruned = s->bm_strategy != SS_BM25_EXHAUSTIVE && (!has_or || rt == SS_RT_TOPK) && s->d_probe && s->d_umax &&
+  // Strategy.  Pruned (probe index, bm25_probe.hip): the top-k reads only the essential / shortest lists; exact counts
+  // of intersections fall out of it, exact counts of unions are popcounts over the index's bit records
+  // (bm25_union_count_kernel).  Exhaustive (bm25_fast.hip): > 4 scored terms, k > 128, no probe index, or
+  // SS_BM25_EXHAUSTIVE selected.
+  const bool pruned = s->bm_strategy != SS_BM25_EXHAUSTIVE && s->d_probe && s->d_umax &&
                       np_max >= 1 && np_max <= 4 && KPL <= 2;  // NOT terms are probed outside the template
   if (!pruned && s->bm_strategy == SS_BM25_PRUNED) return SS_ENOTSUP;
   // Partitions per query (one wave each).  The grid is a whole number of "rounds" of resident waves: a partially
@@ -133,6 +134,12 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
                         : ssi_bm25_launch_scan(p, nt_max, has_and, KPL, st);
   ssi_prof_end(s, 0, st, e0, e1);
   if (rc) return rc;
+  // exact counts of the unions (Count / TopkCount): popcounts over the bit records; intersections and single terms were
+  // counted by the probe kernel
+  if (pruned && has_or && rt != SS_RT_TOPK) {
+    const int rcc = ssi_bm25_launch_union_count(p, s->d_probe, st);
+    if (rcc) return rcc;
+  }
 
   // merge tree over the P partition lists
   SS_SET_MAX_LDS(bm25_merge_kernel, 8192 * 8);

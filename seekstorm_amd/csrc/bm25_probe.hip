@@ -364,8 +364,9 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
   };
   // drivers: unions -> every term in upper-bound order (a stream ends as soon as its term is non-essential);
   // intersections -> the shortest list only
-  stream(std::integral_constant<int, 0>{});
-  if (!is_and) {
+  // (a union whose top-k is not wanted has nothing to do here: its count comes from bm25_union_count_kernel)
+  if (k || is_and || nt == 1) stream(std::integral_constant<int, 0>{});
+  if (!is_and && k) {
     if (NT > 1 && nt > 1) stream(std::integral_constant<int, (NT > 1 ? 1 : 0)>{});
     if (NT > 2 && nt > 2) stream(std::integral_constant<int, (NT > 2 ? 2 : 0)>{});
     if (NT > 3 && nt > 3) stream(std::integral_constant<int, (NT > 3 ? 3 : 0)>{});
@@ -383,6 +384,75 @@ static int launch_probe(const BmParams& p, const uint2* probe, const uint32_t* p
   bm25_probe_kernel<NT, KPL, FILT><<<(A + PB_WAVES - 1) / PB_WAVES, PB_WAVES * 64, BM_LUT_BYTES + PB_WAVES * PB_QCAP * 12, st>>>(
       p.post, p.term_base, p.sub_off, p.comp, probe, probe_z, umax, p.q, p.part_keys, p.total, p.tau, p.exc_off, p.exc_doc, p.exc_tf, p.del, p.del_words, p.n_sub, p.n_terms, p.nq, p.P, p.k,
       p.count);
+  return SS_OK;
+}
+
+// Exact match counts of unions from the probe index's bit records: |A u B u ...| = sum over 64-doc groups of
+// popcount(bits_A | bits_B | ...), minus NOT lists and tombstones -- the reference's own way of counting a union
+// (union_count over bitmaps, union.rs:807-; deleted docs cleared, union.rs:975).  One coalesced 8-byte load per term
+// and group, no scoring: with it a TopkCount union is the pruned top-k plus this count instead of an exhaustive scan.
+// One wave per (query, partition of the group range); queries that are not unions of > 1 terms are left to the probe
+// kernel, which counts intersections and single terms while it ranks them.
+constexpr int CNT_WAVES = 4, CNT_UNROLL = 4;
+__global__ void __launch_bounds__(CNT_WAVES * 64) bm25_union_count_kernel(
+    const uint2* __restrict__ probe, const ss_bm25_query* __restrict__ qs, unsigned long long* __restrict__ total,
+    const uint32_t* __restrict__ del, uint32_t del_words, uint32_t n_sub, uint32_t nq, uint32_t P) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t a = blockIdx.x * CNT_WAVES + (threadIdx.x >> 6);
+  if (a >= nq * P) return;
+  const uint32_t qi = a % nq, part = a / nq;
+  const ss_bm25_query* __restrict__ Q = qs + qi;
+  const uint32_t np = Q->n_terms, n_not = bm_q_nnot(Q->op);
+  if (bm_q_op(Q->op) != SS_OP_UNION || np < 2) return;
+  const uint32_t n_groups = n_sub * (BM_SUB / 64);
+  const uint32_t g_begin = (uint32_t)(((u64)n_groups * part) / P), g_end = (uint32_t)(((u64)n_groups * (part + 1)) / P);
+  const uint2* rows[SS_MAX_QUERY_TERMS];
+#pragma unroll
+  for (int t = 0; t < SS_MAX_QUERY_TERMS; t++)
+    rows[t] = probe + (size_t)Q->term[(uint32_t)t < np + n_not ? t : 0] * n_groups;
+  uint32_t cnt = 0;
+  for (uint32_t g0 = g_begin; g0 < g_end; g0 += 64u * CNT_UNROLL) {
+    u64 acc[CNT_UNROLL], neg[CNT_UNROLL];
+#pragma unroll
+    for (int u = 0; u < CNT_UNROLL; u++) { acc[u] = 0ull; neg[u] = 0ull; }
+#pragma unroll
+    for (int t = 0; t < SS_MAX_QUERY_TERMS; t++) {
+      if ((uint32_t)t >= np + n_not) break;
+#pragma unroll
+      for (int u = 0; u < CNT_UNROLL; u++) {
+        const uint32_t g = g0 + 64u * u + lane;
+        uint2 r = make_uint2(0u, 0u);
+        if (g < g_end) r = rows[t][g];
+        const u64 b = ((u64)r.y << 32) | r.x;
+        if ((uint32_t)t < np) acc[u] |= b; else neg[u] |= b;
+      }
+    }
+    if (del) {
+#pragma unroll
+      for (int u = 0; u < CNT_UNROLL; u++) {
+        const uint32_t g = g0 + 64u * u + lane;  // group g = bitmap words 2g, 2g + 1
+        if (g < g_end && 2u * g + 1u < del_words) {
+          const uint2 r = ((const uint2*)del)[g];
+          neg[u] |= ((u64)r.y << 32) | r.x;
+        } else if (g < g_end && 2u * g < del_words) {
+          neg[u] |= (u64)del[2u * g];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < CNT_UNROLL; u++) cnt += (uint32_t)__popcll(acc[u] & ~neg[u]);
+  }
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  if (lane == 0 && cnt) atomicAdd(&total[qi], (unsigned long long)cnt);
+}
+
+int ssi_bm25_launch_union_count(const BmParams& p, const uint2* probe, hipStream_t st) {
+  // one partition per ~4096 groups and at least enough waves for two rounds of a full chip
+  const uint32_t n_groups = p.n_sub * (BM_SUB / 64);
+  uint32_t P = std::max<uint32_t>(1u, std::min<uint32_t>((2u * 8192u + p.nq - 1) / p.nq, (n_groups + 1023u) / 1024u));
+  const uint32_t A = p.nq * P;
+  bm25_union_count_kernel<<<(A + CNT_WAVES - 1) / CNT_WAVES, CNT_WAVES * 64, 0, st>>>(probe, p.q, p.total, p.del, p.del_words,
+                                                                                     p.n_sub, p.nq, P);
   return SS_OK;
 }
 

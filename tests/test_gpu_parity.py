@@ -359,8 +359,6 @@ def test_deleted_docs_lexical_both_strategies(S, O, lex):
                 tl = tl_all[:4] if strat == 2 else tl_all  # the pruned kernel serves <= 4 terms
                 q = sh.make_queries(tl, qt)
                 for rt in (S.ResultType.TopkCount, S.ResultType.Topk, S.ResultType.Count):
-                    if strat == 2 and rt != S.ResultType.Topk and qt == S.QueryType.Union:
-                        continue  # exact union counts are outside the pruned strategy (ENOTSUP by design)
                     doc, score, cnt, tot = sh.search_lexical_batch(q, 10, rt)
                     for i, terms in enumerate(tl):
                         od, os_, otot = osh.search_exhaustive(terms, oop, 10)
@@ -416,8 +414,6 @@ def test_not_terms_both_strategies(S, O, lex):
                 q = sh.make_queries([c[0] for c in cs], qt, [c[1] for c in cs])
                 assert all(int(o) >> 8 == len(c[1]) for o, c in zip(q["op"], cs))
                 for rt in (S.ResultType.TopkCount, S.ResultType.Topk, S.ResultType.Count):
-                    if strat == 2 and rt != S.ResultType.Topk and qt == S.QueryType.Union:
-                        continue
                     doc, score, cnt, tot = sh.search_lexical_batch(q, 10, rt)
                     for i, (pos, neg) in enumerate(cs):
                         od, os_, otot = osh.search_exhaustive(pos, oop, 10, not_terms=neg)

@@ -97,13 +97,19 @@ def test_pruned_equals_exhaustive_and_oracle(S, O, tie_heavy, big_tf):
                 for i in (1, 30, len(term_lists) - 2):
                     _, _, otot = osh.search_exhaustive(term_lists[i], op, 10)
                     assert int(pt[i]) == otot
-    # exact union counts cannot be pruned: the explicit PRUNED strategy refuses, AUTO falls back to the scan
-    q = sh.make_queries(term_lists[:4], S.QueryType.Union)
-    with pytest.raises(S.SeekStormHipError):
-        _run(S, sh, q, 10, S.ResultType.TopkCount, N.BM25_PRUNED)
-    ad, as_, ac, at = _run(S, sh, q, 10, S.ResultType.TopkCount, N.BM25_AUTO)
+    # exact union counts: popcounts over the probe index's bit records (union_count, union.rs:807-) beside the pruned top-k
+    q = sh.make_queries(term_lists, S.QueryType.Union)
+    for rt in (S.ResultType.TopkCount, S.ResultType.Count):
+        pd, ps, pc, pt = _run(S, sh, q, 10, rt, N.BM25_PRUNED)
+        ed, es, ec, et = _run(S, sh, q, 10, rt, N.BM25_EXHAUSTIVE)
+        assert np.array_equal(pt, et) and np.array_equal(pc, ec) and np.array_equal(ps, es) and np.array_equal(pd, ed)
     for i in range(4):
-        assert int(at[i]) == osh.search_exhaustive(term_lists[i], O.OP_OR, 10)[2]
+        assert int(pt[i]) == osh.search_exhaustive(term_lists[i], O.OP_OR, 10)[2]
+    # more than 4 scored terms: the explicit PRUNED strategy refuses, AUTO falls back to the scan
+    q5 = sh.make_queries([[0, 1, 2, 3, 4]], S.QueryType.Union)
+    with pytest.raises(S.SeekStormHipError):
+        _run(S, sh, q5, 10, S.ResultType.Topk, N.BM25_PRUNED)
+    _run(S, sh, q5, 10, S.ResultType.Topk, N.BM25_AUTO)
     sh.close()
 
 
