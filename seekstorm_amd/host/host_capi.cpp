@@ -100,4 +100,33 @@ int ssh_coalesced_vector_search(ssh_index* ix, int shard, uint32_t n, const floa
   return (int)co.batches_submitted();
 }
 
+// n concurrent single-query lexical searches through a LexicalBatchCoalescer; query i = terms[term_off[i] .. term_off[i+1])
+// followed by its NOT terms not_terms[not_off[i] .. not_off[i+1]); out arrays are [n][length]
+int ssh_coalesced_lexical_search(ssh_index* ix, int shard, uint32_t n, const uint32_t* terms, const uint32_t* term_off,
+                                 const uint32_t* not_terms, const uint32_t* not_off, uint32_t query_type, uint32_t offset,
+                                 uint32_t length, uint32_t result_type, uint32_t max_batch, uint32_t max_wait_us,
+                                 uint64_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total) {
+  LexicalBatchCoalescer co(ix->shards[shard], max_batch, max_wait_us);
+  std::vector<std::future<ResultObject>> fut(n);
+  std::vector<std::thread> th;
+  for (uint32_t i = 0; i < n; i++)
+    th.emplace_back([&, i] {
+      std::vector<uint32_t> t(terms + term_off[i], terms + term_off[i + 1]);
+      std::vector<uint32_t> nt;
+      if (not_terms) nt.assign(not_terms + not_off[i], not_terms + not_off[i + 1]);
+      fut[i] = co.submit(t, (QueryType)query_type, offset + (i % 3), length, (ResultType)result_type, nt);  // mixed offsets
+    });
+  for (auto& t : th) t.join();
+  for (uint32_t i = 0; i < n; i++) {
+    ResultObject ro = fut[i].get();
+    out_count[i] = (uint32_t)ro.results.size();
+    out_total[i] = ro.result_count_total;
+    for (size_t j = 0; j < ro.results.size() && j < length; j++) {
+      out_doc[(size_t)i * length + j] = ro.results[j].doc_id;
+      out_score[(size_t)i * length + j] = ro.results[j].score;
+    }
+  }
+  return (int)co.batches_submitted();
+}
+
 }  // extern "C"

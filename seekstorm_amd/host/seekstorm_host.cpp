@@ -367,4 +367,81 @@ void VectorBatchCoalescer::run() {
   }
 }
 
+// ------------------------------------------------------------------ LexicalBatchCoalescer
+LexicalBatchCoalescer::LexicalBatchCoalescer(std::shared_ptr<Shard> shard, size_t max_batch, unsigned max_wait_us)
+    : shard_(std::move(shard)), max_batch_(std::max<size_t>(1, max_batch)), max_wait_us_(max_wait_us) {
+  worker_ = std::thread([this] { run(); });
+}
+
+LexicalBatchCoalescer::~LexicalBatchCoalescer() {
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    stop_ = true;
+  }
+  cv_.notify_all();
+  worker_.join();
+}
+
+std::future<ResultObject> LexicalBatchCoalescer::submit(const std::vector<uint32_t>& query_terms, QueryType query_type_default,
+                                                        size_t offset, size_t length, ResultType result_type,
+                                                        const std::vector<uint32_t>& not_terms) {
+  auto r = std::make_unique<Req>();
+  r->rc = shard_->make_query(query_terms, query_type_default, &r->q, not_terms);  // idf on the caller's thread
+  r->offset = offset;
+  r->length = length;
+  r->rt = result_type;
+  std::future<ResultObject> f = r->done.get_future();
+  if (r->rc != SS_OK) {  // the reference degrades to an empty result (search.rs:2461-2463)
+    ResultObject ro;
+    ro.last_error = r->rc;
+    r->done.set_value(std::move(ro));
+    return f;
+  }
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    queue_.push_back(std::move(r));
+  }
+  cv_.notify_all();
+  return f;
+}
+
+void LexicalBatchCoalescer::run() {
+  for (;;) {
+    std::vector<std::unique_ptr<Req>> batch;
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_.wait(lk, [this] { return stop_ || !queue_.empty(); });
+      if (queue_.empty()) {
+        if (stop_) return;
+        continue;
+      }
+      const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(max_wait_us_);
+      cv_.wait_until(lk, deadline, [this] { return stop_ || queue_.size() >= max_batch_; });
+      size_t n = 1;
+      while (n < queue_.size() && n < max_batch_ && queue_[n]->rt == queue_[0]->rt) n++;
+      for (size_t i = 0; i < n; i++) batch.push_back(std::move(queue_[i]));
+      queue_.erase(queue_.begin(), queue_.begin() + n);
+      batches_++;
+      queries_ += n;
+    }
+    size_t k = 1;
+    std::vector<ss_bm25_query> qs;
+    qs.reserve(batch.size());
+    for (auto& r : batch) {
+      k = std::max(k, r->offset + r->length);
+      qs.push_back(r->q);
+    }
+    std::vector<ResultObject> res = shard_->search_lexical_batch(qs, k, batch[0]->rt);
+    for (size_t i = 0; i < batch.size(); i++) {
+      ResultObject& ro = res[i];
+      const size_t want = batch[i]->offset + batch[i]->length;
+      if (ro.results.size() > want) ro.results.resize(want);
+      if (batch[i]->offset)  // drain offset (search.rs:3585-3593)
+        ro.results.erase(ro.results.begin(), ro.results.begin() + std::min(batch[i]->offset, ro.results.size()));
+      ro.result_count = ro.results.size();
+      batch[i]->done.set_value(std::move(ro));
+    }
+  }
+}
+
 }  // namespace seekstorm

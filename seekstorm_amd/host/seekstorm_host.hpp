@@ -165,4 +165,37 @@ class VectorBatchCoalescer {
   std::thread worker_;
 };
 
+// The same for the lexical seam: concurrent single-query search_lexical_shard calls (the reference's callers hold only
+// the shard read lock and arrive from many runtime threads) become one ss_bm25_search batch.  A batch
+// runs at the largest offset + length of its members and each answer is its own prefix of that list (the top-k order
+// is total: score desc, doc id asc); requests with a different ResultType start a new batch.
+class LexicalBatchCoalescer {
+ public:
+  LexicalBatchCoalescer(std::shared_ptr<Shard> shard, size_t max_batch = 1024, unsigned max_wait_us = 100);
+  ~LexicalBatchCoalescer();
+  std::future<ResultObject> submit(const std::vector<uint32_t>& query_terms, QueryType query_type_default, size_t offset,
+                                   size_t length, ResultType result_type, const std::vector<uint32_t>& not_terms = {});
+  uint64_t batches_submitted() const { return batches_; }
+  uint64_t queries_submitted() const { return queries_; }
+
+ private:
+  struct Req {
+    ss_bm25_query q;
+    int rc;
+    size_t offset, length;
+    ResultType rt;
+    std::promise<ResultObject> done;
+  };
+  void run();
+  std::shared_ptr<Shard> shard_;
+  size_t max_batch_;
+  unsigned max_wait_us_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::vector<std::unique_ptr<Req>> queue_;
+  bool stop_ = false;
+  uint64_t batches_ = 0, queries_ = 0;
+  std::thread worker_;
+};
+
 }  // namespace seekstorm

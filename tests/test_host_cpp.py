@@ -47,6 +47,8 @@ def H():
                                            C.c_uint32, C.c_uint32, u64p, f32p, u64p]
     L.ssh_coalesced_vector_search.argtypes = [C.c_void_p, C.c_int, C.c_uint32, f32p, C.c_uint32, C.c_uint32, C.c_uint32,
                                               u64p, f32p, u32p]
+    L.ssh_coalesced_lexical_search.argtypes = [C.c_void_p, C.c_int, C.c_uint32, u32p, u32p, u32p, u32p, C.c_uint32, C.c_uint32,
+                                               C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u64p, f32p, u32p, u64p]
     return L
 
 
@@ -174,5 +176,41 @@ def test_cpp_coalescer_batches_concurrent_queries(H):
             od, os_, _, _ = O.vec_search(rows, qs[i], k)
             assert cnt[i] == k and np.allclose(sc[i], os_, rtol=REL, atol=2e-6)
             assert set(map(int, doc[i][:5])) <= set(map(int, od))
+    finally:
+        H.ssh_index_destroy(ix)
+
+
+@pytest.mark.gpu
+def test_cpp_lexical_coalescer_batches_concurrent_queries(H):
+    """concurrent single-query search_lexical_shard callers (no batched search API in the reference) share
+    device batches; mixed offsets, NOT terms, every answer equal to its own single search"""
+    from oracle import oracle as O
+    n_docs, voc = 120_000, [3000, 3400, 3700, 3900, 4050]
+    dl = O.lex_doclen(n_docs)
+    offs, docs, tfs = O.lex_corpus(n_docs, voc)
+    osh = O.Shard(n_docs, dl, offs, docs, tfs)
+    ix = H.ssh_index_create(1, None)
+    try:
+        assert H.ssh_upload_lexical(ix, 0, n_docs, P(dl, u8p), len(voc), P(offs, u64p), P(docs, u32p), P(tfs, u16p)) == 0
+        rng = np.random.default_rng(4)
+        nq, length = 48, 10
+        tl = [[int(x) for x in rng.choice(5, int(rng.integers(1, 4)), replace=False)] for _ in range(nq)]
+        nl = [[t for t in range(5) if t not in q][:int(rng.integers(0, 2))] for q in tl]
+        terms = np.array([t for q in tl for t in q], np.uint32)
+        toff = np.zeros(nq + 1, np.uint32); toff[1:] = np.cumsum([len(q) for q in tl])
+        nots = np.array([t for q in nl for t in q] + [0], np.uint32)
+        noff = np.zeros(nq + 1, np.uint32); noff[1:] = np.cumsum([len(q) for q in nl])
+        for qt, oop in ((1, O.OP_OR), (0, O.OP_AND)):
+            doc = np.zeros((nq, length), np.uint64); sc = np.zeros((nq, length), np.float32)
+            cnt = np.zeros(nq, np.uint32); tot = np.zeros(nq, np.uint64)
+            batches = H.ssh_coalesced_lexical_search(ix, 0, nq, P(terms, u32p), P(toff, u32p), P(nots, u32p), P(noff, u32p), qt, 0,
+                                                     length, 2, 1024, 20000, P(doc, u64p), P(sc, f32p), P(cnt, u32p), P(tot, u64p))
+            assert 1 <= batches < nq
+            for i in range(nq):
+                off = i % 3  # the shim gives query i the offset i % 3
+                od, os_, otot = osh.search_exhaustive(tl[i], oop, off + length, not_terms=nl[i])
+                assert int(tot[i]) == otot
+                assert cnt[i] == max(0, min(length, len(od) - off))
+                assert np.allclose(sc[i][:cnt[i]], os_[off:off + cnt[i]], rtol=REL)
     finally:
         H.ssh_index_destroy(ix)
