@@ -176,6 +176,23 @@ int ss_vec_search_dev(ss_shard* s, uint32_t n_queries, const float* d_queries, u
                       uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total,
                       void* stream);
 
+/* ---- i8 (quantised) vectors: the reference's Precision::I8 embeddings (quantize_f32_to_i8 = round(v * 127) clamped to
+ * +-127, vector_similarity.rs:1226-1232; or a per-record scale with ScalarQuantizationI8).  Score of a record =
+ * dot_i8 as f32 (vector_similarity.rs:1011-1016; Cosine, and Dot without quantisation scales), or with scales
+ * dot_i8_quantized = dot as f32 * query_scale * embedding_scale (1754-1758).  The integer dot product is exact, so
+ * scores are bit-identical to the reference's.  A shard holds ONE vector image: uploading i8 rows replaces f32 rows and
+ * vice versa.  row_scale / query_scale may be NULL (= no scaling).  dim <= 2560.  Semantics of k, threshold_raw,
+ * row_doc_ids, outputs and tombstones as for the f32 functions. */
+int ss_vec_upload_i8(ss_shard* s, uint64_t n_rows, uint32_t dim, const int8_t* rows, const float* row_scale,
+                     const uint32_t* row_doc_ids);
+int ss_vec_synth_i8(ss_shard* s, uint64_t seed, uint64_t n_rows, uint32_t dim); /* ss_vec_synth rows, quantised on the device */
+int ss_vec_read_rows_i8(ss_shard* s, uint64_t first_row, uint64_t n, int8_t* out);
+int ss_vec_search_i8(ss_shard* s, uint32_t n_queries, const int8_t* queries, const float* query_scale, uint32_t k,
+                     float threshold_raw, uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total);
+int ss_vec_search_i8_dev(ss_shard* s, uint32_t n_queries, const int8_t* d_queries, const float* d_query_scale, uint32_t k,
+                         float threshold_raw, uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count,
+                         uint64_t* d_out_total, void* stream);
+
 /* ------------------------------------------------------------------ cross-shard merge + RRF (host side)
  * Inputs are the concatenation over shards of per-shard top-(offset+length) lists with GLOBAL ids
  * (global = local*S + shard, search.rs:1671).  Hybrid = RRF k=0.6, 0-based ranks (search.rs:1962-2035).

@@ -89,6 +89,10 @@ def lib():
     L.so_vec_search_del.restype = C.c_uint32
     L.so_vec_search_del.argtypes = [f32p, C.c_uint64, C.c_uint32, u32p, f32p, C.c_uint32, C.c_float, C.c_int, u64p,
                                     C.c_uint64, u32p, f32p, u64p, u64p]
+    L.so_quantize_f32_to_i8.argtypes = [f32p, C.c_uint32, C.c_void_p]
+    L.so_vec_search_i8.restype = C.c_uint32
+    L.so_vec_search_i8.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, u32p, f32p, C.c_void_p, C.c_int, C.c_float, C.c_uint32,
+                                   C.c_float, u64p, C.c_uint64, u32p, f32p, u64p, u64p]
     L.so_shard_set_deleted.argtypes = [C.c_void_p, u64p, C.c_uint64]
     L.so_vector_score_field.restype = C.c_float
     L.so_vector_score_field.argtypes = [C.c_float]
@@ -242,6 +246,30 @@ def vec_search(rows, query, k, row_doc_ids=None, threshold_raw=-3.40282346638528
     n = lib().so_vec_search_del(_p(rows, f32p), rows.shape[0], rows.shape[1], _p(rd, u32p), _p(query, f32p), k,
                                 threshold_raw, 1 if simd_order else 0, _p(dl, u64p) if len(dl) else None, len(dl),
                                 _p(od, u32p), _p(os_, f32p), C.byref(tot), C.byref(obs))
+    return od[:n].copy(), os_[:n].copy(), tot.value, obs.value
+
+
+def quantize_i8(v):
+    v = np.ascontiguousarray(v, np.float32)
+    out = np.empty(v.shape, np.int8)
+    lib().so_quantize_f32_to_i8(_p(v.reshape(-1), f32p), v.size, out.ctypes.data)
+    return out
+
+
+def vec_search_i8(rows_i8, query_i8, k, row_doc_ids=None, row_scale=None, query_scale=None, threshold_raw=-3.4028234663852886e38,
+                  deleted=None):
+    rows = np.ascontiguousarray(rows_i8, np.int8)
+    q = np.ascontiguousarray(query_i8, np.int8)
+    rd = None if row_doc_ids is None else np.ascontiguousarray(row_doc_ids, np.uint32)
+    rs = None if row_scale is None else np.ascontiguousarray(row_scale, np.float32)
+    scaled = row_scale is not None or query_scale is not None
+    od = np.empty(max(k, 1), np.uint32)
+    os_ = np.empty(max(k, 1), np.float32)
+    tot, obs = C.c_uint64(), C.c_uint64()
+    dl = np.unique(np.ascontiguousarray([] if deleted is None else deleted, np.uint64))
+    n = lib().so_vec_search_i8(rows.ctypes.data, rows.shape[0], rows.shape[1], _p(rd, u32p), _p(rs, f32p), q.ctypes.data,
+                               1 if scaled else 0, 1.0 if query_scale is None else float(query_scale), k, threshold_raw,
+                               _p(dl, u64p) if len(dl) else None, len(dl), _p(od, u32p), _p(os_, f32p), C.byref(tot), C.byref(obs))
     return od[:n].copy(), os_[:n].copy(), tot.value, obs.value
 
 

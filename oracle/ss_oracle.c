@@ -649,16 +649,16 @@ uint32_t so_vec_search(const float* rows, uint64_t n_rows, uint32_t dim, const u
                        uint64_t* out_observed) {
   return so_vec_search_del(rows, n_rows, dim, row_doc, q, k, thr, simd_order, NULL, 0, od, os, out_total, out_observed);
 }
-uint32_t so_vec_search_del(const float* rows, uint64_t n_rows, uint32_t dim, const uint32_t* row_doc, const float* q,
-                           uint32_t k, float thr, int simd_order, const uint64_t* deleted_sorted, uint64_t n_deleted,
-                           uint32_t* od, float* os, uint64_t* out_total, uint64_t* out_observed) {
-  /* TopK::new / push, vector.rs:366-496 */
+/* search_vector_shard, AnnMode::All (vector.rs:1397-1466) over any record scorer: TopK::new / push, vector.rs:366-496 */
+typedef float (*so_score_fn)(const void* ctx, uint64_t row);
+static uint32_t topk_scan(uint64_t n_rows, const uint32_t* row_doc, uint32_t k, float thr, const uint64_t* deleted_sorted,
+                          uint64_t n_deleted, so_score_fn fn, const void* ctx, uint32_t* od, float* os, uint64_t* out_total,
+                          uint64_t* out_observed) {
   so_item* items = (so_item*)malloc((k ? k : 1) * sizeof(so_item));
   for (uint32_t i = 0; i < k; i++) { items[i].doc = 0; items[i].score = -FLT_MAX; }
   uint32_t len = 0; uint64_t total = 0, observed = 0; float lowest = -FLT_MAX;
   for (uint64_t r = 0; r < n_rows; r++) {
-    const float* e = rows + r * dim;
-    float score = simd_order ? so_dot_f32_lanes8(q, e, dim) : so_dot_f32(q, e, dim);
+    float score = fn(ctx, r);
     uint32_t doc = row_doc ? row_doc[r] : (uint32_t)r;
     observed++;
     if (n_deleted) { /* vector.rs:1450-1452: scored, then not pushed */
@@ -692,6 +692,47 @@ uint32_t so_vec_search_del(const float* rows, uint64_t n_rows, uint32_t dim, con
   if (out_observed) *out_observed = observed;
   free(items);
   return len;
+}
+
+typedef struct { const float* rows; const float* q; uint32_t dim; int simd; } so_f32_ctx;
+static float score_f32(const void* c, uint64_t r) {
+  const so_f32_ctx* x = (const so_f32_ctx*)c;
+  const float* e = x->rows + r * x->dim;
+  return x->simd ? so_dot_f32_lanes8(x->q, e, x->dim) : so_dot_f32(x->q, e, x->dim);
+}
+uint32_t so_vec_search_del(const float* rows, uint64_t n_rows, uint32_t dim, const uint32_t* row_doc, const float* q,
+                           uint32_t k, float thr, int simd_order, const uint64_t* deleted_sorted, uint64_t n_deleted,
+                           uint32_t* od, float* os, uint64_t* out_total, uint64_t* out_observed) {
+  so_f32_ctx c = {rows, q, dim, simd_order};
+  return topk_scan(n_rows, row_doc, k, thr, deleted_sorted, n_deleted, score_f32, &c, od, os, out_total, out_observed);
+}
+
+/* ---- i8 embeddings: quantize_f32_to_i8 (vector_similarity.rs:1226-1232), dot_i8 (1011-1016), dot_i8_quantized (1754-1758) */
+void so_quantize_f32_to_i8(const float* v, uint32_t n, int8_t* out) {
+  for (uint32_t i = 0; i < n; i++) {
+    float x = roundf(v[i] * 127.0f); /* f32::round: half away from zero */
+    if (x < -127.0f) x = -127.0f;
+    if (x > 127.0f) x = 127.0f;
+    out[i] = (int8_t)x;
+  }
+}
+int32_t so_dot_i8(const int8_t* a, const int8_t* b, uint32_t dim) {
+  int32_t s = 0;
+  for (uint32_t i = 0; i < dim; i++) s += (int32_t)a[i] * (int32_t)b[i];
+  return s;
+}
+typedef struct { const int8_t* rows; const int8_t* q; uint32_t dim; const float* row_scale; int scaled; float q_scale; } so_i8_ctx;
+static float score_i8(const void* c, uint64_t r) {
+  const so_i8_ctx* x = (const so_i8_ctx*)c;
+  int32_t d = so_dot_i8(x->q, x->rows + r * x->dim, x->dim);
+  if (!x->scaled) return (float)d;                                   /* dot_i8(a, b) as f32 */
+  return (float)d * x->q_scale * (x->row_scale ? x->row_scale[r] : 1.0f); /* dot_i32 as f32 * scale1 * scale2 */
+}
+uint32_t so_vec_search_i8(const int8_t* rows, uint64_t n_rows, uint32_t dim, const uint32_t* row_doc, const float* row_scale,
+                          const int8_t* q, int scaled, float q_scale, uint32_t k, float thr, const uint64_t* deleted_sorted,
+                          uint64_t n_deleted, uint32_t* od, float* os, uint64_t* out_total, uint64_t* out_observed) {
+  so_i8_ctx c = {rows, q, dim, row_scale, scaled, q_scale};
+  return topk_scan(n_rows, row_doc, k, thr, deleted_sorted, n_deleted, score_i8, &c, od, os, out_total, out_observed);
 }
 
 /* ------------------------------------------------------------------ merge / RRF */

@@ -108,6 +108,14 @@ uint32_t so_vec_search_del(const float* rows, uint64_t n_rows, uint32_t dim, con
                            const float* query, uint32_t k, float threshold_raw, int simd_order,
                            const uint64_t* deleted_sorted, uint64_t n_deleted, uint32_t* out_doc, float* out_score,
                            uint64_t* out_total, uint64_t* out_observed);
+/* i8 embeddings: quantize_f32_to_i8 (vector_similarity.rs:1226-1232); record score = dot_i8 as f32 (1011-1016) or, when
+ * scaled, dot_i8_quantized = dot as f32 * q_scale * row_scale[r] (1754-1758; row_scale NULL = 1).  Same TopK. */
+void so_quantize_f32_to_i8(const float* v, uint32_t n, int8_t* out);
+int32_t so_dot_i8(const int8_t* a, const int8_t* b, uint32_t dim);
+uint32_t so_vec_search_i8(const int8_t* rows, uint64_t n_rows, uint32_t dim, const uint32_t* row_doc_ids,
+                          const float* row_scale, const int8_t* query, int scaled, float q_scale, uint32_t k,
+                          float threshold_raw, const uint64_t* deleted_sorted, uint64_t n_deleted, uint32_t* out_doc,
+                          float* out_score, uint64_t* out_total, uint64_t* out_observed);
 /* vector_score field: vector.rs:1495-1499 */
 float so_vector_score_field(float dot);
 /* TopK threshold transform: vector.rs:388-397 */

@@ -55,10 +55,11 @@ int ss_shard_create(int device, ss_shard** out) {
 }
 
 static void free_vec(ss_shard* s) {
-  void* ptrs[] = {s->d_X, s->d_row_doc, s->d_Qf, s->d_vstate, s->d_cand};
+  void* ptrs[] = {s->d_X, s->d_X8, s->d_row_scale, s->d_row_doc, s->d_Qf, s->d_vstate, s->d_cand};
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  s->d_X = nullptr; s->d_row_doc = nullptr; s->d_Qf = nullptr; s->d_vstate = nullptr; s->d_cand = nullptr;
-  s->n_rows = s->n_rows_pad = 0; s->dim = s->dim_pad = 0; s->vec_multi_record = false;
+  s->d_X = nullptr; s->d_X8 = nullptr; s->d_row_scale = nullptr; s->d_row_doc = nullptr; s->d_Qf = nullptr;
+  s->d_vstate = nullptr; s->d_cand = nullptr;
+  s->n_rows = s->n_rows_pad = 0; s->dim = s->dim_pad = s->dim_pad8 = 0; s->vec_multi_record = false;
 }
 static void free_bm25(ss_shard* s) {
   void* ptrs[] = {s->d_post, s->d_term_base, s->d_sub_off, s->d_comp, s->d_probe, s->d_probe_z, s->d_umax, s->d_exc_off, s->d_exc_doc, s->d_exc_tf};
@@ -407,7 +408,7 @@ int ss_vec_synth(ss_shard* s, uint64_t seed, uint64_t n_rows, uint32_t dim) {
 
 int ss_vec_info(ss_shard* s, uint64_t* n_rows, uint32_t* dim) {
   if (!s) return SS_EINVAL;
-  if (!s->d_X) return SS_ESTATE;
+  if (!s->d_X && !s->d_X8) return SS_ESTATE;
   if (n_rows) *n_rows = s->n_rows;
   if (dim) *dim = s->dim;
   return SS_OK;
@@ -439,7 +440,7 @@ int ss_vec_search(ss_shard* s, uint32_t nq, const float* queries, uint32_t k, fl
   int rc = SS_OK;
   for (int attempt = 0; attempt < 2; attempt++) {
     if (hipMemcpyAsync(d_q, queries, (size_t)nq * s->dim * sizeof(float), hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = SS_EDEVICE; break; }
-    rc = ssi_vec_search(s, nq, d_q, k, thr, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->stream,
+    rc = ssi_vec_search(s, nq, d_q, nullptr, k, thr, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->stream,
                         attempt == 1);
     if (rc) break;
     if (hipMemcpyAsync(out_count, s->d_out_count, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
@@ -467,7 +468,141 @@ int ss_vec_search_dev(ss_shard* s, uint32_t nq, const float* d_queries, uint32_t
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   hipStream_t st = stream ? (hipStream_t)stream : s->stream;
-  return ssi_vec_search(s, nq, d_queries, k, thr, d_out_doc, d_out_score, d_out_count, d_out_total, st, false);
+  return ssi_vec_search(s, nq, d_queries, nullptr, k, thr, d_out_doc, d_out_score, d_out_count, d_out_total, st, false);
+}
+
+// ------------------------------------------------------------------ i8 (quantised) vectors
+// i8 image: rows as the reference stores them for Precision::I8 (quantize_f32_to_i8, vector_similarity.rs:1226-1232, or a
+// per-record scale = VectorHeader.scale with ScalarQuantizationI8).  Score = dot_i8 as f32 (vector_similarity.rs:1011-1016)
+// or, with scales, dot_i8_quantized = dot as f32 * query_scale * embedding_scale (1754-1758).
+static int vec8_alloc(ss_shard* s, uint64_t n_rows, uint32_t dim) {
+  free_vec(s);
+  s->n_rows = n_rows;
+  s->dim = dim;
+  s->dim_pad8 = (dim + 127u) / 128u * 128u;
+  if (s->dim_pad8 > 2560u) { free_vec(s); return SS_ENOTSUP; }  // the 64 queries stay in LDS: 64 x dim_pad8 <= 160 KB
+  s->n_rows_pad = (n_rows + VS_TR - 1) / VS_TR * VS_TR;
+  const size_t bytes = (size_t)s->n_rows_pad * s->dim_pad8;
+  SS_HIP(hipMalloc(&s->d_X8, bytes));
+  if (s->dim_pad8 != dim) SS_HIP(hipMemsetAsync(s->d_X8, 0, bytes, s->stream));
+  else if (s->n_rows_pad != n_rows)
+    SS_HIP(hipMemsetAsync(s->d_X8 + (size_t)n_rows * s->dim_pad8, 0, (size_t)(s->n_rows_pad - n_rows) * s->dim_pad8, s->stream));
+  return SS_OK;
+}
+
+int ss_vec_upload_i8(ss_shard* s, uint64_t n_rows, uint32_t dim, const int8_t* rows, const float* row_scale,
+                     const uint32_t* row_doc_ids) {
+  if (!s || !rows || n_rows == 0 || dim == 0) return SS_EINVAL;
+  if (n_rows > 0xFFFFFFFEull) return SS_ENOTSUP;
+  bool multi = false;
+  if (row_doc_ids) {
+    std::vector<uint32_t> tmp(row_doc_ids, row_doc_ids + n_rows);
+    std::sort(tmp.begin(), tmp.end());
+    multi = std::adjacent_find(tmp.begin(), tmp.end()) != tmp.end();
+    if (!tmp.empty() && tmp.back() == SS_NO_DOC) return SS_EINVAL;
+  }
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  SS_HIP(hipStreamSynchronize(s->stream));
+  int rc = vec8_alloc(s, n_rows, dim);
+  if (rc) { free_vec(s); return rc; }
+  SS_HIP(hipMemcpy2DAsync(s->d_X8, (size_t)s->dim_pad8, rows, (size_t)dim, (size_t)dim, n_rows, hipMemcpyHostToDevice, s->stream));
+  s->vec_multi_record = multi;
+  if (row_scale) {
+    SS_HIP(hipMalloc(&s->d_row_scale, n_rows * sizeof(float)));
+    SS_HIP(hipMemcpyAsync(s->d_row_scale, row_scale, n_rows * sizeof(float), hipMemcpyHostToDevice, s->stream));
+  }
+  if (row_doc_ids) {
+    SS_HIP(hipMalloc(&s->d_row_doc, n_rows * sizeof(uint32_t)));
+    SS_HIP(hipMemcpyAsync(s->d_row_doc, row_doc_ids, n_rows * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+  }
+  SS_HIP(hipStreamSynchronize(s->stream));
+  return ssi_vec_alloc_ws(s);
+}
+
+// bench / test utility: the synthetic f32 corpus of ss_vec_synth quantised on the device with quantize_f32_to_i8
+int ss_vec_synth_i8(ss_shard* s, uint64_t seed, uint64_t n_rows, uint32_t dim) {
+  if (!s || n_rows == 0 || dim == 0) return SS_EINVAL;
+  if (n_rows > 0xFFFFFFFEull) return SS_ENOTSUP;
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  SS_HIP(hipStreamSynchronize(s->stream));
+  int rc = vec_alloc(s, n_rows, dim);  // f32 rows first ...
+  if (rc) { free_vec(s); return rc; }
+  SS_TRY(ssi_vec_synth(s, seed, s->stream));
+  float* x32 = s->d_X;
+  const uint32_t pad32 = s->dim_pad;
+  s->d_X = nullptr;  // ... kept aside while the i8 image is allocated (free_vec must not release them)
+  rc = vec8_alloc(s, n_rows, dim);
+  if (rc) { (void)hipFree(x32); return rc; }
+  s->d_X = x32;
+  s->dim_pad = pad32;
+  rc = ssi_vec8_quantize(s, s->stream);
+  (void)hipStreamSynchronize(s->stream);
+  (void)hipFree(x32);
+  s->d_X = nullptr;
+  s->dim_pad = 0;
+  if (rc) { free_vec(s); return rc; }
+  return ssi_vec_alloc_ws(s);
+}
+
+int ss_vec_read_rows_i8(ss_shard* s, uint64_t r0, uint64_t n, int8_t* out) {
+  if (!s || !out) return SS_EINVAL;
+  if (!s->d_X8) return SS_ESTATE;
+  if (r0 + n > s->n_rows) return SS_EINVAL;
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  SS_HIP(hipStreamSynchronize(s->stream));
+  SS_HIP(hipMemcpy2D(out, (size_t)s->dim, s->d_X8 + r0 * s->dim_pad8, (size_t)s->dim_pad8, (size_t)s->dim, n, hipMemcpyDeviceToHost));
+  return SS_OK;
+}
+
+int ss_vec_search_i8(ss_shard* s, uint32_t nq, const int8_t* queries, const float* query_scale, uint32_t k, float thr,
+                     uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total) {
+  if (!s || !queries || !out_doc || !out_score || !out_count || !out_total) return SS_EINVAL;
+  if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
+  if (!s->d_X8) return SS_ESTATE;
+  if (nq == 0) return SS_OK;
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  SS_TRY(ensure_out(s, nq, k));
+  int8_t* d_q = nullptr;
+  float* d_qs = nullptr;
+  SS_HIP(hipMalloc(&d_q, (size_t)nq * s->dim));
+  if (query_scale) SS_HIP(hipMalloc(&d_qs, (size_t)nq * sizeof(float)));
+  int rc = SS_OK;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    if (hipMemcpyAsync(d_q, queries, (size_t)nq * s->dim, hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = SS_EDEVICE; break; }
+    if (d_qs && hipMemcpyAsync(d_qs, query_scale, (size_t)nq * sizeof(float), hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = SS_EDEVICE; break; }
+    rc = ssi_vec_search(s, nq, d_q, d_qs, k, thr, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->stream, attempt == 1);
+    if (rc) break;
+    if (hipMemcpyAsync(out_count, s->d_out_count, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+        hipStreamSynchronize(s->stream) != hipSuccess) { rc = SS_EDEVICE; break; }
+    bool ovf = false;
+    for (uint32_t i = 0; i < nq; i++) ovf |= out_count[i] == 0xFFFFFFFFu;
+    if (!ovf) break;
+    if (attempt == 1) { rc = SS_EDEVICE; break; }
+  }
+  if (rc == SS_OK) {
+    if (hipMemcpy(out_doc, s->d_out_doc, (size_t)nq * k * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(out_score, s->d_out_score, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(out_total, s->d_out_total, (size_t)nq * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess)
+      rc = SS_EDEVICE;
+  }
+  (void)hipFree(d_q);
+  if (d_qs) (void)hipFree(d_qs);
+  return rc;
+}
+
+int ss_vec_search_i8_dev(ss_shard* s, uint32_t nq, const int8_t* d_queries, const float* d_query_scale, uint32_t k, float thr,
+                         uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, void* stream) {
+  if (!s || !d_queries || !d_out_doc || !d_out_score || !d_out_count || !d_out_total) return SS_EINVAL;
+  if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
+  if (!s->d_X8) return SS_ESTATE;
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  hipStream_t st = stream ? (hipStream_t)stream : s->stream;
+  return ssi_vec_search(s, nq, d_queries, d_query_scale, k, thr, d_out_doc, d_out_score, d_out_count, d_out_total, st, false);
 }
 
 // ------------------------------------------------------------------ cross-shard merge + RRF (search.rs:1875-2119)

@@ -64,7 +64,10 @@ struct ss_shard {
   hipStream_t stream = nullptr;
   std::mutex mu;
   // ---- vector image
-  float* d_X = nullptr;          // [n_rows_pad][dim_pad]
+  float* d_X = nullptr;          // [n_rows_pad][dim_pad]   (f32 image)
+  int8_t* d_X8 = nullptr;        // [n_rows_pad][dim_pad8]  (i8 image: quantised embeddings; one of the two is set)
+  float* d_row_scale = nullptr;  // i8 image: per-record scale (VectorHeader.scale) for dot_i8_quantized, null = raw integer dot
+  uint32_t dim_pad8 = 0;         // row stride of the i8 image in bytes (multiple of 128)
   uint32_t* d_row_doc = nullptr; // optional row -> doc id
   bool vec_multi_record = false; // several records per doc: TopK::push dedup (vector.rs:441-452) in the refine kernel
   uint64_t n_rows = 0, n_rows_pad = 0;
@@ -131,8 +134,13 @@ struct ss_shard {
   } while (0)
 
 // ---- implemented in vec_scan.hip
-int ssi_vec_search(ss_shard* s, uint32_t nq, const float* d_queries, uint32_t k, float thr, uint32_t* d_out_doc,
-                   float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, hipStream_t st, bool safe_mode);
+// d_queries: f32 [nq][dim] for the f32 image, i8 [nq][dim] for the i8 image (d_qscale: per-query scale or null)
+int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float* d_qscale, uint32_t k, float thr,
+                   uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, hipStream_t st,
+                   bool safe_mode);
+int ssi_vec8_qprep(ss_shard* s, const int8_t* d_queries, uint32_t nb, hipStream_t st);
+int ssi_vec8_launch_scan(ss_shard* s, uint32_t tile0, uint32_t ntiles, const float* d_qscale, hipStream_t st);
+int ssi_vec8_quantize(ss_shard* s, hipStream_t st);
 int ssi_vec_alloc_ws(ss_shard* s);
 // ---- implemented in bm25.hip
 // ss_bm25_query::op = operator (bits 0-7) | number of NOT terms (bits 8-15); the NOT terms follow the n_terms query

@@ -1,0 +1,181 @@
+// Dense-vector brute-force scan over i8 embeddings (AnnMode::All; the reference's quantised similarity:
+// dot_i8 / dot_i8_quantized, vector_similarity.rs:1011-1016, 1754-1758; quantize_f32_to_i8, 1226-1232) for gfx950.
+//
+//   scores[N x 64] = X8[N x dim] . Q8^T  with v_mfma_i32_32x32x32_i8: an exact integer dot product, so the score
+//   (dot as f32 [* query_scale * embedding_scale]) is bit-identical to the reference's whatever the summation order.
+//
+// At a batch of 64 queries this scan is HBM-bound (128 int ops per byte of X against ~500 for the machine): the kernel
+// is a stream.  Every wave owns 32 rows at a time and loads them STRAIGHT INTO MFMA A-fragments -- a dot product does
+// not care about the order of k as long as A and B agree, so lane (row r, half h) takes the 64 contiguous bytes
+// [64 h, 64 h + 64) of each 128-byte line of its row (four 16-byte loads), and step j of the line multiplies piece
+// 4 h + j of both operands.  The 64 queries (64 x dim bytes, 48 KB at dim 768) live in LDS for the whole launch in the
+// matching fragment order.  Three lines per lane are in flight (prefetch ring in registers), three workgroups per CU.
+// Threshold filter, candidate buffer and the refine / final kernels are those of the f32 scan (vec_scan.hip).
+#include "ss_common.h"
+#include "vec_dev.h"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int V8_WAVES = 4;     // x 32 rows = one 128-row tile per workgroup step (same tile unit as the f32 scan)
+constexpr int V8_D = 3;         // lines (128 bytes of a row) in flight per lane
+constexpr int V8_LINE = 128;
+
+// Qf8[line][j(4)][nt(2)][lane(64)] 16 bytes = Q8[q = nt*32 + (lane & 31)][128 line + 64 (lane >> 5) + 16 j .. + 16)
+__global__ void vec8_qprep_kernel(const int8_t* __restrict__ Q, uint32_t nq, uint32_t dim, int8_t* __restrict__ Qf8) {
+  const uint32_t line = blockIdx.x;
+  for (uint32_t e = threadIdx.x; e < 8192; e += blockDim.x) {
+    const uint32_t b = e & 15, lane = (e >> 4) & 63, nt = (e >> 10) & 1, j = e >> 11;
+    const uint32_t q = nt * 32 + (lane & 31);
+    const uint32_t k = line * V8_LINE + 64 * (lane >> 5) + 16 * j + b;
+    Qf8[(size_t)line * 8192 + e] = (q < nq && k < dim) ? Q[(size_t)q * dim + k] : (int8_t)0;
+  }
+}
+
+// quantize_f32_to_i8 (vector_similarity.rs:1226-1232): (v * 127).round().clamp(-127, 127), round half away from zero
+__global__ void vec8_quantize_kernel(const float* __restrict__ X, uint32_t dim, uint32_t dim_pad_f, unsigned long long n_rows,
+                                     int8_t* __restrict__ X8, uint32_t dim_pad8) {
+  const unsigned long long r = blockIdx.x;
+  if (r >= n_rows) return;
+  for (uint32_t c = threadIdx.x; c < dim; c += blockDim.x) {
+    const float v = roundf(X[r * dim_pad_f + c] * 127.0f);
+    X8[r * dim_pad8 + c] = (int8_t)fminf(fmaxf(v, -127.0f), 127.0f);
+  }
+}
+
+// EVEN: the number of lines per row is a multiple of the ring depth -> the steady state has no conditional loads (the
+// compiler's s_waitcnt insertion then counts the ring exactly instead of draining it with vmcnt(0) at every merge)
+template <bool SCALED, bool EVEN>
+__global__ void __launch_bounds__(V8_WAVES * 64, 3)
+vec8_scan_kernel(const int8_t* __restrict__ X, uint32_t dim_pad, unsigned long long n_rows, const int8_t* __restrict__ Qf8,
+                 uint32_t L, uint32_t tile0, uint32_t ntiles, const float* __restrict__ row_scale,
+                 const float* __restrict__ q_scale, VState* __restrict__ st, unsigned long long* __restrict__ cand) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float tau0 = st->tau[lane & 31];
+  float tau1 = st->tau[32 + (lane & 31)];
+  if (st->ovf) return;
+  for (uint32_t i = tid; i < L * 512u; i += V8_WAVES * 64) ((v4i*)smem)[i] = ((const v4i*)Qf8)[i];
+  float qs0 = 1.f, qs1 = 1.f;
+  if (SCALED && q_scale) { qs0 = q_scale[lane & 31]; qs1 = q_scale[32 + (lane & 31)]; }
+  __syncthreads();
+
+  const uint32_t first = blockIdx.x;
+  if (first >= ntiles) return;
+  const uint32_t my_tiles = (ntiles - first + gridDim.x - 1) / gridDim.x;
+  const uint32_t G = my_tiles * L;  // lines of this wave's row blocks, flattened
+
+  // my row inside the tile and my 64-byte half of every line
+  const size_t lane_off = (size_t)(32u * w + (lane & 31)) * dim_pad + 64u * (lane >> 5);
+  const size_t tile_stride = (size_t)(V8_WAVES * 32) * dim_pad;
+  uint32_t i_tile = 0, i_line = 0;
+  v4i xa[V8_D][4];
+  auto issue = [&](v4i(&buf)[4]) {
+    const uint32_t t = min(i_tile, my_tiles - 1);  // past the end: re-read a line of the last tile (never consumed)
+    const v4i* p = (const v4i*)(X + (size_t)(tile0 + first + (size_t)t * gridDim.x) * tile_stride + lane_off + (size_t)i_line * V8_LINE);
+#pragma unroll
+    for (int j = 0; j < 4; j++) buf[j] = __builtin_nontemporal_load(p + j);
+    if (++i_line == L) { i_line = 0; ++i_tile; }
+  };
+
+  v16i acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }
+#pragma unroll
+  for (int d = 0; d < V8_D; d++) issue(xa[d]);
+
+  uint32_t c_tile = 0, c_line = 0;
+  for (uint32_t g0 = 0; g0 < G; g0 += V8_D) {
+#pragma unroll
+    for (int d = 0; d < V8_D; d++) {
+      if (!EVEN && g0 + d >= G) break;
+      const char* qb = smem + (size_t)c_line * 8192u + lane * 16;
+      v4i b[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) b[j] = *(const v4i*)(qb + j * 1024);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[d][j], b[2 * j], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[d][j], b[2 * j + 1], acc1, 0, 0, 0);
+      }
+      issue(xa[d]);
+      if (++c_line == L) {
+        // ---- threshold filter: lane owns query (lane & 31) + {0, 32}, 16 rows per accumulator
+        const unsigned long long row_base =
+            (unsigned long long)(tile0 + first + (unsigned long long)c_tile * gridDim.x) * (V8_WAVES * 32) + 32u * w + 4u * (lane >> 5);
+        float f0[16], f1[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          f0[r] = (float)acc0[r];
+          f1[r] = (float)acc1[r];
+          if (SCALED) {  // dot_i8_quantized: dot as f32 * scale1 (query) * scale2 (embedding)
+            const unsigned long long row = row_base + (r & 3) + 8 * (r >> 2);
+            const float es = (row_scale && row < n_rows) ? row_scale[row] : 1.f;
+            f0[r] = f0[r] * qs0 * es;
+            f1[r] = f1[r] * qs1 * es;
+          }
+        }
+        float m0 = f0[0], m1 = f1[0];
+#pragma unroll
+        for (int r = 1; r < 16; r++) { m0 = fmaxf(m0, f0[r]); m1 = fmaxf(m1, f1[r]); }
+        if (m0 > tau0) {
+          const uint32_t q = lane & 31;
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const unsigned long long row = row_base + (r & 3) + 8 * (r >> 2);
+            if (f0[r] > tau0 && row < n_rows) {
+              const uint32_t slot = atomicAdd(&st->cnt[q], 1u);
+              if (slot < VS_CAP) cand[(size_t)q * VS_CAP + slot] = mk_key(f0[r], (uint32_t)row);
+            }
+          }
+        }
+        if (m1 > tau1) {
+          const uint32_t q = 32 + (lane & 31);
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const unsigned long long row = row_base + (r & 3) + 8 * (r >> 2);
+            if (f1[r] > tau1 && row < n_rows) {
+              const uint32_t slot = atomicAdd(&st->cnt[q], 1u);
+              if (slot < VS_CAP) cand[(size_t)q * VS_CAP + slot] = mk_key(f1[r], (uint32_t)row);
+            }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }
+        c_line = 0;
+        ++c_tile;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- host side
+int ssi_vec8_qprep(ss_shard* s, const int8_t* d_queries, uint32_t nb, hipStream_t st) {
+  vec8_qprep_kernel<<<s->dim_pad8 / V8_LINE, 512, 0, st>>>(d_queries, nb, s->dim, (int8_t*)s->d_Qf);
+  return SS_OK;
+}
+
+template <bool SCALED, bool EVEN>
+static int launch_vec8(ss_shard* s, uint32_t tile0, uint32_t ntiles, const float* d_qscale, hipStream_t st) {
+  const uint32_t L = s->dim_pad8 / V8_LINE;
+  const uint32_t grid = std::min<uint32_t>(ntiles, 768);
+  SS_SET_MAX_LDS((vec8_scan_kernel<SCALED, EVEN>), 160 * 1024);
+  vec8_scan_kernel<SCALED, EVEN><<<grid, V8_WAVES * 64, L * 8192u, st>>>(
+      s->d_X8, s->dim_pad8, (unsigned long long)s->n_rows, (const int8_t*)s->d_Qf, L, tile0, ntiles, s->d_row_scale, d_qscale,
+      (VState*)s->d_vstate, (unsigned long long*)s->d_cand);
+  return SS_OK;
+}
+
+int ssi_vec8_launch_scan(ss_shard* s, uint32_t tile0, uint32_t ntiles, const float* d_qscale, hipStream_t st) {
+  const bool scaled = s->d_row_scale != nullptr || d_qscale != nullptr;
+  const bool even = (s->dim_pad8 / V8_LINE) % V8_D == 0;
+  if (scaled) return even ? launch_vec8<true, true>(s, tile0, ntiles, d_qscale, st) : launch_vec8<true, false>(s, tile0, ntiles, d_qscale, st);
+  return even ? launch_vec8<false, true>(s, tile0, ntiles, d_qscale, st) : launch_vec8<false, false>(s, tile0, ntiles, d_qscale, st);
+}
+
+int ssi_vec8_quantize(ss_shard* s, hipStream_t st) {
+  vec8_quantize_kernel<<<(unsigned)s->n_rows, 256, 0, st>>>(s->d_X, s->dim, s->dim_pad, (unsigned long long)s->n_rows, s->d_X8, s->dim_pad8);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}

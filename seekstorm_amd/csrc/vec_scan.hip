@@ -15,33 +15,12 @@
 // Q is pre-permuted into MFMA B-fragment order once per batch and re-streamed from L2 per K-chunk.
 // 3-stage LDS ring, counted vmcnt, one raw s_barrier per K-chunk, persistent across tiles.
 #include "ss_common.h"
+#include "vec_dev.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define LPTR(p) ((__attribute__((address_space(3))) void*)(p))
-
-struct VState {
-  float tau[64];
-  uint32_t cnt[64];
-  uint32_t kept[64];
-  uint32_t ovf;
-  uint32_t pad[63];
-  unsigned long long total[64];
-};
-
-__device__ __forceinline__ uint32_t f2ord(float f) {
-  uint32_t u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float ord2f(uint32_t o) {
-  uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
-  return __uint_as_float(u);
-}
-// larger key = better: (score desc, row asc)
-__device__ __forceinline__ unsigned long long mk_key(float s, uint32_t row) {
-  return ((unsigned long long)f2ord(s) << 32) | (unsigned long long)(0xFFFFFFFFu - row);
-}
 
 // ---------------------------------------------------------------- Q -> MFMA B-fragment order
 // Qf[kc][nt(2)][t(4)][lane(64)][j(4)] = Q[q = nt*32 + (lane&31)][k = kc*32 + (2t + (lane>>5))*4 + j]
@@ -314,9 +293,9 @@ __global__ void vec_final_kernel(const VState* __restrict__ st, const unsigned l
 
 // ---------------------------------------------------------------- host side
 int ssi_vec_alloc_ws(ss_shard* s) {
-  if (!s->d_Qf) {
-    const uint32_t nch = s->dim_pad / VS_KC;
-    SS_HIP(hipMalloc(&s->d_Qf, (size_t)nch * 2048 * sizeof(float)));
+  if (!s->d_Qf) {  // queries in MFMA B-fragment order: f32 [dim_pad / 32][2048], i8 [dim_pad8 / 128][8192]
+    const size_t bytes = s->d_X8 ? (size_t)s->dim_pad8 * 64 : (size_t)(s->dim_pad / VS_KC) * 2048 * sizeof(float);
+    SS_HIP(hipMalloc(&s->d_Qf, bytes));
   }
   if (!s->d_vstate) SS_HIP(hipMalloc(&s->d_vstate, sizeof(VState)));
   if (!s->d_cand) SS_HIP(hipMalloc(&s->d_cand, (size_t)64 * VS_CAP * sizeof(unsigned long long)));
@@ -325,9 +304,11 @@ int ssi_vec_alloc_ws(ss_shard* s) {
   return SS_OK;
 }
 
-int ssi_vec_search(ss_shard* s, uint32_t nq, const float* d_queries, uint32_t k, float thr, uint32_t* d_out_doc,
-                   float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, hipStream_t st, bool safe_mode) {
-  if (!s->d_X) return SS_ESTATE;
+int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float* d_qscale, uint32_t k, float thr,
+                   uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, hipStream_t st,
+                   bool safe_mode) {
+  if (!s->d_X && !s->d_X8) return SS_ESTATE;
+  const bool i8 = s->d_X8 != nullptr;
   if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
   int rc = ssi_vec_alloc_ws(s);
   if (rc) return rc;
@@ -357,15 +338,18 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const float* d_queries, uint32_t k,
 
   for (uint32_t g0 = 0; g0 < nq; g0 += SS_VEC_BATCH) {
     const uint32_t nb = std::min<uint32_t>(SS_VEC_BATCH, nq - g0);
-    vec_qprep_kernel<<<nch, 512, 0, st>>>(d_queries + (size_t)g0 * s->dim, nb, s->dim, s->d_Qf);
+    if (i8) ssi_vec8_qprep(s, (const int8_t*)d_queries + (size_t)g0 * s->dim, nb, st);
+    else vec_qprep_kernel<<<nch, 512, 0, st>>>((const float*)d_queries + (size_t)g0 * s->dim, nb, s->dim, s->d_Qf);
     vec_init_kernel<<<1, 64, 0, st>>>(vst, tau_init);
     uint32_t tile0 = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     ssi_prof_begin(s, 1, st, &e0, &e1);
     for (uint32_t c : chunks) {
       uint32_t grid = std::min<uint32_t>(c, 512);
-      vec_scan_kernel<<<grid, VS_WAVES * 64, VS_LDS, st>>>(s->d_X, s->dim_pad, (unsigned long long)s->n_rows, s->d_Qf,
-                                                           nch, tile0, c, vst, cand);
+      if (i8) ssi_vec8_launch_scan(s, tile0, c, d_qscale ? d_qscale + g0 : nullptr, st);
+      else
+        vec_scan_kernel<<<grid, VS_WAVES * 64, VS_LDS, st>>>(s->d_X, s->dim_pad, (unsigned long long)s->n_rows, s->d_Qf,
+                                                             nch, tile0, c, vst, cand);
       vec_refine_kernel<<<SS_VEC_BATCH, 1024, VS_CAP * (sizeof(unsigned long long) + sizeof(uint32_t)), st>>>(
           vst, cand, k, s->vec_multi_record ? s->d_row_doc : nullptr, s->d_row_doc, s->n_deleted ? s->d_deleted : nullptr,
           (uint32_t)s->deleted_words);

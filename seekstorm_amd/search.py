@@ -75,6 +75,13 @@ def normalize_f32(v):
     return (v * (np.float32(1.0) / np.sqrt(s, dtype=np.float32))).astype(np.float32)
 
 
+def quantize_f32_to_i8(v):
+    """vector_similarity.rs:1226-1232: (v * 127).round().clamp(-127, 127) as i8 -- f32::round is half away from zero"""
+    x = np.ascontiguousarray(v, np.float32) * np.float32(127.0)
+    r = np.sign(x) * np.floor(np.abs(x) + np.float32(0.5))
+    return np.clip(r, -127, 127).astype(np.int8)
+
+
 def idf_f32(indexed_doc_count, posting_count):
     """search.rs:3225-3230, all f32."""
     Nf, nf = np.float32(indexed_doc_count), np.float32(posting_count)
@@ -218,6 +225,42 @@ class Shard:
         ids = None if row_doc_ids is None else np.ascontiguousarray(row_doc_ids, np.uint32)
         N.check(N.lib().ss_vec_upload(self._h, r.shape[0], r.shape[1], N.ptr(r, N.f32p), N.ptr(ids, N.u32p)), "ss_vec_upload")
         self.vector_count, self.dim = r.shape
+
+    def upload_vectors_i8(self, rows_i8, row_scale=None, row_doc_ids=None):
+        """Precision::I8 records: i8 components (+ VectorHeader.scale per record for ScalarQuantizationI8 with Dot)"""
+        r = np.ascontiguousarray(rows_i8, np.int8)
+        sc = None if row_scale is None else np.ascontiguousarray(row_scale, np.float32)
+        ids = None if row_doc_ids is None else np.ascontiguousarray(row_doc_ids, np.uint32)
+        N.check(N.lib().ss_vec_upload_i8(self._h, r.shape[0], r.shape[1], r.ctypes.data, N.ptr(sc, N.f32p), N.ptr(ids, N.u32p)),
+                "ss_vec_upload_i8")
+        self.vector_count, self.dim = r.shape
+
+    def synth_vectors_i8(self, seed, n_rows, dim):
+        N.check(N.lib().ss_vec_synth_i8(self._h, int(seed), int(n_rows), int(dim)), "ss_vec_synth_i8")
+        self.vector_count, self.dim = int(n_rows), int(dim)
+
+    def read_rows_i8(self, r0, n):
+        out = np.empty((n, self.dim), np.int8)
+        N.check(N.lib().ss_vec_read_rows_i8(self._h, int(r0), int(n), out.ctypes.data), "ss_vec_read_rows_i8")
+        return out
+
+    def search_vector_batch_i8(self, queries_i8, k, query_scale=None, similarity_threshold_raw=None):
+        """scores = dot_i8 as f32 (* query_scale * embedding_scale with scales): vector_similarity.rs:1011-1016, 1754-1758"""
+        qv = np.ascontiguousarray(queries_i8, np.int8)
+        if qv.ndim == 1:
+            qv = qv[None, :]
+        if qv.shape[1] != self.dim:
+            raise ValueError("query dimension mismatch")
+        nq = qv.shape[0]
+        qs = None if query_scale is None else np.ascontiguousarray(query_scale, np.float32)
+        doc = np.empty((nq, k), np.uint32)
+        score = np.empty((nq, k), np.float32)
+        cnt = np.empty(nq, np.uint32)
+        tot = np.empty(nq, np.uint64)
+        thr = N.FLT_MIN_NEG if similarity_threshold_raw is None else float(similarity_threshold_raw)
+        N.check(N.lib().ss_vec_search_i8(self._h, nq, qv.ctypes.data, N.ptr(qs, N.f32p), k, thr, N.ptr(doc, N.u32p),
+                                         N.ptr(score, N.f32p), N.ptr(cnt, N.u32p), N.ptr(tot, N.u64p)), "ss_vec_search_i8")
+        return doc, score, cnt, tot
 
     def synth_vectors(self, seed, n_rows, dim):
         N.check(N.lib().ss_vec_synth(self._h, int(seed), int(n_rows), int(dim)), "ss_vec_synth")

@@ -457,3 +457,63 @@ def test_not_terms_abi_validation(S, O, lex):
     bad["op"][0] = int(S.QueryType.Union) | (1 << 16)
     with pytest.raises(S.SeekStormHipError):
         sh.search_lexical_batch(bad, 10)
+
+
+@pytest.mark.parametrize("n_rows,dim,nq,k", [(20000, 768, 64, 100), (4099, 100, 3, 10), (300, 384, 70, 50), (50, 32, 2, 100),
+                                             (9000, 1024, 5, 20)])
+def test_vector_i8_parity(S, O, n_rows, dim, nq, k):
+    """Precision::I8: integer dot products are exact -> scores bit-identical to the oracle's, ids identical outside ties"""
+    rows = O.quantize_i8(O.vec_gen(O.VEC_SEED, 0, n_rows, dim))
+    qs = O.quantize_i8(O.vec_gen(O.VECQ_SEED, 0, nq, dim))
+    sh = S.Shard(0)
+    sh.upload_vectors_i8(rows)
+    assert np.array_equal(sh.read_rows_i8(0, min(n_rows, 64)), rows[:64])
+    doc, score, cnt, tot = sh.search_vector_batch_i8(qs, k)
+    full = rows.astype(np.int32) @ qs.astype(np.int32).T
+    for i in range(nq):
+        od, os_, _, _ = O.vec_search_i8(rows, qs[i], k)
+        assert cnt[i] == len(od)
+        assert np.array_equal(score[i][:cnt[i]], os_)  # bit-exact
+        assert np.array_equal(score[i][:cnt[i]], full[doc[i][:cnt[i]], i].astype(np.float32))  # each id really has its score
+        kth = os_[-1]
+        assert {int(x) for x, y in zip(doc[i][:cnt[i]], score[i]) if y > kth} == {int(x) for x, y in zip(od, os_) if y > kth}
+    sh.close()
+
+
+def test_vector_i8_scales_dedup_tombstones_threshold(S, O):
+    n_rows, dim, k = 7000, 256, 30
+    rows = O.quantize_i8(O.vec_gen(O.VEC_SEED, 0, n_rows, dim))
+    qs = O.quantize_i8(O.vec_gen(O.VECQ_SEED, 0, 9, dim))
+    rng = np.random.default_rng(8)
+    rs = rng.uniform(0.002, 0.02, n_rows).astype(np.float32)   # VectorHeader.scale per record
+    qscale = rng.uniform(0.005, 0.01, len(qs)).astype(np.float32)
+    ids = (np.arange(n_rows) // 3).astype(np.uint32)            # three records per doc
+    sh = S.Shard(0)
+    sh.upload_vectors_i8(rows, row_scale=rs, row_doc_ids=ids)
+    gone = [5, 77, 1200]
+    sh.set_deleted(gone)
+    doc, score, cnt, tot = sh.search_vector_batch_i8(qs, k, query_scale=qscale)
+    for i in range(len(qs)):
+        od, os_, _, _ = O.vec_search_i8(rows, qs[i], k, row_doc_ids=ids, row_scale=rs, query_scale=float(qscale[i]), deleted=gone)
+        assert cnt[i] == len(od) and not set(map(int, doc[i][:cnt[i]])) & set(gone)
+        assert np.array_equal(score[i][:cnt[i]], os_)  # (dot as f32 * scale1) * scale2: same two roundings
+        assert len(set(map(int, doc[i][:cnt[i]]))) == cnt[i]
+    # threshold on the raw score (TopK::new, vector.rs:388-397): fewer than k results
+    sh.set_deleted([])
+    thr = float(np.sort(((rows.astype(np.int32) @ qs[0].astype(np.int32)).astype(np.float32) * qscale[0]) * rs)[-5])
+    d2, s2, c2, _ = sh.search_vector_batch_i8(qs[:1], k, query_scale=qscale[:1], similarity_threshold_raw=thr)
+    od, os_, _, _ = O.vec_search_i8(rows, qs[0], k, row_doc_ids=ids, row_scale=rs, query_scale=float(qscale[0]), threshold_raw=thr)
+    assert c2[0] == len(od) <= 5 and np.array_equal(s2[0][:c2[0]], os_)
+    # the f32 entry points refuse an i8 image instead of misreading it
+    with pytest.raises(S.SeekStormHipError):
+        sh.search_vector_batch(np.zeros((1, dim), np.float32), 10)
+    sh.close()
+
+
+def test_vector_i8_synth_is_the_quantised_f32_generator(S, O):
+    sh = S.Shard(0)
+    sh.synth_vectors_i8(O.VEC_SEED, 3000, 96)
+    want = O.quantize_i8(O.vec_gen(O.VEC_SEED, 0, 3000, 96))
+    got = sh.read_rows_i8(0, 3000)
+    assert np.array_equal(got, want)
+    sh.close()

@@ -255,3 +255,21 @@ def test_not_terms_exclude_docs():
         dall, sall, _ = sh.search_exhaustive(pos, op, 2000)
         keep = [(int(d), float(s)) for d, s in zip(dall, sall) if int(d) in want][:10]
         assert [d for d, _ in keep] == [int(d) for d in d2][:len(keep)]
+
+
+def test_i8_quantisation_and_integer_dot():
+    # quantize_f32_to_i8 (vector_similarity.rs:1226-1232): round half away from zero, clamp +-127; dot_i8 exact (1011-1016)
+    v = np.array([0.5 / 127, 1.5 / 127, -0.5 / 127, -1.5 / 127, 2.0, -3.0, 0.3, 0.0, 126.4 / 127], np.float32)
+    assert O.quantize_i8(v).tolist() == [1, 2, -1, -2, 127, -127, 38, 0, 126]
+    rows = O.quantize_i8(O.vec_gen(O.VEC_SEED, 0, 400, 96))
+    q = O.quantize_i8(O.vec_gen(O.VECQ_SEED, 0, 1, 96))[0]
+    d, s, tot, obs = O.vec_search_i8(rows, q, 10)
+    full = rows.astype(np.int64) @ q.astype(np.int64)
+    order = np.lexsort((np.arange(400), -full))[:10]
+    assert obs == 400 and [int(x) for x in s] == [int(full[i]) for i in order]
+    assert {int(x) for x, y in zip(d, s) if y > s[-1]} == {int(i) for i in order if full[i] > s[-1]}
+    # dot_i8_quantized (1754-1758): dot as f32 * query_scale * embedding_scale, in that order
+    rs = np.linspace(0.5, 2.0, 400).astype(np.float32)
+    d2, s2, _, _ = O.vec_search_i8(rows, q, 10, row_scale=rs, query_scale=0.37)
+    want = (full.astype(np.float32) * np.float32(0.37)) * rs
+    assert np.array_equal(np.sort(s2)[::-1], s2) and np.allclose(s2, np.sort(want)[::-1][:10], rtol=0, atol=0)
