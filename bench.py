@@ -319,6 +319,36 @@ def main():
                                              f"oracle so_vec_search (dot_f32_avx2 order, TopK::push); rate divided by {scale:.0f} "
                                              f"(linear scan) to {args.rows} rows"}
 
+        # ---- the same corpus as Precision::I8 records (quantize_f32_to_i8 of the same rows): HBM-bound stream kernel
+        t0 = time.perf_counter()
+        sh.synth_vectors_i8(O.VEC_SEED ^ (rank * 0x9E3779B1), args.rows, args.dim)
+        build8 = time.perf_counter() - t0
+        q8 = torch.from_numpy(O.quantize_i8(O.vec_gen(O.VECQ_SEED, 0, B, args.dim))).to(dev)
+        def vec8_step():
+            N.check(L.ss_vec_search_i8_dev(sh._h, B, q8.data_ptr(), None, kv, N.FLT_MIN_NEG, v_doc.data_ptr(), v_score.data_ptr(),
+                                           v_cnt.data_ptr(), v_tot.data_ptr(), sptr), "ss_vec_search_i8_dev")
+        sh.profile(True)
+        vec8_step()
+        torch.cuda.synchronize()
+        sh.profile_read(1, reset=True)
+        dt8 = timed(vec8_step, vsteps * 2, min(args.warmup, 2))
+        launches8, kms8 = sh.profile_read(1, reset=True)
+        sh.profile(False)
+        assert np.all(v_cnt.cpu().numpy().astype(np.int64) == min(kv, args.rows))
+        vs8, id8 = v_score.cpu().numpy(), v_doc.cpu().numpy()
+        assert np.all(vs8[:, :-1] >= vs8[:, 1:])
+        r8 = sh.read_rows_i8(int(id8[0, 0]), 1)[0]
+        assert float(r8.astype(np.int64) @ q8[0].cpu().numpy().astype(np.int64)) == float(vs8[0, 0]), "i8 score is not the integer dot product"
+        ms8 = kms8 / max(launches8, 1)
+        bytes8 = 1.0 * args.dim * args.rows
+        gbs8 = bytes8 / (ms8 * 1e-3) / 1e9 if ms8 > 0 else 0.0
+        vec["i8"] = {"metric": "queries/sec (i8 dot top-100, batch 64)", "value": B * vsteps * 2 / dt8 * world, "ms_per_step": dt8 / (vsteps * 2) * 1e3,
+                     "build_s": build8,
+                     "roofline": {"bound": "hbm", "kernel": "vec8_scan_kernel (+refine, all row chunks of one pass)", "achieved": gbs8,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs8 / HBM_PEAK_GBS, "traffic": pmc_traffic("vector_i8"),
+                                  "algorithmic_bytes_per_launch": bytes8, "algorithmic_ops_per_launch": 2.0 * args.dim * args.rows * B,
+                                  "avg_launch_ms": ms8, "launches": int(launches8)}}
+
     # ------------------------------------------------------------------ report
     if rank == 0:
         prim = bm if bm is not None else vec
@@ -355,7 +385,9 @@ def main():
             line["vector"] = {"metric": "queries/sec (cosine top-100, 10M x 768 f32, batch 64)", "value": vec["qps"] * world,
                               "global_qps": vec["qps"], "ms_per_step": vec["ms_per_step"], "roofline": vec["roofline"],
                               "cpu_baseline": vec.get("cpu_baseline"), "latency_ms": vec["latency_ms"], "build_s": vec["build_s"],
-                              "rows_per_shard": args.rows, "dim": args.dim}
+                              "rows_per_shard": args.rows, "dim": args.dim, "i8": vec.get("i8")}
+        elif vec is not None:
+            line["i8"] = vec.get("i8")
         print(json.dumps(line), flush=True)
     sh.close()
     if world > 1:

@@ -484,9 +484,7 @@ static int vec8_alloc(ss_shard* s, uint64_t n_rows, uint32_t dim) {
   s->n_rows_pad = (n_rows + VS_TR - 1) / VS_TR * VS_TR;
   const size_t bytes = (size_t)s->n_rows_pad * s->dim_pad8;
   SS_HIP(hipMalloc(&s->d_X8, bytes));
-  if (s->dim_pad8 != dim) SS_HIP(hipMemsetAsync(s->d_X8, 0, bytes, s->stream));
-  else if (s->n_rows_pad != n_rows)
-    SS_HIP(hipMemsetAsync(s->d_X8 + (size_t)n_rows * s->dim_pad8, 0, (size_t)(s->n_rows_pad - n_rows) * s->dim_pad8, s->stream));
+  if (s->dim_pad8 != dim || s->n_rows_pad != n_rows) SS_HIP(hipMemsetAsync(s->d_X8, 0, bytes, s->stream));  // padding is interleaved
   return SS_OK;
 }
 
@@ -506,7 +504,15 @@ int ss_vec_upload_i8(ss_shard* s, uint64_t n_rows, uint32_t dim, const int8_t* r
   SS_HIP(hipStreamSynchronize(s->stream));
   int rc = vec8_alloc(s, n_rows, dim);
   if (rc) { free_vec(s); return rc; }
-  SS_HIP(hipMemcpy2DAsync(s->d_X8, (size_t)s->dim_pad8, rows, (size_t)dim, (size_t)dim, n_rows, hipMemcpyHostToDevice, s->stream));
+  {  // row-major staging on the device, then into fragment order
+    int8_t* stage = nullptr;
+    SS_HIP(hipMalloc(&stage, (size_t)n_rows * dim));
+    if (hipMemcpyAsync(stage, rows, (size_t)n_rows * dim, hipMemcpyHostToDevice, s->stream) != hipSuccess) { (void)hipFree(stage); free_vec(s); return SS_EDEVICE; }
+    rc = ssi_vec8_permute(s, stage, s->stream);
+    (void)hipStreamSynchronize(s->stream);
+    (void)hipFree(stage);
+    if (rc) { free_vec(s); return rc; }
+  }
   s->vec_multi_record = multi;
   if (row_scale) {
     SS_HIP(hipMalloc(&s->d_row_scale, n_rows * sizeof(float)));
@@ -553,8 +559,14 @@ int ss_vec_read_rows_i8(ss_shard* s, uint64_t r0, uint64_t n, int8_t* out) {
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   SS_HIP(hipStreamSynchronize(s->stream));
-  SS_HIP(hipMemcpy2D(out, (size_t)s->dim, s->d_X8 + r0 * s->dim_pad8, (size_t)s->dim_pad8, (size_t)s->dim, n, hipMemcpyDeviceToHost));
-  return SS_OK;
+  if (n == 0) return SS_OK;
+  int8_t* tmp = nullptr;
+  SS_HIP(hipMalloc(&tmp, (size_t)n * s->dim));
+  int rc = ssi_vec8_gather_rows(s, r0, n, tmp, s->stream);
+  if (rc == SS_OK && hipMemcpyAsync(out, tmp, (size_t)n * s->dim, hipMemcpyDeviceToHost, s->stream) != hipSuccess) rc = SS_EDEVICE;
+  (void)hipStreamSynchronize(s->stream);
+  (void)hipFree(tmp);
+  return rc;
 }
 
 int ss_vec_search_i8(ss_shard* s, uint32_t nq, const int8_t* queries, const float* query_scale, uint32_t k, float thr,

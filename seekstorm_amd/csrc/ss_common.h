@@ -19,7 +19,8 @@ constexpr int VS_QS = SS_VEC_BATCH * VS_KC * 4;  // bytes of Q per stage (fragme
 constexpr int VS_STAGE = VS_XS + VS_QS;
 constexpr int VS_LDS = VS_STAGES * VS_STAGE;
 constexpr uint32_t VS_CAP = 8192;           // candidate slots per query
-constexpr int VS_FIRST_TILES = 16;          // first chunk: 2048 rows, everything is a candidate
+constexpr int VS_FIRST_TILES = 16;          // first chunk: 2048 rows, everything is a candidate (64 tiles: the 8192-entry
+                                            // refine after it costs more than the launch it saves)
 
 // ---------------------------------------------------------------- BM25 image geometry
 constexpr int BM_SUB_LOG2 = 12;             // docs per sub-block = 4096 = one wave's 16 KB LDS accumulator tile
@@ -65,7 +66,7 @@ struct ss_shard {
   std::mutex mu;
   // ---- vector image
   float* d_X = nullptr;          // [n_rows_pad][dim_pad]   (f32 image)
-  int8_t* d_X8 = nullptr;        // [n_rows_pad][dim_pad8]  (i8 image: quantised embeddings; one of the two is set)
+  int8_t* d_X8 = nullptr;        // i8 image (quantised embeddings) in MFMA fragment order, vec8_scan.hip v8_index; one of the two is set
   float* d_row_scale = nullptr;  // i8 image: per-record scale (VectorHeader.scale) for dot_i8_quantized, null = raw integer dot
   uint32_t dim_pad8 = 0;         // row stride of the i8 image in bytes (multiple of 128)
   uint32_t* d_row_doc = nullptr; // optional row -> doc id
@@ -141,6 +142,8 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float*
 int ssi_vec8_qprep(ss_shard* s, const int8_t* d_queries, uint32_t nb, hipStream_t st);
 int ssi_vec8_launch_scan(ss_shard* s, uint32_t tile0, uint32_t ntiles, const float* d_qscale, hipStream_t st);
 int ssi_vec8_quantize(ss_shard* s, hipStream_t st);
+int ssi_vec8_permute(ss_shard* s, const int8_t* d_rows_row_major, hipStream_t st);
+int ssi_vec8_gather_rows(ss_shard* s, uint64_t r0, uint64_t n, int8_t* d_out, hipStream_t st);
 int ssi_vec_alloc_ws(ss_shard* s);
 // ---- implemented in bm25.hip
 // ss_bm25_query::op = operator (bits 0-7) | number of NOT terms (bits 8-15); the NOT terms follow the n_terms query

@@ -6,10 +6,13 @@
 //
 // At a batch of 64 queries this scan is HBM-bound (128 int ops per byte of X against ~500 for the machine): the kernel
 // is a stream.  Every wave owns 32 rows at a time and loads them STRAIGHT INTO MFMA A-fragments -- a dot product does
-// not care about the order of k as long as A and B agree, so lane (row r, half h) takes the 64 contiguous bytes
-// [64 h, 64 h + 64) of each 128-byte line of its row (four 16-byte loads), and step j of the line multiplies piece
-// 4 h + j of both operands.  The 64 queries (64 x dim bytes, 48 KB at dim 768) live in LDS for the whole launch in the
-// matching fragment order.  Three lines per lane are in flight (prefetch ring in registers), three workgroups per CU.
+// not care about the order of k as long as A and B agree, so lane (row r, half h) takes the bytes [64 h, 64 h + 64) of
+// each 128-byte line of its row (four 16-byte pieces), and step j of the line multiplies piece 4 h + j of both operands.
+// The IMAGE is stored in that fragment order (v8_index): [128-row tile][wave][line][j][lane][16 B], so each of a wave's
+// load instructions reads one contiguous KB (eight full 128-byte lines) and its whole 32-row block is one linear stream;
+// with row-major rows every instruction would touch 64 different lines (measured: 2.6 TB/s instead of the figure in
+// DESIGN.md).  The 64 queries (64 x dim bytes, 48 KB at dim 768) live in LDS for the whole launch in the matching
+// order.  Three lines per lane are in flight (prefetch ring in registers), three workgroups per CU.
 // Threshold filter, candidate buffer and the refine / final kernels are those of the f32 scan (vec_scan.hip).
 #include "ss_common.h"
 #include "vec_dev.h"
@@ -18,8 +21,42 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr int V8_WAVES = 4;     // x 32 rows = one 128-row tile per workgroup step (same tile unit as the f32 scan)
-constexpr int V8_D = 3;         // lines (128 bytes of a row) in flight per lane
+constexpr int V8_D = 3;         // lines (128 bytes of a row) in flight per lane (6 measured the same)
 constexpr int V8_LINE = 128;
+
+// byte offset of X8[row][k] in the fragment-ordered image; L = lines (128 bytes) per row
+__host__ __device__ inline size_t v8_index(unsigned long long row, uint32_t k, uint32_t L) {
+  const unsigned long long blk = row >> 5;  // 32-row block = (tile, wave)
+  const uint32_t lane = (uint32_t)(row & 31u) + 32u * ((k >> 6) & 1u);
+  return ((((size_t)blk * L + (k >> 7)) * 4u + ((k >> 4) & 3u)) * 64u + lane) * 16u + (k & 15u);
+}
+
+// row-major [n_rows][dim] (device staging) -> fragment order; one thread per 16-byte piece of the padded image
+__global__ void vec8_permute_kernel(const int8_t* __restrict__ src, unsigned long long n_rows, uint32_t dim, uint32_t dim_pad,
+                                    unsigned long long n_rows_pad, int8_t* __restrict__ dst) {
+  const uint32_t L = dim_pad / 128u;
+  const unsigned long long piece = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long total = n_rows_pad * (dim_pad / 16u);
+  if (piece >= total) return;
+  const unsigned long long row = piece / (dim_pad / 16u);
+  const uint32_t k0 = (uint32_t)(piece % (dim_pad / 16u)) * 16u;
+  int8_t v[16];
+#pragma unroll
+  for (int b = 0; b < 16; b++) v[b] = (row < n_rows && k0 + b < dim) ? src[row * dim + k0 + b] : (int8_t)0;
+  int8_t* o = dst + v8_index(row, k0, L);
+#pragma unroll
+  for (int b = 0; b < 16; b++) o[b] = v[b];
+}
+
+// rows [r0, r0 + n) back to row-major [n][dim]
+__global__ void vec8_gather_rows_kernel(const int8_t* __restrict__ img, uint32_t dim, uint32_t dim_pad, unsigned long long r0,
+                                        unsigned long long n, int8_t* __restrict__ out) {
+  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * dim) return;
+  const unsigned long long r = i / dim;
+  const uint32_t k = (uint32_t)(i % dim);
+  out[i] = img[v8_index(r0 + r, k, dim_pad / 128u)];
+}
 
 // Qf8[line][j(4)][nt(2)][lane(64)] 16 bytes = Q8[q = nt*32 + (lane & 31)][128 line + 64 (lane >> 5) + 16 j .. + 16)
 __global__ void vec8_qprep_kernel(const int8_t* __restrict__ Q, uint32_t nq, uint32_t dim, int8_t* __restrict__ Qf8) {
@@ -39,7 +76,7 @@ __global__ void vec8_quantize_kernel(const float* __restrict__ X, uint32_t dim, 
   if (r >= n_rows) return;
   for (uint32_t c = threadIdx.x; c < dim; c += blockDim.x) {
     const float v = roundf(X[r * dim_pad_f + c] * 127.0f);
-    X8[r * dim_pad8 + c] = (int8_t)fminf(fmaxf(v, -127.0f), 127.0f);
+    X8[v8_index(r, c, dim_pad8 / 128u)] = (int8_t)fminf(fmaxf(v, -127.0f), 127.0f);
   }
 }
 
@@ -56,7 +93,19 @@ vec8_scan_kernel(const int8_t* __restrict__ X, uint32_t dim_pad, unsigned long l
   float tau0 = st->tau[lane & 31];
   float tau1 = st->tau[32 + (lane & 31)];
   if (st->ovf) return;
-  for (uint32_t i = tid; i < L * 512u; i += V8_WAVES * 64) ((v4i*)smem)[i] = ((const v4i*)Qf8)[i];
+  for (uint32_t i0 = 0; i0 < L * 512u; i0 += V8_WAVES * 64 * 4) {  // 48 KB at dim 768: loads of four rounds in flight together
+    v4i t[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t i = i0 + u * V8_WAVES * 64 + tid;
+      t[u] = i < L * 512u ? ((const v4i*)Qf8)[i] : v4i{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t i = i0 + u * V8_WAVES * 64 + tid;
+      if (i < L * 512u) ((v4i*)smem)[i] = t[u];
+    }
+  }
   float qs0 = 1.f, qs1 = 1.f;
   if (SCALED && q_scale) { qs0 = q_scale[lane & 31]; qs1 = q_scale[32 + (lane & 31)]; }
   __syncthreads();
@@ -66,16 +115,16 @@ vec8_scan_kernel(const int8_t* __restrict__ X, uint32_t dim_pad, unsigned long l
   const uint32_t my_tiles = (ntiles - first + gridDim.x - 1) / gridDim.x;
   const uint32_t G = my_tiles * L;  // lines of this wave's row blocks, flattened
 
-  // my row inside the tile and my 64-byte half of every line
-  const size_t lane_off = (size_t)(32u * w + (lane & 31)) * dim_pad + 64u * (lane >> 5);
+  // fragment-ordered image: my 32-row block of tile t starts at (4 t + w) * L * 4096, line c at + 4096 c, piece j at + 1024 j
+  const size_t lane_off = (size_t)w * L * 4096u + (size_t)lane * 16u;
   const size_t tile_stride = (size_t)(V8_WAVES * 32) * dim_pad;
   uint32_t i_tile = 0, i_line = 0;
   v4i xa[V8_D][4];
   auto issue = [&](v4i(&buf)[4]) {
     const uint32_t t = min(i_tile, my_tiles - 1);  // past the end: re-read a line of the last tile (never consumed)
-    const v4i* p = (const v4i*)(X + (size_t)(tile0 + first + (size_t)t * gridDim.x) * tile_stride + lane_off + (size_t)i_line * V8_LINE);
+    const v4i* p = (const v4i*)(X + (size_t)(tile0 + first + (size_t)t * gridDim.x) * tile_stride + lane_off + (size_t)i_line * 4096u);
 #pragma unroll
-    for (int j = 0; j < 4; j++) buf[j] = __builtin_nontemporal_load(p + j);
+    for (int j = 0; j < 4; j++) buf[j] = __builtin_nontemporal_load(p + j * 64);
     if (++i_line == L) { i_line = 0; ++i_tile; }
   };
 
@@ -119,28 +168,8 @@ vec8_scan_kernel(const int8_t* __restrict__ X, uint32_t dim_pad, unsigned long l
         float m0 = f0[0], m1 = f1[0];
 #pragma unroll
         for (int r = 1; r < 16; r++) { m0 = fmaxf(m0, f0[r]); m1 = fmaxf(m1, f1[r]); }
-        if (m0 > tau0) {
-          const uint32_t q = lane & 31;
-#pragma unroll
-          for (int r = 0; r < 16; r++) {
-            const unsigned long long row = row_base + (r & 3) + 8 * (r >> 2);
-            if (f0[r] > tau0 && row < n_rows) {
-              const uint32_t slot = atomicAdd(&st->cnt[q], 1u);
-              if (slot < VS_CAP) cand[(size_t)q * VS_CAP + slot] = mk_key(f0[r], (uint32_t)row);
-            }
-          }
-        }
-        if (m1 > tau1) {
-          const uint32_t q = 32 + (lane & 31);
-#pragma unroll
-          for (int r = 0; r < 16; r++) {
-            const unsigned long long row = row_base + (r & 3) + 8 * (r >> 2);
-            if (f1[r] > tau1 && row < n_rows) {
-              const uint32_t slot = atomicAdd(&st->cnt[q], 1u);
-              if (slot < VS_CAP) cand[(size_t)q * VS_CAP + slot] = mk_key(f1[r], (uint32_t)row);
-            }
-          }
-        }
+        if (m0 > tau0) vs_append(f0, tau0, lane & 31, row_base, n_rows, st, cand);
+        if (m1 > tau1) vs_append(f1, tau1, 32 + (lane & 31), row_base, n_rows, st, cand);
 #pragma unroll
         for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }
         c_line = 0;
@@ -159,7 +188,9 @@ int ssi_vec8_qprep(ss_shard* s, const int8_t* d_queries, uint32_t nb, hipStream_
 template <bool SCALED, bool EVEN>
 static int launch_vec8(ss_shard* s, uint32_t tile0, uint32_t ntiles, const float* d_qscale, hipStream_t st) {
   const uint32_t L = s->dim_pad8 / V8_LINE;
-  const uint32_t grid = std::min<uint32_t>(ntiles, 768);
+  uint32_t gmax = 768;
+  if (const char* e = getenv("SS_VEC8_GRID")) gmax = (uint32_t)atoi(e);  // tuning override
+  const uint32_t grid = std::min<uint32_t>(ntiles, gmax);
   SS_SET_MAX_LDS((vec8_scan_kernel<SCALED, EVEN>), 160 * 1024);
   vec8_scan_kernel<SCALED, EVEN><<<grid, V8_WAVES * 64, L * 8192u, st>>>(
       s->d_X8, s->dim_pad8, (unsigned long long)s->n_rows, (const int8_t*)s->d_Qf, L, tile0, ntiles, s->d_row_scale, d_qscale,
@@ -172,6 +203,22 @@ int ssi_vec8_launch_scan(ss_shard* s, uint32_t tile0, uint32_t ntiles, const flo
   const bool even = (s->dim_pad8 / V8_LINE) % V8_D == 0;
   if (scaled) return even ? launch_vec8<true, true>(s, tile0, ntiles, d_qscale, st) : launch_vec8<true, false>(s, tile0, ntiles, d_qscale, st);
   return even ? launch_vec8<false, true>(s, tile0, ntiles, d_qscale, st) : launch_vec8<false, false>(s, tile0, ntiles, d_qscale, st);
+}
+
+// row-major device staging -> the fragment-ordered image
+int ssi_vec8_permute(ss_shard* s, const int8_t* d_rows_row_major, hipStream_t st) {
+  const unsigned long long total = (unsigned long long)s->n_rows_pad * (s->dim_pad8 / 16u);
+  vec8_permute_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(d_rows_row_major, s->n_rows, s->dim, s->dim_pad8,
+                                                                       s->n_rows_pad, s->d_X8);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
+int ssi_vec8_gather_rows(ss_shard* s, uint64_t r0, uint64_t n, int8_t* d_out, hipStream_t st) {
+  const unsigned long long total = (unsigned long long)n * s->dim;
+  vec8_gather_rows_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(s->d_X8, s->dim, s->dim_pad8, r0, n, d_out);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
 }
 
 int ssi_vec8_quantize(ss_shard* s, hipStream_t st) {

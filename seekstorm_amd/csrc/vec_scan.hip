@@ -38,7 +38,7 @@ __global__ void vec_init_kernel(VState* st, float tau_init) {
   int i = threadIdx.x;
   if (i < 64) {
     st->tau[i] = tau_init;
-    st->cnt[i] = 0;
+    st->cnt[i * VS_CNT_STRIDE] = 0;
     st->kept[i] = 0;
     st->total[i] = 0ull;
   }
@@ -145,26 +145,16 @@ vec_scan_kernel(const float* __restrict__ X, uint32_t dim_pad, unsigned long lon
 #pragma unroll
       for (int r = 1; r < 16; r++) { m0 = fmaxf(m0, acc0[r]); m1 = fmaxf(m1, acc1[r]); }
       if (m0 > tau0) {
-        const uint32_t q = lane & 31;
+        float f[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          unsigned long long row = row_base + (r & 3) + 8 * (r >> 2);
-          if (acc0[r] > tau0 && row < n_rows) {
-            uint32_t slot = atomicAdd(&st->cnt[q], 1u);
-            if (slot < VS_CAP) cand[(size_t)q * VS_CAP + slot] = mk_key(acc0[r], (uint32_t)row);
-          }
-        }
+        for (int r = 0; r < 16; r++) f[r] = acc0[r];
+        vs_append(f, tau0, lane & 31, row_base, n_rows, st, cand);
       }
       if (m1 > tau1) {
-        const uint32_t q = 32 + (lane & 31);
+        float f[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          unsigned long long row = row_base + (r & 3) + 8 * (r >> 2);
-          if (acc1[r] > tau1 && row < n_rows) {
-            uint32_t slot = atomicAdd(&st->cnt[q], 1u);
-            if (slot < VS_CAP) cand[(size_t)q * VS_CAP + slot] = mk_key(acc1[r], (uint32_t)row);
-          }
-        }
+        for (int r = 0; r < 16; r++) f[r] = acc1[r];
+        vs_append(f, tau1, 32 + (lane & 31), row_base, n_rows, st, cand);
       }
 #pragma unroll
       for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -203,7 +193,8 @@ __device__ __forceinline__ void vr_bitonic(unsigned long long* keys, uint32_t* d
   }
 }
 
-__global__ void __launch_bounds__(1024) vec_refine_kernel(VState* __restrict__ st, unsigned long long* __restrict__ cand,
+constexpr int VR_THREADS = 1024;  // (256 threads measured twice as slow on the ~1700 candidates a growth-16 chunk leaves)
+__global__ void __launch_bounds__(VR_THREADS) vec_refine_kernel(VState* __restrict__ st, unsigned long long* __restrict__ cand,
                                                          uint32_t k, const uint32_t* __restrict__ row_doc /* non-null: dedup */,
                                                          const uint32_t* __restrict__ doc_map /* row -> doc, null = identity */,
                                                          const uint32_t* __restrict__ del, uint32_t del_words) {
@@ -211,7 +202,7 @@ __global__ void __launch_bounds__(1024) vec_refine_kernel(VState* __restrict__ s
   unsigned long long* keys = (unsigned long long*)smem;
   uint32_t* docs = (uint32_t*)(smem + VS_CAP * sizeof(unsigned long long));
   const uint32_t q = blockIdx.x;
-  const uint32_t raw = st->cnt[q];
+  const uint32_t raw = st->cnt[q * VS_CNT_STRIDE];
   const uint32_t kept = st->kept[q];
   if (raw == kept) return;  // nothing new since the last refine
   if (raw > VS_CAP) {
@@ -242,7 +233,7 @@ __global__ void __launch_bounds__(1024) vec_refine_kernel(VState* __restrict__ s
   if (row_doc) {
     vr_bitonic(keys, docs, np, true);
     // (doc asc, key desc): an entry whose predecessor has the same doc is a worse record of that doc
-    unsigned long long mine[8];
+    unsigned long long mine[VS_CAP / VR_THREADS];
     for (uint32_t j = 0, i = threadIdx.x; i < np; i += blockDim.x, j++)
       mine[j] = (i > 0 && keys[i] && docs[i] == docs[i - 1]) ? 0ull : keys[i];
     __syncthreads();
@@ -260,7 +251,7 @@ __global__ void __launch_bounds__(1024) vec_refine_kernel(VState* __restrict__ s
   for (uint32_t i = threadIdx.x; i < keep; i += blockDim.x) base[i] = keys[i];
   if (threadIdx.x == 0) {
     st->total[q] += (unsigned long long)(n - kept - dropped);
-    st->cnt[q] = keep;
+    st->cnt[q * VS_CNT_STRIDE] = keep;
     st->kept[q] = keep;
     if (nl >= k && k > 0) st->tau[q] = ord2f((uint32_t)(keys[k - 1] >> 32));
   }
@@ -272,7 +263,7 @@ __global__ void vec_final_kernel(const VState* __restrict__ st, const unsigned l
                                  uint32_t* __restrict__ out_count, unsigned long long* __restrict__ out_total) {
   const uint32_t q = blockIdx.x;
   if (q >= nq) return;
-  const uint32_t n = st->cnt[q] < k ? st->cnt[q] : k;
+  const uint32_t n = st->cnt[q * VS_CNT_STRIDE] < k ? st->cnt[q * VS_CNT_STRIDE] : k;
   for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
     uint32_t doc = SS_NO_DOC;
     float sc = 0.f;
@@ -326,7 +317,9 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float*
     uint32_t step = (VS_CAP - k) / VS_TR;
     for (uint32_t d = 0; d < T; d += step) chunks.push_back(std::min(step, T - d));
   } else {
-    double growth = std::max(1.5, std::min(4.0, (double)(VS_CAP - k) / (2.0 * k)));
+    // tau is fixed during a launch: rows in random order, a chunk g times the rows seen so far leaves ~ g k candidates per
+    // query; keep that 2.5 times below the free slots (an adversarial order overflows and re-runs in safe mode)
+    double growth = std::max(1.5, std::min(16.0, (double)(VS_CAP - k) / (2.5 * k)));
     uint32_t done = std::min<uint32_t>(T, VS_FIRST_TILES);
     chunks.push_back(done);
     while (done < T) {
@@ -350,7 +343,7 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float*
       else
         vec_scan_kernel<<<grid, VS_WAVES * 64, VS_LDS, st>>>(s->d_X, s->dim_pad, (unsigned long long)s->n_rows, s->d_Qf,
                                                              nch, tile0, c, vst, cand);
-      vec_refine_kernel<<<SS_VEC_BATCH, 1024, VS_CAP * (sizeof(unsigned long long) + sizeof(uint32_t)), st>>>(
+      vec_refine_kernel<<<SS_VEC_BATCH, VR_THREADS, VS_CAP * (sizeof(unsigned long long) + sizeof(uint32_t)), st>>>(
           vst, cand, k, s->vec_multi_record ? s->d_row_doc : nullptr, s->d_row_doc, s->n_deleted ? s->d_deleted : nullptr,
           (uint32_t)s->deleted_words);
       tile0 += c;
