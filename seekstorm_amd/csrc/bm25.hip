@@ -94,7 +94,8 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   uint32_t P = (rounds * resident) / nq;
   if (const char* e = getenv("SS_BM25_P")) P = (uint32_t)atoi(e);  // tuning override
   P = std::max<uint32_t>(1, std::min<uint32_t>(P, s->bm_n_sub));
-  const size_t need = (size_t)nq * P * KS * 2 + nq + (nq + 1) / 2;  // two ping-pong merge buffers + totals + tau
+  const size_t tau_words = (size_t)nq * BM_TAU_STRIDE / 2;  // u64 words: one 128-byte line per query
+  const size_t need = (size_t)nq * P * KS * 2 + nq + tau_words;  // two ping-pong merge buffers + totals + tau
   if (need > s->part_cap) {
     if (s->d_part) (void)hipFree(s->d_part);
     s->d_part = nullptr;
@@ -106,7 +107,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   u64* bufB = bufA + (size_t)nq * P * KS;
   u64* total = bufB + (size_t)nq * P * KS;
   uint32_t* tau = (uint32_t*)(total + nq);
-  SS_HIP(hipMemsetAsync(total, 0, nq * sizeof(u64) + (size_t)((nq + 1) / 2) * sizeof(u64), st));
+  SS_HIP(hipMemsetAsync(total, 0, (nq + tau_words) * sizeof(u64), st));
 
   BmParams p;
   p.post = s->d_post;

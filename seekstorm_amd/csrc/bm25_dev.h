@@ -28,6 +28,14 @@ struct BmParams {
 
 typedef unsigned long long u64;
 
+// tau[query]: every query's shared threshold on its own 128-byte line (device-scope atomics to one line serialise)
+constexpr uint32_t BM_TAU_STRIDE = 32;
+// publish a raised k-th best score; skipped when another partition already holds a higher one
+__device__ __forceinline__ void bm_publish_tau(uint32_t* tau_q, float wsc) {
+  const uint32_t bits = __float_as_uint(wsc);  // scores are positive floats: their bit patterns order like unsigned integers
+  if (bits > __hip_atomic_load(tau_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(tau_q, bits);
+}
+
 __device__ __forceinline__ u64 shfl64(u64 v, int src) {
   uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)(v >> 32), src);
   return ((u64)hi << 32) | lo;
@@ -374,7 +382,7 @@ __device__ __attribute__((noinline)) BmTop<KPL> bm_scan_tile(BmTop<KPL> T, uint3
     }
   }
   // publish a raised k-th best score (scores are positive floats: their bit patterns order like unsigned integers)
-  if (tau_q && T.wsc > wsc_in && lane == 0) atomicMax(tau_q, __float_as_uint(T.wsc));
+  if (tau_q && T.wsc > wsc_in && lane == 0) bm_publish_tau(tau_q, T.wsc);
   return T;
 }
 

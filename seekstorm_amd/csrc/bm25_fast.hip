@@ -113,7 +113,7 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
     uint32_t B0[NT], B1[NT], B2[NT];
     uint32_t vbnd[NT];  // boundaries s0 .. s0+63 of term t, one per lane (indices past s_end clamp: empty items)
 
-    uint32_t* tau_q = tau + qi;
+    uint32_t* tau_q = tau + (size_t)qi * BM_TAU_STRIDE;
     auto body = [&](u32x4(&cur)[RC], u32x4(&nxt)[RC], uint32_t s, uint32_t i) {
       // the query's shared threshold, refreshed every item (issued ahead of the posting loads: in-order return)
       const uint32_t tau_bits = __hip_atomic_load(tau_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -32,7 +32,7 @@ __device__ __attribute__((noinline)) BmTop<KPL> bm_offer_lane_keys(BmTop<KPL> T,
   const float wsc_in = T.wsc;
   T.worst = topk_offer<KPL>(T.keys, key, 0ull, 0ull, 0ull, T.worst, k);
   if (T.worst) T.wsc = __uint_as_float((uint32_t)(T.worst >> 32));
-  if (tau_q && T.wsc > wsc_in && __lane_id() == 0) atomicMax(tau_q, __float_as_uint(T.wsc));
+  if (tau_q && T.wsc > wsc_in && __lane_id() == 0) bm_publish_tau(tau_q, T.wsc);
   return T;
 }
 
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
   T.worst = 0ull;
   T.wsc = -1.0f;
   T.matched = 0;
-  uint32_t* tau_q = tau + qi;
+  uint32_t* tau_q = tau + (size_t)qi * BM_TAU_STRIDE;
   const int lane4 = lane * 4;
   constexpr int G = 4;  // chunks (64 driver postings each) evaluated together: their gathers overlap
 
