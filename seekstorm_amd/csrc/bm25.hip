@@ -9,20 +9,21 @@
 
 // ---------------------------------------------------------------- merge of partition-local lists (bitonic in LDS)
 // in: [nq][n_lists][KS] sorted-desc lists; each workgroup merges `group` consecutive lists of one query into one
-// sorted-desc list of KS keys: out [nq][ceil(n_lists/group)][KS].
+// sorted-desc list of KS keys: out [nq][ceil(n_lists/group)][KS].  Only the first `take` keys of a list can reach the
+// final top-k (take >= k): the rest is not even read.
 __global__ void __launch_bounds__(1024) bm25_merge_kernel(const u64* __restrict__ in, u64* __restrict__ out,
-                                                         uint32_t n_lists, uint32_t group, uint32_t KS) {
+                                                         uint32_t n_lists, uint32_t group, uint32_t KS, uint32_t take) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   u64* keys = (u64*)smem;
   const uint32_t q = blockIdx.y, g = blockIdx.x;
   const uint32_t n_groups = (n_lists + group - 1) / group;
   const uint32_t l0 = g * group;
   const uint32_t nl = (l0 + group <= n_lists) ? group : (n_lists - l0);
-  const uint32_t n = nl * KS;
+  const uint32_t n = nl * take;
   uint32_t np = 64;
   while (np < n) np <<= 1;
   const u64* src = in + ((size_t)q * n_lists + l0) * KS;
-  for (uint32_t i = threadIdx.x; i < np; i += blockDim.x) keys[i] = i < n ? src[i] : 0ull;
+  for (uint32_t i = threadIdx.x; i < np; i += blockDim.x) keys[i] = i < n ? src[(i / take) * KS + (i % take)] : 0ull;
   __syncthreads();
   for (uint32_t size = 2; size <= np; size <<= 1) {
     for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
@@ -146,10 +147,14 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   SS_SET_MAX_LDS(bm25_merge_kernel, 8192 * 8);
   uint32_t lists = P;
   u64 *src = bufA, *dst = bufB;
-  const uint32_t group = 8192 / KS;
+  uint32_t take = 1;  // power of two >= k (the lists are sorted: deeper entries cannot reach the top-k)
+  while (take < std::max<uint32_t>(k, 1u) && take < KS) take <<= 1;
+  const uint32_t group = 8192 / take;
   while (lists > 1) {
     uint32_t ng = (lists + group - 1) / group;
-    bm25_merge_kernel<<<dim3(ng, nq), 1024, 8192 * 8, st>>>(src, dst, lists, group, KS);
+    uint32_t np = 64;
+    while (np < std::min(lists, group) * take) np <<= 1;
+    bm25_merge_kernel<<<dim3(ng, nq), std::min<uint32_t>(1024u, std::max<uint32_t>(64u, np / 2)), 8192 * 8, st>>>(src, dst, lists, group, KS, take);
     std::swap(src, dst);
     lists = ng;
   }
