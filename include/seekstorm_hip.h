@@ -185,6 +185,9 @@ int ss_vec_search_dev(ss_shard* s, uint32_t n_queries, const float* d_queries, u
  * row_doc_ids, outputs and tombstones as for the f32 functions. */
 int ss_vec_upload_i8(ss_shard* s, uint64_t n_rows, uint32_t dim, const int8_t* rows, const float* row_scale,
                      const uint32_t* row_doc_ids);
+/* vector.bin with Precision::I8 records (24-byte VectorHeader + dim x i8); use_record_scale keeps VectorHeader.scale
+ * for dot_i8_quantized (ScalarQuantizationI8 with Dot), 0 for Cosine / unscaled Dot whose score is the raw integer dot */
+int ss_vec_upload_vector_bin_i8(ss_shard* s, const uint8_t* bytes, uint64_t len, uint32_t dim, int use_record_scale);
 int ss_vec_synth_i8(ss_shard* s, uint64_t seed, uint64_t n_rows, uint32_t dim); /* ss_vec_synth rows, quantised on the device */
 int ss_vec_read_rows_i8(ss_shard* s, uint64_t first_row, uint64_t n, int8_t* out);
 int ss_vec_search_i8(ss_shard* s, uint32_t n_queries, const int8_t* queries, const float* query_scale, uint32_t k,

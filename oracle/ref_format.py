@@ -222,10 +222,10 @@ def write_index_bin(n_docs, doclen_bytes, terms, rng, segment_number_bits=11, ke
     return bytes(out)
 
 
-def write_vector_bin(levels, dim):
+def write_vector_bin(levels, dim, i8=False):
     """vector.bin (vector.rs:1066-1094).  levels: per level a list of clusters, each a list of (doc_id u16, field_id,
-    chunk_id, vector f32[dim]); header = packed VectorHeader (vector.rs:62-73): u16 doc_id, u32 field_id, u32 chunk_id,
-    f32 scale, f32 norm, i16 zero_point, i32 sum_q."""
+    chunk_id, vector f32[dim] | i8[dim][, scale]); header = packed VectorHeader (vector.rs:62-73): u16 doc_id, u32 field_id,
+    u32 chunk_id, f32 scale, f32 norm, i16 zero_point, i32 sum_q."""
     import struct
     out = bytearray()
     for clusters in levels:
@@ -233,8 +233,10 @@ def write_vector_bin(levels, dim):
         for c in clusters:
             out += len(c).to_bytes(4, "little")
         for c in clusters:
-            for doc_id, field_id, chunk_id, v in c:
-                v = np.asarray(v, "<f4")
+            for rec in c:
+                doc_id, field_id, chunk_id, v = rec[:4]
+                scale = float(rec[4]) if len(rec) > 4 else 1.0
+                v = np.asarray(v, "i1" if i8 else "<f4")
                 assert v.shape == (dim,)
-                out += struct.pack("<HIIffhi", doc_id, field_id, chunk_id, 1.0, 1.0, 0, 0) + v.tobytes()
+                out += struct.pack("<HIIffhi", doc_id, field_id, chunk_id, scale, 1.0, 0, int(v.astype(np.int64).sum()) if i8 else 0) + v.tobytes()
     return bytes(out)

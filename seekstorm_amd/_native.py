@@ -76,6 +76,7 @@ SYMBOLS = [
     ("ss_vec_search_dev", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     ("ss_vec_upload_i8", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, f32p, u32p]),
+    ("ss_vec_upload_vector_bin_i8", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int]),
     ("ss_vec_synth_i8", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32]),
     ("ss_vec_read_rows_i8", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
     ("ss_vec_search_i8", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, f32p, C.c_uint32, C.c_float, u32p, f32p, u32p, u64p]),

@@ -339,12 +339,17 @@ int ss_vec_upload(ss_shard* s, uint64_t n_rows, uint32_t dim, const float* rows,
 // then the records cluster after cluster, each a packed 24-byte VectorHeader (u16 doc_id first, vector.rs:62-73) + dim x f32.
 // Shard-local doc id of a record = (level << 16) | doc_id (vector.rs:1448).  The payloads go to HBM straight from the
 // file bytes with a strided copy per level; AnnMode::All visits every cluster, so the cluster structure is not kept.
-int ss_vec_upload_vector_bin(ss_shard* s, const uint8_t* bytes, uint64_t len, uint32_t dim) {
+static int vec8_alloc(ss_shard* s, uint64_t n_rows, uint32_t dim);
+
+// i8 = Precision::I8 records (dim x i8 after the header); use_scale keeps VectorHeader.scale (f32 at byte 10) per record
+// for dot_i8_quantized (ScalarQuantizationI8 with Dot / Euclidean; Cosine scores are the raw integer dot, vector.rs:1331-1333)
+static int vec_bin_upload(ss_shard* s, const uint8_t* bytes, uint64_t len, uint32_t dim, bool i8, bool use_scale) {
   if (!s || !bytes || dim == 0) return SS_EINVAL;
-  const uint64_t rec = 24u + (uint64_t)dim * 4u;
+  const uint64_t rec = 24u + (uint64_t)dim * (i8 ? 1u : 4u);
   struct Lvl { uint64_t first, n; };
   std::vector<Lvl> levels;
   std::vector<uint32_t> ids;
+  std::vector<float> scales;
   uint64_t pos = 0;
   while (pos < len) {
     if (pos + 4 > len) return SS_EINVAL;
@@ -364,6 +369,11 @@ int ss_vec_upload_vector_bin(ss_shard* s, const uint8_t* bytes, uint64_t len, ui
       uint16_t d;
       memcpy(&d, bytes + pos + r * rec, 2);
       ids.push_back((uint32_t)(levels.size() << 16) | d);
+      if (use_scale) {
+        float sc;
+        memcpy(&sc, bytes + pos + r * rec + 10, 4);
+        scales.push_back(sc);
+      }
     }
     levels.push_back({pos, n});
     pos += n * rec;
@@ -377,20 +387,43 @@ int ss_vec_upload_vector_bin(ss_shard* s, const uint8_t* bytes, uint64_t len, ui
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   SS_HIP(hipStreamSynchronize(s->stream));
-  int rc = vec_alloc(s, n_rows, dim);
+  int rc = i8 ? vec8_alloc(s, n_rows, dim) : vec_alloc(s, n_rows, dim);
   if (rc) { free_vec(s); return rc; }
+  int8_t* stage = nullptr;  // i8: row-major staging on the device, permuted into fragment order afterwards
+  if (i8) SS_HIP(hipMalloc(&stage, (size_t)n_rows * dim));
   uint64_t row = 0;
   for (const Lvl& l : levels) {
     if (l.n == 0) continue;
-    SS_HIP(hipMemcpy2DAsync(s->d_X + row * s->dim_pad, (size_t)s->dim_pad * sizeof(float), bytes + l.first + 24u, rec,
-                            (size_t)dim * sizeof(float), l.n, hipMemcpyHostToDevice, s->stream));
+    hipError_t e = i8 ? hipMemcpy2DAsync(stage + row * dim, (size_t)dim, bytes + l.first + 24u, rec, (size_t)dim, l.n,
+                                         hipMemcpyHostToDevice, s->stream)
+                      : hipMemcpy2DAsync(s->d_X + row * s->dim_pad, (size_t)s->dim_pad * sizeof(float), bytes + l.first + 24u, rec,
+                                         (size_t)dim * sizeof(float), l.n, hipMemcpyHostToDevice, s->stream);
+    if (e != hipSuccess) { if (stage) (void)hipFree(stage); free_vec(s); return SS_EDEVICE; }
     row += l.n;
+  }
+  if (i8) {
+    rc = ssi_vec8_permute(s, stage, s->stream);
+    (void)hipStreamSynchronize(s->stream);
+    (void)hipFree(stage);
+    if (rc) { free_vec(s); return rc; }
+    if (use_scale) {
+      SS_HIP(hipMalloc(&s->d_row_scale, n_rows * sizeof(float)));
+      SS_HIP(hipMemcpyAsync(s->d_row_scale, scales.data(), n_rows * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    }
   }
   s->vec_multi_record = multi;
   SS_HIP(hipMalloc(&s->d_row_doc, n_rows * sizeof(uint32_t)));
   SS_HIP(hipMemcpyAsync(s->d_row_doc, ids.data(), n_rows * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
   SS_HIP(hipStreamSynchronize(s->stream));
   return ssi_vec_alloc_ws(s);
+}
+
+int ss_vec_upload_vector_bin(ss_shard* s, const uint8_t* bytes, uint64_t len, uint32_t dim) {
+  return vec_bin_upload(s, bytes, len, dim, false, false);
+}
+
+int ss_vec_upload_vector_bin_i8(ss_shard* s, const uint8_t* bytes, uint64_t len, uint32_t dim, int use_record_scale) {
+  return vec_bin_upload(s, bytes, len, dim, true, use_record_scale != 0);
 }
 
 int ss_vec_synth(ss_shard* s, uint64_t seed, uint64_t n_rows, uint32_t dim) {

@@ -52,6 +52,11 @@ int ssh_upload_lexical(ssh_index* ix, int shard, uint64_t n_docs, const uint8_t*
                        const uint32_t* docs, const uint16_t* tfs) {
   return ix->shards[shard]->upload_lexical(n_docs, doclen, n_terms, offs, docs, tfs);
 }
+int ssh_upload_vectors_i8(ssh_index* ix, int shard, uint64_t n_rows, uint32_t dim, const int8_t* rows, const uint32_t* ids) {
+  return ix->shards[shard]->upload_vectors_i8(n_rows, dim, rows, nullptr, ids);
+}
+void ssh_quantize_f32_to_i8(const float* v, uint64_t n, int8_t* out) { quantize_f32_to_i8(v, (size_t)n, out); }
+
 int ssh_upload_vectors(ssh_index* ix, int shard, uint64_t n_rows, uint32_t dim, const float* rows, const uint32_t* ids) {
   return ix->shards[shard]->upload_vectors(n_rows, dim, rows, ids);
 }

@@ -23,6 +23,11 @@ void normalize_f32(float* v, size_t n) {
   for (size_t i = 0; i < n; i++) v[i] *= f;
 }
 
+void quantize_f32_to_i8(const float* v, size_t n, int8_t* out) {
+  // vector_similarity.rs:1226-1232: (v * 127.0).round().clamp(-127.0, 127.0) as i8; f32::round = half away from zero
+  for (size_t i = 0; i < n; i++) out[i] = (int8_t)std::fmin(std::fmax(std::round(v[i] * 127.0f), -127.0f), 127.0f);
+}
+
 static const float kSimilarityNormalization64I8 = 1.0f / 16129.0f;  // vector.rs:29
 
 float threshold_raw(const float* similarity_threshold) {
@@ -52,6 +57,7 @@ int Shard::upload_lexical(uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t
 
 int Shard::upload_vectors(uint64_t n_rows, uint32_t dim, const float* rows, const uint32_t* row_doc_ids) {
   if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
+  i8_ = false;
   const int rc = ss_vec_upload(h_, n_rows, dim, rows, row_doc_ids);
   n_rows_ = rc == SS_OK ? n_rows : 0;
   dim_ = rc == SS_OK ? dim : 0;
@@ -76,9 +82,19 @@ int Shard::open_index_bin(const uint8_t* bytes, uint64_t len, uint32_t key_head_
   return rc;
 }
 
-int Shard::open_vector_bin(const uint8_t* bytes, uint64_t len, uint32_t dim) {
+int Shard::upload_vectors_i8(uint64_t n_rows, uint32_t dim, const int8_t* rows, const float* row_scale, const uint32_t* row_doc_ids) {
   if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
-  const int rc = ss_vec_upload_vector_bin(h_, bytes, len, dim);
+  const int rc = ss_vec_upload_i8(h_, n_rows, dim, rows, row_scale, row_doc_ids);
+  n_rows_ = rc == SS_OK ? n_rows : 0;
+  dim_ = rc == SS_OK ? dim : 0;
+  i8_ = rc == SS_OK;
+  return rc;
+}
+
+int Shard::open_vector_bin(const uint8_t* bytes, uint64_t len, uint32_t dim, bool i8, bool use_record_scale) {
+  if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
+  const int rc = i8 ? ss_vec_upload_vector_bin_i8(h_, bytes, len, dim, use_record_scale ? 1 : 0) : ss_vec_upload_vector_bin(h_, bytes, len, dim);
+  i8_ = rc == SS_OK && i8;
   uint64_t n = 0;
   uint32_t d = 0;
   if (rc == SS_OK) ss_vec_info(h_, &n, &d);
@@ -172,9 +188,16 @@ std::vector<ResultObject> Shard::search_vector_batch(const float* query_vectors,
   std::vector<uint32_t> doc(n_queries * kk), cnt(n_queries);
   std::vector<float> score(n_queries * kk);
   std::vector<uint64_t> tot(n_queries);
-  const int rc = h_ ? ss_vec_search(h_, (uint32_t)n_queries, query_vectors, (uint32_t)k, threshold_raw(similarity_threshold),
-                                    doc.data(), score.data(), cnt.data(), tot.data())
-                    : (create_rc_ ? create_rc_ : SS_ESTATE);
+  int rc = create_rc_ ? create_rc_ : SS_ESTATE;
+  if (h_ && i8_) {  // the query is quantised like the records (search.rs:1487-1490); score = raw integer dot
+    std::vector<int8_t> q8(n_queries * dim_);
+    quantize_f32_to_i8(query_vectors, q8.size(), q8.data());
+    rc = ss_vec_search_i8(h_, (uint32_t)n_queries, q8.data(), nullptr, (uint32_t)k, threshold_raw(similarity_threshold), doc.data(),
+                          score.data(), cnt.data(), tot.data());
+  } else if (h_) {
+    rc = ss_vec_search(h_, (uint32_t)n_queries, query_vectors, (uint32_t)k, threshold_raw(similarity_threshold), doc.data(),
+                       score.data(), cnt.data(), tot.data());
+  }
   for (size_t q = 0; q < n_queries; q++) {
     ResultObject& ro = out[q];
     if (rc != SS_OK) { ro.last_error = rc; continue; }  // degrade to empty (vector.rs:1222-1224)

@@ -57,6 +57,7 @@ struct ResultObject {
 // ---- host-side scalar pieces of the reference algorithm
 float idf(uint64_t indexed_doc_count, uint64_t posting_count);  // search.rs:3225-3230, all f32
 void normalize_f32(float* v, size_t n);                         // vector_similarity.rs:70-74 (search.rs:1464-1475)
+void quantize_f32_to_i8(const float* v, size_t n, int8_t* out);  // vector_similarity.rs:1226-1232 (query side: search.rs:1487-1490)
 float threshold_raw(const float* similarity_threshold);         // TopK::new, vector.rs:388-397; nullptr = none
 float vector_score_of(float raw_dot);                           // vector.rs:1495-1499: ((dot / 16129) + 1) / 2
 
@@ -79,7 +80,10 @@ class Shard {
   int upload_vectors(uint64_t n_rows, uint32_t dim, const float* rows, const uint32_t* row_doc_ids);
   // shard files as the reference writes them: index.bin (single indexed field), vector.bin (f32), delete.bin
   int open_index_bin(const uint8_t* bytes, uint64_t len, uint32_t key_head_size, std::vector<uint64_t>* term_keys);
-  int open_vector_bin(const uint8_t* bytes, uint64_t len, uint32_t dim);
+  int open_vector_bin(const uint8_t* bytes, uint64_t len, uint32_t dim, bool i8 = false, bool use_record_scale = false);
+  // Precision::I8 records; queries given as f32 are quantised with quantize_f32_to_i8 like the reference's
+  int upload_vectors_i8(uint64_t n_rows, uint32_t dim, const int8_t* rows, const float* row_scale, const uint32_t* row_doc_ids);
+  bool vectors_are_i8() const { return i8_; }
   // delete_hashset (index.rs:1594): replaces the tombstone set; delete_document (index.rs:5110) re-sends it
   int set_deleted(const uint64_t* doc_ids, uint64_t n);
   int synth_lexical(uint64_t seed, uint64_t n_docs, uint32_t n_terms, const uint32_t* thresh32, const uint8_t* len_table1024);
@@ -109,6 +113,7 @@ class Shard {
   int create_rc_ = SS_OK;
   uint64_t n_docs_ = 0, n_rows_ = 0;
   uint32_t dim_ = 0;
+  bool i8_ = false;
 };
 
 // In-process multi-shard index: doc g lives in shard g % S with local id g / S (index.rs:5284).

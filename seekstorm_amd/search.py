@@ -151,6 +151,7 @@ class Shard:
         self.indexed_doc_count = 0
         self.vector_count = 0
         self.dim = 0
+        self.vector_precision = "f32"  # "i8": Precision::I8 image, queries are quantised with quantize_f32_to_i8
 
     def close(self):
         if getattr(self, "_h", None):
@@ -197,9 +198,15 @@ class Shard:
         self.indexed_doc_count = int(ix.indexed_doc_count)
         self._df_cache.clear()
 
-    def upload_vector_bin(self, data, dim):
+    def upload_vector_bin(self, data, dim, i8=False, use_record_scale=False):
+        """vector.bin as the reference writes it: f32 records, or Precision::I8 records (i8=True)"""
         buf = np.frombuffer(bytes(data), np.uint8)
-        N.check(N.lib().ss_vec_upload_vector_bin(self._h, buf.ctypes.data, len(buf), int(dim)), "ss_vec_upload_vector_bin")
+        if i8:
+            N.check(N.lib().ss_vec_upload_vector_bin_i8(self._h, buf.ctypes.data, len(buf), int(dim), 1 if use_record_scale else 0),
+                    "ss_vec_upload_vector_bin_i8")
+        else:
+            N.check(N.lib().ss_vec_upload_vector_bin(self._h, buf.ctypes.data, len(buf), int(dim)), "ss_vec_upload_vector_bin")
+        self.vector_precision = "i8" if i8 else "f32"
         n, d = C.c_uint64(), C.c_uint32()
         N.check(N.lib().ss_vec_info(self._h, C.byref(n), C.byref(d)), "ss_vec_info")
         self.vector_count, self.dim = n.value, d.value
@@ -225,6 +232,7 @@ class Shard:
         ids = None if row_doc_ids is None else np.ascontiguousarray(row_doc_ids, np.uint32)
         N.check(N.lib().ss_vec_upload(self._h, r.shape[0], r.shape[1], N.ptr(r, N.f32p), N.ptr(ids, N.u32p)), "ss_vec_upload")
         self.vector_count, self.dim = r.shape
+        self.vector_precision = "f32"
 
     def upload_vectors_i8(self, rows_i8, row_scale=None, row_doc_ids=None):
         """Precision::I8 records: i8 components (+ VectorHeader.scale per record for ScalarQuantizationI8 with Dot)"""
@@ -234,10 +242,12 @@ class Shard:
         N.check(N.lib().ss_vec_upload_i8(self._h, r.shape[0], r.shape[1], r.ctypes.data, N.ptr(sc, N.f32p), N.ptr(ids, N.u32p)),
                 "ss_vec_upload_i8")
         self.vector_count, self.dim = r.shape
+        self.vector_precision = "i8"
 
     def synth_vectors_i8(self, seed, n_rows, dim):
         N.check(N.lib().ss_vec_synth_i8(self._h, int(seed), int(n_rows), int(dim)), "ss_vec_synth_i8")
         self.vector_count, self.dim = int(n_rows), int(dim)
+        self.vector_precision = "i8"
 
     def read_rows_i8(self, r0, n):
         out = np.empty((n, self.dim), np.int8)
@@ -265,6 +275,7 @@ class Shard:
     def synth_vectors(self, seed, n_rows, dim):
         N.check(N.lib().ss_vec_synth(self._h, int(seed), int(n_rows), int(dim)), "ss_vec_synth")
         self.vector_count, self.dim = int(n_rows), int(dim)
+        self.vector_precision = "f32"
 
     def read_rows(self, r0, n):
         out = np.empty((n, self.dim), np.float32)
@@ -364,7 +375,12 @@ class Shard:
     def search_vector_shard(self, query_vector, length=10, similarity_threshold=None, strict=False) -> ResultObject:
         ro = ResultObject()
         try:
-            doc, score, cnt, tot = self.search_vector_batch(query_vector, length, similarity_threshold)
+            if self.vector_precision == "i8":  # the query is quantised like the records (search.rs:1476-1490), threshold on the raw dot
+                q8 = quantize_f32_to_i8(np.ascontiguousarray(query_vector, np.float32).reshape(1, -1))
+                thr = None if similarity_threshold is None else threshold_raw(similarity_threshold)
+                doc, score, cnt, tot = self.search_vector_batch_i8(q8, length, similarity_threshold_raw=thr)
+            else:
+                doc, score, cnt, tot = self.search_vector_batch(query_vector, length, similarity_threshold)
         except Exception:
             if strict:
                 raise

@@ -47,6 +47,8 @@ def H():
                                            C.c_uint32, C.c_uint32, u64p, f32p, u64p]
     L.ssh_coalesced_vector_search.argtypes = [C.c_void_p, C.c_int, C.c_uint32, f32p, C.c_uint32, C.c_uint32, C.c_uint32,
                                               u64p, f32p, u32p]
+    L.ssh_upload_vectors_i8.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, u32p]
+    L.ssh_quantize_f32_to_i8.argtypes = [f32p, C.c_uint64, C.c_void_p]
     L.ssh_coalesced_lexical_search.argtypes = [C.c_void_p, C.c_int, C.c_uint32, u32p, u32p, u32p, u32p, C.c_uint32, C.c_uint32,
                                                C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u64p, f32p, u32p, u64p]
     return L
@@ -75,6 +77,10 @@ def test_host_scalars_match_oracle(H):
     a = v.copy()
     H.ssh_normalize_f32(P(a, f32p), len(a))
     assert np.allclose(a, O.normalize(v), rtol=0, atol=1e-7) and abs(float(np.dot(a, a)) - 1.0) < 1e-5
+    q8 = np.zeros(9, np.int8)
+    vq = np.array([0.5 / 127, 1.5 / 127, -0.5 / 127, -1.5 / 127, 2.0, -3.0, 0.3, 0.0, 126.4 / 127], np.float32)
+    H.ssh_quantize_f32_to_i8(P(vq, f32p), 9, q8.ctypes.data)
+    assert np.array_equal(q8, O.quantize_i8(vq))  # quantize_f32_to_i8, vector_similarity.rs:1226-1232
     assert H.ssh_threshold_raw(0.7) == np.float32((np.float32(0.7) * np.float32(2) - np.float32(1)) / (np.float32(1) / np.float32(16129)))
     assert abs(H.ssh_vector_score(16129.0) - 1.0) < 1e-6 and abs(H.ssh_vector_score(0.0) - 0.5) < 1e-7
 
@@ -212,5 +218,24 @@ def test_cpp_lexical_coalescer_batches_concurrent_queries(H):
                 assert int(tot[i]) == otot
                 assert cnt[i] == max(0, min(length, len(od) - off))
                 assert np.allclose(sc[i][:cnt[i]], os_[off:off + cnt[i]], rtol=REL)
+    finally:
+        H.ssh_index_destroy(ix)
+
+
+@pytest.mark.gpu
+def test_cpp_index_vector_search_on_i8_image(H):
+    """Index::search in Vector mode over Precision::I8 shards: the f32 query is normalised, quantised like the records
+    (search.rs:1464-1490) and scored with the exact integer dot"""
+    from oracle import oracle as O
+    n_rows, dim, k = 4000, 128, 15
+    rows = O.quantize_i8(O.vec_gen(31, 0, n_rows, dim))
+    qv = O.vec_gen(32, 0, 1, dim, normalize=False)[0] * 2.5
+    ix = H.ssh_index_create(1, None)
+    try:
+        assert H.ssh_upload_vectors_i8(ix, 0, n_rows, dim, rows.ctypes.data, None) == 0
+        d, s, src, ls, vsc, meta = _search(H, ix, [], qv, 1, 1, 0, k)
+        od, os_, _, _ = O.vec_search_i8(rows, O.quantize_i8(O.normalize(qv)), k)
+        assert len(d) == k and np.array_equal(s, os_) and int(d[0]) == int(od[0])
+        assert np.allclose(vsc, (s / np.float32(16129.0) + 1) / 2, rtol=1e-6)
     finally:
         H.ssh_index_destroy(ix)

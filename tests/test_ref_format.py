@@ -211,3 +211,34 @@ def test_upload_index_bin_and_vector_bin_answer_like_the_arrays():
     assert np.array_equal(a.read_rows(0, 700), rows)
     a.close()
     b.close()
+
+
+@pytest.mark.gpu
+def test_vector_bin_i8_records_and_shard_seam():
+    """Precision::I8 vector.bin (header + dim x i8, VectorHeader.scale per record) == the array upload; the shard seam
+    quantises the query like the reference (quantize_f32_to_i8) and reports the raw integer dot"""
+    from oracle import oracle as O
+    dim = 96
+    rows = O.quantize_i8(O.vec_gen(O.VEC_SEED, 0, 500, dim))
+    rng = np.random.default_rng(2)
+    sc = rng.uniform(0.01, 0.02, 500).astype(np.float32)
+    recs = [(int(i % 250), 0, int(i // 250), rows[i], float(sc[i])) for i in range(500)]
+    levels = [[recs[0:100], recs[100:250]], [recs[250:500]]]
+    ids = np.array([r[0] for r in recs[:250]] + [(1 << 16) | r[0] for r in recs[250:]], np.uint32)
+    data = RF.write_vector_bin(levels, dim, i8=True)
+    qs = O.quantize_i8(O.vec_gen(O.VECQ_SEED, 0, 4, dim))
+    a, b = S.Shard(0), S.Shard(0)
+    for use_scale in (False, True):
+        a.upload_vector_bin(data, dim, i8=True, use_record_scale=use_scale)
+        b.upload_vectors_i8(rows, row_scale=sc if use_scale else None, row_doc_ids=ids)
+        assert np.array_equal(a.read_rows_i8(0, 500), rows)
+        qscale = np.full(4, 0.5, np.float32) if use_scale else None
+        for x, y in zip(a.search_vector_batch_i8(qs, 20, query_scale=qscale), b.search_vector_batch_i8(qs, 20, query_scale=qscale)):
+            assert np.array_equal(x, y)
+    a.upload_vector_bin(data, dim, i8=True)
+    qf = O.vec_gen(O.VECQ_SEED, 0, 1, dim)[0]
+    ro = a.search_vector_shard(qf, 10)
+    od, os_, _, _ = O.vec_search_i8(rows, O.quantize_i8(qf), 10, row_doc_ids=ids)
+    assert [r.score for r in ro.results] == [float(x) for x in os_] and ro.results[0].doc_id == int(od[0])
+    a.close()
+    b.close()
