@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--queries", type=int, default=1000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-topk-count", action="store_true", help="skip the TopkCount comparison (keeps counter profiles of the Topk kernels clean)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -190,7 +191,7 @@ def main():
             N.check(L.ss_bm25_search_dev(sh._h, nq, q_dev.data_ptr(), k, N.RT_TOPKCOUNT, 2 | (3 << 8), o_doc.data_ptr(),
                                          o_score.data_ptr(), o_cnt.data_ptr(), o_tot.data_ptr(), sptr), "ss_bm25_search_dev")
         tc = {}
-        for name, strat in (("exhaustive", N.BM25_EXHAUSTIVE), ("auto", N.BM25_AUTO)):
+        for name, strat in (() if args.no_topk_count else (("exhaustive", N.BM25_EXHAUSTIVE), ("auto", N.BM25_AUTO))):
             sh.set_strategy(strat)
             tc_step()
             torch.cuda.synchronize()

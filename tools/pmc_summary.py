@@ -6,7 +6,7 @@ profiles/pmc_traffic.json.
 HBM bytes follow MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are KiB, and on gfx950 FETCH_SIZE reports
 exactly half of a wide coalesced read -> bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  BM25 figures are per FULL launch
 (the dispatches with the largest grid: 1000-query batches; single-query latency probes are excluded); vector figures
-are per 64-query pass (7 row-chunk launches of vec_scan_kernel).
+are per 64-query pass (4 row-chunk launches of vec_scan_kernel / vec8_scan_kernel).
 Usage: python tools/pmc_summary.py <gpurun_out dir> <tag>"""
 import json
 import os
@@ -35,7 +35,9 @@ def main():
                       "`rocprofv3 --pmc <group> --kernel-trace -- python bench.py --workload all --no-cpu --steps 4 --warmup 1`, "
                       "one run per counter group (tools/collect_pmc.sh).  SQ_* wave counters are in quad-cycles "
                       "(MI355X_MICROARCH.md); GRBM_GUI_ACTIVE is summed over the 8 XCDs.", ""]
-    for kern, pat in (("bm25", "bm25_scan_fast_kernel"), ("bm25_pruned", "bm25_probe_kernel"), ("vector", "vec_scan_kernel")):
+    LAUNCHES_PER_PASS = 4  # chunk schedule of the vector scans: 16 tiles, then 16 x the prefix (10 M rows)
+    for kern, pat in (("bm25", "bm25_scan_fast_kernel"), ("bm25_pruned", "bm25_probe_kernel"), ("bm25_union_count", "bm25_union_count_kernel"),
+                      ("vector", "vec_scan_kernel"), ("vector_i8", "vec8_scan_kernel")):
         groups = {g: load(db(g), pat) for g in ("fetch", "write", "sqA", "sqB", "sqC") if os.path.exists(db(g))}
         if not groups.get("fetch"):
             continue
@@ -46,7 +48,7 @@ def main():
                 gmax = max(r["grid"] for r in rows)
                 rows = [r for r in rows if r["grid"] == gmax]
                 return rows, len(rows)
-            return rows, max(1, len(rows) // 7)
+            return rows, max(1, len(rows) // LAUNCHES_PER_PASS)
 
         def tot(g, c):
             rows, n = sel(g)
@@ -58,7 +60,7 @@ def main():
         hbm = (2.0 * fetch / n + write / nw) * 1024.0
         rows, _ = sel("fetch")
         dur_ms = sum(r["dur"] for r in rows) / n / 1e6
-        unit = "full launch (1000 queries)" if kern.startswith("bm25") else "64-query pass (7 launches)"
+        unit = "full launch (1000 queries)" if kern.startswith("bm25") else f"64-query pass ({LAUNCHES_PER_PASS} launches)"
         out[kern] = {"hbm_bytes_per_launch": hbm, "fetch_size_kib_total": fetch, "write_size_kib_total": write,
                      "launches": n, "cycles_per_launch": gui / 8 / n, "kernel_ms_per_launch_profiled": dur_ms}
         lines += [f"## {kern}: `{pat}` -- per {unit}, {n} of them", "",
