@@ -204,14 +204,22 @@ def main():
         ex_ach = bytes_launch / (ex_kms * 1e-3) / 1e9 if ex_kms > 0 else 0.0
         lat_batch = latencies(bm_step, 12)
         lat_one = latencies(lambda: bm_step(1), 60)
+        # Roofline of the dominant kernel of the timed region (bm25_probe_kernel).  A pruning kernel answers WITHOUT reading
+        # most of SURVEY 8d's algorithmic bytes (all postings of the query terms), so dividing those by its time gives a rate
+        # above the HBM peak that says nothing about the kernel.  `achieved` is therefore what it really moves per launch
+        # (PMC FETCH_SIZE / WRITE_SIZE of the same command, profiles/pmc_traffic.json) over the live launch time; the rate on
+        # the algorithmic bytes is kept beside it, and the exhaustive scan -- the kernel that does stream them -- below.
+        moved = pmc_traffic("bm25_pruned")
+        real = (moved if moved else bytes_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         bm = dict(qps=qps, ms_per_step=ms_step, build_s=build_s, info=info,
-                  roofline={"bound": "hbm", "kernel": "bm25_probe_kernel<3,1> (pruned strategy: reads essential terms' postings + probe records)",
-                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                            "traffic": pmc_traffic("bm25_pruned"), "algorithmic_bytes_per_launch": bytes_launch,
+                  roofline={"bound": "hbm", "kernel": "bm25_probe_kernel<3,1> (pruned strategy: essential terms' postings + probe records)",
+                            "achieved": real, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": real / HBM_PEAK_GBS,
+                            "traffic": moved, "algorithmic_bytes_per_launch": bytes_launch,
+                            "effective_GBs_on_algorithmic_bytes": ach,
                             "avg_launch_ms": avg_ms, "launches": launches,
-                            "note": "achieved = SURVEY 8d algorithmic bytes (all postings of the query terms) / kernel time; the pruned "
-                                    "kernel answers without reading most of them, so this is an EFFECTIVE rate -- traffic is what it "
-                                    "really moved; the exhaustive scan below is the kernel that streams the algorithmic bytes"},
+                            "note": "achieved = bytes the kernel really moves (PMC, committed profile) / live kernel time; it answers "
+                                    "without reading most of the SURVEY 8d algorithmic bytes, hence effective_GBs_on_algorithmic_bytes "
+                                    "can exceed the peak; the exhaustive scan below is the kernel that streams the algorithmic bytes"},
                   exhaustive={"value": ex_qps, "unit": "queries/s", "ms_per_step": ex_ms,
                               "roofline": {"bound": "hbm", "kernel": "bm25_scan_fast_kernel<3,false,1>", "achieved": ex_ach,
                                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ex_ach / HBM_PEAK_GBS,
