@@ -517,3 +517,28 @@ def test_vector_i8_synth_is_the_quantised_f32_generator(S, O):
     got = sh.read_rows_i8(0, 3000)
     assert np.array_equal(got, want)
     sh.close()
+
+
+def test_reference_count_assertions_on_the_hip_path(S, O):
+    """The only values the reference's own tests pin for this path, through the C ABI and under both
+    strategies: tests/test.rs:150-177 ("+body2 +test" -> 1 result, total 1), tests/test.rs:181-208 ("test", Count -> 2),
+    tests/test.rs:676-744 (3 vectors, k = 10 -> 3 hits)."""
+    doclen = np.array([O.lib().so_int_to_byte4(x) for x in (3, 4, 4, 3)], np.uint8)  # 4-doc fixture, tests/test.rs:96-148
+    offs = np.array([0, 2, 3], np.uint64)                                            # term 0 = 'test' (docs 1, 2), 1 = 'body2' (doc 1)
+    docs = np.array([1, 2, 1], np.uint32)
+    tfs = np.array([1, 1, 1], np.uint16)
+    sh = S.Shard(0)
+    sh.upload_lexical(4, doclen, offs, docs, tfs)
+    for strat in (0, 1, 2):
+        sh.set_strategy(strat)
+        ro = sh.search_lexical_shard([1, 0], S.QueryType.Intersection, 0, 10, S.ResultType.TopkCount, strict=True)
+        assert ro.result_count == 1 and ro.result_count_total == 1 and ro.results[0].doc_id == 1
+        ro = sh.search_lexical_shard([0], S.QueryType.Union, 0, 10, S.ResultType.Count, strict=True)
+        assert ro.result_count == 0 and ro.result_count_total == 2
+        ro = sh.search_lexical_shard([0, 1], S.QueryType.Union, 0, 10, S.ResultType.TopkCount, strict=True)
+        assert ro.result_count_total == 2 and [r.doc_id for r in ro.results] == [1, 2]
+    rows = O.vec_gen(7, 0, 3, 128)
+    sh.upload_vectors(rows)
+    ro = sh.search_vector_shard(rows[1], 10, strict=True)
+    assert ro.result_count == 3 and ro.result_count_total == 3 and ro.results[0].doc_id == 1 and abs(ro.results[0].score - 1.0) < 1e-5
+    sh.close()
