@@ -100,6 +100,10 @@ int ss_bm25_upload_ref_blocks(ss_shard* s, uint64_t n_docs, const uint8_t* docle
 typedef struct ss_index_bin ss_index_bin;
 int ss_index_bin_open(const uint8_t* bytes, uint64_t len, uint32_t indexed_field_count, uint32_t key_head_size,
                       uint32_t segment_number_bits, ss_index_bin** out);
+/* Drops the keys with fewer than min_posting_count postings (term ids are re-ranked among the kept keys): the device
+ * image is built for the frequent terms that dominate query cost; a query touching a dropped term (ss_index_bin_term_keys
+ * has no entry for it) is answered by the host's own path. */
+int ss_index_bin_filter(ss_index_bin* ix, uint64_t min_posting_count, uint32_t* n_terms_kept);
 int ss_index_bin_close(ss_index_bin* ix);
 int ss_index_bin_info(const ss_index_bin* ix, uint64_t* n_docs, uint64_t* positions_sum_normalized, uint32_t* n_levels,
                       uint32_t* n_terms, uint32_t* n_ngram_keys_skipped);

@@ -251,6 +251,29 @@ extern "C" int ss_index_bin_open(const uint8_t* bytes, uint64_t len, uint32_t in
   return SS_OK;
 }
 
+// Keeps only the keys with at least min_posting_count postings (over all levels) -- the device image spends a directory
+// row and a probe row per term and sub-block, which pays for the frequent terms that dominate query cost and not for the
+// long tail of a real vocabulary; queries that touch a dropped term stay on the host's own path.
+extern "C" int ss_index_bin_filter(ss_index_bin* ix, uint64_t min_posting_count, uint32_t* n_terms_kept) {
+  if (!ix) return SS_EINVAL;
+  std::vector<ss_index_bin::Blk> blocks;
+  std::vector<uint64_t> keys, off;
+  for (size_t t = 0; t < ix->keys.size(); t++) {
+    uint64_t n = 0;
+    for (uint64_t b = ix->term_block_off[t]; b < ix->term_block_off[t + 1]; b++) n += (uint64_t)ix->blocks[b].b.posting_count_m1 + 1u;
+    if (n < min_posting_count) continue;
+    keys.push_back(ix->keys[t]);
+    off.push_back(blocks.size());
+    for (uint64_t b = ix->term_block_off[t]; b < ix->term_block_off[t + 1]; b++) blocks.push_back(ix->blocks[b]);
+  }
+  off.push_back(blocks.size());
+  ix->blocks.swap(blocks);
+  ix->keys.swap(keys);
+  ix->term_block_off.swap(off);
+  if (n_terms_kept) *n_terms_kept = (uint32_t)ix->keys.size();
+  return SS_OK;
+}
+
 extern "C" int ss_index_bin_close(ss_index_bin* ix) {
   delete ix;
   return SS_OK;

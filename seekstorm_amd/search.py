@@ -99,12 +99,14 @@ class IndexBin:
     """Parsed view of a shard's index.bin (ss_index_bin_*; host only -- works without a GPU).  Term id = rank of the
     key_hash among the SingleTerm keys; `term_of_key` is the lookup the Rust side does after hashing the term."""
 
-    def __init__(self, data, indexed_field_count=1, key_head_size=20, segment_number_bits=11):
+    def __init__(self, data, indexed_field_count=1, key_head_size=20, segment_number_bits=11, min_posting_count=0):
         self._buf = np.frombuffer(bytes(data), np.uint8).copy()  # the handle borrows these bytes
         h = C.c_void_p()
         N.check(N.lib().ss_index_bin_open(self._buf.ctypes.data, len(self._buf), indexed_field_count, key_head_size,
                                           segment_number_bits, C.byref(h)), "ss_index_bin_open")
         self._h = h
+        if min_posting_count:  # device image for the frequent terms only; the tail stays with the host's own path
+            N.check(N.lib().ss_index_bin_filter(h, int(min_posting_count), None), "ss_index_bin_filter")
         nd, ps = C.c_uint64(), C.c_uint64()
         nl, nt, ng = C.c_uint32(), C.c_uint32(), C.c_uint32()
         N.check(N.lib().ss_index_bin_info(h, C.byref(nd), C.byref(ps), C.byref(nl), C.byref(nt), C.byref(ng)), "ss_index_bin_info")

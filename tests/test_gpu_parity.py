@@ -542,3 +542,42 @@ def test_reference_count_assertions_on_the_hip_path(S, O):
     ro = sh.search_vector_shard(rows[1], 10, strict=True)
     assert ro.result_count == 3 and ro.result_count_total == 3 and ro.results[0].doc_id == 1 and abs(ro.results[0].score - 1.0) < 1e-5
     sh.close()
+
+
+def test_concurrent_callers_share_a_shard(S, O, lex):
+    """search.rs callers hold only the shard READ lock and arrive from many runtime threads: lexical, vector and
+    tombstone calls from 12 threads on one handle, answers equal to the single-threaded ones"""
+    import threading
+    sh, osh, n_docs = lex
+    rows = O.vec_gen(O.VEC_SEED, 0, 3000, 64)
+    qs = O.vec_gen(O.VECQ_SEED, 0, 4, 64)
+    vs = S.Shard(0)
+    vs.upload_vectors(rows)
+    tl = [[10, 9, 8], [7, 3], [5], [9, 8, 7, 6, 5]]
+    want_l = {i: sh.search_lexical_batch(sh.make_queries([t], S.QueryType.Union), 10) for i, t in enumerate(tl)}
+    want_v = {i: vs.search_vector_batch(qs[i:i + 1], 20) for i in range(4)}
+    errors = []
+
+    def worker(seed):
+        try:
+            rng = np.random.default_rng(seed)
+            for _ in range(25):
+                i = int(rng.integers(0, 4))
+                if rng.random() < 0.5:
+                    got = sh.search_lexical_batch(sh.make_queries([tl[i]], S.QueryType.Union), 10)
+                    ok = all(np.array_equal(a, b) for a, b in zip(got, want_l[i]))
+                else:
+                    got = vs.search_vector_batch(qs[i:i + 1], 20)
+                    ok = all(np.array_equal(a, b) for a, b in zip(got, want_v[i]))
+                if not ok:
+                    errors.append((seed, i))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(s,)) for s in range(12)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:3]
+    vs.close()

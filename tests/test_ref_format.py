@@ -158,6 +158,15 @@ def test_index_bin_walk(head, bits):
         assert np.array_equal(d, docs) and np.array_equal(f, tfs)
     assert ix.term_of_key(terms[0][0] + 8) is None
     ix.close()
+    # frequent terms only: the tail of the vocabulary is dropped and the term ids re-ranked
+    ix = S.IndexBin(data, 1, head, bits, min_posting_count=1000)
+    kept = [t for t in terms if len(t[1]) >= 1000]
+    assert ix.term_count == len(kept) == 3 and [int(k) for k in ix.term_keys] == [t[0] for t in kept]
+    for t, (key, docs, tfs) in enumerate(kept):
+        d, f = ix.postings(t)
+        assert np.array_equal(d, docs) and np.array_equal(f, tfs)
+    assert all(ix.term_of_key(t[0]) is None for t in terms if len(t[1]) < 1000)
+    ix.close()
 
 
 def test_index_bin_rejects_garbage():
