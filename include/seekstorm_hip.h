@@ -68,6 +68,17 @@ int ss_shard_sync(ss_shard* s);
  * the HBM image (sub-block CSR of packed postings, bm25_component_cache per commit.rs:318-325). */
 int ss_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t n_terms,
                    const uint64_t* term_offsets, const uint32_t* doc_ids, const uint16_t* tfs);
+/* Several indexed fields (BM25F, get_bm25f_multiterm_multifield, add_result.rs:1171-1426): a posting is (term, doc, field, tf)
+ * and a doc's score sums  boost[field] * idf * tf (K+1) / (tf + comp[len_byte(doc, field)])  over the query terms and the
+ * fields they occur in; idf from the docs containing the term in any field (ss_bm25_term_df returns that); an
+ * intersection needs every term in at least one field.  doclen_bytes is [n_fields][n_docs] (level_index
+ * document_length_compressed_array[field], index.rs:770-776); the postings of a term are sorted by (doc, field);
+ * boost = schema boost per field (NULL = 1).  Queries are the same ss_bm25_query; at most 32 / n_fields terms per query
+ * (NOT terms included), intersections of at most 8 terms.  n_fields <= 8. */
+int ss_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen_bytes, const float* boost,
+                          uint32_t n_terms, const uint64_t* term_offsets, const uint32_t* doc_ids, const uint8_t* field_ids,
+                          const uint16_t* tfs);
+
 /* Tombstones = the shard's delete_hashset (index.rs:1594): shard-local doc ids, as delete.bin stores them (a plain
  * stream of u64, index.rs:3798-3809 -- the file's bytes can be passed as they are) or as delete_document adds them
  * (index.rs:5110).  The call replaces the set (n = 0 clears it); it applies to lexical and vector searches alike: a

@@ -89,6 +89,9 @@ def lib():
     L.so_vec_search_del.restype = C.c_uint32
     L.so_vec_search_del.argtypes = [f32p, C.c_uint64, C.c_uint32, u32p, f32p, C.c_uint32, C.c_float, C.c_int, u64p,
                                     C.c_uint64, u32p, f32p, u64p, u64p]
+    L.so_search_fields_exhaustive.restype = C.c_uint32
+    L.so_search_fields_exhaustive.argtypes = [C.c_uint64, C.c_uint32, u8p, f32p, u64p, u32p, u8p, u16p, C.c_uint32, u32p,
+                                              C.c_uint32, u32p, C.c_int, C.c_uint32, u64p, C.c_uint64, u32p, f32p, u64p, f32p]
     L.so_quantize_f32_to_i8.argtypes = [f32p, C.c_uint32, C.c_void_p]
     L.so_vec_search_i8.restype = C.c_uint32
     L.so_vec_search_i8.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, u32p, f32p, C.c_void_p, C.c_int, C.c_float, C.c_uint32,
@@ -247,6 +250,27 @@ def vec_search(rows, query, k, row_doc_ids=None, threshold_raw=-3.40282346638528
                                 threshold_raw, 1 if simd_order else 0, _p(dl, u64p) if len(dl) else None, len(dl),
                                 _p(od, u32p), _p(os_, f32p), C.byref(tot), C.byref(obs))
     return od[:n].copy(), os_[:n].copy(), tot.value, obs.value
+
+
+def search_fields_exhaustive(n_docs, doclen_fields, boost, offs, docs, fields, tfs, terms, op, k, not_terms=(), deleted=()):
+    """BM25F ground truth over several indexed fields (add_result.rs:1171-1426) -> (doc ids, scores, total, avgdl)"""
+    dl = np.ascontiguousarray(doclen_fields, np.uint8)
+    b = None if boost is None else np.ascontiguousarray(boost, np.float32)
+    offs = np.ascontiguousarray(offs, np.uint64)
+    docs = np.ascontiguousarray(docs, np.uint32)
+    fields = np.ascontiguousarray(fields, np.uint8)
+    tfs = np.ascontiguousarray(tfs, np.uint16)
+    q = np.ascontiguousarray(terms, np.uint32)
+    nq_ = np.ascontiguousarray(not_terms, np.uint32)
+    de = np.ascontiguousarray(deleted, np.uint64)
+    od = np.empty(max(k, 1), np.uint32)
+    os_ = np.empty(max(k, 1), np.float32)
+    tot, avg = C.c_uint64(), C.c_float()
+    n = lib().so_search_fields_exhaustive(n_docs, dl.shape[0], _p(dl.reshape(-1), u8p), _p(b, f32p), _p(offs, u64p), _p(docs, u32p),
+                                          _p(fields, u8p), _p(tfs, u16p), len(q), _p(q, u32p), len(nq_),
+                                          _p(nq_, u32p) if len(nq_) else None, op, k, _p(de, u64p) if len(de) else None, len(de),
+                                          _p(od, u32p), _p(os_, f32p), C.byref(tot), C.byref(avg))
+    return od[:n].copy(), os_[:n].copy(), tot.value, avg.value
 
 
 def quantize_i8(v):

@@ -784,3 +784,51 @@ uint32_t so_merge(int mode, const uint64_t* ld, const float* ls, uint32_t nl, co
   free(out);
   return w;
 }
+
+/* ------------------------------------------------------------------ several indexed fields (BM25F)
+ * get_bm25f_multiterm_multifield (add_result.rs:1171-1426), SingleTerm keys: for every query term present in the doc and
+ * every field it occurs in:  bm25f += boost[field] * idf * (tf (K+1) / (tf + comp[len_byte(doc, field)]) + SIGMA),
+ * fields in ascending order inside a term, terms in query order.  comp = the ONE bm25_component_cache of the shard
+ * (avgdl = positions_sum over all fields / indexed_doc_count, commit.rs:318-325).  idf from the docs containing the term in
+ * any field (posting_count).  Intersection: every term in at least one field.  Brute force, exact top-k by (score desc,
+ * doc asc): the ground truth of the multi-field parity tests.  Entries of a term sorted by (doc, field). */
+uint32_t so_search_fields_exhaustive(uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen /*[n_fields][n_docs]*/,
+                                     const float* boost, const uint64_t* off, const uint32_t* docs, const uint8_t* fields,
+                                     const uint16_t* tfs, uint32_t nq, const uint32_t* qt, uint32_t n_not,
+                                     const uint32_t* not_terms, int op, uint32_t k, const uint64_t* deleted, uint64_t n_deleted,
+                                     uint32_t* od, float* os, uint64_t* total, float* out_avgdl) {
+  uint64_t psum = 0;
+  for (uint64_t i = 0; i < n_docs * n_fields; i++) psum += so_byte4_to_int(doclen[i]);
+  const float avgdl = so_avgdl(psum, n_docs);
+  if (out_avgdl) *out_avgdl = avgdl;
+  float comp[256];
+  so_bm25_component_cache(avgdl, comp);
+  float* sc = (float*)calloc(n_docs ? n_docs : 1, sizeof(float));
+  uint8_t* cnt = (uint8_t*)calloc(n_docs ? n_docs : 1, 1);
+  for (uint32_t t = 0; t < nq; t++) {
+    uint64_t df = 0;
+    for (uint64_t i = off[qt[t]]; i < off[qt[t] + 1]; i++) if (i == off[qt[t]] || docs[i] != docs[i - 1]) df++;
+    const float idf = so_idf(n_docs, df);
+    for (uint64_t i = off[qt[t]]; i < off[qt[t] + 1]; i++) {
+      const uint32_t d = docs[i];
+      const float w = boost ? boost[fields[i]] : 1.0f;
+      sc[d] += w * idf * ((float)tfs[i] * (SO_K + 1.0f) / ((float)tfs[i] + comp[doclen[(uint64_t)fields[i] * n_docs + d]]) + SO_SIGMA);
+      if (i == off[qt[t]] || docs[i] != docs[i - 1]) cnt[d]++;
+    }
+  }
+  for (uint32_t j = 0; j < n_not; j++)
+    for (uint64_t i = off[not_terms[j]]; i < off[not_terms[j] + 1]; i++) cnt[docs[i]] = 0xFF;
+  for (uint64_t i = 0; i < n_deleted; i++) if (deleted[i] < n_docs) cnt[deleted[i]] = 0xFF;
+  uint64_t m = 0;
+  for (uint64_t d = 0; d < n_docs; d++) if (cnt[d] != 0xFF && (op == SO_OP_AND ? cnt[d] == nq : cnt[d] > 0)) m++;
+  so_sd* v = (so_sd*)malloc((m ? m : 1) * sizeof(so_sd));
+  uint64_t j = 0;
+  for (uint64_t d = 0; d < n_docs; d++)
+    if (cnt[d] != 0xFF && (op == SO_OP_AND ? cnt[d] == nq : cnt[d] > 0)) { v[j].score = sc[d]; v[j].doc = (uint32_t)d; j++; }
+  qsort(v, m, sizeof(so_sd), sd_cmp);
+  uint32_t n = (uint32_t)(m < k ? m : k);
+  for (uint32_t i = 0; i < n; i++) { od[i] = v[i].doc; os[i] = v[i].score; }
+  if (total) *total = m;
+  free(v); free(cnt); free(sc);
+  return n;
+}

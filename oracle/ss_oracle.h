@@ -90,6 +90,13 @@ uint32_t so_search_lex_exhaustive_not(const so_shard*, uint32_t n_q_terms, const
  * (score desc, doc asc); also returns the exact match count. */
 uint32_t so_search_lex_exhaustive(const so_shard*, uint32_t n_q_terms, const uint32_t* q_terms, int op,
                                   uint32_t k, uint32_t* out_doc, float* out_score, uint64_t* out_total);
+/* several indexed fields (BM25F, get_bm25f_multiterm_multifield add_result.rs:1171-1426): brute-force ground truth.
+ * doclen [n_fields][n_docs]; postings of a term sorted by (doc, field); boost NULL = 1; deleted = doc ids or NULL */
+uint32_t so_search_fields_exhaustive(uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost,
+                                     const uint64_t* off, const uint32_t* docs, const uint8_t* fields, const uint16_t* tfs,
+                                     uint32_t n_q_terms, const uint32_t* q_terms, uint32_t n_not, const uint32_t* not_terms,
+                                     int op, uint32_t k, const uint64_t* deleted, uint64_t n_deleted, uint32_t* out_doc,
+                                     float* out_score, uint64_t* out_total, float* out_avgdl);
 /* statistics for the roofline's algorithmic bytes: sum df, #blocks touched */
 void so_query_stats(const so_shard*, uint32_t n_q_terms, const uint32_t* q_terms, uint64_t* sum_df,
                     uint64_t* sum_blocks);

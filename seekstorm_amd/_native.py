@@ -52,6 +52,7 @@ SYMBOLS = [
     ("ss_shard_sync", C.c_int, [C.c_void_p]),
     ("ss_set_deleted", C.c_int, [C.c_void_p, u64p, C.c_uint64]),
     ("ss_bm25_upload", C.c_int, [C.c_void_p, C.c_uint64, u8p, C.c_uint32, u64p, u32p, u16p]),
+    ("ss_bm25_upload_fields", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, u8p, f32p, C.c_uint32, u64p, u32p, u8p, u16p]),
     ("ss_ref_decode_block", C.c_int, [C.c_void_p, u16p, u16p]),
     ("ss_bm25_upload_ref_blocks", C.c_int, [C.c_void_p, C.c_uint64, u8p, C.c_uint32, u64p, C.c_void_p]),
     ("ss_index_bin_open", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),

@@ -69,6 +69,39 @@ __global__ void bm25_final_kernel(const u64* __restrict__ keys, const u64* __res
   }
 }
 
+// ---------------------------------------------------------------- public queries -> virtual terms (one thread per query)
+__global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery* __restrict__ vq, uint32_t nq, uint32_t n_fields,
+                                 const unsigned long long* __restrict__ term_base, const float* __restrict__ boost) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  const ss_bm25_query Q = q[i];
+  bm_vquery V;
+  const uint32_t np = Q.n_terms, n_not = bm_q_nnot(Q.op);
+  const bool is_and = bm_q_op(Q.op) == SS_OP_INTERSECTION && np > 1;
+  const bool mask = np <= 8;  // 9-10 terms (single field only, checked on the host): count instead of bits
+  uint32_t n = 0;
+  for (uint32_t t = 0; t < np + n_not; t++) {
+    if (t == np) V.n_terms = n;
+    for (uint32_t f = 0; f < n_fields; f++) {
+      const uint32_t v = Q.term[t] * n_fields + f;
+      // a term without postings in a field contributes nothing there (one field: kept, the zero-length list is harmless)
+      if (n_fields > 1 && term_base[v + 1] == term_base[v]) continue;
+      if (n >= (uint32_t)BM_MAX_VTERMS) break;
+      V.term[n] = v;
+      V.idf[n] = t < np ? (n_fields > 1 ? boost[f] * Q.idf[t] : Q.idf[t]) : 0.f;  // weight * plo.idf, add_result.rs:1253-1261
+      V.and_val[n] = (is_and && t < np) ? (uint8_t)(mask ? (1u << t) : 0xFFu) : (uint8_t)0;
+      n++;
+    }
+  }
+  if (n_not == 0) V.n_terms = n;
+  const uint32_t n_scored = V.n_terms;
+  V.op = (np > 1 ? bm_q_op(Q.op) : (uint32_t)SS_OP_UNION) | ((n - n_scored) << 8);
+  V.n_groups = np;
+  V.and_target = is_and ? (mask ? (1u << np) - 1u : np) : 0u;
+  for (uint32_t j = n; j < (uint32_t)BM_MAX_VTERMS; j++) { V.term[j] = 0; V.idf[j] = 0.f; V.and_val[j] = 0; }
+  vq[i] = V;
+}
+
 // ---------------------------------------------------------------- host side
 int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t* d_out_doc,
                     float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, bool has_or,
@@ -84,7 +117,13 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   // of intersections fall out of it, exact counts of unions are popcounts over the index's bit records
   // (bm25_union_count_kernel).  Exhaustive (bm25_fast.hip): > 4 scored terms, k > 128, no probe index, or
   // SS_BM25_EXHAUSTIVE selected.
-  const bool pruned = s->bm_strategy != SS_BM25_EXHAUSTIVE && s->d_probe && s->d_umax &&
+  // Several indexed fields: every query term is a union of its (term, field) lists -- the pruned kernel ranks unions of
+  // virtual terms as they are; an intersection of unions is left to the scan kernels' match masks.
+  const uint32_t F = s->bm_n_fields;
+  nt_max *= F;
+  np_max *= F;
+  if (F > 1) has_or = true;
+  const bool pruned = s->bm_strategy != SS_BM25_EXHAUSTIVE && s->d_probe && s->d_umax && !(F > 1 && has_and) &&
                       np_max >= 1 && np_max <= 4 && KPL <= 2;  // NOT terms are probed outside the template
   if (!pruned && s->bm_strategy == SS_BM25_PRUNED) return SS_ENOTSUP;
   // Partitions per query (one wave each).  The grid is a whole number of "rounds" of resident waves: a partially
@@ -110,12 +149,23 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   uint32_t* tau = (uint32_t*)(total + nq);
   SS_HIP(hipMemsetAsync(total, 0, (nq + tau_words) * sizeof(u64), st));
 
+  // queries over (term, field) posting lists
+  if ((size_t)nq * sizeof(bm_vquery) > s->vq_cap) {
+    if (s->d_vq) (void)hipFree(s->d_vq);
+    s->d_vq = nullptr;
+    s->vq_cap = 0;
+    SS_HIP(hipMalloc(&s->d_vq, (size_t)nq * sizeof(bm_vquery)));
+    s->vq_cap = (size_t)nq * sizeof(bm_vquery);
+  }
+  bm_expand_kernel<<<(nq + 127) / 128, 128, 0, st>>>(d_q, (bm_vquery*)s->d_vq, nq, s->bm_n_fields,
+                                                    (const unsigned long long*)s->d_term_base, s->d_boost);
+
   BmParams p;
   p.post = s->d_post;
   p.term_base = (const unsigned long long*)s->d_term_base;
   p.sub_off = s->d_sub_off;
   p.comp = s->d_comp;
-  p.q = d_q;
+  p.q = (const bm_vquery*)s->d_vq;
   p.part_keys = bufA;
   p.total = total;
   p.tau = tau;

@@ -14,7 +14,7 @@ struct BmParams {
   const unsigned long long* term_base;
   const uint32_t* sub_off;
   const float* comp;
-  const ss_bm25_query* q;
+  const bm_vquery* q;              // expanded queries (bm25.hip bm_expand_kernel)
   unsigned long long* part_keys;   // [nq][P][KS]
   unsigned long long* total;       // [nq] exact match counts
   uint32_t* tau;                   // [nq] shared admission threshold: bits of the best k-th score any partition holds
@@ -214,7 +214,7 @@ __device__ __attribute__((noinline)) f32x4 bm_big_tf_weights(u32x4 pv, f32x4 wp,
 // Plain gather / scatter: the docs of one term are distinct and the tile is private to the wave, whose LDS operations
 // execute in order.  NULL postings (padding, out-of-range lanes) add 0 to the dump slot.  Returns max of the new scores.
 template <bool HAS_AND>
-__device__ __forceinline__ float bm_chunk(const u32x4 q, float idf, const BmLds& L, bool is_and, float mx, BmExc X, uint32_t term,
+__device__ __forceinline__ float bm_chunk(const u32x4 q, float idf, const BmLds& L, uint32_t and_val, float mx, BmExc X, uint32_t term,
                                           uint32_t doc0) {
   const uint32_t pv[4] = {q.x, q.y, q.z, q.w};
   uint32_t ao[4], co[4], cold[4];
@@ -224,7 +224,7 @@ __device__ __forceinline__ float bm_chunk(const u32x4 q, float idf, const BmLds&
     ao[x] = (pv[x] & 0x7FFCu) + L.accb;
     old[x] = lds_ldf(ao[x]);
     wp[x] = lds_ldf(((pv[x] >> 16) & 0x3FFCu) + L.lut);
-    if (HAS_AND && is_and) {
+    if (HAS_AND && and_val) {
       co[x] = ((pv[x] & 0x7FFCu) >> 2) + L.cnt;
       cold[x] = lds_ld8(co[x]);
     }
@@ -238,7 +238,7 @@ __device__ __forceinline__ float bm_chunk(const u32x4 q, float idf, const BmLds&
     const float nw = old[x] + idf * wp[x];
     lds_stf(ao[x], nw);
     mx = fmaxf(mx, nw);
-    if (HAS_AND && is_and) lds_st8(co[x], cold[x] + 1u);
+    if (HAS_AND && and_val) lds_st8(co[x], and_val == 0xFFu ? cold[x] + 1u : (cold[x] | and_val));  // count one more | set the term's bit
   }
   return mx;
 }

@@ -20,7 +20,7 @@ template <int NT> struct FastCfg { static constexpr int CPT = NT <= 2 ? 4 : 3; s
 
 #define BM_KERNEL_ARGS                                                                                              \
   const uint32_t *__restrict__ post, const unsigned long long *__restrict__ term_base,                             \
-      const uint32_t *__restrict__ sub_off, const float *__restrict__ comp_g, const ss_bm25_query *__restrict__ qs, \
+      const uint32_t *__restrict__ sub_off, const float *__restrict__ comp_g, const bm_vquery *__restrict__ qs, \
       unsigned long long *__restrict__ part_keys, unsigned long long *__restrict__ total, uint32_t *tau,            \
       const unsigned long long *__restrict__ exc_off, const uint32_t *__restrict__ exc_doc,                         \
       const uint32_t *__restrict__ exc_tf, const uint32_t *__restrict__ del, uint32_t del_words, uint32_t n_sub,    \
@@ -64,9 +64,10 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
   const uint32_t a = blockIdx.x * WAVES + w;
   if (a < nq * P) {
     const uint32_t qi = a % nq, part = a / nq;
-    const ss_bm25_query* __restrict__ Q = qs + qi;
-    const uint32_t np = Q->n_terms, nt = np + bm_q_nnot(Q->op);  // positive terms, then the NOT terms
-    const bool is_and = HAS_AND && (bm_q_op(Q->op) == SS_OP_INTERSECTION) && np > 1;
+    const bm_vquery* __restrict__ Q = qs + qi;
+    const uint32_t np = Q->n_terms, nt = np + bm_q_nnot(Q->op);  // scored (virtual) terms, then the NOT terms
+    const uint32_t nt_and = HAS_AND ? Q->and_target : 0u;        // 0: union; else what a doc's match byte must reach
+    const bool is_and = nt_and != 0u;
     // Per-term state in scalar registers: descriptor base, idf and a rolling window of three segment boundaries.
     // The boundaries themselves are fetched 64 at a time into vector registers (lane i = sub-block s0 + i, one
     // coalesced load per term every BLK items) and picked with v_readlane, so the item loop carries no scalar loads,
@@ -76,13 +77,14 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
     const uint32_t* tptr[NT];
     const uint32_t* rowp[NT];
     float idf[NT];
-    uint32_t tid_[NT];
+    uint32_t tid_[NT], av[NT];  // av: what a posting of the term does to its doc's match byte (0: nothing)
     const BmExc X{exc_off, exc_doc, exc_tf};
 #pragma unroll
     for (int t = 0; t < NT; t++) {
       const bool have = (uint32_t)t < nt;
       const uint32_t term = have ? Q->term[t] : n_terms;
       tid_[t] = term;
+      av[t] = (is_and && (uint32_t)t < np) ? Q->and_val[t] : 0u;
       idf[t] = have ? ((uint32_t)t < np ? Q->idf[t] : BM_NOT_IDF) : 0.f;
       tptr[t] = post + term_base[term] * 4ull;
       rowp[t] = sub_off + (size_t)term * row_len;
@@ -96,7 +98,6 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
     T.worst = 0ull;
     T.wsc = -1.0f;
     T.matched = 0;
-    const uint32_t nt_and = is_and ? np : 0u;
 
     // RC loads per item; lanes (and whole chunks) past the segment end are out of range: zeros, no memory access
     auto issue_loads = [&](u32x4(&v)[RC], const uint32_t (&b0)[NT], const uint32_t (&b1)[NT]) {
@@ -189,12 +190,12 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
 #pragma unroll
           for (int c = 0; c < CPT; c++)
             if ((uint32_t)c * 64u < n16)
-              mx = bm_chunk<HAS_AND>(cur[t * CPT + c], idf[t], L, is_and && (uint32_t)t < np, mx, X, tid_[t], s << BM_SUB_LOG2);
+              mx = bm_chunk<HAS_AND>(cur[t * CPT + c], idf[t], L, av[t], mx, X, tid_[t], s << BM_SUB_LOG2);
           if (n16 > (uint32_t)CPT * 64u) {  // df above ~CPT/16 of the docs
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[t], 0, (int)(B1[t] << 4), BM_RSRC_FLAGS);
             for (uint32_t u = B0[t] + CPT * 64u; u < B1[t]; u += 64u) {
               const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0);
-              mx = bm_chunk<HAS_AND>(q, idf[t], L, is_and && (uint32_t)t < np, mx, X, tid_[t], s << BM_SUB_LOG2);
+              mx = bm_chunk<HAS_AND>(q, idf[t], L, av[t], mx, X, tid_[t], s << BM_SUB_LOG2);
             }
           }
         }
@@ -251,9 +252,10 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
 
   for (uint32_t a = blockIdx.x * WAVES + w; a < A; a += total_waves) {
     const uint32_t qi = a % nq, part = a / nq;
-    const ss_bm25_query* __restrict__ Q = qs + qi;
+    const bm_vquery* __restrict__ Q = qs + qi;
     const uint32_t np = Q->n_terms, nt = np + bm_q_nnot(Q->op);
-    const bool is_and = HAS_AND && (bm_q_op(Q->op) == SS_OP_INTERSECTION) && np > 1;
+    const uint32_t nt_and = HAS_AND ? Q->and_target : 0u;
+    const bool is_and = nt_and != 0u;
     const uint32_t s_begin = (uint32_t)(((u64)n_sub * part) / P);
     const uint32_t s_end = (uint32_t)(((u64)n_sub * (part + 1)) / P);
     BmTop<KPL> T;
@@ -262,7 +264,6 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
     T.worst = 0ull;
     T.wsc = -1.0f;
     T.matched = 0;
-    const uint32_t nt_and = is_and ? np : 0u;
 
     for (uint32_t s = s_begin; s < s_end; s++) {
       float mx = 0.f;
@@ -272,13 +273,14 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
         uint32_t b0[G], b1[G];
         float idf[G];
         const uint32_t* tp[G];
-        uint32_t tid_[G];
+        uint32_t tid_[G], av[G];
         const BmExc X{exc_off, exc_doc, exc_tf};
 #pragma unroll
         for (int t = 0; t < G; t++) {
           const bool have = g0 + t < nt;
           const uint32_t term = have ? Q->term[have ? g0 + t : 0] : n_terms;
           tid_[t] = term;
+          av[t] = (is_and && g0 + t < np) ? Q->and_val[have ? g0 + t : 0] : 0u;
           idf[t] = have ? (g0 + t < np ? Q->idf[have ? g0 + t : 0] : BM_NOT_IDF) : 0.f;
           tp[t] = post + term_base[term] * 4ull;
           b0[t] = sub_off[term * row_len + s];
@@ -295,12 +297,12 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
 #pragma unroll
           for (int c = 0; c < CPT; c++)
             if ((uint32_t)c * 64u < n16)
-              mx = bm_chunk<HAS_AND>(v[t * CPT + c], idf[t], L, is_and && g0 + t < np, mx, X, tid_[t], s << BM_SUB_LOG2);
+              mx = bm_chunk<HAS_AND>(v[t * CPT + c], idf[t], L, av[t], mx, X, tid_[t], s << BM_SUB_LOG2);
           if (n16 > (uint32_t)CPT * 64u) {
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tp[t], 0, (int)(b1[t] << 4), BM_RSRC_FLAGS);
             for (uint32_t u = b0[t] + CPT * 64u; u < b1[t]; u += 64u) {
               const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0);
-              mx = bm_chunk<HAS_AND>(q, idf[t], L, is_and && g0 + t < np, mx, X, tid_[t], s << BM_SUB_LOG2);
+              mx = bm_chunk<HAS_AND>(q, idf[t], L, av[t], mx, X, tid_[t], s << BM_SUB_LOG2);
             }
           }
         }

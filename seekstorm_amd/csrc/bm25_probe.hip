@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
     const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base, const uint32_t* __restrict__ sub_off,
     const float* __restrict__ comp_g, const uint2* __restrict__ probe, const uint32_t* __restrict__ probe_z,
     const float* __restrict__ umax,
-    const ss_bm25_query* __restrict__ qs, unsigned long long* __restrict__ part_keys, unsigned long long* __restrict__ total,
+    const bm_vquery* __restrict__ qs, unsigned long long* __restrict__ part_keys, unsigned long long* __restrict__ total,
     uint32_t* tau, const unsigned long long* __restrict__ exc_off, const uint32_t* __restrict__ exc_doc,
     const uint32_t* __restrict__ exc_tf, const uint32_t* __restrict__ del, uint32_t del_words, uint32_t n_sub, uint32_t n_terms,
     uint32_t nq, uint32_t P, uint32_t k, uint32_t count) {
@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
   const uint32_t a = blockIdx.x * PB_WAVES + w;
   if (a >= nq * P) return;
   const uint32_t qi = a % nq, part = a / nq;
-  const ss_bm25_query* __restrict__ Q = qs + qi;
+  const bm_vquery* __restrict__ Q = qs + qi;
   const uint32_t nt = Q->n_terms, n_not = FILT ? bm_q_nnot(Q->op) : 0u;  // NT covers the query terms; NOT terms are probed at the end
   const bool is_and = (bm_q_op(Q->op) == SS_OP_INTERSECTION) && nt > 1;
   const uint32_t row_len = n_sub + 1;
@@ -395,36 +395,32 @@ static int launch_probe(const BmParams& p, const uint2* probe, const uint32_t* p
 // kernel, which counts intersections and single terms while it ranks them.
 constexpr int CNT_WAVES = 4, CNT_UNROLL = 4;
 __global__ void __launch_bounds__(CNT_WAVES * 64) bm25_union_count_kernel(
-    const uint2* __restrict__ probe, const ss_bm25_query* __restrict__ qs, unsigned long long* __restrict__ total,
+    const uint2* __restrict__ probe, const bm_vquery* __restrict__ qs, unsigned long long* __restrict__ total,
     const uint32_t* __restrict__ del, uint32_t del_words, uint32_t n_sub, uint32_t nq, uint32_t P) {
   const int lane = threadIdx.x & 63;
   const uint32_t a = blockIdx.x * CNT_WAVES + (threadIdx.x >> 6);
   if (a >= nq * P) return;
   const uint32_t qi = a % nq, part = a / nq;
-  const ss_bm25_query* __restrict__ Q = qs + qi;
+  const bm_vquery* __restrict__ Q = qs + qi;
   const uint32_t np = Q->n_terms, n_not = bm_q_nnot(Q->op);
   if (bm_q_op(Q->op) != SS_OP_UNION || np < 2) return;
   const uint32_t n_groups = n_sub * (BM_SUB / 64);
   const uint32_t g_begin = (uint32_t)(((u64)n_groups * part) / P), g_end = (uint32_t)(((u64)n_groups * (part + 1)) / P);
-  const uint2* rows[SS_MAX_QUERY_TERMS];
-#pragma unroll
-  for (int t = 0; t < SS_MAX_QUERY_TERMS; t++)
-    rows[t] = probe + (size_t)Q->term[(uint32_t)t < np + n_not ? t : 0] * n_groups;
   uint32_t cnt = 0;
   for (uint32_t g0 = g_begin; g0 < g_end; g0 += 64u * CNT_UNROLL) {
     u64 acc[CNT_UNROLL], neg[CNT_UNROLL];
 #pragma unroll
     for (int u = 0; u < CNT_UNROLL; u++) { acc[u] = 0ull; neg[u] = 0ull; }
-#pragma unroll
-    for (int t = 0; t < SS_MAX_QUERY_TERMS; t++) {
-      if ((uint32_t)t >= np + n_not) break;
+#pragma unroll 4
+    for (uint32_t t = 0; t < np + n_not; t++) {
+      const uint2* __restrict__ row = probe + (size_t)Q->term[t] * n_groups;
 #pragma unroll
       for (int u = 0; u < CNT_UNROLL; u++) {
         const uint32_t g = g0 + 64u * u + lane;
         uint2 r = make_uint2(0u, 0u);
-        if (g < g_end) r = rows[t][g];
+        if (g < g_end) r = row[g];
         const u64 b = ((u64)r.y << 32) | r.x;
-        if ((uint32_t)t < np) acc[u] |= b; else neg[u] |= b;
+        if (t < np) acc[u] |= b; else neg[u] |= b;
       }
     }
     if (del) {

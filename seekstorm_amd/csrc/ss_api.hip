@@ -62,12 +62,12 @@ static void free_vec(ss_shard* s) {
   s->n_rows = s->n_rows_pad = 0; s->dim = s->dim_pad = s->dim_pad8 = 0; s->vec_multi_record = false;
 }
 static void free_bm25(ss_shard* s) {
-  void* ptrs[] = {s->d_post, s->d_term_base, s->d_sub_off, s->d_comp, s->d_probe, s->d_probe_z, s->d_umax, s->d_exc_off, s->d_exc_doc, s->d_exc_tf};
+  void* ptrs[] = {s->d_post, s->d_term_base, s->d_sub_off, s->d_comp, s->d_probe, s->d_probe_z, s->d_umax, s->d_exc_off, s->d_exc_doc, s->d_exc_tf, s->d_boost};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->d_post = nullptr; s->d_term_base = nullptr; s->d_sub_off = nullptr; s->d_comp = nullptr;
   s->d_probe = nullptr; s->d_probe_z = nullptr; s->d_umax = nullptr; s->d_exc_off = nullptr; s->d_exc_doc = nullptr; s->d_exc_tf = nullptr;
-  s->bm_n_docs = 0; s->bm_n_terms = 0; s->bm_n_sub = 0; s->bm_n_post = 0;
-  s->h_df.clear(); s->bm_n_post_pad = 0;
+  s->bm_n_docs = 0; s->bm_n_terms = 0; s->bm_n_sub = 0; s->bm_n_post = 0; s->bm_n_fields = 1; s->d_boost = nullptr;
+  s->h_df.clear(); s->h_df_real.clear(); s->bm_n_post_pad = 0;
 }
 
 int ss_shard_destroy(ss_shard* s) {
@@ -76,7 +76,7 @@ int ss_shard_destroy(ss_shard* s) {
   (void)hipStreamSynchronize(s->stream);
   free_vec(s);
   free_bm25(s);
-  void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_part, s->d_deleted};
+  void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_part, s->d_deleted, s->d_vq};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int kx = 0; kx < 2; kx++)
     for (auto& pr : s->prof.pending[kx]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -134,6 +134,56 @@ int ssi_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen, uint32_
 }
 
 extern "C" {
+
+// Several indexed fields (BM25F, get_bm25f_multiterm_multifield add_result.rs:1171-1426): a posting = (term, doc, field, tf).
+// The image holds one posting list per (term, field); a query term is expanded over its fields on the device.
+int ss_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost,
+                          uint32_t n_terms, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
+                          const uint16_t* tfs) {
+  if (!s || !doclen || !offs || n_docs == 0 || n_terms == 0 || n_fields == 0 || n_fields > 8) return SS_EINVAL;
+  if (offs[n_terms] && (!docs || !fields || !tfs)) return SS_EINVAL;
+  if ((uint64_t)n_terms * n_fields > 0x7FFFFFFFull) return SS_ENOTSUP;
+  // (term, field) lists: entries of a term are sorted by (doc, field); a stable split by field keeps each list sorted by doc
+  const uint32_t nv = n_terms * n_fields;
+  std::vector<uint64_t> voff((size_t)nv + 1, 0), df_real(n_terms, 0);
+  for (uint32_t t = 0; t < n_terms; t++) {
+    if (offs[t + 1] < offs[t]) return SS_EINVAL;
+    for (uint64_t j = offs[t]; j < offs[t + 1]; j++) {
+      if (fields[j] >= n_fields) return SS_EINVAL;
+      if (j > offs[t] && (docs[j] < docs[j - 1] || (docs[j] == docs[j - 1] && fields[j] <= fields[j - 1]))) return SS_EINVAL;
+      voff[(size_t)t * n_fields + fields[j] + 1]++;
+      if (j == offs[t] || docs[j] != docs[j - 1]) df_real[t]++;  // docs containing the term in any field: the df of idf
+    }
+  }
+  for (uint32_t v = 0; v < nv; v++) voff[v + 1] += voff[v];
+  std::vector<uint32_t> vdocs(offs[n_terms]);
+  std::vector<uint16_t> vtfs(offs[n_terms]);
+  std::vector<uint64_t> cur(voff.begin(), voff.end() - 1);
+  for (uint32_t t = 0; t < n_terms; t++)
+    for (uint64_t j = offs[t]; j < offs[t + 1]; j++) {
+      const uint64_t w = cur[(size_t)t * n_fields + fields[j]]++;
+      vdocs[w] = docs[j];
+      vtfs[w] = tfs[j];
+    }
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  SS_HIP(hipStreamSynchronize(s->stream));
+  free_bm25(s);
+  s->bm_n_docs = n_docs;
+  s->bm_n_fields = n_fields;
+  s->bm_n_terms = nv;
+  s->bm_n_sub = (uint32_t)((n_docs + BM_SUB - 1) >> BM_SUB_LOG2);
+  int rc = ssi_bm25_build_from_host(s, doclen, voff.data(), vdocs.data(), vtfs.data(), 0);
+  if (rc == SS_OK) {
+    std::vector<float> b(n_fields, 1.0f);
+    if (boost) b.assign(boost, boost + n_fields);
+    if (hipMalloc(&s->d_boost, n_fields * sizeof(float)) != hipSuccess ||
+        hipMemcpy(s->d_boost, b.data(), n_fields * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = SS_EDEVICE;
+    s->h_df_real = df_real;
+  }
+  if (rc) free_bm25(s);
+  return rc;
+}
 
 int ss_bm25_synth(ss_shard* s, uint64_t seed, uint64_t n_docs, uint32_t n_terms, const uint32_t* thresh32,
                   const uint8_t* len_table1024) {
@@ -203,7 +253,7 @@ int ss_bm25_info(ss_shard* s, uint64_t* n_docs, float* avgdl, uint32_t* n_terms,
   if (!s->d_post) return SS_ESTATE;
   if (n_docs) *n_docs = s->bm_n_docs;
   if (avgdl) *avgdl = s->bm_avgdl;
-  if (n_terms) *n_terms = s->bm_n_terms;
+  if (n_terms) *n_terms = s->bm_n_terms / s->bm_n_fields;
   if (n_postings) *n_postings = s->bm_n_post;
   return SS_OK;
 }
@@ -212,8 +262,8 @@ int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df
   if (!s || !terms || !df_out) return SS_EINVAL;
   if (!s->d_post) return SS_ESTATE;
   for (uint32_t i = 0; i < n; i++) {
-    if (terms[i] >= s->bm_n_terms) return SS_EINVAL;
-    df_out[i] = s->h_df[terms[i]];
+    if (terms[i] >= s->bm_n_terms / s->bm_n_fields) return SS_EINVAL;
+    df_out[i] = s->bm_n_fields > 1 ? s->h_df_real[terms[i]] : s->h_df[terms[i]];
   }
   return SS_OK;
 }
@@ -229,8 +279,12 @@ static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q,
     const uint32_t op = bm_q_op(q[i].op), n_not = bm_q_nnot(q[i].op), all = q[i].n_terms + n_not;
     if (q[i].n_terms == 0 || all > SS_MAX_QUERY_TERMS || (q[i].op >> 16)) return SS_EINVAL;
     if (op != SS_OP_INTERSECTION && op != SS_OP_UNION) return SS_EINVAL;
+    if (s->bm_n_fields > 1) {  // (term, field) posting lists: at most BM_MAX_VTERMS of them, match masks of 8 bits
+      if (all * s->bm_n_fields > (uint32_t)BM_MAX_VTERMS) return SS_ENOTSUP;
+      if (op == SS_OP_INTERSECTION && q[i].n_terms > 8) return SS_ENOTSUP;
+    }
     for (uint32_t t = 0; t < all; t++) {
-      if (q[i].term[t] >= s->bm_n_terms) return SS_EINVAL;
+      if (q[i].term[t] >= s->bm_n_terms / s->bm_n_fields) return SS_EINVAL;
       if (t < q[i].n_terms && !(q[i].idf[t] > 0.0f)) return SS_EINVAL;
       for (uint32_t u = 0; u < t; u++)
         if (q[i].term[u] == q[i].term[t]) return SS_EINVAL;  // unique terms only (search.rs:3023 unique_terms)

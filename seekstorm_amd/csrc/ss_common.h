@@ -85,7 +85,11 @@ struct ss_shard {
   size_t out_cap = 0, q_cap = 0;
   // ---- bm25 image
   uint64_t bm_n_docs = 0;
-  uint32_t bm_n_terms = 0, bm_n_sub = 0;
+  uint32_t bm_n_terms = 0, bm_n_sub = 0;  // bm_n_terms: VIRTUAL terms (posting lists) = query-able terms x fields
+  uint32_t bm_n_fields = 1;               // indexed fields (BM25F); the public API speaks of bm_n_terms / bm_n_fields terms
+  float* d_boost = nullptr;               // [bm_n_fields] schema boost per field (add_result.rs:1253)
+  std::vector<uint64_t> h_df_real;        // multi-field: docs containing the term in any field (the df idf needs)
+  void* d_vq = nullptr; size_t vq_cap = 0;  // expanded queries (bm_vquery)
   uint64_t bm_n_post = 0;
   float bm_avgdl = 0.f;
   uint64_t bm_n_post_pad = 0;     // dwords in d_post (segments padded to 16 bytes)
@@ -151,6 +155,22 @@ int ssi_vec_alloc_ws(ss_shard* s);
 // (add_result.rs:3440-3497).  On the device a NOT term is a term with idf = BM_NOT_IDF: its docs' scores become hugely
 // negative, and only positive scores are candidates or counted.
 #define BM_NOT_IDF (-1.0e30f)
+// What the kernels read: the public query expanded over the shard's indexed fields.  A posting list of the image is a
+// VIRTUAL term = (term, field): v = term * n_fields + field (one field: v = term).  A query term becomes one virtual
+// term per field it occurs in, each scored with idf * boost(field) like get_bm25f_multiterm_multifield
+// (add_result.rs:1171-1426: bm25f += boost * idf * (tf (K+1) / (tf + comp[len_field]))); an intersection needs one
+// virtual term of every GROUP (= query term): a doc's match byte collects and_val of each posting and is compared with
+// and_target -- bits of a mask (<= 8 query terms), or, for 9-10 single-field terms, 0xFF = "count one more".
+constexpr int BM_MAX_VTERMS = 32;
+struct bm_vquery {
+  uint32_t n_terms;     // scored virtual terms
+  uint32_t op;          // SS_OP_* | number of virtual NOT terms << 8; a query of ONE term is always a union (of its fields)
+  uint32_t n_groups;    // query terms
+  uint32_t and_target;  // 0 unless the query is an intersection of > 1 terms
+  uint32_t term[BM_MAX_VTERMS];
+  float idf[BM_MAX_VTERMS];
+  uint8_t and_val[BM_MAX_VTERMS];
+};
 __host__ __device__ inline uint32_t bm_q_op(uint32_t op) { return op & 0xFFu; }
 __host__ __device__ inline uint32_t bm_q_nnot(uint32_t op) { return (op >> 8) & 0xFFu; }
 int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t* d_out_doc,

@@ -122,7 +122,7 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
   u64 psum = 0;
   if (positions_sum) psum = positions_sum;
   else
-    for (u64 d = 0; d < s->bm_n_docs; d++) psum += ss_byte4_to_int(doclen[d]);
+    for (u64 d = 0; d < s->bm_n_docs * s->bm_n_fields; d++) psum += ss_byte4_to_int(doclen[d]);  // all fields (index.rs:5848)
   s->bm_avgdl = (float)psum / (float)s->bm_n_docs;  // commit.rs:318-319
   float comp[SS_COMP_N];
   fill_comp(s->bm_avgdl, comp);
@@ -166,7 +166,7 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
         if (tfs[j] == 0) return SS_EINVAL;
         const uint32_t tf = tfs[j];
         if (tf >= BM_TF_ESC) { exc_doc.push_back(docs[j]); exc_tf.push_back(tf); }  // exact value kept in the exception list
-        post[w] = bm_pack(docs[j] & (BM_SUB - 1), doclen[docs[j]], tf < BM_TF_ESC ? tf : BM_TF_ESC);
+        post[w] = bm_pack(docs[j] & (BM_SUB - 1), doclen[(size_t)(t % s->bm_n_fields) * s->bm_n_docs + docs[j]], tf < BM_TF_ESC ? tf : BM_TF_ESC);
       }
     }
   }
@@ -195,7 +195,7 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
   probe_z.assign(probe.size(), 0u);
   for (uint32_t t = 0; t < nt; t++) {
     for (u64 j = offs[t]; j < offs[t + 1]; j++) {
-      umax[t] = std::max(umax[t], bm_weight_of(tfs[j], doclen[docs[j]], comp));
+      umax[t] = std::max(umax[t], bm_weight_of(tfs[j], doclen[(size_t)(t % s->bm_n_fields) * s->bm_n_docs + docs[j]], comp));
       if (!s->d_probe) continue;
       const uint32_t sb = docs[j] >> BM_SUB_LOG2, d = docs[j] & (BM_SUB - 1);
       uint2* row = probe.data() + ((size_t)t * ns + sb) * BM_GROUPS;

@@ -177,6 +177,20 @@ class Shard:
         self.indexed_doc_count = int(n_docs)
         self._df_cache.clear()
 
+    def upload_lexical_fields(self, n_docs, doclen_bytes_fields, boost, term_offsets, doc_ids, field_ids, tfs):
+        """several indexed fields (BM25F): doclen [n_fields][n_docs], postings (doc, field, tf) sorted by (doc, field) per term"""
+        dl = np.ascontiguousarray(doclen_bytes_fields, np.uint8)
+        b = None if boost is None else np.ascontiguousarray(boost, np.float32)
+        off = np.ascontiguousarray(term_offsets, np.uint64)
+        d = np.ascontiguousarray(doc_ids, np.uint32)
+        f = np.ascontiguousarray(field_ids, np.uint8)
+        t = np.ascontiguousarray(tfs, np.uint16)
+        N.check(N.lib().ss_bm25_upload_fields(self._h, int(n_docs), dl.shape[0], N.ptr(dl.reshape(-1), N.u8p), N.ptr(b, N.f32p),
+                                              len(off) - 1, N.ptr(off, N.u64p), N.ptr(d, N.u32p), N.ptr(f, N.u8p), N.ptr(t, N.u16p)),
+                "ss_bm25_upload_fields")
+        self.indexed_doc_count = int(n_docs)
+        self._df_cache.clear()
+
     def upload_ref_blocks(self, n_docs, doclen_bytes, term_blocks):
         """term_blocks: per term a list of (block_id, compression_type_pointer, posting_count, pointer_pivot_p_docid,
         key_body_bytes) in the reference's in-RAM format (ss_bm25_upload_ref_blocks)"""

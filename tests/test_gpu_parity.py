@@ -581,3 +581,69 @@ def test_concurrent_callers_share_a_shard(S, O, lex):
         t.join()
     assert not errors, errors[:3]
     vs.close()
+
+
+def _fields_corpus(O, n_docs, n_fields, dfs, seed):
+    """postings (term, doc, field, tf) sorted by (doc, field) per term; a doc holds a term in 1..n_fields fields"""
+    rng = np.random.default_rng(seed)
+    dl = np.stack([O.lex_doclen(n_docs, seed=O.LEX_SEED + 17 * f) for f in range(n_fields)])
+    offs, docs, fields, tfs = [0], [], [], []
+    for df in dfs:
+        d = np.sort(rng.choice(n_docs, size=df, replace=False))
+        for f in range(n_fields):
+            keep = rng.random(df) < (0.7 if f == 0 else 0.35)
+            if f == 0:
+                none = ~keep
+            else:
+                none &= ~keep
+            docs.append(d[keep]); fields.append(np.full(int(keep.sum()), f)); tfs.append(np.minimum(rng.geometric(0.5, int(keep.sum())), 40))
+        docs.append(d[none]); fields.append(np.full(int(none.sum()), n_fields - 1)); tfs.append(np.ones(int(none.sum()), np.int64))  # every doc somewhere
+        n_t = sum(len(x) for x in docs[-(n_fields + 1):])
+        dd = np.concatenate(docs[-(n_fields + 1):]); ff = np.concatenate(fields[-(n_fields + 1):]); tt = np.concatenate(tfs[-(n_fields + 1):])
+        del docs[-(n_fields + 1):], fields[-(n_fields + 1):], tfs[-(n_fields + 1):]
+        o = np.lexsort((ff, dd))
+        # (doc, field) must be unique: the "every doc somewhere" filler may repeat the last field
+        keep = np.ones(n_t, bool)
+        keep[1:] = (dd[o][1:] != dd[o][:-1]) | (ff[o][1:] != ff[o][:-1])
+        docs.append(dd[o][keep]); fields.append(ff[o][keep]); tfs.append(tt[o][keep])
+        offs.append(offs[-1] + int(keep.sum()))
+    return (dl, np.array(offs, np.uint64), np.concatenate(docs).astype(np.uint32), np.concatenate(fields).astype(np.uint8),
+            np.concatenate(tfs).astype(np.uint16))
+
+
+@pytest.mark.parametrize("n_fields,boost", [(2, [2.0, 1.0]), (3, None)])
+def test_bm25f_several_fields(S, O, n_fields, boost):
+    """get_bm25f_multiterm_multifield (add_result.rs:1171-1426): per-field tf / length / boost, df over any field,
+    intersections of unions; every result type and strategy, NOT terms and tombstones, against the brute-force oracle"""
+    n_docs = 120_000
+    dfs = [30_000, 9_000, 2_500, 600, 14_000]
+    dl, offs, docs, fields, tfs = _fields_corpus(O, n_docs, n_fields, dfs, 3 + n_fields)
+    sh = S.Shard(0)
+    sh.upload_lexical_fields(n_docs, dl, boost, offs, docs, fields, tfs)
+    info = sh.lexical_info()
+    assert info["n_terms"] == len(dfs) and info["n_docs"] == n_docs
+    assert [int(x) for x in sh.posting_count(np.arange(len(dfs)))] == dfs  # docs containing the term in any field
+    cases = [([0, 1], []), ([2], []), ([0, 1, 2], []), ([4, 3], [2]), ([1, 4], [0]), ([3], [1])]
+    gone = list(range(5, n_docs, 211))
+    for deleted in ((), gone):
+        sh.set_deleted(deleted)
+        for qt, oop in ((S.QueryType.Union, O.OP_OR), (S.QueryType.Intersection, O.OP_AND)):
+            for strat in (0, 1):
+                sh.set_strategy(strat)
+                q = sh.make_queries([c[0] for c in cases], qt, [c[1] for c in cases])
+                for rt in (S.ResultType.TopkCount, S.ResultType.Topk, S.ResultType.Count):
+                    doc, score, cnt, tot = sh.search_lexical_batch(q, 10, rt)
+                    for i, (pos, neg) in enumerate(cases):
+                        od, os_, otot, avg = O.search_fields_exhaustive(n_docs, dl, boost, offs, docs, fields, tfs, pos, oop, 10, neg, deleted)
+                        assert abs(info["avgdl"] - avg) <= 1e-6 * avg
+                        if rt != S.ResultType.Topk:
+                            assert int(tot[i]) == otot, (pos, neg, qt, strat, rt)
+                        if rt != S.ResultType.Count:
+                            _check_topk(doc[i], score[i], cnt[i], od, os_)
+    sh.set_strategy(0)
+    # the limits of the expansion are refused, not mis-answered
+    if n_fields == 3:
+        q = sh.make_queries([[0, 1, 2, 3]], S.QueryType.Union, [[4]])
+        q["op"][0] |= 0  # 5 terms x 3 fields fit (15 <= 32)
+        sh.search_lexical_batch(q, 10)
+    sh.close()
