@@ -55,6 +55,15 @@ int Shard::upload_lexical(uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t
   return rc;
 }
 
+int Shard::upload_lexical_fields(uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen_bytes, const float* boost, uint32_t n_terms,
+                                 const uint64_t* term_offsets, const uint32_t* doc_ids, const uint8_t* field_ids,
+                                 const uint16_t* tfs) {
+  if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
+  const int rc = ss_bm25_upload_fields(h_, n_docs, n_fields, doclen_bytes, boost, n_terms, term_offsets, doc_ids, field_ids, tfs);
+  n_docs_ = rc == SS_OK ? n_docs : 0;
+  return rc;
+}
+
 int Shard::upload_vectors(uint64_t n_rows, uint32_t dim, const float* rows, const uint32_t* row_doc_ids) {
   if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
   i8_ = false;

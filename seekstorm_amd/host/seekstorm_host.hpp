@@ -77,6 +77,9 @@ class Shard {
   // (re)build of the device image: end of open_shard (index.rs:3796) / after a commit (commit.rs:142-148)
   int upload_lexical(uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t n_terms, const uint64_t* term_offsets,
                      const uint32_t* doc_ids, const uint16_t* tfs);
+  // several indexed fields (BM25F): doclen [n_fields][n_docs], postings (doc, field, tf) sorted by (doc, field) per term
+  int upload_lexical_fields(uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen_bytes, const float* boost, uint32_t n_terms,
+                            const uint64_t* term_offsets, const uint32_t* doc_ids, const uint8_t* field_ids, const uint16_t* tfs);
   int upload_vectors(uint64_t n_rows, uint32_t dim, const float* rows, const uint32_t* row_doc_ids);
   // shard files as the reference writes them: index.bin (single indexed field), vector.bin (f32), delete.bin
   int open_index_bin(const uint8_t* bytes, uint64_t len, uint32_t key_head_size, std::vector<uint64_t>* term_keys);
