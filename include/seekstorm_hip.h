@@ -123,6 +123,14 @@ int ss_index_bin_term_keys(const ss_index_bin* ix, uint64_t* keys_out /*[n_terms
 int ss_index_bin_term_postings(const ss_index_bin* ix, uint32_t term, uint64_t cap, uint32_t* docs_out, uint16_t* tfs_out,
                                uint64_t* n_out);
 int ss_bm25_upload_index_bin(ss_shard* s, const ss_index_bin* ix);
+/* the same for an index with several indexed fields: position records carry a field vector per posting
+ * (decode_positions_multiterm_multifield, add_result.rs:1485-2034; read_multifield_vec 2200-2293) -> ss_bm25_upload_fields.
+ * boost = schema boost per field (schema.json; NULL = 1).  ss_bm25_upload_index_bin calls it with NULL. */
+int ss_bm25_upload_index_bin_fields(ss_shard* s, const ss_index_bin* ix, const float* boost);
+/* one block of a multi-field index: docs_out [65536], first_out [65537] = CSR of the field entries per posting,
+ * field_out / tf_out [65536 * n_fields] */
+int ss_ref_decode_block_fields(const ss_ref_block* block, uint32_t n_fields, uint32_t longest_field_id, uint16_t* docs_out,
+                               uint32_t* first_out, uint8_t* field_out, uint16_t* tf_out);
 
 /* Device-side synthetic corpus (bench/test utility; generator = oracle so_lex_*):
  * posting (t,d) iff (h(seed,t+1,d)>>32) < thresh32[t]; bit-identical to ss_bm25_upload of the same corpus. */

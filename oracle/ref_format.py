@@ -157,39 +157,66 @@ def encode_term(docs, tfs, rng, base_bytes=b"", positions_limit=32768, max_gap=4
 
 
 # ------------------------------------------------------------------------------------------------ index.bin / vector.bin
+def encode_term_fields(docs, fields, tfs, n_fields, longest_field_id, rng, positions_limit=32768, max_gap=40):
+    """(doc, field, tf) entries sorted by (doc, field) -> per-block key bodies like encode_term"""
+    docs = np.asarray(docs, np.int64)
+    fields = np.asarray(fields, np.int64)
+    out = []
+    bid = docs >> 16
+    for b in np.unique(bid):
+        sel = np.nonzero(bid == b)[0]
+        local, postings = [], []
+        for i in sel:
+            d = int(docs[i]) & 0xFFFF
+            if not local or local[-1] != d:
+                local.append(d)
+                postings.append([])
+            postings[-1].append((int(fields[i]), random_positions(rng, int(tfs[i]), max_gap)))
+        body, ctp, cnt, pivot = encode_key_body_fields(local, postings, n_fields, longest_field_id, 0, positions_limit)
+        out.append((int(b), ctp, cnt, pivot, body))
+    return out
+
+
 def write_index_bin(n_docs, doclen_bytes, terms, rng, segment_number_bits=11, key_head_size=20, ngram_keys=(),
-                    positions_sum=None, positions_limit=32768):
-    """index.bin of one shard with one indexed field (commit.rs:264-369 level writer, 467-552 commit_segment,
-    compress_postinglist.rs:339-409 key head).  terms: list of (key_hash with low 3 bits 0, docs ascending, tfs).
+                    positions_sum=None, positions_limit=32768, n_fields=1, longest_field_id=0):
+    """index.bin of one shard (commit.rs:264-369 level writer, 467-552 commit_segment, compress_postinglist.rs:339-409
+    key head).  One indexed field: terms = [(key_hash with low 3 bits 0, docs ascending, tfs)], doclen_bytes [n_docs].
+    Several fields: terms = [(key_hash, docs, fields, tfs)] sorted by (doc, field), doclen_bytes [n_fields][n_docs].
     ngram_keys: key hashes with NgramType bits set, written as 1-posting keys the reader has to skip.
     Segment of a key = (key_hash >> 40) & mask here (the reference uses hash32(term) & mask, tokenizer.rs:660 -- a
-    different hash of the same term; readers never rely on it).  max_docid / max_p_docid (a-12 block-max posting) hold
-    the highest-tf posting: the device image derives its own bounds, no reader under test uses them."""
+    different hash of the same term; readers never rely on it).  max_docid / max_p_docid (a-12 block-max posting) are
+    written as 0: the device image derives its own bounds, no reader under test uses them."""
     from . import oracle as O
     nseg = 1 << segment_number_bits
     dlc = np.array([O.lib().so_byte4_to_int(b) for b in range(256)], np.uint64)  # DOCUMENT_LENGTH_COMPRESSION
-    dl = np.zeros(((n_docs + 65535) >> 16) << 16, np.uint8)
-    dl[:n_docs] = doclen_bytes
+    n_pad = ((n_docs + 65535) >> 16) << 16
+    dl = np.zeros((n_fields, n_pad), np.uint8)
+    dl[:, :n_docs] = np.asarray(doclen_bytes, np.uint8).reshape(n_fields, n_docs)
     out = bytearray()
     out += (6).to_bytes(2, "little") + (1).to_bytes(2, "little")
     psum_cum = 0
     n_levels = (n_docs + 65535) >> 16
     per_term_blocks = []
-    for key, docs, tfs in terms:
-        assert key & 7 == 0
-        per_term_blocks.append({b[0]: b for b in encode_term(docs, tfs, rng, positions_limit=positions_limit)})
+    for term in terms:
+        assert term[0] & 7 == 0
+        if n_fields == 1:
+            blocks = encode_term(term[1], term[2], rng, positions_limit=positions_limit)
+        else:
+            blocks = encode_term_fields(term[1], term[2], term[3], n_fields, longest_field_id, rng, positions_limit)
+        per_term_blocks.append({b[0]: b for b in blocks})
     for level in range(n_levels):
         if level == 0:
-            out += (0).to_bytes(2, "little")  # longest_field_id
-        out += dl[level << 16:(level + 1) << 16].tobytes()
+            out += int(longest_field_id).to_bytes(2, "little")
         docs_cum = min(n_docs, (level + 1) << 16)
-        psum_cum += int(dlc[dl[level << 16:docs_cum]].sum())
+        for f in range(n_fields):
+            out += dl[f, level << 16:(level + 1) << 16].tobytes()
+            psum_cum += int(dlc[dl[f, level << 16:docs_cum]].sum())
         out += docs_cum.to_bytes(8, "little")
         out += (psum_cum if positions_sum is None or level + 1 < n_levels else positions_sum).to_bytes(8, "little")
         segs = [[] for _ in range(nseg)]
-        for (key, _, _), blocks in zip(terms, per_term_blocks):
+        for term, blocks in zip(terms, per_term_blocks):
             if level in blocks:
-                segs[(key >> 40) & (nseg - 1)].append((key, blocks[level]))
+                segs[(term[0] >> 40) & (nseg - 1)].append((term[0], blocks[level]))
         if level == 0:
             for key in ngram_keys:
                 assert key & 7
@@ -202,15 +229,11 @@ def write_index_bin(n_docs, doclen_bytes, terms, rng, segment_number_bits=11, ke
             for key, blk in seg:
                 if blk is None:  # n-gram key: one posting, doc 0, layout irrelevant to a reader that skips it
                     body, ctp, cnt, pivot = encode_key_body([0], [[1]], base=len(bodies))
-                    maxd = maxp = 0
                 else:
                     # re-base the body behind the previous keys' bodies: the pointer is relative to the key-body slice
-                    _, ctp0, cnt, pivot, raw = blk
-                    body = raw
+                    _, ctp0, cnt, pivot, body = blk
                     ctp = (ctp0 & 0xC0000000) | ((ctp0 & 0x3FFFFFFF) + len(bodies))
-                    maxp, maxd = 0, 0
-                h = bytearray(key.to_bytes(8, "little") + (cnt - 1).to_bytes(2, "little") + maxd.to_bytes(2, "little") +
-                              maxp.to_bytes(2, "little"))
+                h = bytearray(key.to_bytes(8, "little") + (cnt - 1).to_bytes(2, "little") + bytes(4))
                 h += bytes(key_head_size - 20)  # n-gram df bytes (22 / 23 byte heads)
                 h += pivot.to_bytes(2, "little") + ctp.to_bytes(4, "little")
                 assert len(h) == key_head_size
@@ -240,3 +263,130 @@ def write_vector_bin(levels, dim, i8=False):
                 assert v.shape == (dim,)
                 out += struct.pack("<HIIffhi", doc_id, field_id, chunk_id, scale, 1.0, 0, int(v.astype(np.int64).sum()) if i8 else 0) + v.tobytes()
     return bytes(out)
+
+
+# ------------------------------------------------------------------------------------------------ several indexed fields
+FIELD_STOP_BIT_1, FIELD_STOP_BIT_2 = 0x20, 0x40  # index.rs:112-113
+
+
+def field_id_bits(n_fields):
+    """index.rs:2569-2570: usize::BITS - (len - 1).leading_zeros()"""
+    return (n_fields - 1).bit_length()
+
+
+def write_field_vec(field_vec, only_longest, id_bits):
+    """index_posting.rs:846-940, more than one indexed field: [(field id, positions_count)] in front of a position record"""
+    out = bytearray()
+    n = len(field_vec)
+    for i, (fid, cnt) in enumerate(field_vec):
+        if only_longest:
+            if cnt < 64:
+                out.append(cnt | 0xC0)
+            elif cnt < 8192:
+                out += bytes([(cnt >> 7) | 0x40, (cnt & 0x7F) | STOP])
+            else:
+                assert cnt < 1048576
+                out += bytes([(cnt >> 14) | 0x40, (cnt >> 7) & 0x7F, (cnt & 0x7F) | STOP])
+            continue
+        stop = (FIELD_STOP_BIT_1 if i == 0 else FIELD_STOP_BIT_2) if i == n - 1 else 0
+        v = (cnt << id_bits) | fid
+        meta_bits = (1 if i == 0 else 0) + cnt.bit_length() + id_bits
+        if meta_bits <= 6:
+            out.append(stop | v | STOP)
+        elif meta_bits <= 13:
+            out += bytes([stop | (v >> 7), (v & 0x7F) | STOP])
+        else:
+            assert meta_bits <= 20
+            out += bytes([stop | (v >> 14), (v >> 7) & 0x7F, (v & 0x7F) | STOP])
+    return bytes(out)
+
+
+def embeddable_fields(field_deltas, only_longest, id_bits, pointer_size):
+    """index_posting.rs:472-562; field_deltas: [(field id, [delta positions])] of the non-empty fields"""
+    pos = [d for _, ds in field_deltas for d in ds]
+    n, nonempty = len(pos), len(field_deltas)
+    b = [_bits(x) for x in pos]
+    if only_longest:
+        if pointer_size == 2:
+            return (n == 1 and b[0] <= 13) or (n == 2 and b[0] <= 6 and b[1] <= 7)
+        return ((n == 1 and b[0] <= 20) or (n == 2 and b[0] <= 10 and b[1] <= 10) or (n == 3 and b[0] <= 6 and b[1] <= 7 and b[2] <= 7) or
+                (n == 4 and max(b) <= 5))
+    used = nonempty * id_bits
+    bits = 12 if pointer_size == 2 else 19
+    if used >= bits:
+        return False
+    rem = bits - used
+    if n == 1:
+        return b[0] <= rem
+    if n == 2:
+        return b[0] <= rem // 2 and b[1] <= rem - rem // 2
+    if n == 3 and (pointer_size == 3 or nonempty == 1):
+        return b[0] <= rem // 3 and b[1] <= (rem - rem // 3) // 2 and b[2] <= rem - (rem - rem // 3) // 2 - rem // 3
+    if n == 4 and pointer_size == 3 and nonempty == 1:
+        b2 = (rem - rem // 4) // 3
+        b3 = (rem - b2 - rem // 4) // 2
+        return b[0] <= rem // 4 and b[1] <= b2 and b[2] <= b3 and b[3] <= rem - rem // 4 - b2 - b3
+    return False
+
+
+def embed_fields(field_deltas, only_longest, id_bits, pointer_size):
+    """index_posting.rs:592-660"""
+    pos = [d for _, ds in field_deltas for d in ds]
+    n, nonempty = len(pos), len(field_deltas)
+    data = 0
+    if not only_longest:
+        for fid, _ in field_deltas:
+            data = (data << id_bits) | fid
+    remaining = pointer_size * 8 - (0 if pointer_size == 2 else 1) - (3 if only_longest else 4 + nonempty * id_bits)
+    for i, d in enumerate(pos):
+        w = remaining // (n - i)
+        remaining -= w
+        data = (data << w) | d
+    counts = [len(ds) for _, ds in field_deltas]
+    if pointer_size == 2:
+        if only_longest:
+            hi = (data >> 8) | 0xC0 | ((n - 1) << 5)
+        elif nonempty == 1:
+            hi = (data >> 8) | 0x80 | ((n - 1) << 4)
+        else:
+            hi = (data >> 8) | 0xB0
+        return bytes([data & 0xFF, hi & 0xFF])
+    if only_longest:
+        top = (data >> 16) | 0xC0 | ((n - 1) << 4)
+    else:
+        top = (data >> 16) | 0x80 | (((n - 1) << 3) if nonempty == 1 else 0x38 if nonempty == 3 else
+                                     0x20 if counts[:2] == [1, 1] else 0x28 if counts[:2] == [1, 2] else 0x30)
+    return bytes([data & 0xFF, (data >> 8) & 0xFF, top & 0xFF])
+
+
+def encode_key_body_fields(local_docs, postings, n_fields, longest_field_id, base=0, positions_limit=32768):
+    """postings[i] = [(field id, [positions ascending]), ...] non-empty fields in ascending field order
+    -> (body, compression_type_pointer, posting_count, pointer_pivot_p_docid), as encode_key_body"""
+    id_bits = field_id_bits(n_fields)
+    size_positions, pivot, three = 0, 0, False
+    pointers, records = [], []
+    for rank, fl in enumerate(postings):
+        fd = [(fid, delta_positions(p)) for fid, p in fl]
+        only_longest = len(fd) == 1 and fd[0][0] == longest_field_id
+        total = sum(len(ds) for _, ds in fd)
+        if not three and size_positions < positions_limit and rank < 65535:
+            pivot, psize = rank + 1, 2
+        else:
+            psize, three = 3, True
+        # embedding is only ever tried for <= 4 positions in fields of <= 4 positions (index_posting.rs:433-438)
+        if total <= 4 and embeddable_fields(fd, only_longest, id_bits, psize):
+            pointers.append(embed_fields(fd, only_longest, id_bits, psize))
+            continue
+        rec = write_field_vec([(fid, len(ds)) for fid, ds in fd], only_longest, id_bits) + \
+            b"".join(position_vint(x) for _, ds in fd for x in ds)
+        if psize == 2 and size_positions + len(rec) >= positions_limit:
+            psize, pivot, three = 3, rank, True
+        size_positions += len(rec)
+        records.append(rec)
+        if psize == 2:
+            pointers.append(bytes([size_positions & 255, (size_positions >> 8) & 127]))
+        else:
+            pointers.append(bytes([size_positions & 255, (size_positions >> 8) & 255, (size_positions >> 16) & 127]))
+    ctype, cont = container(local_docs)
+    body = b"".join(reversed(records)) + b"".join(pointers) + cont
+    return body, (ctype << 30) | (base + size_positions), len(local_docs), pivot

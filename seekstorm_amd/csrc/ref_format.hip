@@ -120,6 +120,166 @@ extern "C" int ss_ref_decode_block(const ss_ref_block* b, uint16_t* docs_out, ui
   return (int)count;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Several indexed fields: a posting's field vector [(field id, positions_count)], SingleTerm keys
+// (decode_positions_multiterm_multifield add_result.rs:1485-2034, read_multifield_vec 2200-2293; writer
+// index_posting.rs:445-660, write_field_vec 846-940).  indexed_field_id_bits = bit length of (field count - 1)
+// (index.rs:2569-2570); longest_field_id from the first level of index.bin (commit.rs:264-274).
+namespace {
+struct FieldEntry { uint8_t field; uint32_t tf; };
+
+// read_multifield_vec, more than one indexed field (add_result.rs:2229-2293)
+bool read_field_vec(const uint8_t* a, uint64_t len, uint64_t pos, uint32_t id_bits, uint32_t longest, FieldEntry* out, int* n_out) {
+  if (pos >= len) return false;
+  int n = 0;
+  if (a[pos] & 0x40u) {  // only the longest field: count in 6 + 7 (+ 7) bits
+    uint32_t c = a[pos++];
+    if (c & 0x80u) c &= 0x3Fu;
+    else {
+      if (pos >= len) return false;
+      c = (c & 0x3Fu) << 7;
+      const uint32_t c2 = a[pos++];
+      if (c2 & 0x80u) c |= c2 & 0x7Fu;
+      else {
+        if (pos >= len) return false;
+        c = (c << 7) | ((c2 & 0x7Fu) << 7) | (a[pos++] & 0x7Fu);
+      }
+    }
+    out[n].field = (uint8_t)longest; out[n].tf = c; n++;
+  } else {
+    bool first = true;
+    for (;;) {
+      if (pos >= len || n >= 8) return false;
+      uint32_t b = a[pos++];
+      const bool field_stop = (b & (first ? 0x20u : 0x40u)) != 0;  // FIELD_STOP_BIT_1 / _2 (index.rs:112-113)
+      uint32_t v = b & (first ? 0x1Fu : 0x3Fu);
+      if (!(b & 0x80u)) {
+        if (pos >= len) return false;
+        b = a[pos++];
+        v = (v << 7) | (b & 0x7Fu);
+        if (!(b & 0x80u)) {
+          if (pos >= len) return false;
+          b = a[pos++];
+          v = (v << 7) | (b & 0x7Fu);
+        }
+      }
+      out[n].field = (uint8_t)(v & ((1u << id_bits) - 1u)); out[n].tf = v >> id_bits; n++;
+      first = false;
+      if ((b & 0x80u) && field_stop) break;
+    }
+  }
+  *n_out = n;
+  return true;
+}
+}  // namespace
+
+// Decodes one block of a multi-field index: docs_out [65536], first_out [65537] = CSR of the field entries per posting,
+// field_out / tf_out [65536 * n_fields].  Returns the posting count or a negative code.
+extern "C" int ss_ref_decode_block_fields(const ss_ref_block* b, uint32_t n_fields, uint32_t longest_field_id, uint16_t* docs_out,
+                                          uint32_t* first_out, uint8_t* field_out, uint16_t* tf_out) {
+  if (!b || !b->byte_array || !docs_out || !first_out || !field_out || !tf_out || n_fields < 2 || n_fields > 8 ||
+      longest_field_id >= n_fields) return SS_EINVAL;
+  // doc ids: the container walk of the single-field reader (tf output unused); run on a one-field view of the pointers
+  // would misread them, so walk the container here again
+  const uint8_t* a = b->byte_array;
+  const uint64_t len = b->byte_array_len;
+  const uint32_t ctype = b->compression_type_pointer >> 30;
+  const uint64_t range = b->compression_type_pointer & 0x3FFFFFFFu;
+  const uint32_t count = (uint32_t)b->posting_count_m1 + 1u;
+  const uint32_t pivot = b->pointer_pivot_p_docid;
+  const uint64_t ptr_bytes = (uint64_t)pivot * 2u + (pivot <= b->posting_count_m1 ? (uint64_t)(count - pivot) * 3u : 0u);
+  const uint64_t cont = range + ptr_bytes;
+  if (cont > len) return SS_EINVAL;
+  uint32_t n = 0;
+  if (ctype == 1u) {
+    if (cont + (uint64_t)count * 2u > len) return SS_EINVAL;
+    for (uint32_t i = 0; i < count; i++) docs_out[n++] = (uint16_t)rd16(a + cont + 2u * i);
+  } else if (ctype == 2u) {
+    if (cont + 8192u > len) return SS_EINVAL;
+    for (uint32_t w = 0; w < 1024u; w++) {
+      uint64_t x;
+      std::memcpy(&x, a + cont + 8u * w, 8);
+      while (x) {
+        if (n >= 65536u) return SS_EINVAL;
+        docs_out[n++] = (uint16_t)(w * 64u + (uint32_t)__builtin_ctzll(x));
+        x &= x - 1;
+      }
+    }
+  } else if (ctype == 3u) {
+    if (cont + 2u > len) return SS_EINVAL;
+    const uint32_t runs = rd16(a + cont);
+    if (cont + 2u + (uint64_t)runs * 4u > len) return SS_EINVAL;
+    for (uint32_t r = 0; r < runs; r++) {
+      const uint32_t st = rd16(a + cont + 2u + 4u * r), l = rd16(a + cont + 4u + 4u * r);
+      for (uint32_t j = 0; j <= l; j++) {
+        if (n >= 65536u || st + j > 65535u) return SS_EINVAL;
+        docs_out[n++] = (uint16_t)(st + j);
+      }
+    }
+  } else {
+    return SS_ENOTSUP;
+  }
+  if (n != count) return SS_EINVAL;
+  for (uint32_t i = 1; i < n; i++)
+    if (docs_out[i] <= docs_out[i - 1]) return SS_EINVAL;
+
+  uint32_t id_bits = 0;
+  while ((1u << id_bits) < n_fields) id_bits++;  // usize::BITS - (len - 1).leading_zeros()
+  const uint32_t id_mask = (1u << id_bits) - 1u;
+  uint32_t w = 0;
+  for (uint32_t r = 0; r < count; r++) {
+    first_out[r] = w;
+    FieldEntry e[8];
+    int ne = 0;
+    const bool two = r < pivot;
+    const uint64_t at = two ? range + (uint64_t)r * 2u : range + (uint64_t)r * 3u - pivot;
+    if (at + (two ? 2u : 3u) > len) return SS_EINVAL;
+    const uint32_t p = two ? rd16(a + at) : rd24(a + at);
+    if (!(p & (two ? 0x8000u : 0x800000u))) {  // record in the position area
+      const uint64_t back = p & (two ? 0x7FFFu : 0x7FFFFFu);
+      if (back > range || !read_field_vec(a, len, range - back, id_bits, longest_field_id, e, &ne)) return SS_EINVAL;
+    } else if (two) {  // embedded, 2 bytes: tag = bits 15..12 (add_result.rs:1606-1737)
+      const uint32_t tag = p >> 12, pb = 12u - id_bits;
+      switch (tag) {
+        case 0xC: case 0xD: e[0] = {(uint8_t)longest_field_id, 1}; ne = 1; break;
+        case 0xE: case 0xF: e[0] = {(uint8_t)longest_field_id, 2}; ne = 1; break;
+        case 0x8: case 0x9: case 0xA: e[0] = {(uint8_t)((p >> pb) & id_mask), tag - 7u}; ne = 1; break;
+        case 0xB: {
+          const uint32_t pb2 = 12u - 2u * id_bits;
+          e[0] = {(uint8_t)((p >> (pb2 + id_bits)) & id_mask), 1};
+          e[1] = {(uint8_t)((p >> pb2) & id_mask), 1};
+          ne = 2;
+          break;
+        }
+        default: return SS_EINVAL;
+      }
+    } else {  // embedded, 3 bytes: tag = bits 23..19 (add_result.rs:1738-2017)
+      const uint32_t tag = p >> 19, pb = 19u - id_bits, pb2 = 19u - 2u * id_bits, pb3 = 19u - 3u * id_bits;
+      if (tag >= 0x18u) { e[0] = {(uint8_t)longest_field_id, ((tag - 0x18u) >> 1) + 1u}; ne = 1; }
+      else if (tag >= 0x10u && tag <= 0x13u) { e[0] = {(uint8_t)((p >> pb) & id_mask), tag - 0x0Fu}; ne = 1; }
+      else if (tag >= 0x14u && tag <= 0x16u) {
+        e[0] = {(uint8_t)((p >> (pb2 + id_bits)) & id_mask), tag == 0x16u ? 2u : 1u};
+        e[1] = {(uint8_t)((p >> pb2) & id_mask), tag == 0x15u ? 2u : 1u};
+        ne = 2;
+      } else if (tag == 0x17u) {
+        e[0] = {(uint8_t)((p >> (pb3 + 2u * id_bits)) & id_mask), 1};
+        e[1] = {(uint8_t)((p >> (pb3 + id_bits)) & id_mask), 1};
+        e[2] = {(uint8_t)((p >> pb3) & id_mask), 1};
+        ne = 3;
+      } else return SS_EINVAL;
+    }
+    for (int i = 0; i < ne; i++) {
+      if (e[i].field >= n_fields || e[i].tf == 0 || e[i].tf > 65535u) return SS_EINVAL;
+      if (i && e[i].field <= e[i - 1].field) return SS_EINVAL;  // the field vector is written in ascending field order
+      field_out[w] = e[i].field;
+      tf_out[w] = (uint16_t)e[i].tf;
+      w++;
+    }
+  }
+  first_out[count] = w;
+  return (int)count;
+}
+
 extern "C" int ss_bm25_upload_ref_blocks(ss_shard* s, uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t n_terms,
                                          const uint64_t* term_block_offsets, const ss_ref_block* blocks) {
   if (!s || !doclen_bytes || !term_block_offsets || n_docs == 0 || n_terms == 0) return SS_EINVAL;
@@ -330,9 +490,60 @@ extern "C" int ss_index_bin_term_postings(const ss_index_bin* ix, uint32_t term,
   return SS_OK;
 }
 
+namespace {
+// multi-field index: (doc, field, tf) entries of every term, doclen rearranged to [field][doc]
+int upload_index_bin_fields(ss_shard* s, const ss_index_bin* ix, const float* boost) {
+  const uint32_t F = ix->n_fields;
+  std::vector<uint64_t> offs(ix->keys.size() + 1, 0);
+  std::vector<uint32_t> docs;
+  std::vector<uint8_t> fields;
+  std::vector<uint16_t> tfs;
+  std::vector<uint16_t> d16(65536), t16((size_t)65536 * F);
+  std::vector<uint32_t> first(65537);
+  std::vector<uint8_t> f8((size_t)65536 * F);
+  for (uint32_t t = 0; t < ix->keys.size(); t++) {
+    offs[t] = docs.size();
+    for (uint64_t bi = ix->term_block_off[t]; bi < ix->term_block_off[t + 1]; bi++) {
+      const ss_ref_block& b = ix->blocks[bi].b;
+      const int n = ss_ref_decode_block_fields(&b, F, ix->longest_field_id, d16.data(), first.data(), f8.data(), t16.data());
+      if (n < 0) return n;
+      for (int i = 0; i < n; i++) {
+        const uint64_t doc = ((uint64_t)b.block_id << 16) | d16[i];
+        if (doc >= ix->n_docs) return SS_EINVAL;
+        for (uint32_t e = first[i]; e < first[i + 1]; e++) {
+          docs.push_back((uint32_t)doc);
+          fields.push_back(f8[e]);
+          tfs.push_back(t16[e]);
+        }
+      }
+    }
+  }
+  offs[ix->keys.size()] = docs.size();
+  std::vector<uint8_t> doclen((size_t)F * ix->n_docs);
+  for (uint32_t f = 0; f < F; f++)
+    for (size_t l = 0; l < ix->doclen.size(); l++) {
+      const uint64_t d0 = (uint64_t)l << 16;
+      if (d0 >= ix->n_docs) break;
+      std::memcpy(doclen.data() + (size_t)f * ix->n_docs + d0, ix->doclen[l] + (size_t)f * 65536u,
+                  (size_t)std::min<uint64_t>(65536u, ix->n_docs - d0));
+    }
+  return ssi_bm25_upload_fields(s, ix->n_docs, F, doclen.data(), boost, (uint32_t)ix->keys.size(), offs.data(), docs.data(),
+                                fields.data(), tfs.data(), ix->positions_sum);
+}
+}  // namespace
+
+extern "C" int ss_bm25_upload_index_bin_fields(ss_shard* s, const ss_index_bin* ix, const float* boost) {
+  if (!s || !ix) return SS_EINVAL;
+  if (ix->keys.empty() || ix->n_docs == 0) return SS_EINVAL;
+  if (ix->n_fields < 2) return ss_bm25_upload_index_bin(s, ix);
+  if (ix->n_fields > 8) return SS_ENOTSUP;
+  return upload_index_bin_fields(s, ix, boost);
+}
+
 extern "C" int ss_bm25_upload_index_bin(ss_shard* s, const ss_index_bin* ix) {
   if (!s || !ix) return SS_EINVAL;
   if (ix->keys.empty() || ix->n_docs == 0) return SS_EINVAL;
+  if (ix->n_fields > 1) return ss_bm25_upload_index_bin_fields(s, ix, nullptr);
   std::vector<uint64_t> offs(ix->keys.size() + 1, 0);
   std::vector<uint32_t> docs;
   std::vector<uint16_t> tfs, d16(65536), t16(65536);

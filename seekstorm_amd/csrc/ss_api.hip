@@ -140,6 +140,14 @@ extern "C" {
 int ss_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost,
                           uint32_t n_terms, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
                           const uint16_t* tfs) {
+  return ssi_bm25_upload_fields(s, n_docs, n_fields, doclen, boost, n_terms, offs, docs, fields, tfs, 0);
+}
+
+}  // extern "C"
+
+int ssi_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost,
+                           uint32_t n_terms, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
+                           const uint16_t* tfs, uint64_t positions_sum) {
   if (!s || !doclen || !offs || n_docs == 0 || n_terms == 0 || n_fields == 0 || n_fields > 8) return SS_EINVAL;
   if (offs[n_terms] && (!docs || !fields || !tfs)) return SS_EINVAL;
   if ((uint64_t)n_terms * n_fields > 0x7FFFFFFFull) return SS_ENOTSUP;
@@ -173,7 +181,7 @@ int ss_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, const
   s->bm_n_fields = n_fields;
   s->bm_n_terms = nv;
   s->bm_n_sub = (uint32_t)((n_docs + BM_SUB - 1) >> BM_SUB_LOG2);
-  int rc = ssi_bm25_build_from_host(s, doclen, voff.data(), vdocs.data(), vtfs.data(), 0);
+  int rc = ssi_bm25_build_from_host(s, doclen, voff.data(), vdocs.data(), vtfs.data(), positions_sum);
   if (rc == SS_OK) {
     std::vector<float> b(n_fields, 1.0f);
     if (boost) b.assign(boost, boost + n_fields);
@@ -184,6 +192,8 @@ int ss_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, const
   if (rc) free_bm25(s);
   return rc;
 }
+
+extern "C" {
 
 int ss_bm25_synth(ss_shard* s, uint64_t seed, uint64_t n_docs, uint32_t n_terms, const uint32_t* thresh32,
                   const uint8_t* len_table1024) {

@@ -184,5 +184,8 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
                              const uint16_t* tfs, uint64_t positions_sum);
 int ssi_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen, uint32_t n_terms, const uint64_t* offs,
                     const uint32_t* docs, const uint16_t* tfs, uint64_t positions_sum);
+int ssi_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost,
+                           uint32_t n_terms, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
+                           const uint16_t* tfs, uint64_t positions_sum);
 void ssi_prof_begin(ss_shard* s, int kernel, hipStream_t st, hipEvent_t* e0, hipEvent_t* e1);
 void ssi_prof_end(ss_shard* s, int kernel, hipStream_t st, hipEvent_t e0, hipEvent_t e1);

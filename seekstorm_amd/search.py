@@ -209,8 +209,10 @@ class Shard:
         self.indexed_doc_count = int(n_docs)
         self._df_cache.clear()
 
-    def upload_index_bin(self, ix: "IndexBin"):
-        N.check(N.lib().ss_bm25_upload_index_bin(self._h, ix._h), "ss_bm25_upload_index_bin")
+    def upload_index_bin(self, ix: "IndexBin", boost=None):
+        """boost: schema boost per indexed field (several fields only; schema.json)"""
+        b = None if boost is None else np.ascontiguousarray(boost, np.float32)
+        N.check(N.lib().ss_bm25_upload_index_bin_fields(self._h, ix._h, N.ptr(b, N.f32p)), "ss_bm25_upload_index_bin")
         self.indexed_doc_count = int(ix.indexed_doc_count)
         self._df_cache.clear()
 

@@ -251,3 +251,93 @@ def test_vector_bin_i8_records_and_shard_seam():
     assert [r.score for r in ro.results] == [float(x) for x in os_] and ro.results[0].doc_id == int(od[0])
     a.close()
     b.close()
+
+
+# ------------------------------------------------------------------------------------------------ several indexed fields
+def _decode_fields(block, n_fields, longest):
+    bid, ctp, cnt, pivot, body = block
+    buf = np.frombuffer(body, np.uint8).copy()
+    rb = N.RefBlock(bid, ctp, cnt - 1, pivot, buf.ctypes.data, len(buf))
+    d = np.zeros(65536, np.uint16); first = np.zeros(65537, np.uint32)
+    f = np.zeros(65536 * n_fields, np.uint8); t = np.zeros(65536 * n_fields, np.uint16)
+    n = N.lib().ss_ref_decode_block_fields(C.byref(rb), n_fields, longest, N.ptr(d, N.u16p), N.ptr(first, N.u32p), N.ptr(f, N.u8p),
+                                           N.ptr(t, N.u16p))
+    return n, d, first, f, t
+
+
+def _fields_postings(rng, n, n_fields, tf_hi, longest):
+    docs = np.sort(rng.choice(65536, size=n, replace=False))
+    d, f, t = [], [], []
+    for doc in docs:
+        k = int(rng.integers(1, n_fields + 1)) if rng.random() < 0.5 else 1
+        fs = np.sort(rng.choice(n_fields, size=k, replace=False)) if rng.random() < 0.7 else np.array([longest])
+        for x in fs:
+            d.append(int(doc)); f.append(int(x)); t.append(int(rng.integers(1, tf_hi + 1)))
+    return np.array(d), np.array(f), np.array(t)
+
+
+@pytest.mark.parametrize("n_fields,longest,n,tf_hi,limit", [(2, 0, 300, 3, 32768), (3, 1, 2000, 6, 32768), (4, 3, 500, 300, 32768),
+                                                           (3, 0, 900, 5, 96), (8, 5, 700, 4, 32768), (2, 1, 5000, 2, 32768)])
+def test_decode_fields_roundtrip(n_fields, longest, n, tf_hi, limit):
+    """decode_positions_multiterm_multifield / read_multifield_vec (add_result.rs:1485-2034, 2200-2293): embedded 2- and
+    3-byte forms (longest-field, one field, two and three fields) and field vectors in front of VINT records"""
+    rng = np.random.default_rng(n_fields * 100 + n)
+    d, f, t = _fields_postings(rng, n, n_fields, tf_hi, longest)
+    blocks = RF.encode_term_fields(d, f, t, n_fields, longest, rng, positions_limit=limit, max_gap=25)
+    assert len(blocks) == 1
+    cnt, dd, first, ff, tt = _decode_fields(blocks[0], n_fields, longest)
+    assert cnt == len(np.unique(d)) and int(first[cnt]) == len(d)
+    assert np.array_equal(np.repeat(dd[:cnt], np.diff(first[:cnt + 1])), d)
+    assert np.array_equal(ff[:len(d)], f) and np.array_equal(tt[:len(d)], t)
+    if limit < 32768:
+        assert 0 < blocks[0][3] < cnt  # 3-byte pointers in use
+
+
+def test_embedded_field_pointer_tags():
+    # 2-byte tags (bits 15..12): 110x / 111x longest field 1 / 2 positions; 1000 / 1001 / 1010 one field 1..3; 1011 two fields
+    # 3-byte tags (bits 23..19): 1100x..1111x longest 1..4; 10000..10011 one field 1..4; 10100 (1,1) 10101 (1,2) 10110 (2,1) 10111 (1,1,1)
+    E = RF.embed_fields
+    assert E([(1, [5])], True, 1, 2)[1] >> 4 in (0xC, 0xD) and E([(1, [5, 6])], True, 1, 2)[1] >> 4 in (0xE, 0xF)
+    assert E([(2, [5])], False, 2, 2)[1] >> 4 == 0x8 and E([(2, [1, 2, 3])], False, 2, 2)[1] >> 4 == 0xA
+    assert E([(0, [1]), (2, [3])], False, 2, 2)[1] >> 4 == 0xB
+    assert E([(1, [9, 9, 9, 9])], True, 1, 3)[2] >> 3 in (0x1E, 0x1F) and E([(1, [7, 7, 7, 7])], False, 2, 3)[2] >> 3 == 0x13
+    assert E([(0, [1]), (1, [2, 3])], False, 2, 3)[2] >> 3 == 0x15 and E([(0, [1, 2]), (1, [3])], False, 2, 3)[2] >> 3 == 0x16
+    assert E([(0, [1]), (1, [2]), (2, [3])], False, 2, 3)[2] >> 3 == 0x17
+
+
+@pytest.mark.gpu
+def test_upload_index_bin_with_several_fields():
+    from oracle import oracle as O
+    rng = np.random.default_rng(41)
+    n_docs, n_fields, longest = 100_000, 3, 1
+    dl = np.stack([O.lex_doclen(n_docs, seed=O.LEX_SEED + 5 * f) for f in range(n_fields)])
+    keys = sorted(int(k) & ~7 for k in rng.integers(1 << 40, 1 << 63, size=4, dtype=np.int64))
+    terms, offs, D, F, T = [], [0], [], [], []
+    for key, df in zip(keys, (20_000, 700, 6_000, 40)):
+        docs = np.sort(rng.choice(n_docs, size=df, replace=False))
+        d, f, t = [], [], []
+        for doc in docs:
+            fs = np.sort(rng.choice(n_fields, size=int(rng.integers(1, n_fields + 1)), replace=False)) if rng.random() < 0.6 else [longest]
+            for x in fs:
+                d.append(int(doc)); f.append(int(x)); t.append(int(min(rng.geometric(0.5), 30)))
+        terms.append((key, np.array(d), np.array(f), np.array(t)))
+        D += d; F += f; T += t
+        offs.append(len(D))
+    data = RF.write_index_bin(n_docs, dl, terms, rng, n_fields=n_fields, longest_field_id=longest)
+    ix = S.IndexBin(data, n_fields)
+    assert ix.indexed_doc_count == n_docs and ix.term_count == 4
+    boost = [1.5, 1.0, 0.5]
+    a, b = S.Shard(0), S.Shard(0)
+    a.upload_index_bin(ix, boost)
+    b.upload_lexical_fields(n_docs, dl, boost, np.array(offs, np.uint64), np.array(D, np.uint32), np.array(F, np.uint8), np.array(T, np.uint16))
+    assert a.lexical_info() == b.lexical_info()
+    for qt, oop in ((S.QueryType.Union, O.OP_OR), (S.QueryType.Intersection, O.OP_AND)):
+        for q in ([0, 2], [1], [0, 1, 2], [3, 0]):
+            ra = a.search_lexical_batch(a.make_queries([q], qt), 10)
+            rb_ = b.search_lexical_batch(b.make_queries([q], qt), 10)
+            for x, y in zip(ra, rb_):
+                assert np.array_equal(x, y)
+            od, os_, otot, _ = O.search_fields_exhaustive(n_docs, dl, boost, offs, D, F, T, q, oop, 10)
+            assert int(ra[3][0]) == otot and np.allclose(ra[1][0][:ra[2][0]], os_, rtol=1e-4)
+    a.close()
+    b.close()
