@@ -341,3 +341,41 @@ def test_upload_index_bin_with_several_fields():
             assert int(ra[3][0]) == otot and np.allclose(ra[1][0][:ra[2][0]], os_, rtol=1e-4)
     a.close()
     b.close()
+
+
+def test_decoders_survive_corrupted_bytes():
+    """bit flips, truncations and random headers: every reader returns a result or an error code, never walks outside the
+    byte array (run under the CPU suite: a crash here would take the process down)"""
+    rng = np.random.default_rng(77)
+    d1, t1 = _case(rng, 400, 65536, 40, False)
+    one = RF.encode_term(d1, t1, rng, base_bytes=bytes(50))[0]
+    d, f, t = _fields_postings(rng, 400, 3, 40, 1)
+    many = RF.encode_term_fields(d, f, t, 3, 1, rng, max_gap=25)[0]
+    for blk, fields in ((one, False), (many, True)):
+        bid, ctp, cnt, pivot, body = blk
+        for trial in range(1500):
+            b = bytearray(body)
+            kind = trial % 5
+            if kind == 0:
+                for _ in range(int(rng.integers(1, 6))):
+                    b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+                blk2 = (bid, ctp, cnt, pivot, bytes(b))
+            elif kind == 1:
+                blk2 = (bid, ctp, cnt, pivot, bytes(b[:int(rng.integers(0, len(b)))]))
+            elif kind == 2:
+                blk2 = (bid, int(rng.integers(0, 1 << 32)), cnt, pivot, bytes(b))
+            elif kind == 3:
+                blk2 = (bid, ctp, int(rng.integers(1, 65537)), int(rng.integers(0, 65536)), bytes(b))
+            else:
+                blk2 = (bid, ctp, cnt, pivot, bytes(rng.integers(0, 256, size=len(b), dtype=np.uint8)))
+            if not blk2[4]:
+                continue
+            n = (_decode_fields(blk2, 3, 1) if fields else _decode(blk2))[0]
+            assert n <= 65536
+    # index.bin / vector headers made of noise
+    for trial in range(200):
+        junk = b"\\x06\\x00\\x01\\x00" + bytes(rng.integers(0, 256, size=int(rng.integers(0, 300_000)), dtype=np.uint8))
+        try:
+            S.IndexBin(junk, int(rng.integers(1, 4)), 20, int(rng.integers(0, 5))).close()
+        except S.SeekStormHipError:
+            pass
