@@ -334,8 +334,9 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
 #pragma unroll
       for (int g = 0; g < G; g++) {
         if (!is_and && k) alive[g] = alive[g] && (idf[J] * w0[g] + rest0) >= thr * 0.99999f;
-        rec[g] = make_uint2(0u, 0u);
-        if (alive[g]) rec[g] = prow[A][(size_t)tile[g] * (BM_SUB / 64) + (dg[g] >> 6)];
+        // unconditional load, dead lanes read record 0 (one cached line): four back-to-back gathers instead of four
+        // exec-masked branches; a dead lane's record is never looked at
+        rec[g] = prow[A][alive[g] ? (size_t)tile[g] * (BM_SUB / 64) + (dg[g] >> 6) : (size_t)0];
       }
 #pragma unroll
       for (int g = 0; g < G; g++) {
