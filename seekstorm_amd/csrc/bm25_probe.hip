@@ -129,6 +129,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
   uint32_t* tau_q = tau + (size_t)qi * BM_TAU_STRIDE;
   const int lane4 = lane * 4;
   constexpr int G = 4;  // chunks (64 driver postings each) evaluated together: their gathers overlap
+  static_assert(PB_QCAP >= 64 * G + 63, "a group can push 64 * G survivors on top of the < 64 left in the queue");
 
   // score in QUERY order with the exhaustive kernels' fma chain (bit-identical results)
   auto combine = [&](const float (&wv)[NT], uint32_t pres) -> float {
