@@ -8,17 +8,18 @@
 //     longest suffix of terms whose U sums to less than thr is NON-ESSENTIAL: a doc made only of them cannot enter the
 //     top-k.  Only the posting streams of essential terms are read ("drivers"), 64 consecutive postings per load, one per
 //     lane, regardless of sub-block boundaries (each lane derives its sub-block from the stream position);
-//   * every other term is PROBED for the driver's doc: one 16-byte record {64 doc bits, index of their first posting}
-//     tells membership and position, and only on a hit is that term's posting fetched for its weight.  Probing stops as
-//     soon as partial score + remaining upper bounds < thr.  A doc present in several essential terms is evaluated by
+//   * every other term is PROBED for the driver's doc: an 8-byte record of 64 doc bits tells membership; only on a hit
+//     are the rank table (index of the group's first posting) and then the posting itself read for its weight.  Probing
+//     stops as soon as partial score + remaining upper bounds < thr.  A doc present in several essential terms is evaluated by
 //     the first; driver streams run one after the other (largest U first), so by the time the second stream would
 //     start the threshold has usually made it non-essential and it is skipped altogether;
 //   * intersections use the shortest list as the only driver and require a hit in every other term; their exact match
 //     count is the number of surviving drivers, so Count / TopkCount need no exhaustive pass either.
 //
 // Scores are combined in query-term order with the same fma chain as the exhaustive kernels, so both produce bit-identical
-// scores.  One wave per (query, partition); no LDS beyond the weight table; G chunks are evaluated together so that
-// their gathers are in flight at the same time.
+// scores.  One wave per (query, partition); LDS holds the weight table and one survivor queue per wave (dense stage ->
+// sparse stage); G chunks are evaluated together so that their gathers are in flight at the same time.  Exact union
+// counts (bm25_union_count_kernel, bottom of the file) are popcounts over the same bit records.
 #include <type_traits>
 
 #include "bm25_dev.h"

@@ -99,8 +99,8 @@ struct ss_shard {
   uint32_t* d_sub_off = nullptr;   // [n_terms][n_sub+1] segment boundaries in 16-byte units relative to the term base
   float* d_comp = nullptr;         // bm25_component_cache[256] + wlut[4096]
   std::vector<uint64_t> h_df;      // posting_count per term (the df the host needs for idf)
-  // probe index (membership + rank of a doc in a term's segment without reading the segment): one 16-byte record
-  // {u64 bits of 64 docs, u32 index (inside the term's posting array) of their first posting} per (term, sub-block, 64-doc group)
+  // probe index: membership (64-doc bit records) and rank (index of each group's first posting) of a doc in a term's
+  // segment without reading the segment; the bit records are also the bitmaps exact union counts are popcounted from
   uint32_t* d_deleted = nullptr;   // tombstone bitmap by shard-local doc id (delete.bin / delete_hashset), null = none
   uint64_t deleted_words = 0, n_deleted = 0;
   uint2* d_probe = nullptr;        // [n_terms + 1][n_sub][BM_SUB / 64] 64 doc bits; row n_terms is all zero (absent terms)
