@@ -390,42 +390,53 @@ static int launch_probe(const BmParams& p, const uint2* probe, const uint32_t* p
   return SS_OK;
 }
 
-// Exact match counts of unions from the probe index's bit records: |A u B u ...| = sum over 64-doc groups of
-// popcount(bits_A | bits_B | ...), minus NOT lists and tombstones -- the reference's own way of counting a union
-// (union_count over bitmaps, union.rs:807-; deleted docs cleared, union.rs:975).  One coalesced 8-byte load per term
-// and group, no scoring: with it a TopkCount union is the pruned top-k plus this count instead of an exhaustive scan.
-// One wave per (query, partition of the group range); queries that are not unions of > 1 terms are left to the probe
-// kernel, which counts intersections and single terms while it ranks them.
+// Exact match counts from the probe index's bit records: |A u B u ...| = sum over 64-doc groups of
+// popcount(bits_A | bits_B | ...), an intersection the popcount of the AND over the query terms (each the OR of its
+// (term, field) lists), minus NOT lists and tombstones -- the reference's own way of counting (union_count over bitmaps,
+// union.rs:807-; deleted docs cleared, union.rs:975; Bitmap x Bitmap intersections, intersection.rs:564-752).  One
+// coalesced 8-byte load per term and group, no scoring: with it a TopkCount request is a top-k kernel (pruned, or the scan
+// without its count mode) plus this count.  One wave per (query, partition of the group range).  all_queries = 0: only
+// unions of > 1 lists (the pruned kernel counts intersections and single lists while it ranks them); 1: every query.
 constexpr int CNT_WAVES = 4, CNT_UNROLL = 4;
 __global__ void __launch_bounds__(CNT_WAVES * 64) bm25_union_count_kernel(
     const uint2* __restrict__ probe, const bm_vquery* __restrict__ qs, unsigned long long* __restrict__ total,
-    const uint32_t* __restrict__ del, uint32_t del_words, uint32_t n_sub, uint32_t nq, uint32_t P) {
+    const uint32_t* __restrict__ del, uint32_t del_words, uint32_t n_sub, uint32_t nq, uint32_t P, uint32_t all_queries) {
   const int lane = threadIdx.x & 63;
   const uint32_t a = blockIdx.x * CNT_WAVES + (threadIdx.x >> 6);
   if (a >= nq * P) return;
   const uint32_t qi = a % nq, part = a / nq;
   const bm_vquery* __restrict__ Q = qs + qi;
   const uint32_t np = Q->n_terms, n_not = bm_q_nnot(Q->op);
-  if (bm_q_op(Q->op) != SS_OP_UNION || np < 2) return;
+  const bool is_and = Q->and_target != 0u;
+  if (!all_queries && (is_and || np < 2)) return;
   const uint32_t n_groups = n_sub * (BM_SUB / 64);
   const uint32_t g_begin = (uint32_t)(((u64)n_groups * part) / P), g_end = (uint32_t)(((u64)n_groups * (part + 1)) / P);
   uint32_t cnt = 0;
   for (uint32_t g0 = g_begin; g0 < g_end; g0 += 64u * CNT_UNROLL) {
-    u64 acc[CNT_UNROLL], neg[CNT_UNROLL];
+    u64 acc[CNT_UNROLL], cur[CNT_UNROLL], neg[CNT_UNROLL];
 #pragma unroll
-    for (int u = 0; u < CNT_UNROLL; u++) { acc[u] = 0ull; neg[u] = 0ull; }
+    for (int u = 0; u < CNT_UNROLL; u++) { acc[u] = is_and ? ~0ull : 0ull; cur[u] = 0ull; neg[u] = 0ull; }
+    uint32_t grp = Q->group[0];
 #pragma unroll 4
     for (uint32_t t = 0; t < np + n_not; t++) {
       const uint2* __restrict__ row = probe + (size_t)Q->term[t] * n_groups;
+      const uint32_t gt = Q->group[t];
+      if (is_and && t < np && gt != grp) {  // next query term: the previous one's fields are complete
+#pragma unroll
+        for (int u = 0; u < CNT_UNROLL; u++) { acc[u] &= cur[u]; cur[u] = 0ull; }
+        grp = gt;
+      }
 #pragma unroll
       for (int u = 0; u < CNT_UNROLL; u++) {
         const uint32_t g = g0 + 64u * u + lane;
         uint2 r = make_uint2(0u, 0u);
         if (g < g_end) r = row[g];
         const u64 b = ((u64)r.y << 32) | r.x;
-        if (t < np) acc[u] |= b; else neg[u] |= b;
+        if (t < np) cur[u] |= b; else neg[u] |= b;
       }
     }
+#pragma unroll
+    for (int u = 0; u < CNT_UNROLL; u++) acc[u] = is_and ? (acc[u] & cur[u]) : cur[u];
     if (del) {
 #pragma unroll
       for (int u = 0; u < CNT_UNROLL; u++) {
@@ -445,13 +456,13 @@ __global__ void __launch_bounds__(CNT_WAVES * 64) bm25_union_count_kernel(
   if (lane == 0 && cnt) atomicAdd(&total[qi], (unsigned long long)cnt);
 }
 
-int ssi_bm25_launch_union_count(const BmParams& p, const uint2* probe, hipStream_t st) {
+int ssi_bm25_launch_union_count(const BmParams& p, const uint2* probe, bool all_queries, hipStream_t st) {
   // one partition per ~4096 groups and at least enough waves for two rounds of a full chip
   const uint32_t n_groups = p.n_sub * (BM_SUB / 64);
   uint32_t P = std::max<uint32_t>(1u, std::min<uint32_t>((2u * 8192u + p.nq - 1) / p.nq, (n_groups + 1023u) / 1024u));
   const uint32_t A = p.nq * P;
   bm25_union_count_kernel<<<(A + CNT_WAVES - 1) / CNT_WAVES, CNT_WAVES * 64, 0, st>>>(probe, p.q, p.total, p.del, p.del_words,
-                                                                                     p.n_sub, p.nq, P);
+                                                                                     p.n_sub, p.nq, P, all_queries ? 1u : 0u);
   return SS_OK;
 }
 

@@ -170,6 +170,7 @@ struct bm_vquery {
   uint32_t term[BM_MAX_VTERMS];
   float idf[BM_MAX_VTERMS];
   uint8_t and_val[BM_MAX_VTERMS];
+  uint8_t group[BM_MAX_VTERMS];  // query term of each virtual term (the virtual terms of a group are contiguous)
 };
 __host__ __device__ inline uint32_t bm_q_op(uint32_t op) { return op & 0xFFu; }
 __host__ __device__ inline uint32_t bm_q_nnot(uint32_t op) { return (op >> 8) & 0xFFu; }
