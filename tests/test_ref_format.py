@@ -379,3 +379,20 @@ def test_decoders_survive_corrupted_bytes():
             S.IndexBin(junk, int(rng.integers(1, 4)), 20, int(rng.integers(0, 5))).close()
         except S.SeekStormHipError:
             pass
+
+
+def test_golden_key_bodies():
+    """committed byte arrays (tests/golden/make_ref_format_golden.py) decode to their committed postings"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_format.npz"))
+    for name in ("array", "bitmap", "rle", "pivot"):
+        bid, ctp, cnt, pivot = (int(x) for x in g[f"s_{name}_head"])
+        n, d, t = _decode((bid, ctp, cnt, pivot, g[f"s_{name}_body"].tobytes()))
+        assert n == cnt and np.array_equal(d, g[f"s_{name}_docs"]) and np.array_equal(t, g[f"s_{name}_tfs"])
+        assert ctp >> 30 == {"array": RF.CT_ARRAY, "bitmap": RF.CT_BITMAP, "rle": RF.CT_RLE, "pivot": RF.CT_ARRAY}[name]
+    bid, ctp, cnt, pivot, nf, longest = (int(x) for x in g["m_head"])
+    n, dd, first, ff, tt = _decode_fields((bid, ctp, cnt, pivot, g["m_body"].tobytes()), nf, longest)
+    m = len(g["m_docs"])
+    assert n == cnt and int(first[cnt]) == m
+    assert np.array_equal(np.repeat(dd[:cnt], np.diff(first[:cnt + 1])), g["m_docs"])
+    assert np.array_equal(ff[:m], g["m_fields"]) and np.array_equal(tt[:m], g["m_tfs"])
