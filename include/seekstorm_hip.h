@@ -144,6 +144,12 @@ int ss_bm25_info(ss_shard* s, uint64_t* n_docs, float* avgdl, uint32_t* n_terms,
  * EXHAUSTIVE scan.  Both return identical results.  SS_BM25_PRUNED fails with SS_ENOTSUP where pruning cannot serve
  * the request (> 4 scored terms, k > 128, no probe index). */
 enum { SS_BM25_AUTO = 0, SS_BM25_EXHAUSTIVE = 1, SS_BM25_PRUNED = 2 };
+/* The probe index costs 12 bytes per 64 docs and posting list (1.9 MB per list at 10 M docs).  Its rows go to the longest
+ * lists first until the budget of the NEXT image build is spent (bytes; 0 = half of the free device memory); queries
+ * touching a list without a row are ranked by the scan kernels (exact counts then come from the scan as well).
+ * ss_bm25_term_probed: 1 per term whose lists all have rows -- what a caller of ss_bm25_search_dev reports in ops_mask bit 2. */
+int ss_bm25_set_probe_budget(ss_shard* s, uint64_t max_bytes);
+int ss_bm25_term_probed(ss_shard* s, uint32_t n, const uint32_t* terms, uint8_t* out);
 int ss_bm25_set_strategy(ss_shard* s, int strategy);
 /* posting_count per term (the df the host needs for idf, search.rs:3225-3230) */
 int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df_out);
@@ -169,7 +175,8 @@ int ss_bm25_search(ss_shard* s, uint32_t n_queries, const ss_bm25_query* queries
  * (term < n_terms, unique terms, idf > 0).  ops_mask: bit 0 set if any query is an intersection of > 1 terms
  * (selects the kernel variant that carries match counters), bit 1 set if any query is a union of > 1 terms; bits 8..15 = the
  * largest n_terms + NOT terms in the batch (0 = unknown: the generic 10-term kernel is used); bits 16..23 = the largest
- * n_terms alone (0 = same as bits 8..15, i.e. no NOT terms). */
+ * n_terms alone (0 = same as bits 8..15, i.e. no NOT terms); bit 2 set if every term of the batch has probe rows
+ * (ss_bm25_term_probed; irrelevant when the probe budget covered all lists). */
 int ss_bm25_search_dev(ss_shard* s, uint32_t n_queries, const ss_bm25_query* d_queries, uint32_t k,
                        uint32_t result_type, uint32_t ops_mask, uint32_t* d_out_doc, float* d_out_score,
                        uint32_t* d_out_count, uint64_t* d_out_total, void* stream);

@@ -68,6 +68,8 @@ SYMBOLS = [
     ("ss_bm25_info", C.c_int, [C.c_void_p, u64p, f32p, u32p, u64p]),
     ("ss_bm25_term_df", C.c_int, [C.c_void_p, C.c_uint32, u32p, u64p]),
     ("ss_bm25_set_strategy", C.c_int, [C.c_void_p, C.c_int]),
+    ("ss_bm25_set_probe_budget", C.c_int, [C.c_void_p, C.c_uint64]),
+    ("ss_bm25_term_probed", C.c_int, [C.c_void_p, C.c_uint32, u32p, u8p]),
     ("ss_bm25_search", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, u32p, f32p, u32p, u64p]),
     ("ss_bm25_search_dev", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

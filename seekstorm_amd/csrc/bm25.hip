@@ -106,7 +106,7 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
 // ---------------------------------------------------------------- host side
 int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t* d_out_doc,
                     float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, bool has_or,
-                    uint32_t nt_max, uint32_t np_max, hipStream_t st) {
+                    uint32_t nt_max, uint32_t np_max, bool all_probed, hipStream_t st) {
   if (!s->d_post) return SS_ESTATE;
   if (nq == 0) return SS_OK;
   if (k > SS_MAX_K) return SS_EINVAL;
@@ -124,7 +124,9 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   nt_max *= F;
   np_max *= F;
   if (F > 1) has_or = true;
-  const bool pruned = s->bm_strategy != SS_BM25_EXHAUSTIVE && s->d_probe && s->d_umax && !(F > 1 && has_and) &&
+  // all_probed: every list the batch touches has a row in the probe index (rows are given to the longest lists first)
+  const bool have_probe = s->d_probe && s->d_umax && all_probed;
+  const bool pruned = s->bm_strategy != SS_BM25_EXHAUSTIVE && have_probe && !(F > 1 && has_and) &&
                       np_max >= 1 && np_max <= 4 && KPL <= 2;  // NOT terms are probed outside the template
   if (!pruned && s->bm_strategy == SS_BM25_PRUNED) return SS_ENOTSUP;
   // Partitions per query (one wave each).  The grid is a whole number of "rounds" of resident waves: a partially
@@ -185,18 +187,18 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   // bit records and the scan runs without its count mode (which scans every sub-block: 5.8 instead of 1.8 ms per 1000 C2
   // queries); a pure Count request then needs no scan at all.  SS_BM25_EXHAUSTIVE keeps the scan's own counts.
   const bool want_counts = rt != SS_RT_TOPK;
-  const bool bit_counts_all = want_counts && !pruned && s->bm_strategy != SS_BM25_EXHAUSTIVE && s->d_probe != nullptr;
+  const bool bit_counts_all = want_counts && !pruned && s->bm_strategy != SS_BM25_EXHAUSTIVE && have_probe;
   p.count = (want_counts && !bit_counts_all) ? 1u : 0u;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   ssi_prof_begin(s, 0, st, &e0, &e1);
   int rc = SS_OK;
   if (bit_counts_all && k == 0) SS_HIP(hipMemsetAsync(bufA, 0, (size_t)nq * P * KS * sizeof(u64), st));  // no ranking wanted
-  else rc = pruned ? ssi_bm25_launch_probe(p, s->d_probe, s->d_probe_z, s->d_umax, np_max, KPL, nt_max != np_max, st)
+  else rc = pruned ? ssi_bm25_launch_probe(p, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_umax, np_max, KPL, nt_max != np_max, st)
                    : ssi_bm25_launch_scan(p, nt_max, has_and, KPL, st);
   ssi_prof_end(s, 0, st, e0, e1);
   if (rc) return rc;
   if (want_counts && ((pruned && has_or) || bit_counts_all)) {
-    const int rcc = ssi_bm25_launch_union_count(p, s->d_probe, bit_counts_all, st);
+    const int rcc = ssi_bm25_launch_union_count(p, s->d_probe, s->d_probe_row, bit_counts_all, st);
     if (rcc) return rcc;
   }
 

@@ -53,7 +53,7 @@ template <int NT, int KPL, bool FILT>
 __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
     const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base, const uint32_t* __restrict__ sub_off,
     const float* __restrict__ comp_g, const uint2* __restrict__ probe, const uint32_t* __restrict__ probe_z,
-    const float* __restrict__ umax,
+    const uint32_t* __restrict__ probe_row, const float* __restrict__ umax,
     const bm_vquery* __restrict__ qs, unsigned long long* __restrict__ part_keys, unsigned long long* __restrict__ total,
     uint32_t* tau, const unsigned long long* __restrict__ exc_off, const uint32_t* __restrict__ exc_doc,
     const uint32_t* __restrict__ exc_tf, const uint32_t* __restrict__ del, uint32_t del_words, uint32_t n_sub, uint32_t n_terms,
@@ -92,8 +92,8 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
     tid_[t] = term;
     tptr[t] = post + term_base[term] * 4ull;
     rowp[t] = sub_off + (size_t)term * row_len;
-    prow[t] = probe + (size_t)term * n_sub * (BM_SUB / 64);
-    zrow[t] = probe_z + (size_t)term * n_sub * (BM_SUB / 64);
+    prow[t] = probe + (size_t)probe_row[term] * n_sub * (BM_SUB / 64);  // the host sends only queries whose lists all have a row
+    zrow[t] = probe_z + (size_t)probe_row[term] * n_sub * (BM_SUB / 64);
     size[t] = have ? term_base[term + 1] - term_base[term] : ~0ull;
   }
   // sort: unions by U descending (absent terms have U = 0: last), intersections by list size ascending (absent: last)
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
     for (uint32_t j = 0; j < n_not; j++) {
       const uint32_t term = Q->term[nt + j];
       uint2 r = make_uint2(0u, 0u);
-      if (lanes) r = probe[((size_t)term * n_sub + (doc >> BM_SUB_LOG2)) * (BM_SUB / 64) + ((doc & (BM_SUB - 1)) >> 6)];
+      if (lanes) r = probe[((size_t)probe_row[term] * n_sub + (doc >> BM_SUB_LOG2)) * (BM_SUB / 64) + ((doc & (BM_SUB - 1)) >> 6)];
       const u64 bits = ((u64)r.y << 32) | r.x;
       found = found || ((bits >> (doc & 63u)) & 1ull);
     }
@@ -382,10 +382,11 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
 }
 
 template <int NT, int KPL, bool FILT>
-static int launch_probe(const BmParams& p, const uint2* probe, const uint32_t* probe_z, const float* umax, hipStream_t st) {
+static int launch_probe(const BmParams& p, const uint2* probe, const uint32_t* probe_z, const uint32_t* probe_row, const float* umax,
+                        hipStream_t st) {
   const uint32_t A = p.nq * p.P;
   bm25_probe_kernel<NT, KPL, FILT><<<(A + PB_WAVES - 1) / PB_WAVES, PB_WAVES * 64, BM_LUT_BYTES + PB_WAVES * PB_QCAP * 12, st>>>(
-      p.post, p.term_base, p.sub_off, p.comp, probe, probe_z, umax, p.q, p.part_keys, p.total, p.tau, p.exc_off, p.exc_doc, p.exc_tf, p.del, p.del_words, p.n_sub, p.n_terms, p.nq, p.P, p.k,
+      p.post, p.term_base, p.sub_off, p.comp, probe, probe_z, probe_row, umax, p.q, p.part_keys, p.total, p.tau, p.exc_off, p.exc_doc, p.exc_tf, p.del, p.del_words, p.n_sub, p.n_terms, p.nq, p.P, p.k,
       p.count);
   return SS_OK;
 }
@@ -399,8 +400,9 @@ static int launch_probe(const BmParams& p, const uint2* probe, const uint32_t* p
 // unions of > 1 lists (the pruned kernel counts intersections and single lists while it ranks them); 1: every query.
 constexpr int CNT_WAVES = 4, CNT_UNROLL = 4;
 __global__ void __launch_bounds__(CNT_WAVES * 64) bm25_union_count_kernel(
-    const uint2* __restrict__ probe, const bm_vquery* __restrict__ qs, unsigned long long* __restrict__ total,
-    const uint32_t* __restrict__ del, uint32_t del_words, uint32_t n_sub, uint32_t nq, uint32_t P, uint32_t all_queries) {
+    const uint2* __restrict__ probe, const uint32_t* __restrict__ probe_row, const bm_vquery* __restrict__ qs,
+    unsigned long long* __restrict__ total, const uint32_t* __restrict__ del, uint32_t del_words, uint32_t n_sub, uint32_t nq,
+    uint32_t P, uint32_t all_queries) {
   const int lane = threadIdx.x & 63;
   const uint32_t a = blockIdx.x * CNT_WAVES + (threadIdx.x >> 6);
   if (a >= nq * P) return;
@@ -411,32 +413,63 @@ __global__ void __launch_bounds__(CNT_WAVES * 64) bm25_union_count_kernel(
   if (!all_queries && (is_and || np < 2)) return;
   const uint32_t n_groups = n_sub * (BM_SUB / 64);
   const uint32_t g_begin = (uint32_t)(((u64)n_groups * part) / P), g_end = (uint32_t)(((u64)n_groups * (part + 1)) / P);
+  // bit rows of the first lists, resolved once (term -> probe row -> address): the loop below then issues plain loads
+  constexpr int CNT_FAST = 8;
+  const uint2* rows[CNT_FAST];
+#pragma unroll
+  for (int t = 0; t < CNT_FAST; t++)
+    rows[t] = probe + (size_t)probe_row[(uint32_t)t < np + n_not ? Q->term[t] : Q->term[0]] * n_groups;
   uint32_t cnt = 0;
   for (uint32_t g0 = g_begin; g0 < g_end; g0 += 64u * CNT_UNROLL) {
     u64 acc[CNT_UNROLL], cur[CNT_UNROLL], neg[CNT_UNROLL];
 #pragma unroll
     for (int u = 0; u < CNT_UNROLL; u++) { acc[u] = is_and ? ~0ull : 0ull; cur[u] = 0ull; neg[u] = 0ull; }
-    uint32_t grp = Q->group[0];
-#pragma unroll 4
-    for (uint32_t t = 0; t < np + n_not; t++) {
-      const uint2* __restrict__ row = probe + (size_t)Q->term[t] * n_groups;
-      const uint32_t gt = Q->group[t];
-      if (is_and && t < np && gt != grp) {  // next query term: the previous one's fields are complete
+    if (!is_and) {  // union: OR of the scored lists (the common case: kept free of the group bookkeeping)
 #pragma unroll
-        for (int u = 0; u < CNT_UNROLL; u++) { acc[u] &= cur[u]; cur[u] = 0ull; }
-        grp = gt;
+      for (int t = 0; t < CNT_FAST; t++) {
+        if ((uint32_t)t >= np + n_not) break;
+#pragma unroll
+        for (int u = 0; u < CNT_UNROLL; u++) {
+          const uint32_t g = g0 + 64u * u + lane;
+          uint2 r = make_uint2(0u, 0u);
+          if (g < g_end) r = rows[t][g];
+          const u64 b = ((u64)r.y << 32) | r.x;
+          if ((uint32_t)t < np) acc[u] |= b; else neg[u] |= b;
+        }
+      }
+      for (uint32_t t = CNT_FAST; t < np + n_not; t++) {
+        const uint2* __restrict__ row = probe + (size_t)probe_row[Q->term[t]] * n_groups;
+#pragma unroll
+        for (int u = 0; u < CNT_UNROLL; u++) {
+          const uint32_t g = g0 + 64u * u + lane;
+          uint2 r = make_uint2(0u, 0u);
+          if (g < g_end) r = row[g];
+          const u64 b = ((u64)r.y << 32) | r.x;
+          if (t < np) acc[u] |= b; else neg[u] |= b;
+        }
+      }
+    } else {  // intersection: AND over the query terms, each the OR of its (term, field) lists
+      uint32_t grp = Q->group[0];
+      for (uint32_t t = 0; t < np + n_not; t++) {
+        const uint2* __restrict__ row = probe + (size_t)probe_row[Q->term[t]] * n_groups;
+        const uint32_t gt = Q->group[t];
+        if (t < np && gt != grp) {  // next query term: the previous one's fields are complete
+#pragma unroll
+          for (int u = 0; u < CNT_UNROLL; u++) { acc[u] &= cur[u]; cur[u] = 0ull; }
+          grp = gt;
+        }
+#pragma unroll
+        for (int u = 0; u < CNT_UNROLL; u++) {
+          const uint32_t g = g0 + 64u * u + lane;
+          uint2 r = make_uint2(0u, 0u);
+          if (g < g_end) r = row[g];
+          const u64 b = ((u64)r.y << 32) | r.x;
+          if (t < np) cur[u] |= b; else neg[u] |= b;
+        }
       }
 #pragma unroll
-      for (int u = 0; u < CNT_UNROLL; u++) {
-        const uint32_t g = g0 + 64u * u + lane;
-        uint2 r = make_uint2(0u, 0u);
-        if (g < g_end) r = row[g];
-        const u64 b = ((u64)r.y << 32) | r.x;
-        if (t < np) cur[u] |= b; else neg[u] |= b;
-      }
+      for (int u = 0; u < CNT_UNROLL; u++) acc[u] &= cur[u];
     }
-#pragma unroll
-    for (int u = 0; u < CNT_UNROLL; u++) acc[u] = is_and ? (acc[u] & cur[u]) : cur[u];
     if (del) {
 #pragma unroll
       for (int u = 0; u < CNT_UNROLL; u++) {
@@ -456,25 +489,25 @@ __global__ void __launch_bounds__(CNT_WAVES * 64) bm25_union_count_kernel(
   if (lane == 0 && cnt) atomicAdd(&total[qi], (unsigned long long)cnt);
 }
 
-int ssi_bm25_launch_union_count(const BmParams& p, const uint2* probe, bool all_queries, hipStream_t st) {
+int ssi_bm25_launch_union_count(const BmParams& p, const uint2* probe, const uint32_t* probe_row, bool all_queries, hipStream_t st) {
   // one partition per ~4096 groups and at least enough waves for two rounds of a full chip
   const uint32_t n_groups = p.n_sub * (BM_SUB / 64);
   uint32_t P = std::max<uint32_t>(1u, std::min<uint32_t>((2u * 8192u + p.nq - 1) / p.nq, (n_groups + 1023u) / 1024u));
   const uint32_t A = p.nq * P;
-  bm25_union_count_kernel<<<(A + CNT_WAVES - 1) / CNT_WAVES, CNT_WAVES * 64, 0, st>>>(probe, p.q, p.total, p.del, p.del_words,
+  bm25_union_count_kernel<<<(A + CNT_WAVES - 1) / CNT_WAVES, CNT_WAVES * 64, 0, st>>>(probe, probe_row, p.q, p.total, p.del, p.del_words,
                                                                                      p.n_sub, p.nq, P, all_queries ? 1u : 0u);
   return SS_OK;
 }
 
 // returns SS_ENOTSUP when there is no instantiation for (nt_max, KPL): the caller falls back to the exhaustive kernels
-int ssi_bm25_launch_probe(const BmParams& p, const uint2* probe, const uint32_t* probe_z, const float* umax, uint32_t nt_max, int KPL,
-                          bool any_not, hipStream_t st) {
-  if (!probe || !probe_z || !umax || nt_max == 0 || nt_max > 4 || (KPL != 1 && KPL != 2)) return SS_ENOTSUP;
+int ssi_bm25_launch_probe(const BmParams& p, const uint2* probe, const uint32_t* probe_z, const uint32_t* probe_row, const float* umax,
+                          uint32_t nt_max, int KPL, bool any_not, hipStream_t st) {
+  if (!probe || !probe_z || !probe_row || !umax || nt_max == 0 || nt_max > 4 || (KPL != 1 && KPL != 2)) return SS_ENOTSUP;
   const int NT = nt_max <= 2 ? 2 : (int)nt_max;
   const bool filt = any_not || p.del != nullptr;
 #define SS_P(NT_, KPL_)                                                                          \
   if (NT == NT_ && KPL == KPL_)                                                                  \
-    return filt ? launch_probe<NT_, KPL_, true>(p, probe, probe_z, umax, st) : launch_probe<NT_, KPL_, false>(p, probe, probe_z, umax, st);
+    return filt ? launch_probe<NT_, KPL_, true>(p, probe, probe_z, probe_row, umax, st) : launch_probe<NT_, KPL_, false>(p, probe, probe_z, probe_row, umax, st);
   SS_P(2, 1) SS_P(3, 1) SS_P(4, 1) SS_P(2, 2) SS_P(3, 2) SS_P(4, 2)
 #undef SS_P
   return SS_ENOTSUP;

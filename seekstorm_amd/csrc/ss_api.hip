@@ -62,10 +62,10 @@ static void free_vec(ss_shard* s) {
   s->n_rows = s->n_rows_pad = 0; s->dim = s->dim_pad = s->dim_pad8 = 0; s->vec_multi_record = false;
 }
 static void free_bm25(ss_shard* s) {
-  void* ptrs[] = {s->d_post, s->d_term_base, s->d_sub_off, s->d_comp, s->d_probe, s->d_probe_z, s->d_umax, s->d_exc_off, s->d_exc_doc, s->d_exc_tf, s->d_boost};
+  void* ptrs[] = {s->d_post, s->d_term_base, s->d_sub_off, s->d_comp, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_umax, s->d_exc_off, s->d_exc_doc, s->d_exc_tf, s->d_boost};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->d_post = nullptr; s->d_term_base = nullptr; s->d_sub_off = nullptr; s->d_comp = nullptr;
-  s->d_probe = nullptr; s->d_probe_z = nullptr; s->d_umax = nullptr; s->d_exc_off = nullptr; s->d_exc_doc = nullptr; s->d_exc_tf = nullptr;
+  s->d_probe = nullptr; s->d_probe_z = nullptr; s->d_probe_row = nullptr; s->h_probe_row.clear(); s->bm_probe_rows = 0; s->d_umax = nullptr; s->d_exc_off = nullptr; s->d_exc_doc = nullptr; s->d_exc_tf = nullptr;
   s->bm_n_docs = 0; s->bm_n_terms = 0; s->bm_n_sub = 0; s->bm_n_post = 0; s->bm_n_fields = 1; s->d_boost = nullptr;
   s->h_df.clear(); s->h_df_real.clear(); s->bm_n_post_pad = 0;
 }
@@ -251,6 +251,31 @@ int ss_set_deleted(ss_shard* s, const uint64_t* doc_ids, uint64_t n) {
   return SS_OK;
 }
 
+// Probe-index budget of the NEXT image build (bytes; 0 = half of the free device memory).  Rows (1.9 MB per posting list
+// at 10 M docs) go to the longest lists first; a query touching a list without a row is ranked by the scan kernels.
+int ss_bm25_set_probe_budget(ss_shard* s, uint64_t max_bytes) {
+  if (!s) return SS_EINVAL;
+  std::lock_guard<std::mutex> g(s->mu);
+  s->probe_budget = max_bytes;
+  return SS_OK;
+}
+
+// 1 per term whose posting lists (all fields) have probe rows: such queries can take the pruned strategy
+int ss_bm25_term_probed(ss_shard* s, uint32_t n, const uint32_t* terms, uint8_t* out) {
+  if (!s || !terms || !out) return SS_EINVAL;
+  if (!s->d_post) return SS_ESTATE;
+  for (uint32_t i = 0; i < n; i++) {
+    if (terms[i] >= s->bm_n_terms / s->bm_n_fields) return SS_EINVAL;
+    uint8_t ok = s->bm_probe_rows != 0;
+    for (uint32_t f = 0; ok && f < s->bm_n_fields; f++) {
+      const uint32_t v = terms[i] * s->bm_n_fields + f;
+      if (s->h_probe_row[v] == BM_NO_PROBE_ROW && s->h_df[v] != 0) ok = 0;
+    }
+    out[i] = ok;
+  }
+  return SS_OK;
+}
+
 int ss_bm25_set_strategy(ss_shard* s, int strategy) {
   if (!s || strategy < SS_BM25_AUTO || strategy > SS_BM25_PRUNED) return SS_EINVAL;
   std::lock_guard<std::mutex> g(s->mu);
@@ -280,7 +305,8 @@ int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df
 
 // nt_max: largest n_terms + NOT terms of the batch (what the scan kernels are specialised on); np_max: largest n_terms
 static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q, bool* has_and, bool* has_or, uint32_t* nt_max,
-                         uint32_t* np_max) {
+                         uint32_t* np_max, bool* all_probed) {
+  *all_probed = s->bm_probe_rows != 0;
   *has_and = false;
   *has_or = false;
   *nt_max = 0;
@@ -295,6 +321,11 @@ static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q,
     }
     for (uint32_t t = 0; t < all; t++) {
       if (q[i].term[t] >= s->bm_n_terms / s->bm_n_fields) return SS_EINVAL;
+      if (*all_probed && s->bm_probe_rows < s->bm_n_terms)  // rows were rationed: does every list of this term have one?
+        for (uint32_t f = 0; f < s->bm_n_fields; f++) {
+          const uint32_t v = q[i].term[t] * s->bm_n_fields + f;
+          if (s->h_probe_row[v] == BM_NO_PROBE_ROW && s->h_df[v] != 0) *all_probed = false;
+        }
       if (t < q[i].n_terms && !(q[i].idf[t] > 0.0f)) return SS_EINVAL;
       for (uint32_t u = 0; u < t; u++)
         if (q[i].term[u] == q[i].term[t]) return SS_EINVAL;  // unique terms only (search.rs:3023 unique_terms)
@@ -316,7 +347,8 @@ int ss_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k,
   if (nq == 0) return SS_OK;
   bool has_and = false, has_or = false;
   uint32_t nt_max = 0, np_max = 0;
-  SS_TRY(check_queries(s, nq, q, &has_and, &has_or, &nt_max, &np_max));
+  bool all_probed = false;
+  SS_TRY(check_queries(s, nq, q, &has_and, &has_or, &nt_max, &np_max, &all_probed));
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   const uint32_t kk = rt == SS_RT_COUNT ? 0 : k;
@@ -329,7 +361,7 @@ int ss_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k,
   }
   SS_HIP(hipMemcpyAsync(s->d_bq, q, (size_t)nq * sizeof(ss_bm25_query), hipMemcpyHostToDevice, s->stream));
   SS_TRY(ssi_bm25_search(s, nq, (const ss_bm25_query*)s->d_bq, kk, rt, s->d_out_doc, s->d_out_score, s->d_out_count,
-                         s->d_out_total, has_and, has_or, nt_max, np_max, s->stream));
+                         s->d_out_total, has_and, has_or, nt_max, np_max, all_probed, s->stream));
   if (kk) {
     SS_HIP(hipMemcpyAsync(out_doc, s->d_out_doc, (size_t)nq * kk * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     SS_HIP(hipMemcpyAsync(out_score, s->d_out_score, (size_t)nq * kk * sizeof(float), hipMemcpyDeviceToHost, s->stream));
@@ -354,7 +386,9 @@ int ss_bm25_search_dev(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint3
                          (ops_mask & 1u) != 0, (ops_mask & 2u) != 0 || (ops_mask & 3u) == 0,
                          (ops_mask >> 8) & 0xFFu ? (ops_mask >> 8) & 0xFFu : SS_MAX_QUERY_TERMS,
                          (ops_mask >> 16) & 0xFFu ? (ops_mask >> 16) & 0xFFu
-                                                  : ((ops_mask >> 8) & 0xFFu ? (ops_mask >> 8) & 0xFFu : SS_MAX_QUERY_TERMS), st);
+                                                  : ((ops_mask >> 8) & 0xFFu ? (ops_mask >> 8) & 0xFFu : SS_MAX_QUERY_TERMS),
+                         // the caller vouches for the probe rows of its terms (ss_bm25_term_probed) unless none were rationed
+                         s->bm_probe_rows != 0 && (s->bm_probe_rows >= s->bm_n_terms || (ops_mask & 4u) != 0), st);
 }
 
 // ------------------------------------------------------------------ vectors

@@ -28,6 +28,7 @@ constexpr int BM_SUB_LOG2 = 12;             // docs per sub-block = 4096 = one w
 constexpr int BM_SUB = 1 << BM_SUB_LOG2;
 constexpr int BM_WAVES_OR = 8 << (12 - BM_SUB_LOG2);   // waves per workgroup (one workgroup per CU), union-only kernels
 constexpr int BM_WAVES_AND = 6 << (12 - BM_SUB_LOG2);  // kernels that also carry match counters
+constexpr uint32_t BM_NO_PROBE_ROW = 0xFFFFFFFFu;
 constexpr uint32_t BM_TF_ESC = 511;         // 9-bit tf field; 511 = "the exact tf (>= 511) is in the term's exception list"
 // Packed posting (one dword).  Laid out so that the two LDS byte offsets the scan needs are single AND / shift+AND
 // extractions and everything else rides in the bits they mask off:
@@ -103,8 +104,14 @@ struct ss_shard {
   // segment without reading the segment; the bit records are also the bitmaps exact union counts are popcounted from
   uint32_t* d_deleted = nullptr;   // tombstone bitmap by shard-local doc id (delete.bin / delete_hashset), null = none
   uint64_t deleted_words = 0, n_deleted = 0;
-  uint2* d_probe = nullptr;        // [n_terms + 1][n_sub][BM_SUB / 64] 64 doc bits; row n_terms is all zero (absent terms)
+  uint2* d_probe = nullptr;        // [probe_rows + 1][n_sub][BM_SUB / 64] 64 doc bits; the last row is all zero (absent terms)
   uint32_t* d_probe_z = nullptr;   // same shape: index inside the term of the group's first posting (read on hits only)
+  uint32_t* d_probe_row = nullptr; // [n_terms + 1] row of each (virtual) term, BM_NO_PROBE_ROW for the lists left without one:
+                                   // rows go to the longest lists until the budget is spent (1.9 MB per list at 10 M docs is
+                                   // the right price for the lists that cost query time, not for a vocabulary's long tail)
+  std::vector<uint32_t> h_probe_row;
+  uint32_t bm_probe_rows = 0;
+  uint64_t probe_budget = 0;       // ss_bm25_set_probe_budget: bytes, 0 = half of the free device memory
   int bm_strategy = SS_BM25_AUTO;  // ss_bm25_set_strategy
   uint64_t* d_exc_off = nullptr;   // [n_terms + 2] CSR of the exception lists (postings with tf >= 511)
   uint32_t* d_exc_doc = nullptr;   // shard-local doc ids, ascending per term
@@ -176,7 +183,7 @@ __host__ __device__ inline uint32_t bm_q_op(uint32_t op) { return op & 0xFFu; }
 __host__ __device__ inline uint32_t bm_q_nnot(uint32_t op) { return (op >> 8) & 0xFFu; }
 int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t* d_out_doc,
                     float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, bool has_or,
-                    uint32_t nt_max, uint32_t np_max, hipStream_t st);
+                    uint32_t nt_max, uint32_t np_max, bool all_probed, hipStream_t st);
 // ---- implemented in synth.hip
 int ssi_vec_synth(ss_shard* s, uint64_t seed, hipStream_t st);
 int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const uint8_t* d_lentab, hipStream_t st);

@@ -84,16 +84,37 @@ constexpr int BM_GROUPS = BM_SUB / 64;
 static int alloc_probe(ss_shard* s, hipStream_t st) {
   // Everything the builders do not overwrite is cleared ON THE BUILD STREAM: the shard stream is non-blocking, so a
   // null-stream hipMemset is not ordered against the generator kernels that follow and could wipe what they wrote.
-  const size_t rows = (size_t)s->bm_n_terms * s->bm_n_sub * BM_GROUPS, zero_row = (size_t)s->bm_n_sub * BM_GROUPS;
-  SS_HIP(hipMalloc(&s->d_umax, ((size_t)s->bm_n_terms + 1) * sizeof(float)));
-  SS_HIP(hipMemsetAsync(s->d_umax, 0, ((size_t)s->bm_n_terms + 1) * sizeof(float), st));
+  const uint32_t nt = s->bm_n_terms;
+  const size_t row_elems = (size_t)s->bm_n_sub * BM_GROUPS;
+  SS_HIP(hipMalloc(&s->d_umax, ((size_t)nt + 1) * sizeof(float)));
+  SS_HIP(hipMemsetAsync(s->d_umax, 0, ((size_t)nt + 1) * sizeof(float), st));
   size_t free_b = 0, total_b = 0;
   SS_HIP(hipMemGetInfo(&free_b, &total_b));
-  if ((rows + zero_row) * (sizeof(uint2) + sizeof(uint32_t)) > free_b / 2) return SS_OK;
-  SS_HIP(hipMalloc(&s->d_probe, (rows + zero_row) * sizeof(uint2)));
-  SS_HIP(hipMalloc(&s->d_probe_z, (rows + zero_row) * sizeof(uint32_t)));
-  SS_HIP(hipMemsetAsync(s->d_probe + rows, 0, zero_row * sizeof(uint2), st));  // row n_terms: absent terms
-  SS_HIP(hipMemsetAsync(s->d_probe_z + rows, 0, zero_row * sizeof(uint32_t), st));
+  const size_t budget = s->probe_budget ? (size_t)s->probe_budget : free_b / 2;
+  const size_t row_bytes = row_elems * (sizeof(uint2) + sizeof(uint32_t));
+  size_t max_rows = row_bytes ? budget / row_bytes : 0;
+  max_rows = max_rows ? max_rows - 1 : 0;  // the all-zero row
+  s->h_probe_row.assign((size_t)nt + 1, BM_NO_PROBE_ROW);
+  s->bm_probe_rows = 0;
+  if (max_rows == 0) return SS_OK;  // no probe index at all: every search scans
+  // rows for the longest lists first (s->h_df is known at this point in both builders)
+  std::vector<uint32_t> order(nt);
+  for (uint32_t t = 0; t < nt; t++) order[t] = t;
+  if (max_rows < nt)
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return s->h_df[x] > s->h_df[y]; });
+  const uint32_t rows = (uint32_t)std::min<size_t>(max_rows, nt);
+  for (uint32_t i = 0; i < rows; i++) s->h_probe_row[order[i]] = i;
+  s->h_probe_row[nt] = rows;  // absent terms of a short query: the zero row
+  for (uint32_t t = 0; t < nt; t++)  // ... which also serves every empty list
+    if (s->h_probe_row[t] == BM_NO_PROBE_ROW && s->h_df[t] == 0) s->h_probe_row[t] = rows;
+  s->bm_probe_rows = rows;
+  SS_HIP(hipMalloc(&s->d_probe, ((size_t)rows + 1) * row_elems * sizeof(uint2)));
+  SS_HIP(hipMalloc(&s->d_probe_z, ((size_t)rows + 1) * row_elems * sizeof(uint32_t)));
+  SS_HIP(hipMalloc(&s->d_probe_row, ((size_t)nt + 1) * sizeof(uint32_t)));
+  SS_HIP(hipMemsetAsync(s->d_probe + (size_t)rows * row_elems, 0, row_elems * sizeof(uint2), st));
+  SS_HIP(hipMemsetAsync(s->d_probe_z + (size_t)rows * row_elems, 0, row_elems * sizeof(uint32_t), st));
+  SS_HIP(hipMemcpyAsync(s->d_probe_row, s->h_probe_row.data(), ((size_t)nt + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  SS_HIP(hipStreamSynchronize(st));  // h_probe_row may be re-assigned by a later build while the copy is in flight
   return SS_OK;
 }
 __host__ __device__ inline float bm_weight_of(uint32_t tf, uint32_t len_byte, const float* comp) {
@@ -191,20 +212,23 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
   std::vector<float> umax((size_t)nt + 1, 0.f);
   std::vector<uint2> probe;
   std::vector<uint32_t> probe_z;
-  if (s->d_probe) probe.assign((size_t)nt * ns * BM_GROUPS, make_uint2(0, 0));
+  if (s->d_probe) probe.assign((size_t)s->bm_probe_rows * ns * BM_GROUPS, make_uint2(0, 0));
   probe_z.assign(probe.size(), 0u);
   for (uint32_t t = 0; t < nt; t++) {
     for (u64 j = offs[t]; j < offs[t + 1]; j++) {
       umax[t] = std::max(umax[t], bm_weight_of(tfs[j], doclen[(size_t)(t % s->bm_n_fields) * s->bm_n_docs + docs[j]], comp));
-      if (!s->d_probe) continue;
+      if (!s->d_probe || s->h_probe_row[t] == BM_NO_PROBE_ROW) continue;
       const uint32_t sb = docs[j] >> BM_SUB_LOG2, d = docs[j] & (BM_SUB - 1);
-      uint2* row = probe.data() + ((size_t)t * ns + sb) * BM_GROUPS;
+      uint2* row = probe.data() + ((size_t)s->h_probe_row[t] * ns + sb) * BM_GROUPS;
       const uint32_t g = d >> 6, b = d & 63;
       if (b < 32) row[g].x |= 1u << b; else row[g].y |= 1u << (b - 32);
     }
   }
+  std::vector<uint32_t> term_of_row(s->bm_probe_rows, 0);
+  for (uint32_t t = 0; t < nt; t++)
+    if (s->d_probe && s->h_probe_row[t] != BM_NO_PROBE_ROW) term_of_row[s->h_probe_row[t]] = t;
   for (size_t r = 0; r < probe.size(); r += BM_GROUPS) {  // z = index (inside the term) of the group's first posting
-    const size_t t = (r / BM_GROUPS) / ns, sb = (r / BM_GROUPS) % ns;
+    const size_t t = term_of_row[(r / BM_GROUPS) / ns], sb = (r / BM_GROUPS) % ns;
     uint32_t run = sub[t * (ns + 1) + sb] * 4u;
     for (int g = 0; g < BM_GROUPS; g++) {
       probe_z[r + g] = run;
@@ -240,7 +264,8 @@ template <bool FILL>
 __global__ void lex_gen_kernel(u64 seed, u64 n_docs, uint32_t n_terms, uint32_t n_sub, const uint32_t* __restrict__ thresh,
                                const uint8_t* __restrict__ doclen, uint32_t* __restrict__ sub /*[nt][ns+1]*/,
                                const u64* __restrict__ term_base, uint32_t* __restrict__ post, u64* __restrict__ df,
-                               uint2* __restrict__ probe, uint32_t* __restrict__ probe_z, uint32_t* __restrict__ umax_bits, const float* __restrict__ comp) {
+                               uint2* __restrict__ probe, uint32_t* __restrict__ probe_z, const uint32_t* __restrict__ probe_row,
+                               uint32_t* __restrict__ umax_bits, const float* __restrict__ comp) {
   const int lane = threadIdx.x & 63;
   const u64 gw = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const u64 total = (u64)n_terms * n_sub;
@@ -264,8 +289,8 @@ __global__ void lex_gen_kernel(u64 seed, u64 n_docs, uint32_t n_terms, uint32_t 
       post[base + pos] = bm_pack((uint32_t)(d & (BM_SUB - 1)), doclen[d], tf);
       wmax = fmaxf(wmax, bm_weight_of(tf, doclen[d], comp));
     }
-    if (FILL && probe && lane == 0) {
-      const size_t gi = ((size_t)t * n_sub + sb) * (BM_SUB / 64) + i;
+    if (FILL && probe && lane == 0 && probe_row[t] != BM_NO_PROBE_ROW) {
+      const size_t gi = ((size_t)probe_row[t] * n_sub + sb) * (BM_SUB / 64) + i;
       probe[gi] = make_uint2((uint32_t)m, (uint32_t)(m >> 32));
       probe_z[gi] = sub[(size_t)t * (n_sub + 1) + sb] * 4u + run;
     }
@@ -340,7 +365,7 @@ int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const u
   const u64 waves = (u64)nt * ns;
   const uint32_t grid = (uint32_t)((waves + 3) / 4);
   lex_gen_kernel<false><<<grid, 256, 0, st>>>(seed, nd, nt, ns, d_thresh, d_doclen, s->d_sub_off, nullptr, nullptr, d_df,
-                                              nullptr, nullptr, nullptr, nullptr);
+                                              nullptr, nullptr, nullptr, nullptr, nullptr);
   lex_scan_rows_kernel<<<nt, 1024, 0, st>>>(s->d_sub_off, ns, d_tot);
   lex_scan_terms_kernel<<<1, 64, 0, st>>>(d_tot, (u64*)s->d_term_base, nt);
   SS_HIP(hipStreamSynchronize(st));
@@ -367,7 +392,7 @@ int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const u
   rc = alloc_probe(s, st);
   if (rc) return rc;
   lex_gen_kernel<true><<<grid, 256, 0, st>>>(seed, nd, nt, ns, d_thresh, d_doclen, s->d_sub_off,
-                                             (const u64*)s->d_term_base, s->d_post, nullptr, s->d_probe, s->d_probe_z,
+                                             (const u64*)s->d_term_base, s->d_post, nullptr, s->d_probe, s->d_probe_z, s->d_probe_row,
                                              (uint32_t*)s->d_umax, s->d_comp);
   SS_HIP(hipStreamSynchronize(st));
   (void)hipFree(d_doclen);

@@ -300,6 +300,16 @@ class Shard:
         N.check(N.lib().ss_vec_read_rows(self._h, int(r0), int(n), N.ptr(out, N.f32p)), "ss_vec_read_rows")
         return out
 
+    def set_probe_budget(self, max_bytes):
+        """bytes of probe index the NEXT image build may spend (rows go to the longest posting lists first); 0 = default"""
+        N.check(N.lib().ss_bm25_set_probe_budget(self._h, int(max_bytes)), "ss_bm25_set_probe_budget")
+
+    def terms_probed(self, terms):
+        t = np.ascontiguousarray(terms, np.uint32)
+        out = np.zeros(len(t), np.uint8)
+        N.check(N.lib().ss_bm25_term_probed(self._h, len(t), N.ptr(t, N.u32p), N.ptr(out, N.u8p)), "ss_bm25_term_probed")
+        return out.astype(bool)
+
     def set_strategy(self, strategy):
         """N.BM25_AUTO / BM25_EXHAUSTIVE / BM25_PRUNED (ss_bm25_set_strategy); both strategies return identical results"""
         N.check(N.lib().ss_bm25_set_strategy(self._h, int(strategy)), "ss_bm25_set_strategy")

@@ -153,3 +153,33 @@ def test_pruned_is_repeatable_on_a_generated_corpus(S, O):
         n = len(sub)
         assert np.array_equal(ps, es[:n]) and np.array_equal(pd, ed[:n]) and np.array_equal(pc, ec[:n]), f"run {rep}"
     sh.close()
+
+
+def test_rationed_probe_rows(S, O):
+    """probe rows only for the longest lists (a real vocabulary's tail gets none): queries over probed lists still take the
+    pruned strategy, queries touching an unprobed list fall back to the scan -- same answers either way"""
+    from seekstorm_amd import _native as N
+    n_docs = 150_000
+    dfs = [0.3, 0.11, 0.05, 0.02, 0.008, 0.002, 0.0009, 0.0004, 0.0]
+    dl, offs, docs, tfs = _corpus(O, n_docs, dfs, 11)
+    full, part = S.Shard(0), S.Shard(0)
+    full.upload_lexical(n_docs, dl, offs, docs, tfs)
+    n_sub = (n_docs + 4095) // 4096
+    part.set_probe_budget((4 + 1) * n_sub * 64 * 12)  # four rows + the zero row
+    part.upload_lexical(n_docs, dl, offs, docs, tfs)
+    assert list(full.terms_probed(np.arange(len(dfs)))) == [True] * len(dfs)
+    assert list(part.terms_probed(np.arange(len(dfs)))) == [True] * 4 + [False] * 5  # (_corpus gives the last list one posting)
+    tl = [[0, 1, 2], [1, 3], [0, 5], [6, 7], [2, 4, 7], [3], [5], [0, 8], [1, 2, 3, 0]]
+    for qt in (S.QueryType.Union, S.QueryType.Intersection):
+        for rt in (S.ResultType.Topk, S.ResultType.TopkCount, S.ResultType.Count):
+            a = full.search_lexical_batch(full.make_queries(tl, qt), 10, rt)
+            b = part.search_lexical_batch(part.make_queries(tl, qt), 10, rt)
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y), (qt, rt)
+    # only-probed batches may force the pruned strategy, batches touching the tail may not
+    part.set_strategy(N.BM25_PRUNED)
+    part.search_lexical_batch(part.make_queries([[0, 1], [2, 3]], S.QueryType.Union), 10, S.ResultType.Topk)
+    with pytest.raises(S.SeekStormHipError):
+        part.search_lexical_batch(part.make_queries([[0, 1], [2, 6]], S.QueryType.Union), 10, S.ResultType.Topk)
+    full.close()
+    part.close()
