@@ -206,14 +206,13 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
       // round 1: z of the A hit, and (speculatively: these are the few survivors) the bits of every remaining term
       const size_t gidx = (size_t)tile * (BM_SUB / 64) + (d >> 6);
       const bool hit_a = alive && pos != 0xFFFFFFFFu;  // pos = rank inside the group
-      uint32_t za = 0u;
-      if (hit_a) za = zrow[A][gidx];
+      const uint32_t za = zrow[A][hit_a ? gidx : (size_t)0];  // unconditional loads (dead lanes: element 0), no exec-masked branches
       uint2 rb[NT];
 #pragma unroll
       for (int t = 0; t < NT; t++) {
         rb[t] = make_uint2(0u, 0u);
         if (t == J || t == A || (uint32_t)t >= nt) continue;
-        if (alive) rb[t] = prow[t][gidx];
+        rb[t] = prow[t][alive ? gidx : (size_t)0];
       }
       // round 2: the A posting, z of the other hits
       uint32_t pa = 0u;
@@ -233,7 +232,8 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
 #pragma unroll
       for (int t = 0; t < NT; t++) {
         hit[t] = hit[t] && alive;
-        if (hit[t]) zt[t] = zrow[t][gidx];
+        if (t == J || t == A || (uint32_t)t >= nt) continue;
+        zt[t] = zrow[t][hit[t] ? gidx : (size_t)0];
       }
       if (hit_a) {
         wv[A] = pb_weight(pa, X, tid_[A], doc);
