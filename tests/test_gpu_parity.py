@@ -647,3 +647,31 @@ def test_bm25f_several_fields(S, O, n_fields, boost):
         q["op"][0] |= 0  # 5 terms x 3 fields fit (15 <= 32)
         sh.search_lexical_batch(q, 10)
     sh.close()
+
+
+def test_c1_standin_one_million_docs_and_pairs(S, O):
+    """BASELINE configs[0] stand-in (LEX-1M, 2-term AND, top-10, df bands [1 %, 5 %] x [5 %, 20 %]): the device
+    generator's corpus against the reference-structured oracle on the host-generated copy of the same corpus"""
+    n_docs = 1_000_000
+    th = O.term_thresholds()
+    df = th.astype(np.float64) / 2.0 ** 32
+    lo = np.nonzero((df >= 0.01) & (df < 0.05))[0]
+    hi = np.nonzero((df >= 0.05) & (df < 0.20))[0]
+    rng = np.random.default_rng(12)
+    pairs = [(int(rng.choice(lo)), int(rng.choice(hi))) for _ in range(40)]
+    sh = S.Shard(0)
+    sh.synth_lexical(O.LEX_SEED, n_docs, th, O.len_table())
+    q = sh.make_queries([list(p) for p in pairs], S.QueryType.Intersection)
+    doc, score, cnt, tot = sh.search_lexical_batch(q, 10, S.ResultType.TopkCount)
+    doc2, score2, cnt2, _ = sh.search_lexical_batch(q, 10, S.ResultType.Topk)
+    assert np.array_equal(score, score2) and np.array_equal(doc, doc2)
+    dl = O.lex_doclen(n_docs)
+    for i in range(0, len(pairs), 4):  # the oracle on every fourth pair: host generation of the two lists + its own search
+        terms = sorted(set(pairs[i]))
+        offs, docs, tfs = O.lex_corpus(n_docs, terms)
+        osh = O.Shard(n_docs, dl, offs, docs, tfs)
+        local = [terms.index(t) for t in pairs[i]]
+        od, os_, otot = osh.search(local, O.OP_AND, 10, O.RT_TOPKCOUNT)
+        assert int(tot[i]) == otot
+        _check_topk(doc[i], score[i], cnt[i], od, os_)
+    sh.close()
