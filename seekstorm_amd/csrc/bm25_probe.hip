@@ -204,15 +204,15 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
       uint32_t pres = 1u << J;
       float known = idf[J] * wv[J];
       // round 1: z of the A hit, and (speculatively: these are the few survivors) the bits of every remaining term
-      const size_t gidx = (size_t)tile * (BM_SUB / 64) + (d >> 6);
+      const uint32_t gidx = tile * (uint32_t)(BM_SUB / 64) + (d >> 6);
       const bool hit_a = alive && pos != 0xFFFFFFFFu;  // pos = rank inside the group
-      const uint32_t za = zrow[A][hit_a ? gidx : (size_t)0];  // unconditional loads (dead lanes: element 0), no exec-masked branches
+      const uint32_t za = zrow[A][hit_a ? gidx : 0u];  // unconditional loads (dead lanes: element 0), no exec-masked branches
       uint2 rb[NT];
 #pragma unroll
       for (int t = 0; t < NT; t++) {
         rb[t] = make_uint2(0u, 0u);
         if (t == J || t == A || (uint32_t)t >= nt) continue;
-        rb[t] = prow[t][alive ? gidx : (size_t)0];
+        rb[t] = prow[t][alive ? gidx : 0u];
       }
       // round 2: the A posting, z of the other hits
       uint32_t pa = 0u;
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
       for (int t = 0; t < NT; t++) {
         hit[t] = hit[t] && alive;
         if (t == J || t == A || (uint32_t)t >= nt) continue;
-        zt[t] = zrow[t][hit[t] ? gidx : (size_t)0];
+        zt[t] = zrow[t][hit[t] ? gidx : 0u];
       }
       if (hit_a) {
         wv[A] = pb_weight(pa, X, tid_[A], doc);
@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
         if (!is_and && k) alive[g] = alive[g] && (idf[J] * w0[g] + rest0) >= thr * 0.99999f;
         // unconditional load, dead lanes read record 0 (one cached line): four back-to-back gathers instead of four
         // exec-masked branches; a dead lane's record is never looked at
-        rec[g] = prow[A][alive[g] ? (size_t)tile[g] * (BM_SUB / 64) + (dg[g] >> 6) : (size_t)0];
+        rec[g] = prow[A][alive[g] ? tile[g] * (uint32_t)(BM_SUB / 64) + (dg[g] >> 6) : 0u];  // 32-bit index: SGPR base + VGPR offset addressing
       }
 #pragma unroll
       for (int g = 0; g < G; g++) {
