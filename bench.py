@@ -148,8 +148,8 @@ def main():
             N.check(L.ss_bm25_search_dev(sh._h, n, q_dev.data_ptr(), k, N.RT_TOPK, 2 | (3 << 8), o_doc.data_ptr(), o_score.data_ptr(),
                                          o_cnt.data_ptr(), o_tot.data_ptr(), sptr), "ss_bm25_search_dev")
             if world > 1:  # one all-gather of the per-shard top-k over RCCL, identical merge on every rank
-                g = D.all_gather_topk(o_doc[:n], o_score[:n], o_cnt[:n])
-                merged["bm25"] = D.merge_gathered_device(*g, sptr, local_rank)
+                g = D.all_gather_topk_packed(o_doc[:n], o_score[:n], o_cnt[:n])  # ONE collective per batch
+                merged["bm25"] = D.merge_gathered_device_packed(g, n, k, sptr, local_rank)
 
         # exact union sizes for the roofline's "1 B per scored candidate" term: one untimed TopkCount pass (exhaustive scan)
         sh.set_strategy(N.BM25_EXHAUSTIVE)
@@ -278,8 +278,8 @@ def main():
             N.check(L.ss_vec_search_dev(sh._h, n, qv.data_ptr(), kv, N.FLT_MIN_NEG, v_doc.data_ptr(), v_score.data_ptr(),
                                         v_cnt.data_ptr(), v_tot.data_ptr(), sptr), "ss_vec_search_dev")
             if world > 1:
-                g = D.all_gather_topk(v_doc[:n], v_score[:n], v_cnt[:n])
-                merged["vec"] = D.merge_gathered_device(*g, sptr, local_rank)
+                g = D.all_gather_topk_packed(v_doc[:n], v_score[:n], v_cnt[:n])
+                merged["vec"] = D.merge_gathered_device_packed(g, n, kv, sptr, local_rank)
 
         sh.profile(True)
         vec_step()

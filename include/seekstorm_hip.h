@@ -241,6 +241,10 @@ int ss_merge_results(int mode, const uint64_t* lex_doc, const float* lex_score, 
 int ss_topk_merge_dev(int device, uint32_t n_queries, uint32_t n_shards, uint32_t k, const uint32_t* d_doc,
                       const float* d_score, const uint32_t* d_count, uint64_t* d_out_doc, float* d_out_score,
                       uint32_t* d_out_count, void* stream);
+/* the same over ONE gathered buffer: per shard [n_queries * k doc ids | n_queries * k score bits | n_queries counts] as
+ * 32-bit words -- a single all-gather per batch (latency bound: three collectives cost three latencies) */
+int ss_topk_merge_dev_packed(int device, uint32_t n_queries, uint32_t n_shards, uint32_t k, const uint32_t* d_packed,
+                             uint64_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, void* stream);
 
 /* ------------------------------------------------------------------ measurement hooks
  * When enabled the library brackets every launch of the dominant kernels with HIP events on the stream

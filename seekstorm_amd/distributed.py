@@ -31,6 +31,41 @@ def all_gather_topk(doc: torch.Tensor, score: torch.Tensor, count: torch.Tensor)
     return g_doc, g_score, g_cnt
 
 
+def pack_topk(doc: torch.Tensor, score: torch.Tensor, count: torch.Tensor) -> torch.Tensor:
+    """[nq * k doc ids | nq * k score bits | nq counts] as int32: one buffer, one all-gather"""
+    return torch.cat([doc.contiguous().view(torch.int32).reshape(-1), score.contiguous().view(torch.int32).reshape(-1),
+                      count.contiguous().view(torch.int32).reshape(-1)])
+
+
+def all_gather_topk_packed(doc: torch.Tensor, score: torch.Tensor, count: torch.Tensor) -> torch.Tensor:
+    """One collective for the whole batch (payload (2 k + 1) nq words per rank; three separate gathers cost three
+    latencies).  Returns the gathered buffer [S, (2 k + 1) nq] int32 for merge_gathered_device_packed / unpack_gathered."""
+    world = dist.get_world_size()
+    x = pack_topk(doc, score, count)
+    out = torch.empty((world * x.shape[0],), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x)
+    return out.view(world, x.shape[0])
+
+
+def unpack_gathered(packed: torch.Tensor, nq: int, k: int):
+    """views [S, nq, k] doc (int32), score (f32), [S, nq] count of a packed gather"""
+    S = packed.shape[0]
+    nk = nq * k
+    return (packed[:, :nk].reshape(S, nq, k), packed[:, nk:2 * nk].contiguous().view(torch.float32).reshape(S, nq, k),
+            packed[:, 2 * nk:].reshape(S, nq))
+
+
+def merge_gathered_device_packed(packed: torch.Tensor, nq: int, k: int, stream_ptr, device_index):
+    """ss_topk_merge_dev_packed on the packed gather; returns (global ids int64 [nq,k], scores, counts)."""
+    S = packed.shape[0]
+    m_doc = torch.empty((nq, k), dtype=torch.int64, device=packed.device)
+    m_score = torch.empty((nq, k), dtype=torch.float32, device=packed.device)
+    m_cnt = torch.empty((nq,), dtype=torch.int32, device=packed.device)
+    N.check(N.lib().ss_topk_merge_dev_packed(device_index, nq, S, k, packed.data_ptr(), m_doc.data_ptr(), m_score.data_ptr(),
+                                             m_cnt.data_ptr(), stream_ptr), "ss_topk_merge_dev_packed")
+    return m_doc, m_score, m_cnt
+
+
 def merge_gathered_host(g_doc, g_score, g_cnt, offset, length, mode=SearchMode.Lexical):
     """Host merge of gathered single-mode lists -> per query (global ids, scores).  Shard of list s is rank s."""
     S, nq, k = g_doc.shape

@@ -326,7 +326,11 @@ def test_device_merge_matches_host_merge(S, O):
     with torch.cuda.stream(st):
         g = [torch.from_numpy(x).to(dev) for x in (doc, score, cnt)]
         m_doc, m_score, m_cnt = D.merge_gathered_device(*g, C.c_void_p(st.cuda_stream), 0)
+        # the packed form (one all-gather per batch): per shard [doc | score bits | count]
+        packed = torch.stack([D.pack_topk(g[0][s_], g[1][s_], g[2][s_]) for s_ in range(Sn)])
+        p_doc, p_score, p_cnt = D.merge_gathered_device_packed(packed, nq, k, C.c_void_p(st.cuda_stream), 0)
         st.synchronize()
+        assert torch.equal(p_doc, m_doc) and torch.equal(p_score, m_score) and torch.equal(p_cnt, m_cnt)
     host = D.merge_gathered_host(torch.from_numpy(doc), torch.from_numpy(score), torch.from_numpy(cnt), 0, k, S.SearchMode.Vector)
     md, ms, mc = m_doc.cpu().numpy(), m_score.cpu().numpy(), m_cnt.cpu().numpy()
     for q in range(nq):

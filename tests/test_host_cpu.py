@@ -117,6 +117,9 @@ def _worker(rank, world, port, nq, k, seed, q):
     out = {}
     for name, (doc, score, cnt), mode in (("lex", lex, SearchMode.Lexical), ("vec", vec, SearchMode.Vector)):
         g = D.all_gather_topk(torch.from_numpy(doc), torch.from_numpy(score), torch.from_numpy(cnt))
+        # the single packed collective the GPU path uses carries the same three arrays
+        gp = D.unpack_gathered(D.all_gather_topk_packed(torch.from_numpy(doc), torch.from_numpy(score), torch.from_numpy(cnt)), nq, k)
+        assert all(torch.equal(a, b) for a, b in zip(g, gp))
         out[name] = D.merge_gathered_host(*g, 0, k, mode)
         out[name + "_g"] = g
     out["hyb"] = D.merge_gathered_hybrid_host(out.pop("lex_g"), out.pop("vec_g"), 0, k)
