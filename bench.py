@@ -295,13 +295,15 @@ def main():
         avg_ms = kms / max(launches, 1)
         ach = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         lat = latencies(vec_step, 8)
+        lat1 = latencies(lambda: vec_step(1), 8)  # <= 32 queries: half of the MFMA work is skipped, the pass is HBM-bound
         vec = dict(qps=B * vsteps / dtv, ms_per_step=dtv / vsteps * 1e3, build_s=vbuild,
                    roofline={"bound": "mfma", "kernel": "vec_scan_kernel (+refine, all row chunks of one pass)", "achieved": ach,
                              "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": pmc_traffic("vector"),
                              "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": 4.0 * args.dim * args.rows,
                              "hbm_GBs": 4.0 * args.dim * args.rows / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
                              "avg_launch_ms": avg_ms, "launches": int(launches)},
-                   latency_ms={"batch64_p50": pct(lat, 50), "batch64_p99": pct(lat, 99)})
+                   latency_ms={"batch64_p50": pct(lat, 50), "batch64_p99": pct(lat, 99), "single_query_p50": pct(lat1, 50),
+                               "single_query_p99": pct(lat1, 99)})
         # property checks at full size: sorted, and the scores really are dot products of the returned rows
         vs = v_score.cpu().numpy()
         assert np.all(vs[:, :-1] >= vs[:, 1:])

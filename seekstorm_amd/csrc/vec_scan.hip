@@ -46,6 +46,9 @@ __global__ void vec_init_kernel(VState* st, float tau_init) {
 }
 
 // ---------------------------------------------------------------- the scan
+// TWO: queries 32..63 are in use.  A batch of <= 32 queries skips their half of the MFMA work, which turns the scan from
+// MFMA-bound (9.2 ms per pass at 10 M x 768) into HBM-bound: the latency of small batches and single queries.
+template <bool TWO>
 __global__ void __launch_bounds__(VS_WAVES * 64, 2)
 vec_scan_kernel(const float* __restrict__ X, uint32_t dim_pad, unsigned long long n_rows,
                 const float* __restrict__ Qf, uint32_t nch, uint32_t tile0, uint32_t ntiles, VState* __restrict__ st,
@@ -126,14 +129,14 @@ vec_scan_kernel(const float* __restrict__ X, uint32_t dim_pad, unsigned long lon
     for (int t = 0; t < 4; t++) {
       xa[t] = *(const f32x4*)(sb + aoff[t]);
       qb0[t] = *(const f32x4*)(sb + boff + t * 1024);
-      qb1[t] = *(const f32x4*)(sb + boff + (4 + t) * 1024);
+      if (TWO) qb1[t] = *(const f32x4*)(sb + boff + (4 + t) * 1024);
     }
 #pragma unroll
     for (int t = 0; t < 4; t++) {
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[t][j], qb0[t][j], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[t][j], qb1[t][j], acc1, 0, 0, 0);
+        if (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[t][j], qb1[t][j], acc1, 0, 0, 0);
       }
     }
 
@@ -141,16 +144,16 @@ vec_scan_kernel(const float* __restrict__ X, uint32_t dim_pad, unsigned long lon
       // ---- fused top-k filter: lane owns query (lane&31)+{0,32}, 16 rows per accumulator
       const unsigned long long row_base =
           (unsigned long long)(tile0 + first + (unsigned long long)c_tile * gridDim.x) * VS_TR + 32u * w + 4u * (lane >> 5);
-      float m0 = acc0[0], m1 = acc1[0];
+      float m0 = acc0[0], m1 = TWO ? acc1[0] : -INFINITY;
 #pragma unroll
-      for (int r = 1; r < 16; r++) { m0 = fmaxf(m0, acc0[r]); m1 = fmaxf(m1, acc1[r]); }
+      for (int r = 1; r < 16; r++) { m0 = fmaxf(m0, acc0[r]); if (TWO) m1 = fmaxf(m1, acc1[r]); }
       if (m0 > tau0) {
         float f[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) f[r] = acc0[r];
         vs_append(f, tau0, lane & 31, row_base, n_rows, st, cand);
       }
-      if (m1 > tau1) {
+      if (TWO && m1 > tau1) {
         float f[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) f[r] = acc1[r];
@@ -290,7 +293,8 @@ int ssi_vec_alloc_ws(ss_shard* s) {
   }
   if (!s->d_vstate) SS_HIP(hipMalloc(&s->d_vstate, sizeof(VState)));
   if (!s->d_cand) SS_HIP(hipMalloc(&s->d_cand, (size_t)64 * VS_CAP * sizeof(unsigned long long)));
-  SS_SET_MAX_LDS(vec_scan_kernel, VS_LDS);
+  SS_SET_MAX_LDS(vec_scan_kernel<true>, VS_LDS);
+  SS_SET_MAX_LDS(vec_scan_kernel<false>, VS_LDS);
   SS_SET_MAX_LDS(vec_refine_kernel, VS_CAP * (sizeof(unsigned long long) + sizeof(uint32_t)));
   return SS_OK;
 }
@@ -340,9 +344,12 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float*
     for (uint32_t c : chunks) {
       uint32_t grid = std::min<uint32_t>(c, 512);
       if (i8) ssi_vec8_launch_scan(s, tile0, c, d_qscale ? d_qscale + g0 : nullptr, st);
+      else if (nb > 32)
+        vec_scan_kernel<true><<<grid, VS_WAVES * 64, VS_LDS, st>>>(s->d_X, s->dim_pad, (unsigned long long)s->n_rows, s->d_Qf,
+                                                                   nch, tile0, c, vst, cand);
       else
-        vec_scan_kernel<<<grid, VS_WAVES * 64, VS_LDS, st>>>(s->d_X, s->dim_pad, (unsigned long long)s->n_rows, s->d_Qf,
-                                                             nch, tile0, c, vst, cand);
+        vec_scan_kernel<false><<<grid, VS_WAVES * 64, VS_LDS, st>>>(s->d_X, s->dim_pad, (unsigned long long)s->n_rows, s->d_Qf,
+                                                                    nch, tile0, c, vst, cand);
       vec_refine_kernel<<<SS_VEC_BATCH, VR_THREADS, VS_CAP * (sizeof(unsigned long long) + sizeof(uint32_t)), st>>>(
           vst, cand, k, s->vec_multi_record ? s->d_row_doc : nullptr, s->d_row_doc, s->n_deleted ? s->d_deleted : nullptr,
           (uint32_t)s->deleted_words);
