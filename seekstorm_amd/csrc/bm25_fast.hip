@@ -16,7 +16,7 @@
 // processed four at a time per item with the term state re-read from a per-wave LDS table (no cross-item prefetch).
 #include "bm25_dev.h"
 
-template <int NT> struct FastCfg { static constexpr int CPT = NT <= 2 ? 4 : 3; static constexpr int RC = NT * CPT; };
+template <int NT> struct FastCfg { static constexpr int CPT = NT <= 2 ? 4 : NT <= 4 ? 3 : 2; static constexpr int RC = NT * CPT; };
 
 #define BM_KERNEL_ARGS                                                                                              \
   const uint32_t *__restrict__ post, const unsigned long long *__restrict__ term_base,                             \
@@ -346,11 +346,12 @@ static int launch_group(const BmParams& p, hipStream_t st) {
 }
 
 int ssi_bm25_launch_scan(const BmParams& p, uint32_t nt_max, bool has_and, int KPL, hipStream_t st) {
-  if (nt_max >= 1 && nt_max <= 4 && (KPL == 1 || KPL == 2)) {
-    const int NT = nt_max <= 2 ? 2 : (int)nt_max;
+  if (nt_max >= 1 && nt_max <= 6 && (KPL == 1 || KPL == 2) && !(nt_max > 4 && KPL == 2)) {
+    const int NT = nt_max <= 2 ? 2 : nt_max <= 4 ? (int)nt_max : 6;  // 5-6 lists (several fields): one instantiation
 #define SS_F(NT_, AND_, KPL_) \
   if (NT == NT_ && has_and == AND_ && KPL == KPL_) return launch_fast<NT_, AND_, KPL_>(p, st);
     SS_F(2, false, 1) SS_F(3, false, 1) SS_F(4, false, 1) SS_F(2, true, 1) SS_F(3, true, 1) SS_F(4, true, 1)
+    SS_F(6, false, 1) SS_F(6, true, 1)
     SS_F(2, false, 2) SS_F(3, false, 2) SS_F(4, false, 2) SS_F(2, true, 2) SS_F(3, true, 2) SS_F(4, true, 2)
 #undef SS_F
   }

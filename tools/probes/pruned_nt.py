@@ -13,7 +13,7 @@ sh.synth_lexical(O.LEX_SEED, 10_000_000, th, O.len_table())
 rng = np.random.default_rng(1)
 df = np.array(sh.posting_count(np.arange(4096)), np.float64) / 1e7
 bands = [np.nonzero((df >= a) & (df < b))[0] for a, b in ((0.005, 0.02), (0.02, 0.05), (0.05, 0.15), (0.002, 0.01), (0.01, 0.04), (0.03, 0.1))]
-for nt in (4, 5, 6):
+for nt in (5, 6):
     tl = [[int(rng.choice(bands[j])) for j in range(nt)] for _ in range(500)]
     q = sh.make_queries(tl, S.QueryType.Union)
     res = {}
