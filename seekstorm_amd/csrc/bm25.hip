@@ -71,9 +71,12 @@ __global__ void bm25_final_kernel(const u64* __restrict__ keys, const u64* __res
 
 // ---------------------------------------------------------------- public queries -> virtual terms (one thread per query)
 __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery* __restrict__ vq, uint32_t nq, uint32_t n_fields,
-                                 const unsigned long long* __restrict__ term_base, const float* __restrict__ boost) {
+                                 const unsigned long long* __restrict__ term_base, const float* __restrict__ boost,
+                                 unsigned long long* __restrict__ total, uint32_t* __restrict__ tau) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq) return;
+  total[i] = 0ull;                      // per-query match count and shared threshold start from zero (no separate memset launch)
+  tau[(size_t)i * BM_TAU_STRIDE] = 0u;
   const ss_bm25_query Q = q[i];
   bm_vquery V;
   const uint32_t np = Q.n_terms, n_not = bm_q_nnot(Q.op);
@@ -153,7 +156,6 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   u64* bufB = bufA + (size_t)nq * P * KS;
   u64* total = bufB + (size_t)nq * P * KS;
   uint32_t* tau = (uint32_t*)(total + nq);
-  SS_HIP(hipMemsetAsync(total, 0, (nq + tau_words) * sizeof(u64), st));
 
   // queries over (term, field) posting lists
   if ((size_t)nq * sizeof(bm_vquery) > s->vq_cap) {
@@ -164,7 +166,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
     s->vq_cap = (size_t)nq * sizeof(bm_vquery);
   }
   bm_expand_kernel<<<(nq + 127) / 128, 128, 0, st>>>(d_q, (bm_vquery*)s->d_vq, nq, s->bm_n_fields,
-                                                    (const unsigned long long*)s->d_term_base, s->d_boost);
+                                                    (const unsigned long long*)s->d_term_base, s->d_boost, total, tau);
 
   BmParams p;
   p.post = s->d_post;
