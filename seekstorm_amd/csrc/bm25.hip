@@ -11,8 +11,13 @@
 // in: [nq][n_lists][KS] sorted-desc lists; each workgroup merges `group` consecutive lists of one query into one
 // sorted-desc list of KS keys: out [nq][ceil(n_lists/group)][KS].  Only the first `take` keys of a list can reach the
 // final top-k (take >= k): the rest is not even read.
+// fin_*: non-null in the LAST pass (one group left): the merged list goes straight to the caller's outputs
+// (what bm25_final_kernel does when there was nothing to merge).
 __global__ void __launch_bounds__(1024) bm25_merge_kernel(const u64* __restrict__ in, u64* __restrict__ out,
-                                                         uint32_t n_lists, uint32_t group, uint32_t KS, uint32_t take) {
+                                                         uint32_t n_lists, uint32_t group, uint32_t KS, uint32_t take,
+                                                         const u64* __restrict__ fin_total, uint32_t k,
+                                                         uint32_t* __restrict__ fin_doc, float* __restrict__ fin_score,
+                                                         uint32_t* __restrict__ fin_count, u64* __restrict__ fin_out_total) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   u64* keys = (u64*)smem;
   const uint32_t q = blockIdx.y, g = blockIdx.x;
@@ -36,6 +41,31 @@ __global__ void __launch_bounds__(1024) bm25_merge_kernel(const u64* __restrict_
       }
       __syncthreads();
     }
+  }
+  if (fin_doc) {  // n_groups == 1
+    __shared__ uint32_t cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    uint32_t local = 0;
+    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
+      const u64 key = (i < KS && i < np) ? keys[i] : 0ull;
+      uint32_t doc = SS_NO_DOC;
+      float sc = 0.f;
+      if (key) {
+        doc = 0xFFFFFFFFu - (uint32_t)key;
+        sc = __uint_as_float((uint32_t)(key >> 32));
+        local++;
+      }
+      fin_doc[(size_t)q * k + i] = doc;
+      fin_score[(size_t)q * k + i] = sc;
+    }
+    if (local) atomicAdd(&cnt, local);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      fin_count[q] = cnt;
+      fin_out_total[q] = fin_total[q];
+    }
+    return;
   }
   u64* dst = out + ((size_t)q * n_groups + g) * KS;
   for (uint32_t i = threadIdx.x; i < KS; i += blockDim.x) dst[i] = i < np ? keys[i] : 0ull;
@@ -218,12 +248,18 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
     uint32_t ng = (lists + group - 1) / group;
     uint32_t np = 64;
     while (np < std::min(lists, group) * take) np <<= 1;
-    bm25_merge_kernel<<<dim3(ng, nq), std::min<uint32_t>(1024u, std::max<uint32_t>(64u, np / 2)), 8192 * 8, st>>>(src, dst, lists, group, KS, take);
+    const bool last = ng == 1;
+    bm25_merge_kernel<<<dim3(ng, nq), std::min<uint32_t>(1024u, std::max<uint32_t>(64u, np / 2)), 8192 * 8, st>>>(
+        src, dst, lists, group, KS, take, total, k, last ? d_out_doc : nullptr, d_out_score, d_out_count, (u64*)d_out_total);
     std::swap(src, dst);
     lists = ng;
+    if (last) {
+      SS_HIP(hipGetLastError());
+      return SS_OK;
+    }
   }
   bm25_final_kernel<<<nq, 64, 0, st>>>(src, total, KS, k, d_out_doc, d_out_score, d_out_count,
-                                       (u64*)d_out_total);
+                                       (u64*)d_out_total);  // P == 1: nothing to merge
   SS_HIP(hipGetLastError());
   return SS_OK;
 }
