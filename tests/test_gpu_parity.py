@@ -679,3 +679,55 @@ def test_c1_standin_one_million_docs_and_pairs(S, O):
         assert int(tot[i]) == otot
         _check_topk(doc[i], score[i], cnt[i], od, os_)
     sh.close()
+
+
+def test_full_size_properties_c2_c3(S, O):
+    """BASELINE.json's full sizes (C2: 10 M docs, 3-term unions top-10; C3: 10 M x 768, batch 64, top-100), where the oracle is
+    too slow: size-independent properties -- both strategies bit-identical, exact counts equal, sorted, idempotent; every
+    returned vector score is the dot product of the row that was returned (f32 and i8)."""
+    from seekstorm_amd import _native as N
+    n = 10_000_000
+    th = O.term_thresholds()
+    sh = S.Shard(0)
+    sh.synth_lexical(O.LEX_SEED, n, th, O.len_table())
+    df = th.astype(np.float64) / 2.0 ** 32
+    bands = [np.nonzero((df >= a) & (df < b))[0] for a, b in ((0.005, 0.02), (0.02, 0.05), (0.05, 0.15))]
+    rng = np.random.default_rng(5)
+    tl = [[int(rng.choice(b)) for b in bands] for _ in range(300)]
+    q = sh.make_queries(tl, S.QueryType.Union)
+    res = {}
+    for strat in (N.BM25_EXHAUSTIVE, N.BM25_AUTO):
+        sh.set_strategy(strat)
+        res[strat] = [sh.search_lexical_batch(q, 10, rt) for rt in (S.ResultType.Topk, S.ResultType.TopkCount)]
+        again = sh.search_lexical_batch(q, 10, S.ResultType.TopkCount)
+        assert all(np.array_equal(a, b) for a, b in zip(res[strat][1], again))  # idempotent
+    for a, b in zip(res[N.BM25_EXHAUSTIVE], res[N.BM25_AUTO]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert np.array_equal(res[N.BM25_EXHAUSTIVE][1][3], res[N.BM25_AUTO][1][3])  # exact totals: scan count mode == bit records
+    doc, score, cnt, tot = res[N.BM25_AUTO][1]
+    assert np.all(cnt == 10) and np.all(score[:, :-1] >= score[:, 1:]) and np.all(score[:, -1] > 0)
+    dfs = np.array(sh.posting_count(np.unique(tl)), np.int64)
+    dfm = dict(zip(np.unique(tl).tolist(), dfs.tolist()))
+    for i, t in enumerate(tl):  # max df <= |union| <= sum df
+        assert max(dfm[x] for x in t) <= int(tot[i]) <= sum(dfm[x] for x in t)
+    sh.set_strategy(N.BM25_AUTO)
+    # C3
+    dim, B, k = 768, 64, 100
+    qs = O.vec_gen(O.VECQ_SEED, 0, B, dim)
+    sh.synth_vectors(O.VEC_SEED, n, dim)
+    d, s, c, t = sh.search_vector_batch(qs, k)
+    assert np.all(c == k) and np.all(s[:, :-1] >= s[:, 1:])
+    for i in (0, 17, 63):
+        rows = np.stack([sh.read_rows(int(r), 1)[0] for r in d[i, :5]])
+        assert np.allclose(rows @ qs[i], s[i, :5], rtol=1e-4, atol=2e-6)
+        assert len(set(d[i].tolist())) == k
+    d1, s1, c1, _ = sh.search_vector_batch(qs[:1], k)  # the <= 32-query instantiation returns the same list
+    assert np.array_equal(d1[0], d[0]) and np.array_equal(s1[0], s[0])
+    q8 = O.quantize_i8(qs)
+    sh.synth_vectors_i8(O.VEC_SEED, n, dim)
+    d8, s8, c8, _ = sh.search_vector_batch_i8(q8, k)
+    assert np.all(c8 == k) and np.all(s8[:, :-1] >= s8[:, 1:])
+    for i in (0, 31, 63):
+        rows = np.stack([sh.read_rows_i8(int(r), 1)[0] for r in d8[i, :5]]).astype(np.int64)
+        assert np.array_equal((rows @ q8[i].astype(np.int64)).astype(np.float32), s8[i, :5])
+    sh.close()
