@@ -307,12 +307,18 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
       uint32_t dg[G];
       bool alive[G];
       float w0[G];
+      uint2 rec[G];
 #pragma unroll
       for (int g = 0; g < G; g++) {
         alive[g] = pg[g] != 0u;
         dg[g] = ((pg[g] >> 2) & 0x1FFFu) - 1u;  // doc inside its sub-block
-        w0[g] = alive[g] ? pb_weight(pg[g], X, tid_[J], (tile[g] << BM_SUB_LOG2) + dg[g]) : 0.f;
+        // The probe of the first other term is issued NOW, for every real posting and before its weight is known: the
+        // weight lookups and bound tests below then run under the gather's latency instead of in front of it (postings the
+        // bound test would have spared cost a cached read).  Unconditional load: NULL lanes read record 0.
+        if (NT > 1) rec[g] = prow[A][alive[g] ? tile[g] * (uint32_t)(BM_SUB / 64) + (dg[g] >> 6) : 0u];
       }
+#pragma unroll
+      for (int g = 0; g < G; g++) w0[g] = alive[g] ? pb_weight(pg[g], X, tid_[J], (tile[g] << BM_SUB_LOG2) + dg[g]) : 0.f;
       if (nt == 1) {  // single-term query: the driver posting is the whole score
 #pragma unroll
         for (int g = 0; g < G; g++) {
@@ -332,14 +338,9 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
         continue;
       }
       const float rest0 = SU[0] - U[J];
-      uint2 rec[G];
 #pragma unroll
-      for (int g = 0; g < G; g++) {
+      for (int g = 0; g < G; g++)
         if (!is_and && k) alive[g] = alive[g] && (idf[J] * w0[g] + rest0) >= thr * 0.99999f;
-        // unconditional load, dead lanes read record 0 (one cached line): four back-to-back gathers instead of four
-        // exec-masked branches; a dead lane's record is never looked at
-        rec[g] = prow[A][alive[g] ? tile[g] * (uint32_t)(BM_SUB / 64) + (dg[g] >> 6) : 0u];  // 32-bit index: SGPR base + VGPR offset addressing
-      }
 #pragma unroll
       for (int g = 0; g < G; g++) {
         const u64 bits = ((u64)rec[g].y << 32) | rec[g].x;
