@@ -108,6 +108,17 @@ static int ensure_out(ss_shard* s, size_t nq, size_t k) {
   return SS_OK;
 }
 
+// grow-only device staging of host-pointer queries (a hipMalloc / hipFree pair per call would synchronise the device)
+static int ensure_qstage(ss_shard* s, size_t bytes) {
+  if (bytes <= s->qstage_cap) return SS_OK;
+  if (s->d_qstage) (void)hipFree(s->d_qstage);
+  s->d_qstage = nullptr;
+  s->qstage_cap = 0;
+  SS_HIP(hipMalloc(&s->d_qstage, bytes));
+  s->qstage_cap = bytes;
+  return SS_OK;
+}
+
 // ------------------------------------------------------------------ BM25
 int ss_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen, uint32_t n_terms, const uint64_t* offs,
                    const uint32_t* docs, const uint16_t* tfs) {
@@ -566,8 +577,8 @@ int ss_vec_search(ss_shard* s, uint32_t nq, const float* queries, uint32_t k, fl
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   SS_TRY(ensure_out(s, nq, k));
-  float* d_q = nullptr;
-  SS_HIP(hipMalloc(&d_q, (size_t)nq * s->dim * sizeof(float)));
+  SS_TRY(ensure_qstage(s, (size_t)nq * s->dim * sizeof(float)));
+  float* d_q = (float*)s->d_qstage;
   int rc = SS_OK;
   for (int attempt = 0; attempt < 2; attempt++) {
     if (hipMemcpyAsync(d_q, queries, (size_t)nq * s->dim * sizeof(float), hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = SS_EDEVICE; break; }
@@ -587,7 +598,6 @@ int ss_vec_search(ss_shard* s, uint32_t nq, const float* queries, uint32_t k, fl
         hipMemcpy(out_total, s->d_out_total, (size_t)nq * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess)
       rc = SS_EDEVICE;
   }
-  (void)hipFree(d_q);
   return rc;
 }
 
@@ -709,10 +719,10 @@ int ss_vec_search_i8(ss_shard* s, uint32_t nq, const int8_t* queries, const floa
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   SS_TRY(ensure_out(s, nq, k));
-  int8_t* d_q = nullptr;
-  float* d_qs = nullptr;
-  SS_HIP(hipMalloc(&d_q, (size_t)nq * s->dim));
-  if (query_scale) SS_HIP(hipMalloc(&d_qs, (size_t)nq * sizeof(float)));
+  const size_t qbytes = ((size_t)nq * s->dim + 15) & ~(size_t)15;
+  SS_TRY(ensure_qstage(s, qbytes + (query_scale ? (size_t)nq * sizeof(float) : 0)));
+  int8_t* d_q = (int8_t*)s->d_qstage;
+  float* d_qs = query_scale ? (float*)((char*)s->d_qstage + qbytes) : nullptr;
   int rc = SS_OK;
   for (int attempt = 0; attempt < 2; attempt++) {
     if (hipMemcpyAsync(d_q, queries, (size_t)nq * s->dim, hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = SS_EDEVICE; break; }
@@ -732,8 +742,6 @@ int ss_vec_search_i8(ss_shard* s, uint32_t nq, const int8_t* queries, const floa
         hipMemcpy(out_total, s->d_out_total, (size_t)nq * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess)
       rc = SS_EDEVICE;
   }
-  (void)hipFree(d_q);
-  if (d_qs) (void)hipFree(d_qs);
   return rc;
 }
 

@@ -78,7 +78,8 @@ struct ss_shard {
   float* d_Qf = nullptr;
   uint32_t* d_vstate = nullptr;  // tau[64] | cnt[64] | kept[64] | flags[64] | total_lo/hi ...
   uint64_t* d_cand = nullptr;    // [64][VS_CAP]
-  float* d_qstage = nullptr;     // host-variant staging of queries
+  void* d_qstage = nullptr;      // host-variant staging of queries (grow-only)
+  size_t qstage_cap = 0;
   uint32_t* d_out_doc = nullptr; // host-variant staging of outputs
   float* d_out_score = nullptr;
   uint32_t* d_out_count = nullptr;
