@@ -226,6 +226,37 @@ int ss_vec_search_i8_dev(ss_shard* s, uint32_t n_queries, const int8_t* d_querie
                          float threshold_raw, uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count,
                          uint64_t* d_out_total, void* stream);
 
+/* ---- ANN modes (AnnMode::Nprobe / Similaritythreshold / NprobeSimilaritythreshold, vector.rs:1300-1392).
+ * The reference clusters the records of every level (65 536 docs) at commit time and stores them cluster after cluster;
+ * the first record of a cluster is its medoid.  A query scores the medoids of a level, keeps the best n_probe of them
+ * (TopK::new(n_probe, cluster threshold), so ties keep the earlier cluster) and visits only those clusters' records.
+ * ss_vec_upload_vector_bin[_i8] keeps the cluster structure of the file; for rows uploaded with ss_vec_upload[_i8] /
+ * ss_vec_synth[_i8] in cluster order, ss_vec_set_clusters declares it: level_clusters[n_levels] = clusters per level,
+ * child_count[sum of level_clusters] = records per cluster (> 0), sum = n_rows.
+ * Medoid similarity uses the reference's own summation order (dot_f32_avx2's 8 fmadd lanes when dim % 8 == 0, else the
+ * sequential dot_f32; the i8 dot is exact), so the selected clusters are the reference's, not merely close to them.
+ * A batch scans the union of its queries' clusters once; a row is a candidate only for the queries that selected its
+ * cluster.  mode == NULL is AnnMode::All.  out_clusters (may be NULL) = observed_cluster_count per query. */
+typedef struct ss_ann_mode {
+  uint32_t n_probe;              /* clusters visited per level; 0 = no limit (AnnMode::Similaritythreshold) */
+  float cluster_threshold_raw;   /* clusters whose medoid scores below it are skipped; -FLT_MAX = none (AnnMode::Nprobe) */
+} ss_ann_mode;
+int ss_vec_set_clusters(ss_shard* s, uint32_t n_levels, const uint32_t* level_clusters, const uint32_t* child_count);
+int ss_vec_cluster_info(ss_shard* s, uint32_t* n_levels, uint32_t* n_clusters);
+int ss_vec_search_ann(ss_shard* s, uint32_t n_queries, const float* queries, uint32_t k, float threshold_raw,
+                      const ss_ann_mode* mode, uint32_t* out_doc, float* out_score, uint32_t* out_count,
+                      uint64_t* out_total, uint32_t* out_clusters);
+int ss_vec_search_ann_dev(ss_shard* s, uint32_t n_queries, const float* d_queries, uint32_t k, float threshold_raw,
+                          const ss_ann_mode* mode, uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count,
+                          uint64_t* d_out_total, uint32_t* d_out_clusters, void* stream);
+int ss_vec_search_i8_ann(ss_shard* s, uint32_t n_queries, const int8_t* queries, const float* query_scale, uint32_t k,
+                         float threshold_raw, const ss_ann_mode* mode, uint32_t* out_doc, float* out_score,
+                         uint32_t* out_count, uint64_t* out_total, uint32_t* out_clusters);
+int ss_vec_search_i8_ann_dev(ss_shard* s, uint32_t n_queries, const int8_t* d_queries, const float* d_query_scale,
+                             uint32_t k, float threshold_raw, const ss_ann_mode* mode, uint32_t* d_out_doc,
+                             float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, uint32_t* d_out_clusters,
+                             void* stream);
+
 /* ------------------------------------------------------------------ cross-shard merge + RRF (host side)
  * Inputs are the concatenation over shards of per-shard top-(offset+length) lists with GLOBAL ids
  * (global = local*S + shard, search.rs:1671).  Hybrid = RRF k=0.6, 0-based ranks (search.rs:1962-2035).

@@ -651,13 +651,46 @@ uint32_t so_vec_search(const float* rows, uint64_t n_rows, uint32_t dim, const u
 }
 /* search_vector_shard, AnnMode::All (vector.rs:1397-1466) over any record scorer: TopK::new / push, vector.rs:366-496 */
 typedef float (*so_score_fn)(const void* ctx, uint64_t row);
-static uint32_t topk_scan(uint64_t n_rows, const uint32_t* row_doc, uint32_t k, float thr, const uint64_t* deleted_sorted,
-                          uint64_t n_deleted, so_score_fn fn, const void* ctx, uint32_t* od, float* os, uint64_t* out_total,
-                          uint64_t* out_observed) {
-  so_item* items = (so_item*)malloc((k ? k : 1) * sizeof(so_item));
-  for (uint32_t i = 0; i < k; i++) { items[i].doc = 0; items[i].score = -FLT_MAX; }
-  uint32_t len = 0; uint64_t total = 0, observed = 0; float lowest = -FLT_MAX;
-  for (uint64_t r = 0; r < n_rows; r++) {
+typedef struct { so_item* items; uint32_t len, k; float thr, lowest; uint64_t total; } so_topk;
+static void topk_new(so_topk* t, uint32_t k, float thr) {
+  t->items = (so_item*)malloc((k ? k : 1) * sizeof(so_item));
+  for (uint32_t i = 0; i < k; i++) { t->items[i].doc = 0; t->items[i].score = -FLT_MAX; }
+  t->len = 0; t->k = k; t->thr = thr; t->lowest = -FLT_MAX; t->total = 0;
+}
+/* TopK::push, vector.rs:410-496 */
+static void topk_push(so_topk* t, uint32_t doc, float score) {
+  so_item* items = t->items;
+  const uint32_t len = t->len, k = t->k;
+  if (score < t->thr || (len == k && score <= t->lowest)) return;
+  t->total++;
+  if (len < k) {
+    for (uint32_t i = 0; i < len; i++) if (items[i].doc == doc) { if (score > items[i].score) items[i].score = score; return; }
+    items[len].doc = doc; items[len].score = score; t->len++;
+    return;
+  }
+  uint32_t min_i = 0; float min_v = items[0].score;
+  for (uint32_t i = 0; i < len; i++) {
+    if (items[i].doc == doc) { if (score > items[i].score) items[i].score = score; return; }
+    if (items[i].score < min_v) { min_v = items[i].score; min_i = i; }
+  }
+  if (score > min_v) { t->lowest = min_v; items[min_i].doc = doc; items[min_i].score = score; }
+}
+static void topk_sort_desc(so_topk* t) { /* vector.rs:1472 sort desc (stable) */
+  so_item* items = t->items;
+  for (uint32_t i = 1; i < t->len; i++) {
+    so_item x = items[i]; uint32_t j = i;
+    while (j > 0 && items[j - 1].score < x.score) { items[j] = items[j - 1]; j--; }
+    items[j] = x;
+  }
+}
+/* order != NULL: the rows visited, in visiting order (the ANN modes); NULL: rows 0 .. n_rows-1 */
+static uint32_t topk_scan_order(uint64_t n_rows, const uint64_t* order, const uint32_t* row_doc, uint32_t k, float thr,
+                                const uint64_t* deleted_sorted, uint64_t n_deleted, so_score_fn fn, const void* ctx, uint32_t* od,
+                                float* os, uint64_t* out_total, uint64_t* out_observed) {
+  so_topk t; topk_new(&t, k, thr);
+  uint64_t observed = 0;
+  for (uint64_t i = 0; i < n_rows; i++) {
+    const uint64_t r = order ? order[i] : i;
     float score = fn(ctx, r);
     uint32_t doc = row_doc ? row_doc[r] : (uint32_t)r;
     observed++;
@@ -666,32 +699,48 @@ static uint32_t topk_scan(uint64_t n_rows, const uint32_t* row_doc, uint32_t k, 
       while (lo < hi) { uint64_t mid = (lo + hi) / 2; if (deleted_sorted[mid] < doc) lo = mid + 1; else hi = mid; }
       if (lo < n_deleted && deleted_sorted[lo] == doc) continue;
     }
-    if (score < thr || (len == k && score <= lowest)) continue;
-    total++;
-    if (len < k) {
-      int dup = 0;
-      for (uint32_t i = 0; i < len; i++) if (items[i].doc == doc) { if (score > items[i].score) items[i].score = score; dup = 1; break; }
-      if (!dup) { items[len].doc = doc; items[len].score = score; len++; }
-      continue;
-    }
-    uint32_t min_i = 0; float min_v = items[0].score; int dup = 0;
-    for (uint32_t i = 0; i < len; i++) {
-      if (items[i].doc == doc) { if (score > items[i].score) items[i].score = score; dup = 1; break; }
-      if (items[i].score < min_v) { min_v = items[i].score; min_i = i; }
-    }
-    if (dup) continue;
-    if (score > min_v) { lowest = min_v; items[min_i].doc = doc; items[min_i].score = score; }
+    if (k == 0) continue;
+    topk_push(&t, doc, score);
   }
-  for (uint32_t i = 1; i < len; i++) { /* vector.rs:1472 sort desc (stable) */
-    so_item x = items[i]; uint32_t j = i;
-    while (j > 0 && items[j - 1].score < x.score) { items[j] = items[j - 1]; j--; }
-    items[j] = x;
-  }
-  for (uint32_t i = 0; i < len; i++) { od[i] = items[i].doc; os[i] = items[i].score; }
-  if (out_total) *out_total = total;
+  topk_sort_desc(&t);
+  for (uint32_t i = 0; i < t.len; i++) { od[i] = t.items[i].doc; os[i] = t.items[i].score; }
+  if (out_total) *out_total = t.total;
   if (out_observed) *out_observed = observed;
-  free(items);
+  uint32_t len = t.len;
+  free(t.items);
   return len;
+}
+static uint32_t topk_scan(uint64_t n_rows, const uint32_t* row_doc, uint32_t k, float thr, const uint64_t* deleted_sorted,
+                          uint64_t n_deleted, so_score_fn fn, const void* ctx, uint32_t* od, float* os, uint64_t* out_total,
+                          uint64_t* out_observed) {
+  return topk_scan_order(n_rows, NULL, row_doc, k, thr, deleted_sorted, n_deleted, fn, ctx, od, os, out_total, out_observed);
+}
+/* The ANN modes of search_vector_shard (vector.rs:1300-1392): per level, every cluster's medoid (= its first record) is
+ * scored and pushed into TopK::new(min(n_probe, clusters), cluster_threshold); the survivors are sorted by score desc
+ * (stable over the TopK array) and their records visited cluster after cluster.  Returns the number of rows in order[]
+ * (caller-allocated, >= total rows); *n_clusters_visited = observed_cluster_count. */
+static uint64_t ann_order(uint32_t n_levels, const uint32_t* level_clusters, const uint32_t* child_count, uint32_t n_probe,
+                          float cluster_thr, so_score_fn fn, const void* ctx, uint64_t* order, uint64_t* n_clusters_visited) {
+  uint64_t n = 0, row0 = 0, visited = 0;
+  const uint32_t* cc = child_count;
+  for (uint32_t l = 0; l < n_levels; l++) {
+    const uint32_t C = level_clusters[l];
+    uint64_t* start = (uint64_t*)malloc((C ? C : 1) * sizeof(uint64_t));
+    uint64_t level_rows = 0;
+    for (uint32_t c = 0; c < C; c++) { start[c] = row0 + level_rows; level_rows += cc[c]; }
+    so_topk t; topk_new(&t, n_probe < C ? n_probe : C, cluster_thr);
+    if (t.k) for (uint32_t c = 0; c < C; c++) topk_push(&t, c, fn(ctx, start[c]));
+    topk_sort_desc(&t);
+    visited += t.len;
+    for (uint32_t i = 0; i < t.len; i++) {
+      const uint32_t c = t.items[i].doc;
+      for (uint32_t j = 0; j < cc[c]; j++) order[n++] = start[c] + j;
+    }
+    free(t.items); free(start);
+    row0 += level_rows; cc += C;
+  }
+  if (n_clusters_visited) *n_clusters_visited = visited;
+  return n;
 }
 
 typedef struct { const float* rows; const float* q; uint32_t dim; int simd; } so_f32_ctx;
@@ -733,6 +782,31 @@ uint32_t so_vec_search_i8(const int8_t* rows, uint64_t n_rows, uint32_t dim, con
                           uint64_t n_deleted, uint32_t* od, float* os, uint64_t* out_total, uint64_t* out_observed) {
   so_i8_ctx c = {rows, q, dim, row_scale, scaled, q_scale};
   return topk_scan(n_rows, row_doc, k, thr, deleted_sorted, n_deleted, score_i8, &c, od, os, out_total, out_observed);
+}
+
+uint32_t so_vec_search_ann(const float* rows, uint64_t n_rows, uint32_t dim, const uint32_t* row_doc, const float* q,
+                           uint32_t k, float thr, int simd_order, uint32_t n_levels, const uint32_t* level_clusters,
+                           const uint32_t* child_count, uint32_t n_probe, float cluster_thr, const uint64_t* deleted_sorted,
+                           uint64_t n_deleted, uint32_t* od, float* os, uint64_t* out_total, uint64_t* out_observed,
+                           uint64_t* out_clusters) {
+  so_f32_ctx c = {rows, q, dim, simd_order};
+  uint64_t* order = (uint64_t*)malloc((n_rows ? n_rows : 1) * sizeof(uint64_t));
+  uint64_t n = ann_order(n_levels, level_clusters, child_count, n_probe, cluster_thr, score_f32, &c, order, out_clusters);
+  uint32_t r = topk_scan_order(n, order, row_doc, k, thr, deleted_sorted, n_deleted, score_f32, &c, od, os, out_total, out_observed);
+  free(order);
+  return r;
+}
+uint32_t so_vec_search_i8_ann(const int8_t* rows, uint64_t n_rows, uint32_t dim, const uint32_t* row_doc, const float* row_scale,
+                              const int8_t* q, int scaled, float q_scale, uint32_t k, float thr, uint32_t n_levels,
+                              const uint32_t* level_clusters, const uint32_t* child_count, uint32_t n_probe, float cluster_thr,
+                              const uint64_t* deleted_sorted, uint64_t n_deleted, uint32_t* od, float* os, uint64_t* out_total,
+                              uint64_t* out_observed, uint64_t* out_clusters) {
+  so_i8_ctx c = {rows, q, dim, row_scale, scaled, q_scale};
+  uint64_t* order = (uint64_t*)malloc((n_rows ? n_rows : 1) * sizeof(uint64_t));
+  uint64_t n = ann_order(n_levels, level_clusters, child_count, n_probe, cluster_thr, score_i8, &c, order, out_clusters);
+  uint32_t r = topk_scan_order(n, order, row_doc, k, thr, deleted_sorted, n_deleted, score_i8, &c, od, os, out_total, out_observed);
+  free(order);
+  return r;
 }
 
 /* ------------------------------------------------------------------ merge / RRF */

@@ -38,6 +38,10 @@ class RefBlock(C.Structure):  # ss_ref_block
                 ("pointer_pivot_p_docid", C.c_uint16), ("byte_array", C.c_void_p), ("byte_array_len", C.c_uint64)]
 
 
+class AnnModeC(C.Structure):  # ss_ann_mode
+    _fields_ = [("n_probe", C.c_uint32), ("cluster_threshold_raw", C.c_float)]
+
+
 BM25_QUERY_DTYPE = np.dtype([("n_terms", np.uint32), ("op", np.uint32), ("term", np.uint32, (SS_MAX_QUERY_TERMS,)),
                              ("idf", np.float32, (SS_MAX_QUERY_TERMS,))])
 assert BM25_QUERY_DTYPE.itemsize == C.sizeof(Bm25Query)
@@ -88,6 +92,15 @@ SYMBOLS = [
     ("ss_vec_search_i8", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, f32p, C.c_uint32, C.c_float, u32p, f32p, u32p, u64p]),
     ("ss_vec_search_i8_dev", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("ss_vec_set_clusters", C.c_int, [C.c_void_p, C.c_uint32, u32p, u32p]),
+    ("ss_vec_cluster_info", C.c_int, [C.c_void_p, u32p, u32p]),
+    ("ss_vec_search_ann", C.c_int, [C.c_void_p, C.c_uint32, f32p, C.c_uint32, C.c_float, C.c_void_p, u32p, f32p, u32p, u64p, u32p]),
+    ("ss_vec_search_ann_dev", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("ss_vec_search_i8_ann", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, f32p, C.c_uint32, C.c_float, C.c_void_p, u32p, f32p,
+                                       u32p, u64p, u32p]),
+    ("ss_vec_search_i8_ann_dev", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("ss_merge_results", C.c_int, [C.c_int, u64p, f32p, C.c_uint32, u64p, f32p, C.c_uint32, C.c_uint32, C.c_uint32,
                                    u64p, f32p, u8p]),
     ("ss_topk_merge_dev", C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,

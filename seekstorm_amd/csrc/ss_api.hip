@@ -60,6 +60,7 @@ static void free_vec(ss_shard* s) {
   s->d_X = nullptr; s->d_X8 = nullptr; s->d_row_scale = nullptr; s->d_row_doc = nullptr; s->d_Qf = nullptr;
   s->d_vstate = nullptr; s->d_cand = nullptr;
   s->n_rows = s->n_rows_pad = 0; s->dim = s->dim_pad = s->dim_pad8 = 0; s->vec_multi_record = false;
+  ssi_vec_free_clusters(s);
 }
 static void free_bm25(ss_shard* s) {
   void* ptrs[] = {s->d_post, s->d_term_base, s->d_sub_off, s->d_comp, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_umax, s->d_exc_off, s->d_exc_doc, s->d_exc_tf, s->d_boost};
@@ -447,7 +448,7 @@ int ss_vec_upload(ss_shard* s, uint64_t n_rows, uint32_t dim, const float* rows,
 // vector.bin (writer vector.rs:1066-1094, reader 1279-1298): per level u32 cluster_count, cluster_count x u32 child_count,
 // then the records cluster after cluster, each a packed 24-byte VectorHeader (u16 doc_id first, vector.rs:62-73) + dim x f32.
 // Shard-local doc id of a record = (level << 16) | doc_id (vector.rs:1448).  The payloads go to HBM straight from the
-// file bytes with a strided copy per level; AnnMode::All visits every cluster, so the cluster structure is not kept.
+// file bytes with a strided copy per level; the cluster structure is kept for the ANN modes (vec_ann.hip).
 static int vec8_alloc(ss_shard* s, uint64_t n_rows, uint32_t dim);
 
 // i8 = Precision::I8 records (dim x i8 after the header); use_scale keeps VectorHeader.scale (f32 at byte 10) per record
@@ -457,7 +458,7 @@ static int vec_bin_upload(ss_shard* s, const uint8_t* bytes, uint64_t len, uint3
   const uint64_t rec = 24u + (uint64_t)dim * (i8 ? 1u : 4u);
   struct Lvl { uint64_t first, n; };
   std::vector<Lvl> levels;
-  std::vector<uint32_t> ids;
+  std::vector<uint32_t> ids, level_clusters, child_counts;
   std::vector<float> scales;
   uint64_t pos = 0;
   while (pos < len) {
@@ -471,7 +472,9 @@ static int vec_bin_upload(ss_shard* s, const uint8_t* bytes, uint64_t len, uint3
       uint32_t child;
       memcpy(&child, bytes + pos + 4ull * c, 4);
       n += child;
+      child_counts.push_back(child);
     }
+    level_clusters.push_back(clusters);
     pos += (uint64_t)clusters * 4u;
     if (n > (len - pos) / rec || levels.size() >= 65536u) return SS_EINVAL;
     for (uint64_t r = 0; r < n; r++) {
@@ -524,6 +527,8 @@ static int vec_bin_upload(ss_shard* s, const uint8_t* bytes, uint64_t len, uint3
   SS_HIP(hipMalloc(&s->d_row_doc, n_rows * sizeof(uint32_t)));
   SS_HIP(hipMemcpyAsync(s->d_row_doc, ids.data(), n_rows * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
   SS_HIP(hipStreamSynchronize(s->stream));
+  rc = ssi_vec_set_clusters(s, (uint32_t)level_clusters.size(), level_clusters.data(), child_counts.data());
+  if (rc != SS_OK && rc != SS_ENOTSUP) { free_vec(s); return rc; }  // ENOTSUP (an empty cluster): AnnMode::All only
   return ssi_vec_alloc_ws(s);
 }
 
@@ -568,22 +573,26 @@ int ss_vec_read_rows(ss_shard* s, uint64_t r0, uint64_t n, float* out) {
   return SS_OK;
 }
 
-int ss_vec_search(ss_shard* s, uint32_t nq, const float* queries, uint32_t k, float thr, uint32_t* out_doc,
-                  float* out_score, uint32_t* out_count, uint64_t* out_total) {
-  if (!s || !queries || !out_doc || !out_score || !out_count || !out_total) return SS_EINVAL;
-  if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
-  if (!s->d_X) return SS_ESTATE;
+// host-pointer searches: queries (f32 or i8 rows) and scales are staged in the shard's grow-only buffer, out_clusters
+// (observed_cluster_count, ANN modes) rides behind them
+static int vec_search_host(ss_shard* s, uint32_t nq, const void* queries, size_t elem, const float* query_scale, uint32_t k,
+                           float thr, const ss_ann_mode* mode, uint32_t* out_doc, float* out_score, uint32_t* out_count,
+                           uint64_t* out_total, uint32_t* out_clusters) {
   if (nq == 0) return SS_OK;
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   SS_TRY(ensure_out(s, nq, k));
-  SS_TRY(ensure_qstage(s, (size_t)nq * s->dim * sizeof(float)));
-  float* d_q = (float*)s->d_qstage;
+  const size_t qbytes = ((size_t)nq * s->dim * elem + 15) & ~(size_t)15;
+  const size_t sbytes = query_scale ? (size_t)nq * sizeof(float) : 0;
+  SS_TRY(ensure_qstage(s, qbytes + sbytes + (out_clusters ? (size_t)nq * sizeof(uint32_t) : 0)));
+  float* d_qs = query_scale ? (float*)((char*)s->d_qstage + qbytes) : nullptr;
+  uint32_t* d_ncl = out_clusters ? (uint32_t*)((char*)s->d_qstage + qbytes + sbytes) : nullptr;
   int rc = SS_OK;
   for (int attempt = 0; attempt < 2; attempt++) {
-    if (hipMemcpyAsync(d_q, queries, (size_t)nq * s->dim * sizeof(float), hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = SS_EDEVICE; break; }
-    rc = ssi_vec_search(s, nq, d_q, nullptr, k, thr, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->stream,
-                        attempt == 1);
+    if (hipMemcpyAsync(s->d_qstage, queries, (size_t)nq * s->dim * elem, hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = SS_EDEVICE; break; }
+    if (d_qs && hipMemcpyAsync(d_qs, query_scale, sbytes, hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = SS_EDEVICE; break; }
+    rc = ssi_vec_search(s, nq, s->d_qstage, d_qs, k, thr, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->stream,
+                        attempt == 1, mode, d_ncl);
     if (rc) break;
     if (hipMemcpyAsync(out_count, s->d_out_count, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
         hipStreamSynchronize(s->stream) != hipSuccess) { rc = SS_EDEVICE; break; }
@@ -595,21 +604,64 @@ int ss_vec_search(ss_shard* s, uint32_t nq, const float* queries, uint32_t k, fl
   if (rc == SS_OK) {
     if (hipMemcpy(out_doc, s->d_out_doc, (size_t)nq * k * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(out_score, s->d_out_score, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(out_total, s->d_out_total, (size_t)nq * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess)
+        hipMemcpy(out_total, s->d_out_total, (size_t)nq * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess ||
+        (d_ncl && hipMemcpy(out_clusters, d_ncl, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess))
       rc = SS_EDEVICE;
   }
   return rc;
 }
+static int ann_mode_ok(const ss_shard* s, const ss_ann_mode* mode) {
+  if (!mode) return SS_OK;
+  if (!s->d_row_cluster) return SS_ESTATE;
+  if (mode->cluster_threshold_raw != mode->cluster_threshold_raw) return SS_EINVAL;
+  return SS_OK;
+}
 
-int ss_vec_search_dev(ss_shard* s, uint32_t nq, const float* d_queries, uint32_t k, float thr, uint32_t* d_out_doc,
-                      float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, void* stream) {
+int ss_vec_search_ann(ss_shard* s, uint32_t nq, const float* queries, uint32_t k, float thr, const ss_ann_mode* mode,
+                      uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total, uint32_t* out_clusters) {
+  if (!s || !queries || !out_doc || !out_score || !out_count || !out_total) return SS_EINVAL;
+  if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
+  if (!s->d_X) return SS_ESTATE;
+  SS_TRY(ann_mode_ok(s, mode));
+  return vec_search_host(s, nq, queries, sizeof(float), nullptr, k, thr, mode, out_doc, out_score, out_count, out_total,
+                         mode ? out_clusters : nullptr);
+}
+int ss_vec_search(ss_shard* s, uint32_t nq, const float* queries, uint32_t k, float thr, uint32_t* out_doc,
+                  float* out_score, uint32_t* out_count, uint64_t* out_total) {
+  return ss_vec_search_ann(s, nq, queries, k, thr, nullptr, out_doc, out_score, out_count, out_total, nullptr);
+}
+
+int ss_vec_search_ann_dev(ss_shard* s, uint32_t nq, const float* d_queries, uint32_t k, float thr, const ss_ann_mode* mode,
+                          uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total,
+                          uint32_t* d_out_clusters, void* stream) {
   if (!s || !d_queries || !d_out_doc || !d_out_score || !d_out_count || !d_out_total) return SS_EINVAL;
   if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
   if (!s->d_X) return SS_ESTATE;
+  SS_TRY(ann_mode_ok(s, mode));
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   hipStream_t st = stream ? (hipStream_t)stream : s->stream;
-  return ssi_vec_search(s, nq, d_queries, nullptr, k, thr, d_out_doc, d_out_score, d_out_count, d_out_total, st, false);
+  return ssi_vec_search(s, nq, d_queries, nullptr, k, thr, d_out_doc, d_out_score, d_out_count, d_out_total, st, false, mode,
+                        mode ? d_out_clusters : nullptr);
+}
+int ss_vec_search_dev(ss_shard* s, uint32_t nq, const float* d_queries, uint32_t k, float thr, uint32_t* d_out_doc,
+                      float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, void* stream) {
+  return ss_vec_search_ann_dev(s, nq, d_queries, k, thr, nullptr, d_out_doc, d_out_score, d_out_count, d_out_total, nullptr, stream);
+}
+
+// ---- cluster structure of the vector image (ANN modes, vec_ann.hip)
+int ss_vec_set_clusters(ss_shard* s, uint32_t n_levels, const uint32_t* level_clusters, const uint32_t* child_count) {
+  if (!s) return SS_EINVAL;
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  return ssi_vec_set_clusters(s, n_levels, level_clusters, child_count);
+}
+int ss_vec_cluster_info(ss_shard* s, uint32_t* n_levels, uint32_t* n_clusters) {
+  if (!s) return SS_EINVAL;
+  std::lock_guard<std::mutex> g(s->mu);
+  if (n_levels) *n_levels = s->vec_n_levels;
+  if (n_clusters) *n_clusters = s->vec_n_clusters;
+  return SS_OK;
 }
 
 // ------------------------------------------------------------------ i8 (quantised) vectors
@@ -710,50 +762,38 @@ int ss_vec_read_rows_i8(ss_shard* s, uint64_t r0, uint64_t n, int8_t* out) {
   return rc;
 }
 
-int ss_vec_search_i8(ss_shard* s, uint32_t nq, const int8_t* queries, const float* query_scale, uint32_t k, float thr,
-                     uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total) {
+int ss_vec_search_i8_ann(ss_shard* s, uint32_t nq, const int8_t* queries, const float* query_scale, uint32_t k, float thr,
+                         const ss_ann_mode* mode, uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total,
+                         uint32_t* out_clusters) {
   if (!s || !queries || !out_doc || !out_score || !out_count || !out_total) return SS_EINVAL;
   if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
   if (!s->d_X8) return SS_ESTATE;
-  if (nq == 0) return SS_OK;
-  std::lock_guard<std::mutex> g(s->mu);
-  SS_HIP(hipSetDevice(s->device));
-  SS_TRY(ensure_out(s, nq, k));
-  const size_t qbytes = ((size_t)nq * s->dim + 15) & ~(size_t)15;
-  SS_TRY(ensure_qstage(s, qbytes + (query_scale ? (size_t)nq * sizeof(float) : 0)));
-  int8_t* d_q = (int8_t*)s->d_qstage;
-  float* d_qs = query_scale ? (float*)((char*)s->d_qstage + qbytes) : nullptr;
-  int rc = SS_OK;
-  for (int attempt = 0; attempt < 2; attempt++) {
-    if (hipMemcpyAsync(d_q, queries, (size_t)nq * s->dim, hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = SS_EDEVICE; break; }
-    if (d_qs && hipMemcpyAsync(d_qs, query_scale, (size_t)nq * sizeof(float), hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = SS_EDEVICE; break; }
-    rc = ssi_vec_search(s, nq, d_q, d_qs, k, thr, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->stream, attempt == 1);
-    if (rc) break;
-    if (hipMemcpyAsync(out_count, s->d_out_count, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
-        hipStreamSynchronize(s->stream) != hipSuccess) { rc = SS_EDEVICE; break; }
-    bool ovf = false;
-    for (uint32_t i = 0; i < nq; i++) ovf |= out_count[i] == 0xFFFFFFFFu;
-    if (!ovf) break;
-    if (attempt == 1) { rc = SS_EDEVICE; break; }
-  }
-  if (rc == SS_OK) {
-    if (hipMemcpy(out_doc, s->d_out_doc, (size_t)nq * k * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(out_score, s->d_out_score, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(out_total, s->d_out_total, (size_t)nq * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess)
-      rc = SS_EDEVICE;
-  }
-  return rc;
+  SS_TRY(ann_mode_ok(s, mode));
+  return vec_search_host(s, nq, queries, 1, query_scale, k, thr, mode, out_doc, out_score, out_count, out_total,
+                         mode ? out_clusters : nullptr);
+}
+int ss_vec_search_i8(ss_shard* s, uint32_t nq, const int8_t* queries, const float* query_scale, uint32_t k, float thr,
+                     uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total) {
+  return ss_vec_search_i8_ann(s, nq, queries, query_scale, k, thr, nullptr, out_doc, out_score, out_count, out_total, nullptr);
 }
 
-int ss_vec_search_i8_dev(ss_shard* s, uint32_t nq, const int8_t* d_queries, const float* d_query_scale, uint32_t k, float thr,
-                         uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, void* stream) {
+int ss_vec_search_i8_ann_dev(ss_shard* s, uint32_t nq, const int8_t* d_queries, const float* d_query_scale, uint32_t k, float thr,
+                             const ss_ann_mode* mode, uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count,
+                             uint64_t* d_out_total, uint32_t* d_out_clusters, void* stream) {
   if (!s || !d_queries || !d_out_doc || !d_out_score || !d_out_count || !d_out_total) return SS_EINVAL;
   if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
   if (!s->d_X8) return SS_ESTATE;
+  SS_TRY(ann_mode_ok(s, mode));
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   hipStream_t st = stream ? (hipStream_t)stream : s->stream;
-  return ssi_vec_search(s, nq, d_queries, d_query_scale, k, thr, d_out_doc, d_out_score, d_out_count, d_out_total, st, false);
+  return ssi_vec_search(s, nq, d_queries, d_query_scale, k, thr, d_out_doc, d_out_score, d_out_count, d_out_total, st, false, mode,
+                        mode ? d_out_clusters : nullptr);
+}
+int ss_vec_search_i8_dev(ss_shard* s, uint32_t nq, const int8_t* d_queries, const float* d_query_scale, uint32_t k, float thr,
+                         uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, void* stream) {
+  return ss_vec_search_i8_ann_dev(s, nq, d_queries, d_query_scale, k, thr, nullptr, d_out_doc, d_out_score, d_out_count,
+                                  d_out_total, nullptr, stream);
 }
 
 // ------------------------------------------------------------------ cross-shard merge + RRF (search.rs:1875-2119)

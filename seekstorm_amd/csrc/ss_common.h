@@ -74,6 +74,17 @@ struct ss_shard {
   bool vec_multi_record = false; // several records per doc: TopK::push dedup (vector.rs:441-452) in the refine kernel
   uint64_t n_rows = 0, n_rows_pad = 0;
   uint32_t dim = 0, dim_pad = 0;
+  // cluster structure (ANN modes, vec_ann.hip); null = none declared
+  uint32_t* d_row_cluster = nullptr;    // [n_rows] shard-wide cluster index of each row
+  uint32_t* d_cluster_first = nullptr;  // [vec_n_clusters] first row (= medoid record) of each cluster
+  uint32_t* d_level_off = nullptr;      // [vec_n_levels + 1] cluster index range of each level
+  uint32_t vec_n_clusters = 0, vec_n_levels = 0;
+  float* d_ann_score = nullptr;         // [64][vec_n_clusters] medoid similarity per query
+  float* d_ann_its = nullptr;           // [64][vec_n_clusters] TopK arrays of the per-level selection (scores)
+  uint32_t* d_ann_itc = nullptr;        //                      (cluster ids)
+  uint32_t* d_ann_sel = nullptr;        // [65][words] selected-cluster bits per query; row 64 = union over the batch
+  uint32_t* d_ann_tiles = nullptr;      // [tiles + 1] ascending tile list of the batch, count in the last slot
+  uint32_t* d_ann_ncl = nullptr;        // [64] observed_cluster_count
   // vector workspace (one 64-query batch in flight per shard)
   float* d_Qf = nullptr;
   uint32_t* d_vstate = nullptr;  // tau[64] | cnt[64] | kept[64] | flags[64] | total_lo/hi ...
@@ -148,11 +159,19 @@ struct ss_shard {
 
 // ---- implemented in vec_scan.hip
 // d_queries: f32 [nq][dim] for the f32 image, i8 [nq][dim] for the i8 image (d_qscale: per-query scale or null)
+// ann_mode: null = AnnMode::All; d_out_clusters: null or [nq] observed_cluster_count
 int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float* d_qscale, uint32_t k, float thr,
                    uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, hipStream_t st,
-                   bool safe_mode);
+                   bool safe_mode, const ss_ann_mode* ann_mode = nullptr, uint32_t* d_out_clusters = nullptr);
+struct VAnn;
 int ssi_vec8_qprep(ss_shard* s, const int8_t* d_queries, uint32_t nb, hipStream_t st);
-int ssi_vec8_launch_scan(ss_shard* s, uint32_t tile0, uint32_t ntiles, const float* d_qscale, hipStream_t st);
+int ssi_vec8_launch_scan(ss_shard* s, uint32_t tile0, uint32_t ntiles, const float* d_qscale, const VAnn* ann, hipStream_t st);
+// ---- implemented in vec_ann.hip
+// after the batch's queries are in s->d_Qf (qprep): medoid scores, per-query selection, tile list -> *out
+int ssi_vec_ann_prepare(ss_shard* s, uint32_t nb, const float* d_qscale, const ss_ann_mode* mode, VAnn* out,
+                        uint32_t* d_out_clusters, hipStream_t st);
+int ssi_vec_set_clusters(ss_shard* s, uint32_t n_levels, const uint32_t* level_clusters, const uint32_t* child_count);
+void ssi_vec_free_clusters(ss_shard* s);
 int ssi_vec8_quantize(ss_shard* s, hipStream_t st);
 int ssi_vec8_permute(ss_shard* s, const int8_t* d_rows_row_major, hipStream_t st);
 int ssi_vec8_gather_rows(ss_shard* s, uint64_t r0, uint64_t n, int8_t* d_out, hipStream_t st);

@@ -20,17 +20,6 @@
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-constexpr int V8_WAVES = 4;     // x 32 rows = one 128-row tile per workgroup step (same tile unit as the f32 scan)
-constexpr int V8_D = 3;         // lines (128 bytes of a row) in flight per lane (6 measured the same)
-constexpr int V8_LINE = 128;
-
-// byte offset of X8[row][k] in the fragment-ordered image; L = lines (128 bytes) per row
-__host__ __device__ inline size_t v8_index(unsigned long long row, uint32_t k, uint32_t L) {
-  const unsigned long long blk = row >> 5;  // 32-row block = (tile, wave)
-  const uint32_t lane = (uint32_t)(row & 31u) + 32u * ((k >> 6) & 1u);
-  return ((((size_t)blk * L + (k >> 7)) * 4u + ((k >> 4) & 3u)) * 64u + lane) * 16u + (k & 15u);
-}
-
 // row-major [n_rows][dim] (device staging) -> fragment order; one thread per 16-byte piece of the padded image
 __global__ void vec8_permute_kernel(const int8_t* __restrict__ src, unsigned long long n_rows, uint32_t dim, uint32_t dim_pad,
                                     unsigned long long n_rows_pad, int8_t* __restrict__ dst) {
@@ -82,11 +71,12 @@ __global__ void vec8_quantize_kernel(const float* __restrict__ X, uint32_t dim, 
 
 // EVEN: the number of lines per row is a multiple of the ring depth -> the steady state has no conditional loads (the
 // compiler's s_waitcnt insertion then counts the ring exactly instead of draining it with vmcnt(0) at every merge)
-template <bool SCALED, bool EVEN>
+// ANN: the launch walks the batch's list of selected tiles and admits a row only for the queries that selected its cluster
+template <bool SCALED, bool EVEN, bool ANN>
 __global__ void __launch_bounds__(V8_WAVES * 64, 3)
 vec8_scan_kernel(const int8_t* __restrict__ X, uint32_t dim_pad, unsigned long long n_rows, const int8_t* __restrict__ Qf8,
                  uint32_t L, uint32_t tile0, uint32_t ntiles, const float* __restrict__ row_scale,
-                 const float* __restrict__ q_scale, VState* __restrict__ st, unsigned long long* __restrict__ cand) {
+                 const float* __restrict__ q_scale, VState* __restrict__ st, unsigned long long* __restrict__ cand, VAnn ann) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -110,6 +100,10 @@ vec8_scan_kernel(const int8_t* __restrict__ X, uint32_t dim_pad, unsigned long l
   if (SCALED && q_scale) { qs0 = q_scale[lane & 31]; qs1 = q_scale[32 + (lane & 31)]; }
   __syncthreads();
 
+  if (ANN) {
+    const uint32_t na = *ann.n_tiles;
+    ntiles = na > tile0 ? min(ntiles, na - tile0) : 0u;
+  }
   const uint32_t first = blockIdx.x;
   if (first >= ntiles) return;
   const uint32_t my_tiles = (ntiles - first + gridDim.x - 1) / gridDim.x;
@@ -118,11 +112,13 @@ vec8_scan_kernel(const int8_t* __restrict__ X, uint32_t dim_pad, unsigned long l
   // fragment-ordered image: my 32-row block of tile t starts at (4 t + w) * L * 4096, line c at + 4096 c, piece j at + 1024 j
   const size_t lane_off = (size_t)w * L * 4096u + (size_t)lane * 16u;
   const size_t tile_stride = (size_t)(V8_WAVES * 32) * dim_pad;
-  uint32_t i_tile = 0, i_line = 0;
+  uint32_t i_tile = 0, i_line = 0, i_tix = 0;
   v4i xa[V8_D][4];
   auto issue = [&](v4i(&buf)[4]) {
     const uint32_t t = min(i_tile, my_tiles - 1);  // past the end: re-read a line of the last tile (never consumed)
-    const v4i* p = (const v4i*)(X + (size_t)(tile0 + first + (size_t)t * gridDim.x) * tile_stride + lane_off + (size_t)i_line * 4096u);
+    if (ANN) { if (i_line == 0) i_tix = ann.tiles[tile0 + first + t * gridDim.x]; }
+    const size_t tix = ANN ? (size_t)i_tix : (size_t)(tile0 + first + (size_t)t * gridDim.x);
+    const v4i* p = (const v4i*)(X + tix * tile_stride + lane_off + (size_t)i_line * 4096u);
 #pragma unroll
     for (int j = 0; j < 4; j++) buf[j] = __builtin_nontemporal_load(p + j * 64);
     if (++i_line == L) { i_line = 0; ++i_tile; }
@@ -151,8 +147,9 @@ vec8_scan_kernel(const int8_t* __restrict__ X, uint32_t dim_pad, unsigned long l
       issue(xa[d]);
       if (++c_line == L) {
         // ---- threshold filter: lane owns query (lane & 31) + {0, 32}, 16 rows per accumulator
-        const unsigned long long row_base =
-            (unsigned long long)(tile0 + first + (unsigned long long)c_tile * gridDim.x) * (V8_WAVES * 32) + 32u * w + 4u * (lane >> 5);
+        const unsigned long long c_tix = ANN ? (unsigned long long)ann.tiles[tile0 + first + c_tile * gridDim.x]
+                                             : (unsigned long long)(tile0 + first + (unsigned long long)c_tile * gridDim.x);
+        const unsigned long long row_base = c_tix * (V8_WAVES * 32) + 32u * w + 4u * (lane >> 5);
         float f0[16], f1[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -168,8 +165,13 @@ vec8_scan_kernel(const int8_t* __restrict__ X, uint32_t dim_pad, unsigned long l
         float m0 = f0[0], m1 = f1[0];
 #pragma unroll
         for (int r = 1; r < 16; r++) { m0 = fmaxf(m0, f0[r]); m1 = fmaxf(m1, f1[r]); }
-        if (m0 > tau0) vs_append(f0, tau0, lane & 31, row_base, n_rows, st, cand);
-        if (m1 > tau1) vs_append(f1, tau1, 32 + (lane & 31), row_base, n_rows, st, cand);
+        if (ANN) {
+          if (m0 > tau0) vs_append_ann(f0, tau0, lane & 31, row_base, n_rows, st, cand, ann);
+          if (m1 > tau1) vs_append_ann(f1, tau1, 32 + (lane & 31), row_base, n_rows, st, cand, ann);
+        } else {
+          if (m0 > tau0) vs_append(f0, tau0, lane & 31, row_base, n_rows, st, cand);
+          if (m1 > tau1) vs_append(f1, tau1, 32 + (lane & 31), row_base, n_rows, st, cand);
+        }
 #pragma unroll
         for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }
         c_line = 0;
@@ -185,24 +187,30 @@ int ssi_vec8_qprep(ss_shard* s, const int8_t* d_queries, uint32_t nb, hipStream_
   return SS_OK;
 }
 
-template <bool SCALED, bool EVEN>
-static int launch_vec8(ss_shard* s, uint32_t tile0, uint32_t ntiles, const float* d_qscale, hipStream_t st) {
+template <bool SCALED, bool EVEN, bool ANN>
+static int launch_vec8(ss_shard* s, uint32_t tile0, uint32_t ntiles, const float* d_qscale, const VAnn& ann, hipStream_t st) {
   const uint32_t L = s->dim_pad8 / V8_LINE;
   uint32_t gmax = 768;
   if (const char* e = getenv("SS_VEC8_GRID")) gmax = (uint32_t)atoi(e);  // tuning override
   const uint32_t grid = std::min<uint32_t>(ntiles, gmax);
-  SS_SET_MAX_LDS((vec8_scan_kernel<SCALED, EVEN>), 160 * 1024);
-  vec8_scan_kernel<SCALED, EVEN><<<grid, V8_WAVES * 64, L * 8192u, st>>>(
+  SS_SET_MAX_LDS((vec8_scan_kernel<SCALED, EVEN, ANN>), 160 * 1024);
+  vec8_scan_kernel<SCALED, EVEN, ANN><<<grid, V8_WAVES * 64, L * 8192u, st>>>(
       s->d_X8, s->dim_pad8, (unsigned long long)s->n_rows, (const int8_t*)s->d_Qf, L, tile0, ntiles, s->d_row_scale, d_qscale,
-      (VState*)s->d_vstate, (unsigned long long*)s->d_cand);
+      (VState*)s->d_vstate, (unsigned long long*)s->d_cand, ann);
   return SS_OK;
 }
 
-int ssi_vec8_launch_scan(ss_shard* s, uint32_t tile0, uint32_t ntiles, const float* d_qscale, hipStream_t st) {
+template <bool ANN>
+static int launch_vec8_ann(ss_shard* s, uint32_t tile0, uint32_t ntiles, const float* d_qscale, const VAnn& ann, hipStream_t st) {
   const bool scaled = s->d_row_scale != nullptr || d_qscale != nullptr;
   const bool even = (s->dim_pad8 / V8_LINE) % V8_D == 0;
-  if (scaled) return even ? launch_vec8<true, true>(s, tile0, ntiles, d_qscale, st) : launch_vec8<true, false>(s, tile0, ntiles, d_qscale, st);
-  return even ? launch_vec8<false, true>(s, tile0, ntiles, d_qscale, st) : launch_vec8<false, false>(s, tile0, ntiles, d_qscale, st);
+  if (scaled) return even ? launch_vec8<true, true, ANN>(s, tile0, ntiles, d_qscale, ann, st) : launch_vec8<true, false, ANN>(s, tile0, ntiles, d_qscale, ann, st);
+  return even ? launch_vec8<false, true, ANN>(s, tile0, ntiles, d_qscale, ann, st) : launch_vec8<false, false, ANN>(s, tile0, ntiles, d_qscale, ann, st);
+}
+
+int ssi_vec8_launch_scan(ss_shard* s, uint32_t tile0, uint32_t ntiles, const float* d_qscale, const VAnn* ann, hipStream_t st) {
+  if (ann) return launch_vec8_ann<true>(s, tile0, ntiles, d_qscale, *ann, st);
+  return launch_vec8_ann<false>(s, tile0, ntiles, d_qscale, VAnn{}, st);
 }
 
 // row-major device staging -> the fragment-ordered image

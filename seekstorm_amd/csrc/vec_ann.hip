@@ -1,0 +1,298 @@
+// The ANN modes of search_vector_shard (AnnMode::Nprobe / Similaritythreshold / NprobeSimilaritythreshold,
+// vector.rs:1300-1392) for gfx950.
+//
+// The reference stores the records of a level (65 536 docs) cluster after cluster; the first record of a cluster is its
+// medoid.  Per query and level it scores every medoid, pushes (cluster, score) through TopK::new(min(n_probe, clusters),
+// cluster threshold) and then visits only the records of the surviving clusters.  Here, per batch of <= 64 queries:
+//
+//   1. ann_medoid_*_kernel   score[q][c] of every medoid, in the REFERENCE's summation order (dot_f32_avx2: 8 fmadd lanes
+//                            summed in order, vector_similarity.rs:1118-1142; dot_f32 for dim % 8 != 0, 1006-1008; the
+//                            i8 dot is an exact integer) -- a cluster chosen on a last-bit difference would change the
+//                            result set, so this is bit-exact rather than "close";
+//   2. ann_select_kernel     one thread per (query, level) replays TopK::push over the level's clusters in file order
+//                            (ties keep the earlier cluster; the evicted entry is the first minimum) and sets bit c of the
+//                            query's selection row and of the batch's union row;
+//   3. ann_tiles_*_kernel    the ascending list of 128-row tiles that hold a row of a cluster in the union.
+//
+// The scan kernels (vec_scan.hip / vec8_scan.hip, ANN instantiation) then walk that tile list instead of the whole image
+// and admit a row only for the queries whose bit is set for the row's cluster.  One pass serves the whole batch: a
+// single query reads n_probe / clusters of the image; a batch of 64 reads the union of 64 selections, never more than
+// AnnMode::All.
+#include <float.h>
+
+#include <algorithm>
+
+#include "ss_common.h"
+#include "vec_dev.h"
+
+constexpr int AQ = 8;  // queries per thread in the medoid kernels
+
+// float offset in Qf (vec_qprep_kernel order) of Q[q][k .. k+3], k % 4 == 0
+__device__ __forceinline__ uint32_t qf_off(uint32_t q, uint32_t k) {
+  const uint32_t g = (k & 31u) >> 2;
+  return (k >> 5) * 2048u + (q >> 5) * 1024u + (g >> 1) * 256u + ((q & 31u) + 32u * (g & 1u)) * 4u;
+}
+// byte offset in Qf8 (vec8_qprep_kernel order) of Q8[q][k .. k+15], k % 16 == 0
+__device__ __forceinline__ uint32_t qf8_off(uint32_t q, uint32_t k) {
+  return ((((k >> 7) * 4u + ((k >> 4) & 3u)) * 2u + (q >> 5)) * 64u + (q & 31u) + 32u * ((k >> 6) & 1u)) * 16u;
+}
+
+// thread = cluster, blockIdx.y = group of AQ queries
+__global__ void __launch_bounds__(64) ann_medoid_f32_kernel(const float* __restrict__ X, uint32_t dim, uint32_t dim_pad,
+                                                           const uint32_t* __restrict__ cluster_first, uint32_t nc,
+                                                           const float* __restrict__ Qf, uint32_t nq, float* __restrict__ score) {
+  const uint32_t c = blockIdx.x * 64u + threadIdx.x;
+  const uint32_t q0 = blockIdx.y * AQ;
+  const float* x = X + (size_t)cluster_first[c < nc ? c : nc - 1] * dim_pad;
+  float s[AQ];
+  if ((dim & 7u) == 0) {  // dot_f32_avx2: lane j accumulates q[8 i + j] * e[8 i + j] with fmadd, then lanes 0..7 are summed
+    float l[AQ][8];
+#pragma unroll
+    for (int a = 0; a < AQ; a++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) l[a][j] = 0.f;
+    for (uint32_t k = 0; k < dim; k += 8) {
+      const float4 xa = *(const float4*)(x + k), xb = *(const float4*)(x + k + 4);
+#pragma unroll
+      for (int a = 0; a < AQ; a++) {
+        const float4 qa = *(const float4*)(Qf + qf_off(q0 + a, k)), qb = *(const float4*)(Qf + qf_off(q0 + a, k + 4));
+        l[a][0] = fmaf(qa.x, xa.x, l[a][0]); l[a][1] = fmaf(qa.y, xa.y, l[a][1]);
+        l[a][2] = fmaf(qa.z, xa.z, l[a][2]); l[a][3] = fmaf(qa.w, xa.w, l[a][3]);
+        l[a][4] = fmaf(qb.x, xb.x, l[a][4]); l[a][5] = fmaf(qb.y, xb.y, l[a][5]);
+        l[a][6] = fmaf(qb.z, xb.z, l[a][6]); l[a][7] = fmaf(qb.w, xb.w, l[a][7]);
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < AQ; a++) {
+      float t = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; j++) t = __fadd_rn(t, l[a][j]);
+      s[a] = t;
+    }
+  } else {  // dot_f32: sequential, product and sum rounded separately
+#pragma unroll
+    for (int a = 0; a < AQ; a++) s[a] = 0.f;
+    for (uint32_t k = 0; k < dim; k++) {
+      const float xv = x[k];
+#pragma unroll
+      for (int a = 0; a < AQ; a++) s[a] = __fadd_rn(s[a], __fmul_rn(Qf[qf_off(q0 + a, k & ~3u) + (k & 3u)], xv));
+    }
+  }
+  if (c < nc)
+#pragma unroll
+    for (int a = 0; a < AQ; a++)
+      if (q0 + a < nq) score[(size_t)(q0 + a) * nc + c] = s[a];
+}
+
+__global__ void __launch_bounds__(64) ann_medoid_i8_kernel(const int8_t* __restrict__ X8, uint32_t dim_pad8,
+                                                          const uint32_t* __restrict__ cluster_first, uint32_t nc,
+                                                          const int8_t* __restrict__ Qf8, uint32_t nq,
+                                                          const float* __restrict__ row_scale, const float* __restrict__ q_scale,
+                                                          int scaled, float* __restrict__ score) {
+  const uint32_t c = blockIdx.x * 64u + threadIdx.x;
+  const uint32_t q0 = blockIdx.y * AQ;
+  const uint32_t row = cluster_first[c < nc ? c : nc - 1];
+  const uint32_t L = dim_pad8 / 128u;
+  int acc[AQ];
+#pragma unroll
+  for (int a = 0; a < AQ; a++) acc[a] = 0;
+  for (uint32_t k = 0; k < dim_pad8; k += 16) {
+    const int4 xv = *(const int4*)(X8 + v8_index(row, k, L));
+    const int xw[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+    for (int a = 0; a < AQ; a++) {
+      const int4 qv = *(const int4*)(Qf8 + qf8_off(q0 + a, k));
+      const int qw[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+      for (int w = 0; w < 4; w++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a] += (int)(int8_t)(xw[w] >> (8 * b)) * (int)(int8_t)(qw[w] >> (8 * b));
+    }
+  }
+  if (c < nc) {
+    const float es = (scaled && row_scale) ? row_scale[row] : 1.f;
+#pragma unroll
+    for (int a = 0; a < AQ; a++)
+      if (q0 + a < nq) {
+        float f = (float)acc[a];
+        if (scaled) f = f * (q_scale ? q_scale[q0 + a] : 1.f) * es;  // dot_i8_quantized: dot as f32 * scale1 * scale2
+        score[(size_t)(q0 + a) * nc + c] = f;
+      }
+  }
+}
+
+// One thread per (query, level): TopK::new(k = min(n_probe, clusters), threshold) and TopK::push (vector.rs:366-496) over
+// the level's medoid scores in cluster order.  Only the surviving SET matters downstream, but which entries survive a tie
+// depends on the order of the pushes and on which minimum is evicted, so the array is replayed as the reference keeps it.
+__global__ void ann_select_kernel(const float* __restrict__ score, const uint32_t* __restrict__ level_off, uint32_t n_levels,
+                                  uint32_t nc, uint32_t nq, uint32_t n_probe, float cthr, float* __restrict__ its,
+                                  uint32_t* __restrict__ itc, uint32_t* __restrict__ sel, uint32_t W, uint32_t* __restrict__ ncl) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nq * n_levels) return;
+  const uint32_t q = idx / n_levels, l = idx % n_levels;
+  const uint32_t c0 = level_off[l], C = level_off[l + 1] - c0;
+  const uint32_t k = (n_probe == 0 || n_probe > C) ? C : n_probe;
+  const float* sc = score + (size_t)q * nc + c0;
+  float* is = its + (size_t)q * nc + c0;
+  uint32_t* ic = itc + (size_t)q * nc + c0;
+  uint32_t len = 0;
+  float lowest = -FLT_MAX;
+  for (uint32_t c = 0; c < C; c++) {
+    const float s = sc[c];
+    if (s < cthr || (len == k && s <= lowest)) continue;
+    if (len < k) { is[len] = s; ic[len] = c; len++; continue; }
+    uint32_t min_i = 0;
+    float min_v = is[0];
+    for (uint32_t i = 1; i < len; i++) {
+      const float v = is[i];
+      if (v < min_v) { min_v = v; min_i = i; }
+    }
+    if (s > min_v) { lowest = min_v; is[min_i] = s; ic[min_i] = c; }
+  }
+  for (uint32_t i = 0; i < len; i++) {
+    const uint32_t cg = c0 + ic[i];
+    atomicOr(&sel[(size_t)q * W + (cg >> 5)], 1u << (cg & 31u));
+    atomicOr(&sel[(size_t)64 * W + (cg >> 5)], 1u << (cg & 31u));
+  }
+  if (len) atomicAdd(&ncl[q], len);
+}
+
+// Tile list of the batch: tile t is listed if a cluster in [cluster of its first row, cluster of its last row] is in the
+// union.  Two launches keep the list ascending (the chunk schedule and the totals then do not depend on timing):
+// flag + rank inside each group of 1024 tiles, then place at the group's base.
+constexpr int AT = 1024;
+__global__ void __launch_bounds__(AT) ann_tiles_flag_kernel(const uint32_t* __restrict__ row_cluster, unsigned long long n_rows,
+                                                           uint32_t T, const uint32_t* __restrict__ sel_union,
+                                                           uint32_t* __restrict__ rank, uint32_t* __restrict__ group_count) {
+  __shared__ uint32_t wsum[AT / 64];
+  const uint32_t t = blockIdx.x * AT + threadIdx.x;
+  bool act = false;
+  if (t < T) {
+    const unsigned long long r_lo = (unsigned long long)t * VS_TR;
+    const unsigned long long r_hi = (r_lo + VS_TR < n_rows ? r_lo + VS_TR : n_rows) - 1;
+    const uint32_t c_lo = row_cluster[r_lo], c_hi = row_cluster[r_hi];
+    for (uint32_t w = c_lo >> 5; w <= (c_hi >> 5) && !act; w++) {
+      uint32_t m = 0xFFFFFFFFu;
+      if (w == (c_lo >> 5)) m &= 0xFFFFFFFFu << (c_lo & 31u);
+      if (w == (c_hi >> 5)) m &= 0xFFFFFFFFu >> (31u - (c_hi & 31u));
+      act = (sel_union[w] & m) != 0;
+    }
+  }
+  const unsigned long long b = __ballot(act);
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  if (lane == 0) wsum[wv] = (uint32_t)__popcll(b);
+  __syncthreads();
+  uint32_t base = 0, total = 0;
+  for (uint32_t i = 0; i < AT / 64; i++) {
+    if (i < wv) base += wsum[i];
+    total += wsum[i];
+  }
+  if (t < T) rank[t] = act ? base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull)) : 0xFFFFFFFFu;
+  if (threadIdx.x == 0) group_count[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(AT) ann_tiles_place_kernel(const uint32_t* __restrict__ rank, const uint32_t* __restrict__ group_count,
+                                                            uint32_t T, uint32_t* __restrict__ tiles) {
+  __shared__ uint32_t sbase;
+  if (threadIdx.x < 64) {
+    uint32_t v = 0;
+    for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 64) v += group_count[i];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if (threadIdx.x == 0) sbase = v;
+  }
+  __syncthreads();
+  const uint32_t t = blockIdx.x * AT + threadIdx.x;
+  if (t < T) {
+    const uint32_t r = rank[t];
+    if (r != 0xFFFFFFFFu) tiles[sbase + r] = t;
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) tiles[T] = sbase + group_count[blockIdx.x];
+}
+
+// ---------------------------------------------------------------- host side
+void ssi_vec_free_clusters(ss_shard* s) {
+  void* ptrs[] = {s->d_row_cluster, s->d_cluster_first, s->d_level_off, s->d_ann_score, s->d_ann_its,
+                  s->d_ann_itc,     s->d_ann_sel,       s->d_ann_tiles, s->d_ann_ncl};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  s->d_row_cluster = nullptr; s->d_cluster_first = nullptr; s->d_level_off = nullptr; s->d_ann_score = nullptr;
+  s->d_ann_its = nullptr; s->d_ann_itc = nullptr; s->d_ann_sel = nullptr; s->d_ann_tiles = nullptr; s->d_ann_ncl = nullptr;
+  s->vec_n_clusters = 0; s->vec_n_levels = 0;
+}
+
+// caller holds the shard lock and has selected the device
+int ssi_vec_set_clusters(ss_shard* s, uint32_t n_levels, const uint32_t* level_clusters, const uint32_t* child_count) {
+  if (!s->d_X && !s->d_X8) return SS_ESTATE;
+  if (n_levels == 0 || !level_clusters || !child_count) return SS_EINVAL;
+  uint64_t nc = 0;
+  for (uint32_t l = 0; l < n_levels; l++) nc += level_clusters[l];
+  if (nc == 0 || nc > 0x7FFFFFFFull) return SS_EINVAL;
+  std::vector<uint32_t> level_off(n_levels + 1), first(nc), row_cluster(s->n_rows);
+  uint64_t row = 0, c = 0;
+  for (uint32_t l = 0; l < n_levels; l++) {
+    level_off[l] = (uint32_t)c;
+    for (uint32_t i = 0; i < level_clusters[l]; i++, c++) {
+      // an empty cluster has no medoid: the reference would score whatever bytes follow (vector.rs:1311-1316)
+      if (child_count[c] == 0) return SS_ENOTSUP;
+      if (row + child_count[c] > s->n_rows) return SS_EINVAL;
+      first[c] = (uint32_t)row;
+      std::fill(row_cluster.begin() + row, row_cluster.begin() + row + child_count[c], (uint32_t)c);
+      row += child_count[c];
+    }
+  }
+  level_off[n_levels] = (uint32_t)c;
+  if (row != s->n_rows) return SS_EINVAL;
+  SS_HIP(hipStreamSynchronize(s->stream));
+  ssi_vec_free_clusters(s);
+  const uint32_t W = (uint32_t)((nc + 31) / 32);
+  const uint32_t T = (uint32_t)(s->n_rows_pad / VS_TR);
+  const uint32_t groups = (T + AT - 1) / AT;
+  SS_HIP(hipMalloc(&s->d_row_cluster, s->n_rows * sizeof(uint32_t)));
+  SS_HIP(hipMalloc(&s->d_cluster_first, nc * sizeof(uint32_t)));
+  SS_HIP(hipMalloc(&s->d_level_off, (n_levels + 1) * sizeof(uint32_t)));
+  SS_HIP(hipMalloc(&s->d_ann_score, (size_t)SS_VEC_BATCH * nc * sizeof(float)));
+  SS_HIP(hipMalloc(&s->d_ann_its, (size_t)SS_VEC_BATCH * nc * sizeof(float)));
+  SS_HIP(hipMalloc(&s->d_ann_itc, (size_t)SS_VEC_BATCH * nc * sizeof(uint32_t)));
+  SS_HIP(hipMalloc(&s->d_ann_sel, (size_t)(SS_VEC_BATCH + 1) * W * sizeof(uint32_t)));
+  SS_HIP(hipMalloc(&s->d_ann_tiles, ((size_t)T + 1 + T + groups) * sizeof(uint32_t)));  // list + count | rank | group counts
+  SS_HIP(hipMalloc(&s->d_ann_ncl, SS_VEC_BATCH * sizeof(uint32_t)));
+  SS_HIP(hipMemcpy(s->d_row_cluster, row_cluster.data(), s->n_rows * sizeof(uint32_t), hipMemcpyHostToDevice));
+  SS_HIP(hipMemcpy(s->d_cluster_first, first.data(), nc * sizeof(uint32_t), hipMemcpyHostToDevice));
+  SS_HIP(hipMemcpy(s->d_level_off, level_off.data(), (n_levels + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+  s->vec_n_clusters = (uint32_t)nc;
+  s->vec_n_levels = n_levels;
+  return SS_OK;
+}
+
+int ssi_vec_ann_prepare(ss_shard* s, uint32_t nb, const float* d_qscale, const ss_ann_mode* mode, VAnn* out,
+                        uint32_t* d_out_clusters, hipStream_t st) {
+  const uint32_t nc = s->vec_n_clusters, W = (nc + 31) / 32;
+  const uint32_t T = (uint32_t)(s->n_rows_pad / VS_TR), groups = (T + AT - 1) / AT;
+  uint32_t* tiles = s->d_ann_tiles;
+  uint32_t* rank = tiles + T + 1;
+  uint32_t* gcount = rank + T;
+  SS_HIP(hipMemsetAsync(s->d_ann_sel, 0, (size_t)(SS_VEC_BATCH + 1) * W * sizeof(uint32_t), st));
+  SS_HIP(hipMemsetAsync(s->d_ann_ncl, 0, SS_VEC_BATCH * sizeof(uint32_t), st));
+  const dim3 grid((nc + 63) / 64, (nb + AQ - 1) / AQ);
+  if (s->d_X8) {
+    const bool scaled = s->d_row_scale != nullptr || d_qscale != nullptr;
+    ann_medoid_i8_kernel<<<grid, 64, 0, st>>>(s->d_X8, s->dim_pad8, s->d_cluster_first, nc, (const int8_t*)s->d_Qf, nb,
+                                               s->d_row_scale, d_qscale, scaled ? 1 : 0, s->d_ann_score);
+  } else {
+    ann_medoid_f32_kernel<<<grid, 64, 0, st>>>(s->d_X, s->dim, s->dim_pad, s->d_cluster_first, nc, s->d_Qf, nb, s->d_ann_score);
+  }
+  const uint32_t nsel = nb * s->vec_n_levels;
+  ann_select_kernel<<<(nsel + 63) / 64, 64, 0, st>>>(s->d_ann_score, s->d_level_off, s->vec_n_levels, nc, nb, mode->n_probe,
+                                                     mode->cluster_threshold_raw, s->d_ann_its, s->d_ann_itc, s->d_ann_sel, W,
+                                                     s->d_ann_ncl);
+  ann_tiles_flag_kernel<<<groups, AT, 0, st>>>(s->d_row_cluster, (unsigned long long)s->n_rows, T,
+                                               s->d_ann_sel + (size_t)SS_VEC_BATCH * W, rank, gcount);
+  ann_tiles_place_kernel<<<groups, AT, 0, st>>>(rank, gcount, T, tiles);
+  if (d_out_clusters) SS_HIP(hipMemcpyAsync(d_out_clusters, s->d_ann_ncl, nb * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+  SS_HIP(hipGetLastError());
+  out->tiles = tiles;
+  out->n_tiles = tiles + T;
+  out->row_cluster = s->d_row_cluster;
+  out->sel = s->d_ann_sel;
+  out->sel_words = W;
+  return SS_OK;
+}

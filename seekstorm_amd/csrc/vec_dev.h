@@ -48,3 +48,49 @@ __device__ __forceinline__ void vs_append(const float (&f)[16], float tau, uint3
     }
   }
 }
+
+// ---------------------------------------------------------------- ANN modes (vec_ann.hip)
+// What a scan launch needs to visit only the clusters some query of the batch selected (AnnMode::Nprobe /
+// Similaritythreshold, vector.rs:1300-1392): the ascending list of 128-row tiles that hold a selected cluster, the
+// cluster of every row and one bit per (query, cluster).  A row is a candidate of query q only if q selected its cluster.
+struct VAnn {
+  const uint32_t* tiles;        // [n_tiles] tile ids, ascending
+  const uint32_t* n_tiles;      // device scalar
+  const uint32_t* row_cluster;  // [n_rows] shard-wide cluster index
+  const uint32_t* sel;          // [64][sel_words] bit c of row q: query q visits cluster c
+  uint32_t sel_words;
+};
+__device__ __forceinline__ void vs_append_ann(const float (&f)[16], float tau, uint32_t q, unsigned long long row_base,
+                                              unsigned long long n_rows, VState* __restrict__ st,
+                                              unsigned long long* __restrict__ cand, const VAnn& ann) {
+  uint32_t m = 0;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const unsigned long long row = row_base + (r & 3) + 8 * (r >> 2);
+    if (f[r] > tau && row < n_rows) {
+      const uint32_t c = ann.row_cluster[row];
+      m |= ((ann.sel[(size_t)q * ann.sel_words + (c >> 5)] >> (c & 31u)) & 1u) << r;
+    }
+  }
+  if (m == 0) return;
+  uint32_t slot = atomicAdd(&st->cnt[q * VS_CNT_STRIDE], (uint32_t)__popc(m));
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    if ((m >> r) & 1u) {
+      const unsigned long long row = row_base + (r & 3) + 8 * (r >> 2);
+      if (slot < VS_CAP) cand[(size_t)q * VS_CAP + slot] = mk_key(f[r], (uint32_t)row);
+      slot++;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- i8 image geometry (vec8_scan.hip)
+constexpr int V8_WAVES = 4;     // x 32 rows = one 128-row tile per workgroup step (same tile unit as the f32 scan)
+constexpr int V8_D = 3;         // lines (128 bytes of a row) in flight per lane (6 measured the same)
+constexpr int V8_LINE = 128;
+// byte offset of X8[row][k] in the fragment-ordered image; L = lines (128 bytes) per row
+__host__ __device__ inline size_t v8_index(unsigned long long row, uint32_t k, uint32_t L) {
+  const unsigned long long blk = row >> 5;  // 32-row block = (tile, wave)
+  const uint32_t lane = (uint32_t)(row & 31u) + 32u * ((k >> 6) & 1u);
+  return ((((size_t)blk * L + (k >> 7)) * 4u + ((k >> 4) & 3u)) * 64u + lane) * 16u + (k & 15u);
+}

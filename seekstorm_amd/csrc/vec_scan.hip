@@ -48,11 +48,13 @@ __global__ void vec_init_kernel(VState* st, float tau_init) {
 // ---------------------------------------------------------------- the scan
 // TWO: queries 32..63 are in use.  A batch of <= 32 queries skips their half of the MFMA work, which turns the scan from
 // MFMA-bound (9.2 ms per pass at 10 M x 768) into HBM-bound: the latency of small batches and single queries.
-template <bool TWO>
+// ANN: the launch walks the batch's list of selected tiles (AnnMode::Nprobe / Similaritythreshold, vec_ann.hip) and admits
+// a row only for the queries that selected its cluster.
+template <bool TWO, bool ANN>
 __global__ void __launch_bounds__(VS_WAVES * 64, 2)
 vec_scan_kernel(const float* __restrict__ X, uint32_t dim_pad, unsigned long long n_rows,
                 const float* __restrict__ Qf, uint32_t nch, uint32_t tile0, uint32_t ntiles, VState* __restrict__ st,
-                unsigned long long* __restrict__ cand) {
+                unsigned long long* __restrict__ cand, VAnn ann) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -66,6 +68,10 @@ vec_scan_kernel(const float* __restrict__ X, uint32_t dim_pad, unsigned long lon
   // would be a vmcnt(0) that drains the LDS-DMA ring once per tile
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(tau0), "+v"(tau1)::"memory");
 
+  if (ANN) {
+    const uint32_t na = *ann.n_tiles;
+    ntiles = na > tile0 ? min(ntiles, na - tile0) : 0u;
+  }
   // tiles of this workgroup: tile0 + blockIdx.x + i * gridDim.x
   const uint32_t first = blockIdx.x;
   if (first >= ntiles) return;
@@ -94,8 +100,11 @@ vec_scan_kernel(const float* __restrict__ X, uint32_t dim_pad, unsigned long lon
   const uint32_t boff = VS_XS + lane * 16u;
 
   uint32_t i_tile = 0, i_kc = 0, i_stage = 0;  // issue cursor
+  uint32_t i_tix = 0;
   auto issue = [&]() {
-    const float* xt = X + (size_t)(tile0 + first + (size_t)i_tile * gridDim.x) * tile_stride + i_kc * VS_KC;
+    if (ANN) { if (i_kc == 0) i_tix = ann.tiles[tile0 + first + i_tile * gridDim.x]; }
+    const size_t tix = ANN ? (size_t)i_tix : (size_t)(tile0 + first + (size_t)i_tile * gridDim.x);
+    const float* xt = X + tix * tile_stride + i_kc * VS_KC;
     char* sb = smem + i_stage * VS_STAGE;
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -142,8 +151,9 @@ vec_scan_kernel(const float* __restrict__ X, uint32_t dim_pad, unsigned long lon
 
     if (++c_kc == nch) {
       // ---- fused top-k filter: lane owns query (lane&31)+{0,32}, 16 rows per accumulator
-      const unsigned long long row_base =
-          (unsigned long long)(tile0 + first + (unsigned long long)c_tile * gridDim.x) * VS_TR + 32u * w + 4u * (lane >> 5);
+      const unsigned long long c_tix = ANN ? (unsigned long long)ann.tiles[tile0 + first + c_tile * gridDim.x]
+                                           : (unsigned long long)(tile0 + first + (unsigned long long)c_tile * gridDim.x);
+      const unsigned long long row_base = c_tix * VS_TR + 32u * w + 4u * (lane >> 5);
       float m0 = acc0[0], m1 = TWO ? acc1[0] : -INFINITY;
 #pragma unroll
       for (int r = 1; r < 16; r++) { m0 = fmaxf(m0, acc0[r]); if (TWO) m1 = fmaxf(m1, acc1[r]); }
@@ -151,13 +161,15 @@ vec_scan_kernel(const float* __restrict__ X, uint32_t dim_pad, unsigned long lon
         float f[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) f[r] = acc0[r];
-        vs_append(f, tau0, lane & 31, row_base, n_rows, st, cand);
+        if (ANN) vs_append_ann(f, tau0, lane & 31, row_base, n_rows, st, cand, ann);
+        else vs_append(f, tau0, lane & 31, row_base, n_rows, st, cand);
       }
       if (TWO && m1 > tau1) {
         float f[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) f[r] = acc1[r];
-        vs_append(f, tau1, 32 + (lane & 31), row_base, n_rows, st, cand);
+        if (ANN) vs_append_ann(f, tau1, 32 + (lane & 31), row_base, n_rows, st, cand, ann);
+        else vs_append(f, tau1, 32 + (lane & 31), row_base, n_rows, st, cand);
       }
 #pragma unroll
       for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -293,16 +305,19 @@ int ssi_vec_alloc_ws(ss_shard* s) {
   }
   if (!s->d_vstate) SS_HIP(hipMalloc(&s->d_vstate, sizeof(VState)));
   if (!s->d_cand) SS_HIP(hipMalloc(&s->d_cand, (size_t)64 * VS_CAP * sizeof(unsigned long long)));
-  SS_SET_MAX_LDS(vec_scan_kernel<true>, VS_LDS);
-  SS_SET_MAX_LDS(vec_scan_kernel<false>, VS_LDS);
+  SS_SET_MAX_LDS((vec_scan_kernel<true, false>), VS_LDS);
+  SS_SET_MAX_LDS((vec_scan_kernel<false, false>), VS_LDS);
+  SS_SET_MAX_LDS((vec_scan_kernel<true, true>), VS_LDS);
+  SS_SET_MAX_LDS((vec_scan_kernel<false, true>), VS_LDS);
   SS_SET_MAX_LDS(vec_refine_kernel, VS_CAP * (sizeof(unsigned long long) + sizeof(uint32_t)));
   return SS_OK;
 }
 
 int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float* d_qscale, uint32_t k, float thr,
                    uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, hipStream_t st,
-                   bool safe_mode) {
+                   bool safe_mode, const ss_ann_mode* ann_mode, uint32_t* d_out_clusters) {
   if (!s->d_X && !s->d_X8) return SS_ESTATE;
+  if (ann_mode && !s->d_row_cluster) return SS_ESTATE;  // the image carries no cluster structure (ss_vec_set_clusters)
   const bool i8 = s->d_X8 != nullptr;
   if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
   int rc = ssi_vec_alloc_ws(s);
@@ -338,18 +353,30 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float*
     if (i8) ssi_vec8_qprep(s, (const int8_t*)d_queries + (size_t)g0 * s->dim, nb, st);
     else vec_qprep_kernel<<<nch, 512, 0, st>>>((const float*)d_queries + (size_t)g0 * s->dim, nb, s->dim, s->d_Qf);
     vec_init_kernel<<<1, 64, 0, st>>>(vst, tau_init);
+    VAnn ann{};
+    if (ann_mode) {  // medoid scores -> per-query cluster selection -> the batch's tile list
+      rc = ssi_vec_ann_prepare(s, nb, d_qscale ? d_qscale + g0 : nullptr, ann_mode, &ann, d_out_clusters ? d_out_clusters + g0 : nullptr, st);
+      if (rc) return rc;
+    }
     uint32_t tile0 = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     ssi_prof_begin(s, 1, st, &e0, &e1);
     for (uint32_t c : chunks) {
       uint32_t grid = std::min<uint32_t>(c, 512);
-      if (i8) ssi_vec8_launch_scan(s, tile0, c, d_qscale ? d_qscale + g0 : nullptr, st);
-      else if (nb > 32)
-        vec_scan_kernel<true><<<grid, VS_WAVES * 64, VS_LDS, st>>>(s->d_X, s->dim_pad, (unsigned long long)s->n_rows, s->d_Qf,
-                                                                   nch, tile0, c, vst, cand);
+      if (i8) ssi_vec8_launch_scan(s, tile0, c, d_qscale ? d_qscale + g0 : nullptr, ann_mode ? &ann : nullptr, st);
+      else if (ann_mode) {
+        if (nb > 32)
+          vec_scan_kernel<true, true><<<grid, VS_WAVES * 64, VS_LDS, st>>>(s->d_X, s->dim_pad, (unsigned long long)s->n_rows,
+                                                                           s->d_Qf, nch, tile0, c, vst, cand, ann);
+        else
+          vec_scan_kernel<false, true><<<grid, VS_WAVES * 64, VS_LDS, st>>>(s->d_X, s->dim_pad, (unsigned long long)s->n_rows,
+                                                                            s->d_Qf, nch, tile0, c, vst, cand, ann);
+      } else if (nb > 32)
+        vec_scan_kernel<true, false><<<grid, VS_WAVES * 64, VS_LDS, st>>>(s->d_X, s->dim_pad, (unsigned long long)s->n_rows,
+                                                                          s->d_Qf, nch, tile0, c, vst, cand, ann);
       else
-        vec_scan_kernel<false><<<grid, VS_WAVES * 64, VS_LDS, st>>>(s->d_X, s->dim_pad, (unsigned long long)s->n_rows, s->d_Qf,
-                                                                    nch, tile0, c, vst, cand);
+        vec_scan_kernel<false, false><<<grid, VS_WAVES * 64, VS_LDS, st>>>(s->d_X, s->dim_pad, (unsigned long long)s->n_rows,
+                                                                           s->d_Qf, nch, tile0, c, vst, cand, ann);
       vec_refine_kernel<<<SS_VEC_BATCH, VR_THREADS, VS_CAP * (sizeof(unsigned long long) + sizeof(uint32_t)), st>>>(
           vst, cand, k, s->vec_multi_record ? s->d_row_doc : nullptr, s->d_row_doc, s->n_deleted ? s->d_deleted : nullptr,
           (uint32_t)s->deleted_words);

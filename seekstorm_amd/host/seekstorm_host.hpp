@@ -33,6 +33,17 @@ namespace seekstorm {
 enum class QueryType : uint32_t { Union = SS_OP_UNION, Intersection = SS_OP_INTERSECTION };      // search.rs:59
 enum class ResultType : uint32_t { Count = SS_RT_COUNT, Topk = SS_RT_TOPK, TopkCount = SS_RT_TOPKCOUNT };  // search.rs:168
 enum class SearchMode : int { Lexical = SS_MODE_LEXICAL, Vector = SS_MODE_VECTOR, Hybrid = SS_MODE_HYBRID };  // search.rs:73
+// search.rs AnnMode (used at vector.rs:1300-1307): All | Similaritythreshold(t) | Nprobe(n) | NprobeSimilaritythreshold(n, t);
+// t is the normalised similarity the reference's callers pass (TopK::new converts it, vector.rs:388-397)
+struct AnnMode {
+  enum class Kind { All, Similaritythreshold, Nprobe, NprobeSimilaritythreshold } kind = Kind::All;
+  size_t n_probe = 0;
+  float similarity_threshold = 0.f;
+  static AnnMode All() { return AnnMode(); }
+  static AnnMode Similaritythreshold(float t) { return AnnMode{Kind::Similaritythreshold, 0, t}; }
+  static AnnMode Nprobe(size_t n) { return AnnMode{Kind::Nprobe, n, 0.f}; }
+  static AnnMode NprobeSimilaritythreshold(size_t n, float t) { return AnnMode{Kind::NprobeSimilaritythreshold, n, t}; }
+};
 enum class ResultSource : uint8_t { Lexical = SS_SRC_LEXICAL, Vector = SS_SRC_VECTOR, Hybrid = SS_SRC_HYBRID };
 
 // min_heap.rs:17-40 with the default feature `vb`
@@ -104,11 +115,13 @@ class Shard {
   ResultObject search_lexical_shard(const std::vector<uint32_t>& query_terms, QueryType query_type_default, size_t offset,
                                     size_t length, ResultType result_type);
   ResultObject search_vector_shard(const float* query_vector /* normalised, dim() floats */, size_t length,
-                                   const float* similarity_threshold);
+                                   const float* similarity_threshold, const AnnMode& ann_mode = AnnMode());
   // batched forms used by the coalescer (results sorted by score desc, shard-local ids)
   std::vector<ResultObject> search_lexical_batch(const std::vector<ss_bm25_query>& queries, size_t k, ResultType result_type);
   std::vector<ResultObject> search_vector_batch(const float* query_vectors, size_t n_queries, size_t k,
-                                                const float* similarity_threshold);
+                                                const float* similarity_threshold, const AnnMode& ann_mode = AnnMode());
+  // cluster structure of rows uploaded in file order (vector.rs:1066-1094); open_vector_bin keeps the file's own
+  int set_clusters(const std::vector<uint32_t>& level_clusters, const std::vector<uint32_t>& child_count);
 
  private:
   ss_shard* h_ = nullptr;
@@ -134,7 +147,8 @@ class Index {
   // offset / truncate through ss_merge_results (search.rs:1875-2119).
   ResultObject search(const std::vector<uint32_t>& query_terms, const float* query_vector, QueryType query_type_default,
                       SearchMode search_mode, size_t offset, size_t length, ResultType result_type,
-                      const float* similarity_threshold = nullptr, bool normalize_query = true);
+                      const float* similarity_threshold = nullptr, bool normalize_query = true,
+                      const AnnMode& ann_mode = AnnMode());
 
  private:
   std::vector<std::shared_ptr<Shard>> shards_;

@@ -61,6 +61,7 @@ class ResultObject:  # search.rs:186-213
     result_count: int = 0
     result_count_total: int = 0
     observed_vector_count: int = 0
+    observed_cluster_count: int = 0
 
 
 SIMILARITY_NORMALIZATION_64_I8 = np.float32(1.0) / np.float32(16129.0)  # vector.rs:29
@@ -93,6 +94,33 @@ def threshold_raw(similarity_threshold):
     if similarity_threshold is None:
         return N.FLT_MIN_NEG
     return float(((np.float32(similarity_threshold) * np.float32(2.0)) - np.float32(1.0)) / SIMILARITY_NORMALIZATION_64_I8)
+
+
+@dataclass(frozen=True)
+class AnnMode:
+    """search.rs AnnMode: All | Similaritythreshold(t) | Nprobe(n) | NprobeSimilaritythreshold(n, t) (vector.rs:1300-1307).
+    n_probe = clusters visited per level (0 = no limit), similarity_threshold = normalised medoid similarity below which a
+    cluster is skipped (None = no threshold).  AnnMode.All is None wherever an ann_mode is accepted."""
+    n_probe: int = 0
+    similarity_threshold: Optional[float] = None
+    All = None
+
+    @staticmethod
+    def Nprobe(n_probe):
+        return AnnMode(int(n_probe), None)
+
+    @staticmethod
+    def Similaritythreshold(threshold):
+        return AnnMode(0, float(threshold))
+
+    @staticmethod
+    def NprobeSimilaritythreshold(n_probe, threshold):
+        return AnnMode(int(n_probe), float(threshold))
+
+    def _c(self):
+        if self.n_probe < 0 or (self.n_probe == 0 and self.similarity_threshold is None):
+            raise ValueError("AnnMode needs n_probe >= 1 or a similarity threshold")
+        return N.AnnModeC(self.n_probe, threshold_raw(self.similarity_threshold))
 
 
 class IndexBin:
@@ -229,6 +257,20 @@ class Shard:
         N.check(N.lib().ss_vec_info(self._h, C.byref(n), C.byref(d)), "ss_vec_info")
         self.vector_count, self.dim = n.value, d.value
 
+    def set_clusters(self, level_clusters, child_count):
+        """cluster structure of rows uploaded in the reference's order (level after level, cluster after cluster, the medoid
+        first; vector.rs:1066-1094): clusters per level, records per cluster.  upload_vector_bin keeps the file's own."""
+        lc = np.ascontiguousarray(level_clusters, np.uint32)
+        cc = np.ascontiguousarray(child_count, np.uint32)
+        if int(lc.sum()) != len(cc):
+            raise ValueError("child_count must have one entry per cluster")
+        N.check(N.lib().ss_vec_set_clusters(self._h, len(lc), N.ptr(lc, N.u32p), N.ptr(cc, N.u32p)), "ss_vec_set_clusters")
+
+    def cluster_info(self):
+        nl, nc = C.c_uint32(), C.c_uint32()
+        N.check(N.lib().ss_vec_cluster_info(self._h, C.byref(nl), C.byref(nc)), "ss_vec_cluster_info")
+        return nl.value, nc.value
+
     def set_deleted(self, doc_ids):
         """delete_hashset of the shard (index.rs:1594): replaces the tombstone set; also takes delete.bin's bytes"""
         if isinstance(doc_ids, (bytes, bytearray, memoryview)):
@@ -272,7 +314,8 @@ class Shard:
         N.check(N.lib().ss_vec_read_rows_i8(self._h, int(r0), int(n), out.ctypes.data), "ss_vec_read_rows_i8")
         return out
 
-    def search_vector_batch_i8(self, queries_i8, k, query_scale=None, similarity_threshold_raw=None):
+    def search_vector_batch_i8(self, queries_i8, k, query_scale=None, similarity_threshold_raw=None, ann_mode=None,
+                               with_clusters=False):
         """scores = dot_i8 as f32 (* query_scale * embedding_scale with scales): vector_similarity.rs:1011-1016, 1754-1758"""
         qv = np.ascontiguousarray(queries_i8, np.int8)
         if qv.ndim == 1:
@@ -286,9 +329,13 @@ class Shard:
         cnt = np.empty(nq, np.uint32)
         tot = np.empty(nq, np.uint64)
         thr = N.FLT_MIN_NEG if similarity_threshold_raw is None else float(similarity_threshold_raw)
-        N.check(N.lib().ss_vec_search_i8(self._h, nq, qv.ctypes.data, N.ptr(qs, N.f32p), k, thr, N.ptr(doc, N.u32p),
-                                         N.ptr(score, N.f32p), N.ptr(cnt, N.u32p), N.ptr(tot, N.u64p)), "ss_vec_search_i8")
-        return doc, score, cnt, tot
+        ncl = np.zeros(nq, np.uint32)
+        mode = None if ann_mode is None else ann_mode._c()
+        N.check(N.lib().ss_vec_search_i8_ann(self._h, nq, qv.ctypes.data, N.ptr(qs, N.f32p), k, thr,
+                                             None if mode is None else C.addressof(mode), N.ptr(doc, N.u32p),
+                                             N.ptr(score, N.f32p), N.ptr(cnt, N.u32p), N.ptr(tot, N.u64p), N.ptr(ncl, N.u32p)),
+                "ss_vec_search_i8_ann")
+        return (doc, score, cnt, tot, ncl) if with_clusters else (doc, score, cnt, tot)
 
     def synth_vectors(self, seed, n_rows, dim):
         N.check(N.lib().ss_vec_synth(self._h, int(seed), int(n_rows), int(dim)), "ss_vec_synth")
@@ -367,7 +414,7 @@ class Shard:
                 "ss_bm25_search")
         return doc, score, cnt, tot
 
-    def search_vector_batch(self, query_vectors, k, similarity_threshold=None):
+    def search_vector_batch(self, query_vectors, k, similarity_threshold=None, ann_mode=None, with_clusters=False):
         qv = np.ascontiguousarray(query_vectors, np.float32)
         if qv.ndim == 1:
             qv = qv[None, :]
@@ -378,10 +425,12 @@ class Shard:
         score = np.zeros((nq, k), np.float32)
         cnt = np.zeros(nq, np.uint32)
         tot = np.zeros(nq, np.uint64)
-        N.check(N.lib().ss_vec_search(self._h, nq, N.ptr(qv, N.f32p), int(k), threshold_raw(similarity_threshold),
-                                      N.ptr(doc, N.u32p), N.ptr(score, N.f32p), N.ptr(cnt, N.u32p), N.ptr(tot, N.u64p)),
-                "ss_vec_search")
-        return doc, score, cnt, tot
+        ncl = np.zeros(nq, np.uint32)
+        mode = None if ann_mode is None else ann_mode._c()
+        N.check(N.lib().ss_vec_search_ann(self._h, nq, N.ptr(qv, N.f32p), int(k), threshold_raw(similarity_threshold),
+                                          None if mode is None else C.addressof(mode), N.ptr(doc, N.u32p), N.ptr(score, N.f32p),
+                                          N.ptr(cnt, N.u32p), N.ptr(tot, N.u64p), N.ptr(ncl, N.u32p)), "ss_vec_search_ann")
+        return (doc, score, cnt, tot, ncl) if with_clusters else (doc, score, cnt, tot)
 
     # ---- the reference's per-shard seams (one query)
     def search_lexical_shard(self, query_terms, query_type_default=QueryType.Union, offset=0, length=10,
@@ -400,15 +449,18 @@ class Shard:
         ro.result_count_total = int(tot[0])
         return ro
 
-    def search_vector_shard(self, query_vector, length=10, similarity_threshold=None, strict=False) -> ResultObject:
+    def search_vector_shard(self, query_vector, length=10, similarity_threshold=None, strict=False,
+                            ann_mode=None) -> ResultObject:
         ro = ResultObject()
         try:
             if self.vector_precision == "i8":  # the query is quantised like the records (search.rs:1476-1490), threshold on the raw dot
                 q8 = quantize_f32_to_i8(np.ascontiguousarray(query_vector, np.float32).reshape(1, -1))
                 thr = None if similarity_threshold is None else threshold_raw(similarity_threshold)
-                doc, score, cnt, tot = self.search_vector_batch_i8(q8, length, similarity_threshold_raw=thr)
+                doc, score, cnt, tot, ncl = self.search_vector_batch_i8(q8, length, similarity_threshold_raw=thr,
+                                                                        ann_mode=ann_mode, with_clusters=True)
             else:
-                doc, score, cnt, tot = self.search_vector_batch(query_vector, length, similarity_threshold)
+                doc, score, cnt, tot, ncl = self.search_vector_batch(query_vector, length, similarity_threshold,
+                                                                     ann_mode=ann_mode, with_clusters=True)
         except Exception:
             if strict:
                 raise
@@ -417,7 +469,11 @@ class Shard:
         ro.results = [Result(int(d), float(s), ResultSource.Vector) for d, s in zip(doc[0, :n], score[0, :n])]
         ro.result_count = n
         ro.result_count_total = int(tot[0])
-        ro.observed_vector_count = self.vector_count  # AnnMode::All observes every record (vector.rs:421)
+        if ann_mode is None:
+            ro.observed_vector_count = self.vector_count  # AnnMode::All observes every record (vector.rs:421)
+            ro.observed_cluster_count = self.cluster_info()[1]
+        else:
+            ro.observed_cluster_count = int(ncl[0])  # vector.rs:1394
         return ro
 
     # ---- measurement hooks

@@ -1,0 +1,251 @@
+"""GPU parity tests (-m gpu) of the ANN modes (AnnMode::Nprobe / Similaritythreshold / NprobeSimilaritythreshold,
+vector.rs:1300-1392) through the C ABI against the oracle's restatement: the SAME clusters must be selected (medoid
+scores are computed in the reference's summation order), then the usual top-k bar applies to the visited records."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def S():
+    import seekstorm_amd
+    return seekstorm_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def l2(m):
+    return np.ascontiguousarray(m / np.linalg.norm(m, axis=1, keepdims=True).astype(np.float32), np.float32)
+
+
+def clustered(O, seed, level_clusters, dim, lo=40, hi=400, spread=0.35):
+    """rows in the reference's file order: level after level, cluster after cluster, centre + noise, L2-normalised;
+    cluster sizes are deliberately not multiples of the 128-row tile"""
+    rng = np.random.default_rng(seed)
+    child, rows = [], []
+    for nc in level_clusters:
+        for _ in range(nc):
+            n = int(rng.integers(lo, hi))
+            centre = rng.standard_normal(dim).astype(np.float32)
+            centre /= np.linalg.norm(centre)
+            pts = centre[None, :] + spread * rng.standard_normal((n, dim)).astype(np.float32) / np.sqrt(dim).astype(np.float32)
+            rows.append(pts)
+            child.append(n)
+    rows = np.concatenate(rows).astype(np.float32)
+    return l2(rows), np.asarray(child, np.uint32)
+
+
+def queries_near(O, rows, seed, nq, noise=0.5):
+    rng = np.random.default_rng(seed)
+    pick = rng.integers(0, len(rows), nq)
+    q = rows[pick] + noise * rng.standard_normal((nq, rows.shape[1])).astype(np.float32) / np.sqrt(rows.shape[1]).astype(np.float32)
+    return l2(q.astype(np.float32))
+
+
+MODES = [("Nprobe", 1, None), ("Nprobe", 3, None), ("Similaritythreshold", 0, 0.50002), ("NprobeSimilaritythreshold", 4, 0.50001)]
+
+
+def mk_mode(S, name, n, t):
+    if name == "Nprobe":
+        return S.AnnMode.Nprobe(n)
+    if name == "Similaritythreshold":
+        return S.AnnMode.Similaritythreshold(t)
+    return S.AnnMode.NprobeSimilaritythreshold(n, t)
+
+
+def oracle_mode_args(S, n, t):
+    from seekstorm_amd.search import threshold_raw
+    return dict(n_probe=n if n else 0xFFFFFFFF, cluster_threshold_raw=threshold_raw(t))
+
+
+@pytest.mark.parametrize("mode", MODES, ids=[m[0] + str(m[1]) for m in MODES])
+@pytest.mark.parametrize("nq", [64, 5])
+def test_ann_i8_parity(S, O, mode, nq):
+    """integer dots are exact: the selected clusters, the scores and (outside ties) the ids are the oracle's"""
+    lc = [7, 12, 5]
+    rows32, child = clustered(O, 11, lc, 128)
+    rows = O.quantize_i8(rows32)
+    qs = O.quantize_i8(queries_near(O, rows32, 12, nq))
+    name, n, t = mode
+    # the i8 score is the raw integer dot (~127^2 * cosine): place the cluster threshold inside the medoid scores
+    t_raw = None
+    am = mk_mode(S, name, n, t)
+    kw = oracle_mode_args(S, n, t)
+    if t is not None:
+        med = rows[np.concatenate([[0], np.cumsum(child.astype(np.int64))[:-1]])].astype(np.int32) @ qs[0].astype(np.int32)
+        t_raw = float(np.sort(med)[-6])
+        from seekstorm_amd.search import SIMILARITY_NORMALIZATION_64_I8
+        tn = (np.float32(t_raw) * SIMILARITY_NORMALIZATION_64_I8 + np.float32(1.0)) / np.float32(2.0)
+        am = mk_mode(S, name, n, float(tn))
+        kw = oracle_mode_args(S, n, float(tn))
+    sh = S.Shard(0)
+    sh.upload_vectors_i8(rows)
+    with pytest.raises(S.SeekStormHipError):
+        sh.search_vector_batch_i8(qs, 10, ann_mode=am)  # no cluster structure declared yet
+    sh.set_clusters(lc, child)
+    assert sh.cluster_info() == (3, 24)
+    k = 20
+    doc, score, cnt, tot, ncl = sh.search_vector_batch_i8(qs, k, ann_mode=am, with_clusters=True)
+    for i in range(nq):
+        od, os_, otot, oobs, oncl = O.vec_search_i8_ann(rows, qs[i], k, lc, child, **kw)
+        assert ncl[i] == oncl
+        assert cnt[i] == len(od)
+        assert np.array_equal(score[i][:cnt[i]], os_)
+        if len(od):
+            kth = os_[-1]
+            assert {int(x) for x, y in zip(doc[i][:cnt[i]], score[i]) if y > kth} == {int(x) for x, y in zip(od, os_) if y > kth}
+        assert np.all(doc[i][cnt[i]:] == 0xFFFFFFFF)
+        assert tot[i] >= cnt[i]
+    sh.close()
+
+
+@pytest.mark.parametrize("dim,simd", [(128, True), (100, False)])
+def test_ann_f32_parity(S, O, dim, simd):
+    """f32: medoids are scored in the reference's order (8 fmadd lanes, or sequential for dim % 8 != 0), so the cluster
+    choice is the oracle's bit for bit; record scores then meet the usual tolerance"""
+    lc = [9, 6, 11, 4]
+    rows, child = clustered(O, 21, lc, dim)
+    qs = queries_near(O, rows, 22, 40)
+    sh = S.Shard(0)
+    sh.upload_vectors(rows)
+    sh.set_clusters(lc, child)
+    k = 25
+    for am, kw in [(S.AnnMode.Nprobe(2), dict(n_probe=2)), (S.AnnMode.Nprobe(5), dict(n_probe=5))]:
+        doc, score, cnt, tot, ncl = sh.search_vector_batch(qs, k, ann_mode=am, with_clusters=True)
+        for i in range(len(qs)):
+            od, os_, otot, oobs, oncl = O.vec_search_ann(rows, qs[i], k, lc, child, simd_order=simd, **kw)
+            assert ncl[i] == oncl == sum(min(kw["n_probe"], c) for c in lc)
+            n = int(cnt[i])
+            assert n == len(od)
+            assert np.all(score[i][:n - 1] >= score[i][1:n])
+            assert np.allclose(score[i][:n], os_, rtol=REL, atol=2e-6)
+            band = abs(float(os_[-1])) * REL + 2e-6
+            strict = lambda dd, ss: {int(x) for x, y in zip(dd, ss) if y > os_[-1] + band}
+            assert strict(doc[i][:n], score[i][:n]) == strict(od, os_)
+    sh.close()
+
+
+def test_ann_every_cluster_equals_all_mode(S, O):
+    """n_probe >= clusters of every level visits everything: identical to AnnMode::All, and to a brute-force product"""
+    lc = [5, 8]
+    rows32, child = clustered(O, 31, lc, 64)
+    rows = O.quantize_i8(rows32)
+    qs = O.quantize_i8(queries_near(O, rows32, 32, 17))
+    sh = S.Shard(0)
+    sh.upload_vectors_i8(rows)
+    sh.set_clusters(lc, child)
+    a = sh.search_vector_batch_i8(qs, 30)
+    b = sh.search_vector_batch_i8(qs, 30, ann_mode=S.AnnMode.Nprobe(1000), with_clusters=True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert np.all(b[4] == 13)
+    full = rows.astype(np.int32) @ qs.astype(np.int32).T
+    for i in range(len(qs)):
+        assert np.array_equal(b[1][i], np.sort(full[:, i])[::-1][:30].astype(np.float32))
+    sh.close()
+
+
+def test_ann_selection_is_per_query_inside_one_batch(S, O):
+    """one pass scans the union of the batch's clusters; a row still counts only for the queries that chose its cluster:
+    every query of a batch gets what it gets alone"""
+    lc = [16, 16]
+    rows32, child = clustered(O, 41, lc, 64, lo=100, hi=300)
+    rows = O.quantize_i8(rows32)
+    qs = O.quantize_i8(queries_near(O, rows32, 42, 64))
+    sh = S.Shard(0)
+    sh.upload_vectors_i8(rows)
+    sh.set_clusters(lc, child)
+    am = S.AnnMode.Nprobe(1)
+    doc, score, cnt, tot = sh.search_vector_batch_i8(qs, 10, ann_mode=am)
+    starts = np.concatenate([[0], np.cumsum(child.astype(np.int64))])
+    cluster_of = np.searchsorted(starts, np.arange(len(rows)), side="right") - 1
+    for i in range(64):
+        d1, s1, c1, _ = sh.search_vector_batch_i8(qs[i:i + 1], 10, ann_mode=am)
+        assert np.array_equal(score[i], s1[0]) and cnt[i] == c1[0]
+        got = cluster_of[doc[i][:cnt[i]]]
+        assert len(set(got[got < 16])) <= 1 and len(set(got[got >= 16])) <= 1  # one cluster per level
+    sh.close()
+
+
+def test_ann_vector_bin_keeps_clusters_with_dedup_and_tombstones(S, O):
+    """a vector.bin as the reference writes it: cluster structure from the file, several records per doc, deleted docs"""
+    from oracle import ref_format as RF
+    dim = 32
+    lc = [4, 3]
+    rows, child = clustered(O, 51, lc, dim, lo=30, hi=90)
+    rng = np.random.default_rng(52)
+    levels, ids, r = [], [], 0
+    ci = 0
+    for lvl, nc in enumerate(lc):
+        clusters = []
+        for _ in range(nc):
+            recs = []
+            for _ in range(int(child[ci])):
+                d = int(rng.integers(0, 60))  # doc ids collide inside a level: several records per doc
+                recs.append((d, 0, 0, rows[r]))
+                ids.append((lvl << 16) | d)
+                r += 1
+            clusters.append(recs)
+            ci += 1
+        levels.append(clusters)
+    ids = np.asarray(ids, np.uint32)
+    sh = S.Shard(0)
+    sh.upload_vector_bin(RF.write_vector_bin(levels, dim), dim)
+    assert sh.cluster_info() == (2, 7)
+    gone = [3, (1 << 16) | 7, 41]
+    sh.set_deleted(gone)
+    qs = queries_near(O, rows, 53, 9)
+    k = 12
+    doc, score, cnt, tot, ncl = sh.search_vector_batch(qs, k, ann_mode=S.AnnMode.Nprobe(2), with_clusters=True)
+    for i in range(len(qs)):
+        od, os_, _, _, oncl = O.vec_search_ann(rows, qs[i], k, lc, child, n_probe=2, row_doc_ids=ids, deleted=gone)
+        n = int(cnt[i])
+        assert ncl[i] == oncl == 4
+        assert n == len(od) and not set(map(int, doc[i][:n])) & set(gone)
+        assert len(set(map(int, doc[i][:n]))) == n
+        assert np.allclose(score[i][:n], os_, rtol=REL, atol=2e-6)
+    sh.close()
+
+
+def test_ann_many_tiles_large_k(S, O):
+    """enough rows for every launch of the chunk schedule, k = 100, a full batch: i8 scores stay bit-exact"""
+    lc = [40, 40, 40]
+    rows32, child = clustered(O, 61, lc, 64, lo=400, hi=1200)
+    rows = O.quantize_i8(rows32)
+    qs = O.quantize_i8(queries_near(O, rows32, 62, 64))
+    sh = S.Shard(0)
+    sh.upload_vectors_i8(rows)
+    sh.set_clusters(lc, child)
+    k = 100
+    doc, score, cnt, tot, ncl = sh.search_vector_batch_i8(qs, k, ann_mode=S.AnnMode.Nprobe(6), with_clusters=True)
+    for i in range(0, 64, 7):
+        od, os_, _, _, oncl = O.vec_search_i8_ann(rows, qs[i], k, lc, child, n_probe=6)
+        assert ncl[i] == oncl == 18 and cnt[i] == len(od)
+        assert np.array_equal(score[i][:cnt[i]], os_)
+    sh.close()
+
+
+def test_ann_abi_validation(S, O):
+    rows = O.quantize_i8(O.vec_gen(O.VEC_SEED, 0, 1000, 32))
+    sh = S.Shard(0)
+    sh.upload_vectors_i8(rows)
+    with pytest.raises(S.SeekStormHipError):
+        sh.set_clusters([2], [400, 500])        # does not cover the rows
+    with pytest.raises(S.SeekStormHipError):
+        sh.set_clusters([3], [400, 0, 600])     # an empty cluster has no medoid
+    with pytest.raises(ValueError):
+        sh.set_clusters([3], [400, 600])
+    with pytest.raises(ValueError):
+        S.AnnMode(0, None)._c()
+    sh.set_clusters([1, 1], [400, 600])
+    d, s, c, t = sh.search_vector_batch_i8(O.quantize_i8(O.vec_gen(O.VECQ_SEED, 0, 1, 32)), 5, ann_mode=S.AnnMode.Nprobe(1))
+    assert c[0] == 5
+    sh.upload_vectors_i8(rows[:500])           # a new image drops the old cluster structure
+    assert sh.cluster_info() == (0, 0)
+    sh.close()

@@ -273,3 +273,43 @@ def test_i8_quantisation_and_integer_dot():
     d2, s2, _, _ = O.vec_search_i8(rows, q, 10, row_scale=rs, query_scale=0.37)
     want = (full.astype(np.float32) * np.float32(0.37)) * rs
     assert np.array_equal(np.sort(s2)[::-1], s2) and np.allclose(s2, np.sort(want)[::-1][:10], rtol=0, atol=0)
+
+
+def test_ann_modes_select_clusters_like_the_reference():
+    # vector.rs:1300-1392: per level, TopK::new(min(n_probe, clusters), cluster threshold) over the medoids (first record
+    # of each cluster), survivors sorted by score desc, their records visited cluster after cluster
+    rng = np.random.default_rng(3)
+    dim, lc = 16, [3, 2]
+    child = np.array([4, 6, 5, 7, 3], np.uint32)
+    rows = rng.standard_normal((25, dim)).astype(np.float32)
+    q = rng.standard_normal(dim).astype(np.float32)
+    first = np.concatenate([[0], np.cumsum(child.astype(np.int64))[:-1]])
+    med = np.array([O.vec_search(rows[f:f + 1], q, 1)[1][0] for f in first])  # medoid scores by the same dot
+    # Nprobe(1): the best medoid of each level
+    best = [int(np.argmax(med[:3])), 3 + int(np.argmax(med[3:]))]
+    visited = np.concatenate([np.arange(first[c], first[c] + child[c]) for c in best])
+    d, s, tot, obs, ncl = O.vec_search_ann(rows, q, 25, lc, child, n_probe=1)
+    assert ncl == 2 and obs == len(visited) and set(map(int, d)) == set(map(int, visited))
+    assert np.all(s[:-1] >= s[1:])
+    # every cluster: AnnMode::All's result
+    d_all, s_all, _, _ = O.vec_search(rows, q, 10)
+    d2, s2, _, obs2, ncl2 = O.vec_search_ann(rows, q, 10, lc, child)
+    assert ncl2 == 5 and obs2 == 25 and np.array_equal(s2, s_all) and set(map(int, d2)) == set(map(int, d_all))
+    # Similaritythreshold: clusters whose medoid scores below the threshold are skipped (score < threshold -> reject)
+    thr = float(np.sort(med)[2])
+    d3, s3, _, obs3, ncl3 = O.vec_search_ann(rows, q, 25, lc, child, cluster_threshold_raw=thr)
+    keep = [c for c in range(5) if med[c] >= thr]
+    assert ncl3 == len(keep) == 3 and obs3 == int(child[keep].sum())
+    # ties between medoids keep the EARLIER cluster (TopK::push admits only score > current minimum)
+    rows_t = rows.copy()
+    rows_t[first[1]] = rows_t[first[0]]
+    rows_t[first[2]] = rows_t[first[0]]
+    d4, _, _, obs4, _ = O.vec_search_ann(rows_t[:15], q, 15, [3], child[:3], n_probe=1)
+    assert obs4 == child[0] and set(map(int, d4)) == set(range(int(child[0])))
+    # i8 records: same walk over exact integer scores
+    r8, q8 = O.quantize_i8(rows / np.abs(rows).max()), O.quantize_i8(q / np.abs(q).max())
+    med8 = r8[first].astype(np.int64) @ q8.astype(np.int64)
+    d5, s5, _, obs5, ncl5 = O.vec_search_i8_ann(r8, q8, 25, lc, child, n_probe=1)
+    best8 = [int(np.argmax(med8[:3])), 3 + int(np.argmax(med8[3:]))]
+    assert ncl5 == 2 and obs5 == int(child[best8].sum())
+    assert sorted(map(int, s5), reverse=True) == [int(x) for x in s5]
