@@ -304,7 +304,37 @@ def main():
                              "avg_launch_ms": avg_ms, "launches": int(launches)},
                    latency_ms={"batch64_p50": pct(lat, 50), "batch64_p99": pct(lat, 99), "single_query_p50": pct(lat1, 50),
                                "single_query_p99": pct(lat1, 99)})
+        # ---- AnnMode::Nprobe on the same image: a cluster STRUCTURE (256 records per cluster, 256 clusters per 65 536-doc
+        # level, as the reference lays a level out) over the synthetic rows -- the cost of the mode does not depend on what
+        # the clusters mean.  16 of 256 clusters per level = 6.25 % of the records per query.
+        ann_lc, ann_cc = [], []
+        for l0 in range(0, args.rows, 65536):
+            n_l = min(65536, args.rows - l0)
+            cl = [256] * (n_l // 256) + ([n_l % 256] if n_l % 256 else [])
+            ann_lc.append(len(cl)); ann_cc += cl
+        ann_mode = S.AnnMode.Nprobe(16)._c()
+        v_ncl = torch.empty((B,), dtype=torch.int32, device=dev)
+        def ann_leg(i8):
+            sh.set_clusters(ann_lc, ann_cc)
+            def step(n):
+                if i8:
+                    N.check(L.ss_vec_search_i8_ann_dev(sh._h, n, q8.data_ptr(), None, kv, N.FLT_MIN_NEG, C.addressof(ann_mode),
+                                                       v_doc.data_ptr(), v_score.data_ptr(), v_cnt.data_ptr(), v_tot.data_ptr(),
+                                                       v_ncl.data_ptr(), sptr), "ss_vec_search_i8_ann_dev")
+                else:
+                    N.check(L.ss_vec_search_ann_dev(sh._h, n, qv.data_ptr(), kv, N.FLT_MIN_NEG, C.addressof(ann_mode), v_doc.data_ptr(),
+                                                    v_score.data_ptr(), v_cnt.data_ptr(), v_tot.data_ptr(), v_ncl.data_ptr(), sptr),
+                            "ss_vec_search_ann_dev")
+            l1 = latencies(lambda: step(1), 8)
+            l64 = latencies(lambda: step(B), 4)
+            assert np.all(v_cnt.cpu().numpy().astype(np.int64) == kv), "ANN candidate overflow or short result in bench"
+            return {"mode": "Nprobe(16) of 256 clusters per level", "clusters_visited_per_query": int(v_ncl[0].item()),
+                    "single_query_ms_p50": pct(l1, 50), "batch64_ms_p50": pct(l64, 50)}
+        if args.rows >= 65536:
+            vec["ann"] = ann_leg(False)
         # property checks at full size: sorted, and the scores really are dot products of the returned rows
+        vec_step()
+        torch.cuda.synchronize()
         vs = v_score.cpu().numpy()
         assert np.all(vs[:, :-1] >= vs[:, 1:])
         ids = v_doc.cpu().numpy()
@@ -353,7 +383,8 @@ def main():
         ms8 = kms8 / max(launches8, 1)
         bytes8 = 1.0 * args.dim * args.rows
         gbs8 = bytes8 / (ms8 * 1e-3) / 1e9 if ms8 > 0 else 0.0
-        vec["i8"] = {"metric": "queries/sec (i8 dot top-100, batch 64)", "value": B * vsteps * 2 / dt8 * world, "ms_per_step": dt8 / (vsteps * 2) * 1e3,
+        ann8 = ann_leg(True) if args.rows >= 65536 else None
+        vec["i8"] = {"metric": "queries/sec (i8 dot top-100, batch 64)", "ann": ann8, "value": B * vsteps * 2 / dt8 * world, "ms_per_step": dt8 / (vsteps * 2) * 1e3,
                      "build_s": build8,
                      "roofline": {"bound": "hbm", "kernel": "vec8_scan_kernel (+refine, all row chunks of one pass)", "achieved": gbs8,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs8 / HBM_PEAK_GBS, "traffic": pmc_traffic("vector_i8"),
@@ -396,7 +427,7 @@ def main():
             line["vector"] = {"metric": "queries/sec (cosine top-100, 10M x 768 f32, batch 64)", "value": vec["qps"] * world,
                               "global_qps": vec["qps"], "ms_per_step": vec["ms_per_step"], "roofline": vec["roofline"],
                               "cpu_baseline": vec.get("cpu_baseline"), "latency_ms": vec["latency_ms"], "build_s": vec["build_s"],
-                              "rows_per_shard": args.rows, "dim": args.dim, "i8": vec.get("i8")}
+                              "rows_per_shard": args.rows, "dim": args.dim, "ann": vec.get("ann"), "i8": vec.get("i8")}
         elif vec is not None:
             line["i8"] = vec.get("i8")
         print(json.dumps(line), flush=True)

@@ -78,7 +78,8 @@ struct ss_shard {
   uint32_t* d_row_cluster = nullptr;    // [n_rows] shard-wide cluster index of each row
   uint32_t* d_cluster_first = nullptr;  // [vec_n_clusters] first row (= medoid record) of each cluster
   uint32_t* d_level_off = nullptr;      // [vec_n_levels + 1] cluster index range of each level
-  uint32_t vec_n_clusters = 0, vec_n_levels = 0;
+  void* d_medoids = nullptr;            // the medoid records, transposed: [k / 8][cluster][8] f32 or [k / 16][cluster][16] i8
+  uint32_t vec_n_clusters = 0, vec_n_levels = 0, vec_max_level_clusters = 0;
   float* d_ann_score = nullptr;         // [64][vec_n_clusters] medoid similarity per query
   float* d_ann_its = nullptr;           // [64][vec_n_clusters] TopK arrays of the per-level selection (scores)
   uint32_t* d_ann_itc = nullptr;        //                      (cluster ids)

@@ -9,10 +9,10 @@
 //                            summed in order, vector_similarity.rs:1118-1142; dot_f32 for dim % 8 != 0, 1006-1008; the
 //                            i8 dot is an exact integer) -- a cluster chosen on a last-bit difference would change the
 //                            result set, so this is bit-exact rather than "close";
-//   2. ann_select_kernel     one thread per (query, level) replays TopK::push over the level's clusters in file order
-//                            (ties keep the earlier cluster; the evicted entry is the first minimum) and sets bit c of the
-//                            query's selection row and of the batch's union row;
-//   3. ann_tiles_*_kernel    the ascending list of 128-row tiles that hold a row of a cluster in the union.
+//   2. ann_select_kernel     one wave per (query, level): the set TopK::push leaves behind over the level's clusters in file
+//                            order (by rank when no tie reaches the last slot, else by replaying the pushes); sets bit c
+//                            of the query's selection row and of the batch's union row;
+//   3. ann_tiles_*_kernel    the list of 128-row tiles that hold a row of a cluster in the union, evenly interleaved.
 //
 // The scan kernels (vec_scan.hip / vec8_scan.hip, ANN instantiation) then walk that tile list instead of the whole image
 // and admit a row only for the queries whose bit is set for the row's cluster.  One pass serves the whole batch: a
@@ -37,13 +37,34 @@ __device__ __forceinline__ uint32_t qf8_off(uint32_t q, uint32_t k) {
   return ((((k >> 7) * 4u + ((k >> 4) & 3u)) * 2u + (q >> 5)) * 64u + (q & 31u) + 32u * ((k >> 6) & 1u)) * 16u;
 }
 
+// The medoid records are copied once (ss_vec_set_clusters) into a matrix of their own, transposed so that the lanes of a
+// wave (= 64 consecutive clusters) read consecutive memory: Mt[k / 8][cluster][8 floats] (i8: Mt8[k / 16][cluster][16 B]).
+// Gathering them from the image, one 3 KB row per lane, measured 74 us for one query at 39 K clusters and 570 us for 64.
+__global__ void ann_gather_medoids_f32_kernel(const float* __restrict__ X, uint32_t dim_pad, const uint32_t* __restrict__ cluster_first,
+                                              uint32_t nc, float* __restrict__ Mt) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (step, cluster)
+  if (i >= (size_t)(dim_pad / 8u) * nc) return;
+  const uint32_t c = (uint32_t)(i % nc), step = (uint32_t)(i / nc);
+  const float4* src = (const float4*)(X + (size_t)cluster_first[c] * dim_pad + step * 8u);
+  float4* dst = (float4*)(Mt + i * 8u);
+  dst[0] = src[0];
+  dst[1] = src[1];
+}
+__global__ void ann_gather_medoids_i8_kernel(const int8_t* __restrict__ X8, uint32_t dim_pad8, const uint32_t* __restrict__ cluster_first,
+                                             uint32_t nc, int8_t* __restrict__ Mt8) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)(dim_pad8 / 16u) * nc) return;
+  const uint32_t c = (uint32_t)(i % nc), step = (uint32_t)(i / nc);
+  *(int4*)(Mt8 + i * 16u) = *(const int4*)(X8 + v8_index(cluster_first[c], step * 16u, dim_pad8 / 128u));
+}
+
 // thread = cluster, blockIdx.y = group of AQ queries
-__global__ void __launch_bounds__(64) ann_medoid_f32_kernel(const float* __restrict__ X, uint32_t dim, uint32_t dim_pad,
-                                                           const uint32_t* __restrict__ cluster_first, uint32_t nc,
+__global__ void __launch_bounds__(64) ann_medoid_f32_kernel(const float* __restrict__ Mt, uint32_t dim, uint32_t nc,
                                                            const float* __restrict__ Qf, uint32_t nq, float* __restrict__ score) {
   const uint32_t c = blockIdx.x * 64u + threadIdx.x;
   const uint32_t q0 = blockIdx.y * AQ;
-  const float* x = X + (size_t)cluster_first[c < nc ? c : nc - 1] * dim_pad;
+  const float* x = Mt + (size_t)(c < nc ? c : nc - 1) * 8u;  // element k at x[(k / 8) * nc * 8 + k % 8]
+  const size_t xs = (size_t)nc * 8u;
   float s[AQ];
   if ((dim & 7u) == 0) {  // dot_f32_avx2: lane j accumulates q[8 i + j] * e[8 i + j] with fmadd, then lanes 0..7 are summed
     float l[AQ][8];
@@ -51,8 +72,9 @@ __global__ void __launch_bounds__(64) ann_medoid_f32_kernel(const float* __restr
     for (int a = 0; a < AQ; a++)
 #pragma unroll
       for (int j = 0; j < 8; j++) l[a][j] = 0.f;
+#pragma unroll 4
     for (uint32_t k = 0; k < dim; k += 8) {
-      const float4 xa = *(const float4*)(x + k), xb = *(const float4*)(x + k + 4);
+      const float4 xa = *(const float4*)(x + (k >> 3) * xs), xb = *(const float4*)(x + (k >> 3) * xs + 4);
 #pragma unroll
       for (int a = 0; a < AQ; a++) {
         const float4 qa = *(const float4*)(Qf + qf_off(q0 + a, k)), qb = *(const float4*)(Qf + qf_off(q0 + a, k + 4));
@@ -73,7 +95,7 @@ __global__ void __launch_bounds__(64) ann_medoid_f32_kernel(const float* __restr
 #pragma unroll
     for (int a = 0; a < AQ; a++) s[a] = 0.f;
     for (uint32_t k = 0; k < dim; k++) {
-      const float xv = x[k];
+      const float xv = x[(k >> 3) * xs + (k & 7u)];
 #pragma unroll
       for (int a = 0; a < AQ; a++) s[a] = __fadd_rn(s[a], __fmul_rn(Qf[qf_off(q0 + a, k & ~3u) + (k & 3u)], xv));
     }
@@ -84,20 +106,21 @@ __global__ void __launch_bounds__(64) ann_medoid_f32_kernel(const float* __restr
       if (q0 + a < nq) score[(size_t)(q0 + a) * nc + c] = s[a];
 }
 
-__global__ void __launch_bounds__(64) ann_medoid_i8_kernel(const int8_t* __restrict__ X8, uint32_t dim_pad8,
+__global__ void __launch_bounds__(64) ann_medoid_i8_kernel(const int8_t* __restrict__ Mt8, uint32_t dim_pad8,
                                                           const uint32_t* __restrict__ cluster_first, uint32_t nc,
                                                           const int8_t* __restrict__ Qf8, uint32_t nq,
                                                           const float* __restrict__ row_scale, const float* __restrict__ q_scale,
                                                           int scaled, float* __restrict__ score) {
   const uint32_t c = blockIdx.x * 64u + threadIdx.x;
   const uint32_t q0 = blockIdx.y * AQ;
-  const uint32_t row = cluster_first[c < nc ? c : nc - 1];
-  const uint32_t L = dim_pad8 / 128u;
+  const uint32_t cc = c < nc ? c : nc - 1;
+  const uint32_t row = cluster_first[cc];
   int acc[AQ];
 #pragma unroll
   for (int a = 0; a < AQ; a++) acc[a] = 0;
+#pragma unroll 4
   for (uint32_t k = 0; k < dim_pad8; k += 16) {
-    const int4 xv = *(const int4*)(X8 + v8_index(row, k, L));
+    const int4 xv = *(const int4*)(Mt8 + ((size_t)(k >> 4) * nc + cc) * 16u);
     const int xw[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
     for (int a = 0; a < AQ; a++) {
@@ -121,12 +144,140 @@ __global__ void __launch_bounds__(64) ann_medoid_i8_kernel(const int8_t* __restr
   }
 }
 
-// One thread per (query, level): TopK::new(k = min(n_probe, clusters), threshold) and TopK::push (vector.rs:366-496) over
-// the level's medoid scores in cluster order.  Only the surviving SET matters downstream, but which entries survive a tie
-// depends on the order of the pushes and on which minimum is evicted, so the array is replayed as the reference keeps it.
-__global__ void ann_select_kernel(const float* __restrict__ score, const uint32_t* __restrict__ level_off, uint32_t n_levels,
-                                  uint32_t nc, uint32_t nq, uint32_t n_probe, float cthr, float* __restrict__ its,
-                                  uint32_t* __restrict__ itc, uint32_t* __restrict__ sel, uint32_t W, uint32_t* __restrict__ ncl) {
+// TopK::new(k = min(n_probe, clusters), threshold) and TopK::push (vector.rs:366-496) over a level's medoid scores in
+// cluster order; only the surviving SET matters downstream.  One WAVE per (query, level), the level's scores in LDS.
+//
+// Fast path: push-and-replace-the-minimum keeps the k best scores seen, whatever the order, as long as no two candidates
+// for the last slot are EQUAL -- a score equal to the current minimum is rejected (`score > minimum` admits), so only a
+// tie at the final boundary makes the result depend on the order of the pushes.  Each lane counts, for its clusters, the
+// level's scores strictly above its own (LDS broadcast reads): fewer than k above = among the k best.  Equal scores have
+// equal counts, so a tie group that straddles the boundary is selected as a whole and shows as MORE than k selected: only
+// then the wave falls back to the replay.
+// Replay: the reference's array, push by push (which of the tied entries survive depends on the order of the pushes and
+// on which minimum is evicted: the first one in array order).  The reference's pre-filter `score <=
+// lowest_similarity_score` (the value evicted last) never rejects what `score > current minimum` would admit, so the
+// replay tests against the current minimum directly.  Sequential over the pushes, parallel inside one: the first-minimum
+// search of an admission is a strided pass over the LDS array + a wave reduction.
+// (One THREAD per (query, level) replaying in global memory measured 1.15 ms at n_probe = 64 of 256 clusters x 153
+// levels, the wave replay alone 0.1-0.3 ms: more than the scans they prepare.)
+constexpr uint32_t ASEL_KMAX = 1024;  // n_probe the LDS replay holds; beyond it the slow kernel below
+constexpr uint32_t ASEL_CMAX = 4096;  // clusters per level the LDS score + rank arrays hold
+constexpr int ASEL_E = 4;             // clusters ranked per lane at a time
+__device__ __forceinline__ void wave_min_first(float& v, uint32_t& i) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o);
+    const uint32_t oi = __shfl_xor(i, o);
+    if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+}
+__global__ void __launch_bounds__(64) ann_select_kernel(const float* __restrict__ score, const uint32_t* __restrict__ level_off,
+                                                       uint32_t n_levels, uint32_t nc, uint32_t n_probe, float cthr,
+                                                       uint32_t* __restrict__ sel, uint32_t W, uint32_t* __restrict__ ncl,
+                                                       uint32_t cmax4) {
+  extern __shared__ __attribute__((aligned(16))) float ss[];  // the level's scores (-inf = below the cluster threshold) | ranks
+  __shared__ float vs[ASEL_KMAX];
+  __shared__ uint32_t vc[ASEL_KMAX];
+  const uint32_t q = blockIdx.x / n_levels, l = blockIdx.x % n_levels;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t c0 = level_off[l], C = level_off[l + 1] - c0;
+  const uint32_t k = (n_probe == 0 || n_probe > C) ? C : n_probe;
+  const float* sc = score + (size_t)q * nc + c0;
+  auto select = [&](uint32_t c) {
+    const uint32_t cg = c0 + c;
+    atomicOr(&sel[(size_t)q * W + (cg >> 5)], 1u << (cg & 31u));
+    atomicOr(&sel[(size_t)64 * W + (cg >> 5)], 1u << (cg & 31u));
+  };
+  if (k == C) {  // every cluster that passes the threshold
+    uint32_t n = 0;
+    for (uint32_t c = lane; c < C; c += 64)
+      if (!(sc[c] < cthr)) { select(c); n++; }
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    if (lane == 0 && n) atomicAdd(&ncl[q], n);
+    return;
+  }
+  const uint32_t C4 = (C + 3u) & ~3u;
+  uint32_t* above = (uint32_t*)(ss + cmax4);  // per cluster: number of eligible scores strictly above its own
+  for (uint32_t c = lane; c < C4; c += 64) {
+    const float v = c < C ? sc[c] : -INFINITY;
+    ss[c] = v < cthr ? -INFINITY : v;
+  }
+  __syncthreads();
+  // ---- fast path.  ASEL_E clusters per lane at a time against four scores per LDS read: the loop is a chain of LDS
+  // latencies otherwise (one cluster per lane, one score per read and a second counter for equal scores measured
+  // 120-550 us per launch)
+  uint32_t n_in = 0;
+  for (uint32_t cb = 0; cb < C; cb += 64 * ASEL_E) {
+    float s[ASEL_E];
+    uint32_t gt[ASEL_E];
+#pragma unroll
+    for (int e = 0; e < ASEL_E; e++) {
+      const uint32_t c = cb + e * 64 + lane;
+      s[e] = c < C ? ss[c] : -INFINITY;
+      gt[e] = 0;
+    }
+    for (uint32_t c2 = 0; c2 < C4; c2 += 4) {
+      const float4 v = *(const float4*)(ss + c2);
+#pragma unroll
+      for (int e = 0; e < ASEL_E; e++)
+        gt[e] += (v.x > s[e] ? 1u : 0u) + (v.y > s[e] ? 1u : 0u) + (v.z > s[e] ? 1u : 0u) + (v.w > s[e] ? 1u : 0u);
+    }
+#pragma unroll
+    for (int e = 0; e < ASEL_E; e++) {
+      const uint32_t c = cb + e * 64 + lane;
+      const bool in = s[e] != -INFINITY && gt[e] < k;
+      n_in += in ? 1u : 0u;
+      if (c < C) above[c] = in ? gt[e] : 0xFFFFFFFFu;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) n_in += __shfl_xor(n_in, o);
+  if (n_in <= k) {  // no tie across the boundary: the clusters with fewer than k scores above them ARE the k best
+    for (uint32_t c = lane; c < C; c += 64)  // own writes only: no barrier needed
+      if (above[c] < k) select(c);
+    if (lane == 0 && n_in) atomicAdd(&ncl[q], n_in);
+    return;
+  }
+  // ---- replay
+  uint32_t len = 0;
+  float cur_min = 0.f;
+  auto array_min = [&](float& mv, uint32_t& mi) {  // first minimum of vs[0 .. k)
+    mv = INFINITY; mi = 0xFFFFFFFFu;
+    for (uint32_t i = lane; i < k; i += 64) {
+      const float v = vs[i];
+      if (v < mv) { mv = v; mi = i; }
+    }
+    wave_min_first(mv, mi);
+  };
+  for (uint32_t c = 0; c < C; c++) {
+    const float s = ss[c];
+    if (s == -INFINITY) continue;
+    if (len < k) {
+      if (lane == 0) { vs[len] = s; vc[len] = c; }
+      len++;
+      if (len == k) {
+        __syncthreads();
+        uint32_t mi;
+        array_min(cur_min, mi);
+      }
+      continue;
+    }
+    if (!(s > cur_min)) continue;
+    float mv; uint32_t mi;
+    array_min(mv, mi);
+    __syncthreads();
+    if (lane == 0) { vs[mi] = s; vc[mi] = c; }
+    __syncthreads();
+    array_min(cur_min, mi);
+  }
+  __syncthreads();
+  for (uint32_t i = lane; i < len; i += 64) select(vc[i]);
+  if (lane == 0 && len) atomicAdd(&ncl[q], len);
+}
+
+// n_probe > ASEL_KMAX: one thread per (query, level), the array in global memory
+__global__ void ann_select_slow_kernel(const float* __restrict__ score, const uint32_t* __restrict__ level_off, uint32_t n_levels,
+                                       uint32_t nc, uint32_t nq, uint32_t n_probe, float cthr, float* __restrict__ its,
+                                       uint32_t* __restrict__ itc, uint32_t* __restrict__ sel, uint32_t W, uint32_t* __restrict__ ncl) {
   const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= nq * n_levels) return;
   const uint32_t q = idx / n_levels, l = idx % n_levels;
@@ -136,10 +287,9 @@ __global__ void ann_select_kernel(const float* __restrict__ score, const uint32_
   float* is = its + (size_t)q * nc + c0;
   uint32_t* ic = itc + (size_t)q * nc + c0;
   uint32_t len = 0;
-  float lowest = -FLT_MAX;
   for (uint32_t c = 0; c < C; c++) {
     const float s = sc[c];
-    if (s < cthr || (len == k && s <= lowest)) continue;
+    if (s < cthr) continue;
     if (len < k) { is[len] = s; ic[len] = c; len++; continue; }
     uint32_t min_i = 0;
     float min_v = is[0];
@@ -147,7 +297,7 @@ __global__ void ann_select_kernel(const float* __restrict__ score, const uint32_
       const float v = is[i];
       if (v < min_v) { min_v = v; min_i = i; }
     }
-    if (s > min_v) { lowest = min_v; is[min_i] = s; ic[min_i] = c; }
+    if (s > min_v) { is[min_i] = s; ic[min_i] = c; }
   }
   for (uint32_t i = 0; i < len; i++) {
     const uint32_t cg = c0 + ic[i];
@@ -158,8 +308,13 @@ __global__ void ann_select_kernel(const float* __restrict__ score, const uint32_
 }
 
 // Tile list of the batch: tile t is listed if a cluster in [cluster of its first row, cluster of its last row] is in the
-// union.  Two launches keep the list ascending (the chunk schedule and the totals then do not depend on timing):
-// flag + rank inside each group of 1024 tiles, then place at the group's base.
+// union.  Two launches: flag + rank inside each group of 1024 tiles, then place.  The list is NOT left ascending: a
+// query's clusters are contiguous runs of rows, so in file order its candidates would arrive in bursts -- a query with
+// nothing in the first launches keeps tau = -inf and then floods its candidate buffer (measured: a batch of 64 with a
+// quarter of the clusters each overflowed every time).  Position j holds the ascending list's entry (j * s) mod n, s ~
+// 0.618 n coprime to n: every prefix of the list is spread evenly over the image (three-distance theorem), so each
+// query meets its rows at its average rate and the chunk schedule's bound (vec_scan.hip) holds as in AnnMode::All.
+// The permutation is a pure function of n: results and totals do not depend on timing.
 constexpr int AT = 1024;
 __global__ void __launch_bounds__(AT) ann_tiles_flag_kernel(const uint32_t* __restrict__ row_cluster, unsigned long long n_rows,
                                                            uint32_t T, const uint32_t* __restrict__ sel_union,
@@ -192,31 +347,49 @@ __global__ void __launch_bounds__(AT) ann_tiles_flag_kernel(const uint32_t* __re
 }
 __global__ void __launch_bounds__(AT) ann_tiles_place_kernel(const uint32_t* __restrict__ rank, const uint32_t* __restrict__ group_count,
                                                             uint32_t T, uint32_t* __restrict__ tiles) {
-  __shared__ uint32_t sbase;
+  __shared__ uint32_t sbase, sn, sinv;
   if (threadIdx.x < 64) {
-    uint32_t v = 0;
-    for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 64) v += group_count[i];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-    if (threadIdx.x == 0) sbase = v;
+    uint32_t v = 0, all = 0;
+    for (uint32_t i = threadIdx.x; i < gridDim.x; i += 64) {
+      const uint32_t g = group_count[i];
+      all += g;
+      if (i < blockIdx.x) v += g;
+    }
+    for (int o = 32; o > 0; o >>= 1) { v += __shfl_down(v, o); all += __shfl_down(all, o); }
+    if (threadIdx.x == 0) {
+      sbase = v;
+      sn = all;
+      uint32_t inv = 1;
+      if (all > 2) {
+        uint32_t s = (uint32_t)((double)all * 0.6180339887498949);
+        auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; };
+        while (s < 2 || gcd(s, all) != 1) s++;  // all - 1 is coprime to all: terminates below all
+        // inverse of s modulo all (extended Euclid): rank R sits at position R * inv mod all, i.e. position j holds rank j * s mod all
+        long long r0 = all, r1 = s, t0 = 0, t1 = 1;
+        while (r1) { const long long qq = r0 / r1, r2 = r0 - qq * r1, t2 = t0 - qq * t1; r0 = r1; r1 = r2; t0 = t1; t1 = t2; }
+        inv = (uint32_t)(t0 < 0 ? t0 + all : t0);
+      }
+      sinv = inv;
+    }
   }
   __syncthreads();
   const uint32_t t = blockIdx.x * AT + threadIdx.x;
   if (t < T) {
     const uint32_t r = rank[t];
-    if (r != 0xFFFFFFFFu) tiles[sbase + r] = t;
+    if (r != 0xFFFFFFFFu) tiles[(uint32_t)(((unsigned long long)(sbase + r) * sinv) % sn)] = t;
   }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) tiles[T] = sbase + group_count[blockIdx.x];
+  if (blockIdx.x == 0 && threadIdx.x == 0) tiles[T] = sn;
 }
 
 // ---------------------------------------------------------------- host side
 void ssi_vec_free_clusters(ss_shard* s) {
   void* ptrs[] = {s->d_row_cluster, s->d_cluster_first, s->d_level_off, s->d_ann_score, s->d_ann_its,
-                  s->d_ann_itc,     s->d_ann_sel,       s->d_ann_tiles, s->d_ann_ncl};
+                  s->d_ann_itc,     s->d_ann_sel,       s->d_ann_tiles, s->d_ann_ncl,   s->d_medoids};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   s->d_row_cluster = nullptr; s->d_cluster_first = nullptr; s->d_level_off = nullptr; s->d_ann_score = nullptr;
-  s->d_ann_its = nullptr; s->d_ann_itc = nullptr; s->d_ann_sel = nullptr; s->d_ann_tiles = nullptr; s->d_ann_ncl = nullptr;
-  s->vec_n_clusters = 0; s->vec_n_levels = 0;
+  s->d_ann_its = nullptr; s->d_ann_itc = nullptr; s->d_ann_sel = nullptr; s->d_ann_tiles = nullptr; s->d_ann_ncl = nullptr; s->d_medoids = nullptr;
+  s->vec_n_clusters = 0; s->vec_n_levels = 0; s->vec_max_level_clusters = 0;
 }
 
 // caller holds the shard lock and has selected the device
@@ -258,8 +431,19 @@ int ssi_vec_set_clusters(ss_shard* s, uint32_t n_levels, const uint32_t* level_c
   SS_HIP(hipMemcpy(s->d_row_cluster, row_cluster.data(), s->n_rows * sizeof(uint32_t), hipMemcpyHostToDevice));
   SS_HIP(hipMemcpy(s->d_cluster_first, first.data(), nc * sizeof(uint32_t), hipMemcpyHostToDevice));
   SS_HIP(hipMemcpy(s->d_level_off, level_off.data(), (n_levels + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+  {  // the medoid records, transposed (ann_gather_medoids_*_kernel)
+    const size_t steps = s->d_X8 ? s->dim_pad8 / 16u : s->dim_pad / 8u;
+    const size_t bytes = steps * nc * (s->d_X8 ? 16u : 32u);
+    SS_HIP(hipMalloc(&s->d_medoids, bytes));
+    const unsigned grid = (unsigned)((steps * nc + 255) / 256);
+    if (s->d_X8) ann_gather_medoids_i8_kernel<<<grid, 256, 0, s->stream>>>(s->d_X8, s->dim_pad8, s->d_cluster_first, (uint32_t)nc, (int8_t*)s->d_medoids);
+    else ann_gather_medoids_f32_kernel<<<grid, 256, 0, s->stream>>>(s->d_X, s->dim_pad, s->d_cluster_first, (uint32_t)nc, (float*)s->d_medoids);
+    SS_HIP(hipGetLastError());
+    SS_HIP(hipStreamSynchronize(s->stream));
+  }
   s->vec_n_clusters = (uint32_t)nc;
   s->vec_n_levels = n_levels;
+  s->vec_max_level_clusters = *std::max_element(level_clusters, level_clusters + n_levels);
   return SS_OK;
 }
 
@@ -275,15 +459,23 @@ int ssi_vec_ann_prepare(ss_shard* s, uint32_t nb, const float* d_qscale, const s
   const dim3 grid((nc + 63) / 64, (nb + AQ - 1) / AQ);
   if (s->d_X8) {
     const bool scaled = s->d_row_scale != nullptr || d_qscale != nullptr;
-    ann_medoid_i8_kernel<<<grid, 64, 0, st>>>(s->d_X8, s->dim_pad8, s->d_cluster_first, nc, (const int8_t*)s->d_Qf, nb,
-                                               s->d_row_scale, d_qscale, scaled ? 1 : 0, s->d_ann_score);
+    ann_medoid_i8_kernel<<<grid, 64, 0, st>>>((const int8_t*)s->d_medoids, s->dim_pad8, s->d_cluster_first, nc,
+                                               (const int8_t*)s->d_Qf, nb, s->d_row_scale, d_qscale, scaled ? 1 : 0, s->d_ann_score);
   } else {
-    ann_medoid_f32_kernel<<<grid, 64, 0, st>>>(s->d_X, s->dim, s->dim_pad, s->d_cluster_first, nc, s->d_Qf, nb, s->d_ann_score);
+    ann_medoid_f32_kernel<<<grid, 64, 0, st>>>((const float*)s->d_medoids, s->dim, nc, s->d_Qf, nb, s->d_ann_score);
   }
   const uint32_t nsel = nb * s->vec_n_levels;
-  ann_select_kernel<<<(nsel + 63) / 64, 64, 0, st>>>(s->d_ann_score, s->d_level_off, s->vec_n_levels, nc, nb, mode->n_probe,
-                                                     mode->cluster_threshold_raw, s->d_ann_its, s->d_ann_itc, s->d_ann_sel, W,
-                                                     s->d_ann_ncl);
+  if (mode->n_probe <= ASEL_KMAX && s->vec_max_level_clusters <= ASEL_CMAX)
+  {
+    const uint32_t cmax4 = (s->vec_max_level_clusters + 3u) & ~3u;
+    ann_select_kernel<<<nsel, 64, (size_t)cmax4 * 2 * sizeof(float), st>>>(
+        s->d_ann_score, s->d_level_off, s->vec_n_levels, nc, mode->n_probe, mode->cluster_threshold_raw, s->d_ann_sel, W,
+        s->d_ann_ncl, cmax4);
+  }
+  else
+    ann_select_slow_kernel<<<(nsel + 63) / 64, 64, 0, st>>>(s->d_ann_score, s->d_level_off, s->vec_n_levels, nc, nb,
+                                                            mode->n_probe, mode->cluster_threshold_raw, s->d_ann_its,
+                                                            s->d_ann_itc, s->d_ann_sel, W, s->d_ann_ncl);
   ann_tiles_flag_kernel<<<groups, AT, 0, st>>>(s->d_row_cluster, (unsigned long long)s->n_rows, T,
                                                s->d_ann_sel + (size_t)SS_VEC_BATCH * W, rank, gcount);
   ann_tiles_place_kernel<<<groups, AT, 0, st>>>(rank, gcount, T, tiles);

@@ -51,10 +51,10 @@ __device__ __forceinline__ void vs_append(const float (&f)[16], float tau, uint3
 
 // ---------------------------------------------------------------- ANN modes (vec_ann.hip)
 // What a scan launch needs to visit only the clusters some query of the batch selected (AnnMode::Nprobe /
-// Similaritythreshold, vector.rs:1300-1392): the ascending list of 128-row tiles that hold a selected cluster, the
+// Similaritythreshold, vector.rs:1300-1392): the list of 128-row tiles that hold a selected cluster, the
 // cluster of every row and one bit per (query, cluster).  A row is a candidate of query q only if q selected its cluster.
 struct VAnn {
-  const uint32_t* tiles;        // [n_tiles] tile ids, ascending
+  const uint32_t* tiles;        // [n_tiles] tile ids, each once, interleaved (vec_ann.hip)
   const uint32_t* n_tiles;      // device scalar
   const uint32_t* row_cluster;  // [n_rows] shard-wide cluster index
   const uint32_t* sel;          // [64][sel_words] bit c of row q: query q visits cluster c

@@ -249,3 +249,32 @@ def test_ann_abi_validation(S, O):
     sh.upload_vectors_i8(rows[:500])           # a new image drops the old cluster structure
     assert sh.cluster_info() == (0, 0)
     sh.close()
+
+
+def test_ann_tied_medoids_follow_the_reference_replay(S, O):
+    """equal medoid scores at the last TopK slot: which of the tied clusters is visited depends on the order of the pushes
+    and on the evicted minimum (vector.rs:410-496) -- the device must visit the oracle's clusters, not just k good ones"""
+    lc = [7, 6]
+    rows32, child = clustered(O, 71, lc, 64, lo=60, hi=200)
+    first = np.concatenate([[0], np.cumsum(child.astype(np.int64))[:-1]])
+    # level 0: clusters 0, 2, 3, 5 share one medoid record; level 1: clusters 8, 9 and 11, 12 pairwise
+    for a, b in ((0, 2), (0, 3), (0, 5), (8, 9), (11, 12)):
+        rows32[first[b]] = rows32[first[a]]
+    rows = O.quantize_i8(rows32)
+    qs = O.quantize_i8(queries_near(O, rows32, 72, 64, noise=1.5))
+    sh = S.Shard(0)
+    sh.upload_vectors_i8(rows)
+    sh.set_clusters(lc, child)
+    med = rows[first].astype(np.int32) @ qs.astype(np.int32).T  # [cluster][query]
+    straddles = 0
+    k = 15
+    for n_probe in (1, 2, 3, 5):
+        doc, score, cnt, tot, ncl = sh.search_vector_batch_i8(qs, k, ann_mode=S.AnnMode.Nprobe(n_probe), with_clusters=True)
+        for i in range(64):
+            m0 = np.sort(med[:7, i])[::-1]
+            straddles += int(m0[n_probe - 1] == m0[n_probe])
+            od, os_, _, _, oncl = O.vec_search_i8_ann(rows, qs[i], k, lc, child, n_probe=n_probe)
+            assert ncl[i] == oncl and cnt[i] == len(od)
+            assert np.array_equal(score[i][:cnt[i]], os_)
+    assert straddles > 20  # the tie really sits on the boundary for many (query, n_probe) pairs
+    sh.close()
