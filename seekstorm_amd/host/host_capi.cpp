@@ -81,6 +81,25 @@ int ssh_search_lexical_shard(ssh_index* ix, int shard, const uint32_t* terms, ui
   return write_out(ro, cap, out_doc, out_score, nullptr, nullptr, nullptr, out_meta);
 }
 
+// Shard::search_vector_shard with an AnnMode: kind 0 All, 1 Similaritythreshold(t), 2 Nprobe(n), 3 NprobeSimilaritythreshold(n, t);
+// out_meta[4] = count, total, observed vectors, last_error; *out_clusters = observed_cluster_count
+int ssh_set_clusters(ssh_index* ix, int shard, uint32_t n_levels, const uint32_t* level_clusters, uint32_t n_clusters,
+                     const uint32_t* child_count) {
+  return ix->shards[shard]->set_clusters(std::vector<uint32_t>(level_clusters, level_clusters + n_levels),
+                                         std::vector<uint32_t>(child_count, child_count + n_clusters));
+}
+int ssh_search_vector_shard_ann(ssh_index* ix, int shard, const float* query_vector, uint32_t length, int kind, uint32_t n_probe,
+                                float threshold, uint32_t cap, uint64_t* out_doc, float* out_score, uint64_t* out_meta,
+                                uint64_t* out_clusters) {
+  AnnMode am;
+  if (kind == 1) am = AnnMode::Similaritythreshold(threshold);
+  else if (kind == 2) am = AnnMode::Nprobe(n_probe);
+  else if (kind == 3) am = AnnMode::NprobeSimilaritythreshold(n_probe, threshold);
+  ResultObject ro = ix->shards[shard]->search_vector_shard(query_vector, length, nullptr, am);
+  if (out_clusters) *out_clusters = ro.observed_cluster_count;
+  return write_out(ro, cap, out_doc, out_score, nullptr, nullptr, nullptr, out_meta);
+}
+
 // n concurrent single-query vector searches through a VectorBatchCoalescer (one submitting thread per query);
 // out arrays are [n][length]; returns the number of device batches used
 int ssh_coalesced_vector_search(ssh_index* ix, int shard, uint32_t n, const float* queries, uint32_t length,

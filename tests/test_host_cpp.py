@@ -51,6 +51,9 @@ def H():
     L.ssh_quantize_f32_to_i8.argtypes = [f32p, C.c_uint64, C.c_void_p]
     L.ssh_coalesced_lexical_search.argtypes = [C.c_void_p, C.c_int, C.c_uint32, u32p, u32p, u32p, u32p, C.c_uint32, C.c_uint32,
                                                C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u64p, f32p, u32p, u64p]
+    L.ssh_set_clusters.argtypes = [C.c_void_p, C.c_int, C.c_uint32, u32p, C.c_uint32, u32p]
+    L.ssh_search_vector_shard_ann.argtypes = [C.c_void_p, C.c_int, f32p, C.c_uint32, C.c_int, C.c_uint32, C.c_float, C.c_uint32,
+                                              u64p, f32p, u64p, u64p]
     return L
 
 
@@ -237,5 +240,49 @@ def test_cpp_index_vector_search_on_i8_image(H):
         od, os_, _, _ = O.vec_search_i8(rows, O.quantize_i8(O.normalize(qv)), k)
         assert len(d) == k and np.array_equal(s, os_) and int(d[0]) == int(od[0])
         assert np.allclose(vsc, (s / np.float32(16129.0) + 1) / 2, rtol=1e-6)
+    finally:
+        H.ssh_index_destroy(ix)
+
+
+@pytest.mark.gpu
+def test_cpp_shard_ann_modes(H):
+    """Shard::search_vector_shard with the reference's AnnMode values (vector.rs:1300-1307) over an i8 image: the C++ mirror
+    converts the normalised cluster threshold like TopK::new and reports observed_cluster_count"""
+    from oracle import oracle as O
+    from seekstorm_amd.search import threshold_raw
+    rng = np.random.default_rng(5)
+    dim, lc = 64, [6, 5]
+    child = rng.integers(50, 300, 11).astype(np.uint32)
+    rows32 = O.vec_gen(41, 0, int(child.sum()), dim)
+    rows = O.quantize_i8(rows32)
+    qv = rows32[17] + 0.05 * O.vec_gen(42, 0, 1, dim)[0]
+    qv = (qv / np.linalg.norm(qv)).astype(np.float32)
+    q8 = O.quantize_i8(qv)
+    first = np.concatenate([[0], np.cumsum(child.astype(np.int64))[:-1]])
+    med = rows[first].astype(np.int32) @ q8.astype(np.int32)
+    t_norm = float((np.float32(np.sort(med)[-4]) / np.float32(16129.0) + np.float32(1.0)) / np.float32(2.0))
+    ix = H.ssh_index_create(1, None)
+    try:
+        assert H.ssh_upload_vectors_i8(ix, 0, len(rows), dim, rows.ctypes.data, None) == 0
+        lcn, ccn = np.asarray(lc, np.uint32), child
+        assert H.ssh_set_clusters(ix, 0, len(lcn), P(lcn, u32p), len(ccn), P(ccn, u32p)) == 0
+        k = 12
+        for kind, n, t, kw in ((2, 2, 0.0, dict(n_probe=2)), (1, 0, t_norm, dict(cluster_threshold_raw=threshold_raw(t_norm))),
+                               (3, 1, t_norm, dict(n_probe=1, cluster_threshold_raw=threshold_raw(t_norm))), (0, 0, 0.0, None)):
+            doc = np.zeros(k, np.uint64); sc = np.zeros(k, np.float32); meta = np.zeros(4, np.uint64); ncl = C.c_uint64()
+            nres = H.ssh_search_vector_shard_ann(ix, 0, P(qv, f32p), k, kind, n, t, k, P(doc, u64p), P(sc, f32p), P(meta, u64p),
+                                                 C.byref(ncl))
+            assert int(meta[3]) == 0
+            if kw is None:
+                od, os_, _, _ = O.vec_search_i8(rows, q8, k)
+                assert ncl.value == 11
+            else:
+                od, os_, _, _, oncl = O.vec_search_i8_ann(rows, q8, k, lc, child, **kw)
+                assert ncl.value == oncl
+            assert nres == len(od) and np.array_equal(sc[:nres], os_)
+        # Nprobe(0) has no TopK slot to push into: refused, the mirror degrades to an empty result with the code kept
+        meta = np.zeros(4, np.uint64)
+        assert H.ssh_search_vector_shard_ann(ix, 0, P(qv, f32p), k, 2, 0, 0.0, k, P(doc, u64p), P(sc, f32p), P(meta, u64p), None) == 0
+        assert int(meta[3]) != 0
     finally:
         H.ssh_index_destroy(ix)
