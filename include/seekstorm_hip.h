@@ -240,7 +240,13 @@ int ss_vec_search_i8_dev(ss_shard* s, uint32_t n_queries, const int8_t* d_querie
 typedef struct ss_ann_mode {
   uint32_t n_probe;              /* clusters visited per level; 0 = no limit (AnnMode::Similaritythreshold) */
   float cluster_threshold_raw;   /* clusters whose medoid scores below it are skipped; -FLT_MAX = none (AnnMode::Nprobe) */
+  uint64_t field_mask;           /* field_filter of search_vector_shard (vector.rs:1225-1237, 1397-1400): bit f set = records
+                                  * of indexed field f are searched, the others are skipped before they are scored; 0 = every
+                                  * field.  Needs the records' field ids (vector.bin upload, or ss_vec_set_fields); fields
+                                  * >= 64 cannot be selected.  n_probe = 0 and no cluster threshold = AnnMode::All + filter. */
 } ss_ann_mode;
+/* VectorHeader.field_id of every record, for rows uploaded with ss_vec_upload[_i8] / ss_vec_synth[_i8] */
+int ss_vec_set_fields(ss_shard* s, uint64_t n_rows, const uint16_t* row_field);
 int ss_vec_set_clusters(ss_shard* s, uint32_t n_levels, const uint32_t* level_clusters, const uint32_t* child_count);
 int ss_vec_cluster_info(ss_shard* s, uint32_t* n_levels, uint32_t* n_clusters);
 int ss_vec_search_ann(ss_shard* s, uint32_t n_queries, const float* queries, uint32_t k, float threshold_raw,

@@ -301,14 +301,28 @@ NO_THRESHOLD = -3.4028234663852886e38
 
 
 def _ann_args(n_rows, level_clusters, child_count):
+    if level_clusters is None:  # AnnMode::All
+        return np.zeros(0, np.uint32), np.zeros(0, np.uint32)
     lc = np.ascontiguousarray(level_clusters, np.uint32)
     cc = np.ascontiguousarray(child_count, np.uint32)
     assert int(lc.sum()) == len(cc) and int(cc.sum()) == n_rows and np.all(cc > 0)
     return lc, cc
 
 
+def _field_args(row_field, fields):
+    if row_field is None or not fields:
+        return None, 0
+    mask = 0
+    for f in fields:
+        mask |= 1 << int(f)
+    return np.ascontiguousarray(row_field, np.uint16), mask
+
+
+u16p = C.POINTER(C.c_uint16)
+
+
 def vec_search_ann(rows, query, k, level_clusters, child_count, n_probe=0xFFFFFFFF, cluster_threshold_raw=NO_THRESHOLD,
-                   row_doc_ids=None, threshold_raw=NO_THRESHOLD, simd_order=True, deleted=None):
+                   row_doc_ids=None, threshold_raw=NO_THRESHOLD, simd_order=True, deleted=None, row_field=None, fields=()):
     """AnnMode::Nprobe / Similaritythreshold / both (vector.rs:1300-1392) -> (docs, scores, total, observed rows, clusters)"""
     rows = np.ascontiguousarray(rows, np.float32)
     query = np.ascontiguousarray(query, np.float32)
@@ -321,15 +335,19 @@ def vec_search_ann(rows, query, k, level_clusters, child_count, n_probe=0xFFFFFF
     f = lib().so_vec_search_ann
     f.restype = C.c_uint32
     f.argtypes = [f32p, C.c_uint64, C.c_uint32, u32p, f32p, C.c_uint32, C.c_float, C.c_int, C.c_uint32, u32p, u32p, C.c_uint32,
-                  C.c_float, u64p, C.c_uint64, u32p, f32p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+                  C.c_float, u64p, C.c_uint64, u16p, C.c_uint64, u32p, f32p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                  C.POINTER(C.c_uint64)]
+    rf, fm = _field_args(row_field, fields)
     n = f(_p(rows, f32p), rows.shape[0], rows.shape[1], _p(rd, u32p), _p(query, f32p), k, threshold_raw, 1 if simd_order else 0,
-          len(lc), _p(lc, u32p), _p(cc, u32p), n_probe, cluster_threshold_raw, _p(dl, u64p) if len(dl) else None, len(dl),
-          _p(od, u32p), _p(os_, f32p), C.byref(tot), C.byref(obs), C.byref(ncl))
+          len(lc), _p(lc, u32p) if len(lc) else None, _p(cc, u32p) if len(cc) else None, n_probe, cluster_threshold_raw,
+          _p(dl, u64p) if len(dl) else None, len(dl), _p(rf, u16p), fm, _p(od, u32p), _p(os_, f32p), C.byref(tot), C.byref(obs),
+          C.byref(ncl))
     return od[:n].copy(), os_[:n].copy(), tot.value, obs.value, ncl.value
 
 
 def vec_search_i8_ann(rows_i8, query_i8, k, level_clusters, child_count, n_probe=0xFFFFFFFF, cluster_threshold_raw=NO_THRESHOLD,
-                      row_doc_ids=None, row_scale=None, query_scale=None, threshold_raw=NO_THRESHOLD, deleted=None):
+                      row_doc_ids=None, row_scale=None, query_scale=None, threshold_raw=NO_THRESHOLD, deleted=None,
+                      row_field=None, fields=()):
     rows = np.ascontiguousarray(rows_i8, np.int8)
     q = np.ascontiguousarray(query_i8, np.int8)
     lc, cc = _ann_args(rows.shape[0], level_clusters, child_count)
@@ -343,12 +361,13 @@ def vec_search_i8_ann(rows_i8, query_i8, k, level_clusters, child_count, n_probe
     f = lib().so_vec_search_i8_ann
     f.restype = C.c_uint32
     f.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, u32p, f32p, C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_float,
-                  C.c_uint32, u32p, u32p, C.c_uint32, C.c_float, u64p, C.c_uint64, u32p, f32p, C.POINTER(C.c_uint64),
-                  C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+                  C.c_uint32, u32p, u32p, C.c_uint32, C.c_float, u64p, C.c_uint64, u16p, C.c_uint64, u32p, f32p,
+                  C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    rf, fm = _field_args(row_field, fields)
     n = f(rows.ctypes.data, rows.shape[0], rows.shape[1], _p(rd, u32p), _p(rs, f32p), q.ctypes.data, 1 if scaled else 0,
-          1.0 if query_scale is None else float(query_scale), k, threshold_raw, len(lc), _p(lc, u32p), _p(cc, u32p), n_probe,
-          cluster_threshold_raw, _p(dl, u64p) if len(dl) else None, len(dl), _p(od, u32p), _p(os_, f32p), C.byref(tot),
-          C.byref(obs), C.byref(ncl))
+          1.0 if query_scale is None else float(query_scale), k, threshold_raw, len(lc), _p(lc, u32p) if len(lc) else None,
+          _p(cc, u32p) if len(cc) else None, n_probe, cluster_threshold_raw, _p(dl, u64p) if len(dl) else None, len(dl),
+          _p(rf, u16p), fm, _p(od, u32p), _p(os_, f32p), C.byref(tot), C.byref(obs), C.byref(ncl))
     return od[:n].copy(), os_[:n].copy(), tot.value, obs.value, ncl.value
 
 

@@ -743,6 +743,30 @@ static uint64_t ann_order(uint32_t n_levels, const uint32_t* level_clusters, con
   return n;
 }
 
+/* rows visited by search_vector_shard, in order: every cluster (AnnMode::All, n_levels = 0: rows 0..n-1) or ann_order's;
+ * with a field filter only the records of the listed indexed fields (vector.rs:1397-1400: the others are skipped before
+ * they are scored -- neither observed nor pushed; medoids are scored whatever their field) */
+static uint64_t visit_order(uint64_t n_rows, uint32_t n_levels, const uint32_t* level_clusters, const uint32_t* child_count,
+                            uint32_t n_probe, float cluster_thr, so_score_fn fn, const void* ctx, const uint16_t* row_field,
+                            uint64_t field_mask, uint64_t* order, uint64_t* n_clusters_visited) {
+  uint64_t n;
+  if (n_levels == 0) {
+    for (n = 0; n < n_rows; n++) order[n] = n;
+    if (n_clusters_visited) *n_clusters_visited = 0;
+  } else {
+    n = ann_order(n_levels, level_clusters, child_count, n_probe, cluster_thr, fn, ctx, order, n_clusters_visited);
+  }
+  if (row_field && field_mask) {
+    uint64_t w = 0;
+    for (uint64_t i = 0; i < n; i++) {
+      const uint16_t f = row_field[order[i]];
+      if (f < 64 && ((field_mask >> f) & 1ull)) order[w++] = order[i];
+    }
+    n = w;
+  }
+  return n;
+}
+
 typedef struct { const float* rows; const float* q; uint32_t dim; int simd; } so_f32_ctx;
 static float score_f32(const void* c, uint64_t r) {
   const so_f32_ctx* x = (const so_f32_ctx*)c;
@@ -787,11 +811,12 @@ uint32_t so_vec_search_i8(const int8_t* rows, uint64_t n_rows, uint32_t dim, con
 uint32_t so_vec_search_ann(const float* rows, uint64_t n_rows, uint32_t dim, const uint32_t* row_doc, const float* q,
                            uint32_t k, float thr, int simd_order, uint32_t n_levels, const uint32_t* level_clusters,
                            const uint32_t* child_count, uint32_t n_probe, float cluster_thr, const uint64_t* deleted_sorted,
-                           uint64_t n_deleted, uint32_t* od, float* os, uint64_t* out_total, uint64_t* out_observed,
-                           uint64_t* out_clusters) {
+                           uint64_t n_deleted, const uint16_t* row_field, uint64_t field_mask, uint32_t* od, float* os,
+                           uint64_t* out_total, uint64_t* out_observed, uint64_t* out_clusters) {
   so_f32_ctx c = {rows, q, dim, simd_order};
   uint64_t* order = (uint64_t*)malloc((n_rows ? n_rows : 1) * sizeof(uint64_t));
-  uint64_t n = ann_order(n_levels, level_clusters, child_count, n_probe, cluster_thr, score_f32, &c, order, out_clusters);
+  uint64_t n = visit_order(n_rows, n_levels, level_clusters, child_count, n_probe, cluster_thr, score_f32, &c, row_field,
+                           field_mask, order, out_clusters);
   uint32_t r = topk_scan_order(n, order, row_doc, k, thr, deleted_sorted, n_deleted, score_f32, &c, od, os, out_total, out_observed);
   free(order);
   return r;
@@ -799,11 +824,13 @@ uint32_t so_vec_search_ann(const float* rows, uint64_t n_rows, uint32_t dim, con
 uint32_t so_vec_search_i8_ann(const int8_t* rows, uint64_t n_rows, uint32_t dim, const uint32_t* row_doc, const float* row_scale,
                               const int8_t* q, int scaled, float q_scale, uint32_t k, float thr, uint32_t n_levels,
                               const uint32_t* level_clusters, const uint32_t* child_count, uint32_t n_probe, float cluster_thr,
-                              const uint64_t* deleted_sorted, uint64_t n_deleted, uint32_t* od, float* os, uint64_t* out_total,
-                              uint64_t* out_observed, uint64_t* out_clusters) {
+                              const uint64_t* deleted_sorted, uint64_t n_deleted, const uint16_t* row_field,
+                              uint64_t field_mask, uint32_t* od, float* os, uint64_t* out_total, uint64_t* out_observed,
+                              uint64_t* out_clusters) {
   so_i8_ctx c = {rows, q, dim, row_scale, scaled, q_scale};
   uint64_t* order = (uint64_t*)malloc((n_rows ? n_rows : 1) * sizeof(uint64_t));
-  uint64_t n = ann_order(n_levels, level_clusters, child_count, n_probe, cluster_thr, score_i8, &c, order, out_clusters);
+  uint64_t n = visit_order(n_rows, n_levels, level_clusters, child_count, n_probe, cluster_thr, score_i8, &c, row_field,
+                           field_mask, order, out_clusters);
   uint32_t r = topk_scan_order(n, order, row_doc, k, thr, deleted_sorted, n_deleted, score_i8, &c, od, os, out_total, out_observed);
   free(order);
   return r;

@@ -127,18 +127,20 @@ uint32_t so_vec_search_i8(const int8_t* rows, uint64_t n_rows, uint32_t dim, con
  * level, cluster after cluster (level_clusters[n_levels] cluster counts, child_count[sum] records per cluster); per level the
  * medoid (first record) of every cluster is pushed into TopK::new(min(n_probe, clusters), cluster_thr) and the records of the
  * surviving clusters are visited in medoid-score order.  n_probe = UINT32_MAX and cluster_thr = -FLT_MAX give the two
- * single-criterion modes.  *out_clusters = observed_cluster_count. */
+ * single-criterion modes.  *out_clusters = observed_cluster_count.  n_levels = 0: AnnMode::All.
+ * row_field / field_mask (bit f = indexed field f is searched; NULL / 0 = no filter): field_filter, vector.rs:1397-1400. */
 uint32_t so_vec_search_ann(const float* rows, uint64_t n_rows, uint32_t dim, const uint32_t* row_doc_ids, const float* query,
                            uint32_t k, float threshold_raw, int simd_order, uint32_t n_levels, const uint32_t* level_clusters,
                            const uint32_t* child_count, uint32_t n_probe, float cluster_threshold_raw,
-                           const uint64_t* deleted_sorted, uint64_t n_deleted, uint32_t* out_doc, float* out_score,
-                           uint64_t* out_total, uint64_t* out_observed, uint64_t* out_clusters);
+                           const uint64_t* deleted_sorted, uint64_t n_deleted, const uint16_t* row_field, uint64_t field_mask,
+                           uint32_t* out_doc, float* out_score, uint64_t* out_total, uint64_t* out_observed,
+                           uint64_t* out_clusters);
 uint32_t so_vec_search_i8_ann(const int8_t* rows, uint64_t n_rows, uint32_t dim, const uint32_t* row_doc_ids,
                               const float* row_scale, const int8_t* query, int scaled, float query_scale, uint32_t k,
                               float threshold_raw, uint32_t n_levels, const uint32_t* level_clusters, const uint32_t* child_count,
                               uint32_t n_probe, float cluster_threshold_raw, const uint64_t* deleted_sorted, uint64_t n_deleted,
-                              uint32_t* out_doc, float* out_score, uint64_t* out_total, uint64_t* out_observed,
-                              uint64_t* out_clusters);
+                              const uint16_t* row_field, uint64_t field_mask, uint32_t* out_doc, float* out_score,
+                              uint64_t* out_total, uint64_t* out_observed, uint64_t* out_clusters);
 /* vector_score field: vector.rs:1495-1499 */
 float so_vector_score_field(float dot);
 /* TopK threshold transform: vector.rs:388-397 */

@@ -39,7 +39,7 @@ class RefBlock(C.Structure):  # ss_ref_block
 
 
 class AnnModeC(C.Structure):  # ss_ann_mode
-    _fields_ = [("n_probe", C.c_uint32), ("cluster_threshold_raw", C.c_float)]
+    _fields_ = [("n_probe", C.c_uint32), ("cluster_threshold_raw", C.c_float), ("field_mask", C.c_uint64)]
 
 
 BM25_QUERY_DTYPE = np.dtype([("n_terms", np.uint32), ("op", np.uint32), ("term", np.uint32, (SS_MAX_QUERY_TERMS,)),
@@ -94,6 +94,7 @@ SYMBOLS = [
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("ss_vec_set_clusters", C.c_int, [C.c_void_p, C.c_uint32, u32p, u32p]),
     ("ss_vec_cluster_info", C.c_int, [C.c_void_p, u32p, u32p]),
+    ("ss_vec_set_fields", C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     ("ss_vec_search_ann", C.c_int, [C.c_void_p, C.c_uint32, f32p, C.c_uint32, C.c_float, C.c_void_p, u32p, f32p, u32p, u64p, u32p]),
     ("ss_vec_search_ann_dev", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

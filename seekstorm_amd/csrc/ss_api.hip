@@ -55,10 +55,10 @@ int ss_shard_create(int device, ss_shard** out) {
 }
 
 static void free_vec(ss_shard* s) {
-  void* ptrs[] = {s->d_X, s->d_X8, s->d_row_scale, s->d_row_doc, s->d_Qf, s->d_vstate, s->d_cand};
+  void* ptrs[] = {s->d_X, s->d_X8, s->d_row_scale, s->d_row_doc, s->d_Qf, s->d_vstate, s->d_cand, s->d_row_field};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->d_X = nullptr; s->d_X8 = nullptr; s->d_row_scale = nullptr; s->d_row_doc = nullptr; s->d_Qf = nullptr;
-  s->d_vstate = nullptr; s->d_cand = nullptr;
+  s->d_vstate = nullptr; s->d_cand = nullptr; s->d_row_field = nullptr;
   s->n_rows = s->n_rows_pad = 0; s->dim = s->dim_pad = s->dim_pad8 = 0; s->vec_multi_record = false;
   ssi_vec_free_clusters(s);
 }
@@ -459,6 +459,7 @@ static int vec_bin_upload(ss_shard* s, const uint8_t* bytes, uint64_t len, uint3
   struct Lvl { uint64_t first, n; };
   std::vector<Lvl> levels;
   std::vector<uint32_t> ids, level_clusters, child_counts;
+  std::vector<uint16_t> fields;  // VectorHeader.field_id (u32 at byte 2); the reference compares it as u16 (vector.rs:1398)
   std::vector<float> scales;
   uint64_t pos = 0;
   while (pos < len) {
@@ -481,6 +482,9 @@ static int vec_bin_upload(ss_shard* s, const uint8_t* bytes, uint64_t len, uint3
       uint16_t d;
       memcpy(&d, bytes + pos + r * rec, 2);
       ids.push_back((uint32_t)(levels.size() << 16) | d);
+      uint32_t fid;
+      memcpy(&fid, bytes + pos + r * rec + 2, 4);
+      fields.push_back((uint16_t)fid);
       if (use_scale) {
         float sc;
         memcpy(&sc, bytes + pos + r * rec + 10, 4);
@@ -526,6 +530,8 @@ static int vec_bin_upload(ss_shard* s, const uint8_t* bytes, uint64_t len, uint3
   s->vec_multi_record = multi;
   SS_HIP(hipMalloc(&s->d_row_doc, n_rows * sizeof(uint32_t)));
   SS_HIP(hipMemcpyAsync(s->d_row_doc, ids.data(), n_rows * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+  SS_HIP(hipMalloc(&s->d_row_field, n_rows * sizeof(uint16_t)));
+  SS_HIP(hipMemcpyAsync(s->d_row_field, fields.data(), n_rows * sizeof(uint16_t), hipMemcpyHostToDevice, s->stream));
   SS_HIP(hipStreamSynchronize(s->stream));
   rc = ssi_vec_set_clusters(s, (uint32_t)level_clusters.size(), level_clusters.data(), child_counts.data());
   if (rc != SS_OK && rc != SS_ENOTSUP) { free_vec(s); return rc; }  // ENOTSUP (an empty cluster): AnnMode::All only
@@ -610,10 +616,14 @@ static int vec_search_host(ss_shard* s, uint32_t nq, const void* queries, size_t
   }
   return rc;
 }
+static bool ann_skips_clusters(const ss_ann_mode* m) { return m->n_probe != 0 || m->cluster_threshold_raw > -3.4028234663852886e38f; }
+// a mode that neither skips clusters nor filters fields is AnnMode::All
+static const ss_ann_mode* ann_effective(const ss_ann_mode* m) { return (m && (ann_skips_clusters(m) || m->field_mask)) ? m : nullptr; }
 static int ann_mode_ok(const ss_shard* s, const ss_ann_mode* mode) {
   if (!mode) return SS_OK;
-  if (!s->d_row_cluster) return SS_ESTATE;
   if (mode->cluster_threshold_raw != mode->cluster_threshold_raw) return SS_EINVAL;
+  if (ann_skips_clusters(mode) && !s->d_row_cluster) return SS_ESTATE;
+  if (mode->field_mask && !s->d_row_field) return SS_ESTATE;
   return SS_OK;
 }
 
@@ -623,6 +633,7 @@ int ss_vec_search_ann(ss_shard* s, uint32_t nq, const float* queries, uint32_t k
   if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
   if (!s->d_X) return SS_ESTATE;
   SS_TRY(ann_mode_ok(s, mode));
+  mode = ann_effective(mode);
   return vec_search_host(s, nq, queries, sizeof(float), nullptr, k, thr, mode, out_doc, out_score, out_count, out_total,
                          mode ? out_clusters : nullptr);
 }
@@ -638,6 +649,7 @@ int ss_vec_search_ann_dev(ss_shard* s, uint32_t nq, const float* d_queries, uint
   if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
   if (!s->d_X) return SS_ESTATE;
   SS_TRY(ann_mode_ok(s, mode));
+  mode = ann_effective(mode);
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   hipStream_t st = stream ? (hipStream_t)stream : s->stream;
@@ -655,6 +667,17 @@ int ss_vec_set_clusters(ss_shard* s, uint32_t n_levels, const uint32_t* level_cl
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   return ssi_vec_set_clusters(s, n_levels, level_clusters, child_count);
+}
+int ss_vec_set_fields(ss_shard* s, uint64_t n_rows, const uint16_t* row_field) {
+  if (!s || !row_field) return SS_EINVAL;
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  if (!s->d_X && !s->d_X8) return SS_ESTATE;
+  if (n_rows != s->n_rows) return SS_EINVAL;
+  SS_HIP(hipStreamSynchronize(s->stream));
+  if (!s->d_row_field) SS_HIP(hipMalloc(&s->d_row_field, n_rows * sizeof(uint16_t)));
+  SS_HIP(hipMemcpy(s->d_row_field, row_field, n_rows * sizeof(uint16_t), hipMemcpyHostToDevice));
+  return SS_OK;
 }
 int ss_vec_cluster_info(ss_shard* s, uint32_t* n_levels, uint32_t* n_clusters) {
   if (!s) return SS_EINVAL;
@@ -769,6 +792,7 @@ int ss_vec_search_i8_ann(ss_shard* s, uint32_t nq, const int8_t* queries, const 
   if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
   if (!s->d_X8) return SS_ESTATE;
   SS_TRY(ann_mode_ok(s, mode));
+  mode = ann_effective(mode);
   return vec_search_host(s, nq, queries, 1, query_scale, k, thr, mode, out_doc, out_score, out_count, out_total,
                          mode ? out_clusters : nullptr);
 }
@@ -784,6 +808,7 @@ int ss_vec_search_i8_ann_dev(ss_shard* s, uint32_t nq, const int8_t* d_queries, 
   if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
   if (!s->d_X8) return SS_ESTATE;
   SS_TRY(ann_mode_ok(s, mode));
+  mode = ann_effective(mode);
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   hipStream_t st = stream ? (hipStream_t)stream : s->stream;

@@ -71,6 +71,7 @@ struct ss_shard {
   float* d_row_scale = nullptr;  // i8 image: per-record scale (VectorHeader.scale) for dot_i8_quantized, null = raw integer dot
   uint32_t dim_pad8 = 0;         // row stride of the i8 image in bytes (multiple of 128)
   uint32_t* d_row_doc = nullptr; // optional row -> doc id
+  uint16_t* d_row_field = nullptr; // optional row -> indexed field id (VectorHeader.field_id): field_filter
   bool vec_multi_record = false; // several records per doc: TopK::push dedup (vector.rs:441-452) in the refine kernel
   uint64_t n_rows = 0, n_rows_pad = 0;
   uint32_t dim = 0, dim_pad = 0;

@@ -100,7 +100,7 @@ vec8_scan_kernel(const int8_t* __restrict__ X, uint32_t dim_pad, unsigned long l
   if (SCALED && q_scale) { qs0 = q_scale[lane & 31]; qs1 = q_scale[32 + (lane & 31)]; }
   __syncthreads();
 
-  if (ANN) {
+  if (ANN && ann.tiles) {
     const uint32_t na = *ann.n_tiles;
     ntiles = na > tile0 ? min(ntiles, na - tile0) : 0u;
   }
@@ -116,7 +116,7 @@ vec8_scan_kernel(const int8_t* __restrict__ X, uint32_t dim_pad, unsigned long l
   v4i xa[V8_D][4];
   auto issue = [&](v4i(&buf)[4]) {
     const uint32_t t = min(i_tile, my_tiles - 1);  // past the end: re-read a line of the last tile (never consumed)
-    if (ANN) { if (i_line == 0) i_tix = ann.tiles[tile0 + first + t * gridDim.x]; }
+    if (ANN) { if (i_line == 0) i_tix = ann.tiles ? ann.tiles[tile0 + first + t * gridDim.x] : tile0 + first + t * gridDim.x; }
     const size_t tix = ANN ? (size_t)i_tix : (size_t)(tile0 + first + (size_t)t * gridDim.x);
     const v4i* p = (const v4i*)(X + tix * tile_stride + lane_off + (size_t)i_line * 4096u);
 #pragma unroll
@@ -147,7 +147,7 @@ vec8_scan_kernel(const int8_t* __restrict__ X, uint32_t dim_pad, unsigned long l
       issue(xa[d]);
       if (++c_line == L) {
         // ---- threshold filter: lane owns query (lane & 31) + {0, 32}, 16 rows per accumulator
-        const unsigned long long c_tix = ANN ? (unsigned long long)ann.tiles[tile0 + first + c_tile * gridDim.x]
+        const unsigned long long c_tix = (ANN && ann.tiles) ? (unsigned long long)ann.tiles[tile0 + first + c_tile * gridDim.x]
                                              : (unsigned long long)(tile0 + first + (unsigned long long)c_tile * gridDim.x);
         const unsigned long long row_base = c_tix * (V8_WAVES * 32) + 32u * w + 4u * (lane >> 5);
         float f0[16], f1[16];

@@ -53,12 +53,16 @@ __device__ __forceinline__ void vs_append(const float (&f)[16], float tau, uint3
 // What a scan launch needs to visit only the clusters some query of the batch selected (AnnMode::Nprobe /
 // Similaritythreshold, vector.rs:1300-1392): the list of 128-row tiles that hold a selected cluster, the
 // cluster of every row and one bit per (query, cluster).  A row is a candidate of query q only if q selected its cluster.
+// The same admission test carries the field filter of search_vector_shard (vector.rs:1397-1400: a record of a field that
+// is not listed is skipped); without an ANN mode the tile list is absent (= every tile) and only the field test runs.
 struct VAnn {
-  const uint32_t* tiles;        // [n_tiles] tile ids, each once, interleaved (vec_ann.hip)
-  const uint32_t* n_tiles;      // device scalar
+  const uint32_t* tiles;        // [n_tiles] tile ids, each once, interleaved (vec_ann.hip); null = every tile in order
+  const uint32_t* n_tiles;      // device scalar (null with tiles)
   const uint32_t* row_cluster;  // [n_rows] shard-wide cluster index
-  const uint32_t* sel;          // [64][sel_words] bit c of row q: query q visits cluster c
+  const uint32_t* sel;          // [64][sel_words] bit c of row q: query q visits cluster c; null = every cluster
   uint32_t sel_words;
+  const uint16_t* row_field;    // [n_rows] indexed field of each record; null = no field filter
+  unsigned long long field_mask;
 };
 __device__ __forceinline__ void vs_append_ann(const float (&f)[16], float tau, uint32_t q, unsigned long long row_base,
                                               unsigned long long n_rows, VState* __restrict__ st,
@@ -68,8 +72,16 @@ __device__ __forceinline__ void vs_append_ann(const float (&f)[16], float tau, u
   for (int r = 0; r < 16; r++) {
     const unsigned long long row = row_base + (r & 3) + 8 * (r >> 2);
     if (f[r] > tau && row < n_rows) {
-      const uint32_t c = ann.row_cluster[row];
-      m |= ((ann.sel[(size_t)q * ann.sel_words + (c >> 5)] >> (c & 31u)) & 1u) << r;
+      uint32_t ok = 1u;
+      if (ann.sel) {
+        const uint32_t c = ann.row_cluster[row];
+        ok = (ann.sel[(size_t)q * ann.sel_words + (c >> 5)] >> (c & 31u)) & 1u;
+      }
+      if (ann.row_field) {
+        const uint32_t fld = ann.row_field[row];
+        ok &= fld < 64u ? (uint32_t)(ann.field_mask >> fld) & 1u : 0u;
+      }
+      m |= ok << r;
     }
   }
   if (m == 0) return;

@@ -68,7 +68,7 @@ vec_scan_kernel(const float* __restrict__ X, uint32_t dim_pad, unsigned long lon
   // would be a vmcnt(0) that drains the LDS-DMA ring once per tile
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(tau0), "+v"(tau1)::"memory");
 
-  if (ANN) {
+  if (ANN && ann.tiles) {
     const uint32_t na = *ann.n_tiles;
     ntiles = na > tile0 ? min(ntiles, na - tile0) : 0u;
   }
@@ -102,7 +102,7 @@ vec_scan_kernel(const float* __restrict__ X, uint32_t dim_pad, unsigned long lon
   uint32_t i_tile = 0, i_kc = 0, i_stage = 0;  // issue cursor
   uint32_t i_tix = 0;
   auto issue = [&]() {
-    if (ANN) { if (i_kc == 0) i_tix = ann.tiles[tile0 + first + i_tile * gridDim.x]; }
+    if (ANN) { if (i_kc == 0) i_tix = ann.tiles ? ann.tiles[tile0 + first + i_tile * gridDim.x] : tile0 + first + i_tile * gridDim.x; }
     const size_t tix = ANN ? (size_t)i_tix : (size_t)(tile0 + first + (size_t)i_tile * gridDim.x);
     const float* xt = X + tix * tile_stride + i_kc * VS_KC;
     char* sb = smem + i_stage * VS_STAGE;
@@ -151,7 +151,7 @@ vec_scan_kernel(const float* __restrict__ X, uint32_t dim_pad, unsigned long lon
 
     if (++c_kc == nch) {
       // ---- fused top-k filter: lane owns query (lane&31)+{0,32}, 16 rows per accumulator
-      const unsigned long long c_tix = ANN ? (unsigned long long)ann.tiles[tile0 + first + c_tile * gridDim.x]
+      const unsigned long long c_tix = (ANN && ann.tiles) ? (unsigned long long)ann.tiles[tile0 + first + c_tile * gridDim.x]
                                            : (unsigned long long)(tile0 + first + (unsigned long long)c_tile * gridDim.x);
       const unsigned long long row_base = c_tix * VS_TR + 32u * w + 4u * (lane >> 5);
       float m0 = acc0[0], m1 = TWO ? acc1[0] : -INFINITY;
@@ -317,7 +317,10 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float*
                    uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, hipStream_t st,
                    bool safe_mode, const ss_ann_mode* ann_mode, uint32_t* d_out_clusters) {
   if (!s->d_X && !s->d_X8) return SS_ESTATE;
-  if (ann_mode && !s->d_row_cluster) return SS_ESTATE;  // the image carries no cluster structure (ss_vec_set_clusters)
+  // an ANN mode proper (some clusters are skipped) or only the field filter riding on the same admission test
+  const bool ann_clusters = ann_mode && (ann_mode->n_probe != 0 || ann_mode->cluster_threshold_raw > -3.4028234663852886e38f);
+  if (ann_clusters && !s->d_row_cluster) return SS_ESTATE;  // the image carries no cluster structure (ss_vec_set_clusters)
+  if (ann_mode && ann_mode->field_mask && !s->d_row_field) return SS_ESTATE;  // nor field ids (ss_vec_set_fields)
   const bool i8 = s->d_X8 != nullptr;
   if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
   int rc = ssi_vec_alloc_ws(s);
@@ -354,9 +357,15 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float*
     else vec_qprep_kernel<<<nch, 512, 0, st>>>((const float*)d_queries + (size_t)g0 * s->dim, nb, s->dim, s->d_Qf);
     vec_init_kernel<<<1, 64, 0, st>>>(vst, tau_init);
     VAnn ann{};
-    if (ann_mode) {  // medoid scores -> per-query cluster selection -> the batch's tile list
+    if (ann_clusters) {  // medoid scores -> per-query cluster selection -> the batch's tile list
       rc = ssi_vec_ann_prepare(s, nb, d_qscale ? d_qscale + g0 : nullptr, ann_mode, &ann, d_out_clusters ? d_out_clusters + g0 : nullptr, st);
       if (rc) return rc;
+    } else if (ann_mode && d_out_clusters) {
+      SS_HIP(hipMemsetAsync(d_out_clusters + g0, 0, nb * sizeof(uint32_t), st));
+    }
+    if (ann_mode && ann_mode->field_mask) {
+      ann.row_field = s->d_row_field;
+      ann.field_mask = ann_mode->field_mask;
     }
     uint32_t tile0 = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -197,8 +197,14 @@ int Shard::set_clusters(const std::vector<uint32_t>& level_clusters, const std::
   return ss_vec_set_clusters(h_, (uint32_t)level_clusters.size(), level_clusters.data(), child_count.data());
 }
 
+int Shard::set_fields(const std::vector<uint16_t>& row_field) {
+  if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
+  return ss_vec_set_fields(h_, row_field.size(), row_field.data());
+}
+
 std::vector<ResultObject> Shard::search_vector_batch(const float* query_vectors, size_t n_queries, size_t k,
-                                                     const float* similarity_threshold, const AnnMode& ann_mode) {
+                                                     const float* similarity_threshold, const AnnMode& ann_mode,
+                                                     const std::vector<uint16_t>& field_filter) {
   std::vector<ResultObject> out(n_queries);
   if (n_queries == 0) return out;
   const size_t kk = std::max<size_t>(k, 1);
@@ -208,22 +214,28 @@ std::vector<ResultObject> Shard::search_vector_batch(const float* query_vectors,
   std::vector<uint32_t> ncl(n_queries, 0);
   int rc = create_rc_ ? create_rc_ : SS_ESTATE;
   // vector.rs:1300-1307: (n_probe, cluster threshold) of the mode; the threshold goes through TopK::new like the record one
-  ss_ann_mode am{0u, threshold_raw(nullptr)};
+  ss_ann_mode am{0u, threshold_raw(nullptr), 0ull};
   const bool ann = ann_mode.kind != AnnMode::Kind::All;
+  bool bad_field = false;
+  for (uint16_t f : field_filter) {
+    if (f < 64) am.field_mask |= 1ull << f;
+    else bad_field = true;
+  }
+  const bool opts = ann || am.field_mask != 0;
   if (ann_mode.kind == AnnMode::Kind::Nprobe || ann_mode.kind == AnnMode::Kind::NprobeSimilaritythreshold)
     am.n_probe = (uint32_t)std::min<size_t>(ann_mode.n_probe, 0xFFFFFFFFu);
   if (ann_mode.kind == AnnMode::Kind::Similaritythreshold || ann_mode.kind == AnnMode::Kind::NprobeSimilaritythreshold)
     am.cluster_threshold_raw = threshold_raw(&ann_mode.similarity_threshold);
-  if (ann && ann_mode.kind != AnnMode::Kind::Similaritythreshold && am.n_probe == 0) {
-    rc = SS_EINVAL;  // Nprobe(0): TopK::new(0, ..) has no slot to push into
+  if ((ann && ann_mode.kind != AnnMode::Kind::Similaritythreshold && am.n_probe == 0) || bad_field) {
+    rc = bad_field ? SS_ENOTSUP : SS_EINVAL;  // Nprobe(0): TopK::new(0, ..) has no slot to push into
   } else if (h_ && i8_) {  // the query is quantised like the records (search.rs:1487-1490); score = raw integer dot
     std::vector<int8_t> q8(n_queries * dim_);
     quantize_f32_to_i8(query_vectors, q8.size(), q8.data());
     rc = ss_vec_search_i8_ann(h_, (uint32_t)n_queries, q8.data(), nullptr, (uint32_t)k, threshold_raw(similarity_threshold),
-                              ann ? &am : nullptr, doc.data(), score.data(), cnt.data(), tot.data(), ncl.data());
+                              opts ? &am : nullptr, doc.data(), score.data(), cnt.data(), tot.data(), ncl.data());
   } else if (h_) {
     rc = ss_vec_search_ann(h_, (uint32_t)n_queries, query_vectors, (uint32_t)k, threshold_raw(similarity_threshold),
-                           ann ? &am : nullptr, doc.data(), score.data(), cnt.data(), tot.data(), ncl.data());
+                           opts ? &am : nullptr, doc.data(), score.data(), cnt.data(), tot.data(), ncl.data());
   }
   uint32_t all_clusters = 0;
   if (h_ && !ann) (void)ss_vec_cluster_info(h_, nullptr, &all_clusters);
@@ -244,7 +256,7 @@ std::vector<ResultObject> Shard::search_vector_batch(const float* query_vectors,
     ro.result_count = n;
     ro.result_count_total = tot[q];
     if (!ann) {
-      ro.observed_vector_count = n_rows_;  // AnnMode::All observes every record (vector.rs:421)
+      if (!am.field_mask) ro.observed_vector_count = n_rows_;  // AnnMode::All observes every record (vector.rs:421)
       ro.observed_cluster_count = all_clusters ? all_clusters : 1;
     } else {
       ro.observed_cluster_count = ncl[q];  // vector.rs:1394
@@ -271,15 +283,16 @@ ResultObject Shard::search_lexical_shard(const std::vector<uint32_t>& query_term
 }
 
 ResultObject Shard::search_vector_shard(const float* query_vector, size_t length, const float* similarity_threshold,
-                                        const AnnMode& ann_mode) {
+                                        const AnnMode& ann_mode, const std::vector<uint16_t>& field_filter) {
   if (!query_vector) return ResultObject();
-  return std::move(search_vector_batch(query_vector, 1, length, similarity_threshold, ann_mode)[0]);
+  return std::move(search_vector_batch(query_vector, 1, length, similarity_threshold, ann_mode, field_filter)[0]);
 }
 
 // ------------------------------------------------------------------ Index::search
 ResultObject Index::search(const std::vector<uint32_t>& query_terms, const float* query_vector, QueryType query_type_default,
                            SearchMode search_mode, size_t offset, size_t length, ResultType result_type,
-                           const float* similarity_threshold, bool normalize_query, const AnnMode& ann_mode) {
+                           const float* similarity_threshold, bool normalize_query, const AnnMode& ann_mode,
+                           const std::vector<uint16_t>& vector_field_filter) {
   ResultObject ro;
   const size_t S = shards_.size();
   if (S == 0) return ro;
@@ -295,7 +308,7 @@ ResultObject Index::search(const std::vector<uint32_t>& query_terms, const float
   auto task = [&](size_t i) {
     Shard& sh = *shards_[i];
     if (want_lex) lex[i] = sh.search_lexical_shard(query_terms, query_type_default, 0, offset + length, result_type);
-    if (want_vec && qv.size() == sh.dim()) vec[i] = sh.search_vector_shard(qv.data(), offset + length, similarity_threshold, ann_mode);
+    if (want_vec && qv.size() == sh.dim()) vec[i] = sh.search_vector_shard(qv.data(), offset + length, similarity_threshold, ann_mode, vector_field_filter);
   };
   if (S == 1) {
     task(0);  // shard_number == 1: called directly, no spawn (search.rs:1434)

@@ -114,12 +114,17 @@ class Shard {
   // the reference's per-shard seams (one query)
   ResultObject search_lexical_shard(const std::vector<uint32_t>& query_terms, QueryType query_type_default, size_t offset,
                                     size_t length, ResultType result_type);
+  // field_filter: indexed field ids to search (the reference resolves the names through schema_map, vector.rs:1225-1237);
+  // empty = every field
   ResultObject search_vector_shard(const float* query_vector /* normalised, dim() floats */, size_t length,
-                                   const float* similarity_threshold, const AnnMode& ann_mode = AnnMode());
+                                   const float* similarity_threshold, const AnnMode& ann_mode = AnnMode(),
+                                   const std::vector<uint16_t>& field_filter = {});
   // batched forms used by the coalescer (results sorted by score desc, shard-local ids)
   std::vector<ResultObject> search_lexical_batch(const std::vector<ss_bm25_query>& queries, size_t k, ResultType result_type);
   std::vector<ResultObject> search_vector_batch(const float* query_vectors, size_t n_queries, size_t k,
-                                                const float* similarity_threshold, const AnnMode& ann_mode = AnnMode());
+                                                const float* similarity_threshold, const AnnMode& ann_mode = AnnMode(),
+                                                const std::vector<uint16_t>& field_filter = {});
+  int set_fields(const std::vector<uint16_t>& row_field);  // VectorHeader.field_id per record of an array upload
   // cluster structure of rows uploaded in file order (vector.rs:1066-1094); open_vector_bin keeps the file's own
   int set_clusters(const std::vector<uint32_t>& level_clusters, const std::vector<uint32_t>& child_count);
 
@@ -148,7 +153,7 @@ class Index {
   ResultObject search(const std::vector<uint32_t>& query_terms, const float* query_vector, QueryType query_type_default,
                       SearchMode search_mode, size_t offset, size_t length, ResultType result_type,
                       const float* similarity_threshold = nullptr, bool normalize_query = true,
-                      const AnnMode& ann_mode = AnnMode());
+                      const AnnMode& ann_mode = AnnMode(), const std::vector<uint16_t>& vector_field_filter = {});
 
  private:
   std::vector<std::shared_ptr<Shard>> shards_;

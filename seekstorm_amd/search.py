@@ -120,7 +120,21 @@ class AnnMode:
     def _c(self):
         if self.n_probe < 0 or (self.n_probe == 0 and self.similarity_threshold is None):
             raise ValueError("AnnMode needs n_probe >= 1 or a similarity threshold")
-        return N.AnnModeC(self.n_probe, threshold_raw(self.similarity_threshold))
+        return N.AnnModeC(self.n_probe, threshold_raw(self.similarity_threshold), 0)
+
+
+def _vector_options(ann_mode, field_filter):
+    """ss_ann_mode of a call: the AnnMode (None = All) and the field filter (indexed field ids, empty = every field)"""
+    mask = 0
+    for f in field_filter or ():
+        if not 0 <= int(f) < 64:
+            raise ValueError("field filter: indexed field ids 0..63")
+        mask |= 1 << int(f)
+    if ann_mode is None and not mask:
+        return None
+    m = N.AnnModeC(0, N.FLT_MIN_NEG, 0) if ann_mode is None else ann_mode._c()
+    m.field_mask = mask
+    return m
 
 
 class IndexBin:
@@ -266,6 +280,11 @@ class Shard:
             raise ValueError("child_count must have one entry per cluster")
         N.check(N.lib().ss_vec_set_clusters(self._h, len(lc), N.ptr(lc, N.u32p), N.ptr(cc, N.u32p)), "ss_vec_set_clusters")
 
+    def set_fields(self, row_field):
+        """VectorHeader.field_id of every record (rows uploaded as arrays; upload_vector_bin reads the file's own)"""
+        rf = np.ascontiguousarray(row_field, np.uint16)
+        N.check(N.lib().ss_vec_set_fields(self._h, len(rf), rf.ctypes.data), "ss_vec_set_fields")
+
     def cluster_info(self):
         nl, nc = C.c_uint32(), C.c_uint32()
         N.check(N.lib().ss_vec_cluster_info(self._h, C.byref(nl), C.byref(nc)), "ss_vec_cluster_info")
@@ -315,7 +334,7 @@ class Shard:
         return out
 
     def search_vector_batch_i8(self, queries_i8, k, query_scale=None, similarity_threshold_raw=None, ann_mode=None,
-                               with_clusters=False):
+                               with_clusters=False, field_filter=None):
         """scores = dot_i8 as f32 (* query_scale * embedding_scale with scales): vector_similarity.rs:1011-1016, 1754-1758"""
         qv = np.ascontiguousarray(queries_i8, np.int8)
         if qv.ndim == 1:
@@ -330,7 +349,7 @@ class Shard:
         tot = np.empty(nq, np.uint64)
         thr = N.FLT_MIN_NEG if similarity_threshold_raw is None else float(similarity_threshold_raw)
         ncl = np.zeros(nq, np.uint32)
-        mode = None if ann_mode is None else ann_mode._c()
+        mode = _vector_options(ann_mode, field_filter)
         N.check(N.lib().ss_vec_search_i8_ann(self._h, nq, qv.ctypes.data, N.ptr(qs, N.f32p), k, thr,
                                              None if mode is None else C.addressof(mode), N.ptr(doc, N.u32p),
                                              N.ptr(score, N.f32p), N.ptr(cnt, N.u32p), N.ptr(tot, N.u64p), N.ptr(ncl, N.u32p)),
@@ -414,7 +433,8 @@ class Shard:
                 "ss_bm25_search")
         return doc, score, cnt, tot
 
-    def search_vector_batch(self, query_vectors, k, similarity_threshold=None, ann_mode=None, with_clusters=False):
+    def search_vector_batch(self, query_vectors, k, similarity_threshold=None, ann_mode=None, with_clusters=False,
+                            field_filter=None):
         qv = np.ascontiguousarray(query_vectors, np.float32)
         if qv.ndim == 1:
             qv = qv[None, :]
@@ -426,7 +446,7 @@ class Shard:
         cnt = np.zeros(nq, np.uint32)
         tot = np.zeros(nq, np.uint64)
         ncl = np.zeros(nq, np.uint32)
-        mode = None if ann_mode is None else ann_mode._c()
+        mode = _vector_options(ann_mode, field_filter)
         N.check(N.lib().ss_vec_search_ann(self._h, nq, N.ptr(qv, N.f32p), int(k), threshold_raw(similarity_threshold),
                                           None if mode is None else C.addressof(mode), N.ptr(doc, N.u32p), N.ptr(score, N.f32p),
                                           N.ptr(cnt, N.u32p), N.ptr(tot, N.u64p), N.ptr(ncl, N.u32p)), "ss_vec_search_ann")
@@ -450,17 +470,19 @@ class Shard:
         return ro
 
     def search_vector_shard(self, query_vector, length=10, similarity_threshold=None, strict=False,
-                            ann_mode=None) -> ResultObject:
+                            ann_mode=None, field_filter=None) -> ResultObject:
         ro = ResultObject()
         try:
             if self.vector_precision == "i8":  # the query is quantised like the records (search.rs:1476-1490), threshold on the raw dot
                 q8 = quantize_f32_to_i8(np.ascontiguousarray(query_vector, np.float32).reshape(1, -1))
                 thr = None if similarity_threshold is None else threshold_raw(similarity_threshold)
                 doc, score, cnt, tot, ncl = self.search_vector_batch_i8(q8, length, similarity_threshold_raw=thr,
-                                                                        ann_mode=ann_mode, with_clusters=True)
+                                                                        ann_mode=ann_mode, with_clusters=True,
+                                                                        field_filter=field_filter)
             else:
                 doc, score, cnt, tot, ncl = self.search_vector_batch(query_vector, length, similarity_threshold,
-                                                                     ann_mode=ann_mode, with_clusters=True)
+                                                                     ann_mode=ann_mode, with_clusters=True,
+                                                                     field_filter=field_filter)
         except Exception:
             if strict:
                 raise
@@ -470,7 +492,8 @@ class Shard:
         ro.result_count = n
         ro.result_count_total = int(tot[0])
         if ann_mode is None:
-            ro.observed_vector_count = self.vector_count  # AnnMode::All observes every record (vector.rs:421)
+            if not field_filter:
+                ro.observed_vector_count = self.vector_count  # AnnMode::All observes every record (vector.rs:421)
             ro.observed_cluster_count = self.cluster_info()[1]
         else:
             ro.observed_cluster_count = int(ncl[0])  # vector.rs:1394

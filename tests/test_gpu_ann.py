@@ -278,3 +278,71 @@ def test_ann_tied_medoids_follow_the_reference_replay(S, O):
             assert np.array_equal(score[i][:cnt[i]], os_)
     assert straddles > 20  # the tie really sits on the boundary for many (query, n_probe) pairs
     sh.close()
+
+
+@pytest.mark.parametrize("i8", [False, True], ids=["f32", "i8"])
+def test_vector_field_filter_all_and_ann(S, O, i8):
+    """field_filter of search_vector_shard (vector.rs:1225-1237, 1397-1400): records of other fields are skipped before
+    they are scored -- in AnnMode::All and inside the clusters an ANN mode visits (medoids are scored whatever their field)"""
+    lc = [8, 7]
+    rows32, child = clustered(O, 81, lc, 64, lo=80, hi=260)
+    n = len(rows32)
+    rng = np.random.default_rng(82)
+    rf = rng.integers(0, 4, n).astype(np.uint16)      # four indexed fields, interleaved like field x chunk records
+    ids = (np.arange(n) // 2).astype(np.uint32)       # two records per doc: the filter acts before the dedup
+    q32 = queries_near(O, rows32, 83, 20)
+    rows, qs = (O.quantize_i8(rows32), O.quantize_i8(q32)) if i8 else (rows32, q32)
+    sh = S.Shard(0)
+    (sh.upload_vectors_i8 if i8 else sh.upload_vectors)(rows, row_doc_ids=ids)
+    search = sh.search_vector_batch_i8 if i8 else sh.search_vector_batch
+    ora = O.vec_search_i8_ann if i8 else O.vec_search_ann
+    with pytest.raises(S.SeekStormHipError):
+        search(qs, 10, field_filter=[1])             # no field ids declared
+    sh.set_fields(rf)
+    sh.set_clusters(lc, child)
+    k = 15
+    for am, lcc, kw in ((None, (None, None), {}), (S.AnnMode.Nprobe(3), (lc, child), dict(n_probe=3))):
+        for fields in ([2], [0, 3], [0, 1, 2, 3]):
+            doc, score, cnt, tot, ncl = search(qs, k, ann_mode=am, field_filter=fields, with_clusters=True)
+            for i in range(len(qs)):
+                od, os_, otot, oobs, oncl = ora(rows, qs[i], k, lcc[0], lcc[1], row_doc_ids=ids, row_field=rf, fields=fields, **kw)
+                c = int(cnt[i])
+                assert c == len(od) and ncl[i] == oncl
+                if i8:
+                    assert np.array_equal(score[i][:c], os_)
+                else:
+                    assert np.allclose(score[i][:c], os_, rtol=REL, atol=2e-6)
+                assert len(set(map(int, doc[i][:c]))) == c
+                if fields != [0, 1, 2, 3]:  # every returned doc has a record of a listed field
+                    assert all(any(rf[r] in fields for r in (2 * int(d), min(2 * int(d) + 1, n - 1))) for d in doc[i][:c])
+    # every field listed == no filter
+    a = search(qs, k)
+    b = search(qs, k, field_filter=[0, 1, 2, 3])
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    sh.close()
+
+
+def test_vector_bin_field_ids_feed_the_filter(S, O):
+    from oracle import ref_format as RF
+    dim = 32
+    rows, child = clustered(O, 91, [3], dim, lo=40, hi=80)
+    rng = np.random.default_rng(92)
+    recs, rf, r = [], [], 0
+    clusters = []
+    for c in child:
+        cl = []
+        for _ in range(int(c)):
+            f = int(rng.integers(0, 3))
+            cl.append((r, f, 0, rows[r]))
+            rf.append(f)
+            r += 1
+        clusters.append(cl)
+    sh = S.Shard(0)
+    sh.upload_vector_bin(RF.write_vector_bin([clusters], dim), dim)
+    qs = queries_near(O, rows, 93, 6)
+    doc, score, cnt, tot = sh.search_vector_batch(qs, 10, field_filter=[1])
+    for i in range(len(qs)):
+        od, os_, _, oobs, _ = O.vec_search_ann(rows, qs[i], 10, None, None, row_field=np.asarray(rf, np.uint16), fields=[1])
+        assert cnt[i] == len(od) and np.allclose(score[i][:cnt[i]], os_, rtol=REL, atol=2e-6)
+        assert all(rf[int(d)] == 1 for d in doc[i][:cnt[i]])
+    sh.close()
