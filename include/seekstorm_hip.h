@@ -99,14 +99,24 @@ typedef struct {
   uint64_t byte_array_len;
 } ss_ref_block;
 int ss_ref_decode_block(const ss_ref_block* block, uint16_t* docs_out /*[65536]*/, uint16_t* tfs_out /*[65536]*/);
+/* a block of an N-GRAM key (key_hash & 7 = NgramType != 0, index.rs:1854-1872; one indexed field): never embedded, every
+ * record starts with the tf of each component term (2: bigram types 1-3, 3: trigram types 4-7) before the positions count
+ * (add_result.rs:2074-2089).  tfs_out = tf of component `component` -- what the n-gram arms of
+ * get_bm25f_multiterm_singlefield (add_result.rs:1454-1477) weigh with idf_ngram{1,2,3}. */
+int ss_ref_decode_block_ngram(const ss_ref_block* block, uint32_t n_components, uint32_t component, uint16_t* docs_out,
+                              uint16_t* tfs_out);
 int ss_bm25_upload_ref_blocks(ss_shard* s, uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t n_terms,
                               const uint64_t* term_block_offsets /*[n_terms+1]*/, const ss_ref_block* blocks);
 /* ... and from a shard's index.bin as it lies on disk / in the mmap (writer commit.rs:264-369 and
  * 467-552, reader index.rs:3263-3740).  ss_index_bin_open only walks the levels, segment head tables and key heads
  * (host, no device needed) and borrows `bytes`, which must outlive the handle.  Term id = rank of the key_hash among
- * the SingleTerm keys, ascending: the Rust side keeps translating term -> key_hash (ahash / gxhash stay in Rust) and
- * binary-searches ss_index_bin_term_keys.  N-gram keys are counted and skipped; more than one indexed field (BM25F)
- * is SS_ENOTSUP at decode time.  indexed_field_count / key_head_size (20 | 22 | 23, index.rs:2806-2812) come from
+ * the keys, ascending: the Rust side keeps translating term -> key_hash (ahash / gxhash stay in Rust) and
+ * binary-searches ss_index_bin_term_keys.  An N-GRAM key (the default index has NgramFF | NgramFFF keys,
+ * index.rs:1422-1424) occupies one term id PER COMPONENT, consecutive and in order (same key_hash, same docs, the
+ * component's tf): a query term that resolved to the n-gram becomes its 2 or 3 component terms with idf_ngram_i each
+ * (from ss_index_bin_term_ngram's component df, search.rs:3231-3262) -- the same documents match, and the scores add up
+ * to the n-gram arm of get_bm25f_multiterm_singlefield (add_result.rs:1454-1477).  With several indexed fields n-gram
+ * keys are counted and skipped.  indexed_field_count / key_head_size (20 | 22 | 23, index.rs:2806-2812) come from
  * schema.json / index.json; segment_number_bits is 11 for every index opened by the reference (index.rs:3285). */
 typedef struct ss_index_bin ss_index_bin;
 int ss_index_bin_open(const uint8_t* bytes, uint64_t len, uint32_t indexed_field_count, uint32_t key_head_size,
@@ -119,6 +129,11 @@ int ss_index_bin_close(ss_index_bin* ix);
 int ss_index_bin_info(const ss_index_bin* ix, uint64_t* n_docs, uint64_t* positions_sum_normalized, uint32_t* n_levels,
                       uint32_t* n_terms, uint32_t* n_ngram_keys_skipped);
 int ss_index_bin_term_keys(const ss_index_bin* ix, uint64_t* keys_out /*[n_terms], ascending*/);
+/* per term (any pointer may be NULL): components of its key (1 = SingleTerm key), which component the term is (0-based),
+ * and for n-gram components the posting count of the component TERM = DOCUMENT_LENGTH_COMPRESSION[
+ * posting_count_ngram_i_compressed] from the key head (compress_postinglist.rs:105-106, 339-409); 0 for SingleTerm */
+int ss_index_bin_term_ngram(const ss_index_bin* ix, uint8_t* n_components_out, uint8_t* component_out,
+                            uint32_t* component_df_out);
 /* decoded postings of one term (tooling / tests); SS_EINVAL with *n_out = needed capacity when cap is too small */
 int ss_index_bin_term_postings(const ss_index_bin* ix, uint32_t term, uint64_t cap, uint32_t* docs_out, uint16_t* tfs_out,
                                uint64_t* n_out);

@@ -92,10 +92,13 @@ def container(local_docs):
     return CT_BITMAP, bm.tobytes()
 
 
-def encode_key_body(local_docs, positions_per_doc, base=0, positions_limit=32768):
+def encode_key_body(local_docs, positions_per_doc, base=0, positions_limit=32768, ngram_tfs=None):
     """One posting list of one block -> (body bytes, compression_type_pointer, posting_count, pointer_pivot_p_docid).
     `base` = offset of the body inside the segment's byte array (the previous keys' bodies).  positions_limit is the
-    reference's 32 768 (index_posting.rs:193, 579-587); tests lower it to reach 3-byte pointers with small inputs."""
+    reference's 32 768 (index_posting.rs:193, 579-587); tests lower it to reach 3-byte pointers with small inputs.
+    ngram_tfs: an n-gram key (NgramType != SingleTerm) -- per posting the tf of each component term (2 or 3): such a
+    posting is never embedded (index_posting.rs:445) and its record starts with the component tfs, each written like the
+    positions count of a single-field record (write_field_vec, index_posting.rs:846-875), before the count (666-722)."""
     n = len(local_docs)
     assert n == len(positions_per_doc) and 1 <= n <= 65536
     size_positions = 0
@@ -111,10 +114,12 @@ def encode_key_body(local_docs, positions_per_doc, base=0, positions_limit=32768
         else:
             psize = 3
             three = True
-        if embeddable(deltas, psize):
+        if ngram_tfs is None and embeddable(deltas, psize):
             pointers.append(embed(deltas, psize))
             continue
         rec = vint(len(pos)) + b"".join(position_vint(x) for x in deltas)
+        if ngram_tfs is not None:
+            rec = b"".join(vint(int(t)) for t in ngram_tfs[rank]) + rec
         if psize == 2 and size_positions + len(rec) >= positions_limit:  # index_posting.rs:579-587
             psize, pivot, three = 3, rank, True
         size_positions += len(rec)
@@ -142,7 +147,7 @@ def random_positions(rng, tf, max_gap=40):
     return [int(x) for x in pos]
 
 
-def encode_term(docs, tfs, rng, base_bytes=b"", positions_limit=32768, max_gap=40):
+def encode_term(docs, tfs, rng, base_bytes=b"", positions_limit=32768, max_gap=40, ngram_tfs=None):
     """Whole posting list -> list of (block_id, compression_type_pointer, posting_count, pivot, byte_array); every block's
     byte array begins with `base_bytes` (standing for other keys' bodies in the same segment)."""
     docs = np.asarray(docs, np.int64)
@@ -151,7 +156,8 @@ def encode_term(docs, tfs, rng, base_bytes=b"", positions_limit=32768, max_gap=4
     for b in np.unique(bid):
         sel = np.nonzero(bid == b)[0]
         pos = [random_positions(rng, int(tfs[i]), max_gap) for i in sel]
-        body, ctp, cnt, pivot = encode_key_body(docs[sel] & 0xFFFF, pos, len(base_bytes), positions_limit)
+        body, ctp, cnt, pivot = encode_key_body(docs[sel] & 0xFFFF, pos, len(base_bytes), positions_limit,
+                                                None if ngram_tfs is None else [ngram_tfs[i] for i in sel])
         out.append((int(b), ctp, cnt, pivot, base_bytes + body))
     return out
 
@@ -177,12 +183,21 @@ def encode_term_fields(docs, fields, tfs, n_fields, longest_field_id, rng, posit
     return out
 
 
+def ngram_components(key_hash):
+    """components of a key by its NgramType (low 3 bits, index.rs:1854-1872): 0 SingleTerm, 1-3 bigrams, 4-7 trigrams"""
+    t = key_hash & 7
+    return 1 if t == 0 else 2 if t <= 3 else 3
+
+
 def write_index_bin(n_docs, doclen_bytes, terms, rng, segment_number_bits=11, key_head_size=20, ngram_keys=(),
-                    positions_sum=None, positions_limit=32768, n_fields=1, longest_field_id=0):
+                    positions_sum=None, positions_limit=32768, n_fields=1, longest_field_id=0, ngram_terms=()):
     """index.bin of one shard (commit.rs:264-369 level writer, 467-552 commit_segment, compress_postinglist.rs:339-409
     key head).  One indexed field: terms = [(key_hash with low 3 bits 0, docs ascending, tfs)], doclen_bytes [n_docs].
     Several fields: terms = [(key_hash, docs, fields, tfs)] sorted by (doc, field), doclen_bytes [n_fields][n_docs].
-    ngram_keys: key hashes with NgramType bits set, written as 1-posting keys the reader has to skip.
+    ngram_keys: key hashes with NgramType bits set, written as 1-posting keys (layout irrelevant: for readers that skip).
+    ngram_terms (one field): [(key_hash with its NgramType bits, docs, positions counts, component tfs [n][C], component
+    df bytes [C])] -- real n-gram keys: records carry the component tfs, the head the components' compressed posting
+    counts (posting_count_ngram_i_compressed = int_to_byte4(df), compress_postinglist.rs:28-232, 339-409).
     Segment of a key = (key_hash >> 40) & mask here (the reference uses hash32(term) & mask, tokenizer.rs:660 -- a
     different hash of the same term; readers never rely on it).  max_docid / max_p_docid (a-12 block-max posting) are
     written as 0: the device image derives its own bounds, no reader under test uses them."""
@@ -198,12 +213,20 @@ def write_index_bin(n_docs, doclen_bytes, terms, rng, segment_number_bits=11, ke
     n_levels = (n_docs + 65535) >> 16
     per_term_blocks = []
     for term in terms:
-        assert term[0] & 7 == 0
+        assert term[0] & 7 == 0  # (n-gram keys: ngram_terms)
         if n_fields == 1:
             blocks = encode_term(term[1], term[2], rng, positions_limit=positions_limit)
         else:
             blocks = encode_term_fields(term[1], term[2], term[3], n_fields, longest_field_id, rng, positions_limit)
         per_term_blocks.append({b[0]: b for b in blocks})
+    terms = list(terms)
+    head_extra = [bytes(key_head_size - 20)] * len(terms)
+    for key, docs, counts, comp_tfs, df_bytes in ngram_terms:
+        assert n_fields == 1 and key & 7 and len(df_bytes) == ngram_components(key) <= key_head_size - 20
+        blocks = encode_term(docs, counts, rng, positions_limit=positions_limit, ngram_tfs=np.asarray(comp_tfs))
+        per_term_blocks.append({b[0]: b for b in blocks})
+        terms.append((key,))
+        head_extra.append(bytes(int(x) for x in df_bytes) + bytes(key_head_size - 20 - len(df_bytes)))
     for level in range(n_levels):
         if level == 0:
             out += int(longest_field_id).to_bytes(2, "little")
@@ -214,19 +237,19 @@ def write_index_bin(n_docs, doclen_bytes, terms, rng, segment_number_bits=11, ke
         out += docs_cum.to_bytes(8, "little")
         out += (psum_cum if positions_sum is None or level + 1 < n_levels else positions_sum).to_bytes(8, "little")
         segs = [[] for _ in range(nseg)]
-        for term, blocks in zip(terms, per_term_blocks):
+        for term, blocks, extra in zip(terms, per_term_blocks, head_extra):
             if level in blocks:
-                segs[(term[0] >> 40) & (nseg - 1)].append((term[0], blocks[level]))
+                segs[(term[0] >> 40) & (nseg - 1)].append((term[0], blocks[level], extra))
         if level == 0:
             for key in ngram_keys:
                 assert key & 7
-                segs[(key >> 40) & (nseg - 1)].append((key, None))
+                segs[(key >> 40) & (nseg - 1)].append((key, None, bytes(key_head_size - 20)))
         heads_tbl = bytearray()
         payload = bytearray()
         for seg in segs:
             seg.sort(key=lambda e: e[0])
             heads, bodies = bytearray(), bytearray()
-            for key, blk in seg:
+            for key, blk, extra in seg:
                 if blk is None:  # n-gram key: one posting, doc 0, layout irrelevant to a reader that skips it
                     body, ctp, cnt, pivot = encode_key_body([0], [[1]], base=len(bodies))
                 else:
@@ -234,7 +257,7 @@ def write_index_bin(n_docs, doclen_bytes, terms, rng, segment_number_bits=11, ke
                     _, ctp0, cnt, pivot, body = blk
                     ctp = (ctp0 & 0xC0000000) | ((ctp0 & 0x3FFFFFFF) + len(bodies))
                 h = bytearray(key.to_bytes(8, "little") + (cnt - 1).to_bytes(2, "little") + bytes(4))
-                h += bytes(key_head_size - 20)  # n-gram df bytes (22 / 23 byte heads)
+                h += extra  # n-gram df bytes (22 / 23 byte heads)
                 h += pivot.to_bytes(2, "little") + ctp.to_bytes(4, "little")
                 assert len(h) == key_head_size
                 heads += h

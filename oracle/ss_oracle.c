@@ -588,10 +588,18 @@ uint32_t so_search_lex_exhaustive(const so_shard* s, uint32_t nq, const uint32_t
 uint32_t so_search_lex_exhaustive_not(const so_shard* s, uint32_t nq, const uint32_t* qt, uint32_t n_not,
                                       const uint32_t* not_terms, int op, uint32_t k, uint32_t* od, float* os,
                                       uint64_t* total) {
+  return so_search_lex_exhaustive_idf(s, nq, qt, NULL, n_not, not_terms, op, k, od, os, total);
+}
+/* idf_in != NULL: the idf of every query term is given.  An n-gram key is searched as its component terms -- posting lists
+ * with the same docs and the component's tf -- each with idf_ngram_i from the component TERM's posting count
+ * (search.rs:3231-3262): their sum is the n-gram arm of get_bm25f_multiterm_singlefield (add_result.rs:1454-1477). */
+uint32_t so_search_lex_exhaustive_idf(const so_shard* s, uint32_t nq, const uint32_t* qt, const float* idf_in, uint32_t n_not,
+                                      const uint32_t* not_terms, int op, uint32_t k, uint32_t* od, float* os,
+                                      uint64_t* total) {
   float* sc = (float*)calloc(s->n_docs ? s->n_docs : 1, sizeof(float));
   uint8_t* cnt = (uint8_t*)calloc(s->n_docs ? s->n_docs : 1, 1);
   for (uint32_t t = 0; t < nq; t++) {
-    float idf = so_idf(s->n_docs, s->terms[qt[t]].posting_count);
+    float idf = idf_in ? idf_in[t] : so_idf(s->n_docs, s->terms[qt[t]].posting_count);
     for (uint64_t i = s->off[qt[t]]; i < s->off[qt[t] + 1]; i++) {
       uint32_t d = s->docs[i];
       sc[d] += so_bm25_term(idf, s->tfs[i], s->comp[s->doclen[d]]);

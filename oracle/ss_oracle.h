@@ -86,6 +86,9 @@ uint32_t so_search_lex_not(const so_shard*, uint32_t n_q_terms, const uint32_t* 
 uint32_t so_search_lex_exhaustive_not(const so_shard*, uint32_t n_q_terms, const uint32_t* q_terms, uint32_t n_not,
                                       const uint32_t* not_terms, int op, uint32_t k, uint32_t* out_doc, float* out_score,
                                       uint64_t* out_total);
+uint32_t so_search_lex_exhaustive_idf(const so_shard* s, uint32_t n_query_terms, const uint32_t* query_terms, const float* idf,
+                                      uint32_t n_not, const uint32_t* not_terms, int op, uint32_t k, uint32_t* out_doc,
+                                      float* out_score, uint64_t* total); /* idf given per term (n-gram components) */
 /* brute-force ground truth (independent code path): exhaustive scoring + exact top-k by
  * (score desc, doc asc); also returns the exact match count. */
 uint32_t so_search_lex_exhaustive(const so_shard*, uint32_t n_q_terms, const uint32_t* q_terms, int op,

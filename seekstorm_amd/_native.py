@@ -64,6 +64,8 @@ SYMBOLS = [
     ("ss_index_bin_close", C.c_int, [C.c_void_p]),
     ("ss_index_bin_info", C.c_int, [C.c_void_p, u64p, u64p, u32p, u32p, u32p]),
     ("ss_index_bin_term_keys", C.c_int, [C.c_void_p, u64p]),
+    ("ss_index_bin_term_ngram", C.c_int, [C.c_void_p, u8p, u8p, u32p]),
+    ("ss_ref_decode_block_ngram", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, u16p, u16p]),
     ("ss_index_bin_term_postings", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, u32p, u16p, u64p]),
     ("ss_bm25_upload_index_bin", C.c_int, [C.c_void_p, C.c_void_p]),
     ("ss_bm25_upload_index_bin_fields", C.c_int, [C.c_void_p, C.c_void_p, f32p]),

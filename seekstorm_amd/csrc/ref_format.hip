@@ -10,8 +10,8 @@
 //
 // tf of a posting = positions_count of its pointer (add_result.rs:2036-2197, single indexed field, SingleTerm keys):
 // embedded pointers carry the count in their top bits, the others point backwards into the VINT area whose first
-// value is the count (read_singlefield_value, add_result.rs:2584-2606).  N-gram keys (extra tf values before the
-// count) and multi-field postings are outside this reader: SS_ENOTSUP.
+// value is the count (read_singlefield_value, add_result.rs:2584-2606).  N-gram keys put the tf of each component term
+// before the count (ss_ref_decode_block_ngram); several indexed fields: ss_ref_decode_block_fields below.
 #include <algorithm>
 #include <cstring>
 #include <memory>
@@ -40,9 +40,27 @@ inline bool read_vint(const uint8_t* a, uint64_t len, uint64_t pos, uint32_t* ou
 
 }  // namespace
 
+namespace {
+int decode_block(const ss_ref_block* b, uint32_t n_components, uint32_t component, uint16_t* docs_out, uint16_t* tfs_out);
+}
 // Decodes one block.  docs_out / tfs_out need room for 65 536 entries.  Returns the posting count or a negative code.
 extern "C" int ss_ref_decode_block(const ss_ref_block* b, uint16_t* docs_out, uint16_t* tfs_out) {
+  return decode_block(b, 1, 0, docs_out, tfs_out);
+}
+// The same for a block of an N-GRAM key (NgramType != SingleTerm, index.rs:1854-1872; one indexed field): its postings are
+// never embedded (index_posting.rs:445) and every record starts with the tf of each component term -- 2 for the bigram
+// types, 3 for the trigram types -- before the positions count (decode_positions_multiterm_singlefield,
+// add_result.rs:2074-2089).  tfs_out = tf of component `component` (0-based), which is what the n-gram arms of
+// get_bm25f_multiterm_singlefield (add_result.rs:1454-1477) score with idf_ngram{1,2,3}.
+extern "C" int ss_ref_decode_block_ngram(const ss_ref_block* b, uint32_t n_components, uint32_t component, uint16_t* docs_out,
+                                         uint16_t* tfs_out) {
+  if (n_components < 2 || n_components > 3 || component >= n_components) return SS_EINVAL;
+  return decode_block(b, n_components, component, docs_out, tfs_out);
+}
+namespace {
+int decode_block(const ss_ref_block* b, uint32_t n_components, uint32_t component, uint16_t* docs_out, uint16_t* tfs_out) {
   if (!b || !b->byte_array || !docs_out || !tfs_out) return SS_EINVAL;
+  const bool ngram = n_components > 1;
   const uint8_t* a = b->byte_array;
   const uint64_t len = b->byte_array_len;
   const uint32_t ctype = b->compression_type_pointer >> 30;                 // CompressionType, index.rs:838-843
@@ -89,6 +107,18 @@ extern "C" int ss_ref_decode_block(const ss_ref_block* b, uint16_t* docs_out, ui
     if (docs_out[i] <= docs_out[i - 1]) return SS_EINVAL;
 
   // ---- tf from the rank/position pointers (add_result.rs:2044-2180)
+  // a record behind a non-embedded pointer: [n-gram keys: tf of each component,] positions count, positions
+  auto record_tf = [&](uint64_t back, uint32_t* tf) -> bool {
+    if (back > range) return false;
+    uint64_t pos = range - back;
+    for (uint32_t c = 0; c < (ngram ? n_components : 1u); c++) {
+      uint32_t v;
+      if (!read_vint(a, len, pos, &v)) return false;
+      if (!ngram || c == component) { *tf = v; return true; }
+      pos += a[pos] & 0x80u ? 1u : (a[pos + 1] & 0x80u ? 2u : 3u);
+    }
+    return false;
+  };
   for (uint32_t r = 0; r < count; r++) {
     uint32_t tf = 0;
     if (r < pivot) {
@@ -96,29 +126,30 @@ extern "C" int ss_ref_decode_block(const ss_ref_block* b, uint16_t* docs_out, ui
       if (at + 2u > len) return SS_EINVAL;
       const uint32_t p = rd16(a + at);
       if (p & 0x8000u) {  // embedded: 10 -> one position, 11 -> two
+        if (ngram) return SS_EINVAL;
         const uint32_t tag = p >> 14;
         tf = tag == 2u ? 1u : tag == 3u ? 2u : 0u;
-      } else {
-        const uint64_t back = p & 0x7FFFu;
-        if (back > range || !read_vint(a, len, range - back, &tf)) return SS_EINVAL;
+      } else if (!record_tf(p & 0x7FFFu, &tf)) {
+        return SS_EINVAL;
       }
     } else {
       const uint64_t at = range + (uint64_t)r * 3u - pivot;
       if (at + 3u > len) return SS_EINVAL;
       const uint32_t p = rd24(a + at);
       if (p & 0x800000u) {  // embedded: 100 / 101 / 110 / 111 -> 1..4 positions
+        if (ngram) return SS_EINVAL;
         const uint32_t tag = p >> 21;
         tf = tag >= 4u ? tag - 3u : 0u;
-      } else {
-        const uint64_t back = p & 0x7FFFFFu;
-        if (back > range || !read_vint(a, len, range - back, &tf)) return SS_EINVAL;
+      } else if (!record_tf(p & 0x7FFFFFu, &tf)) {
+        return SS_EINVAL;
       }
     }
-    if (tf == 0u || tf > 65535u) return SS_EINVAL;  // positions_count >= 1 always
+    if (tf == 0u || tf > 65535u) return SS_EINVAL;  // positions_count >= 1 always; component tfs likewise
     tfs_out[r] = (uint16_t)tf;
   }
   return (int)count;
 }
+}  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
 // Several indexed fields: a posting's field vector [(field id, positions_count)], SingleTerm keys
@@ -333,9 +364,12 @@ struct ss_index_bin {
   struct Blk {
     uint64_t key;
     ss_ref_block b;
+    uint8_t n_comp = 1, comp = 0;      // n-gram key: one entry per component term (2 or 3), SingleTerm: 1 / 0
+    uint8_t df_byte = 0;               // posting_count_ngram_{comp+1}_compressed of the key head
   };
-  std::vector<Blk> blocks;             // sorted by (key, block_id)
-  std::vector<uint64_t> keys;          // ascending; term id = index
+  std::vector<Blk> blocks;             // sorted by (key, component, block_id)
+  std::vector<uint64_t> keys;          // ascending; term id = index.  An n-gram key appears once per component, in order
+  std::vector<uint8_t> term_comp, term_ncomp, term_df_byte;  // per term; df byte of the LAST level (commit.rs:646-653)
   std::vector<uint64_t> term_block_off;
 };
 
@@ -383,27 +417,43 @@ extern "C" int ss_index_bin_open(const uint8_t* bytes, uint64_t len, uint32_t in
         const uint64_t key = rd64(h);
         if (i && key <= prev) return SS_EINVAL;  // heads are binary-searched by key_hash (search.rs:2310-2357)
         prev = key;
-        if (key & 7u) { ix->n_ngram_keys++; continue; }  // NgramType != SingleTerm (index.rs:1854-1872)
-        ss_index_bin::Blk e;
-        e.key = key;
-        e.b.block_id = level;
-        e.b.posting_count_m1 = (uint16_t)rd16(h + 8);
-        e.b.pointer_pivot_p_docid = (uint16_t)rd16(h + key_head_size - 6);
-        e.b.compression_type_pointer = rd32(h + key_head_size - 4);
-        e.b.byte_array = body;
-        e.b.byte_array_len = body_len;
-        ix->blocks.push_back(e);
+        // NgramType (index.rs:1854-1872): 0 SingleTerm, 1-3 bigrams, 4-7 trigrams.  An n-gram key is kept as one posting
+        // list per component term (same docs, the component's tf): scored with idf_ngram_i each, their sum is the
+        // n-gram arm of get_bm25f_multiterm_singlefield (add_result.rs:1454-1477).  Several fields: skipped.
+        const uint32_t ntype = (uint32_t)(key & 7u), n_comp = ntype == 0 ? 1u : ntype <= 3u ? 2u : 3u;
+        if (ntype && (indexed_field_count != 1 || n_comp > key_head_size - 20u)) { ix->n_ngram_keys++; continue; }
+        for (uint32_t c = 0; c < n_comp; c++) {
+          ss_index_bin::Blk e;
+          e.key = key;
+          e.n_comp = (uint8_t)n_comp;
+          e.comp = (uint8_t)c;
+          e.df_byte = ntype ? h[14 + c] : (uint8_t)0;
+          e.b.block_id = level;
+          e.b.posting_count_m1 = (uint16_t)rd16(h + 8);
+          e.b.pointer_pivot_p_docid = (uint16_t)rd16(h + key_head_size - 6);
+          e.b.compression_type_pointer = rd32(h + key_head_size - 4);
+          e.b.byte_array = body;
+          e.b.byte_array_len = body_len;
+          ix->blocks.push_back(e);
+        }
       }
       pos += block_length;
     }
     level++;
   }
-  std::stable_sort(ix->blocks.begin(), ix->blocks.end(),
-                   [](const ss_index_bin::Blk& a, const ss_index_bin::Blk& b) { return a.key < b.key; });  // levels stay ascending
+  std::stable_sort(ix->blocks.begin(), ix->blocks.end(), [](const ss_index_bin::Blk& a, const ss_index_bin::Blk& b) {
+    return a.key != b.key ? a.key < b.key : a.comp < b.comp;  // levels stay ascending
+  });
   for (size_t i = 0; i < ix->blocks.size(); i++) {
-    if (i == 0 || ix->blocks[i].key != ix->blocks[i - 1].key) {
-      ix->keys.push_back(ix->blocks[i].key);
+    const ss_index_bin::Blk& e = ix->blocks[i];
+    if (i == 0 || e.key != ix->blocks[i - 1].key || e.comp != ix->blocks[i - 1].comp) {
+      ix->keys.push_back(e.key);
+      ix->term_comp.push_back(e.comp);
+      ix->term_ncomp.push_back(e.n_comp);
+      ix->term_df_byte.push_back(e.df_byte);
       ix->term_block_off.push_back(i);
+    } else {
+      ix->term_df_byte.back() = e.df_byte;
     }
   }
   ix->term_block_off.push_back(ix->blocks.size());
@@ -418,17 +468,20 @@ extern "C" int ss_index_bin_filter(ss_index_bin* ix, uint64_t min_posting_count,
   if (!ix) return SS_EINVAL;
   std::vector<ss_index_bin::Blk> blocks;
   std::vector<uint64_t> keys, off;
+  std::vector<uint8_t> comp, ncomp, dfb;
   for (size_t t = 0; t < ix->keys.size(); t++) {
     uint64_t n = 0;
     for (uint64_t b = ix->term_block_off[t]; b < ix->term_block_off[t + 1]; b++) n += (uint64_t)ix->blocks[b].b.posting_count_m1 + 1u;
-    if (n < min_posting_count) continue;
+    if (n < min_posting_count) continue;  // (the components of an n-gram key have the same count: kept or dropped together)
     keys.push_back(ix->keys[t]);
+    comp.push_back(ix->term_comp[t]); ncomp.push_back(ix->term_ncomp[t]); dfb.push_back(ix->term_df_byte[t]);
     off.push_back(blocks.size());
     for (uint64_t b = ix->term_block_off[t]; b < ix->term_block_off[t + 1]; b++) blocks.push_back(ix->blocks[b]);
   }
   off.push_back(blocks.size());
   ix->blocks.swap(blocks);
   ix->keys.swap(keys);
+  ix->term_comp.swap(comp); ix->term_ncomp.swap(ncomp); ix->term_df_byte.swap(dfb);
   ix->term_block_off.swap(off);
   if (n_terms_kept) *n_terms_kept = (uint32_t)ix->keys.size();
   return SS_OK;
@@ -450,6 +503,20 @@ extern "C" int ss_index_bin_info(const ss_index_bin* ix, uint64_t* n_docs, uint6
   return SS_OK;
 }
 
+// Per term: components of its key (1 = SingleTerm), which component this term is, and for n-gram components the posting
+// count of the component TERM, DOCUMENT_LENGTH_COMPRESSION[posting_count_ngram_i_compressed] (compress_postinglist.rs:105-106,
+// 209-232) -- the df its idf is computed from (search.rs:3231-3262), not the length of the n-gram's own list.
+extern "C" int ss_index_bin_term_ngram(const ss_index_bin* ix, uint8_t* n_components_out, uint8_t* component_out,
+                                       uint32_t* component_df_out) {
+  if (!ix) return SS_EINVAL;
+  for (size_t t = 0; t < ix->keys.size(); t++) {
+    if (n_components_out) n_components_out[t] = ix->term_ncomp[t];
+    if (component_out) component_out[t] = ix->term_comp[t];
+    if (component_df_out) component_df_out[t] = ix->term_ncomp[t] > 1 ? ss_byte4_to_int(ix->term_df_byte[t]) : 0u;
+  }
+  return SS_OK;
+}
+
 extern "C" int ss_index_bin_term_keys(const ss_index_bin* ix, uint64_t* keys_out) {
   if (!ix || !keys_out) return SS_EINVAL;
   std::memcpy(keys_out, ix->keys.data(), ix->keys.size() * sizeof(uint64_t));
@@ -463,7 +530,7 @@ int index_bin_term(const ss_index_bin* ix, uint32_t term, std::vector<uint32_t>&
   if (ix->n_fields != 1) return SS_ENOTSUP;  // BM25F field vectors: SURVEY section 8 f-2
   for (uint64_t bi = ix->term_block_off[term]; bi < ix->term_block_off[term + 1]; bi++) {
     const ss_ref_block& b = ix->blocks[bi].b;
-    const int n = ss_ref_decode_block(&b, d16, t16);
+    const int n = decode_block(&b, ix->blocks[bi].n_comp, ix->blocks[bi].comp, d16, t16);
     if (n < 0) return n;
     for (int i = 0; i < n; i++) {
       const uint64_t doc = ((uint64_t)b.block_id << 16) | d16[i];

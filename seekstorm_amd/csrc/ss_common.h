@@ -22,6 +22,13 @@ constexpr uint32_t VS_CAP = 8192;           // candidate slots per query
 constexpr int VS_FIRST_TILES = 16;          // first chunk: 2048 rows, everything is a candidate (64 tiles: the 8192-entry
                                             // refine after it costs more than the launch it saves)
 
+// SmallFloat decode (DOCUMENT_LENGTH_COMPRESSION[b]), index.rs:4255-4268
+__host__ __device__ inline uint32_t ss_byte4_to_int(uint32_t b) {
+  if (b < 24u) return b;
+  uint32_t i = b - 24u, bits = i & 7u, shift = i >> 3;
+  return shift == 0 ? 24u + bits : 24u + ((bits | 8u) << (shift - 1u));
+}
+
 // ---------------------------------------------------------------- BM25 image geometry
 constexpr int BM_SUB_LOG2 = 12;             // docs per sub-block = 4096 = one wave's 16 KB LDS accumulator tile
                                             // (2048 with 16 waves/CU measured 17% slower: per-item overhead dominates)

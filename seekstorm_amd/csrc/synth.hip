@@ -18,12 +18,6 @@ __host__ __device__ inline u64 ss_splitmix64(u64 x) {
 __host__ __device__ inline u64 ss_h(u64 seed, u64 a, u64 b) {
   return ss_splitmix64(seed ^ (a * 0x9E3779B97F4A7C15ull) ^ (b * 0xC2B2AE3D27D4EB4Full));
 }
-// SmallFloat decode, index.rs:4255-4268
-__host__ __device__ inline uint32_t ss_byte4_to_int(uint32_t b) {
-  if (b < 24u) return b;
-  uint32_t i = b - 24u, bits = i & 7u, shift = i >> 3;
-  return shift == 0 ? 24u + bits : 24u + ((bits | 8u) << (shift - 1u));
-}
 
 // ---------------------------------------------------------------- vectors
 // one thread per row: uniform(-1,1) from the hash, then normalize_f32 semantics (vector_similarity.rs:70-74):

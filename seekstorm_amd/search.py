@@ -139,7 +139,9 @@ def _vector_options(ann_mode, field_filter):
 
 class IndexBin:
     """Parsed view of a shard's index.bin (ss_index_bin_*; host only -- works without a GPU).  Term id = rank of the
-    key_hash among the SingleTerm keys; `term_of_key` is the lookup the Rust side does after hashing the term."""
+    key_hash among the keys; `term_of_key` is the lookup the Rust side does after hashing the term.  An n-gram key
+    (key_hash & 7 != 0) holds one term id per component term, consecutive: `terms_of_key` returns them with the idf each
+    is scored with (idf_ngram_i, search.rs:3231-3262)."""
 
     def __init__(self, data, indexed_field_count=1, key_head_size=20, segment_number_bits=11, min_posting_count=0):
         self._buf = np.frombuffer(bytes(data), np.uint8).copy()  # the handle borrows these bytes
@@ -157,10 +159,28 @@ class IndexBin:
         self.term_keys = np.zeros(self.term_count, np.uint64)
         if self.term_count:
             N.check(N.lib().ss_index_bin_term_keys(h, N.ptr(self.term_keys, N.u64p)), "ss_index_bin_term_keys")
+        self.term_components = np.ones(self.term_count, np.uint8)   # components of the term's key (1 = SingleTerm)
+        self.term_component = np.zeros(self.term_count, np.uint8)   # which of them this term is
+        self.term_component_df = np.zeros(self.term_count, np.uint32)  # posting count of the component term (n-gram keys)
+        if self.term_count:
+            N.check(N.lib().ss_index_bin_term_ngram(h, N.ptr(self.term_components, N.u8p), N.ptr(self.term_component, N.u8p),
+                                                    N.ptr(self.term_component_df, N.u32p)), "ss_index_bin_term_ngram")
 
     def term_of_key(self, key_hash):
+        """term id of a key (first component for an n-gram key), None if the image does not hold it"""
         i = int(np.searchsorted(self.term_keys, np.uint64(key_hash)))
         return i if i < self.term_count and int(self.term_keys[i]) == int(key_hash) else None
+
+    def terms_of_key(self, key_hash):
+        """[(term id, idf)] a query term with this key contributes: one entry with idf None (= from the list's own posting
+        count, as for any term) for a SingleTerm key, one per component with idf_ngram_i for an n-gram key"""
+        t = self.term_of_key(key_hash)
+        if t is None:
+            return None
+        n = int(self.term_components[t])
+        if n == 1:
+            return [(t, None)]
+        return [(t + c, float(idf_f32(self.indexed_doc_count, int(self.term_component_df[t + c])))) for c in range(n)]
 
     def postings(self, term):
         n = C.c_uint64()
@@ -392,8 +412,10 @@ class Shard:
         return out
 
     # ---- query construction: term resolution + idf stay on the host (search.rs:3066-3358)
-    def make_queries(self, term_lists: Sequence[Sequence[int]], query_types, not_lists=None):
-        """query_list (+ not_query_list: the "-term" operands, add_result.rs:3440-3497) of each query -> ss_bm25_query"""
+    def make_queries(self, term_lists: Sequence[Sequence[int]], query_types, not_lists=None, idf_of=None):
+        """query_list (+ not_query_list: the "-term" operands, add_result.rs:3440-3497) of each query -> ss_bm25_query.
+        idf_of: {term id: idf} for the terms whose idf is not that of their own list -- the component terms of an n-gram
+        key (IndexBin.terms_of_key: idf_ngram_i from the component term's posting count)"""
         nq = len(term_lists)
         if not_lists is None:
             not_lists = [()] * nq
@@ -415,7 +437,7 @@ class Shard:
             q["op"][i] = int(qt) | (len(nl) << 8)
             for j, t in enumerate(tl):
                 q["term"][i, j] = t
-                q["idf"][i, j] = idf_f32(self.indexed_doc_count, self._df_cache[t])
+                q["idf"][i, j] = idf_of[t] if idf_of and t in idf_of else idf_f32(self.indexed_doc_count, self._df_cache[t])
             for j, t in enumerate(nl):
                 q["term"][i, len(tl) + j] = t
         return q

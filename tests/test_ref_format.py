@@ -141,32 +141,91 @@ def _corpus(rng, n_docs, dfs):
     return dl, terms
 
 
+def _ngram_terms(rng, n_docs, head, dfs=(2_500, 70_000)):
+    """real n-gram keys: bigram types for 22-byte heads, a trigram type too for 23-byte heads (index.rs:2806-2812)"""
+    from oracle import oracle as O
+    out = []
+    types = [1, 3] if head == 22 else [2, 5]
+    for df, ty in zip(dfs, types):
+        docs = np.sort(rng.choice(n_docs, size=df, replace=False)).astype(np.uint32)
+        counts = np.minimum(rng.geometric(0.6, size=df), 40).astype(np.uint16)          # occurrences of the n-gram itself
+        nc = RF.ngram_components(ty)
+        comp = (counts[:, None] + rng.integers(0, 300, size=(df, nc))).astype(np.uint32)  # each component occurs at least as often
+        comp[rng.integers(0, df, 5), rng.integers(0, nc, 5)] = 20_000                     # 3-byte VINT
+        key = (int(rng.integers(1 << 40, 1 << 62)) & ~7) | ty
+        df_bytes = [O.lib().so_int_to_byte4(int(x)) for x in rng.integers(df, n_docs, nc)]
+        out.append((key, docs, counts, comp, df_bytes))
+    return out
+
+
 @pytest.mark.parametrize("head,bits", [(20, 11), (22, 4), (23, 4)])
 def test_index_bin_walk(head, bits):
+    from oracle import oracle as O
     rng = np.random.default_rng(head)
     n_docs = 150_000  # 3 levels, the last incomplete
     dl, terms = _corpus(rng, n_docs, [40_000, 3_000, 17, 90_000, 1])
-    ngram = [int(k) | 1 for k in rng.integers(1 << 40, 1 << 63, size=3, dtype=np.int64)] if head != 20 else []
-    data = RF.write_index_bin(n_docs, dl, terms, rng, segment_number_bits=bits, key_head_size=head, ngram_keys=ngram)
+    ngram = _ngram_terms(rng, n_docs, head) if head != 20 else []
+    data = RF.write_index_bin(n_docs, dl, terms, rng, segment_number_bits=bits, key_head_size=head, ngram_terms=ngram)
     ix = S.IndexBin(data, 1, head, bits)
-    assert ix.indexed_doc_count == n_docs and ix.level_count == 3 and ix.term_count == len(terms)
-    assert ix.ngram_keys_skipped == len(ngram)
-    assert [int(k) for k in ix.term_keys] == [t[0] for t in terms]
-    for t, (key, docs, tfs) in enumerate(terms):
-        assert ix.term_of_key(key) == t
+    # every key in hash order; an n-gram key once per component term
+    want = sorted([(t[0], 0, 1, t[1], t[2], 0) for t in terms] +
+                  [(g[0], c, len(g[4]), g[1], g[3][:, c], O.lib().so_byte4_to_int(g[4][c])) for g in ngram for c in range(len(g[4]))],
+                  key=lambda e: (e[0], e[1]))
+    assert ix.indexed_doc_count == n_docs and ix.level_count == 3 and ix.term_count == len(want)
+    assert ix.ngram_keys_skipped == 0
+    assert [int(k) for k in ix.term_keys] == [w[0] for w in want]
+    for t, (key, comp, ncomp, docs, tfs, df) in enumerate(want):
+        assert ix.term_of_key(key) == t - comp
+        assert (ix.term_components[t], ix.term_component[t], ix.term_component_df[t]) == (ncomp, comp, df)
         d, f = ix.postings(t)
         assert np.array_equal(d, docs) and np.array_equal(f, tfs)
+    for g in ngram:  # what a query term that resolved to the n-gram contributes: its components with idf_ngram_i
+        t0 = ix.term_of_key(g[0])
+        got = ix.terms_of_key(g[0])
+        assert [t for t, _ in got] == list(range(t0, t0 + len(g[4])))
+        for (t, w), b in zip(got, g[4]):
+            assert w == float(S.idf_f32(n_docs, O.lib().so_byte4_to_int(b)))
+    assert ix.terms_of_key(terms[0][0]) == [(ix.term_of_key(terms[0][0]), None)]
     assert ix.term_of_key(terms[0][0] + 8) is None
     ix.close()
     # frequent terms only: the tail of the vocabulary is dropped and the term ids re-ranked
     ix = S.IndexBin(data, 1, head, bits, min_posting_count=1000)
-    kept = [t for t in terms if len(t[1]) >= 1000]
-    assert ix.term_count == len(kept) == 3 and [int(k) for k in ix.term_keys] == [t[0] for t in kept]
-    for t, (key, docs, tfs) in enumerate(kept):
+    kept = [w for w in want if len(w[3]) >= 1000]
+    assert ix.term_count == len(kept) == 3 + sum(len(g[4]) for g in ngram) and [int(k) for k in ix.term_keys] == [w[0] for w in kept]
+    for t, (key, comp, ncomp, docs, tfs, df) in enumerate(kept):
         d, f = ix.postings(t)
         assert np.array_equal(d, docs) and np.array_equal(f, tfs)
+        assert (ix.term_components[t], ix.term_component[t]) == (ncomp, comp)
     assert all(ix.term_of_key(t[0]) is None for t in terms if len(t[1]) < 1000)
     ix.close()
+
+
+def test_ngram_block_decoder():
+    """records of an n-gram key: component tfs before the positions count, never embedded (index_posting.rs:445, 666-722)"""
+    rng = np.random.default_rng(7)
+    docs = np.sort(rng.choice(65536, size=3000, replace=False))
+    counts = rng.integers(1, 4, size=3000)
+    for nc in (2, 3):
+        comp = rng.integers(1, 1000, size=(3000, nc))
+        comp[:50] = rng.integers(128, 30_000, size=(50, nc))  # 2- and 3-byte values
+        for limit in (32768, 600):                            # 600: most postings behind 3-byte pointers
+            blk = RF.encode_term(docs, counts, rng, positions_limit=limit, ngram_tfs=comp)[0]
+            bid, ctp, cnt, pivot, body = blk
+            assert limit == 32768 or pivot < cnt
+            buf = np.frombuffer(body, np.uint8).copy()
+            rb = N.RefBlock(bid, ctp, cnt - 1, pivot, buf.ctypes.data, len(buf))
+            d = np.zeros(65536, np.uint16)
+            t = np.zeros(65536, np.uint16)
+            for c in range(nc):
+                n = N.lib().ss_ref_decode_block_ngram(C.byref(rb), nc, c, N.ptr(d, N.u16p), N.ptr(t, N.u16p))
+                assert n == 3000 and np.array_equal(d[:n], docs) and np.array_equal(t[:n], comp[:, c])
+            assert N.lib().ss_ref_decode_block_ngram(C.byref(rb), nc, nc, N.ptr(d, N.u16p), N.ptr(t, N.u16p)) < 0
+            assert N.lib().ss_ref_decode_block_ngram(C.byref(rb), 1, 0, N.ptr(d, N.u16p), N.ptr(t, N.u16p)) < 0
+    # a SingleTerm block with embedded pointers is not an n-gram block
+    blk = RF.encode_term([3, 9], [1, 2], rng)[0]
+    buf = np.frombuffer(blk[4], np.uint8).copy()
+    rb = N.RefBlock(blk[0], blk[1], blk[2] - 1, blk[3], buf.ctypes.data, len(buf))
+    assert N.lib().ss_ref_decode_block_ngram(C.byref(rb), 2, 0, N.ptr(d, N.u16p), N.ptr(t, N.u16p)) < 0
 
 
 def test_index_bin_rejects_garbage():
@@ -220,6 +279,63 @@ def test_upload_index_bin_and_vector_bin_answer_like_the_arrays():
     assert np.array_equal(a.read_rows(0, 700), rows)
     a.close()
     b.close()
+
+
+@pytest.mark.gpu
+def test_ngram_keys_of_an_index_bin_score_like_the_reference_arm():
+    """the default index (NgramFF | NgramFFF, 23-byte key heads): a query term that resolved to an n-gram key is searched
+    as the key's component terms with idf_ngram_i -- same matches, score = the n-gram arm of
+    get_bm25f_multiterm_singlefield (add_result.rs:1454-1477)"""
+    from oracle import oracle as O
+    rng = np.random.default_rng(33)
+    n_docs, head = 140_000, 23
+    dl, terms = _corpus(rng, n_docs, [50_000, 8_000, 20_000])
+    ngram = _ngram_terms(rng, n_docs, head, dfs=(6_000, 30_000))
+    data = RF.write_index_bin(n_docs, dl, terms, rng, key_head_size=head, ngram_terms=ngram)
+    ix = S.IndexBin(data, 1, head)
+    sh = S.Shard(0)
+    sh.upload_index_bin(ix)
+    # the oracle sees one posting list per device term: single terms as they are, n-gram keys as their components
+    lists = []
+    for t in range(ix.term_count):
+        d, f = ix.postings(t)
+        lists.append((d, f))
+    offs = np.zeros(len(lists) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(l[0]) for l in lists])
+    osh = O.Shard(n_docs, dl, offs, np.concatenate([l[0] for l in lists]), np.concatenate([l[1] for l in lists]))
+    single = [ix.term_of_key(t[0]) for t in terms]
+    grams = [ix.terms_of_key(g[0]) for g in ngram]
+    assert [len(g) for g in grams] == [2, 3]
+    for qt, op, keys in ((S.QueryType.Union, O.OP_OR, [grams[0], [(single[0], None)]]),
+                         (S.QueryType.Intersection, O.OP_AND, [grams[1], [(single[0], None)]]),
+                         (S.QueryType.Union, O.OP_OR, [grams[1]]),
+                         (S.QueryType.Intersection, O.OP_AND, [grams[0], grams[1], [(single[2], None)]])):
+        tl = [t for g in keys for t, _ in g]
+        idf_of = {t: w for g in keys for t, w in g if w is not None}
+        idf = [idf_of.get(t, float(S.idf_f32(n_docs, len(lists[t][0])))) for t in tl]
+        doc, score, cnt, tot = sh.search_lexical_batch(sh.make_queries([tl], qt, idf_of=idf_of), 10)
+        od, os_, otot = osh.search_exhaustive(tl, op, 10, idf=idf)
+        n = int(cnt[0])
+        assert int(tot[0]) == otot and n == len(od)
+        assert np.allclose(score[0][:n], os_, rtol=1e-4)
+        assert {int(x) for x, y in zip(doc[0][:n], score[0]) if y > os_[-1] * (1 + 1e-4)} == \
+               {int(x) for x, y in zip(od, os_) if y > os_[-1] * (1 + 1e-4)}
+    # the arm itself, by hand, for the best hit of the lone trigram query
+    tl = [t for t, _ in grams[1]]
+    idf_of = dict(grams[1])
+    doc, score, cnt, tot = sh.search_lexical_batch(sh.make_queries([tl], S.QueryType.Union, idf_of=idf_of), 1)
+    d0 = int(doc[0][0])
+    comp = np.zeros(256, np.float32)
+    O.lib().so_bm25_component_cache(osh.avgdl() if callable(osh.avgdl) else osh.avgdl, comp.ctypes.data_as(C.POINTER(C.c_float)))
+    g = ngram[1]
+    r = int(np.searchsorted(g[1], d0))
+    want = np.float32(0)
+    for c in range(3):
+        tf = np.float32(g[3][r, c])
+        want += np.float32(idf_of[tl[c]]) * (tf * np.float32(2.2) / (tf + comp[dl[d0]]))
+    assert abs(float(want) - float(score[0][0])) <= 1e-4 * float(want)
+    sh.close()
+    ix.close()
 
 
 @pytest.mark.gpu
