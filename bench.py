@@ -330,6 +330,38 @@ def main():
             assert np.all(v_cnt.cpu().numpy().astype(np.int64) == kv), "ANN candidate overflow or short result in bench"
             return {"mode": "Nprobe(16) of 256 clusters per level", "clusters_visited_per_query": int(v_ncl[0].item()),
                     "single_query_ms_p50": pct(l1, 50), "batch64_ms_p50": pct(l64, 50)}
+        # ---- C4 hybrid: query i of C2 paired with query i of C3, each side top-100, RRF(0.6), final top-100 --
+        # lexical search, vector search and the fusion of the whole batch on the device, nothing crosses PCIe in between
+        if bm is not None and world == 1:
+            kh = 100
+            h_ldoc = torch.empty((B, kh), dtype=torch.int32, device=dev); h_lsc = torch.empty((B, kh), dtype=torch.float32, device=dev)
+            h_lcnt = torch.empty((B,), dtype=torch.int32, device=dev); h_ltot = torch.empty((B,), dtype=torch.int64, device=dev)
+            h_doc = torch.empty((B, kh), dtype=torch.int64, device=dev); h_sc = torch.empty((B, kh), dtype=torch.float32, device=dev)
+            h_src = torch.empty((B, kh), dtype=torch.uint8, device=dev); h_cnt = torch.empty((B,), dtype=torch.int32, device=dev)
+            sh.set_strategy(N.BM25_AUTO)
+            def hyb_step():
+                N.check(L.ss_bm25_search_dev(sh._h, B, q_dev.data_ptr(), kh, N.RT_TOPK, 2 | (3 << 8), h_ldoc.data_ptr(), h_lsc.data_ptr(),
+                                             h_lcnt.data_ptr(), h_ltot.data_ptr(), sptr), "ss_bm25_search_dev")
+                N.check(L.ss_vec_search_dev(sh._h, B, qv.data_ptr(), kv, N.FLT_MIN_NEG, v_doc.data_ptr(), v_score.data_ptr(),
+                                            v_cnt.data_ptr(), v_tot.data_ptr(), sptr), "ss_vec_search_dev")
+                N.check(L.ss_rrf_merge_dev(local_rank, B, kh, h_ldoc.data_ptr(), h_lcnt.data_ptr(), kv, v_doc.data_ptr(), v_cnt.data_ptr(), 0,
+                                           0, kh, h_doc.data_ptr(), h_sc.data_ptr(), h_src.data_ptr(), h_cnt.data_ptr(), sptr),
+                        "ss_rrf_merge_dev")
+            hyb_step()
+            torch.cuda.synchronize()
+            # against the host fusion of the same lists (ss_merge_results, the reference's RRF restated on the CPU side)
+            for qi in (0, B - 1):
+                nl_, nv_ = int(h_lcnt[qi].item()), int(v_cnt[qi].item())
+                hd, hs, hsrc = S.merge_results(S.SearchMode.Hybrid,
+                                               (h_ldoc[qi, :nl_].cpu().numpy().astype(np.uint64), h_lsc[qi, :nl_].cpu().numpy()),
+                                               (v_doc[qi, :nv_].cpu().numpy().astype(np.uint64), v_score[qi, :nv_].cpu().numpy()), 0, kh)
+                n_ = int(h_cnt[qi].item())
+                assert n_ == len(hd) and np.array_equal(h_doc[qi, :n_].cpu().numpy().astype(np.uint64), hd)
+                assert np.array_equal(h_sc[qi, :n_].cpu().numpy(), hs), "device RRF differs from ss_merge_results"
+            hsteps = max(4, args.steps // 4)
+            dth = timed(hyb_step, hsteps, 1)
+            vec["hybrid"] = {"workload": "C4: C2 query i + C3 query i, top-100 each, RRF(0.6), final top-100; batch 64, all on device",
+                             "value": B * hsteps / dth, "unit": "queries/s", "ms_per_step": dth / hsteps * 1e3}
         if args.rows >= 65536:
             vec["ann"] = ann_leg(False)
         # property checks at full size: sorted, and the scores really are dot products of the returned rows
@@ -427,7 +459,8 @@ def main():
             line["vector"] = {"metric": "queries/sec (cosine top-100, 10M x 768 f32, batch 64)", "value": vec["qps"] * world,
                               "global_qps": vec["qps"], "ms_per_step": vec["ms_per_step"], "roofline": vec["roofline"],
                               "cpu_baseline": vec.get("cpu_baseline"), "latency_ms": vec["latency_ms"], "build_s": vec["build_s"],
-                              "rows_per_shard": args.rows, "dim": args.dim, "ann": vec.get("ann"), "i8": vec.get("i8")}
+                              "rows_per_shard": args.rows, "dim": args.dim, "hybrid": vec.get("hybrid"), "ann": vec.get("ann"),
+                              "i8": vec.get("i8")}
         elif vec is not None:
             line["i8"] = vec.get("i8")
         print(json.dumps(line), flush=True)

@@ -297,6 +297,18 @@ int ss_topk_merge_dev(int device, uint32_t n_queries, uint32_t n_shards, uint32_
  * 32-bit words -- a single all-gather per batch (latency bound: three collectives cost three latencies) */
 int ss_topk_merge_dev_packed(int device, uint32_t n_queries, uint32_t n_shards, uint32_t k, const uint32_t* d_packed,
                              uint64_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, void* stream);
+/* Hybrid fusion of a query batch on the device: RRF (k = 0.6, 0-based ranks, search.rs:1962-2035) of the lexical and the
+ * vector list of every query, then sort / offset / length (2098-2119) -- ss_merge_results(SS_MODE_HYBRID) for n_queries
+ * queries without a host round trip.  d_lex_doc [n_queries][k_lex] and d_vec_doc [n_queries][k_vec] are the doc-id
+ * outputs of ss_bm25_search_dev / ss_vec_search*_dev (u32 shard-local ids, doc_ids_are_u64 = 0) or of ss_topk_merge_dev*
+ * (u64 global ids, = 1), with their counts; both sorted by score descending with unique ids (the scores themselves are not
+ * needed: only ranks enter the fusion).  Outputs [n_queries][length]: doc (UINT64_MAX = unused), fused score,
+ * source (SS_SRC_*, may be NULL), count.  Equal fused scores: doc id ascending.  k_lex + k_vec <= 4096; k_lex = 0 or
+ * k_vec = 0 leaves the other list's ranks as scores. */
+int ss_rrf_merge_dev(int device, uint32_t n_queries, uint32_t k_lex, const void* d_lex_doc, const uint32_t* d_lex_count,
+                     uint32_t k_vec, const void* d_vec_doc, const uint32_t* d_vec_count, int doc_ids_are_u64, uint32_t offset,
+                     uint32_t length, uint64_t* d_out_doc, float* d_out_score, uint8_t* d_out_source, uint32_t* d_out_count,
+                     void* stream);
 
 /* ------------------------------------------------------------------ measurement hooks
  * When enabled the library brackets every launch of the dominant kernels with HIP events on the stream

@@ -110,6 +110,8 @@ SYMBOLS = [
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("ss_topk_merge_dev_packed", C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p]),
+    ("ss_rrf_merge_dev", C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int,
+                                   C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("ss_profile_enable", C.c_int, [C.c_void_p, C.c_int]),
     ("ss_profile_read", C.c_int, [C.c_void_p, C.c_int, u64p, C.POINTER(C.c_double), C.c_int]),
 ]

@@ -106,3 +106,110 @@ extern "C" int ss_topk_merge_dev_packed(int device, uint32_t n_queries, uint32_t
   SS_HIP(hipGetLastError());
   return SS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Hybrid fusion on device: reciprocal rank fusion of a batch's lexical and vector result lists (search.rs:1962-2035) and
+// the final sort / offset / length (2098-2119), so that a batched hybrid search never leaves the GPU between the two
+// shard searches and its answer.  score(d) = sum over the lists holding d of 1 / (0.6 + rank), rank 0-based in the list;
+// a doc of both lists is `Hybrid`, of one list keeps that list's source.  Equal fused scores: doc id ascending (the
+// reference leaves them in hash order), as ss_merge_results does.  One workgroup per query; the union of the two lists
+// (<= 4096 entries) lives in LDS: match the vector entries against the lexical ones, bitonic sort by (score desc, doc asc).
+// Both lists must be sorted by score descending with unique doc ids -- what the searches and merges above produce.
+__global__ void __launch_bounds__(256) rrf_merge_kernel(uint32_t k_lex, uint32_t k_vec, const void* __restrict__ lex_doc,
+                                                       const uint32_t* __restrict__ lex_cnt, const void* __restrict__ vec_doc,
+                                                       const uint32_t* __restrict__ vec_cnt, int wide_ids, uint32_t offset,
+                                                       uint32_t length, u64* __restrict__ out_doc, float* __restrict__ out_score,
+                                                       uint8_t* __restrict__ out_src, uint32_t* __restrict__ out_cnt, uint32_t np) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u64* docs = (u64*)smem;
+  float* sc = (float*)(docs + np);
+  uint8_t* src = (uint8_t*)(sc + np);
+  const uint32_t q = blockIdx.x;
+  uint32_t nl = lex_doc ? lex_cnt[q] : 0u, nv = vec_doc ? vec_cnt[q] : 0u;
+  if (nl == 0xFFFFFFFFu) nl = 0;  // an overflowed vector batch (ss_vec_search_dev) carries no list
+  if (nv == 0xFFFFFFFFu) nv = 0;
+  nl = nl < k_lex ? nl : k_lex;
+  nv = nv < k_vec ? nv : k_vec;
+  auto id_at = [&](const void* base, size_t i) -> u64 {
+    return wide_ids ? ((const u64*)base)[i] : (u64)((const uint32_t*)base)[i];
+  };
+  for (uint32_t i = threadIdx.x; i < np; i += blockDim.x) {
+    u64 d = ~0ull;
+    float s = -INFINITY;
+    uint8_t so = 0;
+    if (i < nl) {
+      d = id_at(lex_doc, (size_t)q * k_lex + i);
+      s = __fdiv_rn(1.0f, __fadd_rn(0.6f, (float)i));
+      so = SS_SRC_LEXICAL;
+    } else if (i < nl + nv) {
+      d = id_at(vec_doc, (size_t)q * k_vec + (i - nl));
+      s = __fdiv_rn(1.0f, __fadd_rn(0.6f, (float)(i - nl)));
+      so = SS_SRC_VECTOR;
+    }
+    docs[i] = d; sc[i] = s; src[i] = so;
+  }
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j < nv; j += blockDim.x) {  // a vector entry whose doc is in the lexical list joins it
+    const u64 d = docs[nl + j];
+    for (uint32_t i = 0; i < nl; i++) {
+      if (docs[i] == d) {
+        sc[i] = __fadd_rn(sc[i], sc[nl + j]);
+        src[i] = SS_SRC_HYBRID;
+        docs[nl + j] = ~0ull;
+        sc[nl + j] = -INFINITY;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t size = 2; size <= np; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      for (uint32_t i = threadIdx.x; i < (np >> 1); i += blockDim.x) {
+        const uint32_t lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+        const bool first = ((lo & size) == 0);  // this pair is in a run sorted "best first"
+        const float sa = sc[lo], sb = sc[hi];
+        const u64 da = docs[lo], db = docs[hi];
+        const bool a_before_b = sa > sb || (sa == sb && da < db);
+        const bool same = sa == sb && da == db;
+        if (!same && a_before_b != first) {
+          sc[lo] = sb; sc[hi] = sa; docs[lo] = db; docs[hi] = da;
+          const uint8_t t = src[lo]; src[lo] = src[hi]; src[hi] = t;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  __shared__ uint32_t written;
+  if (threadIdx.x == 0) written = 0;
+  __syncthreads();
+  uint32_t local = 0;
+  for (uint32_t i = threadIdx.x; i < length; i += blockDim.x) {
+    const uint32_t at = offset + i;
+    const bool live = at < np && docs[at] != ~0ull;
+    out_doc[(size_t)q * length + i] = live ? docs[at] : ~0ull;
+    out_score[(size_t)q * length + i] = live ? sc[at] : 0.f;
+    if (out_src) out_src[(size_t)q * length + i] = live ? src[at] : (uint8_t)0;
+    local += live ? 1u : 0u;
+  }
+  if (local) atomicAdd(&written, local);
+  __syncthreads();
+  if (threadIdx.x == 0) out_cnt[q] = written;
+}
+
+extern "C" int ss_rrf_merge_dev(int device, uint32_t n_queries, uint32_t k_lex, const void* d_lex_doc, const uint32_t* d_lex_count,
+                                uint32_t k_vec, const void* d_vec_doc, const uint32_t* d_vec_count, int doc_ids_are_u64,
+                                uint32_t offset, uint32_t length, uint64_t* d_out_doc, float* d_out_score, uint8_t* d_out_source,
+                                uint32_t* d_out_count, void* stream) {
+  if ((k_lex && (!d_lex_doc || !d_lex_count)) || (k_vec && (!d_vec_doc || !d_vec_count))) return SS_EINVAL;
+  if (!d_out_doc || !d_out_score || !d_out_count || length == 0) return SS_EINVAL;
+  if ((uint64_t)k_lex + k_vec == 0 || (uint64_t)k_lex + k_vec > 4096) return SS_EINVAL;
+  if (n_queries == 0) return SS_OK;
+  SS_HIP(hipSetDevice(device));
+  uint32_t np = 64;
+  while (np < k_lex + k_vec) np <<= 1;
+  rrf_merge_kernel<<<n_queries, 256, (size_t)np * 13u, (hipStream_t)stream>>>(
+      k_lex, k_vec, k_lex ? d_lex_doc : nullptr, d_lex_count, k_vec ? d_vec_doc : nullptr, d_vec_count, doc_ids_are_u64 ? 1 : 0,
+      offset, length, (u64*)d_out_doc, d_out_score, d_out_source, d_out_count, np);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}

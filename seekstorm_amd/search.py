@@ -547,6 +547,28 @@ def merge_results(mode, lex=None, vec=None, offset=0, length=10):
     return od[:n].copy(), os_[:n].copy(), src[:n].copy()
 
 
+def rrf_merge_device(lex_doc, lex_count, vec_doc, vec_count, offset, length, stream, device=0):
+    """ss_rrf_merge_dev on torch tensors already on `device`: [nq][k_lex] / [nq][k_vec] doc ids (int32 shard-local or int64
+    global) + counts -> (doc int64 [nq][length], fused score, source uint8, count int32).  Either list may be None."""
+    import torch
+    ref = lex_doc if lex_doc is not None else vec_doc
+    nq = ref.shape[0]
+    wide = ref.dtype == torch.int64
+    dev = ref.device
+    od = torch.empty((nq, length), dtype=torch.int64, device=dev)
+    os_ = torch.empty((nq, length), dtype=torch.float32, device=dev)
+    src = torch.empty((nq, length), dtype=torch.uint8, device=dev)
+    cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
+    kl = 0 if lex_doc is None else lex_doc.shape[1]
+    kv = 0 if vec_doc is None else vec_doc.shape[1]
+    N.check(N.lib().ss_rrf_merge_dev(device, nq, kl, None if lex_doc is None else lex_doc.data_ptr(),
+                                     None if lex_doc is None else lex_count.data_ptr(), kv,
+                                     None if vec_doc is None else vec_doc.data_ptr(),
+                                     None if vec_doc is None else vec_count.data_ptr(), 1 if wide else 0, int(offset), int(length),
+                                     od.data_ptr(), os_.data_ptr(), src.data_ptr(), cnt.data_ptr(), stream), "ss_rrf_merge_dev")
+    return od, os_, src, cnt
+
+
 class Index:
     """In-process multi-shard index: doc g lives in shard g % S with local id g // S (index.rs:5284)."""
 

@@ -341,6 +341,51 @@ def test_device_merge_matches_host_merge(S, O):
         assert np.all(md[q, n:] == -1)
 
 
+@pytest.mark.parametrize("wide", [False, True], ids=["u32", "u64"])
+def test_device_rrf_matches_host_rrf(S, O, wide):
+    """ss_rrf_merge_dev == ss_merge_results(Hybrid) per query: fused scores bit for bit, sources, order (ties by doc id),
+    offset / length; also with one list empty or absent"""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(9)
+    nq, kl, kv = 23, 100, 100
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    idt = np.int64 if wide else np.int32
+    hi = (1 << 40) if wide else 400
+    ld = np.zeros((nq, kl), idt); vd = np.zeros((nq, kv), idt)
+    lc = rng.integers(0, kl + 1, nq).astype(np.int32); vc = rng.integers(0, kv + 1, nq).astype(np.int32)
+    lc[0], vc[0] = 0, 0
+    lc[1], vc[1] = kl, 0
+    lc[2], vc[2] = 0, kv
+    for q in range(nq):
+        pool = rng.choice(400, 150, replace=False).astype(np.int64) * (hi // 400)   # small pool: many docs in both lists
+        ld[q] = rng.permutation(pool)[:kl]
+        vd[q] = rng.permutation(pool)[:kv]
+    ls = np.sort(rng.random((nq, kl)).astype(np.float32), axis=1)[:, ::-1]
+    vs = np.sort(rng.random((nq, kv)).astype(np.float32), axis=1)[:, ::-1]
+    with torch.cuda.stream(st):
+        t = [torch.from_numpy(x).to(dev) for x in (ld, lc, vd, vc)]
+        for offset, length in ((0, 100), (7, 30), (0, 250), (190, 20)):
+            od, os_, src, cnt = S.rrf_merge_device(t[0], t[1], t[2], t[3], offset, length, C.c_void_p(st.cuda_stream))
+            st.synchronize()
+            od, os_, src, cnt = od.cpu().numpy(), os_.cpu().numpy(), src.cpu().numpy(), cnt.cpu().numpy()
+            for q in range(nq):
+                hd, hs, hsrc = S.merge_results(S.SearchMode.Hybrid, (ld[q, :lc[q]].astype(np.uint64), ls[q, :lc[q]]),
+                                               (vd[q, :vc[q]].astype(np.uint64), vs[q, :vc[q]]), offset, length)
+                n = int(cnt[q])
+                assert n == len(hd)
+                assert np.array_equal(od[q, :n].astype(np.uint64), hd) and np.array_equal(os_[q, :n], hs)
+                assert np.array_equal(src[q, :n], hsrc) and np.all(od[q, n:] == -1)
+        # a list that is absent altogether: the other one's ranks
+        od, os_, src, cnt = S.rrf_merge_device(None, None, t[2], t[3], 0, 10, C.c_void_p(st.cuda_stream))
+        st.synchronize()
+        q = 5
+        n = min(10, int(vc[q]))
+        assert int(cnt[q]) == n and np.array_equal(od[q, :n].cpu().numpy(), vd[q, :n].astype(np.int64))
+        assert np.all(src[q, :n].cpu().numpy() == int(S.ResultSource.Vector))
+
+
 def test_deleted_docs_lexical_both_strategies(S, O, lex):
     """delete_hashset (add_result.rs:3435, union.rs:975): a tombstoned doc neither counts nor ranks, in any result type,
     under the exhaustive and the pruned strategy; clearing the set restores the answers."""
