@@ -50,6 +50,7 @@ Shard::~Shard() {
 int Shard::upload_lexical(uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t n_terms, const uint64_t* term_offsets,
                           const uint32_t* doc_ids, const uint16_t* tfs) {
   if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
+  ngram_components_.clear(); ngram_component_df_.clear();  // a new image: no index.bin n-gram keys behind the term ids
   const int rc = ss_bm25_upload(h_, n_docs, doclen_bytes, n_terms, term_offsets, doc_ids, tfs);
   n_docs_ = rc == SS_OK ? n_docs : 0;
   return rc;
@@ -59,6 +60,7 @@ int Shard::upload_lexical_fields(uint64_t n_docs, uint32_t n_fields, const uint8
                                  const uint64_t* term_offsets, const uint32_t* doc_ids, const uint8_t* field_ids,
                                  const uint16_t* tfs) {
   if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
+  ngram_components_.clear(); ngram_component_df_.clear();  // a new image: no index.bin n-gram keys behind the term ids
   const int rc = ss_bm25_upload_fields(h_, n_docs, n_fields, doclen_bytes, boost, n_terms, term_offsets, doc_ids, field_ids, tfs);
   n_docs_ = rc == SS_OK ? n_docs : 0;
   return rc;
@@ -85,9 +87,15 @@ int Shard::open_index_bin(const uint8_t* bytes, uint64_t len, uint32_t key_head_
     term_keys->assign(n_terms, 0);
     if (n_terms) ss_index_bin_term_keys(ix, term_keys->data());
   }
+  // n-gram keys: one term id per component; a component's idf comes from the component TERM's posting count in the key
+  // head, not from the n-gram's own list (search.rs:3231-3262) -- remembered here, applied by make_query
+  ngram_components_.assign(n_terms, 1);
+  ngram_component_df_.assign(n_terms, 0);
+  if (n_terms) ss_index_bin_term_ngram(ix, ngram_components_.data(), nullptr, ngram_component_df_.data());
   rc = ss_bm25_upload_index_bin(h_, ix);
   ss_index_bin_close(ix);
   n_docs_ = rc == SS_OK ? n_docs : 0;
+  if (rc != SS_OK) { ngram_components_.clear(); ngram_component_df_.clear(); }
   return rc;
 }
 
@@ -120,6 +128,7 @@ int Shard::set_deleted(const uint64_t* doc_ids, uint64_t n) {
 int Shard::synth_lexical(uint64_t seed, uint64_t n_docs, uint32_t n_terms, const uint32_t* thresh32,
                          const uint8_t* len_table1024) {
   if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
+  ngram_components_.clear(); ngram_component_df_.clear();  // a new image: no index.bin n-gram keys behind the term ids
   const int rc = ss_bm25_synth(h_, seed, n_docs, n_terms, thresh32, len_table1024);
   n_docs_ = rc == SS_OK ? n_docs : 0;
   return rc;
@@ -151,7 +160,8 @@ int Shard::make_query(const std::vector<uint32_t>& terms, QueryType qt, ss_bm25_
   out->op = (uint32_t)qt | SS_OP_NOT_TERMS(nots.size());
   for (size_t i = 0; i < uniq.size(); i++) {
     out->term[i] = uniq[i];
-    out->idf[i] = idf(n_docs_, df[i]);
+    const bool ngram = uniq[i] < ngram_components_.size() && ngram_components_[uniq[i]] > 1;
+    out->idf[i] = idf(n_docs_, ngram ? ngram_component_df_[uniq[i]] : df[i]);  // idf_ngram_i for a component of an n-gram key
   }
   for (size_t i = 0; i < nots.size(); i++) out->term[uniq.size() + i] = nots[i];
   return SS_OK;

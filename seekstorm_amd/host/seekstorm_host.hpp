@@ -92,7 +92,9 @@ class Shard {
   int upload_lexical_fields(uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen_bytes, const float* boost, uint32_t n_terms,
                             const uint64_t* term_offsets, const uint32_t* doc_ids, const uint8_t* field_ids, const uint16_t* tfs);
   int upload_vectors(uint64_t n_rows, uint32_t dim, const float* rows, const uint32_t* row_doc_ids);
-  // shard files as the reference writes them: index.bin (single indexed field), vector.bin (f32), delete.bin
+  // shard files as the reference writes them: index.bin (single indexed field), vector.bin (f32), delete.bin.
+  // term_keys: key_hash of every term id, ascending; an n-gram key (key_hash & 7 != 0) holds one id per component term,
+  // consecutive -- a query term that resolved to it is passed as those ids (make_query applies idf_ngram_i)
   int open_index_bin(const uint8_t* bytes, uint64_t len, uint32_t key_head_size, std::vector<uint64_t>* term_keys);
   int open_vector_bin(const uint8_t* bytes, uint64_t len, uint32_t dim, bool i8 = false, bool use_record_scale = false);
   // Precision::I8 records; queries given as f32 are quantised with quantize_f32_to_i8 like the reference's
@@ -135,6 +137,8 @@ class Shard {
   uint64_t n_docs_ = 0, n_rows_ = 0;
   uint32_t dim_ = 0;
   bool i8_ = false;
+  std::vector<uint8_t> ngram_components_;      // per term id of an opened index.bin: components of its key (1 = SingleTerm)
+  std::vector<uint32_t> ngram_component_df_;   // posting count of the component term (n-gram components)
 };
 
 // In-process multi-shard index: doc g lives in shard g % S with local id g / S (index.rs:5284).

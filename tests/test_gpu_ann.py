@@ -346,3 +346,23 @@ def test_vector_bin_field_ids_feed_the_filter(S, O):
         assert cnt[i] == len(od) and np.allclose(score[i][:cnt[i]], os_, rtol=REL, atol=2e-6)
         assert all(rf[int(d)] == 1 for d in doc[i][:cnt[i]])
     sh.close()
+
+
+def test_ann_many_clusters_per_level_take_the_slow_selection(S, O):
+    """more clusters in a level than the LDS selection holds (4096), and an n_probe beyond its TopK array (1024): the
+    thread-per-level replay serves them -- same clusters as the oracle"""
+    rng = np.random.default_rng(101)
+    dim, C = 32, 5000
+    child = rng.integers(1, 4, C).astype(np.uint32)
+    rows32 = l2(rng.standard_normal((int(child.sum()), dim)).astype(np.float32))
+    rows = O.quantize_i8(rows32)
+    qs = O.quantize_i8(queries_near(O, rows32, 102, 6))
+    sh = S.Shard(0)
+    sh.upload_vectors_i8(rows)
+    sh.set_clusters([C], child)
+    for n_probe in (10, 2000):
+        doc, score, cnt, tot, ncl = sh.search_vector_batch_i8(qs, 20, ann_mode=S.AnnMode.Nprobe(n_probe), with_clusters=True)
+        for i in range(len(qs)):
+            od, os_, _, _, oncl = O.vec_search_i8_ann(rows, qs[i], 20, [C], child, n_probe=n_probe)
+            assert ncl[i] == oncl == n_probe and cnt[i] == len(od) and np.array_equal(score[i][:cnt[i]], os_)
+    sh.close()
