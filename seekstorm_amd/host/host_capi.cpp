@@ -61,6 +61,16 @@ int ssh_upload_vectors(ssh_index* ix, int shard, uint64_t n_rows, uint32_t dim, 
   return ix->shards[shard]->upload_vectors(n_rows, dim, rows, ids);
 }
 
+// Shard::open_index_bin; returns the number of terms (term ids) or a negative code; keys_out [cap] = their key hashes
+int ssh_open_index_bin(ssh_index* ix, int shard, const uint8_t* bytes, uint64_t len, uint32_t key_head_size, uint64_t* keys_out,
+                       uint32_t cap) {
+  std::vector<uint64_t> keys;
+  const int rc = ix->shards[shard]->open_index_bin(bytes, len, key_head_size, &keys);
+  if (rc) return rc;
+  for (size_t i = 0; i < keys.size() && i < cap; i++) keys_out[i] = keys[i];
+  return (int)keys.size();
+}
+
 // Index::search; returns the number of results written (<= cap)
 int ssh_search(ssh_index* ix, const uint32_t* terms, uint32_t n_terms, const float* query_vector, uint32_t query_type,
                int search_mode, uint32_t offset, uint32_t length, uint32_t result_type, int has_threshold, float threshold,

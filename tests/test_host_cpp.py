@@ -51,6 +51,7 @@ def H():
     L.ssh_quantize_f32_to_i8.argtypes = [f32p, C.c_uint64, C.c_void_p]
     L.ssh_coalesced_lexical_search.argtypes = [C.c_void_p, C.c_int, C.c_uint32, u32p, u32p, u32p, u32p, C.c_uint32, C.c_uint32,
                                                C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u64p, f32p, u32p, u64p]
+    L.ssh_open_index_bin.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, u64p, C.c_uint32]
     L.ssh_set_clusters.argtypes = [C.c_void_p, C.c_int, C.c_uint32, u32p, C.c_uint32, u32p]
     L.ssh_search_vector_shard_ann.argtypes = [C.c_void_p, C.c_int, f32p, C.c_uint32, C.c_int, C.c_uint32, C.c_float, C.c_uint32,
                                               u64p, f32p, u64p, u64p]
@@ -286,3 +287,43 @@ def test_cpp_shard_ann_modes(H):
         assert int(meta[3]) != 0
     finally:
         H.ssh_index_destroy(ix)
+
+
+@pytest.mark.gpu
+def test_cpp_shard_opens_an_index_bin_with_ngram_keys(H):
+    """Shard::open_index_bin on a default-style index (23-byte key heads, bigram + trigram keys): term ids in key order, an
+    n-gram key as consecutive component ids, and make_query scoring the components with idf_ngram_i (search.rs:3231-3262)"""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from oracle import oracle as O, ref_format as RF
+    from test_ref_format import _corpus, _ngram_terms
+    import seekstorm_amd as S
+    rng = np.random.default_rng(44)
+    n_docs, head = 100_000, 23
+    dl, terms = _corpus(rng, n_docs, [30_000, 4_000])
+    ngram = _ngram_terms(rng, n_docs, head, dfs=(5_000, 20_000))
+    data = np.frombuffer(RF.write_index_bin(n_docs, dl, terms, rng, key_head_size=head, ngram_terms=ngram), np.uint8).copy()
+    pix = S.IndexBin(data.tobytes(), 1, head)   # the same walk through the Python mirror: lists for the oracle
+    lists = [pix.postings(t) for t in range(pix.term_count)]
+    offs = np.zeros(len(lists) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(l[0]) for l in lists])
+    osh = O.Shard(n_docs, dl, offs, np.concatenate([l[0] for l in lists]), np.concatenate([l[1] for l in lists]))
+    ix = H.ssh_index_create(1, None)
+    try:
+        keys = np.zeros(64, np.uint64)
+        nt = H.ssh_open_index_bin(ix, 0, data.ctypes.data, len(data), head, P(keys, u64p), 64)
+        assert nt == pix.term_count == 2 + 2 + 3 and np.array_equal(keys[:nt], pix.term_keys)
+        tri = pix.terms_of_key(ngram[1][0])
+        single = pix.term_of_key(terms[0][0])
+        tl = [t for t, _ in tri] + [single]
+        idf = [w for _, w in tri] + [float(S.idf_f32(n_docs, len(lists[single][0])))]
+        for qt, op in ((1, O.OP_OR), (0, O.OP_AND)):  # SS_OP_UNION = 1, SS_OP_INTERSECTION = 0
+            t = np.ascontiguousarray(tl, np.uint32)
+            doc = np.zeros(10, np.uint64); sc = np.zeros(10, np.float32); meta = np.zeros(4, np.uint64)
+            n = H.ssh_search_lexical_shard(ix, 0, P(t, u32p), len(t), qt, 0, 10, 2, 10, P(doc, u64p), P(sc, f32p), P(meta, u64p))
+            od, os_, otot = osh.search_exhaustive(tl, op, 10, idf=idf)
+            assert int(meta[3]) == 0 and n == len(od) and int(meta[1]) == otot
+            assert np.allclose(sc[:n], os_, rtol=1e-4)
+    finally:
+        H.ssh_index_destroy(ix)
+        pix.close()
