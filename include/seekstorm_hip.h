@@ -173,6 +173,12 @@ int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df
  * found in one of their posting lists neither counts nor ranks (add_result.rs:3440-3497).  They are stored after the
  * n_terms query terms, their number in bits 8..15 of op:  op = SS_OP_* | SS_OP_NOT_TERMS(n);  n_terms + n <= 10. */
 #define SS_OP_NOT_TERMS(n) ((uint32_t)(n) << 8)
+/* field_filter of search_lexical_shard for an image with several indexed fields (search.rs:2483-2492, add_result.rs:3124-
+ * 3136): bits 16..31 of op, bit f = indexed field f is listed; 0 = no filter.  A doc is kept only if EVERY query term
+ * occurs in at least one listed field; its score still sums all fields.  Offered for intersections and single-term queries
+ * (SS_ENOTSUP for a union of several terms: the reference filters inside union_docid_3's sub-queries, not per doc); ignored
+ * by an image with one indexed field.  For ss_bm25_search_dev such a query counts as an intersection in ops_mask. */
+#define SS_OP_FIELD_FILTER(mask) ((uint32_t)(mask) << 16)
 typedef struct {
   uint32_t n_terms;                  /* 1..SS_MAX_QUERY_TERMS unique terms (scored; all required for an intersection) */
   uint32_t op;                       /* SS_OP_* | SS_OP_NOT_TERMS(number of NOT terms) */

@@ -267,7 +267,8 @@ def vec_search(rows, query, k, row_doc_ids=None, threshold_raw=-3.40282346638528
     return od[:n].copy(), os_[:n].copy(), tot.value, obs.value
 
 
-def search_fields_exhaustive(n_docs, doclen_fields, boost, offs, docs, fields, tfs, terms, op, k, not_terms=(), deleted=()):
+def search_fields_exhaustive(n_docs, doclen_fields, boost, offs, docs, fields, tfs, terms, op, k, not_terms=(), deleted=(),
+                             field_filter=()):
     """BM25F ground truth over several indexed fields (add_result.rs:1171-1426) -> (doc ids, scores, total, avgdl)"""
     dl = np.ascontiguousarray(doclen_fields, np.uint8)
     b = None if boost is None else np.ascontiguousarray(boost, np.float32)
@@ -281,10 +282,17 @@ def search_fields_exhaustive(n_docs, doclen_fields, boost, offs, docs, fields, t
     od = np.empty(max(k, 1), np.uint32)
     os_ = np.empty(max(k, 1), np.float32)
     tot, avg = C.c_uint64(), C.c_float()
-    n = lib().so_search_fields_exhaustive(n_docs, dl.shape[0], _p(dl.reshape(-1), u8p), _p(b, f32p), _p(offs, u64p), _p(docs, u32p),
-                                          _p(fields, u8p), _p(tfs, u16p), len(q), _p(q, u32p), len(nq_),
-                                          _p(nq_, u32p) if len(nq_) else None, op, k, _p(de, u64p) if len(de) else None, len(de),
-                                          _p(od, u32p), _p(os_, f32p), C.byref(tot), C.byref(avg))
+    mask = 0
+    for f_ in field_filter:
+        mask |= 1 << int(f_)
+    assert not mask or op == OP_AND or len(q) == 1, "field filter: intersections and single-term queries"
+    fn = lib().so_search_fields_filtered
+    fn.restype = C.c_uint32
+    fn.argtypes = [C.c_uint64, C.c_uint32, u8p, f32p, u64p, u32p, u8p, u16p, C.c_uint32, u32p, C.c_uint32, u32p, C.c_int,
+                   C.c_uint32, u64p, C.c_uint64, C.c_uint32, u32p, f32p, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
+    n = fn(n_docs, dl.shape[0], _p(dl.reshape(-1), u8p), _p(b, f32p), _p(offs, u64p), _p(docs, u32p),
+           _p(fields, u8p), _p(tfs, u16p), len(q), _p(q, u32p), len(nq_), _p(nq_, u32p) if len(nq_) else None, op, k,
+           _p(de, u64p) if len(de) else None, len(de), mask, _p(od, u32p), _p(os_, f32p), C.byref(tot), C.byref(avg))
     return od[:n].copy(), os_[:n].copy(), tot.value, avg.value
 
 

@@ -906,6 +906,19 @@ uint32_t so_search_fields_exhaustive(uint64_t n_docs, uint32_t n_fields, const u
                                      const uint16_t* tfs, uint32_t nq, const uint32_t* qt, uint32_t n_not,
                                      const uint32_t* not_terms, int op, uint32_t k, const uint64_t* deleted, uint64_t n_deleted,
                                      uint32_t* od, float* os, uint64_t* total, float* out_avgdl) {
+  return so_search_fields_filtered(n_docs, n_fields, doclen, boost, off, docs, fields, tfs, nq, qt, n_not, not_terms, op, k, deleted,
+                                   n_deleted, 0u, od, os, total, out_avgdl);
+}
+/* field_mask != 0: the query's field_filter (add_result.rs:3124-3136, add_result_multiterm_multifield): a doc is dropped
+ * unless EVERY query term it is matched on occurs in at least one listed field (bit f = indexed field f); the score still
+ * sums every field.  Restated for intersections and single-term queries, where "the terms it is matched on" is the whole
+ * query; a union of several terms reaches add_result through union_docid_3's sub-queries (union.rs:1308-1479), whose
+ * interplay with the filter is not a function of the doc alone -- not modelled. */
+uint32_t so_search_fields_filtered(uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen /*[n_fields][n_docs]*/,
+                                   const float* boost, const uint64_t* off, const uint32_t* docs, const uint8_t* fields,
+                                   const uint16_t* tfs, uint32_t nq, const uint32_t* qt, uint32_t n_not,
+                                   const uint32_t* not_terms, int op, uint32_t k, const uint64_t* deleted, uint64_t n_deleted,
+                                   uint32_t field_mask, uint32_t* od, float* os, uint64_t* total, float* out_avgdl) {
   uint64_t psum = 0;
   for (uint64_t i = 0; i < n_docs * n_fields; i++) psum += so_byte4_to_int(doclen[i]);
   const float avgdl = so_avgdl(psum, n_docs);
@@ -922,7 +935,11 @@ uint32_t so_search_fields_exhaustive(uint64_t n_docs, uint32_t n_fields, const u
       const uint32_t d = docs[i];
       const float w = boost ? boost[fields[i]] : 1.0f;
       sc[d] += w * idf * ((float)tfs[i] * (SO_K + 1.0f) / ((float)tfs[i] + comp[doclen[(uint64_t)fields[i] * n_docs + d]]) + SO_SIGMA);
-      if (i == off[qt[t]] || docs[i] != docs[i - 1]) cnt[d]++;
+      if (i == off[qt[t]] || docs[i] != docs[i - 1]) {  // first entry of (term, doc): does the term pass the filter here?
+        int hit = field_mask == 0;
+        for (uint64_t j = i; j < off[qt[t] + 1] && docs[j] == d && !hit; j++) hit = (field_mask >> fields[j]) & 1u;
+        if (hit) cnt[d]++;
+      }
     }
   }
   for (uint32_t j = 0; j < n_not; j++)

@@ -100,6 +100,13 @@ uint32_t so_search_fields_exhaustive(uint64_t n_docs, uint32_t n_fields, const u
                                      uint32_t n_q_terms, const uint32_t* q_terms, uint32_t n_not, const uint32_t* not_terms,
                                      int op, uint32_t k, const uint64_t* deleted, uint64_t n_deleted, uint32_t* out_doc,
                                      float* out_score, uint64_t* out_total, float* out_avgdl);
+/* with the query's field_filter (bit f = indexed field f; 0 = none): every term must occur in a listed field of the doc
+ * (add_result.rs:3124-3136); intersections and single-term queries only */
+uint32_t so_search_fields_filtered(uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost,
+                                   const uint64_t* off, const uint32_t* docs, const uint8_t* fields, const uint16_t* tfs,
+                                   uint32_t n_q_terms, const uint32_t* q_terms, uint32_t n_not, const uint32_t* not_terms,
+                                   int op, uint32_t k, const uint64_t* deleted, uint64_t n_deleted, uint32_t field_mask,
+                                   uint32_t* out_doc, float* out_score, uint64_t* out_total, float* out_avgdl);
 /* statistics for the roofline's algorithmic bytes: sum df, #blocks touched */
 void so_query_stats(const so_shard*, uint32_t n_q_terms, const uint32_t* q_terms, uint64_t* sum_df,
                     uint64_t* sum_blocks);

@@ -110,7 +110,10 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
   const ss_bm25_query Q = q[i];
   bm_vquery V;
   const uint32_t np = Q.n_terms, n_not = bm_q_nnot(Q.op);
-  const bool is_and = bm_q_op(Q.op) == SS_OP_INTERSECTION && np > 1;
+  // field_filter (several indexed fields): every term must occur in a listed field (add_result.rs:3124-3136) -- an
+  // intersection whose match bits only the listed fields' lists may set; a single filtered term is an intersection of one
+  const uint32_t filt = n_fields > 1 ? bm_q_field_filter(Q.op) : 0u;
+  const bool is_and = (bm_q_op(Q.op) == SS_OP_INTERSECTION && np > 1) || filt != 0u;
   const bool mask = np <= 8;  // 9-10 terms (single field only, checked on the host): count instead of bits
   uint32_t n = 0;
   for (uint32_t t = 0; t < np + n_not; t++) {
@@ -122,14 +125,14 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
       if (n >= (uint32_t)BM_MAX_VTERMS) break;
       V.term[n] = v;
       V.idf[n] = t < np ? (n_fields > 1 ? boost[f] * Q.idf[t] : Q.idf[t]) : 0.f;  // weight * plo.idf, add_result.rs:1253-1261
-      V.and_val[n] = (is_and && t < np) ? (uint8_t)(mask ? (1u << t) : 0xFFu) : (uint8_t)0;
+      V.and_val[n] = (is_and && t < np && (!filt || ((filt >> f) & 1u))) ? (uint8_t)(mask ? (1u << t) : 0xFFu) : (uint8_t)0;
       V.group[n] = (uint8_t)t;
       n++;
     }
   }
   if (n_not == 0) V.n_terms = n;
   const uint32_t n_scored = V.n_terms;
-  V.op = (np > 1 ? bm_q_op(Q.op) : (uint32_t)SS_OP_UNION) | ((n - n_scored) << 8);
+  V.op = (filt ? (uint32_t)SS_OP_INTERSECTION : np > 1 ? bm_q_op(Q.op) : (uint32_t)SS_OP_UNION) | ((n - n_scored) << 8);
   V.n_groups = np;
   V.and_target = is_and ? (mask ? (1u << np) - 1u : np) : 0u;
   for (uint32_t j = n; j < (uint32_t)BM_MAX_VTERMS; j++) { V.term[j] = 0; V.idf[j] = 0.f; V.and_val[j] = 0; V.group[j] = 0xFF; }

@@ -450,7 +450,7 @@ __global__ void __launch_bounds__(CNT_WAVES * 64) bm25_union_count_kernel(
         }
       }
     } else {  // intersection: AND over the query terms, each the OR of its (term, field) lists
-      uint32_t grp = Q->group[0];
+      uint32_t grp = Q->group[0], seen = np ? 1u : 0u;
       for (uint32_t t = 0; t < np + n_not; t++) {
         const uint2* __restrict__ row = probe + (size_t)probe_row[Q->term[t]] * n_groups;
         const uint32_t gt = Q->group[t];
@@ -458,18 +458,22 @@ __global__ void __launch_bounds__(CNT_WAVES * 64) bm25_union_count_kernel(
 #pragma unroll
           for (int u = 0; u < CNT_UNROLL; u++) { acc[u] &= cur[u]; cur[u] = 0ull; }
           grp = gt;
+          seen++;
         }
+        // a list outside the query's field filter scores but cannot match its term (and_val = 0, bm_expand_kernel)
+        const bool matches = t >= np || Q->and_val[t] != 0;
 #pragma unroll
         for (int u = 0; u < CNT_UNROLL; u++) {
           const uint32_t g = g0 + 64u * u + lane;
           uint2 r = make_uint2(0u, 0u);
           if (g < g_end) r = row[g];
           const u64 b = ((u64)r.y << 32) | r.x;
-          if (t < np) cur[u] |= b; else neg[u] |= b;
+          if (t < np) { if (matches) cur[u] |= b; } else neg[u] |= b;
         }
       }
+      // a query term without a posting in any field has no list here at all: nothing can match the intersection
 #pragma unroll
-      for (int u = 0; u < CNT_UNROLL; u++) acc[u] &= cur[u];
+      for (int u = 0; u < CNT_UNROLL; u++) acc[u] = seen == Q->n_groups ? acc[u] & cur[u] : 0ull;
     }
     if (del) {
 #pragma unroll

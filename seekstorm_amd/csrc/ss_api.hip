@@ -325,8 +325,14 @@ static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q,
   *np_max = 0;
   for (uint32_t i = 0; i < nq; i++) {
     const uint32_t op = bm_q_op(q[i].op), n_not = bm_q_nnot(q[i].op), all = q[i].n_terms + n_not;
-    if (q[i].n_terms == 0 || all > SS_MAX_QUERY_TERMS || (q[i].op >> 16)) return SS_EINVAL;
+    if (q[i].n_terms == 0 || all > SS_MAX_QUERY_TERMS) return SS_EINVAL;
     if (op != SS_OP_INTERSECTION && op != SS_OP_UNION) return SS_EINVAL;
+    // field_filter: bits of indexed fields; an image with one indexed field has nothing to filter (the reference's set then
+    // holds that field or nothing, search.rs:2483-2492).  Unions of several terms: the reference applies the filter inside
+    // union_docid_3's sub-queries, not per doc -- not offered.
+    const uint32_t filt = s->bm_n_fields > 1 ? bm_q_field_filter(q[i].op) : 0u;
+    if (filt >> s->bm_n_fields) return SS_EINVAL;
+    if (filt && op == SS_OP_UNION && q[i].n_terms > 1) return SS_ENOTSUP;
     if (s->bm_n_fields > 1) {  // (term, field) posting lists: at most BM_MAX_VTERMS of them, match masks of 8 bits
       if (all * s->bm_n_fields > (uint32_t)BM_MAX_VTERMS) return SS_ENOTSUP;
       if (op == SS_OP_INTERSECTION && q[i].n_terms > 8) return SS_ENOTSUP;
@@ -342,7 +348,7 @@ static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q,
       for (uint32_t u = 0; u < t; u++)
         if (q[i].term[u] == q[i].term[t]) return SS_EINVAL;  // unique terms only (search.rs:3023 unique_terms)
     }
-    if (op == SS_OP_INTERSECTION && q[i].n_terms > 1) *has_and = true;
+    if ((op == SS_OP_INTERSECTION && q[i].n_terms > 1) || filt) *has_and = true;
     else if (q[i].n_terms > 1) *has_or = true;  // a single-term query is both: its exact count is its posting count
     *nt_max = std::max(*nt_max, all);
     *np_max = std::max(*np_max, q[i].n_terms);

@@ -210,6 +210,7 @@ struct bm_vquery {
 };
 __host__ __device__ inline uint32_t bm_q_op(uint32_t op) { return op & 0xFFu; }
 __host__ __device__ inline uint32_t bm_q_nnot(uint32_t op) { return (op >> 8) & 0xFFu; }
+__host__ __device__ inline uint32_t bm_q_field_filter(uint32_t op) { return op >> 16; }  // SS_OP_FIELD_FILTER: bit f = field f
 int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t* d_out_doc,
                     float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, bool has_or,
                     uint32_t nt_max, uint32_t np_max, bool all_probed, hipStream_t st);

@@ -412,10 +412,17 @@ class Shard:
         return out
 
     # ---- query construction: term resolution + idf stay on the host (search.rs:3066-3358)
-    def make_queries(self, term_lists: Sequence[Sequence[int]], query_types, not_lists=None, idf_of=None):
+    def make_queries(self, term_lists: Sequence[Sequence[int]], query_types, not_lists=None, idf_of=None, field_filter=None):
         """query_list (+ not_query_list: the "-term" operands, add_result.rs:3440-3497) of each query -> ss_bm25_query.
         idf_of: {term id: idf} for the terms whose idf is not that of their own list -- the component terms of an n-gram
-        key (IndexBin.terms_of_key: idf_ngram_i from the component term's posting count)"""
+        key (IndexBin.terms_of_key: idf_ngram_i from the component term's posting count).
+        field_filter: indexed field ids every term must occur in one of (several indexed fields; intersections and
+        single-term queries, add_result.rs:3124-3136)"""
+        fmask = 0
+        for f in field_filter or ():
+            fmask |= 1 << int(f)
+        if fmask >> 16:
+            raise ValueError("field filter: indexed field ids 0..15")
         nq = len(term_lists)
         if not_lists is None:
             not_lists = [()] * nq
@@ -434,7 +441,7 @@ class Shard:
             if not 1 <= len(tl) or len(tl) + len(nl) > N.SS_MAX_QUERY_TERMS:
                 raise ValueError("1..10 unique terms per query (NOT terms included)")
             q["n_terms"][i] = len(tl)
-            q["op"][i] = int(qt) | (len(nl) << 8)
+            q["op"][i] = int(qt) | (len(nl) << 8) | (fmask << 16)
             for j, t in enumerate(tl):
                 q["term"][i, j] = t
                 q["idf"][i, j] = idf_of[t] if idf_of and t in idf_of else idf_f32(self.indexed_doc_count, self._df_cache[t])

@@ -698,6 +698,47 @@ def test_bm25f_several_fields(S, O, n_fields, boost):
     sh.close()
 
 
+@pytest.mark.parametrize("n_fields", [2, 3])
+def test_bm25f_field_filter(S, O, n_fields):
+    """field_filter on an image with several indexed fields (add_result.rs:3124-3136): a doc stays only if every query term
+    occurs in one of the listed fields; the score still sums all fields.  Intersections and single terms, every result
+    type and strategy, with NOT terms and tombstones; a union of several terms is refused"""
+    n_docs = 90_000
+    dfs = [40_000, 25_000, 6_000, 30_000]
+    dl, offs, docs, fields, tfs = _fields_corpus(O, n_docs, n_fields, dfs, 17 + n_fields)
+    boost = [1.5, 1.0, 0.5][:n_fields]
+    sh = S.Shard(0)
+    sh.upload_lexical_fields(n_docs, dl, boost, offs, docs, fields, tfs)
+    gone = list(range(3, n_docs, 97))
+    sh.set_deleted(gone)
+    cases = [([0, 1], []), ([2], []), ([0, 1, 3], []), ([3, 1], [2]), ([0], [1])]
+    for filt in ([0], [n_fields - 1], [0, n_fields - 1]):
+        for strat in (0, 1):
+            sh.set_strategy(strat)
+            q = sh.make_queries([c[0] for c in cases], S.QueryType.Intersection, [c[1] for c in cases], field_filter=filt)
+            for rt in (S.ResultType.TopkCount, S.ResultType.Topk, S.ResultType.Count):
+                doc, score, cnt, tot = sh.search_lexical_batch(q, 10, rt)
+                for i, (pos, neg) in enumerate(cases):
+                    od, os_, otot, _ = O.search_fields_exhaustive(n_docs, dl, boost, offs, docs, fields, tfs, pos, O.OP_AND, 10, neg,
+                                                                  gone, field_filter=filt)
+                    unf = O.search_fields_exhaustive(n_docs, dl, boost, offs, docs, fields, tfs, pos, O.OP_AND, 10, neg, gone)[2]
+                    assert otot <= unf and (otot < unf or len(filt) == n_fields or otot == 0)  # the filter really bites
+                    if rt != S.ResultType.Topk:
+                        assert int(tot[i]) == otot, (pos, neg, filt, strat, rt)
+                    if rt != S.ResultType.Count:
+                        _check_topk(doc[i], score[i], cnt[i], od, os_)
+    sh.set_strategy(0)
+    # every field listed == no filter
+    a = sh.search_lexical_batch(sh.make_queries([[0, 1]], S.QueryType.Intersection, field_filter=list(range(n_fields))), 10)
+    b = sh.search_lexical_batch(sh.make_queries([[0, 1]], S.QueryType.Intersection), 10)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    with pytest.raises(S.SeekStormHipError):   # union of several terms under a filter: not offered
+        sh.search_lexical_batch(sh.make_queries([[0, 1]], S.QueryType.Union, field_filter=[0]), 10)
+    with pytest.raises(S.SeekStormHipError):   # a field the image does not have
+        sh.search_lexical_batch(sh.make_queries([[0]], S.QueryType.Union, field_filter=[n_fields]), 10)
+    sh.close()
+
+
 def test_c1_standin_one_million_docs_and_pairs(S, O):
     """BASELINE configs[0] stand-in (LEX-1M, 2-term AND, top-10, df bands [1 %, 5 %] x [5 %, 20 %]): the device
     generator's corpus against the reference-structured oracle on the host-generated copy of the same corpus"""
