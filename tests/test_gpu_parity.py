@@ -665,14 +665,14 @@ def test_bm25f_several_fields(S, O, n_fields, boost):
     """get_bm25f_multiterm_multifield (add_result.rs:1171-1426): per-field tf / length / boost, df over any field,
     intersections of unions; every result type and strategy, NOT terms and tombstones, against the brute-force oracle"""
     n_docs = 120_000
-    dfs = [30_000, 9_000, 2_500, 600, 14_000]
+    dfs = [30_000, 9_000, 2_500, 600, 14_000, 0]  # the last term has no posting in any field
     dl, offs, docs, fields, tfs = _fields_corpus(O, n_docs, n_fields, dfs, 3 + n_fields)
     sh = S.Shard(0)
     sh.upload_lexical_fields(n_docs, dl, boost, offs, docs, fields, tfs)
     info = sh.lexical_info()
     assert info["n_terms"] == len(dfs) and info["n_docs"] == n_docs
     assert [int(x) for x in sh.posting_count(np.arange(len(dfs)))] == dfs  # docs containing the term in any field
-    cases = [([0, 1], []), ([2], []), ([0, 1, 2], []), ([4, 3], [2]), ([1, 4], [0]), ([3], [1])]
+    cases = [([0, 1], []), ([2], []), ([0, 1, 2], []), ([4, 3], [2]), ([1, 4], [0]), ([3], [1]), ([0, 5], []), ([5], [])]
     gone = list(range(5, n_docs, 211))
     for deleted in ((), gone):
         sh.set_deleted(deleted)
