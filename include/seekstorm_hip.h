@@ -223,6 +223,11 @@ int ss_vec_read_rows(ss_shard* s, uint64_t r0, uint64_t n, float* out);
  * order-dependent in the reference, an upper bound here; exact when n_rows <= k). */
 int ss_vec_search(ss_shard* s, uint32_t n_queries, const float* queries, uint32_t k, float threshold_raw,
                   uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total);
+/* _dev variants: device pointers, asynchronous on `stream`.  The scan keeps the rows that beat the running threshold in a
+ * fixed candidate buffer per query, sized for rows in no particular order; rows sorted by similarity to a query can
+ * overflow it.  The host-pointer functions notice and re-run the batch with a schedule that cannot overflow; the _dev
+ * functions cannot look at the result, so they flag it: d_out_count[q] = UINT32_MAX for the queries of that batch --
+ * re-issue such a batch through the host-pointer function.  (ss_rrf_merge_dev / ss_topk_merge_dev treat it as empty.) */
 int ss_vec_search_dev(ss_shard* s, uint32_t n_queries, const float* d_queries, uint32_t k, float threshold_raw,
                       uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total,
                       void* stream);
