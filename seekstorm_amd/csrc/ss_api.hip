@@ -330,8 +330,8 @@ static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q,
     // field_filter: bits of indexed fields; an image with one indexed field has nothing to filter (the reference's set then
     // holds that field or nothing, search.rs:2483-2492).  Unions of several terms: the reference applies the filter inside
     // union_docid_3's sub-queries, not per doc -- not offered.
+    if (bm_q_field_filter(q[i].op) >> s->bm_n_fields) return SS_EINVAL;  // a field the image does not have
     const uint32_t filt = s->bm_n_fields > 1 ? bm_q_field_filter(q[i].op) : 0u;
-    if (filt >> s->bm_n_fields) return SS_EINVAL;
     if (filt && op == SS_OP_UNION && q[i].n_terms > 1) return SS_ENOTSUP;
     if (s->bm_n_fields > 1) {  // (term, field) posting lists: at most BM_MAX_VTERMS of them, match masks of 8 bits
       if (all * s->bm_n_fields > (uint32_t)BM_MAX_VTERMS) return SS_ENOTSUP;

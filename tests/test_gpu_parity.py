@@ -503,9 +503,12 @@ def test_not_terms_abi_validation(S, O, lex):
     with pytest.raises(S.SeekStormHipError):
         sh.search_lexical_batch(bad, 10)
     bad = q.copy()
-    bad["op"][0] = int(S.QueryType.Union) | (1 << 16)
+    bad["op"][0] = int(S.QueryType.Union) | (2 << 16)  # field filter naming a field this one-field image does not have
     with pytest.raises(S.SeekStormHipError):
         sh.search_lexical_batch(bad, 10)
+    ok = q.copy()
+    ok["op"][0] |= 1 << 16  # ... and naming its only field: no filter at all
+    assert all(np.array_equal(x, y) for x, y in zip(sh.search_lexical_batch(ok, 10), sh.search_lexical_batch(q, 10)))
 
 
 @pytest.mark.parametrize("n_rows,dim,nq,k", [(20000, 768, 64, 100), (4099, 100, 3, 10), (300, 384, 70, 50), (50, 32, 2, 100),
