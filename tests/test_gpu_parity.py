@@ -92,6 +92,33 @@ def test_vector_multi_record_docs_dedup(S, O, n_rows, n_docs, k):
     sh.close()
 
 
+def test_vector_select_refine_edge_cases(S, O):
+    """the refine's radix select: all scores equal (the k-th key is decided in the row bytes of the key: the k smallest
+    rows win), k = 1, exactly k rows, and a handful of distinct scores over many rows"""
+    dim = 32
+    base = O.vec_gen(O.VEC_SEED, 0, 1, dim)[0]
+    q = O.vec_gen(O.VECQ_SEED, 0, 3, dim)
+    sh = S.Shard(0)
+    rows = np.tile(base, (5000, 1)).astype(np.float32)          # 5000 identical records
+    sh.upload_vectors(rows)
+    for k in (1, 7, 100):
+        doc, score, cnt, tot = sh.search_vector_batch(q, k)
+        for i in range(3):
+            assert cnt[i] == k and np.array_equal(doc[i], np.arange(k)) and len(set(score[i].tolist())) == 1
+    rows8 = np.zeros((6000, dim), np.int8)
+    rows8[:, 0] = (np.arange(6000) % 5) + 1                      # five distinct integer scores, 1200 rows each
+    q8 = np.zeros((2, dim), np.int8); q8[:, 0] = 3
+    sh.upload_vectors_i8(rows8)
+    doc, score, cnt, tot = sh.search_vector_batch_i8(q8, 100)
+    want = np.nonzero(np.arange(6000) % 5 == 4)[0][:100]
+    for i in range(2):
+        assert cnt[i] == 100 and np.all(score[i] == 15.0) and np.array_equal(doc[i], want)
+    sh.upload_vectors_i8(rows8[:100])                             # exactly k rows
+    doc, score, cnt, tot = sh.search_vector_batch_i8(q8, 100)
+    assert cnt[0] == 100 and sorted(doc[0].tolist()) == list(range(100)) and np.all(score[0][:-1] >= score[0][1:])
+    sh.close()
+
+
 def test_vector_threshold(S, O):
     rows = O.vec_gen(5, 0, 5000, 64)
     q = O.vec_gen(6, 0, 1, 64)[0]
