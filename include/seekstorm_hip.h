@@ -178,7 +178,15 @@ int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df
  * occurs in at least one listed field; its score still sums all fields.  Offered for intersections and single-term queries
  * (SS_ENOTSUP for a union of several terms: the reference filters inside union_docid_3's sub-queries, not per doc); ignored
  * by an image with one indexed field.  For ss_bm25_search_dev such a query counts as an intersection in ops_mask. */
-#define SS_OP_FIELD_FILTER(mask) ((uint32_t)(mask) << 16)
+#define SS_OP_FIELD_FILTER(mask) (((uint32_t)(mask) & 0x7FFFu) << 16)
+/* The reference's all_terms_frequent shortcut (intersection.rs:198-209): when the shard holds more than 256 x top_k docs
+ * and EVERY term of an intersection occurs in at least half of them, a doc in which some term has an embedded position
+ * pointer or fewer than 10 positions is counted but never scored (decode_positions_multiterm_singlefield returns true,
+ * add_result.rs:2091-2104, 3541-3556).  An embedded pointer holds at most 4 positions, so the rule is "ranked only if every
+ * term has tf >= 10".  The caller evaluates the condition (it knows N, top_k and the posting counts) and sets this bit on
+ * the query; the host mirrors do.  Intersections of 2..7 terms over one indexed field (SS_ENOTSUP otherwise); counts are
+ * unaffected.  For ss_bm25_search_dev: ops_mask bit 3 = some query carries the bit. */
+#define SS_OP_ALL_TERMS_FREQUENT 0x80000000u
 typedef struct {
   uint32_t n_terms;                  /* 1..SS_MAX_QUERY_TERMS unique terms (scored; all required for an intersection) */
   uint32_t op;                       /* SS_OP_* | SS_OP_NOT_TERMS(number of NOT terms) */
@@ -197,7 +205,8 @@ int ss_bm25_search(ss_shard* s, uint32_t n_queries, const ss_bm25_query* queries
  * (selects the kernel variant that carries match counters), bit 1 set if any query is a union of > 1 terms; bits 8..15 = the
  * largest n_terms + NOT terms in the batch (0 = unknown: the generic 10-term kernel is used); bits 16..23 = the largest
  * n_terms alone (0 = same as bits 8..15, i.e. no NOT terms); bit 2 set if every term of the batch has probe rows
- * (ss_bm25_term_probed; irrelevant when the probe budget covered all lists). */
+ * (ss_bm25_term_probed; irrelevant when the probe budget covered all lists); bit 3 set if some query carries
+ * SS_OP_ALL_TERMS_FREQUENT (or a field filter: bit 0 as well). */
 int ss_bm25_search_dev(ss_shard* s, uint32_t n_queries, const ss_bm25_query* d_queries, uint32_t k,
                        uint32_t result_type, uint32_t ops_mask, uint32_t* d_out_doc, float* d_out_score,
                        uint32_t* d_out_count, uint64_t* d_out_total, void* stream);

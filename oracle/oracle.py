@@ -228,8 +228,31 @@ class Shard:
     def search(self, terms, op, k, rt=RT_TOPKCOUNT, not_terms=()):
         return self._search(lib().so_search_lex_not, terms, not_terms, op, k, rt)
 
-    def search_exhaustive(self, terms, op, k, not_terms=(), idf=None):
-        """idf: the idf of every term, given (n-gram component terms carry idf_ngram_i); None = from the lists' own counts"""
+    def all_terms_frequent(self, terms, top_k):
+        f = lib().so_all_terms_frequent
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_uint32, u32p, C.c_uint32]
+        q = np.ascontiguousarray(terms, np.uint32)
+        return bool(f(self.h, len(q), _p(q, u32p), int(top_k)))
+
+    def search_exhaustive(self, terms, op, k, not_terms=(), idf=None, reference_shortcuts=False):
+        """idf: the idf of every term, given (n-gram component terms carry idf_ngram_i); None = from the lists' own counts.
+        reference_shortcuts: apply all_terms_frequent when its condition holds (intersection.rs:198-209)"""
+        if reference_shortcuts:
+            q = np.ascontiguousarray(terms, np.uint32)
+            nq = np.ascontiguousarray(not_terms, np.uint32)
+            w = None if idf is None else np.ascontiguousarray(idf, np.float32)
+            od = np.empty(max(k, 1), np.uint32)
+            os_ = np.empty(max(k, 1), np.float32)
+            tot = C.c_uint64()
+            f = lib().so_search_lex_exhaustive_opt
+            f.restype = C.c_uint32
+            f.argtypes = [C.c_void_p, C.c_uint32, u32p, f32p, C.c_uint32, u32p, C.c_int, C.c_uint32, C.c_int, u32p, f32p,
+                          C.POINTER(C.c_uint64)]
+            sc = 1 if (op == OP_AND and len(q) > 1 and self.all_terms_frequent(q, k)) else 0
+            n = f(self.h, len(q), _p(q, u32p), _p(w, f32p), len(nq), _p(nq, u32p) if len(nq) else None, op, k, sc, _p(od, u32p),
+                  _p(os_, f32p), C.byref(tot))
+            return od[:n].copy(), os_[:n].copy(), tot.value
         if idf is None:
             return self._search(lib().so_search_lex_exhaustive_not, terms, not_terms, op, k)
         q = np.ascontiguousarray(terms, np.uint32)

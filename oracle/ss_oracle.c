@@ -596,14 +596,33 @@ uint32_t so_search_lex_exhaustive_not(const so_shard* s, uint32_t nq, const uint
 uint32_t so_search_lex_exhaustive_idf(const so_shard* s, uint32_t nq, const uint32_t* qt, const float* idf_in, uint32_t n_not,
                                       const uint32_t* not_terms, int op, uint32_t k, uint32_t* od, float* os,
                                       uint64_t* total) {
+  return so_search_lex_exhaustive_opt(s, nq, qt, idf_in, n_not, not_terms, op, k, 0, od, os, total);
+}
+/* all_terms_frequent (intersection.rs:198-209): indexed_doc_count > top_k << 8 and posting_count / indexed_doc_count >= 0.5
+ * (f32) for every term of an intersection */
+int so_all_terms_frequent(const so_shard* s, uint32_t nq, const uint32_t* qt, uint32_t top_k) {
+  if (!(s->n_docs > ((uint64_t)top_k << 8))) return 0;
+  for (uint32_t t = 0; t < nq; t++)
+    if ((float)s->terms[qt[t]].posting_count / (float)s->n_docs < 0.5f) return 0;
+  return 1;
+}
+/* shortcut != 0: an intersection of several terms is run as the reference runs it under all_terms_frequent (the caller
+ * decides with so_all_terms_frequent): a doc in which some term has an embedded pointer (<= 4 positions) or fewer than 10
+ * positions is counted but not scored (add_result.rs:2091-2104, 3541-3556) -- ranked only if every tf >= 10 */
+uint32_t so_search_lex_exhaustive_opt(const so_shard* s, uint32_t nq, const uint32_t* qt, const float* idf_in, uint32_t n_not,
+                                      const uint32_t* not_terms, int op, uint32_t k, int shortcut, uint32_t* od, float* os,
+                                      uint64_t* total) {
   float* sc = (float*)calloc(s->n_docs ? s->n_docs : 1, sizeof(float));
   uint8_t* cnt = (uint8_t*)calloc(s->n_docs ? s->n_docs : 1, 1);
+  uint8_t* low = (uint8_t*)calloc(s->n_docs ? s->n_docs : 1, 1);  /* some term with tf < 10 */
+  shortcut = shortcut && op == SO_OP_AND && nq > 1;
   for (uint32_t t = 0; t < nq; t++) {
     float idf = idf_in ? idf_in[t] : so_idf(s->n_docs, s->terms[qt[t]].posting_count);
     for (uint64_t i = s->off[qt[t]]; i < s->off[qt[t] + 1]; i++) {
       uint32_t d = s->docs[i];
       sc[d] += so_bm25_term(idf, s->tfs[i], s->comp[s->doclen[d]]);
       cnt[d]++;
+      if (s->tfs[i] < 10) low[d] = 1;
     }
   }
   uint8_t* gone = exclusion_map(s, n_not, not_terms);
@@ -615,12 +634,12 @@ uint32_t so_search_lex_exhaustive_idf(const so_shard* s, uint32_t nq, const uint
   so_sd* v = (so_sd*)malloc((m ? m : 1) * sizeof(so_sd));
   uint64_t j = 0;
   for (uint64_t d = 0; d < s->n_docs; d++)
-    if (op == SO_OP_AND ? cnt[d] == nq : cnt[d] > 0) { v[j].score = sc[d]; v[j].doc = (uint32_t)d; j++; }
-  qsort(v, m, sizeof(so_sd), sd_cmp);
-  uint32_t n = (uint32_t)(m < k ? m : k);
+    if ((op == SO_OP_AND ? cnt[d] == nq : cnt[d] > 0) && !(shortcut && low[d])) { v[j].score = sc[d]; v[j].doc = (uint32_t)d; j++; }
+  qsort(v, j, sizeof(so_sd), sd_cmp);
+  uint32_t n = (uint32_t)(j < k ? j : k);
   for (uint32_t i = 0; i < n; i++) { od[i] = v[i].doc; os[i] = v[i].score; }
   if (total) *total = m;
-  free(v); free(cnt); free(sc);
+  free(v); free(cnt); free(sc); free(low);
   return n;
 }
 void so_query_stats(const so_shard* s, uint32_t nq, const uint32_t* qt, uint64_t* sum_df, uint64_t* sum_blocks) {

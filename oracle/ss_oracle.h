@@ -89,6 +89,12 @@ uint32_t so_search_lex_exhaustive_not(const so_shard*, uint32_t n_q_terms, const
 uint32_t so_search_lex_exhaustive_idf(const so_shard* s, uint32_t n_query_terms, const uint32_t* query_terms, const float* idf,
                                       uint32_t n_not, const uint32_t* not_terms, int op, uint32_t k, uint32_t* out_doc,
                                       float* out_score, uint64_t* total); /* idf given per term (n-gram components) */
+/* the reference's all_terms_frequent condition (intersection.rs:198-209) and the exhaustive search under it (shortcut != 0:
+ * a doc with some tf < 10 is counted but not ranked; add_result.rs:2091-2104, 3541-3556).  idf may be NULL. */
+int so_all_terms_frequent(const so_shard* s, uint32_t n_query_terms, const uint32_t* query_terms, uint32_t top_k);
+uint32_t so_search_lex_exhaustive_opt(const so_shard* s, uint32_t n_query_terms, const uint32_t* query_terms, const float* idf,
+                                      uint32_t n_not, const uint32_t* not_terms, int op, uint32_t k, int shortcut,
+                                      uint32_t* out_doc, float* out_score, uint64_t* total);
 /* brute-force ground truth (independent code path): exhaustive scoring + exact top-k by
  * (score desc, doc asc); also returns the exact match count. */
 uint32_t so_search_lex_exhaustive(const so_shard*, uint32_t n_q_terms, const uint32_t* q_terms, int op,

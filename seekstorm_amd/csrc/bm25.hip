@@ -115,6 +115,9 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
   const uint32_t filt = n_fields > 1 ? bm_q_field_filter(Q.op) : 0u;
   const bool is_and = (bm_q_op(Q.op) == SS_OP_INTERSECTION && np > 1) || filt != 0u;
   const bool mask = np <= 8;  // 9-10 terms (single field only, checked on the host): count instead of bits
+  // all_terms_frequent (intersection.rs:198-209): the caller saw N > 256 k and df >= N / 2 for every term.  One field and
+  // <= 7 terms (bit 7 of the match byte becomes the "some tf < 10" mark; the host refuses the rest).
+  const bool freq = bm_q_all_frequent(Q.op) && bm_q_op(Q.op) == SS_OP_INTERSECTION && np > 1 && np <= 7 && n_fields == 1;
   uint32_t n = 0;
   for (uint32_t t = 0; t < np + n_not; t++) {
     if (t == np) V.n_terms = n;
@@ -134,7 +137,7 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
   const uint32_t n_scored = V.n_terms;
   V.op = (filt ? (uint32_t)SS_OP_INTERSECTION : np > 1 ? bm_q_op(Q.op) : (uint32_t)SS_OP_UNION) | ((n - n_scored) << 8);
   V.n_groups = np;
-  V.and_target = is_and ? (mask ? (1u << np) - 1u : np) : 0u;
+  V.and_target = is_and ? ((mask ? (1u << np) - 1u : np) | (freq ? BM_AND_FREQ : 0u)) : 0u;
   for (uint32_t j = n; j < (uint32_t)BM_MAX_VTERMS; j++) { V.term[j] = 0; V.idf[j] = 0.f; V.and_val[j] = 0; V.group[j] = 0xFF; }
   vq[i] = V;
 }
@@ -142,7 +145,7 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
 // ---------------------------------------------------------------- host side
 int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t* d_out_doc,
                     float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, bool has_or,
-                    uint32_t nt_max, uint32_t np_max, bool all_probed, hipStream_t st) {
+                    uint32_t nt_max, uint32_t np_max, bool all_probed, hipStream_t st, bool any_frequent) {
   if (!s->d_post) return SS_ESTATE;
   if (nq == 0) return SS_OK;
   if (k > SS_MAX_K) return SS_EINVAL;
@@ -162,7 +165,8 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   if (F > 1) has_or = true;
   // all_probed: every list the batch touches has a row in the probe index (rows are given to the longest lists first)
   const bool have_probe = s->d_probe && s->d_umax && all_probed;
-  const bool pruned = s->bm_strategy != SS_BM25_EXHAUSTIVE && have_probe && !(F > 1 && has_and) &&
+  // an intersection under the all_terms_frequent shortcut ranks by a per-posting rule (tf >= 10): scan kernels only
+  const bool pruned = s->bm_strategy != SS_BM25_EXHAUSTIVE && have_probe && !(F > 1 && has_and) && !any_frequent &&
                       np_max >= 1 && np_max <= 4 && KPL <= 2;  // NOT terms are probed outside the template
   if (!pruned && s->bm_strategy == SS_BM25_PRUNED) return SS_ENOTSUP;
   // Partitions per query (one wave each).  The grid is a whole number of "rounds" of resident waves: a partially

@@ -238,7 +238,12 @@ __device__ __forceinline__ float bm_chunk(const u32x4 q, float idf, const BmLds&
     const float nw = old[x] + idf * wp[x];
     lds_stf(ao[x], nw);
     mx = fmaxf(mx, nw);
-    if (HAS_AND && and_val) lds_st8(co[x], and_val == 0xFFu ? cold[x] + 1u : (cold[x] | and_val));  // count one more | set the term's bit
+    if (HAS_AND && and_val) {
+      // count one more | set the term's bit (+ bit 7 under the all_terms_frequent shortcut when this posting's tf < 10)
+      uint32_t nb = and_val == 0xFFu ? cold[x] + 1u : (cold[x] | (and_val & 0xFFu));
+      if (and_val & BM_AND_FREQ) nb |= ((pv[x] & BM_BIG_TF_MASK) == 0u && ((pv[x] >> 26) & 15u) < 10u) ? 0x80u : 0u;
+      lds_st8(co[x], nb);
+    }
   }
   return mx;
 }
@@ -321,6 +326,11 @@ __device__ __attribute__((noinline)) BmTop<KPL> bm_scan_tile(BmTop<KPL> T, uint3
   const float wsc_in = T.wsc;
   const int lane = __lane_id();
   const bool is_and = HAS_AND && nt_and != 0;  // nt_and = number of terms of an intersection, 0 for a union
+  // all_terms_frequent shortcut: bit 7 of a match byte = "some term has tf < 10 here" -- the doc matches (is counted) on
+  // its low 7 bits and is ranked only with bit 7 clear (decode_positions_multiterm_singlefield returns true -> counted,
+  // never scored: add_result.rs:2091-2104, 3541-3556)
+  const uint32_t cmask = (HAS_AND && (nt_and & BM_AND_FREQ)) ? 0x7Fu : 0xFFu;
+  nt_and &= 0xFFu;
   // tombstones of this sub-block (128 words): lane l keeps words l and 64 + l; iteration i needs word 8 i + lane / 8.
   // A deleted doc neither counts nor ranks (add_result.rs:3435, union.rs:975).
   uint32_t dw0 = 0u, dw1 = 0u;
@@ -348,14 +358,14 @@ __device__ __attribute__((noinline)) BmTop<KPL> bm_scan_tile(BmTop<KPL> T, uint3
     if (HAS_AND && is_and) {
       const uint32_t cw = lds_ld32(cntw + slot * 4);
       lds_st32(cntw + slot * 4, 0u);
-      h0 = h0 && (cw & 0xFFu) == nt_and;  // h: score > 0 (not deleted, in no NOT list)
-      h1 = h1 && ((cw >> 8) & 0xFFu) == nt_and;
-      h2 = h2 && ((cw >> 16) & 0xFFu) == nt_and;
-      h3 = h3 && (cw >> 24) == nt_and;
-      if (!h0) x.x = 0.f;
-      if (!h1) x.y = 0.f;
-      if (!h2) x.z = 0.f;
-      if (!h3) x.w = 0.f;
+      h0 = h0 && (cw & cmask) == nt_and;  // h: score > 0 (not deleted, in no NOT list) and every term present
+      h1 = h1 && ((cw >> 8) & cmask) == nt_and;
+      h2 = h2 && ((cw >> 16) & cmask) == nt_and;
+      h3 = h3 && ((cw >> 24) & cmask) == nt_and;
+      if (!h0 || (cw & 0x80u & ~cmask)) x.x = 0.f;  // counted below, ranked only without the tf < 10 mark
+      if (!h1 || ((cw >> 8) & 0x80u & ~cmask)) x.y = 0.f;
+      if (!h2 || ((cw >> 16) & 0x80u & ~cmask)) x.z = 0.f;
+      if (!h3 || ((cw >> 24) & 0x80u & ~cmask)) x.w = 0.f;
     }
     if (count_mode)
       T.matched += __popcll(__ballot(h0)) + __popcll(__ballot(h1)) + __popcll(__ballot(h2)) + __popcll(__ballot(h3));

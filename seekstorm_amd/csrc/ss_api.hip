@@ -317,7 +317,8 @@ int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df
 
 // nt_max: largest n_terms + NOT terms of the batch (what the scan kernels are specialised on); np_max: largest n_terms
 static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q, bool* has_and, bool* has_or, uint32_t* nt_max,
-                         uint32_t* np_max, bool* all_probed) {
+                         uint32_t* np_max, bool* all_probed, bool* any_frequent) {
+  *any_frequent = false;
   *all_probed = s->bm_probe_rows != 0;
   *has_and = false;
   *has_or = false;
@@ -333,6 +334,12 @@ static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q,
     if (bm_q_field_filter(q[i].op) >> s->bm_n_fields) return SS_EINVAL;  // a field the image does not have
     const uint32_t filt = s->bm_n_fields > 1 ? bm_q_field_filter(q[i].op) : 0u;
     if (filt && op == SS_OP_UNION && q[i].n_terms > 1) return SS_ENOTSUP;
+    // all_terms_frequent: an intersection of 2..7 terms over one indexed field (the mark takes bit 7 of the match byte);
+    // on anything else the reference's flag has no effect we model (single terms, unions) or is not offered
+    if (bm_q_all_frequent(q[i].op) && op == SS_OP_INTERSECTION && q[i].n_terms > 1) {
+      if (q[i].n_terms > 7 || s->bm_n_fields > 1) return SS_ENOTSUP;
+      *any_frequent = true;
+    }
     if (s->bm_n_fields > 1) {  // (term, field) posting lists: at most BM_MAX_VTERMS of them, match masks of 8 bits
       if (all * s->bm_n_fields > (uint32_t)BM_MAX_VTERMS) return SS_ENOTSUP;
       if (op == SS_OP_INTERSECTION && q[i].n_terms > 8) return SS_ENOTSUP;
@@ -365,8 +372,8 @@ int ss_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k,
   if (nq == 0) return SS_OK;
   bool has_and = false, has_or = false;
   uint32_t nt_max = 0, np_max = 0;
-  bool all_probed = false;
-  SS_TRY(check_queries(s, nq, q, &has_and, &has_or, &nt_max, &np_max, &all_probed));
+  bool all_probed = false, any_frequent = false;
+  SS_TRY(check_queries(s, nq, q, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent));
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   const uint32_t kk = rt == SS_RT_COUNT ? 0 : k;
@@ -379,7 +386,7 @@ int ss_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k,
   }
   SS_HIP(hipMemcpyAsync(s->d_bq, q, (size_t)nq * sizeof(ss_bm25_query), hipMemcpyHostToDevice, s->stream));
   SS_TRY(ssi_bm25_search(s, nq, (const ss_bm25_query*)s->d_bq, kk, rt, s->d_out_doc, s->d_out_score, s->d_out_count,
-                         s->d_out_total, has_and, has_or, nt_max, np_max, all_probed, s->stream));
+                         s->d_out_total, has_and, has_or, nt_max, np_max, all_probed, s->stream, any_frequent));
   if (kk) {
     SS_HIP(hipMemcpyAsync(out_doc, s->d_out_doc, (size_t)nq * kk * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     SS_HIP(hipMemcpyAsync(out_score, s->d_out_score, (size_t)nq * kk * sizeof(float), hipMemcpyDeviceToHost, s->stream));
@@ -406,7 +413,8 @@ int ss_bm25_search_dev(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint3
                          (ops_mask >> 16) & 0xFFu ? (ops_mask >> 16) & 0xFFu
                                                   : ((ops_mask >> 8) & 0xFFu ? (ops_mask >> 8) & 0xFFu : SS_MAX_QUERY_TERMS),
                          // the caller vouches for the probe rows of its terms (ss_bm25_term_probed) unless none were rationed
-                         s->bm_probe_rows != 0 && (s->bm_probe_rows >= s->bm_n_terms || (ops_mask & 4u) != 0), st);
+                         s->bm_probe_rows != 0 && (s->bm_probe_rows >= s->bm_n_terms || (ops_mask & 4u) != 0), st,
+                         (ops_mask & 8u) != 0);
 }
 
 // ------------------------------------------------------------------ vectors

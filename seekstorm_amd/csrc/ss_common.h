@@ -210,10 +210,15 @@ struct bm_vquery {
 };
 __host__ __device__ inline uint32_t bm_q_op(uint32_t op) { return op & 0xFFu; }
 __host__ __device__ inline uint32_t bm_q_nnot(uint32_t op) { return (op >> 8) & 0xFFu; }
-__host__ __device__ inline uint32_t bm_q_field_filter(uint32_t op) { return op >> 16; }  // SS_OP_FIELD_FILTER: bit f = field f
+__host__ __device__ inline uint32_t bm_q_field_filter(uint32_t op) { return (op >> 16) & 0x7FFFu; }  // SS_OP_FIELD_FILTER: bit f = field f
+__host__ __device__ inline bool bm_q_all_frequent(uint32_t op) { return (op >> 31) != 0u; }         // SS_OP_ALL_TERMS_FREQUENT
+// bm_vquery::and_target bit 8 / a term's and_val bit 8 inside the scan kernels: the intersection runs under the reference's
+// all_terms_frequent shortcut -- a posting with tf < 10 sets bit 7 of its doc's match byte, which keeps the doc counted
+// but out of the ranking (add_result.rs:2091-2104, 3541-3556)
+constexpr uint32_t BM_AND_FREQ = 0x100u;
 int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t* d_out_doc,
                     float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, bool has_or,
-                    uint32_t nt_max, uint32_t np_max, bool all_probed, hipStream_t st);
+                    uint32_t nt_max, uint32_t np_max, bool all_probed, hipStream_t st, bool any_frequent = false);
 // ---- implemented in synth.hip
 int ssi_vec_synth(ss_shard* s, uint64_t seed, hipStream_t st);
 int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const uint8_t* d_lentab, hipStream_t st);

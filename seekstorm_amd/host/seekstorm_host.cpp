@@ -50,7 +50,7 @@ Shard::~Shard() {
 int Shard::upload_lexical(uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t n_terms, const uint64_t* term_offsets,
                           const uint32_t* doc_ids, const uint16_t* tfs) {
   if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
-  ngram_components_.clear(); ngram_component_df_.clear();  // a new image: no index.bin n-gram keys behind the term ids
+  lexical_fields_ = 1; ngram_components_.clear(); ngram_component_df_.clear();  // a new image: no index.bin n-gram keys behind the term ids
   const int rc = ss_bm25_upload(h_, n_docs, doclen_bytes, n_terms, term_offsets, doc_ids, tfs);
   n_docs_ = rc == SS_OK ? n_docs : 0;
   return rc;
@@ -60,7 +60,7 @@ int Shard::upload_lexical_fields(uint64_t n_docs, uint32_t n_fields, const uint8
                                  const uint64_t* term_offsets, const uint32_t* doc_ids, const uint8_t* field_ids,
                                  const uint16_t* tfs) {
   if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
-  ngram_components_.clear(); ngram_component_df_.clear();  // a new image: no index.bin n-gram keys behind the term ids
+  lexical_fields_ = n_fields; ngram_components_.clear(); ngram_component_df_.clear();  // a new image: no index.bin n-gram keys behind the term ids
   const int rc = ss_bm25_upload_fields(h_, n_docs, n_fields, doclen_bytes, boost, n_terms, term_offsets, doc_ids, field_ids, tfs);
   n_docs_ = rc == SS_OK ? n_docs : 0;
   return rc;
@@ -77,6 +77,7 @@ int Shard::upload_vectors(uint64_t n_rows, uint32_t dim, const float* rows, cons
 
 int Shard::open_index_bin(const uint8_t* bytes, uint64_t len, uint32_t key_head_size, std::vector<uint64_t>* term_keys) {
   if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
+  lexical_fields_ = 1;
   ss_index_bin* ix = nullptr;
   int rc = ss_index_bin_open(bytes, len, 1, key_head_size, 11, &ix);  // open_index always uses 2048 segments (index.rs:3285)
   if (rc) return rc;
@@ -128,7 +129,7 @@ int Shard::set_deleted(const uint64_t* doc_ids, uint64_t n) {
 int Shard::synth_lexical(uint64_t seed, uint64_t n_docs, uint32_t n_terms, const uint32_t* thresh32,
                          const uint8_t* len_table1024) {
   if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
-  ngram_components_.clear(); ngram_component_df_.clear();  // a new image: no index.bin n-gram keys behind the term ids
+  lexical_fields_ = 1; ngram_components_.clear(); ngram_component_df_.clear();  // a new image: no index.bin n-gram keys behind the term ids
   const int rc = ss_bm25_synth(h_, seed, n_docs, n_terms, thresh32, len_table1024);
   n_docs_ = rc == SS_OK ? n_docs : 0;
   return rc;
@@ -176,7 +177,26 @@ std::vector<ResultObject> Shard::search_lexical_batch(const std::vector<ss_bm25_
   std::vector<uint32_t> doc(nq * kk), cnt(nq);
   std::vector<float> score(nq * kk);
   std::vector<uint64_t> tot(nq);
-  const int rc = h_ ? ss_bm25_search(h_, (uint32_t)nq, queries.data(), (uint32_t)k, (uint32_t)result_type, doc.data(),
+  // all_terms_frequent (intersection.rs:198-209), evaluated where the reference evaluates it: N > top_k << 8 and
+  // posting_count / N >= 0.5 (f32) for every term of an intersection of several terms -> the query is marked and ranks
+  // only docs whose every tf >= 10 (one indexed field, <= 7 terms)
+  std::vector<ss_bm25_query> marked;
+  const ss_bm25_query* qp = queries.data();
+  if (h_ && lexical_fields_ == 1 && result_type != ResultType::Count && n_docs_ > ((uint64_t)k << 8)) {
+    for (size_t q = 0; q < nq; q++) {
+      const ss_bm25_query& Q = queries[q];
+      if ((Q.op & 0xFFu) != SS_OP_INTERSECTION || Q.n_terms < 2 || Q.n_terms > 7) continue;
+      uint64_t df[SS_MAX_QUERY_TERMS];
+      if (ss_bm25_term_df(h_, Q.n_terms, Q.term, df) != SS_OK) continue;
+      bool all = true;
+      for (uint32_t t = 0; t < Q.n_terms; t++) all = all && (float)df[t] / (float)n_docs_ >= 0.5f;
+      if (!all) continue;
+      if (marked.empty()) marked = queries;
+      marked[q].op |= SS_OP_ALL_TERMS_FREQUENT;
+    }
+    if (!marked.empty()) qp = marked.data();
+  }
+  const int rc = h_ ? ss_bm25_search(h_, (uint32_t)nq, qp, (uint32_t)k, (uint32_t)result_type, doc.data(),
                                      score.data(), cnt.data(), tot.data())
                     : (create_rc_ ? create_rc_ : SS_ESTATE);
   for (size_t q = 0; q < nq; q++) {

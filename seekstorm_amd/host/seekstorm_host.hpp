@@ -137,6 +137,7 @@ class Shard {
   uint64_t n_docs_ = 0, n_rows_ = 0;
   uint32_t dim_ = 0;
   bool i8_ = false;
+  uint32_t lexical_fields_ = 1;                // indexed fields of the lexical image
   std::vector<uint8_t> ngram_components_;      // per term id of an opened index.bin: components of its key (1 = SingleTerm)
   std::vector<uint32_t> ngram_component_df_;   // posting count of the component term (n-gram components)
 };

@@ -145,6 +145,7 @@ class IndexBin:
 
     def __init__(self, data, indexed_field_count=1, key_head_size=20, segment_number_bits=11, min_posting_count=0):
         self._buf = np.frombuffer(bytes(data), np.uint8).copy()  # the handle borrows these bytes
+        self.indexed_field_count = int(indexed_field_count)
         h = C.c_void_p()
         N.check(N.lib().ss_index_bin_open(self._buf.ctypes.data, len(self._buf), indexed_field_count, key_head_size,
                                           segment_number_bits, C.byref(h)), "ss_index_bin_open")
@@ -213,6 +214,7 @@ class Shard:
         self._h = h
         self._df_cache = {}
         self.indexed_doc_count = 0
+        self.lexical_field_count = 1
         self.vector_count = 0
         self.dim = 0
         self.vector_precision = "f32"  # "i8": Precision::I8 image, queries are quantised with quantize_f32_to_i8
@@ -237,6 +239,7 @@ class Shard:
         N.check(N.lib().ss_bm25_upload(self._h, int(n_docs), N.ptr(dl, N.u8p), len(off) - 1, N.ptr(off, N.u64p),
                                        N.ptr(d, N.u32p), N.ptr(t, N.u16p)), "ss_bm25_upload")
         self.indexed_doc_count = int(n_docs)
+        self.lexical_field_count = 1
         self._df_cache.clear()
 
     def upload_lexical_fields(self, n_docs, doclen_bytes_fields, boost, term_offsets, doc_ids, field_ids, tfs):
@@ -251,6 +254,7 @@ class Shard:
                                               len(off) - 1, N.ptr(off, N.u64p), N.ptr(d, N.u32p), N.ptr(f, N.u8p), N.ptr(t, N.u16p)),
                 "ss_bm25_upload_fields")
         self.indexed_doc_count = int(n_docs)
+        self.lexical_field_count = int(dl.shape[0])
         self._df_cache.clear()
 
     def upload_ref_blocks(self, n_docs, doclen_bytes, term_blocks):
@@ -269,6 +273,7 @@ class Shard:
         N.check(N.lib().ss_bm25_upload_ref_blocks(self._h, int(n_docs), N.ptr(dl, N.u8p), len(term_blocks), N.ptr(offs, N.u64p),
                                                   C.cast(arr, C.c_void_p)), "ss_bm25_upload_ref_blocks")
         self.indexed_doc_count = int(n_docs)
+        self.lexical_field_count = 1
         self._df_cache.clear()
 
     def upload_index_bin(self, ix: "IndexBin", boost=None):
@@ -276,6 +281,7 @@ class Shard:
         b = None if boost is None else np.ascontiguousarray(boost, np.float32)
         N.check(N.lib().ss_bm25_upload_index_bin_fields(self._h, ix._h, N.ptr(b, N.f32p)), "ss_bm25_upload_index_bin")
         self.indexed_doc_count = int(ix.indexed_doc_count)
+        self.lexical_field_count = int(ix.indexed_field_count)
         self._df_cache.clear()
 
     def upload_vector_bin(self, data, dim, i8=False, use_record_scale=False):
@@ -324,6 +330,7 @@ class Shard:
         N.check(N.lib().ss_bm25_synth(self._h, int(seed), int(n_docs), len(th), N.ptr(th, N.u32p), N.ptr(tab, N.u8p)),
                 "ss_bm25_synth")
         self.indexed_doc_count = int(n_docs)
+        self.lexical_field_count = 1
         self._df_cache.clear()
 
     def upload_vectors(self, rows, row_doc_ids=None):
@@ -449,8 +456,36 @@ class Shard:
                 q["term"][i, len(tl) + j] = t
         return q
 
+    def mark_all_terms_frequent(self, queries, k):
+        """The reference's all_terms_frequent condition (intersection.rs:198-209), evaluated where the reference evaluates
+        it -- on the host, per query: indexed_doc_count > top_k << 8 and posting_count / indexed_doc_count >= 0.5 (f32) for
+        every term of an intersection of several terms.  Returns the queries with SS_OP_ALL_TERMS_FREQUENT set where it
+        holds (a copy if anything changed): such a query counts every match but ranks only docs whose every tf >= 10."""
+        if self.indexed_doc_count <= (int(k) << 8):
+            return queries
+        cand = np.nonzero(((queries["op"] & 0xFF) == int(QueryType.Intersection)) & (queries["n_terms"] > 1) &
+                          (queries["n_terms"] <= 7))[0]
+        if len(cand) == 0:
+            return queries
+        nf = np.float32(self.indexed_doc_count)
+        out = queries
+        for i in cand:
+            terms = [int(t) for t in queries["term"][i, :int(queries["n_terms"][i])]]
+            missing = [t for t in terms if t not in self._df_cache]
+            if missing:
+                for t, df in zip(missing, self.posting_count(missing)):
+                    self._df_cache[t] = int(df)
+            if all(np.float32(self._df_cache[t]) / nf >= np.float32(0.5) for t in terms):
+                if out is queries:
+                    out = queries.copy()
+                out["op"][i] |= 0x80000000
+        return out
+
     # ---- batched executors (one C-ABI call per batch)
-    def search_lexical_batch(self, queries, k, result_type=ResultType.TopkCount):
+    def search_lexical_batch(self, queries, k, result_type=ResultType.TopkCount, reference_shortcuts=True):
+        """reference_shortcuts: apply all_terms_frequent where its condition holds, as the reference does (one indexed field)"""
+        if reference_shortcuts and result_type != ResultType.Count and self.lexical_field_count == 1:
+            queries = self.mark_all_terms_frequent(queries, k)
         nq = len(queries)
         kk = max(int(k), 1)
         doc = np.full((nq, kk), N.SS_NO_DOC, np.uint32)

@@ -92,6 +92,55 @@ def test_vector_multi_record_docs_dedup(S, O, n_rows, n_docs, k):
     sh.close()
 
 
+def test_all_terms_frequent_shortcut(S, O):
+    """intersection.rs:198-209 + add_result.rs:2091-2104: when N > 256 k and every term of an intersection is in at least
+    half of the docs, a doc with some tf < 10 is counted but not ranked.  The host mirror evaluates the condition like the
+    reference and marks the query; counts stay exact; every result type, both strategies, with NOT terms and tombstones"""
+    rng = np.random.default_rng(77)
+    n_docs = 60_000
+    dl = O.lex_doclen(n_docs)
+    dfs = [40_000, 33_000, 31_000, 9_000]
+    lists = []
+    for df in dfs:
+        d = np.sort(rng.choice(n_docs, df, replace=False)).astype(np.uint32)
+        t = np.minimum(rng.geometric(0.25, df), 700).astype(np.uint16)   # 7.5 % of the postings have tf >= 10
+        lists.append((d, t))
+    offs = np.zeros(len(lists) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(l[0]) for l in lists])
+    docs, tfs = np.concatenate([l[0] for l in lists]), np.concatenate([l[1] for l in lists])
+    sh = S.Shard(0)
+    sh.upload_lexical(n_docs, dl, offs, docs, tfs)
+    osh = O.Shard(n_docs, dl, offs, docs, tfs)
+    gone = list(range(2, n_docs, 53))
+    sh.set_deleted(gone)
+    osh.set_deleted(gone)
+    cases = [([0, 1], []), ([0, 1, 2], []), ([0, 3], []), ([1, 2], [3]), ([2], [])]
+    flagged = [True, True, False, True, False]
+    q = sh.make_queries([c[0] for c in cases], S.QueryType.Intersection, [c[1] for c in cases])
+    differs = 0
+    for k in (10, 200, 300):   # 60 000 > 256 * 200, but not > 256 * 300: no shortcut at k = 300
+        marked = sh.mark_all_terms_frequent(q, k)
+        assert [bool(x >> 31) for x in marked["op"]] == [f and k < 300 for f in flagged]
+        for strat in (0, 1):
+            sh.set_strategy(strat)
+            for rt in (S.ResultType.TopkCount, S.ResultType.Topk):
+                doc, score, cnt, tot = sh.search_lexical_batch(q, k, rt)
+                for i, (pos, neg) in enumerate(cases):
+                    od, os_, otot = osh.search_exhaustive(pos, O.OP_AND, k, neg, reference_shortcuts=True)
+                    plain = osh.search_exhaustive(pos, O.OP_AND, k, neg)
+                    differs += int(flagged[i] and k < 300 and not np.array_equal(plain[0], od))
+                    if rt == S.ResultType.TopkCount:
+                        assert int(tot[i]) == otot == plain[2]
+                    _check_topk(doc[i], score[i], cnt[i], od, os_)
+    assert differs >= 4  # the shortcut really changes answers here
+    sh.set_strategy(0)
+    # without the mirror's marking the answer is the exact top-k
+    doc, score, cnt, tot = sh.search_lexical_batch(q, 10, reference_shortcuts=False)
+    od, os_, _ = osh.search_exhaustive([0, 1], O.OP_AND, 10, [])
+    _check_topk(doc[0], score[0], cnt[0], od, os_)
+    sh.close()
+
+
 def test_vector_select_refine_edge_cases(S, O):
     """the refine's radix select: all scores equal (the k-th key is decided in the row bytes of the key: the k smallest
     rows win), k = 1, exactly k rows, and a handful of distinct scores over many rows"""
