@@ -37,5 +37,15 @@ out["m_body"] = np.frombuffer(body, np.uint8)
 out["m_docs"] = np.array(d, np.uint16)
 out["m_fields"] = np.array(f, np.uint8)
 out["m_tfs"] = np.array(t, np.uint16)
+# an n-gram key (trigram type: three component tfs in front of every record, no embedded pointers), 3-byte pointers inside
+docs = np.sort(rng.choice(65536, 500, replace=False))
+counts = rng.integers(1, 4, size=500)
+comp = rng.integers(1, 400, size=(500, 3))
+comp[:20] = rng.integers(128, 20000, size=(20, 3))
+bid, ctp, cnt, pivot, body = RF.encode_term(docs, counts, rng, base_bytes=bytes(range(9)), positions_limit=900, ngram_tfs=comp)[0]
+out["g_head"] = np.array([bid, ctp, cnt, pivot, 3], np.uint64)
+out["g_body"] = np.frombuffer(body, np.uint8)
+out["g_docs"] = docs.astype(np.uint16)
+out["g_tfs"] = comp.astype(np.uint16)
 np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_format.npz"), **out)
 print({k: v.shape for k, v in out.items()})

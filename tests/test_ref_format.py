@@ -512,3 +512,13 @@ def test_golden_key_bodies():
     assert n == cnt and int(first[cnt]) == m
     assert np.array_equal(np.repeat(dd[:cnt], np.diff(first[:cnt + 1])), g["m_docs"])
     assert np.array_equal(ff[:m], g["m_fields"]) and np.array_equal(tt[:m], g["m_tfs"])
+    # n-gram key: every component's tf
+    bid, ctp, cnt, pivot, nc = (int(x) for x in g["g_head"])
+    buf = g["g_body"].copy()
+    rb = N.RefBlock(bid, ctp, cnt - 1, pivot, buf.ctypes.data, len(buf))
+    d = np.zeros(65536, np.uint16)
+    t = np.zeros(65536, np.uint16)
+    assert 0 < pivot < cnt
+    for c in range(nc):
+        assert N.lib().ss_ref_decode_block_ngram(C.byref(rb), nc, c, N.ptr(d, N.u16p), N.ptr(t, N.u16p)) == cnt
+        assert np.array_equal(d[:cnt], g["g_docs"]) and np.array_equal(t[:cnt], g["g_tfs"][:, c])
