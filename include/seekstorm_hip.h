@@ -211,6 +211,34 @@ int ss_bm25_search_dev(ss_shard* s, uint32_t n_queries, const ss_bm25_query* d_q
                        uint32_t result_type, uint32_t ops_mask, uint32_t* d_out_doc, float* d_out_score,
                        uint32_t* d_out_count, uint64_t* d_out_total, void* stream);
 
+/* ------------------------------------------------------------------ facet filter (search.rs FacetFilter, add_result.rs:341-482)
+ * facet.bin holds one fixed-size record per doc (facets_size_sum bytes, every facet at its offset: facet.json).  A search
+ * with a facet filter drops a doc unless EVERY filter passes -- a numeric value inside the half-open range [lo, hi) as
+ * Rust's Range::contains, a String16 / String32 id inside the wanted set -- before it is counted (add_result.rs:3499-
+ * 3501): a filtered doc neither counts nor ranks.  The filter is evaluated once per call over all docs into an exclusion
+ * bitmap that stands in for the tombstone bitmap; all queries of the call share it (the reference has one filter per
+ * search call).  lo / hi: the value's bits (two's complement for I*, IEEE bits for F32 in the low word / F64); Timestamp =
+ * I64.  Point (distance) filters are not offered.  Calls that share a shard must be stream-ordered (one bitmap per shard). */
+enum { SS_FACET_U8 = 0, SS_FACET_U16, SS_FACET_U32, SS_FACET_U64, SS_FACET_I8, SS_FACET_I16, SS_FACET_I32, SS_FACET_I64,
+       SS_FACET_F32, SS_FACET_F64, SS_FACET_STRING16, SS_FACET_STRING32 };
+#define SS_MAX_FACET_FILTERS 8
+typedef struct ss_facet_filter {
+  uint32_t offset;      /* of the facet inside a record */
+  uint32_t type;        /* SS_FACET_* */
+  uint64_t lo, hi;      /* numeric types: passes iff lo <= value < hi */
+  uint32_t n_values;    /* string types: passes iff the id is one of values[0 .. n_values) (<= 8) */
+  uint32_t values[8];
+  uint32_t reserved;
+} ss_facet_filter;
+int ss_facet_upload(ss_shard* s, uint64_t n_docs, uint32_t record_size, const uint8_t* records);
+int ss_bm25_search_filtered(ss_shard* s, uint32_t n_queries, const ss_bm25_query* queries, uint32_t k, uint32_t result_type,
+                            uint32_t n_filters, const ss_facet_filter* filters /* host */, uint32_t* out_doc, float* out_score,
+                            uint32_t* out_count, uint64_t* out_total);
+int ss_bm25_search_filtered_dev(ss_shard* s, uint32_t n_queries, const ss_bm25_query* d_queries, uint32_t k,
+                                uint32_t result_type, uint32_t ops_mask, uint32_t n_filters,
+                                const ss_facet_filter* filters /* host */, uint32_t* d_out_doc, float* d_out_score,
+                                uint32_t* d_out_count, uint64_t* d_out_total, void* stream);
+
 /* ------------------------------------------------------------------ vector image
  * rows: row-major [n_rows x dim] f32, already L2-normalised for cosine (vector.rs:585-596); the uploader of
  * a real vector.bin strips the 24-byte VectorHeader (vector.rs:62-73).  row_doc_ids may be NULL (= row index).

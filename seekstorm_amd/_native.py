@@ -38,6 +38,15 @@ class RefBlock(C.Structure):  # ss_ref_block
                 ("pointer_pivot_p_docid", C.c_uint16), ("byte_array", C.c_void_p), ("byte_array_len", C.c_uint64)]
 
 
+class FacetFilterC(C.Structure):  # ss_facet_filter
+    _fields_ = [("offset", C.c_uint32), ("type", C.c_uint32), ("lo", C.c_uint64), ("hi", C.c_uint64), ("n_values", C.c_uint32),
+                ("values", C.c_uint32 * 8), ("reserved", C.c_uint32)]
+
+
+FACET_TYPES = {"u8": 0, "u16": 1, "u32": 2, "u64": 3, "i8": 4, "i16": 5, "i32": 6, "i64": 7, "f32": 8, "f64": 9,
+               "string16": 10, "string32": 11}
+
+
 class AnnModeC(C.Structure):  # ss_ann_mode
     _fields_ = [("n_probe", C.c_uint32), ("cluster_threshold_raw", C.c_float), ("field_mask", C.c_uint64)]
 
@@ -94,6 +103,11 @@ SYMBOLS = [
     ("ss_vec_search_i8", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, f32p, C.c_uint32, C.c_float, u32p, f32p, u32p, u64p]),
     ("ss_vec_search_i8_dev", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("ss_facet_upload", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
+    ("ss_bm25_search_filtered", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, u32p,
+                                          f32p, u32p, u64p]),
+    ("ss_bm25_search_filtered_dev", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("ss_vec_set_clusters", C.c_int, [C.c_void_p, C.c_uint32, u32p, u32p]),
     ("ss_vec_cluster_info", C.c_int, [C.c_void_p, u32p, u32p]),
     ("ss_vec_set_fields", C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),

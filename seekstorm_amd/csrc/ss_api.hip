@@ -15,6 +15,25 @@
     if (_rc) return _rc;   \
   } while (0)
 
+namespace {
+// runs `search` with the shard's tombstone bitmap replaced by the filter's exclusion bitmap (built on `st` first)
+template <typename F>
+int with_facet_filter(ss_shard* s, uint32_t n_filters, const ss_facet_filter* filters, hipStream_t st, F search) {
+  if (n_filters == 0) return search();
+  if (!s->d_facets || s->facet_docs < s->bm_n_docs) return SS_ESTATE;  // a record for every doc of the lexical image
+  int rc = ssi_facet_build(s, n_filters, filters, st);
+  if (rc) return rc;
+  uint32_t* del = s->d_deleted;
+  const uint64_t words = s->deleted_words, n = s->n_deleted;
+  s->d_deleted = s->d_filter_bits;
+  s->deleted_words = (s->facet_docs + 31) / 32;
+  s->n_deleted = 1;  // "some doc may be excluded": the kernels take their filtered instantiations
+  rc = search();
+  s->d_deleted = del; s->deleted_words = words; s->n_deleted = n;
+  return rc;
+}
+}  // namespace
+
 extern "C" {
 
 int ss_abi_version(void) { return SS_ABI_VERSION; }
@@ -77,7 +96,7 @@ int ss_shard_destroy(ss_shard* s) {
   (void)hipStreamSynchronize(s->stream);
   free_vec(s);
   free_bm25(s);
-  void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_part, s->d_deleted, s->d_vq};
+  void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_part, s->d_deleted, s->d_vq, s->d_facets, s->d_filter_bits};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int kx = 0; kx < 2; kx++)
     for (auto& pr : s->prof.pending[kx]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -263,6 +282,23 @@ int ss_set_deleted(ss_shard* s, const uint64_t* doc_ids, uint64_t n) {
   return SS_OK;
 }
 
+// ---- facet filter (facet.hip): facet.bin records on the device, a filtered search = the search with the filter's exclusion
+// bitmap standing in for the tombstone bitmap
+int ss_facet_upload(ss_shard* s, uint64_t n_docs, uint32_t record_size, const uint8_t* records) {
+  if (!s || !records || n_docs == 0 || record_size == 0 || n_docs > 0xFFFFFFFEull) return SS_EINVAL;
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  SS_HIP(hipStreamSynchronize(s->stream));
+  if (s->d_facets) { (void)hipFree(s->d_facets); s->d_facets = nullptr; }
+  s->facet_docs = 0; s->facet_record_size = 0;
+  SS_HIP(hipMalloc(&s->d_facets, (size_t)n_docs * record_size));
+  SS_HIP(hipMemcpy(s->d_facets, records, (size_t)n_docs * record_size, hipMemcpyHostToDevice));
+  s->facet_docs = n_docs;
+  s->facet_record_size = record_size;
+  return SS_OK;
+}
+
+
 // Probe-index budget of the NEXT image build (bytes; 0 = half of the free device memory).  Rows (1.9 MB per posting list
 // at 10 M docs) go to the longest lists first; a query touching a list without a row is ranked by the scan kernels.
 int ss_bm25_set_probe_budget(ss_shard* s, uint64_t max_bytes) {
@@ -365,6 +401,12 @@ static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q,
 
 int ss_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k, uint32_t rt, uint32_t* out_doc,
                    float* out_score, uint32_t* out_count, uint64_t* out_total) {
+  return ss_bm25_search_filtered(s, nq, q, k, rt, 0, nullptr, out_doc, out_score, out_count, out_total);
+}
+
+int ss_bm25_search_filtered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k, uint32_t rt, uint32_t n_filters,
+                            const ss_facet_filter* filters, uint32_t* out_doc, float* out_score, uint32_t* out_count,
+                            uint64_t* out_total) {
   if (!s || !q || !out_count || !out_total) return SS_EINVAL;
   if (rt > SS_RT_TOPKCOUNT) return SS_EINVAL;
   if (rt != SS_RT_COUNT && (k == 0 || k > SS_MAX_K || !out_doc || !out_score)) return SS_EINVAL;
@@ -385,8 +427,10 @@ int ss_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k,
     s->bq_cap = (size_t)nq * sizeof(ss_bm25_query);
   }
   SS_HIP(hipMemcpyAsync(s->d_bq, q, (size_t)nq * sizeof(ss_bm25_query), hipMemcpyHostToDevice, s->stream));
-  SS_TRY(ssi_bm25_search(s, nq, (const ss_bm25_query*)s->d_bq, kk, rt, s->d_out_doc, s->d_out_score, s->d_out_count,
-                         s->d_out_total, has_and, has_or, nt_max, np_max, all_probed, s->stream, any_frequent));
+  SS_TRY(with_facet_filter(s, n_filters, filters, s->stream, [&]() {
+    return ssi_bm25_search(s, nq, (const ss_bm25_query*)s->d_bq, kk, rt, s->d_out_doc, s->d_out_score, s->d_out_count,
+                           s->d_out_total, has_and, has_or, nt_max, np_max, all_probed, s->stream, any_frequent);
+  }));
   if (kk) {
     SS_HIP(hipMemcpyAsync(out_doc, s->d_out_doc, (size_t)nq * kk * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     SS_HIP(hipMemcpyAsync(out_score, s->d_out_score, (size_t)nq * kk * sizeof(float), hipMemcpyDeviceToHost, s->stream));
@@ -400,6 +444,12 @@ int ss_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k,
 int ss_bm25_search_dev(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t ops_mask,
                        uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total,
                        void* stream) {
+  return ss_bm25_search_filtered_dev(s, nq, d_q, k, rt, ops_mask, 0, nullptr, d_out_doc, d_out_score, d_out_count, d_out_total, stream);
+}
+
+int ss_bm25_search_filtered_dev(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t ops_mask,
+                                uint32_t n_filters, const ss_facet_filter* filters, uint32_t* d_out_doc, float* d_out_score,
+                                uint32_t* d_out_count, uint64_t* d_out_total, void* stream) {
   if (!s || !d_q || !d_out_count || !d_out_total) return SS_EINVAL;
   if (rt > SS_RT_TOPKCOUNT) return SS_EINVAL;
   if (rt != SS_RT_COUNT && (k == 0 || k > SS_MAX_K || !d_out_doc || !d_out_score)) return SS_EINVAL;
@@ -407,14 +457,16 @@ int ss_bm25_search_dev(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint3
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   hipStream_t st = stream ? (hipStream_t)stream : s->stream;
-  return ssi_bm25_search(s, nq, d_q, rt == SS_RT_COUNT ? 0 : k, rt, d_out_doc, d_out_score, d_out_count, d_out_total,
-                         (ops_mask & 1u) != 0, (ops_mask & 2u) != 0 || (ops_mask & 3u) == 0,
-                         (ops_mask >> 8) & 0xFFu ? (ops_mask >> 8) & 0xFFu : SS_MAX_QUERY_TERMS,
-                         (ops_mask >> 16) & 0xFFu ? (ops_mask >> 16) & 0xFFu
-                                                  : ((ops_mask >> 8) & 0xFFu ? (ops_mask >> 8) & 0xFFu : SS_MAX_QUERY_TERMS),
-                         // the caller vouches for the probe rows of its terms (ss_bm25_term_probed) unless none were rationed
-                         s->bm_probe_rows != 0 && (s->bm_probe_rows >= s->bm_n_terms || (ops_mask & 4u) != 0), st,
-                         (ops_mask & 8u) != 0);
+  return with_facet_filter(s, n_filters, filters, st, [&]() {
+    return ssi_bm25_search(s, nq, d_q, rt == SS_RT_COUNT ? 0 : k, rt, d_out_doc, d_out_score, d_out_count, d_out_total,
+                           (ops_mask & 1u) != 0, (ops_mask & 2u) != 0 || (ops_mask & 3u) == 0,
+                           (ops_mask >> 8) & 0xFFu ? (ops_mask >> 8) & 0xFFu : SS_MAX_QUERY_TERMS,
+                           (ops_mask >> 16) & 0xFFu ? (ops_mask >> 16) & 0xFFu
+                                                    : ((ops_mask >> 8) & 0xFFu ? (ops_mask >> 8) & 0xFFu : SS_MAX_QUERY_TERMS),
+                           // the caller vouches for the probe rows of its terms (ss_bm25_term_probed) unless none were rationed
+                           s->bm_probe_rows != 0 && (s->bm_probe_rows >= s->bm_n_terms || (ops_mask & 4u) != 0), st,
+                           (ops_mask & 8u) != 0);
+  });
 }
 
 // ------------------------------------------------------------------ vectors

@@ -123,6 +123,11 @@ struct ss_shard {
   std::vector<uint64_t> h_df;      // posting_count per term (the df the host needs for idf)
   // probe index: membership (64-doc bit records) and rank (index of each group's first posting) of a doc in a term's
   // segment without reading the segment; the bit records are also the bitmaps exact union counts are popcounted from
+  uint8_t* d_facets = nullptr;     // facet.bin: one record of facet_record_size bytes per doc (ss_facet_upload)
+  uint64_t facet_docs = 0;
+  uint32_t facet_record_size = 0;
+  uint32_t* d_filter_bits = nullptr;  // exclusion bitmap of the facet-filtered search in flight (facet.hip), grow-only
+  uint64_t filter_words_cap = 0;
   uint32_t* d_deleted = nullptr;   // tombstone bitmap by shard-local doc id (delete.bin / delete_hashset), null = none
   uint64_t deleted_words = 0, n_deleted = 0;
   uint2* d_probe = nullptr;        // [probe_rows + 1][n_sub][BM_SUB / 64] 64 doc bits; the last row is all zero (absent terms)
@@ -175,6 +180,8 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float*
 struct VAnn;
 int ssi_vec8_qprep(ss_shard* s, const int8_t* d_queries, uint32_t nb, hipStream_t st);
 int ssi_vec8_launch_scan(ss_shard* s, uint32_t tile0, uint32_t ntiles, const float* d_qscale, const VAnn* ann, hipStream_t st);
+// ---- implemented in facet.hip: exclusion bitmap (failed facet filters | tombstones) into s->d_filter_bits
+int ssi_facet_build(ss_shard* s, uint32_t n_filters, const ss_facet_filter* filters, hipStream_t st);
 // ---- implemented in vec_ann.hip
 // after the batch's queries are in s->d_Qf (qprep): medoid scores, per-query selection, tile list -> *out
 int ssi_vec_ann_prepare(ss_shard* s, uint32_t nb, const float* d_qscale, const ss_ann_mode* mode, VAnn* out,

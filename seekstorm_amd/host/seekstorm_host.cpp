@@ -168,8 +168,13 @@ int Shard::make_query(const std::vector<uint32_t>& terms, QueryType qt, ss_bm25_
   return SS_OK;
 }
 
+int Shard::upload_facets(uint64_t n_docs, uint32_t record_size, const uint8_t* records) {
+  if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
+  return ss_facet_upload(h_, n_docs, record_size, records);
+}
+
 std::vector<ResultObject> Shard::search_lexical_batch(const std::vector<ss_bm25_query>& queries, size_t k,
-                                                      ResultType result_type) {
+                                                      ResultType result_type, const std::vector<ss_facet_filter>& facet_filter) {
   const size_t nq = queries.size();
   std::vector<ResultObject> out(nq);
   if (nq == 0) return out;
@@ -196,8 +201,9 @@ std::vector<ResultObject> Shard::search_lexical_batch(const std::vector<ss_bm25_
     }
     if (!marked.empty()) qp = marked.data();
   }
-  const int rc = h_ ? ss_bm25_search(h_, (uint32_t)nq, qp, (uint32_t)k, (uint32_t)result_type, doc.data(),
-                                     score.data(), cnt.data(), tot.data())
+  const int rc = h_ ? ss_bm25_search_filtered(h_, (uint32_t)nq, qp, (uint32_t)k, (uint32_t)result_type,
+                                              (uint32_t)facet_filter.size(), facet_filter.empty() ? nullptr : facet_filter.data(),
+                                              doc.data(), score.data(), cnt.data(), tot.data())
                     : (create_rc_ ? create_rc_ : SS_ESTATE);
   for (size_t q = 0; q < nq; q++) {
     ResultObject& ro = out[q];
@@ -296,7 +302,7 @@ std::vector<ResultObject> Shard::search_vector_batch(const float* query_vectors,
 }
 
 ResultObject Shard::search_lexical_shard(const std::vector<uint32_t>& query_terms, QueryType query_type_default, size_t offset,
-                                         size_t length, ResultType result_type) {
+                                         size_t length, ResultType result_type, const std::vector<ss_facet_filter>& facet_filter) {
   ss_bm25_query q;
   const int rc = make_query(query_terms, query_type_default, &q);
   if (rc != SS_OK) {
@@ -304,7 +310,7 @@ ResultObject Shard::search_lexical_shard(const std::vector<uint32_t>& query_term
     ro.last_error = rc;
     return ro;
   }
-  ResultObject ro = std::move(search_lexical_batch({q}, offset + length, result_type)[0]);
+  ResultObject ro = std::move(search_lexical_batch({q}, offset + length, result_type, facet_filter)[0]);
   if (offset) {  // drain offset (search.rs:3585-3593)
     ro.results.erase(ro.results.begin(), ro.results.begin() + std::min(offset, ro.results.size()));
     ro.result_count = ro.results.size();

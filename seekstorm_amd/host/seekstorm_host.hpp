@@ -115,14 +115,17 @@ class Shard {
 
   // the reference's per-shard seams (one query)
   ResultObject search_lexical_shard(const std::vector<uint32_t>& query_terms, QueryType query_type_default, size_t offset,
-                                    size_t length, ResultType result_type);
+                                    size_t length, ResultType result_type, const std::vector<ss_facet_filter>& facet_filter = {});
   // field_filter: indexed field ids to search (the reference resolves the names through schema_map, vector.rs:1225-1237);
   // empty = every field
   ResultObject search_vector_shard(const float* query_vector /* normalised, dim() floats */, size_t length,
                                    const float* similarity_threshold, const AnnMode& ann_mode = AnnMode(),
                                    const std::vector<uint16_t>& field_filter = {});
   // batched forms used by the coalescer (results sorted by score desc, shard-local ids)
-  std::vector<ResultObject> search_lexical_batch(const std::vector<ss_bm25_query>& queries, size_t k, ResultType result_type);
+  // facet_filter (search.rs FacetFilter, add_result.rs:341-482): shared by the queries of the call; needs upload_facets
+  std::vector<ResultObject> search_lexical_batch(const std::vector<ss_bm25_query>& queries, size_t k, ResultType result_type,
+                                                 const std::vector<ss_facet_filter>& facet_filter = {});
+  int upload_facets(uint64_t n_docs, uint32_t record_size, const uint8_t* records);  // facet.bin records
   std::vector<ResultObject> search_vector_batch(const float* query_vectors, size_t n_queries, size_t k,
                                                 const float* similarity_threshold, const AnnMode& ann_mode = AnnMode(),
                                                 const std::vector<uint16_t>& field_filter = {});

@@ -456,6 +456,36 @@ class Shard:
                 q["term"][i, len(tl) + j] = t
         return q
 
+    def upload_facets(self, records, record_size=None):
+        """facet.bin: one record of facets_size_sum bytes per doc (bytes, or a [n_docs][record_size] uint8 array)"""
+        if isinstance(records, (bytes, bytearray, memoryview)):
+            r = np.frombuffer(bytes(records), np.uint8).reshape(-1, int(record_size))
+        else:
+            r = np.ascontiguousarray(records, np.uint8)
+        N.check(N.lib().ss_facet_upload(self._h, r.shape[0], r.shape[1], r.ctypes.data), "ss_facet_upload")
+
+    @staticmethod
+    def facet_filters(filters):
+        """[(offset, type, lo, hi)] for numeric facets -- passes iff lo <= value < hi, Rust's Range -- or
+        [(offset, "string16" | "string32", [ids])] -> ss_facet_filter array (FacetFilter / FilterSparse, search.rs:735-)"""
+        arr = (N.FacetFilterC * max(len(filters), 1))()
+        for i, f in enumerate(filters):
+            off, ty = int(f[0]), f[1]
+            arr[i].offset, arr[i].type = off, N.FACET_TYPES[ty]
+            if ty.startswith("string"):
+                ids = [int(x) for x in f[2]]
+                arr[i].n_values = len(ids)
+                for j, v in enumerate(ids):
+                    arr[i].values[j] = v
+            else:
+                dt = {"f32": np.float32, "f64": np.float64}.get(ty)
+                if dt is not None:
+                    bits = np.array([f[2], f[3]], dt).view(np.uint32 if ty == "f32" else np.uint64)
+                    arr[i].lo, arr[i].hi = int(bits[0]), int(bits[1])
+                else:
+                    arr[i].lo, arr[i].hi = int(f[2]) & 0xFFFFFFFFFFFFFFFF, int(f[3]) & 0xFFFFFFFFFFFFFFFF
+        return arr, len(filters)
+
     def mark_all_terms_frequent(self, queries, k):
         """The reference's all_terms_frequent condition (intersection.rs:198-209), evaluated where the reference evaluates
         it -- on the host, per query: indexed_doc_count > top_k << 8 and posting_count / indexed_doc_count >= 0.5 (f32) for
@@ -482,8 +512,9 @@ class Shard:
         return out
 
     # ---- batched executors (one C-ABI call per batch)
-    def search_lexical_batch(self, queries, k, result_type=ResultType.TopkCount, reference_shortcuts=True):
-        """reference_shortcuts: apply all_terms_frequent where its condition holds, as the reference does (one indexed field)"""
+    def search_lexical_batch(self, queries, k, result_type=ResultType.TopkCount, reference_shortcuts=True, facet_filter=None):
+        """reference_shortcuts: apply all_terms_frequent where its condition holds, as the reference does (one indexed field).
+        facet_filter: see facet_filters(); shared by the queries of the call (a filtered doc neither counts nor ranks)"""
         if reference_shortcuts and result_type != ResultType.Count and self.lexical_field_count == 1:
             queries = self.mark_all_terms_frequent(queries, k)
         nq = len(queries)
@@ -492,9 +523,11 @@ class Shard:
         score = np.zeros((nq, kk), np.float32)
         cnt = np.zeros(nq, np.uint32)
         tot = np.zeros(nq, np.uint64)
-        N.check(N.lib().ss_bm25_search(self._h, nq, queries.ctypes.data_as(C.c_void_p), int(k), int(result_type),
-                                       N.ptr(doc, N.u32p), N.ptr(score, N.f32p), N.ptr(cnt, N.u32p), N.ptr(tot, N.u64p)),
-                "ss_bm25_search")
+        farr, nf = self.facet_filters(facet_filter) if facet_filter else (None, 0)
+        N.check(N.lib().ss_bm25_search_filtered(self._h, nq, queries.ctypes.data_as(C.c_void_p), int(k), int(result_type), nf,
+                                                None if farr is None else C.cast(farr, C.c_void_p), N.ptr(doc, N.u32p),
+                                                N.ptr(score, N.f32p), N.ptr(cnt, N.u32p), N.ptr(tot, N.u64p)),
+                "ss_bm25_search_filtered")
         return doc, score, cnt, tot
 
     def search_vector_batch(self, query_vectors, k, similarity_threshold=None, ann_mode=None, with_clusters=False,

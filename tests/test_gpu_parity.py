@@ -92,6 +92,59 @@ def test_vector_multi_record_docs_dedup(S, O, n_rows, n_docs, k):
     sh.close()
 
 
+def test_facet_filter(S, O, lex):
+    """FacetFilter (search.rs:735-, is_facet_filter add_result.rs:341-482): a doc failing any filter neither counts nor
+    ranks.  Records as facet.bin lays them out (packed, unaligned offsets); numeric half-open ranges of every width and sign,
+    floats, string-id sets, several filters at once; unions and intersections, both strategies, on top of tombstones"""
+    sh, osh, n_docs = lex
+    rng = np.random.default_rng(91)
+    rec = np.dtype([("a", "u1"), ("b", "<u2"), ("c", "<i4"), ("d", "<f4"), ("e", "<u8"), ("f", "<i2"), ("g", "<f8"), ("h", "<u4")])
+    assert rec.itemsize == 33
+    v = np.zeros(n_docs, rec)
+    v["a"] = rng.integers(0, 256, n_docs); v["b"] = rng.integers(0, 5000, n_docs); v["c"] = rng.integers(-1000, 1000, n_docs)
+    v["d"] = rng.standard_normal(n_docs); v["e"] = rng.integers(0, 1 << 62, n_docs, dtype=np.uint64)
+    v["f"] = rng.integers(-300, 300, n_docs); v["g"] = rng.random(n_docs) * 1e6; v["h"] = rng.integers(0, 40, n_docs)
+    sh.upload_facets(v.view(np.uint8).reshape(n_docs, 33))
+    off = {n: rec.fields[n][1] for n in rec.names}
+    gone = list(range(11, n_docs, 379))
+    sh.set_deleted(gone)
+    osh.set_deleted(gone)
+    filter_sets = [
+        ([(off["a"], "u8", 10, 200)], (v["a"] >= 10) & (v["a"] < 200)),
+        ([(off["c"], "i32", -50, 400), (off["d"], "f32", -0.5, 1.25)], (v["c"] >= -50) & (v["c"] < 400) & (v["d"] >= np.float32(-0.5)) & (v["d"] < np.float32(1.25))),
+        ([(off["h"], "string32", [3, 17, 39]), (off["b"], "string16", [7, 8, 9, 10, 11, 4999, 0, 1])],
+         np.isin(v["h"], [3, 17, 39]) & np.isin(v["b"], [7, 8, 9, 10, 11, 4999, 0, 1])),
+        ([(off["e"], "u64", 1 << 60, 1 << 62), (off["f"], "i16", -300, 0), (off["g"], "f64", 2.5e5, 7.5e5), (off["b"], "u16", 100, 4000)],
+         (v["e"] >= (1 << 60)) & (v["f"] < 0) & (v["g"] >= 2.5e5) & (v["g"] < 7.5e5) & (v["b"] >= 100) & (v["b"] < 4000)),
+    ]
+    cases = [([10, 9, 8], S.QueryType.Union, O.OP_OR, []), ([10, 9], S.QueryType.Intersection, O.OP_AND, []),
+             ([8], S.QueryType.Union, O.OP_OR, []), ([10, 8], S.QueryType.Union, O.OP_OR, [9])]
+    for filt, keep in filter_sets:
+        excluded = sorted(set(np.nonzero(~keep)[0].tolist()) | set(gone))
+        osh.set_deleted(excluded)
+        for strat in (0, 1):
+            sh.set_strategy(strat)
+            for terms, qt, oop, neg in cases:
+                q = sh.make_queries([terms], qt, [neg])
+                for rt in (S.ResultType.TopkCount, S.ResultType.Count):
+                    doc, score, cnt, tot = sh.search_lexical_batch(q, 10, rt, facet_filter=filt)
+                    od, os_, otot = osh.search_exhaustive(terms, oop, 10, neg)
+                    assert int(tot[0]) == otot, (filt, terms, strat, rt)
+                    if rt != S.ResultType.Count:
+                        _check_topk(doc[0], score[0], cnt[0], od, os_)
+                        assert all(keep[int(d)] for d in doc[0][:cnt[0]])
+    sh.set_strategy(0)
+    # the filter is per call: the next unfiltered search sees only the tombstones again
+    osh.set_deleted(gone)
+    q = sh.make_queries([[10, 9]], S.QueryType.Union)
+    doc, score, cnt, tot = sh.search_lexical_batch(q, 10)
+    assert int(tot[0]) == osh.search_exhaustive([10, 9], O.OP_OR, 10)[2]
+    with pytest.raises(S.SeekStormHipError):
+        sh.search_lexical_batch(q, 10, facet_filter=[(31, "u32", 0, 5)])   # reads past the record
+    sh.set_deleted([])
+    osh.set_deleted([])
+
+
 def test_all_terms_frequent_shortcut(S, O):
     """intersection.rs:198-209 + add_result.rs:2091-2104: when N > 256 k and every term of an intersection is in at least
     half of the docs, a doc with some tf < 10 is counted but not ranked.  The host mirror evaluates the condition like the
