@@ -239,6 +239,17 @@ int ss_bm25_search_filtered_dev(ss_shard* s, uint32_t n_queries, const ss_bm25_q
                                 const ss_facet_filter* filters /* host */, uint32_t* d_out_doc, float* d_out_score,
                                 uint32_t* d_out_count, uint64_t* d_out_total, void* stream);
 
+/* Facet counting of ONE query (query_facets -> facet_count, add_result.rs:484-640): every counted doc -- the query's match set
+ * after NOT terms, tombstones and the facet filter -- adds one to the bucket of its value of the facet at facet_offset:
+ * a String16 / String32 facet's id (buckets = ids 0 .. n_buckets-1), or for a numeric facet the range whose lower bound is
+ * the last one <= the value (range_lower_bounds[n_buckets], ascending, the value's bits as in ss_facet_filter).
+ * out_counts [n_buckets + 1]: the last slot = docs outside the buckets (an id >= n_buckets, a value below the first
+ * bound).  *out_total (may be NULL) = the match count.  The match set is read from the probe index's bit records:
+ * SS_ENOTSUP if a list of the query has no probe row (ss_bm25_term_probed). */
+int ss_bm25_facet_count(ss_shard* s, const ss_bm25_query* query, uint32_t n_filters, const ss_facet_filter* filters,
+                        uint32_t facet_offset, uint32_t facet_type, uint32_t n_buckets, const uint64_t* range_lower_bounds,
+                        uint64_t* out_counts, uint64_t* out_total);
+
 /* ------------------------------------------------------------------ vector image
  * rows: row-major [n_rows x dim] f32, already L2-normalised for cosine (vector.rs:585-596); the uploader of
  * a real vector.bin strips the 24-byte VectorHeader (vector.rs:62-73).  row_doc_ids may be NULL (= row index).

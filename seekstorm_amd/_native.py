@@ -108,6 +108,8 @@ SYMBOLS = [
                                           f32p, u32p, u64p]),
     ("ss_bm25_search_filtered_dev", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("ss_bm25_facet_count", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, u64p, u64p,
+                                      u64p]),
     ("ss_vec_set_clusters", C.c_int, [C.c_void_p, C.c_uint32, u32p, u32p]),
     ("ss_vec_cluster_info", C.c_int, [C.c_void_p, u32p, u32p]),
     ("ss_vec_set_fields", C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),

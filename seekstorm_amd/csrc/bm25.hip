@@ -143,6 +143,31 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
 }
 
 // ---------------------------------------------------------------- host side
+// The match set of ONE query as a bitmap over the docs (bit d of word d / 64), from the probe index's bit records: what
+// facet counting walks (facet.hip).  The caller has checked that every list of the query has a probe row.
+int ssi_bm25_match_bits(ss_shard* s, const ss_bm25_query* d_q, unsigned long long* d_bits, unsigned long long* d_total, hipStream_t st) {
+  if (!s->d_post || !s->d_probe) return SS_ESTATE;
+  if (sizeof(bm_vquery) > s->vq_cap) {
+    if (s->d_vq) (void)hipFree(s->d_vq);
+    s->d_vq = nullptr; s->vq_cap = 0;
+    SS_HIP(hipMalloc(&s->d_vq, 64 * sizeof(bm_vquery)));
+    s->vq_cap = 64 * sizeof(bm_vquery);
+  }
+  uint32_t* tau = (uint32_t*)(d_bits);  // the expansion zeroes one threshold line per query: scratch, overwritten below
+  bm_expand_kernel<<<1, 128, 0, st>>>(d_q, (bm_vquery*)s->d_vq, 1, s->bm_n_fields, (const unsigned long long*)s->d_term_base,
+                                      s->d_boost, d_total, tau);
+  BmParams p{};
+  p.q = (const bm_vquery*)s->d_vq;
+  p.total = d_total;
+  p.del = s->n_deleted ? s->d_deleted : nullptr;
+  p.del_words = (uint32_t)s->deleted_words;
+  p.n_sub = s->bm_n_sub;
+  p.nq = 1;
+  int rc = ssi_bm25_launch_union_count(p, s->d_probe, s->d_probe_row, true, st, d_bits);
+  SS_HIP(hipGetLastError());
+  return rc;
+}
+
 int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t* d_out_doc,
                     float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, bool has_or,
                     uint32_t nt_max, uint32_t np_max, bool all_probed, hipStream_t st, bool any_frequent) {

@@ -399,7 +399,8 @@ __device__ __attribute__((noinline)) BmTop<KPL> bm_scan_tile(BmTop<KPL> T, uint3
 // scan kernels (bm25_fast.hip): NT-specialised for <= 4 terms and k <= 128, grouped generic kernel otherwise
 int ssi_bm25_launch_scan(const BmParams& p, uint32_t nt_max, bool has_and, int KPL, hipStream_t st);
 // exact union counts from the probe index's bit records (bm25_probe.hip)
-int ssi_bm25_launch_union_count(const BmParams& p, const uint2* probe, const uint32_t* probe_row, bool all_queries, hipStream_t st);
+int ssi_bm25_launch_union_count(const BmParams& p, const uint2* probe, const uint32_t* probe_row, bool all_queries, hipStream_t st,
+                                unsigned long long* match_bits = nullptr);
 // pruned top-k over the probe index (bm25_probe.hip); SS_ENOTSUP if it cannot serve the request
 int ssi_bm25_launch_probe(const BmParams& p, const uint2* probe, const uint32_t* probe_z, const uint32_t* probe_row, const float* umax,
                           uint32_t nt_max, int KPL, bool any_not, hipStream_t st);

@@ -403,7 +403,7 @@ constexpr int CNT_WAVES = 4, CNT_UNROLL = 4;
 __global__ void __launch_bounds__(CNT_WAVES * 64) bm25_union_count_kernel(
     const uint2* __restrict__ probe, const uint32_t* __restrict__ probe_row, const bm_vquery* __restrict__ qs,
     unsigned long long* __restrict__ total, const uint32_t* __restrict__ del, uint32_t del_words, uint32_t n_sub, uint32_t nq,
-    uint32_t P, uint32_t all_queries) {
+    uint32_t P, uint32_t all_queries, unsigned long long* __restrict__ match_bits /* nq = 1: the match set itself, or null */) {
   const int lane = threadIdx.x & 63;
   const uint32_t a = blockIdx.x * CNT_WAVES + (threadIdx.x >> 6);
   if (a >= nq * P) return;
@@ -489,18 +489,26 @@ __global__ void __launch_bounds__(CNT_WAVES * 64) bm25_union_count_kernel(
     }
 #pragma unroll
     for (int u = 0; u < CNT_UNROLL; u++) cnt += (uint32_t)__popcll(acc[u] & ~neg[u]);
+    if (match_bits) {  // facet counting (facet.hip) wants the docs, not only their number
+#pragma unroll
+      for (int u = 0; u < CNT_UNROLL; u++) {
+        const uint32_t g = g0 + 64u * u + lane;
+        if (g < g_end) match_bits[g] = acc[u] & ~neg[u];
+      }
+    }
   }
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
   if (lane == 0 && cnt) atomicAdd(&total[qi], (unsigned long long)cnt);
 }
 
-int ssi_bm25_launch_union_count(const BmParams& p, const uint2* probe, const uint32_t* probe_row, bool all_queries, hipStream_t st) {
+int ssi_bm25_launch_union_count(const BmParams& p, const uint2* probe, const uint32_t* probe_row, bool all_queries, hipStream_t st,
+                                unsigned long long* match_bits) {
   // one partition per ~4096 groups and at least enough waves for two rounds of a full chip
   const uint32_t n_groups = p.n_sub * (BM_SUB / 64);
   uint32_t P = std::max<uint32_t>(1u, std::min<uint32_t>((2u * 8192u + p.nq - 1) / p.nq, (n_groups + 1023u) / 1024u));
   const uint32_t A = p.nq * P;
   bm25_union_count_kernel<<<(A + CNT_WAVES - 1) / CNT_WAVES, CNT_WAVES * 64, 0, st>>>(probe, probe_row, p.q, p.total, p.del, p.del_words,
-                                                                                     p.n_sub, p.nq, P, all_queries ? 1u : 0u);
+                                                                                     p.n_sub, p.nq, P, all_queries ? 1u : 0u, match_bits);
   return SS_OK;
 }
 

@@ -99,3 +99,58 @@ int ssi_facet_build(ss_shard* s, uint32_t n_filters, const ss_facet_filter* filt
   SS_HIP(hipGetLastError());
   return SS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Facet counting (facet_count, add_result.rs:484-640): every counted doc adds one to the bucket of its facet value -- a
+// string facet's id, or for a numeric facet the range whose lower bound is the last one <= the value (ranges sorted by
+// lower bound, binary_search_by_key ... map_or_else(|idx| idx - 1, |idx| idx)).  The counted docs are the query's match
+// set after NOT terms, tombstones and the facet filter: the bitmap bm25_union_count_kernel writes from the bit records.
+// One thread per 64-doc group walks its set bits; the histogram lives in global memory (64-bit atomics).
+__device__ __forceinline__ bool facet_le(uint32_t type, unsigned long long bound, unsigned long long v) {  // bound <= v
+  switch (type) {
+    case SS_FACET_I8: case SS_FACET_I16: case SS_FACET_I32: case SS_FACET_I64: return (long long)bound <= (long long)v;
+    case SS_FACET_F32: return __uint_as_float((uint32_t)bound) <= __uint_as_float((uint32_t)v);
+    case SS_FACET_F64: return __longlong_as_double((long long)bound) <= __longlong_as_double((long long)v);
+    default: return bound <= v;
+  }
+}
+__global__ void facet_count_kernel(const unsigned long long* __restrict__ bits, unsigned long long n_docs,
+                                   const uint8_t* __restrict__ records, uint32_t record_size, uint32_t offset, uint32_t type,
+                                   uint32_t n_buckets, const unsigned long long* __restrict__ bounds,
+                                   unsigned long long* __restrict__ counts) {
+  const unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g * 64ull >= n_docs) return;
+  unsigned long long m = bits[g];
+  static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 2, 4};
+  while (m) {
+    const unsigned long long d = g * 64ull + (unsigned long long)__builtin_ctzll(m);
+    m &= m - 1;
+    if (d >= n_docs) break;
+    unsigned long long v = facet_read(records + d * record_size + offset, width[type]);
+    if (type == SS_FACET_I8) v = (unsigned long long)(long long)(int8_t)v;      // sign-extend for the comparisons
+    else if (type == SS_FACET_I16) v = (unsigned long long)(long long)(int16_t)v;
+    else if (type == SS_FACET_I32) v = (unsigned long long)(long long)(int32_t)v;
+    uint32_t b;
+    if (type >= SS_FACET_STRING16) {
+      b = v < n_buckets ? (uint32_t)v : n_buckets;
+    } else {
+      uint32_t lo = 0, hi = n_buckets;  // number of bounds <= v
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (facet_le(type, bounds[mid], v)) lo = mid + 1; else hi = mid;
+      }
+      b = lo ? lo - 1 : n_buckets;  // below the first bound: the reference's index underflows; reported as "other"
+    }
+    atomicAdd(&counts[b], 1ull);
+  }
+}
+
+int ssi_facet_count(ss_shard* s, const unsigned long long* d_bits, uint64_t n_docs, uint32_t offset, uint32_t type, uint32_t n_buckets,
+                    const uint64_t* d_bounds, unsigned long long* d_counts, hipStream_t st) {
+  const uint64_t groups = (n_docs + 63) / 64;
+  facet_count_kernel<<<(unsigned)((groups + 255) / 256), 256, 0, st>>>(d_bits, (unsigned long long)n_docs, s->d_facets,
+                                                                      s->facet_record_size, offset, type, n_buckets,
+                                                                      (const unsigned long long*)d_bounds, d_counts);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}

@@ -441,6 +441,49 @@ int ss_bm25_search_filtered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, ui
   return SS_OK;
 }
 
+// Facet counts of ONE query (query_facets / facet_count, add_result.rs:484-640): histogram of a facet over the query's match
+// set (after NOT terms, tombstones and the facet filter).  out_counts [n_buckets + 1]: a string facet's ids 0 .. n_buckets-1,
+// or the numeric ranges given by their ascending lower bounds; the last slot collects what falls outside.
+int ss_bm25_facet_count(ss_shard* s, const ss_bm25_query* query, uint32_t n_filters, const ss_facet_filter* filters,
+                        uint32_t facet_offset, uint32_t facet_type, uint32_t n_buckets, const uint64_t* range_lower_bounds,
+                        uint64_t* out_counts, uint64_t* out_total) {
+  if (!s || !query || !out_counts || n_buckets == 0 || n_buckets > (1u << 24)) return SS_EINVAL;
+  if (facet_type > SS_FACET_STRING32 || (facet_type < SS_FACET_STRING16 && !range_lower_bounds)) return SS_EINVAL;
+  if (!s->d_post) return SS_ESTATE;
+  bool has_and, has_or, all_probed, any_frequent;
+  uint32_t nt_max, np_max;
+  SS_TRY(check_queries(s, 1, query, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent));
+  if (!all_probed || !s->d_probe) return SS_ENOTSUP;  // the match set comes from the probe index's bit records
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 2, 4};
+  if (!s->d_facets || s->facet_docs < s->bm_n_docs || facet_offset + width[facet_type] > s->facet_record_size) return SS_ESTATE;
+  const uint64_t groups = (uint64_t)s->bm_n_sub * (BM_SUB / 64);
+  const size_t bytes = sizeof(ss_bm25_query) + 8 + groups * 8 + ((size_t)n_buckets + 1) * 8 + (size_t)n_buckets * 8;
+  char* ws = nullptr;
+  SS_HIP(hipMalloc(&ws, bytes));
+  ss_bm25_query* d_q = (ss_bm25_query*)ws;
+  unsigned long long* d_total = (unsigned long long*)(ws + sizeof(ss_bm25_query));
+  unsigned long long* d_bits = d_total + 1;
+  unsigned long long* d_counts = d_bits + groups;
+  uint64_t* d_bounds = (uint64_t*)(d_counts + n_buckets + 1);
+  int rc = SS_OK;
+  if (hipMemcpyAsync(d_q, query, sizeof(ss_bm25_query), hipMemcpyHostToDevice, s->stream) != hipSuccess ||
+      hipMemsetAsync(d_total, 0, 8 + groups * 8 + ((size_t)n_buckets + 1) * 8, s->stream) != hipSuccess ||
+      (facet_type < SS_FACET_STRING16 &&
+       hipMemcpyAsync(d_bounds, range_lower_bounds, (size_t)n_buckets * 8, hipMemcpyHostToDevice, s->stream) != hipSuccess))
+    rc = SS_EDEVICE;
+  if (rc == SS_OK)
+    rc = with_facet_filter(s, n_filters, filters, s->stream, [&]() { return ssi_bm25_match_bits(s, d_q, d_bits, d_total, s->stream); });
+  if (rc == SS_OK) rc = ssi_facet_count(s, d_bits, s->bm_n_docs, facet_offset, facet_type, n_buckets, d_bounds, d_counts, s->stream);
+  if (rc == SS_OK && (hipMemcpyAsync(out_counts, d_counts, ((size_t)n_buckets + 1) * 8, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+                      (out_total && hipMemcpyAsync(out_total, d_total, 8, hipMemcpyDeviceToHost, s->stream) != hipSuccess)))
+    rc = SS_EDEVICE;
+  if (hipStreamSynchronize(s->stream) != hipSuccess && rc == SS_OK) rc = SS_EDEVICE;
+  (void)hipFree(ws);
+  return rc;
+}
+
 int ss_bm25_search_dev(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t ops_mask,
                        uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total,
                        void* stream) {

@@ -180,6 +180,10 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float*
 struct VAnn;
 int ssi_vec8_qprep(ss_shard* s, const int8_t* d_queries, uint32_t nb, hipStream_t st);
 int ssi_vec8_launch_scan(ss_shard* s, uint32_t tile0, uint32_t ntiles, const float* d_qscale, const VAnn* ann, hipStream_t st);
+int ssi_bm25_match_bits(ss_shard* s, const ss_bm25_query* d_q, unsigned long long* d_bits, unsigned long long* d_total, hipStream_t st);
+// facet histogram over a match bitmap: d_counts [n_buckets + 1] (last = values outside the buckets)
+int ssi_facet_count(ss_shard* s, const unsigned long long* d_bits, uint64_t n_docs, uint32_t offset, uint32_t type, uint32_t n_buckets,
+                    const uint64_t* d_bounds, unsigned long long* d_counts, hipStream_t st);
 // ---- implemented in facet.hip: exclusion bitmap (failed facet filters | tombstones) into s->d_filter_bits
 int ssi_facet_build(ss_shard* s, uint32_t n_filters, const ss_facet_filter* filters, hipStream_t st);
 // ---- implemented in vec_ann.hip

@@ -486,6 +486,30 @@ class Shard:
                     arr[i].lo, arr[i].hi = int(f[2]) & 0xFFFFFFFFFFFFFFFF, int(f[3]) & 0xFFFFFFFFFFFFFFFF
         return arr, len(filters)
 
+    def facet_count(self, query, facet_offset, facet_type, n_buckets=None, range_lower_bounds=None, facet_filter=None):
+        """query_facets of one query (facet_count, add_result.rs:484-640): histogram of the facet over the match set.
+        String facets: n_buckets ids; numeric facets: ascending lower bounds of the ranges.  -> (counts [n_buckets], docs
+        outside the buckets, match count)"""
+        if facet_type.startswith("string"):
+            nb, bounds = int(n_buckets), None
+        else:
+            dt = {"f32": np.float32, "f64": np.float64}.get(facet_type)
+            if dt is None:
+                bounds = np.array([int(x) & 0xFFFFFFFFFFFFFFFF for x in range_lower_bounds], np.uint64)
+            elif facet_type == "f32":
+                bounds = np.asarray(range_lower_bounds, np.float32).view(np.uint32).astype(np.uint64)
+            else:
+                bounds = np.asarray(range_lower_bounds, np.float64).view(np.uint64).copy()
+            nb = len(bounds)
+        out = np.zeros(nb + 1, np.uint64)
+        tot = C.c_uint64()
+        farr, nf = self.facet_filters(facet_filter) if facet_filter else (None, 0)
+        q = np.ascontiguousarray(query[:1])
+        N.check(N.lib().ss_bm25_facet_count(self._h, q.ctypes.data, nf, None if farr is None else C.cast(farr, C.c_void_p),
+                                            int(facet_offset), N.FACET_TYPES[facet_type], nb, N.ptr(bounds, N.u64p),
+                                            N.ptr(out, N.u64p), C.byref(tot)), "ss_bm25_facet_count")
+        return out[:nb].copy(), int(out[nb]), tot.value
+
     def mark_all_terms_frequent(self, queries, k):
         """The reference's all_terms_frequent condition (intersection.rs:198-209), evaluated where the reference evaluates
         it -- on the host, per query: indexed_doc_count > top_k << 8 and posting_count / indexed_doc_count >= 0.5 (f32) for

@@ -145,6 +145,43 @@ def test_facet_filter(S, O, lex):
     osh.set_deleted([])
 
 
+def test_facet_counts(S, O, lex):
+    """query_facets (facet_count, add_result.rs:484-640): the histogram of a facet over a query's match set -- after NOT
+    terms, tombstones and the facet filter -- for string ids and numeric ranges (bucket = last lower bound <= value)"""
+    sh, osh, n_docs = lex
+    rng = np.random.default_rng(93)
+    rec = np.dtype([("pad", "u1"), ("cat", "<u2"), ("price", "<f4"), ("year", "<i2"), ("lang", "<u4")])
+    v = np.zeros(n_docs, rec)
+    v["cat"] = rng.integers(0, 50, n_docs); v["price"] = rng.random(n_docs) * 1000 - 100
+    v["year"] = rng.integers(-50, 2030, n_docs); v["lang"] = rng.integers(0, 9, n_docs)
+    sh.upload_facets(v.view(np.uint8).reshape(n_docs, rec.itemsize))
+    off = {n: rec.fields[n][1] for n in rec.names}
+    gone = list(range(5, n_docs, 173))
+    sh.set_deleted(gone)
+    for terms, qt, oop, neg, filt, keep in (
+            ([10, 9, 8], S.QueryType.Union, O.OP_OR, [], None, np.ones(n_docs, bool)),
+            ([10, 9], S.QueryType.Intersection, O.OP_AND, [], None, np.ones(n_docs, bool)),
+            ([10, 8], S.QueryType.Union, O.OP_OR, [9], [(off["lang"], "u32", 2, 6)], (v["lang"] >= 2) & (v["lang"] < 6)),
+            ([7], S.QueryType.Union, O.OP_OR, [], [(off["cat"], "string16", [1, 2, 3, 40])], np.isin(v["cat"], [1, 2, 3, 40]))):
+        osh.set_deleted(sorted(set(np.nonzero(~keep)[0].tolist()) | set(gone)))
+        od, _, otot = osh.search_exhaustive(terms, oop, n_docs, neg)   # k = n_docs: the whole match set
+        assert len(od) == otot
+        q = sh.make_queries([terms], qt, [neg])
+        counts, other, tot = sh.facet_count(q, off["cat"], "string16", n_buckets=40, facet_filter=filt)
+        want = np.bincount(v["cat"][od], minlength=50)
+        assert tot == otot and np.array_equal(counts, want[:40]) and other == int(want[40:].sum())
+        bounds = [0.0, 50.0, 200.0, 500.0]
+        counts, other, tot = sh.facet_count(q, off["price"], "f32", range_lower_bounds=bounds, facet_filter=filt)
+        b = np.searchsorted(np.asarray(bounds, np.float32), v["price"][od], side="right") - 1
+        assert tot == otot and other == int((b < 0).sum()) and np.array_equal(counts, np.bincount(b[b >= 0], minlength=4))
+        ybounds = [-10, 0, 1500, 1999, 2000]
+        counts, other, tot = sh.facet_count(q, off["year"], "i16", range_lower_bounds=ybounds, facet_filter=filt)
+        b = np.searchsorted(np.asarray(ybounds), v["year"][od].astype(np.int64), side="right") - 1
+        assert other == int((b < 0).sum()) and np.array_equal(counts, np.bincount(b[b >= 0], minlength=5))
+    sh.set_deleted([])
+    osh.set_deleted([])
+
+
 def test_all_terms_frequent_shortcut(S, O):
     """intersection.rs:198-209 + add_result.rs:2091-2104: when N > 256 k and every term of an intersection is in at least
     half of the docs, a doc with some tf < 10 is counted but not ranked.  The host mirror evaluates the condition like the
