@@ -91,6 +91,19 @@ int ssh_search_lexical_shard(ssh_index* ix, int shard, const uint32_t* terms, ui
   return write_out(ro, cap, out_doc, out_score, nullptr, nullptr, nullptr, out_meta);
 }
 
+int ssh_upload_facets(ssh_index* ix, int shard, uint64_t n_docs, uint32_t record_size, const uint8_t* records) {
+  return ix->shards[shard]->upload_facets(n_docs, record_size, records);
+}
+int ssh_search_lexical_shard_filtered(ssh_index* ix, int shard, const uint32_t* terms, uint32_t n_terms, uint32_t query_type,
+                                      uint32_t offset, uint32_t length, uint32_t result_type, uint32_t n_filters,
+                                      const ss_facet_filter* filters, uint32_t cap, uint64_t* out_doc, float* out_score,
+                                      uint64_t* out_meta) {
+  std::vector<uint32_t> t(terms, terms + n_terms);
+  std::vector<ss_facet_filter> f(filters, filters + n_filters);
+  ResultObject ro = ix->shards[shard]->search_lexical_shard(t, (QueryType)query_type, offset, length, (ResultType)result_type, f);
+  return write_out(ro, cap, out_doc, out_score, nullptr, nullptr, nullptr, out_meta);
+}
+
 // Shard::search_vector_shard with an AnnMode: kind 0 All, 1 Similaritythreshold(t), 2 Nprobe(n), 3 NprobeSimilaritythreshold(n, t);
 // out_meta[4] = count, total, observed vectors, last_error; *out_clusters = observed_cluster_count
 int ssh_set_clusters(ssh_index* ix, int shard, uint32_t n_levels, const uint32_t* level_clusters, uint32_t n_clusters,

@@ -52,6 +52,9 @@ def H():
     L.ssh_coalesced_lexical_search.argtypes = [C.c_void_p, C.c_int, C.c_uint32, u32p, u32p, u32p, u32p, C.c_uint32, C.c_uint32,
                                                C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u64p, f32p, u32p, u64p]
     L.ssh_open_index_bin.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, u64p, C.c_uint32]
+    L.ssh_upload_facets.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p]
+    L.ssh_search_lexical_shard_filtered.argtypes = [C.c_void_p, C.c_int, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                    C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, u64p, f32p, u64p]
     L.ssh_set_clusters.argtypes = [C.c_void_p, C.c_int, C.c_uint32, u32p, C.c_uint32, u32p]
     L.ssh_search_vector_shard_ann.argtypes = [C.c_void_p, C.c_int, f32p, C.c_uint32, C.c_int, C.c_uint32, C.c_float, C.c_uint32,
                                               u64p, f32p, u64p, u64p]
@@ -327,3 +330,37 @@ def test_cpp_shard_opens_an_index_bin_with_ngram_keys(H):
     finally:
         H.ssh_index_destroy(ix)
         pix.close()
+
+
+@pytest.mark.gpu
+def test_cpp_shard_facet_filter(H):
+    """Shard::search_lexical_shard with a FacetFilter (numeric range + string set) against the oracle with the failing docs
+    excluded; offset / length drain on top"""
+    from oracle import oracle as O
+    import seekstorm_amd as S
+    n_docs = 80_000
+    dl = O.lex_doclen(n_docs)
+    offs, docs, tfs = O.lex_corpus(n_docs, [4095, 4000, 3000])  # three frequent vocabulary terms
+    osh = O.Shard(n_docs, dl, offs, docs, tfs)
+    rng = np.random.default_rng(3)
+    rec = np.dtype([("x", "<i4"), ("s", "<u2")])
+    v = np.zeros(n_docs, rec)
+    v["x"] = rng.integers(-100, 100, n_docs); v["s"] = rng.integers(0, 12, n_docs)
+    keep = (v["x"] >= -20) & (v["x"] < 35) & np.isin(v["s"], [2, 5, 11])
+    osh.set_deleted(np.nonzero(~keep)[0])
+    farr, nf = S.Shard.facet_filters([(0, "i32", -20, 35), (4, "string16", [2, 5, 11])])
+    ix = H.ssh_index_create(1, None)
+    try:
+        assert H.ssh_upload_lexical(ix, 0, n_docs, P(dl, u8p), len(offs) - 1, P(offs, u64p), P(docs, u32p), P(tfs, u16p)) == 0
+        raw = v.view(np.uint8).reshape(n_docs, rec.itemsize).copy()
+        assert H.ssh_upload_facets(ix, 0, n_docs, rec.itemsize, raw.ctypes.data) == 0
+        for qt, op in ((1, O.OP_OR), (0, O.OP_AND)):
+            t = np.ascontiguousarray([0, 1], np.uint32)
+            doc = np.zeros(10, np.uint64); sc = np.zeros(10, np.float32); meta = np.zeros(4, np.uint64)
+            n = H.ssh_search_lexical_shard_filtered(ix, 0, P(t, u32p), 2, qt, 3, 10, 2, nf, C.cast(farr, C.c_void_p), 10,
+                                                    P(doc, u64p), P(sc, f32p), P(meta, u64p))
+            od, os_, otot = osh.search_exhaustive([0, 1], op, 13)
+            assert int(meta[3]) == 0 and int(meta[1]) == otot and n == len(od) - 3
+            assert np.allclose(sc[:n], os_[3:], rtol=1e-4) and all(keep[int(d)] for d in doc[:n])
+    finally:
+        H.ssh_index_destroy(ix)
