@@ -96,7 +96,7 @@ int ss_shard_destroy(ss_shard* s) {
   (void)hipStreamSynchronize(s->stream);
   free_vec(s);
   free_bm25(s);
-  void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_part, s->d_deleted, s->d_vq, s->d_facets, s->d_filter_bits};
+  void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_part, s->d_deleted, s->d_vq, s->d_facets, s->d_filter_bits, s->d_facet_ws};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int kx = 0; kx < 2; kx++)
     for (auto& pr : s->prof.pending[kx]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -460,8 +460,14 @@ int ss_bm25_facet_count(ss_shard* s, const ss_bm25_query* query, uint32_t n_filt
   if (!s->d_facets || s->facet_docs < s->bm_n_docs || facet_offset + width[facet_type] > s->facet_record_size) return SS_ESTATE;
   const uint64_t groups = (uint64_t)s->bm_n_sub * (BM_SUB / 64);
   const size_t bytes = sizeof(ss_bm25_query) + 8 + groups * 8 + ((size_t)n_buckets + 1) * 8 + (size_t)n_buckets * 8;
-  char* ws = nullptr;
-  SS_HIP(hipMalloc(&ws, bytes));
+  if (bytes > s->facet_ws_cap) {  // grow-only workspace (a hipMalloc / hipFree pair per call would synchronise the device)
+    if (s->d_facet_ws) (void)hipFree(s->d_facet_ws);
+    s->d_facet_ws = nullptr;
+    s->facet_ws_cap = 0;
+    SS_HIP(hipMalloc(&s->d_facet_ws, bytes));
+    s->facet_ws_cap = bytes;
+  }
+  char* ws = (char*)s->d_facet_ws;
   ss_bm25_query* d_q = (ss_bm25_query*)ws;
   unsigned long long* d_total = (unsigned long long*)(ws + sizeof(ss_bm25_query));
   unsigned long long* d_bits = d_total + 1;
@@ -480,7 +486,6 @@ int ss_bm25_facet_count(ss_shard* s, const ss_bm25_query* query, uint32_t n_filt
                       (out_total && hipMemcpyAsync(out_total, d_total, 8, hipMemcpyDeviceToHost, s->stream) != hipSuccess)))
     rc = SS_EDEVICE;
   if (hipStreamSynchronize(s->stream) != hipSuccess && rc == SS_OK) rc = SS_EDEVICE;
-  (void)hipFree(ws);
   return rc;
 }
 

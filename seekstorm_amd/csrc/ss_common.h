@@ -128,6 +128,8 @@ struct ss_shard {
   uint32_t facet_record_size = 0;
   uint32_t* d_filter_bits = nullptr;  // exclusion bitmap of the facet-filtered search in flight (facet.hip), grow-only
   uint64_t filter_words_cap = 0;
+  void* d_facet_ws = nullptr;      // ss_bm25_facet_count workspace (query, match words, histogram, bounds), grow-only
+  size_t facet_ws_cap = 0;
   uint32_t* d_deleted = nullptr;   // tombstone bitmap by shard-local doc id (delete.bin / delete_hashset), null = none
   uint64_t deleted_words = 0, n_deleted = 0;
   uint2* d_probe = nullptr;        // [probe_rows + 1][n_sub][BM_SUB / 64] 64 doc bits; the last row is all zero (absent terms)
