@@ -10,9 +10,18 @@
  *                       inputs already resolved by the host: term -> posting list, idf (search.rs:3225-3230)
  *   ss_vec_search    <- SearchVectorShard::search_vector_shard, vector.rs:1105-1115 / 1202-1515
  *                       (AnnMode::All, F32 dot/cosine; query already normalised, search.rs:1464-1475)
+ *   ss_vec_search_ann, ss_vec_search_i8[_ann]
+ *                    <- the same seam with its other arguments: AnnMode::Nprobe / Similaritythreshold (vector.rs:1300-1392),
+ *                       field_filter (1225-1237, 1397-1400), Precision::I8 records (vector_similarity.rs:1011-1016, 1754-1758)
+ *   ss_bm25_search_filtered, ss_bm25_facet_count
+ *                    <- facet_filter / query_facets of search_lexical_shard (add_result.rs:341-640)
+ *   ss_index_bin_*, ss_ref_decode_block*, ss_vec_upload_vector_bin*
+ *                    <- readers of the shard files and in-RAM blocks (index.rs:3263-3740, vector.rs:1066-1094,
+ *                       add_result.rs:2036-2293)
  *   ss_*_upload      <- (re)build of the device image at the end of open_shard (index.rs:3796)
  *                       and after each commit (commit.rs:142-148)
- *   ss_merge_results <- cross-shard gather + RRF + sort/offset/length, search.rs:1875-2119
+ *   ss_merge_results, ss_topk_merge_dev*, ss_rrf_merge_dev
+ *                    <- cross-shard gather + RRF + sort/offset/length, search.rs:1875-2119
  *
  * Conventions (mirroring the reference's search path, search.rs:2461-2463 / vector.rs:1222-1224):
  *   - every function returns 0 on success or a negative SS_E* code; never throws, never aborts;
