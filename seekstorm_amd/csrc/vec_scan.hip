@@ -14,6 +14,9 @@
 // row-line, XOR-swizzled on the SOURCE piece so ds_read_b128 of the MFMA A fragments is conflict-free);
 // Q is pre-permuted into MFMA B-fragment order once per batch and re-streamed from L2 per K-chunk.
 // 3-stage LDS ring, counted vmcnt, one raw s_barrier per K-chunk, persistent across tiles.
+#include <cstdio>
+#include <cstdlib>
+
 #include "ss_common.h"
 #include "vec_dev.h"
 
@@ -442,8 +445,15 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float*
   } else {
     // tau is fixed during a launch: rows in random order, a chunk g times the rows seen so far leaves ~ g k candidates per
     // query; keep that 2.5 times below the free slots (an adversarial order overflows and re-runs in safe mode)
-    double growth = std::max(1.5, std::min(16.0, (double)(VS_CAP - k) / (2.5 * k)));
-    uint32_t done = std::min<uint32_t>(T, VS_FIRST_TILES);
+    double g_cap = 16.0, margin = 2.5;
+    uint32_t first = VS_FIRST_TILES;
+    if (const char* e = getenv("SS_VEC_SCHED")) {  // tuning override: "first_tiles,growth_cap,margin"
+      unsigned f = 0;
+      double a = 0, b = 0;
+      if (sscanf(e, "%u,%lf,%lf", &f, &a, &b) == 3 && f >= 1 && f <= VS_CAP / VS_TR && a >= 1.5 && b >= 1.0) { first = f; g_cap = a; margin = b; }
+    }
+    double growth = std::max(1.5, std::min(g_cap, (double)(VS_CAP - k) / (margin * k)));
+    uint32_t done = std::min<uint32_t>(T, first);
     chunks.push_back(done);
     while (done < T) {
       uint32_t c = (uint32_t)std::min<double>((double)(T - done), std::max(1.0, done * growth));
