@@ -447,7 +447,8 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float*
     // query; keep that 2.5 times below the free slots (an adversarial order overflows and re-runs in safe mode)
     double g_cap = 16.0, margin = 2.5;
     uint32_t first = VS_FIRST_TILES;
-    if (const char* e = getenv("SS_VEC_SCHED")) {  // tuning override: "first_tiles,growth_cap,margin"
+    const char* e = ann_mode ? nullptr : getenv("SS_VEC_SCHED");  // (the ANN tile lists keep the conservative schedule)
+    if (e) {  // tuning override: "first_tiles,growth_cap,margin"
       unsigned f = 0;
       double a = 0, b = 0;
       if (sscanf(e, "%u,%lf,%lf", &f, &a, &b) == 3 && f >= 1 && f <= VS_CAP / VS_TR && a >= 1.5 && b >= 1.0) { first = f; g_cap = a; margin = b; }
