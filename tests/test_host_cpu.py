@@ -32,6 +32,18 @@ def test_struct_layout_matches_header():
     from seekstorm_amd import _native as N
     assert C.sizeof(N.Bm25Query) == 4 + 4 + 4 * 10 + 4 * 10
     assert N.BM25_QUERY_DTYPE.fields["term"][1] == 8 and N.BM25_QUERY_DTYPE.fields["idf"][1] == 48
+    # the structs the header declares, as gcc lays them out
+    import os, subprocess, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "seekstorm_hip.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\\n", '
+           'sizeof(ss_bm25_query), sizeof(ss_ann_mode), offsetof(ss_ann_mode, field_mask), sizeof(ss_facet_filter), '
+           'offsetof(ss_facet_filter, lo), offsetof(ss_facet_filter, values), sizeof(ss_ref_block)); return 0; }\n')
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.run(["gcc", "-std=c11", "-I", os.path.join(root, "include"), "-o", os.path.join(d, "t"), os.path.join(d, "t.c")], check=True)
+        got = [int(x) for x in subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split()]
+    assert got == [C.sizeof(N.Bm25Query), C.sizeof(N.AnnModeC), N.AnnModeC.field_mask.offset, C.sizeof(N.FacetFilterC),
+                   N.FacetFilterC.lo.offset, N.FacetFilterC.values.offset, C.sizeof(N.RefBlock)]
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
