@@ -313,3 +313,48 @@ def test_ann_modes_select_clusters_like_the_reference():
     best8 = [int(np.argmax(med8[:3])), 3 + int(np.argmax(med8[3:]))]
     assert ncl5 == 2 and obs5 == int(child[best8].sum())
     assert sorted(map(int, s5), reverse=True) == [int(x) for x in s5]
+
+
+def test_all_terms_frequent_condition_and_rule():
+    # intersection.rs:198-209: indexed_doc_count > top_k << 8 (strict) and posting_count / indexed_doc_count >= 0.5 for every
+    # term; under it a doc with some tf < 10 (embedded pointers hold <= 4 positions) is counted but not ranked
+    n_docs = 5120
+    dl = np.full(n_docs, 40, np.uint8)
+    a = np.arange(0, n_docs, 2, dtype=np.uint32)            # df = N / 2 exactly: frequent
+    b = np.arange(0, n_docs, 2, dtype=np.uint32)[:-1]       # df = N / 2 - 1: not frequent
+    c = np.arange(0, n_docs, dtype=np.uint32)               # every doc
+    tf_a = np.where(a % 8 == 0, 12, 3).astype(np.uint16)
+    tf_c = np.where(c % 16 == 0, 30, 9).astype(np.uint16)
+    offs = np.array([0, len(a), len(a) + len(b), len(a) + len(b) + len(c)], np.uint64)
+    sh = O.Shard(n_docs, dl, offs, np.concatenate([a, b, c]), np.concatenate([tf_a, np.ones(len(b), np.uint16), tf_c]))
+    assert sh.all_terms_frequent([0, 2], 19) and not sh.all_terms_frequent([0, 2], 20)   # 5120 > 19 * 256 = 4864, not > 5120
+    assert not sh.all_terms_frequent([1, 2], 10)
+    plain = sh.search_exhaustive([0, 2], O.OP_AND, 10)
+    short = sh.search_exhaustive([0, 2], O.OP_AND, 10, reference_shortcuts=True)
+    assert plain[2] == short[2] == len(a)                    # every match is counted either way
+    rankable = {int(d) for d in a if d % 16 == 0}            # tf 12 and 30: both >= 10
+    assert set(map(int, short[0])) <= rankable and len(short[0]) == 10
+    few = sh.search_exhaustive([0, 2], O.OP_AND, 19, reference_shortcuts=True)
+    assert len(few[0]) == 19
+    # an intersection that is not all-frequent, a union, a single term: untouched
+    for terms, op in (([1, 2], O.OP_AND), ([0, 2], O.OP_OR), ([0], O.OP_AND)):
+        x, y = sh.search_exhaustive(terms, op, 10), sh.search_exhaustive(terms, op, 10, reference_shortcuts=True)
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+
+
+def test_field_filter_rule_on_bm25f():
+    # add_result.rs:3124-3136: every term must occur in a listed field; the score still sums all fields
+    n_docs = 6
+    dl = np.full((2, n_docs), 20, np.uint8)
+    # term 0: doc0 field0, doc1 field1, doc2 fields 0+1; term 1: doc0 field1, doc2 field0, doc3 field0
+    offs = np.array([0, 4, 7], np.uint64)
+    docs = np.array([0, 1, 2, 2, 0, 2, 3], np.uint32)
+    fields = np.array([0, 1, 0, 1, 1, 0, 0], np.uint8)
+    tfs = np.array([1, 2, 1, 3, 1, 2, 5], np.uint16)
+    args = (n_docs, dl, None, offs, docs, fields, tfs)
+    assert O.search_fields_exhaustive(*args, [0, 1], O.OP_AND, 10)[2] == 2                            # docs 0, 2
+    d, s, tot, _ = O.search_fields_exhaustive(*args, [0, 1], O.OP_AND, 10, field_filter=[0])
+    assert tot == 1 and list(d) == [2]                                                               # doc 0 has term 1 only in field 1
+    full = O.search_fields_exhaustive(*args, [0, 1], O.OP_AND, 10)
+    assert s[0] == full[1][list(full[0]).index(2)]                                                   # score over all fields
+    assert O.search_fields_exhaustive(*args, [0], O.OP_OR, 10, field_filter=[1])[2] == 2             # docs 1, 2
