@@ -575,11 +575,13 @@ class Shard:
 
     # ---- the reference's per-shard seams (one query)
     def search_lexical_shard(self, query_terms, query_type_default=QueryType.Union, offset=0, length=10,
-                             result_type=ResultType.TopkCount, strict=False, not_terms=()) -> ResultObject:
+                             result_type=ResultType.TopkCount, strict=False, not_terms=(), field_filter=None,
+                             facet_filter=None) -> ResultObject:
+        """search.rs:2427-2442: field_filter = indexed field ids, facet_filter = see facet_filters()"""
         ro = ResultObject()
         try:
-            q = self.make_queries([query_terms], query_type_default, [not_terms])
-            doc, score, cnt, tot = self.search_lexical_batch(q, offset + length, result_type)
+            q = self.make_queries([query_terms], query_type_default, [not_terms], field_filter=field_filter)
+            doc, score, cnt, tot = self.search_lexical_batch(q, offset + length, result_type, facet_filter=facet_filter)
         except Exception:
             if strict:
                 raise
@@ -681,7 +683,9 @@ class Index:
     def search(self, query_terms: Optional[Sequence[int]] = None, query_vector=None,
                query_type_default=QueryType.Union, search_mode=SearchMode.Lexical, offset=0, length=10,
                result_type=ResultType.TopkCount, similarity_threshold=None, normalize_query=True,
-               strict=False) -> ResultObject:
+               strict=False, not_terms=(), field_filter=None, facet_filter=None, ann_mode=None) -> ResultObject:
+        """<IndexArc as Search>::search (search.rs:1134-1150): field_filter applies to both sides (lexical: several indexed
+        fields; vector: records of the listed fields), facet_filter to the lexical side, ann_mode to the vector side"""
         S = self.shard_number
         ro = ResultObject()
         want_lex = search_mode in (SearchMode.Lexical, SearchMode.Hybrid) and query_terms
@@ -692,12 +696,13 @@ class Index:
         for sh in self.shards:  # search.rs:1637-1743: each shard asked for (offset 0, length offset+length)
             lt = vt = 0
             if want_lex:
-                r = sh.search_lexical_shard(query_terms, query_type_default, 0, offset + length, result_type, strict)
+                r = sh.search_lexical_shard(query_terms, query_type_default, 0, offset + length, result_type, strict,
+                                            not_terms, field_filter if sh.lexical_field_count > 1 else None, facet_filter)
                 lex_d += [x.doc_id * S + sh.shard_id for x in r.results]  # search.rs:1671
                 lex_s += [x.score for x in r.results]
                 lt = r.result_count_total
             if want_vec:
-                r = sh.search_vector_shard(query_vector, offset + length, similarity_threshold, strict)
+                r = sh.search_vector_shard(query_vector, offset + length, similarity_threshold, strict, ann_mode, field_filter)
                 vec_d += [x.doc_id * S + sh.shard_id for x in r.results]  # search.rs:1693
                 vec_s += [x.score for x in r.results]
                 vt = r.result_count_total

@@ -473,6 +473,26 @@ def test_index_two_shards_hybrid_matches_oracle(S, O):
         assert np.allclose(got_s, os_, rtol=REL, atol=2e-6)
         band = abs(float(os_[-1])) * REL + 2e-6
         assert {r.doc_id for r in ro.results if r.score > os_[-1] + band} == {int(x) for x, y in zip(od, os_) if y > os_[-1] + band}
+    # the search() options of the same seam: NOT terms, a facet filter (lexical side), an AnnMode (vector side)
+    for sid, sh in enumerate(shards):
+        n_s = sh.indexed_doc_count
+        year = ((np.arange(n_s) * 7 + sid) % 50).astype("<i2")
+        sh.upload_facets(year.view(np.uint8).reshape(n_s, 2))
+        sh.set_clusters([1, 1], [n_s // 2, n_s - n_s // 2])
+        osel = np.nonzero(~((year >= 10) & (year < 40)))[0]
+        oshards[sid].set_deleted(osel)
+    lex_d, lex_s, vec_d, vec_s = [], [], [], []
+    for sid in range(S_n):
+        od, os_, _ = oshards[sid].search_exhaustive([0, 1], O.OP_OR, k, [2])
+        lex_d += [int(x) * S_n + sid for x in od]; lex_s += list(os_)
+        n_s = shards[sid].indexed_doc_count
+        vd, vs, _, _, _ = O.vec_search_ann(orows[sid], qn, k, [1, 1], [n_s // 2, n_s - n_s // 2], n_probe=1)
+        vec_d += [int(x) * S_n + sid for x in vd]; vec_s += list(vs)
+    ro = idx.search([0, 1], qv, S.QueryType.Union, S.SearchMode.Hybrid, 0, k, strict=True, not_terms=[2],
+                    facet_filter=[(0, "i16", 10, 40)], ann_mode=S.AnnMode.Nprobe(1))
+    od, os_, osrc = O.merge(2, (lex_d, lex_s), (vec_d, vec_s), 0, k)
+    assert ro.result_count == len(od)
+    assert np.allclose(np.array([r.score for r in ro.results], np.float32), os_, rtol=REL, atol=2e-6)
     for sh in shards:
         sh.close()
 
