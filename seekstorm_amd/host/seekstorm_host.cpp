@@ -328,7 +328,7 @@ ResultObject Shard::search_vector_shard(const float* query_vector, size_t length
 ResultObject Index::search(const std::vector<uint32_t>& query_terms, const float* query_vector, QueryType query_type_default,
                            SearchMode search_mode, size_t offset, size_t length, ResultType result_type,
                            const float* similarity_threshold, bool normalize_query, const AnnMode& ann_mode,
-                           const std::vector<uint16_t>& vector_field_filter) {
+                           const std::vector<uint16_t>& vector_field_filter, const std::vector<ss_facet_filter>& facet_filter) {
   ResultObject ro;
   const size_t S = shards_.size();
   if (S == 0) return ro;
@@ -343,7 +343,7 @@ ResultObject Index::search(const std::vector<uint32_t>& query_terms, const float
   std::vector<ResultObject> lex(S), vec(S);
   auto task = [&](size_t i) {
     Shard& sh = *shards_[i];
-    if (want_lex) lex[i] = sh.search_lexical_shard(query_terms, query_type_default, 0, offset + length, result_type);
+    if (want_lex) lex[i] = sh.search_lexical_shard(query_terms, query_type_default, 0, offset + length, result_type, facet_filter);
     if (want_vec && qv.size() == sh.dim()) vec[i] = sh.search_vector_shard(qv.data(), offset + length, similarity_threshold, ann_mode, vector_field_filter);
   };
   if (S == 1) {
