@@ -1,22 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- SeekStorm query hot path on MI355X.
 
-Primary workload (BASELINE.json configs[1], "C2"): 10M synthetic docs, 3-term OR, BM25 top-10, one shard per GPU.
-A "step" = one batch of 1000 resolved queries through ss_bm25_search_dev (queries and outputs resident in HBM).
-Secondary workload (configs[2], "C3"), reported in the same JSON line under "vector": 10M x 768 f32, batch-64 cosine
-top-100 brute force through ss_vec_search_dev.
+Primary workload (BASELINE.json configs[1], "C2"): 10 M synthetic docs, 3-term OR, BM25 top-10, one shard per GPU.
+One C-ABI call = one batch of 1000 resolved queries through ss_bm25_search_dev (queries and outputs resident in HBM);
+one "step" = --calls-per-step (default 200) such calls, so that the timed region (exactly --steps steps) covers >= 200
+batches and >= 2 s (SURVEY 8d protocol).  Secondary legs in the same JSON line: the exhaustive strategy (the kernel that
+streams SURVEY 8d's algorithmic bytes), TopkCount, C3 (10 M x 768 f32 cosine top-100, batch 64) + i8, C4 hybrid, ANN,
+host-pointer end-to-end rates, latencies (>= 200 samples), full-size parity against the oracle, and the CPU baseline
+(the oracle's reference-structured dispatch, union_docid_3, timed on the host cores).
 
-Multi-GPU (weak scaling): one process per GPU, one 10M-doc / 10M-row shard per rank, every rank answers
-the same query batch on its shard, one RCCL all-gather of the per-shard top-k, ss_topk_merge_dev on every rank.
-`value` counts shard-queries (queries x shards scanned) per second so that it is the whole-job aggregate;
-`global_qps` is the rate of merged answers over the N-times larger corpus.
+Multi-GPU (SURVEY 8e, weak scaling): one process per GPU; rank r holds shard r of ONE generator stream of
+docs_per_shard x N docs (doc g -> shard g % N, index.rs:5284); every rank answers the same batch on its shard, one RCCL
+all-gather of the per-shard top-k (behind the C ABI: ss_topk_allgather_merge), identical merge on every rank.
+`value` = merged answers per second over the N-times larger corpus.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W      (N > 1 without a launcher: re-executes itself under torchrun)
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,11 +35,34 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: FP32 matrix peak
 
 
-def pmc_traffic(kind):
-    """HBM bytes per launch from the committed PMC run (profiles/pmc_traffic.json, produced by tools/pmc_summary.py
-    from separate rocprofv3 --pmc passes of this same command); None if the file is absent."""
+def kernel_source_hash():
+    """hash of the kernel sources: profiles/pmc_traffic.json is only used when it was collected on THESE kernels"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "seekstorm_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+_PMC = None
+
+
+def pmc_traffic(kind, key="hbm_bytes_per_launch"):
+    """HBM bytes per launch from the committed PMC run (profiles/pmc_traffic.json: tools/collect_pmc.sh + pmc_summary.py,
+    separate rocprofv3 --pmc passes of this command).  None when the file is absent or was collected on other kernel
+    sources (its `kernel_source_hash` must equal kernel_source_hash())."""
+    global _PMC
+    if _PMC is None:
+        try:
+            _PMC = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if _PMC.get("kernel_source_hash") != kernel_source_hash():
+                _PMC = {"stale": True}
+        except Exception:
+            _PMC = {}
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[kind]["hbm_bytes_per_launch"]
+        return _PMC[kind][key]
     except Exception:
         return None
 
@@ -56,20 +85,42 @@ def make_c2_queries(O, n_queries, seed=1234):
     return [[int(rng.choice(b)) for b in bands] for _ in range(n_queries)], th
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--calls-per-step", type=int, default=200, help="C-ABI calls (1000-query batches) per step of the primary leg")
     ap.add_argument("--workload", default="all", choices=["all", "bm25", "vec"])
-    ap.add_argument("--docs", type=int, default=10_000_000)
-    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--docs", type=int, default=10_000_000, help="docs per shard (= per GPU)")
+    ap.add_argument("--rows", type=int, default=10_000_000, help="vector rows per shard")
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--queries", type=int, default=1000)
+    ap.add_argument("--min-seconds", type=float, default=2.0, help="secondary legs: timed for >= this long or >= 200 batches")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-parity", action="store_true", help="skip the full-size oracle comparison")
     ap.add_argument("--no-topk-count", action="store_true", help="skip the TopkCount comparison (keeps counter profiles of the Topk kernels clean)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--quick", action="store_true", help="profiling runs: few calls per leg, no cpu / parity legs")
+    ap.add_argument("--cpu-seconds", type=float, default=5.0)
+    ap.add_argument("--parity-queries", type=int, default=32)
     args = ap.parse_args()
+    if args.quick:
+        args.no_cpu = args.no_parity = True
+        args.calls_per_step, args.min_seconds = min(args.calls_per_step, 2), 0.0
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: start one rank per GPU ourselves (the form the driver uses for N = 1 must work for N > 1 too)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -85,6 +136,9 @@ def main():
 
     import seekstorm_amd as S
     from seekstorm_amd import _native as N
+    from seekstorm_amd import distributed as D
+    from oracle import oracle as O  # query set + thresholds (host constants); checker + cpu_baseline legs
+    from oracle import fullsize as F
     L = S.lib()
 
     def barrier():
@@ -92,14 +146,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # an explicit (non-null) stream: the C ABI treats a NULL stream as "the shard's own stream", and the RCCL
-    # all-gather must be ordered after the search kernels on ONE stream
+    # an explicit (non-null) stream: the C ABI treats a NULL stream as "the shard's own stream", and the collective must be
+    # ordered after the search kernels on ONE stream
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     sptr = C.c_void_p(stream.cuda_stream)
     assert sptr.value, "expected a non-null HIP stream handle"
     sh = S.Shard(local_rank, shard_id=rank)
-    from seekstorm_amd import distributed as D
+    sh.synth_partition(rank, world)
+    comm = D.ShardComm(rank, world, local_rank) if world > 1 else None  # RCCL communicator behind the C ABI (ss_comm_create)
     merged = {}
 
     def timed(step_fn, steps, warmup):
@@ -117,24 +172,48 @@ def main():
             dt = float(t.item())
         return dt
 
-    def latencies(step_fn, n):
+    def timed_for(call_fn, min_calls=200):
+        """secondary legs: >= min_calls calls and >= args.min_seconds; returns (calls, seconds)"""
+        call_fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        call_fn()
+        torch.cuda.synchronize()
+        est = max(time.perf_counter() - t0, 1e-5)
+        n = min_calls if args.min_seconds > 0 else 3
+        n = int(min(max(n, args.min_seconds / est), 20000))
+        return n, timed(call_fn, n, 2)
+
+    def latencies(call_fn, n):
+        """device-side latency samples (HIP events on the launch stream), one sync per sample"""
+        n = n if args.min_seconds > 0 else min(n, 10)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
         for a, b in ev:
             a.record(stream)
-            step_fn()
+            call_fn()
             b.record(stream)
             torch.cuda.synchronize()
         return [a.elapsed_time(b) for a, b in ev]
 
+    def host_latencies(call_fn, n):
+        """submit -> results on the host, host clock"""
+        n = n if args.min_seconds > 0 else min(n, 10)
+        out = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            call_fn()
+            out.append((time.perf_counter() - t0) * 1e3)
+        return out
+
     # ------------------------------------------------------------------ BM25 (primary)
     bm = None
+    parity = {}
     if args.workload in ("all", "bm25"):
-        from oracle import oracle as O  # query set + thresholds come from the generator module (host constants only)
         k = 10
         term_lists, th = make_c2_queries(O, args.queries)
         tab = O.len_table()
         t0 = time.perf_counter()
-        sh.synth_lexical(O.LEX_SEED ^ (rank * 0x9E3779B1), args.docs, th, tab)
+        sh.synth_lexical(O.LEX_SEED, args.docs, th, tab)
         build_s = time.perf_counter() - t0
         info = sh.lexical_info()
         q_np = sh.make_queries(term_lists, S.QueryType.Union)
@@ -144,20 +223,26 @@ def main():
         o_score = torch.empty((nq, k), dtype=torch.float32, device=dev)
         o_cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
         o_tot = torch.empty((nq,), dtype=torch.int64, device=dev)
-        def bm_step(n=nq):
-            N.check(L.ss_bm25_search_dev(sh._h, n, q_dev.data_ptr(), k, N.RT_TOPK, 2 | (3 << 8), o_doc.data_ptr(), o_score.data_ptr(),
+        OPS = 2 | (3 << 8)  # unions of 3 terms, no NOT terms (validated on the device by bm_expand_kernel)
+
+        def bm_call(n=nq, rt=N.RT_TOPK):
+            N.check(L.ss_bm25_search_dev(sh._h, n, q_dev.data_ptr(), k, rt, OPS, o_doc.data_ptr(), o_score.data_ptr(),
                                          o_cnt.data_ptr(), o_tot.data_ptr(), sptr), "ss_bm25_search_dev")
-            if world > 1:  # one all-gather of the per-shard top-k over RCCL, identical merge on every rank
-                g = D.all_gather_topk_packed(o_doc[:n], o_score[:n], o_cnt[:n])  # ONE collective per batch
-                merged["bm25"] = D.merge_gathered_device_packed(g, n, k, sptr, local_rank)
+            if world > 1:  # one all-gather of the per-shard top-k over RCCL + identical merge on every rank, behind the C ABI
+                merged["bm25"] = comm.allgather_merge(o_doc[:n], o_score[:n], o_cnt[:n], k, sptr)
+
+        def bm_step():
+            for _ in range(args.calls_per_step):
+                bm_call()
 
         # exact union sizes for the roofline's "1 B per scored candidate" term: one untimed TopkCount pass (exhaustive scan)
         sh.set_strategy(N.BM25_EXHAUSTIVE)
-        N.check(L.ss_bm25_search_dev(sh._h, nq, q_dev.data_ptr(), k, N.RT_TOPKCOUNT, 2 | (3 << 8), o_doc.data_ptr(),
+        N.check(L.ss_bm25_search_dev(sh._h, nq, q_dev.data_ptr(), k, N.RT_TOPKCOUNT, OPS, o_doc.data_ptr(),
                                      o_score.data_ptr(), o_cnt.data_ptr(), o_tot.data_ptr(), sptr), "ss_bm25_search_dev")
         torch.cuda.synchronize()
         tot = o_tot.cpu().numpy().astype(np.int64)
         ref_scores = o_score.cpu().numpy().copy()
+        ref_docs = o_doc.cpu().numpy().copy()
         # algorithmic bytes: sum_t df_t*(2B id + 1B tf) + 1B per scored candidate + 4B per (term, block) + 8B*k
         uniq = sorted({t for tl in term_lists for t in tl})
         dfm = dict(zip(uniq, (int(x) for x in sh.posting_count(uniq))))
@@ -166,127 +251,186 @@ def main():
                             for i, tl in enumerate(term_lists)], np.float64)
         bytes_launch = float(bytes_q.sum())
 
-        def measure(strategy, steps, warmup):
-            """timed run of one strategy: (qps, ms_per_step, avg kernel ms from the library's HIP events, launches)"""
+        def check_strategy(strategy):
             sh.set_strategy(strategy)
-            sh.profile(True)
-            bm_step()
+            bm_call()
             torch.cuda.synchronize()
             assert np.array_equal(ref_scores, o_score.cpu().numpy()), "Topk ranking differs from the exhaustive TopkCount pass"
-            sh.profile_read(0, reset=True)
-            dt_ = timed(bm_step, steps, warmup)
-            launches_, kms_ = sh.profile_read(0, reset=True)
-            sh.profile(False)
-            return nq * steps / dt_, dt_ / steps * 1e3, kms_ / max(launches_, 1), int(launches_)
 
         # (1) exhaustive scan: every posting of every query term is read -- the kernel the HBM roofline is about
-        ex_qps, ex_ms, ex_kms, ex_n = measure(N.BM25_EXHAUSTIVE, max(4, args.steps // 2), min(args.warmup, 2))
+        check_strategy(N.BM25_EXHAUSTIVE)
+        sh.profile(True)
+        sh.profile_read(0, reset=True)
+        ex_n, ex_dt = timed_for(bm_call)
+        ex_launches, ex_kms = sh.profile_read(0, reset=True)
+        ex_kms /= max(ex_launches, 1)
+        # HIP events are recorded around every launch while profiling is on: the warm-up launches of timed_for are averaged in
+        # as well; all of them are full 1000-query launches of the same kernel.
+        ex_qps, ex_ms = nq * ex_n / ex_dt, ex_dt / ex_n * 1e3
         # (2) the default strategy (AUTO): top-k unions take the pruned path (MaxScore over the probe index)
-        qps, ms_step, avg_ms, launches = measure(N.BM25_AUTO, args.steps, args.warmup)
-        dt = nq * args.steps / qps
+        check_strategy(N.BM25_AUTO)
+        for _ in range(args.warmup):
+            bm_step()
+        sh.profile_read(0, reset=True)  # the accumulators count the timed launches only
+        dt = timed(bm_step, args.steps, 0)
+        launches, kms = sh.profile_read(0, reset=True)
+        sh.profile(False)
+        calls = args.steps * args.calls_per_step
+        assert launches == calls, (launches, calls)
+        avg_ms = kms / max(launches, 1)
+        qps, ms_step = nq * calls / dt, dt / args.steps * 1e3
 
         # (3) ResultType::TopkCount, the reference server's default: pruned top-k + exact union counts (popcounts over the
-        # probe index's bit records) under AUTO, against the exhaustive scan that used to serve it
-        def tc_step():
-            N.check(L.ss_bm25_search_dev(sh._h, nq, q_dev.data_ptr(), k, N.RT_TOPKCOUNT, 2 | (3 << 8), o_doc.data_ptr(),
-                                         o_score.data_ptr(), o_cnt.data_ptr(), o_tot.data_ptr(), sptr), "ss_bm25_search_dev")
+        # probe index's bit records) under AUTO, against the exhaustive scan in count mode
         tc = {}
         for name, strat in (() if args.no_topk_count else (("exhaustive", N.BM25_EXHAUSTIVE), ("auto", N.BM25_AUTO))):
             sh.set_strategy(strat)
-            tc_step()
+            bm_call(rt=N.RT_TOPKCOUNT)
             torch.cuda.synchronize()
             assert np.array_equal(tot, o_tot.cpu().numpy().astype(np.int64)), "TopkCount totals differ between strategies"
             assert np.array_equal(ref_scores, o_score.cpu().numpy())
-            d_ = timed(tc_step, max(4, args.steps // 2), min(args.warmup, 2))
-            tc[name] = {"value": nq * max(4, args.steps // 2) / d_, "unit": "queries/s", "ms_per_step": d_ / max(4, args.steps // 2) * 1e3}
+            n_, d_ = timed_for(lambda: bm_call(rt=N.RT_TOPKCOUNT))
+            tc[name] = {"value": nq * n_ / d_, "unit": "queries/s", "ms_per_call": d_ / n_ * 1e3, "calls": n_}
         sh.set_strategy(N.BM25_AUTO)
-        ach = bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        ach_alg = bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         ex_ach = bytes_launch / (ex_kms * 1e-3) / 1e9 if ex_kms > 0 else 0.0
-        lat_batch = latencies(bm_step, 12)
-        lat_one = latencies(lambda: bm_step(1), 60)
+        lat_batch = latencies(bm_call, 200)
+        lat_one = latencies(lambda: bm_call(1), 400)
+
+        # (4) end to end through the host-pointer entry point: H2D of the queries + kernels + D2H of the results + sync
+        h_doc = np.empty((nq, k), np.uint32); h_score = np.empty((nq, k), np.float32)
+        h_cnt = np.empty(nq, np.uint32); h_tot = np.empty(nq, np.uint64)
+
+        def bm_host_call(n=nq):
+            N.check(L.ss_bm25_search(sh._h, n, q_np.ctypes.data_as(C.c_void_p), k, N.RT_TOPK, N.ptr(h_doc, N.u32p), N.ptr(h_score, N.f32p),
+                                     N.ptr(h_cnt, N.u32p), N.ptr(h_tot, N.u64p)), "ss_bm25_search")
+        bm_host_call()
+        assert np.array_equal(h_score, ref_scores), "host-pointer entry point differs from the device-pointer one"
+        e2e_lat = host_latencies(bm_host_call, 200)
+        e2e_one = host_latencies(lambda: bm_host_call(1), 400)
+        end_to_end = {"value": nq / (np.mean(e2e_lat) * 1e-3), "unit": "queries/s", "entry_point": "ss_bm25_search (host pointers: H2D queries, "
+                      "kernels, D2H results, sync; host clock)", "batch_ms_p50": pct(e2e_lat, 50), "batch_ms_p99": pct(e2e_lat, 99),
+                      "single_query_ms_p50": pct(e2e_one, 50), "single_query_ms_p99": pct(e2e_one, 99), "samples": len(e2e_lat)}
+
         # Roofline of the dominant kernel of the timed region (bm25_probe_kernel).  A pruning kernel answers WITHOUT reading
-        # most of SURVEY 8d's algorithmic bytes (all postings of the query terms), so dividing those by its time gives a rate
-        # above the HBM peak that says nothing about the kernel.  `achieved` is therefore what it really moves per launch
-        # (PMC FETCH_SIZE / WRITE_SIZE of the same command, profiles/pmc_traffic.json) over the live launch time; the rate on
-        # the algorithmic bytes is kept beside it, and the exhaustive scan -- the kernel that does stream them -- below.
+        # most of SURVEY 8d's algorithmic bytes, so algorithmic bytes / time exceeds the HBM peak and says nothing about it:
+        # `achieved` is the traffic the counters saw (profiles/pmc_traffic.json, refused when collected on other kernel
+        # sources; counter -> byte conversion calibrated on this access pattern, tools/probes/pmc_calib.hip) over the live
+        # launch time.  The exhaustive scan below is the kernel SURVEY 8d's figure applies to.
         moved = pmc_traffic("bm25_pruned")
-        real = (moved if moved else bytes_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        moved_lo = pmc_traffic("bm25_pruned", "hbm_bytes_per_launch_low")
+        real = moved / (avg_ms * 1e-3) / 1e9 if (moved and avg_ms > 0) else None
         bm = dict(qps=qps, ms_per_step=ms_step, build_s=build_s, info=info,
                   roofline={"bound": "hbm", "kernel": "bm25_probe_kernel<3,1> (pruned strategy: essential terms' postings + probe records)",
-                            "achieved": real, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": real / HBM_PEAK_GBS,
+                            "achieved": real, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (real / HBM_PEAK_GBS) if real else None,
+                            "frac_counter": (real / HBM_PEAK_GBS) if real else None,
+                            "frac_counter_low": (moved_lo / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (moved_lo and avg_ms > 0) else None,
                             "traffic": moved, "algorithmic_bytes_per_launch": bytes_launch,
-                            "effective_GBs_on_algorithmic_bytes": ach,
-                            "avg_launch_ms": avg_ms, "launches": launches,
-                            "note": "achieved = bytes the kernel really moves (PMC, committed profile) / live kernel time; it answers "
-                                    "without reading most of the SURVEY 8d algorithmic bytes, hence effective_GBs_on_algorithmic_bytes "
-                                    "can exceed the peak; the exhaustive scan below is the kernel that streams the algorithmic bytes"},
-                  exhaustive={"value": ex_qps, "unit": "queries/s", "ms_per_step": ex_ms,
+                            "effective_GBs_on_algorithmic_bytes": ach_alg, "avg_launch_ms": avg_ms, "launches": int(launches),
+                            "pmc_profile": "profiles/pmc_traffic.json" if moved else "absent or collected on other kernel sources (stale): no counter figure",
+                            "note": "achieved = counter-measured HBM bytes of this kernel / live kernel time (the kernel prunes: it answers "
+                                    "without reading most of SURVEY 8d's algorithmic bytes, so effective_GBs_on_algorithmic_bytes may exceed "
+                                    "the peak); exhaustive.roofline is the SURVEY 8d figure"},
+                  exhaustive={"value": ex_qps, "unit": "queries/s", "ms_per_call": ex_ms, "calls": ex_n,
                               "roofline": {"bound": "hbm", "kernel": "bm25_scan_fast_kernel<3,false,1>", "achieved": ex_ach,
                                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ex_ach / HBM_PEAK_GBS,
                                            "traffic": pmc_traffic("bm25"), "algorithmic_bytes_per_launch": bytes_launch,
-                                           "avg_launch_ms": ex_kms, "launches": ex_n}},
+                                           "avg_launch_ms": ex_kms, "launches": int(ex_launches)}},
                   topk_count=dict(tc, note="same batch with ResultType::TopkCount (exact result_count_total, the reference server's "
                                            "default): AUTO = pruned top-k + union counts from the probe index's bit records"),
-                  latency_ms={"batch_p50": pct(lat_batch, 50), "batch_p99": pct(lat_batch, 99),
-                              "single_query_p50": pct(lat_one, 50), "single_query_p99": pct(lat_one, 99)},
+                  latency_ms={"batch_p50": pct(lat_batch, 50), "batch_p99": pct(lat_batch, 99), "batch_samples": len(lat_batch),
+                              "single_query_p50": pct(lat_one, 50), "single_query_p99": pct(lat_one, 99),
+                              "single_query_samples": len(lat_one), "clock": "HIP events on the launch stream (device resident)"},
+                  end_to_end=end_to_end,
                   mean_bytes_per_query=float(bytes_q.mean()), mean_union=float(tot.mean()))
-        # correctness guard inside the bench: sorted, k results, counts sane
+        # correctness guard inside the bench: sorted, k results
+        bm_call()
+        torch.cuda.synchronize()
         sc = o_score.cpu().numpy()
         assert np.all(sc[:, :-1] >= sc[:, 1:]) and np.all(o_cnt.cpu().numpy() == k)
 
-        if rank == 0 and world == 1 and not args.no_cpu:
-            # cpu_baseline: the oracle (reference-structured C port: containers, block-max pruned table scan) on the
-            # host cores, bounded sample of the same query set on the same corpus (terms regenerated on the host)
-            from concurrent.futures import ThreadPoolExecutor
-            ns = 12
-            sample = term_lists[:ns]
-            voc = sorted({t for tl in sample for t in tl})
-            dl = O.lex_doclen(args.docs, O.LEX_SEED)
-            offs, docs, tfs = O.lex_corpus(args.docs, voc, O.LEX_SEED)
-            osh = O.Shard(args.docs, dl, offs, docs, tfs)
-            remap = {t: i for i, t in enumerate(voc)}
-            qs = [[remap[t] for t in tl] for tl in sample]
-            cores = min(os.cpu_count() or 1, 32)
-            od, os_, _ = osh.search(qs[0], O.OP_OR, k, O.RT_TOPK)  # parity spot check GPU vs oracle on query 0
-            assert np.allclose(os_, sc[0][:len(os_)], rtol=1e-4), "bench parity spot check failed"
-            done = 0
+        # ---- full-size parity (C2): a sample of the batch against the oracle on the same 10 M-doc shard, regenerated on
+        # the host -- doc ids outside the tie band, scores 1e-4 relative, exact result_count_total; AUTO and EXHAUSTIVE
+        c2_oracle = None
+        if rank == 0 and not args.no_parity:
             t0 = time.perf_counter()
+            ns = min(args.parity_queries, nq)
+            ans, osh, remap = F.c2_answers(args.docs, term_lists[:ns], th, k, O.OP_OR, O.RT_TOPKCOUNT, part=(rank, world))
+            for i in range(ns):
+                od, os_, otot = ans[i]
+                assert int(tot[i]) == otot, f"C2 full size: result_count_total of query {i}: {int(tot[i])} vs oracle {otot}"
+                F.check_topk(ref_docs[i], ref_scores[i], od, os_, 1e-4, f"C2 full size, exhaustive, query {i}")
+                F.check_topk(o_doc[i].cpu().numpy(), sc[i], od, os_, 1e-4, f"C2 full size, auto, query {i}")
+            parity["c2"] = {"queries": ns, "docs": args.docs, "checked": "top-10 doc ids outside the tie band, scores rtol 1e-4, exact "
+                            "result_count_total; strategies AUTO and EXHAUSTIVE; oracle = so_search_lex_ref on the host-regenerated shard",
+                            "seconds": time.perf_counter() - t0}
+            c2_oracle = (osh, remap, ns)
+
+        if rank == 0 and world == 1 and not args.no_cpu:
+            # cpu_baseline: the reference's own algorithm for this query shape -- union_docid_3's sub-query decomposition over
+            # intersection_blockid / single_blockid with block-max pruning (oracle so_search_lex_ref) -- in the reference's
+            # execution structure: S document-partitioned shards, one task per shard and query.  Bounded sample of the same
+            # queries on the same corpus.
+            from concurrent.futures import ThreadPoolExecutor
+            cores = F.host_threads(128)
+            ns = min(args.parity_queries, nq)
+            if c2_oracle is None:
+                _, osh, remap = F.c2_answers(args.docs, term_lists[:ns], th, k, O.OP_OR, O.RT_TOPK)
+            else:
+                osh, remap, ns = c2_oracle
+            qs = np.array([[remap[t] for t in tl] for tl in term_lists[:ns]], np.uint32)
+            t0 = time.perf_counter()
+            one_tp, _, _ = O.bench_lex([osh], qs, O.OP_OR, k, O.RT_TOPK, 0, cores, args.cpu_seconds)
+            one_lat_qps, _, one_lat = O.bench_lex([osh], qs, O.OP_OR, k, O.RT_TOPK, 1, 1, min(args.cpu_seconds, 3.0))
+            parts = O.split_corpus(args.docs, osh.doclen[:args.docs], osh.offs, osh.docs, osh.tfs, cores)
             with ThreadPoolExecutor(cores) as ex:
-                while time.perf_counter() - t0 < args.cpu_seconds:
-                    list(ex.map(lambda q: osh.search(q, O.OP_OR, k, O.RT_TOPK), qs * max(1, cores // ns + 1)))
-                    done += len(qs) * max(1, cores // ns + 1)
-            el = time.perf_counter() - t0
-            bm["cpu_baseline"] = {"value": done / el, "unit": "queries/s", "cores": cores, "kind": "port",
-                                  "sample": f"{ns} of the {nq} C2 queries repeated for {el:.1f}s on the same {args.docs}-doc "
-                                            f"corpus, {cores} threads, oracle/ss_oracle.c so_search_lex (OR, Topk, k=10)"}
-            del osh
+                shards = list(ex.map(lambda x: O.Shard(*x), parts))
+            s_tp, _, _ = O.bench_lex(shards, qs, O.OP_OR, k, O.RT_TOPK, 0, cores, args.cpu_seconds)
+            s_lat_qps, _, s_lat = O.bench_lex(shards, qs, O.OP_OR, k, O.RT_TOPK, 1, cores, args.cpu_seconds)
+            best = max(one_tp, s_tp)
+            bm["cpu_baseline"] = {
+                "value": best, "unit": "queries/s", "cores": cores, "kind": "port", "algorithm": "union_docid_3",
+                "shards": 1 if best == one_tp else cores,
+                "sample": f"{ns} of the {nq} C2 queries cycled for {args.cpu_seconds:.0f} s per mode on the same {args.docs}-doc corpus "
+                          f"(posting lists of the sample regenerated on the host); oracle/ss_oracle.c so_search_lex_ref = union_docid_3 "
+                          f"sub-query queue over intersection_blockid / single_blockid with block-max pruning, add_topk with docid_hashset",
+                "modes": {
+                    "throughput_1_shard": {"value": one_tp, "threads": cores, "note": "independent queries per core, one 10 M-doc shard (what one GPU holds)"},
+                    "latency_1_shard": {"value": one_lat_qps, "threads": 1, "p50_us": pct(list(one_lat), 50), "p99_us": pct(list(one_lat), 99), "samples": len(one_lat)},
+                    "throughput_S_shards": {"value": s_tp, "shards": cores, "threads": cores, "note": "reference default: S = cores document-partitioned "
+                                            "shards (index.rs:2055-2062), each query = S shard tasks + merge; every core busy with whole queries"},
+                    "latency_S_shards": {"value": s_lat_qps, "shards": cores, "threads": cores, "p50_us": pct(list(s_lat), 50), "p99_us": pct(list(s_lat), 99),
+                                         "samples": len(s_lat), "note": "one query at a time, one thread per shard (search.rs:1637-1650)"}},
+                "published_reference_point": "BASELINE.md section 2: union mean 439 us on 5 M Wikipedia docs, single thread",
+                "seconds": time.perf_counter() - t0}
+            del shards
+        c2_oracle = None
 
     # ------------------------------------------------------------------ vector (secondary)
     vec = None
     if args.workload in ("all", "vec"):
-        from oracle import oracle as O
         kv, B = 100, 64
         t0 = time.perf_counter()
-        sh.synth_vectors(O.VEC_SEED ^ (rank * 0x9E3779B1), args.rows, args.dim)
+        sh.synth_vectors(O.VEC_SEED, args.rows, args.dim)
         vbuild = time.perf_counter() - t0
-        qv = torch.from_numpy(O.vec_gen(O.VECQ_SEED, 0, B, args.dim)).to(dev)
+        qv_np = O.vec_gen(O.VECQ_SEED, 0, B, args.dim)
+        qv = torch.from_numpy(qv_np).to(dev)
         v_doc = torch.empty((B, kv), dtype=torch.int32, device=dev)
         v_score = torch.empty((B, kv), dtype=torch.float32, device=dev)
         v_cnt = torch.empty((B,), dtype=torch.int32, device=dev)
         v_tot = torch.empty((B,), dtype=torch.int64, device=dev)
-        def vec_step(n=B):
+
+        def vec_call(n=B):
             N.check(L.ss_vec_search_dev(sh._h, n, qv.data_ptr(), kv, N.FLT_MIN_NEG, v_doc.data_ptr(), v_score.data_ptr(),
                                         v_cnt.data_ptr(), v_tot.data_ptr(), sptr), "ss_vec_search_dev")
             if world > 1:
-                g = D.all_gather_topk_packed(v_doc[:n], v_score[:n], v_cnt[:n])
-                merged["vec"] = D.merge_gathered_device_packed(g, n, kv, sptr, local_rank)
+                merged["vec"] = comm.allgather_merge(v_doc[:n], v_score[:n], v_cnt[:n], kv, sptr)
 
-        sh.profile(True)
-        vec_step()
+        vec_call()
         torch.cuda.synchronize()
+        sh.profile(True)
         sh.profile_read(1, reset=True)
-        vsteps = max(4, args.steps // 2)
-        dtv = timed(vec_step, vsteps, min(args.warmup, 2))
+        vn, dtv = timed_for(vec_call)
         launches, kms = sh.profile_read(1, reset=True)
         sh.profile(False)
         cnt = v_cnt.cpu().numpy()
@@ -294,16 +438,44 @@ def main():
         flops = 2.0 * args.dim * args.rows * B  # per pass (2*dim*N per query)
         avg_ms = kms / max(launches, 1)
         ach = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        lat = latencies(vec_step, 8)
-        lat1 = latencies(lambda: vec_step(1), 8)  # <= 32 queries: half of the MFMA work is skipped, the pass is HBM-bound
-        vec = dict(qps=B * vsteps / dtv, ms_per_step=dtv / vsteps * 1e3, build_s=vbuild,
+        lat = latencies(vec_call, 200)
+        lat1 = latencies(lambda: vec_call(1), 200)  # <= 32 queries: half of the MFMA work is skipped, the pass is HBM-bound
+        hv_doc = np.empty((B, kv), np.uint32); hv_score = np.empty((B, kv), np.float32)
+        hv_cnt = np.empty(B, np.uint32); hv_tot = np.empty(B, np.uint64)
+
+        def vec_host_call(n=B):
+            N.check(L.ss_vec_search(sh._h, n, N.ptr(qv_np, N.f32p), kv, N.FLT_MIN_NEG, N.ptr(hv_doc, N.u32p), N.ptr(hv_score, N.f32p),
+                                    N.ptr(hv_cnt, N.u32p), N.ptr(hv_tot, N.u64p)), "ss_vec_search")
+        vec_host_call()
+        ve2e = host_latencies(vec_host_call, 100)
+        ve2e1 = host_latencies(lambda: vec_host_call(1), 100)
+        vec = dict(qps=B * vn / dtv, ms_per_step=dtv / vn * 1e3, calls=vn, build_s=vbuild,
                    roofline={"bound": "mfma", "kernel": "vec_scan_kernel (+refine, all row chunks of one pass)", "achieved": ach,
                              "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": pmc_traffic("vector"),
+                             "mfma_util_pmc": pmc_traffic("vector", "mfma_util"),
                              "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": 4.0 * args.dim * args.rows,
                              "hbm_GBs": 4.0 * args.dim * args.rows / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
                              "avg_launch_ms": avg_ms, "launches": int(launches)},
                    latency_ms={"batch64_p50": pct(lat, 50), "batch64_p99": pct(lat, 99), "single_query_p50": pct(lat1, 50),
-                               "single_query_p99": pct(lat1, 99)})
+                               "single_query_p99": pct(lat1, 99), "samples": len(lat), "clock": "HIP events on the launch stream"},
+                   end_to_end={"value": B / (np.mean(ve2e) * 1e-3), "unit": "queries/s", "entry_point": "ss_vec_search (host pointers, host clock)",
+                               "batch64_ms_p50": pct(ve2e, 50), "batch64_ms_p99": pct(ve2e, 99), "single_query_ms_p50": pct(ve2e1, 50),
+                               "single_query_ms_p99": pct(ve2e1, 99), "samples": len(ve2e)})
+        # ---- full-size parity (C3): streamed oracle scan of the same 10 M x 768 rows (regenerated on the host slice by
+        # slice, running TopK), top-100 ids + scores of a sample of the batch
+        vs_all = v_score.cpu().numpy().copy()
+        ids_all = v_doc.cpu().numpy().copy()
+        c3_ref = None
+        if rank == 0 and not args.no_parity:
+            t0 = time.perf_counter()
+            nsv = 4
+            c3_ref = F.c3_answers(args.rows, args.dim, qv_np[:nsv], kv, part=(rank, world), slice_rows=32768)
+            for i in range(nsv):
+                F.check_topk(ids_all[i], vs_all[i], c3_ref[i][0], c3_ref[i][1], 1e-4, f"C3 full size f32, query {i}")
+            parity["c3_f32"] = {"queries": nsv, "rows": args.rows, "dim": args.dim, "checked": "top-100 rows outside the tie band, scores rtol 1e-4; "
+                                "oracle = so_vec_search (dot_f32_avx2 order, TopK::push) streamed over host-regenerated 32 K-row slices",
+                                "seconds": time.perf_counter() - t0}
+
         # ---- AnnMode::Nprobe on the same image: a cluster STRUCTURE (256 records per cluster, 256 clusters per 65 536-doc
         # level, as the reference lays a level out) over the synthetic rows -- the cost of the mode does not depend on what
         # the clusters mean.  16 of 256 clusters per level = 6.25 % of the records per query.
@@ -314,8 +486,10 @@ def main():
             ann_lc.append(len(cl)); ann_cc += cl
         ann_mode = S.AnnMode.Nprobe(16)._c()
         v_ncl = torch.empty((B,), dtype=torch.int32, device=dev)
+
         def ann_leg(i8):
             sh.set_clusters(ann_lc, ann_cc)
+
             def step(n):
                 if i8:
                     N.check(L.ss_vec_search_i8_ann_dev(sh._h, n, q8.data_ptr(), None, kv, N.FLT_MIN_NEG, C.addressof(ann_mode),
@@ -325,11 +499,12 @@ def main():
                     N.check(L.ss_vec_search_ann_dev(sh._h, n, qv.data_ptr(), kv, N.FLT_MIN_NEG, C.addressof(ann_mode), v_doc.data_ptr(),
                                                     v_score.data_ptr(), v_cnt.data_ptr(), v_tot.data_ptr(), v_ncl.data_ptr(), sptr),
                             "ss_vec_search_ann_dev")
-            l1 = latencies(lambda: step(1), 8)
-            l64 = latencies(lambda: step(B), 4)
+            l1 = latencies(lambda: step(1), 200)
+            l64 = latencies(lambda: step(B), 50)
             assert np.all(v_cnt.cpu().numpy().astype(np.int64) == kv), "ANN candidate overflow or short result in bench"
             return {"mode": "Nprobe(16) of 256 clusters per level", "clusters_visited_per_query": int(v_ncl[0].item()),
-                    "single_query_ms_p50": pct(l1, 50), "batch64_ms_p50": pct(l64, 50)}
+                    "single_query_ms_p50": pct(l1, 50), "single_query_ms_p99": pct(l1, 99), "batch64_ms_p50": pct(l64, 50), "samples": len(l1)}
+
         # ---- C4 hybrid: query i of C2 paired with query i of C3, each side top-100, RRF(0.6), final top-100 --
         # lexical search, vector search and the fusion of the whole batch on the device, nothing crosses PCIe in between
         if bm is not None and world == 1:
@@ -339,15 +514,16 @@ def main():
             h_doc = torch.empty((B, kh), dtype=torch.int64, device=dev); h_sc = torch.empty((B, kh), dtype=torch.float32, device=dev)
             h_src = torch.empty((B, kh), dtype=torch.uint8, device=dev); h_cnt = torch.empty((B,), dtype=torch.int32, device=dev)
             sh.set_strategy(N.BM25_AUTO)
-            def hyb_step():
-                N.check(L.ss_bm25_search_dev(sh._h, B, q_dev.data_ptr(), kh, N.RT_TOPK, 2 | (3 << 8), h_ldoc.data_ptr(), h_lsc.data_ptr(),
+
+            def hyb_call():
+                N.check(L.ss_bm25_search_dev(sh._h, B, q_dev.data_ptr(), kh, N.RT_TOPK, OPS, h_ldoc.data_ptr(), h_lsc.data_ptr(),
                                              h_lcnt.data_ptr(), h_ltot.data_ptr(), sptr), "ss_bm25_search_dev")
                 N.check(L.ss_vec_search_dev(sh._h, B, qv.data_ptr(), kv, N.FLT_MIN_NEG, v_doc.data_ptr(), v_score.data_ptr(),
                                             v_cnt.data_ptr(), v_tot.data_ptr(), sptr), "ss_vec_search_dev")
                 N.check(L.ss_rrf_merge_dev(local_rank, B, kh, h_ldoc.data_ptr(), h_lcnt.data_ptr(), kv, v_doc.data_ptr(), v_cnt.data_ptr(), 0,
                                            0, kh, h_doc.data_ptr(), h_sc.data_ptr(), h_src.data_ptr(), h_cnt.data_ptr(), sptr),
                         "ss_rrf_merge_dev")
-            hyb_step()
+            hyb_call()
             torch.cuda.synchronize()
             # against the host fusion of the same lists (ss_merge_results, the reference's RRF restated on the CPU side)
             for qi in (0, B - 1):
@@ -358,32 +534,47 @@ def main():
                 n_ = int(h_cnt[qi].item())
                 assert n_ == len(hd) and np.array_equal(h_doc[qi, :n_].cpu().numpy().astype(np.uint64), hd)
                 assert np.array_equal(h_sc[qi, :n_].cpu().numpy(), hs), "device RRF differs from ss_merge_results"
-            hsteps = max(4, args.steps // 4)
-            dth = timed(hyb_step, hsteps, 1)
+            # full-size parity (C4): the lexical top-100 against the oracle at full size, the vector top-100 (above), and the
+            # fusion of the GPU's lists against the oracle's so_merge of the same lists (ranks only enter an RRF score)
+            if rank == 0 and not args.no_parity and c3_ref is not None:
+                t0 = time.perf_counter()
+                nsh = len(c3_ref)
+                lans, _, _ = F.c2_answers(args.docs, term_lists[:nsh], th, kh, O.OP_OR, O.RT_TOPK, part=(rank, world))
+                for i in range(nsh):
+                    nl_, nv_ = int(h_lcnt[i].item()), int(v_cnt[i].item())
+                    gl = (h_ldoc[i, :nl_].cpu().numpy(), h_lsc[i, :nl_].cpu().numpy())
+                    gv = (v_doc[i, :nv_].cpu().numpy(), v_score[i, :nv_].cpu().numpy())
+                    F.check_topk(gl[0], gl[1], lans[i][0], lans[i][1], 1e-4, f"C4 full size, lexical top-100, query {i}")
+                    F.check_topk(gv[0], gv[1], c3_ref[i][0], c3_ref[i][1], 1e-4, f"C4 full size, vector top-100, query {i}")
+                    od, os_, _ = O.merge(2, (gl[0].astype(np.uint64), gl[1]), (gv[0].astype(np.uint64), gv[1]), 0, kh)
+                    n_ = int(h_cnt[i].item())
+                    assert n_ == len(od) and np.array_equal(h_doc[i, :n_].cpu().numpy().astype(np.uint64), od), f"C4 RRF ids, query {i}"
+                    assert np.allclose(h_sc[i, :n_].cpu().numpy(), os_, rtol=1e-6), f"C4 RRF scores, query {i}"
+                parity["c4"] = {"queries": nsh, "checked": "BM25 top-100 and cosine top-100 against the full-size oracle lists, device RRF against "
+                                "the oracle's so_merge (RRF 0.6) of the same lists", "seconds": time.perf_counter() - t0}
+            hn, dth = timed_for(hyb_call)
             vec["hybrid"] = {"workload": "C4: C2 query i + C3 query i, top-100 each, RRF(0.6), final top-100; batch 64, all on device",
-                             "value": B * hsteps / dth, "unit": "queries/s", "ms_per_step": dth / hsteps * 1e3}
+                             "value": B * hn / dth, "unit": "queries/s", "ms_per_call": dth / hn * 1e3, "calls": hn}
         if args.rows >= 65536:
             vec["ann"] = ann_leg(False)
         # property checks at full size: sorted, and the scores really are dot products of the returned rows
-        vec_step()
+        vec_call()
         torch.cuda.synchronize()
         vs = v_score.cpu().numpy()
         assert np.all(vs[:, :-1] >= vs[:, 1:])
         ids = v_doc.cpu().numpy()
         r0 = sh.read_rows(int(ids[0, 0]), 1)[0]
-        assert abs(float(r0 @ qv[0].cpu().numpy()) - float(vs[0, 0])) < 1e-4
+        assert abs(float(r0 @ qv_np[0]) - float(vs[0, 0])) < 1e-4
         if rank == 0 and world == 1 and not args.no_cpu:
             from concurrent.futures import ThreadPoolExecutor
             M = min(args.rows, 200_000)
             rows = O.vec_gen(O.VEC_SEED, 0, M, args.dim)
-            qh = qv.cpu().numpy()
-            cores = min(os.cpu_count() or 1, 32)
-            od, os_, _, _ = O.vec_search(rows, qh[0], kv)
+            cores = F.host_threads(128)
             done = 0
             t0 = time.perf_counter()
             with ThreadPoolExecutor(cores) as ex:
                 while time.perf_counter() - t0 < args.cpu_seconds:
-                    list(ex.map(lambda q: O.vec_search(rows, q, kv), [qh[i % B] for i in range(cores)]))
+                    list(ex.map(lambda q: O.vec_search(rows, q, kv), [qv_np[i % B] for i in range(cores)]))
                     done += cores
             el = time.perf_counter() - t0
             scale = args.rows / M
@@ -394,17 +585,18 @@ def main():
 
         # ---- the same corpus as Precision::I8 records (quantize_f32_to_i8 of the same rows): HBM-bound stream kernel
         t0 = time.perf_counter()
-        sh.synth_vectors_i8(O.VEC_SEED ^ (rank * 0x9E3779B1), args.rows, args.dim)
+        sh.synth_vectors_i8(O.VEC_SEED, args.rows, args.dim)
         build8 = time.perf_counter() - t0
-        q8 = torch.from_numpy(O.quantize_i8(O.vec_gen(O.VECQ_SEED, 0, B, args.dim))).to(dev)
-        def vec8_step():
+        q8 = torch.from_numpy(O.quantize_i8(qv_np)).to(dev)
+
+        def vec8_call():
             N.check(L.ss_vec_search_i8_dev(sh._h, B, q8.data_ptr(), None, kv, N.FLT_MIN_NEG, v_doc.data_ptr(), v_score.data_ptr(),
                                            v_cnt.data_ptr(), v_tot.data_ptr(), sptr), "ss_vec_search_i8_dev")
-        sh.profile(True)
-        vec8_step()
+        vec8_call()
         torch.cuda.synchronize()
+        sh.profile(True)
         sh.profile_read(1, reset=True)
-        dt8 = timed(vec8_step, vsteps * 2, min(args.warmup, 2))
+        n8, dt8 = timed_for(vec8_call)
         launches8, kms8 = sh.profile_read(1, reset=True)
         sh.profile(False)
         assert np.all(v_cnt.cpu().numpy().astype(np.int64) == min(kv, args.rows))
@@ -412,12 +604,21 @@ def main():
         assert np.all(vs8[:, :-1] >= vs8[:, 1:])
         r8 = sh.read_rows_i8(int(id8[0, 0]), 1)[0]
         assert float(r8.astype(np.int64) @ q8[0].cpu().numpy().astype(np.int64)) == float(vs8[0, 0]), "i8 score is not the integer dot product"
+        if rank == 0 and not args.no_parity:
+            t0 = time.perf_counter()
+            nsv = 4
+            ref8 = F.c3_answers(args.rows, args.dim, qv_np[:nsv], kv, part=(rank, world), slice_rows=32768, i8=True)
+            for i in range(nsv):
+                assert np.array_equal(vs8[i], ref8[i][1]), f"C3 full size i8: scores of query {i} differ from the oracle (integer dot products: ==)"
+                F.check_topk(id8[i], vs8[i], ref8[i][0], ref8[i][1], 0.0, f"C3 full size i8, query {i}")
+            parity["c3_i8"] = {"queries": nsv, "checked": "top-100 scores == (integer dots), rows outside the k-th score's tie group",
+                               "seconds": time.perf_counter() - t0}
         ms8 = kms8 / max(launches8, 1)
         bytes8 = 1.0 * args.dim * args.rows
         gbs8 = bytes8 / (ms8 * 1e-3) / 1e9 if ms8 > 0 else 0.0
         ann8 = ann_leg(True) if args.rows >= 65536 else None
-        vec["i8"] = {"metric": "queries/sec (i8 dot top-100, batch 64)", "ann": ann8, "value": B * vsteps * 2 / dt8 * world, "ms_per_step": dt8 / (vsteps * 2) * 1e3,
-                     "build_s": build8,
+        vec["i8"] = {"metric": "queries/sec (i8 dot top-100, batch 64)", "ann": ann8, "value": B * n8 / dt8, "ms_per_call": dt8 / n8 * 1e3,
+                     "calls": n8, "build_s": build8,
                      "roofline": {"bound": "hbm", "kernel": "vec8_scan_kernel (+refine, all row chunks of one pass)", "achieved": gbs8,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs8 / HBM_PEAK_GBS, "traffic": pmc_traffic("vector_i8"),
                                   "algorithmic_bytes_per_launch": bytes8, "algorithmic_ops_per_launch": 2.0 * args.dim * args.rows * B,
@@ -427,12 +628,15 @@ def main():
     if rank == 0:
         prim = bm if bm is not None else vec
         is_bm = bm is not None
+        gen_note = ("synthetic generators follow SURVEY 8d with two integer-exact substitutions (so that host and device generate "
+                    "identical data): tf = 1 + ctz(hash) (geometric p = 0.5, not 0.6); vector components uniform(-1, 1) then "
+                    "normalize_f32 (not Box-Muller)")
         line = {
             "metric": "queries/sec" + (" (BM25 3-term OR top-10)" if is_bm else " (cosine top-100, batch 64)"),
-            "value": prim["qps"] * world,
+            "value": prim["qps"],
             "unit": "queries/s",
             "n_gpus": world,
-            "steps": args.steps if is_bm else max(4, args.steps // 2),
+            "steps": args.steps if is_bm else prim["calls"],
             "warmup": args.warmup,
             "ms_per_step": prim["ms_per_step"],
             "higher_is_better": True,
@@ -441,14 +645,21 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": ({"workload": "C2: 10M synthetic docs, 3-term OR BM25 top-10, one shard per GPU", "docs_per_shard": args.docs,
-                        "queries_per_step": args.queries, "k": 10, "vocabulary": 4096, "result_type": "Topk", "strategy": "auto (pruned top-k; exhaustive scan reported beside it)",
-                        "value_counts": "queries x shards scanned (one 10M-doc shard per GPU)"} if is_bm else
+                        "queries_per_call": args.queries, "calls_per_step": args.calls_per_step, "k": 10, "vocabulary": 4096,
+                        "result_type": "Topk", "strategy": "auto (pruned top-k; exhaustive scan reported beside it)",
+                        "corpus": f"shard r of {world} of ONE generator stream of {args.docs * world} docs (doc g -> shard g % {world})",
+                        "value_counts": "merged answers per second over all shards (every shard sees every query; weak scaling: the corpus "
+                                        "grows with N, so a flat value is perfect scaling)", "generators": gen_note} if is_bm else
                        {"workload": "C3: 10M x 768 f32, batch-64 cosine top-100 brute force", "rows_per_shard": args.rows,
-                        "dim": args.dim, "batch": 64, "k": 100}),
+                        "dim": args.dim, "batch": 64, "k": 100, "generators": gen_note}),
             "global_qps": prim["qps"],
+            "shard_queries_per_s": prim["qps"] * world,
+            "docs_scanned_per_s": prim["qps"] * world * (args.docs if is_bm else args.rows),
             "roofline": prim["roofline"],
             "cpu_baseline": prim.get("cpu_baseline"),
             "latency_ms": prim["latency_ms"],
+            "end_to_end": prim.get("end_to_end"),
+            "parity_full_size": parity or None,
         }
         if is_bm:
             line["exhaustive"] = bm["exhaustive"]
@@ -456,14 +667,16 @@ def main():
             line["bm25"] = {"build_s": bm["build_s"], "postings": int(bm["info"]["n_postings"]), "avgdl": bm["info"]["avgdl"],
                             "mean_algorithmic_bytes_per_query": bm["mean_bytes_per_query"], "mean_union_size": bm["mean_union"]}
         if vec is not None and is_bm:
-            line["vector"] = {"metric": "queries/sec (cosine top-100, 10M x 768 f32, batch 64)", "value": vec["qps"] * world,
-                              "global_qps": vec["qps"], "ms_per_step": vec["ms_per_step"], "roofline": vec["roofline"],
-                              "cpu_baseline": vec.get("cpu_baseline"), "latency_ms": vec["latency_ms"], "build_s": vec["build_s"],
-                              "rows_per_shard": args.rows, "dim": args.dim, "hybrid": vec.get("hybrid"), "ann": vec.get("ann"),
-                              "i8": vec.get("i8")}
+            line["vector"] = {"metric": "queries/sec (cosine top-100, 10M x 768 f32, batch 64)", "value": vec["qps"],
+                              "global_qps": vec["qps"], "ms_per_call": vec["ms_per_step"], "calls": vec["calls"], "roofline": vec["roofline"],
+                              "cpu_baseline": vec.get("cpu_baseline"), "latency_ms": vec["latency_ms"], "end_to_end": vec.get("end_to_end"),
+                              "build_s": vec["build_s"], "rows_per_shard": args.rows, "dim": args.dim, "hybrid": vec.get("hybrid"),
+                              "ann": vec.get("ann"), "i8": vec.get("i8")}
         elif vec is not None:
             line["i8"] = vec.get("i8")
         print(json.dumps(line), flush=True)
+    if comm is not None:
+        comm.close()
     sh.close()
     if world > 1:
         dist.destroy_process_group()

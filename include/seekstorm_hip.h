@@ -160,6 +160,10 @@ int ss_ref_decode_block_fields(const ss_ref_block* block, uint32_t n_fields, uin
  * posting (t,d) iff (h(seed,t+1,d)>>32) < thresh32[t]; bit-identical to ss_bm25_upload of the same corpus. */
 int ss_bm25_synth(ss_shard* s, uint64_t seed, uint64_t n_docs, uint32_t n_terms, const uint32_t* thresh32,
                   const uint8_t* len_table1024);
+/* The generators above and below build shard `shard_id` of `n_shards` of ONE synthetic corpus, partitioned as the reference
+ * partitions documents (doc g -> shard g % S with local id g / S, index.rs:5284): local doc / row d is global d * S + id of
+ * the generator stream.  Applies to the following ss_bm25_synth / ss_vec_synth[_i8] calls; default 0 of 1. */
+int ss_synth_set_partition(ss_shard* s, uint32_t shard_id, uint32_t n_shards);
 int ss_bm25_info(ss_shard* s, uint64_t* n_docs, float* avgdl, uint32_t* n_terms, uint64_t* n_postings);
 /* Search strategy.  AUTO: requests with <= 4 scored terms and k <= 128 take the PRUNED path (the reference's block-max /
  * sub-query pruning, intersection.rs:2224-2233, union.rs:1355-1405, as MaxScore over a probe index: only essential /
@@ -209,13 +213,17 @@ int ss_bm25_search(ss_shard* s, uint32_t n_queries, const ss_bm25_query* queries
                    uint32_t result_type, uint32_t* out_doc, float* out_score, uint32_t* out_count,
                    uint64_t* out_total);
 /* Same, everything device-resident and asynchronous on `stream` (a hipStream_t passed as void*;
- * NULL = the shard's own stream).  d_queries is a device array of ss_bm25_query that the caller has validated
- * (term < n_terms, unique terms, idf > 0).  ops_mask: bit 0 set if any query is an intersection of > 1 terms
- * (selects the kernel variant that carries match counters), bit 1 set if any query is a union of > 1 terms; bits 8..15 = the
- * largest n_terms + NOT terms in the batch (0 = unknown: the generic 10-term kernel is used); bits 16..23 = the largest
- * n_terms alone (0 = same as bits 8..15, i.e. no NOT terms); bit 2 set if every term of the batch has probe rows
+ * NULL = the shard's own stream).  d_queries is a device array of ss_bm25_query.  ops_mask tells the host, which cannot read
+ * the queries, what the batch contains (it picks the kernel variants by it): bit 0 set if any query is an intersection of
+ * > 1 terms (variant with match counters) or carries a field filter, bit 1 set if any query is a union of > 1 terms;
+ * bits 8..15 = the largest n_terms + NOT terms in the batch (0 = unknown: the generic 10-term kernel is used); bits 16..23 =
+ * the largest n_terms alone (0 = same as bits 8..15, i.e. no NOT terms); bit 2 set if every term of the batch has probe rows
  * (ss_bm25_term_probed; irrelevant when the probe budget covered all lists); bit 3 set if some query carries
- * SS_OP_ALL_TERMS_FREQUENT (or a field filter: bit 0 as well). */
+ * SS_OP_ALL_TERMS_FREQUENT.
+ * The assertion is CHECKED ON THE DEVICE, query by query, before the search kernels run: a query that contradicts ops_mask
+ * (an intersection in a batch declared union-only, more terms than declared, an unprobed term under bit 2, ...) or is
+ * malformed (no terms, a term id outside the vocabulary) is answered as an empty query and flagged
+ * d_out_count[q] = UINT32_MAX -- never a silently wrong list.  (idf > 0 and unique terms remain the caller's duty.) */
 int ss_bm25_search_dev(ss_shard* s, uint32_t n_queries, const ss_bm25_query* d_queries, uint32_t k,
                        uint32_t result_type, uint32_t ops_mask, uint32_t* d_out_doc, float* d_out_score,
                        uint32_t* d_out_count, uint64_t* d_out_total, void* stream);
@@ -365,6 +373,25 @@ int ss_topk_merge_dev(int device, uint32_t n_queries, uint32_t n_shards, uint32_
  * 32-bit words -- a single all-gather per batch (latency bound: three collectives cost three latencies) */
 int ss_topk_merge_dev_packed(int device, uint32_t n_queries, uint32_t n_shards, uint32_t k, const uint32_t* d_packed,
                              uint64_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, void* stream);
+/* ---- the exchange itself, behind the ABI (RCCL over xGMI; replaces search.rs:1875-1940 + 2098-2119 for shards on different
+ * GPUs).  A communicator is one rank of a group of shards, rank = shard id (global id = local * n_ranks + rank, search.rs:1671).
+ *   one process per GPU : rank 0 calls ss_comm_unique_id and hands the 128 bytes to the other ranks (any channel: MPI,
+ *                         a TCP store, a file); every rank calls ss_comm_create with the same id;
+ *   one process, S GPUs : ss_comm_create_all(S, devices, out[S]) (the reference's shape: one process, one task per shard).
+ * ss_topk_allgather_merge: packs this shard's top-k lists of the batch (outputs of ss_*_search_dev, [n_queries][k]), ONE
+ * all-gather, then ss_topk_merge_dev_packed -- every rank ends with the same merged lists.  Asynchronous on `stream`; all
+ * ranks must call it with the same n_queries and k (in a single process: from one thread per rank, as Index::search runs its
+ * shard tasks).  n_ranks * k <= 8192. */
+#define SS_COMM_ID_BYTES 128
+typedef struct ss_comm ss_comm;
+int ss_comm_unique_id(uint8_t id_out[SS_COMM_ID_BYTES]);
+int ss_comm_create(int device, int rank, int n_ranks, const uint8_t id[SS_COMM_ID_BYTES], ss_comm** out);
+int ss_comm_create_all(int n_devices, const int* devices, ss_comm** out /*[n_devices]*/);
+int ss_comm_destroy(ss_comm* c);
+int ss_comm_info(const ss_comm* c, int* rank, int* n_ranks, int* device);
+int ss_topk_allgather_merge(ss_comm* c, uint32_t n_queries, uint32_t k, const uint32_t* d_doc, const float* d_score,
+                            const uint32_t* d_count, uint64_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, void* stream);
+
 /* Hybrid fusion of a query batch on the device: RRF (k = 0.6, 0-based ranks, search.rs:1962-2035) of the lexical and the
  * vector list of every query, then sort / offset / length (2098-2119) -- ss_merge_results(SS_MODE_HYBRID) for n_queries
  * queries without a host round trip.  d_lex_doc [n_queries][k_lex] and d_vec_doc [n_queries][k_vec] are the doc-id

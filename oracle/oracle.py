@@ -228,6 +228,14 @@ class Shard:
     def search(self, terms, op, k, rt=RT_TOPKCOUNT, not_terms=()):
         return self._search(lib().so_search_lex_not, terms, not_terms, op, k, rt)
 
+    def search_ref(self, terms, op, k, rt=RT_TOPKCOUNT, not_terms=()):
+        """the dispatch as the reference structures it (single_blockid / union_docid_2 / union_docid_3 / ...): the function
+        the CPU baseline times; must agree with search()"""
+        f = lib().so_search_lex_ref
+        f.restype = C.c_uint32
+        f.argtypes = [C.c_void_p, C.c_uint32, u32p, C.c_uint32, u32p, C.c_int, C.c_uint32, C.c_int, u32p, f32p, u64p]
+        return self._search(f, terms, not_terms, op, k, rt)
+
     def all_terms_frequent(self, terms, top_k):
         f = lib().so_all_terms_frequent
         f.restype = C.c_int
@@ -274,6 +282,45 @@ class Shard:
         a, b = C.c_uint64(), C.c_uint64()
         lib().so_query_stats(self.h, len(q), _p(q, u32p), C.byref(a), C.byref(b))
         return a.value, b.value
+
+
+def split_corpus(n_docs, doclen, offs, docs, tfs, n_shards):
+    """the reference's document partitioning: doc g -> shard g % S with local id g // S (index.rs:5284); per shard
+    (n_docs, doclen, offs, docs, tfs)"""
+    n_terms = len(offs) - 1
+    S = int(n_shards)
+    term_of = np.repeat(np.arange(n_terms, dtype=np.int64), np.diff(offs.astype(np.int64)))
+    sh_of = (docs % S).astype(np.int64)
+    order = np.argsort(sh_of, kind="stable")  # shard-major; inside a shard the (term, doc) order is kept
+    cnt = np.bincount(sh_of * n_terms + term_of, minlength=S * n_terms).reshape(S, n_terms)
+    starts = np.concatenate([[0], np.cumsum(cnt.sum(axis=1))])
+    d_sorted = (docs[order] // S).astype(np.uint32)
+    t_sorted = tfs[order]
+    out = []
+    for sh in range(S):
+        o = np.zeros(n_terms + 1, np.uint64)
+        o[1:] = np.cumsum(cnt[sh])
+        a, b = int(starts[sh]), int(starts[sh + 1])
+        out.append(((n_docs - sh + S - 1) // S, np.ascontiguousarray(doclen[sh::S]), o, d_sorted[a:b], t_sorted[a:b]))
+    return out
+
+
+def bench_lex(shards, queries, op, k, rt, mode, threads, seconds):
+    """CPU baseline harness (so_bench_lex): shards = list of Shard, queries = [nq][nt] term ids.
+    -> (queries/s, queries answered, latencies in microseconds (latency mode))"""
+    L = lib()
+    f = L.so_bench_lex
+    f.restype = C.c_double
+    f.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, u32p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int,
+                  C.c_uint32, C.c_double, u64p, C.POINTER(C.c_double), C.c_uint32, u32p]
+    hs = (C.c_void_p * len(shards))(*[sh.h for sh in shards])
+    q = np.ascontiguousarray(queries, np.uint32)
+    assert q.ndim == 2
+    lat = np.zeros(1 << 20, np.float64)
+    done, nlat = C.c_uint64(), C.c_uint32()
+    qps = f(hs, len(shards), _p(q.reshape(-1), u32p), q.shape[0], q.shape[1], op, k, rt, mode, threads, float(seconds),
+            C.byref(done), lat.ctypes.data_as(C.POINTER(C.c_double)), len(lat), C.byref(nlat))
+    return qps, done.value, lat[:nlat.value].copy()
 
 
 def vec_search(rows, query, k, row_doc_ids=None, threshold_raw=-3.4028234663852886e38, simd_order=True, deleted=None):

@@ -346,12 +346,12 @@ static int cur_find(so_cur* c, uint32_t d) {
     return 0;
   } else if (b->ctype == SO_CT_BITMAP) {
     if (!((b->cont[d >> 3] >> (d & 7u)) & 1u)) return 0;
-    uint32_t w = d >> 6, r = 0;
-    for (uint32_t i = 0; i < w; i++) { uint64_t x; memcpy(&x, b->cont + 8 * i, 8); r += (uint32_t)__builtin_popcountll(x); }
+    /* running popcount cursor (p_run = words summed, p_run_sum = their bits), intersection.rs:772-789: probes ascend */
+    const uint32_t w = d >> 6;
+    for (; c->pos < w; c->pos++) { uint64_t x; memcpy(&x, b->cont + 8 * c->pos, 8); c->rle_rank += (uint32_t)__builtin_popcountll(x); }
     uint64_t x; memcpy(&x, b->cont + 8 * w, 8);
-    uint32_t bit = d & 63u;
-    if (bit) r += (uint32_t)__builtin_popcountll(x & ((1ull << bit) - 1ull));
-    c->rank = r;
+    const uint32_t bit = d & 63u;
+    c->rank = c->rle_rank + (bit ? (uint32_t)__builtin_popcountll(x & ((1ull << bit) - 1ull)) : 0u);
     return 1;
   } else {
     uint32_t runs = rd16(b->cont);
@@ -976,4 +976,447 @@ uint32_t so_search_fields_filtered(uint64_t n_docs, uint32_t n_fields, const uin
   if (total) *total = m;
   free(v); free(cnt); free(sc);
   return n;
+}
+
+/* ================================================================== reference-structured dispatch
+ * The dispatch block of search_lexical_shard (search.rs:3374-3560) as the reference runs it for ONE indexed field:
+ *   1 term                      -> single_blockid                       (single.rs:292-417, single_docid 23-289)
+ *   union of 2                  -> union_docid_2                        (union.rs:1168-1305)
+ *   union of 3..10, Topk[Count] -> union_docid_3 (sub-query queue)      (union.rs:1308-1479)
+ *   union Count / > 10 terms    -> union_blockid -> union_scan          (search_or above)
+ *   intersection                -> intersection_blockid                 (search_and above)
+ * with MinHeap::add_topk's docid_hashset arm (min_heap.rs:1193-1260), which is what lets the sub-queries of a union
+ * re-offer a doc that an earlier sub-query already placed.  This is the path the CPU baseline times (bench.py).  */
+typedef struct { uint32_t* key; float* val; uint32_t cap, n, used; } so_hset; /* docid_hashset: doc -> score, min_heap.rs:46 */
+#define HS_EMPTY 0xFFFFFFFFu
+#define HS_TOMB 0xFFFFFFFEu
+static void hset_init(so_hset* h, uint32_t cap) {
+  h->cap = cap; h->n = 0; h->used = 0;
+  h->key = (uint32_t*)malloc(cap * sizeof(uint32_t)); h->val = (float*)malloc(cap * sizeof(float));
+  memset(h->key, 0xFF, cap * sizeof(uint32_t));
+}
+static void hset_free(so_hset* h) { free(h->key); free(h->val); }
+static inline uint32_t hs_slot(const so_hset* h, uint32_t d) { return (d * 2654435761u) & (h->cap - 1); }
+static int hset_get(const so_hset* h, uint32_t d, float* v) {
+  for (uint32_t i = hs_slot(h, d);; i = (i + 1) & (h->cap - 1)) {
+    if (h->key[i] == HS_EMPTY) return 0;
+    if (h->key[i] == d) { *v = h->val[i]; return 1; }
+  }
+}
+static void hset_put(so_hset* h, uint32_t d, float v);
+static void hset_grow(so_hset* h) {
+  so_hset o = *h;
+  hset_init(h, o.cap * 2);
+  for (uint32_t i = 0; i < o.cap; i++) if (o.key[i] < HS_TOMB) hset_put(h, o.key[i], o.val[i]);
+  hset_free(&o);
+}
+static void hset_put(so_hset* h, uint32_t d, float v) { /* HashMap::insert: overwrites */
+  if ((h->used + 1) * 2 > h->cap) hset_grow(h);
+  int32_t tomb = -1;
+  for (uint32_t i = hs_slot(h, d);; i = (i + 1) & (h->cap - 1)) {
+    if (h->key[i] == d) { h->val[i] = v; return; }
+    if (h->key[i] == HS_TOMB && tomb < 0) tomb = (int32_t)i;
+    if (h->key[i] == HS_EMPTY) {
+      if (tomb >= 0) i = (uint32_t)tomb; else h->used++;
+      h->key[i] = d; h->val[i] = v; h->n++;
+      return;
+    }
+  }
+}
+static void hset_remove(so_hset* h, uint32_t d) {
+  for (uint32_t i = hs_slot(h, d);; i = (i + 1) & (h->cap - 1)) {
+    if (h->key[i] == HS_EMPTY) return;
+    if (h->key[i] == d) { h->key[i] = HS_TOMB; h->n--; return; }
+  }
+}
+
+typedef struct { so_heap h; so_hset hs; } so_topk_ref;
+/* pop_add, min_heap.rs:1113-1121 */
+static void ref_pop_add(so_topk_ref* T, uint32_t doc, float score) {
+  if (T->hs.n) hset_remove(&T->hs, T->h.e[0].doc);
+  T->h.e[0].doc = doc; T->h.e[0].score = score;
+  heap_down(&T->h, 0);
+}
+/* add_topk, min_heap.rs:1193-1260 (result_sort empty: ordering = score) */
+static int ref_add_topk(so_topk_ref* T, uint32_t doc, float score) {
+  so_heap* h = &T->h;
+  if (h->k == 0) return 0;
+  float old;
+  if (T->hs.n && hset_get(&T->hs, doc, &old)) {
+    if (h->e[0].doc == doc) {
+      if (score > h->e[0].score) { h->e[0].score = score; heap_down(h, 0); return 1; }
+      return 0;
+    }
+    if (old >= score) return 0;
+    uint32_t idx = 0;
+    while (h->e[idx].doc != doc) {
+      if (idx == h->n - 1) { ref_pop_add(T, doc, score); return 1; }
+      idx++;
+    }
+    h->e[idx].score = score;
+    heap_down(h, idx);
+    return 1;
+  }
+  if (h->n < h->k) { h->e[h->n].doc = doc; h->e[h->n].score = score; h->n++; heap_up(h, h->n - 1); return 1; }
+  if (score > h->e[0].score) { ref_pop_add(T, doc, score); return 1; }
+  return 0;
+}
+/* "for i in 0..current_heap_size: docid_hashset.insert(doc, score)" before a sub-query, union.rs:1254-1259, 1348-1353, 1437-1442 */
+static void ref_snapshot(so_topk_ref* T) {
+  for (uint32_t i = 0; i < T->h.n; i++) hset_put(&T->hs, T->h.e[i].doc, T->h.e[i].score);
+}
+
+typedef struct { float score; uint32_t ord; } so_sb;
+static int sb_cmp(const void* a, const void* b) {
+  const so_sb* x = (const so_sb*)a; const so_sb* y = (const so_sb*)b;
+  if (x->score > y->score) return -1;
+  if (x->score < y->score) return 1;
+  return (x->ord > y->ord) - (x->ord < y->ord);
+}
+/* single_blockid + single_docid + add_result_singleterm_singlefield (single.rs:292-417, 23-289; add_result.rs:647-900).
+ * `filtered` as single.rs:307-312 (NOT terms or a delete set).  Blocks in block_score order, at most top_k of them when
+ * unfiltered, stop / skip at block_score <= heap minimum.  Returns what the function adds to result_count. */
+static uint64_t ref_single(const so_shard* s, uint32_t term, float idf, int rt, uint32_t top_k, so_topk_ref* T,
+                           const uint8_t* gone, int unique_terms) {
+  const so_term* Tm = &s->terms[term];
+  const int filtered = gone != NULL;
+  if (rt == SO_RT_COUNT && unique_terms <= 1 && !filtered) return Tm->posting_count; /* single.rs:314-324 */
+  uint64_t local = 0;
+  so_sb* bv = (so_sb*)malloc((Tm->n_blocks ? Tm->n_blocks : 1) * sizeof(so_sb));
+  for (uint32_t b = 0; b < Tm->n_blocks; b++) { bv[b].score = idf * Tm->blocks[b].max_part; bv[b].ord = b; }
+  qsort(bv, Tm->n_blocks, sizeof(so_sb), sb_cmp); /* single.rs:378 */
+  uint16_t* ids = (uint16_t*)malloc(65536 * sizeof(uint16_t));
+  for (uint32_t bi = 0; bi < Tm->n_blocks; bi++) {
+    if (!filtered && bi == top_k) break; /* single.rs:380-382 */
+    const float bs = bv[bi].score;
+    if (T->h.n == top_k && T->h.k && bs <= T->h.e[0].score) { /* single.rs:383-391 */
+      if (!filtered) break;
+      else if (rt == SO_RT_TOPK) continue;
+    }
+    /* single_docid: single.rs:41-50 */
+    if ((rt == SO_RT_COUNT || (T->h.n == top_k && T->h.k && bs <= T->h.e[0].score)) && (!filtered || rt == SO_RT_TOPK)) continue;
+    const so_blk* B = &Tm->blocks[bv[bi].ord];
+    const uint32_t n = decode_block(B, ids);
+    for (uint32_t p = 0; p < n; p++) {
+      const uint32_t docid = (B->block_id << 16) | ids[p];
+      if (gone && gone[docid]) continue; /* add_result.rs:661-663 delete_hashset, 665-727 not_query_list */
+      if (rt == SO_RT_COUNT) { local++; continue; }
+      if (rt == SO_RT_TOPKCOUNT) local++;
+      if (T->h.n >= top_k && bs <= T->h.e[0].score) continue; /* add_result.rs:765-772, 829-836 */
+      const float bm25 = so_bm25_term(idf, B->tf[p], s->comp[s->doclen[docid]]); /* add_result.rs:1090-1096 */
+      ref_add_topk(T, docid, bm25);
+    }
+  }
+  free(ids); free(bv);
+  return filtered ? local : Tm->posting_count; /* single.rs:405-413 */
+}
+
+/* intersection_blockid through the hashset-aware heap: search_and's body with ref_add_topk.  (search_and above keeps the
+ * plain heap for the direct intersection path.) */
+static uint64_t ref_intersection(const so_shard* s, uint32_t nq, const uint32_t* qt, const float* idf, int rt, so_topk_ref* T,
+                                 const uint8_t* gone) {
+  /* the heap is shared: run search_and on a heap view whose add goes through the hashset.  search_and only calls
+   * heap_add_topk / heap_full and reads e[0]; when the hashset is empty both adds are identical (min_heap.rs:1201), so the
+   * plain call is exact then.  With entries present the candidates are collected and re-offered through ref_add_topk. */
+  uint64_t total = 0;
+  if (T->hs.n == 0) { search_and(s, nq, qt, idf, rt, &T->h, &total, gone); return total; }
+  /* general case: replay search_and's loop with the hashset arm */
+  uint32_t ptr[32] = {0};
+  uint32_t nbm = 0, cap = 0;
+  for (uint32_t t = 0; t < nq; t++) if (t == 0 || s->terms[qt[t]].n_blocks < cap) cap = s->terms[qt[t]].n_blocks;
+  so_bm* bms = (so_bm*)malloc((cap ? cap : 1) * sizeof(so_bm));
+  for (;;) {
+    int done = 0; uint32_t mx = 0;
+    for (uint32_t t = 0; t < nq; t++) {
+      const so_term* Tm = &s->terms[qt[t]];
+      if (ptr[t] >= Tm->n_blocks) { done = 1; break; }
+      if (Tm->blocks[ptr[t]].block_id > mx) mx = Tm->blocks[ptr[t]].block_id;
+    }
+    if (done) break;
+    int all = 1;
+    for (uint32_t t = 0; t < nq; t++) {
+      const so_term* Tm = &s->terms[qt[t]];
+      while (ptr[t] < Tm->n_blocks && Tm->blocks[ptr[t]].block_id < mx) ptr[t]++;
+      if (ptr[t] >= Tm->n_blocks) { done = 1; break; }
+      if (Tm->blocks[ptr[t]].block_id != mx) all = 0;
+    }
+    if (done) break;
+    if (!all) continue;
+    so_bm* m = &bms[nbm++];
+    m->block_id = mx; m->score = 0.0f;
+    for (uint32_t t = 0; t < nq; t++) { m->ord[t] = ptr[t]; m->score += idf[t] * s->terms[qt[t]].blocks[ptr[t]].max_part; ptr[t]++; }
+  }
+  if (rt != SO_RT_COUNT) qsort(bms, nbm, sizeof(so_bm), bm_cmp);
+  uint16_t* first = (uint16_t*)malloc(65536 * sizeof(uint16_t));
+  so_heap* heap = &T->h;
+  for (uint32_t bi = 0; bi < nbm; bi++) {
+    so_bm* m = &bms[bi];
+    if (rt == SO_RT_TOPK && heap_full(heap) && heap->k > 0 && m->score <= heap->e[0].score) break;
+    uint32_t order[32];
+    for (uint32_t t = 0; t < nq; t++) order[t] = t;
+    for (uint32_t i = 1; i < nq; i++) {
+      uint32_t x = order[i]; uint32_t j = i;
+      for (; j > 0; j--) {
+        const so_blk* a = &s->terms[qt[order[j - 1]]].blocks[m->ord[order[j - 1]]];
+        const so_blk* b = &s->terms[qt[x]].blocks[m->ord[x]];
+        int abm = a->ctype == SO_CT_BITMAP, bbm = b->ctype == SO_CT_BITMAP;
+        int gt = (abm != bbm) ? (abm > bbm) : (a->count > b->count);
+        if (!gt) break;
+        order[j] = order[j - 1];
+      }
+      order[j] = x;
+    }
+    so_cur cur[32];
+    for (uint32_t i = 0; i < nq; i++) {
+      uint32_t t = order[i];
+      cur[i].b = &s->terms[qt[t]].blocks[m->ord[t]];
+      cur[i].idf = idf[t]; cur[i].pos = 0; cur[i].rle_rank = 0; cur[i].rank = 0;
+    }
+    uint32_t n0 = decode_block(cur[0].b, first);
+    for (uint32_t p0 = 0; p0 < n0; p0++) {
+      uint32_t d = first[p0];
+      int ok = 1;
+      for (uint32_t i = 1; i < nq && ok; i++) ok = cur_find(&cur[i], d);
+      if (!ok) continue;
+      cur[0].rank = p0;
+      uint32_t docid = (m->block_id << 16) | d;
+      if (gone && gone[docid]) continue;
+      if (rt == SO_RT_COUNT) { total++; continue; }
+      if (heap_full(heap) && heap->k > 0 && m->score <= heap->e[0].score) { if (rt == SO_RT_TOPKCOUNT) total++; continue; }
+      float comp = s->comp[s->doclen[docid]];
+      float bm25 = 0.0f;
+      for (uint32_t i = 0; i < nq; i++) bm25 += so_bm25_term(cur[i].idf, cur[i].b->tf[cur[i].rank], comp);
+      total++;
+      ref_add_topk(T, docid, bm25);
+    }
+  }
+  free(first); free(bms);
+  return total;
+}
+
+static float ref_max_list_score(const so_shard* s, uint32_t term, float idf) { /* max_list_score = max block score, index.rs:3239 */
+  float m = 0.0f;
+  for (uint32_t b = 0; b < s->terms[term].n_blocks; b++) { float v = idf * s->terms[term].blocks[b].max_part; if (v > m) m = v; }
+  return m;
+}
+
+/* union_docid_2, union.rs:1168-1305.  Returns result_count. */
+static uint64_t ref_union2(const so_shard* s, const uint32_t* qt, const float* idf, int rt, uint32_t top_k, so_topk_ref* T,
+                           const uint8_t* gone_not, const uint8_t* gone) {
+  /* filtered (union.rs:1184): NOT terms / field filter -- NOT a delete set alone */
+  const int filtered = gone_not != NULL;
+  uint64_t count = 0;
+  if (filtered) {
+    so_topk_ref dummy; memset(&dummy, 0, sizeof dummy);
+    count = ref_single(s, qt[0], idf[0], SO_RT_COUNT, top_k, &dummy, gone, 2) + ref_single(s, qt[1], idf[1], SO_RT_COUNT, top_k, &dummy, gone, 2);
+  }
+  const uint64_t inter = ref_intersection(s, 2, qt, idf, rt, T, gone);
+  uint64_t local = filtered ? count : s->terms[qt[0]].posting_count + s->terms[qt[1]].posting_count;
+  if (local > inter) local -= inter;
+  if (rt == SO_RT_COUNT) return local;
+  for (int i = 0; i < 2; i++)
+    if (T->h.n < top_k || ref_max_list_score(s, qt[i], idf[i]) > T->h.e[0].score) {
+      ref_snapshot(T);
+      ref_single(s, qt[i], idf[i], SO_RT_TOPK, top_k, T, gone, 2);
+    }
+  return local;
+}
+
+typedef struct { uint32_t n, query_index; float max_score; uint32_t term[10]; float idf[10]; } so_qobj;
+/* union_docid_3, union.rs:1308-1479: the queue of sub-queries, best upper bound first; recursion_count < 200 */
+static void ref_union3(const so_shard* s, uint32_t nq, const uint32_t* qt, const float* idf, uint32_t top_k, so_topk_ref* T,
+                       const uint8_t* gone_not, const uint8_t* gone) {
+  uint32_t qcap = 64, qn = 1;
+  so_qobj* queue = (so_qobj*)malloc(qcap * sizeof(so_qobj));
+  queue[0].n = nq; queue[0].query_index = 0; queue[0].max_score = 3.4028235e38f;
+  memcpy(queue[0].term, qt, nq * sizeof(uint32_t)); memcpy(queue[0].idf, idf, nq * sizeof(float));
+  for (uint32_t rec = 0; rec <= 200 && qn; rec++) {
+    so_qobj q = queue[0];
+    memmove(queue, queue + 1, (--qn) * sizeof(so_qobj)); /* query_queue.remove(0) */
+    if (q.n >= 3) {
+      ref_intersection(s, q.n, q.term, q.idf, SO_RT_TOPK, T, gone);
+      ref_snapshot(T);
+      for (uint32_t i = q.query_index; i < q.n; i++) {
+        const uint32_t ii = q.n - 1 - i;
+        so_qobj l; l.n = 0; l.query_index = i; l.max_score = 0.0f;
+        for (uint32_t j = 0; j < q.n; j++) if (j != ii) { l.term[l.n] = q.term[j]; l.idf[l.n] = q.idf[j]; l.n++; }
+        for (uint32_t j = 0; j < l.n; j++) l.max_score += ref_max_list_score(s, l.term[j], l.idf[j]);
+        if (T->h.n < top_k || l.max_score > T->h.e[0].score) {
+          if (qn == qcap) { qcap *= 2; queue = (so_qobj*)realloc(queue, qcap * sizeof(so_qobj)); }
+          uint32_t pos = qn;
+          if (qn && l.max_score > queue[qn - 1].max_score) { /* binary_search_by descending -> insertion point (any among equals) */
+            uint32_t lo = 0, hi = qn;
+            while (lo < hi) { uint32_t mid = (lo + hi) / 2; if (queue[mid].max_score > l.max_score) lo = mid + 1; else hi = mid; }
+            pos = lo;
+          }
+          memmove(queue + pos + 1, queue + pos, (qn - pos) * sizeof(so_qobj));
+          queue[pos] = l; qn++;
+        }
+      }
+    } else {
+      ref_union2(s, q.term, q.idf, SO_RT_TOPK, top_k, T, gone_not, gone);
+    }
+    if (!(qn && (T->h.n < top_k || queue[0].max_score > T->h.e[0].score))) break;
+    ref_snapshot(T);
+  }
+  free(queue);
+}
+
+/* search_lexical_shard's dispatch as the reference structures it (one indexed field, no field / facet filters, no sort).
+ * Same signature as so_search_lex_not.  Known reference quirk kept: a 2-term union's count under a delete set WITHOUT NOT
+ * terms is posting_count sums minus the intersection count (union.rs:1240-1249) and so still counts deleted docs. */
+uint32_t so_search_lex_ref(const so_shard* s, uint32_t nq, const uint32_t* qt, uint32_t n_not, const uint32_t* not_terms,
+                           int op, uint32_t k, int rt, uint32_t* od, float* os, uint64_t* total) {
+  uint64_t tot = 0;
+  if (nq == 0 || nq > 32) { if (total) *total = 0; return 0; }
+  float idf[32];
+  for (uint32_t t = 0; t < nq; t++) {
+    if (qt[t] >= s->n_terms) { if (total) *total = 0; return 0; }
+    idf[t] = so_idf(s->n_docs, s->terms[qt[t]].posting_count);
+  }
+  uint32_t kk = k; if ((uint64_t)kk > s->n_docs) kk = (uint32_t)s->n_docs;
+  if (rt == SO_RT_COUNT) kk = 0;
+  so_topk_ref T;
+  T.h.n = 0; T.h.k = kk; T.h.e = (so_res*)malloc((kk ? kk : 1) * sizeof(so_res));
+  hset_init(&T.hs, 256);
+  uint8_t* gone = exclusion_map(s, n_not, not_terms);
+  const uint8_t* gone_not = n_not ? gone : NULL;
+  if (nq == 1) tot = ref_single(s, qt[0], idf[0], rt, kk, &T, gone, 1);
+  else if (op == SO_OP_AND) search_and(s, nq, qt, idf, rt, &T.h, &tot, gone);
+  else if (rt == SO_RT_COUNT && nq != 2) search_or(s, nq, qt, idf, rt, &T.h, &tot, gone);
+  else if (nq == 2) tot = ref_union2(s, qt, idf, rt, kk, &T, gone_not, gone);
+  else if (nq <= 10) {
+    ref_union3(s, nq, qt, idf, kk, &T, gone_not, gone);
+    if (rt == SO_RT_TOPKCOUNT) { /* union.rs:1455-1477: union_blockid with ResultType::Count */
+      so_heap none; none.n = 0; none.k = 0; none.e = NULL;
+      search_or(s, nq, qt, idf, SO_RT_COUNT, &none, &tot, gone);
+    }
+  } else search_or(s, nq, qt, idf, rt, &T.h, &tot, gone);
+  uint32_t n = heap_drain(&T.h, od, os);
+  free(gone); free(T.h.e); hset_free(&T.hs);
+  if (total) *total = tot;
+  return n;
+}
+
+/* ================================================================== CPU baseline harness (bench.py cpu_baseline leg)
+ * The reference's execution structure for one query over an index of S document-partitioned shards: one task per shard
+ * (search.rs:1637-1743), each single-threaded inside its shard, then gather + sort + truncate (search.rs:1875-1940,
+ * 2098-2119), global id = local * S + shard (search.rs:1671).
+ *   mode 0 (throughput): `threads` workers, each answers whole queries (its S shard tasks one after the other, then the
+ *                        merge) -- every core busy with independent queries;
+ *   mode 1 (latency):    one query at a time, its S shard tasks on S worker threads, merge on the caller -> per-query
+ *                        wall time (p50 / p99 come from out_lat_us).
+ * Queries: q_terms [nq][nt] term ids valid in every shard.  Runs for about `seconds`, cycling through the queries. */
+#include <pthread.h>
+#include <stdatomic.h>
+#include <time.h>
+#include <sched.h>
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+typedef struct { uint64_t doc; float score; } so_gres;
+static int gres_cmp(const void* a, const void* b) {
+  const so_gres* x = (const so_gres*)a; const so_gres* y = (const so_gres*)b;
+  if (x->score > y->score) return -1;
+  if (x->score < y->score) return 1;
+  return 0;
+}
+typedef struct {
+  so_shard* const* shards; uint32_t S; const uint32_t* q; uint32_t nq, nt; int op; uint32_t k; int rt; double t_end;
+  atomic_uint_fast64_t next, done;
+  /* latency mode */
+  atomic_uint_fast64_t gen; atomic_uint_fast32_t pending; atomic_int stop; uint32_t cur_q;
+  uint32_t* r_doc; float* r_score; uint32_t* r_n; /* [S][k] per-shard results */
+  uint64_t checksum;
+} so_bctx;
+typedef struct { so_bctx* c; uint32_t id; } so_barg;
+static void shard_task(so_bctx* c, uint32_t sh, uint32_t qi, uint32_t* od, float* os, uint32_t* n) {
+  uint64_t tot;
+  *n = so_search_lex_ref(c->shards[sh], c->nt, c->q + (size_t)qi * c->nt, 0, NULL, c->op, c->k, c->rt, od, os, &tot);
+}
+static uint64_t merge_shards(so_bctx* c, const uint32_t* r_doc, const float* r_score, const uint32_t* r_n, so_gres* tmp) {
+  uint32_t m = 0;
+  for (uint32_t sh = 0; sh < c->S; sh++)
+    for (uint32_t i = 0; i < r_n[sh]; i++) { tmp[m].doc = (uint64_t)r_doc[(size_t)sh * c->k + i] * c->S + sh; tmp[m].score = r_score[(size_t)sh * c->k + i]; m++; }
+  qsort(tmp, m, sizeof(so_gres), gres_cmp);
+  return m ? tmp[0].doc : 0;
+}
+static void* thr_throughput(void* a_) {
+  so_barg* a = (so_barg*)a_; so_bctx* c = a->c;
+  uint32_t* od = (uint32_t*)malloc((size_t)c->S * c->k * sizeof(uint32_t));
+  float* os = (float*)malloc((size_t)c->S * c->k * sizeof(float));
+  uint32_t* n = (uint32_t*)malloc(c->S * sizeof(uint32_t));
+  so_gres* tmp = (so_gres*)malloc((size_t)c->S * c->k * sizeof(so_gres));
+  uint64_t chk = 0;
+  while (now_s() < c->t_end) {
+    const uint64_t i = atomic_fetch_add(&c->next, 1);
+    const uint32_t qi = (uint32_t)(i % c->nq);
+    for (uint32_t sh = 0; sh < c->S; sh++) shard_task(c, sh, qi, od + (size_t)sh * c->k, os + (size_t)sh * c->k, n + sh);
+    chk += merge_shards(c, od, os, n, tmp);
+    atomic_fetch_add(&c->done, 1);
+  }
+  __atomic_fetch_add(&c->checksum, chk, __ATOMIC_RELAXED);
+  free(od); free(os); free(n); free(tmp);
+  return NULL;
+}
+static void* thr_latency(void* a_) {
+  so_barg* a = (so_barg*)a_; so_bctx* c = a->c;
+  uint64_t seen = 0;
+  for (;;) {
+    uint64_t g;
+    uint32_t spins = 0;
+    while ((g = atomic_load_explicit(&c->gen, memory_order_acquire)) == seen) {
+      if (atomic_load_explicit(&c->stop, memory_order_relaxed)) return NULL;
+      if (++spins > 2000) { sched_yield(); spins = 0; }
+    }
+    seen = g;
+    shard_task(c, a->id, c->cur_q, c->r_doc + (size_t)a->id * c->k, c->r_score + (size_t)a->id * c->k, c->r_n + a->id);
+    atomic_fetch_sub_explicit(&c->pending, 1, memory_order_release);
+  }
+}
+/* returns queries per second; *out_queries = queries answered; latency mode fills out_lat_us[0 .. *out_nlat) */
+double so_bench_lex(so_shard* const* shards, uint32_t S, const uint32_t* q_terms, uint32_t nq, uint32_t nt, int op, uint32_t k,
+                    int rt, int mode, uint32_t threads, double seconds, uint64_t* out_queries, double* out_lat_us,
+                    uint32_t lat_cap, uint32_t* out_nlat) {
+  so_bctx c; memset(&c, 0, sizeof c);
+  c.shards = shards; c.S = S; c.q = q_terms; c.nq = nq; c.nt = nt; c.op = op; c.k = k; c.rt = rt;
+  atomic_init(&c.next, 0); atomic_init(&c.done, 0); atomic_init(&c.gen, 0); atomic_init(&c.pending, 0); atomic_init(&c.stop, 0);
+  const uint32_t nthr = mode == 0 ? threads : S;
+  pthread_t* th = (pthread_t*)malloc(nthr * sizeof(pthread_t));
+  so_barg* args = (so_barg*)malloc(nthr * sizeof(so_barg));
+  double t0 = now_s(), el;
+  uint32_t nlat = 0;
+  if (mode == 0) {
+    c.t_end = t0 + seconds;
+    for (uint32_t i = 0; i < nthr; i++) { args[i].c = &c; args[i].id = i; pthread_create(&th[i], NULL, thr_throughput, &args[i]); }
+    for (uint32_t i = 0; i < nthr; i++) pthread_join(th[i], NULL);
+    el = now_s() - t0;
+  } else {
+    c.r_doc = (uint32_t*)malloc((size_t)S * k * sizeof(uint32_t)); c.r_score = (float*)malloc((size_t)S * k * sizeof(float));
+    c.r_n = (uint32_t*)calloc(S, sizeof(uint32_t));
+    so_gres* tmp = (so_gres*)malloc((size_t)S * k * sizeof(so_gres));
+    for (uint32_t i = 0; i < nthr; i++) { args[i].c = &c; args[i].id = i; pthread_create(&th[i], NULL, thr_latency, &args[i]); }
+    uint64_t qn = 0;
+    t0 = now_s();
+    while (now_s() - t0 < seconds) {
+      const double a = now_s();
+      c.cur_q = (uint32_t)(qn % nq);
+      atomic_store_explicit(&c.pending, S, memory_order_relaxed);
+      atomic_fetch_add_explicit(&c.gen, 1, memory_order_release);
+      uint32_t spins = 0;
+      while (atomic_load_explicit(&c.pending, memory_order_acquire)) if (++spins > 2000) { sched_yield(); spins = 0; }
+      c.checksum += merge_shards(&c, c.r_doc, c.r_score, c.r_n, tmp);
+      const double b = now_s();
+      if (out_lat_us && nlat < lat_cap) out_lat_us[nlat++] = (b - a) * 1e6;
+      qn++;
+    }
+    el = now_s() - t0;
+    atomic_store(&c.stop, 1);
+    for (uint32_t i = 0; i < nthr; i++) pthread_join(th[i], NULL);
+    atomic_store(&c.done, qn);
+    free(c.r_doc); free(c.r_score); free(c.r_n); free(tmp);
+  }
+  free(th); free(args);
+  const uint64_t done = atomic_load(&c.done);
+  if (out_queries) *out_queries = done;
+  if (out_nlat) *out_nlat = nlat;
+  return el > 0 ? (double)done / el : 0.0;
 }

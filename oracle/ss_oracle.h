@@ -83,6 +83,19 @@ uint32_t so_search_lex(const so_shard*, uint32_t n_q_terms, const uint32_t* q_te
 uint32_t so_search_lex_not(const so_shard*, uint32_t n_q_terms, const uint32_t* q_terms, uint32_t n_not,
                            const uint32_t* not_terms, int op, uint32_t k, int result_type, uint32_t* out_doc,
                            float* out_score, uint64_t* out_total);
+/* the same dispatch as the reference structures it: single_blockid (single.rs:292-417), union_docid_2 / union_docid_3 with
+ * their sub-query queue and MinHeap::add_topk's docid_hashset arm (union.rs:1168-1479, min_heap.rs:1193-1260),
+ * intersection_blockid, union_blockid for counts.  Must return what so_search_lex_not returns (tests assert it); it is the
+ * function the CPU baseline times. */
+uint32_t so_search_lex_ref(const so_shard*, uint32_t n_q_terms, const uint32_t* q_terms, uint32_t n_not,
+                           const uint32_t* not_terms, int op, uint32_t k, int result_type, uint32_t* out_doc,
+                           float* out_score, uint64_t* out_total);
+/* CPU baseline harness: S document-partitioned shards, one task per shard and query (search.rs:1637-1743), gather + sort
+ * (1875-1940, 2098-2119).  mode 0 = throughput (`threads` workers, independent queries), mode 1 = latency (one query at a
+ * time over S worker threads).  Returns queries/s. */
+double so_bench_lex(so_shard* const* shards, uint32_t S, const uint32_t* q_terms, uint32_t nq, uint32_t nt, int op, uint32_t k,
+                    int rt, int mode, uint32_t threads, double seconds, uint64_t* out_queries, double* out_lat_us,
+                    uint32_t lat_cap, uint32_t* out_nlat);
 uint32_t so_search_lex_exhaustive_not(const so_shard*, uint32_t n_q_terms, const uint32_t* q_terms, uint32_t n_not,
                                       const uint32_t* not_terms, int op, uint32_t k, uint32_t* out_doc, float* out_score,
                                       uint64_t* out_total);

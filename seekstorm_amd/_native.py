@@ -79,6 +79,7 @@ SYMBOLS = [
     ("ss_bm25_upload_index_bin", C.c_int, [C.c_void_p, C.c_void_p]),
     ("ss_bm25_upload_index_bin_fields", C.c_int, [C.c_void_p, C.c_void_p, f32p]),
     ("ss_ref_decode_block_fields", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, u16p, u32p, u8p, u16p]),
+    ("ss_synth_set_partition", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     ("ss_bm25_synth", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, u32p, u8p]),
     ("ss_bm25_info", C.c_int, [C.c_void_p, u64p, f32p, u32p, u64p]),
     ("ss_bm25_term_df", C.c_int, [C.c_void_p, C.c_uint32, u32p, u64p]),
@@ -126,6 +127,13 @@ SYMBOLS = [
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("ss_topk_merge_dev_packed", C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p]),
+    ("ss_comm_unique_id", C.c_int, [C.c_void_p]),
+    ("ss_comm_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    ("ss_comm_create_all", C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
+    ("ss_comm_destroy", C.c_int, [C.c_void_p]),
+    ("ss_comm_info", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("ss_topk_allgather_merge", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     ("ss_rrf_merge_dev", C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int,
                                    C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("ss_profile_enable", C.c_int, [C.c_void_p, C.c_int]),

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(OUT_DIR, "libseekstorm_hip.so")
-SOURCES = ["ss_api.hip", "vec_scan.hip", "bm25.hip", "synth.hip", "merge.hip", "bm25_fast.hip", "bm25_probe.hip", "ref_format.hip", "vec8_scan.hip", "vec_ann.hip", "facet.hip"]
+SOURCES = ["ss_api.hip", "vec_scan.hip", "bm25.hip", "synth.hip", "merge.hip", "bm25_fast.hip", "bm25_probe.hip", "ref_format.hip", "vec8_scan.hip", "vec_ann.hip", "facet.hip", "comm.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
 
@@ -45,7 +45,7 @@ def build(force=False, verbose=False):
             if verbose and err:
                 print(err)
     if jobs or not os.path.exists(LIB):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs + ["-Wl,-rpath,/opt/rocm/lib"])
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])
     build_host(force or bool(jobs), verbose)
     return LIB
 

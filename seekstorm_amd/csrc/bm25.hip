@@ -11,13 +11,15 @@
 // in: [nq][n_lists][KS] sorted-desc lists; each workgroup merges `group` consecutive lists of one query into one
 // sorted-desc list of KS keys: out [nq][ceil(n_lists/group)][KS].  Only the first `take` keys of a list can reach the
 // final top-k (take >= k): the rest is not even read.
-// fin_*: non-null in the LAST pass (one group left): the merged list goes straight to the caller's outputs
-// (what bm25_final_kernel does when there was nothing to merge).
+// is_last: the LAST pass (one group left): the merged list goes straight to the caller's outputs fin_* (what
+// bm25_final_kernel does when there was nothing to merge); fin_doc / fin_score may be null when k == 0 (Count).
+// A query that contradicted the caller's ops_mask (bm_expand_kernel) reports count = UINT32_MAX.
 __global__ void __launch_bounds__(1024) bm25_merge_kernel(const u64* __restrict__ in, u64* __restrict__ out,
                                                          uint32_t n_lists, uint32_t group, uint32_t KS, uint32_t take,
-                                                         const u64* __restrict__ fin_total, uint32_t k,
+                                                         const u64* __restrict__ fin_total, uint32_t k, uint32_t is_last,
                                                          uint32_t* __restrict__ fin_doc, float* __restrict__ fin_score,
-                                                         uint32_t* __restrict__ fin_count, u64* __restrict__ fin_out_total) {
+                                                         uint32_t* __restrict__ fin_count, u64* __restrict__ fin_out_total,
+                                                         const uint32_t* __restrict__ tau) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   u64* keys = (u64*)smem;
   const uint32_t q = blockIdx.y, g = blockIdx.x;
@@ -42,7 +44,7 @@ __global__ void __launch_bounds__(1024) bm25_merge_kernel(const u64* __restrict_
       __syncthreads();
     }
   }
-  if (fin_doc) {  // n_groups == 1
+  if (is_last) {  // n_groups == 1
     __shared__ uint32_t cnt;
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
@@ -62,7 +64,7 @@ __global__ void __launch_bounds__(1024) bm25_merge_kernel(const u64* __restrict_
     if (local) atomicAdd(&cnt, local);
     __syncthreads();
     if (threadIdx.x == 0) {
-      fin_count[q] = cnt;
+      fin_count[q] = tau[(size_t)q * BM_TAU_STRIDE + 1] ? 0xFFFFFFFFu : cnt;
       fin_out_total[q] = fin_total[q];
     }
     return;
@@ -73,7 +75,7 @@ __global__ void __launch_bounds__(1024) bm25_merge_kernel(const u64* __restrict_
 
 __global__ void bm25_final_kernel(const u64* __restrict__ keys, const u64* __restrict__ total, uint32_t KS, uint32_t k,
                                   uint32_t* __restrict__ out_doc, float* __restrict__ out_score,
-                                  uint32_t* __restrict__ out_count, u64* __restrict__ out_total) {
+                                  uint32_t* __restrict__ out_count, u64* __restrict__ out_total, const uint32_t* __restrict__ tau) {
   const uint32_t q = blockIdx.x;
   __shared__ uint32_t cnt;
   if (threadIdx.x == 0) cnt = 0;
@@ -94,15 +96,22 @@ __global__ void bm25_final_kernel(const u64* __restrict__ keys, const u64* __res
   if (local) atomicAdd(&cnt, local);
   __syncthreads();
   if (threadIdx.x == 0) {
-    out_count[q] = cnt;
+    out_count[q] = tau[(size_t)q * BM_TAU_STRIDE + 1] ? 0xFFFFFFFFu : cnt;
     out_total[q] = total[q];
   }
 }
 
 // ---------------------------------------------------------------- public queries -> virtual terms (one thread per query)
+// `claim` = what the caller of ss_bm25_search_dev asserted about the batch in ops_mask, i.e. what the host chose the kernel
+// variants by (BM_CLAIM_*).  A device-resident query cannot be inspected on the host, so the assertion is checked HERE: a
+// query that contradicts it (an intersection in a batch declared union-only would run a variant without match counters,
+// more terms than declared would overrun the NT-specialised kernel, ...) or that is malformed (term id out of range, no
+// terms) is replaced by an empty query and reports d_out_count = UINT32_MAX instead of a silently wrong answer.
+constexpr uint32_t BM_CLAIM_AND = 1u, BM_CLAIM_OR = 2u, BM_CLAIM_PROBED = 4u, BM_CLAIM_FREQ = 8u;
 __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery* __restrict__ vq, uint32_t nq, uint32_t n_fields,
                                  const unsigned long long* __restrict__ term_base, const float* __restrict__ boost,
-                                 unsigned long long* __restrict__ total, uint32_t* __restrict__ tau) {
+                                 unsigned long long* __restrict__ total, uint32_t* __restrict__ tau, uint32_t claim,
+                                 uint32_t n_vterms, const uint32_t* __restrict__ probe_row) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq) return;
   total[i] = 0ull;                      // per-query match count and shared threshold start from zero (no separate memset launch)
@@ -110,6 +119,32 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
   const ss_bm25_query Q = q[i];
   bm_vquery V;
   const uint32_t np = Q.n_terms, n_not = bm_q_nnot(Q.op);
+  {
+    const uint32_t nt_claim = (claim >> 8) & 0xFFu, np_claim = (claim >> 16) & 0xFFu, ff = n_fields > 1 ? bm_q_field_filter(Q.op) : 0u;
+    bool bad = np == 0 || np + n_not > (uint32_t)SS_MAX_QUERY_TERMS || (np + n_not) * n_fields > (uint32_t)BM_MAX_VTERMS;
+    bad |= np + n_not > nt_claim || np > np_claim;
+    const bool q_and = (bm_q_op(Q.op) == SS_OP_INTERSECTION && np > 1) || ff != 0u;
+    bad |= q_and && !(claim & BM_CLAIM_AND);
+    bad |= !q_and && np > 1 && !(claim & BM_CLAIM_OR);
+    bad |= bm_q_op(Q.op) > (uint32_t)SS_OP_UNION;
+    bad |= bm_q_all_frequent(Q.op) && bm_q_op(Q.op) == SS_OP_INTERSECTION && np > 1 && !(claim & BM_CLAIM_FREQ);
+    if (!bad)
+      for (uint32_t t = 0; t < np + n_not; t++) {
+        bad |= Q.term[t] >= n_vterms / n_fields;
+        if (!bad && (claim & BM_CLAIM_PROBED) && probe_row)
+          for (uint32_t f = 0; f < n_fields; f++) {
+            const uint32_t v = Q.term[t] * n_fields + f;
+            bad |= probe_row[v] == BM_NO_PROBE_ROW && term_base[v + 1] != term_base[v];
+          }
+      }
+    tau[(size_t)i * BM_TAU_STRIDE + 1] = bad ? 1u : 0u;
+    if (bad) {  // the empty query: one absent term (the all-zero directory row n_vterms, idf 0)
+      V.n_terms = 1; V.op = SS_OP_UNION; V.n_groups = 1; V.and_target = 0;
+      for (uint32_t j = 0; j < (uint32_t)BM_MAX_VTERMS; j++) { V.term[j] = j ? 0 : n_vterms; V.idf[j] = 0.f; V.and_val[j] = 0; V.group[j] = j ? 0xFF : 0; }
+      vq[i] = V;
+      return;
+    }
+  }
   // field_filter (several indexed fields): every term must occur in a listed field (add_result.rs:3124-3136) -- an
   // intersection whose match bits only the listed fields' lists may set; a single filtered term is an intersection of one
   const uint32_t filt = n_fields > 1 ? bm_q_field_filter(Q.op) : 0u;
@@ -155,7 +190,8 @@ int ssi_bm25_match_bits(ss_shard* s, const ss_bm25_query* d_q, unsigned long lon
   }
   uint32_t* tau = (uint32_t*)(d_bits);  // the expansion zeroes one threshold line per query: scratch, overwritten below
   bm_expand_kernel<<<1, 128, 0, st>>>(d_q, (bm_vquery*)s->d_vq, 1, s->bm_n_fields, (const unsigned long long*)s->d_term_base,
-                                      s->d_boost, d_total, tau);
+                                      s->d_boost, d_total, tau, BM_CLAIM_AND | BM_CLAIM_OR | BM_CLAIM_FREQ | (0xFFu << 8) | (0xFFu << 16),
+                                      s->bm_n_terms, nullptr);  // the host entry point validated the query
   BmParams p{};
   p.q = (const bm_vquery*)s->d_vq;
   p.total = d_total;
@@ -227,8 +263,12 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
     SS_HIP(hipMalloc(&s->d_vq, (size_t)nq * sizeof(bm_vquery)));
     s->vq_cap = (size_t)nq * sizeof(bm_vquery);
   }
+  // nt_max / np_max count (term, field) lists here; the claim is in public terms
+  const uint32_t claim = (has_and ? BM_CLAIM_AND : 0u) | ((has_or || F > 1) ? BM_CLAIM_OR : 0u) | (all_probed ? BM_CLAIM_PROBED : 0u) |
+                         (any_frequent ? BM_CLAIM_FREQ : 0u) | (std::min(nt_max / F, 255u) << 8) | (std::min(np_max / F, 255u) << 16);
   bm_expand_kernel<<<(nq + 127) / 128, 128, 0, st>>>(d_q, (bm_vquery*)s->d_vq, nq, s->bm_n_fields,
-                                                    (const unsigned long long*)s->d_term_base, s->d_boost, total, tau);
+                                                    (const unsigned long long*)s->d_term_base, s->d_boost, total, tau, claim,
+                                                    s->bm_n_terms, s->d_probe_row);
 
   BmParams p;
   p.post = s->d_post;
@@ -282,7 +322,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
     while (np < std::min(lists, group) * take) np <<= 1;
     const bool last = ng == 1;
     bm25_merge_kernel<<<dim3(ng, nq), std::min<uint32_t>(1024u, std::max<uint32_t>(64u, np / 2)), 8192 * 8, st>>>(
-        src, dst, lists, group, KS, take, total, k, last ? d_out_doc : nullptr, d_out_score, d_out_count, (u64*)d_out_total);
+        src, dst, lists, group, KS, take, total, k, last ? 1u : 0u, d_out_doc, d_out_score, d_out_count, (u64*)d_out_total, tau);
     std::swap(src, dst);
     lists = ng;
     if (last) {
@@ -291,7 +331,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
     }
   }
   bm25_final_kernel<<<nq, 64, 0, st>>>(src, total, KS, k, d_out_doc, d_out_score, d_out_count,
-                                       (u64*)d_out_total);  // P == 1: nothing to merge
+                                       (u64*)d_out_total, tau);  // P == 1: nothing to merge
   SS_HIP(hipGetLastError());
   return SS_OK;
 }

@@ -226,6 +226,14 @@ int ssi_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, cons
 
 extern "C" {
 
+int ss_synth_set_partition(ss_shard* s, uint32_t shard_id, uint32_t n_shards) {
+  if (!s || n_shards == 0 || shard_id >= n_shards) return SS_EINVAL;
+  std::lock_guard<std::mutex> g(s->mu);
+  s->synth_stride = n_shards;
+  s->synth_offset = shard_id;
+  return SS_OK;
+}
+
 int ss_bm25_synth(ss_shard* s, uint64_t seed, uint64_t n_docs, uint32_t n_terms, const uint32_t* thresh32,
                   const uint8_t* len_table1024) {
   if (!s || !thresh32 || !len_table1024 || n_docs == 0 || n_terms == 0) return SS_EINVAL;
@@ -415,8 +423,8 @@ int ss_bm25_search_filtered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, ui
   bool has_and = false, has_or = false;
   uint32_t nt_max = 0, np_max = 0;
   bool all_probed = false, any_frequent = false;
+  std::lock_guard<std::mutex> g(s->mu);  // before check_queries: it reads the image's host-side tables (an upload replaces them)
   SS_TRY(check_queries(s, nq, q, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent));
-  std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   const uint32_t kk = rt == SS_RT_COUNT ? 0 : k;
   SS_TRY(ensure_out(s, nq, std::max<uint32_t>(kk, 1)));
@@ -452,9 +460,9 @@ int ss_bm25_facet_count(ss_shard* s, const ss_bm25_query* query, uint32_t n_filt
   if (!s->d_post) return SS_ESTATE;
   bool has_and, has_or, all_probed, any_frequent;
   uint32_t nt_max, np_max;
+  std::lock_guard<std::mutex> g(s->mu);
   SS_TRY(check_queries(s, 1, query, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent));
   if (!all_probed || !s->d_probe) return SS_ENOTSUP;  // the match set comes from the probe index's bit records
-  std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 2, 4};
   if (!s->d_facets || s->facet_docs < s->bm_n_docs || facet_offset + width[facet_type] > s->facet_record_size) return SS_ESTATE;
@@ -620,7 +628,7 @@ static int vec_bin_upload(ss_shard* s, const uint8_t* bytes, uint64_t len, uint3
   int rc = i8 ? vec8_alloc(s, n_rows, dim) : vec_alloc(s, n_rows, dim);
   if (rc) { free_vec(s); return rc; }
   int8_t* stage = nullptr;  // i8: row-major staging on the device, permuted into fragment order afterwards
-  if (i8) SS_HIP(hipMalloc(&stage, (size_t)n_rows * dim));
+  if (i8 && hipMalloc(&stage, (size_t)n_rows * dim) != hipSuccess) { free_vec(s); return SS_ENOMEM; }
   uint64_t row = 0;
   for (const Lvl& l : levels) {
     if (l.n == 0) continue;

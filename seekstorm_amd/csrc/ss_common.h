@@ -72,6 +72,7 @@ struct ss_shard {
   int device = 0;
   hipStream_t stream = nullptr;
   std::mutex mu;
+  uint64_t synth_stride = 1, synth_offset = 0;  // ss_synth_set_partition: which slice of the generator stream ss_*_synth build
   // ---- vector image
   float* d_X = nullptr;          // [n_rows_pad][dim_pad]   (f32 image)
   int8_t* d_X8 = nullptr;        // i8 image (quantised embeddings) in MFMA fragment order, vec8_scan.hip v8_index; one of the two is set

@@ -22,10 +22,13 @@ __host__ __device__ inline u64 ss_h(u64 seed, u64 a, u64 b) {
 // ---------------------------------------------------------------- vectors
 // one thread per row: uniform(-1,1) from the hash, then normalize_f32 semantics (vector_similarity.rs:70-74):
 // sequential sum of squares (unfused), factor = 1/sqrt(sum), multiply.
-__global__ void vec_synth_kernel(float* __restrict__ X, u64 seed, u64 n_rows, uint32_t dim, uint32_t dim_pad) {
+// gs / go: the shard holds rows go, go + gs, go + 2 gs, ... of ONE generator stream (doc g -> shard g % S, local id g / S,
+// index.rs:5284): local row r is global row r * gs + go (ss_synth_set_partition; 1 / 0 = the whole stream)
+__global__ void vec_synth_kernel(float* __restrict__ X, u64 seed, u64 n_rows, uint32_t dim, uint32_t dim_pad, u64 gs, u64 go) {
   u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_rows) return;
   float* row = X + r * dim_pad;
+  r = r * gs + go;
   float s = 0.f;
   for (uint32_t c = 0; c < dim; c++) {
     int iv = (int)(uint32_t)(ss_h(seed, r, c) >> 32);
@@ -42,7 +45,7 @@ __global__ void vec_synth_kernel(float* __restrict__ X, u64 seed, u64 n_rows, ui
 int ssi_vec_synth(ss_shard* s, uint64_t seed, hipStream_t st) {
   u64 n = s->n_rows;
   uint32_t grid = (uint32_t)((n + 255) / 256);
-  vec_synth_kernel<<<grid, 256, 0, st>>>(s->d_X, seed, n, s->dim, s->dim_pad);
+  vec_synth_kernel<<<grid, 256, 0, st>>>(s->d_X, seed, n, s->dim, s->dim_pad, s->synth_stride, s->synth_offset);
   SS_HIP(hipGetLastError());
   return SS_OK;
 }
@@ -240,11 +243,11 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
 
 // ---------------------------------------------------------------- BM25 synthetic image, generated on device
 __global__ void lex_doclen_kernel(uint8_t* __restrict__ doclen, u64 seed, u64 n_docs, const uint8_t* __restrict__ tab,
-                                  u64* __restrict__ psum) {
+                                  u64* __restrict__ psum, u64 gs, u64 go) {
   u64 d = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   u64 v = 0;
   if (d < n_docs) {
-    uint8_t b = tab[ss_h(seed, 0, d) >> 54];
+    uint8_t b = tab[ss_h(seed, 0, d * gs + go) >> 54];
     doclen[d] = b;
     v = ss_byte4_to_int(b);
   }
@@ -259,7 +262,7 @@ __global__ void lex_gen_kernel(u64 seed, u64 n_docs, uint32_t n_terms, uint32_t 
                                const uint8_t* __restrict__ doclen, uint32_t* __restrict__ sub /*[nt][ns+1]*/,
                                const u64* __restrict__ term_base, uint32_t* __restrict__ post, u64* __restrict__ df,
                                uint2* __restrict__ probe, uint32_t* __restrict__ probe_z, const uint32_t* __restrict__ probe_row,
-                               uint32_t* __restrict__ umax_bits, const float* __restrict__ comp) {
+                               uint32_t* __restrict__ umax_bits, const float* __restrict__ comp, u64 gs, u64 go) {
   const int lane = threadIdx.x & 63;
   const u64 gw = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const u64 total = (u64)n_terms * n_sub;
@@ -273,7 +276,7 @@ __global__ void lex_gen_kernel(u64 seed, u64 n_docs, uint32_t n_terms, uint32_t 
   if (FILL) base = (term_base[t] + sub[(size_t)t * (n_sub + 1) + sb]) * 4;
   for (int i = 0; i < BM_SUB / 64; i++) {
     u64 d = d0 + (u64)i * 64 + lane;
-    u64 hv = ss_h(seed, (u64)t + 1, d);
+    u64 hv = ss_h(seed, (u64)t + 1, d * gs + go);
     bool present = d < n_docs && (uint32_t)(hv >> 32) < th;
     u64 m = __ballot(present);
     if (FILL && present) {
@@ -350,7 +353,7 @@ int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const u
   SS_HIP(hipMalloc(&d_df, (size_t)nt * sizeof(u64)));
   SS_HIP(hipMemsetAsync(d_psum, 0, sizeof(u64), st));
   SS_HIP(hipMemsetAsync(d_df, 0, (size_t)nt * sizeof(u64), st));
-  lex_doclen_kernel<<<(uint32_t)((nd + 255) / 256), 256, 0, st>>>(d_doclen, seed, nd, d_lentab, d_psum);
+  lex_doclen_kernel<<<(uint32_t)((nd + 255) / 256), 256, 0, st>>>(d_doclen, seed, nd, d_lentab, d_psum, s->synth_stride, s->synth_offset);
   const size_t rows = (size_t)nt * (ns + 1);
   SS_HIP(hipMalloc(&s->d_sub_off, (rows + ns + 1) * sizeof(uint32_t)));  // + one all-zero row (absent terms)
   SS_HIP(hipMemsetAsync(s->d_sub_off + rows, 0, ((size_t)ns + 1) * sizeof(uint32_t), st));
@@ -359,7 +362,7 @@ int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const u
   const u64 waves = (u64)nt * ns;
   const uint32_t grid = (uint32_t)((waves + 3) / 4);
   lex_gen_kernel<false><<<grid, 256, 0, st>>>(seed, nd, nt, ns, d_thresh, d_doclen, s->d_sub_off, nullptr, nullptr, d_df,
-                                              nullptr, nullptr, nullptr, nullptr, nullptr);
+                                              nullptr, nullptr, nullptr, nullptr, nullptr, s->synth_stride, s->synth_offset);
   lex_scan_rows_kernel<<<nt, 1024, 0, st>>>(s->d_sub_off, ns, d_tot);
   lex_scan_terms_kernel<<<1, 64, 0, st>>>(d_tot, (u64*)s->d_term_base, nt);
   SS_HIP(hipStreamSynchronize(st));
@@ -387,7 +390,7 @@ int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const u
   if (rc) return rc;
   lex_gen_kernel<true><<<grid, 256, 0, st>>>(seed, nd, nt, ns, d_thresh, d_doclen, s->d_sub_off,
                                              (const u64*)s->d_term_base, s->d_post, nullptr, s->d_probe, s->d_probe_z, s->d_probe_row,
-                                             (uint32_t*)s->d_umax, s->d_comp);
+                                             (uint32_t*)s->d_umax, s->d_comp, s->synth_stride, s->synth_offset);
   SS_HIP(hipStreamSynchronize(st));
   (void)hipFree(d_doclen);
   (void)hipFree(d_psum);

@@ -116,3 +116,41 @@ def merge_gathered_device(g_doc, g_score, g_cnt, stream_ptr, device_index):
     N.check(N.lib().ss_topk_merge_dev(device_index, nq, S, k, g_doc.data_ptr(), g_score.data_ptr(), g_cnt.data_ptr(),
                                       m_doc.data_ptr(), m_score.data_ptr(), m_cnt.data_ptr(), stream_ptr), "ss_topk_merge_dev")
     return m_doc, m_score, m_cnt
+
+
+class ShardComm:
+    """One rank of the RCCL communicator behind the C ABI (ss_comm_create): the per-shard top-k exchange without
+    torch.distributed on the data path.  The 128-byte unique id is handed from rank 0 to the others through
+    torch.distributed's store-backed broadcast_object_list (control plane only; any channel would do)."""
+
+    def __init__(self, rank, world, device_index):
+        import ctypes as C
+        self.rank, self.world, self.device = int(rank), int(world), int(device_index)
+        ident = [None]
+        if self.rank == 0:
+            buf = (C.c_uint8 * 128)()
+            N.check(N.lib().ss_comm_unique_id(buf), "ss_comm_unique_id")
+            ident[0] = bytes(buf)
+        if self.world > 1:
+            dist.broadcast_object_list(ident, src=0)
+        self._id = (C.c_uint8 * 128).from_buffer_copy(ident[0])
+        h = C.c_void_p()
+        N.check(N.lib().ss_comm_create(self.device, self.rank, self.world, self._id, C.byref(h)), "ss_comm_create")
+        self._h = h
+
+    def allgather_merge(self, doc, score, count, k, stream_ptr):
+        """doc / score [nq, k], count [nq] of this rank's shard (device tensors) -> merged (global ids int64 [nq, k], scores,
+        counts) on every rank: ss_topk_allgather_merge (pack, ONE ncclAllGather, ss_topk_merge_dev_packed)"""
+        nq = doc.shape[0]
+        m_doc = torch.empty((nq, k), dtype=torch.int64, device=doc.device)
+        m_score = torch.empty((nq, k), dtype=torch.float32, device=doc.device)
+        m_cnt = torch.empty((nq,), dtype=torch.int32, device=doc.device)
+        N.check(N.lib().ss_topk_allgather_merge(self._h, nq, int(k), doc.data_ptr(), score.data_ptr(), count.data_ptr(),
+                                                m_doc.data_ptr(), m_score.data_ptr(), m_cnt.data_ptr(), stream_ptr),
+                "ss_topk_allgather_merge")
+        return m_doc, m_score, m_cnt
+
+    def close(self):
+        if self._h:
+            N.lib().ss_comm_destroy(self._h)
+            self._h = None

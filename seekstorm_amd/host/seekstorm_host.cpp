@@ -173,8 +173,24 @@ int Shard::upload_facets(uint64_t n_docs, uint32_t record_size, const uint8_t* r
   return ss_facet_upload(h_, n_docs, record_size, records);
 }
 
+// all_terms_frequent (intersection.rs:198-209), evaluated where the reference evaluates it -- on the host, per query:
+// N > top_k << 8 and posting_count / N >= 0.5 (f32) for every term of an intersection of several terms -> the query is
+// marked and ranks only docs whose every tf >= 10 (one indexed field, <= 7 terms).  Not under a field filter
+// (add_result.rs:3545) -- nor under a facet filter (add_result.rs:2096-2100), which the caller knows about.
+bool Shard::mark_all_terms_frequent(ss_bm25_query* q, size_t top_k) const {
+  if (!h_ || lexical_fields_ != 1 || !(n_docs_ > ((uint64_t)top_k << 8))) return false;
+  if ((q->op & 0xFFu) != SS_OP_INTERSECTION || q->n_terms < 2 || q->n_terms > 7 || ((q->op >> 16) & 0x7FFFu)) return false;
+  uint64_t df[SS_MAX_QUERY_TERMS];
+  if (ss_bm25_term_df(h_, q->n_terms, q->term, df) != SS_OK) return false;
+  for (uint32_t t = 0; t < q->n_terms; t++)
+    if (!((float)df[t] / (float)n_docs_ >= 0.5f)) return false;
+  q->op |= SS_OP_ALL_TERMS_FREQUENT;
+  return true;
+}
+
 std::vector<ResultObject> Shard::search_lexical_batch(const std::vector<ss_bm25_query>& queries, size_t k,
-                                                      ResultType result_type, const std::vector<ss_facet_filter>& facet_filter) {
+                                                      ResultType result_type, const std::vector<ss_facet_filter>& facet_filter,
+                                                      bool mark_frequent) {
   const size_t nq = queries.size();
   std::vector<ResultObject> out(nq);
   if (nq == 0) return out;
@@ -182,22 +198,16 @@ std::vector<ResultObject> Shard::search_lexical_batch(const std::vector<ss_bm25_
   std::vector<uint32_t> doc(nq * kk), cnt(nq);
   std::vector<float> score(nq * kk);
   std::vector<uint64_t> tot(nq);
-  // all_terms_frequent (intersection.rs:198-209), evaluated where the reference evaluates it: N > top_k << 8 and
-  // posting_count / N >= 0.5 (f32) for every term of an intersection of several terms -> the query is marked and ranks
-  // only docs whose every tf >= 10 (one indexed field, <= 7 terms)
+  // all_terms_frequent: marked per query unless the caller already did (the coalescer marks every request with its OWN
+  // offset + length) or the call carries a facet filter, which disables the shortcut (add_result.rs:2096-2100)
   std::vector<ss_bm25_query> marked;
   const ss_bm25_query* qp = queries.data();
-  if (h_ && lexical_fields_ == 1 && result_type != ResultType::Count && n_docs_ > ((uint64_t)k << 8)) {
+  if (mark_frequent && facet_filter.empty() && result_type != ResultType::Count) {
     for (size_t q = 0; q < nq; q++) {
-      const ss_bm25_query& Q = queries[q];
-      if ((Q.op & 0xFFu) != SS_OP_INTERSECTION || Q.n_terms < 2 || Q.n_terms > 7) continue;
-      uint64_t df[SS_MAX_QUERY_TERMS];
-      if (ss_bm25_term_df(h_, Q.n_terms, Q.term, df) != SS_OK) continue;
-      bool all = true;
-      for (uint32_t t = 0; t < Q.n_terms; t++) all = all && (float)df[t] / (float)n_docs_ >= 0.5f;
-      if (!all) continue;
+      ss_bm25_query m = queries[q];
+      if (!mark_all_terms_frequent(&m, k)) continue;
       if (marked.empty()) marked = queries;
-      marked[q].op |= SS_OP_ALL_TERMS_FREQUENT;
+      marked[q] = m;
     }
     if (!marked.empty()) qp = marked.data();
   }
@@ -493,6 +503,8 @@ std::future<ResultObject> LexicalBatchCoalescer::submit(const std::vector<uint32
                                                         const std::vector<uint32_t>& not_terms) {
   auto r = std::make_unique<Req>();
   r->rc = shard_->make_query(query_terms, query_type_default, &r->q, not_terms);  // idf on the caller's thread
+  // the shortcut's condition depends on the request's own top_k, not on what else shares its batch
+  if (r->rc == SS_OK && result_type != ResultType::Count) shard_->mark_all_terms_frequent(&r->q, offset + length);
   r->offset = offset;
   r->length = length;
   r->rt = result_type;
@@ -537,7 +549,7 @@ void LexicalBatchCoalescer::run() {
       k = std::max(k, r->offset + r->length);
       qs.push_back(r->q);
     }
-    std::vector<ResultObject> res = shard_->search_lexical_batch(qs, k, batch[0]->rt);
+    std::vector<ResultObject> res = shard_->search_lexical_batch(qs, k, batch[0]->rt, {}, /*mark_frequent=*/false);
     for (size_t i = 0; i < batch.size(); i++) {
       ResultObject& ro = res[i];
       const size_t want = batch[i]->offset + batch[i]->length;

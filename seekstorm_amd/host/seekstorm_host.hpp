@@ -123,8 +123,11 @@ class Shard {
                                    const std::vector<uint16_t>& field_filter = {});
   // batched forms used by the coalescer (results sorted by score desc, shard-local ids)
   // facet_filter (search.rs FacetFilter, add_result.rs:341-482): shared by the queries of the call; needs upload_facets
+  // mark_frequent: evaluate the all_terms_frequent shortcut per query here (false: the caller already marked its queries)
   std::vector<ResultObject> search_lexical_batch(const std::vector<ss_bm25_query>& queries, size_t k, ResultType result_type,
-                                                 const std::vector<ss_facet_filter>& facet_filter = {});
+                                                 const std::vector<ss_facet_filter>& facet_filter = {}, bool mark_frequent = true);
+  // sets SS_OP_ALL_TERMS_FREQUENT on *q when the reference's condition holds for this shard and top_k (intersection.rs:198-209)
+  bool mark_all_terms_frequent(ss_bm25_query* q, size_t top_k) const;
   int upload_facets(uint64_t n_docs, uint32_t record_size, const uint8_t* records);  // facet.bin records
   std::vector<ResultObject> search_vector_batch(const float* query_vectors, size_t n_queries, size_t k,
                                                 const float* similarity_threshold, const AnnMode& ann_mode = AnnMode(),

@@ -323,6 +323,10 @@ class Shard:
         ids = np.ascontiguousarray(doc_ids, np.uint64)
         N.check(N.lib().ss_set_deleted(self._h, N.ptr(ids, N.u64p) if len(ids) else None, len(ids)), "ss_set_deleted")
 
+    def synth_partition(self, shard_id, n_shards):
+        """the following synth_* calls build shard `shard_id` of `n_shards` of one generator stream (doc g -> shard g % S)"""
+        N.check(N.lib().ss_synth_set_partition(self._h, int(shard_id), int(n_shards)), "ss_synth_set_partition")
+
     def synth_lexical(self, seed, n_docs, thresh32, len_table1024):
         th = np.ascontiguousarray(thresh32, np.uint32)
         tab = np.ascontiguousarray(len_table1024, np.uint8)
@@ -518,7 +522,7 @@ class Shard:
         if self.indexed_doc_count <= (int(k) << 8):
             return queries
         cand = np.nonzero(((queries["op"] & 0xFF) == int(QueryType.Intersection)) & (queries["n_terms"] > 1) &
-                          (queries["n_terms"] <= 7))[0]
+                          (queries["n_terms"] <= 7) & (((queries["op"] >> 16) & 0x7FFF) == 0))[0]  # not under a field filter, add_result.rs:3545
         if len(cand) == 0:
             return queries
         nf = np.float32(self.indexed_doc_count)
@@ -539,7 +543,8 @@ class Shard:
     def search_lexical_batch(self, queries, k, result_type=ResultType.TopkCount, reference_shortcuts=True, facet_filter=None):
         """reference_shortcuts: apply all_terms_frequent where its condition holds, as the reference does (one indexed field).
         facet_filter: see facet_filters(); shared by the queries of the call (a filtered doc neither counts nor ranks)"""
-        if reference_shortcuts and result_type != ResultType.Count and self.lexical_field_count == 1:
+        # a facet filter disables the shortcut (add_result.rs:2096-2100: all_terms_frequent && !phrase_query && !facet_filtered)
+        if reference_shortcuts and result_type != ResultType.Count and self.lexical_field_count == 1 and not facet_filter:
             queries = self.mark_all_terms_frequent(queries, k)
         nq = len(queries)
         kk = max(int(k), 1)
@@ -617,7 +622,7 @@ class Shard:
         if ann_mode is None:
             if not field_filter:
                 ro.observed_vector_count = self.vector_count  # AnnMode::All observes every record (vector.rs:421)
-            ro.observed_cluster_count = self.cluster_info()[1]
+            ro.observed_cluster_count = max(self.cluster_info()[1], 1)  # AnnMode::All: every cluster (one when none is declared), as the C++ mirror
         else:
             ro.observed_cluster_count = int(ncl[0])  # vector.rs:1394
         return ro
@@ -706,7 +711,8 @@ class Index:
                 vec_d += [x.doc_id * S + sh.shard_id for x in r.results]  # search.rs:1693
                 vec_s += [x.score for x in r.results]
                 vt = r.result_count_total
-                ro.observed_vector_count += r.observed_vector_count
+                ro.observed_vector_count += r.observed_vector_count  # search.rs:1897, 1923
+                ro.observed_cluster_count += r.observed_cluster_count
             # search.rs:1884,1899 sum; Hybrid: max(lexical, vector) per shard (search.rs:1919-1921)
             ro.result_count_total += max(lt, vt) if search_mode == SearchMode.Hybrid else (lt + vt)
         if result_type != ResultType.Count:

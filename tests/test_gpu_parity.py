@@ -957,9 +957,10 @@ def test_c1_standin_one_million_docs_and_pairs(S, O):
 
 
 def test_full_size_properties_c2_c3(S, O):
-    """BASELINE.json's full sizes (C2: 10 M docs, 3-term unions top-10; C3: 10 M x 768, batch 64, top-100), where the oracle is
-    too slow: size-independent properties -- both strategies bit-identical, exact counts equal, sorted, idempotent; every
-    returned vector score is the dot product of the row that was returned (f32 and i8)."""
+    """BASELINE.json's full sizes (C2: 10 M docs, 3-term unions top-10; C3: 10 M x 768, batch 64, top-100) over a LARGER query
+    set than the oracle comparison of tests/test_gpu_fullsize.py samples: size-independent properties -- both strategies
+    bit-identical, exact counts equal, sorted, idempotent; every returned vector score is the dot product of the row that
+    was returned (f32 and i8)."""
     from seekstorm_amd import _native as N
     n = 10_000_000
     th = O.term_thresholds()

@@ -358,3 +358,69 @@ def test_field_filter_rule_on_bm25f():
     full = O.search_fields_exhaustive(*args, [0, 1], O.OP_AND, 10)
     assert s[0] == full[1][list(full[0]).index(2)]                                                   # score over all fields
     assert O.search_fields_exhaustive(*args, [0], O.OP_OR, 10, field_filter=[1])[2] == 2             # docs 1, 2
+
+
+# ------------------------------------------------------------------ reference-structured dispatch (round 2)
+def test_reference_structured_dispatch_equals_table_scan():
+    """so_search_lex_ref -- single_blockid / union_docid_2 / union_docid_3 with the sub-query queue and add_topk's
+    docid_hashset arm (single.rs:292-417, union.rs:1168-1479, min_heap.rs:1193-1260) -- returns what the union_scan /
+    intersection restatement returns: scores, counts, every result type, NOT terms, tombstones.  The one place they may
+    differ is a quirk of the reference kept on purpose: a 2-term union's count under a delete set without NOT terms
+    (union.rs:1240-1249: posting_count sums minus the intersection count) still counts the deleted docs."""
+    from oracle import oracle as O
+    n_docs = 200_000
+    voc = list(range(2000, 4096, 60))
+    dl = O.lex_doclen(n_docs)
+    offs, docs, tfs = O.lex_corpus(n_docs, voc)
+    sh = O.Shard(n_docs, dl, offs, docs, tfs)
+    rng = np.random.default_rng(5)
+    quirk = 0
+    for it in range(300):
+        nt = int(rng.integers(1, 7))
+        terms = [int(x) for x in rng.choice(len(voc), nt, replace=False)]
+        op = O.OP_OR if rng.random() < 0.7 else O.OP_AND
+        k = int(rng.choice([1, 10, 100]))
+        rt = int(rng.choice([O.RT_TOPK, O.RT_TOPKCOUNT, O.RT_COUNT]))
+        nots = [int(x) for x in rng.choice(len(voc), int(rng.integers(0, 2)), replace=False) if int(x) not in terms]
+        deleted = it % 5 == 0
+        if deleted:
+            sh.set_deleted(rng.choice(n_docs, 1500, replace=False))
+        elif it % 5 == 1:
+            sh.set_deleted([])
+            deleted = False
+        a = sh.search(terms, op, k, rt, nots)
+        b = sh.search_ref(terms, op, k, rt, nots)
+        assert len(a[1]) == len(b[1]) and np.allclose(a[1], b[1], rtol=1e-6), (terms, op, k, rt, nots)
+        if rt != O.RT_TOPK and a[2] != b[2]:
+            assert op == O.OP_OR and nt == 2 and not nots, (terms, op, rt, a[2], b[2])  # only the documented quirk
+            quirk += 1
+    sh.set_deleted([])
+    # the decomposition prunes: a 3-term union over long lists is answered from far fewer postings than the table scan reads;
+    # here only equality matters, and that k docs come back sorted
+    d, s, t = sh.search_ref([0, 1, 2], O.OP_OR, 10, O.RT_TOPK)
+    assert len(d) == 10 and np.all(s[:-1] >= s[1:])
+
+
+def test_split_corpus_and_cpu_baseline_harness():
+    """split_corpus = the reference's document partitioning (doc g -> shard g % S, local g // S, index.rs:5284); the harness
+    (so_bench_lex: S shard tasks per query + merge, throughput and latency modes) answers and merges what the single shard
+    answers when the statistics are shard-local"""
+    from oracle import oracle as O
+    n_docs, S = 120_001, 4
+    voc = [3000, 3400, 3800, 4000]
+    dl = O.lex_doclen(n_docs)
+    offs, docs, tfs = O.lex_corpus(n_docs, voc)
+    parts = O.split_corpus(n_docs, dl, offs, docs, tfs, S)
+    assert sum(p[0] for p in parts) == n_docs
+    for sh, (nd, d, o, dd, tt) in enumerate(parts):
+        assert len(d) == nd and np.array_equal(d, dl[sh::S])
+        for t in range(len(voc)):
+            ref = docs[int(offs[t]):int(offs[t + 1])]
+            m = ref % S == sh
+            assert np.array_equal(dd[int(o[t]):int(o[t + 1])].astype(np.int64) * S + sh, ref[m])
+            assert np.array_equal(tt[int(o[t]):int(o[t + 1])], tfs[int(offs[t]):int(offs[t + 1])][m])
+    shards = [O.Shard(*p) for p in parts]
+    qs = np.array([[0, 1, 2], [1, 2, 3]], np.uint32)
+    for mode, threads in ((0, 2), (1, S)):
+        qps, done, lat = O.bench_lex(shards, qs, O.OP_OR, 10, O.RT_TOPK, mode, threads, 0.2)
+        assert qps > 0 and done > 0 and (mode == 0 or len(lat) == done)
