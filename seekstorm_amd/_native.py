@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libseekstorm_hip.so")
+LIB_PATH = os.environ.get("SEEKSTORM_HIP_LIB") or os.path.join(_HERE, "lib", "libseekstorm_hip.so")  # override: experiment builds (tools/probes)
 
 SS_NO_DOC = 0xFFFFFFFF
 SS_MAX_QUERY_TERMS = 10

@@ -274,14 +274,10 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   p.post = s->d_post;
   p.term_base = (const unsigned long long*)s->d_term_base;
   p.sub_off = s->d_sub_off;
-  p.comp = s->d_comp;
   p.q = (const bm_vquery*)s->d_vq;
   p.part_keys = bufA;
   p.total = total;
   p.tau = tau;
-  p.exc_off = (const unsigned long long*)s->d_exc_off;
-  p.exc_doc = s->d_exc_doc;
-  p.exc_tf = s->d_exc_tf;
   p.del = s->n_deleted ? s->d_deleted : nullptr;
   p.del_words = (uint32_t)s->deleted_words;
   p.n_sub = s->bm_n_sub;

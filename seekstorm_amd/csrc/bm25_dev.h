@@ -2,9 +2,8 @@
 #pragma once
 #include "ss_common.h"
 
-constexpr float BM_K1P = 2.2f;       // K + 1.0 (add_result.rs:20)
-// LDS layout per workgroup: [comp 256 f32][wlut 4096 f32][per wave: BM_WAVE_ACC (+ BM_WAVE_CNT) bytes, ss_common.h]
-constexpr int BM_LUT_BYTES = (256 + 4096) * 4;
+// LDS layout per workgroup: [per wave: BM_WAVE_ACC (+ BM_WAVE_CNT) bytes, ss_common.h] -- nothing else: a posting carries
+// its weight, the kernels hold no table
 constexpr int BM_RSRC_FLAGS = 0x00020000;  // raw buffer descriptor word 3: 32-bit data format
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -13,14 +12,10 @@ struct BmParams {
   const uint32_t* post;
   const unsigned long long* term_base;
   const uint32_t* sub_off;
-  const float* comp;
   const bm_vquery* q;              // expanded queries (bm25.hip bm_expand_kernel)
   unsigned long long* part_keys;   // [nq][P][KS]
   unsigned long long* total;       // [nq] exact match counts
   uint32_t* tau;                   // [nq] shared admission threshold: bits of the best k-th score any partition holds
-  const unsigned long long* exc_off;  // exception lists: postings whose tf does not fit the 9-bit field
-  const uint32_t* exc_doc;
-  const uint32_t* exc_tf;
   const uint32_t* del;             // tombstone bitmap (bit doc & 31 of word doc >> 5), null = no deleted docs
   uint32_t del_words;
   uint32_t n_sub, n_terms, nq, P, k, count;
@@ -176,94 +171,57 @@ __device__ __forceinline__ f32x4 lds_ldf4(uint32_t off) { return *(bm_lds_f32x4*
 __device__ __forceinline__ void lds_stf4(uint32_t off, f32x4 v) { *(bm_lds_f32x4*)(uintptr_t)off = v; }
 
 // Per-wave LDS addresses (bytes): accb + 4*field (field 0 = dump), tile = accb + 4 (16-byte aligned), match counters
-// cnt + field (AND only), lut = weight table base.
+// cnt + field (AND only).
 struct BmLds {
-  uint32_t lut, comp, accb, tile, cnt, cntw;
+  uint32_t accb, tile, cnt, cntw;
 };
+// accumulator address / weight of a posting (2 VALU operations each)
+__device__ __forceinline__ uint32_t bm_acc_addr(uint32_t p, const BmLds& L) { return (bm_doc_field(p) << 2) + L.accb; }
 
-// Exception lists (tf >= 511): exact tf of (term, doc) by binary search.  Cold path.
-struct BmExc {
-  const unsigned long long* off;
-  const uint32_t* doc;
-  const uint32_t* tf;
-};
-__device__ __attribute__((noinline)) float bm_exact_tf(BmExc X, uint32_t term, uint32_t doc) {
-  unsigned long long lo = X.off[term], hi = X.off[term + 1];
-  while (lo < hi) {
-    const unsigned long long mid = (lo + hi) >> 1;
-    if (X.doc[mid] < doc) lo = mid + 1; else hi = mid;
-  }
-  return (float)X.tf[lo];  // present by construction of the image
-}
-// tf >= 16 lies outside the weight table: tf*(K+1)/(tf + comp[len]) computed directly (rare, kept out of line).
-// doc0 = shard-local id of doc field 1 of the sub-block.
-__device__ __attribute__((noinline)) f32x4 bm_big_tf_weights(u32x4 pv, f32x4 wp, uint32_t comp_off, BmExc X, uint32_t term,
-                                                             uint32_t doc0) {
-#pragma unroll
-  for (int x = 0; x < 4; x++) {
-    if (pv[x] & BM_BIG_TF_MASK) {
-      float tf = (float)bm_tf(pv[x]);
-      if (bm_tf(pv[x]) == BM_TF_ESC) tf = bm_exact_tf(X, term, doc0 + ((pv[x] >> 2) & 0x1FFFu) - 1u);
-      wp[x] = tf * BM_K1P * __builtin_amdgcn_rcpf(tf + lds_ldf(comp_off + bm_len(pv[x]) * 4u));
-    }
-  }
-  return wp;
-}
-
-// One 256-posting chunk (4 per lane) of ONE term: acc[doc] += idf * wlut[tf,len]   (add_result.rs:1445-1447).
+// One 256-posting chunk (4 per lane) of ONE term: acc[doc] += idf * weight   (add_result.rs:1445-1447).
 // Plain gather / scatter: the docs of one term are distinct and the tile is private to the wave, whose LDS operations
-// execute in order.  NULL postings (padding, out-of-range lanes) add 0 to the dump slot.  Returns max of the new scores.
+// execute in order.  NULL postings (padding, out-of-range lanes) touch only the dump slot.  Returns max of the new scores.
 template <bool HAS_AND>
-__device__ __forceinline__ float bm_chunk(const u32x4 q, float idf, const BmLds& L, uint32_t and_val, float mx, BmExc X, uint32_t term,
-                                          uint32_t doc0) {
+__device__ __forceinline__ float bm_chunk(const u32x4 q, float idf, const BmLds& L, uint32_t and_val, float mx) {
   const uint32_t pv[4] = {q.x, q.y, q.z, q.w};
   uint32_t ao[4], co[4], cold[4];
-  float old[4], wp[4];
+  float old[4];
 #pragma unroll
   for (int x = 0; x < 4; x++) {
-    ao[x] = (pv[x] & 0x7FFCu) + L.accb;
+    ao[x] = bm_acc_addr(pv[x], L);
     old[x] = lds_ldf(ao[x]);
-    wp[x] = lds_ldf(((pv[x] >> 16) & 0x3FFCu) + L.lut);
     if (HAS_AND && and_val) {
-      co[x] = ((pv[x] & 0x7FFCu) >> 2) + L.cnt;
+      co[x] = bm_doc_field(pv[x]) + L.cnt;
       cold[x] = lds_ld8(co[x]);
     }
   }
-  if (__ballot(((pv[0] | pv[1]) | (pv[2] | pv[3])) & BM_BIG_TF_MASK)) {  // some tf >= 16 (rare)
-    const f32x4 fx = bm_big_tf_weights(q, f32x4{wp[0], wp[1], wp[2], wp[3]}, L.comp, X, term, doc0);
-    wp[0] = fx.x; wp[1] = fx.y; wp[2] = fx.z; wp[3] = fx.w;
-  }
 #pragma unroll
   for (int x = 0; x < 4; x++) {
-    const float nw = old[x] + idf * wp[x];
+    const float nw = old[x] + idf * bm_weight(pv[x]);
     lds_stf(ao[x], nw);
-    mx = fmaxf(mx, nw);
+    mx = fmaxf(mx, pv[x] ? nw : 0.f);  // a NULL posting's decoded weight is not zero: keep the dump slot out of the maximum
     if (HAS_AND && and_val) {
       // count one more | set the term's bit (+ bit 7 under the all_terms_frequent shortcut when this posting's tf < 10)
       uint32_t nb = and_val == 0xFFu ? cold[x] + 1u : (cold[x] | (and_val & 0xFFu));
-      if (and_val & BM_AND_FREQ) nb |= ((pv[x] & BM_BIG_TF_MASK) == 0u && ((pv[x] >> 26) & 15u) < 10u) ? 0x80u : 0u;
+      if (and_val & BM_AND_FREQ) nb |= bm_tf_lt10(pv[x]) ? 0x80u : 0u;
       lds_st8(co[x], nb);
     }
   }
   return mx;
 }
 
-// ---- chunk flavours of the fused item path (unions, items without tf >= 16 postings; bm25_fast.hip):
+// ---- chunk flavours of the fused item path (unions; bm25_fast.hip):
 //   first : the tile is still all zero for this term's docs -> score = idf * w, scattered without a read
 //   keep  : gather / add / scatter, addresses handed back
 //   read  : gather / add only, the new scores stay in registers (last term: scattered or zeroed once the trigger is known)
-// At most 8 LDS reads are in flight per chunk (the LDS counter has 4 bits).
+// The dump slot (NULL postings) takes part like any accumulator and is zeroed with the rest, so what it holds is bounded by
+// NT * idf * 2^-14 per item -- far below any real score; it is never scanned.
 __device__ __forceinline__ float bm_chunk_first(const u32x4 q, float idf, const BmLds& L, float mx, uint32_t (&ao)[4]) {
   const uint32_t pv[4] = {q.x, q.y, q.z, q.w};
-  float w[4];
 #pragma unroll
   for (int x = 0; x < 4; x++) {
-    ao[x] = (pv[x] & 0x7FFCu) + L.accb;
-    w[x] = lds_ldf(((pv[x] >> 16) & 0x3FFCu) + L.lut);
-  }
-#pragma unroll
-  for (int x = 0; x < 4; x++) {
-    const float nw = idf * w[x];
+    ao[x] = bm_acc_addr(pv[x], L);
+    const float nw = idf * bm_weight(pv[x]);
     lds_stf(ao[x], nw);
     mx = fmaxf(mx, nw);
   }
@@ -272,16 +230,15 @@ __device__ __forceinline__ float bm_chunk_first(const u32x4 q, float idf, const 
 __device__ __forceinline__ float bm_chunk_read(const u32x4 q, float idf, const BmLds& L, float mx, uint32_t (&ao)[4],
                                                float (&nw)[4]) {
   const uint32_t pv[4] = {q.x, q.y, q.z, q.w};
-  float old[4], wp[4];
+  float old[4];
 #pragma unroll
   for (int x = 0; x < 4; x++) {
-    ao[x] = (pv[x] & 0x7FFCu) + L.accb;
+    ao[x] = bm_acc_addr(pv[x], L);
     old[x] = lds_ldf(ao[x]);
-    wp[x] = lds_ldf(((pv[x] >> 16) & 0x3FFCu) + L.lut);
   }
 #pragma unroll
   for (int x = 0; x < 4; x++) {
-    nw[x] = old[x] + idf * wp[x];
+    nw[x] = old[x] + idf * bm_weight(pv[x]);
     mx = fmaxf(mx, nw[x]);
   }
   return mx;
@@ -296,6 +253,7 @@ __device__ __forceinline__ float bm_chunk_keep(const u32x4 q, float idf, const B
 
 template <bool HAS_AND>
 __device__ __forceinline__ void bm_clear_tile(const BmLds& L, bool is_and, int lane) {
+  if (lane == 0) lds_stf(L.accb, 0.f);  // the dump slot: NULL postings decode to a tiny non-zero weight
 #pragma unroll
   for (int i = 0; i < BM_SUB / 256; i++) {
     lds_stf4(L.tile + (i * 64 + lane) * 16, f32x4{0.f, 0.f, 0.f, 0.f});
@@ -340,6 +298,7 @@ __device__ __attribute__((noinline)) BmTop<KPL> bm_scan_tile(BmTop<KPL> T, uint3
     if (wb + 64u + (uint32_t)lane < del_words) dw1 = del[wb + 64u + lane];
   }
   const bool any_del = del && __ballot((dw0 | dw1) != 0u);
+  if (lane == 0) lds_stf(tile - 4u, 0.f);  // the dump slot in front of the tile (NULL postings decode to a tiny non-zero weight)
 #pragma unroll 2
   for (int i = 0; i < BM_SUB / 256; i++) {
     const int slot = i * 64 + lane;

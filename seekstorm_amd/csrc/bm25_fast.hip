@@ -8,8 +8,9 @@
 //   phase 1  every term's segment is streamed with raw buffer loads (16 bytes per lane, CPT x 1 KB per term in
 //            flight, prefetched one item ahead).  Segments are 16-byte aligned and NULL padded, and the buffer
 //            descriptor's num_records is the segment end: lanes past it read zeros (= NULL postings) without touching
-//            memory, so nothing in the loop is predicated.  acc[doc] += idf * wlut[tf,len] is a plain LDS
-//            gather / scatter on a tile private to the wave (bm_chunk, bm25_dev.h).
+//            memory, so nothing in the loop is predicated.  A posting carries its finished weight (ss_common.h):
+//            acc[doc] += idf * weight is a plain LDS gather / scatter on a tile private to the wave (bm_chunk,
+//            bm25_dev.h), with no table and no doc-length lookup.
 //   trigger  the running maximum of the updated scores is compared once per item with the current k-th best; only if
 //            some doc could enter the list (or exact counts are wanted) is the tile scanned, otherwise just cleared.
 // bm25_scan_fast_kernel<NT>: <= 4 terms, per-term state in scalar registers.  bm25_scan_group_kernel: up to 10 terms,
@@ -20,30 +21,25 @@ template <int NT> struct FastCfg { static constexpr int CPT = NT <= 2 ? 4 : NT <
 
 #define BM_KERNEL_ARGS                                                                                              \
   const uint32_t *__restrict__ post, const unsigned long long *__restrict__ term_base,                             \
-      const uint32_t *__restrict__ sub_off, const float *__restrict__ comp_g, const bm_vquery *__restrict__ qs, \
+      const uint32_t *__restrict__ sub_off, const bm_vquery *__restrict__ qs,                                      \
       unsigned long long *__restrict__ part_keys, unsigned long long *__restrict__ total, uint32_t *tau,            \
-      const unsigned long long *__restrict__ exc_off, const uint32_t *__restrict__ exc_doc,                         \
-      const uint32_t *__restrict__ exc_tf, const uint32_t *__restrict__ del, uint32_t del_words, uint32_t n_sub,    \
+      const uint32_t *__restrict__ del, uint32_t del_words, uint32_t n_sub,                                         \
       uint32_t n_terms, uint32_t nq, uint32_t P, uint32_t k, uint32_t count
 
 template <bool HAS_AND>
-__device__ __forceinline__ BmLds bm_lds_setup(const float* __restrict__ comp_g, int tid, int lane, int w, int waves) {
+__device__ __forceinline__ BmLds bm_lds_setup(int lane, int w) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WAVE_LDS = BM_WAVE_ACC + (HAS_AND ? BM_WAVE_CNT : 0);
   // the kernels have no static LDS, so the dynamic segment starts at LDS address 0: offsets below are absolute
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
-  for (int i = tid; i < 256 + 4096; i += waves * 64) ((float*)smem)[i] = comp_g[i];
-  const uint32_t wb = BM_LUT_BYTES + (uint32_t)w * WAVE_LDS;
+  const uint32_t wb = (uint32_t)w * WAVE_LDS;
   for (int i = lane; i < WAVE_LDS / 4; i += 64) lds_st32(wb + i * 4, 0u);
   BmLds L;
-  L.comp = 0;
-  L.lut = 1024;
   L.accb = wb + 12;
   L.tile = wb + 16;
   L.cnt = wb + BM_WAVE_ACC + 3;
   L.cntw = wb + BM_WAVE_ACC + 4;
-  __syncthreads();
-  return L;
+  return L;  // every wave initialises and uses only its own slice: no barrier
 }
 
 template <int NT, bool HAS_AND, int KPL>
@@ -53,7 +49,7 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
   constexpr int RC = FastCfg<NT>::RC;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const BmLds L = bm_lds_setup<HAS_AND>(comp_g, tid, lane, w, WAVES);
+  const BmLds L = bm_lds_setup<HAS_AND>(lane, w);
 
   const uint32_t row_len = n_sub + 1;
   const bool count_mode = count != 0;
@@ -77,13 +73,11 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
     const uint32_t* tptr[NT];
     const uint32_t* rowp[NT];
     float idf[NT];
-    uint32_t tid_[NT], av[NT];  // av: what a posting of the term does to its doc's match byte (0: nothing)
-    const BmExc X{exc_off, exc_doc, exc_tf};
+    uint32_t av[NT];  // av: what a posting of the term does to its doc's match byte (0: nothing)
 #pragma unroll
     for (int t = 0; t < NT; t++) {
       const bool have = (uint32_t)t < nt;
       const uint32_t term = have ? Q->term[t] : n_terms;
-      tid_[t] = term;
       av[t] = (is_and && (uint32_t)t < np && Q->and_val[t]) ? (uint32_t)Q->and_val[t] | (nt_and & BM_AND_FREQ) : 0u;
       idf[t] = have ? ((uint32_t)t < np ? Q->idf[t] : BM_NOT_IDF) : 0.f;
       tptr[t] = post + term_base[term] * 4ull;
@@ -124,13 +118,8 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
       uint32_t maxn = 0;
 #pragma unroll
       for (int t = 0; t < NT; t++) maxn = max(maxn, B1[t] - B0[t]);
-      // Postings with tf >= 16 need a computed weight (bm_big_tf_weights): such items (rare) take the general path, so
-      // that the fused path is free of calls and data-dependent branches.
-      uint32_t anyb = 0;
-#pragma unroll
-      for (int i = 0; i < RC; i++) anyb |= (cur[i].x | cur[i].y) | (cur[i].z | cur[i].w);
       const uint32_t nlast = B1[NT - 1] - B0[NT - 1];
-      if (!HAS_AND && nlast != 0 && maxn <= (uint32_t)CPT * 64u && __ballot(anyb & BM_BIG_TF_MASK) == 0) {
+      if (!HAS_AND && nlast != 0 && maxn <= (uint32_t)CPT * 64u) {
         // Fused path (unions, last term present, no oversized segment).  The tile is all zero when an item starts:
         // the first term is a pure scatter, middle terms gather / add / scatter, and the LAST term is only gathered --
         // its new scores stay in registers until the trigger is known.  No trigger (the common case): the tile is never
@@ -190,12 +179,12 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
 #pragma unroll
           for (int c = 0; c < CPT; c++)
             if ((uint32_t)c * 64u < n16)
-              mx = bm_chunk<HAS_AND>(cur[t * CPT + c], idf[t], L, av[t], mx, X, tid_[t], s << BM_SUB_LOG2);
+              mx = bm_chunk<HAS_AND>(cur[t * CPT + c], idf[t], L, av[t], mx);
           if (n16 > (uint32_t)CPT * 64u) {  // df above ~CPT/16 of the docs
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[t], 0, (int)(B1[t] << 4), BM_RSRC_FLAGS);
             for (uint32_t u = B0[t] + CPT * 64u; u < B1[t]; u += 64u) {
               const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0);
-              mx = bm_chunk<HAS_AND>(q, idf[t], L, av[t], mx, X, tid_[t], s << BM_SUB_LOG2);
+              mx = bm_chunk<HAS_AND>(q, idf[t], L, av[t], mx);
             }
           }
         }
@@ -243,7 +232,7 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
   constexpr int G = 4, CPT = 2;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const BmLds L = bm_lds_setup<HAS_AND>(comp_g, tid, lane, w, WAVES);
+  const BmLds L = bm_lds_setup<HAS_AND>(lane, w);
   const uint32_t total_waves = gridDim.x * WAVES;
   const uint32_t A = nq * P;
   const uint32_t row_len = n_sub + 1;
@@ -273,13 +262,11 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
         uint32_t b0[G], b1[G];
         float idf[G];
         const uint32_t* tp[G];
-        uint32_t tid_[G], av[G];
-        const BmExc X{exc_off, exc_doc, exc_tf};
+        uint32_t av[G];
 #pragma unroll
         for (int t = 0; t < G; t++) {
           const bool have = g0 + t < nt;
           const uint32_t term = have ? Q->term[have ? g0 + t : 0] : n_terms;
-          tid_[t] = term;
           av[t] = (is_and && g0 + t < np && Q->and_val[have ? g0 + t : 0]) ? (uint32_t)Q->and_val[have ? g0 + t : 0] | (nt_and & BM_AND_FREQ) : 0u;
           idf[t] = have ? (g0 + t < np ? Q->idf[have ? g0 + t : 0] : BM_NOT_IDF) : 0.f;
           tp[t] = post + term_base[term] * 4ull;
@@ -297,12 +284,12 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
 #pragma unroll
           for (int c = 0; c < CPT; c++)
             if ((uint32_t)c * 64u < n16)
-              mx = bm_chunk<HAS_AND>(v[t * CPT + c], idf[t], L, av[t], mx, X, tid_[t], s << BM_SUB_LOG2);
+              mx = bm_chunk<HAS_AND>(v[t * CPT + c], idf[t], L, av[t], mx);
           if (n16 > (uint32_t)CPT * 64u) {
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tp[t], 0, (int)(b1[t] << 4), BM_RSRC_FLAGS);
             for (uint32_t u = b0[t] + CPT * 64u; u < b1[t]; u += 64u) {
               const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0);
-              mx = bm_chunk<HAS_AND>(q, idf[t], L, av[t], mx, X, tid_[t], s << BM_SUB_LOG2);
+              mx = bm_chunk<HAS_AND>(q, idf[t], L, av[t], mx);
             }
           }
         }
@@ -322,12 +309,12 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
 }
 
 #define BM_PASS_ARGS                                                                                                 \
-  p.post, p.term_base, p.sub_off, p.comp, p.q, p.part_keys, p.total, p.tau, p.exc_off, p.exc_doc, p.exc_tf, p.del, p.del_words, p.n_sub, p.n_terms, p.nq, p.P, p.k, p.count
+  p.post, p.term_base, p.sub_off, p.q, p.part_keys, p.total, p.tau, p.del, p.del_words, p.n_sub, p.n_terms, p.nq, p.P, p.k, p.count
 
 template <int NT, bool HAS_AND, int KPL>
 static int launch_fast(const BmParams& p, hipStream_t st) {
   constexpr int WAVES = HAS_AND ? BM_WAVES_AND : BM_WAVES_OR;
-  constexpr int lds = BM_LUT_BYTES + WAVES * (BM_WAVE_ACC + (HAS_AND ? BM_WAVE_CNT : 0));
+  constexpr int lds = WAVES * (BM_WAVE_ACC + (HAS_AND ? BM_WAVE_CNT : 0));
   SS_SET_MAX_LDS((bm25_scan_fast_kernel<NT, HAS_AND, KPL>), lds);
   const uint32_t A = p.nq * p.P;
   bm25_scan_fast_kernel<NT, HAS_AND, KPL><<<(A + WAVES - 1) / WAVES, WAVES * 64, lds, st>>>(BM_PASS_ARGS);
@@ -337,7 +324,7 @@ static int launch_fast(const BmParams& p, hipStream_t st) {
 template <bool HAS_AND, int KPL>
 static int launch_group(const BmParams& p, hipStream_t st) {
   constexpr int WAVES = HAS_AND ? BM_WAVES_AND : BM_WAVES_OR;
-  constexpr int lds = BM_LUT_BYTES + WAVES * (BM_WAVE_ACC + (HAS_AND ? BM_WAVE_CNT : 0));
+  constexpr int lds = WAVES * (BM_WAVE_ACC + (HAS_AND ? BM_WAVE_CNT : 0));
   SS_SET_MAX_LDS((bm25_scan_group_kernel<HAS_AND, KPL>), lds);
   const uint32_t A = p.nq * p.P;
   const uint32_t grid = std::min<uint32_t>((A + WAVES - 1) / WAVES, 256);

@@ -37,33 +37,22 @@ __device__ __attribute__((noinline)) BmTop<KPL> bm_offer_lane_keys(BmTop<KPL> T,
   return T;
 }
 
-// weight of one posting: table for tf < 16, formula above (exact tf from the exception list when the field is saturated)
-__device__ __forceinline__ float pb_weight(uint32_t p, const BmExc& X, uint32_t term, uint32_t doc) {
-  float w = lds_ldf(((p >> 16) & 0x3FFCu) + 1024u);
-  if (p & BM_BIG_TF_MASK) {
-    float tf = (float)bm_tf(p);
-    if (bm_tf(p) == BM_TF_ESC) tf = bm_exact_tf(X, term, doc);
-    w = tf * BM_K1P * __builtin_amdgcn_rcpf(tf + lds_ldf(bm_len(p) * 4u));
-  }
-  return w;
-}
+// weight of one posting: it is IN the posting (ss_common.h) -- the same decode as the scan kernels'
+__device__ __forceinline__ float pb_weight(uint32_t p) { return bm_weight(p); }
 
 // FILT: tombstones and / or NOT terms are present (a separate instantiation: the unfiltered kernel pays nothing for them)
 template <int NT, int KPL, bool FILT>
 __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
     const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base, const uint32_t* __restrict__ sub_off,
-    const float* __restrict__ comp_g, const uint2* __restrict__ probe, const uint32_t* __restrict__ probe_z,
+    const uint2* __restrict__ probe, const uint32_t* __restrict__ probe_z,
     const uint32_t* __restrict__ probe_row, const float* __restrict__ umax,
     const bm_vquery* __restrict__ qs, unsigned long long* __restrict__ part_keys, unsigned long long* __restrict__ total,
-    uint32_t* tau, const unsigned long long* __restrict__ exc_off, const uint32_t* __restrict__ exc_doc,
-    const uint32_t* __restrict__ exc_tf, const uint32_t* __restrict__ del, uint32_t del_words, uint32_t n_sub, uint32_t n_terms,
+    uint32_t* tau, const uint32_t* __restrict__ del, uint32_t del_words, uint32_t n_sub, uint32_t n_terms,
     uint32_t nq, uint32_t P, uint32_t k, uint32_t count) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < 256 + 4096; i += PB_WAVES * 64) ((float*)smem)[i] = comp_g[i];
-  __syncthreads();
 
   const uint32_t a = blockIdx.x * PB_WAVES + w;
   if (a >= nq * P) return;
@@ -79,17 +68,15 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
   const uint2* prow[NT];   // 64 doc bits per group
   const uint32_t* zrow[NT];  // index of the group's first posting (fetched on hits only)
   float idf[NT], U[NT];
-  uint32_t qpos[NT], tid_[NT];
-  const BmExc X{exc_off, exc_doc, exc_tf};
+  uint32_t qpos[NT];
   unsigned long long size[NT];
 #pragma unroll
   for (int t = 0; t < NT; t++) {
     const bool have = (uint32_t)t < nt;
     const uint32_t term = have ? Q->term[t] : n_terms;
     idf[t] = have ? Q->idf[t] : 0.f;
-    U[t] = idf[t] * umax[term] * 1.000002f;  // upper bound of idf * w over the list (rcp-approximated weights included)
+    U[t] = idf[t] * umax[term];  // upper bound of idf * w over the list (umax = the largest DECODED weight)
     qpos[t] = t;
-    tid_[t] = term;
     tptr[t] = post + term_base[term] * 4ull;
     rowp[t] = sub_off + (size_t)term * row_len;
     prow[t] = probe + (size_t)probe_row[term] * n_sub * (BM_SUB / 64);  // the host sends only queries whose lists all have a row
@@ -107,7 +94,6 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
       { float t_ = idf[x]; idf[x] = idf[y]; idf[y] = t_; }
       { float t_ = U[x]; U[x] = U[y]; U[y] = t_; }
       { uint32_t t_ = qpos[x]; qpos[x] = qpos[y]; qpos[y] = t_; }
-      { uint32_t t_ = tid_[x]; tid_[x] = tid_[y]; tid_[y] = t_; }
       { auto t_ = size[x]; size[x] = size[y]; size[y] = t_; }
     }
   };
@@ -179,7 +165,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
   // term, remaining probes, score).  After the first probe only a few percent of the lanes are still alive; without
   // the queue every later gather round trip would be paid for a handful of lanes.
   constexpr uint32_t QCAP = PB_QCAP;
-  const uint32_t q_doc = BM_LUT_BYTES + (uint32_t)w * (QCAP * 12u), q_w0 = q_doc + QCAP * 4u, q_pos = q_w0 + QCAP * 4u;
+  const uint32_t q_doc = (uint32_t)w * (QCAP * 12u), q_w0 = q_doc + QCAP * 4u, q_pos = q_w0 + QCAP * 4u;
   uint32_t qn = 0;
 
   // one driver stream: the postings of processing term J inside this partition's sub-block range
@@ -236,7 +222,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
         zt[t] = zrow[t][hit[t] ? gidx : 0u];
       }
       if (hit_a) {
-        wv[A] = pb_weight(pa, X, tid_[A], doc);
+        wv[A] = pb_weight(pa);
         pres |= 1u << A;
         known += idf[A] * wv[A];
       }
@@ -248,7 +234,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
         if (t == J || t == A || (uint32_t)t >= nt) continue;
         if (hit[t] && alive) {
           const uint32_t pt = tptr[t][zt[t] + rk[t]];
-          wv[t] = pb_weight(pt, X, tid_[t], doc);
+          wv[t] = pb_weight(pt);
           pres |= 1u << t;
         }
       }
@@ -311,14 +297,14 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
 #pragma unroll
       for (int g = 0; g < G; g++) {
         alive[g] = pg[g] != 0u;
-        dg[g] = ((pg[g] >> 2) & 0x1FFFu) - 1u;  // doc inside its sub-block
+        dg[g] = bm_doc_field(pg[g]) - 1u;  // doc inside its sub-block
         // The probe of the first other term is issued NOW, for every real posting and before its weight is known: the
         // weight lookups and bound tests below then run under the gather's latency instead of in front of it (postings the
         // bound test would have spared cost a cached read).  Unconditional load: NULL lanes read record 0.
         if (NT > 1) rec[g] = prow[A][alive[g] ? tile[g] * (uint32_t)(BM_SUB / 64) + (dg[g] >> 6) : 0u];
       }
 #pragma unroll
-      for (int g = 0; g < G; g++) w0[g] = alive[g] ? pb_weight(pg[g], X, tid_[J], (tile[g] << BM_SUB_LOG2) + dg[g]) : 0.f;
+      for (int g = 0; g < G; g++) w0[g] = alive[g] ? pb_weight(pg[g]) : 0.f;
       if (nt == 1) {  // single-term query: the driver posting is the whole score
 #pragma unroll
         for (int g = 0; g < G; g++) {
@@ -386,8 +372,8 @@ template <int NT, int KPL, bool FILT>
 static int launch_probe(const BmParams& p, const uint2* probe, const uint32_t* probe_z, const uint32_t* probe_row, const float* umax,
                         hipStream_t st) {
   const uint32_t A = p.nq * p.P;
-  bm25_probe_kernel<NT, KPL, FILT><<<(A + PB_WAVES - 1) / PB_WAVES, PB_WAVES * 64, BM_LUT_BYTES + PB_WAVES * PB_QCAP * 12, st>>>(
-      p.post, p.term_base, p.sub_off, p.comp, probe, probe_z, probe_row, umax, p.q, p.part_keys, p.total, p.tau, p.exc_off, p.exc_doc, p.exc_tf, p.del, p.del_words, p.n_sub, p.n_terms, p.nq, p.P, p.k,
+  bm25_probe_kernel<NT, KPL, FILT><<<(A + PB_WAVES - 1) / PB_WAVES, PB_WAVES * 64, PB_WAVES * PB_QCAP * 12, st>>>(
+      p.post, p.term_base, p.sub_off, probe, probe_z, probe_row, umax, p.q, p.part_keys, p.total, p.tau, p.del, p.del_words, p.n_sub, p.n_terms, p.nq, p.P, p.k,
       p.count);
   return SS_OK;
 }

@@ -33,30 +33,48 @@ __host__ __device__ inline uint32_t ss_byte4_to_int(uint32_t b) {
 constexpr int BM_SUB_LOG2 = 12;             // docs per sub-block = 4096 = one wave's 16 KB LDS accumulator tile
                                             // (2048 with 16 waves/CU measured 17% slower: per-item overhead dominates)
 constexpr int BM_SUB = 1 << BM_SUB_LOG2;
-constexpr int BM_WAVES_OR = 8 << (12 - BM_SUB_LOG2);   // waves per workgroup (one workgroup per CU), union-only kernels
-constexpr int BM_WAVES_AND = 6 << (12 - BM_SUB_LOG2);  // kernels that also carry match counters
+#ifndef SS_BM_WAVES_OR
+#define SS_BM_WAVES_OR 8
+#endif
+#ifndef SS_BM_WAVES_AND
+#define SS_BM_WAVES_AND 6
+#endif
+constexpr int BM_WAVES_OR = SS_BM_WAVES_OR;    // waves per workgroup, union-only kernels (16.4 KB of LDS per wave)
+constexpr int BM_WAVES_AND = SS_BM_WAVES_AND;  // kernels that also carry match counters (20.5 KB per wave)
 constexpr uint32_t BM_NO_PROBE_ROW = 0xFFFFFFFFu;
-constexpr uint32_t BM_TF_ESC = 511;         // 9-bit tf field; 511 = "the exact tf (>= 511) is in the term's exception list"
-// Packed posting (one dword).  Laid out so that the two LDS byte offsets the scan needs are single AND / shift+AND
-// extractions and everything else rides in the bits they mask off:
-//   bits  2..14  doc field = doc-in-sub-block + 1 (1..4096)            -> p & 0x7FFC        = 4 * field (accumulator)
-//   bits 18..25  LUT column, bits 26..29 tf & 15                       -> (p >> 16) & 0x3FFC = 4 * ((tf & 15) << 8 | col)
-//                col = (len + 7 * (tf & 15)) & 255: rows of the weight table are rotated against each other so that
-//                equal lengths with different tf (the common case inside one wave) fall into different LDS banks
-//   bit 15, bits 16..17, bits 30..31 = tf bits 4, 5..6, 7..8 (non-zero only when tf >= 16: weight computed, not looked up);
-//                tf >= 511 is stored as 511 and its exact value kept in a per-term exception list (doc, tf) sorted by doc
-// The all-zero dword is the NULL posting (segment padding, and what an out-of-range buffer load returns): its doc
-// field addresses the dump slot in front of a wave's accumulator tile and its table weight (tf = 0) is 0.
-constexpr uint32_t BM_BIG_TF_MASK = 0xC0038000u;
-__host__ __device__ inline uint32_t bm_lut_col(uint32_t len_byte, uint32_t tf) { return (len_byte + 7u * (tf & 15u)) & 0xFFu; }
-__host__ __device__ inline uint32_t bm_pack(uint32_t doc_in_sub, uint32_t len_byte, uint32_t tf) {
-  return (((doc_in_sub + 1u) & 0x1FFFu) << 2) | (((tf >> 4) & 1u) << 15) | (((tf >> 5) & 3u) << 16) |
-         (bm_lut_col(len_byte, tf) << 18) | ((tf & 15u) << 26) | (((tf >> 7) & 3u) << 30);
+// Packed posting (one dword): the doc AND its finished BM25 weight, so that scoring a posting is one multiply-add with
+// idf and never a table or doc-length lookup:
+//   bits  0..12  doc field = doc-in-sub-block + 1 (1..4096); 0 = the NULL posting's dump slot
+//   bits 13..31  W19 = the posting's weight  tf (K + 1) / (tf + bm25_component_cache[len])  (add_result.rs:1445-1447 without
+//                idf), computed in f32 exactly as the reference computes it and then rounded to 15 mantissa bits:
+//                weight = as_float((W19 << 8) + BM_W_BASE), binades 2^-14 .. 2^2, relative rounding error <= 2^-16 = 1.5e-5
+//                (north_star's tolerance is 1e-4).  Any tf fits: there is no tf field, no table and no exception list.
+//                Lists that can take part in the all_terms_frequent shortcut (df >= N / 2, intersection.rs:198-209) give
+//                up the last mantissa bit for the one thing that rule asks of a posting: W19 bit 0 = (tf < 10).
+// The all-zero dword is the NULL posting (segment padding, and what an out-of-range buffer load returns): its doc field
+// addresses the dump slot in front of a wave's accumulator tile; whatever weight it decodes to lands there.
+constexpr uint32_t BM_W_BASE = 0x38800000u;  // f32 bits of 2^-14
+__host__ __device__ inline uint32_t bm_f2u(float f) { union { float f; uint32_t u; } x; x.f = f; return x.u; }
+__host__ __device__ inline float bm_u2f(uint32_t u) { union { float f; uint32_t u; } x; x.u = u; return x.f; }
+__host__ __device__ inline uint32_t bm_wcode(float w) {  // round to nearest; weights below 2^-14 clamp to the smallest code
+  const uint32_t b = bm_f2u(w);
+  if (b < BM_W_BASE + 128u) return 1u;
+  const uint32_t c = (b - BM_W_BASE + 128u) >> 8;
+  return c > 0x7FFFFu ? 0x7FFFFu : c;
 }
-__host__ __device__ inline uint32_t bm_tf(uint32_t p) {
-  return ((p >> 26) & 15u) | (((p >> 15) & 1u) << 4) | (((p >> 16) & 3u) << 5) | ((p >> 30) << 7);
+__host__ __device__ inline float bm_wdecode(uint32_t c) { return bm_u2f((c << 8) + BM_W_BASE); }
+__host__ __device__ inline float bm_weight(uint32_t p) { return bm_u2f(((p >> 13) << 8) + BM_W_BASE); }  // weight of a posting
+__host__ __device__ inline uint32_t bm_pack(uint32_t doc_in_sub, uint32_t wcode) { return (wcode << 13) | ((doc_in_sub + 1u) & 0x1FFFu); }
+__host__ __device__ inline uint32_t bm_doc_field(uint32_t p) { return p & 0x1FFFu; }                  // doc-in-sub-block + 1
+__host__ __device__ inline uint32_t bm_tf_lt10(uint32_t p) { return (p >> 13) & 1u; }                 // flagged lists only
+// one term of get_bm25f_multiterm_singlefield without idf (add_result.rs:1445-1447; SIGMA = 0): the operations and their
+// order are the reference's (tf * (K + 1.0) / (tf + bm25_component)), each rounded to f32
+inline float bm_weight_exact(uint32_t tf, float comp_len) {
+  const float t = (float)tf;
+  const volatile float num = t * (1.2f + 1.0f);  // volatile: no contraction / reassociation whatever the host flags
+  const volatile float den = t + comp_len;
+  return num / den;
 }
-__host__ __device__ inline uint32_t bm_len(uint32_t p) { return (((p >> 18) & 0xFFu) - 7u * ((p >> 26) & 15u)) & 0xFFu; }
 // per-wave LDS: [12 B pad][dump f32][tile BM_SUB f32] (+ [3 B pad][dump u8][BM_SUB u8 match counters])
 constexpr int BM_WAVE_ACC = 16 + BM_SUB * 4;
 constexpr int BM_WAVE_CNT = 16 + BM_SUB;  // counters of doc d at byte 4 + d; the dump counter at byte 3
@@ -120,7 +138,7 @@ struct ss_shard {
                                   // starts 16-byte aligned and is zero-padded (NULL postings) to a multiple of 16 bytes
   uint64_t* d_term_base = nullptr; // [n_terms+1] first 16-byte unit of each term
   uint32_t* d_sub_off = nullptr;   // [n_terms][n_sub+1] segment boundaries in 16-byte units relative to the term base
-  float* d_comp = nullptr;         // bm25_component_cache[256] + wlut[4096]
+  float* d_comp = nullptr;         // bm25_component_cache[256] (kept for inspection; the kernels read weights from the postings)
   std::vector<uint64_t> h_df;      // posting_count per term (the df the host needs for idf)
   // probe index: membership (64-doc bit records) and rank (index of each group's first posting) of a doc in a term's
   // segment without reading the segment; the bit records are also the bitmaps exact union counts are popcounted from
@@ -142,9 +160,6 @@ struct ss_shard {
   uint32_t bm_probe_rows = 0;
   uint64_t probe_budget = 0;       // ss_bm25_set_probe_budget: bytes, 0 = half of the free device memory
   int bm_strategy = SS_BM25_AUTO;  // ss_bm25_set_strategy
-  uint64_t* d_exc_off = nullptr;   // [n_terms + 2] CSR of the exception lists (postings with tf >= 511)
-  uint32_t* d_exc_doc = nullptr;   // shard-local doc ids, ascending per term
-  uint32_t* d_exc_tf = nullptr;    // exact tf
   float* d_umax = nullptr;         // [n_terms + 1] largest weight tf*(K+1)/(tf+comp[len]) of the term (max_list_score / idf)
   // bm25 workspace
   void* d_bq = nullptr; size_t bq_cap = 0;       // staged queries

@@ -51,20 +51,29 @@ int ssi_vec_synth(ss_shard* s, uint64_t seed, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------- BM25 image from host arrays
-// comp[0..255] = bm25_component_cache (commit.rs:321-325); comp[256 + (tf<<8|len)] = tf*(K+1)/(tf+comp[len]) for
-// tf < 16 (add_result.rs:1445-1447 without the idf factor): the table the scan kernel indexes with posting bits.
+// comp[0..255] = bm25_component_cache (commit.rs:321-325): K * (1 - b + b * dl / avgdl) per SmallFloat length byte.
+// The weight of a posting, tf * (K + 1) / (tf + comp[len]) (add_result.rs:1445-1447 without the idf factor), is computed
+// from it at image-build time and stored IN the posting as its 19-bit code (bm_wcode, ss_common.h).
 static void fill_comp(float avgdl, float* comp) {
   for (int i = 0; i < 256; i++) {
     float q = (float)ss_byte4_to_int((uint32_t)i) / avgdl;
     comp[i] = 1.2f * (1.0f - 0.75f + 0.75f * q);
   }
-  for (int tf = 0; tf < 16; tf++)
-    for (int l = 0; l < 256; l++) {
-      float t = (float)tf;
-      comp[256 + (tf << 8) + bm_lut_col((uint32_t)l, (uint32_t)tf)] = tf ? (t * (1.2f + 1.0f) / (t + comp[l])) : 0.0f;
-    }
 }
-constexpr int SS_COMP_N = 256 + 4096;
+constexpr int SS_COMP_N = 256;
+// the device generator's postings have tf <= 32 (1 + ctz of a 32-bit word): their codes come from a host-computed table
+// [33][256] so that no float arithmetic of the weight runs on the device (the host's is the reference's, bit for bit)
+constexpr int SS_SYNTH_TF_MAX = 32;
+// lists that can meet the all_terms_frequent condition (posting_count / indexed_doc_count >= 0.5 in f32, intersection.rs:
+// 198-209; one indexed field) carry (tf < 10) in the last bit of every weight code
+static inline bool bm_list_flagged(const ss_shard* s, uint64_t df) {
+  return s->bm_n_fields == 1 && (float)df / (float)s->bm_n_docs >= 0.5f;
+}
+static inline uint32_t bm_code_of(uint32_t tf, float comp_len, bool flagged) {
+  uint32_t c = bm_wcode(bm_weight_exact(tf, comp_len));
+  if (flagged) c = (c & ~1u) | (tf < 10u ? 1u : 0u);
+  return c;
+}
 
 // segments are padded to 16 bytes; the image ends with 1 KB of NULL postings so that a whole-wave load of the last
 // unit never leaves the allocation
@@ -114,26 +123,6 @@ static int alloc_probe(ss_shard* s, hipStream_t st) {
   SS_HIP(hipStreamSynchronize(st));  // h_probe_row may be re-assigned by a later build while the copy is in flight
   return SS_OK;
 }
-__host__ __device__ inline float bm_weight_of(uint32_t tf, uint32_t len_byte, const float* comp) {
-  // the weight the scan kernels use for this posting: table for tf < 16, formula above (bm_big_tf_weights)
-  return tf < 16u ? comp[256 + (tf << 8) + bm_lut_col(len_byte, tf)] : (float)tf * 2.2f / ((float)tf + comp[len_byte]);
-}
-
-// exception lists: CSR by term of (doc, exact tf) for the postings whose tf saturates the 9-bit field
-static int upload_exceptions(ss_shard* s, const std::vector<u64>& off, const std::vector<uint32_t>& doc,
-                             const std::vector<uint32_t>& tf) {
-  const size_t n = doc.size();
-  SS_HIP(hipMalloc(&s->d_exc_off, off.size() * sizeof(u64)));
-  SS_HIP(hipMalloc(&s->d_exc_doc, (n + 1) * sizeof(uint32_t)));
-  SS_HIP(hipMalloc(&s->d_exc_tf, (n + 1) * sizeof(uint32_t)));
-  SS_HIP(hipMemcpy(s->d_exc_off, off.data(), off.size() * sizeof(u64), hipMemcpyHostToDevice));
-  if (n) {
-    SS_HIP(hipMemcpy(s->d_exc_doc, doc.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
-    SS_HIP(hipMemcpy(s->d_exc_tf, tf.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
-  }
-  return SS_OK;
-}
-
 int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t* offs, const uint32_t* docs,
                              const uint16_t* tfs, uint64_t positions_sum) {
   const uint32_t nt = s->bm_n_terms, ns = s->bm_n_sub;
@@ -169,10 +158,10 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
   }
   tbase[nt] = units;
   std::vector<uint32_t> post(units ? units * 4 : 4, 0u);
-  std::vector<u64> exc_off((size_t)nt + 2, 0);
-  std::vector<uint32_t> exc_doc, exc_tf;
+  std::vector<float> umax((size_t)nt + 1, 0.f);
   for (uint32_t t = 0; t < nt; t++) {
-    exc_off[t] = exc_doc.size();
+    const bool flagged = bm_list_flagged(s, s->h_df[t]);
+    const uint8_t* dl = doclen + (size_t)(t % s->bm_n_fields) * s->bm_n_docs;  // the list's field (virtual term = term * F + field)
     const uint32_t* row = sub.data() + (size_t)t * (ns + 1);
     u64 j = offs[t];
     for (uint32_t sb = 0; sb < ns; sb++) {
@@ -182,18 +171,15 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
         if (docs[j] >= s->bm_n_docs) return SS_EINVAL;
         if (j > offs[t] && docs[j] <= docs[j - 1]) return SS_EINVAL;
         if (tfs[j] == 0) return SS_EINVAL;
-        const uint32_t tf = tfs[j];
-        if (tf >= BM_TF_ESC) { exc_doc.push_back(docs[j]); exc_tf.push_back(tf); }  // exact value kept in the exception list
-        post[w] = bm_pack(docs[j] & (BM_SUB - 1), doclen[(size_t)(t % s->bm_n_fields) * s->bm_n_docs + docs[j]], tf < BM_TF_ESC ? tf : BM_TF_ESC);
+        const uint32_t code = bm_code_of(tfs[j], comp[dl[docs[j]]], flagged);
+        post[w] = bm_pack(docs[j] & (BM_SUB - 1), code);
+        umax[t] = std::max(umax[t], bm_wdecode(code));  // the bound of the pruned kernel: over the weights as the kernels see them
       }
     }
   }
-  exc_off[nt] = exc_off[nt + 1] = exc_doc.size();
   s->bm_n_post = offs[nt];
   const size_t rows = (size_t)nt * (ns + 1);
   int rc = alloc_post(s, units);
-  if (rc) return rc;
-  rc = upload_exceptions(s, exc_off, exc_doc, exc_tf);
   if (rc) return rc;
   SS_HIP(hipMalloc(&s->d_term_base, ((size_t)nt + 1) * sizeof(u64)));
   SS_HIP(hipMalloc(&s->d_sub_off, (rows + ns + 1) * sizeof(uint32_t)));  // + one all-zero row (absent terms)
@@ -206,14 +192,12 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
   rc = alloc_probe(s, s->stream);
   if (rc) return rc;
   SS_HIP(hipStreamSynchronize(s->stream));
-  std::vector<float> umax((size_t)nt + 1, 0.f);
   std::vector<uint2> probe;
   std::vector<uint32_t> probe_z;
   if (s->d_probe) probe.assign((size_t)s->bm_probe_rows * ns * BM_GROUPS, make_uint2(0, 0));
   probe_z.assign(probe.size(), 0u);
   for (uint32_t t = 0; t < nt; t++) {
     for (u64 j = offs[t]; j < offs[t + 1]; j++) {
-      umax[t] = std::max(umax[t], bm_weight_of(tfs[j], doclen[(size_t)(t % s->bm_n_fields) * s->bm_n_docs + docs[j]], comp));
       if (!s->d_probe || s->h_probe_row[t] == BM_NO_PROBE_ROW) continue;
       const uint32_t sb = docs[j] >> BM_SUB_LOG2, d = docs[j] & (BM_SUB - 1);
       uint2* row = probe.data() + ((size_t)s->h_probe_row[t] * ns + sb) * BM_GROUPS;
@@ -262,7 +246,8 @@ __global__ void lex_gen_kernel(u64 seed, u64 n_docs, uint32_t n_terms, uint32_t 
                                const uint8_t* __restrict__ doclen, uint32_t* __restrict__ sub /*[nt][ns+1]*/,
                                const u64* __restrict__ term_base, uint32_t* __restrict__ post, u64* __restrict__ df,
                                uint2* __restrict__ probe, uint32_t* __restrict__ probe_z, const uint32_t* __restrict__ probe_row,
-                               uint32_t* __restrict__ umax_bits, const float* __restrict__ comp, u64 gs, u64 go) {
+                               uint32_t* __restrict__ umax_bits, const uint32_t* __restrict__ wcode /*[33][256] weight codes by (tf, len)*/,
+                               const uint8_t* __restrict__ flagged /*[nt] list carries (tf < 10) in its codes*/, u64 gs, u64 go) {
   const int lane = threadIdx.x & 63;
   const u64 gw = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const u64 total = (u64)n_terms * n_sub;
@@ -283,8 +268,10 @@ __global__ void lex_gen_kernel(u64 seed, u64 n_docs, uint32_t n_terms, uint32_t 
       uint32_t pos = run + __popcll(m & ((1ull << lane) - 1ull));
       uint32_t lo = (uint32_t)hv | 0x80000000u;
       uint32_t tf = 1u + (uint32_t)__builtin_ctz(lo);
-      post[base + pos] = bm_pack((uint32_t)(d & (BM_SUB - 1)), doclen[d], tf);
-      wmax = fmaxf(wmax, bm_weight_of(tf, doclen[d], comp));
+      uint32_t code = wcode[(tf << 8) + doclen[d]];
+      if (flagged[t]) code = (code & ~1u) | (tf < 10u ? 1u : 0u);
+      post[base + pos] = bm_pack((uint32_t)(d & (BM_SUB - 1)), code);
+      wmax = fmaxf(wmax, bm_wdecode(code));
     }
     if (FILL && probe && lane == 0 && probe_row[t] != BM_NO_PROBE_ROW) {
       const size_t gi = ((size_t)probe_row[t] * n_sub + sb) * (BM_SUB / 64) + i;
@@ -362,7 +349,7 @@ int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const u
   const u64 waves = (u64)nt * ns;
   const uint32_t grid = (uint32_t)((waves + 3) / 4);
   lex_gen_kernel<false><<<grid, 256, 0, st>>>(seed, nd, nt, ns, d_thresh, d_doclen, s->d_sub_off, nullptr, nullptr, d_df,
-                                              nullptr, nullptr, nullptr, nullptr, nullptr, s->synth_stride, s->synth_offset);
+                                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s->synth_stride, s->synth_offset);
   lex_scan_rows_kernel<<<nt, 1024, 0, st>>>(s->d_sub_off, ns, d_tot);
   lex_scan_terms_kernel<<<1, 64, 0, st>>>(d_tot, (u64*)s->d_term_base, nt);
   SS_HIP(hipStreamSynchronize(st));
@@ -384,14 +371,26 @@ int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const u
   SS_HIP(hipMemcpy(s->d_comp, comp, sizeof(comp), hipMemcpyHostToDevice));
   int rc = alloc_post(s, units);
   if (rc) return rc;
-  rc = upload_exceptions(s, std::vector<u64>((size_t)nt + 2, 0), {}, {});  // generated tf <= 32: no exceptions
-  if (rc) return rc;
   rc = alloc_probe(s, st);
   if (rc) return rc;
+  // weight codes of every (tf, len) the generator can produce, computed on the host like every other image's
+  std::vector<uint32_t> wtab((size_t)(SS_SYNTH_TF_MAX + 1) * 256, 0u);
+  for (uint32_t tf = 1; tf <= (uint32_t)SS_SYNTH_TF_MAX; tf++)
+    for (uint32_t l = 0; l < 256; l++) wtab[(tf << 8) + l] = bm_code_of(tf, comp[l], false);
+  std::vector<uint8_t> flg(nt);
+  for (uint32_t t = 0; t < nt; t++) flg[t] = bm_list_flagged(s, s->h_df[t]) ? 1 : 0;
+  uint32_t* d_wtab = nullptr;
+  uint8_t* d_flg = nullptr;
+  SS_HIP(hipMalloc(&d_wtab, wtab.size() * sizeof(uint32_t)));
+  SS_HIP(hipMalloc(&d_flg, nt));
+  SS_HIP(hipMemcpyAsync(d_wtab, wtab.data(), wtab.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  SS_HIP(hipMemcpyAsync(d_flg, flg.data(), nt, hipMemcpyHostToDevice, st));
   lex_gen_kernel<true><<<grid, 256, 0, st>>>(seed, nd, nt, ns, d_thresh, d_doclen, s->d_sub_off,
                                              (const u64*)s->d_term_base, s->d_post, nullptr, s->d_probe, s->d_probe_z, s->d_probe_row,
-                                             (uint32_t*)s->d_umax, s->d_comp, s->synth_stride, s->synth_offset);
+                                             (uint32_t*)s->d_umax, d_wtab, d_flg, s->synth_stride, s->synth_offset);
   SS_HIP(hipStreamSynchronize(st));
+  (void)hipFree(d_wtab);
+  (void)hipFree(d_flg);
   (void)hipFree(d_doclen);
   (void)hipFree(d_psum);
   (void)hipFree(d_tot);
