@@ -273,6 +273,20 @@ int ss_bm25_facet_count(ss_shard* s, const ss_bm25_query* query, uint32_t n_filt
  * Several records may share a doc id (one per indexed field x chunk, vector.rs:561-576): the search then returns each
  * doc once with its best record's score, as TopK::push does (vector.rs:441-452, 462-473). */
 int ss_vec_upload(ss_shard* s, uint64_t n_rows, uint32_t dim, const float* rows, const uint32_t* row_doc_ids);
+/* VectorSimilarity of the shard's vector image (the index-wide setting the reference reads as shard.vector_similarity;
+ * similarity arms vector_similarity.rs:118-345, 880-908).  SS_SIM_DOT (default) = Dot and Cosine: a record's similarity is
+ * the dot product.  SS_SIM_EUCLIDEAN: MINUS the squared distance -- -euclidean_f32 (912) for f32 records, -euclidean_i8
+ * (921) for i8 records, -euclidean_i8_quantized = -max(0, norm1 + norm2 - 2 dot_i32 scale1 scale2) (1721-1735) for i8 records
+ * with quantisation scales -- so that larger is still closer and TopK / ANN selection work unchanged; threshold_raw of a
+ * search is then -similarity_threshold (vector.rs:398), scores come back as -distance^2 (vector_score = -score, vector.rs:
+ * 1495).  Returned f32 scores are recomputed in the reference's own summation order (euclidean_f32_avx2 when dim % 8 == 0).
+ * Must be set BEFORE the image is uploaded / generated (the f32 image is laid out with two extra columns); SS_ESTATE
+ * otherwise.  Applies to AnnMode::All and the ANN modes (medoids are scored with the same similarity). */
+enum { SS_SIM_DOT = 0, SS_SIM_EUCLIDEAN = 1 };
+int ss_vec_set_similarity(ss_shard* s, int similarity);
+/* i8 records under Euclidean + ScalarQuantizationI8: VectorHeader.norm of every record (vector.bin uploads with
+ * use_record_scale keep it themselves).  The query's norm goes into ss_vec_search_i8_ann[_dev]'s query_norm. */
+int ss_vec_set_row_norms(ss_shard* s, uint64_t n_rows, const float* row_norm);
 /* Device-side synthetic matrix (generator = oracle so_vec_gen, uniform(-1,1) then normalize_f32). */
 /* Rows straight from a shard's vector.bin (writer vector.rs:1066-1094): per level u32 cluster_count + child counts,
  * then 24-byte VectorHeader + dim x f32 records; doc id = (level << 16) | header.doc_id (vector.rs:1448).  f32 only. */
@@ -353,6 +367,14 @@ int ss_vec_search_i8_ann_dev(ss_shard* s, uint32_t n_queries, const int8_t* d_qu
                              uint32_t k, float threshold_raw, const ss_ann_mode* mode, uint32_t* d_out_doc,
                              float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, uint32_t* d_out_clusters,
                              void* stream);
+/* the same with the per-query norm euclidean_i8_quantized needs (QuantizedVector.norm of the quantised query; NULL = 0) */
+int ss_vec_search_i8_euclid(ss_shard* s, uint32_t n_queries, const int8_t* queries, const float* query_scale,
+                            const float* query_norm, uint32_t k, float threshold_raw, const ss_ann_mode* mode, uint32_t* out_doc,
+                            float* out_score, uint32_t* out_count, uint64_t* out_total, uint32_t* out_clusters);
+int ss_vec_search_i8_euclid_dev(ss_shard* s, uint32_t n_queries, const int8_t* d_queries, const float* d_query_scale,
+                                const float* d_query_norm, uint32_t k, float threshold_raw, const ss_ann_mode* mode,
+                                uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total,
+                                uint32_t* d_out_clusters, void* stream);
 
 /* ------------------------------------------------------------------ cross-shard merge + RRF (host side)
  * Inputs are the concatenation over shards of per-shard top-(offset+length) lists with GLOBAL ids

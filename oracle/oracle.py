@@ -481,3 +481,68 @@ def merge(mode, lex=None, vec=None, offset=0, length=10):
     n = lib().so_merge(mode, _p(ld, u64p), _p(ls, f32p), len(ld), _p(vd, u64p), _p(vs, f32p), len(vd), offset,
                        length, _p(od, u64p), _p(os_, f32p), _p(src, u8p))
     return od[:n].copy(), os_[:n].copy(), src[:n].copy()
+
+
+def vec_search_euclid(rows, query, k, level_clusters=None, child_count=None, n_probe=0xFFFFFFFF, cluster_threshold_raw=NO_THRESHOLD,
+                      row_doc_ids=None, threshold_raw=NO_THRESHOLD, simd_order=True, deleted=None, row_field=None, fields=()):
+    """VectorSimilarity::Euclidean, f32: score = -euclidean_f32[_avx2] (vector_similarity.rs:912 / 938); AnnMode::All when
+    level_clusters is None -> (docs, scores, total, observed rows, clusters)"""
+    rows = np.ascontiguousarray(rows, np.float32)
+    query = np.ascontiguousarray(query, np.float32)
+    lc, cc = _ann_args(rows.shape[0], level_clusters, child_count)
+    rd = None if row_doc_ids is None else np.ascontiguousarray(row_doc_ids, np.uint32)
+    od = np.empty(max(k, 1), np.uint32)
+    os_ = np.empty(max(k, 1), np.float32)
+    tot, obs, ncl = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    dl = np.unique(np.ascontiguousarray([] if deleted is None else deleted, np.uint64))
+    f = lib().so_vec_search_euclid
+    f.restype = C.c_uint32
+    f.argtypes = [f32p, C.c_uint64, C.c_uint32, u32p, f32p, C.c_uint32, C.c_float, C.c_int, C.c_uint32, u32p, u32p, C.c_uint32,
+                  C.c_float, u64p, C.c_uint64, u16p, C.c_uint64, u32p, f32p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                  C.POINTER(C.c_uint64)]
+    rf, fm = _field_args(row_field, fields)
+    n = f(_p(rows, f32p), rows.shape[0], rows.shape[1], _p(rd, u32p), _p(query, f32p), k, threshold_raw, 1 if simd_order else 0,
+          len(lc), _p(lc, u32p) if len(lc) else None, _p(cc, u32p) if len(cc) else None, n_probe, cluster_threshold_raw,
+          _p(dl, u64p) if len(dl) else None, len(dl), _p(rf, u16p), fm, _p(od, u32p), _p(os_, f32p), C.byref(tot), C.byref(obs),
+          C.byref(ncl))
+    return od[:n].copy(), os_[:n].copy(), tot.value, obs.value, ncl.value
+
+
+def vec_search_i8_euclid(rows_i8, query_i8, k, level_clusters=None, child_count=None, n_probe=0xFFFFFFFF,
+                         cluster_threshold_raw=NO_THRESHOLD, row_doc_ids=None, row_scale=None, row_norm=None, query_scale=None,
+                         query_norm=None, threshold_raw=NO_THRESHOLD, deleted=None, row_field=None, fields=()):
+    """VectorSimilarity::Euclidean, i8: -euclidean_i8 (exact), or with scales / norms -euclidean_i8_quantized
+    (vector_similarity.rs:921 / 1721)"""
+    rows = np.ascontiguousarray(rows_i8, np.int8)
+    q = np.ascontiguousarray(query_i8, np.int8)
+    lc, cc = _ann_args(rows.shape[0], level_clusters, child_count)
+    rd = None if row_doc_ids is None else np.ascontiguousarray(row_doc_ids, np.uint32)
+    rs = None if row_scale is None else np.ascontiguousarray(row_scale, np.float32)
+    rn = None if row_norm is None else np.ascontiguousarray(row_norm, np.float32)
+    quantized = row_scale is not None or query_scale is not None
+    od = np.empty(max(k, 1), np.uint32)
+    os_ = np.empty(max(k, 1), np.float32)
+    tot, obs, ncl = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    dl = np.unique(np.ascontiguousarray([] if deleted is None else deleted, np.uint64))
+    f = lib().so_vec_search_i8_euclid
+    f.restype = C.c_uint32
+    f.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, u32p, f32p, f32p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_float,
+                  C.c_uint32, u32p, u32p, C.c_uint32, C.c_float, u64p, C.c_uint64, u16p, C.c_uint64, u32p, f32p,
+                  C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    rf, fm = _field_args(row_field, fields)
+    n = f(rows.ctypes.data, rows.shape[0], rows.shape[1], _p(rd, u32p), _p(rs, f32p), _p(rn, f32p), q.ctypes.data, 1 if quantized else 0,
+          1.0 if query_scale is None else float(query_scale), 0.0 if query_norm is None else float(query_norm), k, threshold_raw,
+          len(lc), _p(lc, u32p) if len(lc) else None, _p(cc, u32p) if len(cc) else None, n_probe, cluster_threshold_raw,
+          _p(dl, u64p) if len(dl) else None, len(dl), _p(rf, u16p), fm, _p(od, u32p), _p(os_, f32p), C.byref(tot), C.byref(obs),
+          C.byref(ncl))
+    return od[:n].copy(), os_[:n].copy(), tot.value, obs.value, ncl.value
+
+
+def euclidean_f32(a, b, simd_order=True):
+    """euclidean_f32_avx2 lane order (simd_order, dim % 8 == 0) or euclidean_f32 sequential (vector_similarity.rs:938 / 912)"""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    f = lib().so_euclidean_f32_lanes8 if simd_order else lib().so_euclidean_f32
+    f.restype = C.c_float
+    f.argtypes = [f32p, f32p, C.c_uint32]
+    return float(f(_p(a, f32p), _p(b, f32p), len(a)))

@@ -794,16 +794,33 @@ static uint64_t visit_order(uint64_t n_rows, uint32_t n_levels, const uint32_t* 
   return n;
 }
 
-typedef struct { const float* rows; const float* q; uint32_t dim; int simd; } so_f32_ctx;
+/* euclidean_f32 (vector_similarity.rs:912-918): sum of (x - y).powi(2), sequential; euclidean_f32_avx2 (938-966): eight
+ * lanes of sub / mul / add over dim / 8 steps, then the lanes summed 0..7.  The similarity is MINUS this (arm at 337 / 907):
+ * larger is closer, TopK unchanged. */
+float so_euclidean_f32(const float* a, const float* b, uint32_t dim) {
+  float s = 0.0f;
+  for (uint32_t i = 0; i < dim; i++) { float d = a[i] - b[i]; s += d * d; }
+  return s;
+}
+float so_euclidean_f32_lanes8(const float* q, const float* e, uint32_t dim) {
+  float lane[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (uint32_t i = 0; i + 8 <= dim; i += 8)
+    for (uint32_t l = 0; l < 8; l++) { float d = q[i + l] - e[i + l]; float sq = d * d; lane[l] = lane[l] + sq; }
+  float s = 0.0f;
+  for (uint32_t l = 0; l < 8; l++) s += lane[l];
+  return s;
+}
+typedef struct { const float* rows; const float* q; uint32_t dim; int simd; int euclid; } so_f32_ctx;
 static float score_f32(const void* c, uint64_t r) {
   const so_f32_ctx* x = (const so_f32_ctx*)c;
   const float* e = x->rows + r * x->dim;
+  if (x->euclid) return -(x->simd ? so_euclidean_f32_lanes8(x->q, e, x->dim) : so_euclidean_f32(x->q, e, x->dim));
   return x->simd ? so_dot_f32_lanes8(x->q, e, x->dim) : so_dot_f32(x->q, e, x->dim);
 }
 uint32_t so_vec_search_del(const float* rows, uint64_t n_rows, uint32_t dim, const uint32_t* row_doc, const float* q,
                            uint32_t k, float thr, int simd_order, const uint64_t* deleted_sorted, uint64_t n_deleted,
                            uint32_t* od, float* os, uint64_t* out_total, uint64_t* out_observed) {
-  so_f32_ctx c = {rows, q, dim, simd_order};
+  so_f32_ctx c = {rows, q, dim, simd_order, 0};
   return topk_scan(n_rows, row_doc, k, thr, deleted_sorted, n_deleted, score_f32, &c, od, os, out_total, out_observed);
 }
 
@@ -821,17 +838,29 @@ int32_t so_dot_i8(const int8_t* a, const int8_t* b, uint32_t dim) {
   for (uint32_t i = 0; i < dim; i++) s += (int32_t)a[i] * (int32_t)b[i];
   return s;
 }
-typedef struct { const int8_t* rows; const int8_t* q; uint32_t dim; const float* row_scale; int scaled; float q_scale; } so_i8_ctx;
+typedef struct { const int8_t* rows; const int8_t* q; uint32_t dim; const float* row_scale; int scaled; float q_scale;
+                 int euclid; const float* row_norm; float q_norm; } so_i8_ctx;
 static float score_i8(const void* c, uint64_t r) {
   const so_i8_ctx* x = (const so_i8_ctx*)c;
-  int32_t d = so_dot_i8(x->q, x->rows + r * x->dim, x->dim);
+  const int8_t* e = x->rows + r * x->dim;
+  if (x->euclid && !x->scaled) { /* -euclidean_i8 (vector_similarity.rs:921-932): integer sum of squared differences as f32 */
+    int32_t s = 0;
+    for (uint32_t i = 0; i < x->dim; i++) { int32_t d = (int32_t)x->q[i] - (int32_t)e[i]; s += d * d; }
+    return -(float)s;
+  }
+  int32_t d = so_dot_i8(x->q, e, x->dim);
+  if (x->euclid) { /* -euclidean_i8_quantized (1721-1735): (norm1 + norm2 - 2.0 * dot).max(0.0), dot = dot_i32 as f32 * scale1 * scale2 */
+    float dot = (float)d * x->q_scale * (x->row_scale ? x->row_scale[r] : 1.0f);
+    float v = x->q_norm + (x->row_norm ? x->row_norm[r] : 0.0f) - 2.0f * dot;
+    return -(v > 0.0f ? v : 0.0f);
+  }
   if (!x->scaled) return (float)d;                                   /* dot_i8(a, b) as f32 */
   return (float)d * x->q_scale * (x->row_scale ? x->row_scale[r] : 1.0f); /* dot_i32 as f32 * scale1 * scale2 */
 }
 uint32_t so_vec_search_i8(const int8_t* rows, uint64_t n_rows, uint32_t dim, const uint32_t* row_doc, const float* row_scale,
                           const int8_t* q, int scaled, float q_scale, uint32_t k, float thr, const uint64_t* deleted_sorted,
                           uint64_t n_deleted, uint32_t* od, float* os, uint64_t* out_total, uint64_t* out_observed) {
-  so_i8_ctx c = {rows, q, dim, row_scale, scaled, q_scale};
+  so_i8_ctx c = {rows, q, dim, row_scale, scaled, q_scale, 0, NULL, 0.0f};
   return topk_scan(n_rows, row_doc, k, thr, deleted_sorted, n_deleted, score_i8, &c, od, os, out_total, out_observed);
 }
 
@@ -840,7 +869,7 @@ uint32_t so_vec_search_ann(const float* rows, uint64_t n_rows, uint32_t dim, con
                            const uint32_t* child_count, uint32_t n_probe, float cluster_thr, const uint64_t* deleted_sorted,
                            uint64_t n_deleted, const uint16_t* row_field, uint64_t field_mask, uint32_t* od, float* os,
                            uint64_t* out_total, uint64_t* out_observed, uint64_t* out_clusters) {
-  so_f32_ctx c = {rows, q, dim, simd_order};
+  so_f32_ctx c = {rows, q, dim, simd_order, 0};
   uint64_t* order = (uint64_t*)malloc((n_rows ? n_rows : 1) * sizeof(uint64_t));
   uint64_t n = visit_order(n_rows, n_levels, level_clusters, child_count, n_probe, cluster_thr, score_f32, &c, row_field,
                            field_mask, order, out_clusters);
@@ -854,7 +883,39 @@ uint32_t so_vec_search_i8_ann(const int8_t* rows, uint64_t n_rows, uint32_t dim,
                               const uint64_t* deleted_sorted, uint64_t n_deleted, const uint16_t* row_field,
                               uint64_t field_mask, uint32_t* od, float* os, uint64_t* out_total, uint64_t* out_observed,
                               uint64_t* out_clusters) {
-  so_i8_ctx c = {rows, q, dim, row_scale, scaled, q_scale};
+  so_i8_ctx c = {rows, q, dim, row_scale, scaled, q_scale, 0, NULL, 0.0f};
+  uint64_t* order = (uint64_t*)malloc((n_rows ? n_rows : 1) * sizeof(uint64_t));
+  uint64_t n = visit_order(n_rows, n_levels, level_clusters, child_count, n_probe, cluster_thr, score_i8, &c, row_field,
+                           field_mask, order, out_clusters);
+  uint32_t r = topk_scan_order(n, order, row_doc, k, thr, deleted_sorted, n_deleted, score_i8, &c, od, os, out_total, out_observed);
+  free(order);
+  return r;
+}
+
+/* VectorSimilarity::Euclidean (vector_similarity.rs:257-345, 905-907): the similarity of a record is MINUS the squared
+ * distance, so the same TopK / thresholds apply (threshold_raw = -similarity_threshold, vector.rs:398).  n_levels = 0:
+ * AnnMode::All.  f32: euclidean_f32 (sequential) or euclidean_f32_avx2 lane order.  i8: quantized != 0 ->
+ * euclidean_i8_quantized with (scale, norm) of query and records, else euclidean_i8 (exact integer). */
+uint32_t so_vec_search_euclid(const float* rows, uint64_t n_rows, uint32_t dim, const uint32_t* row_doc, const float* q,
+                              uint32_t k, float thr, int simd_order, uint32_t n_levels, const uint32_t* level_clusters,
+                              const uint32_t* child_count, uint32_t n_probe, float cluster_thr, const uint64_t* deleted_sorted,
+                              uint64_t n_deleted, const uint16_t* row_field, uint64_t field_mask, uint32_t* od, float* os,
+                              uint64_t* out_total, uint64_t* out_observed, uint64_t* out_clusters) {
+  so_f32_ctx c = {rows, q, dim, simd_order, 1};
+  uint64_t* order = (uint64_t*)malloc((n_rows ? n_rows : 1) * sizeof(uint64_t));
+  uint64_t n = visit_order(n_rows, n_levels, level_clusters, child_count, n_probe, cluster_thr, score_f32, &c, row_field,
+                           field_mask, order, out_clusters);
+  uint32_t r = topk_scan_order(n, order, row_doc, k, thr, deleted_sorted, n_deleted, score_f32, &c, od, os, out_total, out_observed);
+  free(order);
+  return r;
+}
+uint32_t so_vec_search_i8_euclid(const int8_t* rows, uint64_t n_rows, uint32_t dim, const uint32_t* row_doc, const float* row_scale,
+                                 const float* row_norm, const int8_t* q, int quantized, float q_scale, float q_norm, uint32_t k,
+                                 float thr, uint32_t n_levels, const uint32_t* level_clusters, const uint32_t* child_count,
+                                 uint32_t n_probe, float cluster_thr, const uint64_t* deleted_sorted, uint64_t n_deleted,
+                                 const uint16_t* row_field, uint64_t field_mask, uint32_t* od, float* os, uint64_t* out_total,
+                                 uint64_t* out_observed, uint64_t* out_clusters) {
+  so_i8_ctx c = {rows, q, dim, row_scale, quantized, q_scale, 1, row_norm, q_norm};
   uint64_t* order = (uint64_t*)malloc((n_rows ? n_rows : 1) * sizeof(uint64_t));
   uint64_t n = visit_order(n_rows, n_levels, level_clusters, child_count, n_probe, cluster_thr, score_i8, &c, row_field,
                            field_mask, order, out_clusters);

@@ -170,6 +170,23 @@ uint32_t so_vec_search_i8_ann(const int8_t* rows, uint64_t n_rows, uint32_t dim,
                               uint32_t n_probe, float cluster_threshold_raw, const uint64_t* deleted_sorted, uint64_t n_deleted,
                               const uint16_t* row_field, uint64_t field_mask, uint32_t* out_doc, float* out_score,
                               uint64_t* out_total, uint64_t* out_observed, uint64_t* out_clusters);
+/* VectorSimilarity::Euclidean: similarity = MINUS the squared distance (vector_similarity.rs:257-345, 905-907; euclidean_f32 912,
+ * euclidean_f32_avx2 938, euclidean_i8 921, euclidean_i8_quantized 1721); threshold_raw = -similarity_threshold (vector.rs:398) */
+float so_euclidean_f32(const float* a, const float* b, uint32_t dim);
+float so_euclidean_f32_lanes8(const float* q, const float* e, uint32_t dim);
+uint32_t so_vec_search_euclid(const float* rows, uint64_t n_rows, uint32_t dim, const uint32_t* row_doc_ids, const float* query,
+                              uint32_t k, float threshold_raw, int simd_order, uint32_t n_levels, const uint32_t* level_clusters,
+                              const uint32_t* child_count, uint32_t n_probe, float cluster_threshold_raw,
+                              const uint64_t* deleted_sorted, uint64_t n_deleted, const uint16_t* row_field, uint64_t field_mask,
+                              uint32_t* out_doc, float* out_score, uint64_t* out_total, uint64_t* out_observed,
+                              uint64_t* out_clusters);
+uint32_t so_vec_search_i8_euclid(const int8_t* rows, uint64_t n_rows, uint32_t dim, const uint32_t* row_doc_ids,
+                                 const float* row_scale, const float* row_norm, const int8_t* query, int quantized,
+                                 float query_scale, float query_norm, uint32_t k, float threshold_raw, uint32_t n_levels,
+                                 const uint32_t* level_clusters, const uint32_t* child_count, uint32_t n_probe,
+                                 float cluster_threshold_raw, const uint64_t* deleted_sorted, uint64_t n_deleted,
+                                 const uint16_t* row_field, uint64_t field_mask, uint32_t* out_doc, float* out_score,
+                                 uint64_t* out_total, uint64_t* out_observed, uint64_t* out_clusters);
 /* vector_score field: vector.rs:1495-1499 */
 float so_vector_score_field(float dot);
 /* TopK threshold transform: vector.rs:388-397 */

@@ -19,6 +19,7 @@ BM25_AUTO, BM25_EXHAUSTIVE, BM25_PRUNED = 0, 1, 2
 RT_COUNT, RT_TOPK, RT_TOPKCOUNT = 0, 1, 2
 MODE_LEXICAL, MODE_VECTOR, MODE_HYBRID = 0, 1, 2
 SRC_LEXICAL, SRC_VECTOR, SRC_HYBRID = 0, 1, 2
+SIM_DOT, SIM_EUCLIDEAN = 0, 1
 FLT_MIN_NEG = -3.4028234663852886e38
 
 u8p = C.POINTER(C.c_uint8)
@@ -111,6 +112,12 @@ SYMBOLS = [
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("ss_bm25_facet_count", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, u64p, u64p,
                                       u64p]),
+    ("ss_vec_set_similarity", C.c_int, [C.c_void_p, C.c_int]),
+    ("ss_vec_set_row_norms", C.c_int, [C.c_void_p, C.c_uint64, f32p]),
+    ("ss_vec_search_i8_euclid", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, f32p, f32p, C.c_uint32, C.c_float, C.c_void_p, u32p, f32p,
+                                          u32p, u64p, u32p]),
+    ("ss_vec_search_i8_euclid_dev", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("ss_vec_set_clusters", C.c_int, [C.c_void_p, C.c_uint32, u32p, u32p]),
     ("ss_vec_cluster_info", C.c_int, [C.c_void_p, u32p, u32p]),
     ("ss_vec_set_fields", C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),

@@ -139,11 +139,11 @@ __global__ void __launch_bounds__(256) rrf_merge_kernel(uint32_t k_lex, uint32_t
     uint8_t so = 0;
     if (i < nl) {
       d = id_at(lex_doc, (size_t)q * k_lex + i);
-      s = __fdiv_rn(1.0f, __fadd_rn(0.6f, (float)i));
+      s = __fdiv_rn(1.0f, ss_fadd(0.6f, (float)i));
       so = SS_SRC_LEXICAL;
     } else if (i < nl + nv) {
       d = id_at(vec_doc, (size_t)q * k_vec + (i - nl));
-      s = __fdiv_rn(1.0f, __fadd_rn(0.6f, (float)(i - nl)));
+      s = __fdiv_rn(1.0f, ss_fadd(0.6f, (float)(i - nl)));
       so = SS_SRC_VECTOR;
     }
     docs[i] = d; sc[i] = s; src[i] = so;
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256) rrf_merge_kernel(uint32_t k_lex, uint32_t
     const u64 d = docs[nl + j];
     for (uint32_t i = 0; i < nl; i++) {
       if (docs[i] == d) {
-        sc[i] = __fadd_rn(sc[i], sc[nl + j]);
+        sc[i] = ss_fadd(sc[i], sc[nl + j]);
         src[i] = SS_SRC_HYBRID;
         docs[nl + j] = ~0ull;
         sc[nl + j] = -INFINITY;

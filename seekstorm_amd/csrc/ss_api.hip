@@ -74,9 +74,10 @@ int ss_shard_create(int device, ss_shard** out) {
 }
 
 static void free_vec(ss_shard* s) {
-  void* ptrs[] = {s->d_X, s->d_X8, s->d_row_scale, s->d_row_doc, s->d_Qf, s->d_vstate, s->d_cand, s->d_row_field};
+  void* ptrs[] = {s->d_X, s->d_X8, s->d_row_scale, s->d_row_doc, s->d_Qf, s->d_vstate, s->d_cand, s->d_row_field, s->d_row_norm, s->d_row_sq, s->d_qaux};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->d_X = nullptr; s->d_X8 = nullptr; s->d_row_scale = nullptr; s->d_row_doc = nullptr; s->d_Qf = nullptr;
+  s->d_row_norm = nullptr; s->d_row_sq = nullptr; s->d_qaux = nullptr;
   s->d_vstate = nullptr; s->d_cand = nullptr; s->d_row_field = nullptr;
   s->n_rows = s->n_rows_pad = 0; s->dim = s->dim_pad = s->dim_pad8 = 0; s->vec_multi_record = false;
   ssi_vec_free_clusters(s);
@@ -526,11 +527,24 @@ int ss_bm25_search_filtered_dev(ss_shard* s, uint32_t nq, const ss_bm25_query* d
 }
 
 // ------------------------------------------------------------------ vectors
+// end of every vector-image build: the Euclidean side data (f32: the two augmented columns; i8: the records' sums of
+// squares), then the per-batch workspace
+static int vec_finish(ss_shard* s) {
+  if (s->vec_similarity == SS_SIM_EUCLIDEAN) {
+    int rc = s->d_X ? ssi_vec_augment(s, s->stream) : ssi_vec8_row_sq(s, s->stream);
+    if (rc) return rc;
+    SS_HIP(hipStreamSynchronize(s->stream));
+  }
+  return ssi_vec_alloc_ws(s);
+}
+
 static int vec_alloc(ss_shard* s, uint64_t n_rows, uint32_t dim) {
   free_vec(s);
   s->n_rows = n_rows;
   s->dim = dim;
-  s->dim_pad = (dim + VS_KC - 1) / VS_KC * VS_KC;
+  // Euclidean: the scan computes -|q - x|^2 as the dot product of [x, |x|^2, 1] with [2 q, -1, -|q|^2] -- two more columns
+  const uint32_t dim_img = dim + (s->vec_similarity == SS_SIM_EUCLIDEAN ? 2u : 0u);
+  s->dim_pad = (dim_img + VS_KC - 1) / VS_KC * VS_KC;
   s->n_rows_pad = (n_rows + VS_TR - 1) / VS_TR * VS_TR;
   const size_t bytes = (size_t)s->n_rows_pad * s->dim_pad * sizeof(float);
   SS_HIP(hipMalloc(&s->d_X, bytes));
@@ -564,7 +578,7 @@ int ss_vec_upload(ss_shard* s, uint64_t n_rows, uint32_t dim, const float* rows,
     SS_HIP(hipMemcpyAsync(s->d_row_doc, row_doc_ids, n_rows * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
   }
   SS_HIP(hipStreamSynchronize(s->stream));
-  return ssi_vec_alloc_ws(s);
+  return vec_finish(s);
 }
 
 // vector.bin (writer vector.rs:1066-1094, reader 1279-1298): per level u32 cluster_count, cluster_count x u32 child_count,
@@ -582,7 +596,7 @@ static int vec_bin_upload(ss_shard* s, const uint8_t* bytes, uint64_t len, uint3
   std::vector<Lvl> levels;
   std::vector<uint32_t> ids, level_clusters, child_counts;
   std::vector<uint16_t> fields;  // VectorHeader.field_id (u32 at byte 2); the reference compares it as u16 (vector.rs:1398)
-  std::vector<float> scales;
+  std::vector<float> scales, norms;
   uint64_t pos = 0;
   while (pos < len) {
     if (pos + 4 > len) return SS_EINVAL;
@@ -611,6 +625,8 @@ static int vec_bin_upload(ss_shard* s, const uint8_t* bytes, uint64_t len, uint3
         float sc;
         memcpy(&sc, bytes + pos + r * rec + 10, 4);
         scales.push_back(sc);
+        memcpy(&sc, bytes + pos + r * rec + 14, 4);  // VectorHeader.norm: euclidean_i8_quantized
+        norms.push_back(sc);
       }
     }
     levels.push_back({pos, n});
@@ -647,6 +663,8 @@ static int vec_bin_upload(ss_shard* s, const uint8_t* bytes, uint64_t len, uint3
     if (use_scale) {
       SS_HIP(hipMalloc(&s->d_row_scale, n_rows * sizeof(float)));
       SS_HIP(hipMemcpyAsync(s->d_row_scale, scales.data(), n_rows * sizeof(float), hipMemcpyHostToDevice, s->stream));
+      SS_HIP(hipMalloc(&s->d_row_norm, n_rows * sizeof(float)));
+      SS_HIP(hipMemcpyAsync(s->d_row_norm, norms.data(), n_rows * sizeof(float), hipMemcpyHostToDevice, s->stream));
     }
   }
   s->vec_multi_record = multi;
@@ -657,7 +675,7 @@ static int vec_bin_upload(ss_shard* s, const uint8_t* bytes, uint64_t len, uint3
   SS_HIP(hipStreamSynchronize(s->stream));
   rc = ssi_vec_set_clusters(s, (uint32_t)level_clusters.size(), level_clusters.data(), child_counts.data());
   if (rc != SS_OK && rc != SS_ENOTSUP) { free_vec(s); return rc; }  // ENOTSUP (an empty cluster): AnnMode::All only
-  return ssi_vec_alloc_ws(s);
+  return vec_finish(s);
 }
 
 int ss_vec_upload_vector_bin(ss_shard* s, const uint8_t* bytes, uint64_t len, uint32_t dim) {
@@ -678,7 +696,7 @@ int ss_vec_synth(ss_shard* s, uint64_t seed, uint64_t n_rows, uint32_t dim) {
   if (rc) { free_vec(s); return rc; }
   SS_TRY(ssi_vec_synth(s, seed, s->stream));
   SS_HIP(hipStreamSynchronize(s->stream));
-  return ssi_vec_alloc_ws(s);
+  return vec_finish(s);
 }
 
 int ss_vec_info(ss_shard* s, uint64_t* n_rows, uint32_t* dim) {
@@ -705,22 +723,25 @@ int ss_vec_read_rows(ss_shard* s, uint64_t r0, uint64_t n, float* out) {
 // (observed_cluster_count, ANN modes) rides behind them
 static int vec_search_host(ss_shard* s, uint32_t nq, const void* queries, size_t elem, const float* query_scale, uint32_t k,
                            float thr, const ss_ann_mode* mode, uint32_t* out_doc, float* out_score, uint32_t* out_count,
-                           uint64_t* out_total, uint32_t* out_clusters) {
+                           uint64_t* out_total, uint32_t* out_clusters, const float* query_norm = nullptr) {
   if (nq == 0) return SS_OK;
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   SS_TRY(ensure_out(s, nq, k));
   const size_t qbytes = ((size_t)nq * s->dim * elem + 15) & ~(size_t)15;
   const size_t sbytes = query_scale ? (size_t)nq * sizeof(float) : 0;
-  SS_TRY(ensure_qstage(s, qbytes + sbytes + (out_clusters ? (size_t)nq * sizeof(uint32_t) : 0)));
+  const size_t nbytes = query_norm ? (size_t)nq * sizeof(float) : 0;
+  SS_TRY(ensure_qstage(s, qbytes + sbytes + nbytes + (out_clusters ? (size_t)nq * sizeof(uint32_t) : 0)));
   float* d_qs = query_scale ? (float*)((char*)s->d_qstage + qbytes) : nullptr;
-  uint32_t* d_ncl = out_clusters ? (uint32_t*)((char*)s->d_qstage + qbytes + sbytes) : nullptr;
+  float* d_qn = query_norm ? (float*)((char*)s->d_qstage + qbytes + sbytes) : nullptr;
+  uint32_t* d_ncl = out_clusters ? (uint32_t*)((char*)s->d_qstage + qbytes + sbytes + nbytes) : nullptr;
   int rc = SS_OK;
   for (int attempt = 0; attempt < 2; attempt++) {
     if (hipMemcpyAsync(s->d_qstage, queries, (size_t)nq * s->dim * elem, hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = SS_EDEVICE; break; }
     if (d_qs && hipMemcpyAsync(d_qs, query_scale, sbytes, hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = SS_EDEVICE; break; }
+    if (d_qn && hipMemcpyAsync(d_qn, query_norm, nbytes, hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = SS_EDEVICE; break; }
     rc = ssi_vec_search(s, nq, s->d_qstage, d_qs, k, thr, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->stream,
-                        attempt == 1, mode, d_ncl);
+                        attempt == 1, mode, d_ncl, d_qn);
     if (rc) break;
     if (hipMemcpyAsync(out_count, s->d_out_count, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
         hipStreamSynchronize(s->stream) != hipSuccess) { rc = SS_EDEVICE; break; }
@@ -781,6 +802,26 @@ int ss_vec_search_ann_dev(ss_shard* s, uint32_t nq, const float* d_queries, uint
 int ss_vec_search_dev(ss_shard* s, uint32_t nq, const float* d_queries, uint32_t k, float thr, uint32_t* d_out_doc,
                       float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, void* stream) {
   return ss_vec_search_ann_dev(s, nq, d_queries, k, thr, nullptr, d_out_doc, d_out_score, d_out_count, d_out_total, nullptr, stream);
+}
+
+// ---- VectorSimilarity of the image (vector_similarity.rs:118-345): must precede the upload (layout of the f32 image)
+int ss_vec_set_similarity(ss_shard* s, int similarity) {
+  if (!s || (similarity != SS_SIM_DOT && similarity != SS_SIM_EUCLIDEAN)) return SS_EINVAL;
+  std::lock_guard<std::mutex> g(s->mu);
+  if ((s->d_X || s->d_X8) && similarity != s->vec_similarity) return SS_ESTATE;
+  s->vec_similarity = similarity;
+  return SS_OK;
+}
+int ss_vec_set_row_norms(ss_shard* s, uint64_t n_rows, const float* row_norm) {
+  if (!s || !row_norm) return SS_EINVAL;
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  if (!s->d_X8) return SS_ESTATE;
+  if (n_rows != s->n_rows) return SS_EINVAL;
+  SS_HIP(hipStreamSynchronize(s->stream));
+  if (!s->d_row_norm) SS_HIP(hipMalloc(&s->d_row_norm, n_rows * sizeof(float)));
+  SS_HIP(hipMemcpy(s->d_row_norm, row_norm, n_rows * sizeof(float), hipMemcpyHostToDevice));
+  return SS_OK;
 }
 
 // ---- cluster structure of the vector image (ANN modes, vec_ann.hip)
@@ -861,7 +902,7 @@ int ss_vec_upload_i8(ss_shard* s, uint64_t n_rows, uint32_t dim, const int8_t* r
     SS_HIP(hipMemcpyAsync(s->d_row_doc, row_doc_ids, n_rows * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
   }
   SS_HIP(hipStreamSynchronize(s->stream));
-  return ssi_vec_alloc_ws(s);
+  return vec_finish(s);
 }
 
 // bench / test utility: the synthetic f32 corpus of ss_vec_synth quantised on the device with quantize_f32_to_i8
@@ -887,7 +928,7 @@ int ss_vec_synth_i8(ss_shard* s, uint64_t seed, uint64_t n_rows, uint32_t dim) {
   s->d_X = nullptr;
   s->dim_pad = 0;
   if (rc) { free_vec(s); return rc; }
-  return ssi_vec_alloc_ws(s);
+  return vec_finish(s);
 }
 
 int ss_vec_read_rows_i8(ss_shard* s, uint64_t r0, uint64_t n, int8_t* out) {
@@ -907,16 +948,21 @@ int ss_vec_read_rows_i8(ss_shard* s, uint64_t r0, uint64_t n, int8_t* out) {
   return rc;
 }
 
-int ss_vec_search_i8_ann(ss_shard* s, uint32_t nq, const int8_t* queries, const float* query_scale, uint32_t k, float thr,
-                         const ss_ann_mode* mode, uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total,
-                         uint32_t* out_clusters) {
+int ss_vec_search_i8_euclid(ss_shard* s, uint32_t nq, const int8_t* queries, const float* query_scale, const float* query_norm,
+                            uint32_t k, float thr, const ss_ann_mode* mode, uint32_t* out_doc, float* out_score, uint32_t* out_count,
+                            uint64_t* out_total, uint32_t* out_clusters) {
   if (!s || !queries || !out_doc || !out_score || !out_count || !out_total) return SS_EINVAL;
   if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
   if (!s->d_X8) return SS_ESTATE;
   SS_TRY(ann_mode_ok(s, mode));
   mode = ann_effective(mode);
   return vec_search_host(s, nq, queries, 1, query_scale, k, thr, mode, out_doc, out_score, out_count, out_total,
-                         mode ? out_clusters : nullptr);
+                         mode ? out_clusters : nullptr, query_norm);
+}
+int ss_vec_search_i8_ann(ss_shard* s, uint32_t nq, const int8_t* queries, const float* query_scale, uint32_t k, float thr,
+                         const ss_ann_mode* mode, uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total,
+                         uint32_t* out_clusters) {
+  return ss_vec_search_i8_euclid(s, nq, queries, query_scale, nullptr, k, thr, mode, out_doc, out_score, out_count, out_total, out_clusters);
 }
 int ss_vec_search_i8(ss_shard* s, uint32_t nq, const int8_t* queries, const float* query_scale, uint32_t k, float thr,
                      uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total) {
@@ -926,6 +972,12 @@ int ss_vec_search_i8(ss_shard* s, uint32_t nq, const int8_t* queries, const floa
 int ss_vec_search_i8_ann_dev(ss_shard* s, uint32_t nq, const int8_t* d_queries, const float* d_query_scale, uint32_t k, float thr,
                              const ss_ann_mode* mode, uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count,
                              uint64_t* d_out_total, uint32_t* d_out_clusters, void* stream) {
+  return ss_vec_search_i8_euclid_dev(s, nq, d_queries, d_query_scale, nullptr, k, thr, mode, d_out_doc, d_out_score, d_out_count,
+                                     d_out_total, d_out_clusters, stream);
+}
+int ss_vec_search_i8_euclid_dev(ss_shard* s, uint32_t nq, const int8_t* d_queries, const float* d_query_scale, const float* d_query_norm,
+                                uint32_t k, float thr, const ss_ann_mode* mode, uint32_t* d_out_doc, float* d_out_score,
+                                uint32_t* d_out_count, uint64_t* d_out_total, uint32_t* d_out_clusters, void* stream) {
   if (!s || !d_queries || !d_out_doc || !d_out_score || !d_out_count || !d_out_total) return SS_EINVAL;
   if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
   if (!s->d_X8) return SS_ESTATE;
@@ -935,7 +987,7 @@ int ss_vec_search_i8_ann_dev(ss_shard* s, uint32_t nq, const int8_t* d_queries, 
   SS_HIP(hipSetDevice(s->device));
   hipStream_t st = stream ? (hipStream_t)stream : s->stream;
   return ssi_vec_search(s, nq, d_queries, d_query_scale, k, thr, d_out_doc, d_out_score, d_out_count, d_out_total, st, false, mode,
-                        mode ? d_out_clusters : nullptr);
+                        mode ? d_out_clusters : nullptr, d_query_norm);
 }
 int ss_vec_search_i8_dev(ss_shard* s, uint32_t nq, const int8_t* d_queries, const float* d_query_scale, uint32_t k, float thr,
                          uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, void* stream) {

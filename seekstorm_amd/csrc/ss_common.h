@@ -22,6 +22,22 @@ constexpr uint32_t VS_CAP = 8192;           // candidate slots per query
 constexpr int VS_FIRST_TILES = 16;          // first chunk: 2048 rows, everything is a candidate (64 tiles: the 8192-entry
                                             // refine after it costs more than the launch it saves)
 
+// f32 operations rounded ON THEIR OWN, as the reference (Rust never contracts a * b + c) computes them.  HIP's __fmul_rn /
+// __fadd_rn are plain `*` / `+` and the default -ffp-contract=fast fuses them into an fma; an operation emitted under
+// contract(off) carries no `contract` flag and stays unfused after inlining.
+__device__ __forceinline__ float ss_fmul(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float ss_fadd(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float ss_fsub(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+
 // SmallFloat decode (DOCUMENT_LENGTH_COMPRESSION[b]), index.rs:4255-4268
 __host__ __device__ inline uint32_t ss_byte4_to_int(uint32_t b) {
   if (b < 24u) return b;
@@ -95,6 +111,10 @@ struct ss_shard {
   float* d_X = nullptr;          // [n_rows_pad][dim_pad]   (f32 image)
   int8_t* d_X8 = nullptr;        // i8 image (quantised embeddings) in MFMA fragment order, vec8_scan.hip v8_index; one of the two is set
   float* d_row_scale = nullptr;  // i8 image: per-record scale (VectorHeader.scale) for dot_i8_quantized, null = raw integer dot
+  float* d_row_norm = nullptr;   // i8 image, Euclidean + ScalarQuantizationI8: per-record norm (VectorHeader.norm), euclidean_i8_quantized
+  int32_t* d_row_sq = nullptr;   // i8 image, Euclidean without scales: sum of squares of every record (euclidean_i8 as dot products)
+  float* d_qaux = nullptr;       // [2][64] per-query side values of the batch in flight (i8 Euclidean: norm | sum of squares)
+  int vec_similarity = SS_SIM_DOT;  // ss_vec_set_similarity: Dot / Cosine (dot product) or Euclidean (minus the squared distance)
   uint32_t dim_pad8 = 0;         // row stride of the i8 image in bytes (multiple of 128)
   uint32_t* d_row_doc = nullptr; // optional row -> doc id
   uint16_t* d_row_field = nullptr; // optional row -> indexed field id (VectorHeader.field_id): field_filter
@@ -192,12 +212,17 @@ struct ss_shard {
 // ---- implemented in vec_scan.hip
 // d_queries: f32 [nq][dim] for the f32 image, i8 [nq][dim] for the i8 image (d_qscale: per-query scale or null)
 // ann_mode: null = AnnMode::All; d_out_clusters: null or [nq] observed_cluster_count
+// d_qnorm: i8 Euclidean with quantisation scales: per-query norm (QuantizedVector.norm), else null
 int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float* d_qscale, uint32_t k, float thr,
                    uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, hipStream_t st,
-                   bool safe_mode, const ss_ann_mode* ann_mode = nullptr, uint32_t* d_out_clusters = nullptr);
+                   bool safe_mode, const ss_ann_mode* ann_mode = nullptr, uint32_t* d_out_clusters = nullptr,
+                   const float* d_qnorm = nullptr);
+int ssi_vec_augment(ss_shard* s, hipStream_t st);   // f32 Euclidean image: columns dim, dim + 1 = |x|^2, 1
+int ssi_vec8_row_sq(ss_shard* s, hipStream_t st);   // i8 Euclidean image without scales: d_row_sq
 struct VAnn;
 int ssi_vec8_qprep(ss_shard* s, const int8_t* d_queries, uint32_t nb, hipStream_t st);
 int ssi_vec8_launch_scan(ss_shard* s, uint32_t tile0, uint32_t ntiles, const float* d_qscale, const VAnn* ann, hipStream_t st);
+int ssi_vec8_qaux(ss_shard* s, const int8_t* d_queries, uint32_t nb, const float* d_qnorm, hipStream_t st);
 int ssi_bm25_match_bits(ss_shard* s, const ss_bm25_query* d_q, unsigned long long* d_bits, unsigned long long* d_total, hipStream_t st);
 // facet histogram over a match bitmap: d_counts [n_buckets + 1] (last = values outside the buckets)
 int ssi_facet_count(ss_shard* s, const unsigned long long* d_bits, uint64_t n_docs, uint32_t offset, uint32_t type, uint32_t n_buckets,
@@ -207,7 +232,7 @@ int ssi_facet_build(ss_shard* s, uint32_t n_filters, const ss_facet_filter* filt
 // ---- implemented in vec_ann.hip
 // after the batch's queries are in s->d_Qf (qprep): medoid scores, per-query selection, tile list -> *out
 int ssi_vec_ann_prepare(ss_shard* s, uint32_t nb, const float* d_qscale, const ss_ann_mode* mode, VAnn* out,
-                        uint32_t* d_out_clusters, hipStream_t st);
+                        uint32_t* d_out_clusters, hipStream_t st, const float* d_qnorm = nullptr);
 int ssi_vec_set_clusters(ss_shard* s, uint32_t n_levels, const uint32_t* level_clusters, const uint32_t* child_count);
 void ssi_vec_free_clusters(ss_shard* s);
 int ssi_vec8_quantize(ss_shard* s, hipStream_t st);

@@ -32,13 +32,13 @@ __global__ void vec_synth_kernel(float* __restrict__ X, u64 seed, u64 n_rows, ui
   float s = 0.f;
   for (uint32_t c = 0; c < dim; c++) {
     int iv = (int)(uint32_t)(ss_h(seed, r, c) >> 32);
-    float v = __fmul_rn((float)iv, 4.656612873077392578125e-10f);
-    s = __fadd_rn(s, __fmul_rn(v, v));
+    float v = ss_fmul((float)iv, 4.656612873077392578125e-10f);
+    s = ss_fadd(s, ss_fmul(v, v));
   }
   float f = __fdiv_rn(1.0f, __fsqrt_rn(s));
   for (uint32_t c = 0; c < dim; c++) {
     int iv = (int)(uint32_t)(ss_h(seed, r, c) >> 32);
-    row[c] = __fmul_rn(__fmul_rn((float)iv, 4.656612873077392578125e-10f), f);
+    row[c] = ss_fmul(ss_fmul((float)iv, 4.656612873077392578125e-10f), f);
   }
 }
 

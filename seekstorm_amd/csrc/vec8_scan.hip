@@ -69,6 +69,35 @@ __global__ void vec8_quantize_kernel(const float* __restrict__ X, uint32_t dim, 
   }
 }
 
+// ---- VectorSimilarity::Euclidean on i8 records (the SCALED instantiation carries it; mode 0 = dot product)
+//   mode 1  -euclidean_i8 (vector_similarity.rs:921-932): -(sum (a - b)^2) = -(|a|^2 + |b|^2 - 2 a.b), all exact integers
+//   mode 2  -euclidean_i8_quantized (1721-1735): -max(0, norm1 + norm2 - 2 * (dot_i32 as f32 * scale1 * scale2)), every
+//           operation rounded on its own in the reference's order
+// qaux: [0..63] the queries' norms (mode 2), [64..127] their sums of squares as i32 bits (mode 1)
+struct V8Euc {
+  int mode;
+  const float* row_norm;
+  const int32_t* row_sq;
+  const float* qaux;
+};
+__global__ void vec8_row_sq_kernel(const int8_t* __restrict__ X8, uint32_t dim, uint32_t dim_pad8, unsigned long long n_rows,
+                                   int32_t* __restrict__ row_sq) {
+  const unsigned long long r = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  int32_t ss = 0;
+  for (uint32_t c = 0; c < dim; c++) { const int32_t v = X8[v8_index(r, c, dim_pad8 / 128u)]; ss += v * v; }
+  row_sq[r] = ss;
+}
+__global__ void vec8_qaux_kernel(const int8_t* __restrict__ Q, uint32_t nq, uint32_t dim, const float* __restrict__ q_norm,
+                                 float* __restrict__ qaux) {
+  const uint32_t q = threadIdx.x;
+  if (q >= 64) return;
+  int32_t ss = 0;
+  if (q < nq) for (uint32_t c = 0; c < dim; c++) { const int32_t v = Q[(size_t)q * dim + c]; ss += v * v; }
+  qaux[q] = (q < nq && q_norm) ? q_norm[q] : 0.f;
+  qaux[64 + q] = __int_as_float(ss);
+}
+
 // EVEN: the number of lines per row is a multiple of the ring depth -> the steady state has no conditional loads (the
 // compiler's s_waitcnt insertion then counts the ring exactly instead of draining it with vmcnt(0) at every merge)
 // ANN: the launch walks the batch's list of selected tiles and admits a row only for the queries that selected its cluster
@@ -76,7 +105,8 @@ template <bool SCALED, bool EVEN, bool ANN>
 __global__ void __launch_bounds__(V8_WAVES * 64, 3)
 vec8_scan_kernel(const int8_t* __restrict__ X, uint32_t dim_pad, unsigned long long n_rows, const int8_t* __restrict__ Qf8,
                  uint32_t L, uint32_t tile0, uint32_t ntiles, const float* __restrict__ row_scale,
-                 const float* __restrict__ q_scale, VState* __restrict__ st, unsigned long long* __restrict__ cand, VAnn ann) {
+                 const float* __restrict__ q_scale, VState* __restrict__ st, unsigned long long* __restrict__ cand, VAnn ann,
+                 V8Euc euc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -98,6 +128,12 @@ vec8_scan_kernel(const int8_t* __restrict__ X, uint32_t dim_pad, unsigned long l
   }
   float qs0 = 1.f, qs1 = 1.f;
   if (SCALED && q_scale) { qs0 = q_scale[lane & 31]; qs1 = q_scale[32 + (lane & 31)]; }
+  float qn0 = 0.f, qn1 = 0.f;
+  int qq0 = 0, qq1 = 0;
+  if (SCALED && euc.mode) {
+    qn0 = euc.qaux[lane & 31]; qn1 = euc.qaux[32 + (lane & 31)];
+    qq0 = __float_as_int(euc.qaux[64 + (lane & 31)]); qq1 = __float_as_int(euc.qaux[96 + (lane & 31)]);
+  }
   __syncthreads();
 
   if (ANN && ann.tiles) {
@@ -158,8 +194,19 @@ vec8_scan_kernel(const int8_t* __restrict__ X, uint32_t dim_pad, unsigned long l
           if (SCALED) {  // dot_i8_quantized: dot as f32 * scale1 (query) * scale2 (embedding)
             const unsigned long long row = row_base + (r & 3) + 8 * (r >> 2);
             const float es = (row_scale && row < n_rows) ? row_scale[row] : 1.f;
-            f0[r] = f0[r] * qs0 * es;
-            f1[r] = f1[r] * qs1 * es;
+            if (euc.mode == 1) {  // exact integers
+              const int rs = row < n_rows ? euc.row_sq[row] : 0;
+              f0[r] = -(float)(qq0 + rs - 2 * acc0[r]);
+              f1[r] = -(float)(qq1 + rs - 2 * acc1[r]);
+            } else if (euc.mode == 2) {
+              const float rn = (euc.row_norm && row < n_rows) ? euc.row_norm[row] : 0.f;
+              const float d0 = ss_fmul(ss_fmul(f0[r], qs0), es), d1 = ss_fmul(ss_fmul(f1[r], qs1), es);
+              f0[r] = -fmaxf(ss_fsub(ss_fadd(qn0, rn), ss_fmul(2.0f, d0)), 0.0f);
+              f1[r] = -fmaxf(ss_fsub(ss_fadd(qn1, rn), ss_fmul(2.0f, d1)), 0.0f);
+            } else {
+              f0[r] = f0[r] * qs0 * es;
+              f1[r] = f1[r] * qs1 * es;
+            }
           }
         }
         float m0 = f0[0], m1 = f1[0];
@@ -186,6 +233,28 @@ int ssi_vec8_qprep(ss_shard* s, const int8_t* d_queries, uint32_t nb, hipStream_
   vec8_qprep_kernel<<<s->dim_pad8 / V8_LINE, 512, 0, st>>>(d_queries, nb, s->dim, (int8_t*)s->d_Qf);
   return SS_OK;
 }
+int ssi_vec8_qaux(ss_shard* s, const int8_t* d_queries, uint32_t nb, const float* d_qnorm, hipStream_t st) {
+  if (!s->d_qaux) SS_HIP(hipMalloc(&s->d_qaux, 128 * sizeof(float)));
+  vec8_qaux_kernel<<<1, 64, 0, st>>>(d_queries, nb, s->dim, d_qnorm, s->d_qaux);
+  return SS_OK;
+}
+int ssi_vec8_row_sq(ss_shard* s, hipStream_t st) {
+  if (!s->d_X8) return SS_ESTATE;
+  if (!s->d_row_sq) SS_HIP(hipMalloc(&s->d_row_sq, (size_t)s->n_rows * sizeof(int32_t)));
+  vec8_row_sq_kernel<<<(unsigned)((s->n_rows + 255) / 256), 256, 0, st>>>(s->d_X8, s->dim, s->dim_pad8, (unsigned long long)s->n_rows, s->d_row_sq);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+// Euclidean sub-mode of the image in flight: quantised (scales / norms present) or plain integer
+static V8Euc v8_euc(const ss_shard* s, const float* d_qscale) {
+  V8Euc e{0, nullptr, nullptr, nullptr};
+  if (s->vec_similarity != SS_SIM_EUCLIDEAN) return e;
+  e.mode = (s->d_row_scale || d_qscale) ? 2 : 1;
+  e.row_norm = s->d_row_norm;
+  e.row_sq = s->d_row_sq;
+  e.qaux = s->d_qaux;
+  return e;
+}
 
 template <bool SCALED, bool EVEN, bool ANN>
 static int launch_vec8(ss_shard* s, uint32_t tile0, uint32_t ntiles, const float* d_qscale, const VAnn& ann, hipStream_t st) {
@@ -196,13 +265,13 @@ static int launch_vec8(ss_shard* s, uint32_t tile0, uint32_t ntiles, const float
   SS_SET_MAX_LDS((vec8_scan_kernel<SCALED, EVEN, ANN>), 160 * 1024);
   vec8_scan_kernel<SCALED, EVEN, ANN><<<grid, V8_WAVES * 64, L * 8192u, st>>>(
       s->d_X8, s->dim_pad8, (unsigned long long)s->n_rows, (const int8_t*)s->d_Qf, L, tile0, ntiles, s->d_row_scale, d_qscale,
-      (VState*)s->d_vstate, (unsigned long long*)s->d_cand, ann);
+      (VState*)s->d_vstate, (unsigned long long*)s->d_cand, ann, v8_euc(s, d_qscale));
   return SS_OK;
 }
 
 template <bool ANN>
 static int launch_vec8_ann(ss_shard* s, uint32_t tile0, uint32_t ntiles, const float* d_qscale, const VAnn& ann, hipStream_t st) {
-  const bool scaled = s->d_row_scale != nullptr || d_qscale != nullptr;
+  const bool scaled = s->d_row_scale != nullptr || d_qscale != nullptr || s->vec_similarity == SS_SIM_EUCLIDEAN;
   const bool even = (s->dim_pad8 / V8_LINE) % V8_D == 0;
   if (scaled) return even ? launch_vec8<true, true, ANN>(s, tile0, ntiles, d_qscale, ann, st) : launch_vec8<true, false, ANN>(s, tile0, ntiles, d_qscale, ann, st);
   return even ? launch_vec8<false, true, ANN>(s, tile0, ntiles, d_qscale, ann, st) : launch_vec8<false, false, ANN>(s, tile0, ntiles, d_qscale, ann, st);

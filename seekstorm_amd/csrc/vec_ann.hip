@@ -59,8 +59,11 @@ __global__ void ann_gather_medoids_i8_kernel(const int8_t* __restrict__ X8, uint
 }
 
 // thread = cluster, blockIdx.y = group of AQ queries
+// euclid: Qf holds [2 q, -1, -|q|^2] (vec_qprep_kernel): q = 0.5 * Qf exactly, and the medoid's similarity is
+// -euclidean_f32_avx2 / -euclidean_f32 (vector_similarity.rs:938-966 / 912-918): sub, mul, add each rounded on its own
 __global__ void __launch_bounds__(64) ann_medoid_f32_kernel(const float* __restrict__ Mt, uint32_t dim, uint32_t nc,
-                                                           const float* __restrict__ Qf, uint32_t nq, float* __restrict__ score) {
+                                                           const float* __restrict__ Qf, uint32_t nq, float* __restrict__ score,
+                                                           int euclid) {
   const uint32_t c = blockIdx.x * 64u + threadIdx.x;
   const uint32_t q0 = blockIdx.y * AQ;
   const float* x = Mt + (size_t)(c < nc ? c : nc - 1) * 8u;  // element k at x[(k / 8) * nc * 8 + k % 8]
@@ -78,18 +81,28 @@ __global__ void __launch_bounds__(64) ann_medoid_f32_kernel(const float* __restr
 #pragma unroll
       for (int a = 0; a < AQ; a++) {
         const float4 qa = *(const float4*)(Qf + qf_off(q0 + a, k)), qb = *(const float4*)(Qf + qf_off(q0 + a, k + 4));
-        l[a][0] = fmaf(qa.x, xa.x, l[a][0]); l[a][1] = fmaf(qa.y, xa.y, l[a][1]);
-        l[a][2] = fmaf(qa.z, xa.z, l[a][2]); l[a][3] = fmaf(qa.w, xa.w, l[a][3]);
-        l[a][4] = fmaf(qb.x, xb.x, l[a][4]); l[a][5] = fmaf(qb.y, xb.y, l[a][5]);
-        l[a][6] = fmaf(qb.z, xb.z, l[a][6]); l[a][7] = fmaf(qb.w, xb.w, l[a][7]);
+        if (euclid) {
+          const float qv[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+          const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const float d = ss_fsub(0.5f * qv[j], xv[j]);
+            l[a][j] = ss_fadd(l[a][j], ss_fmul(d, d));
+          }
+        } else {
+          l[a][0] = fmaf(qa.x, xa.x, l[a][0]); l[a][1] = fmaf(qa.y, xa.y, l[a][1]);
+          l[a][2] = fmaf(qa.z, xa.z, l[a][2]); l[a][3] = fmaf(qa.w, xa.w, l[a][3]);
+          l[a][4] = fmaf(qb.x, xb.x, l[a][4]); l[a][5] = fmaf(qb.y, xb.y, l[a][5]);
+          l[a][6] = fmaf(qb.z, xb.z, l[a][6]); l[a][7] = fmaf(qb.w, xb.w, l[a][7]);
+        }
       }
     }
 #pragma unroll
     for (int a = 0; a < AQ; a++) {
       float t = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; j++) t = __fadd_rn(t, l[a][j]);
-      s[a] = t;
+      for (int j = 0; j < 8; j++) t = ss_fadd(t, l[a][j]);
+      s[a] = euclid ? -t : t;
     }
   } else {  // dot_f32: sequential, product and sum rounded separately
 #pragma unroll
@@ -97,8 +110,15 @@ __global__ void __launch_bounds__(64) ann_medoid_f32_kernel(const float* __restr
     for (uint32_t k = 0; k < dim; k++) {
       const float xv = x[(k >> 3) * xs + (k & 7u)];
 #pragma unroll
-      for (int a = 0; a < AQ; a++) s[a] = __fadd_rn(s[a], __fmul_rn(Qf[qf_off(q0 + a, k & ~3u) + (k & 3u)], xv));
+      for (int a = 0; a < AQ; a++) {
+        const float qv = Qf[qf_off(q0 + a, k & ~3u) + (k & 3u)];
+        if (euclid) { const float d = ss_fsub(0.5f * qv, xv); s[a] = ss_fadd(s[a], ss_fmul(d, d)); }
+        else s[a] = ss_fadd(s[a], ss_fmul(qv, xv));
+      }
     }
+    if (euclid)
+#pragma unroll
+      for (int a = 0; a < AQ; a++) s[a] = -s[a];
   }
   if (c < nc)
 #pragma unroll
@@ -110,7 +130,9 @@ __global__ void __launch_bounds__(64) ann_medoid_i8_kernel(const int8_t* __restr
                                                           const uint32_t* __restrict__ cluster_first, uint32_t nc,
                                                           const int8_t* __restrict__ Qf8, uint32_t nq,
                                                           const float* __restrict__ row_scale, const float* __restrict__ q_scale,
-                                                          int scaled, float* __restrict__ score) {
+                                                          int scaled, float* __restrict__ score, int euc_mode,
+                                                          const float* __restrict__ row_norm, const int32_t* __restrict__ row_sq,
+                                                          const float* __restrict__ qaux) {
   const uint32_t c = blockIdx.x * 64u + threadIdx.x;
   const uint32_t q0 = blockIdx.y * AQ;
   const uint32_t cc = c < nc ? c : nc - 1;
@@ -138,7 +160,11 @@ __global__ void __launch_bounds__(64) ann_medoid_i8_kernel(const int8_t* __restr
     for (int a = 0; a < AQ; a++)
       if (q0 + a < nq) {
         float f = (float)acc[a];
-        if (scaled) f = f * (q_scale ? q_scale[q0 + a] : 1.f) * es;  // dot_i8_quantized: dot as f32 * scale1 * scale2
+        if (euc_mode == 1) f = -(float)(__float_as_int(qaux[64 + q0 + a]) + row_sq[row] - 2 * acc[a]);  // -euclidean_i8
+        else if (euc_mode == 2) {  // -euclidean_i8_quantized
+          const float d = ss_fmul(ss_fmul(f, q_scale ? q_scale[q0 + a] : 1.f), es);
+          f = -fmaxf(ss_fsub(ss_fadd(qaux[q0 + a], row_norm ? row_norm[row] : 0.f), ss_fmul(2.0f, d)), 0.0f);
+        } else if (scaled) f = f * (q_scale ? q_scale[q0 + a] : 1.f) * es;  // dot_i8_quantized: dot as f32 * scale1 * scale2
         score[(size_t)(q0 + a) * nc + c] = f;
       }
   }
@@ -448,7 +474,9 @@ int ssi_vec_set_clusters(ss_shard* s, uint32_t n_levels, const uint32_t* level_c
 }
 
 int ssi_vec_ann_prepare(ss_shard* s, uint32_t nb, const float* d_qscale, const ss_ann_mode* mode, VAnn* out,
-                        uint32_t* d_out_clusters, hipStream_t st) {
+                        uint32_t* d_out_clusters, hipStream_t st, const float* d_qnorm) {
+  (void)d_qnorm;  // already in s->d_qaux (ssi_vec8_qaux ran before the scan preparation)
+  const bool euclid = s->vec_similarity == SS_SIM_EUCLIDEAN;
   const uint32_t nc = s->vec_n_clusters, W = (nc + 31) / 32;
   const uint32_t T = (uint32_t)(s->n_rows_pad / VS_TR), groups = (T + AT - 1) / AT;
   uint32_t* tiles = s->d_ann_tiles;
@@ -459,10 +487,12 @@ int ssi_vec_ann_prepare(ss_shard* s, uint32_t nb, const float* d_qscale, const s
   const dim3 grid((nc + 63) / 64, (nb + AQ - 1) / AQ);
   if (s->d_X8) {
     const bool scaled = s->d_row_scale != nullptr || d_qscale != nullptr;
+    const int euc_mode = euclid ? (scaled ? 2 : 1) : 0;
     ann_medoid_i8_kernel<<<grid, 64, 0, st>>>((const int8_t*)s->d_medoids, s->dim_pad8, s->d_cluster_first, nc,
-                                               (const int8_t*)s->d_Qf, nb, s->d_row_scale, d_qscale, scaled ? 1 : 0, s->d_ann_score);
+                                               (const int8_t*)s->d_Qf, nb, s->d_row_scale, d_qscale, scaled ? 1 : 0, s->d_ann_score,
+                                               euc_mode, s->d_row_norm, s->d_row_sq, s->d_qaux);
   } else {
-    ann_medoid_f32_kernel<<<grid, 64, 0, st>>>((const float*)s->d_medoids, s->dim, nc, s->d_Qf, nb, s->d_ann_score);
+    ann_medoid_f32_kernel<<<grid, 64, 0, st>>>((const float*)s->d_medoids, s->dim, nc, s->d_Qf, nb, s->d_ann_score, euclid ? 1 : 0);
   }
   const uint32_t nsel = nb * s->vec_n_levels;
   if (mode->n_probe <= ASEL_KMAX && s->vec_max_level_clusters <= ASEL_CMAX)

@@ -27,13 +27,83 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------- Q -> MFMA B-fragment order
 // Qf[kc][nt(2)][t(4)][lane(64)][j(4)] = Q[q = nt*32 + (lane&31)][k = kc*32 + (2t + (lane>>5))*4 + j]
-__global__ void vec_qprep_kernel(const float* __restrict__ Q, uint32_t nq, uint32_t dim, float* __restrict__ Qf) {
+// euclid: the image rows are [x, |x|^2, 1] and the query becomes [2 q, -1, -|q|^2], so that the scan's dot product is
+// 2 q.x - |x|^2 - |q|^2 = -|q - x|^2 (VectorSimilarity::Euclidean: minus the squared distance, larger = closer).  2 q is
+// exact, so the ANN medoid kernel recovers q as 0.5 * Qf.  The scan's value only SELECTS: the scores returned are
+// recomputed in the reference's own summation order (vec_rescore_euclid_kernel).
+__global__ void vec_qprep_kernel(const float* __restrict__ Q, uint32_t nq, uint32_t dim, float* __restrict__ Qf, int euclid) {
   const uint32_t kc = blockIdx.x;
   for (uint32_t e = threadIdx.x; e < 2048; e += blockDim.x) {
     uint32_t j = e & 3, lane = (e >> 2) & 63, t = (e >> 8) & 3, nt = e >> 10;
     uint32_t q = nt * 32 + (lane & 31);
     uint32_t k = kc * 32 + (2 * t + (lane >> 5)) * 4 + j;
-    Qf[(size_t)kc * 2048 + e] = (q < nq && k < dim) ? Q[(size_t)q * dim + k] : 0.0f;
+    float v = 0.0f;
+    if (q < nq) {
+      if (k < dim) v = euclid ? 2.0f * Q[(size_t)q * dim + k] : Q[(size_t)q * dim + k];
+      else if (euclid && k == dim) v = -1.0f;
+      else if (euclid && k == dim + 1) {
+        float ss = 0.0f;
+        for (uint32_t i = 0; i < dim; i++) ss = fmaf(Q[(size_t)q * dim + i], Q[(size_t)q * dim + i], ss);
+        v = -ss;
+      }
+    }
+    Qf[(size_t)kc * 2048 + e] = v;
+  }
+}
+
+// f32 Euclidean image: column dim = |x|^2, column dim + 1 = 1 (one thread per row)
+__global__ void vec_augment_kernel(float* __restrict__ X, unsigned long long n_rows, uint32_t dim, uint32_t dim_pad) {
+  const unsigned long long r = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  float* row = X + r * dim_pad;
+  float ss = 0.0f;
+  for (uint32_t i = 0; i < dim; i++) ss = fmaf(row[i], row[i], ss);
+  row[dim] = ss;
+  row[dim + 1] = 1.0f;
+}
+int ssi_vec_augment(ss_shard* s, hipStream_t st) {
+  if (!s->d_X || s->dim_pad < s->dim + 2) return SS_ESTATE;
+  vec_augment_kernel<<<(unsigned)((s->n_rows + 255) / 256), 256, 0, st>>>(s->d_X, (unsigned long long)s->n_rows, s->dim, s->dim_pad);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
+// The kept candidates of a Euclidean f32 search get the score the reference computes: -euclidean_f32_avx2 (eight lanes of
+// sub / mul / add over dim / 8 steps, lanes summed 0..7, vector_similarity.rs:938-966) when dim % 8 == 0, else
+// -euclidean_f32 (sequential, 912-918) -- every operation rounded on its own, no fma.  One thread per candidate.
+// thr: the search's raw threshold is applied HERE, on the exact score (`score < threshold -> reject`, vector.rs:423): the scan
+// runs without it, because its expanded form 2 q.x - |x|^2 - |q|^2 may land on the other side of a threshold the exact
+// distance meets.  A rejected candidate's key becomes 0 (vec_final_kernel drops it).
+__global__ void vec_rescore_euclid_kernel(const VState* __restrict__ st, unsigned long long* __restrict__ cand, const float* __restrict__ X,
+                                          uint32_t dim, uint32_t dim_pad, const float* __restrict__ Q, uint32_t nq, uint32_t k, float thr) {
+  const uint32_t q = blockIdx.x;
+  if (q >= nq) return;
+  const uint32_t n = st->cnt[q * VS_CNT_STRIDE] < k ? st->cnt[q * VS_CNT_STRIDE] : k;
+  const float* qv = Q + (size_t)q * dim;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const unsigned long long key = cand[(size_t)q * VS_CAP + i];
+    const uint32_t row = 0xFFFFFFFFu - (uint32_t)key;
+    const float* x = X + (size_t)row * dim_pad;
+    float d2;
+    if ((dim & 7u) == 0) {
+      float l[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (uint32_t c = 0; c < dim; c += 8)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const float d = ss_fsub(qv[c + j], x[c + j]);
+          l[j] = ss_fadd(l[j], ss_fmul(d, d));
+        }
+      d2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; j++) d2 = ss_fadd(d2, l[j]);
+    } else {
+      d2 = 0.f;
+      for (uint32_t c = 0; c < dim; c++) {
+        const float d = ss_fsub(qv[c], x[c]);
+        d2 = ss_fadd(d2, ss_fmul(d, d));
+      }
+    }
+    cand[(size_t)q * VS_CAP + i] = (-d2 < thr) ? 0ull : mk_key(-d2, row);
   }
 }
 
@@ -383,10 +453,20 @@ __global__ void vec_final_kernel(const VState* __restrict__ st, const unsigned l
       __syncthreads();
     }
   }
+  __shared__ uint32_t n_valid;  // keys zeroed by the Euclidean rescoring (below the threshold) sorted to the end
+  if (threadIdx.x == 0) n_valid = 0;
+  __syncthreads();
+  {
+    uint32_t c = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) c += keys[i] != 0ull;
+    if (c) atomicAdd(&n_valid, c);
+  }
+  __syncthreads();
+  const uint32_t nv = n_valid;
   for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
     uint32_t doc = SS_NO_DOC;
     float sc = 0.f;
-    if (i < n) {
+    if (i < nv) {
       unsigned long long key = keys[i];
       uint32_t row = 0xFFFFFFFFu - (uint32_t)key;
       doc = row_doc ? row_doc[row] : row;
@@ -396,7 +476,7 @@ __global__ void vec_final_kernel(const VState* __restrict__ st, const unsigned l
     out_score[(size_t)q * k + i] = sc;
   }
   if (threadIdx.x == 0) {
-    out_count[q] = st->ovf ? 0xFFFFFFFFu : n;
+    out_count[q] = st->ovf ? 0xFFFFFFFFu : nv;
     out_total[q] = st->total[q];
   }
 }
@@ -419,8 +499,9 @@ int ssi_vec_alloc_ws(ss_shard* s) {
 
 int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float* d_qscale, uint32_t k, float thr,
                    uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, hipStream_t st,
-                   bool safe_mode, const ss_ann_mode* ann_mode, uint32_t* d_out_clusters) {
+                   bool safe_mode, const ss_ann_mode* ann_mode, uint32_t* d_out_clusters, const float* d_qnorm) {
   if (!s->d_X && !s->d_X8) return SS_ESTATE;
+  const bool euclid = s->vec_similarity == SS_SIM_EUCLIDEAN;
   // an ANN mode proper (some clusters are skipped) or only the field filter riding on the same admission test
   const bool ann_clusters = ann_mode && (ann_mode->n_probe != 0 || ann_mode->cluster_threshold_raw > -3.4028234663852886e38f);
   if (ann_clusters && !s->d_row_cluster) return SS_ESTATE;  // the image carries no cluster structure (ss_vec_set_clusters)
@@ -434,7 +515,8 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float*
   VState* vst = (VState*)s->d_vstate;
   unsigned long long* cand = (unsigned long long*)s->d_cand;
   // `score < threshold -> reject` (vector.rs:423)  ==  admit score > nextafter(threshold, -inf)
-  const float tau_init = (thr <= -3.4028234663852886e38f) ? -INFINITY : nextafterf(thr, -INFINITY);
+  // f32 Euclidean: the threshold is applied on the exact rescored values (vec_rescore_euclid_kernel), the scan runs without
+  const float tau_init = (thr <= -3.4028234663852886e38f || (euclid && !i8)) ? -INFINITY : nextafterf(thr, -INFINITY);
 
   // chunk schedule (data independent): first chunk small (everything is a candidate), then geometric growth
   // so that the expected number of survivors per chunk stays ~ k * growth << VS_CAP.
@@ -465,12 +547,15 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float*
 
   for (uint32_t g0 = 0; g0 < nq; g0 += SS_VEC_BATCH) {
     const uint32_t nb = std::min<uint32_t>(SS_VEC_BATCH, nq - g0);
-    if (i8) ssi_vec8_qprep(s, (const int8_t*)d_queries + (size_t)g0 * s->dim, nb, st);
-    else vec_qprep_kernel<<<nch, 512, 0, st>>>((const float*)d_queries + (size_t)g0 * s->dim, nb, s->dim, s->d_Qf);
+    if (i8) {
+      ssi_vec8_qprep(s, (const int8_t*)d_queries + (size_t)g0 * s->dim, nb, st);
+      if (euclid) { rc = ssi_vec8_qaux(s, (const int8_t*)d_queries + (size_t)g0 * s->dim, nb, d_qnorm ? d_qnorm + g0 : nullptr, st); if (rc) return rc; }
+    } else vec_qprep_kernel<<<nch, 512, 0, st>>>((const float*)d_queries + (size_t)g0 * s->dim, nb, s->dim, s->d_Qf, euclid ? 1 : 0);
     vec_init_kernel<<<1, 64, 0, st>>>(vst, tau_init);
     VAnn ann{};
     if (ann_clusters) {  // medoid scores -> per-query cluster selection -> the batch's tile list
-      rc = ssi_vec_ann_prepare(s, nb, d_qscale ? d_qscale + g0 : nullptr, ann_mode, &ann, d_out_clusters ? d_out_clusters + g0 : nullptr, st);
+      rc = ssi_vec_ann_prepare(s, nb, d_qscale ? d_qscale + g0 : nullptr, ann_mode, &ann, d_out_clusters ? d_out_clusters + g0 : nullptr, st,
+                               d_qnorm ? d_qnorm + g0 : nullptr);
       if (rc) return rc;
     } else if (ann_mode && d_out_clusters) {
       SS_HIP(hipMemsetAsync(d_out_clusters + g0, 0, nb * sizeof(uint32_t), st));
@@ -504,6 +589,8 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float*
       tile0 += c;
     }
     ssi_prof_end(s, 1, st, e0, e1);
+    if (euclid && !i8)
+      vec_rescore_euclid_kernel<<<nb, 256, 0, st>>>(vst, cand, s->d_X, s->dim, s->dim_pad, (const float*)d_queries + (size_t)g0 * s->dim, nb, k, thr);
     vec_final_kernel<<<nb, 256, 0, st>>>(vst, cand, s->d_row_doc, nb, k, d_out_doc + (size_t)g0 * k,
                                          d_out_score + (size_t)g0 * k, d_out_count + g0,
                                          (unsigned long long*)d_out_total + g0);

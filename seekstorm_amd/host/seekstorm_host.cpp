@@ -30,8 +30,9 @@ void quantize_f32_to_i8(const float* v, size_t n, int8_t* out) {
 
 static const float kSimilarityNormalization64I8 = 1.0f / 16129.0f;  // vector.rs:29
 
-float threshold_raw(const float* similarity_threshold) {
+float threshold_raw(const float* similarity_threshold, bool euclidean) {
   if (!similarity_threshold) return -3.4028234663852886e38f;
+  if (euclidean) return -*similarity_threshold;                                    // vector.rs:398
   return ((*similarity_threshold * 2.0f) - 1.0f) / kSimilarityNormalization64I8;  // vector.rs:388-397
 }
 
@@ -63,6 +64,13 @@ int Shard::upload_lexical_fields(uint64_t n_docs, uint32_t n_fields, const uint8
   lexical_fields_ = n_fields; ngram_components_.clear(); ngram_component_df_.clear();  // a new image: no index.bin n-gram keys behind the term ids
   const int rc = ss_bm25_upload_fields(h_, n_docs, n_fields, doclen_bytes, boost, n_terms, term_offsets, doc_ids, field_ids, tfs);
   n_docs_ = rc == SS_OK ? n_docs : 0;
+  return rc;
+}
+
+int Shard::set_vector_similarity(bool euclidean) {
+  if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
+  const int rc = ss_vec_set_similarity(h_, euclidean ? SS_SIM_EUCLIDEAN : SS_SIM_DOT);
+  if (rc == SS_OK) euclidean_ = euclidean;
   return rc;
 }
 
@@ -261,6 +269,7 @@ std::vector<ResultObject> Shard::search_vector_batch(const float* query_vectors,
   int rc = create_rc_ ? create_rc_ : SS_ESTATE;
   // vector.rs:1300-1307: (n_probe, cluster threshold) of the mode; the threshold goes through TopK::new like the record one
   ss_ann_mode am{0u, threshold_raw(nullptr), 0ull};
+  const bool euc = euclidean_;
   const bool ann = ann_mode.kind != AnnMode::Kind::All;
   bool bad_field = false;
   for (uint16_t f : field_filter) {
@@ -271,16 +280,16 @@ std::vector<ResultObject> Shard::search_vector_batch(const float* query_vectors,
   if (ann_mode.kind == AnnMode::Kind::Nprobe || ann_mode.kind == AnnMode::Kind::NprobeSimilaritythreshold)
     am.n_probe = (uint32_t)std::min<size_t>(ann_mode.n_probe, 0xFFFFFFFFu);
   if (ann_mode.kind == AnnMode::Kind::Similaritythreshold || ann_mode.kind == AnnMode::Kind::NprobeSimilaritythreshold)
-    am.cluster_threshold_raw = threshold_raw(&ann_mode.similarity_threshold);
+    am.cluster_threshold_raw = threshold_raw(&ann_mode.similarity_threshold, euc);
   if ((ann && ann_mode.kind != AnnMode::Kind::Similaritythreshold && am.n_probe == 0) || bad_field) {
     rc = bad_field ? SS_ENOTSUP : SS_EINVAL;  // Nprobe(0): TopK::new(0, ..) has no slot to push into
   } else if (h_ && i8_) {  // the query is quantised like the records (search.rs:1487-1490); score = raw integer dot
     std::vector<int8_t> q8(n_queries * dim_);
     quantize_f32_to_i8(query_vectors, q8.size(), q8.data());
-    rc = ss_vec_search_i8_ann(h_, (uint32_t)n_queries, q8.data(), nullptr, (uint32_t)k, threshold_raw(similarity_threshold),
+    rc = ss_vec_search_i8_ann(h_, (uint32_t)n_queries, q8.data(), nullptr, (uint32_t)k, threshold_raw(similarity_threshold, euc),
                               opts ? &am : nullptr, doc.data(), score.data(), cnt.data(), tot.data(), ncl.data());
   } else if (h_) {
-    rc = ss_vec_search_ann(h_, (uint32_t)n_queries, query_vectors, (uint32_t)k, threshold_raw(similarity_threshold),
+    rc = ss_vec_search_ann(h_, (uint32_t)n_queries, query_vectors, (uint32_t)k, threshold_raw(similarity_threshold, euc),
                            opts ? &am : nullptr, doc.data(), score.data(), cnt.data(), tot.data(), ncl.data());
   }
   uint32_t all_clusters = 0;
@@ -293,8 +302,8 @@ std::vector<ResultObject> Shard::search_vector_batch(const float* query_vectors,
     for (size_t i = 0; i < n; i++) {
       Result& r = ro.results[i];
       r.doc_id = doc[q * kk + i];
-      r.score = score[q * kk + i];              // raw dot (vector.rs:1474-1506)
-      r.vector_score = vector_score_of(r.score);
+      r.score = score[q * kk + i];              // raw similarity: dot, or -distance^2 under Euclidean (vector.rs:1474-1506)
+      r.vector_score = euc ? -r.score : vector_score_of(r.score);  // vector.rs:1495-1499
       r.shard_id = shard_id_;
       r.level_id = (uint32_t)(r.doc_id >> 16);
       r.source = ResultSource::Vector;

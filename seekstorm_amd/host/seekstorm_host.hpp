@@ -69,7 +69,7 @@ struct ResultObject {
 float idf(uint64_t indexed_doc_count, uint64_t posting_count);  // search.rs:3225-3230, all f32
 void normalize_f32(float* v, size_t n);                         // vector_similarity.rs:70-74 (search.rs:1464-1475)
 void quantize_f32_to_i8(const float* v, size_t n, int8_t* out);  // vector_similarity.rs:1226-1232 (query side: search.rs:1487-1490)
-float threshold_raw(const float* similarity_threshold);         // TopK::new, vector.rs:388-397; nullptr = none
+float threshold_raw(const float* similarity_threshold, bool euclidean = false);  // TopK::new, vector.rs:388-398; nullptr = none
 float vector_score_of(float raw_dot);                           // vector.rs:1495-1499: ((dot / 16129) + 1) / 2
 
 // One shard image on one MI355X.
@@ -91,6 +91,8 @@ class Shard {
   // several indexed fields (BM25F): doclen [n_fields][n_docs], postings (doc, field, tf) sorted by (doc, field) per term
   int upload_lexical_fields(uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen_bytes, const float* boost, uint32_t n_terms,
                             const uint64_t* term_offsets, const uint32_t* doc_ids, const uint8_t* field_ids, const uint16_t* tfs);
+  // VectorSimilarity of the image (index-wide in the reference): Dot / Cosine (default) or Euclidean; BEFORE the upload
+  int set_vector_similarity(bool euclidean);
   int upload_vectors(uint64_t n_rows, uint32_t dim, const float* rows, const uint32_t* row_doc_ids);
   // shard files as the reference writes them: index.bin (single indexed field), vector.bin (f32), delete.bin.
   // term_keys: key_hash of every term id, ascending; an n-gram key (key_hash & 7 != 0) holds one id per component term,
@@ -143,6 +145,7 @@ class Shard {
   uint64_t n_docs_ = 0, n_rows_ = 0;
   uint32_t dim_ = 0;
   bool i8_ = false;
+  bool euclidean_ = false;
   uint32_t lexical_fields_ = 1;                // indexed fields of the lexical image
   std::vector<uint8_t> ngram_components_;      // per term id of an opened index.bin: components of its key (1 = SingleTerm)
   std::vector<uint32_t> ngram_component_df_;   // posting count of the component term (n-gram components)

@@ -89,10 +89,12 @@ def idf_f32(indexed_doc_count, posting_count):
     return np.float32(np.log(((Nf - nf + np.float32(0.5)) / (nf + np.float32(0.5))) + np.float32(1.0), dtype=np.float32))
 
 
-def threshold_raw(similarity_threshold):
-    """TopK::new, vector.rs:388-397 (Dot/Cosine arm)."""
+def threshold_raw(similarity_threshold, euclidean=False):
+    """TopK::new, vector.rs:388-397: Dot / Cosine ((t * 2) - 1) / SIMILARITY_NORMALIZATION_64_I8, Euclidean -t"""
     if similarity_threshold is None:
         return N.FLT_MIN_NEG
+    if euclidean:
+        return float(-np.float32(similarity_threshold))
     return float(((np.float32(similarity_threshold) * np.float32(2.0)) - np.float32(1.0)) / SIMILARITY_NORMALIZATION_64_I8)
 
 
@@ -117,13 +119,13 @@ class AnnMode:
     def NprobeSimilaritythreshold(n_probe, threshold):
         return AnnMode(int(n_probe), float(threshold))
 
-    def _c(self):
+    def _c(self, euclidean=False):
         if self.n_probe < 0 or (self.n_probe == 0 and self.similarity_threshold is None):
             raise ValueError("AnnMode needs n_probe >= 1 or a similarity threshold")
-        return N.AnnModeC(self.n_probe, threshold_raw(self.similarity_threshold), 0)
+        return N.AnnModeC(self.n_probe, threshold_raw(self.similarity_threshold, euclidean), 0)
 
 
-def _vector_options(ann_mode, field_filter):
+def _vector_options(ann_mode, field_filter, euclidean=False):
     """ss_ann_mode of a call: the AnnMode (None = All) and the field filter (indexed field ids, empty = every field)"""
     mask = 0
     for f in field_filter or ():
@@ -132,7 +134,7 @@ def _vector_options(ann_mode, field_filter):
         mask |= 1 << int(f)
     if ann_mode is None and not mask:
         return None
-    m = N.AnnModeC(0, N.FLT_MIN_NEG, 0) if ann_mode is None else ann_mode._c()
+    m = N.AnnModeC(0, N.FLT_MIN_NEG, 0) if ann_mode is None else ann_mode._c(euclidean)
     m.field_mask = mask
     return m
 
@@ -218,6 +220,7 @@ class Shard:
         self.vector_count = 0
         self.dim = 0
         self.vector_precision = "f32"  # "i8": Precision::I8 image, queries are quantised with quantize_f32_to_i8
+        self.vector_euclidean = False  # set_vector_similarity("euclidean")
 
     def close(self):
         if getattr(self, "_h", None):
@@ -337,6 +340,18 @@ class Shard:
         self.lexical_field_count = 1
         self._df_cache.clear()
 
+    def set_vector_similarity(self, similarity):
+        """VectorSimilarity of the vector image: "dot" (Dot and Cosine: dot product) or "euclidean" (a record's similarity is
+        MINUS its squared distance to the query, vector_similarity.rs:257-345); before the upload"""
+        euclid = str(similarity).lower().startswith("euclid")
+        N.check(N.lib().ss_vec_set_similarity(self._h, N.SIM_EUCLIDEAN if euclid else N.SIM_DOT), "ss_vec_set_similarity")
+        self.vector_euclidean = euclid
+
+    def set_row_norms(self, row_norm):
+        """VectorHeader.norm of the i8 records (Euclidean + ScalarQuantizationI8: euclidean_i8_quantized)"""
+        r = np.ascontiguousarray(row_norm, np.float32)
+        N.check(N.lib().ss_vec_set_row_norms(self._h, len(r), N.ptr(r, N.f32p)), "ss_vec_set_row_norms")
+
     def upload_vectors(self, rows, row_doc_ids=None):
         r = np.ascontiguousarray(rows, np.float32)
         ids = None if row_doc_ids is None else np.ascontiguousarray(row_doc_ids, np.uint32)
@@ -365,8 +380,9 @@ class Shard:
         return out
 
     def search_vector_batch_i8(self, queries_i8, k, query_scale=None, similarity_threshold_raw=None, ann_mode=None,
-                               with_clusters=False, field_filter=None):
-        """scores = dot_i8 as f32 (* query_scale * embedding_scale with scales): vector_similarity.rs:1011-1016, 1754-1758"""
+                               with_clusters=False, field_filter=None, query_norm=None):
+        """scores = dot_i8 as f32 (* query_scale * embedding_scale with scales): vector_similarity.rs:1011-1016, 1754-1758;
+        under Euclidean -euclidean_i8, or -euclidean_i8_quantized with the scales and norms (query_norm per query)"""
         qv = np.ascontiguousarray(queries_i8, np.int8)
         if qv.ndim == 1:
             qv = qv[None, :]
@@ -380,11 +396,12 @@ class Shard:
         tot = np.empty(nq, np.uint64)
         thr = N.FLT_MIN_NEG if similarity_threshold_raw is None else float(similarity_threshold_raw)
         ncl = np.zeros(nq, np.uint32)
-        mode = _vector_options(ann_mode, field_filter)
-        N.check(N.lib().ss_vec_search_i8_ann(self._h, nq, qv.ctypes.data, N.ptr(qs, N.f32p), k, thr,
-                                             None if mode is None else C.addressof(mode), N.ptr(doc, N.u32p),
-                                             N.ptr(score, N.f32p), N.ptr(cnt, N.u32p), N.ptr(tot, N.u64p), N.ptr(ncl, N.u32p)),
-                "ss_vec_search_i8_ann")
+        mode = _vector_options(ann_mode, field_filter, self.vector_euclidean)
+        qn = None if query_norm is None else np.ascontiguousarray(query_norm, np.float32)
+        N.check(N.lib().ss_vec_search_i8_euclid(self._h, nq, qv.ctypes.data, N.ptr(qs, N.f32p), N.ptr(qn, N.f32p), k, thr,
+                                                None if mode is None else C.addressof(mode), N.ptr(doc, N.u32p),
+                                                N.ptr(score, N.f32p), N.ptr(cnt, N.u32p), N.ptr(tot, N.u64p), N.ptr(ncl, N.u32p)),
+                "ss_vec_search_i8_euclid")
         return (doc, score, cnt, tot, ncl) if with_clusters else (doc, score, cnt, tot)
 
     def synth_vectors(self, seed, n_rows, dim):
@@ -572,8 +589,8 @@ class Shard:
         cnt = np.zeros(nq, np.uint32)
         tot = np.zeros(nq, np.uint64)
         ncl = np.zeros(nq, np.uint32)
-        mode = _vector_options(ann_mode, field_filter)
-        N.check(N.lib().ss_vec_search_ann(self._h, nq, N.ptr(qv, N.f32p), int(k), threshold_raw(similarity_threshold),
+        mode = _vector_options(ann_mode, field_filter, self.vector_euclidean)
+        N.check(N.lib().ss_vec_search_ann(self._h, nq, N.ptr(qv, N.f32p), int(k), threshold_raw(similarity_threshold, self.vector_euclidean),
                                           None if mode is None else C.addressof(mode), N.ptr(doc, N.u32p), N.ptr(score, N.f32p),
                                           N.ptr(cnt, N.u32p), N.ptr(tot, N.u64p), N.ptr(ncl, N.u32p)), "ss_vec_search_ann")
         return (doc, score, cnt, tot, ncl) if with_clusters else (doc, score, cnt, tot)
@@ -603,7 +620,7 @@ class Shard:
         try:
             if self.vector_precision == "i8":  # the query is quantised like the records (search.rs:1476-1490), threshold on the raw dot
                 q8 = quantize_f32_to_i8(np.ascontiguousarray(query_vector, np.float32).reshape(1, -1))
-                thr = None if similarity_threshold is None else threshold_raw(similarity_threshold)
+                thr = None if similarity_threshold is None else threshold_raw(similarity_threshold, self.vector_euclidean)
                 doc, score, cnt, tot, ncl = self.search_vector_batch_i8(q8, length, similarity_threshold_raw=thr,
                                                                         ann_mode=ann_mode, with_clusters=True,
                                                                         field_filter=field_filter)

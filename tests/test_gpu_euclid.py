@@ -1,0 +1,145 @@
+"""GPU parity (-m gpu) of VectorSimilarity::Euclidean (vector_similarity.rs:257-345, 905-966, 1721-1735): a record's similarity
+is MINUS its squared distance, f32 and i8 (plain and ScalarQuantizationI8 with scale / norm), AnnMode::All and the ANN modes,
+thresholds (vector.rs:398), and the reference's own vector test shape (tests/test.rs:617-744)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def S():
+    import seekstorm_amd
+    return seekstorm_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def _check(doc, score, cnt, od, os_, abs_tol=1e-6, exact=False):
+    n = int(cnt)
+    assert n == len(od)
+    if exact:
+        assert np.array_equal(score[:n], os_)
+    else:
+        assert np.allclose(score[:n], os_, rtol=REL, atol=abs_tol)
+    if n:
+        band = 0.0 if exact else (abs(float(os_[-1])) * REL + abs_tol)
+        clear = lambda dd, ss: {int(x) for x, y in zip(dd, ss) if y > os_[-1] + 2 * band}
+        assert clear(doc[:n], score[:n]) <= {int(x) for x in od} and clear(od, os_) <= {int(x) for x in doc[:n]}
+
+
+def test_reference_vector_test_shape(S, O):
+    """tests/test.rs:617-744: three 128-d f32 vectors under Euclidean in an index of 2 shards, query = the first vector,
+    AnnMode::All, top-10, TopkCount -> 3 results, result_count 3, result_count_total 3; the first hit is the query itself
+    at distance 0"""
+    vecs = (np.arange(1, 385, dtype=np.float32) * np.float32(0.001)).reshape(3, 128)
+    shards = []
+    for sid in range(2):  # doc g -> shard g % 2 (index.rs:5284)
+        sh = S.Shard(0, shard_id=sid)
+        sh.set_vector_similarity("euclidean")
+        sh.upload_vectors(vecs[sid::2])
+        shards.append(sh)
+    idx = S.Index(shards)
+    ro = idx.search(None, vecs[0], S.QueryType.Union, S.SearchMode.Vector, 0, 10, S.ResultType.TopkCount, normalize_query=False)
+    assert len(ro.results) == 3 and ro.result_count == 3 and ro.result_count_total == 3
+    assert [r.doc_id for r in ro.results] == [0, 1, 2]  # global ids local * 2 + shard, nearest first
+    assert ro.results[0].score == 0.0
+    want = [-O.euclidean_f32(vecs[0], v) for v in vecs]
+    assert [r.score for r in ro.results] == want  # the reference's own summation order: equal bit for bit
+    for sh in shards:
+        sh.close()
+
+
+@pytest.mark.parametrize("n_rows,dim,nq,k,normalize", [(20000, 128, 64, 100, False), (5000, 100, 5, 10, False), (3000, 768, 3, 100, True),
+                                                       (60, 30, 2, 100, False)])
+def test_euclidean_f32_parity(S, O, n_rows, dim, nq, k, normalize):
+    scale = 1.0 if normalize else 40.0
+    rows = O.vec_gen(O.VEC_SEED, 0, n_rows, dim, normalize=normalize) * np.float32(scale)
+    qs = O.vec_gen(O.VECQ_SEED, 0, nq, dim, normalize=normalize) * np.float32(scale)
+    sh = S.Shard(0)
+    sh.set_vector_similarity("euclidean")
+    sh.upload_vectors(rows)
+    assert np.array_equal(sh.read_rows(0, min(n_rows, 50)), rows[:50])
+    doc, score, cnt, tot = sh.search_vector_batch(qs, k)
+    for i in range(nq):
+        od, os_, *_ = O.vec_search_euclid(rows, qs[i], k, simd_order=(dim % 8 == 0))
+        # returned scores are recomputed in the reference's summation order: equal bit for bit wherever the same row is returned
+        same = doc[i][:cnt[i]] == od
+        assert np.array_equal(score[i][:cnt[i]][same], os_[same])
+        _check(doc[i], score[i], cnt[i], od, os_, abs_tol=1e-5 * scale * scale)
+    # a row queried with itself: distance exactly 0, first
+    d2, s2, c2, _ = sh.search_vector_batch(rows[[7, n_rows - 1]], 3)
+    assert list(d2[:, 0]) == [7, n_rows - 1] and np.all(s2[:, 0] == 0.0)
+    # similarity threshold: Euclidean keeps records with distance^2 <= t (raw threshold -t, vector.rs:398)
+    t = float(-score[0][min(5, cnt[0] - 1)])
+    d3, s3, c3, _ = sh.search_vector_batch(qs[:1], k, similarity_threshold=t)
+    od, os_, *_ = O.vec_search_euclid(rows, qs[0], k, simd_order=(dim % 8 == 0), threshold_raw=-np.float32(t))
+    assert c3[0] == len(od) and 1 <= c3[0] <= 8
+    sh.close()
+
+
+def test_euclidean_f32_ann_modes(S, O):
+    dim, k = 64, 20
+    lc = [5, 7, 4]
+    child = [300, 500, 200, 400, 350, 100, 250, 600, 150, 300, 200, 450, 500, 380, 220, 400]
+    n_rows = sum(child)
+    rows = O.vec_gen(41, 0, n_rows, dim, normalize=False) * np.float32(10.0)
+    qs = O.vec_gen(42, 0, 9, dim, normalize=False) * np.float32(10.0)
+    sh = S.Shard(0)
+    sh.set_vector_similarity("euclidean")
+    sh.upload_vectors(rows)
+    sh.set_clusters(lc, child)
+    for am, kw in ((S.AnnMode.Nprobe(2), dict(n_probe=2)), (S.AnnMode.Nprobe(3), dict(n_probe=3)),
+                   (S.AnnMode.NprobeSimilaritythreshold(4, 2600.0), dict(n_probe=4, cluster_threshold_raw=-np.float32(2600.0)))):
+        doc, score, cnt, tot, ncl = sh.search_vector_batch(qs, k, ann_mode=am, with_clusters=True)
+        for i in range(len(qs)):
+            od, os_, otot, oobs, oncl = O.vec_search_euclid(rows, qs[i], k, lc, child, **kw)
+            assert ncl[i] == oncl, (am, i, ncl[i], oncl)
+            _check(doc[i], score[i], cnt[i], od, os_, abs_tol=1e-3)
+    sh.close()
+
+
+def test_euclidean_i8_plain_and_quantized(S, O):
+    """-euclidean_i8 is an exact integer (scores ==); -euclidean_i8_quantized follows the reference's f32 operation order
+    (scores ==): norm1 + norm2 - 2 * (dot as f32 * scale1 * scale2), clamped at 0"""
+    dim, n_rows, nq, k = 256, 9000, 33, 50
+    rng = np.random.default_rng(3)
+    rows = rng.integers(-127, 128, (n_rows, dim)).astype(np.int8)
+    qs = rng.integers(-127, 128, (nq, dim)).astype(np.int8)
+    sh = S.Shard(0)
+    sh.set_vector_similarity("euclidean")
+    sh.upload_vectors_i8(rows)
+    doc, score, cnt, tot = sh.search_vector_batch_i8(qs, k)
+    for i in range(nq):
+        od, os_, *_ = O.vec_search_i8_euclid(rows, qs[i], k)
+        _check(doc[i], score[i], cnt[i], od, os_, exact=True)
+    # ScalarQuantizationI8: per-record scale and norm, per-query scale and norm (QuantizedVector::new_scale_norm on the host)
+    rscale = (rng.random(n_rows).astype(np.float32) * 0.01 + 0.001).astype(np.float32)
+    rnorm = (rng.random(n_rows).astype(np.float32) * 50 + 1).astype(np.float32)
+    qscale = (rng.random(nq).astype(np.float32) * 0.01 + 0.001).astype(np.float32)
+    qnorm = (rng.random(nq).astype(np.float32) * 50 + 1).astype(np.float32)
+    sh.upload_vectors_i8(rows, row_scale=rscale)
+    sh.set_row_norms(rnorm)
+    doc, score, cnt, tot = sh.search_vector_batch_i8(qs, k, query_scale=qscale, query_norm=qnorm)
+    clamped = 0
+    for i in range(nq):
+        od, os_, *_ = O.vec_search_i8_euclid(rows, qs[i], k, row_scale=rscale, row_norm=rnorm, query_scale=float(qscale[i]),
+                                             query_norm=float(qnorm[i]))
+        _check(doc[i], score[i], cnt[i], od, os_, exact=True)
+        clamped += int(np.sum(os_ == 0.0))
+    # ANN over the quantised records
+    lc, child = [3, 2], [2000, 1500, 2500, 1000, 2000]
+    sh.set_clusters(lc, child)
+    doc, score, cnt, tot, ncl = sh.search_vector_batch_i8(qs, k, query_scale=qscale, query_norm=qnorm, ann_mode=S.AnnMode.Nprobe(1),
+                                                           with_clusters=True)
+    for i in range(nq):
+        od, os_, _, _, oncl = O.vec_search_i8_euclid(rows, qs[i], k, lc, child, n_probe=1, row_scale=rscale, row_norm=rnorm,
+                                                     query_scale=float(qscale[i]), query_norm=float(qnorm[i]))
+        assert ncl[i] == oncl == 2
+        _check(doc[i], score[i], cnt[i], od, os_, exact=True)
+    sh.close()
