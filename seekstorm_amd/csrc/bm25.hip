@@ -242,7 +242,9 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   if (const char* e = getenv("SS_BM25_P")) P = (uint32_t)atoi(e);  // tuning override
   P = std::max<uint32_t>(1, std::min<uint32_t>(P, s->bm_n_sub));
   const size_t tau_words = (size_t)nq * BM_TAU_STRIDE / 2;  // u64 words: one 128-byte line per query
-  const size_t need = (size_t)nq * P * KS * 2 + nq + tau_words;  // two ping-pong merge buffers + totals + tau
+  // u64 words: 4 floats per (query, partition) + one float per (query, sub-block) -- the pruned kernel's block-max bounds
+  const size_t pmax_words = (size_t)nq * P * 2 + ((size_t)nq * s->bm_n_sub + 1) / 2;
+  const size_t need = (size_t)nq * P * KS * 2 + nq + tau_words + pmax_words;  // two ping-pong merge buffers + totals + tau + bounds
   if (need > s->part_cap) {
     if (s->d_part) (void)hipFree(s->d_part);
     s->d_part = nullptr;
@@ -254,6 +256,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   u64* bufB = bufA + (size_t)nq * P * KS;
   u64* total = bufB + (size_t)nq * P * KS;
   uint32_t* tau = (uint32_t*)(total + nq);
+  float* pmax_ws = (float*)(total + nq + tau_words);
 
   // queries over (term, field) posting lists
   if ((size_t)nq * sizeof(bm_vquery) > s->vq_cap) {
@@ -292,11 +295,16 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   const bool want_counts = rt != SS_RT_TOPK;
   const bool bit_counts_all = want_counts && !pruned && s->bm_strategy != SS_BM25_EXHAUSTIVE && have_probe;
   p.count = (want_counts && !bit_counts_all) ? 1u : 0u;
+  // per-partition block maxima as the pruned kernel's bounds: where the image's maxima vary over the doc ids (set at build),
+  // SS_BM25_SUBMAX = 1 / 0 forces them on / off
+  static const int force_partmax = [] { const char* e = getenv("SS_BM25_SUBMAX"); return e ? atoi(e) : -1; }();
+  // (small batches are launch-latency bound: the two bound kernels cost more than they save -- 0.103 vs 0.118 ms at 32 queries)
+  const bool use_partmax = force_partmax < 0 ? (s->bm_partmax && nq >= 128) : force_partmax != 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   ssi_prof_begin(s, 0, st, &e0, &e1);
   int rc = SS_OK;
   if (bit_counts_all && k == 0) SS_HIP(hipMemsetAsync(bufA, 0, (size_t)nq * P * KS * sizeof(u64), st));  // no ranking wanted
-  else rc = pruned ? ssi_bm25_launch_probe(p, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_umax, np_max, KPL, nt_max != np_max, st)
+  else rc = pruned ? ssi_bm25_launch_probe(p, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_umax, use_partmax ? s->d_submax : nullptr, pmax_ws, np_max, KPL, nt_max != np_max, st)
                    : ssi_bm25_launch_scan(p, nt_max, has_and, KPL, st);
   ssi_prof_end(s, 0, st, e0, e1);
   if (rc) return rc;

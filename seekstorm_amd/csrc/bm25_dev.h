@@ -362,4 +362,4 @@ int ssi_bm25_launch_union_count(const BmParams& p, const uint2* probe, const uin
                                 unsigned long long* match_bits = nullptr);
 // pruned top-k over the probe index (bm25_probe.hip); SS_ENOTSUP if it cannot serve the request
 int ssi_bm25_launch_probe(const BmParams& p, const uint2* probe, const uint32_t* probe_z, const uint32_t* probe_row, const float* umax,
-                          uint32_t nt_max, int KPL, bool any_not, hipStream_t st);
+                          const float* submax, float* pmax_ws, uint32_t nt_max, int KPL, bool any_not, hipStream_t st);

@@ -20,6 +20,7 @@
 // scores.  One wave per (query, partition); LDS holds the weight table and one survivor queue per wave (dense stage ->
 // sparse stage); G chunks are evaluated together so that their gathers are in flight at the same time.  Exact union
 // counts (bm25_union_count_kernel, bottom of the file) are popcounts over the same bit records.
+#include <cstdlib>
 #include <type_traits>
 
 #include "bm25_dev.h"
@@ -40,12 +41,49 @@ __device__ __attribute__((noinline)) BmTop<KPL> bm_offer_lane_keys(BmTop<KPL> T,
 // weight of one posting: it is IN the posting (ss_common.h) -- the same decode as the scan kernels'
 __device__ __forceinline__ float pb_weight(uint32_t p) { return bm_weight(p); }
 
+// pmax[q][part][t] = largest weight of query term t (query order, t < 4) inside the sub-blocks of partition `part`: one wave
+// per (query, partition), lanes strided over the partition's sub-blocks.  Reads nq * n_terms_of_query * n_sub floats per
+// launch (29 MB for 1000 C2 queries): a few microseconds, and the probe kernel's registers stay what they were (computing
+// the maxima inside it cost 3 VGPRs and pushed the kernel into scratch: 0.57 -> 1.06 ms per 1000 queries).
+__global__ void __launch_bounds__(256) bm_partmax_kernel(const bm_vquery* __restrict__ qs, const float* __restrict__ submax, uint32_t n_sub,
+                                                         uint32_t n_terms, uint32_t nq, uint32_t P, float* __restrict__ pmax) {
+  const uint32_t a = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (a >= nq * P) return;
+  const uint32_t qi = a % nq, part = a / nq;
+  const bm_vquery* __restrict__ Q = qs + qi;
+  const uint32_t s_begin = (uint32_t)(((u64)n_sub * part) / P), s_end = (uint32_t)(((u64)n_sub * (part + 1)) / P);
+  for (uint32_t t = 0; t < 4u; t++) {
+    const uint32_t term = t < Q->n_terms ? Q->term[t] : n_terms;
+    float m = 0.f;
+    for (uint32_t sb = s_begin + (uint32_t)lane; sb < s_end; sb += 64u) m = fmaxf(m, submax[(size_t)term * n_sub + sb]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) pmax[((size_t)qi * P + part) * 4u + t] = m;
+  }
+}
+
+// qbound[q][s] = sum over the query's terms of idf * (largest weight of the term in sub-block s): no doc of sub-block s can
+// score higher.  The driver streams of the probe kernel jump over sub-blocks whose bound lies below the current threshold
+// -- the reference's block skip (single.rs:383-391, intersection.rs:2227-2233) at this image's block size.
+__global__ void __launch_bounds__(256) bm_qbound_kernel(const bm_vquery* __restrict__ qs, const float* __restrict__ submax, uint32_t n_sub,
+                                                        uint32_t nq, float* __restrict__ qbound) {
+  const uint32_t q = blockIdx.y, sb = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq || sb >= n_sub) return;
+  const bm_vquery* __restrict__ Q = qs + q;
+  float b = 0.f;
+  for (uint32_t t = 0; t < Q->n_terms; t++) b = fmaf(Q->idf[t], submax[(size_t)Q->term[t] * n_sub + sb], b);
+  qbound[(size_t)q * n_sub + sb] = b * 1.00001f;  // the sum is rounded in another order than a doc's score
+}
+
 // FILT: tombstones and / or NOT terms are present (a separate instantiation: the unfiltered kernel pays nothing for them)
-template <int NT, int KPL, bool FILT>
+// SKIP: the driver streams jump over sub-blocks whose block-max bound (qbound) lies below the threshold.  A separate
+// instantiation: the few registers the skip needs pushed the common kernel into scratch (C2: 0.55 -> 0.80 ms per 1000 queries).
+template <int NT, int KPL, bool FILT, bool SKIP>
 __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
     const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base, const uint32_t* __restrict__ sub_off,
     const uint2* __restrict__ probe, const uint32_t* __restrict__ probe_z,
-    const uint32_t* __restrict__ probe_row, const float* __restrict__ umax,
+    const uint32_t* __restrict__ probe_row, const float* __restrict__ umax, const float* __restrict__ pmax, const float* __restrict__ qbound,
     const bm_vquery* __restrict__ qs, unsigned long long* __restrict__ part_keys, unsigned long long* __restrict__ total,
     uint32_t* tau, const uint32_t* __restrict__ del, uint32_t del_words, uint32_t n_sub, uint32_t n_terms,
     uint32_t nq, uint32_t P, uint32_t k, uint32_t count) {
@@ -70,12 +108,18 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
   float idf[NT], U[NT];
   uint32_t qpos[NT];
   unsigned long long size[NT];
+  const uint32_t s_begin = (uint32_t)(((u64)n_sub * part) / P);
+  const uint32_t s_end = (uint32_t)(((u64)n_sub * (part + 1)) / P);
 #pragma unroll
   for (int t = 0; t < NT; t++) {
     const bool have = (uint32_t)t < nt;
     const uint32_t term = have ? Q->term[t] : n_terms;
     idf[t] = have ? Q->idf[t] : 0.f;
-    U[t] = idf[t] * umax[term];  // upper bound of idf * w over the list (umax = the largest DECODED weight)
+    // Upper bound of idf * w over the docs THIS wave can see: the largest weight of the term inside the partition's
+    // sub-blocks (bm_partmax_kernel below, from the per-(term, block) maxima -- the reference's max_block_score,
+    // index.rs:2938-3200, used like intersection.rs:2090-2097 / single.rs:373-386): tighter than the list-level maximum
+    // wherever weights are not spread evenly over the doc ids, never looser.  (umax = the largest DECODED weight of the list.)
+    U[t] = idf[t] * (pmax ? pmax[((size_t)qi * P + part) * 4u + t] : umax[term]);
     qpos[t] = t;
     tptr[t] = post + term_base[term] * 4ull;
     rowp[t] = sub_off + (size_t)term * row_len;
@@ -105,8 +149,6 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
 #pragma unroll
   for (int j = NT - 1; j >= 0; j--) SU[j] = SU[j + 1] + U[j];
 
-  const uint32_t s_begin = (uint32_t)(((u64)n_sub * part) / P);
-  const uint32_t s_end = (uint32_t)(((u64)n_sub * (part + 1)) / P);
   BmTop<KPL> T;
 #pragma unroll
   for (int r = 0; r < KPL; r++) T.keys[r] = 0ull;
@@ -255,6 +297,10 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
     // sub-block boundaries of the driver (dword offsets), 64 per block load: lane i = sub-block blk0 + i
     uint32_t blk0 = s_begin;
     uint32_t vb = rowp[J][min(blk0 + (uint32_t)lane, s_end)] * 4u;
+    const bool skip_blocks = SKIP && k != 0 && !count;  // exact counts need every match
+    const float* __restrict__ qbrow = SKIP ? qbound + (size_t)qi * n_sub : nullptr;
+    uint32_t vqb = 0u;  // bound of sub-block blk0 + lane
+    if constexpr (SKIP) { if (skip_blocks) vqb = __float_as_uint(qbrow[min(blk0 + (uint32_t)lane, s_end - 1u)]); }
     auto bnd = [&](uint32_t s) -> uint32_t {  // s in [blk0, blk0 + 64), uniform
       return __builtin_amdgcn_readlane(vb, s - blk0);
     };
@@ -265,6 +311,30 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
     for (uint32_t x = x_begin; x < x_end; x += 64u * G) {
       const float thr = cur_thr();
       if (!is_and && J > 0 && k && SU[J] < thr * 0.99999f) break;  // this and all later terms are non-essential now
+      if constexpr (SKIP) if (skip_blocks) {
+        // block-max skip: while the sub-block holding position x cannot contain a doc that reaches thr, jump to the next one
+        bool moved = false;
+        for (;;) {
+          if (s_cur + 1u - blk0 >= 64u) {
+            blk0 = s_cur;
+            vb = rowp[J][min(blk0 + (uint32_t)lane, s_end)] * 4u;
+            vqb = __float_as_uint(qbrow[min(blk0 + (uint32_t)lane, s_end - 1u)]);
+          }
+          if (s_cur + 1u > s_end) break;
+          const uint32_t b1 = bnd(s_cur + 1u);
+          if (b1 <= x) { s_cur++; continue; }  // x lies beyond this sub-block
+          if (__uint_as_float(__builtin_amdgcn_readlane(vqb, s_cur - blk0)) >= thr * 0.99999f) break;
+          x = b1;  // nothing in the rest of this sub-block can enter the top-k
+          s_cur++;
+          moved = true;
+          if (x >= x_end) break;
+        }
+        if (moved) {
+          if (x >= x_end) break;
+#pragma unroll
+          for (int g = 0; g < G; g++) pn[g] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane4 + g * 256, (int)(x * 4u), 0);
+        }
+      }
       uint32_t pg[G], tile[G];
 #pragma unroll
       for (int g = 0; g < G; g++) {
@@ -281,6 +351,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
         if (s_cur + 1u - blk0 >= 64u) {  // next boundary lies outside the loaded block
           blk0 = s_cur;
           vb = rowp[J][min(blk0 + (uint32_t)lane, s_end)] * 4u;
+          if constexpr (SKIP) { if (skip_blocks) vqb = __float_as_uint(qbrow[min(blk0 + (uint32_t)lane, s_end - 1u)]); }
         }
         if (s_cur + 1u > s_end) break;
         const uint32_t b = bnd(s_cur + 1u);
@@ -368,12 +439,12 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
   if (lane == 0 && T.matched) atomicAdd(&total[qi], T.matched);
 }
 
-template <int NT, int KPL, bool FILT>
+template <int NT, int KPL, bool FILT, bool SKIP>
 static int launch_probe(const BmParams& p, const uint2* probe, const uint32_t* probe_z, const uint32_t* probe_row, const float* umax,
-                        hipStream_t st) {
+                        const float* pmax, const float* qbound, hipStream_t st) {
   const uint32_t A = p.nq * p.P;
-  bm25_probe_kernel<NT, KPL, FILT><<<(A + PB_WAVES - 1) / PB_WAVES, PB_WAVES * 64, PB_WAVES * PB_QCAP * 12, st>>>(
-      p.post, p.term_base, p.sub_off, probe, probe_z, probe_row, umax, p.q, p.part_keys, p.total, p.tau, p.del, p.del_words, p.n_sub, p.n_terms, p.nq, p.P, p.k,
+  bm25_probe_kernel<NT, KPL, FILT, SKIP><<<(A + PB_WAVES - 1) / PB_WAVES, PB_WAVES * 64, PB_WAVES * PB_QCAP * 12, st>>>(
+      p.post, p.term_base, p.sub_off, probe, probe_z, probe_row, umax, pmax, qbound, p.q, p.part_keys, p.total, p.tau, p.del, p.del_words, p.n_sub, p.n_terms, p.nq, p.P, p.k,
       p.count);
   return SS_OK;
 }
@@ -500,13 +571,26 @@ int ssi_bm25_launch_union_count(const BmParams& p, const uint2* probe, const uin
 
 // returns SS_ENOTSUP when there is no instantiation for (nt_max, KPL): the caller falls back to the exhaustive kernels
 int ssi_bm25_launch_probe(const BmParams& p, const uint2* probe, const uint32_t* probe_z, const uint32_t* probe_row, const float* umax,
-                          uint32_t nt_max, int KPL, bool any_not, hipStream_t st) {
+                          const float* submax, float* pmax_ws, uint32_t nt_max, int KPL, bool any_not, hipStream_t st) {
+  const float* pmax = nullptr;
+  const float* qbound = nullptr;
+  if (submax && pmax_ws) {  // workspace: [nq][P][4] partition maxima, then [nq][n_sub] sub-block bounds
+    const uint32_t A = p.nq * p.P;
+    bm_partmax_kernel<<<(A + 3) / 4, 256, 0, st>>>(p.q, submax, p.n_sub, p.n_terms, p.nq, p.P, pmax_ws);
+    float* qb = pmax_ws + (size_t)A * 4u;
+    bm_qbound_kernel<<<dim3((p.n_sub + 255) / 256, p.nq), 256, 0, st>>>(p.q, submax, p.n_sub, p.nq, qb);
+    pmax = pmax_ws;
+    qbound = qb;
+  }
   if (!probe || !probe_z || !probe_row || !umax || nt_max == 0 || nt_max > 4 || (KPL != 1 && KPL != 2)) return SS_ENOTSUP;
   const int NT = nt_max <= 2 ? 2 : (int)nt_max;
   const bool filt = any_not || p.del != nullptr;
 #define SS_P(NT_, KPL_)                                                                          \
   if (NT == NT_ && KPL == KPL_)                                                                  \
-    return filt ? launch_probe<NT_, KPL_, true>(p, probe, probe_z, probe_row, umax, st) : launch_probe<NT_, KPL_, false>(p, probe, probe_z, probe_row, umax, st);
+    return qbound ? (filt ? launch_probe<NT_, KPL_, true, true>(p, probe, probe_z, probe_row, umax, pmax, qbound, st)   \
+                          : launch_probe<NT_, KPL_, false, true>(p, probe, probe_z, probe_row, umax, pmax, qbound, st)) \
+                  : (filt ? launch_probe<NT_, KPL_, true, false>(p, probe, probe_z, probe_row, umax, pmax, qbound, st)  \
+                          : launch_probe<NT_, KPL_, false, false>(p, probe, probe_z, probe_row, umax, pmax, qbound, st));
   SS_P(2, 1) SS_P(3, 1) SS_P(4, 1) SS_P(2, 2) SS_P(3, 2) SS_P(4, 2)
 #undef SS_P
   return SS_ENOTSUP;

@@ -83,12 +83,12 @@ static void free_vec(ss_shard* s) {
   ssi_vec_free_clusters(s);
 }
 static void free_bm25(ss_shard* s) {
-  void* ptrs[] = {s->d_post, s->d_term_base, s->d_sub_off, s->d_comp, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_umax, s->d_boost};
+  void* ptrs[] = {s->d_post, s->d_term_base, s->d_sub_off, s->d_comp, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_umax, s->d_submax, s->d_boost};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->d_post = nullptr; s->d_term_base = nullptr; s->d_sub_off = nullptr; s->d_comp = nullptr;
-  s->d_probe = nullptr; s->d_probe_z = nullptr; s->d_probe_row = nullptr; s->h_probe_row.clear(); s->bm_probe_rows = 0; s->d_umax = nullptr;
+  s->d_probe = nullptr; s->d_probe_z = nullptr; s->d_probe_row = nullptr; s->h_probe_row.clear(); s->bm_probe_rows = 0; s->d_umax = nullptr; s->d_submax = nullptr;
   s->bm_n_docs = 0; s->bm_n_terms = 0; s->bm_n_sub = 0; s->bm_n_post = 0; s->bm_n_fields = 1; s->d_boost = nullptr;
-  s->h_df.clear(); s->h_df_real.clear(); s->bm_n_post_pad = 0;
+  s->h_df.clear(); s->h_df_real.clear(); s->bm_n_post_pad = 0; s->bm_partmax = false;
 }
 
 int ss_shard_destroy(ss_shard* s) {

@@ -181,6 +181,11 @@ struct ss_shard {
   uint64_t probe_budget = 0;       // ss_bm25_set_probe_budget: bytes, 0 = half of the free device memory
   int bm_strategy = SS_BM25_AUTO;  // ss_bm25_set_strategy
   float* d_umax = nullptr;         // [n_terms + 1] largest weight tf*(K+1)/(tf+comp[len]) of the term (max_list_score / idf)
+  bool bm_partmax = false;         // the pruned kernel bounds every partition by its own block maxima (set at image build when the
+                                   // maxima vary over the doc ids; SS_BM25_SUBMAX=1 / 0 forces it on / off)
+  float* d_submax = nullptr;       // [n_terms + 1][n_sub] largest weight of every (term, 4096-doc sub-block) segment, 0 = empty: the
+                                   // reference's per-block max_block_score / idf (get_max_score, index.rs:2938-3200) at this image's
+                                   // block size; the last row (absent terms) is all zero
   // bm25 workspace
   void* d_bq = nullptr; size_t bq_cap = 0;       // staged queries
   uint64_t* d_part = nullptr; size_t part_cap = 0; // partition-local top-k keys

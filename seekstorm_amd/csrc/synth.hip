@@ -94,6 +94,8 @@ static int alloc_probe(ss_shard* s, hipStream_t st) {
   const size_t row_elems = (size_t)s->bm_n_sub * BM_GROUPS;
   SS_HIP(hipMalloc(&s->d_umax, ((size_t)nt + 1) * sizeof(float)));
   SS_HIP(hipMemsetAsync(s->d_umax, 0, ((size_t)nt + 1) * sizeof(float), st));
+  SS_HIP(hipMalloc(&s->d_submax, ((size_t)nt + 1) * s->bm_n_sub * sizeof(float)));
+  SS_HIP(hipMemsetAsync(s->d_submax, 0, ((size_t)nt + 1) * s->bm_n_sub * sizeof(float), st));
   size_t free_b = 0, total_b = 0;
   SS_HIP(hipMemGetInfo(&free_b, &total_b));
   const size_t budget = s->probe_budget ? (size_t)s->probe_budget : free_b / 2;
@@ -159,6 +161,7 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
   tbase[nt] = units;
   std::vector<uint32_t> post(units ? units * 4 : 4, 0u);
   std::vector<float> umax((size_t)nt + 1, 0.f);
+  std::vector<float> submax((size_t)(nt + 1) * ns, 0.f);
   for (uint32_t t = 0; t < nt; t++) {
     const bool flagged = bm_list_flagged(s, s->h_df[t]);
     const uint8_t* dl = doclen + (size_t)(t % s->bm_n_fields) * s->bm_n_docs;  // the list's field (virtual term = term * F + field)
@@ -174,6 +177,7 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
         const uint32_t code = bm_code_of(tfs[j], comp[dl[docs[j]]], flagged);
         post[w] = bm_pack(docs[j] & (BM_SUB - 1), code);
         umax[t] = std::max(umax[t], bm_wdecode(code));  // the bound of the pruned kernel: over the weights as the kernels see them
+        submax[(size_t)t * ns + sb] = std::max(submax[(size_t)t * ns + sb], bm_wdecode(code));
       }
     }
   }
@@ -217,6 +221,30 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
     }
   }
   SS_HIP(hipMemcpy(s->d_umax, umax.data(), umax.size() * sizeof(float), hipMemcpyHostToDevice));
+  SS_HIP(hipMemcpy(s->d_submax, submax.data(), submax.size() * sizeof(float), hipMemcpyHostToDevice));
+  // Are block maxima worth a pass per search?  Only where they vary over the doc ids: for the longest lists, the mean over
+  // 32 equal partitions of (largest weight inside the partition) / (largest weight of the list).  A corpus whose weights are
+  // spread evenly (every synthetic one here) gives ~1; docs ordered by source / time / length give clearly less.
+  {
+    std::vector<uint32_t> order(nt);
+    for (uint32_t t = 0; t < nt; t++) order[t] = t;
+    const uint32_t top = std::min<uint32_t>(nt, 64);
+    std::partial_sort(order.begin(), order.begin() + top, order.end(), [&](uint32_t a, uint32_t b) { return s->h_df[a] > s->h_df[b]; });
+    double worst = 1.0;
+    const uint32_t parts = std::min<uint32_t>(32, ns);
+    for (uint32_t i = 0; i < top; i++) {
+      const uint32_t t = order[i];
+      if (umax[t] <= 0.f || s->h_df[t] < 64) continue;
+      double acc = 0.0;
+      for (uint32_t pi = 0; pi < parts; pi++) {
+        float m = 0.f;
+        for (uint32_t sb = (uint32_t)((u64)ns * pi / parts); sb < (uint32_t)((u64)ns * (pi + 1) / parts); sb++) m = std::max(m, submax[(size_t)t * ns + sb]);
+        acc += m / umax[t];
+      }
+      worst = std::min(worst, acc / parts);
+    }
+    s->bm_partmax = worst < 0.9;
+  }
   if (s->d_probe && !probe.empty())
   {
     SS_HIP(hipMemcpy(s->d_probe, probe.data(), probe.size() * sizeof(uint2), hipMemcpyHostToDevice));
@@ -246,7 +274,8 @@ __global__ void lex_gen_kernel(u64 seed, u64 n_docs, uint32_t n_terms, uint32_t 
                                const uint8_t* __restrict__ doclen, uint32_t* __restrict__ sub /*[nt][ns+1]*/,
                                const u64* __restrict__ term_base, uint32_t* __restrict__ post, u64* __restrict__ df,
                                uint2* __restrict__ probe, uint32_t* __restrict__ probe_z, const uint32_t* __restrict__ probe_row,
-                               uint32_t* __restrict__ umax_bits, const uint32_t* __restrict__ wcode /*[33][256] weight codes by (tf, len)*/,
+                               uint32_t* __restrict__ umax_bits, float* __restrict__ submax /*[nt][n_sub]*/,
+                               const uint32_t* __restrict__ wcode /*[33][256] weight codes by (tf, len)*/,
                                const uint8_t* __restrict__ flagged /*[nt] list carries (tf < 10) in its codes*/, u64 gs, u64 go) {
   const int lane = threadIdx.x & 63;
   const u64 gw = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -283,6 +312,7 @@ __global__ void lex_gen_kernel(u64 seed, u64 n_docs, uint32_t n_terms, uint32_t 
   if (FILL) {
     for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
     if (lane == 0 && wmax > 0.f) atomicMax(&umax_bits[t], __float_as_uint(wmax));  // positive floats order like their bits
+    if (lane == 0) submax[(size_t)t * n_sub + sb] = wmax;
     if ((uint32_t)lane < ((4u - (run & 3u)) & 3u)) post[base + run + lane] = 0u;  // NULL padding
   } else if (lane == 0) {
     sub[(size_t)t * (n_sub + 1) + sb + 1] = (run + 3u) >> 2;  // shifted by one for the exclusive scan
@@ -349,7 +379,7 @@ int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const u
   const u64 waves = (u64)nt * ns;
   const uint32_t grid = (uint32_t)((waves + 3) / 4);
   lex_gen_kernel<false><<<grid, 256, 0, st>>>(seed, nd, nt, ns, d_thresh, d_doclen, s->d_sub_off, nullptr, nullptr, d_df,
-                                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s->synth_stride, s->synth_offset);
+                                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s->synth_stride, s->synth_offset);
   lex_scan_rows_kernel<<<nt, 1024, 0, st>>>(s->d_sub_off, ns, d_tot);
   lex_scan_terms_kernel<<<1, 64, 0, st>>>(d_tot, (u64*)s->d_term_base, nt);
   SS_HIP(hipStreamSynchronize(st));
@@ -387,7 +417,7 @@ int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const u
   SS_HIP(hipMemcpyAsync(d_flg, flg.data(), nt, hipMemcpyHostToDevice, st));
   lex_gen_kernel<true><<<grid, 256, 0, st>>>(seed, nd, nt, ns, d_thresh, d_doclen, s->d_sub_off,
                                              (const u64*)s->d_term_base, s->d_post, nullptr, s->d_probe, s->d_probe_z, s->d_probe_row,
-                                             (uint32_t*)s->d_umax, d_wtab, d_flg, s->synth_stride, s->synth_offset);
+                                             (uint32_t*)s->d_umax, s->d_submax, d_wtab, d_flg, s->synth_stride, s->synth_offset);
   SS_HIP(hipStreamSynchronize(st));
   (void)hipFree(d_wtab);
   (void)hipFree(d_flg);

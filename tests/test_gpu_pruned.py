@@ -183,3 +183,37 @@ def test_rationed_probe_rows(S, O):
         part.search_lexical_batch(part.make_queries([[0, 1], [2, 6]], S.QueryType.Union), 10, S.ResultType.Topk)
     full.close()
     part.close()
+
+
+def test_block_maxima_on_a_skewed_corpus(S, O):
+    """a-12: per-(term, block) maxima (get_max_score, index.rs:2938-3200; used as in intersection.rs:2090-2097, single.rs:373-386).
+    A corpus whose weights are clustered by doc id -- short-doc regions hold the top-k, the long-doc regions' block maxima lie
+    far below the list maxima: the image turns the per-partition bounds on by itself, and the pruned strategy under them still
+    equals the exhaustive one bit for bit and the oracle within tolerance (unions and intersections, Topk / TopkCount)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "probes"))
+    import skew_corpus
+    from seekstorm_amd import _native as N
+    n_docs = 1_200_000
+    dl, offs, docs, tfs = skew_corpus.build(O, n_docs, [0.012, 0.035, 0.10, 0.02])
+    sh = S.Shard(0)
+    sh.upload_lexical(n_docs, dl, offs, docs, tfs)
+    osh = O.Shard(n_docs, dl, offs, docs, tfs)
+    cases = [([0, 1, 2], S.QueryType.Union, O.OP_OR), ([1, 3], S.QueryType.Union, O.OP_OR), ([2], S.QueryType.Union, O.OP_OR),
+             ([0, 2, 3, 1], S.QueryType.Union, O.OP_OR), ([1, 2], S.QueryType.Intersection, O.OP_AND)]
+    q = sh.make_queries([c[0] for c in cases], [c[1] for c in cases])
+    res = {}
+    for strat in (N.BM25_EXHAUSTIVE, N.BM25_AUTO):
+        sh.set_strategy(strat)
+        res[strat] = [sh.search_lexical_batch(q, 10, rt) for rt in (S.ResultType.Topk, S.ResultType.TopkCount)]
+    for a, b in zip(res[N.BM25_EXHAUSTIVE], res[N.BM25_AUTO]):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    doc, score, cnt, tot = res[N.BM25_AUTO][1]
+    for i, (terms, _, op) in enumerate(cases):
+        od, os_, otot = osh.search_ref(terms, op, 10, O.RT_TOPKCOUNT)
+        assert int(tot[i]) == otot and cnt[i] == len(od)
+        assert np.allclose(score[i][:cnt[i]], os_, rtol=1e-4)
+        # every result lives in a short-doc region (region % 8 == 3)
+        assert np.all(((doc[i][:cnt[i]] >> 16) % 8) == 3)
+    sh.set_strategy(N.BM25_AUTO)
+    sh.close()
