@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 1
+#define SS_ABI_VERSION 2
 #define SS_NO_DOC 0xFFFFFFFFu
 #define SS_MAX_QUERY_TERMS 10 /* union_docid_3 handles <= 10 terms, union.rs:1308 */
 #define SS_MAX_K 1024
@@ -53,8 +53,10 @@ enum {
   SS_ESTATE = -5    /* image not uploaded yet */
 };
 
-/* QueryType (search.rs:59) restricted to the two set operations; ResultType (search.rs:168) */
-enum { SS_OP_INTERSECTION = 0, SS_OP_UNION = 1 };
+/* QueryType (search.rs:59): the two set operations and Phrase (an intersection whose docs must carry the words at
+ * consecutive positions, add_result.rs:3586-3684); ResultType (search.rs:168) */
+enum { SS_OP_INTERSECTION = 0, SS_OP_UNION = 1, SS_OP_PHRASE = 2 };
+#define SS_MAX_PHRASE 12 /* words of a phrase query */
 enum { SS_RT_COUNT = 0, SS_RT_TOPK = 1, SS_RT_TOPKCOUNT = 2 };
 /* SearchMode (search.rs:73) for ss_merge_results */
 enum { SS_MODE_LEXICAL = 0, SS_MODE_VECTOR = 1, SS_MODE_HYBRID = 2 };
@@ -87,6 +89,13 @@ int ss_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen_bytes, ui
 int ss_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen_bytes, const float* boost,
                           uint32_t n_terms, const uint64_t* term_offsets, const uint32_t* doc_ids, const uint8_t* field_ids,
                           const uint16_t* tfs);
+
+/* ss_bm25_upload plus the POSITIONS of every posting (one indexed field): positions = for every posting in CSR order its tf
+ * positions inside the field, ascending, each < 65 536 (token_per_field_max, index.rs:5343) -- what the reference decodes from
+ * the position records / embedded pointers (add_result.rs:38-59, 2036-2197; compress_postinglist.rs:949-977).  n_positions must
+ * be the sum of tfs.  2 bytes per position + 4 bytes per posting of HBM; only phrase queries read them. */
+int ss_bm25_upload_positions(ss_shard* s, uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t n_terms, const uint64_t* term_offsets,
+                             const uint32_t* doc_ids, const uint16_t* tfs, const uint16_t* positions, uint64_t n_positions);
 
 /* Tombstones = the shard's delete_hashset (index.rs:1594): shard-local doc ids, as delete.bin stores them (a plain
  * stream of u64, index.rs:3798-3809 -- the file's bytes can be passed as they are) or as delete_document adds them
@@ -205,7 +214,15 @@ typedef struct {
   uint32_t op;                       /* SS_OP_* | SS_OP_NOT_TERMS(number of NOT terms) */
   uint32_t term[SS_MAX_QUERY_TERMS]; /* term index into the uploaded vocabulary; query terms first, then the NOT terms */
   float idf[SS_MAX_QUERY_TERMS];     /* host-computed, search.rs:3225-3230; entries of NOT terms are ignored */
+  uint32_t phrase_len;               /* SS_OP_PHRASE: words of the phrase, 2 .. SS_MAX_PHRASE (non_unique_query_list); else 0 */
+  uint8_t phrase_seq[SS_MAX_PHRASE]; /* word i of the phrase is term[phrase_seq[i]]: a repeated word names its unique term again */
 } ss_bm25_query;
+/* SS_OP_PHRASE ("..." queries, QueryType::Phrase): term[] holds the phrase's UNIQUE terms (query_list), phrase_seq its words in
+ * order.  A doc matches when it contains every unique term and some position p carries word i at p + i for every i
+ * (add_result.rs:3596-3684: the merge over the entries' position lists, fewest positions first); it is scored like the
+ * intersection of the unique terms (get_bm25f_multiterm_singlefield) and counted only when the phrase matches.  Needs the
+ * positions in the image (ss_bm25_upload_positions), one indexed field, every list with a probe row; a batch holds phrase
+ * queries only (ops_mask bit 4 for ss_bm25_search_dev); NOT terms are not offered with phrases (SS_ENOTSUP). */
 
 /* Batched BM25 search.  Outputs: out_doc/out_score [n_queries*k], out_count [n_queries] (= results.len()),
  * out_total [n_queries] (= result_count_total: exact match count for Count/TopkCount). */
@@ -219,7 +236,7 @@ int ss_bm25_search(ss_shard* s, uint32_t n_queries, const ss_bm25_query* queries
  * bits 8..15 = the largest n_terms + NOT terms in the batch (0 = unknown: the generic 10-term kernel is used); bits 16..23 =
  * the largest n_terms alone (0 = same as bits 8..15, i.e. no NOT terms); bit 2 set if every term of the batch has probe rows
  * (ss_bm25_term_probed; irrelevant when the probe budget covered all lists); bit 3 set if some query carries
- * SS_OP_ALL_TERMS_FREQUENT.
+ * SS_OP_ALL_TERMS_FREQUENT; bit 4 set if the batch consists of SS_OP_PHRASE queries (then all of them must be).
  * The assertion is CHECKED ON THE DEVICE, query by query, before the search kernels run: a query that contradicts ops_mask
  * (an intersection in a batch declared union-only, more terms than declared, an unprobed term under bit 2, ...) or is
  * malformed (no terms, a term id outside the vocabulary) is answered as an empty query and flagged

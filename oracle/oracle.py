@@ -236,6 +236,27 @@ class Shard:
         f.argtypes = [C.c_void_p, C.c_uint32, u32p, C.c_uint32, u32p, C.c_int, C.c_uint32, C.c_int, u32p, f32p, u64p]
         return self._search(f, terms, not_terms, op, k, rt)
 
+    def set_positions(self, positions):
+        """positions of every posting in CSR order (tf values each, ascending): what a phrase query walks"""
+        self.positions = np.ascontiguousarray(positions, np.uint16)
+        f = lib().so_shard_set_positions
+        f.argtypes = [C.c_void_p, u16p, C.c_uint64]
+        f.restype = None
+        f(self.h, _p(self.positions, u16p), len(self.positions))
+
+    def search_phrase(self, terms, seq, k, reference_loop=True):
+        """QueryType::Phrase: terms = unique terms, seq = index into terms of every word -> (docs, scores, matches)"""
+        q = np.ascontiguousarray(terms, np.uint32)
+        sq = np.ascontiguousarray(seq, np.uint8)
+        od = np.empty(max(k, 1), np.uint32)
+        os_ = np.empty(max(k, 1), np.float32)
+        tot = C.c_uint64()
+        f = lib().so_search_phrase
+        f.restype = C.c_uint32
+        f.argtypes = [C.c_void_p, C.c_uint32, u32p, C.c_uint32, u8p, C.c_uint32, C.c_int, u32p, f32p, C.POINTER(C.c_uint64)]
+        n = f(self.h, len(q), _p(q, u32p), len(sq), _p(sq, u8p), k, 1 if reference_loop else 0, _p(od, u32p), _p(os_, f32p), C.byref(tot))
+        return od[:n].copy(), os_[:n].copy(), tot.value
+
     def all_terms_frequent(self, terms, top_k):
         f = lib().so_all_terms_frequent
         f.restype = C.c_int
@@ -546,3 +567,27 @@ def euclidean_f32(a, b, simd_order=True):
     f.restype = C.c_float
     f.argtypes = [f32p, f32p, C.c_uint32]
     return float(f(_p(a, f32p), _p(b, f32p), len(a)))
+
+
+def phrase_match(position_lists, reference_loop=True):
+    """so_phrase_match: position_lists[i] = ascending positions of the i-th word of the phrase"""
+    n = len(position_lists)
+    arrs = [np.ascontiguousarray(p, np.uint16) for p in position_lists]
+    ptrs = (u16p * n)(*[_p(a, u16p) if len(a) else C.cast(None, u16p) for a in arrs])
+    cnt = np.array([len(a) for a in arrs], np.uint32)
+    f = lib().so_phrase_match
+    f.restype = C.c_int
+    f.argtypes = [C.c_uint32, C.POINTER(u16p), u32p, C.c_int]
+    return bool(f(n, ptrs, _p(cnt, u32p), 1 if reference_loop else 0))
+
+
+def synth_positions(doclen_bytes, docs, tfs, seed=99):
+    """positions for every posting: tf distinct ascending positions below the doc's (decoded) length, deterministic"""
+    L = lib()
+    dec = np.array([L.so_byte4_to_int(i) for i in range(256)], np.int64)
+    rng = np.random.default_rng(seed)
+    out = []
+    for d, tf in zip(docs, tfs):
+        n = max(int(dec[doclen_bytes[d]]), int(tf), 1)
+        out.append(np.sort(rng.choice(min(n, 65535), int(tf), replace=False)).astype(np.uint16))
+    return np.concatenate(out) if out else np.zeros(0, np.uint16)

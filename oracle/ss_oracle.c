@@ -126,6 +126,8 @@ struct so_shard {
   uint64_t* off;   /* raw CSR copy for the exhaustive ground truth */
   uint32_t* docs;
   uint16_t* tfs;
+  uint64_t* pos_off; /* [postings + 1] CSR of the positions of every posting (so_shard_set_positions), NULL = none */
+  uint16_t* pos;
 };
 
 static inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
@@ -251,7 +253,7 @@ void so_shard_free(so_shard* s) {
     for (uint32_t b = 0; b < s->terms[t].n_blocks; b++) free(s->terms[t].blocks[b].cont);
     free(s->terms[t].blocks);
   }
-  free(s->terms); free(s->doclen); free(s->off); free(s->docs); free(s->tfs); free(s->deleted); free(s);
+  free(s->terms); free(s->doclen); free(s->off); free(s->docs); free(s->tfs); free(s->deleted); free(s->pos_off); free(s->pos); free(s);
 }
 /* delete_hashset: index.rs:1594, filled from delete.bin (index.rs:3798-3809) / delete_document (index.rs:5110) */
 void so_shard_set_deleted(so_shard* s, const uint64_t* doc_ids, uint64_t n) {
@@ -1480,4 +1482,114 @@ double so_bench_lex(so_shard* const* shards, uint32_t S, const uint32_t* q_terms
   if (out_queries) *out_queries = done;
   if (out_nlat) *out_nlat = nlat;
   return el > 0 ? (double)done / el : 0.0;
+}
+
+
+/* ================================================================== phrase queries (QueryType::Phrase)
+ * The phrase check of add_result_multiterm_singlefield (add_result.rs:3586-3684): the positions of every phrase entry
+ * (non_unique_query_list: one entry per word of the phrase, term_index_nonunique = its place in the phrase; repeated words
+ * share a unique term's positions) are walked by a merge on the phrase start pos - term_index_nonunique, the entry with the
+ * fewest positions first (sort at 3616-3617).  Positions are decoded from their delta form first + (delta + 1) ...
+ * (get_next_position_singlefield, add_result.rs:38-59; "pos1 += next + 1" at 3640, 3678).  A doc matches when some start
+ * carries every word at its place.  Two restatements: the reference's merge loop (phrase_match_ref) and the definition
+ * (phrase_match_def); tests assert they agree. */
+void so_shard_set_positions(so_shard* s, const uint16_t* positions, uint64_t n_positions) {
+  free(s->pos_off); free(s->pos);
+  const uint64_t np = s->off[s->n_terms];
+  s->pos_off = (uint64_t*)malloc((np + 1) * sizeof(uint64_t));
+  uint64_t a = 0;
+  for (uint64_t i = 0; i < np; i++) { s->pos_off[i] = a; a += s->tfs[i]; }
+  s->pos_off[np] = a;
+  if (a != n_positions) { free(s->pos_off); s->pos_off = NULL; s->pos = NULL; return; }
+  s->pos = (uint16_t*)malloc((a ? a : 1) * sizeof(uint16_t));
+  memcpy(s->pos, positions, a * sizeof(uint16_t));
+}
+/* definition: exists start with word i at start + i for every i */
+static int phrase_match_def(uint32_t n_seq, const uint16_t* const* pos, const uint32_t* cnt) {
+  for (uint32_t j = 0; j < cnt[0]; j++) {
+    const uint32_t start = pos[0][j];
+    int ok = 1;
+    for (uint32_t i = 1; i < n_seq && ok; i++) {
+      ok = 0;
+      for (uint32_t x = 0; x < cnt[i]; x++) if ((uint32_t)pos[i][x] == start + i) { ok = 1; break; }
+    }
+    if (ok) return 1;
+  }
+  return 0;
+}
+/* the reference's loop, add_result.rs:3596-3684 (phrasematch_count >= 1 ends it) */
+typedef struct { uint32_t idx, count, p_pos, pos; const uint16_t* list; } so_nu;
+static int nu_cmp(const void* a, const void* b) { /* sort_unstable_by positions_count; ties: by idx (any order is legal) */
+  const so_nu* x = (const so_nu*)a; const so_nu* y = (const so_nu*)b;
+  if (x->count != y->count) return x->count < y->count ? -1 : 1;
+  return (x->idx > y->idx) - (x->idx < y->idx);
+}
+static int phrase_match_ref(uint32_t n_seq, const uint16_t* const* pos, const uint32_t* cnt) {
+  so_nu nu[32];
+  if (n_seq < 2) return cnt[0] > 0;
+  for (uint32_t i = 0; i < n_seq; i++) {
+    if (cnt[i] == 0) return 0;
+    nu[i].idx = i; nu[i].count = cnt[i]; nu[i].p_pos = 0; nu[i].list = pos[i]; nu[i].pos = pos[i][0];
+  }
+  qsort(nu, n_seq, sizeof(so_nu), nu_cmp);
+  uint32_t t2 = 1;
+  uint32_t pos1 = nu[0].pos, pos2 = nu[1].pos;
+  for (;;) {
+    const uint32_t l = pos1 + nu[t2].idx, r = pos2 + nu[0].idx;
+    if (l < r) {
+      if (t2 > 1) { t2 = 1; pos2 = nu[t2].pos; }
+      if (++nu[0].p_pos == nu[0].count) return 0;
+      pos1 = nu[0].list[nu[0].p_pos]; /* pos1 += delta + 1: the next absolute position */
+    } else if (l > r) {
+      if (++nu[t2].p_pos == nu[t2].count) return 0;
+      pos2 = nu[t2].list[nu[t2].p_pos];
+      nu[t2].pos = pos2;
+    } else {
+      if (t2 + 1 < n_seq) { t2++; pos2 = nu[t2].pos; continue; }
+      return 1;
+    }
+  }
+}
+int so_phrase_match(uint32_t n_seq, const uint16_t* const* pos, const uint32_t* cnt, int reference_loop) {
+  return reference_loop ? phrase_match_ref(n_seq, pos, cnt) : phrase_match_def(n_seq, pos, cnt);
+}
+
+/* Phrase search over one indexed field: the docs containing every unique term (intersection) whose positions carry the
+ * phrase; scored like the intersection (get_bm25f_multiterm_singlefield over the unique terms, add_result.rs:3573, 3692),
+ * counted only when the phrase matches (3686-3690).  seq[i] = index into q_terms of the i-th word.  Exact top-k by (score
+ * desc, doc asc); *total = matches. */
+uint32_t so_search_phrase(const so_shard* s, uint32_t nq, const uint32_t* qt, uint32_t n_seq, const uint8_t* seq, uint32_t k,
+                          int reference_loop, uint32_t* od, float* os, uint64_t* total) {
+  if (!s->pos || nq == 0 || nq > 32 || n_seq == 0 || n_seq > 32) { if (total) *total = 0; return 0; }
+  float idf[32];
+  for (uint32_t t = 0; t < nq; t++) idf[t] = so_idf(s->n_docs, s->terms[qt[t]].posting_count);
+  uint64_t cur[32];
+  for (uint32_t t = 0; t < nq; t++) cur[t] = s->off[qt[t]];
+  so_sd* v = NULL; uint64_t nv = 0, cap = 0;
+  for (uint64_t i0 = s->off[qt[0]]; i0 < s->off[qt[0] + 1]; i0++) {
+    const uint32_t d = s->docs[i0];
+    int all = 1;
+    uint64_t at[32]; at[0] = i0;
+    for (uint32_t t = 1; t < nq && all; t++) {
+      while (cur[t] < s->off[qt[t] + 1] && s->docs[cur[t]] < d) cur[t]++;
+      all = cur[t] < s->off[qt[t] + 1] && s->docs[cur[t]] == d;
+      at[t] = cur[t];
+    }
+    if (!all) continue;
+    if (s->deleted && s->deleted[d]) continue;
+    const uint16_t* pl[32]; uint32_t pc[32];
+    for (uint32_t i = 0; i < n_seq; i++) { pl[i] = s->pos + s->pos_off[at[seq[i]]]; pc[i] = s->tfs[at[seq[i]]]; }
+    if (!so_phrase_match(n_seq, pl, pc, reference_loop)) continue;
+    float sc = 0.0f;
+    const float comp = s->comp[s->doclen[d]];
+    for (uint32_t t = 0; t < nq; t++) sc += so_bm25_term(idf[t], s->tfs[at[t]], comp);
+    if (nv == cap) { cap = cap ? cap * 2 : 1024; v = (so_sd*)realloc(v, cap * sizeof(so_sd)); }
+    v[nv].score = sc; v[nv].doc = d; nv++;
+  }
+  if (nv) qsort(v, nv, sizeof(so_sd), sd_cmp);
+  const uint32_t n = (uint32_t)(nv < k ? nv : k);
+  for (uint32_t i = 0; i < n; i++) { od[i] = v[i].doc; os[i] = v[i].score; }
+  if (total) *total = nv;
+  free(v);
+  return n;
 }

@@ -126,6 +126,15 @@ uint32_t so_search_fields_filtered(uint64_t n_docs, uint32_t n_fields, const uin
                                    uint32_t n_q_terms, const uint32_t* q_terms, uint32_t n_not, const uint32_t* not_terms,
                                    int op, uint32_t k, const uint64_t* deleted, uint64_t n_deleted, uint32_t field_mask,
                                    uint32_t* out_doc, float* out_score, uint64_t* out_total, float* out_avgdl);
+/* ---- phrase queries (QueryType::Phrase; phrase check add_result.rs:3586-3684, positions add_result.rs:38-59) ----
+ * positions: for every posting in CSR order its tf positions (ascending, < 65 536 per field: index.rs:5343) */
+void so_shard_set_positions(so_shard*, const uint16_t* positions, uint64_t n_positions);
+/* does the phrase match?  pos[i] / cnt[i]: positions of the i-th word of the phrase.  reference_loop != 0: the reference's
+ * merge loop restated; 0: the definition (some start carries word i at start + i) */
+int so_phrase_match(uint32_t n_seq, const uint16_t* const* pos, const uint32_t* cnt, int reference_loop);
+/* q_terms: the unique terms; seq[n_seq]: index into q_terms of every word of the phrase */
+uint32_t so_search_phrase(const so_shard*, uint32_t n_q_terms, const uint32_t* q_terms, uint32_t n_seq, const uint8_t* seq, uint32_t k,
+                          int reference_loop, uint32_t* out_doc, float* out_score, uint64_t* out_total);
 /* statistics for the roofline's algorithmic bytes: sum df, #blocks touched */
 void so_query_stats(const so_shard*, uint32_t n_q_terms, const uint32_t* q_terms, uint64_t* sum_df,
                     uint64_t* sum_blocks);

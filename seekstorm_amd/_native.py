@@ -12,9 +12,10 @@ LIB_PATH = os.environ.get("SEEKSTORM_HIP_LIB") or os.path.join(_HERE, "lib", "li
 
 SS_NO_DOC = 0xFFFFFFFF
 SS_MAX_QUERY_TERMS = 10
+SS_MAX_PHRASE = 12
 SS_MAX_K = 1024
 SS_VEC_BATCH = 64
-OP_INTERSECTION, OP_UNION = 0, 1
+OP_INTERSECTION, OP_UNION, OP_PHRASE = 0, 1, 2
 BM25_AUTO, BM25_EXHAUSTIVE, BM25_PRUNED = 0, 1, 2
 RT_COUNT, RT_TOPK, RT_TOPKCOUNT = 0, 1, 2
 MODE_LEXICAL, MODE_VECTOR, MODE_HYBRID = 0, 1, 2
@@ -31,7 +32,7 @@ f32p = C.POINTER(C.c_float)
 
 class Bm25Query(C.Structure):
     _fields_ = [("n_terms", C.c_uint32), ("op", C.c_uint32), ("term", C.c_uint32 * SS_MAX_QUERY_TERMS),
-                ("idf", C.c_float * SS_MAX_QUERY_TERMS)]
+                ("idf", C.c_float * SS_MAX_QUERY_TERMS), ("phrase_len", C.c_uint32), ("phrase_seq", C.c_uint8 * SS_MAX_PHRASE)]
 
 
 class RefBlock(C.Structure):  # ss_ref_block
@@ -53,7 +54,7 @@ class AnnModeC(C.Structure):  # ss_ann_mode
 
 
 BM25_QUERY_DTYPE = np.dtype([("n_terms", np.uint32), ("op", np.uint32), ("term", np.uint32, (SS_MAX_QUERY_TERMS,)),
-                             ("idf", np.float32, (SS_MAX_QUERY_TERMS,))])
+                             ("idf", np.float32, (SS_MAX_QUERY_TERMS,)), ("phrase_len", np.uint32), ("phrase_seq", np.uint8, (SS_MAX_PHRASE,))])
 assert BM25_QUERY_DTYPE.itemsize == C.sizeof(Bm25Query)
 
 # every symbol include/seekstorm_hip.h declares: (name, restype, argtypes)
@@ -66,6 +67,7 @@ SYMBOLS = [
     ("ss_shard_sync", C.c_int, [C.c_void_p]),
     ("ss_set_deleted", C.c_int, [C.c_void_p, u64p, C.c_uint64]),
     ("ss_bm25_upload", C.c_int, [C.c_void_p, C.c_uint64, u8p, C.c_uint32, u64p, u32p, u16p]),
+    ("ss_bm25_upload_positions", C.c_int, [C.c_void_p, C.c_uint64, u8p, C.c_uint32, u64p, u32p, u16p, u16p, C.c_uint64]),
     ("ss_bm25_upload_fields", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, u8p, f32p, C.c_uint32, u64p, u32p, u8p, u16p]),
     ("ss_ref_decode_block", C.c_int, [C.c_void_p, u16p, u16p]),
     ("ss_bm25_upload_ref_blocks", C.c_int, [C.c_void_p, C.c_uint64, u8p, C.c_uint32, u64p, C.c_void_p]),

@@ -107,7 +107,7 @@ __global__ void bm25_final_kernel(const u64* __restrict__ keys, const u64* __res
 // query that contradicts it (an intersection in a batch declared union-only would run a variant without match counters,
 // more terms than declared would overrun the NT-specialised kernel, ...) or that is malformed (term id out of range, no
 // terms) is replaced by an empty query and reports d_out_count = UINT32_MAX instead of a silently wrong answer.
-constexpr uint32_t BM_CLAIM_AND = 1u, BM_CLAIM_OR = 2u, BM_CLAIM_PROBED = 4u, BM_CLAIM_FREQ = 8u;
+constexpr uint32_t BM_CLAIM_AND = 1u, BM_CLAIM_OR = 2u, BM_CLAIM_PROBED = 4u, BM_CLAIM_FREQ = 8u, BM_CLAIM_PHRASE = 16u;
 __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery* __restrict__ vq, uint32_t nq, uint32_t n_fields,
                                  const unsigned long long* __restrict__ term_base, const float* __restrict__ boost,
                                  unsigned long long* __restrict__ total, uint32_t* __restrict__ tau, uint32_t claim,
@@ -123,10 +123,21 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
     const uint32_t nt_claim = (claim >> 8) & 0xFFu, np_claim = (claim >> 16) & 0xFFu, ff = n_fields > 1 ? bm_q_field_filter(Q.op) : 0u;
     bool bad = np == 0 || np + n_not > (uint32_t)SS_MAX_QUERY_TERMS || (np + n_not) * n_fields > (uint32_t)BM_MAX_VTERMS;
     bad |= np + n_not > nt_claim || np > np_claim;
-    const bool q_and = (bm_q_op(Q.op) == SS_OP_INTERSECTION && np > 1) || ff != 0u;
+    const bool q_and = ((bm_q_op(Q.op) == SS_OP_INTERSECTION || bm_q_op(Q.op) == SS_OP_PHRASE) && np > 1) || ff != 0u;
     bad |= q_and && !(claim & BM_CLAIM_AND);
     bad |= !q_and && np > 1 && !(claim & BM_CLAIM_OR);
-    bad |= bm_q_op(Q.op) > (uint32_t)SS_OP_UNION;
+    // a phrase batch holds phrase queries only (one indexed field, no NOT terms, 2 .. SS_MAX_PHRASE words naming the unique terms)
+    const bool q_phrase = bm_q_op(Q.op) == SS_OP_PHRASE;
+    bad |= bm_q_op(Q.op) > (uint32_t)SS_OP_PHRASE || q_phrase != ((claim & BM_CLAIM_PHRASE) != 0u);
+    if (q_phrase) {
+      bad |= n_fields != 1 || n_not != 0 || Q.phrase_len < 2u || Q.phrase_len > (uint32_t)SS_MAX_PHRASE || np > 6u;
+      uint32_t used = 0;
+      for (uint32_t j = 0; j < (uint32_t)SS_MAX_PHRASE && j < Q.phrase_len; j++) {
+        bad |= Q.phrase_seq[j] >= np;
+        used |= 1u << (Q.phrase_seq[j] & 15u);
+      }
+      bad |= !bad && used != (1u << np) - 1u;  // every unique term is a word of the phrase
+    }
     bad |= bm_q_all_frequent(Q.op) && bm_q_op(Q.op) == SS_OP_INTERSECTION && np > 1 && !(claim & BM_CLAIM_FREQ);
     if (!bad)
       for (uint32_t t = 0; t < np + n_not; t++) {
@@ -141,6 +152,8 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
     if (bad) {  // the empty query: one absent term (the all-zero directory row n_vterms, idf 0)
       V.n_terms = 1; V.op = SS_OP_UNION; V.n_groups = 1; V.and_target = 0;
       for (uint32_t j = 0; j < (uint32_t)BM_MAX_VTERMS; j++) { V.term[j] = j ? 0 : n_vterms; V.idf[j] = 0.f; V.and_val[j] = 0; V.group[j] = j ? 0xFF : 0; }
+      V.phrase_len = (claim & BM_CLAIM_PHRASE) ? 2u : 0u;  // an empty phrase query: both words are the absent term
+      for (int j = 0; j < SS_MAX_PHRASE; j++) V.phrase_seq[j] = 0;
       vq[i] = V;
       return;
     }
@@ -148,7 +161,7 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
   // field_filter (several indexed fields): every term must occur in a listed field (add_result.rs:3124-3136) -- an
   // intersection whose match bits only the listed fields' lists may set; a single filtered term is an intersection of one
   const uint32_t filt = n_fields > 1 ? bm_q_field_filter(Q.op) : 0u;
-  const bool is_and = (bm_q_op(Q.op) == SS_OP_INTERSECTION && np > 1) || filt != 0u;
+  const bool is_and = ((bm_q_op(Q.op) == SS_OP_INTERSECTION || bm_q_op(Q.op) == SS_OP_PHRASE) && np > 1) || filt != 0u;
   const bool mask = np <= 8;  // 9-10 terms (single field only, checked on the host): count instead of bits
   // all_terms_frequent (intersection.rs:198-209): the caller saw N > 256 k and df >= N / 2 for every term.  One field and
   // <= 7 terms (bit 7 of the match byte becomes the "some tf < 10" mark; the host refuses the rest).
@@ -170,10 +183,13 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
   }
   if (n_not == 0) V.n_terms = n;
   const uint32_t n_scored = V.n_terms;
-  V.op = (filt ? (uint32_t)SS_OP_INTERSECTION : np > 1 ? bm_q_op(Q.op) : (uint32_t)SS_OP_UNION) | ((n - n_scored) << 8);
+  V.op = (filt ? (uint32_t)SS_OP_INTERSECTION : np > 1 ? (bm_q_op(Q.op) == SS_OP_PHRASE ? (uint32_t)SS_OP_INTERSECTION : bm_q_op(Q.op)) : (uint32_t)SS_OP_UNION) |
+         ((n - n_scored) << 8);
   V.n_groups = np;
   V.and_target = is_and ? ((mask ? (1u << np) - 1u : np) | (freq ? BM_AND_FREQ : 0u)) : 0u;
   for (uint32_t j = n; j < (uint32_t)BM_MAX_VTERMS; j++) { V.term[j] = 0; V.idf[j] = 0.f; V.and_val[j] = 0; V.group[j] = 0xFF; }
+  V.phrase_len = bm_q_op(Q.op) == SS_OP_PHRASE ? Q.phrase_len : 0u;
+  for (int j = 0; j < SS_MAX_PHRASE; j++) V.phrase_seq[j] = Q.phrase_seq[j];
   vq[i] = V;
 }
 
@@ -206,7 +222,7 @@ int ssi_bm25_match_bits(ss_shard* s, const ss_bm25_query* d_q, unsigned long lon
 
 int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t* d_out_doc,
                     float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, bool has_or,
-                    uint32_t nt_max, uint32_t np_max, bool all_probed, hipStream_t st, bool any_frequent) {
+                    uint32_t nt_max, uint32_t np_max, bool all_probed, hipStream_t st, bool any_frequent, bool phrase) {
   if (!s->d_post) return SS_ESTATE;
   if (nq == 0) return SS_OK;
   if (k > SS_MAX_K) return SS_EINVAL;
@@ -229,16 +245,18 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   // an intersection under the all_terms_frequent shortcut ranks by a per-posting rule (tf >= 10): scan kernels only
   const bool pruned = s->bm_strategy != SS_BM25_EXHAUSTIVE && have_probe && !(F > 1 && has_and) && !any_frequent &&
                       np_max >= 1 && np_max <= 4 && KPL <= 2;  // NOT terms are probed outside the template
-  if (!pruned && s->bm_strategy == SS_BM25_PRUNED) return SS_ENOTSUP;
+  if (!pruned && !phrase && s->bm_strategy == SS_BM25_PRUNED) return SS_ENOTSUP;
+  // phrase queries: their own kernel over the probe index and the positions (bm25_phrase.hip); every strategy
+  if (phrase && (!have_probe || !s->d_pos || F != 1 || KPL > 2 || np_max > 6 || nt_max != np_max)) return !s->d_pos ? SS_ESTATE : SS_ENOTSUP;
   // Partitions per query (one wave each).  The grid is a whole number of "rounds" of resident waves: a partially
   // filled last round costs its full duration (measured on C2: 550K q/s at 1.95 rounds vs 477K at 2.44).  Exhaustive
   // scan: 2048 resident waves (LDS-bound), ~2 rounds; pruned: 6144 resident waves, ~4 rounds of shorter assignments
   // balance its more uneven work (driver streams differ 4x in length between queries).
-  const uint32_t resident = pruned ? 6144u : 2048u, rounds = pruned ? 4u : 2u;
+  const uint32_t resident = (pruned || phrase) ? 6144u : 2048u, rounds = (pruned || phrase) ? 4u : 2u;
   uint32_t P = (rounds * resident) / nq;
   // small batches: beyond ~150 waves the probe kernel gains nothing and every extra partition is one more list to merge
   // (single query on C2: 0.128 ms at P = n_sub = 2442, 0.086 ms at P = 128)
-  if (pruned) P = std::min<uint32_t>(P, 160u);
+  if (pruned || phrase) P = std::min<uint32_t>(P, 160u);
   if (const char* e = getenv("SS_BM25_P")) P = (uint32_t)atoi(e);  // tuning override
   P = std::max<uint32_t>(1, std::min<uint32_t>(P, s->bm_n_sub));
   const size_t tau_words = (size_t)nq * BM_TAU_STRIDE / 2;  // u64 words: one 128-byte line per query
@@ -267,7 +285,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
     s->vq_cap = (size_t)nq * sizeof(bm_vquery);
   }
   // nt_max / np_max count (term, field) lists here; the claim is in public terms
-  const uint32_t claim = (has_and ? BM_CLAIM_AND : 0u) | ((has_or || F > 1) ? BM_CLAIM_OR : 0u) | (all_probed ? BM_CLAIM_PROBED : 0u) |
+  const uint32_t claim = (phrase ? BM_CLAIM_PHRASE : 0u) | (has_and ? BM_CLAIM_AND : 0u) | ((has_or || F > 1) ? BM_CLAIM_OR : 0u) | (all_probed ? BM_CLAIM_PROBED : 0u) |
                          (any_frequent ? BM_CLAIM_FREQ : 0u) | (std::min(nt_max / F, 255u) << 8) | (std::min(np_max / F, 255u) << 16);
   bm_expand_kernel<<<(nq + 127) / 128, 128, 0, st>>>(d_q, (bm_vquery*)s->d_vq, nq, s->bm_n_fields,
                                                     (const unsigned long long*)s->d_term_base, s->d_boost, total, tau, claim,
@@ -293,7 +311,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   // bit records and the scan runs without its count mode (which scans every sub-block: 5.8 instead of 1.8 ms per 1000 C2
   // queries); a pure Count request then needs no scan at all.  SS_BM25_EXHAUSTIVE keeps the scan's own counts.
   const bool want_counts = rt != SS_RT_TOPK;
-  const bool bit_counts_all = want_counts && !pruned && s->bm_strategy != SS_BM25_EXHAUSTIVE && have_probe;
+  const bool bit_counts_all = want_counts && !pruned && !phrase && s->bm_strategy != SS_BM25_EXHAUSTIVE && have_probe;
   p.count = (want_counts && !bit_counts_all) ? 1u : 0u;
   // per-partition block maxima as the pruned kernel's bounds: where the image's maxima vary over the doc ids (set at build),
   // SS_BM25_SUBMAX = 1 / 0 forces them on / off
@@ -304,6 +322,9 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   ssi_prof_begin(s, 0, st, &e0, &e1);
   int rc = SS_OK;
   if (bit_counts_all && k == 0) SS_HIP(hipMemsetAsync(bufA, 0, (size_t)nq * P * KS * sizeof(u64), st));  // no ranking wanted
+  else if (phrase)
+    rc = ssi_bm25_launch_phrase(p, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_pos, s->d_pos_off, (const unsigned long long*)s->d_pos_base,
+                                np_max, KPL, st);
   else rc = pruned ? ssi_bm25_launch_probe(p, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_umax, use_partmax ? s->d_submax : nullptr, pmax_ws, np_max, KPL, nt_max != np_max, st)
                    : ssi_bm25_launch_scan(p, nt_max, has_and, KPL, st);
   ssi_prof_end(s, 0, st, e0, e1);

@@ -355,11 +355,25 @@ __device__ __attribute__((noinline)) BmTop<KPL> bm_scan_tile(BmTop<KPL> T, uint3
   return T;
 }
 
+// one candidate key per lane (0 = none) offered to the wave-resident top-k; publishes a raised k-th best score
+template <int KPL>
+__device__ __attribute__((noinline)) BmTop<KPL> bm_offer_lane_keys(BmTop<KPL> T, u64 key, uint32_t k, uint32_t* tau_q) {
+  const float wsc_in = T.wsc;
+  T.worst = topk_offer<KPL>(T.keys, key, 0ull, 0ull, 0ull, T.worst, k);
+  if (T.worst) T.wsc = __uint_as_float((uint32_t)(T.worst >> 32));
+  if (tau_q && T.wsc > wsc_in && __lane_id() == 0) bm_publish_tau(tau_q, T.wsc);
+  return T;
+}
+
+
 // scan kernels (bm25_fast.hip): NT-specialised for <= 4 terms and k <= 128, grouped generic kernel otherwise
 int ssi_bm25_launch_scan(const BmParams& p, uint32_t nt_max, bool has_and, int KPL, hipStream_t st);
 // exact union counts from the probe index's bit records (bm25_probe.hip)
 int ssi_bm25_launch_union_count(const BmParams& p, const uint2* probe, const uint32_t* probe_row, bool all_queries, hipStream_t st,
                                 unsigned long long* match_bits = nullptr);
 // pruned top-k over the probe index (bm25_probe.hip); SS_ENOTSUP if it cannot serve the request
+// phrase queries (bm25_phrase.hip): intersection over the probe index + position check
+int ssi_bm25_launch_phrase(const BmParams& p, const uint2* probe, const uint32_t* probe_z, const uint32_t* probe_row, const uint16_t* pos,
+                           const uint32_t* pos_off, const unsigned long long* pos_base, uint32_t nt_max, int KPL, hipStream_t st);
 int ssi_bm25_launch_probe(const BmParams& p, const uint2* probe, const uint32_t* probe_z, const uint32_t* probe_row, const float* umax,
                           const float* submax, float* pmax_ws, uint32_t nt_max, int KPL, bool any_not, hipStream_t st);

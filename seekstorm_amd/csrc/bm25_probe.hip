@@ -29,15 +29,6 @@ constexpr int PB_WAVES = 8;
 constexpr int PB_QCAP = 320;  // survivor queue entries per wave: < 64 left over + one group of 4 x 64 pushed
 
 
-template <int KPL>
-__device__ __attribute__((noinline)) BmTop<KPL> bm_offer_lane_keys(BmTop<KPL> T, u64 key, uint32_t k, uint32_t* tau_q) {
-  const float wsc_in = T.wsc;
-  T.worst = topk_offer<KPL>(T.keys, key, 0ull, 0ull, 0ull, T.worst, k);
-  if (T.worst) T.wsc = __uint_as_float((uint32_t)(T.worst >> 32));
-  if (tau_q && T.wsc > wsc_in && __lane_id() == 0) bm_publish_tau(tau_q, T.wsc);
-  return T;
-}
-
 // weight of one posting: it is IN the posting (ss_common.h) -- the same decode as the scan kernels'
 __device__ __forceinline__ float pb_weight(uint32_t p) { return bm_weight(p); }
 

@@ -83,10 +83,10 @@ static void free_vec(ss_shard* s) {
   ssi_vec_free_clusters(s);
 }
 static void free_bm25(ss_shard* s) {
-  void* ptrs[] = {s->d_post, s->d_term_base, s->d_sub_off, s->d_comp, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_umax, s->d_submax, s->d_boost};
+  void* ptrs[] = {s->d_post, s->d_term_base, s->d_sub_off, s->d_comp, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_umax, s->d_submax, s->d_boost, s->d_pos, s->d_pos_off, s->d_pos_base};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->d_post = nullptr; s->d_term_base = nullptr; s->d_sub_off = nullptr; s->d_comp = nullptr;
-  s->d_probe = nullptr; s->d_probe_z = nullptr; s->d_probe_row = nullptr; s->h_probe_row.clear(); s->bm_probe_rows = 0; s->d_umax = nullptr; s->d_submax = nullptr;
+  s->d_probe = nullptr; s->d_probe_z = nullptr; s->d_probe_row = nullptr; s->h_probe_row.clear(); s->bm_probe_rows = 0; s->d_umax = nullptr; s->d_submax = nullptr; s->d_pos = nullptr; s->d_pos_off = nullptr; s->d_pos_base = nullptr;
   s->bm_n_docs = 0; s->bm_n_terms = 0; s->bm_n_sub = 0; s->bm_n_post = 0; s->bm_n_fields = 1; s->d_boost = nullptr;
   s->h_df.clear(); s->h_df_real.clear(); s->bm_n_post_pad = 0; s->bm_partmax = false;
 }
@@ -144,6 +144,18 @@ static int ensure_qstage(ss_shard* s, size_t bytes) {
 int ss_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen, uint32_t n_terms, const uint64_t* offs,
                    const uint32_t* docs, const uint16_t* tfs) {
   return ssi_bm25_upload(s, n_docs, doclen, n_terms, offs, docs, tfs, 0);
+}
+
+int ss_bm25_upload_positions(ss_shard* s, uint64_t n_docs, const uint8_t* doclen, uint32_t n_terms, const uint64_t* offs,
+                             const uint32_t* docs, const uint16_t* tfs, const uint16_t* positions, uint64_t n_positions) {
+  if (n_positions && !positions) return SS_EINVAL;
+  int rc = ssi_bm25_upload(s, n_docs, doclen, n_terms, offs, docs, tfs, 0);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  rc = ssi_bm25_upload_positions(s, offs, docs, tfs, positions, n_positions);
+  if (rc) free_bm25(s);
+  return rc;
 }
 
 }  // extern "C"
@@ -362,7 +374,8 @@ int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df
 
 // nt_max: largest n_terms + NOT terms of the batch (what the scan kernels are specialised on); np_max: largest n_terms
 static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q, bool* has_and, bool* has_or, uint32_t* nt_max,
-                         uint32_t* np_max, bool* all_probed, bool* any_frequent) {
+                         uint32_t* np_max, bool* all_probed, bool* any_frequent, bool* phrase = nullptr) {
+  uint32_t n_phrase = 0;
   *any_frequent = false;
   *all_probed = s->bm_probe_rows != 0;
   *has_and = false;
@@ -372,7 +385,20 @@ static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q,
   for (uint32_t i = 0; i < nq; i++) {
     const uint32_t op = bm_q_op(q[i].op), n_not = bm_q_nnot(q[i].op), all = q[i].n_terms + n_not;
     if (q[i].n_terms == 0 || all > SS_MAX_QUERY_TERMS) return SS_EINVAL;
-    if (op != SS_OP_INTERSECTION && op != SS_OP_UNION) return SS_EINVAL;
+    if (op != SS_OP_INTERSECTION && op != SS_OP_UNION && op != SS_OP_PHRASE) return SS_EINVAL;
+    if (op == SS_OP_PHRASE) {  // QueryType::Phrase: unique terms + the words in order (non_unique_query_list)
+      if (!phrase) return SS_ENOTSUP;
+      if (q[i].phrase_len < 2 || q[i].phrase_len > SS_MAX_PHRASE) return SS_EINVAL;
+      uint32_t used = 0;
+      for (uint32_t j = 0; j < q[i].phrase_len; j++) {
+        if (q[i].phrase_seq[j] >= q[i].n_terms) return SS_EINVAL;
+        used |= 1u << q[i].phrase_seq[j];
+      }
+      if (used != (1u << q[i].n_terms) - 1u) return SS_EINVAL;  // every unique term is a word of the phrase
+      if (n_not || s->bm_n_fields > 1 || q[i].n_terms > 6 || bm_q_field_filter(q[i].op)) return SS_ENOTSUP;
+      if (!s->d_pos) return SS_ESTATE;  // the image carries no positions (ss_bm25_upload_positions)
+      n_phrase++;
+    }
     // field_filter: bits of indexed fields; an image with one indexed field has nothing to filter (the reference's set then
     // holds that field or nothing, search.rs:2483-2492).  Unions of several terms: the reference applies the filter inside
     // union_docid_3's sub-queries, not per doc -- not offered.
@@ -400,11 +426,13 @@ static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q,
       for (uint32_t u = 0; u < t; u++)
         if (q[i].term[u] == q[i].term[t]) return SS_EINVAL;  // unique terms only (search.rs:3023 unique_terms)
     }
-    if ((op == SS_OP_INTERSECTION && q[i].n_terms > 1) || filt) *has_and = true;
+    if (((op == SS_OP_INTERSECTION || op == SS_OP_PHRASE) && q[i].n_terms > 1) || filt) *has_and = true;
     else if (q[i].n_terms > 1) *has_or = true;  // a single-term query is both: its exact count is its posting count
     *nt_max = std::max(*nt_max, all);
     *np_max = std::max(*np_max, q[i].n_terms);
   }
+  if (n_phrase && n_phrase != nq) return SS_ENOTSUP;  // a batch holds phrase queries only
+  if (phrase) *phrase = n_phrase != 0;
   return SS_OK;
 }
 
@@ -423,9 +451,9 @@ int ss_bm25_search_filtered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, ui
   if (nq == 0) return SS_OK;
   bool has_and = false, has_or = false;
   uint32_t nt_max = 0, np_max = 0;
-  bool all_probed = false, any_frequent = false;
+  bool all_probed = false, any_frequent = false, phrase = false;
   std::lock_guard<std::mutex> g(s->mu);  // before check_queries: it reads the image's host-side tables (an upload replaces them)
-  SS_TRY(check_queries(s, nq, q, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent));
+  SS_TRY(check_queries(s, nq, q, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent, &phrase));
   SS_HIP(hipSetDevice(s->device));
   const uint32_t kk = rt == SS_RT_COUNT ? 0 : k;
   SS_TRY(ensure_out(s, nq, std::max<uint32_t>(kk, 1)));
@@ -438,7 +466,7 @@ int ss_bm25_search_filtered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, ui
   SS_HIP(hipMemcpyAsync(s->d_bq, q, (size_t)nq * sizeof(ss_bm25_query), hipMemcpyHostToDevice, s->stream));
   SS_TRY(with_facet_filter(s, n_filters, filters, s->stream, [&]() {
     return ssi_bm25_search(s, nq, (const ss_bm25_query*)s->d_bq, kk, rt, s->d_out_doc, s->d_out_score, s->d_out_count,
-                           s->d_out_total, has_and, has_or, nt_max, np_max, all_probed, s->stream, any_frequent);
+                           s->d_out_total, has_and, has_or, nt_max, np_max, all_probed, s->stream, any_frequent, phrase);
   }));
   if (kk) {
     SS_HIP(hipMemcpyAsync(out_doc, s->d_out_doc, (size_t)nq * kk * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
@@ -522,7 +550,7 @@ int ss_bm25_search_filtered_dev(ss_shard* s, uint32_t nq, const ss_bm25_query* d
                                                     : ((ops_mask >> 8) & 0xFFu ? (ops_mask >> 8) & 0xFFu : SS_MAX_QUERY_TERMS),
                            // the caller vouches for the probe rows of its terms (ss_bm25_term_probed) unless none were rationed
                            s->bm_probe_rows != 0 && (s->bm_probe_rows >= s->bm_n_terms || (ops_mask & 4u) != 0), st,
-                           (ops_mask & 8u) != 0);
+                           (ops_mask & 8u) != 0, (ops_mask & 16u) != 0);
   });
 }
 

@@ -183,6 +183,11 @@ struct ss_shard {
   float* d_umax = nullptr;         // [n_terms + 1] largest weight tf*(K+1)/(tf+comp[len]) of the term (max_list_score / idf)
   bool bm_partmax = false;         // the pruned kernel bounds every partition by its own block maxima (set at image build when the
                                    // maxima vary over the doc ids; SS_BM25_SUBMAX=1 / 0 forces it on / off)
+  // positions of every posting (ss_bm25_upload_positions): only phrase queries read them
+  uint16_t* d_pos = nullptr;       // the positions, posting after posting in image order
+  uint32_t* d_pos_off = nullptr;   // [bm_n_post_pad + 1] first position of the posting at that (padded) image index, relative to its term's
+                                   // base; the posting's count is the distance to the next entry (padding slots repeat their successor)
+  uint64_t* d_pos_base = nullptr;  // [n_terms + 1] first position of every term in d_pos
   float* d_submax = nullptr;       // [n_terms + 1][n_sub] largest weight of every (term, 4096-doc sub-block) segment, 0 = empty: the
                                    // reference's per-block max_block_score / idf (get_max_score, index.rs:2938-3200) at this image's
                                    // block size; the last row (absent terms) is all zero
@@ -266,6 +271,8 @@ struct bm_vquery {
   float idf[BM_MAX_VTERMS];
   uint8_t and_val[BM_MAX_VTERMS];
   uint8_t group[BM_MAX_VTERMS];  // query term of each virtual term (the virtual terms of a group are contiguous)
+  uint32_t phrase_len;           // SS_OP_PHRASE: words of the phrase (one indexed field: virtual term = term), else 0
+  uint8_t phrase_seq[SS_MAX_PHRASE];
 };
 __host__ __device__ inline uint32_t bm_q_op(uint32_t op) { return op & 0xFFu; }
 __host__ __device__ inline uint32_t bm_q_nnot(uint32_t op) { return (op >> 8) & 0xFFu; }
@@ -277,7 +284,7 @@ __host__ __device__ inline bool bm_q_all_frequent(uint32_t op) { return (op >> 3
 constexpr uint32_t BM_AND_FREQ = 0x100u;
 int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t* d_out_doc,
                     float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, bool has_or,
-                    uint32_t nt_max, uint32_t np_max, bool all_probed, hipStream_t st, bool any_frequent = false);
+                    uint32_t nt_max, uint32_t np_max, bool all_probed, hipStream_t st, bool any_frequent = false, bool phrase = false);
 // ---- implemented in synth.hip
 int ssi_vec_synth(ss_shard* s, uint64_t seed, hipStream_t st);
 int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const uint8_t* d_lentab, hipStream_t st);
@@ -286,6 +293,8 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
                              const uint16_t* tfs, uint64_t positions_sum);
 int ssi_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen, uint32_t n_terms, const uint64_t* offs,
                     const uint32_t* docs, const uint16_t* tfs, uint64_t positions_sum);
+int ssi_bm25_upload_positions(ss_shard* s, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs, const uint16_t* positions,
+                              uint64_t n_positions);
 int ssi_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost,
                            uint32_t n_terms, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
                            const uint16_t* tfs, uint64_t positions_sum);

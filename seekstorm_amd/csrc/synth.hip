@@ -253,6 +253,46 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
   return SS_OK;
 }
 
+// ---------------------------------------------------------------- positions (phrase queries)
+// After ssi_bm25_upload of the same CSR (one indexed field): d_pos = every posting's positions in image order, d_pos_off =
+// END offset of the positions of the posting at each (padded) image index relative to its term's first position (the start
+// is the previous slot's end, 0 at the term's first slot; NULL padding slots repeat the running end), d_pos_base = first
+// position of every term.  The image order of the postings equals the CSR order, so the pool is the caller's array as is.
+int ssi_bm25_upload_positions(ss_shard* s, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs, const uint16_t* positions,
+                              uint64_t n_positions) {
+  const uint32_t nt = s->bm_n_terms, ns = s->bm_n_sub;
+  if (s->bm_n_fields != 1) return SS_ENOTSUP;
+  std::vector<u64> pbase((size_t)nt + 1);
+  std::vector<uint32_t> poff((size_t)s->bm_n_post_pad + 1, 0u);
+  u64 total = 0, w = 0;  // w: padded image index (dwords)
+  for (uint32_t t = 0; t < nt; t++) {
+    pbase[t] = total;
+    u64 rel = 0, j = offs[t];
+    for (uint32_t sb = 0; sb < ns; sb++) {
+      const u64 lim = ((u64)sb + 1) << BM_SUB_LOG2;
+      u64 n = 0;
+      for (; j < offs[t + 1] && docs[j] < lim; j++, n++) {
+        for (uint32_t x = 1; x < tfs[j]; x++)
+          if (positions[total + rel + x] <= positions[total + rel + x - 1]) return SS_EINVAL;  // ascending inside a posting
+        rel += tfs[j];
+        if (rel >= (1ull << 32)) return SS_ENOTSUP;
+        poff[w++] = (uint32_t)rel;
+      }
+      for (u64 pad = (4 - (n & 3)) & 3; pad > 0; pad--) poff[w++] = (uint32_t)rel;  // NULL padding of the segment
+    }
+    total += rel;
+  }
+  pbase[nt] = total;
+  if (total != n_positions || w != s->bm_n_post_pad) return SS_EINVAL;
+  SS_HIP(hipMalloc(&s->d_pos, (total ? total : 1) * sizeof(uint16_t)));
+  SS_HIP(hipMalloc(&s->d_pos_off, poff.size() * sizeof(uint32_t)));
+  SS_HIP(hipMalloc(&s->d_pos_base, pbase.size() * sizeof(u64)));
+  if (total) SS_HIP(hipMemcpy(s->d_pos, positions, total * sizeof(uint16_t), hipMemcpyHostToDevice));
+  SS_HIP(hipMemcpy(s->d_pos_off, poff.data(), poff.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  SS_HIP(hipMemcpy(s->d_pos_base, pbase.data(), pbase.size() * sizeof(u64), hipMemcpyHostToDevice));
+  return SS_OK;
+}
+
 // ---------------------------------------------------------------- BM25 synthetic image, generated on device
 __global__ void lex_doclen_kernel(uint8_t* __restrict__ doclen, u64 seed, u64 n_docs, const uint8_t* __restrict__ tab,
                                   u64* __restrict__ psum, u64 gs, u64 go) {

@@ -28,6 +28,7 @@ from . import _native as N
 class QueryType(enum.IntEnum):  # search.rs:59
     Union = N.OP_UNION
     Intersection = N.OP_INTERSECTION
+    Phrase = N.OP_PHRASE  # "...": the terms of the query are the words of the phrase, in order (a word may repeat)
 
 
 class ResultType(enum.IntEnum):  # search.rs:168
@@ -234,13 +235,20 @@ class Shard:
             pass
 
     # ---- image (re)build: end of open_shard (index.rs:3796) / after commit (commit.rs:142-148)
-    def upload_lexical(self, n_docs, doclen_bytes, term_offsets, doc_ids, tfs):
+    def upload_lexical(self, n_docs, doclen_bytes, term_offsets, doc_ids, tfs, positions=None):
+        """positions: for every posting in CSR order its tf positions (ascending) -- needed by phrase queries only"""
         dl = np.ascontiguousarray(doclen_bytes, np.uint8)
         off = np.ascontiguousarray(term_offsets, np.uint64)
         d = np.ascontiguousarray(doc_ids, np.uint32)
         t = np.ascontiguousarray(tfs, np.uint16)
-        N.check(N.lib().ss_bm25_upload(self._h, int(n_docs), N.ptr(dl, N.u8p), len(off) - 1, N.ptr(off, N.u64p),
-                                       N.ptr(d, N.u32p), N.ptr(t, N.u16p)), "ss_bm25_upload")
+        if positions is None:
+            N.check(N.lib().ss_bm25_upload(self._h, int(n_docs), N.ptr(dl, N.u8p), len(off) - 1, N.ptr(off, N.u64p),
+                                           N.ptr(d, N.u32p), N.ptr(t, N.u16p)), "ss_bm25_upload")
+        else:
+            ps = np.ascontiguousarray(positions, np.uint16)
+            N.check(N.lib().ss_bm25_upload_positions(self._h, int(n_docs), N.ptr(dl, N.u8p), len(off) - 1, N.ptr(off, N.u64p),
+                                                     N.ptr(d, N.u32p), N.ptr(t, N.u16p), N.ptr(ps, N.u16p), len(ps)),
+                    "ss_bm25_upload_positions")
         self.indexed_doc_count = int(n_docs)
         self.lexical_field_count = 1
         self._df_cache.clear()
@@ -464,7 +472,17 @@ class Shard:
             for t, df in zip(missing, self.posting_count(missing)):
                 self._df_cache[t] = int(df)
         for i, (tl, qt, nl) in enumerate(zip(term_lists, query_types, not_lists)):
+            words = [int(t) for t in tl]
             tl = list(dict.fromkeys(int(t) for t in tl))  # unique_terms, search.rs:3023
+            if int(qt) == int(QueryType.Phrase):  # non_unique_query_list: the words in order, each naming its unique term
+                if len(words) < 2:
+                    qt = QueryType.Intersection  # a one-word phrase is a term query (search.rs:3544)
+                elif len(words) > N.SS_MAX_PHRASE:
+                    raise ValueError("a phrase of at most %d words" % N.SS_MAX_PHRASE)
+                else:
+                    q["phrase_len"][i] = len(words)
+                    for j, wd in enumerate(words):
+                        q["phrase_seq"][i, j] = tl.index(wd)
             nl = [t for t in dict.fromkeys(int(t) for t in nl) if t not in tl]
             if not 1 <= len(tl) or len(tl) + len(nl) > N.SS_MAX_QUERY_TERMS:
                 raise ValueError("1..10 unique terms per query (NOT terms included)")
@@ -569,6 +587,12 @@ class Shard:
         score = np.zeros((nq, kk), np.float32)
         cnt = np.zeros(nq, np.uint32)
         tot = np.zeros(nq, np.uint64)
+        is_phrase = (queries["op"] & 0xFF) == int(QueryType.Phrase)
+        if is_phrase.any() and not is_phrase.all():  # one C-ABI batch holds phrase queries only: two calls, results back in place
+            for sel in (np.nonzero(is_phrase)[0], np.nonzero(~is_phrase)[0]):
+                d_, s_, c_, t_ = self.search_lexical_batch(queries[sel].copy(), k, result_type, reference_shortcuts, facet_filter)
+                doc[sel], score[sel], cnt[sel], tot[sel] = d_, s_, c_, t_
+            return doc, score, cnt, tot
         farr, nf = self.facet_filters(facet_filter) if facet_filter else (None, 0)
         N.check(N.lib().ss_bm25_search_filtered(self._h, nq, queries.ctypes.data_as(C.c_void_p), int(k), int(result_type), nf,
                                                 None if farr is None else C.cast(farr, C.c_void_p), N.ptr(doc, N.u32p),

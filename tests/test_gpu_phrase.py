@@ -1,0 +1,105 @@
+"""GPU parity (-m gpu) of phrase queries (QueryType::Phrase; phrase check add_result.rs:3586-3684, positions add_result.rs:38-59,
+2036-2197): docs holding every unique term whose positions carry the words consecutively, scored like the intersection,
+counted only on a match -- against the oracle (reference loop restated + the definition), 2- to 6-word phrases, repeated
+words, Count / Topk / TopkCount, tombstones, mixed batches."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    import seekstorm_amd
+    return seekstorm_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def _corpus(O, n_docs, dfs, seed, plant):
+    """postings with positions; `plant` = list of (terms in order, n docs): phrases written into docs on purpose"""
+    rng = np.random.default_rng(seed)
+    dl = O.lex_doclen(n_docs)
+    L = O.lib()
+    dec = np.array([L.so_byte4_to_int(i) for i in range(256)], np.int64)
+    pos_of = [dict() for _ in dfs]  # term -> doc -> set of positions
+    for t, df in enumerate(dfs):
+        for d in rng.choice(n_docs, df, replace=False):
+            n = int(max(dec[dl[d]], 4))
+            tf = int(min(rng.geometric(0.45), n // 2 + 1, 30))
+            pos_of[t][int(d)] = set(int(x) for x in rng.choice(n, tf, replace=False))
+    for terms, nd in plant:
+        for d in rng.choice(n_docs, nd, replace=False):
+            n = int(max(dec[dl[d]], len(terms) + 2))
+            st = int(rng.integers(0, n - len(terms)))
+            for i, t in enumerate(terms):
+                pos_of[t].setdefault(int(d), set()).add(st + i)
+    offs, docs, tfs, positions = [0], [], [], []
+    for t in range(len(dfs)):
+        ds = sorted(pos_of[t])
+        for d in ds:
+            ps = sorted(pos_of[t][d])
+            docs.append(d); tfs.append(len(ps)); positions += ps
+        offs.append(len(docs))
+    return (dl, np.asarray(offs, np.uint64), np.asarray(docs, np.uint32), np.asarray(tfs, np.uint16), np.asarray(positions, np.uint16))
+
+
+def test_phrase_queries_match_oracle(S, O):
+    n_docs = 150_000
+    dfs = [30_000, 22_000, 40_000, 9_000, 15_000, 500]
+    plant = [([0, 1], 400), ([0, 1, 2], 150), ([2, 0, 2], 120), ([3, 4], 60), ([0, 1, 2, 3, 4, 5], 30), ([1, 1], 80), ([4, 0, 1], 70)]
+    dl, offs, docs, tfs, positions = _corpus(O, n_docs, dfs, 5, plant)
+    sh = S.Shard(0)
+    sh.upload_lexical(n_docs, dl, offs, docs, tfs, positions)
+    osh = O.Shard(n_docs, dl, offs, docs, tfs)
+    osh.set_positions(positions)
+    phrases = [[0, 1], [1, 0], [0, 1, 2], [2, 0, 2], [3, 4], [0, 1, 2, 3, 4, 5], [1, 1], [4, 0, 1], [5, 3], [2, 2, 2], [0, 2, 1, 0]]
+    q = sh.make_queries(phrases, S.QueryType.Phrase)
+    gone = list(range(3, n_docs, 97))
+    for deleted in (False, True):
+        sh.set_deleted(gone if deleted else [])
+        osh.set_deleted(gone if deleted else [])
+        for k in (10, 100):
+            res = {rt: sh.search_lexical_batch(q, k, rt) for rt in (S.ResultType.TopkCount, S.ResultType.Topk, S.ResultType.Count)}
+            for i, ph in enumerate(phrases):
+                uniq = list(dict.fromkeys(ph))
+                seq = [uniq.index(w) for w in ph]
+                od, os_, otot = osh.search_phrase(uniq, seq, k, reference_loop=True)
+                od2, os2, otot2 = osh.search_phrase(uniq, seq, k, reference_loop=False)
+                assert otot == otot2 and np.array_equal(od, od2)  # the restated loop and the definition agree on the corpus
+                doc, score, cnt, tot = res[S.ResultType.TopkCount]
+                assert int(tot[i]) == otot, (ph, deleted, int(tot[i]), otot)
+                assert cnt[i] == len(od) and np.allclose(score[i][:cnt[i]], os_, rtol=1e-4)
+                if len(od):
+                    band = abs(float(os_[-1])) * 2e-4
+                    clear = lambda dd, ss: {int(x) for x, y in zip(dd, ss) if y > os_[-1] + band}
+                    assert clear(doc[i][:cnt[i]], score[i][:cnt[i]]) <= set(od.tolist()) and clear(od, os_) <= set(doc[i][:cnt[i]].tolist())
+                d2, s2, c2, _ = res[S.ResultType.Topk]
+                assert c2[i] == cnt[i] and np.array_equal(s2[i], score[i]) and np.array_equal(d2[i], doc[i])
+                assert int(res[S.ResultType.Count][3][i]) == otot and res[S.ResultType.Count][2][i] == 0
+    sh.set_deleted([])
+    osh.set_deleted([])
+    # a phrase is stricter than the intersection of its words, and a planted phrase is found
+    qi = sh.make_queries([[0, 1]], S.QueryType.Intersection)
+    ti = sh.search_lexical_batch(qi, 10)[3][0]
+    tp = sh.search_lexical_batch(sh.make_queries([[0, 1]], S.QueryType.Phrase), 10)[3][0]
+    assert 400 <= tp < ti
+    # mixed batch through the mirror: phrase and set queries side by side
+    qm = sh.make_queries([[0, 1], [0, 1], [2, 0, 2]], [S.QueryType.Phrase, S.QueryType.Union, S.QueryType.Phrase])
+    dm, sm, cm, tm = sh.search_lexical_batch(qm, 10)
+    assert int(tm[0]) == tp and int(tm[1]) == osh.search_exhaustive([0, 1], O.OP_OR, 10)[2]
+    assert int(tm[2]) == osh.search_phrase([2, 0], [0, 1, 0], 10)[2]
+    # the raw ABI refuses what it does not offer
+    from seekstorm_amd import _native as N
+    with pytest.raises(S.SeekStormHipError):
+        sh.search_lexical_batch(sh.make_queries([[0, 1]], S.QueryType.Phrase, [[2]]), 10)  # NOT terms with a phrase
+    sh2 = S.Shard(0)
+    sh2.upload_lexical(n_docs, dl, offs, docs, tfs)  # no positions
+    with pytest.raises(S.SeekStormHipError):
+        sh2.search_lexical_batch(sh2.make_queries([[0, 1]], S.QueryType.Phrase), 10)
+    sh2.close()
+    sh.close()

@@ -424,3 +424,26 @@ def test_split_corpus_and_cpu_baseline_harness():
     for mode, threads in ((0, 2), (1, S)):
         qps, done, lat = O.bench_lex(shards, qs, O.OP_OR, 10, O.RT_TOPK, mode, threads, 0.2)
         assert qps > 0 and done > 0 and (mode == 0 or len(lat) == done)
+
+
+def test_phrase_match_reference_loop_equals_definition():
+    """the reference's phrase merge loop (add_result.rs:3596-3684, restated) decides what the definition decides -- some start
+    carries word i at start + i -- over random position lists, repeated words, 2..6 words"""
+    from oracle import oracle as O
+    rng = np.random.default_rng(17)
+    hits = 0
+    for it in range(4000):
+        n = int(rng.integers(2, 7))
+        span = int(rng.integers(6, 60))
+        uniq = [np.sort(rng.choice(span, int(rng.integers(1, min(span, 12))), replace=False)) for _ in range(n)]
+        seq = [int(rng.integers(0, n)) for _ in range(n)] if it % 3 == 0 else list(range(n))  # repeated words share a list
+        lists = [uniq[i] for i in seq]
+        if it % 5 == 0:  # plant a match
+            st = int(rng.integers(0, span))
+            lists = [np.unique(np.append(l, st + i)) for i, l in enumerate(lists)]
+            if len(set(seq)) < n:  # shared lists must stay shared
+                continue
+        a, b = O.phrase_match(lists, True), O.phrase_match(lists, False)
+        assert a == b, (lists,)
+        hits += a
+    assert 200 < hits < 3800
