@@ -49,10 +49,11 @@ Shard::~Shard() {
 }
 
 int Shard::upload_lexical(uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t n_terms, const uint64_t* term_offsets,
-                          const uint32_t* doc_ids, const uint16_t* tfs) {
+                          const uint32_t* doc_ids, const uint16_t* tfs, const uint16_t* positions, uint64_t n_positions) {
   if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
   lexical_fields_ = 1; ngram_components_.clear(); ngram_component_df_.clear();  // a new image: no index.bin n-gram keys behind the term ids
-  const int rc = ss_bm25_upload(h_, n_docs, doclen_bytes, n_terms, term_offsets, doc_ids, tfs);
+  const int rc = positions ? ss_bm25_upload_positions(h_, n_docs, doclen_bytes, n_terms, term_offsets, doc_ids, tfs, positions, n_positions)
+                           : ss_bm25_upload(h_, n_docs, doclen_bytes, n_terms, term_offsets, doc_ids, tfs);
   n_docs_ = rc == SS_OK ? n_docs : 0;
   return rc;
 }
@@ -166,6 +167,15 @@ int Shard::make_query(const std::vector<uint32_t>& terms, QueryType qt, ss_bm25_
   if (rc != SS_OK) return rc;
   std::memset(out, 0, sizeof(*out));
   out->n_terms = (uint32_t)uniq.size();
+  if (qt == QueryType::Phrase) {  // non_unique_query_list: the words in order, each naming its unique term (search.rs:3304-3331)
+    if (terms.size() < 2) qt = QueryType::Intersection;  // a one-word phrase is a term query
+    else if (terms.size() > SS_MAX_PHRASE) return SS_EINVAL;
+    else {
+      out->phrase_len = (uint32_t)terms.size();
+      for (size_t i = 0; i < terms.size(); i++)
+        out->phrase_seq[i] = (uint8_t)(std::find(uniq.begin(), uniq.end(), terms[i]) - uniq.begin());
+    }
+  }
   out->op = (uint32_t)qt | SS_OP_NOT_TERMS(nots.size());
   for (size_t i = 0; i < uniq.size(); i++) {
     out->term[i] = uniq[i];
@@ -545,7 +555,9 @@ void LexicalBatchCoalescer::run() {
       const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(max_wait_us_);
       cv_.wait_until(lk, deadline, [this] { return stop_ || queue_.size() >= max_batch_; });
       size_t n = 1;
-      while (n < queue_.size() && n < max_batch_ && queue_[n]->rt == queue_[0]->rt) n++;
+      // one device batch: one result type, and phrase queries only among themselves (the C ABI's rule)
+      auto is_phrase = [](const Req& r) { return (r.q.op & 0xFFu) == SS_OP_PHRASE; };
+      while (n < queue_.size() && n < max_batch_ && queue_[n]->rt == queue_[0]->rt && is_phrase(*queue_[n]) == is_phrase(*queue_[0])) n++;
       for (size_t i = 0; i < n; i++) batch.push_back(std::move(queue_[i]));
       queue_.erase(queue_.begin(), queue_.begin() + n);
       batches_++;

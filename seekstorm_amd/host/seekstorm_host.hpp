@@ -30,7 +30,8 @@
 
 namespace seekstorm {
 
-enum class QueryType : uint32_t { Union = SS_OP_UNION, Intersection = SS_OP_INTERSECTION };      // search.rs:59
+// Phrase: the query terms are the words of the phrase, in order (a word may repeat)
+enum class QueryType : uint32_t { Union = SS_OP_UNION, Intersection = SS_OP_INTERSECTION, Phrase = SS_OP_PHRASE };  // search.rs:59
 enum class ResultType : uint32_t { Count = SS_RT_COUNT, Topk = SS_RT_TOPK, TopkCount = SS_RT_TOPKCOUNT };  // search.rs:168
 enum class SearchMode : int { Lexical = SS_MODE_LEXICAL, Vector = SS_MODE_VECTOR, Hybrid = SS_MODE_HYBRID };  // search.rs:73
 // search.rs AnnMode (used at vector.rs:1300-1307): All | Similaritythreshold(t) | Nprobe(n) | NprobeSimilaritythreshold(n, t);
@@ -86,8 +87,9 @@ class Shard {
   uint32_t shard_id() const { return shard_id_; }
 
   // (re)build of the device image: end of open_shard (index.rs:3796) / after a commit (commit.rs:142-148)
+  // positions (optional): every posting's tf positions in CSR order -- what phrase queries walk
   int upload_lexical(uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t n_terms, const uint64_t* term_offsets,
-                     const uint32_t* doc_ids, const uint16_t* tfs);
+                     const uint32_t* doc_ids, const uint16_t* tfs, const uint16_t* positions = nullptr, uint64_t n_positions = 0);
   // several indexed fields (BM25F): doclen [n_fields][n_docs], postings (doc, field, tf) sorted by (doc, field) per term
   int upload_lexical_fields(uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen_bytes, const float* boost, uint32_t n_terms,
                             const uint64_t* term_offsets, const uint32_t* doc_ids, const uint8_t* field_ids, const uint16_t* tfs);
