@@ -1,0 +1,140 @@
+"""Key bodies of the reference's block format assembled BY HAND, byte by byte, from the reference's WRITERS -- independently of
+oracle/ref_format.py (the restated writer the other fixtures come from), so that a misreading shared by that restatement and
+the decoder (seekstorm_amd/csrc/ref_format.hip) cannot hide.  Every byte cites the line of the writer that produces it
+(paths relative to /root/reference/seekstorm/src).  tests/test_ref_format.py::test_hand_assembled_key_bodies feeds them to
+ss_ref_decode_block.
+
+Layout of one key's bytes inside a 65 536-doc block (compress_postinglist.rs:832-946, the Rle writer; Array 694- and Bitmap
+759- lay the first two regions out the same way):
+
+    [ position records, stacked DOWNWARD from R ]  [ rank/position pointers, upward from R ]  [ doc-id container ]
+      docid_iterator:  key_position_pointer_w -= size (compress_postinglist.rs:475, 505)
+      R = rank_position_pointer_range = low 30 bits of compression_type_pointer; bits 30..31 = CompressionType
+          (index.rs:838-843: Array = 1, Bitmap = 2, Rle = 3)
+
+  pointer of posting p: 2 bytes while p < pointer_pivot_p_docid, 3 bytes from there on (single.rs:77-83);
+    not embedded : the running sum of record sizes, low byte first, top bit clear (compress_postinglist.rs:477-482, 507-515);
+                   the record lies at R - that sum (index.rs:2987-2996)
+    embedded     : the positions themselves, top bit set (index_posting.rs:605-660)
+  record of a posting that is not embedded, one indexed field, SingleTerm key (index_posting.rs write_field_vec 848-872, then
+    compress_positions compress_postinglist.rs:949-977): positions_count as a VINT whose LAST byte carries STOP_BIT 0x80, then
+    every position (delta form) as a VINT of 1-3 bytes, last byte | 0x80.
+  tf of a posting = positions_count (add_result.rs:2036-2197): the count bits of an embedded pointer, else the record's first VINT.
+"""
+
+STOP = 0x80
+
+
+def _u16(v):
+    return [v & 0xFF, v >> 8]
+
+
+# ---------------------------------------------------------------------------------------------------------------- H1
+# CompressionType::Array, four postings, every pointer 2 bytes: pointer_pivot_p_docid = 4 (index_posting.rs:193-196: set to
+# posting_count + 1 before each 2-byte posting is added, so after n such postings it reads n).
+#   p0 doc 3      1 position  {5}            embedded   (index_posting.rs:449-451: 1 position of <= 14 bits)
+#   p1 doc 17     2 positions {3, 9}         embedded   (452-454: 2 positions of <= 7 bits each)
+#   p2 doc 300    3 positions {10, 0, 188}   record     (a 2-byte pointer embeds at most 2 positions: 449)
+#   p3 doc 65535  130 positions, all 0       record, positions_count needs a 2-byte VINT
+H1_PREFIX = [0xAA, 0xBB, 0xCC, 0xDD, 0xEE, 0xFF, 0x11]  # 7 bytes of other keys in front of this key's records
+H1_RECORD_P3 = (
+    [130 >> 7, (130 & 0x7F) | STOP]                    # positions_count 130: write_field_vec 861-865 (>= 128: high 7 bits, then low | STOP)
+    + [0 | STOP] * 130                                 # 130 positions of delta 0: compress_positions 955-957
+)                                                      # 132 bytes
+H1_RECORD_P2 = [
+    3 | STOP,                                          # positions_count 3: write_field_vec 858-860 (< 128: one byte | STOP)
+    10 | STOP,                                         # position 10: compress_positions 955-957
+    0 | STOP,                                          # delta 0
+    188 >> 7, (188 & 0x7F) | STOP,                     # delta 188: compress_positions 958-965 (two bytes, STOP on the last)
+]                                                      # 5 bytes
+H1_R = len(H1_PREFIX) + len(H1_RECORD_P3) + len(H1_RECORD_P2)  # = 144: p2's record ends AT R, p3's lies below it (stack)
+H1_POINTERS = [
+    # p0: data = 5 in 14 bits (index_posting.rs:605-619: remaining_bits = 2*8 - 0 - 2 = 14, position_bits = 14 / 1);
+    #     byte0 = data & 0xFF, byte1 = data >> 8 | 0b1000_0000 | (positions - 1) << 6   (622-625)
+    5 & 0xFF, (5 >> 8) | 0x80 | (0 << 6),
+    # p1: data = 3 << 7 | 9 (position_bits 14 / 2 = 7, then 7 / 1 = 7; the first position ends up in the high bits: 615-618)
+    ((3 << 7) | 9) & 0xFF, (((3 << 7) | 9) >> 8) | 0x80 | (1 << 6),
+    # p2: running record size 5 (compress_postinglist.rs:474, 477-482), top bit clear
+    5 & 0xFF, (5 >> 8) & 0x7F,
+    # p3: running record size 5 + 132 = 137
+    137 & 0xFF, (137 >> 8) & 0x7F,
+]
+H1_DOCIDS = _u16(3) + _u16(17) + _u16(300) + _u16(65535)  # Array container: u16 little endian, ascending (single.rs:176-183)
+H1 = dict(
+    name="H1 array, 2-byte pointers, embedded and recorded postings",
+    block_id=5, compression_type_pointer=(1 << 30) | H1_R, posting_count=4, pointer_pivot_p_docid=4,
+    body=bytes(H1_PREFIX + H1_RECORD_P3 + H1_RECORD_P2 + H1_POINTERS + H1_DOCIDS),
+    docs=[3, 17, 300, 65535], tfs=[1, 2, 3, 130])
+
+# ---------------------------------------------------------------------------------------------------------------- H2
+# CompressionType::Array, pivot INSIDE the list: p0 has a 2-byte pointer, p1..p3 3-byte pointers (offset of pointer p >= pivot:
+# 3 p - pivot, index.rs:2978).  The writer moves the pivot when 32 768 bytes of records are reached (index_posting.rs:579-587);
+# the reader only ever looks at the stored value, so a small pivot is a legal header and keeps the fixture readable.
+#   p0 doc 0      1 position  {300}              embedded, 2 bytes
+#   p1 doc 9      4 positions {1, 2, 3, 40}      embedded, 3 bytes (index_posting.rs:466-470: <= 5, 5, 5, 6 bits)
+#   p2 doc 10     2 positions {1000, 2000}       embedded, 3 bytes (459-461: <= 10 and <= 11 bits)
+#   p3 doc 40000  5 positions, all 0             record
+H2_PREFIX = [0x01, 0x02, 0x03]
+H2_RECORD_P3 = [5 | STOP] + [0 | STOP] * 5             # 6 bytes
+H2_R = len(H2_PREFIX) + len(H2_RECORD_P3)              # = 9
+_d1 = (((((1 << 5) | 2) << 5) | 3) << 6) | 40          # remaining_bits 3*8 - 1 - 2 = 21: 21/4 = 5, 16/3 = 5, 11/2 = 5, 6/1 = 6 (605-619)
+_d2 = (1000 << 11) | 2000                              # 21/2 = 10, then 11
+H2_POINTERS = [
+    300 & 0xFF, (300 >> 8) | 0x80 | (0 << 6),                        # p0: 2-byte embedded form (622-625)
+    _d1 & 0xFF, (_d1 >> 8) & 0xFF, (_d1 >> 16) | 0x80 | (3 << 5),    # p1: 3-byte form, (positions - 1) << 5 (636-640)
+    _d2 & 0xFF, (_d2 >> 8) & 0xFF, (_d2 >> 16) | 0x80 | (1 << 5),    # p2
+    6 & 0xFF, (6 >> 8) & 0xFF, (6 >> 16) & 0x7F,                     # p3: running record size 6 (compress_postinglist.rs:507-515)
+]
+H2_DOCIDS = _u16(0) + _u16(9) + _u16(10) + _u16(40000)
+H2 = dict(
+    name="H2 array, pivot inside the list, 3-byte embedded forms",
+    block_id=0, compression_type_pointer=(1 << 30) | H2_R, posting_count=4, pointer_pivot_p_docid=1,
+    body=bytes(H2_PREFIX + H2_RECORD_P3 + H2_POINTERS + H2_DOCIDS),
+    docs=[0, 9, 10, 40000], tfs=[1, 4, 2, 5])
+
+# ---------------------------------------------------------------------------------------------------------------- H3
+# CompressionType::Bitmap: 8 192 bytes, bit d & 7 of byte d >> 3 (single.rs:235-262 reads it as 1 024 u64 words and walks them
+# with tzcnt: the same bits).  The writer chooses a bitmap for a dense block; the reader takes the type from the header.
+# Five postings, each with one embedded position; no records, so R directly follows the prefix.
+H3_DOCS = [0, 1, 63, 64, 65535]
+H3_PREFIX = [0x7E]
+H3_R = len(H3_PREFIX)
+H3_POINTERS = []
+for _pos in (0, 7, 8, 16383, 129):                     # one position each, <= 14 bits: embedded 2-byte pointers (449-451, 622-625)
+    H3_POINTERS += [_pos & 0xFF, (_pos >> 8) | 0x80 | (0 << 6)]
+_bm = bytearray(8192)
+for _d in H3_DOCS:
+    _bm[_d >> 3] |= 1 << (_d & 7)
+H3 = dict(
+    name="H3 bitmap",
+    block_id=2, compression_type_pointer=(2 << 30) | H3_R, posting_count=5, pointer_pivot_p_docid=5,
+    body=bytes(H3_PREFIX + H3_POINTERS) + bytes(_bm),
+    docs=H3_DOCS, tfs=[1, 1, 1, 1, 1])
+
+# ---------------------------------------------------------------------------------------------------------------- H4
+# CompressionType::Rle (compress_postinglist.rs:832-946): u16 runs_count, then per run u16 start and u16 length, where length
+# counts the docs AFTER the start (a run of one doc has length 0: 895-897, 919-936).
+#   runs: 10..12, 100, 65530..65535  -> 10 postings; tf = rank + 1 for the first four (records), 1 for the rest (embedded)
+H4_DOCS = [10, 11, 12, 100, 65530, 65531, 65532, 65533, 65534, 65535]
+H4_TFS = [1, 2, 3, 4, 1, 1, 1, 1, 1, 1]
+H4_PREFIX = [0x55, 0x66]
+# p1, p2, p3 are recorded (3 and 4 positions do not fit a 2-byte pointer; p1's two positions {200, 1} do not either: 200 > 7 bits)
+H4_REC_P1 = [2 | STOP, 200 >> 7, (200 & 0x7F) | STOP, 1 | STOP]   # count 2, delta 200 (two bytes), delta 1 -> 4 bytes
+H4_REC_P2 = [3 | STOP, 4 | STOP, 4 | STOP, 4 | STOP]              # 4 bytes
+H4_REC_P3 = [4 | STOP, 1 | STOP, 1 | STOP, 1 | STOP, 1 | STOP]    # 5 bytes
+H4_R = len(H4_PREFIX) + len(H4_REC_P3) + len(H4_REC_P2) + len(H4_REC_P1)  # = 15 (p1's record is the one touching R)
+H4_POINTERS = (
+    [9 & 0xFF, (9 >> 8) | 0x80 | (0 << 6)]             # p0: position 9 embedded
+    + [4, 0]                                           # p1: running size 4
+    + [8, 0]                                           # p2: 4 + 4
+    + [13, 0]                                          # p3: 8 + 5
+    + [1 & 0xFF, 0x80] * 6                             # p4..p9: position 1 embedded
+)
+H4_CONTAINER = _u16(3) + _u16(10) + _u16(2) + _u16(100) + _u16(0) + _u16(65530) + _u16(5)
+H4 = dict(
+    name="H4 rle",
+    block_id=1, compression_type_pointer=(3 << 30) | H4_R, posting_count=10, pointer_pivot_p_docid=10,
+    body=bytes(H4_PREFIX + H4_REC_P3 + H4_REC_P2 + H4_REC_P1 + H4_POINTERS + H4_CONTAINER),
+    docs=H4_DOCS, tfs=H4_TFS)
+
+BLOCKS = [H1, H2, H3, H4]

@@ -522,3 +522,22 @@ def test_golden_key_bodies():
     for c in range(nc):
         assert N.lib().ss_ref_decode_block_ngram(C.byref(rb), nc, c, N.ptr(d, N.u16p), N.ptr(t, N.u16p)) == cnt
         assert np.array_equal(d[:cnt], g["g_docs"]) and np.array_equal(t[:cnt], g["g_tfs"][:, c])
+
+
+def test_hand_assembled_key_bodies():
+    """Key bodies assembled by hand from the reference's WRITERS (tests/golden/hand_assembled_blocks.py: every byte cites
+    index_posting.rs / compress_postinglist.rs), not by oracle/ref_format.py: Array / Bitmap / Rle containers, 2- and 3-byte
+    pointers with the pivot inside the list, every single-field embedded form, 1- and 2-byte position counts."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("hand_assembled_blocks", os.path.join(os.path.dirname(__file__), "golden", "hand_assembled_blocks.py"))
+    H = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(H)
+    assert len(H.BLOCKS) >= 4
+    for b in H.BLOCKS:
+        blk = (b["block_id"], b["compression_type_pointer"], b["posting_count"], b["pointer_pivot_p_docid"], b["body"])
+        cnt, d, t = _decode(blk)
+        assert cnt == len(b["docs"]), (b["name"], cnt)
+        assert d.tolist() == b["docs"] and t.tolist() == b["tfs"], (b["name"], d.tolist(), t.tolist())
+        # and the restated writer, given the same postings, chooses bytes the decoder reads the same way (two routes, one answer)
+    # the fixture's own arithmetic: pointer ranges
+    assert H.H1_R == 144 and H.H2_R == 9 and H.H4_R == 15
