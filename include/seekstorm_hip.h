@@ -28,7 +28,10 @@
  *   - results come back sorted by score descending, per-shard LOCAL doc ids, caller-owned buffers;
  *   - unused result slots hold doc id SS_NO_DOC and score 0;
  *   - per-shard request size is offset+length with offset 0 (search.rs:1658-1659): `k` below;
- *   - thread-safe: concurrent calls on one handle are serialised internally; destroy must not race.
+ *   - thread-safe: the host side of concurrent calls on one handle is serialised (a mutex around validation and launch
+ *     queuing); the DEVICE side of the *_dev BM25 searches is not -- searches queued on different streams of one shard run
+ *     concurrently, each stream with its own workspace (searches sharing a stream run in order).  The vector searches and the
+ *     facet-filtered BM25 search keep one workspace per shard: queue them on one stream per shard.  Destroy must not race.
  * Plain C types only: no torch / HIP types in any signature (streams cross as void*).
  */
 #ifndef SEEKSTORM_HIP_H

@@ -198,18 +198,20 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
 // facet counting walks (facet.hip).  The caller has checked that every list of the query has a probe row.
 int ssi_bm25_match_bits(ss_shard* s, const ss_bm25_query* d_q, unsigned long long* d_bits, unsigned long long* d_total, hipStream_t st) {
   if (!s->d_post || !s->d_probe) return SS_ESTATE;
-  if (sizeof(bm_vquery) > s->vq_cap) {
-    if (s->d_vq) (void)hipFree(s->d_vq);
-    s->d_vq = nullptr; s->vq_cap = 0;
-    SS_HIP(hipMalloc(&s->d_vq, 64 * sizeof(bm_vquery)));
-    s->vq_cap = 64 * sizeof(bm_vquery);
+  ss_bm_ws& W = s->bm_ws[st];
+  if (sizeof(bm_vquery) > W.vq_cap) {
+    SS_HIP(hipStreamSynchronize(st));
+    if (W.d_vq) (void)hipFree(W.d_vq);
+    W.d_vq = nullptr; W.vq_cap = 0;
+    SS_HIP(hipMalloc(&W.d_vq, 64 * sizeof(bm_vquery)));
+    W.vq_cap = 64 * sizeof(bm_vquery);
   }
   uint32_t* tau = (uint32_t*)(d_bits);  // the expansion zeroes one threshold line per query: scratch, overwritten below
-  bm_expand_kernel<<<1, 128, 0, st>>>(d_q, (bm_vquery*)s->d_vq, 1, s->bm_n_fields, (const unsigned long long*)s->d_term_base,
+  bm_expand_kernel<<<1, 128, 0, st>>>(d_q, (bm_vquery*)W.d_vq, 1, s->bm_n_fields, (const unsigned long long*)s->d_term_base,
                                       s->d_boost, d_total, tau, BM_CLAIM_AND | BM_CLAIM_OR | BM_CLAIM_FREQ | (0xFFu << 8) | (0xFFu << 16),
                                       s->bm_n_terms, nullptr);  // the host entry point validated the query
   BmParams p{};
-  p.q = (const bm_vquery*)s->d_vq;
+  p.q = (const bm_vquery*)W.d_vq;
   p.total = d_total;
   p.del = s->n_deleted ? s->d_deleted : nullptr;
   p.del_words = (uint32_t)s->deleted_words;
@@ -263,31 +265,34 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   // u64 words: 4 floats per (query, partition) + one float per (query, sub-block) -- the pruned kernel's block-max bounds
   const size_t pmax_words = (size_t)nq * P * 2 + ((size_t)nq * s->bm_n_sub + 1) / 2;
   const size_t need = (size_t)nq * P * KS * 2 + nq + tau_words + pmax_words;  // two ping-pong merge buffers + totals + tau + bounds
-  if (need > s->part_cap) {
-    if (s->d_part) (void)hipFree(s->d_part);
-    s->d_part = nullptr;
-    s->part_cap = 0;
-    SS_HIP(hipMalloc(&s->d_part, need * sizeof(u64)));
-    s->part_cap = need;
+  ss_bm_ws& W = s->bm_ws[st];  // this stream's workspace: searches on other streams of the shard run beside this one
+  if (need > W.part_cap) {
+    SS_HIP(hipStreamSynchronize(st));  // earlier searches of this stream may still use the old buffer
+    if (W.d_part) (void)hipFree(W.d_part);
+    W.d_part = nullptr;
+    W.part_cap = 0;
+    SS_HIP(hipMalloc(&W.d_part, need * sizeof(u64)));
+    W.part_cap = need;
   }
-  u64* bufA = (u64*)s->d_part;
+  u64* bufA = (u64*)W.d_part;
   u64* bufB = bufA + (size_t)nq * P * KS;
   u64* total = bufB + (size_t)nq * P * KS;
   uint32_t* tau = (uint32_t*)(total + nq);
   float* pmax_ws = (float*)(total + nq + tau_words);
 
   // queries over (term, field) posting lists
-  if ((size_t)nq * sizeof(bm_vquery) > s->vq_cap) {
-    if (s->d_vq) (void)hipFree(s->d_vq);
-    s->d_vq = nullptr;
-    s->vq_cap = 0;
-    SS_HIP(hipMalloc(&s->d_vq, (size_t)nq * sizeof(bm_vquery)));
-    s->vq_cap = (size_t)nq * sizeof(bm_vquery);
+  if ((size_t)nq * sizeof(bm_vquery) > W.vq_cap) {
+    SS_HIP(hipStreamSynchronize(st));
+    if (W.d_vq) (void)hipFree(W.d_vq);
+    W.d_vq = nullptr;
+    W.vq_cap = 0;
+    SS_HIP(hipMalloc(&W.d_vq, (size_t)nq * sizeof(bm_vquery)));
+    W.vq_cap = (size_t)nq * sizeof(bm_vquery);
   }
   // nt_max / np_max count (term, field) lists here; the claim is in public terms
   const uint32_t claim = (phrase ? BM_CLAIM_PHRASE : 0u) | (has_and ? BM_CLAIM_AND : 0u) | ((has_or || F > 1) ? BM_CLAIM_OR : 0u) | (all_probed ? BM_CLAIM_PROBED : 0u) |
                          (any_frequent ? BM_CLAIM_FREQ : 0u) | (std::min(nt_max / F, 255u) << 8) | (std::min(np_max / F, 255u) << 16);
-  bm_expand_kernel<<<(nq + 127) / 128, 128, 0, st>>>(d_q, (bm_vquery*)s->d_vq, nq, s->bm_n_fields,
+  bm_expand_kernel<<<(nq + 127) / 128, 128, 0, st>>>(d_q, (bm_vquery*)W.d_vq, nq, s->bm_n_fields,
                                                     (const unsigned long long*)s->d_term_base, s->d_boost, total, tau, claim,
                                                     s->bm_n_terms, s->d_probe_row);
 
@@ -295,7 +300,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   p.post = s->d_post;
   p.term_base = (const unsigned long long*)s->d_term_base;
   p.sub_off = s->d_sub_off;
-  p.q = (const bm_vquery*)s->d_vq;
+  p.q = (const bm_vquery*)W.d_vq;
   p.part_keys = bufA;
   p.total = total;
   p.tau = tau;

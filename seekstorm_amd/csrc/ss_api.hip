@@ -97,8 +97,13 @@ int ss_shard_destroy(ss_shard* s) {
   (void)hipStreamSynchronize(s->stream);
   free_vec(s);
   free_bm25(s);
-  void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_part, s->d_deleted, s->d_vq, s->d_facets, s->d_filter_bits, s->d_facet_ws};
+  void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_deleted, s->d_facets, s->d_filter_bits, s->d_facet_ws};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  (void)hipDeviceSynchronize();  // searches queued on the callers' own streams may still use their workspaces
+  for (auto& kv : s->bm_ws) {
+    if (kv.second.d_vq) (void)hipFree(kv.second.d_vq);
+    if (kv.second.d_part) (void)hipFree(kv.second.d_part);
+  }
   for (int kx = 0; kx < 2; kx++)
     for (auto& pr : s->prof.pending[kx]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   (void)hipStreamDestroy(s->stream);

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -102,6 +103,16 @@ struct ss_prof {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[2];
 };
 
+// BM25 workspace of ONE stream: expanded queries + partition lists / totals / thresholds / bounds.  Searches queued on
+// different streams of one shard run concurrently on the device, so each stream owns its buffers (grow-only; a buffer is
+// only replaced after its stream has drained).  The host-pointer entry points use the shard's own stream.
+struct ss_bm_ws {
+  void* d_vq = nullptr;
+  size_t vq_cap = 0;
+  uint64_t* d_part = nullptr;
+  size_t part_cap = 0;
+};
+
 struct ss_shard {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -150,7 +161,7 @@ struct ss_shard {
   uint32_t bm_n_fields = 1;               // indexed fields (BM25F); the public API speaks of bm_n_terms / bm_n_fields terms
   float* d_boost = nullptr;               // [bm_n_fields] schema boost per field (add_result.rs:1253)
   std::vector<uint64_t> h_df_real;        // multi-field: docs containing the term in any field (the df idf needs)
-  void* d_vq = nullptr; size_t vq_cap = 0;  // expanded queries (bm_vquery)
+  std::map<hipStream_t, ss_bm_ws> bm_ws;   // per-stream search workspaces (guarded by mu)
   uint64_t bm_n_post = 0;
   float bm_avgdl = 0.f;
   uint64_t bm_n_post_pad = 0;     // dwords in d_post (segments padded to 16 bytes)
@@ -193,7 +204,6 @@ struct ss_shard {
                                    // block size; the last row (absent terms) is all zero
   // bm25 workspace
   void* d_bq = nullptr; size_t bq_cap = 0;       // staged queries
-  uint64_t* d_part = nullptr; size_t part_cap = 0; // partition-local top-k keys
   uint64_t* d_ptotal = nullptr;                   // per (query, partition) match counts
   ss_prof prof;
 };

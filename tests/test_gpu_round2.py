@@ -158,3 +158,34 @@ def test_comm_allgather_merge_single_rank(S, O, lex):
     torch.cuda.synchronize()
     assert torch.equal(rd, md) and torch.equal(rs, ms) and torch.equal(rc, mc)
     comm.close()
+
+
+def test_bm25_searches_on_two_streams_of_one_shard_overlap_safely(S, O, lex):
+    """per-stream workspaces: device-pointer searches queued on two different streams of ONE shard (different batches, different
+    batch sizes) run concurrently and each returns what it returns alone"""
+    import torch
+    from seekstorm_amd import _native as N
+    sh, osh, n_docs = lex
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(9)
+    batches = []
+    for nq in (700, 90):
+        tl = [[int(x) for x in rng.choice(16, 3, replace=False)] for _ in range(nq)]
+        q = sh.make_queries(tl, S.QueryType.Union)
+        batches.append((nq, torch.from_numpy(q.view(np.uint8).reshape(nq, -1).copy()).to(dev), q))
+    k = 10
+    outs, streams = [], [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    for nq, qd, _ in batches:
+        outs.append((torch.empty((nq, k), dtype=torch.int32, device=dev), torch.empty((nq, k), dtype=torch.float32, device=dev),
+                     torch.empty((nq,), dtype=torch.int32, device=dev), torch.empty((nq,), dtype=torch.int64, device=dev)))
+    torch.cuda.synchronize()
+    L = N.lib()
+    for rep in range(20):  # interleaved launches: both streams busy at the same time
+        for (nq, qd, _), (od, os_, oc, ot), st in zip(batches, outs, streams):
+            N.check(L.ss_bm25_search_dev(sh._h, nq, qd.data_ptr(), k, N.RT_TOPKCOUNT, 2 | (3 << 8), od.data_ptr(), os_.data_ptr(), oc.data_ptr(),
+                                         ot.data_ptr(), C.c_void_p(st.cuda_stream)), "ss_bm25_search_dev")
+    torch.cuda.synchronize()
+    for (nq, qd, q), (od, os_, oc, ot) in zip(batches, outs):
+        d1, s1, c1, t1 = sh.search_lexical_batch(q, k)  # the same batch alone, through the host-pointer entry point
+        assert np.array_equal(os_.cpu().numpy(), s1) and np.array_equal(od.cpu().numpy().view(np.uint32), d1)
+        assert np.array_equal(ot.cpu().numpy().view(np.uint64), t1)
