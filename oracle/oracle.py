@@ -591,3 +591,18 @@ def synth_positions(doclen_bytes, docs, tfs, seed=99):
         n = max(int(dec[doclen_bytes[d]]), int(tf), 1)
         out.append(np.sort(rng.choice(min(n, 65535), int(tf), replace=False)).astype(np.uint16))
     return np.concatenate(out) if out else np.zeros(0, np.uint16)
+
+
+def bench_vec(rows, queries, k, mode, threads, seconds):
+    """CPU baseline harness of the vector path (so_bench_vec) -> (queries/s, queries answered, latencies in microseconds)"""
+    rows = np.ascontiguousarray(rows, np.float32)
+    q = np.ascontiguousarray(queries, np.float32)
+    f = lib().so_bench_vec
+    f.restype = C.c_double
+    f.argtypes = [f32p, C.c_uint64, C.c_uint32, f32p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_double, u64p,
+                  C.POINTER(C.c_double), C.c_uint32, u32p]
+    lat = np.zeros(1 << 16, np.float64)
+    done, nlat = C.c_uint64(), C.c_uint32()
+    qps = f(_p(rows, f32p), rows.shape[0], rows.shape[1], _p(q, f32p), q.shape[0], k, mode, threads, float(seconds), C.byref(done),
+            lat.ctypes.data_as(C.POINTER(C.c_double)), len(lat), C.byref(nlat))
+    return qps, done.value, lat[:nlat.value].copy()

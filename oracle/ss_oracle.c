@@ -1593,3 +1593,100 @@ uint32_t so_search_phrase(const so_shard* s, uint32_t nq, const uint32_t* qt, ui
   free(v);
   return n;
 }
+
+/* ================================================================== CPU baseline harness, vector path (bench.py)
+ * search_vector_shard's AnnMode::All scan (read_record -> dot_f32_avx2 -> TopK::push, vector.rs:1397-1466) in the reference's
+ * execution structure: the records partitioned over S shards, one task per shard and query, gather + sort.
+ *   mode 0 (throughput): `threads` workers, each answers whole queries over ALL rows;
+ *   mode 1 (latency):    one query at a time, `threads` workers each scanning its slice of the rows, merge on the caller.
+ * rows [n_rows][dim] f32, queries [nq][dim].  Returns queries/s. */
+typedef struct {
+  const float* rows; uint64_t n_rows; uint32_t dim; const float* q; uint32_t nq, k; double t_end;
+  atomic_uint_fast64_t next, done, gen; atomic_uint_fast32_t pending; atomic_int stop;
+  uint32_t cur_q, S; uint32_t* r_doc; float* r_score; uint32_t* r_n; uint64_t checksum;
+} so_vctx;
+typedef struct { so_vctx* c; uint32_t id; } so_varg;
+static void* vthr_throughput(void* a_) {
+  so_varg* a = (so_varg*)a_; so_vctx* c = a->c;
+  uint32_t* od = (uint32_t*)malloc(c->k * sizeof(uint32_t));
+  float* os = (float*)malloc(c->k * sizeof(float));
+  uint64_t chk = 0;
+  while (now_s() < c->t_end) {
+    const uint64_t i = atomic_fetch_add(&c->next, 1);
+    so_f32_ctx x = {c->rows, c->q + (size_t)(i % c->nq) * c->dim, c->dim, 1, 0};
+    uint64_t tot, obs;
+    uint32_t n = topk_scan(c->n_rows, NULL, c->k, -3.4028235e38f, NULL, 0, score_f32, &x, od, os, &tot, &obs);
+    chk += n ? od[0] : 0;
+    atomic_fetch_add(&c->done, 1);
+  }
+  __atomic_fetch_add(&c->checksum, chk, __ATOMIC_RELAXED);
+  free(od); free(os);
+  return NULL;
+}
+static void* vthr_latency(void* a_) {
+  so_varg* a = (so_varg*)a_; so_vctx* c = a->c;
+  const uint64_t r0 = c->n_rows * a->id / c->S, r1 = c->n_rows * (a->id + 1) / c->S;
+  uint64_t seen = 0;
+  for (;;) {
+    uint64_t g; uint32_t spins = 0;
+    while ((g = atomic_load_explicit(&c->gen, memory_order_acquire)) == seen) {
+      if (atomic_load_explicit(&c->stop, memory_order_relaxed)) return NULL;
+      if (++spins > 2000) { sched_yield(); spins = 0; }
+    }
+    seen = g;
+    so_f32_ctx x = {c->rows + r0 * c->dim, c->q + (size_t)c->cur_q * c->dim, c->dim, 1, 0};
+    uint64_t tot, obs;
+    c->r_n[a->id] = topk_scan(r1 - r0, NULL, c->k, -3.4028235e38f, NULL, 0, score_f32, &x, c->r_doc + (size_t)a->id * c->k,
+                              c->r_score + (size_t)a->id * c->k, &tot, &obs);
+    atomic_fetch_sub_explicit(&c->pending, 1, memory_order_release);
+  }
+}
+double so_bench_vec(const float* rows, uint64_t n_rows, uint32_t dim, const float* queries, uint32_t nq, uint32_t k, int mode,
+                    uint32_t threads, double seconds, uint64_t* out_queries, double* out_lat_us, uint32_t lat_cap, uint32_t* out_nlat) {
+  so_vctx c; memset(&c, 0, sizeof c);
+  c.rows = rows; c.n_rows = n_rows; c.dim = dim; c.q = queries; c.nq = nq; c.k = k; c.S = threads;
+  atomic_init(&c.next, 0); atomic_init(&c.done, 0); atomic_init(&c.gen, 0); atomic_init(&c.pending, 0); atomic_init(&c.stop, 0);
+  pthread_t* th = (pthread_t*)malloc(threads * sizeof(pthread_t));
+  so_varg* args = (so_varg*)malloc(threads * sizeof(so_varg));
+  double t0 = now_s(), el;
+  uint32_t nlat = 0;
+  if (mode == 0) {
+    c.t_end = t0 + seconds;
+    for (uint32_t i = 0; i < threads; i++) { args[i].c = &c; args[i].id = i; pthread_create(&th[i], NULL, vthr_throughput, &args[i]); }
+    for (uint32_t i = 0; i < threads; i++) pthread_join(th[i], NULL);
+    el = now_s() - t0;
+  } else {
+    c.r_doc = (uint32_t*)malloc((size_t)threads * k * sizeof(uint32_t)); c.r_score = (float*)malloc((size_t)threads * k * sizeof(float));
+    c.r_n = (uint32_t*)calloc(threads, sizeof(uint32_t));
+    so_gres* tmp = (so_gres*)malloc((size_t)threads * k * sizeof(so_gres));
+    for (uint32_t i = 0; i < threads; i++) { args[i].c = &c; args[i].id = i; pthread_create(&th[i], NULL, vthr_latency, &args[i]); }
+    uint64_t qn = 0;
+    t0 = now_s();
+    while (now_s() - t0 < seconds) {
+      const double a = now_s();
+      c.cur_q = (uint32_t)(qn % nq);
+      atomic_store_explicit(&c.pending, threads, memory_order_relaxed);
+      atomic_fetch_add_explicit(&c.gen, 1, memory_order_release);
+      uint32_t spins = 0;
+      while (atomic_load_explicit(&c.pending, memory_order_acquire)) if (++spins > 2000) { sched_yield(); spins = 0; }
+      uint32_t m = 0;
+      for (uint32_t sh = 0; sh < threads; sh++)
+        for (uint32_t i = 0; i < c.r_n[sh]; i++) { tmp[m].doc = c.r_doc[(size_t)sh * k + i]; tmp[m].score = c.r_score[(size_t)sh * k + i]; m++; }
+      qsort(tmp, m, sizeof(so_gres), gres_cmp);
+      c.checksum += m ? tmp[0].doc : 0;
+      const double b = now_s();
+      if (out_lat_us && nlat < lat_cap) out_lat_us[nlat++] = (b - a) * 1e6;
+      qn++;
+    }
+    el = now_s() - t0;
+    atomic_store(&c.stop, 1);
+    for (uint32_t i = 0; i < threads; i++) pthread_join(th[i], NULL);
+    atomic_store(&c.done, qn);
+    free(c.r_doc); free(c.r_score); free(c.r_n); free(tmp);
+  }
+  free(th); free(args);
+  const uint64_t done = atomic_load(&c.done);
+  if (out_queries) *out_queries = done;
+  if (out_nlat) *out_nlat = nlat;
+  return el > 0 ? (double)done / el : 0.0;
+}

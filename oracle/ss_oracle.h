@@ -196,6 +196,11 @@ uint32_t so_vec_search_i8_euclid(const int8_t* rows, uint64_t n_rows, uint32_t d
                                  float cluster_threshold_raw, const uint64_t* deleted_sorted, uint64_t n_deleted,
                                  const uint16_t* row_field, uint64_t field_mask, uint32_t* out_doc, float* out_score,
                                  uint64_t* out_total, uint64_t* out_observed, uint64_t* out_clusters);
+/* CPU baseline harness of the vector path: AnnMode::All scans (dot_f32_avx2 order + TopK::push) on `threads` workers; mode 0 =
+ * throughput (independent queries per worker, all rows each), mode 1 = latency (one query at a time, rows split over the
+ * workers as the reference splits them over shards).  Returns queries/s. */
+double so_bench_vec(const float* rows, uint64_t n_rows, uint32_t dim, const float* queries, uint32_t nq, uint32_t k, int mode,
+                    uint32_t threads, double seconds, uint64_t* out_queries, double* out_lat_us, uint32_t lat_cap, uint32_t* out_nlat);
 /* vector_score field: vector.rs:1495-1499 */
 float so_vector_score_field(float dot);
 /* TopK threshold transform: vector.rs:388-397 */
