@@ -433,6 +433,14 @@ int ss_comm_destroy(ss_comm* c);
 int ss_comm_info(const ss_comm* c, int* rank, int* n_ranks, int* device);
 int ss_topk_allgather_merge(ss_comm* c, uint32_t n_queries, uint32_t k, const uint32_t* d_doc, const float* d_score,
                             const uint32_t* d_count, uint64_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, void* stream);
+/* One shard's part of <IndexArc as Search>::search when the shards live on different GPUs (search.rs:1637-1743 per-shard
+ * task, 1669-1673 global ids, 1875-1940 gather, 1884-1921 totals summed, 2098-2119 sort / truncate): searches shard `s`
+ * (host queries, as ss_bm25_search), exchanges through `c` -- one all-gather of the lists, one all-reduce of the totals --
+ * and hands EVERY rank the merged answer: out_doc [n_queries][k] GLOBAL ids (local * n_ranks + rank; UINT64_MAX = unused),
+ * out_score, out_count, out_total (sum over the shards).  Collective over the communicator: every rank calls it with the
+ * same n_queries / k / result_type (each with its own shard's idf in the queries).  c's device must be s's. */
+int ss_bm25_search_sharded(ss_shard* s, ss_comm* c, uint32_t n_queries, const ss_bm25_query* queries, uint32_t k,
+                           uint32_t result_type, uint64_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total);
 
 /* Hybrid fusion of a query batch on the device: RRF (k = 0.6, 0-based ranks, search.rs:1962-2035) of the lexical and the
  * vector list of every query, then sort / offset / length (2098-2119) -- ss_merge_results(SS_MODE_HYBRID) for n_queries

@@ -19,6 +19,11 @@ struct ss_comm {
   uint32_t* d_send = nullptr;  // [(2 k + 1) nq] packed lists of this rank
   uint32_t* d_recv = nullptr;  // [n_ranks][(2 k + 1) nq]
   size_t cap_words = 0;        // capacity of d_send
+  uint64_t* d_mdoc = nullptr;  // merged lists of ss_*_search_sharded: [nq][k] global ids | scores | counts | summed totals
+  float* d_mscore = nullptr;
+  uint32_t* d_mcount = nullptr;
+  uint64_t* d_mtotal = nullptr;
+  size_t cap_m = 0, cap_mq = 0;
   std::mutex mu;
 };
 
@@ -93,6 +98,10 @@ int ss_comm_destroy(ss_comm* c) {
   if (c->comm) (void)ncclCommDestroy(c->comm);
   if (c->d_send) (void)hipFree(c->d_send);
   if (c->d_recv) (void)hipFree(c->d_recv);
+  if (c->d_mdoc) (void)hipFree(c->d_mdoc);
+  if (c->d_mscore) (void)hipFree(c->d_mscore);
+  if (c->d_mcount) (void)hipFree(c->d_mcount);
+  if (c->d_mtotal) (void)hipFree(c->d_mtotal);
   delete c;
   return SS_OK;
 }
@@ -126,3 +135,41 @@ int ss_topk_allgather_merge(ss_comm* c, uint32_t n_queries, uint32_t k, const ui
 }
 
 }  // extern "C"
+
+// ss_bm25_search_sharded's exchange: the shard's device lists -> merged lists + summed totals on the host of every rank
+// (result_count_total is summed over the shards, search.rs:1884-1921).  k = 0: totals only (ResultType::Count).
+int ssi_comm_exchange_to_host(ss_comm* c, uint32_t nq, uint32_t k, const uint32_t* d_doc, const float* d_score, const uint32_t* d_count,
+                              const uint64_t* d_total, uint64_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total,
+                              hipStream_t st) {
+  if (!c) return SS_EINVAL;
+  SS_HIP(hipSetDevice(c->device));
+  {
+    std::lock_guard<std::mutex> g(c->mu);
+    const size_t nk = (size_t)nq * std::max<uint32_t>(k, 1);
+    if (nk > c->cap_m || nq > c->cap_mq) {
+      SS_HIP(hipStreamSynchronize(st));
+      if (c->d_mdoc) (void)hipFree(c->d_mdoc);
+      if (c->d_mscore) (void)hipFree(c->d_mscore);
+      if (c->d_mcount) (void)hipFree(c->d_mcount);
+      if (c->d_mtotal) (void)hipFree(c->d_mtotal);
+      c->d_mdoc = nullptr; c->d_mscore = nullptr; c->d_mcount = nullptr; c->d_mtotal = nullptr;
+      c->cap_m = c->cap_mq = 0;
+      SS_HIP(hipMalloc(&c->d_mdoc, nk * sizeof(uint64_t)));
+      SS_HIP(hipMalloc(&c->d_mscore, nk * sizeof(float)));
+      SS_HIP(hipMalloc(&c->d_mcount, (size_t)nq * sizeof(uint32_t)));
+      SS_HIP(hipMalloc(&c->d_mtotal, (size_t)nq * sizeof(uint64_t)));
+      c->cap_m = nk; c->cap_mq = nq;
+    }
+  }
+  SS_NCCL(ncclAllReduce(d_total, c->d_mtotal, nq, ncclUint64, ncclSum, c->comm, st));
+  if (k) {
+    int rc = ss_topk_allgather_merge(c, nq, k, d_doc, d_score, d_count, c->d_mdoc, c->d_mscore, c->d_mcount, (void*)st);
+    if (rc) return rc;
+    SS_HIP(hipMemcpyAsync(out_doc, c->d_mdoc, (size_t)nq * k * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    SS_HIP(hipMemcpyAsync(out_score, c->d_mscore, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
+    SS_HIP(hipMemcpyAsync(out_count, c->d_mcount, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  }
+  SS_HIP(hipMemcpyAsync(out_total, c->d_mtotal, (size_t)nq * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  SS_HIP(hipStreamSynchronize(st));
+  return SS_OK;
+}

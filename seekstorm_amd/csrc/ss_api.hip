@@ -446,21 +446,14 @@ int ss_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k,
   return ss_bm25_search_filtered(s, nq, q, k, rt, 0, nullptr, out_doc, out_score, out_count, out_total);
 }
 
-int ss_bm25_search_filtered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k, uint32_t rt, uint32_t n_filters,
-                            const ss_facet_filter* filters, uint32_t* out_doc, float* out_score, uint32_t* out_count,
-                            uint64_t* out_total) {
-  if (!s || !q || !out_count || !out_total) return SS_EINVAL;
-  if (rt > SS_RT_TOPKCOUNT) return SS_EINVAL;
-  if (rt != SS_RT_COUNT && (k == 0 || k > SS_MAX_K || !out_doc || !out_score)) return SS_EINVAL;
-  if (!s->d_post) return SS_ESTATE;
-  if (nq == 0) return SS_OK;
+// the search of ss_bm25_search_filtered / _sharded up to the device lists (s->d_out_*, on s->stream); caller holds s->mu
+static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, uint32_t n_filters,
+                                    const ss_facet_filter* filters) {
   bool has_and = false, has_or = false;
   uint32_t nt_max = 0, np_max = 0;
   bool all_probed = false, any_frequent = false, phrase = false;
-  std::lock_guard<std::mutex> g(s->mu);  // before check_queries: it reads the image's host-side tables (an upload replaces them)
   SS_TRY(check_queries(s, nq, q, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent, &phrase));
   SS_HIP(hipSetDevice(s->device));
-  const uint32_t kk = rt == SS_RT_COUNT ? 0 : k;
   SS_TRY(ensure_out(s, nq, std::max<uint32_t>(kk, 1)));
   if ((size_t)nq * sizeof(ss_bm25_query) > s->bq_cap) {
     if (s->d_bq) (void)hipFree(s->d_bq);
@@ -469,10 +462,23 @@ int ss_bm25_search_filtered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, ui
     s->bq_cap = (size_t)nq * sizeof(ss_bm25_query);
   }
   SS_HIP(hipMemcpyAsync(s->d_bq, q, (size_t)nq * sizeof(ss_bm25_query), hipMemcpyHostToDevice, s->stream));
-  SS_TRY(with_facet_filter(s, n_filters, filters, s->stream, [&]() {
+  return with_facet_filter(s, n_filters, filters, s->stream, [&]() {
     return ssi_bm25_search(s, nq, (const ss_bm25_query*)s->d_bq, kk, rt, s->d_out_doc, s->d_out_score, s->d_out_count,
                            s->d_out_total, has_and, has_or, nt_max, np_max, all_probed, s->stream, any_frequent, phrase);
-  }));
+  });
+}
+
+int ss_bm25_search_filtered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k, uint32_t rt, uint32_t n_filters,
+                            const ss_facet_filter* filters, uint32_t* out_doc, float* out_score, uint32_t* out_count,
+                            uint64_t* out_total) {
+  if (!s || !q || !out_count || !out_total) return SS_EINVAL;
+  if (rt > SS_RT_TOPKCOUNT) return SS_EINVAL;
+  if (rt != SS_RT_COUNT && (k == 0 || k > SS_MAX_K || !out_doc || !out_score)) return SS_EINVAL;
+  if (!s->d_post) return SS_ESTATE;
+  if (nq == 0) return SS_OK;
+  std::lock_guard<std::mutex> g(s->mu);  // before check_queries: it reads the image's host-side tables (an upload replaces them)
+  const uint32_t kk = rt == SS_RT_COUNT ? 0 : k;
+  SS_TRY(bm25_search_host_queries(s, nq, q, kk, rt, n_filters, filters));
   if (kk) {
     SS_HIP(hipMemcpyAsync(out_doc, s->d_out_doc, (size_t)nq * kk * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     SS_HIP(hipMemcpyAsync(out_score, s->d_out_score, (size_t)nq * kk * sizeof(float), hipMemcpyDeviceToHost, s->stream));
@@ -481,6 +487,28 @@ int ss_bm25_search_filtered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, ui
   SS_HIP(hipMemcpyAsync(out_total, s->d_out_total, (size_t)nq * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
   SS_HIP(hipStreamSynchronize(s->stream));
   return SS_OK;
+}
+
+// One shard's part of <IndexArc as Search>::search over shards on different GPUs (search.rs:1637-1743 + 1875-2119): search
+// this shard, ONE all-gather of the lists + an all-reduce of the totals over the communicator, merge on the device; every
+// rank's caller receives the merged answer.  Collective: the rank of every shard of the communicator calls it with the
+// same batch (in one process: one thread per shard).
+int ss_bm25_search_sharded(ss_shard* s, ss_comm* c, uint32_t nq, const ss_bm25_query* q, uint32_t k, uint32_t rt,
+                           uint64_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total) {
+  if (!s || !c || !q || !out_total) return SS_EINVAL;
+  if (rt > SS_RT_TOPKCOUNT) return SS_EINVAL;
+  if (rt != SS_RT_COUNT && (k == 0 || k > SS_MAX_K || !out_doc || !out_score || !out_count)) return SS_EINVAL;
+  int dev = -1, n_ranks = 0;
+  SS_TRY(ss_comm_info(c, nullptr, &n_ranks, &dev));
+  if (dev != s->device) return SS_EINVAL;
+  if (!s->d_post) return SS_ESTATE;
+  if (nq == 0) return SS_OK;
+  std::lock_guard<std::mutex> g(s->mu);
+  const uint32_t kk = rt == SS_RT_COUNT ? 0 : k;
+  if ((uint64_t)n_ranks * kk > 8192) return SS_EINVAL;
+  SS_TRY(bm25_search_host_queries(s, nq, q, kk, rt, 0, nullptr));
+  return ssi_comm_exchange_to_host(c, nq, kk, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, out_doc, out_score,
+                                   out_count, out_total, s->stream);
 }
 
 // Facet counts of ONE query (query_facets / facet_count, add_result.rs:484-640): histogram of a facet over the query's match

@@ -310,3 +310,8 @@ int ssi_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, cons
                            const uint16_t* tfs, uint64_t positions_sum);
 void ssi_prof_begin(ss_shard* s, int kernel, hipStream_t st, hipEvent_t* e0, hipEvent_t* e1);
 void ssi_prof_end(ss_shard* s, int kernel, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
+
+struct ss_comm;
+int ssi_comm_exchange_to_host(ss_comm* c, uint32_t nq, uint32_t k, const uint32_t* d_doc, const float* d_score, const uint32_t* d_count,
+                              const uint64_t* d_total, uint64_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total,
+                              hipStream_t st);

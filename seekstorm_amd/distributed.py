@@ -150,6 +150,20 @@ class ShardComm:
                 "ss_topk_allgather_merge")
         return m_doc, m_score, m_cnt
 
+    def search_lexical_sharded(self, shard, queries, k, result_type=N.RT_TOPKCOUNT):
+        """this rank's part of Index.search over shards on different GPUs (ss_bm25_search_sharded): search `shard`, exchange,
+        merge -> (global ids uint64 [nq, k], scores, counts, totals summed over the shards), the same on every rank"""
+        import numpy as np
+        nq = len(queries)
+        kk = max(int(k), 1)
+        doc = np.full((nq, kk), np.iinfo(np.uint64).max, np.uint64)
+        score = np.zeros((nq, kk), np.float32)
+        cnt = np.zeros(nq, np.uint32)
+        tot = np.zeros(nq, np.uint64)
+        N.check(N.lib().ss_bm25_search_sharded(shard._h, self._h, nq, queries.ctypes.data, int(k), int(result_type), doc.ctypes.data,
+                                               score.ctypes.data, cnt.ctypes.data, tot.ctypes.data), "ss_bm25_search_sharded")
+        return doc, score, cnt, tot
+
     def close(self):
         if self._h:
             N.lib().ss_comm_destroy(self._h)

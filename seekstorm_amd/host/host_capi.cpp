@@ -176,4 +176,29 @@ int ssh_coalesced_lexical_search(ssh_index* ix, int shard, uint32_t n, const uin
   return (int)co.batches_submitted();
 }
 
+// Index::search_lexical_batch: query i = terms[term_off[i] .. term_off[i+1]); out arrays [n][k]; device_exchange != 0 first calls
+// Index::enable_device_exchange and returns its code (negative) on failure
+int ssh_index_search_lexical_batch(ssh_index* ix, uint32_t n, const uint32_t* terms, const uint32_t* term_off, uint32_t query_type,
+                                   uint32_t k, uint32_t result_type, int device_exchange, uint64_t* out_doc, float* out_score,
+                                   uint32_t* out_count, uint64_t* out_total) {
+  if (device_exchange) {
+    const int rc = ix->index->enable_device_exchange();
+    if (rc != SS_OK) return rc;
+  }
+  std::vector<std::vector<uint32_t>> q(n);
+  for (uint32_t i = 0; i < n; i++) q[i].assign(terms + term_off[i], terms + term_off[i + 1]);
+  std::vector<ResultObject> r = ix->index->search_lexical_batch(q, (QueryType)query_type, k, (ResultType)result_type);
+  int err = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    out_count[i] = (uint32_t)r[i].results.size();
+    out_total[i] = r[i].result_count_total;
+    if (r[i].last_error) err = r[i].last_error;
+    for (size_t j = 0; j < r[i].results.size() && j < k; j++) {
+      out_doc[(size_t)i * k + j] = r[i].results[j].doc_id;
+      out_score[(size_t)i * k + j] = r[i].results[j].score;
+    }
+  }
+  return err;
+}
+
 }  // extern "C"

@@ -39,7 +39,7 @@ float threshold_raw(const float* similarity_threshold, bool euclidean) {
 float vector_score_of(float raw_dot) { return ((raw_dot * kSimilarityNormalization64I8) + 1.0f) / 2.0f; }  // vector.rs:1495-1499
 
 // ------------------------------------------------------------------ Shard
-Shard::Shard(int device, uint32_t shard_id) : shard_id_(shard_id) {
+Shard::Shard(int device, uint32_t shard_id) : shard_id_(shard_id), device_(device) {
   create_rc_ = ss_shard_create(device, &h_);
   if (create_rc_ != SS_OK) h_ = nullptr;
 }
@@ -422,6 +422,120 @@ ResultObject Index::search(const std::vector<uint32_t>& query_terms, const float
   }
   ro.result_count = ro.results.size();
   return ro;
+}
+
+Index::~Index() {
+  for (ss_comm* c : comms_) ss_comm_destroy(c);
+}
+
+int Index::enable_device_exchange() {
+  if (!comms_.empty()) return SS_OK;
+  const size_t S = shards_.size();
+  if (S == 0) return SS_ESTATE;
+  std::vector<int> devices(S);
+  for (size_t i = 0; i < S; i++) {
+    if (!shards_[i]->ok() || shards_[i]->shard_id() != i) return SS_ESTATE;  // rank = shard id: global id = local * S + rank
+    devices[i] = shards_[i]->device();
+    for (size_t j = 0; j < i; j++)
+      if (devices[j] == devices[i]) return SS_EINVAL;
+  }
+  std::vector<ss_comm*> c(S, nullptr);
+  const int rc = ss_comm_create_all((int)S, devices.data(), c.data());
+  if (rc != SS_OK) return rc;
+  comms_ = std::move(c);
+  return SS_OK;
+}
+
+std::vector<ResultObject> Index::search_lexical_batch(const std::vector<std::vector<uint32_t>>& query_terms, QueryType query_type_default,
+                                                      size_t k, ResultType result_type) {
+  const size_t S = shards_.size(), nq = query_terms.size();
+  std::vector<ResultObject> out(nq);
+  if (S == 0 || nq == 0) return out;
+  const size_t kk = std::max<size_t>(k, 1);
+  // every shard resolves the batch with its OWN idf (shard-local N and posting counts, search.rs:3225-3230)
+  std::vector<std::vector<ss_bm25_query>> q(S, std::vector<ss_bm25_query>(nq));
+  int bad = SS_OK;
+  for (size_t i = 0; i < S; i++)
+    for (size_t j = 0; j < nq; j++) {
+      const int rc = shards_[i]->make_query(query_terms[j], query_type_default, &q[i][j]);
+      if (rc != SS_OK) bad = rc;
+      else if (result_type != ResultType::Count) shards_[i]->mark_all_terms_frequent(&q[i][j], k);
+    }
+  if (bad != SS_OK) {  // decided BEFORE any shard task starts: a collective must be entered by every rank or by none
+    for (ResultObject& ro : out) ro.last_error = bad;
+    return out;
+  }
+  if (!comms_.empty()) {
+    // device exchange: every shard task ends with the SAME merged lists; the task of shard 0 fills the answer
+    std::vector<uint64_t> doc(nq * kk), tot(nq);
+    std::vector<float> score(nq * kk);
+    std::vector<uint32_t> cnt(nq);
+    std::vector<int> rcs(S, SS_OK);
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < S; i++)
+      th.emplace_back([&, i] {
+        std::vector<uint64_t> d(i ? nq * kk : 0), t(i ? nq : 0);
+        std::vector<float> sc(i ? nq * kk : 0);
+        std::vector<uint32_t> c(i ? nq : 0);
+        rcs[i] = ss_bm25_search_sharded(shards_[i]->handle(), comms_[i], (uint32_t)nq, q[i].data(), (uint32_t)k, (uint32_t)result_type,
+                                        i ? d.data() : doc.data(), i ? sc.data() : score.data(), i ? c.data() : cnt.data(),
+                                        i ? t.data() : tot.data());
+      });
+    for (auto& t : th) t.join();
+    int rc = SS_OK;
+    for (int r : rcs) if (r != SS_OK) rc = r;
+    for (size_t j = 0; j < nq; j++) {
+      ResultObject& ro = out[j];
+      if (rc != SS_OK) { ro.last_error = rc; continue; }
+      const size_t n = result_type == ResultType::Count ? 0 : cnt[j];
+      ro.results.resize(n);
+      for (size_t x = 0; x < n; x++) {
+        Result& r = ro.results[x];
+        r.doc_id = doc[j * kk + x];
+        r.score = r.lexical_score = score[j * kk + x];
+        r.shard_id = (uint32_t)(r.doc_id % S);
+        r.level_id = (uint32_t)((r.doc_id / S) >> 16);
+        r.source = ResultSource::Lexical;
+      }
+      ro.result_count = n;
+      ro.result_count_total = tot[j];
+    }
+    return out;
+  }
+  // host gather: per-shard batches on one thread each, then ss_merge_results per query (search.rs:1875-2119)
+  std::vector<std::vector<ResultObject>> part(S);
+  std::vector<std::thread> th;
+  for (size_t i = 0; i < S; i++)
+    th.emplace_back([&, i] { part[i] = shards_[i]->search_lexical_batch(q[i], k, result_type, {}, false); });
+  for (auto& t : th) t.join();
+  std::vector<uint64_t> ld, od(kk);
+  std::vector<float> ls, os(kk);
+  std::vector<uint8_t> src(kk);
+  for (size_t j = 0; j < nq; j++) {
+    ResultObject& ro = out[j];
+    ld.clear(); ls.clear();
+    for (size_t i = 0; i < S; i++) {
+      const ResultObject& p = part[i][j];
+      for (const Result& r : p.results) { ld.push_back(r.doc_id * S + shards_[i]->shard_id()); ls.push_back(r.score); }
+      ro.result_count_total += p.result_count_total;
+      if (p.last_error) ro.last_error = p.last_error;
+    }
+    if (result_type == ResultType::Count || k == 0) continue;
+    const int n = ss_merge_results(SS_MODE_LEXICAL, ld.data(), ls.data(), (uint32_t)ld.size(), nullptr, nullptr, 0, 0, (uint32_t)k,
+                                   od.data(), os.data(), src.data());
+    if (n < 0) { ro.last_error = n; continue; }
+    ro.results.resize((size_t)n);
+    for (int x = 0; x < n; x++) {
+      Result& r = ro.results[(size_t)x];
+      r.doc_id = od[(size_t)x];
+      r.score = r.lexical_score = os[(size_t)x];
+      r.shard_id = (uint32_t)(r.doc_id % S);
+      r.level_id = (uint32_t)((r.doc_id / S) >> 16);
+      r.source = ResultSource::Lexical;
+    }
+    ro.result_count = ro.results.size();
+  }
+  return out;
 }
 
 // ------------------------------------------------------------------ VectorBatchCoalescer

@@ -85,6 +85,7 @@ class Shard {
   int create_error() const { return create_rc_; }
   ss_shard* handle() const { return h_; }
   uint32_t shard_id() const { return shard_id_; }
+  int device() const { return device_; }
 
   // (re)build of the device image: end of open_shard (index.rs:3796) / after a commit (commit.rs:142-148)
   // positions (optional): every posting's tf positions in CSR order -- what phrase queries walk
@@ -143,6 +144,7 @@ class Shard {
  private:
   ss_shard* h_ = nullptr;
   uint32_t shard_id_ = 0;
+  int device_ = 0;
   int create_rc_ = SS_OK;
   uint64_t n_docs_ = 0, n_rows_ = 0;
   uint32_t dim_ = 0;
@@ -157,7 +159,17 @@ class Shard {
 class Index {
  public:
   explicit Index(std::vector<std::shared_ptr<Shard>> shards) : shards_(std::move(shards)) {}
+  ~Index();
   size_t shard_number() const { return shards_.size(); }
+  // Shards on DIFFERENT GPUs: form one RCCL communicator over them (ss_comm_create_all, rank = shard id).  From then on
+  // search_lexical_batch exchanges and merges the per-shard lists on the devices over xGMI (ss_bm25_search_sharded) instead
+  // of gathering them on the host.  SS_EINVAL when two shards share a device (a communicator holds one rank per GPU).
+  int enable_device_exchange();
+  bool device_exchange() const { return !comms_.empty(); }
+  // A batch of lexical queries over all shards, merged: per query the top `k` of the whole index (global ids) and the
+  // summed totals -- the batched form of search() for SearchMode::Lexical, offset 0.  One host thread per shard.
+  std::vector<ResultObject> search_lexical_batch(const std::vector<std::vector<uint32_t>>& query_terms, QueryType query_type_default,
+                                                 size_t k, ResultType result_type);
   Shard& shard(size_t i) { return *shards_[i]; }
 
   // <IndexArc as Search>::search for this path.  query_terms: resolved term ids (empty = no lexical part);
@@ -174,6 +186,7 @@ class Index {
 
  private:
   std::vector<std::shared_ptr<Shard>> shards_;
+  std::vector<ss_comm*> comms_;  // one per shard once enable_device_exchange succeeded
 };
 
 // Coalesces concurrent single-query vector searches on ONE shard into device batches: a caller enqueues its query

@@ -160,6 +160,27 @@ def test_comm_allgather_merge_single_rank(S, O, lex):
     comm.close()
 
 
+def test_search_sharded_single_rank_equals_plain_search(S, O, lex):
+    """ss_bm25_search_sharded with a communicator of one shard: search + all-gather + all-reduce + merge = ss_bm25_search with
+    u64 ids; Count carries the totals only"""
+    from seekstorm_amd import distributed as D
+    sh, osh, n_docs = lex
+    comm = D.ShardComm(0, 1, 0)
+    q = sh.make_queries([[3, 7, 11], [5, 9], [4], [2, 6]], S.QueryType.Union)
+    q2 = sh.make_queries([[3, 7], [5, 9], [1, 4], [2, 6]], S.QueryType.Intersection)
+    for qq in (q, q2):
+        doc, score, cnt, tot = sh.search_lexical_batch(qq, 10)
+        for _ in range(2):
+            md, ms, mc, mt = comm.search_lexical_sharded(sh, qq, 10)
+            assert np.array_equal(mc, cnt) and np.array_equal(mt, tot)
+            for i in range(len(qq)):
+                assert np.array_equal(md[i, :cnt[i]], doc[i, :cnt[i]].astype(np.uint64))
+                assert np.array_equal(ms[i, :cnt[i]], score[i, :cnt[i]])
+        _, _, _, ct = comm.search_lexical_sharded(sh, qq, 0, result_type=int(S.ResultType.Count))
+        assert np.array_equal(ct, tot)
+    comm.close()
+
+
 def test_bm25_searches_on_two_streams_of_one_shard_overlap_safely(S, O, lex):
     """per-stream workspaces: device-pointer searches queued on two different streams of ONE shard (different batches, different
     batch sizes) run concurrently and each returns what it returns alone"""

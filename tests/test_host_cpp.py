@@ -58,6 +58,8 @@ def H():
     L.ssh_set_clusters.argtypes = [C.c_void_p, C.c_int, C.c_uint32, u32p, C.c_uint32, u32p]
     L.ssh_search_vector_shard_ann.argtypes = [C.c_void_p, C.c_int, f32p, C.c_uint32, C.c_int, C.c_uint32, C.c_float, C.c_uint32,
                                               u64p, f32p, u64p, u64p]
+    L.ssh_index_search_lexical_batch.argtypes = [C.c_void_p, C.c_uint32, u32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                                 u64p, f32p, u32p, u64p]
     return L
 
 
@@ -364,3 +366,65 @@ def test_cpp_shard_facet_filter(H):
             assert np.allclose(sc[:n], os_[3:], rtol=1e-4) and all(keep[int(d)] for d in doc[:n])
     finally:
         H.ssh_index_destroy(ix)
+
+
+@pytest.mark.gpu
+def test_cpp_index_lexical_batch_host_gather_and_device_exchange(H):
+    """Index::search_lexical_batch: (a) two shards on one GPU -> host gather, every query equal to Index::search's single-query
+    answer; (b) a communicator needs one GPU per shard: two shards on device 0 -> SS_EINVAL; (c) one shard with the device
+    exchange on (ss_bm25_search_sharded over a communicator of one) -> the same lists as the host path"""
+    from oracle import oracle as O
+    n_docs, S_n = 60_000, 2
+    voc = [3000, 3300, 3600, 4000, 4040]
+    dl = O.lex_doclen(n_docs)
+    offs, docs, tfs = O.lex_corpus(n_docs, voc)
+    queries = [[0, 1, 2], [3, 4], [2], [1, 3, 4], [0, 4]]
+    tcat = np.asarray([t for q in queries for t in q], np.uint32)
+    toff = np.asarray(np.cumsum([0] + [len(q) for q in queries]), np.uint32)
+    k = 15
+
+    def build(S):
+        ix = H.ssh_index_create(S, (C.c_int * S)(*([0] * S)))
+        for sid in range(S):
+            o2, d2, t2 = [0], [], []
+            for t in range(len(voc)):
+                d = docs[int(offs[t]):int(offs[t + 1])]
+                f = tfs[int(offs[t]):int(offs[t + 1])]
+                m = (d % S) == sid
+                d2.append(d[m] // S); t2.append(f[m]); o2.append(o2[-1] + int(m.sum()))
+            d2 = np.concatenate(d2).astype(np.uint32); t2 = np.concatenate(t2).astype(np.uint16)
+            dls = np.ascontiguousarray(dl[sid::S])
+            assert H.ssh_upload_lexical(ix, sid, len(dls), P(dls, u8p), len(voc), P(np.asarray(o2, np.uint64), u64p), P(d2, u32p),
+                                        P(t2, u16p)) == 0
+        return ix
+
+    def batch(ix, qt, exchange):
+        doc = np.zeros((len(queries), k), np.uint64); sc = np.zeros((len(queries), k), np.float32)
+        cnt = np.zeros(len(queries), np.uint32); tot = np.zeros(len(queries), np.uint64)
+        rc = H.ssh_index_search_lexical_batch(ix, len(queries), P(tcat, u32p), P(toff, u32p), qt, k, 2, exchange, P(doc, u64p),
+                                              P(sc, f32p), P(cnt, u32p), P(tot, u64p))
+        return rc, doc, sc, cnt, tot
+
+    ix2 = build(2)
+    ix1 = build(1)
+    try:
+        for qt in (0, 1):  # Intersection, Union
+            rc, doc, sc, cnt, tot = batch(ix2, qt, 0)
+            assert rc == 0
+            for i, q in enumerate(queries):
+                d, s, src, ls, vs, meta = _search(H, ix2, q, None, qt, 0, 0, k)
+                assert cnt[i] == len(d) and tot[i] == meta[1]
+                assert np.array_equal(doc[i, :cnt[i]], d) and np.array_equal(sc[i, :cnt[i]], s)
+            assert batch(ix2, qt, 1)[0] == -1  # SS_EINVAL: both shards on device 0
+            rc_h, dh, sh_, ch, th = batch(ix1, qt, 0)
+            assert rc_h == 0
+        for qt in (0, 1):
+            rc_h, dh, sh_, ch, th = batch(ix1, qt, 0)
+            rc_x, dx, sx, cx, tx = batch(ix1, qt, 1)
+            assert rc_h == 0 and rc_x == 0
+            assert np.array_equal(ch, cx) and np.array_equal(th, tx)
+            for i in range(len(queries)):
+                assert np.array_equal(dh[i, :ch[i]], dx[i, :cx[i]]) and np.array_equal(sh_[i, :ch[i]], sx[i, :cx[i]])
+    finally:
+        H.ssh_index_destroy(ix2)
+        H.ssh_index_destroy(ix1)

@@ -16,7 +16,7 @@ G[write]="WRITE_SIZE"
 for g in ${3:-sqA sqB sqC fetch write}; do
   d=gpurun_out/pmc_${TAG}_${g}
   rm -rf $d
-  ( cd /tmp && timeout 600 rocprofv3 --pmc ${G[$g]} --kernel-trace -d $OLDPWD/$d -o x -- python $OLDPWD/bench.py --workload $WL --no-cpu --no-topk-count --steps 4 --warmup 1 > $OLDPWD/$d.log 2>&1 )
+  ( cd /tmp && timeout 600 rocprofv3 --pmc ${G[$g]} --kernel-trace -d $OLDPWD/$d -o x -- python $OLDPWD/bench.py --workload $WL --quick --no-topk-count --steps 4 --warmup 1 > $OLDPWD/$d.log 2>&1 )
   db=$(find $d -name "*results.db" | head -1)
   echo "=== group $g ($db)" >> $OUT
   python tools/rocpd_pmc.py $db >> $OUT 2>&1

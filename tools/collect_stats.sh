@@ -1,5 +1,6 @@
 #!/bin/bash
-# rocprofv3 --kernel-trace --stats of the bench (run on the GPU box): bash tools/collect_stats.sh <tag>
+# rocprofv3 --kernel-trace --stats of the default bench command minus its host-only legs (run on the GPU box):
+#   bash tools/collect_stats.sh <tag> ["extra bench flags"]
 # -> gpurun_out/<tag>_kernel_stats.md (per-kernel table) + gpurun_out/<tag>_bench.json (bench line of the same run)
 set -u
 TAG=${1:-x}
@@ -8,7 +9,7 @@ export TMPDIR=/tmp
 R=$PWD
 d=$R/gpurun_out/stats_$TAG
 rm -rf $d
-( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $d -o x -- python $R/bench.py --no-cpu --steps 5 --warmup 1 > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err )
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $d -o x -- python $R/bench.py --no-cpu --no-parity ${2:-} > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err )
 db=$(find $d -name "*results.db" | head -1)
 python tools/rocpd_stats.py $db gpurun_out/${TAG}_kernel_stats.md > /dev/null
 rm -rf $d

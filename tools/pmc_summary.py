@@ -4,15 +4,30 @@ fetch, write, sqA, sqB, sqC -- never combined with API tracing) into profiles/<t
 profiles/pmc_traffic.json.
 
 HBM bytes follow MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are KiB, and on gfx950 FETCH_SIZE reports
-exactly half of a wide coalesced read -> bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  BM25 figures are per FULL launch
+exactly half of the bytes read -> bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  The factor was checked on kernels of known
+traffic (tools/probes/pmc_calib.hip, profiles/r2_pmc_calibration.md): 2.00 for coalesced 16-byte streams AND for scattered
+8-byte gathers (a gather moves a whole 128-byte line and the counter sees half of it); WRITE_SIZE needs no factor.
+hbm_bytes_per_launch_low is the uncorrected reading (FETCH_SIZE + WRITE_SIZE), a floor.  BM25 figures are per FULL launch
 (the dispatches with the largest grid: 1000-query batches; single-query latency probes are excluded); vector figures
 are per 64-query pass (4 row-chunk launches of vec_scan_kernel / vec8_scan_kernel).
 Usage: python tools/pmc_summary.py <gpurun_out dir> <tag>"""
+import hashlib
 import json
 import os
 import sqlite3
 import sys
 from collections import defaultdict
+
+
+def kernel_source_hash():
+    """the same hash bench.py computes: pmc_traffic.json is only believed for the kernel sources it was collected on"""
+    h = hashlib.sha256()
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "seekstorm_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def load(db, pat):
@@ -32,7 +47,7 @@ def main():
     d, tag = sys.argv[1], sys.argv[2]
     db = lambda g: os.path.join(d, f"pmc_{tag}_{g}", "x_results.db")
     out, lines = {}, [f"# PMC summary ({tag})", "",
-                      "`rocprofv3 --pmc <group> --kernel-trace -- python bench.py --workload all --no-cpu --steps 4 --warmup 1`, "
+                      "`rocprofv3 --pmc <group> --kernel-trace -- python bench.py --workload all --quick --no-topk-count --steps 4 --warmup 1`, "
                       "one run per counter group (tools/collect_pmc.sh).  SQ_* wave counters are in quad-cycles "
                       "(MI355X_MICROARCH.md); GRBM_GUI_ACTIVE is summed over the 8 XCDs.", ""]
     LAUNCHES_PER_PASS = 4  # chunk schedule of the vector scans: 16 tiles, then 16 x the prefix (10 M rows)
@@ -61,7 +76,7 @@ def main():
         rows, _ = sel("fetch")
         dur_ms = sum(r["dur"] for r in rows) / n / 1e6
         unit = "full launch (1000 queries)" if kern.startswith("bm25") else f"64-query pass ({LAUNCHES_PER_PASS} launches)"
-        out[kern] = {"hbm_bytes_per_launch": hbm, "fetch_size_kib_total": fetch, "write_size_kib_total": write,
+        out[kern] = {"hbm_bytes_per_launch": hbm, "hbm_bytes_per_launch_low": (fetch / n + write / nw) * 1024.0, "fetch_size_kib_total": fetch, "write_size_kib_total": write,
                      "launches": n, "cycles_per_launch": gui / 8 / n, "kernel_ms_per_launch_profiled": dur_ms}
         lines += [f"## {kern}: `{pat}` -- per {unit}, {n} of them", "",
                   f"- FETCH_SIZE {fetch / n:.4g} KiB, WRITE_SIZE {write / nw:.4g} KiB -> HBM traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 = "
@@ -94,6 +109,8 @@ def main():
             lines.append(f"- **MFMA utilisation** = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x shader cycles) = **{100 * util:.1f} %** "
                          "(64 busy cycles per v_mfma_f32_32x32x2_f32)")
         lines.append("")
+    out["kernel_source_hash"] = kernel_source_hash()
+    out["collected_as"] = tag
     os.makedirs("profiles", exist_ok=True)
     open(os.path.join("profiles", f"{tag}_pmc_summary.md"), "w").write("\n".join(lines) + "\n")
     json.dump(out, open(os.path.join("profiles", "pmc_traffic.json"), "w"), indent=1)
