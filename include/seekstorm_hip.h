@@ -237,7 +237,8 @@ int ss_bm25_search(ss_shard* s, uint32_t n_queries, const ss_bm25_query* queries
  * the queries, what the batch contains (it picks the kernel variants by it): bit 0 set if any query is an intersection of
  * > 1 terms (variant with match counters) or carries a field filter, bit 1 set if any query is a union of > 1 terms;
  * bits 8..15 = the largest n_terms + NOT terms in the batch (0 = unknown: the generic 10-term kernel is used); bits 16..23 =
- * the largest n_terms alone (0 = same as bits 8..15, i.e. no NOT terms); bit 2 set if every term of the batch has probe rows
+ * the largest n_terms alone (0 = same as bits 8..15, i.e. NO query of the batch has NOT terms -- a batch with NOT terms
+ * declares bits 8..15 > bits 16..23 even when its longest query has none); bit 2 set if every term of the batch has probe rows
  * (ss_bm25_term_probed; irrelevant when the probe budget covered all lists); bit 3 set if some query carries
  * SS_OP_ALL_TERMS_FREQUENT; bit 4 set if the batch consists of SS_OP_PHRASE queries (then all of them must be).
  * The assertion is CHECKED ON THE DEVICE, query by query, before the search kernels run: a query that contradicts ops_mask

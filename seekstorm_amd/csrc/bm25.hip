@@ -123,6 +123,7 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
     const uint32_t nt_claim = (claim >> 8) & 0xFFu, np_claim = (claim >> 16) & 0xFFu, ff = n_fields > 1 ? bm_q_field_filter(Q.op) : 0u;
     bool bad = np == 0 || np + n_not > (uint32_t)SS_MAX_QUERY_TERMS || (np + n_not) * n_fields > (uint32_t)BM_MAX_VTERMS;
     bad |= np + n_not > nt_claim || np > np_claim;
+    bad |= n_not != 0 && nt_claim == np_claim;  // nt == np declares a batch without NOT terms (unfiltered kernel variants)
     const bool q_and = ((bm_q_op(Q.op) == SS_OP_INTERSECTION || bm_q_op(Q.op) == SS_OP_PHRASE) && np > 1) || ff != 0u;
     bad |= q_and && !(claim & BM_CLAIM_AND);
     bad |= !q_and && np > 1 && !(claim & BM_CLAIM_OR);
@@ -208,7 +209,7 @@ int ssi_bm25_match_bits(ss_shard* s, const ss_bm25_query* d_q, unsigned long lon
   }
   uint32_t* tau = (uint32_t*)(d_bits);  // the expansion zeroes one threshold line per query: scratch, overwritten below
   bm_expand_kernel<<<1, 128, 0, st>>>(d_q, (bm_vquery*)W.d_vq, 1, s->bm_n_fields, (const unsigned long long*)s->d_term_base,
-                                      s->d_boost, d_total, tau, BM_CLAIM_AND | BM_CLAIM_OR | BM_CLAIM_FREQ | (0xFFu << 8) | (0xFFu << 16),
+                                      s->d_boost, d_total, tau, BM_CLAIM_AND | BM_CLAIM_OR | BM_CLAIM_FREQ | (0xFFu << 8) | (0xFEu << 16),
                                       s->bm_n_terms, nullptr);  // the host entry point validated the query
   BmParams p{};
   p.q = (const bm_vquery*)W.d_vq;
@@ -254,7 +255,16 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   // filled last round costs its full duration (measured on C2: 550K q/s at 1.95 rounds vs 477K at 2.44).  Exhaustive
   // scan: 2048 resident waves (LDS-bound), ~2 rounds; pruned: 6144 resident waves, ~4 rounds of shorter assignments
   // balance its more uneven work (driver streams differ 4x in length between queries).
-  const uint32_t resident = (pruned || phrase) ? 6144u : 2048u, rounds = (pruned || phrase) ? 4u : 2u;
+  // Exact counts (Count / TopkCount).  Pruned: the probe kernel counts intersections and single lists while it ranks them,
+  // unions are popcounted from the bit records.  Scan kernels under AUTO with a probe index: every count comes from the
+  // bit records and the scan runs without its count mode (which scans every sub-block: 5.8 instead of 1.8 ms per 1000 C2
+  // queries); a pure Count request then needs no scan at all.  SS_BM25_EXHAUSTIVE keeps the scan's own counts.
+  const bool want_counts = rt != SS_RT_TOPK;
+  const bool bit_counts_all = want_counts && !pruned && !phrase && s->bm_strategy != SS_BM25_EXHAUSTIVE && have_probe;
+  const bool scan_counts = want_counts && !bit_counts_all;
+  // unions of <= 4 lists ranked by the scan: the 16-bit-accumulator kernel (16 waves per CU instead of 8)
+  const bool scan16 = !pruned && !phrase && ssi_bm25_scan16_serves(nt_max, np_max, has_and, scan_counts, KPL, k);
+  const uint32_t resident = (pruned || phrase) ? 6144u : scan16 ? 4096u : 2048u, rounds = (pruned || phrase) ? 4u : 2u;
   uint32_t P = (rounds * resident) / nq;
   // small batches: beyond ~150 waves the probe kernel gains nothing and every extra partition is one more list to merge
   // (single query on C2: 0.128 ms at P = n_sub = 2442, 0.086 ms at P = 128)
@@ -311,13 +321,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   p.nq = nq;
   p.P = P;
   p.k = k;
-  // Exact counts (Count / TopkCount).  Pruned: the probe kernel counts intersections and single lists while it ranks them,
-  // unions are popcounted from the bit records.  Scan kernels under AUTO with a probe index: every count comes from the
-  // bit records and the scan runs without its count mode (which scans every sub-block: 5.8 instead of 1.8 ms per 1000 C2
-  // queries); a pure Count request then needs no scan at all.  SS_BM25_EXHAUSTIVE keeps the scan's own counts.
-  const bool want_counts = rt != SS_RT_TOPK;
-  const bool bit_counts_all = want_counts && !pruned && !phrase && s->bm_strategy != SS_BM25_EXHAUSTIVE && have_probe;
-  p.count = (want_counts && !bit_counts_all) ? 1u : 0u;
+  p.count = scan_counts ? 1u : 0u;
   // per-partition block maxima as the pruned kernel's bounds: where the image's maxima vary over the doc ids (set at build),
   // SS_BM25_SUBMAX = 1 / 0 forces them on / off
   static const int force_partmax = [] { const char* e = getenv("SS_BM25_SUBMAX"); return e ? atoi(e) : -1; }();
@@ -331,7 +335,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
     rc = ssi_bm25_launch_phrase(p, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_pos, s->d_pos_off, (const unsigned long long*)s->d_pos_base,
                                 np_max, KPL, st);
   else rc = pruned ? ssi_bm25_launch_probe(p, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_umax, use_partmax ? s->d_submax : nullptr, pmax_ws, np_max, KPL, nt_max != np_max, st)
-                   : ssi_bm25_launch_scan(p, nt_max, has_and, KPL, st);
+                   : scan16 ? ssi_bm25_launch_scan16(p, nt_max, KPL, st) : ssi_bm25_launch_scan(p, nt_max, has_and, KPL, st);
   ssi_prof_end(s, 0, st, e0, e1);
   if (rc) return rc;
   if (want_counts && ((pruned && has_or) || bit_counts_all)) {

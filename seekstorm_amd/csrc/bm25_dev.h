@@ -216,14 +216,10 @@ __device__ __forceinline__ float bm_chunk(const u32x4 q, float idf, const BmLds&
 //   read  : gather / add only, the new scores stay in registers (last term: scattered or zeroed once the trigger is known)
 // The dump slot (NULL postings) takes part like any accumulator and is zeroed with the rest, so what it holds is bounded by
 // NT * idf * 2^-14 per item -- far below any real score; it is never scanned.
-// W = components of the lane's 16 bytes that belong to it (1..4): the LAST chunk of a segment is loaded at a lane stride of
-// 4 W bytes (W = ceil(remaining 16-byte units / 16)), so a short tail costs W posting steps per lane instead of 4 -- with one
-// load instruction either way.  Components >= W repeat the next lanes' postings and are ignored.
-template <int W>
 __device__ __forceinline__ float bm_chunk_first(const u32x4 q, float idf, const BmLds& L, float mx, uint32_t (&ao)[4]) {
   const uint32_t pv[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-  for (int x = 0; x < W; x++) {
+  for (int x = 0; x < 4; x++) {
     ao[x] = bm_acc_addr(pv[x], L);
     const float nw = idf * bm_weight(pv[x]);
     lds_stf(ao[x], nw);
@@ -231,49 +227,28 @@ __device__ __forceinline__ float bm_chunk_first(const u32x4 q, float idf, const 
   }
   return mx;
 }
-template <int W>
 __device__ __forceinline__ float bm_chunk_read(const u32x4 q, float idf, const BmLds& L, float mx, uint32_t (&ao)[4],
                                                float (&nw)[4]) {
   const uint32_t pv[4] = {q.x, q.y, q.z, q.w};
   float old[4];
 #pragma unroll
-  for (int x = 0; x < W; x++) {
+  for (int x = 0; x < 4; x++) {
     ao[x] = bm_acc_addr(pv[x], L);
     old[x] = lds_ldf(ao[x]);
   }
 #pragma unroll
-  for (int x = 0; x < W; x++) {
+  for (int x = 0; x < 4; x++) {
     nw[x] = old[x] + idf * bm_weight(pv[x]);
     mx = fmaxf(mx, nw[x]);
   }
   return mx;
 }
-template <int W>
 __device__ __forceinline__ float bm_chunk_keep(const u32x4 q, float idf, const BmLds& L, float mx, uint32_t (&ao)[4]) {
   float nw[4];
-  mx = bm_chunk_read<W>(q, idf, L, mx, ao, nw);
+  mx = bm_chunk_read(q, idf, L, mx, ao, nw);
 #pragma unroll
-  for (int x = 0; x < W; x++) lds_stf(ao[x], nw[x]);
+  for (int x = 0; x < 4; x++) lds_stf(ao[x], nw[x]);
   return mx;
-}
-template <int W>
-__device__ __forceinline__ void bm_chunk_store(const uint32_t (&ao)[4], const float (&v)[4]) {
-#pragma unroll
-  for (int x = 0; x < W; x++) lds_stf(ao[x], v[x]);
-}
-template <int W>
-__device__ __forceinline__ void bm_chunk_zero(const uint32_t (&ao)[4]) {
-#pragma unroll
-  for (int x = 0; x < W; x++) lds_stf(ao[x], 0.f);
-}
-template <int N> struct BmInt { static constexpr int value = N; };
-// dispatch on a wave-uniform chunk width wv in 1..4 (0: chunk absent, nothing happens)
-template <typename F>
-__device__ __forceinline__ void bm_with_width(uint32_t wv, F&& f) {
-  if (wv >= 4u) f(BmInt<4>{});
-  else if (wv == 3u) f(BmInt<3>{});
-  else if (wv == 2u) f(BmInt<2>{});
-  else if (wv == 1u) f(BmInt<1>{});
 }
 
 template <bool HAS_AND>
@@ -393,6 +368,9 @@ __device__ __attribute__((noinline)) BmTop<KPL> bm_offer_lane_keys(BmTop<KPL> T,
 
 // scan kernels (bm25_fast.hip): NT-specialised for <= 4 terms and k <= 128, grouped generic kernel otherwise
 int ssi_bm25_launch_scan(const BmParams& p, uint32_t nt_max, bool has_and, int KPL, hipStream_t st);
+// 16-bit-accumulator scan (bm25_scan16.hip): top-k of unions of <= 4 lists without NOT terms; 16 waves per CU
+bool ssi_bm25_scan16_serves(uint32_t nt_max, uint32_t np_max, bool has_and, bool count, int KPL, uint32_t k);
+int ssi_bm25_launch_scan16(const BmParams& p, uint32_t nt_max, int KPL, hipStream_t st);
 // exact union counts from the probe index's bit records (bm25_probe.hip)
 int ssi_bm25_launch_union_count(const BmParams& p, const uint2* probe, const uint32_t* probe_row, bool all_queries, hipStream_t st,
                                 unsigned long long* match_bits = nullptr);

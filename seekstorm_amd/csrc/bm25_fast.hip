@@ -17,11 +17,6 @@
 // processed four at a time per item with the term state re-read from a per-wave LDS table (no cross-item prefetch).
 #include "bm25_dev.h"
 
-#ifndef SS_BM_NARROW_TAILS
-#define SS_BM_NARROW_TAILS 1
-#endif
-constexpr bool BM_NARROW_TAILS = SS_BM_NARROW_TAILS != 0;
-
 template <int NT> struct FastCfg { static constexpr int CPT = NT <= 2 ? 4 : NT <= 4 ? 3 : 2; static constexpr int RC = NT * CPT; };
 
 #define BM_KERNEL_ARGS                                                                                              \
@@ -58,9 +53,7 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
 
   const uint32_t row_len = n_sub + 1;
   const bool count_mode = count != 0;
-  const int lane16 = lane * 16, lane4 = lane * 4;
-  // short segment tails at W posting steps per lane instead of 4 (unions; the general path masks instead of skipping)
-  constexpr bool NARROW = BM_NARROW_TAILS && !HAS_AND;
+  const int lane16 = lane * 16;
 
   // one (query, partition) assignment per wave; the grid covers all nq * P of them (workgroups are short-lived, the
   // dispatcher balances them over the CUs)
@@ -100,31 +93,15 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
     T.wsc = -1.0f;
     T.matched = 0;
 
-    // RC loads per item; lanes (and whole chunks) past the segment end are out of range: zeros, no memory access.
-    // The last chunk of a segment is read at a lane stride of 4 W bytes, W = ceil(its 16-byte units / 16) (bm25_dev.h):
-    // num_records is extended by the 16 - 4 W bytes a lane's 16-byte access reaches past its own W postings, so the
-    // range check never drops an access that holds real postings (what lies there belongs to components >= W: ignored).
+    // RC loads per item; lanes (and whole chunks) past the segment end are out of range: zeros, no memory access
     auto issue_loads = [&](u32x4(&v)[RC], const uint32_t (&b0)[NT], const uint32_t (&b1)[NT]) {
 #pragma unroll
       for (int t = 0; t < NT; t++) {
-        const uint32_t n16 = b1[t] - b0[t];
-        const uint32_t c_last = NARROW ? (n16 - 1u) >> 6 : 0xFFFFu;            // n16 = 0: no chunk is the last one
-        const uint32_t w_last = NARROW ? (((n16 - 1u) & 63u) >> 4) + 1u : 4u;  // 1..4
-        const uint32_t ext = (NARROW && n16) ? 16u - 4u * w_last : 0u;
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[t], 0, (int)((b1[t] << 4) + ext), BM_RSRC_FLAGS);
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[t], 0, (int)(b1[t] << 4), BM_RSRC_FLAGS);
 #pragma unroll
-        for (int c = 0; c < CPT; c++) {
-          const int voff = NARROW ? lane4 * (int)((uint32_t)c == c_last ? w_last : 4u) : lane16;
-          v[t * CPT + c] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + c * 1024, (int)(b0[t] << 4), 0);
-        }
+        for (int c = 0; c < CPT; c++)
+          v[t * CPT + c] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + c * 1024, (int)(b0[t] << 4), 0);
       }
-    };
-    // width of chunk c of a segment of n16 units: 0 absent, 1..4 posting steps per lane
-    auto chunk_w = [&](uint32_t n16, int c) -> uint32_t {
-      if ((uint32_t)c * 64u >= n16) return 0u;
-      if (!NARROW) return 4u;
-      const uint32_t r = n16 - (uint32_t)c * 64u;
-      return r >= 49u ? 4u : (r + 15u) >> 4;
     };
 
     u32x4 vA[RC], vB[RC];
@@ -155,34 +132,41 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
           const uint32_t n16 = B1[t] - B0[t];
 #pragma unroll
           for (int c = 0; c < CPT; c++)
-            bm_with_width(chunk_w(n16, c), [&](auto W) {
-              if (t == 0) mx = bm_chunk_first<decltype(W)::value>(cur[t * CPT + c], idf[t], L, mx, ao[t * CPT + c]);
-              else mx = bm_chunk_keep<decltype(W)::value>(cur[t * CPT + c], idf[t], L, mx, ao[t * CPT + c]);
-            });
+            if ((uint32_t)c * 64u < n16) {
+              if (t == 0) mx = bm_chunk_first(cur[t * CPT + c], idf[t], L, mx, ao[t * CPT + c]);
+              else mx = bm_chunk_keep(cur[t * CPT + c], idf[t], L, mx, ao[t * CPT + c]);
+            }
         }
         uint32_t aoL[CPT][4];
         float nwL[CPT][4];
 #pragma unroll
         for (int c = 0; c < CPT; c++)
-          bm_with_width(chunk_w(nlast, c), [&](auto W) {
-            mx = bm_chunk_read<decltype(W)::value>(cur[(NT - 1) * CPT + c], idf[NT - 1], L, mx, aoL[c], nwL[c]);
-          });
+          if ((uint32_t)c * 64u < nlast) mx = bm_chunk_read(cur[(NT - 1) * CPT + c], idf[NT - 1], L, mx, aoL[c], nwL[c]);
         const float thr = fmaxf(T.wsc, __uint_as_float(tau_bits));
         if (count_mode || (k && __ballot(mx >= thr))) {
 #pragma unroll
           for (int c = 0; c < CPT; c++)
-            bm_with_width(chunk_w(nlast, c), [&](auto W) { bm_chunk_store<decltype(W)::value>(aoL[c], nwL[c]); });
+            if ((uint32_t)c * 64u < nlast) {
+#pragma unroll
+              for (int x = 0; x < 4; x++) lds_stf(aoL[c][x], nwL[c][x]);
+            }
           T = bm_scan_tile<HAS_AND, KPL>(T, L.tile, L.cntw, nt_and, s << BM_SUB_LOG2, count_mode, k, thr, tau_q, del, del_words);
         } else {
 #pragma unroll
           for (int c = 0; c < CPT; c++)
-            bm_with_width(chunk_w(nlast, c), [&](auto W) { bm_chunk_zero<decltype(W)::value>(aoL[c]); });
+            if ((uint32_t)c * 64u < nlast) {
+#pragma unroll
+              for (int x = 0; x < 4; x++) lds_stf(aoL[c][x], 0.f);
+            }
 #pragma unroll
           for (int t = 0; t + 1 < NT; t++) {
             const uint32_t n16 = B1[t] - B0[t];
 #pragma unroll
             for (int c = 0; c < CPT; c++)
-              bm_with_width(chunk_w(n16, c), [&](auto W) { bm_chunk_zero<decltype(W)::value>(ao[t * CPT + c]); });
+              if ((uint32_t)c * 64u < n16) {
+#pragma unroll
+                for (int x = 0; x < 4; x++) lds_stf(ao[t * CPT + c][x], 0.f);
+              }
           }
         }
       } else if (maxn) {
@@ -194,14 +178,8 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
           const uint32_t n16 = B1[t] - B0[t];
 #pragma unroll
           for (int c = 0; c < CPT; c++)
-            if ((uint32_t)c * 64u < n16) {
-              u32x4 q = cur[t * CPT + c];
-              if (NARROW) {  // components past the chunk's width repeat other lanes' postings: make them NULL
-                const uint32_t wv = chunk_w(n16, c);
-                q.y = wv > 1u ? q.y : 0u; q.z = wv > 2u ? q.z : 0u; q.w = wv > 3u ? q.w : 0u;
-              }
-              mx = bm_chunk<HAS_AND>(q, idf[t], L, av[t], mx);
-            }
+            if ((uint32_t)c * 64u < n16)
+              mx = bm_chunk<HAS_AND>(cur[t * CPT + c], idf[t], L, av[t], mx);
           if (n16 > (uint32_t)CPT * 64u) {  // df above ~CPT/16 of the docs
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[t], 0, (int)(B1[t] << 4), BM_RSRC_FLAGS);
             for (uint32_t u = B0[t] + CPT * 64u; u < B1[t]; u += 64u) {

@@ -1,0 +1,453 @@
+// Exhaustive BM25 union scan with 16-bit accumulators: top-k (k <= 64) of unions of <= 4 lists, ResultType::Topk, no NOT terms.
+// Same reference path as bm25_fast.hip (union_docid_2/3, union_scan, single_blockid with add_result_multiterm_singlefield /
+// get_bm25f_multiterm_singlefield / MinHeap::add_topk) and the same answers, bit for bit.
+//
+// Why a second scan kernel.  bm25_scan_fast_kernel keeps an f32 accumulator per doc of a 4096-doc sub-block: 16 KB of LDS
+// per wave, so 8 waves per CU = 2 per SIMD, and at 2 waves per SIMD it is latency bound (at 1 wave per SIMD it takes 1.72x
+// as long, while VALU and LDS are each about half busy).  The tile does not have to hold scores: it only has
+// to say WHICH docs can reach the threshold.  Here a doc's accumulator is a u16 upper bound of its score in fixed point,
+//     q(posting) = trunc(idf * scale * weight') + 1   >   idf * weight * scale,      scale = 65000 / (4 * sum idf)
+// (weights are < 4 by their encoding, so a sum stays below 65 535), 8 KB of tile per wave, 16 waves per CU.  A doc whose
+// exact score S reaches thr has sum q > S * scale * (1 - 4e-7) >= qthr = trunc(thr * scale * (1 - 1e-5)); the few docs at
+// or above qthr (the real candidates and their closest neighbours) are re-scored EXACTLY from the item's postings, which
+// are still in registers: the f32 sum in query-term order with the fma chain of the other kernels (s16_trigger).
+// The tile is cleared densely (9 wide stores per item), so no address has to be remembered; the last term is only read
+// (its sums reach the tile when the item has candidates).
+// Structure of the item loop: the candidate path is NOT called from inside the streaming loop -- a hit leaves the loop,
+// the candidates are evaluated, and the pipeline is primed again.  With the call inside, the prefetched postings are live
+// across it: the allocator parks them in scratch in every item and the compiler's vmcnt bookkeeping merges the two
+// histories into a wait for everything (measured: 7x slower).
+#include "bm25_dev.h"
+
+namespace {
+
+constexpr int S16_WAVES = 8;                // waves per workgroup; 2 workgroups per CU
+constexpr int S16_WAVE_LDS = 9 * 1024;      // [14 B pad][dump u16][4096 u16][pad to 9 KB: the dense clear is 9 full stores]
+constexpr float S16_QMAX = 65000.0f;
+constexpr float S16_WMAX = 4.0f;            // bm_wdecode(0x7FFFF) < 4
+
+typedef __attribute__((address_space(3))) uint16_t bm_lds_u16;
+typedef __attribute__((address_space(3))) u32x4 bm_lds_u32x4;
+__device__ __forceinline__ uint32_t lds_ld16(uint32_t off) { return *(bm_lds_u16*)(uintptr_t)off; }
+__device__ __forceinline__ void lds_st16(uint32_t off, uint32_t v) { *(bm_lds_u16*)(uintptr_t)off = (uint16_t)v; }
+__device__ __forceinline__ u32x4 lds_ld128(uint32_t off) { return *(bm_lds_u32x4*)(uintptr_t)off; }
+__device__ __forceinline__ void lds_st128(uint32_t off, u32x4 v) { *(bm_lds_u32x4*)(uintptr_t)off = v; }
+
+__device__ __forceinline__ float s16_uniform(float x) {  // a wave-uniform value, pinned to a scalar register
+  return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x)));
+}
+// LDS address of a posting's accumulator: 2 VALU operations (and, shift-add; left alone the compiler shifts, masks and adds)
+__device__ __forceinline__ uint32_t s16_addr(uint32_t p, uint32_t accb) {
+  uint32_t r;
+  asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(r) : "v"(bm_doc_field(p)), "v"(accb));
+  return r;
+}
+// A posting's contribution to its doc's bound, 4 VALU operations: the weight is decoded WITHOUT masking the doc bits that the
+// shift leaves below the 19-bit code -- they only make the float larger, by less than 2^-15 relative, and an upper bound is
+// all the tile has to hold (the exact pass decodes with bm_weight).  q > idf * weight * scale, and
+// sum q <= S * scale * (1 + 2^-15) + NT, which is what S16_SLACK accounts for.
+__device__ __forceinline__ uint32_t s16_q(uint32_t p, float fidf) { return (uint32_t)(fidf * __uint_as_float((p >> 5) + BM_W_BASE)) + 1u; }
+constexpr uint32_t S16_SLACK = 4u;  // + NT: how far a bound can lie above score * scale (NT roundings up, 65535 * 2^-15 from the decode)
+
+// one 256-posting chunk: first = the tile holds nothing of this item yet (no read), keep = read / add / write,
+// read = read / add, sums stay in registers (last term)
+__device__ __forceinline__ uint32_t s16_first(const u32x4 v, float fidf, uint32_t accb, uint32_t mx) {
+  const uint32_t pv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int x = 0; x < 4; x++) {
+    const uint32_t q = s16_q(pv[x], fidf);
+    lds_st16(s16_addr(pv[x], accb), q);
+    mx = max(mx, q);
+  }
+  return mx;
+}
+__device__ __forceinline__ uint32_t s16_read(const u32x4 v, float fidf, uint32_t accb, uint32_t mx, uint32_t (&nw)[4]) {
+  const uint32_t pv[4] = {v.x, v.y, v.z, v.w};
+  uint32_t old[4];
+#pragma unroll
+  for (int x = 0; x < 4; x++) old[x] = lds_ld16(s16_addr(pv[x], accb));
+#pragma unroll
+  for (int x = 0; x < 4; x++) {
+    nw[x] = old[x] + s16_q(pv[x], fidf);
+    mx = max(mx, nw[x]);
+  }
+  return mx;
+}
+__device__ __forceinline__ uint32_t s16_keep(const u32x4 v, float fidf, uint32_t accb, uint32_t mx) {
+  uint32_t nw[4];
+  mx = s16_read(v, fidf, accb, mx, nw);
+  const uint32_t pv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int x = 0; x < 4; x++) lds_st16(s16_addr(pv[x], accb), nw[x]);
+  return mx;
+}
+__device__ __forceinline__ void s16_clear(uint32_t wb, int lane) {
+#pragma unroll
+  for (int i = 0; i < S16_WAVE_LDS / 1024; i++) lds_st128(wb + (uint32_t)(i * 64 + lane) * 16u, u32x4{0u, 0u, 0u, 0u});
+}
+
+constexpr uint32_t S16_LIST = 8320u;   // per-wave candidate list inside the slice's padding: up to S16_LIST_MAX doc-in-sub-block ids (u16)
+constexpr uint32_t S16_LIST_MAX = 64u;
+constexpr uint32_t S16_ACC = 8448u;    // their exact f32 scores while an item's candidates are evaluated
+
+typedef unsigned short s16_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t s16_pkmax(uint32_t a, uint32_t b) {  // v_pk_max_u16
+  const s16_u16x2 r = __builtin_elementwise_max(__builtin_bit_cast(s16_u16x2, a), __builtin_bit_cast(s16_u16x2, b));
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t s16_max8(const u32x4 e) {  // the largest of the eight bounds of one slot
+  const uint32_t m = s16_pkmax(s16_pkmax(e.x, e.y), s16_pkmax(e.z, e.w));
+  return max(m & 0xFFFFu, m >> 16);
+}
+
+// the accumulators alone (dump slot + 4096 entries: bytes 0 .. 8207 of the slice), leaving the candidate list / scores
+__device__ __forceinline__ void s16_clear_tile(uint32_t wb, int lane) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) lds_st128(wb + (uint32_t)(i * 64 + lane) * 16u, u32x4{0u, 0u, 0u, 0u});
+  if (lane == 0) lds_st128(wb + 8192u, u32x4{0u, 0u, 0u, 0u});
+}
+
+template <int RC> struct S16Cur { u32x4 v[RC]; };
+template <int NT> struct S16Item {
+  const uint32_t* tptr[NT];
+  float idf[NT], fidf[NT];
+  uint32_t b0[NT], b1[NT];  // the item's segments, 16-byte units relative to the list
+};
+
+// The candidate path of an item.  Out of line, and called from OUTSIDE the streaming loop (see the kernel): the item's
+// postings arrive by value in registers, everything else is scalar.
+//  1. the cut.  A doc the postings touched has a bound >= 1; qthr is what the query's threshold asks for.  While the list is
+//     not full (or its threshold is still low) hundreds of docs of an item pass that, and only k of them can enter.  Every
+//     lane owns 64 docs of the tile; if k lanes hold a bound >= x, k different docs have exact scores above
+//     (x - NT - S16_SLACK) / scale, so a doc whose bound is below that is not among the item's k best: the cut rises to the
+//     largest such x (bisection over the 64 lane maxima, ballots only).  k > 64 keeps the plain cut.
+//  2. the docs at or above the cut go to the wave's list, at most S16_LIST_MAX at a time, ascending;
+//  3. their EXACT scores are accumulated the way the bounds were -- by walking the item's postings -- but only for them:
+//     the tile is cleared, a candidate's entry gets its list position + 1 as a marker, and a posting whose doc carries a
+//     marker adds idf * weight to that candidate's f32 accumulator: terms in query order, one after the other (the docs
+//     of one term are distinct and LDS operations execute in order) -- the other kernels' sum, bit for bit;
+//  4. keys to the wave-resident top-k; more candidates than the list holds: the bounds are rebuilt and 2-4 repeat.
+template <int NT, int CPT, int KPL>
+__device__ __forceinline__ BmTop<KPL> s16_trigger(BmTop<KPL> T, S16Cur<NT * CPT> cur, S16Item<NT> it, uint32_t wb, uint32_t qthr,
+                                                            float thr, uint32_t doc_base, uint32_t k, uint32_t* tau_q,
+                                                            const uint32_t* __restrict__ del, uint32_t del_words) {
+  const int lane = __lane_id();
+  const int lane16 = lane * 16;
+  const uint32_t tile = wb + 16u, accb = wb + 14u, accf = wb + S16_ACC;
+  const float wsc_in = T.wsc;
+  uint32_t start = 0u;  // docs below it were evaluated by an earlier round
+  for (;;) {
+    uint32_t lm = 0u;  // this lane's largest bound (slot i * 64 + lane holds docs 8 * slot .. 8 * slot + 7)
+#pragma unroll
+    for (int i = 0; i < BM_SUB / 512; i++) lm = max(lm, s16_max8(lds_ld128(tile + (uint32_t)(i * 64 + lane) * 16u)));
+    uint32_t qcut = max(qthr, 1u);
+    if (k <= 64u && (uint32_t)__popcll(__ballot(lm >= qcut)) > k) {
+      uint32_t lo = qcut, hi = 65535u;  // invariant: at least k lanes reach lo
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1u) >> 1;
+        if ((uint32_t)__popcll(__ballot(lm >= mid)) >= k) lo = mid; else hi = mid - 1u;
+      }
+      qcut = max(qcut, lo > (uint32_t)NT + S16_SLACK ? lo - (uint32_t)NT - S16_SLACK : 1u);
+    }
+    uint32_t n = 0u, next = 0xFFFFu;
+#pragma unroll 1
+    for (uint32_t i = start >> 9; i < (uint32_t)(BM_SUB / 512) && next == 0xFFFFu; i++) {
+      const u32x4 e = lds_ld128(tile + (i * 64u + (uint32_t)lane) * 16u);
+      u64 m = __ballot(s16_max8(e) >= qcut);
+      while (m && next == 0xFFFFu) {
+        const uint32_t l = (uint32_t)__ffsll((long long)m) - 1u;
+        m &= m - 1;
+        const uint32_t dw[4] = {(uint32_t)__builtin_amdgcn_readlane((int)e.x, (int)l), (uint32_t)__builtin_amdgcn_readlane((int)e.y, (int)l),
+                                (uint32_t)__builtin_amdgcn_readlane((int)e.z, (int)l), (uint32_t)__builtin_amdgcn_readlane((int)e.w, (int)l)};
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+          const uint32_t bound = (dw[j >> 1] >> ((j & 1u) * 16u)) & 0xFFFFu;
+          const uint32_t din = (i * 64u + l) * 8u + j;
+          if (bound >= qcut && din >= start && next == 0xFFFFu) {
+            if (n == S16_LIST_MAX) next = din;
+            else { lds_st16(wb + S16_LIST + n * 2u, din); n++; }
+          }
+        }
+      }
+    }
+    start = next;
+    s16_clear_tile(wb, lane);
+    uint32_t din = 0u;
+    if ((uint32_t)lane < n) {
+      din = lds_ld16(wb + S16_LIST + (uint32_t)lane * 2u);
+      lds_st16(accb + ((din + 1u) << 1), (uint32_t)lane + 1u);
+      lds_stf(accf + (uint32_t)lane * 4u, 0.f);
+    }
+    auto exact = [&](const u32x4 v, float idf_t) {
+      const uint32_t pv[4] = {v.x, v.y, v.z, v.w};
+      uint32_t mk[4];
+#pragma unroll
+      for (int x = 0; x < 4; x++) mk[x] = lds_ld16(s16_addr(pv[x], accb));
+#pragma unroll
+      for (int x = 0; x < 4; x++)
+        if (mk[x]) {
+          const uint32_t ad = accf + (mk[x] - 1u) * 4u;
+          lds_stf(ad, __builtin_fmaf(idf_t, bm_weight(pv[x]), lds_ldf(ad)));
+        }
+    };
+    if (n) {
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        const uint32_t n16 = it.b1[t] - it.b0[t];
+#pragma unroll
+        for (int c = 0; c < CPT; c++)
+          if ((uint32_t)c * 64u < n16) exact(cur.v[t * CPT + c], it.idf[t]);
+        if (n16 > (uint32_t)CPT * 64u) {  // the part of an oversized segment that was streamed, not kept
+          __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)it.tptr[t], 0, (int)(it.b1[t] << 4), BM_RSRC_FLAGS);
+          for (uint32_t u = it.b0[t] + CPT * 64u; u < it.b1[t]; u += 64u)
+            exact(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0), it.idf[t]);
+        }
+      }
+      u64 key = 0ull;
+      if ((uint32_t)lane < n) {
+        const float sc = lds_ldf(accf + (uint32_t)lane * 4u);
+        const uint32_t doc = doc_base + din;
+        const bool gone = del && (doc >> 5) < del_words && ((del[doc >> 5] >> (doc & 31u)) & 1u);  // add_result.rs:3435, union.rs:975
+        lds_st16(accb + ((din + 1u) << 1), 0u);  // the marker: the tile is all zero again
+        if (!gone && sc > 0.f && sc >= thr) key = ((u64)__float_as_uint(sc) << 32) | (u64)(0xFFFFFFFFu - doc);
+      }
+      key = key > T.worst ? key : 0ull;
+      if (__ballot(key != 0ull)) {
+        T.worst = topk_offer<KPL>(T.keys, key, 0ull, 0ull, 0ull, T.worst, k);
+        if (T.worst) {
+          T.wsc = __uint_as_float((uint32_t)(T.worst >> 32));
+          thr = fmaxf(thr, T.wsc);
+        }
+      }
+    }
+    if (start == 0xFFFFu) break;
+    // more candidates than the list holds (ties, or a list that is still filling): rebuild the bounds and go on
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      const uint32_t n16 = it.b1[t] - it.b0[t];
+      uint32_t dummy = 0u;
+#pragma unroll
+      for (int c = 0; c < CPT; c++)
+        if ((uint32_t)c * 64u < n16) dummy = s16_keep(cur.v[t * CPT + c], it.fidf[t], accb, dummy);
+      if (n16 > (uint32_t)CPT * 64u) {
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)it.tptr[t], 0, (int)(it.b1[t] << 4), BM_RSRC_FLAGS);
+        for (uint32_t u = it.b0[t] + CPT * 64u; u < it.b1[t]; u += 64u)
+          dummy = s16_keep(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0), it.fidf[t], accb, dummy);
+      }
+    }
+  }
+  s16_clear(wb, lane);
+  if (tau_q && T.wsc > wsc_in && lane == 0) bm_publish_tau(tau_q, T.wsc);
+  return T;
+}
+
+template <int NT> struct S16Cfg { static constexpr int CPT = NT <= 2 ? 3 : 2; static constexpr int RC = NT * CPT; };
+
+template <int NT, int KPL>
+__global__ void __launch_bounds__(S16_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base, const uint32_t* __restrict__ sub_off,
+                   const bm_vquery* __restrict__ qs, unsigned long long* __restrict__ part_keys, uint32_t* tau,
+                   const uint32_t* __restrict__ del, uint32_t del_words, uint32_t n_sub, uint32_t n_terms, uint32_t nq, uint32_t P, uint32_t k) {
+  constexpr int CPT = S16Cfg<NT>::CPT;
+  constexpr int RC = S16Cfg<NT>::RC;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();  // offsets below are absolute
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t wb = (uint32_t)w * S16_WAVE_LDS, accb = wb + 14u;  // entry of doc field f at accb + 2 f; field 0 = dump
+  s16_clear(wb, lane);  // every wave initialises and uses only its own slice: no barrier
+  const uint32_t row_len = n_sub + 1;
+  const int lane16 = lane * 16;
+
+  const uint32_t a = blockIdx.x * S16_WAVES + w;
+  if (a >= nq * P) return;
+  const uint32_t qi = a % nq, part = a / nq;
+  const bm_vquery* __restrict__ Q = qs + qi;
+  const uint32_t nt = Q->n_terms;  // no NOT terms in this kernel's batches (dispatch)
+  constexpr uint32_t BLK = 62;     // items per boundary block, as bm25_scan_fast_kernel
+  const uint32_t* tptr[NT];
+  float idf[NT];
+  const uint32_t* rowp[NT];
+  float fidf[NT];
+  float idf_sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    const bool have = (uint32_t)t < nt;
+    const uint32_t term = have ? Q->term[t] : n_terms;
+    idf[t] = have ? Q->idf[t] : 0.f;
+    idf_sum += idf[t];
+    tptr[t] = post + term_base[term] * 4ull;
+    rowp[t] = sub_off + (size_t)term * row_len;
+  }
+  const float scale = S16_QMAX / (S16_WMAX * idf_sum);
+#pragma unroll
+  for (int t = 0; t < NT; t++) fidf[t] = s16_uniform(idf[t] * scale);
+  // wave-uniform constants of the item loop, pinned to scalar registers (left to the allocator, scale_thr went to scratch and
+  // its reload brought a vmcnt(0) -- a wait for the whole prefetch -- into every item)
+  const float scale_thr = s16_uniform(scale * (1.0f - 1e-5f));
+  const uint32_t s_begin = (uint32_t)(((u64)n_sub * part) / P);
+  const uint32_t s_end = (uint32_t)(((u64)n_sub * (part + 1)) / P);
+
+  BmTop<KPL> T;
+#pragma unroll
+  for (int r = 0; r < KPL; r++) T.keys[r] = 0ull;
+  T.worst = 0ull;
+  T.wsc = -1.0f;
+  T.matched = 0;
+
+  auto issue_loads = [&](u32x4(&v)[RC], const uint32_t (&b0)[NT], const uint32_t (&b1)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[t], 0, (int)(b1[t] << 4), BM_RSRC_FLAGS);
+#pragma unroll
+      for (int c = 0; c < CPT; c++)
+        v[t * CPT + c] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + c * 1024, (int)(b0[t] << 4), 0);
+    }
+  };
+
+  u32x4 vA[RC], vB[RC];
+  uint32_t B0[NT], B1[NT], B2[NT];
+  uint32_t vbnd[NT];
+  uint32_t* tau_q = tau + (size_t)qi * BM_TAU_STRIDE;
+
+  // One item: prefetch the next one, accumulate the bounds of this one, decide.  Returns true when some doc may enter the
+  // list -- the caller then LEAVES the streaming loop, runs the candidate path and primes the pipeline again.  The call is
+  // kept out of the loop on purpose: with a call inside, the prefetched registers are live across it, the allocator parks
+  // them in scratch in every item, and the vmcnt bookkeeping merges the two histories into a wait for everything.
+  uint32_t qthr_hit = 0u;
+  float thr_hit = 0.f;
+  uint32_t hb0[NT], hb1[NT];
+  auto body = [&](u32x4(&cur)[RC], u32x4(&nxt)[RC], uint32_t i) -> bool {
+    const uint32_t tau_bits = __hip_atomic_load(tau_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int t = 0; t < NT; t++) B2[t] = __builtin_amdgcn_readlane(vbnd[t], i + 2);
+    issue_loads(nxt, B1, B2);
+    uint32_t maxn = 0;
+#pragma unroll
+    for (int t = 0; t < NT; t++) maxn = max(maxn, B1[t] - B0[t]);
+    bool hit = false;
+    if (maxn) {
+      uint32_t mx = 0u;
+#pragma unroll
+      for (int t = 0; t + 1 < NT; t++) {  // the first term finds an empty tile: written without a read
+        const uint32_t n16 = B1[t] - B0[t];
+#pragma unroll
+        for (int c = 0; c < CPT; c++)
+          if ((uint32_t)c * 64u < n16) {
+            if (t == 0) mx = s16_first(cur[t * CPT + c], fidf[t], accb, mx);
+            else mx = s16_keep(cur[t * CPT + c], fidf[t], accb, mx);
+          }
+        if (n16 > (uint32_t)CPT * 64u) {  // df above ~CPT/16 of the docs: the rest of the segment, loaded synchronously
+          __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[t], 0, (int)(B1[t] << 4), BM_RSRC_FLAGS);
+          for (uint32_t u = B0[t] + CPT * 64u; u < B1[t]; u += 64u)
+            mx = s16_keep(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0), fidf[t], accb, mx);
+        }
+      }
+      // the last term is only READ: its sums stay in registers and reach the tile when the item has candidates -- most
+      // items have none, and the LDS pipe is what this kernel keeps busiest (a third of the scattered writes saved)
+      const uint32_t nlast = B1[NT - 1] - B0[NT - 1];
+      uint32_t nwL[CPT][4];
+#pragma unroll
+      for (int c = 0; c < CPT; c++)
+        if ((uint32_t)c * 64u < nlast) {
+          mx = s16_read(cur[(NT - 1) * CPT + c], fidf[NT - 1], accb, mx, nwL[c]);
+        }
+      if (nlast > (uint32_t)CPT * 64u) {
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[NT - 1], 0, (int)(B1[NT - 1] << 4), BM_RSRC_FLAGS);
+        for (uint32_t u = B0[NT - 1] + CPT * 64u; u < B1[NT - 1]; u += 64u)
+          mx = s16_keep(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0), fidf[NT - 1], accb, mx);
+      }
+      const float thr = fmaxf(T.wsc, __uint_as_float(tau_bits));
+      const uint32_t qthr = thr > 0.f ? (uint32_t)(thr * scale_thr) : 0u;
+      if (__ballot(mx >= qthr)) {
+        hit = true;
+#pragma unroll
+        for (int c = 0; c < CPT; c++)
+          if ((uint32_t)c * 64u < nlast) {
+            const u32x4 v = cur[(NT - 1) * CPT + c];
+            lds_st16(s16_addr(v.x, accb), nwL[c][0]);
+            lds_st16(s16_addr(v.y, accb), nwL[c][1]);
+            lds_st16(s16_addr(v.z, accb), nwL[c][2]);
+            lds_st16(s16_addr(v.w, accb), nwL[c][3]);
+          }
+        qthr_hit = qthr;
+        thr_hit = thr;
+#pragma unroll
+        for (int t = 0; t < NT; t++) { hb0[t] = B0[t]; hb1[t] = B1[t]; }
+      } else {
+        s16_clear(wb, lane);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++) { B0[t] = B1[t]; B1[t] = B2[t]; }
+    return hit;
+  };
+
+  for (uint32_t s0 = s_begin; s0 < s_end; s0 += BLK) {
+    const uint32_t j = s0 + (uint32_t)lane;
+#pragma unroll
+    for (int t = 0; t < NT; t++) vbnd[t] = rowp[t][j < s_end ? j : s_end];
+    const uint32_t cnt = min(BLK, s_end - s0);
+    uint32_t i = 0;
+    while (i < cnt) {
+      // prime: the postings of item i (block start, or the item after a candidate path)
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        B0[t] = __builtin_amdgcn_readlane(vbnd[t], i);
+        B1[t] = __builtin_amdgcn_readlane(vbnd[t], i + 1);
+      }
+      issue_loads(vA, B0, B1);
+      bool hit, in_a;
+      for (;;) {
+        in_a = true;
+        hit = body(vA, vB, i);
+        i++;
+        if (hit || i >= cnt) break;
+        in_a = false;
+        hit = body(vB, vA, i);
+        i++;
+        if (hit || i >= cnt) break;
+      }
+      if (hit) {
+        S16Cur<RC> cc;
+#pragma unroll
+        for (int r = 0; r < RC; r++) cc.v[r] = in_a ? vA[r] : vB[r];
+        S16Item<NT> it;
+#pragma unroll
+        for (int t = 0; t < NT; t++) { it.tptr[t] = tptr[t]; it.idf[t] = idf[t]; it.fidf[t] = fidf[t]; it.b0[t] = hb0[t]; it.b1[t] = hb1[t]; }
+        T = s16_trigger<NT, CPT, KPL>(T, cc, it, wb, qthr_hit, thr_hit, (s0 + i - 1u) << BM_SUB_LOG2, k, tau_q, del, del_words);
+      }
+    }
+  }
+
+  u64* out = part_keys + ((size_t)qi * P + part) * (64 * KPL);
+#pragma unroll
+  for (int r = 0; r < KPL; r++) out[r * 64 + lane] = T.keys[r];
+}
+
+template <int NT, int KPL>
+int launch16(const BmParams& p, hipStream_t st) {
+  constexpr int lds = S16_WAVES * S16_WAVE_LDS;
+  SS_SET_MAX_LDS((bm25_scan16_kernel<NT, KPL>), lds);
+  const uint32_t A = p.nq * p.P;
+  bm25_scan16_kernel<NT, KPL><<<(A + S16_WAVES - 1) / S16_WAVES, S16_WAVES * 64, lds, st>>>(
+      p.post, p.term_base, p.sub_off, p.q, p.part_keys, p.tau, p.del, p.del_words, p.n_sub, p.n_terms, p.nq, p.P, p.k);
+  return SS_OK;
+}
+
+}  // namespace
+
+// unions of <= 4 lists without NOT terms, top-k only (no exact counts), k <= 64 (at k = 100 the f32 scan is 5 % ahead)
+bool ssi_bm25_scan16_serves(uint32_t nt_max, uint32_t np_max, bool has_and, bool count, int KPL, uint32_t k) {
+  static const int off = [] { const char* e = getenv("SS_BM25_SCAN16"); return e ? atoi(e) == 0 : 0; }();
+  return !off && !has_and && !count && k != 0 && nt_max == np_max && nt_max >= 1 && nt_max <= 4 && KPL == 1;
+}
+
+int ssi_bm25_launch_scan16(const BmParams& p, uint32_t nt_max, int KPL, hipStream_t st) {
+  const int NT = nt_max <= 2 ? 2 : (int)nt_max;
+#define SS_F(NT_, KPL_) \
+  if (NT == NT_ && KPL == KPL_) return launch16<NT_, KPL_>(p, st);
+  SS_F(2, 1) SS_F(3, 1) SS_F(4, 1)
+#undef SS_F
+  return SS_ENOTSUP;
+}

@@ -387,6 +387,7 @@ static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q,
   *has_or = false;
   *nt_max = 0;
   *np_max = 0;
+  bool any_not = false;
   for (uint32_t i = 0; i < nq; i++) {
     const uint32_t op = bm_q_op(q[i].op), n_not = bm_q_nnot(q[i].op), all = q[i].n_terms + n_not;
     if (q[i].n_terms == 0 || all > SS_MAX_QUERY_TERMS) return SS_EINVAL;
@@ -435,7 +436,11 @@ static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q,
     else if (q[i].n_terms > 1) *has_or = true;  // a single-term query is both: its exact count is its posting count
     *nt_max = std::max(*nt_max, all);
     *np_max = std::max(*np_max, q[i].n_terms);
+    any_not |= n_not != 0;
   }
+  // "the batch holds NOT terms" travels as nt_max > np_max (the kernels' filtered variants are chosen by it): keep that true
+  // when the query with the NOT terms is not the one with the most terms
+  if (any_not && *nt_max == *np_max) *nt_max = *np_max + 1;
   if (n_phrase && n_phrase != nq) return SS_ENOTSUP;  // a batch holds phrase queries only
   if (phrase) *phrase = n_phrase != 0;
   return SS_OK;

@@ -679,6 +679,25 @@ def test_not_terms_both_strategies(S, O, lex):
         osh.set_deleted([])
 
 
+def test_not_terms_in_a_query_that_is_not_the_longest(S, O, lex):
+    """the batch's longest query has no NOT terms, a shorter one has: n_terms + NOT terms of both are equal, so "the batch
+    holds NOT terms" must not be derived from those maxima alone (the unfiltered kernel variants ignore NOT lists)"""
+    sh, osh, n_docs = lex
+    mixed = [([10, 9, 8], []), ([10, 9], [8]), ([7, 6, 5], []), ([10], [9, 8])]
+    try:
+        for qt, oop in ((S.QueryType.Union, O.OP_OR), (S.QueryType.Intersection, O.OP_AND)):
+            for strat in (0, 1, 2):
+                sh.set_strategy(strat)
+                q = sh.make_queries([c[0] for c in mixed], qt, [c[1] for c in mixed])
+                doc, score, cnt, tot = sh.search_lexical_batch(q, 10)
+                for i, (pos, neg) in enumerate(mixed):
+                    od, os_, otot = osh.search_exhaustive(pos, oop, 10, not_terms=neg)
+                    assert int(tot[i]) == otot, (pos, neg, qt, strat)
+                    _check_topk(doc[i], score[i], cnt[i], od, os_)
+    finally:
+        sh.set_strategy(0)
+
+
 def test_not_terms_abi_validation(S, O, lex):
     sh, osh, n_docs = lex
     q = sh.make_queries([[10, 9]], S.QueryType.Union, [[8]])
