@@ -332,7 +332,7 @@ def main():
                                     "without reading most of SURVEY 8d's algorithmic bytes, so effective_GBs_on_algorithmic_bytes may exceed "
                                     "the peak); exhaustive.roofline is the SURVEY 8d figure"},
                   exhaustive={"value": ex_qps, "unit": "queries/s", "ms_per_call": ex_ms, "calls": ex_n,
-                              "roofline": {"bound": "hbm", "kernel": "bm25_scan_fast_kernel<3,false,1>", "achieved": ex_ach,
+                              "roofline": {"bound": "hbm", "kernel": "bm25_scan16_kernel<3,1> (16-bit bound accumulators + exact re-scoring of the candidates)", "achieved": ex_ach,
                                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ex_ach / HBM_PEAK_GBS,
                                            "traffic": pmc_traffic("bm25"), "algorithmic_bytes_per_launch": bytes_launch,
                                            "avg_launch_ms": ex_kms, "launches": int(ex_launches)}},

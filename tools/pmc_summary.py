@@ -51,7 +51,7 @@ def main():
                       "one run per counter group (tools/collect_pmc.sh).  SQ_* wave counters are in quad-cycles "
                       "(MI355X_MICROARCH.md); GRBM_GUI_ACTIVE is summed over the 8 XCDs.", ""]
     LAUNCHES_PER_PASS = 4  # chunk schedule of the vector scans: 16 tiles, then 16 x the prefix (10 M rows)
-    for kern, pat in (("bm25", "bm25_scan_fast_kernel"), ("bm25_pruned", "bm25_probe_kernel"), ("bm25_union_count", "bm25_union_count_kernel"),
+    for kern, pat in (("bm25", "bm25_scan16_kernel"), ("bm25_f32_scan", "bm25_scan_fast_kernel"), ("bm25_pruned", "bm25_probe_kernel"), ("bm25_union_count", "bm25_union_count_kernel"),
                       ("vector", "vec_scan_kernel<true, false>"), ("vector_small_batch", "vec_scan_kernel<false, false>"),
                       ("vector_i8", "vec8_scan_kernel<false, true, false>")):
         groups = {g: load(db(g), pat) for g in ("fetch", "write", "sqA", "sqB", "sqC") if os.path.exists(db(g))}
