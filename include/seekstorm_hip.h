@@ -120,6 +120,10 @@ typedef struct {
   uint64_t byte_array_len;
 } ss_ref_block;
 int ss_ref_decode_block(const ss_ref_block* block, uint16_t* docs_out /*[65536]*/, uint16_t* tfs_out /*[65536]*/);
+/* the same with the positions of every posting (sum(tf) absolute positions in posting order; SingleTerm keys): returns the
+ * posting count, *n_pos_out = positions written (SS_EINVAL with the needed number when pos_cap is too small) */
+int ss_ref_decode_block_positions(const ss_ref_block* block, uint16_t* docs_out, uint16_t* tfs_out, uint16_t* pos_out,
+                                  uint64_t pos_cap, uint64_t* n_pos_out);
 /* a block of an N-GRAM key (key_hash & 7 = NgramType != 0, index.rs:1854-1872; one indexed field): never embedded, every
  * record starts with the tf of each component term (2: bigram types 1-3, 3: trigram types 4-7) before the positions count
  * (add_result.rs:2074-2089).  tfs_out = tf of component `component` -- what the n-gram arms of
@@ -159,6 +163,11 @@ int ss_index_bin_term_ngram(const ss_index_bin* ix, uint8_t* n_components_out, u
 int ss_index_bin_term_postings(const ss_index_bin* ix, uint32_t term, uint64_t cap, uint32_t* docs_out, uint16_t* tfs_out,
                                uint64_t* n_out);
 int ss_bm25_upload_index_bin(ss_shard* s, const ss_index_bin* ix);
+/* The same plus the positions of every posting, decoded from the rank/position pointers (embedded forms) and the VINT records
+ * (decode_positions_multiterm_singlefield, add_result.rs:2036-2197; stored as first position, then gap - 1): phrase queries
+ * (SS_OP_PHRASE) then work on an image built from the file.  One indexed field, SingleTerm keys only; SS_ENOTSUP for an
+ * index with n-gram keys, several fields, or a position beyond 65 535. */
+int ss_bm25_upload_index_bin_positions(ss_shard* s, const ss_index_bin* ix);
 /* the same for an index with several indexed fields: position records carry a field vector per posting
  * (decode_positions_multiterm_multifield, add_result.rs:1485-2034; read_multifield_vec 2200-2293) -> ss_bm25_upload_fields.
  * boost = schema boost per field (schema.json; NULL = 1).  ss_bm25_upload_index_bin calls it with NULL. */

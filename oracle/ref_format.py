@@ -147,15 +147,16 @@ def random_positions(rng, tf, max_gap=40):
     return [int(x) for x in pos]
 
 
-def encode_term(docs, tfs, rng, base_bytes=b"", positions_limit=32768, max_gap=40, ngram_tfs=None):
+def encode_term(docs, tfs, rng, base_bytes=b"", positions_limit=32768, max_gap=40, ngram_tfs=None, positions=None):
     """Whole posting list -> list of (block_id, compression_type_pointer, posting_count, pivot, byte_array); every block's
-    byte array begins with `base_bytes` (standing for other keys' bodies in the same segment)."""
+    byte array begins with `base_bytes` (standing for other keys' bodies in the same segment).
+    positions: the ascending positions of every posting (len tf each); None = drawn from rng"""
     docs = np.asarray(docs, np.int64)
     out = []
     bid = docs >> 16
     for b in np.unique(bid):
         sel = np.nonzero(bid == b)[0]
-        pos = [random_positions(rng, int(tfs[i]), max_gap) for i in sel]
+        pos = [random_positions(rng, int(tfs[i]), max_gap) if positions is None else [int(x) for x in positions[i]] for i in sel]
         body, ctp, cnt, pivot = encode_key_body(docs[sel] & 0xFFFF, pos, len(base_bytes), positions_limit,
                                                 None if ngram_tfs is None else [ngram_tfs[i] for i in sel])
         out.append((int(b), ctp, cnt, pivot, base_bytes + body))
@@ -215,7 +216,8 @@ def write_index_bin(n_docs, doclen_bytes, terms, rng, segment_number_bits=11, ke
     for term in terms:
         assert term[0] & 7 == 0  # (n-gram keys: ngram_terms)
         if n_fields == 1:
-            blocks = encode_term(term[1], term[2], rng, positions_limit=positions_limit)
+            blocks = encode_term(term[1], term[2], rng, positions_limit=positions_limit,
+                                 positions=term[3] if len(term) > 3 else None)  # (key_hash, docs, tfs[, positions per posting])
         else:
             blocks = encode_term_fields(term[1], term[2], term[3], n_fields, longest_field_id, rng, positions_limit)
         per_term_blocks.append({b[0]: b for b in blocks})

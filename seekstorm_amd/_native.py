@@ -80,6 +80,8 @@ SYMBOLS = [
     ("ss_ref_decode_block_ngram", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, u16p, u16p]),
     ("ss_index_bin_term_postings", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, u32p, u16p, u64p]),
     ("ss_bm25_upload_index_bin", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("ss_bm25_upload_index_bin_positions", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("ss_ref_decode_block_positions", C.c_int, [C.c_void_p, u16p, u16p, u16p, C.c_uint64, u64p]),
     ("ss_bm25_upload_index_bin_fields", C.c_int, [C.c_void_p, C.c_void_p, f32p]),
     ("ss_ref_decode_block_fields", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, u16p, u32p, u8p, u16p]),
     ("ss_synth_set_partition", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),

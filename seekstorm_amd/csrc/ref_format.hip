@@ -41,11 +41,29 @@ inline bool read_vint(const uint8_t* a, uint64_t len, uint64_t pos, uint32_t* ou
 }  // namespace
 
 namespace {
-int decode_block(const ss_ref_block* b, uint32_t n_components, uint32_t component, uint16_t* docs_out, uint16_t* tfs_out);
+// pos_out (optional): the positions of every posting appended in posting order, ABSOLUTE (the file stores the first position
+// and then gap - 1: get_next_position_singlefield + 1, add_result.rs:3596-3684); a position beyond 65 535 -> SS_ENOTSUP
+int decode_block(const ss_ref_block* b, uint32_t n_components, uint32_t component, uint16_t* docs_out, uint16_t* tfs_out,
+                 std::vector<uint16_t>* pos_out = nullptr);
 }
 // Decodes one block.  docs_out / tfs_out need room for 65 536 entries.  Returns the posting count or a negative code.
 extern "C" int ss_ref_decode_block(const ss_ref_block* b, uint16_t* docs_out, uint16_t* tfs_out) {
   return decode_block(b, 1, 0, docs_out, tfs_out);
+}
+// The same with the positions of every posting (SingleTerm keys, one indexed field): what a phrase query walks
+// (decode_positions_multiterm_singlefield's embedded_positions / positions_pointer, add_result.rs:2036-2197, consumed by
+// get_next_position_singlefield).  pos_out receives sum(tf) absolute positions in posting order; *n_pos_out = that sum
+// (SS_EINVAL with the needed size when pos_cap is too small).
+extern "C" int ss_ref_decode_block_positions(const ss_ref_block* b, uint16_t* docs_out, uint16_t* tfs_out, uint16_t* pos_out,
+                                             uint64_t pos_cap, uint64_t* n_pos_out) {
+  if (!n_pos_out) return SS_EINVAL;
+  std::vector<uint16_t> pos;
+  const int n = decode_block(b, 1, 0, docs_out, tfs_out, &pos);
+  if (n < 0) return n;
+  *n_pos_out = pos.size();
+  if (pos.size() > pos_cap) return SS_EINVAL;
+  if (pos_out && !pos.empty()) std::memcpy(pos_out, pos.data(), pos.size() * sizeof(uint16_t));
+  return n;
 }
 // The same for a block of an N-GRAM key (NgramType != SingleTerm, index.rs:1854-1872; one indexed field): its postings are
 // never embedded (index_posting.rs:445) and every record starts with the tf of each component term -- 2 for the bigram
@@ -58,8 +76,10 @@ extern "C" int ss_ref_decode_block_ngram(const ss_ref_block* b, uint32_t n_compo
   return decode_block(b, n_components, component, docs_out, tfs_out);
 }
 namespace {
-int decode_block(const ss_ref_block* b, uint32_t n_components, uint32_t component, uint16_t* docs_out, uint16_t* tfs_out) {
+int decode_block(const ss_ref_block* b, uint32_t n_components, uint32_t component, uint16_t* docs_out, uint16_t* tfs_out,
+                 std::vector<uint16_t>* pos_out) {
   if (!b || !b->byte_array || !docs_out || !tfs_out) return SS_EINVAL;
+  if (pos_out && n_components > 1) return SS_ENOTSUP;  // an n-gram key's positions are the n-gram's, not its components'
   const bool ngram = n_components > 1;
   const uint8_t* a = b->byte_array;
   const uint64_t len = b->byte_array_len;
@@ -119,6 +139,31 @@ int decode_block(const ss_ref_block* b, uint32_t n_components, uint32_t componen
     }
     return false;
   };
+  // the positions of a record behind a non-embedded pointer: `tf` VINTs after the count, each "gap - 1" after the first
+  auto record_positions = [&](uint64_t back, uint32_t tf) -> int {
+    uint64_t pos = range - back;
+    uint32_t v, at = 0;
+    if (!read_vint(a, len, pos, &v)) return SS_EINVAL;  // the count again
+    pos += a[pos] & 0x80u ? 1u : (a[pos + 1] & 0x80u ? 2u : 3u);
+    for (uint32_t i = 0; i < tf; i++) {
+      if (!read_vint(a, len, pos, &v)) return SS_EINVAL;
+      pos += a[pos] & 0x80u ? 1u : (a[pos + 1] & 0x80u ? 2u : 3u);
+      at = i == 0 ? v : at + v + 1u;
+      if (at > 65535u) return SS_ENOTSUP;
+      pos_out->push_back((uint16_t)at);
+    }
+    return SS_OK;
+  };
+  // the positions inside an embedded pointer: widths as decode_positions_multiterm_singlefield unpacks them
+  auto embedded_positions = [&](const uint32_t* d, uint32_t tf) -> int {
+    uint32_t at = 0;
+    for (uint32_t i = 0; i < tf; i++) {
+      at = i == 0 ? d[0] : at + d[i] + 1u;
+      if (at > 65535u) return SS_ENOTSUP;
+      pos_out->push_back((uint16_t)at);
+    }
+    return SS_OK;
+  };
   for (uint32_t r = 0; r < count; r++) {
     uint32_t tf = 0;
     if (r < pivot) {
@@ -129,8 +174,16 @@ int decode_block(const ss_ref_block* b, uint32_t n_components, uint32_t componen
         if (ngram) return SS_EINVAL;
         const uint32_t tag = p >> 14;
         tf = tag == 2u ? 1u : tag == 3u ? 2u : 0u;
+        if (pos_out && tf) {
+          const uint32_t d1[2] = {p & 0x3FFFu, 0u}, d2[2] = {(p >> 7) & 0x7Fu, p & 0x7Fu};
+          const int rc = embedded_positions(tf == 1u ? d1 : d2, tf);
+          if (rc) return rc;
+        }
       } else if (!record_tf(p & 0x7FFFu, &tf)) {
         return SS_EINVAL;
+      } else if (pos_out) {
+        const int rc = record_positions(p & 0x7FFFu, tf);
+        if (rc) return rc;
       }
     } else {
       const uint64_t at = range + (uint64_t)r * 3u - pivot;
@@ -140,8 +193,18 @@ int decode_block(const ss_ref_block* b, uint32_t n_components, uint32_t componen
         if (ngram) return SS_EINVAL;
         const uint32_t tag = p >> 21;
         tf = tag >= 4u ? tag - 3u : 0u;
+        if (pos_out && tf) {
+          const uint32_t d1[4] = {p & 0x1FFFFFu, 0u, 0u, 0u}, d2[4] = {(p >> 11) & 0x3FFu, p & 0x7FFu, 0u, 0u};
+          const uint32_t d3[4] = {(p >> 14) & 0x7Fu, (p >> 7) & 0x7Fu, p & 0x7Fu, 0u};
+          const uint32_t d4[4] = {(p >> 16) & 0x1Fu, (p >> 11) & 0x1Fu, (p >> 6) & 0x1Fu, p & 0x3Fu};
+          const int rc = embedded_positions(tf == 1u ? d1 : tf == 2u ? d2 : tf == 3u ? d3 : d4, tf);
+          if (rc) return rc;
+        }
       } else if (!record_tf(p & 0x7FFFFFu, &tf)) {
         return SS_EINVAL;
+      } else if (pos_out) {
+        const int rc = record_positions(p & 0x7FFFFFu, tf);
+        if (rc) return rc;
       }
     }
     if (tf == 0u || tf > 65535u) return SS_EINVAL;  // positions_count >= 1 always; component tfs likewise
@@ -526,11 +589,11 @@ extern "C" int ss_index_bin_term_keys(const ss_index_bin* ix, uint64_t* keys_out
 namespace {
 // decoded postings of one term appended to docs / tfs
 int index_bin_term(const ss_index_bin* ix, uint32_t term, std::vector<uint32_t>& docs, std::vector<uint16_t>& tfs,
-                   uint16_t* d16, uint16_t* t16) {
+                   uint16_t* d16, uint16_t* t16, std::vector<uint16_t>* pos = nullptr) {
   if (ix->n_fields != 1) return SS_ENOTSUP;  // BM25F field vectors: SURVEY section 8 f-2
   for (uint64_t bi = ix->term_block_off[term]; bi < ix->term_block_off[term + 1]; bi++) {
     const ss_ref_block& b = ix->blocks[bi].b;
-    const int n = decode_block(&b, ix->blocks[bi].n_comp, ix->blocks[bi].comp, d16, t16);
+    const int n = decode_block(&b, ix->blocks[bi].n_comp, ix->blocks[bi].comp, d16, t16, pos);
     if (n < 0) return n;
     for (int i = 0; i < n; i++) {
       const uint64_t doc = ((uint64_t)b.block_id << 16) | d16[i];
@@ -607,22 +670,40 @@ extern "C" int ss_bm25_upload_index_bin_fields(ss_shard* s, const ss_index_bin* 
   return upload_index_bin_fields(s, ix, boost);
 }
 
+namespace {
+int upload_index_bin_single(ss_shard* s, const ss_index_bin* ix, bool with_positions);
+}
 extern "C" int ss_bm25_upload_index_bin(ss_shard* s, const ss_index_bin* ix) {
   if (!s || !ix) return SS_EINVAL;
   if (ix->keys.empty() || ix->n_docs == 0) return SS_EINVAL;
   if (ix->n_fields > 1) return ss_bm25_upload_index_bin_fields(s, ix, nullptr);
+  return upload_index_bin_single(s, ix, false);
+}
+// The image plus the positions of every posting, for phrase queries: one indexed field, SingleTerm keys only (SS_ENOTSUP for
+// an index with n-gram keys or a position beyond 65 535)
+extern "C" int ss_bm25_upload_index_bin_positions(ss_shard* s, const ss_index_bin* ix) {
+  if (!s || !ix) return SS_EINVAL;
+  if (ix->keys.empty() || ix->n_docs == 0) return SS_EINVAL;
+  if (ix->n_fields > 1) return SS_ENOTSUP;
+  return upload_index_bin_single(s, ix, true);
+}
+namespace {
+int upload_index_bin_single(ss_shard* s, const ss_index_bin* ix, bool with_positions) {
   std::vector<uint64_t> offs(ix->keys.size() + 1, 0);
   std::vector<uint32_t> docs;
-  std::vector<uint16_t> tfs, d16(65536), t16(65536);
+  std::vector<uint16_t> tfs, d16(65536), t16(65536), pos;
   for (uint32_t t = 0; t < ix->keys.size(); t++) {
     offs[t] = docs.size();
-    const int rc = index_bin_term(ix, t, docs, tfs, d16.data(), t16.data());
+    const int rc = index_bin_term(ix, t, docs, tfs, d16.data(), t16.data(), with_positions ? &pos : nullptr);
     if (rc) return rc;
   }
   offs[ix->keys.size()] = docs.size();
   std::vector<uint8_t> doclen(ix->doclen.size() * 65536u);
   for (size_t l = 0; l < ix->doclen.size(); l++) std::memcpy(doclen.data() + l * 65536u, ix->doclen[l], 65536u);  // field 0
   // avgdl = positions_sum_normalized / indexed_doc_count as the reference's reader computes it (index.rs:3480-3482)
-  return ssi_bm25_upload(s, ix->n_docs, doclen.data(), (uint32_t)ix->keys.size(), offs.data(), docs.data(), tfs.data(),
-                         ix->positions_sum);
+  int rc = ssi_bm25_upload(s, ix->n_docs, doclen.data(), (uint32_t)ix->keys.size(), offs.data(), docs.data(), tfs.data(),
+                           ix->positions_sum);
+  if (rc || !with_positions) return rc;
+  return ssi_bm25_attach_positions(s, offs.data(), docs.data(), tfs.data(), pos.data(), pos.size());
 }
+}  // namespace

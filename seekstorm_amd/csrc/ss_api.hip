@@ -156,14 +156,20 @@ int ss_bm25_upload_positions(ss_shard* s, uint64_t n_docs, const uint8_t* doclen
   if (n_positions && !positions) return SS_EINVAL;
   int rc = ssi_bm25_upload(s, n_docs, doclen, n_terms, offs, docs, tfs, 0);
   if (rc) return rc;
-  std::lock_guard<std::mutex> g(s->mu);
-  SS_HIP(hipSetDevice(s->device));
-  rc = ssi_bm25_upload_positions(s, offs, docs, tfs, positions, n_positions);
-  if (rc) free_bm25(s);
-  return rc;
+  return ssi_bm25_attach_positions(s, offs, docs, tfs, positions, n_positions);
 }
 
 }  // extern "C"
+
+// positions of the image just built (CSR order); a failure leaves no image behind
+int ssi_bm25_attach_positions(ss_shard* s, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs, const uint16_t* positions,
+                              uint64_t n_positions) {
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  const int rc = ssi_bm25_upload_positions(s, offs, docs, tfs, positions, n_positions);
+  if (rc) free_bm25(s);
+  return rc;
+}
 
 int ssi_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen, uint32_t n_terms, const uint64_t* offs,
                     const uint32_t* docs, const uint16_t* tfs, uint64_t positions_sum) {

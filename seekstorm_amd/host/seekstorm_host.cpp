@@ -84,7 +84,8 @@ int Shard::upload_vectors(uint64_t n_rows, uint32_t dim, const float* rows, cons
   return rc;
 }
 
-int Shard::open_index_bin(const uint8_t* bytes, uint64_t len, uint32_t key_head_size, std::vector<uint64_t>* term_keys) {
+int Shard::open_index_bin(const uint8_t* bytes, uint64_t len, uint32_t key_head_size, std::vector<uint64_t>* term_keys,
+                          bool with_positions) {
   if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
   lexical_fields_ = 1;
   ss_index_bin* ix = nullptr;
@@ -102,7 +103,7 @@ int Shard::open_index_bin(const uint8_t* bytes, uint64_t len, uint32_t key_head_
   ngram_components_.assign(n_terms, 1);
   ngram_component_df_.assign(n_terms, 0);
   if (n_terms) ss_index_bin_term_ngram(ix, ngram_components_.data(), nullptr, ngram_component_df_.data());
-  rc = ss_bm25_upload_index_bin(h_, ix);
+  rc = with_positions ? ss_bm25_upload_index_bin_positions(h_, ix) : ss_bm25_upload_index_bin(h_, ix);
   ss_index_bin_close(ix);
   n_docs_ = rc == SS_OK ? n_docs : 0;
   if (rc != SS_OK) { ngram_components_.clear(); ngram_component_df_.clear(); }

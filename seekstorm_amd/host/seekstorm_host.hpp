@@ -100,7 +100,10 @@ class Shard {
   // shard files as the reference writes them: index.bin (single indexed field), vector.bin (f32), delete.bin.
   // term_keys: key_hash of every term id, ascending; an n-gram key (key_hash & 7 != 0) holds one id per component term,
   // consecutive -- a query term that resolved to it is passed as those ids (make_query applies idf_ngram_i)
-  int open_index_bin(const uint8_t* bytes, uint64_t len, uint32_t key_head_size, std::vector<uint64_t>* term_keys);
+  // with_positions: the positions of every posting are decoded as well (QueryType::Phrase on an opened index; one indexed
+  // field, SingleTerm keys only -- SS_ENOTSUP otherwise)
+  int open_index_bin(const uint8_t* bytes, uint64_t len, uint32_t key_head_size, std::vector<uint64_t>* term_keys,
+                     bool with_positions = false);
   int open_vector_bin(const uint8_t* bytes, uint64_t len, uint32_t dim, bool i8 = false, bool use_record_scale = false);
   // Precision::I8 records; queries given as f32 are quantised with quantize_f32_to_i8 like the reference's
   int upload_vectors_i8(uint64_t n_rows, uint32_t dim, const int8_t* rows, const float* row_scale, const uint32_t* row_doc_ids);

@@ -287,10 +287,14 @@ class Shard:
         self.lexical_field_count = 1
         self._df_cache.clear()
 
-    def upload_index_bin(self, ix: "IndexBin", boost=None):
-        """boost: schema boost per indexed field (several fields only; schema.json)"""
+    def upload_index_bin(self, ix: "IndexBin", boost=None, positions=False):
+        """boost: schema boost per indexed field (several fields only; schema.json)
+        positions: also decode every posting's positions from the file (phrase queries; one field, SingleTerm keys)"""
         b = None if boost is None else np.ascontiguousarray(boost, np.float32)
-        N.check(N.lib().ss_bm25_upload_index_bin_fields(self._h, ix._h, N.ptr(b, N.f32p)), "ss_bm25_upload_index_bin")
+        if positions:
+            N.check(N.lib().ss_bm25_upload_index_bin_positions(self._h, ix._h), "ss_bm25_upload_index_bin_positions")
+        else:
+            N.check(N.lib().ss_bm25_upload_index_bin_fields(self._h, ix._h, N.ptr(b, N.f32p)), "ss_bm25_upload_index_bin")
         self.indexed_doc_count = int(ix.indexed_doc_count)
         self.lexical_field_count = int(ix.indexed_field_count)
         self._df_cache.clear()

@@ -64,7 +64,10 @@ H1 = dict(
     name="H1 array, 2-byte pointers, embedded and recorded postings",
     block_id=5, compression_type_pointer=(1 << 30) | H1_R, posting_count=4, pointer_pivot_p_docid=4,
     body=bytes(H1_PREFIX + H1_RECORD_P3 + H1_RECORD_P2 + H1_POINTERS + H1_DOCIDS),
-    docs=[3, 17, 300, 65535], tfs=[1, 2, 3, 130])
+    docs=[3, 17, 300, 65535], tfs=[1, 2, 3, 130],
+    # absolute positions: the stored values are the first position, then gap - 1 (index_posting.rs:55-64; the reader adds
+    # value + 1, get_next_position_singlefield in add_result.rs:3596-3684)
+    positions=[5] + [3, 13] + [10, 11, 200] + list(range(130)))
 
 # ---------------------------------------------------------------------------------------------------------------- H2
 # CompressionType::Array, pivot INSIDE the list: p0 has a 2-byte pointer, p1..p3 3-byte pointers (offset of pointer p >= pivot:
@@ -90,7 +93,8 @@ H2 = dict(
     name="H2 array, pivot inside the list, 3-byte embedded forms",
     block_id=0, compression_type_pointer=(1 << 30) | H2_R, posting_count=4, pointer_pivot_p_docid=1,
     body=bytes(H2_PREFIX + H2_RECORD_P3 + H2_POINTERS + H2_DOCIDS),
-    docs=[0, 9, 10, 40000], tfs=[1, 4, 2, 5])
+    docs=[0, 9, 10, 40000], tfs=[1, 4, 2, 5],
+    positions=[300] + [1, 4, 8, 49] + [1000, 3001] + [0, 1, 2, 3, 4])
 
 # ---------------------------------------------------------------------------------------------------------------- H3
 # CompressionType::Bitmap: 8 192 bytes, bit d & 7 of byte d >> 3 (single.rs:235-262 reads it as 1 024 u64 words and walks them
@@ -109,7 +113,7 @@ H3 = dict(
     name="H3 bitmap",
     block_id=2, compression_type_pointer=(2 << 30) | H3_R, posting_count=5, pointer_pivot_p_docid=5,
     body=bytes(H3_PREFIX + H3_POINTERS) + bytes(_bm),
-    docs=H3_DOCS, tfs=[1, 1, 1, 1, 1])
+    docs=H3_DOCS, tfs=[1, 1, 1, 1, 1], positions=[0, 7, 8, 16383, 129])
 
 # ---------------------------------------------------------------------------------------------------------------- H4
 # CompressionType::Rle (compress_postinglist.rs:832-946): u16 runs_count, then per run u16 start and u16 length, where length
@@ -135,6 +139,6 @@ H4 = dict(
     name="H4 rle",
     block_id=1, compression_type_pointer=(3 << 30) | H4_R, posting_count=10, pointer_pivot_p_docid=10,
     body=bytes(H4_PREFIX + H4_REC_P3 + H4_REC_P2 + H4_REC_P1 + H4_POINTERS + H4_CONTAINER),
-    docs=H4_DOCS, tfs=H4_TFS)
+    docs=H4_DOCS, tfs=H4_TFS, positions=[9] + [200, 202] + [4, 9, 14] + [1, 3, 5, 7] + [1] * 6)
 
 BLOCKS = [H1, H2, H3, H4]

@@ -103,3 +103,46 @@ def test_phrase_queries_match_oracle(S, O):
         sh2.search_lexical_batch(sh2.make_queries([[0, 1]], S.QueryType.Phrase), 10)
     sh2.close()
     sh.close()
+
+
+def test_phrase_queries_on_an_image_built_from_index_bin(S, O):
+    """the positions decoded from the file's rank/position pointers and VINT records (ss_bm25_upload_index_bin_positions):
+    phrase queries on that image answer exactly like the image uploaded from arrays with the same positions, and like the
+    oracle; a key head / pointer mix with embedded (<= 4 positions) and recorded postings"""
+    from oracle import ref_format as RF
+    n_docs = 140_000
+    dfs = [30_000, 12_000, 20_000, 3_000]
+    plant = [([0, 1], 300), ([0, 1, 2], 100), ([3, 0], 50), ([2, 2], 60)]
+    dl, offs, docs, tfs, positions = _corpus(O, n_docs, dfs, 11, plant)
+    terms, at = [], 0
+    for t in range(len(dfs)):
+        a, b = int(offs[t]), int(offs[t + 1])
+        pl = []
+        for i in range(a, b):
+            pl.append(positions[at:at + int(tfs[i])].tolist())
+            at += int(tfs[i])
+        terms.append((1000 * (t + 1) * 8, docs[a:b].astype(np.int64), tfs[a:b].astype(np.int64), pl))  # key_hash & 7 == 0: SingleTerm
+    rng = np.random.default_rng(3)
+    data = RF.write_index_bin(n_docs, dl, terms, rng)
+    ix = S.IndexBin(data)
+    a, b = S.Shard(0), S.Shard(0)
+    a.upload_index_bin(ix, positions=True)
+    b.upload_lexical(n_docs, dl, offs, docs, tfs, positions)
+    osh = O.Shard(n_docs, dl, offs, docs, tfs)
+    osh.set_positions(positions)
+    phrases = [[0, 1], [0, 1, 2], [3, 0], [2, 2], [1, 0], [2, 0, 1]]
+    for k in (10, 100):
+        ra = a.search_lexical_batch(a.make_queries(phrases, S.QueryType.Phrase), k)
+        rb = b.search_lexical_batch(b.make_queries(phrases, S.QueryType.Phrase), k)
+        for x, y in zip(ra, rb):
+            assert np.array_equal(x, y)
+        for i, ph in enumerate(phrases):
+            uniq = list(dict.fromkeys(ph))
+            od, os_, otot = osh.search_phrase(uniq, [uniq.index(w) for w in ph], k)
+            assert int(ra[3][i]) == otot and ra[2][i] == len(od) and np.allclose(ra[1][i][:len(od)], os_, rtol=1e-4)
+    # without the positions the same file still serves set queries, and refuses phrases
+    a.upload_index_bin(ix)
+    with pytest.raises(S.SeekStormHipError):
+        a.search_lexical_batch(a.make_queries([[0, 1]], S.QueryType.Phrase), 10)
+    a.close()
+    b.close()

@@ -20,6 +20,20 @@ def _decode(block):
     return n, d[:max(n, 0)].copy(), t[:max(n, 0)].copy()
 
 
+def _decode_positions(block):
+    bid, ctp, cnt, pivot, body = block
+    buf = np.frombuffer(body, np.uint8).copy()
+    rb = N.RefBlock(bid, ctp, cnt - 1, pivot, buf.ctypes.data, len(buf))
+    d = np.zeros(65536, np.uint16)
+    t = np.zeros(65536, np.uint16)
+    npos = C.c_uint64()
+    n = N.lib().ss_ref_decode_block_positions(C.byref(rb), N.ptr(d, N.u16p), N.ptr(t, N.u16p), None, 0, C.byref(npos))
+    assert n == -1 or npos.value == 0  # SS_EINVAL + the needed size, unless there is nothing to write
+    pos = np.zeros(max(npos.value, 1), np.uint16)
+    n = N.lib().ss_ref_decode_block_positions(C.byref(rb), N.ptr(d, N.u16p), N.ptr(t, N.u16p), N.ptr(pos, N.u16p), len(pos), C.byref(npos))
+    return n, d[:max(n, 0)].copy(), t[:max(n, 0)].copy(), pos[:npos.value].copy()
+
+
 def _case(rng, n, span, tf_hi, dense_runs=False):
     if dense_runs:
         start = int(rng.integers(0, 65536 - n))
@@ -538,6 +552,21 @@ def test_hand_assembled_key_bodies():
         cnt, d, t = _decode(blk)
         assert cnt == len(b["docs"]), (b["name"], cnt)
         assert d.tolist() == b["docs"] and t.tolist() == b["tfs"], (b["name"], d.tolist(), t.tolist())
+        cnt2, d2, t2, pos = _decode_positions(blk)  # the positions a phrase query walks, as absolute values
+        assert cnt2 == cnt and pos.tolist() == b["positions"], (b["name"], pos.tolist())
         # and the restated writer, given the same postings, chooses bytes the decoder reads the same way (two routes, one answer)
     # the fixture's own arithmetic: pointer ranges
     assert H.H1_R == 144 and H.H2_R == 9 and H.H4_R == 15
+
+
+@pytest.mark.parametrize("n,tf_hi,limit", [(40, 3, 32768), (3000, 6, 32768), (4000, 30, 32768), (500, 5, 600)])
+def test_positions_roundtrip(n, tf_hi, limit):
+    """ss_ref_decode_block_positions against the restated writer: embedded 2- and 3-byte forms, VINT records, the pivot inside
+    the list (real and lowered limits), gaps that need 1- and 2-byte VINTs"""
+    rng = np.random.default_rng(n + tf_hi)
+    docs, tfs = _case(rng, n, 65536, tf_hi)
+    positions = [RF.random_positions(rng, int(tf), max_gap=int(rng.choice([3, 40, 300]))) for tf in tfs]
+    blk = RF.encode_term(docs, tfs, rng, positions_limit=limit, positions=positions)[0]
+    cnt, d, t, pos = _decode_positions(blk)
+    assert cnt == len(docs) and np.array_equal(d, docs) and np.array_equal(t, tfs)
+    assert pos.tolist() == [p for pl in positions for p in pl]
