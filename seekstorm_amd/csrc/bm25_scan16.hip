@@ -137,9 +137,14 @@ __device__ __forceinline__ BmTop<KPL> s16_trigger(BmTop<KPL> T, S16Cur<NT * CPT>
   const float wsc_in = T.wsc;
   uint32_t start = 0u;  // docs below it were evaluated by an earlier round
   for (;;) {
-    uint32_t lm = 0u;  // this lane's largest bound (slot i * 64 + lane holds docs 8 * slot .. 8 * slot + 7)
+    // this lane's 8 slots (slot i * 64 + lane holds docs 8 * slot .. 8 * slot + 7): their largest bounds, packed 2 per register
+    uint32_t sm[4];
 #pragma unroll
-    for (int i = 0; i < BM_SUB / 512; i++) lm = max(lm, s16_max8(lds_ld128(tile + (uint32_t)(i * 64 + lane) * 16u)));
+    for (int i = 0; i < 4; i++)
+      sm[i] = s16_max8(lds_ld128(tile + (uint32_t)(2 * i * 64 + lane) * 16u)) |
+              (s16_max8(lds_ld128(tile + (uint32_t)((2 * i + 1) * 64 + lane) * 16u)) << 16);
+    const uint32_t lmp = s16_pkmax(s16_pkmax(sm[0], sm[1]), s16_pkmax(sm[2], sm[3]));
+    const uint32_t lm = max(lmp & 0xFFFFu, lmp >> 16);  // the lane's largest bound
     uint32_t qcut = max(qthr, 1u);
     if (k <= 64u && (uint32_t)__popcll(__ballot(lm >= qcut)) > k) {
       uint32_t lo = qcut, hi = 65535u;  // invariant: at least k lanes reach lo
@@ -149,16 +154,20 @@ __device__ __forceinline__ BmTop<KPL> s16_trigger(BmTop<KPL> T, S16Cur<NT * CPT>
       }
       qcut = max(qcut, lo > (uint32_t)NT + S16_SLACK ? lo - (uint32_t)NT - S16_SLACK : 1u);
     }
+    uint32_t hotbits = 0u;  // bit i: slot i of this lane holds a bound at or above the cut
+#pragma unroll
+    for (int i = 0; i < 8; i++) hotbits |= (((sm[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu) >= qcut ? 1u : 0u) << i;
     uint32_t n = 0u, next = 0xFFFFu;
+    // candidates in ascending doc order: slot-major, lane-minor -- only the (slot, lane) pairs that hold one are visited
 #pragma unroll 1
     for (uint32_t i = start >> 9; i < (uint32_t)(BM_SUB / 512) && next == 0xFFFFu; i++) {
-      const u32x4 e = lds_ld128(tile + (i * 64u + (uint32_t)lane) * 16u);
-      u64 m = __ballot(s16_max8(e) >= qcut);
+      u64 m = __ballot((hotbits >> i) & 1u);
       while (m && next == 0xFFFFu) {
         const uint32_t l = (uint32_t)__ffsll((long long)m) - 1u;
         m &= m - 1;
-        const uint32_t dw[4] = {(uint32_t)__builtin_amdgcn_readlane((int)e.x, (int)l), (uint32_t)__builtin_amdgcn_readlane((int)e.y, (int)l),
-                                (uint32_t)__builtin_amdgcn_readlane((int)e.z, (int)l), (uint32_t)__builtin_amdgcn_readlane((int)e.w, (int)l)};
+        const u32x4 g = lds_ld128(tile + (i * 64u + l) * 16u);  // one address for the whole wave
+        const uint32_t dw[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)g.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)g.y),
+                                (uint32_t)__builtin_amdgcn_readfirstlane((int)g.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)g.w)};
 #pragma unroll
         for (uint32_t j = 0; j < 8; j++) {
           const uint32_t bound = (dw[j >> 1] >> ((j & 1u) * 16u)) & 0xFFFFu;

@@ -364,6 +364,17 @@ ResultObject Index::search(const std::vector<uint32_t>& query_terms, const float
   if (S == 0) return ro;
   const bool want_lex = (search_mode == SearchMode::Lexical || search_mode == SearchMode::Hybrid) && !query_terms.empty();
   const bool want_vec = (search_mode == SearchMode::Vector || search_mode == SearchMode::Hybrid) && query_vector != nullptr;
+  if (!comms_.empty() && want_lex && !want_vec && facet_filter.empty()) {
+    // shards on different GPUs (enable_device_exchange): every shard task searches its shard and the lists are exchanged and
+    // merged on the devices over xGMI (ss_bm25_search_sharded) -- offset / length are applied to the merged list, as
+    // search.rs:2109-2119 applies them after the gather
+    std::vector<ResultObject> r = search_lexical_batch({query_terms}, query_type_default, offset + length, result_type);
+    ro = std::move(r[0]);
+    if (offset) ro.results.erase(ro.results.begin(), ro.results.begin() + (ptrdiff_t)std::min(offset, ro.results.size()));
+    if (ro.results.size() > length) ro.results.resize(length);
+    ro.result_count = ro.results.size();
+    return ro;
+  }
   std::vector<float> qv;
   if (want_vec) {
     qv.assign(query_vector, query_vector + shards_[0]->dim());

@@ -418,6 +418,7 @@ def test_cpp_index_lexical_batch_host_gather_and_device_exchange(H):
             assert batch(ix2, qt, 1)[0] == -1  # SS_EINVAL: both shards on device 0
             rc_h, dh, sh_, ch, th = batch(ix1, qt, 0)
             assert rc_h == 0
+        d_before = _search(H, ix1, queries[0], None, 1, 0, 2, 7)  # Index::search on the host path, offset 2
         for qt in (0, 1):
             rc_h, dh, sh_, ch, th = batch(ix1, qt, 0)
             rc_x, dx, sx, cx, tx = batch(ix1, qt, 1)
@@ -425,6 +426,9 @@ def test_cpp_index_lexical_batch_host_gather_and_device_exchange(H):
             assert np.array_equal(ch, cx) and np.array_equal(th, tx)
             for i in range(len(queries)):
                 assert np.array_equal(dh[i, :ch[i]], dx[i, :cx[i]]) and np.array_equal(sh_[i, :ch[i]], sx[i, :cx[i]])
+        # Index::search itself goes through the exchange once it is enabled: same answer, offset applied after the merge
+        d_after = _search(H, ix1, queries[0], None, 1, 0, 2, 7)
+        assert np.array_equal(d_before[0], d_after[0]) and np.array_equal(d_before[1], d_after[1]) and d_before[5][1] == d_after[5][1]
     finally:
         H.ssh_index_destroy(ix2)
         H.ssh_index_destroy(ix1)
