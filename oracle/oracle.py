@@ -606,3 +606,21 @@ def bench_vec(rows, queries, k, mode, threads, seconds):
     qps = f(_p(rows, f32p), rows.shape[0], rows.shape[1], _p(q, f32p), q.shape[0], k, mode, threads, float(seconds), C.byref(done),
             lat.ctypes.data_as(C.POINTER(C.c_double)), len(lat), C.byref(nlat))
     return qps, done.value, lat[:nlat.value].copy()
+
+
+def turboquant_i8(rows, seed_mask, avx2=False):
+    """TurboQuant::quantize_f32_i8 of every row -> (i8 [n, dim_pow2], scale [n], norm [n])"""
+    rows = np.ascontiguousarray(rows, np.float32)
+    mask = np.ascontiguousarray(seed_mask, np.float32)
+    dim = len(mask)
+    f = lib().so_turboquant_i8
+    f.restype = None
+    f.argtypes = [f32p, C.c_uint32, f32p, C.c_uint32, C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    q = np.zeros((rows.shape[0], dim), np.int8)
+    sc = np.zeros(rows.shape[0], np.float32)
+    nm = np.zeros(rows.shape[0], np.float32)
+    for i in range(rows.shape[0]):
+        s_, n_ = C.c_float(), C.c_float()
+        f(rows[i].ctypes.data_as(f32p), rows.shape[1], _p(mask, f32p), dim, 1 if avx2 else 0, q[i].ctypes.data, C.byref(s_), C.byref(n_))
+        sc[i], nm[i] = s_.value, n_.value
+    return q, sc, nm

@@ -1690,3 +1690,62 @@ double so_bench_vec(const float* rows, uint64_t n_rows, uint32_t dim, const floa
   if (out_nlat) *out_nlat = nlat;
   return el > 0 ? (double)done / el : 0.0;
 }
+
+/* ================================================================== TurboQuant (Quantization::TurboQuantI8)
+ * TurboQuant::quantize_f32_i8 (vector_similarity.rs:1927-1956) and its AVX2 form (1958-1983): pad to the next power of two,
+ * multiply by the +-1 seed mask, Fast Walsh-Hadamard transform (1861-1879 / 1883-1925: butterflies, then / sqrt(n)),
+ * scale = max(sqrt(sum x^2) / sqrt(dim) / 32, 1e-8) (2011-2039), q = round(x / scale) clamped to +-127, norm = sum q^2 * scale^2.
+ * avx2 != 0: the sum of squares in eight lanes (mul, then add) folded 4+4, 2+2, 1+1 (horizontal_sum_avx2, 119-126), the
+ * division as a multiplication by 1 / scale and the packs saturation (-128 .. 127) of quantize_avx2 (1252-1289).
+ * The seed mask comes from ChaCha8Rng::seed_from_u64(1234) in the reference (1845-1858; rand_chacha is not vendored): an input here.
+ * The quantised vectors are then searched like any scaled i8 vectors: dot_i8_turboquant = dot * s1 * s2 (2072-2076),
+ * euclidean_i8_turboquant = max(0, n1 + n2 - 2 dot_q) (2058-2069). */
+uint32_t so_turboquant_dim(uint32_t n) { uint32_t d = 1; while (d < n) d <<= 1; return d; }
+void so_turboquant_i8(const float* v, uint32_t n, const float* seed_mask, uint32_t dim, int avx2, int8_t* out, float* scale_out,
+                      float* norm_out) {
+  float* a = (float*)calloc(dim, sizeof(float));
+  for (uint32_t i = 0; i < (n < dim ? n : dim); i++) a[i] = v[i];
+  for (uint32_t i = 0; i < dim; i++) a[i] *= seed_mask[i];
+  for (uint32_t h = 1; h < dim; h *= 2)
+    for (uint32_t i = 0; i < dim; i += 2 * h)
+      for (uint32_t j = i; j < i + h; j++) { const float x = a[j], y = a[j + h]; a[j] = x + y; a[j + h] = x - y; }
+  const float nrm = sqrtf((float)dim);
+  for (uint32_t i = 0; i < dim; i++) a[i] /= nrm;
+  float sum_sq;
+  if (avx2 && dim >= 8) {
+    float l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t i = 0; i + 8 <= dim; i += 8)
+      for (int j = 0; j < 8; j++) { const float p = a[i + j] * a[i + j]; l[j] = l[j] + p; }
+    const float x0 = l[4] + l[0], x1 = l[5] + l[1], x2 = l[6] + l[2], x3 = l[7] + l[3];
+    const float y0 = x0 + x2, y1 = x1 + x3;
+    sum_sq = y0 + y1;
+  } else {
+    sum_sq = 0.0f;
+    for (uint32_t i = 0; i < dim; i++) sum_sq += a[i] * a[i];
+  }
+  const float sigma = sqrtf(sum_sq) / sqrtf((float)dim);
+  float scale = sigma / 32.0f;
+  if (!(scale > 1e-8f)) scale = 1e-8f;
+  int32_t sq = 0;
+  const float inv = 1.0f / scale;
+  for (uint32_t i = 0; i < dim; i++) {
+    int32_t q;
+    if (avx2 && dim >= 16) {  /* x * (1 / scale), + copysign(0.5), truncate, saturating packs */
+      const float s = a[i] * inv;
+      const float adj = s + (signbit(s) ? -0.5f : 0.5f);
+      q = (int32_t)adj;
+      if (q > 127) q = 127;
+      if (q < -128) q = -128;
+    } else {
+      float r = roundf(a[i] / scale);
+      if (r < -127.0f) r = -127.0f;
+      if (r > 127.0f) r = 127.0f;
+      q = (int32_t)r;
+    }
+    out[i] = (int8_t)q;
+    sq += q * q;
+  }
+  *scale_out = scale;
+  *norm_out = (float)sq * scale * scale;
+  free(a);
+}

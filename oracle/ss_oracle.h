@@ -201,6 +201,10 @@ uint32_t so_vec_search_i8_euclid(const int8_t* rows, uint64_t n_rows, uint32_t d
  * workers as the reference splits them over shards).  Returns queries/s. */
 double so_bench_vec(const float* rows, uint64_t n_rows, uint32_t dim, const float* queries, uint32_t nq, uint32_t k, int mode,
                     uint32_t threads, double seconds, uint64_t* out_queries, double* out_lat_us, uint32_t lat_cap, uint32_t* out_nlat);
+/* TurboQuant::quantize_f32_i8 (vector_similarity.rs:1927-1983): sign mask, FWHT, scale, i8 + norm; dim = so_turboquant_dim(n) */
+uint32_t so_turboquant_dim(uint32_t n);
+void so_turboquant_i8(const float* v, uint32_t n, const float* seed_mask, uint32_t dim, int avx2, int8_t* out, float* scale_out,
+                      float* norm_out);
 /* vector_score field: vector.rs:1495-1499 */
 float so_vector_score_field(float dot);
 /* TopK threshold transform: vector.rs:388-397 */

@@ -37,6 +37,9 @@ float ssh_idf(uint64_t n_docs, uint64_t posting_count) { return idf(n_docs, post
 void ssh_normalize_f32(float* v, uint64_t n) { normalize_f32(v, (size_t)n); }
 float ssh_threshold_raw(float similarity_threshold) { return threshold_raw(&similarity_threshold); }
 float ssh_vector_score(float raw) { return vector_score_of(raw); }
+void ssh_turboquant(const float* v, uint64_t n, const float* mask, uint64_t dim, int avx2, int8_t* out, float* scale, float* norm) {
+  turboquant_f32_to_i8(v, (size_t)n, mask, (size_t)dim, avx2 != 0, out, scale, norm);
+}
 
 ssh_index* ssh_index_create(int n_shards, const int* devices) {
   ssh_index* ix = new ssh_index();

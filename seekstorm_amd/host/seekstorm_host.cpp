@@ -28,6 +28,62 @@ void quantize_f32_to_i8(const float* v, size_t n, int8_t* out) {
   for (size_t i = 0; i < n; i++) out[i] = (int8_t)std::fmin(std::fmax(std::round(v[i] * 127.0f), -127.0f), 127.0f);
 }
 
+size_t turboquant_dim(size_t n) {  // TurboQuant::next_power_of_two, vector_similarity.rs:1836-1842
+  size_t d = 1;
+  while (d < n) d <<= 1;
+  return d;
+}
+
+void turboquant_f32_to_i8(const float* v, size_t n, const float* seed_mask, size_t dim, bool avx2, int8_t* out, float* scale_out,
+                          float* norm_out) {
+  // TurboQuant::quantize_f32_i8 / _avx2 (vector_similarity.rs:1927-1983): pad, sign mask, FWHT (1861-1925), scale (2011-2039),
+  // round to i8, norm = sum q^2 * scale^2
+  std::vector<float> a(dim, 0.0f);
+  for (size_t i = 0; i < std::min(n, dim); i++) a[i] = v[i];
+  for (size_t i = 0; i < dim; i++) a[i] *= seed_mask[i];
+  for (size_t h = 1; h < dim; h *= 2)
+    for (size_t i = 0; i < dim; i += 2 * h)
+      for (size_t j = i; j < i + h; j++) {
+        const float x = a[j], y = a[j + h];
+        a[j] = x + y;
+        a[j + h] = x - y;
+      }
+  const float nrm = std::sqrt((float)dim);
+  for (size_t i = 0; i < dim; i++) a[i] /= nrm;
+  float sum_sq = 0.0f;
+  if (avx2 && dim >= 8) {  // eight lanes (mul, then add), folded 4+4, 2+2, 1+1 (horizontal_sum_avx2)
+    float l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i + 8 <= dim; i += 8)
+      for (int j = 0; j < 8; j++) {
+        const float p = a[i + j] * a[i + j];
+        l[j] = l[j] + p;
+      }
+    const float x0 = l[4] + l[0], x1 = l[5] + l[1], x2 = l[6] + l[2], x3 = l[7] + l[3];
+    const float y0 = x0 + x2, y1 = x1 + x3;
+    sum_sq = y0 + y1;
+  } else {
+    for (size_t i = 0; i < dim; i++) sum_sq += a[i] * a[i];
+  }
+  float scale = std::sqrt(sum_sq) / std::sqrt((float)dim) / 32.0f;
+  if (!(scale > 1e-8f)) scale = 1e-8f;
+  const float inv = 1.0f / scale;
+  int32_t sq = 0;
+  for (size_t i = 0; i < dim; i++) {
+    int32_t q;
+    if (avx2 && dim >= 16) {  // quantize_avx2 (1252-1289): reciprocal, + copysign(0.5), truncate, saturating packs
+      const float s = a[i] * inv;
+      q = (int32_t)(s + (std::signbit(s) ? -0.5f : 0.5f));
+      q = std::min(127, std::max(-128, q));
+    } else {
+      q = (int32_t)std::fmin(std::fmax(std::round(a[i] / scale), -127.0f), 127.0f);
+    }
+    out[i] = (int8_t)q;
+    sq += q * q;
+  }
+  *scale_out = scale;
+  *norm_out = (float)sq * scale * scale;
+}
+
 static const float kSimilarityNormalization64I8 = 1.0f / 16129.0f;  // vector.rs:29
 
 float threshold_raw(const float* similarity_threshold, bool euclidean) {

@@ -70,6 +70,11 @@ struct ResultObject {
 float idf(uint64_t indexed_doc_count, uint64_t posting_count);  // search.rs:3225-3230, all f32
 void normalize_f32(float* v, size_t n);                         // vector_similarity.rs:70-74 (search.rs:1464-1475)
 void quantize_f32_to_i8(const float* v, size_t n, int8_t* out);  // vector_similarity.rs:1226-1232 (query side: search.rs:1487-1490)
+// Quantization::TurboQuantI8, query side (search.rs:1545-1594): sign mask x FWHT x scalar quantisation; the index's seed mask
+// (TurboQuant::seed_mask, vector_similarity.rs:1845-1858) is handed in.  out: dim = turboquant_dim(n) values.
+size_t turboquant_dim(size_t n);
+void turboquant_f32_to_i8(const float* v, size_t n, const float* seed_mask, size_t dim, bool avx2, int8_t* out, float* scale_out,
+                          float* norm_out);
 float threshold_raw(const float* similarity_threshold, bool euclidean = false);  // TopK::new, vector.rs:388-398; nullptr = none
 float vector_score_of(float raw_dot);                           // vector.rs:1495-1499: ((dot / 16129) + 1) / 2
 

@@ -84,6 +84,58 @@ def quantize_f32_to_i8(v):
     return np.clip(r, -127, 127).astype(np.int8)
 
 
+def turboquant_dim(n):
+    """TurboQuant::next_power_of_two (vector_similarity.rs:1836-1842): the padded dimension of a TurboQuantI8 index"""
+    d = 1
+    while d < int(n):
+        d <<= 1
+    return d
+
+
+def turboquant_f32_to_i8(v, seed_mask, avx2=False):
+    """TurboQuant::quantize_f32_i8 / quantize_f32_i8_avx2 (vector_similarity.rs:1927-1983), the query side of a
+    Quantization::TurboQuantI8 index (search.rs:1545-1594): pad to len(seed_mask) = the next power of two, multiply by the +-1
+    seed mask, Fast Walsh-Hadamard transform, scale = max(sqrt(sum x^2) / sqrt(dim) / 32, 1e-8), round(x / scale) -> i8.
+    -> (i8 vector, scale, norm = sum q^2 * scale^2), to be searched with ss_vec_search_i8 (query_scale) or, under Euclidean,
+    ss_vec_search_i8_euclid (query_scale, query_norm).  seed_mask: the index's TurboQuant::seed_mask (ChaCha8Rng::seed_from_u64
+    (1234) in the reference -- rand_chacha stays on the host side of the boundary).  avx2: the summation order, reciprocal
+    multiplication and packs saturation of the reference's x86 path, which is the one an x86 host indexes with."""
+    f = np.float32
+    mask = np.ascontiguousarray(seed_mask, f)
+    dim = len(mask)
+    a = np.zeros(dim, f)
+    v = np.ascontiguousarray(v, f)
+    a[:min(len(v), dim)] = v[:dim]
+    a = (a * mask).astype(f)
+    h = 1
+    while h < dim:  # butterflies of one stage are independent: elementwise f32 adds, the reference's values bit for bit
+        b = a.reshape(dim // (2 * h), 2, h)
+        a = np.concatenate([(b[:, 0, :] + b[:, 1, :])[:, None, :], (b[:, 0, :] - b[:, 1, :])[:, None, :]], axis=1).reshape(dim).astype(f)
+        h *= 2
+    a = (a / np.sqrt(f(dim), dtype=f)).astype(f)
+    sq = (a * a).astype(f)
+    if avx2 and dim >= 8:
+        lanes = np.add.accumulate(sq.reshape(dim // 8, 8), axis=0, dtype=f)[-1]  # eight sequential f32 chains
+        x = (lanes[4:] + lanes[:4]).astype(f)
+        y = (x[:2] + x[2:]).astype(f)
+        sum_sq = f(y[0] + y[1])
+    else:
+        sum_sq = np.add.accumulate(sq, dtype=f)[-1]  # sequential f32 sum (np.sum adds pairwise)
+    scale = f(f(np.sqrt(sum_sq, dtype=f) / np.sqrt(f(dim), dtype=f)) / f(32.0))
+    if not scale > f(1e-8):
+        scale = f(1e-8)
+    if avx2 and dim >= 16:
+        s_ = (a * f(f(1.0) / scale)).astype(f)
+        adj = (s_ + np.where(np.signbit(s_), f(-0.5), f(0.5)).astype(f)).astype(f)
+        q = np.clip(np.trunc(adj), -128, 127).astype(np.int8)
+    else:
+        x = (a / scale).astype(f)
+        r = np.sign(x) * np.floor(np.abs(x) + f(0.5))
+        q = np.clip(r, -127, 127).astype(np.int8)
+    sqn = int((q.astype(np.int64) ** 2).sum())
+    return q, float(scale), float(f(f(f(sqn) * scale) * scale))
+
+
 def idf_f32(indexed_doc_count, posting_count):
     """search.rs:3225-3230, all f32."""
     Nf, nf = np.float32(indexed_doc_count), np.float32(posting_count)

@@ -58,6 +58,8 @@ def H():
     L.ssh_set_clusters.argtypes = [C.c_void_p, C.c_int, C.c_uint32, u32p, C.c_uint32, u32p]
     L.ssh_search_vector_shard_ann.argtypes = [C.c_void_p, C.c_int, f32p, C.c_uint32, C.c_int, C.c_uint32, C.c_float, C.c_uint32,
                                               u64p, f32p, u64p, u64p]
+    L.ssh_turboquant.restype = None
+    L.ssh_turboquant.argtypes = [f32p, C.c_uint64, f32p, C.c_uint64, C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ssh_index_search_lexical_batch.argtypes = [C.c_void_p, C.c_uint32, u32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                                  u64p, f32p, u32p, u64p]
     return L
@@ -366,6 +368,30 @@ def test_cpp_shard_facet_filter(H):
             assert np.allclose(sc[:n], os_[3:], rtol=1e-4) and all(keep[int(d)] for d in doc[:n])
     finally:
         H.ssh_index_destroy(ix)
+
+
+def test_turboquant_quantiser_mirrors_equal_the_oracle(H):
+    """Quantization::TurboQuantI8, query side (TurboQuant::quantize_f32_i8 and its AVX2 form, vector_similarity.rs:1927-1983):
+    the C++ and the Python mirror against the oracle's restatement, bit for bit -- both summation orders, dims that are and are
+    not powers of two, a zero vector (scale floor 1e-8)"""
+    import seekstorm_amd as S
+    from oracle import oracle as O
+    rng = np.random.default_rng(8)
+    for n in (5, 64, 100, 768):
+        dim = S.turboquant_dim(n)
+        assert dim == {5: 8, 64: 64, 100: 128, 768: 1024}[n]
+        mask = np.where(rng.random(dim) < 0.5, 1.0, -1.0).astype(np.float32)
+        rows = (rng.standard_normal((6, n)) * rng.choice([1e-3, 1.0, 40.0])).astype(np.float32)
+        rows[5] = 0.0
+        for avx2 in (False, True):
+            oq, osc, onm = O.turboquant_i8(rows, mask, avx2)
+            for i in range(len(rows)):
+                q, sc, nm = S.turboquant_f32_to_i8(rows[i], mask, avx2)
+                assert np.array_equal(q, oq[i]) and np.float32(sc) == osc[i] and np.float32(nm) == onm[i], (n, avx2, i)
+                cq = np.zeros(dim, np.int8); cs, cn = C.c_float(), C.c_float()
+                H.ssh_turboquant(P(rows[i], f32p), n, P(mask, f32p), dim, 1 if avx2 else 0, cq.ctypes.data, C.byref(cs), C.byref(cn))
+                assert np.array_equal(cq, oq[i]) and np.float32(cs.value) == osc[i] and np.float32(cn.value) == onm[i], (n, avx2, i)
+        assert osc[5] == np.float32(1e-8) and not oq[5].any()
 
 
 @pytest.mark.gpu
