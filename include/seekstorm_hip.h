@@ -275,8 +275,10 @@ typedef struct ss_facet_filter {
   uint64_t lo, hi;      /* numeric types: passes iff lo <= value < hi */
   uint32_t n_values;    /* string types: passes iff the id is one of values[0 .. n_values) (<= 8) */
   uint32_t values[8];
-  uint32_t reserved;
+  uint32_t reserved;    /* numeric types: SS_FACET_LO_EXCLUSIVE | SS_FACET_HI_INCLUSIVE turn the ends around (0 = [lo, hi)) */
 } ss_facet_filter;
+#define SS_FACET_HI_INCLUSIVE 1u
+#define SS_FACET_LO_EXCLUSIVE 2u
 int ss_facet_upload(ss_shard* s, uint64_t n_docs, uint32_t record_size, const uint8_t* records);
 int ss_bm25_search_filtered(ss_shard* s, uint32_t n_queries, const ss_bm25_query* queries, uint32_t k, uint32_t result_type,
                             uint32_t n_filters, const ss_facet_filter* filters /* host */, uint32_t* out_doc, float* out_score,
@@ -296,6 +298,20 @@ int ss_bm25_search_filtered_dev(ss_shard* s, uint32_t n_queries, const ss_bm25_q
 int ss_bm25_facet_count(ss_shard* s, const ss_bm25_query* query, uint32_t n_filters, const ss_facet_filter* filters,
                         uint32_t facet_offset, uint32_t facet_type, uint32_t n_buckets, const uint64_t* range_lower_bounds,
                         uint64_t* out_counts, uint64_t* out_total);
+
+/* Result sort (search.rs ResultSort; ordering min_heap.rs:574-1050: the sort fields in order, each ascending or descending, the
+ * score last).  ss_bm25_facet_kth finds the PIVOT of such a sort for ONE query: the k-th best value of a numeric facet among
+ * the query's matches (after NOT terms, tombstones and the facet filters) -- *out_value = its stored bits, *out_n_better =
+ * matches strictly better, *out_n_equal = matches with exactly that value, *out_total = all matches (fewer than k matches:
+ * the pivot is the worst match).  The top-k under the sort is then: the n_better docs of a search filtered to "better than
+ * the pivot" (SS_FACET_LO_EXCLUSIVE / _HI_INCLUSIVE) ordered by their values (ss_facet_values), followed by the best
+ * k - n_better docs of a search filtered to "equal to the pivot" -- by the next sort field the same way, by score when none
+ * is left.  String facets (sorted by their strings) and Point facets are not offered (SS_ENOTSUP).
+ * ss_facet_values: the stored bits of a facet for a list of docs (host arrays). */
+int ss_bm25_facet_kth(ss_shard* s, const ss_bm25_query* query, uint32_t n_filters, const ss_facet_filter* filters,
+                      uint32_t facet_offset, uint32_t facet_type, uint32_t descending, uint64_t k, uint64_t* out_value,
+                      uint64_t* out_n_better, uint64_t* out_n_equal, uint64_t* out_total);
+int ss_facet_values(ss_shard* s, uint32_t n, const uint32_t* doc_ids, uint32_t facet_offset, uint32_t facet_type, uint64_t* out_values);
 
 /* ------------------------------------------------------------------ vector image
  * rows: row-major [n_rows x dim] f32, already L2-normalised for cosine (vector.rs:585-596); the uploader of

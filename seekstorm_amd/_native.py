@@ -45,6 +45,8 @@ class FacetFilterC(C.Structure):  # ss_facet_filter
                 ("values", C.c_uint32 * 8), ("reserved", C.c_uint32)]
 
 
+SS_MAX_FACET_FILTERS = 8
+FACET_HI_INCLUSIVE, FACET_LO_EXCLUSIVE = 1, 2
 FACET_TYPES = {"u8": 0, "u16": 1, "u32": 2, "u64": 3, "i8": 4, "i16": 5, "i32": 6, "i64": 7, "f32": 8, "f64": 9,
                "string16": 10, "string32": 11}
 
@@ -145,6 +147,9 @@ SYMBOLS = [
     ("ss_comm_info", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("ss_topk_allgather_merge", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("ss_bm25_facet_kth", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
+                                    u64p, u64p, u64p, u64p]),
+    ("ss_facet_values", C.c_int, [C.c_void_p, C.c_uint32, u32p, C.c_uint32, C.c_uint32, u64p]),
     ("ss_bm25_search_sharded", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p]),
     ("ss_rrf_merge_dev", C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int,

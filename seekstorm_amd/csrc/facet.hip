@@ -21,25 +21,31 @@ __device__ __forceinline__ unsigned long long facet_read(const uint8_t* p, uint3
   return v;
 }
 
+// lo <= v < hi as Rust's Range::contains; the two flag bits turn the ends around (the pivots of a result sort need
+// "strictly above" and "equal to" for every type, and a 64-bit type has no value above its largest to write as an end)
+template <typename T>
+__device__ __forceinline__ bool facet_in(T v, T lo, T hi, uint32_t flags) {
+  const bool above = (flags & SS_FACET_LO_EXCLUSIVE) ? v > lo : v >= lo;
+  const bool below = (flags & SS_FACET_HI_INCLUSIVE) ? v <= hi : v < hi;
+  return above && below;
+}
 __device__ bool facet_pass(const uint8_t* rec, const ss_facet_filter& f) {
   const uint8_t* p = rec + f.offset;
+  const uint32_t fl = f.reserved;
   switch (f.type) {
-    case SS_FACET_U8: { const unsigned long long v = facet_read(p, 1); return v >= f.lo && v < f.hi; }
-    case SS_FACET_U16: { const unsigned long long v = facet_read(p, 2); return v >= f.lo && v < f.hi; }
-    case SS_FACET_U32: { const unsigned long long v = facet_read(p, 4); return v >= f.lo && v < f.hi; }
-    case SS_FACET_U64: { const unsigned long long v = facet_read(p, 8); return v >= f.lo && v < f.hi; }
-    case SS_FACET_I8: { const long long v = (int8_t)facet_read(p, 1); return v >= (long long)f.lo && v < (long long)f.hi; }
-    case SS_FACET_I16: { const long long v = (int16_t)facet_read(p, 2); return v >= (long long)f.lo && v < (long long)f.hi; }
-    case SS_FACET_I32: { const long long v = (int32_t)facet_read(p, 4); return v >= (long long)f.lo && v < (long long)f.hi; }
-    case SS_FACET_I64: { const long long v = (long long)facet_read(p, 8); return v >= (long long)f.lo && v < (long long)f.hi; }
-    case SS_FACET_F32: {
-      const float v = __uint_as_float((uint32_t)facet_read(p, 4));
-      return v >= __uint_as_float((uint32_t)f.lo) && v < __uint_as_float((uint32_t)f.hi);
-    }
-    case SS_FACET_F64: {
-      const double v = __longlong_as_double((long long)facet_read(p, 8));
-      return v >= __longlong_as_double((long long)f.lo) && v < __longlong_as_double((long long)f.hi);
-    }
+    case SS_FACET_U8: return facet_in<unsigned long long>(facet_read(p, 1), f.lo, f.hi, fl);
+    case SS_FACET_U16: return facet_in<unsigned long long>(facet_read(p, 2), f.lo, f.hi, fl);
+    case SS_FACET_U32: return facet_in<unsigned long long>(facet_read(p, 4), f.lo, f.hi, fl);
+    case SS_FACET_U64: return facet_in<unsigned long long>(facet_read(p, 8), f.lo, f.hi, fl);
+    case SS_FACET_I8: return facet_in<long long>((int8_t)facet_read(p, 1), (long long)f.lo, (long long)f.hi, fl);
+    case SS_FACET_I16: return facet_in<long long>((int16_t)facet_read(p, 2), (long long)f.lo, (long long)f.hi, fl);
+    case SS_FACET_I32: return facet_in<long long>((int32_t)facet_read(p, 4), (long long)f.lo, (long long)f.hi, fl);
+    case SS_FACET_I64: return facet_in<long long>((long long)facet_read(p, 8), (long long)f.lo, (long long)f.hi, fl);
+    case SS_FACET_F32:
+      return facet_in<float>(__uint_as_float((uint32_t)facet_read(p, 4)), __uint_as_float((uint32_t)f.lo), __uint_as_float((uint32_t)f.hi), fl);
+    case SS_FACET_F64:
+      return facet_in<double>(__longlong_as_double((long long)facet_read(p, 8)), __longlong_as_double((long long)f.lo),
+                              __longlong_as_double((long long)f.hi), fl);
     case SS_FACET_STRING16:
     case SS_FACET_STRING32: {
       const uint32_t v = (uint32_t)facet_read(p, f.type == SS_FACET_STRING16 ? 2 : 4);
@@ -151,6 +157,101 @@ int ssi_facet_count(ss_shard* s, const unsigned long long* d_bits, uint64_t n_do
   facet_count_kernel<<<(unsigned)((groups + 255) / 256), 256, 0, st>>>(d_bits, (unsigned long long)n_docs, s->d_facets,
                                                                       s->facet_record_size, offset, type, n_buckets,
                                                                       (const unsigned long long*)d_bounds, d_counts);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Result sort (search.rs ResultSort, min_heap.rs:574-1050 result_ordering_shard): results ordered by facet values -- each
+// field ascending or descending, the score last -- instead of by score alone.  The top-k under such an order is found from
+// its PIVOT: the k-th best value of the first sort field among the query's matches (a byte-wise radix select over the match
+// set: one histogram pass per byte of the field), after which "strictly better than the pivot" and "equal to the pivot" are
+// ordinary facet filters on ordinary searches (the hosts compose them: seekstorm_amd/search.py search_lexical_sorted).
+// key: the stored value mapped to an unsigned integer that orders like the value (sign bit flipped for integers, the usual
+// transform for floats), complemented for an ascending sort, so that a larger key is always the better one.
+__host__ __device__ inline unsigned long long facet_order_key(unsigned long long v, uint32_t type, uint32_t bits, bool descending) {
+  const unsigned long long mask = bits == 64 ? ~0ull : ((1ull << bits) - 1ull), top = 1ull << (bits - 1);
+  unsigned long long k = v & mask;
+  if (type >= SS_FACET_I8 && type <= SS_FACET_I64) k ^= top;
+  else if (type == SS_FACET_F32 || type == SS_FACET_F64) k = (k & top) ? (~k & mask) : (k | top);
+  return descending ? k : (~k & mask);
+}
+__host__ inline unsigned long long facet_order_value(unsigned long long k, uint32_t type, uint32_t bits, bool descending) {
+  const unsigned long long mask = bits == 64 ? ~0ull : ((1ull << bits) - 1ull), top = 1ull << (bits - 1);
+  if (!descending) k = ~k & mask;
+  if (type >= SS_FACET_I8 && type <= SS_FACET_I64) k ^= top;
+  else if (type == SS_FACET_F32 || type == SS_FACET_F64) k = (k & top) ? (k & ~top) : (~k & mask);
+  return k;
+}
+// histogram of byte `byte_index` (0 = most significant) of the keys that share `prefix` in the bytes above it
+__global__ void facet_radix_kernel(const unsigned long long* __restrict__ bits, unsigned long long n_docs,
+                                   const uint8_t* __restrict__ records, uint32_t record_size, uint32_t offset, uint32_t type,
+                                   uint32_t key_bits, uint32_t descending, unsigned long long prefix, uint32_t byte_index,
+                                   unsigned long long* __restrict__ hist) {
+  __shared__ unsigned int h[256];
+  h[threadIdx.x & 255u] = 0u;
+  __syncthreads();
+  const unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g * 64ull < n_docs) {
+    unsigned long long m = bits[g];
+    const uint32_t shift = key_bits - 8u * (byte_index + 1u);
+    while (m) {
+      const unsigned long long d = g * 64ull + (unsigned long long)__builtin_ctzll(m);
+      m &= m - 1;
+      if (d >= n_docs) break;
+      const unsigned long long k = facet_order_key(facet_read(records + d * record_size + offset, key_bits / 8u), type, key_bits, descending != 0u);
+      if (byte_index == 0u || (k >> (shift + 8u)) == prefix) atomicAdd(&h[(k >> shift) & 255u], 1u);
+    }
+  }
+  __syncthreads();
+  if (h[threadIdx.x & 255u]) atomicAdd(&hist[threadIdx.x & 255u], (unsigned long long)h[threadIdx.x & 255u]);
+}
+
+// k-th best key of the match set `d_bits` (k >= 1; with fewer than k matches: the worst match).  *n_better = matches
+// strictly better than it, *n_equal = matches equal to it.  d_hist: 256 counters of workspace.
+int ssi_facet_kth(ss_shard* s, const unsigned long long* d_bits, uint64_t n_docs, uint64_t n_matches, uint32_t offset, uint32_t type,
+                  bool descending, uint64_t k, unsigned long long* d_hist, uint64_t* value_bits, uint64_t* n_better, uint64_t* n_equal,
+                  hipStream_t st) {
+  static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8};
+  if (type > SS_FACET_F64) return SS_ENOTSUP;  // string facets sort by their strings, which live in the host's facet.json
+  *n_better = 0; *n_equal = 0; *value_bits = 0;
+  if (n_matches == 0) return SS_OK;
+  const uint32_t key_bits = 8u * width[type];
+  uint64_t want = std::min<uint64_t>(k, n_matches);  // rank (1-based) still to be found inside the current prefix
+  unsigned long long prefix = 0;
+  const uint64_t groups = (n_docs + 63) / 64;
+  unsigned long long hist[256];
+  uint64_t equal = 0;
+  for (uint32_t b = 0; b < key_bits / 8u; b++) {
+    SS_HIP(hipMemsetAsync(d_hist, 0, sizeof(hist), st));
+    facet_radix_kernel<<<(unsigned)((groups + 255) / 256), 256, 0, st>>>(d_bits, (unsigned long long)n_docs, s->d_facets, s->facet_record_size,
+                                                                        offset, type, key_bits, descending ? 1u : 0u, prefix, b, d_hist);
+    SS_HIP(hipGetLastError());
+    SS_HIP(hipMemcpyAsync(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost, st));
+    SS_HIP(hipStreamSynchronize(st));
+    int v = 255;
+    for (; v > 0; v--) {  // from the best byte value down to the bucket that holds the wanted rank
+      if (hist[v] >= want) break;
+      want -= hist[v];
+      *n_better += hist[v];
+    }
+    prefix = (prefix << 8) | (unsigned long long)v;
+    equal = hist[v];
+  }
+  *n_equal = equal;
+  *value_bits = facet_order_value(prefix, type, key_bits, descending);
+  return SS_OK;
+}
+
+__global__ void facet_values_kernel(const uint8_t* __restrict__ records, uint32_t record_size, uint32_t offset, uint32_t bytes,
+                                    const uint32_t* __restrict__ docs, uint32_t n, unsigned long long n_docs, unsigned long long* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = docs[i] < n_docs ? facet_read(records + (size_t)docs[i] * record_size + offset, bytes) : 0ull;
+}
+int ssi_facet_values(ss_shard* s, const uint32_t* d_docs, uint32_t n, uint32_t offset, uint32_t type, unsigned long long* d_out, hipStream_t st) {
+  static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 2, 4};
+  if (n) facet_values_kernel<<<(n + 255) / 256, 256, 0, st>>>(s->d_facets, s->facet_record_size, offset, width[type], d_docs, n,
+                                                               (unsigned long long)s->facet_docs, d_out);
   SS_HIP(hipGetLastError());
   return SS_OK;
 }

@@ -570,6 +570,64 @@ int ss_bm25_facet_count(ss_shard* s, const ss_bm25_query* query, uint32_t n_filt
   return rc;
 }
 
+// The pivot of a result sort (facet.hip): match set from the bit records as for facet counts, then the radix select.
+int ss_bm25_facet_kth(ss_shard* s, const ss_bm25_query* query, uint32_t n_filters, const ss_facet_filter* filters,
+                      uint32_t facet_offset, uint32_t facet_type, uint32_t descending, uint64_t k, uint64_t* out_value,
+                      uint64_t* out_n_better, uint64_t* out_n_equal, uint64_t* out_total) {
+  if (!s || !query || !out_value || !out_n_better || !out_n_equal || k == 0) return SS_EINVAL;
+  if (facet_type > SS_FACET_STRING32) return SS_EINVAL;
+  if (facet_type > SS_FACET_F64) return SS_ENOTSUP;
+  if (!s->d_post) return SS_ESTATE;
+  bool has_and, has_or, all_probed, any_frequent;
+  uint32_t nt_max, np_max;
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_TRY(check_queries(s, 1, query, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent));
+  if (!all_probed || !s->d_probe) return SS_ENOTSUP;
+  SS_HIP(hipSetDevice(s->device));
+  static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 2, 4};
+  if (!s->d_facets || s->facet_docs < s->bm_n_docs || facet_offset + width[facet_type] > s->facet_record_size) return SS_ESTATE;
+  const uint64_t groups = (uint64_t)s->bm_n_sub * (BM_SUB / 64);
+  const size_t bytes = sizeof(ss_bm25_query) + 8 + groups * 8 + 256 * 8;
+  if (bytes > s->facet_ws_cap) {
+    if (s->d_facet_ws) (void)hipFree(s->d_facet_ws);
+    s->d_facet_ws = nullptr;
+    s->facet_ws_cap = 0;
+    SS_HIP(hipMalloc(&s->d_facet_ws, bytes));
+    s->facet_ws_cap = bytes;
+  }
+  char* ws = (char*)s->d_facet_ws;
+  ss_bm25_query* d_q = (ss_bm25_query*)ws;
+  unsigned long long* d_total = (unsigned long long*)(ws + sizeof(ss_bm25_query));
+  unsigned long long* d_bits = d_total + 1;
+  unsigned long long* d_hist = d_bits + groups;
+  SS_HIP(hipMemcpyAsync(d_q, query, sizeof(ss_bm25_query), hipMemcpyHostToDevice, s->stream));
+  SS_HIP(hipMemsetAsync(d_total, 0, 8 + groups * 8, s->stream));
+  SS_TRY(with_facet_filter(s, n_filters, filters, s->stream, [&]() { return ssi_bm25_match_bits(s, d_q, d_bits, d_total, s->stream); }));
+  uint64_t total = 0;
+  SS_HIP(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, s->stream));
+  SS_HIP(hipStreamSynchronize(s->stream));
+  if (out_total) *out_total = total;
+  return ssi_facet_kth(s, d_bits, s->bm_n_docs, total, facet_offset, facet_type, descending != 0, k, d_hist, out_value, out_n_better,
+                       out_n_equal, s->stream);
+}
+
+int ss_facet_values(ss_shard* s, uint32_t n, const uint32_t* doc_ids, uint32_t facet_offset, uint32_t facet_type, uint64_t* out_values) {
+  if (!s || (n && (!doc_ids || !out_values)) || facet_type > SS_FACET_STRING32) return SS_EINVAL;
+  static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 2, 4};
+  std::lock_guard<std::mutex> g(s->mu);
+  if (!s->d_facets || facet_offset + width[facet_type] > s->facet_record_size) return SS_ESTATE;
+  if (n == 0) return SS_OK;
+  SS_HIP(hipSetDevice(s->device));
+  SS_TRY(ensure_qstage(s, (size_t)n * 12));
+  uint32_t* d_docs = (uint32_t*)((char*)s->d_qstage + (size_t)n * 8);
+  unsigned long long* d_out = (unsigned long long*)s->d_qstage;
+  SS_HIP(hipMemcpyAsync(d_docs, doc_ids, (size_t)n * 4, hipMemcpyHostToDevice, s->stream));
+  SS_TRY(ssi_facet_values(s, d_docs, n, facet_offset, facet_type, d_out, s->stream));
+  SS_HIP(hipMemcpyAsync(out_values, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, s->stream));
+  SS_HIP(hipStreamSynchronize(s->stream));
+  return SS_OK;
+}
+
 int ss_bm25_search_dev(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t ops_mask,
                        uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total,
                        void* stream) {

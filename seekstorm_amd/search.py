@@ -572,6 +572,8 @@ class Shard:
                 arr[i].n_values = len(ids)
                 for j, v in enumerate(ids):
                     arr[i].values[j] = v
+            elif len(f) > 4 and f[4] == "bits":  # (offset, type, lo bits, hi bits, "bits", flags): the pivots of a result sort
+                arr[i].lo, arr[i].hi, arr[i].reserved = int(f[2]), int(f[3]), int(f[5])
             else:
                 dt = {"f32": np.float32, "f64": np.float64}.get(ty)
                 if dt is not None:
@@ -580,6 +582,104 @@ class Shard:
                 else:
                     arr[i].lo, arr[i].hi = int(f[2]) & 0xFFFFFFFFFFFFFFFF, int(f[3]) & 0xFFFFFFFFFFFFFFFF
         return arr, len(filters)
+
+    # ---- result sort (search.rs ResultSort; ordering min_heap.rs:574-1050)
+    _FACET_BITS = {"u8": 8, "u16": 16, "u32": 32, "u64": 64, "i8": 8, "i16": 16, "i32": 32, "i64": 64, "f32": 32, "f64": 64}
+
+    @staticmethod
+    def _facet_order_key(bits, ty, descending):
+        """stored bits -> an integer that orders like the value (larger = better under the sort)"""
+        nb = Shard._FACET_BITS[ty]
+        mask, top = (1 << nb) - 1, 1 << (nb - 1)
+        k = int(bits) & mask
+        if ty[0] == "i":
+            k ^= top
+        elif ty[0] == "f":
+            k = (~k & mask) if (k & top) else (k | top)
+        return k if descending else (~k & mask)
+
+    @staticmethod
+    def _facet_filter_bits(v, ty):
+        """stored bits (zero-extended) -> the form ss_facet_filter compares: signed integers sign-extended to 64 bits"""
+        nb = Shard._FACET_BITS[ty]
+        if ty[0] == "i" and nb < 64 and (int(v) >> (nb - 1)) & 1:
+            return int(v) | (0xFFFFFFFFFFFFFFFF & ~((1 << nb) - 1))
+        return int(v)
+
+    @staticmethod
+    def _facet_type_range(ty):
+        """(smallest, largest) value of the type in ss_facet_filter's form"""
+        nb = Shard._FACET_BITS[ty]
+        if ty[0] == "u":
+            return 0, (1 << nb) - 1
+        if ty[0] == "i":
+            return Shard._facet_filter_bits(1 << (nb - 1), ty), (1 << (nb - 1)) - 1
+        return (0xFF800000, 0x7F800000) if nb == 32 else (0xFFF0000000000000, 0x7FF0000000000000)  # -inf, +inf
+
+    def facet_kth(self, query, facet_offset, facet_type, descending, k, facet_filter=None):
+        """the pivot of a result sort: (stored bits of the k-th best value among the query's matches, matches strictly better,
+        matches equal, all matches) -- ss_bm25_facet_kth"""
+        farr, nf = self.facet_filters(facet_filter) if facet_filter else (None, 0)
+        q = np.ascontiguousarray(query[:1])
+        v, nb, ne, tot = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        N.check(N.lib().ss_bm25_facet_kth(self._h, q.ctypes.data, nf, None if farr is None else C.cast(farr, C.c_void_p),
+                                          int(facet_offset), N.FACET_TYPES[facet_type], 1 if descending else 0, int(k), C.byref(v),
+                                          C.byref(nb), C.byref(ne), C.byref(tot)), "ss_bm25_facet_kth")
+        return v.value, nb.value, ne.value, tot.value
+
+    def facet_values(self, doc_ids, facet_offset, facet_type):
+        d = np.ascontiguousarray(doc_ids, np.uint32)
+        out = np.zeros(len(d), np.uint64)
+        N.check(N.lib().ss_facet_values(self._h, len(d), N.ptr(d, N.u32p), int(facet_offset), N.FACET_TYPES[facet_type],
+                                        N.ptr(out, N.u64p)), "ss_facet_values")
+        return out
+
+    def search_lexical_sorted(self, query, result_sort, k, facet_filter=None):
+        """ONE query (a 1-element make_queries array) with result_sort = [(facet offset, type, descending)], the reference's
+        Vec<ResultSort> over numeric facets: the k best matches under (field 1, field 2, ..., score), each field ascending or
+        descending, the score descending last (result_ordering_shard, min_heap.rs:574-1050) -> (doc ids, scores, total).
+        Composed from ordinary searches around the sort's pivot: the k-th best value of the first field among the matches
+        (ss_bm25_facet_kth) splits them into "strictly better" -- fewer than k docs, fetched by a search filtered to that
+        range and ordered here by their values -- and "equal", of which the best by the REMAINING sort fields fill the rest."""
+        flt = list(facet_filter or [])
+        if len(flt) + len(result_sort) > N.SS_MAX_FACET_FILTERS:
+            raise ValueError("at most %d facet filters + sort fields" % N.SS_MAX_FACET_FILTERS)
+        q = np.ascontiguousarray(query[:1])
+        total = [None]
+
+        def topk(sorts, kk, filters):
+            if kk == 0:
+                return []
+            if not sorts:
+                doc, score, cnt, tot = self.search_lexical_batch(q, kk, ResultType.TopkCount, facet_filter=filters or None)
+                if total[0] is None:
+                    total[0] = int(tot[0])
+                return [(int(doc[0][i]), float(score[0][i])) for i in range(int(cnt[0]))]
+            off, ty, desc = sorts[0]
+            nbits = self._FACET_BITS[ty]
+            v, n_better, n_equal, tot = self.facet_kth(q, off, ty, desc, kk, filters or None)
+            if total[0] is None:
+                total[0] = tot
+            if tot == 0:
+                return []
+            out = []
+            vb = self._facet_filter_bits(v, ty)
+            lo_all, hi_all = self._facet_type_range(ty)
+            if n_better:
+                # strictly better than the pivot: above it for a descending sort, below it for an ascending one
+                better = ((off, ty, vb, hi_all, "bits", N.FACET_LO_EXCLUSIVE | N.FACET_HI_INCLUSIVE) if desc
+                          else (off, ty, lo_all, vb, "bits", 0))
+                got = topk([], n_better, filters + [better])
+                docs = [d for d, _ in got]
+                keys = [[self._facet_order_key(x, t_, d_) for x in self.facet_values(docs, o_, t_)] for (o_, t_, d_) in sorts]
+                order = sorted(range(len(got)), key=lambda i: tuple(-kk_[i] for kk_ in keys) + (-got[i][1], got[i][0]))
+                out += [got[i] for i in order]
+            if n_better < kk and n_equal:
+                out += topk(sorts[1:], kk - n_better, filters + [(off, ty, vb, vb, "bits", N.FACET_HI_INCLUSIVE)])
+            return out
+
+        res = topk(list(result_sort), int(k), flt)
+        return (np.array([d for d, _ in res], np.uint32), np.array([s_ for _, s_ in res], np.float32), int(total[0] or 0))
 
     def facet_count(self, query, facet_offset, facet_type, n_buckets=None, range_lower_bounds=None, facet_filter=None):
         """query_facets of one query (facet_count, add_result.rs:484-640): histogram of the facet over the match set.

@@ -1028,3 +1028,50 @@ def test_full_size_properties_c2_c3(S, O):
         rows = np.stack([sh.read_rows_i8(int(r), 1)[0] for r in d8[i, :5]]).astype(np.int64)
         assert np.array_equal((rows @ q8[i].astype(np.int64)).astype(np.float32), s8[i, :5])
     sh.close()
+
+
+def test_result_sort_by_facets(S, O, lex):
+    """result_sort (search.rs ResultSort; ordering min_heap.rs:574-1050): the k best matches under (facet fields..., score) --
+    composed from the pivot (ss_bm25_facet_kth: radix select over the match set) and filtered searches.  Against a brute-force
+    ordering of the oracle's full match list: one and two sort fields, ascending / descending, every numeric width and sign,
+    floats, low-cardinality fields (huge tie groups), fewer matches than k, on top of a facet filter and tombstones."""
+    sh, osh, n_docs = lex
+    rng = np.random.default_rng(17)
+    rec = np.dtype([("a", "u1"), ("c", "<i4"), ("d", "<f4"), ("e", "<u8"), ("f", "<i2"), ("g", "<f8"), ("h", "<u2")])
+    v = np.zeros(n_docs, rec)
+    v["a"] = rng.integers(0, 4, n_docs); v["c"] = rng.integers(-1000, 1000, n_docs); v["d"] = rng.standard_normal(n_docs)
+    v["e"] = rng.integers(0, 1 << 62, n_docs, dtype=np.uint64); v["f"] = rng.integers(-3, 3, n_docs)
+    v["g"] = rng.random(n_docs) * 1e6 - 5e5; v["h"] = rng.integers(0, 50000, n_docs)
+    sh.upload_facets(v.view(np.uint8).reshape(n_docs, rec.itemsize))
+    off = {n: rec.fields[n][1] for n in rec.names}
+    ty = {"a": "u8", "c": "i32", "d": "f32", "e": "u64", "f": "i16", "g": "f64", "h": "u16"}
+    gone = list(range(5, n_docs, 211))
+    cases = [([10, 9, 8], S.QueryType.Union, O.OP_OR), ([10, 9], S.QueryType.Intersection, O.OP_AND), ([3], S.QueryType.Union, O.OP_OR)]
+    sorts = [[("c", True)], [("c", False)], [("d", True)], [("g", False)], [("e", True)], [("h", False)],
+             [("a", True), ("c", False)], [("f", False), ("a", True)], [("a", False), ("f", True), ("d", True)]]
+    try:
+        for deleted in (False, True):
+            sh.set_deleted(gone if deleted else [])
+            osh.set_deleted(gone if deleted else [])
+            for terms, qt, oop in cases:
+                q = sh.make_queries([terms], qt)
+                ad, as_, atot = osh.search_exhaustive(terms, oop, n_docs)  # every match, by score
+                for srt in sorts:
+                    for k, flt in ((10, None), (37, [(off["h"], "u16", 1000, 30000)]), (atot + 5 if atot < 2000 else 100, None)):
+                        keep = np.ones(len(ad), bool) if flt is None else (v["h"][ad] >= 1000) & (v["h"][ad] < 30000)
+                        md, ms = ad[keep], as_[keep]
+                        cols = []
+                        for name, desc in srt:
+                            x = v[name][md].astype(np.float64) if ty[name][0] == "f" else v[name][md].astype(object)
+                            cols.append([(-t if desc else t) for t in x.tolist()])
+                        order = sorted(range(len(md)), key=lambda i: tuple(c[i] for c in cols) + (-float(ms[i]),))[:k]
+                        doc, score, tot = sh.search_lexical_sorted(q, [(off[n], ty[n], d_) for n, d_ in srt], k, facet_filter=flt)
+                        assert tot == len(md), (terms, srt, k, tot, len(md))
+                        assert len(doc) == len(order)
+                        # the sort-field values must agree position by position; docs may swap only inside groups whose fields AND scores tie
+                        for name, _ in srt:
+                            assert np.array_equal(v[name][doc], v[name][md[order]]), (terms, srt, k, name)
+                        assert np.allclose(score, ms[order], rtol=1e-4), (terms, srt, k)
+    finally:
+        sh.set_deleted([])
+        osh.set_deleted([])
