@@ -29,9 +29,10 @@
  *   - unused result slots hold doc id SS_NO_DOC and score 0;
  *   - per-shard request size is offset+length with offset 0 (search.rs:1658-1659): `k` below;
  *   - thread-safe: the host side of concurrent calls on one handle is serialised (a mutex around validation and launch
- *     queuing); the DEVICE side of the *_dev BM25 searches is not -- searches queued on different streams of one shard run
- *     concurrently, each stream with its own workspace (searches sharing a stream run in order).  The vector searches and the
- *     facet-filtered BM25 search keep one workspace per shard: queue them on one stream per shard.  Destroy must not race.
+ *     queuing); the DEVICE side of the *_dev searches is not -- BM25 and vector (AnnMode::All) searches queued on different
+ *     streams of one shard run concurrently, each stream with its own workspace (searches sharing a stream run in order).
+ *     The ANN modes and the facet-filtered BM25 search keep one workspace per shard: queue those on one stream per shard.
+ *     An image upload / rebuild must not race with searches still queued on foreign streams.  Destroy must not race.
  * Plain C types only: no torch / HIP types in any signature (streams cross as void*).
  */
 #ifndef SEEKSTORM_HIP_H

@@ -73,7 +73,31 @@ int ss_shard_create(int device, ss_shard** out) {
   return SS_OK;
 }
 
+// RAII: a search on a stream other than the shard's own runs on that stream's set of scan buffers (swapped into the shard's
+// fields while the launches are enqueued -- under s->mu -- and back afterwards; buffers are allocated lazily by the scan code)
+struct VecWsBind {
+  ss_shard* s;
+  ss_vec_ws* w = nullptr;
+  VecWsBind(ss_shard* s_, hipStream_t st) : s(s_) {
+    if (st == s->stream) return;
+    w = &s->vec_ws[st];
+    swap();
+  }
+  ~VecWsBind() { if (w) swap(); }
+  void swap() {
+    std::swap(s->d_Qf, w->d_Qf);
+    std::swap(s->d_vstate, w->d_vstate);
+    std::swap(s->d_cand, w->d_cand);
+    std::swap(s->d_qaux, w->d_qaux);
+  }
+};
+
 static void free_vec(ss_shard* s) {
+  for (auto& kv : s->vec_ws) {
+    void* wp[] = {kv.second.d_Qf, kv.second.d_vstate, kv.second.d_cand, kv.second.d_qaux};
+    for (void* p : wp) if (p) (void)hipFree(p);
+  }
+  s->vec_ws.clear();
   void* ptrs[] = {s->d_X, s->d_X8, s->d_row_scale, s->d_row_doc, s->d_Qf, s->d_vstate, s->d_cand, s->d_row_field, s->d_row_norm, s->d_row_sq, s->d_qaux};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->d_X = nullptr; s->d_X8 = nullptr; s->d_row_scale = nullptr; s->d_row_doc = nullptr; s->d_Qf = nullptr;
@@ -926,6 +950,7 @@ int ss_vec_search_ann_dev(ss_shard* s, uint32_t nq, const float* d_queries, uint
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   hipStream_t st = stream ? (hipStream_t)stream : s->stream;
+  VecWsBind bind(s, st);
   return ssi_vec_search(s, nq, d_queries, nullptr, k, thr, d_out_doc, d_out_score, d_out_count, d_out_total, st, false, mode,
                         mode ? d_out_clusters : nullptr);
 }
@@ -1116,6 +1141,7 @@ int ss_vec_search_i8_euclid_dev(ss_shard* s, uint32_t nq, const int8_t* d_querie
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   hipStream_t st = stream ? (hipStream_t)stream : s->stream;
+  VecWsBind bind(s, st);
   return ssi_vec_search(s, nq, d_queries, d_query_scale, k, thr, d_out_doc, d_out_score, d_out_count, d_out_total, st, false, mode,
                         mode ? d_out_clusters : nullptr, d_query_norm);
 }

@@ -113,6 +113,17 @@ struct ss_bm_ws {
   size_t part_cap = 0;
 };
 
+// The vector scans' per-batch buffers (queries in fragment order, thresholds / counters, candidate keys, i8 Euclidean side
+// values): the shard's own set serves its own stream; a _dev search on another stream gets a set of its own, so that scans
+// queued on different streams of one shard overlap safely.  (The ANN preparation buffers stay per shard: ANN searches of
+// one shard must be stream-ordered.)
+struct ss_vec_ws {
+  float* d_Qf = nullptr;
+  uint32_t* d_vstate = nullptr;
+  uint64_t* d_cand = nullptr;
+  float* d_qaux = nullptr;
+};
+
 struct ss_shard {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -148,6 +159,7 @@ struct ss_shard {
   float* d_Qf = nullptr;
   uint32_t* d_vstate = nullptr;  // tau[64] | cnt[64] | kept[64] | flags[64] | total_lo/hi ...
   uint64_t* d_cand = nullptr;    // [64][VS_CAP]
+  std::map<hipStream_t, ss_vec_ws> vec_ws;  // the same four buffers for searches on other streams than the shard's own
   void* d_qstage = nullptr;      // host-variant staging of queries (grow-only)
   size_t qstage_cap = 0;
   uint32_t* d_out_doc = nullptr; // host-variant staging of outputs

@@ -210,3 +210,52 @@ def test_bm25_searches_on_two_streams_of_one_shard_overlap_safely(S, O, lex):
         d1, s1, c1, t1 = sh.search_lexical_batch(q, k)  # the same batch alone, through the host-pointer entry point
         assert np.array_equal(os_.cpu().numpy(), s1) and np.array_equal(od.cpu().numpy().view(np.uint32), d1)
         assert np.array_equal(ot.cpu().numpy().view(np.uint64), t1)
+
+
+def test_vector_searches_on_two_streams_of_one_shard_overlap_safely(S, O):
+    """per-stream scan buffers: device-pointer vector searches queued on two different streams of ONE shard (different
+    batches, interleaved, repeated) each return what they return alone -- f32 and i8"""
+    import torch
+    from seekstorm_amd import _native as N
+    dev = torch.device("cuda", 0)
+    n_rows, dim, k = 300_000, 256, 20
+    L = S.lib()
+    for i8 in (False, True):
+        sh = S.Shard(0)
+        if i8:
+            sh.synth_vectors_i8(O.VEC_SEED, n_rows, dim)
+        else:
+            sh.synth_vectors(O.VEC_SEED, n_rows, dim)
+        qs = [O.vec_gen(O.VECQ_SEED, 0, 64, dim), O.vec_gen(O.VECQ_SEED, 64, 40, dim)]
+        if i8:
+            qd = [torch.from_numpy(O.quantize_i8(q)).to(dev) for q in qs]
+        else:
+            qd = [torch.from_numpy(q).to(dev) for q in qs]
+        streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        outs = [[torch.empty((len(q), k), dtype=torch.int32, device=dev), torch.empty((len(q), k), dtype=torch.float32, device=dev),
+                 torch.empty((len(q),), dtype=torch.int32, device=dev), torch.empty((len(q),), dtype=torch.int64, device=dev)] for q in qs]
+
+        def call(j, st):
+            o = outs[j]
+            if i8:
+                N.check(L.ss_vec_search_i8_dev(sh._h, len(qs[j]), qd[j].data_ptr(), None, k, N.FLT_MIN_NEG, o[0].data_ptr(), o[1].data_ptr(),
+                                               o[2].data_ptr(), o[3].data_ptr(), st), "ss_vec_search_i8_dev")
+            else:
+                N.check(L.ss_vec_search_dev(sh._h, len(qs[j]), qd[j].data_ptr(), k, N.FLT_MIN_NEG, o[0].data_ptr(), o[1].data_ptr(),
+                                            o[2].data_ptr(), o[3].data_ptr(), st), "ss_vec_search_dev")
+        alone = []
+        for j in (0, 1):  # each batch alone on the shard's own stream
+            call(j, None)
+            N.check(L.ss_shard_sync(sh._h), "sync")
+            alone.append([t.clone() for t in outs[j][:3]])
+        torch.cuda.synchronize()
+        for rep in range(6):
+            for t in outs[0] + outs[1]:
+                t.zero_()
+            torch.cuda.synchronize()
+            for j in ((0, 1) if rep % 2 == 0 else (1, 0)):
+                call(j, streams[j].cuda_stream)
+            torch.cuda.synchronize()
+            for j in (0, 1):
+                assert torch.equal(outs[j][2], alone[j][2]) and torch.equal(outs[j][0], alone[j][0]) and torch.equal(outs[j][1], alone[j][1]), (i8, rep, j)
+        sh.close()
