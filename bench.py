@@ -182,6 +182,10 @@ def main():
         est = max(time.perf_counter() - t0, 1e-5)
         n = min_calls if args.min_seconds > 0 else 3
         n = int(min(max(n, args.min_seconds / est), 20000))
+        if world > 1:  # every rank must issue the same number of calls: each one holds a collective
+            t = torch.tensor([n], device=dev, dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            n = int(t.item())
         return n, timed(call_fn, n, 2)
 
     def latencies(call_fn, n):
