@@ -35,14 +35,17 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: FP32 matrix peak
 
 
+KERNEL_SOURCES = ("bm25.hip", "bm25_dev.h", "bm25_fast.hip", "bm25_probe.hip", "bm25_scan16.hip", "ss_common.h", "vec8_scan.hip",
+                  "vec_scan.hip")
+
+
 def kernel_source_hash():
     """hash of the kernel sources: profiles/pmc_traffic.json is only used when it was collected on THESE kernels"""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "seekstorm_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in KERNEL_SOURCES:  # the files that define the measured kernels (not the loaders, the ABI layer, the generators)
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -177,6 +177,11 @@ int ss_bm25_upload_index_bin_fields(ss_shard* s, const ss_index_bin* ix, const f
  * field_out / tf_out [65536 * n_fields] */
 int ss_ref_decode_block_fields(const ss_ref_block* block, uint32_t n_fields, uint32_t longest_field_id, uint16_t* docs_out,
                                uint32_t* first_out, uint8_t* field_out, uint16_t* tf_out);
+/* an N-GRAM key's block in a multi-field index: every record starts with the field vector of each component term (2 or 3,
+ * index_posting.rs:664-722 / add_result.rs:1524-1600) before the n-gram's own; output = component `component`'s vector */
+int ss_ref_decode_block_fields_ngram(const ss_ref_block* block, uint32_t n_fields, uint32_t longest_field_id, uint32_t n_components,
+                                     uint32_t component, uint16_t* docs_out, uint32_t* first_out, uint8_t* field_out,
+                                     uint16_t* tf_out);
 
 /* Device-side synthetic corpus (bench/test utility; generator = oracle so_lex_*):
  * posting (t,d) iff (h(seed,t+1,d)>>32) < thresh32[t]; bit-identical to ss_bm25_upload of the same corpus. */

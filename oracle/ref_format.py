@@ -164,22 +164,25 @@ def encode_term(docs, tfs, rng, base_bytes=b"", positions_limit=32768, max_gap=4
 
 
 # ------------------------------------------------------------------------------------------------ index.bin / vector.bin
-def encode_term_fields(docs, fields, tfs, n_fields, longest_field_id, rng, positions_limit=32768, max_gap=40):
-    """(doc, field, tf) entries sorted by (doc, field) -> per-block key bodies like encode_term"""
+def encode_term_fields(docs, fields, tfs, n_fields, longest_field_id, rng, positions_limit=32768, max_gap=40, ngram_vecs=None):
+    """(doc, field, tf) entries sorted by (doc, field) -> per-block key bodies like encode_term
+    ngram_vecs: {doc: [[(field, tf), ...] per component term]} for an n-gram key"""
     docs = np.asarray(docs, np.int64)
     fields = np.asarray(fields, np.int64)
     out = []
     bid = docs >> 16
     for b in np.unique(bid):
         sel = np.nonzero(bid == b)[0]
-        local, postings = [], []
+        local, postings, full = [], [], []
         for i in sel:
             d = int(docs[i]) & 0xFFFF
             if not local or local[-1] != d:
                 local.append(d)
+                full.append(int(docs[i]))
                 postings.append([])
             postings[-1].append((int(fields[i]), random_positions(rng, int(tfs[i]), max_gap)))
-        body, ctp, cnt, pivot = encode_key_body_fields(local, postings, n_fields, longest_field_id, 0, positions_limit)
+        nv = None if ngram_vecs is None else [ngram_vecs[d] for d in full]
+        body, ctp, cnt, pivot = encode_key_body_fields(local, postings, n_fields, longest_field_id, 0, positions_limit, nv)
         out.append((int(b), ctp, cnt, pivot, body))
     return out
 
@@ -223,7 +226,16 @@ def write_index_bin(n_docs, doclen_bytes, terms, rng, segment_number_bits=11, ke
         per_term_blocks.append({b[0]: b for b in blocks})
     terms = list(terms)
     head_extra = [bytes(key_head_size - 20)] * len(terms)
-    for key, docs, counts, comp_tfs, df_bytes in ngram_terms:
+    for gt in ngram_terms:
+        if n_fields > 1:  # (key_hash, docs, fields, counts, {doc: component field vectors}, df bytes): entries sorted by (doc, field)
+            key, docs, flds, counts, comp_vecs, df_bytes = gt
+            assert key & 7 and len(df_bytes) == ngram_components(key) <= key_head_size - 20
+            blocks = encode_term_fields(docs, flds, counts, n_fields, longest_field_id, rng, positions_limit, ngram_vecs=comp_vecs)
+            per_term_blocks.append({b[0]: b for b in blocks})
+            terms.append((key,))
+            head_extra.append(bytes(int(x) for x in df_bytes) + bytes(key_head_size - 20 - len(df_bytes)))
+            continue
+        key, docs, counts, comp_tfs, df_bytes = gt
         assert n_fields == 1 and key & 7 and len(df_bytes) == ngram_components(key) <= key_head_size - 20
         blocks = encode_term(docs, counts, rng, positions_limit=positions_limit, ngram_tfs=np.asarray(comp_tfs))
         per_term_blocks.append({b[0]: b for b in blocks})
@@ -384,8 +396,10 @@ def embed_fields(field_deltas, only_longest, id_bits, pointer_size):
     return bytes([data & 0xFF, (data >> 8) & 0xFF, top & 0xFF])
 
 
-def encode_key_body_fields(local_docs, postings, n_fields, longest_field_id, base=0, positions_limit=32768):
-    """postings[i] = [(field id, [positions ascending]), ...] non-empty fields in ascending field order
+def encode_key_body_fields(local_docs, postings, n_fields, longest_field_id, base=0, positions_limit=32768, ngram_vecs=None):
+    """ngram_vecs[i] = [[(field id, tf), ...] per component term] for an n-gram key (index_posting.rs:664-722: never embedded, the
+    components' field vectors written with write_field_vec in front of the n-gram's own)
+    postings[i] = [(field id, [positions ascending]), ...] non-empty fields in ascending field order
     -> (body, compression_type_pointer, posting_count, pointer_pivot_p_docid), as encode_key_body"""
     id_bits = field_id_bits(n_fields)
     size_positions, pivot, three = 0, 0, False
@@ -398,11 +412,17 @@ def encode_key_body_fields(local_docs, postings, n_fields, longest_field_id, bas
             pivot, psize = rank + 1, 2
         else:
             psize, three = 3, True
-        # embedding is only ever tried for <= 4 positions in fields of <= 4 positions (index_posting.rs:433-438)
-        if total <= 4 and embeddable_fields(fd, only_longest, id_bits, psize):
+        # embedding is only ever tried for <= 4 positions in fields of <= 4 positions (index_posting.rs:433-438), and never
+        # for an n-gram key (445)
+        if ngram_vecs is None and total <= 4 and embeddable_fields(fd, only_longest, id_bits, psize):
             pointers.append(embed_fields(fd, only_longest, id_bits, psize))
             continue
-        rec = write_field_vec([(fid, len(ds)) for fid, ds in fd], only_longest, id_bits) + \
+        head = b""
+        if ngram_vecs is not None:  # the component terms' field vectors first (index_posting.rs:664-722)
+            for cv in ngram_vecs[rank]:
+                cv = [(int(f), int(c)) for f, c in cv]
+                head += write_field_vec(cv, len(cv) == 1 and cv[0][0] == longest_field_id, id_bits)
+        rec = head + write_field_vec([(fid, len(ds)) for fid, ds in fd], only_longest, id_bits) + \
             b"".join(position_vint(x) for _, ds in fd for x in ds)
         if psize == 2 and size_positions + len(rec) >= positions_limit:
             psize, pivot, three = 3, rank, True

@@ -86,6 +86,7 @@ SYMBOLS = [
     ("ss_ref_decode_block_positions", C.c_int, [C.c_void_p, u16p, u16p, u16p, C.c_uint64, u64p]),
     ("ss_bm25_upload_index_bin_fields", C.c_int, [C.c_void_p, C.c_void_p, f32p]),
     ("ss_ref_decode_block_fields", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, u16p, u32p, u8p, u16p]),
+    ("ss_ref_decode_block_fields_ngram", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u16p, u32p, u8p, u16p]),
     ("ss_synth_set_partition", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     ("ss_bm25_synth", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, u32p, u8p]),
     ("ss_bm25_info", C.c_int, [C.c_void_p, u64p, f32p, u32p, u64p]),

@@ -223,7 +223,8 @@ namespace {
 struct FieldEntry { uint8_t field; uint32_t tf; };
 
 // read_multifield_vec, more than one indexed field (add_result.rs:2229-2293)
-bool read_field_vec(const uint8_t* a, uint64_t len, uint64_t pos, uint32_t id_bits, uint32_t longest, FieldEntry* out, int* n_out) {
+bool read_field_vec(const uint8_t* a, uint64_t len, uint64_t pos, uint32_t id_bits, uint32_t longest, FieldEntry* out, int* n_out,
+                    uint64_t* end_out = nullptr) {
   if (pos >= len) return false;
   int n = 0;
   if (a[pos] & 0x40u) {  // only the longest field: count in 6 + 7 (+ 7) bits
@@ -263,16 +264,36 @@ bool read_field_vec(const uint8_t* a, uint64_t len, uint64_t pos, uint32_t id_bi
     }
   }
   *n_out = n;
+  if (end_out) *end_out = pos;
   return true;
 }
+int decode_block_fields(const ss_ref_block* b, uint32_t n_fields, uint32_t longest_field_id, uint32_t n_components, uint32_t component,
+                        uint16_t* docs_out, uint32_t* first_out, uint8_t* field_out, uint16_t* tf_out);
 }  // namespace
 
 // Decodes one block of a multi-field index: docs_out [65536], first_out [65537] = CSR of the field entries per posting,
 // field_out / tf_out [65536 * n_fields].  Returns the posting count or a negative code.
 extern "C" int ss_ref_decode_block_fields(const ss_ref_block* b, uint32_t n_fields, uint32_t longest_field_id, uint16_t* docs_out,
                                           uint32_t* first_out, uint8_t* field_out, uint16_t* tf_out) {
+  return decode_block_fields(b, n_fields, longest_field_id, 1, 0, docs_out, first_out, field_out, tf_out);
+}
+// The same for a block of an N-GRAM key of a multi-field index: never embedded, and every record starts with the field
+// vector of each component term -- 2 for the bigram types, 3 for the trigram types -- before the n-gram's own
+// (index_posting.rs:664-722 writes them with write_field_vec one after the other; decode_positions_multiterm_multifield
+// reads them into field_vec_ngram1..3, add_result.rs:1524-1600).  Output = the field vector of component `component`: what
+// the n-gram arms of get_bm25f_multiterm_multifield (add_result.rs:1171-1426) score with idf_ngram{1,2,3}.
+extern "C" int ss_ref_decode_block_fields_ngram(const ss_ref_block* b, uint32_t n_fields, uint32_t longest_field_id,
+                                                uint32_t n_components, uint32_t component, uint16_t* docs_out, uint32_t* first_out,
+                                                uint8_t* field_out, uint16_t* tf_out) {
+  if (n_components < 2 || n_components > 3 || component >= n_components) return SS_EINVAL;
+  return decode_block_fields(b, n_fields, longest_field_id, n_components, component, docs_out, first_out, field_out, tf_out);
+}
+namespace {
+int decode_block_fields(const ss_ref_block* b, uint32_t n_fields, uint32_t longest_field_id, uint32_t n_components, uint32_t component,
+                        uint16_t* docs_out, uint32_t* first_out, uint8_t* field_out, uint16_t* tf_out) {
   if (!b || !b->byte_array || !docs_out || !first_out || !field_out || !tf_out || n_fields < 2 || n_fields > 8 ||
       longest_field_id >= n_fields) return SS_EINVAL;
+  const bool ngram = n_components > 1;
   // doc ids: the container walk of the single-field reader (tf output unused); run on a one-field view of the pointers
   // would misread them, so walk the container here again
   const uint8_t* a = b->byte_array;
@@ -331,7 +352,13 @@ extern "C" int ss_ref_decode_block_fields(const ss_ref_block* b, uint32_t n_fiel
     const uint32_t p = two ? rd16(a + at) : rd24(a + at);
     if (!(p & (two ? 0x8000u : 0x800000u))) {  // record in the position area
       const uint64_t back = p & (two ? 0x7FFFu : 0x7FFFFFu);
-      if (back > range || !read_field_vec(a, len, range - back, id_bits, longest_field_id, e, &ne)) return SS_EINVAL;
+      if (back > range) return SS_EINVAL;
+      uint64_t at_rec = range - back;
+      for (uint32_t c = 0; c <= (ngram ? component : 0u); c++) {  // n-gram keys: the components' vectors come first
+        if (!read_field_vec(a, len, at_rec, id_bits, longest_field_id, e, &ne, &at_rec)) return SS_EINVAL;
+      }
+    } else if (ngram) {
+      return SS_EINVAL;  // n-gram postings are never embedded (index_posting.rs:445)
     } else if (two) {  // embedded, 2 bytes: tag = bits 15..12 (add_result.rs:1606-1737)
       const uint32_t tag = p >> 12, pb = 12u - id_bits;
       switch (tag) {
@@ -373,6 +400,7 @@ extern "C" int ss_ref_decode_block_fields(const ss_ref_block* b, uint32_t n_fiel
   first_out[count] = w;
   return (int)count;
 }
+}  // namespace
 
 extern "C" int ss_bm25_upload_ref_blocks(ss_shard* s, uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t n_terms,
                                          const uint64_t* term_block_offsets, const ss_ref_block* blocks) {
@@ -484,7 +512,7 @@ extern "C" int ss_index_bin_open(const uint8_t* bytes, uint64_t len, uint32_t in
         // list per component term (same docs, the component's tf): scored with idf_ngram_i each, their sum is the
         // n-gram arm of get_bm25f_multiterm_singlefield (add_result.rs:1454-1477).  Several fields: skipped.
         const uint32_t ntype = (uint32_t)(key & 7u), n_comp = ntype == 0 ? 1u : ntype <= 3u ? 2u : 3u;
-        if (ntype && (indexed_field_count != 1 || n_comp > key_head_size - 20u)) { ix->n_ngram_keys++; continue; }
+        if (ntype && n_comp > key_head_size - 20u) { ix->n_ngram_keys++; continue; }
         for (uint32_t c = 0; c < n_comp; c++) {
           ss_index_bin::Blk e;
           e.key = key;
@@ -635,7 +663,8 @@ int upload_index_bin_fields(ss_shard* s, const ss_index_bin* ix, const float* bo
     offs[t] = docs.size();
     for (uint64_t bi = ix->term_block_off[t]; bi < ix->term_block_off[t + 1]; bi++) {
       const ss_ref_block& b = ix->blocks[bi].b;
-      const int n = ss_ref_decode_block_fields(&b, F, ix->longest_field_id, d16.data(), first.data(), f8.data(), t16.data());
+      const int n = decode_block_fields(&b, F, ix->longest_field_id, ix->blocks[bi].n_comp, ix->blocks[bi].comp, d16.data(), first.data(),
+                                        f8.data(), t16.data());
       if (n < 0) return n;
       for (int i = 0; i < n; i++) {
         const uint64_t doc = ((uint64_t)b.block_id << 16) | d16[i];

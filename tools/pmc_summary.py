@@ -19,14 +19,17 @@ import sys
 from collections import defaultdict
 
 
+KERNEL_SOURCES = ("bm25.hip", "bm25_dev.h", "bm25_fast.hip", "bm25_probe.hip", "bm25_scan16.hip", "ss_common.h", "vec8_scan.hip",
+                  "vec_scan.hip")
+
+
 def kernel_source_hash():
     """the same hash bench.py computes: pmc_traffic.json is only believed for the kernel sources it was collected on"""
     h = hashlib.sha256()
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "seekstorm_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in KERNEL_SOURCES:  # the files that define the measured kernels (not the loaders, the ABI layer, the generators)
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
