@@ -570,3 +570,113 @@ def test_positions_roundtrip(n, tf_hi, limit):
     cnt, d, t, pos = _decode_positions(blk)
     assert cnt == len(docs) and np.array_equal(d, docs) and np.array_equal(t, tfs)
     assert pos.tolist() == [p for pl in positions for p in pl]
+
+
+def _ngram_fields_corpus(rng, n, n_fields, longest, nc, span=65536):
+    """an n-gram key of a multi-field index: per doc the n-gram's own (field, positions count) entries and, per component term,
+    that term's field vector in the doc"""
+    docs = np.sort(rng.choice(span, size=n, replace=False))
+    d, f, t, vecs = [], [], [], {}
+    for doc in docs:
+        fs = np.sort(rng.choice(n_fields, size=int(rng.integers(1, n_fields + 1)), replace=False)) if rng.random() < 0.6 else np.array([longest])
+        for x in fs:
+            d.append(int(doc)); f.append(int(x)); t.append(int(min(rng.geometric(0.6), 20)))
+        cv = []
+        for c in range(nc):
+            if rng.random() < 0.4:
+                cf = [longest]
+            else:
+                cf = sorted(set(int(x) for x in fs) | set(int(x) for x in rng.choice(n_fields, size=int(rng.integers(1, n_fields + 1)), replace=False)))
+            cv.append([(x, int(rng.choice([1, 3, 70, 9000]))) for x in cf])
+        vecs[int(doc)] = cv
+    return np.array(d), np.array(f), np.array(t), vecs
+
+
+@pytest.mark.parametrize("n_fields,longest,nc,n,limit", [(2, 0, 2, 400, 32768), (3, 1, 3, 1500, 32768), (4, 3, 2, 900, 120), (8, 5, 3, 300, 32768)])
+def test_decode_ngram_blocks_of_a_multi_field_index(n_fields, longest, nc, n, limit):
+    """ss_ref_decode_block_fields_ngram: the records of an n-gram key in a multi-field index start with the field vector of
+    each component term (index_posting.rs:664-722, add_result.rs:1524-1600); every component comes back as its own
+    (field, tf) entries, 2- and 3-byte pointers, 1- to 3-byte vector entries"""
+    rng = np.random.default_rng(n_fields * 31 + n)
+    d, f, t, vecs = _ngram_fields_corpus(rng, n, n_fields, longest, nc)
+    blk = RF.encode_term_fields(d, f, t, n_fields, longest, rng, positions_limit=limit, max_gap=25, ngram_vecs=vecs)[0]
+    bid, ctp, cnt, pivot, body = blk
+    buf = np.frombuffer(body, np.uint8).copy()
+    rb = N.RefBlock(bid, ctp, cnt - 1, pivot, buf.ctypes.data, len(buf))
+    docs = np.unique(d)
+    for c in range(nc):
+        dd = np.zeros(65536, np.uint16); first = np.zeros(65537, np.uint32)
+        ff = np.zeros(65536 * n_fields, np.uint8); tt = np.zeros(65536 * n_fields, np.uint16)
+        got = N.lib().ss_ref_decode_block_fields_ngram(C.byref(rb), n_fields, longest, nc, c, N.ptr(dd, N.u16p), N.ptr(first, N.u32p),
+                                                       N.ptr(ff, N.u8p), N.ptr(tt, N.u16p))
+        assert got == len(docs) and np.array_equal(dd[:got], docs)
+        want = [e for doc in docs for e in vecs[int(doc)][c]]
+        assert int(first[got]) == len(want)
+        assert ff[:len(want)].tolist() == [e[0] for e in want] and tt[:len(want)].tolist() == [min(e[1], 65535) for e in want]
+    if limit < 32768:
+        assert 0 < pivot < cnt
+    # the SingleTerm reader misreads such a block or refuses it; the n-gram reader refuses a component that is not there
+    assert N.lib().ss_ref_decode_block_fields_ngram(C.byref(rb), n_fields, longest, nc, nc, None, None, None, None) == -1
+
+
+@pytest.mark.gpu
+def test_ngram_keys_of_a_multi_field_index_score_like_their_component_lists():
+    """index.bin with several indexed fields AND n-gram keys (the default index over several fields): every n-gram key becomes
+    one posting list per component term (its field vectors), scored with idf_ngram_i like the single-field arm -- the image
+    built from the file answers like the array upload of the same (term / component, field) lists and like the oracle"""
+    from oracle import oracle as O
+    rng = np.random.default_rng(77)
+    n_docs, n_fields, longest, head = 90_000, 3, 1, 23
+    dl = np.stack([O.lex_doclen(n_docs, seed=O.LEX_SEED + 5 * f) for f in range(n_fields)])
+    keys = sorted(int(k) & ~7 for k in rng.integers(1 << 40, 1 << 62, size=2, dtype=np.int64))
+    terms = []
+    for key, df in zip(keys, (15_000, 4_000)):
+        docs = np.sort(rng.choice(n_docs, size=df, replace=False))
+        d, f, t = [], [], []
+        for doc in docs:
+            fs = np.sort(rng.choice(n_fields, size=int(rng.integers(1, n_fields + 1)), replace=False)) if rng.random() < 0.6 else [longest]
+            for x in fs:
+                d.append(int(doc)); f.append(int(x)); t.append(int(min(rng.geometric(0.5), 30)))
+        terms.append((key, np.array(d), np.array(f), np.array(t)))
+    ngram = []
+    for ty, df in ((2, 5_000), (5, 1_200)):  # a bigram and a trigram key
+        nc = RF.ngram_components(ty)
+        d, f, t, vecs = _ngram_fields_corpus(rng, df, n_fields, longest, nc, span=n_docs)
+        key = (int(rng.integers(1 << 40, 1 << 62)) & ~7) | ty
+        df_bytes = [O.lib().so_int_to_byte4(int(x)) for x in rng.integers(df, n_docs, nc)]
+        ngram.append((key, d, f, t, vecs, df_bytes))
+    data = RF.write_index_bin(n_docs, dl, terms, rng, key_head_size=head, n_fields=n_fields, longest_field_id=longest, ngram_terms=ngram)
+    ix = S.IndexBin(data, n_fields, head)
+    assert ix.term_count == 2 + 2 + 3
+    boost = [1.5, 1.0, 0.5]
+    a, b = S.Shard(0), S.Shard(0)
+    a.upload_index_bin(ix, boost)
+    # the same lists as arrays: device term ids follow the key order; an n-gram key contributes its components in order
+    entries = sorted([(t_[0], "term", t_) for t_ in terms] + [(g[0], "gram", g) for g in ngram], key=lambda e: e[0])
+    offs, D, F, T = [0], [], [], []
+    for key, kind, e in entries:
+        if kind == "term":
+            D += e[1].tolist(); F += e[2].tolist(); T += e[3].tolist(); offs.append(len(D))
+        else:
+            docs = np.unique(e[1])
+            for c in range(RF.ngram_components(key)):
+                for doc in docs:
+                    for fld, tf in e[4][int(doc)][c]:
+                        D.append(int(doc)); F.append(fld); T.append(min(tf, 65535))
+                offs.append(len(D))
+    b.upload_lexical_fields(n_docs, dl, boost, np.array(offs, np.uint64), np.array(D, np.uint32), np.array(F, np.uint8), np.array(T, np.uint16))
+    assert a.lexical_info() == b.lexical_info()
+    grams = [ix.terms_of_key(g[0]) for g in ngram]
+    assert sorted(len(g) for g in grams) == [2, 3]
+    single = [ix.term_of_key(t_[0]) for t_ in terms]
+    for qt in (S.QueryType.Union, S.QueryType.Intersection):
+        for keyset in ([grams[0]], [grams[1], [(single[0], None)]], [grams[0], grams[1], [(single[1], None)]]):
+            tl = [t_ for g in keyset for t_, _ in g]
+            idf_of = {t_: w for g in keyset for t_, w in g if w is not None}
+            ra = a.search_lexical_batch(a.make_queries([tl], qt, idf_of=idf_of), 10)
+            rb_ = b.search_lexical_batch(b.make_queries([tl], qt, idf_of=idf_of), 10)
+            for x, y in zip(ra, rb_):
+                assert np.array_equal(x, y)
+            assert int(ra[3][0]) > 0
+    a.close()
+    b.close()
