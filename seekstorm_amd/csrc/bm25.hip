@@ -73,6 +73,43 @@ __global__ void __launch_bounds__(1024) bm25_merge_kernel(const u64* __restrict_
   for (uint32_t i = threadIdx.x; i < KS; i += blockDim.x) dst[i] = i < np ? keys[i] : 0ull;
 }
 
+// Small k and P <= 64 lists (the pruned kernel's usual shape: 24 partitions, k = 10): a tournament instead of a sorting
+// network -- one wave per query, lane p holding the head of list p, k rounds of a wave-wide maximum; the winning lane
+// advances.  Keys are unique (doc ids of different partitions differ).  Writes the caller's outputs like the last merge pass.
+__global__ void __launch_bounds__(256) bm25_merge_small_kernel(const u64* __restrict__ in, uint32_t nq, uint32_t n_lists, uint32_t KS,
+                                                              const u64* __restrict__ fin_total, uint32_t k,
+                                                              uint32_t* __restrict__ fin_doc, float* __restrict__ fin_score,
+                                                              uint32_t* __restrict__ fin_count, u64* __restrict__ fin_out_total,
+                                                              const uint32_t* __restrict__ tau) {
+  const uint32_t q = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (q >= nq) return;
+  const u64* lst = in + ((size_t)q * n_lists + lane) * KS;
+  const bool have = lane < n_lists;
+  uint32_t cur = 0;
+  u64 head = have ? lst[0] : 0ull;
+  u64 mine = 0ull;
+  for (uint32_t r = 0; r < k; r++) {
+    u64 m = head;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const u64 x = shflx64(m, o); m = x > m ? x : m; }
+    if (m == 0ull) break;  // wave-uniform: every list is exhausted
+    if (lane == r) mine = m;
+    if (have && head == m) {
+      cur++;
+      head = cur < KS ? lst[cur] : 0ull;
+    }
+  }
+  if (lane < k) {
+    fin_doc[(size_t)q * k + lane] = mine ? 0xFFFFFFFFu - (uint32_t)mine : SS_NO_DOC;
+    fin_score[(size_t)q * k + lane] = mine ? __uint_as_float((uint32_t)(mine >> 32)) : 0.f;
+  }
+  const uint32_t n_res = (uint32_t)__popcll(__ballot(mine != 0ull));
+  if (lane == 0) {
+    fin_count[q] = tau[(size_t)q * BM_TAU_STRIDE + 1] ? 0xFFFFFFFFu : n_res;
+    fin_out_total[q] = fin_total[q];
+  }
+}
+
 __global__ void bm25_final_kernel(const u64* __restrict__ keys, const u64* __restrict__ total, uint32_t KS, uint32_t k,
                                   uint32_t* __restrict__ out_doc, float* __restrict__ out_score,
                                   uint32_t* __restrict__ out_count, u64* __restrict__ out_total, const uint32_t* __restrict__ tau) {
@@ -117,7 +154,7 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
   total[i] = 0ull;                      // per-query match count and shared threshold start from zero (no separate memset launch)
   tau[(size_t)i * BM_TAU_STRIDE] = 0u;
   const ss_bm25_query Q = q[i];
-  bm_vquery V;
+  bm_vquery& V = vq[i];  // written in place: a local copy indexed at run time would live in scratch
   const uint32_t np = Q.n_terms, n_not = bm_q_nnot(Q.op);
   {
     const uint32_t nt_claim = (claim >> 8) & 0xFFu, np_claim = (claim >> 16) & 0xFFu, ff = n_fields > 1 ? bm_q_field_filter(Q.op) : 0u;
@@ -155,7 +192,6 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
       for (uint32_t j = 0; j < (uint32_t)BM_MAX_VTERMS; j++) { V.term[j] = j ? 0 : n_vterms; V.idf[j] = 0.f; V.and_val[j] = 0; V.group[j] = j ? 0xFF : 0; }
       V.phrase_len = (claim & BM_CLAIM_PHRASE) ? 2u : 0u;  // an empty phrase query: both words are the absent term
       for (int j = 0; j < SS_MAX_PHRASE; j++) V.phrase_seq[j] = 0;
-      vq[i] = V;
       return;
     }
   }
@@ -167,9 +203,9 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
   // all_terms_frequent (intersection.rs:198-209): the caller saw N > 256 k and df >= N / 2 for every term.  One field and
   // <= 7 terms (bit 7 of the match byte becomes the "some tf < 10" mark; the host refuses the rest).
   const bool freq = bm_q_all_frequent(Q.op) && bm_q_op(Q.op) == SS_OP_INTERSECTION && np > 1 && np <= 7 && n_fields == 1;
-  uint32_t n = 0;
+  uint32_t n = 0, n_scored = 0;
   for (uint32_t t = 0; t < np + n_not; t++) {
-    if (t == np) V.n_terms = n;
+    if (t == np) n_scored = n;
     for (uint32_t f = 0; f < n_fields; f++) {
       const uint32_t v = Q.term[t] * n_fields + f;
       // a term without postings in a field contributes nothing there (one field: kept, the zero-length list is harmless)
@@ -182,8 +218,8 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
       n++;
     }
   }
-  if (n_not == 0) V.n_terms = n;
-  const uint32_t n_scored = V.n_terms;
+  if (n_not == 0) n_scored = n;
+  V.n_terms = n_scored;
   V.op = (filt ? (uint32_t)SS_OP_INTERSECTION : np > 1 ? (bm_q_op(Q.op) == SS_OP_PHRASE ? (uint32_t)SS_OP_INTERSECTION : bm_q_op(Q.op)) : (uint32_t)SS_OP_UNION) |
          ((n - n_scored) << 8);
   V.n_groups = np;
@@ -191,7 +227,6 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
   for (uint32_t j = n; j < (uint32_t)BM_MAX_VTERMS; j++) { V.term[j] = 0; V.idf[j] = 0.f; V.and_val[j] = 0; V.group[j] = 0xFF; }
   V.phrase_len = bm_q_op(Q.op) == SS_OP_PHRASE ? Q.phrase_len : 0u;
   for (int j = 0; j < SS_MAX_PHRASE; j++) V.phrase_seq[j] = Q.phrase_seq[j];
-  vq[i] = V;
 }
 
 // ---------------------------------------------------------------- host side
@@ -343,6 +378,12 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
     if (rcc) return rcc;
   }
 
+  if (P > 1 && P <= 64 && k >= 1 && k <= 32 && k <= KS) {  // a tournament per query (one wave) instead of the sorting network
+    bm25_merge_small_kernel<<<(nq + 3) / 4, 256, 0, st>>>(bufA, nq, P, KS, total, k, d_out_doc, d_out_score, d_out_count,
+                                                         (u64*)d_out_total, tau);
+    SS_HIP(hipGetLastError());
+    return SS_OK;
+  }
   // merge tree over the P partition lists
   SS_SET_MAX_LDS(bm25_merge_kernel, 8192 * 8);
   uint32_t lists = P;
@@ -355,7 +396,9 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
     uint32_t np = 64;
     while (np < std::min(lists, group) * take) np <<= 1;
     const bool last = ng == 1;
-    bm25_merge_kernel<<<dim3(ng, nq), std::min<uint32_t>(1024u, std::max<uint32_t>(64u, np / 2)), 8192 * 8, st>>>(
+    // LDS for the keys this pass really sorts (a flat 64 KB request kept all but two workgroups off a CU: 26 -> 12 us per
+    // 1000 C2 queries)
+    bm25_merge_kernel<<<dim3(ng, nq), std::min<uint32_t>(1024u, std::max<uint32_t>(64u, np / 2)), (size_t)np * sizeof(u64), st>>>(
         src, dst, lists, group, KS, take, total, k, last ? 1u : 0u, d_out_doc, d_out_score, d_out_count, (u64*)d_out_total, tau);
     std::swap(src, dst);
     lists = ng;
