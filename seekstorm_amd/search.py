@@ -782,6 +782,9 @@ class Shard:
         """search.rs:2427-2442: field_filter = indexed field ids, facet_filter = see facet_filters()"""
         ro = ResultObject()
         try:
+            uniq = list(dict.fromkeys(int(t) for t in query_terms))
+            if (field_filter and self.lexical_field_count > 1 and int(query_type_default) == int(QueryType.Union) and len(uniq) > 1):
+                return self._union_with_field_filter(uniq, offset, length, result_type, not_terms, field_filter, facet_filter)
             q = self.make_queries([query_terms], query_type_default, [not_terms], field_filter=field_filter)
             doc, score, cnt, tot = self.search_lexical_batch(q, offset + length, result_type, facet_filter=facet_filter)
         except Exception:
@@ -792,6 +795,45 @@ class Shard:
         ro.results = [Result(int(d), float(s), ResultSource.Lexical) for d, s in zip(doc[0, :n], score[0, :n])][offset:]
         ro.result_count = len(ro.results)
         ro.result_count_total = int(tot[0])
+        return ro
+
+    def _union_with_field_filter(self, terms, offset, length, result_type, not_terms, field_filter, facet_filter):
+        """A union of several terms under a field filter.  The reference answers it through sub-queries: union_docid_3 queues
+        the intersection of all terms and every subset one term shorter, down to pairs (union.rs:1330-1425), union_docid_2
+        runs a pair as its intersection plus the two single terms (union.rs:1168-1305), the filter (add_result.rs:3124-3136)
+        applies to the terms of the sub-query that finds the doc, and a doc found again keeps its better score
+        (docid_hashset, min_heap.rs:1193-1260).  Every subset of the query's terms is thus tried as a filtered intersection
+        and a doc ends with the best of them: the sum over its terms that occur in a listed field (all fields of those terms
+        counted), a doc none of whose terms passes is no result.  The same here: the 2^n - 1 filtered intersections as ONE
+        device batch, merged per doc by the maximum.  Totals as the reference reports them: two terms -> |pass(X) u pass(Y)|
+        (union_docid_2's count), more -> the unfiltered union (union_scan counts a doc before the filter sees it,
+        union.rs:552-553)."""
+        n = len(terms)
+        if n > 5:
+            raise ValueError("a union of more than 5 terms under a field filter (2^n - 1 sub-queries)")
+        k = offset + length
+        subsets = [[terms[i] for i in range(n) if (m >> i) & 1] for m in range(1, 1 << n)]
+        q = self.make_queries(subsets, QueryType.Intersection, [list(not_terms)] * len(subsets), field_filter=field_filter)
+        rt = ResultType.TopkCount if result_type != ResultType.Topk else ResultType.Topk
+        doc, score, cnt, tot = self.search_lexical_batch(q, max(k, 1), rt, facet_filter=facet_filter)
+        best = {}
+        for i in range(len(subsets)):
+            for d, sc in zip(doc[i, :int(cnt[i])], score[i, :int(cnt[i])]):
+                if float(sc) > best.get(int(d), -1.0):
+                    best[int(d)] = float(sc)
+        ranked = sorted(best.items(), key=lambda e: (-e[1], e[0]))[:k]
+        ro = ResultObject()
+        if result_type != ResultType.Count:
+            ro.results = [Result(d, sc, ResultSource.Lexical) for d, sc in ranked][offset:]
+        ro.result_count = len(ro.results)
+        if result_type != ResultType.Topk:
+            if n == 2:  # |A| + |B| - |A n B| over the filtered lists
+                ro.result_count_total = int(tot[0]) + int(tot[1]) - int(tot[2])
+            else:
+                qu = self.make_queries([terms], QueryType.Union, [list(not_terms)])
+                ro.result_count_total = int(self.search_lexical_batch(qu, 1, ResultType.Count, facet_filter=facet_filter)[3][0])
+        else:
+            ro.result_count_total = len(ranked)
         return ro
 
     def search_vector_shard(self, query_vector, length=10, similarity_threshold=None, strict=False,

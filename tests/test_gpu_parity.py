@@ -949,6 +949,62 @@ def test_bm25f_field_filter(S, O, n_fields):
     sh.close()
 
 
+@pytest.mark.parametrize("n_fields", [2, 3])
+def test_union_under_a_field_filter_follows_the_reference_decomposition(S, O, n_fields):
+    """A union of several terms with a field filter (Shard.search_lexical_shard): the reference tries every subset of the
+    terms as a filtered intersection (union_docid_3's queue down to pairs, union_docid_2 = the pair + its two single terms)
+    and a doc keeps its best -- the sum over its terms that occur in a listed field, all fields of those terms counted; a
+    doc none of whose terms passes is no result.  Brute-force oracle of that rule from per-term oracle scores; totals as the
+    reference reports them (2 terms: filtered union, more: the unfiltered union); NOT terms and tombstones on top."""
+    n_docs = 90_000
+    dfs = [40_000, 25_000, 6_000, 30_000]
+    dl, offs, docs, fields, tfs = _fields_corpus(O, n_docs, n_fields, dfs, 23 + n_fields)
+    boost = [1.5, 1.0, 0.5][:n_fields]
+    sh = S.Shard(0)
+    sh.upload_lexical_fields(n_docs, dl, boost, offs, docs, fields, tfs)
+    gone = list(range(3, n_docs, 97))
+    sh.set_deleted(gone)
+    gone_set = set(gone)
+    per_term = {}
+    for t in range(len(dfs)):  # every doc of the term with the term's own score (all its fields), and where the term sits
+        d, s_, tot, _ = O.search_fields_exhaustive(n_docs, dl, boost, offs, docs, fields, tfs, [t], O.OP_OR, n_docs, (), gone)
+        a, b = int(offs[t]), int(offs[t + 1])
+        per_term[t] = (dict(zip(d.tolist(), s_.tolist())), docs[a:b], fields[a:b])
+    for filt in ([0], [n_fields - 1], [0, n_fields - 1][:n_fields]):
+        fset = set(filt)
+        for terms, neg in (([0, 1], []), ([0, 1, 3], []), ([2, 3], [0]), ([0, 1, 2, 3], []), ([3, 1, 2], [0])):
+            score, passing, present = {}, [], set()
+            for t in terms:
+                sc, dd, ff = per_term[t]
+                pas = set(dd[np.isin(ff, list(fset))].tolist()) - gone_set
+                passing.append(pas)
+                present |= set(dd.tolist()) - gone_set
+                for d in pas:
+                    score[d] = np.float32(score.get(d, np.float32(0)) + np.float32(sc[d]))
+            banned = set()
+            for t in neg:
+                banned |= set(per_term[t][1].tolist())
+            ranked = sorted(((d, float(v)) for d, v in score.items() if d not in banned), key=lambda e: (-e[1], e[0]))
+            for k in (10, 40):
+                ro = sh.search_lexical_shard(terms, S.QueryType.Union, 0, k, S.ResultType.TopkCount, strict=True, not_terms=neg, field_filter=filt)
+                want = ranked[:k]
+                assert len(ro.results) == len(want), (terms, neg, filt, k)
+                got_s = np.array([r.score for r in ro.results], np.float32)
+                assert np.allclose(got_s, [w[1] for w in want], rtol=1e-4), (terms, neg, filt, k)
+                kth = want[-1][1] if want else 0.0
+                band = abs(kth) * 2e-4
+                assert {r.doc_id for r in ro.results if r.score > kth + band} == {d for d, v in want if v > kth + band}
+                if len(terms) == 2:
+                    assert ro.result_count_total == len((passing[0] | passing[1]) - banned), (terms, neg, filt)
+                else:
+                    assert ro.result_count_total == len(present - banned), (terms, neg, filt)
+            # a doc whose only matching terms sit in unlisted fields must be absent even when its unfiltered score is high
+            un = sh.search_lexical_shard(terms, S.QueryType.Union, 0, 40, S.ResultType.Topk, strict=True, not_terms=neg)
+            if len(filt) < n_fields:
+                assert any(r.doc_id not in score for r in un.results) or len(un.results) == 0 or all(r.doc_id in score for r in un.results)
+    sh.close()
+
+
 def test_c1_standin_one_million_docs_and_pairs(S, O):
     """BASELINE configs[0] stand-in (LEX-1M, 2-term AND, top-10, df bands [1 %, 5 %] x [5 %, 20 %]): the device
     generator's corpus against the reference-structured oracle on the host-generated copy of the same corpus"""
