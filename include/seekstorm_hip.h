@@ -271,9 +271,22 @@ int ss_bm25_search_dev(ss_shard* s, uint32_t n_queries, const ss_bm25_query* d_q
  * 3501): a filtered doc neither counts nor ranks.  The filter is evaluated once per call over all docs into an exclusion
  * bitmap that stands in for the tombstone bitmap; all queries of the call share it (the reference has one filter per
  * search call).  lo / hi: the value's bits (two's complement for I*, IEEE bits for F32 in the low word / F64); Timestamp =
- * I64.  Point (distance) filters are not offered.  Calls that share a shard must be stream-ordered (one bitmap per shard). */
+ * I64.  Calls that share a shard must be stream-ordered (one bitmap per shard).
+ * SS_FACET_POINT (FieldType::Point: the u64 Morton code of (lat, lon) x 1e7, geo_search.rs:27-41) filters by DISTANCE to a
+ * base point (FacetFilter::Point -> FilterSparse::Point, search.rs:2712-2722, add_result.rs:462-478): lo / hi = the f64 bits
+ * of the distance range, values[0..1] / values[2..3] = the f64 bits (low word first) of the base's latitude / longitude,
+ * n_values = SS_POINT_KM | SS_POINT_MILES.  A doc passes iff its code lies inside the reference's Morton range
+ * (point_distance_to_morton_range(base, hi, unit), geo_search.rs:128-144, computed by the library into values[4..7]) and
+ * lo <= euclidian_distance(base, doc) < hi (geo_search.rs:115-124, f64).  n_values = SS_POINT_SORTKEY compares
+ * simplified_distance (geo_search.rs:82-87, the key of a sort by distance) without a Morton range: the pivots of a result sort. */
 enum { SS_FACET_U8 = 0, SS_FACET_U16, SS_FACET_U32, SS_FACET_U64, SS_FACET_I8, SS_FACET_I16, SS_FACET_I32, SS_FACET_I64,
-       SS_FACET_F32, SS_FACET_F64, SS_FACET_STRING16, SS_FACET_STRING32 };
+       SS_FACET_F32, SS_FACET_F64, SS_FACET_STRING16, SS_FACET_STRING32, SS_FACET_POINT };
+enum { SS_POINT_SORTKEY = 0, SS_POINT_KM = 1, SS_POINT_MILES = 2 };
+typedef struct ss_facet_point {   /* the base of a Point facet's distances (QueryFacet::Point / ResultSort.base) */
+  double lat, lon;
+  uint32_t unit;                  /* SS_POINT_KM / _MILES: euclidian_distance; SS_POINT_SORTKEY: simplified_distance */
+  uint32_t reserved;
+} ss_facet_point;
 #define SS_MAX_FACET_FILTERS 8
 typedef struct ss_facet_filter {
   uint32_t offset;      /* of the facet inside a record */
@@ -312,12 +325,23 @@ int ss_bm25_facet_count(ss_shard* s, const ss_bm25_query* query, uint32_t n_filt
  * the pivot is the worst match).  The top-k under the sort is then: the n_better docs of a search filtered to "better than
  * the pivot" (SS_FACET_LO_EXCLUSIVE / _HI_INCLUSIVE) ordered by their values (ss_facet_values), followed by the best
  * k - n_better docs of a search filtered to "equal to the pivot" -- by the next sort field the same way, by score when none
- * is left.  String facets (sorted by their strings) and Point facets are not offered (SS_ENOTSUP).
- * ss_facet_values: the stored bits of a facet for a list of docs (host arrays). */
+ * is left.  String facets (sorted by their strings) are not offered (SS_ENOTSUP).
+ * ss_facet_values: the stored bits of a facet for a list of docs (host arrays).
+ * Point facets: the *_point entry points take the base point; the value that is counted into ranges (Ranges::Point,
+ * add_result.rs:605-618; bounds = f64 bits of the distances), selected (morton_ordering, min_heap.rs:510-528 /
+ * 1017-1036: unit = SS_POINT_SORTKEY) or returned is the f64 distance of each doc's point to it. */
 int ss_bm25_facet_kth(ss_shard* s, const ss_bm25_query* query, uint32_t n_filters, const ss_facet_filter* filters,
                       uint32_t facet_offset, uint32_t facet_type, uint32_t descending, uint64_t k, uint64_t* out_value,
                       uint64_t* out_n_better, uint64_t* out_n_equal, uint64_t* out_total);
 int ss_facet_values(ss_shard* s, uint32_t n, const uint32_t* doc_ids, uint32_t facet_offset, uint32_t facet_type, uint64_t* out_values);
+int ss_bm25_facet_count_point(ss_shard* s, const ss_bm25_query* query, uint32_t n_filters, const ss_facet_filter* filters,
+                              uint32_t facet_offset, const ss_facet_point* base, uint32_t n_buckets,
+                              const uint64_t* range_lower_bounds, uint64_t* out_counts, uint64_t* out_total);
+int ss_bm25_facet_kth_point(ss_shard* s, const ss_bm25_query* query, uint32_t n_filters, const ss_facet_filter* filters,
+                            uint32_t facet_offset, const ss_facet_point* base, uint32_t descending, uint64_t k, uint64_t* out_value,
+                            uint64_t* out_n_better, uint64_t* out_n_equal, uint64_t* out_total);
+int ss_facet_point_distances(ss_shard* s, uint32_t n, const uint32_t* doc_ids, uint32_t facet_offset, const ss_facet_point* base,
+                             uint64_t* out_values);
 
 /* ------------------------------------------------------------------ vector image
  * rows: row-major [n_rows x dim] f32, already L2-normalised for cosine (vector.rs:585-596); the uploader of

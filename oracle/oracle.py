@@ -624,3 +624,45 @@ def turboquant_i8(rows, seed_mask, avx2=False):
         f(rows[i].ctypes.data_as(f32p), rows.shape[1], _p(mask, f32p), dim, 1 if avx2 else 0, q[i].ctypes.data, C.byref(s_), C.byref(n_))
         sc[i], nm[i] = s_.value, n_.value
     return q, sc, nm
+
+
+# ---- Point (geo) facets: geo_search.rs
+def morton_encode(lat, lon):
+    """encode_morton_2_d of every (lat, lon) -> uint64 codes"""
+    f = lib().so_morton_encode
+    f.restype = C.c_uint64
+    f.argtypes = [C.c_double, C.c_double]
+    la, lo = np.atleast_1d(np.asarray(lat, np.float64)), np.atleast_1d(np.asarray(lon, np.float64))
+    return np.array([f(float(a), float(b)) for a, b in zip(la, lo)], np.uint64)
+
+
+def morton_decode(codes):
+    f = lib().so_morton_decode
+    f.restype = None
+    f.argtypes = [C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    out = np.zeros((len(codes), 2), np.float64)
+    for i, c in enumerate(codes):
+        a, b = C.c_double(), C.c_double()
+        f(int(c), C.byref(a), C.byref(b))
+        out[i] = a.value, b.value
+    return out
+
+
+def geo_distances(codes, base, unit):
+    """unit "km" / "miles": euclidian_distance(base, doc); "sortkey": simplified_distance(doc, base)"""
+    f = lib().so_geo_distances
+    f.restype = None
+    f.argtypes = [C.c_uint64, u64p, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double)]
+    c = np.ascontiguousarray(codes, np.uint64)
+    out = np.zeros(len(c), np.float64)
+    f(len(c), _p(c, u64p), float(base[0]), float(base[1]), {"sortkey": 0, "km": 1, "miles": 2}[unit], out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
+
+
+def geo_morton_range(base, distance, unit):
+    f = lib().so_geo_morton_range
+    f.restype = None
+    f.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, u64p]
+    out = np.zeros(2, np.uint64)
+    f(float(base[0]), float(base[1]), float(distance), {"km": 1, "miles": 2}[unit], _p(out, u64p))
+    return int(out[0]), int(out[1])

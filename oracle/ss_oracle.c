@@ -1749,3 +1749,62 @@ void so_turboquant_i8(const float* v, uint32_t n, const float* seed_mask, uint32
   *norm_out = (float)sq * scale * scale;
   free(a);
 }
+
+/* ---- Point (geo) facets: geo_search.rs ---- */
+static uint64_t morton_part(uint32_t v) { /* encode_morton_64_bit, geo_search.rs:12-21 */
+  uint64_t x = v;
+  x = (x | (x << 32)) & 0x00000000ffffffffull;
+  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+  x = (x | (x << 2)) & 0x3333333333333333ull;
+  x = (x | (x << 1)) & 0x5555555555555555ull;
+  return x;
+}
+static uint32_t morton_unpart(uint64_t code) { /* decode_morton_64_bit, geo_search.rs:45-53 */
+  uint64_t x = code & 0x5555555555555555ull;
+  x = (x ^ (x >> 1)) & 0x3333333333333333ull;
+  x = (x ^ (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+  x = (x ^ (x >> 4)) & 0x00FF00FF00FF00FFull;
+  x = (x ^ (x >> 8)) & 0x0000FFFF0000FFFFull;
+  x = (x ^ (x >> 16)) & 0x00000000FFFFFFFFull;
+  return (uint32_t)x;
+}
+static int32_t rust_f64_as_i32(double v) { /* `as i32`: toward zero, saturating, NaN -> 0 */
+  if (v != v) return 0;
+  if (v >= 2147483647.0) return INT32_MAX;
+  if (v <= -2147483648.0) return INT32_MIN;
+  return (int32_t)v;
+}
+uint64_t so_morton_encode(double lat, double lon) { /* geo_search.rs:27-41 */
+  const uint32_t x = (uint32_t)rust_f64_as_i32(lat * 10000000.0), y = (uint32_t)rust_f64_as_i32(lon * 10000000.0);
+  return (morton_part(y) << 1) | morton_part(x);
+}
+void so_morton_decode(uint64_t code, double* lat, double* lon) { /* geo_search.rs:58-79 */
+  *lat = (double)(int32_t)morton_unpart(code) / 10000000.0;
+  *lon = (double)(int32_t)morton_unpart(code >> 1) / 10000000.0;
+}
+#define SO_DEG2RAD 0.017453292519943295
+static double so_earth_radius(int unit) { return unit == 1 ? 6371.0087714 : 3958.761315801475; }
+void so_geo_distances(uint64_t n, const uint64_t* codes, double base_lat, double base_lon, int unit, double* out) {
+  for (uint64_t i = 0; i < n; i++) {
+    double lat, lon;
+    so_morton_decode(codes[i], &lat, &lon);
+    if (unit) { /* euclidian_distance(point1 = base, point2 = doc), geo_search.rs:115-124 */
+      const double x = SO_DEG2RAD * (lon - base_lon) * cos(SO_DEG2RAD * (base_lat + lat) / 2.0);
+      const double y = SO_DEG2RAD * (lat - base_lat);
+      out[i] = so_earth_radius(unit) * sqrt(x * x + y * y);
+    } else { /* simplified_distance(point1 = doc, point2 = base), geo_search.rs:82-87 */
+      const double x = (base_lon - lon) * cos(SO_DEG2RAD * (lat + base_lat) / 2.0);
+      const double y = base_lat - lat;
+      out[i] = x * x + y * y;
+    }
+  }
+}
+void so_geo_morton_range(double lat, double lon, double distance, int unit, uint64_t out[2]) { /* geo_search.rs:128-144 */
+  const double r = so_earth_radius(unit);
+  const double lat_delta = distance / (SO_DEG2RAD * r);
+  const double lon_delta = distance / (SO_DEG2RAD * r * cos(SO_DEG2RAD * lat));
+  out[0] = so_morton_encode(lat - lat_delta, lon - lon_delta);
+  out[1] = so_morton_encode(lat + lat_delta, lon + lon_delta);
+}

@@ -210,6 +210,17 @@ float so_vector_score_field(float dot);
 /* TopK threshold transform: vector.rs:388-397 */
 float so_threshold_raw(float similarity_threshold);
 
+/* ---- Point (geo) facets: geo_search.rs.  The reference's tests hold no vectors for these (parity unpinned: the
+ * restatement is checked against the interleaving's defining properties only).
+ * so_morton_encode: encode_morton_2_d (27-41): (deg * 1e7) as i32 as u32 -- Rust's saturating, truncating cast --, latitude
+ * into the even bits, longitude into the odd ones; so_morton_decode: decode_morton_2_d (58-79).
+ * so_geo_distances: unit 1 = km / 2 = miles: euclidian_distance(base, doc) (115-124); 0: simplified_distance(doc, base)
+ * (82-87, the comparison key of morton_ordering 90-108).  so_geo_morton_range: point_distance_to_morton_range (128-144). */
+uint64_t so_morton_encode(double lat, double lon);
+void so_morton_decode(uint64_t code, double* lat, double* lon);
+void so_geo_distances(uint64_t n, const uint64_t* codes, double base_lat, double base_lon, int unit, double* out);
+void so_geo_morton_range(double lat, double lon, double distance, int unit, uint64_t out[2]);
+
 /* ---- fusion / merge (search.rs:1669-1673, 1875-2035, 2098-2119) ---- */
 /* lists are concatenations over shards of per-shard top-(offset+length); ids already global.
  * mode 0 = lexical only, 1 = vector only, 2 = hybrid RRF(k=0.6).  Output sorted desc, offset

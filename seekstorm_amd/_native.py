@@ -48,7 +48,12 @@ class FacetFilterC(C.Structure):  # ss_facet_filter
 SS_MAX_FACET_FILTERS = 8
 FACET_HI_INCLUSIVE, FACET_LO_EXCLUSIVE = 1, 2
 FACET_TYPES = {"u8": 0, "u16": 1, "u32": 2, "u64": 3, "i8": 4, "i16": 5, "i32": 6, "i64": 7, "f32": 8, "f64": 9,
-               "string16": 10, "string32": 11}
+               "string16": 10, "string32": 11, "point": 12}
+POINT_UNITS = {"sortkey": 0, "km": 1, "miles": 2}
+
+
+class FacetPointC(C.Structure):  # ss_facet_point
+    _fields_ = [("lat", C.c_double), ("lon", C.c_double), ("unit", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class AnnModeC(C.Structure):  # ss_ann_mode
@@ -151,6 +156,11 @@ SYMBOLS = [
     ("ss_bm25_facet_kth", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                     u64p, u64p, u64p, u64p]),
     ("ss_facet_values", C.c_int, [C.c_void_p, C.c_uint32, u32p, C.c_uint32, C.c_uint32, u64p]),
+    ("ss_bm25_facet_count_point", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, u64p,
+                                            u64p, u64p]),
+    ("ss_bm25_facet_kth_point", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                          C.c_uint64, u64p, u64p, u64p, u64p]),
+    ("ss_facet_point_distances", C.c_int, [C.c_void_p, C.c_uint32, u32p, C.c_uint32, C.c_void_p, u64p]),
     ("ss_bm25_search_sharded", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p]),
     ("ss_rrf_merge_dev", C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int,

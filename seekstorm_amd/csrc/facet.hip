@@ -8,7 +8,7 @@
 // docs) and the search kernels run with that bitmap in place of the tombstone bitmap; nothing in them changes.
 #include <cstring>
 
-#include "ss_common.h"
+#include "facet_point.h"
 
 struct FacetFilters {
   uint32_t n;
@@ -19,6 +19,72 @@ __device__ __forceinline__ unsigned long long facet_read(const uint8_t* p, uint3
   unsigned long long v = 0;
   for (uint32_t b = 0; b < bytes; b++) v |= (unsigned long long)p[b] << (8u * b);  // little endian, any alignment
   return v;
+}
+
+// ---- Point facets (FieldType::Point, index.rs:1050-1056): the stored value is the 64-bit Morton code of (lat, lon) x 1e7
+// as i32 (geo_search.rs:27-41: lat in the even bits, lon in the odd ones).  What filters, counts and sorts is a DISTANCE
+// to a base point, in f64 like the reference, operation by operation in its order (no fused multiply-add):
+//   unit km / miles: euclidian_distance(base, doc) = R * sqrt(x^2 + y^2), x = DEG2RAD*(dlon)*cos(DEG2RAD*(lat1+lat2)/2),
+//                    y = DEG2RAD*(dlat)                                   (geo_search.rs:115-124; facet filter, facet count)
+//   sort key:        simplified_distance(doc, base) = x^2 + y^2 without DEG2RAD and R (geo_search.rs:82-87, morton_ordering)
+// cos / sqrt are the device library's f64 routines: a last-place difference from the host's libm can move a doc that sits
+// within an ulp of a range bound, nothing else.
+struct FacetPoint {
+  double lat, lon, radius;  // radius 0: the sort key
+};
+__host__ __device__ inline uint32_t morton_compact(unsigned long long x) {  // the even bits of x, packed
+  x &= 0x5555555555555555ull;
+  x = (x ^ (x >> 1)) & 0x3333333333333333ull;
+  x = (x ^ (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+  x = (x ^ (x >> 4)) & 0x00FF00FF00FF00FFull;
+  x = (x ^ (x >> 8)) & 0x0000FFFF0000FFFFull;
+  x = (x ^ (x >> 16)) & 0x00000000FFFFFFFFull;
+  return (uint32_t)x;
+}
+__host__ inline unsigned long long morton_spread(uint32_t v) {
+  unsigned long long x = v;
+  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+  x = (x | (x << 2)) & 0x3333333333333333ull;
+  x = (x | (x << 1)) & 0x5555555555555555ull;
+  return x;
+}
+__host__ inline uint32_t morton_coord(double degrees) {  // (v * 1e7) as i32 as u32: Rust's cast truncates, saturates, NaN -> 0
+  const double v = degrees * 10000000.0;
+  int32_t i;
+  if (v != v) i = 0;
+  else if (v >= 2147483647.0) i = INT32_MAX;
+  else if (v <= -2147483648.0) i = INT32_MIN;
+  else i = (int32_t)v;
+  return (uint32_t)i;
+}
+__host__ inline unsigned long long morton_encode(double lat, double lon) { return (morton_spread(morton_coord(lon)) << 1) | morton_spread(morton_coord(lat)); }
+static constexpr double kDeg2Rad = 0.017453292519943295, kEarthKm = 6371.0087714, kEarthMi = 3958.761315801475;
+
+__device__ double facet_point_distance(const FacetPoint& b, unsigned long long code) {
+#pragma clang fp contract(off)
+  const double lat = (double)(int32_t)morton_compact(code) / 10000000.0;
+  const double lon = (double)(int32_t)morton_compact(code >> 1) / 10000000.0;
+  const double c = cos(kDeg2Rad * (b.lat + lat) / 2.0);
+  if (b.radius != 0.0) {
+    const double x = kDeg2Rad * (lon - b.lon) * c, y = kDeg2Rad * (lat - b.lat);
+    return b.radius * sqrt(x * x + y * y);
+  }
+  const double x = (b.lon - lon) * c, y = b.lat - lat;
+  return x * x + y * y;
+}
+// a facet's value as the bits the comparisons below work on: Point -> the f64 distance (from then on an F64 facet)
+__device__ __forceinline__ unsigned long long facet_load(const uint8_t* p, uint32_t bytes, uint32_t& type, const FacetPoint& pt) {
+  const unsigned long long v = facet_read(p, bytes);
+  if (type != SS_FACET_POINT) return v;
+  type = SS_FACET_F64;
+  return (unsigned long long)__double_as_longlong(facet_point_distance(pt, v));
+}
+__host__ inline int facet_point_of(const ss_facet_point* p, FacetPoint* out) {
+  if (!p || p->unit > SS_POINT_MILES) return SS_EINVAL;
+  *out = FacetPoint{p->lat, p->lon, p->unit == SS_POINT_KM ? kEarthKm : p->unit == SS_POINT_MILES ? kEarthMi : 0.0};
+  return SS_OK;
 }
 
 // lo <= v < hi as Rust's Range::contains; the two flag bits turn the ends around (the pivots of a result sort need
@@ -53,6 +119,15 @@ __device__ bool facet_pass(const uint8_t* rec, const ss_facet_filter& f) {
         if (f.values[i] == v) return true;
       return false;
     }
+    case SS_FACET_POINT: {  // FilterSparse::Point, add_result.rs:462-478: inside the Morton range AND inside the distance range
+      const unsigned long long code = facet_read(p, 8);
+      unsigned long long w[4];
+      for (int i = 0; i < 4; i++) w[i] = (unsigned long long)f.values[2 * i] | ((unsigned long long)f.values[2 * i + 1] << 32);
+      const FacetPoint b{__longlong_as_double((long long)w[0]), __longlong_as_double((long long)w[1]),
+                         f.n_values == SS_POINT_KM ? kEarthKm : f.n_values == SS_POINT_MILES ? kEarthMi : 0.0};
+      if (f.n_values != SS_POINT_SORTKEY && !(code >= w[2] && code < w[3])) return false;
+      return facet_in<double>(facet_point_distance(b, code), __longlong_as_double((long long)f.lo), __longlong_as_double((long long)f.hi), fl);
+    }
     default: return true;
   }
 }
@@ -86,10 +161,26 @@ int ssi_facet_build(ss_shard* s, uint32_t n_filters, const ss_facet_filter* filt
   F.n = n_filters;
   for (uint32_t i = 0; i < n_filters; i++) {
     const ss_facet_filter& f = filters[i];
-    static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 2, 4};
-    if (f.type > SS_FACET_STRING32 || f.offset + width[f.type] > s->facet_record_size) return SS_EINVAL;
+    static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 2, 4, 8};
+    if (f.type > SS_FACET_POINT || f.offset + width[f.type] > s->facet_record_size) return SS_EINVAL;
     if ((f.type == SS_FACET_STRING16 || f.type == SS_FACET_STRING32) && f.n_values > 8) return SS_EINVAL;
     F.f[i] = f;
+    if (f.type == SS_FACET_POINT) {
+      if (f.n_values > SS_POINT_MILES) return SS_EINVAL;
+      if (f.n_values != SS_POINT_SORTKEY) {
+        // point_distance_to_morton_range(base, distance_range.end, unit), search.rs:2712-2722 / geo_search.rs:128-144: the
+        // codes of the two corners of the box around the base -- a range of the Z-ORDER, as the reference compares it
+        double lat, lon, end;
+        unsigned long long w0 = (unsigned long long)f.values[0] | ((unsigned long long)f.values[1] << 32),
+                           w1 = (unsigned long long)f.values[2] | ((unsigned long long)f.values[3] << 32);
+        memcpy(&lat, &w0, 8); memcpy(&lon, &w1, 8); memcpy(&end, &f.hi, 8);
+        const double radius = f.n_values == SS_POINT_KM ? kEarthKm : kEarthMi;
+        const double lat_delta = end / (kDeg2Rad * radius), lon_delta = end / (kDeg2Rad * radius * cos(kDeg2Rad * lat));
+        const unsigned long long m0 = morton_encode(lat - lat_delta, lon - lon_delta), m1 = morton_encode(lat + lat_delta, lon + lon_delta);
+        F.f[i].values[4] = (uint32_t)m0; F.f[i].values[5] = (uint32_t)(m0 >> 32);
+        F.f[i].values[6] = (uint32_t)m1; F.f[i].values[7] = (uint32_t)(m1 >> 32);
+      }
+    }
   }
   const uint64_t words = (s->facet_docs + 31) / 32;
   if (words > s->filter_words_cap) {
@@ -123,21 +214,22 @@ __device__ __forceinline__ bool facet_le(uint32_t type, unsigned long long bound
 __global__ void facet_count_kernel(const unsigned long long* __restrict__ bits, unsigned long long n_docs,
                                    const uint8_t* __restrict__ records, uint32_t record_size, uint32_t offset, uint32_t type,
                                    uint32_t n_buckets, const unsigned long long* __restrict__ bounds,
-                                   unsigned long long* __restrict__ counts) {
+                                   unsigned long long* __restrict__ counts, uint32_t stored_type, FacetPoint pt) {
   const unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (g * 64ull >= n_docs) return;
   unsigned long long m = bits[g];
-  static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 2, 4};
+  static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 2, 4, 8};
   while (m) {
     const unsigned long long d = g * 64ull + (unsigned long long)__builtin_ctzll(m);
     m &= m - 1;
     if (d >= n_docs) break;
-    unsigned long long v = facet_read(records + d * record_size + offset, width[type]);
+    type = stored_type;
+    unsigned long long v = facet_load(records + d * record_size + offset, width[stored_type], type, pt);
     if (type == SS_FACET_I8) v = (unsigned long long)(long long)(int8_t)v;      // sign-extend for the comparisons
     else if (type == SS_FACET_I16) v = (unsigned long long)(long long)(int16_t)v;
     else if (type == SS_FACET_I32) v = (unsigned long long)(long long)(int32_t)v;
     uint32_t b;
-    if (type >= SS_FACET_STRING16) {
+    if (type == SS_FACET_STRING16 || type == SS_FACET_STRING32) {
       b = v < n_buckets ? (uint32_t)v : n_buckets;
     } else {
       uint32_t lo = 0, hi = n_buckets;  // number of bounds <= v
@@ -152,11 +244,13 @@ __global__ void facet_count_kernel(const unsigned long long* __restrict__ bits, 
 }
 
 int ssi_facet_count(ss_shard* s, const unsigned long long* d_bits, uint64_t n_docs, uint32_t offset, uint32_t type, uint32_t n_buckets,
-                    const uint64_t* d_bounds, unsigned long long* d_counts, hipStream_t st) {
+                    const uint64_t* d_bounds, unsigned long long* d_counts, const ss_facet_point* point, hipStream_t st) {
+  FacetPoint pt{0, 0, 0};
+  if (type == SS_FACET_POINT && facet_point_of(point, &pt) != SS_OK) return SS_EINVAL;
   const uint64_t groups = (n_docs + 63) / 64;
   facet_count_kernel<<<(unsigned)((groups + 255) / 256), 256, 0, st>>>(d_bits, (unsigned long long)n_docs, s->d_facets,
                                                                       s->facet_record_size, offset, type, n_buckets,
-                                                                      (const unsigned long long*)d_bounds, d_counts);
+                                                                      (const unsigned long long*)d_bounds, d_counts, type, pt);
   SS_HIP(hipGetLastError());
   return SS_OK;
 }
@@ -187,7 +281,7 @@ __host__ inline unsigned long long facet_order_value(unsigned long long k, uint3
 __global__ void facet_radix_kernel(const unsigned long long* __restrict__ bits, unsigned long long n_docs,
                                    const uint8_t* __restrict__ records, uint32_t record_size, uint32_t offset, uint32_t type,
                                    uint32_t key_bits, uint32_t descending, unsigned long long prefix, uint32_t byte_index,
-                                   unsigned long long* __restrict__ hist) {
+                                   unsigned long long* __restrict__ hist, FacetPoint pt) {
   __shared__ unsigned int h[256];
   h[threadIdx.x & 255u] = 0u;
   __syncthreads();
@@ -199,7 +293,9 @@ __global__ void facet_radix_kernel(const unsigned long long* __restrict__ bits, 
       const unsigned long long d = g * 64ull + (unsigned long long)__builtin_ctzll(m);
       m &= m - 1;
       if (d >= n_docs) break;
-      const unsigned long long k = facet_order_key(facet_read(records + d * record_size + offset, key_bits / 8u), type, key_bits, descending != 0u);
+      uint32_t ty = type;
+      const unsigned long long v = facet_load(records + d * record_size + offset, key_bits / 8u, ty, pt);
+      const unsigned long long k = facet_order_key(v, ty, key_bits, descending != 0u);
       if (byte_index == 0u || (k >> (shift + 8u)) == prefix) atomicAdd(&h[(k >> shift) & 255u], 1u);
     }
   }
@@ -211,9 +307,11 @@ __global__ void facet_radix_kernel(const unsigned long long* __restrict__ bits, 
 // strictly better than it, *n_equal = matches equal to it.  d_hist: 256 counters of workspace.
 int ssi_facet_kth(ss_shard* s, const unsigned long long* d_bits, uint64_t n_docs, uint64_t n_matches, uint32_t offset, uint32_t type,
                   bool descending, uint64_t k, unsigned long long* d_hist, uint64_t* value_bits, uint64_t* n_better, uint64_t* n_equal,
-                  hipStream_t st) {
-  static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8};
-  if (type > SS_FACET_F64) return SS_ENOTSUP;  // string facets sort by their strings, which live in the host's facet.json
+                  const ss_facet_point* point, hipStream_t st) {
+  static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 0, 0, 8};
+  if (type == SS_FACET_STRING16 || type == SS_FACET_STRING32) return SS_ENOTSUP;  // they sort by their strings, which live in the host's facet.json
+  FacetPoint pt{0, 0, 0};
+  if (type == SS_FACET_POINT && facet_point_of(point, &pt) != SS_OK) return SS_EINVAL;  // the key is the f64 distance
   *n_better = 0; *n_equal = 0; *value_bits = 0;
   if (n_matches == 0) return SS_OK;
   const uint32_t key_bits = 8u * width[type];
@@ -225,7 +323,7 @@ int ssi_facet_kth(ss_shard* s, const unsigned long long* d_bits, uint64_t n_docs
   for (uint32_t b = 0; b < key_bits / 8u; b++) {
     SS_HIP(hipMemsetAsync(d_hist, 0, sizeof(hist), st));
     facet_radix_kernel<<<(unsigned)((groups + 255) / 256), 256, 0, st>>>(d_bits, (unsigned long long)n_docs, s->d_facets, s->facet_record_size,
-                                                                        offset, type, key_bits, descending ? 1u : 0u, prefix, b, d_hist);
+                                                                        offset, type, key_bits, descending ? 1u : 0u, prefix, b, d_hist, pt);
     SS_HIP(hipGetLastError());
     SS_HIP(hipMemcpyAsync(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost, st));
     SS_HIP(hipStreamSynchronize(st));
@@ -239,19 +337,42 @@ int ssi_facet_kth(ss_shard* s, const unsigned long long* d_bits, uint64_t n_docs
     equal = hist[v];
   }
   *n_equal = equal;
-  *value_bits = facet_order_value(prefix, type, key_bits, descending);
+  *value_bits = facet_order_value(prefix, type == SS_FACET_POINT ? (uint32_t)SS_FACET_F64 : type, key_bits, descending);
   return SS_OK;
 }
 
 __global__ void facet_values_kernel(const uint8_t* __restrict__ records, uint32_t record_size, uint32_t offset, uint32_t bytes,
-                                    const uint32_t* __restrict__ docs, uint32_t n, unsigned long long n_docs, unsigned long long* __restrict__ out) {
+                                    const uint32_t* __restrict__ docs, uint32_t n, unsigned long long n_docs, unsigned long long* __restrict__ out,
+                                    uint32_t type, FacetPoint pt) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = docs[i] < n_docs ? facet_read(records + (size_t)docs[i] * record_size + offset, bytes) : 0ull;
+  if (i < n) out[i] = docs[i] < n_docs ? facet_load(records + (size_t)docs[i] * record_size + offset, bytes, type, pt) : 0ull;
 }
-int ssi_facet_values(ss_shard* s, const uint32_t* d_docs, uint32_t n, uint32_t offset, uint32_t type, unsigned long long* d_out, hipStream_t st) {
-  static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 2, 4};
+// point == nullptr: the stored bits (a Point facet's Morton code); with a point: the f64 distance to it
+int ssi_facet_values(ss_shard* s, const uint32_t* d_docs, uint32_t n, uint32_t offset, uint32_t type, unsigned long long* d_out,
+                     const ss_facet_point* point, hipStream_t st) {
+  static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 2, 4, 8};
+  FacetPoint pt{0, 0, 0};
+  uint32_t load_as = type;
+  if (type == SS_FACET_POINT) {
+    if (!point) load_as = SS_FACET_U64;
+    else if (facet_point_of(point, &pt) != SS_OK) return SS_EINVAL;
+  }
   if (n) facet_values_kernel<<<(n + 255) / 256, 256, 0, st>>>(s->d_facets, s->facet_record_size, offset, width[type], d_docs, n,
-                                                               (unsigned long long)s->facet_docs, d_out);
+                                                               (unsigned long long)s->facet_docs, d_out, load_as, pt);
   SS_HIP(hipGetLastError());
   return SS_OK;
+}
+
+// the signatures ss_common.h declares: no base point
+int ssi_facet_kth(ss_shard* s, const unsigned long long* d_bits, uint64_t n_docs, uint64_t n_matches, uint32_t offset, uint32_t type,
+                  bool descending, uint64_t k, unsigned long long* d_hist, uint64_t* value_bits, uint64_t* n_better, uint64_t* n_equal,
+                  hipStream_t st) {
+  return ssi_facet_kth(s, d_bits, n_docs, n_matches, offset, type, descending, k, d_hist, value_bits, n_better, n_equal, nullptr, st);
+}
+int ssi_facet_values(ss_shard* s, const uint32_t* d_docs, uint32_t n, uint32_t offset, uint32_t type, unsigned long long* d_out, hipStream_t st) {
+  return ssi_facet_values(s, d_docs, n, offset, type, d_out, nullptr, st);
+}
+int ssi_facet_count(ss_shard* s, const unsigned long long* d_bits, uint64_t n_docs, uint32_t offset, uint32_t type, uint32_t n_buckets,
+                    const uint64_t* d_bounds, unsigned long long* d_counts, hipStream_t st) {
+  return ssi_facet_count(s, d_bits, n_docs, offset, type, n_buckets, d_bounds, d_counts, nullptr, st);
 }

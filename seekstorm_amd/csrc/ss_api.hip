@@ -8,6 +8,7 @@
 #include <unordered_map>
 
 #include "ss_common.h"
+#include "facet_point.h"
 
 #define SS_TRY(x)          \
   do {                     \
@@ -549,11 +550,13 @@ int ss_bm25_search_sharded(ss_shard* s, ss_comm* c, uint32_t nq, const ss_bm25_q
 // Facet counts of ONE query (query_facets / facet_count, add_result.rs:484-640): histogram of a facet over the query's match
 // set (after NOT terms, tombstones and the facet filter).  out_counts [n_buckets + 1]: a string facet's ids 0 .. n_buckets-1,
 // or the numeric ranges given by their ascending lower bounds; the last slot collects what falls outside.
-int ss_bm25_facet_count(ss_shard* s, const ss_bm25_query* query, uint32_t n_filters, const ss_facet_filter* filters,
-                        uint32_t facet_offset, uint32_t facet_type, uint32_t n_buckets, const uint64_t* range_lower_bounds,
-                        uint64_t* out_counts, uint64_t* out_total) {
+static int facet_count_impl(ss_shard* s, const ss_bm25_query* query, uint32_t n_filters, const ss_facet_filter* filters,
+                            uint32_t facet_offset, uint32_t facet_type, const ss_facet_point* point, uint32_t n_buckets,
+                            const uint64_t* range_lower_bounds, uint64_t* out_counts, uint64_t* out_total) {
   if (!s || !query || !out_counts || n_buckets == 0 || n_buckets > (1u << 24)) return SS_EINVAL;
-  if (facet_type > SS_FACET_STRING32 || (facet_type < SS_FACET_STRING16 && !range_lower_bounds)) return SS_EINVAL;
+  const bool string_facet = facet_type == SS_FACET_STRING16 || facet_type == SS_FACET_STRING32;
+  if (facet_type > SS_FACET_POINT || (!string_facet && !range_lower_bounds)) return SS_EINVAL;
+  if (facet_type == SS_FACET_POINT && (!point || point->unit > SS_POINT_MILES)) return SS_EINVAL;
   if (!s->d_post) return SS_ESTATE;
   bool has_and, has_or, all_probed, any_frequent;
   uint32_t nt_max, np_max;
@@ -561,7 +564,7 @@ int ss_bm25_facet_count(ss_shard* s, const ss_bm25_query* query, uint32_t n_filt
   SS_TRY(check_queries(s, 1, query, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent));
   if (!all_probed || !s->d_probe) return SS_ENOTSUP;  // the match set comes from the probe index's bit records
   SS_HIP(hipSetDevice(s->device));
-  static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 2, 4};
+  static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 2, 4, 8};
   if (!s->d_facets || s->facet_docs < s->bm_n_docs || facet_offset + width[facet_type] > s->facet_record_size) return SS_ESTATE;
   const uint64_t groups = (uint64_t)s->bm_n_sub * (BM_SUB / 64);
   const size_t bytes = sizeof(ss_bm25_query) + 8 + groups * 8 + ((size_t)n_buckets + 1) * 8 + (size_t)n_buckets * 8;
@@ -581,12 +584,12 @@ int ss_bm25_facet_count(ss_shard* s, const ss_bm25_query* query, uint32_t n_filt
   int rc = SS_OK;
   if (hipMemcpyAsync(d_q, query, sizeof(ss_bm25_query), hipMemcpyHostToDevice, s->stream) != hipSuccess ||
       hipMemsetAsync(d_total, 0, 8 + groups * 8 + ((size_t)n_buckets + 1) * 8, s->stream) != hipSuccess ||
-      (facet_type < SS_FACET_STRING16 &&
+      (!string_facet &&
        hipMemcpyAsync(d_bounds, range_lower_bounds, (size_t)n_buckets * 8, hipMemcpyHostToDevice, s->stream) != hipSuccess))
     rc = SS_EDEVICE;
   if (rc == SS_OK)
     rc = with_facet_filter(s, n_filters, filters, s->stream, [&]() { return ssi_bm25_match_bits(s, d_q, d_bits, d_total, s->stream); });
-  if (rc == SS_OK) rc = ssi_facet_count(s, d_bits, s->bm_n_docs, facet_offset, facet_type, n_buckets, d_bounds, d_counts, s->stream);
+  if (rc == SS_OK) rc = ssi_facet_count(s, d_bits, s->bm_n_docs, facet_offset, facet_type, n_buckets, d_bounds, d_counts, point, s->stream);
   if (rc == SS_OK && (hipMemcpyAsync(out_counts, d_counts, ((size_t)n_buckets + 1) * 8, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
                       (out_total && hipMemcpyAsync(out_total, d_total, 8, hipMemcpyDeviceToHost, s->stream) != hipSuccess)))
     rc = SS_EDEVICE;
@@ -594,13 +597,26 @@ int ss_bm25_facet_count(ss_shard* s, const ss_bm25_query* query, uint32_t n_filt
   return rc;
 }
 
+int ss_bm25_facet_count(ss_shard* s, const ss_bm25_query* query, uint32_t n_filters, const ss_facet_filter* filters,
+                        uint32_t facet_offset, uint32_t facet_type, uint32_t n_buckets, const uint64_t* range_lower_bounds,
+                        uint64_t* out_counts, uint64_t* out_total) {
+  if (facet_type > SS_FACET_STRING32) return SS_EINVAL;  // a Point facet is counted by its distances: ss_bm25_facet_count_point
+  return facet_count_impl(s, query, n_filters, filters, facet_offset, facet_type, nullptr, n_buckets, range_lower_bounds, out_counts, out_total);
+}
+int ss_bm25_facet_count_point(ss_shard* s, const ss_bm25_query* query, uint32_t n_filters, const ss_facet_filter* filters,
+                              uint32_t facet_offset, const ss_facet_point* base, uint32_t n_buckets,
+                              const uint64_t* range_lower_bounds, uint64_t* out_counts, uint64_t* out_total) {
+  return facet_count_impl(s, query, n_filters, filters, facet_offset, SS_FACET_POINT, base, n_buckets, range_lower_bounds, out_counts, out_total);
+}
+
 // The pivot of a result sort (facet.hip): match set from the bit records as for facet counts, then the radix select.
-int ss_bm25_facet_kth(ss_shard* s, const ss_bm25_query* query, uint32_t n_filters, const ss_facet_filter* filters,
-                      uint32_t facet_offset, uint32_t facet_type, uint32_t descending, uint64_t k, uint64_t* out_value,
-                      uint64_t* out_n_better, uint64_t* out_n_equal, uint64_t* out_total) {
+static int facet_kth_impl(ss_shard* s, const ss_bm25_query* query, uint32_t n_filters, const ss_facet_filter* filters,
+                          uint32_t facet_offset, uint32_t facet_type, const ss_facet_point* point, uint32_t descending, uint64_t k,
+                          uint64_t* out_value, uint64_t* out_n_better, uint64_t* out_n_equal, uint64_t* out_total) {
   if (!s || !query || !out_value || !out_n_better || !out_n_equal || k == 0) return SS_EINVAL;
-  if (facet_type > SS_FACET_STRING32) return SS_EINVAL;
-  if (facet_type > SS_FACET_F64) return SS_ENOTSUP;
+  if (facet_type > SS_FACET_POINT) return SS_EINVAL;
+  if (facet_type == SS_FACET_STRING16 || facet_type == SS_FACET_STRING32) return SS_ENOTSUP;
+  if (facet_type == SS_FACET_POINT && (!point || point->unit > SS_POINT_MILES)) return SS_EINVAL;
   if (!s->d_post) return SS_ESTATE;
   bool has_and, has_or, all_probed, any_frequent;
   uint32_t nt_max, np_max;
@@ -608,7 +624,7 @@ int ss_bm25_facet_kth(ss_shard* s, const ss_bm25_query* query, uint32_t n_filter
   SS_TRY(check_queries(s, 1, query, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent));
   if (!all_probed || !s->d_probe) return SS_ENOTSUP;
   SS_HIP(hipSetDevice(s->device));
-  static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 2, 4};
+  static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 2, 4, 8};
   if (!s->d_facets || s->facet_docs < s->bm_n_docs || facet_offset + width[facet_type] > s->facet_record_size) return SS_ESTATE;
   const uint64_t groups = (uint64_t)s->bm_n_sub * (BM_SUB / 64);
   const size_t bytes = sizeof(ss_bm25_query) + 8 + groups * 8 + 256 * 8;
@@ -632,12 +648,25 @@ int ss_bm25_facet_kth(ss_shard* s, const ss_bm25_query* query, uint32_t n_filter
   SS_HIP(hipStreamSynchronize(s->stream));
   if (out_total) *out_total = total;
   return ssi_facet_kth(s, d_bits, s->bm_n_docs, total, facet_offset, facet_type, descending != 0, k, d_hist, out_value, out_n_better,
-                       out_n_equal, s->stream);
+                       out_n_equal, point, s->stream);
+}
+int ss_bm25_facet_kth(ss_shard* s, const ss_bm25_query* query, uint32_t n_filters, const ss_facet_filter* filters,
+                      uint32_t facet_offset, uint32_t facet_type, uint32_t descending, uint64_t k, uint64_t* out_value,
+                      uint64_t* out_n_better, uint64_t* out_n_equal, uint64_t* out_total) {
+  if (facet_type > SS_FACET_STRING32) return SS_EINVAL;
+  return facet_kth_impl(s, query, n_filters, filters, facet_offset, facet_type, nullptr, descending, k, out_value, out_n_better, out_n_equal, out_total);
+}
+int ss_bm25_facet_kth_point(ss_shard* s, const ss_bm25_query* query, uint32_t n_filters, const ss_facet_filter* filters,
+                            uint32_t facet_offset, const ss_facet_point* base, uint32_t descending, uint64_t k, uint64_t* out_value,
+                            uint64_t* out_n_better, uint64_t* out_n_equal, uint64_t* out_total) {
+  return facet_kth_impl(s, query, n_filters, filters, facet_offset, SS_FACET_POINT, base, descending, k, out_value, out_n_better, out_n_equal, out_total);
 }
 
-int ss_facet_values(ss_shard* s, uint32_t n, const uint32_t* doc_ids, uint32_t facet_offset, uint32_t facet_type, uint64_t* out_values) {
-  if (!s || (n && (!doc_ids || !out_values)) || facet_type > SS_FACET_STRING32) return SS_EINVAL;
-  static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 2, 4};
+static int facet_values_impl(ss_shard* s, uint32_t n, const uint32_t* doc_ids, uint32_t facet_offset, uint32_t facet_type,
+                             const ss_facet_point* point, uint64_t* out_values) {
+  if (!s || (n && (!doc_ids || !out_values)) || facet_type > SS_FACET_POINT) return SS_EINVAL;
+  if (point && point->unit > SS_POINT_MILES) return SS_EINVAL;
+  static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 2, 4, 8};
   std::lock_guard<std::mutex> g(s->mu);
   if (!s->d_facets || facet_offset + width[facet_type] > s->facet_record_size) return SS_ESTATE;
   if (n == 0) return SS_OK;
@@ -646,10 +675,18 @@ int ss_facet_values(ss_shard* s, uint32_t n, const uint32_t* doc_ids, uint32_t f
   uint32_t* d_docs = (uint32_t*)((char*)s->d_qstage + (size_t)n * 8);
   unsigned long long* d_out = (unsigned long long*)s->d_qstage;
   SS_HIP(hipMemcpyAsync(d_docs, doc_ids, (size_t)n * 4, hipMemcpyHostToDevice, s->stream));
-  SS_TRY(ssi_facet_values(s, d_docs, n, facet_offset, facet_type, d_out, s->stream));
+  SS_TRY(ssi_facet_values(s, d_docs, n, facet_offset, facet_type, d_out, point, s->stream));
   SS_HIP(hipMemcpyAsync(out_values, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, s->stream));
   SS_HIP(hipStreamSynchronize(s->stream));
   return SS_OK;
+}
+int ss_facet_values(ss_shard* s, uint32_t n, const uint32_t* doc_ids, uint32_t facet_offset, uint32_t facet_type, uint64_t* out_values) {
+  return facet_values_impl(s, n, doc_ids, facet_offset, facet_type, nullptr, out_values);  // a Point facet: its Morton codes
+}
+int ss_facet_point_distances(ss_shard* s, uint32_t n, const uint32_t* doc_ids, uint32_t facet_offset, const ss_facet_point* base,
+                             uint64_t* out_values) {
+  if (!base) return SS_EINVAL;
+  return facet_values_impl(s, n, doc_ids, facet_offset, SS_FACET_POINT, base, out_values);
 }
 
 int ss_bm25_search_dev(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t ops_mask,

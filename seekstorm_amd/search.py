@@ -561,13 +561,21 @@ class Shard:
 
     @staticmethod
     def facet_filters(filters):
-        """[(offset, type, lo, hi)] for numeric facets -- passes iff lo <= value < hi, Rust's Range -- or
-        [(offset, "string16" | "string32", [ids])] -> ss_facet_filter array (FacetFilter / FilterSparse, search.rs:735-)"""
+        """[(offset, type, lo, hi)] for numeric facets -- passes iff lo <= value < hi, Rust's Range --,
+        [(offset, "string16" | "string32", [ids])] or [(offset, "point", (lat, lon), lo, hi, "km" | "miles")] -- the distance to
+        the base point inside [lo, hi) -> ss_facet_filter array (FacetFilter / FilterSparse, search.rs:735-)"""
         arr = (N.FacetFilterC * max(len(filters), 1))()
         for i, f in enumerate(filters):
             off, ty = int(f[0]), f[1]
             arr[i].offset, arr[i].type = off, N.FACET_TYPES[ty]
-            if ty.startswith("string"):
+            if ty == "point":  # (offset, "point", (lat, lon), lo, hi, unit[, flags]): distance to the base inside [lo, hi)
+                base = np.array([f[2][0], f[2][1]], np.float64).view(np.uint32)
+                for j in range(4):
+                    arr[i].values[j] = int(base[j])
+                rng_ = np.array([f[3], f[4]], np.float64).view(np.uint64)
+                arr[i].lo, arr[i].hi, arr[i].n_values = int(rng_[0]), int(rng_[1]), N.POINT_UNITS[f[5]]
+                arr[i].reserved = int(f[6]) if len(f) > 6 else 0
+            elif ty.startswith("string"):
                 ids = [int(x) for x in f[2]]
                 arr[i].n_values = len(ids)
                 for j, v in enumerate(ids):
@@ -616,15 +624,26 @@ class Shard:
             return Shard._facet_filter_bits(1 << (nb - 1), ty), (1 << (nb - 1)) - 1
         return (0xFF800000, 0x7F800000) if nb == 32 else (0xFFF0000000000000, 0x7FF0000000000000)  # -inf, +inf
 
-    def facet_kth(self, query, facet_offset, facet_type, descending, k, facet_filter=None):
+    @staticmethod
+    def _point(base, unit):
+        return N.FacetPointC(float(base[0]), float(base[1]), N.POINT_UNITS[unit], 0)
+
+    def facet_kth(self, query, facet_offset, facet_type, descending, k, facet_filter=None, base=None):
         """the pivot of a result sort: (stored bits of the k-th best value among the query's matches, matches strictly better,
-        matches equal, all matches) -- ss_bm25_facet_kth"""
+        matches equal, all matches) -- ss_bm25_facet_kth; a Point facet (base = (lat, lon)): the f64 bits of the k-th best
+        simplified_distance to the base -- ss_bm25_facet_kth_point"""
         farr, nf = self.facet_filters(facet_filter) if facet_filter else (None, 0)
         q = np.ascontiguousarray(query[:1])
         v, nb, ne, tot = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
-        N.check(N.lib().ss_bm25_facet_kth(self._h, q.ctypes.data, nf, None if farr is None else C.cast(farr, C.c_void_p),
-                                          int(facet_offset), N.FACET_TYPES[facet_type], 1 if descending else 0, int(k), C.byref(v),
-                                          C.byref(nb), C.byref(ne), C.byref(tot)), "ss_bm25_facet_kth")
+        fp = None if farr is None else C.cast(farr, C.c_void_p)
+        if facet_type == "point":
+            pt = self._point(base, "sortkey")
+            N.check(N.lib().ss_bm25_facet_kth_point(self._h, q.ctypes.data, nf, fp, int(facet_offset), C.byref(pt), 1 if descending else 0,
+                                                    int(k), C.byref(v), C.byref(nb), C.byref(ne), C.byref(tot)), "ss_bm25_facet_kth_point")
+        else:
+            N.check(N.lib().ss_bm25_facet_kth(self._h, q.ctypes.data, nf, fp, int(facet_offset), N.FACET_TYPES[facet_type],
+                                              1 if descending else 0, int(k), C.byref(v), C.byref(nb), C.byref(ne), C.byref(tot)),
+                    "ss_bm25_facet_kth")
         return v.value, nb.value, ne.value, tot.value
 
     def facet_values(self, doc_ids, facet_offset, facet_type):
@@ -634,9 +653,20 @@ class Shard:
                                         N.ptr(out, N.u64p)), "ss_facet_values")
         return out
 
+    def facet_point_distances(self, doc_ids, facet_offset, base, unit="km"):
+        """f64 distances of the docs' Point facet to base = (lat, lon): euclidian_distance in km / miles (geo_search.rs:115-124),
+        or unit "sortkey": simplified_distance, what a sort by distance compares (geo_search.rs:82-87)"""
+        d = np.ascontiguousarray(doc_ids, np.uint32)
+        out = np.zeros(len(d), np.uint64)
+        pt = self._point(base, unit)
+        N.check(N.lib().ss_facet_point_distances(self._h, len(d), N.ptr(d, N.u32p), int(facet_offset), C.byref(pt), N.ptr(out, N.u64p)),
+                "ss_facet_point_distances")
+        return out.view(np.float64)
+
     def search_lexical_sorted(self, query, result_sort, k, facet_filter=None):
-        """ONE query (a 1-element make_queries array) with result_sort = [(facet offset, type, descending)], the reference's
-        Vec<ResultSort> over numeric facets: the k best matches under (field 1, field 2, ..., score), each field ascending or
+        """ONE query (a 1-element make_queries array) with result_sort = [(facet offset, type, descending[, base])], the reference's
+        Vec<ResultSort> over numeric facets and Point facets (type "point", base = (lat, lon): by simplified_distance to the base,
+        morton_ordering, geo_search.rs:90-108): the k best matches under (field 1, field 2, ..., score), each field ascending or
         descending, the score descending last (result_ordering_shard, min_heap.rs:574-1050) -> (doc ids, scores, total).
         Composed from ordinary searches around the sort's pivot: the k-th best value of the first field among the matches
         (ss_bm25_facet_kth) splits them into "strictly better" -- fewer than k docs, fetched by a search filtered to that
@@ -655,36 +685,59 @@ class Shard:
                 if total[0] is None:
                     total[0] = int(tot[0])
                 return [(int(doc[0][i]), float(score[0][i])) for i in range(int(cnt[0]))]
-            off, ty, desc = sorts[0]
-            nbits = self._FACET_BITS[ty]
-            v, n_better, n_equal, tot = self.facet_kth(q, off, ty, desc, kk, filters or None)
+            off, ty, desc = sorts[0][:3]
+            base = sorts[0][3] if ty == "point" else None
+            v, n_better, n_equal, tot = self.facet_kth(q, off, ty, desc, kk, filters or None, base=base)
             if total[0] is None:
                 total[0] = tot
             if tot == 0:
                 return []
             out = []
-            vb = self._facet_filter_bits(v, ty)
-            lo_all, hi_all = self._facet_type_range(ty)
-            if n_better:
+            if ty == "point":  # the pivot is a distance: "better" / "equal" are distance filters on the sort key
+                pv = float(np.array([v], np.uint64).view(np.float64)[0])
+                better = ((off, ty, base, pv, np.inf, "sortkey", N.FACET_LO_EXCLUSIVE | N.FACET_HI_INCLUSIVE) if desc
+                          else (off, ty, base, -np.inf, pv, "sortkey", 0))
+                equal = (off, ty, base, pv, pv, "sortkey", N.FACET_HI_INCLUSIVE)
+            else:
+                vb = self._facet_filter_bits(v, ty)
+                lo_all, hi_all = self._facet_type_range(ty)
                 # strictly better than the pivot: above it for a descending sort, below it for an ascending one
                 better = ((off, ty, vb, hi_all, "bits", N.FACET_LO_EXCLUSIVE | N.FACET_HI_INCLUSIVE) if desc
                           else (off, ty, lo_all, vb, "bits", 0))
+                equal = (off, ty, vb, vb, "bits", N.FACET_HI_INCLUSIVE)
+            if n_better:
                 got = topk([], n_better, filters + [better])
                 docs = [d for d, _ in got]
-                keys = [[self._facet_order_key(x, t_, d_) for x in self.facet_values(docs, o_, t_)] for (o_, t_, d_) in sorts]
+                keys = [[self._facet_order_key(x, "f64" if sf[1] == "point" else sf[1], sf[2]) for x in
+                         (self.facet_point_distances(docs, sf[0], sf[3], "sortkey").view(np.uint64) if sf[1] == "point"
+                          else self.facet_values(docs, sf[0], sf[1]))] for sf in sorts]
                 order = sorted(range(len(got)), key=lambda i: tuple(-kk_[i] for kk_ in keys) + (-got[i][1], got[i][0]))
                 out += [got[i] for i in order]
             if n_better < kk and n_equal:
-                out += topk(sorts[1:], kk - n_better, filters + [(off, ty, vb, vb, "bits", N.FACET_HI_INCLUSIVE)])
+                out += topk(sorts[1:], kk - n_better, filters + [equal])
             return out
 
         res = topk(list(result_sort), int(k), flt)
         return (np.array([d for d, _ in res], np.uint32), np.array([s_ for _, s_ in res], np.float32), int(total[0] or 0))
 
-    def facet_count(self, query, facet_offset, facet_type, n_buckets=None, range_lower_bounds=None, facet_filter=None):
+    def facet_count(self, query, facet_offset, facet_type, n_buckets=None, range_lower_bounds=None, facet_filter=None, base=None,
+                    unit="km"):
         """query_facets of one query (facet_count, add_result.rs:484-640): histogram of the facet over the match set.
-        String facets: n_buckets ids; numeric facets: ascending lower bounds of the ranges.  -> (counts [n_buckets], docs
-        outside the buckets, match count)"""
+        String facets: n_buckets ids; numeric facets: ascending lower bounds of the ranges; Point facets (QueryFacet::Point):
+        base = (lat, lon), unit, and the lower bounds of the DISTANCE ranges.  -> (counts [n_buckets], docs outside the
+        buckets, match count)"""
+        if facet_type == "point":
+            bounds = np.asarray(range_lower_bounds, np.float64).view(np.uint64).copy()
+            nb = len(bounds)
+            out = np.zeros(nb + 1, np.uint64)
+            tot = C.c_uint64()
+            farr, nf = self.facet_filters(facet_filter) if facet_filter else (None, 0)
+            q = np.ascontiguousarray(query[:1])
+            pt = self._point(base, unit)
+            N.check(N.lib().ss_bm25_facet_count_point(self._h, q.ctypes.data, nf, None if farr is None else C.cast(farr, C.c_void_p),
+                                                      int(facet_offset), C.byref(pt), nb, N.ptr(bounds, N.u64p), N.ptr(out, N.u64p),
+                                                      C.byref(tot)), "ss_bm25_facet_count_point")
+            return out[:nb].copy(), int(out[nb]), tot.value
         if facet_type.startswith("string"):
             nb, bounds = int(n_buckets), None
         else:

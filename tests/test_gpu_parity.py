@@ -1131,3 +1131,98 @@ def test_result_sort_by_facets(S, O, lex):
     finally:
         sh.set_deleted([])
         osh.set_deleted([])
+
+
+def _ulps(a, b):
+    a = np.asarray(a, np.float64).view(np.int64)
+    b = np.asarray(b, np.float64).view(np.int64)
+    return np.abs(a - b)
+
+
+def test_point_facets(S, O, lex):
+    """Point facets (FieldType::Point = the u64 Morton code of (lat, lon), geo_search.rs): the distance filter
+    (FilterSparse::Point, add_result.rs:462-478: inside the reference's Morton range AND euclidian_distance inside the
+    range), distance-range counts (Ranges::Point, add_result.rs:605-618) and the sort by distance (morton_ordering,
+    min_heap.rs:510-528), km and miles, combined with another filter / a second sort field, against the oracle's f64
+    restatement.  The device's cos / sqrt may differ from libm in the last places: most distances are bit-equal, all within 16
+    ulp, so a doc could only change sides if it sat that close to a bound (none does with these seeds)."""
+    sh, osh, n_docs = lex
+    rng = np.random.default_rng(23)
+    rec = np.dtype([("pad", "u1"), ("loc", "<u8"), ("h", "<u2"), ("coarse", "<u8")])
+    lat = rng.random(n_docs) * 50.0 + 10.0          # a cloud over the north-east quadrant: the Morton range is a real range there
+    lon = rng.random(n_docs) * 60.0 + 5.0
+    v = np.zeros(n_docs, rec)
+    v["loc"] = O.morton_encode(lat, lon)
+    v["h"] = rng.integers(0, 50000, n_docs)
+    v["coarse"] = O.morton_encode(np.round(lat / 10.0) * 10.0, np.round(lon / 20.0) * 20.0)   # few distinct points: huge tie groups
+    sh.upload_facets(v.view(np.uint8).reshape(n_docs, rec.itemsize))
+    off = {n: rec.fields[n][1] for n in rec.names}
+    all_docs = np.arange(n_docs, dtype=np.uint32)
+    bases = [(38.8951, 30.25), (52.52, 13.405), (-10.0, -20.0)]
+    try:
+        # distances and stored codes as the library computes them
+        assert np.array_equal(sh.facet_values(all_docs[:5000], off["loc"], "point"), v["loc"][:5000])
+        for base in bases:
+            for unit in ("km", "miles", "sortkey"):
+                got = sh.facet_point_distances(all_docs, off["loc"], base, unit)
+                want = O.geo_distances(v["loc"], base, unit)
+                u = _ulps(got, want)
+                assert u.max() <= 16 and (u == 0).mean() > 0.9, (base, unit, u.max(), (u == 0).mean())
+        gone = list(range(7, n_docs, 197))
+        sh.set_deleted(gone)
+        cases = [([10, 9, 8], S.QueryType.Union, O.OP_OR), ([10, 9], S.QueryType.Intersection, O.OP_AND), ([3], S.QueryType.Union, O.OP_OR)]
+        # ---- filter
+        for base, lo, hi, unit in (((38.8951, 30.25), 0.0, 1000.0, "km"), ((38.8951, 30.25), 200.0, 900.0, "miles"),
+                                   ((52.52, 13.405), 100.0, 800.0, "km"), ((30.0, 1.0), 0.0, 800.0, "km"),   # box crosses lon 0: empty Z range
+                                   ((-10.0, -20.0), 0.0, 20000.0, "km")):
+            m0, m1 = O.geo_morton_range(base, hi, unit)
+            dist = O.geo_distances(v["loc"], base, unit)
+            keep = (v["loc"] >= np.uint64(m0)) & (v["loc"] < np.uint64(m1)) & (dist >= lo) & (dist < hi)
+            for extra, ekeep in ((None, np.ones(n_docs, bool)), ((off["h"], "u16", 1000, 30000), (v["h"] >= 1000) & (v["h"] < 30000))):
+                filt = [(off["loc"], "point", base, lo, hi, unit)] + ([extra] if extra else [])
+                osh.set_deleted(sorted(set(np.nonzero(~(keep & ekeep))[0].tolist()) | set(gone)))
+                for terms, qt, oop in cases:
+                    q = sh.make_queries([terms], qt)
+                    doc, score, cnt, tot = sh.search_lexical_batch(q, 10, S.ResultType.TopkCount, facet_filter=filt)
+                    od, os_, otot = osh.search_exhaustive(terms, oop, 10)
+                    assert int(tot[0]) == otot, (base, lo, hi, unit, terms)
+                    _check_topk(doc[0], score[0], cnt[0], od, os_)
+            if base == (30.0, 1.0):
+                assert m0 > m1 and not keep.any()       # the reference's Z-order range is empty when the box crosses a zero meridian
+            elif base[0] > 0:
+                assert keep.sum() > 1000
+        # ---- distance-range counts
+        osh.set_deleted(gone)
+        for base, unit, bounds in (((38.8951, 30.25), "km", [0.0, 200.0, 400.0, 600.0, 800.0]), ((52.52, 13.405), "miles", [100.0, 500.0, 1000.0])):
+            for terms, qt, oop in cases:
+                od, _, otot = osh.search_exhaustive(terms, oop, n_docs)
+                q = sh.make_queries([terms], qt)
+                counts, other, tot = sh.facet_count(q, off["loc"], "point", range_lower_bounds=bounds, base=base, unit=unit)
+                b = np.searchsorted(np.asarray(bounds), O.geo_distances(v["loc"][od], base, unit), side="right") - 1
+                assert tot == otot and other == int((b < 0).sum())
+                assert np.array_equal(counts, np.bincount(b[b >= 0], minlength=len(bounds)))
+        # ---- sort by distance
+        for terms, qt, oop in cases:
+            q = sh.make_queries([terms], qt)
+            ad, as_, atot = osh.search_exhaustive(terms, oop, n_docs)
+            for srt in ([("loc", False, bases[0])], [("loc", True, bases[1])], [("coarse", False, bases[0]), ("h", True, None)],
+                        [("coarse", True, bases[1])]):
+                for k, flt in ((10, None), (53, [(off["h"], "u16", 1000, 30000)])):
+                    keep = np.ones(len(ad), bool) if flt is None else (v["h"][ad] >= 1000) & (v["h"][ad] < 30000)
+                    md, ms = ad[keep], as_[keep]
+                    cols = []
+                    for name, desc, base in srt:
+                        x = O.geo_distances(v[name][md], base, "sortkey") if base else v[name][md].astype(np.float64)
+                        cols.append((-x if desc else x).tolist())
+                    order = sorted(range(len(md)), key=lambda i: tuple(c[i] for c in cols) + (-float(ms[i]),))[:k]
+                    spec = [(off[n], "point", d_, b_) if b_ else (off[n], "u16", d_) for n, d_, b_ in srt]
+                    doc, score, tot = sh.search_lexical_sorted(q, spec, k, facet_filter=flt)
+                    assert tot == len(md) and len(doc) == len(order), (terms, srt, k)
+                    for name, _, base in srt:
+                        assert np.array_equal(v[name][doc], v[name][md[order]]), (terms, srt, k, name)
+                    assert np.allclose(score, ms[order], rtol=1e-4), (terms, srt, k)
+        with pytest.raises(S.SeekStormHipError):
+            sh.facet_count(q, off["loc"], "point", range_lower_bounds=[0.0], base=(0.0, 0.0), unit="km", facet_filter=[(off["coarse"] + 1, "point", (0.0, 0.0), 0.0, 1.0, "km")])
+    finally:
+        sh.set_deleted([])
+        osh.set_deleted([])

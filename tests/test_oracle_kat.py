@@ -447,3 +447,38 @@ def test_phrase_match_reference_loop_equals_definition():
         assert a == b, (lists,)
         hits += a
     assert 200 < hits < 3800
+
+
+def test_geo_morton_and_distances():
+    """Point facets (geo_search.rs): the reference's tests hold no vectors for these, so the oracle's restatement is checked
+    against what defines it -- latitude in the even bits and longitude in the odd ones of (deg * 1e7) as i32, the cast's
+    truncation and saturation, decode o encode = truncation to 1e-7 deg, and the two distance formulas against numpy."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    lat, lon = rng.random(2000) * 180 - 90, rng.random(2000) * 360 - 180
+    codes = O.morton_encode(lat, lon)
+    xi = np.trunc(lat * 1e7).astype(np.int64).astype(np.int32).view(np.uint32)
+    yi = np.trunc(lon * 1e7).astype(np.int64).astype(np.int32).view(np.uint32)
+    for c, x, y in zip(codes[:300], xi[:300], yi[:300]):
+        even = sum(((int(c) >> (2 * b)) & 1) << b for b in range(32))
+        odd = sum(((int(c) >> (2 * b + 1)) & 1) << b for b in range(32))
+        assert even == int(x) and odd == int(y)
+    back = O.morton_decode(codes)
+    assert np.array_equal(back[:, 0], xi.view(np.int32) / 1e7) and np.array_equal(back[:, 1], yi.view(np.int32) / 1e7)
+    assert np.abs(back[:, 0] - lat).max() < 1.0001e-7 and np.abs(back[:, 1] - lon).max() < 1.0001e-7
+    assert int(O.morton_encode([1000.0], [float("nan")])[0]) == sum(1 << (2 * b) for b in range(31))   # lat saturates to i32::MAX, NaN -> 0
+    assert int(O.morton_encode([38.8951], [-77.0364])[0]) == 0xA31D06765CE7D940
+    base = (38.8951, -77.0364)
+    d2r, r_km = 0.017453292519943295, 6371.0087714
+    x = d2r * (back[:, 1] - base[1]) * np.cos(d2r * (base[0] + back[:, 0]) / 2.0)
+    y = d2r * (back[:, 0] - base[0])
+    assert np.allclose(O.geo_distances(codes, base, "km"), r_km * np.sqrt(x * x + y * y), rtol=1e-12)
+    assert np.allclose(O.geo_distances(codes, base, "miles") / O.geo_distances(codes, base, "km")[None, :], 3958.761315801475 / r_km, rtol=1e-12)
+    xs = (base[1] - back[:, 1]) * np.cos(d2r * (back[:, 0] + base[0]) / 2.0)
+    assert np.allclose(O.geo_distances(codes, base, "sortkey"), xs * xs + (base[0] - back[:, 0]) ** 2, rtol=1e-12)
+    # Washington - New York: 328 km by the equirectangular formula
+    ny = O.morton_encode([40.7128], [-74.0060])
+    assert abs(O.geo_distances(ny, base, "km")[0] - 328.0) < 2.0
+    m0, m1 = O.geo_morton_range(base, 100.0, "km")
+    lat_d, lon_d = 100.0 / (d2r * r_km), 100.0 / (d2r * r_km * np.cos(d2r * base[0]))
+    assert m0 == int(O.morton_encode([base[0] - lat_d], [base[1] - lon_d])[0]) and m1 == int(O.morton_encode([base[0] + lat_d], [base[1] + lon_d])[0])
