@@ -107,6 +107,48 @@ int ssh_search_lexical_shard_filtered(ssh_index* ix, int shard, const uint32_t* 
   return write_out(ro, cap, out_doc, out_score, nullptr, nullptr, nullptr, out_meta);
 }
 
+// Shard::search_lexical_shard with every option of the seam: facet filter, NOT terms, field filter, result sort
+struct ssh_result_sort {
+  uint32_t facet_offset, facet_type, descending, reserved;
+  double base[2];
+};
+int ssh_search_lexical_shard_ex(ssh_index* ix, int shard, const uint32_t* terms, uint32_t n_terms, uint32_t query_type,
+                                uint32_t offset, uint32_t length, uint32_t result_type, uint32_t n_filters,
+                                const ss_facet_filter* filters, const uint32_t* not_terms, uint32_t n_not, const uint16_t* field_filter,
+                                uint32_t n_field_filter, const ssh_result_sort* sorts, uint32_t n_sorts, uint32_t cap, uint64_t* out_doc,
+                                float* out_score, uint64_t* out_meta) {
+  std::vector<uint32_t> t(terms, terms + n_terms), nt(not_terms, not_terms + n_not);
+  std::vector<ss_facet_filter> f(filters, filters + n_filters);
+  std::vector<uint16_t> ff(field_filter, field_filter + n_field_filter);
+  std::vector<ResultSort> rs(n_sorts);
+  for (uint32_t i = 0; i < n_sorts; i++) {
+    rs[i].facet_offset = sorts[i].facet_offset;
+    rs[i].facet_type = sorts[i].facet_type;
+    rs[i].descending = sorts[i].descending != 0;
+    rs[i].base[0] = sorts[i].base[0];
+    rs[i].base[1] = sorts[i].base[1];
+  }
+  ResultObject ro = ix->shards[shard]->search_lexical_shard(t, (QueryType)query_type, offset, length, (ResultType)result_type, f, nt, ff, rs);
+  return write_out(ro, cap, out_doc, out_score, nullptr, nullptr, nullptr, out_meta);
+}
+int ssh_upload_lexical_fields(ssh_index* ix, int shard, uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost,
+                              uint32_t n_terms, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields, const uint16_t* tfs) {
+  return ix->shards[shard]->upload_lexical_fields(n_docs, n_fields, doclen, boost, n_terms, offs, docs, fields, tfs);
+}
+// Shard::facet_count of one query; out_counts [n_buckets + 1]
+int ssh_facet_count(ssh_index* ix, int shard, const uint32_t* terms, uint32_t n_terms, uint32_t query_type, uint32_t facet_offset,
+                    uint32_t facet_type, uint32_t n_buckets, const uint64_t* bounds, uint32_t n_bounds, const ss_facet_point* base,
+                    uint32_t n_filters, const ss_facet_filter* filters, uint64_t* out_counts, uint64_t* out_total) {
+  ss_bm25_query q;
+  const int rc = ix->shards[shard]->make_query(std::vector<uint32_t>(terms, terms + n_terms), (QueryType)query_type, &q);
+  if (rc != SS_OK) return rc;
+  std::vector<uint64_t> counts;
+  const int rc2 = ix->shards[shard]->facet_count(q, facet_offset, facet_type, n_buckets, std::vector<uint64_t>(bounds, bounds + n_bounds), &counts,
+                                                 out_total, std::vector<ss_facet_filter>(filters, filters + n_filters), base);
+  if (rc2 == SS_OK) std::memcpy(out_counts, counts.data(), counts.size() * 8);
+  return rc2;
+}
+
 // Shard::search_vector_shard with an AnnMode: kind 0 All, 1 Similaritythreshold(t), 2 Nprobe(n), 3 NprobeSimilaritythreshold(n, t);
 // out_meta[4] = count, total, observed vectors, last_error; *out_clusters = observed_cluster_count
 int ssh_set_clusters(ssh_index* ix, int shard, uint32_t n_levels, const uint32_t* level_clusters, uint32_t n_clusters,

@@ -2,6 +2,8 @@
 #include "seekstorm_host.hpp"
 
 #include <algorithm>
+#include <limits>
+#include <unordered_map>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -210,7 +212,7 @@ int Shard::synth_vectors(uint64_t seed, uint64_t n_rows, uint32_t dim) {
 }
 
 int Shard::make_query(const std::vector<uint32_t>& terms, QueryType qt, ss_bm25_query* out,
-                      const std::vector<uint32_t>& not_terms) {
+                      const std::vector<uint32_t>& not_terms, const std::vector<uint16_t>& field_filter) {
   if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
   std::vector<uint32_t> uniq, nots;  // unique_terms in first-seen order (search.rs:3023)
   for (uint32_t t : terms)
@@ -233,7 +235,12 @@ int Shard::make_query(const std::vector<uint32_t>& terms, QueryType qt, ss_bm25_
         out->phrase_seq[i] = (uint8_t)(std::find(uniq.begin(), uniq.end(), terms[i]) - uniq.begin());
     }
   }
-  out->op = (uint32_t)qt | SS_OP_NOT_TERMS(nots.size());
+  uint32_t fmask = 0;
+  for (uint16_t f : field_filter) {
+    if (f >= 15) return SS_EINVAL;
+    fmask |= 1u << f;
+  }
+  out->op = (uint32_t)qt | SS_OP_NOT_TERMS(nots.size()) | SS_OP_FIELD_FILTER(fmask);
   for (size_t i = 0; i < uniq.size(); i++) {
     out->term[i] = uniq[i];
     const bool ngram = uniq[i] < ngram_components_.size() && ngram_components_[uniq[i]] > 1;
@@ -387,16 +394,233 @@ std::vector<ResultObject> Shard::search_vector_batch(const float* query_vectors,
   return out;
 }
 
-ResultObject Shard::search_lexical_shard(const std::vector<uint32_t>& query_terms, QueryType query_type_default, size_t offset,
-                                         size_t length, ResultType result_type, const std::vector<ss_facet_filter>& facet_filter) {
-  ss_bm25_query q;
-  const int rc = make_query(query_terms, query_type_default, &q);
-  if (rc != SS_OK) {
-    ResultObject ro;
-    ro.last_error = rc;
-    return ro;
+ss_facet_filter point_facet_filter(uint32_t facet_offset, const double base[2], double lo, double hi, uint32_t unit, uint32_t flags) {
+  ss_facet_filter f;
+  std::memset(&f, 0, sizeof(f));
+  f.offset = facet_offset;
+  f.type = SS_FACET_POINT;
+  std::memcpy(&f.lo, &lo, 8);
+  std::memcpy(&f.hi, &hi, 8);
+  std::memcpy(&f.values[0], &base[0], 8);
+  std::memcpy(&f.values[2], &base[1], 8);
+  f.n_values = unit;
+  f.reserved = flags;
+  return f;
+}
+
+int Shard::facet_count(const ss_bm25_query& query, uint32_t facet_offset, uint32_t facet_type, uint32_t n_buckets,
+                       const std::vector<uint64_t>& range_lower_bounds, std::vector<uint64_t>* counts, uint64_t* total,
+                       const std::vector<ss_facet_filter>& facet_filter, const ss_facet_point* base) {
+  if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
+  const bool strings = facet_type == SS_FACET_STRING16 || facet_type == SS_FACET_STRING32;
+  const uint32_t nb = strings ? n_buckets : (uint32_t)range_lower_bounds.size();
+  if (!counts || nb == 0) return SS_EINVAL;
+  counts->assign((size_t)nb + 1, 0);
+  const ss_facet_filter* fp = facet_filter.empty() ? nullptr : facet_filter.data();
+  if (facet_type == SS_FACET_POINT)
+    return ss_bm25_facet_count_point(h_, &query, (uint32_t)facet_filter.size(), fp, facet_offset, base, nb, range_lower_bounds.data(),
+                                     counts->data(), total);
+  return ss_bm25_facet_count(h_, &query, (uint32_t)facet_filter.size(), fp, facet_offset, facet_type, nb,
+                             strings ? nullptr : range_lower_bounds.data(), counts->data(), total);
+}
+
+// ---- result sort (search.rs ResultSort; ordering result_ordering_shard, min_heap.rs:574-1050): the k best matches under
+// (field 1, field 2, ..., score).  Composed from ordinary searches around the sort's pivot -- the k-th best value of the first
+// field among the matches (ss_bm25_facet_kth[_point]): "strictly better" holds fewer than k docs, which are fetched by a
+// search filtered to that range and ordered here by their values; the "equal" ones recurse on the remaining fields.
+namespace {
+uint64_t order_key(uint64_t bits, uint32_t type, bool descending) {  // larger = better under the sort
+  static const uint32_t width[] = {8, 16, 32, 64, 8, 16, 32, 64, 32, 64};
+  const uint32_t nb = width[type];
+  const uint64_t mask = nb == 64 ? ~0ull : ((1ull << nb) - 1ull), top = 1ull << (nb - 1);
+  uint64_t k = bits & mask;
+  if (type >= SS_FACET_I8 && type <= SS_FACET_I64) k ^= top;
+  else if (type == SS_FACET_F32 || type == SS_FACET_F64) k = (k & top) ? (~k & mask) : (k | top);
+  return descending ? k : (~k & mask);
+}
+uint64_t filter_bits(uint64_t v, uint32_t type) {  // stored bits -> ss_facet_filter's form (signed integers sign-extended)
+  switch (type) {
+    case SS_FACET_I8: return (uint64_t)(int64_t)(int8_t)v;
+    case SS_FACET_I16: return (uint64_t)(int64_t)(int16_t)v;
+    case SS_FACET_I32: return (uint64_t)(int64_t)(int32_t)v;
+    default: return v;
   }
-  ResultObject ro = std::move(search_lexical_batch({q}, offset + length, result_type, facet_filter)[0]);
+}
+void type_range(uint32_t type, uint64_t* lo, uint64_t* hi) {  // smallest / largest value of the type in the filter's form
+  static const uint32_t width[] = {8, 16, 32, 64, 8, 16, 32, 64, 32, 64};
+  const uint32_t nb = width[type];
+  if (type <= SS_FACET_U64) { *lo = 0; *hi = nb == 64 ? ~0ull : ((1ull << nb) - 1ull); }
+  else if (type <= SS_FACET_I64) { *lo = (uint64_t)(-(int64_t)(1ull << (nb - 1))); *hi = (1ull << (nb - 1)) - 1ull; }
+  else if (type == SS_FACET_F32) { *lo = 0xFF800000ull; *hi = 0x7F800000ull; }             // -inf, +inf
+  else { *lo = 0xFFF0000000000000ull; *hi = 0x7FF0000000000000ull; }
+}
+ss_facet_filter bits_filter(uint32_t offset, uint32_t type, uint64_t lo, uint64_t hi, uint32_t flags) {
+  ss_facet_filter f;
+  std::memset(&f, 0, sizeof(f));
+  f.offset = offset; f.type = type; f.lo = lo; f.hi = hi; f.reserved = flags;
+  return f;
+}
+}  // namespace
+
+int Shard::sorted_topk(const ss_bm25_query& q, const ResultSort* sorts, size_t n_sorts, size_t k, std::vector<ss_facet_filter> filters,
+                       std::vector<Result>* out, uint64_t* total, bool* have_total) {
+  if (k == 0) return SS_OK;
+  if (n_sorts == 0) {  // by score
+    ResultObject ro = std::move(search_lexical_batch({q}, k, ResultType::TopkCount, filters)[0]);
+    if (ro.last_error != SS_OK) return ro.last_error;
+    if (!*have_total) { *total = ro.result_count_total; *have_total = true; }
+    out->insert(out->end(), ro.results.begin(), ro.results.end());
+    return SS_OK;
+  }
+  if (filters.size() + 1 > SS_MAX_FACET_FILTERS) return SS_EINVAL;
+  const ResultSort& s0 = sorts[0];
+  const bool point = s0.facet_type == SS_FACET_POINT;
+  const ss_facet_filter* fp = filters.empty() ? nullptr : filters.data();
+  uint64_t v = 0, n_better = 0, n_equal = 0, tot = 0;
+  int rc;
+  if (point) {
+    const ss_facet_point base{s0.base[0], s0.base[1], SS_POINT_SORTKEY, 0};
+    rc = ss_bm25_facet_kth_point(h_, &q, (uint32_t)filters.size(), fp, s0.facet_offset, &base, s0.descending ? 1u : 0u, k, &v, &n_better,
+                                 &n_equal, &tot);
+  } else {
+    rc = ss_bm25_facet_kth(h_, &q, (uint32_t)filters.size(), fp, s0.facet_offset, s0.facet_type, s0.descending ? 1u : 0u, k, &v,
+                           &n_better, &n_equal, &tot);
+  }
+  if (rc != SS_OK) return rc;
+  if (!*have_total) { *total = tot; *have_total = true; }
+  if (tot == 0) return SS_OK;
+  ss_facet_filter better, equal;
+  if (point) {
+    double pv;
+    std::memcpy(&pv, &v, 8);
+    const double inf = std::numeric_limits<double>::infinity();
+    better = s0.descending ? point_facet_filter(s0.facet_offset, s0.base, pv, inf, SS_POINT_SORTKEY, SS_FACET_LO_EXCLUSIVE | SS_FACET_HI_INCLUSIVE)
+                           : point_facet_filter(s0.facet_offset, s0.base, -inf, pv, SS_POINT_SORTKEY, 0);
+    equal = point_facet_filter(s0.facet_offset, s0.base, pv, pv, SS_POINT_SORTKEY, SS_FACET_HI_INCLUSIVE);
+  } else {
+    const uint64_t vb = filter_bits(v, s0.facet_type);
+    uint64_t lo_all, hi_all;
+    type_range(s0.facet_type, &lo_all, &hi_all);
+    better = s0.descending ? bits_filter(s0.facet_offset, s0.facet_type, vb, hi_all, SS_FACET_LO_EXCLUSIVE | SS_FACET_HI_INCLUSIVE)
+                           : bits_filter(s0.facet_offset, s0.facet_type, lo_all, vb, 0);
+    equal = bits_filter(s0.facet_offset, s0.facet_type, vb, vb, SS_FACET_HI_INCLUSIVE);
+  }
+  if (n_better) {
+    std::vector<ss_facet_filter> fb = filters;
+    fb.push_back(better);
+    std::vector<Result> got;
+    rc = sorted_topk(q, nullptr, 0, (size_t)n_better, fb, &got, total, have_total);
+    if (rc != SS_OK) return rc;
+    std::vector<uint32_t> docs(got.size());
+    for (size_t i = 0; i < got.size(); i++) docs[i] = (uint32_t)got[i].doc_id;
+    std::vector<std::vector<uint64_t>> keys(n_sorts, std::vector<uint64_t>(got.size()));
+    for (size_t f = 0; f < n_sorts && !got.empty(); f++) {
+      const ResultSort& sf = sorts[f];
+      if (sf.facet_type == SS_FACET_POINT) {
+        const ss_facet_point base{sf.base[0], sf.base[1], SS_POINT_SORTKEY, 0};
+        rc = ss_facet_point_distances(h_, (uint32_t)docs.size(), docs.data(), sf.facet_offset, &base, keys[f].data());
+      } else {
+        rc = ss_facet_values(h_, (uint32_t)docs.size(), docs.data(), sf.facet_offset, sf.facet_type, keys[f].data());
+      }
+      if (rc != SS_OK) return rc;
+      const uint32_t kt = sf.facet_type == SS_FACET_POINT ? (uint32_t)SS_FACET_F64 : sf.facet_type;
+      for (uint64_t& x : keys[f]) x = order_key(x, kt, sf.descending);
+    }
+    std::vector<size_t> order(got.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+      for (size_t f = 0; f < n_sorts; f++)
+        if (keys[f][a] != keys[f][b]) return keys[f][a] > keys[f][b];
+      if (got[a].score != got[b].score) return got[a].score > got[b].score;
+      return got[a].doc_id < got[b].doc_id;
+    });
+    for (size_t i : order) out->push_back(got[i]);
+  }
+  if (n_better < k && n_equal) {
+    filters.push_back(equal);
+    return sorted_topk(q, sorts + 1, n_sorts - 1, k - (size_t)n_better, filters, out, total, have_total);
+  }
+  return SS_OK;
+}
+
+// A union of several terms under a field filter.  The reference answers it through sub-queries: union_docid_3 queues the
+// intersection of all terms and every subset one term shorter, down to pairs (union.rs:1330-1425), union_docid_2 runs a pair as
+// its intersection plus the two single terms (union.rs:1168-1305), the filter (add_result.rs:3124-3136) applies to the terms of
+// the sub-query that finds the doc, and a doc found again keeps its better score (docid_hashset, min_heap.rs:1193-1260): every
+// subset of the terms is tried as a filtered intersection and a doc ends with the best of them.  Here: the 2^n - 1 filtered
+// intersections as ONE device batch, merged per doc by the maximum.  Totals as the reference reports them: two terms ->
+// |pass(X) u pass(Y)| (union_docid_2's count), more -> the unfiltered union (union_scan counts before the filter, union.rs:552).
+ResultObject Shard::union_with_field_filter(const std::vector<uint32_t>& terms, size_t k, ResultType result_type,
+                                            const std::vector<uint32_t>& not_terms, const std::vector<uint16_t>& field_filter,
+                                            const std::vector<ss_facet_filter>& facet_filter) {
+  ResultObject ro;
+  const size_t n = terms.size();
+  if (n > 5) { ro.last_error = SS_ENOTSUP; return ro; }
+  std::vector<ss_bm25_query> qs((1u << n) - 1);
+  for (uint32_t m = 1; m < (1u << n); m++) {
+    std::vector<uint32_t> sub;
+    for (size_t i = 0; i < n; i++)
+      if ((m >> i) & 1u) sub.push_back(terms[i]);
+    const int rc = make_query(sub, QueryType::Intersection, &qs[m - 1], not_terms, field_filter);
+    if (rc != SS_OK) { ro.last_error = rc; return ro; }
+  }
+  const ResultType rt = result_type == ResultType::Topk ? ResultType::Topk : ResultType::TopkCount;
+  std::vector<ResultObject> parts = search_lexical_batch(qs, std::max<size_t>(k, 1), rt, facet_filter);
+  std::unordered_map<uint64_t, Result> best;
+  for (const ResultObject& p : parts) {
+    if (p.last_error != SS_OK) { ro.last_error = p.last_error; return ro; }
+    for (const Result& r : p.results) {
+      auto it = best.find(r.doc_id);
+      if (it == best.end()) best.emplace(r.doc_id, r);
+      else if (r.score > it->second.score) it->second = r;
+    }
+  }
+  std::vector<Result> ranked;
+  ranked.reserve(best.size());
+  for (auto& e : best) ranked.push_back(e.second);
+  std::sort(ranked.begin(), ranked.end(), [](const Result& a, const Result& b) { return a.score != b.score ? a.score > b.score : a.doc_id < b.doc_id; });
+  if (ranked.size() > k) ranked.resize(k);
+  if (result_type == ResultType::Topk) ro.result_count_total = ranked.size();
+  else if (n == 2) ro.result_count_total = parts[0].result_count_total + parts[1].result_count_total - parts[2].result_count_total;
+  else {
+    ss_bm25_query qu;
+    const int rc = make_query(terms, QueryType::Union, &qu, not_terms);
+    if (rc != SS_OK) { ro.last_error = rc; return ro; }
+    ResultObject c = std::move(search_lexical_batch({qu}, 1, ResultType::Count, facet_filter)[0]);
+    if (c.last_error != SS_OK) { ro.last_error = c.last_error; return ro; }
+    ro.result_count_total = c.result_count_total;
+  }
+  if (result_type != ResultType::Count) ro.results = std::move(ranked);
+  ro.result_count = ro.results.size();
+  return ro;
+}
+
+ResultObject Shard::search_lexical_shard(const std::vector<uint32_t>& query_terms, QueryType query_type_default, size_t offset,
+                                         size_t length, ResultType result_type, const std::vector<ss_facet_filter>& facet_filter,
+                                         const std::vector<uint32_t>& not_terms, const std::vector<uint16_t>& field_filter,
+                                         const std::vector<ResultSort>& result_sort) {
+  ResultObject ro;
+  std::vector<uint32_t> uniq;
+  for (uint32_t t : query_terms)
+    if (std::find(uniq.begin(), uniq.end(), t) == uniq.end()) uniq.push_back(t);
+  if (!field_filter.empty() && lexical_fields_ > 1 && query_type_default == QueryType::Union && uniq.size() > 1) {
+    if (!result_sort.empty()) { ro.last_error = SS_ENOTSUP; return ro; }
+    ro = union_with_field_filter(uniq, offset + length, result_type, not_terms, field_filter, facet_filter);
+  } else {
+    ss_bm25_query q;
+    const int rc = make_query(query_terms, query_type_default, &q, not_terms, lexical_fields_ > 1 ? field_filter : std::vector<uint16_t>());
+    if (rc != SS_OK) { ro.last_error = rc; return ro; }
+    if (!result_sort.empty() && result_type != ResultType::Count) {
+      uint64_t total = 0;
+      bool have_total = false;
+      const int rs = sorted_topk(q, result_sort.data(), result_sort.size(), offset + length, facet_filter, &ro.results, &total, &have_total);
+      if (rs != SS_OK) { ro = ResultObject(); ro.last_error = rs; return ro; }
+      ro.result_count_total = total;
+      ro.result_count = ro.results.size();
+    } else {
+      ro = std::move(search_lexical_batch({q}, offset + length, result_type, facet_filter)[0]);
+    }
+  }
   if (offset) {  // drain offset (search.rs:3585-3593)
     ro.results.erase(ro.results.begin(), ro.results.begin() + std::min(offset, ro.results.size()));
     ro.result_count = ro.results.size();

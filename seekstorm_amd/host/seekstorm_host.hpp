@@ -78,6 +78,18 @@ void turboquant_f32_to_i8(const float* v, size_t n, const float* seed_mask, size
 float threshold_raw(const float* similarity_threshold, bool euclidean = false);  // TopK::new, vector.rs:388-398; nullptr = none
 float vector_score_of(float raw_dot);                           // vector.rs:1495-1499: ((dot / 16129) + 1) / 2
 
+// search.rs ResultSort: one sort field of a lexical search -- a numeric facet (its offset inside the facet.bin record and its
+// SS_FACET_* type) ascending or descending, or a Point facet (type SS_FACET_POINT) by its distance to `base` (lat, lon).
+struct ResultSort {
+  uint32_t facet_offset = 0;
+  uint32_t facet_type = SS_FACET_U32;
+  bool descending = false;
+  double base[2] = {0.0, 0.0};
+};
+// FacetFilter::Point (search.rs:852-859) as an ss_facet_filter: the distance to base inside [lo, hi), unit SS_POINT_KM / _MILES
+ss_facet_filter point_facet_filter(uint32_t facet_offset, const double base[2], double lo, double hi, uint32_t unit, uint32_t flags = 0);
+
+
 // One shard image on one MI355X.
 class Shard {
  public:
@@ -123,12 +135,23 @@ class Shard {
   uint32_t dim() const { return dim_; }
 
   // term resolution result -> device query (idf from shard-local N and posting_count, search.rs:3225-3230)
+  // field_filter: indexed field ids every term must occur in one of (several indexed fields, search.rs:2483-2492)
   int make_query(const std::vector<uint32_t>& terms, QueryType qt, ss_bm25_query* out,
-                 const std::vector<uint32_t>& not_terms = {});
+                 const std::vector<uint32_t>& not_terms = {}, const std::vector<uint16_t>& field_filter = {});
 
   // the reference's per-shard seams (one query)
+  // not_terms: the "-term" operands; field_filter: indexed field ids (a union of several terms under it is answered through
+  // the reference's own sub-queries, union.rs:1168-1479); result_sort: Vec<ResultSort> over numeric and Point facets
   ResultObject search_lexical_shard(const std::vector<uint32_t>& query_terms, QueryType query_type_default, size_t offset,
-                                    size_t length, ResultType result_type, const std::vector<ss_facet_filter>& facet_filter = {});
+                                    size_t length, ResultType result_type, const std::vector<ss_facet_filter>& facet_filter = {},
+                                    const std::vector<uint32_t>& not_terms = {}, const std::vector<uint16_t>& field_filter = {},
+                                    const std::vector<ResultSort>& result_sort = {});
+  // query_facets of one query (facet_count, add_result.rs:484-640): counts [n_buckets + 1], the last slot = outside the buckets.
+  // String facets: n_buckets ids (bounds empty); numeric facets: the ranges' ascending lower bounds as the value's bits;
+  // Point facets (facet_type SS_FACET_POINT): base + the lower bounds of the distance ranges as f64 bits.
+  int facet_count(const ss_bm25_query& query, uint32_t facet_offset, uint32_t facet_type, uint32_t n_buckets,
+                  const std::vector<uint64_t>& range_lower_bounds, std::vector<uint64_t>* counts, uint64_t* total,
+                  const std::vector<ss_facet_filter>& facet_filter = {}, const ss_facet_point* base = nullptr);
   // field_filter: indexed field ids to search (the reference resolves the names through schema_map, vector.rs:1225-1237);
   // empty = every field
   ResultObject search_vector_shard(const float* query_vector /* normalised, dim() floats */, size_t length,
@@ -150,6 +173,11 @@ class Shard {
   int set_clusters(const std::vector<uint32_t>& level_clusters, const std::vector<uint32_t>& child_count);
 
  private:
+  ResultObject union_with_field_filter(const std::vector<uint32_t>& terms, size_t k, ResultType result_type,
+                                       const std::vector<uint32_t>& not_terms, const std::vector<uint16_t>& field_filter,
+                                       const std::vector<ss_facet_filter>& facet_filter);
+  int sorted_topk(const ss_bm25_query& q, const ResultSort* sorts, size_t n_sorts, size_t k, std::vector<ss_facet_filter> filters,
+                  std::vector<Result>* out, uint64_t* total, bool* have_total);
   ss_shard* h_ = nullptr;
   uint32_t shard_id_ = 0;
   int device_ = 0;

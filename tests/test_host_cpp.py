@@ -45,6 +45,12 @@ def H():
                              C.c_int, C.c_float, C.c_int, C.c_uint32, u64p, f32p, u8p, f32p, f32p, u64p]
     L.ssh_search_lexical_shard.argtypes = [C.c_void_p, C.c_int, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                            C.c_uint32, C.c_uint32, u64p, f32p, u64p]
+    L.ssh_search_lexical_shard_ex.argtypes = [C.c_void_p, C.c_int, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                              C.c_uint32, C.c_void_p, u32p, C.c_uint32, C.POINTER(C.c_uint16), C.c_uint32, C.c_void_p,
+                                              C.c_uint32, C.c_uint32, u64p, f32p, u64p]
+    L.ssh_upload_lexical_fields.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, u8p, f32p, C.c_uint32, u64p, u32p, u8p, u16p]
+    L.ssh_facet_count.argtypes = [C.c_void_p, C.c_int, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u64p, C.c_uint32,
+                                  C.c_void_p, C.c_uint32, C.c_void_p, u64p, u64p]
     L.ssh_coalesced_vector_search.argtypes = [C.c_void_p, C.c_int, C.c_uint32, f32p, C.c_uint32, C.c_uint32, C.c_uint32,
                                               u64p, f32p, u32p]
     L.ssh_upload_vectors_i8.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, u32p]
@@ -458,3 +464,129 @@ def test_cpp_index_lexical_batch_host_gather_and_device_exchange(H):
     finally:
         H.ssh_index_destroy(ix2)
         H.ssh_index_destroy(ix1)
+
+
+class _SortC(C.Structure):  # ssh_result_sort
+    _fields_ = [("facet_offset", C.c_uint32), ("facet_type", C.c_uint32), ("descending", C.c_uint32), ("reserved", C.c_uint32),
+                ("base", C.c_double * 2)]
+
+
+def _cpp_lexical_ex(H, ix, terms, qt, offset, length, rt, facet_filter=None, not_terms=(), field_filter=(), sorts=()):
+    import seekstorm_amd as S
+    from seekstorm_amd import _native as N
+    t = np.ascontiguousarray(terms, np.uint32)
+    nt = np.ascontiguousarray(list(not_terms), np.uint32)
+    ff = np.ascontiguousarray(list(field_filter), np.uint16)
+    farr, nf = S.Shard.facet_filters(facet_filter) if facet_filter else (None, 0)
+    sarr = (_SortC * max(len(sorts), 1))()
+    for i, so in enumerate(sorts):
+        sarr[i].facet_offset, sarr[i].facet_type, sarr[i].descending = so[0], N.FACET_TYPES[so[1]], 1 if so[2] else 0
+        if so[1] == "point":
+            sarr[i].base[0], sarr[i].base[1] = so[3]
+    cap = offset + length + 1
+    doc = np.zeros(cap, np.uint64); sc = np.zeros(cap, np.float32); meta = np.zeros(4, np.uint64)
+    n = H.ssh_search_lexical_shard_ex(ix, 0, P(t, u32p), len(t), qt, offset, length, rt, nf, None if farr is None else C.cast(farr, C.c_void_p),
+                                      P(nt, u32p), len(nt), ff.ctypes.data_as(C.POINTER(C.c_uint16)), len(ff), C.cast(sarr, C.c_void_p),
+                                      len(sorts), cap, P(doc, u64p), P(sc, f32p), P(meta, u64p))
+    assert int(meta[3]) == 0, int(np.int64(meta[3]))
+    return doc[:n].copy(), sc[:n].copy(), int(meta[1])
+
+
+@pytest.mark.gpu
+def test_cpp_shard_result_sort_point_facets_and_counts(H):
+    """The C++ mirror's search_lexical_shard with result_sort (numeric and Point sort fields, a Point distance filter) and
+    facet_count (numeric ranges, Point distance ranges) answer exactly like the Python mirror -- which the parity tests pin to
+    the oracle (test_result_sort_by_facets, test_point_facets) -- on the same shard contents."""
+    from oracle import oracle as O
+    import seekstorm_amd as S
+    n_docs = 120_000
+    dl = O.lex_doclen(n_docs)
+    offs, docs, tfs = O.lex_corpus(n_docs, [4095, 4000, 3000])
+    rng = np.random.default_rng(29)
+    rec = np.dtype([("c", "<i4"), ("a", "u1"), ("loc", "<u8"), ("g", "<f8")])
+    v = np.zeros(n_docs, rec)
+    v["c"] = rng.integers(-1000, 1000, n_docs); v["a"] = rng.integers(0, 4, n_docs); v["g"] = rng.standard_normal(n_docs)
+    v["loc"] = O.morton_encode(np.round(rng.random(n_docs) * 50.0 + 10.0, 1), np.round(rng.random(n_docs) * 60.0 + 5.0, 1))
+    raw = v.view(np.uint8).reshape(n_docs, rec.itemsize).copy()
+    off = {n: rec.fields[n][1] for n in rec.names}
+    psh = S.Shard(0)
+    psh.upload_lexical(n_docs, dl, offs, docs, tfs)
+    psh.upload_facets(raw)
+    ix = H.ssh_index_create(1, None)
+    try:
+        assert H.ssh_upload_lexical(ix, 0, n_docs, P(dl, u8p), len(offs) - 1, P(offs, u64p), P(docs, u32p), P(tfs, u16p)) == 0
+        assert H.ssh_upload_facets(ix, 0, n_docs, rec.itemsize, raw.ctypes.data) == 0
+        base = (38.9, 30.2)
+        pfilter = [(off["loc"], "point", base, 100.0, 1500.0, "km")]
+        for terms, qt in (([0, 1, 2], 1), ([0, 1], 0)):
+            q = psh.make_queries([terms], S.QueryType(qt))
+            for sorts in ([(off["c"], "i32", True)], [(off["a"], "u8", False), (off["g"], "f64", True)], [(off["loc"], "point", False, base)],
+                          [(off["a"], "u8", True), (off["loc"], "point", True, base), (off["c"], "i32", False)]):
+                for k, flt in ((10, None), (33, pfilter), (25, [(off["c"], "i32", -500, 700)])):
+                    pd, ps, ptot = psh.search_lexical_sorted(q, sorts, k, facet_filter=flt)
+                    cd, cs, ctot = _cpp_lexical_ex(H, ix, terms, qt, 0, k, 2, facet_filter=flt, sorts=sorts)
+                    assert ctot == ptot and len(cd) == len(pd), (terms, sorts, k)
+                    assert np.allclose(cs, ps, rtol=1e-6), (terms, sorts, k)
+                    for name in ("c", "a", "loc", "g"):
+                        assert np.array_equal(v[name][cd.astype(np.int64)], v[name][pd]), (terms, sorts, k, name)
+            # offset drains the head of the sorted list
+            pd, ps, _ = psh.search_lexical_sorted(q, [(off["c"], "i32", True)], 20)
+            cd, cs, _ = _cpp_lexical_ex(H, ix, terms, qt, 5, 15, 2, sorts=[(off["c"], "i32", True)])
+            assert np.allclose(cs, ps[5:], rtol=1e-6)
+            # facet counts
+            t = np.ascontiguousarray(terms, np.uint32)
+            for ftype, foff, bounds, pt in (("i32", off["c"], np.array([-500, 0, 250], np.int64).view(np.uint64), None),
+                                            ("point", off["loc"], np.array([0.0, 500.0, 1000.0, 2000.0]).view(np.uint64), base)):
+                out = np.zeros(len(bounds) + 1, np.uint64)
+                tot = C.c_uint64()
+                from seekstorm_amd import _native as N
+                ptc = N.FacetPointC(pt[0], pt[1], 1, 0) if pt else None
+                farr, nf = S.Shard.facet_filters(pfilter)
+                rc = H.ssh_facet_count(ix, 0, P(t, u32p), len(t), qt, foff, N.FACET_TYPES[ftype], 0, P(bounds, u64p), len(bounds),
+                                       C.byref(ptc) if ptc else None, nf, C.cast(farr, C.c_void_p), P(out, u64p), C.byref(tot))
+                assert rc == 0
+                if pt:
+                    pc, pother, ptot = psh.facet_count(q, foff, "point", range_lower_bounds=bounds.view(np.float64), base=pt, unit="km", facet_filter=pfilter)
+                else:
+                    pc, pother, ptot = psh.facet_count(q, foff, ftype, range_lower_bounds=bounds.view(np.int64), facet_filter=pfilter)
+                assert tot.value == ptot and np.array_equal(out[:-1], pc) and int(out[-1]) == pother
+    finally:
+        H.ssh_index_destroy(ix)
+        psh.close()
+
+
+@pytest.mark.gpu
+def test_cpp_shard_union_under_a_field_filter(H):
+    """The C++ mirror's search_lexical_shard for a union of several terms under a field filter (the reference's sub-query
+    decomposition, union.rs:1168-1479) against the Python mirror, which
+    test_union_under_a_field_filter_follows_the_reference_decomposition pins to a brute-force oracle of the rule; NOT terms on top"""
+    from oracle import oracle as O
+    import seekstorm_amd as S
+    from test_gpu_parity import _fields_corpus
+    n_docs, n_fields = 60_000, 3
+    dfs = [30_000, 18_000, 5_000, 22_000]
+    dl, offs, docs, fields, tfs = _fields_corpus(O, n_docs, n_fields, dfs, 41)
+    boost = np.array([1.5, 1.0, 0.5], np.float32)
+    psh = S.Shard(0)
+    psh.upload_lexical_fields(n_docs, dl, boost, offs, docs, fields, tfs)
+    ix = H.ssh_index_create(1, None)
+    try:
+        dlc = np.ascontiguousarray(dl, np.uint8)
+        assert H.ssh_upload_lexical_fields(ix, 0, n_docs, n_fields, P(dlc.reshape(-1), u8p), P(boost, f32p), len(offs) - 1, P(offs, u64p),
+                                           P(docs, u32p), P(np.ascontiguousarray(fields, np.uint8), u8p), P(tfs, u16p)) == 0
+        for filt in ([0], [2], [0, 2]):
+            for terms, neg in (([0, 1], []), ([0, 1, 3], []), ([2, 3], [0]), ([0, 1, 2, 3], [])):
+                for rt in (S.ResultType.TopkCount, S.ResultType.Topk, S.ResultType.Count):
+                    ro = psh.search_lexical_shard(terms, S.QueryType.Union, 2, 20, rt, strict=True, not_terms=neg, field_filter=filt)
+                    cd, cs, ctot = _cpp_lexical_ex(H, ix, terms, 1, 2, 20, int(rt), not_terms=neg, field_filter=filt)
+                    assert ctot == ro.result_count_total, (filt, terms, neg, rt)
+                    # (the mirrors' idf may differ in the last place: logf here, numpy's float32 log there)
+                    assert np.allclose(cs, np.array([r.score for r in ro.results], np.float32), rtol=1e-6), (filt, terms, neg, rt)
+                    assert list(cd) == [r.doc_id for r in ro.results], (filt, terms, neg, rt)
+                # an intersection under the filter goes straight to the kernels
+                ro = psh.search_lexical_shard(terms, S.QueryType.Intersection, 0, 10, S.ResultType.TopkCount, strict=True, not_terms=neg, field_filter=filt)
+                cd, cs, ctot = _cpp_lexical_ex(H, ix, terms, 0, 0, 10, 2, not_terms=neg, field_filter=filt)
+                assert ctot == ro.result_count_total and np.allclose(cs, np.array([r.score for r in ro.results], np.float32), rtol=1e-6)
+    finally:
+        H.ssh_index_destroy(ix)
+        psh.close()
