@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-parity", action="store_true", help="skip the full-size oracle comparison")
     ap.add_argument("--no-topk-count", action="store_true", help="skip the TopkCount comparison (keeps counter profiles of the Topk kernels clean)")
+    ap.add_argument("--no-rationed", action="store_true", help="skip the rationed-vocabulary leg")
     ap.add_argument("--quick", action="store_true", help="profiling runs: few calls per leg, no cpu / parity legs")
     ap.add_argument("--cpu-seconds", type=float, default=5.0)
     ap.add_argument("--parity-queries", type=int, default=32)
@@ -355,6 +356,38 @@ def main():
         torch.cuda.synchronize()
         sc = o_score.cpu().numpy()
         assert np.all(sc[:, :-1] >= sc[:, 1:]) and np.all(o_cnt.cpu().numpy() == k)
+
+        # (5) a RATIONED vocabulary: the probe index has rows for the longest lists only (ss_bm25_set_probe_budget), as for a
+        # real vocabulary of millions of terms.  Here: rows for the lists with df >= 1 % of the docs, which leaves about half
+        # of the batch's queries (their rarest term comes from the 0.5-2 % band) with a list without a row.  The host-pointer
+        # entry point runs such a batch as two -- pruned strategy for the queries whose lists all have rows, scan kernels for
+        # the others -- instead of scanning everything.  Same corpus, same queries, same answers.
+        if rank == 0 and not args.quick and not args.no_rationed:
+            sr = S.Shard(local_rank)
+            frac = th.astype(np.float64) / 2.0 ** 32
+            n_rows = int((frac >= 0.01).sum())
+            n_sub = (args.docs + 4095) // 4096
+            sr.set_probe_budget((n_rows + 1) * n_sub * 64 * 12)
+            sr.synth_lexical(O.LEX_SEED, args.docs, th, tab)
+            probed_q = np.array([bool(sr.terms_probed(tl).all()) for tl in term_lists])
+
+            def r_call():
+                N.check(L.ss_bm25_search(sr._h, nq, q_np.ctypes.data_as(C.c_void_p), k, N.RT_TOPK, N.ptr(h_doc, N.u32p), N.ptr(h_score, N.f32p),
+                                         N.ptr(h_cnt, N.u32p), N.ptr(h_tot, N.u64p)), "ss_bm25_search")
+            r_call()
+            assert np.array_equal(h_score, ref_scores), "rationed vocabulary: answers differ"
+            r_lat = host_latencies(r_call, 200)
+            sr.set_strategy(N.BM25_EXHAUSTIVE)
+            r_call()
+            x_lat = host_latencies(r_call, 100)
+            bm["rationed_vocabulary"] = {
+                "value": nq / (np.mean(r_lat) * 1e-3), "unit": "queries/s", "entry_point": "ss_bm25_search (host pointers, host clock)",
+                "probe_rows": n_rows, "vocabulary": int(len(th)), "rows_rule": "lists with df >= 1 % of the docs",
+                "queries_with_all_rows": float(probed_q.mean()), "batch_ms_p50": pct(r_lat, 50), "batch_ms_p99": pct(r_lat, 99),
+                "all_scan_value": nq / (np.mean(x_lat) * 1e-3),
+                "note": "mixed batch split in the library: queries whose lists all have probe rows take the pruned strategy, the others the "
+                        "scan kernels; all_scan_value = the same batch with every query on the scan kernels (what an unsplit batch costs)"}
+            sr.close()
 
         # ---- full-size parity (C2): a sample of the batch against the oracle on the same 10 M-doc shard, regenerated on
         # the host -- doc ids outside the tie band, scores 1e-4 relative, exact result_count_total; AUTO and EXHAUSTIVE
@@ -679,6 +712,8 @@ def main():
         if is_bm:
             line["exhaustive"] = bm["exhaustive"]
             line["topk_count"] = bm["topk_count"]
+            if "rationed_vocabulary" in bm:
+                line["rationed_vocabulary"] = bm["rationed_vocabulary"]
             line["bm25"] = {"build_s": bm["build_s"], "postings": int(bm["info"]["n_postings"]), "avgdl": bm["info"]["avgdl"],
                             "mean_algorithmic_bytes_per_query": bm["mean_bytes_per_query"], "mean_union_size": bm["mean_union"]}
         if vec is not None and is_bm:

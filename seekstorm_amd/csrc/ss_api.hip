@@ -483,8 +483,104 @@ int ss_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k,
 }
 
 // the search of ss_bm25_search_filtered / _sharded up to the device lists (s->d_out_*, on s->stream); caller holds s->mu
+// rows of a batch that ran in another order back to the callers' order: row i of the src arrays -> row perm[i] of the dst arrays
+__global__ void bm25_unpermute_kernel(const uint32_t* __restrict__ perm, uint32_t nq, uint32_t kk, const uint32_t* __restrict__ src_doc,
+                                      const float* __restrict__ src_score, const uint32_t* __restrict__ src_count,
+                                      const unsigned long long* __restrict__ src_total, uint32_t* __restrict__ dst_doc,
+                                      float* __restrict__ dst_score, uint32_t* __restrict__ dst_count, unsigned long long* __restrict__ dst_total) {
+  const uint32_t i = blockIdx.x;
+  if (i >= nq) return;
+  const uint32_t o = perm[i];
+  for (uint32_t j = threadIdx.x; j < kk; j += blockDim.x) {
+    dst_doc[(size_t)o * kk + j] = src_doc[(size_t)i * kk + j];
+    dst_score[(size_t)o * kk + j] = src_score[(size_t)i * kk + j];
+  }
+  if (threadIdx.x == 0) {
+    dst_count[o] = src_count[i];
+    dst_total[o] = src_total[i];
+  }
+}
+
+static bool query_lists_probed(const ss_shard* s, const ss_bm25_query& q) {
+  const uint32_t all = q.n_terms + bm_q_nnot(q.op);
+  for (uint32_t t = 0; t < all && t < SS_MAX_QUERY_TERMS; t++) {
+    if (q.term[t] >= s->bm_n_terms / s->bm_n_fields) return false;  // check_queries reports it
+    for (uint32_t f = 0; f < s->bm_n_fields; f++) {
+      const uint32_t v = q.term[t] * s->bm_n_fields + f;
+      if (s->h_probe_row[v] == BM_NO_PROBE_ROW && s->h_df[v] != 0) return false;
+    }
+  }
+  return true;
+}
+
+// A vocabulary larger than the probe budget has rows for its longest lists only (ss_bm25_set_probe_budget).  One query
+// that touches a list without a row must not send its whole batch to the scan kernels: the batch is run as two -- the
+// queries whose lists all have rows (pruned strategy), then the others -- and the answers are put back in the callers' order.
+static int bm25_search_split_batch(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, uint32_t n_filters,
+                                   const ss_facet_filter* filters, const std::vector<uint8_t>& probed, uint32_t n_probed) {
+  // staging that outlives this call: the asynchronous copies below read it until the caller's stream synchronisation (every
+  // caller synchronises s->stream before it returns, under s->mu)
+  static thread_local std::vector<uint32_t> perm;
+  static thread_local std::vector<ss_bm25_query> qs;
+  perm.resize(nq);
+  qs.resize(nq);
+  uint32_t a = 0, b = n_probed;
+  for (uint32_t i = 0; i < nq; i++) {
+    const uint32_t at = probed[i] ? a++ : b++;
+    perm[at] = i;
+    qs[at] = q[i];
+  }
+  struct Part { bool has_and, has_or, all_probed, any_frequent, phrase; uint32_t nt_max, np_max; } part[2];
+  const uint32_t begin[2] = {0, n_probed}, count[2] = {n_probed, nq - n_probed};
+  for (int h = 0; h < 2; h++)
+    SS_TRY(check_queries(s, count[h], qs.data() + begin[h], &part[h].has_and, &part[h].has_or, &part[h].nt_max, &part[h].np_max,
+                         &part[h].all_probed, &part[h].any_frequent, &part[h].phrase));
+  SS_HIP(hipSetDevice(s->device));
+  const uint32_t kw = std::max<uint32_t>(kk, 1);
+  SS_TRY(ensure_out(s, 2 * (size_t)nq, kw));  // upper half: the answers in the order they ran in
+  const size_t qbytes = (size_t)nq * sizeof(ss_bm25_query) + (size_t)nq * sizeof(uint32_t);
+  if (qbytes > s->bq_cap) {
+    if (s->d_bq) (void)hipFree(s->d_bq);
+    s->d_bq = nullptr; s->bq_cap = 0;
+    SS_HIP(hipMalloc(&s->d_bq, qbytes));
+    s->bq_cap = qbytes;
+  }
+  ss_bm25_query* d_q = (ss_bm25_query*)s->d_bq;
+  uint32_t* d_perm = (uint32_t*)(d_q + nq);
+  SS_HIP(hipMemcpyAsync(d_q, qs.data(), (size_t)nq * sizeof(ss_bm25_query), hipMemcpyHostToDevice, s->stream));
+  SS_HIP(hipMemcpyAsync(d_perm, perm.data(), (size_t)nq * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+  uint32_t* t_doc = s->d_out_doc + (size_t)nq * kw;
+  float* t_score = s->d_out_score + (size_t)nq * kw;
+  uint32_t* t_count = s->d_out_count + nq;
+  uint64_t* t_total = s->d_out_total + nq;
+  SS_TRY(with_facet_filter(s, n_filters, filters, s->stream, [&]() {
+    for (int h = 0; h < 2; h++) {
+      const int rc = ssi_bm25_search(s, count[h], d_q + begin[h], kk, rt, t_doc + (size_t)begin[h] * kw, t_score + (size_t)begin[h] * kw,
+                                     t_count + begin[h], t_total + begin[h], part[h].has_and, part[h].has_or, part[h].nt_max,
+                                     part[h].np_max, part[h].all_probed, s->stream, part[h].any_frequent, part[h].phrase);
+      if (rc != SS_OK) return rc;
+    }
+    return (int)SS_OK;
+  }));
+  bm25_unpermute_kernel<<<nq, 64, 0, s->stream>>>(d_perm, nq, kk, t_doc, t_score, t_count, (const unsigned long long*)t_total, s->d_out_doc,
+                                                   s->d_out_score, s->d_out_count, (unsigned long long*)s->d_out_total);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
 static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, uint32_t n_filters,
                                     const ss_facet_filter* filters) {
+  if (nq > 1 && s->bm_probe_rows != 0 && s->bm_probe_rows < s->bm_n_terms) {  // rationed probe rows: a mixed batch runs as two
+    std::vector<uint8_t> probed(nq);
+    uint32_t n_probed = 0;
+    for (uint32_t i = 0; i < nq; i++) n_probed += (probed[i] = query_lists_probed(s, q[i]) ? 1 : 0);
+    if (n_probed != 0 && n_probed != nq) {
+      bool has_and, has_or, all_probed, any_frequent, phrase;
+      uint32_t nt_max, np_max;
+      SS_TRY(check_queries(s, nq, q, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent, &phrase));  // the batch's own errors first
+      return bm25_search_split_batch(s, nq, q, kk, rt, n_filters, filters, probed, n_probed);
+    }
+  }
   bool has_and = false, has_or = false;
   uint32_t nt_max = 0, np_max = 0;
   bool all_probed = false, any_frequent = false, phrase = false;

@@ -176,6 +176,16 @@ def test_rationed_probe_rows(S, O):
             b = part.search_lexical_batch(part.make_queries(tl, qt), 10, rt)
             for x, y in zip(a, b):
                 assert np.array_equal(x, y), (qt, rt)
+    # a mixed batch runs as two -- the queries whose lists all have rows keep the pruned strategy -- and the answers come
+    # back in the callers' order (checked above: tl mixes both kinds); a uniform batch stays one launch
+    part.profile(True)
+    for terms, launches in (([[0, 1], [2, 6], [1, 3], [7, 0], [3, 2]], 2), ([[0, 1], [2, 3]], 1), ([[0, 6], [5, 2]], 1)):
+        part.profile_read(0, reset=True)
+        got = part.search_lexical_batch(part.make_queries(terms, S.QueryType.Union), 10, S.ResultType.Topk)
+        assert part.profile_read(0, reset=True)[0] == launches, terms
+        want = full.search_lexical_batch(full.make_queries(terms, S.QueryType.Union), 10, S.ResultType.Topk)
+        assert all(np.array_equal(x, y) for x, y in zip(got, want))
+    part.profile(False)
     # only-probed batches may force the pruned strategy, batches touching the tail may not
     part.set_strategy(N.BM25_PRUNED)
     part.search_lexical_batch(part.make_queries([[0, 1], [2, 3]], S.QueryType.Union), 10, S.ResultType.Topk)
