@@ -202,7 +202,13 @@ enum { SS_BM25_AUTO = 0, SS_BM25_EXHAUSTIVE = 1, SS_BM25_PRUNED = 2 };
 /* The probe index costs 12 bytes per 64 docs and posting list (1.9 MB per list at 10 M docs).  Its rows go to the longest
  * lists first until the budget of the NEXT image build is spent (bytes; 0 = half of the free device memory); queries
  * touching a list without a row are ranked by the scan kernels (exact counts then come from the scan as well).
- * ss_bm25_term_probed: 1 per term whose lists all have rows -- what a caller of ss_bm25_search_dev reports in ops_mask bit 2. */
+ * When the rows are rationed, a quarter of them (at most 8192; none below 32 rows) form a POOL: a host-pointer batch
+ * (ss_bm25_search[_filtered], ss_bm25_search_sharded, the facet routines) first builds rows for the row-less lists it touches
+ * from their postings -- free pool rows first, then the least recently used ones -- so that its queries still take the pruned
+ * strategy; lists that found no row leave their queries to the scan kernels, and a mixed batch is run as two.
+ * ss_bm25_term_probed: per term 0 = some list without a row, 1 = all lists have rows, 2 = all have rows and one of them is a
+ * pool row, which a later host-pointer batch may take away.  A caller of ss_bm25_search_dev reports "every term has rows" in
+ * ops_mask bit 2 (a vouch gone stale is caught on the device: the query fails loudly). */
 int ss_bm25_set_probe_budget(ss_shard* s, uint64_t max_bytes);
 int ss_bm25_term_probed(ss_shard* s, uint32_t n, const uint32_t* terms, uint8_t* out);
 int ss_bm25_set_strategy(ss_shard* s, int strategy);

@@ -111,6 +111,7 @@ static void free_bm25(ss_shard* s) {
   void* ptrs[] = {s->d_post, s->d_term_base, s->d_sub_off, s->d_comp, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_umax, s->d_submax, s->d_boost, s->d_pos, s->d_pos_off, s->d_pos_base};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->d_post = nullptr; s->d_term_base = nullptr; s->d_sub_off = nullptr; s->d_comp = nullptr;
+  s->probe_pool_begin = 0; s->probe_pool_rows = 0; s->pool_list.clear(); s->pool_tick.clear();
   s->d_probe = nullptr; s->d_probe_z = nullptr; s->d_probe_row = nullptr; s->h_probe_row.clear(); s->bm_probe_rows = 0; s->d_umax = nullptr; s->d_submax = nullptr; s->d_pos = nullptr; s->d_pos_off = nullptr; s->d_pos_base = nullptr;
   s->bm_n_docs = 0; s->bm_n_terms = 0; s->bm_n_sub = 0; s->bm_n_post = 0; s->bm_n_fields = 1; s->d_boost = nullptr;
   s->h_df.clear(); s->h_df_real.clear(); s->bm_n_post_pad = 0; s->bm_partmax = false;
@@ -122,7 +123,7 @@ int ss_shard_destroy(ss_shard* s) {
   (void)hipStreamSynchronize(s->stream);
   free_vec(s);
   free_bm25(s);
-  void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_deleted, s->d_facets, s->d_filter_bits, s->d_facet_ws};
+  void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_deleted, s->d_facets, s->d_filter_bits, s->d_facet_ws, s->d_pool_stage};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   (void)hipDeviceSynchronize();  // searches queued on the callers' own streams may still use their workspaces
   for (auto& kv : s->bm_ws) {
@@ -375,6 +376,8 @@ int ss_bm25_term_probed(ss_shard* s, uint32_t n, const uint32_t* terms, uint8_t*
     for (uint32_t f = 0; ok && f < s->bm_n_fields; f++) {
       const uint32_t v = terms[i] * s->bm_n_fields + f;
       if (s->h_probe_row[v] == BM_NO_PROBE_ROW && s->h_df[v] != 0) ok = 0;
+      else if (s->probe_pool_rows && s->h_probe_row[v] >= s->probe_pool_begin && s->h_probe_row[v] < s->probe_pool_begin + s->probe_pool_rows)
+        ok = 2;  // a row from the pool: a later host-pointer batch may take it away
     }
     out[i] = ok;
   }
@@ -501,6 +504,117 @@ __global__ void bm25_unpermute_kernel(const uint32_t* __restrict__ perm, uint32_
   }
 }
 
+// ---- probe rows on demand.  A rationed vocabulary keeps a pool of rows (alloc_probe); before a host-pointer batch runs, the
+// row-less lists it touches get pool rows -- least recently used rows first, never one this batch needs -- built from the
+// list's own postings: one wave per (list, sub-block) ORs the doc bits of the segment into 64 group masks and writes them
+// with the rank of each group's first posting (what the image builders write for the fixed rows).  A row costs its own
+// bytes once (1.9 MB at 10 M docs) and nothing while it stays in the pool; lists that found no row leave their queries to
+// the scan kernels as before.
+__global__ void probe_row_evict_kernel(const uint32_t* __restrict__ lists, uint32_t n, uint32_t* __restrict__ probe_row) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) probe_row[lists[i]] = BM_NO_PROBE_ROW;
+}
+__global__ void probe_row_fill_kernel(const uint32_t* __restrict__ pairs /* (list, row) */, uint32_t n_pairs, uint32_t n_sub,
+                                      const uint32_t* __restrict__ sub_off, const unsigned long long* __restrict__ term_base,
+                                      const uint32_t* __restrict__ post, uint2* __restrict__ probe, uint32_t* __restrict__ probe_z,
+                                      uint32_t* __restrict__ probe_row) {
+  __shared__ unsigned long long masks[4][BM_SUB / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned long long gw = (unsigned long long)blockIdx.x * 4u + (unsigned)w;
+  if (gw >= (unsigned long long)n_pairs * n_sub) return;
+  const uint32_t pair = (uint32_t)(gw / n_sub), sb = (uint32_t)(gw % n_sub);
+  const uint32_t t = pairs[2 * pair], r = pairs[2 * pair + 1];
+  const uint32_t u0 = sub_off[(size_t)t * (n_sub + 1) + sb], u1 = sub_off[(size_t)t * (n_sub + 1) + sb + 1];
+  const unsigned long long base = (term_base[t] + u0) * 4ull;
+  masks[w][lane] = 0ull;
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t i = (uint32_t)lane; i < (u1 - u0) * 4u; i += 64u) {
+    const uint32_t p = post[base + i];
+    if (p) {  // 0 = the segment's NULL padding
+      const uint32_t d = bm_doc_field(p) - 1u;
+      atomicOr(&masks[w][d >> 6], 1ull << (d & 63u));
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  const unsigned long long m = masks[w][lane];
+  uint32_t run = (uint32_t)__popcll(m);  // exclusive prefix over the 64 groups
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t v = __shfl_up(run, o);
+    if (lane >= o) run += v;
+  }
+  run -= (uint32_t)__popcll(m);
+  const size_t gi = ((size_t)r * n_sub + sb) * (BM_SUB / 64) + (uint32_t)lane;
+  probe[gi] = make_uint2((uint32_t)m, (uint32_t)(m >> 32));
+  probe_z[gi] = u0 * 4u + run;
+  if (sb == 0 && lane == 0) probe_row[t] = r;
+}
+
+static inline bool list_needs_row(const ss_shard* s, uint32_t v) { return s->h_probe_row[v] == BM_NO_PROBE_ROW && s->h_df[v] != 0; }
+
+// caller holds s->mu and synchronises st before the next call on this shard can touch the pool
+static int ssi_bm25_ensure_probe_rows(ss_shard* s, uint32_t nq, const ss_bm25_query* q, hipStream_t st) {
+  if (s->probe_pool_rows == 0 || !s->d_probe) return SS_OK;
+  const uint32_t n_lists_per_term = s->bm_n_fields, n_public = s->bm_n_terms / s->bm_n_fields;
+  const uint64_t now = ++s->pool_clock;
+  std::vector<uint32_t> missing;
+  for (uint32_t i = 0; i < nq; i++) {
+    const uint32_t all = std::min<uint32_t>(q[i].n_terms + bm_q_nnot(q[i].op), SS_MAX_QUERY_TERMS);
+    for (uint32_t t = 0; t < all; t++) {
+      if (q[i].term[t] >= n_public) continue;  // check_queries reports it
+      for (uint32_t f = 0; f < n_lists_per_term; f++) {
+        const uint32_t v = q[i].term[t] * n_lists_per_term + f, r = s->h_probe_row[v];
+        if (r != BM_NO_PROBE_ROW && r >= s->probe_pool_begin && r < s->probe_pool_begin + s->probe_pool_rows)
+          s->pool_tick[r - s->probe_pool_begin] = now;  // a pool row this batch needs: not a victim
+        else if (list_needs_row(s, v))
+          missing.push_back(v);
+      }
+    }
+  }
+  if (missing.empty()) return SS_OK;
+  std::sort(missing.begin(), missing.end());
+  missing.erase(std::unique(missing.begin(), missing.end()), missing.end());
+  // victims: free rows first, then the least recently used ones, never a row of this batch
+  std::vector<uint32_t> victims;
+  for (uint32_t i = 0; i < s->probe_pool_rows; i++)
+    if (s->pool_tick[i] != now) victims.push_back(i);
+  std::sort(victims.begin(), victims.end(), [&](uint32_t a, uint32_t b) {
+    const bool fa = s->pool_list[a] == BM_NO_PROBE_ROW, fb = s->pool_list[b] == BM_NO_PROBE_ROW;
+    if (fa != fb) return fa;
+    return s->pool_tick[a] != s->pool_tick[b] ? s->pool_tick[a] < s->pool_tick[b] : a < b;
+  });
+  const uint32_t n = (uint32_t)std::min(missing.size(), victims.size());
+  if (n == 0) return SS_OK;
+  std::vector<uint32_t> stage;  // [evicted lists | (list, row) pairs]
+  for (uint32_t i = 0; i < n; i++)
+    if (s->pool_list[victims[i]] != BM_NO_PROBE_ROW) stage.push_back(s->pool_list[victims[i]]);
+  const uint32_t n_evict = (uint32_t)stage.size();
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t slot = victims[i], v = missing[i];
+    if (s->pool_list[slot] != BM_NO_PROBE_ROW) s->h_probe_row[s->pool_list[slot]] = BM_NO_PROBE_ROW;
+    s->pool_list[slot] = v;
+    s->pool_tick[slot] = now;
+    s->h_probe_row[v] = s->probe_pool_begin + slot;
+    stage.push_back(v);
+    stage.push_back(s->probe_pool_begin + slot);
+  }
+  SS_HIP(hipSetDevice(s->device));
+  if (stage.size() * sizeof(uint32_t) > s->pool_stage_cap) {
+    if (s->d_pool_stage) (void)hipFree(s->d_pool_stage);
+    s->d_pool_stage = nullptr; s->pool_stage_cap = 0;
+    const size_t cap = std::max<size_t>(stage.size() * sizeof(uint32_t), 4096) * 2;
+    SS_HIP(hipMalloc(&s->d_pool_stage, cap));
+    s->pool_stage_cap = cap;
+  }
+  SS_HIP(hipMemcpy(s->d_pool_stage, stage.data(), stage.size() * sizeof(uint32_t), hipMemcpyHostToDevice));  // small; `stage` dies here
+  if (n_evict) probe_row_evict_kernel<<<(n_evict + 255) / 256, 256, 0, st>>>(s->d_pool_stage, n_evict, s->d_probe_row);
+  const unsigned long long waves = (unsigned long long)n * s->bm_n_sub;
+  probe_row_fill_kernel<<<(unsigned)((waves + 3) / 4), 256, 0, st>>>(s->d_pool_stage + n_evict, n, s->bm_n_sub, s->d_sub_off,
+                                                                   (const unsigned long long*)s->d_term_base, s->d_post, s->d_probe,
+                                                                   s->d_probe_z, s->d_probe_row);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
 static bool query_lists_probed(const ss_shard* s, const ss_bm25_query& q) {
   const uint32_t all = q.n_terms + bm_q_nnot(q.op);
   for (uint32_t t = 0; t < all && t < SS_MAX_QUERY_TERMS; t++) {
@@ -570,6 +684,7 @@ static int bm25_search_split_batch(ss_shard* s, uint32_t nq, const ss_bm25_query
 
 static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, uint32_t n_filters,
                                     const ss_facet_filter* filters) {
+  SS_TRY(ssi_bm25_ensure_probe_rows(s, nq, q, s->stream));
   if (nq > 1 && s->bm_probe_rows != 0 && s->bm_probe_rows < s->bm_n_terms) {  // rationed probe rows: a mixed batch runs as two
     std::vector<uint8_t> probed(nq);
     uint32_t n_probed = 0;
@@ -657,6 +772,7 @@ static int facet_count_impl(ss_shard* s, const ss_bm25_query* query, uint32_t n_
   bool has_and, has_or, all_probed, any_frequent;
   uint32_t nt_max, np_max;
   std::lock_guard<std::mutex> g(s->mu);
+  SS_TRY(ssi_bm25_ensure_probe_rows(s, 1, query, s->stream));
   SS_TRY(check_queries(s, 1, query, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent));
   if (!all_probed || !s->d_probe) return SS_ENOTSUP;  // the match set comes from the probe index's bit records
   SS_HIP(hipSetDevice(s->device));
@@ -717,6 +833,7 @@ static int facet_kth_impl(ss_shard* s, const ss_bm25_query* query, uint32_t n_fi
   bool has_and, has_or, all_probed, any_frequent;
   uint32_t nt_max, np_max;
   std::lock_guard<std::mutex> g(s->mu);
+  SS_TRY(ssi_bm25_ensure_probe_rows(s, 1, query, s->stream));
   SS_TRY(check_queries(s, 1, query, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent));
   if (!all_probed || !s->d_probe) return SS_ENOTSUP;
   SS_HIP(hipSetDevice(s->device));

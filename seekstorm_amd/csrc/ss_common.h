@@ -201,6 +201,15 @@ struct ss_shard {
                                    // the right price for the lists that cost query time, not for a vocabulary's long tail)
   std::vector<uint32_t> h_probe_row;
   uint32_t bm_probe_rows = 0;
+  // When the rows are rationed, the last probe_pool_rows of them are a POOL: rows built on demand for the row-less lists a
+  // batch touches (ssi_bm25_ensure_probe_rows, ss_api.hip), least recently used first.  pool_list[i] = the list that holds
+  // pool row i (BM_NO_PROBE_ROW = free), pool_tick[i] = the last batch that needed it.
+  uint32_t probe_pool_begin = 0, probe_pool_rows = 0;
+  std::vector<uint32_t> pool_list;
+  std::vector<uint64_t> pool_tick;
+  uint64_t pool_clock = 0;
+  uint32_t* d_pool_stage = nullptr;  // (list, row) pairs of the build in flight, grow-only
+  size_t pool_stage_cap = 0;
   uint64_t probe_budget = 0;       // ss_bm25_set_probe_budget: bytes, 0 = half of the free device memory
   int bm_strategy = SS_BM25_AUTO;  // ss_bm25_set_strategy
   float* d_umax = nullptr;         // [n_terms + 1] largest weight tf*(K+1)/(tf+comp[len]) of the term (max_list_score / idf)

@@ -111,7 +111,13 @@ static int alloc_probe(ss_shard* s, hipStream_t st) {
   if (max_rows < nt)
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return s->h_df[x] > s->h_df[y]; });
   const uint32_t rows = (uint32_t)std::min<size_t>(max_rows, nt);
-  for (uint32_t i = 0; i < rows; i++) s->h_probe_row[order[i]] = i;
+  // rationed rows: a quarter of them (at most 8192) stay unassigned as the pool of rows built on demand
+  s->probe_pool_rows = (max_rows < nt && rows >= 32) ? std::min<uint32_t>(rows / 4, 8192u) : 0u;
+  s->probe_pool_begin = rows - s->probe_pool_rows;
+  s->pool_list.assign(s->probe_pool_rows, BM_NO_PROBE_ROW);
+  s->pool_tick.assign(s->probe_pool_rows, 0);
+  s->pool_clock = 0;
+  for (uint32_t i = 0; i < s->probe_pool_begin; i++) s->h_probe_row[order[i]] = i;
   s->h_probe_row[nt] = rows;  // absent terms of a short query: the zero row
   for (uint32_t t = 0; t < nt; t++)  // ... which also serves every empty list
     if (s->h_probe_row[t] == BM_NO_PROBE_ROW && s->h_df[t] == 0) s->h_probe_row[t] = rows;

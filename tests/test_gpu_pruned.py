@@ -195,6 +195,67 @@ def test_rationed_probe_rows(S, O):
     part.close()
 
 
+def test_probe_rows_on_demand(S, O):
+    """A rationed vocabulary with a row pool (>= 32 rows): the row-less lists a host-pointer batch touches get pool rows built
+    from their postings, least recently used first, and the batch keeps the pruned strategy; more row-less lists than pool
+    rows -> the rest scans (mixed batch).  Every answer equals the unrationed shard's, over several rounds of eviction;
+    facet counts over a list that had no row work as well."""
+    from seekstorm_amd import _native as N
+    n_docs = 150_000
+    dfs = [0.2 / (1 + 0.35 * i) for i in range(56)]
+    dl, offs, docs, tfs = _corpus(O, n_docs, dfs, 19)
+    full, part = S.Shard(0), S.Shard(0)
+    full.upload_lexical(n_docs, dl, offs, docs, tfs)
+    n_sub = (n_docs + 4095) // 4096
+    part.set_probe_budget((40 + 1) * n_sub * 64 * 12)   # 40 rows: 30 fixed (the longest lists) + a pool of 10
+    part.upload_lexical(n_docs, dl, offs, docs, tfs)
+    probed = part.terms_probed(np.arange(56))
+    assert probed.sum() == 30 and probed[:30].all()
+    rng = np.random.default_rng(5)
+    part.profile(True)
+    for rnd in range(6):
+        tail = rng.choice(np.arange(30, 56), 8, replace=False)          # 8 row-less lists <= pool
+        tl = [[int(rng.integers(0, 30)), int(t)] for t in tail] + [[int(tail[0]), int(tail[1]), int(rng.integers(0, 30))], [3, 7, 11]]
+        for qt in (S.QueryType.Union, S.QueryType.Intersection):
+            for rt in (S.ResultType.Topk, S.ResultType.TopkCount, S.ResultType.Count):
+                part.profile_read(0, reset=True)
+                a = full.search_lexical_batch(full.make_queries(tl, qt), 10, rt)
+                b = part.search_lexical_batch(part.make_queries(tl, qt), 10, rt)
+                for x, y in zip(a, b):
+                    assert np.array_equal(x, y), (rnd, qt, rt)
+                if rt == S.ResultType.Topk:
+                    assert part.profile_read(0, reset=True)[0] == 1, (rnd, qt, rt)   # one launch: nothing was left to the scans
+        assert N.lib() is not None and (np.asarray(part.terms_probed(tail)) != 0).all()
+        out = np.zeros(len(tail), np.uint8)
+        t32 = np.ascontiguousarray(tail, np.uint32)
+        N.check(N.lib().ss_bm25_term_probed(part._h, len(t32), N.ptr(t32, N.u32p), N.ptr(out, N.u8p)), "ss_bm25_term_probed")
+        assert (out == 2).all()                                          # pool rows
+    # forced PRUNED works on a tail query now
+    part.set_strategy(N.BM25_PRUNED)
+    a = full.search_lexical_batch(full.make_queries([[2, 50]], S.QueryType.Union), 10, S.ResultType.TopkCount)
+    b = part.search_lexical_batch(part.make_queries([[2, 50]], S.QueryType.Union), 10, S.ResultType.TopkCount)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    part.set_strategy(N.BM25_AUTO)
+    # more row-less lists than pool rows: the batch is split, the answers stay
+    tl = [[int(t), int(t) - 29] for t in range(30, 56)]
+    a = full.search_lexical_batch(full.make_queries(tl, S.QueryType.Union), 10, S.ResultType.TopkCount)
+    part.profile_read(0, reset=True)
+    b = part.search_lexical_batch(part.make_queries(tl, S.QueryType.Union), 10, S.ResultType.TopkCount)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert part.profile_read(0, reset=True)[0] == 2
+    part.profile(False)
+    # facet counts read the match set from the bit records: a list that had no row gets one
+    rec = np.zeros((n_docs, 2), np.uint8)
+    rec[:, 0] = np.arange(n_docs) % 7
+    full.upload_facets(rec); part.upload_facets(rec)
+    q = [[1, 44]]
+    ca = full.facet_count(full.make_queries(q, S.QueryType.Union), 0, "string16", n_buckets=7)
+    cb = part.facet_count(part.make_queries(q, S.QueryType.Union), 0, "string16", n_buckets=7)
+    assert np.array_equal(ca[0], cb[0]) and ca[1:] == cb[1:]
+    full.close()
+    part.close()
+
+
 def test_block_maxima_on_a_skewed_corpus(S, O):
     """a-12: per-(term, block) maxima (get_max_score, index.rs:2938-3200; used as in intersection.rs:2090-2097, single.rs:373-386).
     A corpus whose weights are clustered by doc id -- short-doc regions hold the top-k, the long-doc regions' block maxima lie
