@@ -628,6 +628,27 @@ class Shard:
     def _point(base, unit):
         return N.FacetPointC(float(base[0]), float(base[1]), N.POINT_UNITS[unit], 0)
 
+    @staticmethod
+    def string_facet_rank_column(records, facet_offset, facet_type, strings):
+        """Result sort by a String16 / String32 facet (min_heap.rs:860-897, 939-976): the reference compares the STRINGS of the
+        two docs' value ids (Rust String order = byte-wise UTF-8).  The device sorts numbers, so the host appends one derived
+        u32 column to the facet.bin records before ss_facet_upload: rank[id] of the id's string in that order (equal strings
+        share a rank) -- a sort by the string facet is then a sort by this column.  The ranks are as old as the image: a commit
+        that adds strings rebuilds image and column together.  strings[id] = the facet value of id (facet.json).
+        -> (records with the column appended [n_docs][record_size + 4], the column's offset)"""
+        r = np.ascontiguousarray(records, np.uint8)
+        width = {"string16": 2, "string32": 4}[facet_type]
+        ids = np.zeros(r.shape[0], np.uint32)
+        for b in range(width):
+            ids |= r[:, facet_offset + b].astype(np.uint32) << np.uint32(8 * b)
+        keys = [str(x).encode("utf-8") for x in strings]
+        order = sorted(set(keys))
+        rank_of = {kb: i for i, kb in enumerate(order)}
+        rank = np.array([rank_of[kb] for kb in keys], np.uint32)
+        col = rank[np.minimum(ids, len(rank) - 1)]
+        out = np.concatenate([r, col.astype("<u4").view(np.uint8).reshape(-1, 4)], axis=1)
+        return np.ascontiguousarray(out), r.shape[1]
+
     def facet_kth(self, query, facet_offset, facet_type, descending, k, facet_filter=None, base=None):
         """the pivot of a result sort: (stored bits of the k-th best value among the query's matches, matches strictly better,
         matches equal, all matches) -- ss_bm25_facet_kth; a Point facet (base = (lat, lon)): the f64 bits of the k-th best

@@ -1226,3 +1226,37 @@ def test_point_facets(S, O, lex):
     finally:
         sh.set_deleted([])
         osh.set_deleted([])
+
+
+def test_result_sort_by_a_string_facet(S, O, lex):
+    """result_sort over a String16 facet (min_heap.rs:860-897): docs ordered by the STRING of their value id (byte-wise UTF-8,
+    Rust's String order), ids with equal strings tie, then the next field / the score.  The host derives a rank column
+    (Shard.string_facet_rank_column) and the device sorts by it; against a brute-force ordering by the strings themselves."""
+    sh, osh, n_docs = lex
+    rng = np.random.default_rng(41)
+    words = ["zeta", "alpha", "Alpha", "beta", "\u00e9clair", "eclair", "omega", "beta", "a", "", "zz", "\u4e2d\u6587", "alpha ", "b", "B", "beta"]
+    rec = np.dtype([("cat", "<u2"), ("h", "<u2")])
+    v = np.zeros(n_docs, rec)
+    v["cat"] = rng.integers(0, len(words), n_docs); v["h"] = rng.integers(0, 9, n_docs)
+    raw, rank_off = S.Shard.string_facet_rank_column(v.view(np.uint8).reshape(n_docs, rec.itemsize), 0, "string16", words)
+    assert raw.shape[1] == rec.itemsize + 4 and rank_off == rec.itemsize
+    sh.upload_facets(raw)
+    skey = [w.encode("utf-8") for w in words]
+    for terms, qt, oop in (([10, 9, 8], S.QueryType.Union, O.OP_OR), ([10, 9], S.QueryType.Intersection, O.OP_AND)):
+        q = sh.make_queries([terms], qt)
+        ad, as_, atot = osh.search_exhaustive(terms, oop, n_docs)
+        for desc, second in ((False, None), (True, None), (False, ("h", True))):
+            for k in (10, 77):
+                def key(i):
+                    kb = skey[int(v["cat"][ad[i]])]
+                    first = tuple(-b for b in kb) + (1,) if desc else tuple(kb) + (-1,)   # descending: reversed byte order, longer first
+                    nxt = (-int(v["h"][ad[i]]),) if second else ()
+                    return (first,) + nxt + (-float(as_[i]),)
+                order = sorted(range(len(ad)), key=key)[:k]
+                spec = [(rank_off, "u32", desc)] + ([(2, "u16", True)] if second else [])
+                doc, score, tot = sh.search_lexical_sorted(q, spec, k)
+                assert tot == atot and len(doc) == len(order)
+                assert [skey[int(c)] for c in v["cat"][doc]] == [skey[int(c)] for c in v["cat"][ad[order]]], (terms, desc, k)
+                if second:
+                    assert np.array_equal(v["h"][doc], v["h"][ad[order]])
+                assert np.allclose(score, as_[order], rtol=1e-4)
