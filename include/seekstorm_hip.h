@@ -298,10 +298,13 @@ typedef struct ss_facet_filter {
   uint32_t offset;      /* of the facet inside a record */
   uint32_t type;        /* SS_FACET_* */
   uint64_t lo, hi;      /* numeric types: passes iff lo <= value < hi */
-  uint32_t n_values;    /* string types: passes iff the id is one of values[0 .. n_values) (<= 8) */
+  uint32_t n_values;    /* string types: passes iff the id is one of values[0 .. n_values) (<= 8); SS_FACET_IDS_EXTERN: one of the
+                           `hi` ids of the HOST array at (uintptr_t)lo -- any number (a StringSet filter resolves to every set id
+                           that holds the value, search.rs:2643-2710) */
   uint32_t values[8];
   uint32_t reserved;    /* numeric types: SS_FACET_LO_EXCLUSIVE | SS_FACET_HI_INCLUSIVE turn the ends around (0 = [lo, hi)) */
 } ss_facet_filter;
+#define SS_FACET_IDS_EXTERN 0xFFFFFFFFu
 #define SS_FACET_HI_INCLUSIVE 1u
 #define SS_FACET_LO_EXCLUSIVE 2u
 int ss_facet_upload(ss_shard* s, uint64_t n_docs, uint32_t record_size, const uint8_t* records);

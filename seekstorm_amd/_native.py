@@ -47,6 +47,7 @@ class FacetFilterC(C.Structure):  # ss_facet_filter
 
 SS_MAX_FACET_FILTERS = 8
 FACET_HI_INCLUSIVE, FACET_LO_EXCLUSIVE = 1, 2
+FACET_IDS_EXTERN = 0xFFFFFFFF
 FACET_TYPES = {"u8": 0, "u16": 1, "u32": 2, "u64": 3, "i8": 4, "i16": 5, "i32": 6, "i64": 7, "f32": 8, "f64": 9,
                "string16": 10, "string32": 11, "point": 12}
 POINT_UNITS = {"sortkey": 0, "km": 1, "miles": 2}

@@ -6,7 +6,9 @@
 // (add_result.rs:3499-3501 returns before the count) -- exactly what a tombstone does.  So the filter is evaluated ONCE per
 // call over all docs into an exclusion bitmap (OR-ed with the tombstones: ~n_docs x record bytes read, 20-50 us at 10 M
 // docs) and the search kernels run with that bitmap in place of the tombstone bitmap; nothing in them changes.
+#include <algorithm>
 #include <cstring>
+#include <vector>
 
 #include "facet_point.h"
 
@@ -115,6 +117,8 @@ __device__ bool facet_pass(const uint8_t* rec, const ss_facet_filter& f) {
     case SS_FACET_STRING16:
     case SS_FACET_STRING32: {
       const uint32_t v = (uint32_t)facet_read(p, f.type == SS_FACET_STRING16 ? 2 : 4);
+      if (f.n_values == SS_FACET_IDS_EXTERN)  // a set of any size: one bit per id (ssi_facet_build put it behind the exclusion bitmap)
+        return v < f.hi && ((((const uint32_t*)(uintptr_t)f.lo)[v >> 5] >> (v & 31u)) & 1u) != 0u;
       for (uint32_t i = 0; i < f.n_values; i++)
         if (f.values[i] == v) return true;
       return false;
@@ -159,12 +163,25 @@ int ssi_facet_build(ss_shard* s, uint32_t n_filters, const ss_facet_filter* filt
   if (n_filters == 0 || n_filters > SS_MAX_FACET_FILTERS || !filters) return SS_EINVAL;
   FacetFilters F;
   F.n = n_filters;
+  uint64_t set_words = 0, set_begin[SS_MAX_FACET_FILTERS] = {0}, set_bits[SS_MAX_FACET_FILTERS] = {0};
   for (uint32_t i = 0; i < n_filters; i++) {
     const ss_facet_filter& f = filters[i];
     static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 2, 4, 8};
     if (f.type > SS_FACET_POINT || f.offset + width[f.type] > s->facet_record_size) return SS_EINVAL;
-    if ((f.type == SS_FACET_STRING16 || f.type == SS_FACET_STRING32) && f.n_values > 8) return SS_EINVAL;
+    const bool strings = f.type == SS_FACET_STRING16 || f.type == SS_FACET_STRING32;
+    if (strings && f.n_values > 8 && f.n_values != SS_FACET_IDS_EXTERN) return SS_EINVAL;
     F.f[i] = f;
+    if (strings && f.n_values == SS_FACET_IDS_EXTERN) {  // lo = host array of hi ids -> a bitmap over [0, largest id]
+      const uint32_t* ids = (const uint32_t*)(uintptr_t)f.lo;
+      if (f.hi && !ids) return SS_EINVAL;
+      uint64_t bits = 0;
+      for (uint64_t j = 0; j < f.hi; j++) bits = std::max<uint64_t>(bits, (uint64_t)ids[j] + 1);
+      if (f.type == SS_FACET_STRING16) bits = std::min<uint64_t>(bits, 65536);  // ids beyond the facet's width match nothing
+      if (bits > (1ull << 30)) return SS_EINVAL;
+      set_begin[i] = set_words;
+      set_bits[i] = bits;
+      set_words += (bits + 31) / 32;
+    }
     if (f.type == SS_FACET_POINT) {
       if (f.n_values > SS_POINT_MILES) return SS_EINVAL;
       if (f.n_values != SS_POINT_SORTKEY) {
@@ -183,12 +200,27 @@ int ssi_facet_build(ss_shard* s, uint32_t n_filters, const ss_facet_filter* filt
     }
   }
   const uint64_t words = (s->facet_docs + 31) / 32;
-  if (words > s->filter_words_cap) {
+  if (words + set_words > s->filter_words_cap) {
     if (s->d_filter_bits) (void)hipFree(s->d_filter_bits);
     s->d_filter_bits = nullptr;
     s->filter_words_cap = 0;
-    SS_HIP(hipMalloc(&s->d_filter_bits, words * sizeof(uint32_t)));
-    s->filter_words_cap = words;
+    SS_HIP(hipMalloc(&s->d_filter_bits, (words + set_words) * sizeof(uint32_t)));
+    s->filter_words_cap = words + set_words;
+  }
+  if (set_words) {  // the id sets as bitmaps behind the exclusion bitmap
+    // staging that outlives the call (the copy is asynchronous on st; calls that share a shard are stream-ordered)
+    static thread_local std::vector<uint32_t> stage;
+    stage.assign(set_words, 0u);
+    for (uint32_t i = 0; i < n_filters; i++) {
+      const ss_facet_filter& f = filters[i];
+      if (!((f.type == SS_FACET_STRING16 || f.type == SS_FACET_STRING32) && f.n_values == SS_FACET_IDS_EXTERN)) continue;
+      const uint32_t* ids = (const uint32_t*)(uintptr_t)f.lo;
+      for (uint64_t j = 0; j < f.hi; j++)
+        if (ids[j] < set_bits[i]) stage[set_begin[i] + (ids[j] >> 5)] |= 1u << (ids[j] & 31u);
+      F.f[i].lo = (uint64_t)(uintptr_t)(s->d_filter_bits + words + set_begin[i]);
+      F.f[i].hi = set_bits[i];
+    }
+    SS_HIP(hipMemcpyAsync(s->d_filter_bits + words, stage.data(), set_words * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   }
   facet_filter_kernel<<<(unsigned)((s->facet_docs + 255) / 256), 256, 0, st>>>(
       s->d_facets, s->facet_record_size, (unsigned long long)s->facet_docs, F, s->n_deleted ? s->d_deleted : nullptr,

@@ -565,6 +565,8 @@ class Shard:
         [(offset, "string16" | "string32", [ids])] or [(offset, "point", (lat, lon), lo, hi, "km" | "miles")] -- the distance to
         the base point inside [lo, hi) -> ss_facet_filter array (FacetFilter / FilterSparse, search.rs:735-)"""
         arr = (N.FacetFilterC * max(len(filters), 1))()
+        keep = []
+        arr._keep = keep  # the id arrays live as long as the filter array
         for i, f in enumerate(filters):
             off, ty = int(f[0]), f[1]
             arr[i].offset, arr[i].type = off, N.FACET_TYPES[ty]
@@ -577,9 +579,14 @@ class Shard:
                 arr[i].reserved = int(f[6]) if len(f) > 6 else 0
             elif ty.startswith("string"):
                 ids = [int(x) for x in f[2]]
-                arr[i].n_values = len(ids)
-                for j, v in enumerate(ids):
-                    arr[i].values[j] = v
+                if len(ids) > 8:  # any number of ids (what a StringSet filter resolves to): a host array behind lo / hi
+                    ext = np.ascontiguousarray(ids, np.uint32)
+                    keep.append(ext)
+                    arr[i].n_values, arr[i].lo, arr[i].hi = N.FACET_IDS_EXTERN, ext.ctypes.data, len(ext)
+                else:
+                    arr[i].n_values = len(ids)
+                    for j, v in enumerate(ids):
+                        arr[i].values[j] = v
             elif len(f) > 4 and f[4] == "bits":  # (offset, type, lo bits, hi bits, "bits", flags): the pivots of a result sort
                 arr[i].lo, arr[i].hi, arr[i].reserved = int(f[2]), int(f[3]), int(f[5])
             else:

@@ -119,6 +119,14 @@ def test_facet_filter(S, O, lex):
         ([(off["e"], "u64", 1 << 60, 1 << 62), (off["f"], "i16", -300, 0), (off["g"], "f64", 2.5e5, 7.5e5), (off["b"], "u16", 100, 4000)],
          (v["e"] >= (1 << 60)) & (v["f"] < 0) & (v["g"] >= 2.5e5) & (v["g"] < 7.5e5) & (v["b"] >= 100) & (v["b"] < 4000)),
     ]
+    # id sets of any size (a StringSet filter resolves to every set id holding the value, search.rs:2643-2710): SS_FACET_IDS_EXTERN
+    big16 = sorted(set(rng.integers(0, 5000, 700).tolist())) + [70000]           # an id beyond the facet's width matches nothing
+    big32 = sorted(set(rng.integers(0, 40, 25).tolist()))
+    filter_sets += [
+        ([(off["b"], "string16", big16)], np.isin(v["b"], big16)),
+        ([(off["h"], "string32", big32), (off["b"], "string16", big16), (off["a"], "u8", 5, 250)],
+         np.isin(v["h"], big32) & np.isin(v["b"], big16) & (v["a"] >= 5) & (v["a"] < 250)),
+    ]
     cases = [([10, 9, 8], S.QueryType.Union, O.OP_OR, []), ([10, 9], S.QueryType.Intersection, O.OP_AND, []),
              ([8], S.QueryType.Union, O.OP_OR, []), ([10, 8], S.QueryType.Union, O.OP_OR, [9])]
     for filt, keep in filter_sets:
