@@ -364,6 +364,7 @@ def main():
         # rows on the scan kernels (mixed batch as two) -- instead of scanning everything.  Same corpus, same queries, same answers.
         if rank == 0 and not args.quick and not args.no_rationed:
             sr = S.Shard(local_rank)
+            sr.synth_partition(rank, world)  # the same shard of the corpus stream as `sh`
             frac = th.astype(np.float64) / 2.0 ** 32
             n_rows = int((frac >= 0.01).sum())
             n_sub = (args.docs + 4095) // 4096
