@@ -485,7 +485,6 @@ int ss_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k,
   return ss_bm25_search_filtered(s, nq, q, k, rt, 0, nullptr, out_doc, out_score, out_count, out_total);
 }
 
-// the search of ss_bm25_search_filtered / _sharded up to the device lists (s->d_out_*, on s->stream); caller holds s->mu
 // rows of a batch that ran in another order back to the callers' order: row i of the src arrays -> row perm[i] of the dst arrays
 __global__ void bm25_unpermute_kernel(const uint32_t* __restrict__ perm, uint32_t nq, uint32_t kk, const uint32_t* __restrict__ src_doc,
                                       const float* __restrict__ src_score, const uint32_t* __restrict__ src_count,
@@ -682,6 +681,7 @@ static int bm25_search_split_batch(ss_shard* s, uint32_t nq, const ss_bm25_query
   return SS_OK;
 }
 
+// the search of ss_bm25_search_filtered / _sharded up to the device lists (s->d_out_*, on s->stream); caller holds s->mu
 static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, uint32_t n_filters,
                                     const ss_facet_filter* filters) {
   SS_TRY(ssi_bm25_ensure_probe_rows(s, nq, q, s->stream));
