@@ -300,6 +300,31 @@ def main():
             n_, d_ = timed_for(lambda: bm_call(rt=N.RT_TOPKCOUNT))
             tc[name] = {"value": nq * n_ / d_, "unit": "queries/s", "ms_per_call": d_ / n_ * 1e3, "calls": n_}
         sh.set_strategy(N.BM25_AUTO)
+        # (3b) the reference server's default query type: intersections.  C1-shaped 2-term AND top-10 (BASELINE.json configs[0]) on
+        # this 10 M-doc corpus, one term from the 1-5 % band and one from the 5-20 % band, ResultType::TopkCount (exact counts)
+        inter = None
+        if not args.no_topk_count:
+            rng_i = np.random.default_rng(4321)
+            ba, bb = band_terms(th, 0.01, 0.05), band_terms(th, 0.05, 0.20)
+            qi_np = sh.make_queries([[int(rng_i.choice(ba)), int(rng_i.choice(bb))] for _ in range(nq)], S.QueryType.Intersection)
+            qi_dev = torch.from_numpy(qi_np.view(np.uint8).reshape(nq, -1).copy()).to(dev)
+            OPS_AND = 1 | (2 << 8)
+
+            def and_call(rt=N.RT_TOPKCOUNT):
+                N.check(L.ss_bm25_search_dev(sh._h, nq, qi_dev.data_ptr(), k, rt, OPS_AND, o_doc.data_ptr(), o_score.data_ptr(),
+                                             o_cnt.data_ptr(), o_tot.data_ptr(), sptr), "ss_bm25_search_dev")
+            sh.set_strategy(N.BM25_EXHAUSTIVE)
+            and_call()
+            torch.cuda.synchronize()
+            and_ref = (o_score.cpu().numpy().copy(), o_tot.cpu().numpy().copy())
+            sh.set_strategy(N.BM25_AUTO)
+            and_call()
+            torch.cuda.synchronize()
+            assert np.array_equal(and_ref[0], o_score.cpu().numpy()) and np.array_equal(and_ref[1], o_tot.cpu().numpy()), "AND: strategies differ"
+            n_, d_ = timed_for(and_call)
+            inter = {"value": nq * n_ / d_, "unit": "queries/s", "ms_per_call": d_ / n_ * 1e3, "calls": n_, "result_type": "TopkCount",
+                     "workload": "2-term AND top-10, terms from the 1-5 % and 5-20 % df bands, 1000 queries per call, AUTO (pruned: the shorter "
+                                 "list drives, the other is probed; counts are a by-product)", "mean_matches": float(and_ref[1].mean())}
         ach_alg = bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         ex_ach = bytes_launch / (ex_kms * 1e-3) / 1e9 if ex_kms > 0 else 0.0
         lat_batch = latencies(bm_call, 200)
@@ -349,7 +374,7 @@ def main():
                   latency_ms={"batch_p50": pct(lat_batch, 50), "batch_p99": pct(lat_batch, 99), "batch_samples": len(lat_batch),
                               "single_query_p50": pct(lat_one, 50), "single_query_p99": pct(lat_one, 99),
                               "single_query_samples": len(lat_one), "clock": "HIP events on the launch stream (device resident)"},
-                  end_to_end=end_to_end,
+                  end_to_end=end_to_end, intersection=inter,
                   mean_bytes_per_query=float(bytes_q.mean()), mean_union=float(tot.mean()))
         # correctness guard inside the bench: sorted, k results
         bm_call()
@@ -730,6 +755,8 @@ def main():
         if is_bm:
             line["exhaustive"] = bm["exhaustive"]
             line["topk_count"] = bm["topk_count"]
+            if bm.get("intersection"):
+                line["intersection"] = bm["intersection"]
             if "rationed_vocabulary" in bm:
                 line["rationed_vocabulary"] = bm["rationed_vocabulary"]
             line["bm25"] = {"build_s": bm["build_s"], "postings": int(bm["info"]["n_postings"]), "avgdl": bm["info"]["avgdl"],
