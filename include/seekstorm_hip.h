@@ -334,7 +334,8 @@ int ss_bm25_facet_count(ss_shard* s, const ss_bm25_query* query, uint32_t n_filt
  * the pivot is the worst match).  The top-k under the sort is then: the n_better docs of a search filtered to "better than
  * the pivot" (SS_FACET_LO_EXCLUSIVE / _HI_INCLUSIVE) ordered by their values (ss_facet_values), followed by the best
  * k - n_better docs of a search filtered to "equal to the pivot" -- by the next sort field the same way, by score when none
- * is left.  String facets (sorted by their strings) are not offered (SS_ENOTSUP).
+ * is left.  String facets sort by their strings: SS_ENOTSUP on the id column itself -- the host appends a u32 rank column
+ * (rank of each id's string) to the records it uploads and sorts by that.
  * ss_facet_values: the stored bits of a facet for a list of docs (host arrays).
  * Point facets: the *_point entry points take the base point; the value that is counted into ranges (Ranges::Point,
  * add_result.rs:605-618; bounds = f64 bits of the distances), selected (morton_ordering, min_heap.rs:510-528 /
