@@ -88,8 +88,14 @@ int ss_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen_bytes, ui
  * fields they occur in; idf from the docs containing the term in any field (ss_bm25_term_df returns that); an
  * intersection needs every term in at least one field.  doclen_bytes is [n_fields][n_docs] (level_index
  * document_length_compressed_array[field], index.rs:770-776); the postings of a term are sorted by (doc, field);
- * boost = schema boost per field (NULL = 1).  Queries are the same ss_bm25_query; at most 32 / n_fields terms per query
- * (NOT terms included), intersections of at most 8 terms.  n_fields <= 8. */
+ * boost = schema boost per field (NULL = 1).  Queries are the same ss_bm25_query.  n_fields <= 8.
+ * Two or more fields (boosts > 0): the score is additive per (term, field), so the image also carries one MERGED list per term
+ * -- every doc holding the term in any field, with the weight sum_f boost[f] * w_f scaled into the weight code's range (the
+ * scale returns through idf) -- and a query WITHOUT a field filter reads only those: it is a single-field query to every kernel
+ * (pruned strategy, 16-bit scan, plain intersections, up to 10 terms).  Its scores equal the per-field sums up to the code's
+ * rounding (2^-16 relative per term, inside the 1e-4 tolerance); the image holds the postings twice.  A query WITH a field
+ * filter reads the (term, field) lists: at most 32 / n_fields terms (NOT terms included), intersections of at most 8 terms.
+ * SS_BM25_MERGED=0 in the environment builds the image without merged lists. */
 int ss_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen_bytes, const float* boost,
                           uint32_t n_terms, const uint64_t* term_offsets, const uint32_t* doc_ids, const uint8_t* field_ids,
                           const uint16_t* tfs);
@@ -261,7 +267,8 @@ int ss_bm25_search(ss_shard* s, uint32_t n_queries, const ss_bm25_query* queries
  * the largest n_terms alone (0 = same as bits 8..15, i.e. NO query of the batch has NOT terms -- a batch with NOT terms
  * declares bits 8..15 > bits 16..23 even when its longest query has none); bit 2 set if every term of the batch has probe rows
  * (ss_bm25_term_probed; irrelevant when the probe budget covered all lists); bit 3 set if some query carries
- * SS_OP_ALL_TERMS_FREQUENT; bit 4 set if the batch consists of SS_OP_PHRASE queries (then all of them must be).
+ * SS_OP_ALL_TERMS_FREQUENT; bit 4 set if the batch consists of SS_OP_PHRASE queries (then all of them must be); bit 5 set if some
+ * query carries a field filter (several indexed fields: without it every query reads its terms' merged lists, one per term).
  * The assertion is CHECKED ON THE DEVICE, query by query, before the search kernels run: a query that contradicts ops_mask
  * (an intersection in a batch declared union-only, more terms than declared, an unprobed term under bit 2, ...) or is
  * malformed (no terms, a term id outside the vocabulary) is answered as an empty query and flagged

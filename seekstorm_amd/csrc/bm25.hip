@@ -145,10 +145,14 @@ __global__ void bm25_final_kernel(const u64* __restrict__ keys, const u64* __res
 // more terms than declared would overrun the NT-specialised kernel, ...) or that is malformed (term id out of range, no
 // terms) is replaced by an empty query and reports d_out_count = UINT32_MAX instead of a silently wrong answer.
 constexpr uint32_t BM_CLAIM_AND = 1u, BM_CLAIM_OR = 2u, BM_CLAIM_PROBED = 4u, BM_CLAIM_FREQ = 8u, BM_CLAIM_PHRASE = 16u;
-__global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery* __restrict__ vq, uint32_t nq, uint32_t n_fields,
+// n_lists = posting lists per term (bm_n_fields); merged != 0: the last of them is the term's MERGED list (ss_common.h
+// bm_merged) -- a query without a field filter reads only that one and is a single-field query from here on, a query with a
+// field filter reads the n_lists - 1 (term, field) lists.
+constexpr uint32_t BM_CLAIM_FILTER = 32u;  // some query of the batch carries a field filter (variants sized for term x field lists)
+__global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery* __restrict__ vq, uint32_t nq, uint32_t n_lists,
                                  const unsigned long long* __restrict__ term_base, const float* __restrict__ boost,
                                  unsigned long long* __restrict__ total, uint32_t* __restrict__ tau, uint32_t claim,
-                                 uint32_t n_vterms, const uint32_t* __restrict__ probe_row) {
+                                 uint32_t n_vterms, const uint32_t* __restrict__ probe_row, uint32_t merged) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq) return;
   total[i] = 0ull;                      // per-query match count and shared threshold start from zero (no separate memset launch)
@@ -156,9 +160,15 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
   const ss_bm25_query Q = q[i];
   bm_vquery& V = vq[i];  // written in place: a local copy indexed at run time would live in scratch
   const uint32_t np = Q.n_terms, n_not = bm_q_nnot(Q.op);
+  const uint32_t n_fields = n_lists - (merged ? 1u : 0u);                      // indexed fields
+  const uint32_t filt = n_fields > 1 ? bm_q_field_filter(Q.op) : 0u;
+  const bool use_merged = merged != 0u && filt == 0u;                          // this query reads the merged lists only
+  const uint32_t f_begin = use_merged ? n_lists - 1u : 0u, f_end = use_merged ? n_lists : n_fields;  // the lists of a term it reads
+  const uint32_t eff_fields = use_merged ? 1u : n_fields;                      // ... as how many fields the rules below see them
   {
-    const uint32_t nt_claim = (claim >> 8) & 0xFFu, np_claim = (claim >> 16) & 0xFFu, ff = n_fields > 1 ? bm_q_field_filter(Q.op) : 0u;
-    bool bad = np == 0 || np + n_not > (uint32_t)SS_MAX_QUERY_TERMS || (np + n_not) * n_fields > (uint32_t)BM_MAX_VTERMS;
+    const uint32_t nt_claim = (claim >> 8) & 0xFFu, np_claim = (claim >> 16) & 0xFFu, ff = filt;
+    bool bad = np == 0 || np + n_not > (uint32_t)SS_MAX_QUERY_TERMS || (np + n_not) * eff_fields > (uint32_t)BM_MAX_VTERMS;
+    bad |= ff != 0u && merged != 0u && !(claim & BM_CLAIM_FILTER);  // the variants were sized for one list per term
     bad |= np + n_not > nt_claim || np > np_claim;
     bad |= n_not != 0 && nt_claim == np_claim;  // nt == np declares a batch without NOT terms (unfiltered kernel variants)
     const bool q_and = ((bm_q_op(Q.op) == SS_OP_INTERSECTION || bm_q_op(Q.op) == SS_OP_PHRASE) && np > 1) || ff != 0u;
@@ -168,7 +178,7 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
     const bool q_phrase = bm_q_op(Q.op) == SS_OP_PHRASE;
     bad |= bm_q_op(Q.op) > (uint32_t)SS_OP_PHRASE || q_phrase != ((claim & BM_CLAIM_PHRASE) != 0u);
     if (q_phrase) {
-      bad |= n_fields != 1 || n_not != 0 || Q.phrase_len < 2u || Q.phrase_len > (uint32_t)SS_MAX_PHRASE || np > 6u;
+      bad |= n_lists != 1 || n_not != 0 || Q.phrase_len < 2u || Q.phrase_len > (uint32_t)SS_MAX_PHRASE || np > 6u;
       uint32_t used = 0;
       for (uint32_t j = 0; j < (uint32_t)SS_MAX_PHRASE && j < Q.phrase_len; j++) {
         bad |= Q.phrase_seq[j] >= np;
@@ -179,10 +189,10 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
     bad |= bm_q_all_frequent(Q.op) && bm_q_op(Q.op) == SS_OP_INTERSECTION && np > 1 && !(claim & BM_CLAIM_FREQ);
     if (!bad)
       for (uint32_t t = 0; t < np + n_not; t++) {
-        bad |= Q.term[t] >= n_vterms / n_fields;
+        bad |= Q.term[t] >= n_vterms / n_lists;
         if (!bad && (claim & BM_CLAIM_PROBED) && probe_row)
-          for (uint32_t f = 0; f < n_fields; f++) {
-            const uint32_t v = Q.term[t] * n_fields + f;
+          for (uint32_t f = f_begin; f < f_end; f++) {
+            const uint32_t v = Q.term[t] * n_lists + f;
             bad |= probe_row[v] == BM_NO_PROBE_ROW && term_base[v + 1] != term_base[v];
           }
       }
@@ -197,22 +207,21 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
   }
   // field_filter (several indexed fields): every term must occur in a listed field (add_result.rs:3124-3136) -- an
   // intersection whose match bits only the listed fields' lists may set; a single filtered term is an intersection of one
-  const uint32_t filt = n_fields > 1 ? bm_q_field_filter(Q.op) : 0u;
   const bool is_and = ((bm_q_op(Q.op) == SS_OP_INTERSECTION || bm_q_op(Q.op) == SS_OP_PHRASE) && np > 1) || filt != 0u;
   const bool mask = np <= 8;  // 9-10 terms (single field only, checked on the host): count instead of bits
   // all_terms_frequent (intersection.rs:198-209): the caller saw N > 256 k and df >= N / 2 for every term.  One field and
   // <= 7 terms (bit 7 of the match byte becomes the "some tf < 10" mark; the host refuses the rest).
-  const bool freq = bm_q_all_frequent(Q.op) && bm_q_op(Q.op) == SS_OP_INTERSECTION && np > 1 && np <= 7 && n_fields == 1;
+  const bool freq = bm_q_all_frequent(Q.op) && bm_q_op(Q.op) == SS_OP_INTERSECTION && np > 1 && np <= 7 && n_lists == 1;
   uint32_t n = 0, n_scored = 0;
   for (uint32_t t = 0; t < np + n_not; t++) {
     if (t == np) n_scored = n;
-    for (uint32_t f = 0; f < n_fields; f++) {
-      const uint32_t v = Q.term[t] * n_fields + f;
-      // a term without postings in a field contributes nothing there (one field: kept, the zero-length list is harmless)
-      if (n_fields > 1 && term_base[v + 1] == term_base[v]) continue;
+    for (uint32_t f = f_begin; f < f_end; f++) {
+      const uint32_t v = Q.term[t] * n_lists + f;
+      // a term without postings in a field contributes nothing there (one list per term: kept, the zero-length list is harmless)
+      if (eff_fields > 1 && term_base[v + 1] == term_base[v]) continue;
       if (n >= (uint32_t)BM_MAX_VTERMS) break;
       V.term[n] = v;
-      V.idf[n] = t < np ? (n_fields > 1 ? boost[f] * Q.idf[t] : Q.idf[t]) : 0.f;  // weight * plo.idf, add_result.rs:1253-1261
+      V.idf[n] = t < np ? (n_lists > 1 ? boost[f] * Q.idf[t] : Q.idf[t]) : 0.f;  // weight * plo.idf, add_result.rs:1253-1261
       V.and_val[n] = (is_and && t < np && (!filt || ((filt >> f) & 1u))) ? (uint8_t)(mask ? (1u << t) : 0xFFu) : (uint8_t)0;
       V.group[n] = (uint8_t)t;
       n++;
@@ -244,8 +253,8 @@ int ssi_bm25_match_bits(ss_shard* s, const ss_bm25_query* d_q, unsigned long lon
   }
   uint32_t* tau = (uint32_t*)(d_bits);  // the expansion zeroes one threshold line per query: scratch, overwritten below
   bm_expand_kernel<<<1, 128, 0, st>>>(d_q, (bm_vquery*)W.d_vq, 1, s->bm_n_fields, (const unsigned long long*)s->d_term_base,
-                                      s->d_boost, d_total, tau, BM_CLAIM_AND | BM_CLAIM_OR | BM_CLAIM_FREQ | (0xFFu << 8) | (0xFEu << 16),
-                                      s->bm_n_terms, nullptr);  // the host entry point validated the query
+                                      s->d_boost, d_total, tau, BM_CLAIM_AND | BM_CLAIM_OR | BM_CLAIM_FREQ | BM_CLAIM_FILTER | (0xFFu << 8) | (0xFEu << 16),
+                                      s->bm_n_terms, nullptr, s->bm_merged ? 1u : 0u);  // the host entry point validated the query
   BmParams p{};
   p.q = (const bm_vquery*)W.d_vq;
   p.total = d_total;
@@ -260,7 +269,7 @@ int ssi_bm25_match_bits(ss_shard* s, const ss_bm25_query* d_q, unsigned long lon
 
 int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t* d_out_doc,
                     float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, bool has_or,
-                    uint32_t nt_max, uint32_t np_max, bool all_probed, hipStream_t st, bool any_frequent, bool phrase) {
+                    uint32_t nt_max, uint32_t np_max, bool all_probed, hipStream_t st, bool any_frequent, bool phrase, bool any_field_filter) {
   if (!s->d_post) return SS_ESTATE;
   if (nq == 0) return SS_OK;
   if (k > SS_MAX_K) return SS_EINVAL;
@@ -274,7 +283,8 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   // SS_BM25_EXHAUSTIVE selected.
   // Several indexed fields: every query term is a union of its (term, field) lists -- the pruned kernel ranks unions of
   // virtual terms as they are; an intersection of unions is left to the scan kernels' match masks.
-  const uint32_t F = s->bm_n_fields;
+  // With merged lists (ss_common.h bm_merged) a batch without field filters is a single-field batch to everything below.
+  const uint32_t F = (s->bm_merged && !any_field_filter) ? 1u : bm_real_fields(s);
   nt_max *= F;
   np_max *= F;
   if (F > 1) has_or = true;
@@ -285,7 +295,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
                       np_max >= 1 && np_max <= 4 && KPL <= 2;  // NOT terms are probed outside the template
   if (!pruned && !phrase && s->bm_strategy == SS_BM25_PRUNED) return SS_ENOTSUP;
   // phrase queries: their own kernel over the probe index and the positions (bm25_phrase.hip); every strategy
-  if (phrase && (!have_probe || !s->d_pos || F != 1 || KPL > 2 || np_max > 6 || nt_max != np_max)) return !s->d_pos ? SS_ESTATE : SS_ENOTSUP;
+  if (phrase && (!have_probe || !s->d_pos || s->bm_n_fields != 1 || KPL > 2 || np_max > 6 || nt_max != np_max)) return !s->d_pos ? SS_ESTATE : SS_ENOTSUP;
   // Partitions per query (one wave each).  The grid is a whole number of "rounds" of resident waves: a partially
   // filled last round costs its full duration (measured on C2: 550K q/s at 1.95 rounds vs 477K at 2.44).  Exhaustive
   // scan: 2048 resident waves (LDS-bound), ~2 rounds; pruned: 6144 resident waves, ~4 rounds of shorter assignments
@@ -336,10 +346,11 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   }
   // nt_max / np_max count (term, field) lists here; the claim is in public terms
   const uint32_t claim = (phrase ? BM_CLAIM_PHRASE : 0u) | (has_and ? BM_CLAIM_AND : 0u) | ((has_or || F > 1) ? BM_CLAIM_OR : 0u) | (all_probed ? BM_CLAIM_PROBED : 0u) |
-                         (any_frequent ? BM_CLAIM_FREQ : 0u) | (std::min(nt_max / F, 255u) << 8) | (std::min(np_max / F, 255u) << 16);
+                         (any_frequent ? BM_CLAIM_FREQ : 0u) | (any_field_filter ? BM_CLAIM_FILTER : 0u) | (std::min(nt_max / F, 255u) << 8) |
+                         (std::min(np_max / F, 255u) << 16);
   bm_expand_kernel<<<(nq + 127) / 128, 128, 0, st>>>(d_q, (bm_vquery*)W.d_vq, nq, s->bm_n_fields,
                                                     (const unsigned long long*)s->d_term_base, s->d_boost, total, tau, claim,
-                                                    s->bm_n_terms, s->d_probe_row);
+                                                    s->bm_n_terms, s->d_probe_row, s->bm_merged ? 1u : 0u);
 
   BmParams p;
   p.post = s->d_post;

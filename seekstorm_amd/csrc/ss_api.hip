@@ -113,7 +113,7 @@ static void free_bm25(ss_shard* s) {
   s->d_post = nullptr; s->d_term_base = nullptr; s->d_sub_off = nullptr; s->d_comp = nullptr;
   s->probe_pool_begin = 0; s->probe_pool_rows = 0; s->pool_list.clear(); s->pool_tick.clear();
   s->d_probe = nullptr; s->d_probe_z = nullptr; s->d_probe_row = nullptr; s->h_probe_row.clear(); s->bm_probe_rows = 0; s->d_umax = nullptr; s->d_submax = nullptr; s->d_pos = nullptr; s->d_pos_off = nullptr; s->d_pos_base = nullptr;
-  s->bm_n_docs = 0; s->bm_n_terms = 0; s->bm_n_sub = 0; s->bm_n_post = 0; s->bm_n_fields = 1; s->d_boost = nullptr;
+  s->bm_n_docs = 0; s->bm_n_terms = 0; s->bm_n_sub = 0; s->bm_n_post = 0; s->bm_n_fields = 1; s->bm_merged = false; s->d_boost = nullptr;
   s->h_df.clear(); s->h_df_real.clear(); s->bm_n_post_pad = 0; s->bm_partmax = false;
 }
 
@@ -231,44 +231,63 @@ int ssi_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, cons
                            const uint16_t* tfs, uint64_t positions_sum) {
   if (!s || !doclen || !offs || n_docs == 0 || n_terms == 0 || n_fields == 0 || n_fields > 8) return SS_EINVAL;
   if (offs[n_terms] && (!docs || !fields || !tfs)) return SS_EINVAL;
-  if ((uint64_t)n_terms * n_fields > 0x7FFFFFFFull) return SS_ENOTSUP;
-  // (term, field) lists: entries of a term are sorted by (doc, field); a stable split by field keeps each list sorted by doc
-  const uint32_t nv = n_terms * n_fields;
+  // (term, field) lists: entries of a term are sorted by (doc, field); a stable split by field keeps each list sorted by doc.
+  // Two or more fields: one more list per term, the MERGED list (ss_common.h bm_merged) -- every doc of the term once.
+  std::vector<float> b(n_fields, 1.0f);
+  if (boost) b.assign(boost, boost + n_fields);
+  float bmax = 0.f;
+  bool boosts_ok = true;
+  for (float x : b) { boosts_ok = boosts_ok && x > 0.f && x < 1e30f; bmax = std::max(bmax, x); }
+  static const bool merged_off = [] { const char* e = getenv("SS_BM25_MERGED"); return e && atoi(e) == 0; }();
+  const bool merged = n_fields > 1 && boosts_ok && !merged_off;
+  const uint32_t L = n_fields + (merged ? 1u : 0u);
+  if ((uint64_t)n_terms * L > 0x7FFFFFFFull) return SS_ENOTSUP;
+  // weights of a merged posting stay below (K + 1) * n_fields * bmax: the scale brings them under the code's 4.0
+  float scale = bmax;
+  for (uint32_t m = 1; m < n_fields; m <<= 1) scale *= 2.0f;
+  const uint32_t nv = n_terms * L;
   std::vector<uint64_t> voff((size_t)nv + 1, 0), df_real(n_terms, 0);
   for (uint32_t t = 0; t < n_terms; t++) {
     if (offs[t + 1] < offs[t]) return SS_EINVAL;
     for (uint64_t j = offs[t]; j < offs[t + 1]; j++) {
       if (fields[j] >= n_fields) return SS_EINVAL;
       if (j > offs[t] && (docs[j] < docs[j - 1] || (docs[j] == docs[j - 1] && fields[j] <= fields[j - 1]))) return SS_EINVAL;
-      voff[(size_t)t * n_fields + fields[j] + 1]++;
+      voff[(size_t)t * L + fields[j] + 1]++;
       if (j == offs[t] || docs[j] != docs[j - 1]) df_real[t]++;  // docs containing the term in any field: the df of idf
     }
+    if (merged) voff[(size_t)t * L + n_fields + 1] = df_real[t];
   }
   for (uint32_t v = 0; v < nv; v++) voff[v + 1] += voff[v];
-  std::vector<uint32_t> vdocs(offs[n_terms]);
-  std::vector<uint16_t> vtfs(offs[n_terms]);
+  std::vector<uint32_t> vdocs(voff[nv]);
+  std::vector<uint16_t> vtfs(voff[nv]);
   std::vector<uint64_t> cur(voff.begin(), voff.end() - 1);
   for (uint32_t t = 0; t < n_terms; t++)
     for (uint64_t j = offs[t]; j < offs[t + 1]; j++) {
-      const uint64_t w = cur[(size_t)t * n_fields + fields[j]]++;
+      const uint64_t w = cur[(size_t)t * L + fields[j]]++;
       vdocs[w] = docs[j];
       vtfs[w] = tfs[j];
+      if (merged && (j == offs[t] || docs[j] != docs[j - 1])) {
+        const uint64_t m = cur[(size_t)t * L + n_fields]++;
+        vdocs[m] = docs[j];
+        vtfs[m] = 1;  // not a tf: the builder derives the merged weight from the field lists
+      }
     }
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   SS_HIP(hipStreamSynchronize(s->stream));
   free_bm25(s);
   s->bm_n_docs = n_docs;
-  s->bm_n_fields = n_fields;
+  s->bm_n_fields = L;
+  s->bm_merged = merged;
   s->bm_n_terms = nv;
   s->bm_n_sub = (uint32_t)((n_docs + BM_SUB - 1) >> BM_SUB_LOG2);
-  int rc = ssi_bm25_build_from_host(s, doclen, voff.data(), vdocs.data(), vtfs.data(), positions_sum);
+  int rc = ssi_bm25_build_from_host(s, doclen, voff.data(), vdocs.data(), vtfs.data(), positions_sum, merged ? b.data() : nullptr, scale);
   if (rc == SS_OK) {
-    std::vector<float> b(n_fields, 1.0f);
-    if (boost) b.assign(boost, boost + n_fields);
-    if (hipMalloc(&s->d_boost, n_fields * sizeof(float)) != hipSuccess ||
-        hipMemcpy(s->d_boost, b.data(), n_fields * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = SS_EDEVICE;
+    if (merged) b.push_back(scale);  // the merged list's "boost" gives the scale back through idf
+    if (hipMalloc(&s->d_boost, b.size() * sizeof(float)) != hipSuccess ||
+        hipMemcpy(s->d_boost, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = SS_EDEVICE;
     s->h_df_real = df_real;
+    s->bm_n_post = offs[n_terms];  // the postings of the index (the merged lists are a second copy)
   }
   if (rc) free_bm25(s);
   return rc;
@@ -412,9 +431,12 @@ int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df
 }
 
 // nt_max: largest n_terms + NOT terms of the batch (what the scan kernels are specialised on); np_max: largest n_terms
+// any_filter: some query carries a field filter (on an image with merged lists the others read one list per term)
 static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q, bool* has_and, bool* has_or, uint32_t* nt_max,
-                         uint32_t* np_max, bool* all_probed, bool* any_frequent, bool* phrase = nullptr) {
+                         uint32_t* np_max, bool* all_probed, bool* any_frequent, bool* phrase = nullptr, bool* any_filter = nullptr) {
   uint32_t n_phrase = 0;
+  const uint32_t L = s->bm_n_fields, RF = bm_real_fields(s);  // lists per term, indexed fields
+  bool some_filter = false;
   *any_frequent = false;
   *all_probed = s->bm_probe_rows != 0;
   *has_and = false;
@@ -442,24 +464,27 @@ static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q,
     // field_filter: bits of indexed fields; an image with one indexed field has nothing to filter (the reference's set then
     // holds that field or nothing, search.rs:2483-2492).  Unions of several terms: the reference applies the filter inside
     // union_docid_3's sub-queries, not per doc -- not offered.
-    if (bm_q_field_filter(q[i].op) >> s->bm_n_fields) return SS_EINVAL;  // a field the image does not have
-    const uint32_t filt = s->bm_n_fields > 1 ? bm_q_field_filter(q[i].op) : 0u;
+    if (bm_q_field_filter(q[i].op) >> RF) return SS_EINVAL;  // a field the image does not have
+    const uint32_t filt = RF > 1 ? bm_q_field_filter(q[i].op) : 0u;
     if (filt && op == SS_OP_UNION && q[i].n_terms > 1) return SS_ENOTSUP;
+    some_filter |= filt != 0u;
+    const bool use_merged = s->bm_merged && !filt;                    // this query reads the merged lists: one list per term
+    const uint32_t eff_fields = use_merged ? 1u : RF, f_begin = use_merged ? L - 1u : 0u, f_end = use_merged ? L : RF;
     // all_terms_frequent: an intersection of 2..7 terms over one indexed field (the mark takes bit 7 of the match byte);
     // on anything else the reference's flag has no effect we model (single terms, unions) or is not offered
     if (bm_q_all_frequent(q[i].op) && op == SS_OP_INTERSECTION && q[i].n_terms > 1) {
-      if (q[i].n_terms > 7 || s->bm_n_fields > 1) return SS_ENOTSUP;
+      if (q[i].n_terms > 7 || L > 1) return SS_ENOTSUP;
       *any_frequent = true;
     }
-    if (s->bm_n_fields > 1) {  // (term, field) posting lists: at most BM_MAX_VTERMS of them, match masks of 8 bits
-      if (all * s->bm_n_fields > (uint32_t)BM_MAX_VTERMS) return SS_ENOTSUP;
+    if (eff_fields > 1) {  // (term, field) posting lists: at most BM_MAX_VTERMS of them, match masks of 8 bits
+      if (all * eff_fields > (uint32_t)BM_MAX_VTERMS) return SS_ENOTSUP;
       if (op == SS_OP_INTERSECTION && q[i].n_terms > 8) return SS_ENOTSUP;
     }
     for (uint32_t t = 0; t < all; t++) {
-      if (q[i].term[t] >= s->bm_n_terms / s->bm_n_fields) return SS_EINVAL;
-      if (*all_probed && s->bm_probe_rows < s->bm_n_terms)  // rows were rationed: does every list of this term have one?
-        for (uint32_t f = 0; f < s->bm_n_fields; f++) {
-          const uint32_t v = q[i].term[t] * s->bm_n_fields + f;
+      if (q[i].term[t] >= s->bm_n_terms / L) return SS_EINVAL;
+      if (*all_probed && s->bm_probe_rows < s->bm_n_terms)  // rows were rationed: does every list this query reads have one?
+        for (uint32_t f = f_begin; f < f_end; f++) {
+          const uint32_t v = q[i].term[t] * L + f;
           if (s->h_probe_row[v] == BM_NO_PROBE_ROW && s->h_df[v] != 0) *all_probed = false;
         }
       if (t < q[i].n_terms && !(q[i].idf[t] > 0.0f)) return SS_EINVAL;
@@ -477,6 +502,7 @@ static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q,
   if (any_not && *nt_max == *np_max) *nt_max = *np_max + 1;
   if (n_phrase && n_phrase != nq) return SS_ENOTSUP;  // a batch holds phrase queries only
   if (phrase) *phrase = n_phrase != 0;
+  if (any_filter) *any_filter = some_filter;
   return SS_OK;
 }
 
@@ -548,6 +574,13 @@ __global__ void probe_row_fill_kernel(const uint32_t* __restrict__ pairs /* (lis
   if (sb == 0 && lane == 0) probe_row[t] = r;
 }
 
+// the lists of a term that a query reads: the merged list alone without a field filter (bm_merged images), else the fields'
+static inline void query_list_range(const ss_shard* s, const ss_bm25_query& q, uint32_t* f_begin, uint32_t* f_end) {
+  const uint32_t L = s->bm_n_fields, RF = bm_real_fields(s);
+  const bool use_merged = s->bm_merged && !(RF > 1 && bm_q_field_filter(q.op));
+  *f_begin = use_merged ? L - 1u : 0u;
+  *f_end = use_merged ? L : RF;
+}
 static inline bool list_needs_row(const ss_shard* s, uint32_t v) { return s->h_probe_row[v] == BM_NO_PROBE_ROW && s->h_df[v] != 0; }
 
 // caller holds s->mu and synchronises st before the next call on this shard can touch the pool
@@ -558,9 +591,11 @@ static int ssi_bm25_ensure_probe_rows(ss_shard* s, uint32_t nq, const ss_bm25_qu
   std::vector<uint32_t> missing;
   for (uint32_t i = 0; i < nq; i++) {
     const uint32_t all = std::min<uint32_t>(q[i].n_terms + bm_q_nnot(q[i].op), SS_MAX_QUERY_TERMS);
+    uint32_t f_begin, f_end;
+    query_list_range(s, q[i], &f_begin, &f_end);
     for (uint32_t t = 0; t < all; t++) {
       if (q[i].term[t] >= n_public) continue;  // check_queries reports it
-      for (uint32_t f = 0; f < n_lists_per_term; f++) {
+      for (uint32_t f = f_begin; f < f_end; f++) {
         const uint32_t v = q[i].term[t] * n_lists_per_term + f, r = s->h_probe_row[v];
         if (r != BM_NO_PROBE_ROW && r >= s->probe_pool_begin && r < s->probe_pool_begin + s->probe_pool_rows)
           s->pool_tick[r - s->probe_pool_begin] = now;  // a pool row this batch needs: not a victim
@@ -616,9 +651,11 @@ static int ssi_bm25_ensure_probe_rows(ss_shard* s, uint32_t nq, const ss_bm25_qu
 
 static bool query_lists_probed(const ss_shard* s, const ss_bm25_query& q) {
   const uint32_t all = q.n_terms + bm_q_nnot(q.op);
+  uint32_t f_begin, f_end;
+  query_list_range(s, q, &f_begin, &f_end);
   for (uint32_t t = 0; t < all && t < SS_MAX_QUERY_TERMS; t++) {
     if (q.term[t] >= s->bm_n_terms / s->bm_n_fields) return false;  // check_queries reports it
-    for (uint32_t f = 0; f < s->bm_n_fields; f++) {
+    for (uint32_t f = f_begin; f < f_end; f++) {
       const uint32_t v = q.term[t] * s->bm_n_fields + f;
       if (s->h_probe_row[v] == BM_NO_PROBE_ROW && s->h_df[v] != 0) return false;
     }
@@ -643,11 +680,11 @@ static int bm25_search_split_batch(ss_shard* s, uint32_t nq, const ss_bm25_query
     perm[at] = i;
     qs[at] = q[i];
   }
-  struct Part { bool has_and, has_or, all_probed, any_frequent, phrase; uint32_t nt_max, np_max; } part[2];
+  struct Part { bool has_and, has_or, all_probed, any_frequent, phrase, any_filter; uint32_t nt_max, np_max; } part[2];
   const uint32_t begin[2] = {0, n_probed}, count[2] = {n_probed, nq - n_probed};
   for (int h = 0; h < 2; h++)
     SS_TRY(check_queries(s, count[h], qs.data() + begin[h], &part[h].has_and, &part[h].has_or, &part[h].nt_max, &part[h].np_max,
-                         &part[h].all_probed, &part[h].any_frequent, &part[h].phrase));
+                         &part[h].all_probed, &part[h].any_frequent, &part[h].phrase, &part[h].any_filter));
   SS_HIP(hipSetDevice(s->device));
   const uint32_t kw = std::max<uint32_t>(kk, 1);
   SS_TRY(ensure_out(s, 2 * (size_t)nq, kw));  // upper half: the answers in the order they ran in
@@ -670,7 +707,7 @@ static int bm25_search_split_batch(ss_shard* s, uint32_t nq, const ss_bm25_query
     for (int h = 0; h < 2; h++) {
       const int rc = ssi_bm25_search(s, count[h], d_q + begin[h], kk, rt, t_doc + (size_t)begin[h] * kw, t_score + (size_t)begin[h] * kw,
                                      t_count + begin[h], t_total + begin[h], part[h].has_and, part[h].has_or, part[h].nt_max,
-                                     part[h].np_max, part[h].all_probed, s->stream, part[h].any_frequent, part[h].phrase);
+                                     part[h].np_max, part[h].all_probed, s->stream, part[h].any_frequent, part[h].phrase, part[h].any_filter);
       if (rc != SS_OK) return rc;
     }
     return (int)SS_OK;
@@ -698,8 +735,8 @@ static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_quer
   }
   bool has_and = false, has_or = false;
   uint32_t nt_max = 0, np_max = 0;
-  bool all_probed = false, any_frequent = false, phrase = false;
-  SS_TRY(check_queries(s, nq, q, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent, &phrase));
+  bool all_probed = false, any_frequent = false, phrase = false, any_filter = false;
+  SS_TRY(check_queries(s, nq, q, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent, &phrase, &any_filter));
   SS_HIP(hipSetDevice(s->device));
   SS_TRY(ensure_out(s, nq, std::max<uint32_t>(kk, 1)));
   if ((size_t)nq * sizeof(ss_bm25_query) > s->bq_cap) {
@@ -711,7 +748,7 @@ static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_quer
   SS_HIP(hipMemcpyAsync(s->d_bq, q, (size_t)nq * sizeof(ss_bm25_query), hipMemcpyHostToDevice, s->stream));
   return with_facet_filter(s, n_filters, filters, s->stream, [&]() {
     return ssi_bm25_search(s, nq, (const ss_bm25_query*)s->d_bq, kk, rt, s->d_out_doc, s->d_out_score, s->d_out_count,
-                           s->d_out_total, has_and, has_or, nt_max, np_max, all_probed, s->stream, any_frequent, phrase);
+                           s->d_out_total, has_and, has_or, nt_max, np_max, all_probed, s->stream, any_frequent, phrase, any_filter);
   });
 }
 
@@ -926,7 +963,7 @@ int ss_bm25_search_filtered_dev(ss_shard* s, uint32_t nq, const ss_bm25_query* d
                                                     : ((ops_mask >> 8) & 0xFFu ? (ops_mask >> 8) & 0xFFu : SS_MAX_QUERY_TERMS),
                            // the caller vouches for the probe rows of its terms (ss_bm25_term_probed) unless none were rationed
                            s->bm_probe_rows != 0 && (s->bm_probe_rows >= s->bm_n_terms || (ops_mask & 4u) != 0), st,
-                           (ops_mask & 8u) != 0, (ops_mask & 16u) != 0);
+                           (ops_mask & 8u) != 0, (ops_mask & 16u) != 0, (ops_mask & 32u) != 0);
   });
 }
 

@@ -170,8 +170,15 @@ struct ss_shard {
   // ---- bm25 image
   uint64_t bm_n_docs = 0;
   uint32_t bm_n_terms = 0, bm_n_sub = 0;  // bm_n_terms: VIRTUAL terms (posting lists) = query-able terms x fields
-  uint32_t bm_n_fields = 1;               // indexed fields (BM25F); the public API speaks of bm_n_terms / bm_n_fields terms
-  float* d_boost = nullptr;               // [bm_n_fields] schema boost per field (add_result.rs:1253)
+  uint32_t bm_n_fields = 1;               // posting lists per query-able term: the indexed fields (BM25F), + 1 when bm_merged;
+                                          // the public API speaks of bm_n_terms / bm_n_fields terms
+  // Several indexed fields: BM25F is additive per (term, field), so beside the (term, field) lists the image carries one
+  // MERGED list per term -- the last of the term's lists: every doc that holds the term in any field, with the weight
+  // sum_f boost_f * w_f / S (S = the scale that keeps it inside the weight code's range; boost[last] = S gives it back
+  // through idf).  A query WITHOUT a field filter reads only these: it is a single-field query to every kernel (pruned
+  // strategy, 16-bit scan, plain intersections); a query with a field filter reads the (term, field) lists as before.
+  bool bm_merged = false;
+  float* d_boost = nullptr;               // [bm_n_fields] schema boost per field (add_result.rs:1253); merged list: S
   std::vector<uint64_t> h_df_real;        // multi-field: docs containing the term in any field (the df idf needs)
   std::map<hipStream_t, ss_bm_ws> bm_ws;   // per-stream search workspaces (guarded by mu)
   uint64_t bm_n_post = 0;
@@ -319,13 +326,18 @@ __host__ __device__ inline bool bm_q_all_frequent(uint32_t op) { return (op >> 3
 constexpr uint32_t BM_AND_FREQ = 0x100u;
 int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t* d_out_doc,
                     float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, bool has_or,
-                    uint32_t nt_max, uint32_t np_max, bool all_probed, hipStream_t st, bool any_frequent = false, bool phrase = false);
+                    uint32_t nt_max, uint32_t np_max, bool all_probed, hipStream_t st, bool any_frequent = false, bool phrase = false,
+                    bool any_field_filter = true);
+// indexed fields of the image (bm_n_fields counts the merged list as well)
+inline uint32_t bm_real_fields(const ss_shard* s) { return s->bm_n_fields - (s->bm_merged ? 1u : 0u); }
 // ---- implemented in synth.hip
 int ssi_vec_synth(ss_shard* s, uint64_t seed, hipStream_t st);
 int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const uint8_t* d_lentab, hipStream_t st);
 // positions_sum = 0: avgdl from the decoded length bytes; else the reference's stored positions_sum_normalized (index.rs:3480)
+// merged_boost (s->bm_merged images): the real fields' boosts; the last list of every term is then built here as the merged
+// list -- its offs / docs give the docs, its weights come from the term's field lists
 int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t* offs, const uint32_t* docs,
-                             const uint16_t* tfs, uint64_t positions_sum);
+                             const uint16_t* tfs, uint64_t positions_sum, const float* merged_boost = nullptr, float merged_scale = 1.0f);
 int ssi_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen, uint32_t n_terms, const uint64_t* offs,
                     const uint32_t* docs, const uint16_t* tfs, uint64_t positions_sum);
 int ssi_bm25_attach_positions(ss_shard* s, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs, const uint16_t* positions,

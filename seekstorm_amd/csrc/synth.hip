@@ -132,12 +132,14 @@ static int alloc_probe(ss_shard* s, hipStream_t st) {
   return SS_OK;
 }
 int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t* offs, const uint32_t* docs,
-                             const uint16_t* tfs, uint64_t positions_sum) {
+                             const uint16_t* tfs, uint64_t positions_sum, const float* merged_boost, float merged_scale) {
   const uint32_t nt = s->bm_n_terms, ns = s->bm_n_sub;
+  const uint32_t L = s->bm_n_fields, RF = bm_real_fields(s);  // lists per term, indexed fields
+  if (s->bm_merged && !merged_boost) return SS_EINVAL;
   u64 psum = 0;
   if (positions_sum) psum = positions_sum;
   else
-    for (u64 d = 0; d < s->bm_n_docs * s->bm_n_fields; d++) psum += ss_byte4_to_int(doclen[d]);  // all fields (index.rs:5848)
+    for (u64 d = 0; d < s->bm_n_docs * RF; d++) psum += ss_byte4_to_int(doclen[d]);  // all fields (index.rs:5848)
   s->bm_avgdl = (float)psum / (float)s->bm_n_docs;  // commit.rs:318-319
   float comp[SS_COMP_N];
   fill_comp(s->bm_avgdl, comp);
@@ -170,8 +172,12 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
   std::vector<float> submax((size_t)(nt + 1) * ns, 0.f);
   for (uint32_t t = 0; t < nt; t++) {
     const bool flagged = bm_list_flagged(s, s->h_df[t]);
-    const uint8_t* dl = doclen + (size_t)(t % s->bm_n_fields) * s->bm_n_docs;  // the list's field (virtual term = term * F + field)
+    const bool merged = s->bm_merged && t % L == L - 1;  // the term's merged list: weights from its field lists t - RF .. t - 1
+    const uint8_t* dl = doclen + (size_t)(merged ? 0 : t % L) * s->bm_n_docs;  // the list's field (virtual term = term * L + field)
     const uint32_t* row = sub.data() + (size_t)t * (ns + 1);
+    u64 fcur[8];  // cursors into the field lists (merged list only)
+    if (merged)
+      for (uint32_t f = 0; f < RF; f++) fcur[f] = offs[t - RF + f];
     u64 j = offs[t];
     for (uint32_t sb = 0; sb < ns; sb++) {
       const u64 lim = ((u64)sb + 1) << BM_SUB_LOG2;
@@ -180,7 +186,24 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
         if (docs[j] >= s->bm_n_docs) return SS_EINVAL;
         if (j > offs[t] && docs[j] <= docs[j - 1]) return SS_EINVAL;
         if (tfs[j] == 0) return SS_EINVAL;
-        const uint32_t code = bm_code_of(tfs[j], comp[dl[docs[j]]], flagged);
+        uint32_t code;
+        if (merged) {  // sum_f boost_f * tf (K + 1) / (tf + comp[len_f]) over the fields that hold the doc, fields ascending
+          float w = 0.f;
+          bool any = false;
+          for (uint32_t f = 0; f < RF; f++) {
+            const uint32_t vf = t - RF + f;
+            while (fcur[f] < offs[vf + 1] && docs[fcur[f]] < docs[j]) fcur[f]++;
+            if (fcur[f] < offs[vf + 1] && docs[fcur[f]] == docs[j]) {
+              const volatile float part = merged_boost[f] * bm_weight_exact(tfs[fcur[f]], comp[doclen[(size_t)f * s->bm_n_docs + docs[j]]]);
+              w = w + part;
+              any = true;
+            }
+          }
+          if (!any) return SS_EINVAL;  // a doc of the merged list that no field list holds
+          code = bm_wcode(w / merged_scale);
+        } else {
+          code = bm_code_of(tfs[j], comp[dl[docs[j]]], flagged);
+        }
         post[w] = bm_pack(docs[j] & (BM_SUB - 1), code);
         umax[t] = std::max(umax[t], bm_wdecode(code));  // the bound of the pruned kernel: over the weights as the kernels see them
         submax[(size_t)t * ns + sb] = std::max(submax[(size_t)t * ns + sb], bm_wdecode(code));
