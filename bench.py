@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the full-size oracle comparison")
     ap.add_argument("--no-topk-count", action="store_true", help="skip the TopkCount comparison (keeps counter profiles of the Topk kernels clean)")
     ap.add_argument("--no-rationed", action="store_true", help="skip the rationed-vocabulary leg")
+    ap.add_argument("--no-fields", action="store_true", help="skip the multi-field (BM25F) leg")
     ap.add_argument("--quick", action="store_true", help="profiling runs: few calls per leg, no cpu / parity legs")
     ap.add_argument("--cpu-seconds", type=float, default=5.0)
     ap.add_argument("--parity-queries", type=int, default=32)
@@ -381,6 +382,48 @@ def main():
         torch.cuda.synchronize()
         sc = o_score.cpu().numpy()
         assert np.all(sc[:, :-1] >= sc[:, 1:]) and np.all(o_cnt.cpu().numpy() == k)
+
+        # (4b) SEVERAL indexed fields (BM25F; the reference's README benchmarks index title / body / url): a host-built 2 M-doc corpus
+        # with 3 fields (boosts 2 / 1 / 0.5), 96 terms in the C2 df bands; 2-term AND and 3-term OR top-10 with exact counts, 1000
+        # queries per call through the host-pointer entry point.  Queries without a field filter read the merged per-term lists.
+        if rank == 0 and not args.quick and not args.no_fields:
+            t0 = time.perf_counter()
+            rng_f = np.random.default_rng(7)
+            fd, ff_n, ft_n = 2_000_000, 3, 96
+            flens = np.clip(np.round(np.exp(np.log([12, 300, 8])[:, None] + 0.5 * rng_f.standard_normal((3, fd)))), 1, 60000).astype(np.int64)
+            lut = np.array([O.lib().so_int_to_byte4(int(x)) for x in range(0, 60001)], np.uint8)
+            fdl = lut[flens]
+            pf = np.array([0.25, 0.9, 0.15])
+            fdfs = np.concatenate([rng_f.uniform(0.005, 0.02, 32), rng_f.uniform(0.02, 0.05, 32), rng_f.uniform(0.05, 0.15, 32)])
+            foffs, FD, FF, FT = [0], [], [], []
+            for df_ in fdfs:
+                d_ = np.sort(rng_f.choice(fd, int(df_ * fd), replace=False)).astype(np.uint32)
+                m_ = rng_f.random((len(d_), ff_n)) < pf
+                m_[~m_.any(1), 1] = True
+                di_, fi_ = np.nonzero(m_)
+                FD.append(d_[di_]); FF.append(fi_.astype(np.uint8)); FT.append(np.minimum(rng_f.geometric(0.5, len(di_)), 500).astype(np.uint16))
+                foffs.append(foffs[-1] + len(di_))
+            sf = S.Shard(local_rank)
+            sf.upload_lexical_fields(fd, fdl, [2.0, 1.0, 0.5], np.array(foffs, np.uint64), np.concatenate(FD), np.concatenate(FF), np.concatenate(FT))
+            fbuild = time.perf_counter() - t0
+            lo_, mid_, hi_ = np.arange(0, 32), np.arange(32, 64), np.arange(64, 96)
+            legs = {}
+            for name, tl_, qt_ in (("and2", [[int(rng_f.choice(mid_)), int(rng_f.choice(hi_))] for _ in range(nq)], S.QueryType.Intersection),
+                                   ("or3", [[int(rng_f.choice(lo_)), int(rng_f.choice(mid_)), int(rng_f.choice(hi_))] for _ in range(nq)], S.QueryType.Union)):
+                qf = sf.make_queries(tl_, qt_)
+                sf.set_strategy(N.BM25_EXHAUSTIVE)
+                ref_f = sf.search_lexical_batch(qf, k, S.ResultType.TopkCount)
+                sf.set_strategy(N.BM25_AUTO)
+                got_f = sf.search_lexical_batch(qf, k, S.ResultType.TopkCount)
+                assert all(np.array_equal(x, y) for x, y in zip(ref_f, got_f)), "multi-field: strategies differ"
+                lat_f = host_latencies(lambda: sf.search_lexical_batch(qf, k, S.ResultType.TopkCount), 200)
+                legs[name] = {"value": nq / (np.mean(lat_f) * 1e-3), "unit": "queries/s", "batch_ms_p50": pct(lat_f, 50), "batch_ms_p99": pct(lat_f, 99)}
+            bm["multi_field"] = dict(legs, docs=fd, fields=ff_n, boosts=[2.0, 1.0, 0.5], postings=int(foffs[-1]), build_s=fbuild, result_type="TopkCount",
+                                     entry_point="ss_bm25_search (host pointers, host clock; Python mirror call)",
+                                     note="and2 = 2-term AND, or3 = 3-term OR, top-10, 1000 queries per call, no field filter: the queries read one "
+                                          "merged list per term (weights = sum over the fields of boost * w) and take the pruned strategy; AUTO "
+                                          "answers asserted equal to the exhaustive strategy's")
+            sf.close()
 
         # (5) a RATIONED vocabulary: the probe index has rows for the longest lists only (ss_bm25_set_probe_budget), as for a
         # real vocabulary of millions of terms.  Here: a budget of one row per list with df >= 1 % of the docs, which leaves more
@@ -759,6 +802,8 @@ def main():
                 line["intersection"] = bm["intersection"]
             if "rationed_vocabulary" in bm:
                 line["rationed_vocabulary"] = bm["rationed_vocabulary"]
+            if "multi_field" in bm:
+                line["multi_field"] = bm["multi_field"]
             line["bm25"] = {"build_s": bm["build_s"], "postings": int(bm["info"]["n_postings"]), "avgdl": bm["info"]["avgdl"],
                             "mean_algorithmic_bytes_per_query": bm["mean_bytes_per_query"], "mean_union_size": bm["mean_union"]}
         if vec is not None and is_bm:
