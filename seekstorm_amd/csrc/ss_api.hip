@@ -9,6 +9,7 @@
 
 #include "ss_common.h"
 #include "facet_point.h"
+#include "bm25_build.h"
 
 #define SS_TRY(x)          \
   do {                     \
@@ -239,55 +240,65 @@ int ssi_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, cons
   bool boosts_ok = true;
   for (float x : b) { boosts_ok = boosts_ok && x > 0.f && x < 1e30f; bmax = std::max(bmax, x); }
   static const bool merged_off = [] { const char* e = getenv("SS_BM25_MERGED"); return e && atoi(e) == 0; }();
-  const bool merged = n_fields > 1 && boosts_ok && !merged_off;
-  const uint32_t L = n_fields + (merged ? 1u : 0u);
-  if ((uint64_t)n_terms * L > 0x7FFFFFFFull) return SS_ENOTSUP;
-  // weights of a merged posting stay below (K + 1) * n_fields * bmax: the scale brings them under the code's 4.0
-  float scale = bmax;
-  for (uint32_t m = 1; m < n_fields; m <<= 1) scale *= 2.0f;
-  const uint32_t nv = n_terms * L;
-  std::vector<uint64_t> voff((size_t)nv + 1, 0), df_real(n_terms, 0);
+  (void)bmax;
+  std::vector<uint64_t> df_real(n_terms, 0);
   for (uint32_t t = 0; t < n_terms; t++) {
     if (offs[t + 1] < offs[t]) return SS_EINVAL;
     for (uint64_t j = offs[t]; j < offs[t + 1]; j++) {
       if (fields[j] >= n_fields) return SS_EINVAL;
       if (j > offs[t] && (docs[j] < docs[j - 1] || (docs[j] == docs[j - 1] && fields[j] <= fields[j - 1]))) return SS_EINVAL;
-      voff[(size_t)t * L + fields[j] + 1]++;
       if (j == offs[t] || docs[j] != docs[j - 1]) df_real[t]++;  // docs containing the term in any field: the df of idf
     }
-    if (merged) voff[(size_t)t * L + n_fields + 1] = df_real[t];
   }
-  for (uint32_t v = 0; v < nv; v++) voff[v + 1] += voff[v];
-  std::vector<uint32_t> vdocs(voff[nv]);
-  std::vector<uint16_t> vtfs(voff[nv]);
-  std::vector<uint64_t> cur(voff.begin(), voff.end() - 1);
-  for (uint32_t t = 0; t < n_terms; t++)
-    for (uint64_t j = offs[t]; j < offs[t + 1]; j++) {
-      const uint64_t w = cur[(size_t)t * L + fields[j]]++;
-      vdocs[w] = docs[j];
-      vtfs[w] = tfs[j];
-      if (merged && (j == offs[t] || docs[j] != docs[j - 1])) {
-        const uint64_t m = cur[(size_t)t * L + n_fields]++;
-        vdocs[m] = docs[j];
-        vtfs[m] = 1;  // not a tf: the builder derives the merged weight from the field lists
-      }
-    }
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   SS_HIP(hipStreamSynchronize(s->stream));
-  free_bm25(s);
-  s->bm_n_docs = n_docs;
-  s->bm_n_fields = L;
-  s->bm_merged = merged;
-  s->bm_n_terms = nv;
-  s->bm_n_sub = (uint32_t)((n_docs + BM_SUB - 1) >> BM_SUB_LOG2);
-  int rc = ssi_bm25_build_from_host(s, doclen, voff.data(), vdocs.data(), vtfs.data(), positions_sum, merged ? b.data() : nullptr, scale);
-  if (rc == SS_OK) {
-    if (merged) b.push_back(scale);  // the merged list's "boost" gives the scale back through idf
-    if (hipMalloc(&s->d_boost, b.size() * sizeof(float)) != hipSuccess ||
-        hipMemcpy(s->d_boost, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = SS_EDEVICE;
-    s->h_df_real = df_real;
-    s->bm_n_post = offs[n_terms];  // the postings of the index (the merged lists are a second copy)
+  // with merged lists first; a corpus whose merged weights do not fit the weight code is built again without them
+  int rc = SS_OK;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    const bool merged = attempt == 0 && n_fields > 1 && boosts_ok && !merged_off;
+    if (attempt == 0 && !merged) continue;
+    const uint32_t L = n_fields + (merged ? 1u : 0u);
+    if ((uint64_t)n_terms * L > 0x7FFFFFFFull) return SS_ENOTSUP;
+    const uint32_t nv = n_terms * L;
+    std::vector<uint64_t> voff((size_t)nv + 1, 0);
+    for (uint32_t t = 0; t < n_terms; t++) {
+      for (uint64_t j = offs[t]; j < offs[t + 1]; j++) voff[(size_t)t * L + fields[j] + 1]++;
+      if (merged) voff[(size_t)t * L + n_fields + 1] = df_real[t];
+    }
+    for (uint32_t v = 0; v < nv; v++) voff[v + 1] += voff[v];
+    std::vector<uint32_t> vdocs(voff[nv]);
+    std::vector<uint16_t> vtfs(voff[nv]);
+    std::vector<uint64_t> cur(voff.begin(), voff.end() - 1);
+    for (uint32_t t = 0; t < n_terms; t++)
+      for (uint64_t j = offs[t]; j < offs[t + 1]; j++) {
+        const uint64_t w = cur[(size_t)t * L + fields[j]]++;
+        vdocs[w] = docs[j];
+        vtfs[w] = tfs[j];
+        if (merged && (j == offs[t] || docs[j] != docs[j - 1])) {
+          const uint64_t m = cur[(size_t)t * L + n_fields]++;
+          vdocs[m] = docs[j];
+          vtfs[m] = 1;  // not a tf: the builder derives the merged weight from the field lists
+        }
+      }
+    free_bm25(s);
+    s->bm_n_docs = n_docs;
+    s->bm_n_fields = L;
+    s->bm_merged = merged;
+    s->bm_n_terms = nv;
+    s->bm_n_sub = (uint32_t)((n_docs + BM_SUB - 1) >> BM_SUB_LOG2);
+    float scale = 1.0f;
+    rc = ssi_bm25_build_from_host_merged(s, doclen, voff.data(), vdocs.data(), vtfs.data(), positions_sum, merged ? b.data() : nullptr, &scale);
+    if (rc == SS_MERGED_RANGE) continue;  // the merged weights span more than the code: again, without merged lists
+    if (rc == SS_OK) {
+      std::vector<float> bb = b;
+      if (merged) bb.push_back(scale);  // the merged list's "boost" gives the scale back through idf
+      if (hipMalloc(&s->d_boost, bb.size() * sizeof(float)) != hipSuccess ||
+          hipMemcpy(s->d_boost, bb.data(), bb.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = SS_EDEVICE;
+      s->h_df_real = df_real;
+      s->bm_n_post = offs[n_terms];  // the postings of the index (the merged lists are a second copy)
+    }
+    break;
   }
   if (rc) free_bm25(s);
   return rc;

@@ -2,6 +2,7 @@
 // counter-based generator is bit-identical to the CPU oracle's (oracle/ss_oracle.c so_lex_* / so_vec_gen), so a
 // 10M-doc / 10M x 768 corpus never crosses PCIe and the oracle can still regenerate any slice of it.
 #include "ss_common.h"
+#include "bm25_build.h"
 
 #include <cmath>
 #include <cstring>
@@ -133,9 +134,16 @@ static int alloc_probe(ss_shard* s, hipStream_t st) {
 }
 int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t* offs, const uint32_t* docs,
                              const uint16_t* tfs, uint64_t positions_sum, const float* merged_boost, float merged_scale) {
+  (void)merged_scale;
+  if (merged_boost || s->bm_merged) return SS_EINVAL;  // images with merged lists: ssi_bm25_build_from_host_merged
+  return ssi_bm25_build_from_host_merged(s, doclen, offs, docs, tfs, positions_sum, nullptr, nullptr);
+}
+
+int ssi_bm25_build_from_host_merged(ss_shard* s, const uint8_t* doclen, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
+                                    uint64_t positions_sum, const float* merged_boost, float* merged_scale) {
   const uint32_t nt = s->bm_n_terms, ns = s->bm_n_sub;
   const uint32_t L = s->bm_n_fields, RF = bm_real_fields(s);  // lists per term, indexed fields
-  if (s->bm_merged && !merged_boost) return SS_EINVAL;
+  if (s->bm_merged && (!merged_boost || !merged_scale)) return SS_EINVAL;
   u64 psum = 0;
   if (positions_sum) psum = positions_sum;
   else
@@ -143,6 +151,49 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
   s->bm_avgdl = (float)psum / (float)s->bm_n_docs;  // commit.rs:318-319
   float comp[SS_COMP_N];
   fill_comp(s->bm_avgdl, comp);
+  // merged lists: their weights first -- sum_f boost_f * tf (K + 1) / (tf + comp[len_f]) over the fields that hold the doc,
+  // fields ascending -- so that the scale can be chosen from what the corpus really holds: the smallest power of two that
+  // brings the largest weight under the code's 4.0.  The code spans 2^-14 .. 2^2; a corpus whose merged weights do not fit
+  // (boosts very far apart) gets no merged lists rather than clamped scores.
+  std::vector<float> mw;
+  std::vector<u64> mw_base;
+  float mscale = 1.0f;
+  if (s->bm_merged) {
+    mw_base.assign(nt / L + 1, 0);
+    for (uint32_t t = L - 1; t < nt; t += L) mw_base[t / L + 1] = mw_base[t / L] + (offs[t + 1] - offs[t]);
+    mw.resize(mw_base[nt / L]);
+    float wmin = 3.0e38f, wmax = 0.f;
+    for (uint32_t t = L - 1; t < nt; t += L) {
+      u64 fcur[8];
+      for (uint32_t f = 0; f < RF; f++) fcur[f] = offs[t - RF + f];
+      for (u64 j = offs[t]; j < offs[t + 1]; j++) {
+        if (docs[j] >= s->bm_n_docs) return SS_EINVAL;
+        float w = 0.f;
+        bool any = false;
+        for (uint32_t f = 0; f < RF; f++) {
+          const uint32_t vf = t - RF + f;
+          while (fcur[f] < offs[vf + 1] && docs[fcur[f]] < docs[j]) fcur[f]++;
+          if (fcur[f] < offs[vf + 1] && docs[fcur[f]] == docs[j]) {
+            if (tfs[fcur[f]] == 0) return SS_EINVAL;
+            const volatile float part = merged_boost[f] * bm_weight_exact(tfs[fcur[f]], comp[doclen[(size_t)f * s->bm_n_docs + docs[j]]]);
+            w = w + part;
+            any = true;
+          }
+        }
+        if (!any || !(w > 0.f)) return SS_EINVAL;  // a doc of the merged list that no field list holds
+        mw[mw_base[t / L] + (j - offs[t])] = w;
+        wmin = std::min(wmin, w);
+        wmax = std::max(wmax, w);
+      }
+    }
+    if (!mw.empty()) {
+      int e = 0;
+      (void)std::frexp(wmax / 3.99f, &e);  // wmax / 3.99 = m * 2^e, m in [0.5, 1)  ->  2^e > wmax / 3.99
+      mscale = std::ldexp(1.0f, e);
+      if (wmin / mscale < 6.2e-5f) return SS_MERGED_RANGE;  // below 2^-14 + a margin: the code would clamp it
+    }
+    *merged_scale = mscale;
+  }
   // pass 1: validate, segment boundaries in 16-byte units (4 postings, zero padded) relative to the term base
   std::vector<uint32_t> sub((size_t)nt * (ns + 1));
   std::vector<u64> tbase((size_t)nt + 1);
@@ -175,9 +226,6 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
     const bool merged = s->bm_merged && t % L == L - 1;  // the term's merged list: weights from its field lists t - RF .. t - 1
     const uint8_t* dl = doclen + (size_t)(merged ? 0 : t % L) * s->bm_n_docs;  // the list's field (virtual term = term * L + field)
     const uint32_t* row = sub.data() + (size_t)t * (ns + 1);
-    u64 fcur[8];  // cursors into the field lists (merged list only)
-    if (merged)
-      for (uint32_t f = 0; f < RF; f++) fcur[f] = offs[t - RF + f];
     u64 j = offs[t];
     for (uint32_t sb = 0; sb < ns; sb++) {
       const u64 lim = ((u64)sb + 1) << BM_SUB_LOG2;
@@ -187,20 +235,8 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
         if (j > offs[t] && docs[j] <= docs[j - 1]) return SS_EINVAL;
         if (tfs[j] == 0) return SS_EINVAL;
         uint32_t code;
-        if (merged) {  // sum_f boost_f * tf (K + 1) / (tf + comp[len_f]) over the fields that hold the doc, fields ascending
-          float w = 0.f;
-          bool any = false;
-          for (uint32_t f = 0; f < RF; f++) {
-            const uint32_t vf = t - RF + f;
-            while (fcur[f] < offs[vf + 1] && docs[fcur[f]] < docs[j]) fcur[f]++;
-            if (fcur[f] < offs[vf + 1] && docs[fcur[f]] == docs[j]) {
-              const volatile float part = merged_boost[f] * bm_weight_exact(tfs[fcur[f]], comp[doclen[(size_t)f * s->bm_n_docs + docs[j]]]);
-              w = w + part;
-              any = true;
-            }
-          }
-          if (!any) return SS_EINVAL;  // a doc of the merged list that no field list holds
-          code = bm_wcode(w / merged_scale);
+        if (merged) {
+          code = bm_wcode(mw[mw_base[t / L] + (j - offs[t])] / mscale);
         } else {
           code = bm_code_of(tfs[j], comp[dl[docs[j]]], flagged);
         }

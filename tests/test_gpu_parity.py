@@ -931,6 +931,35 @@ def test_bm25f_several_fields(S, O, n_fields, boost):
     sh.close()
 
 
+def test_bm25f_boosts_too_far_apart_for_merged_lists(S, O):
+    """Merged per-term lists hold sum_f boost_f * w_f in the 19-bit weight code (2^-14 .. 2^2 after a power-of-two scale chosen
+    from the corpus).  Boosts 4096 / 1 / 1/4096 span far more: the image is then built WITHOUT merged lists (exact per-field
+    scores rather than clamped ones) -- parity with the oracle as ever, and intersections stay with the scan kernels."""
+    from seekstorm_amd import _native as N
+    n_docs, n_fields = 60_000, 3
+    boost = [4096.0, 1.0, 1.0 / 4096.0]
+    dfs = [20_000, 6_000, 1_500]
+    dl, offs, docs, fields, tfs = _fields_corpus(O, n_docs, n_fields, dfs, 77)
+    sh = S.Shard(0)
+    sh.upload_lexical_fields(n_docs, dl, boost, offs, docs, fields, tfs)
+    for terms, qt, oop in (([0, 1], S.QueryType.Union, O.OP_OR), ([0, 1, 2], S.QueryType.Intersection, O.OP_AND), ([2], S.QueryType.Union, O.OP_OR)):
+        q = sh.make_queries([terms], qt)
+        doc, score, cnt, tot = sh.search_lexical_batch(q, 10, S.ResultType.TopkCount)
+        od, os_, otot, _ = O.search_fields_exhaustive(n_docs, dl, boost, offs, docs, fields, tfs, terms, oop, 10, (), ())
+        assert int(tot[0]) == otot
+        _check_topk(doc[0], score[0], cnt[0], od, os_)
+    sh.set_strategy(N.BM25_PRUNED)
+    with pytest.raises(S.SeekStormHipError):   # (term, field) lists only: an intersection of unions is a scan-kernel query
+        sh.search_lexical_batch(sh.make_queries([[0, 1]], S.QueryType.Intersection), 10, S.ResultType.Topk)
+    sh.close()
+    # ordinary boosts: merged lists, and the pruned strategy serves the same intersection
+    sh = S.Shard(0)
+    sh.upload_lexical_fields(n_docs, dl, [2.0, 1.0, 0.5], offs, docs, fields, tfs)
+    sh.set_strategy(N.BM25_PRUNED)
+    sh.search_lexical_batch(sh.make_queries([[0, 1]], S.QueryType.Intersection), 10, S.ResultType.Topk)
+    sh.close()
+
+
 @pytest.mark.parametrize("n_fields", [2, 3])
 def test_bm25f_field_filter(S, O, n_fields):
     """field_filter on an image with several indexed fields (add_result.rs:3124-3136): a doc stays only if every query term
