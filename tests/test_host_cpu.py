@@ -46,6 +46,52 @@ def test_struct_layout_matches_header():
                    N.FacetFilterC.lo.offset, N.FacetFilterC.values.offset, C.sizeof(N.RefBlock)]
 
 
+def test_rust_ffi_file_is_the_header():
+    """integration/hip_ffi.rs (the extern "C" side of the Rust binding) is generated from the header: the
+    committed file equals a fresh generation, names every entry point, and its #[repr(C)] structs have the sizes and field
+    offsets gcc gives the C structs (computed with the C layout rules from the Rust field types)."""
+    import re, subprocess, sys, tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_rust_ffi as G
+    text, names = G.generate()
+    assert open(os.path.join(ROOT, "integration", "hip_ffi.rs")).read() == text, "run python tools/gen_rust_ffi.py"
+    hdr = open(os.path.join(ROOT, "include", "seekstorm_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(ss_[a-z0-9_]+)\s*\(", hdr)))
+    assert sorted(names) == declared
+    assert text.count("{") == text.count("}") and text.count("(") == text.count(")")
+    size = {"u8": 1, "i8": 1, "u16": 2, "i16": 2, "u32": 4, "i32": 4, "f32": 4, "c_int": 4, "u64": 8, "i64": 8, "f64": 8}
+    consts = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"pub const (SS_\w+): \w+ = (-?\w+);", text)}
+    layouts = {}
+    for m in re.finditer(r"pub struct (Ss\w+) \{\n((?:    pub [^\n]+\n)+)\}", text):
+        off, align, fields = 0, 1, []
+        for f in re.finditer(r"pub (\S+): ([^,]+),", m.group(2)):
+            ty, n = f.group(2).strip(), 1
+            a = re.fullmatch(r"\[(\w+); (\w+)(?: as usize)?\]", ty)
+            if a:
+                ty, n = a.group(1), consts[a.group(2)] if a.group(2) in consts else int(a.group(2))
+            sz = 8 if ty.startswith("*") else size[ty]
+            off = (off + sz - 1) // sz * sz
+            fields.append((f.group(1).replace("r#", ""), off))
+            off += sz * n
+            align = max(align, sz)
+        layouts[m.group(1)] = ((off + align - 1) // align * align, fields)
+    cname = {"SsRefBlock": "ss_ref_block", "SsBm25Query": "ss_bm25_query", "SsFacetPoint": "ss_facet_point", "SsFacetFilter": "ss_facet_filter",
+             "SsAnnMode": "ss_ann_mode"}
+    assert set(layouts) == set(cname)
+    items, want = [], []
+    for rs, (total, fields) in layouts.items():
+        items.append("sizeof(%s)" % cname[rs]); want.append(total)
+        for fname, off in fields:
+            items.append("offsetof(%s, %s)" % (cname[rs], fname)); want.append(off)
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "seekstorm_hip.h"\nint main(void) { size_t v[] = {%s}; '
+           'for (unsigned i = 0; i < sizeof v / sizeof v[0]; i++) printf("%%zu ", v[i]); return 0; }\n' % ", ".join(items))
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(d, "t"), os.path.join(d, "t.c")], check=True)
+        got = [int(x) for x in subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split()]
+    assert got == want
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     import ctypes as C
     import seekstorm_amd as S
