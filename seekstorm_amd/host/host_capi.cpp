@@ -131,6 +131,23 @@ int ssh_search_lexical_shard_ex(ssh_index* ix, int shard, const uint32_t* terms,
   ResultObject ro = ix->shards[shard]->search_lexical_shard(t, (QueryType)query_type, offset, length, (ResultType)result_type, f, nt, ff, rs);
   return write_out(ro, cap, out_doc, out_score, nullptr, nullptr, nullptr, out_meta);
 }
+// Index::search_lexical_sorted over all shards of the index
+int ssh_index_search_sorted(ssh_index* ix, const uint32_t* terms, uint32_t n_terms, uint32_t query_type, uint32_t offset, uint32_t length,
+                            uint32_t n_filters, const ss_facet_filter* filters, const ssh_result_sort* sorts, uint32_t n_sorts, uint32_t cap,
+                            uint64_t* out_doc, float* out_score, uint64_t* out_meta) {
+  std::vector<ResultSort> rs(n_sorts);
+  for (uint32_t i = 0; i < n_sorts; i++) {
+    rs[i].facet_offset = sorts[i].facet_offset;
+    rs[i].facet_type = sorts[i].facet_type;
+    rs[i].descending = sorts[i].descending != 0;
+    rs[i].base[0] = sorts[i].base[0];
+    rs[i].base[1] = sorts[i].base[1];
+  }
+  if (!ix->index) ix->index.reset(new Index(ix->shards));
+  ResultObject ro = ix->index->search_lexical_sorted(std::vector<uint32_t>(terms, terms + n_terms), (QueryType)query_type, offset, length, rs,
+                                                     std::vector<ss_facet_filter>(filters, filters + n_filters));
+  return write_out(ro, cap, out_doc, out_score, nullptr, nullptr, nullptr, out_meta);
+}
 int ssh_upload_lexical_fields(ssh_index* ix, int shard, uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost,
                               uint32_t n_terms, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields, const uint16_t* tfs) {
   return ix->shards[shard]->upload_lexical_fields(n_docs, n_fields, doclen, boost, n_terms, offs, docs, fields, tfs);

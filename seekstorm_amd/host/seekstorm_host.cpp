@@ -462,6 +462,24 @@ ss_facet_filter bits_filter(uint32_t offset, uint32_t type, uint64_t lo, uint64_
 }
 }  // namespace
 
+int Shard::sort_keys(const std::vector<uint32_t>& doc_ids, const ResultSort& sf, std::vector<uint64_t>* keys) {
+  keys->assign(doc_ids.size(), 0);
+  if (doc_ids.empty()) return SS_OK;
+  if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
+  int rc;
+  if (sf.facet_type == SS_FACET_POINT) {
+    const ss_facet_point base{sf.base[0], sf.base[1], SS_POINT_SORTKEY, 0};
+    rc = ss_facet_point_distances(h_, (uint32_t)doc_ids.size(), doc_ids.data(), sf.facet_offset, &base, keys->data());
+  } else {
+    if (sf.facet_type > SS_FACET_F64) return SS_ENOTSUP;
+    rc = ss_facet_values(h_, (uint32_t)doc_ids.size(), doc_ids.data(), sf.facet_offset, sf.facet_type, keys->data());
+  }
+  if (rc != SS_OK) return rc;
+  const uint32_t kt = sf.facet_type == SS_FACET_POINT ? (uint32_t)SS_FACET_F64 : sf.facet_type;
+  for (uint64_t& x : *keys) x = order_key(x, kt, sf.descending);
+  return SS_OK;
+}
+
 int Shard::sorted_topk(const ss_bm25_query& q, const ResultSort* sorts, size_t n_sorts, size_t k, std::vector<ss_facet_filter> filters,
                        std::vector<Result>* out, uint64_t* total, bool* have_total) {
   if (k == 0) return SS_OK;
@@ -632,6 +650,45 @@ ResultObject Shard::search_vector_shard(const float* query_vector, size_t length
                                         const AnnMode& ann_mode, const std::vector<uint16_t>& field_filter) {
   if (!query_vector) return ResultObject();
   return std::move(search_vector_batch(query_vector, 1, length, similarity_threshold, ann_mode, field_filter)[0]);
+}
+
+ResultObject Index::search_lexical_sorted(const std::vector<uint32_t>& query_terms, QueryType query_type_default, size_t offset, size_t length,
+                                          const std::vector<ResultSort>& result_sort, const std::vector<ss_facet_filter>& facet_filter,
+                                          const std::vector<uint32_t>& not_terms) {
+  ResultObject ro;
+  const size_t S = shards_.size();
+  if (S == 0 || result_sort.empty()) { ro.last_error = SS_EINVAL; return ro; }
+  struct Row { std::vector<uint64_t> keys; Result r; };
+  std::vector<Row> rows;
+  for (size_t i = 0; i < S; i++) {
+    Shard& sh = *shards_[i];
+    ResultObject part = sh.search_lexical_shard(query_terms, query_type_default, 0, offset + length, ResultType::TopkCount, facet_filter,
+                                                not_terms, {}, result_sort);
+    if (part.last_error != SS_OK) { ro.last_error = part.last_error; continue; }  // a failing shard degrades to empty
+    ro.result_count_total += part.result_count_total;
+    std::vector<uint32_t> docs(part.results.size());
+    for (size_t j = 0; j < docs.size(); j++) docs[j] = (uint32_t)part.results[j].doc_id;
+    std::vector<std::vector<uint64_t>> keys(result_sort.size());
+    bool ok = true;
+    for (size_t f = 0; f < result_sort.size() && ok; f++) ok = sh.sort_keys(docs, result_sort[f], &keys[f]) == SS_OK;
+    if (!ok) { ro.last_error = SS_EDEVICE; continue; }
+    for (size_t j = 0; j < docs.size(); j++) {
+      Row row;
+      for (size_t f = 0; f < result_sort.size(); f++) row.keys.push_back(keys[f][j]);
+      row.r = part.results[j];
+      row.r.doc_id = row.r.doc_id * S + sh.shard_id();  // search.rs:1671
+      rows.push_back(std::move(row));
+    }
+  }
+  std::sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) {
+    for (size_t f = 0; f < a.keys.size(); f++)
+      if (a.keys[f] != b.keys[f]) return a.keys[f] > b.keys[f];
+    if (a.r.score != b.r.score) return a.r.score > b.r.score;
+    return a.r.doc_id < b.r.doc_id;
+  });
+  for (size_t j = offset; j < rows.size() && j < offset + length; j++) ro.results.push_back(rows[j].r);
+  ro.result_count = ro.results.size();
+  return ro;
 }
 
 // ------------------------------------------------------------------ Index::search

@@ -149,6 +149,9 @@ class Shard {
   // query_facets of one query (facet_count, add_result.rs:484-640): counts [n_buckets + 1], the last slot = outside the buckets.
   // String facets: n_buckets ids (bounds empty); numeric facets: the ranges' ascending lower bounds as the value's bits;
   // Point facets (facet_type SS_FACET_POINT): base + the lower bounds of the distance ranges as f64 bits.
+  // order keys of docs under one sort field: larger = better (the facet's stored value mapped to an unsigned integer that orders
+  // like it, complemented for an ascending sort; Point facets: by simplified_distance to the field's base)
+  int sort_keys(const std::vector<uint32_t>& doc_ids, const ResultSort& field, std::vector<uint64_t>* keys);
   int facet_count(const ss_bm25_query& query, uint32_t facet_offset, uint32_t facet_type, uint32_t n_buckets,
                   const std::vector<uint64_t>& range_lower_bounds, std::vector<uint64_t>* counts, uint64_t* total,
                   const std::vector<ss_facet_filter>& facet_filter = {}, const ss_facet_point* base = nullptr);
@@ -207,6 +210,13 @@ class Index {
   std::vector<ResultObject> search_lexical_batch(const std::vector<std::vector<uint32_t>>& query_terms, QueryType query_type_default,
                                                  size_t k, ResultType result_type);
   Shard& shard(size_t i) { return *shards_[i]; }
+  // search() for SearchMode::Lexical with result_sort: every shard returns its best offset + length under the sort
+  // (Shard::search_lexical_shard with result_sort), the lists are merged under the same order across shards -- the facet
+  // values of the two docs, each read from its own shard, then the score (result_ordering_root, min_heap.rs:56-300;
+  // search.rs:2088) --, then offset / length.  Global ids, totals summed.
+  ResultObject search_lexical_sorted(const std::vector<uint32_t>& query_terms, QueryType query_type_default, size_t offset, size_t length,
+                                     const std::vector<ResultSort>& result_sort, const std::vector<ss_facet_filter>& facet_filter = {},
+                                     const std::vector<uint32_t>& not_terms = {});
 
   // <IndexArc as Search>::search for this path.  query_terms: resolved term ids (empty = no lexical part);
   // query_vector: dim floats or nullptr; Cosine with external inference -> normalised here when normalize_query.

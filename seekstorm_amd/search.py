@@ -1008,11 +1008,37 @@ class Index:
     def search(self, query_terms: Optional[Sequence[int]] = None, query_vector=None,
                query_type_default=QueryType.Union, search_mode=SearchMode.Lexical, offset=0, length=10,
                result_type=ResultType.TopkCount, similarity_threshold=None, normalize_query=True,
-               strict=False, not_terms=(), field_filter=None, facet_filter=None, ann_mode=None) -> ResultObject:
+               strict=False, not_terms=(), field_filter=None, facet_filter=None, ann_mode=None, result_sort=None) -> ResultObject:
         """<IndexArc as Search>::search (search.rs:1134-1150): field_filter applies to both sides (lexical: several indexed
-        fields; vector: records of the listed fields), facet_filter to the lexical side, ann_mode to the vector side"""
+        fields; vector: records of the listed fields), facet_filter to the lexical side, ann_mode to the vector side.
+        result_sort (SearchMode.Lexical; see Shard.search_lexical_sorted): every shard returns its best offset + length under
+        the sort, the lists are merged under the same order across shards -- the facet values of the two docs, each read from its
+        own shard, then the score (result_ordering_root, min_heap.rs:56-300; search.rs:2088)"""
         S = self.shard_number
         ro = ResultObject()
+        if result_sort:
+            if search_mode != SearchMode.Lexical or not query_terms:
+                raise ValueError("result_sort applies to lexical searches")
+            rows = []
+            for sh in self.shards:
+                q = sh.make_queries([list(query_terms)], query_type_default, [list(not_terms)],
+                                    field_filter=field_filter if sh.lexical_field_count > 1 else None)
+                d, sc, tot = sh.search_lexical_sorted(q, list(result_sort), offset + length, facet_filter)
+                ro.result_count_total += tot
+                keys = []
+                for sf in result_sort:
+                    if sf[1] == "point":
+                        vals, ty = sh.facet_point_distances(d, sf[0], sf[3], "sortkey").view(np.uint64), "f64"
+                    else:
+                        vals, ty = sh.facet_values(d, sf[0], sf[1]), sf[1]
+                    keys.append([Shard._facet_order_key(x, ty, sf[2]) for x in vals])
+                for i in range(len(d)):
+                    rows.append((tuple(-kk[i] for kk in keys), -float(sc[i]), int(d[i]) * S + sh.shard_id))
+            rows.sort()
+            if result_type != ResultType.Count:
+                ro.results = [Result(g, -ns, ResultSource.Lexical) for _, ns, g in rows[offset:offset + length]]
+            ro.result_count = len(ro.results)
+            return ro
         want_lex = search_mode in (SearchMode.Lexical, SearchMode.Hybrid) and query_terms
         want_vec = search_mode in (SearchMode.Vector, SearchMode.Hybrid) and query_vector is not None
         if want_vec and normalize_query:

@@ -1314,3 +1314,47 @@ def test_result_sort_by_a_string_facet(S, O, lex):
                 if second:
                     assert np.array_equal(v["h"][doc], v["h"][ad[order]])
                 assert np.allclose(score, as_[order], rtol=1e-4)
+
+
+def test_index_two_shards_result_sort(S, O):
+    """Index.search with result_sort over two shards (result_ordering_root, min_heap.rs:56-300): every shard's best under the
+    sort, merged under the same order with each doc's facet values read from its own shard -- against the same sort on ONE
+    shard holding the whole corpus (sort keys without ties decide the order alone: shard-local idf changes scores, not it)."""
+    n_docs, S_n = 60_000, 2
+    voc = [3000, 3600, 4000]
+    dl = O.lex_doclen(n_docs)
+    offs, docs, tfs = O.lex_corpus(n_docs, voc)
+    rng = np.random.default_rng(3)
+    rec = np.dtype([("u", "<u4"), ("g", "<f8"), ("loc", "<u8")])
+    v = np.zeros(n_docs, rec)
+    v["u"] = rng.permutation(n_docs); v["g"] = rng.standard_normal(n_docs)
+    v["loc"] = O.morton_encode(rng.random(n_docs) * 50 + 10, rng.random(n_docs) * 60 + 5)
+    raw = v.view(np.uint8).reshape(n_docs, rec.itemsize)
+    whole = S.Shard(0)
+    whole.upload_lexical(n_docs, dl, offs, docs, tfs)
+    whole.upload_facets(raw)
+    shards = []
+    for sid in range(S_n):  # doc g -> shard g % S, local id g // S (index.rs:5284)
+        sel = np.arange(sid, n_docs, S_n)
+        o2, d2, t2 = [0], [], []
+        for t in range(len(voc)):
+            d = docs[int(offs[t]):int(offs[t + 1])]
+            f = tfs[int(offs[t]):int(offs[t + 1])]
+            m = (d % S_n) == sid
+            d2.append(d[m] // S_n); t2.append(f[m]); o2.append(o2[-1] + int(m.sum()))
+        sh = S.Shard(0, shard_id=sid)
+        sh.upload_lexical(len(sel), dl[sel], np.asarray(o2, np.uint64), np.concatenate(d2).astype(np.uint32), np.concatenate(t2))
+        sh.upload_facets(np.ascontiguousarray(raw[sel]))
+        shards.append(sh)
+    idx = S.Index(shards)
+    base = (38.9, 30.2)
+    for terms, qt in (([0, 1, 2], S.QueryType.Union), ([0, 1], S.QueryType.Intersection)):
+        q = whole.make_queries([terms], qt)
+        for sort in ([(0, "u32", True)], [(4, "f64", False)], [(12, "point", False, base)]):
+            for off_, length, flt in ((0, 25, None), (7, 10, [(0, "u32", 5000, 50000)])):
+                wd, ws, wtot = whole.search_lexical_sorted(q, sort, off_ + length, facet_filter=flt)
+                ro = idx.search(terms, None, qt, S.SearchMode.Lexical, off_, length, strict=True, facet_filter=flt, result_sort=sort)
+                assert ro.result_count_total == wtot
+                assert [r.doc_id for r in ro.results] == [int(x) for x in wd[off_:off_ + length]], (terms, sort, off_, length)
+    for sh in shards + [whole]:
+        sh.close()

@@ -48,6 +48,8 @@ def H():
     L.ssh_search_lexical_shard_ex.argtypes = [C.c_void_p, C.c_int, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                               C.c_uint32, C.c_void_p, u32p, C.c_uint32, C.POINTER(C.c_uint16), C.c_uint32, C.c_void_p,
                                               C.c_uint32, C.c_uint32, u64p, f32p, u64p]
+    L.ssh_index_search_sorted.argtypes = [C.c_void_p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                          C.c_uint32, C.c_uint32, u64p, f32p, u64p]
     L.ssh_upload_lexical_fields.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, u8p, f32p, C.c_uint32, u64p, u32p, u8p, u16p]
     L.ssh_facet_count.argtypes = [C.c_void_p, C.c_int, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u64p, C.c_uint32,
                                   C.c_void_p, C.c_uint32, C.c_void_p, u64p, u64p]
@@ -590,3 +592,64 @@ def test_cpp_shard_union_under_a_field_filter(H):
     finally:
         H.ssh_index_destroy(ix)
         psh.close()
+
+
+@pytest.mark.gpu
+def test_cpp_index_sorted_search_over_two_shards(H):
+    """Index::search_lexical_sorted (result_ordering_root, min_heap.rs:56-300: the shards' sorted lists merged under the same
+    order, each doc's facet values read from its own shard) against the Python mirror's Index.search(result_sort=...) on the
+    same two shards' contents: numeric and Point sort fields, a facet filter, offset / length"""
+    from oracle import oracle as O
+    import seekstorm_amd as S
+    from seekstorm_amd import _native as N
+    n_docs, S_n = 50_000, 2
+    voc = [3000, 3600, 4000]
+    dl = O.lex_doclen(n_docs)
+    offs, docs, tfs = O.lex_corpus(n_docs, voc)
+    rng = np.random.default_rng(8)
+    rec = np.dtype([("u", "<u4"), ("a", "u1"), ("loc", "<u8")])
+    v = np.zeros(n_docs, rec)
+    v["u"] = rng.permutation(n_docs); v["a"] = rng.integers(0, 5, n_docs)
+    v["loc"] = O.morton_encode(rng.random(n_docs) * 50 + 10, rng.random(n_docs) * 60 + 5)
+    raw = v.view(np.uint8).reshape(n_docs, rec.itemsize)
+    ix = H.ssh_index_create(S_n, None)
+    pshards = []
+    try:
+        for sid in range(S_n):
+            sel = np.arange(sid, n_docs, S_n)
+            o2, d2, t2 = [0], [], []
+            for t in range(len(voc)):
+                d = docs[int(offs[t]):int(offs[t + 1])]
+                f = tfs[int(offs[t]):int(offs[t + 1])]
+                m = (d % S_n) == sid
+                d2.append(d[m] // S_n); t2.append(f[m]); o2.append(o2[-1] + int(m.sum()))
+            o2 = np.asarray(o2, np.uint64); d2 = np.concatenate(d2).astype(np.uint32); t2 = np.concatenate(t2)
+            dls = np.ascontiguousarray(dl[sel]); rs_ = np.ascontiguousarray(raw[sel])
+            assert H.ssh_upload_lexical(ix, sid, len(sel), P(dls, u8p), len(voc), P(o2, u64p), P(d2, u32p), P(t2, u16p)) == 0
+            assert H.ssh_upload_facets(ix, sid, len(sel), rec.itemsize, rs_.ctypes.data) == 0
+            sh = S.Shard(0, shard_id=sid)
+            sh.upload_lexical(len(sel), dls, o2, d2, t2)
+            sh.upload_facets(rs_)
+            pshards.append(sh)
+        pidx = S.Index(pshards)
+        base = (38.9, 30.2)
+        for terms, qt in (([0, 1, 2], 1), ([0, 1], 0)):
+            for sorts in ([(0, "u32", True)], [(4, "u8", False), (0, "u32", False)], [(5, "point", False, base)]):
+                for off_, length, flt in ((0, 20, None), (6, 12, [(0, "u32", 4000, 45000)])):
+                    ro = pidx.search(terms, None, S.QueryType(qt), S.SearchMode.Lexical, off_, length, strict=True, facet_filter=flt, result_sort=sorts)
+                    sarr = (_SortC * len(sorts))()
+                    for i, so in enumerate(sorts):
+                        sarr[i].facet_offset, sarr[i].facet_type, sarr[i].descending = so[0], N.FACET_TYPES[so[1]], 1 if so[2] else 0
+                        if so[1] == "point":
+                            sarr[i].base[0], sarr[i].base[1] = so[3]
+                    farr, nf = S.Shard.facet_filters(flt) if flt else (None, 0)
+                    t = np.ascontiguousarray(terms, np.uint32)
+                    doc = np.zeros(length + 1, np.uint64); sc = np.zeros(length + 1, np.float32); meta = np.zeros(4, np.uint64)
+                    n = H.ssh_index_search_sorted(ix, P(t, u32p), len(t), qt, off_, length, nf, None if farr is None else C.cast(farr, C.c_void_p),
+                                                  C.cast(sarr, C.c_void_p), len(sorts), length + 1, P(doc, u64p), P(sc, f32p), P(meta, u64p))
+                    assert int(meta[3]) == 0 and int(meta[1]) == ro.result_count_total
+                    assert n == ro.result_count and list(doc[:n]) == [r.doc_id for r in ro.results], (terms, sorts, off_, length)
+    finally:
+        H.ssh_index_destroy(ix)
+        for sh in pshards:
+            sh.close()
