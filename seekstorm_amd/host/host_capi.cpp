@@ -131,6 +131,23 @@ int ssh_search_lexical_shard_ex(ssh_index* ix, int shard, const uint32_t* terms,
   ResultObject ro = ix->shards[shard]->search_lexical_shard(t, (QueryType)query_type, offset, length, (ResultType)result_type, f, nt, ff, rs);
   return write_out(ro, cap, out_doc, out_score, nullptr, nullptr, nullptr, out_meta);
 }
+// string_facet_rank_column: strings given as one NUL-separated buffer; out [n_docs][record_size + 4]
+uint32_t ssh_string_rank_column(const uint8_t* records, uint64_t n_docs, uint32_t record_size, uint32_t facet_offset, uint32_t facet_type,
+                                const char* strings, uint64_t strings_len, uint32_t n_strings, uint8_t* out) {
+  std::vector<std::string> v;
+  const char* p = strings;
+  const char* end = strings + strings_len;
+  for (uint32_t i = 0; i < n_strings && p <= end; i++) {
+    const char* q = (const char*)memchr(p, 0, (size_t)(end - p));
+    if (!q) q = end;
+    v.emplace_back(p, q);
+    p = q + 1;
+  }
+  uint32_t off = 0;
+  std::vector<uint8_t> r = string_facet_rank_column(records, n_docs, record_size, facet_offset, facet_type, v, &off);
+  std::memcpy(out, r.data(), r.size());
+  return off;
+}
 // Index::search_lexical_sorted over all shards of the index
 int ssh_index_search_sorted(ssh_index* ix, const uint32_t* terms, uint32_t n_terms, uint32_t query_type, uint32_t offset, uint32_t length,
                             uint32_t n_filters, const ss_facet_filter* filters, const ssh_result_sort* sorts, uint32_t n_sorts, uint32_t cap,

@@ -2,6 +2,7 @@
 #include "seekstorm_host.hpp"
 
 #include <algorithm>
+#include <string>
 #include <limits>
 #include <unordered_map>
 #include <chrono>
@@ -391,6 +392,29 @@ std::vector<ResultObject> Shard::search_vector_batch(const float* query_vectors,
       ro.observed_cluster_count = ncl[q];  // vector.rs:1394
     }
   }
+  return out;
+}
+
+std::vector<uint8_t> string_facet_rank_column(const uint8_t* records, uint64_t n_docs, uint32_t record_size, uint32_t facet_offset,
+                                              uint32_t facet_type, const std::vector<std::string>& strings, uint32_t* rank_offset) {
+  const uint32_t width = facet_type == SS_FACET_STRING16 ? 2u : 4u;
+  std::vector<std::string> order(strings);
+  std::sort(order.begin(), order.end());  // std::string compares bytes as unsigned chars: Rust's String order
+  order.erase(std::unique(order.begin(), order.end()), order.end());
+  std::vector<uint32_t> rank(strings.size());
+  for (size_t i = 0; i < strings.size(); i++)
+    rank[i] = (uint32_t)(std::lower_bound(order.begin(), order.end(), strings[i]) - order.begin());
+  std::vector<uint8_t> out((size_t)n_docs * (record_size + 4u));
+  for (uint64_t d = 0; d < n_docs; d++) {
+    const uint8_t* r = records + d * record_size;
+    uint32_t id = 0;
+    for (uint32_t b = 0; b < width; b++) id |= (uint32_t)r[facet_offset + b] << (8u * b);
+    const uint32_t rk = rank.empty() ? 0u : rank[std::min<size_t>(id, rank.size() - 1)];
+    uint8_t* o = out.data() + d * (record_size + 4u);
+    std::memcpy(o, r, record_size);
+    for (uint32_t b = 0; b < 4; b++) o[record_size + b] = (uint8_t)(rk >> (8u * b));
+  }
+  if (rank_offset) *rank_offset = record_size;
   return out;
 }
 

@@ -24,6 +24,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <string>
 #include <vector>
 
 #include "../../include/seekstorm_hip.h"
@@ -86,6 +87,13 @@ struct ResultSort {
   bool descending = false;
   double base[2] = {0.0, 0.0};
 };
+// Result sort by a String16 / String32 facet (min_heap.rs:860-897, 939-976: the STRINGS of the two docs' value ids are compared,
+// Rust String order = byte-wise UTF-8).  The device sorts numbers: append one derived u32 column to the facet.bin records before
+// upload_facets -- rank[id] of the id's string in that order, equal strings sharing a rank -- and sort by it as SS_FACET_U32.
+// strings[id] = the facet value of id (facet.json).  Returns the records with the column appended ([n_docs][record_size + 4]);
+// *rank_offset = the column's offset.
+std::vector<uint8_t> string_facet_rank_column(const uint8_t* records, uint64_t n_docs, uint32_t record_size, uint32_t facet_offset,
+                                              uint32_t facet_type, const std::vector<std::string>& strings, uint32_t* rank_offset);
 // FacetFilter::Point (search.rs:852-859) as an ss_facet_filter: the distance to base inside [lo, hi), unit SS_POINT_KM / _MILES
 ss_facet_filter point_facet_filter(uint32_t facet_offset, const double base[2], double lo, double hi, uint32_t unit, uint32_t flags = 0);
 

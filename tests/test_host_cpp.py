@@ -653,3 +653,24 @@ def test_cpp_index_sorted_search_over_two_shards(H):
         H.ssh_index_destroy(ix)
         for sh in pshards:
             sh.close()
+
+
+def test_cpp_string_facet_rank_column_equals_the_python_mirror(H):
+    """string_facet_rank_column (host logic, no GPU): ranks by byte-wise UTF-8 order, equal strings share a rank, the column is
+    appended little-endian -- the C++ mirror against the Python mirror, String16 and String32"""
+    import seekstorm_amd as S
+    from seekstorm_amd import _native as N
+    H.ssh_string_rank_column.restype = C.c_uint32
+    H.ssh_string_rank_column.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint64, C.c_uint32, C.c_void_p]
+    words = ["zeta", "alpha", "Alpha", "beta", "\u00e9clair", "eclair", "omega", "beta", "a", "", "zz", "\u4e2d\u6587", "alpha ", "b", "B", "beta"]
+    rng = np.random.default_rng(2)
+    for ty, dt, off in (("string16", "<u2", 3), ("string32", "<u4", 1)):
+        rec = np.dtype([("pad", "u1", (off,)), ("cat", dt), ("x", "<u2")])
+        v = np.zeros(5000, rec)
+        v["cat"] = rng.integers(0, len(words), len(v)); v["x"] = rng.integers(0, 1000, len(v))
+        raw = np.ascontiguousarray(v.view(np.uint8).reshape(len(v), rec.itemsize))
+        want, woff = S.Shard.string_facet_rank_column(raw, off, ty, words)
+        blob = b"\0".join(w.encode("utf-8") for w in words) + b"\0"
+        out = np.zeros((len(v), rec.itemsize + 4), np.uint8)
+        got_off = H.ssh_string_rank_column(raw.ctypes.data, len(v), rec.itemsize, off, N.FACET_TYPES[ty], blob, len(blob), len(words), out.ctypes.data)
+        assert got_off == woff == rec.itemsize and np.array_equal(out, want)
