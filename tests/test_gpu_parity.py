@@ -960,6 +960,36 @@ def test_bm25f_boosts_too_far_apart_for_merged_lists(S, O):
     sh.close()
 
 
+def test_bm25f_merged_lists_with_rationed_probe_rows(S, O):
+    """Several fields + a probe budget below the number of lists: rows go to the longest lists first -- the merged lists --, so
+    queries without a field filter stay on the pruned strategy; a field-filtered intersection reads (term, field) lists, of which
+    the shorter ones get pool rows on demand or leave the query to the scan kernels.  Every answer equals the unrationed
+    shard's, bit for bit."""
+    n_docs, n_fields = 150_000, 3
+    dfs = [int(150_000 * 0.2 / (1 + 0.5 * i)) for i in range(12)]   # 12 terms x (3 fields + merged) = 48 lists
+    dl, offs, docs, fields, tfs = _fields_corpus(O, n_docs, n_fields, dfs, 5)
+    boost = [2.0, 1.0, 0.5]
+    full, part = S.Shard(0), S.Shard(0)
+    full.upload_lexical_fields(n_docs, dl, boost, offs, docs, fields, tfs)
+    n_sub = (n_docs + 4095) // 4096
+    part.set_probe_budget((40 + 1) * n_sub * 64 * 12)   # 40 rows for 48 lists: 30 fixed + a pool of 10
+    part.upload_lexical_fields(n_docs, dl, boost, offs, docs, fields, tfs)
+    rng = np.random.default_rng(9)
+    for rnd in range(3):
+        tl = [[int(x) for x in rng.choice(12, int(rng.integers(1, 4)), replace=False)] for _ in range(12)]
+        for qt in (S.QueryType.Union, S.QueryType.Intersection):
+            for rt in (S.ResultType.TopkCount, S.ResultType.Topk):
+                a = full.search_lexical_batch(full.make_queries(tl, qt), 10, rt)
+                b = part.search_lexical_batch(part.make_queries(tl, qt), 10, rt)
+                assert all(np.array_equal(x, y) for x, y in zip(a, b)), (rnd, qt, rt)
+        for filt in ([0], [2], [1, 2]):
+            a = full.search_lexical_batch(full.make_queries(tl, S.QueryType.Intersection, field_filter=filt), 10, S.ResultType.TopkCount)
+            b = part.search_lexical_batch(part.make_queries(tl, S.QueryType.Intersection, field_filter=filt), 10, S.ResultType.TopkCount)
+            assert all(np.array_equal(x, y) for x, y in zip(a, b)), (rnd, filt)
+    full.close()
+    part.close()
+
+
 @pytest.mark.parametrize("n_fields", [2, 3])
 def test_bm25f_field_filter(S, O, n_fields):
     """field_filter on an image with several indexed fields (add_result.rs:3124-3136): a doc stays only if every query term
