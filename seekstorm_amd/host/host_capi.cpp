@@ -148,6 +148,16 @@ uint32_t ssh_string_rank_column(const uint8_t* records, uint64_t n_docs, uint32_
   std::memcpy(out, r.data(), r.size());
   return off;
 }
+// Index::search, lexical mode, with the seam's NOT terms and field filter
+int ssh_search_lexical_ex(ssh_index* ix, const uint32_t* terms, uint32_t n_terms, uint32_t query_type, uint32_t offset, uint32_t length,
+                          uint32_t result_type, const uint32_t* not_terms, uint32_t n_not, const uint16_t* field_filter, uint32_t n_ff,
+                          uint32_t cap, uint64_t* out_doc, float* out_score, uint64_t* out_meta) {
+  if (!ix->index) ix->index.reset(new Index(ix->shards));
+  ResultObject ro = ix->index->search(std::vector<uint32_t>(terms, terms + n_terms), nullptr, (QueryType)query_type, SearchMode::Lexical, offset,
+                                      length, (ResultType)result_type, nullptr, true, AnnMode(), {}, {},
+                                      std::vector<uint32_t>(not_terms, not_terms + n_not), std::vector<uint16_t>(field_filter, field_filter + n_ff));
+  return write_out(ro, cap, out_doc, out_score, nullptr, nullptr, nullptr, out_meta);
+}
 // Index::search_lexical_sorted over all shards of the index
 int ssh_index_search_sorted(ssh_index* ix, const uint32_t* terms, uint32_t n_terms, uint32_t query_type, uint32_t offset, uint32_t length,
                             uint32_t n_filters, const ss_facet_filter* filters, const ssh_result_sort* sorts, uint32_t n_sorts, uint32_t cap,

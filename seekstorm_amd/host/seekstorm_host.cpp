@@ -719,13 +719,14 @@ ResultObject Index::search_lexical_sorted(const std::vector<uint32_t>& query_ter
 ResultObject Index::search(const std::vector<uint32_t>& query_terms, const float* query_vector, QueryType query_type_default,
                            SearchMode search_mode, size_t offset, size_t length, ResultType result_type,
                            const float* similarity_threshold, bool normalize_query, const AnnMode& ann_mode,
-                           const std::vector<uint16_t>& vector_field_filter, const std::vector<ss_facet_filter>& facet_filter) {
+                           const std::vector<uint16_t>& vector_field_filter, const std::vector<ss_facet_filter>& facet_filter,
+                           const std::vector<uint32_t>& not_terms, const std::vector<uint16_t>& lexical_field_filter) {
   ResultObject ro;
   const size_t S = shards_.size();
   if (S == 0) return ro;
   const bool want_lex = (search_mode == SearchMode::Lexical || search_mode == SearchMode::Hybrid) && !query_terms.empty();
   const bool want_vec = (search_mode == SearchMode::Vector || search_mode == SearchMode::Hybrid) && query_vector != nullptr;
-  if (!comms_.empty() && want_lex && !want_vec && facet_filter.empty()) {
+  if (!comms_.empty() && want_lex && !want_vec && facet_filter.empty() && not_terms.empty() && lexical_field_filter.empty()) {
     // shards on different GPUs (enable_device_exchange): every shard task searches its shard and the lists are exchanged and
     // merged on the devices over xGMI (ss_bm25_search_sharded) -- offset / length are applied to the merged list, as
     // search.rs:2109-2119 applies them after the gather
@@ -745,7 +746,8 @@ ResultObject Index::search(const std::vector<uint32_t>& query_terms, const float
   std::vector<ResultObject> lex(S), vec(S);
   auto task = [&](size_t i) {
     Shard& sh = *shards_[i];
-    if (want_lex) lex[i] = sh.search_lexical_shard(query_terms, query_type_default, 0, offset + length, result_type, facet_filter);
+    if (want_lex) lex[i] = sh.search_lexical_shard(query_terms, query_type_default, 0, offset + length, result_type, facet_filter, not_terms,
+                                                   lexical_field_filter);
     if (want_vec && qv.size() == sh.dim()) vec[i] = sh.search_vector_shard(qv.data(), offset + length, similarity_threshold, ann_mode, vector_field_filter);
   };
   if (S == 1) {

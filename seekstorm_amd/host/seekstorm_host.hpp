@@ -236,7 +236,8 @@ class Index {
                       SearchMode search_mode, size_t offset, size_t length, ResultType result_type,
                       const float* similarity_threshold = nullptr, bool normalize_query = true,
                       const AnnMode& ann_mode = AnnMode(), const std::vector<uint16_t>& vector_field_filter = {},
-                      const std::vector<ss_facet_filter>& facet_filter = {});
+                      const std::vector<ss_facet_filter>& facet_filter = {}, const std::vector<uint32_t>& not_terms = {},
+                      const std::vector<uint16_t>& lexical_field_filter = {});
 
  private:
   std::vector<std::shared_ptr<Shard>> shards_;

@@ -649,6 +649,17 @@ def test_cpp_index_sorted_search_over_two_shards(H):
                                                   C.cast(sarr, C.c_void_p), len(sorts), length + 1, P(doc, u64p), P(sc, f32p), P(meta, u64p))
                     assert int(meta[3]) == 0 and int(meta[1]) == ro.result_count_total
                     assert n == ro.result_count and list(doc[:n]) == [r.doc_id for r in ro.results], (terms, sorts, off_, length)
+        # Index::search with NOT terms (lexical mode) == the Python mirror's
+        H.ssh_search_lexical_ex.argtypes = [C.c_void_p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p, C.c_uint32,
+                                            C.POINTER(C.c_uint16), C.c_uint32, C.c_uint32, u64p, f32p, u64p]
+        for terms, neg, qt in (([0, 1], [2], 1), ([0, 1], [2], 0), ([2], [0], 1)):
+            ro = pidx.search(terms, None, S.QueryType(qt), S.SearchMode.Lexical, 2, 15, strict=True, not_terms=neg)
+            t = np.ascontiguousarray(terms, np.uint32); nt = np.ascontiguousarray(neg, np.uint32); ff = np.zeros(1, np.uint16)
+            doc = np.zeros(16, np.uint64); sc = np.zeros(16, np.float32); meta = np.zeros(4, np.uint64)
+            n = H.ssh_search_lexical_ex(ix, P(t, u32p), len(t), qt, 2, 15, 2, P(nt, u32p), len(nt), ff.ctypes.data_as(C.POINTER(C.c_uint16)), 0, 16,
+                                        P(doc, u64p), P(sc, f32p), P(meta, u64p))
+            assert int(meta[3]) == 0 and int(meta[1]) == ro.result_count_total and n == ro.result_count
+            assert np.allclose(sc[:n], [r.score for r in ro.results], rtol=1e-6)
     finally:
         H.ssh_index_destroy(ix)
         for sh in pshards:
