@@ -29,7 +29,10 @@
  *   - unused result slots hold doc id SS_NO_DOC and score 0;
  *   - per-shard request size is offset+length with offset 0 (search.rs:1658-1659): `k` below;
  *   - thread-safe: the host side of concurrent calls on one handle is serialised (a mutex around validation and launch
- *     queuing); the DEVICE side of the *_dev searches is not -- BM25 and vector (AnnMode::All) searches queued on different
+ *     queuing); concurrent SMALL host-pointer searches (the reference's calling pattern: one query per runtime worker,
+ *     search.rs:1637-1743) do not queue up one behind the other on that mutex but are COALESCED into device batches
+ *     (ss_shard_set_coalescing below; on by default); the DEVICE side of the *_dev searches is not serialised -- BM25 and
+ *     vector (AnnMode::All) searches queued on different
  *     streams of one shard run concurrently, each stream with its own workspace (searches sharing a stream run in order).
  *     The ANN modes and the facet-filtered BM25 search keep one workspace per shard: queue those on one stream per shard.
  *     An image upload / rebuild must not race with searches still queued on foreign streams.  Destroy must not race.
@@ -42,7 +45,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 2
+#define SS_ABI_VERSION 3
 #define SS_NO_DOC 0xFFFFFFFFu
 #define SS_MAX_QUERY_TERMS 10 /* union_docid_3 handles <= 10 terms, union.rs:1308 */
 #define SS_MAX_K 1024
@@ -54,7 +57,8 @@ enum {
   SS_ENOMEM = -2,   /* device or host allocation failed */
   SS_EDEVICE = -3,  /* HIP runtime error (no device, launch failure, ...) */
   SS_ENOTSUP = -4,  /* valid request outside the implemented scope */
-  SS_ESTATE = -5    /* image not uploaded yet */
+  SS_ESTATE = -5,   /* image not uploaded yet */
+  SS_EPEER = -6     /* a collective call (ss_*_search_sharded) failed on ANOTHER rank: every rank returns an error, none blocks */
 };
 
 /* QueryType (search.rs:59): the two set operations and Phrase (an intersection whose docs must carry the words at
@@ -73,6 +77,20 @@ int ss_abi_version(void);
 const char* ss_strerror(int code);
 int ss_device_count(int* out);
 int ss_shard_create(int device, ss_shard** out);
+/* Coalescing of concurrent callers (the reference has no batched search entry point: Search::search takes one query, and many
+ * tokio workers call it at once holding only the shard's read lock -- search.rs:1637-1743).  While one batch of a
+ * shard runs on the device, the plain host-pointer searches that arrive (ss_bm25_search / ss_bm25_search_filtered without
+ * filters, ss_vec_search, ss_vec_search_i8; at most SS_COALESCE_MAX_REQUEST queries per call, same k / result type /
+ * threshold) wait in a queue; the first of them becomes the leader of the next batch, runs ALL queued requests as one device
+ * batch on behalf of their callers and hands every caller its own rows.  A lone caller runs at once (nothing is ever delayed
+ * to wait for company unless max_wait_us > 0); answers are those of separate calls, bit for bit (queries of a batch are
+ * independent); a request that makes its batch fail (an invalid query) is re-run alone so that only its own caller sees the
+ * error.  max_lexical_batch / max_vector_batch: queries per merged batch (0 = coalescing off for that kind; defaults 1024
+ * and SS_VEC_BATCH).  ss_shard_coalescing_stats: batches run and queries served through the coalescer so far. */
+#define SS_COALESCE_MAX_REQUEST 64
+int ss_shard_set_coalescing(ss_shard* s, uint32_t max_lexical_batch, uint32_t max_vector_batch, uint32_t max_wait_us);
+int ss_shard_coalescing_stats(ss_shard* s, uint64_t* lexical_batches, uint64_t* lexical_queries, uint64_t* vector_batches,
+                              uint64_t* vector_queries);
 int ss_shard_destroy(ss_shard* s);
 /* block until all work queued on the shard's stream is done */
 int ss_shard_sync(ss_shard* s);
@@ -508,12 +526,31 @@ int ss_topk_allgather_merge(ss_comm* c, uint32_t n_queries, uint32_t k, const ui
                             const uint32_t* d_count, uint64_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, void* stream);
 /* One shard's part of <IndexArc as Search>::search when the shards live on different GPUs (search.rs:1637-1743 per-shard
  * task, 1669-1673 global ids, 1875-1940 gather, 1884-1921 totals summed, 2098-2119 sort / truncate): searches shard `s`
- * (host queries, as ss_bm25_search), exchanges through `c` -- one all-gather of the lists, one all-reduce of the totals --
- * and hands EVERY rank the merged answer: out_doc [n_queries][k] GLOBAL ids (local * n_ranks + rank; UINT64_MAX = unused),
+ * (host queries, as ss_bm25_search), exchanges through `c` -- ONE all-gather: lists, totals and a status word --
+ * (the totals ride in the same gather) and hands EVERY rank the merged answer: out_doc [n_queries][k] GLOBAL ids (local * n_ranks + rank; UINT64_MAX = unused),
  * out_score, out_count, out_total (sum over the shards).  Collective over the communicator: every rank calls it with the
  * same n_queries / k / result_type (each with its own shard's idf in the queries).  c's device must be s's. */
 int ss_bm25_search_sharded(ss_shard* s, ss_comm* c, uint32_t n_queries, const ss_bm25_query* queries, uint32_t k,
                            uint32_t result_type, uint64_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total);
+
+/* The vector and the hybrid shard task of the same search (search.rs:1680-1689, 1723-1732), same conventions and the same
+ * single all-gather: ss_vec_search_sharded = this shard's AnnMode::All f32 scan (host queries [n_queries][dim], n_queries <=
+ * SS_VEC_BATCH) + merged top-k on every rank.  ss_hybrid_search_sharded = SearchMode::Hybrid: both shard tasks at
+ * k = offset + length, both lists in the one all-gather, the two cross-shard concatenations sorted, RRF over them (ranks run
+ * over the whole concatenation, search.rs:1962-2035), sort / offset / length (2098-2119); out_* [n_queries][length] with
+ * out_source SS_SRC_* (may be NULL); out_total = sum over the shards of max(lexical, vector) totals (1919-1921).
+ * result_type: SS_RT_TOPK or SS_RT_TOPKCOUNT (the lexical task's).  n_ranks * k * 2 <= 4096.
+ * Every ss_*_search_sharded call is a collective in which a rank takes part EVEN IF its own search failed (with empty lists and
+ * a status word): that rank returns its own error, every other rank SS_EPEER -- no rank is left blocking in the exchange. */
+int ss_vec_search_sharded(ss_shard* s, ss_comm* c, uint32_t n_queries, const float* queries, uint32_t k, float threshold_raw,
+                          uint64_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total);
+int ss_hybrid_search_sharded(ss_shard* s, ss_comm* c, uint32_t n_queries, const ss_bm25_query* queries, uint32_t result_type,
+                             const float* query_vectors, float threshold_raw, uint32_t k, uint32_t offset, uint32_t length,
+                             uint64_t* out_doc, float* out_score, uint8_t* out_source, uint32_t* out_count, uint64_t* out_total);
+/* time of the collective itself: when on, every all-gather of the ss_*_search_sharded calls is bracketed with HIP events on
+ * the shard's stream; read = (collectives, their summed microseconds) */
+int ss_comm_profile(ss_comm* c, int on);
+int ss_comm_profile_read(ss_comm* c, uint64_t* collectives, double* total_us, int reset);
 
 /* Hybrid fusion of a query batch on the device: RRF (k = 0.6, 0-based ranks, search.rs:1962-2035) of the lexical and the
  * vector list of every query, then sort / offset / length (2098-2119) -- ss_merge_results(SS_MODE_HYBRID) for n_queries

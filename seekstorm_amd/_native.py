@@ -166,6 +166,14 @@ SYMBOLS = [
                                          C.c_void_p, C.c_void_p]),
     ("ss_rrf_merge_dev", C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int,
                                    C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("ss_vec_search_sharded", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
+    ("ss_hybrid_search_sharded", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_float, C.c_uint32,
+                                           C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("ss_comm_profile", C.c_int, [C.c_void_p, C.c_int]),
+    ("ss_comm_profile_read", C.c_int, [C.c_void_p, u64p, C.POINTER(C.c_double), C.c_int]),
+    ("ss_shard_set_coalescing", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
+    ("ss_shard_coalescing_stats", C.c_int, [C.c_void_p, u64p, u64p, u64p, u64p]),
     ("ss_profile_enable", C.c_int, [C.c_void_p, C.c_int]),
     ("ss_profile_read", C.c_int, [C.c_void_p, C.c_int, u64p, C.POINTER(C.c_double), C.c_int]),
 ]

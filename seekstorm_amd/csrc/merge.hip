@@ -15,7 +15,7 @@ __device__ __forceinline__ uint32_t mg_f2ord(float f) {
 // nq; one packed gather [S][doc | score | cnt]: (2 k + 1) nq for all three)
 __global__ void __launch_bounds__(256) topk_merge_kernel(uint32_t nq, uint32_t S, uint32_t k, const uint32_t* __restrict__ doc,
                                                         const float* __restrict__ score, const uint32_t* __restrict__ cnt,
-                                                        size_t stride_ds, size_t stride_c,
+                                                        size_t stride_ds, size_t stride_c, uint32_t out_len,
                                                         u64* __restrict__ out_doc, float* __restrict__ out_score,
                                                         uint32_t* __restrict__ out_cnt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -51,8 +51,8 @@ __global__ void __launch_bounds__(256) topk_merge_kernel(uint32_t nq, uint32_t S
   if (threadIdx.x == 0) total = 0;
   __syncthreads();
   uint32_t local = 0;
-  for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
-    u64 key = keys[i];
+  for (uint32_t i = threadIdx.x; i < out_len; i += blockDim.x) {  // out_len = k: the merged top-k; S * k: the whole concatenation, sorted
+    u64 key = i < np ? keys[i] : 0ull;
     u64 gd = ~0ull;
     float sc = 0.f;
     if (key) {
@@ -63,8 +63,8 @@ __global__ void __launch_bounds__(256) topk_merge_kernel(uint32_t nq, uint32_t S
       sc = score[at];
       local++;
     }
-    out_doc[(size_t)q * k + i] = gd;
-    out_score[(size_t)q * k + i] = sc;
+    out_doc[(size_t)q * out_len + i] = gd;
+    out_score[(size_t)q * out_len + i] = sc;
   }
   if (local) atomicAdd(&total, local);
   __syncthreads();
@@ -82,7 +82,7 @@ extern "C" int ss_topk_merge_dev(int device, uint32_t n_queries, uint32_t n_shar
   while (np < n_shards * k) np <<= 1;
   SS_SET_MAX_LDS(topk_merge_kernel, 8192 * 8);
   topk_merge_kernel<<<n_queries, 256, np * sizeof(u64), (hipStream_t)stream>>>(n_queries, n_shards, k, d_doc, d_score, d_count,
-                                                                              (size_t)n_queries * k, (size_t)n_queries,
+                                                                              (size_t)n_queries * k, (size_t)n_queries, k,
                                                                               (u64*)d_out_doc, d_out_score, d_out_count);
   SS_HIP(hipGetLastError());
   return SS_OK;
@@ -101,8 +101,24 @@ extern "C" int ss_topk_merge_dev_packed(int device, uint32_t n_queries, uint32_t
   SS_SET_MAX_LDS(topk_merge_kernel, 8192 * 8);
   const size_t nk = (size_t)n_queries * k, stride = 2 * nk + n_queries;
   topk_merge_kernel<<<n_queries, 256, np * sizeof(u64), (hipStream_t)stream>>>(n_queries, n_shards, k, d_packed, (const float*)(d_packed + nk),
-                                                                              d_packed + 2 * nk, stride, stride, (u64*)d_out_doc,
+                                                                              d_packed + 2 * nk, stride, stride, k, (u64*)d_out_doc,
                                                                               d_out_score, d_out_count);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
+// the same kernel for the sharded searches (comm.hip): lists anywhere inside the gathered buffer, out_len = k or S * k entries
+int ssi_topk_merge_launch(int device, uint32_t nq, uint32_t S, uint32_t k, const uint32_t* d_doc, const float* d_score, const uint32_t* d_count,
+                          size_t stride_ds, size_t stride_c, uint32_t out_len, uint64_t* d_out_doc, float* d_out_score, uint32_t* d_out_count,
+                          hipStream_t st) {
+  if (S == 0 || k == 0 || (uint64_t)S * k > 8192 || out_len == 0 || out_len > S * k) return SS_EINVAL;
+  if (nq == 0) return SS_OK;
+  SS_HIP(hipSetDevice(device));
+  uint32_t np = 64;
+  while (np < S * k) np <<= 1;
+  SS_SET_MAX_LDS(topk_merge_kernel, 8192 * 8);
+  topk_merge_kernel<<<nq, 256, np * sizeof(u64), st>>>(nq, S, k, d_doc, d_score, d_count, stride_ds, stride_c, out_len, (u64*)d_out_doc, d_out_score,
+                                                      d_out_count);
   SS_HIP(hipGetLastError());
   return SS_OK;
 }

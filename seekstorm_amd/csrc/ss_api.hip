@@ -1,7 +1,12 @@
 // C ABI of the MI355X-native SeekStorm query hot path (see include/seekstorm_hip.h for the contract and the
 // reference seams each entry point replaces).  Host-side plumbing only; the kernels live in vec_scan.hip / bm25.hip.
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -48,6 +53,7 @@ const char* ss_strerror(int code) {
     case SS_EDEVICE: return "HIP device/runtime error";
     case SS_ENOTSUP: return "not supported by the MI355X hot path (see DESIGN.md)";
     case SS_ESTATE: return "image not uploaded";
+    case SS_EPEER: return "a collective search failed on another rank";
     default: return "unknown error";
   }
 }
@@ -70,6 +76,8 @@ int ss_shard_create(int device, ss_shard** out) {
   ss_shard* s = new (std::nothrow) ss_shard();
   if (!s) return SS_ENOMEM;
   s->device = device;
+  s->co_lex.max_batch = 1024;
+  s->co_vec.max_batch = SS_VEC_BATCH;
   if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return SS_EDEVICE; }
   *out = s;
   return SS_OK;
@@ -763,15 +771,10 @@ static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_quer
   });
 }
 
-int ss_bm25_search_filtered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k, uint32_t rt, uint32_t n_filters,
-                            const ss_facet_filter* filters, uint32_t* out_doc, float* out_score, uint32_t* out_count,
-                            uint64_t* out_total) {
-  if (!s || !q || !out_count || !out_total) return SS_EINVAL;
-  if (rt > SS_RT_TOPKCOUNT) return SS_EINVAL;
-  if (rt != SS_RT_COUNT && (k == 0 || k > SS_MAX_K || !out_doc || !out_score)) return SS_EINVAL;
-  if (!s->d_post) return SS_ESTATE;
-  if (nq == 0) return SS_OK;
+static int bm25_search_direct(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k, uint32_t rt, uint32_t n_filters,
+                              const ss_facet_filter* filters, uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total) {
   std::lock_guard<std::mutex> g(s->mu);  // before check_queries: it reads the image's host-side tables (an upload replaces them)
+  if (!s->d_post) return SS_ESTATE;
   const uint32_t kk = rt == SS_RT_COUNT ? 0 : k;
   SS_TRY(bm25_search_host_queries(s, nq, q, kk, rt, n_filters, filters));
   if (kk) {
@@ -782,6 +785,188 @@ int ss_bm25_search_filtered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, ui
   SS_HIP(hipMemcpyAsync(out_total, s->d_out_total, (size_t)nq * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
   SS_HIP(hipStreamSynchronize(s->stream));
   return SS_OK;
+}
+
+// ------------------------------------------------------------------ coalescing of concurrent callers (group commit)
+static int vec_search_host(ss_shard* s, uint32_t nq, const void* queries, size_t elem, const float* query_scale, uint32_t k,
+                           float thr, const ss_ann_mode* mode, uint32_t* out_doc, float* out_score, uint32_t* out_count,
+                           uint64_t* out_total, uint32_t* out_clusters, const float* query_norm = nullptr);
+static int vec_search_host_lists(ss_shard* s, uint32_t nq, const void* queries, size_t elem, const float* query_scale, uint32_t k,
+                                 float thr, const ss_ann_mode* mode, uint32_t* h_count, uint32_t** d_ncl_out,
+                                 const float* query_norm = nullptr, bool want_clusters = false, size_t out_slot = 0);
+namespace {
+inline void co_futex_wait(std::atomic<uint32_t>* a, uint32_t expect) { (void)syscall(SYS_futex, (uint32_t*)a, FUTEX_WAIT_PRIVATE, expect, nullptr, nullptr, 0); }
+inline void co_futex_wake(std::atomic<uint32_t>* a) { (void)syscall(SYS_futex, (uint32_t*)a, FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0); }
+// set a request's state (1 = done, 3 = lead) and wake its thread if it went to sleep
+inline void co_signal(ss_co_req* r, uint32_t st) {
+  const uint32_t old = r->state.exchange(st, std::memory_order_acq_rel);
+  if (old & 4u) co_futex_wake(&r->state);
+}
+// wait until the state leaves "pending": a short spin (a batch lasts ~0.1-0.3 ms; a sleeping thread costs its leader a
+// system call and itself a wake-up), then the futex
+inline uint32_t co_wait(ss_co_req* r) {
+  for (int i = 0; i < 4000; i++) {
+    const uint32_t v = r->state.load(std::memory_order_acquire);
+    if (v != 0u) return v;
+    __builtin_ia32_pause();
+  }
+  for (;;) {
+    uint32_t v = 0u;
+    if (r->state.compare_exchange_strong(v, 4u, std::memory_order_acq_rel)) v = 4u;
+    if (v != 4u) return v;  // done / lead arrived before (or instead of) the sleep
+    co_futex_wait(&r->state, 4u);
+    v = r->state.load(std::memory_order_acquire);
+    if (v != 4u) return v;
+  }
+}
+// requests that can share a batch.  k may differ: the batch runs at the largest k and every member keeps its own prefix -- the
+// result order is total (score descending, then doc id ascending), so the top-k' of a query is the head of its top-k.
+inline bool co_compatible(const ss_co_req* a, const ss_co_req* b) {
+  return (a->k == 0) == (b->k == 0) && a->rt == b->rt && a->elem == b->elem && a->thr == b->thr && (a->qscale != nullptr) == (b->qscale != nullptr);
+}
+
+int co_run_lexical_one(ss_shard* s, ss_co_req* r) {
+  return bm25_search_direct(s, r->nq, (const ss_bm25_query*)r->q, r->k, r->rt, 0, nullptr, r->out_doc, r->out_score, r->out_count, r->out_total);
+}
+int co_run_vector_one(ss_shard* s, ss_co_req* r) {
+  return vec_search_host(s, r->nq, r->q, r->elem, r->qscale, r->k, r->thr, nullptr, r->out_doc, r->out_score, r->out_count, r->out_total, nullptr);
+}
+
+// one merged batch: the members' queries back to back, one search, every member's rows copied to its own buffers
+int co_run_batch(ss_shard* s, ss_coalescer& co, bool lexical, const std::vector<ss_co_req*>& batch) {
+  ss_co_req* f = batch[0];
+  uint32_t total = 0;
+  for (ss_co_req* r : batch) total += r->nq;
+  uint32_t kk = 0;
+  for (ss_co_req* r : batch) kk = std::max(kk, r->k);
+  const uint32_t kw = std::max<uint32_t>(kk, 1u);
+  const size_t qbytes = lexical ? sizeof(ss_bm25_query) : (size_t)s->dim * f->elem;
+  co.h_q.resize((size_t)total * qbytes);
+  if (f->qscale) co.h_qscale.resize(total);
+  co.h_doc.resize((size_t)total * kw); co.h_score.resize((size_t)total * kw); co.h_count.resize(total); co.h_total.resize(total);
+  uint32_t at = 0;
+  for (ss_co_req* r : batch) {
+    memcpy(co.h_q.data() + (size_t)at * qbytes, r->q, (size_t)r->nq * qbytes);
+    if (f->qscale) memcpy(co.h_qscale.data() + at, r->qscale, (size_t)r->nq * sizeof(float));
+    at += r->nq;
+  }
+  int rc;
+  if (lexical)
+    rc = bm25_search_direct(s, total, (const ss_bm25_query*)co.h_q.data(), kk, f->rt, 0, nullptr, co.h_doc.data(), co.h_score.data(),
+                            co.h_count.data(), co.h_total.data());
+  else
+    rc = vec_search_host(s, total, co.h_q.data(), f->elem, f->qscale ? co.h_qscale.data() : nullptr, kk, f->thr, nullptr, co.h_doc.data(),
+                         co.h_score.data(), co.h_count.data(), co.h_total.data(), nullptr);
+  if (rc != SS_OK) return rc;
+  at = 0;
+  for (ss_co_req* r : batch) {
+    for (uint32_t i = 0; i < r->nq; i++) {
+      if (r->k) {
+        memcpy(r->out_doc + (size_t)i * r->k, co.h_doc.data() + (size_t)(at + i) * kk, (size_t)r->k * sizeof(uint32_t));
+        memcpy(r->out_score + (size_t)i * r->k, co.h_score.data() + (size_t)(at + i) * kk, (size_t)r->k * sizeof(float));
+      }
+      r->out_count[i] = std::min(co.h_count[at + i], r->k);
+      r->out_total[i] = co.h_total[at + i];
+    }
+    r->rc = SS_OK;
+    at += r->nq;
+  }
+  return SS_OK;
+}
+
+int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
+  bool lead;
+  {
+    std::lock_guard<std::mutex> g(co.mu);
+    lead = !co.leader_active;  // invariant: a non-empty queue always has a leader, or a successor already told to lead
+    if (lead) co.leader_active = true;
+    co.queue.push_back(me);
+  }
+  std::vector<ss_co_req*> batch;
+  for (;;) {
+    if (!lead) {
+      const uint32_t v = co_wait(me);
+      if (v == 1u) return me->rc;
+      me->state.store(0u, std::memory_order_release);  // v == 3: this thread leads the next batch (its request is the queue's front)
+      lead = true;
+    }
+    if (co.max_wait_us) {  // optional: give company a moment to arrive (off by default: a lone caller is never delayed)
+      const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(co.max_wait_us);
+      for (;;) {
+        { std::lock_guard<std::mutex> g(co.mu); uint32_t have = 0; for (ss_co_req* r : co.queue) have += r->nq; if (have >= co.max_batch) break; }
+        if (std::chrono::steady_clock::now() >= until) break;
+        __builtin_ia32_pause();
+      }
+    }
+    batch.clear();
+    {
+      std::lock_guard<std::mutex> g(co.mu);
+      uint32_t total = 0;
+      ss_co_req* f = co.queue.front();  // the leader's own request; with it every queued request that can share its batch
+      for (auto it = co.queue.begin(); it != co.queue.end();) {
+        if (co_compatible(f, *it) && (batch.empty() || total + (*it)->nq <= co.max_batch)) {
+          total += (*it)->nq;
+          batch.push_back(*it);
+          it = co.queue.erase(it);
+        } else {
+          ++it;
+        }
+      }
+      co.batches++;
+      co.queries += total;
+    }
+    if (batch.size() == 1) {
+      batch[0]->rc = lexical ? co_run_lexical_one(s, batch[0]) : co_run_vector_one(s, batch[0]);
+    } else if (co_run_batch(s, co, lexical, batch) != SS_OK) {
+      // somebody's request is at fault (or the device is): every member is re-run alone and gets its own verdict
+      for (ss_co_req* r : batch) r->rc = lexical ? co_run_lexical_one(s, r) : co_run_vector_one(s, r);
+    }
+    ss_co_req* succ = nullptr;
+    {
+      std::lock_guard<std::mutex> g(co.mu);
+      if (co.queue.empty()) co.leader_active = false;
+      else succ = co.queue.front();
+    }
+    if (succ) co_signal(succ, 3u);  // first: the next batch forms while this one's members are being woken
+    bool mine = false;
+    for (ss_co_req* r : batch) {
+      if (r == me) mine = true;
+      else co_signal(r, 1u);
+    }
+    if (mine) return me->rc;
+    lead = false;  // (cannot happen while the leader's request is the front of its own batch; kept for safety)
+  }
+}
+}  // namespace
+
+int ss_shard_set_coalescing(ss_shard* s, uint32_t max_lexical_batch, uint32_t max_vector_batch, uint32_t max_wait_us) {
+  if (!s || max_vector_batch > SS_VEC_BATCH) return SS_EINVAL;
+  { std::lock_guard<std::mutex> g(s->co_lex.mu); s->co_lex.max_batch = max_lexical_batch; s->co_lex.max_wait_us = max_wait_us; }
+  { std::lock_guard<std::mutex> g(s->co_vec.mu); s->co_vec.max_batch = max_vector_batch; s->co_vec.max_wait_us = max_wait_us; }
+  return SS_OK;
+}
+int ss_shard_coalescing_stats(ss_shard* s, uint64_t* lexical_batches, uint64_t* lexical_queries, uint64_t* vector_batches, uint64_t* vector_queries) {
+  if (!s) return SS_EINVAL;
+  { std::lock_guard<std::mutex> g(s->co_lex.mu); if (lexical_batches) *lexical_batches = s->co_lex.batches; if (lexical_queries) *lexical_queries = s->co_lex.queries; }
+  { std::lock_guard<std::mutex> g(s->co_vec.mu); if (vector_batches) *vector_batches = s->co_vec.batches; if (vector_queries) *vector_queries = s->co_vec.queries; }
+  return SS_OK;
+}
+
+int ss_bm25_search_filtered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k, uint32_t rt, uint32_t n_filters,
+                            const ss_facet_filter* filters, uint32_t* out_doc, float* out_score, uint32_t* out_count,
+                            uint64_t* out_total) {
+  if (!s || !q || !out_count || !out_total) return SS_EINVAL;
+  if (rt > SS_RT_TOPKCOUNT) return SS_EINVAL;
+  if (rt != SS_RT_COUNT && (k == 0 || k > SS_MAX_K || !out_doc || !out_score)) return SS_EINVAL;
+  if (!s->d_post) return SS_ESTATE;
+  if (nq == 0) return SS_OK;
+  if (n_filters == 0 && nq <= SS_COALESCE_MAX_REQUEST && s->co_lex.max_batch) {
+    ss_co_req r;
+    r.q = q; r.nq = nq; r.k = rt == SS_RT_COUNT ? 0u : k; r.rt = rt;
+    r.out_doc = out_doc; r.out_score = out_score; r.out_count = out_count; r.out_total = out_total;
+    return co_submit(s, s->co_lex, true, &r);
+  }
+  return bm25_search_direct(s, nq, q, k, rt, n_filters, filters, out_doc, out_score, out_count, out_total);
 }
 
 // One shard's part of <IndexArc as Search>::search over shards on different GPUs (search.rs:1637-1743 + 1875-2119): search
@@ -795,15 +980,62 @@ int ss_bm25_search_sharded(ss_shard* s, ss_comm* c, uint32_t nq, const ss_bm25_q
   if (rt != SS_RT_COUNT && (k == 0 || k > SS_MAX_K || !out_doc || !out_score || !out_count)) return SS_EINVAL;
   int dev = -1, n_ranks = 0;
   SS_TRY(ss_comm_info(c, nullptr, &n_ranks, &dev));
-  if (dev != s->device) return SS_EINVAL;
-  if (!s->d_post) return SS_ESTATE;
+  const uint32_t kk = rt == SS_RT_COUNT ? 0 : k;
+  if ((uint64_t)n_ranks * kk > 8192) return SS_EINVAL;  // the same on every rank: nobody enters the collective
+  if (nq == 0) return SS_OK;
+  // From here on a failure is a matter of THIS shard (image missing, a query its lists cannot serve, an allocation): the rank
+  // still enters the exchange, empty-handed, and every rank returns an error (ssi_comm_exchange) instead of blocking in it.
+  std::lock_guard<std::mutex> g(s->mu);
+  int rc = dev != s->device ? SS_EINVAL : !s->d_post ? SS_ESTATE : SS_OK;
+  if (rc == SS_OK) rc = bm25_search_host_queries(s, nq, q, kk, rt, 0, nullptr);
+  const ss_dev_list L{s->d_out_doc, s->d_out_score, s->d_out_count, kk};
+  return ssi_comm_exchange(c, nq, kk ? 1 : 0, &L, s->d_out_total, nullptr, rc, false, 0, 0, out_doc, out_score, nullptr, out_count, out_total,
+                           s->stream);
+}
+
+// The vector and hybrid shard tasks of the same search (search.rs:1680-1689, 1723-1732; RRF after the gather, 1962-2035):
+// this shard's f32 scan (AnnMode::All; host queries), the same single all-gather, the merged top-k on every rank.
+int ss_vec_search_sharded(ss_shard* s, ss_comm* c, uint32_t nq, const float* queries, uint32_t k, float thr, uint64_t* out_doc,
+                          float* out_score, uint32_t* out_count, uint64_t* out_total) {
+  if (!s || !c || !queries || !out_doc || !out_score || !out_count || !out_total) return SS_EINVAL;
+  if (k == 0 || k > SS_MAX_K || nq > SS_VEC_BATCH) return SS_EINVAL;
+  int dev = -1, n_ranks = 0;
+  SS_TRY(ss_comm_info(c, nullptr, &n_ranks, &dev));
+  if ((uint64_t)n_ranks * k > 8192) return SS_EINVAL;
   if (nq == 0) return SS_OK;
   std::lock_guard<std::mutex> g(s->mu);
-  const uint32_t kk = rt == SS_RT_COUNT ? 0 : k;
-  if ((uint64_t)n_ranks * kk > 8192) return SS_EINVAL;
-  SS_TRY(bm25_search_host_queries(s, nq, q, kk, rt, 0, nullptr));
-  return ssi_comm_exchange_to_host(c, nq, kk, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, out_doc, out_score,
-                                   out_count, out_total, s->stream);
+  int rc = dev != s->device ? SS_EINVAL : !s->d_X ? SS_ESTATE : SS_OK;
+  std::vector<uint32_t> h_count(nq);
+  if (rc == SS_OK) rc = vec_search_host_lists(s, nq, queries, sizeof(float), nullptr, k, thr, nullptr, h_count.data(), nullptr);
+  const ss_dev_list L{s->d_out_doc, s->d_out_score, s->d_out_count, k};
+  return ssi_comm_exchange(c, nq, 1, &L, s->d_out_total, nullptr, rc, false, 0, 0, out_doc, out_score, nullptr, out_count, out_total, s->stream);
+}
+
+// SearchMode::Hybrid over shards on different GPUs: both shard tasks with (offset 0, length k = offset + length), ONE all-gather
+// of both lists, the two cross-shard concatenations sorted, RRF over them and sort / offset / length (search.rs:1962-2035,
+// 2098-2119) on the device; result_count_total = sum over the shards of max(lexical, vector) (1919-1921).
+int ss_hybrid_search_sharded(ss_shard* s, ss_comm* c, uint32_t nq, const ss_bm25_query* q, uint32_t rt, const float* queries, float thr,
+                             uint32_t k, uint32_t offset, uint32_t length, uint64_t* out_doc, float* out_score, uint8_t* out_source,
+                             uint32_t* out_count, uint64_t* out_total) {
+  if (!s || !c || !q || !queries || !out_doc || !out_score || !out_count || !out_total) return SS_EINVAL;
+  if (rt != SS_RT_TOPK && rt != SS_RT_TOPKCOUNT) return SS_EINVAL;
+  if (k == 0 || k > SS_MAX_K || length == 0 || nq > SS_VEC_BATCH) return SS_EINVAL;
+  int dev = -1, n_ranks = 0;
+  SS_TRY(ss_comm_info(c, nullptr, &n_ranks, &dev));
+  if ((uint64_t)n_ranks * k * 2 > 4096) return SS_EINVAL;  // both concatenations live in the fusion kernel's LDS
+  if (nq == 0) return SS_OK;
+  std::lock_guard<std::mutex> g(s->mu);
+  int rc = dev != s->device ? SS_EINVAL : (!s->d_post || !s->d_X) ? SS_ESTATE : SS_OK;
+  // outputs of the two searches side by side: the vector lists behind the lexical ones (reserved before either runs)
+  if (rc == SS_OK && hipSetDevice(s->device) != hipSuccess) rc = SS_EDEVICE;
+  if (rc == SS_OK) rc = ensure_out(s, 2 * (size_t)nq, k);
+  if (rc == SS_OK) rc = bm25_search_host_queries(s, nq, q, k, rt, 0, nullptr);
+  std::vector<uint32_t> h_count(nq);
+  if (rc == SS_OK) rc = vec_search_host_lists(s, nq, queries, sizeof(float), nullptr, k, thr, nullptr, h_count.data(), nullptr, nullptr, false, nq);
+  const ss_dev_list L[2] = {{s->d_out_doc, s->d_out_score, s->d_out_count, k},
+                            {s->d_out_doc + (size_t)nq * k, s->d_out_score + (size_t)nq * k, s->d_out_count + nq, k}};
+  return ssi_comm_exchange(c, nq, 2, L, s->d_out_total, s->d_out_total + nq, rc, true, offset, length, out_doc, out_score, out_source,
+                           out_count, out_total, s->stream);
 }
 
 // Facet counts of ONE query (query_facets / facet_count, add_result.rs:484-640): histogram of a facet over the query's match
@@ -1171,37 +1403,52 @@ int ss_vec_read_rows(ss_shard* s, uint64_t r0, uint64_t n, float* out) {
   return SS_OK;
 }
 
-// host-pointer searches: queries (f32 or i8 rows) and scales are staged in the shard's grow-only buffer, out_clusters
-// (observed_cluster_count, ANN modes) rides behind them
-static int vec_search_host(ss_shard* s, uint32_t nq, const void* queries, size_t elem, const float* query_scale, uint32_t k,
-                           float thr, const ss_ann_mode* mode, uint32_t* out_doc, float* out_score, uint32_t* out_count,
-                           uint64_t* out_total, uint32_t* out_clusters, const float* query_norm = nullptr) {
-  if (nq == 0) return SS_OK;
-  std::lock_guard<std::mutex> g(s->mu);
+// the search up to the device lists (s->d_out_* on s->stream, counts checked on the host: an overflowed batch is re-run in
+// safe mode); caller holds s->mu.  h_count: nq words of host scratch.
+static int vec_search_host_lists(ss_shard* s, uint32_t nq, const void* queries, size_t elem, const float* query_scale, uint32_t k,
+                                 float thr, const ss_ann_mode* mode, uint32_t* h_count, uint32_t** d_ncl_out,
+                                 const float* query_norm, bool want_clusters, size_t out_slot) {
   SS_HIP(hipSetDevice(s->device));
-  SS_TRY(ensure_out(s, nq, k));
+  SS_TRY(ensure_out(s, out_slot + nq, k));  // out_slot: the lists go behind those of `out_slot` earlier queries (hybrid)
+  uint32_t* const o_doc = s->d_out_doc + out_slot * k;
+  float* const o_score = s->d_out_score + out_slot * k;
+  uint32_t* const o_count = s->d_out_count + out_slot;
+  uint64_t* const o_total = s->d_out_total + out_slot;
   const size_t qbytes = ((size_t)nq * s->dim * elem + 15) & ~(size_t)15;
   const size_t sbytes = query_scale ? (size_t)nq * sizeof(float) : 0;
   const size_t nbytes = query_norm ? (size_t)nq * sizeof(float) : 0;
-  SS_TRY(ensure_qstage(s, qbytes + sbytes + nbytes + (out_clusters ? (size_t)nq * sizeof(uint32_t) : 0)));
+  SS_TRY(ensure_qstage(s, qbytes + sbytes + nbytes + (want_clusters ? (size_t)nq * sizeof(uint32_t) : 0)));
   float* d_qs = query_scale ? (float*)((char*)s->d_qstage + qbytes) : nullptr;
   float* d_qn = query_norm ? (float*)((char*)s->d_qstage + qbytes + sbytes) : nullptr;
-  uint32_t* d_ncl = out_clusters ? (uint32_t*)((char*)s->d_qstage + qbytes + sbytes + nbytes) : nullptr;
+  uint32_t* d_ncl = want_clusters ? (uint32_t*)((char*)s->d_qstage + qbytes + sbytes + nbytes) : nullptr;
+  if (d_ncl_out) *d_ncl_out = d_ncl;
   int rc = SS_OK;
   for (int attempt = 0; attempt < 2; attempt++) {
     if (hipMemcpyAsync(s->d_qstage, queries, (size_t)nq * s->dim * elem, hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = SS_EDEVICE; break; }
     if (d_qs && hipMemcpyAsync(d_qs, query_scale, sbytes, hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = SS_EDEVICE; break; }
     if (d_qn && hipMemcpyAsync(d_qn, query_norm, nbytes, hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = SS_EDEVICE; break; }
-    rc = ssi_vec_search(s, nq, s->d_qstage, d_qs, k, thr, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->stream,
+    rc = ssi_vec_search(s, nq, s->d_qstage, d_qs, k, thr, o_doc, o_score, o_count, o_total, s->stream,
                         attempt == 1, mode, d_ncl, d_qn);
     if (rc) break;
-    if (hipMemcpyAsync(out_count, s->d_out_count, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+    if (hipMemcpyAsync(h_count, o_count, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
         hipStreamSynchronize(s->stream) != hipSuccess) { rc = SS_EDEVICE; break; }
     bool ovf = false;
-    for (uint32_t i = 0; i < nq; i++) ovf |= out_count[i] == 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < nq; i++) ovf |= h_count[i] == 0xFFFFFFFFu;
     if (!ovf) break;
     if (attempt == 1) { rc = SS_EDEVICE; break; }  // cannot overflow in safe mode
   }
+  return rc;
+}
+
+// host-pointer searches: queries (f32 or i8 rows) and scales are staged in the shard's grow-only buffer, out_clusters
+// (observed_cluster_count, ANN modes) rides behind them
+static int vec_search_host(ss_shard* s, uint32_t nq, const void* queries, size_t elem, const float* query_scale, uint32_t k,
+                           float thr, const ss_ann_mode* mode, uint32_t* out_doc, float* out_score, uint32_t* out_count,
+                           uint64_t* out_total, uint32_t* out_clusters, const float* query_norm) {
+  if (nq == 0) return SS_OK;
+  std::lock_guard<std::mutex> g(s->mu);
+  uint32_t* d_ncl = nullptr;
+  int rc = vec_search_host_lists(s, nq, queries, elem, query_scale, k, thr, mode, out_count, &d_ncl, query_norm, out_clusters != nullptr);
   if (rc == SS_OK) {
     if (hipMemcpy(out_doc, s->d_out_doc, (size_t)nq * k * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(out_score, s->d_out_score, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
@@ -1229,6 +1476,12 @@ int ss_vec_search_ann(ss_shard* s, uint32_t nq, const float* queries, uint32_t k
   if (!s->d_X) return SS_ESTATE;
   SS_TRY(ann_mode_ok(s, mode));
   mode = ann_effective(mode);
+  if (!mode && nq != 0 && nq <= SS_COALESCE_MAX_REQUEST && s->co_vec.max_batch) {  // AnnMode::All from concurrent callers: one pass serves them
+    ss_co_req r;
+    r.q = queries; r.nq = nq; r.k = k; r.elem = (uint32_t)sizeof(float); r.thr = thr;
+    r.out_doc = out_doc; r.out_score = out_score; r.out_count = out_count; r.out_total = out_total;
+    return co_submit(s, s->co_vec, false, &r);
+  }
   return vec_search_host(s, nq, queries, sizeof(float), nullptr, k, thr, mode, out_doc, out_score, out_count, out_total,
                          mode ? out_clusters : nullptr);
 }
@@ -1401,14 +1654,28 @@ int ss_vec_read_rows_i8(ss_shard* s, uint64_t r0, uint64_t n, int8_t* out) {
   return rc;
 }
 
+// euclidean_i8_quantized (scales present) = max(0, n1 + n2 - 2 dot s1 s2) needs BOTH norms: the reference always carries
+// VectorHeader.norm / QuantizedVector.norm.  Without them the ranking would silently be that of -max(0, -2 dot s1 s2).
+static int vec8_euclid_norms_ok(const ss_shard* s, bool have_qscale, bool have_qnorm) {
+  if (s->vec_similarity != SS_SIM_EUCLIDEAN || (!s->d_row_scale && !have_qscale)) return SS_OK;
+  if (!s->d_row_norm) return SS_ESTATE;  // ss_vec_set_row_norms
+  return have_qnorm ? SS_OK : SS_EINVAL;
+}
 int ss_vec_search_i8_euclid(ss_shard* s, uint32_t nq, const int8_t* queries, const float* query_scale, const float* query_norm,
                             uint32_t k, float thr, const ss_ann_mode* mode, uint32_t* out_doc, float* out_score, uint32_t* out_count,
                             uint64_t* out_total, uint32_t* out_clusters) {
   if (!s || !queries || !out_doc || !out_score || !out_count || !out_total) return SS_EINVAL;
   if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
   if (!s->d_X8) return SS_ESTATE;
+  SS_TRY(vec8_euclid_norms_ok(s, query_scale != nullptr, query_norm != nullptr));
   SS_TRY(ann_mode_ok(s, mode));
   mode = ann_effective(mode);
+  if (!mode && !query_norm && nq != 0 && nq <= SS_COALESCE_MAX_REQUEST && s->co_vec.max_batch) {
+    ss_co_req r;
+    r.q = queries; r.qscale = query_scale; r.nq = nq; r.k = k; r.elem = 1; r.thr = thr;
+    r.out_doc = out_doc; r.out_score = out_score; r.out_count = out_count; r.out_total = out_total;
+    return co_submit(s, s->co_vec, false, &r);
+  }
   return vec_search_host(s, nq, queries, 1, query_scale, k, thr, mode, out_doc, out_score, out_count, out_total,
                          mode ? out_clusters : nullptr, query_norm);
 }
@@ -1434,6 +1701,7 @@ int ss_vec_search_i8_euclid_dev(ss_shard* s, uint32_t nq, const int8_t* d_querie
   if (!s || !d_queries || !d_out_doc || !d_out_score || !d_out_count || !d_out_total) return SS_EINVAL;
   if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
   if (!s->d_X8) return SS_ESTATE;
+  SS_TRY(vec8_euclid_norms_ok(s, d_query_scale != nullptr, d_query_norm != nullptr));
   SS_TRY(ann_mode_ok(s, mode));
   mode = ann_effective(mode);
   std::lock_guard<std::mutex> g(s->mu);

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -124,10 +125,41 @@ struct ss_vec_ws {
   float* d_qaux = nullptr;
 };
 
+// ---- coalescing of concurrent small host-pointer searches (ss_api.hip; seekstorm_hip.h ss_shard_set_coalescing).  Group commit:
+// requests that arrive while a batch runs are queued; the previous leader hands leadership to the thread of the queue's front,
+// which runs every compatible queued request as ONE device batch.  A request's thread waits on its own state word (spin, then
+// futex), so completing a batch wakes exactly its members.
+struct ss_co_req {
+  const void* q = nullptr;          // lexical: ss_bm25_query[nq]; vector: nq rows of dim elements (f32 or i8)
+  const float* qscale = nullptr;    // i8 vectors: per-query scales or null
+  uint32_t nq = 0, k = 0, rt = 0, elem = 0;
+  float thr = 0.f;
+  uint32_t* out_doc = nullptr;
+  float* out_score = nullptr;
+  uint32_t* out_count = nullptr;
+  uint64_t* out_total = nullptr;
+  int rc = 0;
+  std::atomic<uint32_t> state{0};   // 0 = pending, 1 = done, 3 = "lead the next batch"; bit 2 (value 4) = its thread sleeps on the futex
+};
+struct ss_coalescer {
+  std::mutex mu;
+  std::deque<ss_co_req*> queue;
+  bool leader_active = false;
+  uint32_t max_batch = 0, max_wait_us = 0;
+  uint64_t batches = 0, queries = 0;
+  // host staging of a merged batch: only the leader of the moment touches it
+  std::vector<char> h_q;
+  std::vector<float> h_qscale;
+  std::vector<uint32_t> h_doc, h_count;
+  std::vector<float> h_score;
+  std::vector<uint64_t> h_total;
+};
+
 struct ss_shard {
   int device = 0;
   hipStream_t stream = nullptr;
   std::mutex mu;
+  ss_coalescer co_lex, co_vec;
   uint64_t synth_stride = 1, synth_offset = 0;  // ss_synth_set_partition: which slice of the generator stream ss_*_synth build
   // ---- vector image
   float* d_X = nullptr;          // [n_rows_pad][dim_pad]   (f32 image)
@@ -351,6 +383,14 @@ void ssi_prof_begin(ss_shard* s, int kernel, hipStream_t st, hipEvent_t* e0, hip
 void ssi_prof_end(ss_shard* s, int kernel, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 
 struct ss_comm;
-int ssi_comm_exchange_to_host(ss_comm* c, uint32_t nq, uint32_t k, const uint32_t* d_doc, const float* d_score, const uint32_t* d_count,
-                              const uint64_t* d_total, uint64_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total,
-                              hipStream_t st);
+// one per-shard result list of a batch on the device: [nq][k] doc ids / scores, [nq] counts
+struct ss_dev_list { const uint32_t* doc; const float* score; const uint32_t* count; uint32_t k; };
+// The exchange of the ss_*_search_sharded entry points (comm.hip): one all-gather of the rank's lists + totals + status, merge,
+// (hybrid: RRF over the merged lists), answers to the host of every rank.  local_rc != 0: this rank's search failed -- it still
+// takes part (empty lists) so that no peer blocks; every rank then returns an error (the failing one its own, the others SS_EPEER).
+int ssi_comm_exchange(ss_comm* c, uint32_t nq, int n_lists, const ss_dev_list* L, const uint64_t* d_tot_a, const uint64_t* d_tot_b,
+                      int local_rc, bool hybrid, uint32_t offset, uint32_t length, uint64_t* out_doc, float* out_score,
+                      uint8_t* out_source, uint32_t* out_count, uint64_t* out_total, hipStream_t st);
+int ssi_topk_merge_launch(int device, uint32_t nq, uint32_t S, uint32_t k, const uint32_t* d_doc, const float* d_score, const uint32_t* d_count,
+                          size_t stride_ds, size_t stride_c, uint32_t out_len, uint64_t* d_out_doc, float* d_out_score, uint32_t* d_out_count,
+                          hipStream_t st);

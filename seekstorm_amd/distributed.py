@@ -118,6 +118,52 @@ def merge_gathered_device(g_doc, g_score, g_cnt, stream_ptr, device_index):
     return m_doc, m_score, m_cnt
 
 
+class PeerError(RuntimeError):
+    """a collective search failed on some rank: every rank raises (SS_EPEER on the ranks that were healthy)"""
+
+
+def exchange_one_gather(lists, totals, local_error=0):
+    """The exchange of ss_*_search_sharded (csrc/comm.hip) in torch.distributed terms, for the CPU tests and as its
+    specification: ONE all-gather of [per list: nq*k doc ids | nq*k score bits | nq counts] + [nq totals (u64) | status].
+    lists: [(doc [nq,k] int32, score [nq,k] f32, count [nq] int32), ...] of THIS rank; totals [nq] (uint64-valued) per
+    query.  A rank whose local search failed passes local_error != 0: it still takes part, with empty lists, and every
+    rank raises after the gather.  Returns ([(g_doc [S,nq,k], g_score, g_cnt), ...], summed totals [nq])."""
+    world = dist.get_world_size()
+    parts, shapes = [], []
+    for doc, score, cnt in lists:
+        shapes.append(tuple(doc.shape))
+        if local_error:
+            doc, score, cnt = torch.zeros_like(doc), torch.zeros_like(score), torch.zeros_like(cnt)
+        parts.append(pack_topk(doc, score, cnt))
+    tot = torch.zeros(len(totals) + 1, dtype=torch.int64)
+    if not local_error:
+        tot[:-1] = torch.as_tensor(np.asarray(totals, np.int64))
+    tot[-1] = 1 if local_error else 0
+    parts.append(tot.view(torch.int32).reshape(-1))
+    x = torch.cat(parts)
+    out = torch.empty((world * x.shape[0],), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x)
+    out = out.view(world, x.shape[0])
+    at, gathered = 0, []
+    for nq, k in shapes:
+        n = 2 * nq * k + nq
+        gathered.append(unpack_gathered(out[:, at:at + n], nq, k))
+        at += n
+    gt = out[:, at:].contiguous().view(torch.int64)  # [S, nq + 1]
+    if int(gt[:, -1].sum()) != 0:
+        raise PeerError("local search failed" if local_error else "a peer's search failed")
+    return gathered, gt[:, :-1].sum(dim=0).numpy().astype(np.uint64)
+
+
+def search_hybrid_exchanged(lex, vec, lex_total, vec_total, offset, length, local_error=0):
+    """SearchMode.Hybrid of Index.search over one shard per rank: both per-shard lists (top offset + length each) in one gather,
+    RRF over the cross-shard concatenations, sort / offset / length (search.rs:1962-2035, 2098-2119); totals = sum over the
+    shards of max(lexical, vector) (1919-1921).  Returns (per-query merge_results tuples, totals)."""
+    both = np.maximum(np.asarray(lex_total, np.uint64), np.asarray(vec_total, np.uint64))
+    (g_lex, g_vec), tot = exchange_one_gather([lex, vec], both, local_error)
+    return merge_gathered_hybrid_host(g_lex, g_vec, offset, length), tot
+
+
 class ShardComm:
     """One rank of the RCCL communicator behind the C ABI (ss_comm_create): the per-shard top-k exchange without
     torch.distributed on the data path.  The 128-byte unique id is handed from rank 0 to the others through
@@ -163,6 +209,45 @@ class ShardComm:
         N.check(N.lib().ss_bm25_search_sharded(shard._h, self._h, nq, queries.ctypes.data, int(k), int(result_type), doc.ctypes.data,
                                                score.ctypes.data, cnt.ctypes.data, tot.ctypes.data), "ss_bm25_search_sharded")
         return doc, score, cnt, tot
+
+    def search_vector_sharded(self, shard, queries, k, threshold=N.FLT_MIN_NEG):
+        """the vector shard task of the same search (ss_vec_search_sharded): AnnMode.All f32 scan of `shard`, exchange, merge"""
+        q = np.ascontiguousarray(queries, np.float32)
+        nq = q.shape[0]
+        doc = np.full((nq, int(k)), np.iinfo(np.uint64).max, np.uint64)
+        score = np.zeros((nq, int(k)), np.float32)
+        cnt = np.zeros(nq, np.uint32)
+        tot = np.zeros(nq, np.uint64)
+        N.check(N.lib().ss_vec_search_sharded(shard._h, self._h, nq, q.ctypes.data, int(k), float(threshold), doc.ctypes.data,
+                                              score.ctypes.data, cnt.ctypes.data, tot.ctypes.data), "ss_vec_search_sharded")
+        return doc, score, cnt, tot
+
+    def search_hybrid_sharded(self, shard, queries, query_vectors, offset, length, result_type=N.RT_TOPKCOUNT, threshold=N.FLT_MIN_NEG):
+        """SearchMode.Hybrid over shards on different GPUs (ss_hybrid_search_sharded): both shard tasks at k = offset + length, ONE
+        all-gather, RRF over the cross-shard concatenations -> (global ids uint64 [nq, length], fused scores, sources, counts,
+        totals = sum over the shards of max(lexical, vector))"""
+        q = np.ascontiguousarray(query_vectors, np.float32)
+        nq = q.shape[0]
+        assert len(queries) == nq
+        doc = np.full((nq, int(length)), np.iinfo(np.uint64).max, np.uint64)
+        score = np.zeros((nq, int(length)), np.float32)
+        src = np.zeros((nq, int(length)), np.uint8)
+        cnt = np.zeros(nq, np.uint32)
+        tot = np.zeros(nq, np.uint64)
+        N.check(N.lib().ss_hybrid_search_sharded(shard._h, self._h, nq, queries.ctypes.data, int(result_type), q.ctypes.data, float(threshold),
+                                                 int(offset + length), int(offset), int(length), doc.ctypes.data, score.ctypes.data,
+                                                 src.ctypes.data, cnt.ctypes.data, tot.ctypes.data), "ss_hybrid_search_sharded")
+        return doc, score, src, cnt, tot
+
+    def profile(self, on=True):
+        N.check(N.lib().ss_comm_profile(self._h, 1 if on else 0), "ss_comm_profile")
+
+    def profile_read(self, reset=True):
+        """(collectives, mean microseconds per all-gather) of the sharded searches since the last reset"""
+        import ctypes as C
+        n, us = C.c_uint64(), C.c_double()
+        N.check(N.lib().ss_comm_profile_read(self._h, C.byref(n), C.byref(us), 1 if reset else 0), "ss_comm_profile_read")
+        return int(n.value), (us.value / n.value if n.value else 0.0)
 
     def close(self):
         if self._h:

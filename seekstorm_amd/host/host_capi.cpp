@@ -1,6 +1,10 @@
 // Flat C shim over the C++ host mirror (seekstorm_host.hpp) so that the parity tests can drive it through ctypes.
 // Test plumbing only: a C++ application links seekstorm_host.hpp directly.
+#include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstring>
+#include <thread>
 
 #include "seekstorm_host.hpp"
 
@@ -9,7 +13,6 @@ using namespace seekstorm;
 struct ssh_index {
   std::vector<std::shared_ptr<Shard>> shards;
   std::unique_ptr<Index> index;
-  std::vector<std::unique_ptr<VectorBatchCoalescer>> coalescers;
 };
 
 static int write_out(const ResultObject& ro, uint32_t cap, uint64_t* out_doc, float* out_score, uint8_t* out_source,
@@ -212,49 +215,61 @@ int ssh_search_vector_shard_ann(ssh_index* ix, int shard, const float* query_vec
   return write_out(ro, cap, out_doc, out_score, nullptr, nullptr, nullptr, out_meta);
 }
 
-// n concurrent single-query vector searches through a VectorBatchCoalescer (one submitting thread per query);
+// n concurrent single-query vector searches: one thread per query, each calling Shard::search_vector_shard as the reference's
+// runtime workers call search_vector_shard -- the C ABI coalesces them into device batches (ss_shard_set_coalescing);
 // out arrays are [n][length]; returns the number of device batches used
 int ssh_coalesced_vector_search(ssh_index* ix, int shard, uint32_t n, const float* queries, uint32_t length,
                                 uint32_t max_batch, uint32_t max_wait_us, uint64_t* out_doc, float* out_score,
                                 uint32_t* out_count) {
   Shard& sh = *ix->shards[shard];
-  VectorBatchCoalescer co(ix->shards[shard], max_batch, max_wait_us);
+  if (ss_shard_set_coalescing(sh.handle(), 1024, max_batch, max_wait_us) != SS_OK) return SS_EINVAL;
+  uint64_t b0 = 0, b1 = 0;
+  (void)ss_shard_coalescing_stats(sh.handle(), nullptr, nullptr, &b0, nullptr);
   const uint32_t dim = sh.dim();
-  std::vector<std::future<ResultObject>> fut(n);
+  std::vector<ResultObject> res(n);
   std::vector<std::thread> th;
   for (uint32_t i = 0; i < n; i++)
-    th.emplace_back([&, i] { fut[i] = co.submit(std::vector<float>(queries + (size_t)i * dim, queries + (size_t)(i + 1) * dim), length, nullptr); });
+    th.emplace_back([&, i] { res[i] = sh.search_vector_shard(queries + (size_t)i * dim, length, nullptr); });
   for (auto& t : th) t.join();
+  (void)ss_shard_coalescing_stats(sh.handle(), nullptr, nullptr, &b1, nullptr);
+  (void)ss_shard_set_coalescing(sh.handle(), 1024, SS_VEC_BATCH, 0);
   for (uint32_t i = 0; i < n; i++) {
-    ResultObject ro = fut[i].get();
+    const ResultObject& ro = res[i];
+    if (ro.last_error) return ro.last_error;
     out_count[i] = (uint32_t)ro.results.size();
     for (size_t j = 0; j < ro.results.size() && j < length; j++) {
       out_doc[(size_t)i * length + j] = ro.results[j].doc_id;
       out_score[(size_t)i * length + j] = ro.results[j].score;
     }
   }
-  return (int)co.batches_submitted();
+  return (int)(b1 - b0);
 }
 
-// n concurrent single-query lexical searches through a LexicalBatchCoalescer; query i = terms[term_off[i] .. term_off[i+1])
-// followed by its NOT terms not_terms[not_off[i] .. not_off[i+1]); out arrays are [n][length]
+// n concurrent single-query lexical searches (one thread per query through Shard::search_lexical_shard); query i =
+// terms[term_off[i] .. term_off[i+1]) followed by its NOT terms not_terms[not_off[i] .. not_off[i+1]); out arrays are [n][length]
 int ssh_coalesced_lexical_search(ssh_index* ix, int shard, uint32_t n, const uint32_t* terms, const uint32_t* term_off,
                                  const uint32_t* not_terms, const uint32_t* not_off, uint32_t query_type, uint32_t offset,
                                  uint32_t length, uint32_t result_type, uint32_t max_batch, uint32_t max_wait_us,
                                  uint64_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total) {
-  LexicalBatchCoalescer co(ix->shards[shard], max_batch, max_wait_us);
-  std::vector<std::future<ResultObject>> fut(n);
+  Shard& sh = *ix->shards[shard];
+  if (ss_shard_set_coalescing(sh.handle(), max_batch, SS_VEC_BATCH, max_wait_us) != SS_OK) return SS_EINVAL;
+  uint64_t b0 = 0, b1 = 0;
+  (void)ss_shard_coalescing_stats(sh.handle(), &b0, nullptr, nullptr, nullptr);
+  std::vector<ResultObject> res(n);
   std::vector<std::thread> th;
   for (uint32_t i = 0; i < n; i++)
     th.emplace_back([&, i] {
       std::vector<uint32_t> t(terms + term_off[i], terms + term_off[i + 1]);
       std::vector<uint32_t> nt;
       if (not_terms) nt.assign(not_terms + not_off[i], not_terms + not_off[i + 1]);
-      fut[i] = co.submit(t, (QueryType)query_type, offset + (i % 3), length, (ResultType)result_type, nt);  // mixed offsets
+      res[i] = sh.search_lexical_shard(t, (QueryType)query_type, offset + (i % 3), length, (ResultType)result_type, {}, nt);  // mixed offsets
     });
   for (auto& t : th) t.join();
+  (void)ss_shard_coalescing_stats(sh.handle(), &b1, nullptr, nullptr, nullptr);
+  (void)ss_shard_set_coalescing(sh.handle(), 1024, SS_VEC_BATCH, 0);
   for (uint32_t i = 0; i < n; i++) {
-    ResultObject ro = fut[i].get();
+    const ResultObject& ro = res[i];
+    if (ro.last_error) return ro.last_error;
     out_count[i] = (uint32_t)ro.results.size();
     out_total[i] = ro.result_count_total;
     for (size_t j = 0; j < ro.results.size() && j < length; j++) {
@@ -262,7 +277,63 @@ int ssh_coalesced_lexical_search(ssh_index* ix, int shard, uint32_t n, const uin
       out_score[(size_t)i * length + j] = ro.results[j].score;
     }
   }
-  return (int)co.batches_submitted();
+  return (int)(b1 - b0);
+}
+
+int ssh_synth_lexical(ssh_index* ix, int shard, uint64_t seed, uint64_t n_docs, uint32_t n_terms, const uint32_t* thresh32,
+                      const uint8_t* len_table1024) {
+  return ix->shards[shard]->synth_lexical(seed, n_docs, n_terms, thresh32, len_table1024, (uint32_t)ix->shards.size());
+}
+int ssh_synth_vectors(ssh_index* ix, int shard, uint64_t seed, uint64_t n_rows, uint32_t dim) {
+  return ix->shards[shard]->synth_vectors(seed, n_rows, dim, (uint32_t)ix->shards.size());
+}
+
+// The reference's REAL calling pattern, measured: n_threads host threads, each issuing ONE query per call through Index::search
+// (search.rs:1637-1743: one search per runtime worker, no batched entry point) for `seconds` of wall time.  mode: SS_MODE_*;
+// query i of the n_queries given = terms[term_off[i] .. term_off[i+1]) and / or vectors[i * dim ..]; threads draw queries round
+// robin.  out[0] = completed searches, out[1] = wall seconds, out[2] / out[3] = p50 / p99 of the per-call latency in
+// microseconds (host clock around the call), out[4] = calls that came back with an error.
+int ssh_bench_concurrent(ssh_index* ix, int mode, uint32_t n_threads, double seconds, uint32_t n_queries, const uint32_t* terms,
+                         const uint32_t* term_off, const float* vectors, uint32_t query_type, uint32_t length, uint32_t result_type,
+                         double* out /* [5] */) {
+  if (!ix->index || n_threads == 0 || n_queries == 0) return SS_EINVAL;
+  const uint32_t dim = ix->shards[0]->dim();
+  std::atomic<uint64_t> next{0}, errors{0};
+  std::atomic<bool> go{false}, stop{false};
+  std::vector<std::vector<float>> lat(n_threads);
+  std::vector<std::thread> th;
+  for (uint32_t t = 0; t < n_threads; t++)
+    th.emplace_back([&, t] {
+      lat[t].reserve(1 << 16);
+      while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+      while (!stop.load(std::memory_order_relaxed)) {
+        const uint32_t i = (uint32_t)(next.fetch_add(1, std::memory_order_relaxed) % n_queries);
+        std::vector<uint32_t> q;
+        if (mode != SS_MODE_VECTOR) q.assign(terms + term_off[i], terms + term_off[i + 1]);
+        const float* v = mode != SS_MODE_LEXICAL ? vectors + (size_t)i * dim : nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        ResultObject ro = ix->index->search(q, v, (QueryType)query_type, (SearchMode)mode, 0, length, (ResultType)result_type, nullptr,
+                                            false /* the bench's vectors are normalised already */);
+        const auto t1 = std::chrono::steady_clock::now();
+        if (ro.last_error || ro.results.empty()) errors.fetch_add(1, std::memory_order_relaxed);
+        lat[t].push_back((float)std::chrono::duration<double, std::micro>(t1 - t0).count());
+      }
+    });
+  const auto w0 = std::chrono::steady_clock::now();
+  go.store(true, std::memory_order_release);
+  std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+  stop.store(true, std::memory_order_relaxed);
+  for (auto& t : th) t.join();
+  const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+  std::vector<float> all;
+  for (auto& l : lat) all.insert(all.end(), l.begin(), l.end());
+  std::sort(all.begin(), all.end());
+  out[0] = (double)all.size();
+  out[1] = wall;
+  out[2] = all.empty() ? 0.0 : all[all.size() / 2];
+  out[3] = all.empty() ? 0.0 : all[std::min(all.size() - 1, (size_t)((double)all.size() * 0.99))];
+  out[4] = (double)errors.load();
+  return SS_OK;
 }
 
 // Index::search_lexical_batch: query i = terms[term_off[i] .. term_off[i+1]); out arrays [n][k]; device_exchange != 0 first calls

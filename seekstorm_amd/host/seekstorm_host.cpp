@@ -127,6 +127,25 @@ int Shard::upload_lexical_fields(uint64_t n_docs, uint32_t n_fields, const uint8
   return rc;
 }
 
+int Shard::synth_lexical(uint64_t seed, uint64_t n_docs, uint32_t n_terms, const uint32_t* thresh32, const uint8_t* len_table1024, uint32_t n_shards) {
+  if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
+  lexical_fields_ = 1; ngram_components_.clear(); ngram_component_df_.clear();
+  int rc = ss_synth_set_partition(h_, shard_id_, n_shards);
+  if (rc == SS_OK) rc = ss_bm25_synth(h_, seed, n_docs, n_terms, thresh32, len_table1024);
+  n_docs_ = rc == SS_OK ? n_docs : 0;
+  return rc;
+}
+
+int Shard::synth_vectors(uint64_t seed, uint64_t n_rows, uint32_t dim, uint32_t n_shards) {
+  if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
+  i8_ = false;
+  int rc = ss_synth_set_partition(h_, shard_id_, n_shards);
+  if (rc == SS_OK) rc = ss_vec_synth(h_, seed, n_rows, dim);
+  n_rows_ = rc == SS_OK ? n_rows : 0;
+  dim_ = rc == SS_OK ? dim : 0;
+  return rc;
+}
+
 int Shard::set_vector_similarity(bool euclidean) {
   if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
   const int rc = ss_vec_set_similarity(h_, euclidean ? SS_SIM_EUCLIDEAN : SS_SIM_DOT);
@@ -742,6 +761,65 @@ ResultObject Index::search(const std::vector<uint32_t>& query_terms, const float
     qv.assign(query_vector, query_vector + shards_[0]->dim());
     if (normalize_query) normalize_f32(qv.data(), qv.size());  // search.rs:1464-1475
   }
+  bool f32_images = true;
+  for (const auto& sh : shards_) f32_images = f32_images && !sh->vectors_are_i8() && sh->dim() == qv.size();
+  if (!comms_.empty() && want_vec && (want_lex || search_mode == SearchMode::Vector) && f32_images && ann_mode.kind == AnnMode::Kind::All &&
+      vector_field_filter.empty() && facet_filter.empty() && not_terms.empty() && lexical_field_filter.empty() &&
+      result_type != ResultType::Count && length > 0) {
+    // Vector / Hybrid over shards on different GPUs: every shard task runs its searches at (0, offset + length), the lists travel
+    // in ONE all-gather and are merged -- Hybrid: fused by RRF over the cross-shard concatenations -- on the devices
+    // (ss_vec_search_sharded / ss_hybrid_search_sharded; search.rs:1680-1689, 1723-1732, 1962-2035, 2098-2119).  A shard whose own
+    // search fails still enters the exchange; every task then reports an error (SS_EPEER on the healthy ones).
+    const bool hybrid = want_lex;
+    const uint32_t k = (uint32_t)(offset + length);
+    const size_t out_len = hybrid ? length : k;
+    std::vector<uint64_t> doc(out_len);
+    std::vector<float> score(out_len);
+    std::vector<uint8_t> src(out_len);
+    uint32_t cnt = 0;
+    uint64_t tot = 0;
+    std::vector<int> rcs(S, SS_OK);
+    std::vector<ss_bm25_query> q(S);
+    for (size_t i = 0; i < S && hybrid; i++) {
+      const int rc = shards_[i]->make_query(query_terms, query_type_default, &q[i]);
+      if (rc != SS_OK) { ro.last_error = rc; return ro; }
+      shards_[i]->mark_all_terms_frequent(&q[i], k);
+    }
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < S; i++)
+      th.emplace_back([&, i] {
+        std::vector<uint64_t> d(i ? out_len : 0);
+        std::vector<float> sc(i ? out_len : 0);
+        std::vector<uint8_t> so(i ? out_len : 0);
+        uint32_t c = 0;
+        uint64_t t = 0;
+        const float thr = threshold_raw(similarity_threshold, shards_[i]->euclidean());
+        if (hybrid)
+          rcs[i] = ss_hybrid_search_sharded(shards_[i]->handle(), comms_[i], 1, &q[i], (uint32_t)result_type, qv.data(), thr, k, (uint32_t)offset,
+                                            (uint32_t)length, i ? d.data() : doc.data(), i ? sc.data() : score.data(), i ? so.data() : src.data(),
+                                            i ? &c : &cnt, i ? &t : &tot);
+        else
+          rcs[i] = ss_vec_search_sharded(shards_[i]->handle(), comms_[i], 1, qv.data(), k, thr, i ? d.data() : doc.data(),
+                                         i ? sc.data() : score.data(), i ? &c : &cnt, i ? &t : &tot);
+      });
+    for (auto& t : th) t.join();
+    for (int r : rcs) if (r != SS_OK) ro.last_error = r;
+    if (ro.last_error != SS_OK) return ro;  // degrade to empty
+    ro.result_count_total = tot;
+    const size_t first = hybrid ? 0 : std::min<size_t>(offset, cnt);  // the fused list is already cut; a vector list is cut here
+    for (size_t x = first; x < cnt && ro.results.size() < length; x++) {
+      Result r;
+      r.doc_id = doc[x];
+      r.score = score[x];
+      r.source = hybrid ? (ResultSource)src[x] : ResultSource::Vector;
+      if (!hybrid) r.vector_score = vector_score_of(score[x]);
+      r.shard_id = (uint32_t)(r.doc_id % S);
+      r.level_id = (uint32_t)((r.doc_id / S) >> 16);
+      ro.results.push_back(r);
+    }
+    ro.result_count = ro.results.size();
+    return ro;
+  }
   // one host thread per shard; lexical then vector sequentially inside the task for Hybrid (search.rs:1698-1740)
   std::vector<ResultObject> lex(S), vec(S);
   auto task = [&](size_t i) {
@@ -911,165 +989,6 @@ std::vector<ResultObject> Index::search_lexical_batch(const std::vector<std::vec
     ro.result_count = ro.results.size();
   }
   return out;
-}
-
-// ------------------------------------------------------------------ VectorBatchCoalescer
-VectorBatchCoalescer::VectorBatchCoalescer(std::shared_ptr<Shard> shard, size_t max_batch, unsigned max_wait_us)
-    : shard_(std::move(shard)), max_batch_(std::max<size_t>(1, max_batch)), max_wait_us_(max_wait_us) {
-  worker_ = std::thread([this] { run(); });
-}
-
-VectorBatchCoalescer::~VectorBatchCoalescer() {
-  {
-    std::lock_guard<std::mutex> g(mu_);
-    stop_ = true;
-  }
-  cv_.notify_all();
-  worker_.join();
-}
-
-std::future<ResultObject> VectorBatchCoalescer::submit(std::vector<float> query_vector, size_t length,
-                                                       const float* similarity_threshold) {
-  auto r = std::make_unique<Req>();
-  r->q = std::move(query_vector);
-  r->length = length;
-  r->has_thr = similarity_threshold != nullptr;
-  r->thr = similarity_threshold ? *similarity_threshold : 0.f;
-  std::future<ResultObject> f = r->done.get_future();
-  {
-    std::lock_guard<std::mutex> g(mu_);
-    queue_.push_back(std::move(r));
-  }
-  cv_.notify_all();
-  return f;
-}
-
-void VectorBatchCoalescer::run() {
-  for (;;) {
-    std::vector<std::unique_ptr<Req>> batch;
-    {
-      std::unique_lock<std::mutex> lk(mu_);
-      cv_.wait(lk, [this] { return stop_ || !queue_.empty(); });
-      if (queue_.empty()) {
-        if (stop_) return;
-        continue;
-      }
-      // give late arrivals a moment: wait until the batch is full or max_wait_us has elapsed
-      const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(max_wait_us_);
-      cv_.wait_until(lk, deadline, [this] { return stop_ || queue_.size() >= max_batch_; });
-      // one batch = the longest prefix with the same threshold and dimension, at most max_batch requests
-      size_t n = 1;
-      while (n < queue_.size() && n < max_batch_ && queue_[n]->has_thr == queue_[0]->has_thr &&
-             queue_[n]->thr == queue_[0]->thr && queue_[n]->q.size() == queue_[0]->q.size())
-        n++;
-      for (size_t i = 0; i < n; i++) batch.push_back(std::move(queue_[i]));
-      queue_.erase(queue_.begin(), queue_.begin() + n);
-      batches_++;
-      queries_ += n;
-    }
-    const size_t dim = batch[0]->q.size();
-    size_t k = 0;
-    for (auto& r : batch) k = std::max(k, r->length);
-    std::vector<ResultObject> res;
-    if (dim == shard_->dim() && k > 0) {
-      std::vector<float> flat(batch.size() * dim);
-      for (size_t i = 0; i < batch.size(); i++) std::memcpy(&flat[i * dim], batch[i]->q.data(), dim * sizeof(float));
-      const float thr = batch[0]->thr;
-      res = shard_->search_vector_batch(flat.data(), batch.size(), k, batch[0]->has_thr ? &thr : nullptr);
-    } else {
-      res.resize(batch.size());
-      for (auto& r : res) r.last_error = SS_EINVAL;
-    }
-    for (size_t i = 0; i < batch.size(); i++) {
-      ResultObject& ro = res[i];
-      if (ro.results.size() > batch[i]->length) {  // a batch runs at the largest k of its members
-        ro.results.resize(batch[i]->length);
-        ro.result_count = ro.results.size();
-      }
-      batch[i]->done.set_value(std::move(ro));
-    }
-  }
-}
-
-// ------------------------------------------------------------------ LexicalBatchCoalescer
-LexicalBatchCoalescer::LexicalBatchCoalescer(std::shared_ptr<Shard> shard, size_t max_batch, unsigned max_wait_us)
-    : shard_(std::move(shard)), max_batch_(std::max<size_t>(1, max_batch)), max_wait_us_(max_wait_us) {
-  worker_ = std::thread([this] { run(); });
-}
-
-LexicalBatchCoalescer::~LexicalBatchCoalescer() {
-  {
-    std::lock_guard<std::mutex> g(mu_);
-    stop_ = true;
-  }
-  cv_.notify_all();
-  worker_.join();
-}
-
-std::future<ResultObject> LexicalBatchCoalescer::submit(const std::vector<uint32_t>& query_terms, QueryType query_type_default,
-                                                        size_t offset, size_t length, ResultType result_type,
-                                                        const std::vector<uint32_t>& not_terms) {
-  auto r = std::make_unique<Req>();
-  r->rc = shard_->make_query(query_terms, query_type_default, &r->q, not_terms);  // idf on the caller's thread
-  // the shortcut's condition depends on the request's own top_k, not on what else shares its batch
-  if (r->rc == SS_OK && result_type != ResultType::Count) shard_->mark_all_terms_frequent(&r->q, offset + length);
-  r->offset = offset;
-  r->length = length;
-  r->rt = result_type;
-  std::future<ResultObject> f = r->done.get_future();
-  if (r->rc != SS_OK) {  // the reference degrades to an empty result (search.rs:2461-2463)
-    ResultObject ro;
-    ro.last_error = r->rc;
-    r->done.set_value(std::move(ro));
-    return f;
-  }
-  {
-    std::lock_guard<std::mutex> g(mu_);
-    queue_.push_back(std::move(r));
-  }
-  cv_.notify_all();
-  return f;
-}
-
-void LexicalBatchCoalescer::run() {
-  for (;;) {
-    std::vector<std::unique_ptr<Req>> batch;
-    {
-      std::unique_lock<std::mutex> lk(mu_);
-      cv_.wait(lk, [this] { return stop_ || !queue_.empty(); });
-      if (queue_.empty()) {
-        if (stop_) return;
-        continue;
-      }
-      const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(max_wait_us_);
-      cv_.wait_until(lk, deadline, [this] { return stop_ || queue_.size() >= max_batch_; });
-      size_t n = 1;
-      // one device batch: one result type, and phrase queries only among themselves (the C ABI's rule)
-      auto is_phrase = [](const Req& r) { return (r.q.op & 0xFFu) == SS_OP_PHRASE; };
-      while (n < queue_.size() && n < max_batch_ && queue_[n]->rt == queue_[0]->rt && is_phrase(*queue_[n]) == is_phrase(*queue_[0])) n++;
-      for (size_t i = 0; i < n; i++) batch.push_back(std::move(queue_[i]));
-      queue_.erase(queue_.begin(), queue_.begin() + n);
-      batches_++;
-      queries_ += n;
-    }
-    size_t k = 1;
-    std::vector<ss_bm25_query> qs;
-    qs.reserve(batch.size());
-    for (auto& r : batch) {
-      k = std::max(k, r->offset + r->length);
-      qs.push_back(r->q);
-    }
-    std::vector<ResultObject> res = shard_->search_lexical_batch(qs, k, batch[0]->rt, {}, /*mark_frequent=*/false);
-    for (size_t i = 0; i < batch.size(); i++) {
-      ResultObject& ro = res[i];
-      const size_t want = batch[i]->offset + batch[i]->length;
-      if (ro.results.size() > want) ro.results.resize(want);
-      if (batch[i]->offset)  // drain offset (search.rs:3585-3593)
-        ro.results.erase(ro.results.begin(), ro.results.begin() + std::min(batch[i]->offset, ro.results.size()));
-      ro.result_count = ro.results.size();
-      batch[i]->done.set_value(std::move(ro));
-    }
-  }
 }
 
 }  // namespace seekstorm

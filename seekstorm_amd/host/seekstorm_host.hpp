@@ -8,7 +8,7 @@
 //   Shard::search_lexical_shard                             search.rs:2427-2442 (dispatch block 3374-3560 -> ss_bm25_search)
 //   Shard::search_vector_shard                              vector.rs:1105-1115 (-> ss_vec_search)
 //   Index::search                                           <IndexArc as Search>::search, search.rs:1134-1150 / 1154-2131
-//   BatchCoalescer                                          new: the reference has no batched entry point (one query per
+//   (batch coalescing)                                      behind the C ABI: the reference has no batched entry point (one query per
 //                                                           request, http_server.rs:218-289); concurrent callers are
 //                                                           coalesced into one C-ABI batch per device pass
 //
@@ -122,6 +122,9 @@ class Shard {
   // VectorSimilarity of the image (index-wide in the reference): Dot / Cosine (default) or Euclidean; BEFORE the upload
   int set_vector_similarity(bool euclidean);
   int upload_vectors(uint64_t n_rows, uint32_t dim, const float* rows, const uint32_t* row_doc_ids);
+  // device-side synthetic images (bench / tests: the generators of ss_bm25_synth / ss_vec_synth), shard `shard_id` of n_shards
+  int synth_lexical(uint64_t seed, uint64_t n_docs, uint32_t n_terms, const uint32_t* thresh32, const uint8_t* len_table1024, uint32_t n_shards = 1);
+  int synth_vectors(uint64_t seed, uint64_t n_rows, uint32_t dim, uint32_t n_shards = 1);
   // shard files as the reference writes them: index.bin (single indexed field), vector.bin (f32), delete.bin.
   // term_keys: key_hash of every term id, ascending; an n-gram key (key_hash & 7 != 0) holds one id per component term,
   // consecutive -- a query term that resolved to it is passed as those ids (make_query applies idf_ngram_i)
@@ -133,6 +136,7 @@ class Shard {
   // Precision::I8 records; queries given as f32 are quantised with quantize_f32_to_i8 like the reference's
   int upload_vectors_i8(uint64_t n_rows, uint32_t dim, const int8_t* rows, const float* row_scale, const uint32_t* row_doc_ids);
   bool vectors_are_i8() const { return i8_; }
+  bool euclidean() const { return euclidean_; }
   // delete_hashset (index.rs:1594): replaces the tombstone set; delete_document (index.rs:5110) re-sends it
   int set_deleted(const uint64_t* doc_ids, uint64_t n);
   int synth_lexical(uint64_t seed, uint64_t n_docs, uint32_t n_terms, const uint32_t* thresh32, const uint8_t* len_table1024);
@@ -244,70 +248,9 @@ class Index {
   std::vector<ss_comm*> comms_;  // one per shard once enable_device_exchange succeeded
 };
 
-// Coalesces concurrent single-query vector searches on ONE shard into device batches: a caller enqueues its query
-// and blocks on a future; a worker thread submits whatever has arrived (up to max_batch, after at most max_wait_us
-// since the first queued request) as one ss_vec_search call.  All requests of a batch share k = the largest requested
-// length (each result list is cut back to its own length) and must share the similarity threshold (requests with a
-// different threshold start a new batch).
-class VectorBatchCoalescer {
- public:
-  VectorBatchCoalescer(std::shared_ptr<Shard> shard, size_t max_batch = SS_VEC_BATCH, unsigned max_wait_us = 200);
-  ~VectorBatchCoalescer();
-  std::future<ResultObject> submit(std::vector<float> query_vector, size_t length, const float* similarity_threshold);
-  uint64_t batches_submitted() const { return batches_; }
-  uint64_t queries_submitted() const { return queries_; }
-
- private:
-  struct Req {
-    std::vector<float> q;
-    size_t length;
-    bool has_thr;
-    float thr;
-    std::promise<ResultObject> done;
-  };
-  void run();
-  std::shared_ptr<Shard> shard_;
-  size_t max_batch_;
-  unsigned max_wait_us_;
-  std::mutex mu_;
-  std::condition_variable cv_;
-  std::vector<std::unique_ptr<Req>> queue_;
-  bool stop_ = false;
-  uint64_t batches_ = 0, queries_ = 0;
-  std::thread worker_;
-};
-
-// The same for the lexical seam: concurrent single-query search_lexical_shard calls (the reference's callers hold only
-// the shard read lock and arrive from many runtime threads) become one ss_bm25_search batch.  A batch
-// runs at the largest offset + length of its members and each answer is its own prefix of that list (the top-k order
-// is total: score desc, doc id asc); requests with a different ResultType start a new batch.
-class LexicalBatchCoalescer {
- public:
-  LexicalBatchCoalescer(std::shared_ptr<Shard> shard, size_t max_batch = 1024, unsigned max_wait_us = 100);
-  ~LexicalBatchCoalescer();
-  std::future<ResultObject> submit(const std::vector<uint32_t>& query_terms, QueryType query_type_default, size_t offset,
-                                   size_t length, ResultType result_type, const std::vector<uint32_t>& not_terms = {});
-  uint64_t batches_submitted() const { return batches_; }
-  uint64_t queries_submitted() const { return queries_; }
-
- private:
-  struct Req {
-    ss_bm25_query q;
-    int rc;
-    size_t offset, length;
-    ResultType rt;
-    std::promise<ResultObject> done;
-  };
-  void run();
-  std::shared_ptr<Shard> shard_;
-  size_t max_batch_;
-  unsigned max_wait_us_;
-  std::mutex mu_;
-  std::condition_variable cv_;
-  std::vector<std::unique_ptr<Req>> queue_;
-  bool stop_ = false;
-  uint64_t batches_ = 0, queries_ = 0;
-  std::thread worker_;
-};
+// Concurrent single-query callers need no helper here: the reference's calling pattern -- many runtime workers, each inside
+// Search::search with ONE query -- is coalesced into device batches BEHIND the C ABI (ss_shard_set_coalescing,
+// include/seekstorm_hip.h), so Shard::search_lexical_shard / search_vector_shard and Index::search are simply called from as
+// many threads as the host has.  (Rounds 1-2 kept batch coalescer classes in this mirror; a Rust host does not link the mirror.)
 
 }  // namespace seekstorm

@@ -948,6 +948,19 @@ class Shard:
         return ro
 
     # ---- measurement hooks
+    def set_coalescing(self, max_lexical_batch=1024, max_vector_batch=N.SS_VEC_BATCH, max_wait_us=0):
+        """concurrent small host-pointer searches of this shard are merged into device batches behind the C ABI
+        (ss_shard_set_coalescing; on by default, a batch size of 0 switches a kind off)"""
+        N.check(N.lib().ss_shard_set_coalescing(self._h, int(max_lexical_batch), int(max_vector_batch), int(max_wait_us)),
+                "ss_shard_set_coalescing")
+
+    def coalescing_stats(self):
+        """(lexical batches, lexical queries, vector batches, vector queries) served through the coalescer so far"""
+        import ctypes as C
+        v = [C.c_uint64() for _ in range(4)]
+        N.check(N.lib().ss_shard_coalescing_stats(self._h, *[C.byref(x) for x in v]), "ss_shard_coalescing_stats")
+        return tuple(int(x.value) for x in v)
+
     def profile(self, on=True):
         N.check(N.lib().ss_profile_enable(self._h, 1 if on else 0), "ss_profile_enable")
 

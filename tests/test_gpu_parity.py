@@ -847,6 +847,74 @@ def test_concurrent_callers_share_a_shard(S, O, lex):
     for t in th:
         t.join()
     assert not errors, errors[:3]
+    # every one of those calls went through the coalescer of its shard (one query per call, no filters)
+    lb, lq, _, _ = sh.coalescing_stats()
+    _, _, vb, vq = vs.coalescing_stats()
+    assert lq + vq >= 12 * 25 and lb <= lq and vb <= vq
+    # callers that arrive together SHARE device batches (the reference's workers hold only the shard read lock): 16
+    # threads released by a barrier, the leader waits up to 50 ms for company -> far fewer batches than calls, and every caller
+    # still gets its own answer, cut to its own k (the top-k' of a query is the head of its top-k)
+    sh.set_coalescing(1024, 64, 50000)
+    vs.set_coalescing(1024, 64, 50000)
+    lb0, lq0, _, _ = sh.coalescing_stats()
+    _, _, vb0, vq0 = vs.coalescing_stats()
+    bar = threading.Barrier(16)
+    got = {}
+
+    def burst(j):
+        try:
+            i, kk = j % 4, (10, 7, 4)[j % 3]
+            bar.wait()
+            if j < 10:
+                got[j] = ("l", i, kk, sh.search_lexical_batch(sh.make_queries([tl[i]], S.QueryType.Union), kk))
+            else:
+                got[j] = ("v", i, kk, vs.search_vector_batch(qs[i:i + 1], 2 * kk))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=burst, args=(j,)) for j in range(16)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:3]
+    lb1, lq1, _, _ = sh.coalescing_stats()
+    _, _, vb1, vq1 = vs.coalescing_stats()
+    assert lq1 - lq0 == 10 and vq1 - vq0 == 6
+    assert lb1 - lb0 <= 3 and vb1 - vb0 <= 3, (lb1 - lb0, vb1 - vb0)  # 10 + 6 concurrent calls, a handful of device batches
+    for j, (kind, i, kk, g) in got.items():
+        want = want_l[i] if kind == "l" else want_v[i]
+        kq = kk if kind == "l" else 2 * kk
+        assert np.array_equal(g[0][0][:kq], want[0][0][:kq]) and np.array_equal(g[1][0][:kq], want[1][0][:kq]), (j, kind)
+        if kind == "l":
+            assert int(g[3][0]) == int(want[3][0])  # exact match counts do not depend on k
+    sh.set_coalescing()
+    vs.set_coalescing()
+    # an invalid request inside a merged batch fails ALONE: its batch-mates get their answers
+    sh.set_coalescing(1024, 64, 50000)
+    bar = threading.Barrier(6)
+    outcome = {}
+
+    def mixed(j):
+        q = sh.make_queries([tl[j % 4]], S.QueryType.Union)
+        if j == 2:
+            q["term"][0][0] = 0xFFFFFF  # no such term
+        bar.wait()
+        try:
+            outcome[j] = sh.search_lexical_batch(q, 10)
+        except Exception as e:  # noqa: BLE001
+            outcome[j] = e
+
+    th = [threading.Thread(target=mixed, args=(j,)) for j in range(6)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    sh.set_coalescing()
+    assert isinstance(outcome[2], Exception)
+    for j in (0, 1, 3, 4, 5):
+        assert not isinstance(outcome[j], Exception), outcome[j]
+        assert all(np.array_equal(a, b) for a, b in zip(outcome[j], want_l[j % 4]))
     vs.close()
 
 

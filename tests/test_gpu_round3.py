@@ -1,0 +1,121 @@
+"""GPU tests (-m gpu) added in round 3: the vector and hybrid shard tasks behind the RCCL exchange (ss_vec_search_sharded,
+ss_hybrid_search_sharded) with a communicator of one rank, the status agreement of the collective searches, the timing hook of
+the collective, i8 Euclidean searches without their norms."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    import seekstorm_amd
+    return seekstorm_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def both(S, O):
+    """one shard holding a lexical and a vector image over the same doc ids"""
+    n_docs, voc, dim = 60_000, list(range(2600, 4096, 150)), 96
+    dl = O.lex_doclen(n_docs)
+    offs, docs, tfs = O.lex_corpus(n_docs, voc)
+    rows = O.vec_gen(O.VEC_SEED, 0, n_docs, dim)
+    sh = S.Shard(0)
+    sh.upload_lexical(n_docs, dl, offs, docs, tfs)
+    sh.upload_vectors(rows)
+    yield sh, rows, n_docs, dim
+    sh.close()
+
+
+def test_vector_and_hybrid_sharded_single_rank(S, O, both):
+    """with ONE rank the exchange is the identity: ss_vec_search_sharded = ss_vec_search with u64 ids, ss_hybrid_search_sharded =
+    Index.search(SearchMode.Hybrid) of the Python mirror (two searches + ss_merge_results on the host), totals = max(lexical,
+    vector); the collective's time is reported per all-gather"""
+    from seekstorm_amd import distributed as D
+    sh, rows, n_docs, dim = both
+    comm = D.ShardComm(0, 1, 0)
+    comm.profile(True)
+    nq, k = 5, 20
+    qs = O.vec_gen(O.VECQ_SEED, 0, nq, dim)
+    doc, score, cnt, tot = sh.search_vector_batch(qs, k)
+    for _ in range(2):
+        md, ms, mc, mt = comm.search_vector_sharded(sh, qs, k)
+        assert np.array_equal(mc, cnt) and np.array_equal(mt, tot)
+        for i in range(nq):
+            assert np.array_equal(md[i, :cnt[i]], doc[i, :cnt[i]].astype(np.uint64)) and np.array_equal(ms[i, :cnt[i]], score[i, :cnt[i]])
+    tl = [[3, 7, 9], [5, 2], [4], [1, 8, 6], [0, 9]]
+    q = sh.make_queries(tl, S.QueryType.Union)
+    ix = S.Index([sh])
+    for offset, length in ((0, 15), (3, 10)):
+        hd, hs, hsrc, hc, ht = comm.search_hybrid_sharded(sh, q, qs, offset, length)
+        ld, ls, lc, lt = sh.search_lexical_batch(q, offset + length)
+        vd, vs, vc, vt = sh.search_vector_batch(qs, offset + length)
+        for i in range(nq):
+            ro = ix.search(tl[i], qs[i], S.QueryType.Union, S.SearchMode.Hybrid, offset, length, normalize_query=False)
+            want_ids = [r.doc_id for r in ro.results]
+            want_sc = np.array([r.score for r in ro.results], np.float32)
+            assert hc[i] == len(want_ids) and hd[i, :hc[i]].tolist() == want_ids
+            assert np.array_equal(hs[i, :hc[i]], want_sc)  # RRF scores: the same f32 operations on the device and on the host
+            assert hsrc[i, :hc[i]].tolist() == [int(r.source) for r in ro.results]
+            assert int(ht[i]) == max(int(lt[i]), int(vt[i])) == ro.result_count_total
+    n, us = comm.profile_read()
+    assert n == 2 + 2 and 0.0 < us < 5e4  # one all-gather per sharded call
+    comm.close()
+
+
+def test_sharded_search_reports_a_local_failure_instead_of_hanging(S, O, both):
+    """a rank whose own search fails (no image; a term its shard does not have) still enters the collective and returns ITS error
+    -- with more ranks the others would return SS_EPEER (the gloo world-2 test drives that through the protocol's mirror)"""
+    from seekstorm_amd import _native as N
+    from seekstorm_amd import distributed as D
+    sh, rows, n_docs, dim = both
+    comm = D.ShardComm(0, 1, 0)
+    empty = S.Shard(0)
+    qs = O.vec_gen(O.VECQ_SEED, 0, 2, dim)
+    with pytest.raises(N.SeekStormHipError) as e:
+        comm.search_vector_sharded(empty, qs, 10)
+    assert e.value.code == -5  # SS_ESTATE
+    q = sh.make_queries([[3, 7], [5]], S.QueryType.Union)
+    q["term"][1][0] = 0xFFFFF0  # not a term of this shard
+    with pytest.raises(N.SeekStormHipError) as e:
+        comm.search_lexical_sharded(sh, q, 10)
+    assert e.value.code == -1
+    # the communicator is still usable afterwards
+    q = sh.make_queries([[3, 7], [5]], S.QueryType.Union)
+    md, ms, mc, mt = comm.search_lexical_sharded(sh, q, 10)
+    d, s_, c, t = sh.search_lexical_batch(q, 10)
+    assert np.array_equal(mc, c) and np.array_equal(mt, t) and np.array_equal(ms, s_)
+    assert N.lib().ss_strerror(-6).decode().startswith("a collective search failed")
+    empty.close()
+    comm.close()
+
+
+def test_i8_euclidean_with_scales_needs_both_norms(S, O):
+    """euclidean_i8_quantized = max(0, n1 + n2 - 2 dot s1 s2): with scales but without the record norms (ss_vec_set_row_norms) or
+    the query norm the ranking would silently be wrong -- the search refuses instead (the reference always carries both norms)"""
+    from seekstorm_amd import _native as N
+    rows = O.quantize_i8(O.vec_gen(5, 0, 2000, 64))
+    q8 = O.quantize_i8(O.vec_gen(6, 0, 2, 64))
+    sh = S.Shard(0)
+    sh.set_vector_similarity("euclidean")
+    scale = np.full(2000, 0.5, np.float32)
+    sh.upload_vectors_i8(rows, row_scale=scale)
+    L = N.lib()
+    doc = np.zeros((2, 5), np.uint32); sc = np.zeros((2, 5), np.float32); cnt = np.zeros(2, np.uint32); tot = np.zeros(2, np.uint64)
+    qscale = np.full(2, 0.25, np.float32)
+    qnorm = np.full(2, 3.0, np.float32)
+    args = lambda qn: (sh._h, 2, q8.ctypes.data_as(C.c_void_p), N.ptr(qscale, N.f32p), qn, 5, N.FLT_MIN_NEG, None, N.ptr(doc, N.u32p),
+                       N.ptr(sc, N.f32p), N.ptr(cnt, N.u32p), N.ptr(tot, N.u64p), None)
+    assert L.ss_vec_search_i8_euclid(*args(N.ptr(qnorm, N.f32p))) == -5  # SS_ESTATE: no record norms yet
+    sh.set_row_norms(np.full(2000, 2.0, np.float32))
+    assert L.ss_vec_search_i8_euclid(*args(None)) == -1                  # SS_EINVAL: no query norm
+    assert L.ss_vec_search_i8_euclid(*args(N.ptr(qnorm, N.f32p))) == 0
+    sh.close()

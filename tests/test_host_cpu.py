@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in seekstorm_hip.h but not exported"
     bound = {s[0] for s in N.SYMBOLS}
     assert set(declared) == bound, (set(declared) ^ bound)
-    assert N.lib().ss_abi_version() == 2
+    assert N.lib().ss_abi_version() == 3
     assert N.lib().ss_strerror(-4).decode().startswith("not supported")
 
 
@@ -233,3 +233,68 @@ def test_two_process_gloo_gather_merge_equals_single_process():
         od, os_, _ = O.merge(2, cat["lex"], cat["vec"], 0, k)
         gd, gs = got[0]["hyb"][qi]
         assert gd == [int(x) for x in od] and np.allclose(gs, os_, rtol=1e-6)
+
+
+# ------------------------------------------------------------------ world_size-2 gloo: the ss_*_search_sharded exchange protocol
+def _worker_exchange(rank, world, port, nq, k, seed, fail_rank, q):
+    import torch
+    import torch.distributed as dist
+    from seekstorm_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lists = _fake_shard_lists(world, nq, k, seed)
+    (ld, ls, lc), (vd, vs, vc) = lists[rank]
+    rng = np.random.default_rng(seed + 100 * rank)
+    lt, vt = rng.integers(0, 10**6, nq), rng.integers(0, 10**6, nq)
+    T = torch.from_numpy
+    res = {}
+    hyb, tot = D.search_hybrid_exchanged((T(ld), T(ls), T(lc)), (T(vd), T(vs), T(vc)), lt, vt, 2, k - 2)
+    res["hyb"] = [(np.asarray(a).tolist(), np.asarray(b).tolist()) for a, b, *_ in hyb]
+    res["tot"] = tot.tolist()
+    res["own"] = (lt.tolist(), vt.tolist())
+    # a rank whose own search failed still enters the collective; EVERY rank then reports the failure, none blocks
+    try:
+        D.search_hybrid_exchanged((T(ld), T(ls), T(lc)), (T(vd), T(vs), T(vc)), lt, vt, 0, k, local_error=-5 if rank == fail_rank else 0)
+        res["fail"] = "no error"
+    except D.PeerError as e:
+        res["fail"] = str(e)
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_process_gloo_hybrid_exchange_in_one_gather():
+    """Index-level hybrid merge over two ranks through the one-gather protocol of ss_hybrid_search_sharded (lists of both modes,
+    totals and a status word in ONE collective): equal to the oracle's merge of the concatenated lists on every rank; totals =
+    sum over the shards of max(lexical, vector); a failing rank makes every rank fail instead of hanging the others"""
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    world, nq, k, seed = 2, 4, 12, 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_exchange, args=(r, world, port, nq, k, seed, 1, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0]["hyb"] == got[1]["hyb"] and got[0]["tot"] == got[1]["tot"]
+    lists = _fake_shard_lists(world, nq, k, seed)
+    for qi in range(nq):
+        cat = []
+        for mi in range(2):
+            ids, sc = [], []
+            for s in range(world):
+                doc, score, cnt = lists[s][mi]
+                n = int(cnt[qi])
+                ids += [int(x) * world + s for x in doc[qi, :n]]
+                sc += [float(x) for x in score[qi, :n]]
+            cat.append((ids, sc))
+        od, os_, _ = O.merge(2, cat[0], cat[1], 2, k - 2)
+        gd, gs = got[0]["hyb"][qi]
+        assert gd == [int(x) for x in od] and np.allclose(gs, os_, rtol=1e-6)
+        assert got[0]["tot"][qi] == sum(max(got[r]["own"][0][qi], got[r]["own"][1][qi]) for r in range(world))
+    assert "local search failed" in got[1]["fail"] and "peer" in got[0]["fail"]
