@@ -506,6 +506,11 @@ int ss_topk_merge_dev(int device, uint32_t n_queries, uint32_t n_shards, uint32_
  * 32-bit words -- a single all-gather per batch (latency bound: three collectives cost three latencies) */
 int ss_topk_merge_dev_packed(int device, uint32_t n_queries, uint32_t n_shards, uint32_t k, const uint32_t* d_packed,
                              uint64_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, void* stream);
+/* the WHOLE concatenation of the gathered lists, sorted: outputs [n_queries][n_shards * k] -- what the RRF ranks of a hybrid
+ * search over several shards run over (search.rs:1962-2035 sorts the appended lists untruncated); feeds ss_rrf_merge_dev with
+ * k_lex / k_vec = n_shards * k.  n_shards * k <= 8192. */
+int ss_topk_concat_dev_packed(int device, uint32_t n_queries, uint32_t n_shards, uint32_t k, const uint32_t* d_packed,
+                              uint64_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, void* stream);
 /* ---- the exchange itself, behind the ABI (RCCL over xGMI; replaces search.rs:1875-1940 + 2098-2119 for shards on different
  * GPUs).  A communicator is one rank of a group of shards, rank = shard id (global id = local * n_ranks + rank, search.rs:1671).
  *   one process per GPU : rank 0 calls ss_comm_unique_id and hands the 128 bytes to the other ranks (any channel: MPI,

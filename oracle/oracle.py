@@ -60,6 +60,10 @@ def lib():
     L.so_lex_term_postings.restype = C.c_uint64
     L.so_lex_term_postings.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, u32p, u16p, C.c_uint64]
     L.so_vec_gen.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, f32p]
+    L.so_vec_gen_strided.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, f32p]
+    L.so_vec_gen_strided.restype = None
+    L.so_geom06.argtypes = [C.c_uint32]
+    L.so_geom06.restype = C.c_uint32
     L.so_shard_build.restype = C.c_void_p
     L.so_shard_build.argtypes = [C.c_uint64, u8p, C.c_uint32, u64p, u32p, u16p]
     L.so_shard_free.argtypes = [C.c_void_p]
@@ -170,6 +174,13 @@ def lex_corpus(n_docs, terms, seed=LEX_SEED, thresholds=None):
 def vec_gen(seed, r0, n, dim, normalize=True):
     out = np.empty((n, dim), np.float32)
     lib().so_vec_gen(seed, r0, n, dim, 1 if normalize else 0, _p(out, f32p))
+    return out
+
+
+def vec_gen_strided(seed, r0, stride, n, dim, normalize=True):
+    """rows r0, r0 + stride, ...: one shard's rows of a partitioned generator stream"""
+    out = np.empty((n, dim), np.float32)
+    lib().so_vec_gen_strided(seed, r0, stride, n, dim, 1 if normalize else 0, _p(out, f32p))
     return out
 
 

@@ -62,6 +62,16 @@ uint64_t so_h(uint64_t seed, uint64_t a, uint64_t b) {
 void so_lex_doclen(uint64_t seed, uint64_t d0, uint64_t n, const uint8_t* tab, uint8_t* out) {
   for (uint64_t i = 0; i < n; i++) out[i] = tab[so_h(seed, 0, d0 + i) >> 54];
 }
+/* tf - 1 of a synthetic posting: geometric with p = 0.6 (tf = 1 + min(geom(p = 0.6), 254)), integer-exact so that the
+ * device generator reproduces it bit for bit: P(j >= m) = 0.4^m, j = how many of floor(0.4^m * 2^32), m = 1.., lie above u */
+uint32_t so_geom06(uint32_t u) {
+  static const uint32_t T[24] = {1717986918u, 687194767u, 274877906u, 109951162u, 43980465u, 17592186u, 7036874u, 2814749u,
+                                 1125899u,    450359u,    180143u,    72057u,     28823u,    11529u,    4611u,    1844u,
+                                 737u,        295u,       118u,       47u,        18u,       7u,        3u,       1u};
+  uint32_t j = 0;
+  while (j < 24u && u < T[j]) j++;
+  return j;
+}
 uint64_t so_lex_term_postings(uint64_t seed, uint32_t term, uint32_t thresh32, uint64_t n_docs,
                               uint32_t* out_docs, uint16_t* out_tfs, uint64_t cap) {
   uint64_t c = 0;
@@ -69,9 +79,8 @@ uint64_t so_lex_term_postings(uint64_t seed, uint32_t term, uint32_t thresh32, u
     uint64_t hv = so_h(seed, (uint64_t)term + 1u, d);
     if ((uint32_t)(hv >> 32) < thresh32) {
       if (out_docs && c < cap) {
-        uint32_t lo = (uint32_t)hv | 0x80000000u;
         out_docs[c] = (uint32_t)d;
-        out_tfs[c] = (uint16_t)(1u + (uint32_t)__builtin_ctz(lo));
+        out_tfs[c] = (uint16_t)(1u + so_geom06((uint32_t)hv));
       }
       c++;
     }
@@ -97,6 +106,11 @@ void so_vec_gen(uint64_t seed, uint64_t r0, uint64_t n, uint32_t dim, int normal
     }
     if (normalize) so_normalize_f32(row, dim);
   }
+}
+
+/* rows r0, r0 + stride, ...: the rows of ONE shard of a partitioned stream (row g -> shard g % S) without the others */
+void so_vec_gen_strided(uint64_t seed, uint64_t r0, uint64_t stride, uint64_t n, uint32_t dim, int normalize, float* out) {
+  for (uint64_t r = 0; r < n; r++) so_vec_gen(seed, r0 + r * stride, 1, dim, normalize, out + r * dim);
 }
 
 /* ------------------------------------------------------------------ shard model */

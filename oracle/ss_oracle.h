@@ -52,6 +52,8 @@ uint64_t so_lex_term_postings(uint64_t seed, uint32_t term, uint32_t thresh32, u
                               uint32_t* out_docs, uint16_t* out_tfs, uint64_t cap);
 /* vector rows [r0,r0+n) x dim, uniform(-1,1) then normalize_f32 semantics */
 void so_vec_gen(uint64_t seed, uint64_t r0, uint64_t n, uint32_t dim, int normalize, float* out);
+void so_vec_gen_strided(uint64_t seed, uint64_t r0, uint64_t stride, uint64_t n, uint32_t dim, int normalize, float* out);
+uint32_t so_geom06(uint32_t u); /* tf - 1 of a synthetic posting: geometric p = 0.6 from 32 hash bits */
 
 /* ---- lexical shard model (index.rs:770-860, compress_postinglist.rs:240-332) ---- */
 typedef struct so_shard so_shard;

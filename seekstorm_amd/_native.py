@@ -147,6 +147,8 @@ SYMBOLS = [
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("ss_topk_merge_dev_packed", C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p]),
+    ("ss_topk_concat_dev_packed", C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]),
     ("ss_comm_unique_id", C.c_int, [C.c_void_p]),
     ("ss_comm_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     ("ss_comm_create_all", C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),

@@ -123,6 +123,16 @@ int ssi_topk_merge_launch(int device, uint32_t nq, uint32_t S, uint32_t k, const
   return SS_OK;
 }
 
+// the WHOLE concatenation, sorted: [n_queries][n_shards * k] -- what the RRF ranks of a hybrid search over several shards run
+// over (search.rs:1962-2035 sorts the appended per-shard lists, untruncated); feeds ss_rrf_merge_dev with k_lex = n_shards * k
+extern "C" int ss_topk_concat_dev_packed(int device, uint32_t n_queries, uint32_t n_shards, uint32_t k, const uint32_t* d_packed,
+                                         uint64_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, void* stream) {
+  if (!d_packed || !d_out_doc || !d_out_score || !d_out_count) return SS_EINVAL;
+  const size_t nk = (size_t)n_queries * k, stride = 2 * nk + n_queries;
+  return ssi_topk_merge_launch(device, n_queries, n_shards, k, d_packed, (const float*)(d_packed + nk), d_packed + 2 * nk, stride, stride,
+                               n_shards * k, d_out_doc, d_out_score, d_out_count, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Hybrid fusion on device: reciprocal rank fusion of a batch's lexical and vector result lists (search.rs:1962-2035) and
 // the final sort / offset / length (2098-2119), so that a batched hybrid search never leaves the GPU between the two

@@ -189,6 +189,13 @@ int ss_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen, uint32_t
 int ss_bm25_upload_positions(ss_shard* s, uint64_t n_docs, const uint8_t* doclen, uint32_t n_terms, const uint64_t* offs,
                              const uint32_t* docs, const uint16_t* tfs, const uint16_t* positions, uint64_t n_positions) {
   if (n_positions && !positions) return SS_EINVAL;
+  // the positions array must hold exactly sum(tf) entries -- checked BEFORE anything is built or read: the walk over the
+  // postings indexes it by the running sum of the tfs
+  if (!offs || n_terms == 0) return SS_EINVAL;
+  if (offs[n_terms] && !tfs) return SS_EINVAL;
+  uint64_t need = 0;
+  for (uint64_t j = offs[0]; j < offs[n_terms]; j++) need += tfs[j];
+  if (need != n_positions || (need && !positions)) return SS_EINVAL;
   int rc = ssi_bm25_upload(s, n_docs, doclen, n_terms, offs, docs, tfs, 0);
   if (rc) return rc;
   return ssi_bm25_attach_positions(s, offs, docs, tfs, positions, n_positions);

@@ -62,7 +62,7 @@ static void fill_comp(float avgdl, float* comp) {
   }
 }
 constexpr int SS_COMP_N = 256;
-// the device generator's postings have tf <= 32 (1 + ctz of a 32-bit word): their codes come from a host-computed table
+// the device generator's postings have tf <= 25 (1 + a geometric draw from 32 hash bits, lex_geom06): their codes come from a host-computed table
 // [33][256] so that no float arithmetic of the weight runs on the device (the host's is the reference's, bit for bit)
 constexpr int SS_SYNTH_TF_MAX = 32;
 // lists that can meet the all_terms_frequent condition (posting_count / indexed_doc_count >= 0.5 in f32, intersection.rs:
@@ -337,6 +337,7 @@ int ssi_bm25_upload_positions(ss_shard* s, const uint64_t* offs, const uint32_t*
       const u64 lim = ((u64)sb + 1) << BM_SUB_LOG2;
       u64 n = 0;
       for (; j < offs[t + 1] && docs[j] < lim; j++, n++) {
+        if (total + rel + tfs[j] > n_positions) return SS_EINVAL;  // never read past the caller's array (index.bin path: counts come from the file)
         for (uint32_t x = 1; x < tfs[j]; x++)
           if (positions[total + rel + x] <= positions[total + rel + x - 1]) return SS_EINVAL;  // ascending inside a posting
         rel += tfs[j];
@@ -372,6 +373,19 @@ __global__ void lex_doclen_kernel(uint8_t* __restrict__ doclen, u64 seed, u64 n_
   if ((threadIdx.x & 63) == 0 && v) atomicAdd(psum, v);
 }
 
+// tf - 1 of a synthetic posting: geometric with p = 0.6 (SURVEY 8d's C2 corpus: tf = 1 + min(geom(0.6), 254)) from 32 hash
+// bits, integer-exact (the host-side generator of the tests draws the same value): P(j >= m) = 0.4^m, j = how many of the
+// thresholds floor(0.4^m * 2^32), m = 1 .. 24, lie above u.  tf <= 25.
+__device__ __forceinline__ uint32_t lex_geom06(uint32_t u) {
+  constexpr uint32_t T[24] = {1717986918u, 687194767u, 274877906u, 109951162u, 43980465u, 17592186u, 7036874u, 2814749u,
+                              1125899u,    450359u,    180143u,    72057u,     28823u,    11529u,    4611u,    1844u,
+                              737u,        295u,       118u,       47u,        18u,       7u,        3u,       1u};
+  uint32_t j = 0;
+#pragma unroll
+  for (int m = 0; m < 24; m++) j += u < T[m] ? 1u : 0u;
+  return j;
+}
+
 // one wave per (term, sub-block): count / fill postings in ascending doc order.
 // !FILL: sub[t][sb+1] = padded units (for the exclusive scan), cnt[t] += postings.  FILL: postings + zero padding.
 template <bool FILL>
@@ -400,8 +414,7 @@ __global__ void lex_gen_kernel(u64 seed, u64 n_docs, uint32_t n_terms, uint32_t 
     u64 m = __ballot(present);
     if (FILL && present) {
       uint32_t pos = run + __popcll(m & ((1ull << lane) - 1ull));
-      uint32_t lo = (uint32_t)hv | 0x80000000u;
-      uint32_t tf = 1u + (uint32_t)__builtin_ctz(lo);
+      uint32_t tf = 1u + lex_geom06((uint32_t)hv);
       uint32_t code = wcode[(tf << 8) + doclen[d]];
       if (flagged[t]) code = (code & ~1u) | (tf < 10u ? 1u : 0u);
       post[base + pos] = bm_pack((uint32_t)(d & (BM_SUB - 1)), code);

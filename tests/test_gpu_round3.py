@@ -119,3 +119,25 @@ def test_i8_euclidean_with_scales_needs_both_norms(S, O):
     assert L.ss_vec_search_i8_euclid(*args(None)) == -1                  # SS_EINVAL: no query norm
     assert L.ss_vec_search_i8_euclid(*args(N.ptr(qnorm, N.f32p))) == 0
     sh.close()
+
+
+def test_upload_positions_checks_the_array_length_first(S, O):
+    """ss_bm25_upload_positions with fewer positions than sum(tf), or none at all: SS_EINVAL before any posting is walked (the
+    walk indexes the array by the running sum of the tfs), and no image is left behind"""
+    from seekstorm_amd import _native as N
+    n_docs = 5000
+    dl = O.lex_doclen(n_docs)
+    offs, docs, tfs = O.lex_corpus(n_docs, [3000, 3600])
+    tfs = np.maximum(tfs, 2).astype(np.uint16)  # every posting has >= 2 positions
+    need = int(tfs.sum())
+    pos = np.concatenate([np.arange(1, t + 1, dtype=np.uint16) for t in tfs])
+    sh = S.Shard(0)
+    L = N.lib()
+    up = lambda p, n: L.ss_bm25_upload_positions(sh._h, n_docs, N.ptr(dl, N.u8p), 2, N.ptr(offs, N.u64p), N.ptr(docs, N.u32p), N.ptr(tfs, N.u16p), p, n)
+    assert up(N.ptr(pos[:need // 2].copy(), N.u16p), need // 2) == -1
+    assert up(None, 0) == -1
+    assert up(None, need) == -1
+    n, a, t, p = C.c_uint64(), C.c_float(), C.c_uint32(), C.c_uint64()
+    assert L.ss_bm25_info(sh._h, C.byref(n), C.byref(a), C.byref(t), C.byref(p)) == -5  # SS_ESTATE: nothing was built
+    assert up(N.ptr(pos, N.u16p), need) == 0
+    sh.close()
