@@ -6,7 +6,9 @@ One C-ABI call = one batch of 1000 resolved queries through ss_bm25_search_dev (
 one "step" = --calls-per-step (default 200) such calls, so that the timed region (exactly --steps steps) covers >= 200
 batches and >= 2 s (SURVEY 8d protocol).  Secondary legs in the same JSON line: the exhaustive strategy (the kernel that
 streams SURVEY 8d's algorithmic bytes), TopkCount, C3 (10 M x 768 f32 cosine top-100, batch 64) + i8, C4 hybrid, ANN,
-host-pointer end-to-end rates, latencies (>= 200 samples), full-size parity against the oracle, and the CPU baseline
+host-pointer end-to-end rates, latencies (>= 1000 samples), concurrent single-query callers through the C++ mirror (T = 64 / 256
+threads), the multi-shard entry points (one all-gather per call, allgather_us), full-size parity against the oracle on ALL queries
+of the batches, and the CPU baseline
 (the oracle's reference-structured dispatch, union_docid_3, timed on the host cores).
 
 Multi-GPU (SURVEY 8e, weak scaling): one process per GPU; rank r holds shard r of ONE generator stream of
@@ -115,7 +117,9 @@ def main():
     ap.add_argument("--no-fields", action="store_true", help="skip the multi-field (BM25F) leg")
     ap.add_argument("--quick", action="store_true", help="profiling runs: few calls per leg, no cpu / parity legs")
     ap.add_argument("--cpu-seconds", type=float, default=5.0)
-    ap.add_argument("--parity-queries", type=int, default=32)
+    ap.add_argument("--parity-queries", type=int, default=1000, help="C2 queries checked against the full-size oracle (all of the batch by default)")
+    ap.add_argument("--cpu-queries", type=int, default=32, help="C2 queries the cpu_baseline leg cycles through")
+    ap.add_argument("--no-concurrent", action="store_true", help="skip the concurrent-callers legs (T host threads, one query per call)")
     args = ap.parse_args()
     if args.quick:
         args.no_cpu = args.no_parity = True
@@ -159,7 +163,7 @@ def main():
     assert sptr.value, "expected a non-null HIP stream handle"
     sh = S.Shard(local_rank, shard_id=rank)
     sh.synth_partition(rank, world)
-    comm = D.ShardComm(rank, world, local_rank) if world > 1 else None  # RCCL communicator behind the C ABI (ss_comm_create)
+    comm = D.ShardComm(rank, world, local_rank)  # RCCL communicator behind the C ABI (ss_comm_create); one rank at N = 1
     merged = {}
 
     def timed(step_fn, steps, warmup):
@@ -228,21 +232,30 @@ def main():
         q_np = sh.make_queries(term_lists, S.QueryType.Union)
         nq = len(q_np)
         q_dev = torch.from_numpy(q_np.view(np.uint8).reshape(nq, -1).copy()).to(dev)
+        # the timed regions rotate through NB different 1000-query batches (batch 0 = the one every check refers to)
+        NB = 8 if not args.quick else 2
+        rot_lists = [term_lists] + [make_c2_queries(O, args.queries, seed=5000 + i)[0] for i in range(1, NB)]
+        rot_dev = [q_dev] + [torch.from_numpy(sh.make_queries(tl_, S.QueryType.Union).view(np.uint8).reshape(nq, -1).copy()).to(dev) for tl_ in rot_lists[1:]]
+        rot_i = [0]
         o_doc = torch.empty((nq, k), dtype=torch.int32, device=dev)
         o_score = torch.empty((nq, k), dtype=torch.float32, device=dev)
         o_cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
         o_tot = torch.empty((nq,), dtype=torch.int64, device=dev)
         OPS = 2 | (3 << 8)  # unions of 3 terms, no NOT terms (validated on the device by bm_expand_kernel)
 
-        def bm_call(n=nq, rt=N.RT_TOPK):
-            N.check(L.ss_bm25_search_dev(sh._h, n, q_dev.data_ptr(), k, rt, OPS, o_doc.data_ptr(), o_score.data_ptr(),
+        def bm_call(n=nq, rt=N.RT_TOPK, qd=None):
+            N.check(L.ss_bm25_search_dev(sh._h, n, (q_dev if qd is None else qd).data_ptr(), k, rt, OPS, o_doc.data_ptr(), o_score.data_ptr(),
                                          o_cnt.data_ptr(), o_tot.data_ptr(), sptr), "ss_bm25_search_dev")
             if world > 1:  # one all-gather of the per-shard top-k over RCCL + identical merge on every rank, behind the C ABI
                 merged["bm25"] = comm.allgather_merge(o_doc[:n], o_score[:n], o_cnt[:n], k, sptr)
 
+        def bm_rot_call():
+            bm_call(qd=rot_dev[rot_i[0] % NB])
+            rot_i[0] += 1
+
         def bm_step():
             for _ in range(args.calls_per_step):
-                bm_call()
+                bm_rot_call()
 
         # exact union sizes for the roofline's "1 B per scored candidate" term: one untimed TopkCount pass (exhaustive scan)
         sh.set_strategy(N.BM25_EXHAUSTIVE)
@@ -253,12 +266,19 @@ def main():
         ref_scores = o_score.cpu().numpy().copy()
         ref_docs = o_doc.cpu().numpy().copy()
         # algorithmic bytes: sum_t df_t*(2B id + 1B tf) + 1B per scored candidate + 4B per (term, block) + 8B*k
-        uniq = sorted({t for tl in term_lists for t in tl})
+        uniq = sorted({t for tl_ in rot_lists for tl in tl_ for t in tl})
         dfm = dict(zip(uniq, (int(x) for x in sh.posting_count(uniq))))
         n_blocks = (args.docs + 65535) // 65536
-        bytes_q = np.array([sum(dfm[t] for t in tl) * 3 + int(tot[i]) + 4 * n_blocks * len(tl) + 8 * k
-                            for i, tl in enumerate(term_lists)], np.float64)
-        bytes_launch = float(bytes_q.sum())
+
+        def batch_bytes(tls, totals):
+            return np.array([sum(dfm[t] for t in tl) * 3 + int(totals[i]) + 4 * n_blocks * len(tl) + 8 * k for i, tl in enumerate(tls)], np.float64)
+        bytes_q = batch_bytes(term_lists, tot)
+        rot_bytes = [float(bytes_q.sum())]
+        for b in range(1, NB):  # exact union sizes of the other batches of the rotation: one untimed TopkCount pass each
+            bm_call(rt=N.RT_TOPKCOUNT, qd=rot_dev[b])
+            torch.cuda.synchronize()
+            rot_bytes.append(float(batch_bytes(rot_lists[b], o_tot.cpu().numpy().astype(np.int64)).sum()))
+        bytes_launch = float(np.mean(rot_bytes))  # the timed launches rotate through the NB batches evenly
 
         def check_strategy(strategy):
             sh.set_strategy(strategy)
@@ -270,7 +290,7 @@ def main():
         check_strategy(N.BM25_EXHAUSTIVE)
         sh.profile(True)
         sh.profile_read(0, reset=True)
-        ex_n, ex_dt = timed_for(bm_call)
+        ex_n, ex_dt = timed_for(bm_rot_call)
         ex_launches, ex_kms = sh.profile_read(0, reset=True)
         ex_kms /= max(ex_launches, 1)
         # HIP events are recorded around every launch while profiling is on: the warm-up launches of timed_for are averaged in
@@ -328,8 +348,8 @@ def main():
                                  "list drives, the other is probed; counts are a by-product)", "mean_matches": float(and_ref[1].mean())}
         ach_alg = bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         ex_ach = bytes_launch / (ex_kms * 1e-3) / 1e9 if ex_kms > 0 else 0.0
-        lat_batch = latencies(bm_call, 200)
-        lat_one = latencies(lambda: bm_call(1), 400)
+        lat_batch = latencies(bm_rot_call, 1000)
+        lat_one = latencies(lambda: bm_call(1), 1000)
 
         # (4) end to end through the host-pointer entry point: H2D of the queries + kernels + D2H of the results + sync
         h_doc = np.empty((nq, k), np.uint32); h_score = np.empty((nq, k), np.float32)
@@ -340,8 +360,8 @@ def main():
                                      N.ptr(h_cnt, N.u32p), N.ptr(h_tot, N.u64p)), "ss_bm25_search")
         bm_host_call()
         assert np.array_equal(h_score, ref_scores), "host-pointer entry point differs from the device-pointer one"
-        e2e_lat = host_latencies(bm_host_call, 200)
-        e2e_one = host_latencies(lambda: bm_host_call(1), 400)
+        e2e_lat = host_latencies(bm_host_call, 1000)
+        e2e_one = host_latencies(lambda: bm_host_call(1), 1000)
         end_to_end = {"value": nq / (np.mean(e2e_lat) * 1e-3), "unit": "queries/s", "entry_point": "ss_bm25_search (host pointers: H2D queries, "
                       "kernels, D2H results, sync; host clock)", "batch_ms_p50": pct(e2e_lat, 50), "batch_ms_p99": pct(e2e_lat, 99),
                       "single_query_ms_p50": pct(e2e_one, 50), "single_query_ms_p99": pct(e2e_one, 99), "samples": len(e2e_lat)}
@@ -477,20 +497,45 @@ def main():
 
         # ---- full-size parity (C2): a sample of the batch against the oracle on the same 10 M-doc shard, regenerated on
         # the host -- doc ids outside the tie band, scores 1e-4 relative, exact result_count_total; AUTO and EXHAUSTIVE
-        c2_oracle = None
         if rank == 0 and not args.no_parity:
             t0 = time.perf_counter()
             ns = min(args.parity_queries, nq)
-            ans, osh, remap = F.c2_answers(args.docs, term_lists[:ns], th, k, O.OP_OR, O.RT_TOPKCOUNT, part=(rank, world))
-            for i in range(ns):
-                od, os_, otot = ans[i]
-                assert int(tot[i]) == otot, f"C2 full size: result_count_total of query {i}: {int(tot[i])} vs oracle {otot}"
-                F.check_topk(ref_docs[i], ref_scores[i], od, os_, 1e-4, f"C2 full size, exhaustive, query {i}")
-                F.check_topk(o_doc[i].cpu().numpy(), sc[i], od, os_, 1e-4, f"C2 full size, auto, query {i}")
+            ans = F.c2_answers_chunked(args.docs, term_lists[:ns], th, k, O.OP_OR, O.RT_TOPKCOUNT, part=(rank, world))
+            runs = {}
+            for sname, strat in (("exhaustive", N.BM25_EXHAUSTIVE), ("auto", N.BM25_AUTO)):
+                sh.set_strategy(strat)
+                for rname, rt_ in (("Topk", N.RT_TOPK), ("TopkCount", N.RT_TOPKCOUNT)):
+                    N.check(L.ss_bm25_search_dev(sh._h, nq, q_dev.data_ptr(), k, rt_, OPS, o_doc.data_ptr(), o_score.data_ptr(), o_cnt.data_ptr(),
+                                                 o_tot.data_ptr(), sptr), "ss_bm25_search_dev")  # this shard's own lists (no exchange)
+                    torch.cuda.synchronize()
+                    runs[(sname, rname)] = (o_doc.cpu().numpy().copy(), o_score.cpu().numpy().copy(), o_tot.cpu().numpy().astype(np.int64))
+            for (sname, rname), (gd, gs, gt) in runs.items():
+                for i in range(ns):
+                    od, os_, otot = ans[i]
+                    F.check_topk(gd[i], gs[i], od, os_, 1e-4, f"C2 full size, {sname} {rname}, query {i}")
+                    if rname == "TopkCount":
+                        assert int(gt[i]) == otot, f"C2 full size: result_count_total of query {i}: {int(gt[i])} vs oracle {otot}"
             parity["c2"] = {"queries": ns, "docs": args.docs, "checked": "top-10 doc ids outside the tie band, scores rtol 1e-4, exact "
-                            "result_count_total; strategies AUTO and EXHAUSTIVE; oracle = so_search_lex_ref on the host-regenerated shard",
-                            "seconds": time.perf_counter() - t0}
-            c2_oracle = (osh, remap, ns)
+                            "result_count_total; strategies AUTO and EXHAUSTIVE x Topk and TopkCount; oracle = so_search_lex_ref "
+                            "(union_docid_3) on the host-regenerated shard", "seconds": time.perf_counter() - t0}
+            # 2-term intersections of the AND leg: exact counts, ids outside ties, both strategies
+            if inter is not None:
+                t0 = time.perf_counter()
+                na = min(256, nq)
+                and_lists = [[int(x) for x in qi_np["term"][i][:2]] for i in range(na)]
+                aans = F.c2_answers_chunked(args.docs, and_lists, th, k, O.OP_AND, O.RT_TOPKCOUNT, part=(rank, world), chunk=128)
+                for sname, strat in (("exhaustive", N.BM25_EXHAUSTIVE), ("auto", N.BM25_AUTO)):
+                    sh.set_strategy(strat)
+                    and_call()
+                    torch.cuda.synchronize()
+                    gd, gs, gc, gt = o_doc.cpu().numpy(), o_score.cpu().numpy(), o_cnt.cpu().numpy(), o_tot.cpu().numpy().astype(np.int64)
+                    for i in range(na):
+                        od, os_, otot = aans[i]
+                        assert int(gt[i]) == otot, f"AND full size, {sname}: count of query {i}: {int(gt[i])} vs oracle {otot}"
+                        F.check_topk(gd[i, :gc[i]], gs[i, :gc[i]], od, os_, 1e-4, f"AND full size, {sname}, query {i}")
+                parity["and2"] = {"queries": na, "checked": "exact match counts, top-10 ids outside the tie band, scores rtol 1e-4; AUTO and EXHAUSTIVE",
+                                  "seconds": time.perf_counter() - t0}
+            sh.set_strategy(N.BM25_AUTO)
 
         if rank == 0 and world == 1 and not args.no_cpu:
             # cpu_baseline: the reference's own algorithm for this query shape -- union_docid_3's sub-query decomposition over
@@ -499,11 +544,8 @@ def main():
             # queries on the same corpus.
             from concurrent.futures import ThreadPoolExecutor
             cores = F.host_threads(128)
-            ns = min(args.parity_queries, nq)
-            if c2_oracle is None:
-                _, osh, remap = F.c2_answers(args.docs, term_lists[:ns], th, k, O.OP_OR, O.RT_TOPK)
-            else:
-                osh, remap, ns = c2_oracle
+            ns = min(args.cpu_queries, nq)
+            _, osh, remap = F.c2_answers(args.docs, term_lists[:ns], th, k, O.OP_OR, O.RT_TOPK)
             qs = np.array([[remap[t] for t in tl] for tl in term_lists[:ns]], np.uint32)
             t0 = time.perf_counter()
             one_tp, _, _ = O.bench_lex([osh], qs, O.OP_OR, k, O.RT_TOPK, 0, cores, args.cpu_seconds)
@@ -530,7 +572,6 @@ def main():
                 "published_reference_point": "BASELINE.md section 2: union mean 439 us on 5 M Wikipedia docs, single thread",
                 "seconds": time.perf_counter() - t0}
             del shards
-        c2_oracle = None
 
     # ------------------------------------------------------------------ vector (secondary)
     vec = None
@@ -564,8 +605,8 @@ def main():
         flops = 2.0 * args.dim * args.rows * B  # per pass (2*dim*N per query)
         avg_ms = kms / max(launches, 1)
         ach = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        lat = latencies(vec_call, 200)
-        lat1 = latencies(lambda: vec_call(1), 200)  # <= 32 queries: half of the MFMA work is skipped, the pass is HBM-bound
+        lat = latencies(vec_call, 400)
+        lat1 = latencies(lambda: vec_call(1), 1000)  # <= 32 queries: half of the MFMA work is skipped, the pass is HBM-bound
         hv_doc = np.empty((B, kv), np.uint32); hv_score = np.empty((B, kv), np.float32)
         hv_cnt = np.empty(B, np.uint32); hv_tot = np.empty(B, np.uint64)
 
@@ -594,7 +635,7 @@ def main():
         c3_ref = None
         if rank == 0 and not args.no_parity:
             t0 = time.perf_counter()
-            nsv = 4
+            nsv = B
             c3_ref = F.c3_answers(args.rows, args.dim, qv_np[:nsv], kv, part=(rank, world), slice_rows=32768)
             for i in range(nsv):
                 F.check_topk(ids_all[i], vs_all[i], c3_ref[i][0], c3_ref[i][1], 1e-4, f"C3 full size f32, query {i}")
@@ -665,7 +706,7 @@ def main():
             if rank == 0 and not args.no_parity and c3_ref is not None:
                 t0 = time.perf_counter()
                 nsh = len(c3_ref)
-                lans, _, _ = F.c2_answers(args.docs, term_lists[:nsh], th, kh, O.OP_OR, O.RT_TOPK, part=(rank, world))
+                lans = F.c2_answers_chunked(args.docs, term_lists[:nsh], th, kh, O.OP_OR, O.RT_TOPK, part=(rank, world))
                 for i in range(nsh):
                     nl_, nv_ = int(h_lcnt[i].item()), int(v_cnt[i].item())
                     gl = (h_ldoc[i, :nl_].cpu().numpy(), h_lsc[i, :nl_].cpu().numpy())
@@ -681,6 +722,66 @@ def main():
             hn, dth = timed_for(hyb_call)
             vec["hybrid"] = {"workload": "C4: C2 query i + C3 query i, top-100 each, RRF(0.6), final top-100; batch 64, all on device",
                              "value": B * hn / dth, "unit": "queries/s", "ms_per_call": dth / hn * 1e3, "calls": hn}
+        # ---- the multi-shard entry points: this rank's shard task + ONE all-gather + merge (hybrid: RRF after the gather)
+        # behind the C ABI, host queries in, merged answers out on every rank; with one rank the exchange is the identity.
+        # allgather_us = HIP events around the collective alone (ss_comm_profile).
+        if bm is not None and not args.quick:
+            comm.profile(True)
+            sh.set_strategy(N.BM25_AUTO)
+            sharded = {}
+            qh = np.ascontiguousarray(q_np[:B])
+
+            def leg(name, fn, n_q):
+                fn()
+                comm.profile_read()
+                n_, d_ = timed_for(fn, min_calls=50)
+                nc, us = comm.profile_read()
+                sharded[name] = {"value": n_q * n_ / d_, "unit": "queries/s", "ms_per_call": d_ / n_ * 1e3, "calls": n_, "queries_per_call": n_q,
+                                 "allgather_us": us, "collectives": nc}
+            leg("lexical_top10", lambda: comm.search_lexical_sharded(sh, q_np, k, N.RT_TOPK), nq)
+            leg("vector_top100", lambda: comm.search_vector_sharded(sh, qv_np, kv), B)
+            leg("hybrid_top100", lambda: comm.search_hybrid_sharded(sh, qh, qv_np, 0, 100, N.RT_TOPK), B)
+            comm.profile(False)
+            sharded["note"] = ("ss_bm25_search_sharded / ss_vec_search_sharded / ss_hybrid_search_sharded: host queries in, this rank's shard "
+                               "searched, ONE RCCL all-gather of the lists + totals + status, merge (hybrid: RRF over the cross-shard "
+                               f"concatenations) on the device, merged answers on every rank's host; {world} rank(s); value = merged answers per second")
+            vec["sharded"] = sharded
+
+        # ---- the reference's REAL calling pattern (search.rs:1637-1743: one search per runtime worker, no batched entry point): T host
+        # threads, each issuing ONE query per call through Index::search of the C++ mirror; the C ABI coalesces the concurrent callers
+        # into device batches (ss_shard_set_coalescing).  Host clock around every call.
+        if bm is not None and world == 1 and rank == 0 and not args.quick and not args.no_concurrent:
+            HL = C.CDLL(os.path.join(ROOT, "seekstorm_amd", "lib", "libseekstorm_host.so"))
+            HL.ssh_index_adopt.restype = C.c_void_p
+            HL.ssh_index_adopt.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+            HL.ssh_index_destroy.argtypes = [C.c_void_p]
+            HL.ssh_bench_concurrent.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
+            hs_ = (C.c_void_p * 1)(sh._h)
+            hd_ = (C.c_int * 1)(local_rank)
+            ixp = HL.ssh_index_adopt(1, hs_, hd_)
+            flat = np.array([t for tl in term_lists for t in tl], np.uint32)
+            toff = np.zeros(nq + 1, np.uint32)
+            toff[1:] = np.cumsum([len(tl) for tl in term_lists])
+            conc = {}
+            for name, mode, T, nqq, length in (("lexical_top10_T64", N.MODE_LEXICAL, 64, nq, 10), ("lexical_top10_T256", N.MODE_LEXICAL, 256, nq, 10),
+                                               ("vector_top100_T64", N.MODE_VECTOR, 64, B, 100), ("vector_top100_T256", N.MODE_VECTOR, 256, B, 100),
+                                               ("hybrid_top100_T64", N.MODE_HYBRID, 64, B, 100), ("hybrid_top100_T256", N.MODE_HYBRID, 256, B, 100)):
+                out5 = (C.c_double * 5)()
+                st0 = sh.coalescing_stats()
+                N.check(HL.ssh_bench_concurrent(ixp, mode, T, max(args.min_seconds, 1.0), nqq, flat.ctypes.data, toff.ctypes.data, qv_np.ctypes.data,
+                                                int(S.QueryType.Union), length, N.RT_TOPK, out5), "ssh_bench_concurrent")
+                st1 = sh.coalescing_stats()
+                lb, lq, vb, vq = (st1[i] - st0[i] for i in range(4))
+                conc[name] = {"value": out5[0] / out5[1], "unit": "queries/s", "threads": T, "searches": int(out5[0]), "seconds": out5[1],
+                              "latency_us_p50": out5[2], "latency_us_p99": out5[3], "errors": int(out5[4]),
+                              "mean_lexical_batch": (lq / lb) if lb else None, "mean_vector_batch": (vq / vb) if vb else None}
+                assert out5[4] == 0, f"concurrent leg {name}: {int(out5[4])} searches failed"
+            HL.ssh_index_destroy(ixp)
+            conc["note"] = ("T host threads, each ONE query per call through Index::search (C++ mirror) -> ss_bm25_search / ss_vec_search; the C ABI "
+                            "merges the concurrent callers into device batches (group commit: whoever arrives while a batch runs joins the next "
+                            "one); host clock per call; mean_*_batch = queries per merged device batch")
+            vec["concurrent_callers"] = conc
         if args.rows >= 65536:
             vec["ann"] = ann_leg(False)
         # property checks at full size: sorted, and the scores really are dot products of the returned rows
@@ -693,28 +794,39 @@ def main():
         assert abs(float(r0 @ qv_np[0]) - float(vs[0, 0])) < 1e-4
         if rank == 0 and world == 1 and not args.no_cpu:
             from concurrent.futures import ThreadPoolExecutor
-            # cpu_baseline: AnnMode::All scans of a 1 M-row sample (3 GB, beyond the caches like the full matrix) in the
-            # reference's structure -- throughput: one whole query per worker; latency: one query, rows split over workers
-            M = min(args.rows, 1_000_000)
+            # cpu_baseline: AnnMode::All scans in the reference's structure.  (a) the reference's default execution -- S = cores
+            # document-partitioned shards, one task per shard and query (index.rs:2055-2062, search.rs:1637-1650) -- on the FULL matrix
+            # (10 M x 768 regenerated on the host, 30.7 GB) when the host has the memory: measured, nothing extrapolated;
+            # (b) throughput mode (every core answers whole queries) on a 1 M-row sample, scaled linearly, beside it.
             cores = F.host_threads(128)
+            try:
+                avail_gb = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] / 1e6
+            except Exception:
+                avail_gb = 0.0
+            full = avail_gb > 4.0 * args.dim * args.rows / 1e9 * 1.5
+            M = args.rows if full else min(args.rows, 1_000_000)
             rows = np.empty((M, args.dim), np.float32)
-            cuts = np.linspace(0, M, cores * 2 + 1).astype(np.int64)
+            cuts = np.linspace(0, M, cores * 8 + 1).astype(np.int64)
 
             def gen_slice(i):
                 rows[cuts[i]:cuts[i + 1]] = O.vec_gen(O.VEC_SEED, int(cuts[i]), int(cuts[i + 1] - cuts[i]), args.dim)
+            t0 = time.perf_counter()
             with ThreadPoolExecutor(cores) as ex:
-                list(ex.map(gen_slice, range(cores * 2)))
+                list(ex.map(gen_slice, range(cores * 8)))
+            gen_s = time.perf_counter() - t0
             scale = args.rows / M
-            qps_t, done_t, _ = O.bench_vec(rows, qv_np, kv, 0, cores, args.cpu_seconds)
-            qps_l, done_l, lat = O.bench_vec(rows, qv_np, kv, 1, cores, min(args.cpu_seconds, 5.0))
+            qps_l, done_l, lat = O.bench_vec(rows, qv_np, kv, 1, cores, args.cpu_seconds)
+            Ms = min(M, 1_000_000)
+            qps_t, done_t, _ = O.bench_vec(rows[:Ms], qv_np, kv, 0, cores, args.cpu_seconds)
             vec["cpu_baseline"] = {
-                "value": qps_t / scale, "unit": "queries/s", "cores": cores, "kind": "port",
-                "sample": f"{done_t} top-100 scans of the first {M} rows in {args.cpu_seconds:.0f}s, {cores} threads each answering whole "
-                          f"queries (oracle so_bench_vec: dot_f32_avx2 order + TopK::push); rate divided by {scale:.0f} (linear scan) "
-                          f"to {args.rows} rows",
-                "latency_mode": {"queries_per_s": qps_l / scale, "p50_ms": float(np.percentile(lat, 50)) * scale / 1e3 if len(lat) else None,
-                                 "samples": int(len(lat)),
-                                 "sample": f"one query at a time, the {M} rows split over {cores} workers + merge; scaled x{scale:.0f}"}}
+                "value": qps_l / scale, "unit": "queries/s", "cores": cores, "kind": "port", "rows": int(M), "host_generation_s": gen_s,
+                "sample": (f"{done_l} top-100 queries over {'ALL' if full else 'the first'} {M} rows in {args.cpu_seconds:.0f}s: one query at a time, the rows "
+                           f"split over {cores} workers + merge = the reference's default S = cores shards, one task per shard and query "
+                           f"(oracle so_bench_vec: dot_f32_avx2 order + TopK::push)" + ("" if full else f"; rate divided by {scale:.0f} (linear scan) to {args.rows} rows")),
+                "latency_p50_ms": float(np.percentile(lat, 50)) * scale / 1e3 if len(lat) else None, "latency_samples": int(len(lat)),
+                "throughput_mode_sample": {"queries_per_s": qps_t / (args.rows / Ms), "rows": int(Ms),
+                                           "sample": f"{done_t} scans of a {Ms}-row slice, {cores} threads each answering whole queries; rate divided by "
+                                                     f"{args.rows / Ms:.0f} to {args.rows} rows"}}
             del rows
 
         # ---- the same corpus as Precision::I8 records (quantize_f32_to_i8 of the same rows): HBM-bound stream kernel
@@ -740,7 +852,7 @@ def main():
         assert float(r8.astype(np.int64) @ q8[0].cpu().numpy().astype(np.int64)) == float(vs8[0, 0]), "i8 score is not the integer dot product"
         if rank == 0 and not args.no_parity:
             t0 = time.perf_counter()
-            nsv = 4
+            nsv = B
             ref8 = F.c3_answers(args.rows, args.dim, qv_np[:nsv], kv, part=(rank, world), slice_rows=32768, i8=True)
             for i in range(nsv):
                 assert np.array_equal(vs8[i], ref8[i][1]), f"C3 full size i8: scores of query {i} differ from the oracle (integer dot products: ==)"
@@ -762,9 +874,11 @@ def main():
     if rank == 0:
         prim = bm if bm is not None else vec
         is_bm = bm is not None
-        gen_note = ("synthetic generators follow SURVEY 8d with two integer-exact substitutions (so that host and device generate "
-                    "identical data): tf = 1 + ctz(hash) (geometric p = 0.5, not 0.6); vector components uniform(-1, 1) then "
-                    "normalize_f32 (not Box-Muller)")
+        gen_note = ("synthetic generators follow SURVEY 8d, integer-exact so that host and device generate identical data: tf = 1 + "
+                    "geometric(p = 0.6) drawn from 32 hash bits by thresholds floor(0.4^m 2^32); vector components uniform(-1, 1) "
+                    "then normalize_f32 instead of Box-Muller (f32 log / cos differ between host libm and the device; after "
+                    "normalisation to the unit sphere at dim 768 both give dot products ~ N(0, 1/768), and a brute-force scan does the "
+                    "same work whatever the values)")
         line = {
             "metric": "queries/sec" + (" (BM25 3-term OR top-10)" if is_bm else " (cosine top-100, batch 64)"),
             "value": prim["qps"],
@@ -793,6 +907,7 @@ def main():
             "cpu_baseline": prim.get("cpu_baseline"),
             "latency_ms": prim["latency_ms"],
             "end_to_end": prim.get("end_to_end"),
+            "value_end_to_end": (prim.get("end_to_end") or {}).get("value"),
             "parity_full_size": parity or None,
         }
         if is_bm:
@@ -812,11 +927,14 @@ def main():
                               "cpu_baseline": vec.get("cpu_baseline"), "latency_ms": vec["latency_ms"], "end_to_end": vec.get("end_to_end"),
                               "build_s": vec["build_s"], "rows_per_shard": args.rows, "dim": args.dim, "hybrid": vec.get("hybrid"),
                               "ann": vec.get("ann"), "i8": vec.get("i8")}
+            if vec.get("sharded"):
+                line["sharded"] = vec["sharded"]
+            if vec.get("concurrent_callers"):
+                line["concurrent_callers"] = vec["concurrent_callers"]
         elif vec is not None:
             line["i8"] = vec.get("i8")
         print(json.dumps(line), flush=True)
-    if comm is not None:
-        comm.close()
+    comm.close()
     sh.close()
     if world > 1:
         dist.destroy_process_group()

@@ -141,6 +141,8 @@ int ss_shard_destroy(ss_shard* s) {
   }
   for (int kx = 0; kx < 2; kx++)
     for (auto& pr : s->prof.pending[kx]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  if (s->co_lex.h_pin) (void)hipHostFree(s->co_lex.h_pin);
+  if (s->co_vec.h_pin) (void)hipHostFree(s->co_vec.h_pin);
   (void)hipStreamDestroy(s->stream);
   delete s;
   return SS_OK;
@@ -809,13 +811,18 @@ inline void co_signal(ss_co_req* r, uint32_t st) {
   const uint32_t old = r->state.exchange(st, std::memory_order_acq_rel);
   if (old & 4u) co_futex_wake(&r->state);
 }
-// wait until the state leaves "pending": a short spin (a batch lasts ~0.1-0.3 ms; a sleeping thread costs its leader a
-// system call and itself a wake-up), then the futex
-inline uint32_t co_wait(ss_co_req* r) {
-  for (int i = 0; i < 4000; i++) {
-    const uint32_t v = r->state.load(std::memory_order_acquire);
-    if (v != 0u) return v;
-    __builtin_ia32_pause();
+// wait until the state leaves "pending": a SHORT spin, then the futex.  (Spinning for about a batch's duration -- a sleeping
+// follower costs its leader a system call, ~1.5 us each -- was measured and is wrong for a library: 64 spinning callers ran the
+// process into its CPU quota, 185 K -> 47 K q/s with a p99 of 73 ms, the CFS throttling period; gpurun_out/conc_linger2.log)
+inline uint32_t co_wait(ss_co_req* r, uint32_t spin_us) {
+  const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us);
+  for (;;) {
+    for (int i = 0; i < 64; i++) {
+      const uint32_t v = r->state.load(std::memory_order_acquire);
+      if (v != 0u) return v;
+      __builtin_ia32_pause();
+    }
+    if (std::chrono::steady_clock::now() >= until) break;
   }
   for (;;) {
     uint32_t v = 0u;
@@ -842,38 +849,48 @@ int co_run_vector_one(ss_shard* s, ss_co_req* r) {
 // one merged batch: the members' queries back to back, one search, every member's rows copied to its own buffers
 int co_run_batch(ss_shard* s, ss_coalescer& co, bool lexical, const std::vector<ss_co_req*>& batch) {
   ss_co_req* f = batch[0];
-  uint32_t total = 0;
-  for (ss_co_req* r : batch) total += r->nq;
-  uint32_t kk = 0;
-  for (ss_co_req* r : batch) kk = std::max(kk, r->k);
+  uint32_t total = 0, kk = 0;
+  for (ss_co_req* r : batch) { total += r->nq; kk = std::max(kk, r->k); }
   const uint32_t kw = std::max<uint32_t>(kk, 1u);
   const size_t qbytes = lexical ? sizeof(ss_bm25_query) : (size_t)s->dim * f->elem;
-  co.h_q.resize((size_t)total * qbytes);
-  if (f->qscale) co.h_qscale.resize(total);
-  co.h_doc.resize((size_t)total * kw); co.h_score.resize((size_t)total * kw); co.h_count.resize(total); co.h_total.resize(total);
+  auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
+  const size_t o_q = 0, o_qs = o_q + al((size_t)total * qbytes), o_doc = o_qs + al((size_t)total * 4), o_sc = o_doc + al((size_t)total * kw * 4),
+               o_cnt = o_sc + al((size_t)total * kw * 4), o_tot = o_cnt + al((size_t)total * 4), need = o_tot + al((size_t)total * 8);
+  if (need > co.h_pin_cap) {
+    SS_HIP(hipSetDevice(s->device));
+    if (co.h_pin) (void)hipHostFree(co.h_pin);
+    co.h_pin = nullptr; co.h_pin_cap = 0;
+    const size_t cap = std::max<size_t>(need * 2, 1u << 20);
+    SS_HIP(hipHostMalloc((void**)&co.h_pin, cap, hipHostMallocDefault));
+    co.h_pin_cap = cap;
+  }
+  char* h_q = co.h_pin + o_q;
+  float* h_qs = (float*)(co.h_pin + o_qs);
+  uint32_t* h_doc = (uint32_t*)(co.h_pin + o_doc);
+  float* h_sc = (float*)(co.h_pin + o_sc);
+  uint32_t* h_cnt = (uint32_t*)(co.h_pin + o_cnt);
+  uint64_t* h_tot = (uint64_t*)(co.h_pin + o_tot);
   uint32_t at = 0;
   for (ss_co_req* r : batch) {
-    memcpy(co.h_q.data() + (size_t)at * qbytes, r->q, (size_t)r->nq * qbytes);
-    if (f->qscale) memcpy(co.h_qscale.data() + at, r->qscale, (size_t)r->nq * sizeof(float));
+    memcpy(h_q + (size_t)at * qbytes, r->q, (size_t)r->nq * qbytes);
+    if (f->qscale) memcpy(h_qs + at, r->qscale, (size_t)r->nq * sizeof(float));
     at += r->nq;
   }
   int rc;
   if (lexical)
-    rc = bm25_search_direct(s, total, (const ss_bm25_query*)co.h_q.data(), kk, f->rt, 0, nullptr, co.h_doc.data(), co.h_score.data(),
-                            co.h_count.data(), co.h_total.data());
+    rc = bm25_search_direct(s, total, (const ss_bm25_query*)h_q, kk, f->rt, 0, nullptr, h_doc, h_sc, h_cnt, h_tot);
   else
-    rc = vec_search_host(s, total, co.h_q.data(), f->elem, f->qscale ? co.h_qscale.data() : nullptr, kk, f->thr, nullptr, co.h_doc.data(),
-                         co.h_score.data(), co.h_count.data(), co.h_total.data(), nullptr);
+    rc = vec_search_host(s, total, h_q, f->elem, f->qscale ? h_qs : nullptr, kk, f->thr, nullptr, h_doc, h_sc, h_cnt, h_tot, nullptr);
   if (rc != SS_OK) return rc;
   at = 0;
   for (ss_co_req* r : batch) {
     for (uint32_t i = 0; i < r->nq; i++) {
       if (r->k) {
-        memcpy(r->out_doc + (size_t)i * r->k, co.h_doc.data() + (size_t)(at + i) * kk, (size_t)r->k * sizeof(uint32_t));
-        memcpy(r->out_score + (size_t)i * r->k, co.h_score.data() + (size_t)(at + i) * kk, (size_t)r->k * sizeof(float));
+        memcpy(r->out_doc + (size_t)i * r->k, h_doc + (size_t)(at + i) * kk, (size_t)r->k * sizeof(uint32_t));
+        memcpy(r->out_score + (size_t)i * r->k, h_sc + (size_t)(at + i) * kk, (size_t)r->k * sizeof(float));
       }
-      r->out_count[i] = std::min(co.h_count[at + i], r->k);
-      r->out_total[i] = co.h_total[at + i];
+      r->out_count[i] = std::min(h_cnt[at + i], r->k);
+      r->out_total[i] = h_tot[at + i];
     }
     r->rc = SS_OK;
     at += r->nq;
@@ -892,19 +909,34 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
   std::vector<ss_co_req*> batch;
   for (;;) {
     if (!lead) {
-      const uint32_t v = co_wait(me);
+      const uint32_t v = co_wait(me, 30u);
       if (v == 1u) return me->rc;
       me->state.store(0u, std::memory_order_release);  // v == 3: this thread leads the next batch (its request is the queue's front)
       lead = true;
     }
-    if (co.max_wait_us) {  // optional: give company a moment to arrive (off by default: a lone caller is never delayed)
-      const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(co.max_wait_us);
-      for (;;) {
-        { std::lock_guard<std::mutex> g(co.mu); uint32_t have = 0; for (ss_co_req* r : co.queue) have += r->nq; if (have >= co.max_batch) break; }
-        if (std::chrono::steady_clock::now() >= until) break;
-        __builtin_ia32_pause();
+    // Linger.  With T callers in a loop and one batch in flight, half of them ride in the batch and half wait: batches of T / 2
+    // (vectors, T = 64: two 32-query passes of 7.5 ms where one 64-query pass takes 9 ms).  The callers a finished batch has just
+    // released are back within microseconds, so the next leader waits for them -- until as many requests are queued as callers
+    // seem to be around, at most an eighth of the last batch's duration (<= 1 ms), and only if that batch had company at all: a
+    // lone caller is never delayed.  max_wait_us > 0 (ss_shard_set_coalescing) waits that long unconditionally.
+    {
+      static const int linger_on = [] { const char* e = getenv("SS_COALESCE_LINGER"); return e ? atoi(e) : 1; }();
+      uint32_t want, wait_us;
+      {
+        std::lock_guard<std::mutex> g(co.mu);
+        want = co.max_wait_us ? co.max_batch : std::min(co.callers_est, co.max_batch);
+        wait_us = co.max_wait_us ? co.max_wait_us : (linger_on && co.callers_est > 1 ? std::min<uint32_t>(1000u, co.last_batch_us / 8u) : 0u);
+      }
+      if (wait_us) {
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(wait_us);
+        for (;;) {
+          { std::lock_guard<std::mutex> g(co.mu); uint32_t have = 0; for (ss_co_req* r : co.queue) have += r->nq; if (have >= want) break; }
+          if (std::chrono::steady_clock::now() >= until) break;
+          for (int i = 0; i < 32; i++) __builtin_ia32_pause();
+        }
       }
     }
+    const auto batch_t0 = std::chrono::steady_clock::now();
     batch.clear();
     {
       std::lock_guard<std::mutex> g(co.mu);
@@ -931,6 +963,11 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
     ss_co_req* succ = nullptr;
     {
       std::lock_guard<std::mutex> g(co.mu);
+      uint32_t members = 0, queued = 0;
+      for (ss_co_req* r : batch) members += r->nq;
+      for (ss_co_req* r : co.queue) queued += r->nq;
+      co.callers_est = batch.size() + co.queue.size() > 1 ? members + queued : 0u;
+      co.last_batch_us = (uint32_t)std::min<long long>(1000000, std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - batch_t0).count());
       if (co.queue.empty()) co.leader_active = false;
       else succ = co.queue.front();
     }
@@ -1557,7 +1594,8 @@ int ss_vec_set_fields(ss_shard* s, uint64_t n_rows, const uint16_t* row_field) {
 }
 int ss_vec_cluster_info(ss_shard* s, uint32_t* n_levels, uint32_t* n_clusters) {
   if (!s) return SS_EINVAL;
-  std::lock_guard<std::mutex> g(s->mu);
+  // no lock: two words that only an image (re)build changes, read by every vector search of the host mirrors -- behind s->mu each
+  // such read queued up with the batch in flight (64 concurrent callers: mean merged batch 1.3, p99 0.6 s; bench round 3)
   if (n_levels) *n_levels = s->vec_n_levels;
   if (n_clusters) *n_clusters = s->vec_n_clusters;
   return SS_OK;

@@ -147,12 +147,13 @@ struct ss_coalescer {
   bool leader_active = false;
   uint32_t max_batch = 0, max_wait_us = 0;
   uint64_t batches = 0, queries = 0;
-  // host staging of a merged batch: only the leader of the moment touches it
-  std::vector<char> h_q;
-  std::vector<float> h_qscale;
-  std::vector<uint32_t> h_doc, h_count;
-  std::vector<float> h_score;
-  std::vector<uint64_t> h_total;
+  // linger: how many callers seem to be around (members of the last batch + what was queued when it finished) and how long that
+  // batch took -- the next leader gives the callers the last batch has just released a moment to come back (co_submit)
+  uint32_t callers_est = 0, last_batch_us = 0;
+  // host staging of a merged batch, PINNED (hipHostMalloc, grow-only): the copies to and from the device are then real
+  // asynchronous DMA instead of staged pageable copies; only the leader of the moment touches it
+  char* h_pin = nullptr;
+  size_t h_pin_cap = 0;
 };
 
 struct ss_shard {

@@ -50,6 +50,13 @@ ssh_index* ssh_index_create(int n_shards, const int* devices) {
   ix->index.reset(new Index(ix->shards));
   return ix;
 }
+// an index over shard images that already exist (handles owned by the caller, e.g. the Python mirror's shards)
+ssh_index* ssh_index_adopt(int n_shards, void* const* handles, const int* devices) {
+  ssh_index* ix = new ssh_index();
+  for (int i = 0; i < n_shards; i++) ix->shards.push_back(std::make_shared<Shard>((ss_shard*)handles[i], devices ? devices[i] : 0, (uint32_t)i));
+  ix->index.reset(new Index(ix->shards));
+  return ix;
+}
 void ssh_index_destroy(ssh_index* ix) { delete ix; }
 int ssh_shard_ok(ssh_index* ix, int shard) { return ix->shards[shard]->ok() ? 1 : 0; }
 int ssh_shard_create_error(ssh_index* ix, int shard) { return ix->shards[shard]->create_error(); }

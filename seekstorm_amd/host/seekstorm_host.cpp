@@ -103,8 +103,16 @@ Shard::Shard(int device, uint32_t shard_id) : shard_id_(shard_id), device_(devic
   if (create_rc_ != SS_OK) h_ = nullptr;
 }
 
+Shard::Shard(ss_shard* borrowed, int device, uint32_t shard_id) : h_(borrowed), owns_(false), shard_id_(shard_id), device_(device) {
+  if (!h_) { create_rc_ = SS_EINVAL; return; }
+  uint64_t n = 0;
+  uint32_t d = 0;
+  if (ss_bm25_info(h_, &n, nullptr, nullptr, nullptr) == SS_OK) n_docs_ = n;
+  if (ss_vec_info(h_, &n, &d) == SS_OK) { n_rows_ = n; dim_ = d; }
+}
+
 Shard::~Shard() {
-  if (h_) ss_shard_destroy(h_);
+  if (h_ && owns_) ss_shard_destroy(h_);
 }
 
 int Shard::upload_lexical(uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t n_terms, const uint64_t* term_offsets,

@@ -102,6 +102,9 @@ ss_facet_filter point_facet_filter(uint32_t facet_offset, const double base[2], 
 class Shard {
  public:
   Shard(int device, uint32_t shard_id);  // failure (no device, no library) leaves an unusable shard: searches return empty
+  // a view of a shard image that somebody else built and owns (its handle outlives this object): the planner and the seams over
+  // an existing ss_shard -- single indexed field, SingleTerm keys; image sizes are read back from the handle
+  Shard(ss_shard* borrowed, int device, uint32_t shard_id);
   ~Shard();
   Shard(const Shard&) = delete;
   Shard& operator=(const Shard&) = delete;
@@ -194,6 +197,7 @@ class Shard {
   int sorted_topk(const ss_bm25_query& q, const ResultSort* sorts, size_t n_sorts, size_t k, std::vector<ss_facet_filter> filters,
                   std::vector<Result>* out, uint64_t* total, bool* have_total);
   ss_shard* h_ = nullptr;
+  bool owns_ = true;
   uint32_t shard_id_ = 0;
   int device_ = 0;
   int create_rc_ = SS_OK;

@@ -1,0 +1,36 @@
+"""the concurrent-callers legs of bench.py alone (T host threads, ONE query per call through the C++ mirror's Index::search) on the
+C2 / C3 images:  python tools/probes/concurrent_bench.py [seconds]   (SS_COALESCE_LINGER=0 switches the linger off)"""
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+sys.path.insert(0, ROOT)
+import torch  # noqa: F401
+import seekstorm_amd as S
+from seekstorm_amd import _native as N
+from oracle import oracle as O
+import bench
+secs = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
+docs, rows, dim = int(os.environ.get("DOCS", 10_000_000)), int(os.environ.get("ROWS", 10_000_000)), 768
+sh = S.Shard(0)
+tl, th = bench.make_c2_queries(O, 1000)
+sh.synth_lexical(O.LEX_SEED, docs, th, O.len_table())
+sh.synth_vectors(O.VEC_SEED, rows, dim)
+qv = O.vec_gen(O.VECQ_SEED, 0, 64, dim)
+HL = C.CDLL(os.path.join(ROOT, "seekstorm_amd", "lib", "libseekstorm_host.so"))
+HL.ssh_index_adopt.restype = C.c_void_p
+HL.ssh_index_adopt.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+HL.ssh_bench_concurrent.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                    C.c_uint32, C.POINTER(C.c_double)]
+ix = HL.ssh_index_adopt(1, (C.c_void_p * 1)(sh._h), (C.c_int * 1)(0))
+flat = np.array([t for q in tl for t in q], np.uint32)
+toff = np.zeros(len(tl) + 1, np.uint32); toff[1:] = np.cumsum([len(q) for q in tl])
+for name, mode, nq, length in (("lexical", N.MODE_LEXICAL, 1000, 10), ("vector", N.MODE_VECTOR, 64, 100), ("hybrid", N.MODE_HYBRID, 64, 100)):
+    for T in (1, 8, 64, 256, 1024):
+        out = (C.c_double * 5)()
+        s0 = sh.coalescing_stats()
+        N.check(HL.ssh_bench_concurrent(ix, mode, T, secs, nq, flat.ctypes.data, toff.ctypes.data, qv.ctypes.data, int(S.QueryType.Union), length,
+                                        N.RT_TOPK, out), "bench")
+        s1 = sh.coalescing_stats()
+        lb, lq, vb, vq = (s1[i] - s0[i] for i in range(4))
+        print("%-8s T=%-4d %9.0f q/s  p50 %8.1f us  p99 %9.1f us  errors %d  lexical batch %s  vector batch %s" % (
+            name, T, out[0] / out[1], out[2], out[3], int(out[4]), "%.1f" % (lq / lb) if lb else "-", "%.1f" % (vq / vb) if vb else "-"), flush=True)
