@@ -308,7 +308,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   const bool bit_counts_all = want_counts && !pruned && !phrase && s->bm_strategy != SS_BM25_EXHAUSTIVE && have_probe;
   const bool scan_counts = want_counts && !bit_counts_all;
   // unions of <= 4 lists ranked by the scan: the 16-bit-accumulator kernel (16 waves per CU instead of 8)
-  const bool scan16 = !pruned && !phrase && ssi_bm25_scan16_serves(nt_max, np_max, has_and, scan_counts, KPL, k);
+  const bool scan16 = !pruned && !phrase && ssi_bm25_scan16_serves(nt_max, np_max, has_and, scan_counts, s->n_deleted != 0, KPL, k);
   // (16-bit scan: 1.415 ms per 1000 C2 queries at 4 rounds against 1.496 at 2 -- its work per assignment follows the query's
   // posting count, which differs 3x between C2's queries; round 3 also tried workgroups made of the partitions of ONE query
   // instead of 8 queries of one partition, tools/probes/map_sweep.py: 1.48 ms at the same 16 partitions, no better than the

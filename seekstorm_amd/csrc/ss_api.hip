@@ -651,13 +651,8 @@ static int ssi_bm25_ensure_probe_rows(ss_shard* s, uint32_t nq, const ss_bm25_qu
     if (s->pool_list[victims[i]] != BM_NO_PROBE_ROW) stage.push_back(s->pool_list[victims[i]]);
   const uint32_t n_evict = (uint32_t)stage.size();
   for (uint32_t i = 0; i < n; i++) {
-    const uint32_t slot = victims[i], v = missing[i];
-    if (s->pool_list[slot] != BM_NO_PROBE_ROW) s->h_probe_row[s->pool_list[slot]] = BM_NO_PROBE_ROW;
-    s->pool_list[slot] = v;
-    s->pool_tick[slot] = now;
-    s->h_probe_row[v] = s->probe_pool_begin + slot;
-    stage.push_back(v);
-    stage.push_back(s->probe_pool_begin + slot);
+    stage.push_back(missing[i]);
+    stage.push_back(s->probe_pool_begin + victims[i]);
   }
   SS_HIP(hipSetDevice(s->device));
   if (stage.size() * sizeof(uint32_t) > s->pool_stage_cap) {
@@ -668,6 +663,25 @@ static int ssi_bm25_ensure_probe_rows(ss_shard* s, uint32_t nq, const ss_bm25_qu
     s->pool_stage_cap = cap;
   }
   SS_HIP(hipMemcpy(s->d_pool_stage, stage.data(), stage.size() * sizeof(uint32_t), hipMemcpyHostToDevice));  // small; `stage` dies here
+  // A row about to change hands may still be read by *_dev searches queued on the callers' OWN streams (they vouched for their
+  // rows through ss_bm25_term_probed): the evict / fill kernels on `st` wait for everything those streams hold so far.
+  if (n_evict)
+    for (auto& kv : s->bm_ws) {
+      if (kv.first == st) continue;
+      hipEvent_t ev = nullptr;
+      SS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      const bool ok = hipEventRecord(ev, kv.first) == hipSuccess && hipStreamWaitEvent(st, ev, 0) == hipSuccess;
+      (void)hipEventDestroy(ev);  // released once the wait has been satisfied
+      if (!ok) return SS_EDEVICE;
+    }
+  // the host tables change only now that nothing above can fail any more: host and device views stay in step
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t slot = victims[i], v = missing[i];
+    if (s->pool_list[slot] != BM_NO_PROBE_ROW) s->h_probe_row[s->pool_list[slot]] = BM_NO_PROBE_ROW;
+    s->pool_list[slot] = v;
+    s->pool_tick[slot] = now;
+    s->h_probe_row[v] = s->probe_pool_begin + slot;
+  }
   if (n_evict) probe_row_evict_kernel<<<(n_evict + 255) / 256, 256, 0, st>>>(s->d_pool_stage, n_evict, s->d_probe_row);
   const unsigned long long waves = (unsigned long long)n * s->bm_n_sub;
   probe_row_fill_kernel<<<(unsigned)((waves + 3) / 4), 256, 0, st>>>(s->d_pool_stage + n_evict, n, s->bm_n_sub, s->d_sub_off,
