@@ -329,7 +329,7 @@ def main():
             ba, bb = band_terms(th, 0.01, 0.05), band_terms(th, 0.05, 0.20)
             qi_np = sh.make_queries([[int(rng_i.choice(ba)), int(rng_i.choice(bb))] for _ in range(nq)], S.QueryType.Intersection)
             qi_dev = torch.from_numpy(qi_np.view(np.uint8).reshape(nq, -1).copy()).to(dev)
-            OPS_AND = 1 | (2 << 8)
+            OPS_AND = 1 | 64 | (2 << 8) | (2 << 16)  # intersections, every query with exactly 2 terms
 
             def and_call(rt=N.RT_TOPKCOUNT):
                 N.check(L.ss_bm25_search_dev(sh._h, nq, qi_dev.data_ptr(), k, rt, OPS_AND, o_doc.data_ptr(), o_score.data_ptr(),
@@ -343,7 +343,24 @@ def main():
             torch.cuda.synchronize()
             assert np.array_equal(and_ref[0], o_score.cpu().numpy()) and np.array_equal(and_ref[1], o_tot.cpu().numpy()), "AND: strategies differ"
             n_, d_ = timed_for(and_call)
+            sh.set_strategy(N.BM25_EXHAUSTIVE)
+            sh.profile(True)
+            sh.profile_read(0, reset=True)
+            nx_, dx_ = timed_for(and_call)
+            xl_, xms_ = sh.profile_read(0, reset=True)
+            sh.profile(False)
+            sh.set_strategy(N.BM25_AUTO)
+            and_u = sorted({int(t) for q_ in qi_np["term"][:, :2] for t in q_})
+            and_df = dict(zip(and_u, (int(x) for x in sh.posting_count(and_u))))
+            and_bytes = float(sum((and_df[int(a_)] + and_df[int(b_)]) * 3 + int(m_) + 4 * ((args.docs + 65535) // 65536) * 2 + 8 * k
+                                  for (a_, b_), m_ in zip(qi_np["term"][:, :2], and_ref[1])))
+            xk_ = xms_ / max(xl_, 1)
             inter = {"value": nq * n_ / d_, "unit": "queries/s", "ms_per_call": d_ / n_ * 1e3, "calls": n_, "result_type": "TopkCount",
+                     "exhaustive": {"value": nq * nx_ / dx_, "unit": "queries/s", "ms_per_call": dx_ / nx_ * 1e3, "calls": nx_,
+                                    "roofline": {"bound": "hbm", "kernel": "bm25_scan16_kernel<2,1,count,AND> (entries with a level: only the first term creates them)",
+                                                 "achieved": and_bytes / (xk_ * 1e-3) / 1e9 if xk_ > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                 "frac": and_bytes / (xk_ * 1e-3) / 1e9 / HBM_PEAK_GBS if xk_ > 0 else None,
+                                                 "algorithmic_bytes_per_launch": and_bytes, "avg_launch_ms": xk_, "launches": int(xl_)}},
                      "workload": "2-term AND top-10, terms from the 1-5 % and 5-20 % df bands, 1000 queries per call, AUTO (pruned: the shorter "
                                  "list drives, the other is probed; counts are a by-product)", "mean_matches": float(and_ref[1].mean())}
         ach_alg = bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0

@@ -149,6 +149,7 @@ constexpr uint32_t BM_CLAIM_AND = 1u, BM_CLAIM_OR = 2u, BM_CLAIM_PROBED = 4u, BM
 // bm_merged) -- a query without a field filter reads only that one and is a single-field query from here on, a query with a
 // field filter reads the n_lists - 1 (term, field) lists.
 constexpr uint32_t BM_CLAIM_FILTER = 32u;  // some query of the batch carries a field filter (variants sized for term x field lists)
+constexpr uint32_t BM_CLAIM_UNIFORM = 64u;  // every query has exactly np_claim terms (the 16-bit scan's intersection instance)
 __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery* __restrict__ vq, uint32_t nq, uint32_t n_lists,
                                  const unsigned long long* __restrict__ term_base, const float* __restrict__ boost,
                                  unsigned long long* __restrict__ total, uint32_t* __restrict__ tau, uint32_t claim,
@@ -170,6 +171,7 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
     bool bad = np == 0 || np + n_not > (uint32_t)SS_MAX_QUERY_TERMS || (np + n_not) * eff_fields > (uint32_t)BM_MAX_VTERMS;
     bad |= ff != 0u && merged != 0u && !(claim & BM_CLAIM_FILTER);  // the variants were sized for one list per term
     bad |= np + n_not > nt_claim || np > np_claim;
+    bad |= (claim & BM_CLAIM_UNIFORM) != 0u && np != np_claim;
     bad |= n_not != 0 && nt_claim == np_claim;  // nt == np declares a batch without NOT terms (unfiltered kernel variants)
     const bool q_and = ((bm_q_op(Q.op) == SS_OP_INTERSECTION || bm_q_op(Q.op) == SS_OP_PHRASE) && np > 1) || ff != 0u;
     bad |= q_and && !(claim & BM_CLAIM_AND);
@@ -269,7 +271,8 @@ int ssi_bm25_match_bits(ss_shard* s, const ss_bm25_query* d_q, unsigned long lon
 
 int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t* d_out_doc,
                     float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, bool has_or,
-                    uint32_t nt_max, uint32_t np_max, bool all_probed, hipStream_t st, bool any_frequent, bool phrase, bool any_field_filter) {
+                    uint32_t nt_max, uint32_t np_max, bool all_probed, hipStream_t st, bool any_frequent, bool phrase, bool any_field_filter,
+                    bool uniform_terms) {
   if (!s->d_post) return SS_ESTATE;
   if (nq == 0) return SS_OK;
   if (k > SS_MAX_K) return SS_EINVAL;
@@ -308,7 +311,10 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   const bool bit_counts_all = want_counts && !pruned && !phrase && s->bm_strategy != SS_BM25_EXHAUSTIVE && have_probe;
   const bool scan_counts = want_counts && !bit_counts_all;
   // unions of <= 4 lists ranked by the scan: the 16-bit-accumulator kernel (16 waves per CU instead of 8)
-  const bool scan16 = !pruned && !phrase && ssi_bm25_scan16_serves(nt_max, np_max, has_and, scan_counts, s->n_deleted != 0, KPL, k);
+  // ... and intersections of 2 or 3 terms when the batch holds nothing else: every query an intersection over one list per term
+  // with exactly np_max terms, no NOT terms, no all_terms_frequent shortcut
+  const uint32_t and_exact_nt = (has_and && !has_or && F == 1 && uniform_terms && nt_max == np_max && !any_frequent && !any_field_filter) ? np_max : 0u;
+  const bool scan16 = !pruned && !phrase && ssi_bm25_scan16_serves(nt_max, np_max, has_and, scan_counts, s->n_deleted != 0, KPL, k, and_exact_nt);
   // (16-bit scan: 1.415 ms per 1000 C2 queries at 4 rounds against 1.496 at 2 -- its work per assignment follows the query's
   // posting count, which differs 3x between C2's queries; round 3 also tried workgroups made of the partitions of ONE query
   // instead of 8 queries of one partition, tools/probes/map_sweep.py: 1.48 ms at the same 16 partitions, no better than the
@@ -350,7 +356,8 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   }
   // nt_max / np_max count (term, field) lists here; the claim is in public terms
   const uint32_t claim = (phrase ? BM_CLAIM_PHRASE : 0u) | (has_and ? BM_CLAIM_AND : 0u) | ((has_or || F > 1) ? BM_CLAIM_OR : 0u) | (all_probed ? BM_CLAIM_PROBED : 0u) |
-                         (any_frequent ? BM_CLAIM_FREQ : 0u) | (any_field_filter ? BM_CLAIM_FILTER : 0u) | (std::min(nt_max / F, 255u) << 8) |
+                         (any_frequent ? BM_CLAIM_FREQ : 0u) | (any_field_filter ? BM_CLAIM_FILTER : 0u) | (uniform_terms ? BM_CLAIM_UNIFORM : 0u) |
+                         (std::min(nt_max / F, 255u) << 8) |
                          (std::min(np_max / F, 255u) << 16);
   bm_expand_kernel<<<(nq + 127) / 128, 128, 0, st>>>(d_q, (bm_vquery*)W.d_vq, nq, s->bm_n_fields,
                                                     (const unsigned long long*)s->d_term_base, s->d_boost, total, tau, claim,
@@ -385,7 +392,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
     rc = ssi_bm25_launch_phrase(p, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_pos, s->d_pos_off, (const unsigned long long*)s->d_pos_base,
                                 np_max, KPL, st);
   else rc = pruned ? ssi_bm25_launch_probe(p, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_umax, use_partmax ? s->d_submax : nullptr, pmax_ws, np_max, KPL, nt_max != np_max, st)
-                   : scan16 ? ssi_bm25_launch_scan16(p, nt_max, KPL, st) : ssi_bm25_launch_scan(p, nt_max, has_and, KPL, st);
+                   : scan16 ? ssi_bm25_launch_scan16(p, nt_max, has_and, KPL, st) : ssi_bm25_launch_scan(p, nt_max, has_and, KPL, st);
   ssi_prof_end(s, 0, st, e0, e1);
   if (rc) return rc;
   if (want_counts && ((pruned && has_or) || bit_counts_all)) {

@@ -95,6 +95,54 @@ __device__ __forceinline__ void s16_clear(uint32_t wb, int lane) {
   for (int i = 0; i < S16_WAVE_LDS / 1024; i++) lds_st128(wb + (uint32_t)(i * 64 + lane) * 16u, u32x4{0u, 0u, 0u, 0u});
 }
 
+// ---- intersections (AND template instance; 2 or 3 terms, every query of the batch with exactly NT terms).  An entry is
+// (bound << 2) | level: level = how many of the query's terms the doc has been found in so far (1, 2), 3 = in ALL of them.
+// Only the FIRST term creates entries; a later term adds to an entry only if the doc was in every term before it, the last
+// term only reads: a doc matches when its entry stands at level NT - 1, and its bound is the entry's + the last posting's.
+// Matches are counted on the way (exact intersection counts for TopkCount / Count).  Bounds: q as for unions at a quarter of
+// the scale (14 bits).
+constexpr float S16_QMAX_AND = 16000.0f;
+__device__ __forceinline__ void s16a_first(const u32x4 v, float fidf, uint32_t accb) {
+  const uint32_t pv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int x = 0; x < 4; x++) lds_st16(s16_addr(pv[x], accb), (s16_q(pv[x], fidf) << 2) | 1u);
+}
+__device__ __forceinline__ void s16a_mid(const u32x4 v, float fidf, uint32_t accb, uint32_t level) {
+  const uint32_t pv[4] = {v.x, v.y, v.z, v.w};
+  uint32_t ad[4], old[4];
+#pragma unroll
+  for (int x = 0; x < 4; x++) { ad[x] = s16_addr(pv[x], accb); old[x] = lds_ld16(ad[x]); }
+#pragma unroll
+  for (int x = 0; x < 4; x++) lds_st16(ad[x], (old[x] & 3u) == level ? old[x] + (s16_q(pv[x], fidf) << 2) + 1u : old[x]);
+}
+// WRITE = false: the streaming loop -- the largest bound of a matching doc and the number of matches; true: the candidate path
+// -- a matching doc's entry becomes (bound << 2) | 3
+template <bool CNT, bool WRITE>
+__device__ __forceinline__ uint32_t s16a_last(const u32x4 v, float fidf, uint32_t accb, uint32_t level, uint32_t mx, uint32_t& cnt) {
+  const uint32_t pv[4] = {v.x, v.y, v.z, v.w};
+  uint32_t ad[4], old[4];
+#pragma unroll
+  for (int x = 0; x < 4; x++) { ad[x] = s16_addr(pv[x], accb); old[x] = lds_ld16(ad[x]); }
+#pragma unroll
+  for (int x = 0; x < 4; x++) {
+    const bool m = (old[x] & 3u) == level && pv[x] != 0u;  // (a NULL posting reads whatever the dump slot holds)
+    const uint32_t sum = (old[x] >> 2) + s16_q(pv[x], fidf);
+    mx = max(mx, m ? sum : 0u);
+    if (CNT) cnt += (uint32_t)__popcll(__ballot(m));
+    if (WRITE) lds_st16(ad[x], m ? ((sum << 2) | 3u) : old[x]);
+  }
+  return mx;
+}
+// the entries of the first term's docs that did not make it to "in all terms" go back to 0
+__device__ __forceinline__ void s16a_clean(const u32x4 v, uint32_t accb) {
+  const uint32_t pv[4] = {v.x, v.y, v.z, v.w};
+  uint32_t ad[4], old[4];
+#pragma unroll
+  for (int x = 0; x < 4; x++) { ad[x] = s16_addr(pv[x], accb); old[x] = lds_ld16(ad[x]); }
+#pragma unroll
+  for (int x = 0; x < 4; x++) lds_st16(ad[x], (old[x] & 3u) == 3u ? old[x] : 0u);
+}
+
 constexpr uint32_t S16_LIST = 8320u;   // per-wave candidate list inside the slice's padding: up to S16_LIST_MAX doc-in-sub-block ids (u16)
 constexpr uint32_t S16_LIST_MAX = 64u;
 constexpr uint32_t S16_ACC = 8448u;    // their exact f32 scores while an item's candidates are evaluated
@@ -136,7 +184,34 @@ template <int NT> struct S16Item {
 //     marker adds idf * weight to that candidate's f32 accumulator: terms in query order, one after the other (the docs
 //     of one term are distinct and LDS operations execute in order) -- the other kernels' sum, bit for bit;
 //  4. keys to the wave-resident top-k; more candidates than the list holds: the bounds are rebuilt and 2-4 repeat.
-template <int NT, int CPT, int KPL>
+// Every segment of an item through one chunk routine: the chunks held in registers, then whatever of an oversized segment was
+// streamed rather than kept (loaded again, synchronously: the candidate path is rare)
+template <int NT, int CPT, typename F>
+__device__ __forceinline__ void s16_each_chunk(const S16Cur<NT * CPT>& cur, const S16Item<NT>& it, int t, int lane16, F f) {
+  const uint32_t n16 = it.b1[t] - it.b0[t];
+#pragma unroll
+  for (int c = 0; c < CPT; c++)
+    if ((uint32_t)c * 64u < n16) f(cur.v[t * CPT + c]);
+  if (n16 > (uint32_t)CPT * 64u) {
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)it.tptr[t], 0, (int)(it.b1[t] << 4), BM_RSRC_FLAGS);
+    for (uint32_t u = it.b0[t] + CPT * 64u; u < it.b1[t]; u += 64u) f(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0));
+  }
+}
+// intersections: the tile as the candidate path wants it -- (bound << 2) | 3 for the docs found in every term, 0 elsewhere.
+// from_scratch = false: the streaming loop has left the first NT - 1 terms accumulated (levels) and the last one unread.
+template <int NT, int CPT>
+__device__ __forceinline__ void s16a_build(const S16Cur<NT * CPT>& cur, const S16Item<NT>& it, uint32_t accb, int lane16, bool from_scratch) {
+  uint32_t nocount = 0u;
+  if (from_scratch) {
+    s16_each_chunk<NT, CPT>(cur, it, 0, lane16, [&](const u32x4 v) { s16a_first(v, it.fidf[0], accb); });
+#pragma unroll
+    for (int t = 1; t + 1 < NT; t++) s16_each_chunk<NT, CPT>(cur, it, t, lane16, [&](const u32x4 v) { s16a_mid(v, it.fidf[t], accb, (uint32_t)t); });
+  }
+  s16_each_chunk<NT, CPT>(cur, it, NT - 1, lane16, [&](const u32x4 v) { (void)s16a_last<false, true>(v, it.fidf[NT - 1], accb, (uint32_t)NT - 1u, 0u, nocount); });
+  s16_each_chunk<NT, CPT>(cur, it, 0, lane16, [&](const u32x4 v) { s16a_clean(v, accb); });
+}
+
+template <int NT, int CPT, int KPL, bool AND>
 __device__ __forceinline__ BmTop<KPL> s16_trigger(BmTop<KPL> T, S16Cur<NT * CPT> cur, S16Item<NT> it, uint32_t wb, uint32_t qthr,
                                                             float thr, uint32_t doc_base, uint32_t k, uint32_t* tau_q,
                                                             const uint32_t* __restrict__ del, uint32_t del_words) {
@@ -145,6 +220,12 @@ __device__ __forceinline__ BmTop<KPL> s16_trigger(BmTop<KPL> T, S16Cur<NT * CPT>
   const uint32_t tile = wb + 16u, accb = wb + 14u, accf = wb + S16_ACC;
   const float wsc_in = T.wsc;
   uint32_t start = 0u;  // docs below it were evaluated by an earlier round
+  // intersections: entries are (bound << 2) | 3 -- thresholds and slack move up with them (the 3 sits below one unit of bound)
+  constexpr uint32_t SH = AND ? 2u : 0u;
+  if (AND) {
+    qthr <<= 2;
+    s16a_build<NT, CPT>(cur, it, accb, lane16, false);
+  }
   for (;;) {
     // this lane's 8 slots (slot i * 64 + lane holds docs 8 * slot .. 8 * slot + 7): their largest bounds, packed 2 per register
     uint32_t sm[4];
@@ -161,7 +242,7 @@ __device__ __forceinline__ BmTop<KPL> s16_trigger(BmTop<KPL> T, S16Cur<NT * CPT>
         const uint32_t mid = (lo + hi + 1u) >> 1;
         if ((uint32_t)__popcll(__ballot(lm >= mid)) >= k) lo = mid; else hi = mid - 1u;
       }
-      qcut = max(qcut, lo > (uint32_t)NT + S16_SLACK ? lo - (uint32_t)NT - S16_SLACK : 1u);
+      qcut = max(qcut, lo > (((uint32_t)NT + S16_SLACK) << SH) ? lo - (((uint32_t)NT + S16_SLACK) << SH) : 1u);
     }
     uint32_t hotbits = 0u;  // bit i: slot i of this lane holds a bound at or above the cut
 #pragma unroll
@@ -240,6 +321,10 @@ __device__ __forceinline__ BmTop<KPL> s16_trigger(BmTop<KPL> T, S16Cur<NT * CPT>
     }
     if (start == 0xFFFFu) break;
     // more candidates than the list holds (ties, or a list that is still filling): rebuild the bounds and go on
+    if (AND) {
+      s16a_build<NT, CPT>(cur, it, accb, lane16, true);
+      continue;
+    }
 #pragma unroll
     for (int t = 0; t < NT; t++) {
       const uint32_t n16 = it.b1[t] - it.b0[t];
@@ -261,7 +346,7 @@ __device__ __forceinline__ BmTop<KPL> s16_trigger(BmTop<KPL> T, S16Cur<NT * CPT>
 
 template <int NT> struct S16Cfg { static constexpr int CPT = NT <= 2 ? 3 : 2; static constexpr int RC = NT * CPT; };
 
-template <int NT, int KPL, bool CNT>
+template <int NT, int KPL, bool CNT, bool AND>
 __global__ void __launch_bounds__(S16_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base, const uint32_t* __restrict__ sub_off,
                    const bm_vquery* __restrict__ qs, unsigned long long* __restrict__ part_keys, unsigned long long* __restrict__ total, uint32_t* tau,
@@ -297,7 +382,7 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
     tptr[t] = post + term_base[term] * 4ull;
     rowp[t] = sub_off + (size_t)term * row_len;
   }
-  const float scale = S16_QMAX / (S16_WMAX * idf_sum);
+  const float scale = (AND ? S16_QMAX_AND : S16_QMAX) / (S16_WMAX * idf_sum);
 #pragma unroll
   for (int t = 0; t < NT; t++) fidf[t] = s16_uniform(idf[t] * scale);
   // wave-uniform constants of the item loop, pinned to scalar registers (left to the allocator, scale_thr went to scratch and
@@ -344,7 +429,51 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
 #pragma unroll
     for (int t = 0; t < NT; t++) maxn = max(maxn, B1[t] - B0[t]);
     bool hit = false;
-    if (maxn) {
+    if constexpr (AND) {
+      uint32_t minn = 0xFFFFFFFFu;
+#pragma unroll
+      for (int t = 0; t < NT; t++) minn = min(minn, B1[t] - B0[t]);
+      if (minn) {  // a sub-block one of the terms has no doc in holds no match: nothing is touched
+        uint32_t mx = 0u, cnt = 0u;
+        auto seg = [&](int t, auto f) {
+          const uint32_t n16 = B1[t] - B0[t];
+#pragma unroll
+          for (int c = 0; c < CPT; c++)
+            if ((uint32_t)c * 64u < n16) f(cur[t * CPT + c]);
+          if (n16 > (uint32_t)CPT * 64u) {
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[t], 0, (int)(B1[t] << 4), BM_RSRC_FLAGS);
+            for (uint32_t u = B0[t] + CPT * 64u; u < B1[t]; u += 64u) f(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0));
+          }
+        };
+        seg(0, [&](const u32x4 v) { s16a_first(v, fidf[0], accb); });
+#pragma unroll
+        for (int t = 1; t + 1 < NT; t++) seg(t, [&](const u32x4 v) { s16a_mid(v, fidf[t], accb, (uint32_t)t); });
+        seg(NT - 1, [&](const u32x4 v) { mx = s16a_last<CNT, false>(v, fidf[NT - 1], accb, (uint32_t)NT - 1u, mx, cnt); });
+        if (CNT) T.matched += cnt;
+        const float thr = fmaxf(T.wsc, __uint_as_float(tau_bits));
+        const uint32_t qthr = k ? (thr > 0.f ? (uint32_t)(thr * scale_thr) : 0u) : 0xFFFFFFFFu;
+        if (__ballot(mx != 0u && mx >= qthr)) {
+          hit = true;
+          qthr_hit = qthr;
+          thr_hit = thr;
+#pragma unroll
+          for (int t = 0; t < NT; t++) { hb0[t] = B0[t]; hb1[t] = B1[t]; }
+        } else if (B1[0] - B0[0] <= (uint32_t)CPT * 64u) {  // only the first term's docs have entries
+          const uint32_t n16 = B1[0] - B0[0];
+#pragma unroll
+          for (int c = 0; c < CPT; c++)
+            if ((uint32_t)c * 64u < n16) {
+              const u32x4 v = cur[c];
+              lds_st16(s16_addr(v.x, accb), 0u);
+              lds_st16(s16_addr(v.y, accb), 0u);
+              lds_st16(s16_addr(v.z, accb), 0u);
+              lds_st16(s16_addr(v.w, accb), 0u);
+            }
+        } else {
+          s16_clear(wb, lane);
+        }
+      }
+    } else if (maxn) {
       uint32_t mx = 0u, cnt = 0u;
 #pragma unroll
       for (int t = 0; t + 1 < NT; t++) {  // the first term finds an empty tile: written without a read
@@ -450,7 +579,7 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
         S16Item<NT> it;
 #pragma unroll
         for (int t = 0; t < NT; t++) { it.tptr[t] = tptr[t]; it.idf[t] = idf[t]; it.fidf[t] = fidf[t]; it.b0[t] = hb0[t]; it.b1[t] = hb1[t]; }
-        T = s16_trigger<NT, CPT, KPL>(T, cc, it, wb, qthr_hit, thr_hit, (s0 + i - 1u) << BM_SUB_LOG2, k, tau_q, del, del_words);
+        T = s16_trigger<NT, CPT, KPL, AND>(T, cc, it, wb, qthr_hit, thr_hit, (s0 + i - 1u) << BM_SUB_LOG2, k, tau_q, del, del_words);
       }
     }
   }
@@ -461,12 +590,12 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
   if (CNT && lane == 0 && T.matched) atomicAdd(&total[qi], T.matched);
 }
 
-template <int NT, int KPL, bool CNT>
+template <int NT, int KPL, bool CNT, bool AND>
 int launch16(const BmParams& p, hipStream_t st) {
   constexpr int lds = S16_WAVES * S16_WAVE_LDS;
-  SS_SET_MAX_LDS((bm25_scan16_kernel<NT, KPL, CNT>), lds);
+  SS_SET_MAX_LDS((bm25_scan16_kernel<NT, KPL, CNT, AND>), lds);
   const uint32_t A = p.nq * p.P;
-  bm25_scan16_kernel<NT, KPL, CNT><<<(A + S16_WAVES - 1) / S16_WAVES, S16_WAVES * 64, lds, st>>>(
+  bm25_scan16_kernel<NT, KPL, CNT, AND><<<(A + S16_WAVES - 1) / S16_WAVES, S16_WAVES * 64, lds, st>>>(
       p.post, p.term_base, p.sub_off, p.q, p.part_keys, p.total, p.tau, p.del, p.del_words, p.n_sub, p.n_terms, p.nq, p.P, p.k);
   return SS_OK;
 }
@@ -475,18 +604,26 @@ int launch16(const BmParams& p, hipStream_t st) {
 
 // unions of <= 4 lists without NOT terms, k <= 64 (at k = 100 the f32 scan is 5 % ahead); exact counts (TopkCount, and Count
 // with k = 0) as long as the shard has no tombstones -- a deleted doc must not count, and only the f32 kernel's dense tile scan
-// looks at the tombstone bitmap of every doc
-bool ssi_bm25_scan16_serves(uint32_t nt_max, uint32_t np_max, bool has_and, bool count, bool tombstones, int KPL, uint32_t k) {
+// looks at the tombstone bitmap of every doc.  Intersections (and_exact_nt != 0): batches of intersections only, every query
+// with exactly and_exact_nt = 2 or 3 terms over one list each, no all_terms_frequent shortcut (the dispatch checks).
+bool ssi_bm25_scan16_serves(uint32_t nt_max, uint32_t np_max, bool has_and, bool count, bool tombstones, int KPL, uint32_t k, uint32_t and_exact_nt) {
   static const int off = [] { const char* e = getenv("SS_BM25_SCAN16"); return e ? atoi(e) == 0 : 0; }();
   static const int cnt_off = [] { const char* e = getenv("SS_BM25_SCAN16_COUNT"); return e ? atoi(e) == 0 : 0; }();
+  static const int and_off = [] { const char* e = getenv("SS_BM25_SCAN16_AND"); return e ? atoi(e) == 0 : 0; }();
   if (count && (tombstones || cnt_off)) return false;
-  return !off && !has_and && (k != 0 || count) && nt_max == np_max && nt_max >= 1 && nt_max <= 4 && KPL == 1;
+  if (has_and && (and_off || and_exact_nt < 2 || and_exact_nt > 3 || and_exact_nt != nt_max)) return false;
+  return !off && (k != 0 || count) && nt_max == np_max && nt_max >= 1 && nt_max <= 4 && KPL == 1;
 }
 
-int ssi_bm25_launch_scan16(const BmParams& p, uint32_t nt_max, int KPL, hipStream_t st) {
+int ssi_bm25_launch_scan16(const BmParams& p, uint32_t nt_max, bool is_and, int KPL, hipStream_t st) {
   const int NT = nt_max <= 2 ? 2 : (int)nt_max;
+  if (is_and) {
+    if (NT == 2 && KPL == 1) return p.count ? launch16<2, 1, true, true>(p, st) : launch16<2, 1, false, true>(p, st);
+    if (NT == 3 && KPL == 1) return p.count ? launch16<3, 1, true, true>(p, st) : launch16<3, 1, false, true>(p, st);
+    return SS_ENOTSUP;
+  }
 #define SS_F(NT_, KPL_)                                                    \
-  if (NT == NT_ && KPL == KPL_) return p.count ? launch16<NT_, KPL_, true>(p, st) : launch16<NT_, KPL_, false>(p, st);
+  if (NT == NT_ && KPL == KPL_) return p.count ? launch16<NT_, KPL_, true, false>(p, st) : launch16<NT_, KPL_, false, false>(p, st);
   SS_F(2, 1) SS_F(3, 1) SS_F(4, 1)
 #undef SS_F
   return SS_ENOTSUP;

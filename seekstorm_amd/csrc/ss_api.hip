@@ -461,8 +461,9 @@ int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df
 // nt_max: largest n_terms + NOT terms of the batch (what the scan kernels are specialised on); np_max: largest n_terms
 // any_filter: some query carries a field filter (on an image with merged lists the others read one list per term)
 static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q, bool* has_and, bool* has_or, uint32_t* nt_max,
-                         uint32_t* np_max, bool* all_probed, bool* any_frequent, bool* phrase = nullptr, bool* any_filter = nullptr) {
-  uint32_t n_phrase = 0;
+                         uint32_t* np_max, bool* all_probed, bool* any_frequent, bool* phrase = nullptr, bool* any_filter = nullptr,
+                         bool* uniform = nullptr) {
+  uint32_t n_phrase = 0, np_min = 0xFFFFFFFFu;
   const uint32_t L = s->bm_n_fields, RF = bm_real_fields(s);  // lists per term, indexed fields
   bool some_filter = false;
   *any_frequent = false;
@@ -523,8 +524,10 @@ static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q,
     else if (q[i].n_terms > 1) *has_or = true;  // a single-term query is both: its exact count is its posting count
     *nt_max = std::max(*nt_max, all);
     *np_max = std::max(*np_max, q[i].n_terms);
+    np_min = std::min(np_min, q[i].n_terms);
     any_not |= n_not != 0;
   }
+  if (uniform) *uniform = np_min == *np_max;  // every query with the same number of terms
   // "the batch holds NOT terms" travels as nt_max > np_max (the kernels' filtered variants are chosen by it): keep that true
   // when the query with the NOT terms is not the one with the most terms
   if (any_not && *nt_max == *np_max) *nt_max = *np_max + 1;
@@ -722,11 +725,11 @@ static int bm25_search_split_batch(ss_shard* s, uint32_t nq, const ss_bm25_query
     perm[at] = i;
     qs[at] = q[i];
   }
-  struct Part { bool has_and, has_or, all_probed, any_frequent, phrase, any_filter; uint32_t nt_max, np_max; } part[2];
+  struct Part { bool has_and, has_or, all_probed, any_frequent, phrase, any_filter, uniform; uint32_t nt_max, np_max; } part[2];
   const uint32_t begin[2] = {0, n_probed}, count[2] = {n_probed, nq - n_probed};
   for (int h = 0; h < 2; h++)
     SS_TRY(check_queries(s, count[h], qs.data() + begin[h], &part[h].has_and, &part[h].has_or, &part[h].nt_max, &part[h].np_max,
-                         &part[h].all_probed, &part[h].any_frequent, &part[h].phrase, &part[h].any_filter));
+                         &part[h].all_probed, &part[h].any_frequent, &part[h].phrase, &part[h].any_filter, &part[h].uniform));
   SS_HIP(hipSetDevice(s->device));
   const uint32_t kw = std::max<uint32_t>(kk, 1);
   SS_TRY(ensure_out(s, 2 * (size_t)nq, kw));  // upper half: the answers in the order they ran in
@@ -749,7 +752,7 @@ static int bm25_search_split_batch(ss_shard* s, uint32_t nq, const ss_bm25_query
     for (int h = 0; h < 2; h++) {
       const int rc = ssi_bm25_search(s, count[h], d_q + begin[h], kk, rt, t_doc + (size_t)begin[h] * kw, t_score + (size_t)begin[h] * kw,
                                      t_count + begin[h], t_total + begin[h], part[h].has_and, part[h].has_or, part[h].nt_max,
-                                     part[h].np_max, part[h].all_probed, s->stream, part[h].any_frequent, part[h].phrase, part[h].any_filter);
+                                     part[h].np_max, part[h].all_probed, s->stream, part[h].any_frequent, part[h].phrase, part[h].any_filter, part[h].uniform);
       if (rc != SS_OK) return rc;
     }
     return (int)SS_OK;
@@ -777,8 +780,8 @@ static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_quer
   }
   bool has_and = false, has_or = false;
   uint32_t nt_max = 0, np_max = 0;
-  bool all_probed = false, any_frequent = false, phrase = false, any_filter = false;
-  SS_TRY(check_queries(s, nq, q, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent, &phrase, &any_filter));
+  bool all_probed = false, any_frequent = false, phrase = false, any_filter = false, uniform = false;
+  SS_TRY(check_queries(s, nq, q, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent, &phrase, &any_filter, &uniform));
   SS_HIP(hipSetDevice(s->device));
   SS_TRY(ensure_out(s, nq, std::max<uint32_t>(kk, 1)));
   if ((size_t)nq * sizeof(ss_bm25_query) > s->bq_cap) {
@@ -790,7 +793,7 @@ static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_quer
   SS_HIP(hipMemcpyAsync(s->d_bq, q, (size_t)nq * sizeof(ss_bm25_query), hipMemcpyHostToDevice, s->stream));
   return with_facet_filter(s, n_filters, filters, s->stream, [&]() {
     return ssi_bm25_search(s, nq, (const ss_bm25_query*)s->d_bq, kk, rt, s->d_out_doc, s->d_out_score, s->d_out_count,
-                           s->d_out_total, has_and, has_or, nt_max, np_max, all_probed, s->stream, any_frequent, phrase, any_filter);
+                           s->d_out_total, has_and, has_or, nt_max, np_max, all_probed, s->stream, any_frequent, phrase, any_filter, uniform);
   });
 }
 
@@ -1264,7 +1267,7 @@ int ss_bm25_search_filtered_dev(ss_shard* s, uint32_t nq, const ss_bm25_query* d
                                                     : ((ops_mask >> 8) & 0xFFu ? (ops_mask >> 8) & 0xFFu : SS_MAX_QUERY_TERMS),
                            // the caller vouches for the probe rows of its terms (ss_bm25_term_probed) unless none were rationed
                            s->bm_probe_rows != 0 && (s->bm_probe_rows >= s->bm_n_terms || (ops_mask & 4u) != 0), st,
-                           (ops_mask & 8u) != 0, (ops_mask & 16u) != 0, (ops_mask & 32u) != 0);
+                           (ops_mask & 8u) != 0, (ops_mask & 16u) != 0, (ops_mask & 32u) != 0, (ops_mask & 64u) != 0);
   });
 }
 

@@ -360,7 +360,7 @@ constexpr uint32_t BM_AND_FREQ = 0x100u;
 int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t* d_out_doc,
                     float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, bool has_or,
                     uint32_t nt_max, uint32_t np_max, bool all_probed, hipStream_t st, bool any_frequent = false, bool phrase = false,
-                    bool any_field_filter = true);
+                    bool any_field_filter = true, bool uniform_terms = false);
 // indexed fields of the image (bm_n_fields counts the merged list as well)
 inline uint32_t bm_real_fields(const ss_shard* s) { return s->bm_n_fields - (s->bm_merged ? 1u : 0u); }
 // ---- implemented in synth.hip

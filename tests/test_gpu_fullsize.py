@@ -87,13 +87,17 @@ def test_c2_full_size_intersections_and_counts(S, O, F, c2):
     ans = F.c2_answers_chunked(N_FULL, pairs, th, k, O.OP_AND, O.RT_TOPKCOUNT, chunk=160)
     for strat in (N.BM25_AUTO, N.BM25_EXHAUSTIVE):
         sh.set_strategy(strat)
-        doc, score, cnt, tot = sh.search_lexical_batch(q, k, S.ResultType.TopkCount)
-        for i in range(len(pairs)):
-            od, os_, otot = ans[i]
-            assert int(tot[i]) == otot, (strat, i, int(tot[i]), otot)
-            F.check_topk(doc[i, :cnt[i]], score[i, :cnt[i]], od, os_, 1e-4, f"C2 AND strategy {strat} query {i}")
-            if len(od) < k:  # fewer matches than k: the doc-id SET is the whole intersection -- bit exact
-                assert set(doc[i, :cnt[i]].tolist()) == set(int(x) for x in od)
+        # the whole (mixed 2- / 3-term) batch, and the two uniform halves on their own: under EXHAUSTIVE a batch whose queries
+        # all have the same number of terms takes the 16-bit scan's intersection instance, a mixed one the f32 kernel
+        for lo, hi in ((0, len(pairs)), (0, 256), (256, len(pairs))):
+            doc, score, cnt, tot = sh.search_lexical_batch(q[lo:hi].copy(), k, S.ResultType.TopkCount)
+            for j in range(hi - lo):
+                i = lo + j
+                od, os_, otot = ans[i]
+                assert int(tot[j]) == otot, (strat, i, int(tot[j]), otot)
+                F.check_topk(doc[j, :cnt[j]], score[j, :cnt[j]], od, os_, 1e-4, f"C2 AND strategy {strat} query {i}")
+                if len(od) < k:  # fewer matches than k: the doc-id SET is the whole intersection -- bit exact
+                    assert set(doc[j, :cnt[j]].tolist()) == set(int(x) for x in od)
     sh.set_strategy(N.BM25_AUTO)
 
 

@@ -1,6 +1,6 @@
 """quick probe: 2-term AND top-10 (C1-shaped queries on the C2 corpus), pruned vs exhaustive"""
 import sys, time, ctypes as C, numpy as np, torch
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import seekstorm_amd as S
 from seekstorm_amd import _native as N
 from oracle import oracle as O
@@ -23,7 +23,7 @@ for name, strat in (("exhaustive", N.BM25_EXHAUSTIVE), ("pruned", N.BM25_PRUNED)
     sh.set_strategy(strat)
     for rt, rn in ((N.RT_TOPK, "Topk"), (N.RT_TOPKCOUNT, "TopkCount")):
         def step():
-            N.check(L.ss_bm25_search_dev(sh._h, 1000, qd.data_ptr(), k, rt, 1 | (2 << 8), od.data_ptr(), os_.data_ptr(), oc.data_ptr(), ot.data_ptr(), None), "s")
+            N.check(L.ss_bm25_search_dev(sh._h, 1000, qd.data_ptr(), k, rt, 1 | 64 | (2 << 8) | (2 << 16), od.data_ptr(), os_.data_ptr(), oc.data_ptr(), ot.data_ptr(), None), "s")
         step(); sh_sync = L.ss_shard_sync(sh._h)
         t0 = time.perf_counter()
         for _ in range(10): step()
