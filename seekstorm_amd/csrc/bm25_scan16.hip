@@ -48,6 +48,16 @@ __device__ __forceinline__ uint32_t s16_addr(uint32_t p, uint32_t accb) {
 // sum q <= S * scale * (1 + 2^-15) + NT, which is what S16_SLACK accounts for.
 __device__ __forceinline__ uint32_t s16_q(uint32_t p, float fidf) { return (uint32_t)(fidf * __uint_as_float((p >> 5) + BM_W_BASE)) + 1u; }
 constexpr uint32_t S16_SLACK = 4u;  // + NT: how far a bound can lie above score * scale (NT roundings up, 65535 * 2^-15 from the decode)
+// The unions' form of the same bound, two VALU operations cheaper per posting: the product is added to 2^23 + 1.5 in ONE fma,
+// which leaves round(idf * scale * weight' + 1.5) in the low mantissa bits of the result -- an integer in (x + 1, x + 2], still
+// an upper bound -- and the float's BITS are used as they are: the low 16 bits are the bound (ds_write_b16 stores just those), and
+// since every such value carries the same upper bits 0x4B00, sums "old entry + bits" and their maxima compare like the bounds
+// themselves (a tile sum stays below 2^16: no carry).  No v_cvt, no "+ 1".  Each posting can now lie up to 2 above its product
+// (the slack of the cut counts 2 NT).
+constexpr uint32_t S16_MBITS = 0x4B000000u;  // bits of 2^23
+__device__ __forceinline__ uint32_t s16_qm(uint32_t p, float fidf) {
+  return __float_as_uint(__builtin_fmaf(fidf, __uint_as_float((p >> 5) + BM_W_BASE), 8388609.5f));
+}
 
 // one 256-posting chunk: first = the tile holds nothing of this item yet (no read), keep = read / add / write,
 // read = read / add, sums stay in registers (last term)
@@ -60,7 +70,7 @@ __device__ __forceinline__ uint32_t s16_first(const u32x4 v, float fidf, uint32_
   const uint32_t pv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
   for (int x = 0; x < 4; x++) {
-    const uint32_t q = s16_q(pv[x], fidf);
+    const uint32_t q = s16_qm(pv[x], fidf);
     lds_st16(s16_addr(pv[x], accb), q);
     mx = max(mx, q);
     if (CNT) cnt += (uint32_t)__popcll(__ballot(pv[x] != 0u));
@@ -75,7 +85,7 @@ __device__ __forceinline__ uint32_t s16_read(const u32x4 v, float fidf, uint32_t
   for (int x = 0; x < 4; x++) old[x] = lds_ld16(s16_addr(pv[x], accb));
 #pragma unroll
   for (int x = 0; x < 4; x++) {
-    nw[x] = old[x] + s16_q(pv[x], fidf);
+    nw[x] = old[x] + s16_qm(pv[x], fidf);
     mx = max(mx, nw[x]);
     if (CNT) cnt += (uint32_t)__popcll(__ballot(old[x] == 0u && pv[x] != 0u));
   }
@@ -242,7 +252,8 @@ __device__ __forceinline__ BmTop<KPL> s16_trigger(BmTop<KPL> T, S16Cur<NT * CPT>
         const uint32_t mid = (lo + hi + 1u) >> 1;
         if ((uint32_t)__popcll(__ballot(lm >= mid)) >= k) lo = mid; else hi = mid - 1u;
       }
-      qcut = max(qcut, lo > (((uint32_t)NT + S16_SLACK) << SH) ? lo - (((uint32_t)NT + S16_SLACK) << SH) : 1u);
+      constexpr uint32_t SLACK = ((AND ? (uint32_t)NT : 2u * (uint32_t)NT) + S16_SLACK) << SH;
+      qcut = max(qcut, lo > SLACK ? lo - SLACK : 1u);
     }
     uint32_t hotbits = 0u;  // bit i: slot i of this lane holds a bound at or above the cut
 #pragma unroll
@@ -507,7 +518,7 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
       if (CNT) T.matched += cnt;
       const float thr = fmaxf(T.wsc, __uint_as_float(tau_bits));
       const uint32_t qthr = k ? (thr > 0.f ? (uint32_t)(thr * scale_thr) : 0u) : 0xFFFFFFFFu;  // k = 0 (ResultType::Count): nothing is ranked
-      if (__ballot(mx >= qthr)) {
+      if (__ballot(mx >= (k ? qthr + S16_MBITS : 0xFFFFFFFFu))) {  // mx = the bits of 2^23 + the largest bound (s16_qm)
         hit = true;
 #pragma unroll
         for (int c = 0; c < CPT; c++)
