@@ -120,9 +120,11 @@ def main():
     ap.add_argument("--parity-queries", type=int, default=1000, help="C2 queries checked against the full-size oracle (all of the batch by default)")
     ap.add_argument("--cpu-queries", type=int, default=32, help="C2 queries the cpu_baseline leg cycles through")
     ap.add_argument("--no-concurrent", action="store_true", help="skip the concurrent-callers legs (T host threads, one query per call)")
+    ap.add_argument("--no-sharded", action="store_true", help="skip the ss_*_search_sharded legs at N = 1 (no RCCL communicator is then created: "
+                    "profiler runs -- RCCL's initialisation faults under rocprofv3 on this image)")
     args = ap.parse_args()
     if args.quick:
-        args.no_cpu = args.no_parity = True
+        args.no_cpu = args.no_parity = args.no_sharded = True
         args.calls_per_step, args.min_seconds = min(args.calls_per_step, 2), 0.0
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -163,7 +165,8 @@ def main():
     assert sptr.value, "expected a non-null HIP stream handle"
     sh = S.Shard(local_rank, shard_id=rank)
     sh.synth_partition(rank, world)
-    comm = D.ShardComm(rank, world, local_rank)  # RCCL communicator behind the C ABI (ss_comm_create); one rank at N = 1
+    # RCCL communicator behind the C ABI (ss_comm_create); at N = 1 only for the sharded legs (one rank: the exchange is the identity)
+    comm = D.ShardComm(rank, world, local_rank) if (world > 1 or not args.no_sharded) else None
     merged = {}
 
     def timed(step_fn, steps, warmup):
@@ -742,7 +745,7 @@ def main():
         # ---- the multi-shard entry points: this rank's shard task + ONE all-gather + merge (hybrid: RRF after the gather)
         # behind the C ABI, host queries in, merged answers out on every rank; with one rank the exchange is the identity.
         # allgather_us = HIP events around the collective alone (ss_comm_profile).
-        if bm is not None and not args.quick:
+        if bm is not None and comm is not None and not args.quick:
             comm.profile(True)
             sh.set_strategy(N.BM25_AUTO)
             sharded = {}
@@ -951,7 +954,8 @@ def main():
         elif vec is not None:
             line["i8"] = vec.get("i8")
         print(json.dumps(line), flush=True)
-    comm.close()
+    if comm is not None:
+        comm.close()
     sh.close()
     if world > 1:
         dist.destroy_process_group()

@@ -16,9 +16,16 @@ G[write]="WRITE_SIZE"
 for g in ${3:-sqA sqB sqC fetch write}; do
   d=gpurun_out/pmc_${TAG}_${g}
   rm -rf $d
-  ( cd /tmp && timeout 600 rocprofv3 --pmc ${G[$g]} --kernel-trace -d $OLDPWD/$d -o x -- python $OLDPWD/bench.py --workload $WL --quick --no-topk-count --steps 4 --warmup 1 > $OLDPWD/$d.log 2>&1 )
+  ( cd /tmp && timeout -k 5 240 rocprofv3 --pmc ${G[$g]} --kernel-trace -d $OLDPWD/$d -o x -- python $OLDPWD/bench.py --workload $WL --quick --no-topk-count --steps 4 --warmup 1 > $OLDPWD/$d.log 2>&1 )
   db=$(find $d -name "*results.db" | head -1)
   echo "=== group $g ($db)" >> $OUT
   python tools/rocpd_pmc.py $db >> $OUT 2>&1
 done
 tail -3 gpurun_out/pmc_${TAG}_sqA.log >> $OUT
+# the rocpd databases are far too large to travel back from the GPU box (gpurun_out/ is merged only below 64 MiB): reduce them
+# HERE to the summary + pmc_traffic.json, keep those in gpurun_out/ (copy them into profiles/ afterwards), drop the databases
+if [ -z "${3:-}" ]; then
+  python tools/pmc_summary.py gpurun_out $TAG > /dev/null 2>> $OUT
+  cp profiles/${TAG}_pmc_summary.md profiles/pmc_traffic.json gpurun_out/ 2>> $OUT
+  rm -rf gpurun_out/pmc_${TAG}_*/
+fi

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 R=$PWD
 d=$R/gpurun_out/stats_$TAG
 rm -rf $d
-( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $d -o x -- python $R/bench.py --no-cpu --no-parity ${2:-} > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err )
+( cd /tmp && timeout -k 5 420 rocprofv3 --kernel-trace --stats -d $d -o x -- python $R/bench.py --no-cpu --no-parity --no-sharded ${2:-} > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err )
 db=$(find $d -name "*results.db" | head -1)
 python tools/rocpd_stats.py $db gpurun_out/${TAG}_kernel_stats.md > /dev/null
 rm -rf $d
