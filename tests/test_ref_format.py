@@ -680,3 +680,63 @@ def test_ngram_keys_of_a_multi_field_index_score_like_their_component_lists():
             assert int(ra[3][0]) > 0
     a.close()
     b.close()
+
+
+def _hand_index_bin():
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("hand_assembled_index_bin", os.path.join(os.path.dirname(__file__), "golden", "hand_assembled_index_bin.py"))
+    H = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(H)
+    return H
+
+
+@pytest.mark.parametrize("head", [20, 22, 23])
+def test_hand_assembled_whole_index_bin(head):
+    """the FILE WALK (version header, per-level header, length bytes, cumulative counts, segment head table, sorted key heads of
+    20 / 22 / 23 bytes, re-based key bodies, an incomplete last level) on a file assembled by hand from the reference's writers
+    (tests/golden/hand_assembled_index_bin.py: every field cites commit.rs / compress_postinglist.rs / index.rs) -- not by
+    oracle/ref_format.py, the restated writer the other index.bin tests use"""
+    H = _hand_index_bin()
+    data, psum = H.build(head)
+    ix = S.IndexBin(data, 1, head, H.SEGMENT_NUMBER_BITS)
+    assert ix.indexed_doc_count == H.N_DOCS and ix.level_count == 2 and ix.positions_sum_normalized == psum
+    assert ix.term_count == 3 and ix.ngram_keys_skipped == 0
+    assert [int(k) for k in ix.term_keys] == sorted(H.EXPECT)  # term id = rank of the key hash
+    for key, (docs, tfs) in H.EXPECT.items():
+        d, f = ix.postings(ix.term_of_key(key))
+        assert d.tolist() == list(docs) and f.tolist() == list(tfs), hex(key)
+    ix.close()
+    # a truncated file and a key head that points outside its segment are refused, not read past
+    for bad in (data[:len(data) - 7], data[:4 + 2 + 65536 + 16 + 3]):
+        with pytest.raises(Exception):
+            S.IndexBin(bad, 1, head, H.SEGMENT_NUMBER_BITS)
+
+
+@pytest.mark.gpu
+def test_hand_assembled_index_bin_answers_like_its_arrays():
+    """the image built from the hand-assembled file = the image built from the postings the file was assembled from: same lexical
+    info (avgdl from the stored positions_sum_normalized / indexed_doc_count), same answers, and the oracle's scores"""
+    from oracle import oracle as O
+    H = _hand_index_bin()
+    data, psum = H.build(20)
+    ix = S.IndexBin(data, 1, 20, H.SEGMENT_NUMBER_BITS)
+    a, b = S.Shard(0), S.Shard(0)
+    a.upload_index_bin(ix)
+    keys = sorted(H.EXPECT)
+    dl = np.array(H.doclen_bytes(0) + H.doclen_bytes(1)[:H.LEVEL1_DOCS], np.uint8)
+    offs = np.zeros(len(keys) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(H.EXPECT[k][0]) for k in keys])
+    alld = np.concatenate([np.asarray(H.EXPECT[k][0], np.uint32) for k in keys])
+    allt = np.concatenate([np.asarray(H.EXPECT[k][1], np.uint16) for k in keys])
+    b.upload_lexical(H.N_DOCS, dl, offs, alld, allt)
+    osh = O.Shard(H.N_DOCS, dl, offs, alld, allt)
+    assert a.lexical_info() == b.lexical_info()
+    for qt, op, q in ((S.QueryType.Union, O.OP_OR, [0, 1, 2]), (S.QueryType.Union, O.OP_OR, [0]), (S.QueryType.Intersection, O.OP_AND, [1, 2])):
+        ra = a.search_lexical_batch(a.make_queries([q], qt), 10)
+        rb_ = b.search_lexical_batch(b.make_queries([q], qt), 10)
+        for x, y in zip(ra, rb_):
+            assert np.array_equal(x, y)
+        od, os_, otot = osh.search_exhaustive(q, op, 10)
+        assert int(ra[3][0]) == otot and np.allclose(ra[1][0][:ra[2][0]], os_, rtol=1e-4)
+    a.close()
+    b.close()
