@@ -216,6 +216,20 @@ int ss_bm25_synth(ss_shard* s, uint64_t seed, uint64_t n_docs, uint32_t n_terms,
  * the generator stream.  Applies to the following ss_bm25_synth / ss_vec_synth[_i8] calls; default 0 of 1. */
 int ss_synth_set_partition(ss_shard* s, uint32_t shard_id, uint32_t n_shards);
 int ss_bm25_info(ss_shard* s, uint64_t* n_docs, float* avgdl, uint32_t* n_terms, uint64_t* n_postings);
+/* SPARSE TIER: the posting lists of RARE terms as plain sorted arrays -- no per-sub-block directory row (4 B per 4096 docs and
+ * list: 9.8 KB at 10 M docs, whatever the list's length), no probe row; 8 bytes per posting.  A real vocabulary holds millions of
+ * keys, almost all rare (key_count per segment, index.rs:3419-3740): they go here, the lists that cost query time stay in the
+ * dense image.  Appends n_lists lists (CSR over offs[n_lists + 1]: ascending doc ids, tf >= 1) to an image with ONE indexed
+ * field; sparse list i of the call becomes term *first_term_id_out + i (ids continue behind the dense terms and earlier appends).
+ * A query may mix dense and sparse terms through the host-pointer entry points (ss_bm25_search[_filtered without filters],
+ * ss_bm25_search_sharded, the coalesced single-query calls): unions -- the dense terms through the ordinary kernels, every doc of a
+ * sparse list scored in full by binary-search probes of the query's other lists (north_star's galloping, intersection.rs:352-362),
+ * the two lists merged per query; intersections -- the shortest sparse list drives.  Exact counts, tombstones, NOT terms
+ * (in a union: dense NOT terms only).  k <= 128; no phrases, field filters or facet filters over sparse terms (SS_ENOTSUP);
+ * the device-pointer entry points take dense terms only.  ss_bm25_term_df covers the sparse ids. */
+int ss_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
+                          uint32_t* first_term_id_out);
+int ss_bm25_sparse_info(ss_shard* s, uint32_t* n_lists, uint64_t* n_postings, uint64_t* bytes);
 /* Search strategy.  AUTO: requests with <= 4 scored terms and k <= 128 take the PRUNED path (the reference's block-max /
  * sub-query pruning, intersection.rs:2224-2233, union.rs:1355-1405, as MaxScore over a probe index: only essential /
  * shortest lists are read; exact union counts are popcounts over the index's bit records like union_count,

@@ -1,0 +1,246 @@
+// Sparse tier of the BM25 image: posting lists of RARE terms as plain sorted arrays, without a per-sub-block directory row and
+// without probe rows.  A real vocabulary holds millions of keys (a segment's key_count, index.rs:3419-3740), almost all of them
+// rare: in the dense tier every list costs a directory row of 4 B per 4096-doc sub-block whatever its length (9.8 KB at 10 M
+// docs -- 10 GB per million terms); here a posting costs 8 bytes and a list nothing else.  north_star's "galloping intersection"
+// (intersection.rs:352-362) is what such lists are read by: every doc of a sparse list is looked up in the query's other lists
+// by binary search -- in another sparse list over the whole array, in a dense list inside the doc's (term, sub-block) segment.
+//
+// Term ids: dense lists keep 0 .. bm_n_terms - 1, sparse list i is term bm_n_terms + i (ss_bm25_append_sparse).
+// A query that names a sparse term is answered in two parts (ss_api.hip bm25_search_tiered):
+//   * unions: its DENSE terms alone through the ordinary kernels (any strategy), and every doc of its sparse lists scored in
+//     FULL here (own posting + every other term probed).  A doc holding a sparse term is thus complete in this kernel's list and
+//     at most partial in the dense list; a doc without one is complete in the dense list.  The union of the two lists, a doc kept
+//     once with its larger (= full) score, holds the exact top-k: a doc of the true top-k that holds no sparse term is outranked in
+//     the dense pass only by docs whose partial, hence full, scores are higher -- fewer than k of them;
+//     exact count = the dense union's count + the docs found here in no dense list (each counted under the first sparse list
+//     that holds it);
+//   * intersections: the shortest sparse list drives, every other term must hit: this kernel alone answers (and counts).
+// Scores: fma chain in query-term order, weights from the same 19-bit codes -- what the dense kernels compute for the same doc.
+#include "bm25_dev.h"
+
+namespace {
+
+constexpr int SP_WAVES = 4;
+
+// index of doc in the sparse list [lo, hi) (ascending docs in the low 32 bits), or ~0
+__device__ __forceinline__ unsigned long long sp_find(const unsigned long long* __restrict__ sp, unsigned long long lo, unsigned long long hi, uint32_t doc) {
+  while (lo < hi) {
+    const unsigned long long mid = (lo + hi) >> 1;
+    const uint32_t d = (uint32_t)sp[mid];
+    if (d < doc) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+// weight code of doc in a DENSE list, 0 = absent: binary search inside the doc's (term, sub-block) segment -- packed postings
+// ascending by doc field, NULL (zero) padding at the segment's end ordering as +infinity
+__device__ __forceinline__ uint32_t dense_find(const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base,
+                                               const uint32_t* __restrict__ sub_off, uint32_t n_sub, uint32_t row, uint32_t doc) {
+  const uint32_t sb = doc >> BM_SUB_LOG2, want = (doc & (BM_SUB - 1)) + 1u;
+  const uint32_t* r = sub_off + (size_t)row * (n_sub + 1);
+  const unsigned long long base = (term_base[row] + r[sb]) * 4ull;
+  uint32_t lo = 0, hi = (r[sb + 1] - r[sb]) * 4u;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    const uint32_t f = bm_doc_field(post[base + mid]);
+    if (f != 0u && f < want) lo = mid + 1; else hi = mid;
+  }
+  if (lo < (r[sb + 1] - r[sb]) * 4u) {
+    const uint32_t p = post[base + lo];
+    if (bm_doc_field(p) == want) return p >> 13 ? p >> 13 : 1u;  // (a code of 0 cannot occur: bm_wcode clamps to 1)
+  }
+  return 0u;
+}
+
+template <int KPL>
+__global__ void __launch_bounds__(SP_WAVES * 64) bm25_sparse_kernel(
+    const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base, const uint32_t* __restrict__ sub_off, uint32_t n_sub,
+    uint32_t n_dense, const unsigned long long* __restrict__ sp_base, const unsigned long long* __restrict__ sp_post, uint32_t n_sparse,
+    const ss_bm25_query* __restrict__ qs, uint32_t nq, uint32_t k, const uint32_t* __restrict__ del, uint32_t del_words,
+    unsigned long long* __restrict__ out_keys /* [nq][64 KPL] */, unsigned long long* __restrict__ out_extra /* [nq] */) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t qi = blockIdx.x * SP_WAVES + (threadIdx.x >> 6);
+  if (qi >= nq) return;
+  const ss_bm25_query* __restrict__ Q = qs + qi;
+  const uint32_t nt = Q->n_terms, n_not = bm_q_nnot(Q->op);
+  const bool is_and = bm_q_op(Q->op) == SS_OP_INTERSECTION && nt > 1;
+  BmTop<KPL> T;
+#pragma unroll
+  for (int r = 0; r < KPL; r++) T.keys[r] = 0ull;
+  T.worst = 0ull;
+  T.wsc = -1.0f;
+  T.matched = 0;
+  // the driver lists: a union walks every sparse list of the query, an intersection only its shortest one
+  uint32_t first = 0, last = nt;
+  if (is_and) {
+    unsigned long long best = ~0ull;
+    for (uint32_t t = 0; t < nt; t++)
+      if (Q->term[t] >= n_dense) {
+        const uint32_t i = Q->term[t] - n_dense;
+        const unsigned long long len = sp_base[i + 1] - sp_base[i];
+        if (len < best) { best = len; first = t; }
+      }
+    last = first + 1;
+  }
+  for (uint32_t s = first; s < last; s++) {
+    if (Q->term[s] < n_dense) continue;
+    const uint32_t si = Q->term[s] - n_dense;
+    const unsigned long long b0 = sp_base[si], b1 = sp_base[si + 1];
+    for (unsigned long long x = b0; x < b1; x += 64) {
+      const bool live0 = x + (unsigned)lane < b1;
+      const unsigned long long e = live0 ? sp_post[x + lane] : 0ull;
+      const uint32_t doc = (uint32_t)e;
+      bool live = live0, in_dense = false;
+      float wv[SS_MAX_QUERY_TERMS];
+      uint32_t pres = 0u;
+#pragma unroll
+      for (int t = 0; t < SS_MAX_QUERY_TERMS; t++) wv[t] = 0.f;
+#pragma unroll
+      for (int t = 0; t < SS_MAX_QUERY_TERMS; t++) {
+        if ((uint32_t)t >= nt + n_not) break;
+        uint32_t code = 0u;
+        if ((uint32_t)t == s) {
+          code = (uint32_t)(e >> 32);
+        } else if (live) {
+          const uint32_t term = Q->term[t];
+          if (term >= n_dense) {
+            const uint32_t j = term - n_dense;
+            const unsigned long long p = sp_find(sp_post, sp_base[j], sp_base[j + 1], doc);
+            if (p < sp_base[j + 1] && (uint32_t)sp_post[p] == doc) code = (uint32_t)(sp_post[p] >> 32);
+            // a union scores a doc under the FIRST sparse list of the query that holds it
+            if (code && !is_and && (uint32_t)t < s && (uint32_t)t < nt) live = false;
+          } else {
+            code = dense_find(post, term_base, sub_off, n_sub, term, doc);
+            if (code && (uint32_t)t < nt) in_dense = true;
+          }
+        }
+        if ((uint32_t)t >= nt) {  // NOT terms: a doc found in one is no result (add_result.rs:3440-3497)
+          if (code) live = false;
+        } else {
+          if (is_and && !code) live = false;
+          if (code) { wv[t] = bm_wdecode(code); pres |= 1u << t; }
+        }
+      }
+      if (live && del && (doc >> 5) < del_words && ((del[doc >> 5] >> (doc & 31u)) & 1u)) live = false;  // add_result.rs:3435
+      // exact counts: an intersection's matches; of a union the docs the dense pass cannot have counted
+      const unsigned long long cm = __ballot(is_and ? live : (live && !in_dense));
+      T.matched += (unsigned long long)__popcll(cm);
+      if (k && __ballot(live)) {
+        float score = 0.f;
+#pragma unroll
+        for (int t = 0; t < SS_MAX_QUERY_TERMS; t++)
+          if ((uint32_t)t < nt && ((pres >> t) & 1u)) score = fmaf(Q->idf[t], wv[t], score);
+        unsigned long long key = (live && score > 0.f) ? (((unsigned long long)__float_as_uint(score) << 32) | (unsigned long long)(0xFFFFFFFFu - doc)) : 0ull;
+        key = key > T.worst ? key : 0ull;
+        if (__ballot(key != 0ull)) T = bm_offer_lane_keys<KPL>(T, key, k, nullptr);
+      }
+    }
+  }
+  unsigned long long* out = out_keys + (size_t)qi * (64 * KPL);
+#pragma unroll
+  for (int r = 0; r < KPL; r++) out[r * 64 + lane] = T.keys[r];
+  if (lane == 0) out_extra[qi] = T.matched;
+}
+
+// The answer of a tiered query: dense list (this query's dense terms through the ordinary kernels; none for an intersection or a
+// query without dense terms: dense_row = ~0) and the sparse kernel's list, a doc kept once with its larger score, top-k by
+// (score desc, doc asc); total = dense total + the sparse kernel's count.  Rows of queries without sparse terms are copied.
+// One wave per query.
+template <int KPL>
+__global__ void __launch_bounds__(SP_WAVES * 64) bm25_tier_merge_kernel(
+    uint32_t nq, uint32_t k, uint32_t kk /* row stride of the dense lists, max(k, 1) */, const uint32_t* __restrict__ dense_row /* [nq] row in the dense outputs or ~0 */,
+    const uint32_t* __restrict__ sparse_row /* [nq] row in the sparse outputs or ~0 */, const uint32_t* __restrict__ d_doc,
+    const float* __restrict__ d_score, const uint32_t* __restrict__ d_count, const unsigned long long* __restrict__ d_total,
+    const unsigned long long* __restrict__ sp_keys, const unsigned long long* __restrict__ sp_extra, uint32_t* __restrict__ o_doc,
+    float* __restrict__ o_score, uint32_t* __restrict__ o_count, unsigned long long* __restrict__ o_total) {
+  __shared__ unsigned long long skeys[SP_WAVES][64 * KPL];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t qi = blockIdx.x * SP_WAVES + w;
+  if (qi >= nq) return;
+  const uint32_t dr = dense_row[qi], sr = sparse_row[qi];
+  BmTop<KPL> T;
+#pragma unroll
+  for (int r = 0; r < KPL; r++) T.keys[r] = 0ull;
+  T.worst = 0ull; T.wsc = -1.f; T.matched = 0;
+  unsigned long long total = 0ull;
+  if (sr != 0xFFFFFFFFu) {
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+      T.keys[r] = sp_keys[(size_t)sr * (64 * KPL) + r * 64 + lane];  // sorted, rank r * 64 + lane
+      skeys[w][r * 64 + lane] = T.keys[r];
+    }
+    total += sp_extra[sr];
+    T.worst = topk_finish<KPL>(T.keys, max(k, 1u), lane);
+  } else {
+#pragma unroll
+    for (int r = 0; r < KPL; r++) skeys[w][r * 64 + lane] = 0ull;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (dr != 0xFFFFFFFFu) {
+    total += d_total[dr];
+    uint32_t n = d_count[dr];
+    if (n == 0xFFFFFFFFu) n = 0;
+    n = min(n, k);
+    for (uint32_t x = 0; x < n; x += 64) {
+      unsigned long long key = 0ull;
+      if (x + (uint32_t)lane < n) {
+        const uint32_t doc = d_doc[(size_t)dr * kk + x + lane];
+        key = ((unsigned long long)__float_as_uint(d_score[(size_t)dr * kk + x + lane]) << 32) | (unsigned long long)(0xFFFFFFFFu - doc);
+        const uint32_t lowkey = 0xFFFFFFFFu - doc;
+        for (int j = 0; j < 64 * KPL; j++) {  // the doc is in the sparse list as well: that entry carries the full score
+          const unsigned long long sk = skeys[w][j];
+          if (sk == 0ull) break;
+          if ((uint32_t)sk == lowkey) { key = 0ull; break; }
+        }
+      }
+      T.worst = topk_merge64<KPL>(T.keys, key, max(k, 1u), lane);
+    }
+  }
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int r = 0; r < KPL; r++) {
+    const uint32_t rank = r * 64 + lane;
+    if (rank < k) {
+      const unsigned long long key = T.keys[r];
+      o_doc[(size_t)qi * kk + rank] = key ? 0xFFFFFFFFu - (uint32_t)key : 0xFFFFFFFFu;
+      o_score[(size_t)qi * kk + rank] = key ? __uint_as_float((uint32_t)(key >> 32)) : 0.f;
+    }
+    cnt += (uint32_t)__popcll(__ballot(rank < k && T.keys[r] != 0ull));
+  }
+  if (lane == 0) { o_count[qi] = cnt; o_total[qi] = total; }
+}
+
+}  // namespace
+
+int ssi_bm25_launch_sparse(const ss_shard* s, const ss_bm25_query* d_q, uint32_t nq, uint32_t k, unsigned long long* d_keys,
+                           unsigned long long* d_extra, hipStream_t st) {
+  const int KPL = std::max<uint32_t>(k, 1) <= 64 ? 1 : 2;
+  const uint32_t grid = (nq + SP_WAVES - 1) / SP_WAVES;
+  const uint32_t* del = s->n_deleted ? s->d_deleted : nullptr;
+  if (KPL == 1)
+    bm25_sparse_kernel<1><<<grid, SP_WAVES * 64, 0, st>>>(s->d_post, (const unsigned long long*)s->d_term_base, s->d_sub_off, s->bm_n_sub, s->bm_n_terms,
+                                                         (const unsigned long long*)s->d_sp_base, (const unsigned long long*)s->d_sp_post, s->sp_n, d_q, nq, k,
+                                                         del, (uint32_t)s->deleted_words, d_keys, d_extra);
+  else
+    bm25_sparse_kernel<2><<<grid, SP_WAVES * 64, 0, st>>>(s->d_post, (const unsigned long long*)s->d_term_base, s->d_sub_off, s->bm_n_sub, s->bm_n_terms,
+                                                         (const unsigned long long*)s->d_sp_base, (const unsigned long long*)s->d_sp_post, s->sp_n, d_q, nq, k,
+                                                         del, (uint32_t)s->deleted_words, d_keys, d_extra);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
+int ssi_bm25_launch_tier_merge(uint32_t nq, uint32_t k, const uint32_t* d_dense_row, const uint32_t* d_sparse_row, const uint32_t* d_doc,
+                               const float* d_score, const uint32_t* d_count, const unsigned long long* d_total, const unsigned long long* d_keys,
+                               const unsigned long long* d_extra, uint32_t* o_doc, float* o_score, uint32_t* o_count, unsigned long long* o_total,
+                               hipStream_t st) {
+  const uint32_t kk = std::max<uint32_t>(k, 1);
+  const int KPL = kk <= 64 ? 1 : 2;
+  const uint32_t grid = (nq + SP_WAVES - 1) / SP_WAVES;
+  if (KPL == 1)
+    bm25_tier_merge_kernel<1><<<grid, SP_WAVES * 64, 0, st>>>(nq, k, kk, d_dense_row, d_sparse_row, d_doc, d_score, d_count, d_total, d_keys, d_extra, o_doc,
+                                                             o_score, o_count, o_total);
+  else
+    bm25_tier_merge_kernel<2><<<grid, SP_WAVES * 64, 0, st>>>(nq, k, kk, d_dense_row, d_sparse_row, d_doc, d_score, d_count, d_total, d_keys, d_extra, o_doc,
+                                                             o_score, o_count, o_total);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}

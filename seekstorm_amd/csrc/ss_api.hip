@@ -117,8 +117,10 @@ static void free_vec(ss_shard* s) {
   ssi_vec_free_clusters(s);
 }
 static void free_bm25(ss_shard* s) {
-  void* ptrs[] = {s->d_post, s->d_term_base, s->d_sub_off, s->d_comp, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_umax, s->d_submax, s->d_boost, s->d_pos, s->d_pos_off, s->d_pos_base};
+  void* ptrs[] = {s->d_post, s->d_term_base, s->d_sub_off, s->d_comp, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_umax, s->d_submax, s->d_boost, s->d_pos, s->d_pos_off, s->d_pos_base,
+                  s->d_doclen, s->d_sp_base, s->d_sp_post};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  s->d_doclen = nullptr; s->d_sp_base = nullptr; s->d_sp_post = nullptr; s->sp_n = 0; s->h_sp_base.clear();
   s->d_post = nullptr; s->d_term_base = nullptr; s->d_sub_off = nullptr; s->d_comp = nullptr;
   s->probe_pool_begin = 0; s->probe_pool_rows = 0; s->pool_list.clear(); s->pool_tick.clear();
   s->d_probe = nullptr; s->d_probe_z = nullptr; s->d_probe_row = nullptr; s->h_probe_row.clear(); s->bm_probe_rows = 0; s->d_umax = nullptr; s->d_submax = nullptr; s->d_pos = nullptr; s->d_pos_off = nullptr; s->d_pos_base = nullptr;
@@ -132,7 +134,7 @@ int ss_shard_destroy(ss_shard* s) {
   (void)hipStreamSynchronize(s->stream);
   free_vec(s);
   free_bm25(s);
-  void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_deleted, s->d_facets, s->d_filter_bits, s->d_facet_ws, s->d_pool_stage};
+  void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_deleted, s->d_facets, s->d_filter_bits, s->d_facet_ws, s->d_pool_stage, s->d_tier_ws};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   (void)hipDeviceSynchronize();  // searches queued on the callers' own streams may still use their workspaces
   for (auto& kv : s->bm_ws) {
@@ -452,9 +454,31 @@ int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df
   if (!s || !terms || !df_out) return SS_EINVAL;
   if (!s->d_post) return SS_ESTATE;
   for (uint32_t i = 0; i < n; i++) {
-    if (terms[i] >= s->bm_n_terms / s->bm_n_fields) return SS_EINVAL;
-    df_out[i] = s->bm_n_fields > 1 ? s->h_df_real[terms[i]] : s->h_df[terms[i]];
+    const uint32_t n_dense = s->bm_n_terms / s->bm_n_fields;
+    if (terms[i] >= n_dense + s->sp_n) return SS_EINVAL;
+    if (terms[i] >= n_dense) df_out[i] = s->h_sp_base[terms[i] - n_dense + 1] - s->h_sp_base[terms[i] - n_dense];  // sparse tier
+    else df_out[i] = s->bm_n_fields > 1 ? s->h_df_real[terms[i]] : s->h_df[terms[i]];
   }
+  return SS_OK;
+}
+
+int ss_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
+                          uint32_t* first_term_id_out) {
+  if (!s || !offs || (n_lists && offs[n_lists] > offs[0] && (!docs || !tfs))) return SS_EINVAL;
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  SS_HIP(hipStreamSynchronize(s->stream));  // searches in flight still read the arrays an append replaces
+  const uint32_t first = s->bm_n_terms + s->sp_n;
+  SS_TRY(ssi_bm25_append_sparse(s, n_lists, offs, docs, tfs));
+  if (first_term_id_out) *first_term_id_out = first;
+  return SS_OK;
+}
+int ss_bm25_sparse_info(ss_shard* s, uint32_t* n_lists, uint64_t* n_postings, uint64_t* bytes) {
+  if (!s) return SS_EINVAL;
+  const uint64_t np = s->h_sp_base.empty() ? 0 : s->h_sp_base.back();
+  if (n_lists) *n_lists = s->sp_n;
+  if (n_postings) *n_postings = np;
+  if (bytes) *bytes = np * 8 + ((uint64_t)s->sp_n + 1) * 8;
   return SS_OK;
 }
 
@@ -763,9 +787,102 @@ static int bm25_search_split_batch(ss_shard* s, uint32_t nq, const ss_bm25_query
   return SS_OK;
 }
 
+static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, uint32_t n_filters,
+                                    const ss_facet_filter* filters);
+
+// A batch in which some query names a term of the SPARSE tier (bm25_sparse.hip).  Those queries are answered in two parts -- their
+// dense terms through the ordinary path (together with the batch's all-dense queries: one sub-batch), their sparse lists by the
+// sparse kernel, which scores every doc of a sparse list in full -- and put together per query by bm25_tier_merge_kernel; the
+// answers land in s->d_out_* in the callers' order, like any other batch's.  Caller holds s->mu.
+static int bm25_search_tiered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt) {
+  const uint32_t n_dense = s->bm_n_terms;
+  if (s->bm_n_fields != 1) return SS_ENOTSUP;
+  if (kk > 128) return SS_ENOTSUP;  // the two lists of a query are merged in one wave's registers
+  std::vector<ss_bm25_query> sub;      // the dense sub-batch: all-dense queries as they are, tiered unions reduced to their dense terms
+  std::vector<ss_bm25_query> spq;      // the tiered queries, whole, for the sparse kernel
+  std::vector<uint32_t> dense_row(nq, 0xFFFFFFFFu), sparse_row(nq, 0xFFFFFFFFu);
+  for (uint32_t i = 0; i < nq; i++) {
+    const uint32_t op = bm_q_op(q[i].op), n_not = bm_q_nnot(q[i].op), all = q[i].n_terms + n_not;
+    if (q[i].n_terms == 0 || all > SS_MAX_QUERY_TERMS) return SS_EINVAL;
+    bool any_sparse = false, sparse_not = false;
+    for (uint32_t t = 0; t < all; t++) {
+      if (q[i].term[t] >= n_dense + s->sp_n) return SS_EINVAL;
+      if (q[i].term[t] >= n_dense) { any_sparse = true; sparse_not |= t >= q[i].n_terms; }
+      if (t < q[i].n_terms && !(q[i].idf[t] > 0.0f)) return SS_EINVAL;
+      for (uint32_t u = 0; u < t; u++)
+        if (q[i].term[u] == q[i].term[t]) return SS_EINVAL;
+    }
+    if (!any_sparse) {
+      dense_row[i] = (uint32_t)sub.size();
+      sub.push_back(q[i]);
+      continue;
+    }
+    if (op != SS_OP_INTERSECTION && op != SS_OP_UNION) return SS_ENOTSUP;  // no phrases over sparse lists
+    if (bm_q_field_filter(q[i].op) || bm_q_all_frequent(q[i].op)) return SS_ENOTSUP;
+    const bool is_and = op == SS_OP_INTERSECTION && q[i].n_terms > 1;
+    if (sparse_not && !is_and) return SS_ENOTSUP;  // a union's dense part could not honour a sparse NOT list
+    sparse_row[i] = (uint32_t)spq.size();
+    spq.push_back(q[i]);
+    if (!is_and) {  // the union's dense terms (with its NOT terms) as a query of their own
+      ss_bm25_query d = q[i];
+      uint32_t n = 0;
+      for (uint32_t t = 0; t < q[i].n_terms; t++)
+        if (q[i].term[t] < n_dense) { d.term[n] = q[i].term[t]; d.idf[n] = q[i].idf[t]; n++; }
+      if (n) {
+        for (uint32_t t = 0; t < n_not; t++) d.term[n + t] = q[i].term[q[i].n_terms + t];
+        for (uint32_t t = n + n_not; t < (uint32_t)SS_MAX_QUERY_TERMS; t++) { d.term[t] = 0; if (t >= n) d.idf[t] = 0.f; }
+        d.n_terms = n;
+        dense_row[i] = (uint32_t)sub.size();
+        sub.push_back(d);
+      }
+    }
+  }
+  SS_HIP(hipSetDevice(s->device));
+  const uint32_t kw = std::max<uint32_t>(kk, 1), ns = (uint32_t)spq.size(), nd = (uint32_t)sub.size();
+  const int KPL = kw <= 64 ? 1 : 2;
+  SS_TRY(ensure_out(s, std::max<size_t>(nq, nd), kw));  // reserved before the sub-batch runs: its own ensure_out then keeps the buffers
+  // workspace: [sparse queries][row maps 2 nq][sparse keys][sparse counts][merged doc | score | count | total]
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t o_q = 0, o_dr = o_q + al((size_t)ns * sizeof(ss_bm25_query)), o_sr = o_dr + al((size_t)nq * 4), o_keys = o_sr + al((size_t)nq * 4),
+               o_ext = o_keys + al((size_t)ns * 64 * KPL * 8), o_doc = o_ext + al((size_t)ns * 8), o_sc = o_doc + al((size_t)nq * kw * 4),
+               o_cnt = o_sc + al((size_t)nq * kw * 4), o_tot = o_cnt + al((size_t)nq * 4), need = o_tot + al((size_t)nq * 8);
+  if (need > s->tier_ws_cap) {
+    SS_HIP(hipStreamSynchronize(s->stream));
+    if (s->d_tier_ws) (void)hipFree(s->d_tier_ws);
+    s->d_tier_ws = nullptr; s->tier_ws_cap = 0;
+    SS_HIP(hipMalloc(&s->d_tier_ws, need * 2));
+    s->tier_ws_cap = need * 2;
+  }
+  char* W = (char*)s->d_tier_ws;
+  if (nd) SS_TRY(bm25_search_host_queries(s, nd, sub.data(), kk, rt, 0, nullptr));  // -> s->d_out_* rows [0, nd)
+  // (the host vectors are read by synchronous copies: they may die with this frame)
+  SS_HIP(hipMemcpy(W + o_q, spq.data(), (size_t)ns * sizeof(ss_bm25_query), hipMemcpyHostToDevice));
+  SS_HIP(hipMemcpy(W + o_dr, dense_row.data(), (size_t)nq * 4, hipMemcpyHostToDevice));
+  SS_HIP(hipMemcpy(W + o_sr, sparse_row.data(), (size_t)nq * 4, hipMemcpyHostToDevice));
+  SS_TRY(ssi_bm25_launch_sparse(s, (const ss_bm25_query*)(W + o_q), ns, kk, (unsigned long long*)(W + o_keys), (unsigned long long*)(W + o_ext), s->stream));
+  SS_TRY(ssi_bm25_launch_tier_merge(nq, kk, (const uint32_t*)(W + o_dr), (const uint32_t*)(W + o_sr), s->d_out_doc, s->d_out_score, s->d_out_count,
+                                    (const unsigned long long*)s->d_out_total, (const unsigned long long*)(W + o_keys),
+                                    (const unsigned long long*)(W + o_ext), (uint32_t*)(W + o_doc), (float*)(W + o_sc), (uint32_t*)(W + o_cnt),
+                                    (unsigned long long*)(W + o_tot), s->stream));
+  if (kk) {
+    SS_HIP(hipMemcpyAsync(s->d_out_doc, W + o_doc, (size_t)nq * kw * 4, hipMemcpyDeviceToDevice, s->stream));
+    SS_HIP(hipMemcpyAsync(s->d_out_score, W + o_sc, (size_t)nq * kw * 4, hipMemcpyDeviceToDevice, s->stream));
+  }
+  SS_HIP(hipMemcpyAsync(s->d_out_count, W + o_cnt, (size_t)nq * 4, hipMemcpyDeviceToDevice, s->stream));
+  SS_HIP(hipMemcpyAsync(s->d_out_total, W + o_tot, (size_t)nq * 8, hipMemcpyDeviceToDevice, s->stream));
+  return SS_OK;
+}
+
 // the search of ss_bm25_search_filtered / _sharded up to the device lists (s->d_out_*, on s->stream); caller holds s->mu
 static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, uint32_t n_filters,
                                     const ss_facet_filter* filters) {
+  if (s->sp_n) {  // an image with a sparse tier: does the batch name one of its terms?
+    bool any_sparse = false;
+    for (uint32_t i = 0; i < nq && !any_sparse; i++)
+      for (uint32_t t = 0; t < std::min<uint32_t>(q[i].n_terms + bm_q_nnot(q[i].op), SS_MAX_QUERY_TERMS); t++)
+        any_sparse |= q[i].term[t] >= s->bm_n_terms && q[i].term[t] < s->bm_n_terms + s->sp_n;
+    if (any_sparse) return n_filters ? (int)SS_ENOTSUP : bm25_search_tiered(s, nq, q, kk, rt);
+  }
   SS_TRY(ssi_bm25_ensure_probe_rows(s, nq, q, s->stream));
   if (nq > 1 && s->bm_probe_rows != 0 && s->bm_probe_rows < s->bm_n_terms) {  // rationed probe rows: a mixed batch runs as two
     std::vector<uint8_t> probed(nq);

@@ -263,6 +263,15 @@ struct ss_shard {
   float* d_submax = nullptr;       // [n_terms + 1][n_sub] largest weight of every (term, 4096-doc sub-block) segment, 0 = empty: the
                                    // reference's per-block max_block_score / idf (get_max_score, index.rs:2938-3200) at this image's
                                    // block size; the last row (absent terms) is all zero
+  // ---- sparse tier (bm25_sparse.hip): rare terms as plain sorted lists, no directory row, no probe row.  Sparse list i is term
+  // bm_n_terms + i of a single-field image; a posting = weight code << 32 | doc
+  uint8_t* d_doclen = nullptr;       // the length bytes of the docs (one indexed field), kept for ss_bm25_append_sparse
+  uint64_t* d_sp_base = nullptr;     // [sp_n + 1] first posting of every sparse list
+  uint64_t* d_sp_post = nullptr;     // the postings, list after list, ascending docs inside a list
+  uint32_t sp_n = 0;
+  std::vector<uint64_t> h_sp_base;   // host copy of d_sp_base (posting counts = the df the host needs for idf)
+  void* d_tier_ws = nullptr;         // workspace of a tiered search (sub-queries, row maps, sparse lists, merged answers), grow-only
+  size_t tier_ws_cap = 0;
   // bm25 workspace
   void* d_bq = nullptr; size_t bq_cap = 0;       // staged queries
   uint64_t* d_ptotal = nullptr;                   // per (query, partition) match counts
@@ -383,6 +392,14 @@ int ssi_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, cons
 void ssi_prof_begin(ss_shard* s, int kernel, hipStream_t st, hipEvent_t* e0, hipEvent_t* e1);
 void ssi_prof_end(ss_shard* s, int kernel, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 
+// ---- sparse tier (synth.hip: append; bm25_sparse.hip: kernels)
+int ssi_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs);
+int ssi_bm25_launch_sparse(const ss_shard* s, const ss_bm25_query* d_q, uint32_t nq, uint32_t k, unsigned long long* d_keys,
+                           unsigned long long* d_extra, hipStream_t st);
+int ssi_bm25_launch_tier_merge(uint32_t nq, uint32_t k, const uint32_t* d_dense_row, const uint32_t* d_sparse_row, const uint32_t* d_doc,
+                               const float* d_score, const uint32_t* d_count, const unsigned long long* d_total, const unsigned long long* d_keys,
+                               const unsigned long long* d_extra, uint32_t* o_doc, float* o_score, uint32_t* o_count, unsigned long long* o_total,
+                               hipStream_t st);
 struct ss_comm;
 // one per-shard result list of a batch on the device: [nq][k] doc ids / scores, [nq] counts
 struct ss_dev_list { const uint32_t* doc; const float* score; const uint32_t* count; uint32_t k; };

@@ -258,6 +258,10 @@ int ssi_bm25_build_from_host_merged(ss_shard* s, const uint8_t* doclen, const ui
   SS_HIP(hipMemcpy(s->d_term_base, tbase.data(), ((size_t)nt + 1) * sizeof(u64), hipMemcpyHostToDevice));
   SS_HIP(hipMemcpy(s->d_sub_off, sub.data(), sub.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   SS_HIP(hipMemcpy(s->d_comp, comp, sizeof(comp), hipMemcpyHostToDevice));
+  if (L == 1) {  // one indexed field: the length bytes stay on the device for ss_bm25_append_sparse
+    SS_HIP(hipMalloc(&s->d_doclen, s->bm_n_docs));
+    SS_HIP(hipMemcpy(s->d_doclen, doclen, s->bm_n_docs, hipMemcpyHostToDevice));
+  }
   rc = alloc_probe(s, s->stream);
   if (rc) return rc;
   SS_HIP(hipStreamSynchronize(s->stream));
@@ -315,6 +319,46 @@ int ssi_bm25_build_from_host_merged(ss_shard* s, const uint8_t* doclen, const ui
     SS_HIP(hipMemcpy(s->d_probe, probe.data(), probe.size() * sizeof(uint2), hipMemcpyHostToDevice));
     SS_HIP(hipMemcpy(s->d_probe_z, probe_z.data(), probe_z.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
+  return SS_OK;
+}
+
+// ---------------------------------------------------------------- sparse tier: append lists of rare terms to the image
+// (bm25_sparse.hip).  The weights are computed here, on the host, by the same routine and component cache as every dense
+// posting's (bm_code_of): the length bytes come back from the device once per call.
+int ssi_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs) {
+  if (!s->d_post || !s->d_doclen) return SS_ESTATE;
+  if (s->bm_n_fields != 1 || s->bm_merged) return SS_ENOTSUP;
+  if ((uint64_t)s->sp_n + n_lists > 0x7FFFFFFFull - s->bm_n_terms) return SS_ENOTSUP;
+  const u64 n_new = offs[n_lists] - offs[0];
+  std::vector<uint8_t> dl(s->bm_n_docs);
+  SS_HIP(hipMemcpy(dl.data(), s->d_doclen, s->bm_n_docs, hipMemcpyDeviceToHost));
+  float comp[SS_COMP_N];
+  fill_comp(s->bm_avgdl, comp);
+  std::vector<u64> packed(n_new ? n_new : 1);
+  for (uint32_t i = 0; i < n_lists; i++) {
+    if (offs[i + 1] < offs[i]) return SS_EINVAL;
+    for (u64 j = offs[i]; j < offs[i + 1]; j++) {
+      if (docs[j] >= s->bm_n_docs || tfs[j] == 0 || (j > offs[i] && docs[j] <= docs[j - 1])) return SS_EINVAL;
+      packed[j - offs[0]] = ((u64)bm_code_of(tfs[j], comp[dl[docs[j]]], false) << 32) | docs[j];
+    }
+  }
+  const u64 old_n = s->h_sp_base.empty() ? 0 : s->h_sp_base.back();
+  uint64_t *nb = nullptr, *np = nullptr;
+  SS_HIP(hipMalloc(&nb, ((size_t)s->sp_n + n_lists + 1) * sizeof(u64)));
+  if (hipMalloc(&np, (size_t)std::max<u64>(old_n + n_new, 1) * sizeof(u64)) != hipSuccess) { (void)hipFree(nb); return SS_ENOMEM; }
+  std::vector<uint64_t> base = s->h_sp_base;
+  if (base.empty()) base.push_back(0);
+  for (uint32_t i = 0; i < n_lists; i++) base.push_back(old_n + (offs[i + 1] - offs[0]));
+  bool ok = hipMemcpy(nb, base.data(), base.size() * sizeof(u64), hipMemcpyHostToDevice) == hipSuccess;
+  if (ok && old_n) ok = hipMemcpy(np, s->d_sp_post, old_n * sizeof(u64), hipMemcpyDeviceToDevice) == hipSuccess;
+  if (ok && n_new) ok = hipMemcpy(np + old_n, packed.data(), n_new * sizeof(u64), hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) { (void)hipFree(nb); (void)hipFree(np); return SS_EDEVICE; }
+  if (s->d_sp_base) (void)hipFree(s->d_sp_base);
+  if (s->d_sp_post) (void)hipFree(s->d_sp_post);
+  s->d_sp_base = nb;
+  s->d_sp_post = np;
+  s->h_sp_base = std::move(base);
+  s->sp_n += n_lists;
   return SS_OK;
 }
 
@@ -539,7 +583,7 @@ int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const u
   SS_HIP(hipStreamSynchronize(st));
   (void)hipFree(d_wtab);
   (void)hipFree(d_flg);
-  (void)hipFree(d_doclen);
+  s->d_doclen = d_doclen;  // kept: ss_bm25_append_sparse weighs its postings with the docs' length bytes
   (void)hipFree(d_psum);
   (void)hipFree(d_tot);
   (void)hipFree(d_df);

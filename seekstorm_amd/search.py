@@ -948,6 +948,24 @@ class Shard:
         return ro
 
     # ---- measurement hooks
+    def append_sparse(self, term_offsets, doc_ids, tfs):
+        """lists of RARE terms into the image's sparse tier (ss_bm25_append_sparse: plain sorted lists, no directory / probe rows);
+        returns the term id of the first appended list -- the ids continue behind the dense terms"""
+        offs = np.ascontiguousarray(term_offsets, np.uint64)
+        d = np.ascontiguousarray(doc_ids, np.uint32)
+        t = np.ascontiguousarray(tfs, np.uint16)
+        first = C.c_uint32()
+        N.check(N.lib().ss_bm25_append_sparse(self._h, len(offs) - 1, N.ptr(offs, N.u64p), N.ptr(d, N.u32p), N.ptr(t, N.u16p), C.byref(first)),
+                "ss_bm25_append_sparse")
+        self._df_cache.clear()
+        return int(first.value)
+
+    def sparse_info(self):
+        """(sparse lists, their postings, bytes of the sparse tier)"""
+        n, p, b = C.c_uint32(), C.c_uint64(), C.c_uint64()
+        N.check(N.lib().ss_bm25_sparse_info(self._h, C.byref(n), C.byref(p), C.byref(b)), "ss_bm25_sparse_info")
+        return int(n.value), int(p.value), int(b.value)
+
     def set_coalescing(self, max_lexical_batch=1024, max_vector_batch=N.SS_VEC_BATCH, max_wait_us=0):
         """concurrent small host-pointer searches of this shard are merged into device batches behind the C ABI
         (ss_shard_set_coalescing; on by default, a batch size of 0 switches a kind off)"""

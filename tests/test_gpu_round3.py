@@ -206,3 +206,75 @@ def test_exhaustive_16bit_scan_counts_and_intersections(S, O):
             od, os_, otot = osh.search_exhaustive(terms, op, 10)
             assert int(t[i]) == otot and np.allclose(s_[i, :c[i]], os_, rtol=1e-4)
     sh.close()
+
+
+def test_sparse_tier_queries_against_the_oracle(S, O):
+    """rare terms in the SPARSE tier (plain sorted lists, no directory / probe rows; ss_bm25_append_sparse), queries mixing them with
+    dense terms: unions (dense part through the ordinary kernels + every doc of a sparse list scored in full + per-query merge),
+    intersections (the shortest sparse list drives), exact counts, NOT terms, tombstones, two appends, the coalesced single-query
+    path -- against the oracle holding ALL lists as ordinary lists"""
+    from seekstorm_amd import _native as N
+    n_docs = 200_000
+    dense_df = [0.002, 0.01, 0.04, 0.11, 0.3]
+    sparse_n = [1, 3, 40, 250, 900, 1800, 7, 64, 65, 1200]
+    dl = O.lex_doclen(n_docs)
+    d_offs, d_docs, d_tfs = _dense_corpus(O, n_docs, dense_df, seed=5)
+    rng = np.random.default_rng(11)
+    s_offs, s_docs, s_tfs = [0], [], []
+    hot = np.sort(rng.choice(n_docs, 3000, replace=False))  # sparse lists overlap each other and the dense lists often
+    for n in sparse_n:
+        d = np.sort(rng.choice(hot, n, replace=False)).astype(np.uint32)
+        s_docs.append(d); s_tfs.append(np.minimum(rng.geometric(0.5, n), 30).astype(np.uint16)); s_offs.append(s_offs[-1] + n)
+    s_docs, s_tfs, s_offs = np.concatenate(s_docs), np.concatenate(s_tfs), np.asarray(s_offs, np.uint64)
+    sh = S.Shard(0)
+    sh.upload_lexical(n_docs, dl, d_offs, d_docs, d_tfs)
+    nd = len(dense_df)
+    first = sh.append_sparse(s_offs[:7], s_docs[:int(s_offs[6])], s_tfs[:int(s_offs[6])])          # two appends: ids continue
+    second = sh.append_sparse(s_offs[6:] - s_offs[6], s_docs[int(s_offs[6]):], s_tfs[int(s_offs[6]):])
+    assert first == nd and second == nd + 6 and sh.sparse_info()[:2] == (len(sparse_n), int(s_offs[-1]))
+    # the oracle: one shard with every list as an ordinary list (term ids: dense, then sparse)
+    a_offs = np.concatenate([d_offs, d_offs[-1] + s_offs[1:]])
+    osh = O.Shard(n_docs, dl, a_offs, np.concatenate([d_docs, s_docs]), np.concatenate([d_tfs, s_tfs]))
+    assert [int(x) for x in sh.posting_count(list(range(nd, nd + len(sparse_n))))] == sparse_n
+    nt_all = nd + len(sparse_n)
+    cases = []
+    for _ in range(60):
+        n = int(rng.integers(1, 5))
+        terms = [int(x) for x in rng.choice(nt_all, n, replace=False)]
+        cases.append((terms, []))
+    cases += [([nd + 3, nd + 4], []), ([nd + 5], []), ([0, nd], []), ([nd + 9, 4, 3], [2]), ([nd + 4, nd + 5, 1], [0])]
+    for op, qt in ((O.OP_OR, S.QueryType.Union), (O.OP_AND, S.QueryType.Intersection)):
+        tl = [c[0] for c in cases]
+        nl = [c[1] for c in cases]
+        q = sh.make_queries(tl, qt, nl)
+        for k in (10, 100):
+            for rt in (S.ResultType.TopkCount, S.ResultType.Count):
+                d, s_, c, t = sh.search_lexical_batch(q, k, rt, reference_shortcuts=False)
+                for i, (terms, nots) in enumerate(cases):
+                    od, os_, otot = osh.search_exhaustive(terms, op, k, not_terms=nots)
+                    assert int(t[i]) == otot, (op, k, i, terms, nots, int(t[i]), otot)
+                    if rt == S.ResultType.Count:
+                        continue
+                    assert c[i] == len(od), (op, k, i, terms, c[i], len(od))
+                    assert np.allclose(s_[i, :c[i]], os_, rtol=1e-4), (op, k, i, terms)
+                    if len(od) < k:
+                        assert set(d[i, :c[i]].tolist()) == set(int(x) for x in od)
+    # a sparse NOT list inside an intersection; refused in a union (its dense part could not honour it)
+    q = sh.make_queries([[3, nd + 8]], S.QueryType.Intersection, [[nd + 4]])
+    d, s_, c, t = sh.search_lexical_batch(q, 10, reference_shortcuts=False)
+    od, os_, otot = osh.search_exhaustive([3, nd + 8], O.OP_AND, 10, not_terms=[nd + 4])
+    assert int(t[0]) == otot and np.allclose(s_[0, :c[0]], os_, rtol=1e-4)
+    with pytest.raises(N.SeekStormHipError):
+        sh.search_lexical_batch(sh.make_queries([[3, nd + 8]], S.QueryType.Union, [[nd + 4]]), 10)
+    # tombstones: neither counted nor ranked, in either part
+    gone = [int(x) for x in hot[::3]]
+    sh.set_deleted(gone)
+    osh.set_deleted(gone)
+    q = sh.make_queries([[nd + 5, 3], [nd + 4, nd + 9, 2], [nd + 5, nd + 9]], [S.QueryType.Union, S.QueryType.Union, S.QueryType.Intersection])
+    d, s_, c, t = sh.search_lexical_batch(q, 10, reference_shortcuts=False)
+    for i, (terms, op) in enumerate((([nd + 5, 3], O.OP_OR), ([nd + 4, nd + 9, 2], O.OP_OR), ([nd + 5, nd + 9], O.OP_AND))):
+        od, os_, otot = osh.search_exhaustive(terms, op, 10)
+        assert c[i] == len(od) and np.allclose(s_[i, :c[i]], os_, rtol=1e-4)
+        if op == O.OP_AND or True:
+            assert int(t[i]) == otot, (i, int(t[i]), otot)
+    sh.close()
