@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--no-topk-count", action="store_true", help="skip the TopkCount comparison (keeps counter profiles of the Topk kernels clean)")
     ap.add_argument("--no-rationed", action="store_true", help="skip the rationed-vocabulary leg")
     ap.add_argument("--no-fields", action="store_true", help="skip the multi-field (BM25F) leg")
+    ap.add_argument("--no-vocab", action="store_true", help="skip the realistic-vocabulary leg (1 M rare terms in the sparse tier)")
+    ap.add_argument("--vocab-terms", type=int, default=1_000_000)
     ap.add_argument("--quick", action="store_true", help="profiling runs: few calls per leg, no cpu / parity legs")
     ap.add_argument("--cpu-seconds", type=float, default=5.0)
     ap.add_argument("--parity-queries", type=int, default=1000, help="C2 queries checked against the full-size oracle (all of the batch by default)")
@@ -514,6 +516,92 @@ def main():
                         "includes building them); queries still left without rows run on the scan kernels (mixed batch split in the library); "
                         "all_scan_value = the same batch with every query on the scan kernels"}
             sr.close()
+
+        # (6) a REALISTIC vocabulary: the 4096 lists above are only the head of a real index's dictionary.  --vocab-terms rare terms
+        # (Zipfian tail: df = df_min_head * 4096 / rank, >= 2) go into the image's SPARSE tier (plain sorted lists, no directory / probe
+        # rows; ss_bm25_append_sparse); 3-term OR queries whose terms are drawn by rank popularity (P ~ 1 / rank over the WHOLE
+        # vocabulary, dense head ranked by df) -- most queries then name at least one rare term -- through the host-pointer entry
+        # point, against the same queries with their rare terms dropped (what the dense image alone would answer).
+        if rank == 0 and world == 1 and not args.quick and not args.no_vocab:
+            t0 = time.perf_counter()
+            rng_v = np.random.default_rng(99)
+            n_head, n_tail = len(th), int(args.vocab_terms)
+            head_df = np.array([int(x) for x in sh.posting_count(list(range(n_head)))], np.int64)
+            head_by_rank = np.argsort(-head_df, kind="stable")
+            df_min = max(int(head_df.min()), 2)
+            ranks_tail = np.arange(n_head + 1, n_head + n_tail + 1, dtype=np.float64)
+            tail_df = np.maximum(2, (df_min * n_head / ranks_tail).astype(np.int64))
+            tot_tail = int(tail_df.sum())
+            lid = np.repeat(np.arange(n_tail, dtype=np.uint64), tail_df)
+            key = np.unique((lid << np.uint64(32)) | rng_v.integers(0, args.docs, tot_tail, dtype=np.uint64))  # sorted by (list, doc), duplicates gone
+            v_docs = (key & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+            v_offs = np.zeros(n_tail + 1, np.uint64)
+            v_offs[1:] = np.cumsum(np.bincount((key >> np.uint64(32)).astype(np.int64), minlength=n_tail))
+            v_tfs = np.minimum(rng_v.geometric(0.6, len(v_docs)), 60).astype(np.uint16)
+            gen_s = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            first_sparse = sh.append_sparse(v_offs, v_docs, v_tfs)
+            append_s = time.perf_counter() - t0
+            assert first_sparse == n_head
+            # queries: P(rank r) ~ 1 / r over ranks 1 .. n_head + n_tail
+            pr = 1.0 / np.arange(1, n_head + n_tail + 1, dtype=np.float64)
+            pr /= pr.sum()
+            draws = rng_v.choice(n_head + n_tail, size=(nq, 3), p=pr)
+            v_lists = []
+            for row in draws:
+                ids = []
+                for r_ in row:
+                    tid = int(head_by_rank[r_]) if r_ < n_head else int(n_head + (r_ - n_head))
+                    if tid not in ids:
+                        ids.append(tid)
+                v_lists.append(ids)
+            with_sparse = np.array([any(t >= n_head for t in tl) for tl in v_lists])
+            dense_only = [[t for t in tl if t < n_head] or [tl[0] % n_head] for tl in v_lists]
+            qv_full = sh.make_queries(v_lists, S.QueryType.Union)
+            qv_dense = sh.make_queries(dense_only, S.QueryType.Union)
+            vh_doc = np.empty((nq, k), np.uint32); vh_score = np.empty((nq, k), np.float32); vh_cnt = np.empty(nq, np.uint32); vh_tot = np.empty(nq, np.uint64)
+
+            def v_call(qq, rt=N.RT_TOPK):
+                N.check(L.ss_bm25_search(sh._h, nq, qq.ctypes.data_as(C.c_void_p), k, rt, N.ptr(vh_doc, N.u32p), N.ptr(vh_score, N.f32p),
+                                         N.ptr(vh_cnt, N.u32p), N.ptr(vh_tot, N.u64p)), "ss_bm25_search")
+            sh.set_strategy(N.BM25_AUTO)
+            v_call(qv_full, N.RT_TOPKCOUNT)
+            got_v = (vh_doc.copy(), vh_score.copy(), vh_cnt.copy(), vh_tot.copy())
+            lat_full = host_latencies(lambda: v_call(qv_full), 200)
+            lat_dense = host_latencies(lambda: v_call(qv_dense), 200)
+            n_sp, p_sp, b_sp = sh.sparse_info()
+            dense_bytes = int(info["n_postings"]) * 4 + n_head * ((args.docs + 4095) // 4096 + 1) * 4
+            # parity: 16 of the queries that name a rare term against the oracle holding dense and rare lists alike
+            if not args.no_parity:
+                pick = [i for i in range(nq) if with_sparse[i]][:16]
+                voc_d = sorted({t for i in pick for t in v_lists[i] if t < n_head})
+                voc_s = sorted({t for i in pick for t in v_lists[i] if t >= n_head})
+                dl_h, o_h, d_h, t_h = F.c2_corpus(args.docs, voc_d, th) if voc_d else (O.lex_doclen(args.docs), np.zeros(1, np.uint64), np.zeros(0, np.uint32), np.zeros(0, np.uint16))
+                so = [0]; sd = []; stf = []
+                for t in voc_s:
+                    a_, b_ = int(v_offs[t - n_head]), int(v_offs[t - n_head + 1])
+                    sd.append(v_docs[a_:b_]); stf.append(v_tfs[a_:b_]); so.append(so[-1] + (b_ - a_))
+                osh_v = O.Shard(args.docs, dl_h, np.concatenate([o_h, o_h[-1] + np.asarray(so[1:], np.uint64)]),
+                                np.concatenate([d_h] + sd), np.concatenate([t_h] + stf))
+                remap_v = {t: j for j, t in enumerate(voc_d + voc_s)}
+                for i in pick:
+                    od, os_, otot = osh_v.search_exhaustive([remap_v[t] for t in v_lists[i]], O.OP_OR, k)
+                    assert int(got_v[3][i]) == otot, f"vocabulary leg: count of query {i}: {int(got_v[3][i])} vs oracle {otot}"
+                    F.check_topk(got_v[0][i, :got_v[2][i]], got_v[1][i, :got_v[2][i]], od, os_, 1e-4, f"vocabulary leg, query {i}")
+                parity["vocabulary"] = {"queries": len(pick), "checked": "3-term unions naming rare (sparse-tier) terms: exact counts, top-10 ids outside the tie band, scores rtol 1e-4"}
+            bm["realistic_vocabulary"] = {
+                "value": nq / (np.mean(lat_full) * 1e-3), "unit": "queries/s", "entry_point": "ss_bm25_search (host pointers, host clock), 1000 queries per call",
+                "batch_ms_p50": pct(lat_full, 50), "batch_ms_p99": pct(lat_full, 99),
+                "same_queries_without_their_rare_terms": nq / (np.mean(lat_dense) * 1e-3),
+                "vocabulary": n_head + n_sp, "dense_terms": n_head, "sparse_terms": n_sp, "sparse_postings": p_sp,
+                "sparse_tier_bytes": b_sp, "dense_postings_and_directory_bytes": dense_bytes,
+                "directory_bytes_if_dense": int(n_sp) * ((args.docs + 4095) // 4096 + 1) * 4,
+                "queries_naming_a_rare_term": float(with_sparse.mean()), "mean_rare_df": float(tail_df.mean()),
+                "host_generation_s": gen_s, "append_s": append_s,
+                "note": "terms drawn with P ~ 1 / rank over the whole vocabulary (head = the 4096 dense lists ranked by df, tail = the rare terms); "
+                        "a query's dense terms run through the ordinary kernels, every doc of its rare lists is scored in full by binary-search "
+                        "probes of the other lists (bm25_sparse_kernel), the two lists are merged per query; directory_bytes_if_dense = what "
+                        "the rare lists' sub-block directory rows alone would cost in the dense image"}
 
         # ---- full-size parity (C2): a sample of the batch against the oracle on the same 10 M-doc shard, regenerated on
         # the host -- doc ids outside the tie band, scores 1e-4 relative, exact result_count_total; AUTO and EXHAUSTIVE
@@ -939,6 +1027,8 @@ def main():
                 line["rationed_vocabulary"] = bm["rationed_vocabulary"]
             if "multi_field" in bm:
                 line["multi_field"] = bm["multi_field"]
+            if "realistic_vocabulary" in bm:
+                line["realistic_vocabulary"] = bm["realistic_vocabulary"]
             line["bm25"] = {"build_s": bm["build_s"], "postings": int(bm["info"]["n_postings"]), "avgdl": bm["info"]["avgdl"],
                             "mean_algorithmic_bytes_per_query": bm["mean_bytes_per_query"], "mean_union_size": bm["mean_union"]}
         if vec is not None and is_bm:

@@ -18,6 +18,9 @@ print("intersection", f(g(d, "intersection", "value")))
 print("latency", {k: f(v) for k, v in d["latency_ms"].items() if k != "clock"})
 print("e2e", {k: f(v) for k, v in (d.get("end_to_end") or {}).items() if k not in ("entry_point", "unit")})
 print("rationed", f(g(d, "rationed_vocabulary", "value")), "churn", f(g(d, "rationed_vocabulary", "churn_value")), " multi_field", {k: f(v["value"]) for k, v in (d.get("multi_field") or {}).items() if isinstance(v, dict)})
+rv = d.get("realistic_vocabulary")
+if rv: print("vocabulary", rv["vocabulary"], "terms:", f(rv["value"]), "q/s; dense parts only", f(rv["same_queries_without_their_rare_terms"]), "; rare-term queries", f(rv["queries_naming_a_rare_term"]),
+             "sparse MB", rv["sparse_tier_bytes"] >> 20, "vs directory if dense MB", rv["directory_bytes_if_dense"] >> 20, "gen/append s", f(rv["host_generation_s"]), f(rv["append_s"]))
 print("cpu_baseline", f(g(d, "cpu_baseline", "value")), "cores", g(d, "cpu_baseline", "cores"))
 v = d.get("vector")
 if v:
@@ -31,4 +34,4 @@ for k, x in (d.get("sharded") or {}).items():
     if isinstance(x, dict): print("sharded", k, f(x["value"]), "q/s ms/call", f(x["ms_per_call"]), "allgather_us", f(x["allgather_us"]))
 for k, x in (d.get("concurrent_callers") or {}).items():
     if isinstance(x, dict): print("concurrent", k, f(x["value"]), "q/s p50", f(x["latency_us_p50"]), "p99", f(x["latency_us_p99"]), "batch", f(x["mean_lexical_batch"]), f(x["mean_vector_batch"]))
-print("parity", {k: (v["queries"], round(v["seconds"], 1)) for k, v in (d.get("parity_full_size") or {}).items()})
+print("parity", {k: (v["queries"], round(v.get("seconds", 0.0), 1)) for k, v in (d.get("parity_full_size") or {}).items()})
