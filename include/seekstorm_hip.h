@@ -258,10 +258,14 @@ int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df
  * n_terms query terms, their number in bits 8..15 of op:  op = SS_OP_* | SS_OP_NOT_TERMS(n);  n_terms + n <= 10. */
 #define SS_OP_NOT_TERMS(n) ((uint32_t)(n) << 8)
 /* field_filter of search_lexical_shard for an image with several indexed fields (search.rs:2483-2492, add_result.rs:3124-
- * 3136): bits 16..31 of op, bit f = indexed field f is listed; 0 = no filter.  A doc is kept only if EVERY query term
- * occurs in at least one listed field; its score still sums all fields.  Offered for intersections and single-term queries
- * (SS_ENOTSUP for a union of several terms: the reference filters inside union_docid_3's sub-queries, not per doc); ignored
- * by an image with one indexed field.  For ss_bm25_search_dev such a query counts as an intersection in ops_mask. */
+ * 3136): bits 16..31 of op, bit f = indexed field f is listed; 0 = no filter.  Intersections and single-term queries: a doc is
+ * kept only if EVERY query term occurs in at least one listed field; its score still sums all fields.  A UNION of several terms
+ * (<= 7; ABI v3): the reference filters inside union_docid_3's sub-queries (union.rs:1330-1425, 1168-1305), which comes to -- a doc's
+ * score is the sum over its terms that occur in a listed field (all fields of those terms counted), a doc none of whose terms passes
+ * is no result; exact count: two terms |pass(X) u pass(Y)|, more terms the UNFILTERED union (union_scan counts a doc before the
+ * filter sees it, union.rs:552-553).  Answered by the scan kernels with per-term gating of a doc's score.  Ignored by an image with
+ * one indexed field.  For ss_bm25_search_dev such a query counts as an intersection in ops_mask (bit 0) and a filtered union of
+ * several terms sets bit 7 as well. */
 #define SS_OP_FIELD_FILTER(mask) (((uint32_t)(mask) & 0x7FFFu) << 16)
 /* The reference's all_terms_frequent shortcut (intersection.rs:198-209): when the shard holds more than 256 x top_k docs
  * and EVERY term of an intersection occurs in at least half of them, a doc in which some term has an embedded position
@@ -302,7 +306,8 @@ int ss_bm25_search(ss_shard* s, uint32_t n_queries, const ss_bm25_query* queries
  * SS_OP_ALL_TERMS_FREQUENT; bit 4 set if the batch consists of SS_OP_PHRASE queries (then all of them must be); bit 5 set if some
  * query carries a field filter (several indexed fields: without it every query reads its terms' merged lists, one per term);
  * bit 6 set if EVERY query has exactly bits 16..23 terms (optional: a batch of nothing but 2- or 3-term intersections is then
- * answered, under the exhaustive strategy or without probe rows, by the 16-bit scan instead of the f32 scan -- 4-10x faster).
+ * answered, under the exhaustive strategy or without probe rows, by the 16-bit scan instead of the f32 scan -- 4-10x faster);
+ * bit 7 set if some query is a union of several terms under a field filter.
  * The assertion is CHECKED ON THE DEVICE, query by query, before the search kernels run: a query that contradicts ops_mask
  * (an intersection in a batch declared union-only, more terms than declared, an unprobed term under bit 2, ...) or is
  * malformed (no terms, a term id outside the vocabulary) is answered as an empty query and flagged

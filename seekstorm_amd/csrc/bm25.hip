@@ -150,6 +150,7 @@ constexpr uint32_t BM_CLAIM_AND = 1u, BM_CLAIM_OR = 2u, BM_CLAIM_PROBED = 4u, BM
 // field filter reads the n_lists - 1 (term, field) lists.
 constexpr uint32_t BM_CLAIM_FILTER = 32u;  // some query of the batch carries a field filter (variants sized for term x field lists)
 constexpr uint32_t BM_CLAIM_UNIFORM = 64u;  // every query has exactly np_claim terms (the 16-bit scan's intersection instance)
+constexpr uint32_t BM_CLAIM_GATED = 128u;   // some query is a UNION of several terms under a field filter (exact counts then come from the scan)
 __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery* __restrict__ vq, uint32_t nq, uint32_t n_lists,
                                  const unsigned long long* __restrict__ term_base, const float* __restrict__ boost,
                                  unsigned long long* __restrict__ total, uint32_t* __restrict__ tau, uint32_t claim,
@@ -174,6 +175,8 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
     bad |= (claim & BM_CLAIM_UNIFORM) != 0u && np != np_claim;
     bad |= n_not != 0 && nt_claim == np_claim;  // nt == np declares a batch without NOT terms (unfiltered kernel variants)
     const bool q_and = ((bm_q_op(Q.op) == SS_OP_INTERSECTION || bm_q_op(Q.op) == SS_OP_PHRASE) && np > 1) || ff != 0u;
+    const bool q_gated = ff != 0u && bm_q_op(Q.op) == SS_OP_UNION && np > 1;  // a union under a field filter: BM_AND_GATED
+    bad |= q_gated && (np > 7u || !(claim & BM_CLAIM_GATED));
     bad |= q_and && !(claim & BM_CLAIM_AND);
     bad |= !q_and && np > 1 && !(claim & BM_CLAIM_OR);
     // a phrase batch holds phrase queries only (one indexed field, no NOT terms, 2 .. SS_MAX_PHRASE words naming the unique terms)
@@ -214,27 +217,34 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
   // all_terms_frequent (intersection.rs:198-209): the caller saw N > 256 k and df >= N / 2 for every term.  One field and
   // <= 7 terms (bit 7 of the match byte becomes the "some tf < 10" mark; the host refuses the rest).
   const bool freq = bm_q_all_frequent(Q.op) && bm_q_op(Q.op) == SS_OP_INTERSECTION && np > 1 && np <= 7 && n_lists == 1;
+  // a UNION of several terms under a field filter (ss_common.h BM_AND_GATED): a term's listed fields first -- their postings add
+  // and set the term's bit --, then its unlisted fields, which add only where the bit is set
+  const bool gated = filt != 0u && bm_q_op(Q.op) == SS_OP_UNION && np > 1;
   uint32_t n = 0, n_scored = 0;
   for (uint32_t t = 0; t < np + n_not; t++) {
     if (t == np) n_scored = n;
-    for (uint32_t f = f_begin; f < f_end; f++) {
-      const uint32_t v = Q.term[t] * n_lists + f;
-      // a term without postings in a field contributes nothing there (one list per term: kept, the zero-length list is harmless)
-      if (eff_fields > 1 && term_base[v + 1] == term_base[v]) continue;
-      if (n >= (uint32_t)BM_MAX_VTERMS) break;
-      V.term[n] = v;
-      V.idf[n] = t < np ? (n_lists > 1 ? boost[f] * Q.idf[t] : Q.idf[t]) : 0.f;  // weight * plo.idf, add_result.rs:1253-1261
-      V.and_val[n] = (is_and && t < np && (!filt || ((filt >> f) & 1u))) ? (uint8_t)(mask ? (1u << t) : 0xFFu) : (uint8_t)0;
-      V.group[n] = (uint8_t)t;
-      n++;
-    }
+    for (uint32_t pass = 0; pass < ((gated && t < np) ? 2u : 1u); pass++)
+      for (uint32_t f = f_begin; f < f_end; f++) {
+        const bool listed = !filt || ((filt >> f) & 1u);
+        if (gated && t < np && listed != (pass == 0)) continue;
+        const uint32_t v = Q.term[t] * n_lists + f;
+        // a term without postings in a field contributes nothing there (one list per term: kept, the zero-length list is harmless)
+        if (eff_fields > 1 && term_base[v + 1] == term_base[v]) continue;
+        if (n >= (uint32_t)BM_MAX_VTERMS) break;
+        V.term[n] = v;
+        V.idf[n] = t < np ? (n_lists > 1 ? boost[f] * Q.idf[t] : Q.idf[t]) : 0.f;  // weight * plo.idf, add_result.rs:1253-1261
+        if (gated && t < np) V.and_val[n] = (uint8_t)((listed ? 0u : 0x80u) | (1u << t));
+        else V.and_val[n] = (is_and && t < np && listed) ? (uint8_t)(mask ? (1u << t) : 0xFFu) : (uint8_t)0;
+        V.group[n] = (uint8_t)t;
+        n++;
+      }
   }
   if (n_not == 0) n_scored = n;
   V.n_terms = n_scored;
   V.op = (filt ? (uint32_t)SS_OP_INTERSECTION : np > 1 ? (bm_q_op(Q.op) == SS_OP_PHRASE ? (uint32_t)SS_OP_INTERSECTION : bm_q_op(Q.op)) : (uint32_t)SS_OP_UNION) |
          ((n - n_scored) << 8);
   V.n_groups = np;
-  V.and_target = is_and ? ((mask ? (1u << np) - 1u : np) | (freq ? BM_AND_FREQ : 0u)) : 0u;
+  V.and_target = gated ? (1u | BM_AND_GATED | (np > 2 ? BM_AND_TOUCH : 0u)) : is_and ? ((mask ? (1u << np) - 1u : np) | (freq ? BM_AND_FREQ : 0u)) : 0u;
   for (uint32_t j = n; j < (uint32_t)BM_MAX_VTERMS; j++) { V.term[j] = 0; V.idf[j] = 0.f; V.and_val[j] = 0; V.group[j] = 0xFF; }
   V.phrase_len = bm_q_op(Q.op) == SS_OP_PHRASE ? Q.phrase_len : 0u;
   for (int j = 0; j < SS_MAX_PHRASE; j++) V.phrase_seq[j] = Q.phrase_seq[j];
@@ -272,7 +282,7 @@ int ssi_bm25_match_bits(ss_shard* s, const ss_bm25_query* d_q, unsigned long lon
 int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t* d_out_doc,
                     float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, bool has_or,
                     uint32_t nt_max, uint32_t np_max, bool all_probed, hipStream_t st, bool any_frequent, bool phrase, bool any_field_filter,
-                    bool uniform_terms) {
+                    bool uniform_terms, bool any_gated) {
   if (!s->d_post) return SS_ESTATE;
   if (nq == 0) return SS_OK;
   if (k > SS_MAX_K) return SS_EINVAL;
@@ -308,7 +318,8 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   // bit records and the scan runs without its count mode (which scans every sub-block: 5.8 instead of 1.8 ms per 1000 C2
   // queries); a pure Count request then needs no scan at all.  SS_BM25_EXHAUSTIVE keeps the scan's own counts.
   const bool want_counts = rt != SS_RT_TOPK;
-  const bool bit_counts_all = want_counts && !pruned && !phrase && s->bm_strategy != SS_BM25_EXHAUSTIVE && have_probe;
+  // (a union under a field filter counts by its own rule, BM_AND_GATED / _TOUCH: from the scan)
+  const bool bit_counts_all = want_counts && !pruned && !phrase && s->bm_strategy != SS_BM25_EXHAUSTIVE && have_probe && !any_gated;
   const bool scan_counts = want_counts && !bit_counts_all;
   // unions of <= 4 lists ranked by the scan: the 16-bit-accumulator kernel (16 waves per CU instead of 8)
   // ... and intersections of 2 or 3 terms when the batch holds nothing else: every query an intersection over one list per term
@@ -356,7 +367,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   }
   // nt_max / np_max count (term, field) lists here; the claim is in public terms
   const uint32_t claim = (phrase ? BM_CLAIM_PHRASE : 0u) | (has_and ? BM_CLAIM_AND : 0u) | ((has_or || F > 1) ? BM_CLAIM_OR : 0u) | (all_probed ? BM_CLAIM_PROBED : 0u) |
-                         (any_frequent ? BM_CLAIM_FREQ : 0u) | (any_field_filter ? BM_CLAIM_FILTER : 0u) | (uniform_terms ? BM_CLAIM_UNIFORM : 0u) |
+                         (any_frequent ? BM_CLAIM_FREQ : 0u) | (any_field_filter ? BM_CLAIM_FILTER : 0u) | (uniform_terms ? BM_CLAIM_UNIFORM : 0u) | (any_gated ? BM_CLAIM_GATED : 0u) |
                          (std::min(nt_max / F, 255u) << 8) |
                          (std::min(np_max / F, 255u) << 16);
   bm_expand_kernel<<<(nq + 127) / 128, 128, 0, st>>>(d_q, (bm_vquery*)W.d_vq, nq, s->bm_n_fields,

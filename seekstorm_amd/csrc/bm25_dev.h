@@ -197,13 +197,16 @@ __device__ __forceinline__ float bm_chunk(const u32x4 q, float idf, const BmLds&
   }
 #pragma unroll
   for (int x = 0; x < 4; x++) {
-    const float nw = old[x] + idf * bm_weight(pv[x]);
+    const bool gated_list = HAS_AND && (and_val & BM_AND_GATED) && (and_val & 0x80u);  // an unlisted field of a filtered union's term
+    float nw = __builtin_fmaf(idf, bm_weight(pv[x]), old[x]);                           // (one fma: the chain every kernel sums a score with)
+    if (gated_list && !(cold[x] & (and_val & 0x7Fu))) nw = old[x];                      // ... adds only where the term passed
     lds_stf(ao[x], nw);
     mx = fmaxf(mx, pv[x] ? nw : 0.f);  // a NULL posting's decoded weight is not zero: keep the dump slot out of the maximum
     if (HAS_AND && and_val) {
       // count one more | set the term's bit (+ bit 7 under the all_terms_frequent shortcut when this posting's tf < 10)
       uint32_t nb = and_val == 0xFFu ? cold[x] + 1u : (cold[x] | (and_val & 0xFFu));
       if (and_val & BM_AND_FREQ) nb |= bm_tf_lt10(pv[x]) ? 0x80u : 0u;
+      if (and_val & BM_AND_GATED) nb = cold[x] | (gated_list ? 0u : (and_val & 0x7Fu)) | ((and_val & BM_AND_TOUCH) ? 0x80u : 0u);
       lds_st8(co[x], nb);
     }
   }
@@ -288,6 +291,7 @@ __device__ __attribute__((noinline)) BmTop<KPL> bm_scan_tile(BmTop<KPL> T, uint3
   // its low 7 bits and is ranked only with bit 7 clear (decode_positions_multiterm_singlefield returns true -> counted,
   // never scored: add_result.rs:2091-2104, 3541-3556)
   const uint32_t cmask = (HAS_AND && (nt_and & BM_AND_FREQ)) ? 0x7Fu : 0xFFu;
+  const bool gated = HAS_AND && (nt_and & BM_AND_GATED), touch = HAS_AND && (nt_and & BM_AND_TOUCH);  // a union under a field filter
   nt_and &= 0xFFu;
   // tombstones of this sub-block (128 words): lane l keeps words l and 64 + l; iteration i needs word 8 i + lane / 8.
   // A deleted doc neither counts nor ranks (add_result.rs:3435, union.rs:975).
@@ -314,19 +318,31 @@ __device__ __attribute__((noinline)) BmTop<KPL> bm_scan_tile(BmTop<KPL> T, uint3
       if (nib & 8u) x.w = 0.f;
     }
     bool h0 = x.x > 0.f, h1 = x.y > 0.f, h2 = x.z > 0.f, h3 = x.w > 0.f;  // a doc of a NOT list has a negative score
+    bool c0 = false, c1 = false, c2 = false, c3 = false;  // gated unions of > 2 terms: what is COUNTED (the unfiltered union)
     if (HAS_AND && is_and) {
       const uint32_t cw = lds_ld32(cntw + slot * 4);
       lds_st32(cntw + slot * 4, 0u);
-      h0 = h0 && (cw & cmask) == nt_and;  // h: score > 0 (not deleted, in no NOT list) and every term present
-      h1 = h1 && ((cw >> 8) & cmask) == nt_and;
-      h2 = h2 && ((cw >> 16) & cmask) == nt_and;
-      h3 = h3 && ((cw >> 24) & cmask) == nt_and;
-      if (!h0 || (cw & 0x80u & ~cmask)) x.x = 0.f;  // counted below, ranked only without the tf < 10 mark
-      if (!h1 || ((cw >> 8) & 0x80u & ~cmask)) x.y = 0.f;
-      if (!h2 || ((cw >> 16) & 0x80u & ~cmask)) x.z = 0.f;
-      if (!h3 || ((cw >> 24) & 0x80u & ~cmask)) x.w = 0.f;
+      if (gated) {
+        // h stays "score > 0": a doc none of whose terms occurs in a listed field has accumulated nothing.  touch: a doc any list
+        // of the query holds counts unless it is deleted (score zeroed above) or in a NOT list (negative score)
+        c0 = (cw & 0x80u) && !(nib & 1u) && !(x.x < 0.f);
+        c1 = ((cw >> 8) & 0x80u) && !(nib & 2u) && !(x.y < 0.f);
+        c2 = ((cw >> 16) & 0x80u) && !(nib & 4u) && !(x.z < 0.f);
+        c3 = ((cw >> 24) & 0x80u) && !(nib & 8u) && !(x.w < 0.f);
+      } else {
+        h0 = h0 && (cw & cmask) == nt_and;  // h: score > 0 (not deleted, in no NOT list) and every term present
+        h1 = h1 && ((cw >> 8) & cmask) == nt_and;
+        h2 = h2 && ((cw >> 16) & cmask) == nt_and;
+        h3 = h3 && ((cw >> 24) & cmask) == nt_and;
+        if (!h0 || (cw & 0x80u & ~cmask)) x.x = 0.f;  // counted below, ranked only without the tf < 10 mark
+        if (!h1 || ((cw >> 8) & 0x80u & ~cmask)) x.y = 0.f;
+        if (!h2 || ((cw >> 16) & 0x80u & ~cmask)) x.z = 0.f;
+        if (!h3 || ((cw >> 24) & 0x80u & ~cmask)) x.w = 0.f;
+      }
     }
-    if (count_mode)
+    if (count_mode && touch)
+      T.matched += __popcll(__ballot(c0)) + __popcll(__ballot(c1)) + __popcll(__ballot(c2)) + __popcll(__ballot(c3));
+    else if (count_mode)
       T.matched += __popcll(__ballot(h0)) + __popcll(__ballot(h1)) + __popcll(__ballot(h2)) + __popcll(__ballot(h3));
     if (k) {
       const float m = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));

@@ -78,7 +78,7 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
     for (int t = 0; t < NT; t++) {
       const bool have = (uint32_t)t < nt;
       const uint32_t term = have ? Q->term[t] : n_terms;
-      av[t] = (is_and && (uint32_t)t < np && Q->and_val[t]) ? (uint32_t)Q->and_val[t] | (nt_and & BM_AND_FREQ) : 0u;
+      av[t] = (is_and && (uint32_t)t < np && Q->and_val[t]) ? (uint32_t)Q->and_val[t] | (nt_and & (BM_AND_FREQ | BM_AND_GATED | BM_AND_TOUCH)) : 0u;
       idf[t] = have ? ((uint32_t)t < np ? Q->idf[t] : BM_NOT_IDF) : 0.f;
       tptr[t] = post + term_base[term] * 4ull;
       rowp[t] = sub_off + (size_t)term * row_len;
@@ -267,7 +267,7 @@ __global__ void __launch_bounds__((HAS_AND ? BM_WAVES_AND : BM_WAVES_OR) * 64) b
         for (int t = 0; t < G; t++) {
           const bool have = g0 + t < nt;
           const uint32_t term = have ? Q->term[have ? g0 + t : 0] : n_terms;
-          av[t] = (is_and && g0 + t < np && Q->and_val[have ? g0 + t : 0]) ? (uint32_t)Q->and_val[have ? g0 + t : 0] | (nt_and & BM_AND_FREQ) : 0u;
+          av[t] = (is_and && g0 + t < np && Q->and_val[have ? g0 + t : 0]) ? (uint32_t)Q->and_val[have ? g0 + t : 0] | (nt_and & (BM_AND_FREQ | BM_AND_GATED | BM_AND_TOUCH)) : 0u;
           idf[t] = have ? (g0 + t < np ? Q->idf[have ? g0 + t : 0] : BM_NOT_IDF) : 0.f;
           tp[t] = post + term_base[term] * 4ull;
           b0[t] = sub_off[term * row_len + s];

@@ -486,8 +486,9 @@ int ss_bm25_sparse_info(ss_shard* s, uint32_t* n_lists, uint64_t* n_postings, ui
 // any_filter: some query carries a field filter (on an image with merged lists the others read one list per term)
 static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q, bool* has_and, bool* has_or, uint32_t* nt_max,
                          uint32_t* np_max, bool* all_probed, bool* any_frequent, bool* phrase = nullptr, bool* any_filter = nullptr,
-                         bool* uniform = nullptr) {
+                         bool* uniform = nullptr, bool* gated = nullptr) {
   uint32_t n_phrase = 0, np_min = 0xFFFFFFFFu;
+  bool some_gated = false;
   const uint32_t L = s->bm_n_fields, RF = bm_real_fields(s);  // lists per term, indexed fields
   bool some_filter = false;
   *any_frequent = false;
@@ -519,7 +520,10 @@ static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q,
     // union_docid_3's sub-queries, not per doc -- not offered.
     if (bm_q_field_filter(q[i].op) >> RF) return SS_EINVAL;  // a field the image does not have
     const uint32_t filt = RF > 1 ? bm_q_field_filter(q[i].op) : 0u;
-    if (filt && op == SS_OP_UNION && q[i].n_terms > 1) return SS_ENOTSUP;
+    if (filt && op == SS_OP_UNION && q[i].n_terms > 1) {  // a union under a field filter: per-term gating in the scan kernels (BM_AND_GATED)
+      if (q[i].n_terms > 7 || !gated) return SS_ENOTSUP;
+      some_gated = true;
+    }
     some_filter |= filt != 0u;
     const bool use_merged = s->bm_merged && !filt;                    // this query reads the merged lists: one list per term
     const uint32_t eff_fields = use_merged ? 1u : RF, f_begin = use_merged ? L - 1u : 0u, f_end = use_merged ? L : RF;
@@ -552,6 +556,7 @@ static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q,
     any_not |= n_not != 0;
   }
   if (uniform) *uniform = np_min == *np_max;  // every query with the same number of terms
+  if (gated) *gated = some_gated;
   // "the batch holds NOT terms" travels as nt_max > np_max (the kernels' filtered variants are chosen by it): keep that true
   // when the query with the NOT terms is not the one with the most terms
   if (any_not && *nt_max == *np_max) *nt_max = *np_max + 1;
@@ -749,11 +754,11 @@ static int bm25_search_split_batch(ss_shard* s, uint32_t nq, const ss_bm25_query
     perm[at] = i;
     qs[at] = q[i];
   }
-  struct Part { bool has_and, has_or, all_probed, any_frequent, phrase, any_filter, uniform; uint32_t nt_max, np_max; } part[2];
+  struct Part { bool has_and, has_or, all_probed, any_frequent, phrase, any_filter, uniform, gated; uint32_t nt_max, np_max; } part[2];
   const uint32_t begin[2] = {0, n_probed}, count[2] = {n_probed, nq - n_probed};
   for (int h = 0; h < 2; h++)
     SS_TRY(check_queries(s, count[h], qs.data() + begin[h], &part[h].has_and, &part[h].has_or, &part[h].nt_max, &part[h].np_max,
-                         &part[h].all_probed, &part[h].any_frequent, &part[h].phrase, &part[h].any_filter, &part[h].uniform));
+                         &part[h].all_probed, &part[h].any_frequent, &part[h].phrase, &part[h].any_filter, &part[h].uniform, &part[h].gated));
   SS_HIP(hipSetDevice(s->device));
   const uint32_t kw = std::max<uint32_t>(kk, 1);
   SS_TRY(ensure_out(s, 2 * (size_t)nq, kw));  // upper half: the answers in the order they ran in
@@ -776,7 +781,7 @@ static int bm25_search_split_batch(ss_shard* s, uint32_t nq, const ss_bm25_query
     for (int h = 0; h < 2; h++) {
       const int rc = ssi_bm25_search(s, count[h], d_q + begin[h], kk, rt, t_doc + (size_t)begin[h] * kw, t_score + (size_t)begin[h] * kw,
                                      t_count + begin[h], t_total + begin[h], part[h].has_and, part[h].has_or, part[h].nt_max,
-                                     part[h].np_max, part[h].all_probed, s->stream, part[h].any_frequent, part[h].phrase, part[h].any_filter, part[h].uniform);
+                                     part[h].np_max, part[h].all_probed, s->stream, part[h].any_frequent, part[h].phrase, part[h].any_filter, part[h].uniform, part[h].gated);
       if (rc != SS_OK) return rc;
     }
     return (int)SS_OK;
@@ -891,14 +896,15 @@ static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_quer
     if (n_probed != 0 && n_probed != nq) {
       bool has_and, has_or, all_probed, any_frequent, phrase;
       uint32_t nt_max, np_max;
-      SS_TRY(check_queries(s, nq, q, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent, &phrase));  // the batch's own errors first
+      bool any_filter_ = false, uniform_ = false, gated_ = false;
+      SS_TRY(check_queries(s, nq, q, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent, &phrase, &any_filter_, &uniform_, &gated_));  // the batch's own errors first
       return bm25_search_split_batch(s, nq, q, kk, rt, n_filters, filters, probed, n_probed);
     }
   }
   bool has_and = false, has_or = false;
   uint32_t nt_max = 0, np_max = 0;
-  bool all_probed = false, any_frequent = false, phrase = false, any_filter = false, uniform = false;
-  SS_TRY(check_queries(s, nq, q, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent, &phrase, &any_filter, &uniform));
+  bool all_probed = false, any_frequent = false, phrase = false, any_filter = false, uniform = false, gated = false;
+  SS_TRY(check_queries(s, nq, q, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent, &phrase, &any_filter, &uniform, &gated));
   SS_HIP(hipSetDevice(s->device));
   SS_TRY(ensure_out(s, nq, std::max<uint32_t>(kk, 1)));
   if ((size_t)nq * sizeof(ss_bm25_query) > s->bq_cap) {
@@ -910,7 +916,7 @@ static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_quer
   SS_HIP(hipMemcpyAsync(s->d_bq, q, (size_t)nq * sizeof(ss_bm25_query), hipMemcpyHostToDevice, s->stream));
   return with_facet_filter(s, n_filters, filters, s->stream, [&]() {
     return ssi_bm25_search(s, nq, (const ss_bm25_query*)s->d_bq, kk, rt, s->d_out_doc, s->d_out_score, s->d_out_count,
-                           s->d_out_total, has_and, has_or, nt_max, np_max, all_probed, s->stream, any_frequent, phrase, any_filter, uniform);
+                           s->d_out_total, has_and, has_or, nt_max, np_max, all_probed, s->stream, any_frequent, phrase, any_filter, uniform, gated);
   });
 }
 
@@ -1384,7 +1390,7 @@ int ss_bm25_search_filtered_dev(ss_shard* s, uint32_t nq, const ss_bm25_query* d
                                                     : ((ops_mask >> 8) & 0xFFu ? (ops_mask >> 8) & 0xFFu : SS_MAX_QUERY_TERMS),
                            // the caller vouches for the probe rows of its terms (ss_bm25_term_probed) unless none were rationed
                            s->bm_probe_rows != 0 && (s->bm_probe_rows >= s->bm_n_terms || (ops_mask & 4u) != 0), st,
-                           (ops_mask & 8u) != 0, (ops_mask & 16u) != 0, (ops_mask & 32u) != 0, (ops_mask & 64u) != 0);
+                           (ops_mask & 8u) != 0, (ops_mask & 16u) != 0, (ops_mask & 32u) != 0, (ops_mask & 64u) != 0, (ops_mask & 128u) != 0);
   });
 }
 

@@ -366,10 +366,18 @@ __host__ __device__ inline bool bm_q_all_frequent(uint32_t op) { return (op >> 3
 // all_terms_frequent shortcut -- a posting with tf < 10 sets bit 7 of its doc's match byte, which keeps the doc counted
 // but out of the ranking (add_result.rs:2091-2104, 3541-3556)
 constexpr uint32_t BM_AND_FREQ = 0x100u;
+// A UNION under a field filter (add_result.rs:3124-3136 applied inside union_docid_3's sub-queries, union.rs:1330-1425: a doc ends
+// with the sum over its terms that occur in a LISTED field, all fields of those terms counted; a doc none of whose terms passes is
+// no result).  BM_AND_GATED in and_target / a term's av: the lists of a term come listed fields first (their postings add and set
+// the term's bit in the doc's match byte), then the unlisted fields, whose list is marked 0x80 in its and_val and adds only where
+// the term's bit is set; a doc is a result iff its score is positive.  BM_AND_TOUCH (more than two terms): every posting also sets
+// bit 7 of the match byte and the exact count is that of the UNFILTERED union -- union_scan counts a doc before the filter sees it
+// (union.rs:552-553); two terms count |pass(X) u pass(Y)| (union_docid_2).  <= 7 terms (bits 0..6).
+constexpr uint32_t BM_AND_GATED = 0x200u, BM_AND_TOUCH = 0x400u;
 int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t* d_out_doc,
                     float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, bool has_or,
                     uint32_t nt_max, uint32_t np_max, bool all_probed, hipStream_t st, bool any_frequent = false, bool phrase = false,
-                    bool any_field_filter = true, bool uniform_terms = false);
+                    bool any_field_filter = true, bool uniform_terms = false, bool any_gated = false);
 // indexed fields of the image (bm_n_fields counts the merged list as well)
 inline uint32_t bm_real_fields(const ss_shard* s) { return s->bm_n_fields - (s->bm_merged ? 1u : 0u); }
 // ---- implemented in synth.hip

@@ -672,7 +672,9 @@ ResultObject Shard::search_lexical_shard(const std::vector<uint32_t>& query_term
   std::vector<uint32_t> uniq;
   for (uint32_t t : query_terms)
     if (std::find(uniq.begin(), uniq.end(), t) == uniq.end()) uniq.push_back(t);
-  if (!field_filter.empty() && lexical_fields_ > 1 && query_type_default == QueryType::Union && uniq.size() > 1) {
+  // a union of several terms under a field filter: per-term gating inside the scan kernels (<= 7 terms, round 3: the query goes
+  // down like any other); beyond that the composition from the reference's own sub-queries (rounds 1-2)
+  if (!field_filter.empty() && lexical_fields_ > 1 && query_type_default == QueryType::Union && uniq.size() > 7) {
     if (!result_sort.empty()) { ro.last_error = SS_ENOTSUP; return ro; }
     ro = union_with_field_filter(uniq, offset + length, result_type, not_terms, field_filter, facet_filter);
   } else {

@@ -260,6 +260,7 @@ class IndexBin:
 
 class Shard:
     """One shard image on one MI355X (opaque ss_shard handle)."""
+    compose_filtered_unions = False  # True: unions under a field filter through 2^n - 1 filtered intersections (rounds 1-2) instead of the kernels
 
     def __init__(self, device=0, shard_id=0):
         self.device = device
@@ -864,7 +865,10 @@ class Shard:
         ro = ResultObject()
         try:
             uniq = list(dict.fromkeys(int(t) for t in query_terms))
-            if (field_filter and self.lexical_field_count > 1 and int(query_type_default) == int(QueryType.Union) and len(uniq) > 1):
+            # a union of several terms under a field filter: per-term gating inside the scan kernels (<= 7 terms, round 3); the
+            # composition from the reference's own sub-queries below stays as the second route (compose_filtered_unions = True)
+            if (field_filter and self.lexical_field_count > 1 and int(query_type_default) == int(QueryType.Union) and len(uniq) > 1
+                    and (self.compose_filtered_unions or len(uniq) > 7)):
                 return self._union_with_field_filter(uniq, offset, length, result_type, not_terms, field_filter, facet_filter)
             q = self.make_queries([query_terms], query_type_default, [not_terms], field_filter=field_filter)
             doc, score, cnt, tot = self.search_lexical_batch(q, offset + length, result_type, facet_filter=facet_filter)

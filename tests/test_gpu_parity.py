@@ -1094,8 +1094,9 @@ def test_bm25f_field_filter(S, O, n_fields):
     b = sh.search_lexical_batch(sh.make_queries([[0, 1]], S.QueryType.Intersection), 10)
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.allclose(a[1], b[1], rtol=1e-4)
     assert set(a[0][0].tolist()) == set(b[0][0].tolist()) or np.allclose(a[1][0][-1], b[1][0][-1], rtol=1e-4)
-    with pytest.raises(S.SeekStormHipError):   # union of several terms under a filter: not offered
-        sh.search_lexical_batch(sh.make_queries([[0, 1]], S.QueryType.Union, field_filter=[0]), 10)
+    # a union of several terms under a filter is answered by the scan kernels since round 3 (per-term gating; the rule is checked in
+    # test_union_under_a_field_filter_follows_the_reference_decomposition); more than 7 terms: not offered
+    sh.search_lexical_batch(sh.make_queries([[0, 1]], S.QueryType.Union, field_filter=[0]), 10)
     with pytest.raises(S.SeekStormHipError):   # a field the image does not have
         sh.search_lexical_batch(sh.make_queries([[0]], S.QueryType.Union, field_filter=[n_fields]), 10)
     sh.close()
@@ -1137,8 +1138,12 @@ def test_union_under_a_field_filter_follows_the_reference_decomposition(S, O, n_
             for t in neg:
                 banned |= set(per_term[t][1].tolist())
             ranked = sorted(((d, float(v)) for d, v in score.items() if d not in banned), key=lambda e: (-e[1], e[0]))
-            for k in (10, 40):
+            # both routes: per-term gating inside the scan kernels (round 3: BM_AND_GATED), and the composition from the
+            # reference's own sub-queries (2^n - 1 filtered intersections merged by the maximum)
+            for k, compose in ((10, False), (40, False), (10, True), (40, True)):
+                sh.compose_filtered_unions = compose
                 ro = sh.search_lexical_shard(terms, S.QueryType.Union, 0, k, S.ResultType.TopkCount, strict=True, not_terms=neg, field_filter=filt)
+                sh.compose_filtered_unions = False
                 want = ranked[:k]
                 assert len(ro.results) == len(want), (terms, neg, filt, k)
                 got_s = np.array([r.score for r in ro.results], np.float32)
