@@ -287,8 +287,9 @@ typedef struct {
  * order.  A doc matches when it contains every unique term and some position p carries word i at p + i for every i
  * (add_result.rs:3596-3684: the merge over the entries' position lists, fewest positions first); it is scored like the
  * intersection of the unique terms (get_bm25f_multiterm_singlefield) and counted only when the phrase matches.  Needs the
- * positions in the image (ss_bm25_upload_positions), one indexed field, every list with a probe row; a batch holds phrase
- * queries only (ops_mask bit 4 for ss_bm25_search_dev); NOT terms are not offered with phrases (SS_ENOTSUP). */
+ * positions in the image (ss_bm25_upload_positions), one indexed field, every list with a probe row.  Host-pointer batches may mix
+ * phrase queries with others (run as two sub-batches inside the library, answers back in the callers' order); a DEVICE-resident
+ * batch (ss_bm25_search_dev) holds phrase queries only (ops_mask bit 4); NOT terms are not offered with phrases (SS_ENOTSUP). */
 
 /* Batched BM25 search.  Outputs: out_doc/out_score [n_queries*k], out_count [n_queries] (= results.len()),
  * out_total [n_queries] (= result_count_total: exact match count for Count/TopkCount). */

@@ -889,6 +889,12 @@ static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_quer
     if (any_sparse) return n_filters ? (int)SS_ENOTSUP : bm25_search_tiered(s, nq, q, kk, rt);
   }
   SS_TRY(ssi_bm25_ensure_probe_rows(s, nq, q, s->stream));
+  if (nq > 1) {  // phrase queries have a kernel of their own: a batch that mixes them with others runs as two, answers back in place
+    std::vector<uint8_t> is_phrase(nq);
+    uint32_t n_phrase = 0;
+    for (uint32_t i = 0; i < nq; i++) n_phrase += (is_phrase[i] = bm_q_op(q[i].op) == SS_OP_PHRASE ? 1 : 0);
+    if (n_phrase != 0 && n_phrase != nq) return bm25_search_split_batch(s, nq, q, kk, rt, n_filters, filters, is_phrase, n_phrase);
+  }
   if (nq > 1 && s->bm_probe_rows != 0 && s->bm_probe_rows < s->bm_n_terms) {  // rationed probe rows: a mixed batch runs as two
     std::vector<uint8_t> probed(nq);
     uint32_t n_probed = 0;

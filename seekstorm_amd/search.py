@@ -825,12 +825,7 @@ class Shard:
         score = np.zeros((nq, kk), np.float32)
         cnt = np.zeros(nq, np.uint32)
         tot = np.zeros(nq, np.uint64)
-        is_phrase = (queries["op"] & 0xFF) == int(QueryType.Phrase)
-        if is_phrase.any() and not is_phrase.all():  # one C-ABI batch holds phrase queries only: two calls, results back in place
-            for sel in (np.nonzero(is_phrase)[0], np.nonzero(~is_phrase)[0]):
-                d_, s_, c_, t_ = self.search_lexical_batch(queries[sel].copy(), k, result_type, reference_shortcuts, facet_filter)
-                doc[sel], score[sel], cnt[sel], tot[sel] = d_, s_, c_, t_
-            return doc, score, cnt, tot
+        # (a batch may mix phrase queries with others: the library runs it as two and puts the answers back in place)
         farr, nf = self.facet_filters(facet_filter) if facet_filter else (None, 0)
         N.check(N.lib().ss_bm25_search_filtered(self._h, nq, queries.ctypes.data_as(C.c_void_p), int(k), int(result_type), nf,
                                                 None if farr is None else C.cast(farr, C.c_void_p), N.ptr(doc, N.u32p),

@@ -278,3 +278,30 @@ def test_sparse_tier_queries_against_the_oracle(S, O):
         if op == O.OP_AND or True:
             assert int(t[i]) == otot, (i, int(t[i]), otot)
     sh.close()
+
+
+def test_mixed_phrase_and_plain_batches_through_the_abi(S, O):
+    """one C-ABI batch mixing phrase queries with unions and intersections (the coalescer merges whatever concurrent callers bring):
+    the library runs it as two sub-batches and puts the answers back in the callers' order -- equal to the homogeneous calls"""
+    n_docs = 30_000
+    dl = O.lex_doclen(n_docs)
+    rng = np.random.default_rng(8)
+    offs, docs, tfs, pos = [0], [], [], []
+    for df in (6000, 5000, 4000, 900):
+        d = np.sort(rng.choice(n_docs, df, replace=False)).astype(np.uint32)
+        t = np.minimum(rng.geometric(0.5, df), 6).astype(np.uint16)
+        for n in t:
+            pos.append(np.sort(rng.choice(40, int(n), replace=False)).astype(np.uint16))
+        docs.append(d); tfs.append(t); offs.append(offs[-1] + df)
+    sh = S.Shard(0)
+    sh.upload_lexical(n_docs, dl, np.asarray(offs, np.uint64), np.concatenate(docs), np.concatenate(tfs), positions=np.concatenate(pos))
+    tl = [[0, 1], [0, 1], [2, 1, 0], [3], [1, 2], [0, 2]]
+    qt = [S.QueryType.Phrase, S.QueryType.Union, S.QueryType.Phrase, S.QueryType.Union, S.QueryType.Intersection, S.QueryType.Phrase]
+    q = sh.make_queries(tl, qt)
+    for rt in (S.ResultType.TopkCount, S.ResultType.Topk):
+        mixed = sh.search_lexical_batch(q, 10, rt, reference_shortcuts=False)
+        for i in range(len(tl)):
+            alone = sh.search_lexical_batch(sh.make_queries([tl[i]], [qt[i]]), 10, rt, reference_shortcuts=False)
+            for a, b in zip(mixed, alone):
+                assert np.array_equal(a[i], b[0]), (i, int(rt))
+    sh.close()
