@@ -175,6 +175,13 @@ int ss_index_bin_open(const uint8_t* bytes, uint64_t len, uint32_t indexed_field
  * image is built for the frequent terms that dominate query cost; a query touching a dropped term (ss_index_bin_term_keys
  * has no entry for it) is answered by the host's own path. */
 int ss_index_bin_filter(ss_index_bin* ix, uint64_t min_posting_count, uint32_t* n_terms_kept);
+/* Two tiers instead of dropping the tail: keys with at least dense_min_posting_count postings come first (ascending key hash) and
+ * become the dense image's terms, the others follow (ascending key hash) and go to the SPARSE tier (ss_bm25_append_sparse) when
+ * the index is uploaded with ss_bm25_upload_index_bin -- a real vocabulary's millions of rare keys then cost 8 bytes per posting,
+ * not a directory row each, and every key of the index stays searchable on the device.  Term id = position in that order
+ * (ss_index_bin_term_keys): the host looks a key hash up with one binary search per tier, *n_dense_out = first sparse term id.
+ * One indexed field (SS_ENOTSUP otherwise); not with ss_bm25_upload_index_bin_positions (no phrases over sparse lists). */
+int ss_index_bin_tier(ss_index_bin* ix, uint64_t dense_min_posting_count, uint32_t* n_dense_out);
 int ss_index_bin_close(ss_index_bin* ix);
 int ss_index_bin_info(const ss_index_bin* ix, uint64_t* n_docs, uint64_t* positions_sum_normalized, uint32_t* n_levels,
                       uint32_t* n_terms, uint32_t* n_ngram_keys_skipped);

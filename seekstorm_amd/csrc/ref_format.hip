@@ -462,6 +462,7 @@ struct ss_index_bin {
   std::vector<uint64_t> keys;          // ascending; term id = index.  An n-gram key appears once per component, in order
   std::vector<uint8_t> term_comp, term_ncomp, term_df_byte;  // per term; df byte of the LAST level (commit.rs:646-653)
   std::vector<uint64_t> term_block_off;
+  uint32_t n_dense = 0xFFFFFFFFu;      // ss_index_bin_tier: terms [0, n_dense) go to the dense image, the rest to the sparse tier
 };
 
 namespace {
@@ -575,6 +576,40 @@ extern "C" int ss_index_bin_filter(ss_index_bin* ix, uint64_t min_posting_count,
   ix->term_comp.swap(comp); ix->term_ncomp.swap(ncomp); ix->term_df_byte.swap(dfb);
   ix->term_block_off.swap(off);
   if (n_terms_kept) *n_terms_kept = (uint32_t)ix->keys.size();
+  return SS_OK;
+}
+
+// Two tiers instead of dropping the tail: the keys with at least dense_min_posting_count postings come first (ascending key
+// hash) and become the DENSE image's terms, the rest follow (ascending key hash) and go to the SPARSE tier (bm25_sparse.hip: plain
+// sorted lists, no directory / probe rows) -- a real vocabulary's millions of rare keys then cost 8 bytes per posting instead of
+// a directory row each.  Term id = position in that order (ss_index_bin_term_keys); the host finds a key with two binary searches,
+// one per tier (*n_dense_out = where the second starts).  The components of an n-gram key stay consecutive inside their tier.
+extern "C" int ss_index_bin_tier(ss_index_bin* ix, uint64_t dense_min_posting_count, uint32_t* n_dense_out) {
+  if (!ix) return SS_EINVAL;
+  if (ix->n_fields > 1) return SS_ENOTSUP;  // the sparse tier holds single-field images
+  std::vector<ss_index_bin::Blk> blocks;
+  std::vector<uint64_t> keys, off;
+  std::vector<uint8_t> comp, ncomp, dfb;
+  uint32_t n_dense = 0;
+  for (int tier = 0; tier < 2; tier++) {
+    for (size_t t = 0; t < ix->keys.size(); t++) {
+      uint64_t n = 0;
+      for (uint64_t b = ix->term_block_off[t]; b < ix->term_block_off[t + 1]; b++) n += (uint64_t)ix->blocks[b].b.posting_count_m1 + 1u;
+      if ((n >= dense_min_posting_count) != (tier == 0)) continue;
+      keys.push_back(ix->keys[t]);
+      comp.push_back(ix->term_comp[t]); ncomp.push_back(ix->term_ncomp[t]); dfb.push_back(ix->term_df_byte[t]);
+      off.push_back(blocks.size());
+      for (uint64_t b = ix->term_block_off[t]; b < ix->term_block_off[t + 1]; b++) blocks.push_back(ix->blocks[b]);
+    }
+    if (tier == 0) n_dense = (uint32_t)keys.size();
+  }
+  off.push_back(blocks.size());
+  ix->blocks.swap(blocks);
+  ix->keys.swap(keys);
+  ix->term_comp.swap(comp); ix->term_ncomp.swap(ncomp); ix->term_df_byte.swap(dfb);
+  ix->term_block_off.swap(off);
+  ix->n_dense = n_dense;
+  if (n_dense_out) *n_dense_out = n_dense;
   return SS_OK;
 }
 
@@ -718,21 +753,36 @@ extern "C" int ss_bm25_upload_index_bin_positions(ss_shard* s, const ss_index_bi
 }
 namespace {
 int upload_index_bin_single(ss_shard* s, const ss_index_bin* ix, bool with_positions) {
-  std::vector<uint64_t> offs(ix->keys.size() + 1, 0);
+  const uint32_t n_all = (uint32_t)ix->keys.size(), n_dense = std::min<uint32_t>(ix->n_dense, n_all);  // ss_index_bin_tier
+  if (n_dense == 0) return SS_EINVAL;           // the dense image needs at least one list
+  if (with_positions && n_dense != n_all) return SS_ENOTSUP;  // no phrases over sparse lists
+  std::vector<uint64_t> offs((size_t)n_dense + 1, 0);
   std::vector<uint32_t> docs;
   std::vector<uint16_t> tfs, d16(65536), t16(65536), pos;
-  for (uint32_t t = 0; t < ix->keys.size(); t++) {
+  for (uint32_t t = 0; t < n_dense; t++) {
     offs[t] = docs.size();
     const int rc = index_bin_term(ix, t, docs, tfs, d16.data(), t16.data(), with_positions ? &pos : nullptr);
     if (rc) return rc;
   }
-  offs[ix->keys.size()] = docs.size();
+  offs[n_dense] = docs.size();
   std::vector<uint8_t> doclen(ix->doclen.size() * 65536u);
   for (size_t l = 0; l < ix->doclen.size(); l++) std::memcpy(doclen.data() + l * 65536u, ix->doclen[l], 65536u);  // field 0
   // avgdl = positions_sum_normalized / indexed_doc_count as the reference's reader computes it (index.rs:3480-3482)
-  int rc = ssi_bm25_upload(s, ix->n_docs, doclen.data(), (uint32_t)ix->keys.size(), offs.data(), docs.data(), tfs.data(),
-                           ix->positions_sum);
-  if (rc || !with_positions) return rc;
+  int rc = ssi_bm25_upload(s, ix->n_docs, doclen.data(), n_dense, offs.data(), docs.data(), tfs.data(), ix->positions_sum);
+  if (rc) return rc;
+  if (n_dense < n_all) {  // the rare keys: decoded the same way, appended to the sparse tier (term ids continue behind the dense ones)
+    std::vector<uint64_t> so((size_t)(n_all - n_dense) + 1, 0);
+    std::vector<uint32_t> sd;
+    std::vector<uint16_t> st;
+    for (uint32_t t = n_dense; t < n_all; t++) {
+      so[t - n_dense] = sd.size();
+      rc = index_bin_term(ix, t, sd, st, d16.data(), t16.data(), nullptr);
+      if (rc) return rc;
+    }
+    so[n_all - n_dense] = sd.size();
+    return ss_bm25_append_sparse(s, n_all - n_dense, so.data(), sd.data(), st.data(), nullptr);
+  }
+  if (!with_positions) return rc;
   return ssi_bm25_attach_positions(s, offs.data(), docs.data(), tfs.data(), pos.data(), pos.size());
 }
 }  // namespace

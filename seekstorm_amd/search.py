@@ -222,10 +222,26 @@ class IndexBin:
             N.check(N.lib().ss_index_bin_term_ngram(h, N.ptr(self.term_components, N.u8p), N.ptr(self.term_component, N.u8p),
                                                     N.ptr(self.term_component_df, N.u32p)), "ss_index_bin_term_ngram")
 
+    def tier(self, dense_min_posting_count):
+        """keys with fewer postings go to the image's SPARSE tier instead of being dropped (ss_index_bin_tier): term ids = the frequent
+        keys in hash order, then the rare keys in hash order; returns the first sparse term id"""
+        nd = C.c_uint32()
+        N.check(N.lib().ss_index_bin_tier(self._h, int(dense_min_posting_count), C.byref(nd)), "ss_index_bin_tier")
+        self.n_dense = int(nd.value)
+        N.check(N.lib().ss_index_bin_term_keys(self._h, N.ptr(self.term_keys, N.u64p)), "ss_index_bin_term_keys")
+        N.check(N.lib().ss_index_bin_term_ngram(self._h, N.ptr(self.term_components, N.u8p), N.ptr(self.term_component, N.u8p),
+                                                N.ptr(self.term_component_df, N.u32p)), "ss_index_bin_term_ngram")
+        return self.n_dense
+
     def term_of_key(self, key_hash):
-        """term id of a key (first component for an n-gram key), None if the image does not hold it"""
-        i = int(np.searchsorted(self.term_keys, np.uint64(key_hash)))
-        return i if i < self.term_count and int(self.term_keys[i]) == int(key_hash) else None
+        """term id of a key (first component for an n-gram key), None if the image does not hold it; a tiered index (tier())
+        keeps its keys sorted inside each tier: one binary search per tier"""
+        nd = getattr(self, "n_dense", None)
+        for lo, hi in (((0, self.term_count),) if nd is None else ((0, nd), (nd, self.term_count))):
+            i = lo + int(np.searchsorted(self.term_keys[lo:hi], np.uint64(key_hash)))
+            if i < hi and int(self.term_keys[i]) == int(key_hash):
+                return i
+        return None
 
     def terms_of_key(self, key_hash):
         """[(term id, idf)] a query term with this key contributes: one entry with idf None (= from the list's own posting

@@ -740,3 +740,64 @@ def test_hand_assembled_index_bin_answers_like_its_arrays():
         assert int(ra[3][0]) == otot and np.allclose(ra[1][0][:ra[2][0]], os_, rtol=1e-4)
     a.close()
     b.close()
+
+
+def test_index_bin_tiers_keep_every_key():
+    """ss_index_bin_tier: the frequent keys first (hash order), the rare keys behind them (hash order) -- nothing is dropped, a key
+    is found with one binary search per tier, n-gram components stay consecutive"""
+    rng = np.random.default_rng(5)
+    n_docs = 100_000
+    dl, terms = _corpus(rng, n_docs, [30_000, 12, 4_000, 3, 900, 20_000, 1, 55])
+    ngram = _ngram_terms(rng, n_docs, 23)
+    data = RF.write_index_bin(n_docs, dl, terms, rng, segment_number_bits=4, key_head_size=23, ngram_terms=ngram)
+    ix = S.IndexBin(data, 1, 23, 4)
+    before = {int(k): ix.postings(t) for t, k in enumerate(ix.term_keys) if ix.term_component[t] == 0}
+    n_all = ix.term_count
+    nd = ix.tier(1000)
+    assert ix.term_count == n_all and 0 < nd < n_all
+    keys = [int(k) for k in ix.term_keys]
+    assert keys[:nd] == sorted(keys[:nd]) and keys[nd:] == sorted(keys[nd:])
+    for t in range(n_all):
+        n = len(ix.postings(t)[0])
+        assert (n >= 1000) == (t < nd)
+    for key, (d, f) in before.items():
+        t = ix.term_of_key(key)
+        d2, f2 = ix.postings(t)
+        assert np.array_equal(d, d2) and np.array_equal(f, f2)
+        for c in range(int(ix.term_components[t])):  # the components of an n-gram key follow one another inside their tier
+            assert int(ix.term_keys[t + c]) == key and int(ix.term_component[t + c]) == c
+    ix.close()
+
+
+@pytest.mark.gpu
+def test_tiered_index_bin_upload_answers_like_the_arrays():
+    """an index.bin uploaded in two tiers (frequent keys -> dense image, rare keys -> sparse tier): queries over keys of both tiers
+    answer like the same postings uploaded as one dense image, and like the oracle"""
+    from oracle import oracle as O
+    rng = np.random.default_rng(31)
+    n_docs = 120_000
+    sizes = [50_000, 9_000, 40, 700, 25_000, 3, 150, 1]
+    dl, terms = _corpus(rng, n_docs, sizes)
+    data = RF.write_index_bin(n_docs, dl, terms, rng)
+    ix = S.IndexBin(data)
+    nd = ix.tier(1000)
+    assert nd == 3
+    a, b = S.Shard(0), S.Shard(0)
+    a.upload_index_bin(ix)
+    assert a.sparse_info()[0] == len(sizes) - nd
+    by_id = [terms[[int(t[0]) for t in terms].index(int(k))] for k in ix.term_keys]  # the file's terms in tiered id order
+    offs = np.zeros(len(by_id) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(t[1]) for t in by_id])
+    alld, allt = np.concatenate([t[1] for t in by_id]), np.concatenate([t[2] for t in by_id])
+    b.upload_lexical(n_docs, dl, offs, alld, allt)
+    osh = O.Shard(n_docs, dl, offs, alld, allt)
+    assert [int(x) for x in a.posting_count(list(range(len(by_id))))] == [len(t[1]) for t in by_id]
+    for qt, op, q in ((S.QueryType.Union, O.OP_OR, [0, 1, 4]), (S.QueryType.Union, O.OP_OR, [3, 6]), (S.QueryType.Intersection, O.OP_AND, [0, 3]),
+                      (S.QueryType.Union, O.OP_OR, [5, 2, 7, 1]), (S.QueryType.Intersection, O.OP_AND, [4, 6, 0])):
+        ra = a.search_lexical_batch(a.make_queries([q], qt), 10, reference_shortcuts=False)
+        rb_ = b.search_lexical_batch(b.make_queries([q], qt), 10, reference_shortcuts=False)
+        assert np.array_equal(ra[2], rb_[2]) and np.array_equal(ra[3], rb_[3]) and np.allclose(ra[1], rb_[1], rtol=1e-6)
+        od, os_, otot = osh.search_exhaustive(q, op, 10)
+        assert int(ra[3][0]) == otot and np.allclose(ra[1][0][:ra[2][0]], os_, rtol=1e-4)
+    a.close()
+    b.close()
