@@ -20,7 +20,10 @@
 
 namespace {
 
-constexpr int SP_WAVES = 4;
+constexpr int SP_WAVES = 4;   // waves per workgroup of the merge kernel (one query per wave)
+constexpr int SP_QWAVES = 8;  // waves per QUERY in the sparse kernel: a list of a few thousand postings is 64-posting steps of ~20 dependent
+                              // loads each (binary searches) -- walked by one wave, the longest list of a batch set the kernel's time
+                              // (1.0 ms at 5000 postings); the steps are dealt to 8 waves, whose lists the first one merges
 
 // index of doc in the sparse list [lo, hi) (ascending docs in the low 32 bits), or ~0
 __device__ __forceinline__ unsigned long long sp_find(const unsigned long long* __restrict__ sp, unsigned long long lo, unsigned long long hi, uint32_t doc) {
@@ -52,14 +55,15 @@ __device__ __forceinline__ uint32_t dense_find(const uint32_t* __restrict__ post
 }
 
 template <int KPL>
-__global__ void __launch_bounds__(SP_WAVES * 64) bm25_sparse_kernel(
+__global__ void __launch_bounds__(SP_QWAVES * 64) bm25_sparse_kernel(
     const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base, const uint32_t* __restrict__ sub_off, uint32_t n_sub,
     uint32_t n_dense, const unsigned long long* __restrict__ sp_base, const unsigned long long* __restrict__ sp_post, uint32_t n_sparse,
     const ss_bm25_query* __restrict__ qs, uint32_t nq, uint32_t k, const uint32_t* __restrict__ del, uint32_t del_words,
     unsigned long long* __restrict__ out_keys /* [nq][64 KPL] */, unsigned long long* __restrict__ out_extra /* [nq] */) {
-  const int lane = threadIdx.x & 63;
-  const uint32_t qi = blockIdx.x * SP_WAVES + (threadIdx.x >> 6);
-  if (qi >= nq) return;
+  __shared__ unsigned long long wkeys[SP_QWAVES][64 * KPL];
+  __shared__ unsigned long long wcount[SP_QWAVES];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t qi = blockIdx.x;  // one workgroup per query
   const ss_bm25_query* __restrict__ Q = qs + qi;
   const uint32_t nt = Q->n_terms, n_not = bm_q_nnot(Q->op);
   const bool is_and = bm_q_op(Q->op) == SS_OP_INTERSECTION && nt > 1;
@@ -85,7 +89,7 @@ __global__ void __launch_bounds__(SP_WAVES * 64) bm25_sparse_kernel(
     if (Q->term[s] < n_dense) continue;
     const uint32_t si = Q->term[s] - n_dense;
     const unsigned long long b0 = sp_base[si], b1 = sp_base[si + 1];
-    for (unsigned long long x = b0; x < b1; x += 64) {
+    for (unsigned long long x = b0 + (unsigned)w * 64u; x < b1; x += 64ull * SP_QWAVES) {
       const bool live0 = x + (unsigned)lane < b1;
       const unsigned long long e = live0 ? sp_post[x + lane] : 0ull;
       const uint32_t doc = (uint32_t)e;
@@ -135,10 +139,25 @@ __global__ void __launch_bounds__(SP_WAVES * 64) bm25_sparse_kernel(
       }
     }
   }
+  // the waves' lists -> one: wave 0 merges the others' (sorted) keys into its own
+#pragma unroll
+  for (int r = 0; r < KPL; r++) wkeys[w][r * 64 + lane] = T.keys[r];
+  if (lane == 0) wcount[w] = T.matched;
+  __syncthreads();
+  if (w != 0) return;
+  unsigned long long matched = 0ull;
+  for (int j = 0; j < SP_QWAVES; j++) matched += wcount[j];
+  for (int j = 1; j < SP_QWAVES; j++) {
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+      const unsigned long long key = wkeys[j][r * 64 + lane];
+      if (__ballot(key != 0ull)) T.worst = topk_merge64<KPL>(T.keys, key, max(k, 1u), lane);
+    }
+  }
   unsigned long long* out = out_keys + (size_t)qi * (64 * KPL);
 #pragma unroll
   for (int r = 0; r < KPL; r++) out[r * 64 + lane] = T.keys[r];
-  if (lane == 0) out_extra[qi] = T.matched;
+  if (lane == 0) out_extra[qi] = matched;
 }
 
 // The answer of a tiered query: dense list (this query's dense terms through the ordinary kernels; none for an intersection or a
@@ -214,14 +233,15 @@ __global__ void __launch_bounds__(SP_WAVES * 64) bm25_tier_merge_kernel(
 int ssi_bm25_launch_sparse(const ss_shard* s, const ss_bm25_query* d_q, uint32_t nq, uint32_t k, unsigned long long* d_keys,
                            unsigned long long* d_extra, hipStream_t st) {
   const int KPL = std::max<uint32_t>(k, 1) <= 64 ? 1 : 2;
-  const uint32_t grid = (nq + SP_WAVES - 1) / SP_WAVES;
+  const uint32_t grid = nq;
+  if (nq == 0) return SS_OK;
   const uint32_t* del = s->n_deleted ? s->d_deleted : nullptr;
   if (KPL == 1)
-    bm25_sparse_kernel<1><<<grid, SP_WAVES * 64, 0, st>>>(s->d_post, (const unsigned long long*)s->d_term_base, s->d_sub_off, s->bm_n_sub, s->bm_n_terms,
+    bm25_sparse_kernel<1><<<grid, SP_QWAVES * 64, 0, st>>>(s->d_post, (const unsigned long long*)s->d_term_base, s->d_sub_off, s->bm_n_sub, s->bm_n_terms,
                                                          (const unsigned long long*)s->d_sp_base, (const unsigned long long*)s->d_sp_post, s->sp_n, d_q, nq, k,
                                                          del, (uint32_t)s->deleted_words, d_keys, d_extra);
   else
-    bm25_sparse_kernel<2><<<grid, SP_WAVES * 64, 0, st>>>(s->d_post, (const unsigned long long*)s->d_term_base, s->d_sub_off, s->bm_n_sub, s->bm_n_terms,
+    bm25_sparse_kernel<2><<<grid, SP_QWAVES * 64, 0, st>>>(s->d_post, (const unsigned long long*)s->d_term_base, s->d_sub_off, s->bm_n_sub, s->bm_n_terms,
                                                          (const unsigned long long*)s->d_sp_base, (const unsigned long long*)s->d_sp_post, s->sp_n, d_q, nq, k,
                                                          del, (uint32_t)s->deleted_words, d_keys, d_extra);
   SS_HIP(hipGetLastError());
