@@ -174,11 +174,23 @@ __device__ __forceinline__ void s16_clear_tile(uint32_t wb, int lane) {
   if (lane == 0) lds_st128(wb + 8192u, u32x4{0u, 0u, 0u, 0u});
 }
 
+// Chunks (256 postings = 64 lanes x 16 B) held in registers per term and item.  The terms are processed SORTED BY LIST LENGTH
+// (shortest first; exact sums keep the query's order through qpos), so the budget follows the position: a 3-term union keeps
+// 1 / 1 / 3 chunks -- 5 x 4 registers per buffer where round 2 kept 2 / 2 / 2 = 6 x 4 -- and the longest list of a C2 query (up to
+// 15 % of a sub-block = 614 postings) fits without the synchronous remainder loop, which used to cost every item of the 17 % of
+// the queries whose third term lies above 12.5 % a full memory round trip.
+template <int NT> struct S16Cfg {
+  static constexpr int cpt(int t) { return NT == 3 ? (t == 2 ? 3 : 1) : NT == 2 ? (t == 1 ? 3 : 2) : 2; }
+  static constexpr int off(int t) { int o = 0; for (int i = 0; i < t; i++) o += cpt(i); return o; }
+  static constexpr int RC = off(NT);
+  static constexpr int CPTMAX = 3;
+};
 template <int RC> struct S16Cur { u32x4 v[RC]; };
 template <int NT> struct S16Item {
   const uint32_t* tptr[NT];
   float idf[NT], fidf[NT];
   uint32_t b0[NT], b1[NT];  // the item's segments, 16-byte units relative to the list
+  uint32_t qpos[NT];        // position of the term in the QUERY (the order a score is summed in)
 };
 
 // The candidate path of an item.  Out of line, and called from OUTSIDE the streaming loop (see the kernel): the item's
@@ -196,33 +208,49 @@ template <int NT> struct S16Item {
 //  4. keys to the wave-resident top-k; more candidates than the list holds: the bounds are rebuilt and 2-4 repeat.
 // Every segment of an item through one chunk routine: the chunks held in registers, then whatever of an oversized segment was
 // streamed rather than kept (loaded again, synchronously: the candidate path is rare)
-template <int NT, int CPT, typename F>
-__device__ __forceinline__ void s16_each_chunk(const S16Cur<NT * CPT>& cur, const S16Item<NT>& it, int t, int lane16, F f) {
-  const uint32_t n16 = it.b1[t] - it.b0[t];
+template <int NT, int TT, typename F>
+__device__ __forceinline__ void s16_each_chunk(const S16Cur<S16Cfg<NT>::RC>& cur, const S16Item<NT>& it, int lane16, F f) {
+  constexpr int CPT = S16Cfg<NT>::cpt(TT), OFF = S16Cfg<NT>::off(TT);
+  const uint32_t n16 = it.b1[TT] - it.b0[TT];
 #pragma unroll
   for (int c = 0; c < CPT; c++)
-    if ((uint32_t)c * 64u < n16) f(cur.v[t * CPT + c]);
+    if ((uint32_t)c * 64u < n16) f(cur.v[OFF + c]);
   if (n16 > (uint32_t)CPT * 64u) {
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)it.tptr[t], 0, (int)(it.b1[t] << 4), BM_RSRC_FLAGS);
-    for (uint32_t u = it.b0[t] + CPT * 64u; u < it.b1[t]; u += 64u) f(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0));
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)it.tptr[TT], 0, (int)(it.b1[TT] << 4), BM_RSRC_FLAGS);
+    for (uint32_t u = it.b0[TT] + CPT * 64u; u < it.b1[TT]; u += 64u) f(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0));
+  }
+}
+// ... for every term position TT in [A, B), f(chunk, TT)
+template <int NT, int A, int B, typename F>
+__device__ __forceinline__ void s16_each_term(const S16Cur<S16Cfg<NT>::RC>& cur, const S16Item<NT>& it, int lane16, F f) {
+  if constexpr (A < B) {
+    s16_each_chunk<NT, A>(cur, it, lane16, [&](const u32x4 v) { f(v, std::integral_constant<int, A>{}); });
+    s16_each_term<NT, A + 1, B>(cur, it, lane16, f);
   }
 }
 // intersections: the tile as the candidate path wants it -- (bound << 2) | 3 for the docs found in every term, 0 elsewhere.
 // from_scratch = false: the streaming loop has left the first NT - 1 terms accumulated (levels) and the last one unread.
-template <int NT, int CPT>
-__device__ __forceinline__ void s16a_build(const S16Cur<NT * CPT>& cur, const S16Item<NT>& it, uint32_t accb, int lane16, bool from_scratch) {
+// ... for the ONE term that stands at position qp of the query
+template <int NT, int A, typename F>
+__device__ __forceinline__ void s16_term_at(const S16Cur<S16Cfg<NT>::RC>& cur, const S16Item<NT>& it, int lane16, uint32_t qp, F f) {
+  if constexpr (A < NT) {
+    if (it.qpos[A] == qp) s16_each_chunk<NT, A>(cur, it, lane16, [&](const u32x4 v) { f(v, std::integral_constant<int, A>{}); });
+    else s16_term_at<NT, A + 1>(cur, it, lane16, qp, f);
+  }
+}
+template <int NT>
+__device__ __forceinline__ void s16a_build(const S16Cur<S16Cfg<NT>::RC>& cur, const S16Item<NT>& it, uint32_t accb, int lane16, bool from_scratch) {
   uint32_t nocount = 0u;
   if (from_scratch) {
-    s16_each_chunk<NT, CPT>(cur, it, 0, lane16, [&](const u32x4 v) { s16a_first(v, it.fidf[0], accb); });
-#pragma unroll
-    for (int t = 1; t + 1 < NT; t++) s16_each_chunk<NT, CPT>(cur, it, t, lane16, [&](const u32x4 v) { s16a_mid(v, it.fidf[t], accb, (uint32_t)t); });
+    s16_each_chunk<NT, 0>(cur, it, lane16, [&](const u32x4 v) { s16a_first(v, it.fidf[0], accb); });
+    s16_each_term<NT, 1, NT - 1>(cur, it, lane16, [&](const u32x4 v, auto tc) { s16a_mid(v, it.fidf[decltype(tc)::value], accb, (uint32_t)decltype(tc)::value); });
   }
-  s16_each_chunk<NT, CPT>(cur, it, NT - 1, lane16, [&](const u32x4 v) { (void)s16a_last<false, true>(v, it.fidf[NT - 1], accb, (uint32_t)NT - 1u, 0u, nocount); });
-  s16_each_chunk<NT, CPT>(cur, it, 0, lane16, [&](const u32x4 v) { s16a_clean(v, accb); });
+  s16_each_chunk<NT, NT - 1>(cur, it, lane16, [&](const u32x4 v) { (void)s16a_last<false, true>(v, it.fidf[NT - 1], accb, (uint32_t)NT - 1u, 0u, nocount); });
+  s16_each_chunk<NT, 0>(cur, it, lane16, [&](const u32x4 v) { s16a_clean(v, accb); });
 }
 
-template <int NT, int CPT, int KPL, bool AND>
-__device__ __forceinline__ BmTop<KPL> s16_trigger(BmTop<KPL> T, S16Cur<NT * CPT> cur, S16Item<NT> it, uint32_t wb, uint32_t qthr,
+template <int NT, int KPL, bool AND>
+__device__ __forceinline__ BmTop<KPL> s16_trigger(BmTop<KPL> T, S16Cur<S16Cfg<NT>::RC> cur, S16Item<NT> it, uint32_t wb, uint32_t qthr,
                                                             float thr, uint32_t doc_base, uint32_t k, uint32_t* tau_q,
                                                             const uint32_t* __restrict__ del, uint32_t del_words) {
   const int lane = __lane_id();
@@ -234,7 +262,7 @@ __device__ __forceinline__ BmTop<KPL> s16_trigger(BmTop<KPL> T, S16Cur<NT * CPT>
   constexpr uint32_t SH = AND ? 2u : 0u;
   if (AND) {
     qthr <<= 2;
-    s16a_build<NT, CPT>(cur, it, accb, lane16, false);
+    s16a_build<NT>(cur, it, accb, lane16, false);
   }
   for (;;) {
     // this lane's 8 slots (slot i * 64 + lane holds docs 8 * slot .. 8 * slot + 7): their largest bounds, packed 2 per register
@@ -301,18 +329,11 @@ __device__ __forceinline__ BmTop<KPL> s16_trigger(BmTop<KPL> T, S16Cur<NT * CPT>
         }
     };
     if (n) {
+      // terms in the QUERY's order (the fma chain of every other kernel), whatever order they are processed in: for each query
+      // position the term that stands there (one of NT wave-uniform branches)
 #pragma unroll
-      for (int t = 0; t < NT; t++) {
-        const uint32_t n16 = it.b1[t] - it.b0[t];
-#pragma unroll
-        for (int c = 0; c < CPT; c++)
-          if ((uint32_t)c * 64u < n16) exact(cur.v[t * CPT + c], it.idf[t]);
-        if (n16 > (uint32_t)CPT * 64u) {  // the part of an oversized segment that was streamed, not kept
-          __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)it.tptr[t], 0, (int)(it.b1[t] << 4), BM_RSRC_FLAGS);
-          for (uint32_t u = it.b0[t] + CPT * 64u; u < it.b1[t]; u += 64u)
-            exact(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0), it.idf[t]);
-        }
-      }
+      for (int qp = 0; qp < NT; qp++)
+        s16_term_at<NT, 0>(cur, it, lane16, (uint32_t)qp, [&](const u32x4 v, auto tc) { exact(v, it.idf[decltype(tc)::value]); });
       u64 key = 0ull;
       if ((uint32_t)lane < n) {
         const float sc = lds_ldf(accf + (uint32_t)lane * 4u);
@@ -333,21 +354,12 @@ __device__ __forceinline__ BmTop<KPL> s16_trigger(BmTop<KPL> T, S16Cur<NT * CPT>
     if (start == 0xFFFFu) break;
     // more candidates than the list holds (ties, or a list that is still filling): rebuild the bounds and go on
     if (AND) {
-      s16a_build<NT, CPT>(cur, it, accb, lane16, true);
+      s16a_build<NT>(cur, it, accb, lane16, true);
       continue;
     }
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-      const uint32_t n16 = it.b1[t] - it.b0[t];
+    {
       uint32_t dummy = 0u, nocount = 0u;  // (the docs of this item were counted when its bounds were first accumulated)
-#pragma unroll
-      for (int c = 0; c < CPT; c++)
-        if ((uint32_t)c * 64u < n16) dummy = s16_keep<false>(cur.v[t * CPT + c], it.fidf[t], accb, dummy, nocount);
-      if (n16 > (uint32_t)CPT * 64u) {
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)it.tptr[t], 0, (int)(it.b1[t] << 4), BM_RSRC_FLAGS);
-        for (uint32_t u = it.b0[t] + CPT * 64u; u < it.b1[t]; u += 64u)
-          dummy = s16_keep<false>(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0), it.fidf[t], accb, dummy, nocount);
-      }
+      s16_each_term<NT, 0, NT>(cur, it, lane16, [&](const u32x4 v, auto tc) { dummy = s16_keep<false>(v, it.fidf[decltype(tc)::value], accb, dummy, nocount); });
     }
   }
   s16_clear(wb, lane);
@@ -355,15 +367,15 @@ __device__ __forceinline__ BmTop<KPL> s16_trigger(BmTop<KPL> T, S16Cur<NT * CPT>
   return T;
 }
 
-template <int NT> struct S16Cfg { static constexpr int CPT = NT <= 2 ? 3 : 2; static constexpr int RC = NT * CPT; };
+
 
 template <int NT, int KPL, bool CNT, bool AND>
 __global__ void __launch_bounds__(S16_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base, const uint32_t* __restrict__ sub_off,
                    const bm_vquery* __restrict__ qs, unsigned long long* __restrict__ part_keys, unsigned long long* __restrict__ total, uint32_t* tau,
                    const uint32_t* __restrict__ del, uint32_t del_words, uint32_t n_sub, uint32_t n_terms, uint32_t nq, uint32_t P, uint32_t k) {
-  constexpr int CPT = S16Cfg<NT>::CPT;
-  constexpr int RC = S16Cfg<NT>::RC;
+  using Cfg = S16Cfg<NT>;
+  constexpr int RC = Cfg::RC;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();  // offsets below are absolute
   const int tid = threadIdx.x, lane = tid & 63;
@@ -383,6 +395,8 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
   float idf[NT];
   const uint32_t* rowp[NT];
   float fidf[NT];
+  uint32_t qpos[NT];
+  unsigned long long tlen[NT];
   float idf_sum = 0.f;
 #pragma unroll
   for (int t = 0; t < NT; t++) {
@@ -392,7 +406,23 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
     idf_sum += idf[t];
     tptr[t] = post + term_base[term] * 4ull;
     rowp[t] = sub_off + (size_t)term * row_len;
+    qpos[t] = (uint32_t)t;
+    tlen[t] = have ? term_base[term + 1] - term_base[term] : 0ull;  // absent terms (a short query) sort to the front: empty lists
   }
+  // processing order: by list length, shortest first (the chunk budgets of S16Cfg follow the position; an intersection's entries
+  // are created by its first = shortest list); qpos keeps every term's place in the query for the exact sums
+  auto cswap = [&](int x, int y) {
+    if (tlen[y] < tlen[x]) {
+      { auto t_ = tptr[x]; tptr[x] = tptr[y]; tptr[y] = t_; }
+      { auto t_ = rowp[x]; rowp[x] = rowp[y]; rowp[y] = t_; }
+      { float t_ = idf[x]; idf[x] = idf[y]; idf[y] = t_; }
+      { uint32_t t_ = qpos[x]; qpos[x] = qpos[y]; qpos[y] = t_; }
+      { auto t_ = tlen[x]; tlen[x] = tlen[y]; tlen[y] = t_; }
+    }
+  };
+  if (NT == 2) { cswap(0, 1); }
+  if (NT == 3) { cswap(0, 1); cswap(1, 2); cswap(0, 1); }
+  if (NT == 4) { cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2); }
   const float scale = (AND ? S16_QMAX_AND : S16_QMAX) / (S16_WMAX * idf_sum);
 #pragma unroll
   for (int t = 0; t < NT; t++) fidf[t] = s16_uniform(idf[t] * scale);
@@ -414,8 +444,8 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
     for (int t = 0; t < NT; t++) {
       __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[t], 0, (int)(b1[t] << 4), BM_RSRC_FLAGS);
 #pragma unroll
-      for (int c = 0; c < CPT; c++)
-        v[t * CPT + c] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + c * 1024, (int)(b0[t] << 4), 0);
+      for (int c = 0; c < Cfg::CPTMAX; c++)
+        if (c < Cfg::cpt(t)) v[Cfg::off(t) + c] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + c * 1024, (int)(b0[t] << 4), 0);
     }
   };
 
@@ -446,20 +476,20 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
       for (int t = 0; t < NT; t++) minn = min(minn, B1[t] - B0[t]);
       if (minn) {  // a sub-block one of the terms has no doc in holds no match: nothing is touched
         uint32_t mx = 0u, cnt = 0u;
-        auto seg = [&](int t, auto f) {
+        auto seg = [&](auto tc, auto f) {
+          constexpr int t = decltype(tc)::value;
           const uint32_t n16 = B1[t] - B0[t];
 #pragma unroll
-          for (int c = 0; c < CPT; c++)
-            if ((uint32_t)c * 64u < n16) f(cur[t * CPT + c]);
-          if (n16 > (uint32_t)CPT * 64u) {
+          for (int c = 0; c < Cfg::cpt(t); c++)
+            if ((uint32_t)c * 64u < n16) f(cur[Cfg::off(t) + c]);
+          if (n16 > (uint32_t)Cfg::cpt(t) * 64u) {
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[t], 0, (int)(B1[t] << 4), BM_RSRC_FLAGS);
-            for (uint32_t u = B0[t] + CPT * 64u; u < B1[t]; u += 64u) f(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0));
+            for (uint32_t u = B0[t] + Cfg::cpt(t) * 64u; u < B1[t]; u += 64u) f(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0));
           }
         };
-        seg(0, [&](const u32x4 v) { s16a_first(v, fidf[0], accb); });
-#pragma unroll
-        for (int t = 1; t + 1 < NT; t++) seg(t, [&](const u32x4 v) { s16a_mid(v, fidf[t], accb, (uint32_t)t); });
-        seg(NT - 1, [&](const u32x4 v) { mx = s16a_last<CNT, false>(v, fidf[NT - 1], accb, (uint32_t)NT - 1u, mx, cnt); });
+        seg(std::integral_constant<int, 0>{}, [&](const u32x4 v) { s16a_first(v, fidf[0], accb); });
+        if constexpr (NT == 3) seg(std::integral_constant<int, 1>{}, [&](const u32x4 v) { s16a_mid(v, fidf[1], accb, 1u); });
+        seg(std::integral_constant<int, NT - 1>{}, [&](const u32x4 v) { mx = s16a_last<CNT, false>(v, fidf[NT - 1], accb, (uint32_t)NT - 1u, mx, cnt); });
         if (CNT) T.matched += cnt;
         const float thr = fmaxf(T.wsc, __uint_as_float(tau_bits));
         const uint32_t qthr = k ? (thr > 0.f ? (uint32_t)(thr * scale_thr) : 0u) : 0xFFFFFFFFu;
@@ -469,10 +499,10 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
           thr_hit = thr;
 #pragma unroll
           for (int t = 0; t < NT; t++) { hb0[t] = B0[t]; hb1[t] = B1[t]; }
-        } else if (B1[0] - B0[0] <= (uint32_t)CPT * 64u) {  // only the first term's docs have entries
+        } else if (B1[0] - B0[0] <= (uint32_t)Cfg::cpt(0) * 64u) {  // only the first term's docs have entries
           const uint32_t n16 = B1[0] - B0[0];
 #pragma unroll
-          for (int c = 0; c < CPT; c++)
+          for (int c = 0; c < Cfg::cpt(0); c++)
             if ((uint32_t)c * 64u < n16) {
               const u32x4 v = cur[c];
               lds_st16(s16_addr(v.x, accb), 0u);
@@ -486,33 +516,37 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
       }
     } else if (maxn) {
       uint32_t mx = 0u, cnt = 0u;
+      bool over = false;  // some segment is longer than its register chunks: the remainder is streamed synchronously (and written)
+#pragma unroll
+      for (int t = 0; t < NT; t++) over = over || (B1[t] - B0[t]) > (uint32_t)Cfg::cpt(t) * 64u;
 #pragma unroll
       for (int t = 0; t + 1 < NT; t++) {  // the first term finds an empty tile: written without a read
         const uint32_t n16 = B1[t] - B0[t];
 #pragma unroll
-        for (int c = 0; c < CPT; c++)
-          if ((uint32_t)c * 64u < n16) {
-            if (t == 0) mx = s16_first<CNT>(cur[t * CPT + c], fidf[t], accb, mx, cnt);
-            else mx = s16_keep<CNT>(cur[t * CPT + c], fidf[t], accb, mx, cnt);
+        for (int c = 0; c < Cfg::CPTMAX; c++)
+          if (c < Cfg::cpt(t) && (uint32_t)c * 64u < n16) {
+            if (t == 0) mx = s16_first<CNT>(cur[Cfg::off(t) + c], fidf[t], accb, mx, cnt);
+            else mx = s16_keep<CNT>(cur[Cfg::off(t) + c], fidf[t], accb, mx, cnt);
           }
-        if (n16 > (uint32_t)CPT * 64u) {  // df above ~CPT/16 of the docs: the rest of the segment, loaded synchronously
+        if (n16 > (uint32_t)Cfg::cpt(t) * 64u) {  // the rest of the segment, loaded synchronously
           __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[t], 0, (int)(B1[t] << 4), BM_RSRC_FLAGS);
-          for (uint32_t u = B0[t] + CPT * 64u; u < B1[t]; u += 64u)
+          for (uint32_t u = B0[t] + Cfg::cpt(t) * 64u; u < B1[t]; u += 64u)
             mx = s16_keep<CNT>(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0), fidf[t], accb, mx, cnt);
         }
       }
       // the last term is only READ: its sums stay in registers and reach the tile when the item has candidates -- most
       // items have none, and the LDS pipe is what this kernel keeps busiest (a third of the scattered writes saved)
+      constexpr int CL = Cfg::cpt(NT - 1), OL = Cfg::off(NT - 1);
       const uint32_t nlast = B1[NT - 1] - B0[NT - 1];
-      uint32_t nwL[CPT][4];
+      uint32_t nwL[CL][4];
 #pragma unroll
-      for (int c = 0; c < CPT; c++)
+      for (int c = 0; c < CL; c++)
         if ((uint32_t)c * 64u < nlast) {
-          mx = s16_read<CNT>(cur[(NT - 1) * CPT + c], fidf[NT - 1], accb, mx, nwL[c], cnt);
+          mx = s16_read<CNT>(cur[OL + c], fidf[NT - 1], accb, mx, nwL[c], cnt);
         }
-      if (nlast > (uint32_t)CPT * 64u) {
+      if (nlast > (uint32_t)CL * 64u) {
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[NT - 1], 0, (int)(B1[NT - 1] << 4), BM_RSRC_FLAGS);
-        for (uint32_t u = B0[NT - 1] + CPT * 64u; u < B1[NT - 1]; u += 64u)
+        for (uint32_t u = B0[NT - 1] + CL * 64u; u < B1[NT - 1]; u += 64u)
           mx = s16_keep<CNT>(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0), fidf[NT - 1], accb, mx, cnt);
       }
       if (CNT) T.matched += cnt;
@@ -521,9 +555,9 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
       if (__ballot(mx >= (k ? qthr + S16_MBITS : 0xFFFFFFFFu))) {  // mx = the bits of 2^23 + the largest bound (s16_qm)
         hit = true;
 #pragma unroll
-        for (int c = 0; c < CPT; c++)
+        for (int c = 0; c < CL; c++)
           if ((uint32_t)c * 64u < nlast) {
-            const u32x4 v = cur[(NT - 1) * CPT + c];
+            const u32x4 v = cur[OL + c];
             lds_st16(s16_addr(v.x, accb), nwL[c][0]);
             lds_st16(s16_addr(v.y, accb), nwL[c][1]);
             lds_st16(s16_addr(v.z, accb), nwL[c][2]);
@@ -533,16 +567,16 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
         thr_hit = thr;
 #pragma unroll
         for (int t = 0; t < NT; t++) { hb0[t] = B0[t]; hb1[t] = B1[t]; }
-      } else if (maxn <= (uint32_t)CPT * 64u) {
+      } else if (!over) {
         // no candidate (the common case): only the entries the first NT - 1 terms wrote are dirty (the last term was only
         // read) -- zero those through their postings, 4 narrow stores per chunk, instead of 9 wide ones for the whole tile
 #pragma unroll
         for (int t = 0; t + 1 < NT; t++) {
           const uint32_t n16 = B1[t] - B0[t];
 #pragma unroll
-          for (int c = 0; c < CPT; c++)
-            if ((uint32_t)c * 64u < n16) {
-              const u32x4 v = cur[t * CPT + c];
+          for (int c = 0; c < Cfg::CPTMAX; c++)
+            if (c < Cfg::cpt(t) && (uint32_t)c * 64u < n16) {
+              const u32x4 v = cur[Cfg::off(t) + c];
               lds_st16(s16_addr(v.x, accb), 0u);
               lds_st16(s16_addr(v.y, accb), 0u);
               lds_st16(s16_addr(v.z, accb), 0u);
@@ -589,8 +623,8 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
         for (int r = 0; r < RC; r++) cc.v[r] = in_a ? vA[r] : vB[r];
         S16Item<NT> it;
 #pragma unroll
-        for (int t = 0; t < NT; t++) { it.tptr[t] = tptr[t]; it.idf[t] = idf[t]; it.fidf[t] = fidf[t]; it.b0[t] = hb0[t]; it.b1[t] = hb1[t]; }
-        T = s16_trigger<NT, CPT, KPL, AND>(T, cc, it, wb, qthr_hit, thr_hit, (s0 + i - 1u) << BM_SUB_LOG2, k, tau_q, del, del_words);
+        for (int t = 0; t < NT; t++) { it.tptr[t] = tptr[t]; it.idf[t] = idf[t]; it.fidf[t] = fidf[t]; it.b0[t] = hb0[t]; it.b1[t] = hb1[t]; it.qpos[t] = qpos[t]; }
+        T = s16_trigger<NT, KPL, AND>(T, cc, it, wb, qthr_hit, thr_hit, (s0 + i - 1u) << BM_SUB_LOG2, k, tau_q, del, del_words);
       }
     }
   }
