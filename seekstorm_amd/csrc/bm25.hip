@@ -326,11 +326,12 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   // with exactly np_max terms, no NOT terms, no all_terms_frequent shortcut
   const uint32_t and_exact_nt = (has_and && !has_or && F == 1 && uniform_terms && nt_max == np_max && !any_frequent && !any_field_filter) ? np_max : 0u;
   const bool scan16 = !pruned && !phrase && ssi_bm25_scan16_serves(nt_max, np_max, has_and, scan_counts, s->n_deleted != 0, KPL, k, and_exact_nt);
-  // (16-bit scan: 1.415 ms per 1000 C2 queries at 4 rounds against 1.496 at 2 -- its work per assignment follows the query's
-  // posting count, which differs 3x between C2's queries; round 3 also tried workgroups made of the partitions of ONE query
-  // instead of 8 queries of one partition, tools/probes/map_sweep.py: 1.48 ms at the same 16 partitions, no better than the
-  // plain map for the pruned kernel either)
-  const uint32_t resident = (pruned || phrase) ? 6144u : scan16 ? 4096u : 2048u, rounds = (pruned || phrase || scan16) ? 4u : 2u;
+  // (16-bit scan, round 3: while the longest lists of C2 overflowed their register chunks -- a synchronous load per item for 17 % of
+  // the queries -- 4 rounds beat 2 (1.415 against 1.496 ms per 1000 queries); with the chunk budgets following the sorted terms the
+  // imbalance is gone and fewer, longer assignments win again: 1.08 ms at 8 partitions per query, 1.10 at 10 / 12, 1.11 at 16, 1.15 at
+  // 24 (tools/probes/psweep.sh).  Workgroups made of the partitions of ONE query instead of 8 queries of one partition were tried as
+  // well (profiles/r3_map_sweep.log): no better, for the pruned kernel neither.)
+  const uint32_t resident = (pruned || phrase) ? 6144u : scan16 ? 4096u : 2048u, rounds = (pruned || phrase) ? 4u : 2u;
   uint32_t P = (rounds * resident) / nq;
   // small batches: beyond ~150 waves the probe kernel gains nothing and every extra partition is one more list to merge
   // (single query on C2: 0.128 ms at P = n_sub = 2442, 0.086 ms at P = 128)
