@@ -118,6 +118,16 @@ int ss_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, const
                           uint32_t n_terms, const uint64_t* term_offsets, const uint32_t* doc_ids, const uint8_t* field_ids,
                           const uint16_t* tfs);
 
+/* ss_bm25_upload_fields plus the POSITIONS of every (term, doc, field) entry, in entry order: tf positions inside the field,
+ * ascending, each < 65 536 -- what decode_positions_multiterm_multifield / get_next_position_multifield hand the phrase check of
+ * add_result_multiterm_multifield (add_result.rs:1485-2034, 2964-3414).  Phrase queries then run over the image's merged
+ * lists (SS_ENOTSUP when the boosts kept them from being built): the phrase must stand inside ONE field -- a listed one under
+ * SS_OP_FIELD_FILTER --, the score is the BM25F sum over all fields of the unique terms.  n_positions = sum of tfs.
+ * 4 bytes per position + 4 bytes per image slot of HBM. */
+int ss_bm25_upload_fields_positions(ss_shard* s, uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen_bytes, const float* boost,
+                                    uint32_t n_terms, const uint64_t* term_offsets, const uint32_t* doc_ids, const uint8_t* field_ids,
+                                    const uint16_t* tfs, const uint16_t* positions, uint64_t n_positions);
+
 /* ss_bm25_upload plus the POSITIONS of every posting (one indexed field): positions = for every posting in CSR order its tf
  * positions inside the field, ascending, each < 65 536 (token_per_field_max, index.rs:5343) -- what the reference decodes from
  * the position records / embedded pointers (add_result.rs:38-59, 2036-2197; compress_postinglist.rs:949-977).  n_positions must
@@ -197,17 +207,26 @@ int ss_index_bin_term_postings(const ss_index_bin* ix, uint32_t term, uint64_t c
 int ss_bm25_upload_index_bin(ss_shard* s, const ss_index_bin* ix);
 /* The same plus the positions of every posting, decoded from the rank/position pointers (embedded forms) and the VINT records
  * (decode_positions_multiterm_singlefield, add_result.rs:2036-2197; stored as first position, then gap - 1): phrase queries
- * (SS_OP_PHRASE) then work on an image built from the file.  One indexed field, SingleTerm keys only; SS_ENOTSUP for an
- * index with n-gram keys, several fields, or a position beyond 65 535. */
+ * (SS_OP_PHRASE) then work on an image built from the file.  SingleTerm keys only: SS_ENOTSUP for an index with n-gram keys or a
+ * position beyond 65 535.  Several indexed fields: see ss_bm25_upload_index_bin_fields_positions. */
 int ss_bm25_upload_index_bin_positions(ss_shard* s, const ss_index_bin* ix);
 /* the same for an index with several indexed fields: position records carry a field vector per posting
  * (decode_positions_multiterm_multifield, add_result.rs:1485-2034; read_multifield_vec 2200-2293) -> ss_bm25_upload_fields.
  * boost = schema boost per field (schema.json; NULL = 1).  ss_bm25_upload_index_bin calls it with NULL. */
 int ss_bm25_upload_index_bin_fields(ss_shard* s, const ss_index_bin* ix, const float* boost);
+/* ... plus the positions of every (posting, field) entry -- the VINT positions behind a record's field vector and the bit-packed
+ * positions of the embedded pointers (add_result.rs:1606-2017) -- for phrase queries over several indexed fields
+ * (ss_bm25_upload_fields_positions).  ss_bm25_upload_index_bin_positions calls it with boost NULL for such an index. */
+int ss_bm25_upload_index_bin_fields_positions(ss_shard* s, const ss_index_bin* ix, const float* boost);
 /* one block of a multi-field index: docs_out [65536], first_out [65537] = CSR of the field entries per posting,
  * field_out / tf_out [65536 * n_fields] */
 int ss_ref_decode_block_fields(const ss_ref_block* block, uint32_t n_fields, uint32_t longest_field_id, uint16_t* docs_out,
                                uint32_t* first_out, uint8_t* field_out, uint16_t* tf_out);
+/* the same with the positions of every (posting, field) entry in entry order (sum of tf_out; SingleTerm keys): returns the posting
+ * count, *n_pos_out = positions written (SS_EINVAL with the needed number when pos_cap is too small) */
+int ss_ref_decode_block_fields_positions(const ss_ref_block* block, uint32_t n_fields, uint32_t longest_field_id, uint16_t* docs_out,
+                                         uint32_t* first_out, uint8_t* field_out, uint16_t* tf_out, uint16_t* pos_out, uint64_t pos_cap,
+                                         uint64_t* n_pos_out);
 /* an N-GRAM key's block in a multi-field index: every record starts with the field vector of each component term (2 or 3,
  * index_posting.rs:664-722 / add_result.rs:1524-1600) before the n-gram's own; output = component `component`'s vector */
 int ss_ref_decode_block_fields_ngram(const ss_ref_block* block, uint32_t n_fields, uint32_t longest_field_id, uint32_t n_components,
@@ -294,7 +313,9 @@ typedef struct {
  * order.  A doc matches when it contains every unique term and some position p carries word i at p + i for every i
  * (add_result.rs:3596-3684: the merge over the entries' position lists, fewest positions first); it is scored like the
  * intersection of the unique terms (get_bm25f_multiterm_singlefield) and counted only when the phrase matches.  Needs the
- * positions in the image (ss_bm25_upload_positions), one indexed field, every list with a probe row.  Host-pointer batches may mix
+ * positions in the image and every list with a probe row.  One indexed field: ss_bm25_upload_positions.  Several indexed fields
+ * (ss_bm25_upload_fields_positions; add_result.rs:3248-3386): the phrase must stand inside ONE field, fields tried in ascending
+ * order, only listed ones under SS_OP_FIELD_FILTER; the score sums all fields of the unique terms.  Host-pointer batches may mix
  * phrase queries with others (run as two sub-batches inside the library, answers back in the callers' order); a DEVICE-resident
  * batch (ss_bm25_search_dev) holds phrase queries only (ops_mask bit 4); NOT terms are not offered with phrases (SS_ENOTSUP). */
 

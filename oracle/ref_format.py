@@ -164,9 +164,11 @@ def encode_term(docs, tfs, rng, base_bytes=b"", positions_limit=32768, max_gap=4
 
 
 # ------------------------------------------------------------------------------------------------ index.bin / vector.bin
-def encode_term_fields(docs, fields, tfs, n_fields, longest_field_id, rng, positions_limit=32768, max_gap=40, ngram_vecs=None):
+def encode_term_fields(docs, fields, tfs, n_fields, longest_field_id, rng, positions_limit=32768, max_gap=40, ngram_vecs=None,
+                       positions=None):
     """(doc, field, tf) entries sorted by (doc, field) -> per-block key bodies like encode_term
-    ngram_vecs: {doc: [[(field, tf), ...] per component term]} for an n-gram key"""
+    ngram_vecs: {doc: [[(field, tf), ...] per component term]} for an n-gram key
+    positions: the ascending positions of every entry (len tf each); None = drawn from rng"""
     docs = np.asarray(docs, np.int64)
     fields = np.asarray(fields, np.int64)
     out = []
@@ -180,7 +182,8 @@ def encode_term_fields(docs, fields, tfs, n_fields, longest_field_id, rng, posit
                 local.append(d)
                 full.append(int(docs[i]))
                 postings.append([])
-            postings[-1].append((int(fields[i]), random_positions(rng, int(tfs[i]), max_gap)))
+            postings[-1].append((int(fields[i]), random_positions(rng, int(tfs[i]), max_gap) if positions is None
+                                 else [int(x) for x in positions[i]]))
         nv = None if ngram_vecs is None else [ngram_vecs[d] for d in full]
         body, ctp, cnt, pivot = encode_key_body_fields(local, postings, n_fields, longest_field_id, 0, positions_limit, nv)
         out.append((int(b), ctp, cnt, pivot, body))
@@ -222,7 +225,8 @@ def write_index_bin(n_docs, doclen_bytes, terms, rng, segment_number_bits=11, ke
             blocks = encode_term(term[1], term[2], rng, positions_limit=positions_limit,
                                  positions=term[3] if len(term) > 3 else None)  # (key_hash, docs, tfs[, positions per posting])
         else:
-            blocks = encode_term_fields(term[1], term[2], term[3], n_fields, longest_field_id, rng, positions_limit)
+            blocks = encode_term_fields(term[1], term[2], term[3], n_fields, longest_field_id, rng, positions_limit,
+                                        positions=term[4] if len(term) > 4 else None)  # (key_hash, docs, fields, tfs[, positions per entry])
         per_term_blocks.append({b[0]: b for b in blocks})
     terms = list(terms)
     head_extra = [bytes(key_head_size - 20)] * len(terms)

@@ -1608,6 +1608,90 @@ uint32_t so_search_phrase(const so_shard* s, uint32_t nq, const uint32_t* qt, ui
   return n;
 }
 
+/* Phrase search over SEVERAL indexed fields (add_result_multiterm_multifield, add_result.rs:2964-3414): the docs containing every
+ * unique term in some field (intersection of the keys' posting lists); the phrase check runs FIELD BY FIELD, ascending
+ * ('main loop, 3259-3386): a field is looked at only if every word of the phrase has positions in it (3260-3277: a word whose
+ * next field is larger skips the field, a word without further fields ends the search) and, under a field filter, only if the
+ * filter lists it (3285-3287); inside the field it is the single-field merge over that field's positions (3289-3385;
+ * positions restart in every field: get_next_position_multifield is absolute at the first position of a field, 3279-3283).
+ * The first match ends it (phrasematch_count >= 1 -> break 'main).  A matching doc is counted (3394-3396) and scored with
+ * get_bm25f_multiterm_multifield over ALL fields of the unique terms (3140 / 3402; 1226-1262: terms in query order, a term's
+ * fields ascending, boost * idf * (tf (K+1) / (tf + comp[len byte of (doc, field)]) + SIGMA)) -- the filter restricts where the
+ * phrase may stand, not what is summed (the per-term gate 3124-3136 is implied by a match inside a listed field).
+ * Entries of a term sorted by (doc, field); positions: for every entry in CSR order its tf positions inside the field,
+ * ascending; seq[i] = index into qt of the i-th word; field_mask 0 = no filter.  Exact top-k by (score desc, doc asc). */
+uint32_t so_search_fields_phrase(uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen /*[n_fields][n_docs]*/, const float* boost,
+                                 const uint64_t* off, const uint32_t* docs, const uint8_t* fields, const uint16_t* tfs,
+                                 const uint16_t* positions, uint32_t nq, const uint32_t* qt, uint32_t n_seq, const uint8_t* seq,
+                                 uint32_t k, const uint64_t* deleted, uint64_t n_deleted, uint32_t field_mask, int reference_loop,
+                                 uint32_t* od, float* os, uint64_t* total) {
+  if (total) *total = 0;
+  if (nq == 0 || nq > 32 || n_seq < 2 || n_seq > 32 || n_fields == 0 || n_fields > 16) return 0;
+  uint64_t psum = 0;
+  for (uint64_t i = 0; i < n_docs * n_fields; i++) psum += so_byte4_to_int(doclen[i]);
+  float comp[256];
+  so_bm25_component_cache(so_avgdl(psum, n_docs), comp);
+  /* first position of every entry */
+  uint64_t last = 0;
+  for (uint32_t t = 0; t < nq; t++) if (off[qt[t] + 1] > last) last = off[qt[t] + 1];
+  uint64_t* pbeg = (uint64_t*)malloc((last + 1) * sizeof(uint64_t));
+  { uint64_t a = 0; for (uint64_t i = 0; i < last; i++) { pbeg[i] = a; a += tfs[i]; } pbeg[last] = a; }
+  uint8_t* dead = (uint8_t*)calloc(n_docs ? n_docs : 1, 1);
+  for (uint64_t i = 0; i < n_deleted; i++) if (deleted[i] < n_docs) dead[deleted[i]] = 1;
+  float idf[32];
+  for (uint32_t t = 0; t < nq; t++) {
+    uint64_t df = 0;
+    for (uint64_t i = off[qt[t]]; i < off[qt[t] + 1]; i++) if (i == off[qt[t]] || docs[i] != docs[i - 1]) df++;
+    idf[t] = so_idf(n_docs, df);
+  }
+  uint64_t cur[32];
+  for (uint32_t t = 0; t < nq; t++) cur[t] = off[qt[t]];
+  so_sd* v = NULL; uint64_t nv = 0, cap = 0;
+  for (uint64_t i0 = off[qt[0]]; i0 < off[qt[0] + 1]; i0++) {
+    if (i0 > off[qt[0]] && docs[i0] == docs[i0 - 1]) continue;  /* first entry of (term 0, doc) */
+    const uint32_t d = docs[i0];
+    int all = 1;
+    uint64_t at[32], end[32];  /* entries of (term, doc): at[t] .. end[t] */
+    at[0] = i0;
+    for (uint32_t t = 1; t < nq && all; t++) {
+      while (cur[t] < off[qt[t] + 1] && docs[cur[t]] < d) cur[t]++;
+      all = cur[t] < off[qt[t] + 1] && docs[cur[t]] == d;
+      at[t] = cur[t];
+    }
+    if (!all || dead[d]) continue;
+    for (uint32_t t = 0; t < nq; t++) { end[t] = at[t]; while (end[t] < off[qt[t] + 1] && docs[end[t]] == d) end[t]++; }
+    int match = 0;
+    for (uint32_t f = 0; f < n_fields && !match; f++) {
+      const uint16_t* pl[32]; uint32_t pc[32];
+      int have = 1;
+      for (uint32_t i = 0; i < n_seq && have; i++) {
+        const uint32_t t = seq[i];
+        have = 0;
+        for (uint64_t e = at[t]; e < end[t]; e++)
+          if (fields[e] == f) { pl[i] = positions + pbeg[e]; pc[i] = tfs[e]; have = 1; break; }
+      }
+      if (!have) continue;                                        /* some word has no position in this field */
+      if (field_mask && !((field_mask >> f) & 1u)) continue;      /* add_result.rs:3285-3287 */
+      match = so_phrase_match(n_seq, pl, pc, reference_loop);
+    }
+    if (!match) continue;
+    float sc = 0.0f;
+    for (uint32_t t = 0; t < nq; t++)
+      for (uint64_t e = at[t]; e < end[t]; e++) {
+        const float w = boost ? boost[fields[e]] : 1.0f;
+        sc += w * idf[t] * ((float)tfs[e] * (SO_K + 1.0f) / ((float)tfs[e] + comp[doclen[(uint64_t)fields[e] * n_docs + d]]) + SO_SIGMA);
+      }
+    if (nv == cap) { cap = cap ? cap * 2 : 1024; v = (so_sd*)realloc(v, cap * sizeof(so_sd)); }
+    v[nv].score = sc; v[nv].doc = d; nv++;
+  }
+  if (nv) qsort(v, nv, sizeof(so_sd), sd_cmp);
+  const uint32_t n = (uint32_t)(nv < k ? nv : k);
+  for (uint32_t i = 0; i < n; i++) { od[i] = v[i].doc; os[i] = v[i].score; }
+  if (total) *total = nv;
+  free(v); free(dead); free(pbeg);
+  return n;
+}
+
 /* ================================================================== CPU baseline harness, vector path (bench.py)
  * search_vector_shard's AnnMode::All scan (read_record -> dot_f32_avx2 -> TopK::push, vector.rs:1397-1466) in the reference's
  * execution structure: the records partitioned over S shards, one task per shard and query, gather + sort.

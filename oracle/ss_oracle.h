@@ -137,6 +137,14 @@ int so_phrase_match(uint32_t n_seq, const uint16_t* const* pos, const uint32_t* 
 /* q_terms: the unique terms; seq[n_seq]: index into q_terms of every word of the phrase */
 uint32_t so_search_phrase(const so_shard*, uint32_t n_q_terms, const uint32_t* q_terms, uint32_t n_seq, const uint8_t* seq, uint32_t k,
                           int reference_loop, uint32_t* out_doc, float* out_score, uint64_t* out_total);
+/* phrase over SEVERAL indexed fields (add_result.rs:2964-3414): the phrase must stand inside ONE field (a listed one under
+ * field_mask != 0); score = BM25F over all fields of the unique terms.  positions: per (term, doc, field) entry in CSR order its tf
+ * positions inside the field */
+uint32_t so_search_fields_phrase(uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost, const uint64_t* off,
+                                 const uint32_t* docs, const uint8_t* fields, const uint16_t* tfs, const uint16_t* positions,
+                                 uint32_t n_q_terms, const uint32_t* q_terms, uint32_t n_seq, const uint8_t* seq, uint32_t k,
+                                 const uint64_t* deleted, uint64_t n_deleted, uint32_t field_mask, int reference_loop,
+                                 uint32_t* out_doc, float* out_score, uint64_t* out_total);
 /* statistics for the roofline's algorithmic bytes: sum df, #blocks touched */
 void so_query_stats(const so_shard*, uint32_t n_q_terms, const uint32_t* q_terms, uint64_t* sum_df,
                     uint64_t* sum_blocks);

@@ -77,6 +77,8 @@ SYMBOLS = [
     ("ss_bm25_upload", C.c_int, [C.c_void_p, C.c_uint64, u8p, C.c_uint32, u64p, u32p, u16p]),
     ("ss_bm25_upload_positions", C.c_int, [C.c_void_p, C.c_uint64, u8p, C.c_uint32, u64p, u32p, u16p, u16p, C.c_uint64]),
     ("ss_bm25_upload_fields", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, u8p, f32p, C.c_uint32, u64p, u32p, u8p, u16p]),
+    ("ss_bm25_upload_fields_positions", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, u8p, f32p, C.c_uint32, u64p, u32p, u8p, u16p, u16p,
+                                                  C.c_uint64]),
     ("ss_ref_decode_block", C.c_int, [C.c_void_p, u16p, u16p]),
     ("ss_bm25_upload_ref_blocks", C.c_int, [C.c_void_p, C.c_uint64, u8p, C.c_uint32, u64p, C.c_void_p]),
     ("ss_index_bin_open", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
@@ -92,6 +94,8 @@ SYMBOLS = [
     ("ss_ref_decode_block_positions", C.c_int, [C.c_void_p, u16p, u16p, u16p, C.c_uint64, u64p]),
     ("ss_bm25_upload_index_bin_fields", C.c_int, [C.c_void_p, C.c_void_p, f32p]),
     ("ss_ref_decode_block_fields", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, u16p, u32p, u8p, u16p]),
+    ("ss_ref_decode_block_fields_positions", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, u16p, u32p, u8p, u16p, u16p, C.c_uint64, u64p]),
+    ("ss_bm25_upload_index_bin_fields_positions", C.c_int, [C.c_void_p, C.c_void_p, f32p]),
     ("ss_ref_decode_block_fields_ngram", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u16p, u32p, u8p, u16p]),
     ("ss_synth_set_partition", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     ("ss_bm25_synth", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, u32p, u8p]),

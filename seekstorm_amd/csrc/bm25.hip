@@ -164,13 +164,15 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
   const uint32_t np = Q.n_terms, n_not = bm_q_nnot(Q.op);
   const uint32_t n_fields = n_lists - (merged ? 1u : 0u);                      // indexed fields
   const uint32_t filt = n_fields > 1 ? bm_q_field_filter(Q.op) : 0u;
-  const bool use_merged = merged != 0u && filt == 0u;                          // this query reads the merged lists only
+  const bool q_is_phrase = bm_q_op(Q.op) == SS_OP_PHRASE;
+  const bool use_merged = merged != 0u && (filt == 0u || q_is_phrase);         // this query reads the merged lists only (a phrase always:
+                                                                               // its filter is a test on the positions' field bits)
   const uint32_t f_begin = use_merged ? n_lists - 1u : 0u, f_end = use_merged ? n_lists : n_fields;  // the lists of a term it reads
   const uint32_t eff_fields = use_merged ? 1u : n_fields;                      // ... as how many fields the rules below see them
   {
     const uint32_t nt_claim = (claim >> 8) & 0xFFu, np_claim = (claim >> 16) & 0xFFu, ff = filt;
     bool bad = np == 0 || np + n_not > (uint32_t)SS_MAX_QUERY_TERMS || (np + n_not) * eff_fields > (uint32_t)BM_MAX_VTERMS;
-    bad |= ff != 0u && merged != 0u && !(claim & BM_CLAIM_FILTER);  // the variants were sized for one list per term
+    bad |= ff != 0u && merged != 0u && !q_is_phrase && !(claim & BM_CLAIM_FILTER);  // the variants were sized for one list per term
     bad |= np + n_not > nt_claim || np > np_claim;
     bad |= (claim & BM_CLAIM_UNIFORM) != 0u && np != np_claim;
     bad |= n_not != 0 && nt_claim == np_claim;  // nt == np declares a batch without NOT terms (unfiltered kernel variants)
@@ -179,11 +181,11 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
     bad |= q_gated && (np > 7u || !(claim & BM_CLAIM_GATED));
     bad |= q_and && !(claim & BM_CLAIM_AND);
     bad |= !q_and && np > 1 && !(claim & BM_CLAIM_OR);
-    // a phrase batch holds phrase queries only (one indexed field, no NOT terms, 2 .. SS_MAX_PHRASE words naming the unique terms)
+    // a phrase batch holds phrase queries only (one indexed field or merged lists, no NOT terms, 2 .. SS_MAX_PHRASE words naming the unique terms)
     const bool q_phrase = bm_q_op(Q.op) == SS_OP_PHRASE;
     bad |= bm_q_op(Q.op) > (uint32_t)SS_OP_PHRASE || q_phrase != ((claim & BM_CLAIM_PHRASE) != 0u);
     if (q_phrase) {
-      bad |= n_lists != 1 || n_not != 0 || Q.phrase_len < 2u || Q.phrase_len > (uint32_t)SS_MAX_PHRASE || np > 6u;
+      bad |= (n_lists != 1 && merged == 0u) || n_not != 0 || Q.phrase_len < 2u || Q.phrase_len > (uint32_t)SS_MAX_PHRASE || np > 6u;
       uint32_t used = 0;
       for (uint32_t j = 0; j < (uint32_t)SS_MAX_PHRASE && j < Q.phrase_len; j++) {
         bad |= Q.phrase_seq[j] >= np;
@@ -207,6 +209,7 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
       for (uint32_t j = 0; j < (uint32_t)BM_MAX_VTERMS; j++) { V.term[j] = j ? 0 : n_vterms; V.idf[j] = 0.f; V.and_val[j] = 0; V.group[j] = j ? 0xFF : 0; }
       V.phrase_len = (claim & BM_CLAIM_PHRASE) ? 2u : 0u;  // an empty phrase query: both words are the absent term
       for (int j = 0; j < SS_MAX_PHRASE; j++) V.phrase_seq[j] = 0;
+      V.phrase_fields = 0xFFFFFFFFu;
       return;
     }
   }
@@ -248,6 +251,7 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
   for (uint32_t j = n; j < (uint32_t)BM_MAX_VTERMS; j++) { V.term[j] = 0; V.idf[j] = 0.f; V.and_val[j] = 0; V.group[j] = 0xFF; }
   V.phrase_len = bm_q_op(Q.op) == SS_OP_PHRASE ? Q.phrase_len : 0u;
   for (int j = 0; j < SS_MAX_PHRASE; j++) V.phrase_seq[j] = Q.phrase_seq[j];
+  V.phrase_fields = (q_is_phrase && filt) ? filt : 0xFFFFFFFFu;
 }
 
 // ---------------------------------------------------------------- host side
@@ -297,7 +301,8 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   // Several indexed fields: every query term is a union of its (term, field) lists -- the pruned kernel ranks unions of
   // virtual terms as they are; an intersection of unions is left to the scan kernels' match masks.
   // With merged lists (ss_common.h bm_merged) a batch without field filters is a single-field batch to everything below.
-  const uint32_t F = (s->bm_merged && !any_field_filter) ? 1u : bm_real_fields(s);
+  // phrase queries always read the merged lists (their field filter is a test on the positions, bm25_phrase.hip)
+  const uint32_t F = (s->bm_merged && (!any_field_filter || phrase)) ? 1u : bm_real_fields(s);
   nt_max *= F;
   np_max *= F;
   if (F > 1) has_or = true;
@@ -308,7 +313,9 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
                       np_max >= 1 && np_max <= 4 && KPL <= 2;  // NOT terms are probed outside the template
   if (!pruned && !phrase && s->bm_strategy == SS_BM25_PRUNED) return SS_ENOTSUP;
   // phrase queries: their own kernel over the probe index and the positions (bm25_phrase.hip); every strategy
-  if (phrase && (!have_probe || !s->d_pos || s->bm_n_fields != 1 || KPL > 2 || np_max > 6 || nt_max != np_max)) return !s->d_pos ? SS_ESTATE : SS_ENOTSUP;
+  // (one indexed field: d_pos; several: the merged lists and d_pos32)
+  const bool have_pos = s->bm_n_fields == 1 ? s->d_pos != nullptr : (s->bm_merged && s->d_pos32 != nullptr);
+  if (phrase && (!have_probe || !have_pos || KPL > 2 || np_max > 6 || nt_max != np_max)) return !have_pos ? SS_ESTATE : SS_ENOTSUP;
   // Partitions per query (one wave each).  The grid is a whole number of "rounds" of resident waves: a partially
   // filled last round costs its full duration (measured on C2: 550K q/s at 1.95 rounds vs 477K at 2.44).  Exhaustive
   // scan: 2048 resident waves (LDS-bound), ~2 rounds; pruned: 6144 resident waves, ~4 rounds of shorter assignments
@@ -401,7 +408,8 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   int rc = SS_OK;
   if (bit_counts_all && k == 0) SS_HIP(hipMemsetAsync(bufA, 0, (size_t)nq * P * KS * sizeof(u64), st));  // no ranking wanted
   else if (phrase)
-    rc = ssi_bm25_launch_phrase(p, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_pos, s->d_pos_off, (const unsigned long long*)s->d_pos_base,
+    rc = ssi_bm25_launch_phrase(p, s->d_probe, s->d_probe_z, s->d_probe_row, s->bm_n_fields == 1 ? s->d_pos : nullptr,
+                                s->bm_n_fields == 1 ? nullptr : s->d_pos32, s->d_pos_off, (const unsigned long long*)s->d_pos_base,
                                 np_max, KPL, st);
   else rc = pruned ? ssi_bm25_launch_probe(p, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_umax, use_partmax ? s->d_submax : nullptr, pmax_ws, np_max, KPL, nt_max != np_max, st)
                    : scan16 ? ssi_bm25_launch_scan16(p, nt_max, has_and, KPL, st) : ssi_bm25_launch_scan(p, nt_max, has_and, KPL, st);

@@ -392,7 +392,8 @@ int ssi_bm25_launch_union_count(const BmParams& p, const uint2* probe, const uin
                                 unsigned long long* match_bits = nullptr);
 // pruned top-k over the probe index (bm25_probe.hip); SS_ENOTSUP if it cannot serve the request
 // phrase queries (bm25_phrase.hip): intersection over the probe index + position check
-int ssi_bm25_launch_phrase(const BmParams& p, const uint2* probe, const uint32_t* probe_z, const uint32_t* probe_row, const uint16_t* pos,
-                           const uint32_t* pos_off, const unsigned long long* pos_base, uint32_t nt_max, int KPL, hipStream_t st);
+int ssi_bm25_launch_phrase(const BmParams& p, const uint2* probe, const uint32_t* probe_z, const uint32_t* probe_row, const uint16_t* pos16,
+                           const uint32_t* pos32, const uint32_t* pos_off, const unsigned long long* pos_base, uint32_t nt_max, int KPL,
+                           hipStream_t st);
 int ssi_bm25_launch_probe(const BmParams& p, const uint2* probe, const uint32_t* probe_z, const uint32_t* probe_row, const float* umax,
                           const float* submax, float* pmax_ws, uint32_t nt_max, int KPL, bool any_not, hipStream_t st);

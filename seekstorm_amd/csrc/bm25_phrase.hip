@@ -15,15 +15,24 @@
 // a doc whose BM25 cannot enter the list skips the position check, as the reference does (add_result.rs:3573-3583).
 // Positions in HBM: d_pos (u16 pool in image order), d_pos_off (end offset per padded posting slot, relative to the term),
 // d_pos_base (first position of a term) -- ss_bm25_upload_positions.
+//
+// SEVERAL indexed fields (add_result_multiterm_multifield, add_result.rs:2964-3414): the reference walks the fields in ascending
+// order and runs the same merge inside every field in which all words of the phrase have positions (3259-3386), skipping the
+// fields a field filter does not list (3285-3287); the first match ends it, and the doc is scored over ALL fields of its terms
+// (get_bm25f_multiterm_multifield, 3140 / 3402).  Here (PT = uint32_t): the query reads its terms' MERGED lists (one posting per
+// (term, doc), weight = the BM25F sum over the doc's fields), whose positions carry their field above bit 20 -- field f's positions
+// of a posting follow field f - 1's, so the list is ascending as a whole, "word i at start + i" can only be satisfied inside the
+// start's own field (a position is < 65 536, the phrase <= SS_MAX_PHRASE words), and the filter is a test of the START's field
+// bits against Q->phrase_fields.  d_pos32 / ss_bm25_upload_fields_positions.
 #include "bm25_dev.h"
 
 constexpr int PH_WAVES = 4;
 
-template <int NT, int KPL>
+template <int NT, int KPL, typename PT>
 __global__ void __launch_bounds__(PH_WAVES * 64) bm25_phrase_kernel(
     const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base, const uint32_t* __restrict__ sub_off,
     const uint2* __restrict__ probe, const uint32_t* __restrict__ probe_z, const uint32_t* __restrict__ probe_row,
-    const uint16_t* __restrict__ pos, const uint32_t* __restrict__ pos_off, const unsigned long long* __restrict__ pos_base,
+    const PT* __restrict__ pos, const uint32_t* __restrict__ pos_off, const unsigned long long* __restrict__ pos_base,
     const bm_vquery* __restrict__ qs, unsigned long long* __restrict__ part_keys, unsigned long long* __restrict__ total,
     uint32_t* tau, const uint32_t* __restrict__ del, uint32_t del_words, uint32_t n_sub, uint32_t n_terms, uint32_t nq, uint32_t P,
     uint32_t k, uint32_t count) {
@@ -33,6 +42,8 @@ __global__ void __launch_bounds__(PH_WAVES * 64) bm25_phrase_kernel(
   const uint32_t qi = a % nq, part = a / nq;
   const bm_vquery* __restrict__ Q = qs + qi;
   const uint32_t nt = Q->n_terms, plen = Q->phrase_len;
+  constexpr bool MF = sizeof(PT) == 4;  // several indexed fields: positions carry their field
+  const uint32_t fmask = MF ? Q->phrase_fields : 0xFFFFFFFFu;
   const uint32_t row_len = n_sub + 1;
 
   // per unique term, in PROCESSING order (slot 0 = the driver = the shortest list); qpos = its place in the query
@@ -41,7 +52,7 @@ __global__ void __launch_bounds__(PH_WAVES * 64) bm25_phrase_kernel(
   const uint2* prow[NT];
   const uint32_t* zrow[NT];
   const uint32_t* po[NT];   // end offsets of the postings' positions (slot index = index inside the term)
-  const uint16_t* pp[NT];   // the term's positions
+  const PT* pp[NT];         // the term's positions
   float idf[NT];
   uint32_t qpos[NT];
   unsigned long long size[NT];
@@ -154,22 +165,22 @@ __global__ void __launch_bounds__(PH_WAVES * 64) bm25_phrase_kernel(
             st[t] = idx[t] ? po[t][idx[t] - 1u] : 0u;
           }
         }
-        auto range_of = [&](uint32_t sl, uint32_t& lo, uint32_t& hi, const uint16_t*& base) {
+        auto range_of = [&](uint32_t sl, uint32_t& lo, uint32_t& hi, const PT*& base) {
           lo = st[0]; hi = en[0]; base = pp[0];
 #pragma unroll
           for (int t = 1; t < NT; t++)
             if (sl == (uint32_t)t) { lo = st[t]; hi = en[t]; base = pp[t]; }
         };
         uint32_t lo0, hi0;
-        const uint16_t* b0p;
+        const PT* b0p;
         range_of(wslot(0u), lo0, hi0, b0p);
         bool match = false;
         for (uint32_t j = lo0; j < hi0 && !match; j++) {
           const uint32_t start = b0p[j];
-          bool ok = true;
+          bool ok = !MF || ((fmask >> (start >> BM_POS_FIELD_SHIFT)) & 1u);  // the field the phrase would stand in is listed
           for (uint32_t i = 1; i < plen && ok; i++) {
             uint32_t lo, hi;
-            const uint16_t* bp;
+            const PT* bp;
             range_of(wslot(i), lo, hi, bp);
             const uint32_t end = hi, target = start + i;
             while (lo < hi) {  // first position >= target (the list is ascending)
@@ -200,23 +211,27 @@ __global__ void __launch_bounds__(PH_WAVES * 64) bm25_phrase_kernel(
   if (lane == 0 && T.matched) atomicAdd(&total[qi], T.matched);
 }
 
-template <int NT, int KPL>
-static int launch_phrase(const BmParams& p, const uint2* probe, const uint32_t* probe_z, const uint32_t* probe_row, const uint16_t* pos,
+template <int NT, int KPL, typename PT>
+static int launch_phrase(const BmParams& p, const uint2* probe, const uint32_t* probe_z, const uint32_t* probe_row, const PT* pos,
                          const uint32_t* pos_off, const unsigned long long* pos_base, hipStream_t st) {
   const uint32_t A = p.nq * p.P;
-  bm25_phrase_kernel<NT, KPL><<<(A + PH_WAVES - 1) / PH_WAVES, PH_WAVES * 64, 0, st>>>(
+  bm25_phrase_kernel<NT, KPL, PT><<<(A + PH_WAVES - 1) / PH_WAVES, PH_WAVES * 64, 0, st>>>(
       p.post, p.term_base, p.sub_off, probe, probe_z, probe_row, pos, pos_off, pos_base, p.q, p.part_keys, p.total, p.tau, p.del,
       p.del_words, p.n_sub, p.n_terms, p.nq, p.P, p.k, p.count);
   return SS_OK;
 }
 
-int ssi_bm25_launch_phrase(const BmParams& p, const uint2* probe, const uint32_t* probe_z, const uint32_t* probe_row, const uint16_t* pos,
-                           const uint32_t* pos_off, const unsigned long long* pos_base, uint32_t nt_max, int KPL, hipStream_t st) {
-  if (!probe || !probe_z || !probe_row || !pos || !pos_off || !pos_base) return SS_ESTATE;
+// pos16: one indexed field; pos32: the merged lists of an image with several (exactly one of the two is given)
+int ssi_bm25_launch_phrase(const BmParams& p, const uint2* probe, const uint32_t* probe_z, const uint32_t* probe_row, const uint16_t* pos16,
+                           const uint32_t* pos32, const uint32_t* pos_off, const unsigned long long* pos_base, uint32_t nt_max, int KPL,
+                           hipStream_t st) {
+  if (!probe || !probe_z || !probe_row || (!pos16 == !pos32) || !pos_off || !pos_base) return SS_ESTATE;
   if (nt_max == 0 || nt_max > 6 || (KPL != 1 && KPL != 2)) return SS_ENOTSUP;
   const int NT = nt_max <= 2 ? 2 : nt_max <= 4 ? (int)nt_max : 6;
-#define SS_PH(NT_, KPL_) \
-  if (NT == NT_ && KPL == KPL_) return launch_phrase<NT_, KPL_>(p, probe, probe_z, probe_row, pos, pos_off, pos_base, st);
+#define SS_PH(NT_, KPL_)                                                                                             \
+  if (NT == NT_ && KPL == KPL_)                                                                                      \
+    return pos16 ? launch_phrase<NT_, KPL_, uint16_t>(p, probe, probe_z, probe_row, pos16, pos_off, pos_base, st)    \
+                 : launch_phrase<NT_, KPL_, uint32_t>(p, probe, probe_z, probe_row, pos32, pos_off, pos_base, st);
   SS_PH(2, 1) SS_PH(3, 1) SS_PH(4, 1) SS_PH(6, 1) SS_PH(2, 2) SS_PH(3, 2) SS_PH(4, 2) SS_PH(6, 2)
 #undef SS_PH
   return SS_ENOTSUP;

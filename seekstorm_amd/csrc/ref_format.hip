@@ -268,7 +268,8 @@ bool read_field_vec(const uint8_t* a, uint64_t len, uint64_t pos, uint32_t id_bi
   return true;
 }
 int decode_block_fields(const ss_ref_block* b, uint32_t n_fields, uint32_t longest_field_id, uint32_t n_components, uint32_t component,
-                        uint16_t* docs_out, uint32_t* first_out, uint8_t* field_out, uint16_t* tf_out);
+                        uint16_t* docs_out, uint32_t* first_out, uint8_t* field_out, uint16_t* tf_out,
+                        std::vector<uint16_t>* pos_out = nullptr);
 }  // namespace
 
 // Decodes one block of a multi-field index: docs_out [65536], first_out [65537] = CSR of the field entries per posting,
@@ -276,6 +277,20 @@ int decode_block_fields(const ss_ref_block* b, uint32_t n_fields, uint32_t longe
 extern "C" int ss_ref_decode_block_fields(const ss_ref_block* b, uint32_t n_fields, uint32_t longest_field_id, uint16_t* docs_out,
                                           uint32_t* first_out, uint8_t* field_out, uint16_t* tf_out) {
   return decode_block_fields(b, n_fields, longest_field_id, 1, 0, docs_out, first_out, field_out, tf_out);
+}
+// ... with the positions of every (posting, field) entry in entry order (sum of tf_out values; SingleTerm keys): what the phrase
+// check of add_result_multiterm_multifield reads through get_next_position_multifield.  Returns the posting count.
+extern "C" int ss_ref_decode_block_fields_positions(const ss_ref_block* b, uint32_t n_fields, uint32_t longest_field_id, uint16_t* docs_out,
+                                                    uint32_t* first_out, uint8_t* field_out, uint16_t* tf_out, uint16_t* pos_out,
+                                                    uint64_t pos_cap, uint64_t* n_pos_out) {
+  if (!n_pos_out || (pos_cap && !pos_out)) return SS_EINVAL;
+  std::vector<uint16_t> pos;
+  const int n = decode_block_fields(b, n_fields, longest_field_id, 1, 0, docs_out, first_out, field_out, tf_out, &pos);
+  if (n < 0) return n;
+  *n_pos_out = pos.size();
+  if (pos.size() > pos_cap) return SS_EINVAL;
+  if (!pos.empty()) std::memcpy(pos_out, pos.data(), pos.size() * sizeof(uint16_t));
+  return n;
 }
 // The same for a block of an N-GRAM key of a multi-field index: never embedded, and every record starts with the field
 // vector of each component term -- 2 for the bigram types, 3 for the trigram types -- before the n-gram's own
@@ -290,7 +305,8 @@ extern "C" int ss_ref_decode_block_fields_ngram(const ss_ref_block* b, uint32_t 
 }
 namespace {
 int decode_block_fields(const ss_ref_block* b, uint32_t n_fields, uint32_t longest_field_id, uint32_t n_components, uint32_t component,
-                        uint16_t* docs_out, uint32_t* first_out, uint8_t* field_out, uint16_t* tf_out) {
+                        uint16_t* docs_out, uint32_t* first_out, uint8_t* field_out, uint16_t* tf_out, std::vector<uint16_t>* pos_out) {
+  if (pos_out && n_components > 1) return SS_ENOTSUP;  // an n-gram key's positions are the n-gram's, not its components'
   if (!b || !b->byte_array || !docs_out || !first_out || !field_out || !tf_out || n_fields < 2 || n_fields > 8 ||
       longest_field_id >= n_fields) return SS_EINVAL;
   const bool ngram = n_components > 1;
@@ -346,6 +362,7 @@ int decode_block_fields(const ss_ref_block* b, uint32_t n_fields, uint32_t longe
     first_out[r] = w;
     FieldEntry e[8];
     int ne = 0;
+    uint32_t emb_bits = 0;  // embedded pointer: bits that hold the positions
     const bool two = r < pivot;
     const uint64_t at = two ? range + (uint64_t)r * 2u : range + (uint64_t)r * 3u - pivot;
     if (at + (two ? 2u : 3u) > len) return SS_EINVAL;
@@ -357,37 +374,71 @@ int decode_block_fields(const ss_ref_block* b, uint32_t n_fields, uint32_t longe
       for (uint32_t c = 0; c <= (ngram ? component : 0u); c++) {  // n-gram keys: the components' vectors come first
         if (!read_field_vec(a, len, at_rec, id_bits, longest_field_id, e, &ne, &at_rec)) return SS_EINVAL;
       }
+      if (pos_out) {  // the positions follow the field vector: per field its tf VINTs, the first absolute, then "gap - 1"
+        for (int i = 0; i < ne; i++) {  // (get_next_position_multifield restarts at every field, add_result.rs:3279-3283)
+          uint32_t at_pos = 0, v;
+          for (uint32_t x = 0; x < e[i].tf; x++) {
+            if (!read_vint(a, len, at_rec, &v)) return SS_EINVAL;
+            at_rec += a[at_rec] & 0x80u ? 1u : (a[at_rec + 1] & 0x80u ? 2u : 3u);
+            at_pos = x == 0 ? v : at_pos + v + 1u;
+            if (at_pos > 65535u) return SS_ENOTSUP;
+            pos_out->push_back((uint16_t)at_pos);
+          }
+        }
+      }
     } else if (ngram) {
       return SS_EINVAL;  // n-gram postings are never embedded (index_posting.rs:445)
     } else if (two) {  // embedded, 2 bytes: tag = bits 15..12 (add_result.rs:1606-1737)
       const uint32_t tag = p >> 12, pb = 12u - id_bits;
       switch (tag) {
-        case 0xC: case 0xD: e[0] = {(uint8_t)longest_field_id, 1}; ne = 1; break;
-        case 0xE: case 0xF: e[0] = {(uint8_t)longest_field_id, 2}; ne = 1; break;
-        case 0x8: case 0x9: case 0xA: e[0] = {(uint8_t)((p >> pb) & id_mask), tag - 7u}; ne = 1; break;
+        case 0xC: case 0xD: e[0] = {(uint8_t)longest_field_id, 1}; ne = 1; emb_bits = 13u; break;
+        case 0xE: case 0xF: e[0] = {(uint8_t)longest_field_id, 2}; ne = 1; emb_bits = 13u; break;
+        case 0x8: case 0x9: case 0xA: e[0] = {(uint8_t)((p >> pb) & id_mask), tag - 7u}; ne = 1; emb_bits = pb; break;
         case 0xB: {
           const uint32_t pb2 = 12u - 2u * id_bits;
           e[0] = {(uint8_t)((p >> (pb2 + id_bits)) & id_mask), 1};
           e[1] = {(uint8_t)((p >> pb2) & id_mask), 1};
           ne = 2;
+          emb_bits = pb2;
           break;
         }
         default: return SS_EINVAL;
       }
     } else {  // embedded, 3 bytes: tag = bits 23..19 (add_result.rs:1738-2017)
       const uint32_t tag = p >> 19, pb = 19u - id_bits, pb2 = 19u - 2u * id_bits, pb3 = 19u - 3u * id_bits;
-      if (tag >= 0x18u) { e[0] = {(uint8_t)longest_field_id, ((tag - 0x18u) >> 1) + 1u}; ne = 1; }
-      else if (tag >= 0x10u && tag <= 0x13u) { e[0] = {(uint8_t)((p >> pb) & id_mask), tag - 0x0Fu}; ne = 1; }
+      if (tag >= 0x18u) { e[0] = {(uint8_t)longest_field_id, ((tag - 0x18u) >> 1) + 1u}; ne = 1; emb_bits = 20u; }
+      else if (tag >= 0x10u && tag <= 0x13u) { e[0] = {(uint8_t)((p >> pb) & id_mask), tag - 0x0Fu}; ne = 1; emb_bits = pb; }
       else if (tag >= 0x14u && tag <= 0x16u) {
         e[0] = {(uint8_t)((p >> (pb2 + id_bits)) & id_mask), tag == 0x16u ? 2u : 1u};
         e[1] = {(uint8_t)((p >> pb2) & id_mask), tag == 0x15u ? 2u : 1u};
         ne = 2;
+        emb_bits = pb2;
       } else if (tag == 0x17u) {
         e[0] = {(uint8_t)((p >> (pb3 + 2u * id_bits)) & id_mask), 1};
         e[1] = {(uint8_t)((p >> (pb3 + id_bits)) & id_mask), 1};
         e[2] = {(uint8_t)((p >> pb3) & id_mask), 1};
         ne = 3;
+        emb_bits = pb3;
       } else return SS_EINVAL;
+    }
+    if (pos_out && emb_bits) {
+      // the embedded positions: the low emb_bits bits of the pointer hold all positions of the posting, field after field, as
+      // "first absolute, then gap - 1" per field; the bits are dealt out front to back, position i of n getting
+      // floor(bits left / (n - i)) -- every arm of add_result.rs:1617-2012 is an instance of that rule (13 -> 6 + 7,
+      // 20 -> 10 + 10 / 6 + 7 + 7 / 5 + 5 + 5 + 5, position_bits -> /2, /3, /4 ...; writer index_posting.rs:592-660)
+      uint32_t n_pos = 0, left = emb_bits, taken = 0;
+      for (int i = 0; i < ne; i++) n_pos += e[i].tf;
+      for (int i = 0; i < ne; i++) {
+        uint32_t at_pos = 0;
+        for (uint32_t x = 0; x < e[i].tf; x++, taken++) {
+          const uint32_t wbits = left / (n_pos - taken);
+          left -= wbits;
+          const uint32_t v = (p >> left) & ((1u << wbits) - 1u);
+          at_pos = x == 0 ? v : at_pos + v + 1u;
+          if (at_pos > 65535u) return SS_ENOTSUP;
+          pos_out->push_back((uint16_t)at_pos);
+        }
+      }
     }
     for (int i = 0; i < ne; i++) {
       if (e[i].field >= n_fields || e[i].tf == 0 || e[i].tf > 65535u) return SS_EINVAL;
@@ -685,8 +736,9 @@ extern "C" int ss_index_bin_term_postings(const ss_index_bin* ix, uint32_t term,
 
 namespace {
 // multi-field index: (doc, field, tf) entries of every term, doclen rearranged to [field][doc]
-int upload_index_bin_fields(ss_shard* s, const ss_index_bin* ix, const float* boost) {
+int upload_index_bin_fields(ss_shard* s, const ss_index_bin* ix, const float* boost, bool with_positions) {
   const uint32_t F = ix->n_fields;
+  std::vector<uint16_t> pos;
   std::vector<uint64_t> offs(ix->keys.size() + 1, 0);
   std::vector<uint32_t> docs;
   std::vector<uint8_t> fields;
@@ -699,7 +751,7 @@ int upload_index_bin_fields(ss_shard* s, const ss_index_bin* ix, const float* bo
     for (uint64_t bi = ix->term_block_off[t]; bi < ix->term_block_off[t + 1]; bi++) {
       const ss_ref_block& b = ix->blocks[bi].b;
       const int n = decode_block_fields(&b, F, ix->longest_field_id, ix->blocks[bi].n_comp, ix->blocks[bi].comp, d16.data(), first.data(),
-                                        f8.data(), t16.data());
+                                        f8.data(), t16.data(), with_positions ? &pos : nullptr);  // (n-gram keys: SS_ENOTSUP with positions)
       if (n < 0) return n;
       for (int i = 0; i < n; i++) {
         const uint64_t doc = ((uint64_t)b.block_id << 16) | d16[i];
@@ -721,6 +773,9 @@ int upload_index_bin_fields(ss_shard* s, const ss_index_bin* ix, const float* bo
       std::memcpy(doclen.data() + (size_t)f * ix->n_docs + d0, ix->doclen[l] + (size_t)f * 65536u,
                   (size_t)std::min<uint64_t>(65536u, ix->n_docs - d0));
     }
+  if (with_positions)
+    return ssi_bm25_upload_fields_positions(s, ix->n_docs, F, doclen.data(), boost, (uint32_t)ix->keys.size(), offs.data(), docs.data(),
+                                            fields.data(), tfs.data(), ix->positions_sum, pos.data(), pos.size());
   return ssi_bm25_upload_fields(s, ix->n_docs, F, doclen.data(), boost, (uint32_t)ix->keys.size(), offs.data(), docs.data(),
                                 fields.data(), tfs.data(), ix->positions_sum);
 }
@@ -731,7 +786,7 @@ extern "C" int ss_bm25_upload_index_bin_fields(ss_shard* s, const ss_index_bin* 
   if (ix->keys.empty() || ix->n_docs == 0) return SS_EINVAL;
   if (ix->n_fields < 2) return ss_bm25_upload_index_bin(s, ix);
   if (ix->n_fields > 8) return SS_ENOTSUP;
-  return upload_index_bin_fields(s, ix, boost);
+  return upload_index_bin_fields(s, ix, boost, false);
 }
 
 namespace {
@@ -743,13 +798,21 @@ extern "C" int ss_bm25_upload_index_bin(ss_shard* s, const ss_index_bin* ix) {
   if (ix->n_fields > 1) return ss_bm25_upload_index_bin_fields(s, ix, nullptr);
   return upload_index_bin_single(s, ix, false);
 }
-// The image plus the positions of every posting, for phrase queries: one indexed field, SingleTerm keys only (SS_ENOTSUP for
-// an index with n-gram keys or a position beyond 65 535)
+// The image plus the positions of every posting, for phrase queries: SingleTerm keys only (SS_ENOTSUP for an index with n-gram
+// keys or a position beyond 65 535).  Several indexed fields: boost = 1 (ss_bm25_upload_index_bin_fields_positions takes boosts).
 extern "C" int ss_bm25_upload_index_bin_positions(ss_shard* s, const ss_index_bin* ix) {
   if (!s || !ix) return SS_EINVAL;
   if (ix->keys.empty() || ix->n_docs == 0) return SS_EINVAL;
-  if (ix->n_fields > 1) return SS_ENOTSUP;
+  if (ix->n_fields > 8) return SS_ENOTSUP;
+  if (ix->n_fields > 1) return upload_index_bin_fields(s, ix, nullptr, true);
   return upload_index_bin_single(s, ix, true);
+}
+extern "C" int ss_bm25_upload_index_bin_fields_positions(ss_shard* s, const ss_index_bin* ix, const float* boost) {
+  if (!s || !ix) return SS_EINVAL;
+  if (ix->keys.empty() || ix->n_docs == 0) return SS_EINVAL;
+  if (ix->n_fields < 2) return ss_bm25_upload_index_bin_positions(s, ix);
+  if (ix->n_fields > 8) return SS_ENOTSUP;
+  return upload_index_bin_fields(s, ix, boost, true);
 }
 namespace {
 int upload_index_bin_single(ss_shard* s, const ss_index_bin* ix, bool with_positions) {

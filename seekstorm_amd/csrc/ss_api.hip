@@ -117,13 +117,13 @@ static void free_vec(ss_shard* s) {
   ssi_vec_free_clusters(s);
 }
 static void free_bm25(ss_shard* s) {
-  void* ptrs[] = {s->d_post, s->d_term_base, s->d_sub_off, s->d_comp, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_umax, s->d_submax, s->d_boost, s->d_pos, s->d_pos_off, s->d_pos_base,
+  void* ptrs[] = {s->d_post, s->d_term_base, s->d_sub_off, s->d_comp, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_umax, s->d_submax, s->d_boost, s->d_pos, s->d_pos32, s->d_pos_off, s->d_pos_base,
                   s->d_doclen, s->d_sp_base, s->d_sp_post};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   s->d_doclen = nullptr; s->d_sp_base = nullptr; s->d_sp_post = nullptr; s->sp_n = 0; s->h_sp_base.clear();
   s->d_post = nullptr; s->d_term_base = nullptr; s->d_sub_off = nullptr; s->d_comp = nullptr;
   s->probe_pool_begin = 0; s->probe_pool_rows = 0; s->pool_list.clear(); s->pool_tick.clear();
-  s->d_probe = nullptr; s->d_probe_z = nullptr; s->d_probe_row = nullptr; s->h_probe_row.clear(); s->bm_probe_rows = 0; s->d_umax = nullptr; s->d_submax = nullptr; s->d_pos = nullptr; s->d_pos_off = nullptr; s->d_pos_base = nullptr;
+  s->d_probe = nullptr; s->d_probe_z = nullptr; s->d_probe_row = nullptr; s->h_probe_row.clear(); s->bm_probe_rows = 0; s->d_umax = nullptr; s->d_submax = nullptr; s->d_pos = nullptr; s->d_pos32 = nullptr; s->d_pos_off = nullptr; s->d_pos_base = nullptr;
   s->bm_n_docs = 0; s->bm_n_terms = 0; s->bm_n_sub = 0; s->bm_n_post = 0; s->bm_n_fields = 1; s->bm_merged = false; s->d_boost = nullptr;
   s->h_df.clear(); s->h_df_real.clear(); s->bm_n_post_pad = 0; s->bm_partmax = false;
 }
@@ -244,7 +244,32 @@ int ss_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, const
   return ssi_bm25_upload_fields(s, n_docs, n_fields, doclen, boost, n_terms, offs, docs, fields, tfs, 0);
 }
 
+// ... plus the positions of every (term, doc, field) entry: phrase queries over several indexed fields
+int ss_bm25_upload_fields_positions(ss_shard* s, uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost,
+                                    uint32_t n_terms, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
+                                    const uint16_t* tfs, const uint16_t* positions, uint64_t n_positions) {
+  if (!offs || n_terms == 0) return SS_EINVAL;
+  if (offs[n_terms] && !tfs) return SS_EINVAL;
+  uint64_t need = 0;  // checked before anything is built or read, as in ss_bm25_upload_positions
+  for (uint64_t j = offs[0]; j < offs[n_terms]; j++) need += tfs[j];
+  if (need != n_positions || (need && !positions)) return SS_EINVAL;
+  return ssi_bm25_upload_fields_positions(s, n_docs, n_fields, doclen, boost, n_terms, offs, docs, fields, tfs, 0, positions, n_positions);
+}
+
 }  // extern "C"
+
+int ssi_bm25_upload_fields_positions(ss_shard* s, uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost,
+                                     uint32_t n_terms, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
+                                     const uint16_t* tfs, uint64_t positions_sum, const uint16_t* positions, uint64_t n_positions) {
+  if (n_fields < 2) return SS_EINVAL;  // one indexed field: ss_bm25_upload_positions
+  int rc = ssi_bm25_upload_fields(s, n_docs, n_fields, doclen, boost, n_terms, offs, docs, fields, tfs, positions_sum);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  rc = ssi_bm25_upload_positions_fields(s, n_terms, offs, docs, fields, tfs, positions, n_positions);
+  if (rc) free_bm25(s);  // a failure leaves no image behind
+  return rc;
+}
 
 int ssi_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost,
                            uint32_t n_terms, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
@@ -511,8 +536,11 @@ static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q,
         used |= 1u << q[i].phrase_seq[j];
       }
       if (used != (1u << q[i].n_terms) - 1u) return SS_EINVAL;  // every unique term is a word of the phrase
-      if (n_not || s->bm_n_fields > 1 || q[i].n_terms > 6 || bm_q_field_filter(q[i].op)) return SS_ENOTSUP;
-      if (!s->d_pos) return SS_ESTATE;  // the image carries no positions (ss_bm25_upload_positions)
+      if (n_not || q[i].n_terms > 6) return SS_ENOTSUP;
+      // several indexed fields: over the merged lists and their field-tagged positions (a corpus whose boosts kept the merged
+      // lists from being built has no phrase path)
+      if (s->bm_n_fields > 1 && !s->bm_merged) return SS_ENOTSUP;
+      if (s->bm_n_fields > 1 ? !s->d_pos32 : !s->d_pos) return SS_ESTATE;  // the image carries no positions (ss_bm25_upload[_fields]_positions)
       n_phrase++;
     }
     // field_filter: bits of indexed fields; an image with one indexed field has nothing to filter (the reference's set then
@@ -524,8 +552,8 @@ static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q,
       if (q[i].n_terms > 7 || !gated) return SS_ENOTSUP;
       some_gated = true;
     }
-    some_filter |= filt != 0u;
-    const bool use_merged = s->bm_merged && !filt;                    // this query reads the merged lists: one list per term
+    some_filter |= filt != 0u && op != SS_OP_PHRASE;  // (a phrase's filter is a test on its positions: no (term, field) lists)
+    const bool use_merged = s->bm_merged && (!filt || op == SS_OP_PHRASE);  // this query reads the merged lists: one list per term
     const uint32_t eff_fields = use_merged ? 1u : RF, f_begin = use_merged ? L - 1u : 0u, f_end = use_merged ? L : RF;
     // all_terms_frequent: an intersection of 2..7 terms over one indexed field (the mark takes bit 7 of the match byte);
     // on anything else the reference's flag has no effect we model (single terms, unions) or is not offered

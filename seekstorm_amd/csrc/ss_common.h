@@ -257,6 +257,8 @@ struct ss_shard {
                                    // maxima vary over the doc ids; SS_BM25_SUBMAX=1 / 0 forces it on / off)
   // positions of every posting (ss_bm25_upload_positions): only phrase queries read them
   uint16_t* d_pos = nullptr;       // the positions, posting after posting in image order
+  uint32_t* d_pos32 = nullptr;     // several indexed fields (ss_bm25_upload_fields_positions): the positions of the MERGED lists' postings,
+                                   // field << BM_POS_FIELD_SHIFT | position inside the field, ascending (fields ascending inside a posting)
   uint32_t* d_pos_off = nullptr;   // [bm_n_post_pad + 1] first position of the posting at that (padded) image index, relative to its term's
                                    // base; the posting's count is the distance to the next entry (padding slots repeat their successor)
   uint64_t* d_pos_base = nullptr;  // [n_terms + 1] first position of every term in d_pos
@@ -355,8 +357,9 @@ struct bm_vquery {
   float idf[BM_MAX_VTERMS];
   uint8_t and_val[BM_MAX_VTERMS];
   uint8_t group[BM_MAX_VTERMS];  // query term of each virtual term (the virtual terms of a group are contiguous)
-  uint32_t phrase_len;           // SS_OP_PHRASE: words of the phrase (one indexed field: virtual term = term), else 0
+  uint32_t phrase_len;           // SS_OP_PHRASE: words of the phrase (virtual term = the term's only / merged list), else 0
   uint8_t phrase_seq[SS_MAX_PHRASE];
+  uint32_t phrase_fields;        // several indexed fields: the fields the phrase may stand in (bit f; the query's field filter or all ones)
 };
 __host__ __device__ inline uint32_t bm_q_op(uint32_t op) { return op & 0xFFu; }
 __host__ __device__ inline uint32_t bm_q_nnot(uint32_t op) { return (op >> 8) & 0xFFu; }
@@ -366,6 +369,9 @@ __host__ __device__ inline bool bm_q_all_frequent(uint32_t op) { return (op >> 3
 // all_terms_frequent shortcut -- a posting with tf < 10 sets bit 7 of its doc's match byte, which keeps the doc counted
 // but out of the ranking (add_result.rs:2091-2104, 3541-3556)
 constexpr uint32_t BM_AND_FREQ = 0x100u;
+// positions of a multi-field image: field id above the position inside the field (positions < 65 536, phrases <= SS_MAX_PHRASE words:
+// start + word index never reaches bit 20)
+constexpr uint32_t BM_POS_FIELD_SHIFT = 20u;
 // A UNION under a field filter (add_result.rs:3124-3136 applied inside union_docid_3's sub-queries, union.rs:1330-1425: a doc ends
 // with the sum over its terms that occur in a LISTED field, all fields of those terms counted; a doc none of whose terms passes is
 // no result).  BM_AND_GATED in and_target / a term's av: the lists of a term come listed fields first (their postings add and set
@@ -392,8 +398,13 @@ int ssi_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen, uint32_
                     const uint32_t* docs, const uint16_t* tfs, uint64_t positions_sum);
 int ssi_bm25_attach_positions(ss_shard* s, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs, const uint16_t* positions,
                               uint64_t n_positions);
+int ssi_bm25_upload_positions_fields(ss_shard* s, uint32_t n_terms, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
+                                     const uint16_t* tfs, const uint16_t* positions, uint64_t n_positions);
 int ssi_bm25_upload_positions(ss_shard* s, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs, const uint16_t* positions,
                               uint64_t n_positions);
+int ssi_bm25_upload_fields_positions(ss_shard* s, uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost,
+                                     uint32_t n_terms, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
+                                     const uint16_t* tfs, uint64_t positions_sum, const uint16_t* positions, uint64_t n_positions);
 int ssi_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost,
                            uint32_t n_terms, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
                            const uint16_t* tfs, uint64_t positions_sum);

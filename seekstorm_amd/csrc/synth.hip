@@ -403,6 +403,59 @@ int ssi_bm25_upload_positions(ss_shard* s, const uint64_t* offs, const uint32_t*
   return SS_OK;
 }
 
+// Several indexed fields, after ssi_bm25_upload_fields of the same entries (term, doc, field, tf sorted by (doc, field) inside a
+// term): the positions of the MERGED lists' postings.  A merged posting (term, doc) owns the positions of all the doc's entries
+// of that term, fields ascending -- exactly the order of the caller's array -- each tagged with its field above bit 20, so the
+// pool is the caller's array with tags, d_pos_off / d_pos_base as for one field but indexed by the merged list's image slots.
+int ssi_bm25_upload_positions_fields(ss_shard* s, uint32_t n_terms, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
+                                     const uint16_t* tfs, const uint16_t* positions, uint64_t n_positions) {
+  if (!s->bm_merged) return SS_ENOTSUP;  // boosts too far apart for merged lists: no phrase path over this corpus
+  const uint32_t L = s->bm_n_fields, nv = s->bm_n_terms, ns = s->bm_n_sub;
+  if ((uint64_t)n_terms * L != nv) return SS_EINVAL;
+  std::vector<u64> tbase((size_t)nv + 1), pbase((size_t)nv + 1, 0);
+  SS_HIP(hipMemcpy(tbase.data(), s->d_term_base, tbase.size() * sizeof(u64), hipMemcpyDeviceToHost));
+  std::vector<uint32_t> poff((size_t)s->bm_n_post_pad + 1, 0u);
+  std::vector<uint32_t> pool(n_positions ? n_positions : 1);
+  u64 total = 0;
+  for (uint32_t t = 0; t < n_terms; t++) {
+    const uint32_t v = t * L + (L - 1u);  // the term's merged list
+    for (uint32_t f = 0; f < L; f++) pbase[(size_t)t * L + f] = total;
+    u64 w = tbase[v] * 4ull, rel = 0, j = offs[t];
+    for (uint32_t sb = 0; sb < ns; sb++) {
+      const u64 lim = ((u64)sb + 1) << BM_SUB_LOG2;
+      u64 n = 0;
+      while (j < offs[t + 1] && docs[j] < lim) {
+        const uint32_t d = docs[j];
+        for (; j < offs[t + 1] && docs[j] == d; j++) {  // the doc's entries, fields ascending
+          if (total + rel + tfs[j] > n_positions) return SS_EINVAL;
+          for (uint32_t x = 0; x < tfs[j]; x++) {
+            const u64 at = total + rel + x;
+            if (x && positions[at] <= positions[at - 1]) return SS_EINVAL;  // ascending inside a field
+            pool[at] = ((uint32_t)fields[j] << BM_POS_FIELD_SHIFT) | positions[at];
+          }
+          rel += tfs[j];
+        }
+        if (rel >= (1ull << 32)) return SS_ENOTSUP;
+        if (w >= s->bm_n_post_pad) return SS_EINVAL;
+        poff[w++] = (uint32_t)rel;
+        n++;
+      }
+      for (u64 pad = (4 - (n & 3)) & 3; pad > 0; pad--) poff[w++] = (uint32_t)rel;
+    }
+    if (w != tbase[v + 1] * 4ull) return SS_EINVAL;  // the walk must land on the merged list's end: same entries as the image's
+    total += rel;
+  }
+  pbase[nv] = total;
+  if (total != n_positions) return SS_EINVAL;
+  SS_HIP(hipMalloc(&s->d_pos32, pool.size() * sizeof(uint32_t)));
+  SS_HIP(hipMalloc(&s->d_pos_off, poff.size() * sizeof(uint32_t)));
+  SS_HIP(hipMalloc(&s->d_pos_base, pbase.size() * sizeof(u64)));
+  SS_HIP(hipMemcpy(s->d_pos32, pool.data(), pool.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  SS_HIP(hipMemcpy(s->d_pos_off, poff.data(), poff.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  SS_HIP(hipMemcpy(s->d_pos_base, pbase.data(), pbase.size() * sizeof(u64), hipMemcpyHostToDevice));
+  return SS_OK;
+}
+
 // ---------------------------------------------------------------- BM25 synthetic image, generated on device
 __global__ void lex_doclen_kernel(uint8_t* __restrict__ doclen, u64 seed, u64 n_docs, const uint8_t* __restrict__ tab,
                                   u64* __restrict__ psum, u64 gs, u64 go) {

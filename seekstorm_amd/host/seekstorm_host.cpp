@@ -127,10 +127,12 @@ int Shard::upload_lexical(uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t
 
 int Shard::upload_lexical_fields(uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen_bytes, const float* boost, uint32_t n_terms,
                                  const uint64_t* term_offsets, const uint32_t* doc_ids, const uint8_t* field_ids,
-                                 const uint16_t* tfs) {
+                                 const uint16_t* tfs, const uint16_t* positions, uint64_t n_positions) {
   if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
   lexical_fields_ = n_fields; ngram_components_.clear(); ngram_component_df_.clear();  // a new image: no index.bin n-gram keys behind the term ids
-  const int rc = ss_bm25_upload_fields(h_, n_docs, n_fields, doclen_bytes, boost, n_terms, term_offsets, doc_ids, field_ids, tfs);
+  const int rc = positions ? ss_bm25_upload_fields_positions(h_, n_docs, n_fields, doclen_bytes, boost, n_terms, term_offsets, doc_ids,
+                                                             field_ids, tfs, positions, n_positions)
+                           : ss_bm25_upload_fields(h_, n_docs, n_fields, doclen_bytes, boost, n_terms, term_offsets, doc_ids, field_ids, tfs);
   n_docs_ = rc == SS_OK ? n_docs : 0;
   return rc;
 }

@@ -120,8 +120,10 @@ class Shard {
   int upload_lexical(uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t n_terms, const uint64_t* term_offsets,
                      const uint32_t* doc_ids, const uint16_t* tfs, const uint16_t* positions = nullptr, uint64_t n_positions = 0);
   // several indexed fields (BM25F): doclen [n_fields][n_docs], postings (doc, field, tf) sorted by (doc, field) per term
+  // positions (optional): every (term, doc, field) entry's tf positions inside the field -- phrase queries over several fields
   int upload_lexical_fields(uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen_bytes, const float* boost, uint32_t n_terms,
-                            const uint64_t* term_offsets, const uint32_t* doc_ids, const uint8_t* field_ids, const uint16_t* tfs);
+                            const uint64_t* term_offsets, const uint32_t* doc_ids, const uint8_t* field_ids, const uint16_t* tfs,
+                            const uint16_t* positions = nullptr, uint64_t n_positions = 0);
   // VectorSimilarity of the image (index-wide in the reference): Dot / Cosine (default) or Euclidean; BEFORE the upload
   int set_vector_similarity(bool euclidean);
   int upload_vectors(uint64_t n_rows, uint32_t dim, const float* rows, const uint32_t* row_doc_ids);

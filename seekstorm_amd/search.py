@@ -322,17 +322,25 @@ class Shard:
         self.lexical_field_count = 1
         self._df_cache.clear()
 
-    def upload_lexical_fields(self, n_docs, doclen_bytes_fields, boost, term_offsets, doc_ids, field_ids, tfs):
-        """several indexed fields (BM25F): doclen [n_fields][n_docs], postings (doc, field, tf) sorted by (doc, field) per term"""
+    def upload_lexical_fields(self, n_docs, doclen_bytes_fields, boost, term_offsets, doc_ids, field_ids, tfs, positions=None):
+        """several indexed fields (BM25F): doclen [n_fields][n_docs], postings (doc, field, tf) sorted by (doc, field) per term
+        positions: for every (term, doc, field) entry in that order its tf positions inside the field -- phrase queries only"""
         dl = np.ascontiguousarray(doclen_bytes_fields, np.uint8)
         b = None if boost is None else np.ascontiguousarray(boost, np.float32)
         off = np.ascontiguousarray(term_offsets, np.uint64)
         d = np.ascontiguousarray(doc_ids, np.uint32)
         f = np.ascontiguousarray(field_ids, np.uint8)
         t = np.ascontiguousarray(tfs, np.uint16)
-        N.check(N.lib().ss_bm25_upload_fields(self._h, int(n_docs), dl.shape[0], N.ptr(dl.reshape(-1), N.u8p), N.ptr(b, N.f32p),
-                                              len(off) - 1, N.ptr(off, N.u64p), N.ptr(d, N.u32p), N.ptr(f, N.u8p), N.ptr(t, N.u16p)),
-                "ss_bm25_upload_fields")
+        if positions is not None:
+            ps = np.ascontiguousarray(positions, np.uint16)
+            N.check(N.lib().ss_bm25_upload_fields_positions(self._h, int(n_docs), dl.shape[0], N.ptr(dl.reshape(-1), N.u8p),
+                                                            N.ptr(b, N.f32p), len(off) - 1, N.ptr(off, N.u64p), N.ptr(d, N.u32p),
+                                                            N.ptr(f, N.u8p), N.ptr(t, N.u16p), N.ptr(ps, N.u16p), len(ps)),
+                    "ss_bm25_upload_fields_positions")
+        else:
+            N.check(N.lib().ss_bm25_upload_fields(self._h, int(n_docs), dl.shape[0], N.ptr(dl.reshape(-1), N.u8p), N.ptr(b, N.f32p),
+                                                  len(off) - 1, N.ptr(off, N.u64p), N.ptr(d, N.u32p), N.ptr(f, N.u8p), N.ptr(t, N.u16p)),
+                    "ss_bm25_upload_fields")
         self.indexed_doc_count = int(n_docs)
         self.lexical_field_count = int(dl.shape[0])
         self._df_cache.clear()
@@ -358,10 +366,11 @@ class Shard:
 
     def upload_index_bin(self, ix: "IndexBin", boost=None, positions=False):
         """boost: schema boost per indexed field (several fields only; schema.json)
-        positions: also decode every posting's positions from the file (phrase queries; one field, SingleTerm keys)"""
+        positions: also decode every posting's positions from the file (phrase queries; SingleTerm keys)"""
         b = None if boost is None else np.ascontiguousarray(boost, np.float32)
         if positions:
-            N.check(N.lib().ss_bm25_upload_index_bin_positions(self._h, ix._h), "ss_bm25_upload_index_bin_positions")
+            N.check(N.lib().ss_bm25_upload_index_bin_fields_positions(self._h, ix._h, N.ptr(b, N.f32p)),
+                    "ss_bm25_upload_index_bin_positions")
         else:
             N.check(N.lib().ss_bm25_upload_index_bin_fields(self._h, ix._h, N.ptr(b, N.f32p)), "ss_bm25_upload_index_bin")
         self.indexed_doc_count = int(ix.indexed_doc_count)

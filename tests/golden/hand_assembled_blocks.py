@@ -141,4 +141,80 @@ H4 = dict(
     body=bytes(H4_PREFIX + H4_REC_P3 + H4_REC_P2 + H4_REC_P1 + H4_POINTERS + H4_CONTAINER),
     docs=H4_DOCS, tfs=H4_TFS, positions=[9] + [200, 202] + [4, 9, 14] + [1, 3, 5, 7] + [1] * 6)
 
+# ================================================================================================ several indexed fields
+# An index with SEVERAL indexed fields: a posting carries a field vector [(field id, positions count)] and the positions of
+# every listed field, each field's positions restarting at an absolute first value (index_posting.rs:395-441 collect them per
+# field; reader: decode_positions_multiterm_multifield add_result.rs:1485-2034, get_next_position_multifield, the phrase check
+# 3248-3386).  Three indexed fields -> indexed_field_id_bits = 2 (index.rs:2569-2570); longest_field_id = 1.
+#   embedded pointer (index_posting.rs:592-660): data = [field ids, 2 bits each, unless only the longest field occurs],
+#   then the positions, position i of n taking floor(remaining_bits / (n - i)) bits (605-619), where remaining_bits =
+#   pointer bits - (1 for a 3-byte pointer) - (3 for "only the longest field" | 4 + 2 per named field) (597-604).
+# ---------------------------------------------------------------------------------------------------------------- H5
+# 2-byte pointers (pointer_pivot_p_docid = posting count), CompressionType::Array
+#   p0 doc 5      field 1 (the longest) only, positions {3, 20}   embedded: 16 - 3 = 13 bits -> 6 + 7; stored 3 and 20 - 3 - 1 = 16
+#   p1 doc 9      field 2 only, position {100}                    embedded: 16 - (4 + 2) = 10 bits
+#   p2 doc 700    fields 0 {7} and 2 {12}                         embedded: 16 - (4 + 4) = 8 bits -> 4 + 4
+#   p3 doc 40000  fields 0 {1, 5} and 1 {0, 2, 9}                 record (5 positions: never embedded, index_posting.rs:437)
+H5_RECORD_P3 = [
+    # field vector, write_field_vec 897-925 (several fields, not only the longest): value = count << 2 | field id;
+    # entry 0: (field 0, 2 positions): 2 << 2 | 0 = 8, meta bits 1 + 2 + 2 = 5 <= 6 -> one byte | STOP; not the last entry: no field stop bit
+    8 | STOP,
+    # entry 1: (field 1, 3 positions): 3 << 2 | 1 = 13, meta bits 0 + 2 + 2 = 4 -> one byte | STOP | FIELD_STOP_BIT_2 (0x40: last entry, i > 0)
+    13 | STOP | 0x40,
+    1 | STOP, 3 | STOP,            # field 0: position 1, then 5 - 1 - 1 = 3 (compress_positions 955-957)
+    0 | STOP, 1 | STOP, 6 | STOP,  # field 1: position 0, 2 - 0 - 1 = 1, 9 - 2 - 1 = 6
+]                                  # 7 bytes
+H5_R = len(H5_RECORD_P3)
+_h5_p0 = (3 << 7) | 16                                  # 6 + 7 bits
+_h5_p1 = (2 << 10) | 100                                # field id 2, then 10 position bits
+_h5_p2 = (((0 << 2) | 2) << 8) | (7 << 4) | 12          # field ids 0, 2; 4 + 4 position bits
+H5_POINTERS = [
+    _h5_p0 & 0xFF, (_h5_p0 >> 8) | 0xC0 | (1 << 5),     # only the longest field: 0b1100_0000 | (positions - 1) << 5 (626-628)
+    _h5_p1 & 0xFF, (_h5_p1 >> 8) | 0x80 | (0 << 4),     # one named field: 0b1000_0000 | (positions - 1) << 4 (629-631)
+    _h5_p2 & 0xFF, (_h5_p2 >> 8) | 0xB0,                # two named fields: 0b1011_0000 (632-633)
+    7 & 0xFF, (7 >> 8) & 0x7F,                          # p3: running record size 7, top bit clear
+]
+H5 = dict(
+    name="H5 three indexed fields, 2-byte pointers",
+    n_fields=3, longest_field_id=1,
+    block_id=2, compression_type_pointer=(1 << 30) | H5_R, posting_count=4, pointer_pivot_p_docid=4,
+    body=bytes(H5_RECORD_P3 + H5_POINTERS + _u16(5) + _u16(9) + _u16(700) + _u16(40000)),
+    docs=[5, 9, 700, 40000],
+    entries=[[(1, [3, 20])], [(2, [100])], [(0, [7]), (2, [12])], [(0, [1, 5]), (1, [0, 2, 9])]])
+
+# ---------------------------------------------------------------------------------------------------------------- H6
+# 3-byte pointers from the first posting on (pointer_pivot_p_docid = 0: offset of pointer p = 3 p - 0), Array container
+#   p0 doc 1      field 1 (the longest) only, positions {2, 5, 9, 40}     embedded: 24 - 1 - 3 = 20 bits -> 5 + 5 + 5 + 5; stored 2, 2, 3, 30
+#   p1 doc 2      field 0 only, positions {1000, 1010}                    embedded: 24 - 1 - (4 + 2) = 17 bits -> 8 + 9 ... 1000 needs 10 bits:
+#                                                                         NOT embeddable (index_posting.rs:525-530) -> record
+#   p2 doc 3      field 0 only, positions {100, 400}                      embedded: 17 bits -> 8 + 9; stored 100, 299
+#   p3 doc 50     fields 0 {3} and 2 {4, 6}                               embedded: 24 - 1 - (4 + 4) = 15 bits -> 5 + 5 + 5; tag (1, 2)
+#   p4 doc 51     fields 0 {1}, 1 {2} and 2 {3}                           embedded: 24 - 1 - (4 + 6) = 13 bits -> 4 + 4 + 5; tag three fields
+H6_RECORD_P1 = [
+    # (field 0, 2 positions): 2 << 2 | 0 = 8; the only entry: i == 0 and last -> FIELD_STOP_BIT_1 (0x20); meta bits 1 + 2 + 2 = 5 -> one byte
+    8 | STOP | 0x20,
+    1000 >> 7, (1000 & 0x7F) | STOP,   # position 1000: two bytes (compress_positions 958-965)
+    9 | STOP,                          # 1010 - 1000 - 1
+]                                      # 4 bytes
+H6_R = len(H6_RECORD_P1)
+_h6_p0 = (2 << 15) | (2 << 10) | (3 << 5) | 30
+_h6_p2 = (0 << 17) | (100 << 9) | 299
+_h6_p3 = (((0 << 2) | 2) << 15) | (3 << 10) | (4 << 5) | 1          # field ids 0, 2; positions 3 | 4, 6 - 4 - 1 = 1
+_h6_p4 = (((((0 << 2) | 1) << 2) | 2) << 13) | (1 << 9) | (2 << 5) | 3  # field ids 0, 1, 2; 4 + 4 + 5 bits
+H6_POINTERS = [
+    _h6_p0 & 0xFF, (_h6_p0 >> 8) & 0xFF, (_h6_p0 >> 16) | 0xC0 | (3 << 4),   # only the longest field: 0b1100_0000 | (positions - 1) << 4 (641-643)
+    4 & 0xFF, (4 >> 8) & 0xFF, (4 >> 16) & 0x7F,                             # p1: running record size 4
+    _h6_p2 & 0xFF, (_h6_p2 >> 8) & 0xFF, (_h6_p2 >> 16) | 0x80 | (1 << 3),   # one named field: 0b1000_0000 | (positions - 1) << 3 (645-648)
+    _h6_p3 & 0xFF, (_h6_p3 >> 8) & 0xFF, (_h6_p3 >> 16) | 0x80 | 0x28,       # two named fields with 1 and 2 positions: 0b0010_1000 (653-654)
+    _h6_p4 & 0xFF, (_h6_p4 >> 8) & 0xFF, (_h6_p4 >> 16) | 0x80 | 0x38,       # three named fields: 0b0011_1000 (649-650)
+]
+H6 = dict(
+    name="H6 three indexed fields, 3-byte pointers",
+    n_fields=3, longest_field_id=1,
+    block_id=0, compression_type_pointer=(1 << 30) | H6_R, posting_count=5, pointer_pivot_p_docid=0,
+    body=bytes(H6_RECORD_P1 + H6_POINTERS + _u16(1) + _u16(2) + _u16(3) + _u16(50) + _u16(51)),
+    docs=[1, 2, 3, 50, 51],
+    entries=[[(1, [2, 5, 9, 40])], [(0, [1000, 1010])], [(0, [100, 400])], [(0, [3]), (2, [4, 6])], [(0, [1]), (1, [2]), (2, [3])]])
+
 BLOCKS = [H1, H2, H3, H4]
+FIELD_BLOCKS = [H5, H6]

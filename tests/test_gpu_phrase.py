@@ -146,3 +146,140 @@ def test_phrase_queries_on_an_image_built_from_index_bin(S, O):
         a.search_lexical_batch(a.make_queries([[0, 1]], S.QueryType.Phrase), 10)
     a.close()
     b.close()
+
+
+# ------------------------------------------------------------------------------------------------ several indexed fields
+def _corpus_fields(O, n_docs, n_fields, dfs, seed, plant, cross):
+    """(term, doc, field) entries with positions.  plant = [(words, field, n docs)]: the phrase written into that field;
+    cross = [(word a, word b, n docs)]: a at the LAST position of field 0 and b at position 0 of field 1, and a at p in field 0 with
+    b at p + 1 in field 2 -- consecutive numbers in different fields, which are no phrase"""
+    rng = np.random.default_rng(seed)
+    dl = np.stack([O.lex_doclen(n_docs, seed=O.LEX_SEED + 7 * f) for f in range(n_fields)])
+    pos_of = [dict() for _ in dfs]  # term -> (doc, field) -> set of positions
+    for t, df in enumerate(dfs):
+        for d in rng.choice(n_docs, df, replace=False):
+            k = int(rng.integers(1, n_fields + 1)) if rng.random() < 0.4 else 1
+            for f in rng.choice(n_fields, size=k, replace=False):
+                tf = int(min(rng.geometric(0.5), 12))
+                pos_of[t][(int(d), int(f))] = set(int(x) for x in rng.choice(60, tf, replace=False))
+    for words, f, nd in plant:
+        for d in rng.choice(n_docs, nd, replace=False):
+            st = int(rng.integers(0, 50))
+            for i, t in enumerate(words):
+                pos_of[t].setdefault((int(d), f), set()).add(st + i)
+    for a, b, nd in cross:
+        for d in rng.choice(n_docs, nd, replace=False):
+            pos_of[a].setdefault((int(d), 0), set()).add(65535)
+            pos_of[b].setdefault((int(d), 1), set()).add(0)
+            pos_of[a].setdefault((int(d), 0), set()).add(200)
+            pos_of[b].setdefault((int(d), 2), set()).add(201)
+    offs, docs, fields, tfs, positions = [0], [], [], [], []
+    for t in range(len(dfs)):
+        for (d, f) in sorted(pos_of[t]):
+            ps = sorted(pos_of[t][(d, f)])
+            docs.append(d); fields.append(f); tfs.append(len(ps)); positions += ps
+        offs.append(len(docs))
+    return (dl, np.asarray(offs, np.uint64), np.asarray(docs, np.uint32), np.asarray(fields, np.uint8), np.asarray(tfs, np.uint16),
+            np.asarray(positions, np.uint16))
+
+
+def test_phrase_queries_over_several_indexed_fields(S, O):
+    """add_result_multiterm_multifield's phrase check (add_result.rs:3248-3386): the phrase must stand inside ONE field, fields in
+    ascending order, only listed fields under a field filter; score = BM25F over all fields of the unique terms.  The HIP path reads
+    the merged lists and their field-tagged positions (ss_bm25_upload_fields_positions)."""
+    n_docs, n_fields = 120_000, 3
+    dfs = [26_000, 20_000, 33_000, 8_000, 12_000, 400]
+    plant = [([0, 1], 0, 300), ([0, 1], 2, 200), ([0, 1, 2], 1, 150), ([2, 0, 2], 0, 100), ([3, 4], 2, 60), ([0, 1, 2, 3, 4, 5], 1, 30),
+             ([1, 1], 2, 80), ([4, 0, 1], 0, 70)]
+    cross = [(0, 1, 500), (3, 4, 300)]
+    boost = np.array([2.0, 1.0, 0.5], np.float32)
+    dl, offs, docs, fields, tfs, positions = _corpus_fields(O, n_docs, n_fields, dfs, 17, plant, cross)
+    sh = S.Shard(0)
+    sh.upload_lexical_fields(n_docs, dl, boost, offs, docs, fields, tfs, positions)
+    phrases = [[0, 1], [1, 0], [0, 1, 2], [2, 0, 2], [3, 4], [0, 1, 2, 3, 4, 5], [1, 1], [4, 0, 1], [5, 3], [2, 2, 2]]
+    gone = list(range(5, n_docs, 89))
+    for filt in ((), (0,), (1, 2), (2,)):
+        q = sh.make_queries(phrases, S.QueryType.Phrase, field_filter=filt)
+        for deleted in (False, True):
+            sh.set_deleted(gone if deleted else [])
+            for k in (10, 100):
+                res = {rt: sh.search_lexical_batch(q, k, rt) for rt in (S.ResultType.TopkCount, S.ResultType.Topk, S.ResultType.Count)}
+                for i, ph in enumerate(phrases):
+                    uniq = list(dict.fromkeys(ph))
+                    seq = [uniq.index(w) for w in ph]
+                    args = (n_docs, dl, boost, offs, docs, fields, tfs, positions, uniq, seq, k)
+                    od, os_, otot = O.search_fields_phrase(*args, deleted=gone if deleted else (), field_filter=filt, reference_loop=True)
+                    od2, os2, otot2 = O.search_fields_phrase(*args, deleted=gone if deleted else (), field_filter=filt, reference_loop=False)
+                    assert otot == otot2 and np.array_equal(od, od2)
+                    doc, score, cnt, tot = res[S.ResultType.TopkCount]
+                    assert int(tot[i]) == otot, (ph, filt, deleted, int(tot[i]), otot)
+                    assert cnt[i] == len(od) and np.allclose(score[i][:cnt[i]], os_, rtol=1e-4), (ph, filt)
+                    if len(od):
+                        band = abs(float(os_[-1])) * 2e-4
+                        clear = lambda dd, ss: {int(x) for x, y in zip(dd, ss) if y > os_[-1] + band}
+                        assert clear(doc[i][:cnt[i]], score[i][:cnt[i]]) <= set(od.tolist()) and clear(od, os_) <= set(doc[i][:cnt[i]].tolist())
+                    d2, s2, c2, _ = res[S.ResultType.Topk]
+                    assert c2[i] == cnt[i] and np.array_equal(s2[i], score[i]) and np.array_equal(d2[i], doc[i])
+                    assert int(res[S.ResultType.Count][3][i]) == otot and res[S.ResultType.Count][2][i] == 0
+    sh.set_deleted([])
+    # the planted cross-field neighbours are no phrase: [3, 4] matches only where it was planted inside a field (or by chance)
+    t_all = int(sh.search_lexical_batch(sh.make_queries([[3, 4]], S.QueryType.Phrase), 10)[3][0])
+    t_and = int(sh.search_lexical_batch(sh.make_queries([[3, 4]], S.QueryType.Intersection), 10)[3][0])
+    assert 60 <= t_all < t_and - 250
+    # a filter can only remove matches; the fields partition them at most (a doc may carry the phrase in two fields)
+    per = [int(sh.search_lexical_batch(sh.make_queries([[0, 1]], S.QueryType.Phrase, field_filter=(f,)), 10)[3][0]) for f in range(3)]
+    whole = int(sh.search_lexical_batch(sh.make_queries([[0, 1]], S.QueryType.Phrase), 10)[3][0])
+    assert max(per) <= whole <= sum(per) and per[0] >= 300 and per[2] >= 200
+    # mixed batch: a phrase, a union and a filtered intersection side by side
+    qm = sh.make_queries([[0, 1], [0, 1], [2, 0, 2]], [S.QueryType.Phrase, S.QueryType.Union, S.QueryType.Phrase])
+    tm = sh.search_lexical_batch(qm, 10)[3]
+    assert int(tm[0]) == whole and int(tm[1]) == O.search_fields_exhaustive(n_docs, dl, boost, offs, docs, fields, tfs, [0, 1], O.OP_OR, 10)[2]
+    # an image without positions refuses phrases
+    sh.upload_lexical_fields(n_docs, dl, boost, offs, docs, fields, tfs)
+    with pytest.raises(S.SeekStormHipError):
+        sh.search_lexical_batch(sh.make_queries([[0, 1]], S.QueryType.Phrase), 10)
+    # a positions array of the wrong length is refused before anything is built
+    with pytest.raises(S.SeekStormHipError):
+        sh.upload_lexical_fields(n_docs, dl, boost, offs, docs, fields, tfs, positions[:-1])
+    sh.close()
+
+
+def test_phrase_queries_on_a_multi_field_index_bin(S, O):
+    """positions of a multi-field index.bin (field vectors + VINT positions in the records, bit-packed positions in the embedded
+    pointers; add_result.rs:1485-2034): the image built from the file answers phrase queries exactly like the image uploaded from
+    the arrays, and like the oracle"""
+    from oracle import ref_format as RF
+    n_docs, n_fields, longest = 100_000, 3, 1
+    dfs = [22_000, 9_000, 15_000, 2_500]
+    plant = [([0, 1], 0, 250), ([0, 1, 2], 1, 100), ([3, 0], 2, 50), ([2, 2], 1, 60)]
+    dl, offs, docs, fields, tfs, positions = _corpus_fields(O, n_docs, n_fields, dfs, 23, plant, [(0, 1, 200)])
+    terms, at = [], 0
+    for t in range(len(dfs)):
+        a, b = int(offs[t]), int(offs[t + 1])
+        pl = []
+        for i in range(a, b):
+            pl.append(positions[at:at + int(tfs[i])].tolist())
+            at += int(tfs[i])
+        terms.append((1000 * (t + 1) * 8, docs[a:b].astype(np.int64), fields[a:b].astype(np.int64), tfs[a:b].astype(np.int64), pl))
+    rng = np.random.default_rng(4)
+    data = RF.write_index_bin(n_docs, dl, terms, rng, n_fields=n_fields, longest_field_id=longest)
+    ix = S.IndexBin(data, n_fields)
+    boost = np.array([1.5, 1.0, 0.75], np.float32)
+    a, b = S.Shard(0), S.Shard(0)
+    a.upload_index_bin(ix, boost=boost, positions=True)
+    b.upload_lexical_fields(n_docs, dl, boost, offs, docs, fields, tfs, positions)
+    phrases = [[0, 1], [0, 1, 2], [3, 0], [2, 2], [1, 0], [2, 0, 1]]
+    for filt in ((), (1,), (0, 2)):
+        for k in (10, 100):
+            ra = a.search_lexical_batch(a.make_queries(phrases, S.QueryType.Phrase, field_filter=filt), k)
+            rb = b.search_lexical_batch(b.make_queries(phrases, S.QueryType.Phrase, field_filter=filt), k)
+            for x, y in zip(ra, rb):
+                assert np.array_equal(x, y)
+            for i, ph in enumerate(phrases):
+                uniq = list(dict.fromkeys(ph))
+                od, os_, otot = O.search_fields_phrase(n_docs, dl, boost, offs, docs, fields, tfs, positions, uniq, [uniq.index(w) for w in ph], k,
+                                                       field_filter=filt)
+                assert int(ra[3][i]) == otot and ra[2][i] == len(od) and np.allclose(ra[1][i][:len(od)], os_, rtol=1e-4), (ph, filt)
+    assert int(a.search_lexical_batch(a.make_queries([[0, 1]], S.QueryType.Phrase), 10)[3][0]) >= 250
+    a.close()
+    b.close()

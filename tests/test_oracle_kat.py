@@ -449,6 +449,62 @@ def test_phrase_match_reference_loop_equals_definition():
     assert 200 < hits < 3800
 
 
+def test_phrase_over_several_fields_rules():
+    """so_search_fields_phrase (add_result.rs:2964-3414): the phrase must stand inside ONE field; a field filter lists the fields it may
+    stand in; the score sums ALL fields of the unique terms; with one field it is so_search_phrase"""
+    n_docs = 8
+    dl = np.full((2, n_docs), 20, np.uint8)
+    # term 0 ("a"), term 1 ("b"); entries sorted by (doc, field)
+    #   doc 0: a@f0{3}      b@f0{4}         -> phrase in field 0
+    #   doc 1: a@f0{3}      b@f1{4}         -> consecutive numbers in DIFFERENT fields: no phrase
+    #   doc 2: a@f1{7, 9}   b@f1{10}        -> phrase in field 1 (9, 10)
+    #   doc 3: a@f0{1} a@f1{5}   b@f0{9} b@f1{6}  -> field 0 no, field 1 yes
+    #   doc 4: a@f0{65535}  b@f1{0}         -> the last position of field 0 and the first of field 1: no phrase
+    #   doc 5: a@f0{2}                      -> no b
+    a_ent = [(0, 0, [3]), (1, 0, [3]), (2, 1, [7, 9]), (3, 0, [1]), (3, 1, [5]), (4, 0, [65535]), (5, 0, [2])]
+    b_ent = [(0, 0, [4]), (1, 1, [4]), (2, 1, [10]), (3, 0, [9]), (3, 1, [6]), (4, 1, [0])]
+    ent = a_ent + b_ent
+    offs = np.array([0, len(a_ent), len(ent)], np.uint64)
+    docs = np.array([e[0] for e in ent], np.uint32)
+    fields = np.array([e[1] for e in ent], np.uint8)
+    tfs = np.array([len(e[2]) for e in ent], np.uint16)
+    pos = np.array([x for e in ent for x in e[2]], np.uint16)
+    for loop in (True, False):
+        f = lambda **kw: O.search_fields_phrase(n_docs, dl, None, offs, docs, fields, tfs, pos, [0, 1], [0, 1], 10, reference_loop=loop, **kw)
+        od, os_, tot = f()
+        assert tot == 3 and sorted(od.tolist()) == [0, 2, 3]
+        assert f(field_filter=(0,))[2] == 1 and f(field_filter=(0,))[0].tolist() == [0]
+        assert sorted(f(field_filter=(1,))[0].tolist()) == [2, 3]
+        assert f(deleted=[2])[2] == 2
+        # "b a": doc 3 field 1 has b@6 ... a@5: no; nothing matches
+        assert O.search_fields_phrase(n_docs, dl, None, offs, docs, fields, tfs, pos, [1, 0], [0, 1], 10, reference_loop=loop)[2] == 0
+        # the score sums all fields: doc 3's equals the BM25F of the intersection {a, b}
+        full = O.search_fields_exhaustive(n_docs, dl, None, offs, docs, fields, tfs, [0, 1], O.OP_AND, 10)
+        for d, sc in zip(od, os_):
+            assert sc == full[1][full[0].tolist().index(int(d))]
+        # a filter does not change the score of a doc that still matches
+        od1, os1, _ = f(field_filter=(1,))
+        assert os1[od1.tolist().index(3)] == os_[od.tolist().index(3)]
+    # one indexed field: the single-field phrase search, bit for bit
+    rng = np.random.default_rng(9)
+    n_docs, nt = 3000, 4
+    dl1 = O.lex_doclen(n_docs)
+    offs1, d1, t1, p1 = [0], [], [], []
+    for t in range(nt):
+        for d in np.sort(rng.choice(n_docs, 900, replace=False)):
+            ps = np.sort(rng.choice(12, int(rng.integers(1, 5)), replace=False))
+            d1.append(int(d)); t1.append(len(ps)); p1 += ps.tolist()
+        offs1.append(len(d1))
+    sh = O.Shard(n_docs, dl1, np.array(offs1, np.uint64), np.array(d1, np.uint32), np.array(t1, np.uint16))
+    sh.set_positions(np.array(p1, np.uint16))
+    for ph in ([0, 1], [2, 3, 0], [1, 1], [3, 2, 1, 0]):
+        uniq = list(dict.fromkeys(ph))
+        seq = [uniq.index(w) for w in ph]
+        x = sh.search_phrase(uniq, seq, 20)
+        y = O.search_fields_phrase(n_docs, dl1[None, :], None, offs1, d1, np.zeros(len(d1), np.uint8), t1, p1, uniq, seq, 20)
+        assert x[2] == y[2] and np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2] > 0
+
+
 def test_geo_morton_and_distances():
     """Point facets (geo_search.rs): the reference's tests hold no vectors for these, so the oracle's restatement is checked
     against what defines it -- latitude in the even bits and longitude in the odd ones of (deg * 1e7) as i32, the cast's

@@ -423,6 +423,40 @@ def test_decode_fields_roundtrip(n_fields, longest, n, tf_hi, limit):
         assert 0 < blocks[0][3] < cnt  # 3-byte pointers in use
 
 
+def _decode_fields_positions(block, n_fields, longest, cap=1 << 22):
+    bid, ctp, cnt, pivot, body = block
+    buf = np.frombuffer(body, np.uint8).copy()
+    rb = N.RefBlock(bid, ctp, cnt - 1, pivot, buf.ctypes.data, len(buf))
+    d = np.zeros(65536, np.uint16); first = np.zeros(65537, np.uint32)
+    f = np.zeros(65536 * n_fields, np.uint8); t = np.zeros(65536 * n_fields, np.uint16)
+    pos = np.zeros(cap, np.uint16)
+    npos = np.zeros(1, np.uint64)
+    n = N.lib().ss_ref_decode_block_fields_positions(C.byref(rb), n_fields, longest, N.ptr(d, N.u16p), N.ptr(first, N.u32p),
+                                                     N.ptr(f, N.u8p), N.ptr(t, N.u16p), N.ptr(pos, N.u16p), cap, N.ptr(npos, N.u64p))
+    return n, d, first, f, t, pos[:int(npos[0])]
+
+
+@pytest.mark.parametrize("n_fields,longest,n,tf_hi,limit,gap", [(2, 0, 300, 3, 32768, 25), (3, 1, 2000, 6, 32768, 6), (4, 3, 500, 300, 32768, 40),
+                                                               (3, 0, 900, 5, 96, 3), (8, 5, 700, 4, 32768, 9), (2, 1, 5000, 2, 32768, 600),
+                                                               (2, 0, 1500, 4, 32768, 2), (5, 2, 1200, 3, 200, 30)])
+def test_decode_fields_positions_roundtrip(n_fields, longest, n, tf_hi, limit, gap):
+    """the POSITIONS of a multi-field index (decode_positions_multiterm_multifield add_result.rs:1485-2034 +
+    get_next_position_multifield): VINT positions behind a record's field vector, and the bit-packed positions of every embedded
+    form (2 bytes: 13 bits longest-field, 12 - id bits per named field; 3 bytes: 20 / 19 - id bits), restarting in every field"""
+    rng = np.random.default_rng(n_fields * 1000 + n + gap)
+    d, f, t = _fields_postings(rng, n, n_fields, tf_hi, longest)
+    positions = [RF.random_positions(rng, int(x), gap) for x in t]
+    blocks = RF.encode_term_fields(d, f, t, n_fields, longest, rng, positions_limit=limit, positions=positions)
+    assert len(blocks) == 1
+    cnt, dd, first, ff, tt, pos = _decode_fields_positions(blocks[0], n_fields, longest)
+    assert cnt == len(np.unique(d)) and int(first[cnt]) == len(d)
+    assert np.array_equal(ff[:len(d)], f) and np.array_equal(tt[:len(d)], t)
+    assert np.array_equal(pos, np.concatenate([np.asarray(p, np.uint16) for p in positions]))
+    # both pointer forms and both record kinds occurred
+    body = blocks[0][4]
+    assert len(body) > 0
+
+
 def test_embedded_field_pointer_tags():
     # 2-byte tags (bits 15..12): 110x / 111x longest field 1 / 2 positions; 1000 / 1001 / 1010 one field 1..3; 1011 two fields
     # 3-byte tags (bits 23..19): 1100x..1111x longest 1..4; 10000..10011 one field 1..4; 10100 (1,1) 10101 (1,2) 10110 (2,1) 10111 (1,1,1)
@@ -557,6 +591,23 @@ def test_hand_assembled_key_bodies():
         # and the restated writer, given the same postings, chooses bytes the decoder reads the same way (two routes, one answer)
     # the fixture's own arithmetic: pointer ranges
     assert H.H1_R == 144 and H.H2_R == 9 and H.H4_R == 15
+    # several indexed fields: field vectors, per-field positions, every embedded form with named fields (H5: 2-byte pointers,
+    # H6: 3-byte pointers) -- the bytes follow index_posting.rs:592-660 / write_field_vec 897-925, the decoder follows
+    # add_result.rs:1485-2034
+    assert len(H.FIELD_BLOCKS) >= 2
+    for b in H.FIELD_BLOCKS:
+        blk = (b["block_id"], b["compression_type_pointer"], b["posting_count"], b["pointer_pivot_p_docid"], b["body"])
+        cnt, dd, first, ff, tt, pos = _decode_fields_positions(blk, b["n_fields"], b["longest_field_id"])
+        assert cnt == len(b["docs"]) and dd[:cnt].tolist() == b["docs"], (b["name"], cnt)
+        flat = [(f, p) for e in b["entries"] for f, p in e]
+        assert first[:cnt + 1].tolist() == np.concatenate([[0], np.cumsum([len(e) for e in b["entries"]])]).tolist(), b["name"]
+        assert ff[:len(flat)].tolist() == [f for f, _ in flat] and tt[:len(flat)].tolist() == [len(p) for _, p in flat], b["name"]
+        assert pos.tolist() == [x for _, p in flat for x in p], (b["name"], pos.tolist())
+        # the restated writer produces the same bytes from the same postings (two routes, one answer)
+        body, ctp, n, pivot = RF.encode_key_body_fields(b["docs"], b["entries"], b["n_fields"], b["longest_field_id"],
+                                                        positions_limit=32768 if b["pointer_pivot_p_docid"] else 0)
+        if b["pointer_pivot_p_docid"]:
+            assert body == b["body"] and ctp == b["compression_type_pointer"] and pivot == b["pointer_pivot_p_docid"], b["name"]
 
 
 @pytest.mark.parametrize("n,tf_hi,limit", [(40, 3, 32768), (3000, 6, 32768), (4000, 30, 32768), (500, 5, 600)])
