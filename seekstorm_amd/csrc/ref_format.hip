@@ -38,6 +38,21 @@ inline bool read_vint(const uint8_t* a, uint64_t len, uint64_t pos, uint32_t* ou
   return true;
 }
 
+// a POSITION of a record (compress_positions, compress_postinglist.rs:948-976; get_next_position_singlefield / _multifield,
+// add_result.rs:36-88): one and two bytes like the VINT above, but the THREE-byte form keeps bit 13 twice -- the writer stores
+// delta >> 13, (delta >> 7) & 0x7F, delta & 0x7F and the reader ORs b0 << 13 | b1 << 7 | b2 -- so it is not the count's VINT
+inline bool read_position(const uint8_t* a, uint64_t len, uint64_t pos, uint32_t* out) {
+  if (pos >= len) return false;
+  const uint32_t v = a[pos];
+  if (v & 0x80u) { *out = v & 0x7Fu; return true; }
+  if (pos + 1 >= len) return false;
+  const uint32_t b2 = a[pos + 1];
+  if (b2 & 0x80u) { *out = (v << 7) | (b2 & 0x7Fu); return true; }
+  if (pos + 2 >= len) return false;
+  *out = (v << 13) | (b2 << 7) | (a[pos + 2] & 0x7Fu);
+  return true;
+}
+
 }  // namespace
 
 namespace {
@@ -146,7 +161,7 @@ int decode_block(const ss_ref_block* b, uint32_t n_components, uint32_t componen
     if (!read_vint(a, len, pos, &v)) return SS_EINVAL;  // the count again
     pos += a[pos] & 0x80u ? 1u : (a[pos + 1] & 0x80u ? 2u : 3u);
     for (uint32_t i = 0; i < tf; i++) {
-      if (!read_vint(a, len, pos, &v)) return SS_EINVAL;
+      if (!read_position(a, len, pos, &v)) return SS_EINVAL;
       pos += a[pos] & 0x80u ? 1u : (a[pos + 1] & 0x80u ? 2u : 3u);
       at = i == 0 ? v : at + v + 1u;
       if (at > 65535u) return SS_ENOTSUP;
@@ -378,7 +393,7 @@ int decode_block_fields(const ss_ref_block* b, uint32_t n_fields, uint32_t longe
         for (int i = 0; i < ne; i++) {  // (get_next_position_multifield restarts at every field, add_result.rs:3279-3283)
           uint32_t at_pos = 0, v;
           for (uint32_t x = 0; x < e[i].tf; x++) {
-            if (!read_vint(a, len, at_rec, &v)) return SS_EINVAL;
+            if (!read_position(a, len, at_rec, &v)) return SS_EINVAL;
             at_rec += a[at_rec] & 0x80u ? 1u : (a[at_rec + 1] & 0x80u ? 2u : 3u);
             at_pos = x == 0 ? v : at_pos + v + 1u;
             if (at_pos > 65535u) return SS_ENOTSUP;

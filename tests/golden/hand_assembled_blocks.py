@@ -141,6 +141,25 @@ H4 = dict(
     body=bytes(H4_PREFIX + H4_REC_P3 + H4_REC_P2 + H4_REC_P1 + H4_POINTERS + H4_CONTAINER),
     docs=H4_DOCS, tfs=H4_TFS, positions=[9] + [200, 202] + [4, 9, 14] + [1, 3, 5, 7] + [1] * 6)
 
+# ---------------------------------------------------------------------------------------------------------------- H7
+# Positions of 16 384 and more: compress_positions' THREE-byte form (compress_postinglist.rs:966-975) stores
+#   delta >> 13 (& 0x7F), (delta >> 7) & 0x7F, (delta & 0x7F) | STOP
+# -- bit 13 of delta lands in the first AND the second byte --, and the readers put it back together as
+#   b0 << 13 | b1 << 7 | b2 & 0x7F      (get_next_position_singlefield / _multifield, add_result.rs:51-56, 82-87),
+# which is NOT the three-byte form of the counts (write_field_vec 866-873: >> 14, >> 7).  One posting, doc 77, positions
+# {20000, 60000, 60001}: stored 20000, 60000 - 20000 - 1 = 39999, 0.
+H7_RECORD = [
+    3 | STOP,                                                      # positions_count 3
+    (20000 >> 13) & 0x7F, (20000 >> 7) & 0x7F, (20000 & 0x7F) | STOP,   # = 0x02, 0x1C, 0xA0
+    (39999 >> 13) & 0x7F, (39999 >> 7) & 0x7F, (39999 & 0x7F) | STOP,   # = 0x04, 0x38, 0xBF  (39999 >> 7 = 312 = 0b1_0011_1000: bit 13 again)
+    0 | STOP,
+]                                                                  # 8 bytes
+H7 = dict(
+    name="H7 three-byte positions",
+    block_id=3, compression_type_pointer=(1 << 30) | len(H7_RECORD), posting_count=1, pointer_pivot_p_docid=1,
+    body=bytes(H7_RECORD + [8, 0] + _u16(77)),
+    docs=[77], tfs=[3], positions=[20000, 60000, 60001])
+
 # ================================================================================================ several indexed fields
 # An index with SEVERAL indexed fields: a posting carries a field vector [(field id, positions count)] and the positions of
 # every listed field, each field's positions restarting at an absolute first value (index_posting.rs:395-441 collect them per
@@ -216,5 +235,5 @@ H6 = dict(
     docs=[1, 2, 3, 50, 51],
     entries=[[(1, [2, 5, 9, 40])], [(0, [1000, 1010])], [(0, [100, 400])], [(0, [3]), (2, [4, 6])], [(0, [1]), (1, [2]), (2, [3])]])
 
-BLOCKS = [H1, H2, H3, H4]
+BLOCKS = [H1, H2, H3, H4, H7]
 FIELD_BLOCKS = [H5, H6]

@@ -438,7 +438,7 @@ def _decode_fields_positions(block, n_fields, longest, cap=1 << 22):
 
 @pytest.mark.parametrize("n_fields,longest,n,tf_hi,limit,gap", [(2, 0, 300, 3, 32768, 25), (3, 1, 2000, 6, 32768, 6), (4, 3, 500, 300, 32768, 40),
                                                                (3, 0, 900, 5, 96, 3), (8, 5, 700, 4, 32768, 9), (2, 1, 5000, 2, 32768, 600),
-                                                               (2, 0, 1500, 4, 32768, 2), (5, 2, 1200, 3, 200, 30)])
+                                                               (2, 0, 1500, 4, 32768, 2), (5, 2, 1200, 3, 200, 30), (3, 1, 800, 3, 32768, 21000)])
 def test_decode_fields_positions_roundtrip(n_fields, longest, n, tf_hi, limit, gap):
     """the POSITIONS of a multi-field index (decode_positions_multiterm_multifield add_result.rs:1485-2034 +
     get_next_position_multifield): VINT positions behind a record's field vector, and the bit-packed positions of every embedded
@@ -610,14 +610,15 @@ def test_hand_assembled_key_bodies():
             assert body == b["body"] and ctp == b["compression_type_pointer"] and pivot == b["pointer_pivot_p_docid"], b["name"]
 
 
-@pytest.mark.parametrize("n,tf_hi,limit", [(40, 3, 32768), (3000, 6, 32768), (4000, 30, 32768), (500, 5, 600)])
+@pytest.mark.parametrize("n,tf_hi,limit", [(40, 3, 32768), (3000, 6, 32768), (4000, 30, 32768), (500, 5, 600), (700, 3, 32769)])
 def test_positions_roundtrip(n, tf_hi, limit):
     """ss_ref_decode_block_positions against the restated writer: embedded 2- and 3-byte forms, VINT records, the pivot inside
     the list (real and lowered limits), gaps that need 1- and 2-byte VINTs"""
     rng = np.random.default_rng(n + tf_hi)
     docs, tfs = _case(rng, n, 65536, tf_hi)
-    positions = [RF.random_positions(rng, int(tf), max_gap=int(rng.choice([3, 40, 300]))) for tf in tfs]
-    blk = RF.encode_term(docs, tfs, rng, positions_limit=limit, positions=positions)[0]
+    # (limit 32769 marks the case with gaps of 16 384 and more: the three-byte position form, which keeps bit 13 twice)
+    positions = [RF.random_positions(rng, int(tf), max_gap=int(rng.choice([3, 40, 300] if limit != 32769 else [300, 20000, 30000]))) for tf in tfs]
+    blk = RF.encode_term(docs, tfs, rng, positions_limit=min(limit, 32768), positions=positions)[0]
     cnt, d, t, pos = _decode_positions(blk)
     assert cnt == len(docs) and np.array_equal(d, docs) and np.array_equal(t, tfs)
     assert pos.tolist() == [p for pl in positions for p in pl]
