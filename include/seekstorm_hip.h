@@ -510,7 +510,15 @@ typedef struct ss_ann_mode {
                                   * of indexed field f are searched, the others are skipped before they are scored; 0 = every
                                   * field.  Needs the records' field ids (vector.bin upload, or ss_vec_set_fields); fields
                                   * >= 64 cannot be selected.  n_probe = 0 and no cluster threshold = AnnMode::All + filter. */
+  uint32_t flags;                /* SS_ANN_* */
+  uint32_t reserved;             /* 0 */
 } ss_ann_mode;
+/* flags bit 0: also report observed_vector_count (TopK::push calls, vector.rs:421, 1510): the records of the visited clusters
+ * that pass the field filter and are not tombstoned (vector.rs:1397-1400, 1450-1452).  out_clusters then holds THREE words per
+ * query: [3 q] observed_cluster_count, [3 q + 1] / [3 q + 2] the low / high word of observed_vector_count.  A mode that skips
+ * no cluster (n_probe 0, no threshold) reports observed_cluster_count 0 -- every cluster, the host knows their number
+ * (ss_vec_cluster_info) -- and the count over the whole image. */
+#define SS_ANN_REPORT_OBSERVED 1u
 /* VectorHeader.field_id of every record, for rows uploaded with ss_vec_upload[_i8] / ss_vec_synth[_i8] */
 int ss_vec_set_fields(ss_shard* s, uint64_t n_rows, const uint16_t* row_field);
 int ss_vec_set_clusters(ss_shard* s, uint32_t n_levels, const uint32_t* level_clusters, const uint32_t* child_count);

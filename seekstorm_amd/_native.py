@@ -58,7 +58,11 @@ class FacetPointC(C.Structure):  # ss_facet_point
 
 
 class AnnModeC(C.Structure):  # ss_ann_mode
-    _fields_ = [("n_probe", C.c_uint32), ("cluster_threshold_raw", C.c_float), ("field_mask", C.c_uint64)]
+    _fields_ = [("n_probe", C.c_uint32), ("cluster_threshold_raw", C.c_float), ("field_mask", C.c_uint64), ("flags", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+SS_ANN_REPORT_OBSERVED = 1
 
 
 BM25_QUERY_DTYPE = np.dtype([("n_terms", np.uint32), ("op", np.uint32), ("term", np.uint32, (SS_MAX_QUERY_TERMS,)),

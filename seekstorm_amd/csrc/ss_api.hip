@@ -1635,7 +1635,7 @@ static int vec_search_host_lists(ss_shard* s, uint32_t nq, const void* queries, 
   const size_t qbytes = ((size_t)nq * s->dim * elem + 15) & ~(size_t)15;
   const size_t sbytes = query_scale ? (size_t)nq * sizeof(float) : 0;
   const size_t nbytes = query_norm ? (size_t)nq * sizeof(float) : 0;
-  SS_TRY(ensure_qstage(s, qbytes + sbytes + nbytes + (want_clusters ? (size_t)nq * sizeof(uint32_t) : 0)));
+  SS_TRY(ensure_qstage(s, qbytes + sbytes + nbytes + (want_clusters ? (size_t)nq * 3 * sizeof(uint32_t) : 0)));  // (three words with SS_ANN_REPORT_OBSERVED)
   float* d_qs = query_scale ? (float*)((char*)s->d_qstage + qbytes) : nullptr;
   float* d_qn = query_norm ? (float*)((char*)s->d_qstage + qbytes + sbytes) : nullptr;
   uint32_t* d_ncl = want_clusters ? (uint32_t*)((char*)s->d_qstage + qbytes + sbytes + nbytes) : nullptr;
@@ -1671,14 +1671,17 @@ static int vec_search_host(ss_shard* s, uint32_t nq, const void* queries, size_t
     if (hipMemcpy(out_doc, s->d_out_doc, (size_t)nq * k * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(out_score, s->d_out_score, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(out_total, s->d_out_total, (size_t)nq * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess ||
-        (d_ncl && hipMemcpy(out_clusters, d_ncl, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess))
+        (d_ncl && hipMemcpy(out_clusters, d_ncl, (size_t)nq * ((mode && (mode->flags & SS_ANN_REPORT_OBSERVED)) ? 3 : 1) * sizeof(uint32_t),
+                            hipMemcpyDeviceToHost) != hipSuccess))
       rc = SS_EDEVICE;
   }
   return rc;
 }
 static bool ann_skips_clusters(const ss_ann_mode* m) { return m->n_probe != 0 || m->cluster_threshold_raw > -3.4028234663852886e38f; }
 // a mode that neither skips clusters nor filters fields is AnnMode::All
-static const ss_ann_mode* ann_effective(const ss_ann_mode* m) { return (m && (ann_skips_clusters(m) || m->field_mask)) ? m : nullptr; }
+static const ss_ann_mode* ann_effective(const ss_ann_mode* m) {
+  return (m && (ann_skips_clusters(m) || m->field_mask || (m->flags & SS_ANN_REPORT_OBSERVED))) ? m : nullptr;
+}
 static int ann_mode_ok(const ss_shard* s, const ss_ann_mode* mode) {
   if (!mode) return SS_OK;
   if (mode->cluster_threshold_raw != mode->cluster_threshold_raw) return SS_EINVAL;

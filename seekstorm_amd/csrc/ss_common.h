@@ -188,6 +188,8 @@ struct ss_shard {
   uint32_t* d_ann_sel = nullptr;        // [65][words] selected-cluster bits per query; row 64 = union over the batch
   uint32_t* d_ann_tiles = nullptr;      // [tiles + 1] ascending tile list of the batch, count in the last slot
   uint32_t* d_ann_ncl = nullptr;        // [64] observed_cluster_count
+  uint32_t* d_ann_live = nullptr;       // [2 + n_clusters]: u64 live records of the image, then per cluster (ssi_vec_observed_prepare)
+  size_t ann_live_cap = 0;
   // vector workspace (one 64-query batch in flight per shard)
   float* d_Qf = nullptr;
   uint32_t* d_vstate = nullptr;  // tau[64] | cnt[64] | kept[64] | flags[64] | total_lo/hi ...
@@ -326,6 +328,9 @@ int ssi_facet_count(ss_shard* s, const unsigned long long* d_bits, uint64_t n_do
 // ---- implemented in facet.hip: exclusion bitmap (failed facet filters | tombstones) into s->d_filter_bits
 int ssi_facet_build(ss_shard* s, uint32_t n_filters, const ss_facet_filter* filters, hipStream_t st);
 // ---- implemented in vec_ann.hip
+// observed_vector_count (SS_ANN_REPORT_OBSERVED): live records per cluster once per call, then the triples of every batch
+int ssi_vec_observed_prepare(ss_shard* s, unsigned long long field_mask, hipStream_t st);
+int ssi_vec_observed_report(ss_shard* s, uint32_t nb, bool clusters_selected, uint32_t* d_out3, hipStream_t st);
 // after the batch's queries are in s->d_Qf (qprep): medoid scores, per-query selection, tile list -> *out
 int ssi_vec_ann_prepare(ss_shard* s, uint32_t nb, const float* d_qscale, const ss_ann_mode* mode, VAnn* out,
                         uint32_t* d_out_clusters, hipStream_t st, const float* d_qnorm = nullptr);

@@ -410,11 +410,12 @@ __global__ void __launch_bounds__(AT) ann_tiles_place_kernel(const uint32_t* __r
 // ---------------------------------------------------------------- host side
 void ssi_vec_free_clusters(ss_shard* s) {
   void* ptrs[] = {s->d_row_cluster, s->d_cluster_first, s->d_level_off, s->d_ann_score, s->d_ann_its,
-                  s->d_ann_itc,     s->d_ann_sel,       s->d_ann_tiles, s->d_ann_ncl,   s->d_medoids};
+                  s->d_ann_itc,     s->d_ann_sel,       s->d_ann_tiles, s->d_ann_ncl,   s->d_medoids,   s->d_ann_live};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   s->d_row_cluster = nullptr; s->d_cluster_first = nullptr; s->d_level_off = nullptr; s->d_ann_score = nullptr;
   s->d_ann_its = nullptr; s->d_ann_itc = nullptr; s->d_ann_sel = nullptr; s->d_ann_tiles = nullptr; s->d_ann_ncl = nullptr; s->d_medoids = nullptr;
+  s->d_ann_live = nullptr; s->ann_live_cap = 0;
   s->vec_n_clusters = 0; s->vec_n_levels = 0; s->vec_max_level_clusters = 0;
 }
 
@@ -470,6 +471,93 @@ int ssi_vec_set_clusters(ss_shard* s, uint32_t n_levels, const uint32_t* level_c
   s->vec_n_clusters = (uint32_t)nc;
   s->vec_n_levels = n_levels;
   s->vec_max_level_clusters = *std::max_element(level_clusters, level_clusters + n_levels);
+  return SS_OK;
+}
+
+// ---------------------------------------------------------------- observed_vector_count (SS_ANN_REPORT_OBSERVED)
+// TopK::push counts every record it is handed (vector.rs:421): the records of the visited clusters whose field the filter lists
+// (1397-1400) and whose doc is not tombstoned (1450-1452).  Two small passes: the live records of every cluster (rows of a
+// cluster are contiguous and row_cluster ascends, so a wave counts its segments with ballots), then per query the sum over its
+// selected clusters.  Without clusters (or a mode that skips none): one count over the whole image.
+__global__ void __launch_bounds__(256) ann_live_kernel(const uint32_t* __restrict__ row_cluster, const uint16_t* __restrict__ row_field,
+                                                       unsigned long long field_mask, const uint32_t* __restrict__ row_doc,
+                                                       const uint32_t* __restrict__ del, uint32_t del_words, unsigned long long n_rows,
+                                                       uint32_t* __restrict__ cluster_live, unsigned long long* __restrict__ all_live) {
+  const unsigned long long r = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63u;
+  bool pass = r < n_rows;
+  if (pass && field_mask) {
+    const uint32_t f = row_field[r];
+    pass = f < 64u && ((field_mask >> f) & 1ull);
+  }
+  if (pass && del) {
+    const uint32_t doc = row_doc ? row_doc[r] : (uint32_t)r;
+    pass = !((doc >> 5) < del_words && ((del[doc >> 5] >> (doc & 31u)) & 1u));
+  }
+  const unsigned long long pb = __ballot(pass);
+  if (lane == 0 && pb) atomicAdd(all_live, (unsigned long long)__popcll(pb));
+  if (!row_cluster) return;
+  const uint32_t c = r < n_rows ? row_cluster[r] : 0xFFFFFFFFu;
+  const uint32_t prev = __shfl_up(c, 1);
+  const bool head = lane == 0 || prev != c;
+  const unsigned long long hb = __ballot(head);
+  if (head && c != 0xFFFFFFFFu) {
+    const unsigned long long above = lane == 63 ? 0ull : (hb >> (lane + 1)) << (lane + 1);  // heads after this lane
+    const uint32_t end = above ? (uint32_t)__builtin_ctzll(above) : 64u;                     // first lane of the next segment
+    const unsigned long long seg = (end == 64u ? ~0ull : ((1ull << end) - 1ull)) & ~((1ull << lane) - 1ull);
+    const uint32_t n = (uint32_t)__popcll(pb & seg);
+    if (n) atomicAdd(&cluster_live[c], n);
+  }
+}
+// one wave per query: out[3 q] = clusters visited, out[3 q + 1 .. 2] = observed records
+__global__ void __launch_bounds__(64) ann_observed_kernel(const uint32_t* __restrict__ sel, uint32_t W, const uint32_t* __restrict__ cluster_live,
+                                                          const uint32_t* __restrict__ ncl, const unsigned long long* __restrict__ all_live,
+                                                          uint32_t* __restrict__ out) {
+  const uint32_t q = blockIdx.x, lane = threadIdx.x;
+  unsigned long long n = 0;
+  if (sel) {
+    for (uint32_t w = lane; w < W; w += 64u) {
+      uint32_t m = sel[(size_t)q * W + w];
+      while (m) {
+        const uint32_t b = (uint32_t)__builtin_ctz(m);
+        m &= m - 1u;
+        n += cluster_live[w * 32u + b];
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+  } else {
+    n = *all_live;
+  }
+  if (lane == 0) {
+    out[3u * q] = ncl ? ncl[q] : 0u;
+    out[3u * q + 1u] = (uint32_t)n;
+    out[3u * q + 2u] = (uint32_t)(n >> 32);
+  }
+}
+// live counts of the image under (field_mask, tombstones): once per call, before the batches
+int ssi_vec_observed_prepare(ss_shard* s, unsigned long long field_mask, hipStream_t st) {
+  const size_t words = (size_t)s->vec_n_clusters + 2;
+  if (s->ann_live_cap < words) {
+    SS_HIP(hipStreamSynchronize(st));
+    if (s->d_ann_live) (void)hipFree(s->d_ann_live);
+    s->d_ann_live = nullptr; s->ann_live_cap = 0;
+    SS_HIP(hipMalloc(&s->d_ann_live, words * sizeof(uint32_t) + 8));
+    s->ann_live_cap = words;
+  }
+  SS_HIP(hipMemsetAsync(s->d_ann_live, 0, words * sizeof(uint32_t) + 8, st));
+  if (s->n_rows)
+    ann_live_kernel<<<(uint32_t)((s->n_rows + 255) / 256), 256, 0, st>>>(
+        s->d_row_cluster, s->d_row_field, s->d_row_field ? field_mask : 0ull, s->d_row_doc, s->n_deleted ? s->d_deleted : nullptr,
+        (uint32_t)s->deleted_words, (unsigned long long)s->n_rows, s->d_ann_live + 2, (unsigned long long*)s->d_ann_live);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+// the triples of one batch; clusters_selected: ssi_vec_ann_prepare ran for it (s->d_ann_sel / d_ann_ncl hold its selection)
+int ssi_vec_observed_report(ss_shard* s, uint32_t nb, bool clusters_selected, uint32_t* d_out3, hipStream_t st) {
+  const uint32_t W = (s->vec_n_clusters + 31) / 32;
+  ann_observed_kernel<<<nb, 64, 0, st>>>(clusters_selected ? s->d_ann_sel : nullptr, W, s->d_ann_live + 2, clusters_selected ? s->d_ann_ncl : nullptr,
+                                         (const unsigned long long*)s->d_ann_live, d_out3);
+  SS_HIP(hipGetLastError());
   return SS_OK;
 }
 

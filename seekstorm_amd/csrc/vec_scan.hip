@@ -510,6 +510,12 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float*
   if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
   int rc = ssi_vec_alloc_ws(s);
   if (rc) return rc;
+  // SS_ANN_REPORT_OBSERVED: d_out_clusters holds three words per query (clusters, observed records low / high)
+  const bool observed = ann_mode && (ann_mode->flags & SS_ANN_REPORT_OBSERVED) && d_out_clusters;
+  const uint32_t ocw = observed ? 3u : 1u;
+  if (observed) { rc = ssi_vec_observed_prepare(s, ann_mode->field_mask, st); if (rc) return rc; }
+  // a mode that only asks for the report scans like AnnMode::All
+  if (ann_mode && !ann_clusters && !ann_mode->field_mask) ann_mode = nullptr;
   const uint32_t nch = s->dim_pad / VS_KC;
   const uint32_t T = (uint32_t)(s->n_rows_pad / VS_TR);
   VState* vst = (VState*)s->d_vstate;
@@ -554,12 +560,13 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float*
     vec_init_kernel<<<1, 64, 0, st>>>(vst, tau_init);
     VAnn ann{};
     if (ann_clusters) {  // medoid scores -> per-query cluster selection -> the batch's tile list
-      rc = ssi_vec_ann_prepare(s, nb, d_qscale ? d_qscale + g0 : nullptr, ann_mode, &ann, d_out_clusters ? d_out_clusters + g0 : nullptr, st,
-                               d_qnorm ? d_qnorm + g0 : nullptr);
+      rc = ssi_vec_ann_prepare(s, nb, d_qscale ? d_qscale + g0 : nullptr, ann_mode, &ann,
+                               (d_out_clusters && !observed) ? d_out_clusters + g0 : nullptr, st, d_qnorm ? d_qnorm + g0 : nullptr);
       if (rc) return rc;
-    } else if (ann_mode && d_out_clusters) {
+    } else if (ann_mode && d_out_clusters && !observed) {
       SS_HIP(hipMemsetAsync(d_out_clusters + g0, 0, nb * sizeof(uint32_t), st));
     }
+    if (observed) { rc = ssi_vec_observed_report(s, nb, ann_clusters, d_out_clusters + (size_t)g0 * ocw, st); if (rc) return rc; }
     if (ann_mode && ann_mode->field_mask) {
       ann.row_field = s->d_row_field;
       ann.field_mask = ann_mode->field_mask;

@@ -221,7 +221,9 @@ int Shard::open_vector_bin(const uint8_t* bytes, uint64_t len, uint32_t dim, boo
 
 int Shard::set_deleted(const uint64_t* doc_ids, uint64_t n) {
   if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
-  return ss_set_deleted(h_, doc_ids, n);
+  const int rc = ss_set_deleted(h_, doc_ids, n);
+  if (rc == SS_OK) n_deleted_ = n;
+  return rc;
 }
 
 int Shard::synth_lexical(uint64_t seed, uint64_t n_docs, uint32_t n_terms, const uint32_t* thresh32,
@@ -369,10 +371,10 @@ std::vector<ResultObject> Shard::search_vector_batch(const float* query_vectors,
   std::vector<uint32_t> doc(n_queries * kk), cnt(n_queries);
   std::vector<float> score(n_queries * kk);
   std::vector<uint64_t> tot(n_queries);
-  std::vector<uint32_t> ncl(n_queries, 0);
+  std::vector<uint32_t> ncl(n_queries * 3, 0);  // SS_ANN_REPORT_OBSERVED: clusters, observed records (low, high) per query
   int rc = create_rc_ ? create_rc_ : SS_ESTATE;
   // vector.rs:1300-1307: (n_probe, cluster threshold) of the mode; the threshold goes through TopK::new like the record one
-  ss_ann_mode am{0u, threshold_raw(nullptr), 0ull};
+  ss_ann_mode am{0u, threshold_raw(nullptr), 0ull, 0u, 0u};
   const bool euc = euclidean_;
   const bool ann = ann_mode.kind != AnnMode::Kind::All;
   bool bad_field = false;
@@ -380,7 +382,11 @@ std::vector<ResultObject> Shard::search_vector_batch(const float* query_vectors,
     if (f < 64) am.field_mask |= 1ull << f;
     else bad_field = true;
   }
-  const bool opts = ann || am.field_mask != 0;
+  // observed_vector_count is counted on the device wherever it is not simply the record count: ANN modes, a field filter,
+  // tombstones (TopK::push is only handed live records of listed fields, vector.rs:1397-1400, 1450-1452).  AnnMode::All on a
+  // shard without tombstones keeps mode == NULL: those calls coalesce behind the ABI.
+  const bool opts = ann || am.field_mask != 0 || n_deleted_ != 0;
+  if (opts) am.flags = SS_ANN_REPORT_OBSERVED;
   if (ann_mode.kind == AnnMode::Kind::Nprobe || ann_mode.kind == AnnMode::Kind::NprobeSimilaritythreshold)
     am.n_probe = (uint32_t)std::min<size_t>(ann_mode.n_probe, 0xFFFFFFFFu);
   if (ann_mode.kind == AnnMode::Kind::Similaritythreshold || ann_mode.kind == AnnMode::Kind::NprobeSimilaritythreshold)
@@ -414,12 +420,10 @@ std::vector<ResultObject> Shard::search_vector_batch(const float* query_vectors,
     }
     ro.result_count = n;
     ro.result_count_total = tot[q];
-    if (!ann) {
-      if (!am.field_mask) ro.observed_vector_count = n_rows_;  // AnnMode::All observes every record (vector.rs:421)
-      ro.observed_cluster_count = all_clusters ? all_clusters : 1;
-    } else {
-      ro.observed_cluster_count = ncl[q];  // vector.rs:1394
-    }
+    ro.observed_vector_count = opts ? ((uint64_t)ncl[3 * q + 1] | ((uint64_t)ncl[3 * q + 2] << 32))
+                                    : n_rows_;  // AnnMode::All, nothing filtered: every record is pushed (vector.rs:421)
+    if (!ann) ro.observed_cluster_count = all_clusters ? all_clusters : 1;
+    else ro.observed_cluster_count = ncl[3 * q];  // vector.rs:1394
   }
   return out;
 }

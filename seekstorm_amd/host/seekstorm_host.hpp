@@ -203,7 +203,7 @@ class Shard {
   uint32_t shard_id_ = 0;
   int device_ = 0;
   int create_rc_ = SS_OK;
-  uint64_t n_docs_ = 0, n_rows_ = 0;
+  uint64_t n_docs_ = 0, n_rows_ = 0, n_deleted_ = 0;
   uint32_t dim_ = 0;
   bool i8_ = false;
   bool euclidean_ = false;

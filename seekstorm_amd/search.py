@@ -178,18 +178,28 @@ class AnnMode:
         return N.AnnModeC(self.n_probe, threshold_raw(self.similarity_threshold, euclidean), 0)
 
 
-def _vector_options(ann_mode, field_filter, euclidean=False):
-    """ss_ann_mode of a call: the AnnMode (None = All) and the field filter (indexed field ids, empty = every field)"""
+def _vector_options(ann_mode, field_filter, euclidean=False, observed=False):
+    """ss_ann_mode of a call: the AnnMode (None = All) and the field filter (indexed field ids, empty = every field);
+    observed: also report observed_vector_count (SS_ANN_REPORT_OBSERVED: three words per query in out_clusters)"""
     mask = 0
     for f in field_filter or ():
         if not 0 <= int(f) < 64:
             raise ValueError("field filter: indexed field ids 0..63")
         mask |= 1 << int(f)
-    if ann_mode is None and not mask:
+    if ann_mode is None and not mask and not observed:
         return None
     m = N.AnnModeC(0, N.FLT_MIN_NEG, 0) if ann_mode is None else ann_mode._c(euclidean)
     m.field_mask = mask
+    m.flags = N.SS_ANN_REPORT_OBSERVED if observed else 0
     return m
+
+
+def _split_clusters(ncl, nq, observed):
+    """out_clusters of a call -> (observed_cluster_count [nq], observed_vector_count [nq] or None)"""
+    if not observed:
+        return ncl, None
+    t = ncl.reshape(nq, 3)
+    return t[:, 0].copy(), t[:, 1].astype(np.uint64) | (t[:, 2].astype(np.uint64) << np.uint64(32))
 
 
 class IndexBin:
@@ -415,6 +425,7 @@ class Shard:
             doc_ids = np.frombuffer(bytes(doc_ids), "<u8")
         ids = np.ascontiguousarray(doc_ids, np.uint64)
         N.check(N.lib().ss_set_deleted(self._h, N.ptr(ids, N.u64p) if len(ids) else None, len(ids)), "ss_set_deleted")
+        self._n_deleted = len(ids)
 
     def synth_partition(self, shard_id, n_shards):
         """the following synth_* calls build shard `shard_id` of `n_shards` of one generator stream (doc g -> shard g % S)"""
@@ -470,7 +481,7 @@ class Shard:
         return out
 
     def search_vector_batch_i8(self, queries_i8, k, query_scale=None, similarity_threshold_raw=None, ann_mode=None,
-                               with_clusters=False, field_filter=None, query_norm=None):
+                               with_clusters=False, field_filter=None, query_norm=None, with_observed=False):
         """scores = dot_i8 as f32 (* query_scale * embedding_scale with scales): vector_similarity.rs:1011-1016, 1754-1758;
         under Euclidean -euclidean_i8, or -euclidean_i8_quantized with the scales and norms (query_norm per query)"""
         qv = np.ascontiguousarray(queries_i8, np.int8)
@@ -485,13 +496,16 @@ class Shard:
         cnt = np.empty(nq, np.uint32)
         tot = np.empty(nq, np.uint64)
         thr = N.FLT_MIN_NEG if similarity_threshold_raw is None else float(similarity_threshold_raw)
-        ncl = np.zeros(nq, np.uint32)
-        mode = _vector_options(ann_mode, field_filter, self.vector_euclidean)
+        ncl = np.zeros(nq * (3 if with_observed else 1), np.uint32)
+        mode = _vector_options(ann_mode, field_filter, self.vector_euclidean, with_observed)
         qn = None if query_norm is None else np.ascontiguousarray(query_norm, np.float32)
         N.check(N.lib().ss_vec_search_i8_euclid(self._h, nq, qv.ctypes.data, N.ptr(qs, N.f32p), N.ptr(qn, N.f32p), k, thr,
                                                 None if mode is None else C.addressof(mode), N.ptr(doc, N.u32p),
                                                 N.ptr(score, N.f32p), N.ptr(cnt, N.u32p), N.ptr(tot, N.u64p), N.ptr(ncl, N.u32p)),
                 "ss_vec_search_i8_euclid")
+        ncl, obs = _split_clusters(ncl, nq, with_observed)
+        if with_observed:
+            return doc, score, cnt, tot, ncl, obs
         return (doc, score, cnt, tot, ncl) if with_clusters else (doc, score, cnt, tot)
 
     def synth_vectors(self, seed, n_rows, dim):
@@ -859,7 +873,8 @@ class Shard:
         return doc, score, cnt, tot
 
     def search_vector_batch(self, query_vectors, k, similarity_threshold=None, ann_mode=None, with_clusters=False,
-                            field_filter=None):
+                            field_filter=None, with_observed=False):
+        """with_observed: -> (..., observed_cluster_count, observed_vector_count) per query (vector.rs:421, 1394, 1510)"""
         qv = np.ascontiguousarray(query_vectors, np.float32)
         if qv.ndim == 1:
             qv = qv[None, :]
@@ -870,11 +885,14 @@ class Shard:
         score = np.zeros((nq, k), np.float32)
         cnt = np.zeros(nq, np.uint32)
         tot = np.zeros(nq, np.uint64)
-        ncl = np.zeros(nq, np.uint32)
-        mode = _vector_options(ann_mode, field_filter, self.vector_euclidean)
+        ncl = np.zeros(nq * (3 if with_observed else 1), np.uint32)
+        mode = _vector_options(ann_mode, field_filter, self.vector_euclidean, with_observed)
         N.check(N.lib().ss_vec_search_ann(self._h, nq, N.ptr(qv, N.f32p), int(k), threshold_raw(similarity_threshold, self.vector_euclidean),
                                           None if mode is None else C.addressof(mode), N.ptr(doc, N.u32p), N.ptr(score, N.f32p),
                                           N.ptr(cnt, N.u32p), N.ptr(tot, N.u64p), N.ptr(ncl, N.u32p)), "ss_vec_search_ann")
+        ncl, obs = _split_clusters(ncl, nq, with_observed)
+        if with_observed:
+            return doc, score, cnt, tot, ncl, obs
         return (doc, score, cnt, tot, ncl) if with_clusters else (doc, score, cnt, tot)
 
     # ---- the reference's per-shard seams (one query)
@@ -948,13 +966,17 @@ class Shard:
             if self.vector_precision == "i8":  # the query is quantised like the records (search.rs:1476-1490), threshold on the raw dot
                 q8 = quantize_f32_to_i8(np.ascontiguousarray(query_vector, np.float32).reshape(1, -1))
                 thr = None if similarity_threshold is None else threshold_raw(similarity_threshold, self.vector_euclidean)
-                doc, score, cnt, tot, ncl = self.search_vector_batch_i8(q8, length, similarity_threshold_raw=thr,
-                                                                        ann_mode=ann_mode, with_clusters=True,
-                                                                        field_filter=field_filter)
+                doc, score, cnt, tot, ncl, obs = self.search_vector_batch_i8(q8, length, similarity_threshold_raw=thr,
+                                                                             ann_mode=ann_mode, field_filter=field_filter,
+                                                                             with_observed=True)
             else:
-                doc, score, cnt, tot, ncl = self.search_vector_batch(query_vector, length, similarity_threshold,
-                                                                     ann_mode=ann_mode, with_clusters=True,
-                                                                     field_filter=field_filter)
+                # (AnnMode::All on a shard without tombstones and without a field filter observes every record: no mode is
+                # passed, and such calls coalesce behind the ABI)
+                plain = ann_mode is None and not field_filter and not getattr(self, "_n_deleted", 0)
+                r = self.search_vector_batch(query_vector, length, similarity_threshold, ann_mode=ann_mode, field_filter=field_filter,
+                                             with_observed=not plain, with_clusters=True)
+                doc, score, cnt, tot, ncl = r[:5]
+                obs = r[5] if not plain else np.array([self.vector_count], np.uint64)
         except Exception:
             if strict:
                 raise
@@ -963,9 +985,10 @@ class Shard:
         ro.results = [Result(int(d), float(s), ResultSource.Vector) for d, s in zip(doc[0, :n], score[0, :n])]
         ro.result_count = n
         ro.result_count_total = int(tot[0])
+        # TopK::push counts every record it is handed (vector.rs:421, 1510): those of the visited clusters that pass the field
+        # filter and are not tombstoned -- counted on the device (SS_ANN_REPORT_OBSERVED)
+        ro.observed_vector_count = int(obs[0])
         if ann_mode is None:
-            if not field_filter:
-                ro.observed_vector_count = self.vector_count  # AnnMode::All observes every record (vector.rs:421)
             ro.observed_cluster_count = max(self.cluster_info()[1], 1)  # AnnMode::All: every cluster (one when none is declared), as the C++ mirror
         else:
             ro.observed_cluster_count = int(ncl[0])  # vector.rs:1394

@@ -366,3 +366,50 @@ def test_ann_many_clusters_per_level_take_the_slow_selection(S, O):
             od, os_, _, _, oncl = O.vec_search_i8_ann(rows, qs[i], 20, [C], child, n_probe=n_probe)
             assert ncl[i] == oncl == n_probe and cnt[i] == len(od) and np.array_equal(score[i][:cnt[i]], os_)
     sh.close()
+
+
+@pytest.mark.parametrize("i8", [False, True])
+def test_observed_vector_count_in_every_mode(S, O, i8):
+    """observed_vector_count = TopK::push calls (vector.rs:421, 1510): the records of the VISITED clusters whose field the filter
+    lists (1397-1400) and whose doc is not tombstoned (1450-1452) -- counted on the device (SS_ANN_REPORT_OBSERVED: three words
+    per query) in AnnMode::All, with a field filter, in the ANN modes, with tombstones, over more than one 64-query batch"""
+    lc = [8, 7, 5]
+    rows32, child = clustered(O, 181, lc, 64, lo=70, hi=240)
+    n = len(rows32)
+    rng = np.random.default_rng(182)
+    rf = rng.integers(0, 3, n).astype(np.uint16)
+    ids = (np.arange(n) // 2).astype(np.uint32)       # two records per doc
+    q32 = queries_near(O, rows32, 183, 70)            # two device batches
+    rows, qs = (O.quantize_i8(rows32), O.quantize_i8(q32)) if i8 else (rows32, q32)
+    sh = S.Shard(0)
+    (sh.upload_vectors_i8 if i8 else sh.upload_vectors)(rows, row_doc_ids=ids)
+    sh.set_fields(rf)
+    sh.set_clusters(lc, child)
+    search = sh.search_vector_batch_i8 if i8 else sh.search_vector_batch
+    ora = O.vec_search_i8_ann if i8 else O.vec_search_ann
+    gone = [int(x) for x in rng.choice(n // 2, 40, replace=False)]
+    k = 10
+    for deleted in ([], gone):
+        sh.set_deleted(deleted)
+        for am, lcc, kw in ((None, (None, None), {}), (S.AnnMode.Nprobe(2), (lc, child), dict(n_probe=2)),
+                            (S.AnnMode.Nprobe(6), (lc, child), dict(n_probe=6))):
+            for fields in ((), [1], [0, 2]):
+                doc, score, cnt, tot, ncl, obs = search(qs, k, ann_mode=am, field_filter=fields, with_observed=True)
+                plain = search(qs, k, ann_mode=am, field_filter=fields, with_clusters=True)
+                assert np.array_equal(plain[0], doc) and np.array_equal(plain[1], score) and np.array_equal(plain[4], ncl)  # the report changes nothing else
+                for i in range(0, len(qs), 3):
+                    od, os_, otot, oobs, oncl = ora(rows, qs[i], k, lcc[0], lcc[1], row_doc_ids=ids, row_field=rf if fields else None,
+                                                    fields=fields, deleted=deleted, **kw)
+                    assert int(obs[i]) == oobs, (i8, am, fields, bool(deleted), i, int(obs[i]), oobs)
+                    assert int(ncl[i]) == oncl
+                    assert int(cnt[i]) == len(od)
+    # the reference's per-shard seam reports it in the ResultObject
+    sh.set_deleted(gone)
+    ro = sh.search_vector_shard(q32[0], 10, ann_mode=S.AnnMode.Nprobe(2), field_filter=[1])
+    oobs = ora(rows, qs[0], 10, lc, child, row_doc_ids=ids, row_field=rf, fields=[1], deleted=gone, n_probe=2)[3]
+    assert ro.observed_vector_count == oobs and ro.observed_cluster_count == sum(min(2, c) for c in lc)
+    ro = sh.search_vector_shard(q32[0], 10)  # AnnMode::All with tombstones: the live records
+    assert ro.observed_vector_count == ora(rows, qs[0], 10, None, None, row_doc_ids=ids, deleted=gone)[3] < n
+    sh.set_deleted([])
+    assert sh.search_vector_shard(q32[0], 10).observed_vector_count == n
+    sh.close()
