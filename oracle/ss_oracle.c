@@ -736,12 +736,12 @@ static uint32_t topk_scan_order(uint64_t n_rows, const uint64_t* order, const ui
     const uint64_t r = order ? order[i] : i;
     float score = fn(ctx, r);
     uint32_t doc = row_doc ? row_doc[r] : (uint32_t)r;
-    observed++;
     if (n_deleted) { /* vector.rs:1450-1452: scored, then not pushed */
       uint64_t lo = 0, hi = n_deleted;
       while (lo < hi) { uint64_t mid = (lo + hi) / 2; if (deleted_sorted[mid] < doc) lo = mid + 1; else hi = mid; }
       if (lo < n_deleted && deleted_sorted[lo] == doc) continue;
     }
+    observed++; /* observed_vector_count is counted INSIDE TopK::push (vector.rs:421): a tombstoned record never gets there */
     if (k == 0) continue;
     topk_push(&t, doc, score);
   }
