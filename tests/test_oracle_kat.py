@@ -232,7 +232,8 @@ def test_deleted_docs_neither_count_nor_rank():
     qv = O.vec_gen(O.VECQ_SEED, 0, 1, 64)[0]
     d0, s0, tot0, obs0 = O.vec_search(rows, qv, 20)
     d1, s1, tot1, obs1 = O.vec_search(rows, qv, 20, deleted=[int(d0[0]), int(d0[5])])
-    assert obs1 == obs0 == 3000 and int(d0[0]) not in d1 and int(d0[5]) not in d1
+    # observed_vector_count counts TopK::push calls (vector.rs:421): the two tombstoned records never reach it (1450-1452)
+    assert obs0 == 3000 and obs1 == 2998 and int(d0[0]) not in d1 and int(d0[5]) not in d1
     assert [int(x) for x in d1[:4]] == [int(x) for x in d0[1:5]]
 
 
