@@ -242,6 +242,10 @@ int ss_bm25_synth(ss_shard* s, uint64_t seed, uint64_t n_docs, uint32_t n_terms,
  * the generator stream.  Applies to the following ss_bm25_synth / ss_vec_synth[_i8] calls; default 0 of 1. */
 int ss_synth_set_partition(ss_shard* s, uint32_t shard_id, uint32_t n_shards);
 int ss_bm25_info(ss_shard* s, uint64_t* n_docs, float* avgdl, uint32_t* n_terms, uint64_t* n_postings);
+/* indexed fields of the image; merged_lists = 1 when an image with several fields carries one merged list per term (always,
+ * unless the boosts are so far apart that the merged weights leave the weight code's range, or SS_BM25_MERGED=0): phrase queries
+ * and SS_OP_ALL_TERMS_FREQUENT over several fields need them; positions = 1 when phrase queries can be answered */
+int ss_bm25_fields_info(ss_shard* s, uint32_t* n_fields, uint32_t* merged_lists, uint32_t* positions);
 /* SPARSE TIER: the posting lists of RARE terms as plain sorted arrays -- no per-sub-block directory row (4 B per 4096 docs and
  * list: 9.8 KB at 10 M docs, whatever the list's length), no probe row; 8 bytes per posting.  A real vocabulary holds millions of
  * keys, almost all rare (key_count per segment, index.rs:3419-3740): they go here, the lists that cost query time stay in the
@@ -298,8 +302,12 @@ int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df
  * pointer or fewer than 10 positions is counted but never scored (decode_positions_multiterm_singlefield returns true,
  * add_result.rs:2091-2104, 3541-3556).  An embedded pointer holds at most 4 positions, so the rule is "ranked only if every
  * term has tf >= 10".  The caller evaluates the condition (it knows N, top_k and the posting counts) and sets this bit on
- * the query; the host mirrors do.  Intersections of 2..7 terms over one indexed field (SS_ENOTSUP otherwise); counts are
- * unaffected.  For ss_bm25_search_dev: ops_mask bit 3 = some query carries the bit. */
+ * the query; the host mirrors do.  Intersections of 2..7 terms (SS_ENOTSUP otherwise); counts are unaffected.  Several indexed
+ * fields (decode_positions_multiterm_multifield, add_result.rs:1595-1607: an embedded pointer, or a record whose FIRST field has
+ * fewer than 10 positions -> counted, not ranked): "ranked only if every term has >= 10 positions in the lowest field that holds
+ * the doc", over the image's merged lists (ss_bm25_fields_info; SS_ENOTSUP without them); under a field filter the reference
+ * switches the shortcut off (add_result.rs:3116) and the bit is ignored.  For ss_bm25_search_dev: ops_mask bit 3 = some query
+ * carries the bit. */
 #define SS_OP_ALL_TERMS_FREQUENT 0x80000000u
 typedef struct {
   uint32_t n_terms;                  /* 1..SS_MAX_QUERY_TERMS unique terms (scored; all required for an intersection) */

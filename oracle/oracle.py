@@ -398,6 +398,28 @@ def search_fields_exhaustive(n_docs, doclen_fields, boost, offs, docs, fields, t
     return od[:n].copy(), os_[:n].copy(), tot.value, avg.value
 
 
+def search_fields_shortcut(n_docs, doclen_fields, boost, offs, docs, fields, tfs, terms, k, deleted=()):
+    """intersection under all_terms_frequent, several indexed fields (add_result.rs:1595-1607) -> (doc ids, scores, total)"""
+    dl = np.ascontiguousarray(doclen_fields, np.uint8)
+    b = None if boost is None else np.ascontiguousarray(boost, np.float32)
+    offs = np.ascontiguousarray(offs, np.uint64)
+    docs = np.ascontiguousarray(docs, np.uint32)
+    fields = np.ascontiguousarray(fields, np.uint8)
+    tfs = np.ascontiguousarray(tfs, np.uint16)
+    q = np.ascontiguousarray(terms, np.uint32)
+    de = np.ascontiguousarray(deleted, np.uint64)
+    od = np.empty(max(k, 1), np.uint32)
+    os_ = np.empty(max(k, 1), np.float32)
+    tot = C.c_uint64()
+    fn = lib().so_search_fields_shortcut
+    fn.restype = C.c_uint32
+    fn.argtypes = [C.c_uint64, C.c_uint32, u8p, f32p, u64p, u32p, u8p, u16p, C.c_uint32, u32p, C.c_uint32, u64p, C.c_uint64, u32p, f32p,
+                   C.POINTER(C.c_uint64)]
+    n = fn(n_docs, dl.shape[0], _p(dl.reshape(-1), u8p), _p(b, f32p), _p(offs, u64p), _p(docs, u32p), _p(fields, u8p), _p(tfs, u16p),
+           len(q), _p(q, u32p), k, _p(de, u64p) if len(de) else None, len(de), _p(od, u32p), _p(os_, f32p), C.byref(tot))
+    return od[:n].copy(), os_[:n].copy(), tot.value
+
+
 def search_fields_phrase(n_docs, doclen_fields, boost, offs, docs, fields, tfs, positions, terms, seq, k, deleted=(), field_filter=(),
                          reference_loop=True):
     """phrase over several indexed fields (add_result.rs:2964-3414) -> (doc ids, scores, total)

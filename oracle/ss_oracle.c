@@ -1010,11 +1010,35 @@ uint32_t so_search_fields_exhaustive(uint64_t n_docs, uint32_t n_fields, const u
  * sums every field.  Restated for intersections and single-term queries, where "the terms it is matched on" is the whole
  * query; a union of several terms reaches add_result through union_docid_3's sub-queries (union.rs:1308-1479), whose
  * interplay with the filter is not a function of the doc alone -- not modelled. */
+static uint32_t fields_core(uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost, const uint64_t* off,
+                            const uint32_t* docs, const uint8_t* fields, const uint16_t* tfs, uint32_t nq, const uint32_t* qt,
+                            uint32_t n_not, const uint32_t* not_terms, int op, uint32_t k, const uint64_t* deleted, uint64_t n_deleted,
+                            uint32_t field_mask, int shortcut, uint32_t* od, float* os, uint64_t* total, float* out_avgdl);
 uint32_t so_search_fields_filtered(uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen /*[n_fields][n_docs]*/,
                                    const float* boost, const uint64_t* off, const uint32_t* docs, const uint8_t* fields,
                                    const uint16_t* tfs, uint32_t nq, const uint32_t* qt, uint32_t n_not,
                                    const uint32_t* not_terms, int op, uint32_t k, const uint64_t* deleted, uint64_t n_deleted,
                                    uint32_t field_mask, uint32_t* od, float* os, uint64_t* total, float* out_avgdl) {
+  return fields_core(n_docs, n_fields, doclen, boost, off, docs, fields, tfs, nq, qt, n_not, not_terms, op, k, deleted, n_deleted,
+                     field_mask, 0, od, os, total, out_avgdl);
+}
+/* an INTERSECTION under the all_terms_frequent shortcut, several indexed fields (decode_positions_multiterm_multifield returns
+ * true = "count the doc, do not rank it", add_result.rs:1595-1607, 3111-3122): for an embedded pointer always, for a record when its
+ * FIRST field has fewer than 10 positions.  A posting whose first field holds >= 10 positions is never embedded (index_posting.rs:
+ * 437: embedding stops at 4 positions), so: a doc is ranked only if, for every query term, the term's positions count in the LOWEST
+ * field that holds the doc is >= 10; every matching doc is counted.  The caller has checked the condition
+ * (so_all_terms_frequent's: N > 256 k, every df >= N / 2); no field filter (3116). */
+uint32_t so_search_fields_shortcut(uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost, const uint64_t* off,
+                                   const uint32_t* docs, const uint8_t* fields, const uint16_t* tfs, uint32_t nq, const uint32_t* qt,
+                                   uint32_t k, const uint64_t* deleted, uint64_t n_deleted, uint32_t* od, float* os, uint64_t* total) {
+  return fields_core(n_docs, n_fields, doclen, boost, off, docs, fields, tfs, nq, qt, 0, NULL, SO_OP_AND, k, deleted, n_deleted, 0u, 1,
+                     od, os, total, NULL);
+}
+static uint32_t fields_core(uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost, const uint64_t* off,
+                            const uint32_t* docs, const uint8_t* fields, const uint16_t* tfs, uint32_t nq, const uint32_t* qt,
+                            uint32_t n_not, const uint32_t* not_terms, int op, uint32_t k, const uint64_t* deleted, uint64_t n_deleted,
+                            uint32_t field_mask, int shortcut, uint32_t* od, float* os, uint64_t* total, float* out_avgdl) {
+  uint8_t* low = shortcut ? (uint8_t*)calloc(n_docs ? n_docs : 1, 1) : NULL;  /* some term's first field has < 10 positions */
   uint64_t psum = 0;
   for (uint64_t i = 0; i < n_docs * n_fields; i++) psum += so_byte4_to_int(doclen[i]);
   const float avgdl = so_avgdl(psum, n_docs);
@@ -1032,6 +1056,7 @@ uint32_t so_search_fields_filtered(uint64_t n_docs, uint32_t n_fields, const uin
       const float w = boost ? boost[fields[i]] : 1.0f;
       sc[d] += w * idf * ((float)tfs[i] * (SO_K + 1.0f) / ((float)tfs[i] + comp[doclen[(uint64_t)fields[i] * n_docs + d]]) + SO_SIGMA);
       if (i == off[qt[t]] || docs[i] != docs[i - 1]) {  // first entry of (term, doc): does the term pass the filter here?
+        if (low && tfs[i] < 10) low[d] = 1;             // ... = the doc's lowest field for this term
         int hit = field_mask == 0;
         for (uint64_t j = i; j < off[qt[t] + 1] && docs[j] == d && !hit; j++) hit = (field_mask >> fields[j]) & 1u;
         if (hit) cnt[d]++;
@@ -1046,12 +1071,12 @@ uint32_t so_search_fields_filtered(uint64_t n_docs, uint32_t n_fields, const uin
   so_sd* v = (so_sd*)malloc((m ? m : 1) * sizeof(so_sd));
   uint64_t j = 0;
   for (uint64_t d = 0; d < n_docs; d++)
-    if (cnt[d] != 0xFF && (op == SO_OP_AND ? cnt[d] == nq : cnt[d] > 0)) { v[j].score = sc[d]; v[j].doc = (uint32_t)d; j++; }
-  qsort(v, m, sizeof(so_sd), sd_cmp);
-  uint32_t n = (uint32_t)(m < k ? m : k);
+    if (cnt[d] != 0xFF && (op == SO_OP_AND ? cnt[d] == nq : cnt[d] > 0) && !(low && low[d])) { v[j].score = sc[d]; v[j].doc = (uint32_t)d; j++; }
+  qsort(v, j, sizeof(so_sd), sd_cmp);
+  uint32_t n = (uint32_t)(j < k ? j : k);
   for (uint32_t i = 0; i < n; i++) { od[i] = v[i].doc; os[i] = v[i].score; }
   if (total) *total = m;
-  free(v); free(cnt); free(sc);
+  free(v); free(cnt); free(sc); free(low);
   return n;
 }
 

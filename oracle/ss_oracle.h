@@ -128,6 +128,12 @@ uint32_t so_search_fields_filtered(uint64_t n_docs, uint32_t n_fields, const uin
                                    uint32_t n_q_terms, const uint32_t* q_terms, uint32_t n_not, const uint32_t* not_terms,
                                    int op, uint32_t k, const uint64_t* deleted, uint64_t n_deleted, uint32_t field_mask,
                                    uint32_t* out_doc, float* out_score, uint64_t* out_total, float* out_avgdl);
+/* an intersection under the all_terms_frequent shortcut over several indexed fields (add_result.rs:1595-1607, 3111-3122): every
+ * matching doc is counted, a doc is ranked only if every term has >= 10 positions in the lowest field that holds the doc */
+uint32_t so_search_fields_shortcut(uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost, const uint64_t* off,
+                                   const uint32_t* docs, const uint8_t* fields, const uint16_t* tfs, uint32_t n_q_terms,
+                                   const uint32_t* q_terms, uint32_t k, const uint64_t* deleted, uint64_t n_deleted, uint32_t* out_doc,
+                                   float* out_score, uint64_t* out_total);
 /* ---- phrase queries (QueryType::Phrase; phrase check add_result.rs:3586-3684, positions add_result.rs:38-59) ----
  * positions: for every posting in CSR order its tf positions (ascending, < 65 536 per field: index.rs:5343) */
 void so_shard_set_positions(so_shard*, const uint16_t* positions, uint64_t n_positions);

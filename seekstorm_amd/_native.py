@@ -80,6 +80,7 @@ SYMBOLS = [
     ("ss_set_deleted", C.c_int, [C.c_void_p, u64p, C.c_uint64]),
     ("ss_bm25_upload", C.c_int, [C.c_void_p, C.c_uint64, u8p, C.c_uint32, u64p, u32p, u16p]),
     ("ss_bm25_upload_positions", C.c_int, [C.c_void_p, C.c_uint64, u8p, C.c_uint32, u64p, u32p, u16p, u16p, C.c_uint64]),
+    ("ss_bm25_fields_info", C.c_int, [C.c_void_p, u32p, u32p, u32p]),
     ("ss_bm25_upload_fields", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, u8p, f32p, C.c_uint32, u64p, u32p, u8p, u16p]),
     ("ss_bm25_upload_fields_positions", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, u8p, f32p, C.c_uint32, u64p, u32p, u8p, u16p, u16p,
                                                   C.c_uint64]),

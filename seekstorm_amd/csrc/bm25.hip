@@ -193,7 +193,7 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
       }
       bad |= !bad && used != (1u << np) - 1u;  // every unique term is a word of the phrase
     }
-    bad |= bm_q_all_frequent(Q.op) && bm_q_op(Q.op) == SS_OP_INTERSECTION && np > 1 && !(claim & BM_CLAIM_FREQ);
+    bad |= bm_q_all_frequent(Q.op) && bm_q_op(Q.op) == SS_OP_INTERSECTION && np > 1 && ff == 0u && !(claim & BM_CLAIM_FREQ);
     if (!bad)
       for (uint32_t t = 0; t < np + n_not; t++) {
         bad |= Q.term[t] >= n_vterms / n_lists;
@@ -219,7 +219,8 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
   const bool mask = np <= 8;  // 9-10 terms (single field only, checked on the host): count instead of bits
   // all_terms_frequent (intersection.rs:198-209): the caller saw N > 256 k and df >= N / 2 for every term.  One field and
   // <= 7 terms (bit 7 of the match byte becomes the "some tf < 10" mark; the host refuses the rest).
-  const bool freq = bm_q_all_frequent(Q.op) && bm_q_op(Q.op) == SS_OP_INTERSECTION && np > 1 && np <= 7 && n_lists == 1;
+  // (several indexed fields: over the merged lists only -- a field filter switches the shortcut off, add_result.rs:3116)
+  const bool freq = bm_q_all_frequent(Q.op) && bm_q_op(Q.op) == SS_OP_INTERSECTION && np > 1 && np <= 7 && (n_lists == 1 || (use_merged && filt == 0u));
   // a UNION of several terms under a field filter (ss_common.h BM_AND_GATED): a term's listed fields first -- their postings add
   // and set the term's bit --, then its unlisted fields, which add only where the bit is set
   const bool gated = filt != 0u && bm_q_op(Q.op) == SS_OP_UNION && np > 1;

@@ -465,6 +465,14 @@ int ss_bm25_set_strategy(ss_shard* s, int strategy) {
   return SS_OK;
 }
 
+int ss_bm25_fields_info(ss_shard* s, uint32_t* n_fields, uint32_t* merged_lists, uint32_t* positions) {
+  if (!s) return SS_EINVAL;
+  if (!s->d_post) return SS_ESTATE;
+  if (n_fields) *n_fields = bm_real_fields(s);
+  if (merged_lists) *merged_lists = s->bm_merged ? 1u : 0u;
+  if (positions) *positions = (s->bm_n_fields == 1 ? s->d_pos != nullptr : s->d_pos32 != nullptr) ? 1u : 0u;
+  return SS_OK;
+}
 int ss_bm25_info(ss_shard* s, uint64_t* n_docs, float* avgdl, uint32_t* n_terms, uint64_t* n_postings) {
   if (!s) return SS_EINVAL;
   if (!s->d_post) return SS_ESTATE;
@@ -557,8 +565,11 @@ static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q,
     const uint32_t eff_fields = use_merged ? 1u : RF, f_begin = use_merged ? L - 1u : 0u, f_end = use_merged ? L : RF;
     // all_terms_frequent: an intersection of 2..7 terms over one indexed field (the mark takes bit 7 of the match byte);
     // on anything else the reference's flag has no effect we model (single terms, unions) or is not offered
-    if (bm_q_all_frequent(q[i].op) && op == SS_OP_INTERSECTION && q[i].n_terms > 1) {
-      if (q[i].n_terms > 7 || L > 1) return SS_ENOTSUP;
+    // (several indexed fields: over the merged lists, whose codes carry the multi-field form of the per-posting rule; under a field
+    // filter the reference switches the shortcut off -- add_result.rs:3116 "all_terms_frequent && field_filter_set.is_empty()" --
+    // and so does the expansion)
+    if (bm_q_all_frequent(q[i].op) && op == SS_OP_INTERSECTION && q[i].n_terms > 1 && !filt) {
+      if (q[i].n_terms > 7 || (L > 1 && !s->bm_merged)) return SS_ENOTSUP;
       *any_frequent = true;
     }
     if (eff_fields > 1) {  // (term, field) posting lists: at most BM_MAX_VTERMS of them, match masks of 8 bits

@@ -70,6 +70,13 @@ constexpr int SS_SYNTH_TF_MAX = 32;
 static inline bool bm_list_flagged(const ss_shard* s, uint64_t df) {
   return s->bm_n_fields == 1 && (float)df / (float)s->bm_n_docs >= 0.5f;
 }
+// several indexed fields: the MERGED list of such a term (its df is the term's posting_count) carries the multi-field form of the
+// rule in the same bit -- decode_positions_multiterm_multifield returns "counted, not ranked" for an embedded pointer and for a
+// record whose FIRST field has fewer than 10 positions (add_result.rs:1595-1607); a posting whose first field holds >= 10 positions
+// is never embedded (embedding stops at 4 positions, index_posting.rs:437), so the rule is "tf of the doc's lowest field < 10"
+static inline bool bm_merged_list_flagged(const ss_shard* s, uint64_t df) {
+  return s->bm_merged && (float)df / (float)s->bm_n_docs >= 0.5f;
+}
 static inline uint32_t bm_code_of(uint32_t tf, float comp_len, bool flagged) {
   uint32_t c = bm_wcode(bm_weight_exact(tf, comp_len));
   if (flagged) c = (c & ~1u) | (tf < 10u ? 1u : 0u);
@@ -156,12 +163,14 @@ int ssi_bm25_build_from_host_merged(ss_shard* s, const uint8_t* doclen, const ui
   // brings the largest weight under the code's 4.0.  The code spans 2^-14 .. 2^2; a corpus whose merged weights do not fit
   // (boosts very far apart) gets no merged lists rather than clamped scores.
   std::vector<float> mw;
+  std::vector<uint8_t> mw_lt10;  // tf of the doc's lowest field < 10 (bm_merged_list_flagged)
   std::vector<u64> mw_base;
   float mscale = 1.0f;
   if (s->bm_merged) {
     mw_base.assign(nt / L + 1, 0);
     for (uint32_t t = L - 1; t < nt; t += L) mw_base[t / L + 1] = mw_base[t / L] + (offs[t + 1] - offs[t]);
     mw.resize(mw_base[nt / L]);
+    mw_lt10.assign(mw_base[nt / L], 0);
     float wmin = 3.0e38f, wmax = 0.f;
     for (uint32_t t = L - 1; t < nt; t += L) {
       u64 fcur[8];
@@ -177,6 +186,7 @@ int ssi_bm25_build_from_host_merged(ss_shard* s, const uint8_t* doclen, const ui
             if (tfs[fcur[f]] == 0) return SS_EINVAL;
             const volatile float part = merged_boost[f] * bm_weight_exact(tfs[fcur[f]], comp[doclen[(size_t)f * s->bm_n_docs + docs[j]]]);
             w = w + part;
+            if (!any) mw_lt10[mw_base[t / L] + (j - offs[t])] = tfs[fcur[f]] < 10u ? 1 : 0;  // the lowest field that holds the doc
             any = true;
           }
         }
@@ -237,6 +247,7 @@ int ssi_bm25_build_from_host_merged(ss_shard* s, const uint8_t* doclen, const ui
         uint32_t code;
         if (merged) {
           code = bm_wcode(mw[mw_base[t / L] + (j - offs[t])] / mscale);
+          if (bm_merged_list_flagged(s, s->h_df[t])) code = (code & ~1u) | mw_lt10[mw_base[t / L] + (j - offs[t])];
         } else {
           code = bm_code_of(tfs[j], comp[dl[docs[j]]], flagged);
         }

@@ -289,10 +289,14 @@ int Shard::upload_facets(uint64_t n_docs, uint32_t record_size, const uint8_t* r
 
 // all_terms_frequent (intersection.rs:198-209), evaluated where the reference evaluates it -- on the host, per query:
 // N > top_k << 8 and posting_count / N >= 0.5 (f32) for every term of an intersection of several terms -> the query is
-// marked and ranks only docs whose every tf >= 10 (one indexed field, <= 7 terms).  Not under a field filter
+// marked and ranks only docs whose every tf >= 10 (<= 7 terms; several indexed fields: the tf in the doc's lowest field).  Not under a field filter
 // (add_result.rs:3545) -- nor under a facet filter (add_result.rs:2096-2100), which the caller knows about.
 bool Shard::mark_all_terms_frequent(ss_bm25_query* q, size_t top_k) const {
-  if (!h_ || lexical_fields_ != 1 || !(n_docs_ > ((uint64_t)top_k << 8))) return false;
+  if (!h_ || !(n_docs_ > ((uint64_t)top_k << 8))) return false;
+  if (lexical_fields_ != 1) {  // several indexed fields: over the image's merged lists (add_result.rs:1595-1607)
+    uint32_t merged = 0;
+    if (ss_bm25_fields_info(h_, nullptr, &merged, nullptr) != SS_OK || !merged) return false;
+  }
   if ((q->op & 0xFFu) != SS_OP_INTERSECTION || q->n_terms < 2 || q->n_terms > 7 || ((q->op >> 16) & 0x7FFFu)) return false;
   uint64_t df[SS_MAX_QUERY_TERMS];
   if (ss_bm25_term_df(h_, q->n_terms, q->term, df) != SS_OK) return false;

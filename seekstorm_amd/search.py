@@ -826,11 +826,18 @@ class Shard:
                                             N.ptr(out, N.u64p), C.byref(tot)), "ss_bm25_facet_count")
         return out[:nb].copy(), int(out[nb]), tot.value
 
+    def fields_info(self):
+        """(indexed fields, merged lists present, positions present) of the lexical image"""
+        nf, mg, ps = (np.zeros(1, np.uint32) for _ in range(3))
+        N.check(N.lib().ss_bm25_fields_info(self._h, N.ptr(nf, N.u32p), N.ptr(mg, N.u32p), N.ptr(ps, N.u32p)), "ss_bm25_fields_info")
+        return int(nf[0]), bool(mg[0]), bool(ps[0])
+
     def mark_all_terms_frequent(self, queries, k):
         """The reference's all_terms_frequent condition (intersection.rs:198-209), evaluated where the reference evaluates
         it -- on the host, per query: indexed_doc_count > top_k << 8 and posting_count / indexed_doc_count >= 0.5 (f32) for
         every term of an intersection of several terms.  Returns the queries with SS_OP_ALL_TERMS_FREQUENT set where it
-        holds (a copy if anything changed): such a query counts every match but ranks only docs whose every tf >= 10."""
+        holds (a copy if anything changed): such a query counts every match but ranks only docs whose every tf >= 10 (several
+        indexed fields: the tf in the lowest field that holds the doc, add_result.rs:1595-1607)."""
         if self.indexed_doc_count <= (int(k) << 8):
             return queries
         cand = np.nonzero(((queries["op"] & 0xFF) == int(QueryType.Intersection)) & (queries["n_terms"] > 1) &
@@ -853,10 +860,11 @@ class Shard:
 
     # ---- batched executors (one C-ABI call per batch)
     def search_lexical_batch(self, queries, k, result_type=ResultType.TopkCount, reference_shortcuts=True, facet_filter=None):
-        """reference_shortcuts: apply all_terms_frequent where its condition holds, as the reference does (one indexed field).
+        """reference_shortcuts: apply all_terms_frequent where its condition holds, as the reference does.
         facet_filter: see facet_filters(); shared by the queries of the call (a filtered doc neither counts nor ranks)"""
         # a facet filter disables the shortcut (add_result.rs:2096-2100: all_terms_frequent && !phrase_query && !facet_filtered)
-        if reference_shortcuts and result_type != ResultType.Count and self.lexical_field_count == 1 and not facet_filter:
+        if reference_shortcuts and result_type != ResultType.Count and not facet_filter and \
+                (self.lexical_field_count == 1 or self.fields_info()[1]):  # several fields: over the merged lists
             queries = self.mark_all_terms_frequent(queries, k)
         nq = len(queries)
         kk = max(int(k), 1)

@@ -305,3 +305,68 @@ def test_mixed_phrase_and_plain_batches_through_the_abi(S, O):
             for a, b in zip(mixed, alone):
                 assert np.array_equal(a[i], b[0]), (i, int(rt))
     sh.close()
+
+
+def test_all_terms_frequent_over_several_indexed_fields(S, O):
+    """decode_positions_multiterm_multifield's form of the shortcut (add_result.rs:1595-1607, 3111-3122): when N > 256 k and every
+    term of an intersection is in at least half of the docs, a doc is counted but ranked only if every term has >= 10 positions in the
+    LOWEST field that holds the doc (an embedded pointer -- <= 4 positions -- or a record whose first field has < 10).  Over the
+    image's merged lists; off under a field filter (3116); both mirrors mark the query like the reference"""
+    rng = np.random.default_rng(91)
+    n_docs, n_fields = 50_000, 3
+    dl = np.stack([O.lex_doclen(n_docs, seed=O.LEX_SEED + 3 * f) for f in range(n_fields)])
+    boost = np.array([1.5, 1.0, 0.5], np.float32)
+    dfs = [34_000, 30_000, 27_000, 6_000]
+    offs, D, F, T = [0], [], [], []
+    for df in dfs:
+        for d in np.sort(rng.choice(n_docs, df, replace=False)):
+            fs = np.sort(rng.choice(n_fields, size=int(rng.integers(1, n_fields + 1)), replace=False))
+            for f in fs:
+                D.append(int(d)); F.append(int(f)); T.append(int(min(rng.geometric(0.2), 600)))  # ~13 % of the entries have tf >= 10
+        offs.append(len(D))
+    offs, D, F, T = np.array(offs, np.uint64), np.array(D, np.uint32), np.array(F, np.uint8), np.array(T, np.uint16)
+    sh = S.Shard(0)
+    sh.upload_lexical_fields(n_docs, dl, boost, offs, D, F, T)
+    assert sh.fields_info() == (3, True, False)
+    gone = list(range(1, n_docs, 61))
+    sh.set_deleted(gone)
+    cases = [[0, 1], [0, 1, 2], [0, 3], [1, 2]]
+    flagged = [True, True, False, True]
+    q = sh.make_queries(cases, S.QueryType.Intersection)
+    rel = 1e-4
+    differs = 0
+    for k in (10, 150, 250):  # 50 000 > 256 * 150 but not > 256 * 250
+        marked = sh.mark_all_terms_frequent(q, k)
+        assert [bool(x >> 31) for x in marked["op"]] == [f and k < 250 for f in flagged]
+        for strat in (0, 1):
+            sh.set_strategy(strat)
+            for rt in (S.ResultType.TopkCount, S.ResultType.Topk):
+                doc, score, cnt, tot = sh.search_lexical_batch(q, k, rt)
+                for i, terms in enumerate(cases):
+                    plain = O.search_fields_exhaustive(n_docs, dl, boost, offs, D, F, T, terms, O.OP_AND, k, deleted=gone)
+                    if flagged[i] and k < 250:
+                        od, os_, otot = O.search_fields_shortcut(n_docs, dl, boost, offs, D, F, T, terms, k, deleted=gone)
+                        differs += int(not np.array_equal(od, plain[0]))
+                    else:
+                        od, os_, otot = plain[:3]
+                    if rt == S.ResultType.TopkCount:
+                        assert int(tot[i]) == otot == plain[2]
+                    n = int(cnt[i])
+                    assert n == len(od) and np.allclose(score[i][:n], os_, rtol=rel)
+                    if n:
+                        band = abs(float(os_[-1])) * rel
+                        clear = lambda dd, ss: {int(x) for x, y in zip(dd, ss) if y > os_[-1] + 2 * band}
+                        assert clear(doc[i][:n], score[i][:n]) <= set(od.tolist()) and clear(od, os_) <= set(doc[i][:n].tolist())
+    assert differs >= 6  # the shortcut really changes answers here
+    sh.set_strategy(0)
+    # under a field filter the reference switches the shortcut off: the marked bit changes nothing
+    qf = sh.make_queries([[0, 1]], S.QueryType.Intersection, field_filter=[0, 2])
+    a = sh.search_lexical_batch(qf, 10)
+    qm = qf.copy()
+    qm["op"][0] |= 0x80000000
+    b = sh.search_lexical_batch(qm, 10, reference_shortcuts=False)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    od, os_, otot, _ = O.search_fields_exhaustive(n_docs, dl, boost, offs, D, F, T, [0, 1], O.OP_AND, 10, deleted=gone, field_filter=[0, 2])
+    assert int(a[3][0]) == otot and np.allclose(a[1][0][:len(od)], os_, rtol=rel)
+    sh.close()
