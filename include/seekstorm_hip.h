@@ -321,7 +321,8 @@ typedef struct {
  * order.  A doc matches when it contains every unique term and some position p carries word i at p + i for every i
  * (add_result.rs:3596-3684: the merge over the entries' position lists, fewest positions first); it is scored like the
  * intersection of the unique terms (get_bm25f_multiterm_singlefield) and counted only when the phrase matches.  Needs the
- * positions in the image and every list with a probe row.  One indexed field: ss_bm25_upload_positions.  Several indexed fields
+ * positions in the image and every list with a probe row (on a rationed vocabulary the rows built on demand go to a batch's phrase
+ * queries first; SS_ENOTSUP when the pool cannot hold the lists of its phrases).  One indexed field: ss_bm25_upload_positions.  Several indexed fields
  * (ss_bm25_upload_fields_positions; add_result.rs:3248-3386): the phrase must stand inside ONE field, fields tried in ascending
  * order, only listed ones under SS_OP_FIELD_FILTER; the score sums all fields of the unique terms.  Host-pointer batches may mix
  * phrase queries with others (run as two sub-batches inside the library, answers back in the callers' order); a DEVICE-resident

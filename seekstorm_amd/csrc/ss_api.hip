@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <iterator>
 #include <new>
 #include <unordered_map>
 
@@ -676,7 +677,7 @@ __global__ void probe_row_fill_kernel(const uint32_t* __restrict__ pairs /* (lis
 // the lists of a term that a query reads: the merged list alone without a field filter (bm_merged images), else the fields'
 static inline void query_list_range(const ss_shard* s, const ss_bm25_query& q, uint32_t* f_begin, uint32_t* f_end) {
   const uint32_t L = s->bm_n_fields, RF = bm_real_fields(s);
-  const bool use_merged = s->bm_merged && !(RF > 1 && bm_q_field_filter(q.op));
+  const bool use_merged = s->bm_merged && (!(RF > 1 && bm_q_field_filter(q.op)) || bm_q_op(q.op) == SS_OP_PHRASE);  // (a phrase always reads the merged lists)
   *f_begin = use_merged ? L - 1u : 0u;
   *f_end = use_merged ? L : RF;
 }
@@ -687,8 +688,10 @@ static int ssi_bm25_ensure_probe_rows(ss_shard* s, uint32_t nq, const ss_bm25_qu
   if (s->probe_pool_rows == 0 || !s->d_probe) return SS_OK;
   const uint32_t n_lists_per_term = s->bm_n_fields, n_public = s->bm_n_terms / s->bm_n_fields;
   const uint64_t now = ++s->pool_clock;
-  std::vector<uint32_t> missing;
+  // phrase queries first: without rows for all of their lists they have no kernel at all (the others fall back to the scans)
+  std::vector<uint32_t> missing, missing_phrase;
   for (uint32_t i = 0; i < nq; i++) {
+    const bool is_phrase = bm_q_op(q[i].op) == SS_OP_PHRASE;
     const uint32_t all = std::min<uint32_t>(q[i].n_terms + bm_q_nnot(q[i].op), SS_MAX_QUERY_TERMS);
     uint32_t f_begin, f_end;
     query_list_range(s, q[i], &f_begin, &f_end);
@@ -699,13 +702,21 @@ static int ssi_bm25_ensure_probe_rows(ss_shard* s, uint32_t nq, const ss_bm25_qu
         if (r != BM_NO_PROBE_ROW && r >= s->probe_pool_begin && r < s->probe_pool_begin + s->probe_pool_rows)
           s->pool_tick[r - s->probe_pool_begin] = now;  // a pool row this batch needs: not a victim
         else if (list_needs_row(s, v))
-          missing.push_back(v);
+          (is_phrase ? missing_phrase : missing).push_back(v);
       }
     }
   }
-  if (missing.empty()) return SS_OK;
+  if (missing.empty() && missing_phrase.empty()) return SS_OK;
+  std::sort(missing_phrase.begin(), missing_phrase.end());
+  missing_phrase.erase(std::unique(missing_phrase.begin(), missing_phrase.end()), missing_phrase.end());
   std::sort(missing.begin(), missing.end());
   missing.erase(std::unique(missing.begin(), missing.end()), missing.end());
+  {
+    std::vector<uint32_t> rest;
+    std::set_difference(missing.begin(), missing.end(), missing_phrase.begin(), missing_phrase.end(), std::back_inserter(rest));
+    missing = missing_phrase;
+    missing.insert(missing.end(), rest.begin(), rest.end());
+  }
   // victims: free rows first, then the least recently used ones, never a row of this batch
   std::vector<uint32_t> victims;
   for (uint32_t i = 0; i < s->probe_pool_rows; i++)
