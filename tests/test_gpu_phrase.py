@@ -290,29 +290,30 @@ def test_phrase_queries_take_the_pool_rows_first_on_a_rationed_vocabulary(S, O):
     rows built on demand go to a batch's phrase queries first; the other queries of the batch whose lists found no row are answered by
     the scan kernels.  Same answers as the unrationed shard; a batch whose phrases alone exceed the pool is refused loudly."""
     n_docs = 120_000
-    dfs = [int(120_000 * 0.25 / (1 + 0.6 * i)) for i in range(24)]
-    plant = [([20, 21], 200), ([22, 23, 20], 90), ([18, 19], 120), ([2, 3], 300)]
+    dfs = [int(120_000 * 0.25 / (1 + 0.3 * i)) for i in range(48)]
+    plant = [([40, 41], 200), ([42, 43, 40], 90), ([44, 45], 120), ([2, 3], 300)]
     dl, offs, docs, tfs, positions = _corpus(O, n_docs, dfs, 31, plant)
     full, part = S.Shard(0), S.Shard(0)
     full.upload_lexical(n_docs, dl, offs, docs, tfs, positions)
     n_sub = (n_docs + 4095) // 4096
-    part.set_probe_budget((16 + 1) * n_sub * 64 * 12)   # 16 rows for 24 lists: 12 fixed (the longest) + a pool of 4
+    part.set_probe_budget((40 + 1) * n_sub * 64 * 12)   # 40 rows for 48 lists: 30 fixed (the longest) + a pool of 10
     part.upload_lexical(n_docs, dl, offs, docs, tfs, positions)
-    assert not part.terms_probed([20, 21, 22, 23]).any()
-    # one batch: unions over row-less lists in front, then the phrases (their 4 lists take the whole pool)
-    tl = [[12, 13, 14], [15, 16], [17, 18, 19], [20, 21], [22, 23, 20], [2, 3]]
-    qt = [S.QueryType.Union] * 3 + [S.QueryType.Phrase] * 3
+    assert not part.terms_probed(list(range(30, 48))).any()
+    # one batch: unions over 12 row-less lists in front, then the phrases over 6 more -- 18 lists for a pool of 10
+    tl = [[30, 31, 32], [33, 34, 35], [36, 37, 38], [39, 46, 47], [40, 41], [42, 43, 40], [44, 45], [2, 3]]
+    qt = [S.QueryType.Union] * 4 + [S.QueryType.Phrase] * 4
     for k in (10, 100):
         a = full.search_lexical_batch(full.make_queries(tl, qt), k)
         b = part.search_lexical_batch(part.make_queries(tl, qt), k)
         assert all(np.array_equal(x, y) for x, y in zip(a, b)), k
-    assert int(a[3][3]) >= 200 and int(a[3][4]) >= 90
-    # five row-less lists in phrases > a pool of four
+    assert int(a[3][4]) >= 200 and int(a[3][5]) >= 90 and int(a[3][6]) >= 120
+    assert part.terms_probed([40, 41, 42, 43, 44, 45]).all()
+    # eleven row-less lists in phrases > a pool of ten
     with pytest.raises(S.SeekStormHipError):
-        part.search_lexical_batch(part.make_queries([[20, 21], [22, 23], [19, 18]], S.QueryType.Phrase), 10)
+        part.search_lexical_batch(part.make_queries([[30, 31, 32, 33], [34, 35, 36, 37], [38, 39, 46]], S.QueryType.Phrase), 10)
     # and the next batch that fits is answered again
-    b = part.search_lexical_batch(part.make_queries([[18, 19]], S.QueryType.Phrase), 10)
-    a = full.search_lexical_batch(full.make_queries([[18, 19]], S.QueryType.Phrase), 10)
+    b = part.search_lexical_batch(part.make_queries([[44, 45]], S.QueryType.Phrase), 10)
+    a = full.search_lexical_batch(full.make_queries([[44, 45]], S.QueryType.Phrase), 10)
     assert all(np.array_equal(x, y) for x, y in zip(a, b)) and int(a[3][0]) >= 120
     full.close()
     part.close()
