@@ -91,6 +91,8 @@ __device__ __forceinline__ uint32_t s16_read(const u32x4 v, float fidf, uint32_t
   }
   return mx;
 }
+// (An LDS atomic for the middle term -- ds_add_rtn_u32 on the dword holding the 16-bit entry, one operation instead of read +
+// write -- was measured: 1.78 ms against 1.08 ms per 1000 C2 queries.  Returning LDS atomics run far below the plain pipe's rate.)
 template <bool CNT>
 __device__ __forceinline__ uint32_t s16_keep(const u32x4 v, float fidf, uint32_t accb, uint32_t mx, uint32_t& cnt) {
   uint32_t nw[4];
