@@ -181,11 +181,22 @@ __device__ __forceinline__ void s16_clear_tile(uint32_t wb, int lane) {
 // 1 / 1 / 3 chunks -- 5 x 4 registers per buffer where round 2 kept 2 / 2 / 2 = 6 x 4 -- and the longest list of a C2 query (up to
 // 15 % of a sub-block = 614 postings) fits without the synchronous remainder loop, which used to cost every item of the 17 % of
 // the queries whose third term lies above 12.5 % a full memory round trip.
+// Two terms: 1 / 4 (the 2-term intersections of the bench -- a 1-5 % list with a 5-20 % one -- went from 1.55 to 1.32 ms per 1000
+// queries against 2 / 3, unions of two terms are unchanged); four terms: 1 / 1 / 1 / 3 (C2's three terms + a 0.2-0.5 % one: 1.88 ->
+// 1.34 ms against 2 chunks per term, same answers).  S16_NT4_LAST / S16_NT1: experiment knobs (tools/probes/scan16_ab.py).
+#ifndef S16_NT4_LAST
+#define S16_NT4_LAST 3  // 0: 2 chunks per term; n: 1 / 1 / 1 / n
+#endif
+#ifndef S16_NT1
+#define S16_NT1 2
+#endif
 template <int NT> struct S16Cfg {
-  static constexpr int cpt(int t) { return NT == 3 ? (t == 2 ? 3 : 1) : NT == 2 ? (t == 1 ? 3 : 2) : 2; }
+  static constexpr int cpt(int t) {
+    return NT == 3 ? (t == 2 ? 3 : 1) : NT == 2 ? (t == 1 ? 4 : 1) : NT == 1 ? S16_NT1 : (S16_NT4_LAST ? (t == NT - 1 ? S16_NT4_LAST : 1) : 2);
+  }
   static constexpr int off(int t) { int o = 0; for (int i = 0; i < t; i++) o += cpt(i); return o; }
   static constexpr int RC = off(NT);
-  static constexpr int CPTMAX = 3;
+  static constexpr int CPTMAX = 4;
 };
 template <int RC> struct S16Cur { u32x4 v[RC]; };
 template <int NT> struct S16Item {
