@@ -51,6 +51,9 @@ def H():
     L.ssh_index_search_sorted.argtypes = [C.c_void_p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                           C.c_uint32, C.c_uint32, u64p, f32p, u64p]
     L.ssh_upload_lexical_fields.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, u8p, f32p, C.c_uint32, u64p, u32p, u8p, u16p]
+    L.ssh_upload_lexical_fields_positions.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, u8p, f32p, C.c_uint32, u64p, u32p, u8p, u16p,
+                                                      u16p, C.c_uint64]
+    L.ssh_set_deleted.argtypes = [C.c_void_p, C.c_int, u64p, C.c_uint64]
     L.ssh_facet_count.argtypes = [C.c_void_p, C.c_int, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u64p, C.c_uint32,
                                   C.c_void_p, C.c_uint32, C.c_void_p, u64p, u64p]
     L.ssh_coalesced_vector_search.argtypes = [C.c_void_p, C.c_int, C.c_uint32, f32p, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -290,12 +293,22 @@ def test_cpp_shard_ann_modes(H):
                                                  C.byref(ncl))
             assert int(meta[3]) == 0
             if kw is None:
-                od, os_, _, _ = O.vec_search_i8(rows, q8, k)
+                od, os_, _, oobs = O.vec_search_i8(rows, q8, k)
                 assert ncl.value == 11
             else:
-                od, os_, _, _, oncl = O.vec_search_i8_ann(rows, q8, k, lc, child, **kw)
+                od, os_, _, oobs, oncl = O.vec_search_i8_ann(rows, q8, k, lc, child, **kw)
                 assert ncl.value == oncl
             assert nres == len(od) and np.array_equal(sc[:nres], os_)
+            assert int(meta[2]) == oobs  # observed_vector_count: the records of the visited clusters (vector.rs:421, 1510)
+        # ... and with tombstones only the live ones, in AnnMode::All too
+        gone = np.array([3, 40, 41, 500], np.uint64)
+        assert H.ssh_set_deleted(ix, 0, P(gone, u64p), len(gone)) == 0
+        for kind, n, kw in ((2, 2, dict(n_probe=2)), (0, 0, {})):
+            meta = np.zeros(4, np.uint64)
+            H.ssh_search_vector_shard_ann(ix, 0, P(qv, f32p), k, kind, n, 0.0, k, P(doc, u64p), P(sc, f32p), P(meta, u64p), None)
+            oobs = (O.vec_search_i8_ann(rows, q8, k, lc, child, deleted=gone, **kw) if kw else O.vec_search_i8_ann(rows, q8, k, None, None, deleted=gone))[3]
+            assert int(meta[3]) == 0 and int(meta[2]) == oobs
+        assert H.ssh_set_deleted(ix, 0, None, 0) == 0
         # Nprobe(0) has no TopK slot to push into: refused, the mirror degrades to an empty result with the code kept
         meta = np.zeros(4, np.uint64)
         assert H.ssh_search_vector_shard_ann(ix, 0, P(qv, f32p), k, 2, 0, 0.0, k, P(doc, u64p), P(sc, f32p), P(meta, u64p), None) == 0
@@ -592,6 +605,41 @@ def test_cpp_shard_union_under_a_field_filter(H):
     finally:
         H.ssh_index_destroy(ix)
         psh.close()
+
+
+@pytest.mark.gpu
+def test_cpp_shard_phrase_over_several_fields(H):
+    """QueryType::Phrase through the C++ mirror on an image with several indexed fields (positions per (term, doc, field) entry;
+    add_result.rs:3248-3386), with and without a field filter, against the oracle; and the multi-field all_terms_frequent marking"""
+    from oracle import oracle as O
+    from test_gpu_phrase import _corpus_fields
+    n_docs, n_fields = 80_000, 3
+    dfs = [45_000, 42_000, 9_000, 6_000]
+    plant = [([0, 1], 0, 200), ([0, 1, 2], 1, 90), ([3, 2], 2, 50), ([1, 1], 2, 40)]
+    dl, offs, docs, fields, tfs, positions = _corpus_fields(O, n_docs, n_fields, dfs, 29, plant, [(0, 1, 150)])
+    boost = np.array([1.5, 1.0, 0.5], np.float32)
+    ix = H.ssh_index_create(1, None)
+    try:
+        dlc = np.ascontiguousarray(dl, np.uint8)
+        assert H.ssh_upload_lexical_fields_positions(ix, 0, n_docs, n_fields, P(dlc.reshape(-1), u8p), P(boost, f32p), len(offs) - 1,
+                                                     P(offs, u64p), P(docs, u32p), P(fields, u8p), P(tfs, u16p), P(positions, u16p),
+                                                     len(positions)) == 0
+        for filt in ((), (0,), (1, 2)):
+            for ph in ([0, 1], [0, 1, 2], [3, 2], [1, 1], [1, 0]):
+                uniq = list(dict.fromkeys(ph))
+                od, os_, otot = O.search_fields_phrase(n_docs, dl, boost, offs, docs, fields, tfs, positions, uniq, [uniq.index(w) for w in ph], 10,
+                                                       field_filter=filt)
+                cd, cs, ctot = _cpp_lexical_ex(H, ix, ph, 2, 0, 10, 2, field_filter=filt)  # QueryType::Phrase = 2, TopkCount
+                assert ctot == otot, (filt, ph, ctot, otot)
+                assert len(cd) == len(od) and np.allclose(cs, os_, rtol=REL)
+        # terms 0 and 1 are in more than half of the docs and 80 000 > 256 * 10: the mirror marks the intersection like the reference
+        od, os_, otot = O.search_fields_shortcut(n_docs, dl, boost, offs, docs, fields, tfs, [0, 1], 10)
+        plain = O.search_fields_exhaustive(n_docs, dl, boost, offs, docs, fields, tfs, [0, 1], O.OP_AND, 10)
+        cd, cs, ctot = _cpp_lexical_ex(H, ix, [0, 1], 1, 0, 10, 2)
+        assert ctot == otot == plain[2] and len(cd) == len(od) and np.allclose(cs, os_, rtol=REL)
+        assert not np.array_equal(plain[0], od)
+    finally:
+        H.ssh_index_destroy(ix)
 
 
 @pytest.mark.gpu
