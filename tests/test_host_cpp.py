@@ -635,7 +635,7 @@ def test_cpp_shard_phrase_over_several_fields(H):
         # terms 0 and 1 are in more than half of the docs and 80 000 > 256 * 10: the mirror marks the intersection like the reference
         od, os_, otot = O.search_fields_shortcut(n_docs, dl, boost, offs, docs, fields, tfs, [0, 1], 10)
         plain = O.search_fields_exhaustive(n_docs, dl, boost, offs, docs, fields, tfs, [0, 1], O.OP_AND, 10)
-        cd, cs, ctot = _cpp_lexical_ex(H, ix, [0, 1], 1, 0, 10, 2)
+        cd, cs, ctot = _cpp_lexical_ex(H, ix, [0, 1], 0, 0, 10, 2)  # QueryType::Intersection = 0
         assert ctot == otot == plain[2] and len(cd) == len(od) and np.allclose(cs, os_, rtol=REL)
         assert not np.array_equal(plain[0], od)
     finally:
