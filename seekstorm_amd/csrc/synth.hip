@@ -43,9 +43,32 @@ __global__ void vec_synth_kernel(float* __restrict__ X, u64 seed, u64 n_rows, ui
   }
 }
 
+// SURVEY 8d's own generator for the rows -- Box-Muller N(0, 1) components, then normalize_f32 -- as a device-only EXPERIMENT
+// (SS_VEC_SYNTH_BOXMULLER=1): f32 log / cos differ between the host's libm and the device, so no oracle can regenerate these rows
+// and no parity test uses them; tools/probes/generators_ab.sh shows that the scan's throughput does not depend on the choice.
+__global__ void vec_synth_boxmuller_kernel(float* __restrict__ X, u64 seed, u64 n_rows, uint32_t dim, uint32_t dim_pad, u64 gs, u64 go) {
+  u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  float* row = X + r * dim_pad;
+  r = r * gs + go;
+  auto comp = [&](uint32_t c) {
+    const u64 h = ss_h(seed, r, c);
+    const float u1 = ((float)(uint32_t)(h >> 32) + 1.0f) * 2.3283064365386963e-10f;  // (0, 1]
+    const float u2 = (float)(uint32_t)h * 2.3283064365386963e-10f;
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+  };
+  float s = 0.f;
+  for (uint32_t c = 0; c < dim; c++) { const float v = comp(c); s += v * v; }
+  const float f = 1.0f / sqrtf(s);
+  for (uint32_t c = 0; c < dim; c++) row[c] = comp(c) * f;
+}
+
 int ssi_vec_synth(ss_shard* s, uint64_t seed, hipStream_t st) {
   u64 n = s->n_rows;
   uint32_t grid = (uint32_t)((n + 255) / 256);
+  static const bool boxmuller = [] { const char* e = getenv("SS_VEC_SYNTH_BOXMULLER"); return e && atoi(e) != 0; }();
+  if (boxmuller) vec_synth_boxmuller_kernel<<<grid, 256, 0, st>>>(s->d_X, seed, n, s->dim, s->dim_pad, s->synth_stride, s->synth_offset);
+  else
   vec_synth_kernel<<<grid, 256, 0, st>>>(s->d_X, seed, n, s->dim, s->dim_pad, s->synth_stride, s->synth_offset);
   SS_HIP(hipGetLastError());
   return SS_OK;
