@@ -253,6 +253,142 @@ vec_scan_kernel(const float* __restrict__ X, uint32_t dim_pad, unsigned long lon
   }
 }
 
+// ---------------------------------------------------------------- ANN batches: the sparse instantiation
+// A batch of independent queries under AnnMode::Nprobe selects, per query, n_probe of every level's clusters; the batch's UNION of
+// tiles is nearly the whole image (64 queries x 16 of 256 clusters: 98 %), but a given tile concerns only a few of the queries
+// (4 of 64 on average).  The MFMA kernel above still multiplies every tile with all 64 queries -- the whole brute-force work plus
+// the preparation.  This kernel does the arithmetic only for the queries a tile concerns, on the VALU: per tile the interested
+// queries are found from the selection bitmaps; up to 8 at a time are staged in LDS (3 KB each at dim 768, one copy per
+// workgroup); the tile's rows stream from HBM straight into registers (a wave reads one row per instruction group, fully
+// coalesced, dim / 64 components per lane), four rows at a time, and every query vector read from LDS is used for the four of
+// them.  The 4 x 8 partial sums are summed over the wave by a transposing butterfly -- 16 + 8 + 4 + 2 + 1 exchanges leave lane L
+// with the sum over its 32-lane half of value L & 31, one more adds the halves: 8 exchanges per row instead of 48 -- after which
+// lane L < 32 holds the score of (row L >> 3, query slot L & 7).  The pass is then bound by HBM, not by the matrix cores.
+// f32 dot / cosine, dim = dim_pad a multiple of 256; everything else (and batches of <= 32 queries, whose MFMA pass is HBM bound
+// already) keeps the kernel above.  The summation order differs from the MFMA kernel's (and from the reference's avx2 order), inside
+// the same 1e-4 tolerance.
+template <int NV>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) vec_ann_sparse_kernel(const float* __restrict__ X, uint32_t dim_pad, unsigned long long n_rows,
+                                                            const float* __restrict__ Q, uint32_t nb, uint32_t tile0, uint32_t ntiles,
+                                                            VState* __restrict__ st, unsigned long long* __restrict__ cand, VAnn ann) {
+  __shared__ __attribute__((aligned(16))) float qs[8 * NV * 256];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (st->ovf) return;
+  {
+    const uint32_t na = *ann.n_tiles;
+    ntiles = na > tile0 ? min(ntiles, na - tile0) : 0u;
+  }
+  const float tau_l = st->tau[lane];  // lane q holds query q's threshold (fixed during a launch)
+  const uint32_t W = ann.sel_words;
+  const uint32_t slot = (uint32_t)lane & 7u;
+  for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const unsigned long long tix = ann.tiles[tile0 + t];
+    const unsigned long long row0 = tix * VS_TR;
+    if (row0 >= n_rows) continue;  // (uniform over the workgroup)
+    const unsigned long long rlast = min(row0 + (unsigned long long)VS_TR, n_rows) - 1ull;
+    const uint32_t c_lo = ann.row_cluster[row0], c_hi = ann.row_cluster[rlast];
+    // the queries this tile concerns: some selected cluster among the tile's (the same mask in all four waves)
+    bool intr = false;
+    if ((uint32_t)lane < nb)
+      for (uint32_t x = c_lo >> 5; x <= (c_hi >> 5); x++) {
+        uint32_t m = 0xFFFFFFFFu;
+        if (x == (c_lo >> 5)) m &= 0xFFFFFFFFu << (c_lo & 31u);
+        if (x == (c_hi >> 5)) m &= 0xFFFFFFFFu >> (31u - (c_hi & 31u));
+        intr = intr || (ann.sel[(size_t)lane * W + x] & m) != 0u;
+      }
+    unsigned long long im = __ballot(intr);
+    while (im) {
+      // up to 8 of them: their indices are uniform
+      uint32_t qidx[8];
+      uint32_t nqk = 0;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        if (im) { qidx[j] = (uint32_t)__builtin_ctzll(im); im &= im - 1ull; nqk++; }
+        else qidx[j] = qidx[0];
+      }
+      __syncthreads();  // the previous chunk's readers are done with qs
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        for (uint32_t e = (uint32_t)tid; e < (uint32_t)NV * 64u; e += 256u)
+          *(f32x4*)(qs + (uint32_t)j * NV * 256u + e * 4u) = *(const f32x4*)(Q + (size_t)qidx[j] * dim_pad + e * 4u);
+      __syncthreads();
+      uint32_t my_q = qidx[0];
+#pragma unroll
+      for (int j = 1; j < 8; j++) my_q = slot == (uint32_t)j ? qidx[j] : my_q;
+      const float my_tau = __shfl(tau_l, (int)my_q);
+      const unsigned long long wrow0 = row0 + 32ull * (unsigned long long)w;
+      auto load4 = [&](f32x4(&x)[4][NV], uint32_t g) {  // rows 4 g .. 4 g + 3 of my 32
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          unsigned long long rr = wrow0 + 4u * g + (uint32_t)r;
+          rr = rr < n_rows ? rr : n_rows - 1ull;  // rows past the end are computed and dropped
+          const float* xr = X + rr * dim_pad + (uint32_t)lane * 4u;
+#pragma unroll
+          for (int v = 0; v < NV; v++) x[r][v] = *(const f32x4*)(xr + (uint32_t)v * 256u);
+        }
+      };
+      auto group = [&](const f32x4(&x)[4][NV], uint32_t g) {
+        float a[32];  // a[r * 8 + j]: row r of the group, query slot j -- my lane's part of the dot product
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          f32x4 qv[NV];
+#pragma unroll
+          for (int v = 0; v < NV; v++) qv[v] = *(const f32x4*)(qs + (uint32_t)j * NV * 256u + (uint32_t)v * 256u + (uint32_t)lane * 4u);
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            float acc = 0.f;
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+              acc = __builtin_fmaf(x[r][v][0], qv[v][0], acc);
+              acc = __builtin_fmaf(x[r][v][1], qv[v][1], acc);
+              acc = __builtin_fmaf(x[r][v][2], qv[v][2], acc);
+              acc = __builtin_fmaf(x[r][v][3], qv[v][3], acc);
+            }
+            a[r * 8 + j] = acc;
+          }
+          __builtin_amdgcn_sched_barrier(0);  // one query vector live at a time (the scheduler would hoist all 8 x NV LDS reads: 96 registers)
+        }
+        // 32 values -> 1 over the lane bits 4 .. 0: the lane with the bit set keeps the upper half
+#pragma unroll
+        for (int h = 16; h >= 1; h >>= 1) {
+          const bool up = ((uint32_t)lane & (uint32_t)h) != 0u;
+#pragma unroll
+          for (int i = 0; i < h; i++) {
+            const float keep = up ? a[i + h] : a[i];
+            const float send = up ? a[i] : a[i + h];
+            a[i] = keep + __shfl_xor(send, h);
+          }
+        }
+        const float score = a[0] + __shfl_xor(a[0], 32);  // value index lane & 31 = (row (lane >> 3) & 3, slot lane & 7)
+        const unsigned long long row = wrow0 + 4u * g + (((uint32_t)lane >> 3) & 3u);
+        bool ok = lane < 32 && slot < nqk && row < n_rows && score > my_tau;
+        if (ok) {
+          const uint32_t c = ann.row_cluster[row];
+          ok = (ann.sel[(size_t)my_q * W + (c >> 5)] >> (c & 31u)) & 1u;
+          if (ok && ann.row_field) {
+            const uint32_t fld = ann.row_field[row];
+            ok = fld < 64u && ((ann.field_mask >> fld) & 1ull);
+          }
+        }
+        if (ok) {
+          const uint32_t at = atomicAdd(&st->cnt[my_q * VS_CNT_STRIDE], 1u);
+          if (at < VS_CAP) cand[(size_t)my_q * VS_CAP + at] = mk_key(score, (uint32_t)row);
+        }
+      };
+      // no software prefetch: four waves per SIMD, each with its four rows (dim x 16 B) in flight, cover the memory latency
+      // between them, and the registers a second buffer would take are what keeps them at four
+#pragma unroll 1
+      for (uint32_t g = 0; g < 8u; g++) {
+        f32x4 xa[4][NV];
+        load4(xa, g);
+        group(xa, g);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- refine: exact top-k of the candidates, raise tau
 // One workgroup per query.  Sorts the (<= VS_CAP) candidate keys descending in LDS (bitonic), keeps the best k
 // at the front of the buffer, sets tau = k-th best score (TopK::push admits only score > current minimum).
@@ -572,12 +708,27 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float*
       ann.field_mask = ann_mode->field_mask;
     }
     uint32_t tile0 = 0;
+    // the sparse ANN instantiation (vec_ann_sparse_kernel): a batch of more than 32 queries under Nprobe whose tiles concern few
+    // of its queries each -- expected interested queries per tile = nb x n_probe / (clusters per level) <= 8
+    uint32_t sparse_nv = 0;
+    {
+      static const int sparse_on = [] { const char* e = getenv("SS_VEC_ANN_SPARSE"); return e ? atoi(e) : 1; }();
+      if (sparse_on && ann_clusters && !i8 && !euclid && nb > 32 && ann_mode->n_probe != 0 && s->dim == s->dim_pad && s->dim % 256u == 0 &&
+          s->dim <= 1024u && s->vec_n_clusters && (double)nb * ann_mode->n_probe * s->vec_n_levels <= 8.0 * s->vec_n_clusters)
+        sparse_nv = s->dim / 256u;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     ssi_prof_begin(s, 1, st, &e0, &e1);
     for (uint32_t c : chunks) {
       uint32_t grid = std::min<uint32_t>(c, 512);
       if (i8) ssi_vec8_launch_scan(s, tile0, c, d_qscale ? d_qscale + g0 : nullptr, ann_mode ? &ann : nullptr, st);
-      else if (ann_mode) {
+      else if (ann_mode && sparse_nv) {
+        const uint32_t sg = std::min<uint32_t>(c, 1024);
+        const float* qraw = (const float*)d_queries + (size_t)g0 * s->dim;
+#define SS_SPARSE(NV_) vec_ann_sparse_kernel<NV_><<<sg, 256, 0, st>>>(s->d_X, s->dim_pad, (unsigned long long)s->n_rows, qraw, nb, tile0, c, vst, cand, ann)
+        if (sparse_nv == 1) SS_SPARSE(1); else if (sparse_nv == 2) SS_SPARSE(2); else if (sparse_nv == 3) SS_SPARSE(3); else SS_SPARSE(4);
+#undef SS_SPARSE
+      } else if (ann_mode) {
         if (nb > 32)
           vec_scan_kernel<true, true><<<grid, VS_WAVES * 64, VS_LDS, st>>>(s->d_X, s->dim_pad, (unsigned long long)s->n_rows,
                                                                            s->d_Qf, nch, tile0, c, vst, cand, ann);

@@ -413,3 +413,46 @@ def test_observed_vector_count_in_every_mode(S, O, i8):
     sh.set_deleted([])
     assert sh.search_vector_shard(q32[0], 10).observed_vector_count == n
     sh.close()
+
+
+@pytest.mark.parametrize("dim", [256, 768])
+def test_ann_sparse_batches_match_oracle(S, O, dim):
+    """batches of more than 32 queries under Nprobe on an f32 image whose dim is a multiple of 256 take the sparse kernel (per tile only
+    the queries that selected one of its clusters are multiplied, on the VALU): same clusters, same answers as the oracle, with a
+    field filter, several records per doc and tombstones; a second chunk of 8 queries per tile (every query on the same clusters)"""
+    lc = [40, 36]
+    rows, child = clustered(O, 301 + dim, lc, dim, lo=30, hi=150)
+    n = len(rows)
+    rng = np.random.default_rng(302)
+    rf = rng.integers(0, 3, n).astype(np.uint16)
+    ids = (np.arange(n) // 2).astype(np.uint32)
+    qs = queries_near(O, rows, 303, 48)
+    sh = S.Shard(0)
+    sh.upload_vectors(rows, row_doc_ids=ids)
+    sh.set_fields(rf)
+    sh.set_clusters(lc, child)
+    gone = [int(x) for x in rng.choice(n // 2, 30, replace=False)]
+    k = 20
+    for deleted in ([], gone):
+        sh.set_deleted(deleted)
+        for npb in (2, 3):
+            for fields in ((), [1]):
+                doc, score, cnt, tot, ncl, obs = sh.search_vector_batch(qs, k, ann_mode=S.AnnMode.Nprobe(npb), field_filter=fields, with_observed=True)
+                for i in range(len(qs)):
+                    od, os_, otot, oobs, oncl = O.vec_search_ann(rows, qs[i], k, lc, child, row_doc_ids=ids, row_field=rf if fields else None,
+                                                                 fields=fields, deleted=deleted, n_probe=npb, simd_order=True)
+                    c = int(cnt[i])
+                    assert c == len(od) and int(ncl[i]) == oncl and int(obs[i]) == oobs, (dim, npb, fields, i)
+                    assert np.allclose(score[i][:c], os_, rtol=REL, atol=2e-6)
+                    band = abs(float(os_[-1])) * REL + 2e-6
+                    strict = lambda dd, ss: {int(x) for x, y in zip(dd, ss) if y > os_[-1] + band}
+                    assert strict(doc[i][:c], score[i][:c]) == strict(od, os_)
+    sh.set_deleted([])
+    # 40 copies of ONE query: every tile of its clusters concerns 40 queries -- five chunks of 8 per tile
+    same = np.repeat(qs[:1], 40, axis=0)
+    doc, score, cnt, tot = sh.search_vector_batch(same, k, ann_mode=S.AnnMode.Nprobe(2))
+    od, os_, _, _, _ = O.vec_search_ann(rows, qs[0], k, lc, child, row_doc_ids=ids, n_probe=2)
+    for i in range(40):
+        assert int(cnt[i]) == len(od) and np.array_equal(doc[i], doc[0]) and np.array_equal(score[i], score[0])
+    assert np.allclose(score[0][:len(od)], os_, rtol=REL, atol=2e-6)
+    sh.close()
