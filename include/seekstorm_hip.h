@@ -511,7 +511,10 @@ int ss_vec_search_i8_dev(ss_shard* s, uint32_t n_queries, const int8_t* d_querie
  * Medoid similarity uses the reference's own summation order (dot_f32_avx2's 8 fmadd lanes when dim % 8 == 0, else the
  * sequential dot_f32; the i8 dot is exact), so the selected clusters are the reference's, not merely close to them.
  * A batch scans the union of its queries' clusters once; a row is a candidate only for the queries that selected its
- * cluster.  mode == NULL is AnnMode::All.  out_clusters (may be NULL) = observed_cluster_count per query. */
+ * cluster.  mode == NULL is AnnMode::All.  out_clusters (may be NULL) = observed_cluster_count per query.
+ * The selection state of a search with a mode (medoid scores, cluster bitmaps, tile list) is one set of buffers per shard: such
+ * searches queued on different streams are ordered one after the other by the library (an event wait), searches without a mode
+ * stay concurrent. */
 typedef struct ss_ann_mode {
   uint32_t n_probe;              /* clusters visited per level; 0 = no limit (AnnMode::Similaritythreshold) */
   float cluster_threshold_raw;   /* clusters whose medoid scores below it are skipped; -FLT_MAX = none (AnnMode::Nprobe) */

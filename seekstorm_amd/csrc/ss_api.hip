@@ -103,6 +103,24 @@ struct VecWsBind {
   }
 };
 
+// The ANN selection state (medoid scores, per-query cluster bitmaps, the tile list, the live counts) is ONE set of buffers per
+// shard: a search with an ss_ann_mode queued on another stream than the previous one first waits for that one to finish.
+// Caller holds s->mu.  (Searches without a mode touch none of it and stay concurrent across streams.)
+struct AnnStateGuard {
+  ss_shard* s;
+  hipStream_t st;
+  bool on;
+  AnnStateGuard(ss_shard* s_, hipStream_t st_, const ss_ann_mode* mode) : s(s_), st(st_), on(mode != nullptr) {
+    if (on && s->ann_ev_set && s->ann_ev_stream != st) (void)hipStreamWaitEvent(st, s->ann_ev, 0);
+  }
+  ~AnnStateGuard() {
+    if (!on) return;
+    if (!s->ann_ev && hipEventCreateWithFlags(&s->ann_ev, hipEventDisableTiming) != hipSuccess) { s->ann_ev = nullptr; s->ann_ev_set = false; return; }
+    s->ann_ev_set = hipEventRecord(s->ann_ev, st) == hipSuccess;
+    s->ann_ev_stream = st;
+  }
+};
+
 static void free_vec(ss_shard* s) {
   for (auto& kv : s->vec_ws) {
     void* wp[] = {kv.second.d_Qf, kv.second.d_vstate, kv.second.d_cand, kv.second.d_qaux};
@@ -116,6 +134,8 @@ static void free_vec(ss_shard* s) {
   s->d_vstate = nullptr; s->d_cand = nullptr; s->d_row_field = nullptr;
   s->n_rows = s->n_rows_pad = 0; s->dim = s->dim_pad = s->dim_pad8 = 0; s->vec_multi_record = false;
   ssi_vec_free_clusters(s);
+  if (s->ann_ev) (void)hipEventDestroy(s->ann_ev);
+  s->ann_ev = nullptr; s->ann_ev_set = false; s->ann_ev_stream = nullptr;
 }
 static void free_bm25(ss_shard* s) {
   void* ptrs[] = {s->d_post, s->d_term_base, s->d_sub_off, s->d_comp, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_umax, s->d_submax, s->d_boost, s->d_pos, s->d_pos32, s->d_pos_off, s->d_pos_base,
@@ -1663,6 +1683,7 @@ static int vec_search_host_lists(ss_shard* s, uint32_t nq, const void* queries, 
   uint32_t* d_ncl = want_clusters ? (uint32_t*)((char*)s->d_qstage + qbytes + sbytes + nbytes) : nullptr;
   if (d_ncl_out) *d_ncl_out = d_ncl;
   int rc = SS_OK;
+  AnnStateGuard ann_guard(s, s->stream, mode);
   for (int attempt = 0; attempt < 2; attempt++) {
     if (hipMemcpyAsync(s->d_qstage, queries, (size_t)nq * s->dim * elem, hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = SS_EDEVICE; break; }
     if (d_qs && hipMemcpyAsync(d_qs, query_scale, sbytes, hipMemcpyHostToDevice, s->stream) != hipSuccess) { rc = SS_EDEVICE; break; }
@@ -1745,6 +1766,7 @@ int ss_vec_search_ann_dev(ss_shard* s, uint32_t nq, const float* d_queries, uint
   SS_HIP(hipSetDevice(s->device));
   hipStream_t st = stream ? (hipStream_t)stream : s->stream;
   VecWsBind bind(s, st);
+  AnnStateGuard ann_guard(s, st, mode);
   return ssi_vec_search(s, nq, d_queries, nullptr, k, thr, d_out_doc, d_out_score, d_out_count, d_out_total, st, false, mode,
                         mode ? d_out_clusters : nullptr);
 }
@@ -1952,6 +1974,7 @@ int ss_vec_search_i8_euclid_dev(ss_shard* s, uint32_t nq, const int8_t* d_querie
   SS_HIP(hipSetDevice(s->device));
   hipStream_t st = stream ? (hipStream_t)stream : s->stream;
   VecWsBind bind(s, st);
+  AnnStateGuard ann_guard(s, st, mode);
   return ssi_vec_search(s, nq, d_queries, d_query_scale, k, thr, d_out_doc, d_out_score, d_out_count, d_out_total, st, false, mode,
                         mode ? d_out_clusters : nullptr, d_query_norm);
 }

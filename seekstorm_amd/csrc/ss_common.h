@@ -190,6 +190,9 @@ struct ss_shard {
   uint32_t* d_ann_ncl = nullptr;        // [64] observed_cluster_count
   uint32_t* d_ann_live = nullptr;       // [2 + n_clusters]: u64 live records of the image, then per cluster (ssi_vec_observed_prepare)
   size_t ann_live_cap = 0;
+  hipEvent_t ann_ev = nullptr;          // end of the last search that used the (per-shard) ANN selection state, and its stream:
+  hipStream_t ann_ev_stream = nullptr;  // a search with an ss_ann_mode on ANOTHER stream waits for it before it overwrites that state
+  bool ann_ev_set = false;
   // vector workspace (one 64-query batch in flight per shard)
   float* d_Qf = nullptr;
   uint32_t* d_vstate = nullptr;  // tau[64] | cnt[64] | kept[64] | flags[64] | total_lo/hi ...

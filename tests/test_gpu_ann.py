@@ -456,3 +456,46 @@ def test_ann_sparse_batches_match_oracle(S, O, dim):
         assert int(cnt[i]) == len(od) and np.array_equal(doc[i], doc[0]) and np.array_equal(score[i], score[0])
     assert np.allclose(score[0][:len(od)], os_, rtol=REL, atol=2e-6)
     sh.close()
+
+
+def test_ann_searches_on_two_streams_do_not_share_their_selection(S, O):
+    """device-resident ANN searches queued on two streams without a sync in between: the per-shard selection state (cluster
+    bitmaps, tile list) is handed from one to the other by an event wait inside the library, so each gets its own answer"""
+    import ctypes as C
+    import torch
+    from seekstorm_amd import _native as N
+    lc = [12, 10, 9]
+    rows, child = clustered(O, 401, lc, 128, lo=200, hi=900)
+    qa, qb = queries_near(O, rows, 402, 24), queries_near(O, rows, 403, 24)
+    sh = S.Shard(0)
+    sh.upload_vectors(rows)
+    sh.set_clusters(lc, child)
+    k = 15
+    dev = torch.device("cuda", 0)
+    L = S.lib()
+    mode = S.AnnMode.Nprobe(2)._c()
+
+    def bufs():
+        return (torch.empty((24, k), dtype=torch.int32, device=dev), torch.empty((24, k), dtype=torch.float32, device=dev),
+                torch.empty((24,), dtype=torch.int32, device=dev), torch.empty((24,), dtype=torch.int64, device=dev),
+                torch.empty((24,), dtype=torch.int32, device=dev))
+    ta, tb = torch.from_numpy(qa).to(dev), torch.from_numpy(qb).to(dev)
+    ref = {}
+    for name, t in (("a", ta), ("b", tb)):  # one at a time
+        o = bufs()
+        N.check(L.ss_vec_search_ann_dev(sh._h, 24, t.data_ptr(), k, N.FLT_MIN_NEG, C.addressof(mode), o[0].data_ptr(), o[1].data_ptr(),
+                                        o[2].data_ptr(), o[3].data_ptr(), o[4].data_ptr(), None), "ann")
+        N.check(L.ss_shard_sync(sh._h), "sync")
+        ref[name] = [x.cpu().numpy().copy() for x in o]
+    sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
+    for rnd in range(6):
+        oa, ob = bufs(), bufs()
+        for t, o, st in ((ta, oa, sa), (tb, ob, sb), (ta, oa, sa), (tb, ob, sb)):  # interleaved, nothing waits on the host
+            N.check(L.ss_vec_search_ann_dev(sh._h, 24, t.data_ptr(), k, N.FLT_MIN_NEG, C.addressof(mode), o[0].data_ptr(), o[1].data_ptr(),
+                                            o[2].data_ptr(), o[3].data_ptr(), o[4].data_ptr(), C.c_void_p(st.cuda_stream)), "ann")
+        torch.cuda.synchronize()
+        for name, o in (("a", oa), ("b", ob)):
+            for x, y in zip(ref[name], o):
+                assert np.array_equal(x, y.cpu().numpy()), (rnd, name)
+    sh.close()
