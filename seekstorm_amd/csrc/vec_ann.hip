@@ -211,9 +211,8 @@ __global__ void __launch_bounds__(64) ann_select_kernel(const float* __restrict_
   const float* sc = score + (size_t)q * nc + c0;
   auto select = [&](uint32_t c) {
     const uint32_t cg = c0 + c;
-    atomicOr(&sel[(size_t)q * W + (cg >> 5)], 1u << (cg & 31u));
-    atomicOr(&sel[(size_t)64 * W + (cg >> 5)], 1u << (cg & 31u));
-  };
+    atomicOr(&sel[(size_t)q * W + (cg >> 5)], 1u << (cg & 31u));  // (the batch's union row: ann_union_kernel -- 64 queries' atomics
+  };                                                               //  on the same few words serialised, ~100 us of a 180 us launch)
   if (k == C) {  // every cluster that passes the threshold
     uint32_t n = 0;
     for (uint32_t c = lane; c < C; c += 64)
@@ -328,9 +327,16 @@ __global__ void ann_select_slow_kernel(const float* __restrict__ score, const ui
   for (uint32_t i = 0; i < len; i++) {
     const uint32_t cg = c0 + ic[i];
     atomicOr(&sel[(size_t)q * W + (cg >> 5)], 1u << (cg & 31u));
-    atomicOr(&sel[(size_t)64 * W + (cg >> 5)], 1u << (cg & 31u));
   }
   if (len) atomicAdd(&ncl[q], len);
+}
+// the batch's union row (row 64) = OR of the queries' selection rows
+__global__ void ann_union_kernel(uint32_t* __restrict__ sel, uint32_t W, uint32_t nb) {
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= W) return;
+  uint32_t u = 0;
+  for (uint32_t q = 0; q < nb; q++) u |= sel[(size_t)q * W + w];
+  sel[(size_t)64 * W + w] = u;
 }
 
 // Tile list of the batch: tile t is listed if a cluster in [cluster of its first row, cluster of its last row] is in the
@@ -594,6 +600,7 @@ int ssi_vec_ann_prepare(ss_shard* s, uint32_t nb, const float* d_qscale, const s
     ann_select_slow_kernel<<<(nsel + 63) / 64, 64, 0, st>>>(s->d_ann_score, s->d_level_off, s->vec_n_levels, nc, nb,
                                                             mode->n_probe, mode->cluster_threshold_raw, s->d_ann_its,
                                                             s->d_ann_itc, s->d_ann_sel, W, s->d_ann_ncl);
+  ann_union_kernel<<<(W + 255) / 256, 256, 0, st>>>(s->d_ann_sel, W, nb);
   ann_tiles_flag_kernel<<<groups, AT, 0, st>>>(s->d_row_cluster, (unsigned long long)s->n_rows, T,
                                                s->d_ann_sel + (size_t)SS_VEC_BATCH * W, rank, gcount);
   ann_tiles_place_kernel<<<groups, AT, 0, st>>>(rank, gcount, T, tiles);
