@@ -211,8 +211,8 @@ __global__ void __launch_bounds__(64) ann_select_kernel(const float* __restrict_
   const float* sc = score + (size_t)q * nc + c0;
   auto select = [&](uint32_t c) {
     const uint32_t cg = c0 + c;
-    atomicOr(&sel[(size_t)q * W + (cg >> 5)], 1u << (cg & 31u));  // (the batch's union row: ann_union_kernel -- 64 queries' atomics
-  };                                                               //  on the same few words serialised, ~100 us of a 180 us launch)
+    atomicOr(&sel[(size_t)q * W + (cg >> 5)], 1u << (cg & 31u));  // (the batch's union row is ORed together afterwards: ann_union_kernel)
+  };
   if (k == C) {  // every cluster that passes the threshold
     uint32_t n = 0;
     for (uint32_t c = lane; c < C; c += 64)
