@@ -149,10 +149,25 @@ vec8_scan_kernel(const int8_t* __restrict__ X, uint32_t dim_pad, unsigned long l
   const size_t lane_off = (size_t)w * L * 4096u + (size_t)lane * 16u;
   const size_t tile_stride = (size_t)(V8_WAVES * 32) * dim_pad;
   uint32_t i_tile = 0, i_line = 0, i_tix = 0;
+  // ANN: the id of a tile comes from the batch's list -- a load the first line of the tile would have to wait for.  It is fetched
+  // one tile ahead (i_tix_next), and the ids of the tiles in flight stay in a small ring for the epilogue (tix_ring).
+  uint32_t i_tix_next = (ANN && ann.tiles) ? ann.tiles[tile0 + first] : 0u;
+  uint32_t tix_ring[4] = {0u, 0u, 0u, 0u};
   v4i xa[V8_D][4];
   auto issue = [&](v4i(&buf)[4]) {
     const uint32_t t = min(i_tile, my_tiles - 1);  // past the end: re-read a line of the last tile (never consumed)
-    if (ANN) { if (i_line == 0) i_tix = ann.tiles ? ann.tiles[tile0 + first + t * gridDim.x] : tile0 + first + t * gridDim.x; }
+    if (ANN) {
+      if (i_line == 0) {
+        if (ann.tiles) {
+          i_tix = i_tix_next;
+          i_tix_next = ann.tiles[tile0 + first + min(i_tile + 1u, my_tiles - 1u) * gridDim.x];
+        } else {
+          i_tix = tile0 + first + t * gridDim.x;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) tix_ring[r] = (i_tile & 3u) == (uint32_t)r ? i_tix : tix_ring[r];
+      }
+    }
     const size_t tix = ANN ? (size_t)i_tix : (size_t)(tile0 + first + (size_t)t * gridDim.x);
     const v4i* p = (const v4i*)(X + tix * tile_stride + lane_off + (size_t)i_line * 4096u);
 #pragma unroll
@@ -183,8 +198,10 @@ vec8_scan_kernel(const int8_t* __restrict__ X, uint32_t dim_pad, unsigned long l
       issue(xa[d]);
       if (++c_line == L) {
         // ---- threshold filter: lane owns query (lane & 31) + {0, 32}, 16 rows per accumulator
-        const unsigned long long c_tix = (ANN && ann.tiles) ? (unsigned long long)ann.tiles[tile0 + first + c_tile * gridDim.x]
-                                             : (unsigned long long)(tile0 + first + (unsigned long long)c_tile * gridDim.x);
+        uint32_t c_ring = tix_ring[0];
+#pragma unroll
+        for (int r = 1; r < 4; r++) c_ring = (c_tile & 3u) == (uint32_t)r ? tix_ring[r] : c_ring;
+        const unsigned long long c_tix = ANN ? (unsigned long long)c_ring : (unsigned long long)(tile0 + first + (unsigned long long)c_tile * gridDim.x);
         const unsigned long long row_base = c_tix * (V8_WAVES * 32) + 32u * w + 4u * (lane >> 5);
         float f0[16], f1[16];
 #pragma unroll
