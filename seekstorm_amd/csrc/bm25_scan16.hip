@@ -192,7 +192,8 @@ __device__ __forceinline__ void s16_clear_tile(uint32_t wb, int lane) {
 #endif
 template <int NT> struct S16Cfg {
   static constexpr int cpt(int t) {
-    return NT == 3 ? (t == 2 ? 3 : 1) : NT == 2 ? (t == 1 ? 4 : 1) : NT == 1 ? S16_NT1 : (S16_NT4_LAST ? (t == NT - 1 ? S16_NT4_LAST : 1) : 2);
+    return NT >= 5 ? (t == NT - 1 ? 2 : 1)  // five / six lists: 1 ... 1 / 2 (6 / 7 chunks: the registers of 2 per term would not fit)
+           : NT == 3 ? (t == 2 ? 3 : 1) : NT == 2 ? (t == 1 ? 4 : 1) : NT == 1 ? S16_NT1 : (S16_NT4_LAST ? (t == NT - 1 ? S16_NT4_LAST : 1) : 2);
   }
   static constexpr int off(int t) { int o = 0; for (int i = 0; i < t; i++) o += cpt(i); return o; }
   static constexpr int RC = off(NT);
@@ -436,6 +437,11 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
   if (NT == 2) { cswap(0, 1); }
   if (NT == 3) { cswap(0, 1); cswap(1, 2); cswap(0, 1); }
   if (NT == 4) { cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2); }
+  if (NT == 5) { cswap(0, 1); cswap(3, 4); cswap(2, 4); cswap(2, 3); cswap(0, 3); cswap(0, 2); cswap(1, 4); cswap(1, 3); cswap(1, 2); }
+  if (NT == 6) {
+    cswap(1, 2); cswap(4, 5); cswap(0, 2); cswap(3, 5); cswap(0, 1); cswap(3, 4); cswap(2, 5); cswap(0, 3); cswap(1, 4); cswap(2, 4);
+    cswap(1, 3); cswap(2, 3);
+  }
   const float scale = (AND ? S16_QMAX_AND : S16_QMAX) / (S16_WMAX * idf_sum);
 #pragma unroll
   for (int t = 0; t < NT; t++) fidf[t] = s16_uniform(idf[t] * scale);
@@ -660,7 +666,7 @@ int launch16(const BmParams& p, hipStream_t st) {
 
 }  // namespace
 
-// unions of <= 4 lists without NOT terms, k <= 64 (at k = 100 the f32 scan is 5 % ahead); exact counts (TopkCount, and Count
+// unions of <= 4 lists (five and six: top-k only) without NOT terms, k <= 64 (at k = 100 the f32 scan is 5 % ahead); exact counts (TopkCount, and Count
 // with k = 0) as long as the shard has no tombstones -- a deleted doc must not count, and only the f32 kernel's dense tile scan
 // looks at the tombstone bitmap of every doc.  Intersections (and_exact_nt != 0): batches of intersections only, every query
 // with exactly and_exact_nt = 2 or 3 terms over one list each, no all_terms_frequent shortcut (the dispatch checks).
@@ -670,7 +676,9 @@ bool ssi_bm25_scan16_serves(uint32_t nt_max, uint32_t np_max, bool has_and, bool
   static const int and_off = [] { const char* e = getenv("SS_BM25_SCAN16_AND"); return e ? atoi(e) == 0 : 0; }();
   if (count && (tombstones || cnt_off)) return false;
   if (has_and && (and_off || and_exact_nt < 2 || and_exact_nt > 3 || and_exact_nt != nt_max)) return false;
-  return !off && (k != 0 || count) && nt_max == np_max && nt_max >= 1 && nt_max <= 4 && KPL == 1;
+  static const int wide_off = [] { const char* e = getenv("SS_BM25_SCAN16_WIDE"); return e ? atoi(e) == 0 : 0; }();
+  if (nt_max > 4 && (has_and || count || wide_off)) return false;  // five / six lists: plain top-k unions
+  return !off && (k != 0 || count) && nt_max == np_max && nt_max >= 1 && nt_max <= 6 && KPL == 1;
 }
 
 int ssi_bm25_launch_scan16(const BmParams& p, uint32_t nt_max, bool is_and, int KPL, hipStream_t st) {
@@ -684,5 +692,7 @@ int ssi_bm25_launch_scan16(const BmParams& p, uint32_t nt_max, bool is_and, int 
   if (NT == NT_ && KPL == KPL_) return p.count ? launch16<NT_, KPL_, true, false>(p, st) : launch16<NT_, KPL_, false, false>(p, st);
   SS_F(2, 1) SS_F(3, 1) SS_F(4, 1)
 #undef SS_F
+  if (NT == 5 && KPL == 1 && !p.count) return launch16<5, 1, false, false>(p, st);
+  if (NT == 6 && KPL == 1 && !p.count) return launch16<6, 1, false, false>(p, st);
   return SS_ENOTSUP;
 }

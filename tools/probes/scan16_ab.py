@@ -19,6 +19,10 @@ shapes = {
     "3t C2 k100": ([[int(rng.choice(band(0.005, 0.02))), int(rng.choice(band(0.02, 0.05))), int(rng.choice(band(0.05, 0.15)))] for _ in range(1000)], 100),
     "2t k10": ([[int(rng.choice(band(0.02, 0.05))), int(rng.choice(band(0.05, 0.15)))] for _ in range(1000)], 10),
     "4t k10": ([[int(rng.choice(band(0.005, 0.02))), int(rng.choice(band(0.02, 0.05))), int(rng.choice(band(0.05, 0.15))), int(rng.choice(band(0.002, 0.005)))] for _ in range(1000)], 10),
+    "5t k10": ([[int(rng.choice(band(0.005, 0.02))), int(rng.choice(band(0.02, 0.05))), int(rng.choice(band(0.05, 0.15))), int(rng.choice(band(0.002, 0.005))),
+                 int(rng.choice(band(0.0005, 0.002)))] for _ in range(1000)], 10),
+    "6t k10": ([[int(rng.choice(band(0.005, 0.02))), int(rng.choice(band(0.02, 0.05))), int(rng.choice(band(0.05, 0.15))), int(rng.choice(band(0.002, 0.005))),
+                 int(rng.choice(band(0.0005, 0.002))), int(rng.choice(band(0.01, 0.03)))] for _ in range(1000)], 10),
     "1t k10": ([[int(rng.choice(band(0.02, 0.15)))] for _ in range(1000)], 10),
     "3t dense k10": ([[int(x) for x in rng.choice(band(0.15, 0.7), 3, replace=False)] for _ in range(1000)], 10),
     "2t sparse k10": ([[int(x) for x in rng.choice(band(0.0005, 0.005), 2, replace=False)] for _ in range(1000)], 10),
@@ -26,6 +30,8 @@ shapes = {
 L = S.lib()
 sh.set_strategy(N.BM25_EXHAUSTIVE)
 for name, (tl, k) in shapes.items():
+    tl = [t for t in tl if len(set(t)) == len(t)] + [tl[0]] * sum(len(set(t)) != len(t) for t in tl)
+    tl = [t if len(set(t)) == len(t) else tl[0] for t in tl]
     if len(band(0.15, 0.7)) < 3 and "dense" in name:
         continue
     q = sh.make_queries(tl, S.QueryType.Union)
