@@ -98,6 +98,10 @@ int decode_block(const ss_ref_block* b, uint32_t n_components, uint32_t componen
   const bool ngram = n_components > 1;
   const uint8_t* a = b->byte_array;
   const uint64_t len = b->byte_array_len;
+  // a position takes at least one byte of its record, an embedded pointer holds at most 4: a block cannot carry more positions
+  // than that -- corrupted pointers that send many postings to the same bytes are refused instead of decoded 65 536 times
+  const size_t pos_base = pos_out ? pos_out->size() : 0;
+  const uint64_t pos_cap = len + 4ull * 65536ull;
   const uint32_t ctype = b->compression_type_pointer >> 30;                 // CompressionType, index.rs:838-843
   const uint64_t range = b->compression_type_pointer & 0x3FFFFFFFu;         // rank_position_pointer_range
   const uint32_t count = (uint32_t)b->posting_count_m1 + 1u;
@@ -165,6 +169,7 @@ int decode_block(const ss_ref_block* b, uint32_t n_components, uint32_t componen
       pos += a[pos] & 0x80u ? 1u : (a[pos + 1] & 0x80u ? 2u : 3u);
       at = i == 0 ? v : at + v + 1u;
       if (at > 65535u) return SS_ENOTSUP;
+      if (pos_out->size() - pos_base >= pos_cap) return SS_EINVAL;  // more positions than the bytes can hold: overlapping records
       pos_out->push_back((uint16_t)at);
     }
     return SS_OK;
@@ -322,6 +327,7 @@ namespace {
 int decode_block_fields(const ss_ref_block* b, uint32_t n_fields, uint32_t longest_field_id, uint32_t n_components, uint32_t component,
                         uint16_t* docs_out, uint32_t* first_out, uint8_t* field_out, uint16_t* tf_out, std::vector<uint16_t>* pos_out) {
   if (pos_out && n_components > 1) return SS_ENOTSUP;  // an n-gram key's positions are the n-gram's, not its components'
+  const size_t pos_base = pos_out ? pos_out->size() : 0;
   if (!b || !b->byte_array || !docs_out || !first_out || !field_out || !tf_out || n_fields < 2 || n_fields > 8 ||
       longest_field_id >= n_fields) return SS_EINVAL;
   const bool ngram = n_components > 1;
@@ -397,6 +403,7 @@ int decode_block_fields(const ss_ref_block* b, uint32_t n_fields, uint32_t longe
             at_rec += a[at_rec] & 0x80u ? 1u : (a[at_rec + 1] & 0x80u ? 2u : 3u);
             at_pos = x == 0 ? v : at_pos + v + 1u;
             if (at_pos > 65535u) return SS_ENOTSUP;
+            if (pos_out->size() - pos_base >= len + 4ull * 65536ull) return SS_EINVAL;  // overlapping records (corrupted pointers)
             pos_out->push_back((uint16_t)at_pos);
           }
         }

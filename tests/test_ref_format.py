@@ -536,6 +536,17 @@ def test_decoders_survive_corrupted_bytes():
                 continue
             n = (_decode_fields(blk2, 3, 1) if fields else _decode(blk2))[0]
             assert n <= 65536
+            # ... and the position decoders: never more positions than the bytes (+ 4 embedded per posting) can hold, however the
+            # corrupted pointers overlap
+            if fields:
+                r = _decode_fields_positions(blk2, 3, 1)
+                assert r[0] <= 65536 and len(r[-1]) <= len(blk2[4]) + 4 * 65536
+            else:
+                buf = np.frombuffer(blk2[4], np.uint8).copy()
+                rb = N.RefBlock(blk2[0], blk2[1], blk2[2] - 1, blk2[3], buf.ctypes.data, len(buf))
+                dd, tt, pp, npos = np.zeros(65536, np.uint16), np.zeros(65536, np.uint16), np.zeros(1 << 20, np.uint16), C.c_uint64()
+                n2 = N.lib().ss_ref_decode_block_positions(C.byref(rb), N.ptr(dd, N.u16p), N.ptr(tt, N.u16p), N.ptr(pp, N.u16p), len(pp), C.byref(npos))
+                assert n2 <= 65536 and (n2 < 0 or npos.value <= len(buf) + 4 * 65536)
     # index.bin / vector headers made of noise
     for trial in range(200):
         junk = b"\\x06\\x00\\x01\\x00" + bytes(rng.integers(0, 256, size=int(rng.integers(0, 300_000)), dtype=np.uint8))
