@@ -506,6 +506,32 @@ def test_phrase_over_several_fields_rules():
         assert x[2] == y[2] and np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2] > 0
 
 
+def test_all_terms_frequent_rule_over_several_fields():
+    """so_search_fields_shortcut (add_result.rs:1595-1607): every matching doc is counted; a doc is ranked only if EVERY term has
+    >= 10 positions in the LOWEST field that holds the doc for that term -- positions in later fields do not help"""
+    n_docs = 6
+    dl = np.full((3, n_docs), 30, np.uint8)
+    # term 0 / term 1 entries (doc, field, tf), sorted by (doc, field)
+    #   doc 0: t0 f0:12          t1 f1:10          -> ranked (both first fields >= 10)
+    #   doc 1: t0 f0:9  f1:40    t1 f0:15          -> counted, not ranked (t0's lowest field has 9)
+    #   doc 2: t0 f1:10          t1 f0:3 f2:50     -> counted, not ranked (t1's lowest field has 3)
+    #   doc 3: t0 f2:11          t1 f2:10          -> ranked
+    #   doc 4: t0 f0:20                            -> no t1: not a match
+    e0 = [(0, 0, 12), (1, 0, 9), (1, 1, 40), (2, 1, 10), (3, 2, 11), (4, 0, 20)]
+    e1 = [(0, 1, 10), (1, 0, 15), (2, 0, 3), (2, 2, 50), (3, 2, 10)]
+    ent = e0 + e1
+    offs = np.array([0, len(e0), len(ent)], np.uint64)
+    docs = np.array([e[0] for e in ent], np.uint32)
+    fields = np.array([e[1] for e in ent], np.uint8)
+    tfs = np.array([e[2] for e in ent], np.uint16)
+    od, os_, tot = O.search_fields_shortcut(n_docs, dl, None, offs, docs, fields, tfs, [0, 1], 10)
+    full = O.search_fields_exhaustive(n_docs, dl, None, offs, docs, fields, tfs, [0, 1], O.OP_AND, 10)
+    assert tot == full[2] == 4 and sorted(od.tolist()) == [0, 3] and sorted(full[0].tolist()) == [0, 1, 2, 3]
+    for d, sc in zip(od, os_):  # a ranked doc keeps its full BM25F score
+        assert sc == full[1][full[0].tolist().index(int(d))]
+    assert O.search_fields_shortcut(n_docs, dl, None, offs, docs, fields, tfs, [0, 1], 10, deleted=[3])[2] == 3
+
+
 def test_geo_morton_and_distances():
     """Point facets (geo_search.rs): the reference's tests hold no vectors for these, so the oracle's restatement is checked
     against what defines it -- latitude in the even bits and longitude in the odd ones of (deg * 1e7) as i32, the cast's
