@@ -298,3 +298,19 @@ def test_two_process_gloo_hybrid_exchange_in_one_gather():
         assert gd == [int(x) for x in od] and np.allclose(gs, os_, rtol=1e-6)
         assert got[0]["tot"][qi] == sum(max(got[r]["own"][0][qi], got[r]["own"][1][qi]) for r in range(world))
     assert "local search failed" in got[1]["fail"] and "peer" in got[0]["fail"]
+
+
+def test_ann_mode_struct_matches_the_header():
+    """ss_ann_mode grew flags / reserved in ABI v3: the ctypes mirror, the header and the generated Rust declaration agree"""
+    import ctypes as C
+    import re
+    from seekstorm_amd import _native as N
+    assert C.sizeof(N.AnnModeC) == 24 and N.AnnModeC.flags.offset == 16 and N.AnnModeC.field_mask.offset == 8
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "seekstorm_hip.h")).read()
+    body = hdr[hdr.index("typedef struct ss_ann_mode {"):hdr.index("} ss_ann_mode;")]
+    names = re.findall(r"^\s*(?:uint32_t|uint64_t|float)\s+(\w+);", body, re.M)
+    assert names == ["n_probe", "cluster_threshold_raw", "field_mask", "flags", "reserved"]
+    assert int(re.search(r"#define SS_ANN_REPORT_OBSERVED (\d+)u", hdr).group(1)) == N.SS_ANN_REPORT_OBSERVED
+    rs = open(os.path.join(root, "integration", "hip_ffi.rs")).read()
+    assert "flags" in rs[rs.index("struct SsAnnMode"):rs.index("struct SsAnnMode") + 400]
