@@ -368,6 +368,79 @@ def main():
                                                  "algorithmic_bytes_per_launch": and_bytes, "avg_launch_ms": xk_, "launches": int(xl_)}},
                      "workload": "2-term AND top-10, terms from the 1-5 % and 5-20 % df bands, 1000 queries per call, AUTO (pruned: the shorter "
                                  "list drives, the other is probed; counts are a by-product)", "mean_matches": float(and_ref[1].mean())}
+        # (3c) the exhaustive strategy under EXCLUSIONS: C2's queries + one NOT term each (2-5 % band), 1 % of the docs tombstoned,
+        # ResultType::TopkCount -- the 16-bit tile's EXCL instance (the NOT list streamed beside the terms, the sub-block's tombstone
+        # words per item) against the f32 tile that used to take every such request (SS_BM25_EXHAUSTIVE_F32)
+        excl = None
+        if not args.no_topk_count and world == 1 and not args.quick:
+            sx = S.Shard(local_rank, shard_id=rank)
+            sx.synth_partition(rank, world)
+            sx.synth_lexical(O.LEX_SEED, args.docs, th, tab)
+            rng_x = np.random.default_rng(2468)
+            gone_x = np.unique(rng_x.integers(0, args.docs, args.docs // 100, dtype=np.uint64))
+            sx.set_deleted(gone_x)
+            nband = band_terms(th, 0.02, 0.05)
+            not_lists = []
+            for tl in term_lists:
+                t_ = int(rng_x.choice(nband))
+                while t_ in tl:
+                    t_ = int(rng_x.choice(nband))
+                not_lists.append([t_])
+            qx_np = sx.make_queries(term_lists, S.QueryType.Union, not_lists)
+            qx_dev = torch.from_numpy(qx_np.view(np.uint8).reshape(nq, -1).copy()).to(dev)
+            OPS_X = 2 | (4 << 8) | (3 << 16) | (1 << 24)  # unions of 3 terms + 1 NOT term (bits 24..27: the most NOT terms of any query)
+
+            def x_call(rt=N.RT_TOPKCOUNT):
+                N.check(L.ss_bm25_search_dev(sx._h, nq, qx_dev.data_ptr(), k, rt, OPS_X, o_doc.data_ptr(), o_score.data_ptr(),
+                                             o_cnt.data_ptr(), o_tot.data_ptr(), sptr), "ss_bm25_search_dev")
+            xres, xt = {}, {}
+            for name, strat in (("scan16", N.BM25_EXHAUSTIVE), ("f32_tile", N.BM25_EXHAUSTIVE_F32), ("auto", N.BM25_AUTO)):
+                sx.set_strategy(strat)
+                x_call()
+                torch.cuda.synchronize()
+                xres[name] = (o_doc.cpu().numpy().copy(), o_score.cpu().numpy().copy(), o_tot.cpu().numpy().astype(np.int64))
+                sx.profile(True)
+                sx.profile_read(0, reset=True)
+                n_, d_ = timed_for(x_call, min_calls=50 if name == "f32_tile" else 200)
+                xl_, xms_ = sx.profile_read(0, reset=True)
+                sx.profile(False)
+                xt[name] = (nq * n_ / d_, d_ / n_ * 1e3, n_, xms_ / max(xl_, 1), int(xl_))
+            for name in ("f32_tile", "auto"):
+                assert np.array_equal(xres["scan16"][1], xres[name][1]) and np.array_equal(xres["scan16"][2], xres[name][2]), \
+                    f"NOT + tombstones: 16-bit tile differs from {name}"
+            assert not np.isin(xres["scan16"][0].astype(np.uint64), gone_x).any(), "a tombstoned doc was ranked"
+            xu = sorted({t for tl in term_lists for t in tl} | {t for nl in not_lists for t in nl})
+            xdf = dict(zip(xu, (int(x) for x in sx.posting_count(xu))))
+            # algorithmic bytes: SURVEY 8d's formula for the scored lists + 2 B doc id per NOT posting + the tombstone bitmap (1 bit per doc)
+            x_bytes = float(sum(sum(xdf[t] for t in tl) * 3 + xdf[nl[0]] * 2 + int(m_) + args.docs // 8 + 4 * n_blocks * 4 + 8 * k
+                                for tl, nl, m_ in zip(term_lists, not_lists, xres["scan16"][2])))
+
+            def x_roof(name, kernel):
+                ms_ = xt[name][3]
+                return {"bound": "hbm", "kernel": kernel, "achieved": x_bytes / (ms_ * 1e-3) / 1e9 if ms_ > 0 else None, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": x_bytes / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_ > 0 else None,
+                        "algorithmic_bytes_per_launch": x_bytes, "avg_launch_ms": ms_, "launches": xt[name][4]}
+            excl = {"value": xt["scan16"][0], "unit": "queries/s", "ms_per_call": xt["scan16"][1], "calls": xt["scan16"][2], "result_type": "TopkCount",
+                    "roofline": x_roof("scan16", "bm25_scan16_kernel<3,1,count,OR,EXCL> (NOT list streamed, tombstone words per item, first-touch counts corrected)"),
+                    "f32_tile": {"value": xt["f32_tile"][0], "unit": "queries/s", "ms_per_call": xt["f32_tile"][1], "calls": xt["f32_tile"][2],
+                                 "roofline": x_roof("f32_tile", "bm25_scan_fast_kernel<4> (SS_BM25_EXHAUSTIVE_F32: what served this request before round 4)")},
+                    "auto": {"value": xt["auto"][0], "unit": "queries/s", "ms_per_call": xt["auto"][1], "calls": xt["auto"][2]},
+                    "deleted_docs": int(len(gone_x)), "mean_total": float(xres["scan16"][2].mean()),
+                    "workload": "the C2 batch + one NOT term per query (df 2-5 %), 1 % of the docs tombstoned, TopkCount; scores and totals of the "
+                                "three strategies asserted identical"}
+            if not args.no_parity:
+                t0 = time.perf_counter()
+                nsx = min(128, nq)
+                xans, _, _ = F.c2_answers(args.docs, term_lists[:nsx], th, k, O.OP_OR, O.RT_TOPKCOUNT, part=(rank, world),
+                                          not_lists=not_lists[:nsx], deleted=gone_x)
+                for i in range(nsx):
+                    od, os_, otot = xans[i]
+                    assert int(xres["scan16"][2][i]) == otot, f"NOT + tombstones: count of query {i}: {int(xres['scan16'][2][i])} vs oracle {otot}"
+                    F.check_topk(xres["scan16"][0][i], xres["scan16"][1][i], od, os_, 1e-4, f"NOT + tombstones, query {i}")
+                parity["not_tombstones"] = {"queries": nsx, "checked": "exact result_count_total, top-10 ids outside the tie band, scores rtol 1e-4; oracle = "
+                                            "so_search_lex_ref with not_query_list and delete_hashset on the host-regenerated shard",
+                                            "seconds": time.perf_counter() - t0}
+            sx.close()
         ach_alg = bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         ex_ach = bytes_launch / (ex_kms * 1e-3) / 1e9 if ex_kms > 0 else 0.0
         lat_batch = latencies(bm_rot_call, 1000)
@@ -403,6 +476,19 @@ def main():
                             "frac_counter_low": (moved_lo / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (moved_lo and avg_ms > 0) else None,
                             "traffic": moved, "algorithmic_bytes_per_launch": bytes_launch,
                             "effective_GBs_on_algorithmic_bytes": ach_alg, "avg_launch_ms": avg_ms, "launches": int(launches),
+                            # SURVEY 8(d)'s own figure -- algorithmic bytes / live launch time -- for the kernels it applies to (the exhaustive
+                            # strategy streams every posting), inside `roofline` so that the driver's record keeps them:
+                            "sec8d_kernel": "bm25_scan16_kernel<3,1> (exhaustive strategy on the same batches)",
+                            "sec8d_frac": ex_ach / HBM_PEAK_GBS, "sec8d_achieved_GBs": ex_ach, "sec8d_avg_launch_ms": ex_kms,
+                            "sec8d_algorithmic_bytes": bytes_launch, "sec8d_launches": int(ex_launches), "sec8d_traffic": pmc_traffic("bm25"),
+                            "and_exhaustive_frac": ((inter or {}).get("exhaustive", {}).get("roofline", {}) or {}).get("frac"),
+                            "and_exhaustive_avg_launch_ms": ((inter or {}).get("exhaustive", {}).get("roofline", {}) or {}).get("avg_launch_ms"),
+                            "and_exhaustive_algorithmic_bytes": ((inter or {}).get("exhaustive", {}).get("roofline", {}) or {}).get("algorithmic_bytes_per_launch"),
+                            "not_tombstones_frac": ((excl or {}).get("roofline") or {}).get("frac"),
+                            "not_tombstones_avg_launch_ms": ((excl or {}).get("roofline") or {}).get("avg_launch_ms"),
+                            "not_tombstones_algorithmic_bytes": ((excl or {}).get("roofline") or {}).get("algorithmic_bytes_per_launch"),
+                            "fallback_f32_frac": (((excl or {}).get("f32_tile") or {}).get("roofline") or {}).get("frac"),
+                            "fallback_f32_avg_launch_ms": (((excl or {}).get("f32_tile") or {}).get("roofline") or {}).get("avg_launch_ms"),
                             "pmc_profile": "profiles/pmc_traffic.json" if moved else "absent or collected on other kernel sources (stale): no counter figure",
                             "note": "achieved = counter-measured HBM bytes of this kernel / live kernel time (the kernel prunes: it answers "
                                     "without reading most of SURVEY 8d's algorithmic bytes, so effective_GBs_on_algorithmic_bytes may exceed "
@@ -417,7 +503,7 @@ def main():
                   latency_ms={"batch_p50": pct(lat_batch, 50), "batch_p99": pct(lat_batch, 99), "batch_samples": len(lat_batch),
                               "single_query_p50": pct(lat_one, 50), "single_query_p99": pct(lat_one, 99),
                               "single_query_samples": len(lat_one), "clock": "HIP events on the launch stream (device resident)"},
-                  end_to_end=end_to_end, intersection=inter,
+                  end_to_end=end_to_end, intersection=inter, exhaustive_not_tombstones=excl,
                   mean_bytes_per_query=float(bytes_q.mean()), mean_union=float(tot.mean()))
         # correctness guard inside the bench: sorted, k results
         bm_call()
@@ -651,7 +737,8 @@ def main():
             # execution structure: S document-partitioned shards, one task per shard and query.  Bounded sample of the same
             # queries on the same corpus.
             from concurrent.futures import ThreadPoolExecutor
-            cores = F.host_threads(128)
+            eff_cpus, cpu_info = F.effective_cpus()
+            cores = max(1, min(F.host_threads(128), int(np.ceil(eff_cpus))))  # threads spawned: one per CPU the process can really run on
             ns = min(args.cpu_queries, nq)
             _, osh, remap = F.c2_answers(args.docs, term_lists[:ns], th, k, O.OP_OR, O.RT_TOPK)
             qs = np.array([[remap[t] for t in tl] for tl in term_lists[:ns]], np.uint32)
@@ -665,7 +752,9 @@ def main():
             s_lat_qps, _, s_lat = O.bench_lex(shards, qs, O.OP_OR, k, O.RT_TOPK, 1, cores, args.cpu_seconds)
             best = max(one_tp, s_tp)
             bm["cpu_baseline"] = {
-                "value": best, "unit": "queries/s", "cores": cores, "kind": "port", "algorithm": "union_docid_3",
+                "value": best, "unit": "queries/s", "cores": eff_cpus, "threads": cores, "cpu_info": cpu_info, "kind": "port", "algorithm": "union_docid_3",
+                "cores_note": "cores = the CPUs this process can run on at once (min of logical CPUs, affinity mask, cgroup CPU quota); "
+                              "threads = worker threads spawned",
                 "shards": 1 if best == one_tp else cores,
                 "sample": f"{ns} of the {nq} C2 queries cycled for {args.cpu_seconds:.0f} s per mode on the same {args.docs}-doc corpus "
                           f"(posting lists of the sample regenerated on the host); oracle/ss_oracle.c so_search_lex_ref = union_docid_3 "
@@ -906,7 +995,8 @@ def main():
             # document-partitioned shards, one task per shard and query (index.rs:2055-2062, search.rs:1637-1650) -- on the FULL matrix
             # (10 M x 768 regenerated on the host, 30.7 GB) when the host has the memory: measured, nothing extrapolated;
             # (b) throughput mode (every core answers whole queries) on a 1 M-row sample, scaled linearly, beside it.
-            cores = F.host_threads(128)
+            eff_cpus, cpu_info = F.effective_cpus()
+            cores = max(1, min(F.host_threads(128), int(np.ceil(eff_cpus))))  # threads spawned: one per CPU the process can really run on
             try:
                 avail_gb = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] / 1e6
             except Exception:
@@ -927,7 +1017,8 @@ def main():
             Ms = min(M, 1_000_000)
             qps_t, done_t, _ = O.bench_vec(rows[:Ms], qv_np, kv, 0, cores, args.cpu_seconds)
             vec["cpu_baseline"] = {
-                "value": qps_l / scale, "unit": "queries/s", "cores": cores, "kind": "port", "rows": int(M), "host_generation_s": gen_s,
+                "value": qps_l / scale, "unit": "queries/s", "cores": eff_cpus, "threads": cores, "cpu_info": cpu_info, "kind": "port", "rows": int(M),
+                "host_generation_s": gen_s,
                 "sample": (f"{done_l} top-100 queries over {'ALL' if full else 'the first'} {M} rows in {args.cpu_seconds:.0f}s: one query at a time, the rows "
                            f"split over {cores} workers + merge = the reference's default S = cores shards, one task per shard and query "
                            f"(oracle so_bench_vec: dot_f32_avx2 order + TopK::push)" + ("" if full else f"; rate divided by {scale:.0f} (linear scan) to {args.rows} rows")),
@@ -1023,6 +1114,8 @@ def main():
             line["topk_count"] = bm["topk_count"]
             if bm.get("intersection"):
                 line["intersection"] = bm["intersection"]
+            if bm.get("exhaustive_not_tombstones"):
+                line["exhaustive_not_tombstones"] = bm["exhaustive_not_tombstones"]
             if "rationed_vocabulary" in bm:
                 line["rationed_vocabulary"] = bm["rationed_vocabulary"]
             if "multi_field" in bm:

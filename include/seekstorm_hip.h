@@ -65,6 +65,7 @@ enum {
  * consecutive positions, add_result.rs:3586-3684); ResultType (search.rs:168) */
 enum { SS_OP_INTERSECTION = 0, SS_OP_UNION = 1, SS_OP_PHRASE = 2 };
 #define SS_MAX_PHRASE 12 /* words of a phrase query */
+#define SS_PHRASE_SKIP 0xFFu /* phrase_seq entry of a word place that lies inside an n-gram key (its entry stands at the key's first word) */
 enum { SS_RT_COUNT = 0, SS_RT_TOPK = 1, SS_RT_TOPKCOUNT = 2 };
 /* SearchMode (search.rs:73) for ss_merge_results */
 enum { SS_MODE_LEXICAL = 0, SS_MODE_VECTOR = 1, SS_MODE_HYBRID = 2 };
@@ -165,6 +166,12 @@ int ss_ref_decode_block_positions(const ss_ref_block* block, uint16_t* docs_out,
  * get_bm25f_multiterm_singlefield (add_result.rs:1454-1477) weigh with idf_ngram{1,2,3}. */
 int ss_ref_decode_block_ngram(const ss_ref_block* block, uint32_t n_components, uint32_t component, uint16_t* docs_out,
                               uint16_t* tfs_out);
+/* ... with the key's OWN positions: the positions_count and the positions that follow the component tfs in every record -- the
+ * places of the n-gram's FIRST word (tokenizer.rs:699), which the phrase check walks for a query entry that resolved to the key
+ * (add_result.rs:2074-2089, 3596-3684).  npos_out [65536] = positions per posting, pos_out their concatenation (absolute,
+ * ascending per posting); tfs_out = tf of component 0.  SS_EINVAL with *n_pos_out = needed size when pos_cap is too small. */
+int ss_ref_decode_block_ngram_positions(const ss_ref_block* block, uint32_t n_components, uint16_t* docs_out, uint16_t* tfs_out,
+                                        uint16_t* npos_out, uint16_t* pos_out, uint64_t pos_cap, uint64_t* n_pos_out);
 int ss_bm25_upload_ref_blocks(ss_shard* s, uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t n_terms,
                               const uint64_t* term_block_offsets /*[n_terms+1]*/, const ss_ref_block* blocks);
 /* ... and from a shard's index.bin as it lies on disk / in the mmap (writer commit.rs:264-369 and
@@ -175,8 +182,11 @@ int ss_bm25_upload_ref_blocks(ss_shard* s, uint64_t n_docs, const uint8_t* docle
  * index.rs:1422-1424) occupies one term id PER COMPONENT, consecutive and in order (same key_hash, same docs, the
  * component's tf): a query term that resolved to the n-gram becomes its 2 or 3 component terms with idf_ngram_i each
  * (from ss_index_bin_term_ngram's component df, search.rs:3231-3262) -- the same documents match, and the scores add up
- * to the n-gram arm of get_bm25f_multiterm_singlefield (add_result.rs:1454-1477).  With several indexed fields n-gram
- * keys are counted and skipped.  indexed_field_count / key_head_size (20 | 22 | 23, index.rs:2806-2812) come from
+ * to the n-gram arm of get_bm25f_multiterm_singlefield (add_result.rs:1454-1477); with several indexed fields each component's
+ * field vector is decoded the same way (add_result.rs:1524-1600).  In a PHRASE the key is ONE entry whose positions are those of
+ * its first word and which spans 2 / 3 places (search.rs:3305-3328): ss_bm25_upload_index_bin_positions puts the key's positions
+ * behind its FIRST component term; the query names that term at the key's first place and SS_PHRASE_SKIP at its other places, the
+ * other component terms are scored only.  indexed_field_count / key_head_size (20 | 22 | 23, index.rs:2806-2812) come from
  * schema.json / index.json; segment_number_bits is 11 for every index opened by the reference (index.rs:3285). */
 typedef struct ss_index_bin ss_index_bin;
 int ss_index_bin_open(const uint8_t* bytes, uint64_t len, uint32_t indexed_field_count, uint32_t key_head_size,
@@ -190,7 +200,8 @@ int ss_index_bin_filter(ss_index_bin* ix, uint64_t min_posting_count, uint32_t* 
  * the index is uploaded with ss_bm25_upload_index_bin -- a real vocabulary's millions of rare keys then cost 8 bytes per posting,
  * not a directory row each, and every key of the index stays searchable on the device.  Term id = position in that order
  * (ss_index_bin_term_keys): the host looks a key hash up with one binary search per tier, *n_dense_out = first sparse term id.
- * One indexed field (SS_ENOTSUP otherwise); not with ss_bm25_upload_index_bin_positions (no phrases over sparse lists). */
+ * One indexed field (SS_ENOTSUP otherwise).  With ss_bm25_upload_index_bin_positions the dense terms carry positions: phrases over
+ * dense terms work, a phrase naming a sparse term is refused (SS_ENOTSUP). */
 int ss_index_bin_tier(ss_index_bin* ix, uint64_t dense_min_posting_count, uint32_t* n_dense_out);
 int ss_index_bin_close(ss_index_bin* ix);
 int ss_index_bin_info(const ss_index_bin* ix, uint64_t* n_docs, uint64_t* positions_sum_normalized, uint32_t* n_levels,
@@ -207,8 +218,9 @@ int ss_index_bin_term_postings(const ss_index_bin* ix, uint32_t term, uint64_t c
 int ss_bm25_upload_index_bin(ss_shard* s, const ss_index_bin* ix);
 /* The same plus the positions of every posting, decoded from the rank/position pointers (embedded forms) and the VINT records
  * (decode_positions_multiterm_singlefield, add_result.rs:2036-2197; stored as first position, then gap - 1): phrase queries
- * (SS_OP_PHRASE) then work on an image built from the file.  SingleTerm keys only: SS_ENOTSUP for an index with n-gram keys or a
- * position beyond 65 535.  Several indexed fields: see ss_bm25_upload_index_bin_fields_positions. */
+ * (SS_OP_PHRASE) then work on an image built from the file -- also on the reference's DEFAULT index (NgramFF | NgramFFF keys,
+ * 22 / 23-byte key heads): an n-gram key's positions go to its first component term (see ss_index_bin_open).  SS_ENOTSUP for a
+ * position beyond 65 535.  Several indexed fields: see ss_bm25_upload_index_bin_fields_positions (n-gram keys there: SS_ENOTSUP). */
 int ss_bm25_upload_index_bin_positions(ss_shard* s, const ss_index_bin* ix);
 /* the same for an index with several indexed fields: position records carry a field vector per posting
  * (decode_positions_multiterm_multifield, add_result.rs:1485-2034; read_multifield_vec 2200-2293) -> ss_bm25_upload_fields.
@@ -265,8 +277,10 @@ int ss_bm25_sparse_info(ss_shard* s, uint32_t* n_lists, uint64_t* n_postings, ui
  * shortest lists are read; exact union counts are popcounts over the index's bit records like union_count,
  * union.rs:807-); everything else, and every request when the probe index did not fit in device memory, takes the
  * EXHAUSTIVE scan.  Both return identical results.  SS_BM25_PRUNED fails with SS_ENOTSUP where pruning cannot serve
- * the request (> 4 scored terms, k > 128, no probe index). */
-enum { SS_BM25_AUTO = 0, SS_BM25_EXHAUSTIVE = 1, SS_BM25_PRUNED = 2 };
+ * the request (> 4 scored terms, k > 128, no probe index).  SS_BM25_EXHAUSTIVE_F32 holds the exhaustive strategy on the
+ * f32-tile scan kernel that the 16-bit-tile kernel replaced for unions of <= 6 lists / intersections of 2-3 terms at k <= 64
+ * (same answers; kept selectable for measurements and cross-checks). */
+enum { SS_BM25_AUTO = 0, SS_BM25_EXHAUSTIVE = 1, SS_BM25_PRUNED = 2, SS_BM25_EXHAUSTIVE_F32 = 3 };
 /* The probe index costs 12 bytes per 64 docs and posting list (1.9 MB per list at 10 M docs).  Its rows go to the longest
  * lists first until the budget of the NEXT image build is spent (bytes; 0 = half of the free device memory); queries
  * touching a list without a row are ranked by the scan kernels (exact counts then come from the scan as well).
@@ -315,11 +329,14 @@ typedef struct {
   uint32_t term[SS_MAX_QUERY_TERMS]; /* term index into the uploaded vocabulary; query terms first, then the NOT terms */
   float idf[SS_MAX_QUERY_TERMS];     /* host-computed, search.rs:3225-3230; entries of NOT terms are ignored */
   uint32_t phrase_len;               /* SS_OP_PHRASE: words of the phrase, 2 .. SS_MAX_PHRASE (non_unique_query_list); else 0 */
-  uint8_t phrase_seq[SS_MAX_PHRASE]; /* word i of the phrase is term[phrase_seq[i]]: a repeated word names its unique term again */
+  uint8_t phrase_seq[SS_MAX_PHRASE]; /* word i of the phrase is term[phrase_seq[i]]: a repeated word names its unique term again;
+                                        SS_PHRASE_SKIP = a place inside an n-gram key (never place 0) */
 } ss_bm25_query;
 /* SS_OP_PHRASE ("..." queries, QueryType::Phrase): term[] holds the phrase's UNIQUE terms (query_list), phrase_seq its words in
  * order.  A doc matches when it contains every unique term and some position p carries word i at p + i for every i
- * (add_result.rs:3596-3684: the merge over the entries' position lists, fewest positions first); it is scored like the
+ * (add_result.rs:3596-3684: the merge over the entries' position lists, fewest positions first; an n-gram key is one entry
+ * at its first place -- the positions of its first component term --, its other places are SS_PHRASE_SKIP, its other component
+ * terms are unique terms that no place names); it is scored like the
  * intersection of the unique terms (get_bm25f_multiterm_singlefield) and counted only when the phrase matches.  Needs the
  * positions in the image and every list with a probe row (on a rationed vocabulary the rows built on demand go to a batch's phrase
  * queries first; SS_ENOTSUP when the pool cannot hold the lists of its phrases).  One indexed field: ss_bm25_upload_positions.  Several indexed fields
@@ -345,7 +362,9 @@ int ss_bm25_search(ss_shard* s, uint32_t n_queries, const ss_bm25_query* queries
  * query carries a field filter (several indexed fields: without it every query reads its terms' merged lists, one per term);
  * bit 6 set if EVERY query has exactly bits 16..23 terms (optional: a batch of nothing but 2- or 3-term intersections is then
  * answered, under the exhaustive strategy or without probe rows, by the 16-bit scan instead of the f32 scan -- 4-10x faster);
- * bit 7 set if some query is a union of several terms under a field filter.
+ * bit 7 set if some query is a union of several terms under a field filter; bits 24..27 = the most NOT terms any ONE query of the
+ * batch has (optional, 0 = not stated: the host then assumes whatever bits 8..15 leave room for beside one scored term, and a
+ * TopkCount / Count request with NOT terms under the exhaustive strategy takes the slower f32-tile kernel unless 1 is stated).
  * The assertion is CHECKED ON THE DEVICE, query by query, before the search kernels run: a query that contradicts ops_mask
  * (an intersection in a batch declared union-only, more terms than declared, an unprobed term under bit 2, ...) or is
  * malformed (no terms, a term id outside the vocabulary) is answered as an empty query and flagged

@@ -22,6 +22,30 @@ def host_threads(cap=64):
     return max(1, min(os.cpu_count() or 1, cap))
 
 
+def effective_cpus():
+    """the CPUs this process can really use: min(affinity mask, cgroup CPU quota) -- os.cpu_count() reports the box's logical
+    CPUs, which a container with a CFS quota cannot all run on.  -> (cpus as float, {"cpu_count", "affinity", "quota"})"""
+    info = {"cpu_count": os.cpu_count() or 1, "affinity": None, "quota": None}
+    try:
+        info["affinity"] = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:  # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            info["quota"] = float(q) / float(per)
+    except Exception:
+        try:  # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                info["quota"] = q / per
+        except Exception:
+            pass
+    eff = float(min(x for x in (info["cpu_count"], info["affinity"], info["quota"]) if x))
+    return eff, info
+
+
 def c2_corpus(n_docs_shard, terms, thresholds, seed=O.LEX_SEED, part=(0, 1), threads=None):
     """decoded postings of `terms` for shard `part` of the generator stream -> (doclen, offs, docs, tfs), CSR row i <-> terms[i]"""
     sid, S = part
@@ -44,18 +68,22 @@ def c2_corpus(n_docs_shard, terms, thresholds, seed=O.LEX_SEED, part=(0, 1), thr
 
 
 def c2_answers(n_docs_shard, term_lists, thresholds, k, op=O.OP_OR, rt=O.RT_TOPKCOUNT, seed=O.LEX_SEED, part=(0, 1), threads=None,
-               structured=True):
+               structured=True, not_lists=None, deleted=None):
     """oracle answers of the sampled queries on the full-size shard: list of (docs, scores, total).
-    structured: the reference-structured dispatch (union_docid_3 ...), else the union_scan table scan -- same answers."""
+    structured: the reference-structured dispatch (union_docid_3 ...), else the union_scan table scan -- same answers.
+    not_lists: per query the NOT terms (not_query_list); deleted: shard-local tombstoned doc ids (delete_hashset)."""
     threads = threads or host_threads()
-    voc = sorted({int(t) for tl in term_lists for t in tl})
+    not_lists = not_lists if not_lists is not None else [[] for _ in term_lists]
+    voc = sorted({int(t) for tl in term_lists for t in tl} | {int(t) for tl in not_lists for t in tl})
     dl, offs, docs, tfs = c2_corpus(n_docs_shard, voc, thresholds, seed, part, threads)
     sh = O.Shard(n_docs_shard, dl, offs, docs, tfs)
+    if deleted is not None and len(deleted):
+        sh.set_deleted(deleted)
     remap = {t: i for i, t in enumerate(voc)}
-    qs = [[remap[int(t)] for t in tl] for tl in term_lists]
+    qs = [([remap[int(t)] for t in tl], [remap[int(t)] for t in nl]) for tl, nl in zip(term_lists, not_lists)]
     fn = sh.search_ref if structured else sh.search
     with ThreadPoolExecutor(threads) as ex:
-        out = list(ex.map(lambda q: fn(q, op, k, rt), qs))
+        out = list(ex.map(lambda q: fn(q[0], op, k, rt, not_terms=q[1]), qs))
     return out, sh, remap
 
 

@@ -16,7 +16,7 @@ SS_MAX_PHRASE = 12
 SS_MAX_K = 1024
 SS_VEC_BATCH = 64
 OP_INTERSECTION, OP_UNION, OP_PHRASE = 0, 1, 2
-BM25_AUTO, BM25_EXHAUSTIVE, BM25_PRUNED = 0, 1, 2
+BM25_AUTO, BM25_EXHAUSTIVE, BM25_PRUNED, BM25_EXHAUSTIVE_F32 = 0, 1, 2, 3
 RT_COUNT, RT_TOPK, RT_TOPKCOUNT = 0, 1, 2
 MODE_LEXICAL, MODE_VECTOR, MODE_HYBRID = 0, 1, 2
 SRC_LEXICAL, SRC_VECTOR, SRC_HYBRID = 0, 1, 2
@@ -93,6 +93,7 @@ SYMBOLS = [
     ("ss_index_bin_term_keys", C.c_int, [C.c_void_p, u64p]),
     ("ss_index_bin_term_ngram", C.c_int, [C.c_void_p, u8p, u8p, u32p]),
     ("ss_ref_decode_block_ngram", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, u16p, u16p]),
+    ("ss_ref_decode_block_ngram_positions", C.c_int, [C.c_void_p, C.c_uint32, u16p, u16p, u16p, u16p, C.c_uint64, u64p]),
     ("ss_index_bin_term_postings", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, u32p, u16p, u64p]),
     ("ss_bm25_upload_index_bin", C.c_int, [C.c_void_p, C.c_void_p]),
     ("ss_bm25_upload_index_bin_positions", C.c_int, [C.c_void_p, C.c_void_p]),

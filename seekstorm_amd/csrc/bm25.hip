@@ -186,12 +186,9 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
     bad |= bm_q_op(Q.op) > (uint32_t)SS_OP_PHRASE || q_phrase != ((claim & BM_CLAIM_PHRASE) != 0u);
     if (q_phrase) {
       bad |= (n_lists != 1 && merged == 0u) || n_not != 0 || Q.phrase_len < 2u || Q.phrase_len > (uint32_t)SS_MAX_PHRASE || np > 6u;
-      uint32_t used = 0;
-      for (uint32_t j = 0; j < (uint32_t)SS_MAX_PHRASE && j < Q.phrase_len; j++) {
-        bad |= Q.phrase_seq[j] >= np;
-        used |= 1u << (Q.phrase_seq[j] & 15u);
-      }
-      bad |= !bad && used != (1u << np) - 1u;  // every unique term is a word of the phrase
+      // (a word place inside an n-gram key carries SS_PHRASE_SKIP; the key's other component terms are scored, not placed)
+      bad |= Q.phrase_seq[0] >= np;
+      for (uint32_t j = 1; j < (uint32_t)SS_MAX_PHRASE && j < Q.phrase_len; j++) bad |= Q.phrase_seq[j] >= np && Q.phrase_seq[j] != SS_PHRASE_SKIP;
     }
     bad |= bm_q_all_frequent(Q.op) && bm_q_op(Q.op) == SS_OP_INTERSECTION && np > 1 && ff == 0u && !(claim & BM_CLAIM_FREQ);
     if (!bad)
@@ -287,7 +284,7 @@ int ssi_bm25_match_bits(ss_shard* s, const ss_bm25_query* d_q, unsigned long lon
 int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t* d_out_doc,
                     float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, bool has_or,
                     uint32_t nt_max, uint32_t np_max, bool all_probed, hipStream_t st, bool any_frequent, bool phrase, bool any_field_filter,
-                    bool uniform_terms, bool any_gated) {
+                    bool uniform_terms, bool any_gated, uint32_t nn_max) {
   if (!s->d_post) return SS_ESTATE;
   if (nq == 0) return SS_OK;
   if (k > SS_MAX_K) return SS_EINVAL;
@@ -304,13 +301,19 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   // With merged lists (ss_common.h bm_merged) a batch without field filters is a single-field batch to everything below.
   // phrase queries always read the merged lists (their field filter is a test on the positions, bm25_phrase.hip)
   const uint32_t F = (s->bm_merged && (!any_field_filter || phrase)) ? 1u : bm_real_fields(s);
+  // nn_max: the most NOT terms of any query (0xFFFFFFFF = unknown, a device-resident batch that did not say: then whatever nt_max
+  // leaves room for beside ONE scored term); in lists, like nt_max / np_max below
+  if (nn_max == 0xFFFFFFFFu) nn_max = nt_max > np_max ? nt_max - 1u : 0u;
   nt_max *= F;
   np_max *= F;
+  nn_max *= F;
   if (F > 1) has_or = true;
   // all_probed: every list the batch touches has a row in the probe index (rows are given to the longest lists first)
   const bool have_probe = s->d_probe && s->d_umax && all_probed;
   // an intersection under the all_terms_frequent shortcut ranks by a per-posting rule (tf >= 10): scan kernels only
-  const bool pruned = s->bm_strategy != SS_BM25_EXHAUSTIVE && have_probe && !(F > 1 && has_and) && !any_frequent &&
+  // SS_BM25_EXHAUSTIVE_F32: the exhaustive strategy held on the f32 tile (what the 16-bit scan replaced; measurements and cross-checks)
+  const bool exhaustive = s->bm_strategy == SS_BM25_EXHAUSTIVE || s->bm_strategy == SS_BM25_EXHAUSTIVE_F32;
+  const bool pruned = !exhaustive && have_probe && !(F > 1 && has_and) && !any_frequent &&
                       np_max >= 1 && np_max <= 4 && KPL <= 2;  // NOT terms are probed outside the template
   if (!pruned && !phrase && s->bm_strategy == SS_BM25_PRUNED) return SS_ENOTSUP;
   // phrase queries: their own kernel over the probe index and the positions (bm25_phrase.hip); every strategy
@@ -327,13 +330,13 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   // queries); a pure Count request then needs no scan at all.  SS_BM25_EXHAUSTIVE keeps the scan's own counts.
   const bool want_counts = rt != SS_RT_TOPK;
   // (a union under a field filter counts by its own rule, BM_AND_GATED / _TOUCH: from the scan)
-  const bool bit_counts_all = want_counts && !pruned && !phrase && s->bm_strategy != SS_BM25_EXHAUSTIVE && have_probe && !any_gated;
+  const bool bit_counts_all = want_counts && !pruned && !phrase && !exhaustive && have_probe && !any_gated;
   const bool scan_counts = want_counts && !bit_counts_all;
   // unions of <= 4 lists ranked by the scan: the 16-bit-accumulator kernel (16 waves per CU instead of 8)
   // ... and intersections of 2 or 3 terms when the batch holds nothing else: every query an intersection over one list per term
   // with exactly np_max terms, no NOT terms, no all_terms_frequent shortcut
-  const uint32_t and_exact_nt = (has_and && !has_or && F == 1 && uniform_terms && nt_max == np_max && !any_frequent && !any_field_filter) ? np_max : 0u;
-  const bool scan16 = !pruned && !phrase && ssi_bm25_scan16_serves(nt_max, np_max, has_and, scan_counts, s->n_deleted != 0, KPL, k, and_exact_nt);
+  const uint32_t and_exact_nt = (has_and && !has_or && F == 1 && uniform_terms && !any_frequent && !any_field_filter) ? np_max : 0u;
+  const bool scan16 = !pruned && !phrase && s->bm_strategy != SS_BM25_EXHAUSTIVE_F32 && !any_gated && !(F > 1 && has_and) && ssi_bm25_scan16_serves(nn_max, np_max, has_and, scan_counts, s->n_deleted != 0, KPL, k, and_exact_nt);
   // (16-bit scan, round 3: while the longest lists of C2 overflowed their register chunks -- a synchronous load per item for 17 % of
   // the queries -- 4 rounds beat 2 (1.415 against 1.496 ms per 1000 queries); with the chunk budgets following the sorted terms the
   // imbalance is gone and fewer, longer assignments win again: 1.08 ms at 8 partitions per query, 1.10 at 10 / 12, 1.11 at 16, 1.15 at
@@ -413,7 +416,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
                                 s->bm_n_fields == 1 ? nullptr : s->d_pos32, s->d_pos_off, (const unsigned long long*)s->d_pos_base,
                                 np_max, KPL, st);
   else rc = pruned ? ssi_bm25_launch_probe(p, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_umax, use_partmax ? s->d_submax : nullptr, pmax_ws, np_max, KPL, nt_max != np_max, st)
-                   : scan16 ? ssi_bm25_launch_scan16(p, nt_max, has_and, KPL, st) : ssi_bm25_launch_scan(p, nt_max, has_and, KPL, st);
+                   : scan16 ? ssi_bm25_launch_scan16(p, np_max, nn_max, has_and, KPL, st) : ssi_bm25_launch_scan(p, nt_max, has_and, KPL, st);
   ssi_prof_end(s, 0, st, e0, e1);
   if (rc) return rc;
   if (want_counts && ((pruned && has_or) || bit_counts_all)) {

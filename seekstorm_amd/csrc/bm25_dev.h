@@ -384,9 +384,9 @@ __device__ __attribute__((noinline)) BmTop<KPL> bm_offer_lane_keys(BmTop<KPL> T,
 
 // scan kernels (bm25_fast.hip): NT-specialised for <= 4 terms and k <= 128, grouped generic kernel otherwise
 int ssi_bm25_launch_scan(const BmParams& p, uint32_t nt_max, bool has_and, int KPL, hipStream_t st);
-// 16-bit-accumulator scan (bm25_scan16.hip): top-k of unions of <= 4 lists without NOT terms; 16 waves per CU
-bool ssi_bm25_scan16_serves(uint32_t nt_max, uint32_t np_max, bool has_and, bool count, bool tombstones, int KPL, uint32_t k, uint32_t and_exact_nt);
-int ssi_bm25_launch_scan16(const BmParams& p, uint32_t nt_max, bool is_and, int KPL, hipStream_t st);
+// 16-bit-accumulator scan (bm25_scan16.hip): unions of <= 6 lists / intersections of 2-3, k <= 64, NOT lists, tombstones, exact counts; 16 waves per CU
+bool ssi_bm25_scan16_serves(uint32_t nn_max, uint32_t np_max, bool has_and, bool count, bool tombstones, int KPL, uint32_t k, uint32_t and_exact_nt);
+int ssi_bm25_launch_scan16(const BmParams& p, uint32_t np_max, uint32_t nn_max, bool is_and, int KPL, hipStream_t st);
 // exact union counts from the probe index's bit records (bm25_probe.hip)
 int ssi_bm25_launch_union_count(const BmParams& p, const uint2* probe, const uint32_t* probe_row, bool all_queries, hipStream_t st,
                                 unsigned long long* match_bits = nullptr);

@@ -86,11 +86,15 @@ __global__ void __launch_bounds__(PH_WAVES * 64) bm25_phrase_kernel(
     }
   }
   // slot of every word of the phrase (uniform per wave): word i is unique term phrase_seq[i], which sits in slot slot_of(..)
-  // (3 bits per word packed in one scalar: a register array indexed by the running word would live in scratch)
+  // (3 bits per word packed in one scalar: a register array indexed by the running word would live in scratch).
+  // N-gram keys (the reference's default index, index.rs:1422-1424): a bigram / trigram key of the query is ONE entry of
+  // non_unique_query_list whose positions are those of its first word and whose successor stands 2 / 3 places later
+  // (term_index_nonunique = entries before it + preceding_ngram_count, search.rs:3305-3328): its first component term holds the
+  // key's positions, the places of its other words carry no entry -- phrase_seq = SS_PHRASE_SKIP, slot 7 here.
   u64 wpack = 0ull;
 #pragma unroll
   for (int i = 0; i < SS_MAX_PHRASE; i++) {
-    uint32_t sl = 0;
+    uint32_t sl = Q->phrase_seq[i] == SS_PHRASE_SKIP ? 7u : 0u;
 #pragma unroll
     for (int t = 0; t < NT; t++)
       if (qpos[t] == (uint32_t)Q->phrase_seq[i]) sl = t;
@@ -181,6 +185,7 @@ __global__ void __launch_bounds__(PH_WAVES * 64) bm25_phrase_kernel(
           for (uint32_t i = 1; i < plen && ok; i++) {
             uint32_t lo, hi;
             const PT* bp;
+            if (wslot(i) == 7u) continue;  // a place inside an n-gram key: no entry of its own
             range_of(wslot(i), lo, hi, bp);
             const uint32_t end = hi, target = start + i;
             while (lo < hi) {  // first position >= target (the list is ascending)

@@ -29,6 +29,8 @@ constexpr float S16_WMAX = 4.0f;            // bm_wdecode(0x7FFFF) < 4
 typedef __attribute__((address_space(3))) uint16_t bm_lds_u16;
 typedef __attribute__((address_space(3))) u32x4 bm_lds_u32x4;
 __device__ __forceinline__ uint32_t lds_ld16(uint32_t off) { return *(bm_lds_u16*)(uintptr_t)off; }
+typedef __attribute__((address_space(3))) int16_t bm_lds_i16;
+__device__ __forceinline__ uint32_t lds_ld16s(uint32_t off) { return (uint32_t)(int32_t)*(bm_lds_i16*)(uintptr_t)off; }  // sign-extending
 __device__ __forceinline__ void lds_st16(uint32_t off, uint32_t v) { *(bm_lds_u16*)(uintptr_t)off = (uint16_t)v; }
 __device__ __forceinline__ u32x4 lds_ld128(uint32_t off) { return *(bm_lds_u32x4*)(uintptr_t)off; }
 __device__ __forceinline__ void lds_st128(uint32_t off, u32x4 v) { *(bm_lds_u32x4*)(uintptr_t)off = v; }
@@ -77,12 +79,16 @@ __device__ __forceinline__ uint32_t s16_first(const u32x4 v, float fidf, uint32_
   }
   return mx;
 }
-template <bool CNT>
+// SGN (the union count instances under exclusions, EXCL): entries are read SIGN-EXTENDED.  An excluded doc (NOT list, tombstone) carries
+// the mark 0x8000 before the terms are accumulated: as a negative number it keeps "old + bound" below every threshold (no trigger),
+// it is not zero (no first-touch count), and bounds added to it stay inside 0x8000..0xFFFF (the scale of these instances keeps a
+// doc's sum below 2^15) -- an excluded doc rides along untouched by any extra instruction.
+template <bool CNT, bool SGN = false>
 __device__ __forceinline__ uint32_t s16_read(const u32x4 v, float fidf, uint32_t accb, uint32_t mx, uint32_t (&nw)[4], uint32_t& cnt) {
   const uint32_t pv[4] = {v.x, v.y, v.z, v.w};
   uint32_t old[4];
 #pragma unroll
-  for (int x = 0; x < 4; x++) old[x] = lds_ld16(s16_addr(pv[x], accb));
+  for (int x = 0; x < 4; x++) old[x] = SGN ? lds_ld16s(s16_addr(pv[x], accb)) : lds_ld16(s16_addr(pv[x], accb));
 #pragma unroll
   for (int x = 0; x < 4; x++) {
     nw[x] = old[x] + s16_qm(pv[x], fidf);
@@ -93,10 +99,10 @@ __device__ __forceinline__ uint32_t s16_read(const u32x4 v, float fidf, uint32_t
 }
 // (An LDS atomic for the middle term -- ds_add_rtn_u32 on the dword holding the 16-bit entry, one operation instead of read +
 // write -- was measured: 1.78 ms against 1.08 ms per 1000 C2 queries.  Returning LDS atomics run far below the plain pipe's rate.)
-template <bool CNT>
+template <bool CNT, bool SGN = false>
 __device__ __forceinline__ uint32_t s16_keep(const u32x4 v, float fidf, uint32_t accb, uint32_t mx, uint32_t& cnt) {
   uint32_t nw[4];
-  mx = s16_read<CNT>(v, fidf, accb, mx, nw, cnt);
+  mx = s16_read<CNT, SGN>(v, fidf, accb, mx, nw, cnt);
   const uint32_t pv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
   for (int x = 0; x < 4; x++) lds_st16(s16_addr(pv[x], accb), nw[x]);
@@ -105,6 +111,79 @@ __device__ __forceinline__ uint32_t s16_keep(const u32x4 v, float fidf, uint32_t
 __device__ __forceinline__ void s16_clear(uint32_t wb, int lane) {
 #pragma unroll
   for (int i = 0; i < S16_WAVE_LDS / 1024; i++) lds_st128(wb + (uint32_t)(i * 64 + lane) * 16u, u32x4{0u, 0u, 0u, 0u});
+}
+
+// ---- exclusions: NOT terms (add_result.rs:3440-3497, union.rs:483-530: the docs of a NOT list are zeroed in the scan table) and
+// tombstones (add_result.rs:3435, union.rs:975).  An excluded doc's entry goes back to 0 -- it is then no candidate, and in the count
+// instances (EXCL) an entry that was NOT zero had been counted by its first posting: one decrement.
+template <bool CNT>
+__device__ __forceinline__ void s16_not_chunk(const u32x4 v, uint32_t accb, uint32_t& dec) {
+  const uint32_t pv[4] = {v.x, v.y, v.z, v.w};
+  uint32_t ad[4], old[4];
+#pragma unroll
+  for (int x = 0; x < 4; x++) { ad[x] = s16_addr(pv[x], accb); old[x] = lds_ld16(ad[x]); }
+#pragma unroll
+  for (int x = 0; x < 4; x++) {
+    if (CNT) dec += (uint32_t)__popcll(__ballot(old[x] != 0u && pv[x] != 0u));  // (a NULL posting reads the dump slot)
+    lds_st16(ad[x], 0u);
+  }
+}
+constexpr uint32_t S16_MARK = 0x8000u;  // an excluded doc's entry in the union count instances (s16_read<.., SGN>)
+constexpr float S16_QMAX_EXCL = 32000.0f;  // ... whose bounds must leave bit 15 alone
+__device__ __forceinline__ void s16_mark_chunk(const u32x4 v, uint32_t accb) {
+  lds_st16(s16_addr(v.x, accb), S16_MARK);
+  lds_st16(s16_addr(v.y, accb), S16_MARK);
+  lds_st16(s16_addr(v.z, accb), S16_MARK);
+  lds_st16(s16_addr(v.w, accb), S16_MARK);
+}
+__device__ __forceinline__ void s16_mark_bits(uint32_t w0, uint32_t w1, uint32_t accb, int lane) {
+  u64 m = (u64)w0 | ((u64)w1 << 32);
+  while (__ballot(m != 0ull)) {
+    const bool act = m != 0ull;
+    const uint32_t b = act ? (uint32_t)__ffsll((long long)m) - 1u : 0u;
+    m &= m - 1ull;
+    lds_st16(act ? accb + (((uint32_t)lane * 64u + b + 1u) << 1) : accb, S16_MARK);
+  }
+}
+// the tombstone bits of the 64 docs this lane owns in the sub-block (docs 64 lane .. 64 lane + 63): lanes walk their set bits
+// together, a lane that has run out parks on the dump slot
+template <bool CNT>
+__device__ __forceinline__ void s16_del_bits(uint32_t w0, uint32_t w1, uint32_t accb, int lane, uint32_t& dec) {
+  u64 m = (u64)w0 | ((u64)w1 << 32);
+  while (__ballot(m != 0ull)) {
+    const bool act = m != 0ull;
+    const uint32_t b = act ? (uint32_t)__ffsll((long long)m) - 1u : 0u;
+    m &= m - 1ull;
+    const uint32_t ad = act ? accb + (((uint32_t)lane * 64u + b + 1u) << 1) : accb;
+    const uint32_t old = lds_ld16(ad);
+    if (CNT) dec += (uint32_t)__popcll(__ballot(act && old != 0u));
+    lds_st16(ad, 0u);
+  }
+}
+// What the candidate path knows of a query's exclusions: everything is fetched when needed (the path is rare), nothing of it lives
+// in registers across the streaming loop.
+struct S16Excl {
+  const bm_vquery* Q;              // NOT lists: Q->term[nt .. nt + nn)
+  const uint32_t* post;
+  const unsigned long long* term_base;
+  const uint32_t* sub_off;
+  const uint32_t* del;             // tombstone bitmap or null
+  uint32_t nt, nn, row_len, del_words, item;
+};
+__device__ __forceinline__ void s16_exclude(const S16Excl& e, uint32_t accb, int lane) {
+  uint32_t nodec = 0u;
+  for (uint32_t j = 0; j < e.nn; j++) {
+    const uint32_t term = e.Q->term[e.nt + j];
+    const uint32_t* row = e.sub_off + (size_t)term * e.row_len;
+    const uint32_t b0 = row[e.item], b1 = row[e.item + 1];
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(e.post + e.term_base[term] * 4ull), 0, (int)(b1 << 4), BM_RSRC_FLAGS);
+    for (uint32_t u = b0; u < b1; u += 64u) s16_not_chunk<false>(__builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, (int)(u << 4), 0), accb, nodec);
+  }
+  if (e.del) {
+    const uint32_t w = e.item * (uint32_t)(BM_SUB / 32) + (uint32_t)lane * 2u;
+    const uint32_t w0 = w < e.del_words ? e.del[w] : 0u, w1 = w + 1u < e.del_words ? e.del[w + 1u] : 0u;
+    s16_del_bits<false>(w0, w1, accb, lane, nodec);
+  }
 }
 
 // ---- intersections (AND template instance; 2 or 3 terms, every query of the batch with exactly NT terms).  An entry is
@@ -265,8 +344,9 @@ __device__ __forceinline__ void s16a_build(const S16Cur<S16Cfg<NT>::RC>& cur, co
 
 template <int NT, int KPL, bool AND>
 __device__ __forceinline__ BmTop<KPL> s16_trigger(BmTop<KPL> T, S16Cur<S16Cfg<NT>::RC> cur, S16Item<NT> it, uint32_t wb, uint32_t qthr,
-                                                            float thr, uint32_t doc_base, uint32_t k, uint32_t* tau_q,
-                                                            const uint32_t* __restrict__ del, uint32_t del_words) {
+                                                            float thr, uint32_t doc_base, uint32_t k, uint32_t* tau_q, const S16Excl ex) {
+  const uint32_t* __restrict__ del = ex.del;
+  const uint32_t del_words = ex.del_words;
   const int lane = __lane_id();
   const int lane16 = lane * 16;
   const uint32_t tile = wb + 16u, accb = wb + 14u, accf = wb + S16_ACC;
@@ -278,6 +358,11 @@ __device__ __forceinline__ BmTop<KPL> s16_trigger(BmTop<KPL> T, S16Cur<S16Cfg<NT
     qthr <<= 2;
     s16a_build<NT>(cur, it, accb, lane16, false);
   }
+  // NOT lists and tombstones: their docs leave the tile BEFORE the cut looks at it (k lanes holding a bound >= x must mean k docs
+  // that can be results).  The plain top-k instances never read a NOT list anywhere else: an excluded doc only ever made a bound
+  // too large, i.e. a trigger too many.
+  const bool excl = ex.nn != 0u || ex.del != nullptr;
+  if (excl) s16_exclude(ex, accb, lane);
   for (;;) {
     // this lane's 8 slots (slot i * 64 + lane holds docs 8 * slot .. 8 * slot + 7): their largest bounds, packed 2 per register
     uint32_t sm[4];
@@ -369,12 +454,11 @@ __device__ __forceinline__ BmTop<KPL> s16_trigger(BmTop<KPL> T, S16Cur<S16Cfg<NT
     // more candidates than the list holds (ties, or a list that is still filling): rebuild the bounds and go on
     if (AND) {
       s16a_build<NT>(cur, it, accb, lane16, true);
-      continue;
-    }
-    {
+    } else {
       uint32_t dummy = 0u, nocount = 0u;  // (the docs of this item were counted when its bounds were first accumulated)
       s16_each_term<NT, 0, NT>(cur, it, lane16, [&](const u32x4 v, auto tc) { dummy = s16_keep<false>(v, it.fidf[decltype(tc)::value], accb, dummy, nocount); });
     }
+    if (excl) s16_exclude(ex, accb, lane);
   }
   s16_clear(wb, lane);
   if (tau_q && T.wsc > wsc_in && lane == 0) bm_publish_tau(tau_q, T.wsc);
@@ -383,13 +467,22 @@ __device__ __forceinline__ BmTop<KPL> s16_trigger(BmTop<KPL> T, S16Cur<S16Cfg<NT
 
 
 
-template <int NT, int KPL, bool CNT, bool AND>
+// EXCL (count instances only): the exclusions are applied INSIDE the streaming loop, because an exact count has to see every item --
+// one NOT list streamed beside the query's terms (CN register chunks per item) and the sub-block's 128 tombstone words (8 bytes per
+// lane).  Unions: the excluded docs are MARKED before the terms are accumulated (S16_MARK, s16_read<.., SGN>): a marked doc is no
+// first touch and reaches no threshold.  Intersections: the exclusions follow the first term, the only one that creates entries
+// (an excluded doc's entry goes back to 0: it can reach no level).  Without EXCL a query's NOT lists and the tombstones are only looked at by the candidate path.
+template <int NT, int KPL, bool CNT, bool AND, bool EXCL>
 __global__ void __launch_bounds__(S16_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base, const uint32_t* __restrict__ sub_off,
                    const bm_vquery* __restrict__ qs, unsigned long long* __restrict__ part_keys, unsigned long long* __restrict__ total, uint32_t* tau,
                    const uint32_t* __restrict__ del, uint32_t del_words, uint32_t n_sub, uint32_t n_terms, uint32_t nq, uint32_t P, uint32_t k) {
   using Cfg = S16Cfg<NT>;
   constexpr int RC = Cfg::RC;
+  constexpr int CN = EXCL ? (NT <= 3 ? 2 : 1) : 0;  // register chunks of the streamed NOT list
+  constexpr int DX = RC + CN;                        // EXCL: the chunk whose .x / .y hold this lane's two tombstone words
+  constexpr int RCX = RC + CN + (EXCL ? 1 : 0);
+  static_assert(!EXCL || CNT, "exclusions inside the streaming loop are what exact counts need");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();  // offsets below are absolute
   const int tid = threadIdx.x, lane = tid & 63;
@@ -403,7 +496,7 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
   if (a >= nq * P) return;
   const uint32_t qi = a % nq, part = a / nq;
   const bm_vquery* __restrict__ Q = qs + qi;
-  const uint32_t nt = Q->n_terms;  // no NOT terms in this kernel's batches (dispatch)
+  const uint32_t nt = Q->n_terms;  // (a query's NOT lists follow in Q->term: candidate path, or the EXCL instances' stream)
   constexpr uint32_t BLK = 62;     // items per boundary block, as bm25_scan_fast_kernel
   const uint32_t* tptr[NT];
   float idf[NT];
@@ -442,7 +535,13 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
     cswap(1, 2); cswap(4, 5); cswap(0, 2); cswap(3, 5); cswap(0, 1); cswap(3, 4); cswap(2, 5); cswap(0, 3); cswap(1, 4); cswap(2, 4);
     cswap(1, 3); cswap(2, 3);
   }
-  const float scale = (AND ? S16_QMAX_AND : S16_QMAX) / (S16_WMAX * idf_sum);
+  // EXCL: the one NOT list that is streamed (none: the empty list of the absent term); a query with more of them contradicts what
+  // the host chose this instance by: flagged like any query that contradicts its batch's declaration (count = UINT32_MAX)
+  if (EXCL && bm_q_nnot(Q->op) > 1u && lane == 0) tau[(size_t)qi * BM_TAU_STRIDE + 1] = 1u;
+  const uint32_t nterm = (EXCL && bm_q_nnot(Q->op)) ? Q->term[nt] : n_terms;
+  const uint32_t* ntptr = post + term_base[nterm] * 4ull;
+  const uint32_t* nrowp = sub_off + (size_t)nterm * row_len;
+  const float scale = (AND ? S16_QMAX_AND : EXCL ? S16_QMAX_EXCL : S16_QMAX) / (S16_WMAX * idf_sum);
 #pragma unroll
   for (int t = 0; t < NT; t++) fidf[t] = s16_uniform(idf[t] * scale);
   // wave-uniform constants of the item loop, pinned to scalar registers (left to the allocator, scale_thr went to scratch and
@@ -458,7 +557,7 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
   T.wsc = -1.0f;
   T.matched = 0;
 
-  auto issue_loads = [&](u32x4(&v)[RC], const uint32_t (&b0)[NT], const uint32_t (&b1)[NT]) {
+  auto issue_loads = [&](u32x4(&v)[RCX], const uint32_t (&b0)[NT], const uint32_t (&b1)[NT], uint32_t nb0, uint32_t nb1, uint32_t item) {
 #pragma unroll
     for (int t = 0; t < NT; t++) {
       __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[t], 0, (int)(b1[t] << 4), BM_RSRC_FLAGS);
@@ -466,11 +565,21 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
       for (int c = 0; c < Cfg::CPTMAX; c++)
         if (c < Cfg::cpt(t)) v[Cfg::off(t) + c] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + c * 1024, (int)(b0[t] << 4), 0);
     }
+    if constexpr (EXCL) {
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ntptr, 0, (int)(nb1 << 4), BM_RSRC_FLAGS);
+#pragma unroll
+      for (int c = 0; c < CN; c++) v[RC + c] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + c * 1024, (int)(nb0 << 4), 0);
+      // tombstones: words 2 lane, 2 lane + 1 of the sub-block's 128; no bitmap / past its end: zeros without a memory access
+      __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(del ? del : post), 0, del ? (int)(del_words << 2) : 0, BM_RSRC_FLAGS);
+      const auto dw = __builtin_amdgcn_raw_buffer_load_b64(rd, lane * 8, (int)(item * (uint32_t)(BM_SUB / 8)), 0);
+      v[DX] = u32x4{dw[0], dw[1], 0u, 0u};
+    }
   };
 
-  u32x4 vA[RC], vB[RC];
+  u32x4 vA[RCX], vB[RCX];
   uint32_t B0[NT], B1[NT], B2[NT];
   uint32_t vbnd[NT];
+  uint32_t NB0 = 0u, NB1 = 0u, NB2 = 0u, vbndN = 0u, item0 = 0u;  // the NOT list's boundaries (EXCL); item0 = first item of the boundary block
   uint32_t* tau_q = tau + (size_t)qi * BM_TAU_STRIDE;
 
   // One item: prefetch the next one, accumulate the bounds of this one, decide.  Returns true when some doc may enter the
@@ -480,11 +589,28 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
   uint32_t qthr_hit = 0u;
   float thr_hit = 0.f;
   uint32_t hb0[NT], hb1[NT];
-  auto body = [&](u32x4(&cur)[RC], u32x4(&nxt)[RC], uint32_t i) -> bool {
+  auto body = [&](u32x4(&cur)[RCX], u32x4(&nxt)[RCX], uint32_t i) -> bool {
     const uint32_t tau_bits = __hip_atomic_load(tau_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int t = 0; t < NT; t++) B2[t] = __builtin_amdgcn_readlane(vbnd[t], i + 2);
-    issue_loads(nxt, B1, B2);
+    if constexpr (EXCL) NB2 = __builtin_amdgcn_readlane(vbndN, i + 2);
+    issue_loads(nxt, B1, B2, NB1, NB2, item0 + i + 1u);
+    // EXCL: the NOT list's chunks of this item and the tombstone words, applied where the instance wants them
+    auto exclusions = [&](uint32_t& dec, bool& over) {
+      if constexpr (EXCL) {
+        const uint32_t nn16 = NB1 - NB0;
+#pragma unroll
+        for (int c = 0; c < CN; c++)
+          if ((uint32_t)c * 64u < nn16) s16_not_chunk<CNT && !AND>(cur[RC + c], accb, dec);
+        if (nn16 > (uint32_t)CN * 64u) {
+          over = true;
+          __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ntptr, 0, (int)(NB1 << 4), BM_RSRC_FLAGS);
+          for (uint32_t u = NB0 + CN * 64u; u < NB1; u += 64u)
+            s16_not_chunk<CNT && !AND>(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0), accb, dec);
+        }
+        if (del) s16_del_bits<CNT && !AND>(cur[DX].x, cur[DX].y, accb, lane, dec);
+      }
+    };
     uint32_t maxn = 0;
 #pragma unroll
     for (int t = 0; t < NT; t++) maxn = max(maxn, B1[t] - B0[t]);
@@ -507,6 +633,11 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
           }
         };
         seg(std::integral_constant<int, 0>{}, [&](const u32x4 v) { s16a_first(v, fidf[0], accb); });
+        if constexpr (EXCL) {  // an excluded doc loses the entry its first posting created: it can reach no level
+          uint32_t nodec = 0u;
+          bool noover = false;
+          exclusions(nodec, noover);
+        }
         if constexpr (NT == 3) seg(std::integral_constant<int, 1>{}, [&](const u32x4 v) { s16a_mid(v, fidf[1], accb, 1u); });
         seg(std::integral_constant<int, NT - 1>{}, [&](const u32x4 v) { mx = s16a_last<CNT, false>(v, fidf[NT - 1], accb, (uint32_t)NT - 1u, mx, cnt); });
         if (CNT) T.matched += cnt;
@@ -538,6 +669,67 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
       bool over = false;  // some segment is longer than its register chunks: the remainder is streamed synchronously (and written)
 #pragma unroll
       for (int t = 0; t < NT; t++) over = over || (B1[t] - B0[t]) > (uint32_t)Cfg::cpt(t) * 64u;
+      if constexpr (EXCL) {
+        // the exclusions FIRST, as marks (S16_MARK): the NOT list's docs and the tombstoned docs of the sub-block; the terms then
+        // accumulate as always -- reading sign-extended, so a marked doc neither counts as a first touch nor reaches a threshold --
+        // and the last term is only read, as in the plain instances
+        {
+          const uint32_t nn16 = NB1 - NB0;
+#pragma unroll
+          for (int c = 0; c < CN; c++)
+            if ((uint32_t)c * 64u < nn16) s16_mark_chunk(cur[RC + c], accb);
+          if (nn16 > (uint32_t)CN * 64u) {
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ntptr, 0, (int)(NB1 << 4), BM_RSRC_FLAGS);
+            for (uint32_t u = NB0 + CN * 64u; u < NB1; u += 64u) s16_mark_chunk(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0), accb);
+          }
+          if (del) s16_mark_bits(cur[DX].x, cur[DX].y, accb, lane);
+        }
+#pragma unroll
+        for (int t = 0; t + 1 < NT; t++) {
+          const uint32_t n16 = B1[t] - B0[t];
+#pragma unroll
+          for (int c = 0; c < Cfg::CPTMAX; c++)
+            if (c < Cfg::cpt(t) && (uint32_t)c * 64u < n16) mx = s16_keep<CNT, true>(cur[Cfg::off(t) + c], fidf[t], accb, mx, cnt);
+          if (n16 > (uint32_t)Cfg::cpt(t) * 64u) {
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[t], 0, (int)(B1[t] << 4), BM_RSRC_FLAGS);
+            for (uint32_t u = B0[t] + Cfg::cpt(t) * 64u; u < B1[t]; u += 64u)
+              mx = s16_keep<CNT, true>(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0), fidf[t], accb, mx, cnt);
+          }
+        }
+        constexpr int CL = Cfg::cpt(NT - 1), OL = Cfg::off(NT - 1);
+        const uint32_t nlast = B1[NT - 1] - B0[NT - 1];
+        uint32_t nwL[CL][4];
+#pragma unroll
+        for (int c = 0; c < CL; c++)
+          if ((uint32_t)c * 64u < nlast) mx = s16_read<CNT, true>(cur[OL + c], fidf[NT - 1], accb, mx, nwL[c], cnt);
+        if (nlast > (uint32_t)CL * 64u) {
+          __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[NT - 1], 0, (int)(B1[NT - 1] << 4), BM_RSRC_FLAGS);
+          for (uint32_t u = B0[NT - 1] + CL * 64u; u < B1[NT - 1]; u += 64u)
+            mx = s16_keep<CNT, true>(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0), fidf[NT - 1], accb, mx, cnt);
+        }
+        T.matched += cnt;
+        const float thr = fmaxf(T.wsc, __uint_as_float(tau_bits));
+        const uint32_t qthr = k ? (thr > 0.f ? (uint32_t)(thr * scale_thr) : 0u) : 0xFFFFFFFFu;
+        if (__ballot(mx >= (k ? qthr + S16_MBITS : 0xFFFFFFFFu))) {
+          // the candidate path clears the excluded docs (marks and what was added to them) before it looks at the tile
+          hit = true;
+#pragma unroll
+          for (int c = 0; c < CL; c++)
+            if ((uint32_t)c * 64u < nlast) {
+              const u32x4 v = cur[OL + c];
+              lds_st16(s16_addr(v.x, accb), nwL[c][0]);
+              lds_st16(s16_addr(v.y, accb), nwL[c][1]);
+              lds_st16(s16_addr(v.z, accb), nwL[c][2]);
+              lds_st16(s16_addr(v.w, accb), nwL[c][3]);
+            }
+          qthr_hit = qthr;
+          thr_hit = thr;
+#pragma unroll
+          for (int t = 0; t < NT; t++) { hb0[t] = B0[t]; hb1[t] = B1[t]; }
+        } else {
+          s16_clear(wb, lane);  // (terms, marks: more narrow stores than the 9 wide ones of the whole slice)
+        }
+      } else {
 #pragma unroll
       for (int t = 0; t + 1 < NT; t++) {  // the first term finds an empty tile: written without a read
         const uint32_t n16 = B1[t] - B0[t];
@@ -605,9 +797,11 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
       } else {
         s16_clear(wb, lane);
       }
+      }  // !EXCL
     }
 #pragma unroll
     for (int t = 0; t < NT; t++) { B0[t] = B1[t]; B1[t] = B2[t]; }
+    if constexpr (EXCL) { NB0 = NB1; NB1 = NB2; }
     return hit;
   };
 
@@ -615,6 +809,7 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
     const uint32_t j = s0 + (uint32_t)lane;
 #pragma unroll
     for (int t = 0; t < NT; t++) vbnd[t] = rowp[t][j < s_end ? j : s_end];
+    if constexpr (EXCL) { vbndN = nrowp[j < s_end ? j : s_end]; item0 = s0; }
     const uint32_t cnt = min(BLK, s_end - s0);
     uint32_t i = 0;
     while (i < cnt) {
@@ -624,7 +819,8 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
         B0[t] = __builtin_amdgcn_readlane(vbnd[t], i);
         B1[t] = __builtin_amdgcn_readlane(vbnd[t], i + 1);
       }
-      issue_loads(vA, B0, B1);
+      if constexpr (EXCL) { NB0 = __builtin_amdgcn_readlane(vbndN, i); NB1 = __builtin_amdgcn_readlane(vbndN, i + 1); }
+      issue_loads(vA, B0, B1, NB0, NB1, s0 + i);
       bool hit, in_a;
       for (;;) {
         in_a = true;
@@ -643,7 +839,9 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
         S16Item<NT> it;
 #pragma unroll
         for (int t = 0; t < NT; t++) { it.tptr[t] = tptr[t]; it.idf[t] = idf[t]; it.fidf[t] = fidf[t]; it.b0[t] = hb0[t]; it.b1[t] = hb1[t]; it.qpos[t] = qpos[t]; }
-        T = s16_trigger<NT, KPL, AND>(T, cc, it, wb, qthr_hit, thr_hit, (s0 + i - 1u) << BM_SUB_LOG2, k, tau_q, del, del_words);
+        const bm_vquery* __restrict__ Qh = qs + qi;  // (fetched here: nothing of the exclusions lives across the streaming loop)
+        const S16Excl ex{Qh, post, term_base, sub_off, del, Qh->n_terms, bm_q_nnot(Qh->op), row_len, del_words, s0 + i - 1u};
+        T = s16_trigger<NT, KPL, AND>(T, cc, it, wb, qthr_hit, thr_hit, (s0 + i - 1u) << BM_SUB_LOG2, k, tau_q, ex);
       }
     }
   }
@@ -654,45 +852,59 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
   if (CNT && lane == 0 && T.matched) atomicAdd(&total[qi], T.matched);
 }
 
-template <int NT, int KPL, bool CNT, bool AND>
+template <int NT, int KPL, bool CNT, bool AND, bool EXCL = false>
 int launch16(const BmParams& p, hipStream_t st) {
   constexpr int lds = S16_WAVES * S16_WAVE_LDS;
-  SS_SET_MAX_LDS((bm25_scan16_kernel<NT, KPL, CNT, AND>), lds);
+  SS_SET_MAX_LDS((bm25_scan16_kernel<NT, KPL, CNT, AND, EXCL>), lds);
   const uint32_t A = p.nq * p.P;
-  bm25_scan16_kernel<NT, KPL, CNT, AND><<<(A + S16_WAVES - 1) / S16_WAVES, S16_WAVES * 64, lds, st>>>(
+  bm25_scan16_kernel<NT, KPL, CNT, AND, EXCL><<<(A + S16_WAVES - 1) / S16_WAVES, S16_WAVES * 64, lds, st>>>(
       p.post, p.term_base, p.sub_off, p.q, p.part_keys, p.total, p.tau, p.del, p.del_words, p.n_sub, p.n_terms, p.nq, p.P, p.k);
   return SS_OK;
 }
 
 }  // namespace
 
-// unions of <= 4 lists (five and six: top-k only) without NOT terms, k <= 64 (at k = 100 the f32 scan is 5 % ahead); exact counts (TopkCount, and Count
-// with k = 0) as long as the shard has no tombstones -- a deleted doc must not count, and only the f32 kernel's dense tile scan
-// looks at the tombstone bitmap of every doc.  Intersections (and_exact_nt != 0): batches of intersections only, every query
-// with exactly and_exact_nt = 2 or 3 terms over one list each, no all_terms_frequent shortcut (the dispatch checks).
-bool ssi_bm25_scan16_serves(uint32_t nt_max, uint32_t np_max, bool has_and, bool count, bool tombstones, int KPL, uint32_t k, uint32_t and_exact_nt) {
+// What the 16-bit tile serves (everything else of the exhaustive strategy stays on bm25_scan_fast_kernel's f32 tile):
+//  * unions of <= 4 lists (five and six: top-k only), k <= 64, exact counts (TopkCount, and Count with k = 0);
+//  * NOT lists (nn_max of them in some query): a top-k request never streams them -- the candidate path clears their docs from the tile before it
+//    looks at it (s16_exclude); a count request streams ONE NOT list beside the terms (EXCL instances);
+//  * tombstones: top-k in the candidate path, counts in the EXCL instances (the sub-block's 128 tombstone words per item);
+//  * intersections (and_exact_nt != 0): batches of intersections only, every query with exactly and_exact_nt = 2 or 3 terms over one
+//    list each, no all_terms_frequent shortcut (the dispatch checks); NOT lists / tombstones as for unions.
+bool ssi_bm25_scan16_serves(uint32_t nn_max, uint32_t np_max, bool has_and, bool count, bool tombstones, int KPL, uint32_t k, uint32_t and_exact_nt) {
   static const int off = [] { const char* e = getenv("SS_BM25_SCAN16"); return e ? atoi(e) == 0 : 0; }();
   static const int cnt_off = [] { const char* e = getenv("SS_BM25_SCAN16_COUNT"); return e ? atoi(e) == 0 : 0; }();
   static const int and_off = [] { const char* e = getenv("SS_BM25_SCAN16_AND"); return e ? atoi(e) == 0 : 0; }();
-  if (count && (tombstones || cnt_off)) return false;
-  if (has_and && (and_off || and_exact_nt < 2 || and_exact_nt > 3 || and_exact_nt != nt_max)) return false;
+  static const int excl_off = [] { const char* e = getenv("SS_BM25_SCAN16_EXCL"); return e ? atoi(e) == 0 : 0; }();
   static const int wide_off = [] { const char* e = getenv("SS_BM25_SCAN16_WIDE"); return e ? atoi(e) == 0 : 0; }();
-  if (nt_max > 4 && (has_and || count || wide_off)) return false;  // five / six lists: plain top-k unions
-  return !off && (k != 0 || count) && nt_max == np_max && nt_max >= 1 && nt_max <= 6 && KPL == 1;
+  const uint32_t nn = nn_max;  // NOT lists of the query that has the most
+  if (count && cnt_off) return false;
+  if ((nn || tombstones) && excl_off) return false;
+  if (count && nn > 1) return false;    // the count instances stream one NOT list
+  if (nn > 8) return false;
+  if (has_and && (and_off || and_exact_nt < 2 || and_exact_nt > 3 || and_exact_nt != np_max)) return false;
+  if (np_max > 4 && (has_and || count || wide_off)) return false;  // five / six lists: plain top-k unions
+  return !off && (k != 0 || count) && np_max >= 1 && np_max <= 6 && KPL == 1;
 }
 
-int ssi_bm25_launch_scan16(const BmParams& p, uint32_t nt_max, bool is_and, int KPL, hipStream_t st) {
-  const int NT = nt_max <= 2 ? 2 : (int)nt_max;
+int ssi_bm25_launch_scan16(const BmParams& p, uint32_t np_max, uint32_t nn_max, bool is_and, int KPL, hipStream_t st) {
+  const int NT = np_max <= 2 ? 2 : (int)np_max;
+  const bool excl = p.count && (p.del != nullptr || nn_max != 0);  // exclusions inside the streaming loop: exact counts only
+  if (KPL != 1) return SS_ENOTSUP;
   if (is_and) {
-    if (NT == 2 && KPL == 1) return p.count ? launch16<2, 1, true, true>(p, st) : launch16<2, 1, false, true>(p, st);
-    if (NT == 3 && KPL == 1) return p.count ? launch16<3, 1, true, true>(p, st) : launch16<3, 1, false, true>(p, st);
+#define SS_A(NT_)                                                                                                          \
+  if (NT == NT_)                                                                                                           \
+    return !p.count ? launch16<NT_, 1, false, true>(p, st) : excl ? launch16<NT_, 1, true, true, true>(p, st) : launch16<NT_, 1, true, true>(p, st);
+    SS_A(2) SS_A(3)
+#undef SS_A
     return SS_ENOTSUP;
   }
-#define SS_F(NT_, KPL_)                                                    \
-  if (NT == NT_ && KPL == KPL_) return p.count ? launch16<NT_, KPL_, true, false>(p, st) : launch16<NT_, KPL_, false, false>(p, st);
-  SS_F(2, 1) SS_F(3, 1) SS_F(4, 1)
+#define SS_F(NT_)                                                                                                          \
+  if (NT == NT_)                                                                                                           \
+    return !p.count ? launch16<NT_, 1, false, false>(p, st) : excl ? launch16<NT_, 1, true, false, true>(p, st) : launch16<NT_, 1, true, false>(p, st);
+  SS_F(2) SS_F(3) SS_F(4)
 #undef SS_F
-  if (NT == 5 && KPL == 1 && !p.count) return launch16<5, 1, false, false>(p, st);
-  if (NT == 6 && KPL == 1 && !p.count) return launch16<6, 1, false, false>(p, st);
+  if (NT == 5 && !p.count) return launch16<5, 1, false, false>(p, st);
+  if (NT == 6 && !p.count) return launch16<6, 1, false, false>(p, st);
   return SS_ENOTSUP;
 }

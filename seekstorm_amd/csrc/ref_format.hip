@@ -58,8 +58,11 @@ inline bool read_position(const uint8_t* a, uint64_t len, uint64_t pos, uint32_t
 namespace {
 // pos_out (optional): the positions of every posting appended in posting order, ABSOLUTE (the file stores the first position
 // and then gap - 1: get_next_position_singlefield + 1, add_result.rs:3596-3684); a position beyond 65 535 -> SS_ENOTSUP
+// N-gram keys (n_components 2 / 3): the record's positions are the KEY's own (the positions of its first word, tokenizer.rs:699:
+// "position - 1"); they are handed out with component 0 and counted in npos_out, the other components get none.
+// npos_out (with pos_out): positions per posting -- the tf for a SingleTerm key, the key's positions_count / 0 for n-gram components.
 int decode_block(const ss_ref_block* b, uint32_t n_components, uint32_t component, uint16_t* docs_out, uint16_t* tfs_out,
-                 std::vector<uint16_t>* pos_out = nullptr);
+                 std::vector<uint16_t>* pos_out = nullptr, std::vector<uint16_t>* npos_out = nullptr);
 }
 // Decodes one block.  docs_out / tfs_out need room for 65 536 entries.  Returns the posting count or a negative code.
 extern "C" int ss_ref_decode_block(const ss_ref_block* b, uint16_t* docs_out, uint16_t* tfs_out) {
@@ -90,12 +93,27 @@ extern "C" int ss_ref_decode_block_ngram(const ss_ref_block* b, uint32_t n_compo
   if (n_components < 2 || n_components > 3 || component >= n_components) return SS_EINVAL;
   return decode_block(b, n_components, component, docs_out, tfs_out);
 }
+// ... and the n-gram key's OWN positions (the record's positions_count and positions behind the component tfs: what the phrase
+// check walks for a query term that resolved to the key, add_result.rs:2074-2089, 3596-3684): npos_out [65536] = positions per
+// posting, pos_out = their concatenation.  tfs_out = tf of component 0.
+extern "C" int ss_ref_decode_block_ngram_positions(const ss_ref_block* b, uint32_t n_components, uint16_t* docs_out, uint16_t* tfs_out,
+                                                   uint16_t* npos_out, uint16_t* pos_out, uint64_t pos_cap, uint64_t* n_pos_out) {
+  if (n_components < 2 || n_components > 3 || !npos_out || !n_pos_out) return SS_EINVAL;
+  std::vector<uint16_t> pos, np;
+  const int n = decode_block(b, n_components, 0, docs_out, tfs_out, &pos, &np);
+  if (n < 0) return n;
+  *n_pos_out = pos.size();
+  if (pos.size() > pos_cap) return SS_EINVAL;
+  if (pos_out && !pos.empty()) std::memcpy(pos_out, pos.data(), pos.size() * sizeof(uint16_t));
+  std::memcpy(npos_out, np.data(), np.size() * sizeof(uint16_t));
+  return n;
+}
 namespace {
 int decode_block(const ss_ref_block* b, uint32_t n_components, uint32_t component, uint16_t* docs_out, uint16_t* tfs_out,
-                 std::vector<uint16_t>* pos_out) {
+                 std::vector<uint16_t>* pos_out, std::vector<uint16_t>* npos_out) {
   if (!b || !b->byte_array || !docs_out || !tfs_out) return SS_EINVAL;
-  if (pos_out && n_components > 1) return SS_ENOTSUP;  // an n-gram key's positions are the n-gram's, not its components'
   const bool ngram = n_components > 1;
+  if (pos_out && ngram && !npos_out) return SS_EINVAL;  // an n-gram key's positions are the key's, not its components': counted apart
   const uint8_t* a = b->byte_array;
   const uint64_t len = b->byte_array_len;
   // a position takes at least one byte of its record, an embedded pointer holds at most 4: a block cannot carry more positions
@@ -158,12 +176,18 @@ int decode_block(const ss_ref_block* b, uint32_t n_components, uint32_t componen
     }
     return false;
   };
-  // the positions of a record behind a non-embedded pointer: `tf` VINTs after the count, each "gap - 1" after the first
-  auto record_positions = [&](uint64_t back, uint32_t tf) -> int {
+  // the positions of a record behind a non-embedded pointer: [n-gram keys: the component tfs,] the count, then that many VINTs,
+  // each "gap - 1" after the first
+  auto record_positions = [&](uint64_t back, uint32_t* count_out) -> int {
     uint64_t pos = range - back;
-    uint32_t v, at = 0;
-    if (!read_vint(a, len, pos, &v)) return SS_EINVAL;  // the count again
-    pos += a[pos] & 0x80u ? 1u : (a[pos + 1] & 0x80u ? 2u : 3u);
+    uint32_t v, at = 0, tf = 0;
+    for (uint32_t c = 0; c <= (ngram ? n_components : 0u); c++) {  // (component tfs,) the count
+      if (!read_vint(a, len, pos, &v)) return SS_EINVAL;
+      pos += a[pos] & 0x80u ? 1u : (a[pos + 1] & 0x80u ? 2u : 3u);
+      tf = v;
+    }
+    if (tf == 0u || tf > 65535u) return SS_EINVAL;
+    *count_out = tf;
     for (uint32_t i = 0; i < tf; i++) {
       if (!read_position(a, len, pos, &v)) return SS_EINVAL;
       pos += a[pos] & 0x80u ? 1u : (a[pos + 1] & 0x80u ? 2u : 3u);
@@ -185,7 +209,7 @@ int decode_block(const ss_ref_block* b, uint32_t n_components, uint32_t componen
     return SS_OK;
   };
   for (uint32_t r = 0; r < count; r++) {
-    uint32_t tf = 0;
+    uint32_t tf = 0, np_r = 0xFFFFFFFFu;  // np_r: positions of a recorded posting (embedded ones carry their tf)
     if (r < pivot) {
       const uint64_t at = range + (uint64_t)r * 2u;
       if (at + 2u > len) return SS_EINVAL;
@@ -201,8 +225,8 @@ int decode_block(const ss_ref_block* b, uint32_t n_components, uint32_t componen
         }
       } else if (!record_tf(p & 0x7FFFu, &tf)) {
         return SS_EINVAL;
-      } else if (pos_out) {
-        const int rc = record_positions(p & 0x7FFFu, tf);
+      } else if (pos_out && (!ngram || component == 0u)) {
+        const int rc = record_positions(p & 0x7FFFu, &np_r);
         if (rc) return rc;
       }
     } else {
@@ -222,13 +246,14 @@ int decode_block(const ss_ref_block* b, uint32_t n_components, uint32_t componen
         }
       } else if (!record_tf(p & 0x7FFFFFu, &tf)) {
         return SS_EINVAL;
-      } else if (pos_out) {
-        const int rc = record_positions(p & 0x7FFFFFu, tf);
+      } else if (pos_out && (!ngram || component == 0u)) {
+        const int rc = record_positions(p & 0x7FFFFFu, &np_r);
         if (rc) return rc;
       }
     }
     if (tf == 0u || tf > 65535u) return SS_EINVAL;  // positions_count >= 1 always; component tfs likewise
     tfs_out[r] = (uint16_t)tf;
+    if (pos_out && npos_out) npos_out->push_back((uint16_t)(ngram ? (component == 0u ? np_r : 0u) : tf));
   }
   return (int)count;
 }
@@ -725,11 +750,11 @@ extern "C" int ss_index_bin_term_keys(const ss_index_bin* ix, uint64_t* keys_out
 namespace {
 // decoded postings of one term appended to docs / tfs
 int index_bin_term(const ss_index_bin* ix, uint32_t term, std::vector<uint32_t>& docs, std::vector<uint16_t>& tfs,
-                   uint16_t* d16, uint16_t* t16, std::vector<uint16_t>* pos = nullptr) {
+                   uint16_t* d16, uint16_t* t16, std::vector<uint16_t>* pos = nullptr, std::vector<uint16_t>* npos = nullptr) {
   if (ix->n_fields != 1) return SS_ENOTSUP;  // BM25F field vectors: SURVEY section 8 f-2
   for (uint64_t bi = ix->term_block_off[term]; bi < ix->term_block_off[term + 1]; bi++) {
     const ss_ref_block& b = ix->blocks[bi].b;
-    const int n = decode_block(&b, ix->blocks[bi].n_comp, ix->blocks[bi].comp, d16, t16, pos);
+    const int n = decode_block(&b, ix->blocks[bi].n_comp, ix->blocks[bi].comp, d16, t16, pos, npos);
     if (n < 0) return n;
     for (int i = 0; i < n; i++) {
       const uint64_t doc = ((uint64_t)b.block_id << 16) | d16[i];
@@ -820,8 +845,9 @@ extern "C" int ss_bm25_upload_index_bin(ss_shard* s, const ss_index_bin* ix) {
   if (ix->n_fields > 1) return ss_bm25_upload_index_bin_fields(s, ix, nullptr);
   return upload_index_bin_single(s, ix, false);
 }
-// The image plus the positions of every posting, for phrase queries: SingleTerm keys only (SS_ENOTSUP for an index with n-gram
-// keys or a position beyond 65 535).  Several indexed fields: boost = 1 (ss_bm25_upload_index_bin_fields_positions takes boosts).
+// The image plus the positions of every posting, for phrase queries (SS_ENOTSUP for a position beyond 65 535).  An n-gram key's
+// own positions go to its first component term (one indexed field; several: still SS_ENOTSUP).  Several indexed fields: boost = 1
+// (ss_bm25_upload_index_bin_fields_positions takes boosts).
 extern "C" int ss_bm25_upload_index_bin_positions(ss_shard* s, const ss_index_bin* ix) {
   if (!s || !ix) return SS_EINVAL;
   if (ix->keys.empty() || ix->n_docs == 0) return SS_EINVAL;
@@ -840,13 +866,14 @@ namespace {
 int upload_index_bin_single(ss_shard* s, const ss_index_bin* ix, bool with_positions) {
   const uint32_t n_all = (uint32_t)ix->keys.size(), n_dense = std::min<uint32_t>(ix->n_dense, n_all);  // ss_index_bin_tier
   if (n_dense == 0) return SS_EINVAL;           // the dense image needs at least one list
-  if (with_positions && n_dense != n_all) return SS_ENOTSUP;  // no phrases over sparse lists
+  // (positions with a sparse tier: the dense terms get theirs -- phrases over dense terms work, a phrase naming a sparse term is
+  // refused at search time like every phrase / filter over sparse terms)
   std::vector<uint64_t> offs((size_t)n_dense + 1, 0);
   std::vector<uint32_t> docs;
-  std::vector<uint16_t> tfs, d16(65536), t16(65536), pos;
+  std::vector<uint16_t> tfs, d16(65536), t16(65536), pos, npos;
   for (uint32_t t = 0; t < n_dense; t++) {
     offs[t] = docs.size();
-    const int rc = index_bin_term(ix, t, docs, tfs, d16.data(), t16.data(), with_positions ? &pos : nullptr);
+    const int rc = index_bin_term(ix, t, docs, tfs, d16.data(), t16.data(), with_positions ? &pos : nullptr, with_positions ? &npos : nullptr);
     if (rc) return rc;
   }
   offs[n_dense] = docs.size();
@@ -855,6 +882,10 @@ int upload_index_bin_single(ss_shard* s, const ss_index_bin* ix, bool with_posit
   // avgdl = positions_sum_normalized / indexed_doc_count as the reference's reader computes it (index.rs:3480-3482)
   int rc = ssi_bm25_upload(s, ix->n_docs, doclen.data(), n_dense, offs.data(), docs.data(), tfs.data(), ix->positions_sum);
   if (rc) return rc;
+  if (with_positions) {
+    rc = ssi_bm25_attach_positions(s, offs.data(), docs.data(), tfs.data(), pos.data(), pos.size(), npos.data());
+    if (rc) return rc;
+  }
   if (n_dense < n_all) {  // the rare keys: decoded the same way, appended to the sparse tier (term ids continue behind the dense ones)
     std::vector<uint64_t> so((size_t)(n_all - n_dense) + 1, 0);
     std::vector<uint32_t> sd;
@@ -867,7 +898,6 @@ int upload_index_bin_single(ss_shard* s, const ss_index_bin* ix, bool with_posit
     so[n_all - n_dense] = sd.size();
     return ss_bm25_append_sparse(s, n_all - n_dense, so.data(), sd.data(), st.data(), nullptr);
   }
-  if (!with_positions) return rc;
-  return ssi_bm25_attach_positions(s, offs.data(), docs.data(), tfs.data(), pos.data(), pos.size());
+  return rc;
 }
 }  // namespace

@@ -230,10 +230,10 @@ int ss_bm25_upload_positions(ss_shard* s, uint64_t n_docs, const uint8_t* doclen
 
 // positions of the image just built (CSR order); a failure leaves no image behind
 int ssi_bm25_attach_positions(ss_shard* s, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs, const uint16_t* positions,
-                              uint64_t n_positions) {
+                              uint64_t n_positions, const uint16_t* npos) {
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
-  const int rc = ssi_bm25_upload_positions(s, offs, docs, tfs, positions, n_positions);
+  const int rc = ssi_bm25_upload_positions(s, offs, docs, tfs, positions, n_positions, npos);
   if (rc) free_bm25(s);
   return rc;
 }
@@ -480,7 +480,7 @@ int ss_bm25_term_probed(ss_shard* s, uint32_t n, const uint32_t* terms, uint8_t*
 }
 
 int ss_bm25_set_strategy(ss_shard* s, int strategy) {
-  if (!s || strategy < SS_BM25_AUTO || strategy > SS_BM25_PRUNED) return SS_EINVAL;
+  if (!s || strategy < SS_BM25_AUTO || strategy > SS_BM25_EXHAUSTIVE_F32) return SS_EINVAL;
   std::lock_guard<std::mutex> g(s->mu);
   s->bm_strategy = strategy;
   return SS_OK;
@@ -540,8 +540,8 @@ int ss_bm25_sparse_info(ss_shard* s, uint32_t* n_lists, uint64_t* n_postings, ui
 // any_filter: some query carries a field filter (on an image with merged lists the others read one list per term)
 static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q, bool* has_and, bool* has_or, uint32_t* nt_max,
                          uint32_t* np_max, bool* all_probed, bool* any_frequent, bool* phrase = nullptr, bool* any_filter = nullptr,
-                         bool* uniform = nullptr, bool* gated = nullptr) {
-  uint32_t n_phrase = 0, np_min = 0xFFFFFFFFu;
+                         bool* uniform = nullptr, bool* gated = nullptr, uint32_t* nn_max = nullptr) {
+  uint32_t n_phrase = 0, np_min = 0xFFFFFFFFu, most_not = 0;
   bool some_gated = false;
   const uint32_t L = s->bm_n_fields, RF = bm_real_fields(s);  // lists per term, indexed fields
   bool some_filter = false;
@@ -559,12 +559,11 @@ static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q,
     if (op == SS_OP_PHRASE) {  // QueryType::Phrase: unique terms + the words in order (non_unique_query_list)
       if (!phrase) return SS_ENOTSUP;
       if (q[i].phrase_len < 2 || q[i].phrase_len > SS_MAX_PHRASE) return SS_EINVAL;
-      uint32_t used = 0;
-      for (uint32_t j = 0; j < q[i].phrase_len; j++) {
-        if (q[i].phrase_seq[j] >= q[i].n_terms) return SS_EINVAL;
-        used |= 1u << q[i].phrase_seq[j];
-      }
-      if (used != (1u << q[i].n_terms) - 1u) return SS_EINVAL;  // every unique term is a word of the phrase
+      // every place names a unique term, or SS_PHRASE_SKIP: a place inside an n-gram key, whose entry stands at the key's first word
+      // (the key's other component terms are scored with the rest, they are no words of the phrase)
+      if (q[i].phrase_seq[0] >= q[i].n_terms) return SS_EINVAL;
+      for (uint32_t j = 1; j < q[i].phrase_len; j++)
+        if (q[i].phrase_seq[j] >= q[i].n_terms && q[i].phrase_seq[j] != SS_PHRASE_SKIP) return SS_EINVAL;
       if (n_not || q[i].n_terms > 6) return SS_ENOTSUP;
       // several indexed fields: over the merged lists and their field-tagged positions (a corpus whose boosts kept the merged
       // lists from being built has no phrase path)
@@ -614,7 +613,9 @@ static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q,
     *np_max = std::max(*np_max, q[i].n_terms);
     np_min = std::min(np_min, q[i].n_terms);
     any_not |= n_not != 0;
+    most_not = std::max(most_not, n_not);
   }
+  if (nn_max) *nn_max = most_not;  // the most NOT terms any query of the batch has (nt_max - np_max says only that there are some)
   if (uniform) *uniform = np_min == *np_max;  // every query with the same number of terms
   if (gated) *gated = some_gated;
   // "the batch holds NOT terms" travels as nt_max > np_max (the kernels' filtered variants are chosen by it): keep that true
@@ -824,11 +825,11 @@ static int bm25_search_split_batch(ss_shard* s, uint32_t nq, const ss_bm25_query
     perm[at] = i;
     qs[at] = q[i];
   }
-  struct Part { bool has_and, has_or, all_probed, any_frequent, phrase, any_filter, uniform, gated; uint32_t nt_max, np_max; } part[2];
+  struct Part { bool has_and, has_or, all_probed, any_frequent, phrase, any_filter, uniform, gated; uint32_t nt_max, np_max, nn_max; } part[2];
   const uint32_t begin[2] = {0, n_probed}, count[2] = {n_probed, nq - n_probed};
   for (int h = 0; h < 2; h++)
     SS_TRY(check_queries(s, count[h], qs.data() + begin[h], &part[h].has_and, &part[h].has_or, &part[h].nt_max, &part[h].np_max,
-                         &part[h].all_probed, &part[h].any_frequent, &part[h].phrase, &part[h].any_filter, &part[h].uniform, &part[h].gated));
+                         &part[h].all_probed, &part[h].any_frequent, &part[h].phrase, &part[h].any_filter, &part[h].uniform, &part[h].gated, &part[h].nn_max));
   SS_HIP(hipSetDevice(s->device));
   const uint32_t kw = std::max<uint32_t>(kk, 1);
   SS_TRY(ensure_out(s, 2 * (size_t)nq, kw));  // upper half: the answers in the order they ran in
@@ -851,7 +852,7 @@ static int bm25_search_split_batch(ss_shard* s, uint32_t nq, const ss_bm25_query
     for (int h = 0; h < 2; h++) {
       const int rc = ssi_bm25_search(s, count[h], d_q + begin[h], kk, rt, t_doc + (size_t)begin[h] * kw, t_score + (size_t)begin[h] * kw,
                                      t_count + begin[h], t_total + begin[h], part[h].has_and, part[h].has_or, part[h].nt_max,
-                                     part[h].np_max, part[h].all_probed, s->stream, part[h].any_frequent, part[h].phrase, part[h].any_filter, part[h].uniform, part[h].gated);
+                                     part[h].np_max, part[h].all_probed, s->stream, part[h].any_frequent, part[h].phrase, part[h].any_filter, part[h].uniform, part[h].gated, part[h].nn_max);
       if (rc != SS_OK) return rc;
     }
     return (int)SS_OK;
@@ -978,9 +979,9 @@ static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_quer
     }
   }
   bool has_and = false, has_or = false;
-  uint32_t nt_max = 0, np_max = 0;
+  uint32_t nt_max = 0, np_max = 0, nn_max = 0;
   bool all_probed = false, any_frequent = false, phrase = false, any_filter = false, uniform = false, gated = false;
-  SS_TRY(check_queries(s, nq, q, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent, &phrase, &any_filter, &uniform, &gated));
+  SS_TRY(check_queries(s, nq, q, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent, &phrase, &any_filter, &uniform, &gated, &nn_max));
   SS_HIP(hipSetDevice(s->device));
   SS_TRY(ensure_out(s, nq, std::max<uint32_t>(kk, 1)));
   if ((size_t)nq * sizeof(ss_bm25_query) > s->bq_cap) {
@@ -992,7 +993,7 @@ static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_quer
   SS_HIP(hipMemcpyAsync(s->d_bq, q, (size_t)nq * sizeof(ss_bm25_query), hipMemcpyHostToDevice, s->stream));
   return with_facet_filter(s, n_filters, filters, s->stream, [&]() {
     return ssi_bm25_search(s, nq, (const ss_bm25_query*)s->d_bq, kk, rt, s->d_out_doc, s->d_out_score, s->d_out_count,
-                           s->d_out_total, has_and, has_or, nt_max, np_max, all_probed, s->stream, any_frequent, phrase, any_filter, uniform, gated);
+                           s->d_out_total, has_and, has_or, nt_max, np_max, all_probed, s->stream, any_frequent, phrase, any_filter, uniform, gated, nn_max);
   });
 }
 
@@ -1030,13 +1031,20 @@ inline void co_signal(ss_co_req* r, uint32_t st) {
 // wait until the state leaves "pending": a SHORT spin, then the futex.  (Spinning for about a batch's duration -- a sleeping
 // follower costs its leader a system call, ~1.5 us each -- was measured and is wrong for a library: 64 spinning callers ran the
 // process into its CPU quota, 185 K -> 47 K q/s with a p99 of 73 ms, the CFS throttling period; gpurun_out/conc_linger2.log)
+inline void co_cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield");
+#endif
+}
 inline uint32_t co_wait(ss_co_req* r, uint32_t spin_us) {
   const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us);
   for (;;) {
     for (int i = 0; i < 64; i++) {
       const uint32_t v = r->state.load(std::memory_order_acquire);
       if (v != 0u) return v;
-      __builtin_ia32_pause();
+      co_cpu_relax();
     }
     if (std::chrono::steady_clock::now() >= until) break;
   }
@@ -1051,8 +1059,12 @@ inline uint32_t co_wait(ss_co_req* r, uint32_t spin_us) {
 }
 // requests that can share a batch.  k may differ: the batch runs at the largest k and every member keeps its own prefix -- the
 // result order is total (score descending, then doc id ascending), so the top-k' of a query is the head of its top-k.
+// Only requests of one k CLASS merge (<= 64, <= 128, <= 256, more -- the kernels' top-k register budgets): a caller with a large k
+// must not push the others off the pruned / 16-bit kernels, which serve k <= 128 / k <= 64.
+inline uint32_t co_k_class(uint32_t k) { return k <= 64u ? 0u : k <= 128u ? 1u : k <= 256u ? 2u : 3u; }
 inline bool co_compatible(const ss_co_req* a, const ss_co_req* b) {
-  return (a->k == 0) == (b->k == 0) && a->rt == b->rt && a->elem == b->elem && a->thr == b->thr && (a->qscale != nullptr) == (b->qscale != nullptr);
+  return (a->k == 0) == (b->k == 0) && co_k_class(a->k) == co_k_class(b->k) && a->rt == b->rt && a->elem == b->elem && a->thr == b->thr &&
+         (a->qscale != nullptr) == (b->qscale != nullptr);
 }
 
 int co_run_lexical_one(ss_shard* s, ss_co_req* r) {
@@ -1466,7 +1478,8 @@ int ss_bm25_search_filtered_dev(ss_shard* s, uint32_t nq, const ss_bm25_query* d
                                                     : ((ops_mask >> 8) & 0xFFu ? (ops_mask >> 8) & 0xFFu : SS_MAX_QUERY_TERMS),
                            // the caller vouches for the probe rows of its terms (ss_bm25_term_probed) unless none were rationed
                            s->bm_probe_rows != 0 && (s->bm_probe_rows >= s->bm_n_terms || (ops_mask & 4u) != 0), st,
-                           (ops_mask & 8u) != 0, (ops_mask & 16u) != 0, (ops_mask & 32u) != 0, (ops_mask & 64u) != 0, (ops_mask & 128u) != 0);
+                           (ops_mask & 8u) != 0, (ops_mask & 16u) != 0, (ops_mask & 32u) != 0, (ops_mask & 64u) != 0, (ops_mask & 128u) != 0,
+                           (ops_mask >> 24) & 0xFu ? (ops_mask >> 24) & 0xFu : 0xFFFFFFFFu);
   });
 }
 

@@ -391,7 +391,7 @@ constexpr uint32_t BM_AND_GATED = 0x200u, BM_AND_TOUCH = 0x400u;
 int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t* d_out_doc,
                     float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, bool has_or,
                     uint32_t nt_max, uint32_t np_max, bool all_probed, hipStream_t st, bool any_frequent = false, bool phrase = false,
-                    bool any_field_filter = true, bool uniform_terms = false, bool any_gated = false);
+                    bool any_field_filter = true, bool uniform_terms = false, bool any_gated = false, uint32_t nn_max = 0xFFFFFFFFu);
 // indexed fields of the image (bm_n_fields counts the merged list as well)
 inline uint32_t bm_real_fields(const ss_shard* s) { return s->bm_n_fields - (s->bm_merged ? 1u : 0u); }
 // ---- implemented in synth.hip
@@ -405,11 +405,11 @@ int ssi_bm25_build_from_host(ss_shard* s, const uint8_t* doclen, const uint64_t*
 int ssi_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen, uint32_t n_terms, const uint64_t* offs,
                     const uint32_t* docs, const uint16_t* tfs, uint64_t positions_sum);
 int ssi_bm25_attach_positions(ss_shard* s, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs, const uint16_t* positions,
-                              uint64_t n_positions);
+                              uint64_t n_positions, const uint16_t* npos = nullptr);
 int ssi_bm25_upload_positions_fields(ss_shard* s, uint32_t n_terms, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
                                      const uint16_t* tfs, const uint16_t* positions, uint64_t n_positions);
 int ssi_bm25_upload_positions(ss_shard* s, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs, const uint16_t* positions,
-                              uint64_t n_positions);
+                              uint64_t n_positions, const uint16_t* npos = nullptr);
 int ssi_bm25_upload_fields_positions(ss_shard* s, uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost,
                                      uint32_t n_terms, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
                                      const uint16_t* tfs, uint64_t positions_sum, const uint16_t* positions, uint64_t n_positions);

@@ -401,12 +401,15 @@ int ssi_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, 
 // END offset of the positions of the posting at each (padded) image index relative to its term's first position (the start
 // is the previous slot's end, 0 at the term's first slot; NULL padding slots repeat the running end), d_pos_base = first
 // position of every term.  The image order of the postings equals the CSR order, so the pool is the caller's array as is.
+// npos (optional): the number of positions of every posting where that is not its tf -- the component terms of an n-gram key
+// (ref_format.hip): the key's own positions stand behind its FIRST component's postings, the other components have none.
 int ssi_bm25_upload_positions(ss_shard* s, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs, const uint16_t* positions,
-                              uint64_t n_positions) {
+                              uint64_t n_positions, const uint16_t* npos) {
+  if (!npos) npos = tfs;
   const uint32_t nt = s->bm_n_terms, ns = s->bm_n_sub;
   if (s->bm_n_fields != 1) return SS_ENOTSUP;
   std::vector<u64> pbase((size_t)nt + 1);
-  std::vector<uint32_t> poff((size_t)s->bm_n_post_pad + 1, 0u);
+  std::vector<uint32_t> poff((size_t)s->bm_n_post_pad + 5, 0u);  // + 4: the padding loop of a segment may run to the next multiple of 4 before the walk is checked
   u64 total = 0, w = 0;  // w: padded image index (dwords)
   for (uint32_t t = 0; t < nt; t++) {
     pbase[t] = total;
@@ -415,11 +418,12 @@ int ssi_bm25_upload_positions(ss_shard* s, const uint64_t* offs, const uint32_t*
       const u64 lim = ((u64)sb + 1) << BM_SUB_LOG2;
       u64 n = 0;
       for (; j < offs[t + 1] && docs[j] < lim; j++, n++) {
-        if (total + rel + tfs[j] > n_positions) return SS_EINVAL;  // never read past the caller's array (index.bin path: counts come from the file)
-        for (uint32_t x = 1; x < tfs[j]; x++)
+        if (total + rel + npos[j] > n_positions) return SS_EINVAL;  // never read past the caller's array (index.bin path: counts come from the file)
+        for (uint32_t x = 1; x < npos[j]; x++)
           if (positions[total + rel + x] <= positions[total + rel + x - 1]) return SS_EINVAL;  // ascending inside a posting
-        rel += tfs[j];
+        rel += npos[j];
         if (rel >= (1ull << 32)) return SS_ENOTSUP;
+        if (w >= s->bm_n_post_pad) return SS_EINVAL;  // more postings than the image holds: not the CSR it was built from
         poff[w++] = (uint32_t)rel;
       }
       for (u64 pad = (4 - (n & 3)) & 3; pad > 0; pad--) poff[w++] = (uint32_t)rel;  // NULL padding of the segment
@@ -448,7 +452,7 @@ int ssi_bm25_upload_positions_fields(ss_shard* s, uint32_t n_terms, const uint64
   if ((uint64_t)n_terms * L != nv) return SS_EINVAL;
   std::vector<u64> tbase((size_t)nv + 1), pbase((size_t)nv + 1, 0);
   SS_HIP(hipMemcpy(tbase.data(), s->d_term_base, tbase.size() * sizeof(u64), hipMemcpyDeviceToHost));
-  std::vector<uint32_t> poff((size_t)s->bm_n_post_pad + 1, 0u);
+  std::vector<uint32_t> poff((size_t)s->bm_n_post_pad + 5, 0u);  // + 4: the padding loop of a segment may run to the next multiple of 4 before the walk is checked
   std::vector<uint32_t> pool(n_positions ? n_positions : 1);
   u64 total = 0;
   for (uint32_t t = 0; t < n_terms; t++) {
