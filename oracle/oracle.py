@@ -247,13 +247,34 @@ class Shard:
         f.argtypes = [C.c_void_p, C.c_uint32, u32p, C.c_uint32, u32p, C.c_int, C.c_uint32, C.c_int, u32p, f32p, u64p]
         return self._search(f, terms, not_terms, op, k, rt)
 
-    def set_positions(self, positions):
-        """positions of every posting in CSR order (tf values each, ascending): what a phrase query walks"""
-        self.positions = np.ascontiguousarray(positions, np.uint16)
-        f = lib().so_shard_set_positions
-        f.argtypes = [C.c_void_p, u16p, C.c_uint64]
+    def set_positions(self, positions, counts=None):
+        """positions of every posting in CSR order; counts: positions per posting where that is not the tf (the component lists
+        of an n-gram key: the key's positions behind its first component, 0 for the others)"""
+        ps = np.ascontiguousarray(positions, np.uint16)
+        f = lib().so_shard_set_positions_counts
         f.restype = None
-        f(self.h, _p(self.positions, u16p), len(self.positions))
+        f.argtypes = [C.c_void_p, u16p, C.c_uint64, u16p]
+        cn = None if counts is None else np.ascontiguousarray(counts, np.uint16)
+        f(self.h, _p(ps, u16p), len(ps), None if cn is None else _p(cn, u16p))
+
+    def search_phrase_items(self, terms, seq, places, k, idf=None, reference_loop=True):
+        """QueryType::Phrase with n-gram keys among its entries: terms = unique terms (an n-gram key: its component lists), seq[i] =
+        index into terms of entry i (an n-gram key: its first component), places[i] = term_index_nonunique of entry i, idf = per
+        unique term or None -> (docs, scores, matches)"""
+        q = np.ascontiguousarray(terms, np.uint32)
+        sq = np.ascontiguousarray(seq, np.uint8)
+        pl = np.ascontiguousarray(places, np.uint8)
+        assert len(pl) == len(sq)
+        idf_a = None if idf is None else np.ascontiguousarray(idf, np.float32)
+        od = np.empty(max(k, 1), np.uint32)
+        os_ = np.empty(max(k, 1), np.float32)
+        tot = C.c_uint64()
+        f = lib().so_search_phrase_items
+        f.restype = C.c_uint32
+        f.argtypes = [C.c_void_p, C.c_uint32, u32p, f32p, C.c_uint32, u8p, u8p, C.c_uint32, C.c_int, u32p, f32p, C.POINTER(C.c_uint64)]
+        n = f(self.h, len(q), _p(q, u32p), None if idf_a is None else _p(idf_a, f32p), len(sq), _p(sq, u8p), _p(pl, u8p), k,
+              1 if reference_loop else 0, _p(od, u32p), _p(os_, f32p), C.byref(tot))
+        return od[:n].copy(), os_[:n].copy(), tot.value
 
     def search_phrase(self, terms, seq, k, reference_loop=True):
         """QueryType::Phrase: terms = unique terms, seq = index into terms of every word -> (docs, scores, matches)"""
@@ -633,16 +654,18 @@ def euclidean_f32(a, b, simd_order=True):
     return float(f(_p(a, f32p), _p(b, f32p), len(a)))
 
 
-def phrase_match(position_lists, reference_loop=True):
-    """so_phrase_match: position_lists[i] = ascending positions of the i-th word of the phrase"""
+def phrase_match(position_lists, reference_loop=True, places=None):
+    """so_phrase_match_places: position_lists[i] = ascending positions of the i-th entry of the phrase, places[i] = its place
+    (term_index_nonunique; None = 0, 1, 2, ...: a phrase of single terms)"""
     n = len(position_lists)
     arrs = [np.ascontiguousarray(p, np.uint16) for p in position_lists]
     ptrs = (u16p * n)(*[_p(a, u16p) if len(a) else C.cast(None, u16p) for a in arrs])
     cnt = np.array([len(a) for a in arrs], np.uint32)
-    f = lib().so_phrase_match
+    pl = None if places is None else np.ascontiguousarray(places, np.uint32)
+    f = lib().so_phrase_match_places
     f.restype = C.c_int
-    f.argtypes = [C.c_uint32, C.POINTER(u16p), u32p, C.c_int]
-    return bool(f(n, ptrs, _p(cnt, u32p), 1 if reference_loop else 0))
+    f.argtypes = [C.c_uint32, C.POINTER(u16p), u32p, u32p, C.c_int]
+    return bool(f(n, ptrs, _p(cnt, u32p), None if pl is None else _p(pl, u32p), 1 if reference_loop else 0))
 
 
 def synth_positions(doclen_bytes, docs, tfs, seed=99):

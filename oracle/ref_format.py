@@ -203,7 +203,7 @@ def write_index_bin(n_docs, doclen_bytes, terms, rng, segment_number_bits=11, ke
     Several fields: terms = [(key_hash, docs, fields, tfs)] sorted by (doc, field), doclen_bytes [n_fields][n_docs].
     ngram_keys: key hashes with NgramType bits set, written as 1-posting keys (layout irrelevant: for readers that skip).
     ngram_terms (one field): [(key_hash with its NgramType bits, docs, positions counts, component tfs [n][C], component
-    df bytes [C])] -- real n-gram keys: records carry the component tfs, the head the components' compressed posting
+    df bytes [C][, the key's positions per posting])] -- real n-gram keys: records carry the component tfs, the head the components' compressed posting
     counts (posting_count_ngram_i_compressed = int_to_byte4(df), compress_postinglist.rs:28-232, 339-409).
     Segment of a key = (key_hash >> 40) & mask here (the reference uses hash32(term) & mask, tokenizer.rs:660 -- a
     different hash of the same term; readers never rely on it).  max_docid / max_p_docid (a-12 block-max posting) are
@@ -239,9 +239,10 @@ def write_index_bin(n_docs, doclen_bytes, terms, rng, segment_number_bits=11, ke
             terms.append((key,))
             head_extra.append(bytes(int(x) for x in df_bytes) + bytes(key_head_size - 20 - len(df_bytes)))
             continue
-        key, docs, counts, comp_tfs, df_bytes = gt
+        key, docs, counts, comp_tfs, df_bytes = gt[:5]  # (+ optional 6th: the key's positions per posting, ascending)
         assert n_fields == 1 and key & 7 and len(df_bytes) == ngram_components(key) <= key_head_size - 20
-        blocks = encode_term(docs, counts, rng, positions_limit=positions_limit, ngram_tfs=np.asarray(comp_tfs))
+        blocks = encode_term(docs, counts, rng, positions_limit=positions_limit, ngram_tfs=np.asarray(comp_tfs),
+                             positions=gt[5] if len(gt) > 5 else None)
         per_term_blocks.append({b[0]: b for b in blocks})
         terms.append((key,))
         head_extra.append(bytes(int(x) for x in df_bytes) + bytes(key_head_size - 20 - len(df_bytes)))

@@ -1532,25 +1532,32 @@ double so_bench_lex(so_shard* const* shards, uint32_t S, const uint32_t* q_terms
  * (get_next_position_singlefield, add_result.rs:38-59; "pos1 += next + 1" at 3640, 3678).  A doc matches when some start
  * carries every word at its place.  Two restatements: the reference's merge loop (phrase_match_ref) and the definition
  * (phrase_match_def); tests assert they agree. */
-void so_shard_set_positions(so_shard* s, const uint16_t* positions, uint64_t n_positions) {
+/* counts (optional): positions per posting where that is not the tf -- the lists an N-GRAM key is held as (one per component term,
+ * same docs, the component's tf, add_result.rs:2074-2089): the key's own positions_count / positions belong to the key, here kept
+ * behind the FIRST component's postings (count 0 for the others). */
+void so_shard_set_positions_counts(so_shard* s, const uint16_t* positions, uint64_t n_positions, const uint16_t* counts) {
   free(s->pos_off); free(s->pos);
   const uint64_t np = s->off[s->n_terms];
   s->pos_off = (uint64_t*)malloc((np + 1) * sizeof(uint64_t));
   uint64_t a = 0;
-  for (uint64_t i = 0; i < np; i++) { s->pos_off[i] = a; a += s->tfs[i]; }
+  for (uint64_t i = 0; i < np; i++) { s->pos_off[i] = a; a += counts ? counts[i] : s->tfs[i]; }
   s->pos_off[np] = a;
   if (a != n_positions) { free(s->pos_off); s->pos_off = NULL; s->pos = NULL; return; }
   s->pos = (uint16_t*)malloc((a ? a : 1) * sizeof(uint16_t));
   memcpy(s->pos, positions, a * sizeof(uint16_t));
 }
-/* definition: exists start with word i at start + i for every i */
-static int phrase_match_def(uint32_t n_seq, const uint16_t* const* pos, const uint32_t* cnt) {
+void so_shard_set_positions(so_shard* s, const uint16_t* positions, uint64_t n_positions) {
+  so_shard_set_positions_counts(s, positions, n_positions, NULL);
+}
+/* definition: exists start with entry i at start + place[i] for every i (place[i] = term_index_nonunique: i for a phrase of single
+ * terms; an n-gram key is one entry spanning 2 / 3 places, search.rs:3305-3328) */
+static int phrase_match_def(uint32_t n_seq, const uint16_t* const* pos, const uint32_t* cnt, const uint32_t* place) {
   for (uint32_t j = 0; j < cnt[0]; j++) {
     const uint32_t start = pos[0][j];
     int ok = 1;
     for (uint32_t i = 1; i < n_seq && ok; i++) {
       ok = 0;
-      for (uint32_t x = 0; x < cnt[i]; x++) if ((uint32_t)pos[i][x] == start + i) { ok = 1; break; }
+      for (uint32_t x = 0; x < cnt[i]; x++) if ((uint32_t)pos[i][x] + place[0] == start + place[i]) { ok = 1; break; }
     }
     if (ok) return 1;
   }
@@ -1563,12 +1570,12 @@ static int nu_cmp(const void* a, const void* b) { /* sort_unstable_by positions_
   if (x->count != y->count) return x->count < y->count ? -1 : 1;
   return (x->idx > y->idx) - (x->idx < y->idx);
 }
-static int phrase_match_ref(uint32_t n_seq, const uint16_t* const* pos, const uint32_t* cnt) {
+static int phrase_match_ref(uint32_t n_seq, const uint16_t* const* pos, const uint32_t* cnt, const uint32_t* place) {
   so_nu nu[32];
   if (n_seq < 2) return cnt[0] > 0;
   for (uint32_t i = 0; i < n_seq; i++) {
     if (cnt[i] == 0) return 0;
-    nu[i].idx = i; nu[i].count = cnt[i]; nu[i].p_pos = 0; nu[i].list = pos[i]; nu[i].pos = pos[i][0];
+    nu[i].idx = place[i]; nu[i].count = cnt[i]; nu[i].p_pos = 0; nu[i].list = pos[i]; nu[i].pos = pos[i][0];
   }
   qsort(nu, n_seq, sizeof(so_nu), nu_cmp);
   uint32_t t2 = 1;
@@ -1589,8 +1596,15 @@ static int phrase_match_ref(uint32_t n_seq, const uint16_t* const* pos, const ui
     }
   }
 }
+/* place: the entries' places in the phrase (term_index_nonunique), NULL = 0, 1, 2, ... */
+int so_phrase_match_places(uint32_t n_seq, const uint16_t* const* pos, const uint32_t* cnt, const uint32_t* place, int reference_loop) {
+  uint32_t ident[32];
+  if (n_seq > 32) return 0;
+  if (!place) { for (uint32_t i = 0; i < n_seq; i++) ident[i] = i; place = ident; }
+  return reference_loop ? phrase_match_ref(n_seq, pos, cnt, place) : phrase_match_def(n_seq, pos, cnt, place);
+}
 int so_phrase_match(uint32_t n_seq, const uint16_t* const* pos, const uint32_t* cnt, int reference_loop) {
-  return reference_loop ? phrase_match_ref(n_seq, pos, cnt) : phrase_match_def(n_seq, pos, cnt);
+  return so_phrase_match_places(n_seq, pos, cnt, NULL, reference_loop);
 }
 
 /* Phrase search over one indexed field: the docs containing every unique term (intersection) whose positions carry the
@@ -1599,9 +1613,20 @@ int so_phrase_match(uint32_t n_seq, const uint16_t* const* pos, const uint32_t* 
  * desc, doc asc); *total = matches. */
 uint32_t so_search_phrase(const so_shard* s, uint32_t nq, const uint32_t* qt, uint32_t n_seq, const uint8_t* seq, uint32_t k,
                           int reference_loop, uint32_t* od, float* os, uint64_t* total) {
+  return so_search_phrase_items(s, nq, qt, NULL, n_seq, seq, NULL, k, reference_loop, od, os, total);
+}
+/* ... with N-GRAM keys among the phrase's entries (the reference's default index, index.rs:1422-1424).  The unique terms qt hold,
+ * for an n-gram key, its 2 / 3 component lists (scored with idf_in[t] = idf_ngram_i, search.rs:3231-3262; NULL = every idf from
+ * the list's own posting count); entry i of the phrase = unique term seq[i] (an n-gram key: its FIRST component, which carries the
+ * key's positions, so_shard_set_positions_counts) at place[i] = entries before it + the extra places of the n-gram keys before it
+ * (term_index_nonunique, search.rs:3305-3328). */
+uint32_t so_search_phrase_items(const so_shard* s, uint32_t nq, const uint32_t* qt, const float* idf_in, uint32_t n_seq, const uint8_t* seq,
+                                const uint8_t* place_in, uint32_t k, int reference_loop, uint32_t* od, float* os, uint64_t* total) {
   if (!s->pos || nq == 0 || nq > 32 || n_seq == 0 || n_seq > 32) { if (total) *total = 0; return 0; }
   float idf[32];
-  for (uint32_t t = 0; t < nq; t++) idf[t] = so_idf(s->n_docs, s->terms[qt[t]].posting_count);
+  uint32_t place[32];
+  for (uint32_t i = 0; i < n_seq; i++) place[i] = place_in ? place_in[i] : i;
+  for (uint32_t t = 0; t < nq; t++) idf[t] = idf_in ? idf_in[t] : so_idf(s->n_docs, s->terms[qt[t]].posting_count);
   uint64_t cur[32];
   for (uint32_t t = 0; t < nq; t++) cur[t] = s->off[qt[t]];
   so_sd* v = NULL; uint64_t nv = 0, cap = 0;
@@ -1617,8 +1642,8 @@ uint32_t so_search_phrase(const so_shard* s, uint32_t nq, const uint32_t* qt, ui
     if (!all) continue;
     if (s->deleted && s->deleted[d]) continue;
     const uint16_t* pl[32]; uint32_t pc[32];
-    for (uint32_t i = 0; i < n_seq; i++) { pl[i] = s->pos + s->pos_off[at[seq[i]]]; pc[i] = s->tfs[at[seq[i]]]; }
-    if (!so_phrase_match(n_seq, pl, pc, reference_loop)) continue;
+    for (uint32_t i = 0; i < n_seq; i++) { pl[i] = s->pos + s->pos_off[at[seq[i]]]; pc[i] = (uint32_t)(s->pos_off[at[seq[i]] + 1] - s->pos_off[at[seq[i]]]); }
+    if (n_seq >= 2 && !so_phrase_match_places(n_seq, pl, pc, place, reference_loop)) continue;  /* one entry: a term query (search.rs:3544) */
     float sc = 0.0f;
     const float comp = s->comp[s->doclen[d]];
     for (uint32_t t = 0; t < nq; t++) sc += so_bm25_term(idf[t], s->tfs[at[t]], comp);

@@ -137,6 +137,11 @@ uint32_t so_search_fields_shortcut(uint64_t n_docs, uint32_t n_fields, const uin
 /* ---- phrase queries (QueryType::Phrase; phrase check add_result.rs:3586-3684, positions add_result.rs:38-59) ----
  * positions: for every posting in CSR order its tf positions (ascending, < 65 536 per field: index.rs:5343) */
 void so_shard_set_positions(so_shard*, const uint16_t* positions, uint64_t n_positions);
+void so_shard_set_positions_counts(so_shard*, const uint16_t* positions, uint64_t n_positions, const uint16_t* counts /* per posting, NULL = tf */);
+int so_phrase_match_places(uint32_t n_seq, const uint16_t* const* pos, const uint32_t* cnt, const uint32_t* place, int reference_loop);
+uint32_t so_search_phrase_items(const so_shard*, uint32_t n_q_terms, const uint32_t* q_terms, const float* idf /* NULL = from df */, uint32_t n_seq,
+                                const uint8_t* seq, const uint8_t* place /* NULL = 0, 1, ... */, uint32_t k, int reference_loop, uint32_t* out_doc,
+                                float* out_score, uint64_t* total);
 /* does the phrase match?  pos[i] / cnt[i]: positions of the i-th word of the phrase.  reference_loop != 0: the reference's
  * merge loop restated; 0: the definition (some start carries word i at start + i) */
 int so_phrase_match(uint32_t n_seq, const uint16_t* const* pos, const uint32_t* cnt, int reference_loop);

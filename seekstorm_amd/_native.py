@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("SEEKSTORM_HIP_LIB") or os.path.join(_HERE, "lib", "li
 SS_NO_DOC = 0xFFFFFFFF
 SS_MAX_QUERY_TERMS = 10
 SS_MAX_PHRASE = 12
+SS_PHRASE_SKIP = 0xFF
 SS_MAX_K = 1024
 SS_VEC_BATCH = 64
 OP_INTERSECTION, OP_UNION, OP_PHRASE = 0, 1, 2

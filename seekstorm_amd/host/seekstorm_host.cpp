@@ -118,7 +118,7 @@ Shard::~Shard() {
 int Shard::upload_lexical(uint64_t n_docs, const uint8_t* doclen_bytes, uint32_t n_terms, const uint64_t* term_offsets,
                           const uint32_t* doc_ids, const uint16_t* tfs, const uint16_t* positions, uint64_t n_positions) {
   if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
-  lexical_fields_ = 1; ngram_components_.clear(); ngram_component_df_.clear();  // a new image: no index.bin n-gram keys behind the term ids
+  lexical_fields_ = 1; ngram_components_.clear(); ngram_component_.clear(); ngram_component_df_.clear();  // a new image: no index.bin n-gram keys behind the term ids
   const int rc = positions ? ss_bm25_upload_positions(h_, n_docs, doclen_bytes, n_terms, term_offsets, doc_ids, tfs, positions, n_positions)
                            : ss_bm25_upload(h_, n_docs, doclen_bytes, n_terms, term_offsets, doc_ids, tfs);
   n_docs_ = rc == SS_OK ? n_docs : 0;
@@ -129,7 +129,7 @@ int Shard::upload_lexical_fields(uint64_t n_docs, uint32_t n_fields, const uint8
                                  const uint64_t* term_offsets, const uint32_t* doc_ids, const uint8_t* field_ids,
                                  const uint16_t* tfs, const uint16_t* positions, uint64_t n_positions) {
   if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
-  lexical_fields_ = n_fields; ngram_components_.clear(); ngram_component_df_.clear();  // a new image: no index.bin n-gram keys behind the term ids
+  lexical_fields_ = n_fields; ngram_components_.clear(); ngram_component_.clear(); ngram_component_df_.clear();  // a new image: no index.bin n-gram keys behind the term ids
   const int rc = positions ? ss_bm25_upload_fields_positions(h_, n_docs, n_fields, doclen_bytes, boost, n_terms, term_offsets, doc_ids,
                                                              field_ids, tfs, positions, n_positions)
                            : ss_bm25_upload_fields(h_, n_docs, n_fields, doclen_bytes, boost, n_terms, term_offsets, doc_ids, field_ids, tfs);
@@ -139,7 +139,7 @@ int Shard::upload_lexical_fields(uint64_t n_docs, uint32_t n_fields, const uint8
 
 int Shard::synth_lexical(uint64_t seed, uint64_t n_docs, uint32_t n_terms, const uint32_t* thresh32, const uint8_t* len_table1024, uint32_t n_shards) {
   if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
-  lexical_fields_ = 1; ngram_components_.clear(); ngram_component_df_.clear();
+  lexical_fields_ = 1; ngram_components_.clear(); ngram_component_.clear(); ngram_component_df_.clear();
   int rc = ss_synth_set_partition(h_, shard_id_, n_shards);
   if (rc == SS_OK) rc = ss_bm25_synth(h_, seed, n_docs, n_terms, thresh32, len_table1024);
   n_docs_ = rc == SS_OK ? n_docs : 0;
@@ -189,12 +189,13 @@ int Shard::open_index_bin(const uint8_t* bytes, uint64_t len, uint32_t key_head_
   // n-gram keys: one term id per component; a component's idf comes from the component TERM's posting count in the key
   // head, not from the n-gram's own list (search.rs:3231-3262) -- remembered here, applied by make_query
   ngram_components_.assign(n_terms, 1);
+  ngram_component_.assign(n_terms, 0);
   ngram_component_df_.assign(n_terms, 0);
-  if (n_terms) ss_index_bin_term_ngram(ix, ngram_components_.data(), nullptr, ngram_component_df_.data());
+  if (n_terms) ss_index_bin_term_ngram(ix, ngram_components_.data(), ngram_component_.data(), ngram_component_df_.data());
   rc = with_positions ? ss_bm25_upload_index_bin_positions(h_, ix) : ss_bm25_upload_index_bin(h_, ix);
   ss_index_bin_close(ix);
   n_docs_ = rc == SS_OK ? n_docs : 0;
-  if (rc != SS_OK) { ngram_components_.clear(); ngram_component_df_.clear(); }
+  if (rc != SS_OK) { ngram_components_.clear(); ngram_component_.clear(); ngram_component_df_.clear(); }
   return rc;
 }
 
@@ -229,7 +230,7 @@ int Shard::set_deleted(const uint64_t* doc_ids, uint64_t n) {
 int Shard::synth_lexical(uint64_t seed, uint64_t n_docs, uint32_t n_terms, const uint32_t* thresh32,
                          const uint8_t* len_table1024) {
   if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
-  lexical_fields_ = 1; ngram_components_.clear(); ngram_component_df_.clear();  // a new image: no index.bin n-gram keys behind the term ids
+  lexical_fields_ = 1; ngram_components_.clear(); ngram_component_.clear(); ngram_component_df_.clear();  // a new image: no index.bin n-gram keys behind the term ids
   const int rc = ss_bm25_synth(h_, seed, n_docs, n_terms, thresh32, len_table1024);
   n_docs_ = rc == SS_OK ? n_docs : 0;
   return rc;
@@ -258,13 +259,22 @@ int Shard::make_query(const std::vector<uint32_t>& terms, QueryType qt, ss_bm25_
   if (rc != SS_OK) return rc;
   std::memset(out, 0, sizeof(*out));
   out->n_terms = (uint32_t)uniq.size();
-  if (qt == QueryType::Phrase) {  // non_unique_query_list: the words in order, each naming its unique term (search.rs:3304-3331)
-    if (terms.size() < 2) qt = QueryType::Intersection;  // a one-word phrase is a term query
+  if (qt == QueryType::Phrase) {  // non_unique_query_list: the entries in order, each naming its unique term (search.rs:3304-3331)
+    // an n-gram key of an opened index.bin arrives as its component term ids, consecutive: ONE entry, at the place of its first
+    // word (its first component carries the key's positions), spanning 2 / 3 places -- the places of its other words carry no
+    // entry (term_index_nonunique = entries before + preceding_ngram_count, search.rs:3305-3328)
+    size_t entries = 0;
+    for (size_t i = 0; i < terms.size(); i++)
+      if (!(terms[i] < ngram_component_.size() && ngram_component_[terms[i]] != 0)) entries++;
+    if (entries < 2) qt = QueryType::Intersection;  // a one-entry phrase is a term query
     else if (terms.size() > SS_MAX_PHRASE) return SS_EINVAL;
     else {
       out->phrase_len = (uint32_t)terms.size();
-      for (size_t i = 0; i < terms.size(); i++)
-        out->phrase_seq[i] = (uint8_t)(std::find(uniq.begin(), uniq.end(), terms[i]) - uniq.begin());
+      for (size_t i = 0; i < terms.size(); i++) {
+        const bool inner = terms[i] < ngram_component_.size() && ngram_component_[terms[i]] != 0;  // 2nd / 3rd component of a key
+        if (inner && i == 0) return SS_EINVAL;
+        out->phrase_seq[i] = inner ? (uint8_t)SS_PHRASE_SKIP : (uint8_t)(std::find(uniq.begin(), uniq.end(), terms[i]) - uniq.begin());
+      }
     }
   }
   uint32_t fmask = 0;

@@ -134,7 +134,7 @@ class Shard {
   // term_keys: key_hash of every term id, ascending; an n-gram key (key_hash & 7 != 0) holds one id per component term,
   // consecutive -- a query term that resolved to it is passed as those ids (make_query applies idf_ngram_i)
   // with_positions: the positions of every posting are decoded as well (QueryType::Phrase on an opened index; one indexed
-  // field, SingleTerm keys only -- SS_ENOTSUP otherwise)
+  // field; an n-gram key's own positions stand behind its first component term: in a phrase the key is one entry, make_query)
   int open_index_bin(const uint8_t* bytes, uint64_t len, uint32_t key_head_size, std::vector<uint64_t>* term_keys,
                      bool with_positions = false);
   int open_vector_bin(const uint8_t* bytes, uint64_t len, uint32_t dim, bool i8 = false, bool use_record_scale = false);
@@ -209,6 +209,7 @@ class Shard {
   bool euclidean_ = false;
   uint32_t lexical_fields_ = 1;                // indexed fields of the lexical image
   std::vector<uint8_t> ngram_components_;      // per term id of an opened index.bin: components of its key (1 = SingleTerm)
+  std::vector<uint8_t> ngram_component_;       // ... and which of them the term is (0 = a SingleTerm key or a key's first component)
   std::vector<uint32_t> ngram_component_df_;   // posting count of the component term (n-gram components)
 };
 

@@ -549,7 +549,10 @@ class Shard:
         idf_of: {term id: idf} for the terms whose idf is not that of their own list -- the component terms of an n-gram
         key (IndexBin.terms_of_key: idf_ngram_i from the component term's posting count).
         field_filter: indexed field ids every term must occur in one of (several indexed fields; intersections and
-        single-term queries, add_result.rs:3124-3136)"""
+        single-term queries, add_result.rs:3124-3136).
+        An N-GRAM key among a query's terms is written as the tuple of its component term ids (IndexBin.terms_of_key, with their
+        idf_ngram_i in idf_of): all components are scored; in a Phrase the key is ONE entry at its first place -- its first
+        component, which carries the key's positions -- spanning len(tuple) places (search.rs:3305-3328)."""
         fmask = 0
         for f in field_filter or ():
             fmask |= 1 << int(f)
@@ -561,25 +564,36 @@ class Shard:
         if isinstance(query_types, (int, QueryType)):
             query_types = [query_types] * nq
         q = np.zeros(nq, N.BM25_QUERY_DTYPE)
-        flat = np.fromiter((t for tl in list(term_lists) + list(not_lists) for t in tl), np.uint32)
+        def _flat(tl):
+            for t in tl:
+                if isinstance(t, (tuple, list)):
+                    yield from (int(x) for x in t)
+                else:
+                    yield int(t)
+        flat = np.fromiter((t for tl in list(term_lists) + list(not_lists) for t in _flat(tl)), np.uint32)
         uniq = np.unique(flat)
         missing = [int(t) for t in uniq if int(t) not in self._df_cache]
         if missing:
             for t, df in zip(missing, self.posting_count(missing)):
                 self._df_cache[t] = int(df)
         for i, (tl, qt, nl) in enumerate(zip(term_lists, query_types, not_lists)):
-            words = [int(t) for t in tl]
-            tl = list(dict.fromkeys(int(t) for t in tl))  # unique_terms, search.rs:3023
-            if int(qt) == int(QueryType.Phrase):  # non_unique_query_list: the words in order, each naming its unique term
-                if len(words) < 2:
-                    qt = QueryType.Intersection  # a one-word phrase is a term query (search.rs:3544)
-                elif len(words) > N.SS_MAX_PHRASE:
+            entries = [tuple(int(x) for x in t) if isinstance(t, (tuple, list)) else (int(t),) for t in tl]
+            tl = list(dict.fromkeys(_flat(tl)))  # unique_terms, search.rs:3023
+            if int(qt) == int(QueryType.Phrase):  # non_unique_query_list: the entries in order, each naming its unique term
+                places = sum(len(e) for e in entries)
+                if len(entries) < 2:
+                    qt = QueryType.Intersection  # a one-entry phrase is a term query (search.rs:3544)
+                elif places > N.SS_MAX_PHRASE:
                     raise ValueError("a phrase of at most %d words" % N.SS_MAX_PHRASE)
                 else:
-                    q["phrase_len"][i] = len(words)
-                    for j, wd in enumerate(words):
-                        q["phrase_seq"][i, j] = tl.index(wd)
-            nl = [t for t in dict.fromkeys(int(t) for t in nl) if t not in tl]
+                    q["phrase_len"][i] = places
+                    at = 0
+                    for e in entries:
+                        q["phrase_seq"][i, at] = tl.index(e[0])
+                        for x in range(1, len(e)):
+                            q["phrase_seq"][i, at + x] = N.SS_PHRASE_SKIP  # a place inside the n-gram key
+                        at += len(e)
+            nl = [t for t in dict.fromkeys(_flat(nl)) if t not in tl]
             if not 1 <= len(tl) or len(tl) + len(nl) > N.SS_MAX_QUERY_TERMS:
                 raise ValueError("1..10 unique terms per query (NOT terms included)")
             q["n_terms"][i] = len(tl)

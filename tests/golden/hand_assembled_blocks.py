@@ -235,5 +235,55 @@ H6 = dict(
     docs=[1, 2, 3, 50, 51],
     entries=[[(1, [2, 5, 9, 40])], [(0, [1000, 1010])], [(0, [100, 400])], [(0, [3]), (2, [4, 6])], [(0, [1]), (1, [2]), (2, [3])]])
 
+# ================================================================================================ n-gram keys, one indexed field
+# A key whose NgramType (low 3 bits of key_hash) is not SingleTerm: its postings are NEVER embedded (index_posting.rs:445: the
+# embedding arm asks for NgramType::SingleTerm) and every record starts with the positions count of each COMPONENT term in this
+# doc -- field_vec_ngram1, field_vec_ngram2 (, field_vec_ngram3), each through write_field_vec (index_posting.rs:666-722), which
+# for one indexed field is the count VINT of a SingleTerm record (848-872) -- BEFORE the key's own field vector (724-732: its
+# positions_count) and its positions (734-741: positions_compressed).  The key's positions are the places of its FIRST word
+# (tokenizer.rs:699: "position as u16 - 1" for a bigram).  Readers: the component tfs decode_positions_multiterm_singlefield
+# add_result.rs:2074-2086 (scored by the n-gram arms of get_bm25f_multiterm_singlefield 1454-1477), the count 2089, the positions
+# get_next_position_singlefield in the phrase check 3596-3684.
+# ---------------------------------------------------------------------------------------------------------------- H8
+# NgramType::NgramFF (two components), CompressionType::Array, pivot inside the list: p0, p1 2-byte pointers, p2 a 3-byte pointer
+#   p0 doc 4     component tfs (3, 130)   key positions {7, 20}     130 needs the 2-byte count form
+#   p1 doc 90    component tfs (1, 1)     key positions {0}
+#   p2 doc 7000  component tfs (5, 2)     key positions {300, 301}  300 needs the 2-byte position form
+H8_REC_P0 = [
+    3 | STOP,                          # field_vec_ngram1 = [(0, 3)]: write_field_vec 858-860
+    130 >> 7, (130 & 0x7F) | STOP,     # field_vec_ngram2 = [(0, 130)]: 861-865
+    2 | STOP,                          # the key's own positions_count 2 (724-732)
+    7 | STOP, 12 | STOP,               # positions 7, then 20 - 7 - 1 = 12 (compress_positions 955-957)
+]                                      # 6 bytes
+H8_REC_P1 = [1 | STOP, 1 | STOP, 1 | STOP, 0 | STOP]                       # tfs 1, 1; count 1; position 0 -> 4 bytes
+H8_REC_P2 = [5 | STOP, 2 | STOP, 2 | STOP, 300 >> 7, (300 & 0x7F) | STOP, 0 | STOP]  # tfs 5, 2; count 2; 300 (958-965), 301 - 300 - 1 = 0 -> 6 bytes
+H8_PREFIX = [0x42, 0x43]
+H8_R = len(H8_PREFIX) + len(H8_REC_P2) + len(H8_REC_P1) + len(H8_REC_P0)   # = 18: p0's record touches R, the later ones lie below
+H8_POINTERS = [
+    6, 0,                              # p0: running record size 6, 2 bytes, top bit clear (compress_postinglist.rs:477-482)
+    10, 0,                             # p1: 6 + 4
+    16, 0, 0,                          # p2: 10 + 6, 3 bytes (507-515)
+]
+H8 = dict(
+    name="H8 bigram key, component tfs before the key's positions",
+    n_components=2,
+    block_id=1, compression_type_pointer=(1 << 30) | H8_R, posting_count=3, pointer_pivot_p_docid=2,
+    body=bytes(H8_PREFIX + H8_REC_P2 + H8_REC_P1 + H8_REC_P0 + H8_POINTERS + _u16(4) + _u16(90) + _u16(7000)),
+    docs=[4, 90, 7000], component_tfs=[[3, 130], [1, 1], [5, 2]], counts=[2, 1, 2], positions=[7, 20] + [0] + [300, 301])
+# ---------------------------------------------------------------------------------------------------------------- H9
+# NgramType::NgramFFF (three components), CompressionType::Rle, one run of two docs, 2-byte pointers
+#   p0 doc 500   component tfs (2, 9, 200)   key positions {1}
+#   p1 doc 501   component tfs (1, 1, 1)     key positions {40, 41, 42}
+H9_REC_P0 = [2 | STOP, 9 | STOP, 200 >> 7, (200 & 0x7F) | STOP, 1 | STOP, 1 | STOP]   # 6 bytes
+H9_REC_P1 = [1 | STOP, 1 | STOP, 1 | STOP, 3 | STOP, 40 | STOP, 0 | STOP, 0 | STOP]  # 7 bytes
+H9_R = len(H9_REC_P1) + len(H9_REC_P0)                                                # = 13
+H9 = dict(
+    name="H9 trigram key, rle container",
+    n_components=3,
+    block_id=0, compression_type_pointer=(3 << 30) | H9_R, posting_count=2, pointer_pivot_p_docid=2,
+    body=bytes(H9_REC_P1 + H9_REC_P0 + [6, 0, 13, 0] + _u16(1) + _u16(500) + _u16(1)),   # Rle: 1 run, start 500, one doc after it
+    docs=[500, 501], component_tfs=[[2, 9, 200], [1, 1, 1]], counts=[1, 3], positions=[1] + [40, 41, 42])
+
 BLOCKS = [H1, H2, H3, H4, H7]
 FIELD_BLOCKS = [H5, H6]
+NGRAM_BLOCKS = [H8, H9]

@@ -148,6 +148,83 @@ def test_phrase_queries_on_an_image_built_from_index_bin(S, O):
     b.close()
 
 
+def test_phrase_queries_on_a_default_index_with_ngram_keys(S, O):
+    """The reference's DEFAULT index (NgramFF | NgramFFF, index.rs:1422-1424; 23-byte key heads): sequences of frequent terms are
+    indexed as n-gram keys beside their single terms, and a phrase query that names such a sequence resolves to the KEY -- one
+    entry whose positions are those of its first word and whose successor stands 2 / 3 places later (search.rs:3305-3328).
+    ss_bm25_upload_index_bin_positions puts the key's positions behind its first component term; phrases mixing keys and single
+    terms answer like the oracle (so_search_phrase_items: same docs as the phrase over the single terms, scored by the n-gram arm)."""
+    import ngram_corpus as NG
+    from oracle import ref_format as RF
+    from seekstorm_amd.search import idf_f32
+    n_docs = 140_000
+    C = NG.build(O, _corpus, n_docs, [30_000, 12_000, 20_000, 3_000],
+                 [([0, 1], 300), ([0, 1, 2], 200), ([3, 0, 1], 80), ([0, 1, 3], 90), ([0, 1, 2, 3], 40), ([2, 0, 1], 70), ([0, 1, 0, 1], 25), ([3, 0, 1, 2], 35)], 12)
+    data = RF.write_index_bin(n_docs, C.dl, C.terms, np.random.default_rng(3), key_head_size=23, ngram_terms=C.ngram_terms)
+    ix = S.IndexBin(data, key_head_size=23)
+    a = S.Shard(0)
+    a.upload_index_bin(ix, positions=True)
+    tid = {t: ix.term_of_key(NG.KEY(t)) for t in range(4)}
+    ent, idf_of = {}, {}
+    for words, key in NG.KEYS.items():
+        comp = ix.terms_of_key(key)
+        assert len(comp) == len(words)
+        ent[words] = tuple(t for t, _ in comp)
+        idf_of.update({t: i for t, i in comp})
+    osh = C.oracle_shard(O)
+    gq = a.make_queries([[ent[e] if isinstance(e, tuple) else tid[e] for e in ph] for ph in NG.PHRASES], S.QueryType.Phrase, idf_of=idf_of)
+    sq = a.make_queries([[tid[w] for w in ph] for ph in NG.SAME_DOCS_AS], S.QueryType.Phrase)
+    for k in (10, 100):
+        for rt in (S.ResultType.TopkCount, S.ResultType.Count):
+            rg = a.search_lexical_batch(gq, k, rt)
+            rs = a.search_lexical_batch(sq, k, rt)
+            for i, ph in enumerate(NG.PHRASES):
+                uniq, seq, places, idf = C.oracle_query(ph, lambda e, c: idf_of[ent[e][c]], lambda l: float(idf_f32(n_docs, osh.df(l))))
+                od, os_, otot = osh.search_phrase_items(uniq, seq, places, k, idf=idf, reference_loop=True)
+                assert otot > 0, ph
+                assert int(rg[3][i]) == otot, (ph, int(rg[3][i]), otot)
+                assert int(rs[3][i]) == otot, ("the phrase over the single terms matches the same docs", ph)
+                if rt == S.ResultType.TopkCount:
+                    assert rg[2][i] == len(od) and np.allclose(rg[1][i][:len(od)], os_, rtol=1e-4), ph
+                    band = abs(float(os_[-1])) * 2e-4
+                    clear = lambda dd, ss: {int(x) for x, y in zip(dd, ss) if y > os_[-1] + band}
+                    assert clear(rg[0][i][:rg[2][i]], rg[1][i][:rg[2][i]]) <= set(od.tolist()) and clear(od, os_) <= set(rg[0][i][:rg[2][i]].tolist())
+    # a phrase that is nothing but ONE key is a term query over the key (search.rs:3544): every doc of the key, no position check
+    one = a.search_lexical_batch(a.make_queries([[ent[NG.AB]]], S.QueryType.Phrase, idf_of=idf_of), 10)
+    assert int(one[3][0]) == len(C.rows_of[NG.AB])
+    a.close()
+
+
+def test_positions_beside_a_sparse_tier(S, O):
+    """ss_index_bin_tier + ss_bm25_upload_index_bin_positions: the dense terms carry positions (phrases over them answer like the
+    untiered image), the rare keys sit in the sparse tier and still serve set queries; a phrase naming a sparse term is refused"""
+    import ngram_corpus as NG
+    from oracle import ref_format as RF
+    n_docs = 70_000
+    C = NG.build(O, _corpus, n_docs, [9_000, 5_000, 7_000, 60], [([0, 1], 200), ([0, 1, 2], 100), ([3, 0], 20)], 31)
+    data = RF.write_index_bin(n_docs, C.dl, C.terms, np.random.default_rng(4), key_head_size=23, ngram_terms=C.ngram_terms)
+    ix_t, ix_u = S.IndexBin(data, key_head_size=23), S.IndexBin(data, key_head_size=23)
+    n_dense = ix_t.tier(1000)  # term 3 (df ~ 80) and the keys' lists (a few hundred docs) go to the sparse tier
+    assert 0 < n_dense < ix_t.term_count
+    a, b = S.Shard(0), S.Shard(0)
+    a.upload_index_bin(ix_t, positions=True)
+    b.upload_index_bin(ix_u, positions=True)
+    ta = {t: ix_t.term_of_key(NG.KEY(t)) for t in range(4)}
+    tb = {t: ix_u.term_of_key(NG.KEY(t)) for t in range(4)}
+    assert ta[3] >= n_dense and max(ta[0], ta[1], ta[2]) < n_dense
+    for ph in ([0, 1], [0, 1, 2], [1, 0], [2, 0, 1]):
+        ra = a.search_lexical_batch(a.make_queries([[ta[w] for w in ph]], S.QueryType.Phrase), 10)
+        rb = b.search_lexical_batch(b.make_queries([[tb[w] for w in ph]], S.QueryType.Phrase), 10)
+        assert int(ra[3][0]) == int(rb[3][0]) and np.array_equal(ra[1], rb[1]) and np.array_equal(ra[0], rb[0]), ph
+    ua = a.search_lexical_batch(a.make_queries([[ta[3], ta[0]]], S.QueryType.Union), 10)
+    ub = b.search_lexical_batch(b.make_queries([[tb[3], tb[0]]], S.QueryType.Union), 10)
+    assert int(ua[3][0]) == int(ub[3][0]) and np.allclose(ua[1], ub[1], rtol=1e-6)
+    with pytest.raises(S.SeekStormHipError):
+        a.search_lexical_batch(a.make_queries([[ta[3], ta[0]]], S.QueryType.Phrase), 10)
+    a.close()
+    b.close()
+
+
 # ------------------------------------------------------------------------------------------------ several indexed fields
 def _corpus_fields(O, n_docs, n_fields, dfs, seed, plant, cross):
     """(term, doc, field) entries with positions.  plant = [(words, field, n docs)]: the phrase written into that field;

@@ -450,6 +450,46 @@ def test_phrase_match_reference_loop_equals_definition():
     assert 200 < hits < 3800
 
 
+def test_phrase_entries_with_places_ngram_keys():
+    """n-gram keys in a phrase (search.rs:3305-3328): an entry's place = entries before it + the extra places of the keys before it.
+    (a) the restated merge loop agrees with the definition for arbitrary places; (b) on a corpus laid out like the reference's
+    default index, a phrase whose entries are keys matches exactly the docs the phrase over the single terms matches, and a
+    one-entry phrase is a term query over the key."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import ngram_corpus as NG
+    from test_gpu_phrase import _corpus
+    rng = np.random.default_rng(23)
+    hits = 0
+    for it in range(3000):
+        n = int(rng.integers(2, 6))
+        span = int(rng.integers(8, 60))
+        lists = [np.sort(rng.choice(span, int(rng.integers(1, min(span, 10))), replace=False)) for _ in range(n)]
+        places = np.cumsum([0] + [int(rng.integers(1, 4)) for _ in range(n - 1)])  # entries span 1..3 places
+        if it % 4 == 0:
+            st = int(rng.integers(0, span))
+            lists = [np.unique(np.append(l, st + int(pl))) for l, pl in zip(lists, places)]
+        a, b = O.phrase_match(lists, True, places), O.phrase_match(lists, False, places)
+        assert a == b, (lists, places)
+        hits += a
+    assert 300 < hits < 2800
+    n_docs = 20_000
+    C = NG.build(O, _corpus, n_docs, [6_000, 3_000, 4_000, 900], [([0, 1], 120), ([0, 1, 2], 90), ([3, 0, 1], 40), ([0, 1, 3], 50), ([0, 1, 2, 3], 30),
+                                                                  ([2, 0, 1], 40), ([0, 1, 0, 1], 20), ([3, 0, 1, 2], 25)], 12)
+    osh = C.oracle_shard(O)
+    single = O.Shard(n_docs, C.dl, C.offs, C.docs, C.tfs)
+    single.set_positions(C.positions)
+    for ph, same in zip(NG.PHRASES, NG.SAME_DOCS_AS):
+        uniq, seq, places, idf = C.oracle_query(ph, lambda e, c: 1.0 + c, lambda l: 2.0)
+        od, os_, tot = osh.search_phrase_items(uniq, seq, places, 20_000, idf=idf)
+        od2, _, tot2 = osh.search_phrase_items(uniq, seq, places, 20_000, idf=idf, reference_loop=False)
+        su = list(dict.fromkeys(same))
+        sd, _, stot = single.search_phrase(su, [su.index(w) for w in same], 20_000)
+        assert tot == tot2 == stot > 0 and set(od.tolist()) == set(od2.tolist()) == set(sd.tolist()), (ph, tot, tot2, stot)
+    uniq, seq, places, idf = C.oracle_query([NG.AB], lambda e, c: 1.0, lambda l: 1.0)
+    assert osh.search_phrase_items(uniq, seq, places, 10, idf=idf)[2] == len(C.rows_of[NG.AB])
+
+
 def test_phrase_over_several_fields_rules():
     """so_search_fields_phrase (add_result.rs:2964-3414): the phrase must stand inside ONE field; a field filter lists the fields it may
     stand in; the score sums ALL fields of the unique terms; with one field it is so_search_phrase"""

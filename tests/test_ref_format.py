@@ -621,6 +621,64 @@ def test_hand_assembled_key_bodies():
             assert body == b["body"] and ctp == b["compression_type_pointer"] and pivot == b["pointer_pivot_p_docid"], b["name"]
 
 
+def _decode_ngram_positions(block, nc):
+    bid, ctp, cnt, pivot, body = block
+    buf = np.frombuffer(body, np.uint8).copy()
+    rb = N.RefBlock(bid, ctp, cnt - 1, pivot, buf.ctypes.data, len(buf))
+    d, t, c = np.zeros(65536, np.uint16), np.zeros(65536, np.uint16), np.zeros(65536, np.uint16)
+    npos = C.c_uint64()
+    N.lib().ss_ref_decode_block_ngram_positions(C.byref(rb), nc, N.ptr(d, N.u16p), N.ptr(t, N.u16p), N.ptr(c, N.u16p), None, 0, C.byref(npos))
+    pos = np.zeros(max(npos.value, 1), np.uint16)
+    n = N.lib().ss_ref_decode_block_ngram_positions(C.byref(rb), nc, N.ptr(d, N.u16p), N.ptr(t, N.u16p), N.ptr(c, N.u16p), N.ptr(pos, N.u16p),
+                                                    len(pos), C.byref(npos))
+    return n, d[:max(n, 0)].copy(), t[:max(n, 0)].copy(), c[:max(n, 0)].copy(), pos[:npos.value].copy(), rb, buf
+
+
+def test_hand_assembled_ngram_key_bodies():
+    """H8 / H9 (tests/golden/hand_assembled_blocks.py): records of n-gram keys assembled from index_posting.rs:666-741 -- the
+    component tfs, then the key's OWN positions_count and positions, which a phrase entry that resolved to the key walks"""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("hand_assembled_blocks", os.path.join(os.path.dirname(__file__), "golden", "hand_assembled_blocks.py"))
+    H = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(H)
+    assert len(H.NGRAM_BLOCKS) == 2 and H.H8_R == 18 and H.H9_R == 13
+    d16, t16 = np.zeros(65536, np.uint16), np.zeros(65536, np.uint16)
+    for b in H.NGRAM_BLOCKS:
+        blk = (b["block_id"], b["compression_type_pointer"], b["posting_count"], b["pointer_pivot_p_docid"], b["body"])
+        nc = b["n_components"]
+        n, d, t, c, pos, rb, buf = _decode_ngram_positions(blk, nc)
+        assert n == len(b["docs"]) and d.tolist() == b["docs"], b["name"]
+        assert t.tolist() == [x[0] for x in b["component_tfs"]] and c.tolist() == b["counts"] and pos.tolist() == b["positions"], (b["name"], pos.tolist())
+        for comp in range(nc):
+            assert N.lib().ss_ref_decode_block_ngram(C.byref(rb), nc, comp, N.ptr(d16, N.u16p), N.ptr(t16, N.u16p)) == n
+            assert t16[:n].tolist() == [x[comp] for x in b["component_tfs"]], (b["name"], comp)
+        # the restated writer, given the same postings, writes the same bytes behind a prefix of the same length (two routes, one answer)
+        per_doc, at = [], 0
+        for k_ in b["counts"]:
+            per_doc.append(b["positions"][at:at + k_]); at += k_
+        prefix = len(b["body"]) - len(RF.encode_key_body(b["docs"], per_doc, 0, 32768, b["component_tfs"])[0])
+        if b["pointer_pivot_p_docid"] == b["posting_count"]:  # (H8 moves the pivot by hand: legal header, not the writer's choice)
+            body, ctp, cnt, pivot = RF.encode_key_body(b["docs"], per_doc, prefix, 32768, b["component_tfs"])
+            assert b["body"][prefix:] == body and ctp == b["compression_type_pointer"] and pivot == b["pointer_pivot_p_docid"], b["name"]
+
+
+@pytest.mark.parametrize("limit", [32768, 400])
+def test_ngram_positions_roundtrip(limit):
+    """the key's own positions behind the component tfs: restated writer -> decoder (2- and 3-byte pointers)"""
+    rng = np.random.default_rng(21)
+    n = 2500
+    docs = np.sort(rng.choice(65536, size=n, replace=False))
+    counts = rng.integers(1, 6, size=n)
+    per_doc = [RF.random_positions(rng, int(k_), 300) for k_ in counts]
+    for nc in (2, 3):
+        comp = rng.integers(1, 400, size=(n, nc))
+        blk = RF.encode_term(docs, counts, rng, positions_limit=limit, ngram_tfs=comp, positions=per_doc)[0]
+        assert limit == 32768 or blk[3] < blk[2]
+        cnt, d, t, c, pos, _, _ = _decode_ngram_positions(blk, nc)
+        assert cnt == n and np.array_equal(d, docs) and np.array_equal(t, comp[:, 0]) and np.array_equal(c, counts)
+        assert pos.tolist() == [x for p_ in per_doc for x in p_]
+
+
 @pytest.mark.parametrize("n,tf_hi,limit", [(40, 3, 32768), (3000, 6, 32768), (4000, 30, 32768), (500, 5, 600), (700, 3, 32769)])
 def test_positions_roundtrip(n, tf_hi, limit):
     """ss_ref_decode_block_positions against the restated writer: embedded 2- and 3-byte forms, VINT records, the pivot inside
