@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--no-fields", action="store_true", help="skip the multi-field (BM25F) leg")
     ap.add_argument("--no-vocab", action="store_true", help="skip the realistic-vocabulary leg (1 M rare terms in the sparse tier)")
     ap.add_argument("--vocab-terms", type=int, default=1_000_000)
+    ap.add_argument("--no-real-format", action="store_true", help="skip the drop-in rehearsal on a million-doc index.bin / vector.bin / delete.bin")
+    ap.add_argument("--real-format-docs", type=int, default=1_000_000)
     ap.add_argument("--quick", action="store_true", help="profiling runs: few calls per leg, no cpu / parity legs")
     ap.add_argument("--cpu-seconds", type=float, default=5.0)
     ap.add_argument("--parity-queries", type=int, default=1000, help="C2 queries checked against the full-size oracle (all of the batch by default)")
@@ -689,6 +691,18 @@ def main():
                         "probes of the other lists (bm25_sparse_kernel), the two lists are merged per query; directory_bytes_if_dense = what "
                         "the rare lists' sub-block directory rows alone would cost in the dense image"}
 
+        # (7) DROP-IN REHEARSAL: a shard's files as the reference writes them (index.bin of a text-shaped corpus with >= 1 M keys, clustered
+        # doc ids, NgramFF | NgramFFF keys and positions; vector.bin; delete.bin -- oracle/ss_textindex.c is the mini indexer) opened through
+        # ss_index_bin_open -> tier -> upload with positions, queried with 2-term ANDs, 3-term ORs, phrases over n-gram keys, hybrid; every
+        # answer against the oracle; 64 concurrent callers through Index::search of the C++ mirror (tools/real_format.py)
+        if rank == 0 and world == 1 and not args.quick and not args.no_real_format:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import real_format
+            bm["real_format"] = real_format.run(n_docs=args.real_format_docs, vocab=args.real_format_docs, parity=not args.no_parity,
+                                                seconds=max(args.min_seconds, 1.0))
+            if "parity" in bm["real_format"]:
+                parity["real_format"] = bm["real_format"].pop("parity")
+
         # ---- full-size parity (C2): a sample of the batch against the oracle on the same 10 M-doc shard, regenerated on
         # the host -- doc ids outside the tie band, scores 1e-4 relative, exact result_count_total; AUTO and EXHAUSTIVE
         if rank == 0 and not args.no_parity:
@@ -1122,6 +1136,8 @@ def main():
                 line["multi_field"] = bm["multi_field"]
             if "realistic_vocabulary" in bm:
                 line["realistic_vocabulary"] = bm["realistic_vocabulary"]
+            if "real_format" in bm:
+                line["real_format"] = bm["real_format"]
             line["bm25"] = {"build_s": bm["build_s"], "postings": int(bm["info"]["n_postings"]), "avgdl": bm["info"]["avgdl"],
                             "mean_algorithmic_bytes_per_query": bm["mean_bytes_per_query"], "mean_union_size": bm["mean_union"]}
         if vec is not None and is_bm:

@@ -250,6 +250,25 @@ uint32_t so_merge(int mode, const uint64_t* lex_doc, const float* lex_score, uin
                   const uint64_t* vec_doc, const float* vec_score, uint32_t n_vec, uint32_t offset,
                   uint32_t length, uint64_t* out_doc, float* out_score, uint8_t* out_source);
 
+/* ================================================================== text-shaped corpus + the reference's indexing path (ss_textindex.c)
+ * A mini indexer as test infrastructure: Zipf tokens with topic clusters, SingleTerm postings with real positions, NgramFF /
+ * NgramFFF keys over the frequent ranks (tokenizer.rs:674-782, index_posting.rs:666-741), index.bin as commit.rs:264-552 writes it. */
+typedef struct so_text so_text;
+so_text* so_text_build(uint64_t seed, uint64_t n_docs, uint32_t vocab, uint32_t n_frequent, int ngrams /* NgramSet bits: 1 FF, 8 FFF */,
+                       double topic_share, double mean_len);
+void so_text_free(so_text*);
+void so_text_info(const so_text*, uint64_t* n_tokens, uint32_t* n_keys, uint32_t* n_keys_nonempty, uint64_t* n_postings, uint32_t* n_ngram_keys);
+const uint8_t* so_text_doclen(const so_text*);
+uint32_t so_text_doc_tokens(const so_text*, uint64_t doc, uint32_t cap, uint32_t* out);
+uint32_t so_text_ngram_key(const so_text*, uint32_t n, const uint32_t* component_ranks);
+uint64_t so_text_key_hash(const so_text*, uint32_t key);
+uint64_t so_text_key_df(const so_text*, uint32_t key);
+uint64_t so_text_key_postings(const so_text*, uint32_t key, uint32_t component, uint32_t* docs, uint16_t* tfs, uint16_t* counts,
+                              uint16_t* positions, uint64_t pos_cap, uint64_t* n_pos_out);
+int so_text_write_index_bin(const so_text*, uint32_t segment_number_bits, uint32_t key_head_size, uint32_t positions_limit, uint8_t** out,
+                            uint64_t* out_len);
+void so_text_free_bytes(uint8_t*);
+
 #ifdef __cplusplus
 }
 #endif

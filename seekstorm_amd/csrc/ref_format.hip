@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "ss_common.h"
+#include "ss_threads.h"
 
 namespace {
 
@@ -577,63 +578,103 @@ extern "C" int ss_index_bin_open(const uint8_t* bytes, uint64_t len, uint32_t in
   ix->bytes = bytes; ix->len = len;
   ix->n_fields = indexed_field_count; ix->key_head_size = key_head_size; ix->seg_bits = segment_number_bits;
   const uint64_t nseg = 1ull << segment_number_bits;
-  uint64_t pos = 4;
-  uint32_t level = 0;
-  while (pos < len) {
-    if (level == 0) {
-      if (pos + 2 > len) return SS_EINVAL;
-      ix->longest_field_id = (uint16_t)rd16(bytes + pos);
-      pos += 2;
+  // ---- the level headers, one after the other (a level's size is only known from its segment head table): where every segment lies
+  struct Seg { uint32_t level; uint64_t pos, block_length, key_count; };
+  std::vector<Seg> segs;
+  {
+    uint64_t pos = 4;
+    uint32_t level = 0;
+    while (pos < len) {
+      if (level == 0) {
+        if (pos + 2 > len) return SS_EINVAL;
+        ix->longest_field_id = (uint16_t)rd16(bytes + pos);
+        pos += 2;
+      }
+      const uint64_t fixed = (uint64_t)indexed_field_count * 65536u + 16u + nseg * 8u;
+      if (pos + fixed > len) return SS_EINVAL;
+      ix->doclen.push_back(bytes + pos);
+      pos += (uint64_t)indexed_field_count * 65536u;
+      const uint64_t docs = rd64(bytes + pos), psum = rd64(bytes + pos + 8);
+      if (docs < ix->n_docs || docs > ((uint64_t)level + 1) * 65536u || docs <= (uint64_t)level * 65536u) return SS_EINVAL;
+      ix->n_docs = docs; ix->positions_sum = psum;
+      pos += 16;
+      const uint8_t* heads = bytes + pos;
+      pos += nseg * 8u;
+      for (uint64_t k0 = 0; k0 < nseg; k0++) {
+        const uint64_t block_length = rd32(heads + 8 * k0), key_count = rd32(heads + 8 * k0 + 4);
+        if (key_count * key_head_size > block_length || pos + block_length > len) return SS_EINVAL;
+        if (key_count) segs.push_back(Seg{level, pos, block_length, key_count});
+        pos += block_length;
+      }
+      level++;
     }
-    const uint64_t fixed = (uint64_t)indexed_field_count * 65536u + 16u + nseg * 8u;
-    if (pos + fixed > len) return SS_EINVAL;
-    ix->doclen.push_back(bytes + pos);
-    pos += (uint64_t)indexed_field_count * 65536u;
-    const uint64_t docs = rd64(bytes + pos), psum = rd64(bytes + pos + 8);
-    if (docs < ix->n_docs || docs > ((uint64_t)level + 1) * 65536u || docs <= (uint64_t)level * 65536u) return SS_EINVAL;
-    ix->n_docs = docs; ix->positions_sum = psum;
-    pos += 16;
-    const uint8_t* heads = bytes + pos;
-    pos += nseg * 8u;
-    for (uint64_t k0 = 0; k0 < nseg; k0++) {
-      const uint64_t block_length = rd32(heads + 8 * k0), key_count = rd32(heads + 8 * k0 + 4);
-      const uint64_t head_bytes = key_count * key_head_size;
-      if (head_bytes > block_length || pos + block_length > len) return SS_EINVAL;
-      const uint8_t* body = bytes + pos + head_bytes;
-      const uint64_t body_len = block_length - head_bytes;
+  }
+  // ---- the key heads of every segment, segments in parallel: one entry per (key, component, level), dealt into 256 buckets by the
+  // key hash's top byte (hashes: even buckets), each bucket then sorted on its own -- the concatenation is the sorted whole
+  constexpr unsigned NB = 256;
+  const unsigned T = ss_loader_threads();
+  std::vector<std::vector<ss_index_bin::Blk>> part((size_t)T * NB);
+  std::vector<uint32_t> skipped(T, 0);
+  std::atomic<int> bad{0};
+  ss_parallel_for(segs.size(), 16, [&](size_t a, size_t b, unsigned w) {
+    for (size_t si = a; si < b; si++) {
+      const Seg& sg = segs[si];
+      const uint64_t head_bytes = sg.key_count * key_head_size;
+      const uint8_t* body = bytes + sg.pos + head_bytes;
+      const uint64_t body_len = sg.block_length - head_bytes;
       uint64_t prev = 0;
-      for (uint64_t i = 0; i < key_count; i++) {
-        const uint8_t* h = bytes + pos + i * key_head_size;
+      for (uint64_t i = 0; i < sg.key_count; i++) {
+        const uint8_t* h = bytes + sg.pos + i * key_head_size;
         const uint64_t key = rd64(h);
-        if (i && key <= prev) return SS_EINVAL;  // heads are binary-searched by key_hash (search.rs:2310-2357)
+        if (i && key <= prev) { bad.store(1); return; }  // heads are binary-searched by key_hash (search.rs:2310-2357)
         prev = key;
         // NgramType (index.rs:1854-1872): 0 SingleTerm, 1-3 bigrams, 4-7 trigrams.  An n-gram key is kept as one posting
         // list per component term (same docs, the component's tf): scored with idf_ngram_i each, their sum is the
-        // n-gram arm of get_bm25f_multiterm_singlefield (add_result.rs:1454-1477).  Several fields: skipped.
+        // n-gram arm of get_bm25f_multiterm_singlefield (add_result.rs:1454-1477); several fields: the components' field vectors.
         const uint32_t ntype = (uint32_t)(key & 7u), n_comp = ntype == 0 ? 1u : ntype <= 3u ? 2u : 3u;
-        if (ntype && n_comp > key_head_size - 20u) { ix->n_ngram_keys++; continue; }
+        if (ntype && n_comp > key_head_size - 20u) { skipped[w]++; continue; }  // a head without room for the component df bytes
         for (uint32_t c = 0; c < n_comp; c++) {
           ss_index_bin::Blk e;
           e.key = key;
           e.n_comp = (uint8_t)n_comp;
           e.comp = (uint8_t)c;
           e.df_byte = ntype ? h[14 + c] : (uint8_t)0;
-          e.b.block_id = level;
+          e.b.block_id = sg.level;
           e.b.posting_count_m1 = (uint16_t)rd16(h + 8);
           e.b.pointer_pivot_p_docid = (uint16_t)rd16(h + key_head_size - 6);
           e.b.compression_type_pointer = rd32(h + key_head_size - 4);
           e.b.byte_array = body;
           e.b.byte_array_len = body_len;
-          ix->blocks.push_back(e);
+          part[(size_t)w * NB + (key >> 56)].push_back(e);
         }
       }
-      pos += block_length;
     }
-    level++;
-  }
-  std::stable_sort(ix->blocks.begin(), ix->blocks.end(), [](const ss_index_bin::Blk& a, const ss_index_bin::Blk& b) {
-    return a.key != b.key ? a.key < b.key : a.comp < b.comp;  // levels stay ascending
   });
+  if (bad.load()) return SS_EINVAL;
+  for (unsigned w = 0; w < T; w++) ix->n_ngram_keys += skipped[w];
+  std::vector<uint64_t> boff(NB + 1, 0);
+  for (unsigned bkt = 0; bkt < NB; bkt++) {
+    uint64_t n = 0;
+    for (unsigned w = 0; w < T; w++) n += part[(size_t)w * NB + bkt].size();
+    boff[bkt + 1] = boff[bkt] + n;
+  }
+  ix->blocks.resize(boff[NB]);
+  ss_parallel_for(NB, 1, [&](size_t a, size_t b, unsigned) {
+    for (size_t bkt = a; bkt < b; bkt++) {
+      ss_index_bin::Blk* dst = ix->blocks.data() + boff[bkt];
+      uint64_t at = 0;
+      for (unsigned w = 0; w < T; w++) {
+        auto& v = part[(size_t)w * NB + bkt];
+        if (!v.empty()) std::memcpy((void*)(dst + at), (const void*)v.data(), v.size() * sizeof(ss_index_bin::Blk));
+        at += v.size();
+        std::vector<ss_index_bin::Blk>().swap(v);
+      }
+      std::sort(dst, dst + at, [](const ss_index_bin::Blk& x, const ss_index_bin::Blk& y) {
+        return x.key != y.key ? x.key < y.key : x.comp != y.comp ? x.comp < y.comp : x.b.block_id < y.b.block_id;  // levels ascending
+      });
+    }
+  });
+  ix->keys.reserve(ix->blocks.size() / 2 + 1);
   for (size_t i = 0; i < ix->blocks.size(); i++) {
     const ss_index_bin::Blk& e = ix->blocks[i];
     if (i == 0 || e.key != ix->blocks[i - 1].key || e.comp != ix->blocks[i - 1].comp) {
@@ -651,28 +692,50 @@ extern "C" int ss_index_bin_open(const uint8_t* bytes, uint64_t len, uint32_t in
   return SS_OK;
 }
 
+namespace {
+// the terms of `order` (old term ids) become the handle's terms, in that order
+void index_bin_reorder(ss_index_bin* ix, const std::vector<uint32_t>& order) {
+  std::vector<uint64_t> off(order.size() + 1, 0);
+  for (size_t i = 0; i < order.size(); i++) off[i + 1] = off[i] + (ix->term_block_off[order[i] + 1] - ix->term_block_off[order[i]]);
+  std::vector<ss_index_bin::Blk> blocks(off[order.size()]);
+  std::vector<uint64_t> keys(order.size());
+  std::vector<uint8_t> comp(order.size()), ncomp(order.size()), dfb(order.size());
+  ss_parallel_for(order.size(), 4096, [&](size_t a, size_t b, unsigned) {
+    for (size_t i = a; i < b; i++) {
+      const uint32_t t = order[i];
+      keys[i] = ix->keys[t]; comp[i] = ix->term_comp[t]; ncomp[i] = ix->term_ncomp[t]; dfb[i] = ix->term_df_byte[t];
+      const uint64_t n = ix->term_block_off[t + 1] - ix->term_block_off[t];
+      if (n) std::memcpy((void*)(blocks.data() + off[i]), (const void*)(ix->blocks.data() + ix->term_block_off[t]), n * sizeof(ss_index_bin::Blk));
+    }
+  });
+  ix->blocks.swap(blocks);
+  ix->keys.swap(keys);
+  ix->term_comp.swap(comp); ix->term_ncomp.swap(ncomp); ix->term_df_byte.swap(dfb);
+  ix->term_block_off.swap(off);
+}
+std::vector<uint64_t> index_bin_term_counts(const ss_index_bin* ix) {
+  std::vector<uint64_t> n(ix->keys.size(), 0);
+  ss_parallel_for(ix->keys.size(), 8192, [&](size_t a, size_t b, unsigned) {
+    for (size_t t = a; t < b; t++) {
+      uint64_t c = 0;
+      for (uint64_t bi = ix->term_block_off[t]; bi < ix->term_block_off[t + 1]; bi++) c += (uint64_t)ix->blocks[bi].b.posting_count_m1 + 1u;
+      n[t] = c;
+    }
+  });
+  return n;
+}
+}  // namespace
+
 // Keeps only the keys with at least min_posting_count postings (over all levels) -- the device image spends a directory
 // row and a probe row per term and sub-block, which pays for the frequent terms that dominate query cost and not for the
 // long tail of a real vocabulary; queries that touch a dropped term stay on the host's own path.
 extern "C" int ss_index_bin_filter(ss_index_bin* ix, uint64_t min_posting_count, uint32_t* n_terms_kept) {
   if (!ix) return SS_EINVAL;
-  std::vector<ss_index_bin::Blk> blocks;
-  std::vector<uint64_t> keys, off;
-  std::vector<uint8_t> comp, ncomp, dfb;
-  for (size_t t = 0; t < ix->keys.size(); t++) {
-    uint64_t n = 0;
-    for (uint64_t b = ix->term_block_off[t]; b < ix->term_block_off[t + 1]; b++) n += (uint64_t)ix->blocks[b].b.posting_count_m1 + 1u;
-    if (n < min_posting_count) continue;  // (the components of an n-gram key have the same count: kept or dropped together)
-    keys.push_back(ix->keys[t]);
-    comp.push_back(ix->term_comp[t]); ncomp.push_back(ix->term_ncomp[t]); dfb.push_back(ix->term_df_byte[t]);
-    off.push_back(blocks.size());
-    for (uint64_t b = ix->term_block_off[t]; b < ix->term_block_off[t + 1]; b++) blocks.push_back(ix->blocks[b]);
-  }
-  off.push_back(blocks.size());
-  ix->blocks.swap(blocks);
-  ix->keys.swap(keys);
-  ix->term_comp.swap(comp); ix->term_ncomp.swap(ncomp); ix->term_df_byte.swap(dfb);
-  ix->term_block_off.swap(off);
+  const std::vector<uint64_t> n = index_bin_term_counts(ix);
+  std::vector<uint32_t> order;
+  for (size_t t = 0; t < ix->keys.size(); t++)
+    if (n[t] >= min_posting_count) order.push_back((uint32_t)t);  // (the components of an n-gram key have the same count: kept or dropped together)
+  index_bin_reorder(ix, order);
   if (n_terms_kept) *n_terms_kept = (uint32_t)ix->keys.size();
   return SS_OK;
 }
@@ -685,29 +748,16 @@ extern "C" int ss_index_bin_filter(ss_index_bin* ix, uint64_t min_posting_count,
 extern "C" int ss_index_bin_tier(ss_index_bin* ix, uint64_t dense_min_posting_count, uint32_t* n_dense_out) {
   if (!ix) return SS_EINVAL;
   if (ix->n_fields > 1) return SS_ENOTSUP;  // the sparse tier holds single-field images
-  std::vector<ss_index_bin::Blk> blocks;
-  std::vector<uint64_t> keys, off;
-  std::vector<uint8_t> comp, ncomp, dfb;
-  uint32_t n_dense = 0;
+  const std::vector<uint64_t> n = index_bin_term_counts(ix);
+  std::vector<uint32_t> order;
+  order.reserve(ix->keys.size());
   for (int tier = 0; tier < 2; tier++) {
-    for (size_t t = 0; t < ix->keys.size(); t++) {
-      uint64_t n = 0;
-      for (uint64_t b = ix->term_block_off[t]; b < ix->term_block_off[t + 1]; b++) n += (uint64_t)ix->blocks[b].b.posting_count_m1 + 1u;
-      if ((n >= dense_min_posting_count) != (tier == 0)) continue;
-      keys.push_back(ix->keys[t]);
-      comp.push_back(ix->term_comp[t]); ncomp.push_back(ix->term_ncomp[t]); dfb.push_back(ix->term_df_byte[t]);
-      off.push_back(blocks.size());
-      for (uint64_t b = ix->term_block_off[t]; b < ix->term_block_off[t + 1]; b++) blocks.push_back(ix->blocks[b]);
-    }
-    if (tier == 0) n_dense = (uint32_t)keys.size();
+    for (size_t t = 0; t < ix->keys.size(); t++)
+      if ((n[t] >= dense_min_posting_count) == (tier == 0)) order.push_back((uint32_t)t);
+    if (tier == 0) ix->n_dense = (uint32_t)order.size();
   }
-  off.push_back(blocks.size());
-  ix->blocks.swap(blocks);
-  ix->keys.swap(keys);
-  ix->term_comp.swap(comp); ix->term_ncomp.swap(ncomp); ix->term_df_byte.swap(dfb);
-  ix->term_block_off.swap(off);
-  ix->n_dense = n_dense;
-  if (n_dense_out) *n_dense_out = n_dense;
+  index_bin_reorder(ix, order);
+  if (n_dense_out) *n_dense_out = ix->n_dense;
   return SS_OK;
 }
 
@@ -763,6 +813,75 @@ int index_bin_term(const ss_index_bin* ix, uint32_t term, std::vector<uint32_t>&
       tfs.push_back(t16[i]);
     }
   }
+  return SS_OK;
+}
+}  // namespace
+
+namespace {
+// decoded postings of the terms [t0, t1), terms in parallel: CSR offsets relative to the range, docs / tfs (+ positions and their
+// per-posting counts).  Every worker decodes whole terms into its own vectors; the pieces are then laid out in term order.
+struct DecodedRange {
+  std::vector<uint64_t> offs;  // [t1 - t0 + 1]
+  std::vector<uint32_t> docs;
+  std::vector<uint16_t> tfs, pos, npos;
+};
+int index_bin_decode_range(const ss_index_bin* ix, uint32_t t0, uint32_t t1, bool with_positions, DecodedRange* out) {
+  const size_t nt = t1 - t0;
+  struct Piece { std::vector<uint32_t> docs; std::vector<uint16_t> tfs, pos, npos; std::vector<uint64_t> n_doc, n_pos; size_t first = 0; };
+  // chunks of terms with about the same number of postings each (a term's count is known from its key heads)
+  std::vector<uint64_t> cum(nt + 1, 0);
+  for (size_t i = 0; i < nt; i++) {
+    uint64_t c = 0;
+    for (uint64_t bi = ix->term_block_off[t0 + i]; bi < ix->term_block_off[t0 + i + 1]; bi++) c += (uint64_t)ix->blocks[bi].b.posting_count_m1 + 1u;
+    cum[i + 1] = cum[i] + c;
+  }
+  const uint64_t per = std::max<uint64_t>(cum[nt] / (8ull * ss_loader_threads()) + 1, 1u << 16);
+  std::vector<size_t> cuts{0};
+  for (size_t i = 1; i <= nt; i++)
+    if (i == nt || cum[i] - cum[cuts.back()] >= per) cuts.push_back(i);
+  const size_t nc = cuts.size() - 1;
+  std::vector<Piece> pc(nc);
+  std::atomic<int> rc_all{SS_OK};
+  ss_parallel_for(nc, 1, [&](size_t a, size_t b, unsigned) {
+    std::vector<uint16_t> d16(65536), t16(65536);
+    for (size_t c = a; c < b; c++) {
+      Piece& P = pc[c];
+      P.first = cuts[c];
+      P.docs.reserve(cum[cuts[c + 1]] - cum[cuts[c]]);
+      P.tfs.reserve(cum[cuts[c + 1]] - cum[cuts[c]]);
+      for (size_t i = cuts[c]; i < cuts[c + 1]; i++) {
+        const size_t d_before = P.docs.size(), p_before = P.pos.size();
+        const int rc = index_bin_term(ix, (uint32_t)(t0 + i), P.docs, P.tfs, d16.data(), t16.data(), with_positions ? &P.pos : nullptr,
+                                      with_positions ? &P.npos : nullptr);
+        if (rc) { int ok = SS_OK; rc_all.compare_exchange_strong(ok, rc); return; }
+        P.n_doc.push_back(P.docs.size() - d_before);
+        P.n_pos.push_back(P.pos.size() - p_before);
+      }
+    }
+  });
+  if (rc_all.load()) return rc_all.load();
+  out->offs.assign(nt + 1, 0);
+  std::vector<uint64_t> d_at(nc + 1, 0), p_at(nc + 1, 0);
+  for (size_t c = 0; c < nc; c++) {
+    d_at[c + 1] = d_at[c] + pc[c].docs.size();
+    p_at[c + 1] = p_at[c] + pc[c].pos.size();
+    uint64_t at = d_at[c];
+    for (size_t j = 0; j < pc[c].n_doc.size(); j++) { out->offs[pc[c].first + j] = at; at += pc[c].n_doc[j]; }
+  }
+  out->offs[nt] = d_at[nc];
+  out->docs.resize(d_at[nc]); out->tfs.resize(d_at[nc]);
+  if (with_positions) { out->pos.resize(p_at[nc]); out->npos.resize(d_at[nc]); }
+  ss_parallel_for(nc, 1, [&](size_t a, size_t b, unsigned) {
+    for (size_t c = a; c < b; c++) {
+      if (!pc[c].docs.empty()) {
+        std::memcpy(out->docs.data() + d_at[c], pc[c].docs.data(), pc[c].docs.size() * 4);
+        std::memcpy(out->tfs.data() + d_at[c], pc[c].tfs.data(), pc[c].tfs.size() * 2);
+        if (with_positions) std::memcpy(out->npos.data() + d_at[c], pc[c].npos.data(), pc[c].npos.size() * 2);
+      }
+      if (with_positions && !pc[c].pos.empty()) std::memcpy(out->pos.data() + p_at[c], pc[c].pos.data(), pc[c].pos.size() * 2);
+      Piece().docs.swap(pc[c].docs);
+    }
+  });
   return SS_OK;
 }
 }  // namespace
@@ -868,35 +987,23 @@ int upload_index_bin_single(ss_shard* s, const ss_index_bin* ix, bool with_posit
   if (n_dense == 0) return SS_EINVAL;           // the dense image needs at least one list
   // (positions with a sparse tier: the dense terms get theirs -- phrases over dense terms work, a phrase naming a sparse term is
   // refused at search time like every phrase / filter over sparse terms)
-  std::vector<uint64_t> offs((size_t)n_dense + 1, 0);
-  std::vector<uint32_t> docs;
-  std::vector<uint16_t> tfs, d16(65536), t16(65536), pos, npos;
-  for (uint32_t t = 0; t < n_dense; t++) {
-    offs[t] = docs.size();
-    const int rc = index_bin_term(ix, t, docs, tfs, d16.data(), t16.data(), with_positions ? &pos : nullptr, with_positions ? &npos : nullptr);
-    if (rc) return rc;
-  }
-  offs[n_dense] = docs.size();
+  DecodedRange D;
+  int rc = index_bin_decode_range(ix, 0, n_dense, with_positions, &D);
+  if (rc) return rc;
   std::vector<uint8_t> doclen(ix->doclen.size() * 65536u);
   for (size_t l = 0; l < ix->doclen.size(); l++) std::memcpy(doclen.data() + l * 65536u, ix->doclen[l], 65536u);  // field 0
   // avgdl = positions_sum_normalized / indexed_doc_count as the reference's reader computes it (index.rs:3480-3482)
-  int rc = ssi_bm25_upload(s, ix->n_docs, doclen.data(), n_dense, offs.data(), docs.data(), tfs.data(), ix->positions_sum);
+  rc = ssi_bm25_upload(s, ix->n_docs, doclen.data(), n_dense, D.offs.data(), D.docs.data(), D.tfs.data(), ix->positions_sum);
   if (rc) return rc;
   if (with_positions) {
-    rc = ssi_bm25_attach_positions(s, offs.data(), docs.data(), tfs.data(), pos.data(), pos.size(), npos.data());
+    rc = ssi_bm25_attach_positions(s, D.offs.data(), D.docs.data(), D.tfs.data(), D.pos.data(), D.pos.size(), D.npos.data());
     if (rc) return rc;
   }
   if (n_dense < n_all) {  // the rare keys: decoded the same way, appended to the sparse tier (term ids continue behind the dense ones)
-    std::vector<uint64_t> so((size_t)(n_all - n_dense) + 1, 0);
-    std::vector<uint32_t> sd;
-    std::vector<uint16_t> st;
-    for (uint32_t t = n_dense; t < n_all; t++) {
-      so[t - n_dense] = sd.size();
-      rc = index_bin_term(ix, t, sd, st, d16.data(), t16.data(), nullptr);
-      if (rc) return rc;
-    }
-    so[n_all - n_dense] = sd.size();
-    return ss_bm25_append_sparse(s, n_all - n_dense, so.data(), sd.data(), st.data(), nullptr);
+    DecodedRange R;
+    rc = index_bin_decode_range(ix, n_dense, n_all, false, &R);
+    if (rc) return rc;
+    return ss_bm25_append_sparse(s, n_all - n_dense, R.offs.data(), R.docs.data(), R.tfs.data(), nullptr);
   }
   return rc;
 }

@@ -2,6 +2,7 @@
 // counter-based generator is bit-identical to the CPU oracle's (oracle/ss_oracle.c so_lex_* / so_vec_gen), so a
 // 10M-doc / 10M x 768 corpus never crosses PCIe and the oracle can still regenerate any slice of it.
 #include "ss_common.h"
+#include "ss_threads.h"
 #include "bm25_build.h"
 
 #include <cmath>
@@ -228,33 +229,39 @@ int ssi_bm25_build_from_host_merged(ss_shard* s, const uint8_t* doclen, const ui
     *merged_scale = mscale;
   }
   // pass 1: validate, segment boundaries in 16-byte units (4 postings, zero padded) relative to the term base
+  // (the per-term loops below run on the loader's worker threads: a term's rows, postings and probe row are its own)
   std::vector<uint32_t> sub((size_t)nt * (ns + 1));
   std::vector<u64> tbase((size_t)nt + 1);
   s->h_df.assign(nt, 0);
-  u64 units = 0;
-  for (uint32_t t = 0; t < nt; t++) {
+  for (uint32_t t = 0; t < nt; t++)
     if (offs[t + 1] < offs[t]) return SS_EINVAL;
-    tbase[t] = units;
-    s->h_df[t] = offs[t + 1] - offs[t];
-    uint32_t* row = sub.data() + (size_t)t * (ns + 1);
-    u64 i = offs[t], u = 0;
-    for (uint32_t sb = 0; sb < ns; sb++) {
-      row[sb] = (uint32_t)u;
-      const u64 lim = ((u64)sb + 1) << BM_SUB_LOG2;
-      const u64 i0 = i;
-      while (i < offs[t + 1] && docs[i] < lim) i++;
-      u += (i - i0 + 3) >> 2;
-      if (u >= (1ull << 28)) return SS_ENOTSUP;  // a term's segment offsets must stay below 4 GB
+  std::atomic<int> fail{SS_OK};
+  ss_parallel_for(nt, 64, [&](size_t ta, size_t tb, unsigned) {
+    for (size_t t = ta; t < tb; t++) {
+      s->h_df[t] = offs[t + 1] - offs[t];
+      uint32_t* row = sub.data() + (size_t)t * (ns + 1);
+      u64 i = offs[t], u = 0;
+      for (uint32_t sb = 0; sb < ns; sb++) {
+        row[sb] = (uint32_t)u;
+        const u64 lim = ((u64)sb + 1) << BM_SUB_LOG2;
+        const u64 i0 = i;
+        while (i < offs[t + 1] && docs[i] < lim) i++;
+        u += (i - i0 + 3) >> 2;
+        if (u >= (1ull << 28)) { fail.store(SS_ENOTSUP); return; }  // a term's segment offsets must stay below 4 GB
+      }
+      row[ns] = (uint32_t)u;
+      if (i != offs[t + 1]) { fail.store(SS_EINVAL); return; }  // doc id >= n_docs
     }
-    row[ns] = (uint32_t)u;
-    if (i != offs[t + 1]) return SS_EINVAL;  // doc id >= n_docs
-    units += u;
-  }
+  });
+  if (fail.load()) return fail.load();
+  u64 units = 0;
+  for (uint32_t t = 0; t < nt; t++) { tbase[t] = units; units += sub[(size_t)t * (ns + 1) + ns]; }
   tbase[nt] = units;
   std::vector<uint32_t> post(units ? units * 4 : 4, 0u);
   std::vector<float> umax((size_t)nt + 1, 0.f);
   std::vector<float> submax((size_t)(nt + 1) * ns, 0.f);
-  for (uint32_t t = 0; t < nt; t++) {
+  ss_parallel_for(nt, 16, [&](size_t ta, size_t tb, unsigned) {
+   for (size_t t = ta; t < tb; t++) {
     const bool flagged = bm_list_flagged(s, s->h_df[t]);
     const bool merged = s->bm_merged && t % L == L - 1;  // the term's merged list: weights from its field lists t - RF .. t - 1
     const uint8_t* dl = doclen + (size_t)(merged ? 0 : t % L) * s->bm_n_docs;  // the list's field (virtual term = term * L + field)
@@ -264,9 +271,7 @@ int ssi_bm25_build_from_host_merged(ss_shard* s, const uint8_t* doclen, const ui
       const u64 lim = ((u64)sb + 1) << BM_SUB_LOG2;
       u64 w = (tbase[t] + row[sb]) * 4;
       for (; j < offs[t + 1] && docs[j] < lim; j++, w++) {
-        if (docs[j] >= s->bm_n_docs) return SS_EINVAL;
-        if (j > offs[t] && docs[j] <= docs[j - 1]) return SS_EINVAL;
-        if (tfs[j] == 0) return SS_EINVAL;
+        if (docs[j] >= s->bm_n_docs || (j > offs[t] && docs[j] <= docs[j - 1]) || tfs[j] == 0) { fail.store(SS_EINVAL); return; }
         uint32_t code;
         if (merged) {
           code = bm_wcode(mw[mw_base[t / L] + (j - offs[t])] / mscale);
@@ -279,7 +284,9 @@ int ssi_bm25_build_from_host_merged(ss_shard* s, const uint8_t* doclen, const ui
         submax[(size_t)t * ns + sb] = std::max(submax[(size_t)t * ns + sb], bm_wdecode(code));
       }
     }
-  }
+   }
+  });
+  if (fail.load()) return fail.load();
   s->bm_n_post = offs[nt];
   const size_t rows = (size_t)nt * (ns + 1);
   int rc = alloc_post(s, units);
@@ -303,26 +310,31 @@ int ssi_bm25_build_from_host_merged(ss_shard* s, const uint8_t* doclen, const ui
   std::vector<uint32_t> probe_z;
   if (s->d_probe) probe.assign((size_t)s->bm_probe_rows * ns * BM_GROUPS, make_uint2(0, 0));
   probe_z.assign(probe.size(), 0u);
-  for (uint32_t t = 0; t < nt; t++) {
-    for (u64 j = offs[t]; j < offs[t + 1]; j++) {
-      if (!s->d_probe || s->h_probe_row[t] == BM_NO_PROBE_ROW) continue;
-      const uint32_t sb = docs[j] >> BM_SUB_LOG2, d = docs[j] & (BM_SUB - 1);
-      uint2* row = probe.data() + ((size_t)s->h_probe_row[t] * ns + sb) * BM_GROUPS;
-      const uint32_t g = d >> 6, b = d & 63;
-      if (b < 32) row[g].x |= 1u << b; else row[g].y |= 1u << (b - 32);
-    }
-  }
+  if (s->d_probe)
+    ss_parallel_for(nt, 16, [&](size_t ta, size_t tb, unsigned) {  // (every term sets bits in its own row)
+      for (size_t t = ta; t < tb; t++) {
+        if (s->h_probe_row[t] == BM_NO_PROBE_ROW) continue;
+        for (u64 j = offs[t]; j < offs[t + 1]; j++) {
+          const uint32_t sb = docs[j] >> BM_SUB_LOG2, d = docs[j] & (BM_SUB - 1);
+          uint2* row = probe.data() + ((size_t)s->h_probe_row[t] * ns + sb) * BM_GROUPS;
+          const uint32_t g = d >> 6, b = d & 63;
+          if (b < 32) row[g].x |= 1u << b; else row[g].y |= 1u << (b - 32);
+        }
+      }
+    });
   std::vector<uint32_t> term_of_row(s->bm_probe_rows, 0);
   for (uint32_t t = 0; t < nt; t++)
     if (s->d_probe && s->h_probe_row[t] != BM_NO_PROBE_ROW) term_of_row[s->h_probe_row[t]] = t;
-  for (size_t r = 0; r < probe.size(); r += BM_GROUPS) {  // z = index (inside the term) of the group's first posting
-    const size_t t = term_of_row[(r / BM_GROUPS) / ns], sb = (r / BM_GROUPS) % ns;
-    uint32_t run = sub[t * (ns + 1) + sb] * 4u;
-    for (int g = 0; g < BM_GROUPS; g++) {
-      probe_z[r + g] = run;
-      run += (uint32_t)__builtin_popcount(probe[r + g].x) + (uint32_t)__builtin_popcount(probe[r + g].y);
+  ss_parallel_for(probe.size() / BM_GROUPS, 4096, [&](size_t ra, size_t rb, unsigned) {  // z = index (inside the term) of the group's first posting
+    for (size_t rr = ra; rr < rb; rr++) {
+      const size_t r = rr * BM_GROUPS, t = term_of_row[rr / ns], sb = rr % ns;
+      uint32_t run = sub[t * (ns + 1) + sb] * 4u;
+      for (int g = 0; g < BM_GROUPS; g++) {
+        probe_z[r + g] = run;
+        run += (uint32_t)__builtin_popcount(probe[r + g].x) + (uint32_t)__builtin_popcount(probe[r + g].y);
+      }
     }
-  }
+  });
   SS_HIP(hipMemcpy(s->d_umax, umax.data(), umax.size() * sizeof(float), hipMemcpyHostToDevice));
   SS_HIP(hipMemcpy(s->d_submax, submax.data(), submax.size() * sizeof(float), hipMemcpyHostToDevice));
   // Are block maxima worth a pass per search?  Only where they vary over the doc ids: for the longest lists, the mean over
@@ -369,13 +381,17 @@ int ssi_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, 
   float comp[SS_COMP_N];
   fill_comp(s->bm_avgdl, comp);
   std::vector<u64> packed(n_new ? n_new : 1);
-  for (uint32_t i = 0; i < n_lists; i++) {
+  for (uint32_t i = 0; i < n_lists; i++)
     if (offs[i + 1] < offs[i]) return SS_EINVAL;
-    for (u64 j = offs[i]; j < offs[i + 1]; j++) {
-      if (docs[j] >= s->bm_n_docs || tfs[j] == 0 || (j > offs[i] && docs[j] <= docs[j - 1])) return SS_EINVAL;
-      packed[j - offs[0]] = ((u64)bm_code_of(tfs[j], comp[dl[docs[j]]], false) << 32) | docs[j];
-    }
-  }
+  std::atomic<int> fail{SS_OK};
+  ss_parallel_for(n_lists, 4096, [&](size_t a, size_t b, unsigned) {
+    for (size_t i = a; i < b; i++)
+      for (u64 j = offs[i]; j < offs[i + 1]; j++) {
+        if (docs[j] >= s->bm_n_docs || tfs[j] == 0 || (j > offs[i] && docs[j] <= docs[j - 1])) { fail.store(SS_EINVAL); return; }
+        packed[j - offs[0]] = ((u64)bm_code_of(tfs[j], comp[dl[docs[j]]], false) << 32) | docs[j];
+      }
+  });
+  if (fail.load()) return fail.load();
   const u64 old_n = s->h_sp_base.empty() ? 0 : s->h_sp_base.back();
   uint64_t *nb = nullptr, *np = nullptr;
   SS_HIP(hipMalloc(&nb, ((size_t)s->sp_n + n_lists + 1) * sizeof(u64)));
@@ -408,30 +424,41 @@ int ssi_bm25_upload_positions(ss_shard* s, const uint64_t* offs, const uint32_t*
   if (!npos) npos = tfs;
   const uint32_t nt = s->bm_n_terms, ns = s->bm_n_sub;
   if (s->bm_n_fields != 1) return SS_ENOTSUP;
-  std::vector<u64> pbase((size_t)nt + 1);
+  std::vector<u64> pbase((size_t)nt + 1), tbase((size_t)nt + 1);
+  SS_HIP(hipMemcpy(tbase.data(), s->d_term_base, tbase.size() * sizeof(u64), hipMemcpyDeviceToHost));
   std::vector<uint32_t> poff((size_t)s->bm_n_post_pad + 5, 0u);  // + 4: the padding loop of a segment may run to the next multiple of 4 before the walk is checked
-  u64 total = 0, w = 0;  // w: padded image index (dwords)
-  for (uint32_t t = 0; t < nt; t++) {
-    pbase[t] = total;
-    u64 rel = 0, j = offs[t];
-    for (uint32_t sb = 0; sb < ns; sb++) {
-      const u64 lim = ((u64)sb + 1) << BM_SUB_LOG2;
-      u64 n = 0;
-      for (; j < offs[t + 1] && docs[j] < lim; j++, n++) {
-        if (total + rel + npos[j] > n_positions) return SS_EINVAL;  // never read past the caller's array (index.bin path: counts come from the file)
-        for (uint32_t x = 1; x < npos[j]; x++)
-          if (positions[total + rel + x] <= positions[total + rel + x - 1]) return SS_EINVAL;  // ascending inside a posting
-        rel += npos[j];
-        if (rel >= (1ull << 32)) return SS_ENOTSUP;
-        if (w >= s->bm_n_post_pad) return SS_EINVAL;  // more postings than the image holds: not the CSR it was built from
-        poff[w++] = (uint32_t)rel;
-      }
-      for (u64 pad = (4 - (n & 3)) & 3; pad > 0; pad--) poff[w++] = (uint32_t)rel;  // NULL padding of the segment
-    }
-    total += rel;
+  // a term's positions: the sum of its postings' counts (terms in parallel), then every term fills its own slots
+  pbase[0] = 0;
+  {
+    std::vector<u64> tsum(nt, 0);
+    ss_parallel_for(nt, 64, [&](size_t a, size_t b, unsigned) {
+      for (size_t t = a; t < b; t++) { u64 c = 0; for (u64 j = offs[t]; j < offs[t + 1]; j++) c += npos[j]; tsum[t] = c; }
+    });
+    for (uint32_t t = 0; t < nt; t++) pbase[t + 1] = pbase[t] + tsum[t];
   }
-  pbase[nt] = total;
-  if (total != n_positions || w != s->bm_n_post_pad) return SS_EINVAL;
+  const u64 total = pbase[nt];
+  if (total != n_positions) return SS_EINVAL;  // never read past the caller's array (index.bin path: counts come from the file)
+  std::atomic<int> fail{SS_OK};
+  ss_parallel_for(nt, 16, [&](size_t ta, size_t tb, unsigned) {
+    for (size_t t = ta; t < tb; t++) {
+      u64 rel = 0, j = offs[t], w = tbase[t] * 4ull;
+      for (uint32_t sb = 0; sb < ns; sb++) {
+        const u64 lim = ((u64)sb + 1) << BM_SUB_LOG2;
+        u64 n = 0;
+        for (; j < offs[t + 1] && docs[j] < lim; j++, n++) {
+          for (uint32_t x = 1; x < npos[j]; x++)
+            if (positions[pbase[t] + rel + x] <= positions[pbase[t] + rel + x - 1]) { fail.store(SS_EINVAL); return; }  // ascending inside a posting
+          rel += npos[j];
+          if (rel >= (1ull << 32)) { fail.store(SS_ENOTSUP); return; }
+          if (w >= tbase[t + 1] * 4ull) { fail.store(SS_EINVAL); return; }  // more postings than the image holds: not the CSR it was built from
+          poff[w++] = (uint32_t)rel;
+        }
+        for (u64 pad = (4 - (n & 3)) & 3; pad > 0; pad--) poff[w++] = (uint32_t)rel;  // NULL padding of the segment
+      }
+      if (w != tbase[t + 1] * 4ull || j != offs[t + 1]) { fail.store(SS_EINVAL); return; }
+    }
+  });
+  if (fail.load()) return fail.load();
   SS_HIP(hipMalloc(&s->d_pos, (total ? total : 1) * sizeof(uint16_t)));
   SS_HIP(hipMalloc(&s->d_pos_off, poff.size() * sizeof(uint32_t)));
   SS_HIP(hipMalloc(&s->d_pos_base, pbase.size() * sizeof(u64)));

@@ -155,3 +155,19 @@ def test_dense_not_list_and_heavy_tombstones(S, O, lex):
         sh.set_strategy(0)
         sh.set_deleted([])
         osh.set_deleted([])
+
+
+def test_drop_in_rehearsal_on_a_million_doc_index_bin(S, O):
+    """index.bin (1 M docs, >= 1 M keys, clustered doc ids, NgramFF | NgramFFF keys, positions) + vector.bin +
+    delete.bin as the reference lays them out -> ss_index_bin_open -> tier -> upload with positions; 2-term ANDs, 3-term ORs (rare
+    terms from the sparse tier included), phrases over n-gram keys, vector and hybrid queries, every answer against the oracle;
+    64 concurrent callers through Index::search of the C++ mirror.  tools/real_format.py holds the rehearsal (bench.py runs it too)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import real_format
+    r = real_format.run(n_docs=1_000_000, vocab=1_000_000, n_queries=64, seconds=0.6)
+    assert r["files"]["keys"] >= 1_000_000 and r["files"]["ngram_keys"] > 10_000
+    assert r["open"]["sparse_terms"] > 900_000 and r["open"]["dense_terms"] > 1000
+    assert r["queries"]["phrases_with_ngram_keys"] > 0 and r["queries"]["ors_naming_a_sparse_term"] > 0
+    assert set(r["parity"]["queries"]) == {"and2", "or3", "phrase", "vector", "hybrid"}
+    assert all(v["errors"] == 0 for v in r["concurrent_callers"].values())

@@ -922,3 +922,49 @@ def test_tiered_index_bin_upload_answers_like_the_arrays():
         assert int(ra[3][0]) == otot and np.allclose(ra[1][0][:ra[2][0]], os_, rtol=1e-4)
     a.close()
     b.close()
+
+
+def _python_writer_of(T, RF, O, key_head_size, positions_limit):
+    """the same corpus through oracle/ref_format.py: single terms, then the n-gram keys with their component tfs / df bytes"""
+    terms, ngt = [], []
+    lut = lambda df: int(O.lib().so_int_to_byte4(int(df)))
+    for k in range(T.n_keys):
+        if T.key_df(k) == 0:
+            continue
+        docs, tfs, cnt, pos = T.key_postings(k)
+        per = [p.tolist() for p in np.split(pos, np.cumsum(cnt.astype(np.int64))[:-1])]
+        h = T.key_hash(k)
+        if k < T.vocab:
+            terms.append((h, docs.astype(np.int64), tfs.astype(np.int64), per))
+        elif (2 if (h & 7) == 1 else 3) <= key_head_size - 20:
+            ngt.append((h, docs.astype(np.int64), cnt.astype(np.int64), k, per))
+    return terms, ngt, lut
+
+
+@pytest.mark.parametrize("head,limit", [(23, 32768), (22, 300), (20, 32768)])
+def test_c_indexer_writes_what_the_restated_python_writer_writes(head, limit):
+    """oracle/ss_textindex.c (the mini indexer that produces config-size index.bin files) against oracle/ref_format.py (the restated
+    writer the hand-assembled fixtures pin): the same corpus -> the same bytes; and the product's walker reads every key back"""
+    from oracle import oracle as O, textindex as TI
+    T = TI.TextCorpus(7, 70_000, 3000, n_frequent=12, mean_len=7.0, topic_share=0.4)
+    assert T.n_ngram_keys > 100 and T.n_tokens > 400_000
+    data = T.write_index_bin(key_head_size=head, positions_limit=limit)
+    terms, ngt, lut = _python_writer_of(T, RF, O, head, limit)
+    ng_terms = []
+    for h, docs, cnt, k, per in ngt:
+        nc = 2 if (h & 7) == 1 else 3
+        comp = np.stack([T.key_postings(k, c, False)[1] for c in range(nc)], 1).astype(np.int64)
+        # the component ranks: the single terms whose tf in the key's first doc equals the component tfs are not unique -- take them
+        # from the doc's tokens at the key's first position
+        toks = T.doc_tokens(int(docs[0]))
+        ranks = [int(toks[per[0][0] + i]) for i in range(nc)]
+        assert T.ngram_key(ranks) == k
+        ng_terms.append((h, docs, cnt, comp, [lut(T.key_df(r)) for r in ranks], per))
+    ref = RF.write_index_bin(T.n_docs, T.doclen, terms, np.random.default_rng(0), key_head_size=head, positions_limit=limit, ngram_terms=ng_terms)
+    assert len(data) == len(ref)
+    assert data == ref
+    ix = S.IndexBin(data, key_head_size=head)
+    assert ix.indexed_doc_count == T.n_docs and ix.term_count >= len(terms)
+    for h, docs, tfs, per in terms[::97]:
+        d, t = ix.postings(ix.term_of_key(h))
+        assert np.array_equal(d, docs) and np.array_equal(t, tfs)
