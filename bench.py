@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--no-fields", action="store_true", help="skip the multi-field (BM25F) leg")
     ap.add_argument("--no-vocab", action="store_true", help="skip the realistic-vocabulary leg (1 M rare terms in the sparse tier)")
     ap.add_argument("--vocab-terms", type=int, default=1_000_000)
+    ap.add_argument("--scale-check", action="store_true", help="self-verification of a multi-rank run (always on when N > 1): every rank reports the ranks its "
+                    "communicator spans, the microseconds of the all-gather and a checksum of the merged answers; rank 0 asserts they agree")
+    ap.add_argument("--no-clustered", action="store_true", help="skip the clustered-corpus leg (10 M docs whose term densities vary with the doc's cluster)")
     ap.add_argument("--no-real-format", action="store_true", help="skip the drop-in rehearsal on a million-doc index.bin / vector.bin / delete.bin")
     ap.add_argument("--real-format-docs", type=int, default=1_000_000)
     ap.add_argument("--quick", action="store_true", help="profiling runs: few calls per leg, no cpu / parity legs")
@@ -316,6 +319,34 @@ def main():
         avg_ms = kms / max(launches, 1)
         qps, ms_step = nq * calls / dt, dt / args.steps * 1e3
 
+        # self-verification of the exchange: what every rank's communicator spans, what one all-gather costs, and that all
+        # ranks hold the SAME merged answers.  The first real multi-rank run checks itself; at N = 1 only with --scale-check.
+        scale_check = None
+        if comm is not None and (world > 1 or args.scale_check):
+            comm.profile(True)
+            comm.profile_read()
+            sh_out = comm.search_lexical_sharded(sh, q_np, k, N.RT_TOPK)  # ss_bm25_search_sharded: search, ONE all-gather, merge
+            n_coll, ag_us = comm.profile_read()
+            comm.profile(False)
+            bm_call()
+            torch.cuda.synchronize()
+            m_doc, m_score, m_cnt = (merged["bm25"] if world > 1 else (o_doc.to(torch.int64), o_score, o_cnt))
+            digest = hashlib.sha256(m_doc.cpu().numpy().tobytes() + m_score.cpu().numpy().tobytes() + m_cnt.cpu().numpy().tobytes()).hexdigest()[:16]
+            digest_h = hashlib.sha256(sh_out[0].tobytes() + sh_out[1].tobytes() + sh_out[2].tobytes()).hexdigest()[:16]
+            r_, n_, d_ = comm.info()
+            mine = {"rank": rank, "comm_rank": r_, "ranks_seen": n_, "device": d_, "allgather_us": ag_us, "collectives": n_coll,
+                    "merged_checksum_dev": digest, "merged_checksum_sharded": digest_h}
+            print("SCALE_CHECK " + json.dumps(mine), file=sys.stderr, flush=True)
+            every = [mine]
+            if world > 1:
+                every = [None] * world
+                dist.all_gather_object(every, mine)
+            if rank == 0:
+                assert all(e["ranks_seen"] == world for e in every), f"a communicator does not span {world} ranks: {every}"
+                assert len({e["merged_checksum_dev"] for e in every}) == 1 and len({e["merged_checksum_sharded"] for e in every}) == 1, \
+                    f"ranks hold different merged answers: {every}"
+                scale_check = {"ranks": every, "agree": True}
+
         # (3) ResultType::TopkCount, the reference server's default: pruned top-k + exact union counts (popcounts over the
         # probe index's bit records) under AUTO, against the exhaustive scan in count mode
         tc = {}
@@ -443,6 +474,58 @@ def main():
                                             "so_search_lex_ref with not_query_list and delete_hashset on the host-regenerated shard",
                                             "seconds": time.perf_counter() - t0}
             sx.close()
+        # (3d) a CLUSTERED corpus at full size (every full-size corpus was uniform-random): the same 10 M docs / 4096
+        # terms, but a term's density varies 32-fold with the doc's cluster (runs of 1024 / 8192 doc ids; oracle so_lex_cluster_thresh,
+        # device lex_cluster_thresh) -- doc ids in bursts, uneven block maxima, sub-blocks a term skips entirely.  Same queries.
+        clustered = None
+        if not args.no_topk_count and world == 1 and not args.quick and not args.no_clustered:
+            sc = S.Shard(local_rank, shard_id=rank)
+            sc.synth_partition(rank, world)
+            sc.synth_lexical(O.LEX_SEED_CLUSTERED, args.docs, th, tab)
+            qc_np = sc.make_queries(term_lists, S.QueryType.Union)
+            qc_dev = torch.from_numpy(qc_np.view(np.uint8).reshape(nq, -1).copy()).to(dev)
+
+            def c_call(rt=N.RT_TOPK):
+                N.check(L.ss_bm25_search_dev(sc._h, nq, qc_dev.data_ptr(), k, rt, OPS, o_doc.data_ptr(), o_score.data_ptr(),
+                                             o_cnt.data_ptr(), o_tot.data_ptr(), sptr), "ss_bm25_search_dev")
+            cres, ct = {}, {}
+            for name, strat, rt_ in (("exhaustive", N.BM25_EXHAUSTIVE, N.RT_TOPKCOUNT), ("auto", N.BM25_AUTO, N.RT_TOPKCOUNT), ("auto_topk", N.BM25_AUTO, N.RT_TOPK),
+                                     ("exhaustive_topk", N.BM25_EXHAUSTIVE, N.RT_TOPK)):
+                sc.set_strategy(strat)
+                c_call(rt_)
+                torch.cuda.synchronize()
+                cres[name] = (o_doc.cpu().numpy().copy(), o_score.cpu().numpy().copy(), o_tot.cpu().numpy().astype(np.int64))
+                sc.profile(True)
+                sc.profile_read(0, reset=True)
+                n_, d_ = timed_for(lambda: c_call(rt_))
+                cl_, cms_ = sc.profile_read(0, reset=True)
+                sc.profile(False)
+                ct[name] = {"value": nq * n_ / d_, "unit": "queries/s", "ms_per_call": d_ / n_ * 1e3, "calls": n_, "kernel_ms": cms_ / max(cl_, 1)}
+            assert np.array_equal(cres["exhaustive"][1], cres["auto"][1]) and np.array_equal(cres["exhaustive"][2], cres["auto"][2]), "clustered corpus: strategies differ"
+            assert np.array_equal(cres["exhaustive"][1], cres["auto_topk"][1]) and np.array_equal(cres["exhaustive"][1], cres["exhaustive_topk"][1])
+            cu = sorted({t for tl in term_lists for t in tl})
+            cdf = dict(zip(cu, (int(x) for x in sc.posting_count(cu))))
+            c_bytes = float(sum(sum(cdf[t] for t in tl) * 3 + int(m_) + 4 * n_blocks * len(tl) + 8 * k for tl, m_ in zip(term_lists, cres["exhaustive"][2])))
+            clustered = dict(ct, docs=args.docs, mean_union=float(cres["exhaustive"][2].mean()), mean_df_ratio_to_uniform=float(np.mean([cdf[t] / max(dfm.get(t, 1), 1) for t in cu if t in dfm])),
+                             exhaustive_roofline={"bound": "hbm", "kernel": "bm25_scan16_kernel<3,1> on the clustered corpus", "algorithmic_bytes_per_launch": c_bytes,
+                                                  "avg_launch_ms": ct["exhaustive_topk"]["kernel_ms"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                  "achieved": c_bytes / (ct["exhaustive_topk"]["kernel_ms"] * 1e-3) / 1e9 if ct["exhaustive_topk"]["kernel_ms"] > 0 else None,
+                                                  "frac": c_bytes / (ct["exhaustive_topk"]["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if ct["exhaustive_topk"]["kernel_ms"] > 0 else None},
+                             pruned_effective_GBs_on_algorithmic_bytes=c_bytes / (ct["auto_topk"]["kernel_ms"] * 1e-3) / 1e9 if ct["auto_topk"]["kernel_ms"] > 0 else None,
+                             workload="the C2 batch (3-term OR top-10, 1000 queries per call) on a 10 M-doc corpus whose term densities vary 32-fold with the doc's "
+                                      "cluster (seed bit 63); exhaustive / auto = TopkCount, *_topk = Topk; answers of all four asserted identical")
+            if not args.no_parity:
+                t0 = time.perf_counter()
+                nsc = min(128, nq)
+                cans = F.c2_answers_chunked(args.docs, term_lists[:nsc], th, k, O.OP_OR, O.RT_TOPKCOUNT, seed=O.LEX_SEED_CLUSTERED, part=(rank, world), chunk=64)
+                for i in range(nsc):
+                    od, os_, otot = cans[i]
+                    assert int(cres["auto"][2][i]) == otot, f"clustered corpus: count of query {i}: {int(cres['auto'][2][i])} vs oracle {otot}"
+                    F.check_topk(cres["auto"][0][i], cres["auto"][1][i], od, os_, 1e-4, f"clustered corpus, query {i}")
+                parity["clustered"] = {"queries": nsc, "docs": args.docs, "checked": "exact result_count_total, top-10 ids outside the tie band, scores rtol 1e-4; "
+                                       "oracle = so_search_lex_ref on the host-regenerated clustered shard (Rle / Bitmap / Array containers by the reference's chooser)",
+                                       "seconds": time.perf_counter() - t0}
+            sc.close()
         ach_alg = bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         ex_ach = bytes_launch / (ex_kms * 1e-3) / 1e9 if ex_kms > 0 else 0.0
         lat_batch = latencies(bm_rot_call, 1000)
@@ -491,6 +574,8 @@ def main():
                             "not_tombstones_algorithmic_bytes": ((excl or {}).get("roofline") or {}).get("algorithmic_bytes_per_launch"),
                             "fallback_f32_frac": (((excl or {}).get("f32_tile") or {}).get("roofline") or {}).get("frac"),
                             "fallback_f32_avg_launch_ms": (((excl or {}).get("f32_tile") or {}).get("roofline") or {}).get("avg_launch_ms"),
+                            "clustered_exhaustive_frac": ((clustered or {}).get("exhaustive_roofline") or {}).get("frac"),
+                            "clustered_exhaustive_avg_launch_ms": ((clustered or {}).get("exhaustive_roofline") or {}).get("avg_launch_ms"),
                             "pmc_profile": "profiles/pmc_traffic.json" if moved else "absent or collected on other kernel sources (stale): no counter figure",
                             "note": "achieved = counter-measured HBM bytes of this kernel / live kernel time (the kernel prunes: it answers "
                                     "without reading most of SURVEY 8d's algorithmic bytes, so effective_GBs_on_algorithmic_bytes may exceed "
@@ -505,7 +590,7 @@ def main():
                   latency_ms={"batch_p50": pct(lat_batch, 50), "batch_p99": pct(lat_batch, 99), "batch_samples": len(lat_batch),
                               "single_query_p50": pct(lat_one, 50), "single_query_p99": pct(lat_one, 99),
                               "single_query_samples": len(lat_one), "clock": "HIP events on the launch stream (device resident)"},
-                  end_to_end=end_to_end, intersection=inter, exhaustive_not_tombstones=excl,
+                  end_to_end=end_to_end, intersection=inter, exhaustive_not_tombstones=excl, clustered=clustered, scale_check=scale_check,
                   mean_bytes_per_query=float(bytes_q.mean()), mean_union=float(tot.mean()))
         # correctness guard inside the bench: sorted, k results
         bm_call()
@@ -1130,6 +1215,10 @@ def main():
                 line["intersection"] = bm["intersection"]
             if bm.get("exhaustive_not_tombstones"):
                 line["exhaustive_not_tombstones"] = bm["exhaustive_not_tombstones"]
+            if bm.get("clustered"):
+                line["clustered"] = bm["clustered"]
+            if bm.get("scale_check"):
+                line["scale_check"] = bm["scale_check"]
             if "rationed_vocabulary" in bm:
                 line["rationed_vocabulary"] = bm["rationed_vocabulary"]
             if "multi_field" in bm:

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 3
+#define SS_ABI_VERSION 4
 #define SS_NO_DOC 0xFFFFFFFFu
 #define SS_MAX_QUERY_TERMS 10 /* union_docid_3 handles <= 10 terms, union.rs:1308 */
 #define SS_MAX_K 1024
@@ -272,6 +272,19 @@ int ss_bm25_fields_info(ss_shard* s, uint32_t* n_fields, uint32_t* merged_lists,
 int ss_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
                           uint32_t* first_term_id_out);
 int ss_bm25_sparse_info(ss_shard* s, uint32_t* n_lists, uint64_t* n_postings, uint64_t* bytes);
+/* INCREMENTAL COMMIT (commit.rs:142-148 commit -> warmup, 264-369; index.rs:3796 -- the "(re)build device image" seam after a commit).
+ * The reference commits one 65 536-doc level at a time.  ss_bm25_append_level hands over the decoded postings of ONE level -- the
+ * length bytes of its docs and, per term, (shard-local doc id, tf) ascending, doc ids inside [level * 65536, level * 65536 +
+ * n_level_docs) -- and the image then covers every level committed so far.  level = the number of levels committed (append) or the
+ * last committed level (replace: the re-commit of a partial level); only the last level may hold fewer than 65 536 docs.  n_terms may
+ * grow from call to call (term ids are the caller's and stable: new terms get the next ids).  The first call on an empty shard creates
+ * the image; a shard whose image came from another builder answers SS_ESTATE.  One indexed field, no positions, no sparse tier.
+ * Cost: the level's bytes over PCIe + a device-side rebuild of the image from the levels' postings kept in HBM (6 bytes per posting):
+ * BM25 weights depend on avgdl, which every commit moves (commit.rs:318-325), so the reference too refreshes every block's scores.
+ * Searches keep running on the previous image until the new one is swapped in (the call then waits for the searches in flight). */
+int ss_bm25_append_level(ss_shard* s, uint32_t level, uint32_t n_level_docs, const uint8_t* level_doclen, uint32_t n_terms,
+                         const uint64_t* term_offsets /*[n_terms+1]*/, const uint32_t* doc_ids, const uint16_t* tfs);
+int ss_bm25_incremental_info(ss_shard* s, uint32_t* n_levels, uint64_t* raw_bytes, double* last_append_ms, double* last_rebuild_ms);
 /* Search strategy.  AUTO: requests with <= 4 scored terms and k <= 128 take the PRUNED path (the reference's block-max /
  * sub-query pruning, intersection.rs:2224-2233, union.rs:1355-1405, as MaxScore over a probe index: only essential /
  * shortest lists are read; exact union counts are popcounts over the index's bit records like union_count,

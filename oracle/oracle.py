@@ -114,6 +114,7 @@ def lib():
 
 # ---------------------------------------------------------------- synthetic corpora
 LEX_SEED = 0x5EEC5701
+LEX_SEED_CLUSTERED = LEX_SEED | (1 << 63)  # bit 63: a term's density varies with the doc's cluster (so_lex_cluster_thresh)
 VEC_SEED = 0xC051AE01
 VECQ_SEED = 0xC051AE02
 N_VOCAB = 4096

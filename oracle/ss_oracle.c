@@ -72,12 +72,24 @@ uint32_t so_geom06(uint32_t u) {
   while (j < 24u && u < T[j]) j++;
   return j;
 }
+/* CLUSTERED corpora (seeds with bit 63 set): a term's density varies with the doc's cluster -- runs of 1024 (odd terms) or 8192 (even
+ * terms) consecutive doc ids; in 70 % of its clusters the term is 8 times rarer than its threshold says, in 25 % as the threshold
+ * says, in 5 % four times denser.  Doc ids of a list come in bursts (Rle / Bitmap-shaped blocks, uneven block maxima), as in a
+ * corpus ordered by source or time; the uniform corpora (bit 63 clear) keep postings independent per doc. */
+uint32_t so_lex_cluster_thresh(uint64_t seed, uint32_t term, uint64_t d, uint32_t thresh32) {
+  const uint64_t c = (term & 1u) ? (d >> 10) : (d >> 13);
+  const uint32_t r = (uint32_t)(so_h(seed ^ 0xC1ull, (uint64_t)term + 1u, c) >> 40) & 0xFFFFu;
+  const uint64_t m = r < 45875u ? 1u : r < 62259u ? 8u : 32u;
+  const uint64_t v = ((uint64_t)thresh32 * m) >> 3;
+  return v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v;
+}
 uint64_t so_lex_term_postings(uint64_t seed, uint32_t term, uint32_t thresh32, uint64_t n_docs,
                               uint32_t* out_docs, uint16_t* out_tfs, uint64_t cap) {
   uint64_t c = 0;
+  const int clustered = (int)(seed >> 63);
   for (uint64_t d = 0; d < n_docs; d++) {
     uint64_t hv = so_h(seed, (uint64_t)term + 1u, d);
-    if ((uint32_t)(hv >> 32) < thresh32) {
+    if ((uint32_t)(hv >> 32) < (clustered ? so_lex_cluster_thresh(seed, term, d, thresh32) : thresh32)) {
       if (out_docs && c < cap) {
         out_docs[c] = (uint32_t)d;
         out_tfs[c] = (uint16_t)(1u + so_geom06((uint32_t)hv));

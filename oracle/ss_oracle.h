@@ -48,6 +48,7 @@ uint64_t so_h(uint64_t seed, uint64_t a, uint64_t b);
 void so_lex_doclen(uint64_t seed, uint64_t d0, uint64_t n, const uint8_t* len_table1024, uint8_t* out);
 /* postings of term t over docs [0,n_docs): posting present iff (h(seed,t+1,d)>>32) < thresh32;
  * tf = 1 + min(ctz(low32), 31).  Returns the count; out arrays may be NULL to count only. */
+uint32_t so_lex_cluster_thresh(uint64_t seed, uint32_t term, uint64_t doc, uint32_t thresh32); /* clustered corpora: seeds with bit 63 set */
 uint64_t so_lex_term_postings(uint64_t seed, uint32_t term, uint32_t thresh32, uint64_t n_docs,
                               uint32_t* out_docs, uint16_t* out_tfs, uint64_t cap);
 /* vector rows [r0,r0+n) x dim, uniform(-1,1) then normalize_f32 semantics */

@@ -22,7 +22,8 @@ def _newer(dst, srcs):
 
 def build(force=False, verbose=False):
     os.makedirs(OUT_DIR, exist_ok=True)
-    deps = [os.path.join(CSRC, "ss_common.h"), os.path.join(CSRC, "bm25_dev.h"), os.path.join(HERE, "..", "include", "seekstorm_hip.h")]
+    # every header of csrc/ (they are few and included widely) + the public header: editing any of them rebuilds every object
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(HERE, "..", "include", "seekstorm_hip.h")]
     objs = []
     jobs = []
     for src in SOURCES:

@@ -154,11 +154,11 @@ constexpr uint32_t BM_CLAIM_GATED = 128u;   // some query is a UNION of several 
 __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery* __restrict__ vq, uint32_t nq, uint32_t n_lists,
                                  const unsigned long long* __restrict__ term_base, const float* __restrict__ boost,
                                  unsigned long long* __restrict__ total, uint32_t* __restrict__ tau, uint32_t claim,
-                                 uint32_t n_vterms, const uint32_t* __restrict__ probe_row, uint32_t merged) {
+                                 uint32_t n_vterms, const uint32_t* __restrict__ probe_row, uint32_t merged, uint32_t keep_tau = 0u) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq) return;
   total[i] = 0ull;                      // per-query match count and shared threshold start from zero (no separate memset launch)
-  tau[(size_t)i * BM_TAU_STRIDE] = 0u;
+  if (!keep_tau) tau[(size_t)i * BM_TAU_STRIDE] = 0u;  // (keep_tau: an experiment -- the same batch again with the thresholds it ended on)
   const ss_bm25_query Q = q[i];
   bm_vquery& V = vq[i];  // written in place: a local copy indexed at run time would live in scratch
   const uint32_t np = Q.n_terms, n_not = bm_q_nnot(Q.op);
@@ -384,7 +384,8 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
                          (std::min(np_max / F, 255u) << 16);
   bm_expand_kernel<<<(nq + 127) / 128, 128, 0, st>>>(d_q, (bm_vquery*)W.d_vq, nq, s->bm_n_fields,
                                                     (const unsigned long long*)s->d_term_base, s->d_boost, total, tau, claim,
-                                                    s->bm_n_terms, s->d_probe_row, s->bm_merged ? 1u : 0u);
+                                                    s->bm_n_terms, s->d_probe_row, s->bm_merged ? 1u : 0u,
+                                                    getenv("SS_BM25_KEEP_TAU") && atoi(getenv("SS_BM25_KEEP_TAU")) ? 1u : 0u);
 
   BmParams p;
   p.post = s->d_post;

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstring>
 #include <iterator>
+#include <memory>
 #include <new>
 #include <unordered_map>
 
@@ -137,10 +138,18 @@ static void free_vec(ss_shard* s) {
   if (s->ann_ev) (void)hipEventDestroy(s->ann_ev);
   s->ann_ev = nullptr; s->ann_ev_set = false; s->ann_ev_stream = nullptr;
 }
+static void free_raw_levels(ss_shard* s) {
+  for (ss_raw_level& L : s->raw)
+    for (void* p : {(void*)L.d_off, (void*)L.d_doc, (void*)L.d_tf}) if (p) (void)hipFree(p);
+  s->raw.clear();
+  s->h_doclen.clear();
+}
 static void free_bm25(ss_shard* s) {
+  free_raw_levels(s);
   void* ptrs[] = {s->d_post, s->d_term_base, s->d_sub_off, s->d_comp, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_umax, s->d_submax, s->d_boost, s->d_pos, s->d_pos32, s->d_pos_off, s->d_pos_base,
                   s->d_doclen, s->d_sp_base, s->d_sp_post};
-  for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (void* p : ptrs) if (p) { s->blocks.drop(p); (void)hipFree(p); }
+  s->blocks.clear_idle();
   s->d_doclen = nullptr; s->d_sp_base = nullptr; s->d_sp_post = nullptr; s->sp_n = 0; s->h_sp_base.clear();
   s->d_post = nullptr; s->d_term_base = nullptr; s->d_sub_off = nullptr; s->d_comp = nullptr;
   s->probe_pool_begin = 0; s->probe_pool_rows = 0; s->pool_list.clear(); s->pool_tick.clear();
@@ -401,6 +410,124 @@ int ss_bm25_synth(ss_shard* s, uint64_t seed, uint64_t n_docs, uint32_t n_terms,
   (void)hipFree(d_tab);
   if (rc) free_bm25(s);
   return rc;
+}
+
+// Incremental commit.  The reference commits one 65 536-doc level at a time and rebuilds its in-RAM structures for it (commit.rs:142-148
+// commit -> warmup, 264-369 the level writer; index.rs:3796); a BM25 weight depends on avgdl, which every commit moves (commit.rs:318-325
+// refills bm25_component_cache), so no posting of the image survives a commit unchanged.  Here the decoded postings of every level stay
+// in HBM as they arrived (6 bytes per posting) and the image is rebuilt from them ON THE DEVICE (ssi_bm25_rebuild_from_raw: count,
+// scan, fill -- the raw postings read once, the image written once): a commit costs the level's H2D + a few milliseconds per GB of
+// image, not a host pass over the shard.  The new image is built beside the old one; searches keep running on the old image until the
+// swap, which waits for the searches in flight and releases the old arrays.
+int ss_bm25_append_level(ss_shard* s, uint32_t level, uint32_t n_level_docs, const uint8_t* level_doclen, uint32_t n_terms, const uint64_t* offs,
+                         const uint32_t* docs, const uint16_t* tfs) {
+  if (!s || !level_doclen || !offs || n_terms == 0 || n_level_docs == 0 || n_level_docs > 65536u) return SS_EINVAL;
+  if (offs[n_terms] && (!docs || !tfs)) return SS_EINVAL;
+  const auto t_begin = std::chrono::steady_clock::now();
+  SS_HIP(hipSetDevice(s->device));
+  std::vector<ss_raw_level> levels;
+  std::vector<uint8_t> doclen;
+  uint32_t nt_old = 0;
+  {
+    std::lock_guard<std::mutex> g(s->mu);
+    if (s->d_post && s->raw.empty()) return SS_ESTATE;       // an image that was not built level by level
+    if (level > s->raw.size() || level + 1 < s->raw.size()) return SS_EINVAL;  // append the next level, or replace the last one (a re-commit)
+    if (level >= 1 && s->raw[level - 1].n_docs != 65536u) return SS_EINVAL;    // only the last level may be partial
+    if ((uint64_t)level * 65536u + n_level_docs > 0xFFFFFFFFull) return SS_ENOTSUP;
+    nt_old = s->raw.empty() ? 0u : s->bm_n_terms;
+    if (n_terms < nt_old) return SS_EINVAL;                    // the vocabulary only grows; new terms get the next ids
+    levels.assign(s->raw.begin(), s->raw.begin() + level);
+    doclen.assign(s->h_doclen.begin(), s->h_doclen.begin() + (size_t)level * 65536u);
+  }
+  // validation: docs of a term ascending and inside the level
+  const uint64_t d_lo = (uint64_t)level * 65536u, d_hi = d_lo + n_level_docs;
+  for (uint32_t t = 0; t < n_terms; t++) {
+    if (offs[t + 1] < offs[t]) return SS_EINVAL;
+    for (uint64_t j = offs[t]; j < offs[t + 1]; j++)
+      if (docs[j] < d_lo || docs[j] >= d_hi || tfs[j] == 0 || (j > offs[t] && docs[j] <= docs[j - 1])) return SS_EINVAL;
+  }
+  ss_raw_level L;
+  L.n_docs = n_level_docs; L.n_terms = n_terms; L.n_post = offs[n_terms] - offs[0];
+  for (uint32_t d = 0; d < n_level_docs; d++) L.psum += ss_byte4_to_int(level_doclen[d]);
+  hipStream_t bst = nullptr;
+  std::unique_ptr<ss_shard> img(new ss_shard);
+  auto fail = [&](int rc) {
+    for (void* p : {(void*)L.d_off, (void*)L.d_doc, (void*)L.d_tf}) if (p) (void)hipFree(p);
+    void* ip[] = {img->d_post, img->d_term_base, img->d_sub_off, img->d_comp, img->d_probe, img->d_probe_z, img->d_probe_row, img->d_umax, img->d_submax, img->d_doclen};
+    for (void* p : ip) if (p && !s->blocks.release(p)) (void)hipFree(p);
+    if (bst) (void)hipStreamDestroy(bst);
+    return rc;
+  };
+#define SS_HIP_F(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? SS_ENOMEM : SS_EDEVICE); } while (0)
+  SS_HIP_F(hipStreamCreateWithFlags(&bst, hipStreamNonBlocking));
+  std::vector<uint64_t> rel((size_t)n_terms + 1);
+  for (uint32_t t = 0; t <= n_terms; t++) rel[t] = offs[t] - offs[0];
+  SS_HIP_F(hipMalloc(&L.d_off, rel.size() * sizeof(uint64_t)));
+  SS_HIP_F(hipMalloc(&L.d_doc, std::max<uint64_t>(L.n_post, 1) * sizeof(uint32_t)));
+  SS_HIP_F(hipMalloc(&L.d_tf, std::max<uint64_t>(L.n_post, 1) * sizeof(uint16_t)));
+  SS_HIP_F(hipMemcpyAsync(L.d_off, rel.data(), rel.size() * sizeof(uint64_t), hipMemcpyHostToDevice, bst));
+  if (L.n_post) {
+    SS_HIP_F(hipMemcpyAsync(L.d_doc, docs + offs[0], L.n_post * sizeof(uint32_t), hipMemcpyHostToDevice, bst));
+    SS_HIP_F(hipMemcpyAsync(L.d_tf, tfs + offs[0], L.n_post * sizeof(uint16_t), hipMemcpyHostToDevice, bst));
+  }
+  SS_HIP_F(hipStreamSynchronize(bst));  // (rel dies with this frame; the caller's arrays are free again)
+  levels.push_back(L);
+  doclen.insert(doclen.end(), level_doclen, level_doclen + n_level_docs);
+  const auto t_build = std::chrono::steady_clock::now();
+  int rc = ssi_bm25_rebuild_from_raw(s, levels, n_terms, doclen, img.get(), bst);
+  if (rc) return fail(rc);
+  const double rebuild_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count();
+  {  // the swap: searches in flight finish on the old image, whose arrays are then released
+    std::lock_guard<std::mutex> g(s->mu);
+    if (level > s->raw.size() || level + 1 < s->raw.size()) return fail(SS_ESTATE);  // another commit got in between (the caller's write lock forbids it)
+    (void)hipStreamSynchronize(s->stream);
+    for (auto& kv : s->bm_ws) (void)hipStreamSynchronize(kv.first);
+    ss_raw_level replaced;
+    const bool replace = level < s->raw.size();
+    if (replace) replaced = s->raw[level];
+    std::vector<ss_raw_level> keep(s->raw.begin(), s->raw.begin() + level);
+    s->raw.clear();  // (free_bm25 must not release the levels that stay)
+    {  // the old image's arrays go back to the block pool: the next commit builds into them
+      void** op[] = {(void**)&s->d_post, (void**)&s->d_term_base, (void**)&s->d_sub_off, (void**)&s->d_comp, (void**)&s->d_probe, (void**)&s->d_probe_z,
+                     (void**)&s->d_probe_row, (void**)&s->d_umax, (void**)&s->d_submax, (void**)&s->d_doclen};
+      s->blocks.gen++;
+      for (void** pp : op) if (*pp && s->blocks.release(*pp)) *pp = nullptr;
+      std::vector<ss_block_pool::Idle> idle;
+      idle.swap(s->blocks.idle);   // (free_bm25 clears the idle list: these stay)
+      free_bm25(s);
+      s->blocks.idle.swap(idle);
+      s->blocks.trim(3);
+    }
+    if (replace) for (void* p : {(void*)replaced.d_off, (void*)replaced.d_doc, (void*)replaced.d_tf}) if (p) (void)hipFree(p);
+    keep.push_back(L);
+    s->raw.swap(keep);
+    s->h_doclen.swap(doclen);
+    s->bm_n_docs = img->bm_n_docs; s->bm_n_terms = img->bm_n_terms; s->bm_n_sub = img->bm_n_sub; s->bm_n_fields = 1; s->bm_merged = false;
+    s->bm_n_post = img->bm_n_post; s->bm_n_post_pad = img->bm_n_post_pad; s->bm_avgdl = img->bm_avgdl; s->bm_partmax = img->bm_partmax;
+    s->d_post = img->d_post; s->d_term_base = img->d_term_base; s->d_sub_off = img->d_sub_off; s->d_comp = img->d_comp;
+    s->d_probe = img->d_probe; s->d_probe_z = img->d_probe_z; s->d_probe_row = img->d_probe_row; s->d_umax = img->d_umax; s->d_submax = img->d_submax;
+    s->d_doclen = img->d_doclen;
+    s->h_df.swap(img->h_df); s->h_probe_row.swap(img->h_probe_row); s->bm_probe_rows = img->bm_probe_rows;
+    s->probe_pool_begin = img->probe_pool_begin; s->probe_pool_rows = img->probe_pool_rows; s->pool_list.swap(img->pool_list); s->pool_tick.swap(img->pool_tick);
+    s->pool_clock = 0;
+    s->raw_last_rebuild_ms = rebuild_ms;
+    s->raw_last_append_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  }
+#undef SS_HIP_F
+  (void)hipStreamDestroy(bst);
+  return SS_OK;
+}
+
+int ss_bm25_incremental_info(ss_shard* s, uint32_t* n_levels, uint64_t* raw_bytes, double* last_append_ms, double* last_rebuild_ms) {
+  if (!s) return SS_EINVAL;
+  std::lock_guard<std::mutex> g(s->mu);
+  uint64_t b = 0;
+  for (const ss_raw_level& L : s->raw) b += ((uint64_t)L.n_terms + 1) * 8u + L.n_post * 6u;
+  if (n_levels) *n_levels = (uint32_t)s->raw.size();
+  if (raw_bytes) *raw_bytes = b;
+  if (last_append_ms) *last_append_ms = s->raw_last_append_ms;
+  if (last_rebuild_ms) *last_rebuild_ms = s->raw_last_rebuild_ms;
+  return SS_OK;
 }
 
 // Tombstones: delete_hashset of the shard (index.rs:1594; filled from delete.bin, index.rs:3798-3809, and by

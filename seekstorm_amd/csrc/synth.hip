@@ -5,7 +5,9 @@
 #include "ss_threads.h"
 #include "bm25_build.h"
 
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 
 typedef unsigned long long u64;
@@ -107,11 +109,18 @@ static inline uint32_t bm_code_of(uint32_t tf, float comp_len, bool flagged) {
   return c;
 }
 
+// an image array: from the owner's block pool when the image is an incremental one (ss_block_pool), else a plain allocation
+template <class T>
+static hipError_t img_malloc(ss_shard* s, T** p, size_t bytes) {
+  if (!s->pool) return hipMalloc(p, bytes);
+  const int rc = s->pool->alloc((void**)p, bytes);
+  return rc == 0 ? hipSuccess : rc == -2 ? hipErrorOutOfMemory : hipErrorUnknown;
+}
 // segments are padded to 16 bytes; the image ends with 1 KB of NULL postings so that a whole-wave load of the last
 // unit never leaves the allocation
 static int alloc_post(ss_shard* s, u64 n_units) {
   s->bm_n_post_pad = n_units * 4;
-  SS_HIP(hipMalloc(&s->d_post, (s->bm_n_post_pad + 256) * sizeof(uint32_t)));
+  SS_HIP(img_malloc(s, &s->d_post, (s->bm_n_post_pad + 256) * sizeof(uint32_t)));
   SS_HIP(hipMemset(s->d_post + s->bm_n_post_pad, 0, 256 * sizeof(uint32_t)));
   return SS_OK;
 }
@@ -124,9 +133,9 @@ static int alloc_probe(ss_shard* s, hipStream_t st) {
   // null-stream hipMemset is not ordered against the generator kernels that follow and could wipe what they wrote.
   const uint32_t nt = s->bm_n_terms;
   const size_t row_elems = (size_t)s->bm_n_sub * BM_GROUPS;
-  SS_HIP(hipMalloc(&s->d_umax, ((size_t)nt + 1) * sizeof(float)));
+  SS_HIP(img_malloc(s, &s->d_umax, ((size_t)nt + 1) * sizeof(float)));
   SS_HIP(hipMemsetAsync(s->d_umax, 0, ((size_t)nt + 1) * sizeof(float), st));
-  SS_HIP(hipMalloc(&s->d_submax, ((size_t)nt + 1) * s->bm_n_sub * sizeof(float)));
+  SS_HIP(img_malloc(s, &s->d_submax, ((size_t)nt + 1) * s->bm_n_sub * sizeof(float)));
   SS_HIP(hipMemsetAsync(s->d_submax, 0, ((size_t)nt + 1) * s->bm_n_sub * sizeof(float), st));
   size_t free_b = 0, total_b = 0;
   SS_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -154,9 +163,9 @@ static int alloc_probe(ss_shard* s, hipStream_t st) {
   for (uint32_t t = 0; t < nt; t++)  // ... which also serves every empty list
     if (s->h_probe_row[t] == BM_NO_PROBE_ROW && s->h_df[t] == 0) s->h_probe_row[t] = rows;
   s->bm_probe_rows = rows;
-  SS_HIP(hipMalloc(&s->d_probe, ((size_t)rows + 1) * row_elems * sizeof(uint2)));
-  SS_HIP(hipMalloc(&s->d_probe_z, ((size_t)rows + 1) * row_elems * sizeof(uint32_t)));
-  SS_HIP(hipMalloc(&s->d_probe_row, ((size_t)nt + 1) * sizeof(uint32_t)));
+  SS_HIP(img_malloc(s, &s->d_probe, ((size_t)rows + 1) * row_elems * sizeof(uint2)));
+  SS_HIP(img_malloc(s, &s->d_probe_z, ((size_t)rows + 1) * row_elems * sizeof(uint32_t)));
+  SS_HIP(img_malloc(s, &s->d_probe_row, ((size_t)nt + 1) * sizeof(uint32_t)));
   SS_HIP(hipMemsetAsync(s->d_probe + (size_t)rows * row_elems, 0, row_elems * sizeof(uint2), st));
   SS_HIP(hipMemsetAsync(s->d_probe_z + (size_t)rows * row_elems, 0, row_elems * sizeof(uint32_t), st));
   SS_HIP(hipMemcpyAsync(s->d_probe_row, s->h_probe_row.data(), ((size_t)nt + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
@@ -368,6 +377,205 @@ int ssi_bm25_build_from_host_merged(ss_shard* s, const uint8_t* doclen, const ui
   return SS_OK;
 }
 
+// Are block maxima worth a pass per search?  Only where they vary over the doc ids: for the 64 longest lists, the mean over 32 equal
+// partitions of (largest weight inside the partition) / (largest weight of the list) -- ~1 on a corpus whose weights are spread evenly,
+// clearly less where docs are ordered by source / time / length.  The host builder applies the rule to its own arrays; the device
+// builders (synthetic corpora, incremental images) fetch what it needs: umax and the 64 rows of submax.
+static int bm_decide_partmax_dev(ss_shard* img) {
+  const uint32_t nt = img->bm_n_terms, ns = img->bm_n_sub;
+  std::vector<uint32_t> order(nt);
+  for (uint32_t t = 0; t < nt; t++) order[t] = t;
+  const uint32_t top = std::min<uint32_t>(nt, 64);
+  std::partial_sort(order.begin(), order.begin() + top, order.end(), [&](uint32_t a, uint32_t b) { return img->h_df[a] > img->h_df[b]; });
+  std::vector<float> um(nt), row(ns);
+  SS_HIP(hipMemcpy(um.data(), img->d_umax, (size_t)nt * sizeof(float), hipMemcpyDeviceToHost));
+  double worst = 1.0;
+  const uint32_t parts = std::min<uint32_t>(32, ns);
+  for (uint32_t i = 0; i < top; i++) {
+    const uint32_t t = order[i];
+    if (um[t] <= 0.f || img->h_df[t] < 64) continue;
+    SS_HIP(hipMemcpy(row.data(), img->d_submax + (size_t)t * ns, (size_t)ns * sizeof(float), hipMemcpyDeviceToHost));
+    double acc = 0.0;
+    for (uint32_t pi = 0; pi < parts; pi++) {
+      float m = 0.f;
+      for (uint32_t sb = (uint32_t)((u64)ns * pi / parts); sb < (uint32_t)((u64)ns * (pi + 1) / parts); sb++) m = std::max(m, row[sb]);
+      acc += m / um[t];
+    }
+    worst = std::min(worst, acc / parts);
+  }
+  img->bm_partmax = worst < 0.9;
+  return SS_OK;
+}
+
+// ---------------------------------------------------------------- image from the raw levels of an incremental shard, ON THE DEVICE
+// What ssi_bm25_build_from_host does on the host, as three launches over (term, sub-block) pairs -- count, scan, fill -- so that a
+// commit costs a rebuild at HBM speed instead of a host pass + PCIe: the raw postings are read once, the image written once.
+__global__ void lex_scan_rows_kernel(uint32_t* __restrict__ sub, uint32_t n_sub, u64* __restrict__ term_tot);
+__global__ void lex_scan_terms_kernel(const u64* __restrict__ tot, u64* __restrict__ base, uint32_t n_terms);
+struct RawLevelDev { const unsigned long long* off; const uint32_t* doc; const uint16_t* tf; uint32_t n_terms, pad; };
+__device__ __forceinline__ void raw_segment(const RawLevelDev* __restrict__ levels, uint32_t t, uint32_t sb, u64* lo_out, u64* hi_out,
+                                            const uint32_t** doc_out, const uint16_t** tf_out) {
+  const RawLevelDev L = levels[sb >> (16 - BM_SUB_LOG2)];  // a level = 65 536 docs
+  *doc_out = L.doc; *tf_out = L.tf;
+  if (t >= L.n_terms) { *lo_out = 0; *hi_out = 0; return; }
+  const u64 a = L.off[t], b = L.off[t + 1];
+  const uint32_t d0 = sb << BM_SUB_LOG2, d1 = d0 + (uint32_t)BM_SUB;
+  u64 lo = a, hi = b;
+  while (lo < hi) { const u64 m = (lo + hi) >> 1; if (L.doc[m] < d0) lo = m + 1; else hi = m; }
+  const u64 first = lo;
+  hi = b;
+  while (lo < hi) { const u64 m = (lo + hi) >> 1; if (L.doc[m] < d1) lo = m + 1; else hi = m; }
+  *lo_out = first; *hi_out = lo;
+}
+// one thread per (term, sub-block): the segment's size in 16-byte units (shifted by one for the exclusive scan) and the term's df
+__global__ void raw_count_kernel(const RawLevelDev* __restrict__ levels, uint32_t n_terms, uint32_t n_sub, uint32_t* __restrict__ sub,
+                                 u64* __restrict__ df) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (u64)n_terms * n_sub) return;
+  const uint32_t t = (uint32_t)(i / n_sub), sb = (uint32_t)(i % n_sub);
+  u64 lo, hi;
+  const uint32_t* dp; const uint16_t* tp;
+  raw_segment(levels, t, sb, &lo, &hi, &dp, &tp);
+  const uint32_t n = (uint32_t)(hi - lo);
+  sub[(size_t)t * (n_sub + 1) + sb + 1] = (n + 3u) >> 2;
+  if (n) atomicAdd(&df[t], (u64)n);
+}
+// one wave per (term, sub-block): packs the segment's postings (weight code from tf and the doc's length byte, computed with the
+// host builder's operations: t * (K + 1) / (t + comp), every step rounded to f32), writes the probe row's 64-doc bit records and
+// ranks, the segment's and the list's largest weight, the NULL padding
+__global__ void raw_fill_kernel(const RawLevelDev* __restrict__ levels, uint32_t n_terms, uint32_t n_sub, const uint8_t* __restrict__ doclen,
+                                const float* __restrict__ comp, float k1, const uint32_t* __restrict__ sub, const u64* __restrict__ term_base,
+                                uint32_t* __restrict__ post, uint2* __restrict__ probe, uint32_t* __restrict__ probe_z,
+                                const uint32_t* __restrict__ probe_row, uint32_t* __restrict__ umax_bits, float* __restrict__ submax,
+                                const uint8_t* __restrict__ flagged) {
+  __shared__ unsigned long long masks[4][BM_SUB / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const u64 gw = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (gw >= (u64)n_terms * n_sub) return;
+  const uint32_t t = (uint32_t)(gw / n_sub), sb = (uint32_t)(gw % n_sub);
+  u64 lo, hi;
+  const uint32_t* dp; const uint16_t* tp;
+  raw_segment(levels, t, sb, &lo, &hi, &dp, &tp);
+  const uint32_t seg0 = sub[(size_t)t * (n_sub + 1) + sb] * 4u;
+  const u64 base = term_base[t] * 4ull + seg0;
+  const bool flg = flagged[t] != 0;
+  const bool have_row = probe && probe_row[t] != BM_NO_PROBE_ROW;
+  masks[w][lane] = 0ull;
+  __builtin_amdgcn_wave_barrier();
+  float wmax = 0.f;
+  for (u64 i = lo + (u64)lane; i < hi; i += 64u) {
+    const uint32_t d = dp[i], tf = tp[i];
+    const float tt = (float)tf;
+    const float wgt = __fdiv_rn(ss_fmul(tt, k1), ss_fadd(tt, comp[doclen[d]]));  // bm_weight_exact
+    uint32_t code = bm_wcode(wgt);
+    if (flg) code = (code & ~1u) | (tf < 10u ? 1u : 0u);
+    const uint32_t din = d & (uint32_t)(BM_SUB - 1);
+    post[base + (i - lo)] = bm_pack(din, code);
+    wmax = fmaxf(wmax, bm_wdecode(code));
+    if (have_row) atomicOr(&masks[w][din >> 6], 1ull << (din & 63u));
+  }
+  const uint32_t n = (uint32_t)(hi - lo);
+  if ((uint32_t)lane < ((4u - (n & 3u)) & 3u)) post[base + n + lane] = 0u;  // NULL padding
+  for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+  if (lane == 0) {
+    submax[(size_t)t * n_sub + sb] = wmax;
+    if (wmax > 0.f) atomicMax(&umax_bits[t], __float_as_uint(wmax));
+  }
+  if (have_row) {
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long m = masks[w][lane];
+    uint32_t run = (uint32_t)__popcll(m);
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(run, o); if (lane >= o) run += v; }
+    run -= (uint32_t)__popcll(m);
+    const size_t gi = ((size_t)probe_row[t] * n_sub + sb) * (BM_SUB / 64) + (uint32_t)lane;
+    probe[gi] = make_uint2((uint32_t)m, (uint32_t)(m >> 32));
+    probe_z[gi] = seg0 + run;
+  }
+}
+
+int ssi_bm25_rebuild_from_raw(const ss_shard* s, const std::vector<ss_raw_level>& levels, uint32_t n_terms, const std::vector<uint8_t>& doclen,
+                              ss_shard* img, hipStream_t st) {
+  u64 nd = 0, psum = 0, npost = 0;
+  for (const ss_raw_level& L : levels) { nd += L.n_docs; psum += L.psum; npost += L.n_post; }
+  if (nd == 0 || n_terms == 0 || doclen.size() != nd) return SS_EINVAL;
+  const uint32_t nt = n_terms, ns = (uint32_t)((nd + BM_SUB - 1) >> BM_SUB_LOG2);
+  img->device = s->device;
+  img->probe_budget = s->probe_budget;
+  img->pool = const_cast<ss_block_pool*>(&s->blocks);  // (the caller serialises commits: nobody else touches the pool meanwhile)
+  img->bm_n_docs = nd; img->bm_n_terms = nt; img->bm_n_sub = ns; img->bm_n_fields = 1; img->bm_merged = false;
+  img->bm_n_post = npost;
+  img->bm_avgdl = (float)psum / (float)nd;  // commit.rs:318-319
+  static const bool trace = [] { const char* e = getenv("SS_APPEND_TRACE"); return e && atoi(e) != 0; }();
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto t0 = now();
+  std::vector<RawLevelDev> lv(levels.size());
+  for (size_t i = 0; i < levels.size(); i++) lv[i] = RawLevelDev{(const unsigned long long*)levels[i].d_off, levels[i].d_doc, levels[i].d_tf, levels[i].n_terms, 0u};
+  RawLevelDev* d_lv = nullptr;
+  u64 *d_tot = nullptr, *d_df = nullptr;
+  uint8_t* d_flg = nullptr;
+  auto cleanup = [&]() { for (void* p : {(void*)d_lv, (void*)d_tot, (void*)d_df, (void*)d_flg}) if (p) (void)hipFree(p); };
+#define SS_HIP_C(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return e_ == hipErrorOutOfMemory ? SS_ENOMEM : SS_EDEVICE; } } while (0)
+  SS_HIP_C(hipMalloc(&d_lv, lv.size() * sizeof(RawLevelDev)));
+  SS_HIP_C(hipMemcpyAsync(d_lv, lv.data(), lv.size() * sizeof(RawLevelDev), hipMemcpyHostToDevice, st));
+  SS_HIP_C(hipMalloc(&d_tot, (size_t)nt * sizeof(u64)));
+  SS_HIP_C(hipMalloc(&d_df, (size_t)nt * sizeof(u64)));
+  SS_HIP_C(hipMemsetAsync(d_df, 0, (size_t)nt * sizeof(u64), st));
+  SS_HIP_C(img_malloc(img, &img->d_doclen, nd));
+  SS_HIP_C(hipMemcpyAsync(img->d_doclen, doclen.data(), nd, hipMemcpyHostToDevice, st));
+  const size_t rows = (size_t)nt * (ns + 1);
+  SS_HIP_C(img_malloc(img, &img->d_sub_off, (rows + ns + 1) * sizeof(uint32_t)));  // + one all-zero row (absent terms)
+  SS_HIP_C(hipMemsetAsync(img->d_sub_off + rows, 0, ((size_t)ns + 1) * sizeof(uint32_t), st));
+  SS_HIP_C(img_malloc(img, &img->d_term_base, ((size_t)nt + 1) * sizeof(u64)));
+  SS_HIP_C(img_malloc(img, &img->d_comp, SS_COMP_N * sizeof(float)));
+  float comp[SS_COMP_N];
+  fill_comp(img->bm_avgdl, comp);
+  SS_HIP_C(hipMemcpyAsync(img->d_comp, comp, sizeof(comp), hipMemcpyHostToDevice, st));
+  const u64 pairs = (u64)nt * ns;
+  const auto t1 = now();
+  raw_count_kernel<<<(uint32_t)((pairs + 255) / 256), 256, 0, st>>>(d_lv, nt, ns, img->d_sub_off, d_df);
+  lex_scan_rows_kernel<<<nt, 1024, 0, st>>>(img->d_sub_off, ns, d_tot);
+  lex_scan_terms_kernel<<<1, 64, 0, st>>>(d_tot, (u64*)img->d_term_base, nt);
+  SS_HIP_C(hipStreamSynchronize(st));
+  std::vector<u64> tot(nt);
+  img->h_df.resize(nt);
+  SS_HIP_C(hipMemcpy(tot.data(), d_tot, (size_t)nt * sizeof(u64), hipMemcpyDeviceToHost));
+  SS_HIP_C(hipMemcpy(img->h_df.data(), d_df, (size_t)nt * sizeof(u64), hipMemcpyDeviceToHost));
+  u64 units = 0;
+  for (uint32_t t = 0; t < nt; t++) {
+    if (tot[t] >= (1ull << 28)) { cleanup(); return SS_ENOTSUP; }  // a term's segment offsets must stay below 4 GB
+    units += tot[t];
+  }
+  const auto t2 = now();
+  int rc = alloc_post(img, units);
+  if (rc) { cleanup(); return rc; }
+  rc = alloc_probe(img, st);
+  if (rc) { cleanup(); return rc; }
+  const auto t3 = now();
+  std::vector<uint8_t> flg(nt);
+  for (uint32_t t = 0; t < nt; t++) flg[t] = bm_list_flagged(img, img->h_df[t]) ? 1 : 0;
+  SS_HIP_C(hipMalloc(&d_flg, nt));
+  SS_HIP_C(hipMemcpyAsync(d_flg, flg.data(), nt, hipMemcpyHostToDevice, st));
+  const volatile float k1 = 1.2f + 1.0f;  // (K + 1) as bm_weight_exact forms it
+  raw_fill_kernel<<<(uint32_t)((pairs + 3) / 4), 256, 0, st>>>(d_lv, nt, ns, img->d_doclen, img->d_comp, k1, img->d_sub_off,
+                                                              (const u64*)img->d_term_base, img->d_post, img->d_probe, img->d_probe_z,
+                                                              img->d_probe_row, (uint32_t*)img->d_umax, img->d_submax, d_flg);
+  SS_HIP_C(hipGetLastError());
+  SS_HIP_C(hipStreamSynchronize(st));
+  const auto t4 = now();
+  // block maxima worth a pass per search?  (the host builder's rule, on the 64 longest lists)
+  {
+    const int rcp = bm_decide_partmax_dev(img);
+    if (rcp) { cleanup(); return rcp; }
+  }
+  if (trace)
+    fprintf(stderr, "[append] docs %llu postings %llu: setup+copies %.2f ms, count+scan %.2f, alloc post+probe %.2f, fill %.2f, maxima rule %.2f\n",
+            (unsigned long long)nd, (unsigned long long)npost, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, now()));
+#undef SS_HIP_C
+  cleanup();
+  return SS_OK;
+}
+
 // ---------------------------------------------------------------- sparse tier: append lists of rare terms to the image
 // (bm25_sparse.hip).  The weights are computed here, on the host, by the same routine and component cache as every dense
 // posting's (bm_code_of): the length bytes come back from the device once per call.
@@ -548,6 +756,18 @@ __device__ __forceinline__ uint32_t lex_geom06(uint32_t u) {
   return j;
 }
 
+// CLUSTERED corpora (seeds with bit 63 set; oracle so_lex_cluster_thresh, bit for bit): a term's density varies with the doc's cluster
+// -- runs of 1024 (odd terms) or 8192 (even terms) consecutive GLOBAL doc ids: 70 % of a term's clusters hold it 8 times more
+// rarely than its threshold says, 25 % as the threshold says, 5 % four times more densely.  Doc ids then come in bursts and the
+// per-block maxima are uneven, as in a corpus ordered by source or time.
+__device__ __forceinline__ uint32_t lex_cluster_thresh(u64 seed, uint32_t t, u64 d, uint32_t th) {
+  const u64 c = (t & 1u) ? (d >> 10) : (d >> 13);
+  const uint32_t r = (uint32_t)(ss_h(seed ^ 0xC1ull, (u64)t + 1, c) >> 40) & 0xFFFFu;
+  const u64 m = r < 45875u ? 1u : r < 62259u ? 8u : 32u;
+  const u64 v = ((u64)th * m) >> 3;
+  return v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v;
+}
+
 // one wave per (term, sub-block): count / fill postings in ascending doc order.
 // !FILL: sub[t][sb+1] = padded units (for the exclusive scan), cnt[t] += postings.  FILL: postings + zero padding.
 template <bool FILL>
@@ -572,7 +792,7 @@ __global__ void lex_gen_kernel(u64 seed, u64 n_docs, uint32_t n_terms, uint32_t 
   for (int i = 0; i < BM_SUB / 64; i++) {
     u64 d = d0 + (u64)i * 64 + lane;
     u64 hv = ss_h(seed, (u64)t + 1, d * gs + go);
-    bool present = d < n_docs && (uint32_t)(hv >> 32) < th;
+    bool present = d < n_docs && (uint32_t)(hv >> 32) < ((seed >> 63) ? lex_cluster_thresh(seed, t, d * gs + go, th) : th);
     u64 m = __ballot(present);
     if (FILL && present) {
       uint32_t pos = run + __popcll(m & ((1ull << lane) - 1ull));
@@ -701,6 +921,8 @@ int ssi_bm25_synth(ss_shard* s, uint64_t seed, const uint32_t* d_thresh, const u
   SS_HIP(hipStreamSynchronize(st));
   (void)hipFree(d_wtab);
   (void)hipFree(d_flg);
+  rc = bm_decide_partmax_dev(s);  // (uniform corpora: no; clustered ones -- seed bit 63 -- : yes)
+  if (rc) return rc;
   s->d_doclen = d_doclen;  // kept: ss_bm25_append_sparse weighs its postings with the docs' length bytes
   (void)hipFree(d_psum);
   (void)hipFree(d_tot);

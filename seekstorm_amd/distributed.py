@@ -239,6 +239,13 @@ class ShardComm:
                                                  src.ctypes.data, cnt.ctypes.data, tot.ctypes.data), "ss_hybrid_search_sharded")
         return doc, score, src, cnt, tot
 
+    def info(self):
+        """(rank, ranks the communicator really spans -- ncclCommCount --, device) as the library sees them (ss_comm_info)"""
+        import ctypes as C
+        r, n, d = C.c_int(), C.c_int(), C.c_int()
+        N.check(N.lib().ss_comm_info(self._h, C.byref(r), C.byref(n), C.byref(d)), "ss_comm_info")
+        return int(r.value), int(n.value), int(d.value)
+
     def profile(self, on=True):
         N.check(N.lib().ss_comm_profile(self._h, 1 if on else 0), "ss_comm_profile")
 

@@ -374,6 +374,25 @@ class Shard:
         self.lexical_field_count = 1
         self._df_cache.clear()
 
+    def append_level(self, level, level_doclen, term_offsets, doc_ids, tfs):
+        """one committed 65 536-doc level (commit.rs:142-148): its docs' length bytes and per term (shard-local doc id, tf); level =
+        levels committed so far (append) or the last one (re-commit of a partial level)"""
+        dl = np.ascontiguousarray(level_doclen, np.uint8)
+        off = np.ascontiguousarray(term_offsets, np.uint64)
+        d = np.ascontiguousarray(doc_ids, np.uint32)
+        t = np.ascontiguousarray(tfs, np.uint16)
+        N.check(N.lib().ss_bm25_append_level(self._h, int(level), len(dl), N.ptr(dl, N.u8p), len(off) - 1, N.ptr(off, N.u64p), N.ptr(d, N.u32p),
+                                             N.ptr(t, N.u16p)), "ss_bm25_append_level")
+        self.indexed_doc_count = int(level) * 65536 + len(dl)
+        self.lexical_field_count = 1
+        self._df_cache.clear()
+
+    def incremental_info(self):
+        """(levels, bytes of the raw postings kept for rebuilds, ms of the last append, of which the device rebuild)"""
+        nl, rb, a, b = C.c_uint32(), C.c_uint64(), C.c_double(), C.c_double()
+        N.check(N.lib().ss_bm25_incremental_info(self._h, C.byref(nl), C.byref(rb), C.byref(a), C.byref(b)), "ss_bm25_incremental_info")
+        return int(nl.value), int(rb.value), float(a.value), float(b.value)
+
     def upload_index_bin(self, ix: "IndexBin", boost=None, positions=False):
         """boost: schema boost per indexed field (several fields only; schema.json)
         positions: also decode every posting's positions from the file (phrase queries; SingleTerm keys)"""

@@ -171,3 +171,137 @@ def test_drop_in_rehearsal_on_a_million_doc_index_bin(S, O):
     assert r["queries"]["phrases_with_ngram_keys"] > 0 and r["queries"]["ors_naming_a_sparse_term"] > 0
     assert set(r["parity"]["queries"]) == {"and2", "or3", "phrase", "vector", "hybrid"}
     assert all(v["errors"] == 0 for v in r["concurrent_callers"].values())
+
+
+def _level_slices(n_docs, offs, docs, tfs, n_terms=None):
+    """CSR of a corpus -> per 65 536-doc level (doclen slice bounds, offs, docs, tfs) over the first n_terms terms"""
+    nt = len(offs) - 1 if n_terms is None else n_terms
+    out = []
+    for lv in range((n_docs + 65535) // 65536):
+        lo, hi = lv * 65536, min(n_docs, (lv + 1) * 65536)
+        lo_, do_, to_ = [0], [], []
+        for t in range(nt):
+            a, b = int(offs[t]), int(offs[t + 1])
+            i0, i1 = a + int(np.searchsorted(docs[a:b], lo)), a + int(np.searchsorted(docs[a:b], hi))
+            do_.append(docs[i0:i1]); to_.append(tfs[i0:i1]); lo_.append(lo_[-1] + (i1 - i0))
+        out.append((lo, hi, np.asarray(lo_, np.uint64), np.concatenate(do_) if do_ else np.zeros(0, np.uint32),
+                    np.concatenate(to_) if to_ else np.zeros(0, np.uint16)))
+    return out
+
+
+def test_append_level_by_level_equals_the_one_shot_upload(S, O):
+    """ss_bm25_append_level (commit.rs:142-148): the image after every commit answers exactly like a one-shot upload of the docs
+    committed so far -- ids, scores (==), counts, both strategies; the vocabulary grows on the way; the last, partial level is
+    re-committed with more docs; NOT terms / tombstones ride along; the device rebuild takes milliseconds"""
+    from seekstorm_amd import _native as N
+    n_docs = 300_000
+    dl = O.lex_doclen(n_docs)
+    offs, docs, tfs = O.lex_corpus(n_docs, VOC)
+    levels = _level_slices(n_docs, offs, docs, tfs)
+    inc, ref = S.Shard(0), S.Shard(0)
+    tl_or = [[10, 9, 8], [7, 3], [10], [9, 8, 7, 6], [5, 4, 3, 2, 1], [10, 2]]
+    tl_and = [[10, 9], [10, 9, 8], [8, 5]]
+
+    committed = []  # the levels as they were handed over: (offs, docs, tfs) -- the one-shot image holds exactly these postings
+
+    def same(n_now, nt_now, what):
+        so = np.zeros(nt_now + 1, np.uint64)
+        dd, tt = [], []
+        for t in range(nt_now):
+            for lo_, do_, to_ in committed:
+                if t < len(lo_) - 1:
+                    dd.append(do_[int(lo_[t]):int(lo_[t + 1])]); tt.append(to_[int(lo_[t]):int(lo_[t + 1])])
+            so[t + 1] = sum(len(x) for x in dd)
+        ref.upload_lexical(n_now, dl[:n_now], so, np.concatenate(dd), np.concatenate(tt))
+        ok_terms = lambda tl: [q for q in tl if max(q) < nt_now]
+        for qt, tls in ((S.QueryType.Union, ok_terms(tl_or)), (S.QueryType.Intersection, ok_terms(tl_and))):
+            if not tls:
+                continue
+            for strat in (N.BM25_AUTO, N.BM25_EXHAUSTIVE):
+                inc.set_strategy(strat); ref.set_strategy(strat)
+                for rt in (S.ResultType.TopkCount, S.ResultType.Topk):
+                    x = inc.search_lexical_batch(inc.make_queries(tls, qt), 10, rt)
+                    y = ref.search_lexical_batch(ref.make_queries(tls, qt), 10, rt)
+                    for u, v, name in zip(x, y, ("doc", "score", "count", "total")):
+                        assert np.array_equal(u, v), (what, qt, strat, rt, name)
+    try:
+        nt_first = 7  # the first two commits know 7 terms, the vocabulary then grows to 11
+        for lv, (lo, hi, lo_, do_, to_) in enumerate(levels):
+            nt_now = nt_first if lv < 2 else len(VOC)
+            if nt_now < len(VOC):
+                cut = int(lo_[nt_now])
+                lo_, do_, to_ = lo_[:nt_now + 1], do_[:cut], to_[:cut]
+            if lv == len(levels) - 1:  # the last level: first committed half full, then re-committed whole
+                half = lo + (hi - lo) // 2
+                keep = do_ < half
+                lo_h = np.zeros(len(lo_), np.uint64)
+                for t in range(len(lo_) - 1):
+                    lo_h[t + 1] = lo_h[t] + int(keep[int(lo_[t]):int(lo_[t + 1])].sum())
+                inc.append_level(lv, dl[lo:half], lo_h, do_[keep], to_[keep])
+                committed.append((lo_h, do_[keep], to_[keep]))
+                same(half, nt_now, ("partial", lv))
+                committed.pop()
+            inc.append_level(lv, dl[lo:hi], lo_, do_, to_)
+            committed.append((lo_, do_, to_))
+            nl, raw_b, ms_all, ms_dev = inc.incremental_info()
+            assert nl == lv + 1 and raw_b > 0 and 0 < ms_dev <= ms_all < 2000
+            same(hi, nt_now, ("level", lv))
+        # tombstones set before a commit survive it; NOT terms work on the rebuilt image
+        gone = list(range(5, n_docs, 211))
+        inc.set_deleted(gone); ref.set_deleted(gone)
+        lo, hi, lo_, do_, to_ = levels[-1]
+        inc.append_level(len(levels) - 1, dl[lo:hi], lo_, do_, to_)  # re-commit once more
+        q = ([[10, 9, 8], [9, 7]], S.QueryType.Union, [[7], [10]])
+        x = inc.search_lexical_batch(inc.make_queries(*q), 10)
+        y = ref.search_lexical_batch(ref.make_queries(*q), 10)
+        assert all(np.array_equal(u, v) for u, v in zip(x, y))
+        # what the ABI refuses: a gap, a shrinking vocabulary, docs outside the level, an image from another builder
+        with pytest.raises(S.SeekStormHipError):
+            inc.append_level(len(levels) + 1, dl[:10], np.zeros(len(VOC) + 1, np.uint64), np.zeros(0, np.uint32), np.zeros(0, np.uint16))
+        with pytest.raises(S.SeekStormHipError):
+            inc.append_level(len(levels) - 1, dl[lo:hi], lo_[:4], do_[:int(lo_[3])], to_[:int(lo_[3])])
+        with pytest.raises(S.SeekStormHipError):
+            inc.append_level(len(levels) - 1, dl[lo:hi], lo_, do_ - np.uint32(70000), to_)
+        with pytest.raises(S.SeekStormHipError):
+            ref.append_level(0, dl[:100], np.zeros(len(VOC) + 1, np.uint64), np.zeros(0, np.uint32), np.zeros(0, np.uint16))
+    finally:
+        inc.close()
+        ref.close()
+
+
+def test_clustered_generator_device_equals_oracle(S, O):
+    """seeds with bit 63 set: a term's density varies with the doc's cluster (device lex_cluster_thresh == oracle so_lex_cluster_thresh);
+    the corpus really is clustered (per-block posting counts differ many-fold), and the strategies agree on it (block maxima in use)"""
+    from seekstorm_amd import _native as N
+    n_docs, nt = 300_000, 16
+    th = O.term_thresholds(nt)
+    seed = O.LEX_SEED_CLUSTERED
+    a, b = S.Shard(0), S.Shard(0)
+    try:
+        a.synth_lexical(seed, n_docs, th, O.len_table())
+        dl = O.lex_doclen(n_docs, seed)
+        offs, docs, tfs = O.lex_corpus(n_docs, list(range(nt)), seed=seed, thresholds=th)
+        b.upload_lexical(n_docs, dl, offs, docs, tfs)
+        assert a.lexical_info() == b.lexical_info()
+        assert np.array_equal(a.posting_count(np.arange(nt)), b.posting_count(np.arange(nt)))
+        d15 = docs[int(offs[15]):int(offs[16])]
+        per_block = np.bincount(d15 >> 13, minlength=n_docs >> 13)[:n_docs >> 13]
+        assert per_block.max() > 8 * max(per_block.min(), 1)
+        osh = O.Shard(n_docs, dl, offs, docs, tfs)
+        tl = [[15, 14, 9], [13, 2], [15], [12, 11, 10, 3], [15, 14]]
+        for qt, oop in ((S.QueryType.Union, O.OP_OR), (S.QueryType.Intersection, O.OP_AND)):
+            res = {}
+            for strat in (N.BM25_AUTO, N.BM25_EXHAUSTIVE, N.BM25_PRUNED):
+                a.set_strategy(strat); b.set_strategy(strat)
+                ra = a.search_lexical_batch(a.make_queries(tl, qt), 10)
+                rb = b.search_lexical_batch(b.make_queries(tl, qt), 10)
+                assert all(np.array_equal(x, y) for x, y in zip(ra, rb))
+                res[strat] = ra
+            for strat in (N.BM25_EXHAUSTIVE, N.BM25_PRUNED):
+                assert all(np.array_equal(x, y) for x, y in zip(res[N.BM25_AUTO], res[strat]))
+            for i, q in enumerate(tl):
+                od, os_, otot = osh.search_exhaustive(q, oop, 10)
+                assert int(res[N.BM25_AUTO][3][i]) == otot
+                _check_topk(res[N.BM25_AUTO][0][i], res[N.BM25_AUTO][1][i], res[N.BM25_AUTO][2][i], od, os_)
+    finally:
+        a.close(); b.close()
