@@ -220,7 +220,8 @@ int ss_bm25_upload_index_bin(ss_shard* s, const ss_index_bin* ix);
  * (decode_positions_multiterm_singlefield, add_result.rs:2036-2197; stored as first position, then gap - 1): phrase queries
  * (SS_OP_PHRASE) then work on an image built from the file -- also on the reference's DEFAULT index (NgramFF | NgramFFF keys,
  * 22 / 23-byte key heads): an n-gram key's positions go to its first component term (see ss_index_bin_open).  SS_ENOTSUP for a
- * position beyond 65 535.  Several indexed fields: see ss_bm25_upload_index_bin_fields_positions (n-gram keys there: SS_ENOTSUP). */
+ * position beyond 65 535.  Several indexed fields: see ss_bm25_upload_index_bin_fields_positions (n-gram keys alike: the key's own
+ * field vector and positions behind its first component term). */
 int ss_bm25_upload_index_bin_positions(ss_shard* s, const ss_index_bin* ix);
 /* the same for an index with several indexed fields: position records carry a field vector per posting
  * (decode_positions_multiterm_multifield, add_result.rs:1485-2034; read_multifield_vec 2200-2293) -> ss_bm25_upload_fields.
@@ -244,6 +245,12 @@ int ss_ref_decode_block_fields_positions(const ss_ref_block* block, uint32_t n_f
 int ss_ref_decode_block_fields_ngram(const ss_ref_block* block, uint32_t n_fields, uint32_t longest_field_id, uint32_t n_components,
                                      uint32_t component, uint16_t* docs_out, uint32_t* first_out, uint8_t* field_out,
                                      uint16_t* tf_out);
+/* ... with the key's OWN positions (several indexed fields): the key's field vector and positions follow the components' vectors in the
+ * record.  Entries = those of component 0; npos_out [65536 * n_fields] = the key's positions behind every entry (0 where the key does not
+ * stand in that field), pos_out their concatenation.  SS_EINVAL with *n_pos_out = needed size when pos_cap is too small. */
+int ss_ref_decode_block_fields_ngram_positions(const ss_ref_block* block, uint32_t n_fields, uint32_t longest_field_id, uint32_t n_components,
+                                               uint16_t* docs_out, uint32_t* first_out, uint8_t* field_out, uint16_t* tf_out,
+                                               uint16_t* npos_out, uint16_t* pos_out, uint64_t pos_cap, uint64_t* n_pos_out);
 
 /* Device-side synthetic corpus (bench/test utility; generator = oracle so_lex_*):
  * posting (t,d) iff (h(seed,t+1,d)>>32) < thresh32[t]; bit-identical to ss_bm25_upload of the same corpus. */
@@ -356,7 +363,8 @@ typedef struct {
  * (ss_bm25_upload_fields_positions; add_result.rs:3248-3386): the phrase must stand inside ONE field, fields tried in ascending
  * order, only listed ones under SS_OP_FIELD_FILTER; the score sums all fields of the unique terms.  Host-pointer batches may mix
  * phrase queries with others (run as two sub-batches inside the library, answers back in the callers' order); a DEVICE-resident
- * batch (ss_bm25_search_dev) holds phrase queries only (ops_mask bit 4); NOT terms are not offered with phrases (SS_ENOTSUP). */
+ * batch (ss_bm25_search_dev) holds phrase queries only (ops_mask bit 4).  NOT terms work with phrases as with every query type
+ * (add_result.rs:3440-3497; ABI v4): a doc found in a NOT list is no match. */
 
 /* Batched BM25 search.  Outputs: out_doc/out_score [n_queries*k], out_count [n_queries] (= results.len()),
  * out_total [n_queries] (= result_count_total: exact match count for Count/TopkCount). */

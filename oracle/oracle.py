@@ -473,6 +473,40 @@ def search_fields_phrase(n_docs, doclen_fields, boost, offs, docs, fields, tfs, 
     return od[:n].copy(), os_[:n].copy(), tot.value
 
 
+def search_fields_phrase_items(n_docs, doclen_fields, boost, offs, docs, fields, tfs, counts, positions, terms, seq, places, k, idf=None,
+                               deleted=(), field_filter=(), reference_loop=True):
+    """search_fields_phrase with n-gram keys among the entries: counts = positions behind every (list, doc, field) entry (the key's own
+    count with its first component, 0 elsewhere), places = term_index_nonunique of every entry, idf per list (idf_ngram_i)"""
+    dl = np.ascontiguousarray(doclen_fields, np.uint8)
+    b = None if boost is None else np.ascontiguousarray(boost, np.float32)
+    offs = np.ascontiguousarray(offs, np.uint64)
+    docs = np.ascontiguousarray(docs, np.uint32)
+    fields = np.ascontiguousarray(fields, np.uint8)
+    tfs = np.ascontiguousarray(tfs, np.uint16)
+    cnt = np.ascontiguousarray(counts, np.uint16)
+    pos = np.ascontiguousarray(positions, np.uint16)
+    assert len(pos) == int(cnt.astype(np.uint64).sum()) and len(cnt) == len(tfs)
+    q = np.ascontiguousarray(terms, np.uint32)
+    sq = np.ascontiguousarray(seq, np.uint8)
+    pl = np.ascontiguousarray(places, np.uint8)
+    idf_a = None if idf is None else np.ascontiguousarray(idf, np.float32)
+    de = np.ascontiguousarray(deleted, np.uint64)
+    od = np.empty(max(k, 1), np.uint32)
+    os_ = np.empty(max(k, 1), np.float32)
+    tot = C.c_uint64()
+    mask = 0
+    for f_ in field_filter:
+        mask |= 1 << int(f_)
+    fn = lib().so_search_fields_phrase_items
+    fn.restype = C.c_uint32
+    fn.argtypes = [C.c_uint64, C.c_uint32, u8p, f32p, u64p, u32p, u8p, u16p, u16p, u16p, C.c_uint32, u32p, f32p, C.c_uint32, u8p, u8p, C.c_uint32,
+                   u64p, C.c_uint64, C.c_uint32, C.c_int, u32p, f32p, C.POINTER(C.c_uint64)]
+    n = fn(n_docs, dl.shape[0], _p(dl.reshape(-1), u8p), _p(b, f32p), _p(offs, u64p), _p(docs, u32p), _p(fields, u8p), _p(tfs, u16p), _p(cnt, u16p),
+           _p(pos, u16p), len(q), _p(q, u32p), None if idf_a is None else _p(idf_a, f32p), len(sq), _p(sq, u8p), _p(pl, u8p), k,
+           _p(de, u64p) if len(de) else None, len(de), mask, 1 if reference_loop else 0, _p(od, u32p), _p(os_, f32p), C.byref(tot))
+    return od[:n].copy(), os_[:n].copy(), tot.value
+
+
 def quantize_i8(v):
     v = np.ascontiguousarray(v, np.float32)
     out = np.empty(v.shape, np.int8)

@@ -232,9 +232,10 @@ def write_index_bin(n_docs, doclen_bytes, terms, rng, segment_number_bits=11, ke
     head_extra = [bytes(key_head_size - 20)] * len(terms)
     for gt in ngram_terms:
         if n_fields > 1:  # (key_hash, docs, fields, counts, {doc: component field vectors}, df bytes): entries sorted by (doc, field)
-            key, docs, flds, counts, comp_vecs, df_bytes = gt
+            key, docs, flds, counts, comp_vecs, df_bytes = gt[:6]  # (+ optional 7th: the key's positions per (doc, field) entry, ascending)
             assert key & 7 and len(df_bytes) == ngram_components(key) <= key_head_size - 20
-            blocks = encode_term_fields(docs, flds, counts, n_fields, longest_field_id, rng, positions_limit, ngram_vecs=comp_vecs)
+            blocks = encode_term_fields(docs, flds, counts, n_fields, longest_field_id, rng, positions_limit, ngram_vecs=comp_vecs,
+                                        positions=gt[6] if len(gt) > 6 else None)
             per_term_blocks.append({b[0]: b for b in blocks})
             terms.append((key,))
             head_extra.append(bytes(int(x) for x in df_bytes) + bytes(key_head_size - 20 - len(df_bytes)))

@@ -1687,7 +1687,23 @@ uint32_t so_search_fields_phrase(uint64_t n_docs, uint32_t n_fields, const uint8
                                  const uint16_t* positions, uint32_t nq, const uint32_t* qt, uint32_t n_seq, const uint8_t* seq,
                                  uint32_t k, const uint64_t* deleted, uint64_t n_deleted, uint32_t field_mask, int reference_loop,
                                  uint32_t* od, float* os, uint64_t* total) {
+  return so_search_fields_phrase_items(n_docs, n_fields, doclen, boost, off, docs, fields, tfs, NULL, positions, nq, qt, NULL, n_seq, seq, NULL, k,
+                                       deleted, n_deleted, field_mask, reference_loop, od, os, total);
+}
+/* ... with N-GRAM keys among the phrase's entries (several indexed fields: add_result.rs:1524-1600 reads the components' field vectors,
+ * then the key's own vector and positions).  The lists qt hold, for an n-gram key, its 2 / 3 component lists -- entries (doc, field,
+ * tf of the component in the field) --, counts[e] = positions behind entry e: the key's own count in that field with its FIRST
+ * component, 0 with the others and where the key does not stand in the field (NULL = tfs: SingleTerm lists only); idf_in per list
+ * (idf_ngram_i; NULL = from the list's docs); place[i] = term_index_nonunique of entry i (NULL = 0, 1, ...). */
+uint32_t so_search_fields_phrase_items(uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost, const uint64_t* off,
+                                       const uint32_t* docs, const uint8_t* fields, const uint16_t* tfs, const uint16_t* counts,
+                                       const uint16_t* positions, uint32_t nq, const uint32_t* qt, const float* idf_in, uint32_t n_seq,
+                                       const uint8_t* seq, const uint8_t* place_in, uint32_t k, const uint64_t* deleted, uint64_t n_deleted,
+                                       uint32_t field_mask, int reference_loop, uint32_t* od, float* os, uint64_t* total) {
   if (total) *total = 0;
+  if (!counts) counts = tfs;
+  uint32_t place[32];
+  for (uint32_t i = 0; i < n_seq && i < 32; i++) place[i] = place_in ? place_in[i] : i;
   if (nq == 0 || nq > 32 || n_seq < 2 || n_seq > 32 || n_fields == 0 || n_fields > 16) return 0;
   uint64_t psum = 0;
   for (uint64_t i = 0; i < n_docs * n_fields; i++) psum += so_byte4_to_int(doclen[i]);
@@ -1697,14 +1713,14 @@ uint32_t so_search_fields_phrase(uint64_t n_docs, uint32_t n_fields, const uint8
   uint64_t last = 0;
   for (uint32_t t = 0; t < nq; t++) if (off[qt[t] + 1] > last) last = off[qt[t] + 1];
   uint64_t* pbeg = (uint64_t*)malloc((last + 1) * sizeof(uint64_t));
-  { uint64_t a = 0; for (uint64_t i = 0; i < last; i++) { pbeg[i] = a; a += tfs[i]; } pbeg[last] = a; }
+  { uint64_t a = 0; for (uint64_t i = 0; i < last; i++) { pbeg[i] = a; a += counts[i]; } pbeg[last] = a; }
   uint8_t* dead = (uint8_t*)calloc(n_docs ? n_docs : 1, 1);
   for (uint64_t i = 0; i < n_deleted; i++) if (deleted[i] < n_docs) dead[deleted[i]] = 1;
   float idf[32];
   for (uint32_t t = 0; t < nq; t++) {
     uint64_t df = 0;
     for (uint64_t i = off[qt[t]]; i < off[qt[t] + 1]; i++) if (i == off[qt[t]] || docs[i] != docs[i - 1]) df++;
-    idf[t] = so_idf(n_docs, df);
+    idf[t] = idf_in ? idf_in[t] : so_idf(n_docs, df);
   }
   uint64_t cur[32];
   for (uint32_t t = 0; t < nq; t++) cur[t] = off[qt[t]];
@@ -1730,11 +1746,11 @@ uint32_t so_search_fields_phrase(uint64_t n_docs, uint32_t n_fields, const uint8
         const uint32_t t = seq[i];
         have = 0;
         for (uint64_t e = at[t]; e < end[t]; e++)
-          if (fields[e] == f) { pl[i] = positions + pbeg[e]; pc[i] = tfs[e]; have = 1; break; }
+          if (fields[e] == f && counts[e]) { pl[i] = positions + pbeg[e]; pc[i] = counts[e]; have = 1; break; }
       }
       if (!have) continue;                                        /* some word has no position in this field */
       if (field_mask && !((field_mask >> f) & 1u)) continue;      /* add_result.rs:3285-3287 */
-      match = so_phrase_match(n_seq, pl, pc, reference_loop);
+      match = so_phrase_match_places(n_seq, pl, pc, place, reference_loop);
     }
     if (!match) continue;
     float sc = 0.0f;

@@ -157,6 +157,12 @@ uint32_t so_search_fields_phrase(uint64_t n_docs, uint32_t n_fields, const uint8
                                  uint32_t n_q_terms, const uint32_t* q_terms, uint32_t n_seq, const uint8_t* seq, uint32_t k,
                                  const uint64_t* deleted, uint64_t n_deleted, uint32_t field_mask, int reference_loop,
                                  uint32_t* out_doc, float* out_score, uint64_t* out_total);
+uint32_t so_search_fields_phrase_items(uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost, const uint64_t* off,
+                                       const uint32_t* docs, const uint8_t* fields, const uint16_t* tfs, const uint16_t* counts /* NULL = tfs */,
+                                       const uint16_t* positions, uint32_t nq, const uint32_t* qt, const float* idf /* NULL = from the lists */,
+                                       uint32_t n_seq, const uint8_t* seq, const uint8_t* place /* NULL = 0, 1, ... */, uint32_t k,
+                                       const uint64_t* deleted, uint64_t n_deleted, uint32_t field_mask, int reference_loop, uint32_t* od, float* os,
+                                       uint64_t* total);
 /* statistics for the roofline's algorithmic bytes: sum df, #blocks touched */
 void so_query_stats(const so_shard*, uint32_t n_q_terms, const uint32_t* q_terms, uint64_t* sum_df,
                     uint64_t* sum_blocks);

@@ -96,6 +96,7 @@ SYMBOLS = [
     ("ss_index_bin_term_keys", C.c_int, [C.c_void_p, u64p]),
     ("ss_index_bin_term_ngram", C.c_int, [C.c_void_p, u8p, u8p, u32p]),
     ("ss_ref_decode_block_ngram", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, u16p, u16p]),
+    ("ss_ref_decode_block_fields_ngram_positions", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, u16p, u32p, u8p, u16p, u16p, u16p, C.c_uint64, u64p]),
     ("ss_ref_decode_block_ngram_positions", C.c_int, [C.c_void_p, C.c_uint32, u16p, u16p, u16p, u16p, C.c_uint64, u64p]),
     ("ss_index_bin_term_postings", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, u32p, u16p, u64p]),
     ("ss_bm25_upload_index_bin", C.c_int, [C.c_void_p, C.c_void_p]),

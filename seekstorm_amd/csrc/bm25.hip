@@ -185,7 +185,7 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
     const bool q_phrase = bm_q_op(Q.op) == SS_OP_PHRASE;
     bad |= bm_q_op(Q.op) > (uint32_t)SS_OP_PHRASE || q_phrase != ((claim & BM_CLAIM_PHRASE) != 0u);
     if (q_phrase) {
-      bad |= (n_lists != 1 && merged == 0u) || n_not != 0 || Q.phrase_len < 2u || Q.phrase_len > (uint32_t)SS_MAX_PHRASE || np > 6u;
+      bad |= (n_lists != 1 && merged == 0u) || Q.phrase_len < 2u || Q.phrase_len > (uint32_t)SS_MAX_PHRASE || np > 6u;
       // (a word place inside an n-gram key carries SS_PHRASE_SKIP; the key's other component terms are scored, not placed)
       bad |= Q.phrase_seq[0] >= np;
       for (uint32_t j = 1; j < (uint32_t)SS_MAX_PHRASE && j < Q.phrase_len; j++) bad |= Q.phrase_seq[j] >= np && Q.phrase_seq[j] != SS_PHRASE_SKIP;
@@ -319,7 +319,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   // phrase queries: their own kernel over the probe index and the positions (bm25_phrase.hip); every strategy
   // (one indexed field: d_pos; several: the merged lists and d_pos32)
   const bool have_pos = s->bm_n_fields == 1 ? s->d_pos != nullptr : (s->bm_merged && s->d_pos32 != nullptr);
-  if (phrase && (!have_probe || !have_pos || KPL > 2 || np_max > 6 || nt_max != np_max)) return !have_pos ? SS_ESTATE : SS_ENOTSUP;
+  if (phrase && (!have_probe || !have_pos || KPL > 2 || np_max > 6)) return !have_pos ? SS_ESTATE : SS_ENOTSUP;  // (NOT lists: probed in the kernel)
   // Partitions per query (one wave each).  The grid is a whole number of "rounds" of resident waves: a partially
   // filled last round costs its full duration (measured on C2: 550K q/s at 1.95 rounds vs 477K at 2.44).  Exhaustive
   // scan: 2048 resident waves (LDS-bound), ~2 rounds; pruned: 6144 resident waves, ~4 rounds of shorter assignments

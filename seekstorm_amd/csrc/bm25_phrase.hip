@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(PH_WAVES * 64) bm25_phrase_kernel(
   if (a >= nq * P) return;
   const uint32_t qi = a % nq, part = a / nq;
   const bm_vquery* __restrict__ Q = qs + qi;
-  const uint32_t nt = Q->n_terms, plen = Q->phrase_len;
+  const uint32_t nt = Q->n_terms, plen = Q->phrase_len, n_not = bm_q_nnot(Q->op);
   constexpr bool MF = sizeof(PT) == 4;  // several indexed fields: positions carry their field
   const uint32_t fmask = MF ? Q->phrase_fields : 0xFFFFFFFFu;
   const uint32_t row_len = n_sub + 1;
@@ -138,6 +138,15 @@ __global__ void __launch_bounds__(PH_WAVES * 64) bm25_phrase_kernel(
           alive = hit;
           idx[t] = z + rk;
         }
+      }
+      if (__ballot(alive) == 0ull) continue;
+      // NOT terms (not_query_list applies to every query type, add_result.rs:3440-3497): a doc found in one of their lists is dropped
+      // -- one bit record per NOT list and surviving lane
+      for (uint32_t j = 0; j < n_not; j++) {
+        const uint32_t nterm = Q->term[nt + j];
+        const uint2 r = (probe + (size_t)probe_row[nterm] * n_sub * (BM_SUB / 64))[alive ? gidx : 0u];
+        const u64 bits = ((u64)r.y << 32) | r.x;
+        if ((bits >> (d & 63u)) & 1ull) alive = false;
       }
       if (__ballot(alive) == 0ull) continue;
       const uint32_t doc = (s << BM_SUB_LOG2) + d;

@@ -313,9 +313,11 @@ bool read_field_vec(const uint8_t* a, uint64_t len, uint64_t pos, uint32_t id_bi
   if (end_out) *end_out = pos;
   return true;
 }
+// npos_out (with pos_out): positions per ENTRY -- its tf for a SingleTerm key; for an n-gram key the key's OWN count in the entry's
+// field with component 0 (the key's field vector and positions follow the components' vectors in the record), 0 with the others
 int decode_block_fields(const ss_ref_block* b, uint32_t n_fields, uint32_t longest_field_id, uint32_t n_components, uint32_t component,
                         uint16_t* docs_out, uint32_t* first_out, uint8_t* field_out, uint16_t* tf_out,
-                        std::vector<uint16_t>* pos_out = nullptr);
+                        std::vector<uint16_t>* pos_out = nullptr, std::vector<uint16_t>* npos_out = nullptr);
 }  // namespace
 
 // Decodes one block of a multi-field index: docs_out [65536], first_out [65537] = CSR of the field entries per posting,
@@ -349,10 +351,28 @@ extern "C" int ss_ref_decode_block_fields_ngram(const ss_ref_block* b, uint32_t 
   if (n_components < 2 || n_components > 3 || component >= n_components) return SS_EINVAL;
   return decode_block_fields(b, n_fields, longest_field_id, n_components, component, docs_out, first_out, field_out, tf_out);
 }
+// ... and the key's OWN positions of a multi-field n-gram block: the entries are those of component 0 (field, the component's tf);
+// npos_out [65536 * n_fields] = the key's positions behind every entry (0 where the key does not stand in that field), pos_out their
+// concatenation, field by field inside a posting.
+extern "C" int ss_ref_decode_block_fields_ngram_positions(const ss_ref_block* b, uint32_t n_fields, uint32_t longest_field_id,
+                                                          uint32_t n_components, uint16_t* docs_out, uint32_t* first_out, uint8_t* field_out,
+                                                          uint16_t* tf_out, uint16_t* npos_out, uint16_t* pos_out, uint64_t pos_cap,
+                                                          uint64_t* n_pos_out) {
+  if (n_components < 2 || n_components > 3 || !npos_out || !n_pos_out || (pos_cap && !pos_out)) return SS_EINVAL;
+  std::vector<uint16_t> pos, np;
+  const int n = decode_block_fields(b, n_fields, longest_field_id, n_components, 0, docs_out, first_out, field_out, tf_out, &pos, &np);
+  if (n < 0) return n;
+  *n_pos_out = pos.size();
+  if (pos.size() > pos_cap) return SS_EINVAL;
+  if (!pos.empty()) std::memcpy(pos_out, pos.data(), pos.size() * sizeof(uint16_t));
+  if (!np.empty()) std::memcpy(npos_out, np.data(), np.size() * sizeof(uint16_t));
+  return n;
+}
 namespace {
 int decode_block_fields(const ss_ref_block* b, uint32_t n_fields, uint32_t longest_field_id, uint32_t n_components, uint32_t component,
-                        uint16_t* docs_out, uint32_t* first_out, uint8_t* field_out, uint16_t* tf_out, std::vector<uint16_t>* pos_out) {
-  if (pos_out && n_components > 1) return SS_ENOTSUP;  // an n-gram key's positions are the n-gram's, not its components'
+                        uint16_t* docs_out, uint32_t* first_out, uint8_t* field_out, uint16_t* tf_out, std::vector<uint16_t>* pos_out,
+                        std::vector<uint16_t>* npos_out) {
+  if (pos_out && n_components > 1 && !npos_out) return SS_EINVAL;  // an n-gram key's positions are the key's own: counted apart
   const size_t pos_base = pos_out ? pos_out->size() : 0;
   if (!b || !b->byte_array || !docs_out || !first_out || !field_out || !tf_out || n_fields < 2 || n_fields > 8 ||
       longest_field_id >= n_fields) return SS_EINVAL;
@@ -409,6 +429,8 @@ int decode_block_fields(const ss_ref_block* b, uint32_t n_fields, uint32_t longe
     first_out[r] = w;
     FieldEntry e[8];
     int ne = 0;
+    uint32_t own_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // positions handed out per entry (recorded postings; embedded ones: their tf)
+    bool recorded = false;
     uint32_t emb_bits = 0;  // embedded pointer: bits that hold the positions
     const bool two = r < pivot;
     const uint64_t at = two ? range + (uint64_t)r * 2u : range + (uint64_t)r * 3u - pivot;
@@ -417,14 +439,37 @@ int decode_block_fields(const ss_ref_block* b, uint32_t n_fields, uint32_t longe
     if (!(p & (two ? 0x8000u : 0x800000u))) {  // record in the position area
       const uint64_t back = p & (two ? 0x7FFFu : 0x7FFFFFu);
       if (back > range) return SS_EINVAL;
+      recorded = true;
       uint64_t at_rec = range - back;
       for (uint32_t c = 0; c <= (ngram ? component : 0u); c++) {  // n-gram keys: the components' vectors come first
         if (!read_field_vec(a, len, at_rec, id_bits, longest_field_id, e, &ne, &at_rec)) return SS_EINVAL;
       }
+      // whose positions follow: the posting's own vector (SingleTerm) / the key's own vector behind ALL component vectors (n-gram
+      // key, handed out with component 0: index_posting.rs:666-741)
+      FieldEntry own[8];
+      int nown = 0;
+      if (pos_out && ngram && component == 0u) {
+        FieldEntry skip[8];
+        int nskip = 0;
+        for (uint32_t c = 1; c < n_components; c++)
+          if (!read_field_vec(a, len, at_rec, id_bits, longest_field_id, skip, &nskip, &at_rec)) return SS_EINVAL;
+        if (!read_field_vec(a, len, at_rec, id_bits, longest_field_id, own, &nown, &at_rec)) return SS_EINVAL;
+        for (int i = 0, k = 0; i < nown; i++) {  // the key stands in a field only where its first word does
+          while (k < ne && e[k].field < own[i].field) k++;
+          if (k == ne || e[k].field != own[i].field || own[i].tf == 0 || own[i].tf > 65535u) return SS_EINVAL;
+        }
+      } else if (pos_out && !ngram) {
+        nown = ne;
+        for (int i = 0; i < ne; i++) own[i] = e[i];
+      }
+      for (int i = 0; i < ne; i++) own_cnt[i] = 0;
+      for (int i = 0; i < nown; i++)
+        for (int k = 0; k < ne; k++)
+          if (e[k].field == own[i].field) own_cnt[k] = own[i].tf;
       if (pos_out) {  // the positions follow the field vector: per field its tf VINTs, the first absolute, then "gap - 1"
-        for (int i = 0; i < ne; i++) {  // (get_next_position_multifield restarts at every field, add_result.rs:3279-3283)
+        for (int i = 0; i < nown; i++) {  // (get_next_position_multifield restarts at every field, add_result.rs:3279-3283)
           uint32_t at_pos = 0, v;
-          for (uint32_t x = 0; x < e[i].tf; x++) {
+          for (uint32_t x = 0; x < own[i].tf; x++) {
             if (!read_position(a, len, at_rec, &v)) return SS_EINVAL;
             at_rec += a[at_rec] & 0x80u ? 1u : (a[at_rec + 1] & 0x80u ? 2u : 3u);
             at_pos = x == 0 ? v : at_pos + v + 1u;
@@ -493,6 +538,7 @@ int decode_block_fields(const ss_ref_block* b, uint32_t n_fields, uint32_t longe
       if (i && e[i].field <= e[i - 1].field) return SS_EINVAL;  // the field vector is written in ascending field order
       field_out[w] = e[i].field;
       tf_out[w] = (uint16_t)e[i].tf;
+      if (pos_out && npos_out) npos_out->push_back((uint16_t)(recorded ? own_cnt[i] : e[i].tf));
       w++;
     }
   }
@@ -904,7 +950,7 @@ namespace {
 // multi-field index: (doc, field, tf) entries of every term, doclen rearranged to [field][doc]
 int upload_index_bin_fields(ss_shard* s, const ss_index_bin* ix, const float* boost, bool with_positions) {
   const uint32_t F = ix->n_fields;
-  std::vector<uint16_t> pos;
+  std::vector<uint16_t> pos, npos;
   std::vector<uint64_t> offs(ix->keys.size() + 1, 0);
   std::vector<uint32_t> docs;
   std::vector<uint8_t> fields;
@@ -917,7 +963,7 @@ int upload_index_bin_fields(ss_shard* s, const ss_index_bin* ix, const float* bo
     for (uint64_t bi = ix->term_block_off[t]; bi < ix->term_block_off[t + 1]; bi++) {
       const ss_ref_block& b = ix->blocks[bi].b;
       const int n = decode_block_fields(&b, F, ix->longest_field_id, ix->blocks[bi].n_comp, ix->blocks[bi].comp, d16.data(), first.data(),
-                                        f8.data(), t16.data(), with_positions ? &pos : nullptr);  // (n-gram keys: SS_ENOTSUP with positions)
+                                        f8.data(), t16.data(), with_positions ? &pos : nullptr, with_positions ? &npos : nullptr);
       if (n < 0) return n;
       for (int i = 0; i < n; i++) {
         const uint64_t doc = ((uint64_t)b.block_id << 16) | d16[i];
@@ -941,7 +987,7 @@ int upload_index_bin_fields(ss_shard* s, const ss_index_bin* ix, const float* bo
     }
   if (with_positions)
     return ssi_bm25_upload_fields_positions(s, ix->n_docs, F, doclen.data(), boost, (uint32_t)ix->keys.size(), offs.data(), docs.data(),
-                                            fields.data(), tfs.data(), ix->positions_sum, pos.data(), pos.size());
+                                            fields.data(), tfs.data(), ix->positions_sum, pos.data(), pos.size(), npos.data());
   return ssi_bm25_upload_fields(s, ix->n_docs, F, doclen.data(), boost, (uint32_t)ix->keys.size(), offs.data(), docs.data(),
                                 fields.data(), tfs.data(), ix->positions_sum);
 }

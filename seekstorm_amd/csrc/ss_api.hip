@@ -15,6 +15,7 @@
 #include <unordered_map>
 
 #include "ss_common.h"
+#include "ss_threads.h"
 #include "facet_point.h"
 #include "bm25_build.h"
 
@@ -247,6 +248,48 @@ int ssi_bm25_attach_positions(ss_shard* s, const uint64_t* offs, const uint32_t*
   return rc;
 }
 
+// the arrays of a whole-image upload -> device, validated on the way (terms in parallel); the image is built by the device kernels
+static int bm25_upload_device_build(ss_shard* s, const uint8_t* doclen, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
+                                    uint64_t positions_sum) {
+  const uint32_t nt = s->bm_n_terms;
+  const uint64_t nd = s->bm_n_docs, np = offs[nt] - offs[0];
+  for (uint32_t t = 0; t < nt; t++)
+    if (offs[t + 1] < offs[t]) return SS_EINVAL;
+  std::atomic<int> bad{0};
+  ss_parallel_for(nt, 64, [&](size_t a, size_t b, unsigned) {
+    for (size_t t = a; t < b; t++)
+      for (uint64_t j = offs[t]; j < offs[t + 1]; j++)
+        if (docs[j] >= nd || tfs[j] == 0 || (j > offs[t] && docs[j] <= docs[j - 1])) { bad.store(1); return; }
+  });
+  if (bad.load()) return SS_EINVAL;
+  ss_raw_level L;
+  L.n_docs = 0; L.n_terms = nt; L.n_post = np;
+  if (positions_sum) L.psum = positions_sum;
+  else {
+    std::vector<uint64_t> part(ss_loader_threads() + 1, 0);
+    ss_parallel_for(nd, 1u << 20, [&](size_t a, size_t b, unsigned w) { uint64_t c = 0; for (size_t d = a; d < b; d++) c += ss_byte4_to_int(doclen[d]); part[w] += c; });
+    for (uint64_t c : part) L.psum += c;
+  }
+  auto drop = [&]() { for (void* p : {(void*)L.d_off, (void*)L.d_doc, (void*)L.d_tf}) if (p) (void)hipFree(p); };
+#define SS_HIP_D(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { drop(); return e_ == hipErrorOutOfMemory ? SS_ENOMEM : SS_EDEVICE; } } while (0)
+  std::vector<uint64_t> rel((size_t)nt + 1);
+  for (uint32_t t = 0; t <= nt; t++) rel[t] = offs[t] - offs[0];
+  SS_HIP_D(hipMalloc(&L.d_off, rel.size() * sizeof(uint64_t)));
+  SS_HIP_D(hipMalloc(&L.d_doc, std::max<uint64_t>(np, 1) * sizeof(uint32_t)));
+  SS_HIP_D(hipMalloc(&L.d_tf, std::max<uint64_t>(np, 1) * sizeof(uint16_t)));
+  SS_HIP_D(hipMemcpyAsync(L.d_off, rel.data(), rel.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream));
+  if (np) {
+    SS_HIP_D(hipMemcpyAsync(L.d_doc, docs + offs[0], np * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+    SS_HIP_D(hipMemcpyAsync(L.d_tf, tfs + offs[0], np * sizeof(uint16_t), hipMemcpyHostToDevice, s->stream));
+  }
+  SS_HIP_D(hipStreamSynchronize(s->stream));
+#undef SS_HIP_D
+  std::vector<ss_raw_level> one{L};
+  const int rc = ssi_bm25_rebuild_from_raw(s, one, nt, doclen, nd, s, s->stream, true);
+  drop();
+  return rc;
+}
+
 int ssi_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen, uint32_t n_terms, const uint64_t* offs,
                     const uint32_t* docs, const uint16_t* tfs, uint64_t positions_sum) {
   if (!s || !doclen || !offs || n_docs == 0 || n_terms == 0) return SS_EINVAL;
@@ -259,7 +302,16 @@ int ssi_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen, uint32_
   s->bm_n_docs = n_docs;
   s->bm_n_terms = n_terms;
   s->bm_n_sub = (uint32_t)((n_docs + BM_SUB - 1) >> BM_SUB_LOG2);
-  int rc = ssi_bm25_build_from_host(s, doclen, offs, docs, tfs, positions_sum);
+  // One indexed field: the image is BUILT ON THE DEVICE from the decoded arrays (the kernels of the incremental rebuild, synth.hip
+  // ssi_bm25_rebuild_from_raw) -- the host validates and copies 6 bytes per posting instead of packing, sorting out segments and
+  // filling probe rows.  SS_BM25_HOST_BUILD=1 keeps the host builder (the two are compared by the tests).
+  static const bool host_build = [] { const char* e = getenv("SS_BM25_HOST_BUILD"); return e && atoi(e) != 0; }();
+  int rc;
+  if (host_build) {
+    rc = ssi_bm25_build_from_host(s, doclen, offs, docs, tfs, positions_sum);
+  } else {
+    rc = bm25_upload_device_build(s, doclen, offs, docs, tfs, positions_sum);
+  }
   if (rc) free_bm25(s);
   return rc;
 }
@@ -290,13 +342,13 @@ int ss_bm25_upload_fields_positions(ss_shard* s, uint64_t n_docs, uint32_t n_fie
 
 int ssi_bm25_upload_fields_positions(ss_shard* s, uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost,
                                      uint32_t n_terms, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
-                                     const uint16_t* tfs, uint64_t positions_sum, const uint16_t* positions, uint64_t n_positions) {
+                                     const uint16_t* tfs, uint64_t positions_sum, const uint16_t* positions, uint64_t n_positions, const uint16_t* npos) {
   if (n_fields < 2) return SS_EINVAL;  // one indexed field: ss_bm25_upload_positions
   int rc = ssi_bm25_upload_fields(s, n_docs, n_fields, doclen, boost, n_terms, offs, docs, fields, tfs, positions_sum);
   if (rc) return rc;
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
-  rc = ssi_bm25_upload_positions_fields(s, n_terms, offs, docs, fields, tfs, positions, n_positions);
+  rc = ssi_bm25_upload_positions_fields(s, n_terms, offs, docs, fields, tfs, positions, n_positions, npos);
   if (rc) free_bm25(s);  // a failure leaves no image behind
   return rc;
 }
@@ -474,7 +526,7 @@ int ss_bm25_append_level(ss_shard* s, uint32_t level, uint32_t n_level_docs, con
   levels.push_back(L);
   doclen.insert(doclen.end(), level_doclen, level_doclen + n_level_docs);
   const auto t_build = std::chrono::steady_clock::now();
-  int rc = ssi_bm25_rebuild_from_raw(s, levels, n_terms, doclen, img.get(), bst);
+  int rc = ssi_bm25_rebuild_from_raw(s, levels, n_terms, doclen.data(), doclen.size(), img.get(), bst);
   if (rc) return fail(rc);
   const double rebuild_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count();
   {  // the swap: searches in flight finish on the old image, whose arrays are then released
@@ -691,7 +743,7 @@ static int check_queries(const ss_shard* s, uint32_t nq, const ss_bm25_query* q,
       if (q[i].phrase_seq[0] >= q[i].n_terms) return SS_EINVAL;
       for (uint32_t j = 1; j < q[i].phrase_len; j++)
         if (q[i].phrase_seq[j] >= q[i].n_terms && q[i].phrase_seq[j] != SS_PHRASE_SKIP) return SS_EINVAL;
-      if (n_not || q[i].n_terms > 6) return SS_ENOTSUP;
+      if (q[i].n_terms > 6) return SS_ENOTSUP;  // (NOT terms: their lists are probed by the phrase kernel like everywhere else)
       // several indexed fields: over the merged lists and their field-tagged positions (a corpus whose boosts kept the merged
       // lists from being built has no phrase path)
       if (s->bm_n_fields > 1 && !s->bm_merged) return SS_ENOTSUP;

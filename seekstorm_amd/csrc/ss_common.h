@@ -463,12 +463,12 @@ int ssi_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen, uint32_
 int ssi_bm25_attach_positions(ss_shard* s, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs, const uint16_t* positions,
                               uint64_t n_positions, const uint16_t* npos = nullptr);
 int ssi_bm25_upload_positions_fields(ss_shard* s, uint32_t n_terms, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
-                                     const uint16_t* tfs, const uint16_t* positions, uint64_t n_positions);
+                                     const uint16_t* tfs, const uint16_t* positions, uint64_t n_positions, const uint16_t* npos = nullptr);
 int ssi_bm25_upload_positions(ss_shard* s, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs, const uint16_t* positions,
                               uint64_t n_positions, const uint16_t* npos = nullptr);
 int ssi_bm25_upload_fields_positions(ss_shard* s, uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost,
                                      uint32_t n_terms, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
-                                     const uint16_t* tfs, uint64_t positions_sum, const uint16_t* positions, uint64_t n_positions);
+                                     const uint16_t* tfs, uint64_t positions_sum, const uint16_t* positions, uint64_t n_positions, const uint16_t* npos = nullptr);
 int ssi_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost,
                            uint32_t n_terms, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
                            const uint16_t* tfs, uint64_t positions_sum);
@@ -477,8 +477,8 @@ void ssi_prof_end(ss_shard* s, int kernel, hipStream_t st, hipEvent_t e0, hipEve
 
 // ---- incremental image (synth.hip): `img` = a scratch ss_shard that receives the new image (its bm_* / d_* image fields); the raw
 // levels are read from `s`
-int ssi_bm25_rebuild_from_raw(const ss_shard* s, const std::vector<ss_raw_level>& levels, uint32_t n_terms, const std::vector<uint8_t>& doclen,
-                              ss_shard* img, hipStream_t st);
+int ssi_bm25_rebuild_from_raw(const ss_shard* s, const std::vector<ss_raw_level>& levels, uint32_t n_terms, const uint8_t* doclen, uint64_t n_doclen,
+                              ss_shard* img, hipStream_t st, bool one_shot = false);
 // ---- sparse tier (synth.hip: append; bm25_sparse.hip: kernels)
 int ssi_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs);
 int ssi_bm25_launch_sparse(const ss_shard* s, const ss_bm25_query* d_q, uint32_t nq, uint32_t k, unsigned long long* d_keys,

@@ -413,9 +413,9 @@ static int bm_decide_partmax_dev(ss_shard* img) {
 __global__ void lex_scan_rows_kernel(uint32_t* __restrict__ sub, uint32_t n_sub, u64* __restrict__ term_tot);
 __global__ void lex_scan_terms_kernel(const u64* __restrict__ tot, u64* __restrict__ base, uint32_t n_terms);
 struct RawLevelDev { const unsigned long long* off; const uint32_t* doc; const uint16_t* tf; uint32_t n_terms, pad; };
-__device__ __forceinline__ void raw_segment(const RawLevelDev* __restrict__ levels, uint32_t t, uint32_t sb, u64* lo_out, u64* hi_out,
-                                            const uint32_t** doc_out, const uint16_t** tf_out) {
-  const RawLevelDev L = levels[sb >> (16 - BM_SUB_LOG2)];  // a level = 65 536 docs
+__device__ __forceinline__ void raw_segment(const RawLevelDev* __restrict__ levels, uint32_t level_shift, uint32_t t, uint32_t sb, u64* lo_out,
+                                            u64* hi_out, const uint32_t** doc_out, const uint16_t** tf_out) {
+  const RawLevelDev L = levels[sb >> level_shift];  // incremental images: a level = 65 536 docs = 16 sub-blocks; a one-shot upload: one "level"
   *doc_out = L.doc; *tf_out = L.tf;
   if (t >= L.n_terms) { *lo_out = 0; *hi_out = 0; return; }
   const u64 a = L.off[t], b = L.off[t + 1];
@@ -428,14 +428,14 @@ __device__ __forceinline__ void raw_segment(const RawLevelDev* __restrict__ leve
   *lo_out = first; *hi_out = lo;
 }
 // one thread per (term, sub-block): the segment's size in 16-byte units (shifted by one for the exclusive scan) and the term's df
-__global__ void raw_count_kernel(const RawLevelDev* __restrict__ levels, uint32_t n_terms, uint32_t n_sub, uint32_t* __restrict__ sub,
-                                 u64* __restrict__ df) {
+__global__ void raw_count_kernel(const RawLevelDev* __restrict__ levels, uint32_t level_shift, uint32_t n_terms, uint32_t n_sub,
+                                 uint32_t* __restrict__ sub, u64* __restrict__ df) {
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (u64)n_terms * n_sub) return;
   const uint32_t t = (uint32_t)(i / n_sub), sb = (uint32_t)(i % n_sub);
   u64 lo, hi;
   const uint32_t* dp; const uint16_t* tp;
-  raw_segment(levels, t, sb, &lo, &hi, &dp, &tp);
+  raw_segment(levels, level_shift, t, sb, &lo, &hi, &dp, &tp);
   const uint32_t n = (uint32_t)(hi - lo);
   sub[(size_t)t * (n_sub + 1) + sb + 1] = (n + 3u) >> 2;
   if (n) atomicAdd(&df[t], (u64)n);
@@ -443,7 +443,8 @@ __global__ void raw_count_kernel(const RawLevelDev* __restrict__ levels, uint32_
 // one wave per (term, sub-block): packs the segment's postings (weight code from tf and the doc's length byte, computed with the
 // host builder's operations: t * (K + 1) / (t + comp), every step rounded to f32), writes the probe row's 64-doc bit records and
 // ranks, the segment's and the list's largest weight, the NULL padding
-__global__ void raw_fill_kernel(const RawLevelDev* __restrict__ levels, uint32_t n_terms, uint32_t n_sub, const uint8_t* __restrict__ doclen,
+__global__ void raw_fill_kernel(const RawLevelDev* __restrict__ levels, uint32_t level_shift, uint32_t n_terms, uint32_t n_sub,
+                                const uint8_t* __restrict__ doclen,
                                 const float* __restrict__ comp, float k1, const uint32_t* __restrict__ sub, const u64* __restrict__ term_base,
                                 uint32_t* __restrict__ post, uint2* __restrict__ probe, uint32_t* __restrict__ probe_z,
                                 const uint32_t* __restrict__ probe_row, uint32_t* __restrict__ umax_bits, float* __restrict__ submax,
@@ -455,7 +456,7 @@ __global__ void raw_fill_kernel(const RawLevelDev* __restrict__ levels, uint32_t
   const uint32_t t = (uint32_t)(gw / n_sub), sb = (uint32_t)(gw % n_sub);
   u64 lo, hi;
   const uint32_t* dp; const uint16_t* tp;
-  raw_segment(levels, t, sb, &lo, &hi, &dp, &tp);
+  raw_segment(levels, level_shift, t, sb, &lo, &hi, &dp, &tp);
   const uint32_t seg0 = sub[(size_t)t * (n_sub + 1) + sb] * 4u;
   const u64 base = term_base[t] * 4ull + seg0;
   const bool flg = flagged[t] != 0;
@@ -493,15 +494,19 @@ __global__ void raw_fill_kernel(const RawLevelDev* __restrict__ levels, uint32_t
   }
 }
 
-int ssi_bm25_rebuild_from_raw(const ss_shard* s, const std::vector<ss_raw_level>& levels, uint32_t n_terms, const std::vector<uint8_t>& doclen,
-                              ss_shard* img, hipStream_t st) {
+// one_shot: `levels` holds ONE set of arrays covering every doc (a whole-image upload builds through the same kernels: the host then
+// only validates and copies), the image arrays are plain allocations and `img` may be the shard itself
+int ssi_bm25_rebuild_from_raw(const ss_shard* s, const std::vector<ss_raw_level>& levels, uint32_t n_terms, const uint8_t* doclen, uint64_t n_doclen,
+                              ss_shard* img, hipStream_t st, bool one_shot) {
   u64 nd = 0, psum = 0, npost = 0;
   for (const ss_raw_level& L : levels) { nd += L.n_docs; psum += L.psum; npost += L.n_post; }
-  if (nd == 0 || n_terms == 0 || doclen.size() != nd) return SS_EINVAL;
+  if (one_shot) nd = n_doclen;
+  if (nd == 0 || n_terms == 0 || n_doclen != nd || (one_shot && levels.size() != 1)) return SS_EINVAL;
+  const uint32_t level_shift = one_shot ? 31u : (uint32_t)(16 - BM_SUB_LOG2);
   const uint32_t nt = n_terms, ns = (uint32_t)((nd + BM_SUB - 1) >> BM_SUB_LOG2);
   img->device = s->device;
   img->probe_budget = s->probe_budget;
-  img->pool = const_cast<ss_block_pool*>(&s->blocks);  // (the caller serialises commits: nobody else touches the pool meanwhile)
+  img->pool = one_shot ? nullptr : const_cast<ss_block_pool*>(&s->blocks);  // (the caller serialises commits: nobody else touches the pool meanwhile)
   img->bm_n_docs = nd; img->bm_n_terms = nt; img->bm_n_sub = ns; img->bm_n_fields = 1; img->bm_merged = false;
   img->bm_n_post = npost;
   img->bm_avgdl = (float)psum / (float)nd;  // commit.rs:318-319
@@ -522,7 +527,7 @@ int ssi_bm25_rebuild_from_raw(const ss_shard* s, const std::vector<ss_raw_level>
   SS_HIP_C(hipMalloc(&d_df, (size_t)nt * sizeof(u64)));
   SS_HIP_C(hipMemsetAsync(d_df, 0, (size_t)nt * sizeof(u64), st));
   SS_HIP_C(img_malloc(img, &img->d_doclen, nd));
-  SS_HIP_C(hipMemcpyAsync(img->d_doclen, doclen.data(), nd, hipMemcpyHostToDevice, st));
+  SS_HIP_C(hipMemcpyAsync(img->d_doclen, doclen, nd, hipMemcpyHostToDevice, st));
   const size_t rows = (size_t)nt * (ns + 1);
   SS_HIP_C(img_malloc(img, &img->d_sub_off, (rows + ns + 1) * sizeof(uint32_t)));  // + one all-zero row (absent terms)
   SS_HIP_C(hipMemsetAsync(img->d_sub_off + rows, 0, ((size_t)ns + 1) * sizeof(uint32_t), st));
@@ -533,7 +538,7 @@ int ssi_bm25_rebuild_from_raw(const ss_shard* s, const std::vector<ss_raw_level>
   SS_HIP_C(hipMemcpyAsync(img->d_comp, comp, sizeof(comp), hipMemcpyHostToDevice, st));
   const u64 pairs = (u64)nt * ns;
   const auto t1 = now();
-  raw_count_kernel<<<(uint32_t)((pairs + 255) / 256), 256, 0, st>>>(d_lv, nt, ns, img->d_sub_off, d_df);
+  raw_count_kernel<<<(uint32_t)((pairs + 255) / 256), 256, 0, st>>>(d_lv, level_shift, nt, ns, img->d_sub_off, d_df);
   lex_scan_rows_kernel<<<nt, 1024, 0, st>>>(img->d_sub_off, ns, d_tot);
   lex_scan_terms_kernel<<<1, 64, 0, st>>>(d_tot, (u64*)img->d_term_base, nt);
   SS_HIP_C(hipStreamSynchronize(st));
@@ -557,7 +562,7 @@ int ssi_bm25_rebuild_from_raw(const ss_shard* s, const std::vector<ss_raw_level>
   SS_HIP_C(hipMalloc(&d_flg, nt));
   SS_HIP_C(hipMemcpyAsync(d_flg, flg.data(), nt, hipMemcpyHostToDevice, st));
   const volatile float k1 = 1.2f + 1.0f;  // (K + 1) as bm_weight_exact forms it
-  raw_fill_kernel<<<(uint32_t)((pairs + 3) / 4), 256, 0, st>>>(d_lv, nt, ns, img->d_doclen, img->d_comp, k1, img->d_sub_off,
+  raw_fill_kernel<<<(uint32_t)((pairs + 3) / 4), 256, 0, st>>>(d_lv, level_shift, nt, ns, img->d_doclen, img->d_comp, k1, img->d_sub_off,
                                                               (const u64*)img->d_term_base, img->d_post, img->d_probe, img->d_probe_z,
                                                               img->d_probe_row, (uint32_t*)img->d_umax, img->d_submax, d_flg);
   SS_HIP_C(hipGetLastError());
@@ -681,8 +686,9 @@ int ssi_bm25_upload_positions(ss_shard* s, const uint64_t* offs, const uint32_t*
 // of that term, fields ascending -- exactly the order of the caller's array -- each tagged with its field above bit 20, so the
 // pool is the caller's array with tags, d_pos_off / d_pos_base as for one field but indexed by the merged list's image slots.
 int ssi_bm25_upload_positions_fields(ss_shard* s, uint32_t n_terms, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
-                                     const uint16_t* tfs, const uint16_t* positions, uint64_t n_positions) {
+                                     const uint16_t* tfs, const uint16_t* positions, uint64_t n_positions, const uint16_t* npos) {
   if (!s->bm_merged) return SS_ENOTSUP;  // boosts too far apart for merged lists: no phrase path over this corpus
+  if (!npos) npos = tfs;  // (npos: positions per entry where that is not its tf -- the component terms of an n-gram key)
   const uint32_t L = s->bm_n_fields, nv = s->bm_n_terms, ns = s->bm_n_sub;
   if ((uint64_t)n_terms * L != nv) return SS_EINVAL;
   std::vector<u64> tbase((size_t)nv + 1), pbase((size_t)nv + 1, 0);
@@ -700,13 +706,13 @@ int ssi_bm25_upload_positions_fields(ss_shard* s, uint32_t n_terms, const uint64
       while (j < offs[t + 1] && docs[j] < lim) {
         const uint32_t d = docs[j];
         for (; j < offs[t + 1] && docs[j] == d; j++) {  // the doc's entries, fields ascending
-          if (total + rel + tfs[j] > n_positions) return SS_EINVAL;
-          for (uint32_t x = 0; x < tfs[j]; x++) {
+          if (total + rel + npos[j] > n_positions) return SS_EINVAL;
+          for (uint32_t x = 0; x < npos[j]; x++) {
             const u64 at = total + rel + x;
             if (x && positions[at] <= positions[at - 1]) return SS_EINVAL;  // ascending inside a field
             pool[at] = ((uint32_t)fields[j] << BM_POS_FIELD_SHIFT) | positions[at];
           }
-          rel += tfs[j];
+          rel += npos[j];
         }
         if (rel >= (1ull << 32)) return SS_ENOTSUP;
         if (w >= s->bm_n_post_pad) return SS_EINVAL;

@@ -95,8 +95,21 @@ def test_phrase_queries_match_oracle(S, O):
     assert int(tm[2]) == osh.search_phrase([2, 0], [0, 1, 0], 10)[2]
     # the raw ABI refuses what it does not offer
     from seekstorm_amd import _native as N
-    with pytest.raises(S.SeekStormHipError):
-        sh.search_lexical_batch(sh.make_queries([[0, 1]], S.QueryType.Phrase, [[2]]), 10)  # NOT terms with a phrase
+    # NOT terms with a phrase (not_query_list applies to every query type, add_result.rs:3440-3497): the phrase's matches minus the
+    # docs of the NOT lists -- against the oracle's full match list
+    for ph, neg in (([0, 1], [2]), ([0, 1, 2], [3]), ([2, 0, 2], [1, 4]), ([3, 4], [0])):
+        uniq = list(dict.fromkeys(ph))
+        od, os_, otot = osh.search_phrase(uniq, [uniq.index(w) for w in ph], n_docs)
+        gone_docs = set()
+        for t in neg:
+            gone_docs |= set(docs[int(offs[t]):int(offs[t + 1])].tolist())
+        keep = [i for i, d in enumerate(od.tolist()) if d not in gone_docs]
+        for rt in (S.ResultType.TopkCount, S.ResultType.Count):
+            doc, score, cnt, tot = sh.search_lexical_batch(sh.make_queries([ph], S.QueryType.Phrase, [neg]), 10, rt)
+            assert int(tot[0]) == len(keep) < otot, (ph, neg, int(tot[0]), len(keep), otot)
+            if rt == S.ResultType.TopkCount:
+                assert cnt[0] == min(10, len(keep)) and np.allclose(score[0][:cnt[0]], os_[keep[:10]], rtol=1e-4)
+                assert not set(doc[0][:cnt[0]].tolist()) & gone_docs
     sh2 = S.Shard(0)
     sh2.upload_lexical(n_docs, dl, offs, docs, tfs)  # no positions
     with pytest.raises(S.SeekStormHipError):
@@ -360,6 +373,108 @@ def test_phrase_queries_on_a_multi_field_index_bin(S, O):
     assert int(a.search_lexical_batch(a.make_queries([[0, 1]], S.QueryType.Phrase), 10)[3][0]) >= 250
     a.close()
     b.close()
+
+
+def test_phrase_queries_over_ngram_keys_of_a_multi_field_index(S, O):
+    """a DEFAULT index with several indexed fields: an n-gram key's record carries the field vector of every component term, then the
+    key's own field vector and positions (index_posting.rs:666-741; reader add_result.rs:1524-1600).  The key's positions go behind its
+    first component term, field by field; phrases whose entries are keys answer like the oracle (so_search_fields_phrase_items) and
+    match the docs the phrase over the single terms matches, with and without a field filter."""
+    from oracle import ref_format as RF
+    from seekstorm_amd.search import idf_f32
+    n_docs, n_fields, longest = 80_000, 3, 1
+    dfs = [18_000, 8_000, 12_000, 2_500]
+    plant = [([0, 1], 0, 250), ([0, 1, 2], 1, 120), ([3, 0, 1], 2, 60), ([0, 1, 3], 1, 70), ([2, 0, 1], 0, 50), ([0, 1, 2, 3], 2, 40)]
+    dl, offs, docs, fields, tfs, positions = _corpus_fields(O, n_docs, n_fields, dfs, 29, plant, [(0, 1, 150)])
+    ent_pos, at = [dict() for _ in dfs], 0  # term -> (doc, field) -> positions
+    for t in range(len(dfs)):
+        for i in range(int(offs[t]), int(offs[t + 1])):
+            ent_pos[t][(int(docs[i]), int(fields[i]))] = positions[at:at + int(tfs[i])].tolist()
+            at += int(tfs[i])
+    doc_fields = [dict() for _ in dfs]          # term -> doc -> [(field, tf)]
+    for t in range(len(dfs)):
+        for (d, f), ps in sorted(ent_pos[t].items()):
+            doc_fields[t].setdefault(d, []).append((f, len(ps)))
+    KEY = lambda t: 1000 * (t + 1) * 8
+    keys = {(0, 1): 0x7000_0000_0000 | 1, (0, 1, 2): 0x7100_0000_0000 | 4}
+    lut = lambda df: int(O.lib().so_int_to_byte4(int(df)))
+    ngram_terms, rows_of = [], {}
+    for words, key in keys.items():
+        rows = {}  # doc -> [(field, positions of the key in the field)]
+        for (d, f), ps in sorted(ent_pos[words[0]].items()):
+            if all((d, f) in ent_pos[w] for w in words[1:]):
+                sets = [set(ent_pos[w][(d, f)]) for w in words]
+                hit = [p_ for p_ in ps if all(p_ + i in sets[i] for i in range(1, len(words)))]
+                if hit:
+                    rows.setdefault(d, []).append((f, hit))
+        rows_of[words] = rows
+        kd, kf, kc, kp, vecs = [], [], [], [], {}
+        for d in sorted(rows):
+            for f, hit in rows[d]:
+                kd.append(d); kf.append(f); kc.append(len(hit)); kp.append(hit)
+            vecs[d] = [doc_fields[w][d] for w in words]
+        ngram_terms.append((key, np.array(kd, np.int64), np.array(kf, np.int64), np.array(kc, np.int64), vecs, [lut(len(doc_fields[w])) for w in words], kp))
+    terms = []
+    for t in range(len(dfs)):
+        a, b = int(offs[t]), int(offs[t + 1])
+        terms.append((KEY(t), docs[a:b].astype(np.int64), fields[a:b].astype(np.int64), tfs[a:b].astype(np.int64),
+                      [ent_pos[t][(int(docs[i]), int(fields[i]))] for i in range(a, b)]))
+    data = RF.write_index_bin(n_docs, dl, terms, np.random.default_rng(4), n_fields=n_fields, longest_field_id=longest, key_head_size=23,
+                              ngram_terms=ngram_terms)
+    ix = S.IndexBin(data, n_fields, key_head_size=23)
+    boost = np.array([1.5, 1.0, 0.75], np.float32)
+    a = S.Shard(0)
+    a.upload_index_bin(ix, boost=boost, positions=True)
+    tid = {t: ix.term_of_key(KEY(t)) for t in range(len(dfs))}
+    ent, idf_of = {}, {}
+    for words, key in keys.items():
+        comp = ix.terms_of_key(key)
+        ent[words] = tuple(t for t, _ in comp)
+        idf_of.update({t: i for t, i in comp})
+    # the oracle's lists: single terms, then one list per component of every key; counts = positions behind every entry
+    o_offs, o_docs, o_f, o_tf, o_cnt, o_pos, o_id = [0], [], [], [], [], [], {}
+    for t in range(len(dfs)):
+        o_id[("t", t)] = len(o_offs) - 1
+        for (d, f), ps in sorted(ent_pos[t].items()):
+            o_docs.append(d); o_f.append(f); o_tf.append(len(ps)); o_cnt.append(len(ps)); o_pos += ps
+        o_offs.append(len(o_docs))
+    for words in keys:
+        for c, w in enumerate(words):
+            o_id[(words, c)] = len(o_offs) - 1
+            for d in sorted(rows_of[words]):
+                own = dict(rows_of[words][d])
+                for f, tf in doc_fields[w][d]:
+                    hit = own.get(f, []) if c == 0 else []
+                    o_docs.append(d); o_f.append(f); o_tf.append(tf); o_cnt.append(len(hit)); o_pos += hit
+            o_offs.append(len(o_docs))
+    AB, ABC = (0, 1), (0, 1, 2)
+    phrases = [[AB, 3], [3, AB], [ABC, 3], [2, AB], [AB, 2]]
+    same_docs_as = [[0, 1, 3], [3, 0, 1], [0, 1, 2, 3], [2, 0, 1], [0, 1, 2]]
+    for filt in ((), (1,), (0, 2)):
+        gq = a.make_queries([[ent[e] if isinstance(e, tuple) else tid[e] for e in ph] for ph in phrases], S.QueryType.Phrase, idf_of=idf_of, field_filter=filt)
+        sq = a.make_queries([[tid[w] for w in ph] for ph in same_docs_as], S.QueryType.Phrase, field_filter=filt)
+        for k in (10, 100):
+            rg = a.search_lexical_batch(gq, k)
+            rs = a.search_lexical_batch(sq, k)
+            for i, ph in enumerate(phrases):
+                uniq, seq, places, idf, at_place = [], [], [], [], 0
+                for e in ph:
+                    lists = [o_id[(e, c)] for c in range(len(e))] if isinstance(e, tuple) else [o_id[("t", e)]]
+                    for c, l in enumerate(lists):
+                        if l not in uniq:
+                            uniq.append(l)
+                            n_l = len({o_docs[j] for j in range(o_offs[l], o_offs[l + 1])})
+                            idf.append(idf_of[ent[e][c]] if isinstance(e, tuple) else float(idf_f32(n_docs, n_l)))
+                    seq.append(uniq.index(lists[0])); places.append(at_place)
+                    at_place += len(lists)
+                od, os_, otot = O.search_fields_phrase_items(n_docs, dl, boost, o_offs, o_docs, o_f, o_tf, o_cnt, o_pos, uniq, seq, places, k, idf=idf,
+                                                             field_filter=filt)
+                assert int(rg[3][i]) == otot, (ph, filt, int(rg[3][i]), otot)
+                assert int(rs[3][i]) == otot, ("the phrase over the single terms matches the same docs", ph, filt)
+                assert rg[2][i] == len(od) and np.allclose(rg[1][i][:len(od)], os_, rtol=1e-4), (ph, filt)
+        if not filt:
+            assert all(int(x) > 0 for x in rg[3])
+    a.close()
 
 
 def test_phrase_queries_take_the_pool_rows_first_on_a_rationed_vocabulary(S, O):

@@ -968,3 +968,49 @@ def test_c_indexer_writes_what_the_restated_python_writer_writes(head, limit):
     for h, docs, tfs, per in terms[::97]:
         d, t = ix.postings(ix.term_of_key(h))
         assert np.array_equal(d, docs) and np.array_equal(t, tfs)
+
+
+@pytest.mark.parametrize("n_fields,longest,nc,limit", [(3, 1, 2, 32768), (2, 0, 3, 32768), (4, 3, 2, 500)])
+def test_multi_field_ngram_key_positions_roundtrip(n_fields, longest, nc, limit):
+    """an n-gram key's record in a multi-field index: the components' field vectors, then the key's own vector and positions
+    (index_posting.rs:666-741) -- restated writer -> decoder: the key's positions come out behind component 0's entries, field by field"""
+    rng = np.random.default_rng(33)
+    n = 1500
+    docs = np.sort(rng.choice(65536, size=n, replace=False))
+    postings, vecs, e_docs, e_fields, e_counts, e_pos = [], {}, [], [], [], []
+    for d in docs:
+        comp_fields = sorted(rng.choice(n_fields, size=int(rng.integers(1, n_fields + 1)), replace=False).tolist())
+        own_fields = sorted(rng.choice(comp_fields, size=int(rng.integers(1, len(comp_fields) + 1)), replace=False).tolist())
+        vecs[int(d)] = [[(f, int(rng.integers(1, 300))) for f in comp_fields]] + \
+                       [[(f, int(rng.integers(1, 40))) for f in sorted(rng.choice(n_fields, size=int(rng.integers(1, n_fields + 1)), replace=False).tolist())]
+                        for _ in range(nc - 1)]
+        for f in own_fields:
+            ps = RF.random_positions(rng, int(rng.integers(1, 6)), 200)
+            e_docs.append(int(d)); e_fields.append(f); e_counts.append(len(ps)); e_pos.append(ps)
+    blk = RF.encode_term_fields(e_docs, e_fields, e_counts, n_fields, longest, rng, positions_limit=limit, ngram_vecs=vecs, positions=e_pos)[0]
+    bid, ctp, cnt, pivot, body = blk
+    assert cnt == n and (limit == 32768 or pivot < cnt)
+    buf = np.frombuffer(body, np.uint8).copy()
+    rb = N.RefBlock(bid, ctp, cnt - 1, pivot, buf.ctypes.data, len(buf))
+    d16 = np.zeros(65536, np.uint16); first = np.zeros(65537, np.uint32)
+    f8 = np.zeros(65536 * n_fields, np.uint8); t16 = np.zeros(65536 * n_fields, np.uint16); np16 = np.zeros(65536 * n_fields, np.uint16)
+    npos = C.c_uint64()
+    N.lib().ss_ref_decode_block_fields_ngram_positions(C.byref(rb), n_fields, longest, nc, N.ptr(d16, N.u16p), N.ptr(first, N.u32p), N.ptr(f8, N.u8p),
+                                                      N.ptr(t16, N.u16p), N.ptr(np16, N.u16p), None, 0, C.byref(npos))
+    pos = np.zeros(max(npos.value, 1), np.uint16)
+    got = N.lib().ss_ref_decode_block_fields_ngram_positions(C.byref(rb), n_fields, longest, nc, N.ptr(d16, N.u16p), N.ptr(first, N.u32p), N.ptr(f8, N.u8p),
+                                                            N.ptr(t16, N.u16p), N.ptr(np16, N.u16p), N.ptr(pos, N.u16p), len(pos), C.byref(npos))
+    assert got == n and np.array_equal(d16[:n], docs)
+    own = {}
+    for d, f, ps in zip(e_docs, e_fields, e_pos):
+        own.setdefault(d, {})[f] = ps
+    want_pos, at = [], 0
+    for i, d in enumerate(docs):
+        ents = vecs[int(d)][0]
+        assert first[i + 1] - first[i] == len(ents)
+        for j, (f, tf) in enumerate(ents):
+            e = first[i] + j
+            ps = own[int(d)].get(f, [])
+            assert f8[e] == f and t16[e] == tf and np16[e] == len(ps), (i, j)
+            want_pos += ps
+    assert pos[:npos.value].tolist() == want_pos
