@@ -81,6 +81,11 @@ int ss_shard_create(int device, ss_shard** out) {
   s->device = device;
   s->co_lex.max_batch = 1024;
   s->co_vec.max_batch = SS_VEC_BATCH;
+  // ONE batch in flight per kind.  A second lane (SS_COALESCE_LANES=2: lexical batches enqueue behind each other while their leaders
+  // stage / distribute in parallel) was built and measured in round 4: the callers split over two batches of half the size, and the
+  // device's fixed cost per batch -- not the host part of a cycle -- is what bounds small batches: T = 8 54 K -> 25 K q/s, T = 64
+  // 186 K -> 156 K, T = 256 318 K -> 327 K (profiles/r4k_lanes.log).  Kept as a switch, off.
+  { const char* e = getenv("SS_COALESCE_LANES"); s->co_lex.n_lanes = (e && atoi(e) == 2) ? 2u : 1u; }
   if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return SS_EDEVICE; }
   *out = s;
   return SS_OK;
@@ -174,8 +179,11 @@ int ss_shard_destroy(ss_shard* s) {
   }
   for (int kx = 0; kx < 2; kx++)
     for (auto& pr : s->prof.pending[kx]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-  if (s->co_lex.h_pin) (void)hipHostFree(s->co_lex.h_pin);
-  if (s->co_vec.h_pin) (void)hipHostFree(s->co_vec.h_pin);
+  for (ss_coalescer* co : {&s->co_lex, &s->co_vec})
+    for (auto& ln : co->lane) {
+      if (ln.h_pin) (void)hipHostFree(ln.h_pin);
+      if (ln.ev) (void)hipEventDestroy(ln.ev);
+    }
   (void)hipStreamDestroy(s->stream);
   delete s;
   return SS_OK;
@@ -1192,6 +1200,28 @@ static int bm25_search_direct(ss_shard* s, uint32_t nq, const ss_bm25_query* q, 
   return SS_OK;
 }
 
+// the same for a coalesced batch on a lane: the shard mutex is held while the batch is ENQUEUED (queries from the lane's pinned staging,
+// kernels, results back into it, the lane's event behind them -- all on s->stream); the wait for the event happens outside, so the next
+// lane's leader can enqueue behind this batch at once
+static int bm25_search_direct_lane(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k, uint32_t rt, uint32_t* out_doc, float* out_score,
+                                   uint32_t* out_count, uint64_t* out_total, hipEvent_t ev) {
+  {
+    std::lock_guard<std::mutex> g(s->mu);
+    if (!s->d_post) return SS_ESTATE;
+    const uint32_t kk = rt == SS_RT_COUNT ? 0 : k;
+    SS_TRY(bm25_search_host_queries(s, nq, q, kk, rt, 0, nullptr));
+    if (kk) {
+      SS_HIP(hipMemcpyAsync(out_doc, s->d_out_doc, (size_t)nq * kk * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+      SS_HIP(hipMemcpyAsync(out_score, s->d_out_score, (size_t)nq * kk * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    }
+    SS_HIP(hipMemcpyAsync(out_count, s->d_out_count, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    SS_HIP(hipMemcpyAsync(out_total, s->d_out_total, (size_t)nq * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
+    SS_HIP(hipEventRecord(ev, s->stream));
+  }
+  SS_HIP(hipEventSynchronize(ev));
+  return SS_OK;
+}
+
 // ------------------------------------------------------------------ coalescing of concurrent callers (group commit)
 static int vec_search_host(ss_shard* s, uint32_t nq, const void* queries, size_t elem, const float* query_scale, uint32_t k,
                            float thr, const ss_ann_mode* mode, uint32_t* out_doc, float* out_score, uint32_t* out_count,
@@ -1254,8 +1284,9 @@ int co_run_vector_one(ss_shard* s, ss_co_req* r) {
 }
 
 // one merged batch: the members' queries back to back, one search, every member's rows copied to its own buffers
-int co_run_batch(ss_shard* s, ss_coalescer& co, bool lexical, const std::vector<ss_co_req*>& batch) {
+int co_run_batch(ss_shard* s, ss_coalescer& co, bool lexical, const std::vector<ss_co_req*>& batch, uint32_t lane_ix) {
   ss_co_req* f = batch[0];
+  ss_coalescer::Lane& ln = co.lane[lane_ix];
   uint32_t total = 0, kk = 0;
   for (ss_co_req* r : batch) { total += r->nq; kk = std::max(kk, r->k); }
   const uint32_t kw = std::max<uint32_t>(kk, 1u);
@@ -1263,20 +1294,21 @@ int co_run_batch(ss_shard* s, ss_coalescer& co, bool lexical, const std::vector<
   auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
   const size_t o_q = 0, o_qs = o_q + al((size_t)total * qbytes), o_doc = o_qs + al((size_t)total * 4), o_sc = o_doc + al((size_t)total * kw * 4),
                o_cnt = o_sc + al((size_t)total * kw * 4), o_tot = o_cnt + al((size_t)total * 4), need = o_tot + al((size_t)total * 8);
-  if (need > co.h_pin_cap) {
-    SS_HIP(hipSetDevice(s->device));
-    if (co.h_pin) (void)hipHostFree(co.h_pin);
-    co.h_pin = nullptr; co.h_pin_cap = 0;
+  SS_HIP(hipSetDevice(s->device));
+  if (need > ln.h_pin_cap) {
+    if (ln.h_pin) (void)hipHostFree(ln.h_pin);
+    ln.h_pin = nullptr; ln.h_pin_cap = 0;
     const size_t cap = std::max<size_t>(need * 2, 1u << 20);
-    SS_HIP(hipHostMalloc((void**)&co.h_pin, cap, hipHostMallocDefault));
-    co.h_pin_cap = cap;
+    SS_HIP(hipHostMalloc((void**)&ln.h_pin, cap, hipHostMallocDefault));
+    ln.h_pin_cap = cap;
   }
-  char* h_q = co.h_pin + o_q;
-  float* h_qs = (float*)(co.h_pin + o_qs);
-  uint32_t* h_doc = (uint32_t*)(co.h_pin + o_doc);
-  float* h_sc = (float*)(co.h_pin + o_sc);
-  uint32_t* h_cnt = (uint32_t*)(co.h_pin + o_cnt);
-  uint64_t* h_tot = (uint64_t*)(co.h_pin + o_tot);
+  if (!ln.ev) SS_HIP(hipEventCreateWithFlags(&ln.ev, hipEventDisableTiming));
+  char* h_q = ln.h_pin + o_q;
+  float* h_qs = (float*)(ln.h_pin + o_qs);
+  uint32_t* h_doc = (uint32_t*)(ln.h_pin + o_doc);
+  float* h_sc = (float*)(ln.h_pin + o_sc);
+  uint32_t* h_cnt = (uint32_t*)(ln.h_pin + o_cnt);
+  uint64_t* h_tot = (uint64_t*)(ln.h_pin + o_tot);
   uint32_t at = 0;
   for (ss_co_req* r : batch) {
     memcpy(h_q + (size_t)at * qbytes, r->q, (size_t)r->nq * qbytes);
@@ -1285,7 +1317,7 @@ int co_run_batch(ss_shard* s, ss_coalescer& co, bool lexical, const std::vector<
   }
   int rc;
   if (lexical)
-    rc = bm25_search_direct(s, total, (const ss_bm25_query*)h_q, kk, f->rt, 0, nullptr, h_doc, h_sc, h_cnt, h_tot);
+    rc = bm25_search_direct_lane(s, total, (const ss_bm25_query*)h_q, kk, f->rt, h_doc, h_sc, h_cnt, h_tot, ln.ev);
   else
     rc = vec_search_host(s, total, h_q, f->elem, f->qscale ? h_qs : nullptr, kk, f->thr, nullptr, h_doc, h_sc, h_cnt, h_tot, nullptr);
   if (rc != SS_OK) return rc;
@@ -1309,8 +1341,14 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
   bool lead;
   {
     std::lock_guard<std::mutex> g(co.mu);
-    lead = !co.leader_active;  // invariant: a non-empty queue always has a leader, or a successor already told to lead
-    if (lead) co.leader_active = true;
+    // a free lane: this thread leads a batch on it at once (nobody in flight: alone, straight away -- a lone caller pays nothing);
+    // invariant: a non-empty queue always has a leader at work, or a successor already told to lead
+    lead = co.leaders < co.n_lanes;
+    if (lead) {
+      co.leaders++;
+      me->lane = co.lane[0].busy ? 1u : 0u;
+      co.lane[me->lane].busy = true;
+    }
     co.queue.push_back(me);
   }
   std::vector<ss_co_req*> batch;
@@ -1331,7 +1369,8 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
       uint32_t want, wait_us;
       {
         std::lock_guard<std::mutex> g(co.mu);
-        want = co.max_wait_us ? co.max_batch : std::min(co.callers_est, co.max_batch);
+        // (several lanes: the callers around are shared between the batches in flight)
+        want = co.max_wait_us ? co.max_batch : std::min(co.callers_est / std::max(co.leaders, 1u), co.max_batch);
         wait_us = co.max_wait_us ? co.max_wait_us : (linger_on && co.callers_est > 1 ? std::min<uint32_t>(1000u, co.last_batch_us / 8u) : 0u);
       }
       if (wait_us) {
@@ -1348,9 +1387,16 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
     {
       std::lock_guard<std::mutex> g(co.mu);
       uint32_t total = 0;
-      ss_co_req* f = co.queue.front();  // the leader's own request; with it every queued request that can share its batch
+      // the leader's own request (told to lead as the queue's front, or just arrived -- then another lane's leader may have taken
+      // requests ahead of it, never its own); with it every queued request that can share its batch
+      ss_co_req* f = me;
+      for (auto it = co.queue.begin(); it != co.queue.end(); ++it)
+        if (*it == me) { co.queue.erase(it); break; }
+      batch.push_back(me);  // first, whatever else fits
+      total = me->nq;
       for (auto it = co.queue.begin(); it != co.queue.end();) {
-        if (co_compatible(f, *it) && (batch.empty() || total + (*it)->nq <= co.max_batch)) {
+        if ((*it)->lane == 0xFFFFFFFFu &&  // (a request that leads a lane itself is not a member of anybody's batch)
+            co_compatible(f, *it) && total + (*it)->nq <= co.max_batch) {
           total += (*it)->nq;
           batch.push_back(*it);
           it = co.queue.erase(it);
@@ -1363,7 +1409,7 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
     }
     if (batch.size() == 1) {
       batch[0]->rc = lexical ? co_run_lexical_one(s, batch[0]) : co_run_vector_one(s, batch[0]);
-    } else if (co_run_batch(s, co, lexical, batch) != SS_OK) {
+    } else if (co_run_batch(s, co, lexical, batch, me->lane) != SS_OK) {
       // somebody's request is at fault (or the device is): every member is re-run alone and gets its own verdict
       for (ss_co_req* r : batch) r->rc = lexical ? co_run_lexical_one(s, r) : co_run_vector_one(s, r);
     }
@@ -1375,8 +1421,11 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
       for (ss_co_req* r : co.queue) queued += r->nq;
       co.callers_est = batch.size() + co.queue.size() > 1 ? members + queued : 0u;
       co.last_batch_us = (uint32_t)std::min<long long>(1000000, std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - batch_t0).count());
-      if (co.queue.empty()) co.leader_active = false;
-      else succ = co.queue.front();
+      // hand the lane to the queue's front unless another lane's leader already told it to lead
+      for (ss_co_req* r : co.queue)
+        if (r->lane == 0xFFFFFFFFu) { succ = r; break; }
+      if (succ) succ->lane = me->lane;
+      else { co.leaders--; co.lane[me->lane].busy = false; }
     }
     if (succ) co_signal(succ, 3u);  // first: the next batch forms while this one's members are being woken
     bool mine = false;

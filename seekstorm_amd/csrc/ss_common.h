@@ -140,20 +140,25 @@ struct ss_co_req {
   uint64_t* out_total = nullptr;
   int rc = 0;
   std::atomic<uint32_t> state{0};   // 0 = pending, 1 = done, 3 = "lead the next batch"; bit 2 (value 4) = its thread sleeps on the futex
+  uint32_t lane = 0xFFFFFFFFu;      // the lane a leader works on (its own on arrival, its predecessor's when told to lead); none: a follower
 };
 struct ss_coalescer {
   std::mutex mu;
   std::deque<ss_co_req*> queue;
-  bool leader_active = false;
+  // LANES (round 4): up to n_lanes batches in flight at once.  Every lane has its own pinned staging and completion event; the device
+  // work of all lanes goes to the shard's ONE stream in the order it was enqueued (so every stream synchronisation elsewhere in the
+  // library still covers it), but a leader holds the shard mutex only while it enqueues and waits for its batch's event outside --
+  // the next leader stages, checks and enqueues its batch while this one runs, and distributes results while the next one runs.
+  uint32_t leaders = 0;             // leaders at work (<= n_lanes); invariant: a non-empty queue has a leader or a successor told to lead
+  uint32_t n_lanes = 1;
+  struct Lane { char* h_pin = nullptr; size_t h_pin_cap = 0; hipEvent_t ev = nullptr; bool busy = false; } lane[2];
   uint32_t max_batch = 0, max_wait_us = 0;
   uint64_t batches = 0, queries = 0;
   // linger: how many callers seem to be around (members of the last batch + what was queued when it finished) and how long that
   // batch took -- the next leader gives the callers the last batch has just released a moment to come back (co_submit)
   uint32_t callers_est = 0, last_batch_us = 0;
-  // host staging of a merged batch, PINNED (hipHostMalloc, grow-only): the copies to and from the device are then real
-  // asynchronous DMA instead of staged pageable copies; only the leader of the moment touches it
-  char* h_pin = nullptr;
-  size_t h_pin_cap = 0;
+  // (host staging of a merged batch: PINNED, hipHostMalloc, grow-only, per lane -- the copies to and from the device are then real
+  // asynchronous DMA instead of staged pageable copies; only the lane's leader of the moment touches it)
 };
 
 // Incremental images (ss_bm25_append_level): the decoded postings of every committed level stay in HBM as they arrived -- (doc, tf)
