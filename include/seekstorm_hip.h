@@ -274,8 +274,9 @@ int ss_bm25_fields_info(ss_shard* s, uint32_t* n_fields, uint32_t* merged_lists,
  * ss_bm25_search_sharded, the coalesced single-query calls): unions -- the dense terms through the ordinary kernels, every doc of a
  * sparse list scored in full by binary-search probes of the query's other lists (north_star's galloping, intersection.rs:352-362),
  * the two lists merged per query; intersections -- the shortest sparse list drives.  Exact counts, tombstones, NOT terms
- * (in a union: dense NOT terms only).  k <= 128; no phrases, field filters or facet filters over sparse terms (SS_ENOTSUP);
- * the device-pointer entry points take dense terms only.  ss_bm25_term_df covers the sparse ids. */
+ * (a union that excludes a SPARSE term is answered on its own, under an exclusion bitmap = tombstones | the list's docs), facet
+ * filters, k <= SS_MAX_K.  No phrases or field filters over sparse terms (SS_ENOTSUP).  The device-pointer entry points take
+ * sparse terms when ops_mask bit 28 says so (one host round trip).  ss_bm25_term_df covers the sparse ids. */
 int ss_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
                           uint32_t* first_term_id_out);
 int ss_bm25_sparse_info(ss_shard* s, uint32_t* n_lists, uint64_t* n_postings, uint64_t* bytes);
@@ -385,7 +386,10 @@ int ss_bm25_search(ss_shard* s, uint32_t n_queries, const ss_bm25_query* queries
  * answered, under the exhaustive strategy or without probe rows, by the 16-bit scan instead of the f32 scan -- 4-10x faster);
  * bit 7 set if some query is a union of several terms under a field filter; bits 24..27 = the most NOT terms any ONE query of the
  * batch has (optional, 0 = not stated: the host then assumes whatever bits 8..15 leave room for beside one scored term, and a
- * TopkCount / Count request with NOT terms under the exhaustive strategy takes the slower f32-tile kernel unless 1 is stated).
+ * TopkCount / Count request with NOT terms under the exhaustive strategy takes the slower f32-tile kernel unless 1 is stated);
+ * bit 28 set if some query may name a term of the SPARSE tier (ss_bm25_append_sparse): the batch is then split into its dense and
+ * sparse parts on the host -- the queries are copied back once (a stream synchronisation), errors are reported as the host-pointer
+ * entry points report them (return code, not per-query flags), the answers are in the device arrays when the call returns.
  * The assertion is CHECKED ON THE DEVICE, query by query, before the search kernels run: a query that contradicts ops_mask
  * (an intersection in a batch declared union-only, more terms than declared, an unprobed term under bit 2, ...) or is
  * malformed (no terms, a term id outside the vocabulary) is answered as an empty query and flagged

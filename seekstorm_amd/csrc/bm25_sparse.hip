@@ -54,14 +54,14 @@ __device__ __forceinline__ uint32_t dense_find(const uint32_t* __restrict__ post
   return 0u;
 }
 
-template <int KPL>
-__global__ void __launch_bounds__(SP_QWAVES * 64) bm25_sparse_kernel(
+template <int KPL, int QW>
+__global__ void __launch_bounds__(QW * 64) bm25_sparse_kernel(
     const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base, const uint32_t* __restrict__ sub_off, uint32_t n_sub,
     uint32_t n_dense, const unsigned long long* __restrict__ sp_base, const unsigned long long* __restrict__ sp_post, uint32_t n_sparse,
     const ss_bm25_query* __restrict__ qs, uint32_t nq, uint32_t k, const uint32_t* __restrict__ del, uint32_t del_words,
     unsigned long long* __restrict__ out_keys /* [nq][64 KPL] */, unsigned long long* __restrict__ out_extra /* [nq] */) {
-  __shared__ unsigned long long wkeys[SP_QWAVES][64 * KPL];
-  __shared__ unsigned long long wcount[SP_QWAVES];
+  __shared__ unsigned long long wkeys[QW][64 * KPL];
+  __shared__ unsigned long long wcount[QW];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t qi = blockIdx.x;  // one workgroup per query
   const ss_bm25_query* __restrict__ Q = qs + qi;
@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(SP_QWAVES * 64) bm25_sparse_kernel(
     if (Q->term[s] < n_dense) continue;
     const uint32_t si = Q->term[s] - n_dense;
     const unsigned long long b0 = sp_base[si], b1 = sp_base[si + 1];
-    for (unsigned long long x = b0 + (unsigned)w * 64u; x < b1; x += 64ull * SP_QWAVES) {
+    for (unsigned long long x = b0 + (unsigned)w * 64u; x < b1; x += 64ull * QW) {
       const bool live0 = x + (unsigned)lane < b1;
       const unsigned long long e = live0 ? sp_post[x + lane] : 0ull;
       const uint32_t doc = (uint32_t)e;
@@ -146,8 +146,8 @@ __global__ void __launch_bounds__(SP_QWAVES * 64) bm25_sparse_kernel(
   __syncthreads();
   if (w != 0) return;
   unsigned long long matched = 0ull;
-  for (int j = 0; j < SP_QWAVES; j++) matched += wcount[j];
-  for (int j = 1; j < SP_QWAVES; j++) {
+  for (int j = 0; j < QW; j++) matched += wcount[j];
+  for (int j = 1; j < QW; j++) {
 #pragma unroll
     for (int r = 0; r < KPL; r++) {
       const unsigned long long key = wkeys[j][r * 64 + lane];
@@ -228,22 +228,58 @@ __global__ void __launch_bounds__(SP_WAVES * 64) bm25_tier_merge_kernel(
   if (lane == 0) { o_count[qi] = cnt; o_total[qi] = total; }
 }
 
+// The exclusion bitmap of ONE query that excludes sparse terms (ss_api.hip bm25_search_tiered_excl): the bitmap in force (tombstones
+// or a facet filter's, or none) with the docs of the query's sparse NOT lists set on top.
+struct SpLists { uint32_t id[SS_MAX_QUERY_TERMS]; uint32_t n; };
+__global__ void sp_excl_init_kernel(const uint32_t* __restrict__ base, uint32_t base_words, uint32_t* __restrict__ out, uint32_t words) {
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < words) out[w] = (base && w < base_words) ? base[w] : 0u;
+}
+__global__ void sp_excl_mark_kernel(const unsigned long long* __restrict__ sp_base, const unsigned long long* __restrict__ sp_post, SpLists L,
+                                    uint32_t* __restrict__ out, uint32_t words) {
+  const uint32_t li = blockIdx.y;
+  if (li >= L.n) return;
+  const unsigned long long b0 = sp_base[L.id[li]], b1 = sp_base[L.id[li] + 1];
+  for (unsigned long long x = b0 + blockIdx.x * blockDim.x + threadIdx.x; x < b1; x += (unsigned long long)gridDim.x * blockDim.x) {
+    const uint32_t doc = (uint32_t)sp_post[x];
+    if ((doc >> 5) < words) atomicOr(out + (doc >> 5), 1u << (doc & 31u));
+  }
+}
+
 }  // namespace
+
+int ssi_bm25_sparse_excl_bits(const ss_shard* s, const uint32_t* d_base_bits, uint32_t base_words, const uint32_t* lists, uint32_t n_lists,
+                              uint32_t* d_out, uint32_t words, hipStream_t st) {
+  if (n_lists > (uint32_t)SS_MAX_QUERY_TERMS) return SS_EINVAL;
+  SpLists L;
+  L.n = n_lists;
+  for (uint32_t i = 0; i < (uint32_t)SS_MAX_QUERY_TERMS; i++) L.id[i] = i < n_lists ? lists[i] : 0u;
+  for (uint32_t i = 0; i < n_lists; i++)
+    if (lists[i] >= s->sp_n) return SS_EINVAL;
+  sp_excl_init_kernel<<<(words + 255) / 256, 256, 0, st>>>(d_base_bits, base_words, d_out, words);
+  if (n_lists)
+    sp_excl_mark_kernel<<<dim3(16, n_lists), 256, 0, st>>>((const unsigned long long*)s->d_sp_base, (const unsigned long long*)s->d_sp_post, L, d_out, words);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
 
 int ssi_bm25_launch_sparse(const ss_shard* s, const ss_bm25_query* d_q, uint32_t nq, uint32_t k, unsigned long long* d_keys,
                            unsigned long long* d_extra, hipStream_t st) {
-  const int KPL = std::max<uint32_t>(k, 1) <= 64 ? 1 : 2;
+  const uint32_t kk = std::max<uint32_t>(k, 1);
+  const int KPL = ssi_bm25_sparse_kpl(kk);
   const uint32_t grid = nq;
   if (nq == 0) return SS_OK;
   const uint32_t* del = s->n_deleted ? s->d_deleted : nullptr;
-  if (KPL == 1)
-    bm25_sparse_kernel<1><<<grid, SP_QWAVES * 64, 0, st>>>(s->d_post, (const unsigned long long*)s->d_term_base, s->d_sub_off, s->bm_n_sub, s->bm_n_terms,
-                                                         (const unsigned long long*)s->d_sp_base, (const unsigned long long*)s->d_sp_post, s->sp_n, d_q, nq, k,
-                                                         del, (uint32_t)s->deleted_words, d_keys, d_extra);
-  else
-    bm25_sparse_kernel<2><<<grid, SP_QWAVES * 64, 0, st>>>(s->d_post, (const unsigned long long*)s->d_term_base, s->d_sub_off, s->bm_n_sub, s->bm_n_terms,
-                                                         (const unsigned long long*)s->d_sp_base, (const unsigned long long*)s->d_sp_post, s->sp_n, d_q, nq, k,
-                                                         del, (uint32_t)s->deleted_words, d_keys, d_extra);
+#define SS_SP(KPL_, QW_)                                                                                                                          \
+  bm25_sparse_kernel<KPL_, QW_><<<grid, QW_ * 64, 0, st>>>(s->d_post, (const unsigned long long*)s->d_term_base, s->d_sub_off, s->bm_n_sub,        \
+                                                         s->bm_n_terms, (const unsigned long long*)s->d_sp_base,                                  \
+                                                         (const unsigned long long*)s->d_sp_post, s->sp_n, d_q, nq, k, del,                       \
+                                                         (uint32_t)s->deleted_words, d_keys, d_extra)
+  if (KPL == 1) SS_SP(1, SP_QWAVES);
+  else if (KPL == 2) SS_SP(2, SP_QWAVES);
+  else if (KPL == 4) SS_SP(4, SP_QWAVES);
+  else SS_SP(16, 4);  // (the waves' lists are merged through LDS: 64 KB hold four of 1024 keys)
+#undef SS_SP
   SS_HIP(hipGetLastError());
   return SS_OK;
 }
@@ -253,14 +289,16 @@ int ssi_bm25_launch_tier_merge(uint32_t nq, uint32_t k, const uint32_t* d_dense_
                                const unsigned long long* d_extra, uint32_t* o_doc, float* o_score, uint32_t* o_count, unsigned long long* o_total,
                                hipStream_t st) {
   const uint32_t kk = std::max<uint32_t>(k, 1);
-  const int KPL = kk <= 64 ? 1 : 2;
+  const int KPL = ssi_bm25_sparse_kpl(kk);
   const uint32_t grid = (nq + SP_WAVES - 1) / SP_WAVES;
-  if (KPL == 1)
-    bm25_tier_merge_kernel<1><<<grid, SP_WAVES * 64, 0, st>>>(nq, k, kk, d_dense_row, d_sparse_row, d_doc, d_score, d_count, d_total, d_keys, d_extra, o_doc,
-                                                             o_score, o_count, o_total);
-  else
-    bm25_tier_merge_kernel<2><<<grid, SP_WAVES * 64, 0, st>>>(nq, k, kk, d_dense_row, d_sparse_row, d_doc, d_score, d_count, d_total, d_keys, d_extra, o_doc,
-                                                             o_score, o_count, o_total);
+#define SS_TM(KPL_)                                                                                                                              \
+  bm25_tier_merge_kernel<KPL_><<<grid, SP_WAVES * 64, 0, st>>>(nq, k, kk, d_dense_row, d_sparse_row, d_doc, d_score, d_count, d_total, d_keys,    \
+                                                              d_extra, o_doc, o_score, o_count, o_total)
+  if (KPL == 1) SS_TM(1);
+  else if (KPL == 2) SS_TM(2);
+  else if (KPL == 4) SS_TM(4);
+  else SS_TM(16);
+#undef SS_TM
   SS_HIP(hipGetLastError());
   return SS_OK;
 }

@@ -170,7 +170,7 @@ int ss_shard_destroy(ss_shard* s) {
   (void)hipStreamSynchronize(s->stream);
   free_vec(s);
   free_bm25(s);
-  void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_deleted, s->d_facets, s->d_filter_bits, s->d_facet_ws, s->d_pool_stage, s->d_tier_ws};
+  void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_deleted, s->d_facets, s->d_filter_bits, s->d_facet_ws, s->d_pool_stage, s->d_tier_ws, s->d_tier_hold, s->d_excl_bits};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   (void)hipDeviceSynchronize();  // searches queued on the callers' own streams may still use their workspaces
   for (auto& kv : s->bm_ws) {
@@ -1057,20 +1057,21 @@ static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_quer
 // dense terms through the ordinary path (together with the batch's all-dense queries: one sub-batch), their sparse lists by the
 // sparse kernel, which scores every doc of a sparse list in full -- and put together per query by bm25_tier_merge_kernel; the
 // answers land in s->d_out_* in the callers' order, like any other batch's.  Caller holds s->mu.
+static int bm25_search_tiered_excl(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, const std::vector<uint32_t>& special);
 static int bm25_search_tiered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt) {
   const uint32_t n_dense = s->bm_n_terms;
   if (s->bm_n_fields != 1) return SS_ENOTSUP;
-  if (kk > 128) return SS_ENOTSUP;  // the two lists of a query are merged in one wave's registers
+  std::vector<uint32_t> special;       // unions with a SPARSE NOT term: answered one by one under a per-query exclusion bitmap
   std::vector<ss_bm25_query> sub;      // the dense sub-batch: all-dense queries as they are, tiered unions reduced to their dense terms
   std::vector<ss_bm25_query> spq;      // the tiered queries, whole, for the sparse kernel
   std::vector<uint32_t> dense_row(nq, 0xFFFFFFFFu), sparse_row(nq, 0xFFFFFFFFu);
   for (uint32_t i = 0; i < nq; i++) {
     const uint32_t op = bm_q_op(q[i].op), n_not = bm_q_nnot(q[i].op), all = q[i].n_terms + n_not;
     if (q[i].n_terms == 0 || all > SS_MAX_QUERY_TERMS) return SS_EINVAL;
-    bool any_sparse = false, sparse_not = false;
+    bool any_sparse = false, sparse_not = false, sparse_pos = false;
     for (uint32_t t = 0; t < all; t++) {
       if (q[i].term[t] >= n_dense + s->sp_n) return SS_EINVAL;
-      if (q[i].term[t] >= n_dense) { any_sparse = true; sparse_not |= t >= q[i].n_terms; }
+      if (q[i].term[t] >= n_dense) { any_sparse = true; sparse_not |= t >= q[i].n_terms; sparse_pos |= t < q[i].n_terms; }
       if (t < q[i].n_terms && !(q[i].idf[t] > 0.0f)) return SS_EINVAL;
       for (uint32_t u = 0; u < t; u++)
         if (q[i].term[u] == q[i].term[t]) return SS_EINVAL;
@@ -1083,7 +1084,8 @@ static int bm25_search_tiered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, 
     if (op != SS_OP_INTERSECTION && op != SS_OP_UNION) return SS_ENOTSUP;  // no phrases over sparse lists
     if (bm_q_field_filter(q[i].op) || bm_q_all_frequent(q[i].op)) return SS_ENOTSUP;
     const bool is_and = op == SS_OP_INTERSECTION && q[i].n_terms > 1;
-    if (sparse_not && !is_and) return SS_ENOTSUP;  // a union's dense part could not honour a sparse NOT list
+    // (a union's dense part cannot probe a sparse NOT list; an intersection is driven by a sparse list -- it needs one)
+    if (sparse_not && (!is_and || !sparse_pos)) special.push_back(i);
     sparse_row[i] = (uint32_t)spq.size();
     spq.push_back(q[i]);
     if (!is_and) {  // the union's dense terms (with its NOT terms) as a query of their own
@@ -1101,8 +1103,9 @@ static int bm25_search_tiered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, 
     }
   }
   SS_HIP(hipSetDevice(s->device));
+  if (!special.empty()) return bm25_search_tiered_excl(s, nq, q, kk, rt, special);
   const uint32_t kw = std::max<uint32_t>(kk, 1), ns = (uint32_t)spq.size(), nd = (uint32_t)sub.size();
-  const int KPL = kw <= 64 ? 1 : 2;
+  const int KPL = ssi_bm25_sparse_kpl(kw);
   SS_TRY(ensure_out(s, std::max<size_t>(nq, nd), kw));  // reserved before the sub-batch runs: its own ensure_out then keeps the buffers
   // workspace: [sparse queries][row maps 2 nq][sparse keys][sparse counts][merged doc | score | count | total]
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -1117,11 +1120,13 @@ static int bm25_search_tiered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, 
     s->tier_ws_cap = need * 2;
   }
   char* W = (char*)s->d_tier_ws;
-  if (nd) SS_TRY(bm25_search_host_queries(s, nd, sub.data(), kk, rt, 0, nullptr));  // -> s->d_out_* rows [0, nd)
-  // (the host vectors are read by synchronous copies: they may die with this frame)
+  // the host vectors are read by synchronous copies (they may die with this frame) -- which do not wait for the stream: a tiered
+  // search still queued (the device-pointer entry point returns early, bm25_search_tiered_excl runs several) reads this workspace
+  SS_HIP(hipStreamSynchronize(s->stream));
   SS_HIP(hipMemcpy(W + o_q, spq.data(), (size_t)ns * sizeof(ss_bm25_query), hipMemcpyHostToDevice));
   SS_HIP(hipMemcpy(W + o_dr, dense_row.data(), (size_t)nq * 4, hipMemcpyHostToDevice));
   SS_HIP(hipMemcpy(W + o_sr, sparse_row.data(), (size_t)nq * 4, hipMemcpyHostToDevice));
+  if (nd) SS_TRY(bm25_search_host_queries(s, nd, sub.data(), kk, rt, 0, nullptr));  // -> s->d_out_* rows [0, nd)
   SS_TRY(ssi_bm25_launch_sparse(s, (const ss_bm25_query*)(W + o_q), ns, kk, (unsigned long long*)(W + o_keys), (unsigned long long*)(W + o_ext), s->stream));
   SS_TRY(ssi_bm25_launch_tier_merge(nq, kk, (const uint32_t*)(W + o_dr), (const uint32_t*)(W + o_sr), s->d_out_doc, s->d_out_score, s->d_out_count,
                                     (const unsigned long long*)s->d_out_total, (const unsigned long long*)(W + o_keys),
@@ -1136,6 +1141,75 @@ static int bm25_search_tiered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, 
   return SS_OK;
 }
 
+// A UNION that excludes a SPARSE term, or an intersection of dense terms that does (add_result.rs:3440-3497 applies NOT lists to every
+// query type): the dense kernels probe NOT lists through directory rows a sparse list does not have.  Such a query -- rare: a rare word after a minus sign -- is answered on
+// its own with the docs of its sparse NOT lists added to the exclusion bitmap the kernels already honour (tombstones, or a facet
+// filter's bitmap): top-k and exact counts then follow from the paths that serve a shard with deleted docs.  The other queries of
+// the batch run together as always; the single answers are put back into their rows.
+static int bm25_search_tiered_excl(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, const std::vector<uint32_t>& special) {
+  const uint32_t kw = std::max<uint32_t>(kk, 1), n_sp = (uint32_t)special.size(), n_dense = s->bm_n_terms;
+  const size_t words = ((size_t)s->bm_n_docs + 31) / 32;
+  SS_TRY(ensure_out(s, nq, kw));
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t h_doc = 0, h_sc = h_doc + al((size_t)n_sp * kw * 4), h_cnt = h_sc + al((size_t)n_sp * kw * 4), h_tot = h_cnt + al((size_t)n_sp * 4),
+               h_need = h_tot + al((size_t)n_sp * 8);
+  if (h_need > s->tier_hold_cap || words > s->excl_words_cap) SS_HIP(hipStreamSynchronize(s->stream));
+  if (h_need > s->tier_hold_cap) {
+    if (s->d_tier_hold) (void)hipFree(s->d_tier_hold);
+    s->d_tier_hold = nullptr; s->tier_hold_cap = 0;
+    SS_HIP(hipMalloc(&s->d_tier_hold, h_need * 2));
+    s->tier_hold_cap = h_need * 2;
+  }
+  if (words > s->excl_words_cap) {
+    if (s->d_excl_bits) (void)hipFree(s->d_excl_bits);
+    s->d_excl_bits = nullptr; s->excl_words_cap = 0;
+    SS_HIP(hipMalloc(&s->d_excl_bits, words * 4));
+    s->excl_words_cap = words;
+  }
+  char* H = (char*)s->d_tier_hold;
+  std::vector<ss_bm25_query> rest(q, q + nq);
+  for (uint32_t j = 0; j < n_sp; j++) {
+    const ss_bm25_query& Q = q[special[j]];
+    const uint32_t np = Q.n_terms, n_not = bm_q_nnot(Q.op);
+    ss_bm25_query R = Q;  // the query without its sparse NOT terms
+    uint32_t lists[SS_MAX_QUERY_TERMS], n_lists = 0, kept = 0;
+    for (uint32_t t = 0; t < n_not; t++) {
+      const uint32_t term = Q.term[np + t];
+      if (term >= n_dense) lists[n_lists++] = term - n_dense;
+      else R.term[np + kept++] = term;
+    }
+    for (uint32_t t = np + kept; t < (uint32_t)SS_MAX_QUERY_TERMS; t++) R.term[t] = 0;
+    R.op = (Q.op & ~0xFF00u) | SS_OP_NOT_TERMS(kept);
+    rest[special[j]] = R;  // keeps the row's place in the batch below; its answer is overwritten
+    const bool had = s->n_deleted != 0;
+    SS_TRY(ssi_bm25_sparse_excl_bits(s, had ? s->d_deleted : nullptr, had ? (uint32_t)s->deleted_words : 0u, lists, n_lists, s->d_excl_bits, (uint32_t)words, s->stream));
+    uint32_t* del = s->d_deleted;
+    const uint64_t dw = s->deleted_words, nd = s->n_deleted;
+    s->d_deleted = s->d_excl_bits; s->deleted_words = words; s->n_deleted = 1;
+    const int rc = bm25_search_host_queries(s, 1, &R, kk, rt, 0, nullptr);
+    s->d_deleted = del; s->deleted_words = dw; s->n_deleted = nd;
+    if (rc != SS_OK) return rc;
+    if (nq == 1) return SS_OK;  // the answer stands in row 0 already
+    if (kk) {
+      SS_HIP(hipMemcpyAsync(H + h_doc + (size_t)j * kw * 4, s->d_out_doc, (size_t)kw * 4, hipMemcpyDeviceToDevice, s->stream));
+      SS_HIP(hipMemcpyAsync(H + h_sc + (size_t)j * kw * 4, s->d_out_score, (size_t)kw * 4, hipMemcpyDeviceToDevice, s->stream));
+    }
+    SS_HIP(hipMemcpyAsync(H + h_cnt + (size_t)j * 4, s->d_out_count, 4, hipMemcpyDeviceToDevice, s->stream));
+    SS_HIP(hipMemcpyAsync(H + h_tot + (size_t)j * 8, s->d_out_total, 8, hipMemcpyDeviceToDevice, s->stream));
+  }
+  SS_TRY(bm25_search_host_queries(s, nq, rest.data(), kk, rt, 0, nullptr));
+  for (uint32_t j = 0; j < n_sp; j++) {
+    const size_t i = special[j];
+    if (kk) {
+      SS_HIP(hipMemcpyAsync(s->d_out_doc + i * kw, H + h_doc + (size_t)j * kw * 4, (size_t)kw * 4, hipMemcpyDeviceToDevice, s->stream));
+      SS_HIP(hipMemcpyAsync(s->d_out_score + i * kw, H + h_sc + (size_t)j * kw * 4, (size_t)kw * 4, hipMemcpyDeviceToDevice, s->stream));
+    }
+    SS_HIP(hipMemcpyAsync(s->d_out_count + i, H + h_cnt + (size_t)j * 4, 4, hipMemcpyDeviceToDevice, s->stream));
+    SS_HIP(hipMemcpyAsync(s->d_out_total + i, H + h_tot + (size_t)j * 8, 8, hipMemcpyDeviceToDevice, s->stream));
+  }
+  return SS_OK;
+}
+
 // the search of ss_bm25_search_filtered / _sharded up to the device lists (s->d_out_*, on s->stream); caller holds s->mu
 static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, uint32_t n_filters,
                                     const ss_facet_filter* filters) {
@@ -1144,7 +1218,8 @@ static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_quer
     for (uint32_t i = 0; i < nq && !any_sparse; i++)
       for (uint32_t t = 0; t < std::min<uint32_t>(q[i].n_terms + bm_q_nnot(q[i].op), SS_MAX_QUERY_TERMS); t++)
         any_sparse |= q[i].term[t] >= s->bm_n_terms && q[i].term[t] < s->bm_n_terms + s->sp_n;
-    if (any_sparse) return n_filters ? (int)SS_ENOTSUP : bm25_search_tiered(s, nq, q, kk, rt);
+    // (a facet filter: the sparse kernel reads the same exclusion bitmap as the dense ones)
+    if (any_sparse) return with_facet_filter(s, n_filters, filters, s->stream, [&]() { return bm25_search_tiered(s, nq, q, kk, rt); });
   }
   SS_TRY(ssi_bm25_ensure_probe_rows(s, nq, q, s->stream));
   if (nq > 1) {  // phrase queries have a kernel of their own: a batch that mixes them with others runs as two, answers back in place
@@ -1698,6 +1773,23 @@ int ss_bm25_search_filtered_dev(ss_shard* s, uint32_t nq, const ss_bm25_query* d
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   hipStream_t st = stream ? (hipStream_t)stream : s->stream;
+  if ((ops_mask & (1u << 28)) && s->sp_n) {
+    // the batch may name terms of the SPARSE tier: splitting it into its dense and sparse parts is host work, so the queries make
+    // one trip to the host (the cost the header states); the answers are left in the caller's device arrays, ordered on `st`
+    const uint32_t kk = rt == SS_RT_COUNT ? 0 : k, kw = std::max<uint32_t>(kk, 1);
+    std::vector<ss_bm25_query> hq(nq);
+    SS_HIP(hipMemcpyAsync(hq.data(), d_q, (size_t)nq * sizeof(ss_bm25_query), hipMemcpyDeviceToHost, st));
+    SS_HIP(hipStreamSynchronize(st));
+    SS_TRY(bm25_search_host_queries(s, nq, hq.data(), kk, rt, n_filters, filters));
+    if (kk) {
+      SS_HIP(hipMemcpyAsync(d_out_doc, s->d_out_doc, (size_t)nq * kw * 4, hipMemcpyDeviceToDevice, s->stream));
+      SS_HIP(hipMemcpyAsync(d_out_score, s->d_out_score, (size_t)nq * kw * 4, hipMemcpyDeviceToDevice, s->stream));
+    }
+    SS_HIP(hipMemcpyAsync(d_out_count, s->d_out_count, (size_t)nq * 4, hipMemcpyDeviceToDevice, s->stream));
+    SS_HIP(hipMemcpyAsync(d_out_total, s->d_out_total, (size_t)nq * 8, hipMemcpyDeviceToDevice, s->stream));
+    if (st != s->stream) SS_HIP(hipStreamSynchronize(s->stream));
+    return SS_OK;
+  }
   return with_facet_filter(s, n_filters, filters, st, [&]() {
     return ssi_bm25_search(s, nq, d_q, rt == SS_RT_COUNT ? 0 : k, rt, d_out_doc, d_out_score, d_out_count, d_out_total,
                            (ops_mask & 1u) != 0, (ops_mask & 2u) != 0 || (ops_mask & 3u) == 0,

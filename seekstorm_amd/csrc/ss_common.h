@@ -334,6 +334,10 @@ struct ss_shard {
   std::vector<uint64_t> h_sp_base;   // host copy of d_sp_base (posting counts = the df the host needs for idf)
   void* d_tier_ws = nullptr;         // workspace of a tiered search (sub-queries, row maps, sparse lists, merged answers), grow-only
   size_t tier_ws_cap = 0;
+  void* d_tier_hold = nullptr;       // answers of the queries a tiered batch runs one by one (unions with a sparse NOT term), grow-only
+  size_t tier_hold_cap = 0;
+  uint32_t* d_excl_bits = nullptr;   // per-query exclusion bitmap of such a query: tombstones | docs of its sparse NOT lists
+  size_t excl_words_cap = 0;
   // incremental image (ss_bm25_append_level)
   ss_block_pool blocks;              // the image arrays of incremental images come from here
   ss_block_pool* pool = nullptr;     // set on the scratch shard a rebuild fills: its image arrays are taken from the owner's pool
@@ -486,8 +490,12 @@ int ssi_bm25_rebuild_from_raw(const ss_shard* s, const std::vector<ss_raw_level>
                               ss_shard* img, hipStream_t st, bool one_shot = false);
 // ---- sparse tier (synth.hip: append; bm25_sparse.hip: kernels)
 int ssi_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs);
+// keys per lane of the sparse tier's top-k lists (rows of 64 * KPL keys), as the dense kernels choose theirs
+inline int ssi_bm25_sparse_kpl(uint32_t kk) { return kk <= 64 ? 1 : kk <= 128 ? 2 : kk <= 256 ? 4 : 16; }
 int ssi_bm25_launch_sparse(const ss_shard* s, const ss_bm25_query* d_q, uint32_t nq, uint32_t k, unsigned long long* d_keys,
                            unsigned long long* d_extra, hipStream_t st);
+int ssi_bm25_sparse_excl_bits(const ss_shard* s, const uint32_t* d_base_bits, uint32_t base_words, const uint32_t* lists, uint32_t n_lists,
+                              uint32_t* d_out, uint32_t words, hipStream_t st);
 int ssi_bm25_launch_tier_merge(uint32_t nq, uint32_t k, const uint32_t* d_dense_row, const uint32_t* d_sparse_row, const uint32_t* d_doc,
                                const float* d_score, const uint32_t* d_count, const unsigned long long* d_total, const unsigned long long* d_keys,
                                const unsigned long long* d_extra, uint32_t* o_doc, float* o_score, uint32_t* o_count, unsigned long long* o_total,

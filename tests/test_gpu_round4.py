@@ -1,6 +1,8 @@
 """Round 4 (-m gpu): NOT lists, tombstones and exact counts on the 16-bit tile of the exhaustive strategy
 (bm25_scan16.hip: candidate-path exclusions, EXCL instances) -- against the oracle and, bit for bit, against the f32-tile
 kernel they replace (SS_BM25_EXHAUSTIVE_F32)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -305,3 +307,127 @@ def test_clustered_generator_device_equals_oracle(S, O):
                 _check_topk(res[N.BM25_AUTO][0][i], res[N.BM25_AUTO][1][i], res[N.BM25_AUTO][2][i], od, os_)
     finally:
         a.close(); b.close()
+
+
+def _tiered_shard(S, O, n_docs=150_000, seed=21):
+    """a dense image of 5 lists + 9 sparse lists that overlap each other and the dense lists; the oracle holds all 14 as ordinary lists"""
+    rng = np.random.default_rng(seed)
+    dl = O.lex_doclen(n_docs)
+    offs, docs, tfs = [0], [], []
+    for df in (0.004, 0.02, 0.07, 0.15, 0.33):
+        d = np.sort(rng.choice(n_docs, int(df * n_docs), replace=False)).astype(np.uint32)
+        docs.append(d); tfs.append(np.minimum(rng.geometric(0.6, len(d)), 60).astype(np.uint16)); offs.append(offs[-1] + len(d))
+    nd = len(offs) - 1
+    hot = np.sort(rng.choice(n_docs, 6000, replace=False))
+    sp_n = [2, 50, 400, 1500, 3000, 9, 65, 2200, 700]
+    s_offs, s_docs, s_tfs = [0], [], []
+    for n in sp_n:
+        d = np.sort(rng.choice(hot, n, replace=False)).astype(np.uint32)
+        s_docs.append(d); s_tfs.append(np.minimum(rng.geometric(0.5, n), 30).astype(np.uint16)); s_offs.append(s_offs[-1] + n)
+    d_offs, d_docs, d_tfs = np.asarray(offs, np.uint64), np.concatenate(docs), np.concatenate(tfs)
+    s_offs, s_docs, s_tfs = np.asarray(s_offs, np.uint64), np.concatenate(s_docs), np.concatenate(s_tfs)
+    sh = S.Shard(0)
+    sh.upload_lexical(n_docs, dl, d_offs, d_docs, d_tfs)
+    assert sh.append_sparse(s_offs, s_docs, s_tfs) == nd
+    osh = O.Shard(n_docs, dl, np.concatenate([d_offs, d_offs[-1] + s_offs[1:]]), np.concatenate([d_docs, s_docs]), np.concatenate([d_tfs, s_tfs]))
+    return sh, osh, nd, len(sp_n), hot, n_docs
+
+
+def _check_against(osh, O, S, out, cases, op, k, rt):
+    d, s_, c, t = out
+    for i, (terms, nots) in enumerate(cases):
+        od, os_, otot = osh.search_exhaustive(terms, op, k, not_terms=nots)
+        assert int(t[i]) == otot, (op, k, i, terms, nots, int(t[i]), otot)
+        if rt == S.ResultType.Count:
+            continue
+        assert c[i] == len(od), (op, k, i, terms, nots, int(c[i]), len(od))
+        assert np.allclose(s_[i, :c[i]], os_, rtol=1e-4), (op, k, i, terms, nots)
+        if len(od) < k:
+            assert set(d[i, :c[i]].tolist()) == set(int(x) for x in od)
+
+
+def test_sparse_tier_not_terms_in_unions_large_k_and_facet_filters(S, O):
+    """the sparse tier next to the dense tier's abilities: a UNION that excludes a sparse term (alone and inside a batch, with dense NOT
+    terms beside it, on a shard with tombstones), k up to SS_MAX_K, facet filters over queries naming sparse terms -- against the
+    oracle holding every list as an ordinary list"""
+    from seekstorm_amd import _native as N
+    sh, osh, nd, ns, hot, n_docs = _tiered_shard(S, O)
+    rng = np.random.default_rng(4)
+    U, A = S.QueryType.Union, S.QueryType.Intersection
+    # unions with sparse NOT terms: single calls, then a batch mixing them with ordinary queries
+    cases = [([3, nd + 3], [nd + 4]), ([4, 2], [nd + 4]), ([nd + 7, nd + 2, 1], [nd + 3, 0]), ([2], [nd + 4, nd + 7]), ([nd + 4], [nd + 7]),
+             ([4, 3, 2], [nd + 4, 1, nd + 8])]
+    for strat in (N.BM25_AUTO, N.BM25_EXHAUSTIVE):
+        sh.set_strategy(strat)
+        for gone in ([], [int(x) for x in hot[::4]]):
+            sh.set_deleted(gone); osh.set_deleted(gone)
+            for k in (10, 100):
+                for rt in (S.ResultType.TopkCount, S.ResultType.Topk, S.ResultType.Count):
+                    for terms, nots in cases:
+                        out = sh.search_lexical_batch(sh.make_queries([terms], U, [nots]), k, rt, reference_shortcuts=False)
+                        if rt != S.ResultType.Topk:
+                            _check_against(osh, O, S, out, [(terms, nots)], O.OP_OR, k, rt)
+                        else:
+                            od, os_, _ = osh.search_exhaustive(terms, O.OP_OR, k, not_terms=nots)
+                            assert out[2][0] == len(od) and np.allclose(out[1][0, :len(od)], os_, rtol=1e-4)
+                    mixed = [([0, 1, 2], []), cases[0], ([nd + 4, 3], []), cases[2], ([4], [2]), cases[3], ([1, nd + 6], [3])]
+                    if rt != S.ResultType.Topk:
+                        out = sh.search_lexical_batch(sh.make_queries([c[0] for c in mixed], U, [c[1] for c in mixed]), k, rt, reference_shortcuts=False)
+                        _check_against(osh, O, S, out, mixed, O.OP_OR, k, rt)
+    sh.set_strategy(N.BM25_AUTO)
+    sh.set_deleted([]); osh.set_deleted([])
+    # k beyond 128: the lists of both parts are merged at any k the dense tier serves
+    big = [([nd + 4, 3], []), ([nd + 3, nd + 7, 2], []), ([4, nd + 8], [1]), ([nd + 4], []), ([nd + 4, nd + 3], []), ([0, 1], [])]
+    for k in (200, 256, 700, 1024):
+        for op, qt in ((O.OP_OR, U), (O.OP_AND, A)):
+            out = sh.search_lexical_batch(sh.make_queries([c[0] for c in big], qt, [c[1] for c in big]), k, S.ResultType.TopkCount, reference_shortcuts=False)
+            _check_against(osh, O, S, out, big, op, k, S.ResultType.TopkCount)
+    # facet filters: the sparse kernel honours the filter's bitmap like the dense ones
+    val = rng.integers(0, 100, n_docs).astype(np.uint8)
+    sh.upload_facets(val.reshape(n_docs, 1))
+    keep = (val >= 20) & (val < 70)
+    gone = [int(x) for x in hot[1::5]]
+    sh.set_deleted(gone)
+    osh.set_deleted(sorted(set(np.nonzero(~keep)[0].tolist()) | set(gone)))
+    fcases = [([nd + 4, 3], []), ([nd + 3, nd + 7, 2], [1]), ([nd + 4, nd + 7], []), ([2, 3], [nd + 4]), ([nd + 2], []), ([4, nd + 4], [nd + 7, 0])]
+    for op, qt in ((O.OP_OR, U), (O.OP_AND, A)):
+        for rt in (S.ResultType.TopkCount, S.ResultType.Count):
+            out = sh.search_lexical_batch(sh.make_queries([c[0] for c in fcases], qt, [c[1] for c in fcases]), 10, rt, reference_shortcuts=False,
+                                          facet_filter=[(0, "u8", 20, 70)])
+            _check_against(osh, O, S, out, fcases, op, 10, rt)
+            if rt != S.ResultType.Count:
+                assert all(keep[int(x)] for i in range(len(fcases)) for x in out[0][i, :out[2][i]])
+    # the next unfiltered call sees the tombstones only
+    osh.set_deleted(gone)
+    out = sh.search_lexical_batch(sh.make_queries([[nd + 4, 3]], U), 10, reference_shortcuts=False)
+    _check_against(osh, O, S, out, [([nd + 4, 3], [])], O.OP_OR, 10, S.ResultType.TopkCount)
+    sh.close()
+
+
+def test_sparse_terms_through_the_device_pointer_entry_point(S, O):
+    """ss_bm25_search_dev with ops_mask bit 28: a device-resident batch naming sparse terms is split on the host (one round trip) and
+    answered into the caller's device arrays; without the bit a sparse term id is outside the dense vocabulary and flagged"""
+    import torch
+    from seekstorm_amd import _native as N
+    sh, osh, nd, ns, hot, n_docs = _tiered_shard(S, O, n_docs=80_000, seed=9)
+    cases = [([nd + 4, 3], []), ([0, 1, 2], []), ([nd + 3, nd + 7, 2], [1]), ([2, 3], [nd + 4]), ([nd + 1], [])]
+    q = sh.make_queries([c[0] for c in cases], S.QueryType.Union, [c[1] for c in cases])
+    nq, k = len(cases), 10
+    qd = torch.from_numpy(q.view(np.uint8).copy()).cuda()
+    doc = torch.zeros((nq, k), dtype=torch.int32, device="cuda"); score = torch.zeros((nq, k), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(nq, dtype=torch.int32, device="cuda"); tot = torch.zeros(nq, dtype=torch.int64, device="cuda")
+    st = torch.cuda.Stream()
+    for stream in (None, C.c_void_p(st.cuda_stream)):
+        ops = 2 | (4 << 8) | (3 << 16) | (1 << 28)
+        N.check(N.lib().ss_bm25_search_dev(sh._h, nq, qd.data_ptr(), k, N.RT_TOPKCOUNT, ops, doc.data_ptr(), score.data_ptr(), cnt.data_ptr(),
+                                           tot.data_ptr(), stream), "ss_bm25_search_dev")
+        torch.cuda.synchronize()
+        out = (doc.cpu().numpy().view(np.uint32), score.cpu().numpy(), cnt.cpu().numpy().view(np.uint32), tot.cpu().numpy().view(np.uint64))
+        _check_against(osh, O, S, out, cases, O.OP_OR, k, S.ResultType.TopkCount)
+        doc.zero_(); score.zero_(); cnt.zero_(); tot.zero_()
+    N.check(N.lib().ss_bm25_search_dev(sh._h, nq, qd.data_ptr(), k, N.RT_TOPKCOUNT, 2 | (4 << 8) | (3 << 16), doc.data_ptr(), score.data_ptr(),
+                                       cnt.data_ptr(), tot.data_ptr(), None), "ss_bm25_search_dev")
+    torch.cuda.synchronize()
+    flagged = cnt.cpu().numpy().view(np.uint32) == 0xFFFFFFFF
+    assert flagged.tolist() == [True, False, True, True, True]
+    sh.close()
