@@ -269,7 +269,7 @@ int ss_bm25_fields_info(ss_shard* s, uint32_t* n_fields, uint32_t* merged_lists,
  * list: 9.8 KB at 10 M docs, whatever the list's length), no probe row; 8 bytes per posting.  A real vocabulary holds millions of
  * keys, almost all rare (key_count per segment, index.rs:3419-3740): they go here, the lists that cost query time stay in the
  * dense image.  Appends n_lists lists (CSR over offs[n_lists + 1]: ascending doc ids, tf >= 1) to an image with ONE indexed
- * field; sparse list i of the call becomes term *first_term_id_out + i (ids continue behind the dense terms and earlier appends).
+ * field (several: ss_bm25_append_sparse_fields); sparse list i of the call becomes term *first_term_id_out + i (ids continue behind the dense terms and earlier appends).
  * A query may mix dense and sparse terms through the host-pointer entry points (ss_bm25_search[_filtered without filters],
  * ss_bm25_search_sharded, the coalesced single-query calls): unions -- the dense terms through the ordinary kernels, every doc of a
  * sparse list scored in full by binary-search probes of the query's other lists (north_star's galloping, intersection.rs:352-362),
@@ -279,6 +279,13 @@ int ss_bm25_fields_info(ss_shard* s, uint32_t* n_fields, uint32_t* merged_lists,
  * sparse terms when ops_mask bit 28 says so (one host round trip).  ss_bm25_term_df covers the sparse ids. */
 int ss_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
                           uint32_t* first_term_id_out);
+/* ... on an image with SEVERAL indexed fields (and merged lists, ss_bm25_fields_info): the entries (doc, field, tf) of every rare
+ * term, sorted by (doc, field) as ss_bm25_upload_fields takes them.  The tier keeps a term's MERGED list -- every doc once, weighted
+ * sum_f boost_f * tf (K + 1) / (tf + comp[len_f]) -- which is what a query without a field filter reads of a dense term as well;
+ * a field filter over a sparse term stays SS_ENOTSUP.  SS_ENOTSUP too when a weight falls outside the range the dense merged lists
+ * fixed the weight code to (boosts / lengths unlike anything in the dense image). */
+int ss_bm25_append_sparse_fields(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
+                                 const uint16_t* tfs, uint32_t* first_term_id_out);
 int ss_bm25_sparse_info(ss_shard* s, uint32_t* n_lists, uint64_t* n_postings, uint64_t* bytes);
 /* INCREMENTAL COMMIT (commit.rs:142-148 commit -> warmup, 264-369; index.rs:3796 -- the "(re)build device image" seam after a commit).
  * The reference commits one 65 536-doc level at a time.  ss_bm25_append_level hands over the decoded postings of ONE level -- the

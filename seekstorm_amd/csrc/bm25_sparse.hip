@@ -57,7 +57,9 @@ __device__ __forceinline__ uint32_t dense_find(const uint32_t* __restrict__ post
 template <int KPL, int QW>
 __global__ void __launch_bounds__(QW * 64) bm25_sparse_kernel(
     const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base, const uint32_t* __restrict__ sub_off, uint32_t n_sub,
-    uint32_t n_dense, const unsigned long long* __restrict__ sp_base, const unsigned long long* __restrict__ sp_post, uint32_t n_sparse,
+    uint32_t n_dense, uint32_t n_lists /* lists per dense term; > 1: the last one is the MERGED list, the one read here */,
+    float idf_scale /* the merged lists' scale (d_boost[n_lists - 1]); one indexed field: unused */,
+    const unsigned long long* __restrict__ sp_base, const unsigned long long* __restrict__ sp_post, uint32_t n_sparse,
     const ss_bm25_query* __restrict__ qs, uint32_t nq, uint32_t k, const uint32_t* __restrict__ del, uint32_t del_words,
     unsigned long long* __restrict__ out_keys /* [nq][64 KPL] */, unsigned long long* __restrict__ out_extra /* [nq] */) {
   __shared__ unsigned long long wkeys[QW][64 * KPL];
@@ -113,7 +115,7 @@ __global__ void __launch_bounds__(QW * 64) bm25_sparse_kernel(
             // a union scores a doc under the FIRST sparse list of the query that holds it
             if (code && !is_and && (uint32_t)t < s && (uint32_t)t < nt) live = false;
           } else {
-            code = dense_find(post, term_base, sub_off, n_sub, term, doc);
+            code = dense_find(post, term_base, sub_off, n_sub, term * n_lists + (n_lists - 1u), doc);
             if (code && (uint32_t)t < nt) in_dense = true;
           }
         }
@@ -132,7 +134,7 @@ __global__ void __launch_bounds__(QW * 64) bm25_sparse_kernel(
         float score = 0.f;
 #pragma unroll
         for (int t = 0; t < SS_MAX_QUERY_TERMS; t++)
-          if ((uint32_t)t < nt && ((pres >> t) & 1u)) score = fmaf(Q->idf[t], wv[t], score);
+          if ((uint32_t)t < nt && ((pres >> t) & 1u)) score = fmaf(n_lists > 1u ? idf_scale * Q->idf[t] : Q->idf[t], wv[t], score);  // bm_expand_kernel's idf
         unsigned long long key = (live && score > 0.f) ? (((unsigned long long)__float_as_uint(score) << 32) | (unsigned long long)(0xFFFFFFFFu - doc)) : 0ull;
         key = key > T.worst ? key : 0ull;
         if (__ballot(key != 0ull)) T = bm_offer_lane_keys<KPL>(T, key, k, nullptr);
@@ -270,9 +272,11 @@ int ssi_bm25_launch_sparse(const ss_shard* s, const ss_bm25_query* d_q, uint32_t
   const uint32_t grid = nq;
   if (nq == 0) return SS_OK;
   const uint32_t* del = s->n_deleted ? s->d_deleted : nullptr;
+  const float idf_scale = s->bm_n_fields > 1 && s->h_boost.size() == s->bm_n_fields ? s->h_boost[s->bm_n_fields - 1] : 1.0f;
 #define SS_SP(KPL_, QW_)                                                                                                                          \
   bm25_sparse_kernel<KPL_, QW_><<<grid, QW_ * 64, 0, st>>>(s->d_post, (const unsigned long long*)s->d_term_base, s->d_sub_off, s->bm_n_sub,        \
-                                                         s->bm_n_terms, (const unsigned long long*)s->d_sp_base,                                  \
+                                                         s->bm_n_terms / s->bm_n_fields, s->bm_n_fields, idf_scale,                               \
+                                                         (const unsigned long long*)s->d_sp_base,                                                 \
                                                          (const unsigned long long*)s->d_sp_post, s->sp_n, d_q, nq, k, del,                       \
                                                          (uint32_t)s->deleted_words, d_keys, d_extra)
   if (KPL == 1) SS_SP(1, SP_QWAVES);

@@ -793,7 +793,7 @@ extern "C" int ss_index_bin_filter(ss_index_bin* ix, uint64_t min_posting_count,
 // one per tier (*n_dense_out = where the second starts).  The components of an n-gram key stay consecutive inside their tier.
 extern "C" int ss_index_bin_tier(ss_index_bin* ix, uint64_t dense_min_posting_count, uint32_t* n_dense_out) {
   if (!ix) return SS_EINVAL;
-  if (ix->n_fields > 1) return SS_ENOTSUP;  // the sparse tier holds single-field images
+  // (several indexed fields: the sparse tier takes the rare keys' merged lists -- an image whose boosts rule merged lists out refuses them)
   const std::vector<uint64_t> n = index_bin_term_counts(ix);
   std::vector<uint32_t> order;
   order.reserve(ix->keys.size());
@@ -948,22 +948,20 @@ extern "C" int ss_index_bin_term_postings(const ss_index_bin* ix, uint32_t term,
 
 namespace {
 // multi-field index: (doc, field, tf) entries of every term, doclen rearranged to [field][doc]
-int upload_index_bin_fields(ss_shard* s, const ss_index_bin* ix, const float* boost, bool with_positions) {
+// the entries (doc, field, tf) of the keys [t0, t1), CSR over offs [t1 - t0 + 1]
+int decode_fields_range(const ss_index_bin* ix, uint32_t t0, uint32_t t1, std::vector<uint64_t>& offs, std::vector<uint32_t>& docs,
+                        std::vector<uint8_t>& fields, std::vector<uint16_t>& tfs, std::vector<uint16_t>* pos, std::vector<uint16_t>* npos) {
   const uint32_t F = ix->n_fields;
-  std::vector<uint16_t> pos, npos;
-  std::vector<uint64_t> offs(ix->keys.size() + 1, 0);
-  std::vector<uint32_t> docs;
-  std::vector<uint8_t> fields;
-  std::vector<uint16_t> tfs;
   std::vector<uint16_t> d16(65536), t16((size_t)65536 * F);
   std::vector<uint32_t> first(65537);
   std::vector<uint8_t> f8((size_t)65536 * F);
-  for (uint32_t t = 0; t < ix->keys.size(); t++) {
-    offs[t] = docs.size();
+  offs.assign((size_t)(t1 - t0) + 1, 0);
+  for (uint32_t t = t0; t < t1; t++) {
+    offs[t - t0] = docs.size();
     for (uint64_t bi = ix->term_block_off[t]; bi < ix->term_block_off[t + 1]; bi++) {
       const ss_ref_block& b = ix->blocks[bi].b;
       const int n = decode_block_fields(&b, F, ix->longest_field_id, ix->blocks[bi].n_comp, ix->blocks[bi].comp, d16.data(), first.data(),
-                                        f8.data(), t16.data(), with_positions ? &pos : nullptr, with_positions ? &npos : nullptr);
+                                        f8.data(), t16.data(), pos, npos);
       if (n < 0) return n;
       for (int i = 0; i < n; i++) {
         const uint64_t doc = ((uint64_t)b.block_id << 16) | d16[i];
@@ -976,7 +974,21 @@ int upload_index_bin_fields(ss_shard* s, const ss_index_bin* ix, const float* bo
       }
     }
   }
-  offs[ix->keys.size()] = docs.size();
+  offs[t1 - t0] = docs.size();
+  return SS_OK;
+}
+
+int upload_index_bin_fields(ss_shard* s, const ss_index_bin* ix, const float* boost, bool with_positions) {
+  const uint32_t F = ix->n_fields;
+  const uint32_t n_all = (uint32_t)ix->keys.size(), n_dense = std::min<uint32_t>(ix->n_dense, n_all);  // ss_index_bin_tier
+  if (n_dense == 0) return SS_EINVAL;
+  std::vector<uint16_t> pos, npos;
+  std::vector<uint64_t> offs;
+  std::vector<uint32_t> docs;
+  std::vector<uint8_t> fields;
+  std::vector<uint16_t> tfs;
+  int rc = decode_fields_range(ix, 0, n_dense, offs, docs, fields, tfs, with_positions ? &pos : nullptr, with_positions ? &npos : nullptr);
+  if (rc) return rc;
   std::vector<uint8_t> doclen((size_t)F * ix->n_docs);
   for (uint32_t f = 0; f < F; f++)
     for (size_t l = 0; l < ix->doclen.size(); l++) {
@@ -986,10 +998,20 @@ int upload_index_bin_fields(ss_shard* s, const ss_index_bin* ix, const float* bo
                   (size_t)std::min<uint64_t>(65536u, ix->n_docs - d0));
     }
   if (with_positions)
-    return ssi_bm25_upload_fields_positions(s, ix->n_docs, F, doclen.data(), boost, (uint32_t)ix->keys.size(), offs.data(), docs.data(),
-                                            fields.data(), tfs.data(), ix->positions_sum, pos.data(), pos.size(), npos.data());
-  return ssi_bm25_upload_fields(s, ix->n_docs, F, doclen.data(), boost, (uint32_t)ix->keys.size(), offs.data(), docs.data(),
-                                fields.data(), tfs.data(), ix->positions_sum);
+    rc = ssi_bm25_upload_fields_positions(s, ix->n_docs, F, doclen.data(), boost, n_dense, offs.data(), docs.data(),
+                                          fields.data(), tfs.data(), ix->positions_sum, pos.data(), pos.size(), npos.data());
+  else
+    rc = ssi_bm25_upload_fields(s, ix->n_docs, F, doclen.data(), boost, n_dense, offs.data(), docs.data(), fields.data(), tfs.data(),
+                                ix->positions_sum);
+  if (rc || n_dense == n_all) return rc;
+  // the rare keys: their entries decoded the same way, their merged lists appended to the sparse tier (ids continue behind the dense ones)
+  std::vector<uint64_t> r_offs;
+  std::vector<uint32_t> r_docs;
+  std::vector<uint8_t> r_fields;
+  std::vector<uint16_t> r_tfs;
+  rc = decode_fields_range(ix, n_dense, n_all, r_offs, r_docs, r_fields, r_tfs, nullptr, nullptr);
+  if (rc) return rc;
+  return ss_bm25_append_sparse_fields(s, n_all - n_dense, r_offs.data(), r_docs.data(), r_fields.data(), r_tfs.data(), nullptr);
 }
 }  // namespace
 

@@ -161,7 +161,7 @@ static void free_bm25(ss_shard* s) {
   s->probe_pool_begin = 0; s->probe_pool_rows = 0; s->pool_list.clear(); s->pool_tick.clear();
   s->d_probe = nullptr; s->d_probe_z = nullptr; s->d_probe_row = nullptr; s->h_probe_row.clear(); s->bm_probe_rows = 0; s->d_umax = nullptr; s->d_submax = nullptr; s->d_pos = nullptr; s->d_pos32 = nullptr; s->d_pos_off = nullptr; s->d_pos_base = nullptr;
   s->bm_n_docs = 0; s->bm_n_terms = 0; s->bm_n_sub = 0; s->bm_n_post = 0; s->bm_n_fields = 1; s->bm_merged = false; s->d_boost = nullptr;
-  s->h_df.clear(); s->h_df_real.clear(); s->bm_n_post_pad = 0; s->bm_partmax = false;
+  s->h_df.clear(); s->h_df_real.clear(); s->h_boost.clear(); s->bm_n_post_pad = 0; s->bm_partmax = false;
 }
 
 int ss_shard_destroy(ss_shard* s) {
@@ -430,6 +430,7 @@ int ssi_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, cons
       if (hipMalloc(&s->d_boost, bb.size() * sizeof(float)) != hipSuccess ||
           hipMemcpy(s->d_boost, bb.data(), bb.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = SS_EDEVICE;
       s->h_df_real = df_real;
+      s->h_boost = bb;
       s->bm_n_post = offs[n_terms];  // the postings of the index (the merged lists are a second copy)
     }
     break;
@@ -711,6 +712,17 @@ int ss_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, c
   SS_HIP(hipStreamSynchronize(s->stream));  // searches in flight still read the arrays an append replaces
   const uint32_t first = s->bm_n_terms + s->sp_n;
   SS_TRY(ssi_bm25_append_sparse(s, n_lists, offs, docs, tfs));
+  if (first_term_id_out) *first_term_id_out = first;
+  return SS_OK;
+}
+int ss_bm25_append_sparse_fields(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
+                                 const uint16_t* tfs, uint32_t* first_term_id_out) {
+  if (!s || !offs || (n_lists && offs[n_lists] > offs[0] && (!docs || !fields || !tfs))) return SS_EINVAL;
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  SS_HIP(hipStreamSynchronize(s->stream));
+  const uint32_t first = s->bm_n_terms / std::max<uint32_t>(s->bm_n_fields, 1) + s->sp_n;
+  SS_TRY(ssi_bm25_append_sparse_fields(s, n_lists, offs, docs, fields, tfs));
   if (first_term_id_out) *first_term_id_out = first;
   return SS_OK;
 }
@@ -1059,8 +1071,8 @@ static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_quer
 // answers land in s->d_out_* in the callers' order, like any other batch's.  Caller holds s->mu.
 static int bm25_search_tiered_excl(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, const std::vector<uint32_t>& special);
 static int bm25_search_tiered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt) {
-  const uint32_t n_dense = s->bm_n_terms;
-  if (s->bm_n_fields != 1) return SS_ENOTSUP;
+  const uint32_t n_dense = s->bm_n_terms / s->bm_n_fields;  // public terms of the dense image
+  if (s->bm_n_fields != 1 && !s->bm_merged) return SS_ENOTSUP;  // (several indexed fields: the sparse tier holds merged weights)
   std::vector<uint32_t> special;       // unions with a SPARSE NOT term: answered one by one under a per-query exclusion bitmap
   std::vector<ss_bm25_query> sub;      // the dense sub-batch: all-dense queries as they are, tiered unions reduced to their dense terms
   std::vector<ss_bm25_query> spq;      // the tiered queries, whole, for the sparse kernel
@@ -1147,7 +1159,7 @@ static int bm25_search_tiered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, 
 // filter's bitmap): top-k and exact counts then follow from the paths that serve a shard with deleted docs.  The other queries of
 // the batch run together as always; the single answers are put back into their rows.
 static int bm25_search_tiered_excl(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, const std::vector<uint32_t>& special) {
-  const uint32_t kw = std::max<uint32_t>(kk, 1), n_sp = (uint32_t)special.size(), n_dense = s->bm_n_terms;
+  const uint32_t kw = std::max<uint32_t>(kk, 1), n_sp = (uint32_t)special.size(), n_dense = s->bm_n_terms / s->bm_n_fields;
   const size_t words = ((size_t)s->bm_n_docs + 31) / 32;
   SS_TRY(ensure_out(s, nq, kw));
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -1217,7 +1229,7 @@ static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_quer
     bool any_sparse = false;
     for (uint32_t i = 0; i < nq && !any_sparse; i++)
       for (uint32_t t = 0; t < std::min<uint32_t>(q[i].n_terms + bm_q_nnot(q[i].op), SS_MAX_QUERY_TERMS); t++)
-        any_sparse |= q[i].term[t] >= s->bm_n_terms && q[i].term[t] < s->bm_n_terms + s->sp_n;
+        any_sparse |= q[i].term[t] >= s->bm_n_terms / s->bm_n_fields && q[i].term[t] < s->bm_n_terms / s->bm_n_fields + s->sp_n;
     // (a facet filter: the sparse kernel reads the same exclusion bitmap as the dense ones)
     if (any_sparse) return with_facet_filter(s, n_filters, filters, s->stream, [&]() { return bm25_search_tiered(s, nq, q, kk, rt); });
   }

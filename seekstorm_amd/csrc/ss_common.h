@@ -273,6 +273,7 @@ struct ss_shard {
   bool bm_merged = false;
   float* d_boost = nullptr;               // [bm_n_fields] schema boost per field (add_result.rs:1253); merged list: S
   std::vector<uint64_t> h_df_real;        // multi-field: docs containing the term in any field (the df idf needs)
+  std::vector<float> h_boost;             // host copy of d_boost (several indexed fields)
   std::map<hipStream_t, ss_bm_ws> bm_ws;   // per-stream search workspaces (guarded by mu)
   uint64_t bm_n_post = 0;
   float bm_avgdl = 0.f;
@@ -325,9 +326,10 @@ struct ss_shard {
   float* d_submax = nullptr;       // [n_terms + 1][n_sub] largest weight of every (term, 4096-doc sub-block) segment, 0 = empty: the
                                    // reference's per-block max_block_score / idf (get_max_score, index.rs:2938-3200) at this image's
                                    // block size; the last row (absent terms) is all zero
-  // ---- sparse tier (bm25_sparse.hip): rare terms as plain sorted lists, no directory row, no probe row.  Sparse list i is term
-  // bm_n_terms + i of a single-field image; a posting = weight code << 32 | doc
-  uint8_t* d_doclen = nullptr;       // the length bytes of the docs (one indexed field), kept for ss_bm25_append_sparse
+  // ---- sparse tier (bm25_sparse.hip): rare terms as plain sorted lists, no directory row, no probe row.  Sparse list i is public
+  // term bm_n_terms / bm_n_fields + i; a posting = weight code << 32 | doc (several indexed fields: the code of the term's MERGED weight)
+  uint8_t* d_doclen = nullptr;       // the length bytes of the docs ([indexed fields][n_docs]; several fields: images with merged lists only),
+                                     // kept for ss_bm25_append_sparse[_fields]
   uint64_t* d_sp_base = nullptr;     // [sp_n + 1] first posting of every sparse list
   uint64_t* d_sp_post = nullptr;     // the postings, list after list, ascending docs inside a list
   uint32_t sp_n = 0;
@@ -490,6 +492,7 @@ int ssi_bm25_rebuild_from_raw(const ss_shard* s, const std::vector<ss_raw_level>
                               ss_shard* img, hipStream_t st, bool one_shot = false);
 // ---- sparse tier (synth.hip: append; bm25_sparse.hip: kernels)
 int ssi_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs);
+int ssi_bm25_append_sparse_fields(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields, const uint16_t* tfs);
 // keys per lane of the sparse tier's top-k lists (rows of 64 * KPL keys), as the dense kernels choose theirs
 inline int ssi_bm25_sparse_kpl(uint32_t kk) { return kk <= 64 ? 1 : kk <= 128 ? 2 : kk <= 256 ? 4 : 16; }
 int ssi_bm25_launch_sparse(const ss_shard* s, const ss_bm25_query* d_q, uint32_t nq, uint32_t k, unsigned long long* d_keys,

@@ -308,9 +308,9 @@ int ssi_bm25_build_from_host_merged(ss_shard* s, const uint8_t* doclen, const ui
   SS_HIP(hipMemcpy(s->d_term_base, tbase.data(), ((size_t)nt + 1) * sizeof(u64), hipMemcpyHostToDevice));
   SS_HIP(hipMemcpy(s->d_sub_off, sub.data(), sub.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   SS_HIP(hipMemcpy(s->d_comp, comp, sizeof(comp), hipMemcpyHostToDevice));
-  if (L == 1) {  // one indexed field: the length bytes stay on the device for ss_bm25_append_sparse
-    SS_HIP(hipMalloc(&s->d_doclen, s->bm_n_docs));
-    SS_HIP(hipMemcpy(s->d_doclen, doclen, s->bm_n_docs, hipMemcpyHostToDevice));
+  if (L == 1 || s->bm_merged) {  // the length bytes ([indexed fields][n_docs]) stay on the device for ss_bm25_append_sparse[_fields]
+    SS_HIP(hipMalloc(&s->d_doclen, (size_t)RF * s->bm_n_docs));
+    SS_HIP(hipMemcpy(s->d_doclen, doclen, (size_t)RF * s->bm_n_docs, hipMemcpyHostToDevice));
   }
   rc = alloc_probe(s, s->stream);
   if (rc) return rc;
@@ -584,9 +584,12 @@ int ssi_bm25_rebuild_from_raw(const ss_shard* s, const std::vector<ss_raw_level>
 // ---------------------------------------------------------------- sparse tier: append lists of rare terms to the image
 // (bm25_sparse.hip).  The weights are computed here, on the host, by the same routine and component cache as every dense
 // posting's (bm_code_of): the length bytes come back from the device once per call.
+// the packed postings of n_lists new sparse lists (list i: base[i] .. base[i + 1] of `packed`) behind the ones the tier holds
+static int sparse_install(ss_shard* s, uint32_t n_lists, const std::vector<u64>& lbase, const std::vector<u64>& packed);
+
 int ssi_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs) {
   if (!s->d_post || !s->d_doclen) return SS_ESTATE;
-  if (s->bm_n_fields != 1 || s->bm_merged) return SS_ENOTSUP;
+  if (s->bm_n_fields != 1 || s->bm_merged) return SS_ENOTSUP;  // several indexed fields: ssi_bm25_append_sparse_fields
   if ((uint64_t)s->sp_n + n_lists > 0x7FFFFFFFull - s->bm_n_terms) return SS_ENOTSUP;
   const u64 n_new = offs[n_lists] - offs[0];
   std::vector<uint8_t> dl(s->bm_n_docs);
@@ -605,6 +608,70 @@ int ssi_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, 
       }
   });
   if (fail.load()) return fail.load();
+  std::vector<u64> lbase((size_t)n_lists + 1);
+  for (uint32_t i = 0; i <= n_lists; i++) lbase[i] = offs[i] - offs[0];
+  packed.resize(n_new);
+  return sparse_install(s, n_lists, lbase, packed);
+}
+
+// Several indexed fields (an image with MERGED lists): the entries (doc, field, tf) of every rare term, sorted by (doc, field) like
+// ssi_bm25_upload_fields takes them.  The sparse tier keeps a term's MERGED list only -- every doc once, its weight the sum over the
+// doc's fields of boost_f * tf (K + 1) / (tf + comp[len_f]), fields ascending, coded against the scale the dense merged lists were
+// built with (ssi_bm25_build_from_host_merged): what a query without a field filter reads of a dense term, too.
+int ssi_bm25_append_sparse_fields(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields, const uint16_t* tfs) {
+  if (!s->d_post) return SS_ESTATE;
+  const uint32_t L = s->bm_n_fields, RF = bm_real_fields(s);
+  if (L == 1) return SS_EINVAL;
+  if (!s->bm_merged || !s->d_doclen || s->h_boost.size() != L) return SS_ENOTSUP;  // boosts too far apart for merged lists: no sparse tier either
+  if ((uint64_t)s->sp_n + n_lists > 0x7FFFFFFFull - s->bm_n_terms / L) return SS_ENOTSUP;
+  std::vector<uint8_t> dl((size_t)RF * s->bm_n_docs);
+  SS_HIP(hipMemcpy(dl.data(), s->d_doclen, dl.size(), hipMemcpyDeviceToHost));
+  float comp[SS_COMP_N];
+  fill_comp(s->bm_avgdl, comp);
+  const float mscale = s->h_boost[L - 1];
+  for (uint32_t i = 0; i < n_lists; i++)
+    if (offs[i + 1] < offs[i]) return SS_EINVAL;
+  // docs per list first (an entry opens a doc when its doc id differs from the entry before)
+  std::vector<u64> lbase((size_t)n_lists + 1, 0);
+  std::atomic<int> fail{SS_OK};
+  ss_parallel_for(n_lists, 4096, [&](size_t a, size_t b, unsigned) {
+    for (size_t i = a; i < b; i++) {
+      u64 n = 0;
+      for (u64 j = offs[i]; j < offs[i + 1]; j++) {
+        if (docs[j] >= s->bm_n_docs || tfs[j] == 0 || fields[j] >= RF) { fail.store(SS_EINVAL); return; }
+        if (j > offs[i] && (docs[j] < docs[j - 1] || (docs[j] == docs[j - 1] && fields[j] <= fields[j - 1]))) { fail.store(SS_EINVAL); return; }
+        n += (j == offs[i] || docs[j] != docs[j - 1]) ? 1u : 0u;
+      }
+      lbase[i + 1] = n;
+    }
+  });
+  if (fail.load()) return fail.load();
+  for (uint32_t i = 0; i < n_lists; i++) lbase[i + 1] += lbase[i];
+  std::vector<u64> packed(lbase[n_lists]);
+  ss_parallel_for(n_lists, 4096, [&](size_t a, size_t b, unsigned) {
+    for (size_t i = a; i < b; i++) {
+      u64 w_at = lbase[i];
+      for (u64 j = offs[i]; j < offs[i + 1];) {
+        float w = 0.f;
+        u64 e = j;
+        for (; e < offs[i + 1] && docs[e] == docs[j]; e++) {
+          const volatile float part = s->h_boost[fields[e]] * bm_weight_exact(tfs[e], comp[dl[(size_t)fields[e] * s->bm_n_docs + docs[e]]]);
+          w = w + part;
+        }
+        // the dense lists chose the scale from their own weights: a sparse weight outside the code's range is refused, not clamped
+        if (!(w > 0.f) || w / mscale < 6.2e-5f || w / mscale >= 4.0f) { fail.store(SS_ENOTSUP); return; }
+        packed[w_at++] = ((u64)bm_wcode(w / mscale) << 32) | docs[j];
+        j = e;
+      }
+    }
+  });
+  if (fail.load()) return fail.load();
+  return sparse_install(s, n_lists, lbase, packed);
+}
+
+static int sparse_install(ss_shard* s, uint32_t n_lists, const std::vector<u64>& lbase, const std::vector<u64>& packed) {
+  const u64 n_new = packed.size();
+  const u64* offs = lbase.data();
   const u64 old_n = s->h_sp_base.empty() ? 0 : s->h_sp_base.back();
   uint64_t *nb = nullptr, *np = nullptr;
   SS_HIP(hipMalloc(&nb, ((size_t)s->sp_n + n_lists + 1) * sizeof(u64)));

@@ -1052,6 +1052,19 @@ class Shard:
         self._df_cache.clear()
         return int(first.value)
 
+    def append_sparse_fields(self, term_offsets, doc_ids, field_ids, tfs):
+        """... on an image with several indexed fields: entries (doc, field, tf) sorted by (doc, field) per term; the tier keeps the
+        terms' merged lists (ss_bm25_append_sparse_fields)"""
+        offs = np.ascontiguousarray(term_offsets, np.uint64)
+        d = np.ascontiguousarray(doc_ids, np.uint32)
+        f = np.ascontiguousarray(field_ids, np.uint8)
+        t = np.ascontiguousarray(tfs, np.uint16)
+        first = C.c_uint32()
+        N.check(N.lib().ss_bm25_append_sparse_fields(self._h, len(offs) - 1, N.ptr(offs, N.u64p), N.ptr(d, N.u32p), N.ptr(f, N.u8p),
+                                                     N.ptr(t, N.u16p), C.byref(first)), "ss_bm25_append_sparse_fields")
+        self._df_cache.clear()
+        return int(first.value)
+
     def sparse_info(self):
         """(sparse lists, their postings, bytes of the sparse tier)"""
         n, p, b = C.c_uint32(), C.c_uint64(), C.c_uint64()

@@ -431,3 +431,48 @@ def test_sparse_terms_through_the_device_pointer_entry_point(S, O):
     flagged = cnt.cpu().numpy().view(np.uint32) == 0xFFFFFFFF
     assert flagged.tolist() == [True, False, True, True, True]
     sh.close()
+
+
+def test_sparse_tier_on_an_image_with_several_indexed_fields(S, O):
+    """rare terms of a multi-field (BM25F) index in the sparse tier: their MERGED lists (every doc once, weight = the boosted sum over
+    the doc's fields) next to the dense image's merged lists -- unions, intersections, NOT terms of either tier, tombstones, counts,
+    against the brute-force BM25F oracle over ALL entries; a field filter over a sparse term is refused"""
+    from seekstorm_amd import _native as N
+    from test_gpu_parity import _fields_corpus, _check_topk
+    n_docs, n_fields, boost = 100_000, 3, [2.0, 1.0, 0.5]
+    dfs = [30_000, 9_000, 14_000, 4_000, 600, 50, 1_200, 5, 300, 2_500]
+    nd = 4
+    dl, offs, docs, fields, tfs = _fields_corpus(O, n_docs, n_fields, dfs, 12)
+    sh = S.Shard(0)
+    e = int(offs[nd])
+    sh.upload_lexical_fields(n_docs, dl, boost, offs[:nd + 1], docs[:e], fields[:e], tfs[:e])
+    assert sh.fields_info()[1]  # merged lists
+    mid = nd + 3  # two appends: the ids continue
+    first = sh.append_sparse_fields(offs[nd:mid + 1] - offs[nd], docs[e:int(offs[mid])], fields[e:int(offs[mid])], tfs[e:int(offs[mid])])
+    second = sh.append_sparse_fields(offs[mid:] - offs[mid], docs[int(offs[mid]):], fields[int(offs[mid]):], tfs[int(offs[mid]):])
+    assert (first, second) == (nd, mid) and sh.sparse_info()[0] == len(dfs) - nd
+    assert [int(x) for x in sh.posting_count(np.arange(len(dfs)))] == dfs  # docs holding the term in any field
+    cases = [([0, 4], []), ([6, 1, 2], []), ([9, 6], []), ([4], []), ([7, 5, 0], []), ([3, 9], [1]), ([2, 1], [9]), ([6, 9, 0], [4, 3]),
+             ([0, 1], []), ([8, 9, 6, 4], [])]
+    gone = list(range(3, n_docs, 97))
+    for deleted in ((), gone):
+        sh.set_deleted(deleted)
+        for qt, oop in ((S.QueryType.Union, O.OP_OR), (S.QueryType.Intersection, O.OP_AND)):
+            for strat in (N.BM25_AUTO, N.BM25_EXHAUSTIVE):
+                sh.set_strategy(strat)
+                q = sh.make_queries([c[0] for c in cases], qt, [c[1] for c in cases])
+                for k in (10, 150):
+                    for rt in (S.ResultType.TopkCount, S.ResultType.Count):
+                        doc, score, cnt, tot = sh.search_lexical_batch(q, k, rt, reference_shortcuts=False)
+                        for i, (pos, neg) in enumerate(cases):
+                            od, os_, otot, _ = O.search_fields_exhaustive(n_docs, dl, boost, offs, docs, fields, tfs, pos, oop, k, neg, deleted)
+                            assert int(tot[i]) == otot, (pos, neg, qt, strat, rt, k, int(tot[i]), otot)
+                            if rt != S.ResultType.Count:
+                                _check_topk(doc[i], score[i], cnt[i], od, os_)
+    sh.set_strategy(N.BM25_AUTO)
+    sh.set_deleted(())
+    with pytest.raises(N.SeekStormHipError):  # the tier holds merged lists: nothing to filter by field
+        sh.search_lexical_batch(sh.make_queries([[0, 4]], S.QueryType.Intersection, field_filter=[0]), 10)
+    # a dense-only query of the same image still takes its field filter
+    sh.search_lexical_batch(sh.make_queries([[0, 1]], S.QueryType.Intersection, field_filter=[0]), 10)
+    sh.close()

@@ -924,6 +924,49 @@ def test_tiered_index_bin_upload_answers_like_the_arrays():
     b.close()
 
 
+@pytest.mark.gpu
+def test_tiered_upload_of_an_index_bin_with_several_fields():
+    """a multi-field index.bin in two tiers: the rare keys' merged lists in the sparse tier -- answers like the same entries uploaded
+    as one dense multi-field image, and like the BM25F oracle"""
+    from oracle import oracle as O
+    rng = np.random.default_rng(43)
+    n_docs, n_fields, longest = 90_000, 3, 1
+    dl = np.stack([O.lex_doclen(n_docs, seed=O.LEX_SEED + 5 * f) for f in range(n_fields)])
+    keys = sorted(int(k) & ~7 for k in rng.integers(1 << 40, 1 << 63, size=7, dtype=np.int64))
+    terms = []
+    for key, df in zip(keys, (20_000, 300, 6_000, 40, 11_000, 900, 2)):
+        d, f, t = [], [], []
+        for doc in np.sort(rng.choice(n_docs, size=df, replace=False)):
+            fs = np.sort(rng.choice(n_fields, size=int(rng.integers(1, n_fields + 1)), replace=False)) if rng.random() < 0.6 else [longest]
+            for x in fs:
+                d.append(int(doc)); f.append(int(x)); t.append(int(min(rng.geometric(0.5), 30)))
+        terms.append((key, np.array(d), np.array(f), np.array(t)))
+    data = RF.write_index_bin(n_docs, dl, terms, rng, n_fields=n_fields, longest_field_id=longest)
+    ix = S.IndexBin(data, n_fields)
+    nd = ix.tier(2000)
+    assert nd == 3
+    boost = [1.5, 1.0, 0.5]
+    a, b = S.Shard(0), S.Shard(0)
+    a.upload_index_bin(ix, boost)
+    assert a.sparse_info()[0] == len(terms) - nd
+    by_id = [terms[keys.index(int(k))] for k in ix.term_keys]  # the file's terms in tiered id order
+    offs = np.zeros(len(by_id) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(t[1]) for t in by_id])
+    D, F, T = (np.concatenate([t[i] for t in by_id]) for i in (1, 2, 3))
+    b.upload_lexical_fields(n_docs, dl, boost, offs, D.astype(np.uint32), F.astype(np.uint8), T.astype(np.uint16))
+    n = len(by_id)
+    assert [int(x) for x in a.posting_count(list(range(n)))] == [int(x) for x in b.posting_count(list(range(n)))]
+    for qt, oop in ((S.QueryType.Union, O.OP_OR), (S.QueryType.Intersection, O.OP_AND)):
+        for q in ([0, 3], [4], [1, 5, 2], [0, 1, 2], [6, 3], [5, 4, 0]):
+            ra = a.search_lexical_batch(a.make_queries([q], qt), 10, reference_shortcuts=False)
+            rb_ = b.search_lexical_batch(b.make_queries([q], qt), 10, reference_shortcuts=False)
+            assert np.array_equal(ra[2], rb_[2]) and np.array_equal(ra[3], rb_[3]) and np.allclose(ra[1], rb_[1], rtol=1e-6)
+            od, os_, otot, _ = O.search_fields_exhaustive(n_docs, dl, boost, offs, D, F, T, q, oop, 10)
+            assert int(ra[3][0]) == otot and np.allclose(ra[1][0][:ra[2][0]], os_, rtol=1e-4)
+    a.close()
+    b.close()
+
+
 def _python_writer_of(T, RF, O, key_head_size, positions_limit):
     """the same corpus through oracle/ref_format.py: single terms, then the n-gram keys with their component tfs / df bytes"""
     terms, ngt = [], []
