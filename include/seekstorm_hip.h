@@ -275,7 +275,7 @@ int ss_bm25_fields_info(ss_shard* s, uint32_t* n_fields, uint32_t* merged_lists,
  * sparse list scored in full by binary-search probes of the query's other lists (north_star's galloping, intersection.rs:352-362),
  * the two lists merged per query; intersections -- the shortest sparse list drives.  Exact counts, tombstones, NOT terms
  * (a union that excludes a SPARSE term is answered on its own, under an exclusion bitmap = tombstones | the list's docs), facet
- * filters, k <= SS_MAX_K.  No phrases or field filters over sparse terms (SS_ENOTSUP).  The device-pointer entry points take
+ * filters, k <= SS_MAX_K, phrases (ss_bm25_append_sparse_positions).  No field filters over sparse terms other than a phrase's (SS_ENOTSUP).  The device-pointer entry points take
  * sparse terms when ops_mask bit 28 says so (one host round trip).  ss_bm25_term_df covers the sparse ids. */
 int ss_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
                           uint32_t* first_term_id_out);
@@ -286,6 +286,19 @@ int ss_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, c
  * fixed the weight code to (boosts / lengths unlike anything in the dense image). */
 int ss_bm25_append_sparse_fields(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
                                  const uint16_t* tfs, uint32_t* first_term_id_out);
+/* ... with POSITIONS, for phrase queries naming a sparse term (a quoted rare word: the tier's typical phrase).  positions: for every
+ * posting (ss_bm25_append_sparse_positions) / every (doc, field) entry (..._fields_positions) in order its positions, ascending --
+ * tf of them, or npos[i] where that is not the tf (npos may be NULL): the component terms of an n-gram key, whose own positions
+ * stand behind its FIRST component's postings as in the dense tier (ss_bm25_upload_index_bin_positions).  Such a phrase is an
+ * intersection driven by its shortest sparse list; every other word is found by binary search, its positions with it -- a dense
+ * word's in the image's pool, so the image must carry positions as well (SS_ESTATE otherwise).  Several indexed fields: a phrase's
+ * field filter is honoured (a test on the start position's field tag).  Appends without positions to a tier that has some leave
+ * those postings without any (a phrase then never matches there). */
+int ss_bm25_append_sparse_positions(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
+                                    const uint16_t* positions, uint64_t n_positions, const uint16_t* npos, uint32_t* first_term_id_out);
+int ss_bm25_append_sparse_fields_positions(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
+                                           const uint16_t* tfs, const uint16_t* positions, uint64_t n_positions, const uint16_t* npos,
+                                           uint32_t* first_term_id_out);
 int ss_bm25_sparse_info(ss_shard* s, uint32_t* n_lists, uint64_t* n_postings, uint64_t* bytes);
 /* INCREMENTAL COMMIT (commit.rs:142-148 commit -> warmup, 264-369; index.rs:3796 -- the "(re)build device image" seam after a commit).
  * The reference commits one 65 536-doc level at a time.  ss_bm25_append_level hands over the decoded postings of ONE level -- the

@@ -191,6 +191,8 @@ SYMBOLS = [
     ("ss_index_bin_tier", C.c_int, [C.c_void_p, C.c_uint64, u32p]),
     ("ss_bm25_append_sparse", C.c_int, [C.c_void_p, C.c_uint32, u64p, u32p, u16p, u32p]),
     ("ss_bm25_append_sparse_fields", C.c_int, [C.c_void_p, C.c_uint32, u64p, u32p, u8p, u16p, u32p]),
+    ("ss_bm25_append_sparse_positions", C.c_int, [C.c_void_p, C.c_uint32, u64p, u32p, u16p, u16p, C.c_uint64, u16p, u32p]),
+    ("ss_bm25_append_sparse_fields_positions", C.c_int, [C.c_void_p, C.c_uint32, u64p, u32p, u8p, u16p, u16p, C.c_uint64, u16p, u32p]),
     ("ss_bm25_sparse_info", C.c_int, [C.c_void_p, u32p, u64p, u64p]),
     ("ss_shard_set_coalescing", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
     ("ss_shard_coalescing_stats", C.c_int, [C.c_void_p, u64p, u64p, u64p, u64p]),

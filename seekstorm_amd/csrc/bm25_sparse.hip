@@ -35,9 +35,11 @@ __device__ __forceinline__ unsigned long long sp_find(const unsigned long long* 
   return lo;
 }
 // weight code of doc in a DENSE list, 0 = absent: binary search inside the doc's (term, sub-block) segment -- packed postings
-// ascending by doc field, NULL (zero) padding at the segment's end ordering as +infinity
+// ascending by doc field, NULL (zero) padding at the segment's end ordering as +infinity.  *slot = the posting's index inside the
+// term's image (what d_pos_off is indexed by).
 __device__ __forceinline__ uint32_t dense_find(const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base,
-                                               const uint32_t* __restrict__ sub_off, uint32_t n_sub, uint32_t row, uint32_t doc) {
+                                               const uint32_t* __restrict__ sub_off, uint32_t n_sub, uint32_t row, uint32_t doc,
+                                               uint32_t* slot = nullptr) {
   const uint32_t sb = doc >> BM_SUB_LOG2, want = (doc & (BM_SUB - 1)) + 1u;
   const uint32_t* r = sub_off + (size_t)row * (n_sub + 1);
   const unsigned long long base = (term_base[row] + r[sb]) * 4ull;
@@ -49,6 +51,7 @@ __device__ __forceinline__ uint32_t dense_find(const uint32_t* __restrict__ post
   }
   if (lo < (r[sb + 1] - r[sb]) * 4u) {
     const uint32_t p = post[base + lo];
+    if (slot) *slot = r[sb] * 4u + lo;
     if (bm_doc_field(p) == want) return p >> 13 ? p >> 13 : 1u;  // (a code of 0 cannot occur: bm_wcode clamps to 1)
   }
   return 0u;
@@ -142,6 +145,170 @@ __global__ void __launch_bounds__(QW * 64) bm25_sparse_kernel(
     }
   }
   // the waves' lists -> one: wave 0 merges the others' (sorted) keys into its own
+#pragma unroll
+  for (int r = 0; r < KPL; r++) wkeys[w][r * 64 + lane] = T.keys[r];
+  if (lane == 0) wcount[w] = T.matched;
+  __syncthreads();
+  if (w != 0) return;
+  unsigned long long matched = 0ull;
+  for (int j = 0; j < QW; j++) matched += wcount[j];
+  for (int j = 1; j < QW; j++) {
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+      const unsigned long long key = wkeys[j][r * 64 + lane];
+      if (__ballot(key != 0ull)) T.worst = topk_merge64<KPL>(T.keys, key, max(k, 1u), lane);
+    }
+  }
+  unsigned long long* out = out_keys + (size_t)qi * (64 * KPL);
+#pragma unroll
+  for (int r = 0; r < KPL; r++) out[r * 64 + lane] = T.keys[r];
+  if (lane == 0) out_extra[qi] = matched;
+}
+
+// PHRASES naming a sparse term (QueryType::Phrase over a rare word: the common case of a quoted name).  A phrase is an intersection
+// whose survivors pass the position check (add_result.rs:3586-3684, bm25_phrase.hip): the shortest SPARSE list of the phrase drives,
+// every other unique term is looked up by binary search -- which yields the doc's posting, hence its positions: a sparse posting's
+// in d_sp_pos (sp_pos_end), a dense posting's in the image's pool (pos_off by slot).  Each lane then checks ITS doc: a start offered
+// by the first word's positions, every other word by binary search at start + its place (places inside an n-gram key: SS_PHRASE_SKIP).
+// PT = uint32_t: several indexed fields -- merged lists, positions tagged with their field, the field filter a test on the start's tag.
+template <int KPL, int QW, typename PT>
+__global__ void __launch_bounds__(QW * 64) bm25_sparse_phrase_kernel(
+    const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base, const uint32_t* __restrict__ sub_off, uint32_t n_sub,
+    uint32_t n_dense, uint32_t n_lists, float idf_scale, const unsigned long long* __restrict__ sp_base,
+    const unsigned long long* __restrict__ sp_post, const PT* __restrict__ sp_pos, const unsigned long long* __restrict__ sp_pos_end,
+    const PT* __restrict__ pos, const uint32_t* __restrict__ pos_off, const unsigned long long* __restrict__ pos_base,
+    const ss_bm25_query* __restrict__ qs, uint32_t nq, uint32_t k, const uint32_t* __restrict__ del, uint32_t del_words,
+    unsigned long long* __restrict__ out_keys, unsigned long long* __restrict__ out_extra) {
+  constexpr int NT = 6;  // unique terms of a phrase (the dense kernel's limit)
+  constexpr bool MF = sizeof(PT) == 4;
+  __shared__ unsigned long long wkeys[QW][64 * KPL];
+  __shared__ unsigned long long wcount[QW];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t qi = blockIdx.x;
+  const ss_bm25_query* __restrict__ Q = qs + qi;
+  const uint32_t nt = min(Q->n_terms, (uint32_t)NT), n_not = bm_q_nnot(Q->op), plen = Q->phrase_len;
+  const uint32_t filt = MF ? bm_q_field_filter(Q->op) : 0u, fmask = filt ? filt : 0xFFFFFFFFu;
+  BmTop<KPL> T;
+#pragma unroll
+  for (int r = 0; r < KPL; r++) T.keys[r] = 0ull;
+  T.worst = 0ull;
+  T.wsc = -1.0f;
+  T.matched = 0;
+  uint32_t drv = 0;
+  {
+    unsigned long long best = ~0ull;
+    for (uint32_t t = 0; t < nt; t++)
+      if (Q->term[t] >= n_dense) {
+        const uint32_t i = Q->term[t] - n_dense;
+        const unsigned long long len = sp_base[i + 1] - sp_base[i];
+        if (len < best) { best = len; drv = t; }
+      }
+  }
+  // place i of the phrase -> unique term (7 = a place inside an n-gram key), 3 bits each
+  unsigned long long wpack = 0ull;
+#pragma unroll
+  for (int i = 0; i < SS_MAX_PHRASE; i++) wpack |= (unsigned long long)(Q->phrase_seq[i] == SS_PHRASE_SKIP ? 7u : (Q->phrase_seq[i] & 7u)) << (3 * i);
+  auto wslot = [&](uint32_t i) -> uint32_t { return (uint32_t)(wpack >> (3u * i)) & 7u; };
+  if (Q->term[drv] >= n_dense) {
+    const uint32_t si = Q->term[drv] - n_dense;
+    const unsigned long long b0 = sp_base[si], b1 = sp_base[si + 1];
+    for (unsigned long long x = b0 + (unsigned)w * 64u; x < b1; x += 64ull * QW) {
+      const bool live0 = x + (unsigned)lane < b1;
+      const unsigned long long e = live0 ? sp_post[x + lane] : 0ull;
+      const uint32_t doc = (uint32_t)e;
+      bool live = live0;
+      float wv[NT];
+      const PT* pp[NT];  // the doc's positions of every unique term
+      uint32_t pn[NT];
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        wv[t] = 0.f; pp[t] = sp_pos; pn[t] = 0u;
+        if ((uint32_t)t >= nt || !live) continue;
+        const uint32_t term = Q->term[t];
+        uint32_t code = 0u;
+        if (term >= n_dense) {
+          unsigned long long p = x + lane;
+          if ((uint32_t)t == drv) {
+            code = (uint32_t)(e >> 32);
+          } else {
+            const uint32_t j = term - n_dense;
+            p = sp_find(sp_post, sp_base[j], sp_base[j + 1], doc);
+            if (p < sp_base[j + 1] && (uint32_t)sp_post[p] == doc) code = (uint32_t)(sp_post[p] >> 32);
+          }
+          if (code) {
+            const unsigned long long st = p ? sp_pos_end[p - 1] : 0ull;
+            pp[t] = sp_pos + st;
+            pn[t] = (uint32_t)(sp_pos_end[p] - st);
+          }
+        } else {
+          const uint32_t row = term * n_lists + (n_lists - 1u);
+          uint32_t slot = 0u;
+          code = dense_find(post, term_base, sub_off, n_sub, row, doc, &slot);
+          if (code) {
+            const uint32_t* po = pos_off + term_base[row] * 4ull;
+            const uint32_t st = slot ? po[slot - 1u] : 0u;
+            pp[t] = pos + pos_base[row] + st;
+            pn[t] = po[slot] - st;
+          }
+        }
+        if (!code) live = false;
+        else wv[t] = bm_wdecode(code);
+      }
+      // NOT terms of either tier (add_result.rs:3440-3497)
+      for (uint32_t j = 0; j < n_not && live; j++) {
+        const uint32_t term = Q->term[Q->n_terms + j];
+        if (term >= n_dense) {
+          const uint32_t l = term - n_dense;
+          const unsigned long long p = sp_find(sp_post, sp_base[l], sp_base[l + 1], doc);
+          if (p < sp_base[l + 1] && (uint32_t)sp_post[p] == doc) live = false;
+        } else if (dense_find(post, term_base, sub_off, n_sub, term * n_lists + (n_lists - 1u), doc)) {
+          live = false;
+        }
+      }
+      if (live && del && (doc >> 5) < del_words && ((del[doc >> 5] >> (doc & 31u)) & 1u)) live = false;
+      if (live) {  // the phrase: start = a position of word 0, word i must sit at start + i
+        auto range_of = [&](uint32_t sl, const PT*& base, uint32_t& n) {
+          base = pp[0]; n = pn[0];
+#pragma unroll
+          for (int t = 1; t < NT; t++)
+            if (sl == (uint32_t)t) { base = pp[t]; n = pn[t]; }
+        };
+        const PT* b0p;
+        uint32_t n0;
+        range_of(wslot(0u), b0p, n0);
+        bool match = false;
+        for (uint32_t j = 0; j < n0 && !match; j++) {
+          const uint32_t start = b0p[j];
+          bool ok = !MF || ((fmask >> (start >> BM_POS_FIELD_SHIFT)) & 1u);
+          for (uint32_t i = 1; i < plen && ok; i++) {
+            if (wslot(i) == 7u) continue;
+            const PT* bp;
+            uint32_t n;
+            range_of(wslot(i), bp, n);
+            const uint32_t target = start + i;
+            uint32_t lo = 0, hi = n;
+            while (lo < hi) {
+              const uint32_t mid = (lo + hi) >> 1;
+              if ((uint32_t)bp[mid] < target) lo = mid + 1u; else hi = mid;
+            }
+            ok = lo < n && (uint32_t)bp[lo] == target;
+          }
+          match = ok;
+        }
+        live = match;
+      }
+      T.matched += (unsigned long long)__popcll(__ballot(live));
+      if (k && __ballot(live)) {
+        float score = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+          if ((uint32_t)t < nt) score = fmaf(n_lists > 1u ? idf_scale * Q->idf[t] : Q->idf[t], wv[t], score);
+        unsigned long long key = (live && score > 0.f) ? (((unsigned long long)__float_as_uint(score) << 32) | (unsigned long long)(0xFFFFFFFFu - doc)) : 0ull;
+        key = key > T.worst ? key : 0ull;
+        if (__ballot(key != 0ull)) T = bm_offer_lane_keys<KPL>(T, key, k, nullptr);
+      }
+    }
+  }
 #pragma unroll
   for (int r = 0; r < KPL; r++) wkeys[w][r * 64 + lane] = T.keys[r];
   if (lane == 0) wcount[w] = T.matched;
@@ -284,6 +451,33 @@ int ssi_bm25_launch_sparse(const ss_shard* s, const ss_bm25_query* d_q, uint32_t
   else if (KPL == 4) SS_SP(4, SP_QWAVES);
   else SS_SP(16, 4);  // (the waves' lists are merged through LDS: 64 KB hold four of 1024 keys)
 #undef SS_SP
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
+// the phrase queries of a tiered batch (rows of the same key / count arrays as ssi_bm25_launch_sparse's)
+int ssi_bm25_launch_sparse_phrase(const ss_shard* s, const ss_bm25_query* d_q, uint32_t nq, uint32_t k, unsigned long long* d_keys,
+                                  unsigned long long* d_extra, hipStream_t st) {
+  if (nq == 0) return SS_OK;
+  const uint32_t kk = std::max<uint32_t>(k, 1);
+  const int KPL = ssi_bm25_sparse_kpl(kk);
+  const uint32_t* del = s->n_deleted ? s->d_deleted : nullptr;
+  const float idf_scale = s->bm_n_fields > 1 && s->h_boost.size() == s->bm_n_fields ? s->h_boost[s->bm_n_fields - 1] : 1.0f;
+  const bool mf = s->bm_n_fields > 1;
+  if (!s->d_sp_pos_end || s->sp_pos_elem != (mf ? 4u : 2u)) return SS_ESTATE;  // the tier carries no positions
+#define SS_SPP(KPL_, QW_, PT_, POS_)                                                                                                              \
+  bm25_sparse_phrase_kernel<KPL_, QW_, PT_><<<nq, QW_ * 64, 0, st>>>(                                                                            \
+      s->d_post, (const unsigned long long*)s->d_term_base, s->d_sub_off, s->bm_n_sub, s->bm_n_terms / s->bm_n_fields, s->bm_n_fields, idf_scale, \
+      (const unsigned long long*)s->d_sp_base, (const unsigned long long*)s->d_sp_post, (const PT_*)s->d_sp_pos,                                  \
+      (const unsigned long long*)s->d_sp_pos_end, (const PT_*)(POS_), s->d_pos_off, (const unsigned long long*)s->d_pos_base, d_q, nq, k, del,     \
+      (uint32_t)s->deleted_words, d_keys, d_extra)
+#define SS_SPP2(KPL_, QW_) do { if (mf) SS_SPP(KPL_, QW_, uint32_t, s->d_pos32); else SS_SPP(KPL_, QW_, uint16_t, s->d_pos); } while (0)
+  if (KPL == 1) SS_SPP2(1, SP_QWAVES);
+  else if (KPL == 2) SS_SPP2(2, SP_QWAVES);
+  else if (KPL == 4) SS_SPP2(4, SP_QWAVES);
+  else SS_SPP2(16, 4);
+#undef SS_SPP2
+#undef SS_SPP
   SS_HIP(hipGetLastError());
   return SS_OK;
 }

@@ -1009,8 +1009,12 @@ int upload_index_bin_fields(ss_shard* s, const ss_index_bin* ix, const float* bo
   std::vector<uint32_t> r_docs;
   std::vector<uint8_t> r_fields;
   std::vector<uint16_t> r_tfs;
-  rc = decode_fields_range(ix, n_dense, n_all, r_offs, r_docs, r_fields, r_tfs, nullptr, nullptr);
+  std::vector<uint16_t> r_pos, r_npos;
+  rc = decode_fields_range(ix, n_dense, n_all, r_offs, r_docs, r_fields, r_tfs, with_positions ? &r_pos : nullptr, with_positions ? &r_npos : nullptr);
   if (rc) return rc;
+  if (with_positions)
+    return ss_bm25_append_sparse_fields_positions(s, n_all - n_dense, r_offs.data(), r_docs.data(), r_fields.data(), r_tfs.data(), r_pos.data(),
+                                                  r_pos.size(), r_npos.data(), nullptr);
   return ss_bm25_append_sparse_fields(s, n_all - n_dense, r_offs.data(), r_docs.data(), r_fields.data(), r_tfs.data(), nullptr);
 }
 }  // namespace
@@ -1053,8 +1057,7 @@ namespace {
 int upload_index_bin_single(ss_shard* s, const ss_index_bin* ix, bool with_positions) {
   const uint32_t n_all = (uint32_t)ix->keys.size(), n_dense = std::min<uint32_t>(ix->n_dense, n_all);  // ss_index_bin_tier
   if (n_dense == 0) return SS_EINVAL;           // the dense image needs at least one list
-  // (positions with a sparse tier: the dense terms get theirs -- phrases over dense terms work, a phrase naming a sparse term is
-  // refused at search time like every phrase / filter over sparse terms)
+  // (positions with a sparse tier: both tiers get theirs -- a phrase naming a rare word is driven by that word's sparse list)
   DecodedRange D;
   int rc = index_bin_decode_range(ix, 0, n_dense, with_positions, &D);
   if (rc) return rc;
@@ -1069,8 +1072,11 @@ int upload_index_bin_single(ss_shard* s, const ss_index_bin* ix, bool with_posit
   }
   if (n_dense < n_all) {  // the rare keys: decoded the same way, appended to the sparse tier (term ids continue behind the dense ones)
     DecodedRange R;
-    rc = index_bin_decode_range(ix, n_dense, n_all, false, &R);
+    rc = index_bin_decode_range(ix, n_dense, n_all, with_positions, &R);
     if (rc) return rc;
+    if (with_positions)  // (an n-gram key's own positions behind its first component, as in the dense tier)
+      return ss_bm25_append_sparse_positions(s, n_all - n_dense, R.offs.data(), R.docs.data(), R.tfs.data(), R.pos.data(), R.pos.size(),
+                                             R.npos.data(), nullptr);
     return ss_bm25_append_sparse(s, n_all - n_dense, R.offs.data(), R.docs.data(), R.tfs.data(), nullptr);
   }
   return rc;

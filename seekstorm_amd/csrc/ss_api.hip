@@ -153,10 +153,11 @@ static void free_raw_levels(ss_shard* s) {
 static void free_bm25(ss_shard* s) {
   free_raw_levels(s);
   void* ptrs[] = {s->d_post, s->d_term_base, s->d_sub_off, s->d_comp, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_umax, s->d_submax, s->d_boost, s->d_pos, s->d_pos32, s->d_pos_off, s->d_pos_base,
-                  s->d_doclen, s->d_sp_base, s->d_sp_post};
+                  s->d_doclen, s->d_sp_base, s->d_sp_post, s->d_sp_pos, s->d_sp_pos_end};
   for (void* p : ptrs) if (p) { s->blocks.drop(p); (void)hipFree(p); }
   s->blocks.clear_idle();
   s->d_doclen = nullptr; s->d_sp_base = nullptr; s->d_sp_post = nullptr; s->sp_n = 0; s->h_sp_base.clear();
+  s->d_sp_pos = nullptr; s->d_sp_pos_end = nullptr; s->sp_pos_n = 0; s->sp_pos_elem = 0;
   s->d_post = nullptr; s->d_term_base = nullptr; s->d_sub_off = nullptr; s->d_comp = nullptr;
   s->probe_pool_begin = 0; s->probe_pool_rows = 0; s->pool_list.clear(); s->pool_tick.clear();
   s->d_probe = nullptr; s->d_probe_z = nullptr; s->d_probe_row = nullptr; s->h_probe_row.clear(); s->bm_probe_rows = 0; s->d_umax = nullptr; s->d_submax = nullptr; s->d_pos = nullptr; s->d_pos32 = nullptr; s->d_pos_off = nullptr; s->d_pos_base = nullptr;
@@ -726,6 +727,31 @@ int ss_bm25_append_sparse_fields(ss_shard* s, uint32_t n_lists, const uint64_t* 
   if (first_term_id_out) *first_term_id_out = first;
   return SS_OK;
 }
+int ss_bm25_append_sparse_positions(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
+                                    const uint16_t* positions, uint64_t n_positions, const uint16_t* npos, uint32_t* first_term_id_out) {
+  if (!s || !offs || (n_lists && offs[n_lists] > offs[0] && (!docs || !tfs)) || (n_positions && !positions)) return SS_EINVAL;
+  static const uint16_t none = 0;
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  SS_HIP(hipStreamSynchronize(s->stream));
+  const uint32_t first = s->bm_n_terms + s->sp_n;
+  SS_TRY(ssi_bm25_append_sparse(s, n_lists, offs, docs, tfs, positions ? positions : &none, n_positions, npos));
+  if (first_term_id_out) *first_term_id_out = first;
+  return SS_OK;
+}
+int ss_bm25_append_sparse_fields_positions(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
+                                           const uint16_t* tfs, const uint16_t* positions, uint64_t n_positions, const uint16_t* npos,
+                                           uint32_t* first_term_id_out) {
+  if (!s || !offs || (n_lists && offs[n_lists] > offs[0] && (!docs || !fields || !tfs)) || (n_positions && !positions)) return SS_EINVAL;
+  static const uint16_t none = 0;
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  SS_HIP(hipStreamSynchronize(s->stream));
+  const uint32_t first = s->bm_n_terms / std::max<uint32_t>(s->bm_n_fields, 1) + s->sp_n;
+  SS_TRY(ssi_bm25_append_sparse_fields(s, n_lists, offs, docs, fields, tfs, positions ? positions : &none, n_positions, npos));
+  if (first_term_id_out) *first_term_id_out = first;
+  return SS_OK;
+}
 int ss_bm25_sparse_info(ss_shard* s, uint32_t* n_lists, uint64_t* n_postings, uint64_t* bytes) {
   if (!s) return SS_EINVAL;
   const uint64_t np = s->h_sp_base.empty() ? 0 : s->h_sp_base.back();
@@ -1076,6 +1102,7 @@ static int bm25_search_tiered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, 
   std::vector<uint32_t> special;       // unions with a SPARSE NOT term: answered one by one under a per-query exclusion bitmap
   std::vector<ss_bm25_query> sub;      // the dense sub-batch: all-dense queries as they are, tiered unions reduced to their dense terms
   std::vector<ss_bm25_query> spq;      // the tiered queries, whole, for the sparse kernel
+  std::vector<ss_bm25_query> spq_phrase;  // ... the phrases among them, for the sparse phrase kernel
   std::vector<uint32_t> dense_row(nq, 0xFFFFFFFFu), sparse_row(nq, 0xFFFFFFFFu);
   for (uint32_t i = 0; i < nq; i++) {
     const uint32_t op = bm_q_op(q[i].op), n_not = bm_q_nnot(q[i].op), all = q[i].n_terms + n_not;
@@ -1093,11 +1120,28 @@ static int bm25_search_tiered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, 
       sub.push_back(q[i]);
       continue;
     }
-    if (op != SS_OP_INTERSECTION && op != SS_OP_UNION) return SS_ENOTSUP;  // no phrases over sparse lists
-    if (bm_q_field_filter(q[i].op) || bm_q_all_frequent(q[i].op)) return SS_ENOTSUP;
-    const bool is_and = op == SS_OP_INTERSECTION && q[i].n_terms > 1;
+    if (op != SS_OP_INTERSECTION && op != SS_OP_UNION && op != SS_OP_PHRASE) return SS_EINVAL;
+    const bool is_phrase = op == SS_OP_PHRASE;
+    // a field filter needs the (term, field) lists the tier does not keep -- except a phrase's, which is a test on its positions' tags
+    if ((bm_q_field_filter(q[i].op) && !(is_phrase && s->bm_n_fields > 1)) || bm_q_all_frequent(q[i].op)) return SS_ENOTSUP;
+    if (bm_q_field_filter(q[i].op) >> bm_real_fields(s)) return SS_EINVAL;
+    const bool is_and = (op == SS_OP_INTERSECTION && q[i].n_terms > 1) || is_phrase;
     // (a union's dense part cannot probe a sparse NOT list; an intersection is driven by a sparse list -- it needs one)
-    if (sparse_not && (!is_and || !sparse_pos)) special.push_back(i);
+    const bool is_special = sparse_not && (!is_and || !sparse_pos);
+    if (is_special) special.push_back(i);
+    if (is_phrase && !is_special) {  // the sparse phrase kernel (bm25_sparse.hip): its shortest sparse list drives
+      if (q[i].phrase_len < 2 || q[i].phrase_len > SS_MAX_PHRASE || q[i].phrase_seq[0] >= q[i].n_terms) return SS_EINVAL;
+      for (uint32_t j = 1; j < q[i].phrase_len; j++)
+        if (q[i].phrase_seq[j] >= q[i].n_terms && q[i].phrase_seq[j] != SS_PHRASE_SKIP) return SS_EINVAL;
+      if (q[i].n_terms > 6) return SS_ENOTSUP;
+      bool dense_pos = false;
+      for (uint32_t t = 0; t < q[i].n_terms; t++) dense_pos |= q[i].term[t] < n_dense;
+      // positions: the tier's own, and the image's for the phrase's dense words
+      if (!s->d_sp_pos_end || (dense_pos && (s->bm_n_fields > 1 ? !s->d_pos32 : !s->d_pos))) return SS_ESTATE;
+      sparse_row[i] = 0x80000000u | (uint32_t)spq_phrase.size();  // row behind the plain queries' (fixed up below)
+      spq_phrase.push_back(q[i]);
+      continue;
+    }
     sparse_row[i] = (uint32_t)spq.size();
     spq.push_back(q[i]);
     if (!is_and) {  // the union's dense terms (with its NOT terms) as a query of their own
@@ -1116,6 +1160,10 @@ static int bm25_search_tiered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, 
   }
   SS_HIP(hipSetDevice(s->device));
   if (!special.empty()) return bm25_search_tiered_excl(s, nq, q, kk, rt, special);
+  const uint32_t ns_plain = (uint32_t)spq.size();
+  for (uint32_t i = 0; i < nq; i++)
+    if (sparse_row[i] != 0xFFFFFFFFu && (sparse_row[i] & 0x80000000u)) sparse_row[i] = ns_plain + (sparse_row[i] & 0x7FFFFFFFu);
+  spq.insert(spq.end(), spq_phrase.begin(), spq_phrase.end());
   const uint32_t kw = std::max<uint32_t>(kk, 1), ns = (uint32_t)spq.size(), nd = (uint32_t)sub.size();
   const int KPL = ssi_bm25_sparse_kpl(kw);
   SS_TRY(ensure_out(s, std::max<size_t>(nq, nd), kw));  // reserved before the sub-batch runs: its own ensure_out then keeps the buffers
@@ -1139,7 +1187,9 @@ static int bm25_search_tiered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, 
   SS_HIP(hipMemcpy(W + o_dr, dense_row.data(), (size_t)nq * 4, hipMemcpyHostToDevice));
   SS_HIP(hipMemcpy(W + o_sr, sparse_row.data(), (size_t)nq * 4, hipMemcpyHostToDevice));
   if (nd) SS_TRY(bm25_search_host_queries(s, nd, sub.data(), kk, rt, 0, nullptr));  // -> s->d_out_* rows [0, nd)
-  SS_TRY(ssi_bm25_launch_sparse(s, (const ss_bm25_query*)(W + o_q), ns, kk, (unsigned long long*)(W + o_keys), (unsigned long long*)(W + o_ext), s->stream));
+  SS_TRY(ssi_bm25_launch_sparse(s, (const ss_bm25_query*)(W + o_q), ns_plain, kk, (unsigned long long*)(W + o_keys), (unsigned long long*)(W + o_ext), s->stream));
+  SS_TRY(ssi_bm25_launch_sparse_phrase(s, (const ss_bm25_query*)(W + o_q) + ns_plain, ns - ns_plain, kk,
+                                       (unsigned long long*)(W + o_keys) + (size_t)ns_plain * 64 * KPL, (unsigned long long*)(W + o_ext) + ns_plain, s->stream));
   SS_TRY(ssi_bm25_launch_tier_merge(nq, kk, (const uint32_t*)(W + o_dr), (const uint32_t*)(W + o_sr), s->d_out_doc, s->d_out_score, s->d_out_count,
                                     (const unsigned long long*)s->d_out_total, (const unsigned long long*)(W + o_keys),
                                     (const unsigned long long*)(W + o_ext), (uint32_t*)(W + o_doc), (float*)(W + o_sc), (uint32_t*)(W + o_cnt),

@@ -333,6 +333,10 @@ struct ss_shard {
   uint64_t* d_sp_base = nullptr;     // [sp_n + 1] first posting of every sparse list
   uint64_t* d_sp_post = nullptr;     // the postings, list after list, ascending docs inside a list
   uint32_t sp_n = 0;
+  void* d_sp_pos = nullptr;          // positions of the sparse postings (phrase queries): u16 (one indexed field) or u32 field << 20 | position
+  uint64_t* d_sp_pos_end = nullptr;  // [sparse postings] END of every posting's positions in d_sp_pos (its start = the posting before's end)
+  uint64_t sp_pos_n = 0;
+  uint32_t sp_pos_elem = 0;          // 2 | 4
   std::vector<uint64_t> h_sp_base;   // host copy of d_sp_base (posting counts = the df the host needs for idf)
   void* d_tier_ws = nullptr;         // workspace of a tiered search (sub-queries, row maps, sparse lists, merged answers), grow-only
   size_t tier_ws_cap = 0;
@@ -491,12 +495,16 @@ void ssi_prof_end(ss_shard* s, int kernel, hipStream_t st, hipEvent_t e0, hipEve
 int ssi_bm25_rebuild_from_raw(const ss_shard* s, const std::vector<ss_raw_level>& levels, uint32_t n_terms, const uint8_t* doclen, uint64_t n_doclen,
                               ss_shard* img, hipStream_t st, bool one_shot = false);
 // ---- sparse tier (synth.hip: append; bm25_sparse.hip: kernels)
-int ssi_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs);
-int ssi_bm25_append_sparse_fields(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields, const uint16_t* tfs);
+int ssi_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
+                           const uint16_t* positions = nullptr, uint64_t n_positions = 0, const uint16_t* npos = nullptr);
+int ssi_bm25_append_sparse_fields(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields, const uint16_t* tfs,
+                                  const uint16_t* positions = nullptr, uint64_t n_positions = 0, const uint16_t* npos = nullptr);
 // keys per lane of the sparse tier's top-k lists (rows of 64 * KPL keys), as the dense kernels choose theirs
 inline int ssi_bm25_sparse_kpl(uint32_t kk) { return kk <= 64 ? 1 : kk <= 128 ? 2 : kk <= 256 ? 4 : 16; }
 int ssi_bm25_launch_sparse(const ss_shard* s, const ss_bm25_query* d_q, uint32_t nq, uint32_t k, unsigned long long* d_keys,
                            unsigned long long* d_extra, hipStream_t st);
+int ssi_bm25_launch_sparse_phrase(const ss_shard* s, const ss_bm25_query* d_q, uint32_t nq, uint32_t k, unsigned long long* d_keys,
+                                  unsigned long long* d_extra, hipStream_t st);
 int ssi_bm25_sparse_excl_bits(const ss_shard* s, const uint32_t* d_base_bits, uint32_t base_words, const uint32_t* lists, uint32_t n_lists,
                               uint32_t* d_out, uint32_t words, hipStream_t st);
 int ssi_bm25_launch_tier_merge(uint32_t nq, uint32_t k, const uint32_t* d_dense_row, const uint32_t* d_sparse_row, const uint32_t* d_doc,

@@ -585,9 +585,12 @@ int ssi_bm25_rebuild_from_raw(const ss_shard* s, const std::vector<ss_raw_level>
 // (bm25_sparse.hip).  The weights are computed here, on the host, by the same routine and component cache as every dense
 // posting's (bm_code_of): the length bytes come back from the device once per call.
 // the packed postings of n_lists new sparse lists (list i: base[i] .. base[i + 1] of `packed`) behind the ones the tier holds
-static int sparse_install(ss_shard* s, uint32_t n_lists, const std::vector<u64>& lbase, const std::vector<u64>& packed);
+// counts / pos (optional): positions per new posting and their concatenation (elem = 2: u16, one indexed field; 4: u32 field-tagged)
+static int sparse_install(ss_shard* s, uint32_t n_lists, const std::vector<u64>& lbase, const std::vector<u64>& packed,
+                          const std::vector<uint32_t>* counts = nullptr, const void* pos = nullptr, u64 n_pos = 0, size_t elem = 0);
 
-int ssi_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs) {
+int ssi_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
+                           const uint16_t* positions, uint64_t n_positions, const uint16_t* npos) {
   if (!s->d_post || !s->d_doclen) return SS_ESTATE;
   if (s->bm_n_fields != 1 || s->bm_merged) return SS_ENOTSUP;  // several indexed fields: ssi_bm25_append_sparse_fields
   if ((uint64_t)s->sp_n + n_lists > 0x7FFFFFFFull - s->bm_n_terms) return SS_ENOTSUP;
@@ -611,14 +614,20 @@ int ssi_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, 
   std::vector<u64> lbase((size_t)n_lists + 1);
   for (uint32_t i = 0; i <= n_lists; i++) lbase[i] = offs[i] - offs[0];
   packed.resize(n_new);
-  return sparse_install(s, n_lists, lbase, packed);
+  if (!positions) return sparse_install(s, n_lists, lbase, packed);
+  // positions (phrase queries): per posting its tf positions -- or npos of them: the component terms of an n-gram key, whose own
+  // positions stand behind the FIRST component's postings (ssi_bm25_upload_positions)
+  std::vector<uint32_t> counts(n_new);
+  for (u64 j = 0; j < n_new; j++) counts[j] = npos ? npos[offs[0] + j] : tfs[offs[0] + j];
+  return sparse_install(s, n_lists, lbase, packed, &counts, positions, n_positions, sizeof(uint16_t));
 }
 
 // Several indexed fields (an image with MERGED lists): the entries (doc, field, tf) of every rare term, sorted by (doc, field) like
 // ssi_bm25_upload_fields takes them.  The sparse tier keeps a term's MERGED list only -- every doc once, its weight the sum over the
 // doc's fields of boost_f * tf (K + 1) / (tf + comp[len_f]), fields ascending, coded against the scale the dense merged lists were
 // built with (ssi_bm25_build_from_host_merged): what a query without a field filter reads of a dense term, too.
-int ssi_bm25_append_sparse_fields(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields, const uint16_t* tfs) {
+int ssi_bm25_append_sparse_fields(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields, const uint16_t* tfs,
+                                  const uint16_t* positions, uint64_t n_positions, const uint16_t* npos) {
   if (!s->d_post) return SS_ESTATE;
   const uint32_t L = s->bm_n_fields, RF = bm_real_fields(s);
   if (L == 1) return SS_EINVAL;
@@ -666,14 +675,41 @@ int ssi_bm25_append_sparse_fields(ss_shard* s, uint32_t n_lists, const uint64_t*
     }
   });
   if (fail.load()) return fail.load();
-  return sparse_install(s, n_lists, lbase, packed);
+  if (!positions) return sparse_install(s, n_lists, lbase, packed);
+  // positions: per ENTRY (doc, field) in order; a merged posting owns those of all the doc's entries, each tagged with its field
+  // (ssi_bm25_upload_positions_fields)
+  if (!npos) npos = tfs;
+  std::vector<uint32_t> counts(packed.size()), pool(n_positions ? n_positions : 1);
+  u64 at = 0, w = 0;
+  for (uint32_t i = 0; i < n_lists; i++)
+    for (u64 j = offs[i]; j < offs[i + 1];) {
+      uint32_t c = 0;
+      u64 e = j;
+      for (; e < offs[i + 1] && docs[e] == docs[j]; e++) {
+        if (at + npos[e] > n_positions) return SS_EINVAL;
+        for (uint32_t x = 0; x < npos[e]; x++, at++) {
+          if (x && positions[at] <= positions[at - 1]) return SS_EINVAL;  // ascending inside a field
+          pool[at] = ((uint32_t)fields[e] << BM_POS_FIELD_SHIFT) | positions[at];
+        }
+        c += npos[e];
+      }
+      counts[w++] = c;
+      j = e;
+    }
+  if (at != n_positions) return SS_EINVAL;
+  return sparse_install(s, n_lists, lbase, packed, &counts, pool.data(), n_positions, sizeof(uint32_t));
 }
 
-static int sparse_install(ss_shard* s, uint32_t n_lists, const std::vector<u64>& lbase, const std::vector<u64>& packed) {
+static int sparse_install(ss_shard* s, uint32_t n_lists, const std::vector<u64>& lbase, const std::vector<u64>& packed,
+                          const std::vector<uint32_t>* counts, const void* pos, u64 n_pos, size_t elem) {
   const u64 n_new = packed.size();
   const u64* offs = lbase.data();
   const u64 old_n = s->h_sp_base.empty() ? 0 : s->h_sp_base.back();
-  uint64_t *nb = nullptr, *np = nullptr;
+  if (counts && s->d_sp_pos_end && s->sp_pos_elem != elem) return SS_EINVAL;
+  uint64_t *nb = nullptr, *np = nullptr, *ne = nullptr;
+  void* npp = nullptr;
+  const bool with_pos = counts != nullptr || s->d_sp_pos_end != nullptr;  // the tier carries positions from the first append that brings some
+  const size_t el = counts ? elem : s->sp_pos_elem;
   SS_HIP(hipMalloc(&nb, ((size_t)s->sp_n + n_lists + 1) * sizeof(u64)));
   if (hipMalloc(&np, (size_t)std::max<u64>(old_n + n_new, 1) * sizeof(u64)) != hipSuccess) { (void)hipFree(nb); return SS_ENOMEM; }
   std::vector<uint64_t> base = s->h_sp_base;
@@ -682,7 +718,26 @@ static int sparse_install(ss_shard* s, uint32_t n_lists, const std::vector<u64>&
   bool ok = hipMemcpy(nb, base.data(), base.size() * sizeof(u64), hipMemcpyHostToDevice) == hipSuccess;
   if (ok && old_n) ok = hipMemcpy(np, s->d_sp_post, old_n * sizeof(u64), hipMemcpyDeviceToDevice) == hipSuccess;
   if (ok && n_new) ok = hipMemcpy(np + old_n, packed.data(), n_new * sizeof(u64), hipMemcpyHostToDevice) == hipSuccess;
-  if (!ok) { (void)hipFree(nb); (void)hipFree(np); return SS_EDEVICE; }
+  if (ok && with_pos) {
+    // END of every posting's positions in the pool (a posting appended without positions has none: its end = its start)
+    std::vector<u64> ends(std::max<u64>(old_n + n_new, 1), 0);
+    if (old_n && s->d_sp_pos_end) ok = hipMemcpy(ends.data(), s->d_sp_pos_end, old_n * sizeof(u64), hipMemcpyDeviceToHost) == hipSuccess;
+    u64 run = s->sp_pos_n;
+    for (u64 x = 0; x < n_new; x++) { run += counts ? (*counts)[x] : 0u; ends[old_n + x] = run; }
+    if (ok && counts && run - s->sp_pos_n != n_pos) { (void)hipFree(nb); (void)hipFree(np); return SS_EINVAL; }
+    ok = ok && hipMalloc(&ne, ends.size() * sizeof(u64)) == hipSuccess &&
+         hipMemcpy(ne, ends.data(), ends.size() * sizeof(u64), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMalloc(&npp, (size_t)std::max<u64>(run, 1) * el) == hipSuccess;
+    if (ok && s->sp_pos_n) ok = hipMemcpy(npp, s->d_sp_pos, s->sp_pos_n * el, hipMemcpyDeviceToDevice) == hipSuccess;
+    if (ok && counts && n_pos) ok = hipMemcpy((char*)npp + s->sp_pos_n * el, pos, n_pos * el, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+      if (s->d_sp_pos_end) (void)hipFree(s->d_sp_pos_end);
+      if (s->d_sp_pos) (void)hipFree(s->d_sp_pos);
+      s->d_sp_pos_end = ne; s->d_sp_pos = npp; s->sp_pos_n = run; s->sp_pos_elem = (uint32_t)el;
+      ne = nullptr; npp = nullptr;
+    }
+  }
+  if (!ok) { (void)hipFree(nb); (void)hipFree(np); if (ne) (void)hipFree(ne); if (npp) (void)hipFree(npp); return SS_EDEVICE; }
   if (s->d_sp_base) (void)hipFree(s->d_sp_base);
   if (s->d_sp_post) (void)hipFree(s->d_sp_post);
   s->d_sp_base = nb;

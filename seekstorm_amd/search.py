@@ -1040,26 +1040,44 @@ class Shard:
         return ro
 
     # ---- measurement hooks
-    def append_sparse(self, term_offsets, doc_ids, tfs):
+    def append_sparse(self, term_offsets, doc_ids, tfs, positions=None, npos=None):
         """lists of RARE terms into the image's sparse tier (ss_bm25_append_sparse: plain sorted lists, no directory / probe rows);
-        returns the term id of the first appended list -- the ids continue behind the dense terms"""
+        returns the term id of the first appended list -- the ids continue behind the dense terms.
+        positions: every posting's positions in order (phrase queries naming a sparse term); npos: their number per posting where
+        that is not the tf"""
         offs = np.ascontiguousarray(term_offsets, np.uint64)
         d = np.ascontiguousarray(doc_ids, np.uint32)
         t = np.ascontiguousarray(tfs, np.uint16)
         first = C.c_uint32()
+        if positions is not None:
+            ps = np.ascontiguousarray(positions, np.uint16)
+            npc = None if npos is None else np.ascontiguousarray(npos, np.uint16)
+            N.check(N.lib().ss_bm25_append_sparse_positions(self._h, len(offs) - 1, N.ptr(offs, N.u64p), N.ptr(d, N.u32p), N.ptr(t, N.u16p),
+                                                            N.ptr(ps, N.u16p), len(ps), N.ptr(npc, N.u16p), C.byref(first)),
+                    "ss_bm25_append_sparse_positions")
+            self._df_cache.clear()
+            return int(first.value)
         N.check(N.lib().ss_bm25_append_sparse(self._h, len(offs) - 1, N.ptr(offs, N.u64p), N.ptr(d, N.u32p), N.ptr(t, N.u16p), C.byref(first)),
                 "ss_bm25_append_sparse")
         self._df_cache.clear()
         return int(first.value)
 
-    def append_sparse_fields(self, term_offsets, doc_ids, field_ids, tfs):
+    def append_sparse_fields(self, term_offsets, doc_ids, field_ids, tfs, positions=None, npos=None):
         """... on an image with several indexed fields: entries (doc, field, tf) sorted by (doc, field) per term; the tier keeps the
-        terms' merged lists (ss_bm25_append_sparse_fields)"""
+        terms' merged lists (ss_bm25_append_sparse_fields); positions: every entry's positions inside its field"""
         offs = np.ascontiguousarray(term_offsets, np.uint64)
         d = np.ascontiguousarray(doc_ids, np.uint32)
         f = np.ascontiguousarray(field_ids, np.uint8)
         t = np.ascontiguousarray(tfs, np.uint16)
         first = C.c_uint32()
+        if positions is not None:
+            ps = np.ascontiguousarray(positions, np.uint16)
+            npc = None if npos is None else np.ascontiguousarray(npos, np.uint16)
+            N.check(N.lib().ss_bm25_append_sparse_fields_positions(self._h, len(offs) - 1, N.ptr(offs, N.u64p), N.ptr(d, N.u32p), N.ptr(f, N.u8p),
+                                                                   N.ptr(t, N.u16p), N.ptr(ps, N.u16p), len(ps), N.ptr(npc, N.u16p),
+                                                                   C.byref(first)), "ss_bm25_append_sparse_fields_positions")
+            self._df_cache.clear()
+            return int(first.value)
         N.check(N.lib().ss_bm25_append_sparse_fields(self._h, len(offs) - 1, N.ptr(offs, N.u64p), N.ptr(d, N.u32p), N.ptr(f, N.u8p),
                                                      N.ptr(t, N.u16p), C.byref(first)), "ss_bm25_append_sparse_fields")
         self._df_cache.clear()

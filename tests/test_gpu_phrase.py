@@ -210,7 +210,7 @@ def test_phrase_queries_on_a_default_index_with_ngram_keys(S, O):
 
 def test_positions_beside_a_sparse_tier(S, O):
     """ss_index_bin_tier + ss_bm25_upload_index_bin_positions: the dense terms carry positions (phrases over them answer like the
-    untiered image), the rare keys sit in the sparse tier and still serve set queries; a phrase naming a sparse term is refused"""
+    untiered image), the rare keys sit in the sparse tier with THEIR positions: set queries and phrases naming the rare word"""
     import ngram_corpus as NG
     from oracle import ref_format as RF
     n_docs = 70_000
@@ -232,10 +232,81 @@ def test_positions_beside_a_sparse_tier(S, O):
     ua = a.search_lexical_batch(a.make_queries([[ta[3], ta[0]]], S.QueryType.Union), 10)
     ub = b.search_lexical_batch(b.make_queries([[tb[3], tb[0]]], S.QueryType.Union), 10)
     assert int(ua[3][0]) == int(ub[3][0]) and np.allclose(ua[1], ub[1], rtol=1e-6)
-    with pytest.raises(S.SeekStormHipError):
-        a.search_lexical_batch(a.make_queries([[ta[3], ta[0]]], S.QueryType.Phrase), 10)
+    # a phrase naming the rare word: driven by its sparse list, positions of both tiers -- the untiered image's answer
+    for ph in ([3, 0], [0, 3], [3, 0, 1], [3, 3]):
+        ra = a.search_lexical_batch(a.make_queries([[ta[w] for w in ph]], S.QueryType.Phrase), 10)
+        rb = b.search_lexical_batch(b.make_queries([[tb[w] for w in ph]], S.QueryType.Phrase), 10)
+        assert int(ra[3][0]) == int(rb[3][0]) and np.array_equal(ra[2], rb[2]) and np.allclose(ra[1], rb[1], rtol=1e-6), ph
+        n = int(ra[2][0])
+        assert set(ra[0][0][:n].tolist()) == set(rb[0][0][:n].tolist())
+    assert int(a.search_lexical_batch(a.make_queries([[ta[3], ta[0]]], S.QueryType.Phrase), 10)[3][0]) >= 20  # the planted ones
     a.close()
     b.close()
+
+
+def test_phrases_naming_sparse_terms(S, O):
+    """phrases whose rare words sit in the SPARSE tier (ss_bm25_append_sparse_positions): the shortest sparse list drives, every other
+    word is found by binary search with its positions (sparse: the tier's pool; dense: the image's) -- 2- to 5-word phrases, repeated
+    words, NOT terms of either tier, tombstones, counts, k = 10 / 100, mixed batches; against the oracle holding every list"""
+    from seekstorm_amd import _native as N
+    n_docs = 120_000
+    dfs = [30_000, 22_000, 9_000, 500, 300, 1_500, 40]
+    nd = 3
+    plant = [([0, 3], 80), ([3, 4], 40), ([1, 3, 2], 60), ([5, 0, 5], 50), ([4, 4], 30), ([0, 1], 300), ([6, 5, 3, 0, 1], 12), ([2, 5], 70)]
+    dl, offs, docs, tfs, positions = _corpus(O, n_docs, dfs, 23, plant)
+    e = int(offs[nd])
+    pe = int(tfs[:e].astype(np.int64).sum())
+    sh = S.Shard(0)
+    sh.upload_lexical(n_docs, dl, offs[:nd + 1], docs[:e], tfs[:e], positions[:pe])
+    mid = nd + 2
+    m = int(offs[mid]); pm = int(tfs[:m].astype(np.int64).sum())
+    assert sh.append_sparse(offs[nd:mid + 1] - offs[nd], docs[e:m], tfs[e:m], positions=positions[pe:pm]) == nd
+    assert sh.append_sparse(offs[mid:] - offs[mid], docs[m:], tfs[m:], positions=positions[pm:]) == mid
+    osh = O.Shard(n_docs, dl, offs, docs, tfs)
+    osh.set_positions(positions)
+    cases = [([0, 3], []), ([3, 0], []), ([3, 4], []), ([1, 3, 2], []), ([5, 0, 5], []), ([4, 4], []), ([6, 5, 3, 0, 1], []), ([2, 5], []),
+             ([0, 3], [1]), ([2, 5], [3, 0]), ([3, 4], [5]), ([0, 1], [3]), ([0, 1], []), ([5, 2], [])]
+    q = sh.make_queries([c[0] for c in cases], S.QueryType.Phrase, [c[1] for c in cases])
+    gone = list(range(3, n_docs, 61))
+    for deleted in (False, True):
+        sh.set_deleted(gone if deleted else [])
+        osh.set_deleted(gone if deleted else [])
+        for k in (10, 100):
+            res = {rt: sh.search_lexical_batch(q, k, rt) for rt in (S.ResultType.TopkCount, S.ResultType.Count)}
+            for i, (ph, neg) in enumerate(cases):
+                uniq = list(dict.fromkeys(ph))
+                seq = [uniq.index(w) for w in ph]
+                od, os_, otot = osh.search_phrase(uniq, seq, n_docs)
+                drop = set()
+                for t in neg:
+                    drop |= set(docs[int(offs[t]):int(offs[t + 1])].tolist())
+                keep = [j for j, d in enumerate(od.tolist()) if d not in drop]
+                od, os_ = od[keep][:k], os_[keep][:k]
+                doc, score, cnt, tot = res[S.ResultType.TopkCount]
+                assert int(tot[i]) == len(keep), (ph, neg, deleted, k, int(tot[i]), len(keep))
+                assert cnt[i] == len(od) and np.allclose(score[i][:cnt[i]], os_, rtol=1e-4), (ph, neg)
+                if len(od) < k:
+                    assert set(doc[i][:cnt[i]].tolist()) == set(od.tolist())
+                assert int(res[S.ResultType.Count][3][i]) == len(keep)
+    sh.set_deleted([])
+    osh.set_deleted([])
+    assert int(sh.search_lexical_batch(sh.make_queries([[0, 3]], S.QueryType.Phrase), 10)[3][0]) >= 80
+    # a batch mixing sparse phrases with set queries and dense phrases
+    qm = sh.make_queries([[0, 3], [0, 3], [0, 1], [3, 4], [3, 0]], [S.QueryType.Phrase, S.QueryType.Union, S.QueryType.Phrase, S.QueryType.Intersection,
+                                                                    S.QueryType.Phrase])
+    tm = sh.search_lexical_batch(qm, 10, reference_shortcuts=False)[3]
+    assert int(tm[0]) == osh.search_phrase([0, 3], [0, 1], 10)[2] and int(tm[1]) == osh.search_exhaustive([0, 3], O.OP_OR, 10)[2]
+    assert int(tm[2]) == osh.search_phrase([0, 1], [0, 1], 10)[2] and int(tm[3]) == osh.search_exhaustive([3, 4], O.OP_AND, 10)[2]
+    assert int(tm[4]) == osh.search_phrase([3, 0], [0, 1], 10)[2]
+    # a tier without positions refuses the phrase, not the set query
+    sh2 = S.Shard(0)
+    sh2.upload_lexical(n_docs, dl, offs[:nd + 1], docs[:e], tfs[:e], positions[:pe])
+    sh2.append_sparse(offs[nd:] - offs[nd], docs[e:], tfs[e:])
+    with pytest.raises(N.SeekStormHipError):
+        sh2.search_lexical_batch(sh2.make_queries([[0, 3]], S.QueryType.Phrase), 10)
+    sh2.search_lexical_batch(sh2.make_queries([[0, 3]], S.QueryType.Intersection), 10)
+    sh2.close()
+    sh.close()
 
 
 # ------------------------------------------------------------------------------------------------ several indexed fields
@@ -331,6 +402,47 @@ def test_phrase_queries_over_several_indexed_fields(S, O):
     # a positions array of the wrong length is refused before anything is built
     with pytest.raises(S.SeekStormHipError):
         sh.upload_lexical_fields(n_docs, dl, boost, offs, docs, fields, tfs, positions[:-1])
+    sh.close()
+
+
+def test_phrases_naming_sparse_terms_over_several_indexed_fields(S, O):
+    """the sparse tier of a multi-field image with positions (ss_bm25_append_sparse_fields_positions): merged lists, field-tagged
+    positions; the phrase must stand inside one field, a field filter lists the fields it may stand in -- against the BM25F phrase oracle"""
+    n_docs, n_fields = 90_000, 3
+    dfs = [26_000, 20_000, 8_000, 400, 900, 150]
+    nd = 3
+    plant = [([0, 3], 0, 90), ([0, 3], 2, 60), ([3, 4], 1, 50), ([1, 4, 2], 2, 40), ([5, 0, 5], 0, 30), ([3, 3], 1, 25), ([0, 1], 0, 200)]
+    cross = [(0, 3, 200), (3, 4, 100)]
+    boost = np.array([2.0, 1.0, 0.5], np.float32)
+    dl, offs, docs, fields, tfs, positions = _corpus_fields(O, n_docs, n_fields, dfs, 29, plant, cross)
+    e = int(offs[nd]); pe = int(tfs[:e].astype(np.int64).sum())
+    sh = S.Shard(0)
+    sh.upload_lexical_fields(n_docs, dl, boost, offs[:nd + 1], docs[:e], fields[:e], tfs[:e], positions[:pe])
+    assert sh.append_sparse_fields(offs[nd:] - offs[nd], docs[e:], fields[e:], tfs[e:], positions=positions[pe:]) == nd
+    phrases = [[0, 3], [3, 0], [3, 4], [1, 4, 2], [5, 0, 5], [3, 3], [4, 3], [0, 1]]
+    gone = list(range(5, n_docs, 89))
+    for filt in ((), (0,), (1, 2)):
+        q = sh.make_queries(phrases, S.QueryType.Phrase, field_filter=filt)
+        for deleted in (False, True):
+            sh.set_deleted(gone if deleted else [])
+            for k in (10, 100):
+                res = {rt: sh.search_lexical_batch(q, k, rt) for rt in (S.ResultType.TopkCount, S.ResultType.Count)}
+                for i, ph in enumerate(phrases):
+                    uniq = list(dict.fromkeys(ph))
+                    seq = [uniq.index(w) for w in ph]
+                    od, os_, otot = O.search_fields_phrase(n_docs, dl, boost, offs, docs, fields, tfs, positions, uniq, seq, k,
+                                                           deleted=gone if deleted else (), field_filter=filt, reference_loop=False)
+                    doc, score, cnt, tot = res[S.ResultType.TopkCount]
+                    assert int(tot[i]) == otot, (ph, filt, deleted, int(tot[i]), otot)
+                    assert cnt[i] == len(od) and np.allclose(score[i][:cnt[i]], os_, rtol=1e-4), (ph, filt)
+                    if len(od) < k:
+                        assert set(doc[i][:cnt[i]].tolist()) == set(od.tolist())
+                    assert int(res[S.ResultType.Count][3][i]) == otot
+    sh.set_deleted([])
+    # the cross-field neighbours are no phrase
+    t_ph = int(sh.search_lexical_batch(sh.make_queries([[0, 3]], S.QueryType.Phrase), 10)[3][0])
+    t_and = int(sh.search_lexical_batch(sh.make_queries([[0, 3]], S.QueryType.Intersection), 10, reference_shortcuts=False)[3][0])
+    assert 150 <= t_ph <= t_and - 150
     sh.close()
 
 
