@@ -275,15 +275,18 @@ int ss_bm25_fields_info(ss_shard* s, uint32_t* n_fields, uint32_t* merged_lists,
  * sparse list scored in full by binary-search probes of the query's other lists (north_star's galloping, intersection.rs:352-362),
  * the two lists merged per query; intersections -- the shortest sparse list drives.  Exact counts, tombstones, NOT terms
  * (a union that excludes a SPARSE term is answered on its own, under an exclusion bitmap = tombstones | the list's docs), facet
- * filters, k <= SS_MAX_K, phrases (ss_bm25_append_sparse_positions).  No field filters over sparse terms other than a phrase's (SS_ENOTSUP).  The device-pointer entry points take
+ * filters, k <= SS_MAX_K, phrases (ss_bm25_append_sparse_positions), field filters of intersections, single terms and phrases (a UNION
+ * of several terms under a field filter that names a sparse term: SS_ENOTSUP).  The device-pointer entry points take
  * sparse terms when ops_mask bit 28 says so (one host round trip).  ss_bm25_term_df covers the sparse ids. */
 int ss_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
                           uint32_t* first_term_id_out);
 /* ... on an image with SEVERAL indexed fields (and merged lists, ss_bm25_fields_info): the entries (doc, field, tf) of every rare
  * term, sorted by (doc, field) as ss_bm25_upload_fields takes them.  The tier keeps a term's MERGED list -- every doc once, weighted
  * sum_f boost_f * tf (K + 1) / (tf + comp[len_f]) -- which is what a query without a field filter reads of a dense term as well;
- * a field filter over a sparse term stays SS_ENOTSUP.  SS_ENOTSUP too when a weight falls outside the range the dense merged lists
- * fixed the weight code to (boosts / lengths unlike anything in the dense image). */
+ * beside the weight a posting records the fields that hold the term, which is what a field filter asks of it (intersections, single
+ * terms; the score of a filtered query stays the merged weight, within the weight code's 1.5e-5 of the per-field sum).  SS_ENOTSUP
+ * when a weight falls outside the range the dense merged lists fixed the weight code to (boosts / lengths unlike anything in the
+ * dense image). */
 int ss_bm25_append_sparse_fields(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
                                  const uint16_t* tfs, uint32_t* first_term_id_out);
 /* ... with POSITIONS, for phrase queries naming a sparse term (a quoted rare word: the tier's typical phrase).  positions: for every

@@ -72,6 +72,9 @@ __global__ void __launch_bounds__(QW * 64) bm25_sparse_kernel(
   const ss_bm25_query* __restrict__ Q = qs + qi;
   const uint32_t nt = Q->n_terms, n_not = bm_q_nnot(Q->op);
   const bool is_and = bm_q_op(Q->op) == SS_OP_INTERSECTION && nt > 1;
+  // a field filter (several indexed fields; intersections and single terms): every term must stand in a listed field -- a sparse
+  // posting carries its fields, a dense term is looked up in its listed (term, field) lists; the score stays the merged weight's
+  const uint32_t filt = n_lists > 1u ? bm_q_field_filter(Q->op) : 0u;
   BmTop<KPL> T;
 #pragma unroll
   for (int r = 0; r < KPL; r++) T.keys[r] = 0ull;
@@ -109,23 +112,32 @@ __global__ void __launch_bounds__(QW * 64) bm25_sparse_kernel(
         uint32_t code = 0u;
         if ((uint32_t)t == s) {
           code = (uint32_t)(e >> 32);
+          if (filt && !((code >> BM_SP_FIELD_SHIFT) & filt)) live = false;
         } else if (live) {
           const uint32_t term = Q->term[t];
           if (term >= n_dense) {
             const uint32_t j = term - n_dense;
             const unsigned long long p = sp_find(sp_post, sp_base[j], sp_base[j + 1], doc);
             if (p < sp_base[j + 1] && (uint32_t)sp_post[p] == doc) code = (uint32_t)(sp_post[p] >> 32);
+            if (filt && (uint32_t)t < nt && !((code >> BM_SP_FIELD_SHIFT) & filt)) code = 0u;
             // a union scores a doc under the FIRST sparse list of the query that holds it
             if (code && !is_and && (uint32_t)t < s && (uint32_t)t < nt) live = false;
           } else {
             code = dense_find(post, term_base, sub_off, n_sub, term * n_lists + (n_lists - 1u), doc);
+            if (code && filt && (uint32_t)t < nt) {
+              bool listed = false;
+              for (uint32_t f = 0; f + 1u < n_lists; f++)
+                if (((filt >> f) & 1u) && !listed) listed = dense_find(post, term_base, sub_off, n_sub, term * n_lists + f, doc) != 0u;
+              if (!listed) code = 0u;
+            }
             if (code && (uint32_t)t < nt) in_dense = true;
           }
         }
+        code &= BM_SP_CODE_MASK;
         if ((uint32_t)t >= nt) {  // NOT terms: a doc found in one is no result (add_result.rs:3440-3497)
           if (code) live = false;
         } else {
-          if (is_and && !code) live = false;
+          if ((is_and || filt) && !code) live = false;
           if (code) { wv[t] = bm_wdecode(code); pres |= 1u << t; }
         }
       }
@@ -229,11 +241,11 @@ __global__ void __launch_bounds__(QW * 64) bm25_sparse_phrase_kernel(
         if (term >= n_dense) {
           unsigned long long p = x + lane;
           if ((uint32_t)t == drv) {
-            code = (uint32_t)(e >> 32);
+            code = (uint32_t)(e >> 32) & BM_SP_CODE_MASK;
           } else {
             const uint32_t j = term - n_dense;
             p = sp_find(sp_post, sp_base[j], sp_base[j + 1], doc);
-            if (p < sp_base[j + 1] && (uint32_t)sp_post[p] == doc) code = (uint32_t)(sp_post[p] >> 32);
+            if (p < sp_base[j + 1] && (uint32_t)sp_post[p] == doc) code = (uint32_t)(sp_post[p] >> 32) & BM_SP_CODE_MASK;
           }
           if (code) {
             const unsigned long long st = p ? sp_pos_end[p - 1] : 0ull;

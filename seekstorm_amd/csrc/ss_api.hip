@@ -1122,9 +1122,12 @@ static int bm25_search_tiered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, 
     }
     if (op != SS_OP_INTERSECTION && op != SS_OP_UNION && op != SS_OP_PHRASE) return SS_EINVAL;
     const bool is_phrase = op == SS_OP_PHRASE;
-    // a field filter needs the (term, field) lists the tier does not keep -- except a phrase's, which is a test on its positions' tags
-    if ((bm_q_field_filter(q[i].op) && !(is_phrase && s->bm_n_fields > 1)) || bm_q_all_frequent(q[i].op)) return SS_ENOTSUP;
+    // a field filter (several indexed fields): a phrase's is a test on its positions' tags; an intersection's / a single term's asks
+    // every term for a listed field -- a sparse posting carries its fields; a UNION of several terms under a filter is the dense tier's
+    // gated scan over (term, field) lists, which the tier does not keep
     if (bm_q_field_filter(q[i].op) >> bm_real_fields(s)) return SS_EINVAL;
+    const bool filtered = s->bm_n_fields > 1 && bm_q_field_filter(q[i].op) != 0u;
+    if ((filtered && op == SS_OP_UNION && q[i].n_terms > 1) || bm_q_all_frequent(q[i].op)) return SS_ENOTSUP;
     const bool is_and = (op == SS_OP_INTERSECTION && q[i].n_terms > 1) || is_phrase;
     // (a union's dense part cannot probe a sparse NOT list; an intersection is driven by a sparse list -- it needs one)
     const bool is_special = sparse_not && (!is_and || !sparse_pos);

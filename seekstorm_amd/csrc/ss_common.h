@@ -451,6 +451,8 @@ constexpr uint32_t BM_AND_FREQ = 0x100u;
 // positions of a multi-field image: field id above the position inside the field (positions < 65 536, phrases <= SS_MAX_PHRASE words:
 // start + word index never reaches bit 20)
 constexpr uint32_t BM_POS_FIELD_SHIFT = 20u;
+// a sparse posting's upper word: the 19-bit weight code, above it (several indexed fields) bit f = the doc holds the term in field f
+constexpr uint32_t BM_SP_FIELD_SHIFT = 19u, BM_SP_CODE_MASK = 0x7FFFFu;
 // A UNION under a field filter (add_result.rs:3124-3136 applied inside union_docid_3's sub-queries, union.rs:1330-1425: a doc ends
 // with the sum over its terms that occur in a LISTED field, all fields of those terms counted; a doc none of whose terms passes is
 // no result).  BM_AND_GATED in and_target / a term's av: the lists of a term come listed fields first (their postings add and set

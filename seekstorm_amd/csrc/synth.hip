@@ -663,13 +663,15 @@ int ssi_bm25_append_sparse_fields(ss_shard* s, uint32_t n_lists, const uint64_t*
       for (u64 j = offs[i]; j < offs[i + 1];) {
         float w = 0.f;
         u64 e = j;
+        uint32_t fmask = 0u;  // the fields that hold the term in this doc: what a field filter asks of a sparse posting
         for (; e < offs[i + 1] && docs[e] == docs[j]; e++) {
           const volatile float part = s->h_boost[fields[e]] * bm_weight_exact(tfs[e], comp[dl[(size_t)fields[e] * s->bm_n_docs + docs[e]]]);
           w = w + part;
+          fmask |= 1u << fields[e];
         }
         // the dense lists chose the scale from their own weights: a sparse weight outside the code's range is refused, not clamped
         if (!(w > 0.f) || w / mscale < 6.2e-5f || w / mscale >= 4.0f) { fail.store(SS_ENOTSUP); return; }
-        packed[w_at++] = ((u64)bm_wcode(w / mscale) << 32) | docs[j];
+        packed[w_at++] = ((u64)(bm_wcode(w / mscale) | (fmask << BM_SP_FIELD_SHIFT)) << 32) | docs[j];
         j = e;
       }
     }

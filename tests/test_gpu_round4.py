@@ -471,8 +471,21 @@ def test_sparse_tier_on_an_image_with_several_indexed_fields(S, O):
                                 _check_topk(doc[i], score[i], cnt[i], od, os_)
     sh.set_strategy(N.BM25_AUTO)
     sh.set_deleted(())
-    with pytest.raises(N.SeekStormHipError):  # the tier holds merged lists: nothing to filter by field
-        sh.search_lexical_batch(sh.make_queries([[0, 4]], S.QueryType.Intersection, field_filter=[0]), 10)
-    # a dense-only query of the same image still takes its field filter
-    sh.search_lexical_batch(sh.make_queries([[0, 1]], S.QueryType.Intersection, field_filter=[0]), 10)
+    # field filters (intersections and single terms: every term must stand in a listed field -- a sparse posting records its fields)
+    fcases = [([0, 4], []), ([6, 9], []), ([4], []), ([9, 6, 1], []), ([6, 0], [9]), ([2, 1], [6]), ([9], [0]), ([0, 1], [])]
+    for deleted in ((), gone):
+        sh.set_deleted(deleted)
+        for filt in ((0,), (1, 2), (2,)):
+            q = sh.make_queries([c[0] for c in fcases], S.QueryType.Intersection, [c[1] for c in fcases], field_filter=filt)
+            for rt in (S.ResultType.TopkCount, S.ResultType.Count):
+                doc, score, cnt, tot = sh.search_lexical_batch(q, 10, rt, reference_shortcuts=False)
+                for i, (pos, neg) in enumerate(fcases):
+                    od, os_, otot, _ = O.search_fields_exhaustive(n_docs, dl, boost, offs, docs, fields, tfs, pos, O.OP_AND, 10, neg, deleted,
+                                                                  field_filter=filt)
+                    assert int(tot[i]) == otot, (pos, neg, filt, rt, int(tot[i]), otot)
+                    if rt != S.ResultType.Count:
+                        _check_topk(doc[i], score[i], cnt[i], od, os_)
+    sh.set_deleted(())
+    with pytest.raises(N.SeekStormHipError):  # a UNION of several terms under a filter is the dense tier's gated scan over (term, field) lists
+        sh.search_lexical_batch(sh.make_queries([[0, 4]], S.QueryType.Union, field_filter=[0]), 10)
     sh.close()
