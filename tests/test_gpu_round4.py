@@ -171,6 +171,7 @@ def test_drop_in_rehearsal_on_a_million_doc_index_bin(S, O):
     assert r["files"]["keys"] >= 1_000_000 and r["files"]["ngram_keys"] > 10_000
     assert r["open"]["sparse_terms"] > 900_000 and r["open"]["dense_terms"] > 1000
     assert r["queries"]["phrases_with_ngram_keys"] > 0 and r["queries"]["ors_naming_a_sparse_term"] > 0
+    assert r["queries"]["phrases_naming_a_sparse_term"] > 0
     assert set(r["parity"]["queries"]) == {"and2", "or3", "phrase", "vector", "hybrid"}
     assert all(v["errors"] == 0 for v in r["concurrent_callers"].values())
 

@@ -107,7 +107,7 @@ def run(n_docs=1_000_000, vocab=1_000_000, dim=64, n_queries=96, dense_min=2000,
             ln = int(rng.integers(2, 5))
             win = [int(r) for r in toks[st:st + ln]]
             ents = T.query_entries(win)
-            ok = len(ents) >= 2 and all(e[0] is not None and T.key_df(e[0]) >= dense_min for e in ents)  # (phrases over dense keys)
+            ok = len(ents) >= 2 and all(e[0] is not None and T.key_df(e[0]) > 0 for e in ents)  # keys of either tier (a rare word: the sparse phrase kernel)
             if ok and sum(len(e[1]) for e in ents) <= N.SS_MAX_PHRASE:
                 phrases.append(ents)
     idf_of = {}
@@ -141,6 +141,7 @@ def run(n_docs=1_000_000, vocab=1_000_000, dim=64, n_queries=96, dense_min=2000,
     out["queries"] = dict(lat, n=n_queries, mean_and_matches=float(res["and2"][3].mean()), mean_or_matches=float(res["or3"][3].mean()),
                           mean_phrase_matches=float(res["phrase"][3].mean()),
                           phrases_with_ngram_keys=int(sum(any(len(e[1]) > 1 for e in q) for q in phrases)),
+                          phrases_naming_a_sparse_term=int(sum(any(tid(e[0])[0][0] >= n_dense for e in q) for q in phrases)),
                           ors_naming_a_sparse_term=int(sum(any(single(r) >= n_dense for r in q) for q in ors)))
     say("queries", out["queries"])
     # ---- parity: every query against the oracle on the corpus' own lists
