@@ -524,6 +524,31 @@ int ss_vec_set_similarity(ss_shard* s, int similarity);
 /* i8 records under Euclidean + ScalarQuantizationI8: VectorHeader.norm of every record (vector.bin uploads with
  * use_record_scale keep it themselves).  The query's norm goes into ss_vec_search_i8_ann[_dev]'s query_norm. */
 int ss_vec_set_row_norms(ss_shard* s, uint64_t n_rows, const float* row_norm);
+
+/* Append of ONE committed level of vector records (commit.rs:142-148 -> the writer of vector.rs:1066-1094 puts a level's clusters
+ * and records behind the earlier levels'): the commit seam of the vector image, beside ss_bm25_append_level.  The records are written
+ * behind the image's rows in place -- O(level), not O(shard); the image and its per-row arrays grow by half when their room is used up.
+ * The level brings exactly what the image carries per row: doc ids iff the image was uploaded with them, scales / norms iff the i8
+ * image has them (ss_vec_upload_i8 / ss_vec_set_row_norms), field ids iff it has them (ss_vec_set_fields), its clusters (child
+ * counts summing to n_rows) iff the image has a cluster structure (ss_vec_set_clusters / a vector.bin upload) -- SS_EINVAL otherwise.
+ * Searches on the shard wait for the append (the call synchronises the device); answers afterwards are those of a one-shot upload of
+ * all rows. */
+typedef struct ss_vec_level {
+  uint64_t n_rows;
+  const void* rows;             /* [n_rows][dim]: f32, or i8 when elem_i8 != 0 -- the image's own precision */
+  uint32_t elem_i8;
+  uint32_t n_clusters;          /* clusters of the level (0 = the image has no cluster structure) */
+  const uint32_t* row_doc_ids;  /* [n_rows] or NULL */
+  const float* row_scale;       /* [n_rows] or NULL (i8 image with per-record scales) */
+  const float* row_norm;        /* [n_rows] or NULL (i8, Euclidean, quantised) */
+  const uint16_t* row_field;    /* [n_rows] or NULL */
+  const uint32_t* child_count;  /* [n_clusters] or NULL */
+} ss_vec_level;
+int ss_vec_append_rows(ss_shard* s, const ss_vec_level* level);
+/* Room for n_rows_cap rows in the image and its per-row arrays, taken once (at open time) instead of by the first append that finds
+ * none: growing a 30 GB image means a 45 GB allocation and a device-to-device copy -- 1.0 s measured at 10 M x 768 f32 --, an append
+ * into reserved room 3.6 ms per 65 536-row level (profiles/r4m_vec_append.log). */
+int ss_vec_reserve_rows(ss_shard* s, uint64_t n_rows_cap);
 /* Device-side synthetic matrix (generator = oracle so_vec_gen, uniform(-1,1) then normalize_f32). */
 /* Rows straight from a shard's vector.bin (writer vector.rs:1066-1094): per level u32 cluster_count + child counts,
  * then 24-byte VectorHeader + dim x f32 records; doc id = (level << 16) | header.doc_id (vector.rs:1448).  f32 only. */

@@ -66,6 +66,11 @@ class AnnModeC(C.Structure):  # ss_ann_mode
 SS_ANN_REPORT_OBSERVED = 1
 
 
+class VecLevelC(C.Structure):  # ss_vec_level
+    _fields_ = [("n_rows", C.c_uint64), ("rows", C.c_void_p), ("elem_i8", C.c_uint32), ("n_clusters", C.c_uint32), ("row_doc_ids", C.c_void_p),
+                ("row_scale", C.c_void_p), ("row_norm", C.c_void_p), ("row_field", C.c_void_p), ("child_count", C.c_void_p)]
+
+
 BM25_QUERY_DTYPE = np.dtype([("n_terms", np.uint32), ("op", np.uint32), ("term", np.uint32, (SS_MAX_QUERY_TERMS,)),
                              ("idf", np.float32, (SS_MAX_QUERY_TERMS,)), ("phrase_len", np.uint32), ("phrase_seq", np.uint8, (SS_MAX_PHRASE,))])
 assert BM25_QUERY_DTYPE.itemsize == C.sizeof(Bm25Query)
@@ -189,6 +194,8 @@ SYMBOLS = [
     ("ss_comm_profile", C.c_int, [C.c_void_p, C.c_int]),
     ("ss_comm_profile_read", C.c_int, [C.c_void_p, u64p, C.POINTER(C.c_double), C.c_int]),
     ("ss_index_bin_tier", C.c_int, [C.c_void_p, C.c_uint64, u32p]),
+    ("ss_vec_append_rows", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("ss_vec_reserve_rows", C.c_int, [C.c_void_p, C.c_uint64]),
     ("ss_bm25_append_sparse", C.c_int, [C.c_void_p, C.c_uint32, u64p, u32p, u16p, u32p]),
     ("ss_bm25_append_sparse_fields", C.c_int, [C.c_void_p, C.c_uint32, u64p, u32p, u8p, u16p, u32p]),
     ("ss_bm25_append_sparse_positions", C.c_int, [C.c_void_p, C.c_uint32, u64p, u32p, u16p, u16p, C.c_uint64, u16p, u32p]),

@@ -139,7 +139,7 @@ static void free_vec(ss_shard* s) {
   s->d_X = nullptr; s->d_X8 = nullptr; s->d_row_scale = nullptr; s->d_row_doc = nullptr; s->d_Qf = nullptr;
   s->d_row_norm = nullptr; s->d_row_sq = nullptr; s->d_qaux = nullptr;
   s->d_vstate = nullptr; s->d_cand = nullptr; s->d_row_field = nullptr;
-  s->n_rows = s->n_rows_pad = 0; s->dim = s->dim_pad = s->dim_pad8 = 0; s->vec_multi_record = false;
+  s->n_rows = s->n_rows_pad = 0; s->dim = s->dim_pad = s->dim_pad8 = 0; s->vec_multi_record = false; s->vec_rows_cap = 0;
   ssi_vec_free_clusters(s);
   if (s->ann_ev) (void)hipEventDestroy(s->ann_ev);
   s->ann_ev = nullptr; s->ann_ev_set = false; s->ann_ev_stream = nullptr;
@@ -2188,7 +2188,7 @@ int ss_vec_set_row_norms(ss_shard* s, uint64_t n_rows, const float* row_norm) {
   if (!s->d_X8) return SS_ESTATE;
   if (n_rows != s->n_rows) return SS_EINVAL;
   SS_HIP(hipStreamSynchronize(s->stream));
-  if (!s->d_row_norm) SS_HIP(hipMalloc(&s->d_row_norm, n_rows * sizeof(float)));
+  if (!s->d_row_norm) SS_HIP(hipMalloc(&s->d_row_norm, std::max<uint64_t>(n_rows, s->vec_rows_cap) * sizeof(float)));
   SS_HIP(hipMemcpy(s->d_row_norm, row_norm, n_rows * sizeof(float), hipMemcpyHostToDevice));
   return SS_OK;
 }
@@ -2207,7 +2207,7 @@ int ss_vec_set_fields(ss_shard* s, uint64_t n_rows, const uint16_t* row_field) {
   if (!s->d_X && !s->d_X8) return SS_ESTATE;
   if (n_rows != s->n_rows) return SS_EINVAL;
   SS_HIP(hipStreamSynchronize(s->stream));
-  if (!s->d_row_field) SS_HIP(hipMalloc(&s->d_row_field, n_rows * sizeof(uint16_t)));
+  if (!s->d_row_field) SS_HIP(hipMalloc(&s->d_row_field, std::max<uint64_t>(n_rows, s->vec_rows_cap) * sizeof(uint16_t)));
   SS_HIP(hipMemcpy(s->d_row_field, row_field, n_rows * sizeof(uint16_t), hipMemcpyHostToDevice));
   return SS_OK;
 }
@@ -2273,6 +2273,118 @@ int ss_vec_upload_i8(ss_shard* s, uint64_t n_rows, uint32_t dim, const int8_t* r
   }
   SS_HIP(hipStreamSynchronize(s->stream));
   return vec_finish(s);
+}
+
+// ------------------------------------------------------------------ append of one committed level of vector records
+// The reference commits 65 536 docs at a time and writes the level's clusters and records behind the earlier ones
+// (vector.rs:1066-1094); a rebuild of the whole image per commit would cost O(shard).  Rows are independent, so the new records are
+// written behind the image's rows IN PLACE (f32: a strided copy; i8: through a row-major staging and the fragment-order scatter of the
+// rows' range), the Euclidean side data is computed for the new range only, the per-row side arrays (doc ids, scales, norms, field
+// ids) are extended, and the cluster structure -- if the image has one -- is declared again with the level added (O(rows) words, not
+// O(image bytes)).  The image and the side arrays grow by half when their room is used up (one device-to-device copy, amortised).
+static int grow_rows(void** p, size_t elem, uint64_t old_rows, uint64_t new_cap, bool zero_tail) {
+  if (!*p) return SS_OK;
+  void* q = nullptr;
+  SS_HIP(hipMalloc(&q, (size_t)new_cap * elem));
+  if (hipMemcpy(q, *p, (size_t)old_rows * elem, hipMemcpyDeviceToDevice) != hipSuccess ||
+      (zero_tail && hipMemset((char*)q + (size_t)old_rows * elem, 0, (size_t)(new_cap - old_rows) * elem) != hipSuccess)) {
+    (void)hipFree(q);
+    return SS_EDEVICE;
+  }
+  (void)hipFree(*p);
+  *p = q;
+  return SS_OK;
+}
+
+// room for new_cap rows in the image and every per-row array it carries (caller holds s->mu, the device is idle)
+static int vec_grow(ss_shard* s, uint64_t new_cap) {
+  const bool i8 = s->d_X8 != nullptr;
+  const size_t row_bytes = i8 ? (size_t)s->dim_pad8 : (size_t)s->dim_pad * sizeof(float);
+  const uint64_t old_n = s->n_rows;
+  // the image: rows [0, n_rows_pad) are data + zero padding, the room behind them starts as padding (zero)
+  SS_TRY(grow_rows(i8 ? (void**)&s->d_X8 : (void**)&s->d_X, row_bytes, s->n_rows_pad, new_cap, true));
+  SS_TRY(grow_rows((void**)&s->d_row_doc, sizeof(uint32_t), old_n, new_cap, false));
+  SS_TRY(grow_rows((void**)&s->d_row_scale, sizeof(float), old_n, new_cap, false));
+  SS_TRY(grow_rows((void**)&s->d_row_norm, sizeof(float), old_n, new_cap, false));
+  SS_TRY(grow_rows((void**)&s->d_row_sq, sizeof(int32_t), old_n, new_cap, false));
+  SS_TRY(grow_rows((void**)&s->d_row_field, sizeof(uint16_t), old_n, new_cap, false));
+  s->vec_rows_cap = new_cap;
+  return SS_OK;
+}
+
+int ss_vec_reserve_rows(ss_shard* s, uint64_t n_rows_cap) {
+  if (!s) return SS_EINVAL;
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  if (!s->d_X && !s->d_X8) return SS_ESTATE;
+  if (n_rows_cap > 0xFFFFFFFEull) return SS_ENOTSUP;
+  const uint64_t cap = s->vec_rows_cap ? s->vec_rows_cap : s->n_rows_pad, want = (n_rows_cap + VS_TR - 1) / VS_TR * VS_TR;
+  if (want <= cap && s->vec_rows_cap) return SS_OK;
+  SS_HIP(hipDeviceSynchronize());
+  return vec_grow(s, std::max(want, cap));
+}
+
+int ss_vec_append_rows(ss_shard* s, const ss_vec_level* lv) {
+  if (!s || !lv || !lv->rows || lv->n_rows == 0) return SS_EINVAL;
+  const uint64_t n_new = lv->n_rows;
+  bool multi = false;
+  if (lv->row_doc_ids) {  // (a level's records share doc ids only among themselves: (level << 16) | doc_id, vector.rs:1448)
+    std::vector<uint32_t> tmp(lv->row_doc_ids, lv->row_doc_ids + n_new);
+    std::sort(tmp.begin(), tmp.end());
+    multi = std::adjacent_find(tmp.begin(), tmp.end()) != tmp.end();
+    if (tmp.back() == SS_NO_DOC) return SS_EINVAL;
+  }
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  if (!s->d_X && !s->d_X8) return SS_ESTATE;
+  const bool i8 = s->d_X8 != nullptr;
+  if ((lv->elem_i8 != 0) != i8) return SS_EINVAL;
+  // what the image carries per row, the level must bring -- and nothing else
+  if ((s->d_row_doc != nullptr) != (lv->row_doc_ids != nullptr) || (s->d_row_scale != nullptr) != (lv->row_scale != nullptr) ||
+      (s->d_row_norm != nullptr) != (lv->row_norm != nullptr) || (s->d_row_field != nullptr) != (lv->row_field != nullptr) ||
+      (s->vec_n_clusters != 0) != (lv->n_clusters != 0))
+    return SS_EINVAL;
+  if (lv->n_clusters) {
+    if (!lv->child_count) return SS_EINVAL;
+    uint64_t sum = 0;
+    for (uint32_t c = 0; c < lv->n_clusters; c++) { if (lv->child_count[c] == 0) return SS_ENOTSUP; sum += lv->child_count[c]; }
+    if (sum != n_new) return SS_EINVAL;
+  }
+  const uint64_t old_n = s->n_rows, new_n = old_n + n_new;
+  if (new_n > 0xFFFFFFFEull) return SS_ENOTSUP;
+  const uint64_t new_pad = (new_n + VS_TR - 1) / VS_TR * VS_TR;
+  SS_HIP(hipDeviceSynchronize());  // searches on the callers' own streams read the arrays that are written / replaced here
+  const uint64_t cap = s->vec_rows_cap ? s->vec_rows_cap : s->n_rows_pad;
+  if (new_pad > cap || !s->vec_rows_cap)  // (an opener that expects commits reserves the room once: ss_vec_reserve_rows)
+    SS_TRY(vec_grow(s, (std::max<uint64_t>(new_pad, cap + cap / 2) + VS_TR - 1) / VS_TR * VS_TR));
+  if (!i8) {
+    SS_HIP(hipMemcpy2DAsync(s->d_X + (size_t)old_n * s->dim_pad, (size_t)s->dim_pad * sizeof(float), lv->rows, (size_t)s->dim * sizeof(float),
+                            (size_t)s->dim * sizeof(float), n_new, hipMemcpyHostToDevice, s->stream));
+  } else {
+    int8_t* stage = nullptr;
+    SS_HIP(hipMalloc(&stage, (size_t)n_new * s->dim));
+    int rc = hipMemcpyAsync(stage, lv->rows, (size_t)n_new * s->dim, hipMemcpyHostToDevice, s->stream) == hipSuccess ? SS_OK : SS_EDEVICE;
+    if (rc == SS_OK) rc = ssi_vec8_permute_range(s, stage, old_n, n_new, s->stream);
+    (void)hipStreamSynchronize(s->stream);
+    (void)hipFree(stage);
+    if (rc) return rc;
+  }
+  if (lv->row_doc_ids) SS_HIP(hipMemcpyAsync(s->d_row_doc + old_n, lv->row_doc_ids, n_new * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+  if (lv->row_scale) SS_HIP(hipMemcpyAsync(s->d_row_scale + old_n, lv->row_scale, n_new * sizeof(float), hipMemcpyHostToDevice, s->stream));
+  if (lv->row_norm) SS_HIP(hipMemcpyAsync(s->d_row_norm + old_n, lv->row_norm, n_new * sizeof(float), hipMemcpyHostToDevice, s->stream));
+  if (lv->row_field) SS_HIP(hipMemcpyAsync(s->d_row_field + old_n, lv->row_field, n_new * sizeof(uint16_t), hipMemcpyHostToDevice, s->stream));
+  s->n_rows = new_n;
+  s->n_rows_pad = new_pad;
+  s->vec_multi_record = s->vec_multi_record || multi;
+  if (s->vec_similarity == SS_SIM_EUCLIDEAN) SS_TRY(s->d_X ? ssi_vec_augment(s, s->stream, old_n) : ssi_vec8_row_sq(s, s->stream, old_n));
+  SS_HIP(hipStreamSynchronize(s->stream));
+  if (lv->n_clusters) {  // the structure with the level added, declared again (row -> cluster words, the new medoids, tile lists)
+    std::vector<uint32_t> lc = s->h_level_clusters, cc = s->h_child_count;
+    lc.push_back(lv->n_clusters);
+    cc.insert(cc.end(), lv->child_count, lv->child_count + lv->n_clusters);
+    SS_TRY(ssi_vec_set_clusters(s, (uint32_t)lc.size(), lc.data(), cc.data()));
+  }
+  return SS_OK;
 }
 
 // bench / test utility: the synthetic f32 corpus of ss_vec_synth quantised on the device with quantize_f32_to_i8

@@ -230,6 +230,7 @@ struct ss_shard {
   uint16_t* d_row_field = nullptr; // optional row -> indexed field id (VectorHeader.field_id): field_filter
   bool vec_multi_record = false; // several records per doc: TopK::push dedup (vector.rs:441-452) in the refine kernel
   uint64_t n_rows = 0, n_rows_pad = 0;
+  uint64_t vec_rows_cap = 0;     // rows the image and its per-row side arrays have room for (0: exactly n_rows_pad / n_rows -- ss_vec_append_rows grows them)
   uint32_t dim = 0, dim_pad = 0;
   // cluster structure (ANN modes, vec_ann.hip); null = none declared
   uint32_t* d_row_cluster = nullptr;    // [n_rows] shard-wide cluster index of each row
@@ -237,6 +238,7 @@ struct ss_shard {
   uint32_t* d_level_off = nullptr;      // [vec_n_levels + 1] cluster index range of each level
   void* d_medoids = nullptr;            // the medoid records, transposed: [k / 8][cluster][8] f32 or [k / 16][cluster][16] i8
   uint32_t vec_n_clusters = 0, vec_n_levels = 0, vec_max_level_clusters = 0;
+  std::vector<uint32_t> h_level_clusters, h_child_count;  // the declared structure (ss_vec_append_rows extends it by a level)
   float* d_ann_score = nullptr;         // [64][vec_n_clusters] medoid similarity per query
   float* d_ann_its = nullptr;           // [64][vec_n_clusters] TopK arrays of the per-level selection (scores)
   uint32_t* d_ann_itc = nullptr;        //                      (cluster ids)
@@ -385,8 +387,9 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float*
                    uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, hipStream_t st,
                    bool safe_mode, const ss_ann_mode* ann_mode = nullptr, uint32_t* d_out_clusters = nullptr,
                    const float* d_qnorm = nullptr);
-int ssi_vec_augment(ss_shard* s, hipStream_t st);   // f32 Euclidean image: columns dim, dim + 1 = |x|^2, 1
-int ssi_vec8_row_sq(ss_shard* s, hipStream_t st);   // i8 Euclidean image without scales: d_row_sq
+int ssi_vec_augment(ss_shard* s, hipStream_t st, uint64_t r0 = 0);   // f32 Euclidean image: columns dim, dim + 1 = |x|^2, 1 (rows r0 .. n_rows)
+int ssi_vec8_row_sq(ss_shard* s, hipStream_t st, uint64_t r0 = 0);   // i8 Euclidean image without scales: d_row_sq
+int ssi_vec8_permute_range(ss_shard* s, const int8_t* d_rows_row_major, uint64_t r0, uint64_t n, hipStream_t st);  // appended rows -> fragment order
 struct VAnn;
 int ssi_vec8_qprep(ss_shard* s, const int8_t* d_queries, uint32_t nb, hipStream_t st);
 int ssi_vec8_launch_scan(ss_shard* s, uint32_t tile0, uint32_t ntiles, const float* d_qscale, const VAnn* ann, hipStream_t st);

@@ -37,6 +37,22 @@ __global__ void vec8_permute_kernel(const int8_t* __restrict__ src, unsigned lon
   for (int b = 0; b < 16; b++) o[b] = v[b];
 }
 
+// appended rows: row-major [n][dim] staging -> rows [r0, r0 + n) of the image (the padding around them is zero already)
+__global__ void vec8_permute_range_kernel(const int8_t* __restrict__ src, unsigned long long r0, unsigned long long n, uint32_t dim,
+                                          uint32_t dim_pad, int8_t* __restrict__ dst) {
+  const uint32_t L = dim_pad / 128u;
+  const unsigned long long piece = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (piece >= n * (dim_pad / 16u)) return;
+  const unsigned long long row = piece / (dim_pad / 16u);
+  const uint32_t k0 = (uint32_t)(piece % (dim_pad / 16u)) * 16u;
+  int8_t v[16];
+#pragma unroll
+  for (int b = 0; b < 16; b++) v[b] = k0 + b < dim ? src[row * dim + k0 + b] : (int8_t)0;
+  int8_t* o = dst + v8_index(r0 + row, k0, L);
+#pragma unroll
+  for (int b = 0; b < 16; b++) o[b] = v[b];
+}
+
 // rows [r0, r0 + n) back to row-major [n][dim]
 __global__ void vec8_gather_rows_kernel(const int8_t* __restrict__ img, uint32_t dim, uint32_t dim_pad, unsigned long long r0,
                                         unsigned long long n, int8_t* __restrict__ out) {
@@ -80,9 +96,9 @@ struct V8Euc {
   const int32_t* row_sq;
   const float* qaux;
 };
-__global__ void vec8_row_sq_kernel(const int8_t* __restrict__ X8, uint32_t dim, uint32_t dim_pad8, unsigned long long n_rows,
+__global__ void vec8_row_sq_kernel(const int8_t* __restrict__ X8, uint32_t dim, uint32_t dim_pad8, unsigned long long r0, unsigned long long n_rows,
                                    int32_t* __restrict__ row_sq) {
-  const unsigned long long r = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long r = r0 + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_rows) return;
   int32_t ss = 0;
   for (uint32_t c = 0; c < dim; c++) { const int32_t v = X8[v8_index(r, c, dim_pad8 / 128u)]; ss += v * v; }
@@ -255,10 +271,11 @@ int ssi_vec8_qaux(ss_shard* s, const int8_t* d_queries, uint32_t nb, const float
   vec8_qaux_kernel<<<1, 64, 0, st>>>(d_queries, nb, s->dim, d_qnorm, s->d_qaux);
   return SS_OK;
 }
-int ssi_vec8_row_sq(ss_shard* s, hipStream_t st) {
+int ssi_vec8_row_sq(ss_shard* s, hipStream_t st, uint64_t r0) {
   if (!s->d_X8) return SS_ESTATE;
-  if (!s->d_row_sq) SS_HIP(hipMalloc(&s->d_row_sq, (size_t)s->n_rows * sizeof(int32_t)));
-  vec8_row_sq_kernel<<<(unsigned)((s->n_rows + 255) / 256), 256, 0, st>>>(s->d_X8, s->dim, s->dim_pad8, (unsigned long long)s->n_rows, s->d_row_sq);
+  if (!s->d_row_sq) SS_HIP(hipMalloc(&s->d_row_sq, (size_t)std::max<uint64_t>(s->n_rows, s->vec_rows_cap) * sizeof(int32_t)));
+  if (r0 >= s->n_rows) return SS_OK;
+  vec8_row_sq_kernel<<<(unsigned)((s->n_rows - r0 + 255) / 256), 256, 0, st>>>(s->d_X8, s->dim, s->dim_pad8, (unsigned long long)r0, (unsigned long long)s->n_rows, s->d_row_sq);
   SS_HIP(hipGetLastError());
   return SS_OK;
 }
@@ -304,6 +321,14 @@ int ssi_vec8_permute(ss_shard* s, const int8_t* d_rows_row_major, hipStream_t st
   const unsigned long long total = (unsigned long long)s->n_rows_pad * (s->dim_pad8 / 16u);
   vec8_permute_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(d_rows_row_major, s->n_rows, s->dim, s->dim_pad8,
                                                                        s->n_rows_pad, s->d_X8);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
+int ssi_vec8_permute_range(ss_shard* s, const int8_t* d_rows_row_major, uint64_t r0, uint64_t n, hipStream_t st) {
+  const unsigned long long total = (unsigned long long)n * (s->dim_pad8 / 16u);
+  if (!total) return SS_OK;
+  vec8_permute_range_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(d_rows_row_major, r0, n, s->dim, s->dim_pad8, s->d_X8);
   SS_HIP(hipGetLastError());
   return SS_OK;
 }

@@ -423,6 +423,7 @@ void ssi_vec_free_clusters(ss_shard* s) {
   s->d_ann_its = nullptr; s->d_ann_itc = nullptr; s->d_ann_sel = nullptr; s->d_ann_tiles = nullptr; s->d_ann_ncl = nullptr; s->d_medoids = nullptr;
   s->d_ann_live = nullptr; s->ann_live_cap = 0;
   s->vec_n_clusters = 0; s->vec_n_levels = 0; s->vec_max_level_clusters = 0;
+  s->h_level_clusters.clear(); s->h_child_count.clear();
 }
 
 // caller holds the shard lock and has selected the device
@@ -432,6 +433,10 @@ int ssi_vec_set_clusters(ss_shard* s, uint32_t n_levels, const uint32_t* level_c
   uint64_t nc = 0;
   for (uint32_t l = 0; l < n_levels; l++) nc += level_clusters[l];
   if (nc == 0 || nc > 0x7FFFFFFFull) return SS_EINVAL;
+  // host copies of the declared structure (ss_vec_append_rows extends it by a level and declares it again)
+  std::vector<uint32_t> lc(level_clusters, level_clusters + n_levels), cc(child_count, child_count + nc);
+  level_clusters = lc.data();
+  child_count = cc.data();
   std::vector<uint32_t> level_off(n_levels + 1), first(nc), row_cluster(s->n_rows);
   uint64_t row = 0, c = 0;
   for (uint32_t l = 0; l < n_levels; l++) {
@@ -474,6 +479,8 @@ int ssi_vec_set_clusters(ss_shard* s, uint32_t n_levels, const uint32_t* level_c
     SS_HIP(hipGetLastError());
     SS_HIP(hipStreamSynchronize(s->stream));
   }
+  s->h_level_clusters.swap(lc);
+  s->h_child_count.swap(cc);
   s->vec_n_clusters = (uint32_t)nc;
   s->vec_n_levels = n_levels;
   s->vec_max_level_clusters = *std::max_element(level_clusters, level_clusters + n_levels);

@@ -52,8 +52,8 @@ __global__ void vec_qprep_kernel(const float* __restrict__ Q, uint32_t nq, uint3
 }
 
 // f32 Euclidean image: column dim = |x|^2, column dim + 1 = 1 (one thread per row)
-__global__ void vec_augment_kernel(float* __restrict__ X, unsigned long long n_rows, uint32_t dim, uint32_t dim_pad) {
-  const unsigned long long r = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void vec_augment_kernel(float* __restrict__ X, unsigned long long r0, unsigned long long n_rows, uint32_t dim, uint32_t dim_pad) {
+  const unsigned long long r = r0 + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_rows) return;
   float* row = X + r * dim_pad;
   float ss = 0.0f;
@@ -61,9 +61,10 @@ __global__ void vec_augment_kernel(float* __restrict__ X, unsigned long long n_r
   row[dim] = ss;
   row[dim + 1] = 1.0f;
 }
-int ssi_vec_augment(ss_shard* s, hipStream_t st) {
+int ssi_vec_augment(ss_shard* s, hipStream_t st, uint64_t r0) {
   if (!s->d_X || s->dim_pad < s->dim + 2) return SS_ESTATE;
-  vec_augment_kernel<<<(unsigned)((s->n_rows + 255) / 256), 256, 0, st>>>(s->d_X, (unsigned long long)s->n_rows, s->dim, s->dim_pad);
+  if (r0 >= s->n_rows) return SS_OK;
+  vec_augment_kernel<<<(unsigned)((s->n_rows - r0 + 255) / 256), 256, 0, st>>>(s->d_X, (unsigned long long)r0, (unsigned long long)s->n_rows, s->dim, s->dim_pad);
   SS_HIP(hipGetLastError());
   return SS_OK;
 }

@@ -1040,6 +1040,35 @@ class Shard:
         return ro
 
     # ---- measurement hooks
+    def reserve_vector_rows(self, n_rows_cap):
+        """room for n_rows_cap rows, once, so that the appends that follow write in place (ss_vec_reserve_rows)"""
+        N.check(N.lib().ss_vec_reserve_rows(self._h, int(n_rows_cap)), "ss_vec_reserve_rows")
+
+    def append_vector_rows(self, rows, row_doc_ids=None, row_scale=None, row_norm=None, row_field=None, child_count=None):
+        """one committed level of vector records behind the image's rows (ss_vec_append_rows): rows f32 [n][dim], or int8 for an i8
+        image; the per-row arrays and the level's cluster child counts exactly as the image carries them"""
+        r = np.ascontiguousarray(rows)
+        i8 = r.dtype == np.int8
+        if not i8:
+            r = np.ascontiguousarray(r, np.float32)
+        if r.ndim != 2 or r.shape[1] != self.dim:
+            raise ValueError("rows must be [n][dim]")
+        keep = [r]
+
+        def p(a, dt):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dt)
+            keep.append(a)
+            return a.ctypes.data
+        cc = None if child_count is None else np.ascontiguousarray(child_count, np.uint32)
+        lv = N.VecLevelC(r.shape[0], r.ctypes.data, 1 if i8 else 0, 0 if cc is None else len(cc), p(row_doc_ids, np.uint32), p(row_scale, np.float32),
+                         p(row_norm, np.float32), p(row_field, np.uint16), None if cc is None else cc.ctypes.data)
+        N.check(N.lib().ss_vec_append_rows(self._h, C.byref(lv)), "ss_vec_append_rows")
+        n, d = C.c_uint64(), C.c_uint32()
+        N.check(N.lib().ss_vec_info(self._h, C.byref(n), C.byref(d)), "ss_vec_info")
+        self.vector_count = n.value
+
     def append_sparse(self, term_offsets, doc_ids, tfs, positions=None, npos=None):
         """lists of RARE terms into the image's sparse tier (ss_bm25_append_sparse: plain sorted lists, no directory / probe rows);
         returns the term id of the first appended list -- the ids continue behind the dense terms.

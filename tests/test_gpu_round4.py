@@ -490,3 +490,87 @@ def test_sparse_tier_on_an_image_with_several_indexed_fields(S, O):
     with pytest.raises(N.SeekStormHipError):  # a UNION of several terms under a filter is the dense tier's gated scan over (term, field) lists
         sh.search_lexical_batch(sh.make_queries([[0, 4]], S.QueryType.Union, field_filter=[0]), 10)
     sh.close()
+
+
+def _same_answers(a, b):
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("euclid", [False, True])
+def test_vector_rows_appended_level_by_level_equal_the_one_shot_upload(S, O, euclid):
+    """ss_vec_append_rows: levels of vector records written behind the image in place (f32; doc ids with several records per doc,
+    field ids, a cluster structure for the ANN modes) -- the answers are those of the one-shot upload, bit for bit, after every level"""
+    dim = 96
+    sizes = [5000, 65536, 700, 129, 20000]
+    rng = np.random.default_rng(12)
+    n_all = sum(sizes)
+    rows = O.vec_gen(O.VEC_SEED, 0, n_all, dim)
+    ids = np.concatenate([np.sort(rng.integers(0, max(n // 2, 1), n)).astype(np.uint32) + np.uint32(l << 16) for l, n in enumerate(sizes)])
+    fld = rng.integers(0, 3, n_all).astype(np.uint16)
+    child = []
+    for n in sizes:  # clusters of a level: a few, uneven
+        cuts = np.sort(rng.choice(np.arange(1, n), size=min(6, n - 1), replace=False))
+        child.append(np.diff(np.concatenate([[0], cuts, [n]])).astype(np.uint32))
+    qs = O.vec_gen(O.VECQ_SEED, 0, 9, dim)
+    inc = S.Shard(0)
+    if euclid:
+        inc.set_vector_similarity("euclidean")
+    inc.upload_vectors(rows[:sizes[0]], ids[:sizes[0]])
+    inc.set_fields(fld[:sizes[0]])
+    inc.set_clusters([len(child[0])], child[0])
+    at = sizes[0]
+    for l in range(1, len(sizes)):
+        n = sizes[l]
+        inc.append_vector_rows(rows[at:at + n], row_doc_ids=ids[at:at + n], row_field=fld[at:at + n], child_count=child[l])
+        at += n
+        ref = S.Shard(0)
+        if euclid:
+            ref.set_vector_similarity("euclidean")
+        ref.upload_vectors(rows[:at], ids[:at])
+        ref.set_fields(fld[:at])
+        ref.set_clusters([len(c) for c in child[:l + 1]], np.concatenate(child[:l + 1]))
+        assert inc.cluster_info() == ref.cluster_info() and inc.vector_count == at
+        for k in (10, 100):
+            _same_answers(inc.search_vector_batch(qs, k), ref.search_vector_batch(qs, k))
+            _same_answers(inc.search_vector_batch(qs, k, field_filter=[1]), ref.search_vector_batch(qs, k, field_filter=[1]))
+            if not euclid:
+                _same_answers(inc.search_vector_batch(qs, k, ann_mode=S.AnnMode(n_probe=2), with_clusters=True),
+                              ref.search_vector_batch(qs, k, ann_mode=S.AnnMode(n_probe=2), with_clusters=True))
+        ref.close()
+    # the level must bring what the image carries per row
+    from seekstorm_amd import _native as N
+    with pytest.raises(N.SeekStormHipError):
+        inc.append_vector_rows(rows[:10], row_doc_ids=ids[:10], row_field=fld[:10])          # no clusters
+    with pytest.raises(N.SeekStormHipError):
+        inc.append_vector_rows(rows[:10], row_field=fld[:10], child_count=[10])               # no doc ids
+    inc.close()
+
+
+def test_i8_vector_rows_appended_equal_the_one_shot_upload(S, O):
+    """... for Precision::I8 records with per-record scales (the fragment-ordered image: rows scattered into their tiles), plain ids"""
+    dim, sizes = 200, [3000, 65536, 130, 9000]
+    rng = np.random.default_rng(5)
+    n_all = sum(sizes)
+    rows = rng.integers(-127, 128, (n_all, dim)).astype(np.int8)
+    scale = (rng.random(n_all) * 0.01 + 0.001).astype(np.float32)
+    qs = rng.integers(-127, 128, (7, dim)).astype(np.int8)
+    qsc = (rng.random(7) * 0.01 + 0.001).astype(np.float32)
+    for euclid in (False, True):
+        inc = S.Shard(0)
+        if euclid:
+            inc.set_vector_similarity("euclidean")
+        inc.upload_vectors_i8(rows[:sizes[0]], None if euclid else scale[:sizes[0]])
+        inc.reserve_vector_rows(70_000)  # the first two appends find room, the third grows the image
+        at = sizes[0]
+        for n in sizes[1:]:
+            inc.append_vector_rows(rows[at:at + n], row_scale=None if euclid else scale[at:at + n])
+            at += n
+            ref = S.Shard(0)
+            if euclid:
+                ref.set_vector_similarity("euclidean")
+            ref.upload_vectors_i8(rows[:at], None if euclid else scale[:at])
+            for k in (10, 100):
+                _same_answers(inc.search_vector_batch_i8(qs, k, None if euclid else qsc), ref.search_vector_batch_i8(qs, k, None if euclid else qsc))
+            ref.close()
+        inc.close()
