@@ -495,6 +495,24 @@ int ss_bm25_facet_kth(ss_shard* s, const ss_bm25_query* query, uint32_t n_filter
                       uint32_t facet_offset, uint32_t facet_type, uint32_t descending, uint64_t k, uint64_t* out_value,
                       uint64_t* out_n_better, uint64_t* out_n_equal, uint64_t* out_total);
 int ss_facet_values(ss_shard* s, uint32_t n, const uint32_t* doc_ids, uint32_t facet_offset, uint32_t facet_type, uint64_t* out_values);
+/* The same sort as ONE call for a batch of queries, pivots on the device: per query the radix selects of all sort fields run
+ * back to back on the device (the prefix never visits the host), leaving two doc sets -- the docs that are in the answer for sure
+ * (strictly better than a pivot at some field) and the tie group of the last pivot --, which two ordinary searches under exclusion
+ * bitmaps turn into scored lists and a compose kernel orders by (field 1, ..., field n, score desc, doc asc).  The host only
+ * launches: one synchronisation per call.  n_sorts <= SS_MAX_SORT_FIELDS numeric or Point fields (n_sorts = 0: by score alone);
+ * every list of every query needs a probe row (SS_ENOTSUP otherwise, as for ss_bm25_facet_kth); no phrase queries.
+ * out_doc / out_score [n_queries][k], out_count [n_queries], out_total [n_queries] = all matches of the query. */
+#define SS_MAX_SORT_FIELDS 4
+typedef struct ss_result_sort {   /* search.rs ResultSort */
+  uint32_t facet_offset;
+  uint32_t facet_type;            /* SS_FACET_U8 .. SS_FACET_F64, or SS_FACET_POINT: by simplified_distance to the base */
+  uint32_t descending;            /* SortOrder */
+  uint32_t reserved;
+  double base_lat, base_lon;      /* Point facets */
+} ss_result_sort;
+int ss_bm25_search_sorted(ss_shard* s, uint32_t n_queries, const ss_bm25_query* queries, uint32_t n_sorts, const ss_result_sort* sorts,
+                          uint32_t k, uint32_t n_filters, const ss_facet_filter* filters, uint32_t* out_doc, float* out_score,
+                          uint32_t* out_count, uint64_t* out_total);
 int ss_bm25_facet_count_point(ss_shard* s, const ss_bm25_query* query, uint32_t n_filters, const ss_facet_filter* filters,
                               uint32_t facet_offset, const ss_facet_point* base, uint32_t n_buckets,
                               const uint64_t* range_lower_bounds, uint64_t* out_counts, uint64_t* out_total);

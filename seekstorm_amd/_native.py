@@ -66,6 +66,14 @@ class AnnModeC(C.Structure):  # ss_ann_mode
 SS_ANN_REPORT_OBSERVED = 1
 
 
+class ResultSortC(C.Structure):  # ss_result_sort
+    _fields_ = [("facet_offset", C.c_uint32), ("facet_type", C.c_uint32), ("descending", C.c_uint32), ("reserved", C.c_uint32),
+                ("base_lat", C.c_double), ("base_lon", C.c_double)]
+
+
+SS_MAX_SORT_FIELDS = 4
+
+
 class VecLevelC(C.Structure):  # ss_vec_level
     _fields_ = [("n_rows", C.c_uint64), ("rows", C.c_void_p), ("elem_i8", C.c_uint32), ("n_clusters", C.c_uint32), ("row_doc_ids", C.c_void_p),
                 ("row_scale", C.c_void_p), ("row_norm", C.c_void_p), ("row_field", C.c_void_p), ("child_count", C.c_void_p)]
@@ -194,6 +202,8 @@ SYMBOLS = [
     ("ss_comm_profile", C.c_int, [C.c_void_p, C.c_int]),
     ("ss_comm_profile_read", C.c_int, [C.c_void_p, u64p, C.POINTER(C.c_double), C.c_int]),
     ("ss_index_bin_tier", C.c_int, [C.c_void_p, C.c_uint64, u32p]),
+    ("ss_bm25_search_sorted", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                                        u32p, f32p, u32p, u64p]),
     ("ss_vec_append_rows", C.c_int, [C.c_void_p, C.c_void_p]),
     ("ss_vec_reserve_rows", C.c_int, [C.c_void_p, C.c_uint64]),
     ("ss_bm25_append_sparse", C.c_int, [C.c_void_p, C.c_uint32, u64p, u32p, u16p, u32p]),

@@ -395,6 +395,210 @@ int ssi_facet_values(ss_shard* s, const uint32_t* d_docs, uint32_t n, uint32_t o
   return SS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Result sort for a BATCH, pivots on the device (ss_bm25_search_sorted).  The composition above -- pivot of the first field, a search
+// filtered to "better", a search filtered to "equal" that recurses on the next field -- cost a host round trip per radix byte and per
+// search.  Here the whole chain stays on the device, per query:
+//   E = the match set (bits), B = {} ; per sort field: radix select over E for the k_left-th best key (histogram pass + a one-block
+//   decide kernel per byte, the prefix kept in device memory), then a classify pass: docs of E strictly better than the pivot move to
+//   B, worse ones leave E; k_left -= |moved|.  After the last field B holds the (< k) docs that are in the answer for sure, E the tie
+//   group of the last pivot, of which the best by SCORE fill the rest.  Two ordinary searches under exclusion bitmaps ~B and ~E (the
+//   bitmap the kernels honour for tombstones / facet filters) give both lists with their scores; a compose kernel orders B's docs by
+//   (field 1, ..., field m, score, doc) -- a bitonic sort of <= 1024 tuples in LDS -- and appends the first k - |B| of E's.
+struct SortState { unsigned long long prefix, want, n_better, n_equal, count_e, k_left, better_total, pad; };
+struct SortFieldsDev {
+  uint32_t n;
+  uint32_t offset[SS_MAX_SORT_FIELDS], type[SS_MAX_SORT_FIELDS], bytes[SS_MAX_SORT_FIELDS], desc[SS_MAX_SORT_FIELDS];
+  FacetPoint pt[SS_MAX_SORT_FIELDS];
+};
+
+__global__ void sort_begin_kernel(SortState* st, const unsigned long long* total, unsigned long long k) {
+  if (threadIdx.x == 0) { st->count_e = *total; st->k_left = k; st->better_total = 0ull; }
+}
+__global__ void sort_level_begin_kernel(SortState* st, unsigned long long* hist) {
+  hist[threadIdx.x & 255u] = 0ull;
+  if (threadIdx.x == 0) { st->want = st->k_left < st->count_e ? st->k_left : st->count_e; st->prefix = 0ull; st->n_better = 0ull; st->n_equal = 0ull; }
+}
+__global__ void sort_radix_kernel(const unsigned long long* __restrict__ bits, unsigned long long n_docs, const uint8_t* __restrict__ records,
+                                  uint32_t record_size, uint32_t offset, uint32_t type, uint32_t key_bits, uint32_t descending,
+                                  const SortState* __restrict__ st, uint32_t byte_index, unsigned long long* __restrict__ hist, FacetPoint pt) {
+  __shared__ unsigned int h[256];
+  if (st->want == 0ull) return;
+  const unsigned long long prefix = st->prefix;
+  h[threadIdx.x & 255u] = 0u;
+  __syncthreads();
+  const unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g * 64ull < n_docs) {
+    unsigned long long m = bits[g];
+    const uint32_t shift = key_bits - 8u * (byte_index + 1u);
+    while (m) {
+      const unsigned long long d = g * 64ull + (unsigned long long)__builtin_ctzll(m);
+      m &= m - 1;
+      if (d >= n_docs) break;
+      uint32_t ty = type;
+      const unsigned long long v = facet_load(records + d * record_size + offset, key_bits / 8u, ty, pt);
+      const unsigned long long k = facet_order_key(v, ty, key_bits, descending != 0u);
+      if (byte_index == 0u || (k >> (shift + 8u)) == prefix) atomicAdd(&h[(k >> shift) & 255u], 1u);
+    }
+  }
+  __syncthreads();
+  if (h[threadIdx.x & 255u]) atomicAdd(&hist[threadIdx.x & 255u], (unsigned long long)h[threadIdx.x & 255u]);
+}
+// one byte decided: from the best byte value down to the bucket that holds the wanted rank (ssi_facet_kth's host loop)
+__global__ void sort_decide_kernel(SortState* st, unsigned long long* hist) {
+  if (threadIdx.x == 0) {
+    unsigned long long want = st->want, nb = st->n_better;
+    int v = 255;
+    if (want != 0ull)
+      for (; v > 0; v--) {
+        if (hist[v] >= want) break;
+        want -= hist[v];
+        nb += hist[v];
+      }
+    st->prefix = (st->prefix << 8) | (unsigned long long)v;
+    st->n_equal = st->want != 0ull ? hist[v] : 0ull;
+    st->want = want;
+    st->n_better = nb;
+  }
+  __syncthreads();
+  hist[threadIdx.x & 255u] = 0ull;
+}
+// E: docs equal to the pivot stay; strictly better ones move to B; worse ones leave
+__global__ void sort_classify_kernel(unsigned long long* __restrict__ E, unsigned long long* __restrict__ B, unsigned long long n_docs,
+                                     const uint8_t* __restrict__ records, uint32_t record_size, uint32_t offset, uint32_t type, uint32_t key_bits,
+                                     uint32_t descending, const SortState* __restrict__ st, FacetPoint pt) {
+  const unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g * 64ull >= n_docs) return;
+  const unsigned long long pivot = st->prefix;
+  unsigned long long m = E[g], keep = 0ull, better = 0ull;
+  while (m) {
+    const int b = __builtin_ctzll(m);
+    const unsigned long long d = g * 64ull + (unsigned long long)b;
+    m &= m - 1;
+    if (d >= n_docs) break;
+    uint32_t ty = type;
+    const unsigned long long v = facet_load(records + d * record_size + offset, key_bits / 8u, ty, pt);
+    const unsigned long long k = facet_order_key(v, ty, key_bits, descending != 0u);
+    if (k > pivot) better |= 1ull << b;
+    else if (k == pivot) keep |= 1ull << b;
+  }
+  E[g] = keep;
+  if (better) B[g] |= better;
+}
+__global__ void sort_level_end_kernel(SortState* st) {
+  if (threadIdx.x == 0) { st->k_left -= st->n_better; st->count_e = st->n_equal; st->better_total += st->n_better; }
+}
+__global__ void sort_excl_kernel(const unsigned long long* __restrict__ E, const unsigned long long* __restrict__ B,
+                                 unsigned long long* __restrict__ ex_b, unsigned long long* __restrict__ ex_e, unsigned long long groups) {
+  const unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < groups) { ex_b[g] = ~B[g]; ex_e[g] = ~E[g]; }
+}
+// the answer of one query: list A (the docs of B with their scores, any order) ordered by (sort keys, score desc, doc asc), then the
+// first k - |A| of list C (the tie group of the last pivot, by score)
+__global__ void __launch_bounds__(1024) sort_compose_kernel(const uint32_t* __restrict__ a_doc, const float* __restrict__ a_score,
+                                                            const uint32_t* __restrict__ a_cnt, const uint32_t* __restrict__ c_doc,
+                                                            const float* __restrict__ c_score, const uint32_t* __restrict__ c_cnt,
+                                                            const unsigned long long* __restrict__ total, const uint8_t* __restrict__ records,
+                                                            uint32_t record_size, unsigned long long n_facet_docs, SortFieldsDev F, uint32_t k,
+                                                            uint32_t* __restrict__ out_doc, float* __restrict__ out_score,
+                                                            uint32_t* __restrict__ out_count, unsigned long long* __restrict__ out_total) {
+  __shared__ unsigned long long key[SS_MAX_SORT_FIELDS][1024];
+  __shared__ float sc[1024];
+  __shared__ uint32_t dc[1024];
+  __shared__ uint16_t perm[1024];
+  const uint32_t i = threadIdx.x;
+  const uint32_t na = min(*a_cnt == 0xFFFFFFFFu ? 0u : *a_cnt, k);
+  const uint32_t nc = min(*c_cnt == 0xFFFFFFFFu ? 0u : *c_cnt, k - na);
+  perm[i] = (uint16_t)i;
+  dc[i] = i < na ? a_doc[i] : 0xFFFFFFFFu;
+  sc[i] = i < na ? a_score[i] : -INFINITY;
+  for (uint32_t f = 0; f < (uint32_t)SS_MAX_SORT_FIELDS; f++) {
+    unsigned long long kk = 0ull;
+    if (i < na && f < F.n && dc[i] < n_facet_docs) {
+      uint32_t ty = F.type[f];
+      const unsigned long long v = facet_load(records + (size_t)dc[i] * record_size + F.offset[f], F.bytes[f], ty, F.pt[f]);
+      kk = facet_order_key(v, ty, 8u * F.bytes[f], F.desc[f] != 0u);
+    }
+    key[f][i] = kk;
+  }
+  __syncthreads();
+  auto before = [&](uint32_t a, uint32_t b) -> bool {  // a stands before b in the answer
+    const bool la = a < na, lb = b < na;
+    if (la != lb) return la;
+    if (!la) return a < b;
+    for (uint32_t f = 0; f < F.n; f++)
+      if (key[f][a] != key[f][b]) return key[f][a] > key[f][b];
+    if (sc[a] != sc[b]) return sc[a] > sc[b];
+    return dc[a] < dc[b];
+  };
+  for (uint32_t size = 2; size <= 1024u; size <<= 1)
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      const uint32_t j = i ^ stride;
+      if (j > i) {
+        const uint32_t a = perm[i], b = perm[j];
+        const bool up = (i & size) == 0u;  // ascending block: the better one first
+        if (up ? before(b, a) : before(a, b)) { perm[i] = (uint16_t)b; perm[j] = (uint16_t)a; }
+      }
+      __syncthreads();
+    }
+  if (i < na) { out_doc[i] = dc[perm[i]]; out_score[i] = sc[perm[i]]; }
+  else if (i < na + nc) { out_doc[i] = c_doc[i - na]; out_score[i] = c_score[i - na]; }
+  else if (i < k) { out_doc[i] = 0xFFFFFFFFu; out_score[i] = 0.f; }
+  if (i == 0) { *out_count = na + nc; *out_total = *total; }
+}
+
+// the device chain of ONE query up to the two exclusion bitmaps (the caller then runs the two searches and ssi_sort_compose)
+int ssi_sort_select(ss_shard* s, unsigned long long* d_E, unsigned long long* d_B, unsigned long long* d_ex_b, unsigned long long* d_ex_e,
+                    const unsigned long long* d_total, unsigned long long* d_hist, void* d_state, uint32_t n_sorts, const ss_result_sort* sorts,
+                    uint32_t k, hipStream_t st) {
+  static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 0, 0, 8};
+  const unsigned long long n_docs = s->bm_n_docs, groups = (unsigned long long)s->bm_n_sub * (BM_SUB / 64);
+  const unsigned grid = (unsigned)((groups + 255) / 256);
+  SortState* state = (SortState*)d_state;
+  SS_HIP(hipMemsetAsync(d_B, 0, groups * 8, st));
+  sort_begin_kernel<<<1, 64, 0, st>>>(state, d_total, (unsigned long long)k);
+  for (uint32_t f = 0; f < n_sorts; f++) {
+    const uint32_t type = sorts[f].facet_type;
+    FacetPoint pt{0, 0, 0};
+    if (type == SS_FACET_POINT) {
+      const ss_facet_point base{sorts[f].base_lat, sorts[f].base_lon, SS_POINT_SORTKEY, 0};
+      if (facet_point_of(&base, &pt) != SS_OK) return SS_EINVAL;
+    }
+    const uint32_t key_bits = 8u * width[type];
+    sort_level_begin_kernel<<<1, 256, 0, st>>>(state, d_hist);
+    for (uint32_t b = 0; b < key_bits / 8u; b++) {
+      sort_radix_kernel<<<grid, 256, 0, st>>>(d_E, n_docs, s->d_facets, s->facet_record_size, sorts[f].facet_offset, type, key_bits,
+                                              sorts[f].descending ? 1u : 0u, state, b, d_hist, pt);
+      sort_decide_kernel<<<1, 256, 0, st>>>(state, d_hist);
+    }
+    sort_classify_kernel<<<grid, 256, 0, st>>>(d_E, d_B, n_docs, s->d_facets, s->facet_record_size, sorts[f].facet_offset, type, key_bits,
+                                               sorts[f].descending ? 1u : 0u, state, pt);
+    sort_level_end_kernel<<<1, 64, 0, st>>>(state);
+  }
+  sort_excl_kernel<<<grid, 256, 0, st>>>(d_E, d_B, d_ex_b, d_ex_e, groups);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+int ssi_sort_compose(ss_shard* s, const uint32_t* a_doc, const float* a_score, const uint32_t* a_cnt, const uint32_t* c_doc, const float* c_score,
+                     const uint32_t* c_cnt, const unsigned long long* d_total, uint32_t n_sorts, const ss_result_sort* sorts, uint32_t k,
+                     uint32_t* out_doc, float* out_score, uint32_t* out_count, unsigned long long* out_total, hipStream_t st) {
+  static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 0, 0, 8};
+  SortFieldsDev F;
+  memset(&F, 0, sizeof(F));
+  F.n = n_sorts;
+  for (uint32_t f = 0; f < n_sorts; f++) {
+    F.offset[f] = sorts[f].facet_offset; F.type[f] = sorts[f].facet_type; F.bytes[f] = width[sorts[f].facet_type]; F.desc[f] = sorts[f].descending ? 1u : 0u;
+    if (sorts[f].facet_type == SS_FACET_POINT) {
+      const ss_facet_point base{sorts[f].base_lat, sorts[f].base_lon, SS_POINT_SORTKEY, 0};
+      if (facet_point_of(&base, &F.pt[f]) != SS_OK) return SS_EINVAL;
+    }
+  }
+  sort_compose_kernel<<<1, 1024, 0, st>>>(a_doc, a_score, a_cnt, c_doc, c_score, c_cnt, d_total, s->d_facets, s->facet_record_size,
+                                          (unsigned long long)s->facet_docs, F, k, out_doc, out_score, out_count, out_total);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
 // the signatures ss_common.h declares: no base point
 int ssi_facet_kth(ss_shard* s, const unsigned long long* d_bits, uint64_t n_docs, uint64_t n_matches, uint32_t offset, uint32_t type,
                   bool descending, uint64_t k, unsigned long long* d_hist, uint64_t* value_bits, uint64_t* n_better, uint64_t* n_equal,

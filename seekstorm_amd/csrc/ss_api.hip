@@ -171,7 +171,7 @@ int ss_shard_destroy(ss_shard* s) {
   (void)hipStreamSynchronize(s->stream);
   free_vec(s);
   free_bm25(s);
-  void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_deleted, s->d_facets, s->d_filter_bits, s->d_facet_ws, s->d_pool_stage, s->d_tier_ws, s->d_tier_hold, s->d_excl_bits};
+  void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_deleted, s->d_facets, s->d_filter_bits, s->d_facet_ws, s->d_pool_stage, s->d_tier_ws, s->d_tier_hold, s->d_excl_bits, s->d_sort_ws};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   (void)hipDeviceSynchronize();  // searches queued on the callers' own streams may still use their workspaces
   for (auto& kv : s->bm_ws) {
@@ -1793,6 +1793,81 @@ int ss_bm25_facet_kth_point(ss_shard* s, const ss_bm25_query* query, uint32_t n_
                             uint32_t facet_offset, const ss_facet_point* base, uint32_t descending, uint64_t k, uint64_t* out_value,
                             uint64_t* out_n_better, uint64_t* out_n_equal, uint64_t* out_total) {
   return facet_kth_impl(s, query, n_filters, filters, facet_offset, SS_FACET_POINT, base, descending, k, out_value, out_n_better, out_n_equal, out_total);
+}
+
+// Result sort for a batch (facet.hip: "Result sort for a BATCH, pivots on the device").  Per query, everything queued on the shard's
+// stream: match bits -> radix selects + classification of every sort field -> the two exclusion bitmaps -> two searches under them
+// -> compose into the query's output row; one synchronisation at the end of the call.
+int ss_bm25_search_sorted(ss_shard* s, uint32_t nq, const ss_bm25_query* queries, uint32_t n_sorts, const ss_result_sort* sorts, uint32_t k,
+                          uint32_t n_filters, const ss_facet_filter* filters, uint32_t* out_doc, float* out_score, uint32_t* out_count,
+                          uint64_t* out_total) {
+  if (!s || !queries || nq == 0 || !out_doc || !out_score || !out_count || !out_total || k == 0 || k > SS_MAX_K) return SS_EINVAL;
+  if (n_sorts == 0) return ss_bm25_search_filtered(s, nq, queries, k, SS_RT_TOPKCOUNT, n_filters, filters, out_doc, out_score, out_count, out_total);
+  if (!sorts) return SS_EINVAL;
+  if (n_sorts > SS_MAX_SORT_FIELDS) return SS_ENOTSUP;
+  static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 2, 4, 8};
+  for (uint32_t f = 0; f < n_sorts; f++) {
+    if (sorts[f].facet_type > SS_FACET_POINT) return SS_EINVAL;
+    if (sorts[f].facet_type == SS_FACET_STRING16 || sorts[f].facet_type == SS_FACET_STRING32) return SS_ENOTSUP;  // by their strings: the host's rank column
+  }
+  if (!s->d_post) return SS_ESTATE;
+  std::lock_guard<std::mutex> g(s->mu);
+  SS_HIP(hipSetDevice(s->device));
+  if (!s->d_facets || s->facet_docs < s->bm_n_docs) return SS_ESTATE;
+  for (uint32_t f = 0; f < n_sorts; f++)
+    if (sorts[f].facet_offset + width[sorts[f].facet_type] > s->facet_record_size) return SS_ESTATE;
+  const uint64_t groups = (uint64_t)s->bm_n_sub * (BM_SUB / 64);
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t o_q = 0, o_tot = o_q + al(sizeof(ss_bm25_query)), o_state = o_tot + 256, o_hist = o_state + 256, o_E = o_hist + 256 * 8,
+               o_B = o_E + al(groups * 8), o_xb = o_B + al(groups * 8), o_xe = o_xb + al(groups * 8), o_ad = o_xe + al(groups * 8),
+               o_as = o_ad + al((size_t)k * 4), o_ac = o_as + al((size_t)k * 4), o_cd = o_ac + 256, o_cs = o_cd + al((size_t)k * 4),
+               o_cc = o_cs + al((size_t)k * 4), o_od = o_cc + 256, o_os = o_od + al((size_t)nq * k * 4), o_oc = o_os + al((size_t)nq * k * 4),
+               o_ot = o_oc + al((size_t)nq * 4), need = o_ot + al((size_t)nq * 8);
+  if (need > s->sort_ws_cap) {
+    SS_HIP(hipStreamSynchronize(s->stream));
+    if (s->d_sort_ws) (void)hipFree(s->d_sort_ws);
+    s->d_sort_ws = nullptr; s->sort_ws_cap = 0;
+    SS_HIP(hipMalloc(&s->d_sort_ws, need));
+    s->sort_ws_cap = need;
+  }
+  char* W = (char*)s->d_sort_ws;
+  ss_bm25_query* d_q = (ss_bm25_query*)(W + o_q);
+  unsigned long long* d_total = (unsigned long long*)(W + o_tot);
+  unsigned long long *d_E = (unsigned long long*)(W + o_E), *d_B = (unsigned long long*)(W + o_B), *d_xb = (unsigned long long*)(W + o_xb),
+                     *d_xe = (unsigned long long*)(W + o_xe);
+  SS_TRY(ensure_out(s, 1, k));
+  for (uint32_t i = 0; i < nq; i++) {
+    bool has_and, has_or, all_probed, any_frequent, phrase = false;
+    uint32_t nt_max, np_max;
+    SS_TRY(ssi_bm25_ensure_probe_rows(s, 1, queries + i, s->stream));
+    SS_TRY(check_queries(s, 1, queries + i, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent, &phrase));
+    if (!all_probed || !s->d_probe || phrase) return SS_ENOTSUP;
+    SS_HIP(hipMemcpyAsync(d_q, queries + i, sizeof(ss_bm25_query), hipMemcpyHostToDevice, s->stream));
+    SS_HIP(hipMemsetAsync(d_total, 0, 8, s->stream));
+    SS_HIP(hipMemsetAsync(d_E, 0, groups * 8, s->stream));
+    SS_TRY(with_facet_filter(s, n_filters, filters, s->stream, [&]() { return ssi_bm25_match_bits(s, d_q, d_E, d_total, s->stream); }));
+    SS_TRY(ssi_sort_select(s, d_E, d_B, d_xb, d_xe, d_total, (unsigned long long*)(W + o_hist), W + o_state, n_sorts, sorts, k, s->stream));
+    for (int part = 0; part < 2; part++) {  // the docs that are in for sure, then the last pivot's tie group -- by score, under their bitmaps
+      uint32_t* del = s->d_deleted;
+      const uint64_t dw = s->deleted_words, nd = s->n_deleted;
+      s->d_deleted = (uint32_t*)(part == 0 ? d_xb : d_xe); s->deleted_words = groups * 2; s->n_deleted = 1;
+      const int rc = bm25_search_host_queries(s, 1, queries + i, k, SS_RT_TOPK, 0, nullptr);
+      s->d_deleted = del; s->deleted_words = dw; s->n_deleted = nd;
+      if (rc != SS_OK) return rc;
+      SS_HIP(hipMemcpyAsync(W + (part == 0 ? o_ad : o_cd), s->d_out_doc, (size_t)k * 4, hipMemcpyDeviceToDevice, s->stream));
+      SS_HIP(hipMemcpyAsync(W + (part == 0 ? o_as : o_cs), s->d_out_score, (size_t)k * 4, hipMemcpyDeviceToDevice, s->stream));
+      SS_HIP(hipMemcpyAsync(W + (part == 0 ? o_ac : o_cc), s->d_out_count, 4, hipMemcpyDeviceToDevice, s->stream));
+    }
+    SS_TRY(ssi_sort_compose(s, (const uint32_t*)(W + o_ad), (const float*)(W + o_as), (const uint32_t*)(W + o_ac), (const uint32_t*)(W + o_cd),
+                            (const float*)(W + o_cs), (const uint32_t*)(W + o_cc), d_total, n_sorts, sorts, k, (uint32_t*)(W + o_od) + (size_t)i * k,
+                            (float*)(W + o_os) + (size_t)i * k, (uint32_t*)(W + o_oc) + i, (unsigned long long*)(W + o_ot) + i, s->stream));
+  }
+  SS_HIP(hipMemcpyAsync(out_doc, W + o_od, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s->stream));
+  SS_HIP(hipMemcpyAsync(out_score, W + o_os, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s->stream));
+  SS_HIP(hipMemcpyAsync(out_count, W + o_oc, (size_t)nq * 4, hipMemcpyDeviceToHost, s->stream));
+  SS_HIP(hipMemcpyAsync(out_total, W + o_ot, (size_t)nq * 8, hipMemcpyDeviceToHost, s->stream));
+  SS_HIP(hipStreamSynchronize(s->stream));
+  return SS_OK;
 }
 
 static int facet_values_impl(ss_shard* s, uint32_t n, const uint32_t* doc_ids, uint32_t facet_offset, uint32_t facet_type,

@@ -554,6 +554,26 @@ int Shard::sort_keys(const std::vector<uint32_t>& doc_ids, const ResultSort& sf,
 int Shard::sorted_topk(const ss_bm25_query& q, const ResultSort* sorts, size_t n_sorts, size_t k, std::vector<ss_facet_filter> filters,
                        std::vector<Result>* out, uint64_t* total, bool* have_total) {
   if (k == 0) return SS_OK;
+  // round 4: one ABI call -- the pivots of every sort field are found on the device (ss_bm25_search_sorted); the composition below
+  // remains for more sort fields than the call takes and as the recursion's own by-score leaf
+  if (n_sorts >= 1 && n_sorts <= SS_MAX_SORT_FIELDS && !*have_total && out->empty()) {
+    if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
+    std::vector<ss_result_sort> rs(n_sorts);
+    for (size_t f = 0; f < n_sorts; f++) {
+      rs[f].facet_offset = sorts[f].facet_offset; rs[f].facet_type = sorts[f].facet_type; rs[f].descending = sorts[f].descending ? 1u : 0u;
+      rs[f].reserved = 0; rs[f].base_lat = sorts[f].base[0]; rs[f].base_lon = sorts[f].base[1];
+    }
+    std::vector<uint32_t> doc(k);
+    std::vector<float> score(k);
+    uint32_t cnt = 0;
+    uint64_t tot = 0;
+    const int rc = ss_bm25_search_sorted(h_, 1, &q, (uint32_t)n_sorts, rs.data(), (uint32_t)k, (uint32_t)filters.size(),
+                                         filters.empty() ? nullptr : filters.data(), doc.data(), score.data(), &cnt, &tot);
+    if (rc != SS_OK) return rc;
+    *total = tot; *have_total = true;
+    for (uint32_t i = 0; i < cnt; i++) { Result r; r.doc_id = doc[i]; r.score = r.lexical_score = score[i]; out->push_back(r); }
+    return SS_OK;
+  }
   if (n_sorts == 0) {  // by score
     ResultObject ro = std::move(search_lexical_batch({q}, k, ResultType::TopkCount, filters)[0]);
     if (ro.last_error != SS_OK) return ro.last_error;

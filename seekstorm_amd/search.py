@@ -764,8 +764,42 @@ class Shard:
                 "ss_facet_point_distances")
         return out.view(np.float64)
 
+    def search_lexical_sorted_batch(self, queries, result_sort, k, facet_filter=None):
+        """a BATCH of queries under result_sort = [(facet offset, type, descending[, base])] (numeric facets, Point facets by
+        simplified_distance to base = (lat, lon)): ss_bm25_search_sorted -- the pivots of every sort field are found on the device, two
+        searches under exclusion bitmaps and a compose kernel per query, one synchronisation per call.
+        -> (doc [nq][k], score [nq][k], count [nq], total [nq])"""
+        n = len(result_sort)
+        arr = (N.ResultSortC * max(n, 1))()
+        for i, sf in enumerate(result_sort):
+            off, ty, desc = sf[:3]
+            arr[i].facet_offset, arr[i].descending = int(off), 1 if desc else 0
+            if ty == "point":
+                arr[i].facet_type, arr[i].base_lat, arr[i].base_lon = N.FACET_TYPES["point"], float(sf[3][0]), float(sf[3][1])
+            else:
+                arr[i].facet_type = N.FACET_TYPES[ty]
+        q = np.ascontiguousarray(queries)
+        nq, kk = len(q), int(k)
+        doc = np.full((nq, kk), N.SS_NO_DOC, np.uint32)
+        score = np.zeros((nq, kk), np.float32)
+        cnt = np.zeros(nq, np.uint32)
+        tot = np.zeros(nq, np.uint64)
+        farr, nf = self.facet_filters(facet_filter) if facet_filter else (None, 0)
+        N.check(N.lib().ss_bm25_search_sorted(self._h, nq, q.ctypes.data_as(C.c_void_p), n, C.cast(arr, C.c_void_p), kk, nf,
+                                              None if farr is None else C.cast(farr, C.c_void_p), N.ptr(doc, N.u32p), N.ptr(score, N.f32p),
+                                              N.ptr(cnt, N.u32p), N.ptr(tot, N.u64p)), "ss_bm25_search_sorted")
+        return doc, score, cnt, tot
+
     def search_lexical_sorted(self, query, result_sort, k, facet_filter=None):
-        """ONE query (a 1-element make_queries array) with result_sort = [(facet offset, type, descending[, base])], the reference's
+        """ONE query (a 1-element make_queries array) under result_sort -> (doc ids, scores, total): ss_bm25_search_sorted"""
+        if len(result_sort) > N.SS_MAX_SORT_FIELDS:
+            return self.search_lexical_sorted_composed(query, result_sort, k, facet_filter)
+        doc, score, cnt, tot = self.search_lexical_sorted_batch(query[:1], result_sort, k, facet_filter)
+        return doc[0][:cnt[0]].copy(), score[0][:cnt[0]].copy(), int(tot[0])
+
+    def search_lexical_sorted_composed(self, query, result_sort, k, facet_filter=None):
+        """the same answer composed on the HOST from the older entry points (kept as the second route and as a cross-check):
+        ONE query (a 1-element make_queries array) with result_sort = [(facet offset, type, descending[, base])], the reference's
         Vec<ResultSort> over numeric facets and Point facets (type "point", base = (lat, lon): by simplified_distance to the base,
         morton_ordering, geo_search.rs:90-108): the k best matches under (field 1, field 2, ..., score), each field ascending or
         descending, the score descending last (result_ordering_shard, min_heap.rs:574-1050) -> (doc ids, scores, total).

@@ -1285,6 +1285,19 @@ def test_result_sort_by_facets(S, O, lex):
                         for name, _ in srt:
                             assert np.array_equal(v[name][doc], v[name][md[order]]), (terms, srt, k, name)
                         assert np.allclose(score, ms[order], rtol=1e-4), (terms, srt, k)
+            # one call for a batch of queries (ss_bm25_search_sorted): row i = the single call's answer; and the host-composed route
+            # (pivot + filtered searches through the older entry points) agrees on fields and scores
+            qb = np.concatenate([sh.make_queries([t], qt) for t, qt, _ in cases])
+            for srt in ([("c", True)], [("a", False), ("f", True), ("d", True)]):
+                spec = [(off[n], ty[n], d_) for n, d_ in srt]
+                bd, bs, bc, bt = sh.search_lexical_sorted_batch(qb, spec, 25)
+                for i in range(len(cases)):
+                    doc, score, tot = sh.search_lexical_sorted(qb[i:i + 1], spec, 25)
+                    assert int(bt[i]) == tot and int(bc[i]) == len(doc) and np.array_equal(bd[i][:bc[i]], doc) and np.array_equal(bs[i][:bc[i]], score)
+                    cd, cs, ctot = sh.search_lexical_sorted_composed(qb[i:i + 1], spec, 25)
+                    assert ctot == tot and len(cd) == len(doc) and np.allclose(cs, score, rtol=1e-6)
+                    for name, _ in srt:
+                        assert np.array_equal(v[name][cd], v[name][doc])
     finally:
         sh.set_deleted([])
         osh.set_deleted([])

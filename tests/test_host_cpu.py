@@ -76,7 +76,7 @@ def test_rust_ffi_file_is_the_header():
             align = max(align, sz)
         layouts[m.group(1)] = ((off + align - 1) // align * align, fields)
     cname = {"SsRefBlock": "ss_ref_block", "SsBm25Query": "ss_bm25_query", "SsFacetPoint": "ss_facet_point", "SsFacetFilter": "ss_facet_filter",
-             "SsAnnMode": "ss_ann_mode", "SsVecLevel": "ss_vec_level"}
+             "SsAnnMode": "ss_ann_mode", "SsVecLevel": "ss_vec_level", "SsResultSort": "ss_result_sort"}
     assert set(layouts) == set(cname)
     items, want = [], []
     for rs, (total, fields) in layouts.items():
