@@ -381,6 +381,24 @@ __device__ __forceinline__ BmTop<KPL> s16_trigger(BmTop<KPL> T, S16Cur<S16Cfg<NT
       }
       constexpr uint32_t SLACK = ((AND ? (uint32_t)NT : 2u * (uint32_t)NT) + S16_SLACK) << SH;
       qcut = max(qcut, lo > SLACK ? lo - SLACK : 1u);
+    } else if (KPL > 1 && k > 64u) {
+      // k of 65 .. 128: more results than lanes -- the same cut over the 512 SLOTS (8 docs each, one maximum per slot): k slots holding a
+      // bound >= x are k distinct docs that reach x
+      auto slots_at = [&](uint32_t x) -> uint32_t {
+        uint32_t c = 0u;
+#pragma unroll
+        for (int i = 0; i < 8; i++) c += (uint32_t)__popcll(__ballot(((sm[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu) >= x));
+        return c;
+      };
+      if (slots_at(qcut) > k) {
+        uint32_t lo = qcut, hi = 65535u;  // invariant: at least k slots reach lo
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi + 1u) >> 1;
+          if (slots_at(mid) >= k) lo = mid; else hi = mid - 1u;
+        }
+        constexpr uint32_t SLACK2 = ((AND ? (uint32_t)NT : 2u * (uint32_t)NT) + S16_SLACK) << SH;
+        qcut = max(qcut, lo > SLACK2 ? lo - SLACK2 : 1u);
+      }
     }
     uint32_t hotbits = 0u;  // bit i: slot i of this lane holds a bound at or above the cut
 #pragma unroll
@@ -865,7 +883,7 @@ int launch16(const BmParams& p, hipStream_t st) {
 }  // namespace
 
 // What the 16-bit tile serves (everything else of the exhaustive strategy stays on bm25_scan_fast_kernel's f32 tile):
-//  * unions of <= 4 lists (five and six: top-k only), k <= 64, exact counts (TopkCount, and Count with k = 0);
+//  * unions of <= 4 lists, k <= 128 (five and six lists: top-k only, k <= 64), exact counts (TopkCount, and Count with k = 0);
 //  * NOT lists (nn_max of them in some query): a top-k request never streams them -- the candidate path clears their docs from the tile before it
 //    looks at it (s16_exclude); a count request streams ONE NOT list beside the terms (EXCL instances);
 //  * tombstones: top-k in the candidate path, counts in the EXCL instances (the sub-block's 128 tombstone words per item);
@@ -884,27 +902,29 @@ bool ssi_bm25_scan16_serves(uint32_t nn_max, uint32_t np_max, bool has_and, bool
   if (nn > 8) return false;
   if (has_and && (and_off || and_exact_nt < 2 || and_exact_nt > 3 || and_exact_nt != np_max)) return false;
   if (np_max > 4 && (has_and || count || wide_off)) return false;  // five / six lists: plain top-k unions
-  return !off && (k != 0 || count) && np_max >= 1 && np_max <= 6 && KPL == 1;
+  static const int k128_off = [] { const char* e = getenv("SS_BM25_SCAN16_K128"); return e ? atoi(e) == 0 : 0; }();
+  if (KPL == 2 && (k128_off || np_max > 4)) return false;  // k <= 128: two keys per lane in the candidate path (no k-lane cut), <= 4 lists
+  return !off && (k != 0 || count) && np_max >= 1 && np_max <= 6 && KPL <= 2;
 }
 
 int ssi_bm25_launch_scan16(const BmParams& p, uint32_t np_max, uint32_t nn_max, bool is_and, int KPL, hipStream_t st) {
   const int NT = np_max <= 2 ? 2 : (int)np_max;
   const bool excl = p.count && (p.del != nullptr || nn_max != 0);  // exclusions inside the streaming loop: exact counts only
-  if (KPL != 1) return SS_ENOTSUP;
+  if (KPL != 1 && KPL != 2) return SS_ENOTSUP;
   if (is_and) {
-#define SS_A(NT_)                                                                                                          \
-  if (NT == NT_)                                                                                                           \
-    return !p.count ? launch16<NT_, 1, false, true>(p, st) : excl ? launch16<NT_, 1, true, true, true>(p, st) : launch16<NT_, 1, true, true>(p, st);
-    SS_A(2) SS_A(3)
+#define SS_A(NT_, KPL_)                                                                                                    \
+  if (NT == NT_ && KPL == KPL_)                                                                                            \
+    return !p.count ? launch16<NT_, KPL_, false, true>(p, st) : excl ? launch16<NT_, KPL_, true, true, true>(p, st) : launch16<NT_, KPL_, true, true>(p, st);
+    SS_A(2, 1) SS_A(3, 1) SS_A(2, 2) SS_A(3, 2)
 #undef SS_A
     return SS_ENOTSUP;
   }
-#define SS_F(NT_)                                                                                                          \
-  if (NT == NT_)                                                                                                           \
-    return !p.count ? launch16<NT_, 1, false, false>(p, st) : excl ? launch16<NT_, 1, true, false, true>(p, st) : launch16<NT_, 1, true, false>(p, st);
-  SS_F(2) SS_F(3) SS_F(4)
+#define SS_F(NT_, KPL_)                                                                                                    \
+  if (NT == NT_ && KPL == KPL_)                                                                                            \
+    return !p.count ? launch16<NT_, KPL_, false, false>(p, st) : excl ? launch16<NT_, KPL_, true, false, true>(p, st) : launch16<NT_, KPL_, true, false>(p, st);
+  SS_F(2, 1) SS_F(3, 1) SS_F(4, 1) SS_F(2, 2) SS_F(3, 2) SS_F(4, 2)
 #undef SS_F
-  if (NT == 5 && !p.count) return launch16<5, 1, false, false>(p, st);
-  if (NT == 6 && !p.count) return launch16<6, 1, false, false>(p, st);
+  if (NT == 5 && !p.count && KPL == 1) return launch16<5, 1, false, false>(p, st);
+  if (NT == 6 && !p.count && KPL == 1) return launch16<6, 1, false, false>(p, st);
   return SS_ENOTSUP;
 }

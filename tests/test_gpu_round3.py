@@ -175,7 +175,7 @@ def test_exhaustive_16bit_scan_counts_and_intersections(S, O):
                            (2, O.OP_OR, S.QueryType.Union), (3, O.OP_OR, S.QueryType.Union), (4, O.OP_OR, S.QueryType.Union)):
         tl = [[int(x) for x in rng.choice(nt_all, nterms, replace=False)] for _ in range(40)]
         q = sh.make_queries(tl, qt)
-        for k in (10, 64):
+        for k in (10, 64, 100, 128):
             want = [osh.search_exhaustive(t, op, k) for t in tl]
             sh.set_strategy(N.BM25_AUTO)
             pd, ps, pc, pt = sh.search_lexical_batch(q, k, S.ResultType.TopkCount, reference_shortcuts=False)

@@ -56,10 +56,10 @@ def _same(a, b, what):
         assert np.array_equal(x, y), (what, name)
 
 
-def _oracle_check(S, O, osh, cs, oop, rt, got):
+def _oracle_check(S, O, osh, cs, oop, rt, got, k=10):
     doc, score, cnt, tot = got
     for i, (pos, neg) in enumerate(cs):
-        od, os_, otot = osh.search_exhaustive(pos, oop, 10, not_terms=neg)
+        od, os_, otot = osh.search_exhaustive(pos, oop, k, not_terms=neg)
         if rt != S.ResultType.Topk:
             assert int(tot[i]) == otot, (pos, neg, rt)
         if rt != S.ResultType.Count:
@@ -89,12 +89,13 @@ def test_exclusions_on_the_16_bit_tile_equal_the_f32_tile_and_the_oracle(S, O, l
                                      (ands3, S.QueryType.Intersection, O.OP_AND, (S.ResultType.Topk, S.ResultType.TopkCount))):
                 q = sh.make_queries([c[0] for c in cs], qt, [c[1] for c in cs])
                 for rt in rts:
-                    sh.set_strategy(N.BM25_EXHAUSTIVE)
-                    a = sh.search_lexical_batch(q, 10, rt)
-                    sh.set_strategy(N.BM25_EXHAUSTIVE_F32)
-                    b = sh.search_lexical_batch(q, 10, rt)
-                    _same(a, b, (qt, rt, bool(gone)))
-                    _oracle_check(S, O, osh, cs, oop, rt, a)
+                    for k in (10, 100):  # (k = 100: two keys per lane in the candidate path, no k-lane cut)
+                        sh.set_strategy(N.BM25_EXHAUSTIVE)
+                        a = sh.search_lexical_batch(q, k, rt)
+                        sh.set_strategy(N.BM25_EXHAUSTIVE_F32)
+                        b = sh.search_lexical_batch(q, k, rt)
+                        _same(a, b, (qt, rt, bool(gone), k))
+                        _oracle_check(S, O, osh, cs, oop, rt, a, k)
     finally:
         sh.set_strategy(0)
         sh.set_deleted([])
