@@ -269,6 +269,30 @@ __device__ __forceinline__ void s16_clear_tile(uint32_t wb, int lane) {
 #ifndef S16_NT1
 #define S16_NT1 2
 #endif
+// The part of a segment beyond its register chunks, streamed.  S16_REST4: four 64-lane chunks in flight at a time instead of one load
+// per step (a dense segment is then no chain of dependent HBM round trips).  (Loads past the segment's end return NULL postings; they
+// are not processed.)
+#ifndef S16_REST4
+#define S16_REST4 0
+#endif
+template <typename F>
+__device__ __forceinline__ void s16_rest(__amdgpu_buffer_rsrc_t rs, int lane16, uint32_t u0, uint32_t u1, F f) {
+#if S16_REST4
+  for (uint32_t u = u0; u < u1; u += 256u) {
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + 1024, (int)(u << 4), 0);
+    const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + 2048, (int)(u << 4), 0);
+    const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + 3072, (int)(u << 4), 0);
+    f(a);
+    if (u + 64u < u1) f(b);
+    if (u + 128u < u1) f(c);
+    if (u + 192u < u1) f(d);
+  }
+#else
+  for (uint32_t u = u0; u < u1; u += 64u) f(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0));
+#endif
+}
+
 template <int NT> struct S16Cfg {
   static constexpr int cpt(int t) {
     return NT >= 5 ? (t == NT - 1 ? 2 : 1)  // five / six lists: 1 ... 1 / 2 (6 / 7 chunks: the registers of 2 per term would not fit)
@@ -310,7 +334,7 @@ __device__ __forceinline__ void s16_each_chunk(const S16Cur<S16Cfg<NT>::RC>& cur
     if ((uint32_t)c * 64u < n16) f(cur.v[OFF + c]);
   if (n16 > (uint32_t)CPT * 64u) {
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)it.tptr[TT], 0, (int)(it.b1[TT] << 4), BM_RSRC_FLAGS);
-    for (uint32_t u = it.b0[TT] + CPT * 64u; u < it.b1[TT]; u += 64u) f(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0));
+    s16_rest(rs, lane16, it.b0[TT] + CPT * 64u, it.b1[TT], f);
   }
 }
 // ... for every term position TT in [A, B), f(chunk, TT)
@@ -623,8 +647,7 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
         if (nn16 > (uint32_t)CN * 64u) {
           over = true;
           __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ntptr, 0, (int)(NB1 << 4), BM_RSRC_FLAGS);
-          for (uint32_t u = NB0 + CN * 64u; u < NB1; u += 64u)
-            s16_not_chunk<CNT && !AND>(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0), accb, dec);
+          s16_rest(rs, lane16, NB0 + CN * 64u, NB1, [&](const u32x4 v) { s16_not_chunk<CNT && !AND>(v, accb, dec); });
         }
         if (del) s16_del_bits<CNT && !AND>(cur[DX].x, cur[DX].y, accb, lane, dec);
       }
@@ -647,7 +670,7 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
             if ((uint32_t)c * 64u < n16) f(cur[Cfg::off(t) + c]);
           if (n16 > (uint32_t)Cfg::cpt(t) * 64u) {
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[t], 0, (int)(B1[t] << 4), BM_RSRC_FLAGS);
-            for (uint32_t u = B0[t] + Cfg::cpt(t) * 64u; u < B1[t]; u += 64u) f(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0));
+            s16_rest(rs, lane16, B0[t] + Cfg::cpt(t) * 64u, B1[t], f);
           }
         };
         seg(std::integral_constant<int, 0>{}, [&](const u32x4 v) { s16a_first(v, fidf[0], accb); });
@@ -698,7 +721,7 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
             if ((uint32_t)c * 64u < nn16) s16_mark_chunk(cur[RC + c], accb);
           if (nn16 > (uint32_t)CN * 64u) {
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ntptr, 0, (int)(NB1 << 4), BM_RSRC_FLAGS);
-            for (uint32_t u = NB0 + CN * 64u; u < NB1; u += 64u) s16_mark_chunk(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0), accb);
+            s16_rest(rs, lane16, NB0 + CN * 64u, NB1, [&](const u32x4 v) { s16_mark_chunk(v, accb); });
           }
           if (del) s16_mark_bits(cur[DX].x, cur[DX].y, accb, lane);
         }
@@ -710,8 +733,7 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
             if (c < Cfg::cpt(t) && (uint32_t)c * 64u < n16) mx = s16_keep<CNT, true>(cur[Cfg::off(t) + c], fidf[t], accb, mx, cnt);
           if (n16 > (uint32_t)Cfg::cpt(t) * 64u) {
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[t], 0, (int)(B1[t] << 4), BM_RSRC_FLAGS);
-            for (uint32_t u = B0[t] + Cfg::cpt(t) * 64u; u < B1[t]; u += 64u)
-              mx = s16_keep<CNT, true>(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0), fidf[t], accb, mx, cnt);
+            s16_rest(rs, lane16, B0[t] + Cfg::cpt(t) * 64u, B1[t], [&](const u32x4 v) { mx = s16_keep<CNT, true>(v, fidf[t], accb, mx, cnt); });
           }
         }
         constexpr int CL = Cfg::cpt(NT - 1), OL = Cfg::off(NT - 1);
@@ -722,8 +744,7 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
           if ((uint32_t)c * 64u < nlast) mx = s16_read<CNT, true>(cur[OL + c], fidf[NT - 1], accb, mx, nwL[c], cnt);
         if (nlast > (uint32_t)CL * 64u) {
           __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[NT - 1], 0, (int)(B1[NT - 1] << 4), BM_RSRC_FLAGS);
-          for (uint32_t u = B0[NT - 1] + CL * 64u; u < B1[NT - 1]; u += 64u)
-            mx = s16_keep<CNT, true>(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0), fidf[NT - 1], accb, mx, cnt);
+          s16_rest(rs, lane16, B0[NT - 1] + CL * 64u, B1[NT - 1], [&](const u32x4 v) { mx = s16_keep<CNT, true>(v, fidf[NT - 1], accb, mx, cnt); });
         }
         T.matched += cnt;
         const float thr = fmaxf(T.wsc, __uint_as_float(tau_bits));
@@ -759,8 +780,7 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
           }
         if (n16 > (uint32_t)Cfg::cpt(t) * 64u) {  // the rest of the segment, loaded synchronously
           __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[t], 0, (int)(B1[t] << 4), BM_RSRC_FLAGS);
-          for (uint32_t u = B0[t] + Cfg::cpt(t) * 64u; u < B1[t]; u += 64u)
-            mx = s16_keep<CNT>(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0), fidf[t], accb, mx, cnt);
+          s16_rest(rs, lane16, B0[t] + Cfg::cpt(t) * 64u, B1[t], [&](const u32x4 v) { mx = s16_keep<CNT>(v, fidf[t], accb, mx, cnt); });
         }
       }
       // the last term is only READ: its sums stay in registers and reach the tile when the item has candidates -- most
@@ -775,8 +795,7 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
         }
       if (nlast > (uint32_t)CL * 64u) {
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tptr[NT - 1], 0, (int)(B1[NT - 1] << 4), BM_RSRC_FLAGS);
-        for (uint32_t u = B0[NT - 1] + CL * 64u; u < B1[NT - 1]; u += 64u)
-          mx = s16_keep<CNT>(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0), fidf[NT - 1], accb, mx, cnt);
+        s16_rest(rs, lane16, B0[NT - 1] + CL * 64u, B1[NT - 1], [&](const u32x4 v) { mx = s16_keep<CNT>(v, fidf[NT - 1], accb, mx, cnt); });
       }
       if (CNT) T.matched += cnt;
       const float thr = fmaxf(T.wsc, __uint_as_float(tau_bits));
