@@ -493,6 +493,7 @@ int ss_bm25_append_level(ss_shard* s, uint32_t level, uint32_t n_level_docs, con
   {
     std::lock_guard<std::mutex> g(s->mu);
     if (s->d_post && s->raw.empty()) return SS_ESTATE;       // an image that was not built level by level
+    if (s->sp_n) return SS_ENOTSUP;                          // a sparse tier numbers its terms behind the dense ones: a grown vocabulary would shift them
     if (level > s->raw.size() || level + 1 < s->raw.size()) return SS_EINVAL;  // append the next level, or replace the last one (a re-commit)
     if (level >= 1 && s->raw[level - 1].n_docs != 65536u) return SS_EINVAL;    // only the last level may be partial
     if ((uint64_t)level * 65536u + n_level_docs > 0xFFFFFFFFull) return SS_ENOTSUP;
@@ -710,7 +711,7 @@ int ss_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, c
   if (!s || !offs || (n_lists && offs[n_lists] > offs[0] && (!docs || !tfs))) return SS_EINVAL;
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
-  SS_HIP(hipStreamSynchronize(s->stream));  // searches in flight still read the arrays an append replaces
+  SS_HIP(hipDeviceSynchronize());  // searches on the callers' own streams may still read the arrays an append replaces
   const uint32_t first = s->bm_n_terms + s->sp_n;
   SS_TRY(ssi_bm25_append_sparse(s, n_lists, offs, docs, tfs));
   if (first_term_id_out) *first_term_id_out = first;
@@ -721,7 +722,7 @@ int ss_bm25_append_sparse_fields(ss_shard* s, uint32_t n_lists, const uint64_t* 
   if (!s || !offs || (n_lists && offs[n_lists] > offs[0] && (!docs || !fields || !tfs))) return SS_EINVAL;
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
-  SS_HIP(hipStreamSynchronize(s->stream));
+  SS_HIP(hipDeviceSynchronize());  // searches on the callers' own streams may still read the arrays an append replaces
   const uint32_t first = s->bm_n_terms / std::max<uint32_t>(s->bm_n_fields, 1) + s->sp_n;
   SS_TRY(ssi_bm25_append_sparse_fields(s, n_lists, offs, docs, fields, tfs));
   if (first_term_id_out) *first_term_id_out = first;
@@ -733,7 +734,7 @@ int ss_bm25_append_sparse_positions(ss_shard* s, uint32_t n_lists, const uint64_
   static const uint16_t none = 0;
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
-  SS_HIP(hipStreamSynchronize(s->stream));
+  SS_HIP(hipDeviceSynchronize());  // searches on the callers' own streams may still read the arrays an append replaces
   const uint32_t first = s->bm_n_terms + s->sp_n;
   SS_TRY(ssi_bm25_append_sparse(s, n_lists, offs, docs, tfs, positions ? positions : &none, n_positions, npos));
   if (first_term_id_out) *first_term_id_out = first;
@@ -746,7 +747,7 @@ int ss_bm25_append_sparse_fields_positions(ss_shard* s, uint32_t n_lists, const 
   static const uint16_t none = 0;
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
-  SS_HIP(hipStreamSynchronize(s->stream));
+  SS_HIP(hipDeviceSynchronize());  // searches on the callers' own streams may still read the arrays an append replaces
   const uint32_t first = s->bm_n_terms / std::max<uint32_t>(s->bm_n_fields, 1) + s->sp_n;
   SS_TRY(ssi_bm25_append_sparse_fields(s, n_lists, offs, docs, fields, tfs, positions ? positions : &none, n_positions, npos));
   if (first_term_id_out) *first_term_id_out = first;
