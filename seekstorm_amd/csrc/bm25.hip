@@ -255,10 +255,11 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
 // ---------------------------------------------------------------- host side
 // The match set of ONE query as a bitmap over the docs (bit d of word d / 64), from the probe index's bit records: what
 // facet counting walks (facet.hip).  The caller has checked that every list of the query has a probe row.
-int ssi_bm25_match_bits(ss_shard* s, const ss_bm25_query* d_q, unsigned long long* d_bits, unsigned long long* d_total, hipStream_t st) {
+int ssi_bm25_match_bits(ss_shard* s, const ss_bm25_query* d_q, unsigned long long* d_bits, unsigned long long* d_total, hipStream_t st, uint32_t nq) {
   if (!s->d_post || !s->d_probe) return SS_ESTATE;
+  if (nq == 0 || nq > 64) return SS_EINVAL;
   ss_bm_ws& W = s->bm_ws[st];
-  if (sizeof(bm_vquery) > W.vq_cap) {
+  if (64 * sizeof(bm_vquery) > W.vq_cap) {
     SS_HIP(hipStreamSynchronize(st));
     if (W.d_vq) (void)hipFree(W.d_vq);
     W.d_vq = nullptr; W.vq_cap = 0;
@@ -266,7 +267,7 @@ int ssi_bm25_match_bits(ss_shard* s, const ss_bm25_query* d_q, unsigned long lon
     W.vq_cap = 64 * sizeof(bm_vquery);
   }
   uint32_t* tau = (uint32_t*)(d_bits);  // the expansion zeroes one threshold line per query: scratch, overwritten below
-  bm_expand_kernel<<<1, 128, 0, st>>>(d_q, (bm_vquery*)W.d_vq, 1, s->bm_n_fields, (const unsigned long long*)s->d_term_base,
+  bm_expand_kernel<<<1, 128, 0, st>>>(d_q, (bm_vquery*)W.d_vq, nq, s->bm_n_fields, (const unsigned long long*)s->d_term_base,
                                       s->d_boost, d_total, tau, BM_CLAIM_AND | BM_CLAIM_OR | BM_CLAIM_FREQ | BM_CLAIM_FILTER | (0xFFu << 8) | (0xFEu << 16),
                                       s->bm_n_terms, nullptr, s->bm_merged ? 1u : 0u);  // the host entry point validated the query
   BmParams p{};
@@ -275,7 +276,7 @@ int ssi_bm25_match_bits(ss_shard* s, const ss_bm25_query* d_q, unsigned long lon
   p.del = s->n_deleted ? s->d_deleted : nullptr;
   p.del_words = (uint32_t)s->deleted_words;
   p.n_sub = s->bm_n_sub;
-  p.nq = 1;
+  p.nq = nq;  // (nq > 1: d_bits holds nq match sets back to back, d_total nq counts)
   int rc = ssi_bm25_launch_union_count(p, s->d_probe, s->d_probe_row, true, st, d_bits);
   SS_HIP(hipGetLastError());
   return rc;
@@ -397,6 +398,10 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   p.tau = tau;
   p.del = s->n_deleted ? s->d_deleted : nullptr;
   p.del_words = (uint32_t)s->deleted_words;
+  if (s->del_per_query) {  // one exclusion bitmap per query (ss_bm25_search_sorted): the pruned kernel's filtered instances read them
+    if (!pruned || phrase || want_counts || !p.del || (p.del_words >> 31)) return SS_ENOTSUP;
+    p.del_words |= 0x80000000u;
+  }
   p.n_sub = s->bm_n_sub;
   p.n_terms = s->bm_n_terms;
   p.nq = nq;

@@ -86,6 +86,9 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
   const uint32_t a = blockIdx.x * PB_WAVES + w;
   if (a >= nq * P) return;
   const uint32_t qi = a % nq, part = a / nq;
+  // del_words bit 31: ONE exclusion bitmap PER QUERY, del_words words each, back to back (ss_bm25_search_sorted: every query of the
+  // batch is searched inside its own doc set)
+  if (FILT && (del_words >> 31)) { del_words &= 0x7FFFFFFFu; del += (size_t)qi * del_words; }
   const bm_vquery* __restrict__ Q = qs + qi;
   const uint32_t nt = Q->n_terms, n_not = FILT ? bm_q_nnot(Q->op) : 0u;  // NT covers the query terms; NOT terms are probed at the end
   const bool is_and = (bm_q_op(Q->op) == SS_OP_INTERSECTION) && nt > 1;
@@ -451,7 +454,7 @@ constexpr int CNT_WAVES = 4, CNT_UNROLL = 4;
 __global__ void __launch_bounds__(CNT_WAVES * 64) bm25_union_count_kernel(
     const uint2* __restrict__ probe, const uint32_t* __restrict__ probe_row, const bm_vquery* __restrict__ qs,
     unsigned long long* __restrict__ total, const uint32_t* __restrict__ del, uint32_t del_words, uint32_t n_sub, uint32_t nq,
-    uint32_t P, uint32_t all_queries, unsigned long long* __restrict__ match_bits /* nq = 1: the match set itself, or null */) {
+    uint32_t P, uint32_t all_queries, unsigned long long* __restrict__ match_bits /* the match sets themselves ([nq][groups]), or null */) {
   const int lane = threadIdx.x & 63;
   const uint32_t a = blockIdx.x * CNT_WAVES + (threadIdx.x >> 6);
   if (a >= nq * P) return;
@@ -461,6 +464,7 @@ __global__ void __launch_bounds__(CNT_WAVES * 64) bm25_union_count_kernel(
   const bool is_and = Q->and_target != 0u;
   if (!all_queries && (is_and || np < 2)) return;
   const uint32_t n_groups = n_sub * (BM_SUB / 64);
+  if (match_bits) match_bits += (size_t)qi * n_groups;
   const uint32_t g_begin = (uint32_t)(((u64)n_groups * part) / P), g_end = (uint32_t)(((u64)n_groups * (part + 1)) / P);
   // bit rows of the first lists, resolved once (term -> probe row -> address): the loop below then issues plain loads
   constexpr int CNT_FAST = 8;

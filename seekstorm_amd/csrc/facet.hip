@@ -412,40 +412,64 @@ struct SortFieldsDev {
   FacetPoint pt[SS_MAX_SORT_FIELDS];
 };
 
+// (every kernel below: blockIdx.y / blockIdx.x of the one-block kernels = the query of the batch; bit sets [nq][groups], states [nq],
+// histograms [nq][256])
 __global__ void sort_begin_kernel(SortState* st, const unsigned long long* total, unsigned long long k) {
-  if (threadIdx.x == 0) { st->count_e = *total; st->k_left = k; st->better_total = 0ull; }
+  st += blockIdx.x;
+  if (threadIdx.x == 0) { st->count_e = total[blockIdx.x]; st->k_left = k; st->better_total = 0ull; }
 }
 __global__ void sort_level_begin_kernel(SortState* st, unsigned long long* hist) {
-  hist[threadIdx.x & 255u] = 0ull;
+  st += blockIdx.x;
+  hist[(size_t)blockIdx.x * 256u + (threadIdx.x & 255u)] = 0ull;
   if (threadIdx.x == 0) { st->want = st->k_left < st->count_e ? st->k_left : st->count_e; st->prefix = 0ull; st->n_better = 0ull; st->n_equal = 0ull; }
 }
-__global__ void sort_radix_kernel(const unsigned long long* __restrict__ bits, unsigned long long n_docs, const uint8_t* __restrict__ records,
-                                  uint32_t record_size, uint32_t offset, uint32_t type, uint32_t key_bits, uint32_t descending,
-                                  const SortState* __restrict__ st, uint32_t byte_index, unsigned long long* __restrict__ hist, FacetPoint pt) {
+// One byte of the select: the histogram of byte `byte_index` over the docs of E that share the prefix decided so far -- and, on the way,
+// the classification by that prefix: a doc above it moves to B, a doc below it leaves E.  E thus shrinks 256-fold per byte, and only
+// the first two passes of a field touch every match (each doc's record is a scattered read: they are what a sort by a wide field costs).
+__global__ void sort_radix_kernel(unsigned long long* __restrict__ bits, unsigned long long* __restrict__ B, unsigned long long n_docs,
+                                  unsigned long long groups, const uint8_t* __restrict__ records, uint32_t record_size, uint32_t offset,
+                                  uint32_t type, uint32_t key_bits, uint32_t descending, const SortState* __restrict__ st, uint32_t byte_index,
+                                  unsigned long long* __restrict__ hist, FacetPoint pt) {
   __shared__ unsigned int h[256];
+  st += blockIdx.y;
   if (st->want == 0ull) return;
+  bits += (size_t)blockIdx.y * groups;
+  B += (size_t)blockIdx.y * groups;
+  hist += (size_t)blockIdx.y * 256u;
   const unsigned long long prefix = st->prefix;
   h[threadIdx.x & 255u] = 0u;
   __syncthreads();
   const unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (g * 64ull < n_docs) {
-    unsigned long long m = bits[g];
+    const unsigned long long m0 = bits[g];
+    unsigned long long m = m0, keep = m0, better = 0ull;
     const uint32_t shift = key_bits - 8u * (byte_index + 1u);
     while (m) {
-      const unsigned long long d = g * 64ull + (unsigned long long)__builtin_ctzll(m);
+      const int b = __builtin_ctzll(m);
+      const unsigned long long d = g * 64ull + (unsigned long long)b;
       m &= m - 1;
       if (d >= n_docs) break;
       uint32_t ty = type;
       const unsigned long long v = facet_load(records + d * record_size + offset, key_bits / 8u, ty, pt);
       const unsigned long long k = facet_order_key(v, ty, key_bits, descending != 0u);
-      if (byte_index == 0u || (k >> (shift + 8u)) == prefix) atomicAdd(&h[(k >> shift) & 255u], 1u);
+      if (byte_index == 0u) {
+        atomicAdd(&h[(k >> shift) & 255u], 1u);
+      } else {
+        const unsigned long long kp = k >> (shift + 8u);
+        if (kp == prefix) atomicAdd(&h[(k >> shift) & 255u], 1u);
+        else { keep &= ~(1ull << b); if (kp > prefix) better |= 1ull << b; }
+      }
     }
+    if (keep != m0) bits[g] = keep;
+    if (better) B[g] |= better;
   }
   __syncthreads();
   if (h[threadIdx.x & 255u]) atomicAdd(&hist[threadIdx.x & 255u], (unsigned long long)h[threadIdx.x & 255u]);
 }
 // one byte decided: from the best byte value down to the bucket that holds the wanted rank (ssi_facet_kth's host loop)
 __global__ void sort_decide_kernel(SortState* st, unsigned long long* hist) {
+  st += blockIdx.x;
+  hist += (size_t)blockIdx.x * 256u;
   if (threadIdx.x == 0) {
     unsigned long long want = st->want, nb = st->n_better;
     int v = 255;
@@ -465,10 +489,13 @@ __global__ void sort_decide_kernel(SortState* st, unsigned long long* hist) {
 }
 // E: docs equal to the pivot stay; strictly better ones move to B; worse ones leave
 __global__ void sort_classify_kernel(unsigned long long* __restrict__ E, unsigned long long* __restrict__ B, unsigned long long n_docs,
-                                     const uint8_t* __restrict__ records, uint32_t record_size, uint32_t offset, uint32_t type, uint32_t key_bits,
-                                     uint32_t descending, const SortState* __restrict__ st, FacetPoint pt) {
+                                     unsigned long long groups, const uint8_t* __restrict__ records, uint32_t record_size, uint32_t offset,
+                                     uint32_t type, uint32_t key_bits, uint32_t descending, const SortState* __restrict__ st, FacetPoint pt) {
   const unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (g * 64ull >= n_docs) return;
+  st += blockIdx.y;
+  E += (size_t)blockIdx.y * groups;
+  B += (size_t)blockIdx.y * groups;
   const unsigned long long pivot = st->prefix;
   unsigned long long m = E[g], keep = 0ull, better = 0ull;
   while (m) {
@@ -486,15 +513,17 @@ __global__ void sort_classify_kernel(unsigned long long* __restrict__ E, unsigne
   if (better) B[g] |= better;
 }
 __global__ void sort_level_end_kernel(SortState* st) {
+  st += blockIdx.x;
   if (threadIdx.x == 0) { st->k_left -= st->n_better; st->count_e = st->n_equal; st->better_total += st->n_better; }
 }
 __global__ void sort_excl_kernel(const unsigned long long* __restrict__ E, const unsigned long long* __restrict__ B,
                                  unsigned long long* __restrict__ ex_b, unsigned long long* __restrict__ ex_e, unsigned long long groups) {
   const unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g < groups) { ex_b[g] = ~B[g]; ex_e[g] = ~E[g]; }
+  const size_t o = (size_t)blockIdx.y * groups + g;
+  if (g < groups) { ex_b[o] = ~B[o]; ex_e[o] = ~E[o]; }
 }
-// the answer of one query: list A (the docs of B with their scores, any order) ordered by (sort keys, score desc, doc asc), then the
-// first k - |A| of list C (the tie group of the last pivot, by score)
+// the answer of one query (blockIdx.x): list A (the docs of B with their scores, any order) ordered by (sort keys, score desc, doc asc),
+// then the first k - |A| of list C (the tie group of the last pivot, by score)
 __global__ void __launch_bounds__(1024) sort_compose_kernel(const uint32_t* __restrict__ a_doc, const float* __restrict__ a_score,
                                                             const uint32_t* __restrict__ a_cnt, const uint32_t* __restrict__ c_doc,
                                                             const float* __restrict__ c_score, const uint32_t* __restrict__ c_cnt,
@@ -506,9 +535,11 @@ __global__ void __launch_bounds__(1024) sort_compose_kernel(const uint32_t* __re
   __shared__ float sc[1024];
   __shared__ uint32_t dc[1024];
   __shared__ uint16_t perm[1024];
-  const uint32_t i = threadIdx.x;
-  const uint32_t na = min(*a_cnt == 0xFFFFFFFFu ? 0u : *a_cnt, k);
-  const uint32_t nc = min(*c_cnt == 0xFFFFFFFFu ? 0u : *c_cnt, k - na);
+  const uint32_t i = threadIdx.x, q = blockIdx.x;
+  a_doc += (size_t)q * k; a_score += (size_t)q * k; c_doc += (size_t)q * k; c_score += (size_t)q * k;
+  out_doc += (size_t)q * k; out_score += (size_t)q * k;
+  const uint32_t na = min(a_cnt[q] == 0xFFFFFFFFu ? 0u : a_cnt[q], k);
+  const uint32_t nc = min(c_cnt[q] == 0xFFFFFFFFu ? 0u : c_cnt[q], k - na);
   perm[i] = (uint16_t)i;
   dc[i] = i < na ? a_doc[i] : 0xFFFFFFFFu;
   sc[i] = i < na ? a_score[i] : -INFINITY;
@@ -544,19 +575,20 @@ __global__ void __launch_bounds__(1024) sort_compose_kernel(const uint32_t* __re
   if (i < na) { out_doc[i] = dc[perm[i]]; out_score[i] = sc[perm[i]]; }
   else if (i < na + nc) { out_doc[i] = c_doc[i - na]; out_score[i] = c_score[i - na]; }
   else if (i < k) { out_doc[i] = 0xFFFFFFFFu; out_score[i] = 0.f; }
-  if (i == 0) { *out_count = na + nc; *out_total = *total; }
+  if (i == 0) { out_count[q] = na + nc; out_total[q] = total[q]; }
 }
 
-// the device chain of ONE query up to the two exclusion bitmaps (the caller then runs the two searches and ssi_sort_compose)
-int ssi_sort_select(ss_shard* s, unsigned long long* d_E, unsigned long long* d_B, unsigned long long* d_ex_b, unsigned long long* d_ex_e,
+// the device chain of nq queries up to the exclusion bitmaps (the caller then runs the two searches and ssi_sort_compose);
+// bit sets [nq][groups], d_total / d_state [nq], d_hist [nq][256]
+int ssi_sort_select(ss_shard* s, uint32_t nq, unsigned long long* d_E, unsigned long long* d_B, unsigned long long* d_ex_b, unsigned long long* d_ex_e,
                     const unsigned long long* d_total, unsigned long long* d_hist, void* d_state, uint32_t n_sorts, const ss_result_sort* sorts,
                     uint32_t k, hipStream_t st) {
   static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 0, 0, 8};
   const unsigned long long n_docs = s->bm_n_docs, groups = (unsigned long long)s->bm_n_sub * (BM_SUB / 64);
-  const unsigned grid = (unsigned)((groups + 255) / 256);
+  const dim3 grid((unsigned)((groups + 255) / 256), nq);
   SortState* state = (SortState*)d_state;
-  SS_HIP(hipMemsetAsync(d_B, 0, groups * 8, st));
-  sort_begin_kernel<<<1, 64, 0, st>>>(state, d_total, (unsigned long long)k);
+  SS_HIP(hipMemsetAsync(d_B, 0, (size_t)nq * groups * 8, st));
+  sort_begin_kernel<<<nq, 64, 0, st>>>(state, d_total, (unsigned long long)k);
   for (uint32_t f = 0; f < n_sorts; f++) {
     const uint32_t type = sorts[f].facet_type;
     FacetPoint pt{0, 0, 0};
@@ -565,23 +597,24 @@ int ssi_sort_select(ss_shard* s, unsigned long long* d_E, unsigned long long* d_
       if (facet_point_of(&base, &pt) != SS_OK) return SS_EINVAL;
     }
     const uint32_t key_bits = 8u * width[type];
-    sort_level_begin_kernel<<<1, 256, 0, st>>>(state, d_hist);
+    sort_level_begin_kernel<<<nq, 256, 0, st>>>(state, d_hist);
     for (uint32_t b = 0; b < key_bits / 8u; b++) {
-      sort_radix_kernel<<<grid, 256, 0, st>>>(d_E, n_docs, s->d_facets, s->facet_record_size, sorts[f].facet_offset, type, key_bits,
+      sort_radix_kernel<<<grid, 256, 0, st>>>(d_E, d_B, n_docs, groups, s->d_facets, s->facet_record_size, sorts[f].facet_offset, type, key_bits,
                                               sorts[f].descending ? 1u : 0u, state, b, d_hist, pt);
-      sort_decide_kernel<<<1, 256, 0, st>>>(state, d_hist);
+      sort_decide_kernel<<<nq, 256, 0, st>>>(state, d_hist);
     }
-    sort_classify_kernel<<<grid, 256, 0, st>>>(d_E, d_B, n_docs, s->d_facets, s->facet_record_size, sorts[f].facet_offset, type, key_bits,
+    sort_classify_kernel<<<grid, 256, 0, st>>>(d_E, d_B, n_docs, groups, s->d_facets, s->facet_record_size, sorts[f].facet_offset, type, key_bits,
                                                sorts[f].descending ? 1u : 0u, state, pt);
-    sort_level_end_kernel<<<1, 64, 0, st>>>(state);
+    sort_level_end_kernel<<<nq, 64, 0, st>>>(state);
   }
   sort_excl_kernel<<<grid, 256, 0, st>>>(d_E, d_B, d_ex_b, d_ex_e, groups);
   SS_HIP(hipGetLastError());
   return SS_OK;
 }
-int ssi_sort_compose(ss_shard* s, const uint32_t* a_doc, const float* a_score, const uint32_t* a_cnt, const uint32_t* c_doc, const float* c_score,
-                     const uint32_t* c_cnt, const unsigned long long* d_total, uint32_t n_sorts, const ss_result_sort* sorts, uint32_t k,
-                     uint32_t* out_doc, float* out_score, uint32_t* out_count, unsigned long long* out_total, hipStream_t st) {
+// lists [nq][k], counts / totals / outputs per query
+int ssi_sort_compose(ss_shard* s, uint32_t nq, const uint32_t* a_doc, const float* a_score, const uint32_t* a_cnt, const uint32_t* c_doc,
+                     const float* c_score, const uint32_t* c_cnt, const unsigned long long* d_total, uint32_t n_sorts, const ss_result_sort* sorts,
+                     uint32_t k, uint32_t* out_doc, float* out_score, uint32_t* out_count, unsigned long long* out_total, hipStream_t st) {
   static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 0, 0, 8};
   SortFieldsDev F;
   memset(&F, 0, sizeof(F));
@@ -593,8 +626,8 @@ int ssi_sort_compose(ss_shard* s, const uint32_t* a_doc, const float* a_score, c
       if (facet_point_of(&base, &F.pt[f]) != SS_OK) return SS_EINVAL;
     }
   }
-  sort_compose_kernel<<<1, 1024, 0, st>>>(a_doc, a_score, a_cnt, c_doc, c_score, c_cnt, d_total, s->d_facets, s->facet_record_size,
-                                          (unsigned long long)s->facet_docs, F, k, out_doc, out_score, out_count, out_total);
+  sort_compose_kernel<<<nq, 1024, 0, st>>>(a_doc, a_score, a_cnt, c_doc, c_score, c_cnt, d_total, s->d_facets, s->facet_record_size,
+                                           (unsigned long long)s->facet_docs, F, k, out_doc, out_score, out_count, out_total);
   SS_HIP(hipGetLastError());
   return SS_OK;
 }

@@ -1796,9 +1796,11 @@ int ss_bm25_facet_kth_point(ss_shard* s, const ss_bm25_query* query, uint32_t n_
   return facet_kth_impl(s, query, n_filters, filters, facet_offset, SS_FACET_POINT, base, descending, k, out_value, out_n_better, out_n_equal, out_total);
 }
 
-// Result sort for a batch (facet.hip: "Result sort for a BATCH, pivots on the device").  Per query, everything queued on the shard's
-// stream: match bits -> radix selects + classification of every sort field -> the two exclusion bitmaps -> two searches under them
-// -> compose into the query's output row; one synchronisation at the end of the call.
+// Result sort for a batch (facet.hip: "Result sort for a BATCH, pivots on the device").  The batch runs in chunks of <= 64 queries,
+// every step a grid over the chunk: match sets (one expansion + one bit-record pass) -> per sort field the radix select and the
+// classification -> the exclusion bitmaps -> TWO batched searches, each query inside its own doc set (the pruned kernel's filtered
+// instances take one bitmap per query) -> compose into the queries' output rows.  One synchronisation per call.  A chunk the pruned
+// kernel does not serve (k > 128, more than 4 lists per query, the exhaustive strategy) runs its searches query by query instead.
 int ss_bm25_search_sorted(ss_shard* s, uint32_t nq, const ss_bm25_query* queries, uint32_t n_sorts, const ss_result_sort* sorts, uint32_t k,
                           uint32_t n_filters, const ss_facet_filter* filters, uint32_t* out_doc, float* out_score, uint32_t* out_count,
                           uint64_t* out_total) {
@@ -1818,12 +1820,15 @@ int ss_bm25_search_sorted(ss_shard* s, uint32_t nq, const ss_bm25_query* queries
   for (uint32_t f = 0; f < n_sorts; f++)
     if (sorts[f].facet_offset + width[sorts[f].facet_type] > s->facet_record_size) return SS_ESTATE;
   const uint64_t groups = (uint64_t)s->bm_n_sub * (BM_SUB / 64);
+  const uint32_t CH = std::min<uint32_t>(nq, 64u);
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  const size_t o_q = 0, o_tot = o_q + al(sizeof(ss_bm25_query)), o_state = o_tot + 256, o_hist = o_state + 256, o_E = o_hist + 256 * 8,
-               o_B = o_E + al(groups * 8), o_xb = o_B + al(groups * 8), o_xe = o_xb + al(groups * 8), o_ad = o_xe + al(groups * 8),
-               o_as = o_ad + al((size_t)k * 4), o_ac = o_as + al((size_t)k * 4), o_cd = o_ac + 256, o_cs = o_cd + al((size_t)k * 4),
-               o_cc = o_cs + al((size_t)k * 4), o_od = o_cc + 256, o_os = o_od + al((size_t)nq * k * 4), o_oc = o_os + al((size_t)nq * k * 4),
-               o_ot = o_oc + al((size_t)nq * 4), need = o_ot + al((size_t)nq * 8);
+  const size_t o_q = 0, o_tot = o_q + al((size_t)CH * sizeof(ss_bm25_query)), o_state = o_tot + al((size_t)CH * 8), o_hist = o_state + al((size_t)CH * 64),
+               o_E = o_hist + al((size_t)CH * 256 * 8), o_B = o_E + al((size_t)CH * groups * 8), o_xb = o_B + al((size_t)CH * groups * 8),
+               o_xe = o_xb + al((size_t)CH * groups * 8), o_ad = o_xe + al((size_t)CH * groups * 8), o_as = o_ad + al((size_t)CH * k * 4),
+               o_ac = o_as + al((size_t)CH * k * 4), o_cd = o_ac + al((size_t)CH * 4), o_cs = o_cd + al((size_t)CH * k * 4),
+               o_cc = o_cs + al((size_t)CH * k * 4), o_at = o_cc + al((size_t)CH * 4), o_od = o_at + al((size_t)CH * 8),
+               o_os = o_od + al((size_t)nq * k * 4), o_oc = o_os + al((size_t)nq * k * 4), o_ot = o_oc + al((size_t)nq * 4),
+               need = o_ot + al((size_t)nq * 8);
   if (need > s->sort_ws_cap) {
     SS_HIP(hipStreamSynchronize(s->stream));
     if (s->d_sort_ws) (void)hipFree(s->d_sort_ws);
@@ -1837,31 +1842,47 @@ int ss_bm25_search_sorted(ss_shard* s, uint32_t nq, const ss_bm25_query* queries
   unsigned long long *d_E = (unsigned long long*)(W + o_E), *d_B = (unsigned long long*)(W + o_B), *d_xb = (unsigned long long*)(W + o_xb),
                      *d_xe = (unsigned long long*)(W + o_xe);
   SS_TRY(ensure_out(s, 1, k));
-  for (uint32_t i = 0; i < nq; i++) {
-    bool has_and, has_or, all_probed, any_frequent, phrase = false;
-    uint32_t nt_max, np_max;
-    SS_TRY(ssi_bm25_ensure_probe_rows(s, 1, queries + i, s->stream));
-    SS_TRY(check_queries(s, 1, queries + i, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent, &phrase));
+  static const int batched_off = [] { const char* e = getenv("SS_SORT_BATCHED"); return e ? atoi(e) == 0 : 0; }();
+  for (uint32_t c0 = 0; c0 < nq; c0 += CH) {
+    const uint32_t nb = std::min<uint32_t>(CH, nq - c0);
+    const ss_bm25_query* qc = queries + c0;
+    bool has_and, has_or, all_probed, any_frequent, phrase = false, any_filter = false, uniform = false, gated = false;
+    uint32_t nt_max, np_max, nn_max = 0;
+    SS_TRY(ssi_bm25_ensure_probe_rows(s, nb, qc, s->stream));
+    SS_TRY(check_queries(s, nb, qc, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent, &phrase, &any_filter, &uniform, &gated, &nn_max));
     if (!all_probed || !s->d_probe || phrase) return SS_ENOTSUP;
-    SS_HIP(hipMemcpyAsync(d_q, queries + i, sizeof(ss_bm25_query), hipMemcpyHostToDevice, s->stream));
-    SS_HIP(hipMemsetAsync(d_total, 0, 8, s->stream));
-    SS_HIP(hipMemsetAsync(d_E, 0, groups * 8, s->stream));
-    SS_TRY(with_facet_filter(s, n_filters, filters, s->stream, [&]() { return ssi_bm25_match_bits(s, d_q, d_E, d_total, s->stream); }));
-    SS_TRY(ssi_sort_select(s, d_E, d_B, d_xb, d_xe, d_total, (unsigned long long*)(W + o_hist), W + o_state, n_sorts, sorts, k, s->stream));
-    for (int part = 0; part < 2; part++) {  // the docs that are in for sure, then the last pivot's tie group -- by score, under their bitmaps
+    SS_HIP(hipMemcpyAsync(d_q, qc, (size_t)nb * sizeof(ss_bm25_query), hipMemcpyHostToDevice, s->stream));
+    SS_TRY(with_facet_filter(s, n_filters, filters, s->stream, [&]() { return ssi_bm25_match_bits(s, d_q, d_E, d_total, s->stream, nb); }));
+    SS_TRY(ssi_sort_select(s, nb, d_E, d_B, d_xb, d_xe, d_total, (unsigned long long*)(W + o_hist), W + o_state, n_sorts, sorts, k, s->stream));
+    bool batched = !batched_off;
+    for (int part = 0; part < 2 && batched; part++) {  // both searches as ONE batch each: every query under its own exclusion bitmap
       uint32_t* del = s->d_deleted;
       const uint64_t dw = s->deleted_words, nd = s->n_deleted;
-      s->d_deleted = (uint32_t*)(part == 0 ? d_xb : d_xe); s->deleted_words = groups * 2; s->n_deleted = 1;
-      const int rc = bm25_search_host_queries(s, 1, queries + i, k, SS_RT_TOPK, 0, nullptr);
-      s->d_deleted = del; s->deleted_words = dw; s->n_deleted = nd;
-      if (rc != SS_OK) return rc;
-      SS_HIP(hipMemcpyAsync(W + (part == 0 ? o_ad : o_cd), s->d_out_doc, (size_t)k * 4, hipMemcpyDeviceToDevice, s->stream));
-      SS_HIP(hipMemcpyAsync(W + (part == 0 ? o_as : o_cs), s->d_out_score, (size_t)k * 4, hipMemcpyDeviceToDevice, s->stream));
-      SS_HIP(hipMemcpyAsync(W + (part == 0 ? o_ac : o_cc), s->d_out_count, 4, hipMemcpyDeviceToDevice, s->stream));
+      s->d_deleted = (uint32_t*)(part == 0 ? d_xb : d_xe); s->deleted_words = groups * 2; s->n_deleted = 1; s->del_per_query = 1;
+      const int rc = ssi_bm25_search(s, nb, d_q, k, SS_RT_TOPK, (uint32_t*)(W + (part == 0 ? o_ad : o_cd)), (float*)(W + (part == 0 ? o_as : o_cs)),
+                                     (uint32_t*)(W + (part == 0 ? o_ac : o_cc)), (uint64_t*)(W + o_at), has_and, has_or, nt_max, np_max, all_probed,
+                                     s->stream, any_frequent, false, any_filter, uniform, gated, nn_max);
+      s->d_deleted = del; s->deleted_words = dw; s->n_deleted = nd; s->del_per_query = 0;
+      if (rc == SS_ENOTSUP && part == 0) batched = false;  // not the pruned kernel's batch: query by query below
+      else if (rc != SS_OK) return rc;
     }
-    SS_TRY(ssi_sort_compose(s, (const uint32_t*)(W + o_ad), (const float*)(W + o_as), (const uint32_t*)(W + o_ac), (const uint32_t*)(W + o_cd),
-                            (const float*)(W + o_cs), (const uint32_t*)(W + o_cc), d_total, n_sorts, sorts, k, (uint32_t*)(W + o_od) + (size_t)i * k,
-                            (float*)(W + o_os) + (size_t)i * k, (uint32_t*)(W + o_oc) + i, (unsigned long long*)(W + o_ot) + i, s->stream));
+    if (!batched) {
+      for (uint32_t i = 0; i < nb; i++)
+        for (int part = 0; part < 2; part++) {
+          uint32_t* del = s->d_deleted;
+          const uint64_t dw = s->deleted_words, nd = s->n_deleted;
+          s->d_deleted = (uint32_t*)((part == 0 ? d_xb : d_xe) + (size_t)i * groups); s->deleted_words = groups * 2; s->n_deleted = 1;
+          const int rc = bm25_search_host_queries(s, 1, qc + i, k, SS_RT_TOPK, 0, nullptr);
+          s->d_deleted = del; s->deleted_words = dw; s->n_deleted = nd;
+          if (rc != SS_OK) return rc;
+          SS_HIP(hipMemcpyAsync(W + (part == 0 ? o_ad : o_cd) + (size_t)i * k * 4, s->d_out_doc, (size_t)k * 4, hipMemcpyDeviceToDevice, s->stream));
+          SS_HIP(hipMemcpyAsync(W + (part == 0 ? o_as : o_cs) + (size_t)i * k * 4, s->d_out_score, (size_t)k * 4, hipMemcpyDeviceToDevice, s->stream));
+          SS_HIP(hipMemcpyAsync(W + (part == 0 ? o_ac : o_cc) + (size_t)i * 4, s->d_out_count, 4, hipMemcpyDeviceToDevice, s->stream));
+        }
+    }
+    SS_TRY(ssi_sort_compose(s, nb, (const uint32_t*)(W + o_ad), (const float*)(W + o_as), (const uint32_t*)(W + o_ac), (const uint32_t*)(W + o_cd),
+                            (const float*)(W + o_cs), (const uint32_t*)(W + o_cc), d_total, n_sorts, sorts, k, (uint32_t*)(W + o_od) + (size_t)c0 * k,
+                            (float*)(W + o_os) + (size_t)c0 * k, (uint32_t*)(W + o_oc) + c0, (unsigned long long*)(W + o_ot) + c0, s->stream));
   }
   SS_HIP(hipMemcpyAsync(out_doc, W + o_od, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s->stream));
   SS_HIP(hipMemcpyAsync(out_score, W + o_os, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s->stream));

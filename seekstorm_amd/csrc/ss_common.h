@@ -342,6 +342,7 @@ struct ss_shard {
   std::vector<uint64_t> h_sp_base;   // host copy of d_sp_base (posting counts = the df the host needs for idf)
   void* d_tier_ws = nullptr;         // workspace of a tiered search (sub-queries, row maps, sparse lists, merged answers), grow-only
   size_t tier_ws_cap = 0;
+  uint32_t del_per_query = 0;        // d_deleted holds one bitmap of deleted_words words PER QUERY of the batch in flight (ss_bm25_search_sorted)
   void* d_sort_ws = nullptr;         // workspace of ss_bm25_search_sorted, grow-only
   size_t sort_ws_cap = 0;
   void* d_tier_hold = nullptr;       // answers of the queries a tiered batch runs one by one (unions with a sparse NOT term), grow-only
@@ -396,7 +397,7 @@ struct VAnn;
 int ssi_vec8_qprep(ss_shard* s, const int8_t* d_queries, uint32_t nb, hipStream_t st);
 int ssi_vec8_launch_scan(ss_shard* s, uint32_t tile0, uint32_t ntiles, const float* d_qscale, const VAnn* ann, hipStream_t st);
 int ssi_vec8_qaux(ss_shard* s, const int8_t* d_queries, uint32_t nb, const float* d_qnorm, hipStream_t st);
-int ssi_bm25_match_bits(ss_shard* s, const ss_bm25_query* d_q, unsigned long long* d_bits, unsigned long long* d_total, hipStream_t st);
+int ssi_bm25_match_bits(ss_shard* s, const ss_bm25_query* d_q, unsigned long long* d_bits, unsigned long long* d_total, hipStream_t st, uint32_t nq = 1);
 // facet histogram over a match bitmap: d_counts [n_buckets + 1] (last = values outside the buckets)
 int ssi_facet_kth(ss_shard* s, const unsigned long long* d_bits, uint64_t n_docs, uint64_t n_matches, uint32_t offset, uint32_t type,
                   bool descending, uint64_t k, unsigned long long* d_hist, uint64_t* value_bits, uint64_t* n_better, uint64_t* n_equal,
@@ -406,12 +407,12 @@ int ssi_facet_count(ss_shard* s, const unsigned long long* d_bits, uint64_t n_do
                     const uint64_t* d_bounds, unsigned long long* d_counts, hipStream_t st);
 // ---- implemented in facet.hip: exclusion bitmap (failed facet filters | tombstones) into s->d_filter_bits
 int ssi_facet_build(ss_shard* s, uint32_t n_filters, const ss_facet_filter* filters, hipStream_t st);
-int ssi_sort_select(ss_shard* s, unsigned long long* d_E, unsigned long long* d_B, unsigned long long* d_ex_b, unsigned long long* d_ex_e,
+int ssi_sort_select(ss_shard* s, uint32_t nq, unsigned long long* d_E, unsigned long long* d_B, unsigned long long* d_ex_b, unsigned long long* d_ex_e,
                     const unsigned long long* d_total, unsigned long long* d_hist, void* d_state, uint32_t n_sorts, const ss_result_sort* sorts,
                     uint32_t k, hipStream_t st);
-int ssi_sort_compose(ss_shard* s, const uint32_t* a_doc, const float* a_score, const uint32_t* a_cnt, const uint32_t* c_doc, const float* c_score,
-                     const uint32_t* c_cnt, const unsigned long long* d_total, uint32_t n_sorts, const ss_result_sort* sorts, uint32_t k,
-                     uint32_t* out_doc, float* out_score, uint32_t* out_count, unsigned long long* out_total, hipStream_t st);
+int ssi_sort_compose(ss_shard* s, uint32_t nq, const uint32_t* a_doc, const float* a_score, const uint32_t* a_cnt, const uint32_t* c_doc,
+                     const float* c_score, const uint32_t* c_cnt, const unsigned long long* d_total, uint32_t n_sorts, const ss_result_sort* sorts,
+                     uint32_t k, uint32_t* out_doc, float* out_score, uint32_t* out_count, unsigned long long* out_total, hipStream_t st);
 // ---- implemented in vec_ann.hip
 // observed_vector_count (SS_ANN_REPORT_OBSERVED): live records per cluster once per call, then the triples of every batch
 int ssi_vec_observed_prepare(ss_shard* s, unsigned long long field_mask, hipStream_t st);
