@@ -263,6 +263,15 @@ uint32_t so_merge(int mode, const uint64_t* lex_doc, const float* lex_score, uin
 typedef struct so_text so_text;
 so_text* so_text_build(uint64_t seed, uint64_t n_docs, uint32_t vocab, uint32_t n_frequent, int ngrams /* NgramSet bits: 1 FF, 8 FFF */,
                        double topic_share, double mean_len);
+/* ... the docs' tokens cut into n_fields (<= 4) consecutive spans indexed as separate fields: positions restart in every field, n-grams
+ * stay inside one, the writer emits the multi-field records (field vectors, index_posting.rs:433-940) */
+so_text* so_text_build_fields(uint64_t seed, uint64_t n_docs, uint32_t vocab, uint32_t n_frequent, int ngrams, double topic_share, double mean_len,
+                              uint32_t n_fields, uint32_t longest_field_id);
+const uint8_t* so_text_doclen_fields(const so_text*);   /* [n_fields][n_docs] */
+uint32_t so_text_fields(const so_text*, uint32_t* longest_field);
+uint32_t so_text_doc_field_tokens(const so_text*, uint64_t doc, uint32_t field, uint32_t cap, uint32_t* out);
+uint64_t so_text_key_entries(const so_text*, uint32_t key, uint32_t component, uint32_t* docs, uint8_t* fields, uint16_t* tfs, uint16_t* counts,
+                             uint16_t* positions, uint64_t pos_cap, uint64_t* n_pos_out);
 void so_text_free(so_text*);
 void so_text_info(const so_text*, uint64_t* n_tokens, uint32_t* n_keys, uint32_t* n_keys_nonempty, uint64_t* n_postings, uint32_t* n_ngram_keys);
 const uint8_t* so_text_doclen(const so_text*);

@@ -48,7 +48,26 @@ struct so_text {
   uint64_t* p_pos;     /* [n_post + 1] first position */
   uint16_t* pos;       /* [sum] */
   uint32_t* term_df;   /* [vocab] */
+  /* several indexed fields (so_text_build_fields): a doc's tokens are cut into n_fields consecutive spans, positions restart in every
+   * field, an n-gram never crosses a field boundary */
+  uint32_t n_fields, longest_field;
+  uint8_t* fdoclen;    /* [n_fields][n_docs] int_to_byte4(tokens of the field); NULL with one field */
+  uint8_t* efld;       /* field of every entry of `pos` (NULL with one field) */
 };
+
+/* the span [a, b) (token indices) of field f of doc d: field 0 ("title") = the first max(1, L / 8) tokens, the last field ("tags") = the
+ * last max(1, L / 8), the fields between share the rest evenly (the first of them takes the remainder); L >= 4 */
+static void field_span(const so_text* T, uint64_t d, uint32_t f, uint32_t* a, uint32_t* b) {
+  const uint32_t a0 = T->doc_off[d], L = T->doc_off[d + 1] - a0, F = T->n_fields;
+  if (F == 1) { *a = a0; *b = a0 + L; return; }
+  const uint32_t n0 = L / 8 ? L / 8 : 1, nl = F > 2 ? (L / 8 ? L / 8 : 1) : 0, mid = L - n0 - nl, nm = F > 2 ? F - 2 : 1;
+  if (f == 0) { *a = a0; *b = a0 + n0; return; }
+  if (F == 2) { *a = a0 + n0; *b = a0 + L; return; }
+  if (f == F - 1) { *a = a0 + L - nl; *b = a0 + L; return; }
+  const uint32_t each = mid / nm, extra = mid - each * nm, j = f - 1;  /* middle field j of nm */
+  *a = a0 + n0 + j * each + (j ? extra : 0);
+  *b = *a + each + (j == 0 ? extra : 0);
+}
 
 static uint64_t key_hash_of(uint64_t seed, uint32_t n, const uint32_t* c) {
   uint64_t h = so_h(seed ^ 0x6B65795F68617368ull, c[0] + 1u, n);
@@ -63,14 +82,18 @@ static uint64_t ng_pack(uint32_t n, const uint32_t* c) { return ((uint64_t)n << 
 void so_text_free(so_text* t) {
   if (!t) return;
   free(t->doc_off); free(t->tok); free(t->doclen); free(t->ncomp); free(t->comp); free(t->key_hash); free(t->key_off);
-  free(t->p_doc); free(t->p_pos); free(t->pos); free(t->term_df); free(t);
+  free(t->p_doc); free(t->p_pos); free(t->pos); free(t->term_df); free(t->fdoclen); free(t->efld); free(t);
 }
 
 /* n_frequent < 2^20 (ranks packed in 20 bits for the n-gram table); ngrams: bit 0 = NgramFF, bit 3 = NgramFFF (NgramSet, index.rs:1840-1850) */
 so_text* so_text_build(uint64_t seed, uint64_t n_docs, uint32_t vocab, uint32_t n_frequent, int ngrams, double topic_share, double mean_len) {
-  if (n_docs == 0 || n_docs > 0xFFFFFFFFull || vocab < 64 || n_frequent >= (1u << 20)) return NULL;
+  return so_text_build_fields(seed, n_docs, vocab, n_frequent, ngrams, topic_share, mean_len, 1, 0);
+}
+so_text* so_text_build_fields(uint64_t seed, uint64_t n_docs, uint32_t vocab, uint32_t n_frequent, int ngrams, double topic_share, double mean_len,
+                              uint32_t n_fields, uint32_t longest_field) {
+  if (n_docs == 0 || n_docs > 0xFFFFFFFFull || vocab < 64 || n_frequent >= (1u << 20) || n_fields == 0 || n_fields > 4 || longest_field >= n_fields) return NULL;
   so_text* T = (so_text*)calloc(1, sizeof(so_text));
-  T->seed = seed; T->n_docs = n_docs; T->vocab = vocab; T->n_freq = n_frequent;
+  T->seed = seed; T->n_docs = n_docs; T->vocab = vocab; T->n_freq = n_frequent; T->n_fields = n_fields; T->longest_field = longest_field;
   T->doc_off = (uint32_t*)malloc((n_docs + 1) * sizeof(uint32_t));
   T->doclen = (uint8_t*)malloc(n_docs);
   /* lengths: clamp(round(exp(ln mean_len + 0.55 z)), 4, 1500), z ~ N(0,1) by Box-Muller on two hash words */
@@ -112,6 +135,15 @@ so_text* so_text_build(uint64_t seed, uint64_t n_docs, uint32_t vocab, uint32_t 
       T->tok[i] = r;
     }
   }
+  if (n_fields > 1) {
+    T->fdoclen = (uint8_t*)malloc((size_t)n_fields * n_docs);
+    for (uint64_t d = 0; d < n_docs; d++)
+      for (uint32_t f = 0; f < n_fields; f++) {
+        uint32_t a, b;
+        field_span(T, d, f, &a, &b);
+        T->fdoclen[(size_t)f * n_docs + d] = so_int_to_byte4(b - a);
+      }
+  }
   /* ---- n-gram keys: discover the distinct ones */
   ng_tab G; G.mask = (1ull << 22) - 1; G.k = (uint64_t*)calloc(G.mask + 1, 8); G.v = (uint32_t*)malloc((G.mask + 1) * 4);
   uint32_t n_ng = 0, ng_cap = 1u << 16;
@@ -142,11 +174,13 @@ so_text* so_text_build(uint64_t seed, uint64_t n_docs, uint32_t vocab, uint32_t 
   for (uint64_t i = 0; i < total; i++) cnt[T->tok[i]]++;
   uint64_t ng_occ = 0;
   uint32_t* occ_key = NULL;   /* n-gram occurrences in token order: key id (relative), doc, pos */
-  uint32_t* occ_doc = NULL; uint16_t* occ_pos = NULL;
+  uint32_t* occ_doc = NULL; uint16_t* occ_pos = NULL; uint8_t* occ_fld = NULL;
   uint64_t occ_cap = 0;
   if (ngrams & 9) {
-    for (uint64_t d = 0; d < n_docs; d++) {
-      const uint32_t a = T->doc_off[d], b = T->doc_off[d + 1];
+    for (uint64_t d = 0; d < n_docs; d++)
+     for (uint32_t fl = 0; fl < n_fields; fl++) {  /* an n-gram stands inside ONE field: positions count from the field's first token */
+      uint32_t a, b;
+      field_span(T, d, fl, &a, &b);
       for (uint32_t i = a + 1; i < b; i++) {
         const uint32_t t0 = T->tok[i], t1 = T->tok[i - 1];
         if (t0 >= n_frequent || t1 >= n_frequent) continue;
@@ -160,12 +194,14 @@ so_text* so_text_build(uint64_t seed, uint64_t n_docs, uint32_t vocab, uint32_t 
           if (ng_occ == occ_cap) {
             occ_cap = occ_cap ? occ_cap * 2 : (1u << 20);
             occ_key = (uint32_t*)realloc(occ_key, occ_cap * 4); occ_doc = (uint32_t*)realloc(occ_doc, occ_cap * 4); occ_pos = (uint16_t*)realloc(occ_pos, occ_cap * 2);
+            occ_fld = (uint8_t*)realloc(occ_fld, occ_cap);
           }
           occ_key[ng_occ] = id; occ_doc[ng_occ] = (uint32_t)d; occ_pos[ng_occ] = (uint16_t)(i - a - (tri ? 2u : 1u));  /* the place of the FIRST word */
+          occ_fld[ng_occ] = (uint8_t)fl;
           ng_occ++;
         }
       }
-    }
+     }
   }
   free(G.k); free(G.v);
   /* ---- keys */
@@ -189,18 +225,26 @@ so_text* so_text_build(uint64_t seed, uint64_t n_docs, uint32_t vocab, uint32_t 
   for (uint32_t k = 0; k < T->n_keys; k++) eoff[k + 1] += eoff[k];
   uint32_t* e_doc = (uint32_t*)malloc((n_ent ? n_ent : 1) * 4);
   uint16_t* e_pos = (uint16_t*)malloc((n_ent ? n_ent : 1) * 2);
+  uint8_t* e_fld = n_fields > 1 ? (uint8_t*)malloc(n_ent ? n_ent : 1) : NULL;
   uint64_t* cur = (uint64_t*)malloc((size_t)T->n_keys * 8);
   memcpy(cur, eoff, (size_t)T->n_keys * 8);
   for (uint64_t d = 0; d < n_docs; d++)
-    for (uint32_t i = T->doc_off[d]; i < T->doc_off[d + 1]; i++) {
-      const uint64_t w = cur[T->tok[i]]++;
-      e_doc[w] = (uint32_t)d; e_pos[w] = (uint16_t)(i - T->doc_off[d]);
+    for (uint32_t fl = 0; fl < n_fields; fl++) {
+      uint32_t a, b;
+      field_span(T, d, fl, &a, &b);
+      for (uint32_t i = a; i < b; i++) {
+        const uint64_t w = cur[T->tok[i]]++;
+        e_doc[w] = (uint32_t)d; e_pos[w] = (uint16_t)(i - a);
+        if (e_fld) e_fld[w] = (uint8_t)fl;
+      }
     }
   for (uint64_t i = 0; i < ng_occ; i++) {
     const uint64_t w = cur[vocab + occ_key[i]]++;
     e_doc[w] = occ_doc[i]; e_pos[w] = occ_pos[i];
+    if (e_fld) e_fld[w] = occ_fld[i];
   }
-  free(cur); free(cnt); free(occ_key); free(occ_doc); free(occ_pos);
+  T->efld = e_fld;
+  free(cur); free(cnt); free(occ_key); free(occ_doc); free(occ_pos); free(occ_fld);
   /* postings = runs of equal doc inside a key */
   T->key_off = (uint64_t*)malloc(((size_t)T->n_keys + 1) * 8);
   uint64_t np = 0;
@@ -275,6 +319,56 @@ uint64_t so_text_key_postings(const so_text* T, uint32_t key, uint32_t component
   return b - a;
 }
 
+const uint8_t* so_text_doclen_fields(const so_text* T) { return T->n_fields > 1 ? T->fdoclen : T->doclen; }
+uint32_t so_text_fields(const so_text* T, uint32_t* longest_field) { if (longest_field) *longest_field = T->longest_field; return T->n_fields; }
+/* tokens of field f of doc d */
+uint32_t so_text_doc_field_tokens(const so_text* T, uint64_t d, uint32_t f, uint32_t cap, uint32_t* out) {
+  uint32_t a, b;
+  field_span(T, d, f, &a, &b);
+  for (uint32_t i = a; i < b && i - a < cap; i++) out[i - a] = T->tok[i];
+  return b - a;
+}
+/* Several indexed fields: the (doc, field) ENTRIES of a key as the oracle's multi-field model wants them (so_search_fields_*_items):
+ * a single term: one entry per field that holds it, tf = count = its positions there; component c of an n-gram key: one entry per
+ * field of the doc in which the COMPONENT TERM occurs (its tf there), count = the key's own positions in that field for c == 0 (0
+ * where the key does not stand in the field, and for the other components), positions = the key's, field after field.
+ * Returns the number of entries (call with NULL arrays to size them). */
+uint64_t so_text_key_entries(const so_text* T, uint32_t key, uint32_t component, uint32_t* docs, uint8_t* fields, uint16_t* tfs, uint16_t* counts,
+                             uint16_t* positions, uint64_t pos_cap, uint64_t* n_pos_out) {
+  const uint64_t a = T->key_off[key], b = T->key_off[key + 1];
+  const uint32_t F = T->n_fields;
+  uint64_t ne = 0, np = 0;
+  for (uint64_t p = a; p < b; p++) {
+    const uint32_t d = T->p_doc[p];
+    const uint64_t e0 = T->p_pos[p], e1 = T->p_pos[p + 1];
+    for (uint32_t f = 0; f < F; f++) {
+      uint32_t own = 0;  /* the key's positions in field f */
+      uint64_t first = e1;
+      for (uint64_t e = e0; e < e1; e++)
+        if ((T->efld ? T->efld[e] : 0u) == f) { if (!own) first = e; own++; }
+      uint32_t tf = own;
+      if (T->ncomp[key] > 1) {
+        const uint32_t r = T->comp[3 * (size_t)key + component];
+        uint32_t fa, fb;
+        field_span(T, d, f, &fa, &fb);
+        tf = 0;
+        for (uint32_t i = fa; i < fb; i++) tf += T->tok[i] == r;
+        if (component != 0) own = 0;
+      }
+      if (!tf) continue;
+      if (docs) docs[ne] = d;
+      if (fields) fields[ne] = (uint8_t)f;
+      if (tfs) tfs[ne] = (uint16_t)tf;
+      if (counts) counts[ne] = (uint16_t)own;
+      if (positions) for (uint32_t x = 0; x < own && np + x < pos_cap; x++) positions[np + x] = T->pos[first + x];
+      np += own;
+      ne++;
+    }
+  }
+  if (n_pos_out) *n_pos_out = np;
+  return ne;
+}
+
 /* ================================================================== index.bin writer */
 typedef struct { uint8_t* p; uint64_t n, cap; } buf;
 static void b_need(buf* b, uint64_t more) {
@@ -313,6 +407,7 @@ static void embed(buf* out, uint32_t n, const uint32_t* dl, int psize) {  /* ind
   else { b_u8(out, data & 0xFF); b_u8(out, (data >> 8) & 0xFF); b_u8(out, ((data >> 16) | 0x80 | ((n - 1) << 5)) & 0xFF); }
 }
 
+static void container_of(const so_text* T, uint64_t a, uint32_t n, buf* bodies, uint32_t* ctype_out);
 /* one key's postings [a, b) of one level -> body appended to `bodies`; returns head fields */
 static void encode_key_body(const so_text* T, uint32_t key, uint64_t a, uint64_t b, uint32_t positions_limit, buf* bodies, buf* recs /* scratch */,
                             buf* ptrs /* scratch */, uint32_t* ctp_out, uint32_t* pivot_out) {
@@ -361,7 +456,13 @@ static void encode_key_body(const so_text* T, uint32_t key, uint64_t a, uint64_t
   }
   free(rec_end);
   b_put(bodies, ptrs->p, ptrs->n);
-  /* doc-id container: chooser compress_postinglist.rs:256-332, writers :694 / :759 / :832 */
+  uint32_t ctype;
+  container_of(T, a, n, bodies, &ctype);
+  *ctp_out = (ctype << 30) | (uint32_t)(base + size_positions);
+  *pivot_out = pivot;
+}
+/* doc-id container: chooser compress_postinglist.rs:256-332, writers :694 / :759 / :832 */
+static void container_of(const so_text* T, uint64_t a, uint32_t n, buf* bodies, uint32_t* ctype_out) {
   uint32_t runs = 1;
   for (uint32_t r = 1; r < n; r++) runs += (T->p_doc[a + r] & 0xFFFFu) != (T->p_doc[a + r - 1] & 0xFFFFu) + 1u;
   const uint32_t thr = n < 4096 ? n / 2 : 2048;
@@ -386,6 +487,137 @@ static void encode_key_body(const so_text* T, uint32_t key, uint64_t a, uint64_t
     for (uint32_t r = 0; r < n; r++) { const uint32_t d = T->p_doc[a + r] & 0xFFFFu; bodies->p[bodies->n + (d >> 3)] |= (uint8_t)(1u << (d & 7)); }
     bodies->n += 8192;
   }
+  *ctype_out = ctype;
+}
+
+/* ---- several indexed fields (index_posting.rs:433-940; the rules of oracle/ref_format.py encode_key_body_fields, byte for byte) */
+static uint32_t field_id_bits(uint32_t n_fields) { return bitlen(n_fields - 1u); }  /* index.rs:2569-2570 */
+/* [(field id, positions_count)] in front of a position record (index_posting.rs:846-940) */
+static void write_field_vec(buf* out, uint32_t n, const uint32_t* fid, const uint32_t* cnt, int only_longest, uint32_t id_bits) {
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t c = cnt[i];
+    if (only_longest) {
+      if (c < 64) b_u8(out, c | 0xC0);
+      else if (c < 8192) { b_u8(out, (c >> 7) | 0x40); b_u8(out, (c & 0x7F) | 0x80); }
+      else { b_u8(out, (c >> 14) | 0x40); b_u8(out, (c >> 7) & 0x7F); b_u8(out, (c & 0x7F) | 0x80); }
+      continue;
+    }
+    const uint32_t stop = i == n - 1 ? (i == 0 ? 0x20u : 0x40u) : 0u;  /* FIELD_STOP_BIT_1 / _2 (index.rs:112-113) */
+    const uint32_t v = (c << id_bits) | fid[i];
+    const uint32_t meta = (i == 0 ? 1u : 0u) + bitlen(c) + id_bits;
+    if (meta <= 6) b_u8(out, stop | v | 0x80);
+    else if (meta <= 13) { b_u8(out, stop | (v >> 7)); b_u8(out, (v & 0x7F) | 0x80); }
+    else { b_u8(out, stop | (v >> 14)); b_u8(out, (v >> 7) & 0x7F); b_u8(out, (v & 0x7F) | 0x80); }
+  }
+}
+/* nf non-empty fields (ids fid[], counts cnt[]), their delta positions concatenated in dl[n] (index_posting.rs:472-562) */
+static int embeddable_fields(uint32_t n, const uint32_t* dl, uint32_t nf, int only_longest, uint32_t id_bits, int psize) {
+  uint32_t b[4];
+  if (n == 0 || n > 4) return 0;
+  for (uint32_t i = 0; i < n; i++) b[i] = bitlen(dl[i]);
+  if (only_longest) {
+    if (psize == 2) return (n == 1 && b[0] <= 13) || (n == 2 && b[0] <= 6 && b[1] <= 7);
+    uint32_t mx = 0;
+    for (uint32_t i = 0; i < n; i++) mx = b[i] > mx ? b[i] : mx;
+    return (n == 1 && b[0] <= 20) || (n == 2 && b[0] <= 10 && b[1] <= 10) || (n == 3 && b[0] <= 6 && b[1] <= 7 && b[2] <= 7) || (n == 4 && mx <= 5);
+  }
+  const uint32_t used = nf * id_bits, bits = psize == 2 ? 12u : 19u;
+  if (used >= bits) return 0;
+  const uint32_t rem = bits - used;
+  if (n == 1) return b[0] <= rem;
+  if (n == 2) return b[0] <= rem / 2 && b[1] <= rem - rem / 2;
+  if (n == 3 && (psize == 3 || nf == 1)) return b[0] <= rem / 3 && b[1] <= (rem - rem / 3) / 2 && b[2] <= rem - (rem - rem / 3) / 2 - rem / 3;
+  if (n == 4 && psize == 3 && nf == 1) {
+    const uint32_t b2 = (rem - rem / 4) / 3, b3 = (rem - b2 - rem / 4) / 2;
+    return b[0] <= rem / 4 && b[1] <= b2 && b[2] <= b3 && b[3] <= rem - rem / 4 - b2 - b3;
+  }
+  return 0;
+}
+static void embed_fields(buf* out, uint32_t n, const uint32_t* dl, uint32_t nf, const uint32_t* fid, const uint32_t* cnt, int only_longest,
+                         uint32_t id_bits, int psize) {  /* index_posting.rs:592-660 */
+  uint32_t data = 0;
+  if (!only_longest)
+    for (uint32_t i = 0; i < nf; i++) data = (data << id_bits) | fid[i];
+  uint32_t remaining = (uint32_t)psize * 8u - (psize == 2 ? 0u : 1u) - (only_longest ? 3u : 4u + nf * id_bits);
+  for (uint32_t i = 0; i < n; i++) { const uint32_t w = remaining / (n - i); remaining -= w; data = (data << w) | dl[i]; }
+  if (psize == 2) {
+    uint32_t hi;
+    if (only_longest) hi = (data >> 8) | 0xC0 | ((n - 1) << 5);
+    else if (nf == 1) hi = (data >> 8) | 0x80 | ((n - 1) << 4);
+    else hi = (data >> 8) | 0xB0;
+    b_u8(out, data & 0xFF); b_u8(out, hi & 0xFF);
+    return;
+  }
+  uint32_t top;
+  if (only_longest) top = (data >> 16) | 0xC0 | ((n - 1) << 4);
+  else top = (data >> 16) | 0x80 | (nf == 1 ? ((n - 1) << 3) : nf == 3 ? 0x38u : (cnt[0] == 1 && cnt[1] == 1) ? 0x20u : (cnt[0] == 1 && cnt[1] == 2) ? 0x28u : 0x30u);
+  b_u8(out, data & 0xFF); b_u8(out, (data >> 8) & 0xFF); b_u8(out, top & 0xFF);
+}
+static void container_of(const so_text* T, uint64_t a, uint32_t n, buf* bodies, uint32_t* ctype_out);
+
+static void encode_key_body_fields(const so_text* T, uint32_t key, uint64_t a, uint64_t b, uint32_t positions_limit, buf* bodies, buf* recs, buf* ptrs,
+                                   uint32_t* ctp_out, uint32_t* pivot_out) {
+  const uint32_t n = (uint32_t)(b - a), nc = T->ncomp[key], F = T->n_fields, id_bits = field_id_bits(F);
+  const uint64_t base = bodies->n;
+  uint32_t size_positions = 0, pivot = 0;
+  int three = 0;
+  recs->n = 0; ptrs->n = 0;
+  uint32_t* rec_end = (uint32_t*)malloc((size_t)n * 4);
+  uint32_t n_rec = 0;
+  uint32_t* dl = NULL;
+  uint32_t dl_cap = 0;
+  for (uint32_t r = 0; r < n; r++) {
+    const uint64_t p = a + r, e0 = T->p_pos[p], e1 = T->p_pos[p + 1];
+    const uint32_t total = (uint32_t)(e1 - e0);
+    /* the non-empty fields of the posting, ascending, and the delta positions field after field */
+    uint32_t fid[8], cnt[8], nf = 0;
+    if (total > dl_cap) { dl_cap = total * 2; dl = (uint32_t*)realloc(dl, (size_t)dl_cap * 4); }
+    for (uint64_t e = e0; e < e1; e++) {
+      const uint32_t f = T->efld[e];
+      if (nf == 0 || fid[nf - 1] != f) { fid[nf] = f; cnt[nf] = 0; nf++; }
+      dl[e - e0] = cnt[nf - 1] == 0 ? T->pos[e] : (uint32_t)T->pos[e] - T->pos[e - 1] - 1u;
+      cnt[nf - 1]++;
+    }
+    const int only_longest = nf == 1 && fid[0] == T->longest_field;
+    int psize;
+    if (!three && size_positions < positions_limit && r < 65535u) { pivot = r + 1; psize = 2; }
+    else { psize = 3; three = 1; }
+    if (nc == 1 && total <= 4 && embeddable_fields(total, dl, nf, only_longest, id_bits, psize)) {
+      embed_fields(ptrs, total, dl, nf, fid, cnt, only_longest, id_bits, psize);
+      continue;
+    }
+    const uint64_t r0 = recs->n;
+    if (nc > 1) {  /* the component terms' field vectors first (index_posting.rs:664-722) */
+      const uint32_t d = T->p_doc[p];
+      for (uint32_t ci = 0; ci < nc; ci++) {
+        const uint32_t rk = T->comp[3 * (size_t)key + ci];
+        uint32_t cf[8], cc[8], ncf = 0;
+        for (uint32_t f = 0; f < F; f++) {
+          uint32_t fa, fb, tf = 0;
+          field_span(T, d, f, &fa, &fb);
+          for (uint32_t i = fa; i < fb; i++) tf += T->tok[i] == rk;
+          if (tf) { cf[ncf] = f; cc[ncf] = tf; ncf++; }
+        }
+        write_field_vec(recs, ncf, cf, cc, ncf == 1 && cf[0] == T->longest_field, id_bits);
+      }
+    }
+    write_field_vec(recs, nf, fid, cnt, only_longest, id_bits);
+    for (uint32_t i = 0; i < total; i++) b_posvint(recs, dl[i]);
+    const uint32_t len = (uint32_t)(recs->n - r0);
+    if (psize == 2 && size_positions + len >= positions_limit) { psize = 3; pivot = r; three = 1; }
+    size_positions += len;
+    rec_end[n_rec++] = (uint32_t)recs->n;
+    if (psize == 2) { b_u8(ptrs, size_positions & 255); b_u8(ptrs, (size_positions >> 8) & 127); }
+    else { b_u8(ptrs, size_positions & 255); b_u8(ptrs, (size_positions >> 8) & 255); b_u8(ptrs, (size_positions >> 16) & 127); }
+  }
+  for (uint32_t i = n_rec; i > 0; i--) {
+    const uint32_t s0 = i > 1 ? rec_end[i - 2] : 0u, e = rec_end[i - 1];
+    b_put(bodies, recs->p + s0, e - s0);
+  }
+  free(rec_end); free(dl);
+  b_put(bodies, ptrs->p, ptrs->n);
+  uint32_t ctype;
+  container_of(T, a, n, bodies, &ctype);
   *ctp_out = (ctype << 30) | (uint32_t)(base + size_positions);
   *pivot_out = pivot;
 }
@@ -430,11 +662,14 @@ int so_text_write_index_bin(const so_text* T, uint32_t segment_number_bits, uint
   for (uint32_t s = 0; s < nseg; s++) qsort(se + seg_cnt[s], seg_cnt[s + 1] - seg_cnt[s], sizeof(seg_ent), seg_cmp);
   uint64_t psum = 0;
   for (uint32_t level = 0; level < n_levels; level++) {
-    if (level == 0) b_le(&F, 0, 2);  /* longest_field_id */
+    if (level == 0) b_le(&F, T->longest_field, 2);  /* longest_field_id */
     const uint64_t d0 = (uint64_t)level << 16, d1 = T->n_docs < d0 + 65536 ? T->n_docs : d0 + 65536;
-    b_put(&F, T->doclen + d0, d1 - d0);
-    for (uint64_t z = d1 - d0; z < 65536; z++) b_u8(&F, 0);
-    for (uint64_t d = d0; d < d1; d++) psum += so_byte4_to_int(T->doclen[d]);
+    for (uint32_t f = 0; f < T->n_fields; f++) {  /* document_length_compressed_array of every indexed field */
+      const uint8_t* dlf = T->n_fields > 1 ? T->fdoclen + (size_t)f * T->n_docs : T->doclen;
+      b_put(&F, dlf + d0, d1 - d0);
+      for (uint64_t z = d1 - d0; z < 65536; z++) b_u8(&F, 0);
+      for (uint64_t d = d0; d < d1; d++) psum += so_byte4_to_int(dlf[d]);
+    }
     b_le(&F, d1, 8);
     b_le(&F, psum, 8);
     tbl.n = 0; payload.n = 0;
@@ -449,7 +684,8 @@ int so_text_write_index_bin(const so_text* T, uint32_t segment_number_bits, uint
         if (b == a) continue;
         cur[k] = b;
         uint32_t ctp, pivot;
-        encode_key_body(T, k, a, b, positions_limit, &bodies, &recs, &ptrs, &ctp, &pivot);
+        if (T->n_fields > 1) encode_key_body_fields(T, k, a, b, positions_limit, &bodies, &recs, &ptrs, &ctp, &pivot);
+        else encode_key_body(T, k, a, b, positions_limit, &bodies, &recs, &ptrs, &ctp, &pivot);
         b_le(&heads, T->key_hash[k], 8);
         b_le(&heads, (uint32_t)(b - a) - 1u, 2);
         b_le(&heads, 0, 4);  /* max_docid, max_p_docid: the device image derives its own bounds */

@@ -34,14 +34,27 @@ def _lib():
         L.so_text_write_index_bin.restype = C.c_int
         L.so_text_write_index_bin.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.POINTER(C.c_uint8)), u64p]
         L.so_text_free_bytes.argtypes = [C.POINTER(C.c_uint8)]
+        L.so_text_build_fields.restype = C.c_void_p
+        L.so_text_build_fields.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_double, C.c_double, C.c_uint32, C.c_uint32]
+        L.so_text_doclen_fields.restype = C.POINTER(C.c_uint8)
+        L.so_text_doclen_fields.argtypes = [C.c_void_p]
+        L.so_text_doc_field_tokens.restype = C.c_uint32
+        L.so_text_doc_field_tokens.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, u32p]
+        L.so_text_key_entries.restype = C.c_uint64
+        L.so_text_key_entries.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, u32p, u8p, u16p, u16p, u16p, C.c_uint64, u64p]
         L._text_ready = True
     return L
 
 
 class TextCorpus:
-    def __init__(self, seed, n_docs, vocab, n_frequent=64, ngrams=NGRAM_FF | NGRAM_FFF, topic_share=0.35, mean_len=100.0):
+    def __init__(self, seed, n_docs, vocab, n_frequent=64, ngrams=NGRAM_FF | NGRAM_FFF, topic_share=0.35, mean_len=100.0, n_fields=1,
+                 longest_field=0):
+        """n_fields > 1: the docs' tokens cut into that many consecutive spans indexed as separate fields (positions restart per field,
+        n-grams stay inside one); longest_field = the longest_field_id the file declares"""
         self.n_docs, self.vocab, self.n_frequent, self.ngrams = int(n_docs), int(vocab), int(n_frequent), int(ngrams)
-        self._h = _lib().so_text_build(int(seed), int(n_docs), int(vocab), int(n_frequent), int(ngrams), float(topic_share), float(mean_len))
+        self.n_fields, self.longest_field = int(n_fields), int(longest_field)
+        self._h = _lib().so_text_build_fields(int(seed), int(n_docs), int(vocab), int(n_frequent), int(ngrams), float(topic_share), float(mean_len),
+                                              int(n_fields), int(longest_field))
         if not self._h:
             raise ValueError("so_text_build refused the arguments")
         nt, np_ = C.c_uint64(), C.c_uint64()
@@ -49,6 +62,8 @@ class TextCorpus:
         _lib().so_text_info(self._h, C.byref(nt), C.byref(nk), C.byref(ne), C.byref(np_), C.byref(ng))
         self.n_tokens, self.n_keys, self.n_keys_nonempty, self.n_postings, self.n_ngram_keys = nt.value, nk.value, ne.value, np_.value, ng.value
         self.doclen = np.ctypeslib.as_array(_lib().so_text_doclen(self._h), shape=(self.n_docs,)).copy()
+        # [n_fields][n_docs] length bytes of the indexed fields (one field: the same bytes)
+        self.doclen_fields = np.ctypeslib.as_array(_lib().so_text_doclen_fields(self._h), shape=(self.n_fields, self.n_docs)).copy()
 
     def close(self):
         if getattr(self, "_h", None):
@@ -65,6 +80,24 @@ class TextCorpus:
         out = np.zeros(1500, np.uint32)
         n = _lib().so_text_doc_tokens(self._h, int(d), len(out), O._p(out, u32p))
         return out[:n].copy()
+
+    def doc_field_tokens(self, d, f):
+        out = np.zeros(1500, np.uint32)
+        n = _lib().so_text_doc_field_tokens(self._h, int(d), int(f), len(out), O._p(out, u32p))
+        return out[:n].copy()
+
+    def key_entries(self, key, component=0, positions=True):
+        """several indexed fields: (docs, fields, tfs, counts, positions) of the key's (doc, field) entries -- for component c of an n-gram
+        key the fields in which the component TERM stands, counts / positions = the key's own (component 0 only)"""
+        n = _lib().so_text_key_entries(self._h, int(key), int(component), None, None, None, None, None, 0, None)
+        docs, flds, tfs, cnt = np.zeros(n, np.uint32), np.zeros(n, np.uint8), np.zeros(n, np.uint16), np.zeros(n, np.uint16)
+        npos = C.c_uint64()
+        _lib().so_text_key_entries(self._h, int(key), int(component), O._p(docs, u32p), O._p(flds, u8p), O._p(tfs, u16p), O._p(cnt, u16p), None, 0,
+                                   C.byref(npos))
+        pos = np.zeros(npos.value if positions else 0, np.uint16)
+        if positions and npos.value:
+            _lib().so_text_key_entries(self._h, int(key), int(component), None, None, None, None, O._p(pos, u16p), len(pos), C.byref(npos))
+        return docs, flds, tfs, cnt, pos
 
     def ngram_key(self, ranks):
         """key id of the n-gram over these 2 / 3 ranks, None if the corpus holds none"""

@@ -13,6 +13,7 @@
 // value is the count (read_singlefield_value, add_result.rs:2584-2606).  N-gram keys put the tf of each component term
 // before the count (ss_ref_decode_block_ngram); several indexed fields: ss_ref_decode_block_fields below.
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -948,38 +949,91 @@ extern "C" int ss_index_bin_term_postings(const ss_index_bin* ix, uint32_t term,
 
 namespace {
 // multi-field index: (doc, field, tf) entries of every term, doclen rearranged to [field][doc]
-// the entries (doc, field, tf) of the keys [t0, t1), CSR over offs [t1 - t0 + 1]
+// the entries (doc, field, tf) of the keys [t0, t1), CSR over offs [t1 - t0 + 1]; the keys are decoded on the loader's worker threads in
+// chunks of about equal posting counts (index_bin_decode_range's scheme), the pieces then copied into place
 int decode_fields_range(const ss_index_bin* ix, uint32_t t0, uint32_t t1, std::vector<uint64_t>& offs, std::vector<uint32_t>& docs,
                         std::vector<uint8_t>& fields, std::vector<uint16_t>& tfs, std::vector<uint16_t>* pos, std::vector<uint16_t>* npos) {
   const uint32_t F = ix->n_fields;
-  std::vector<uint16_t> d16(65536), t16((size_t)65536 * F);
-  std::vector<uint32_t> first(65537);
-  std::vector<uint8_t> f8((size_t)65536 * F);
-  offs.assign((size_t)(t1 - t0) + 1, 0);
-  for (uint32_t t = t0; t < t1; t++) {
-    offs[t - t0] = docs.size();
-    for (uint64_t bi = ix->term_block_off[t]; bi < ix->term_block_off[t + 1]; bi++) {
-      const ss_ref_block& b = ix->blocks[bi].b;
-      const int n = decode_block_fields(&b, F, ix->longest_field_id, ix->blocks[bi].n_comp, ix->blocks[bi].comp, d16.data(), first.data(),
-                                        f8.data(), t16.data(), pos, npos);
-      if (n < 0) return n;
-      for (int i = 0; i < n; i++) {
-        const uint64_t doc = ((uint64_t)b.block_id << 16) | d16[i];
-        if (doc >= ix->n_docs) return SS_EINVAL;
-        for (uint32_t e = first[i]; e < first[i + 1]; e++) {
-          docs.push_back((uint32_t)doc);
-          fields.push_back(f8[e]);
-          tfs.push_back(t16[e]);
+  const size_t nt = t1 - t0;
+  struct Piece { std::vector<uint32_t> docs; std::vector<uint8_t> fields; std::vector<uint16_t> tfs, pos, npos; std::vector<uint64_t> n_ent; size_t first = 0; };
+  std::vector<uint64_t> cum(nt + 1, 0);
+  for (size_t i = 0; i < nt; i++) {
+    uint64_t c = 0;
+    for (uint64_t bi = ix->term_block_off[t0 + i]; bi < ix->term_block_off[t0 + i + 1]; bi++) c += (uint64_t)ix->blocks[bi].b.posting_count_m1 + 1u;
+    cum[i + 1] = cum[i] + c;
+  }
+  const uint64_t per = std::max<uint64_t>(cum[nt] / (8ull * ss_loader_threads()) + 1, 1u << 16);
+  std::vector<size_t> cuts{0};
+  for (size_t i = 1; i <= nt; i++)
+    if (i == nt || cum[i] - cum[cuts.back()] >= per) cuts.push_back(i);
+  const size_t nc = cuts.size() - 1;
+  std::vector<Piece> pc(nc);
+  std::atomic<int> rc_all{SS_OK};
+  ss_parallel_for(nc, 1, [&](size_t ca, size_t cb, unsigned) {
+    std::vector<uint16_t> d16(65536), t16((size_t)65536 * F);
+    std::vector<uint32_t> first(65537);
+    std::vector<uint8_t> f8((size_t)65536 * F);
+    for (size_t c = ca; c < cb; c++) {
+      Piece& P = pc[c];
+      P.first = cuts[c];
+      for (size_t i = cuts[c]; i < cuts[c + 1]; i++) {
+        const uint32_t t = (uint32_t)(t0 + i);
+        const size_t before = P.docs.size();
+        for (uint64_t bi = ix->term_block_off[t]; bi < ix->term_block_off[t + 1]; bi++) {
+          const ss_ref_block& b = ix->blocks[bi].b;
+          const int n = decode_block_fields(&b, F, ix->longest_field_id, ix->blocks[bi].n_comp, ix->blocks[bi].comp, d16.data(), first.data(),
+                                            f8.data(), t16.data(), pos ? &P.pos : nullptr, npos ? &P.npos : nullptr);
+          if (n < 0) { int ok = SS_OK; rc_all.compare_exchange_strong(ok, n); return; }
+          for (int x = 0; x < n; x++) {
+            const uint64_t doc = ((uint64_t)b.block_id << 16) | d16[x];
+            if (doc >= ix->n_docs) { int ok = SS_OK; rc_all.compare_exchange_strong(ok, (int)SS_EINVAL); return; }
+            for (uint32_t e = first[x]; e < first[x + 1]; e++) {
+              P.docs.push_back((uint32_t)doc);
+              P.fields.push_back(f8[e]);
+              P.tfs.push_back(t16[e]);
+            }
+          }
         }
+        P.n_ent.push_back(P.docs.size() - before);
       }
     }
+  });
+  if (rc_all.load()) return rc_all.load();
+  offs.assign(nt + 1, 0);
+  std::vector<uint64_t> d_at(nc + 1, 0), p_at(nc + 1, 0);
+  for (size_t c = 0; c < nc; c++) {
+    d_at[c + 1] = d_at[c] + pc[c].docs.size();
+    p_at[c + 1] = p_at[c] + pc[c].pos.size();
+    uint64_t at = d_at[c];
+    for (size_t x = 0; x < pc[c].n_ent.size(); x++) { offs[pc[c].first + x] = at; at += pc[c].n_ent[x]; }
   }
-  offs[t1 - t0] = docs.size();
-  return SS_OK;
+  offs[nt] = d_at[nc];
+  docs.resize(d_at[nc]); fields.resize(d_at[nc]); tfs.resize(d_at[nc]);
+  if (pos) pos->resize(p_at[nc]);
+  if (npos) npos->resize(d_at[nc]);
+  std::atomic<int> bad{0};
+  ss_parallel_for(nc, 1, [&](size_t ca, size_t cb, unsigned) {
+    for (size_t c = ca; c < cb; c++) {
+      Piece& P = pc[c];
+      if (!P.docs.empty()) {
+        std::memcpy(docs.data() + d_at[c], P.docs.data(), P.docs.size() * 4);
+        std::memcpy(fields.data() + d_at[c], P.fields.data(), P.fields.size());
+        std::memcpy(tfs.data() + d_at[c], P.tfs.data(), P.tfs.size() * 2);
+        if (npos) { if (P.npos.size() != P.docs.size()) bad.store(1); else std::memcpy(npos->data() + d_at[c], P.npos.data(), P.npos.size() * 2); }
+      }
+      if (pos && !P.pos.empty()) std::memcpy(pos->data() + p_at[c], P.pos.data(), P.pos.size() * 2);
+      Piece().docs.swap(P.docs); Piece().pos.swap(P.pos);
+    }
+  });
+  return bad.load() ? (int)SS_EINVAL : (int)SS_OK;
 }
 
 int upload_index_bin_fields(ss_shard* s, const ss_index_bin* ix, const float* boost, bool with_positions) {
   const uint32_t F = ix->n_fields;
+  static const bool trace = getenv("SS_LOAD_TRACE") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto t_0 = now();
   const uint32_t n_all = (uint32_t)ix->keys.size(), n_dense = std::min<uint32_t>(ix->n_dense, n_all);  // ss_index_bin_tier
   if (n_dense == 0) return SS_EINVAL;
   std::vector<uint16_t> pos, npos;
@@ -989,6 +1043,7 @@ int upload_index_bin_fields(ss_shard* s, const ss_index_bin* ix, const float* bo
   std::vector<uint16_t> tfs;
   int rc = decode_fields_range(ix, 0, n_dense, offs, docs, fields, tfs, with_positions ? &pos : nullptr, with_positions ? &npos : nullptr);
   if (rc) return rc;
+  const auto t_1 = now();
   std::vector<uint8_t> doclen((size_t)F * ix->n_docs);
   for (uint32_t f = 0; f < F; f++)
     for (size_t l = 0; l < ix->doclen.size(); l++) {
@@ -1003,6 +1058,8 @@ int upload_index_bin_fields(ss_shard* s, const ss_index_bin* ix, const float* bo
   else
     rc = ssi_bm25_upload_fields(s, ix->n_docs, F, doclen.data(), boost, n_dense, offs.data(), docs.data(), fields.data(), tfs.data(),
                                 ix->positions_sum);
+  const auto t_2 = now();
+  if (trace) fprintf(stderr, "[load] dense tier: decode %.0f ms (%zu entries, %zu positions), image build + upload %.0f ms\n", ms(t_0, t_1), docs.size(), pos.size(), ms(t_1, t_2));
   if (rc || n_dense == n_all) return rc;
   // the rare keys: their entries decoded the same way, their merged lists appended to the sparse tier (ids continue behind the dense ones)
   std::vector<uint64_t> r_offs;
@@ -1012,7 +1069,14 @@ int upload_index_bin_fields(ss_shard* s, const ss_index_bin* ix, const float* bo
   std::vector<uint16_t> r_pos, r_npos;
   rc = decode_fields_range(ix, n_dense, n_all, r_offs, r_docs, r_fields, r_tfs, with_positions ? &r_pos : nullptr, with_positions ? &r_npos : nullptr);
   if (rc) return rc;
-  if (with_positions)
+  const auto t_3 = now();
+  if (with_positions) {
+    rc = ss_bm25_append_sparse_fields_positions(s, n_all - n_dense, r_offs.data(), r_docs.data(), r_fields.data(), r_tfs.data(), r_pos.data(),
+                                                r_pos.size(), r_npos.data(), nullptr);
+    if (trace) fprintf(stderr, "[load] sparse tier: decode %.0f ms (%zu entries), append %.0f ms\n", ms(t_2, t_3), r_docs.size(), ms(t_3, now()));
+    return rc;
+  }
+  if (false)
     return ss_bm25_append_sparse_fields_positions(s, n_all - n_dense, r_offs.data(), r_docs.data(), r_fields.data(), r_tfs.data(), r_pos.data(),
                                                   r_pos.size(), r_npos.data(), nullptr);
   return ss_bm25_append_sparse_fields(s, n_all - n_dense, r_offs.data(), r_docs.data(), r_fields.data(), r_tfs.data(), nullptr);

@@ -377,13 +377,19 @@ int ssi_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, cons
   static const bool merged_off = [] { const char* e = getenv("SS_BM25_MERGED"); return e && atoi(e) == 0; }();
   (void)bmax;
   std::vector<uint64_t> df_real(n_terms, 0);
-  for (uint32_t t = 0; t < n_terms; t++) {
+  for (uint32_t t = 0; t < n_terms; t++)
     if (offs[t + 1] < offs[t]) return SS_EINVAL;
-    for (uint64_t j = offs[t]; j < offs[t + 1]; j++) {
-      if (fields[j] >= n_fields) return SS_EINVAL;
-      if (j > offs[t] && (docs[j] < docs[j - 1] || (docs[j] == docs[j - 1] && fields[j] <= fields[j - 1]))) return SS_EINVAL;
-      if (j == offs[t] || docs[j] != docs[j - 1]) df_real[t]++;  // docs containing the term in any field: the df of idf
-    }
+  {  // (per-term loops on the loader's worker threads, here and below: a term's entries and lists are its own)
+    std::atomic<int> bad{0};
+    ss_parallel_for(n_terms, 64, [&](size_t ta, size_t tb, unsigned) {
+      for (size_t t = ta; t < tb; t++)
+        for (uint64_t j = offs[t]; j < offs[t + 1]; j++) {
+          if (fields[j] >= n_fields) { bad.store(1); return; }
+          if (j > offs[t] && (docs[j] < docs[j - 1] || (docs[j] == docs[j - 1] && fields[j] <= fields[j - 1]))) { bad.store(1); return; }
+          if (j == offs[t] || docs[j] != docs[j - 1]) df_real[t]++;  // docs containing the term in any field: the df of idf
+        }
+    });
+    if (bad.load()) return SS_EINVAL;
   }
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
@@ -397,25 +403,29 @@ int ssi_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, cons
     if ((uint64_t)n_terms * L > 0x7FFFFFFFull) return SS_ENOTSUP;
     const uint32_t nv = n_terms * L;
     std::vector<uint64_t> voff((size_t)nv + 1, 0);
-    for (uint32_t t = 0; t < n_terms; t++) {
-      for (uint64_t j = offs[t]; j < offs[t + 1]; j++) voff[(size_t)t * L + fields[j] + 1]++;
-      if (merged) voff[(size_t)t * L + n_fields + 1] = df_real[t];
-    }
+    ss_parallel_for(n_terms, 64, [&](size_t ta, size_t tb, unsigned) {
+      for (size_t t = ta; t < tb; t++) {
+        for (uint64_t j = offs[t]; j < offs[t + 1]; j++) voff[t * L + fields[j] + 1]++;
+        if (merged) voff[t * L + n_fields + 1] = df_real[t];
+      }
+    });
     for (uint32_t v = 0; v < nv; v++) voff[v + 1] += voff[v];
     std::vector<uint32_t> vdocs(voff[nv]);
     std::vector<uint16_t> vtfs(voff[nv]);
     std::vector<uint64_t> cur(voff.begin(), voff.end() - 1);
-    for (uint32_t t = 0; t < n_terms; t++)
-      for (uint64_t j = offs[t]; j < offs[t + 1]; j++) {
-        const uint64_t w = cur[(size_t)t * L + fields[j]]++;
-        vdocs[w] = docs[j];
-        vtfs[w] = tfs[j];
-        if (merged && (j == offs[t] || docs[j] != docs[j - 1])) {
-          const uint64_t m = cur[(size_t)t * L + n_fields]++;
-          vdocs[m] = docs[j];
-          vtfs[m] = 1;  // not a tf: the builder derives the merged weight from the field lists
+    ss_parallel_for(n_terms, 64, [&](size_t ta, size_t tb, unsigned) {
+      for (size_t t = ta; t < tb; t++)
+        for (uint64_t j = offs[t]; j < offs[t + 1]; j++) {
+          const uint64_t w = cur[t * L + fields[j]]++;
+          vdocs[w] = docs[j];
+          vtfs[w] = tfs[j];
+          if (merged && (j == offs[t] || docs[j] != docs[j - 1])) {
+            const uint64_t m = cur[t * L + n_fields]++;
+            vdocs[m] = docs[j];
+            vtfs[m] = 1;  // not a tf: the builder derives the merged weight from the field lists
+          }
         }
-      }
+    });
     free_bm25(s);
     s->bm_n_docs = n_docs;
     s->bm_n_fields = L;

@@ -205,29 +205,44 @@ int ssi_bm25_build_from_host_merged(ss_shard* s, const uint8_t* doclen, const ui
     mw.resize(mw_base[nt / L]);
     mw_lt10.assign(mw_base[nt / L], 0);
     float wmin = 3.0e38f, wmax = 0.f;
-    for (uint32_t t = L - 1; t < nt; t += L) {
-      u64 fcur[8];
-      for (uint32_t f = 0; f < RF; f++) fcur[f] = offs[t - RF + f];
-      for (u64 j = offs[t]; j < offs[t + 1]; j++) {
-        if (docs[j] >= s->bm_n_docs) return SS_EINVAL;
-        float w = 0.f;
-        bool any = false;
-        for (uint32_t f = 0; f < RF; f++) {
-          const uint32_t vf = t - RF + f;
-          while (fcur[f] < offs[vf + 1] && docs[fcur[f]] < docs[j]) fcur[f]++;
-          if (fcur[f] < offs[vf + 1] && docs[fcur[f]] == docs[j]) {
-            if (tfs[fcur[f]] == 0) return SS_EINVAL;
-            const volatile float part = merged_boost[f] * bm_weight_exact(tfs[fcur[f]], comp[doclen[(size_t)f * s->bm_n_docs + docs[j]]]);
-            w = w + part;
-            if (!any) mw_lt10[mw_base[t / L] + (j - offs[t])] = tfs[fcur[f]] < 10u ? 1 : 0;  // the lowest field that holds the doc
-            any = true;
+    {  // (terms in parallel; the extremes per worker, then combined)
+      const unsigned nw = ss_loader_threads();
+      std::vector<float> wmins(nw + 1, 3.0e38f), wmaxs(nw + 1, 0.f);
+      std::atomic<int> bad{0};
+      ss_parallel_for(nt / L, 16, [&](size_t ia, size_t ib, unsigned wk) {
+        float lo = 3.0e38f, hi = 0.f;
+        for (size_t ti = ia; ti < ib; ti++) {
+          const uint32_t t = (uint32_t)(ti * L + (L - 1));
+          u64 fcur[8];
+          for (uint32_t f = 0; f < RF; f++) fcur[f] = offs[t - RF + f];
+          for (u64 j = offs[t]; j < offs[t + 1]; j++) {
+            if (docs[j] >= s->bm_n_docs) { bad.store(1); return; }
+            float w = 0.f;
+            bool any = false;
+            for (uint32_t f = 0; f < RF; f++) {
+              const uint32_t vf = t - RF + f;
+              while (fcur[f] < offs[vf + 1] && docs[fcur[f]] < docs[j]) fcur[f]++;
+              if (fcur[f] < offs[vf + 1] && docs[fcur[f]] == docs[j]) {
+                if (tfs[fcur[f]] == 0) { bad.store(1); return; }
+                const volatile float part = merged_boost[f] * bm_weight_exact(tfs[fcur[f]], comp[doclen[(size_t)f * s->bm_n_docs + docs[j]]]);
+                w = w + part;
+                if (!any) mw_lt10[mw_base[t / L] + (j - offs[t])] = tfs[fcur[f]] < 10u ? 1 : 0;  // the lowest field that holds the doc
+                any = true;
+              }
+            }
+            if (!any || !(w > 0.f)) { bad.store(1); return; }  // a doc of the merged list that no field list holds
+            mw[mw_base[t / L] + (j - offs[t])] = w;
+            lo = std::min(lo, w);
+            hi = std::max(hi, w);
           }
         }
-        if (!any || !(w > 0.f)) return SS_EINVAL;  // a doc of the merged list that no field list holds
-        mw[mw_base[t / L] + (j - offs[t])] = w;
-        wmin = std::min(wmin, w);
-        wmax = std::max(wmax, w);
-      }
+        const size_t slot = std::min<size_t>(wk, nw);
+        wmins[slot] = std::min(wmins[slot], lo);
+        wmaxs[slot] = std::max(wmaxs[slot], hi);
+      });
+      if (bad.load()) return SS_EINVAL;
+      for (float x : wmins) wmin = std::min(wmin, x);
+      for (float x : wmaxs) wmax = std::max(wmax, x);
     }
     if (!mw.empty()) {
       int e = 0;
@@ -682,23 +697,35 @@ int ssi_bm25_append_sparse_fields(ss_shard* s, uint32_t n_lists, const uint64_t*
   // (ssi_bm25_upload_positions_fields)
   if (!npos) npos = tfs;
   std::vector<uint32_t> counts(packed.size()), pool(n_positions ? n_positions : 1);
-  u64 at = 0, w = 0;
-  for (uint32_t i = 0; i < n_lists; i++)
-    for (u64 j = offs[i]; j < offs[i + 1];) {
-      uint32_t c = 0;
-      u64 e = j;
-      for (; e < offs[i + 1] && docs[e] == docs[j]; e++) {
-        if (at + npos[e] > n_positions) return SS_EINVAL;
-        for (uint32_t x = 0; x < npos[e]; x++, at++) {
-          if (x && positions[at] <= positions[at - 1]) return SS_EINVAL;  // ascending inside a field
-          pool[at] = ((uint32_t)fields[e] << BM_POS_FIELD_SHIFT) | positions[at];
-        }
-        c += npos[e];
-      }
-      counts[w++] = c;
-      j = e;
+  std::vector<u64> lstart((size_t)n_lists + 1, 0);  // first position of every list (lists in parallel below)
+  ss_parallel_for(n_lists, 4096, [&](size_t a, size_t b, unsigned) {
+    for (size_t i = a; i < b; i++) {
+      u64 c = 0;
+      for (u64 j = offs[i]; j < offs[i + 1]; j++) c += npos[j];
+      lstart[i + 1] = c;
     }
-  if (at != n_positions) return SS_EINVAL;
+  });
+  for (uint32_t i = 0; i < n_lists; i++) lstart[i + 1] += lstart[i];
+  if (lstart[n_lists] != n_positions) return SS_EINVAL;
+  ss_parallel_for(n_lists, 4096, [&](size_t a, size_t b, unsigned) {
+    for (size_t i = a; i < b; i++) {
+      u64 at = lstart[i], w = lbase[i];
+      for (u64 j = offs[i]; j < offs[i + 1];) {
+        uint32_t c = 0;
+        u64 e = j;
+        for (; e < offs[i + 1] && docs[e] == docs[j]; e++) {
+          for (uint32_t x = 0; x < npos[e]; x++, at++) {
+            if (x && positions[at] <= positions[at - 1]) { fail.store(SS_EINVAL); return; }  // ascending inside a field
+            pool[at] = ((uint32_t)fields[e] << BM_POS_FIELD_SHIFT) | positions[at];
+          }
+          c += npos[e];
+        }
+        counts[w++] = c;
+        j = e;
+      }
+    }
+  });
+  if (fail.load()) return fail.load();
   return sparse_install(s, n_lists, lbase, packed, &counts, pool.data(), n_positions, sizeof(uint32_t));
 }
 
@@ -819,37 +846,50 @@ int ssi_bm25_upload_positions_fields(ss_shard* s, uint32_t n_terms, const uint64
   SS_HIP(hipMemcpy(tbase.data(), s->d_term_base, tbase.size() * sizeof(u64), hipMemcpyDeviceToHost));
   std::vector<uint32_t> poff((size_t)s->bm_n_post_pad + 5, 0u);  // + 4: the padding loop of a segment may run to the next multiple of 4 before the walk is checked
   std::vector<uint32_t> pool(n_positions ? n_positions : 1);
-  u64 total = 0;
-  for (uint32_t t = 0; t < n_terms; t++) {
-    const uint32_t v = t * L + (L - 1u);  // the term's merged list
-    for (uint32_t f = 0; f < L; f++) pbase[(size_t)t * L + f] = total;
-    u64 w = tbase[v] * 4ull, rel = 0, j = offs[t];
-    for (uint32_t sb = 0; sb < ns; sb++) {
-      const u64 lim = ((u64)sb + 1) << BM_SUB_LOG2;
-      u64 n = 0;
-      while (j < offs[t + 1] && docs[j] < lim) {
-        const uint32_t d = docs[j];
-        for (; j < offs[t + 1] && docs[j] == d; j++) {  // the doc's entries, fields ascending
-          if (total + rel + npos[j] > n_positions) return SS_EINVAL;
-          for (uint32_t x = 0; x < npos[j]; x++) {
-            const u64 at = total + rel + x;
-            if (x && positions[at] <= positions[at - 1]) return SS_EINVAL;  // ascending inside a field
-            pool[at] = ((uint32_t)fields[j] << BM_POS_FIELD_SHIFT) | positions[at];
-          }
-          rel += npos[j];
-        }
-        if (rel >= (1ull << 32)) return SS_ENOTSUP;
-        if (w >= s->bm_n_post_pad) return SS_EINVAL;
-        poff[w++] = (uint32_t)rel;
-        n++;
-      }
-      for (u64 pad = (4 - (n & 3)) & 3; pad > 0; pad--) poff[w++] = (uint32_t)rel;
+  // a term's positions: the sum of its entries' counts (terms in parallel), then every term fills its own slots
+  std::vector<u64> tstart((size_t)n_terms + 1, 0);
+  ss_parallel_for(n_terms, 64, [&](size_t ta, size_t tb, unsigned) {
+    for (size_t t = ta; t < tb; t++) {
+      u64 c = 0;
+      for (u64 j = offs[t]; j < offs[t + 1]; j++) c += npos[j];
+      tstart[t + 1] = c;
     }
-    if (w != tbase[v + 1] * 4ull) return SS_EINVAL;  // the walk must land on the merged list's end: same entries as the image's
-    total += rel;
-  }
+  });
+  for (uint32_t t = 0; t < n_terms; t++) tstart[t + 1] += tstart[t];
+  if (tstart[n_terms] != n_positions) return SS_EINVAL;
+  std::atomic<int> fail{SS_OK};
+  ss_parallel_for(n_terms, 16, [&](size_t ta, size_t tb, unsigned) {
+    for (size_t t = ta; t < tb; t++) {
+      const uint32_t v = (uint32_t)t * L + (L - 1u);  // the term's merged list
+      const u64 total = tstart[t];
+      for (uint32_t f = 0; f < L; f++) pbase[t * L + f] = total;
+      u64 w = tbase[v] * 4ull, rel = 0, j = offs[t];
+      for (uint32_t sb = 0; sb < ns; sb++) {
+        const u64 lim = ((u64)sb + 1) << BM_SUB_LOG2;
+        u64 n = 0;
+        while (j < offs[t + 1] && docs[j] < lim) {
+          const uint32_t d = docs[j];
+          for (; j < offs[t + 1] && docs[j] == d; j++) {  // the doc's entries, fields ascending
+            for (uint32_t x = 0; x < npos[j]; x++) {
+              const u64 at = total + rel + x;
+              if (x && positions[at] <= positions[at - 1]) { fail.store(SS_EINVAL); return; }  // ascending inside a field
+              pool[at] = ((uint32_t)fields[j] << BM_POS_FIELD_SHIFT) | positions[at];
+            }
+            rel += npos[j];
+          }
+          if (rel >= (1ull << 32)) { fail.store(SS_ENOTSUP); return; }
+          if (w >= s->bm_n_post_pad) { fail.store(SS_EINVAL); return; }
+          poff[w++] = (uint32_t)rel;
+          n++;
+        }
+        for (u64 pad = (4 - (n & 3)) & 3; pad > 0; pad--) poff[w++] = (uint32_t)rel;
+      }
+      if (w != tbase[v + 1] * 4ull) { fail.store(SS_EINVAL); return; }  // the walk must land on the merged list's end: same entries as the image's
+    }
+  });
+  if (fail.load()) return fail.load();
+  const u64 total = tstart[n_terms];
   pbase[nv] = total;
-  if (total != n_positions) return SS_EINVAL;
   SS_HIP(hipMalloc(&s->d_pos32, pool.size() * sizeof(uint32_t)));
   SS_HIP(hipMalloc(&s->d_pos_off, poff.size() * sizeof(uint32_t)));
   SS_HIP(hipMalloc(&s->d_pos_base, pbase.size() * sizeof(u64)));

@@ -177,6 +177,22 @@ def test_drop_in_rehearsal_on_a_million_doc_index_bin(S, O):
     assert all(v["errors"] == 0 for v in r["concurrent_callers"].values())
 
 
+def test_drop_in_rehearsal_on_an_index_bin_with_three_fields(S, O):
+    """the same rehearsal over THREE indexed fields (title / body / tags spans; multi-field records and n-gram keys with their
+    components' field vectors in the file, BM25F boosts): tiers with the rare keys' merged lists in the sparse tier, positions of both
+    tiers, 2-term ANDs (also under a field filter), 3-term ORs, phrases inside one field over keys of either tier, vector + hybrid --
+    every answer against the BM25F oracle over the mini indexer's own (doc, field) entries; 64 callers through the C++ mirror"""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import real_format
+    r = real_format.run(n_docs=400_000, vocab=400_000, n_queries=48, seconds=0.4, n_fields=3)
+    assert r["indexed_fields"] == 3 and r["files"]["ngram_keys"] > 10_000
+    assert r["open"]["sparse_terms"] > 300_000 and r["open"]["dense_terms"] > 500
+    assert r["queries"]["phrases_with_ngram_keys"] > 0 and r["queries"]["ors_naming_a_sparse_term"] > 0
+    assert set(r["parity"]["queries"]) == {"and2", "or3", "and2_body", "phrase", "vector", "hybrid"}
+    assert all(v["errors"] == 0 for v in r["concurrent_callers"].values())
+
+
 def _level_slices(n_docs, offs, docs, tfs, n_terms=None):
     """CSR of a corpus -> per 65 536-doc level (doclen slice bounds, offs, docs, tfs) over the first n_terms terms"""
     nt = len(offs) - 1 if n_terms is None else n_terms

@@ -984,6 +984,50 @@ def _python_writer_of(T, RF, O, key_head_size, positions_limit):
     return terms, ngt, lut
 
 
+@pytest.mark.parametrize("head,limit,n_fields,longest", [(23, 32768, 3, 1), (22, 300, 2, 0), (20, 32768, 3, 2)])
+def test_c_indexer_multi_field_writes_what_the_restated_python_writer_writes(head, limit, n_fields, longest):
+    """... with SEVERAL indexed fields (the docs' tokens cut into consecutive spans; field vectors in front of the records, embedded
+    pointers with field tags, n-gram records with their components' field vectors): the same bytes as oracle/ref_format.py; the
+    product's walker and multi-field decoder read every key back"""
+    from oracle import oracle as O, textindex as TI
+    T = TI.TextCorpus(11, 30_000, 2500, n_frequent=12, mean_len=12.0, topic_share=0.4, n_fields=n_fields, longest_field=longest)
+    assert T.n_ngram_keys > 100 and T.doclen_fields.shape == (n_fields, T.n_docs)
+    data = T.write_index_bin(key_head_size=head, positions_limit=limit)
+    lut = lambda df: int(O.lib().so_int_to_byte4(int(df)))
+    terms, ng_terms = [], []
+    for k in range(T.n_keys):
+        if T.key_df(k) == 0:
+            continue
+        h = T.key_hash(k)
+        docs, flds, tfs, cnt, pos = T.key_entries(k, 0)
+        own = cnt > 0
+        per = [p.tolist() for p in np.split(pos, np.cumsum(cnt[own].astype(np.int64))[:-1])] if own.any() else []
+        if k < T.vocab:
+            assert own.all() and np.array_equal(tfs, cnt)
+            terms.append((h, docs.astype(np.int64), flds.astype(np.int64), tfs.astype(np.int64), per))
+            continue
+        nc = 2 if (h & 7) == 1 else 3
+        if nc > head - 20:
+            continue
+        vecs = {}
+        for c in range(nc):
+            cd, cf, ct, _, _ = T.key_entries(k, c, positions=False)
+            for d_, f_, t_ in zip(cd.tolist(), cf.tolist(), ct.tolist()):
+                vecs.setdefault(d_, [[] for _ in range(nc)])[c].append((f_, t_))
+        d0, f0 = int(docs[own][0]), int(flds[own][0])
+        toks = T.doc_field_tokens(d0, f0)
+        ranks = [int(toks[per[0][0] + i]) for i in range(nc)]
+        assert T.ngram_key(ranks) == k
+        ng_terms.append((h, docs[own].astype(np.int64), flds[own].astype(np.int64), cnt[own].astype(np.int64), vecs, [lut(T.key_df(r)) for r in ranks], per))
+    ref = RF.write_index_bin(T.n_docs, T.doclen_fields, terms, np.random.default_rng(0), key_head_size=head, positions_limit=limit, n_fields=n_fields,
+                             longest_field_id=longest, ngram_terms=ng_terms)
+    assert len(data) == len(ref)
+    assert data == ref
+    ix = S.IndexBin(data, n_fields, key_head_size=head)
+    assert ix.indexed_doc_count == T.n_docs and ix.term_count >= len(terms)
+    ix.close()
+
+
 @pytest.mark.parametrize("head,limit", [(23, 32768), (22, 300), (20, 32768)])
 def test_c_indexer_writes_what_the_restated_python_writer_writes(head, limit):
     """oracle/ss_textindex.c (the mini indexer that produces config-size index.bin files) against oracle/ref_format.py (the restated

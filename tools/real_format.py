@@ -34,7 +34,10 @@ def vector_bin(rows, dim):
     return bytes(out)
 
 
-def run(n_docs=1_000_000, vocab=1_000_000, dim=64, n_queries=96, dense_min=2000, k=10, seed=11, parity=True, callers=64, seconds=1.0, log=None):
+def run(n_docs=1_000_000, vocab=1_000_000, dim=64, n_queries=96, dense_min=2000, k=10, seed=11, parity=True, callers=64, seconds=1.0, log=None,
+        n_fields=1, boost=None):
+    """n_fields > 1: the same rehearsal over an index with several indexed fields (title / body / tags spans of every doc; BM25F with
+    `boost`, multi-field records and n-gram keys in the file, the sparse tier's merged lists, phrases inside one field, field-filtered ANDs)"""
     import seekstorm_amd as S
     from seekstorm_amd import _native as N
     from seekstorm_amd.search import idf_f32
@@ -45,8 +48,12 @@ def run(n_docs=1_000_000, vocab=1_000_000, dim=64, n_queries=96, dense_min=2000,
     out = {"docs": n_docs, "vocabulary": vocab}
     # ---- the files (test infrastructure: the mini indexer)
     t0 = time.perf_counter()
-    T = TI.TextCorpus(seed, n_docs, vocab, n_frequent=64, mean_len=100.0, topic_share=0.35)
+    MF = n_fields > 1
+    if MF and boost is None:
+        boost = [2.0, 1.0, 0.5, 0.25][:n_fields]
+    T = TI.TextCorpus(seed, n_docs, vocab, n_frequent=64, mean_len=100.0, topic_share=0.35, n_fields=n_fields, longest_field=1 if MF else 0)
     data = T.write_index_bin(key_head_size=23)
+    out["indexed_fields"] = n_fields
     rng = np.random.default_rng(seed)
     rows = O.vec_gen(O.VEC_SEED, 0, n_docs, dim)
     vbin = vector_bin(rows, dim)
@@ -58,13 +65,13 @@ def run(n_docs=1_000_000, vocab=1_000_000, dim=64, n_queries=96, dense_min=2000,
     # ---- open: walk, tier, decode, upload (what open_shard's end would call)
     sh = S.Shard(0)
     t0 = time.perf_counter()
-    ix = S.IndexBin(data, key_head_size=23)
+    ix = S.IndexBin(data, n_fields, key_head_size=23)
     t_open = time.perf_counter() - t0
     t0 = time.perf_counter()
     n_dense = ix.tier(dense_min)
     t_tier = time.perf_counter() - t0
     t0 = time.perf_counter()
-    sh.upload_index_bin(ix, positions=True)
+    sh.upload_index_bin(ix, boost, positions=True)
     t_up = time.perf_counter() - t0
     t0 = time.perf_counter()
     sh.upload_vector_bin(vbin, dim)
@@ -103,9 +110,14 @@ def run(n_docs=1_000_000, vocab=1_000_000, dim=64, n_queries=96, dense_min=2000,
             pick = [uniq[i] for i in rng.choice(len(uniq), 3, replace=False)]  # any ranks: rare terms live in the sparse tier
             ors.append(pick)
         if len(phrases) < n_queries:
-            st = int(rng.integers(0, len(toks) - 4))
+            ptoks = toks
+            if MF:  # a phrase stands inside ONE field
+                ptoks = T.doc_field_tokens(d, int(rng.integers(0, n_fields)))
+                if len(ptoks) < 5:
+                    ptoks = T.doc_field_tokens(d, 1)
+            st = int(rng.integers(0, len(ptoks) - 4))
             ln = int(rng.integers(2, 5))
-            win = [int(r) for r in toks[st:st + ln]]
+            win = [int(r) for r in ptoks[st:st + ln]]
             ents = T.query_entries(win)
             ok = len(ents) >= 2 and all(e[0] is not None and T.key_df(e[0]) > 0 for e in ents)  # keys of either tier (a rare word: the sparse phrase kernel)
             if ok and sum(len(e[1]) for e in ents) <= N.SS_MAX_PHRASE:
@@ -125,7 +137,10 @@ def run(n_docs=1_000_000, vocab=1_000_000, dim=64, n_queries=96, dense_min=2000,
     qv = O.vec_gen(O.VECQ_SEED, 0, n_queries, dim)
     res = {}
     lat = {}
-    for name, q in (("and2", q_and), ("or3", q_or), ("phrase", q_ph)):
+    legs = [("and2", q_and), ("or3", q_or), ("phrase", q_ph)]
+    if MF:  # every term must stand in the body (field 1): intersections under a field filter, sparse-tier terms included
+        legs.append(("and2_body", sh.make_queries([[single(r) for r in q] for q in ands], S.QueryType.Intersection, field_filter=[1])))
+    for name, q in legs:
         res[name] = sh.search_lexical_batch(q, k, S.ResultType.TopkCount)
         t0 = time.perf_counter()
         reps = 0
@@ -138,6 +153,8 @@ def run(n_docs=1_000_000, vocab=1_000_000, dim=64, n_queries=96, dense_min=2000,
     # hybrid: the OR query + the vector, RRF over the two top-k lists (search.rs:1962-2035)
     hyb = [S.merge_results(S.SearchMode.Hybrid, (res["or3"][0][i][:res["or3"][2][i]].astype(np.uint64), res["or3"][1][i][:res["or3"][2][i]]),
                            (res["vec"][0][i][:res["vec"][2][i]].astype(np.uint64), res["vec"][1][i][:res["vec"][2][i]]), 0, k) for i in range(n_queries)]
+    if MF:
+        lat["mean_and_body_matches"] = float(res["and2_body"][3].mean())
     out["queries"] = dict(lat, n=n_queries, mean_and_matches=float(res["and2"][3].mean()), mean_or_matches=float(res["or3"][3].mean()),
                           mean_phrase_matches=float(res["phrase"][3].mean()),
                           phrases_with_ngram_keys=int(sum(any(len(e[1]) > 1 for e in q) for q in phrases)),
@@ -145,7 +162,58 @@ def run(n_docs=1_000_000, vocab=1_000_000, dim=64, n_queries=96, dense_min=2000,
                           ors_naming_a_sparse_term=int(sum(any(single(r) >= n_dense for r in q) for q in ors)))
     say("queries", out["queries"])
     # ---- parity: every query against the oracle on the corpus' own lists
-    if parity:
+    if parity and MF:
+        t0 = time.perf_counter()
+        keys = sorted({r for q in ands + ors for r in q} | {e[0] for q in phrases for e in q})
+        o_offs, o_docs, o_flds, o_tfs, o_cnt, o_pos, o_id = [0], [], [], [], [], [], {}
+        for key in keys:
+            for c in range(len(tid(key))):
+                docs, flds, tfs, cnt, pos = T.key_entries(key, c, positions=(c == 0))
+                o_id[(key, c)] = len(o_offs) - 1
+                o_docs.append(docs); o_flds.append(flds); o_tfs.append(tfs); o_cnt.append(cnt); o_pos.append(pos)
+                o_offs.append(o_offs[-1] + len(docs))
+        A = dict(offs=np.asarray(o_offs, np.uint64), docs=np.concatenate(o_docs), flds=np.concatenate(o_flds), tfs=np.concatenate(o_tfs),
+                 cnt=np.concatenate(o_cnt), pos=np.concatenate(o_pos))
+        dlf = T.doclen_fields
+        gone_l = [int(x) for x in gone]
+        for name, qs, oop, filt in (("and2", ands, O.OP_AND, ()), ("or3", ors, O.OP_OR, ()), ("and2_body", ands, O.OP_AND, (1,))):
+            doc, score, cnt, tot = res[name]
+            for i, q in enumerate(qs):
+                od, os_, otot, _ = O.search_fields_exhaustive(n_docs, dlf, boost, A["offs"], A["docs"], A["flds"], A["tfs"], [o_id[(r, 0)] for r in q], oop,
+                                                              k, (), gone_l, field_filter=filt)
+                assert int(tot[i]) == otot, f"real format ({n_fields} fields), {name} query {i}: count {int(tot[i])} vs oracle {otot}"
+                F.check_topk(doc[i][:cnt[i]], score[i][:cnt[i]], od, os_, 1e-4, f"real format ({n_fields} fields), {name} query {i}")
+        doc, score, cnt, tot = res["phrase"]
+        for i, q in enumerate(phrases):
+            uniq, seq, places, idf, at = [], [], [], [], 0
+            for e in q:
+                comp = tid(e[0])
+                lists = [o_id[(e[0], c)] for c in range(len(comp))]
+                for c, l in enumerate(lists):
+                    if l not in uniq:
+                        uniq.append(l)
+                        a_, b_ = int(A["offs"][l]), int(A["offs"][l + 1])
+                        idf.append(comp[c][1] if comp[c][1] is not None else float(idf_f32(n_docs, len(np.unique(A["docs"][a_:b_])))))
+                seq.append(uniq.index(lists[0])); places.append(at)
+                at += len(e[1])
+            od, os_, otot = O.search_fields_phrase_items(n_docs, dlf, boost, A["offs"], A["docs"], A["flds"], A["tfs"], A["cnt"], A["pos"], uniq, seq, places,
+                                                         k, idf=idf, deleted=gone_l, reference_loop=False)
+            assert otot >= 1 and int(tot[i]) == otot, f"real format ({n_fields} fields), phrase {i}: count {int(tot[i])} vs oracle {otot}"
+            F.check_topk(doc[i][:cnt[i]], score[i][:cnt[i]], od, os_, 1e-4, f"real format ({n_fields} fields), phrase {i}")
+        vd, vs, vc, _ = res["vec"]
+        for i in range(min(n_queries, 16)):
+            od, os_, _, _ = O.vec_search(rows, qv[i], k, deleted=gone)
+            F.check_topk(vd[i][:vc[i]], vs[i][:vc[i]], od, os_, 1e-4, f"real format, vector query {i}")
+            ol = (res["or3"][0][i][:res["or3"][2][i]].astype(np.uint64), res["or3"][1][i][:res["or3"][2][i]])
+            hd, hs, _ = O.merge(2, ol, (vd[i][:vc[i]].astype(np.uint64), vs[i][:vc[i]]), 0, k)
+            assert np.array_equal(hyb[i][0], hd) and np.allclose(hyb[i][1], hs, rtol=1e-6), f"real format, hybrid query {i}"
+        out["parity"] = {"queries": {"and2": len(ands), "or3": len(ors), "and2_body": len(ands), "phrase": len(phrases), "vector": min(n_queries, 16),
+                                     "hybrid": min(n_queries, 16)},
+                         "checked": "exact result_count_total, top-k ids outside the tie band, scores rtol 1e-4 against the BM25F oracle over the mini "
+                                    "indexer's own (doc, field) entries, positions and n-gram component field vectors; phrases inside one field; "
+                                    "intersections under a field filter; 0.5 % of the docs tombstoned through delete.bin", "seconds": time.perf_counter() - t0}
+        say("parity", out["parity"])
+    elif parity:
         t0 = time.perf_counter()
         keys = sorted({r for q in ands + ors for r in q} | {e[0] for q in phrases for e in q})
         o_offs, o_docs, o_tfs, o_pos, o_cnt, o_id = [0], [], [], [], [], {}
@@ -230,5 +298,6 @@ if __name__ == "__main__":
     import sys
     sys.path.insert(0, ROOT)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-    r = run(n_docs=n, vocab=n, log=lambda *a: print(*a, flush=True))
+    nf = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    r = run(n_docs=n, vocab=n, n_fields=nf, log=lambda *a: print(*a, flush=True))
     print(json.dumps(r))
