@@ -353,11 +353,16 @@ int ssi_bm25_upload_fields_positions(ss_shard* s, uint64_t n_docs, uint32_t n_fi
                                      uint32_t n_terms, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
                                      const uint16_t* tfs, uint64_t positions_sum, const uint16_t* positions, uint64_t n_positions, const uint16_t* npos) {
   if (n_fields < 2) return SS_EINVAL;  // one indexed field: ss_bm25_upload_positions
+  static const bool trace = getenv("SS_LOAD_TRACE") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
   int rc = ssi_bm25_upload_fields(s, n_docs, n_fields, doclen, boost, n_terms, offs, docs, fields, tfs, positions_sum);
   if (rc) return rc;
+  const auto t1 = std::chrono::steady_clock::now();
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   rc = ssi_bm25_upload_positions_fields(s, n_terms, offs, docs, fields, tfs, positions, n_positions, npos);
+  if (trace) fprintf(stderr, "[load]   fields image %.0f ms, positions %.0f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
   if (rc) free_bm25(s);  // a failure leaves no image behind
   return rc;
 }
@@ -433,7 +438,10 @@ int ssi_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, cons
     s->bm_n_terms = nv;
     s->bm_n_sub = (uint32_t)((n_docs + BM_SUB - 1) >> BM_SUB_LOG2);
     float scale = 1.0f;
+    const auto tb0 = std::chrono::steady_clock::now();
     rc = ssi_bm25_build_from_host_merged(s, doclen, voff.data(), vdocs.data(), vtfs.data(), positions_sum, merged ? b.data() : nullptr, &scale);
+    if (getenv("SS_LOAD_TRACE")) fprintf(stderr, "[load]     build_from_host_merged %.0f ms (attempt %d)\n",
+                                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count(), attempt);
     if (rc == SS_MERGED_RANGE) continue;  // the merged weights span more than the code: again, without merged lists
     if (rc == SS_OK) {
       std::vector<float> bb = b;
@@ -929,6 +937,30 @@ __global__ void probe_row_fill_kernel(const uint32_t* __restrict__ pairs /* (lis
   probe[gi] = make_uint2((uint32_t)m, (uint32_t)(m >> 32));
   probe_z[gi] = u0 * 4u + run;
   if (sb == 0 && lane == 0) probe_row[t] = r;
+}
+
+// the FIXED probe rows of a host-built image, from the image itself (ssi_bm25_build_from_host_merged): the rows used to be assembled on
+// the host and copied -- 188 KB per list and million docs, 4.5 GB for the 23 760 lists of a 1 M-doc 3-field index: 1.0 s of zeroing
+// and bit setting + 0.45 s of pageable copies, against a pass over the uploaded postings here
+extern "C++" int ssi_bm25_fill_fixed_probe_rows(ss_shard* s, hipStream_t st) {
+  if (!s->d_probe || !s->bm_probe_rows) return SS_OK;
+  std::vector<uint32_t> pairs;
+  for (uint32_t t = 0; t < s->bm_n_terms; t++)
+    // (an EMPTY list may own a row as well -- alloc_probe deals rows before it points the row-less empty lists at the zero row: built too, as zeros)
+    if (s->h_probe_row[t] != BM_NO_PROBE_ROW && s->h_probe_row[t] < s->bm_probe_rows) { pairs.push_back(t); pairs.push_back(s->h_probe_row[t]); }
+  const uint32_t n = (uint32_t)(pairs.size() / 2);
+  if (!n) return SS_OK;
+  uint32_t* d_pairs = nullptr;
+  SS_HIP(hipMalloc(&d_pairs, pairs.size() * sizeof(uint32_t)));
+  int rc = hipMemcpyAsync(d_pairs, pairs.data(), pairs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st) == hipSuccess ? SS_OK : SS_EDEVICE;
+  if (rc == SS_OK) {
+    const unsigned long long waves = (unsigned long long)n * s->bm_n_sub;
+    probe_row_fill_kernel<<<(unsigned)((waves + 3) / 4), 256, 0, st>>>(d_pairs, n, s->bm_n_sub, s->d_sub_off, (const unsigned long long*)s->d_term_base,
+                                                                     s->d_post, s->d_probe, s->d_probe_z, s->d_probe_row);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = SS_EDEVICE;
+  }
+  (void)hipFree(d_pairs);
+  return rc;
 }
 
 // the lists of a term that a query reads: the merged list alone without a field filter (bm_merged images), else the fields'

@@ -509,6 +509,7 @@ void ssi_prof_end(ss_shard* s, int kernel, hipStream_t st, hipEvent_t e0, hipEve
 int ssi_bm25_rebuild_from_raw(const ss_shard* s, const std::vector<ss_raw_level>& levels, uint32_t n_terms, const uint8_t* doclen, uint64_t n_doclen,
                               ss_shard* img, hipStream_t st, bool one_shot = false);
 // ---- sparse tier (synth.hip: append; bm25_sparse.hip: kernels)
+int ssi_bm25_fill_fixed_probe_rows(ss_shard* s, hipStream_t st);  // the fixed probe rows from the uploaded postings (ss_api.hip)
 int ssi_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
                            const uint16_t* positions = nullptr, uint64_t n_positions = 0, const uint16_t* npos = nullptr);
 int ssi_bm25_append_sparse_fields(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields, const uint16_t* tfs,

@@ -184,6 +184,14 @@ int ssi_bm25_build_from_host_merged(ss_shard* s, const uint8_t* doclen, const ui
   const uint32_t nt = s->bm_n_terms, ns = s->bm_n_sub;
   const uint32_t L = s->bm_n_fields, RF = bm_real_fields(s);  // lists per term, indexed fields
   if (s->bm_merged && (!merged_boost || !merged_scale)) return SS_EINVAL;
+  static const bool trace = getenv("SS_LOAD_TRACE") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    const auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[load]       %s %.0f ms\n", what, std::chrono::duration<double, std::milli>(n - t_prev).count());
+    t_prev = n;
+  };
   u64 psum = 0;
   if (positions_sum) psum = positions_sum;
   else
@@ -252,6 +260,7 @@ int ssi_bm25_build_from_host_merged(ss_shard* s, const uint8_t* doclen, const ui
     }
     *merged_scale = mscale;
   }
+  lap("merged weights");
   // pass 1: validate, segment boundaries in 16-byte units (4 postings, zero padded) relative to the term base
   // (the per-term loops below run on the loader's worker threads: a term's rows, postings and probe row are its own)
   std::vector<uint32_t> sub((size_t)nt * (ns + 1));
@@ -311,6 +320,7 @@ int ssi_bm25_build_from_host_merged(ss_shard* s, const uint8_t* doclen, const ui
    }
   });
   if (fail.load()) return fail.load();
+  lap("segments + packing");
   s->bm_n_post = offs[nt];
   const size_t rows = (size_t)nt * (ns + 1);
   int rc = alloc_post(s, units);
@@ -327,38 +337,14 @@ int ssi_bm25_build_from_host_merged(ss_shard* s, const uint8_t* doclen, const ui
     SS_HIP(hipMalloc(&s->d_doclen, (size_t)RF * s->bm_n_docs));
     SS_HIP(hipMemcpy(s->d_doclen, doclen, (size_t)RF * s->bm_n_docs, hipMemcpyHostToDevice));
   }
+  lap("image arrays to the device");
   rc = alloc_probe(s, s->stream);
   if (rc) return rc;
   SS_HIP(hipStreamSynchronize(s->stream));
-  std::vector<uint2> probe;
-  std::vector<uint32_t> probe_z;
-  if (s->d_probe) probe.assign((size_t)s->bm_probe_rows * ns * BM_GROUPS, make_uint2(0, 0));
-  probe_z.assign(probe.size(), 0u);
-  if (s->d_probe)
-    ss_parallel_for(nt, 16, [&](size_t ta, size_t tb, unsigned) {  // (every term sets bits in its own row)
-      for (size_t t = ta; t < tb; t++) {
-        if (s->h_probe_row[t] == BM_NO_PROBE_ROW) continue;
-        for (u64 j = offs[t]; j < offs[t + 1]; j++) {
-          const uint32_t sb = docs[j] >> BM_SUB_LOG2, d = docs[j] & (BM_SUB - 1);
-          uint2* row = probe.data() + ((size_t)s->h_probe_row[t] * ns + sb) * BM_GROUPS;
-          const uint32_t g = d >> 6, b = d & 63;
-          if (b < 32) row[g].x |= 1u << b; else row[g].y |= 1u << (b - 32);
-        }
-      }
-    });
-  std::vector<uint32_t> term_of_row(s->bm_probe_rows, 0);
-  for (uint32_t t = 0; t < nt; t++)
-    if (s->d_probe && s->h_probe_row[t] != BM_NO_PROBE_ROW) term_of_row[s->h_probe_row[t]] = t;
-  ss_parallel_for(probe.size() / BM_GROUPS, 4096, [&](size_t ra, size_t rb, unsigned) {  // z = index (inside the term) of the group's first posting
-    for (size_t rr = ra; rr < rb; rr++) {
-      const size_t r = rr * BM_GROUPS, t = term_of_row[rr / ns], sb = rr % ns;
-      uint32_t run = sub[t * (ns + 1) + sb] * 4u;
-      for (int g = 0; g < BM_GROUPS; g++) {
-        probe_z[r + g] = run;
-        run += (uint32_t)__builtin_popcount(probe[r + g].x) + (uint32_t)__builtin_popcount(probe[r + g].y);
-      }
-    }
-  });
+  // the fixed probe rows: built on the device from the postings just uploaded (ssi_bm25_fill_fixed_probe_rows)
+  rc = ssi_bm25_fill_fixed_probe_rows(s, s->stream);
+  if (rc) return rc;
+  lap("probe rows");
   SS_HIP(hipMemcpy(s->d_umax, umax.data(), umax.size() * sizeof(float), hipMemcpyHostToDevice));
   SS_HIP(hipMemcpy(s->d_submax, submax.data(), submax.size() * sizeof(float), hipMemcpyHostToDevice));
   // Are block maxima worth a pass per search?  Only where they vary over the doc ids: for the longest lists, the mean over
@@ -384,11 +370,7 @@ int ssi_bm25_build_from_host_merged(ss_shard* s, const uint8_t* doclen, const ui
     }
     s->bm_partmax = worst < 0.9;
   }
-  if (s->d_probe && !probe.empty())
-  {
-    SS_HIP(hipMemcpy(s->d_probe, probe.data(), probe.size() * sizeof(uint2), hipMemcpyHostToDevice));
-    SS_HIP(hipMemcpy(s->d_probe_z, probe_z.data(), probe_z.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  }
+
   return SS_OK;
 }
 
