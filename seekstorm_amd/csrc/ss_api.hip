@@ -44,6 +44,12 @@ int with_facet_filter(ss_shard* s, uint32_t n_filters, const ss_facet_filter* fi
 }
 }  // namespace
 
+// SS_CO_TRACE: where a coalesced lexical batch spends its time (sums in us; printed when the shard is destroyed)
+struct CoTrace { std::atomic<uint64_t> n{0}, stage{0}, enqueue{0}, wait{0}, scatter{0}, linger{0}; };
+static CoTrace g_co_trace;
+static const bool g_co_trace_on = getenv("SS_CO_TRACE") != nullptr;
+static inline uint64_t co_now_us() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 extern "C" {
 
 int ss_abi_version(void) { return SS_ABI_VERSION; }
@@ -167,6 +173,12 @@ static void free_bm25(ss_shard* s) {
 
 int ss_shard_destroy(ss_shard* s) {
   if (!s) return SS_EINVAL;
+  if (g_co_trace_on && g_co_trace.n.load()) {
+    const double n = (double)g_co_trace.n.load() * 1000.0;  // ns -> us per batch
+    fprintf(stderr, "[co] %llu lexical batches: stage %.1f us, search call %.1f us (enqueue %.1f + device wait %.1f), scatter %.1f us per batch\n",
+            (unsigned long long)g_co_trace.n.load(), g_co_trace.stage.load() / n, g_co_trace.wait.load() / n, g_co_trace.enqueue.load() / n,
+            g_co_trace.linger.load() / n, g_co_trace.scatter.load() / n);
+  }
   (void)hipSetDevice(s->device);
   (void)hipStreamSynchronize(s->stream);
   free_vec(s);
@@ -1386,13 +1398,31 @@ static int bm25_search_direct(ss_shard* s, uint32_t nq, const ss_bm25_query* q, 
 // the same for a coalesced batch on a lane: the shard mutex is held while the batch is ENQUEUED (queries from the lane's pinned staging,
 // kernels, results back into it, the lane's event behind them -- all on s->stream); the wait for the event happens outside, so the next
 // lane's leader can enqueue behind this batch at once
+// the answers of a coalesced batch straight into the leader's PINNED buffers: one small kernel writing over PCIe instead of four
+// device-to-host copies queued one behind the other (each a DMA submission of ~8 us for a few KB)
+__global__ void co_pack_kernel(const uint32_t* __restrict__ d_doc, const float* __restrict__ d_score, const uint32_t* __restrict__ d_count,
+                               const unsigned long long* __restrict__ d_total, uint32_t nq, uint32_t kk, uint32_t* __restrict__ h_doc,
+                               float* __restrict__ h_score, uint32_t* __restrict__ h_count, unsigned long long* __restrict__ h_total) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nq * kk) { h_doc[i] = d_doc[i]; h_score[i] = d_score[i]; }
+  if (i < nq) { h_count[i] = d_count[i]; h_total[i] = d_total[i]; }
+}
 static int bm25_search_direct_lane(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k, uint32_t rt, uint32_t* out_doc, float* out_score,
                                    uint32_t* out_count, uint64_t* out_total, hipEvent_t ev) {
+  static const int pack = [] { const char* e = getenv("SS_COALESCE_PACK"); return e ? atoi(e) : 0; }();  // measured: no difference -- off
+  const uint64_t t_in = g_co_trace_on ? co_now_us() : 0;
   {
     std::lock_guard<std::mutex> g(s->mu);
     if (!s->d_post) return SS_ESTATE;
     const uint32_t kk = rt == SS_RT_COUNT ? 0 : k;
     SS_TRY(bm25_search_host_queries(s, nq, q, kk, rt, 0, nullptr));
+    if (pack) {
+      const uint32_t n = std::max<uint32_t>(nq * kk, nq);
+      co_pack_kernel<<<(n + 255) / 256, 256, 0, s->stream>>>(s->d_out_doc, s->d_out_score, s->d_out_count, (const unsigned long long*)s->d_out_total, nq, kk,
+                                                            out_doc, out_score, out_count, (unsigned long long*)out_total);
+      SS_HIP(hipGetLastError());
+      SS_HIP(hipEventRecord(ev, s->stream));
+    } else {
     if (kk) {
       SS_HIP(hipMemcpyAsync(out_doc, s->d_out_doc, (size_t)nq * kk * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
       SS_HIP(hipMemcpyAsync(out_score, s->d_out_score, (size_t)nq * kk * sizeof(float), hipMemcpyDeviceToHost, s->stream));
@@ -1400,8 +1430,11 @@ static int bm25_search_direct_lane(ss_shard* s, uint32_t nq, const ss_bm25_query
     SS_HIP(hipMemcpyAsync(out_count, s->d_out_count, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     SS_HIP(hipMemcpyAsync(out_total, s->d_out_total, (size_t)nq * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
     SS_HIP(hipEventRecord(ev, s->stream));
+    }
   }
+  const uint64_t te = g_co_trace_on ? co_now_us() : 0;
   SS_HIP(hipEventSynchronize(ev));
+  if (g_co_trace_on) { g_co_trace.enqueue += te - t_in; g_co_trace.linger += co_now_us() - te; }
   return SS_OK;
 }
 
@@ -1492,18 +1525,21 @@ int co_run_batch(ss_shard* s, ss_coalescer& co, bool lexical, const std::vector<
   float* h_sc = (float*)(ln.h_pin + o_sc);
   uint32_t* h_cnt = (uint32_t*)(ln.h_pin + o_cnt);
   uint64_t* h_tot = (uint64_t*)(ln.h_pin + o_tot);
+  const uint64_t tr0 = g_co_trace_on ? co_now_us() : 0;
   uint32_t at = 0;
   for (ss_co_req* r : batch) {
     memcpy(h_q + (size_t)at * qbytes, r->q, (size_t)r->nq * qbytes);
     if (f->qscale) memcpy(h_qs + at, r->qscale, (size_t)r->nq * sizeof(float));
     at += r->nq;
   }
+  const uint64_t tr1 = g_co_trace_on ? co_now_us() : 0;
   int rc;
   if (lexical)
     rc = bm25_search_direct_lane(s, total, (const ss_bm25_query*)h_q, kk, f->rt, h_doc, h_sc, h_cnt, h_tot, ln.ev);
   else
     rc = vec_search_host(s, total, h_q, f->elem, f->qscale ? h_qs : nullptr, kk, f->thr, nullptr, h_doc, h_sc, h_cnt, h_tot, nullptr);
   if (rc != SS_OK) return rc;
+  const uint64_t tr2 = g_co_trace_on ? co_now_us() : 0;
   at = 0;
   for (ss_co_req* r : batch) {
     for (uint32_t i = 0; i < r->nq; i++) {
@@ -1516,6 +1552,9 @@ int co_run_batch(ss_shard* s, ss_coalescer& co, bool lexical, const std::vector<
     }
     r->rc = SS_OK;
     at += r->nq;
+  }
+  if (g_co_trace_on && lexical) {
+    g_co_trace.n++; g_co_trace.stage += tr1 - tr0; g_co_trace.wait += tr2 - tr1; g_co_trace.scatter += co_now_us() - tr2;
   }
   return SS_OK;
 }

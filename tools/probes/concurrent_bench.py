@@ -14,7 +14,7 @@ docs, rows, dim = int(os.environ.get("DOCS", 10_000_000)), int(os.environ.get("R
 sh = S.Shard(0)
 tl, th = bench.make_c2_queries(O, 1000)
 sh.synth_lexical(O.LEX_SEED, docs, th, O.len_table())
-sh.synth_vectors(O.VEC_SEED, rows, dim)
+sh.synth_vectors(O.VEC_SEED, rows if not os.environ.get('LEX_ONLY') else 1024, dim)
 qv = O.vec_gen(O.VECQ_SEED, 0, 64, dim)
 HL = C.CDLL(os.path.join(ROOT, "seekstorm_amd", "lib", "libseekstorm_host.so"))
 HL.ssh_index_adopt.restype = C.c_void_p
@@ -24,8 +24,11 @@ HL.ssh_bench_concurrent.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_double,
 ix = HL.ssh_index_adopt(1, (C.c_void_p * 1)(sh._h), (C.c_int * 1)(0))
 flat = np.array([t for q in tl for t in q], np.uint32)
 toff = np.zeros(len(tl) + 1, np.uint32); toff[1:] = np.cumsum([len(q) for q in tl])
-for name, mode, nq, length in (("lexical", N.MODE_LEXICAL, 1000, 10), ("vector", N.MODE_VECTOR, 64, 100), ("hybrid", N.MODE_HYBRID, 64, 100)):
-    for T in (1, 8, 64, 256, 1024):
+LEGS = (("lexical", N.MODE_LEXICAL, 1000, 10), ("vector", N.MODE_VECTOR, 64, 100), ("hybrid", N.MODE_HYBRID, 64, 100))
+if os.environ.get("LEX_ONLY"):
+    LEGS = LEGS[:1]
+for name, mode, nq, length in LEGS:
+    for T in ((8, 64, 256) if os.environ.get("LEX_ONLY") else (1, 8, 64, 256, 1024)):
         out = (C.c_double * 5)()
         s0 = sh.coalescing_stats()
         N.check(HL.ssh_bench_concurrent(ix, mode, T, secs, nq, flat.ctypes.data, toff.ctypes.data, qv.ctypes.data, int(S.QueryType.Union), length,
@@ -34,3 +37,4 @@ for name, mode, nq, length in (("lexical", N.MODE_LEXICAL, 1000, 10), ("vector",
         lb, lq, vb, vq = (s1[i] - s0[i] for i in range(4))
         print("%-8s T=%-4d %9.0f q/s  p50 %8.1f us  p99 %9.1f us  errors %d  lexical batch %s  vector batch %s" % (
             name, T, out[0] / out[1], out[2], out[3], int(out[4]), "%.1f" % (lq / lb) if lb else "-", "%.1f" % (vq / vb) if vb else "-"), flush=True)
+sh.close()
