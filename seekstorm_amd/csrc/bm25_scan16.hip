@@ -67,6 +67,16 @@ __device__ __forceinline__ uint32_t s16_qm(uint32_t p, float fidf) {
 // whose doc's entry is still 0 is the doc's FIRST posting in this item (every bound is >= 1, the tile is all zero when an item
 // starts), so |A u B u ...| = sum over the postings of [entry was 0].  One ballot + scalar popcount per posting step; the NULL
 // postings (dump slot) are kept out by p != 0.  The f32 kernel's count mode scans every tile densely instead (5.8 vs 1.4 ms).
+// S16_LANE_COUNT: the count of a posting step kept per LANE (one v_addc) and summed over the wave once per partition, instead of a
+// ballot + scalar popcount per step (a VALU -> SALU hand-over each)
+#ifndef S16_LANE_COUNT
+#define S16_LANE_COUNT 1
+#endif
+#if S16_LANE_COUNT
+#define S16_CNT(c) ((c) ? 1u : 0u)
+#else
+#define S16_CNT(c) ((uint32_t)__popcll(__ballot(c)))
+#endif
 template <bool CNT>
 __device__ __forceinline__ uint32_t s16_first(const u32x4 v, float fidf, uint32_t accb, uint32_t mx, uint32_t& cnt) {
   const uint32_t pv[4] = {v.x, v.y, v.z, v.w};
@@ -75,7 +85,7 @@ __device__ __forceinline__ uint32_t s16_first(const u32x4 v, float fidf, uint32_
     const uint32_t q = s16_qm(pv[x], fidf);
     lds_st16(s16_addr(pv[x], accb), q);
     mx = max(mx, q);
-    if (CNT) cnt += (uint32_t)__popcll(__ballot(pv[x] != 0u));
+    if (CNT) cnt += S16_CNT(pv[x] != 0u);
   }
   return mx;
 }
@@ -93,7 +103,7 @@ __device__ __forceinline__ uint32_t s16_read(const u32x4 v, float fidf, uint32_t
   for (int x = 0; x < 4; x++) {
     nw[x] = old[x] + s16_qm(pv[x], fidf);
     mx = max(mx, nw[x]);
-    if (CNT) cnt += (uint32_t)__popcll(__ballot(old[x] == 0u && pv[x] != 0u));
+    if (CNT) cnt += S16_CNT(old[x] == 0u && pv[x] != 0u);
   }
   return mx;
 }
@@ -219,7 +229,7 @@ __device__ __forceinline__ uint32_t s16a_last(const u32x4 v, float fidf, uint32_
     const bool m = (old[x] & 3u) == level && pv[x] != 0u;  // (a NULL posting reads whatever the dump slot holds)
     const uint32_t sum = (old[x] >> 2) + s16_q(pv[x], fidf);
     mx = max(mx, m ? sum : 0u);
-    if (CNT) cnt += (uint32_t)__popcll(__ballot(m));
+    if (CNT) cnt += S16_CNT(m);
     if (WRITE) lds_st16(ad[x], m ? ((sum << 2) | 3u) : old[x]);
   }
   return mx;
@@ -886,6 +896,17 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
   u64* out = part_keys + ((size_t)qi * P + part) * (64 * KPL);
 #pragma unroll
   for (int r = 0; r < KPL; r++) out[r * 64 + lane] = T.keys[r];
+#if S16_LANE_COUNT
+  if (CNT) {
+    uint32_t lo = (uint32_t)T.matched, hi = (uint32_t)(T.matched >> 32);
+    for (int o = 32; o > 0; o >>= 1) {
+      const u64 other = ((u64)__shfl_xor(hi, o) << 32) | __shfl_xor(lo, o);
+      const u64 sum = (((u64)hi << 32) | lo) + other;
+      lo = (uint32_t)sum; hi = (uint32_t)(sum >> 32);
+    }
+    T.matched = ((u64)hi << 32) | lo;
+  }
+#endif
   if (CNT && lane == 0 && T.matched) atomicAdd(&total[qi], T.matched);
 }
 
