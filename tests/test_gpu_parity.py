@@ -1298,6 +1298,13 @@ def test_result_sort_by_facets(S, O, lex):
                     assert ctot == tot and len(cd) == len(doc) and np.allclose(cs, score, rtol=1e-6)
                     for name, _ in srt:
                         assert np.array_equal(v[name][cd], v[name][doc])
+            # more queries than one chunk of the batched pipeline holds (64): rows repeat with the queries
+            big = np.concatenate([qb] * 50)
+            bd2, bs2, bc2, bt2 = sh.search_lexical_sorted_batch(big, [(off["c"], ty["c"], True)], 12)
+            b0 = sh.search_lexical_sorted_batch(qb, [(off["c"], ty["c"], True)], 12)
+            for i in range(len(big)):
+                j = i % len(qb)
+                assert int(bt2[i]) == int(b0[3][j]) and int(bc2[i]) == int(b0[2][j]) and np.array_equal(bd2[i], b0[0][j]) and np.array_equal(bs2[i], b0[1][j])
     finally:
         sh.set_deleted([])
         osh.set_deleted([])
