@@ -315,6 +315,13 @@ int ss_bm25_sparse_info(ss_shard* s, uint32_t* n_lists, uint64_t* n_postings, ui
  * Searches keep running on the previous image until the new one is swapped in (the call then waits for the searches in flight). */
 int ss_bm25_append_level(ss_shard* s, uint32_t level, uint32_t n_level_docs, const uint8_t* level_doclen, uint32_t n_terms,
                          const uint64_t* term_offsets /*[n_terms+1]*/, const uint32_t* doc_ids, const uint16_t* tfs);
+/* ... with the postings' POSITIONS, so that phrase queries work on an image that grows by commits: positions = every posting's in CSR
+ * order (ascending inside a posting), tf of them each, or npos[i] where that is not the tf (npos may be NULL) -- the component terms of
+ * an n-gram key, whose own positions stand behind its FIRST component's postings (ss_bm25_upload_index_bin_positions).  Every level of
+ * an image brings positions, or none does (SS_EINVAL).  The position arrays of the image are rebuilt on the device with the rest. */
+int ss_bm25_append_level_positions(ss_shard* s, uint32_t level, uint32_t n_level_docs, const uint8_t* level_doclen, uint32_t n_terms,
+                                   const uint64_t* term_offsets, const uint32_t* doc_ids, const uint16_t* tfs, const uint16_t* npos,
+                                   const uint16_t* positions, uint64_t n_positions);
 int ss_bm25_incremental_info(ss_shard* s, uint32_t* n_levels, uint64_t* raw_bytes, double* last_append_ms, double* last_rebuild_ms);
 /* Search strategy.  AUTO: requests with <= 4 scored terms and k <= 128 take the PRUNED path (the reference's block-max /
  * sub-query pruning, intersection.rs:2224-2233, union.rs:1355-1405, as MaxScore over a probe index: only essential /

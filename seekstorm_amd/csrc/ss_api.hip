@@ -152,7 +152,7 @@ static void free_vec(ss_shard* s) {
 }
 static void free_raw_levels(ss_shard* s) {
   for (ss_raw_level& L : s->raw)
-    for (void* p : {(void*)L.d_off, (void*)L.d_doc, (void*)L.d_tf}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)L.d_off, (void*)L.d_doc, (void*)L.d_tf, (void*)L.d_npos, (void*)L.d_prel, (void*)L.d_tpos, (void*)L.d_pos}) if (p) (void)hipFree(p);
   s->raw.clear();
   s->h_doclen.clear();
 }
@@ -511,8 +511,23 @@ int ss_bm25_synth(ss_shard* s, uint64_t seed, uint64_t n_docs, uint32_t n_terms,
 // scan, fill -- the raw postings read once, the image written once): a commit costs the level's H2D + a few milliseconds per GB of
 // image, not a host pass over the shard.  The new image is built beside the old one; searches keep running on the old image until the
 // swap, which waits for the searches in flight and releases the old arrays.
+static int append_level_impl(ss_shard* s, uint32_t level, uint32_t n_level_docs, const uint8_t* level_doclen, uint32_t n_terms, const uint64_t* offs,
+                             const uint32_t* docs, const uint16_t* tfs, bool with_pos, const uint16_t* npos, const uint16_t* positions, uint64_t n_positions);
 int ss_bm25_append_level(ss_shard* s, uint32_t level, uint32_t n_level_docs, const uint8_t* level_doclen, uint32_t n_terms, const uint64_t* offs,
                          const uint32_t* docs, const uint16_t* tfs) {
+  return append_level_impl(s, level, n_level_docs, level_doclen, n_terms, offs, docs, tfs, false, nullptr, nullptr, 0);
+}
+// ... with the postings' POSITIONS (phrase queries on an image that grows by commits): positions = every posting's, in CSR order, tf of
+// them each -- or npos[i] where that is not the tf (npos may be NULL): the component terms of an n-gram key, whose own positions stand
+// behind its first component's postings.  Every level of an image brings positions, or none does.
+int ss_bm25_append_level_positions(ss_shard* s, uint32_t level, uint32_t n_level_docs, const uint8_t* level_doclen, uint32_t n_terms,
+                                   const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs, const uint16_t* npos, const uint16_t* positions,
+                                   uint64_t n_positions) {
+  if (n_positions && !positions) return SS_EINVAL;
+  return append_level_impl(s, level, n_level_docs, level_doclen, n_terms, offs, docs, tfs, true, npos, positions, n_positions);
+}
+static int append_level_impl(ss_shard* s, uint32_t level, uint32_t n_level_docs, const uint8_t* level_doclen, uint32_t n_terms, const uint64_t* offs,
+                             const uint32_t* docs, const uint16_t* tfs, bool with_pos, const uint16_t* npos, const uint16_t* positions, uint64_t n_positions) {
   if (!s || !level_doclen || !offs || n_terms == 0 || n_level_docs == 0 || n_level_docs > 65536u) return SS_EINVAL;
   if (offs[n_terms] && (!docs || !tfs)) return SS_EINVAL;
   const auto t_begin = std::chrono::steady_clock::now();
@@ -529,24 +544,65 @@ int ss_bm25_append_level(ss_shard* s, uint32_t level, uint32_t n_level_docs, con
     if ((uint64_t)level * 65536u + n_level_docs > 0xFFFFFFFFull) return SS_ENOTSUP;
     nt_old = s->raw.empty() ? 0u : s->bm_n_terms;
     if (n_terms < nt_old) return SS_EINVAL;                    // the vocabulary only grows; new terms get the next ids
+    if (level > 0 && (s->raw[0].d_tpos != nullptr) != with_pos) return SS_EINVAL;  // positions for every level of an image, or for none
     levels.assign(s->raw.begin(), s->raw.begin() + level);
     doclen.assign(s->h_doclen.begin(), s->h_doclen.begin() + (size_t)level * 65536u);
   }
   // validation: docs of a term ascending and inside the level
   const uint64_t d_lo = (uint64_t)level * 65536u, d_hi = d_lo + n_level_docs;
-  for (uint32_t t = 0; t < n_terms; t++) {
+  for (uint32_t t = 0; t < n_terms; t++)
     if (offs[t + 1] < offs[t]) return SS_EINVAL;
-    for (uint64_t j = offs[t]; j < offs[t + 1]; j++)
-      if (docs[j] < d_lo || docs[j] >= d_hi || tfs[j] == 0 || (j > offs[t] && docs[j] <= docs[j - 1])) return SS_EINVAL;
+  {
+    std::atomic<int> bad{0};
+    ss_parallel_for(n_terms, 64, [&](size_t ta, size_t tb, unsigned) {
+      for (size_t t = ta; t < tb; t++)
+        for (uint64_t j = offs[t]; j < offs[t + 1]; j++)
+          if (docs[j] < d_lo || docs[j] >= d_hi || tfs[j] == 0 || (j > offs[t] && docs[j] <= docs[j - 1])) { bad.store(1); return; }
+    });
+    if (bad.load()) return SS_EINVAL;
   }
   ss_raw_level L;
   L.n_docs = n_level_docs; L.n_terms = n_terms; L.n_post = offs[n_terms] - offs[0];
   for (uint32_t d = 0; d < n_level_docs; d++) L.psum += ss_byte4_to_int(level_doclen[d]);
+  // positions: per posting its count, the positions of the term's earlier postings of this level, per term its first position
+  std::vector<uint16_t> h_npos;
+  std::vector<uint32_t> h_prel;
+  std::vector<uint64_t> h_tpos;
+  if (with_pos) {
+    h_npos.resize(L.n_post); h_prel.resize(L.n_post); h_tpos.assign((size_t)n_terms + 1, 0);
+    ss_parallel_for(n_terms, 64, [&](size_t ta, size_t tb, unsigned) {  // a term's positions: the sum of its postings' counts
+      for (size_t t = ta; t < tb; t++) {
+        uint64_t c = 0;
+        for (uint64_t j = offs[t]; j < offs[t + 1]; j++) c += npos ? npos[j] : tfs[j];
+        h_tpos[t + 1] = c;
+      }
+    });
+    for (uint32_t t = 0; t < n_terms; t++) h_tpos[t + 1] += h_tpos[t];
+    if (h_tpos[n_terms] != n_positions) return SS_EINVAL;
+    std::atomic<int> bad{SS_OK};
+    ss_parallel_for(n_terms, 64, [&](size_t ta, size_t tb, unsigned) {
+      for (size_t t = ta; t < tb; t++) {
+        const uint64_t at = h_tpos[t];
+        uint64_t rel = 0;
+        for (uint64_t j = offs[t]; j < offs[t + 1]; j++) {
+          const uint32_t c = npos ? npos[j] : tfs[j];
+          if (rel >= (1ull << 32)) { bad.store(SS_ENOTSUP); return; }
+          h_npos[j - offs[0]] = (uint16_t)c; h_prel[j - offs[0]] = (uint32_t)rel;
+          for (uint32_t x = 1; x < c; x++)
+            if (positions[at + rel + x] <= positions[at + rel + x - 1]) { bad.store(SS_EINVAL); return; }  // ascending inside a posting
+          rel += c;
+        }
+      }
+    });
+    if (bad.load()) return bad.load();
+    L.n_pos = n_positions;
+  }
   hipStream_t bst = nullptr;
   std::unique_ptr<ss_shard> img(new ss_shard);
   auto fail = [&](int rc) {
-    for (void* p : {(void*)L.d_off, (void*)L.d_doc, (void*)L.d_tf}) if (p) (void)hipFree(p);
-    void* ip[] = {img->d_post, img->d_term_base, img->d_sub_off, img->d_comp, img->d_probe, img->d_probe_z, img->d_probe_row, img->d_umax, img->d_submax, img->d_doclen};
+    for (void* p : {(void*)L.d_off, (void*)L.d_doc, (void*)L.d_tf, (void*)L.d_npos, (void*)L.d_prel, (void*)L.d_tpos, (void*)L.d_pos}) if (p) (void)hipFree(p);
+    void* ip[] = {img->d_post, img->d_term_base, img->d_sub_off, img->d_comp, img->d_probe, img->d_probe_z, img->d_probe_row, img->d_umax, img->d_submax, img->d_doclen,
+                  img->d_pos, img->d_pos_off, img->d_pos_base};
     for (void* p : ip) if (p && !s->blocks.release(p)) (void)hipFree(p);
     if (bst) (void)hipStreamDestroy(bst);
     return rc;
@@ -562,6 +618,18 @@ int ss_bm25_append_level(ss_shard* s, uint32_t level, uint32_t n_level_docs, con
   if (L.n_post) {
     SS_HIP_F(hipMemcpyAsync(L.d_doc, docs + offs[0], L.n_post * sizeof(uint32_t), hipMemcpyHostToDevice, bst));
     SS_HIP_F(hipMemcpyAsync(L.d_tf, tfs + offs[0], L.n_post * sizeof(uint16_t), hipMemcpyHostToDevice, bst));
+  }
+  if (with_pos) {
+    SS_HIP_F(hipMalloc(&L.d_npos, std::max<uint64_t>(L.n_post, 1) * sizeof(uint16_t)));
+    SS_HIP_F(hipMalloc(&L.d_prel, std::max<uint64_t>(L.n_post, 1) * sizeof(uint32_t)));
+    SS_HIP_F(hipMalloc(&L.d_tpos, h_tpos.size() * sizeof(uint64_t)));
+    SS_HIP_F(hipMalloc(&L.d_pos, std::max<uint64_t>(n_positions, 1) * sizeof(uint16_t)));
+    if (L.n_post) {
+      SS_HIP_F(hipMemcpyAsync(L.d_npos, h_npos.data(), L.n_post * sizeof(uint16_t), hipMemcpyHostToDevice, bst));
+      SS_HIP_F(hipMemcpyAsync(L.d_prel, h_prel.data(), L.n_post * sizeof(uint32_t), hipMemcpyHostToDevice, bst));
+    }
+    SS_HIP_F(hipMemcpyAsync(L.d_tpos, h_tpos.data(), h_tpos.size() * sizeof(uint64_t), hipMemcpyHostToDevice, bst));
+    if (n_positions) SS_HIP_F(hipMemcpyAsync(L.d_pos, positions, n_positions * sizeof(uint16_t), hipMemcpyHostToDevice, bst));
   }
   SS_HIP_F(hipStreamSynchronize(bst));  // (rel dies with this frame; the caller's arrays are free again)
   levels.push_back(L);
@@ -582,7 +650,8 @@ int ss_bm25_append_level(ss_shard* s, uint32_t level, uint32_t n_level_docs, con
     s->raw.clear();  // (free_bm25 must not release the levels that stay)
     {  // the old image's arrays go back to the block pool: the next commit builds into them
       void** op[] = {(void**)&s->d_post, (void**)&s->d_term_base, (void**)&s->d_sub_off, (void**)&s->d_comp, (void**)&s->d_probe, (void**)&s->d_probe_z,
-                     (void**)&s->d_probe_row, (void**)&s->d_umax, (void**)&s->d_submax, (void**)&s->d_doclen};
+                     (void**)&s->d_probe_row, (void**)&s->d_umax, (void**)&s->d_submax, (void**)&s->d_doclen, (void**)&s->d_pos, (void**)&s->d_pos_off,
+                     (void**)&s->d_pos_base};
       s->blocks.gen++;
       for (void** pp : op) if (*pp && s->blocks.release(*pp)) *pp = nullptr;
       std::vector<ss_block_pool::Idle> idle;
@@ -591,7 +660,10 @@ int ss_bm25_append_level(ss_shard* s, uint32_t level, uint32_t n_level_docs, con
       s->blocks.idle.swap(idle);
       s->blocks.trim(3);
     }
-    if (replace) for (void* p : {(void*)replaced.d_off, (void*)replaced.d_doc, (void*)replaced.d_tf}) if (p) (void)hipFree(p);
+    if (replace)
+      for (void* p : {(void*)replaced.d_off, (void*)replaced.d_doc, (void*)replaced.d_tf, (void*)replaced.d_npos, (void*)replaced.d_prel, (void*)replaced.d_tpos,
+                      (void*)replaced.d_pos})
+        if (p) (void)hipFree(p);
     keep.push_back(L);
     s->raw.swap(keep);
     s->h_doclen.swap(doclen);
@@ -600,6 +672,7 @@ int ss_bm25_append_level(ss_shard* s, uint32_t level, uint32_t n_level_docs, con
     s->d_post = img->d_post; s->d_term_base = img->d_term_base; s->d_sub_off = img->d_sub_off; s->d_comp = img->d_comp;
     s->d_probe = img->d_probe; s->d_probe_z = img->d_probe_z; s->d_probe_row = img->d_probe_row; s->d_umax = img->d_umax; s->d_submax = img->d_submax;
     s->d_doclen = img->d_doclen;
+    s->d_pos = img->d_pos; s->d_pos_off = img->d_pos_off; s->d_pos_base = img->d_pos_base;
     s->h_df.swap(img->h_df); s->h_probe_row.swap(img->h_probe_row); s->bm_probe_rows = img->bm_probe_rows;
     s->probe_pool_begin = img->probe_pool_begin; s->probe_pool_rows = img->probe_pool_rows; s->pool_list.swap(img->pool_list); s->pool_tick.swap(img->pool_tick);
     s->pool_clock = 0;
@@ -615,7 +688,8 @@ int ss_bm25_incremental_info(ss_shard* s, uint32_t* n_levels, uint64_t* raw_byte
   if (!s) return SS_EINVAL;
   std::lock_guard<std::mutex> g(s->mu);
   uint64_t b = 0;
-  for (const ss_raw_level& L : s->raw) b += ((uint64_t)L.n_terms + 1) * 8u + L.n_post * 6u;
+  for (const ss_raw_level& L : s->raw)
+    b += ((uint64_t)L.n_terms + 1) * 8u + L.n_post * 6u + (L.d_tpos ? ((uint64_t)L.n_terms + 1) * 8u + L.n_post * 6u + L.n_pos * 2u : 0u);
   if (n_levels) *n_levels = (uint32_t)s->raw.size();
   if (raw_bytes) *raw_bytes = b;
   if (last_append_ms) *last_append_ms = s->raw_last_append_ms;

@@ -170,6 +170,12 @@ struct ss_raw_level {
   uint64_t* d_off = nullptr;         // [n_terms + 1]
   uint32_t* d_doc = nullptr;         // shard-local doc ids, ascending inside a term
   uint16_t* d_tf = nullptr;
+  // positions (ss_bm25_append_level_positions; all levels of an image carry them, or none)
+  uint16_t* d_npos = nullptr;        // [n_post] positions of every posting (tf, or what the caller said: n-gram component terms)
+  uint32_t* d_prel = nullptr;        // [n_post] positions of the term's earlier postings IN THIS LEVEL
+  uint64_t* d_tpos = nullptr;        // [n_terms + 1] first position of every term in d_pos
+  uint16_t* d_pos = nullptr;         // the level's positions, term after term, posting after posting, ascending
+  uint64_t n_pos = 0;
 };
 
 // Device blocks of an incremental image, recycled from commit to commit.  Every commit builds a slightly larger image beside the old

@@ -409,7 +409,10 @@ static int bm_decide_partmax_dev(ss_shard* img) {
 // commit costs a rebuild at HBM speed instead of a host pass + PCIe: the raw postings are read once, the image written once.
 __global__ void lex_scan_rows_kernel(uint32_t* __restrict__ sub, uint32_t n_sub, u64* __restrict__ term_tot);
 __global__ void lex_scan_terms_kernel(const u64* __restrict__ tot, u64* __restrict__ base, uint32_t n_terms);
-struct RawLevelDev { const unsigned long long* off; const uint32_t* doc; const uint16_t* tf; uint32_t n_terms, pad; };
+struct RawLevelDev {
+  const unsigned long long* off; const uint32_t* doc; const uint16_t* tf; uint32_t n_terms, pad;
+  const uint16_t* npos; const uint32_t* prel; const unsigned long long* tpos; const uint16_t* pos;  // positions (or null)
+};
 __device__ __forceinline__ void raw_segment(const RawLevelDev* __restrict__ levels, uint32_t level_shift, uint32_t t, uint32_t sb, u64* lo_out,
                                             u64* hi_out, const uint32_t** doc_out, const uint16_t** tf_out) {
   const RawLevelDev L = levels[sb >> level_shift];  // incremental images: a level = 65 536 docs = 16 sub-blocks; a one-shot upload: one "level"
@@ -491,6 +494,68 @@ __global__ void raw_fill_kernel(const RawLevelDev* __restrict__ levels, uint32_t
   }
 }
 
+// ---- positions of an incremental image (phrase queries after commits): what ssi_bm25_upload_positions builds on the host, from the
+// levels' own position pools.  d_pos = every term's positions, term after term, level after level (= doc order); d_pos_base = a term's
+// first; d_pos_off = per image slot the END of its posting's positions relative to the term (padding slots repeat the running end).
+// lstart [n_terms][n_levels]: positions of the term in the levels before level l (the two kernels below look it up per block / wave)
+__global__ void raw_pos_total_kernel(const RawLevelDev* __restrict__ levels, uint32_t n_levels, uint32_t n_terms, u64* __restrict__ tot,
+                                     u64* __restrict__ lstart) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_terms) return;
+  u64 c = 0;
+  for (uint32_t l = 0; l < n_levels; l++) {
+    lstart[(size_t)t * n_levels + l] = c;
+    if (t < levels[l].n_terms) c += levels[l].tpos[t + 1] - levels[l].tpos[t];
+  }
+  tot[t] = c;
+}
+// one block per (term, level): the level's positions of the term into the term's pool, behind the earlier levels'
+__global__ void raw_pos_copy_kernel(const RawLevelDev* __restrict__ levels, uint32_t n_levels, uint32_t n_terms, const u64* __restrict__ pos_base,
+                                    const u64* __restrict__ lstart, uint16_t* __restrict__ pos) {
+  const uint32_t t = blockIdx.x, l = blockIdx.y;
+  if (t >= levels[l].n_terms) return;
+  const u64 a = levels[l].tpos[t], b = levels[l].tpos[t + 1];
+  if (a == b) return;
+  const u64 at = pos_base[t] + lstart[(size_t)t * n_levels + l];
+  const uint16_t* __restrict__ src = levels[l].pos + a;
+  for (u64 i = threadIdx.x; i < b - a; i += blockDim.x) pos[at + i] = src[i];
+}
+// one wave per (term, sub-block): the END offsets of the segment's postings
+__global__ void raw_pos_off_kernel(const RawLevelDev* __restrict__ levels, uint32_t n_levels, uint32_t level_shift, uint32_t n_terms, uint32_t n_sub,
+                                   const uint32_t* __restrict__ sub, const u64* __restrict__ term_base, const u64* __restrict__ lstart,
+                                   uint32_t* __restrict__ pos_off) {
+  const int lane = threadIdx.x & 63;
+  const u64 gw = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (gw >= (u64)n_terms * n_sub) return;
+  const uint32_t t = (uint32_t)(gw / n_sub), sb = (uint32_t)(gw % n_sub);
+  u64 lo, hi;
+  const uint32_t* dp; const uint16_t* tp;
+  raw_segment(levels, level_shift, t, sb, &lo, &hi, &dp, &tp);
+  const uint32_t li = sb >> level_shift;
+  const RawLevelDev L = levels[li];
+  // positions of the term before this segment: the earlier levels' + the earlier postings of this level
+  u64 start = lstart[(size_t)t * n_levels + li];
+  const uint32_t seg0 = sub[(size_t)t * (n_sub + 1) + sb] * 4u, seg1 = sub[(size_t)t * (n_sub + 1) + sb + 1] * 4u;
+  const u64 base = term_base[t] * 4ull + seg0;
+  const uint32_t n = (uint32_t)(hi - lo);
+  if (n) start += L.prel[lo];
+  else if (t < L.n_terms) {  // an empty segment: the running end = the positions of the postings before its place
+    const u64 a = L.off[t], b = L.off[t + 1];
+    start += lo < b ? (u64)L.prel[lo] : (L.tpos[t + 1] - L.tpos[t]);
+    (void)a;
+  }
+  u64 run = start;
+  for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+    const uint32_t i = i0 + (uint32_t)lane;
+    uint32_t c = i < n ? (uint32_t)L.npos[lo + i] : 0u, inc = c;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+    if (i < n) pos_off[base + i] = (uint32_t)(run + inc);
+    run += (u64)__shfl(inc, 63);
+  }
+  const uint32_t pad = seg1 - seg0 - n;  // NULL padding slots of the segment (0 .. 3)
+  if ((uint32_t)lane < pad) pos_off[base + n + lane] = (uint32_t)run;
+}
+
 // one_shot: `levels` holds ONE set of arrays covering every doc (a whole-image upload builds through the same kernels: the host then
 // only validates and copies), the image arrays are plain allocations and `img` may be the shard itself
 int ssi_bm25_rebuild_from_raw(const ss_shard* s, const std::vector<ss_raw_level>& levels, uint32_t n_terms, const uint8_t* doclen, uint64_t n_doclen,
@@ -512,7 +577,15 @@ int ssi_bm25_rebuild_from_raw(const ss_shard* s, const std::vector<ss_raw_level>
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   const auto t0 = now();
   std::vector<RawLevelDev> lv(levels.size());
-  for (size_t i = 0; i < levels.size(); i++) lv[i] = RawLevelDev{(const unsigned long long*)levels[i].d_off, levels[i].d_doc, levels[i].d_tf, levels[i].n_terms, 0u};
+  for (size_t i = 0; i < levels.size(); i++)
+    lv[i] = RawLevelDev{(const unsigned long long*)levels[i].d_off, levels[i].d_doc, levels[i].d_tf, levels[i].n_terms, 0u,
+                        levels[i].d_npos, levels[i].d_prel, (const unsigned long long*)levels[i].d_tpos, levels[i].d_pos};
+  const bool with_pos = !levels.empty() && levels[0].d_tpos != nullptr;
+  u64 n_positions = 0;
+  for (const ss_raw_level& L : levels) {
+    if ((L.d_tpos != nullptr) != with_pos) return SS_EINVAL;  // positions for every level or for none
+    n_positions += L.n_pos;
+  }
   RawLevelDev* d_lv = nullptr;
   u64 *d_tot = nullptr, *d_df = nullptr;
   uint8_t* d_flg = nullptr;
@@ -563,6 +636,26 @@ int ssi_bm25_rebuild_from_raw(const ss_shard* s, const std::vector<ss_raw_level>
                                                               (const u64*)img->d_term_base, img->d_post, img->d_probe, img->d_probe_z,
                                                               img->d_probe_row, (uint32_t*)img->d_umax, img->d_submax, d_flg);
   SS_HIP_C(hipGetLastError());
+  if (with_pos) {  // the position arrays, from the levels' pools
+    u64 *d_ptot = nullptr, *d_lstart = nullptr;
+    SS_HIP_C(hipMalloc(&d_ptot, (size_t)nt * sizeof(u64)));
+    if (hipMalloc(&d_lstart, (size_t)nt * lv.size() * sizeof(u64)) != hipSuccess) { (void)hipFree(d_ptot); cleanup(); return SS_ENOMEM; }
+    auto drop = [&]() { (void)hipFree(d_ptot); (void)hipFree(d_lstart); };
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = img_malloc(img, &img->d_pos_base, ((size_t)nt + 1) * sizeof(u64));
+    if (e == hipSuccess) e = img_malloc(img, &img->d_pos, (size_t)std::max<u64>(n_positions, 1) * sizeof(uint16_t));
+    if (e == hipSuccess) e = img_malloc(img, &img->d_pos_off, ((size_t)img->bm_n_post_pad + 8) * sizeof(uint32_t));
+    if (e != hipSuccess) { drop(); cleanup(); return e == hipErrorOutOfMemory ? SS_ENOMEM : SS_EDEVICE; }
+    raw_pos_total_kernel<<<(nt + 255) / 256, 256, 0, st>>>(d_lv, (uint32_t)lv.size(), nt, d_ptot, d_lstart);
+    lex_scan_terms_kernel<<<1, 64, 0, st>>>(d_ptot, (u64*)img->d_pos_base, nt);
+    raw_pos_copy_kernel<<<dim3(nt, (uint32_t)lv.size()), 256, 0, st>>>(d_lv, (uint32_t)lv.size(), nt, (const u64*)img->d_pos_base, d_lstart, img->d_pos);
+    raw_pos_off_kernel<<<(uint32_t)((pairs + 3) / 4), 256, 0, st>>>(d_lv, (uint32_t)lv.size(), level_shift, nt, ns, img->d_sub_off,
+                                                                    (const u64*)img->d_term_base, d_lstart, img->d_pos_off);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    drop();
+    if (e != hipSuccess) { cleanup(); return SS_EDEVICE; }
+  }
   SS_HIP_C(hipStreamSynchronize(st));
   const auto t4 = now();
   // block maxima worth a pass per search?  (the host builder's rule, on the 64 longest lists)

@@ -374,15 +374,22 @@ class Shard:
         self.lexical_field_count = 1
         self._df_cache.clear()
 
-    def append_level(self, level, level_doclen, term_offsets, doc_ids, tfs):
+    def append_level(self, level, level_doclen, term_offsets, doc_ids, tfs, positions=None, npos=None):
         """one committed 65 536-doc level (commit.rs:142-148): its docs' length bytes and per term (shard-local doc id, tf); level =
-        levels committed so far (append) or the last one (re-commit of a partial level)"""
+        levels committed so far (append) or the last one (re-commit of a partial level).
+        positions: every posting's positions in CSR order (phrase queries after commits); npos: their number per posting where not tf"""
         dl = np.ascontiguousarray(level_doclen, np.uint8)
         off = np.ascontiguousarray(term_offsets, np.uint64)
         d = np.ascontiguousarray(doc_ids, np.uint32)
         t = np.ascontiguousarray(tfs, np.uint16)
-        N.check(N.lib().ss_bm25_append_level(self._h, int(level), len(dl), N.ptr(dl, N.u8p), len(off) - 1, N.ptr(off, N.u64p), N.ptr(d, N.u32p),
-                                             N.ptr(t, N.u16p)), "ss_bm25_append_level")
+        if positions is not None:
+            ps = np.ascontiguousarray(positions, np.uint16)
+            npc = None if npos is None else np.ascontiguousarray(npos, np.uint16)
+            N.check(N.lib().ss_bm25_append_level_positions(self._h, int(level), len(dl), N.ptr(dl, N.u8p), len(off) - 1, N.ptr(off, N.u64p), N.ptr(d, N.u32p),
+                                                           N.ptr(t, N.u16p), N.ptr(npc, N.u16p), N.ptr(ps, N.u16p), len(ps)), "ss_bm25_append_level_positions")
+        else:
+            N.check(N.lib().ss_bm25_append_level(self._h, int(level), len(dl), N.ptr(dl, N.u8p), len(off) - 1, N.ptr(off, N.u64p), N.ptr(d, N.u32p),
+                                                 N.ptr(t, N.u16p)), "ss_bm25_append_level")
         self.indexed_doc_count = int(level) * 65536 + len(dl)
         self.lexical_field_count = 1
         self._df_cache.clear()

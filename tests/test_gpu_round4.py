@@ -591,3 +591,55 @@ def test_i8_vector_rows_appended_equal_the_one_shot_upload(S, O):
                 _same_answers(inc.search_vector_batch_i8(qs, k, None if euclid else qsc), ref.search_vector_batch_i8(qs, k, None if euclid else qsc))
             ref.close()
         inc.close()
+
+
+def test_append_levels_with_positions_answer_phrases_like_the_one_shot_upload(S, O):
+    """ss_bm25_append_level_positions: an image that grows by commits serves PHRASE queries -- the position arrays (pool, per-slot end
+    offsets, per-term bases) are rebuilt on the device from the levels' own pools.  After every level: phrases (2 - 4 words, repeated
+    words, NOT terms), unions and intersections == a one-shot upload with positions of the docs committed so far"""
+    from test_gpu_phrase import _corpus
+    n_docs = 200_000  # 3 full levels + a partial one
+    dfs = [30_000, 22_000, 40_000, 9_000, 700]
+    plant = [([0, 1], 500), ([0, 1, 2], 200), ([2, 0, 2], 150), ([3, 4], 80), ([1, 1], 90), ([4, 0, 1, 3], 40)]
+    dl, offs, docs, tfs, positions = _corpus(O, n_docs, dfs, 41, plant)
+    pstart = np.zeros(len(docs) + 1, np.int64)
+    pstart[1:] = np.cumsum(tfs.astype(np.int64))
+    nt = len(dfs)
+    inc = S.Shard(0)
+    phrases = [[0, 1], [1, 0], [0, 1, 2], [2, 0, 2], [3, 4], [1, 1], [4, 0, 1, 3], [2, 2]]
+    sets = [[0, 1], [2, 3, 4], [0, 4]]
+    n_levels = (n_docs + 65535) >> 16
+    for l in range(n_levels):
+        d0, d1 = l << 16, min(n_docs, (l + 1) << 16)
+        lo, ld, lt, lp = [0], [], [], []
+        for t in range(nt):
+            a, b = int(offs[t]), int(offs[t + 1])
+            i0, i1 = a + int(np.searchsorted(docs[a:b], d0)), a + int(np.searchsorted(docs[a:b], d1))
+            ld.append(docs[i0:i1]); lt.append(tfs[i0:i1]); lp.append(positions[pstart[i0]:pstart[i1]]); lo.append(lo[-1] + (i1 - i0))
+        inc.append_level(l, dl[d0:d1], np.asarray(lo, np.uint64), np.concatenate(ld), np.concatenate(lt), positions=np.concatenate(lp))
+        # the reference image: everything committed so far, uploaded at once
+        ro, rd, rt_, rp = [0], [], [], []
+        for t in range(nt):
+            a, b = int(offs[t]), int(offs[t + 1])
+            i1 = a + int(np.searchsorted(docs[a:b], d1))
+            rd.append(docs[a:i1]); rt_.append(tfs[a:i1]); rp.append(positions[pstart[a]:pstart[i1]]); ro.append(ro[-1] + (i1 - a))
+        ref = S.Shard(0)
+        ref.upload_lexical(d1, dl[:d1], np.asarray(ro, np.uint64), np.concatenate(rd), np.concatenate(rt_), np.concatenate(rp))
+        assert inc.fields_info()[2] == 1  # positions present
+        for k in (10, 100):
+            for rt in (S.ResultType.TopkCount, S.ResultType.Count):
+                a = inc.search_lexical_batch(inc.make_queries(phrases, S.QueryType.Phrase), k, rt)
+                b = ref.search_lexical_batch(ref.make_queries(phrases, S.QueryType.Phrase), k, rt)
+                _same(a, b, ("phrases", l, k, rt))
+        a = inc.search_lexical_batch(inc.make_queries([[0, 1], [3, 4]], S.QueryType.Phrase, [[2], [0]]), 10)
+        b = ref.search_lexical_batch(ref.make_queries([[0, 1], [3, 4]], S.QueryType.Phrase, [[2], [0]]), 10)
+        _same(a, b, ("phrases with NOT terms", l))
+        for qt in (S.QueryType.Union, S.QueryType.Intersection):
+            _same(inc.search_lexical_batch(inc.make_queries(sets, qt), 10), ref.search_lexical_batch(ref.make_queries(sets, qt), 10), ("sets", l, qt))
+        ref.close()
+    assert int(inc.search_lexical_batch(inc.make_queries([[0, 1]], S.QueryType.Phrase), 10)[3][0]) >= 500
+    # a level without positions after levels with them is refused
+    from seekstorm_amd import _native as N
+    with pytest.raises(N.SeekStormHipError):
+        inc.append_level(n_levels - 1, dl[(n_levels - 1) << 16:], np.asarray(lo, np.uint64), np.concatenate(ld), np.concatenate(lt))
+    inc.close()

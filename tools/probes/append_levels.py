@@ -33,7 +33,12 @@ for lv in range(n_levels):
     offs[1:] = np.cumsum([int(b[lv + 1] - b[lv]) for b in bounds])
     docs = np.concatenate([parts[i][0][bounds[i][lv]:bounds[i][lv + 1]] for i in range(len(terms))]).astype(np.uint32)
     tfs = np.concatenate([parts[i][1][bounds[i][lv]:bounds[i][lv + 1]] for i in range(len(terms))]).astype(np.uint16)
-    inc.append_level(lv, dl[lo:hi], offs, docs, tfs)
+    if os.environ.get("POS"):  # with positions (POS=1): 0 .. tf - 1 of every posting -- the content is irrelevant to the commit's cost
+        st = np.zeros(len(tfs) + 1, np.int64); st[1:] = np.cumsum(tfs.astype(np.int64))
+        positions = (np.arange(st[-1], dtype=np.int64) - np.repeat(st[:-1], tfs.astype(np.int64))).astype(np.uint16)
+        inc.append_level(lv, dl[lo:hi], offs, docs, tfs, positions=positions)
+    else:
+        inc.append_level(lv, dl[lo:hi], offs, docs, tfs)
     _, raw_b, a, b = inc.incremental_info()
     ms_all.append(a); ms_dev.append(b)
     if lv % 16 == 0 or lv == n_levels - 1:
