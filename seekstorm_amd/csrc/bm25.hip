@@ -348,6 +348,13 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   // small batches: beyond ~150 waves the probe kernel gains nothing and every extra partition is one more list to merge
   // (single query on C2: 0.128 ms at P = n_sub = 2442, 0.086 ms at P = 128)
   if (pruned || phrase) P = std::min<uint32_t>(P, 160u);
+  // Round 4, the pruned kernel re-measured over the batch sizes the coalescer forms and the headline's (tools/probes/small_batch_p.py,
+  // pruned_p_sweep.py): at most 64 partitions -- the lists of <= 64 partitions are merged by ONE tournament launch --, and about 4096
+  // waves in all, but never fewer than 16 partitions (150 sub-blocks per wave at 10 M docs): host-pointer calls of 8 / 64 / 145 / 256
+  // queries 179 -> 159 / 280 -> 229 / 385 -> 290 / 488 -> 390 us, device-resident calls of 256 / 500 / 1000 queries 0.407 -> 0.275 /
+  // 0.440 -> 0.39 / 0.625 -> 0.586 ms against the "four rounds, at most 160" rule above.
+  static const int p_rule = [] { const char* e = getenv("SS_BM25_P_RULE"); return e ? atoi(e) : 1; }();
+  if (pruned && p_rule) P = std::max<uint32_t>(16u, std::min<uint32_t>(64u, 4096u / std::max<uint32_t>(nq, 1u)));
   if (const char* e = getenv("SS_BM25_P")) P = (uint32_t)atoi(e);  // tuning override
   P = std::max<uint32_t>(1, std::min<uint32_t>(P, s->bm_n_sub));
   const size_t tau_words = (size_t)nq * BM_TAU_STRIDE / 2;  // u64 words: one 128-byte line per query
