@@ -195,6 +195,9 @@ int ss_index_bin_open(const uint8_t* bytes, uint64_t len, uint32_t indexed_field
  * image is built for the frequent terms that dominate query cost; a query touching a dropped term (ss_index_bin_term_keys
  * has no entry for it) is answered by the host's own path. */
 int ss_index_bin_filter(ss_index_bin* ix, uint64_t min_posting_count, uint32_t* n_terms_kept);
+/* Host only: decodes every key as the uploads do (worker threads) and reports the postings ((doc, field) entries with several indexed
+ * fields) and positions that came out -- what an open will have to move, and the decoder's speed on its own. */
+int ss_index_bin_decode_stats(const ss_index_bin* ix, int with_positions, uint64_t* n_postings_out, uint64_t* n_positions_out);
 /* Two tiers instead of dropping the tail: keys with at least dense_min_posting_count postings come first (ascending key hash) and
  * become the dense image's terms, the others follow (ascending key hash) and go to the SPARSE tier (ss_bm25_append_sparse) when
  * the index is uploaded with ss_bm25_upload_index_bin -- a real vocabulary's millions of rare keys then cost 8 bytes per posting,

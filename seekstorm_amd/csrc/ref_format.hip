@@ -933,6 +933,36 @@ int index_bin_decode_range(const ss_index_bin* ix, uint32_t t0, uint32_t t1, boo
 }
 }  // namespace
 
+namespace {
+int decode_fields_range(const ss_index_bin* ix, uint32_t t0, uint32_t t1, std::vector<uint64_t>& offs, std::vector<uint32_t>& docs,
+                        std::vector<uint8_t>& fields, std::vector<uint16_t>& tfs, std::vector<uint16_t>* pos, std::vector<uint16_t>* npos);
+}
+// Host only (no device): decodes every key of the index the way the uploads do -- on the loader's worker threads -- and reports what
+// came out.  For a host that wants to know what an open will cost before it takes the shard's write lock, and for timing the decoder
+// alone (tools/probes/decode_bench.py).
+extern "C" int ss_index_bin_decode_stats(const ss_index_bin* ix, int with_positions, uint64_t* n_postings_out, uint64_t* n_positions_out) {
+  if (!ix) return SS_EINVAL;
+  uint64_t npost = 0, npos = 0;
+  const uint32_t n_all = (uint32_t)ix->keys.size();
+  if (ix->n_fields == 1) {
+    DecodedRange D;
+    const int rc = index_bin_decode_range(ix, 0, n_all, with_positions != 0, &D);
+    if (rc) return rc;
+    npost = D.docs.size(); npos = D.pos.size();
+  } else {
+    std::vector<uint64_t> offs;
+    std::vector<uint32_t> docs;
+    std::vector<uint8_t> fields;
+    std::vector<uint16_t> tfs, pos, cnt;
+    const int rc = decode_fields_range(ix, 0, n_all, offs, docs, fields, tfs, with_positions ? &pos : nullptr, with_positions ? &cnt : nullptr);
+    if (rc) return rc;
+    npost = docs.size(); npos = pos.size();
+  }
+  if (n_postings_out) *n_postings_out = npost;
+  if (n_positions_out) *n_positions_out = npos;
+  return SS_OK;
+}
+
 extern "C" int ss_index_bin_term_postings(const ss_index_bin* ix, uint32_t term, uint64_t cap, uint32_t* docs_out,
                                           uint16_t* tfs_out, uint64_t* n_out) {
   if (!ix || term >= ix->keys.size() || !n_out) return SS_EINVAL;
