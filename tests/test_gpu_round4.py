@@ -643,3 +643,84 @@ def test_append_levels_with_positions_answer_phrases_like_the_one_shot_upload(S,
     with pytest.raises(N.SeekStormHipError):
         inc.append_level(n_levels - 1, dl[(n_levels - 1) << 16:], np.asarray(lo, np.uint64), np.concatenate(ld), np.concatenate(lt))
     inc.close()
+
+
+def test_append_levels_with_ngram_key_positions_against_the_oracle(S, O):
+    """the incremental image over a DEFAULT-index vocabulary: n-gram keys as their component terms, the key's own positions behind the
+    first component (npos), committed level by level with positions -- phrases resolved the way the query tokenizer resolves them
+    (greedy trigram / bigram keys over frequent words) against the oracle's phrase check over the mini indexer's own lists"""
+    from oracle import textindex as TI
+    from seekstorm_amd.search import idf_f32
+    T = TI.TextCorpus(5, 140_000, 3000, n_frequent=12, mean_len=8.0, topic_share=0.4)
+    n_docs = T.n_docs
+    term_of, lists = {}, []
+    for k in range(T.n_keys):
+        if T.key_df(k) == 0:
+            continue
+        nc = 1 if k < T.vocab else (2 if (T.key_hash(k) & 7) == 1 else 3)
+        for c in range(nc):
+            docs, tfs, cnt, pos = T.key_postings(k, c, positions=(c == 0))
+            term_of[(k, c)] = len(lists)
+            lists.append((docs, tfs, cnt if c == 0 else np.zeros(len(docs), np.uint16), pos if c == 0 else np.zeros(0, np.uint16)))
+    nt = len(lists)
+    pst = []
+    for docs, tfs, cnt, pos in lists:
+        p = np.zeros(len(docs) + 1, np.int64)
+        p[1:] = np.cumsum(cnt.astype(np.int64))
+        pst.append(p)
+    inc = S.Shard(0)
+    n_levels = (n_docs + 65535) >> 16
+    for l in range(n_levels):
+        d0, d1 = l << 16, min(n_docs, (l + 1) << 16)
+        lo, ld, lt, ln, lp = [0], [], [], [], []
+        for t, (docs, tfs, cnt, pos) in enumerate(lists):
+            i0, i1 = int(np.searchsorted(docs, d0)), int(np.searchsorted(docs, d1))
+            ld.append(docs[i0:i1]); lt.append(tfs[i0:i1]); ln.append(cnt[i0:i1]); lp.append(pos[pst[t][i0]:pst[t][i1]]); lo.append(lo[-1] + (i1 - i0))
+        inc.append_level(l, T.doclen[d0:d1], np.asarray(lo, np.uint64), np.concatenate(ld), np.concatenate(lt), positions=np.concatenate(lp),
+                         npos=np.concatenate(ln))
+    offs = np.zeros(nt + 1, np.uint64)
+    offs[1:] = np.cumsum([len(x[0]) for x in lists])
+    osh = O.Shard(n_docs, T.doclen, offs, np.concatenate([x[0] for x in lists]), np.concatenate([x[1] for x in lists]))
+    osh.set_positions(np.concatenate([x[3] for x in lists]), np.concatenate([x[2] for x in lists]))
+    rng = np.random.default_rng(2)
+    phrases = []
+    while len(phrases) < 60:
+        d = int(rng.integers(0, n_docs))
+        toks = T.doc_tokens(d)
+        if len(toks) < 6:
+            continue
+        st = int(rng.integers(0, len(toks) - 4))
+        ents = T.query_entries([int(r) for r in toks[st:st + int(rng.integers(2, 5))]])
+        if len(ents) >= 2 and all(e[0] is not None for e in ents):
+            phrases.append(ents)
+    assert any(len(e[1]) > 1 for q in phrases for e in q)  # some entries are n-gram keys
+    idf_of = {}
+    qlists = []
+    for q in phrases:
+        row = []
+        for key, ranks in q:
+            if len(ranks) == 1:
+                row.append(term_of[(key, 0)])
+            else:
+                comp = tuple(term_of[(key, c)] for c in range(len(ranks)))
+                for c, r in enumerate(ranks):
+                    idf_of[comp[c]] = float(idf_f32(n_docs, T.key_df(r)))  # idf_ngram_i: from the component TERM's posting count
+                row.append(comp)
+        qlists.append(row)
+    q = inc.make_queries(qlists, S.QueryType.Phrase, idf_of=idf_of)
+    doc, score, cnt, tot = inc.search_lexical_batch(q, 10, S.ResultType.TopkCount)
+    for i, ents in enumerate(phrases):
+        uniq, seq, places, idf, at = [], [], [], [], 0
+        for key, ranks in ents:
+            ls = [term_of[(key, c)] for c in range(len(ranks))]
+            for c, l in enumerate(ls):
+                if l not in uniq:
+                    uniq.append(l)
+                    idf.append(idf_of[l] if l in idf_of else float(idf_f32(n_docs, osh.df(l))))
+            seq.append(uniq.index(ls[0])); places.append(at)
+            at += len(ranks)
+        od, os_, otot = osh.search_phrase_items(uniq, seq, places, 10, idf=idf)
+        assert otot >= 1 and int(tot[i]) == otot, (i, ents, int(tot[i]), otot)
+        assert cnt[i] == len(od) and np.allclose(score[i][:cnt[i]], os_, rtol=1e-4)
+    inc.close()
+    T.close()
