@@ -356,7 +356,13 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   static const int p_rule = [] { const char* e = getenv("SS_BM25_P_RULE"); return e ? atoi(e) : 1; }();
   // (intersections -- the shortest list drives, the others are probed: shorter assignments balance better -- keep at least 48: 1000
   // 2-term ANDs 1.035 ms at 16 partitions, 0.975 at 24, 0.947 at 48, 0.972 at 64)
-  if (pruned && p_rule) P = std::max<uint32_t>(has_and ? 48u : 16u, std::min<uint32_t>(64u, 4096u / std::max<uint32_t>(nq, 1u)));
+  // (heavy queries want more partitions: a head-heavy mix of 4.2 M postings per query 3.68 ms per 1000 at 16 partitions, 3.34 at 48; C2's
+  // 1.35 M per query is best at 16 -- where the host has seen the queries, about one partition per 84 K postings)
+  if (pruned && p_rule) {
+    uint32_t floor_p = has_and ? 48u : 16u;
+    if (s->bm_batch_postings) floor_p = std::max<uint32_t>(floor_p, (uint32_t)std::min<uint64_t>(64u, s->bm_batch_postings / 84000u));
+    P = std::max<uint32_t>(floor_p, std::min<uint32_t>(64u, 4096u / std::max<uint32_t>(nq, 1u)));
+  }
   if (const char* e = getenv("SS_BM25_P")) P = (uint32_t)atoi(e);  // tuning override
   P = std::max<uint32_t>(1, std::min<uint32_t>(P, s->bm_n_sub));
   const size_t tau_words = (size_t)nq * BM_TAU_STRIDE / 2;  // u64 words: one 128-byte line per query

@@ -1449,10 +1449,23 @@ static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_quer
     s->bq_cap = (size_t)nq * sizeof(ss_bm25_query);
   }
   SS_HIP(hipMemcpyAsync(s->d_bq, q, (size_t)nq * sizeof(ss_bm25_query), hipMemcpyHostToDevice, s->stream));
-  return with_facet_filter(s, n_filters, filters, s->stream, [&]() {
+  {  // the batch's weight, for the pruned kernel's partition rule: the host has the queries in hand here
+    uint64_t sum = 0;
+    const bool mf = s->bm_n_fields > 1;
+    for (uint32_t i = 0; i < nq; i++)
+      for (uint32_t t = 0; t < q[i].n_terms && t < (uint32_t)SS_MAX_QUERY_TERMS; t++) {
+        const uint32_t term = q[i].term[t];
+        if (mf) { if (term < s->h_df_real.size()) sum += s->h_df_real[term]; }
+        else if (term < s->h_df.size()) sum += s->h_df[term];
+      }
+    s->bm_batch_postings = sum / nq;
+  }
+  const int rc_search = with_facet_filter(s, n_filters, filters, s->stream, [&]() {
     return ssi_bm25_search(s, nq, (const ss_bm25_query*)s->d_bq, kk, rt, s->d_out_doc, s->d_out_score, s->d_out_count,
                            s->d_out_total, has_and, has_or, nt_max, np_max, all_probed, s->stream, any_frequent, phrase, any_filter, uniform, gated, nn_max);
   });
+  s->bm_batch_postings = 0;
+  return rc_search;
 }
 
 static int bm25_search_direct(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k, uint32_t rt, uint32_t n_filters,

@@ -348,6 +348,7 @@ struct ss_shard {
   std::vector<uint64_t> h_sp_base;   // host copy of d_sp_base (posting counts = the df the host needs for idf)
   void* d_tier_ws = nullptr;         // workspace of a tiered search (sub-queries, row maps, sparse lists, merged answers), grow-only
   size_t tier_ws_cap = 0;
+  uint64_t bm_batch_postings = 0;    // mean postings per query of the host-pointer batch about to run (0 = unknown: a device-resident batch)
   uint32_t del_per_query = 0;        // d_deleted holds one bitmap of deleted_words words PER QUERY of the batch in flight (ss_bm25_search_sorted)
   void* d_sort_ws = nullptr;         // workspace of ss_bm25_search_sorted, grow-only
   size_t sort_ws_cap = 0;
