@@ -361,7 +361,9 @@ int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df
  * (<= 7; ABI v3): the reference filters inside union_docid_3's sub-queries (union.rs:1330-1425, 1168-1305), which comes to -- a doc's
  * score is the sum over its terms that occur in a listed field (all fields of those terms counted), a doc none of whose terms passes
  * is no result; exact count: two terms |pass(X) u pass(Y)|, more terms the UNFILTERED union (union_scan counts a doc before the
- * filter sees it, union.rs:552-553).  Answered by the scan kernels with per-term gating of a doc's score.  Ignored by an image with
+ * filter sees it, union.rs:552-553).  Answered by the scan kernels with per-term gating of a doc's score; one that names a term of
+ * the sparse tier (<= 5 terms) by the reference's own sub-queries, behind this call: every subset of its terms as a filtered
+ * intersection through both tiers, a doc keeps its best.  Ignored by an image with
  * one indexed field.  For ss_bm25_search_dev such a query counts as an intersection in ops_mask (bit 0) and a filtered union of
  * several terms sets bit 7 as well. */
 #define SS_OP_FIELD_FILTER(mask) (((uint32_t)(mask) & 0x7FFFu) << 16)

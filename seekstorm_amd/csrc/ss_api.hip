@@ -1225,10 +1225,12 @@ static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_quer
 // sparse kernel, which scores every doc of a sparse list in full -- and put together per query by bm25_tier_merge_kernel; the
 // answers land in s->d_out_* in the callers' order, like any other batch's.  Caller holds s->mu.
 static int bm25_search_tiered_excl(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, const std::vector<uint32_t>& special);
+static int bm25_search_tiered_compose(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, const std::vector<uint32_t>& composed);
 static int bm25_search_tiered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt) {
   const uint32_t n_dense = s->bm_n_terms / s->bm_n_fields;  // public terms of the dense image
   if (s->bm_n_fields != 1 && !s->bm_merged) return SS_ENOTSUP;  // (several indexed fields: the sparse tier holds merged weights)
   std::vector<uint32_t> special;       // unions with a SPARSE NOT term: answered one by one under a per-query exclusion bitmap
+  std::vector<uint32_t> composed;      // unions of several terms under a field filter: the reference's own sub-queries, one by one
   std::vector<ss_bm25_query> sub;      // the dense sub-batch: all-dense queries as they are, tiered unions reduced to their dense terms
   std::vector<ss_bm25_query> spq;      // the tiered queries, whole, for the sparse kernel
   std::vector<ss_bm25_query> spq_phrase;  // ... the phrases among them, for the sparse phrase kernel
@@ -1253,10 +1255,15 @@ static int bm25_search_tiered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, 
     const bool is_phrase = op == SS_OP_PHRASE;
     // a field filter (several indexed fields): a phrase's is a test on its positions' tags; an intersection's / a single term's asks
     // every term for a listed field -- a sparse posting carries its fields; a UNION of several terms under a filter is the dense tier's
-    // gated scan over (term, field) lists, which the tier does not keep
+    // gated scan over (term, field) lists, which the tier does not keep: composed from filtered intersections (<= 5 terms)
     if (bm_q_field_filter(q[i].op) >> bm_real_fields(s)) return SS_EINVAL;
     const bool filtered = s->bm_n_fields > 1 && bm_q_field_filter(q[i].op) != 0u;
-    if ((filtered && op == SS_OP_UNION && q[i].n_terms > 1) || bm_q_all_frequent(q[i].op)) return SS_ENOTSUP;
+    if (bm_q_all_frequent(q[i].op)) return SS_ENOTSUP;
+    if (filtered && op == SS_OP_UNION && q[i].n_terms > 1) {
+      if (q[i].n_terms > 5) return SS_ENOTSUP;
+      composed.push_back(i);
+      continue;
+    }
     const bool is_and = (op == SS_OP_INTERSECTION && q[i].n_terms > 1) || is_phrase;
     // (a union's dense part cannot probe a sparse NOT list; an intersection is driven by a sparse list -- it needs one)
     const bool is_special = sparse_not && (!is_and || !sparse_pos);
@@ -1291,6 +1298,7 @@ static int bm25_search_tiered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, 
     }
   }
   SS_HIP(hipSetDevice(s->device));
+  if (!composed.empty()) return bm25_search_tiered_compose(s, nq, q, kk, rt, composed);
   if (!special.empty()) return bm25_search_tiered_excl(s, nq, q, kk, rt, special);
   const uint32_t ns_plain = (uint32_t)spq.size();
   for (uint32_t i = 0; i < nq; i++)
@@ -1402,6 +1410,95 @@ static int bm25_search_tiered_excl(ss_shard* s, uint32_t nq, const ss_bm25_query
     }
     SS_HIP(hipMemcpyAsync(s->d_out_count + i, H + h_cnt + (size_t)j * 4, 4, hipMemcpyDeviceToDevice, s->stream));
     SS_HIP(hipMemcpyAsync(s->d_out_total + i, H + h_tot + (size_t)j * 8, 8, hipMemcpyDeviceToDevice, s->stream));
+  }
+  return SS_OK;
+}
+
+// A UNION of several terms under a field filter that names a term of the sparse tier.  The dense tier answers such a union by gating
+// every term's unlisted (term, field) lists inside the scan (BM_AND_GATED); the sparse tier keeps one merged list per term.  So the
+// query is answered the way the reference itself answers it (union.rs:1168-1305, 1330-1425: union_docid_3 queues the intersection
+// of all terms and every subset down to pairs, union_docid_2 runs a pair as its intersection plus the two single terms; the filter
+// applies to the terms of the sub-query that finds the doc, add_result.rs:3124-3136; a doc found again keeps its better score,
+// min_heap.rs:1193-1260): the 2^n - 1 filtered intersections as ONE batch through both tiers, merged per doc by the maximum -- a doc
+// of the union's top-k is in the top-k of the sub-query that gives it its score.  Totals as the reference reports them: two terms
+// |pass(X) u pass(Y)| (union_docid_2's count), more the UNFILTERED union (union_scan counts a doc before the filter sees it,
+// union.rs:552-553).  Rare (a rare word in a multi-word query under a field filter); <= 5 terms; the merge is the host's.
+static int bm25_search_tiered_compose(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, const std::vector<uint32_t>& composed) {
+  const uint32_t kw = std::max<uint32_t>(kk, 1), n_co = (uint32_t)composed.size();
+  std::vector<uint32_t> a_doc((size_t)n_co * kw, SS_NO_DOC), a_cnt(n_co, 0);
+  std::vector<float> a_score((size_t)n_co * kw, 0.f);
+  std::vector<unsigned long long> a_tot(n_co, 0);
+  std::vector<ss_bm25_query> rest(q, q + nq);
+  const uint32_t rt_sub = rt == SS_RT_TOPK ? SS_RT_TOPK : (rt == SS_RT_COUNT ? SS_RT_COUNT : SS_RT_TOPKCOUNT);
+  for (uint32_t j = 0; j < n_co; j++) {
+    const ss_bm25_query& Q = q[composed[j]];
+    const uint32_t n = Q.n_terms, nn = bm_q_nnot(Q.op);
+    const uint32_t op_sub = SS_OP_INTERSECTION | SS_OP_NOT_TERMS(nn) | SS_OP_FIELD_FILTER(bm_q_field_filter(Q.op));
+    std::vector<ss_bm25_query> subs;
+    for (uint32_t m = 1; m < (1u << n); m++) {
+      ss_bm25_query S;
+      memset(&S, 0, sizeof(S));
+      for (uint32_t t = 0; t < n; t++)
+        if ((m >> t) & 1u) { S.term[S.n_terms] = Q.term[t]; S.idf[S.n_terms] = Q.idf[t]; S.n_terms++; }
+      if (S.n_terms + nn > (uint32_t)SS_MAX_QUERY_TERMS) return SS_EINVAL;
+      for (uint32_t t = 0; t < nn; t++) S.term[S.n_terms + t] = Q.term[n + t];
+      S.op = op_sub;
+      subs.push_back(S);
+    }
+    rest[composed[j]] = subs[0];  // keeps the row's place in the batch below; its answer is overwritten
+    rest[composed[j]].op = SS_OP_INTERSECTION | SS_OP_FIELD_FILTER(bm_q_field_filter(Q.op));
+    const uint32_t ns = (uint32_t)subs.size();
+    std::vector<unsigned long long> tot(ns, 0);
+    std::vector<std::pair<float, uint32_t>> ranked;
+    const bool need_subs = rt != SS_RT_COUNT || n == 2;
+    if (need_subs) {
+      SS_TRY(bm25_search_host_queries(s, ns, subs.data(), kk, rt_sub, 0, nullptr));
+      std::vector<uint32_t> doc((size_t)ns * kw), cnt(ns);
+      std::vector<float> score((size_t)ns * kw);
+      SS_HIP(hipStreamSynchronize(s->stream));
+      if (kk && rt != SS_RT_COUNT) {
+        SS_HIP(hipMemcpy(doc.data(), s->d_out_doc, (size_t)ns * kw * 4, hipMemcpyDeviceToHost));
+        SS_HIP(hipMemcpy(score.data(), s->d_out_score, (size_t)ns * kw * 4, hipMemcpyDeviceToHost));
+        SS_HIP(hipMemcpy(cnt.data(), s->d_out_count, (size_t)ns * 4, hipMemcpyDeviceToHost));
+        std::unordered_map<uint32_t, float> best;
+        for (uint32_t i = 0; i < ns; i++)
+          for (uint32_t r = 0; r < std::min(cnt[i], kk); r++) {
+            auto it = best.find(doc[(size_t)i * kw + r]);
+            if (it == best.end()) best.emplace(doc[(size_t)i * kw + r], score[(size_t)i * kw + r]);
+            else if (score[(size_t)i * kw + r] > it->second) it->second = score[(size_t)i * kw + r];
+          }
+        ranked.reserve(best.size());
+        for (const auto& e : best) ranked.emplace_back(e.second, e.first);
+        std::sort(ranked.begin(), ranked.end(), [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) {
+          return a.first != b.first ? a.first > b.first : a.second < b.second;
+        });
+        if (ranked.size() > kk) ranked.resize(kk);
+      }
+      if (rt != SS_RT_TOPK) SS_HIP(hipMemcpy(tot.data(), s->d_out_total, (size_t)ns * 8, hipMemcpyDeviceToHost));
+    }
+    for (size_t r = 0; r < ranked.size(); r++) { a_doc[(size_t)j * kw + r] = ranked[r].second; a_score[(size_t)j * kw + r] = ranked[r].first; }
+    a_cnt[j] = (uint32_t)ranked.size();
+    if (rt == SS_RT_TOPK) a_tot[j] = ranked.size();
+    else if (n == 2) a_tot[j] = tot[0] + tot[1] - tot[2];  // subsets in mask order: {X}, {Y}, {X, Y}
+    else {
+      ss_bm25_query U = Q;
+      U.op = SS_OP_UNION | SS_OP_NOT_TERMS(nn);
+      SS_TRY(bm25_search_host_queries(s, 1, &U, 0, SS_RT_COUNT, 0, nullptr));
+      SS_HIP(hipStreamSynchronize(s->stream));
+      SS_HIP(hipMemcpy(&a_tot[j], s->d_out_total, 8, hipMemcpyDeviceToHost));
+    }
+  }
+  if (n_co < nq) SS_TRY(bm25_search_host_queries(s, nq, rest.data(), kk, rt, 0, nullptr));
+  else SS_TRY(ensure_out(s, nq, kw));
+  SS_HIP(hipStreamSynchronize(s->stream));
+  for (uint32_t j = 0; j < n_co; j++) {
+    const size_t i = composed[j];
+    if (kk && rt != SS_RT_COUNT) {
+      SS_HIP(hipMemcpy(s->d_out_doc + i * kw, a_doc.data() + (size_t)j * kw, (size_t)kw * 4, hipMemcpyHostToDevice));
+      SS_HIP(hipMemcpy(s->d_out_score + i * kw, a_score.data() + (size_t)j * kw, (size_t)kw * 4, hipMemcpyHostToDevice));
+    }
+    SS_HIP(hipMemcpy(s->d_out_count + i, &a_cnt[j], 4, hipMemcpyHostToDevice));
+    SS_HIP(hipMemcpy(s->d_out_total + i, &a_tot[j], 8, hipMemcpyHostToDevice));
   }
   return SS_OK;
 }

@@ -503,9 +503,53 @@ def test_sparse_tier_on_an_image_with_several_indexed_fields(S, O):
                     assert int(tot[i]) == otot, (pos, neg, filt, rt, int(tot[i]), otot)
                     if rt != S.ResultType.Count:
                         _check_topk(doc[i], score[i], cnt[i], od, os_)
+    # a UNION of several terms under a filter that names a sparse term: the reference's own sub-queries (every subset of the terms as
+    # a filtered intersection, a doc keeps its best) behind the ABI -- the sum over the doc's terms that stand in a listed field, a doc
+    # none of whose terms passes is no result; totals: two terms |pass(X) u pass(Y)|, more the unfiltered union
+    ucases = [([0, 4], []), ([6, 9], []), ([0, 1, 4], []), ([9, 6, 1, 0], []), ([4, 0], [1]), ([6, 2], [9]), ([0, 1], []), ([8, 4, 6, 9, 2], [])]
+    for deleted in ((), gone):
+        sh.set_deleted(deleted)
+        gone_set = set(deleted)
+        per_term = {}
+        for t in range(len(dfs)):
+            d, s_, _, _ = O.search_fields_exhaustive(n_docs, dl, boost, offs, docs, fields, tfs, [t], O.OP_OR, n_docs, (), deleted)
+            a, b = int(offs[t]), int(offs[t + 1])
+            per_term[t] = (dict(zip(d.tolist(), s_.tolist())), docs[a:b], fields[a:b])
+        for filt in ((0,), (1, 2)):
+            q = sh.make_queries([c[0] for c in ucases], S.QueryType.Union, [c[1] for c in ucases], field_filter=filt)
+            for k in (10, 40):
+                for rt in (S.ResultType.TopkCount, S.ResultType.Count, S.ResultType.Topk):
+                    doc, score, cnt, tot = sh.search_lexical_batch(q, k, rt, reference_shortcuts=False)
+                    for i, (pos, neg) in enumerate(ucases):
+                        sc, passing, present = {}, [], set()
+                        for t in pos:
+                            ts, dd, ff = per_term[t]
+                            pas = set(dd[np.isin(ff, list(filt))].tolist()) - gone_set
+                            passing.append(pas)
+                            present |= set(dd.tolist()) - gone_set
+                            for d in pas:
+                                sc[d] = np.float32(sc.get(d, np.float32(0)) + np.float32(ts[d]))
+                        banned = set()
+                        for t in neg:
+                            banned |= set(per_term[t][1].tolist())
+                        want = sorted(((d, float(v)) for d, v in sc.items() if d not in banned), key=lambda e: (-e[1], e[0]))[:k]
+                        if rt != S.ResultType.Topk:
+                            exp = len((passing[0] | passing[1]) - banned) if len(pos) == 2 else len(present - banned)
+                            assert int(tot[i]) == exp, (pos, neg, filt, rt, k, int(tot[i]), exp)
+                        if rt != S.ResultType.Count:
+                            n = int(cnt[i])
+                            assert n == len(want), (pos, neg, filt, k, n, len(want))
+                            assert np.allclose(score[i, :n], [w[1] for w in want], rtol=1e-4), (pos, neg, filt, k)
+                            kth = want[-1][1] if want else 0.0
+                            band = abs(kth) * 2e-4
+                            assert {int(d) for d, v in zip(doc[i, :n], score[i, :n]) if v > kth + band} == {d for d, v in want if v > kth + band}
     sh.set_deleted(())
-    with pytest.raises(N.SeekStormHipError):  # a UNION of several terms under a filter is the dense tier's gated scan over (term, field) lists
-        sh.search_lexical_batch(sh.make_queries([[0, 4]], S.QueryType.Union, field_filter=[0]), 10)
+    one = sh.search_lexical_shard([0, 4], S.QueryType.Union, 0, 10, S.ResultType.TopkCount, strict=True, field_filter=[1, 2])  # a call of its own
+    q = sh.make_queries([[0, 4]], S.QueryType.Union, field_filter=(1, 2))
+    doc, score, cnt, tot = sh.search_lexical_batch(q, 10, S.ResultType.TopkCount, reference_shortcuts=False)
+    assert [r.doc_id for r in one.results] == doc[0, :int(cnt[0])].tolist() and one.result_count_total == int(tot[0]) and int(cnt[0]) > 0
+    with pytest.raises(N.SeekStormHipError):  # 2^n - 1 sub-queries: at most 5 terms
+        sh.search_lexical_batch(sh.make_queries([[0, 4, 1, 2, 3, 5]], S.QueryType.Union, field_filter=[0]), 10)
     sh.close()
 
 
