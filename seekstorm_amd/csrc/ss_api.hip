@@ -15,6 +15,7 @@
 #include <unordered_map>
 
 #include "ss_common.h"
+#include "sparse_levels.h"
 #include "ss_threads.h"
 #include "facet_point.h"
 #include "bm25_build.h"
@@ -156,14 +157,20 @@ static void free_raw_levels(ss_shard* s) {
   s->raw.clear();
   s->h_doclen.clear();
 }
-static void free_bm25(ss_shard* s) {
+// keep_tier: the dense image goes (a commit swaps in its successor), the sparse tier stays
+static void free_bm25(ss_shard* s, bool keep_tier = false) {
   free_raw_levels(s);
   void* ptrs[] = {s->d_post, s->d_term_base, s->d_sub_off, s->d_comp, s->d_probe, s->d_probe_z, s->d_probe_row, s->d_umax, s->d_submax, s->d_boost, s->d_pos, s->d_pos32, s->d_pos_off, s->d_pos_base,
-                  s->d_doclen, s->d_sp_base, s->d_sp_post, s->d_sp_pos, s->d_sp_pos_end};
+                  s->d_doclen};
   for (void* p : ptrs) if (p) { s->blocks.drop(p); (void)hipFree(p); }
   s->blocks.clear_idle();
-  s->d_doclen = nullptr; s->d_sp_base = nullptr; s->d_sp_post = nullptr; s->sp_n = 0; s->h_sp_base.clear();
-  s->d_sp_pos = nullptr; s->d_sp_pos_end = nullptr; s->sp_pos_n = 0; s->sp_pos_elem = 0;
+  s->d_doclen = nullptr;
+  if (!keep_tier) {
+    for (void* p : {(void*)s->d_sp_base, (void*)s->d_sp_post, (void*)s->d_sp_pos, (void*)s->d_sp_pos_end}) if (p) (void)hipFree(p);
+    s->d_sp_base = nullptr; s->d_sp_post = nullptr; s->sp_n = 0; s->h_sp_base.clear();
+    s->d_sp_pos = nullptr; s->d_sp_pos_end = nullptr; s->sp_pos_n = 0; s->sp_pos_elem = 0;
+    ssi_bm25_sparse_levels_drop(s);
+  }
   s->d_post = nullptr; s->d_term_base = nullptr; s->d_sub_off = nullptr; s->d_comp = nullptr;
   s->probe_pool_begin = 0; s->probe_pool_rows = 0; s->pool_list.clear(); s->pool_tick.clear();
   s->d_probe = nullptr; s->d_probe_z = nullptr; s->d_probe_row = nullptr; s->h_probe_row.clear(); s->bm_probe_rows = 0; s->d_umax = nullptr; s->d_submax = nullptr; s->d_pos = nullptr; s->d_pos32 = nullptr; s->d_pos_off = nullptr; s->d_pos_base = nullptr;
@@ -538,7 +545,9 @@ static int append_level_impl(ss_shard* s, uint32_t level, uint32_t n_level_docs,
   {
     std::lock_guard<std::mutex> g(s->mu);
     if (s->d_post && s->raw.empty()) return SS_ESTATE;       // an image that was not built level by level
-    if (s->sp_n) return SS_ENOTSUP;                          // a sparse tier numbers its terms behind the dense ones: a grown vocabulary would shift them
+    // a sparse tier numbers its terms behind the dense ones: a grown dense vocabulary would shift them -- new terms of an image with a
+    // tier join the tier (ss_bm25_append_sparse_level), whose postings must come level by level too (their tfs are kept for re-coding)
+    if (s->sp_n && (!ssi_bm25_sparse_levels_has(s) || n_terms != s->bm_n_terms || level < s->raw.size())) return SS_ENOTSUP;
     if (level > s->raw.size() || level + 1 < s->raw.size()) return SS_EINVAL;  // append the next level, or replace the last one (a re-commit)
     if (level >= 1 && s->raw[level - 1].n_docs != 65536u) return SS_EINVAL;    // only the last level may be partial
     if ((uint64_t)level * 65536u + n_level_docs > 0xFFFFFFFFull) return SS_ENOTSUP;
@@ -656,7 +665,7 @@ static int append_level_impl(ss_shard* s, uint32_t level, uint32_t n_level_docs,
       for (void** pp : op) if (*pp && s->blocks.release(*pp)) *pp = nullptr;
       std::vector<ss_block_pool::Idle> idle;
       idle.swap(s->blocks.idle);   // (free_bm25 clears the idle list: these stay)
-      free_bm25(s);
+      free_bm25(s, /*keep_tier=*/true);
       s->blocks.idle.swap(idle);
       s->blocks.trim(3);
     }
@@ -676,6 +685,10 @@ static int append_level_impl(ss_shard* s, uint32_t level, uint32_t n_level_docs,
     s->h_df.swap(img->h_df); s->h_probe_row.swap(img->h_probe_row); s->bm_probe_rows = img->bm_probe_rows;
     s->probe_pool_begin = img->probe_pool_begin; s->probe_pool_rows = img->probe_pool_rows; s->pool_list.swap(img->pool_list); s->pool_tick.swap(img->pool_tick);
     s->pool_clock = 0;
+    if (s->sp_n) {  // the average length moved: the sparse postings' codes follow (their docs of this level: ss_bm25_append_sparse_level)
+      const int rc_sp = ssi_bm25_sparse_levels_recode(s, s->stream);
+      if (rc_sp == SS_OK) (void)hipStreamSynchronize(s->stream);
+    }
     s->raw_last_rebuild_ms = rebuild_ms;
     s->raw_last_append_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   }
@@ -810,6 +823,15 @@ int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df
   return SS_OK;
 }
 
+int ss_bm25_append_sparse_level(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs, const uint16_t* npos,
+                                const uint16_t* positions, uint64_t n_positions) {
+  if (!s || !offs || n_lists == 0 || (offs[n_lists] > offs[0] && (!docs || !tfs))) return SS_EINVAL;
+  std::lock_guard<std::mutex> g(s->mu);
+  if (s->raw.empty()) return SS_ESTATE;  // an image that grows level by level (ss_bm25_append_level)
+  SS_HIP(hipSetDevice(s->device));
+  SS_HIP(hipDeviceSynchronize());  // searches on the callers' own streams may still read the arrays the level replaces
+  return ssi_bm25_append_sparse_level(s, n_lists, offs, docs, tfs, npos, positions, n_positions);
+}
 int ss_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
                           uint32_t* first_term_id_out) {
   if (!s || !offs || (n_lists && offs[n_lists] > offs[0] && (!docs || !tfs))) return SS_EINVAL;

@@ -4,6 +4,7 @@
 #include "ss_common.h"
 #include "ss_threads.h"
 #include "bm25_build.h"
+#include "sparse_levels.h"
 
 #include <chrono>
 #include <cmath>
@@ -806,6 +807,7 @@ int ssi_bm25_append_sparse_fields(ss_shard* s, uint32_t n_lists, const uint64_t*
 
 static int sparse_install(ss_shard* s, uint32_t n_lists, const std::vector<u64>& lbase, const std::vector<u64>& packed,
                           const std::vector<uint32_t>* counts, const void* pos, u64 n_pos, size_t elem) {
+  if (ssi_bm25_sparse_levels_has(s)) return SS_ESTATE;  // a tier that grows level by level takes levels only (ss_bm25_append_sparse_level)
   const u64 n_new = packed.size();
   const u64* offs = lbase.data();
   const u64 old_n = s->h_sp_base.empty() ? 0 : s->h_sp_base.back();
@@ -848,6 +850,240 @@ static int sparse_install(ss_shard* s, uint32_t n_lists, const std::vector<u64>&
   s->d_sp_post = np;
   s->h_sp_base = std::move(base);
   s->sp_n += n_lists;
+  return SS_OK;
+}
+
+// ---------------------------------------------------------------- the sparse tier level by level (sparse_levels.h)
+namespace {
+struct SparseLevels {
+  uint16_t* d_tf = nullptr;    // [sparse postings] the tf behind every posting's code
+  std::vector<uint64_t> h_pbase;    // [sp_n + 1] first position of every list in d_sp_pos (a tier with positions)
+};
+std::mutex g_spl_mu;
+std::unordered_map<const ss_shard*, SparseLevels> g_spl;
+
+struct SpExtend {
+  const uint64_t* old_base; uint32_t n_old; const uint64_t* new_base; uint32_t n_lists;
+  const uint64_t* old_post; const uint16_t* old_tf; uint64_t* new_post; uint16_t* new_tf;
+  const uint64_t* lvl_off; const uint32_t* lvl_doc; const uint16_t* lvl_tf;
+  const uint64_t* old_pbase; const uint64_t* new_pbase; const uint64_t* old_pend; uint64_t* new_pend;  // positions (new_pend == nullptr: a tier without)
+  const uint16_t* old_pool; uint16_t* new_pool; const uint32_t* lvl_pend; const uint64_t* lvl_pbase; const uint16_t* lvl_pool;
+  uint32_t n_docs; uint32_t* bad;
+};
+}  // namespace
+// one wave per list: the list's old postings (and their positions) to their new places, the level's behind them
+__global__ void __launch_bounds__(256) sp_extend_kernel(SpExtend A) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t i64 = ((uint64_t)blockIdx.x * 256u + threadIdx.x) >> 6;
+  if (i64 >= A.n_lists) return;
+  const uint32_t i = (uint32_t)i64;
+  const bool was = i < A.n_old;
+  const uint64_t ob = was ? A.old_base[i] : 0ull, no = was ? A.old_base[i + 1] - ob : 0ull;
+  const uint64_t nb = A.new_base[i], lo = A.lvl_off[i], nn = A.lvl_off[i + 1] - lo;
+  const bool pos = A.new_pend != nullptr;
+  const uint64_t opb = (pos && was) ? A.old_pbase[i] : 0ull, opn = (pos && was) ? A.old_pbase[i + 1] - opb : 0ull;
+  const uint64_t npb = pos ? A.new_pbase[i] : 0ull;
+  for (uint64_t j = lane; j < no; j += 64u) {
+    A.new_post[nb + j] = A.old_post[ob + j];
+    A.new_tf[nb + j] = A.old_tf[ob + j];
+    if (pos) A.new_pend[nb + j] = npb + (A.old_pend[ob + j] - opb);
+  }
+  for (uint64_t j = lane; j < nn; j += 64u) {
+    const uint32_t d = A.lvl_doc[lo + j];
+    bool ok = d < A.n_docs && A.lvl_tf[lo + j] != 0;
+    if (j > 0) ok = ok && d > A.lvl_doc[lo + j - 1];
+    else if (no) ok = ok && d > (uint32_t)A.old_post[ob + no - 1];  // behind everything the list holds
+    if (!ok) atomicOr(A.bad, 1u);
+    A.new_post[nb + no + j] = (uint64_t)d;  // (its code: sp_recode_kernel)
+    A.new_tf[nb + no + j] = A.lvl_tf[lo + j];
+    if (pos) A.new_pend[nb + no + j] = npb + opn + A.lvl_pend[lo + j];
+  }
+  if (pos) {
+    for (uint64_t j = lane; j < opn; j += 64u) A.new_pool[npb + j] = A.old_pool[opb + j];
+    const uint64_t lpb = A.lvl_pbase[i], lpn = A.lvl_pbase[i + 1] - lpb;
+    for (uint64_t j = lane; j < lpn; j += 64u) A.new_pool[npb + opn + j] = A.lvl_pool[lpb + j];
+  }
+}
+// a sparse posting's code from its tf and its doc's length byte -- the operations of bm_weight_exact / raw_fill_kernel
+__global__ void __launch_bounds__(256) sp_recode_kernel(uint64_t* __restrict__ post, const uint16_t* __restrict__ tf, uint64_t n,
+                                                        const uint8_t* __restrict__ doclen, const float* __restrict__ comp, float k1) {
+  for (uint64_t p = (uint64_t)blockIdx.x * 256u + threadIdx.x; p < n; p += (uint64_t)gridDim.x * 256u) {
+    const uint32_t d = (uint32_t)post[p];
+    const float tt = (float)tf[p];
+    const float wgt = __fdiv_rn(ss_fmul(tt, k1), ss_fadd(tt, comp[doclen[d]]));
+    post[p] = ((uint64_t)bm_wcode(wgt) << 32) | d;
+  }
+}
+
+bool ssi_bm25_sparse_levels_has(const ss_shard* s) {
+  std::lock_guard<std::mutex> g(g_spl_mu);
+  return g_spl.find(s) != g_spl.end();
+}
+void ssi_bm25_sparse_levels_drop(const ss_shard* s) {
+  std::lock_guard<std::mutex> g(g_spl_mu);
+  auto it = g_spl.find(s);
+  if (it == g_spl.end()) return;
+  if (it->second.d_tf) (void)hipFree(it->second.d_tf);
+  g_spl.erase(it);
+}
+int ssi_bm25_sparse_levels_recode(ss_shard* s, hipStream_t st) {
+  uint16_t* d_tf = nullptr;
+  {
+    std::lock_guard<std::mutex> g(g_spl_mu);
+    auto it = g_spl.find(s);
+    if (it == g_spl.end()) return SS_OK;
+    d_tf = it->second.d_tf;
+  }
+  const uint64_t n = s->h_sp_base.empty() ? 0 : s->h_sp_base.back();
+  if (!n) return SS_OK;
+  if (!s->d_sp_post || !d_tf || !s->d_doclen || !s->d_comp) return SS_ESTATE;
+  const volatile float k1 = 1.2f + 1.0f;  // (K + 1) as bm_weight_exact forms it
+  sp_recode_kernel<<<(uint32_t)std::min<uint64_t>((n + 255) / 256, 65536), 256, 0, st>>>(s->d_sp_post, d_tf, n, s->d_doclen, s->d_comp, k1);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
+int ssi_bm25_append_sparse_level(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
+                                 const uint16_t* npos, const uint16_t* positions, uint64_t n_positions) {
+  if (!s->d_post || !s->d_doclen || !s->d_comp) return SS_ESTATE;
+  if (s->bm_n_fields != 1 || s->bm_merged) return SS_ENOTSUP;  // several indexed fields: whole-image uploads
+  const bool fresh = s->sp_n == 0;
+  if (!fresh && !ssi_bm25_sparse_levels_has(s)) return SS_ESTATE;  // a tier of whole lists (ss_bm25_append_sparse) keeps no tfs
+  if (n_lists < s->sp_n || (uint64_t)n_lists > 0x7FFFFFFFull - s->bm_n_terms) return n_lists < s->sp_n ? SS_EINVAL : SS_ENOTSUP;
+  const bool with_pos = fresh ? positions != nullptr : s->d_sp_pos_end != nullptr;
+  if (!with_pos && (positions || n_positions)) return SS_EINVAL;  // positions for every level of a tier, or for none
+  if (with_pos && n_positions && !positions) return SS_EINVAL;
+  if (with_pos && !fresh && s->sp_pos_elem != sizeof(uint16_t)) return SS_ESTATE;
+  for (uint32_t i = 0; i < n_lists; i++)
+    if (offs[i + 1] < offs[i]) return SS_EINVAL;
+  const uint64_t n_new = offs[n_lists] - offs[0], o0 = offs[0];
+  const uint32_t n_old = s->sp_n;
+  const uint64_t old_n = s->h_sp_base.empty() ? 0 : s->h_sp_base.back();
+  std::atomic<int> fail{SS_OK};
+  ss_parallel_for(n_lists, 4096, [&](size_t a, size_t b, unsigned) {
+    for (size_t i = a; i < b; i++)
+      for (uint64_t j = offs[i]; j < offs[i + 1]; j++)
+        if (docs[j] >= s->bm_n_docs || tfs[j] == 0 || (j > offs[i] && docs[j] <= docs[j - 1])) { fail.store(SS_EINVAL); return; }
+  });
+  if (fail.load()) return fail.load();
+  // the new starts of the lists (postings; positions), the level's own offsets
+  std::vector<uint64_t> base((size_t)n_lists + 1, 0), lvl_off((size_t)n_lists + 1), pbase, lvl_pbase, old_pbase;
+  for (uint32_t i = 0; i < n_lists; i++)
+    base[i + 1] = base[i] + (i < n_old ? s->h_sp_base[i + 1] - s->h_sp_base[i] : 0ull) + (offs[i + 1] - offs[i]);
+  for (uint32_t i = 0; i <= n_lists; i++) lvl_off[i] = offs[i] - o0;
+  std::vector<uint32_t> lvl_pend;
+  if (with_pos) {
+    {
+      std::lock_guard<std::mutex> g(g_spl_mu);
+      auto it = g_spl.find(s);
+      if (it != g_spl.end()) old_pbase = it->second.h_pbase;
+    }
+    if (old_pbase.size() != (size_t)n_old + 1) { if (n_old) return SS_ESTATE; old_pbase.assign(1, 0); }
+    lvl_pend.resize(n_new ? n_new : 1);
+    lvl_pbase.assign((size_t)n_lists + 1, 0);
+    ss_parallel_for(n_lists, 4096, [&](size_t a, size_t b, unsigned) {
+      for (size_t i = a; i < b; i++) {
+        uint64_t run = 0;
+        for (uint64_t j = offs[i]; j < offs[i + 1]; j++) {
+          run += npos ? npos[j] : tfs[j];
+          if (run >= (1ull << 32)) { fail.store(SS_ENOTSUP); return; }
+          lvl_pend[j - o0] = (uint32_t)run;
+        }
+        lvl_pbase[i + 1] = run;
+      }
+    });
+    if (fail.load()) return fail.load();
+    for (uint32_t i = 0; i < n_lists; i++) lvl_pbase[i + 1] += lvl_pbase[i];
+    if (lvl_pbase[n_lists] != n_positions) return SS_EINVAL;
+    pbase.assign((size_t)n_lists + 1, 0);
+    for (uint32_t i = 0; i < n_lists; i++)
+      pbase[i + 1] = pbase[i] + (i < n_old ? old_pbase[i + 1] - old_pbase[i] : 0ull) + (lvl_pbase[i + 1] - lvl_pbase[i]);
+    if (pbase[n_lists] != s->sp_pos_n + n_positions) return SS_ESTATE;
+  }
+  // device: the new arrays, the level's staging
+  std::vector<void*> owned;
+  auto dalloc = [&](size_t bytes) -> void* {
+    void* p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(bytes, 8)) != hipSuccess) return nullptr;
+    owned.push_back(p);
+    return p;
+  };
+  auto drop_all = [&]() { for (void* p : owned) (void)hipFree(p); owned.clear(); };
+  auto up = [&](void* d, const void* h, size_t bytes) { return bytes == 0 || hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) == hipSuccess; };
+  const uint64_t tot = old_n + n_new;
+  uint64_t* nbase = (uint64_t*)dalloc(base.size() * 8);
+  uint64_t* npost = (uint64_t*)dalloc((size_t)tot * 8);
+  uint16_t* ntf = (uint16_t*)dalloc((size_t)tot * 2);
+  uint64_t* d_lvl_off = (uint64_t*)dalloc(lvl_off.size() * 8);
+  uint32_t* d_lvl_doc = (uint32_t*)dalloc((size_t)n_new * 4);
+  uint16_t* d_lvl_tf = (uint16_t*)dalloc((size_t)n_new * 2);
+  uint32_t* d_bad = (uint32_t*)dalloc(4);
+  uint64_t *d_old_pbase = nullptr, *d_new_pbase = nullptr, *npend = nullptr, *d_lvl_pbase = nullptr;
+  uint16_t *npool = nullptr, *d_lvl_pool = nullptr;
+  uint32_t* d_lvl_pend = nullptr;
+  bool ok = nbase && npost && ntf && d_lvl_off && d_lvl_doc && d_lvl_tf && d_bad;
+  if (ok && with_pos) {
+    d_old_pbase = (uint64_t*)dalloc(old_pbase.size() * 8);
+    d_new_pbase = (uint64_t*)dalloc(pbase.size() * 8);
+    npend = (uint64_t*)dalloc((size_t)tot * 8);
+    d_lvl_pbase = (uint64_t*)dalloc(lvl_pbase.size() * 8);
+    npool = (uint16_t*)dalloc((size_t)pbase[n_lists] * 2);
+    d_lvl_pool = (uint16_t*)dalloc((size_t)n_positions * 2);
+    d_lvl_pend = (uint32_t*)dalloc((size_t)n_new * 4);
+    ok = d_old_pbase && d_new_pbase && npend && d_lvl_pbase && npool && d_lvl_pool && d_lvl_pend;
+  }
+  if (!ok) { drop_all(); return SS_ENOMEM; }
+  const uint32_t zero = 0;
+  ok = up(nbase, base.data(), base.size() * 8) && up(d_lvl_off, lvl_off.data(), lvl_off.size() * 8) && up(d_lvl_doc, docs + o0, (size_t)n_new * 4) &&
+       up(d_lvl_tf, tfs + o0, (size_t)n_new * 2) && up(d_bad, &zero, 4);
+  if (ok && with_pos)
+    ok = up(d_old_pbase, old_pbase.data(), old_pbase.size() * 8) && up(d_new_pbase, pbase.data(), pbase.size() * 8) &&
+         up(d_lvl_pbase, lvl_pbase.data(), lvl_pbase.size() * 8) && up(d_lvl_pool, positions, (size_t)n_positions * 2) &&
+         up(d_lvl_pend, lvl_pend.data(), (size_t)n_new * 4);
+  if (!ok) { drop_all(); return SS_EDEVICE; }
+  uint16_t* old_tf = nullptr;
+  {
+    std::lock_guard<std::mutex> g(g_spl_mu);
+    auto it = g_spl.find(s);
+    if (it != g_spl.end()) old_tf = it->second.d_tf;
+  }
+  SpExtend A;
+  A.old_base = s->d_sp_base; A.n_old = n_old; A.new_base = nbase; A.n_lists = n_lists;
+  A.old_post = s->d_sp_post; A.old_tf = old_tf; A.new_post = npost; A.new_tf = ntf;
+  A.lvl_off = d_lvl_off; A.lvl_doc = d_lvl_doc; A.lvl_tf = d_lvl_tf;
+  A.old_pbase = d_old_pbase; A.new_pbase = d_new_pbase; A.old_pend = s->d_sp_pos_end; A.new_pend = with_pos ? npend : nullptr;
+  A.old_pool = (const uint16_t*)s->d_sp_pos; A.new_pool = npool; A.lvl_pend = d_lvl_pend; A.lvl_pbase = d_lvl_pbase; A.lvl_pool = d_lvl_pool;
+  A.n_docs = s->bm_n_docs; A.bad = d_bad;
+  sp_extend_kernel<<<(n_lists + 3u) / 4u, 256, 0, s->stream>>>(A);
+  uint32_t bad = 0;
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess ||
+      hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost) != hipSuccess) { drop_all(); return SS_EDEVICE; }
+  if (bad) { drop_all(); return SS_EINVAL; }  // a level posting not behind its list's last doc: the tier stays as it was
+  // the swap (the caller holds s->mu and found the device idle)
+  auto keep = [&](void* p) { owned.erase(std::find(owned.begin(), owned.end(), p)); };
+  keep(nbase); keep(npost); keep(ntf);
+  if (with_pos) { keep(npend); keep(npool); }
+  drop_all();  // the staging
+  if (s->d_sp_base) (void)hipFree(s->d_sp_base);
+  if (s->d_sp_post) (void)hipFree(s->d_sp_post);
+  s->d_sp_base = nbase; s->d_sp_post = npost;
+  if (with_pos) {
+    if (s->d_sp_pos_end) (void)hipFree(s->d_sp_pos_end);
+    if (s->d_sp_pos) (void)hipFree(s->d_sp_pos);
+    s->d_sp_pos_end = npend; s->d_sp_pos = npool; s->sp_pos_n = pbase[n_lists]; s->sp_pos_elem = (uint32_t)sizeof(uint16_t);
+  }
+  s->h_sp_base = std::move(base);
+  s->sp_n = n_lists;
+  {
+    std::lock_guard<std::mutex> g(g_spl_mu);
+    SparseLevels& E = g_spl[s];
+    if (E.d_tf) (void)hipFree(E.d_tf);
+    E.d_tf = ntf;
+    E.h_pbase = std::move(pbase);
+  }
+  const int rc = ssi_bm25_sparse_levels_recode(s, s->stream);
+  if (rc != SS_OK) return rc;
+  SS_HIP(hipStreamSynchronize(s->stream));
   return SS_OK;
 }
 

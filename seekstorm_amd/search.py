@@ -1132,6 +1132,23 @@ class Shard:
         self._df_cache.clear()
         return int(first.value)
 
+    def append_sparse_level(self, term_offsets, doc_ids, tfs, positions=None, npos=None):
+        """the committed level's postings of the RARE terms of an image that grows by levels (ss_bm25_append_sparse_level, after
+        append_level of its dense terms): list i continues sparse list i, further lists are new terms"""
+        offs = np.ascontiguousarray(term_offsets, np.uint64)
+        d = np.ascontiguousarray(doc_ids, np.uint32)
+        t = np.ascontiguousarray(tfs, np.uint16)
+        ps = None if positions is None else np.ascontiguousarray(positions, np.uint16)
+        if ps is not None and len(ps) == 0:
+            ps = np.zeros(1, np.uint16)  # (a non-null pointer says "this tier carries positions")
+            n_ps = 0
+        else:
+            n_ps = 0 if ps is None else len(ps)
+        npc = None if npos is None else np.ascontiguousarray(npos, np.uint16)
+        N.check(N.lib().ss_bm25_append_sparse_level(self._h, len(offs) - 1, N.ptr(offs, N.u64p), N.ptr(d, N.u32p), N.ptr(t, N.u16p),
+                                                    N.ptr(npc, N.u16p), N.ptr(ps, N.u16p), n_ps), "ss_bm25_append_sparse_level")
+        self._df_cache.clear()
+
     def append_sparse_fields(self, term_offsets, doc_ids, field_ids, tfs, positions=None, npos=None):
         """... on an image with several indexed fields: entries (doc, field, tf) sorted by (doc, field) per term; the tier keeps the
         terms' merged lists (ss_bm25_append_sparse_fields); positions: every entry's positions inside its field"""

@@ -768,3 +768,89 @@ def test_append_levels_with_ngram_key_positions_against_the_oracle(S, O):
         assert cnt[i] == len(od) and np.allclose(score[i][:cnt[i]], os_, rtol=1e-4)
     inc.close()
     T.close()
+
+
+def test_sparse_tier_committed_level_by_level_equals_the_one_shot_tiered_upload(S, O):
+    """ss_bm25_append_sparse_level: an image WITH A SPARSE TIER that grows by commits -- per level the dense terms through append_level,
+    the rare terms' postings into their sparse lists (new rare terms join as new lists), the tier's codes re-made on the device as the
+    average length moves.  After every level: phrases over both tiers, unions, intersections, NOT terms, k 10 / 100, counts ==
+    a one-shot upload of the docs committed so far (dense image + whole sparse lists, positions and all), bit for bit"""
+    from test_gpu_phrase import _corpus
+    from seekstorm_amd import _native as N
+    n_docs, nd = 170_000, 3  # 2 full levels + a partial one; terms 0..2 dense, 3.. sparse
+    dfs = [30_000, 22_000, 40_000, 9_000, 700, 60, 3, 2_000]
+    plant = [([0, 3], 300), ([3, 4], 80), ([1, 4, 0], 60), ([3, 3], 50), ([7, 0], 100), ([5, 1], 20), ([0, 1], 400)]
+    dl, offs, docs, tfs, positions = _corpus(O, n_docs, dfs, 43, plant)
+    pstart = np.zeros(len(docs) + 1, np.int64)
+    pstart[1:] = np.cumsum(tfs.astype(np.int64))
+    lists = []
+    for t in range(len(dfs)):
+        a, b = int(offs[t]), int(offs[t + 1])
+        first = a + int(np.searchsorted(docs[a:b], 65536)) if t == 7 else a  # term 7 enters the vocabulary with level 1
+        lists.append((docs[first:b], tfs[first:b], positions[pstart[first]:pstart[b]]))
+
+    def cut(t, d0, d1):
+        d, tf, ps = lists[t]
+        i0, i1 = int(np.searchsorted(d, d0)), int(np.searchsorted(d, d1))
+        pst = np.zeros(len(d) + 1, np.int64)
+        pst[1:] = np.cumsum(tf.astype(np.int64))
+        return d[i0:i1], tf[i0:i1], ps[pst[i0]:pst[i1]]
+
+    def csr(terms, d0, d1):
+        o, dd, tt, pp = [0], [], [], []
+        for t in terms:
+            d, tf, ps = cut(t, d0, d1)
+            dd.append(d); tt.append(tf); pp.append(ps); o.append(o[-1] + len(d))
+        return np.asarray(o, np.uint64), np.concatenate(dd), np.concatenate(tt), np.concatenate(pp)
+
+    phrases = [[0, 3], [3, 4], [1, 4, 0], [3, 3], [7, 0], [5, 1], [0, 1], [4, 3]]
+    sets = [[0, 3], [4, 1, 2], [5, 6, 0], [3, 4], [7, 3, 1], [6], [7], [1, 2]]
+    nots = [([0, 1], [3]), ([3], [0]), ([4, 2], [7]), ([3, 7], [1])]
+    inc = S.Shard(0)
+    n_levels = (n_docs + 65535) >> 16
+    ref = None
+    for l in range(n_levels):
+        d0, d1 = l << 16, min(n_docs, (l + 1) << 16)
+        sparse_terms = list(range(nd, 7 if l == 0 else 8))
+        o, dd, tt, pp = csr(range(nd), d0, d1)
+        inc.append_level(l, dl[d0:d1], o, dd, tt, positions=pp)
+        o, dd, tt, pp = csr(sparse_terms, d0, d1)
+        inc.append_sparse_level(o, dd, tt, positions=pp)
+        assert inc.sparse_info()[0] == len(sparse_terms)
+        if ref is not None:
+            ref.close()
+        ref = S.Shard(0)
+        o, dd, tt, pp = csr(range(nd), 0, d1)
+        ref.upload_lexical(d1, dl[:d1], o, dd, tt, pp)
+        o, dd, tt, pp = csr(sparse_terms, 0, d1)
+        assert ref.append_sparse(o, dd, tt, positions=pp) == nd
+        known = lambda q: all(t < nd + len(sparse_terms) for t in q)
+        ph, st = [q for q in phrases if known(q)], [q for q in sets if known(q)]
+        nt_ = [c for c in nots if known(c[0] + c[1])]
+        assert np.array_equal(inc.posting_count(np.arange(nd + len(sparse_terms))), ref.posting_count(np.arange(nd + len(sparse_terms))))
+        for k in (10, 100):
+            for rt in (S.ResultType.TopkCount, S.ResultType.Count):
+                _same(inc.search_lexical_batch(inc.make_queries(ph, S.QueryType.Phrase), k, rt),
+                      ref.search_lexical_batch(ref.make_queries(ph, S.QueryType.Phrase), k, rt), ("phrases", l, k, rt))
+                for qt in (S.QueryType.Union, S.QueryType.Intersection):
+                    _same(inc.search_lexical_batch(inc.make_queries(st, qt), k, rt), ref.search_lexical_batch(ref.make_queries(st, qt), k, rt),
+                          ("sets", l, k, rt, qt))
+                    _same(inc.search_lexical_batch(inc.make_queries([c[0] for c in nt_], qt, [c[1] for c in nt_]), k, rt),
+                          ref.search_lexical_batch(ref.make_queries([c[0] for c in nt_], qt, [c[1] for c in nt_]), k, rt), ("NOT terms", l, k, rt, qt))
+    assert int(inc.search_lexical_batch(inc.make_queries([[0, 3]], S.QueryType.Phrase), 10)[3][0]) >= 300
+    # refused, and the tier stays what it was: postings that are not behind their list's last doc; whole lists into a tier of levels;
+    # a grown DENSE vocabulary under a tier
+    o, dd, tt, pp = csr(range(nd, 8), (n_levels - 1) << 16, n_docs)
+    with pytest.raises(N.SeekStormHipError):
+        inc.append_sparse_level(o, dd, tt, positions=pp)
+    with pytest.raises(N.SeekStormHipError):
+        inc.append_sparse(o, dd, tt, positions=pp)
+    with pytest.raises(N.SeekStormHipError):
+        inc.append_sparse_level(o, dd, tt)  # no positions for a tier that carries them
+    o4, d4, t4, p4 = csr(range(nd + 1), (n_levels - 1) << 16, n_docs)
+    with pytest.raises(N.SeekStormHipError):
+        inc.append_level(n_levels - 1, dl[(n_levels - 1) << 16:], o4, d4, t4, positions=p4)
+    _same(inc.search_lexical_batch(inc.make_queries(sets, S.QueryType.Union), 10), ref.search_lexical_batch(ref.make_queries(sets, S.QueryType.Union), 10),
+          "after the refusals")
+    ref.close()
+    inc.close()
