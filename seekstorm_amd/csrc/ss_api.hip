@@ -884,7 +884,7 @@ int ss_bm25_sparse_info(ss_shard* s, uint32_t* n_lists, uint64_t* n_postings, ui
   const uint64_t np = s->h_sp_base.empty() ? 0 : s->h_sp_base.back();
   if (n_lists) *n_lists = s->sp_n;
   if (n_postings) *n_postings = np;
-  if (bytes) *bytes = np * 8 + ((uint64_t)s->sp_n + 1) * 8;
+  if (bytes) *bytes = np * (ssi_bm25_sparse_levels_has(s) ? 10 : 8) + ((uint64_t)s->sp_n + 1) * 8;  // (a tier of levels keeps the tfs)
   return SS_OK;
 }
 
