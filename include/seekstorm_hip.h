@@ -327,13 +327,15 @@ int ss_bm25_append_level_positions(ss_shard* s, uint32_t level, uint32_t n_level
                                    const uint16_t* positions, uint64_t n_positions);
 /* ... on an image WITH A SPARSE TIER (one indexed field): after ss_bm25_append_level[_positions] of the level's dense terms (whose
  * number then stays what it was: n_terms as before, SS_ENOTSUP otherwise -- new terms start rare), the level's postings of the RARE
- * terms: list i continues sparse list i (term id = dense terms + i) with docs behind everything the list holds; n_lists >= the tier's
- * current lists -- the further ones are new terms.  The first call creates the tier.  The tier keeps every posting's tf (2 bytes
+ * terms in that level (level = the one just committed): list i continues sparse list i (term id = dense terms + i), doc ids inside the
+ * level; n_lists >= the tier's current lists -- the further ones are new terms.  A level the tier has seen already is REPLACED by the
+ * call (the re-commit of a level that was incomplete, commit.rs:204-206: first ss_bm25_append_level with the same level, then this);
+ * levels without rare postings may be skipped.  The first call creates the tier.  The tier keeps every posting's tf (2 bytes
  * beside its 8) and re-codes all its postings on the device after every commit, as the average length moves (commit.rs:318-325); with
  * positions (every level brings them, or none does; same meaning as above) phrases may name its terms.  A tier filled by whole lists
  * (ss_bm25_append_sparse) takes no levels, and this one no whole lists (SS_ESTATE).  SS_EINVAL leaves the tier as it was. */
-int ss_bm25_append_sparse_level(ss_shard* s, uint32_t n_lists, const uint64_t* offs /*[n_lists+1]*/, const uint32_t* doc_ids, const uint16_t* tfs,
-                                const uint16_t* npos, const uint16_t* positions, uint64_t n_positions);
+int ss_bm25_append_sparse_level(ss_shard* s, uint32_t level, uint32_t n_lists, const uint64_t* offs /*[n_lists+1]*/, const uint32_t* doc_ids,
+                                const uint16_t* tfs, const uint16_t* npos, const uint16_t* positions, uint64_t n_positions);
 int ss_bm25_incremental_info(ss_shard* s, uint32_t* n_levels, uint64_t* raw_bytes, double* last_append_ms, double* last_rebuild_ms);
 /* Search strategy.  AUTO: requests with <= 4 scored terms and k <= 128 take the PRUNED path (the reference's block-max /
  * sub-query pruning, intersection.rs:2224-2233, union.rs:1355-1405, as MaxScore over a probe index: only essential /

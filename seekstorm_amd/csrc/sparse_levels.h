@@ -9,7 +9,8 @@ bool ssi_bm25_sparse_levels_has(const ss_shard* s);
 void ssi_bm25_sparse_levels_drop(const ss_shard* s);
 // every sparse posting's code again from its tf, the image's d_doclen and d_comp (after a commit moved the average length)
 int ssi_bm25_sparse_levels_recode(ss_shard* s, hipStream_t st);
-// the level's postings of the rare terms: list i continues sparse list i (ascending docs, all behind the list's last), lists past
-// the tier's current count are new terms.  Caller holds s->mu, the device is idle.
-int ssi_bm25_append_sparse_level(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
+// the postings of the rare terms in `level` (the level the dense image committed last): list i continues sparse list i (ascending
+// docs, all behind the list's last), lists past the tier's current count are new terms; a level the tier has seen already is
+// replaced.  Caller holds s->mu, the device is idle.
+int ssi_bm25_append_sparse_level(ss_shard* s, uint32_t level, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
                                  const uint16_t* npos, const uint16_t* positions, uint64_t n_positions);

@@ -547,7 +547,7 @@ static int append_level_impl(ss_shard* s, uint32_t level, uint32_t n_level_docs,
     if (s->d_post && s->raw.empty()) return SS_ESTATE;       // an image that was not built level by level
     // a sparse tier numbers its terms behind the dense ones: a grown dense vocabulary would shift them -- new terms of an image with a
     // tier join the tier (ss_bm25_append_sparse_level), whose postings must come level by level too (their tfs are kept for re-coding)
-    if (s->sp_n && (!ssi_bm25_sparse_levels_has(s) || n_terms != s->bm_n_terms || level < s->raw.size())) return SS_ENOTSUP;
+    if (s->sp_n && (!ssi_bm25_sparse_levels_has(s) || n_terms != s->bm_n_terms)) return SS_ENOTSUP;
     if (level > s->raw.size() || level + 1 < s->raw.size()) return SS_EINVAL;  // append the next level, or replace the last one (a re-commit)
     if (level >= 1 && s->raw[level - 1].n_docs != 65536u) return SS_EINVAL;    // only the last level may be partial
     if ((uint64_t)level * 65536u + n_level_docs > 0xFFFFFFFFull) return SS_ENOTSUP;
@@ -823,14 +823,14 @@ int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df
   return SS_OK;
 }
 
-int ss_bm25_append_sparse_level(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs, const uint16_t* npos,
-                                const uint16_t* positions, uint64_t n_positions) {
+int ss_bm25_append_sparse_level(ss_shard* s, uint32_t level, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
+                                const uint16_t* npos, const uint16_t* positions, uint64_t n_positions) {
   if (!s || !offs || n_lists == 0 || (offs[n_lists] > offs[0] && (!docs || !tfs))) return SS_EINVAL;
   std::lock_guard<std::mutex> g(s->mu);
   if (s->raw.empty()) return SS_ESTATE;  // an image that grows level by level (ss_bm25_append_level)
   SS_HIP(hipSetDevice(s->device));
   SS_HIP(hipDeviceSynchronize());  // searches on the callers' own streams may still read the arrays the level replaces
-  return ssi_bm25_append_sparse_level(s, n_lists, offs, docs, tfs, npos, positions, n_positions);
+  return ssi_bm25_append_sparse_level(s, level, n_lists, offs, docs, tfs, npos, positions, n_positions);
 }
 int ss_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
                           uint32_t* first_term_id_out) {

@@ -858,6 +858,8 @@ namespace {
 struct SparseLevels {
   uint16_t* d_tf = nullptr;    // [sparse postings] the tf behind every posting's code
   std::vector<uint64_t> h_pbase;    // [sp_n + 1] first position of every list in d_sp_pos (a tier with positions)
+  int64_t last_level = -1;          // the level the last call brought (a re-commit of it replaces what it brought) ...
+  std::vector<uint32_t> h_last_n, h_last_pos;  // ... per list: its postings / positions of that level, the lists' tails
 };
 std::mutex g_spl_mu;
 std::unordered_map<const ss_shard*, SparseLevels> g_spl;
@@ -866,6 +868,7 @@ struct SpExtend {
   const uint64_t* old_base; uint32_t n_old; const uint64_t* new_base; uint32_t n_lists;
   const uint64_t* old_post; const uint16_t* old_tf; uint64_t* new_post; uint16_t* new_tf;
   const uint64_t* lvl_off; const uint32_t* lvl_doc; const uint16_t* lvl_tf;
+  const uint32_t* drop_n; const uint32_t* drop_p;  // a replaced level: the postings / positions at every old list's tail that go (or nullptr)
   const uint64_t* old_pbase; const uint64_t* new_pbase; const uint64_t* old_pend; uint64_t* new_pend;  // positions (new_pend == nullptr: a tier without)
   const uint16_t* old_pool; uint16_t* new_pool; const uint32_t* lvl_pend; const uint64_t* lvl_pbase; const uint16_t* lvl_pool;
   uint32_t n_docs; uint32_t* bad;
@@ -878,10 +881,10 @@ __global__ void __launch_bounds__(256) sp_extend_kernel(SpExtend A) {
   if (i64 >= A.n_lists) return;
   const uint32_t i = (uint32_t)i64;
   const bool was = i < A.n_old;
-  const uint64_t ob = was ? A.old_base[i] : 0ull, no = was ? A.old_base[i + 1] - ob : 0ull;
+  const uint64_t ob = was ? A.old_base[i] : 0ull, no = was ? A.old_base[i + 1] - ob - (A.drop_n ? A.drop_n[i] : 0u) : 0ull;
   const uint64_t nb = A.new_base[i], lo = A.lvl_off[i], nn = A.lvl_off[i + 1] - lo;
   const bool pos = A.new_pend != nullptr;
-  const uint64_t opb = (pos && was) ? A.old_pbase[i] : 0ull, opn = (pos && was) ? A.old_pbase[i + 1] - opb : 0ull;
+  const uint64_t opb = (pos && was) ? A.old_pbase[i] : 0ull, opn = (pos && was) ? A.old_pbase[i + 1] - opb - (A.drop_p ? A.drop_p[i] : 0u) : 0ull;
   const uint64_t npb = pos ? A.new_pbase[i] : 0ull;
   for (uint64_t j = lane; j < no; j += 64u) {
     A.new_post[nb + j] = A.old_post[ob + j];
@@ -906,9 +909,10 @@ __global__ void __launch_bounds__(256) sp_extend_kernel(SpExtend A) {
 }
 // a sparse posting's code from its tf and its doc's length byte -- the operations of bm_weight_exact / raw_fill_kernel
 __global__ void __launch_bounds__(256) sp_recode_kernel(uint64_t* __restrict__ post, const uint16_t* __restrict__ tf, uint64_t n,
-                                                        const uint8_t* __restrict__ doclen, const float* __restrict__ comp, float k1) {
+                                                        const uint8_t* __restrict__ doclen, uint32_t n_docs, const float* __restrict__ comp, float k1) {
   for (uint64_t p = (uint64_t)blockIdx.x * 256u + threadIdx.x; p < n; p += (uint64_t)gridDim.x * 256u) {
     const uint32_t d = (uint32_t)post[p];
+    if (d >= n_docs) continue;  // (a re-committed level that shrank: its sparse postings go with the sparse re-commit)
     const float tt = (float)tf[p];
     const float wgt = __fdiv_rn(ss_fmul(tt, k1), ss_fadd(tt, comp[doclen[d]]));
     post[p] = ((uint64_t)bm_wcode(wgt) << 32) | d;
@@ -938,12 +942,12 @@ int ssi_bm25_sparse_levels_recode(ss_shard* s, hipStream_t st) {
   if (!n) return SS_OK;
   if (!s->d_sp_post || !d_tf || !s->d_doclen || !s->d_comp) return SS_ESTATE;
   const volatile float k1 = 1.2f + 1.0f;  // (K + 1) as bm_weight_exact forms it
-  sp_recode_kernel<<<(uint32_t)std::min<uint64_t>((n + 255) / 256, 65536), 256, 0, st>>>(s->d_sp_post, d_tf, n, s->d_doclen, s->d_comp, k1);
+  sp_recode_kernel<<<(uint32_t)std::min<uint64_t>((n + 255) / 256, 65536), 256, 0, st>>>(s->d_sp_post, d_tf, n, s->d_doclen, s->bm_n_docs, s->d_comp, k1);
   SS_HIP(hipGetLastError());
   return SS_OK;
 }
 
-int ssi_bm25_append_sparse_level(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
+int ssi_bm25_append_sparse_level(ss_shard* s, uint32_t level, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
                                  const uint16_t* npos, const uint16_t* positions, uint64_t n_positions) {
   if (!s->d_post || !s->d_doclen || !s->d_comp) return SS_ESTATE;
   if (s->bm_n_fields != 1 || s->bm_merged) return SS_ENOTSUP;  // several indexed fields: whole-image uploads
@@ -959,25 +963,41 @@ int ssi_bm25_append_sparse_level(ss_shard* s, uint32_t n_lists, const uint64_t* 
   const uint64_t n_new = offs[n_lists] - offs[0], o0 = offs[0];
   const uint32_t n_old = s->sp_n;
   const uint64_t old_n = s->h_sp_base.empty() ? 0 : s->h_sp_base.back();
+  // the level: the one the dense image committed last; a level this tier has seen already is replaced (the re-commit of a level
+  // that was incomplete, commit.rs:204-206 merge_incomplete_index_level_to_level0)
+  if ((uint64_t)level + 1 != s->raw.size()) return SS_EINVAL;
+  std::vector<uint32_t> drop_n, drop_p;
+  std::vector<uint64_t> old_pbase;
+  {
+    std::lock_guard<std::mutex> g(g_spl_mu);
+    auto it = g_spl.find(s);
+    if (it != g_spl.end()) {
+      if ((int64_t)level < it->second.last_level) return SS_EINVAL;
+      if ((int64_t)level == it->second.last_level) { drop_n = it->second.h_last_n; drop_p = it->second.h_last_pos; }
+      old_pbase = it->second.h_pbase;
+    }
+  }
+  const bool replace = !drop_n.empty();
+  if (replace && (drop_n.size() != n_old || (with_pos && drop_p.size() != n_old))) return SS_ESTATE;
+  const uint64_t d_lo = (uint64_t)level << 16;
   std::atomic<int> fail{SS_OK};
   ss_parallel_for(n_lists, 4096, [&](size_t a, size_t b, unsigned) {
     for (size_t i = a; i < b; i++)
       for (uint64_t j = offs[i]; j < offs[i + 1]; j++)
-        if (docs[j] >= s->bm_n_docs || tfs[j] == 0 || (j > offs[i] && docs[j] <= docs[j - 1])) { fail.store(SS_EINVAL); return; }
+        if (docs[j] < d_lo || docs[j] >= s->bm_n_docs || tfs[j] == 0 || (j > offs[i] && docs[j] <= docs[j - 1])) { fail.store(SS_EINVAL); return; }
   });
   if (fail.load()) return fail.load();
   // the new starts of the lists (postings; positions), the level's own offsets
-  std::vector<uint64_t> base((size_t)n_lists + 1, 0), lvl_off((size_t)n_lists + 1), pbase, lvl_pbase, old_pbase;
-  for (uint32_t i = 0; i < n_lists; i++)
-    base[i + 1] = base[i] + (i < n_old ? s->h_sp_base[i + 1] - s->h_sp_base[i] : 0ull) + (offs[i + 1] - offs[i]);
+  std::vector<uint64_t> base((size_t)n_lists + 1, 0), lvl_off((size_t)n_lists + 1), pbase, lvl_pbase;
+  uint64_t dropped_p = 0;
+  for (uint32_t i = 0; i < n_lists; i++) {
+    uint64_t had = i < n_old ? s->h_sp_base[i + 1] - s->h_sp_base[i] : 0ull;
+    if (replace && i < n_old) { if (drop_n[i] > had) return SS_ESTATE; had -= drop_n[i]; }
+    base[i + 1] = base[i] + had + (offs[i + 1] - offs[i]);
+  }
   for (uint32_t i = 0; i <= n_lists; i++) lvl_off[i] = offs[i] - o0;
   std::vector<uint32_t> lvl_pend;
   if (with_pos) {
-    {
-      std::lock_guard<std::mutex> g(g_spl_mu);
-      auto it = g_spl.find(s);
-      if (it != g_spl.end()) old_pbase = it->second.h_pbase;
-    }
     if (old_pbase.size() != (size_t)n_old + 1) { if (n_old) return SS_ESTATE; old_pbase.assign(1, 0); }
     lvl_pend.resize(n_new ? n_new : 1);
     lvl_pbase.assign((size_t)n_lists + 1, 0);
@@ -996,9 +1016,12 @@ int ssi_bm25_append_sparse_level(ss_shard* s, uint32_t n_lists, const uint64_t* 
     for (uint32_t i = 0; i < n_lists; i++) lvl_pbase[i + 1] += lvl_pbase[i];
     if (lvl_pbase[n_lists] != n_positions) return SS_EINVAL;
     pbase.assign((size_t)n_lists + 1, 0);
-    for (uint32_t i = 0; i < n_lists; i++)
-      pbase[i + 1] = pbase[i] + (i < n_old ? old_pbase[i + 1] - old_pbase[i] : 0ull) + (lvl_pbase[i + 1] - lvl_pbase[i]);
-    if (pbase[n_lists] != s->sp_pos_n + n_positions) return SS_ESTATE;
+    for (uint32_t i = 0; i < n_lists; i++) {
+      uint64_t had = i < n_old ? old_pbase[i + 1] - old_pbase[i] : 0ull;
+      if (replace && i < n_old) { if (drop_p[i] > had) return SS_ESTATE; had -= drop_p[i]; dropped_p += drop_p[i]; }
+      pbase[i + 1] = pbase[i] + had + (lvl_pbase[i + 1] - lvl_pbase[i]);
+    }
+    if (pbase[n_lists] != s->sp_pos_n - dropped_p + n_positions) return SS_ESTATE;
   }
   // device: the new arrays, the level's staging
   std::vector<void*> owned;
@@ -1010,7 +1033,8 @@ int ssi_bm25_append_sparse_level(ss_shard* s, uint32_t n_lists, const uint64_t* 
   };
   auto drop_all = [&]() { for (void* p : owned) (void)hipFree(p); owned.clear(); };
   auto up = [&](void* d, const void* h, size_t bytes) { return bytes == 0 || hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) == hipSuccess; };
-  const uint64_t tot = old_n + n_new;
+  const uint64_t tot = base[n_lists];
+  (void)old_n;
   uint64_t* nbase = (uint64_t*)dalloc(base.size() * 8);
   uint64_t* npost = (uint64_t*)dalloc((size_t)tot * 8);
   uint16_t* ntf = (uint16_t*)dalloc((size_t)tot * 2);
@@ -1018,6 +1042,7 @@ int ssi_bm25_append_sparse_level(ss_shard* s, uint32_t n_lists, const uint64_t* 
   uint32_t* d_lvl_doc = (uint32_t*)dalloc((size_t)n_new * 4);
   uint16_t* d_lvl_tf = (uint16_t*)dalloc((size_t)n_new * 2);
   uint32_t* d_bad = (uint32_t*)dalloc(4);
+  uint32_t *d_drop_n = nullptr, *d_drop_p = nullptr;
   uint64_t *d_old_pbase = nullptr, *d_new_pbase = nullptr, *npend = nullptr, *d_lvl_pbase = nullptr;
   uint16_t *npool = nullptr, *d_lvl_pool = nullptr;
   uint32_t* d_lvl_pend = nullptr;
@@ -1032,6 +1057,11 @@ int ssi_bm25_append_sparse_level(ss_shard* s, uint32_t n_lists, const uint64_t* 
     d_lvl_pend = (uint32_t*)dalloc((size_t)n_new * 4);
     ok = d_old_pbase && d_new_pbase && npend && d_lvl_pbase && npool && d_lvl_pool && d_lvl_pend;
   }
+  if (ok && replace && n_old) {
+    d_drop_n = (uint32_t*)dalloc((size_t)n_old * 4);
+    if (with_pos) d_drop_p = (uint32_t*)dalloc((size_t)n_old * 4);
+    ok = d_drop_n && (!with_pos || d_drop_p);
+  }
   if (!ok) { drop_all(); return SS_ENOMEM; }
   const uint32_t zero = 0;
   ok = up(nbase, base.data(), base.size() * 8) && up(d_lvl_off, lvl_off.data(), lvl_off.size() * 8) && up(d_lvl_doc, docs + o0, (size_t)n_new * 4) &&
@@ -1040,6 +1070,7 @@ int ssi_bm25_append_sparse_level(ss_shard* s, uint32_t n_lists, const uint64_t* 
     ok = up(d_old_pbase, old_pbase.data(), old_pbase.size() * 8) && up(d_new_pbase, pbase.data(), pbase.size() * 8) &&
          up(d_lvl_pbase, lvl_pbase.data(), lvl_pbase.size() * 8) && up(d_lvl_pool, positions, (size_t)n_positions * 2) &&
          up(d_lvl_pend, lvl_pend.data(), (size_t)n_new * 4);
+  if (ok && d_drop_n) ok = up(d_drop_n, drop_n.data(), (size_t)n_old * 4) && (!d_drop_p || up(d_drop_p, drop_p.data(), (size_t)n_old * 4));
   if (!ok) { drop_all(); return SS_EDEVICE; }
   uint16_t* old_tf = nullptr;
   {
@@ -1051,6 +1082,7 @@ int ssi_bm25_append_sparse_level(ss_shard* s, uint32_t n_lists, const uint64_t* 
   A.old_base = s->d_sp_base; A.n_old = n_old; A.new_base = nbase; A.n_lists = n_lists;
   A.old_post = s->d_sp_post; A.old_tf = old_tf; A.new_post = npost; A.new_tf = ntf;
   A.lvl_off = d_lvl_off; A.lvl_doc = d_lvl_doc; A.lvl_tf = d_lvl_tf;
+  A.drop_n = d_drop_n; A.drop_p = d_drop_p;
   A.old_pbase = d_old_pbase; A.new_pbase = d_new_pbase; A.old_pend = s->d_sp_pos_end; A.new_pend = with_pos ? npend : nullptr;
   A.old_pool = (const uint16_t*)s->d_sp_pos; A.new_pool = npool; A.lvl_pend = d_lvl_pend; A.lvl_pbase = d_lvl_pbase; A.lvl_pool = d_lvl_pool;
   A.n_docs = s->bm_n_docs; A.bad = d_bad;
@@ -1080,6 +1112,14 @@ int ssi_bm25_append_sparse_level(ss_shard* s, uint32_t n_lists, const uint64_t* 
     if (E.d_tf) (void)hipFree(E.d_tf);
     E.d_tf = ntf;
     E.h_pbase = std::move(pbase);
+    E.last_level = level;
+    E.h_last_n.resize(n_lists);
+    for (uint32_t i = 0; i < n_lists; i++) E.h_last_n[i] = (uint32_t)(offs[i + 1] - offs[i]);
+    E.h_last_pos.clear();
+    if (with_pos) {
+      E.h_last_pos.resize(n_lists);
+      for (uint32_t i = 0; i < n_lists; i++) E.h_last_pos[i] = (uint32_t)(lvl_pbase[i + 1] - lvl_pbase[i]);
+    }
   }
   const int rc = ssi_bm25_sparse_levels_recode(s, s->stream);
   if (rc != SS_OK) return rc;

@@ -1132,9 +1132,9 @@ class Shard:
         self._df_cache.clear()
         return int(first.value)
 
-    def append_sparse_level(self, term_offsets, doc_ids, tfs, positions=None, npos=None):
+    def append_sparse_level(self, level, term_offsets, doc_ids, tfs, positions=None, npos=None):
         """the committed level's postings of the RARE terms of an image that grows by levels (ss_bm25_append_sparse_level, after
-        append_level of its dense terms): list i continues sparse list i, further lists are new terms"""
+        append_level of its dense terms): list i continues sparse list i, further lists are new terms; a level brought before is replaced"""
         offs = np.ascontiguousarray(term_offsets, np.uint64)
         d = np.ascontiguousarray(doc_ids, np.uint32)
         t = np.ascontiguousarray(tfs, np.uint16)
@@ -1145,7 +1145,7 @@ class Shard:
         else:
             n_ps = 0 if ps is None else len(ps)
         npc = None if npos is None else np.ascontiguousarray(npos, np.uint16)
-        N.check(N.lib().ss_bm25_append_sparse_level(self._h, len(offs) - 1, N.ptr(offs, N.u64p), N.ptr(d, N.u32p), N.ptr(t, N.u16p),
+        N.check(N.lib().ss_bm25_append_sparse_level(self._h, int(level), len(offs) - 1, N.ptr(offs, N.u64p), N.ptr(d, N.u32p), N.ptr(t, N.u16p),
                                                     N.ptr(npc, N.u16p), N.ptr(ps, N.u16p), n_ps), "ss_bm25_append_sparse_level")
         self._df_cache.clear()
 

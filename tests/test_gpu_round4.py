@@ -809,13 +809,14 @@ def test_sparse_tier_committed_level_by_level_equals_the_one_shot_tiered_upload(
     inc = S.Shard(0)
     n_levels = (n_docs + 65535) >> 16
     ref = None
-    for l in range(n_levels):
-        d0, d1 = l << 16, min(n_docs, (l + 1) << 16)
+    # the last level is committed half full first and re-committed whole (commit.rs:204-206): both calls replace what it brought
+    for l, d1 in [(0, 65536), (1, 131072), (2, 150_000), (2, n_docs)]:
+        d0 = l << 16
         sparse_terms = list(range(nd, 7 if l == 0 else 8))
         o, dd, tt, pp = csr(range(nd), d0, d1)
         inc.append_level(l, dl[d0:d1], o, dd, tt, positions=pp)
         o, dd, tt, pp = csr(sparse_terms, d0, d1)
-        inc.append_sparse_level(o, dd, tt, positions=pp)
+        inc.append_sparse_level(l, o, dd, tt, positions=pp)
         assert inc.sparse_info()[0] == len(sparse_terms)
         if ref is not None:
             ref.close()
@@ -838,15 +839,18 @@ def test_sparse_tier_committed_level_by_level_equals_the_one_shot_tiered_upload(
                     _same(inc.search_lexical_batch(inc.make_queries([c[0] for c in nt_], qt, [c[1] for c in nt_]), k, rt),
                           ref.search_lexical_batch(ref.make_queries([c[0] for c in nt_], qt, [c[1] for c in nt_]), k, rt), ("NOT terms", l, k, rt, qt))
     assert int(inc.search_lexical_batch(inc.make_queries([[0, 3]], S.QueryType.Phrase), 10)[3][0]) >= 300
-    # refused, and the tier stays what it was: postings that are not behind their list's last doc; whole lists into a tier of levels;
-    # a grown DENSE vocabulary under a tier
+    # refused, and the tier stays what it was: a level other than the one just committed; docs outside the level; whole lists into a
+    # tier of levels; no positions for a tier that carries them; a grown DENSE vocabulary under a tier
     o, dd, tt, pp = csr(range(nd, 8), (n_levels - 1) << 16, n_docs)
     with pytest.raises(N.SeekStormHipError):
-        inc.append_sparse_level(o, dd, tt, positions=pp)
+        inc.append_sparse_level(n_levels - 2, o, dd, tt, positions=pp)
+    o1, d1_, t1, p1 = csr(range(nd, 8), (n_levels - 2) << 16, n_docs)
+    with pytest.raises(N.SeekStormHipError):
+        inc.append_sparse_level(n_levels - 1, o1, d1_, t1, positions=p1)
     with pytest.raises(N.SeekStormHipError):
         inc.append_sparse(o, dd, tt, positions=pp)
     with pytest.raises(N.SeekStormHipError):
-        inc.append_sparse_level(o, dd, tt)  # no positions for a tier that carries them
+        inc.append_sparse_level(n_levels - 1, o, dd, tt)
     o4, d4, t4, p4 = csr(range(nd + 1), (n_levels - 1) << 16, n_docs)
     with pytest.raises(N.SeekStormHipError):
         inc.append_level(n_levels - 1, dl[(n_levels - 1) << 16:], o4, d4, t4, positions=p4)

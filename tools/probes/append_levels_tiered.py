@@ -42,7 +42,7 @@ for lv in range(n_levels):
     t1 = time.perf_counter()
     inc.append_level(lv, dl[lo:hi], offs, docs, tfs)
     t2 = time.perf_counter()
-    inc.append_sparse_level(s_offs, s_docs, s_tfs)
+    inc.append_sparse_level(lv, s_offs, s_docs, s_tfs)
     t3 = time.perf_counter()
     ms_d.append((t2 - t1) * 1e3); ms_s.append((t3 - t2) * 1e3)
     if lv % 16 == 0 or lv == n_levels - 1:
