@@ -220,6 +220,29 @@ int Shard::open_vector_bin(const uint8_t* bytes, uint64_t len, uint32_t dim, boo
   return rc;
 }
 
+int Shard::commit_level(uint32_t level, uint32_t n_level_docs, const uint8_t* level_doclen, uint32_t n_terms, uint32_t n_dense_terms,
+                        const uint64_t* term_offsets, const uint32_t* doc_ids, const uint16_t* tfs, const uint16_t* positions,
+                        uint64_t n_positions, const uint16_t* npos) {
+  if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
+  if (!term_offsets || n_dense_terms == 0 || n_dense_terms > n_terms) return SS_EINVAL;
+  // the CSR is in id order: the dense terms' part and the rare terms' part are its two ends, the positions pool splits where the
+  // dense postings' positions end
+  const uint64_t cut = term_offsets[n_dense_terms];
+  uint64_t p_cut = 0;
+  if (positions)
+    for (uint64_t j = term_offsets[0]; j < cut; j++) p_cut += npos ? npos[j] : tfs[j];
+  if (positions && p_cut > n_positions) return SS_EINVAL;
+  int rc = positions ? ss_bm25_append_level_positions(h_, level, n_level_docs, level_doclen, n_dense_terms, term_offsets, doc_ids, tfs, npos, positions, p_cut)
+                     : ss_bm25_append_level(h_, level, n_level_docs, level_doclen, n_dense_terms, term_offsets, doc_ids, tfs);
+  if (rc != SS_OK) return rc;
+  lexical_fields_ = 1;
+  n_docs_ = (uint64_t)level * 65536u + n_level_docs;
+  if (n_dense_terms < n_terms)
+    rc = ss_bm25_append_sparse_level(h_, level, n_terms - n_dense_terms, term_offsets + n_dense_terms, doc_ids, tfs, npos,
+                                     positions ? positions + p_cut : nullptr, positions ? n_positions - p_cut : 0);
+  return rc;
+}
+
 int Shard::set_deleted(const uint64_t* doc_ids, uint64_t n) {
   if (!h_) return create_rc_ ? create_rc_ : SS_ESTATE;
   const int rc = ss_set_deleted(h_, doc_ids, n);

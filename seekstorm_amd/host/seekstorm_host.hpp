@@ -124,6 +124,13 @@ class Shard {
   int upload_lexical_fields(uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen_bytes, const float* boost, uint32_t n_terms,
                             const uint64_t* term_offsets, const uint32_t* doc_ids, const uint8_t* field_ids, const uint16_t* tfs,
                             const uint16_t* positions = nullptr, uint64_t n_positions = 0);
+  // one commit (commit.rs:142-148 commit -> warmup; the re-commit of an incomplete level, 204-206, is the same call with the same
+  // level): the level's length bytes and its postings of ALL known terms in id order -- ids below n_dense_terms belong to the dense
+  // image, the others are the sparse tier's lists, new rare terms extend the id range (n_dense_terms == n_terms: no tier).
+  // positions (optional): every posting's, tf of them each or npos[i]
+  int commit_level(uint32_t level, uint32_t n_level_docs, const uint8_t* level_doclen, uint32_t n_terms, uint32_t n_dense_terms,
+                   const uint64_t* term_offsets, const uint32_t* doc_ids, const uint16_t* tfs, const uint16_t* positions = nullptr,
+                   uint64_t n_positions = 0, const uint16_t* npos = nullptr);
   // VectorSimilarity of the image (index-wide in the reference): Dot / Cosine (default) or Euclidean; BEFORE the upload
   int set_vector_similarity(bool euclidean);
   int upload_vectors(uint64_t n_rows, uint32_t dim, const float* rows, const uint32_t* row_doc_ids);

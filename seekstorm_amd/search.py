@@ -394,6 +394,28 @@ class Shard:
         self.lexical_field_count = 1
         self._df_cache.clear()
 
+    def commit_level(self, level, level_doclen, term_offsets, doc_ids, tfs, n_dense_terms=None, positions=None, npos=None):
+        """one commit as the seam sees it (commit.rs:142-148): the level's postings of ALL known terms in id order --
+        ids below n_dense_terms belong to the dense image (ss_bm25_append_level), the others are the sparse tier's lists
+        (ss_bm25_append_sparse_level; new rare terms simply extend the id range).  n_dense_terms None: no tier, every term is dense."""
+        off = np.ascontiguousarray(term_offsets, np.uint64)
+        nt = len(off) - 1
+        nd = nt if n_dense_terms is None else int(n_dense_terms)
+        if nd > nt:
+            raise ValueError("fewer terms than the dense image holds")
+        d = np.ascontiguousarray(doc_ids, np.uint32)
+        t = np.ascontiguousarray(tfs, np.uint16)
+        cut = int(off[nd])
+        p_cut = None
+        if positions is not None:
+            cnt = t if npos is None else np.ascontiguousarray(npos, np.uint16)
+            p_cut = int(cnt[int(off[0]):cut].astype(np.int64).sum())
+        npd = None if npos is None else npos[:cut]
+        self.append_level(level, level_doclen, off[:nd + 1], d[:cut], t[:cut], None if positions is None else positions[:p_cut], npd)
+        if nd < nt:
+            self.append_sparse_level(level, off[nd:] - off[nd], d[cut:], t[cut:], None if positions is None else positions[p_cut:],
+                                     None if npos is None else npos[cut:])
+
     def incremental_info(self):
         """(levels, bytes of the raw postings kept for rebuilds, ms of the last append, of which the device rebuild)"""
         nl, rb, a, b = C.c_uint32(), C.c_uint64(), C.c_double(), C.c_double()

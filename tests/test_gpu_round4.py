@@ -813,10 +813,14 @@ def test_sparse_tier_committed_level_by_level_equals_the_one_shot_tiered_upload(
     for l, d1 in [(0, 65536), (1, 131072), (2, 150_000), (2, n_docs)]:
         d0 = l << 16
         sparse_terms = list(range(nd, 7 if l == 0 else 8))
-        o, dd, tt, pp = csr(range(nd), d0, d1)
-        inc.append_level(l, dl[d0:d1], o, dd, tt, positions=pp)
-        o, dd, tt, pp = csr(sparse_terms, d0, d1)
-        inc.append_sparse_level(l, o, dd, tt, positions=pp)
+        if l == 1:  # the two ABI calls on their own ...
+            o, dd, tt, pp = csr(range(nd), d0, d1)
+            inc.append_level(l, dl[d0:d1], o, dd, tt, positions=pp)
+            o, dd, tt, pp = csr(sparse_terms, d0, d1)
+            inc.append_sparse_level(l, o, dd, tt, positions=pp)
+        else:       # ... and as the one commit of the mirrors: the level's postings of all known terms in id order
+            o, dd, tt, pp = csr(list(range(nd)) + sparse_terms, d0, d1)
+            inc.commit_level(l, dl[d0:d1], o, dd, tt, n_dense_terms=nd, positions=pp)
         assert inc.sparse_info()[0] == len(sparse_terms)
         if ref is not None:
             ref.close()
