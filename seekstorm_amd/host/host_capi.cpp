@@ -196,6 +196,11 @@ int ssh_upload_lexical_fields_positions(ssh_index* ix, int shard, uint64_t n_doc
   return ix->shards[shard]->upload_lexical_fields(n_docs, n_fields, doclen, boost, n_terms, offs, docs, fields, tfs, positions, n_positions);
 }
 int ssh_set_deleted(ssh_index* ix, int shard, const uint64_t* doc_ids, uint64_t n) { return ix->shards[shard]->set_deleted(doc_ids, n); }
+int ssh_commit_level(ssh_index* ix, int shard, uint32_t level, uint32_t n_level_docs, const uint8_t* level_doclen, uint32_t n_terms,
+                     uint32_t n_dense_terms, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs, const uint16_t* positions,
+                     uint64_t n_positions) {
+  return ix->shards[shard]->commit_level(level, n_level_docs, level_doclen, n_terms, n_dense_terms, offs, docs, tfs, positions, n_positions);
+}
 // Shard::facet_count of one query; out_counts [n_buckets + 1]
 int ssh_facet_count(ssh_index* ix, int shard, const uint32_t* terms, uint32_t n_terms, uint32_t query_type, uint32_t facet_offset,
                     uint32_t facet_type, uint32_t n_buckets, const uint64_t* bounds, uint32_t n_bounds, const ss_facet_point* base,

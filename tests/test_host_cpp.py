@@ -54,6 +54,7 @@ def H():
     L.ssh_upload_lexical_fields_positions.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, u8p, f32p, C.c_uint32, u64p, u32p, u8p, u16p,
                                                       u16p, C.c_uint64]
     L.ssh_set_deleted.argtypes = [C.c_void_p, C.c_int, u64p, C.c_uint64]
+    L.ssh_commit_level.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, u8p, C.c_uint32, C.c_uint32, u64p, u32p, u16p, u16p, C.c_uint64]
     L.ssh_facet_count.argtypes = [C.c_void_p, C.c_int, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u64p, C.c_uint32,
                                   C.c_void_p, C.c_uint32, C.c_void_p, u64p, u64p]
     L.ssh_coalesced_vector_search.argtypes = [C.c_void_p, C.c_int, C.c_uint32, f32p, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -605,6 +606,57 @@ def test_cpp_shard_union_under_a_field_filter(H):
     finally:
         H.ssh_index_destroy(ix)
         psh.close()
+
+
+@pytest.mark.gpu
+def test_cpp_shard_commits_levels_on_a_tiered_vocabulary(H):
+    """Shard::commit_level of the C++ mirror (commit.rs:142-148 as the seam sees it: a level's postings of all known terms, dense ids
+    first, rare terms behind them) level by level, the last level half full first and re-committed whole, against the Python mirror's
+    one-shot upload of the same docs (dense image + whole sparse lists): unions, intersections, NOT terms over both tiers"""
+    from oracle import oracle as O
+    import seekstorm_amd as S
+    n_docs, nd = 150_000, 3
+    rng = np.random.default_rng(77)
+    dl = O.lex_doclen(n_docs)
+    lists = []
+    for df in (40_000, 15_000, 60_000, 5_000, 300, 20, 1_500):
+        d = np.sort(rng.choice(n_docs, df, replace=False)).astype(np.uint32)
+        lists.append((d, np.minimum(rng.geometric(0.5, df), 40).astype(np.uint16)))
+
+    def csr(terms, d0, d1):
+        o, dd, tt = [0], [], []
+        for t in terms:
+            d, tf = lists[t]
+            i0, i1 = int(np.searchsorted(d, d0)), int(np.searchsorted(d, d1))
+            dd.append(d[i0:i1]); tt.append(tf[i0:i1]); o.append(o[-1] + (i1 - i0))
+        return np.asarray(o, np.uint64), np.concatenate(dd), np.concatenate(tt)
+
+    ix = H.ssh_index_create(1, None)
+    psh = None
+    try:
+        for l, d1 in [(0, 65536), (1, 131072), (2, 140_000), (2, n_docs)]:
+            d0 = l << 16
+            o, dd, tt = csr(range(len(lists)), d0, d1)
+            lv = np.ascontiguousarray(dl[d0:d1], np.uint8)
+            assert H.ssh_commit_level(ix, 0, l, d1 - d0, P(lv, u8p), len(lists), nd, P(o, u64p), P(dd, u32p), P(tt, u16p), None, 0) == 0
+            if psh is not None:
+                psh.close()
+            psh = S.Shard(0)
+            o, dd, tt = csr(range(nd), 0, d1)
+            psh.upload_lexical(d1, dl[:d1], o, dd, tt)
+            o, dd, tt = csr(range(nd, len(lists)), 0, d1)
+            assert psh.append_sparse(o, dd, tt) == nd
+            for terms, neg in (([0, 3], []), ([4, 1, 2], []), ([5, 6, 0], []), ([3, 4], []), ([6], []), ([0, 1], [3]), ([3, 6], [1]), ([1, 2], [])):
+                for qt in (S.QueryType.Union, S.QueryType.Intersection):
+                    ro = psh.search_lexical_shard(terms, qt, 0, 10, S.ResultType.TopkCount, strict=True, not_terms=neg)
+                    cd, cs, ctot = _cpp_lexical_ex(H, ix, terms, int(qt), 0, 10, 2, not_terms=neg)
+                    assert ctot == ro.result_count_total, (l, d1, terms, neg, qt)
+                    assert np.allclose(cs, np.array([r.score for r in ro.results], np.float32), rtol=1e-6), (l, d1, terms, neg, qt)
+                    assert list(cd) == [r.doc_id for r in ro.results], (l, d1, terms, neg, qt)
+    finally:
+        H.ssh_index_destroy(ix)
+        if psh is not None:
+            psh.close()
 
 
 @pytest.mark.gpu
