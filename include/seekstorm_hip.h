@@ -198,6 +198,12 @@ int ss_index_bin_filter(ss_index_bin* ix, uint64_t min_posting_count, uint32_t* 
 /* Host only: decodes every key as the uploads do (worker threads) and reports the postings ((doc, field) entries with several indexed
  * fields) and positions that came out -- what an open will have to move, and the decoder's speed on its own. */
 int ss_index_bin_decode_stats(const ss_index_bin* ix, int with_positions, uint64_t* n_postings_out, uint64_t* n_positions_out);
+/* ... and hands the decoded postings over (one indexed field; sizes from ss_index_bin_decode_stats): offs [terms + 1], doc_ids / tfs
+ * [postings] in term-id order; positions_out != NULL: npos [postings] = positions per posting (the tf for a SingleTerm key, the key's
+ * own count behind the FIRST component of an n-gram key, 0 behind the others) and their concatenation.  SS_EINVAL when a capacity is
+ * too small.  What the image builders consume -- for hosts that assemble levels themselves (ss_bm25_append_level) and for tests. */
+int ss_index_bin_decode_all(const ss_index_bin* ix, uint64_t* offs_out, uint32_t* doc_ids_out, uint16_t* tfs_out, uint64_t postings_cap,
+                            uint16_t* npos_out, uint16_t* positions_out, uint64_t positions_cap);
 /* Two tiers instead of dropping the tail: keys with at least dense_min_posting_count postings come first (ascending key hash) and
  * become the dense image's terms, the others follow (ascending key hash) and go to the SPARSE tier (ss_bm25_append_sparse) when
  * the index is uploaded with ss_bm25_upload_index_bin -- a real vocabulary's millions of rare keys then cost 8 bytes per posting,

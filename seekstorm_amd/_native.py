@@ -107,6 +107,7 @@ SYMBOLS = [
     ("ss_index_bin_open", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     ("ss_index_bin_filter", C.c_int, [C.c_void_p, C.c_uint64, u32p]),
     ("ss_index_bin_decode_stats", C.c_int, [C.c_void_p, C.c_int, u64p, u64p]),
+    ("ss_index_bin_decode_all", C.c_int, [C.c_void_p, u64p, u32p, u16p, C.c_uint64, u16p, u16p, C.c_uint64]),
     ("ss_index_bin_close", C.c_int, [C.c_void_p]),
     ("ss_index_bin_info", C.c_int, [C.c_void_p, u64p, u64p, u32p, u32p, u32p]),
     ("ss_index_bin_term_keys", C.c_int, [C.c_void_p, u64p]),

@@ -590,6 +590,22 @@ extern "C" int ss_bm25_upload_ref_blocks(ss_shard* s, uint64_t n_docs, const uin
 //   key head (compress_postinglist.rs:339-409): u64 key_hash @0 (low 3 bits = NgramType), u16 posting_count - 1 @8,
 //     u16 max_docid @10, u16 max_p_docid @12, n-gram df bytes @14.., u16 pointer_pivot_p_docid @size-6,
 //     u32 compression_type_pointer @size-4
+// vector storage that is not value-initialised: resize() of the 10^7-entry block table would otherwise zero (and page in) the whole
+// array on one thread before the workers fill it
+template <class T>
+struct NoInitAlloc {
+  using value_type = T;
+  NoInitAlloc() = default;
+  template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+  T* allocate(size_t n) { return static_cast<T*>(::operator new(n * sizeof(T))); }
+  void deallocate(T* p, size_t) { ::operator delete(p); }
+  template <class U, class... A>
+  void construct(U* p, A&&... a) {
+    if constexpr (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...);
+  }
+  template <class U> bool operator==(const NoInitAlloc<U>&) const { return true; }
+  template <class U> bool operator!=(const NoInitAlloc<U>&) const { return false; }
+};
 struct ss_index_bin {
   const uint8_t* bytes = nullptr;
   uint64_t len = 0;
@@ -601,10 +617,10 @@ struct ss_index_bin {
   struct Blk {
     uint64_t key;
     ss_ref_block b;
-    uint8_t n_comp = 1, comp = 0;      // n-gram key: one entry per component term (2 or 3), SingleTerm: 1 / 0
-    uint8_t df_byte = 0;               // posting_count_ngram_{comp+1}_compressed of the key head
-  };
-  std::vector<Blk> blocks;             // sorted by (key, component, block_id)
+    uint8_t n_comp, comp;              // n-gram key: one entry per component term (2 or 3), SingleTerm: 1 / 0
+    uint8_t df_byte;                   // posting_count_ngram_{comp+1}_compressed of the key head
+  };                                   // (trivially constructible: see NoInitAlloc)
+  std::vector<Blk, NoInitAlloc<Blk>> blocks;  // sorted by (key, component, block_id)
   std::vector<uint64_t> keys;          // ascending; term id = index.  An n-gram key appears once per component, in order
   std::vector<uint8_t> term_comp, term_ncomp, term_df_byte;  // per term; df byte of the LAST level (commit.rs:646-653)
   std::vector<uint64_t> term_block_off;
@@ -622,6 +638,14 @@ extern "C" int ss_index_bin_open(const uint8_t* bytes, uint64_t len, uint32_t in
   if (key_head_size != 20 && key_head_size != 22 && key_head_size != 23) return SS_EINVAL;  // index.rs:2806-2812
   if (rd16(bytes) != 6u) return SS_ENOTSUP;  // INDEX_FORMAT_VERSION_MAJOR
   std::unique_ptr<ss_index_bin> ix(new ss_index_bin);
+  static const bool trace = getenv("SS_LOAD_TRACE") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[load] open: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+    t_last = t;
+  };
   ix->bytes = bytes; ix->len = len;
   ix->n_fields = indexed_field_count; ix->key_head_size = key_head_size; ix->seg_bits = segment_number_bits;
   const uint64_t nseg = 1ull << segment_number_bits;
@@ -656,6 +680,7 @@ extern "C" int ss_index_bin_open(const uint8_t* bytes, uint64_t len, uint32_t in
       level++;
     }
   }
+  lap("level headers");
   // ---- the key heads of every segment, segments in parallel: one entry per (key, component, level), dealt into 256 buckets by the
   // key hash's top byte (hashes: even buckets), each bucket then sorted on its own -- the concatenation is the sorted whole
   constexpr unsigned NB = 256;
@@ -681,7 +706,7 @@ extern "C" int ss_index_bin_open(const uint8_t* bytes, uint64_t len, uint32_t in
         const uint32_t ntype = (uint32_t)(key & 7u), n_comp = ntype == 0 ? 1u : ntype <= 3u ? 2u : 3u;
         if (ntype && n_comp > key_head_size - 20u) { skipped[w]++; continue; }  // a head without room for the component df bytes
         for (uint32_t c = 0; c < n_comp; c++) {
-          ss_index_bin::Blk e;
+          ss_index_bin::Blk e{};
           e.key = key;
           e.n_comp = (uint8_t)n_comp;
           e.comp = (uint8_t)c;
@@ -698,6 +723,7 @@ extern "C" int ss_index_bin_open(const uint8_t* bytes, uint64_t len, uint32_t in
     }
   });
   if (bad.load()) return SS_EINVAL;
+  lap("key heads into buckets");
   for (unsigned w = 0; w < T; w++) ix->n_ngram_keys += skipped[w];
   std::vector<uint64_t> boff(NB + 1, 0);
   for (unsigned bkt = 0; bkt < NB; bkt++) {
@@ -705,7 +731,11 @@ extern "C" int ss_index_bin_open(const uint8_t* bytes, uint64_t len, uint32_t in
     for (unsigned w = 0; w < T; w++) n += part[(size_t)w * NB + bkt].size();
     boff[bkt + 1] = boff[bkt] + n;
   }
-  ix->blocks.resize(boff[NB]);
+  ix->blocks.resize(boff[NB]);  // (not initialised: the bucket workers below touch their own ranges)
+  lap("blocks array");
+  // a bucket's terms while it is hot: runs of equal (key, component) -- a key never spans buckets
+  struct TermPiece { std::vector<uint64_t> keys, first; std::vector<uint8_t> comp, ncomp, dfb; };
+  std::vector<TermPiece> tp(NB);
   ss_parallel_for(NB, 1, [&](size_t a, size_t b, unsigned) {
     for (size_t bkt = a; bkt < b; bkt++) {
       ss_index_bin::Blk* dst = ix->blocks.data() + boff[bkt];
@@ -719,22 +749,38 @@ extern "C" int ss_index_bin_open(const uint8_t* bytes, uint64_t len, uint32_t in
       std::sort(dst, dst + at, [](const ss_index_bin::Blk& x, const ss_index_bin::Blk& y) {
         return x.key != y.key ? x.key < y.key : x.comp != y.comp ? x.comp < y.comp : x.b.block_id < y.b.block_id;  // levels ascending
       });
+      TermPiece& P = tp[bkt];
+      for (uint64_t i = 0; i < at; i++) {
+        const ss_index_bin::Blk& e = dst[i];
+        if (i == 0 || e.key != dst[i - 1].key || e.comp != dst[i - 1].comp) {
+          P.keys.push_back(e.key); P.comp.push_back(e.comp); P.ncomp.push_back(e.n_comp); P.dfb.push_back(e.df_byte);
+          P.first.push_back(boff[bkt] + i);
+        } else {
+          P.dfb.back() = e.df_byte;  // df byte of the LAST level
+        }
+      }
     }
   });
-  ix->keys.reserve(ix->blocks.size() / 2 + 1);
-  for (size_t i = 0; i < ix->blocks.size(); i++) {
-    const ss_index_bin::Blk& e = ix->blocks[i];
-    if (i == 0 || e.key != ix->blocks[i - 1].key || e.comp != ix->blocks[i - 1].comp) {
-      ix->keys.push_back(e.key);
-      ix->term_comp.push_back(e.comp);
-      ix->term_ncomp.push_back(e.n_comp);
-      ix->term_df_byte.push_back(e.df_byte);
-      ix->term_block_off.push_back(i);
-    } else {
-      ix->term_df_byte.back() = e.df_byte;
+  lap("buckets gathered, sorted, cut into terms");
+  std::vector<uint64_t> toff(NB + 1, 0);
+  for (unsigned bkt = 0; bkt < NB; bkt++) toff[bkt + 1] = toff[bkt] + tp[bkt].keys.size();
+  const size_t n_terms = toff[NB];
+  ix->keys.resize(n_terms); ix->term_comp.resize(n_terms); ix->term_ncomp.resize(n_terms); ix->term_df_byte.resize(n_terms);
+  ix->term_block_off.resize(n_terms + 1);
+  ss_parallel_for(NB, 1, [&](size_t a, size_t b, unsigned) {
+    for (size_t bkt = a; bkt < b; bkt++) {
+      const TermPiece& P = tp[bkt];
+      const size_t n = P.keys.size();
+      if (!n) continue;
+      std::memcpy(ix->keys.data() + toff[bkt], P.keys.data(), n * 8);
+      std::memcpy(ix->term_block_off.data() + toff[bkt], P.first.data(), n * 8);
+      std::memcpy(ix->term_comp.data() + toff[bkt], P.comp.data(), n);
+      std::memcpy(ix->term_ncomp.data() + toff[bkt], P.ncomp.data(), n);
+      std::memcpy(ix->term_df_byte.data() + toff[bkt], P.dfb.data(), n);
     }
-  }
-  ix->term_block_off.push_back(ix->blocks.size());
+  });
+  ix->term_block_off[n_terms] = ix->blocks.size();
+  lap("terms");
   *out = ix.release();
   return SS_OK;
 }
@@ -744,7 +790,7 @@ namespace {
 void index_bin_reorder(ss_index_bin* ix, const std::vector<uint32_t>& order) {
   std::vector<uint64_t> off(order.size() + 1, 0);
   for (size_t i = 0; i < order.size(); i++) off[i + 1] = off[i] + (ix->term_block_off[order[i] + 1] - ix->term_block_off[order[i]]);
-  std::vector<ss_index_bin::Blk> blocks(off[order.size()]);
+  std::vector<ss_index_bin::Blk, NoInitAlloc<ss_index_bin::Blk>> blocks(off[order.size()]);  // (filled by the workers below)
   std::vector<uint64_t> keys(order.size());
   std::vector<uint8_t> comp(order.size()), ncomp(order.size()), dfb(order.size());
   ss_parallel_for(order.size(), 4096, [&](size_t a, size_t b, unsigned) {
@@ -866,69 +912,85 @@ int index_bin_term(const ss_index_bin* ix, uint32_t term, std::vector<uint32_t>&
 
 namespace {
 // decoded postings of the terms [t0, t1), terms in parallel: CSR offsets relative to the range, docs / tfs (+ positions and their
-// per-posting counts).  Every worker decodes whole terms into its own vectors; the pieces are then laid out in term order.
+// per-posting counts).  A term's posting count is known from its key heads, so docs / tfs / counts are decoded straight into their
+// final places; only the positions, whose number the heads do not tell, are gathered per chunk and copied once.  The arrays are
+// NOT value-initialised (a vector would zero a gigabyte on one thread first): the worker that decodes a range touches its pages.
+template <class T>
+struct RawBuf {
+  std::unique_ptr<T[]> p;
+  size_t n = 0;
+  void alloc(size_t m) { p.reset(new T[std::max<size_t>(m, 1)]); n = m; }
+  T* data() { return p.get(); }
+  const T* data() const { return p.get(); }
+  size_t size() const { return n; }
+};
 struct DecodedRange {
   std::vector<uint64_t> offs;  // [t1 - t0 + 1]
-  std::vector<uint32_t> docs;
-  std::vector<uint16_t> tfs, pos, npos;
+  RawBuf<uint32_t> docs;
+  RawBuf<uint16_t> tfs, pos, npos;
 };
 int index_bin_decode_range(const ss_index_bin* ix, uint32_t t0, uint32_t t1, bool with_positions, DecodedRange* out) {
+  if (ix->n_fields != 1) return SS_ENOTSUP;
   const size_t nt = t1 - t0;
-  struct Piece { std::vector<uint32_t> docs; std::vector<uint16_t> tfs, pos, npos; std::vector<uint64_t> n_doc, n_pos; size_t first = 0; };
   // chunks of terms with about the same number of postings each (a term's count is known from its key heads)
-  std::vector<uint64_t> cum(nt + 1, 0);
-  for (size_t i = 0; i < nt; i++) {
-    uint64_t c = 0;
-    for (uint64_t bi = ix->term_block_off[t0 + i]; bi < ix->term_block_off[t0 + i + 1]; bi++) c += (uint64_t)ix->blocks[bi].b.posting_count_m1 + 1u;
-    cum[i + 1] = cum[i] + c;
-  }
-  const uint64_t per = std::max<uint64_t>(cum[nt] / (8ull * ss_loader_threads()) + 1, 1u << 16);
+  std::vector<uint64_t>& cum = out->offs;
+  cum.assign(nt + 1, 0);
+  ss_parallel_for(nt, 16384, [&](size_t a, size_t b, unsigned) {
+    for (size_t i = a; i < b; i++) {
+      uint64_t c = 0;
+      for (uint64_t bi = ix->term_block_off[t0 + i]; bi < ix->term_block_off[t0 + i + 1]; bi++) c += (uint64_t)ix->blocks[bi].b.posting_count_m1 + 1u;
+      cum[i + 1] = c;
+    }
+  });
+  for (size_t i = 0; i < nt; i++) cum[i + 1] += cum[i];
+  const uint64_t total = cum[nt];
+  const uint64_t per = std::max<uint64_t>(total / (8ull * ss_loader_threads()) + 1, 1u << 16);
   std::vector<size_t> cuts{0};
   for (size_t i = 1; i <= nt; i++)
     if (i == nt || cum[i] - cum[cuts.back()] >= per) cuts.push_back(i);
   const size_t nc = cuts.size() - 1;
-  std::vector<Piece> pc(nc);
+  out->docs.alloc(total); out->tfs.alloc(total);
+  if (with_positions) out->npos.alloc(total);
+  std::vector<std::vector<uint16_t>> piece_pos(with_positions ? nc : 0);
   std::atomic<int> rc_all{SS_OK};
   ss_parallel_for(nc, 1, [&](size_t a, size_t b, unsigned) {
-    std::vector<uint16_t> d16(65536), t16(65536);
+    std::vector<uint16_t> d16(65536), t16(65536), np;
     for (size_t c = a; c < b; c++) {
-      Piece& P = pc[c];
-      P.first = cuts[c];
-      P.docs.reserve(cum[cuts[c + 1]] - cum[cuts[c]]);
-      P.tfs.reserve(cum[cuts[c + 1]] - cum[cuts[c]]);
+      std::vector<uint16_t>* pos = with_positions ? &piece_pos[c] : nullptr;
+      if (pos) pos->reserve((size_t)((cum[cuts[c + 1]] - cum[cuts[c]]) * 5 / 4) + 1024);
       for (size_t i = cuts[c]; i < cuts[c + 1]; i++) {
-        const size_t d_before = P.docs.size(), p_before = P.pos.size();
-        const int rc = index_bin_term(ix, (uint32_t)(t0 + i), P.docs, P.tfs, d16.data(), t16.data(), with_positions ? &P.pos : nullptr,
-                                      with_positions ? &P.npos : nullptr);
-        if (rc) { int ok = SS_OK; rc_all.compare_exchange_strong(ok, rc); return; }
-        P.n_doc.push_back(P.docs.size() - d_before);
-        P.n_pos.push_back(P.pos.size() - p_before);
+        uint64_t at = cum[i];
+        for (uint64_t bi = ix->term_block_off[t0 + i]; bi < ix->term_block_off[t0 + i + 1]; bi++) {
+          const ss_ref_block& blk = ix->blocks[bi].b;
+          np.clear();
+          const int n = decode_block(&blk, ix->blocks[bi].n_comp, ix->blocks[bi].comp, d16.data(), t16.data(), pos, pos ? &np : nullptr);
+          int rc = n < 0 ? n : SS_OK;
+          if (rc == SS_OK && (at + (uint64_t)n > cum[i + 1] || (pos && np.size() != (size_t)n))) rc = SS_EINVAL;  // the key head's count is the block's
+          if (rc == SS_OK && n && (((uint64_t)blk.block_id << 16) | d16[n - 1]) >= ix->n_docs) rc = SS_EINVAL;  // (ascending inside a block)
+          if (rc) { int ok = SS_OK; rc_all.compare_exchange_strong(ok, rc); return; }
+          uint32_t* dd = out->docs.data() + at;
+          uint16_t* tt = out->tfs.data() + at;
+          const uint32_t hi = (uint32_t)blk.block_id << 16;
+          for (int j = 0; j < n; j++) { dd[j] = hi | d16[j]; tt[j] = t16[j]; }
+          if (pos) std::memcpy(out->npos.data() + at, np.data(), (size_t)n * sizeof(uint16_t));
+          at += (uint64_t)n;
+        }
+        if (at != cum[i + 1]) { int ok = SS_OK; rc_all.compare_exchange_strong(ok, SS_EINVAL); return; }
       }
     }
   });
   if (rc_all.load()) return rc_all.load();
-  out->offs.assign(nt + 1, 0);
-  std::vector<uint64_t> d_at(nc + 1, 0), p_at(nc + 1, 0);
-  for (size_t c = 0; c < nc; c++) {
-    d_at[c + 1] = d_at[c] + pc[c].docs.size();
-    p_at[c + 1] = p_at[c] + pc[c].pos.size();
-    uint64_t at = d_at[c];
-    for (size_t j = 0; j < pc[c].n_doc.size(); j++) { out->offs[pc[c].first + j] = at; at += pc[c].n_doc[j]; }
-  }
-  out->offs[nt] = d_at[nc];
-  out->docs.resize(d_at[nc]); out->tfs.resize(d_at[nc]);
-  if (with_positions) { out->pos.resize(p_at[nc]); out->npos.resize(d_at[nc]); }
-  ss_parallel_for(nc, 1, [&](size_t a, size_t b, unsigned) {
-    for (size_t c = a; c < b; c++) {
-      if (!pc[c].docs.empty()) {
-        std::memcpy(out->docs.data() + d_at[c], pc[c].docs.data(), pc[c].docs.size() * 4);
-        std::memcpy(out->tfs.data() + d_at[c], pc[c].tfs.data(), pc[c].tfs.size() * 2);
-        if (with_positions) std::memcpy(out->npos.data() + d_at[c], pc[c].npos.data(), pc[c].npos.size() * 2);
+  if (with_positions) {
+    std::vector<uint64_t> p_at(nc + 1, 0);
+    for (size_t c = 0; c < nc; c++) p_at[c + 1] = p_at[c] + piece_pos[c].size();
+    out->pos.alloc(p_at[nc]);
+    ss_parallel_for(nc, 1, [&](size_t a, size_t b, unsigned) {
+      for (size_t c = a; c < b; c++) {
+        if (!piece_pos[c].empty()) std::memcpy(out->pos.data() + p_at[c], piece_pos[c].data(), piece_pos[c].size() * sizeof(uint16_t));
+        std::vector<uint16_t>().swap(piece_pos[c]);
       }
-      if (with_positions && !pc[c].pos.empty()) std::memcpy(out->pos.data() + p_at[c], pc[c].pos.data(), pc[c].pos.size() * 2);
-      Piece().docs.swap(pc[c].docs);
-    }
-  });
+    });
+  }
   return SS_OK;
 }
 }  // namespace
@@ -960,6 +1022,24 @@ extern "C" int ss_index_bin_decode_stats(const ss_index_bin* ix, int with_positi
   }
   if (n_postings_out) *n_postings_out = npost;
   if (n_positions_out) *n_positions_out = npos;
+  return SS_OK;
+}
+
+extern "C" int ss_index_bin_decode_all(const ss_index_bin* ix, uint64_t* offs_out, uint32_t* doc_ids_out, uint16_t* tfs_out, uint64_t postings_cap,
+                                       uint16_t* npos_out, uint16_t* positions_out, uint64_t positions_cap) {
+  if (!ix || !offs_out || !doc_ids_out || !tfs_out || (positions_out && !npos_out)) return SS_EINVAL;
+  if (ix->n_fields != 1) return SS_ENOTSUP;
+  DecodedRange D;
+  const int rc = index_bin_decode_range(ix, 0, (uint32_t)ix->keys.size(), positions_out != nullptr, &D);
+  if (rc) return rc;
+  if (D.docs.size() > postings_cap || (positions_out && D.pos.size() > positions_cap)) return SS_EINVAL;
+  std::memcpy(offs_out, D.offs.data(), D.offs.size() * sizeof(uint64_t));
+  std::memcpy(doc_ids_out, D.docs.data(), D.docs.size() * sizeof(uint32_t));
+  std::memcpy(tfs_out, D.tfs.data(), D.tfs.size() * sizeof(uint16_t));
+  if (positions_out) {
+    std::memcpy(npos_out, D.npos.data(), D.npos.size() * sizeof(uint16_t));
+    std::memcpy(positions_out, D.pos.data(), D.pos.size() * sizeof(uint16_t));
+  }
   return SS_OK;
 }
 

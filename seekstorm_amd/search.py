@@ -272,6 +272,20 @@ class IndexBin:
                 "ss_index_bin_term_postings")
         return docs, tfs
 
+    def decode_all(self, positions=False):
+        """every key's postings, decoded on the loader's worker threads (one indexed field): (offs, docs, tfs) or, with positions,
+        (offs, docs, tfs, npos, positions)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        N.check(N.lib().ss_index_bin_decode_stats(self._h, 1 if positions else 0, C.byref(a), C.byref(b)), "ss_index_bin_decode_stats")
+        offs = np.zeros(self.term_count + 1, np.uint64)
+        docs, tfs = np.zeros(a.value, np.uint32), np.zeros(a.value, np.uint16)
+        npos = np.zeros(a.value if positions else 0, np.uint16)
+        pos = np.zeros(max(b.value, 1) if positions else 0, np.uint16)
+        N.check(N.lib().ss_index_bin_decode_all(self._h, N.ptr(offs, N.u64p), N.ptr(docs, N.u32p), N.ptr(tfs, N.u16p), a.value,
+                                                N.ptr(npos, N.u16p) if positions else None, N.ptr(pos, N.u16p) if positions else None,
+                                                b.value), "ss_index_bin_decode_all")
+        return (offs, docs, tfs, npos, pos[:b.value]) if positions else (offs, docs, tfs)
+
     def close(self):
         if self._h:
             N.lib().ss_index_bin_close(self._h)

@@ -1101,3 +1101,40 @@ def test_multi_field_ngram_key_positions_roundtrip(n_fields, longest, nc, limit)
             assert f8[e] == f and t16[e] == tf and np16[e] == len(ps), (i, j)
             want_pos += ps
     assert pos[:npos.value].tolist() == want_pos
+
+
+@pytest.mark.parametrize("tiered", [False, True])
+def test_decode_all_equals_the_mini_indexers_lists(tiered):
+    """ss_index_bin_decode_all -- the decoder of the image builders (terms in parallel on the worker threads, postings written straight
+    into their final places, positions gathered per chunk) -- against the lists the mini indexer wrote the file from: every key's docs,
+    the tf of every component, the key's own positions behind its first component; before and after ss_index_bin_tier.  Host only."""
+    from oracle import textindex as TI
+    T = TI.TextCorpus(9, 90_000, 2500, n_frequent=12, mean_len=9.0, topic_share=0.4)
+    assert T.n_ngram_keys > 100
+    ix = S.IndexBin(T.write_index_bin(key_head_size=23), key_head_size=23)
+    if tiered:
+        assert 0 < ix.tier(400) < ix.term_count
+    by_hash = {}
+    for k in range(T.n_keys):
+        if T.key_df(k):
+            by_hash[T.key_hash(k)] = k
+    offs, docs, tfs, npos, pos = ix.decode_all(positions=True)
+    offs2, docs2, tfs2 = ix.decode_all()
+    assert np.array_equal(offs, offs2) and np.array_equal(docs, docs2) and np.array_equal(tfs, tfs2)
+    assert len(offs) == ix.term_count + 1 and int(offs[-1]) == len(docs) == len(npos) and int(npos.astype(np.int64).sum()) == len(pos)
+    pst = np.zeros(len(npos) + 1, np.int64)
+    pst[1:] = np.cumsum(npos.astype(np.int64))
+    seen = 0
+    for t in range(ix.term_count):
+        k = by_hash[int(ix.term_keys[t])]
+        c = int(ix.term_component[t])
+        d, tf, cnt, ps = T.key_postings(k, c, positions=(c == 0))
+        a, b = int(offs[t]), int(offs[t + 1])
+        assert np.array_equal(docs[a:b], d) and np.array_equal(tfs[a:b], tf), (t, k, c)
+        if c == 0:
+            assert np.array_equal(npos[a:b], cnt) and np.array_equal(pos[pst[a]:pst[b]], ps), (t, k)
+        else:
+            assert not npos[a:b].any(), (t, k, c)
+        seen += 1
+    assert seen == ix.term_count
+    ix.close()
