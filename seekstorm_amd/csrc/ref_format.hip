@@ -590,22 +590,6 @@ extern "C" int ss_bm25_upload_ref_blocks(ss_shard* s, uint64_t n_docs, const uin
 //   key head (compress_postinglist.rs:339-409): u64 key_hash @0 (low 3 bits = NgramType), u16 posting_count - 1 @8,
 //     u16 max_docid @10, u16 max_p_docid @12, n-gram df bytes @14.., u16 pointer_pivot_p_docid @size-6,
 //     u32 compression_type_pointer @size-4
-// vector storage that is not value-initialised: resize() of the 10^7-entry block table would otherwise zero (and page in) the whole
-// array on one thread before the workers fill it
-template <class T>
-struct NoInitAlloc {
-  using value_type = T;
-  NoInitAlloc() = default;
-  template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
-  T* allocate(size_t n) { return static_cast<T*>(::operator new(n * sizeof(T))); }
-  void deallocate(T* p, size_t) { ::operator delete(p); }
-  template <class U, class... A>
-  void construct(U* p, A&&... a) {
-    if constexpr (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...);
-  }
-  template <class U> bool operator==(const NoInitAlloc<U>&) const { return true; }
-  template <class U> bool operator!=(const NoInitAlloc<U>&) const { return false; }
-};
 struct ss_index_bin {
   const uint8_t* bytes = nullptr;
   uint64_t len = 0;
@@ -996,8 +980,8 @@ int index_bin_decode_range(const ss_index_bin* ix, uint32_t t0, uint32_t t1, boo
 }  // namespace
 
 namespace {
-int decode_fields_range(const ss_index_bin* ix, uint32_t t0, uint32_t t1, std::vector<uint64_t>& offs, std::vector<uint32_t>& docs,
-                        std::vector<uint8_t>& fields, std::vector<uint16_t>& tfs, std::vector<uint16_t>* pos, std::vector<uint16_t>* npos);
+int decode_fields_range(const ss_index_bin* ix, uint32_t t0, uint32_t t1, std::vector<uint64_t>& offs, NoInitVec<uint32_t>& docs,
+                        NoInitVec<uint8_t>& fields, NoInitVec<uint16_t>& tfs, NoInitVec<uint16_t>* pos, NoInitVec<uint16_t>* npos);
 }
 // Host only (no device): decodes every key of the index the way the uploads do -- on the loader's worker threads -- and reports what
 // came out.  For a host that wants to know what an open will cost before it takes the shard's write lock, and for timing the decoder
@@ -1013,9 +997,9 @@ extern "C" int ss_index_bin_decode_stats(const ss_index_bin* ix, int with_positi
     npost = D.docs.size(); npos = D.pos.size();
   } else {
     std::vector<uint64_t> offs;
-    std::vector<uint32_t> docs;
-    std::vector<uint8_t> fields;
-    std::vector<uint16_t> tfs, pos, cnt;
+    NoInitVec<uint32_t> docs;
+    NoInitVec<uint8_t> fields;
+    NoInitVec<uint16_t> tfs, pos, cnt;
     const int rc = decode_fields_range(ix, 0, n_all, offs, docs, fields, tfs, with_positions ? &pos : nullptr, with_positions ? &cnt : nullptr);
     if (rc) return rc;
     npost = docs.size(); npos = pos.size();
@@ -1061,17 +1045,20 @@ namespace {
 // multi-field index: (doc, field, tf) entries of every term, doclen rearranged to [field][doc]
 // the entries (doc, field, tf) of the keys [t0, t1), CSR over offs [t1 - t0 + 1]; the keys are decoded on the loader's worker threads in
 // chunks of about equal posting counts (index_bin_decode_range's scheme), the pieces then copied into place
-int decode_fields_range(const ss_index_bin* ix, uint32_t t0, uint32_t t1, std::vector<uint64_t>& offs, std::vector<uint32_t>& docs,
-                        std::vector<uint8_t>& fields, std::vector<uint16_t>& tfs, std::vector<uint16_t>* pos, std::vector<uint16_t>* npos) {
+int decode_fields_range(const ss_index_bin* ix, uint32_t t0, uint32_t t1, std::vector<uint64_t>& offs, NoInitVec<uint32_t>& docs,
+                        NoInitVec<uint8_t>& fields, NoInitVec<uint16_t>& tfs, NoInitVec<uint16_t>* pos, NoInitVec<uint16_t>* npos) {
   const uint32_t F = ix->n_fields;
   const size_t nt = t1 - t0;
   struct Piece { std::vector<uint32_t> docs; std::vector<uint8_t> fields; std::vector<uint16_t> tfs, pos, npos; std::vector<uint64_t> n_ent; size_t first = 0; };
   std::vector<uint64_t> cum(nt + 1, 0);
-  for (size_t i = 0; i < nt; i++) {
-    uint64_t c = 0;
-    for (uint64_t bi = ix->term_block_off[t0 + i]; bi < ix->term_block_off[t0 + i + 1]; bi++) c += (uint64_t)ix->blocks[bi].b.posting_count_m1 + 1u;
-    cum[i + 1] = cum[i] + c;
-  }
+  ss_parallel_for(nt, 16384, [&](size_t a, size_t b, unsigned) {
+    for (size_t i = a; i < b; i++) {
+      uint64_t c = 0;
+      for (uint64_t bi = ix->term_block_off[t0 + i]; bi < ix->term_block_off[t0 + i + 1]; bi++) c += (uint64_t)ix->blocks[bi].b.posting_count_m1 + 1u;
+      cum[i + 1] = c;
+    }
+  });
+  for (size_t i = 0; i < nt; i++) cum[i + 1] += cum[i];
   const uint64_t per = std::max<uint64_t>(cum[nt] / (8ull * ss_loader_threads()) + 1, 1u << 16);
   std::vector<size_t> cuts{0};
   for (size_t i = 1; i <= nt; i++)
@@ -1086,6 +1073,12 @@ int decode_fields_range(const ss_index_bin* ix, uint32_t t0, uint32_t t1, std::v
     for (size_t c = ca; c < cb; c++) {
       Piece& P = pc[c];
       P.first = cuts[c];
+      {  // entries >= postings (a doc may hold the term in several fields): room for a quarter more, grown from there
+        const size_t room = (size_t)((cum[cuts[c + 1]] - cum[cuts[c]]) * 5 / 4) + 1024;
+        P.docs.reserve(room); P.fields.reserve(room); P.tfs.reserve(room);
+        if (npos) P.npos.reserve(room);
+        if (pos) P.pos.reserve(room);
+      }
       for (size_t i = cuts[c]; i < cuts[c + 1]; i++) {
         const uint32_t t = (uint32_t)(t0 + i);
         const size_t before = P.docs.size();
@@ -1146,11 +1139,11 @@ int upload_index_bin_fields(ss_shard* s, const ss_index_bin* ix, const float* bo
   const auto t_0 = now();
   const uint32_t n_all = (uint32_t)ix->keys.size(), n_dense = std::min<uint32_t>(ix->n_dense, n_all);  // ss_index_bin_tier
   if (n_dense == 0) return SS_EINVAL;
-  std::vector<uint16_t> pos, npos;
+  NoInitVec<uint16_t> pos, npos;
   std::vector<uint64_t> offs;
-  std::vector<uint32_t> docs;
-  std::vector<uint8_t> fields;
-  std::vector<uint16_t> tfs;
+  NoInitVec<uint32_t> docs;
+  NoInitVec<uint8_t> fields;
+  NoInitVec<uint16_t> tfs;
   int rc = decode_fields_range(ix, 0, n_dense, offs, docs, fields, tfs, with_positions ? &pos : nullptr, with_positions ? &npos : nullptr);
   if (rc) return rc;
   const auto t_1 = now();
@@ -1173,10 +1166,10 @@ int upload_index_bin_fields(ss_shard* s, const ss_index_bin* ix, const float* bo
   if (rc || n_dense == n_all) return rc;
   // the rare keys: their entries decoded the same way, their merged lists appended to the sparse tier (ids continue behind the dense ones)
   std::vector<uint64_t> r_offs;
-  std::vector<uint32_t> r_docs;
-  std::vector<uint8_t> r_fields;
-  std::vector<uint16_t> r_tfs;
-  std::vector<uint16_t> r_pos, r_npos;
+  NoInitVec<uint32_t> r_docs;
+  NoInitVec<uint8_t> r_fields;
+  NoInitVec<uint16_t> r_tfs;
+  NoInitVec<uint16_t> r_pos, r_npos;
   rc = decode_fields_range(ix, n_dense, n_all, r_offs, r_docs, r_fields, r_tfs, with_positions ? &r_pos : nullptr, with_positions ? &r_npos : nullptr);
   if (rc) return rc;
   const auto t_3 = now();

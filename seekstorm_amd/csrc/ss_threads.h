@@ -6,7 +6,9 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <new>
 #include <thread>
+#include <utility>
 #include <vector>
 
 inline unsigned ss_loader_threads() {
@@ -41,3 +43,22 @@ inline void ss_parallel_for(size_t n, size_t grain, F f) {
   work(0);
   for (auto& t : th) t.join();
 }
+
+// vector storage that is not value-initialised: resize() of the 10^7-entry block table would otherwise zero (and page in) the whole
+// array on one thread before the workers fill it
+template <class T>
+struct NoInitAlloc {
+  using value_type = T;
+  NoInitAlloc() = default;
+  template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+  T* allocate(size_t n) { return static_cast<T*>(::operator new(n * sizeof(T))); }
+  void deallocate(T* p, size_t) { ::operator delete(p); }
+  template <class U, class... A>
+  void construct(U* p, A&&... a) {
+    if constexpr (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...);
+  }
+  template <class U> bool operator==(const NoInitAlloc<U>&) const { return true; }
+  template <class U> bool operator!=(const NoInitAlloc<U>&) const { return false; }
+};
+template <class T>
+using NoInitVec = std::vector<T, NoInitAlloc<T>>;

@@ -677,8 +677,8 @@ int ssi_bm25_rebuild_from_raw(const ss_shard* s, const std::vector<ss_raw_level>
 // posting's (bm_code_of): the length bytes come back from the device once per call.
 // the packed postings of n_lists new sparse lists (list i: base[i] .. base[i + 1] of `packed`) behind the ones the tier holds
 // counts / pos (optional): positions per new posting and their concatenation (elem = 2: u16, one indexed field; 4: u32 field-tagged)
-static int sparse_install(ss_shard* s, uint32_t n_lists, const std::vector<u64>& lbase, const std::vector<u64>& packed,
-                          const std::vector<uint32_t>* counts = nullptr, const void* pos = nullptr, u64 n_pos = 0, size_t elem = 0);
+static int sparse_install(ss_shard* s, uint32_t n_lists, const std::vector<u64>& lbase, const NoInitVec<u64>& packed,
+                          const NoInitVec<uint32_t>* counts = nullptr, const void* pos = nullptr, u64 n_pos = 0, size_t elem = 0);
 
 int ssi_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
                            const uint16_t* positions, uint64_t n_positions, const uint16_t* npos) {
@@ -690,7 +690,7 @@ int ssi_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, 
   SS_HIP(hipMemcpy(dl.data(), s->d_doclen, s->bm_n_docs, hipMemcpyDeviceToHost));
   float comp[SS_COMP_N];
   fill_comp(s->bm_avgdl, comp);
-  std::vector<u64> packed(n_new ? n_new : 1);
+  NoInitVec<u64> packed(n_new ? n_new : 1);  // (not value-initialised: the workers below touch their own ranges)
   for (uint32_t i = 0; i < n_lists; i++)
     if (offs[i + 1] < offs[i]) return SS_EINVAL;
   std::atomic<int> fail{SS_OK};
@@ -708,8 +708,10 @@ int ssi_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, 
   if (!positions) return sparse_install(s, n_lists, lbase, packed);
   // positions (phrase queries): per posting its tf positions -- or npos of them: the component terms of an n-gram key, whose own
   // positions stand behind the FIRST component's postings (ssi_bm25_upload_positions)
-  std::vector<uint32_t> counts(n_new);
-  for (u64 j = 0; j < n_new; j++) counts[j] = npos ? npos[offs[0] + j] : tfs[offs[0] + j];
+  NoInitVec<uint32_t> counts(n_new);
+  ss_parallel_for(n_new, 1u << 20, [&](size_t a, size_t b, unsigned) {
+    for (size_t j = a; j < b; j++) counts[j] = npos ? npos[offs[0] + j] : tfs[offs[0] + j];
+  });
   return sparse_install(s, n_lists, lbase, packed, &counts, positions, n_positions, sizeof(uint16_t));
 }
 
@@ -747,7 +749,7 @@ int ssi_bm25_append_sparse_fields(ss_shard* s, uint32_t n_lists, const uint64_t*
   });
   if (fail.load()) return fail.load();
   for (uint32_t i = 0; i < n_lists; i++) lbase[i + 1] += lbase[i];
-  std::vector<u64> packed(lbase[n_lists]);
+  NoInitVec<u64> packed(lbase[n_lists]);
   ss_parallel_for(n_lists, 4096, [&](size_t a, size_t b, unsigned) {
     for (size_t i = a; i < b; i++) {
       u64 w_at = lbase[i];
@@ -772,7 +774,7 @@ int ssi_bm25_append_sparse_fields(ss_shard* s, uint32_t n_lists, const uint64_t*
   // positions: per ENTRY (doc, field) in order; a merged posting owns those of all the doc's entries, each tagged with its field
   // (ssi_bm25_upload_positions_fields)
   if (!npos) npos = tfs;
-  std::vector<uint32_t> counts(packed.size()), pool(n_positions ? n_positions : 1);
+  NoInitVec<uint32_t> counts(packed.size()), pool(n_positions ? n_positions : 1);
   std::vector<u64> lstart((size_t)n_lists + 1, 0);  // first position of every list (lists in parallel below)
   ss_parallel_for(n_lists, 4096, [&](size_t a, size_t b, unsigned) {
     for (size_t i = a; i < b; i++) {
@@ -805,8 +807,8 @@ int ssi_bm25_append_sparse_fields(ss_shard* s, uint32_t n_lists, const uint64_t*
   return sparse_install(s, n_lists, lbase, packed, &counts, pool.data(), n_positions, sizeof(uint32_t));
 }
 
-static int sparse_install(ss_shard* s, uint32_t n_lists, const std::vector<u64>& lbase, const std::vector<u64>& packed,
-                          const std::vector<uint32_t>* counts, const void* pos, u64 n_pos, size_t elem) {
+static int sparse_install(ss_shard* s, uint32_t n_lists, const std::vector<u64>& lbase, const NoInitVec<u64>& packed,
+                          const NoInitVec<uint32_t>* counts, const void* pos, u64 n_pos, size_t elem) {
   if (ssi_bm25_sparse_levels_has(s)) return SS_ESTATE;  // a tier that grows level by level takes levels only (ss_bm25_append_sparse_level)
   const u64 n_new = packed.size();
   const u64* offs = lbase.data();
@@ -826,10 +828,29 @@ static int sparse_install(ss_shard* s, uint32_t n_lists, const std::vector<u64>&
   if (ok && n_new) ok = hipMemcpy(np + old_n, packed.data(), n_new * sizeof(u64), hipMemcpyHostToDevice) == hipSuccess;
   if (ok && with_pos) {
     // END of every posting's positions in the pool (a posting appended without positions has none: its end = its start)
-    std::vector<u64> ends(std::max<u64>(old_n + n_new, 1), 0);
+    NoInitVec<u64> ends(std::max<u64>(old_n + n_new, 1));
+    ends[0] = 0;
     if (old_n && s->d_sp_pos_end) ok = hipMemcpy(ends.data(), s->d_sp_pos_end, old_n * sizeof(u64), hipMemcpyDeviceToHost) == hipSuccess;
-    u64 run = s->sp_pos_n;
-    for (u64 x = 0; x < n_new; x++) { run += counts ? (*counts)[x] : 0u; ends[old_n + x] = run; }
+    else if (old_n) std::fill(ends.begin(), ends.begin() + old_n, (u64)0);  // (appended without positions: none)
+    // running ends: per list its positions (lists in parallel), the lists' starts, then every list fills its own postings
+    std::vector<u64> lsum((size_t)n_lists + 1, 0);
+    if (counts)
+      ss_parallel_for(n_lists, 4096, [&](size_t a, size_t b, unsigned) {
+        for (size_t i = a; i < b; i++) {
+          u64 c = 0;
+          for (u64 x = offs[i] - offs[0]; x < offs[i + 1] - offs[0]; x++) c += (*counts)[x];
+          lsum[i + 1] = c;
+        }
+      });
+    lsum[0] = s->sp_pos_n;
+    for (uint32_t i = 0; i < n_lists; i++) lsum[i + 1] += lsum[i];
+    const u64 run = lsum[n_lists];
+    ss_parallel_for(n_lists, 4096, [&](size_t a, size_t b, unsigned) {
+      for (size_t i = a; i < b; i++) {
+        u64 r = lsum[i];
+        for (u64 x = offs[i] - offs[0]; x < offs[i + 1] - offs[0]; x++) { r += counts ? (*counts)[x] : 0u; ends[old_n + x] = r; }
+      }
+    });
     if (ok && counts && run - s->sp_pos_n != n_pos) { (void)hipFree(nb); (void)hipFree(np); return SS_EINVAL; }
     ok = ok && hipMalloc(&ne, ends.size() * sizeof(u64)) == hipSuccess &&
          hipMemcpy(ne, ends.data(), ends.size() * sizeof(u64), hipMemcpyHostToDevice) == hipSuccess;
@@ -1141,7 +1162,10 @@ int ssi_bm25_upload_positions(ss_shard* s, const uint64_t* offs, const uint32_t*
   if (s->bm_n_fields != 1) return SS_ENOTSUP;
   std::vector<u64> pbase((size_t)nt + 1), tbase((size_t)nt + 1);
   SS_HIP(hipMemcpy(tbase.data(), s->d_term_base, tbase.size() * sizeof(u64), hipMemcpyDeviceToHost));
-  std::vector<uint32_t> poff((size_t)s->bm_n_post_pad + 5, 0u);  // + 4: the padding loop of a segment may run to the next multiple of 4 before the walk is checked
+  // (+ 4: the padding loop of a segment may run to the next multiple of 4 before the walk is checked; not value-initialised -- every
+  // slot of a term is written by the term's worker below, the slots behind the last term here)
+  NoInitVec<uint32_t> poff((size_t)s->bm_n_post_pad + 5);
+  for (size_t w = (size_t)std::min<u64>(tbase[nt] * 4ull, poff.size()); w < poff.size(); w++) poff[w] = 0u;
   // a term's positions: the sum of its postings' counts (terms in parallel), then every term fills its own slots
   pbase[0] = 0;
   {
