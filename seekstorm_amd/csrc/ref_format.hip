@@ -667,69 +667,86 @@ extern "C" int ss_index_bin_open(const uint8_t* bytes, uint64_t len, uint32_t in
   lap("level headers");
   // ---- the key heads of every segment, segments in parallel: one entry per (key, component, level), dealt into 256 buckets by the
   // key hash's top byte (hashes: even buckets), each bucket then sorted on its own -- the concatenation is the sorted whole
-  constexpr unsigned NB = 256;
-  const unsigned T = ss_loader_threads();
-  std::vector<std::vector<ss_index_bin::Blk>> part((size_t)T * NB);
-  std::vector<uint32_t> skipped(T, 0);
+  constexpr unsigned NB_LOG2 = 8, NB = 1u << NB_LOG2;  // (more buckets: smaller sorts but a slower scatter -- 1024 / 4096 measured, no gain)
+  constexpr size_t GRAIN = 16;  // segments per chunk of work
+  const size_t n_chunks = (segs.size() + GRAIN - 1) / GRAIN;
+  // pass 1: how many entries every chunk of segments sends to every bucket (the heads' keys alone are read); then every chunk knows
+  // where its entries go in the block table, and pass 2 writes them there directly -- nothing is staged, nothing grows
+  std::vector<uint32_t> cnt(n_chunks * NB, 0u), skipped(n_chunks, 0u);
   std::atomic<int> bad{0};
-  ss_parallel_for(segs.size(), 16, [&](size_t a, size_t b, unsigned w) {
+  auto n_components = [&](uint64_t key, bool* skip) {
+    // NgramType (index.rs:1854-1872): 0 SingleTerm, 1-3 bigrams, 4-7 trigrams.  An n-gram key is kept as one posting
+    // list per component term (same docs, the component's tf): scored with idf_ngram_i each, their sum is the
+    // n-gram arm of get_bm25f_multiterm_singlefield (add_result.rs:1454-1477); several fields: the components' field vectors.
+    const uint32_t ntype = (uint32_t)(key & 7u), n_comp = ntype == 0 ? 1u : ntype <= 3u ? 2u : 3u;
+    *skip = ntype && n_comp > key_head_size - 20u;  // a head without room for the component df bytes
+    return n_comp;
+  };
+  ss_parallel_for(segs.size(), GRAIN, [&](size_t a, size_t b, unsigned) {
+    uint32_t* c = cnt.data() + (a / GRAIN) * NB;
+    for (size_t si = a; si < b; si++) {
+      const Seg& sg = segs[si];
+      uint64_t prev = 0;
+      for (uint64_t i = 0; i < sg.key_count; i++) {
+        const uint64_t key = rd64(bytes + sg.pos + i * key_head_size);
+        if (i && key <= prev) { bad.store(1); return; }  // heads are binary-searched by key_hash (search.rs:2310-2357)
+        prev = key;
+        bool skip;
+        const uint32_t n_comp = n_components(key, &skip);
+        if (skip) { skipped[a / GRAIN]++; continue; }
+        c[key >> (64 - NB_LOG2)] += n_comp;
+      }
+    }
+  });
+  if (bad.load()) return SS_EINVAL;
+  lap("key heads counted");
+  for (size_t ch = 0; ch < n_chunks; ch++) ix->n_ngram_keys += skipped[ch];
+  std::vector<uint64_t> boff(NB + 1, 0);
+  std::vector<uint64_t> start(n_chunks * NB);
+  for (unsigned bkt = 0; bkt < NB; bkt++) {
+    uint64_t at = boff[bkt];
+    for (size_t ch = 0; ch < n_chunks; ch++) { start[ch * NB + bkt] = at; at += cnt[ch * NB + bkt]; }
+    boff[bkt + 1] = at;
+  }
+  ix->blocks.resize(boff[NB]);  // (not initialised: pass 2 writes every entry)
+  ss_parallel_for(segs.size(), GRAIN, [&](size_t a, size_t b, unsigned) {
+    uint64_t* at = start.data() + (a / GRAIN) * NB;
     for (size_t si = a; si < b; si++) {
       const Seg& sg = segs[si];
       const uint64_t head_bytes = sg.key_count * key_head_size;
       const uint8_t* body = bytes + sg.pos + head_bytes;
       const uint64_t body_len = sg.block_length - head_bytes;
-      uint64_t prev = 0;
       for (uint64_t i = 0; i < sg.key_count; i++) {
         const uint8_t* h = bytes + sg.pos + i * key_head_size;
         const uint64_t key = rd64(h);
-        if (i && key <= prev) { bad.store(1); return; }  // heads are binary-searched by key_hash (search.rs:2310-2357)
-        prev = key;
-        // NgramType (index.rs:1854-1872): 0 SingleTerm, 1-3 bigrams, 4-7 trigrams.  An n-gram key is kept as one posting
-        // list per component term (same docs, the component's tf): scored with idf_ngram_i each, their sum is the
-        // n-gram arm of get_bm25f_multiterm_singlefield (add_result.rs:1454-1477); several fields: the components' field vectors.
-        const uint32_t ntype = (uint32_t)(key & 7u), n_comp = ntype == 0 ? 1u : ntype <= 3u ? 2u : 3u;
-        if (ntype && n_comp > key_head_size - 20u) { skipped[w]++; continue; }  // a head without room for the component df bytes
+        bool skip;
+        const uint32_t n_comp = n_components(key, &skip);
+        if (skip) continue;
         for (uint32_t c = 0; c < n_comp; c++) {
           ss_index_bin::Blk e{};
           e.key = key;
           e.n_comp = (uint8_t)n_comp;
           e.comp = (uint8_t)c;
-          e.df_byte = ntype ? h[14 + c] : (uint8_t)0;
+          e.df_byte = (key & 7u) ? h[14 + c] : (uint8_t)0;
           e.b.block_id = sg.level;
           e.b.posting_count_m1 = (uint16_t)rd16(h + 8);
           e.b.pointer_pivot_p_docid = (uint16_t)rd16(h + key_head_size - 6);
           e.b.compression_type_pointer = rd32(h + key_head_size - 4);
           e.b.byte_array = body;
           e.b.byte_array_len = body_len;
-          part[(size_t)w * NB + (key >> 56)].push_back(e);
+          ix->blocks[at[key >> (64 - NB_LOG2)]++] = e;
         }
       }
     }
   });
-  if (bad.load()) return SS_EINVAL;
-  lap("key heads into buckets");
-  for (unsigned w = 0; w < T; w++) ix->n_ngram_keys += skipped[w];
-  std::vector<uint64_t> boff(NB + 1, 0);
-  for (unsigned bkt = 0; bkt < NB; bkt++) {
-    uint64_t n = 0;
-    for (unsigned w = 0; w < T; w++) n += part[(size_t)w * NB + bkt].size();
-    boff[bkt + 1] = boff[bkt] + n;
-  }
-  ix->blocks.resize(boff[NB]);  // (not initialised: the bucket workers below touch their own ranges)
-  lap("blocks array");
+  lap("key heads into the block table");
   // a bucket's terms while it is hot: runs of equal (key, component) -- a key never spans buckets
   struct TermPiece { std::vector<uint64_t> keys, first; std::vector<uint8_t> comp, ncomp, dfb; };
   std::vector<TermPiece> tp(NB);
   ss_parallel_for(NB, 1, [&](size_t a, size_t b, unsigned) {
     for (size_t bkt = a; bkt < b; bkt++) {
       ss_index_bin::Blk* dst = ix->blocks.data() + boff[bkt];
-      uint64_t at = 0;
-      for (unsigned w = 0; w < T; w++) {
-        auto& v = part[(size_t)w * NB + bkt];
-        if (!v.empty()) std::memcpy((void*)(dst + at), (const void*)v.data(), v.size() * sizeof(ss_index_bin::Blk));
-        at += v.size();
-        std::vector<ss_index_bin::Blk>().swap(v);
-      }
+      const uint64_t at = boff[bkt + 1] - boff[bkt];
       std::sort(dst, dst + at, [](const ss_index_bin::Blk& x, const ss_index_bin::Blk& y) {
         return x.key != y.key ? x.key < y.key : x.comp != y.comp ? x.comp < y.comp : x.b.block_id < y.b.block_id;  // levels ascending
       });
@@ -745,7 +762,7 @@ extern "C" int ss_index_bin_open(const uint8_t* bytes, uint64_t len, uint32_t in
       }
     }
   });
-  lap("buckets gathered, sorted, cut into terms");
+  lap("buckets sorted, cut into terms");
   std::vector<uint64_t> toff(NB + 1, 0);
   for (unsigned bkt = 0; bkt < NB; bkt++) toff[bkt + 1] = toff[bkt] + tp[bkt].keys.size();
   const size_t n_terms = toff[NB];
