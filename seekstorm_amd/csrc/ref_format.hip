@@ -933,6 +933,14 @@ struct DecodedRange {
 int index_bin_decode_range(const ss_index_bin* ix, uint32_t t0, uint32_t t1, bool with_positions, DecodedRange* out) {
   if (ix->n_fields != 1) return SS_ENOTSUP;
   const size_t nt = t1 - t0;
+  static const bool trace = getenv("SS_LOAD_TRACE") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[load] decode: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+    t_last = t;
+  };
   // chunks of terms with about the same number of postings each (a term's count is known from its key heads)
   std::vector<uint64_t>& cum = out->offs;
   cum.assign(nt + 1, 0);
@@ -950,6 +958,7 @@ int index_bin_decode_range(const ss_index_bin* ix, uint32_t t0, uint32_t t1, boo
   for (size_t i = 1; i <= nt; i++)
     if (i == nt || cum[i] - cum[cuts.back()] >= per) cuts.push_back(i);
   const size_t nc = cuts.size() - 1;
+  lap("posting counts, chunks");
   out->docs.alloc(total); out->tfs.alloc(total);
   if (with_positions) out->npos.alloc(total);
   std::vector<std::vector<uint16_t>> piece_pos(with_positions ? nc : 0);
@@ -981,6 +990,7 @@ int index_bin_decode_range(const ss_index_bin* ix, uint32_t t0, uint32_t t1, boo
     }
   });
   if (rc_all.load()) return rc_all.load();
+  lap("terms decoded");
   if (with_positions) {
     std::vector<uint64_t> p_at(nc + 1, 0);
     for (size_t c = 0; c < nc; c++) p_at[c + 1] = p_at[c] + piece_pos[c].size();
@@ -991,6 +1001,7 @@ int index_bin_decode_range(const ss_index_bin* ix, uint32_t t0, uint32_t t1, boo
         std::vector<uint16_t>().swap(piece_pos[c]);
       }
     });
+    lap("positions into place");
   }
   return SS_OK;
 }
