@@ -103,6 +103,19 @@ def test_no_gpu_means_loud_failure_not_fallback():
         S.Shard(0)
 
 
+def test_commit_entry_points_refuse_missing_arguments():
+    """the commit seam's entry points (ABI v4) check their arguments before they touch a device: no shard / no offsets -> SS_EINVAL (-1)"""
+    import ctypes as C
+    from seekstorm_amd import _native as N
+    L = N.lib()
+    offs = np.zeros(2, np.uint64)
+    assert L.ss_bm25_append_sparse_level(None, 0, 1, N.ptr(offs, N.u64p), None, None, None, None, 0) == -1
+    assert L.ss_bm25_append_level(None, 0, 1, None, 1, N.ptr(offs, N.u64p), None, None) == -1
+    assert L.ss_index_bin_decode_all(None, None, None, None, 0, None, None, 0) == -1
+    assert L.ss_index_bin_decode_stats(None, 0, None, None) == -1
+    assert L.ss_vec_append_rows(None, None) == -1
+
+
 def test_product_sources_do_not_reference_oracle_code():
     pkg = os.path.join(ROOT, "seekstorm_amd")
     for dp, _, files in os.walk(pkg):
