@@ -548,6 +548,9 @@ static int append_level_impl(ss_shard* s, uint32_t level, uint32_t n_level_docs,
     // a sparse tier numbers its terms behind the dense ones: a grown dense vocabulary would shift them -- new terms of an image with a
     // tier join the tier (ss_bm25_append_sparse_level), whose postings must come level by level too (their tfs are kept for re-coding)
     if (s->sp_n && (!ssi_bm25_sparse_levels_has(s) || n_terms != s->bm_n_terms)) return SS_ENOTSUP;
+    // (a re-committed level only grows, commit.rs:204-206; a shrinking one would leave the tier's postings of the level pointing
+    // past the image until ss_bm25_append_sparse_level replaces them)
+    if (s->sp_n && level < s->raw.size() && n_level_docs < s->raw[level].n_docs) return SS_ENOTSUP;
     if (level > s->raw.size() || level + 1 < s->raw.size()) return SS_EINVAL;  // append the next level, or replace the last one (a re-commit)
     if (level >= 1 && s->raw[level - 1].n_docs != 65536u) return SS_EINVAL;    // only the last level may be partial
     if ((uint64_t)level * 65536u + n_level_docs > 0xFFFFFFFFull) return SS_ENOTSUP;
