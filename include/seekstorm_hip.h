@@ -209,8 +209,8 @@ int ss_index_bin_decode_all(const ss_index_bin* ix, uint64_t* offs_out, uint32_t
  * the index is uploaded with ss_bm25_upload_index_bin -- a real vocabulary's millions of rare keys then cost 8 bytes per posting,
  * not a directory row each, and every key of the index stays searchable on the device.  Term id = position in that order
  * (ss_index_bin_term_keys): the host looks a key hash up with one binary search per tier, *n_dense_out = first sparse term id.
- * One indexed field (SS_ENOTSUP otherwise).  With ss_bm25_upload_index_bin_positions the dense terms carry positions: phrases over
- * dense terms work, a phrase naming a sparse term is refused (SS_ENOTSUP). */
+ * One or several indexed fields (several: the rare keys' MERGED lists go to the tier, ss_bm25_append_sparse_fields).  With
+ * ss_bm25_upload_index_bin[_fields]_positions both tiers carry positions: phrases may name terms of either. */
 int ss_index_bin_tier(ss_index_bin* ix, uint64_t dense_min_posting_count, uint32_t* n_dense_out);
 int ss_index_bin_close(ss_index_bin* ix);
 int ss_index_bin_info(const ss_index_bin* ix, uint64_t* n_docs, uint64_t* positions_sum_normalized, uint32_t* n_levels,

@@ -454,7 +454,8 @@ def test_sparse_terms_through_the_device_pointer_entry_point(S, O):
 def test_sparse_tier_on_an_image_with_several_indexed_fields(S, O):
     """rare terms of a multi-field (BM25F) index in the sparse tier: their MERGED lists (every doc once, weight = the boosted sum over
     the doc's fields) next to the dense image's merged lists -- unions, intersections, NOT terms of either tier, tombstones, counts,
-    against the brute-force BM25F oracle over ALL entries; a field filter over a sparse term is refused"""
+    against the brute-force BM25F oracle over ALL entries; field filters over sparse terms: intersections and single terms by the
+    postings' field masks, unions of several terms composed from the reference's own sub-queries"""
     from seekstorm_amd import _native as N
     from test_gpu_parity import _fields_corpus, _check_topk
     n_docs, n_fields, boost = 100_000, 3, [2.0, 1.0, 0.5]
