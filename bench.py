@@ -121,6 +121,7 @@ def main():
                     "communicator spans, the microseconds of the all-gather and a checksum of the merged answers; rank 0 asserts they agree")
     ap.add_argument("--no-clustered", action="store_true", help="skip the clustered-corpus leg (10 M docs whose term densities vary with the doc's cluster)")
     ap.add_argument("--no-real-format", action="store_true", help="skip the drop-in rehearsal on a million-doc index.bin / vector.bin / delete.bin")
+    ap.add_argument("--no-commit", action="store_true", help="skip the commit leg (an image with a sparse tier built level by level, tools/commit_leg.py)")
     ap.add_argument("--real-format-docs", type=int, default=1_000_000)
     ap.add_argument("--quick", action="store_true", help="profiling runs: few calls per leg, no cpu / parity legs")
     ap.add_argument("--cpu-seconds", type=float, default=5.0)
@@ -788,6 +789,16 @@ def main():
             if "parity" in bm["real_format"]:
                 parity["real_format"] = bm["real_format"].pop("parity")
 
+        # (8) COMMITS: an image with a sparse tier built by 16 commits of one level each (dense terms + the level's rare postings), ms per
+        # commit, answers == a one-shot upload of the same docs (tools/commit_leg.py).  A leg that fails reports its error and nothing else.
+        if rank == 0 and world == 1 and not args.quick and not args.no_commit:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import commit_leg
+                bm["commit"] = commit_leg.run(S, O, th)
+            except Exception as e:  # noqa: BLE001 -- the headline must not depend on a secondary leg
+                bm["commit"] = {"error": repr(e)[:300]}
+
         # ---- full-size parity (C2): a sample of the batch against the oracle on the same 10 M-doc shard, regenerated on
         # the host -- doc ids outside the tie band, scores 1e-4 relative, exact result_count_total; AUTO and EXHAUSTIVE
         if rank == 0 and not args.no_parity:
@@ -1227,6 +1238,8 @@ def main():
                 line["realistic_vocabulary"] = bm["realistic_vocabulary"]
             if "real_format" in bm:
                 line["real_format"] = bm["real_format"]
+            if "commit" in bm:
+                line["commit"] = bm["commit"]
             line["bm25"] = {"build_s": bm["build_s"], "postings": int(bm["info"]["n_postings"]), "avgdl": bm["info"]["avgdl"],
                             "mean_algorithmic_bytes_per_query": bm["mean_bytes_per_query"], "mean_union_size": bm["mean_union"]}
         if vec is not None and is_bm:
