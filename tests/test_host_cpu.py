@@ -116,6 +116,43 @@ def test_commit_entry_points_refuse_missing_arguments():
     assert L.ss_vec_append_rows(None, None) == -1
 
 
+def test_commit_level_splits_a_level_between_the_tiers():
+    """Shard.commit_level (the mirror of the commit seam): one CSR of all known terms in id order -> the dense terms' part for
+    ss_bm25_append_level, the rare terms' part (offsets rebased, positions pool cut where the dense postings' positions end) for
+    ss_bm25_append_sparse_level.  Host logic only: the two ABI calls are captured."""
+    import seekstorm_amd as S
+    calls = {}
+
+    class Capture(S.Shard):
+        def __init__(self):  # no device
+            pass
+
+        def append_level(self, level, level_doclen, offs, docs, tfs, positions=None, npos=None):
+            calls["dense"] = (level, np.asarray(offs), np.asarray(docs), np.asarray(tfs), positions, npos)
+
+        def append_sparse_level(self, level, offs, docs, tfs, positions=None, npos=None):
+            calls["sparse"] = (level, np.asarray(offs), np.asarray(docs), np.asarray(tfs), positions, npos)
+
+    offs = np.array([0, 2, 3, 3, 5, 6], np.uint64)            # 5 terms: 3 dense, 2 rare
+    docs = np.array([70000, 70010, 70001, 70002, 70020, 70005], np.uint32)
+    tfs = np.array([2, 1, 3, 1, 2, 1], np.uint16)
+    pos = np.arange(int(tfs.sum()), dtype=np.uint16)
+    sh = Capture()
+    sh.commit_level(1, np.zeros(100, np.uint8), offs, docs, tfs, n_dense_terms=3, positions=pos)
+    lv, o, d, t, p, n = calls["dense"]
+    assert lv == 1 and o.tolist() == [0, 2, 3, 3] and d.tolist() == [70000, 70010, 70001] and t.tolist() == [2, 1, 3] and p.tolist() == list(range(6))
+    lv, o, d, t, p, n = calls["sparse"]
+    assert lv == 1 and o.tolist() == [0, 2, 3] and d.tolist() == [70002, 70020, 70005] and t.tolist() == [1, 2, 1] and p.tolist() == [6, 7, 8, 9]
+    # counts from npos where given (n-gram components): the cut follows them
+    npos = np.array([2, 0, 3, 1, 0, 1], np.uint16)
+    sh.commit_level(1, np.zeros(100, np.uint8), offs, docs, tfs, n_dense_terms=3, positions=np.arange(7, dtype=np.uint16), npos=npos)
+    assert calls["dense"][4].tolist() == [0, 1, 2, 3, 4] and calls["dense"][5].tolist() == [2, 0, 3]
+    assert calls["sparse"][4].tolist() == [5, 6] and calls["sparse"][5].tolist() == [1, 0, 1]
+    calls.clear()
+    sh.commit_level(0, np.zeros(10, np.uint8), offs[:4], docs[:3], tfs[:3])  # no tier: every term is dense
+    assert "sparse" not in calls and calls["dense"][1].tolist() == [0, 2, 3, 3]
+
+
 def test_product_sources_do_not_reference_oracle_code():
     pkg = os.path.join(ROOT, "seekstorm_amd")
     for dp, _, files in os.walk(pkg):
