@@ -98,6 +98,102 @@ def free_port():
     return p
 
 
+def _pick(d, keys):
+    return {k_: d[k_] for k_ in keys if isinstance(d, dict) and d.get(k_) is not None}
+
+
+def _r(x, nd=4):
+    """shorten floats for the compact line (the side file keeps full precision)"""
+    if isinstance(x, float):
+        return float(f"{x:.{nd + 2}g}")
+    if isinstance(x, dict):
+        return {k_: _r(v_, nd) for k_, v_ in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v_, nd) for v_ in x]
+    return x
+
+
+def compact_line(line):
+    """The ONE stdout line the driver parses (<= 4 KB).  Everything else goes to bench_details.json.
+
+    roofline = SURVEY 8(d)'s own fraction -- algorithmic bytes / live launch time -- of the kernel that STREAMS those bytes
+    (bm25_scan16_kernel, the exhaustive strategy on the same batches); the pruned kernel the headline `value` is timed on answers
+    without reading most of them, so its figure is counter traffic / time and is named traffic_frac (roofline.pruned)."""
+    is_bm = "exhaustive" in line
+    out = _pick(line, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling"))
+    out["vs_baseline"] = None
+    out["dtype"] = line["dtype"]
+    out["data"] = "synthetic"
+    out["config"] = _pick(line["config"], ("workload", "docs_per_shard", "queries_per_call", "calls_per_step", "k", "result_type", "rows_per_shard", "dim", "batch"))
+    rf = line.get("roofline") or {}
+    if is_bm:
+        ex = (line["exhaustive"].get("roofline") or {})
+        roof = _pick(ex, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "launches"))
+        roof["kernel"] = "bm25_scan16_kernel<3,1> (exhaustive strategy, same batches: streams SURVEY 8d's bytes)"
+        roof["exhaustive_value_qps"] = line["exhaustive"].get("value")
+        roof["pruned"] = {"kernel": "bm25_probe_kernel<3,1> (the kernel `value` is timed on; prunes, so priced on counter traffic)",
+                          "traffic_frac": rf.get("frac_counter"), "traffic": rf.get("traffic"), "avg_launch_ms": rf.get("avg_launch_ms"),
+                          "launches": rf.get("launches")}
+        for k_ in ("clustered_exhaustive_frac", "and_exhaustive_frac", "not_tombstones_frac", "fallback_f32_frac"):
+            if rf.get(k_) is not None:
+                roof[k_] = rf[k_]
+    else:
+        roof = _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "mfma_util_pmc", "algorithmic_flops_per_launch",
+                          "algorithmic_bytes_per_launch", "avg_launch_ms", "launches"))
+    out["roofline"] = roof
+    cb = line.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "threads", "kind", "algorithm", "shards"))
+        out["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
+    lat = line.get("latency_ms") or {}
+    out["latency_ms"] = _pick(lat, ("batch_p50", "batch_p99", "single_query_p50", "single_query_p99", "batch64_p50", "batch64_p99"))
+    e2e = line.get("end_to_end") or {}
+    if e2e:
+        out["end_to_end"] = _pick(e2e, ("value", "batch_ms_p50", "batch_ms_p99", "single_query_ms_p50", "single_query_ms_p99", "batch64_ms_p50"))
+    v = line.get("vector")
+    if v:
+        vr = v.get("roofline") or {}
+        out["vector"] = {"metric": "queries/sec (C3: cosine top-100, 10M x 768 f32, batch 64)", "value": v.get("value"), "ms_per_call": v.get("ms_per_call"),
+                         "roofline": _pick(vr, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "mfma_util_pmc",
+                                                "algorithmic_flops_per_launch", "avg_launch_ms", "launches")),
+                         "cpu_baseline": _pick(v.get("cpu_baseline") or {}, ("value", "unit", "cores", "kind"))}
+        hy = v.get("hybrid") or {}
+        if hy:
+            out["hybrid"] = _pick(hy, ("value", "unit", "ms_per_call", "batch_ms_p50"))
+    cc = line.get("concurrent_callers")
+    if cc:
+        out["concurrent_callers"] = {n_: _pick(l_, ("value", "threads", "latency_us_p50", "latency_us_p99")) for n_, l_ in cc.items() if isinstance(l_, dict)}
+    if line.get("scale_check"):
+        sc = line["scale_check"]
+        out["scale_check"] = {"agree": sc.get("agree"), "ranks": [_pick(e, ("rank", "ranks_seen", "allgather_us", "merged_checksum_dev")) for e in sc.get("ranks", [])]}
+    if line.get("parity_full_size"):
+        out["parity_full_size"] = {n_: (p_.get("queries") if isinstance(p_, dict) else p_) for n_, p_ in line["parity_full_size"].items()}
+    out["details"] = "bench_details.json (every secondary leg; also on stderr)"
+    out = _r(out)
+    # hard bound: the driver keeps a bounded tail of stdout and must find ONE parseable line in it
+    for drop in ("parity_full_size", "concurrent_callers", "hybrid", "end_to_end", "latency_ms"):
+        if len(json.dumps(out)) <= 3900:
+            break
+        out.pop(drop, None)
+    assert len(json.dumps(out)) <= 4096, len(json.dumps(out))
+    return out
+
+
+def emit(line, world):
+    """details -> bench_details.json (+ stderr); the compact line -> the LAST line of stdout"""
+    text = json.dumps(line, indent=1)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, "bench_details.json" if world == 1 else f"bench_details_n{world}.json"), "w") as f:
+                    f.write(text)
+        except OSError:
+            pass
+    print("BENCH_DETAILS " + json.dumps(line), file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    print(json.dumps(compact_line(line)), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1199,7 +1295,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 sums of 16-bit posting weight codes (BM25); f32 MFMA (vector)" if is_bm else "f32",
             "data": "synthetic",
             "config": ({"workload": "C2: 10M synthetic docs, 3-term OR BM25 top-10, one shard per GPU", "docs_per_shard": args.docs,
                         "queries_per_call": args.queries, "calls_per_step": args.calls_per_step, "k": 10, "vocabulary": 4096,
@@ -1254,7 +1350,7 @@ def main():
                 line["concurrent_callers"] = vec["concurrent_callers"]
         elif vec is not None:
             line["i8"] = vec.get("i8")
-        print(json.dumps(line), flush=True)
+        emit(line, world)
     if comm is not None:
         comm.close()
     sh.close()
