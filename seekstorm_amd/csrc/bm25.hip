@@ -154,11 +154,13 @@ constexpr uint32_t BM_CLAIM_GATED = 128u;   // some query is a UNION of several 
 __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery* __restrict__ vq, uint32_t nq, uint32_t n_lists,
                                  const unsigned long long* __restrict__ term_base, const float* __restrict__ boost,
                                  unsigned long long* __restrict__ total, uint32_t* __restrict__ tau, uint32_t claim,
-                                 uint32_t n_vterms, const uint32_t* __restrict__ probe_row, uint32_t merged, uint32_t keep_tau = 0u) {
+                                 uint32_t n_vterms, const uint32_t* __restrict__ probe_row, uint32_t merged, uint32_t keep_tau = 0u,
+                                 const float* __restrict__ kthw = nullptr, uint32_t kth_sel = 3u) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq) return;
   total[i] = 0ull;                      // per-query match count and shared threshold start from zero (no separate memset launch)
   if (!keep_tau) tau[(size_t)i * BM_TAU_STRIDE] = 0u;  // (keep_tau: an experiment -- the same batch again with the thresholds it ended on)
+                                                       // (a union without exclusions raises it to its seed at the end of the expansion)
   const ss_bm25_query Q = q[i];
   bm_vquery& V = vq[i];  // written in place: a local copy indexed at run time would live in scratch
   const uint32_t np = Q.n_terms, n_not = bm_q_nnot(Q.op);
@@ -250,6 +252,93 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
   V.phrase_len = bm_q_op(Q.op) == SS_OP_PHRASE ? Q.phrase_len : 0u;
   for (int j = 0; j < SS_MAX_PHRASE; j++) V.phrase_seq[j] = Q.phrase_seq[j];
   V.phrase_fields = (q_is_phrase && filt) ? filt : 0xFFFFFFFFu;
+  // threshold seed (bm_kth_kernel): a union -- every list adds to the score of a doc that holds it -- with nothing that could take a
+  // doc away again (the caller passes kthw only when no tombstone / filter bitmap is in force; NOT terms, field filters, a phrase's position test --
+  // a phrase of ONE unique term is a "union" of one list here --: none of them)
+  if (kthw && kth_sel < 3u && !keep_tau && !is_and && !q_is_phrase && !gated && n_not == 0u && filt == 0u && n == n_scored) {
+    float seed = 0.f;
+    for (uint32_t j = 0; j < n; j++) seed = fmaxf(seed, V.idf[j] * kthw[(size_t)V.term[j] * 4u + kth_sel]);
+    tau[(size_t)i * BM_TAU_STRIDE] = __float_as_uint(seed);
+  }
+}
+
+// ---------------------------------------------------------------- threshold seeds: the K-th largest weight of every list
+// A union's score is a sum of positive terms, so the K docs holding a list's K largest weights all score at least idf * (the K-th
+// largest weight): the query's k-th best score is at least the largest such product over its lists (k <= K) -- known before a single
+// posting is read ("quantile" threshold estimation of MaxScore / WAND engines; the reference reaches the same state through its
+// block-max ordering, intersection.rs:2225).  One workgroup per list, two passes of a radix select over the 19-bit weight codes
+// (high 10 bits, then the low 9 bits inside the three bins the ranks fall into).
+constexpr uint32_t KTH_RANKS[3] = {10u, 100u, 1000u};
+__global__ void __launch_bounds__(256) bm_kth_kernel(const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base, uint32_t n_terms,
+                                                     float* __restrict__ kthw) {
+  __shared__ uint32_t hist[1024];
+  __shared__ uint32_t hist2[3][512];
+  __shared__ uint32_t bin_of[3], rank_in[3];
+  const uint32_t t = blockIdx.x;
+  if (t >= n_terms) return;
+  const u64 d0 = term_base[t] * 4ull, d1 = term_base[t + 1] * 4ull;  // dword range of the list (padding postings are zero)
+  for (uint32_t i = threadIdx.x; i < 1024u; i += blockDim.x) hist[i] = 0u;
+  for (uint32_t i = threadIdx.x; i < 3u * 512u; i += blockDim.x) (&hist2[0][0])[i] = 0u;
+  __syncthreads();
+  for (u64 i = d0 + threadIdx.x; i < d1; i += blockDim.x) {
+    const uint32_t p = post[i];
+    if (p) atomicAdd(&hist[p >> 22], 1u);  // code = p >> 13 (19 bits): its high 10 bits
+  }
+  __syncthreads();
+  if (threadIdx.x < 3u) {
+    const uint32_t want = KTH_RANKS[threadIdx.x];
+    uint32_t seen = 0u, b = 0xFFFFFFFFu, r = 0u;
+    for (int i = 1023; i >= 0; i--) {
+      if (seen + hist[i] >= want) { b = (uint32_t)i; r = want - seen; break; }
+      seen += hist[i];
+    }
+    bin_of[threadIdx.x] = b;   // none: the list holds fewer postings
+    rank_in[threadIdx.x] = r;  // the rank inside the bin, 1-based from the top
+  }
+  __syncthreads();
+  const uint32_t b0 = bin_of[0], b1 = bin_of[1], b2 = bin_of[2];
+  for (u64 i = d0 + threadIdx.x; i < d1; i += blockDim.x) {
+    const uint32_t p = post[i];
+    if (!p) continue;
+    const uint32_t hi = p >> 22, lo = (p >> 13) & 511u;
+    if (hi == b0) atomicAdd(&hist2[0][lo], 1u);
+    if (hi == b1) atomicAdd(&hist2[1][lo], 1u);
+    if (hi == b2) atomicAdd(&hist2[2][lo], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 3u) {
+    float w = 0.f;
+    if (bin_of[threadIdx.x] != 0xFFFFFFFFu) {
+      uint32_t seen = 0u;
+      for (int i = 511; i >= 0; i--) {
+        seen += hist2[threadIdx.x][i];
+        if (seen >= rank_in[threadIdx.x]) { w = bm_weight(((bin_of[threadIdx.x] << 9) | (uint32_t)i) << 13); break; }
+      }
+    }
+    kthw[(size_t)t * 4u + threadIdx.x] = w;
+  }
+  if (threadIdx.x == 3u) kthw[(size_t)t * 4u + 3u] = 0.f;
+}
+
+void ssi_bm25_drop_kth(ss_shard* s) {
+  if (s->d_kthw) (void)hipFree(s->d_kthw);
+  s->d_kthw = nullptr;
+  s->h_kthw.clear();
+}
+// built once per image, on the stream of the search that first wants it (the image does not change under a search: s->mu);
+// SS_BM25_SEED=0 switches the seeds off (measurements)
+int ssi_bm25_ensure_kth(ss_shard* s, hipStream_t st) {
+  static const int on = [] { const char* e = getenv("SS_BM25_SEED"); return e ? atoi(e) : 1; }();
+  if (s->d_kthw || !on || !s->d_post || s->bm_n_terms == 0) return SS_OK;
+  const size_t n = ((size_t)s->bm_n_terms + 1) * 4u;
+  SS_HIP(hipMalloc(&s->d_kthw, n * sizeof(float)));
+  SS_HIP(hipMemsetAsync(s->d_kthw, 0, n * sizeof(float), st));
+  bm_kth_kernel<<<s->bm_n_terms, 256, 0, st>>>(s->d_post, (const unsigned long long*)s->d_term_base, s->bm_n_terms, s->d_kthw);
+  SS_HIP(hipGetLastError());
+  s->h_kthw.resize(n);
+  SS_HIP(hipMemcpyAsync(s->h_kthw.data(), s->d_kthw, n * sizeof(float), hipMemcpyDeviceToHost, st));
+  SS_HIP(hipStreamSynchronize(st));
+  return SS_OK;
 }
 
 // ---------------------------------------------------------------- host side
@@ -393,6 +482,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
     SS_HIP(hipMalloc(&W.d_vq, (size_t)nq * sizeof(bm_vquery)));
     W.vq_cap = (size_t)nq * sizeof(bm_vquery);
   }
+  if (k && !s->d_kthw) { const int rck = ssi_bm25_ensure_kth(s, st); if (rck) return rck; }
   // nt_max / np_max count (term, field) lists here; the claim is in public terms
   const uint32_t claim = (phrase ? BM_CLAIM_PHRASE : 0u) | (has_and ? BM_CLAIM_AND : 0u) | ((has_or || F > 1) ? BM_CLAIM_OR : 0u) | (all_probed ? BM_CLAIM_PROBED : 0u) |
                          (any_frequent ? BM_CLAIM_FREQ : 0u) | (any_field_filter ? BM_CLAIM_FILTER : 0u) | (uniform_terms ? BM_CLAIM_UNIFORM : 0u) | (any_gated ? BM_CLAIM_GATED : 0u) |
@@ -401,7 +491,8 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   bm_expand_kernel<<<(nq + 127) / 128, 128, 0, st>>>(d_q, (bm_vquery*)W.d_vq, nq, s->bm_n_fields,
                                                     (const unsigned long long*)s->d_term_base, s->d_boost, total, tau, claim,
                                                     s->bm_n_terms, s->d_probe_row, s->bm_merged ? 1u : 0u,
-                                                    getenv("SS_BM25_KEEP_TAU") && atoi(getenv("SS_BM25_KEEP_TAU")) ? 1u : 0u);
+                                                    getenv("SS_BM25_KEEP_TAU") && atoi(getenv("SS_BM25_KEEP_TAU")) ? 1u : 0u,
+                                                    (s->n_deleted || s->del_per_query || k == 0) ? nullptr : s->d_kthw, bm_kth_sel(k));
 
   BmParams p;
   p.post = s->d_post;

@@ -165,6 +165,7 @@ static void free_bm25(ss_shard* s, bool keep_tier = false) {
   for (void* p : ptrs) if (p) { s->blocks.drop(p); (void)hipFree(p); }
   s->blocks.clear_idle();
   s->d_doclen = nullptr;
+  ssi_bm25_drop_kth(s);
   if (!keep_tier) {
     for (void* p : {(void*)s->d_sp_base, (void*)s->d_sp_post, (void*)s->d_sp_pos, (void*)s->d_sp_pos_end}) if (p) (void)hipFree(p);
     s->d_sp_base = nullptr; s->d_sp_post = nullptr; s->sp_n = 0; s->h_sp_base.clear();
@@ -204,6 +205,8 @@ int ss_shard_destroy(ss_shard* s) {
       if (ln.h_pin) (void)hipHostFree(ln.h_pin);
       if (ln.ev) (void)hipEventDestroy(ln.ev);
     }
+  if (s->d_small_ws) (void)hipFree(s->d_small_ws);
+  if (s->h_small) (void)hipHostFree(s->h_small);
   (void)hipStreamDestroy(s->stream);
   delete s;
   return SS_OK;
@@ -1590,11 +1593,94 @@ static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_quer
   return rc_search;
 }
 
+// ---- the one-launch path of small batches (bm25_small.hip).  Pinned block of the shard: three 64-byte flag slots (0: direct calls,
+// 1 / 2: the coalescer's lanes), then answer staging for direct calls (64 queries x k <= 128).
+constexpr size_t SM_H_DOC = 256, SM_H_SCORE = SM_H_DOC + 64 * 128 * 4, SM_H_COUNT = SM_H_SCORE + 64 * 128 * 4, SM_H_TOTAL = SM_H_COUNT + 64 * 4,
+                 SM_H_BYTES = SM_H_TOTAL + 64 * 8;
+// Tries the batch on the one-launch path: *handled = false (and SS_OK) when it is not of that shape -- the staged pipeline then runs it.
+// p_* = pinned buffers the kernel answers into (null: the shard's own staging).  Called under s->mu.
+static int bm25_small_try(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, uint32_t n_filters, uint32_t slot,
+                          uint32_t* p_doc, float* p_score, uint32_t* p_count, uint64_t* p_total, bool* handled, uint32_t* seq_out) {
+  *handled = false;
+  if (n_filters != 0 || kk == 0 || !ssi_bm25_small_serves(s, nq, kk, 1, 0)) return SS_OK;
+  if (s->sp_n)  // a term of the sparse tier: the tiered path
+    for (uint32_t i = 0; i < nq; i++)
+      for (uint32_t t = 0; t < std::min<uint32_t>(q[i].n_terms + bm_q_nnot(q[i].op), SS_MAX_QUERY_TERMS); t++)
+        if (q[i].term[t] >= s->bm_n_terms && q[i].term[t] < s->bm_n_terms + s->sp_n) return SS_OK;
+  for (uint32_t i = 0; i < nq; i++)
+    if (bm_q_op(q[i].op) == SS_OP_PHRASE) return SS_OK;  // phrase queries have a kernel of their own (and a mixed batch is split first)
+  SS_TRY(ssi_bm25_ensure_probe_rows(s, nq, q, s->stream));
+  bool has_and = false, has_or = false, all_probed = false, any_frequent = false, phrase = false, any_filter = false, uniform = false, gated = false;
+  uint32_t nt_max = 0, np_max = 0, nn_max = 0;
+  SS_TRY(check_queries(s, nq, q, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent, &phrase, &any_filter, &uniform, &gated, &nn_max));
+  if (phrase || any_frequent || !all_probed || any_filter || gated || !ssi_bm25_small_serves(s, nq, kk, np_max, nn_max)) return SS_OK;
+  SS_HIP(hipSetDevice(s->device));
+  if (!s->d_small_ws) {
+    SS_HIP(hipMalloc(&s->d_small_ws, ssi_bm25_small_ws_bytes()));
+    SS_HIP(hipMemsetAsync(s->d_small_ws, 0, ssi_bm25_small_ws_bytes(), s->stream));
+  }
+  SS_TRY(ssi_bm25_ensure_kth(s, s->stream));
+  if (!s->h_small) {
+    SS_HIP(hipHostMalloc((void**)&s->h_small, SM_H_BYTES, hipHostMallocDefault));
+    memset(s->h_small, 0, SM_H_BYTES);
+  }
+  const uint32_t seq = ++s->small_seq ? s->small_seq : ++s->small_seq;  // never 0
+  if (!p_doc) {
+    p_doc = (uint32_t*)(s->h_small + SM_H_DOC); p_score = (float*)(s->h_small + SM_H_SCORE);
+    p_count = (uint32_t*)(s->h_small + SM_H_COUNT); p_total = (uint64_t*)(s->h_small + SM_H_TOTAL);
+  }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ssi_prof_begin(s, 0, s->stream, &e0, &e1);
+  const int rc = ssi_bm25_small_launch(s, s->d_small_ws, nq, q, kk, rt != SS_RT_TOPK, has_and, has_or, np_max, nt_max != np_max, p_doc, p_score, p_count, p_total,
+                                      (uint32_t*)(s->h_small + 64 * slot), seq, s->stream);
+  ssi_prof_end(s, 0, s->stream, e0, e1);
+  if (rc != SS_OK) {  // (the per-query state may be half-way: start the next launch from zero)
+    (void)hipMemsetAsync(s->d_small_ws, 0, ssi_bm25_small_ws_bytes(), s->stream);
+    return rc;
+  }
+  s->small_launches++;
+  *seq_out = seq;
+  *handled = true;
+  return SS_OK;
+}
+// waits for the flag of `slot` to show `seq`: the kernel raises it behind the last answer.  Polled -- the answers are a few
+// microseconds old when the loop sees it, where a stream synchronisation adds the completion signal's round trip
+static int bm25_small_wait(ss_shard* s, uint32_t slot, uint32_t seq) {
+  volatile uint32_t* flag = (volatile uint32_t*)(s->h_small + 64 * slot);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t spins = 0;; spins++) {
+    if (__atomic_load_n((const uint32_t*)flag, __ATOMIC_ACQUIRE) == seq) return SS_OK;
+    __builtin_ia32_pause();
+    if ((spins & 0x3FFu) == 0x3FFu) {
+      const auto dt = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+      if (dt > 2000) {  // long past any small batch: ask the runtime (a kernel that died leaves the flag untouched)
+        const hipError_t e = hipStreamQuery(s->stream);
+        if (e != hipSuccess && e != hipErrorNotReady) return SS_EDEVICE;
+        if (e == hipSuccess) return __atomic_load_n((const uint32_t*)flag, __ATOMIC_ACQUIRE) == seq ? SS_OK : SS_EDEVICE;
+        if (dt > 10000000) return SS_EDEVICE;
+      }
+    }
+  }
+}
+
 static int bm25_search_direct(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k, uint32_t rt, uint32_t n_filters,
                               const ss_facet_filter* filters, uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total) {
   std::lock_guard<std::mutex> g(s->mu);  // before check_queries: it reads the image's host-side tables (an upload replaces them)
   if (!s->d_post) return SS_ESTATE;
   const uint32_t kk = rt == SS_RT_COUNT ? 0 : k;
+  {
+    bool handled = false;
+    uint32_t seq = 0;
+    SS_TRY(bm25_small_try(s, nq, q, kk, rt, n_filters, 0, nullptr, nullptr, nullptr, nullptr, &handled, &seq));
+    if (handled) {
+      SS_TRY(bm25_small_wait(s, 0, seq));
+      memcpy(out_doc, s->h_small + SM_H_DOC, (size_t)nq * kk * sizeof(uint32_t));
+      memcpy(out_score, s->h_small + SM_H_SCORE, (size_t)nq * kk * sizeof(float));
+      memcpy(out_count, s->h_small + SM_H_COUNT, (size_t)nq * sizeof(uint32_t));
+      memcpy(out_total, s->h_small + SM_H_TOTAL, (size_t)nq * sizeof(uint64_t));
+      return SS_OK;
+    }
+  }
   SS_TRY(bm25_search_host_queries(s, nq, q, kk, rt, n_filters, filters));
   if (kk) {
     SS_HIP(hipMemcpyAsync(out_doc, s->d_out_doc, (size_t)nq * kk * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
@@ -1619,13 +1705,18 @@ __global__ void co_pack_kernel(const uint32_t* __restrict__ d_doc, const float* 
   if (i < nq) { h_count[i] = d_count[i]; h_total[i] = d_total[i]; }
 }
 static int bm25_search_direct_lane(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k, uint32_t rt, uint32_t* out_doc, float* out_score,
-                                   uint32_t* out_count, uint64_t* out_total, hipEvent_t ev) {
+                                   uint32_t* out_count, uint64_t* out_total, hipEvent_t ev, uint32_t lane_slot) {
   static const int pack = [] { const char* e = getenv("SS_COALESCE_PACK"); return e ? atoi(e) : 0; }();  // measured: no difference -- off
   const uint64_t t_in = g_co_trace_on ? co_now_us() : 0;
+  bool small = false;
+  uint32_t small_seq = 0;
   {
     std::lock_guard<std::mutex> g(s->mu);
     if (!s->d_post) return SS_ESTATE;
     const uint32_t kk = rt == SS_RT_COUNT ? 0 : k;
+    // the lane's buffers are pinned: the one-launch path answers straight into them (flag slot 1 / 2 by the lane's event)
+    SS_TRY(bm25_small_try(s, nq, q, kk, rt, 0, lane_slot, out_doc, out_score, out_count, out_total, &small, &small_seq));
+    if (!small) {
     SS_TRY(bm25_search_host_queries(s, nq, q, kk, rt, 0, nullptr));
     if (pack) {
       const uint32_t n = std::max<uint32_t>(nq * kk, nq);
@@ -1642,9 +1733,11 @@ static int bm25_search_direct_lane(ss_shard* s, uint32_t nq, const ss_bm25_query
     SS_HIP(hipMemcpyAsync(out_total, s->d_out_total, (size_t)nq * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
     SS_HIP(hipEventRecord(ev, s->stream));
     }
+    }
   }
   const uint64_t te = g_co_trace_on ? co_now_us() : 0;
-  SS_HIP(hipEventSynchronize(ev));
+  if (small) SS_TRY(bm25_small_wait(s, lane_slot, small_seq));
+  else SS_HIP(hipEventSynchronize(ev));
   if (g_co_trace_on) { g_co_trace.enqueue += te - t_in; g_co_trace.linger += co_now_us() - te; }
   return SS_OK;
 }
@@ -1746,7 +1839,7 @@ int co_run_batch(ss_shard* s, ss_coalescer& co, bool lexical, const std::vector<
   const uint64_t tr1 = g_co_trace_on ? co_now_us() : 0;
   int rc;
   if (lexical)
-    rc = bm25_search_direct_lane(s, total, (const ss_bm25_query*)h_q, kk, f->rt, h_doc, h_sc, h_cnt, h_tot, ln.ev);
+    rc = bm25_search_direct_lane(s, total, (const ss_bm25_query*)h_q, kk, f->rt, h_doc, h_sc, h_cnt, h_tot, ln.ev, 1u + lane_ix);
   else
     rc = vec_search_host(s, total, h_q, f->elem, f->qscale ? h_qs : nullptr, kk, f->thr, nullptr, h_doc, h_sc, h_cnt, h_tot, nullptr);
   if (rc != SS_OK) return rc;

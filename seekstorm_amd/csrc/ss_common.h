@@ -322,6 +322,11 @@ struct ss_shard {
   uint64_t probe_budget = 0;       // ss_bm25_set_probe_budget: bytes, 0 = half of the free device memory
   int bm_strategy = SS_BM25_AUTO;  // ss_bm25_set_strategy
   float* d_umax = nullptr;         // [n_terms + 1] largest weight tf*(K+1)/(tf+comp[len]) of the term (max_list_score / idf)
+  // [n_terms + 1][4] the 10th / 100th / 1000th largest weight of every list (0 = the list is shorter), built from the finished image
+  // the first time a search wants it (ssi_bm25_ensure_kth, bm25.hip): idf * that weight is a score k docs of a UNION reach for sure,
+  // so the shared threshold of such a query starts there instead of at zero
+  float* d_kthw = nullptr;
+  std::vector<float> h_kthw;
   bool bm_partmax = false;         // the pruned kernel bounds every partition by its own block maxima (set at image build when the
                                    // maxima vary over the doc ids; SS_BM25_SUBMAX=1 / 0 forces it on / off)
   // positions of every posting (ss_bm25_upload_positions): only phrase queries read them
@@ -365,8 +370,23 @@ struct ss_shard {
   // bm25 workspace
   void* d_bq = nullptr; size_t bq_cap = 0;       // staged queries
   uint64_t* d_ptotal = nullptr;                   // per (query, partition) match counts
+  // one-launch path of small host-pointer batches (bm25_small.hip): device workspace (zero between launches), pinned answer
+  // staging + completion flags (slot 0: direct calls, 1 / 2: the coalescer's lanes), launch counter
+  void* d_small_ws = nullptr;
+  char* h_small = nullptr;
+  uint32_t small_seq = 0;
+  uint64_t small_launches = 0;
   ss_prof prof;
 };
+int ssi_bm25_ensure_kth(ss_shard* s, hipStream_t st);   // bm25.hip
+void ssi_bm25_drop_kth(ss_shard* s);
+inline uint32_t bm_kth_sel(uint32_t k) { return k == 0u ? 3u : k <= 10u ? 0u : k <= 100u ? 1u : k <= 1000u ? 2u : 3u; }  // column of d_kthw (3 = none)
+// bm25_small.hip
+size_t ssi_bm25_small_ws_bytes();
+bool ssi_bm25_small_serves(const ss_shard* s, uint32_t nq, uint32_t k, uint32_t np_max, uint32_t nn_max);
+int ssi_bm25_small_launch(ss_shard* s, void* ws, uint32_t nq, const ss_bm25_query* hq, uint32_t k, bool want_counts, bool has_and, bool has_or,
+                          uint32_t np_max, bool any_not, uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total,
+                          uint32_t* flag, uint32_t seq, hipStream_t st);
 
 // Opt-in to more than 64 KB of dynamic LDS is a per-device function attribute: set it once per (kernel, device) --
 // one process may hold shards on several GPUs (C++ host Index), and concurrent searches may race to be first.
