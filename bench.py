@@ -639,9 +639,19 @@ def main():
         assert np.array_equal(h_score, ref_scores), "host-pointer entry point differs from the device-pointer one"
         e2e_lat = host_latencies(bm_host_call, 1000)
         e2e_one = host_latencies(lambda: bm_host_call(1), 1000)
+        # small host-pointer batches (the reference's call shape is ONE query per call): <= 64 queries take the one-launch path of
+        # bm25_small.hip -- queries in the kernel arguments, answers + completion flag written straight into pinned host memory
+        small = {}
+        for n_ in (8, 32, 64):
+            if n_ <= nq:
+                assert np.array_equal(h_score[:n_], ref_scores[:n_])
+                l_ = host_latencies(lambda: bm_host_call(n_), 400)
+                assert np.array_equal(h_score[:n_], ref_scores[:n_]), "one-launch path differs from the staged pipeline"
+                small[f"nq{n_}_ms_p50"] = pct(l_, 50); small[f"nq{n_}_ms_p99"] = pct(l_, 99); small[f"nq{n_}_qps"] = n_ / (np.mean(l_) * 1e-3)
         end_to_end = {"value": nq / (np.mean(e2e_lat) * 1e-3), "unit": "queries/s", "entry_point": "ss_bm25_search (host pointers: H2D queries, "
                       "kernels, D2H results, sync; host clock)", "batch_ms_p50": pct(e2e_lat, 50), "batch_ms_p99": pct(e2e_lat, 99),
-                      "single_query_ms_p50": pct(e2e_one, 50), "single_query_ms_p99": pct(e2e_one, 99), "samples": len(e2e_lat)}
+                      "single_query_ms_p50": pct(e2e_one, 50), "single_query_ms_p99": pct(e2e_one, 99), "samples": len(e2e_lat),
+                      "small_batches": small, "small_batches_path": "bm25_small_kernel: ONE launch per call of <= 64 queries (SS_BM25_SMALL=0: the staged pipeline)"}
 
         # Roofline of the dominant kernel of the timed region (bm25_probe_kernel).  A pruning kernel answers WITHOUT reading
         # most of SURVEY 8d's algorithmic bytes, so algorithmic bytes / time exceeds the HBM peak and says nothing about it:

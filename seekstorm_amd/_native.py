@@ -217,6 +217,7 @@ SYMBOLS = [
     ("ss_bm25_sparse_info", C.c_int, [C.c_void_p, u32p, u64p, u64p]),
     ("ss_shard_set_coalescing", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
     ("ss_shard_coalescing_stats", C.c_int, [C.c_void_p, u64p, u64p, u64p, u64p]),
+    ("ss_bm25_path_stats", C.c_int, [C.c_void_p, u64p]),
     ("ss_profile_enable", C.c_int, [C.c_void_p, C.c_int]),
     ("ss_profile_read", C.c_int, [C.c_void_p, C.c_int, u64p, C.POINTER(C.c_double), C.c_int]),
 ]

@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
   const uint32_t a = blockIdx.x * PB_WAVES + w;
   if (a >= nq * P) return;
   const uint32_t qi = a % nq, part = a / nq;
-  const BmTop<KPL> T = pb_wave<NT, KPL, FILT, SKIP, false>(post, term_base, sub_off, probe, probe_z, probe_row, umax, pmax, qbound, PbQueryMem{qs + qi}, tau, del,
+  const BmTop<KPL> T = pb_wave<NT, KPL, FILT, SKIP, false, 4>(post, term_base, sub_off, probe, probe_z, probe_row, umax, pmax, qbound, PbQueryMem{qs + qi}, tau, del,
                                                     del_words, n_sub, n_terms, P, k, count, qi, part, w, lane);
 
   u64* out = part_keys + ((size_t)qi * P + part) * (64 * KPL);

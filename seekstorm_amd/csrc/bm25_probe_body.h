@@ -8,7 +8,9 @@
 #include "bm25_dev.h"
 
 constexpr int PB_WAVES = 8;
-constexpr int PB_QCAP = 320;  // survivor queue entries per wave: < 64 left over + one group of 4 x 64 pushed
+// survivor queue entries per wave: < 64 left over + one group of G x 64 pushed (G = chunks of 64 driver postings evaluated together)
+constexpr int pb_qcap(int G) { return 64 * G + 64; }
+constexpr int PB_QCAP = pb_qcap(4);
 
 // weight of one posting: it is IN the posting (ss_common.h) -- the same decode as the scan kernels'
 __device__ __forceinline__ float pb_weight(uint32_t p) { return bm_weight(p); }
@@ -38,7 +40,9 @@ struct PbQueryRegs {
 // SKIP: the driver streams jump over sub-blocks whose block-max bound (qbound) lies below the threshold.  A separate
 // instantiation: the few registers the skip needs pushed the common kernel into scratch (C2: 0.55 -> 0.80 ms per 1000 queries).
 // SEEDED: the caller knows a score k docs of the query reach for sure (thr0, bm_kth_kernel): the threshold never lies below it
-template <int NT, int KPL, bool FILT, bool SKIP, bool SEEDED, typename QV>
+// G: chunks of 64 driver postings per group -- their gathers are in flight together (4 in the staged kernel, whose registers are capped
+// for occupancy; 8 in the one-launch kernel of small batches, which is bound by the number of dependent round trips per wave)
+template <int NT, int KPL, bool FILT, bool SKIP, bool SEEDED, int G, typename QV>
 __device__ __forceinline__ BmTop<KPL> pb_wave(
     const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base, const uint32_t* __restrict__ sub_off,
     const uint2* __restrict__ probe, const uint32_t* __restrict__ probe_z,
@@ -109,8 +113,6 @@ __device__ __forceinline__ BmTop<KPL> pb_wave(
   T.matched = 0;
   uint32_t* tau_q = tau + (size_t)qi * BM_TAU_STRIDE;
   const int lane4 = lane * 4;
-  constexpr int G = 4;  // chunks (64 driver postings each) evaluated together: their gathers overlap
-  static_assert(PB_QCAP >= 64 * G + 63, "a group can push 64 * G survivors on top of the < 64 left in the queue");
 
   // score in QUERY order with the exhaustive kernels' fma chain (bit-identical results)
   auto combine = [&](const float (&wv)[NT], uint32_t pres) -> float {
@@ -159,7 +161,7 @@ __device__ __forceinline__ BmTop<KPL> pb_wave(
   // other term probed -- wait here until 64 of them can take the SPARSE stage together (posting fetch of the probed
   // term, remaining probes, score).  After the first probe only a few percent of the lanes are still alive; without
   // the queue every later gather round trip would be paid for a handful of lanes.
-  constexpr uint32_t QCAP = PB_QCAP;
+  constexpr uint32_t QCAP = pb_qcap(G);
   const uint32_t q_doc = (uint32_t)w * (QCAP * 12u), q_w0 = q_doc + QCAP * 4u, q_pos = q_w0 + QCAP * 4u;
   uint32_t qn = 0;
 

@@ -22,6 +22,9 @@
 constexpr uint32_t SM_MAX_Q = 64;   // queries per launch (their 60-byte forms must fit the 4 KB of kernel arguments)
 constexpr uint32_t SM_MAX_PB = 64;  // workgroups (of 8 partitions) per query: the final tournament plays one list per lane
 constexpr uint32_t SM_MAX_CB = 20;  // counting workgroups per query
+#ifndef SM_G
+#define SM_G 8  // chunks of 64 driver postings per group (bm25_probe_body.h)
+#endif
 
 struct pb_squery {
   uint32_t n_terms, op;  // op = SS_OP_* | NOT terms << 8 (bm_q_op / bm_q_nnot)
@@ -93,7 +96,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 4) bm25_small_kernel(const PbSm
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t nq = fz->nq, PB = fz->PB, k = fz->k, b = blockIdx.x;
   constexpr uint32_t KS = 64u * KPL;
-  constexpr uint32_t WREG = PB_QCAP * 12u;  // a wave's LDS region (its survivor queue while it probes, its list afterwards)
+  constexpr uint32_t WREG = pb_qcap(SM_G) * 12u;  // a wave's LDS region (its survivor queue while it probes, its list afterwards)
   // What one workgroup hands to another (partition lists, counts) travels in device-scope atomic accesses -- they meet at the
   // coherence point of the 8 XCDs' L2s by themselves.  No __threadfence(): on this part an agent-scope fence writes back and
   // invalidates the XCD's L2, and one per wave made a batch of 64 TopkCount queries take 595 us instead of 230.
@@ -111,7 +114,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 4) bm25_small_kernel(const PbSm
     for (int t = 0; t < NT; t++) { Q.term_[t] = fz->q[qi].term[t]; Q.idf_[t] = fz->q[qi].idf[t]; }
 #pragma unroll
     for (int j = 0; j < 4; j++) Q.not_[j] = FILT ? fz->q[qi].term[min(Q.nt_ + (uint32_t)j, 7u)] : 0u;
-    BmTop<KPL> T = pb_wave<NT, KPL, FILT, false, true>(fz->post, fz->term_base, fz->sub_off, fz->probe, fz->probe_z, fz->probe_row, fz->umax, nullptr, nullptr,
+    BmTop<KPL> T = pb_wave<NT, KPL, FILT, false, true, SM_G>(fz->post, fz->term_base, fz->sub_off, fz->probe, fz->probe_z, fz->probe_row, fz->umax, nullptr, nullptr,
                                                  Q, fz->tau, fz->del, fz->del_words, fz->n_sub, fz->n_terms, PB * PB_WAVES, k, fz->count & 1u, qi, part, w, lane, fz->q[qi].thr0);
     // the workgroup's eight lists -> one (LDS: every wave's queue is empty by now and its region its own)
     const uint32_t lb = (uint32_t)w * WREG;
@@ -346,7 +349,7 @@ int ssi_bm25_small_launch(ss_shard* s, void* ws, uint32_t nq, const ss_bm25_quer
   const uint32_t NT = np_max <= 2 ? 2u : np_max;
   const bool filt = any_not || a.del != nullptr;
   const dim3 grid(nq * (PB + CB)), block(PB_WAVES * 64);
-  const size_t lds = (size_t)PB_WAVES * PB_QCAP * 12;
+  const size_t lds = (size_t)PB_WAVES * pb_qcap(SM_G) * 12;
 #define SS_S(NT_, KPL_)                                                                    \
   if (NT == NT_ && KPL == KPL_) {                                                          \
     if (filt) bm25_small_kernel<NT_, KPL_, true><<<grid, block, lds, st>>>(a);             \

@@ -1971,6 +1971,12 @@ int ss_shard_set_coalescing(ss_shard* s, uint32_t max_lexical_batch, uint32_t ma
   { std::lock_guard<std::mutex> g(s->co_vec.mu); s->co_vec.max_batch = max_vector_batch; s->co_vec.max_wait_us = max_wait_us; }
   return SS_OK;
 }
+int ss_bm25_path_stats(ss_shard* s, uint64_t* one_launch_batches) {
+  if (!s || !one_launch_batches) return SS_EINVAL;
+  std::lock_guard<std::mutex> g(s->mu);
+  *one_launch_batches = s->small_launches;
+  return SS_OK;
+}
 int ss_shard_coalescing_stats(ss_shard* s, uint64_t* lexical_batches, uint64_t* lexical_queries, uint64_t* vector_batches, uint64_t* vector_queries) {
   if (!s) return SS_EINVAL;
   { std::lock_guard<std::mutex> g(s->co_lex.mu); if (lexical_batches) *lexical_batches = s->co_lex.batches; if (lexical_queries) *lexical_queries = s->co_lex.queries; }

@@ -1218,6 +1218,12 @@ class Shard:
         N.check(N.lib().ss_shard_set_coalescing(self._h, int(max_lexical_batch), int(max_vector_batch), int(max_wait_us)),
                 "ss_shard_set_coalescing")
 
+    def one_launch_batches(self):
+        """lexical host-pointer batches that took the one-launch path of small batches (ss_bm25_path_stats)"""
+        v = C.c_uint64(0)
+        N.check(N.lib().ss_bm25_path_stats(self._h, C.byref(v)), "ss_bm25_path_stats")
+        return int(v.value)
+
     def coalescing_stats(self):
         """(lexical batches, lexical queries, vector batches, vector queries) served through the coalescer so far"""
         import ctypes as C

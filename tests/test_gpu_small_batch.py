@@ -1,0 +1,189 @@
+"""The one-launch path of small host-pointer lexical batches (csrc/bm25_small.hip; the reference's call shape is ONE query per
+call, search.rs:1637-1743): its answers must be those of the staged pipeline (expand -> probe -> merge -> copies) BIT FOR BIT and
+agree with the CPU oracle -- unions / intersections of 1..4 terms, NOT terms, tombstones, exact counts, k from 1 to 128,
+1..64 queries per call -- and batches outside its shape must still be answered (by the staged pipeline).  The threshold seeds
+(the K-th largest weight of every list, bm_kth_kernel) are checked through what they must never do: cost a query a result."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    import seekstorm_amd
+    return seekstorm_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+N_DOCS = 300_000
+DFS = [0.004, 0.012, 0.03, 0.05, 0.09, 0.15, 0.0005, 0.22]
+
+
+def _corpus(O, seed=11):
+    rng = np.random.default_rng(seed)
+    lens = np.clip(np.round(np.exp(np.log(120) + 0.6 * rng.standard_normal(N_DOCS))), 8, 2000).astype(np.int64)
+    lut = {int(x): int(O.lib().so_int_to_byte4(int(x))) for x in np.unique(lens)}
+    doclen = np.array([lut[int(x)] for x in lens], np.uint8)
+    offs, docs, tfs = [0], [], []
+    for df in DFS:
+        n = max(1, int(round(df * N_DOCS)))
+        docs.append(np.sort(rng.choice(N_DOCS, n, replace=False)).astype(np.uint32))
+        tfs.append(rng.geometric(0.55, n).clip(1, 300).astype(np.uint16))
+        offs.append(offs[-1] + n)
+    return doclen, np.asarray(offs, np.uint64), np.concatenate(docs), np.concatenate(tfs)
+
+
+@pytest.fixture(scope="module")
+def world(S, O):
+    dl, offs, docs, tfs = _corpus(O)
+    sh = S.Shard(0)
+    sh.upload_lexical(N_DOCS, dl, offs, docs, tfs)
+    osh = O.Shard(N_DOCS, dl, offs, docs, tfs)
+    yield sh, osh
+    sh.close()
+
+
+def _dev_search(S, sh, q, k, rt, ops):
+    """the staged pipeline, by construction: device-resident queries through ss_bm25_search_dev"""
+    import ctypes as C
+    import torch
+    from seekstorm_amd import _native as N
+    dev = torch.device("cuda", 0)
+    nq = len(q)
+    qd = torch.from_numpy(q.view(np.uint8).reshape(nq, -1).copy()).to(dev)
+    kk = max(k, 1)
+    o_doc = torch.empty((nq, kk), dtype=torch.int32, device=dev); o_score = torch.empty((nq, kk), dtype=torch.float32, device=dev)
+    o_cnt = torch.empty((nq,), dtype=torch.int32, device=dev); o_tot = torch.empty((nq,), dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream(dev)
+    N.check(N.lib().ss_bm25_search_dev(sh._h, nq, qd.data_ptr(), k, int(rt), ops, o_doc.data_ptr(), o_score.data_ptr(), o_cnt.data_ptr(),
+                                       o_tot.data_ptr(), C.c_void_p(st.cuda_stream)), "ss_bm25_search_dev")
+    torch.cuda.synchronize()
+    return (o_doc.cpu().numpy().view(np.uint32), o_score.cpu().numpy(), o_cnt.cpu().numpy().view(np.uint32), o_tot.cpu().numpy().view(np.uint64))
+
+
+def _queries(rng, n, n_terms, n_not=0):
+    out, nots = [], []
+    for _ in range(n):
+        t = rng.choice(len(DFS), n_terms + n_not, replace=False)
+        out.append([int(x) for x in t[:n_terms]])
+        nots.append([int(x) for x in t[n_terms:]])
+    return out, nots
+
+
+@pytest.mark.parametrize("shape", ["or", "and", "or_not", "and_not", "tombstones"])
+def test_one_launch_equals_staged_pipeline_and_oracle(S, O, world, shape):
+    sh, osh = world
+    rng = np.random.default_rng({"or": 1, "and": 2, "or_not": 3, "and_not": 4, "tombstones": 5}[shape])
+    gone = np.unique(rng.integers(0, N_DOCS, N_DOCS // 50)).astype(np.uint64) if shape == "tombstones" else np.zeros(0, np.uint64)
+    sh.set_deleted(gone); osh.set_deleted([int(x) for x in gone])
+    try:
+        for nq, nt, k in ((1, 1, 10), (1, 3, 10), (7, 2, 1), (64, 3, 10), (33, 4, 32), (5, 3, 33), (16, 2, 100), (3, 4, 128)):
+            n_not = 2 if shape.endswith("_not") else 0
+            if nt + n_not > len(DFS):
+                continue
+            lists, nots = _queries(rng, nq, nt, n_not)
+            is_and = shape.startswith("and")
+            qt = S.QueryType.Intersection if is_and else S.QueryType.Union
+            q = sh.make_queries(lists, qt, nots if n_not else None)
+            ops = (1 if is_and else 2) | ((nt + n_not) << 8) | (nt << 16) | (n_not << 24)
+            for rt in (S.ResultType.Topk, S.ResultType.TopkCount):
+                before = sh.one_launch_batches()
+                got = sh.search_lexical_batch(q, k, rt, reference_shortcuts=False)
+                assert sh.one_launch_batches() == before + 1, "the batch did not take the one-launch path"
+                ref = _dev_search(S, sh, q, k, rt, ops)
+                assert np.array_equal(got[2], ref[2]), (shape, nq, nt, k, rt)
+                for i in range(nq):
+                    c = int(got[2][i])
+                    assert np.array_equal(got[0][i][:c], ref[0][i][:c]) and np.array_equal(got[1][i][:c], ref[1][i][:c]), (shape, nq, nt, k, rt, i)
+                if rt == S.ResultType.TopkCount:
+                    assert np.array_equal(got[3], ref[3]), (shape, nq, nt, k)
+                # the oracle on a few queries of the batch: exact counts, scores within 1e-4, ids outside the k-th score's tie band
+                for i in range(min(nq, 3)):
+                    od, os_, otot = osh.search_exhaustive(lists[i], O.OP_AND if (is_and and nt > 1) else O.OP_OR, k, not_terms=nots[i] if n_not else ())
+                    c = int(got[2][i])
+                    assert c == len(od), (shape, i, c, len(od))
+                    assert np.allclose(got[1][i][:c], os_, rtol=1e-4)
+                    if rt == S.ResultType.TopkCount:
+                        assert int(got[3][i]) == otot
+                    if c:
+                        band = abs(float(os_[-1])) * 2e-4
+                        clear = lambda dd, ss: {int(x) for x, y in zip(dd, ss) if y > os_[-1] + band}
+                        assert clear(got[0][i][:c], got[1][i][:c]) <= set(od.tolist()) and clear(od, os_) <= set(got[0][i][:c].tolist())
+    finally:
+        sh.set_deleted([]); osh.set_deleted([])
+
+
+def test_batches_outside_the_shape_take_the_staged_pipeline(S, O, world):
+    sh, osh = world
+    rng = np.random.default_rng(3)
+    # 65 queries, 5 scored terms, k = 129, a Count request: all answered, none by the one-launch path
+    for lists, k, rt in ((_queries(rng, 65, 3)[0], 10, S.ResultType.Topk), (_queries(rng, 4, 5)[0], 10, S.ResultType.Topk),
+                         (_queries(rng, 4, 3)[0], 129, S.ResultType.Topk), (_queries(rng, 4, 3)[0], 10, S.ResultType.Count)):
+        q = sh.make_queries(lists, S.QueryType.Union)
+        before = sh.one_launch_batches()
+        d, s, c, t = sh.search_lexical_batch(q, k, rt, reference_shortcuts=False)
+        assert sh.one_launch_batches() == before
+        for i in range(min(len(lists), 2)):
+            od, os_, otot = osh.search_exhaustive(lists[i], O.OP_OR, k)
+            if rt == S.ResultType.Count:
+                assert int(t[i]) == otot
+            else:
+                assert int(c[i]) == len(od) and np.allclose(s[i][:c[i]], os_, rtol=1e-4)
+    # an invalid query keeps its error code on this path too (term id out of range)
+    from seekstorm_amd import _native as N
+    q = sh.make_queries([[0, 1]], S.QueryType.Union)
+    q["term"][0, 0] = 10_000
+    with pytest.raises(N.SeekStormHipError):
+        sh.search_lexical_batch(q, 10, S.ResultType.Topk, reference_shortcuts=False)
+    # and the shard still answers afterwards (the per-query state of the one-launch path is left clean)
+    q = sh.make_queries([[0, 1, 2]], S.QueryType.Union)
+    d, s, c, t = sh.search_lexical_batch(q, 10, S.ResultType.TopkCount, reference_shortcuts=False)
+    od, os_, otot = osh.search_exhaustive([0, 1, 2], O.OP_OR, 10)
+    assert int(t[0]) == otot and np.allclose(s[0][:c[0]], os_, rtol=1e-4)
+
+
+def test_threshold_seeds_never_cost_a_result(S, O):
+    """lists whose K largest weights sit in a handful of docs, ties AT the seed, lists shorter than K, k on both sides of 10 / 100:
+    seeded searches (default) return what the exhaustive strategy returns"""
+    rng = np.random.default_rng(77)
+    n_docs = 120_000
+    lens = rng.choice([20, 21, 300], n_docs)  # few distinct lengths: large groups of equal weights, i.e. ties at the K-th weight
+    lut = {int(x): int(O.lib().so_int_to_byte4(int(x))) for x in np.unique(lens)}
+    dl = np.array([lut[int(x)] for x in lens], np.uint8)
+    offs, docs, tfs = [0], [], []
+    for n, big in ((9, 0), (60, 3), (5000, 12), (40000, 200), (15000, 1000), (100, 100)):
+        d = np.sort(rng.choice(n_docs, n, replace=False)).astype(np.uint32)
+        tf = np.ones(n, np.uint16)
+        if big:
+            tf[rng.choice(n, min(big, n), replace=False)] = 25
+        docs.append(d); tfs.append(tf); offs.append(offs[-1] + n)
+    offs = np.asarray(offs, np.uint64); docs = np.concatenate(docs); tfs = np.concatenate(tfs)
+    from seekstorm_amd import _native as N
+    sh = S.Shard(0)
+    sh.upload_lexical(n_docs, dl, offs, docs, tfs)
+    osh = O.Shard(n_docs, dl, offs, docs, tfs)
+    try:
+        lists = [[0], [1], [2], [3], [0, 1], [2, 3], [1, 2, 3], [0, 2, 4], [3, 4, 5], [2, 3, 4, 5], [5], [4, 5]]
+        for k in (1, 9, 10, 11, 99, 100, 101, 128):
+            q = sh.make_queries(lists, S.QueryType.Union)
+            seeded = sh.search_lexical_batch(q, k, S.ResultType.TopkCount, reference_shortcuts=False)       # one launch, host seeds
+            big = sh.make_queries(lists * 6, S.QueryType.Union)                                           # 72 queries: staged, device seeds
+            staged = sh.search_lexical_batch(big, k, S.ResultType.TopkCount, reference_shortcuts=False)
+            sh.set_strategy(N.BM25_EXHAUSTIVE)
+            exh = sh.search_lexical_batch(q, k, S.ResultType.TopkCount, reference_shortcuts=False)
+            sh.set_strategy(N.BM25_AUTO)
+            for i, tl in enumerate(lists):
+                c = int(exh[2][i])
+                assert int(seeded[2][i]) == c == int(staged[2][i]), (k, tl, int(seeded[2][i]), int(staged[2][i]), c)
+                assert np.array_equal(seeded[1][i][:c], exh[1][i][:c]) and np.array_equal(staged[1][i][:c], exh[1][i][:c]), (k, tl)
+                assert int(seeded[3][i]) == int(exh[3][i]) == int(staged[3][i])
+                od, os_, otot = osh.search_exhaustive(tl, O.OP_OR, k)
+                assert c == len(od) and np.allclose(seeded[1][i][:c], os_, rtol=1e-4) and int(seeded[3][i]) == otot
+    finally:
+        sh.close()
