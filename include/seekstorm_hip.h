@@ -45,9 +45,11 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 4
+#define SS_ABI_VERSION 5
 #define SS_NO_DOC 0xFFFFFFFFu
-#define SS_MAX_QUERY_TERMS 10 /* union_docid_3 handles <= 10 terms, union.rs:1308 */
+/* scored + NOT terms of one query: union_docid_3 takes unions of <= 10 terms (union.rs:1308), union_blockid -> union_scan_32 those of
+ * 11..32 (search.rs:3497-3520, union.rs:598-805; its 32-bit match mask is the limit) */
+#define SS_MAX_QUERY_TERMS 32
 #define SS_MAX_K 1024
 #define SS_VEC_BATCH 64 /* queries scanned per pass over the matrix */
 
@@ -116,7 +118,7 @@ int ss_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen_bytes, ui
  * Two or more fields (boosts > 0): the score is additive per (term, field), so the image also carries one MERGED list per term
  * -- every doc holding the term in any field, with the weight sum_f boost[f] * w_f scaled into the weight code's range (the
  * scale returns through idf) -- and a query WITHOUT a field filter reads only those: it is a single-field query to every kernel
- * (pruned strategy, 16-bit scan, plain intersections, up to 10 terms).  Its scores equal the per-field sums up to the code's
+ * (pruned strategy, 16-bit scan, plain intersections, up to SS_MAX_QUERY_TERMS terms).  Its scores equal the per-field sums up to the code's
  * rounding (2^-16 relative per term, inside the 1e-4 tolerance); the image holds the postings twice.  A query WITH a field
  * filter reads the (term, field) lists: at most 32 / n_fields terms (NOT terms included), intersections of at most 8 terms.
  * SS_BM25_MERGED=0 in the environment builds the image without merged lists. */
@@ -375,7 +377,7 @@ int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df
 
 /* query_list + not_query_list of the dispatch block (search.rs:3374-3560).  NOT terms ("-term", not_query_list): a doc
  * found in one of their posting lists neither counts nor ranks (add_result.rs:3440-3497).  They are stored after the
- * n_terms query terms, their number in bits 8..15 of op:  op = SS_OP_* | SS_OP_NOT_TERMS(n);  n_terms + n <= 10. */
+ * n_terms query terms, their number in bits 8..15 of op:  op = SS_OP_* | SS_OP_NOT_TERMS(n);  n_terms + n <= SS_MAX_QUERY_TERMS. */
 #define SS_OP_NOT_TERMS(n) ((uint32_t)(n) << 8)
 /* field_filter of search_lexical_shard for an image with several indexed fields (search.rs:2483-2492, add_result.rs:3124-
  * 3136): bits 16..31 of op, bit f = indexed field f is listed; 0 = no filter.  Intersections and single-term queries: a doc is

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEEKSTORM_HIP_LIB") or os.path.join(_HERE, "lib", "libseekstorm_hip.so")  # override: experiment builds (tools/probes)
 
 SS_NO_DOC = 0xFFFFFFFF
-SS_MAX_QUERY_TERMS = 10
+SS_MAX_QUERY_TERMS = 32
 SS_MAX_PHRASE = 12
 SS_PHRASE_SKIP = 0xFF
 SS_MAX_K = 1024

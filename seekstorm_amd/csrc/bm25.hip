@@ -161,7 +161,7 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
   total[i] = 0ull;                      // per-query match count and shared threshold start from zero (no separate memset launch)
   if (!keep_tau) tau[(size_t)i * BM_TAU_STRIDE] = 0u;  // (keep_tau: an experiment -- the same batch again with the thresholds it ended on)
                                                        // (a union without exclusions raises it to its seed at the end of the expansion)
-  const ss_bm25_query Q = q[i];
+  const ss_bm25_query& Q = q[i];  // (read in place: a local copy indexed at run time would live in scratch)
   bm_vquery& V = vq[i];  // written in place: a local copy indexed at run time would live in scratch
   const uint32_t np = Q.n_terms, n_not = bm_q_nnot(Q.op);
   const uint32_t n_fields = n_lists - (merged ? 1u : 0u);                      // indexed fields

@@ -23,15 +23,15 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in seekstorm_hip.h but not exported"
     bound = {s[0] for s in N.SYMBOLS}
     assert set(declared) == bound, (set(declared) ^ bound)
-    assert N.lib().ss_abi_version() == 4
+    assert N.lib().ss_abi_version() == 5
     assert N.lib().ss_strerror(-4).decode().startswith("not supported")
 
 
 def test_struct_layout_matches_header():
     import ctypes as C
     from seekstorm_amd import _native as N
-    assert C.sizeof(N.Bm25Query) == 4 + 4 + 4 * 10 + 4 * 10 + 4 + 12
-    assert N.BM25_QUERY_DTYPE.fields["term"][1] == 8 and N.BM25_QUERY_DTYPE.fields["idf"][1] == 48
+    assert C.sizeof(N.Bm25Query) == 4 + 4 + 4 * 32 + 4 * 32 + 4 + 12  # SS_MAX_QUERY_TERMS = 32 (ABI v5)
+    assert N.BM25_QUERY_DTYPE.fields["term"][1] == 8 and N.BM25_QUERY_DTYPE.fields["idf"][1] == 8 + 4 * 32
     # the structs the header declares, as gcc lays them out
     import os, subprocess, tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
