@@ -920,6 +920,278 @@ int launch16(const BmParams& p, hipStream_t st) {
   return SS_OK;
 }
 
+
+// ---------------------------------------------------------------- unions of MANY lists (5 .. 32): bm25_scan16m_kernel
+// The reference scans unions of more than 10 terms with a 32-bit match mask per doc of the block (union_scan_32, union.rs:598-805) and
+// sends unions of up to 10 through sub-query decomposition (union_docid_3); several indexed fields multiply a query's lists as well.
+// The NT-specialised kernel above keeps an item's postings in registers for its candidate path -- 6 lists are what fits.  Here the
+// number of lists is a RUN-TIME value: per-list constants live one per LANE (lane t: term, list address, idf, fixed-point idf, the
+// list's boundary in the current and the next sub-block) and are fetched with v_readlane as the lists are walked; the lists of an item
+// are streamed one after the other into the same 16-bit bound tile (the first chunk of list t + 1 in flight while list t is
+// accumulated); the rare candidate path re-reads the item's segments (they are in the L2) to sum its candidates' exact scores in
+// query order -- the fma chain of every other kernel.  Top-k only (exact counts come from the probe index's bit records; without one
+// the f32 tile's count mode serves), NOT lists and tombstones through the candidate path as in the plain instances.
+struct S16MLists {
+  uint32_t v_tlo, v_thi;  // lane t: address of list t's postings
+  uint32_t v_a, v_b;      // lane t: the item's segment of list t, [a, b) in 16-byte units relative to the list
+  uint32_t v_idf, v_fidf; // lane t: idf (bits), idf * scale (bits)
+  uint32_t nt;
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t s16m_rsrc(const S16MLists& L, uint32_t t, uint32_t b1) {
+  const u64 a = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)L.v_thi, t) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)L.v_tlo, t);
+  return __builtin_amdgcn_make_buffer_rsrc((void*)a, 0, (int)(b1 << 4), BM_RSRC_FLAGS);
+}
+// every chunk (64 lanes x 16 B) of the item's segment of list t
+template <typename F>
+__device__ __forceinline__ void s16m_each_chunk(const S16MLists& L, uint32_t t, int lane16, F f) {
+  const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)L.v_a, t), b1 = (uint32_t)__builtin_amdgcn_readlane((int)L.v_b, t);
+  if (b0 == b1) return;
+  __amdgpu_buffer_rsrc_t rs = s16m_rsrc(L, t, b1);
+  for (uint32_t u = b0; u < b1; u += 256u) {  // four chunks in flight
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + 1024, (int)(u << 4), 0);
+    const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + 2048, (int)(u << 4), 0);
+    const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + 3072, (int)(u << 4), 0);
+    f(a);
+    if (u + 64u < b1) f(b);
+    if (u + 128u < b1) f(c);
+    if (u + 192u < b1) f(d);
+  }
+}
+// the candidate path of an item (s16_trigger's steps with the postings re-read instead of held): cut, list, exact sums, keys
+template <int KPL>
+__device__ __attribute__((noinline)) BmTop<KPL> s16m_trigger(BmTop<KPL> T, const S16MLists L, uint32_t wb, uint32_t qthr, float thr, uint32_t doc_base,
+                                                           uint32_t k, uint32_t* tau_q, const S16Excl ex) {
+  const uint32_t* __restrict__ del = ex.del;
+  const uint32_t del_words = ex.del_words;
+  const int lane = __lane_id();
+  const int lane16 = lane * 16;
+  const uint32_t tile = wb + 16u, accb = wb + 14u, accf = wb + S16_ACC;
+  const float wsc_in = T.wsc;
+  uint32_t start = 0u;
+  const bool excl = ex.nn != 0u || ex.del != nullptr;
+  if (excl) s16_exclude(ex, accb, lane);
+  const uint32_t SLACK = 2u * L.nt + S16_SLACK;
+  for (;;) {
+    uint32_t sm[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      sm[i] = s16_max8(lds_ld128(tile + (uint32_t)(2 * i * 64 + lane) * 16u)) |
+              (s16_max8(lds_ld128(tile + (uint32_t)((2 * i + 1) * 64 + lane) * 16u)) << 16);
+    const uint32_t lmp = s16_pkmax(s16_pkmax(sm[0], sm[1]), s16_pkmax(sm[2], sm[3]));
+    const uint32_t lm = max(lmp & 0xFFFFu, lmp >> 16);
+    uint32_t qcut = max(qthr, 1u);
+    if (k <= 64u && (uint32_t)__popcll(__ballot(lm >= qcut)) > k) {
+      uint32_t lo = qcut, hi = 65535u;  // invariant: at least k lanes reach lo
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1u) >> 1;
+        if ((uint32_t)__popcll(__ballot(lm >= mid)) >= k) lo = mid; else hi = mid - 1u;
+      }
+      qcut = max(qcut, lo > SLACK ? lo - SLACK : 1u);
+    } else if (KPL > 1 && k > 64u) {
+      auto slots_at = [&](uint32_t x) -> uint32_t {
+        uint32_t c = 0u;
+#pragma unroll
+        for (int i = 0; i < 8; i++) c += (uint32_t)__popcll(__ballot(((sm[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu) >= x));
+        return c;
+      };
+      if (slots_at(qcut) > k) {
+        uint32_t lo = qcut, hi = 65535u;
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi + 1u) >> 1;
+          if (slots_at(mid) >= k) lo = mid; else hi = mid - 1u;
+        }
+        qcut = max(qcut, lo > SLACK ? lo - SLACK : 1u);
+      }
+    }
+    uint32_t hotbits = 0u;
+#pragma unroll
+    for (int i = 0; i < 8; i++) hotbits |= (((sm[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu) >= qcut ? 1u : 0u) << i;
+    uint32_t n = 0u, next = 0xFFFFu;
+#pragma unroll 1
+    for (uint32_t i = start >> 9; i < (uint32_t)(BM_SUB / 512) && next == 0xFFFFu; i++) {
+      u64 m = __ballot((hotbits >> i) & 1u);
+      while (m && next == 0xFFFFu) {
+        const uint32_t l = (uint32_t)__ffsll((long long)m) - 1u;
+        m &= m - 1;
+        const u32x4 g = lds_ld128(tile + (i * 64u + l) * 16u);
+        const uint32_t dw[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)g.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)g.y),
+                                (uint32_t)__builtin_amdgcn_readfirstlane((int)g.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)g.w)};
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+          const uint32_t bound = (dw[j >> 1] >> ((j & 1u) * 16u)) & 0xFFFFu;
+          const uint32_t din = (i * 64u + l) * 8u + j;
+          if (bound >= qcut && din >= start && next == 0xFFFFu) {
+            if (n == S16_LIST_MAX) next = din;
+            else { lds_st16(wb + S16_LIST + n * 2u, din); n++; }
+          }
+        }
+      }
+    }
+    start = next;
+    s16_clear_tile(wb, lane);
+    uint32_t din = 0u;
+    if ((uint32_t)lane < n) {
+      din = lds_ld16(wb + S16_LIST + (uint32_t)lane * 2u);
+      lds_st16(accb + ((din + 1u) << 1), (uint32_t)lane + 1u);
+      lds_stf(accf + (uint32_t)lane * 4u, 0.f);
+    }
+    if (n) {
+      for (uint32_t t = 0; t < L.nt; t++) {  // lists stand in query order: the sum is the other kernels', bit for bit
+        const float idf_t = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)L.v_idf, t));
+        s16m_each_chunk(L, t, lane16, [&](const u32x4 v) {
+          const uint32_t pv[4] = {v.x, v.y, v.z, v.w};
+          uint32_t mk[4];
+#pragma unroll
+          for (int x = 0; x < 4; x++) mk[x] = lds_ld16(s16_addr(pv[x], accb));
+#pragma unroll
+          for (int x = 0; x < 4; x++)
+            if (mk[x]) {
+              const uint32_t ad = accf + (mk[x] - 1u) * 4u;
+              lds_stf(ad, __builtin_fmaf(idf_t, bm_weight(pv[x]), lds_ldf(ad)));
+            }
+        });
+      }
+      u64 key = 0ull;
+      if ((uint32_t)lane < n) {
+        const float sc = lds_ldf(accf + (uint32_t)lane * 4u);
+        const uint32_t doc = doc_base + din;
+        const bool gone = del && (doc >> 5) < del_words && ((del[doc >> 5] >> (doc & 31u)) & 1u);
+        lds_st16(accb + ((din + 1u) << 1), 0u);
+        if (!gone && sc > 0.f && sc >= thr) key = ((u64)__float_as_uint(sc) << 32) | (u64)(0xFFFFFFFFu - doc);
+      }
+      key = key > T.worst ? key : 0ull;
+      if (__ballot(key != 0ull)) {
+        T.worst = topk_offer<KPL>(T.keys, key, 0ull, 0ull, 0ull, T.worst, k);
+        if (T.worst) {
+          T.wsc = __uint_as_float((uint32_t)(T.worst >> 32));
+          thr = fmaxf(thr, T.wsc);
+        }
+      }
+    }
+    if (start == 0xFFFFu) break;
+    // more candidates than the list holds: the bounds again, the exclusions again, the next 64
+    {
+      uint32_t dummy = 0u, nocount = 0u;
+      for (uint32_t t = 0; t < L.nt; t++) {
+        const float fidf_t = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)L.v_fidf, t));
+        s16m_each_chunk(L, t, lane16, [&](const u32x4 v) { dummy = s16_keep<false>(v, fidf_t, accb, dummy, nocount); });
+      }
+    }
+    if (excl) s16_exclude(ex, accb, lane);
+  }
+  s16_clear(wb, lane);
+  if (tau_q && T.wsc > wsc_in && lane == 0) bm_publish_tau(tau_q, T.wsc);
+  return T;
+}
+
+template <int KPL>
+__global__ void __launch_bounds__(S16_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+bm25_scan16m_kernel(const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base, const uint32_t* __restrict__ sub_off,
+                    const bm_vquery* __restrict__ qs, unsigned long long* __restrict__ part_keys, uint32_t* tau,
+                    const uint32_t* __restrict__ del, uint32_t del_words, uint32_t n_sub, uint32_t n_terms, uint32_t nq, uint32_t P, uint32_t k) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t wb = (uint32_t)w * S16_WAVE_LDS, accb = wb + 14u;
+  s16_clear(wb, lane);
+  const uint32_t row_len = n_sub + 1;
+  const int lane16 = lane * 16;
+  const uint32_t a = blockIdx.x * S16_WAVES + w;
+  if (a >= nq * P) return;
+  const uint32_t qi = a % nq, part = a / nq;
+  const bm_vquery* __restrict__ Q = qs + qi;
+  const uint32_t nt = min(Q->n_terms, (uint32_t)BM_MAX_VTERMS);
+  // lane t: everything about list t
+  const bool mine = (uint32_t)lane < nt;
+  const uint32_t term = mine ? Q->term[mine ? lane : 0] : n_terms;
+  const float idf = mine ? Q->idf[mine ? lane : 0] : 0.f;
+  float idf_sum = idf;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) idf_sum += __shfl_xor(idf_sum, o);
+  const float scale = S16_QMAX / (S16_WMAX * idf_sum);
+  const float scale_thr = s16_uniform(scale * (1.0f - 1e-5f));
+  const u64 taddr = (u64)(uintptr_t)(post + term_base[term] * 4ull);
+  const uint32_t* __restrict__ rowp = sub_off + (size_t)term * row_len;
+  S16MLists L;
+  L.v_tlo = (uint32_t)taddr; L.v_thi = (uint32_t)(taddr >> 32);
+  L.v_idf = __float_as_uint(idf); L.v_fidf = __float_as_uint(idf * scale);
+  L.nt = nt;
+  const uint32_t s_begin = (uint32_t)(((u64)n_sub * part) / P);
+  const uint32_t s_end = (uint32_t)(((u64)n_sub * (part + 1)) / P);
+  BmTop<KPL> T;
+#pragma unroll
+  for (int r = 0; r < KPL; r++) T.keys[r] = 0ull;
+  T.worst = 0ull;
+  T.wsc = -1.0f;
+  T.matched = 0;
+  uint32_t* tau_q = tau + (size_t)qi * BM_TAU_STRIDE;
+  if (s_begin < s_end) {
+    L.v_a = rowp[s_begin];
+    L.v_b = rowp[s_begin + 1u];
+    for (uint32_t s = s_begin; s < s_end; s++) {
+      const uint32_t tau_bits = __hip_atomic_load(tau_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t v_c = rowp[min(s + 2u, n_sub)];  // the boundaries the NEXT item ends on: in flight under this item's lists
+      uint32_t mx = 0u, nocount = 0u;
+      bool any = false;
+      // list t + 1's first chunk is requested before list t is accumulated
+      uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)L.v_a, 0), b1 = (uint32_t)__builtin_amdgcn_readlane((int)L.v_b, 0);
+      u32x4 nxt = __builtin_amdgcn_raw_buffer_load_b128(s16m_rsrc(L, 0, b1), lane16, (int)(b0 << 4), 0);
+      for (uint32_t t = 0; t < nt; t++) {
+        const u32x4 cur = nxt;
+        const uint32_t c0 = b0, c1 = b1;
+        if (t + 1u < nt) {
+          b0 = (uint32_t)__builtin_amdgcn_readlane((int)L.v_a, t + 1u); b1 = (uint32_t)__builtin_amdgcn_readlane((int)L.v_b, t + 1u);
+          nxt = __builtin_amdgcn_raw_buffer_load_b128(s16m_rsrc(L, t + 1u, b1), lane16, (int)(b0 << 4), 0);
+        }
+        if (c0 == c1) continue;
+        any = true;
+        const float fidf_t = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)L.v_fidf, t));
+        mx = s16_keep<false>(cur, fidf_t, accb, mx, nocount);
+        if (c1 - c0 > 64u) {  // a dense segment: the rest, four chunks in flight
+          __amdgpu_buffer_rsrc_t rs = s16m_rsrc(L, t, c1);
+          for (uint32_t u = c0 + 64u; u < c1; u += 256u) {
+            const u32x4 x0 = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0);
+            const u32x4 x1 = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + 1024, (int)(u << 4), 0);
+            const u32x4 x2 = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + 2048, (int)(u << 4), 0);
+            const u32x4 x3 = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + 3072, (int)(u << 4), 0);
+            mx = s16_keep<false>(x0, fidf_t, accb, mx, nocount);
+            if (u + 64u < c1) mx = s16_keep<false>(x1, fidf_t, accb, mx, nocount);
+            if (u + 128u < c1) mx = s16_keep<false>(x2, fidf_t, accb, mx, nocount);
+            if (u + 192u < c1) mx = s16_keep<false>(x3, fidf_t, accb, mx, nocount);
+          }
+        }
+      }
+      if (any) {
+        const float thr = fmaxf(T.wsc, __uint_as_float(tau_bits));
+        const uint32_t qthr = thr > 0.f ? (uint32_t)(thr * scale_thr) : 0u;
+        if (__ballot(mx >= qthr + S16_MBITS)) {  // mx = the bits of 2^23 + the largest bound (s16_qm)
+          const S16Excl ex{Q, post, term_base, sub_off, del, Q->n_terms, bm_q_nnot(Q->op), row_len, del_words, s};
+          T = s16m_trigger<KPL>(T, L, wb, qthr, thr, s << BM_SUB_LOG2, k, tau_q, ex);
+        } else {
+          s16_clear(wb, lane);
+        }
+      }
+      L.v_a = L.v_b;
+      L.v_b = v_c;
+    }
+  }
+  u64* out = part_keys + ((size_t)qi * P + part) * (64 * KPL);
+#pragma unroll
+  for (int r = 0; r < KPL; r++) out[r * 64 + lane] = T.keys[r];
+}
+
+template <int KPL>
+int launch16m(const BmParams& p, hipStream_t st) {
+  constexpr int lds = S16_WAVES * S16_WAVE_LDS;
+  SS_SET_MAX_LDS((bm25_scan16m_kernel<KPL>), lds);
+  const uint32_t A = p.nq * p.P;
+  bm25_scan16m_kernel<KPL><<<(A + S16_WAVES - 1) / S16_WAVES, S16_WAVES * 64, lds, st>>>(
+      p.post, p.term_base, p.sub_off, p.q, p.part_keys, p.tau, p.del, p.del_words, p.n_sub, p.n_terms, p.nq, p.P, p.k);
+  return SS_OK;
+}
+
 }  // namespace
 
 // What the 16-bit tile serves (everything else of the exhaustive strategy stays on bm25_scan_fast_kernel's f32 tile):
@@ -941,9 +1213,12 @@ bool ssi_bm25_scan16_serves(uint32_t nn_max, uint32_t np_max, bool has_and, bool
   if (count && nn > 1) return false;    // the count instances stream one NOT list
   if (nn > 8) return false;
   if (has_and && (and_off || and_exact_nt < 2 || and_exact_nt > 3 || and_exact_nt != np_max)) return false;
-  if (np_max > 4 && (has_and || count || wide_off)) return false;  // five / six lists: plain top-k unions
+  if (np_max > 4 && (has_and || count || wide_off)) return false;  // five and more lists: plain top-k unions
   static const int k128_off = [] { const char* e = getenv("SS_BM25_SCAN16_K128"); return e ? atoi(e) == 0 : 0; }();
-  if (KPL == 2 && (k128_off || np_max > 4)) return false;  // k <= 128: two keys per lane in the candidate path (no k-lane cut), <= 4 lists
+  static const int many_off = [] { const char* e = getenv("SS_BM25_SCAN16_MANY"); return e ? atoi(e) == 0 : 0; }();
+  // 7 .. 32 lists, and 5 / 6 at k of 65 .. 128: bm25_scan16m_kernel (lists as a run-time loop)
+  if (np_max > 6 || (np_max > 4 && KPL == 2)) return !off && !many_off && !k128_off && k != 0 && np_max <= (uint32_t)BM_MAX_VTERMS && KPL <= 2;
+  if (KPL == 2 && k128_off) return false;  // k <= 128: two keys per lane in the candidate path (no k-lane cut)
   return !off && (k != 0 || count) && np_max >= 1 && np_max <= 6 && KPL <= 2;
 }
 
@@ -966,5 +1241,6 @@ int ssi_bm25_launch_scan16(const BmParams& p, uint32_t np_max, uint32_t nn_max, 
 #undef SS_F
   if (NT == 5 && !p.count && KPL == 1) return launch16<5, 1, false, false>(p, st);
   if (NT == 6 && !p.count && KPL == 1) return launch16<6, 1, false, false>(p, st);
+  if (NT >= 5 && !p.count) return KPL == 1 ? launch16m<1>(p, st) : launch16m<2>(p, st);
   return SS_ENOTSUP;
 }

@@ -74,6 +74,14 @@ def test_unions_of_11_to_32_terms_match_the_oracle(S, O, world, deleted):
             for k in (10, 100):
                 for rt in (S.ResultType.Topk, S.ResultType.TopkCount, S.ResultType.Count):
                     got = sh.search_lexical_batch(q, k, rt, reference_shortcuts=False)
+                    # the 16-bit many-list scan (bm25_scan16m_kernel, what AUTO runs here) against the f32 tile: the same sums, bit for bit
+                    from seekstorm_amd import _native as N
+                    sh.set_strategy(N.BM25_EXHAUSTIVE_F32)
+                    f32 = sh.search_lexical_batch(q, k, rt, reference_shortcuts=False)
+                    sh.set_strategy(N.BM25_AUTO)
+                    assert np.array_equal(got[2], f32[2]) and np.array_equal(got[3], f32[3]), (nt, n_not, k, int(rt))
+                    for i in range(len(lists)):
+                        assert np.array_equal(got[1][i][:got[2][i]], f32[1][i][:got[2][i]]), (nt, n_not, k, int(rt), i)
                     for i in range(len(lists)):
                         what = (nt, n_not, k, int(rt), i, deleted)
                         od, os_, otot = osh.search_exhaustive(lists[i], O.OP_OR, k, not_terms=nots[i])  # the definition
