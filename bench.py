@@ -137,6 +137,9 @@ def compact_line(line):
         for k_ in ("clustered_exhaustive_frac", "and_exhaustive_frac", "not_tombstones_frac", "fallback_f32_frac"):
             if rf.get(k_) is not None:
                 roof[k_] = rf[k_]
+        u16 = ((line.get("union16") or {}).get("roofline") or {}).get("frac")
+        if u16 is not None:
+            roof["union16_frac"] = u16
     else:
         roof = _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "mfma_util_pmc", "algorithmic_flops_per_launch",
                           "algorithmic_bytes_per_launch", "avg_launch_ms", "launches"))
@@ -571,6 +574,62 @@ def main():
                                             "so_search_lex_ref with not_query_list and delete_hashset on the host-regenerated shard",
                                             "seconds": time.perf_counter() - t0}
             sx.close()
+        # (3c') unions of MANY terms (11..32 terms go to union_blockid -> union_scan_32 in the reference, search.rs:3497-3520):
+        # 64 queries of 16 terms each -- 12 from the 0.5-5 % df bands, 4 from the 5-15 % band -- top-10, on the C2 corpus.  AUTO runs the
+        # 16-bit many-list scan (bm25_scan16m_kernel; exact counts from the probe index's bit records), against the f32 tile that served
+        # such a request before (SS_BM25_EXHAUSTIVE_F32).  Roofline: SURVEY 8d's bytes from the exact df / union sizes.
+        many = None
+        if not args.no_topk_count and world == 1 and not args.quick:
+            rng_m = np.random.default_rng(1357)
+            lo_b, hi_b = band_terms(th, 0.005, 0.05), band_terms(th, 0.05, 0.15)
+            nqm, ntm = 64, 16
+            m_lists = [[int(x) for x in rng_m.choice(lo_b, 12, replace=False)] + [int(x) for x in rng_m.choice(hi_b, 4, replace=False)] for _ in range(nqm)]
+            qm_np = sh.make_queries(m_lists, S.QueryType.Union)
+            qm_dev = torch.from_numpy(qm_np.view(np.uint8).reshape(nqm, -1).copy()).to(dev)
+            OPS_M = 2 | (ntm << 8) | (ntm << 16)
+
+            def m_call(rt=N.RT_TOPK):
+                N.check(L.ss_bm25_search_dev(sh._h, nqm, qm_dev.data_ptr(), k, rt, OPS_M, o_doc.data_ptr(), o_score.data_ptr(),
+                                             o_cnt.data_ptr(), o_tot.data_ptr(), sptr), "ss_bm25_search_dev")
+            mres, mt = {}, {}
+            for name, strat in (("scan16m", N.BM25_AUTO), ("f32_tile", N.BM25_EXHAUSTIVE_F32)):
+                sh.set_strategy(strat)
+                m_call(N.RT_TOPKCOUNT)
+                torch.cuda.synchronize()
+                mres[name] = (o_doc[:nqm].cpu().numpy().copy(), o_score[:nqm].cpu().numpy().copy(), o_tot[:nqm].cpu().numpy().astype(np.int64))
+                sh.profile(True)
+                sh.profile_read(0, reset=True)
+                n_, d_ = timed_for(m_call, min_calls=30 if name == "f32_tile" else 100)
+                ml_, mms_ = sh.profile_read(0, reset=True)
+                sh.profile(False)
+                mt[name] = (nqm * n_ / d_, d_ / n_ * 1e3, n_, mms_ / max(ml_, 1), int(ml_))
+            sh.set_strategy(N.BM25_AUTO)
+            assert np.array_equal(mres["scan16m"][1], mres["f32_tile"][1]) and np.array_equal(mres["scan16m"][2], mres["f32_tile"][2]), "16-term unions: the two tiles differ"
+            mu = sorted({t for tl in m_lists for t in tl})
+            mdf = dict(zip(mu, (int(x) for x in sh.posting_count(mu))))
+            m_bytes = float(sum(sum(mdf[t] for t in tl) * 3 + int(u_) + 4 * n_blocks * ntm + 8 * k for tl, u_ in zip(m_lists, mres["scan16m"][2])))
+
+            def m_roof(name, kernel):
+                ms_ = mt[name][3]
+                return {"bound": "hbm", "kernel": kernel, "achieved": m_bytes / (ms_ * 1e-3) / 1e9 if ms_ > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": m_bytes / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_ > 0 else None, "algorithmic_bytes_per_launch": m_bytes,
+                        "avg_launch_ms": ms_, "launches": mt[name][4]}
+            many = {"value": mt["scan16m"][0], "unit": "queries/s", "ms_per_call": mt["scan16m"][1], "calls": mt["scan16m"][2], "terms_per_query": ntm,
+                    "queries_per_call": nqm, "mean_union": float(mres["scan16m"][2].mean()), "mean_postings_per_query": float(np.mean([sum(mdf[t] for t in tl) for tl in m_lists])),
+                    "roofline": m_roof("scan16m", "bm25_scan16m_kernel<1> (16 lists as a run-time loop; Topk -- the timed call; counts: bit records)"),
+                    "f32_tile": {"value": mt["f32_tile"][0], "ms_per_call": mt["f32_tile"][1], "calls": mt["f32_tile"][2],
+                                 "roofline": m_roof("f32_tile", "bm25_scan_group_kernel (SS_BM25_EXHAUSTIVE_F32: what served > 6 lists before round 5)")},
+                    "workload": "64 unions of 16 terms (12 from the 0.5-5 % df bands, 4 from 5-15 %), top-10, C2 corpus; scores and exact counts of the two strategies asserted identical"}
+            if not args.no_parity:
+                t0 = time.perf_counter()
+                nsm = 16
+                mans = F.c2_answers_chunked(args.docs, m_lists[:nsm], th, k, O.OP_OR, O.RT_TOPKCOUNT, part=(rank, world), chunk=4)
+                for i in range(nsm):
+                    od, os_, otot = mans[i]
+                    assert int(mres["scan16m"][2][i]) == otot, f"16-term unions: count of query {i}: {int(mres['scan16m'][2][i])} vs oracle {otot}"
+                    F.check_topk(mres["scan16m"][0][i], mres["scan16m"][1][i], od, os_, 1e-4, f"16-term unions, query {i}")
+                parity["union16"] = {"queries": nsm, "checked": "unions of 16 terms at full size: exact result_count_total, top-10 ids outside the tie band, scores rtol 1e-4; "
+                                     "oracle = so_search_lex_ref (> 10 terms: union_scan's table walk, search_or)", "seconds": time.perf_counter() - t0}
         # (3d) a CLUSTERED corpus at full size (every full-size corpus was uniform-random): the same 10 M docs / 4096
         # terms, but a term's density varies 32-fold with the doc's cluster (runs of 1024 / 8192 doc ids; oracle so_lex_cluster_thresh,
         # device lex_cluster_thresh) -- doc ids in bursts, uneven block maxima, sub-blocks a term skips entirely.  Same queries.
@@ -697,7 +756,7 @@ def main():
                   latency_ms={"batch_p50": pct(lat_batch, 50), "batch_p99": pct(lat_batch, 99), "batch_samples": len(lat_batch),
                               "single_query_p50": pct(lat_one, 50), "single_query_p99": pct(lat_one, 99),
                               "single_query_samples": len(lat_one), "clock": "HIP events on the launch stream (device resident)"},
-                  end_to_end=end_to_end, intersection=inter, exhaustive_not_tombstones=excl, clustered=clustered, scale_check=scale_check,
+                  end_to_end=end_to_end, intersection=inter, exhaustive_not_tombstones=excl, clustered=clustered, scale_check=scale_check, union16=many,
                   mean_bytes_per_query=float(bytes_q.mean()), mean_union=float(tot.mean()))
         # correctness guard inside the bench: sorted, k results
         bm_call()
@@ -1334,6 +1393,8 @@ def main():
                 line["exhaustive_not_tombstones"] = bm["exhaustive_not_tombstones"]
             if bm.get("clustered"):
                 line["clustered"] = bm["clustered"]
+            if bm.get("union16"):
+                line["union16"] = bm["union16"]
             if bm.get("scale_check"):
                 line["scale_check"] = bm["scale_check"]
             if "rationed_vocabulary" in bm:

@@ -947,7 +947,11 @@ __device__ __forceinline__ void s16m_each_chunk(const S16MLists& L, uint32_t t, 
   const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)L.v_a, t), b1 = (uint32_t)__builtin_amdgcn_readlane((int)L.v_b, t);
   if (b0 == b1) return;
   __amdgpu_buffer_rsrc_t rs = s16m_rsrc(L, t, b1);
-  for (uint32_t u = b0; u < b1; u += 256u) {  // four chunks in flight
+  if (b1 - b0 <= 64u) {  // the usual case: one chunk
+    f(__builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(b0 << 4), 0));
+    return;
+  }
+  for (uint32_t u = b0; u < b1; u += 256u) {  // a dense segment: four chunks in flight
     const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (int)(u << 4), 0);
     const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + 1024, (int)(u << 4), 0);
     const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + 2048, (int)(u << 4), 0);
@@ -1135,16 +1139,18 @@ bm25_scan16m_kernel(const uint32_t* __restrict__ post, const unsigned long long*
       const uint32_t v_c = rowp[min(s + 2u, n_sub)];  // the boundaries the NEXT item ends on: in flight under this item's lists
       uint32_t mx = 0u, nocount = 0u;
       bool any = false;
-      // list t + 1's first chunk is requested before list t is accumulated
-      uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)L.v_a, 0), b1 = (uint32_t)__builtin_amdgcn_readlane((int)L.v_b, 0);
-      u32x4 nxt = __builtin_amdgcn_raw_buffer_load_b128(s16m_rsrc(L, 0, b1), lane16, (int)(b0 << 4), 0);
+      // the first chunks of lists t + 1 .. t + 3 are in flight while list t is accumulated (a list past the query's last one: lane nt
+      // and above hold the absent term's empty segment, the load returns NULL postings without touching memory)
+      auto first_chunk = [&](uint32_t t) -> u32x4 {
+        const uint32_t x0 = (uint32_t)__builtin_amdgcn_readlane((int)L.v_a, t), x1 = (uint32_t)__builtin_amdgcn_readlane((int)L.v_b, t);
+        return __builtin_amdgcn_raw_buffer_load_b128(s16m_rsrc(L, t, x1), lane16, (int)(x0 << 4), 0);
+      };
+      u32x4 n1 = first_chunk(0), n2 = first_chunk(1), n3 = first_chunk(2);
       for (uint32_t t = 0; t < nt; t++) {
-        const u32x4 cur = nxt;
-        const uint32_t c0 = b0, c1 = b1;
-        if (t + 1u < nt) {
-          b0 = (uint32_t)__builtin_amdgcn_readlane((int)L.v_a, t + 1u); b1 = (uint32_t)__builtin_amdgcn_readlane((int)L.v_b, t + 1u);
-          nxt = __builtin_amdgcn_raw_buffer_load_b128(s16m_rsrc(L, t + 1u, b1), lane16, (int)(b0 << 4), 0);
-        }
+        const u32x4 cur = n1;
+        n1 = n2; n2 = n3;
+        n3 = first_chunk(min(t + 3u, 63u));
+        const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)L.v_a, t), c1 = (uint32_t)__builtin_amdgcn_readlane((int)L.v_b, t);
         if (c0 == c1) continue;
         any = true;
         const float fidf_t = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)L.v_fidf, t));
@@ -1166,7 +1172,11 @@ bm25_scan16m_kernel(const uint32_t* __restrict__ post, const unsigned long long*
       if (any) {
         const float thr = fmaxf(T.wsc, __uint_as_float(tau_bits));
         const uint32_t qthr = thr > 0.f ? (uint32_t)(thr * scale_thr) : 0u;
+#ifdef S16M_NOTRIG  // measurement only: the streaming loop without its candidate path (answers are wrong)
+        if (false) {
+#else
         if (__ballot(mx >= qthr + S16_MBITS)) {  // mx = the bits of 2^23 + the largest bound (s16_qm)
+#endif
           const S16Excl ex{Q, post, term_base, sub_off, del, Q->n_terms, bm_q_nnot(Q->op), row_len, del_words, s};
           T = s16m_trigger<KPL>(T, L, wb, qthr, thr, s << BM_SUB_LOG2, k, tau_q, ex);
         } else {
