@@ -616,8 +616,15 @@ inline uint64_t rd64(const uint8_t* p) { uint64_t v; std::memcpy(&v, p, 8); retu
 inline uint32_t rd32(const uint8_t* p) { uint32_t v; std::memcpy(&v, p, 4); return v; }
 }  // namespace
 
+static int index_bin_open_impl(const uint8_t* bytes, uint64_t len, uint32_t indexed_field_count, uint32_t key_head_size,
+                               uint32_t segment_number_bits, ss_index_bin** out);
 extern "C" int ss_index_bin_open(const uint8_t* bytes, uint64_t len, uint32_t indexed_field_count, uint32_t key_head_size,
                                  uint32_t segment_number_bits, ss_index_bin** out) {
+  // (the walk allocates per-key tables on worker threads: a std::bad_alloc of any of them comes back as SS_ENOMEM, ss_threads.h)
+  return ss_guard([&] { return index_bin_open_impl(bytes, len, indexed_field_count, key_head_size, segment_number_bits, out); }, SS_ENOMEM, SS_EDEVICE);
+}
+static int index_bin_open_impl(const uint8_t* bytes, uint64_t len, uint32_t indexed_field_count, uint32_t key_head_size,
+                               uint32_t segment_number_bits, ss_index_bin** out) {
   if (!bytes || !out || len < 4 || indexed_field_count == 0 || segment_number_bits > 16) return SS_EINVAL;
   if (key_head_size != 20 && key_head_size != 22 && key_head_size != 23) return SS_EINVAL;  // index.rs:2806-2812
   if (rd16(bytes) != 6u) return SS_ENOTSUP;  // INDEX_FORMAT_VERSION_MAJOR
@@ -1219,7 +1226,7 @@ extern "C" int ss_bm25_upload_index_bin_fields(ss_shard* s, const ss_index_bin* 
   if (ix->keys.empty() || ix->n_docs == 0) return SS_EINVAL;
   if (ix->n_fields < 2) return ss_bm25_upload_index_bin(s, ix);
   if (ix->n_fields > 8) return SS_ENOTSUP;
-  return upload_index_bin_fields(s, ix, boost, false);
+  return ss_guard([&] { return upload_index_bin_fields(s, ix, boost, false); }, SS_ENOMEM, SS_EDEVICE);  // (host-side decode buffers: std::bad_alloc -> SS_ENOMEM)
 }
 
 namespace {
@@ -1229,7 +1236,7 @@ extern "C" int ss_bm25_upload_index_bin(ss_shard* s, const ss_index_bin* ix) {
   if (!s || !ix) return SS_EINVAL;
   if (ix->keys.empty() || ix->n_docs == 0) return SS_EINVAL;
   if (ix->n_fields > 1) return ss_bm25_upload_index_bin_fields(s, ix, nullptr);
-  return upload_index_bin_single(s, ix, false);
+  return ss_guard([&] { return upload_index_bin_single(s, ix, false); }, SS_ENOMEM, SS_EDEVICE);  // (host-side decode buffers: std::bad_alloc -> SS_ENOMEM)
 }
 // The image plus the positions of every posting, for phrase queries (SS_ENOTSUP for a position beyond 65 535).  An n-gram key's
 // own positions go to its first component term (one indexed field; several: still SS_ENOTSUP).  Several indexed fields: boost = 1
@@ -1238,15 +1245,15 @@ extern "C" int ss_bm25_upload_index_bin_positions(ss_shard* s, const ss_index_bi
   if (!s || !ix) return SS_EINVAL;
   if (ix->keys.empty() || ix->n_docs == 0) return SS_EINVAL;
   if (ix->n_fields > 8) return SS_ENOTSUP;
-  if (ix->n_fields > 1) return upload_index_bin_fields(s, ix, nullptr, true);
-  return upload_index_bin_single(s, ix, true);
+  if (ix->n_fields > 1) return ss_guard([&] { return upload_index_bin_fields(s, ix, nullptr, true); }, SS_ENOMEM, SS_EDEVICE);
+  return ss_guard([&] { return upload_index_bin_single(s, ix, true); }, SS_ENOMEM, SS_EDEVICE);  // (host-side decode buffers: std::bad_alloc -> SS_ENOMEM)
 }
 extern "C" int ss_bm25_upload_index_bin_fields_positions(ss_shard* s, const ss_index_bin* ix, const float* boost) {
   if (!s || !ix) return SS_EINVAL;
   if (ix->keys.empty() || ix->n_docs == 0) return SS_EINVAL;
   if (ix->n_fields < 2) return ss_bm25_upload_index_bin_positions(s, ix);
   if (ix->n_fields > 8) return SS_ENOTSUP;
-  return upload_index_bin_fields(s, ix, boost, true);
+  return ss_guard([&] { return upload_index_bin_fields(s, ix, boost, true); }, SS_ENOMEM, SS_EDEVICE);  // (host-side decode buffers: std::bad_alloc -> SS_ENOMEM)
 }
 namespace {
 int upload_index_bin_single(ss_shard* s, const ss_index_bin* ix, bool with_positions) {

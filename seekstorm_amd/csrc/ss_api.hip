@@ -205,6 +205,8 @@ int ss_shard_destroy(ss_shard* s) {
       if (ln.h_pin) (void)hipHostFree(ln.h_pin);
       if (ln.ev) (void)hipEventDestroy(ln.ev);
     }
+  if (s->h_bq) (void)hipHostFree(s->h_bq);
+  if (s->bq_ev) (void)hipEventDestroy(s->bq_ev);
   if (s->d_small_ws) (void)hipFree(s->d_small_ws);
   if (s->h_small) (void)hipHostFree(s->h_small);
   (void)hipStreamDestroy(s->stream);
@@ -249,7 +251,7 @@ static int ensure_qstage(ss_shard* s, size_t bytes) {
 // ------------------------------------------------------------------ BM25
 int ss_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen, uint32_t n_terms, const uint64_t* offs,
                    const uint32_t* docs, const uint16_t* tfs) {
-  return ssi_bm25_upload(s, n_docs, doclen, n_terms, offs, docs, tfs, 0);
+  return ss_guard([&] { return ssi_bm25_upload(s, n_docs, doclen, n_terms, offs, docs, tfs, 0); }, SS_ENOMEM, SS_EDEVICE);
 }
 
 int ss_bm25_upload_positions(ss_shard* s, uint64_t n_docs, const uint8_t* doclen, uint32_t n_terms, const uint64_t* offs,
@@ -354,7 +356,7 @@ extern "C" {
 int ss_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen, const float* boost,
                           uint32_t n_terms, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
                           const uint16_t* tfs) {
-  return ssi_bm25_upload_fields(s, n_docs, n_fields, doclen, boost, n_terms, offs, docs, fields, tfs, 0);
+  return ss_guard([&] { return ssi_bm25_upload_fields(s, n_docs, n_fields, doclen, boost, n_terms, offs, docs, fields, tfs, 0); }, SS_ENOMEM, SS_EDEVICE);
 }
 
 // ... plus the positions of every (term, doc, field) entry: phrase queries over several indexed fields
@@ -366,7 +368,8 @@ int ss_bm25_upload_fields_positions(ss_shard* s, uint64_t n_docs, uint32_t n_fie
   uint64_t need = 0;  // checked before anything is built or read, as in ss_bm25_upload_positions
   for (uint64_t j = offs[0]; j < offs[n_terms]; j++) need += tfs[j];
   if (need != n_positions || (need && !positions)) return SS_EINVAL;
-  return ssi_bm25_upload_fields_positions(s, n_docs, n_fields, doclen, boost, n_terms, offs, docs, fields, tfs, 0, positions, n_positions);
+  return ss_guard([&] { return ssi_bm25_upload_fields_positions(s, n_docs, n_fields, doclen, boost, n_terms, offs, docs, fields, tfs, 0, positions, n_positions); },
+                  SS_ENOMEM, SS_EDEVICE);
 }
 
 }  // extern "C"
@@ -525,7 +528,7 @@ static int append_level_impl(ss_shard* s, uint32_t level, uint32_t n_level_docs,
                              const uint32_t* docs, const uint16_t* tfs, bool with_pos, const uint16_t* npos, const uint16_t* positions, uint64_t n_positions);
 int ss_bm25_append_level(ss_shard* s, uint32_t level, uint32_t n_level_docs, const uint8_t* level_doclen, uint32_t n_terms, const uint64_t* offs,
                          const uint32_t* docs, const uint16_t* tfs) {
-  return append_level_impl(s, level, n_level_docs, level_doclen, n_terms, offs, docs, tfs, false, nullptr, nullptr, 0);
+  return ss_guard([&] { return append_level_impl(s, level, n_level_docs, level_doclen, n_terms, offs, docs, tfs, false, nullptr, nullptr, 0); }, SS_ENOMEM, SS_EDEVICE);
 }
 // ... with the postings' POSITIONS (phrase queries on an image that grows by commits): positions = every posting's, in CSR order, tf of
 // them each -- or npos[i] where that is not the tf (npos may be NULL): the component terms of an n-gram key, whose own positions stand
@@ -534,7 +537,7 @@ int ss_bm25_append_level_positions(ss_shard* s, uint32_t level, uint32_t n_level
                                    const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs, const uint16_t* npos, const uint16_t* positions,
                                    uint64_t n_positions) {
   if (n_positions && !positions) return SS_EINVAL;
-  return append_level_impl(s, level, n_level_docs, level_doclen, n_terms, offs, docs, tfs, true, npos, positions, n_positions);
+  return ss_guard([&] { return append_level_impl(s, level, n_level_docs, level_doclen, n_terms, offs, docs, tfs, true, npos, positions, n_positions); }, SS_ENOMEM, SS_EDEVICE);
 }
 static int append_level_impl(ss_shard* s, uint32_t level, uint32_t n_level_docs, const uint8_t* level_doclen, uint32_t n_terms, const uint64_t* offs,
                              const uint32_t* docs, const uint16_t* tfs, bool with_pos, const uint16_t* npos, const uint16_t* positions, uint64_t n_positions) {
@@ -653,6 +656,7 @@ static int append_level_impl(ss_shard* s, uint32_t level, uint32_t n_level_docs,
   int rc = ssi_bm25_rebuild_from_raw(s, levels, n_terms, doclen.data(), doclen.size(), img.get(), bst);
   if (rc) return fail(rc);
   const double rebuild_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count();
+  int rc_recode = SS_OK;
   {  // the swap: searches in flight finish on the old image, whose arrays are then released
     std::lock_guard<std::mutex> g(s->mu);
     if (level > s->raw.size() || level + 1 < s->raw.size()) return fail(SS_ESTATE);  // another commit got in between (the caller's write lock forbids it)
@@ -692,15 +696,17 @@ static int append_level_impl(ss_shard* s, uint32_t level, uint32_t n_level_docs,
     s->probe_pool_begin = img->probe_pool_begin; s->probe_pool_rows = img->probe_pool_rows; s->pool_list.swap(img->pool_list); s->pool_tick.swap(img->pool_tick);
     s->pool_clock = 0;
     if (s->sp_n) {  // the average length moved: the sparse postings' codes follow (their docs of this level: ss_bm25_append_sparse_level)
-      const int rc_sp = ssi_bm25_sparse_levels_recode(s, s->stream);
-      if (rc_sp == SS_OK) (void)hipStreamSynchronize(s->stream);
+      rc_recode = ssi_bm25_sparse_levels_recode(s, s->stream);
+      if (rc_recode == SS_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc_recode = SS_EDEVICE;
     }
     s->raw_last_rebuild_ms = rebuild_ms;
     s->raw_last_append_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   }
 #undef SS_HIP_F
+  // the dense image is swapped in either way; a sparse tier that could not follow the new average length would score its terms with
+  // the old one: the caller hears about it, and commits again or rebuilds
   (void)hipStreamDestroy(bst);
-  return SS_OK;
+  return rc_recode;
 }
 
 int ss_bm25_incremental_info(ss_shard* s, uint32_t* n_levels, uint64_t* raw_bytes, double* last_append_ms, double* last_rebuild_ms) {
@@ -887,6 +893,7 @@ int ss_bm25_append_sparse_fields_positions(ss_shard* s, uint32_t n_lists, const 
 }
 int ss_bm25_sparse_info(ss_shard* s, uint32_t* n_lists, uint64_t* n_postings, uint64_t* bytes) {
   if (!s) return SS_EINVAL;
+  std::lock_guard<std::mutex> g(s->mu);
   const uint64_t np = s->h_sp_base.empty() ? 0 : s->h_sp_base.back();
   if (n_lists) *n_lists = s->sp_n;
   if (n_postings) *n_postings = np;
@@ -1573,7 +1580,23 @@ static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_quer
     SS_HIP(hipMalloc(&s->d_bq, (size_t)nq * sizeof(ss_bm25_query)));
     s->bq_cap = (size_t)nq * sizeof(ss_bm25_query);
   }
-  SS_HIP(hipMemcpyAsync(s->d_bq, q, (size_t)nq * sizeof(ss_bm25_query), hipMemcpyHostToDevice, s->stream));
+  {
+    const size_t qbytes = (size_t)nq * sizeof(ss_bm25_query);
+    if (qbytes > s->h_bq_cap) {
+      if (s->bq_ev_set) SS_HIP(hipEventSynchronize(s->bq_ev));
+      if (s->h_bq) (void)hipHostFree(s->h_bq);
+      s->h_bq = nullptr; s->h_bq_cap = 0;
+      const size_t cap = std::max<size_t>(qbytes * 2, 64u << 10);
+      SS_HIP(hipHostMalloc(&s->h_bq, cap, hipHostMallocDefault));
+      s->h_bq_cap = cap;
+    }
+    if (!s->bq_ev) SS_HIP(hipEventCreateWithFlags(&s->bq_ev, hipEventDisableTiming));
+    if (s->bq_ev_set) SS_HIP(hipEventSynchronize(s->bq_ev));  // (the copy of the batch before: long done unless the stream is backed up)
+    memcpy(s->h_bq, q, qbytes);
+    SS_HIP(hipMemcpyAsync(s->d_bq, s->h_bq, qbytes, hipMemcpyHostToDevice, s->stream));
+    SS_HIP(hipEventRecord(s->bq_ev, s->stream));
+    s->bq_ev_set = true;
+  }
   {  // the batch's weight, for the pruned kernel's partition rule: the host has the queries in hand here
     uint64_t sum = 0;
     const bool mf = s->bm_n_fields > 1;
@@ -2204,8 +2227,8 @@ int ss_bm25_search_sorted(ss_shard* s, uint32_t nq, const ss_bm25_query* queries
     if (sorts[f].facet_type > SS_FACET_POINT) return SS_EINVAL;
     if (sorts[f].facet_type == SS_FACET_STRING16 || sorts[f].facet_type == SS_FACET_STRING32) return SS_ENOTSUP;  // by their strings: the host's rank column
   }
+  std::lock_guard<std::mutex> g(s->mu);  // (before the image is looked at: a commit swaps its arrays under this lock)
   if (!s->d_post) return SS_ESTATE;
-  std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
   if (!s->d_facets || s->facet_docs < s->bm_n_docs) return SS_ESTATE;
   for (uint32_t f = 0; f < n_sorts; f++)
@@ -2340,7 +2363,7 @@ int ss_bm25_search_filtered_dev(ss_shard* s, uint32_t nq, const ss_bm25_query* d
     }
     SS_HIP(hipMemcpyAsync(d_out_count, s->d_out_count, (size_t)nq * 4, hipMemcpyDeviceToDevice, s->stream));
     SS_HIP(hipMemcpyAsync(d_out_total, s->d_out_total, (size_t)nq * 8, hipMemcpyDeviceToDevice, s->stream));
-    if (st != s->stream) SS_HIP(hipStreamSynchronize(s->stream));
+    SS_HIP(hipStreamSynchronize(s->stream));  // (this path has made a trip to the host already; nothing of this frame is left in flight)
     return SS_OK;
   }
   return with_facet_filter(s, n_filters, filters, st, [&]() {
@@ -2770,32 +2793,35 @@ int ss_vec_upload_i8(ss_shard* s, uint64_t n_rows, uint32_t dim, const int8_t* r
 // rows' range), the Euclidean side data is computed for the new range only, the per-row side arrays (doc ids, scales, norms, field
 // ids) are extended, and the cluster structure -- if the image has one -- is declared again with the level added (O(rows) words, not
 // O(image bytes)).  The image and the side arrays grow by half when their room is used up (one device-to-device copy, amortised).
-static int grow_rows(void** p, size_t elem, uint64_t old_rows, uint64_t new_cap, bool zero_tail) {
-  if (!*p) return SS_OK;
-  void* q = nullptr;
-  SS_HIP(hipMalloc(&q, (size_t)new_cap * elem));
-  if (hipMemcpy(q, *p, (size_t)old_rows * elem, hipMemcpyDeviceToDevice) != hipSuccess ||
-      (zero_tail && hipMemset((char*)q + (size_t)old_rows * elem, 0, (size_t)(new_cap - old_rows) * elem) != hipSuccess)) {
-    (void)hipFree(q);
-    return SS_EDEVICE;
-  }
-  (void)hipFree(*p);
-  *p = q;
-  return SS_OK;
-}
-
-// room for new_cap rows in the image and every per-row array it carries (caller holds s->mu, the device is idle)
-static int vec_grow(ss_shard* s, uint64_t new_cap) {
+// room for new_cap rows in the image and every per-row array it carries (caller holds s->mu, the device is idle).  ALL OR NOTHING:
+// every new array is allocated before anything is copied or swapped, so a failure (SS_ENOMEM) leaves the shard as it was.
+// grow_image = false: the image already has the room (its row padding), only the side arrays follow.
+static int vec_grow(ss_shard* s, uint64_t new_cap, bool grow_image = true) {
   const bool i8 = s->d_X8 != nullptr;
   const size_t row_bytes = i8 ? (size_t)s->dim_pad8 : (size_t)s->dim_pad * sizeof(float);
   const uint64_t old_n = s->n_rows;
+  struct G { void** p; size_t elem; uint64_t old_rows; bool zero_tail; void* q; };
   // the image: rows [0, n_rows_pad) are data + zero padding, the room behind them starts as padding (zero)
-  SS_TRY(grow_rows(i8 ? (void**)&s->d_X8 : (void**)&s->d_X, row_bytes, s->n_rows_pad, new_cap, true));
-  SS_TRY(grow_rows((void**)&s->d_row_doc, sizeof(uint32_t), old_n, new_cap, false));
-  SS_TRY(grow_rows((void**)&s->d_row_scale, sizeof(float), old_n, new_cap, false));
-  SS_TRY(grow_rows((void**)&s->d_row_norm, sizeof(float), old_n, new_cap, false));
-  SS_TRY(grow_rows((void**)&s->d_row_sq, sizeof(int32_t), old_n, new_cap, false));
-  SS_TRY(grow_rows((void**)&s->d_row_field, sizeof(uint16_t), old_n, new_cap, false));
+  G gs[] = {{i8 ? (void**)&s->d_X8 : (void**)&s->d_X, row_bytes, s->n_rows_pad, true, nullptr},
+            {(void**)&s->d_row_doc, sizeof(uint32_t), old_n, false, nullptr},   {(void**)&s->d_row_scale, sizeof(float), old_n, false, nullptr},
+            {(void**)&s->d_row_norm, sizeof(float), old_n, false, nullptr},     {(void**)&s->d_row_sq, sizeof(int32_t), old_n, false, nullptr},
+            {(void**)&s->d_row_field, sizeof(uint16_t), old_n, false, nullptr}};
+  int rc = SS_OK;
+  for (size_t i = grow_image ? 0 : 1; i < sizeof(gs) / sizeof(gs[0]) && rc == SS_OK; i++) {
+    G& g = gs[i];
+    if (!*g.p) continue;
+    const hipError_t e = hipMalloc(&g.q, (size_t)new_cap * g.elem);
+    if (e != hipSuccess) { g.q = nullptr; rc = e == hipErrorOutOfMemory ? SS_ENOMEM : SS_EDEVICE; break; }
+    if (hipMemcpy(g.q, *g.p, (size_t)g.old_rows * g.elem, hipMemcpyDeviceToDevice) != hipSuccess ||
+        (g.zero_tail && hipMemset((char*)g.q + (size_t)g.old_rows * g.elem, 0, (size_t)(new_cap - g.old_rows) * g.elem) != hipSuccess))
+      rc = SS_EDEVICE;
+  }
+  if (rc != SS_OK) {
+    for (G& g : gs) if (g.q) (void)hipFree(g.q);
+    return rc;
+  }
+  for (G& g : gs)
+    if (g.q) { (void)hipFree(*g.p); *g.p = g.q; }
   s->vec_rows_cap = new_cap;
   return SS_OK;
 }
@@ -2843,8 +2869,13 @@ int ss_vec_append_rows(ss_shard* s, const ss_vec_level* lv) {
   const uint64_t new_pad = (new_n + VS_TR - 1) / VS_TR * VS_TR;
   SS_HIP(hipDeviceSynchronize());  // searches on the callers' own streams read the arrays that are written / replaced here
   const uint64_t cap = s->vec_rows_cap ? s->vec_rows_cap : s->n_rows_pad;
-  if (new_pad > cap || !s->vec_rows_cap)  // (an opener that expects commits reserves the room once: ss_vec_reserve_rows)
-    SS_TRY(vec_grow(s, (std::max<uint64_t>(new_pad, cap + cap / 2) + VS_TR - 1) / VS_TR * VS_TR));
+  // (an opener that expects commits reserves the room once: ss_vec_reserve_rows).  Otherwise: what is needed plus a bounded headroom
+  // -- half of what there is, at most 4 M rows: old and new image are both live during the copy -- and on the FIRST append only the side
+  // arrays (allocated for exactly n_rows) when the level still fits the image's own row padding
+  if (new_pad > cap)
+    SS_TRY(vec_grow(s, (std::max<uint64_t>(new_pad, std::min<uint64_t>(cap + cap / 2, new_pad + (4u << 20))) + VS_TR - 1) / VS_TR * VS_TR));
+  else if (!s->vec_rows_cap)
+    SS_TRY(vec_grow(s, cap, /*grow_image=*/false));
   if (!i8) {
     SS_HIP(hipMemcpy2DAsync(s->d_X + (size_t)old_n * s->dim_pad, (size_t)s->dim_pad * sizeof(float), lv->rows, (size_t)s->dim * sizeof(float),
                             (size_t)s->dim * sizeof(float), n_new, hipMemcpyHostToDevice, s->stream));

@@ -369,6 +369,10 @@ struct ss_shard {
   double raw_last_append_ms = 0.0, raw_last_rebuild_ms = 0.0;
   // bm25 workspace
   void* d_bq = nullptr; size_t bq_cap = 0;       // staged queries
+  // ... and their way there: PINNED host staging the asynchronous copy reads from (the callers' own arrays -- pageable, often a local
+  // of a frame that returns before the stream is synchronised -- are never handed to hipMemcpyAsync), with the event behind the last
+  // copy out of it: the next batch waits for it before it overwrites the staging
+  void* h_bq = nullptr; size_t h_bq_cap = 0; hipEvent_t bq_ev = nullptr; bool bq_ev_set = false;
   uint64_t* d_ptotal = nullptr;                   // per (query, partition) match counts
   // one-launch path of small host-pointer batches (bm25_small.hip): device workspace (zero between launches), pinned answer
   // staging + completion flags (slot 0: direct calls, 1 / 2: the coalescer's lanes), launch counter

@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <exception>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <utility>
@@ -21,7 +23,10 @@ inline unsigned ss_loader_threads() {
   }();
   return n;
 }
-// f(begin, end, worker) over [0, n) in chunks of `grain`; f must not throw.  Runs inline when one chunk (or one thread) suffices.
+// f(begin, end, worker) over [0, n) in chunks of `grain`.  Runs inline when one chunk (or one thread) suffices.  A worker that throws
+// (std::bad_alloc on a multi-GB index.bin) stops the hand-out of chunks; every thread is joined and the first exception is rethrown on
+// the CALLER's thread (the loaders' entry points turn it into SS_ENOMEM, ss_guard below) -- never std::terminate with joinable
+// threads.  Threads that cannot be created (std::system_error) leave their share to the others.
 template <class F>
 inline void ss_parallel_for(size_t n, size_t grain, F f) {
   if (n == 0) return;
@@ -30,18 +35,42 @@ inline void ss_parallel_for(size_t n, size_t grain, F f) {
   const unsigned T = (unsigned)std::min<size_t>(ss_loader_threads(), chunks);
   if (T <= 1) { f((size_t)0, n, 0u); return; }
   std::atomic<size_t> next{0};
+  std::atomic<bool> failed{false};
+  std::exception_ptr first;
+  std::mutex first_mu;
   auto work = [&](unsigned w) {
-    for (;;) {
-      const size_t c = next.fetch_add(1, std::memory_order_relaxed);
-      if (c >= chunks) break;
-      f(c * grain, std::min(n, (c + 1) * grain), w);
+    try {
+      for (;;) {
+        const size_t c = next.fetch_add(1, std::memory_order_relaxed);
+        if (c >= chunks || failed.load(std::memory_order_relaxed)) break;
+        f(c * grain, std::min(n, (c + 1) * grain), w);
+      }
+    } catch (...) {
+      failed.store(true, std::memory_order_relaxed);
+      std::lock_guard<std::mutex> g(first_mu);
+      if (!first) first = std::current_exception();
     }
   };
   std::vector<std::thread> th;
-  th.reserve(T - 1);
-  for (unsigned w = 1; w < T; w++) th.emplace_back(work, w);
+  try {
+    th.reserve(T - 1);
+    for (unsigned w = 1; w < T; w++) th.emplace_back(work, w);
+  } catch (...) {  // fewer helpers than planned: the chunks are handed out dynamically, nothing is lost
+  }
   work(0);
   for (auto& t : th) t.join();
+  if (first) std::rethrow_exception(first);
+}
+// the C ABI never throws: a loader entry point runs its body under this
+template <class F>
+inline int ss_guard(F f, int enomem, int eother) {
+  try {
+    return f();
+  } catch (const std::bad_alloc&) {
+    return enomem;
+  } catch (...) {
+    return eother;
+  }
 }
 
 // vector storage that is not value-initialised: resize() of the 10^7-entry block table would otherwise zero (and page in) the whole
