@@ -1,7 +1,5 @@
-"""GPU tests (-m gpu) added in round 2: device-side validation of ops_mask, Count with null list outputs, the RCCL exchange
-behind the C ABI, the all_terms_frequent shortcut under a facet filter."""
+"""The device-pointer entry points and the ABI's argument checks: ops_mask validated on the device, null output lists, searches on several streams of one shard, uploads that check their arrays first."""
 import ctypes as C
-
 import numpy as np
 import pytest
 
@@ -49,6 +47,32 @@ def _dev_search(S, sh, q_np, k, rt, ops_mask, null_lists=False):
     return doc.cpu().numpy().view(np.uint32), score.cpu().numpy(), cnt.cpu().numpy().view(np.uint32), tot.cpu().numpy().view(np.uint64)
 
 
+@pytest.fixture(scope="module")
+def both(S, O):
+    """one shard holding a lexical and a vector image over the same doc ids"""
+    n_docs, voc, dim = 60_000, list(range(2600, 4096, 150)), 96
+    dl = O.lex_doclen(n_docs)
+    offs, docs, tfs = O.lex_corpus(n_docs, voc)
+    rows = O.vec_gen(O.VEC_SEED, 0, n_docs, dim)
+    sh = S.Shard(0)
+    sh.upload_lexical(n_docs, dl, offs, docs, tfs)
+    sh.upload_vectors(rows)
+    yield sh, rows, n_docs, dim
+    sh.close()
+
+
+def _dense_corpus(O, n_docs, dfs, seed=77):
+    """posting lists with the given document frequencies (fractions of n_docs), tf geometric, ascending docs"""
+    rng = np.random.default_rng(seed)
+    offs, docs, tfs = [0], [], []
+    for df in dfs:
+        d = np.sort(rng.choice(n_docs, int(df * n_docs), replace=False)).astype(np.uint32)
+        docs.append(d)
+        tfs.append(np.minimum(rng.geometric(0.6, len(d)), 60).astype(np.uint16))
+        offs.append(offs[-1] + len(d))
+    return np.asarray(offs, np.uint64), np.concatenate(docs), np.concatenate(tfs)
+
+
 def test_ops_mask_is_validated_on_the_device(S, O, lex):
     """a device-resident batch is described by ops_mask; a query that contradicts it is flagged count = UINT32_MAX and
     answered as empty instead of running a kernel variant that cannot serve it"""
@@ -90,95 +114,6 @@ def test_count_with_null_list_outputs(S, O, lex, strategy):
     for i, (terms, _, op) in enumerate(cases):
         assert cnt[i] == 0 and int(tot[i]) == osh.search_exhaustive(terms, op, 10)[2]
     sh.set_strategy(0)
-
-
-def test_all_terms_frequent_is_off_under_a_facet_filter(S, O):
-    """add_result.rs:2096-2100: the shortcut applies only when !facet_filtered -- with a facet filter every match is scored,
-    so the answer is the exact top-k of the filtered match set, not the tf >= 10 subset"""
-    rng = np.random.default_rng(78)
-    n_docs = 60_000
-    dl = O.lex_doclen(n_docs)
-    lists = []
-    for df in (40_000, 33_000):
-        d = np.sort(rng.choice(n_docs, df, replace=False)).astype(np.uint32)
-        lists.append((d, np.minimum(rng.geometric(0.25, df), 700).astype(np.uint16)))
-    offs = np.zeros(3, np.uint64)
-    offs[1:] = np.cumsum([len(l[0]) for l in lists])
-    docs, tfs = np.concatenate([l[0] for l in lists]), np.concatenate([l[1] for l in lists])
-    sh = S.Shard(0)
-    sh.upload_lexical(n_docs, dl, offs, docs, tfs)
-    osh = O.Shard(n_docs, dl, offs, docs, tfs)
-    facet = rng.integers(0, 256, n_docs).astype(np.uint8)
-    sh.upload_facets(facet.reshape(n_docs, 1))
-    keep = (facet >= 16) & (facet < 240)
-    q = sh.make_queries([[0, 1]], S.QueryType.Intersection)
-    assert sh.mark_all_terms_frequent(q, 10)["op"][0] >> 31  # the condition itself holds
-    # unfiltered: the shortcut changes the answer
-    d0, s0, c0, t0 = sh.search_lexical_batch(q, 10)
-    sc_d, sc_s, sc_t = osh.search_exhaustive([0, 1], O.OP_AND, 10, reference_shortcuts=True)
-    ex_d, ex_s, _ = osh.search_exhaustive([0, 1], O.OP_AND, 10)
-    assert np.allclose(s0[0][:c0[0]], sc_s, rtol=1e-4) and not np.array_equal(sc_d, ex_d)
-    # filtered: exact top-k over the docs that pass
-    osh.set_deleted(np.nonzero(~keep)[0])
-    fd, fs, ft = osh.search_exhaustive([0, 1], O.OP_AND, 10)
-    for strat in (0, 1):
-        sh.set_strategy(strat)
-        d1, s1, c1, t1 = sh.search_lexical_batch(q, 10, facet_filter=[(0, "u8", 16, 240)])
-        assert int(t1[0]) == ft and c1[0] == len(fd)
-        assert np.allclose(s1[0][:c1[0]], fs, rtol=1e-4) and set(d1[0][:c1[0]].tolist()) == set(fd.tolist())
-    sh.close()
-
-
-def test_comm_allgather_merge_single_rank(S, O, lex):
-    """ss_comm_create / ss_topk_allgather_merge (RCCL behind the C ABI) with a group of one: pack + all-gather + merge must
-    equal ss_topk_merge_dev of the same lists (global id = local * 1 + 0)"""
-    import torch
-    from seekstorm_amd import _native as N
-    from seekstorm_amd import distributed as D
-    sh, osh, n_docs = lex
-    dev = torch.device("cuda", 0)
-    comm = D.ShardComm(0, 1, 0)
-    r, n, d = C.c_int(-1), C.c_int(-1), C.c_int(-1)
-    N.check(N.lib().ss_comm_info(comm._h, C.byref(r), C.byref(n), C.byref(d)), "ss_comm_info")
-    assert (r.value, n.value, d.value) == (0, 1, 0)
-    q = sh.make_queries([[3, 7, 11], [5, 9], [4]], S.QueryType.Union)
-    k = 10
-    doc, score, cnt, tot = sh.search_lexical_batch(q, k)
-    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev).view(dt)
-    td, ts, tc = t(doc.view(np.int32), torch.int32), t(score, torch.float32), t(cnt.view(np.int32), torch.int32)
-    st = torch.cuda.current_stream(dev)
-    for _ in range(2):  # second call reuses the communicator's buffers
-        md, ms, mc = comm.allgather_merge(td, ts, tc, k, st.cuda_stream)
-        torch.cuda.synchronize()
-        assert np.array_equal(mc.cpu().numpy().view(np.uint32), cnt)
-        for i in range(len(q)):
-            assert np.array_equal(md[i, :cnt[i]].cpu().numpy(), doc[i, :cnt[i]].astype(np.int64))
-            assert np.array_equal(ms[i, :cnt[i]].cpu().numpy(), score[i, :cnt[i]])
-    rd, rs, rc = D.merge_gathered_device(td[None], ts[None], tc[None], st.cuda_stream, 0)
-    torch.cuda.synchronize()
-    assert torch.equal(rd, md) and torch.equal(rs, ms) and torch.equal(rc, mc)
-    comm.close()
-
-
-def test_search_sharded_single_rank_equals_plain_search(S, O, lex):
-    """ss_bm25_search_sharded with a communicator of one shard: search + all-gather + all-reduce + merge = ss_bm25_search with
-    u64 ids; Count carries the totals only"""
-    from seekstorm_amd import distributed as D
-    sh, osh, n_docs = lex
-    comm = D.ShardComm(0, 1, 0)
-    q = sh.make_queries([[3, 7, 11], [5, 9], [4], [2, 6]], S.QueryType.Union)
-    q2 = sh.make_queries([[3, 7], [5, 9], [1, 4], [2, 6]], S.QueryType.Intersection)
-    for qq in (q, q2):
-        doc, score, cnt, tot = sh.search_lexical_batch(qq, 10)
-        for _ in range(2):
-            md, ms, mc, mt = comm.search_lexical_sharded(sh, qq, 10)
-            assert np.array_equal(mc, cnt) and np.array_equal(mt, tot)
-            for i in range(len(qq)):
-                assert np.array_equal(md[i, :cnt[i]], doc[i, :cnt[i]].astype(np.uint64))
-                assert np.array_equal(ms[i, :cnt[i]], score[i, :cnt[i]])
-        _, _, _, ct = comm.search_lexical_sharded(sh, qq, 0, result_type=int(S.ResultType.Count))
-        assert np.array_equal(ct, tot)
-    comm.close()
 
 
 def test_bm25_searches_on_two_streams_of_one_shard_overlap_safely(S, O, lex):
@@ -259,3 +194,48 @@ def test_vector_searches_on_two_streams_of_one_shard_overlap_safely(S, O):
             for j in (0, 1):
                 assert torch.equal(outs[j][2], alone[j][2]) and torch.equal(outs[j][0], alone[j][0]) and torch.equal(outs[j][1], alone[j][1]), (i8, rep, j)
         sh.close()
+
+
+def test_i8_euclidean_with_scales_needs_both_norms(S, O):
+    """euclidean_i8_quantized = max(0, n1 + n2 - 2 dot s1 s2): with scales but without the record norms (ss_vec_set_row_norms) or
+    the query norm the ranking would silently be wrong -- the search refuses instead (the reference always carries both norms)"""
+    from seekstorm_amd import _native as N
+    rows = O.quantize_i8(O.vec_gen(5, 0, 2000, 64))
+    q8 = O.quantize_i8(O.vec_gen(6, 0, 2, 64))
+    sh = S.Shard(0)
+    sh.set_vector_similarity("euclidean")
+    scale = np.full(2000, 0.5, np.float32)
+    sh.upload_vectors_i8(rows, row_scale=scale)
+    L = N.lib()
+    doc = np.zeros((2, 5), np.uint32); sc = np.zeros((2, 5), np.float32); cnt = np.zeros(2, np.uint32); tot = np.zeros(2, np.uint64)
+    qscale = np.full(2, 0.25, np.float32)
+    qnorm = np.full(2, 3.0, np.float32)
+    args = lambda qn: (sh._h, 2, q8.ctypes.data_as(C.c_void_p), N.ptr(qscale, N.f32p), qn, 5, N.FLT_MIN_NEG, None, N.ptr(doc, N.u32p),
+                       N.ptr(sc, N.f32p), N.ptr(cnt, N.u32p), N.ptr(tot, N.u64p), None)
+    assert L.ss_vec_search_i8_euclid(*args(N.ptr(qnorm, N.f32p))) == -5  # SS_ESTATE: no record norms yet
+    sh.set_row_norms(np.full(2000, 2.0, np.float32))
+    assert L.ss_vec_search_i8_euclid(*args(None)) == -1                  # SS_EINVAL: no query norm
+    assert L.ss_vec_search_i8_euclid(*args(N.ptr(qnorm, N.f32p))) == 0
+    sh.close()
+
+
+def test_upload_positions_checks_the_array_length_first(S, O):
+    """ss_bm25_upload_positions with fewer positions than sum(tf), or none at all: SS_EINVAL before any posting is walked (the
+    walk indexes the array by the running sum of the tfs), and no image is left behind"""
+    from seekstorm_amd import _native as N
+    n_docs = 5000
+    dl = O.lex_doclen(n_docs)
+    offs, docs, tfs = O.lex_corpus(n_docs, [3000, 3600])
+    tfs = np.maximum(tfs, 2).astype(np.uint16)  # every posting has >= 2 positions
+    need = int(tfs.sum())
+    pos = np.concatenate([np.arange(1, t + 1, dtype=np.uint16) for t in tfs])
+    sh = S.Shard(0)
+    L = N.lib()
+    up = lambda p, n: L.ss_bm25_upload_positions(sh._h, n_docs, N.ptr(dl, N.u8p), 2, N.ptr(offs, N.u64p), N.ptr(docs, N.u32p), N.ptr(tfs, N.u16p), p, n)
+    assert up(N.ptr(pos[:need // 2].copy(), N.u16p), need // 2) == -1
+    assert up(None, 0) == -1
+    assert up(None, need) == -1
+    n, a, t, p = C.c_uint64(), C.c_float(), C.c_uint32(), C.c_uint64()
+    assert L.ss_bm25_info(sh._h, C.byref(n), C.byref(a), C.byref(t), C.byref(p)) == -5  # SS_ESTATE: nothing was built
+    assert up(N.ptr(pos, N.u16p), need) == 0
+    sh.close()
