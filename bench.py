@@ -798,7 +798,11 @@ def main():
                 got_f = sf.search_lexical_batch(qf, k, S.ResultType.TopkCount)
                 assert all(np.array_equal(x, y) for x, y in zip(ref_f, got_f)), "multi-field: strategies differ"
                 lat_f = host_latencies(lambda: sf.search_lexical_batch(qf, k, S.ResultType.TopkCount), 200)
-                legs[name] = {"value": nq / (np.mean(lat_f) * 1e-3), "unit": "queries/s", "batch_ms_p50": pct(lat_f, 50), "batch_ms_p99": pct(lat_f, 99)}
+                ab_f = sf.algorithmic_bytes(qf, got_f[3], k, fd)
+                legs[name] = {"value": nq / (np.mean(lat_f) * 1e-3), "unit": "queries/s", "batch_ms_p50": pct(lat_f, 50), "batch_ms_p99": pct(lat_f, 99),
+                              "roofline": {"bound": "hbm", "achieved": ab_f / (np.mean(lat_f) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": ab_f / (np.mean(lat_f) * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_call": ab_f,
+                                           "clock": "host clock around the whole call (H2D, kernels, D2H); df = docs holding the term in any field"}}
             bm["multi_field"] = dict(legs, docs=fd, fields=ff_n, boosts=[2.0, 1.0, 0.5], postings=int(foffs[-1]), build_s=fbuild, result_type="TopkCount",
                                      entry_point="ss_bm25_search (host pointers, host clock; Python mirror call)",
                                      note="and2 = 2-term AND, or3 = 3-term OR, top-10, 1000 queries per call, no field filter: the queries read one "
@@ -928,7 +932,12 @@ def main():
                     assert int(got_v[3][i]) == otot, f"vocabulary leg: count of query {i}: {int(got_v[3][i])} vs oracle {otot}"
                     F.check_topk(got_v[0][i, :got_v[2][i]], got_v[1][i, :got_v[2][i]], od, os_, 1e-4, f"vocabulary leg, query {i}")
                 parity["vocabulary"] = {"queries": len(pick), "checked": "3-term unions naming rare (sparse-tier) terms: exact counts, top-10 ids outside the tie band, scores rtol 1e-4"}
+            ab_v = sh.algorithmic_bytes(qv_full, got_v[3], k, args.docs)
             bm["realistic_vocabulary"] = {
+                "roofline": {"bound": "hbm", "achieved": ab_v / (np.mean(lat_full) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": ab_v / (np.mean(lat_full) * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_call": ab_v,
+                             "clock": "host clock around the whole call: queries in, the dense tier's pruned kernels, the sparse kernel, the per-query merge, answers "
+                                      "out.  The dense part prunes (it answers without most of these bytes), so the fraction is effective bytes per second"},
                 "value": nq / (np.mean(lat_full) * 1e-3), "unit": "queries/s", "entry_point": "ss_bm25_search (host pointers, host clock), 1000 queries per call",
                 "batch_ms_p50": pct(lat_full, 50), "batch_ms_p99": pct(lat_full, 99),
                 "same_queries_without_their_rare_terms": nq / (np.mean(lat_dense) * 1e-3),

@@ -605,6 +605,19 @@ class Shard:
         N.check(N.lib().ss_bm25_term_df(self._h, len(terms), N.ptr(terms, N.u32p), N.ptr(out, N.u64p)), "ss_bm25_term_df")
         return out
 
+    def algorithmic_bytes(self, queries, totals, k, n_docs=None):
+        """SURVEY 8(d)'s algorithmic bytes of a batch (measurement only): per query sum_t df_t * (2 B doc id + 1 B tf) + 1 B per scored
+        candidate (`totals`: the exact result_count_total of every query -- size of the union / intersection) + 4 B per (term, 65 536-doc
+        block) + 8 B * k.  df = the docs holding the term in any indexed field (dense or sparse tier)."""
+        n_docs = int(n_docs if n_docs is not None else self.lexical_info()["n_docs"])
+        n_blocks = (n_docs + 65535) // 65536
+        total = 0.0
+        for q, cand in zip(queries, totals):
+            nt = int(q["n_terms"])
+            df = self.posting_count([int(t) for t in q["term"][:nt]])
+            total += float(df.sum()) * 3.0 + float(cand) + 4.0 * n_blocks * nt + 8.0 * k
+        return total
+
     # ---- query construction: term resolution + idf stay on the host (search.rs:3066-3358)
     def make_queries(self, term_lists: Sequence[Sequence[int]], query_types, not_lists=None, idf_of=None, field_filter=None):
         """query_list (+ not_query_list: the "-term" operands, add_result.rs:3440-3497) of each query -> ss_bm25_query.

@@ -147,8 +147,14 @@ def run(n_docs=1_000_000, vocab=1_000_000, dim=64, n_queries=96, dense_min=2000,
         while time.perf_counter() - t0 < seconds / 2:
             sh.search_lexical_batch(q, k, S.ResultType.TopkCount)
             reps += 1
-        lat[name] = {"value": reps * len(q) / (time.perf_counter() - t0), "unit": "queries/s", "queries_per_call": len(q),
-                     "entry_point": "ss_bm25_search (host pointers, host clock), TopkCount"}
+        dt_ = time.perf_counter() - t0
+        ab_ = sh.algorithmic_bytes(q, res[name][3], k, n_docs)  # SURVEY 8d bytes of one call, from the exact counts
+        lat[name] = {"value": reps * len(q) / dt_, "unit": "queries/s", "queries_per_call": len(q),
+                     "entry_point": "ss_bm25_search (host pointers, host clock), TopkCount",
+                     "roofline": {"bound": "hbm", "achieved": ab_ * reps / dt_ / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": ab_ * reps / dt_ / 1e9 / 8000.0,
+                                  "algorithmic_bytes_per_call": ab_, "ms_per_call": dt_ / reps * 1e3,
+                                  "clock": "host clock around the whole call (copies in / out, every kernel of the tiered search): at "
+                                           f"{len(q)} queries of a {n_docs}-doc shard a call is launch latency, not bandwidth -- the fraction says how far"}}
     res["vec"] = sh.search_vector_batch(qv, k)
     # hybrid: the OR query + the vector, RRF over the two top-k lists (search.rs:1962-2035)
     hyb = [S.merge_results(S.SearchMode.Hybrid, (res["or3"][0][i][:res["or3"][2][i]].astype(np.uint64), res["or3"][1][i][:res["or3"][2][i]]),
