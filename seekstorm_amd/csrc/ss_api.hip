@@ -1920,7 +1920,10 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
         std::lock_guard<std::mutex> g(co.mu);
         // (several lanes: the callers around are shared between the batches in flight)
         want = co.max_wait_us ? co.max_batch : std::min(co.callers_est / std::max(co.leaders, 1u), co.max_batch);
-        wait_us = co.max_wait_us ? co.max_wait_us : (linger_on && co.callers_est > 1 ? std::min<uint32_t>(1000u, co.last_batch_us / 8u) : 0u);
+        // (SS_COALESCE_LINGER_DIV: the divisor -- measured at 8 / 4 / 2 / 1 on the C2 image, T = 64: 247 / 245 / 233 / 254 K q/s at batches of
+        // 39 / 48 / 62 / 64: a longer wait buys bigger batches and pays for them in waiting; profiles/r5_linger.log)
+        static const uint32_t linger_div = [] { const char* e = getenv("SS_COALESCE_LINGER_DIV"); return e ? (uint32_t)std::max(1, atoi(e)) : 8u; }();
+        wait_us = co.max_wait_us ? co.max_wait_us : (linger_on && co.callers_est > 1 ? std::min<uint32_t>(1000u, co.last_batch_us / linger_div) : 0u);
       }
       if (wait_us) {
         const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(wait_us);
