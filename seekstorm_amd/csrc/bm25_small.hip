@@ -335,7 +335,8 @@ int ssi_bm25_small_launch(ss_shard* s, void* ws, uint32_t nq, const ss_bm25_quer
   // partitions: about 4096 waves in all (the staged path's rule), 16 .. 256 per query; intersections at least 48 (the shortest list
   // drives, shorter assignments balance better); never more than the sub-blocks can feed
   static const int pb_env = [] { const char* e = getenv("SS_BM25_SMALL_PB"); return e ? atoi(e) : 0; }();
-  uint32_t PB = std::max<uint32_t>(has_and ? 6u : 2u, std::min<uint32_t>(32u, 512u / nq));
+  // (measured on C2, tools/probes/small_fused.py: one query 54.9 us at 32 workgroups, 50.6 at 64; 8 queries 71.5 / 68.4; 32 queries best at 16)
+  uint32_t PB = std::max<uint32_t>(has_and ? 6u : 2u, std::min<uint32_t>(SM_MAX_PB, 512u / nq));
   if (pb_env > 0) PB = (uint32_t)pb_env;
   PB = std::max<uint32_t>(1u, std::min<uint32_t>(std::min<uint32_t>(PB, SM_MAX_PB), (s->bm_n_sub + PB_WAVES - 1) / PB_WAVES));
   a.PB = PB;
