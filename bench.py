@@ -37,8 +37,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: FP32 matrix peak
 
 
-KERNEL_SOURCES = ("bm25.hip", "bm25_dev.h", "bm25_fast.hip", "bm25_probe.hip", "bm25_scan16.hip", "ss_common.h", "vec8_scan.hip",
-                  "vec_scan.hip")
+KERNEL_SOURCES = ("bm25.hip", "bm25_dev.h", "bm25_fast.hip", "bm25_probe.hip", "bm25_probe_body.h", "bm25_scan16.hip", "bm25_small.hip", "ss_common.h",
+                  "vec8_scan.hip", "vec_scan.hip")
 
 
 def kernel_source_hash():

@@ -19,8 +19,8 @@ import sys
 from collections import defaultdict
 
 
-KERNEL_SOURCES = ("bm25.hip", "bm25_dev.h", "bm25_fast.hip", "bm25_probe.hip", "bm25_scan16.hip", "ss_common.h", "vec8_scan.hip",
-                  "vec_scan.hip")
+KERNEL_SOURCES = ("bm25.hip", "bm25_dev.h", "bm25_fast.hip", "bm25_probe.hip", "bm25_probe_body.h", "bm25_scan16.hip", "bm25_small.hip", "ss_common.h",
+                  "vec8_scan.hip", "vec_scan.hip")
 
 
 def kernel_source_hash():
