@@ -194,6 +194,10 @@ def emit(line, world):
             pass
     print("BENCH_DETAILS " + json.dumps(line), file=sys.stderr, flush=True)
     sys.stdout.flush()
+    try:  # RCCL prints its version banner through C stdio, which would otherwise be flushed at exit -- BEHIND the line the driver parses
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
     print(json.dumps(compact_line(line)), flush=True)
 
 
@@ -1430,12 +1434,16 @@ def main():
                 line["concurrent_callers"] = vec["concurrent_callers"]
         elif vec is not None:
             line["i8"] = vec.get("i8")
-        emit(line, world)
+        final_line = line
+    else:
+        final_line = None
     if comm is not None:
         comm.close()
     sh.close()
     if world > 1:
         dist.destroy_process_group()
+    if final_line is not None:  # LAST: whatever the libraries print while they shut down stands before the line the driver parses
+        emit(final_line, world)
 
 
 if __name__ == "__main__":
