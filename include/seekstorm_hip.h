@@ -95,8 +95,8 @@ int ss_shard_set_coalescing(ss_shard* s, uint32_t max_lexical_batch, uint32_t ma
 int ss_shard_coalescing_stats(ss_shard* s, uint64_t* lexical_batches, uint64_t* lexical_queries, uint64_t* vector_batches,
                               uint64_t* vector_queries);
 /* Small host-pointer lexical batches -- the reference's call shape is ONE query per call (search.rs:1637-1743: one task per shard and
- * query) -- take a one-launch path (csrc/bm25_small.hip: <= 64 queries of <= 4 scored and <= 4 NOT terms each, k <= 128, one indexed
- * field, every list with a probe row, no facet filter): same answers bit for bit, a third of the latency.  ss_bm25_path_stats: how
+ * query) -- take a one-launch path (csrc/bm25_small.hip: <= 64 queries of <= 4 scored and <= 4 NOT terms each, k <= 128, one list per
+ * term -- one indexed field, or several with merged lists and no field filter --, every list with a probe row, no facet filter): same answers bit for bit, a third of the latency.  ss_bm25_path_stats: how
  * many ss_bm25_search[_filtered] batches (coalesced ones included) took it so far. */
 int ss_bm25_path_stats(ss_shard* s, uint64_t* one_launch_batches);
 int ss_shard_destroy(ss_shard* s);

@@ -277,7 +277,8 @@ size_t ssi_bm25_small_ws_bytes() {
 // can this batch take the one-launch path?  (the caller has run check_queries: no phrase, no all_terms_frequent, every list with a probe row)
 bool ssi_bm25_small_serves(const ss_shard* s, uint32_t nq, uint32_t k, uint32_t np_max, uint32_t nn_max) {
   static const int on = [] { const char* e = getenv("SS_BM25_SMALL"); return e ? atoi(e) : 1; }();
-  return on && nq >= 1 && nq <= SM_MAX_Q && s->bm_n_fields == 1 && s->d_probe && s->d_probe_z && s->d_probe_row && s->d_umax && k >= 1 && k <= 128 &&
+  // (several indexed fields: images with MERGED lists -- a query without a field filter reads one list per term, ss_common.h bm_merged)
+  return on && nq >= 1 && nq <= SM_MAX_Q && (s->bm_n_fields == 1 || (s->bm_merged && s->h_boost.size() == s->bm_n_fields)) && s->d_probe && s->d_probe_z && s->d_probe_row && s->d_umax && k >= 1 && k <= 128 &&
          np_max >= 1 && np_max <= 4 && nn_max <= 4 && !s->del_per_query && s->bm_strategy != SS_BM25_EXHAUSTIVE && s->bm_strategy != SS_BM25_EXHAUSTIVE_F32;
 }
 
@@ -297,12 +298,16 @@ int ssi_bm25_small_launch(ss_shard* s, void* ws, uint32_t nq, const ss_bm25_quer
     o.n_terms = np;
     // a query of ONE term is always a union (bm_expand_kernel); nothing else of `op` reaches the kernel
     o.op = (np > 1 ? bm_q_op(Q.op) : (uint32_t)SS_OP_UNION) | (n_not << 8);
-    for (uint32_t t = 0; t < 8; t++) o.term[t] = t < np + n_not ? Q.term[t] : s->bm_n_terms;  // (absent: the all-zero row)
-    for (uint32_t t = 0; t < 4; t++) o.idf[t] = t < np ? Q.idf[t] : 0.f;
+    // the list a term reads: its only one, or -- several indexed fields -- its MERGED list (the last of the term's L lists), whose
+    // weights carry sum_f boost_f w_f / S and whose "boost" S gives the scale back through idf (bm_expand_kernel does the same)
+    const uint32_t L = s->bm_n_fields;
+    const float scale = L > 1 ? s->h_boost[L - 1] : 1.0f;
+    for (uint32_t t = 0; t < 8; t++) o.term[t] = t < np + n_not ? Q.term[t] * L + (L - 1u) : s->bm_n_terms;  // (absent: the all-zero row)
+    for (uint32_t t = 0; t < 4; t++) o.idf[t] = t < np ? (L > 1 ? scale * Q.idf[t] : Q.idf[t]) : 0.f;
     // threshold seed: a union with nothing that takes a doc away again (no NOT terms, no tombstones / filter bitmap)
     o.thr0 = 0.f;
     if (ksel < 3u && n_not == 0 && !s->n_deleted && !s->h_kthw.empty() && (np == 1 || bm_q_op(Q.op) == SS_OP_UNION))
-      for (uint32_t t = 0; t < np; t++) o.thr0 = std::max(o.thr0, Q.idf[t] * s->h_kthw[(size_t)Q.term[t] * 4u + ksel]);
+      for (uint32_t t = 0; t < np; t++) o.thr0 = std::max(o.thr0, o.idf[t] * s->h_kthw[(size_t)o.term[t] * 4u + ksel]);
   }
   for (uint32_t i = nq; i < SM_MAX_Q; i++) memset(&a.q[i], 0, sizeof(pb_squery));
   const int KPL = k <= 64 ? 1 : 2;

@@ -1629,7 +1629,7 @@ static int bm25_small_try(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint
   if (s->sp_n)  // a term of the sparse tier: the tiered path
     for (uint32_t i = 0; i < nq; i++)
       for (uint32_t t = 0; t < std::min<uint32_t>(q[i].n_terms + bm_q_nnot(q[i].op), SS_MAX_QUERY_TERMS); t++)
-        if (q[i].term[t] >= s->bm_n_terms && q[i].term[t] < s->bm_n_terms + s->sp_n) return SS_OK;
+        if (q[i].term[t] >= s->bm_n_terms / s->bm_n_fields && q[i].term[t] < s->bm_n_terms / s->bm_n_fields + s->sp_n) return SS_OK;
   for (uint32_t i = 0; i < nq; i++)
     if (bm_q_op(q[i].op) == SS_OP_PHRASE) return SS_OK;  // phrase queries have a kernel of their own (and a mixed batch is split first)
   SS_TRY(ssi_bm25_ensure_probe_rows(s, nq, q, s->stream));

@@ -187,3 +187,53 @@ def test_threshold_seeds_never_cost_a_result(S, O):
                 assert c == len(od) and np.allclose(seeded[1][i][:c], os_, rtol=1e-4) and int(seeded[3][i]) == otot
     finally:
         sh.close()
+
+
+def test_one_launch_on_an_image_with_several_indexed_fields(S, O):
+    """several indexed fields (BM25F): a query without a field filter reads the merged per-term lists, i.e. one list per term --
+    the one-launch path serves it; a query WITH a field filter does not take it.  Answers == the staged pipeline's, and the oracle's"""
+    rng = np.random.default_rng(9)
+    n_docs, n_fields = 90_000, 3
+    lens = np.clip(np.round(np.exp(np.log([12, 200, 8])[:, None] + 0.5 * rng.standard_normal((n_fields, n_docs)))), 1, 60000).astype(np.int64)
+    lut = {int(x): int(O.lib().so_int_to_byte4(int(x))) for x in np.unique(lens)}
+    dl = np.vectorize(lut.get)(lens).astype(np.uint8)
+    boost = [2.0, 1.0, 0.5]
+    offs, D, F, T = [0], [], [], []
+    for df in (0.01, 0.03, 0.06, 0.12, 0.004):
+        d = np.sort(rng.choice(n_docs, int(df * n_docs), replace=False)).astype(np.uint32)
+        m = rng.random((len(d), n_fields)) < np.array([0.3, 0.9, 0.2])
+        m[~m.any(1), 1] = True
+        di, fi = np.nonzero(m)
+        D.append(d[di]); F.append(fi.astype(np.uint8)); T.append(np.minimum(rng.geometric(0.5, len(di)), 300).astype(np.uint16))
+        offs.append(offs[-1] + len(di))
+    offs = np.asarray(offs, np.uint64); D = np.concatenate(D); F = np.concatenate(F); T = np.concatenate(T)
+    sh = S.Shard(0)
+    try:
+        sh.upload_lexical_fields(n_docs, dl, boost, offs, D, F, T)
+        if not sh.fields_info()[1]:
+            pytest.skip("the image was built without merged lists")
+        for qt, oop, is_and in ((S.QueryType.Union, O.OP_OR, False), (S.QueryType.Intersection, O.OP_AND, True)):
+            lists = [[0, 1], [1, 2, 3], [4], [0, 2, 3, 4], [2, 3]]
+            nots = [[], [4], [], [], [0]]
+            q = sh.make_queries(lists, qt, nots)
+            for rt in (S.ResultType.Topk, S.ResultType.TopkCount):
+                before = sh.one_launch_batches()
+                got = sh.search_lexical_batch(q, 10, rt, reference_shortcuts=False)
+                assert sh.one_launch_batches() == before + 1, "a multi-field batch without a field filter did not take the one-launch path"
+                ops = (1 if is_and else 0) | 2 | (5 << 8) | (4 << 16) | (1 << 24)
+                ref = _dev_search(S, sh, q, 10, rt, ops)
+                assert np.array_equal(got[2], ref[2])
+                for i in range(len(lists)):
+                    c = int(got[2][i])
+                    assert np.array_equal(got[1][i][:c], ref[1][i][:c]) and np.array_equal(got[0][i][:c], ref[0][i][:c]), (qt, rt, i)
+                    od, os_, otot, _ = O.search_fields_exhaustive(n_docs, dl, boost, offs, D, F, T, lists[i], oop if len(lists[i]) > 1 else O.OP_OR, 10, nots[i])
+                    assert c == len(od) and np.allclose(got[1][i][:c], os_, rtol=1e-4), (qt, rt, i)
+                    if rt == S.ResultType.TopkCount:
+                        assert int(got[3][i]) == otot and np.array_equal(got[3], ref[3])
+        # under a field filter the query reads (term, field) lists: the staged pipeline
+        qf = sh.make_queries([[0, 1]], S.QueryType.Intersection, field_filter=[1])
+        before = sh.one_launch_batches()
+        sh.search_lexical_batch(qf, 10, S.ResultType.TopkCount, reference_shortcuts=False)
+        assert sh.one_launch_batches() == before
+    finally:
+        sh.close()
