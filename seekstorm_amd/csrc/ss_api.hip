@@ -92,7 +92,17 @@ int ss_shard_create(int device, ss_shard** out) {
   // stage / distribute in parallel) was built and measured in round 4: the callers split over two batches of half the size, and the
   // device's fixed cost per batch -- not the host part of a cycle -- is what bounds small batches: T = 8 54 K -> 25 K q/s, T = 64
   // 186 K -> 156 K, T = 256 318 K -> 327 K (profiles/r4k_lanes.log).  Kept as a switch, off.
-  { const char* e = getenv("SS_COALESCE_LANES"); s->co_lex.n_lanes = (e && atoi(e) == 2) ? 2u : 1u; }
+  // Round 5, re-measured with the one-launch kernel (a batch of 32 costs 112 us against 164 us for 64): a second lane that opens only
+  // while ~32 or more callers are around (SS_COALESCE_LANES=auto) gives lexical callers T = 64 244 -> 261 K q/s (p99 356 -> 284 us) and
+  // T = 256 338 -> 341 K (p99 1.18 -> 0.78 ms) without the T = 8 collapse of two unconditional lanes (96 -> 26 K) -- but it spreads HYBRID
+  // callers' lexical halves over more, smaller batches, and a caller that misses its vector pass waits for the next (p99 15 -> 18 ms at
+  // T = 64).  One lane stays the default; =2 forces two, =auto is the adaptive form (profiles/r5_lanes.log).
+  {
+    const char* e = getenv("SS_COALESCE_LANES");
+    const bool two = e && atoi(e) == 2, adaptive = e && strcmp(e, "auto") == 0;
+    s->co_lex.n_lanes = (two || adaptive) ? 2u : 1u;
+    s->co_lex.lanes_forced = two;
+  }
   if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return SS_EDEVICE; }
   *out = s;
   return SS_OK;
@@ -1892,7 +1902,7 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
     std::lock_guard<std::mutex> g(co.mu);
     // a free lane: this thread leads a batch on it at once (nobody in flight: alone, straight away -- a lone caller pays nothing);
     // invariant: a non-empty queue always has a leader at work, or a successor already told to lead
-    lead = co.leaders < co.n_lanes;
+    lead = co.leaders < ((co.n_lanes == 2u && (co.lanes_forced || co.callers_est >= 32u)) ? 2u : 1u);
     if (lead) {
       co.leaders++;
       me->lane = co.lane[0].busy ? 1u : 0u;

@@ -151,6 +151,7 @@ struct ss_coalescer {
   // the next leader stages, checks and enqueues its batch while this one runs, and distributes results while the next one runs.
   uint32_t leaders = 0;             // leaders at work (<= n_lanes); invariant: a non-empty queue has a leader or a successor told to lead
   uint32_t n_lanes = 1;
+  bool lanes_forced = false;        // SS_COALESCE_LANES=2: the second lane whatever the number of callers (else: from ~32 callers on)
   struct Lane { char* h_pin = nullptr; size_t h_pin_cap = 0; hipEvent_t ev = nullptr; bool busy = false; } lane[2];
   uint32_t max_batch = 0, max_wait_us = 0;
   uint64_t batches = 0, queries = 0;
