@@ -155,9 +155,14 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
                                  const unsigned long long* __restrict__ term_base, const float* __restrict__ boost,
                                  unsigned long long* __restrict__ total, uint32_t* __restrict__ tau, uint32_t claim,
                                  uint32_t n_vterms, const uint32_t* __restrict__ probe_row, uint32_t merged, uint32_t keep_tau = 0u,
-                                 const float* __restrict__ kthw = nullptr, uint32_t kth_sel = 3u) {
+                                 const float* __restrict__ kthw = nullptr, uint32_t kth_sel = 3u,
+                                 unsigned long long* __restrict__ best_slots = nullptr, uint32_t best_P = 0u, uint32_t best_KS = 0u) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq) return;
+  // rank 0 of every partition's list doubles as the partition's BEST-SO-FAR key while the many-list scan runs (bm25_scan16m_kernel
+  // derives the query's threshold from the k-th largest of them): they start from "none"
+  if (best_slots)
+    for (uint32_t p_ = 0; p_ < best_P; p_++) best_slots[((size_t)i * best_P + p_) * best_KS] = 0ull;
   total[i] = 0ull;                      // per-query match count and shared threshold start from zero (no separate memset launch)
   if (!keep_tau) tau[(size_t)i * BM_TAU_STRIDE] = 0u;  // (keep_tau: an experiment -- the same batch again with the thresholds it ended on)
                                                        // (a union without exclusions raises it to its seed at the end of the expansion)
@@ -432,6 +437,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   // imbalance is gone and fewer, longer assignments win again: 1.08 ms at 8 partitions per query, 1.10 at 10 / 12, 1.11 at 16, 1.15 at
   // 24 (tools/probes/psweep.sh).  Workgroups made of the partitions of ONE query instead of 8 queries of one partition were tried as
   // well (profiles/r3_map_sweep.log): no better, for the pruned kernel neither.)
+  const bool scan16m = scan16 && (np_max > 6 || (np_max > 4 && KPL == 2));  // the many-list instance (its waves share their best keys)
   const uint32_t resident = (pruned || phrase) ? 6144u : scan16 ? 4096u : 2048u, rounds = (pruned || phrase) ? 4u : 2u;
   uint32_t P = (rounds * resident) / nq;
   // small batches: beyond ~150 waves the probe kernel gains nothing and every extra partition is one more list to merge
@@ -492,7 +498,8 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
                                                     (const unsigned long long*)s->d_term_base, s->d_boost, total, tau, claim,
                                                     s->bm_n_terms, s->d_probe_row, s->bm_merged ? 1u : 0u,
                                                     getenv("SS_BM25_KEEP_TAU") && atoi(getenv("SS_BM25_KEEP_TAU")) ? 1u : 0u,
-                                                    (s->n_deleted || s->del_per_query || k == 0) ? nullptr : s->d_kthw, bm_kth_sel(k));
+                                                    (s->n_deleted || s->del_per_query || k == 0) ? nullptr : s->d_kthw, bm_kth_sel(k),
+                                                    scan16m ? bufA : nullptr, P, KS);
 
   BmParams p;
   p.post = s->d_post;

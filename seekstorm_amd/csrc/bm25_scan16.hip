@@ -1179,6 +1179,24 @@ bm25_scan16m_kernel(const uint32_t* __restrict__ post, const unsigned long long*
 #endif
           const S16Excl ex{Q, post, term_base, sub_off, del, Q->n_terms, bm_q_nnot(Q->op), row_len, del_words, s};
           T = s16m_trigger<KPL>(T, L, wb, qthr, thr, s << BM_SUB_LOG2, k, tau_q, ex);
+          // A partition's own k-th best says little about the QUERY's: with 128 partitions the query's ten best docs sit in ten of them,
+          // and the largest "tenth best of one partition" (what tau carried) stayed at 21 where the answer's tenth score was above 30 --
+          // 40 % of the items of a 16-term union took the candidate path.  The partitions' BEST keys are k distinct docs as soon as k
+          // partitions have one: the k-th largest of them bounds the query's k-th best score from below, and it is close.  Every
+          // partition keeps its best key in rank 0 of its output list (zeroed by bm_expand_kernel); whoever has just been through the
+          // candidate path reads them all and raises tau.
+          if (KPL == 1 && k <= 64u) {
+            u64* slots = part_keys + (size_t)qi * P * 64u;
+            if (lane == 0) __hip_atomic_store(slots + (size_t)part * 64u, T.keys[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            u64 m = 0ull;
+            for (uint32_t p_ = (uint32_t)lane; p_ < P; p_ += 64u) {
+              const u64 x = __hip_atomic_load(slots + (size_t)p_ * 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              m = x > m ? x : m;
+            }
+            m = wave_sort_desc(m, lane);
+            const u64 kth = rdlane64(m, (int)k - 1);
+            if (kth && lane == 0) bm_publish_tau(tau_q, __uint_as_float((uint32_t)(kth >> 32)));
+          }
         } else {
           s16_clear(wb, lane);
         }

@@ -20,7 +20,7 @@ for name, strat in (("auto", N.BM25_AUTO), ("f32", N.BM25_EXHAUSTIVE_F32)):
     for _ in range(5):
         r = sh.search_lexical_batch(q, 10, S.ResultType.Topk, reference_shortcuts=False)
     t0 = time.perf_counter()
-    n = 50
+    n = int(os.environ.get("N", 50))
     for _ in range(n):
         r = sh.search_lexical_batch(q, 10, S.ResultType.Topk, reference_shortcuts=False)
     print("%-5s %.3f ms per call of 65 queries x %d terms   top score %.4f" % (name, (time.perf_counter() - t0) / n * 1e3, nt, r[1][0][0]), flush=True)
