@@ -437,6 +437,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   // imbalance is gone and fewer, longer assignments win again: 1.08 ms at 8 partitions per query, 1.10 at 10 / 12, 1.11 at 16, 1.15 at
   // 24 (tools/probes/psweep.sh).  Workgroups made of the partitions of ONE query instead of 8 queries of one partition were tried as
   // well (profiles/r3_map_sweep.log): no better, for the pruned kernel neither.)
+  static const bool staged_kthb = [] { const char* e = getenv("SS_BM25_STAGED_KTHB"); return e ? atoi(e) != 0 : true; }();  // (only read by builds with -DPB_STAGED_KTHB=1)
   const bool scan16m = scan16 && (np_max > 6 || (np_max > 4 && KPL == 2));  // the many-list instance (its waves share their best keys)
   const uint32_t resident = (pruned || phrase) ? 6144u : scan16 ? 4096u : 2048u, rounds = (pruned || phrase) ? 4u : 2u;
   uint32_t P = (rounds * resident) / nq;
@@ -499,7 +500,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
                                                     s->bm_n_terms, s->d_probe_row, s->bm_merged ? 1u : 0u,
                                                     getenv("SS_BM25_KEEP_TAU") && atoi(getenv("SS_BM25_KEEP_TAU")) ? 1u : 0u,
                                                     (s->n_deleted || s->del_per_query || k == 0) ? nullptr : s->d_kthw, bm_kth_sel(k),
-                                                    scan16m ? bufA : nullptr, P, KS);
+                                                    (scan16m || (pruned && staged_kthb)) ? bufA : nullptr, P, KS);
 
   BmParams p;
   p.post = s->d_post;

@@ -78,8 +78,13 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 6) bm25_probe_kernel(
   const uint32_t a = blockIdx.x * PB_WAVES + w;
   if (a >= nq * P) return;
   const uint32_t qi = a % nq, part = a / nq;
-  const BmTop<KPL> T = pb_wave<NT, KPL, FILT, SKIP, false, 4>(post, term_base, sub_off, probe, probe_z, probe_row, umax, pmax, qbound, PbQueryMem{qs + qi}, tau, del,
-                                                    del_words, n_sub, n_terms, P, k, count, qi, part, w, lane);
+#ifndef PB_STAGED_KTHB
+#define PB_STAGED_KTHB 0
+#endif
+  // (PB_STAGED_KTHB: rank 0 of every partition's output list as its best-so-far key, zeroed by bm_expand_kernel -- measurement switch)
+  const BmTop<KPL> T = pb_wave<NT, KPL, FILT, SKIP, false, 4, PB_STAGED_KTHB != 0>(post, term_base, sub_off, probe, probe_z, probe_row, umax, pmax, qbound, PbQueryMem{qs + qi}, tau, del,
+                                                    del_words, n_sub, n_terms, P, k, count, qi, part, w, lane, 0.f,
+                                                    (PB_STAGED_KTHB != 0 && k <= 64u && P >= k && k != 0u) ? part_keys + (size_t)qi * P * (64 * KPL) : nullptr, 64u * KPL);
 
   u64* out = part_keys + ((size_t)qi * P + part) * (64 * KPL);
 #pragma unroll

@@ -36,19 +36,41 @@ struct PbQueryRegs {
   __device__ __forceinline__ uint32_t not_term(uint32_t, uint32_t j) const { return j == 0u ? not_[0] : j == 1u ? not_[1] : j == 2u ? not_[2] : not_[3]; }
 };
 
+// The query's threshold from the partitions' BEST keys (bm25_scan16.hip has the measurement that led here): `bests` holds one key per
+// partition of the query (0 = none yet); a partition that has just raised its own stores it, reads all of them and publishes the k-th
+// largest -- k distinct docs reach it, so the query's k-th best score does -- into the shared threshold.  Out of line: rare, and its
+// sort would cost the probe loop registers.
+__device__ __attribute__((noinline)) void pb_publish_kth_best(unsigned long long* bests, uint32_t stride, uint32_t P, uint32_t part, uint32_t k, u64 best, uint32_t* tau_q) {
+  const int lane = __lane_id();
+  if (lane == 0) __hip_atomic_store(bests + (size_t)part * stride, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // (at most 256 of the partitions are read -- every (P / 256)-th: the k-th largest over a SUBSET of the docs is a lower bound all the same,
+  // and a single query runs as 512 partitions whose every wave would otherwise read 512 slots each time its best key moves)
+  const uint32_t step = (P + 255u) / 256u;
+  u64 m = 0ull;
+  for (uint32_t p_ = (uint32_t)lane * step; p_ < P; p_ += 64u * step) {
+    const u64 x = p_ == part ? best : __hip_atomic_load(bests + (size_t)p_ * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    m = x > m ? x : m;
+  }
+  m = wave_sort_desc(m, lane);
+  const u64 kth = rdlane64(m, (int)k - 1);
+  if (kth && lane == 0) bm_publish_tau(tau_q, __uint_as_float((uint32_t)(kth >> 32)));
+}
+
 // FILT: tombstones and / or NOT terms are present (a separate instantiation: the unfiltered kernel pays nothing for them)
 // SKIP: the driver streams jump over sub-blocks whose block-max bound (qbound) lies below the threshold.  A separate
 // instantiation: the few registers the skip needs pushed the common kernel into scratch (C2: 0.55 -> 0.80 ms per 1000 queries).
 // SEEDED: the caller knows a score k docs of the query reach for sure (thr0, bm_kth_kernel): the threshold never lies below it
 // G: chunks of 64 driver postings per group -- their gathers are in flight together (4 in the staged kernel, whose registers are capped
 // for occupancy; 8 in the one-launch kernel of small batches, which is bound by the number of dependent round trips per wave)
-template <int NT, int KPL, bool FILT, bool SKIP, bool SEEDED, int G, typename QV>
+// KTHB: the partitions publish their best keys and derive the query's threshold from them (pb_publish_kth_best; `bests` + `bests_stride`)
+template <int NT, int KPL, bool FILT, bool SKIP, bool SEEDED, int G, bool KTHB, typename QV>
 __device__ __forceinline__ BmTop<KPL> pb_wave(
     const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base, const uint32_t* __restrict__ sub_off,
     const uint2* __restrict__ probe, const uint32_t* __restrict__ probe_z,
     const uint32_t* __restrict__ probe_row, const float* __restrict__ umax, const float* __restrict__ pmax, const float* __restrict__ qbound,
     const QV Q, uint32_t* tau, const uint32_t* __restrict__ del, uint32_t del_words, uint32_t n_sub, uint32_t n_terms,
-    uint32_t P, uint32_t k, uint32_t count, const uint32_t qi, const uint32_t part, const int w, const int lane, const float thr0 = 0.f) {
+    uint32_t P, uint32_t k, uint32_t count, const uint32_t qi, const uint32_t part, const int w, const int lane, const float thr0 = 0.f,
+    unsigned long long* bests = nullptr /* KTHB: best key of partition p of the query at bests[p * bests_stride] */, const uint32_t bests_stride = 1u) {
   // del_words bit 31: ONE exclusion bitmap PER QUERY, del_words words each, back to back (ss_bm25_search_sorted: every query of the
   // batch is searched inside its own doc set)
   if (FILT && (del_words >> 31)) { del_words &= 0x7FFFFFFFu; del += (size_t)qi * del_words; }
@@ -112,6 +134,7 @@ __device__ __forceinline__ BmTop<KPL> pb_wave(
   T.wsc = -1.0f;
   T.matched = 0;
   uint32_t* tau_q = tau + (size_t)qi * BM_TAU_STRIDE;
+  u64 last_best = 0ull;  // (KTHB: the best key this partition has published)
   const int lane4 = lane * 4;
 
   // score in QUERY order with the exhaustive kernels' fma chain (bit-identical results)
@@ -130,7 +153,14 @@ __device__ __forceinline__ BmTop<KPL> pb_wave(
     if (__ballot(cand)) {
       const u64 key = cand ? (((u64)__float_as_uint(score) << 32) | (u64)(0xFFFFFFFFu - doc)) : 0ull;
       const u64 key2 = key > T.worst ? key : 0ull;
-      if (__ballot(key2 != 0ull)) T = bm_offer_lane_keys<KPL>(T, key2, k, tau_q);
+      if (__ballot(key2 != 0ull)) {
+        T = bm_offer_lane_keys<KPL>(T, key2, k, tau_q);
+        if (KTHB && KPL == 1) {  // (k <= 64: one key per lane)
+          const u64 best = rdlane64(T.keys[0], 0);
+          // (intersections: the driver list is read whatever the threshold -- nothing to gain there)
+          if (bests && !is_and && best != last_best) { last_best = best; pb_publish_kth_best(bests, bests_stride, P, part, k, best, tau_q); }
+        }
+      }
     }
   };
   // tombstone test (delete_hashset, add_result.rs:3435): only ever evaluated for the few lanes that still hold a candidate

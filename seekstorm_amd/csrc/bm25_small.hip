@@ -52,6 +52,7 @@ struct PbSmall {
   float* out_score;
   uint32_t* out_count;
   unsigned long long* out_total;
+  unsigned long long* bests;      // [SM_MAX_Q][SM_MAX_PB * 8] best key of every partition (zero between launches): pb_publish_kth_best
   uint32_t* flag;                 // pinned host word: = seq when every answer is in place
   uint32_t del_words, n_sub, n_terms, nq, PB, CB, k, count, seq;
 };
@@ -114,8 +115,9 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 4) bm25_small_kernel(const PbSm
     for (int t = 0; t < NT; t++) { Q.term_[t] = fz->q[qi].term[t]; Q.idf_[t] = fz->q[qi].idf[t]; }
 #pragma unroll
     for (int j = 0; j < 4; j++) Q.not_[j] = FILT ? fz->q[qi].term[min(Q.nt_ + (uint32_t)j, 7u)] : 0u;
-    BmTop<KPL> T = pb_wave<NT, KPL, FILT, false, true, SM_G>(fz->post, fz->term_base, fz->sub_off, fz->probe, fz->probe_z, fz->probe_row, fz->umax, nullptr, nullptr,
-                                                 Q, fz->tau, fz->del, fz->del_words, fz->n_sub, fz->n_terms, PB * PB_WAVES, k, fz->count & 1u, qi, part, w, lane, fz->q[qi].thr0);
+    BmTop<KPL> T = pb_wave<NT, KPL, FILT, false, true, SM_G, true>(fz->post, fz->term_base, fz->sub_off, fz->probe, fz->probe_z, fz->probe_row, fz->umax, nullptr, nullptr,
+                                                 Q, fz->tau, fz->del, fz->del_words, fz->n_sub, fz->n_terms, PB * PB_WAVES, k, fz->count & 1u, qi, part, w, lane, fz->q[qi].thr0,
+                                                 (fz->count & 4u) && k <= 64u && PB * PB_WAVES >= k ? fz->bests + (size_t)qi * (SM_MAX_PB * PB_WAVES) : nullptr);
     // the workgroup's eight lists -> one (LDS: every wave's queue is empty by now and its region its own)
     const uint32_t lb = (uint32_t)w * WREG;
 #pragma unroll
@@ -259,6 +261,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 4) bm25_small_kernel(const PbSm
     if (!(fz->count & 2u)) fz->tau[(size_t)qi * BM_TAU_STRIDE] = 0u;  // (bit 1: an experiment -- the next launch starts from these thresholds)
     fz->arrive[qi] = 0u;
   }
+  for (uint32_t p_ = (uint32_t)lane; p_ < PB * PB_WAVES; p_ += 64u) fz->bests[(size_t)qi * (SM_MAX_PB * PB_WAVES) + p_] = 0ull;
   __threadfence_system();  // the answers (host memory) before the flag
   if (lane == 0) {
     const uint32_t done = atomicAdd(&fz->arrive[SM_MAX_Q], 1u);
@@ -271,7 +274,8 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 4) bm25_small_kernel(const PbSm
 
 // ---------------------------------------------------------------- host side
 size_t ssi_bm25_small_ws_bytes() {
-  return (size_t)SM_MAX_Q * SM_MAX_PB * 128u * sizeof(u64) + SM_MAX_Q * sizeof(u64) + (size_t)SM_MAX_Q * BM_TAU_STRIDE * 4u + (SM_MAX_Q + 1u) * 4u + 64u;
+  return (size_t)SM_MAX_Q * SM_MAX_PB * 128u * sizeof(u64) + SM_MAX_Q * sizeof(u64) + (size_t)SM_MAX_Q * BM_TAU_STRIDE * 4u + (SM_MAX_Q + 1u) * 4u + 64u +
+         (size_t)SM_MAX_Q * SM_MAX_PB * PB_WAVES * sizeof(u64) + 8u;
 }
 
 // can this batch take the one-launch path?  (the caller has run check_queries: no phrase, no all_terms_frequent, every list with a probe row)
@@ -320,6 +324,8 @@ int ssi_bm25_small_launch(ss_shard* s, void* ws, uint32_t nq, const ss_bm25_quer
   a.tau = (uint32_t*)w;
   w += (size_t)SM_MAX_Q * BM_TAU_STRIDE * 4u;
   a.arrive = (uint32_t*)w;
+  w += ((SM_MAX_Q + 1u) * 4u + 64u + 7u) & ~(size_t)7u;
+  a.bests = (unsigned long long*)w;
   (void)KS;
   a.post = s->d_post;
   a.term_base = (const unsigned long long*)s->d_term_base;
@@ -334,14 +340,20 @@ int ssi_bm25_small_launch(ss_shard* s, void* ws, uint32_t nq, const ss_bm25_quer
   a.n_terms = s->bm_n_terms;
   a.nq = nq;
   a.k = k;
-  a.count = (want_counts ? 1u : 0u) | (keep_tau ? 2u : 0u);
+  // bit 2: the query's threshold from the partitions' best keys (pb_publish_kth_best).  From 16 queries per call on: 64 queries 164 -> 105 us,
+  // 32 queries 112 -> 87 us; a call of 1 / 8 queries -- 512 partitions per query, a handful of groups each -- pays 6 / 13 us for the
+  // re-computations and gains nothing (tools/probes/small_fused.py, profiles/r5_small_kth_best.log)
+  static const int bests_min = [] { const char* e = getenv("SS_BM25_SMALL_BESTS_MIN"); return e ? atoi(e) : 16; }();
+  const bool use_bests = nq >= (uint32_t)bests_min;
+  a.count = (want_counts ? 1u : 0u) | (keep_tau ? 2u : 0u) | (use_bests ? 4u : 0u);
   a.seq = seq;
   a.out_doc = out_doc; a.out_score = out_score; a.out_count = out_count; a.out_total = (unsigned long long*)out_total; a.flag = flag;
   // partitions: about 4096 waves in all (the staged path's rule), 16 .. 256 per query; intersections at least 48 (the shortest list
   // drives, shorter assignments balance better); never more than the sub-blocks can feed
   static const int pb_env = [] { const char* e = getenv("SS_BM25_SMALL_PB"); return e ? atoi(e) : 0; }();
   // (measured on C2, tools/probes/small_fused.py: one query 54.9 us at 32 workgroups, 50.6 at 64; 8 queries 71.5 / 68.4; 32 queries best at 16)
-  uint32_t PB = std::max<uint32_t>(has_and ? 6u : 2u, std::min<uint32_t>(SM_MAX_PB, 512u / nq));
+  // (with the best-keys threshold 16 .. 31 queries are best at 2048 waves in all: 16 queries 84.5 us at 32 workgroups each, 77.7 at 16)
+  uint32_t PB = std::max<uint32_t>(has_and ? 6u : 2u, std::min<uint32_t>(SM_MAX_PB, ((use_bests && nq < 32u && !has_and) ? 256u : 512u) / nq));
   if (pb_env > 0) PB = (uint32_t)pb_env;
   PB = std::max<uint32_t>(1u, std::min<uint32_t>(std::min<uint32_t>(PB, SM_MAX_PB), (s->bm_n_sub + PB_WAVES - 1) / PB_WAVES));
   a.PB = PB;
