@@ -46,7 +46,7 @@ int with_facet_filter(ss_shard* s, uint32_t n_filters, const ss_facet_filter* fi
 }  // namespace
 
 // SS_CO_TRACE: where a coalesced lexical batch spends its time (sums in us; printed when the shard is destroyed)
-struct CoTrace { std::atomic<uint64_t> n{0}, stage{0}, enqueue{0}, wait{0}, scatter{0}, linger{0}; };
+struct CoTrace { std::atomic<uint64_t> n{0}, stage{0}, enqueue{0}, wait{0}, scatter{0}, linger{0}, wake{0}, members{0}; };
 static CoTrace g_co_trace;
 static const bool g_co_trace_on = getenv("SS_CO_TRACE") != nullptr;
 static inline uint64_t co_now_us() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -193,9 +193,9 @@ int ss_shard_destroy(ss_shard* s) {
   if (!s) return SS_EINVAL;
   if (g_co_trace_on && g_co_trace.n.load()) {
     const double n = (double)g_co_trace.n.load() * 1000.0;  // ns -> us per batch
-    fprintf(stderr, "[co] %llu lexical batches: stage %.1f us, search call %.1f us (enqueue %.1f + device wait %.1f), scatter %.1f us per batch\n",
+    fprintf(stderr, "[co] %llu lexical batches: stage %.1f us, search call %.1f us (enqueue %.1f + device wait %.1f), scatter %.1f us, waking %.1f members %.1f us per batch\n",
             (unsigned long long)g_co_trace.n.load(), g_co_trace.stage.load() / n, g_co_trace.wait.load() / n, g_co_trace.enqueue.load() / n,
-            g_co_trace.linger.load() / n, g_co_trace.scatter.load() / n);
+            g_co_trace.linger.load() / n, g_co_trace.scatter.load() / n, g_co_trace.members.load() / (double)g_co_trace.n.load(), g_co_trace.wake.load() / n);
   }
   (void)hipSetDevice(s->device);
   (void)hipStreamSynchronize(s->stream);
@@ -1989,12 +1989,14 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
       if (succ) succ->lane = me->lane;
       else { co.leaders--; co.lane[me->lane].busy = false; }
     }
+    const uint64_t tw0 = g_co_trace_on ? co_now_us() : 0;
     if (succ) co_signal(succ, 3u);  // first: the next batch forms while this one's members are being woken
     bool mine = false;
     for (ss_co_req* r : batch) {
       if (r == me) mine = true;
       else co_signal(r, 1u);
     }
+    if (g_co_trace_on && lexical && batch.size() > 1) { g_co_trace.wake += co_now_us() - tw0; g_co_trace.members += batch.size() - 1; }
     if (mine) return me->rc;
     lead = false;  // (cannot happen while the leader's request is the front of its own batch; kept for safety)
   }
