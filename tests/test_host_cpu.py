@@ -364,3 +364,48 @@ def test_ann_mode_struct_matches_the_header():
     assert int(re.search(r"#define SS_ANN_REPORT_OBSERVED (\d+)u", hdr).group(1)) == N.SS_ANN_REPORT_OBSERVED
     rs = open(os.path.join(root, "integration", "hip_ffi.rs")).read()
     assert "flags" in rs[rs.index("struct SsAnnMode"):rs.index("struct SsAnnMode") + 400]
+
+
+def test_bench_compact_line_keeps_the_contract_and_its_bound():
+    """bench.py's last stdout line: built from the FULL line of the round's final run (profiles/r5_bench_details.json),
+    and from the same line blown up with junk legs -- one parseable object under 4096 bytes either way, the contract's keys whole."""
+    import json
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r5_bench_details.json")))
+    for extra in (0, 400):
+        line = dict(full)
+        if extra:  # more callers' legs than any run holds: sections are dropped before the bound is exceeded, the contract never
+            line["concurrent_callers"] = dict(line.get("concurrent_callers") or {})
+            for i in range(extra):
+                line["concurrent_callers"][f"junk_{i}"] = {"value": 1.0 * i, "threads": i, "latency_us_p50": 1.0, "latency_us_p99": 2.0}
+        out = bench.compact_line(line)
+        txt = json.dumps(out)
+        assert len(txt.encode()) <= 4096, len(txt)
+        back = json.loads(txt)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                  "roofline", "cpu_baseline"):
+            assert k in back, k
+        assert back["vs_baseline"] is None and back["data"] == "synthetic" and "workload" in back["config"] and "model" not in back["config"]
+        rf = back["roofline"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in rf, k
+        assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in back["cpu_baseline"], k
+        assert back["cpu_baseline"]["kind"] in ("port", "reference")
+
+
+def test_committed_bench_line_and_counter_file_belong_together():
+    """profiles/r5_bench_line.json is the line of the round's final run; its `traffic` figures come from profiles/pmc_traffic.json,
+    which bench.py only uses while it was collected on the kernel sources of the tree (kernel_source_hash)."""
+    import json
+    import bench
+    line = json.load(open(os.path.join(ROOT, "profiles", "r5_bench_line.json")))
+    assert line["n_gpus"] == 1 and line["unit"] == "queries/s" and line["value"] > 1e6
+    assert len(json.dumps(line).encode()) <= 4096
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    for leg in ("bm25", "bm25_pruned", "vector", "vector_i8"):
+        assert pmc[leg]["hbm_bytes_per_launch"] > 0 and pmc[leg]["launches"] > 0
+    assert abs(line["roofline"]["traffic"] - pmc["bm25"]["hbm_bytes_per_launch"]) / pmc["bm25"]["hbm_bytes_per_launch"] < 1e-3
+    if pmc["kernel_source_hash"] != bench.kernel_source_hash():
+        pytest.skip("profiles/pmc_traffic.json predates the kernel sources of this tree: bench.py reports traffic = null until tools/collect_pmc.sh is re-run")
