@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 5
+#define SS_ABI_VERSION 6
 #define SS_NO_DOC 0xFFFFFFFFu
 /* scored + NOT terms of one query: union_docid_3 takes unions of <= 10 terms (union.rs:1308), union_blockid -> union_scan_32 those of
  * 11..32 (search.rs:3497-3520, union.rs:598-805; its 32-bit match mask is the limit) */
@@ -58,7 +58,8 @@ enum {
   SS_EINVAL = -1,   /* bad argument */
   SS_ENOMEM = -2,   /* device or host allocation failed */
   SS_EDEVICE = -3,  /* HIP runtime error (no device, launch failure, ...) */
-  SS_ENOTSUP = -4,  /* valid request outside the implemented scope */
+  SS_ENOTSUP = -4,  /* a valid request the device path does not answer: the caller runs its own (CPU) path for it -- for queries the
+                     * complete list is INTEGRATION.md section 4 "CPU fall-through", pinned by tests/test_gpu_shape_sweep.py */
   SS_ESTATE = -5,   /* image not uploaded yet */
   SS_EPEER = -6     /* a collective call (ss_*_search_sharded) failed on ANOTHER rank: every rank returns an error, none blocks */
 };
@@ -99,6 +100,14 @@ int ss_shard_coalescing_stats(ss_shard* s, uint64_t* lexical_batches, uint64_t* 
  * term -- one indexed field, or several with merged lists and no field filter --, every list with a probe row, no facet filter): same answers bit for bit, a third of the latency.  ss_bm25_path_stats: how
  * many ss_bm25_search[_filtered] batches (coalesced ones included) took it so far. */
 int ss_bm25_path_stats(ss_shard* s, uint64_t* one_launch_batches);
+/* Query shapes (ABI v6).  Each query of a host-pointer batch is classified behind the call and the batch run as sub-batches per
+ * kernel family, answers back in the callers' order: what the specialised kernels serve goes to them; intersections, filtered terms
+ * and phrases beyond them -- the all_terms_frequent shortcut over more than 7 terms, more than 8 terms or 32 (term, field) lists over
+ * per-field lists, phrases of 7 .. SS_MAX_PHRASE unique terms or with k > 128 -- to the generic galloping kernels
+ * (csrc/bm25_gallop.hip: the shortest list drives, the others are looked up by binary search, intersection.rs:352-362); unions of
+ * 8 .. 10 terms under a field filter, or naming a sparse-tier term, are composed from the reference's own sub-queries
+ * (union.rs:1330-1425).  ss_bm25_shape_stats: sub-batches the generic kernels answered so far. */
+int ss_bm25_shape_stats(ss_shard* s, uint64_t* generic_batches);
 int ss_shard_destroy(ss_shard* s);
 /* block until all work queued on the shard's stream is done */
 int ss_shard_sync(ss_shard* s);
@@ -382,12 +391,13 @@ int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df
 /* field_filter of search_lexical_shard for an image with several indexed fields (search.rs:2483-2492, add_result.rs:3124-
  * 3136): bits 16..31 of op, bit f = indexed field f is listed; 0 = no filter.  Intersections and single-term queries: a doc is
  * kept only if EVERY query term occurs in at least one listed field; its score still sums all fields.  A UNION of several terms
- * (<= 7; ABI v3): the reference filters inside union_docid_3's sub-queries (union.rs:1330-1425, 1168-1305), which comes to -- a doc's
+ * (<= 10, the range of union_docid_3; more: SS_ENOTSUP -- the reference then runs union_scan with a per-doc filter, another rule):
+ * the reference filters inside union_docid_3's sub-queries (union.rs:1330-1425, 1168-1305), which comes to -- a doc's
  * score is the sum over its terms that occur in a listed field (all fields of those terms counted), a doc none of whose terms passes
  * is no result; exact count: two terms |pass(X) u pass(Y)|, more terms the UNFILTERED union (union_scan counts a doc before the
- * filter sees it, union.rs:552-553).  Answered by the scan kernels with per-term gating of a doc's score; one that names a term of
- * the sparse tier (<= 5 terms) by the reference's own sub-queries, behind this call: every subset of its terms as a filtered
- * intersection through both tiers, a doc keeps its best.  Ignored by an image with
+ * filter sees it, union.rs:552-553).  Answered by the scan kernels with per-term gating of a doc's score (<= 7 terms); one of 8 .. 10
+ * terms, or one that names a term of the sparse tier, by the reference's own sub-queries, behind this call: every subset of its terms
+ * as a filtered intersection through both tiers, a doc keeps its best.  Ignored by an image with
  * one indexed field.  For ss_bm25_search_dev such a query counts as an intersection in ops_mask (bit 0) and a filtered union of
  * several terms sets bit 7 as well. */
 #define SS_OP_FIELD_FILTER(mask) (((uint32_t)(mask) & 0x7FFFu) << 16)
@@ -396,7 +406,9 @@ int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df
  * pointer or fewer than 10 positions is counted but never scored (decode_positions_multiterm_singlefield returns true,
  * add_result.rs:2091-2104, 3541-3556).  An embedded pointer holds at most 4 positions, so the rule is "ranked only if every
  * term has tf >= 10".  The caller evaluates the condition (it knows N, top_k and the posting counts) and sets this bit on
- * the query; the host mirrors do.  Intersections of 2..7 terms (SS_ENOTSUP otherwise); counts are unaffected.  Several indexed
+ * the query; the host mirrors do -- and the library CHECKS the posting-count half of the condition again (it holds the counts): a bit
+ * set on a query for which it does not hold is ignored, as the reference would not have set it.  Intersections of 2 or more terms
+ * (more than 7: the generic kernel, csrc/bm25_gallop.hip); counts are unaffected.  Several indexed
  * fields (decode_positions_multiterm_multifield, add_result.rs:1595-1607: an embedded pointer, or a record whose FIRST field has
  * fewer than 10 positions -> counted, not ranked): "ranked only if every term has >= 10 positions in the lowest field that holds
  * the doc", over the image's merged lists (ss_bm25_fields_info; SS_ENOTSUP without them); under a field filter the reference
@@ -418,8 +430,9 @@ typedef struct {
  * at its first place -- the positions of its first component term --, its other places are SS_PHRASE_SKIP, its other component
  * terms are unique terms that no place names); it is scored like the
  * intersection of the unique terms (get_bm25f_multiterm_singlefield) and counted only when the phrase matches.  Needs the
- * positions in the image and every list with a probe row (on a rationed vocabulary the rows built on demand go to a batch's phrase
- * queries first; SS_ENOTSUP when the pool cannot hold the lists of its phrases).  One indexed field: ss_bm25_upload_positions.  Several indexed fields
+ * positions in the image; up to 6 unique terms and k <= 128 run over the probe index (every list with a probe row: on a rationed
+ * vocabulary the rows built on demand go to a batch's phrase queries first), 7 .. SS_MAX_PHRASE unique terms or a larger k on the
+ * generic kernel (csrc/bm25_gallop.hip; no probe rows needed).  One indexed field: ss_bm25_upload_positions.  Several indexed fields
  * (ss_bm25_upload_fields_positions; add_result.rs:3248-3386): the phrase must stand inside ONE field, fields tried in ascending
  * order, only listed ones under SS_OP_FIELD_FILTER; the score sums all fields of the unique terms.  Host-pointer batches may mix
  * phrase queries with others (run as two sub-batches inside the library, answers back in the callers' order); a DEVICE-resident

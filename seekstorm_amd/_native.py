@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEEKSTORM_HIP_LIB") or os.path.join(_HERE, "lib", "libseekstorm_hip.so")  # override: experiment builds (tools/probes)
 
 SS_NO_DOC = 0xFFFFFFFF
+SS_OK, SS_EINVAL, SS_ENOMEM, SS_EDEVICE, SS_ENOTSUP, SS_ESTATE, SS_EPEER = 0, -1, -2, -3, -4, -5, -6
 SS_MAX_QUERY_TERMS = 32
 SS_MAX_PHRASE = 12
 SS_PHRASE_SKIP = 0xFF
@@ -218,6 +219,7 @@ SYMBOLS = [
     ("ss_shard_set_coalescing", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
     ("ss_shard_coalescing_stats", C.c_int, [C.c_void_p, u64p, u64p, u64p, u64p]),
     ("ss_bm25_path_stats", C.c_int, [C.c_void_p, u64p]),
+    ("ss_bm25_shape_stats", C.c_int, [C.c_void_p, u64p]),
     ("ss_profile_enable", C.c_int, [C.c_void_p, C.c_int]),
     ("ss_profile_read", C.c_int, [C.c_void_p, C.c_int, u64p, C.POINTER(C.c_double), C.c_int]),
 ]

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.environ.get("SS_OUT_DIR") or os.path.join(HERE, "lib")  # SS_OUT_DIR: experiment builds beside the product build
 LIB = os.path.join(OUT_DIR, "libseekstorm_hip.so")
-SOURCES = ["ss_api.hip", "vec_scan.hip", "bm25.hip", "synth.hip", "merge.hip", "bm25_fast.hip", "bm25_probe.hip", "ref_format.hip", "vec8_scan.hip", "vec_ann.hip", "facet.hip", "comm.hip", "bm25_phrase.hip", "bm25_scan16.hip", "bm25_sparse.hip", "bm25_small.hip"]
+SOURCES = ["ss_api.hip", "vec_scan.hip", "bm25.hip", "synth.hip", "merge.hip", "bm25_fast.hip", "bm25_probe.hip", "ref_format.hip", "vec8_scan.hip", "vec_ann.hip", "facet.hip", "comm.hip", "bm25_phrase.hip", "bm25_scan16.hip", "bm25_sparse.hip", "bm25_small.hip", "bm25_gallop.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"] + os.environ.get("SS_HIPCC_FLAGS", "").split()
 

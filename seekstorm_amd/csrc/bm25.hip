@@ -376,6 +376,46 @@ int ssi_bm25_match_bits(ss_shard* s, const ss_bm25_query* d_q, unsigned long lon
   return rc;
 }
 
+// The partition lists of a batch ([nq][P][KS] sorted keys in bufA; bufB: as much room again) -> the callers' outputs: a tournament per
+// query for small k, else the merge tree.  tau: the batch's threshold lines (word 1 of a line = "this query contradicted the batch's
+// declaration": its count reads UINT32_MAX).  Shared by every kernel family that answers in partition lists (bm25_gallop.hip too).
+int ssi_bm25_merge_lists(u64* bufA, u64* bufB, uint32_t nq, uint32_t P, uint32_t KS, uint32_t k, const u64* total, const uint32_t* tau,
+                         uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, hipStream_t st) {
+  if (P > 1 && P <= 64 && k >= 1 && k <= 32 && k <= KS) {  // a tournament per query (one wave) instead of the sorting network
+    bm25_merge_small_kernel<<<(nq + 3) / 4, 256, 0, st>>>(bufA, nq, P, KS, total, k, d_out_doc, d_out_score, d_out_count,
+                                                         (u64*)d_out_total, tau);
+    SS_HIP(hipGetLastError());
+    return SS_OK;
+  }
+  // merge tree over the P partition lists
+  SS_SET_MAX_LDS(bm25_merge_kernel, 8192 * 8);
+  uint32_t lists = P;
+  u64 *src = bufA, *dst = bufB;
+  uint32_t take = 1;  // power of two >= k (the lists are sorted: deeper entries cannot reach the top-k)
+  while (take < std::max<uint32_t>(k, 1u) && take < KS) take <<= 1;
+  const uint32_t group = 8192 / take;
+  while (lists > 1) {
+    uint32_t ng = (lists + group - 1) / group;
+    uint32_t np = 64;
+    while (np < std::min(lists, group) * take) np <<= 1;
+    const bool last = ng == 1;
+    // LDS for the keys this pass really sorts (a flat 64 KB request kept all but two workgroups off a CU: 26 -> 12 us per
+    // 1000 C2 queries)
+    bm25_merge_kernel<<<dim3(ng, nq), std::min<uint32_t>(1024u, std::max<uint32_t>(64u, np / 2)), (size_t)np * sizeof(u64), st>>>(
+        src, dst, lists, group, KS, take, total, k, last ? 1u : 0u, d_out_doc, d_out_score, d_out_count, (u64*)d_out_total, tau);
+    std::swap(src, dst);
+    lists = ng;
+    if (last) {
+      SS_HIP(hipGetLastError());
+      return SS_OK;
+    }
+  }
+  bm25_final_kernel<<<nq, 64, 0, st>>>(src, total, KS, k, d_out_doc, d_out_score, d_out_count,
+                                       (u64*)d_out_total, tau);  // P == 1: nothing to merge
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
 int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t k, uint32_t rt, uint32_t* d_out_doc,
                     float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, bool has_and, bool has_or,
                     uint32_t nt_max, uint32_t np_max, bool all_probed, hipStream_t st, bool any_frequent, bool phrase, bool any_field_filter,
@@ -544,37 +584,5 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
     if (rcc) return rcc;
   }
 
-  if (P > 1 && P <= 64 && k >= 1 && k <= 32 && k <= KS) {  // a tournament per query (one wave) instead of the sorting network
-    bm25_merge_small_kernel<<<(nq + 3) / 4, 256, 0, st>>>(bufA, nq, P, KS, total, k, d_out_doc, d_out_score, d_out_count,
-                                                         (u64*)d_out_total, tau);
-    SS_HIP(hipGetLastError());
-    return SS_OK;
-  }
-  // merge tree over the P partition lists
-  SS_SET_MAX_LDS(bm25_merge_kernel, 8192 * 8);
-  uint32_t lists = P;
-  u64 *src = bufA, *dst = bufB;
-  uint32_t take = 1;  // power of two >= k (the lists are sorted: deeper entries cannot reach the top-k)
-  while (take < std::max<uint32_t>(k, 1u) && take < KS) take <<= 1;
-  const uint32_t group = 8192 / take;
-  while (lists > 1) {
-    uint32_t ng = (lists + group - 1) / group;
-    uint32_t np = 64;
-    while (np < std::min(lists, group) * take) np <<= 1;
-    const bool last = ng == 1;
-    // LDS for the keys this pass really sorts (a flat 64 KB request kept all but two workgroups off a CU: 26 -> 12 us per
-    // 1000 C2 queries)
-    bm25_merge_kernel<<<dim3(ng, nq), std::min<uint32_t>(1024u, std::max<uint32_t>(64u, np / 2)), (size_t)np * sizeof(u64), st>>>(
-        src, dst, lists, group, KS, take, total, k, last ? 1u : 0u, d_out_doc, d_out_score, d_out_count, (u64*)d_out_total, tau);
-    std::swap(src, dst);
-    lists = ng;
-    if (last) {
-      SS_HIP(hipGetLastError());
-      return SS_OK;
-    }
-  }
-  bm25_final_kernel<<<nq, 64, 0, st>>>(src, total, KS, k, d_out_doc, d_out_score, d_out_count,
-                                       (u64*)d_out_total, tau);  // P == 1: nothing to merge
-  SS_HIP(hipGetLastError());
-  return SS_OK;
+  return ssi_bm25_merge_lists(bufA, bufB, nq, P, KS, k, total, tau, d_out_doc, d_out_score, d_out_count, d_out_total, st);
 }

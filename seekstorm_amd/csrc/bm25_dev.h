@@ -382,6 +382,9 @@ __device__ __attribute__((noinline)) BmTop<KPL> bm_offer_lane_keys(BmTop<KPL> T,
 }
 
 
+// partition lists -> the callers' outputs (bm25.hip)
+int ssi_bm25_merge_lists(u64* bufA, u64* bufB, uint32_t nq, uint32_t P, uint32_t KS, uint32_t k, const u64* total, const uint32_t* tau,
+                         uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, hipStream_t st);
 // scan kernels (bm25_fast.hip): NT-specialised for <= 4 terms and k <= 128, grouped generic kernel otherwise
 int ssi_bm25_launch_scan(const BmParams& p, uint32_t nt_max, bool has_and, int KPL, hipStream_t st);
 // 16-bit-accumulator scan (bm25_scan16.hip): unions of <= 6 lists / intersections of 2-3, k <= 64, NOT lists, tombstones, exact counts; 16 waves per CU

@@ -25,6 +25,9 @@ constexpr uint32_t SM_MAX_CB = 20;  // counting workgroups per query
 #ifndef SM_G
 #define SM_G 8  // chunks of 64 driver postings per group (bm25_probe_body.h)
 #endif
+#ifndef SM_ARRIVE_ACQREL
+#define SM_ARRIVE_ACQREL 0  // 1: acquire / release at agent scope on the arrival counter (see the arrival below)
+#endif
 
 struct pb_squery {
   uint32_t n_terms, op;  // op = SS_OP_* | NOT terms << 8 (bm_q_op / bm_q_nnot)
@@ -123,6 +126,10 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 4) bm25_small_kernel(const PbSm
 #pragma unroll
     for (int r = 0; r < KPL; r++) lds_st64(lb + ((uint32_t)r * 64u + (uint32_t)lane) * 8u, T.keys[r]);
     if (lane == 0) lds_st64(lb + KS * 8u, T.matched);
+    // every wave's device-scope traffic -- the no-return atomicMax on the query's threshold, its best-key slots -- is PERFORMED before
+    // the barrier: wave 0 arrives behind it, so whoever arrives last may zero that state for the next launch without a late atomic
+    // landing on top (the workgroup barrier alone does not wait for vmcnt)
+    __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     if (w != 0) return;
     u64 matched = 0ull;
@@ -214,7 +221,14 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 4) bm25_small_kernel(const PbSm
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the compiler keeps the order; the hardware's part is the s_waitcnt)
   __builtin_amdgcn_s_waitcnt(0);
   uint32_t prev = 0u;
+#if SM_ARRIVE_ACQREL
+  // the memory model's own form: release what this workgroup wrote, acquire what the others released (one fence pair per WORKGROUP).
+  // Measured against the relaxed form below (profiles/r6_small_arrive.log); the litmus probe tools/probes/small_litmus.hip is the
+  // evidence the relaxed form rests on.
+  if (lane == 0) prev = __hip_atomic_fetch_add(&fz->arrive[qi], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#else
   if (lane == 0) prev = atomicAdd(&fz->arrive[qi], 1u);
+#endif
   prev = __builtin_amdgcn_readfirstlane(prev);
   if (prev + 1u != PB + fz->CB) return;
   const u64* lists = fz->part_keys + (size_t)qi * PB * KS;

@@ -2,6 +2,8 @@
 // reference seams each entry point replaces).  Host-side plumbing only; the kernels live in vec_scan.hip / bm25.hip.
 #include <linux/futex.h>
 #include <sys/syscall.h>
+#include <sched.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -61,7 +63,7 @@ const char* ss_strerror(int code) {
     case SS_EINVAL: return "invalid argument";
     case SS_ENOMEM: return "out of memory";
     case SS_EDEVICE: return "HIP device/runtime error";
-    case SS_ENOTSUP: return "not supported by the MI355X hot path (see DESIGN.md)";
+    case SS_ENOTSUP: return "not answered by the device path: the caller's own (CPU) path applies (INTEGRATION.md section 4)";
     case SS_ESTATE: return "image not uploaded";
     case SS_EPEER: return "a collective search failed on another rank";
     default: return "unknown error";
@@ -201,7 +203,7 @@ int ss_shard_destroy(ss_shard* s) {
   (void)hipStreamSynchronize(s->stream);
   free_vec(s);
   free_bm25(s);
-  void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_deleted, s->d_facets, s->d_filter_bits, s->d_facet_ws, s->d_pool_stage, s->d_tier_ws, s->d_tier_hold, s->d_excl_bits, s->d_sort_ws};
+  void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_deleted, s->d_facets, s->d_filter_bits, s->d_facet_ws, s->d_pool_stage, s->d_tier_ws, s->d_tier_hold, s->d_excl_bits, s->d_sort_ws, s->d_route_ws};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   (void)hipDeviceSynchronize();  // searches queued on the callers' own streams may still use their workspaces
   for (auto& kv : s->bm_ws) {
@@ -1270,7 +1272,7 @@ static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_quer
 // sparse kernel, which scores every doc of a sparse list in full -- and put together per query by bm25_tier_merge_kernel; the
 // answers land in s->d_out_* in the callers' order, like any other batch's.  Caller holds s->mu.
 static int bm25_search_tiered_excl(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, const std::vector<uint32_t>& special);
-static int bm25_search_tiered_compose(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, const std::vector<uint32_t>& composed);
+static int bm25_search_compose(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, const std::vector<uint32_t>& composed);  // (defined below)
 static int bm25_search_tiered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt) {
   const uint32_t n_dense = s->bm_n_terms / s->bm_n_fields;  // public terms of the dense image
   if (s->bm_n_fields != 1 && !s->bm_merged) return SS_ENOTSUP;  // (several indexed fields: the sparse tier holds merged weights)
@@ -1304,8 +1306,8 @@ static int bm25_search_tiered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, 
     if (bm_q_field_filter(q[i].op) >> bm_real_fields(s)) return SS_EINVAL;
     const bool filtered = s->bm_n_fields > 1 && bm_q_field_filter(q[i].op) != 0u;
     if (bm_q_all_frequent(q[i].op)) return SS_ENOTSUP;
-    if (filtered && op == SS_OP_UNION && q[i].n_terms > 1) {
-      if (q[i].n_terms > 5) return SS_ENOTSUP;
+    if (filtered && op == SS_OP_UNION && q[i].n_terms > 1) {  // (bm25_route_shapes sends these to bm25_search_compose before they get here)
+      if (q[i].n_terms > 10) return SS_ENOTSUP;
       composed.push_back(i);
       continue;
     }
@@ -1343,7 +1345,7 @@ static int bm25_search_tiered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, 
     }
   }
   SS_HIP(hipSetDevice(s->device));
-  if (!composed.empty()) return bm25_search_tiered_compose(s, nq, q, kk, rt, composed);
+  if (!composed.empty()) return bm25_search_compose(s, nq, q, kk, rt, composed);
   if (!special.empty()) return bm25_search_tiered_excl(s, nq, q, kk, rt, special);
   const uint32_t ns_plain = (uint32_t)spq.size();
   for (uint32_t i = 0; i < nq; i++)
@@ -1459,16 +1461,19 @@ static int bm25_search_tiered_excl(ss_shard* s, uint32_t nq, const ss_bm25_query
   return SS_OK;
 }
 
-// A UNION of several terms under a field filter that names a term of the sparse tier.  The dense tier answers such a union by gating
-// every term's unlisted (term, field) lists inside the scan (BM_AND_GATED); the sparse tier keeps one merged list per term.  So the
+// A UNION of several terms under a field filter that the gated scan does not take: one that names a term of the sparse tier (the dense
+// tier gates every term's unlisted (term, field) lists inside the scan, BM_AND_GATED; the sparse tier keeps one merged list per term),
+// or one of 8 .. 10 terms (the match byte holds 7 term bits).  The
 // query is answered the way the reference itself answers it (union.rs:1168-1305, 1330-1425: union_docid_3 queues the intersection
 // of all terms and every subset down to pairs, union_docid_2 runs a pair as its intersection plus the two single terms; the filter
 // applies to the terms of the sub-query that finds the doc, add_result.rs:3124-3136; a doc found again keeps its better score,
 // min_heap.rs:1193-1260): the 2^n - 1 filtered intersections as ONE batch through both tiers, merged per doc by the maximum -- a doc
 // of the union's top-k is in the top-k of the sub-query that gives it its score.  Totals as the reference reports them: two terms
 // |pass(X) u pass(Y)| (union_docid_2's count), more the UNFILTERED union (union_scan counts a doc before the filter sees it,
-// union.rs:552-553).  Rare (a rare word in a multi-word query under a field filter); <= 5 terms; the merge is the host's.
-static int bm25_search_tiered_compose(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, const std::vector<uint32_t>& composed) {
+// union.rs:552-553).  Rare (a rare word in a multi-word query under a field filter, or 8+ words under one); <= 10 terms -- the range
+// of union_docid_3 (search.rs:3497-3520) -- i.e. <= 1023 sub-queries in one batch (the sub-queries the specialised kernels do not take
+// run on bm25_gallop.hip); the merge is the host's.
+static int bm25_search_compose(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, const std::vector<uint32_t>& composed) {
   const uint32_t kw = std::max<uint32_t>(kk, 1), n_co = (uint32_t)composed.size();
   std::vector<uint32_t> a_doc((size_t)n_co * kw, SS_NO_DOC), a_cnt(n_co, 0);
   std::vector<float> a_score((size_t)n_co * kw, 0.f);
@@ -1548,9 +1553,181 @@ static int bm25_search_tiered_compose(ss_shard* s, uint32_t nq, const ss_bm25_qu
   return SS_OK;
 }
 
+// ---------------------------------------------------------------- query shapes (VERDICT r5 "next" 1)
+// Every host-pointer batch passes here first.  The specialised kernel families each serve a range of shapes (check_queries,
+// bm25_search_tiered); what lies outside used to come back SS_ENOTSUP -- to a drop-in caller an EMPTY result for a query the reference
+// answers.  Now a query is classified and the batch run as sub-batches per kernel family, answers back in the callers' order:
+//   NATIVE         what the specialised paths serve (unchanged)
+//   GALLOP         intersections / filtered single terms beyond them: all_terms_frequent with > 7 terms, > 8 terms or > BM_MAX_VTERMS
+//                  (term, field) lists over per-field lists (a field filter, or an image without merged lists)  -> bm25_gallop.hip
+//   GALLOP_PHRASE  phrases of 7 .. SS_MAX_PHRASE unique terms, or k > 128, either tier                                 -> bm25_gallop.hip
+//   COMPOSE        unions of 2 .. 10 terms under a field filter that the gated scan does not take (8 .. 10 terms, or a term of the
+//                  sparse tier): the reference's own sub-queries (union.rs:1330-1425), bm25_search_compose
+// SS_ENOTSUP remains for the shapes INTEGRATION.md section 4 lists as CPU fall-through (tests/test_gpu_shape_sweep.py pins the list).
+enum : uint8_t { SH_NATIVE = 0, SH_GALLOP = 1, SH_GALLOP_PHRASE = 2, SH_COMPOSE = 3 };
+
+// postings of the list(s) a query walks for `term` when it drives (dense: its only / merged list, or all its field lists)
+static uint64_t shape_term_postings(const ss_shard* s, uint32_t term) {
+  const uint32_t L = s->bm_n_fields, n_dense = s->bm_n_terms / L;
+  if (term >= n_dense) { const uint32_t i = term - n_dense; return i + 1 < s->h_sp_base.size() ? s->h_sp_base[i + 1] - s->h_sp_base[i] : 0; }
+  if (L == 1 || s->bm_merged) return s->h_df[(size_t)term * L + (L - 1u)];
+  uint64_t n = 0;
+  for (uint32_t f = 0; f < L; f++) n += s->h_df[(size_t)term * L + f];
+  return n;
+}
+// the reference's own condition for all_terms_frequent (intersection.rs:198-209: posting_count / indexed_doc_count >= 0.5 in f32 for
+// EVERY term), which is also the builders' rule for the lists whose codes carry the tf < 10 mark (synth.hip bm_list_flagged): a bit
+// set on a query the rule does not hold for is dropped -- the reference would not have set it, and the mark is not there to read
+static bool shape_freq_rule(const ss_shard* s, const ss_bm25_query& Q) {
+  const uint32_t L = s->bm_n_fields, n_dense = s->bm_n_terms / L;
+  for (uint32_t t = 0; t < Q.n_terms; t++) {
+    if (Q.term[t] >= n_dense) return false;  // (a sparse list's codes carry no mark; ss_index_bin_tier keeps lists of half the docs dense)
+    const uint64_t df = (L > 1 && !s->bm_merged) ? (Q.term[t] < s->h_df_real.size() ? s->h_df_real[Q.term[t]] : 0) : s->h_df[(size_t)Q.term[t] * L + (L - 1u)];
+    if (!((float)df / (float)s->bm_n_docs >= 0.5f)) return false;
+  }
+  return true;
+}
+
+static int bm25_shape_of(const ss_shard* s, const ss_bm25_query& Q, uint32_t kk, uint8_t* shape, bool* drop_freq, uint64_t* driver_len) {
+  const uint32_t L = s->bm_n_fields, RF = bm_real_fields(s), n_dense = s->bm_n_terms / L;
+  const uint32_t op = bm_q_op(Q.op), n_not = bm_q_nnot(Q.op), np = Q.n_terms, all = np + n_not;
+  *shape = SH_NATIVE; *drop_freq = false; *driver_len = 0;
+  if (np == 0 || all > (uint32_t)SS_MAX_QUERY_TERMS) return SS_EINVAL;
+  if (op != SS_OP_INTERSECTION && op != SS_OP_UNION && op != SS_OP_PHRASE) return SS_EINVAL;
+  if (bm_q_field_filter(Q.op) >> RF) return SS_EINVAL;  // a field the image does not have
+  const uint32_t filt = RF > 1 ? bm_q_field_filter(Q.op) : 0u;
+  bool any_sparse = false;
+  uint64_t best = ~0ull;
+  for (uint32_t t = 0; t < all; t++) {
+    if (Q.term[t] >= n_dense + s->sp_n) return SS_EINVAL;
+    if (t < np && !(Q.idf[t] > 0.0f)) return SS_EINVAL;
+    for (uint32_t u = 0; u < t; u++)
+      if (Q.term[u] == Q.term[t]) return SS_EINVAL;  // unique terms only (search.rs:3023 unique_terms)
+    any_sparse |= Q.term[t] >= n_dense;
+    if (t < np) best = std::min(best, shape_term_postings(s, Q.term[t]));
+  }
+  *driver_len = best;
+  const bool is_and = op == SS_OP_INTERSECTION && np > 1;
+  if (bm_q_all_frequent(Q.op) && is_and && !filt) {  // (anywhere else the bit has no effect: single terms, unions, phrases, under a field filter)
+    if (!shape_freq_rule(s, Q)) *drop_freq = true;
+    else if (L > 1 && !s->bm_merged) return SS_ENOTSUP;  // the several-fields form of the rule is coded into the merged lists
+    else if (np > 7) *shape = SH_GALLOP;
+  }
+  if (op == SS_OP_PHRASE) {
+    if (Q.phrase_len < 2 || Q.phrase_len > SS_MAX_PHRASE || Q.phrase_seq[0] >= np) return SS_EINVAL;
+    for (uint32_t j = 1; j < Q.phrase_len; j++)
+      if (Q.phrase_seq[j] >= np && Q.phrase_seq[j] != SS_PHRASE_SKIP) return SS_EINVAL;
+    if (L > 1 && !s->bm_merged) return SS_ENOTSUP;  // phrases of several indexed fields run over the merged lists' field-tagged positions
+    if (np > 6 || kk > 128) *shape = SH_GALLOP_PHRASE;
+    return SS_OK;
+  }
+  if (filt && op == SS_OP_UNION && np > 1) {  // a union under a field filter: the gated scan (<= 7 dense terms), else composed
+    if (np > 10) return SS_ENOTSUP;  // the reference: union_scan + a per-doc filter, another rule
+    if (any_sparse || np > 7) *shape = SH_COMPOSE;
+    return SS_OK;
+  }
+  // per-field lists: under a field filter, or on an image without merged lists
+  if (RF > 1 && (filt || !s->bm_merged) && !any_sparse && (all * RF > (uint32_t)BM_MAX_VTERMS || (is_and && np > 8))) {
+    if (is_and || np == 1 || filt) *shape = SH_GALLOP;
+    else return SS_ENOTSUP;  // a union of more than BM_MAX_VTERMS (term, field) lists on an image without merged lists
+  }
+  return SS_OK;
+}
+
+static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, uint32_t n_filters,
+                                    const ss_facet_filter* filters);
+static int bm25_search_compose(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, const std::vector<uint32_t>& composed);
+
+// *handled = false: every query is NATIVE (`*use` = the batch to run: q itself, or `norm` -- the copy with the dropped bits)
+static int bm25_route_shapes(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, std::vector<ss_bm25_query>& norm,
+                             const ss_bm25_query** use, bool* handled) {
+  *handled = false;
+  *use = q;
+  std::vector<uint8_t> shape(nq);
+  std::vector<uint64_t> dlen(nq);
+  uint32_t n_class[4] = {0, 0, 0, 0};
+  for (uint32_t i = 0; i < nq; i++) {
+    bool drop = false;
+    SS_TRY(bm25_shape_of(s, q[i], kk, &shape[i], &drop, &dlen[i]));
+    if (drop) {
+      if (norm.empty()) norm.assign(q, q + nq);
+      norm[i].op &= ~SS_OP_ALL_TERMS_FREQUENT;
+    }
+    n_class[shape[i]]++;
+  }
+  if (!norm.empty()) *use = norm.data();
+  if (n_class[SH_NATIVE] == nq) return SS_OK;
+  *handled = true;
+  const ss_bm25_query* Q = *use;
+  if (n_class[SH_COMPOSE]) {  // (the rest of the batch comes back here through bm25_search_host_queries)
+    std::vector<uint32_t> composed;
+    for (uint32_t i = 0; i < nq; i++)
+      if (shape[i] == SH_COMPOSE) composed.push_back(i);
+    return bm25_search_compose(s, nq, Q, kk, rt, composed);
+  }
+  // sub-batches per kernel family; their answers are held until all have run (each writes s->d_out_* rows 0 ..)
+  const uint32_t kw = std::max<uint32_t>(kk, 1);
+  SS_HIP(hipSetDevice(s->device));
+  SS_TRY(ensure_out(s, nq, kw));
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t o_q = 0, o_perm = o_q + al((size_t)nq * sizeof(ss_bm25_query)), o_doc = o_perm + al((size_t)nq * 4), o_sc = o_doc + al((size_t)nq * kw * 4),
+               o_cnt = o_sc + al((size_t)nq * kw * 4), o_tot = o_cnt + al((size_t)nq * 4), need = o_tot + al((size_t)nq * 8);
+  SS_HIP(hipStreamSynchronize(s->stream));  // the workspace may still be read by the batch before; the copies below are synchronous
+  if (need > s->route_ws_cap) {
+    if (s->d_route_ws) (void)hipFree(s->d_route_ws);
+    s->d_route_ws = nullptr; s->route_ws_cap = 0;
+    SS_HIP(hipMalloc(&s->d_route_ws, need * 2));
+    s->route_ws_cap = need * 2;
+  }
+  char* W = (char*)s->d_route_ws;
+  std::vector<ss_bm25_query> sub;
+  std::vector<uint32_t> perm;
+  uint32_t at = 0;
+  for (uint8_t c : {SH_NATIVE, SH_GALLOP, SH_GALLOP_PHRASE}) {
+    if (!n_class[c]) continue;
+    sub.clear(); perm.clear();
+    uint64_t longest = 0;
+    for (uint32_t i = 0; i < nq; i++)
+      if (shape[i] == c) { sub.push_back(Q[i]); perm.push_back(i); longest = std::max(longest, dlen[i]); }
+    const uint32_t n = (uint32_t)sub.size();
+    SS_HIP(hipMemcpy(W + o_perm + (size_t)at * 4, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    if (c == SH_NATIVE) {
+      SS_TRY(bm25_search_host_queries(s, n, sub.data(), kk, rt, 0, nullptr));
+    } else {
+      SS_HIP(hipMemcpy(W + o_q + (size_t)at * sizeof(ss_bm25_query), sub.data(), (size_t)n * sizeof(ss_bm25_query), hipMemcpyHostToDevice));
+      SS_TRY(ssi_bm25_gallop_search(s, n, (const ss_bm25_query*)(W + o_q) + at, c == SH_GALLOP_PHRASE, longest, kk, rt, s->d_out_doc, s->d_out_score,
+                                    s->d_out_count, s->d_out_total, s->stream));
+      s->gallop_batches++;
+    }
+    bm25_unpermute_kernel<<<n, 64, 0, s->stream>>>((const uint32_t*)(W + o_perm) + at, n, kk, s->d_out_doc, s->d_out_score, s->d_out_count,
+                                                  (const unsigned long long*)s->d_out_total, (uint32_t*)(W + o_doc), (float*)(W + o_sc),
+                                                  (uint32_t*)(W + o_cnt), (unsigned long long*)(W + o_tot));
+    SS_HIP(hipGetLastError());
+    at += n;
+  }
+  SS_TRY(ensure_out(s, nq, kw));  // (a sub-batch never needs more rows than the batch: the buffers are the ones reserved above)
+  if (kk) {
+    SS_HIP(hipMemcpyAsync(s->d_out_doc, W + o_doc, (size_t)nq * kw * 4, hipMemcpyDeviceToDevice, s->stream));
+    SS_HIP(hipMemcpyAsync(s->d_out_score, W + o_sc, (size_t)nq * kw * 4, hipMemcpyDeviceToDevice, s->stream));
+  }
+  SS_HIP(hipMemcpyAsync(s->d_out_count, W + o_cnt, (size_t)nq * 4, hipMemcpyDeviceToDevice, s->stream));
+  SS_HIP(hipMemcpyAsync(s->d_out_total, W + o_tot, (size_t)nq * 8, hipMemcpyDeviceToDevice, s->stream));
+  return SS_OK;
+}
+
 // the search of ss_bm25_search_filtered / _sharded up to the device lists (s->d_out_*, on s->stream); caller holds s->mu
 static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, uint32_t n_filters,
                                     const ss_facet_filter* filters) {
+  // (a facet filter: its exclusion bitmap stands in for the tombstones of everything below -- every kernel family reads the same one)
+  if (n_filters) return with_facet_filter(s, n_filters, filters, s->stream, [&]() { return bm25_search_host_queries(s, nq, q, kk, rt, 0, nullptr); });
+  std::vector<ss_bm25_query> norm;
+  {
+    bool handled = false;
+    const ss_bm25_query* use = q;
+    SS_TRY(bm25_route_shapes(s, nq, q, kk, rt, norm, &use, &handled));
+    if (handled) return SS_OK;
+    q = use;
+  }
   if (s->sp_n) {  // an image with a sparse tier: does the batch name one of its terms?
     bool any_sparse = false;
     for (uint32_t i = 0; i < nq && !any_sparse; i++)
@@ -1636,16 +1813,24 @@ static int bm25_small_try(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint
                           uint32_t* p_doc, float* p_score, uint32_t* p_count, uint64_t* p_total, bool* handled, uint32_t* seq_out) {
   *handled = false;
   if (n_filters != 0 || kk == 0 || !ssi_bm25_small_serves(s, nq, kk, 1, 0)) return SS_OK;
-  if (s->sp_n)  // a term of the sparse tier: the tiered path
-    for (uint32_t i = 0; i < nq; i++)
-      for (uint32_t t = 0; t < std::min<uint32_t>(q[i].n_terms + bm_q_nnot(q[i].op), SS_MAX_QUERY_TERMS); t++)
-        if (q[i].term[t] >= s->bm_n_terms / s->bm_n_fields && q[i].term[t] < s->bm_n_terms / s->bm_n_fields + s->sp_n) return SS_OK;
-  for (uint32_t i = 0; i < nq; i++)
-    if (bm_q_op(q[i].op) == SS_OP_PHRASE) return SS_OK;  // phrase queries have a kernel of their own (and a mixed batch is split first)
+  // the cheap part of the shape first: nothing of the probe pool is touched for a batch the staged pipeline will run anyway
+  {
+    const uint32_t n_dense = s->bm_n_terms / s->bm_n_fields, RF = bm_real_fields(s);
+    for (uint32_t i = 0; i < nq; i++) {
+      const uint32_t np = q[i].n_terms, nn = bm_q_nnot(q[i].op);
+      if (np == 0 || np > 4 || nn > 4 || bm_q_op(q[i].op) == SS_OP_PHRASE || bm_q_all_frequent(q[i].op) || (RF > 1 && bm_q_field_filter(q[i].op))) return SS_OK;
+      for (uint32_t t = 0; t < np + nn; t++)
+        if (q[i].term[t] >= n_dense) return SS_OK;  // a term of the sparse tier (or an invalid one: the staged path reports it)
+    }
+  }
   SS_TRY(ssi_bm25_ensure_probe_rows(s, nq, q, s->stream));
   bool has_and = false, has_or = false, all_probed = false, any_frequent = false, phrase = false, any_filter = false, uniform = false, gated = false;
   uint32_t nt_max = 0, np_max = 0, nn_max = 0;
-  SS_TRY(check_queries(s, nq, q, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent, &phrase, &any_filter, &uniform, &gated, &nn_max));
+  {
+    const int rc = check_queries(s, nq, q, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent, &phrase, &any_filter, &uniform, &gated, &nn_max);
+    if (rc == SS_ENOTSUP) return SS_OK;  // a shape of another kernel family: the staged pipeline routes it (bm25_route_shapes)
+    if (rc) return rc;
+  }
   if (phrase || any_frequent || !all_probed || any_filter || gated || !ssi_bm25_small_serves(s, nq, kk, np_max, nn_max)) return SS_OK;
   SS_HIP(hipSetDevice(s->device));
   if (!s->d_small_ws) {
@@ -1678,22 +1863,40 @@ static int bm25_small_try(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint
 }
 // waits for the flag of `slot` to show `seq`: the kernel raises it behind the last answer.  Polled -- the answers are a few
 // microseconds old when the loop sees it, where a stream synchronisation adds the completion signal's round trip
-static int bm25_small_wait(ss_shard* s, uint32_t slot, uint32_t seq) {
+// mu_held: the caller holds s->mu (the direct path); the coalescer's lanes wait outside it
+static int bm25_small_wait(ss_shard* s, uint32_t slot, uint32_t seq, bool mu_held) {
   volatile uint32_t* flag = (volatile uint32_t*)(s->h_small + 64 * slot);
   const auto t0 = std::chrono::steady_clock::now();
+  int rc = SS_EDEVICE;
   for (uint32_t spins = 0;; spins++) {
     if (__atomic_load_n((const uint32_t*)flag, __ATOMIC_ACQUIRE) == seq) return SS_OK;
     __builtin_ia32_pause();
-    if ((spins & 0x3FFu) == 0x3FFu) {
+    if ((spins & 0xFFu) == 0xFFu) {
       const auto dt = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+      // a small batch is back within ~0.2 ms; past that the stream is backed up behind somebody's long work (a hybrid caller's vector
+      // pass): give the core away between looks instead of burning it
+      if (dt > 300) sched_yield();
       if (dt > 2000) {  // long past any small batch: ask the runtime (a kernel that died leaves the flag untouched)
         const hipError_t e = hipStreamQuery(s->stream);
-        if (e != hipSuccess && e != hipErrorNotReady) return SS_EDEVICE;
-        if (e == hipSuccess) return __atomic_load_n((const uint32_t*)flag, __ATOMIC_ACQUIRE) == seq ? SS_OK : SS_EDEVICE;
-        if (dt > 10000000) return SS_EDEVICE;
+        if (e != hipSuccess && e != hipErrorNotReady) break;
+        if (e == hipSuccess) { if (__atomic_load_n((const uint32_t*)flag, __ATOMIC_ACQUIRE) == seq) return SS_OK; break; }
+        if (dt > 10000000) break;
+        struct timespec ts = {0, 50000};
+        nanosleep(&ts, nullptr);
       }
     }
   }
+  // The launch did not come back: its per-query state (arrival counters, thresholds, totals) may be half-way, and the kernel may still
+  // be writing the lane's pinned answers.  Drain the stream, start the next launch from zero, and tell the caller (VERDICT r5 weak 12,
+  // ADVICE r5): without this every later one-launch batch would merge on a wrong "last arriver" or wait out the 10 s cap.
+  std::unique_lock<std::mutex> g(s->mu, std::defer_lock);
+  if (!mu_held) g.lock();  // (nobody enqueues another launch while the state is being zeroed)
+  (void)hipStreamSynchronize(s->stream);
+  if (s->d_small_ws) {
+    (void)hipMemsetAsync(s->d_small_ws, 0, ssi_bm25_small_ws_bytes(), s->stream);
+    (void)hipStreamSynchronize(s->stream);
+  }
+  return rc;
 }
 
 static int bm25_search_direct(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k, uint32_t rt, uint32_t n_filters,
@@ -1706,7 +1909,7 @@ static int bm25_search_direct(ss_shard* s, uint32_t nq, const ss_bm25_query* q, 
     uint32_t seq = 0;
     SS_TRY(bm25_small_try(s, nq, q, kk, rt, n_filters, 0, nullptr, nullptr, nullptr, nullptr, &handled, &seq));
     if (handled) {
-      SS_TRY(bm25_small_wait(s, 0, seq));
+      SS_TRY(bm25_small_wait(s, 0, seq, true));
       memcpy(out_doc, s->h_small + SM_H_DOC, (size_t)nq * kk * sizeof(uint32_t));
       memcpy(out_score, s->h_small + SM_H_SCORE, (size_t)nq * kk * sizeof(float));
       memcpy(out_count, s->h_small + SM_H_COUNT, (size_t)nq * sizeof(uint32_t));
@@ -1769,7 +1972,7 @@ static int bm25_search_direct_lane(ss_shard* s, uint32_t nq, const ss_bm25_query
     }
   }
   const uint64_t te = g_co_trace_on ? co_now_us() : 0;
-  if (small) SS_TRY(bm25_small_wait(s, lane_slot, small_seq));
+  if (small) SS_TRY(bm25_small_wait(s, lane_slot, small_seq, false));
   else SS_HIP(hipEventSynchronize(ev));
   if (g_co_trace_on) { g_co_trace.enqueue += te - t_in; g_co_trace.linger += co_now_us() - te; }
   return SS_OK;
@@ -2013,6 +2216,12 @@ int ss_bm25_path_stats(ss_shard* s, uint64_t* one_launch_batches) {
   if (!s || !one_launch_batches) return SS_EINVAL;
   std::lock_guard<std::mutex> g(s->mu);
   *one_launch_batches = s->small_launches;
+  return SS_OK;
+}
+int ss_bm25_shape_stats(ss_shard* s, uint64_t* generic_batches) {
+  if (!s || !generic_batches) return SS_EINVAL;
+  std::lock_guard<std::mutex> g(s->mu);
+  *generic_batches = s->gallop_batches;
   return SS_OK;
 }
 int ss_shard_coalescing_stats(ss_shard* s, uint64_t* lexical_batches, uint64_t* lexical_queries, uint64_t* vector_batches, uint64_t* vector_queries) {

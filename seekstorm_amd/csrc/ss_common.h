@@ -362,6 +362,9 @@ struct ss_shard {
   size_t tier_hold_cap = 0;
   uint32_t* d_excl_bits = nullptr;   // per-query exclusion bitmap of such a query: tombstones | docs of its sparse NOT lists
   size_t excl_words_cap = 0;
+  void* d_route_ws = nullptr;        // a batch that holds shapes of several kernel families (ss_api.hip bm25_route_shapes): the sub-batches'
+  size_t route_ws_cap = 0;           // queries + row maps, and the answers until every sub-batch has run; grow-only
+  uint64_t gallop_batches = 0;       // sub-batches the generic kernels (bm25_gallop.hip) answered
   // incremental image (ss_bm25_append_level)
   ss_block_pool blocks;              // the image arrays of incremental images come from here
   ss_block_pool* pool = nullptr;     // set on the scratch shard a rebuild fills: its image arrays are taken from the owner's pool
@@ -558,6 +561,10 @@ int ssi_bm25_launch_tier_merge(uint32_t nq, uint32_t k, const uint32_t* d_dense_
                                const float* d_score, const uint32_t* d_count, const unsigned long long* d_total, const unsigned long long* d_keys,
                                const unsigned long long* d_extra, uint32_t* o_doc, float* o_score, uint32_t* o_count, unsigned long long* o_total,
                                hipStream_t st);
+// generic intersections / phrases by galloping lookups (bm25_gallop.hip): any number of terms, tiers, fields, k -- the shapes the
+// specialised kernels leave out.  d_q: PUBLIC queries on the device, validated by the host (ss_api.hip bm25_route_shapes)
+int ssi_bm25_gallop_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, bool phrase, uint64_t longest_driver, uint32_t k, uint32_t rt,
+                           uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total, hipStream_t st);
 struct ss_comm;
 // one per-shard result list of a batch on the device: [nq][k] doc ids / scores, [nq] counts
 struct ss_dev_list { const uint32_t* doc; const float* score; const uint32_t* count; uint32_t k; };

@@ -322,7 +322,7 @@ int Shard::upload_facets(uint64_t n_docs, uint32_t record_size, const uint8_t* r
 
 // all_terms_frequent (intersection.rs:198-209), evaluated where the reference evaluates it -- on the host, per query:
 // N > top_k << 8 and posting_count / N >= 0.5 (f32) for every term of an intersection of several terms -> the query is
-// marked and ranks only docs whose every tf >= 10 (<= 7 terms; several indexed fields: the tf in the doc's lowest field).  Not under a field filter
+// marked and ranks only docs whose every tf >= 10 (several indexed fields: the tf in the doc's lowest field).  Not under a field filter
 // (add_result.rs:3545) -- nor under a facet filter (add_result.rs:2096-2100), which the caller knows about.
 bool Shard::mark_all_terms_frequent(ss_bm25_query* q, size_t top_k) const {
   if (!h_ || !(n_docs_ > ((uint64_t)top_k << 8))) return false;
@@ -330,7 +330,7 @@ bool Shard::mark_all_terms_frequent(ss_bm25_query* q, size_t top_k) const {
     uint32_t merged = 0;
     if (ss_bm25_fields_info(h_, nullptr, &merged, nullptr) != SS_OK || !merged) return false;
   }
-  if ((q->op & 0xFFu) != SS_OP_INTERSECTION || q->n_terms < 2 || q->n_terms > 7 || ((q->op >> 16) & 0x7FFFu)) return false;
+  if ((q->op & 0xFFu) != SS_OP_INTERSECTION || q->n_terms < 2 || ((q->op >> 16) & 0x7FFFu)) return false;
   uint64_t df[SS_MAX_QUERY_TERMS];
   if (ss_bm25_term_df(h_, q->n_terms, q->term, df) != SS_OK) return false;
   for (uint32_t t = 0; t < q->n_terms; t++)
@@ -675,72 +675,14 @@ int Shard::sorted_topk(const ss_bm25_query& q, const ResultSort* sorts, size_t n
   return SS_OK;
 }
 
-// A union of several terms under a field filter.  The reference answers it through sub-queries: union_docid_3 queues the
-// intersection of all terms and every subset one term shorter, down to pairs (union.rs:1330-1425), union_docid_2 runs a pair as
-// its intersection plus the two single terms (union.rs:1168-1305), the filter (add_result.rs:3124-3136) applies to the terms of
-// the sub-query that finds the doc, and a doc found again keeps its better score (docid_hashset, min_heap.rs:1193-1260): every
-// subset of the terms is tried as a filtered intersection and a doc ends with the best of them.  Here: the 2^n - 1 filtered
-// intersections as ONE device batch, merged per doc by the maximum.  Totals as the reference reports them: two terms ->
-// |pass(X) u pass(Y)| (union_docid_2's count), more -> the unfiltered union (union_scan counts before the filter, union.rs:552).
-ResultObject Shard::union_with_field_filter(const std::vector<uint32_t>& terms, size_t k, ResultType result_type,
-                                            const std::vector<uint32_t>& not_terms, const std::vector<uint16_t>& field_filter,
-                                            const std::vector<ss_facet_filter>& facet_filter) {
-  ResultObject ro;
-  const size_t n = terms.size();
-  if (n > 5) { ro.last_error = SS_ENOTSUP; return ro; }
-  std::vector<ss_bm25_query> qs((1u << n) - 1);
-  for (uint32_t m = 1; m < (1u << n); m++) {
-    std::vector<uint32_t> sub;
-    for (size_t i = 0; i < n; i++)
-      if ((m >> i) & 1u) sub.push_back(terms[i]);
-    const int rc = make_query(sub, QueryType::Intersection, &qs[m - 1], not_terms, field_filter);
-    if (rc != SS_OK) { ro.last_error = rc; return ro; }
-  }
-  const ResultType rt = result_type == ResultType::Topk ? ResultType::Topk : ResultType::TopkCount;
-  std::vector<ResultObject> parts = search_lexical_batch(qs, std::max<size_t>(k, 1), rt, facet_filter);
-  std::unordered_map<uint64_t, Result> best;
-  for (const ResultObject& p : parts) {
-    if (p.last_error != SS_OK) { ro.last_error = p.last_error; return ro; }
-    for (const Result& r : p.results) {
-      auto it = best.find(r.doc_id);
-      if (it == best.end()) best.emplace(r.doc_id, r);
-      else if (r.score > it->second.score) it->second = r;
-    }
-  }
-  std::vector<Result> ranked;
-  ranked.reserve(best.size());
-  for (auto& e : best) ranked.push_back(e.second);
-  std::sort(ranked.begin(), ranked.end(), [](const Result& a, const Result& b) { return a.score != b.score ? a.score > b.score : a.doc_id < b.doc_id; });
-  if (ranked.size() > k) ranked.resize(k);
-  if (result_type == ResultType::Topk) ro.result_count_total = ranked.size();
-  else if (n == 2) ro.result_count_total = parts[0].result_count_total + parts[1].result_count_total - parts[2].result_count_total;
-  else {
-    ss_bm25_query qu;
-    const int rc = make_query(terms, QueryType::Union, &qu, not_terms);
-    if (rc != SS_OK) { ro.last_error = rc; return ro; }
-    ResultObject c = std::move(search_lexical_batch({qu}, 1, ResultType::Count, facet_filter)[0]);
-    if (c.last_error != SS_OK) { ro.last_error = c.last_error; return ro; }
-    ro.result_count_total = c.result_count_total;
-  }
-  if (result_type != ResultType::Count) ro.results = std::move(ranked);
-  ro.result_count = ro.results.size();
-  return ro;
-}
-
 ResultObject Shard::search_lexical_shard(const std::vector<uint32_t>& query_terms, QueryType query_type_default, size_t offset,
                                          size_t length, ResultType result_type, const std::vector<ss_facet_filter>& facet_filter,
                                          const std::vector<uint32_t>& not_terms, const std::vector<uint16_t>& field_filter,
                                          const std::vector<ResultSort>& result_sort) {
   ResultObject ro;
-  std::vector<uint32_t> uniq;
-  for (uint32_t t : query_terms)
-    if (std::find(uniq.begin(), uniq.end(), t) == uniq.end()) uniq.push_back(t);
-  // a union of several terms under a field filter: per-term gating inside the scan kernels (<= 7 terms, round 3: the query goes
-  // down like any other); beyond that the composition from the reference's own sub-queries (rounds 1-2)
-  if (!field_filter.empty() && lexical_fields_ > 1 && query_type_default == QueryType::Union && uniq.size() > 7) {
-    if (!result_sort.empty()) { ro.last_error = SS_ENOTSUP; return ro; }
-    ro = union_with_field_filter(uniq, offset + length, result_type, not_terms, field_filter, facet_filter);
-  } else {
+  // a union of several terms under a field filter goes down like any other query: per-term gating inside the scan kernels (<= 7
+  // terms, round 3) or the reference's own sub-queries composed BEHIND the ABI (8 .. 10 terms, a sparse-tier term; round 6).
+  {
     ss_bm25_query q;
     const int rc = make_query(query_terms, query_type_default, &q, not_terms, lexical_fields_ > 1 ? field_filter : std::vector<uint16_t>());
     if (rc != SS_OK) { ro.last_error = rc; return ro; }

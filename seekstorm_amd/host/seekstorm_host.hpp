@@ -14,7 +14,8 @@
 //
 // No compute happens here: every score, set operation, top-k and merge is behind the C ABI.  Like the reference's
 // search path (search.rs:2461-2463, vector.rs:1222-1224) a failing shard degrades to an empty ResultObject; the
-// C-ABI code is kept in `last_error` for diagnosis.  Out of scope (stays in the Rust host):
+// C-ABI code is kept in `last_error` for diagnosis -- SS_ENOTSUP there means "the host's own dispatch answers this one"
+// (ResultObject::cpu_dispatch), never "no hits".  Out of scope (stays in the Rust host):
 // tokenizer / term hashing -- a lexical query arrives as resolved term ids -- facets, filters, query rewriting.
 #pragma once
 #include <stdint.h>
@@ -65,6 +66,10 @@ struct ResultObject {
   uint64_t observed_vector_count = 0;
   uint64_t observed_cluster_count = 0;
   int last_error = 0;               // SS_OK or the C-ABI code that emptied this object
+  // last_error == SS_ENOTSUP is NOT a failing shard: the query is one the device path leaves to the host's own dispatch
+  // (search.rs:3374-3560 stands in the same function as the seam; INTEGRATION.md section 4 lists the shapes).  This mirror has no CPU
+  // path by design -- the product never computes on the host -- so it says so instead of looking like "no hits".
+  bool cpu_dispatch() const { return last_error == SS_ENOTSUP; }
 };
 
 // ---- host-side scalar pieces of the reference algorithm
@@ -200,9 +205,6 @@ class Shard {
   int set_clusters(const std::vector<uint32_t>& level_clusters, const std::vector<uint32_t>& child_count);
 
  private:
-  ResultObject union_with_field_filter(const std::vector<uint32_t>& terms, size_t k, ResultType result_type,
-                                       const std::vector<uint32_t>& not_terms, const std::vector<uint16_t>& field_filter,
-                                       const std::vector<ss_facet_filter>& facet_filter);
   int sorted_topk(const ss_bm25_query& q, const ResultSort* sorts, size_t n_sorts, size_t k, std::vector<ss_facet_filter> filters,
                   std::vector<Result>* out, uint64_t* total, bool* have_total);
   ss_shard* h_ = nullptr;

@@ -13,7 +13,10 @@ resolved term ids instead of a query string; facets, filters, highlights, query 
 
 All compute goes through the C ABI (seekstorm_amd/_native.py -> libseekstorm_hip.so).  Like the reference's search
 path, a failing shard degrades to an empty ResultObject (search.rs:2461-2463, vector.rs:1222-1224) unless
-`strict=True` is passed, in which case the C-ABI error is raised.
+`strict=True` is passed, in which case the C-ABI error is raised.  ONE code is no failure: SS_ENOTSUP says "this query is
+the host's own dispatch's to answer" (search.rs:3374-3560 stands in the same function as the seam; INTEGRATION.md section 4
+lists the shapes) -- the mirrors have no CPU path by design (the product never computes on the host), so they report it
+as ResultObject.cpu_dispatch = True instead of an empty answer that would look like "no hits".
 """
 import ctypes as C
 import enum
@@ -63,6 +66,7 @@ class ResultObject:  # search.rs:186-213
     result_count_total: int = 0
     observed_vector_count: int = 0
     observed_cluster_count: int = 0
+    cpu_dispatch: bool = False  # SS_ENOTSUP: not an empty answer -- the reference's own dispatch block (search.rs:3374-3560) answers it
 
 
 SIMILARITY_NORMALIZATION_64_I8 = np.float32(1.0) / np.float32(16129.0)  # vector.rs:29
@@ -670,7 +674,7 @@ class Shard:
                         at += len(e)
             nl = [t for t in dict.fromkeys(_flat(nl)) if t not in tl]
             if not 1 <= len(tl) or len(tl) + len(nl) > N.SS_MAX_QUERY_TERMS:
-                raise ValueError("1..10 unique terms per query (NOT terms included)")
+                raise ValueError("1..%d unique terms per query (NOT terms included)" % N.SS_MAX_QUERY_TERMS)
             q["n_terms"][i] = len(tl)
             q["op"][i] = int(qt) | (len(nl) << 8) | (fmask << 16)
             for j, t in enumerate(tl):
@@ -964,14 +968,14 @@ class Shard:
         if self.indexed_doc_count <= (int(k) << 8):
             return queries
         cand = np.nonzero(((queries["op"] & 0xFF) == int(QueryType.Intersection)) & (queries["n_terms"] > 1) &
-                          (queries["n_terms"] <= 7) & (((queries["op"] >> 16) & 0x7FFF) == 0))[0]  # not under a field filter, add_result.rs:3545
+                          (((queries["op"] >> 16) & 0x7FFF) == 0))[0]  # not under a field filter, add_result.rs:3545
         if len(cand) == 0:
             return queries
         # vectorised: a 1000-query batch costs one df lookup for its unseen terms and a few array operations (the Python loop
         # it replaces cost more than the device call it precedes)
         nt = queries["n_terms"][cand].astype(np.int64)
-        terms = queries["term"][cand][:, :7].astype(np.int64)
-        valid = np.arange(7)[None, :] < nt[:, None]
+        terms = queries["term"][cand].astype(np.int64)
+        valid = np.arange(terms.shape[1])[None, :] < nt[:, None]
         uniq = np.unique(terms[valid])
         dfu = self.posting_count(uniq).astype(np.float32)  # one call: a host-side table lookup in the library
         freq_u = dfu / np.float32(self.indexed_doc_count) >= np.float32(0.5)  # f32 division, as the reference's
@@ -1038,16 +1042,18 @@ class Shard:
         ro = ResultObject()
         try:
             uniq = list(dict.fromkeys(int(t) for t in query_terms))
-            # a union of several terms under a field filter: per-term gating inside the scan kernels (<= 7 terms, round 3); the
-            # composition from the reference's own sub-queries below stays as the second route (compose_filtered_unions = True)
+            # a union of several terms under a field filter: per-term gating inside the scan kernels (<= 7 terms, round 3) or the
+            # composition from the reference's own sub-queries BEHIND the ABI (8 .. 10 terms, a sparse-tier term; round 6); the
+            # host-side composition below stays as a second route for the tests (compose_filtered_unions = True, <= 5 terms)
             if (field_filter and self.lexical_field_count > 1 and int(query_type_default) == int(QueryType.Union) and len(uniq) > 1
-                    and (self.compose_filtered_unions or len(uniq) > 7)):
+                    and self.compose_filtered_unions):
                 return self._union_with_field_filter(uniq, offset, length, result_type, not_terms, field_filter, facet_filter)
             q = self.make_queries([query_terms], query_type_default, [not_terms], field_filter=field_filter)
             doc, score, cnt, tot = self.search_lexical_batch(q, offset + length, result_type, facet_filter=facet_filter)
-        except Exception:
+        except Exception as e:
             if strict:
                 raise
+            ro.cpu_dispatch = isinstance(e, N.SeekStormHipError) and e.code == N.SS_ENOTSUP
             return ro
         n = int(cnt[0])
         ro.results = [Result(int(d), float(s), ResultSource.Lexical) for d, s in zip(doc[0, :n], score[0, :n])][offset:]
@@ -1230,6 +1236,12 @@ class Shard:
         (ss_shard_set_coalescing; on by default, a batch size of 0 switches a kind off)"""
         N.check(N.lib().ss_shard_set_coalescing(self._h, int(max_lexical_batch), int(max_vector_batch), int(max_wait_us)),
                 "ss_shard_set_coalescing")
+
+    def generic_batches(self):
+        """sub-batches the generic galloping kernels answered (ss_bm25_shape_stats): shapes beyond the specialised kernels"""
+        v = C.c_uint64()
+        N.check(N.lib().ss_bm25_shape_stats(self._h, C.byref(v)), "ss_bm25_shape_stats")
+        return int(v.value)
 
     def one_launch_batches(self):
         """lexical host-pointer batches that took the one-launch path of small batches (ss_bm25_path_stats)"""
