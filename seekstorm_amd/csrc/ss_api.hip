@@ -1209,6 +1209,17 @@ static bool query_lists_probed(const ss_shard* s, const ss_bm25_query& q) {
   return true;
 }
 
+// ... of its DENSE terms (the one-launch path takes terms of either tier: a sparse list has no row and needs none)
+static bool query_lists_probed_dense(const ss_shard* s, const ss_bm25_query& q) {
+  const uint32_t all = q.n_terms + bm_q_nnot(q.op), L = s->bm_n_fields, n_dense = s->bm_n_terms / L;
+  for (uint32_t t = 0; t < all && t < SS_MAX_QUERY_TERMS; t++) {
+    if (q.term[t] >= n_dense) continue;
+    const uint32_t v = q.term[t] * L + (L - 1u);  // (no field filter on this path: the only / merged list)
+    if (s->h_probe_row[v] == BM_NO_PROBE_ROW && s->h_df[v] != 0) return false;
+  }
+  return true;
+}
+
 // A vocabulary larger than the probe budget has rows for its longest lists only (ss_bm25_set_probe_budget).  One query
 // that touches a list without a row must not send its whole batch to the scan kernels: the batch is run as two -- the
 // queries whose lists all have rows (pruned strategy), then the others -- and the answers are put back in the callers' order.
@@ -1813,25 +1824,57 @@ static int bm25_small_try(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint
                           uint32_t* p_doc, float* p_score, uint32_t* p_count, uint64_t* p_total, bool* handled, uint32_t* seq_out) {
   *handled = false;
   if (n_filters != 0 || kk == 0 || !ssi_bm25_small_serves(s, nq, kk, 1, 0)) return SS_OK;
-  // the cheap part of the shape first: nothing of the probe pool is touched for a batch the staged pipeline will run anyway
+  // The batch's shape, cheap parts first (nothing of the probe pool is touched for a batch the staged pipeline will run
+  // anyway).  What the one launch takes: unions and intersections of <= 4 scored and <= 4 NOT terms over one list per term, no field
+  // filter, no all_terms_frequent mark; terms of either tier (a sparse term: k <= 32, and its NOT terms only where the sparse role
+  // meets them -- an intersection that has a sparse scored term); phrases of <= 4 unique terms that name a sparse term.
+  ss_small_shape sh{rt != SS_RT_TOPK, false, false, false, false, false, 0u};
+  uint32_t nn_max = 0;
   {
-    const uint32_t n_dense = s->bm_n_terms / s->bm_n_fields, RF = bm_real_fields(s);
+    const uint32_t L = s->bm_n_fields, n_dense = s->bm_n_terms / L, RF = bm_real_fields(s);
     for (uint32_t i = 0; i < nq; i++) {
-      const uint32_t np = q[i].n_terms, nn = bm_q_nnot(q[i].op);
-      if (np == 0 || np > 4 || nn > 4 || bm_q_op(q[i].op) == SS_OP_PHRASE || bm_q_all_frequent(q[i].op) || (RF > 1 && bm_q_field_filter(q[i].op))) return SS_OK;
-      for (uint32_t t = 0; t < np + nn; t++)
-        if (q[i].term[t] >= n_dense) return SS_OK;  // a term of the sparse tier (or an invalid one: the staged path reports it)
+      const uint32_t np = q[i].n_terms, nn = bm_q_nnot(q[i].op), op = bm_q_op(q[i].op);
+      if (np == 0 || np > 4 || nn > 4 || op > (uint32_t)SS_OP_PHRASE || bm_q_all_frequent(q[i].op) || (RF > 1 && bm_q_field_filter(q[i].op))) return SS_OK;
+      uint32_t nd = 0;
+      bool sp_scored = false, sp_not = false;
+      for (uint32_t t = 0; t < np + nn; t++) {
+        if (q[i].term[t] >= n_dense + s->sp_n) return SS_OK;  // (an invalid term: the staged path reports it)
+        if (t < np && !(q[i].idf[t] > 0.0f)) return SS_OK;
+        for (uint32_t u = 0; u < t; u++)
+          if (q[i].term[u] == q[i].term[t]) return SS_OK;
+        if (q[i].term[t] >= n_dense) { if (t < np) sp_scored = true; else sp_not = true; }
+        else if (t < np) nd++;
+      }
+      const bool is_and = op == SS_OP_INTERSECTION && np > 1;
+      if (op == SS_OP_PHRASE) {
+        // phrases: the sparse role's (its shortest sparse list drives); all-dense phrases keep their staged kernel (bm25_phrase.hip)
+        if (!sp_scored || q[i].phrase_len < 2 || q[i].phrase_len > (uint32_t)SS_MAX_PHRASE || q[i].phrase_seq[0] >= np) return SS_OK;
+        for (uint32_t j = 1; j < q[i].phrase_len; j++)
+          if (q[i].phrase_seq[j] >= np && q[i].phrase_seq[j] != SS_PHRASE_SKIP) return SS_OK;
+        if (!s->d_sp_pos_end || s->sp_pos_elem != (L > 1 ? 4u : 2u) || (nd && (L > 1 ? !s->d_pos32 : !s->d_pos))) return SS_OK;
+        sh.any_phrase = true;
+      } else if (sp_not && !(is_and && sp_scored)) {
+        return SS_OK;  // a sparse NOT list the dense roles would have to probe: the staged path's per-query exclusion bitmap
+      }
+      if (sp_scored || sp_not) {
+        if (kk > 32) return SS_OK;
+        sh.any_sparse = true;
+      }
+      const bool dense_roles = nd != 0 && !(sp_scored && (is_and || op == SS_OP_PHRASE));  // (an intersection with a sparse term: the sparse role alone)
+      if (dense_roles) {
+        if (is_and && nd > 1) sh.has_and = true;
+        else if (nd > 1) sh.has_or = true;
+        sh.np_max = std::max(sh.np_max, nd);
+      }
+      sh.any_not |= nn != 0;
+      nn_max = std::max(nn_max, nn);
     }
+    if ((sh.any_sparse || sh.any_phrase) && L > 1 && !(s->bm_merged && s->h_boost.size() == L)) return SS_OK;
   }
   SS_TRY(ssi_bm25_ensure_probe_rows(s, nq, q, s->stream));
-  bool has_and = false, has_or = false, all_probed = false, any_frequent = false, phrase = false, any_filter = false, uniform = false, gated = false;
-  uint32_t nt_max = 0, np_max = 0, nn_max = 0;
-  {
-    const int rc = check_queries(s, nq, q, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent, &phrase, &any_filter, &uniform, &gated, &nn_max);
-    if (rc == SS_ENOTSUP) return SS_OK;  // a shape of another kernel family: the staged pipeline routes it (bm25_route_shapes)
-    if (rc) return rc;
-  }
-  if (phrase || any_frequent || !all_probed || any_filter || gated || !ssi_bm25_small_serves(s, nq, kk, np_max, nn_max)) return SS_OK;
+  for (uint32_t i = 0; i < nq; i++)  // every dense list the batch reads has a probe row now, or the scans take the batch
+    if (!query_lists_probed_dense(s, q[i])) return SS_OK;
+  if (!ssi_bm25_small_serves(s, nq, kk, sh.np_max, nn_max)) return SS_OK;
   SS_HIP(hipSetDevice(s->device));
   if (!s->d_small_ws) {
     SS_HIP(hipMalloc(&s->d_small_ws, ssi_bm25_small_ws_bytes()));
@@ -1849,8 +1892,7 @@ static int bm25_small_try(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   ssi_prof_begin(s, 0, s->stream, &e0, &e1);
-  const int rc = ssi_bm25_small_launch(s, s->d_small_ws, nq, q, kk, rt != SS_RT_TOPK, has_and, has_or, np_max, nt_max != np_max, p_doc, p_score, p_count, p_total,
-                                      (uint32_t*)(s->h_small + 64 * slot), seq, s->stream);
+  const int rc = ssi_bm25_small_launch(s, s->d_small_ws, nq, q, kk, sh, p_doc, p_score, p_count, p_total, (uint32_t*)(s->h_small + 64 * slot), seq, s->stream);
   ssi_prof_end(s, 0, s->stream, e0, e1);
   if (rc != SS_OK) {  // (the per-query state may be half-way: start the next launch from zero)
     (void)hipMemsetAsync(s->d_small_ws, 0, ssi_bm25_small_ws_bytes(), s->stream);

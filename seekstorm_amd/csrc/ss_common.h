@@ -392,9 +392,11 @@ inline uint32_t bm_kth_sel(uint32_t k) { return k == 0u ? 3u : k <= 10u ? 0u : k
 // bm25_small.hip
 size_t ssi_bm25_small_ws_bytes();
 bool ssi_bm25_small_serves(const ss_shard* s, uint32_t nq, uint32_t k, uint32_t np_max, uint32_t nn_max);
-int ssi_bm25_small_launch(ss_shard* s, void* ws, uint32_t nq, const ss_bm25_query* hq, uint32_t k, bool want_counts, bool has_and, bool has_or,
-                          uint32_t np_max, bool any_not, uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total,
-                          uint32_t* flag, uint32_t seq, hipStream_t st);
+// what a batch of the one-launch path holds: counts wanted; some query is an intersection of several DENSE terms / a union of two or more
+// dense lists (the counting workgroups); NOT terms; a term of the sparse tier; a phrase (naming a sparse term); the most DENSE scored terms
+struct ss_small_shape { bool want_counts, has_and, has_or, any_not, any_sparse, any_phrase; uint32_t np_max; };
+int ssi_bm25_small_launch(ss_shard* s, void* ws, uint32_t nq, const ss_bm25_query* hq, uint32_t k, const ss_small_shape& sh, uint32_t* out_doc,
+                          float* out_score, uint32_t* out_count, uint64_t* out_total, uint32_t* flag, uint32_t seq, hipStream_t st);
 
 // Opt-in to more than 64 KB of dynamic LDS is a per-device function attribute: set it once per (kernel, device) --
 // one process may hold shards on several GPUs (C++ host Index), and concurrent searches may race to be first.

@@ -237,3 +237,195 @@ def test_one_launch_on_an_image_with_several_indexed_fields(S, O):
         assert sh.one_launch_batches() == before
     finally:
         sh.close()
+
+
+# ------------------------------------------------------------------------------------------------ the tiered image (round 6)
+def _staged_tiered(S, sh, q, k, rt):
+    """the staged tiered pipeline by construction: a device-resident batch that declares sparse-tier terms (ops_mask bit 28) is split on
+    the host and never takes the one-launch path"""
+    return _dev_search(S, sh, q, k, rt, 1 << 28)
+
+
+def _same_answers(got, ref, rt, S, what):
+    assert np.array_equal(got[2], ref[2]), (what, "counts", got[2], ref[2])
+    for i in range(len(got[2])):
+        c = int(got[2][i])
+        assert np.array_equal(got[0][i][:c], ref[0][i][:c]) and np.array_equal(got[1][i][:c], ref[1][i][:c]), (what, i, got[0][i][:c], ref[0][i][:c])
+    if rt == S.ResultType.TopkCount:
+        assert np.array_equal(got[3], ref[3]), (what, "totals", got[3], ref[3])
+
+
+def test_one_launch_on_a_tiered_image(S, O):
+    """a realistic vocabulary: a few dense lists, rare terms in the SPARSE tier.  Small batches naming sparse terms take ONE launch (role 3
+    of bm25_small_kernel) -- unions and intersections of 1 .. 4 terms of either tier, NOT terms, tombstones, exact counts, k <= 32, batches
+    mixing tiered and all-dense queries: bit-identical to the staged tiered pipeline, and within tolerance of the oracle"""
+    rng = np.random.default_rng(61)
+    n_docs = 200_000
+    dens = [0.2, 0.09, 0.05, 0.02, 0.011, 0.004]
+    rare = [3000, 1400, 800, 300, 120, 60, 25, 9, 3, 1]
+    lens = np.clip(np.round(np.exp(np.log(120) + 0.6 * rng.standard_normal(n_docs))), 8, 2000).astype(np.int64)
+    lut = {int(x): int(O.lib().so_int_to_byte4(int(x))) for x in np.unique(lens)}
+    dl = np.array([lut[int(x)] for x in lens], np.uint8)
+    offs, docs, tfs = [0], [], []
+    for n in [int(x * n_docs) for x in dens] + rare:
+        docs.append(np.sort(rng.choice(n_docs, n, replace=False)).astype(np.uint32))
+        tfs.append(rng.geometric(0.5, n).clip(1, 200).astype(np.uint16))
+        offs.append(offs[-1] + n)
+    offs, docs, tfs = np.asarray(offs, np.uint64), np.concatenate(docs), np.concatenate(tfs)
+    nd, nt_all = len(dens), len(dens) + len(rare)
+    e = int(offs[nd])
+    sh = S.Shard(0)
+    sh.upload_lexical(n_docs, dl, offs[:nd + 1], docs[:e], tfs[:e])
+    assert sh.append_sparse(offs[nd:] - offs[nd], docs[e:], tfs[e:]) == nd
+    osh = O.Shard(n_docs, dl, offs, docs, tfs)
+    D, R = list(range(nd)), list(range(nd, nt_all))
+
+    def batch(n, n_terms, n_sparse, n_not_dense=0, n_not_sparse=0):
+        lists, nots = [], []
+        for _ in range(n):
+            sp = [int(x) for x in rng.choice(R, n_sparse + n_not_sparse, replace=False)]
+            de = [int(x) for x in rng.choice(D, n_terms - n_sparse + n_not_dense, replace=False)]
+            t = sp[:n_sparse] + de[:n_terms - n_sparse]
+            rng.shuffle(t)
+            lists.append([int(x) for x in t])
+            nots.append(de[n_terms - n_sparse:] + sp[n_sparse:])
+        return lists, nots
+
+    gone = np.unique(rng.integers(0, n_docs, n_docs // 40)).astype(np.uint64)
+    try:
+        for deleted in (False, True):
+            sh.set_deleted(gone if deleted else [])
+            osh.set_deleted([int(x) for x in gone] if deleted else [])
+            for qt, oop in ((S.QueryType.Union, O.OP_OR), (S.QueryType.Intersection, O.OP_AND)):
+                shapes = [(1, 1, 1, 0, 0), (1, 3, 1, 0, 0), (7, 2, 1, 0, 0), (64, 3, 1, 0, 0), (33, 4, 2, 0, 0), (5, 4, 4, 0, 0), (16, 3, 2, 2, 0), (9, 2, 2, 1, 0)]
+                if qt == S.QueryType.Intersection:
+                    shapes += [(6, 3, 1, 1, 1), (4, 2, 2, 0, 2)]  # a sparse NOT list where the sparse role meets it
+                for nq, nt, ns, nnd, nns in shapes:
+                    lists, nots = batch(nq, nt, ns, nnd, nns)
+                    if nq >= 7:  # mixed: some all-dense queries ride along
+                        for j in range(0, nq, 3):
+                            lists[j] = [int(x) for x in rng.choice(D, min(nt, 4), replace=False)]
+                            nots[j] = [t for t in nots[j] if t < nd and t not in lists[j]]
+                    q = sh.make_queries(lists, qt, nots)
+                    for k in (1, 10, 32):
+                        for rt in (S.ResultType.Topk, S.ResultType.TopkCount):
+                            before = sh.one_launch_batches()
+                            got = sh.search_lexical_batch(q, k, rt, reference_shortcuts=False)
+                            assert sh.one_launch_batches() == before + 1, ("not one launch", qt, nq, nt, ns, nnd, nns, k, rt)
+                            ref = _staged_tiered(S, sh, q, k, rt)
+                            _same_answers(got, ref, rt, S, (qt, nq, nt, ns, nnd, nns, k, rt, deleted))
+                            for i in range(min(nq, 4)):
+                                od, os_, otot = osh.search_exhaustive(lists[i], oop if len(lists[i]) > 1 else O.OP_OR, k, not_terms=nots[i])
+                                c = int(got[2][i])
+                                assert c == len(od) and np.allclose(got[1][i][:c], os_, rtol=1e-4), (qt, lists[i], nots[i], k)
+                                if rt == S.ResultType.TopkCount:
+                                    assert int(got[3][i]) == otot, (qt, lists[i], nots[i], int(got[3][i]), otot)
+                                if c < k:
+                                    assert set(got[0][i][:c].tolist()) == set(od.tolist())
+        # outside the shape: a union with a SPARSE NOT term, k = 33 -- answered by the staged pipeline
+        sh.set_deleted([]); osh.set_deleted([])
+        for lists, nots, k in (([[0, 1]], [[nd + 2]], 10), ([[0, nd]], [[]], 33)):
+            before = sh.one_launch_batches()
+            d, s_, c, t = sh.search_lexical_batch(sh.make_queries(lists, S.QueryType.Union, nots), k, reference_shortcuts=False)
+            assert sh.one_launch_batches() == before
+            od, os_, otot = osh.search_exhaustive(lists[0], O.OP_OR, k, not_terms=nots[0])
+            assert int(t[0]) == otot and int(c[0]) == len(od) and np.allclose(s_[0][:c[0]], os_, rtol=1e-4)
+    finally:
+        sh.close()
+
+
+def test_one_launch_phrases_naming_sparse_terms(S, O):
+    """phrases of <= 4 unique terms that name a sparse-tier term -- the common case of a quoted name -- are role 3 of the one launch: bit-identical
+    to the staged sparse phrase kernel, and the oracle's answers; NOT terms of either tier, tombstones, counts, mixed with set queries"""
+    from test_gpu_phrase import _corpus
+    n_docs = 120_000
+    dfs = [30_000, 22_000, 9_000, 500, 300, 1_500, 40]
+    nd = 3
+    plant = [([0, 3], 80), ([3, 4], 40), ([1, 3, 2], 60), ([5, 0, 5], 50), ([4, 4], 30), ([0, 1], 300), ([6, 5, 3, 0], 12), ([2, 5], 70), ([3, 0, 1, 3], 25)]
+    dl, offs, docs, tfs, positions = _corpus(O, n_docs, dfs, 23, plant)
+    e = int(offs[nd]); pe = int(tfs[:e].astype(np.int64).sum())
+    sh = S.Shard(0)
+    sh.upload_lexical(n_docs, dl, offs[:nd + 1], docs[:e], tfs[:e], positions[:pe])
+    assert sh.append_sparse(offs[nd:] - offs[nd], docs[e:], tfs[e:], positions=positions[pe:]) == nd
+    osh = O.Shard(n_docs, dl, offs, docs, tfs)
+    osh.set_positions(positions)
+    cases = [([0, 3], []), ([3, 0], []), ([3, 4], []), ([1, 3, 2], []), ([5, 0, 5], []), ([4, 4], []), ([6, 5, 3, 0], []), ([2, 5], []), ([3, 0, 1, 3], []),
+             ([0, 3], [1]), ([2, 5], [3, 0]), ([3, 4], [5]), ([5, 2], [])]
+    gone = list(range(3, n_docs, 61))
+    try:
+        for deleted in (False, True):
+            sh.set_deleted(gone if deleted else [])
+            osh.set_deleted(gone if deleted else [])
+            for sel in (list(range(len(cases))), [0], [6, 8]):
+                q = sh.make_queries([cases[i][0] for i in sel], S.QueryType.Phrase, [cases[i][1] for i in sel])
+                for k in (10, 32):
+                    for rt in (S.ResultType.TopkCount, S.ResultType.Topk):
+                        before = sh.one_launch_batches()
+                        got = sh.search_lexical_batch(q, k, rt, reference_shortcuts=False)
+                        assert sh.one_launch_batches() == before + 1, ("phrases: not one launch", sel, k, rt)
+                        ref = _dev_search(S, sh, q, k, rt, (1 << 28) | 16)
+                        _same_answers(got, ref, rt, S, ("phrase", sel, k, rt, deleted))
+                        for j, ci in enumerate(sel):
+                            ph, neg = cases[ci]
+                            uniq = list(dict.fromkeys(ph))
+                            od, os_, otot = osh.search_phrase(uniq, [uniq.index(w) for w in ph], n_docs)
+                            drop = set()
+                            for t in neg:
+                                drop |= set(docs[int(offs[t]):int(offs[t + 1])].tolist())
+                            keep = [x for x, d in enumerate(od.tolist()) if d not in drop]
+                            c = int(got[2][j])
+                            assert c == min(k, len(keep)) and np.allclose(got[1][j][:c], os_[keep][:k], rtol=1e-4), (ph, neg, k)
+                            if rt == S.ResultType.TopkCount:
+                                assert int(got[3][j]) == len(keep), (ph, neg, int(got[3][j]), len(keep))
+        # a batch mixing sparse phrases with set queries of both tiers: still one launch
+        sh.set_deleted([]); osh.set_deleted([])
+        qm = sh.make_queries([[0, 3], [0, 3], [3, 4], [0, 1], [3, 0]], [S.QueryType.Phrase, S.QueryType.Union, S.QueryType.Intersection, S.QueryType.Union, S.QueryType.Phrase])
+        before = sh.one_launch_batches()
+        tm = sh.search_lexical_batch(qm, 10, reference_shortcuts=False)[3]
+        assert sh.one_launch_batches() == before + 1
+        assert int(tm[0]) == osh.search_phrase([0, 3], [0, 1], 10)[2] and int(tm[1]) == osh.search_exhaustive([0, 3], O.OP_OR, 10)[2]
+        assert int(tm[2]) == osh.search_exhaustive([3, 4], O.OP_AND, 10)[2] and int(tm[3]) == osh.search_exhaustive([0, 1], O.OP_OR, 10)[2]
+        assert int(tm[4]) == osh.search_phrase([3, 0], [0, 1], 10)[2]
+    finally:
+        sh.close()
+
+
+def test_one_launch_on_a_tiered_image_with_several_indexed_fields(S, O):
+    """merged lists + a sparse tier of merged weights (BM25F): unions, intersections and phrases naming sparse terms in one launch"""
+    from test_gpu_parity import _fields_corpus, _check_topk
+    from test_gpu_phrase import _corpus_fields
+    n_docs, n_fields, boost = 60_000, 3, [2.0, 1.0, 0.5]
+    dfs = [18_000, 9_000, 5_000, 2_500, 400, 90, 30, 7]
+    nd = 4
+    plant = [([0, 4], 0, 30), ([4, 5], 2, 20), ([1, 4, 2], 1, 25), ([6, 0], 0, 10)]
+    dl, offs, docs, fields, tfs, positions = _corpus_fields(O, n_docs, n_fields, dfs, 31, plant, [(0, 1, 20)])
+    e = int(offs[nd]); pe = int(tfs[:e].astype(np.int64).sum())
+    sh = S.Shard(0)
+    sh.upload_lexical_fields(n_docs, dl, boost, offs[:nd + 1], docs[:e], fields[:e], tfs[:e], positions[:pe])
+    assert sh.append_sparse_fields(offs[nd:] - offs[nd], docs[e:], fields[e:], tfs[e:], positions=positions[pe:]) == nd
+    try:
+        cases = [([0, 4], []), ([6, 1, 2], []), ([5, 6], []), ([4], []), ([7, 5, 0], []), ([3, 5], [1]), ([4, 5, 0, 1], [2])]
+        for qt, oop in ((S.QueryType.Union, O.OP_OR), (S.QueryType.Intersection, O.OP_AND)):
+            q = sh.make_queries([c[0] for c in cases], qt, [c[1] for c in cases])
+            for k in (10, 32):
+                before = sh.one_launch_batches()
+                got = sh.search_lexical_batch(q, k, S.ResultType.TopkCount, reference_shortcuts=False)
+                assert sh.one_launch_batches() == before + 1
+                ref = _staged_tiered(S, sh, q, k, S.ResultType.TopkCount)
+                _same_answers(got, ref, S.ResultType.TopkCount, S, ("3f", qt, k))
+                for i, (pos, neg) in enumerate(cases):
+                    od, os_, otot, _ = O.search_fields_exhaustive(n_docs, dl, boost, offs, docs, fields, tfs, pos, oop if len(pos) > 1 else O.OP_OR, k, neg, ())
+                    assert int(got[3][i]) == otot, (qt, pos, neg, int(got[3][i]), otot)
+                    _check_topk(got[0][i], got[1][i], got[2][i], od, os_)
+        phrases = [[0, 4], [4, 5], [1, 4, 2], [6, 0]]
+        q = sh.make_queries(phrases, S.QueryType.Phrase)
+        before = sh.one_launch_batches()
+        got = sh.search_lexical_batch(q, 10, S.ResultType.TopkCount, reference_shortcuts=False)
+        assert sh.one_launch_batches() == before + 1
+        ref = _dev_search(S, sh, q, 10, S.ResultType.TopkCount, (1 << 28) | 16)
+        _same_answers(got, ref, S.ResultType.TopkCount, S, "3f phrases")
+        for i, ph in enumerate(phrases):
+            od, os_, otot = O.search_fields_phrase(n_docs, dl, boost, offs, docs, fields, tfs, positions, ph, list(range(len(ph))), 10)
+            assert int(got[3][i]) == otot >= 10 and np.allclose(got[1][i][:got[2][i]], os_, rtol=1e-4), (ph, int(got[3][i]), otot)
+    finally:
+        sh.close()

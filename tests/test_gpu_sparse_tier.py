@@ -432,6 +432,15 @@ def test_sparse_tier_on_an_image_with_several_indexed_fields(S, O):
     q = sh.make_queries([[0, 4]], S.QueryType.Union, field_filter=(1, 2))
     doc, score, cnt, tot = sh.search_lexical_batch(q, 10, S.ResultType.TopkCount, reference_shortcuts=False)
     assert [r.doc_id for r in one.results] == doc[0, :int(cnt[0])].tolist() and one.result_count_total == int(tot[0]) and int(cnt[0]) > 0
-    with pytest.raises(N.SeekStormHipError):  # 2^n - 1 sub-queries: at most 5 terms
-        sh.search_lexical_batch(sh.make_queries([[0, 4, 1, 2, 3, 5]], S.QueryType.Union, field_filter=[0]), 10)
+    # 6 .. 10 terms (63 .. 1023 sub-queries in one batch): composed behind the ABI since round 6 -- the range of union_docid_3
+    from test_gpu_shape_sweep import _gated_union_oracle, _check
+    per_term = {}
+    for t in range(len(dfs)):
+        d, s_, _, _ = O.search_fields_exhaustive(n_docs, dl, boost, offs, docs, fields, tfs, [t], O.OP_OR, n_docs, (), ())
+        a, b = int(offs[t]), int(offs[t + 1])
+        per_term[t] = (dict(zip(d.tolist(), s_.tolist())), docs[a:b], fields[a:b])
+    for terms, neg in (([0, 4, 1, 2, 3, 5], []), (list(range(10)), []), ([9, 8, 7, 6, 5, 4, 3], [0])):
+        doc, score, cnt, tot = sh.search_lexical_batch(sh.make_queries([terms], S.QueryType.Union, [neg], field_filter=[0]), 10, reference_shortcuts=False)
+        od, os_, otot = _gated_union_oracle(per_term, terms, neg, (0,), set(), 10)
+        _check(doc[0], score[0], cnt[0], tot[0], od, os_, otot, S.ResultType.TopkCount, 10, S, ("composed", terms, neg))
     sh.close()
