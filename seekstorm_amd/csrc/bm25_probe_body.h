@@ -295,7 +295,10 @@ __device__ __forceinline__ BmTop<KPL> pb_wave(
     for (int g = 0; g < G; g++) pn[g] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane4 + g * 256, (int)(x_begin * 4u), 0);
     for (uint32_t x = x_begin; x < x_end; x += 64u * G) {
       const float thr = cur_thr();
-      if (!is_and && J > 0 && k && SU[J] < thr * 0.99999f) break;  // this and all later terms are non-essential now
+      // this and all later terms are non-essential now.  J = 0: NO list is essential -- the threshold came from outside these lists (the
+      // sparse role of a tiered query, bm25_small.hip: its docs carry the rare terms' idf) and nothing they hold alone can reach it;
+      // (a single list under exact counts is read to its end: it counts its own matches)
+      if (!is_and && k && SU[J] < thr * 0.99999f && (J > 0 || !(count && nt == 1))) break;
       if constexpr (SKIP) if (skip_blocks) {
         // block-max skip: while the sub-block holding position x cannot contain a doc that reaches thr, jump to the next one
         bool moved = false;

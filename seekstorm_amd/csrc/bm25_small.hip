@@ -32,11 +32,15 @@
 constexpr uint32_t SM_MAX_Q = 64;   // queries per launch (their 60-byte forms must fit the 4 KB of kernel arguments)
 constexpr uint32_t SM_MAX_PB = 64;  // workgroups (of 8 partitions) per query: the final tournament plays one list per lane
 constexpr uint32_t SM_MAX_CB = 20;  // counting workgroups per query
+constexpr uint32_t SM_MAX_SB = 4;   // role-3 workgroups per query (a sparse list is walked 64 postings per wave and step)
 #ifndef SM_G
 #define SM_G 8  // chunks of 64 driver postings per group (bm25_probe_body.h)
 #endif
 #ifndef SM_ARRIVE_ACQREL
 #define SM_ARRIVE_ACQREL 0  // 1: acquire / release at agent scope on the arrival counter (see the arrival below)
+#endif
+#ifndef SM_DBG_SKIP
+#define SM_DBG_SKIP 0  // experiment builds (tools/probes/tiered_roles.sh): bit 0 = role 1 does nothing, bit 1 = role 3 does nothing -- where a launch's time goes
 #endif
 
 constexpr uint32_t SM_SPARSE = 0x80000000u;  // pb_squery::term: a list of the SPARSE tier (low bits: its index), else the dense list's row
@@ -81,7 +85,7 @@ struct PbSmall {
   const void* sp_pos;
   const unsigned long long* sp_pos_end;
   uint32_t del_words, n_sub, n_terms, nq, PB, CB, k, count, seq;
-  uint32_t SB;                    // 1: every query has a role-3 workgroup (those without a sparse term leave at once)
+  uint32_t SB;                    // role-3 workgroups per query (those of a query without a sparse term leave at once)
 };
 static_assert(sizeof(PbSmall) <= 4096, "kernel arguments are limited to 4 KB");
 
@@ -126,6 +130,26 @@ __device__ __forceinline__ uint32_t sm_pick8(const uint32_t (&a)[8], uint32_t i)
   return r;
 }
 
+// A doc's posting in a DENSE list through the probe index (every dense list of a one-launch batch has a row): the doc's 64-doc bit
+// record says whether the list holds it and how many postings of the group stand before it, the group's z where its first posting lies --
+// three dependent loads where the binary search inside the (term, sub-block) segment (bm25_find.h dense_find) takes ten.  Returns the
+// posting's weight code (0 = absent); *slot = its index inside the term's image (what d_pos_off is indexed by).
+__device__ __forceinline__ uint32_t sm_probe_find(const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base,
+                                                 const uint2* __restrict__ probe, const uint32_t* __restrict__ probe_z,
+                                                 const uint32_t* __restrict__ probe_row, uint32_t n_sub, uint32_t row, uint32_t doc, bool lanes,
+                                                 uint32_t* slot = nullptr) {
+  const size_t rb = (size_t)probe_row[row] * n_sub * (BM_SUB / 64);
+  const uint32_t gidx = (doc >> BM_SUB_LOG2) * (uint32_t)(BM_SUB / 64) + ((doc & (BM_SUB - 1)) >> 6);
+  const uint2 r = probe[rb + (lanes ? gidx : 0u)];
+  const u64 bits = ((u64)r.y << 32) | r.x;
+  const bool hit = lanes && ((bits >> (doc & 63u)) & 1ull);
+  if (!hit) return 0u;
+  const uint32_t at = probe_z[rb + gidx] + (uint32_t)__popcll(bits & ((1ull << (doc & 63u)) - 1ull));
+  if (slot) *slot = at;
+  const uint32_t p = post[term_base[row] * 4ull + at];
+  return p >> 13 ? p >> 13 : 1u;
+}
+
 // ---- role 3, set queries: the body of bm25_sparse_kernel (bm25_sparse.hip has the story) for a query held in scalars -- tt: scored
 // terms then NOT terms (SM_SPARSE | index, or a dense row), idf: of the scored terms (several indexed fields: already scaled).
 // A union walks every sparse list of the query (a doc is scored under the FIRST one that holds it), an intersection its shortest one;
@@ -133,10 +157,12 @@ __device__ __forceinline__ uint32_t sm_pick8(const uint32_t (&a)[8], uint32_t i)
 // the others).
 template <int KPL>
 __device__ __forceinline__ BmTop<KPL> sm_sparse_wave(const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base,
-                                                    const uint32_t* __restrict__ sub_off, uint32_t n_sub, const unsigned long long* __restrict__ sp_base,
+                                                    const uint2* __restrict__ probe, const uint32_t* __restrict__ probe_z,
+                                                    const uint32_t* __restrict__ probe_row, uint32_t n_sub, const unsigned long long* __restrict__ sp_base,
                                                     const unsigned long long* __restrict__ sp_post, const uint32_t (&tt)[8], const float (&idf)[4],
                                                     uint32_t np, uint32_t n_not, bool is_and, uint32_t k, const uint32_t* __restrict__ del,
-                                                    uint32_t del_words, int w, int lane) {
+                                                    uint32_t del_words, uint32_t gw /* this wave among the query's role-3 waves */, uint32_t n_gw,
+                                                    uint32_t* tau_q, int lane) {
   BmTop<KPL> T;
 #pragma unroll
   for (int r = 0; r < KPL; r++) T.keys[r] = 0ull;
@@ -158,7 +184,7 @@ __device__ __forceinline__ BmTop<KPL> sm_sparse_wave(const uint32_t* __restrict_
     if (!(ts & SM_SPARSE)) continue;
     const uint32_t si = ts & ~SM_SPARSE;
     const unsigned long long b0 = sp_base[si], b1 = sp_base[si + 1];
-    for (unsigned long long x = b0 + (unsigned)w * 64u; x < b1; x += 64ull * PB_WAVES) {
+    for (unsigned long long x = b0 + (unsigned long long)gw * 64u; x < b1; x += 64ull * n_gw) {
       const bool live0 = x + (unsigned)lane < b1;
       const unsigned long long e = live0 ? sp_post[x + lane] : 0ull;
       const uint32_t doc = (uint32_t)e;
@@ -179,7 +205,7 @@ __device__ __forceinline__ BmTop<KPL> sm_sparse_wave(const uint32_t* __restrict_
             if (p < sp_base[j + 1] && (uint32_t)sp_post[p] == doc) code = (uint32_t)(sp_post[p] >> 32);
             if (code && !is_and && (uint32_t)t < s && (uint32_t)t < np) live = false;  // scored under the earlier sparse list
           } else {
-            code = dense_find(post, term_base, sub_off, n_sub, term, doc);
+            code = sm_probe_find(post, term_base, probe, probe_z, probe_row, n_sub, term, doc, live);
             if (code && (uint32_t)t < np) in_dense = true;
           }
         }
@@ -200,7 +226,9 @@ __device__ __forceinline__ BmTop<KPL> sm_sparse_wave(const uint32_t* __restrict_
           if ((uint32_t)t < np && ((pres >> t) & 1u)) score = fmaf(idf[t], wv[t], score);
         u64 key = (live && score > 0.f) ? (((u64)__float_as_uint(score) << 32) | (u64)(0xFFFFFFFFu - doc)) : 0ull;
         key = key > T.worst ? key : 0ull;
-        if (__ballot(key != 0ull)) T = bm_offer_lane_keys<KPL>(T, key, k, nullptr);
+        // (tau_q: the scores here are FULL scores -- once k docs stand in this wave's list, its k-th is a score k docs of the query reach,
+        // and the dense partitions, whose own threshold knows partial scores only, stop reading what cannot reach it)
+        if (__ballot(key != 0ull)) T = bm_offer_lane_keys<KPL>(T, key, k, tau_q);
       }
     }
   }
@@ -213,12 +241,14 @@ __device__ __forceinline__ BmTop<KPL> sm_sparse_wave(const uint32_t* __restrict_
 // (7 = a place inside an n-gram key).  PT = uint32_t: several indexed fields -- merged lists, positions tagged with their field.
 template <int KPL, typename PT>
 __device__ __forceinline__ BmTop<KPL> sm_phrase_wave(const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base,
-                                                    const uint32_t* __restrict__ sub_off, uint32_t n_sub, const unsigned long long* __restrict__ sp_base,
+                                                    const uint2* __restrict__ probe, const uint32_t* __restrict__ probe_z,
+                                                    const uint32_t* __restrict__ probe_row, uint32_t n_sub, const unsigned long long* __restrict__ sp_base,
                                                     const unsigned long long* __restrict__ sp_post, const PT* __restrict__ sp_pos,
                                                     const unsigned long long* __restrict__ sp_pos_end, const PT* __restrict__ pos,
                                                     const uint32_t* __restrict__ pos_off, const unsigned long long* __restrict__ pos_base,
                                                     const uint32_t (&tt)[8], const float (&idf)[4], uint32_t np, uint32_t n_not, uint32_t plen,
-                                                    unsigned long long places, uint32_t k, const uint32_t* __restrict__ del, uint32_t del_words, int w, int lane) {
+                                                    unsigned long long places, uint32_t k, const uint32_t* __restrict__ del, uint32_t del_words,
+                                                    uint32_t gw, uint32_t n_gw, int lane) {
   BmTop<KPL> T;
 #pragma unroll
   for (int r = 0; r < KPL; r++) T.keys[r] = 0ull;
@@ -239,7 +269,7 @@ __device__ __forceinline__ BmTop<KPL> sm_phrase_wave(const uint32_t* __restrict_
   auto wslot = [&](uint32_t i) -> uint32_t { return (uint32_t)(places >> (3u * i)) & 7u; };
   const uint32_t si = td & ~SM_SPARSE;
   const unsigned long long b0 = sp_base[si], b1 = sp_base[si + 1];
-  for (unsigned long long x = b0 + (unsigned)w * 64u; x < b1; x += 64ull * PB_WAVES) {
+  for (unsigned long long x = b0 + (unsigned long long)gw * 64u; x < b1; x += 64ull * n_gw) {
     const bool live0 = x + (unsigned)lane < b1;
     const unsigned long long e = live0 ? sp_post[x + lane] : 0ull;
     const uint32_t doc = (uint32_t)e;
@@ -269,7 +299,7 @@ __device__ __forceinline__ BmTop<KPL> sm_phrase_wave(const uint32_t* __restrict_
         }
       } else {
         uint32_t slot = 0u;
-        code = dense_find(post, term_base, sub_off, n_sub, term, doc, &slot);
+        code = sm_probe_find(post, term_base, probe, probe_z, probe_row, n_sub, term, doc, live, &slot);
         if (code) {
           const uint32_t* po = pos_off + term_base[term] * 4ull;
           const uint32_t st = slot ? po[slot - 1u] : 0u;
@@ -290,7 +320,7 @@ __device__ __forceinline__ BmTop<KPL> sm_phrase_wave(const uint32_t* __restrict_
         const uint32_t l = term & ~SM_SPARSE;
         const unsigned long long p = sp_find(sp_post, sp_base[l], sp_base[l + 1], doc);
         if (p < sp_base[l + 1] && (uint32_t)sp_post[p] == doc) live = false;
-      } else if (dense_find(post, term_base, sub_off, n_sub, term, doc)) {
+      } else if (sm_probe_find(post, term_base, probe, probe_z, probe_row, n_sub, term, doc, live)) {
         live = false;
       }
     }
@@ -360,8 +390,11 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 4) bm25_small_kernel(const PbSm
   // invalidates the XCD's L2, and one per wave made a batch of 64 TopkCount queries take 595 us instead of 230.
   auto ldk = [&](const u64* p) -> u64 { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   auto stk = [&](u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-  const bool role_list = b < nq * PB || (TIER && b >= nq * (PB + CB));  // roles 1 and 3 end in a list of the query
-  const uint32_t qi = b < nq * PB ? b % nq : b < nq * (PB + CB) ? (b - nq * PB) % nq : (b - nq * (PB + CB)) % nq;
+  // block order: role 3 first (its lists are short and its k-th score is what lets the dense partitions stop early), then roles 1, 2
+  const uint32_t b1_ = b - nq * SB;  // (meaningful from role 1 on)
+  const bool role3 = TIER && b < nq * SB, role1 = !role3 && b1_ < nq * PB;
+  const bool role_list = role3 || role1;  // roles 1 and 3 end in a list of the query
+  const uint32_t qi = role3 ? b % nq : role1 ? b1_ % nq : (b1_ - nq * PB) % nq;
   // the query's scalars; its DENSE view (the scored terms of the dense tier, compacted in query order) is what roles 1 and 2 read
   const uint32_t np = fz->q[qi].n_terms & 0xFFu, qop = fz->q[qi].op, n_not = bm_q_nnot(qop);
   uint32_t dm = 0u;  // bit t: scored term t is dense
@@ -376,17 +409,21 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 4) bm25_small_kernel(const PbSm
   const bool tiered = TIER && nd != np;                                                  // names a sparse scored term: role 3 answers (part of) it
   const bool q_and = (bm_q_op(qop) == SS_OP_INTERSECTION || bm_q_op(qop) == SS_OP_PHRASE) && np > 1u;
   const bool dense_active = nd != 0u && !(tiered && (q_and || bm_q_op(qop) == SS_OP_PHRASE));  // an intersection with a sparse term is role 3's alone
+  // Who counts a union's dense part (TopkCount)?  Two or more dense lists: role 2, from the bit records.  ONE dense list counts itself
+  // while it is read -- unless reading it to its end is the price: under tombstones (a bitmap lookup per posting) or beside a sparse role
+  // (whose threshold would let the list stop early): then role 2 counts it as well, and the list is free to stop.
+  const bool count_by_bits = bm_q_op(qop) == SS_OP_UNION && (nd >= 2u || (nd == 1u && CB != 0u && (tiered || (FILT && fz->del != nullptr))));
   if (role_list) {
     BmTop<KPL> T;
 #pragma unroll
     for (int r = 0; r < KPL; r++) T.keys[r] = 0ull;
     T.worst = 0ull; T.wsc = -1.0f; T.matched = 0;
     uint32_t slot;  // the list of the query this workgroup writes
-    if (b < nq * PB) {
+    if (role1) {
       // ---- role 1: eight partitions of query qi
-      const uint32_t pb = b / nq, part = pb * PB_WAVES + (uint32_t)w;
+      const uint32_t pb = b1_ / nq, part = pb * PB_WAVES + (uint32_t)w;
       slot = pb;
-      if (dense_active) {
+      if (dense_active && !(SM_DBG_SKIP & 1)) {
         PbQueryRegs<NT> Q;
         Q.nt_ = nd;
         Q.op_ = (nd > 1u ? bm_q_op(qop) : (uint32_t)SS_OP_UNION) | (n_not << 8);  // a query of ONE term is always a union (bm_expand_kernel)
@@ -412,12 +449,14 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 4) bm25_small_kernel(const PbSm
 #pragma unroll
         for (int j = 0; j < 4; j++) Q.not_[j] = FILT ? fz->q[qi].term[min(np + (uint32_t)j, 7u)] : 0u;
         T = pb_wave<NT, KPL, FILT, false, true, SM_G, true>(fz->post, fz->term_base, fz->sub_off, fz->probe, fz->probe_z, fz->probe_row, fz->umax, nullptr, nullptr,
-                                                   Q, fz->tau, fz->del, fz->del_words, fz->n_sub, fz->n_terms, PB * PB_WAVES, k, fz->count & 1u, qi, part, w, lane, fz->q[qi].thr0,
+                                                   Q, fz->tau, fz->del, fz->del_words, fz->n_sub, fz->n_terms, PB * PB_WAVES, k, (fz->count & 1u) && !count_by_bits ? 1u : 0u, qi, part, w, lane, fz->q[qi].thr0,
                                                    (fz->count & 4u) && k <= 64u && PB * PB_WAVES >= k ? fz->bests + (size_t)qi * (SM_MAX_PB * PB_WAVES) : nullptr);
       }
     } else {
-      // ---- role 3: the sparse lists of query qi (a query without a sparse term has none: its workgroup leaves, nobody waits for it)
-      slot = PB;
+      // ---- role 3: a share of the sparse lists of query qi (a query without a sparse term has none: its workgroups leave, nobody
+      // waits for them)
+      const uint32_t sbi = b / nq, gw = sbi * PB_WAVES + (uint32_t)w, n_gw = SB * PB_WAVES;
+      slot = PB + sbi;
       if (!tiered) return;
       if constexpr (TIER != 0) {
         uint32_t tt[8];
@@ -427,14 +466,16 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 4) bm25_small_kernel(const PbSm
 #pragma unroll
         for (int t = 0; t < 4; t++) idf[t] = fz->q[qi].idf[t];
         const uint32_t* del = FILT ? fz->del : nullptr;
-        if (bm_q_op(qop) != SS_OP_PHRASE) {
-          T = sm_sparse_wave<KPL>(fz->post, fz->term_base, fz->sub_off, fz->n_sub, fz->sp_base, fz->sp_post, tt, idf, np, n_not, q_and, k, del, fz->del_words, w, lane);
+        if (SM_DBG_SKIP & 2) {
+        } else if (bm_q_op(qop) != SS_OP_PHRASE) {
+          T = sm_sparse_wave<KPL>(fz->post, fz->term_base, fz->probe, fz->probe_z, fz->probe_row, fz->n_sub, fz->sp_base, fz->sp_post, tt, idf, np, n_not, q_and, k, del,
+                                  fz->del_words, gw, n_gw, (q_and || !k) ? nullptr : fz->tau + (size_t)qi * BM_TAU_STRIDE, lane);
         } else if constexpr (TIER >= 2) {
           typedef typename std::conditional<TIER == 3, uint32_t, uint16_t>::type PT;
           const unsigned long long places = (unsigned long long)fz->q[qi].places | ((unsigned long long)((qop >> 16) & 0x3Fu) << 30);
-          T = sm_phrase_wave<KPL, PT>(fz->post, fz->term_base, fz->sub_off, fz->n_sub, fz->sp_base, fz->sp_post, (const PT*)fz->sp_pos, fz->sp_pos_end,
+          T = sm_phrase_wave<KPL, PT>(fz->post, fz->term_base, fz->probe, fz->probe_z, fz->probe_row, fz->n_sub, fz->sp_base, fz->sp_post, (const PT*)fz->sp_pos, fz->sp_pos_end,
                                       (const PT*)fz->pos, fz->pos_off, fz->pos_base, tt, idf, np, n_not, (fz->q[qi].n_terms >> 8) & 0xFFu, places, k, del,
-                                      fz->del_words, w, lane);
+                                      fz->del_words, gw, n_gw, lane);
         }
       }
     }
@@ -458,6 +499,10 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 4) bm25_small_kernel(const PbSm
       const u64 m = pb_tournament(lane < PB_WAVES, k, [&](uint32_t rank) -> u64 { return rank < KS ? lds_ld64(ob + rank * 8u) : 0ull; }, lane, PbNoSkip{}, 0u);
       stk(mine + lane, m);  // ranks >= k: 0 (KPL = 1: k <= 32 < 64)
       if (KPL == 2) stk(mine + 64 + lane, 0ull);
+      if (TIER && role3 && !q_and) {  // k docs with FULL scores: their k-th is a score k docs of the query reach (see sm_sparse_wave)
+        const u64 kth = rdlane64(m, (int)k - 1);
+        if (kth && lane == 0) bm_publish_tau(fz->tau + (size_t)qi * BM_TAU_STRIDE, __uint_as_float((uint32_t)(kth >> 32)));
+      }
     } else {
 #pragma unroll 1
       for (int ww = 1; ww < PB_WAVES; ww++) {
@@ -475,9 +520,9 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 4) bm25_small_kernel(const PbSm
   } else {
     // ---- role 2: exact count of a union of >= 2 DENSE lists, popcounted from the bit records (bm25_union_count_kernel's job; the
     // bodies above count intersections, single lists and what the sparse lists add themselves)
-    const uint32_t c = b - nq * PB;
+    const uint32_t c = b1_ - nq * PB;
     const uint32_t cpart = (c / nq) * PB_WAVES + (uint32_t)w, CP = CB * PB_WAVES;
-    if (bm_q_op(qop) == SS_OP_UNION && nd >= 2u) {
+    if (count_by_bits) {
       const uint32_t n_groups = fz->n_sub * (uint32_t)(BM_SUB / 64);
       const uint32_t g_begin = (uint32_t)(((u64)n_groups * cpart) / CP), g_end = (uint32_t)(((u64)n_groups * (cpart + 1u)) / CP);
       const uint2* rows[8];
@@ -549,8 +594,8 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 4) bm25_small_kernel(const PbSm
   if (lane == 0) prev = atomicAdd(&fz->arrive[qi], 1u);
 #endif
   prev = __builtin_amdgcn_readfirstlane(prev);
-  if (prev + 1u != PB + CB + (tiered ? 1u : 0u)) return;
-  const uint32_t n_lists = PB + (tiered ? 1u : 0u);
+  if (prev + 1u != PB + CB + (tiered ? SB : 0u)) return;
+  const uint32_t n_lists = PB + (tiered ? SB : 0u);
   const u64* lists = fz->part_keys + (size_t)qi * LPQ * KS;
   uint32_t* o_doc = fz->out_doc + (size_t)qi * k;
   float* o_score = fz->out_score + (size_t)qi * k;
@@ -559,10 +604,18 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 4) bm25_small_kernel(const PbSm
     const u64* lst = lists + (size_t)min((uint32_t)lane, n_lists - 1u) * KS;
     // a tiered union: the dense entry (a partial score) of a doc the sparse list holds takes no place -- the sparse entry carries the
     // full score (bm25_tier_merge_kernel's rule); lane j holds entry j of the sparse list (k <= 32: one key per lane)
-    const u64 sk = (TIER && tiered) ? ldk(lists + (size_t)PB * KS + (uint32_t)lane) : 0ull;
-    auto skip = [&](u64 m) -> bool { return TIER && tiered && __ballot(sk != 0ull && (uint32_t)sk == (uint32_t)m && sk != m) != 0ull; };
+    // (<= SM_MAX_SB sparse lists; a doc stands in at most one of them -- each workgroup of role 3 walks its own postings)
+    u64 sk[SM_MAX_SB];
+#pragma unroll
+    for (int i = 0; i < (int)SM_MAX_SB; i++) sk[i] = (TIER && tiered && (uint32_t)i < SB) ? ldk(lists + (size_t)(PB + (uint32_t)i) * KS + (uint32_t)lane) : 0ull;
+    auto skip = [&](u64 m) -> bool {
+      bool dup = false;
+#pragma unroll
+      for (int i = 0; i < (int)SM_MAX_SB; i++) dup = dup || (sk[i] != 0ull && (uint32_t)sk[i] == (uint32_t)m && sk[i] != m);
+      return TIER && tiered && __ballot(dup) != 0ull;
+    };
     const u64 m = pb_tournament((uint32_t)lane < n_lists, k, [&](uint32_t rank) -> u64 { return rank < KS ? ldk(lst + rank) : 0ull; }, lane, skip,
-                                (TIER && tiered) ? 64u : 0u);
+                                (TIER && tiered) ? 64u * SM_MAX_SB : 0u);
     if ((uint32_t)lane < k) {
       o_doc[lane] = m ? 0xFFFFFFFFu - (uint32_t)m : SS_NO_DOC;
       o_score[lane] = m ? __uint_as_float((uint32_t)(m >> 32)) : 0.f;
@@ -702,7 +755,16 @@ int ssi_bm25_small_launch(ss_shard* s, void* ws, uint32_t nq, const ss_bm25_quer
   a.sp_pos = s->d_sp_pos;
   a.sp_pos_end = (const unsigned long long*)s->d_sp_pos_end;
   const int TIER = sh.any_phrase ? (L > 1 ? 3 : 2) : sh.any_sparse ? 1 : 0;
-  a.SB = TIER ? 1u : 0u;
+  // role-3 workgroups per query: a step of a wave is ~10 dependent loads for 64 postings -- the longest sparse list of the batch in one or
+  // two steps per wave (a workgroup = 512 postings per step)
+  a.SB = 0u;
+  if (TIER) {
+    uint64_t longest = 0;
+    for (uint32_t i = 0; i < nq; i++)
+      for (uint32_t t = 0; t < hq[i].n_terms; t++)
+        if (hq[i].term[t] >= n_dense) { const uint32_t j = hq[i].term[t] - n_dense; longest = std::max<uint64_t>(longest, s->h_sp_base[j + 1] - s->h_sp_base[j]); }
+    a.SB = (uint32_t)std::min<uint64_t>(SM_MAX_SB, std::max<uint64_t>(1u, (longest + 767u) / 768u));
+  }
   // bit 2: the query's threshold from the partitions' best keys (pb_publish_kth_best).  From 16 queries per call on: 64 queries 164 -> 105 us,
   // 32 queries 112 -> 87 us; a call of 1 / 8 queries -- 512 partitions per query, a handful of groups each -- pays 6 / 13 us for the
   // re-computations and gains nothing (tools/probes/small_fused.py, profiles/r5_small_kth_best.log)

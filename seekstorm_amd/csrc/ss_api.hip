@@ -1630,6 +1630,14 @@ static int bm25_shape_of(const ss_shard* s, const ss_bm25_query& Q, uint32_t kk,
       if (Q.phrase_seq[j] >= np && Q.phrase_seq[j] != SS_PHRASE_SKIP) return SS_EINVAL;
     if (L > 1 && !s->bm_merged) return SS_ENOTSUP;  // phrases of several indexed fields run over the merged lists' field-tagged positions
     if (np > 6 || kk > 128) *shape = SH_GALLOP_PHRASE;
+    // a rationed vocabulary: the phrase kernel of the probe index needs a row for EVERY list it reads and has no scan to fall back on -- a
+    // phrase over a list without one takes the generic kernel, which needs none (round 5 built pool rows for it first and refused the
+    // batch whose phrases alone exceeded the pool); the pool stays with the queries that gain from it
+    if (!any_sparse && s->bm_probe_rows != 0 && s->bm_probe_rows < s->bm_n_terms)
+      for (uint32_t t = 0; t < all; t++) {
+        const uint32_t v = Q.term[t] * L + (L - 1u);
+        if (s->h_probe_row[v] == BM_NO_PROBE_ROW && s->h_df[v] != 0) *shape = SH_GALLOP_PHRASE;
+      }
     return SS_OK;
   }
   if (filt && op == SS_OP_UNION && np > 1) {  // a union under a field filter: the gated scan (<= 7 dense terms), else composed
@@ -1815,66 +1823,79 @@ static int bm25_search_host_queries(ss_shard* s, uint32_t nq, const ss_bm25_quer
 }
 
 // ---- the one-launch path of small batches (bm25_small.hip).  Pinned block of the shard: three 64-byte flag slots (0: direct calls,
-// 1 / 2: the coalescer's lanes), then answer staging for direct calls (64 queries x k <= 128).
-constexpr size_t SM_H_DOC = 256, SM_H_SCORE = SM_H_DOC + 64 * 128 * 4, SM_H_COUNT = SM_H_SCORE + 64 * 128 * 4, SM_H_TOTAL = SM_H_COUNT + 64 * 4,
-                 SM_H_BYTES = SM_H_TOTAL + 64 * 8;
+// 1 / 2: the coalescer's lanes), then answer staging for direct calls (SM_H_QUERIES queries x k <= 128).
+constexpr uint32_t SM_H_QUERIES = 256;  // queries of ONE host-pointer call the path takes (launches of <= 64)
+constexpr size_t SM_H_DOC = 256, SM_H_SCORE = SM_H_DOC + SM_H_QUERIES * 128 * 4, SM_H_COUNT = SM_H_SCORE + SM_H_QUERIES * 128 * 4, SM_H_TOTAL = SM_H_COUNT + SM_H_QUERIES * 4,
+                 SM_H_BYTES = SM_H_TOTAL + SM_H_QUERIES * 8;
+// Does ONE query fit the one-launch path?  What it takes: unions and intersections of <= 4 scored and <= 4 NOT terms over one list per
+// term, no field filter, no all_terms_frequent mark; terms of either tier (a sparse term: k <= 32, and a sparse NOT term only where the
+// sparse role meets it -- an intersection that has a sparse scored term); phrases of <= 4 unique terms that name a sparse term (all-dense
+// phrases keep their staged kernel, bm25_phrase.hip).  Cheap: host tables only, nothing of the probe pool is touched.
+// sh / nn_max: the query's part in its batch's shape.  An invalid query does not fit: the staged path reports it.
+static bool small_query_fits(const ss_shard* s, const ss_bm25_query& Q, uint32_t kk, ss_small_shape* sh, uint32_t* nn_max) {
+  const uint32_t L = s->bm_n_fields, n_dense = s->bm_n_terms / L, RF = bm_real_fields(s);
+  const uint32_t np = Q.n_terms, nn = bm_q_nnot(Q.op), op = bm_q_op(Q.op);
+  if (np == 0 || np > 4 || nn > 4 || op > (uint32_t)SS_OP_PHRASE || bm_q_all_frequent(Q.op) || (RF > 1 && bm_q_field_filter(Q.op)) ||
+      (bm_q_field_filter(Q.op) >> RF))  // (a field the image does not have: the staged path reports it)
+    return false;
+  uint32_t nd = 0;
+  bool sp_scored = false, sp_not = false;
+  for (uint32_t t = 0; t < np + nn; t++) {
+    if (Q.term[t] >= n_dense + s->sp_n) return false;
+    if (t < np && !(Q.idf[t] > 0.0f)) return false;
+    for (uint32_t u = 0; u < t; u++)
+      if (Q.term[u] == Q.term[t]) return false;
+    if (Q.term[t] >= n_dense) { if (t < np) sp_scored = true; else sp_not = true; }
+    else if (t < np) nd++;
+  }
+  const bool is_and = op == SS_OP_INTERSECTION && np > 1;
+  bool phrase = false;
+  if (op == SS_OP_PHRASE) {
+    if (!sp_scored || Q.phrase_len < 2 || Q.phrase_len > (uint32_t)SS_MAX_PHRASE || Q.phrase_seq[0] >= np) return false;
+    for (uint32_t j = 1; j < Q.phrase_len; j++)
+      if (Q.phrase_seq[j] >= np && Q.phrase_seq[j] != SS_PHRASE_SKIP) return false;
+    if (!s->d_sp_pos_end || s->sp_pos_elem != (L > 1 ? 4u : 2u) || (nd && (L > 1 ? !s->d_pos32 : !s->d_pos))) return false;
+    phrase = true;
+  } else if (sp_not && !(is_and && sp_scored)) {
+    return false;  // a sparse NOT list the dense roles would have to probe: the staged path's per-query exclusion bitmap
+  }
+  if (sp_scored || sp_not) {
+    if (kk > 32 || (L > 1 && !(s->bm_merged && s->h_boost.size() == L))) return false;
+    sh->any_sparse = true;
+  }
+  sh->any_phrase |= phrase;
+  const bool dense_roles = nd != 0 && !(sp_scored && (is_and || phrase));  // (an intersection with a sparse term: the sparse role alone)
+  if (dense_roles) {
+    if (is_and && nd > 1) sh->has_and = true;
+    // (counting workgroups: unions of two or more dense lists; ONE dense list where reading it to its end would be the price of counting
+    // it in passing -- under tombstones, or beside a sparse role whose threshold lets it stop early; bm25_small.hip count_by_bits)
+    else if (nd > 1 || ((sp_scored || s->n_deleted) && !phrase)) sh->has_or = true;
+    sh->np_max = std::max(sh->np_max, nd);
+  }
+  sh->any_not |= nn != 0;
+  *nn_max = std::max(*nn_max, nn);
+  return true;
+}
+
 // Tries the batch on the one-launch path: *handled = false (and SS_OK) when it is not of that shape -- the staged pipeline then runs it.
 // p_* = pinned buffers the kernel answers into (null: the shard's own staging).  Called under s->mu.
 static int bm25_small_try(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, uint32_t n_filters, uint32_t slot,
                           uint32_t* p_doc, float* p_score, uint32_t* p_count, uint64_t* p_total, bool* handled, uint32_t* seq_out) {
   *handled = false;
-  if (n_filters != 0 || kk == 0 || !ssi_bm25_small_serves(s, nq, kk, 1, 0)) return SS_OK;
-  // The batch's shape, cheap parts first (nothing of the probe pool is touched for a batch the staged pipeline will run
-  // anyway).  What the one launch takes: unions and intersections of <= 4 scored and <= 4 NOT terms over one list per term, no field
-  // filter, no all_terms_frequent mark; terms of either tier (a sparse term: k <= 32, and its NOT terms only where the sparse role
-  // meets them -- an intersection that has a sparse scored term); phrases of <= 4 unique terms that name a sparse term.
-  ss_small_shape sh{rt != SS_RT_TOPK, false, false, false, false, false, 0u};
-  uint32_t nn_max = 0;
+  // up to SM_H_QUERIES queries: launches of <= 64 back to back on the stream (each answers into its own rows; the flag shows the last
+  // launch's number once ITS answers are in place, and the launches of one stream finish in order).  A 96-query call of the tiered image
+  // was six launches and seven copies of the staged pipeline: 402 us; two launches: see profiles/r6_real_format_1m.log
+  if (n_filters != 0 || kk == 0 || nq == 0 || nq > SM_H_QUERIES || !ssi_bm25_small_serves(s, std::min<uint32_t>(nq, 64u), kk, 1, 0)) return SS_OK;
   {
-    const uint32_t L = s->bm_n_fields, n_dense = s->bm_n_terms / L, RF = bm_real_fields(s);
-    for (uint32_t i = 0; i < nq; i++) {
-      const uint32_t np = q[i].n_terms, nn = bm_q_nnot(q[i].op), op = bm_q_op(q[i].op);
-      if (np == 0 || np > 4 || nn > 4 || op > (uint32_t)SS_OP_PHRASE || bm_q_all_frequent(q[i].op) || (RF > 1 && bm_q_field_filter(q[i].op))) return SS_OK;
-      uint32_t nd = 0;
-      bool sp_scored = false, sp_not = false;
-      for (uint32_t t = 0; t < np + nn; t++) {
-        if (q[i].term[t] >= n_dense + s->sp_n) return SS_OK;  // (an invalid term: the staged path reports it)
-        if (t < np && !(q[i].idf[t] > 0.0f)) return SS_OK;
-        for (uint32_t u = 0; u < t; u++)
-          if (q[i].term[u] == q[i].term[t]) return SS_OK;
-        if (q[i].term[t] >= n_dense) { if (t < np) sp_scored = true; else sp_not = true; }
-        else if (t < np) nd++;
-      }
-      const bool is_and = op == SS_OP_INTERSECTION && np > 1;
-      if (op == SS_OP_PHRASE) {
-        // phrases: the sparse role's (its shortest sparse list drives); all-dense phrases keep their staged kernel (bm25_phrase.hip)
-        if (!sp_scored || q[i].phrase_len < 2 || q[i].phrase_len > (uint32_t)SS_MAX_PHRASE || q[i].phrase_seq[0] >= np) return SS_OK;
-        for (uint32_t j = 1; j < q[i].phrase_len; j++)
-          if (q[i].phrase_seq[j] >= np && q[i].phrase_seq[j] != SS_PHRASE_SKIP) return SS_OK;
-        if (!s->d_sp_pos_end || s->sp_pos_elem != (L > 1 ? 4u : 2u) || (nd && (L > 1 ? !s->d_pos32 : !s->d_pos))) return SS_OK;
-        sh.any_phrase = true;
-      } else if (sp_not && !(is_and && sp_scored)) {
-        return SS_OK;  // a sparse NOT list the dense roles would have to probe: the staged path's per-query exclusion bitmap
-      }
-      if (sp_scored || sp_not) {
-        if (kk > 32) return SS_OK;
-        sh.any_sparse = true;
-      }
-      const bool dense_roles = nd != 0 && !(sp_scored && (is_and || op == SS_OP_PHRASE));  // (an intersection with a sparse term: the sparse role alone)
-      if (dense_roles) {
-        if (is_and && nd > 1) sh.has_and = true;
-        else if (nd > 1) sh.has_or = true;
-        sh.np_max = std::max(sh.np_max, nd);
-      }
-      sh.any_not |= nn != 0;
-      nn_max = std::max(nn_max, nn);
-    }
-    if ((sh.any_sparse || sh.any_phrase) && L > 1 && !(s->bm_merged && s->h_boost.size() == L)) return SS_OK;
+    ss_small_shape sh{};
+    uint32_t nn_max = 0;
+    for (uint32_t i = 0; i < nq; i++)
+      if (!small_query_fits(s, q[i], kk, &sh, &nn_max)) return SS_OK;
+    if (!ssi_bm25_small_serves(s, std::min<uint32_t>(nq, 64u), kk, sh.np_max, nn_max)) return SS_OK;
   }
   SS_TRY(ssi_bm25_ensure_probe_rows(s, nq, q, s->stream));
   for (uint32_t i = 0; i < nq; i++)  // every dense list the batch reads has a probe row now, or the scans take the batch
     if (!query_lists_probed_dense(s, q[i])) return SS_OK;
-  if (!ssi_bm25_small_serves(s, nq, kk, sh.np_max, nn_max)) return SS_OK;
   SS_HIP(hipSetDevice(s->device));
   if (!s->d_small_ws) {
     SS_HIP(hipMalloc(&s->d_small_ws, ssi_bm25_small_ws_bytes()));
@@ -1885,18 +1906,27 @@ static int bm25_small_try(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint
     SS_HIP(hipHostMalloc((void**)&s->h_small, SM_H_BYTES, hipHostMallocDefault));
     memset(s->h_small, 0, SM_H_BYTES);
   }
-  const uint32_t seq = ++s->small_seq ? s->small_seq : ++s->small_seq;  // never 0
   if (!p_doc) {
     p_doc = (uint32_t*)(s->h_small + SM_H_DOC); p_score = (float*)(s->h_small + SM_H_SCORE);
     p_count = (uint32_t*)(s->h_small + SM_H_COUNT); p_total = (uint64_t*)(s->h_small + SM_H_TOTAL);
   }
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  ssi_prof_begin(s, 0, s->stream, &e0, &e1);
-  const int rc = ssi_bm25_small_launch(s, s->d_small_ws, nq, q, kk, sh, p_doc, p_score, p_count, p_total, (uint32_t*)(s->h_small + 64 * slot), seq, s->stream);
-  ssi_prof_end(s, 0, s->stream, e0, e1);
-  if (rc != SS_OK) {  // (the per-query state may be half-way: start the next launch from zero)
-    (void)hipMemsetAsync(s->d_small_ws, 0, ssi_bm25_small_ws_bytes(), s->stream);
-    return rc;
+  uint32_t seq = 0;
+  for (uint32_t c0 = 0; c0 < nq; c0 += 64u) {
+    const uint32_t n = std::min<uint32_t>(64u, nq - c0);
+    ss_small_shape sh{rt != SS_RT_TOPK, false, false, false, false, false, 0u};
+    uint32_t nn_max = 0;
+    for (uint32_t i = 0; i < n; i++) (void)small_query_fits(s, q[c0 + i], kk, &sh, &nn_max);  // this launch's own shape
+    seq = ++s->small_seq ? s->small_seq : ++s->small_seq;  // never 0
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ssi_prof_begin(s, 0, s->stream, &e0, &e1);
+    const int rc = ssi_bm25_small_launch(s, s->d_small_ws, n, q + c0, kk, sh, p_doc + (size_t)c0 * kk, p_score + (size_t)c0 * kk, p_count + c0, p_total + c0,
+                                        (uint32_t*)(s->h_small + 64 * slot), seq, s->stream);
+    ssi_prof_end(s, 0, s->stream, e0, e1);
+    if (rc != SS_OK) {  // (the per-query state may be half-way: start the next launch from zero; launches already queued finish first)
+      (void)hipStreamSynchronize(s->stream);
+      (void)hipMemsetAsync(s->d_small_ws, 0, ssi_bm25_small_ws_bytes(), s->stream);
+      return rc;
+    }
   }
   s->small_launches++;
   *seq_out = seq;
@@ -1945,11 +1975,35 @@ static int bm25_search_direct(ss_shard* s, uint32_t nq, const ss_bm25_query* q, 
                               const ss_facet_filter* filters, uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total) {
   std::lock_guard<std::mutex> g(s->mu);  // before check_queries: it reads the image's host-side tables (an upload replaces them)
   if (!s->d_post) return SS_ESTATE;
-  const uint32_t kk = rt == SS_RT_COUNT ? 0 : k;
-  {
-    bool handled = false;
-    uint32_t seq = 0;
-    SS_TRY(bm25_small_try(s, nq, q, kk, rt, n_filters, 0, nullptr, nullptr, nullptr, nullptr, &handled, &seq));
+  const uint32_t kk = rt == SS_RT_COUNT ? 0 : k, kw = std::max<uint32_t>(kk, 1u);
+  // by shape, like a coalesced batch (bm25_search_direct_lane): the queries that fit the one-launch path take it, the staged pipeline
+  // runs the rest -- one all-dense phrase among a caller's 96 queries used to send all of them down the staged tiered pipeline
+  static thread_local std::vector<ss_bm25_query> qs;
+  static thread_local std::vector<uint32_t> row_of;
+  uint32_t n_fit = nq;
+  bool split = false;
+  // (a rationed vocabulary: one pass over the whole batch deals the pool's rows -- no split)
+  if (kk && nq > 1 && n_filters == 0 && !(s->bm_probe_rows != 0 && s->bm_probe_rows < s->bm_n_terms)) {
+    ss_small_shape sh{};
+    uint32_t nn_max = 0;
+    std::vector<uint8_t> fits(nq);
+    n_fit = 0;
+    for (uint32_t i = 0; i < nq; i++) n_fit += (fits[i] = (n_fit < SM_H_QUERIES && small_query_fits(s, q[i], kk, &sh, &nn_max)) ? 1 : 0);
+    if (n_fit != 0 && n_fit != nq) {
+      split = true;
+      qs.resize(nq); row_of.resize(nq);
+      uint32_t a = 0, b = n_fit;
+      for (uint32_t i = 0; i < nq; i++) { const uint32_t at = fits[i] ? a++ : b++; row_of[i] = at; qs[at] = q[i]; }
+    } else {
+      n_fit = nq;
+    }
+  }
+  const ss_bm25_query* qq = split ? qs.data() : q;
+  bool handled = false;
+  uint32_t seq = 0;
+  SS_TRY(bm25_small_try(s, n_fit, qq, kk, rt, n_filters, 0, nullptr, nullptr, nullptr, nullptr, &handled, &seq));
+  const uint32_t r0 = handled ? n_fit : 0u, nr = nq - r0;  // what the staged pipeline runs: the rest, or (no launch) everything
+  if (!split) {  // the whole call one way or the other: straight into the caller's arrays
     if (handled) {
       SS_TRY(bm25_small_wait(s, 0, seq, true));
       memcpy(out_doc, s->h_small + SM_H_DOC, (size_t)nq * kk * sizeof(uint32_t));
@@ -1958,66 +2012,110 @@ static int bm25_search_direct(ss_shard* s, uint32_t nq, const ss_bm25_query* q, 
       memcpy(out_total, s->h_small + SM_H_TOTAL, (size_t)nq * sizeof(uint64_t));
       return SS_OK;
     }
-  }
-  SS_TRY(bm25_search_host_queries(s, nq, q, kk, rt, n_filters, filters));
-  if (kk) {
-    SS_HIP(hipMemcpyAsync(out_doc, s->d_out_doc, (size_t)nq * kk * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-    SS_HIP(hipMemcpyAsync(out_score, s->d_out_score, (size_t)nq * kk * sizeof(float), hipMemcpyDeviceToHost, s->stream));
-  }
-  SS_HIP(hipMemcpyAsync(out_count, s->d_out_count, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-  SS_HIP(hipMemcpyAsync(out_total, s->d_out_total, (size_t)nq * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
-  SS_HIP(hipStreamSynchronize(s->stream));
-  return SS_OK;
-}
-
-// the same for a coalesced batch on a lane: the shard mutex is held while the batch is ENQUEUED (queries from the lane's pinned staging,
-// kernels, results back into it, the lane's event behind them -- all on s->stream); the wait for the event happens outside, so the next
-// lane's leader can enqueue behind this batch at once
-// the answers of a coalesced batch straight into the leader's PINNED buffers: one small kernel writing over PCIe instead of four
-// device-to-host copies queued one behind the other (each a DMA submission of ~8 us for a few KB)
-__global__ void co_pack_kernel(const uint32_t* __restrict__ d_doc, const float* __restrict__ d_score, const uint32_t* __restrict__ d_count,
-                               const unsigned long long* __restrict__ d_total, uint32_t nq, uint32_t kk, uint32_t* __restrict__ h_doc,
-                               float* __restrict__ h_score, uint32_t* __restrict__ h_count, unsigned long long* __restrict__ h_total) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nq * kk) { h_doc[i] = d_doc[i]; h_score[i] = d_score[i]; }
-  if (i < nq) { h_count[i] = d_count[i]; h_total[i] = d_total[i]; }
-}
-static int bm25_search_direct_lane(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k, uint32_t rt, uint32_t* out_doc, float* out_score,
-                                   uint32_t* out_count, uint64_t* out_total, hipEvent_t ev, uint32_t lane_slot) {
-  static const int pack = [] { const char* e = getenv("SS_COALESCE_PACK"); return e ? atoi(e) : 0; }();  // measured: no difference -- off
-  const uint64_t t_in = g_co_trace_on ? co_now_us() : 0;
-  bool small = false;
-  uint32_t small_seq = 0;
-  {
-    std::lock_guard<std::mutex> g(s->mu);
-    if (!s->d_post) return SS_ESTATE;
-    const uint32_t kk = rt == SS_RT_COUNT ? 0 : k;
-    // the lane's buffers are pinned: the one-launch path answers straight into them (flag slot 1 / 2 by the lane's event)
-    SS_TRY(bm25_small_try(s, nq, q, kk, rt, 0, lane_slot, out_doc, out_score, out_count, out_total, &small, &small_seq));
-    if (!small) {
-    SS_TRY(bm25_search_host_queries(s, nq, q, kk, rt, 0, nullptr));
-    if (pack) {
-      const uint32_t n = std::max<uint32_t>(nq * kk, nq);
-      co_pack_kernel<<<(n + 255) / 256, 256, 0, s->stream>>>(s->d_out_doc, s->d_out_score, s->d_out_count, (const unsigned long long*)s->d_out_total, nq, kk,
-                                                            out_doc, out_score, out_count, (unsigned long long*)out_total);
-      SS_HIP(hipGetLastError());
-      SS_HIP(hipEventRecord(ev, s->stream));
-    } else {
+    SS_TRY(bm25_search_host_queries(s, nq, q, kk, rt, n_filters, filters));
     if (kk) {
       SS_HIP(hipMemcpyAsync(out_doc, s->d_out_doc, (size_t)nq * kk * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
       SS_HIP(hipMemcpyAsync(out_score, s->d_out_score, (size_t)nq * kk * sizeof(float), hipMemcpyDeviceToHost, s->stream));
     }
     SS_HIP(hipMemcpyAsync(out_count, s->d_out_count, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     SS_HIP(hipMemcpyAsync(out_total, s->d_out_total, (size_t)nq * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
-    SS_HIP(hipEventRecord(ev, s->stream));
+    SS_HIP(hipStreamSynchronize(s->stream));
+    return SS_OK;
+  }
+  // split: the staged part behind the launch on the same stream, its answers into rows [r0, nq) of a host copy in run order
+  static thread_local std::vector<uint32_t> t_doc, t_cnt;
+  static thread_local std::vector<float> t_score;
+  static thread_local std::vector<uint64_t> t_tot;
+  t_doc.resize((size_t)nq * kw); t_score.resize((size_t)nq * kw); t_cnt.resize(nq); t_tot.resize(nq);
+  int rc = SS_OK;
+  if (nr) {
+    rc = bm25_search_host_queries(s, nr, qq + r0, kk, rt, 0, nullptr);
+    if (rc == SS_OK) {
+      SS_HIP(hipStreamSynchronize(s->stream));  // (the launch ahead of it on the stream is done as well)
+      SS_HIP(hipMemcpy(t_doc.data() + (size_t)r0 * kw, s->d_out_doc, (size_t)nr * kk * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      SS_HIP(hipMemcpy(t_score.data() + (size_t)r0 * kw, s->d_out_score, (size_t)nr * kk * sizeof(float), hipMemcpyDeviceToHost));
+      SS_HIP(hipMemcpy(t_cnt.data() + r0, s->d_out_count, (size_t)nr * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      SS_HIP(hipMemcpy(t_tot.data() + r0, s->d_out_total, (size_t)nr * sizeof(uint64_t), hipMemcpyDeviceToHost));
     }
+  }
+  if (handled) {  // (waited for even when the staged part failed: the kernel writes the shard's pinned staging)
+    const int rw = bm25_small_wait(s, 0, seq, true);
+    if (rc == SS_OK) rc = rw;
+    if (rc == SS_OK) {
+      memcpy(t_doc.data(), s->h_small + SM_H_DOC, (size_t)n_fit * kk * sizeof(uint32_t));
+      memcpy(t_score.data(), s->h_small + SM_H_SCORE, (size_t)n_fit * kk * sizeof(float));
+      memcpy(t_cnt.data(), s->h_small + SM_H_COUNT, (size_t)n_fit * sizeof(uint32_t));
+      memcpy(t_tot.data(), s->h_small + SM_H_TOTAL, (size_t)n_fit * sizeof(uint64_t));
+    }
+  }
+  if (rc != SS_OK) return rc;
+  for (uint32_t i = 0; i < nq; i++) {
+    const size_t r = row_of[i];
+    memcpy(out_doc + (size_t)i * kk, t_doc.data() + r * kw, (size_t)kk * sizeof(uint32_t));
+    memcpy(out_score + (size_t)i * kk, t_score.data() + r * kw, (size_t)kk * sizeof(float));
+    out_count[i] = t_cnt[r];
+    out_total[i] = t_tot[r];
+  }
+  return SS_OK;
+}
+
+// the same for a coalesced batch on a lane: the shard mutex is held while the batch is ENQUEUED (queries from the lane's pinned staging,
+// kernels, results back into it, the lane's event behind them -- all on s->stream); the wait for the event happens outside, so the next
+// lane's leader can enqueue behind this batch at once.
+// A coalesced batch is whoever happened to call at the same time: ONE query outside the one-launch shape (a phrase of dense words only,
+// five terms, ...) must not send sixty-three others down the staged pipeline.  The batch is therefore split by shape: the queries that
+// fit take the one launch (answers in rows 0 .. of the lane's pinned buffers), the rest the staged pipeline (rows behind them); row_of[i]
+// = where query i's answer stands.
+static int bm25_search_direct_lane(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k, uint32_t rt, uint32_t* out_doc, float* out_score,
+                                   uint32_t* out_count, uint64_t* out_total, hipEvent_t ev, uint32_t lane_slot, std::vector<uint32_t>& row_of) {
+  const uint64_t t_in = g_co_trace_on ? co_now_us() : 0;
+  bool small = false, staged = false;
+  uint32_t small_seq = 0;
+  row_of.resize(nq);
+  for (uint32_t i = 0; i < nq; i++) row_of[i] = i;
+  {
+    std::lock_guard<std::mutex> g(s->mu);
+    if (!s->d_post) return SS_ESTATE;
+    const uint32_t kk = rt == SS_RT_COUNT ? 0 : k, kw = std::max<uint32_t>(kk, 1u);
+    std::vector<ss_bm25_query> qs;  // the batch in the order it runs in: the fitting queries first
+    uint32_t n_fit = 0;
+    if (kk && nq > 1 && !(s->bm_probe_rows != 0 && s->bm_probe_rows < s->bm_n_terms)) {  // (a rationed vocabulary: one pass deals the pool's rows)
+      ss_small_shape sh{};
+      uint32_t nn_max = 0;
+      std::vector<uint8_t> fits(nq);
+      for (uint32_t i = 0; i < nq; i++) n_fit += (fits[i] = (n_fit < SM_H_QUERIES && small_query_fits(s, q[i], kk, &sh, &nn_max)) ? 1 : 0);  // (what one call takes)
+      if (n_fit != 0 && n_fit != nq) {
+        qs.resize(nq);
+        uint32_t a = 0, b = n_fit;
+        for (uint32_t i = 0; i < nq; i++) { const uint32_t at = fits[i] ? a++ : b++; row_of[i] = at; qs[at] = q[i]; }
+        q = qs.data();
+      } else {
+        n_fit = nq;  // all of one kind: one attempt on the whole batch
+      }
+    } else {
+      n_fit = nq;
+    }
+    // the lane's buffers are pinned: the one-launch path answers straight into them (flag slot 1 / 2 by the lane's event)
+    SS_TRY(bm25_small_try(s, n_fit, q, kk, rt, 0, lane_slot, out_doc, out_score, out_count, out_total, &small, &small_seq));
+    const uint32_t r0 = small ? n_fit : 0u, nr = nq - r0;  // what the staged pipeline runs: the rest, or (no launch) everything
+    if (nr) {
+      staged = true;
+      SS_TRY(bm25_search_host_queries(s, nr, q + r0, kk, rt, 0, nullptr));
+      if (kk) {
+        SS_HIP(hipMemcpyAsync(out_doc + (size_t)r0 * kw, s->d_out_doc, (size_t)nr * kk * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+        SS_HIP(hipMemcpyAsync(out_score + (size_t)r0 * kw, s->d_out_score, (size_t)nr * kk * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+      }
+      SS_HIP(hipMemcpyAsync(out_count + r0, s->d_out_count, (size_t)nr * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+      SS_HIP(hipMemcpyAsync(out_total + r0, s->d_out_total, (size_t)nr * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
+      SS_HIP(hipEventRecord(ev, s->stream));
     }
   }
   const uint64_t te = g_co_trace_on ? co_now_us() : 0;
-  if (small) SS_TRY(bm25_small_wait(s, lane_slot, small_seq, false));
-  else SS_HIP(hipEventSynchronize(ev));
+  int rc = SS_OK;
+  if (small) rc = bm25_small_wait(s, lane_slot, small_seq, false);
+  if (staged && hipEventSynchronize(ev) != hipSuccess && rc == SS_OK) rc = SS_EDEVICE;  // (both waited for whatever the first says: the buffers are the lane's)
   if (g_co_trace_on) { g_co_trace.enqueue += te - t_in; g_co_trace.linger += co_now_us() - te; }
-  return SS_OK;
+  return rc;
 }
 
 // ------------------------------------------------------------------ coalescing of concurrent callers (group commit)
@@ -2116,8 +2214,9 @@ int co_run_batch(ss_shard* s, ss_coalescer& co, bool lexical, const std::vector<
   }
   const uint64_t tr1 = g_co_trace_on ? co_now_us() : 0;
   int rc;
+  static thread_local std::vector<uint32_t> row_of;  // lexical: the row of the lane's buffers that holds query i's answer (bm25_search_direct_lane)
   if (lexical)
-    rc = bm25_search_direct_lane(s, total, (const ss_bm25_query*)h_q, kk, f->rt, h_doc, h_sc, h_cnt, h_tot, ln.ev, 1u + lane_ix);
+    rc = bm25_search_direct_lane(s, total, (const ss_bm25_query*)h_q, kk, f->rt, h_doc, h_sc, h_cnt, h_tot, ln.ev, 1u + lane_ix, row_of);
   else
     rc = vec_search_host(s, total, h_q, f->elem, f->qscale ? h_qs : nullptr, kk, f->thr, nullptr, h_doc, h_sc, h_cnt, h_tot, nullptr);
   if (rc != SS_OK) return rc;
@@ -2125,12 +2224,13 @@ int co_run_batch(ss_shard* s, ss_coalescer& co, bool lexical, const std::vector<
   at = 0;
   for (ss_co_req* r : batch) {
     for (uint32_t i = 0; i < r->nq; i++) {
+      const size_t row = lexical ? row_of[at + i] : at + i;
       if (r->k) {
-        memcpy(r->out_doc + (size_t)i * r->k, h_doc + (size_t)(at + i) * kk, (size_t)r->k * sizeof(uint32_t));
-        memcpy(r->out_score + (size_t)i * r->k, h_sc + (size_t)(at + i) * kk, (size_t)r->k * sizeof(float));
+        memcpy(r->out_doc + (size_t)i * r->k, h_doc + row * kk, (size_t)r->k * sizeof(uint32_t));
+        memcpy(r->out_score + (size_t)i * r->k, h_sc + row * kk, (size_t)r->k * sizeof(float));
       }
-      r->out_count[i] = std::min(h_cnt[at + i], r->k);
-      r->out_total[i] = h_tot[at + i];
+      r->out_count[i] = std::min(h_cnt[row], r->k);
+      r->out_total[i] = h_tot[row];
     }
     r->rc = SS_OK;
     at += r->nq;

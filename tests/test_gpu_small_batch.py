@@ -83,7 +83,7 @@ def test_one_launch_equals_staged_pipeline_and_oracle(S, O, world, shape):
     gone = np.unique(rng.integers(0, N_DOCS, N_DOCS // 50)).astype(np.uint64) if shape == "tombstones" else np.zeros(0, np.uint64)
     sh.set_deleted(gone); osh.set_deleted([int(x) for x in gone])
     try:
-        for nq, nt, k in ((1, 1, 10), (1, 3, 10), (7, 2, 1), (64, 3, 10), (33, 4, 32), (5, 3, 33), (16, 2, 100), (3, 4, 128)):
+        for nq, nt, k in ((1, 1, 10), (1, 3, 10), (7, 2, 1), (64, 3, 10), (33, 4, 32), (5, 3, 33), (16, 2, 100), (3, 4, 128), (65, 3, 10), (200, 2, 10), (256, 3, 32)):
             n_not = 2 if shape.endswith("_not") else 0
             if nt + n_not > len(DFS):
                 continue
@@ -122,8 +122,9 @@ def test_one_launch_equals_staged_pipeline_and_oracle(S, O, world, shape):
 def test_batches_outside_the_shape_take_the_staged_pipeline(S, O, world):
     sh, osh = world
     rng = np.random.default_rng(3)
-    # 65 queries, 5 scored terms, k = 129, a Count request: all answered, none by the one-launch path
-    for lists, k, rt in ((_queries(rng, 65, 3)[0], 10, S.ResultType.Topk), (_queries(rng, 4, 5)[0], 10, S.ResultType.Topk),
+    # 5 scored terms, k = 129, a Count request: all answered, none by the one-launch path (a call of more than 256 queries: its first 256
+    # fitting queries take it, launches of 64 back to back, the rest the staged pipeline -- checked below)
+    for lists, k, rt in ((_queries(rng, 4, 5)[0], 10, S.ResultType.Topk),
                          (_queries(rng, 4, 3)[0], 129, S.ResultType.Topk), (_queries(rng, 4, 3)[0], 10, S.ResultType.Count)):
         q = sh.make_queries(lists, S.QueryType.Union)
         before = sh.one_launch_batches()
@@ -135,6 +136,17 @@ def test_batches_outside_the_shape_take_the_staged_pipeline(S, O, world):
                 assert int(t[i]) == otot
             else:
                 assert int(c[i]) == len(od) and np.allclose(s[i][:c[i]], os_, rtol=1e-4)
+    # a call split by shape: 300 queries (256 by launches of 64, 44 staged), every fifth one of 5 terms (staged) -- answers in the callers' order
+    lists = _queries(rng, 300, 3)[0]
+    for j in range(0, 300, 5):
+        lists[j] = _queries(rng, 1, 5)[0][0]
+    q = sh.make_queries(lists, S.QueryType.Union)
+    before = sh.one_launch_batches()
+    d, s, c, t = sh.search_lexical_batch(q, 10, S.ResultType.TopkCount, reference_shortcuts=False)
+    assert sh.one_launch_batches() == before + 1
+    for i in list(range(0, 12)) + [255, 256, 257, 298, 299]:
+        od, os_, otot = osh.search_exhaustive(lists[i], O.OP_OR, 10)
+        assert int(t[i]) == otot and int(c[i]) == len(od) and np.allclose(s[i][:c[i]], os_, rtol=1e-4), i
     # an invalid query keeps its error code on this path too (term id out of range)
     from seekstorm_amd import _native as N
     q = sh.make_queries([[0, 1]], S.QueryType.Union)
@@ -173,7 +185,7 @@ def test_threshold_seeds_never_cost_a_result(S, O):
         for k in (1, 9, 10, 11, 99, 100, 101, 128):
             q = sh.make_queries(lists, S.QueryType.Union)
             seeded = sh.search_lexical_batch(q, k, S.ResultType.TopkCount, reference_shortcuts=False)       # one launch, host seeds
-            big = sh.make_queries(lists * 6, S.QueryType.Union)                                           # 72 queries: staged, device seeds
+            big = sh.make_queries(lists * 22, S.QueryType.Union)                                          # 264 queries: staged, device seeds
             staged = sh.search_lexical_batch(big, k, S.ResultType.TopkCount, reference_shortcuts=False)
             sh.set_strategy(N.BM25_EXHAUSTIVE)
             exh = sh.search_lexical_batch(q, k, S.ResultType.TopkCount, reference_shortcuts=False)

@@ -35,7 +35,7 @@ def vector_bin(rows, dim):
 
 
 def run(n_docs=1_000_000, vocab=1_000_000, dim=64, n_queries=96, dense_min=2000, k=10, seed=11, parity=True, callers=64, seconds=1.0, log=None,
-        n_fields=1, boost=None):
+        n_fields=1, boost=None, probe=False):
     """n_fields > 1: the same rehearsal over an index with several indexed fields (title / body / tags spans of every doc; BM25F with
     `boost`, multi-field records and n-gram keys in the file, the sparse tier's merged lists, phrases inside one field, field-filtered ANDs)"""
     import seekstorm_amd as S
@@ -155,6 +155,33 @@ def run(n_docs=1_000_000, vocab=1_000_000, dim=64, n_queries=96, dense_min=2000,
                                   "algorithmic_bytes_per_call": ab_, "ms_per_call": dt_ / reps * 1e3,
                                   "clock": "host clock around the whole call (copies in / out, every kernel of the tiered search): at "
                                            f"{len(q)} queries of a {n_docs}-doc shard a call is launch latency, not bandwidth -- the fraction says how far"}}
+    if probe:  # where a small call's time goes: call sizes x result types, tiered and all-dense queries apart (host clock, Python caller)
+        pr = {}
+        for name, q, qs in (("and2", q_and, ands), ("or3", q_or, ors), ("phrase", q_ph, None)):
+            sp = np.array([any(int(t) >= n_dense for t in q["term"][i][:int(q["n_terms"][i])]) for i in range(len(q))])
+            for label, sel in (("all", np.arange(len(q))), ("tiered", np.nonzero(sp)[0]), ("dense", np.nonzero(~sp)[0])):
+                for nb in (1, 8, 32, 64):
+                    if len(sel) < nb:
+                        continue
+                    for rt in (S.ResultType.Topk, S.ResultType.TopkCount):
+                        if isinstance(probe, str) and probe not in f"{name}/{label}/{nb}/{rt.name}":
+                            continue
+                        qq = q[sel[:nb]]
+                        sh.search_lexical_batch(qq, k, rt, reference_shortcuts=False)
+                        b0 = sh.one_launch_batches()
+                        sh.profile(True)
+                        sh.profile_read(0)
+                        t0 = time.perf_counter()
+                        for _ in range(200):
+                            sh.search_lexical_batch(qq, k, rt, reference_shortcuts=False)
+                        dt_ = time.perf_counter() - t0
+                        pn, pms = sh.profile_read(0)
+                        sh.profile(False)
+                        pr[f"{name}/{label}/{nb}/{rt.name}"] = {"us_per_call": dt_ / 200 * 1e6, "one_launch": sh.one_launch_batches() - b0,
+                                                               "kernel_us": pms / max(pn, 1) * 1e3, "kernels": pn}
+        out["probe"] = pr
+        for kk_, v in pr.items():
+            say(kk_, round(v["us_per_call"], 1), v["one_launch"], "kernel us", round(v["kernel_us"], 1), v["kernels"])
     res["vec"] = sh.search_vector_batch(qv, k)
     # hybrid: the OR query + the vector, RRF over the two top-k lists (search.rs:1962-2035)
     hyb = [S.merge_results(S.SearchMode.Hybrid, (res["or3"][0][i][:res["or3"][2][i]].astype(np.uint64), res["or3"][1][i][:res["or3"][2][i]]),
@@ -290,7 +317,28 @@ def run(n_docs=1_000_000, vocab=1_000_000, dim=64, n_queries=96, dense_min=2000,
                                             N.RT_TOPKCOUNT, o5), "ssh_bench_concurrent")
             conc[name] = {"value": o5[0] / o5[1], "unit": "queries/s", "threads": callers, "latency_us_p50": o5[2], "latency_us_p99": o5[3], "errors": int(o5[4])}
             assert o5[4] == 0, f"real format, concurrent {name}: {int(o5[4])} searches failed"
+        # ... phrases whose entries are plain keys (an n-gram key arrives at the mirror as its component ids: the batch legs above), and the
+        # reference's call shape alone: ONE caller, one query per call -- submit -> results on the host (VERDICT r5 "next" 2: <= 80 us)
+        plain = [[e[0] for e in q] for q in phrases if all(len(tid(e[0])) == 1 for e in q)]
+        single_caller = {}
+        for name, mode, qs, qt, thr in (("phrase", N.MODE_LEXICAL, plain, S.QueryType.Phrase, callers), ("and2", N.MODE_LEXICAL, ands, S.QueryType.Intersection, 1),
+                                        ("or3", N.MODE_LEXICAL, ors, S.QueryType.Union, 1), ("phrase", N.MODE_LEXICAL, plain, S.QueryType.Phrase, 1)):
+            if not qs:
+                continue
+            flat = np.array([single(r) for q in qs for r in q], np.uint32)
+            toff = np.zeros(len(qs) + 1, np.uint32)
+            toff[1:] = np.cumsum([len(q) for q in qs])
+            o5 = (C.c_double * 5)()
+            before = sh.one_launch_batches()
+            N.check(HL.ssh_bench_concurrent(ixp, mode, thr, float(seconds), len(qs), flat.ctypes.data, toff.ctypes.data, qv.ctypes.data, int(qt), k,
+                                            N.RT_TOPKCOUNT, o5), "ssh_bench_concurrent")
+            rec = {"value": o5[0] / o5[1], "unit": "queries/s", "threads": thr, "latency_us_p50": o5[2], "latency_us_p99": o5[3], "errors": int(o5[4]),
+                   "queries": len(qs), "one_launch_batches": sh.one_launch_batches() - before}
+            assert o5[4] == 0, f"real format, {thr} caller(s) {name}: {int(o5[4])} searches failed"
+            (conc if thr != 1 else single_caller)[name] = rec
         HL.ssh_index_destroy(ixp)
+        out["single_caller"] = single_caller
+        say("single caller", single_caller)
         out["concurrent_callers"] = conc
         say("concurrent", conc)
     sh.close()
@@ -305,5 +353,6 @@ if __name__ == "__main__":
     sys.path.insert(0, ROOT)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
     nf = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    r = run(n_docs=n, vocab=n, n_fields=nf, log=lambda *a: print(*a, flush=True))
+    r = run(n_docs=n, vocab=n, n_fields=nf, log=lambda *a: print(*a, flush=True), probe=(sys.argv[sys.argv.index("--probe") + 1] if "--probe" in sys.argv and len(sys.argv) > sys.argv.index("--probe") + 1 else "--probe" in sys.argv), callers=0 if "--probe" in sys.argv else 64,
+            parity="--probe" not in sys.argv)
     print(json.dumps(r))
