@@ -267,6 +267,14 @@ __global__ void bm_expand_kernel(const ss_bm25_query* __restrict__ q, bm_vquery*
   }
 }
 
+// a threshold seed from outside the batch's own lists (ss_common.h d_ext_seed): the query's shared threshold starts at least there
+__global__ void bm_ext_seed_kernel(const float* __restrict__ seed, uint32_t nq, uint32_t* __restrict__ tau) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  const uint32_t b = __float_as_uint(seed[i]);  // (scores are positive floats: their bit patterns order like unsigned integers)
+  if (seed[i] > 0.f && b > tau[(size_t)i * BM_TAU_STRIDE]) tau[(size_t)i * BM_TAU_STRIDE] = b;
+}
+
 // ---------------------------------------------------------------- threshold seeds: the K-th largest weight of every list
 // A union's score is a sum of positive terms, so the K docs holding a list's K largest weights all score at least idf * (the K-th
 // largest weight): the query's k-th best score is at least the largest such product over its lists (k <= K) -- known before a single
@@ -541,6 +549,11 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
                                                     getenv("SS_BM25_KEEP_TAU") && atoi(getenv("SS_BM25_KEEP_TAU")) ? 1u : 0u,
                                                     (s->n_deleted || s->del_per_query || k == 0) ? nullptr : s->d_kthw, bm_kth_sel(k),
                                                     (scan16m || (pruned && staged_kthb)) ? bufA : nullptr, P, KS);
+
+  if (s->d_ext_seed && s->ext_seed_n == nq && k) {  // (a sub-batch the tiered search split further runs without: its rows moved)
+    bm_ext_seed_kernel<<<(nq + 255) / 256, 256, 0, st>>>(s->d_ext_seed, nq, tau);
+    SS_HIP(hipGetLastError());
+  }
 
   BmParams p;
   p.post = s->d_post;

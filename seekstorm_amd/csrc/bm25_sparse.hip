@@ -378,6 +378,23 @@ __global__ void __launch_bounds__(SP_WAVES * 64) bm25_tier_merge_kernel(
   if (lane == 0) { o_count[qi] = cnt; o_total[qi] = total; }
 }
 
+// Threshold seeds for the dense sub-batch of a tiered batch (ss_api.hip bm25_search_tiered runs the sparse kernel FIRST): a union's sparse
+// list holds docs with their FULL scores -- when it holds k of them, its k-th score is one k docs of the query reach, and the query's
+// dense terms alone (frequent words, low idf) need not be read below it.  seed[dense_row[i]] = that score, 0 = none.
+__global__ void sp_seed_kernel(uint32_t nq, uint32_t k, uint32_t keys_per_list, const uint32_t* __restrict__ dense_row, const uint32_t* __restrict__ sparse_row,
+                               const ss_bm25_query* __restrict__ spq, const unsigned long long* __restrict__ sp_keys, float* __restrict__ seed) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  const uint32_t dr = dense_row[i], sr = sparse_row[i];
+  if (dr == 0xFFFFFFFFu) return;
+  float v = 0.f;
+  if (sr != 0xFFFFFFFFu && k >= 1u && k <= keys_per_list && bm_q_op(spq[sr].op) == SS_OP_UNION) {
+    const unsigned long long key = sp_keys[(size_t)sr * keys_per_list + (k - 1u)];
+    if (key) v = __uint_as_float((uint32_t)(key >> 32));
+  }
+  seed[dr] = v;
+}
+
 // The exclusion bitmap of ONE query that excludes sparse terms (ss_api.hip bm25_search_tiered_excl): the bitmap in force (tombstones
 // or a facet filter's, or none) with the docs of the query's sparse NOT lists set on top.
 struct SpLists { uint32_t id[SS_MAX_QUERY_TERMS]; uint32_t n; };
@@ -478,6 +495,15 @@ int ssi_bm25_launch_tier_merge(uint32_t nq, uint32_t k, const uint32_t* d_dense_
   else if (KPL == 4) SS_TM(4);
   else SS_TM(16);
 #undef SS_TM
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
+int ssi_bm25_launch_sparse_seeds(uint32_t nq, uint32_t k, const uint32_t* d_dense_row, const uint32_t* d_sparse_row, const ss_bm25_query* d_spq,
+                                 const unsigned long long* d_keys, float* d_seed, hipStream_t st) {
+  if (nq == 0 || k == 0) return SS_OK;
+  const uint32_t kpl = (uint32_t)ssi_bm25_sparse_kpl(k);
+  sp_seed_kernel<<<(nq + 255) / 256, 256, 0, st>>>(nq, k, 64u * kpl, d_dense_row, d_sparse_row, d_spq, d_keys, d_seed);
   SS_HIP(hipGetLastError());
   return SS_OK;
 }

@@ -50,6 +50,10 @@ int with_facet_filter(ss_shard* s, uint32_t n_filters, const ss_facet_filter* fi
 // SS_CO_TRACE: where a coalesced lexical batch spends its time (sums in us; printed when the shard is destroyed)
 struct CoTrace { std::atomic<uint64_t> n{0}, stage{0}, enqueue{0}, wait{0}, scatter{0}, linger{0}, wake{0}, members{0}; };
 static CoTrace g_co_trace;
+// ... and of the VECTOR coalescer, batch by batch (SS_CO_TRACE: what a pass waited for and whom it left behind)
+struct CoVecBatch { uint32_t members, left_queued, linger_us, batch_us; uint64_t t_formed_us; };
+static std::vector<CoVecBatch> g_co_vec_trace;
+static std::mutex g_co_vec_trace_mu;
 static const bool g_co_trace_on = getenv("SS_CO_TRACE") != nullptr;
 static inline uint64_t co_now_us() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -105,7 +109,13 @@ int ss_shard_create(int device, ss_shard** out) {
     s->co_lex.n_lanes = (two || adaptive) ? 2u : 1u;
     s->co_lex.lanes_forced = two;
   }
-  if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return SS_EDEVICE; }
+  // the shard's stream carries the latency-bound work (lexical searches: tens of microseconds a launch) at the device's HIGHEST priority;
+  // the coalesced vector scans (milliseconds a pass) run on vstream at the lowest: a lexical kernel that arrives during a scan is
+  // dispatched as the scan's workgroups retire instead of waiting for the pass to end
+  int pr_least = 0, pr_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
+  if (hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, pr_greatest) != hipSuccess) { delete s; return SS_EDEVICE; }
+  if (hipStreamCreateWithPriority(&s->vstream, hipStreamNonBlocking, pr_least) != hipSuccess) { (void)hipStreamDestroy(s->stream); delete s; return SS_EDEVICE; }
   *out = s;
   return SS_OK;
 }
@@ -148,6 +158,7 @@ struct AnnStateGuard {
 };
 
 static void free_vec(ss_shard* s) {
+  if (s->vstream) (void)hipStreamSynchronize(s->vstream);  // a coalesced scan still running reads the arrays released below
   for (auto& kv : s->vec_ws) {
     void* wp[] = {kv.second.d_Qf, kv.second.d_vstate, kv.second.d_cand, kv.second.d_qaux};
     for (void* p : wp) if (p) (void)hipFree(p);
@@ -199,10 +210,27 @@ int ss_shard_destroy(ss_shard* s) {
             (unsigned long long)g_co_trace.n.load(), g_co_trace.stage.load() / n, g_co_trace.wait.load() / n, g_co_trace.enqueue.load() / n,
             g_co_trace.linger.load() / n, g_co_trace.scatter.load() / n, g_co_trace.members.load() / (double)g_co_trace.n.load(), g_co_trace.wake.load() / n);
   }
+  if (g_co_trace_on && !g_co_vec_trace.empty()) {
+    std::lock_guard<std::mutex> gt(g_co_vec_trace_mu);
+    std::vector<uint32_t> m, l, q;
+    std::vector<uint64_t> gap;
+    for (size_t i = 0; i < g_co_vec_trace.size(); i++) {
+      m.push_back(g_co_vec_trace[i].members); l.push_back(g_co_vec_trace[i].linger_us); q.push_back(g_co_vec_trace[i].left_queued);
+      if (i) gap.push_back(g_co_vec_trace[i].t_formed_us - g_co_vec_trace[i - 1].t_formed_us);
+    }
+    auto pc = [](std::vector<uint32_t> v, double p) { std::sort(v.begin(), v.end()); return v[(size_t)(p * (v.size() - 1))]; };
+    auto pc64 = [](std::vector<uint64_t> v, double p) { if (v.empty()) return (uint64_t)0; std::sort(v.begin(), v.end()); return v[(size_t)(p * (v.size() - 1))]; };
+    fprintf(stderr, "[co-vec] %zu batches: members p1 %u p10 %u p50 %u; linger us p50 %u p90 %u p99 %u; left queued p50 %u p90 %u p99 %u; formed-to-formed us p50 %llu p90 %llu p99 %llu\n",
+            m.size(), pc(m, 0.01), pc(m, 0.10), pc(m, 0.50), pc(l, 0.50), pc(l, 0.90), pc(l, 0.99), pc(q, 0.50), pc(q, 0.90), pc(q, 0.99),
+            (unsigned long long)pc64(gap, 0.50), (unsigned long long)pc64(gap, 0.90), (unsigned long long)pc64(gap, 0.99));
+    g_co_vec_trace.clear();
+  }
   (void)hipSetDevice(s->device);
   (void)hipStreamSynchronize(s->stream);
+  if (s->vstream) (void)hipStreamSynchronize(s->vstream);
   free_vec(s);
   free_bm25(s);
+  for (void* p_ : {(void*)s->d_vq, (void*)s->d_vdoc, (void*)s->d_vscore, (void*)s->d_vcount, (void*)s->d_vtotal}) if (p_) (void)hipFree(p_);
   void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_deleted, s->d_facets, s->d_filter_bits, s->d_facet_ws, s->d_pool_stage, s->d_tier_ws, s->d_tier_hold, s->d_excl_bits, s->d_sort_ws, s->d_route_ws};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   (void)hipDeviceSynchronize();  // searches queued on the callers' own streams may still use their workspaces
@@ -222,6 +250,7 @@ int ss_shard_destroy(ss_shard* s) {
   if (s->d_small_ws) (void)hipFree(s->d_small_ws);
   if (s->h_small) (void)hipHostFree(s->h_small);
   (void)hipStreamDestroy(s->stream);
+  if (s->vstream) (void)hipStreamDestroy(s->vstream);
   delete s;
   return SS_OK;
 }
@@ -230,6 +259,7 @@ int ss_shard_sync(ss_shard* s) {
   if (!s) return SS_EINVAL;
   SS_HIP(hipSetDevice(s->device));
   SS_HIP(hipStreamSynchronize(s->stream));
+  if (s->vstream) SS_HIP(hipStreamSynchronize(s->vstream));
   return SS_OK;
 }
 
@@ -745,6 +775,7 @@ int ss_set_deleted(ss_shard* s, const uint64_t* doc_ids, uint64_t n) {
     mx = std::max(mx, doc_ids[i]);
   }
   std::lock_guard<std::mutex> g(s->mu);
+  if (s->vstream) (void)hipStreamSynchronize(s->vstream);  // (a coalesced scan in flight reads what this call replaces; none starts while mu is ours)
   SS_HIP(hipSetDevice(s->device));
   SS_HIP(hipStreamSynchronize(s->stream));
   if (s->d_deleted) { (void)hipFree(s->d_deleted); s->d_deleted = nullptr; }
@@ -1365,11 +1396,11 @@ static int bm25_search_tiered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, 
   const uint32_t kw = std::max<uint32_t>(kk, 1), ns = (uint32_t)spq.size(), nd = (uint32_t)sub.size();
   const int KPL = ssi_bm25_sparse_kpl(kw);
   SS_TRY(ensure_out(s, std::max<size_t>(nq, nd), kw));  // reserved before the sub-batch runs: its own ensure_out then keeps the buffers
-  // workspace: [sparse queries][row maps 2 nq][sparse keys][sparse counts][merged doc | score | count | total]
+  // workspace: [sparse queries][row maps 2 nq][sparse keys][sparse counts][merged doc | score | count | total][seeds of the dense sub-batch]
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t o_q = 0, o_dr = o_q + al((size_t)ns * sizeof(ss_bm25_query)), o_sr = o_dr + al((size_t)nq * 4), o_keys = o_sr + al((size_t)nq * 4),
                o_ext = o_keys + al((size_t)ns * 64 * KPL * 8), o_doc = o_ext + al((size_t)ns * 8), o_sc = o_doc + al((size_t)nq * kw * 4),
-               o_cnt = o_sc + al((size_t)nq * kw * 4), o_tot = o_cnt + al((size_t)nq * 4), need = o_tot + al((size_t)nq * 8);
+               o_cnt = o_sc + al((size_t)nq * kw * 4), o_tot = o_cnt + al((size_t)nq * 4), o_seed = o_tot + al((size_t)nq * 8), need = o_seed + al((size_t)nd * 4 + 4);
   if (need > s->tier_ws_cap) {
     SS_HIP(hipStreamSynchronize(s->stream));
     if (s->d_tier_ws) (void)hipFree(s->d_tier_ws);
@@ -1380,16 +1411,30 @@ static int bm25_search_tiered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, 
   char* W = (char*)s->d_tier_ws;
   // the host vectors are read by synchronous copies (they may die with this frame) -- which do not wait for the stream: a tiered
   // search still queued (the device-pointer entry point returns early, bm25_search_tiered_excl runs several) reads this workspace.
-  // Waited for HERE, while nothing of this call is queued yet (the stream is idle then, as a rule): the copies below run while the
-  // dense sub-batch's kernels do (with the wait and the copies ahead of the sub-batch a 96-query call was 17 % slower)
+  // Waited for HERE, while nothing of this call is queued yet (the stream is idle then, as a rule).
   SS_HIP(hipStreamSynchronize(s->stream));
-  if (nd) SS_TRY(bm25_search_host_queries(s, nd, sub.data(), kk, rt, 0, nullptr));  // -> s->d_out_* rows [0, nd)
   SS_HIP(hipMemcpy(W + o_q, spq.data(), (size_t)ns * sizeof(ss_bm25_query), hipMemcpyHostToDevice));
   SS_HIP(hipMemcpy(W + o_dr, dense_row.data(), (size_t)nq * 4, hipMemcpyHostToDevice));
   SS_HIP(hipMemcpy(W + o_sr, sparse_row.data(), (size_t)nq * 4, hipMemcpyHostToDevice));
+  // The SPARSE kernel first (round 6; it used to run behind the dense sub-batch): its lists are short, its docs carry FULL scores -- a
+  // union that finds k docs among its rare terms hands their k-th score to its dense terms as a threshold seed (sp_seed_kernel), and the
+  // dense kernels stop reading frequent words' lists that cannot reach it.  (Small calls take the one-launch path, where the same idea
+  // is role 3 publishing into the query's shared threshold; bm25_small.hip.)
   SS_TRY(ssi_bm25_launch_sparse(s, (const ss_bm25_query*)(W + o_q), ns_plain, kk, (unsigned long long*)(W + o_keys), (unsigned long long*)(W + o_ext), s->stream));
   SS_TRY(ssi_bm25_launch_sparse_phrase(s, (const ss_bm25_query*)(W + o_q) + ns_plain, ns - ns_plain, kk,
                                        (unsigned long long*)(W + o_keys) + (size_t)ns_plain * 64 * KPL, (unsigned long long*)(W + o_ext) + ns_plain, s->stream));
+  if (nd) {
+    if (kk) {
+      SS_HIP(hipMemsetAsync(W + o_seed, 0, (size_t)nd * 4, s->stream));
+      SS_TRY(ssi_bm25_launch_sparse_seeds(nq, kk, (const uint32_t*)(W + o_dr), (const uint32_t*)(W + o_sr), (const ss_bm25_query*)(W + o_q),
+                                          (const unsigned long long*)(W + o_keys), (float*)(W + o_seed), s->stream));
+      s->d_ext_seed = (const float*)(W + o_seed);
+      s->ext_seed_n = nd;
+    }
+    const int rc_sub = bm25_search_host_queries(s, nd, sub.data(), kk, rt, 0, nullptr);  // -> s->d_out_* rows [0, nd)
+    s->d_ext_seed = nullptr; s->ext_seed_n = 0;
+    if (rc_sub != SS_OK) return rc_sub;
+  }
   SS_TRY(ssi_bm25_launch_tier_merge(nq, kk, (const uint32_t*)(W + o_dr), (const uint32_t*)(W + o_sr), s->d_out_doc, s->d_out_score, s->d_out_count,
                                     (const unsigned long long*)s->d_out_total, (const unsigned long long*)(W + o_keys),
                                     (const unsigned long long*)(W + o_ext), (uint32_t*)(W + o_doc), (float*)(W + o_sc), (uint32_t*)(W + o_cnt),
@@ -1983,7 +2028,9 @@ static int bm25_search_direct(ss_shard* s, uint32_t nq, const ss_bm25_query* q, 
   uint32_t n_fit = nq;
   bool split = false;
   // (a rationed vocabulary: one pass over the whole batch deals the pool's rows -- no split)
-  if (kk && nq > 1 && n_filters == 0 && !(s->bm_probe_rows != 0 && s->bm_probe_rows < s->bm_n_terms)) {
+  // (a call of more than SM_H_QUERIES queries is the staged pipeline's whole: its fixed cost is spread thin there -- 1000 C2 queries 0.70 ms --
+  // where launches of 64 cost 0.1 ms each)
+  if (kk && nq > 1 && nq <= SM_H_QUERIES && n_filters == 0 && !(s->bm_probe_rows != 0 && s->bm_probe_rows < s->bm_n_terms)) {
     ss_small_shape sh{};
     uint32_t nn_max = 0;
     std::vector<uint8_t> fits(nq);
@@ -2079,7 +2126,7 @@ static int bm25_search_direct_lane(ss_shard* s, uint32_t nq, const ss_bm25_query
     const uint32_t kk = rt == SS_RT_COUNT ? 0 : k, kw = std::max<uint32_t>(kk, 1u);
     std::vector<ss_bm25_query> qs;  // the batch in the order it runs in: the fitting queries first
     uint32_t n_fit = 0;
-    if (kk && nq > 1 && !(s->bm_probe_rows != 0 && s->bm_probe_rows < s->bm_n_terms)) {  // (a rationed vocabulary: one pass deals the pool's rows)
+    if (kk && nq > 1 && nq <= SM_H_QUERIES && !(s->bm_probe_rows != 0 && s->bm_probe_rows < s->bm_n_terms)) {  // (a rationed vocabulary: one pass deals the pool's rows)
       ss_small_shape sh{};
       uint32_t nn_max = 0;
       std::vector<uint8_t> fits(nq);
@@ -2125,6 +2172,8 @@ static int vec_search_host(ss_shard* s, uint32_t nq, const void* queries, size_t
 static int vec_search_host_lists(ss_shard* s, uint32_t nq, const void* queries, size_t elem, const float* query_scale, uint32_t k,
                                  float thr, const ss_ann_mode* mode, uint32_t* h_count, uint32_t** d_ncl_out,
                                  const float* query_norm = nullptr, bool want_clusters = false, size_t out_slot = 0);
+static int vec_search_host_lane(ss_shard* s, uint32_t nq, const void* queries, size_t elem, const float* query_scale, uint32_t k, float thr,
+                                uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total);
 namespace {
 inline void co_futex_wait(std::atomic<uint32_t>* a, uint32_t expect) { (void)syscall(SYS_futex, (uint32_t*)a, FUTEX_WAIT_PRIVATE, expect, nullptr, nullptr, 0); }
 inline void co_futex_wake(std::atomic<uint32_t>* a) { (void)syscall(SYS_futex, (uint32_t*)a, FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0); }
@@ -2218,7 +2267,7 @@ int co_run_batch(ss_shard* s, ss_coalescer& co, bool lexical, const std::vector<
   if (lexical)
     rc = bm25_search_direct_lane(s, total, (const ss_bm25_query*)h_q, kk, f->rt, h_doc, h_sc, h_cnt, h_tot, ln.ev, 1u + lane_ix, row_of);
   else
-    rc = vec_search_host(s, total, h_q, f->elem, f->qscale ? h_qs : nullptr, kk, f->thr, nullptr, h_doc, h_sc, h_cnt, h_tot, nullptr);
+    rc = vec_search_host_lane(s, total, h_q, f->elem, f->qscale ? h_qs : nullptr, kk, f->thr, h_doc, h_sc, h_cnt, h_tot);
   if (rc != SS_OK) return rc;
   const uint64_t tr2 = g_co_trace_on ? co_now_us() : 0;
   at = 0;
@@ -2268,17 +2317,20 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
     // released are back within microseconds, so the next leader waits for them -- until as many requests are queued as callers
     // seem to be around, at most an eighth of the last batch's duration (<= 1 ms), and only if that batch had company at all: a
     // lone caller is never delayed.  max_wait_us > 0 (ss_shard_set_coalescing) waits that long unconditionally.
+    const uint64_t trace_t_lead_ns = g_co_trace_on && !lexical ? co_now_us() : 0;
     {
-      static const int linger_on = [] { const char* e = getenv("SS_COALESCE_LINGER"); return e ? atoi(e) : 1; }();
       uint32_t want, wait_us;
       {
         std::lock_guard<std::mutex> g(co.mu);
         // (several lanes: the callers around are shared between the batches in flight)
         want = co.max_wait_us ? co.max_batch : std::min(co.callers_est / std::max(co.leaders, 1u), co.max_batch);
-        // (SS_COALESCE_LINGER_DIV: the divisor -- measured at 8 / 4 / 2 / 1 on the C2 image, T = 64: 247 / 245 / 233 / 254 K q/s at batches of
-        // 39 / 48 / 62 / 64: a longer wait buys bigger batches and pays for them in waiting; profiles/r5_linger.log)
-        static const uint32_t linger_div = [] { const char* e = getenv("SS_COALESCE_LINGER_DIV"); return e ? (uint32_t)std::max(1, atoi(e)) : 8u; }();
-        wait_us = co.max_wait_us ? co.max_wait_us : (linger_on && co.callers_est > 1 ? std::min<uint32_t>(1000u, co.last_batch_us / linger_div) : 0u);
+        // at most an eighth of the last batch's duration, <= 1 ms (lexical: measured at 8 / 4 / 2 / 1 on the C2 image, T = 64: 247 / 245 / 233 /
+        // 254 K q/s at batches of 39 / 48 / 62 / 64 -- a longer wait buys bigger batches and pays for them in waiting; profiles/r5_linger.log).
+        // VECTOR passes: a quarter, <= 3 ms.  A pass costs the same 9 ms for 44 queries as for 64, so whoever misses it pays a whole pass
+        // more -- and a hybrid caller comes back through its lexical half first, which at k = 100 takes 0.5 - 1.5 ms for 64 callers
+        // (profiles/r6_co_vec_trace.log: with the 1 ms cap 6 % of the hybrid searches missed their pass, p99 = 2.3 x p50).
+        const uint32_t div = lexical ? 8u : 4u, cap = lexical ? 1000u : 3000u;
+        wait_us = co.max_wait_us ? co.max_wait_us : (co.callers_est > 1 ? std::min<uint32_t>(cap, co.last_batch_us / div) : 0u);
       }
       if (wait_us) {
         const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(wait_us);
@@ -2290,6 +2342,7 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
       }
     }
     const auto batch_t0 = std::chrono::steady_clock::now();
+    const uint64_t trace_linger_ns = g_co_trace_on && !lexical ? co_now_us() : 0;
     batch.clear();
     {
       std::lock_guard<std::mutex> g(co.mu);
@@ -2313,9 +2366,17 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
       }
       co.batches++;
       co.queries += total;
+      if (g_co_trace_on && !lexical) {
+        uint32_t left = 0;
+        for (ss_co_req* r : co.queue) left += r->nq;
+        std::lock_guard<std::mutex> gt(g_co_vec_trace_mu);
+        g_co_vec_trace.push_back(CoVecBatch{total, left, (uint32_t)((trace_linger_ns - trace_t_lead_ns) / 1000), 0u, trace_linger_ns / 1000});
+      }
     }
-    if (batch.size() == 1) {
-      batch[0]->rc = lexical ? co_run_lexical_one(s, batch[0]) : co_run_vector_one(s, batch[0]);
+    // (a lone VECTOR request takes the batch form too: the lane's pinned staging and the scan's own stream -- its pass must not hold the
+    // shard mutex either)
+    if (batch.size() == 1 && lexical) {
+      batch[0]->rc = co_run_lexical_one(s, batch[0]);
     } else if (co_run_batch(s, co, lexical, batch, me->lane) != SS_OK) {
       // somebody's request is at fault (or the device is): every member is re-run alone and gets its own verdict
       for (ss_co_req* r : batch) r->rc = lexical ? co_run_lexical_one(s, r) : co_run_vector_one(s, r);
@@ -2326,7 +2387,10 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
       uint32_t members = 0, queued = 0;
       for (ss_co_req* r : batch) members += r->nq;
       for (ss_co_req* r : co.queue) queued += r->nq;
-      co.callers_est = batch.size() + co.queue.size() > 1 ? members + queued : 0u;
+      // (callers seen at THIS moment miss those on their way back -- a hybrid caller is in its lexical half just now: the estimate falls by
+      // a sixteenth per batch at most, so a straggler of the last round is still waited for in this one; a lone caller: none, at once)
+      const uint32_t seen = members + queued, floor_ = co.callers_est - std::max(1u, co.callers_est / 16u);
+      co.callers_est = batch.size() + co.queue.size() > 1 ? std::max(seen, co.callers_est > 1u ? floor_ : 0u) : 0u;
       co.last_batch_us = (uint32_t)std::min<long long>(1000000, std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - batch_t0).count());
       // hand the lane to the queue's front unless another lane's leader already told it to lead
       for (ss_co_req* r : co.queue)
@@ -2976,6 +3040,56 @@ static int vec_search_host_lists(ss_shard* s, uint32_t nq, const void* queries, 
   return rc;
 }
 
+// A COALESCED vector batch (AnnMode::All; f32 or i8 rows): queries from, and answers into, the lane's PINNED buffers; its own stream and
+// staging (ss_common.h vmu / vstream).  The shard mutex is held while the pass is enqueued -- the scan buffers of the stream are bound
+// into the shard's fields for that long (VecWsBind) -- and NOT while it runs: 9 ms at 10 M x 768, during which lexical searches of the
+// shard (a hybrid caller's first half) used to wait for the mutex, then for the stream.
+static int vec_search_host_lane(ss_shard* s, uint32_t nq, const void* queries, size_t elem, const float* query_scale, uint32_t k, float thr,
+                                uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total) {
+  if (nq == 0) return SS_OK;
+  std::lock_guard<std::mutex> gv(s->vmu);
+  for (int attempt = 0; attempt < 2; attempt++) {
+    {
+      std::lock_guard<std::mutex> g(s->mu);
+      SS_HIP(hipSetDevice(s->device));
+      if ((elem == sizeof(float)) ? !s->d_X : !s->d_X8) return SS_ESTATE;
+      const size_t qbytes = ((size_t)nq * s->dim * elem + 15) & ~(size_t)15, sbytes = query_scale ? (size_t)nq * sizeof(float) : 0;
+      if (qbytes + sbytes > s->vq_cap) {  // (vstream is idle: vmu is ours and the batch before synchronised it)
+        if (s->d_vq) (void)hipFree(s->d_vq);
+        s->d_vq = nullptr; s->vq_cap = 0;
+        SS_HIP(hipMalloc(&s->d_vq, (qbytes + sbytes) * 2));
+        s->vq_cap = (qbytes + sbytes) * 2;
+      }
+      if ((size_t)nq * k > s->vout_cap || nq > s->vq_rows_cap) {
+        for (void* p_ : {(void*)s->d_vdoc, (void*)s->d_vscore, (void*)s->d_vcount, (void*)s->d_vtotal}) if (p_) (void)hipFree(p_);
+        s->d_vdoc = nullptr; s->d_vscore = nullptr; s->d_vcount = nullptr; s->d_vtotal = nullptr; s->vout_cap = 0; s->vq_rows_cap = 0;
+        const size_t rows = std::max<size_t>(nq, SS_VEC_BATCH), cells = std::max<size_t>((size_t)nq * k, (size_t)SS_VEC_BATCH * k);
+        SS_HIP(hipMalloc(&s->d_vdoc, cells * sizeof(uint32_t)));
+        SS_HIP(hipMalloc(&s->d_vscore, cells * sizeof(float)));
+        SS_HIP(hipMalloc(&s->d_vcount, rows * sizeof(uint32_t)));
+        SS_HIP(hipMalloc(&s->d_vtotal, rows * sizeof(uint64_t)));
+        s->vout_cap = cells; s->vq_rows_cap = rows;
+      }
+      float* d_qs = query_scale ? (float*)((char*)s->d_vq + qbytes) : nullptr;
+      SS_HIP(hipMemcpyAsync(s->d_vq, queries, (size_t)nq * s->dim * elem, hipMemcpyHostToDevice, s->vstream));
+      if (d_qs) SS_HIP(hipMemcpyAsync(d_qs, query_scale, sbytes, hipMemcpyHostToDevice, s->vstream));
+      {
+        VecWsBind bind(s, s->vstream);
+        SS_TRY(ssi_vec_search(s, nq, s->d_vq, d_qs, k, thr, s->d_vdoc, s->d_vscore, s->d_vcount, s->d_vtotal, s->vstream, attempt == 1, nullptr, nullptr, nullptr));
+      }
+      SS_HIP(hipMemcpyAsync(out_count, s->d_vcount, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s->vstream));
+      SS_HIP(hipMemcpyAsync(out_doc, s->d_vdoc, (size_t)nq * k * sizeof(uint32_t), hipMemcpyDeviceToHost, s->vstream));
+      SS_HIP(hipMemcpyAsync(out_score, s->d_vscore, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, s->vstream));
+      SS_HIP(hipMemcpyAsync(out_total, s->d_vtotal, (size_t)nq * sizeof(uint64_t), hipMemcpyDeviceToHost, s->vstream));
+    }
+    SS_HIP(hipStreamSynchronize(s->vstream));  // the pass itself: nobody waits for us but this batch's callers
+    bool ovf = false;
+    for (uint32_t i = 0; i < nq; i++) ovf |= out_count[i] == 0xFFFFFFFFu;
+    if (!ovf) return SS_OK;  // (an adversarial row order overflowed the candidate slots: once more in safe mode)
+  }
+  return SS_EDEVICE;  // cannot overflow in safe mode
+}
+
 // host-pointer searches: queries (f32 or i8 rows) and scales are staged in the shard's grow-only buffer, out_clusters
 // (observed_cluster_count, ANN modes) rides behind them
 static int vec_search_host(ss_shard* s, uint32_t nq, const void* queries, size_t elem, const float* query_scale, uint32_t k,
@@ -3061,6 +3175,7 @@ int ss_vec_set_similarity(ss_shard* s, int similarity) {
 int ss_vec_set_row_norms(ss_shard* s, uint64_t n_rows, const float* row_norm) {
   if (!s || !row_norm) return SS_EINVAL;
   std::lock_guard<std::mutex> g(s->mu);
+  if (s->vstream) (void)hipStreamSynchronize(s->vstream);  // (a coalesced scan in flight reads what this call replaces; none starts while mu is ours)
   SS_HIP(hipSetDevice(s->device));
   if (!s->d_X8) return SS_ESTATE;
   if (n_rows != s->n_rows) return SS_EINVAL;
@@ -3074,12 +3189,14 @@ int ss_vec_set_row_norms(ss_shard* s, uint64_t n_rows, const float* row_norm) {
 int ss_vec_set_clusters(ss_shard* s, uint32_t n_levels, const uint32_t* level_clusters, const uint32_t* child_count) {
   if (!s) return SS_EINVAL;
   std::lock_guard<std::mutex> g(s->mu);
+  if (s->vstream) (void)hipStreamSynchronize(s->vstream);  // (a coalesced scan in flight reads what this call replaces; none starts while mu is ours)
   SS_HIP(hipSetDevice(s->device));
   return ssi_vec_set_clusters(s, n_levels, level_clusters, child_count);
 }
 int ss_vec_set_fields(ss_shard* s, uint64_t n_rows, const uint16_t* row_field) {
   if (!s || !row_field) return SS_EINVAL;
   std::lock_guard<std::mutex> g(s->mu);
+  if (s->vstream) (void)hipStreamSynchronize(s->vstream);  // (a coalesced scan in flight reads what this call replaces; none starts while mu is ours)
   SS_HIP(hipSetDevice(s->device));
   if (!s->d_X && !s->d_X8) return SS_ESTATE;
   if (n_rows != s->n_rows) return SS_EINVAL;
@@ -3195,6 +3312,7 @@ static int vec_grow(ss_shard* s, uint64_t new_cap, bool grow_image = true) {
 int ss_vec_reserve_rows(ss_shard* s, uint64_t n_rows_cap) {
   if (!s) return SS_EINVAL;
   std::lock_guard<std::mutex> g(s->mu);
+  if (s->vstream) (void)hipStreamSynchronize(s->vstream);  // (a coalesced scan in flight reads what this call replaces; none starts while mu is ours)
   SS_HIP(hipSetDevice(s->device));
   if (!s->d_X && !s->d_X8) return SS_ESTATE;
   if (n_rows_cap > 0xFFFFFFFEull) return SS_ENOTSUP;
@@ -3215,6 +3333,7 @@ int ss_vec_append_rows(ss_shard* s, const ss_vec_level* lv) {
     if (tmp.back() == SS_NO_DOC) return SS_EINVAL;
   }
   std::lock_guard<std::mutex> g(s->mu);
+  if (s->vstream) (void)hipStreamSynchronize(s->vstream);  // (a coalesced scan in flight reads what this call replaces; none starts while mu is ours)
   SS_HIP(hipSetDevice(s->device));
   if (!s->d_X && !s->d_X8) return SS_ESTATE;
   const bool i8 = s->d_X8 != nullptr;

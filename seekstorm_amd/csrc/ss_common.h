@@ -269,6 +269,15 @@ struct ss_shard {
   uint32_t* d_out_count = nullptr;
   uint64_t* d_out_total = nullptr;
   size_t out_cap = 0, q_cap = 0;
+  // Coalesced vector batches (ss_api.hip vec_search_host_lane) run on a stream and staging of their OWN: a batch-64 scan of a 10 M x 768
+  // image is 9 ms of device time, during which the shard's other work -- a hybrid caller's lexical half above all -- must neither wait for
+  // the shard mutex nor queue behind the scan on the shard's stream (p99 2.3-2.5 x p50 on a deterministic pass).
+  // vmu serialises those batches among themselves (lock order: vmu, then mu); mu is held only while a batch is ENQUEUED.
+  std::mutex vmu;
+  hipStream_t vstream = nullptr;
+  void* d_vq = nullptr; size_t vq_cap = 0;                 // staged queries (+ scales)
+  uint32_t* d_vdoc = nullptr; float* d_vscore = nullptr; uint32_t* d_vcount = nullptr; uint64_t* d_vtotal = nullptr;
+  size_t vout_cap = 0, vq_rows_cap = 0;
   // ---- bm25 image
   uint64_t bm_n_docs = 0;
   uint32_t bm_n_terms = 0, bm_n_sub = 0;  // bm_n_terms: VIRTUAL terms (posting lists) = query-able terms x fields
@@ -362,6 +371,10 @@ struct ss_shard {
   size_t tier_hold_cap = 0;
   uint32_t* d_excl_bits = nullptr;   // per-query exclusion bitmap of such a query: tombstones | docs of its sparse NOT lists
   size_t excl_words_cap = 0;
+  // threshold seeds from OUTSIDE a batch's own lists (bm25_search_tiered: the k-th FULL score the sparse kernel found for a union whose dense
+  // terms this batch carries): [ext_seed_n] floats, row i for query i of the NEXT ssi_bm25_search call of exactly ext_seed_n queries
+  const float* d_ext_seed = nullptr;
+  uint32_t ext_seed_n = 0;
   void* d_route_ws = nullptr;        // a batch that holds shapes of several kernel families (ss_api.hip bm25_route_shapes): the sub-batches'
   size_t route_ws_cap = 0;           // queries + row maps, and the answers until every sub-batch has run; grow-only
   uint64_t gallop_batches = 0;       // sub-batches the generic kernels (bm25_gallop.hip) answered
@@ -557,6 +570,8 @@ int ssi_bm25_launch_sparse(const ss_shard* s, const ss_bm25_query* d_q, uint32_t
                            unsigned long long* d_extra, hipStream_t st);
 int ssi_bm25_launch_sparse_phrase(const ss_shard* s, const ss_bm25_query* d_q, uint32_t nq, uint32_t k, unsigned long long* d_keys,
                                   unsigned long long* d_extra, hipStream_t st);
+int ssi_bm25_launch_sparse_seeds(uint32_t nq, uint32_t k, const uint32_t* d_dense_row, const uint32_t* d_sparse_row, const ss_bm25_query* d_spq,
+                                 const unsigned long long* d_keys, float* d_seed, hipStream_t st);
 int ssi_bm25_sparse_excl_bits(const ss_shard* s, const uint32_t* d_base_bits, uint32_t base_words, const uint32_t* lists, uint32_t n_lists,
                               uint32_t* d_out, uint32_t words, hipStream_t st);
 int ssi_bm25_launch_tier_merge(uint32_t nq, uint32_t k, const uint32_t* d_dense_row, const uint32_t* d_sparse_row, const uint32_t* d_doc,

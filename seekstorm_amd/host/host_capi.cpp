@@ -3,6 +3,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -319,8 +321,10 @@ int ssh_bench_concurrent(ssh_index* ix, int mode, uint32_t n_threads, double sec
   const uint32_t dim = ix->shards[0]->dim();
   std::atomic<uint64_t> next{0}, errors{0};
   std::atomic<bool> go{false}, stop{false};
-  std::vector<std::vector<float>> lat(n_threads);
+  std::vector<std::vector<float>> lat(n_threads), at(n_threads);  // per call: its latency, and when it began (us since the start)
   std::vector<std::thread> th;
+  const bool hist = getenv("SSH_BENCH_HIST") != nullptr;  // diagnostics on stderr: the tail's shape and WHEN its calls happened
+  std::chrono::steady_clock::time_point w0;
   for (uint32_t t = 0; t < n_threads; t++)
     th.emplace_back([&, t] {
       lat[t].reserve(1 << 16);
@@ -336,9 +340,10 @@ int ssh_bench_concurrent(ssh_index* ix, int mode, uint32_t n_threads, double sec
         const auto t1 = std::chrono::steady_clock::now();
         if (ro.last_error || ro.results.empty()) errors.fetch_add(1, std::memory_order_relaxed);
         lat[t].push_back((float)std::chrono::duration<double, std::micro>(t1 - t0).count());
+        if (hist) at[t].push_back((float)std::chrono::duration<double, std::micro>(t0 - w0).count());
       }
     });
-  const auto w0 = std::chrono::steady_clock::now();
+  w0 = std::chrono::steady_clock::now();
   go.store(true, std::memory_order_release);
   std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
   stop.store(true, std::memory_order_relaxed);
@@ -352,6 +357,21 @@ int ssh_bench_concurrent(ssh_index* ix, int mode, uint32_t n_threads, double sec
   out[2] = all.empty() ? 0.0 : all[all.size() / 2];
   out[3] = all.empty() ? 0.0 : all[std::min(all.size() - 1, (size_t)((double)all.size() * 0.99))];
   out[4] = (double)errors.load();
+  if (hist && !all.empty()) {
+    auto pc = [&](double p) { return all[std::min(all.size() - 1, (size_t)((double)all.size() * p))]; };
+    const float slow = 1.5f * (float)out[2];
+    size_t n_slow = 0;
+    std::vector<uint32_t> when((size_t)(wall * 10.0) + 2, 0u), per_thread(n_threads, 0u);
+    for (uint32_t t = 0; t < n_threads; t++)
+      for (size_t j = 0; j < lat[t].size(); j++)
+        if (lat[t][j] > slow) { n_slow++; per_thread[t]++; when[std::min(when.size() - 1, (size_t)(at[t][j] / 1e5f))]++; }
+    uint32_t thr_hit = 0, thr_max = 0;
+    for (uint32_t c : per_thread) { thr_hit += c != 0; thr_max = std::max(thr_max, c); }
+    fprintf(stderr, "[hist] T=%u: %zu calls; us p10 %.0f p50 %.0f p90 %.0f p95 %.0f p99 %.0f p99.9 %.0f max %.0f; slow (> 1.5 x p50): %zu calls on %u threads (most on one: %u); by start time, per 100 ms:",
+            n_threads, all.size(), pc(0.10), pc(0.50), pc(0.90), pc(0.95), pc(0.99), pc(0.999), all.back(), n_slow, thr_hit, thr_max);
+    for (uint32_t c : when) fprintf(stderr, " %u", c);
+    fprintf(stderr, "\n");
+  }
   return SS_OK;
 }
 

@@ -122,9 +122,8 @@ def test_one_launch_equals_staged_pipeline_and_oracle(S, O, world, shape):
 def test_batches_outside_the_shape_take_the_staged_pipeline(S, O, world):
     sh, osh = world
     rng = np.random.default_rng(3)
-    # 5 scored terms, k = 129, a Count request: all answered, none by the one-launch path (a call of more than 256 queries: its first 256
-    # fitting queries take it, launches of 64 back to back, the rest the staged pipeline -- checked below)
-    for lists, k, rt in ((_queries(rng, 4, 5)[0], 10, S.ResultType.Topk),
+    # 257 queries (up to 256: launches of 64 back to back), 5 scored terms, k = 129, a Count request: all answered, none by the one-launch path
+    for lists, k, rt in ((_queries(rng, 257, 3)[0], 10, S.ResultType.Topk), (_queries(rng, 4, 5)[0], 10, S.ResultType.Topk),
                          (_queries(rng, 4, 3)[0], 129, S.ResultType.Topk), (_queries(rng, 4, 3)[0], 10, S.ResultType.Count)):
         q = sh.make_queries(lists, S.QueryType.Union)
         before = sh.one_launch_batches()
@@ -136,15 +135,15 @@ def test_batches_outside_the_shape_take_the_staged_pipeline(S, O, world):
                 assert int(t[i]) == otot
             else:
                 assert int(c[i]) == len(od) and np.allclose(s[i][:c[i]], os_, rtol=1e-4)
-    # a call split by shape: 300 queries (256 by launches of 64, 44 staged), every fifth one of 5 terms (staged) -- answers in the callers' order
-    lists = _queries(rng, 300, 3)[0]
-    for j in range(0, 300, 5):
+    # a call split by shape: 200 queries, every fifth one of 5 terms (staged), the others by launches of 64 -- answers in the callers' order
+    lists = _queries(rng, 200, 3)[0]
+    for j in range(0, 200, 5):
         lists[j] = _queries(rng, 1, 5)[0][0]
     q = sh.make_queries(lists, S.QueryType.Union)
     before = sh.one_launch_batches()
     d, s, c, t = sh.search_lexical_batch(q, 10, S.ResultType.TopkCount, reference_shortcuts=False)
     assert sh.one_launch_batches() == before + 1
-    for i in list(range(0, 12)) + [255, 256, 257, 298, 299]:
+    for i in list(range(0, 12)) + [63, 64, 65, 128, 198, 199]:
         od, os_, otot = osh.search_exhaustive(lists[i], O.OP_OR, 10)
         assert int(t[i]) == otot and int(c[i]) == len(od) and np.allclose(s[i][:c[i]], os_, rtol=1e-4), i
     # an invalid query keeps its error code on this path too (term id out of range)

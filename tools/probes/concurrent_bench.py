@@ -27,14 +27,36 @@ toff = np.zeros(len(tl) + 1, np.uint32); toff[1:] = np.cumsum([len(q) for q in t
 LEGS = (("lexical", N.MODE_LEXICAL, 1000, 10), ("vector", N.MODE_VECTOR, 64, 100), ("hybrid", N.MODE_HYBRID, 64, 100))
 if os.environ.get("LEX_ONLY"):
     LEGS = LEGS[:1]
+ONLY = os.environ.get("ONLY")  # e.g. ONLY=hybrid:64,256 -- one leg (the SS_CO_TRACE summaries are per process)
+if ONLY:
+    LEGS = tuple(l for l in LEGS if l[0] == ONLY.split(":")[0])
+def cpu_stat():
+    """(cgroup: periods throttled, us throttled, us of CPU used) -- a process over its CPU quota is stopped for the rest of the 100 ms period"""
+    d = {}
+    for f in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            for ln in open(f):
+                k_, v_ = ln.split()
+                d[k_] = int(v_)
+            break
+        except OSError:
+            pass
+    return d.get("nr_throttled", 0), d.get("throttled_usec", d.get("throttled_time", 0) // 1000), d.get("usage_usec", 0)
+
+
 for name, mode, nq, length in LEGS:
-    for T in ((8, 64, 256) if os.environ.get("LEX_ONLY") else (1, 8, 64, 256, 1024)):
+    for T in ((8, 64, 256) if os.environ.get("LEX_ONLY") else tuple(int(x) for x in ONLY.split(":")[1].split(",")) if ONLY else (1, 8, 64, 256, 1024)):
         out = (C.c_double * 5)()
         s0 = sh.coalescing_stats()
+        c0, t0_ = cpu_stat(), os.times()
         N.check(HL.ssh_bench_concurrent(ix, mode, T, secs, nq, flat.ctypes.data, toff.ctypes.data, qv.ctypes.data, int(S.QueryType.Union), length,
                                         N.RT_TOPK, out), "bench")
         s1 = sh.coalescing_stats()
         lb, lq, vb, vq = (s1[i] - s0[i] for i in range(4))
         print("%-8s T=%-4d %9.0f q/s  p50 %8.1f us  p99 %9.1f us  errors %d  lexical batch %s  vector batch %s" % (
             name, T, out[0] / out[1], out[2], out[3], int(out[4]), "%.1f" % (lq / lb) if lb else "-", "%.1f" % (vq / vb) if vb else "-"), flush=True)
+        if os.environ.get("SSH_BENCH_HIST"):
+            c1, t1_ = cpu_stat(), os.times()
+            print("         cpu: %.1f cores busy (user %.2f s + sys %.2f s over %.2f s); cgroup throttled %d periods, %.1f ms" % (
+                ((t1_.user - t0_.user) + (t1_.system - t0_.system)) / out[1], t1_.user - t0_.user, t1_.system - t0_.system, out[1], c1[0] - c0[0], (c1[1] - c0[1]) / 1e3), flush=True)
 sh.close()
