@@ -21,6 +21,9 @@ constexpr int VS_QS = SS_VEC_BATCH * VS_KC * 4;  // bytes of Q per stage (fragme
 constexpr int VS_STAGE = VS_XS + VS_QS;
 constexpr int VS_LDS = VS_STAGES * VS_STAGE;
 constexpr uint32_t VS_CAP = 8192;           // candidate slots per query
+#ifndef VS_GRID_MULT
+#define VS_GRID_MULT 32u                    // scan workgroups per launch = 512 x this (vec_scan.hip: how long a workgroup holds its CU)
+#endif
 constexpr int VS_FIRST_TILES = 16;          // first chunk: 2048 rows, everything is a candidate (64 tiles: the 8192-entry
                                             // refine after it costs more than the launch it saves)
 

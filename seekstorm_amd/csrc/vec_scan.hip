@@ -1094,7 +1094,12 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float*
       #ifdef VS_VARIANTS
       uint32_t grid = std::min<uint32_t>(c, scan_q == 1 ? 256u * (uint32_t)vq_wgs : 512u);
 #else
-      uint32_t grid = std::min<uint32_t>(c, 512);
+      // workgroups per launch: 2 per CU at a time (72 KB of LDS each).  A grid of exactly 512 would be PERSISTENT -- every workgroup lives as
+      // long as the chunk, 8 ms for the last one of a 10 M-row pass, and nothing else gets a CU's LDS meanwhile: a lexical launch on the
+      // shard's high-priority stream (a hybrid caller's first half) then waits for the pass to end (profiles/r6_hybrid_hist.log: 7.6 ms of
+      // device wait per lexical batch under T = 256 hybrid callers).  VS_GRID_MULT x as many workgroups, each walking 1 / VS_GRID_MULT of
+      // the tiles: a workgroup retires every few hundred microseconds and the dispatcher hands its CU to the higher-priority queue first.
+      uint32_t grid = std::min<uint32_t>(c, 512u * VS_GRID_MULT);
 #endif
       if (i8) ssi_vec8_launch_scan(s, tile0, c, d_qscale ? d_qscale + g0 : nullptr, ann_mode ? &ann : nullptr, st);
       else if (ann_mode && sparse_nv) {

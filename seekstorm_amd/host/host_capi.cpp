@@ -3,9 +3,11 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <thread>
 
 #include "seekstorm_host.hpp"
@@ -312,7 +314,7 @@ int ssh_synth_vectors(ssh_index* ix, int shard, uint64_t seed, uint64_t n_rows, 
 // The reference's REAL calling pattern, measured: n_threads host threads, each issuing ONE query per call through Index::search
 // (search.rs:1637-1743: one search per runtime worker, no batched entry point) for `seconds` of wall time.  mode: SS_MODE_*;
 // query i of the n_queries given = terms[term_off[i] .. term_off[i+1]) and / or vectors[i * dim ..]; threads draw queries round
-// robin.  out[0] = completed searches, out[1] = wall seconds, out[2] / out[3] = p50 / p99 of the per-call latency in
+// robin.  Every thread's first call is a warm-up: not recorded, not counted.  out[0] = completed searches, out[1] = wall seconds, out[2] / out[3] = p50 / p99 of the per-call latency in
 // microseconds (host clock around the call), out[4] = calls that came back with an error.
 int ssh_bench_concurrent(ssh_index* ix, int mode, uint32_t n_threads, double seconds, uint32_t n_queries, const uint32_t* terms,
                          const uint32_t* term_off, const float* vectors, uint32_t query_type, uint32_t length, uint32_t result_type,
@@ -321,6 +323,8 @@ int ssh_bench_concurrent(ssh_index* ix, int mode, uint32_t n_threads, double sec
   const uint32_t dim = ix->shards[0]->dim();
   std::atomic<uint64_t> next{0}, errors{0};
   std::atomic<bool> go{false}, stop{false};
+  std::mutex go_mu;  // (the threads sleep until the start: 256 of them spinning on yield() spent the process's CPU quota before the first call)
+  std::condition_variable go_cv;
   std::vector<std::vector<float>> lat(n_threads), at(n_threads);  // per call: its latency, and when it began (us since the start)
   std::vector<std::thread> th;
   const bool hist = getenv("SSH_BENCH_HIST") != nullptr;  // diagnostics on stderr: the tail's shape and WHEN its calls happened
@@ -328,7 +332,11 @@ int ssh_bench_concurrent(ssh_index* ix, int mode, uint32_t n_threads, double sec
   for (uint32_t t = 0; t < n_threads; t++)
     th.emplace_back([&, t] {
       lat[t].reserve(1 << 16);
-      while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+      { std::unique_lock<std::mutex> lk(go_mu); go_cv.wait(lk, [&] { return go.load(std::memory_order_acquire); }); }
+      // every thread's FIRST call is a warm-up and is not recorded: all n_threads arrive at once, find the coalescer empty and the lanes'
+      // staging unallocated -- T = 256 hybrid callers: 256 calls of 90 .. 120 ms, 1.3 % of a 3 s run, which is where its "p99" then sat
+      // (profiles/r6_hybrid_hist.log: every slow call began in the first 100 ms, one per thread)
+      bool warm = false;
       while (!stop.load(std::memory_order_relaxed)) {
         const uint32_t i = (uint32_t)(next.fetch_add(1, std::memory_order_relaxed) % n_queries);
         std::vector<uint32_t> q;
@@ -339,12 +347,14 @@ int ssh_bench_concurrent(ssh_index* ix, int mode, uint32_t n_threads, double sec
                                             false /* the bench's vectors are normalised already */);
         const auto t1 = std::chrono::steady_clock::now();
         if (ro.last_error || ro.results.empty()) errors.fetch_add(1, std::memory_order_relaxed);
+        if (!warm) { warm = true; continue; }
         lat[t].push_back((float)std::chrono::duration<double, std::micro>(t1 - t0).count());
         if (hist) at[t].push_back((float)std::chrono::duration<double, std::micro>(t0 - w0).count());
       }
     });
   w0 = std::chrono::steady_clock::now();
-  go.store(true, std::memory_order_release);
+  { std::lock_guard<std::mutex> lk(go_mu); go.store(true, std::memory_order_release); }
+  go_cv.notify_all();
   std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
   stop.store(true, std::memory_order_relaxed);
   for (auto& t : th) t.join();

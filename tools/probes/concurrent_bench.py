@@ -16,7 +16,8 @@ tl, th = bench.make_c2_queries(O, 1000)
 sh.synth_lexical(O.LEX_SEED, docs, th, O.len_table())
 sh.synth_vectors(O.VEC_SEED, rows if not os.environ.get('LEX_ONLY') else 1024, dim)
 qv = O.vec_gen(O.VECQ_SEED, 0, 64, dim)
-HL = C.CDLL(os.path.join(ROOT, "seekstorm_amd", "lib", "libseekstorm_host.so"))
+_libdir = os.path.dirname(os.environ["SEEKSTORM_HIP_LIB"]) if os.environ.get("SEEKSTORM_HIP_LIB") else os.path.join(ROOT, "seekstorm_amd", "lib")  # (an experiment build: its own host library beside it)
+HL = C.CDLL(os.path.join(_libdir, "libseekstorm_host.so"))
 HL.ssh_index_adopt.restype = C.c_void_p
 HL.ssh_index_adopt.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
 HL.ssh_bench_concurrent.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
