@@ -63,7 +63,8 @@ __device__ __attribute__((noinline)) void pb_publish_kth_best(unsigned long long
 // G: chunks of 64 driver postings per group -- their gathers are in flight together (4 in the staged kernel, whose registers are capped
 // for occupancy; 8 in the one-launch kernel of small batches, which is bound by the number of dependent round trips per wave)
 // KTHB: the partitions publish their best keys and derive the query's threshold from them (pb_publish_kth_best; `bests` + `bests_stride`)
-template <int NT, int KPL, bool FILT, bool SKIP, bool SEEDED, int G, bool KTHB, typename QV>
+// EXT: the query's shared threshold may rise from OUTSIDE these lists while they are read (bm25_small.hip, the tiered instances)
+template <int NT, int KPL, bool FILT, bool SKIP, bool SEEDED, int G, bool KTHB, bool EXT = false, typename QV>
 __device__ __forceinline__ BmTop<KPL> pb_wave(
     const uint32_t* __restrict__ post, const unsigned long long* __restrict__ term_base, const uint32_t* __restrict__ sub_off,
     const uint2* __restrict__ probe, const uint32_t* __restrict__ probe_z,
@@ -201,6 +202,11 @@ __device__ __forceinline__ BmTop<KPL> pb_wave(
     constexpr int A = J == 0 ? 1 : 0;  // the first other term in probe order
     const uint32_t x_begin = rowp[J][s_begin] * 4u, x_end = rowp[J][s_end] * 4u;  // dword range of the stream
     if (x_begin == x_end) return;
+    // J = 0 and a threshold above SU[0]: NO list is essential -- the threshold came from outside these lists (a tiered query's sparse lists,
+    // whose docs carry the rare terms' idf: bm25_small.hip role 3 while this runs, or the staged tiered pipeline's seeds before it,
+    // bm_ext_seed_kernel) and nothing the dense lists hold alone can reach it.  (A single list under exact counts is read to its end: it
+    // counts its own matches.)
+    if (J == 0 && !is_and && k && !(count && nt == 1) && SU[0] < cur_thr() * 0.99999f) return;
 
     // ---- sparse stage: the LAST n queue entries (n <= 64), one per lane
     auto drain = [&](uint32_t n) {
@@ -295,10 +301,10 @@ __device__ __forceinline__ BmTop<KPL> pb_wave(
     for (int g = 0; g < G; g++) pn[g] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane4 + g * 256, (int)(x_begin * 4u), 0);
     for (uint32_t x = x_begin; x < x_end; x += 64u * G) {
       const float thr = cur_thr();
-      // this and all later terms are non-essential now.  J = 0: NO list is essential -- the threshold came from outside these lists (the
-      // sparse role of a tiered query, bm25_small.hip: its docs carry the rare terms' idf) and nothing they hold alone can reach it;
-      // (a single list under exact counts is read to its end: it counts its own matches)
-      if (!is_and && k && SU[J] < thr * 0.99999f && (J > 0 || !(count && nt == 1))) break;
+      // this and all later terms are non-essential now
+      // (J = 0 is tested inside the loop by the EXT instances only -- the test in the first, longest stream of every query cost the C2
+      // headline 11 %, 0.567 -> 0.631 ms per 1000 queries, profiles/r6_break_ab.log; the others test it once, before the stream: above)
+      if (!is_and && k && (J > 0 || (EXT && !(count && nt == 1))) && SU[J] < thr * 0.99999f) break;
       if constexpr (SKIP) if (skip_blocks) {
         // block-max skip: while the sub-block holding position x cannot contain a doc that reaches thr, jump to the next one
         bool moved = false;

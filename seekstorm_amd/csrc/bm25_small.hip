@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 4) bm25_small_kernel(const PbSm
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) Q.not_[j] = FILT ? fz->q[qi].term[min(np + (uint32_t)j, 7u)] : 0u;
-        T = pb_wave<NT, KPL, FILT, false, true, SM_G, true>(fz->post, fz->term_base, fz->sub_off, fz->probe, fz->probe_z, fz->probe_row, fz->umax, nullptr, nullptr,
+        T = pb_wave<NT, KPL, FILT, false, true, SM_G, true, TIER != 0>(fz->post, fz->term_base, fz->sub_off, fz->probe, fz->probe_z, fz->probe_row, fz->umax, nullptr, nullptr,
                                                    Q, fz->tau, fz->del, fz->del_words, fz->n_sub, fz->n_terms, PB * PB_WAVES, k, (fz->count & 1u) && !count_by_bits ? 1u : 0u, qi, part, w, lane, fz->q[qi].thr0,
                                                    (fz->count & 4u) && k <= 64u && PB * PB_WAVES >= k ? fz->bests + (size_t)qi * (SM_MAX_PB * PB_WAVES) : nullptr);
       }
