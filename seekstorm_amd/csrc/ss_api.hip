@@ -249,6 +249,8 @@ int ss_shard_destroy(ss_shard* s) {
   if (s->bq_ev) (void)hipEventDestroy(s->bq_ev);
   if (s->d_small_ws) (void)hipFree(s->d_small_ws);
   if (s->h_small) (void)hipHostFree(s->h_small);
+  if (s->h_ans) (void)hipHostFree(s->h_ans);
+  if (s->d_ans_done) (void)hipFree(s->d_ans_done);
   (void)hipStreamDestroy(s->stream);
   if (s->vstream) (void)hipStreamDestroy(s->vstream);
   delete s;
@@ -2016,6 +2018,80 @@ static int bm25_small_wait(ss_shard* s, uint32_t slot, uint32_t seq, bool mu_hel
   return rc;
 }
 
+// The staged pipeline's answers home: rows [0, nq) of the shard's output arrays -> one pinned block [doc | score | count | total], the
+// last block to finish raises the flag behind them (system-scope fence before its arrival, as bm25_small_kernel does).  The host polls
+// the flag and copies into the caller's arrays: a 1000-query C2 call came home in 4 pageable copies + a stream synchronisation, ~95 us
+// of its 770 (profiles/r6_bench_a.json: 0.769 ms end to end against 0.674 ms device-resident).
+__global__ void __launch_bounds__(256) bm25_answers_home_kernel(const uint32_t* __restrict__ d_doc, const uint32_t* __restrict__ d_score,
+                                                                const uint32_t* __restrict__ d_count, const uint32_t* __restrict__ d_total,
+                                                                uint32_t n_cells, uint32_t nq, uint32_t* __restrict__ h, uint32_t* done,
+                                                                uint32_t* flag, uint32_t seq) {
+  const uint32_t n = 2u * n_cells + 3u * nq;  // dwords: docs, scores, counts, totals (two each)
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    uint32_t v;
+    if (i < n_cells) v = d_doc[i];
+    else if (i < 2u * n_cells) v = d_score[i - n_cells];
+    else if (i < 2u * n_cells + nq) v = d_count[i - 2u * n_cells];
+    else v = d_total[i - 2u * n_cells - nq];
+    h[i] = v;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t prev = atomicAdd(done, 1u);
+    if (prev + 1u == gridDim.x) {
+      *done = 0u;
+      __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+static int bm25_small_wait(ss_shard* s, uint32_t slot, uint32_t seq, bool mu_held);
+// rows [0, nq) of s->d_out_* -> the caller's arrays.  Called under s->mu, behind the search on s->stream.
+static int bm25_answers_home(ss_shard* s, uint32_t nq, uint32_t kk, uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total) {
+  const size_t cells = (size_t)nq * kk, dwords = 2 * cells + 3 * (size_t)nq;
+  if (dwords > (64u << 20)) {  // (a huge call: the copies' bandwidth is what counts)
+    if (kk) {
+      SS_HIP(hipMemcpyAsync(out_doc, s->d_out_doc, cells * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+      SS_HIP(hipMemcpyAsync(out_score, s->d_out_score, cells * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    }
+    SS_HIP(hipMemcpyAsync(out_count, s->d_out_count, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    SS_HIP(hipMemcpyAsync(out_total, s->d_out_total, (size_t)nq * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
+    SS_HIP(hipStreamSynchronize(s->stream));
+    return SS_OK;
+  }
+  if (!s->h_small) {
+    SS_HIP(hipHostMalloc((void**)&s->h_small, SM_H_BYTES, hipHostMallocDefault));
+    memset(s->h_small, 0, SM_H_BYTES);
+  }
+  if (dwords * 4 > s->h_ans_cap) {
+    SS_HIP(hipStreamSynchronize(s->stream));
+    if (s->h_ans) (void)hipHostFree(s->h_ans);
+    s->h_ans = nullptr; s->h_ans_cap = 0;
+    const size_t cap = std::max<size_t>(dwords * 4 * 2, 256u << 10);
+    SS_HIP(hipHostMalloc((void**)&s->h_ans, cap, hipHostMallocDefault));
+    s->h_ans_cap = cap;
+  }
+  if (!s->d_ans_done) {
+    SS_HIP(hipMalloc(&s->d_ans_done, 64));
+    SS_HIP(hipMemsetAsync(s->d_ans_done, 0, 64, s->stream));
+  }
+  const uint32_t seq = ++s->small_seq ? s->small_seq : ++s->small_seq;  // never 0
+  const uint32_t grid = (uint32_t)std::min<size_t>(256, (dwords + 1023) / 1024);
+  bm25_answers_home_kernel<<<std::max(grid, 1u), 256, 0, s->stream>>>(s->d_out_doc, (const uint32_t*)s->d_out_score, s->d_out_count, (const uint32_t*)s->d_out_total,
+                                                                      (uint32_t)cells, nq, (uint32_t*)s->h_ans, s->d_ans_done, (uint32_t*)s->h_small, seq);
+  SS_HIP(hipGetLastError());
+  const int rc = bm25_small_wait(s, 0, seq, true);
+  if (rc != SS_OK) { (void)hipMemsetAsync(s->d_ans_done, 0, 64, s->stream); return rc; }
+  const uint32_t* h = (const uint32_t*)s->h_ans;
+  if (kk) {
+    memcpy(out_doc, h, cells * 4);
+    memcpy(out_score, h + cells, cells * 4);
+  }
+  memcpy(out_count, h + 2 * cells, (size_t)nq * 4);
+  memcpy(out_total, h + 2 * cells + nq, (size_t)nq * 8);
+  return SS_OK;
+}
+
 static int bm25_search_direct(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k, uint32_t rt, uint32_t n_filters,
                               const ss_facet_filter* filters, uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total) {
   std::lock_guard<std::mutex> g(s->mu);  // before check_queries: it reads the image's host-side tables (an upload replaces them)
@@ -2060,14 +2136,7 @@ static int bm25_search_direct(ss_shard* s, uint32_t nq, const ss_bm25_query* q, 
       return SS_OK;
     }
     SS_TRY(bm25_search_host_queries(s, nq, q, kk, rt, n_filters, filters));
-    if (kk) {
-      SS_HIP(hipMemcpyAsync(out_doc, s->d_out_doc, (size_t)nq * kk * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-      SS_HIP(hipMemcpyAsync(out_score, s->d_out_score, (size_t)nq * kk * sizeof(float), hipMemcpyDeviceToHost, s->stream));
-    }
-    SS_HIP(hipMemcpyAsync(out_count, s->d_out_count, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-    SS_HIP(hipMemcpyAsync(out_total, s->d_out_total, (size_t)nq * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
-    SS_HIP(hipStreamSynchronize(s->stream));
-    return SS_OK;
+    return bm25_answers_home(s, nq, kk, out_doc, out_score, out_count, out_total);
   }
   // split: the staged part behind the launch on the same stream, its answers into rows [r0, nq) of a host copy in run order
   static thread_local std::vector<uint32_t> t_doc, t_cnt;

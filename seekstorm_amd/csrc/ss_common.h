@@ -399,6 +399,11 @@ struct ss_shard {
   void* d_small_ws = nullptr;
   char* h_small = nullptr;
   uint32_t small_seq = 0;
+  // the STAGED pipeline's answers of a direct host-pointer call take the same road home (ss_api.hip bm25_answers_home): one kernel writes
+  // them into this pinned block and raises flag slot 0 behind them -- instead of four copies into the caller's pageable arrays and a
+  // stream synchronisation
+  char* h_ans = nullptr; size_t h_ans_cap = 0;
+  uint32_t* d_ans_done = nullptr;  // blocks of that kernel that have finished (zero between launches)
   uint64_t small_launches = 0;
   ss_prof prof;
 };

@@ -38,5 +38,17 @@ for _ in range(300):
     call(1)
 N.check(L.ss_shard_sync(sh._h), "sync")
 d1 = time.perf_counter() - t0
+import ctypes as C
+hd = np.empty((nq, k), np.uint32); hs = np.empty((nq, k), np.float32); hc = np.empty(nq, np.uint32); ht = np.empty(nq, np.uint64)
+def hcall():
+    N.check(L.ss_bm25_search(sh._h, nq, q.ctypes.data_as(C.c_void_p), k, N.RT_TOPK, N.ptr(hd, N.u32p), N.ptr(hs, N.f32p), N.ptr(hc, N.u32p), N.ptr(ht, N.u64p)), "ss_bm25_search")
+for _ in range(5):
+    hcall()
+assert np.array_equal(hs, ref), "host-pointer call differs"
+lat = []
+for _ in range(300):
+    t0 = time.perf_counter(); hcall(); lat.append(time.perf_counter() - t0)
+lat = np.sort(lat) * 1e3
+print("variant %-8s host pointers in, answers on the host: p50 %.3f ms p99 %.3f ms (%.0f q/s at the mean)" % (tag or "base", lat[150], lat[297], nq / (lat.mean() * 1e-3)), flush=True)
 print("variant %-8s submax=%s: %.3f ms per 1000-query call (%.0f q/s), probe kernel %.3f ms; single query %.3f ms" % (
     tag or "base", os.environ.get("SS_BM25_SUBMAX", "1"), dt / 300 * 1e3, nq * 300 / dt, ms / max(n, 1), d1 / 300 * 1e3), flush=True)
