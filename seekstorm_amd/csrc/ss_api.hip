@@ -2469,6 +2469,10 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
     }
     const uint64_t tw0 = g_co_trace_on ? co_now_us() : 0;
     if (succ) co_signal(succ, 3u);  // first: the next batch forms while this one's members are being woken
+    // (one futex wake per sleeping member, 1.26 us each.  Waking them faster was built twice and is wrong on a CPU quota: one shared futex
+    // with FUTEX_WAKE(all), round 5, and a tree -- the leader wakes every 8th member, who wakes its group --, round 6: the leader's part falls
+    // 47 -> 4.4 us per batch, all members run, spin and re-submit at once, and the process is throttled: T = 256 344 K -> 75 K q/s with
+    // p99 = 78 ms, the CFS period; T = 64 283 K -> 220 K.  The serial wake is the pacing.  profiles/r6_tree_wake_rejected.log)
     bool mine = false;
     for (ss_co_req* r : batch) {
       if (r == me) mine = true;
