@@ -205,6 +205,75 @@ def emit(line, world):
     print(json.dumps(compact_line(line)), flush=True)
 
 
+def one_process_main(args):
+    """bench.py --one-process S: C2 through the C++ mirror's Index::search_lexical_batch over S shards of ONE process (VERDICT r5 "next" 9).
+    Shard i = the docs g % S == i of one generator stream of S x --docs docs on GPU i; a call = 1000 queries resolved per shard (shard-local
+    idf), one task (thread) per shard, each ending in ss_bm25_search_sharded: search, ONE all-gather, merge on the device, answers on the
+    host.  Same timing protocol and line as the rank-per-GPU form (one process: no barrier to take a maximum over)."""
+    import ctypes as C
+    import torch  # noqa: F401  (first: the HIP runtime torch loads is then shared with the libraries)
+    import seekstorm_amd as S
+    from seekstorm_amd import _native as N
+    from oracle import oracle as O
+    n_sh = args.one_process
+    if torch.cuda.device_count() < n_sh:
+        raise SystemExit(f"--one-process {n_sh}: only {torch.cuda.device_count()} GPU(s) visible")
+    S.lib()
+    HL = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(S.__file__)), "lib", "libseekstorm_host.so"))
+    HL.ssh_index_create.restype = C.c_void_p
+    HL.ssh_index_create.argtypes = [C.c_int, C.POINTER(C.c_int)]
+    HL.ssh_index_destroy.argtypes = [C.c_void_p]
+    HL.ssh_synth_lexical.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
+    HL.ssh_index_search_lexical_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    ix = HL.ssh_index_create(n_sh, (C.c_int * n_sh)(*range(n_sh)))
+    nq, k = args.queries, 10
+    term_lists, th = make_c2_queries(O, nq)
+    th32 = np.ascontiguousarray(th, np.uint32)
+    tab = np.ascontiguousarray(O.len_table(), np.uint8)
+    t0 = time.perf_counter()
+    for i in range(n_sh):
+        N.check(HL.ssh_synth_lexical(ix, i, int(O.LEX_SEED), int(args.docs), len(th32), th32.ctypes.data, tab.ctypes.data), "ssh_synth_lexical")
+    build_s = time.perf_counter() - t0
+    NB = 8
+    rot = [term_lists] + [make_c2_queries(O, nq, seed=5000 + i)[0] for i in range(1, NB)]
+    flats = [np.array([t for q in tl_ for t in q], np.uint32) for tl_ in rot]
+    offs = [np.concatenate([[0], np.cumsum([len(q) for q in tl_])]).astype(np.uint32) for tl_ in rot]
+    doc = np.empty((nq, k), np.uint64); score = np.empty((nq, k), np.float32); cnt = np.empty(nq, np.uint32); tot = np.empty(nq, np.uint64)
+    it = [0]
+
+    def call():
+        b = it[0] % NB
+        it[0] += 1
+        N.check(HL.ssh_index_search_lexical_batch(ix, nq, flats[b].ctypes.data, offs[b].ctypes.data, int(S.QueryType.Union), k, N.RT_TOPK, 1,
+                                                  doc.ctypes.data, score.ctypes.data, cnt.ctypes.data, tot.ctypes.data), "ssh_index_search_lexical_batch")
+
+    call()
+    # self-check: every query of batch 0 has k results, scores descending, global ids spread over all shards (id % S = its shard)
+    assert int(cnt.min()) == k and np.all(np.diff(score, axis=1) <= 0), "merged lists are not top-k lists"
+    shards_seen = np.unique(doc % n_sh)
+    assert len(shards_seen) == n_sh, ("answers name docs of shards", shards_seen.tolist())
+    checksum = float(score.astype(np.float64).sum())
+    for _ in range(args.warmup * args.calls_per_step):
+        call()
+    t0 = time.perf_counter()
+    for _ in range(args.steps * args.calls_per_step):
+        call()
+    dt = time.perf_counter() - t0
+    calls = args.steps * args.calls_per_step
+    line = {"metric": "queries/sec (BM25 3-term OR top-10)", "value": nq * calls / dt, "unit": "queries/s", "n_gpus": n_sh, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 sums of 16-bit posting weight codes (BM25)", "data": "synthetic",
+            "config": {"workload": "C2: 10M synthetic docs per shard, 3-term OR BM25 top-10; host pointers in, merged answers on the host",
+                       "docs_per_shard": args.docs, "queries_per_call": nq, "calls_per_step": args.calls_per_step, "k": k,
+                       "parallelism": f"ONE process, {n_sh} shard tasks (host threads), one all-gather per call (ss_comm_create_all)",
+                       "entry_point": "seekstorm_host Index::search_lexical_batch -> ss_bm25_search_sharded per shard"},
+            "ms_per_call": dt / calls * 1e3, "build_s": build_s, "checksum_batch0": checksum, "shards_in_answers": shards_seen.tolist()}
+    HL.ssh_index_destroy(ix)
+    print(json.dumps(_r(line)), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,7 +306,12 @@ def main():
     ap.add_argument("--no-concurrent", action="store_true", help="skip the concurrent-callers legs (T host threads, one query per call)")
     ap.add_argument("--no-sharded", action="store_true", help="skip the ss_*_search_sharded legs at N = 1 (no RCCL communicator is then created: "
                     "profiler runs -- RCCL's initialisation faults under rocprofv3 on this image)")
+    ap.add_argument("--one-process", type=int, default=0, metavar="S",
+                    help="the reference's OWN shape instead of one rank per GPU: ONE process, S shards on GPUs 0 .. S-1, one host thread per shard and call "
+                         "(search.rs:1637-1650), the lists exchanged over RCCL communicators made by ss_comm_create_all; prints one line of the same form")
     args = ap.parse_args()
+    if args.one_process:
+        return one_process_main(args)
     if args.quick:
         args.no_cpu = args.no_parity = args.no_sharded = True
         args.calls_per_step, args.min_seconds = min(args.calls_per_step, 2), 0.0

@@ -339,10 +339,8 @@ void ssi_bm25_drop_kth(ss_shard* s) {
   s->h_kthw.clear();
 }
 // built once per image, on the stream of the search that first wants it (the image does not change under a search: s->mu);
-// SS_BM25_SEED=0 switches the seeds off (measurements)
 int ssi_bm25_ensure_kth(ss_shard* s, hipStream_t st) {
-  static const int on = [] { const char* e = getenv("SS_BM25_SEED"); return e ? atoi(e) : 1; }();
-  if (s->d_kthw || !on || !s->d_post || s->bm_n_terms == 0) return SS_OK;
+  if (s->d_kthw || !s->d_post || s->bm_n_terms == 0) return SS_OK;
   const size_t n = ((size_t)s->bm_n_terms + 1) * 4u;
   SS_HIP(hipMalloc(&s->d_kthw, n * sizeof(float)));
   SS_HIP(hipMemsetAsync(s->d_kthw, 0, n * sizeof(float), st));
@@ -485,7 +483,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   // imbalance is gone and fewer, longer assignments win again: 1.08 ms at 8 partitions per query, 1.10 at 10 / 12, 1.11 at 16, 1.15 at
   // 24 (tools/probes/psweep.sh).  Workgroups made of the partitions of ONE query instead of 8 queries of one partition were tried as
   // well (profiles/r3_map_sweep.log): no better, for the pruned kernel neither.)
-  static const bool staged_kthb = [] { const char* e = getenv("SS_BM25_STAGED_KTHB"); return e ? atoi(e) != 0 : true; }();  // (only read by builds with -DPB_STAGED_KTHB=1)
+  constexpr bool staged_kthb = true;  // (only read by builds with -DPB_STAGED_KTHB=1)
   const bool scan16m = scan16 && (np_max > 6 || (np_max > 4 && KPL == 2));  // the many-list instance (its waves share their best keys)
   const uint32_t resident = (pruned || phrase) ? 6144u : scan16 ? 4096u : 2048u, rounds = (pruned || phrase) ? 4u : 2u;
   uint32_t P = (rounds * resident) / nq;
@@ -497,12 +495,11 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   // waves in all, but never fewer than 16 partitions (150 sub-blocks per wave at 10 M docs): host-pointer calls of 8 / 64 / 145 / 256
   // queries 179 -> 159 / 280 -> 229 / 385 -> 290 / 488 -> 390 us, device-resident calls of 256 / 500 / 1000 queries 0.407 -> 0.275 /
   // 0.440 -> 0.39 / 0.625 -> 0.586 ms against the "four rounds, at most 160" rule above.
-  static const int p_rule = [] { const char* e = getenv("SS_BM25_P_RULE"); return e ? atoi(e) : 1; }();
   // (intersections -- the shortest list drives, the others are probed: shorter assignments balance better -- keep at least 48: 1000
   // 2-term ANDs 1.035 ms at 16 partitions, 0.975 at 24, 0.947 at 48, 0.972 at 64)
   // (heavy queries want more partitions: a head-heavy mix of 4.2 M postings per query 3.68 ms per 1000 at 16 partitions, 3.34 at 48; C2's
   // 1.35 M per query is best at 16 -- where the host has seen the queries, about one partition per 84 K postings)
-  if (pruned && p_rule) {
+  if (pruned) {
     uint32_t floor_p = has_and ? 48u : 16u;
     if (s->bm_batch_postings) floor_p = std::max<uint32_t>(floor_p, (uint32_t)std::min<uint64_t>(64u, s->bm_batch_postings / 84000u));
     P = std::max<uint32_t>(floor_p, std::min<uint32_t>(64u, 4096u / std::max<uint32_t>(nq, 1u)));
@@ -546,7 +543,7 @@ int ssi_bm25_search(ss_shard* s, uint32_t nq, const ss_bm25_query* d_q, uint32_t
   bm_expand_kernel<<<(nq + 127) / 128, 128, 0, st>>>(d_q, (bm_vquery*)W.d_vq, nq, s->bm_n_fields,
                                                     (const unsigned long long*)s->d_term_base, s->d_boost, total, tau, claim,
                                                     s->bm_n_terms, s->d_probe_row, s->bm_merged ? 1u : 0u,
-                                                    getenv("SS_BM25_KEEP_TAU") && atoi(getenv("SS_BM25_KEEP_TAU")) ? 1u : 0u,
+                                                    0u /* keep_tau: the ceiling experiment of round 3, tools/probes/tau_ceiling.py */,
                                                     (s->n_deleted || s->del_per_query || k == 0) ? nullptr : s->d_kthw, bm_kth_sel(k),
                                                     (scan16m || (pruned && staged_kthb)) ? bufA : nullptr, P, KS);
 

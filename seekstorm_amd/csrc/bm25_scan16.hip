@@ -1230,11 +1230,9 @@ int launch16m(const BmParams& p, hipStream_t st) {
 //  * intersections (and_exact_nt != 0): batches of intersections only, every query with exactly and_exact_nt = 2 or 3 terms over one
 //    list each, no all_terms_frequent shortcut (the dispatch checks); NOT lists / tombstones as for unions.
 bool ssi_bm25_scan16_serves(uint32_t nn_max, uint32_t np_max, bool has_and, bool count, bool tombstones, int KPL, uint32_t k, uint32_t and_exact_nt) {
-  static const int off = [] { const char* e = getenv("SS_BM25_SCAN16"); return e ? atoi(e) == 0 : 0; }();
-  static const int cnt_off = [] { const char* e = getenv("SS_BM25_SCAN16_COUNT"); return e ? atoi(e) == 0 : 0; }();
-  static const int and_off = [] { const char* e = getenv("SS_BM25_SCAN16_AND"); return e ? atoi(e) == 0 : 0; }();
-  static const int excl_off = [] { const char* e = getenv("SS_BM25_SCAN16_EXCL"); return e ? atoi(e) == 0 : 0; }();
-  static const int wide_off = [] { const char* e = getenv("SS_BM25_SCAN16_WIDE"); return e ? atoi(e) == 0 : 0; }();
+  // (the per-family switches of rounds 3-5 -- SS_BM25_SCAN16[_COUNT|_AND|_EXCL|_WIDE|_K128|_MANY]=0 -- are gone: SS_BM25_EXHAUSTIVE_F32 is
+  // the strategy that holds a batch on the f32 tile)
+  constexpr int off = 0, cnt_off = 0, and_off = 0, excl_off = 0, wide_off = 0;
   const uint32_t nn = nn_max;  // NOT lists of the query that has the most
   if (count && cnt_off) return false;
   if ((nn || tombstones) && excl_off) return false;
@@ -1242,8 +1240,7 @@ bool ssi_bm25_scan16_serves(uint32_t nn_max, uint32_t np_max, bool has_and, bool
   if (nn > 8) return false;
   if (has_and && (and_off || and_exact_nt < 2 || and_exact_nt > 3 || and_exact_nt != np_max)) return false;
   if (np_max > 4 && (has_and || count || wide_off)) return false;  // five and more lists: plain top-k unions
-  static const int k128_off = [] { const char* e = getenv("SS_BM25_SCAN16_K128"); return e ? atoi(e) == 0 : 0; }();
-  static const int many_off = [] { const char* e = getenv("SS_BM25_SCAN16_MANY"); return e ? atoi(e) == 0 : 0; }();
+  constexpr int k128_off = 0, many_off = 0;
   // 7 .. 32 lists, and 5 / 6 at k of 65 .. 128: bm25_scan16m_kernel (lists as a run-time loop)
   if (np_max > 6 || (np_max > 4 && KPL == 2)) return !off && !many_off && !k128_off && k != 0 && np_max <= (uint32_t)BM_MAX_VTERMS && KPL <= 2;
   if (KPL == 2 && k128_off) return false;  // k <= 128: two keys per lane in the candidate path (no k-lane cut)

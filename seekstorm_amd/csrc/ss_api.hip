@@ -382,7 +382,7 @@ int ssi_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen, uint32_
   // One indexed field: the image is BUILT ON THE DEVICE from the decoded arrays (the kernels of the incremental rebuild, synth.hip
   // ssi_bm25_rebuild_from_raw) -- the host validates and copies 6 bytes per posting instead of packing, sorting out segments and
   // filling probe rows.  SS_BM25_HOST_BUILD=1 keeps the host builder (the two are compared by the tests).
-  static const bool host_build = [] { const char* e = getenv("SS_BM25_HOST_BUILD"); return e && atoi(e) != 0; }();
+  constexpr bool host_build = false;  // (the host builder: images with several fields, and what the device builder was checked against)
   int rc;
   if (host_build) {
     rc = ssi_bm25_build_from_host(s, doclen, offs, docs, tfs, positions_sum);
@@ -448,7 +448,7 @@ int ssi_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, cons
   float bmax = 0.f;
   bool boosts_ok = true;
   for (float x : b) { boosts_ok = boosts_ok && x > 0.f && x < 1e30f; bmax = std::max(bmax, x); }
-  static const bool merged_off = [] { const char* e = getenv("SS_BM25_MERGED"); return e && atoi(e) == 0; }();
+  constexpr bool merged_off = false;
   (void)bmax;
   std::vector<uint64_t> df_real(n_terms, 0);
   for (uint32_t t = 0; t < n_terms; t++)
@@ -2759,7 +2759,7 @@ int ss_bm25_search_sorted(ss_shard* s, uint32_t nq, const ss_bm25_query* queries
   unsigned long long *d_E = (unsigned long long*)(W + o_E), *d_B = (unsigned long long*)(W + o_B), *d_xb = (unsigned long long*)(W + o_xb),
                      *d_xe = (unsigned long long*)(W + o_xe);
   SS_TRY(ensure_out(s, 1, k));
-  static const int batched_off = [] { const char* e = getenv("SS_SORT_BATCHED"); return e ? atoi(e) == 0 : 0; }();
+  constexpr int batched_off = 0;
   for (uint32_t c0 = 0; c0 < nq; c0 += CH) {
     const uint32_t nb = std::min<uint32_t>(CH, nq - c0);
     const ss_bm25_query* qc = queries + c0;

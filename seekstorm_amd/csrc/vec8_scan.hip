@@ -293,8 +293,7 @@ static V8Euc v8_euc(const ss_shard* s, const float* d_qscale) {
 template <bool SCALED, bool EVEN, bool ANN>
 static int launch_vec8(ss_shard* s, uint32_t tile0, uint32_t ntiles, const float* d_qscale, const VAnn& ann, hipStream_t st) {
   const uint32_t L = s->dim_pad8 / V8_LINE;
-  uint32_t gmax = 768;
-  if (const char* e = getenv("SS_VEC8_GRID")) gmax = (uint32_t)atoi(e);  // tuning override
+  const uint32_t gmax = 768;  // (3 workgroups per CU; profiles/r5: 512 / 768 / 1024 measured)
   const uint32_t grid = std::min<uint32_t>(ntiles, gmax);
   SS_SET_MAX_LDS((vec8_scan_kernel<SCALED, EVEN, ANN>), 160 * 1024);
   vec8_scan_kernel<SCALED, EVEN, ANN><<<grid, V8_WAVES * 64, L * 8192u, st>>>(

@@ -199,20 +199,11 @@ vec_scan_kernel(const float* __restrict__ X, uint32_t dim_pad, unsigned long lon
   if (G > 1) issue();
 
   uint32_t c_tile = 0, c_kc = 0, c_stage = 0;  // consume cursor
-#ifdef VS_PROF  // measurement build: where a wave's cycles go (s_memtime around the phases of a chunk; printed by two waves of the big launch)
-  unsigned long long pf_wait = 0, pf_bar = 0, pf_read = 0, pf_mma = 0, pf_epi = 0, pf_t = __builtin_readcyclecounter();
-  const unsigned long long pf_c0 = pf_t, pf_w0 = wall_clock64();
-#define PF(acc_) { const unsigned long long t_ = __builtin_readcyclecounter(); acc_ += t_ - pf_t; pf_t = t_; }
-#else
-#define PF(acc_)
-#endif
   for (uint32_t g = 0; g < G; ++g) {
     // my own 6 LDS-DMA pieces of chunk g have landed (chunk g+1's 6 may still be in flight)
     if (g + 1 < G) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PF(pf_wait)
     __builtin_amdgcn_s_barrier();  // everyone's pieces landed; everyone finished reading stage (g-1)%3
-    PF(pf_bar)
     if (g + 2 < G) issue();        // refill the stage consumed in iteration g-1
 
     const char* sb = smem + c_stage * VS_STAGE;
@@ -223,10 +214,6 @@ vec_scan_kernel(const float* __restrict__ X, uint32_t dim_pad, unsigned long lon
       qb0[t] = *(const f32x4*)(sb + boff + t * 1024);
       if (TWO) qb1[t] = *(const f32x4*)(sb + boff + (4 + t) * 1024);
     }
-#ifdef VS_PROF
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    PF(pf_read)
-#endif
 #pragma unroll
     for (int t = 0; t < 4; t++) {
 #pragma unroll
@@ -235,7 +222,6 @@ vec_scan_kernel(const float* __restrict__ X, uint32_t dim_pad, unsigned long lon
         if (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[t][j], qb1[t][j], acc1, 0, 0, 0);
       }
     }
-    PF(pf_mma)
 
     if (++c_kc == nch) {
       // ---- fused top-k filter: lane owns query (lane&31)+{0,32}, 16 rows per accumulator
@@ -265,346 +251,9 @@ vec_scan_kernel(const float* __restrict__ X, uint32_t dim_pad, unsigned long lon
       ++c_tile;
     }
     if (++c_stage == VS_STAGES) c_stage = 0;
-    PF(pf_epi)
-  }
-#ifdef VS_PROF
-  if (G > 2000 && lane == 0 && (w == 0 || w == 3) && (blockIdx.x == 0 || blockIdx.x == 300)) {
-    const unsigned long long c = __builtin_readcyclecounter() - pf_c0, wl = wall_clock64() - pf_w0;
-    printf("VS_PROF block %u wave %d chunks %u: cycles %llu (%.0f MHz)  per chunk: wait %.0f barrier %.0f issue+read %.0f mfma %.0f epilogue %.0f\n", blockIdx.x, w, G, c,
-           (double)c / ((double)wl / 100.0), (double)pf_wait / G, (double)pf_bar / G, (double)pf_read / G, (double)pf_mma / G, (double)pf_epi / G);
-  }
-#endif
-#undef PF
-}
-
-// ================================================================ measurement builds only (-DVS_VARIANTS=1)
-// Two other structures of the same scan, built in round 5 against "0.69 of the MFMA peak" and kept for the A/B
-// (tools/probes/vec_scan_ab.py, SS_VEC_SCAN_Q=2 / 1): neither beats vec_scan_kernel -- all three land at 105-108 TFLOP/s, because
-// under this load (matrix pipe + 3.3 TB/s of HBM) the chip holds ~2.0 GHz, not the 2.4 GHz the 157.3 TFLOP/s peak assumes (the
-// wave's own s_memtime / s_memrealtime, -DVS_PROF=1), while an MFMA-only loop holds 2.39 GHz and 0.98 of the peak
-// (tools/probes/mfma_peak.hip).  DESIGN 3.1, profiles/r5_vec_scan_variants.log.
-#ifdef VS_VARIANTS
-// ---------------------------------------------------------------- the scan, operands one chunk ahead (round 5)
-// vec_scan_kernel reads a chunk's twelve operand fragments from LDS AFTER the chunk's barrier and multiplies when they arrive; the two
-// waves of a SIMD (one per workgroup) take turns on the matrix pipe, finish their chunks together and then both sit in that
-// barrier + read phase: the pipe idles 20 % of the cycles.  Here a wave multiplies chunk g from REGISTERS while its reads of chunk
-// g + 1 are in flight (two operand sets, 48 more VGPRs -- there are 256 at two waves per SIMD): after the barrier of a chunk the
-// first MFMA issues at once.  Ring and counting: at the top of chunk g the wave waits for its reads of chunk g (lgkmcnt(0): nobody
-// may still read the stage the next DMA overwrites) and for its own DMA pieces of chunk g + 1 (vmcnt(6): chunk g + 2 stays in
-// flight), meets the others, issues the DMA of chunk g + 3 into the stage chunk g has left, reads chunk g + 1, multiplies chunk g.
-struct VpOps { f32x4 xa[4], q0[4], q1[4]; };
-
-template <bool TWO, bool ANN>
-__global__ void __launch_bounds__(VS_WAVES * 64, 2)
-vec_scan_p_kernel(const float* __restrict__ X, uint32_t dim_pad, unsigned long long n_rows,
-                  const float* __restrict__ Qf, uint32_t nch, uint32_t tile0, uint32_t ntiles, VState* __restrict__ st,
-                  unsigned long long* __restrict__ cand, VAnn ann) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  float tau0 = st->tau[lane & 31];
-  float tau1 = st->tau[32 + (lane & 31)];
-  if (st->ovf) return;
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(tau0), "+v"(tau1)::"memory");
-
-  if (ANN && ann.tiles) {
-    const uint32_t na = *ann.n_tiles;
-    ntiles = na > tile0 ? min(ntiles, na - tile0) : 0u;
-  }
-  const uint32_t first = blockIdx.x;
-  if (first >= ntiles) return;
-  const uint32_t my_tiles = (ntiles - first + gridDim.x - 1) / gridDim.x;
-  const uint32_t G = my_tiles * nch;
-
-  uint32_t xsrc[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    uint32_t rl = 32u * w + 8u * i + (lane >> 3);
-    uint32_t f = (rl >> 1) & 7u;
-    uint32_t piece = (uint32_t)(lane & 7) ^ f;
-    xsrc[i] = rl * dim_pad + piece * 4u;
-  }
-  const size_t tile_stride = (size_t)VS_TR * dim_pad;
-  uint32_t aoff[4];
-  {
-    uint32_t rw = 32u * w + (lane & 31);
-    uint32_t f = (rw >> 1) & 7u;
-#pragma unroll
-    for (int t = 0; t < 4; t++) aoff[t] = rw * 128u + (((2u * t + (lane >> 5)) ^ f) << 4);
-  }
-  const uint32_t boff = VS_XS + lane * 16u;
-
-  uint32_t i_tile = 0, i_kc = 0, i_stage = 0, i_tix = 0;
-  auto issue = [&]() {
-    if (ANN) { if (i_kc == 0) i_tix = ann.tiles ? ann.tiles[tile0 + first + i_tile * gridDim.x] : tile0 + first + i_tile * gridDim.x; }
-    const size_t tix = ANN ? (size_t)i_tix : (size_t)(tile0 + first + (size_t)i_tile * gridDim.x);
-    const float* xt = X + tix * tile_stride + i_kc * VS_KC;
-    char* sb = smem + i_stage * VS_STAGE;
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-      __builtin_amdgcn_global_load_lds(GPTR(xt + xsrc[i]), LPTR(sb + (32 * w + 8 * i) * 128), 16, 0, 0);
-    const float* qs = Qf + (size_t)i_kc * 2048 + lane * 4;
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-      __builtin_amdgcn_global_load_lds(GPTR(qs + (2 * w + i) * 256), LPTR(sb + VS_XS + (2 * w + i) * 1024), 16, 0, 0);
-    if (++i_kc == nch) { i_kc = 0; ++i_tile; }
-    if (++i_stage == VS_STAGES) i_stage = 0;
-  };
-  uint32_t r_stage = 0;  // stage of the next chunk to read
-  auto read_ops = [&](VpOps& R) {
-    const char* sb = smem + r_stage * VS_STAGE;
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      R.xa[t] = *(const f32x4*)(sb + aoff[t]);
-      R.q0[t] = *(const f32x4*)(sb + boff + t * 1024);
-      if (TWO) R.q1[t] = *(const f32x4*)(sb + boff + (4 + t) * 1024);
-    }
-    if (++r_stage == VS_STAGES) r_stage = 0;
-  };
-
-  f32x16 acc0, acc1;
-#pragma unroll
-  for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
-  uint32_t c_tile = 0, c_kc = 0;
-
-  // chunk g: cur = its operands (read during chunk g - 1), nxt = where chunk g + 1's go
-  auto step = [&](const VpOps& cur, VpOps& nxt, uint32_t g) {
-    if (g + 2 < G) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (g + 3 < G) issue();
-    read_ops(nxt);  // (past the last chunk: a stage that holds nothing new -- read and never used)
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.xa[t][j], cur.q0[t][j], acc0, 0, 0, 0);
-        if (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.xa[t][j], cur.q1[t][j], acc1, 0, 0, 0);
-      }
-    }
-    if (++c_kc == nch) {
-      const unsigned long long c_tix = (ANN && ann.tiles) ? (unsigned long long)ann.tiles[tile0 + first + c_tile * gridDim.x]
-                                           : (unsigned long long)(tile0 + first + (unsigned long long)c_tile * gridDim.x);
-      const unsigned long long row_base = c_tix * VS_TR + 32u * w + 4u * (lane >> 5);
-      float m0 = acc0[0], m1 = TWO ? acc1[0] : -INFINITY;
-#pragma unroll
-      for (int r = 1; r < 16; r++) { m0 = fmaxf(m0, acc0[r]); if (TWO) m1 = fmaxf(m1, acc1[r]); }
-      if (m0 > tau0) {
-        float f[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) f[r] = acc0[r];
-        if (ANN) vs_append_ann(f, tau0, lane & 31, row_base, n_rows, st, cand, ann);
-        else vs_append(f, tau0, lane & 31, row_base, n_rows, st, cand);
-      }
-      if (TWO && m1 > tau1) {
-        float f[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) f[r] = acc1[r];
-        if (ANN) vs_append_ann(f, tau1, 32 + (lane & 31), row_base, n_rows, st, cand, ann);
-        else vs_append(f, tau1, 32 + (lane & 31), row_base, n_rows, st, cand);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
-      c_kc = 0;
-      ++c_tile;
-    }
-  };
-
-  issue();
-  if (G > 1) issue();
-  if (G > 2) issue();
-  if (G > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else if (G > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  VpOps R0, R1;
-  read_ops(R0);
-  for (uint32_t g = 0; g < G; g += 2) {
-    step(R0, R1, g);
-    if (g + 1 < G) step(R1, R0, g + 1);
   }
 }
 
-// ---------------------------------------------------------------- the scan, waves on their own (round 5)
-// The kernel above shares ONE copy of the query chunk per workgroup in LDS -- which is what its barrier per K-chunk is for: the
-// four waves advance in lock step, 2 workgroups (2 waves per SIMD) fit a CU beside their 72 KB rings, and the matrix pipe is
-// busy 80 % of the cycles.  Here a wave takes its B operands STRAIGHT from the fragment-ordered query image (8 coalesced
-// 1 KB loads per chunk, L1 / L2 hits: the image is 196 KB for 64 x 768) into registers, one chunk ahead, and keeps a ring
-// of only its own 32 rows in LDS (VQ_STAGES x 4 KB): no barrier anywhere, no wave waits for another, and 12 KB per wave
-// lets three workgroups share a CU.  vmcnt is counted by hand: per chunk the order of issue is Q(g+1), X(g+2), so at the top of
-// chunk g everything but the four X pieces of chunk g+1 has landed at vmcnt(4).
-#ifndef VQ_OCC
-#define VQ_OCC 3
-#endif
-constexpr int VQ_STAGES = 3;
-constexpr int VQ_WAVE_LDS = VQ_STAGES * 32 * 128;
-constexpr int VQ_LDS = VS_WAVES * VQ_WAVE_LDS;
-
-struct VqFrag { f32x4 q0[4], q1[4]; };
-
-// The query fragments are loaded by inline asm: the compiler's own wait for a register loaded in the previous trip of the loop
-// is vmcnt(0) (measured: the ring drains every chunk).  What it cannot know is that the registers are not valid until the hand-placed
-// wait, so it must never COPY them in between: the streaming loop below has no condition around its loads (a phi between "loaded"
-// and "kept" is a copy), handles two chunks per trip (A and B keep their registers across the back edge), waits at the END of a chunk
-// for the next one's fragments, and leaves the last chunks to a plain loop whose loads the compiler sees.
-template <bool TWO>
-__device__ __forceinline__ void vq_load_asm(VqFrag& F, const float* p) {
-  const float* p1 = p + 1024;  // (the second 32 queries' fragments; an instruction offset reaches 4095 B)
-#pragma unroll
-  for (int t = 0; t < 4; t++) {
-    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(F.q0[t]) : "v"(p), "n"(t * 1024) : "memory");
-    if (TWO) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(F.q1[t]) : "v"(p1), "n"(t * 1024) : "memory");
-  }
-}
-template <bool TWO>
-__device__ __forceinline__ void vq_load(VqFrag& F, const float* p) {
-#pragma unroll
-  for (int t = 0; t < 4; t++) {
-    F.q0[t] = *(const f32x4*)(p + t * 256);
-    if (TWO) F.q1[t] = *(const f32x4*)(p + 1024 + t * 256);
-  }
-}
-
-template <bool TWO, bool ANN>
-__global__ void __launch_bounds__(VS_WAVES * 64, VQ_OCC)
-vec_scan_q_kernel(const float* __restrict__ X, uint32_t dim_pad, unsigned long long n_rows,
-                  const float* __restrict__ Qf, uint32_t nch, uint32_t tile0, uint32_t ntiles, VState* __restrict__ st,
-                  unsigned long long* __restrict__ cand, VAnn ann) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  float tau0 = st->tau[lane & 31];
-  float tau1 = st->tau[32 + (lane & 31)];
-  if (st->ovf) return;
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(tau0), "+v"(tau1)::"memory");
-
-  if (ANN && ann.tiles) {
-    const uint32_t na = *ann.n_tiles;
-    ntiles = na > tile0 ? min(ntiles, na - tile0) : 0u;
-  }
-  const uint32_t first = blockIdx.x;
-  if (first >= ntiles) return;
-  const uint32_t my_tiles = (ntiles - first + gridDim.x - 1) / gridDim.x;
-  const uint32_t G = my_tiles * nch;
-
-  uint32_t xsrc[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    uint32_t rl = 32u * w + 8u * i + (lane >> 3);
-    uint32_t f = (rl >> 1) & 7u;
-    uint32_t piece = (uint32_t)(lane & 7) ^ f;
-    xsrc[i] = rl * dim_pad + piece * 4u;
-  }
-  const size_t tile_stride = (size_t)VS_TR * dim_pad;
-  char* ring = smem + w * VQ_WAVE_LDS;  // this wave's own rows
-  uint32_t aoff[4];
-  {
-    const uint32_t r = (uint32_t)lane & 31u;
-    const uint32_t f = (r >> 1) & 7u;  // (= the producer's key: 32 w + r has the same bits 1..3)
-#pragma unroll
-    for (int t = 0; t < 4; t++) aoff[t] = r * 128u + (((2u * t + ((uint32_t)lane >> 5)) ^ f) << 4);
-  }
-  const float* qlane = Qf + lane * 4;
-
-  uint32_t i_tile = 0, i_kc = 0, i_stage = 0, i_tix = 0;  // issue cursor of the X ring
-  auto issue_x = [&]() {
-    if (ANN) { if (i_kc == 0) i_tix = ann.tiles ? ann.tiles[tile0 + first + i_tile * gridDim.x] : tile0 + first + i_tile * gridDim.x; }
-    const size_t tix = ANN ? (size_t)i_tix : (size_t)(tile0 + first + (size_t)i_tile * gridDim.x);
-    const float* xt = X + tix * tile_stride + i_kc * VS_KC;
-    char* sb = ring + i_stage * 4096;
-#pragma unroll
-    for (int i = 0; i < 4; i++) __builtin_amdgcn_global_load_lds(GPTR(xt + xsrc[i]), LPTR(sb + i * 1024), 16, 0, 0);
-    if (++i_kc == nch) { i_kc = 0; ++i_tile; }
-    if (++i_stage == VQ_STAGES) i_stage = 0;
-  };
-
-  f32x16 acc0, acc1;
-#pragma unroll
-  for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
-  uint32_t c_tile = 0, c_kc = 0, c_stage = 0, q_kc = 0;  // consume cursor; q_kc: chunk of the NEXT query fragments to load
-
-  // the arithmetic of one chunk and, after a tile's last chunk, the fused top-k filter (as in vec_scan_kernel)
-  auto consume = [&](const VqFrag& cur) {
-    const char* sb = ring + c_stage * 4096;
-    f32x4 xa[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) xa[t] = *(const f32x4*)(sb + aoff[t]);
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[t][j], cur.q0[t][j], acc0, 0, 0, 0);
-        if (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[t][j], cur.q1[t][j], acc1, 0, 0, 0);
-      }
-    }
-    if (++c_kc == nch) {
-      const unsigned long long c_tix = (ANN && ann.tiles) ? (unsigned long long)ann.tiles[tile0 + first + c_tile * gridDim.x]
-                                           : (unsigned long long)(tile0 + first + (unsigned long long)c_tile * gridDim.x);
-      const unsigned long long row_base = c_tix * VS_TR + 32u * w + 4u * (lane >> 5);
-      float m0 = acc0[0], m1 = TWO ? acc1[0] : -INFINITY;
-#pragma unroll
-      for (int r = 1; r < 16; r++) { m0 = fmaxf(m0, acc0[r]); if (TWO) m1 = fmaxf(m1, acc1[r]); }
-      if (m0 > tau0) {
-        float f[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) f[r] = acc0[r];
-        if (ANN) vs_append_ann(f, tau0, lane & 31, row_base, n_rows, st, cand, ann);
-        else vs_append(f, tau0, lane & 31, row_base, n_rows, st, cand);
-      }
-      if (TWO && m1 > tau1) {
-        float f[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) f[r] = acc1[r];
-        if (ANN) vs_append_ann(f, tau1, 32 + (lane & 31), row_base, n_rows, st, cand, ann);
-        else vs_append(f, tau1, 32 + (lane & 31), row_base, n_rows, st, cand);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
-      c_kc = 0;
-      ++c_tile;
-    }
-    if (++c_stage == VQ_STAGES) c_stage = 0;
-  };
-  // a streaming chunk g: every load of it is unconditional (the caller guarantees that chunks g + 1 and g + 2 exist), and it ENDS
-  // with the wait for what the next chunk consumes -- Q(g+1) and X(g+1); only the four pieces of X(g+2) stay in flight -- so that
-  // nothing loaded by asm is pending at the back edge or at the loop's exit, where the compiler may copy registers
-  auto stream = [&](const VqFrag& cur, VqFrag& nxt) {
-    vq_load_asm<TWO>(nxt, qlane + (size_t)q_kc * 2048);
-    if (++q_kc == nch) q_kc = 0;
-    issue_x();
-    consume(cur);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  };
-
-  VqFrag A, B;
-  issue_x();                       // X(0)
-  vq_load_asm<TWO>(A, qlane);      // Q(0)
-  q_kc = nch > 1 ? 1u : 0u;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (G > 1) issue_x();            // X(1)
-  uint32_t g = 0;
-  for (; g + 3 < G; g += 2) {      // chunks g, g + 1: both have two successors
-    stream(A, B);
-    stream(B, A);
-  }
-  // the last one to three chunks, one at a time: A = Q(g) and X(g) have landed, X(g+1) is on its way, q_kc names chunk g + 1
-  VqFrag T = A;
-  for (; g < G; ++g) {
-    VqFrag N;
-    const bool more = g + 1 < G;
-    if (more) { vq_load<TWO>(N, qlane + (size_t)q_kc * 2048); if (++q_kc == nch) q_kc = 0; }
-    if (g + 2 < G) issue_x();
-    consume(T);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (more) T = N;
-  }
-}
-
-#endif  // VS_VARIANTS
 
 // ---------------------------------------------------------------- ANN batches: the sparse instantiation
 // A batch of independent queries under AnnMode::Nprobe selects, per query, n_probe of every level's clusters; the batch's UNION of
@@ -982,16 +631,6 @@ int ssi_vec_alloc_ws(ss_shard* s) {
   SS_SET_MAX_LDS((vec_scan_kernel<false, false>), VS_LDS);
   SS_SET_MAX_LDS((vec_scan_kernel<true, true>), VS_LDS);
   SS_SET_MAX_LDS((vec_scan_kernel<false, true>), VS_LDS);
-#ifdef VS_VARIANTS
-  SS_SET_MAX_LDS((vec_scan_p_kernel<true, false>), VS_LDS);
-  SS_SET_MAX_LDS((vec_scan_p_kernel<false, false>), VS_LDS);
-  SS_SET_MAX_LDS((vec_scan_p_kernel<true, true>), VS_LDS);
-  SS_SET_MAX_LDS((vec_scan_p_kernel<false, true>), VS_LDS);
-  SS_SET_MAX_LDS((vec_scan_q_kernel<true, false>), 160 * 1024);
-  SS_SET_MAX_LDS((vec_scan_q_kernel<false, false>), 160 * 1024);
-  SS_SET_MAX_LDS((vec_scan_q_kernel<true, true>), 160 * 1024);
-  SS_SET_MAX_LDS((vec_scan_q_kernel<false, true>), 160 * 1024);
-#endif
   SS_SET_MAX_LDS(vec_refine_kernel, VS_CAP * (sizeof(unsigned long long) + sizeof(uint32_t)));
   return SS_OK;
 }
@@ -1034,12 +673,6 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float*
     // query; keep that 2.5 times below the free slots (an adversarial order overflows and re-runs in safe mode)
     double g_cap = 16.0, margin = 2.5;
     uint32_t first = VS_FIRST_TILES;
-    const char* e = ann_mode ? nullptr : getenv("SS_VEC_SCHED");  // (the ANN tile lists keep the conservative schedule)
-    if (e) {  // tuning override: "first_tiles,growth_cap,margin"
-      unsigned f = 0;
-      double a = 0, b = 0;
-      if (sscanf(e, "%u,%lf,%lf", &f, &a, &b) == 3 && f >= 1 && f <= VS_CAP / VS_TR && a >= 1.5 && b >= 1.0) { first = f; g_cap = a; margin = b; }
-    }
     double growth = std::max(1.5, std::min(g_cap, (double)(VS_CAP - k) / (margin * k)));
     uint32_t done = std::min<uint32_t>(T, first);
     chunks.push_back(done);
@@ -1075,32 +708,19 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float*
     // of its queries each -- expected interested queries per tile = nb x n_probe / (clusters per level) <= 8
     uint32_t sparse_nv = 0;
     {
-      static const int sparse_on = [] { const char* e = getenv("SS_VEC_ANN_SPARSE"); return e ? atoi(e) : 1; }();
-      if (sparse_on && ann_clusters && !i8 && !euclid && nb > 32 && ann_mode->n_probe != 0 && s->dim == s->dim_pad && s->dim % 256u == 0 &&
+      if (ann_clusters && !i8 && !euclid && nb > 32 && ann_mode->n_probe != 0 && s->dim == s->dim_pad && s->dim % 256u == 0 &&
           s->dim <= 1024u && s->vec_n_clusters && (double)nb * ann_mode->n_probe * s->vec_n_levels <= 8.0 * s->vec_n_clusters)
         sparse_nv = s->dim / 256u;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     ssi_prof_begin(s, 1, st, &e0, &e1);
-#ifdef VS_VARIANTS
-    // measurement switches, read per call: SS_VEC_SCAN_Q = 2 operands one chunk ahead, 1 waves on their own (SS_VQ_PAD extra LDS bytes
-    // per workgroup = fewer workgroups per CU; SS_VQ_WGS persistent workgroups per CU), 0 the product kernel
-    const auto env_int = [](const char* n, int d) { const char* e = getenv(n); return e ? atoi(e) : d; };
-    const int scan_q = env_int("SS_VEC_SCAN_Q", 0), vq_pad = env_int("SS_VQ_PAD", 0), vq_wgs = env_int("SS_VQ_WGS", VQ_OCC);
-#else
-    // (product build: vec_scan_kernel only)
-#endif
     for (uint32_t c : chunks) {
-      #ifdef VS_VARIANTS
-      uint32_t grid = std::min<uint32_t>(c, scan_q == 1 ? 256u * (uint32_t)vq_wgs : 512u);
-#else
       // workgroups per launch: 2 per CU at a time (72 KB of LDS each).  A grid of exactly 512 would be PERSISTENT -- every workgroup lives as
       // long as the chunk, 8 ms for the last one of a 10 M-row pass, and nothing else gets a CU's LDS meanwhile: a lexical launch on the
       // shard's high-priority stream (a hybrid caller's first half) then waits for the pass to end (profiles/r6_hybrid_hist.log: 7.6 ms of
       // device wait per lexical batch under T = 256 hybrid callers).  VS_GRID_MULT x as many workgroups, each walking 1 / VS_GRID_MULT of
       // the tiles: a workgroup retires every few hundred microseconds and the dispatcher hands its CU to the higher-priority queue first.
       uint32_t grid = std::min<uint32_t>(c, 512u * VS_GRID_MULT);
-#endif
       if (i8) ssi_vec8_launch_scan(s, tile0, c, d_qscale ? d_qscale + g0 : nullptr, ann_mode ? &ann : nullptr, st);
       else if (ann_mode && sparse_nv) {
         const uint32_t sg = std::min<uint32_t>(c, 1024);
@@ -1108,18 +728,6 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float*
 #define SS_SPARSE(NV_) vec_ann_sparse_kernel<NV_><<<sg, 256, 0, st>>>(s->d_X, s->dim_pad, (unsigned long long)s->n_rows, qraw, nb, tile0, c, vst, cand, ann)
         if (sparse_nv == 1) SS_SPARSE(1); else if (sparse_nv == 2) SS_SPARSE(2); else if (sparse_nv == 3) SS_SPARSE(3); else SS_SPARSE(4);
 #undef SS_SPARSE
-#ifdef VS_VARIANTS
-      } else if (scan_q == 2) {
-#define SS_VP(TWO_, ANN_) vec_scan_p_kernel<TWO_, ANN_><<<grid, VS_WAVES * 64, VS_LDS, st>>>(s->d_X, s->dim_pad, (unsigned long long)s->n_rows, s->d_Qf, nch, tile0, c, vst, cand, ann)
-        if (ann_mode) { if (nb > 32) SS_VP(true, true); else SS_VP(false, true); }
-        else { if (nb > 32) SS_VP(true, false); else SS_VP(false, false); }
-#undef SS_VP
-      } else if (scan_q) {
-#define SS_VQ(TWO_, ANN_) vec_scan_q_kernel<TWO_, ANN_><<<grid, VS_WAVES * 64, VQ_LDS + vq_pad, st>>>(s->d_X, s->dim_pad, (unsigned long long)s->n_rows, s->d_Qf, nch, tile0, c, vst, cand, ann)
-        if (ann_mode) { if (nb > 32) SS_VQ(true, true); else SS_VQ(false, true); }
-        else { if (nb > 32) SS_VQ(true, false); else SS_VQ(false, false); }
-#undef SS_VQ
-#endif
       } else if (ann_mode) {
         if (nb > 32)
           vec_scan_kernel<true, true><<<grid, VS_WAVES * 64, VS_LDS, st>>>(s->d_X, s->dim_pad, (unsigned long long)s->n_rows,

@@ -409,3 +409,10 @@ def test_committed_bench_line_and_counter_file_belong_together():
     assert abs(line["roofline"]["traffic"] - pmc["bm25"]["hbm_bytes_per_launch"]) / pmc["bm25"]["hbm_bytes_per_launch"] < 1e-3
     if pmc["kernel_source_hash"] != bench.kernel_source_hash():
         pytest.skip("profiles/pmc_traffic.json predates the kernel sources of this tree: bench.py reports traffic = null until tools/collect_pmc.sh is re-run")
+
+
+def test_bench_offers_the_one_process_shape():
+    """bench.py --one-process S: the reference's own shape (one process, one task per shard; VERDICT r5 "next" 9) beside the rank-per-GPU form"""
+    import subprocess, sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "--one-process" in out.stdout and "--gpus" in out.stdout
