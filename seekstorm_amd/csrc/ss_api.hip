@@ -2515,7 +2515,8 @@ int ss_bm25_search_filtered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, ui
                             uint64_t* out_total) {
   if (!s || !q || !out_count || !out_total) return SS_EINVAL;
   if (rt > SS_RT_TOPKCOUNT) return SS_EINVAL;
-  if (rt != SS_RT_COUNT && (k == 0 || k > SS_MAX_K || !out_doc || !out_score)) return SS_EINVAL;
+  if (rt != SS_RT_COUNT && (k == 0 || !out_doc || !out_score)) return SS_EINVAL;
+  if (rt != SS_RT_COUNT && k > SS_MAX_K) return SS_ENOTSUP;  // (the crate's offset + length is unbounded, search.rs:1658-1659: its own dispatch pages that deep)
   if (!s->d_post) return SS_ESTATE;
   if (nq == 0) return SS_OK;
   if (n_filters == 0 && nq <= SS_COALESCE_MAX_REQUEST && s->co_lex.max_batch) {
@@ -2535,7 +2536,8 @@ int ss_bm25_search_sharded(ss_shard* s, ss_comm* c, uint32_t nq, const ss_bm25_q
                            uint64_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total) {
   if (!s || !c || !q || !out_total) return SS_EINVAL;
   if (rt > SS_RT_TOPKCOUNT) return SS_EINVAL;
-  if (rt != SS_RT_COUNT && (k == 0 || k > SS_MAX_K || !out_doc || !out_score || !out_count)) return SS_EINVAL;
+  if (rt != SS_RT_COUNT && (k == 0 || !out_doc || !out_score || !out_count)) return SS_EINVAL;
+  if (rt != SS_RT_COUNT && k > SS_MAX_K) return SS_ENOTSUP;
   int dev = -1, n_ranks = 0;
   SS_TRY(ss_comm_info(c, nullptr, &n_ranks, &dev));
   const uint32_t kk = rt == SS_RT_COUNT ? 0 : k;
@@ -2556,7 +2558,8 @@ int ss_bm25_search_sharded(ss_shard* s, ss_comm* c, uint32_t nq, const ss_bm25_q
 int ss_vec_search_sharded(ss_shard* s, ss_comm* c, uint32_t nq, const float* queries, uint32_t k, float thr, uint64_t* out_doc,
                           float* out_score, uint32_t* out_count, uint64_t* out_total) {
   if (!s || !c || !queries || !out_doc || !out_score || !out_count || !out_total) return SS_EINVAL;
-  if (k == 0 || k > SS_MAX_K || nq > SS_VEC_BATCH) return SS_EINVAL;
+  if (k == 0 || nq > SS_VEC_BATCH) return SS_EINVAL;
+  if (k > SS_MAX_K) return SS_ENOTSUP;
   int dev = -1, n_ranks = 0;
   SS_TRY(ss_comm_info(c, nullptr, &n_ranks, &dev));
   if ((uint64_t)n_ranks * k > 8192) return SS_EINVAL;
@@ -2577,7 +2580,8 @@ int ss_hybrid_search_sharded(ss_shard* s, ss_comm* c, uint32_t nq, const ss_bm25
                              uint32_t* out_count, uint64_t* out_total) {
   if (!s || !c || !q || !queries || !out_doc || !out_score || !out_count || !out_total) return SS_EINVAL;
   if (rt != SS_RT_TOPK && rt != SS_RT_TOPKCOUNT) return SS_EINVAL;
-  if (k == 0 || k > SS_MAX_K || length == 0 || nq > SS_VEC_BATCH) return SS_EINVAL;
+  if (k == 0 || length == 0 || nq > SS_VEC_BATCH) return SS_EINVAL;
+  if (k > SS_MAX_K) return SS_ENOTSUP;
   int dev = -1, n_ranks = 0;
   SS_TRY(ss_comm_info(c, nullptr, &n_ranks, &dev));
   if ((uint64_t)n_ranks * k * 2 > 4096) return SS_EINVAL;  // both concatenations live in the fusion kernel's LDS
@@ -2721,7 +2725,8 @@ int ss_bm25_facet_kth_point(ss_shard* s, const ss_bm25_query* query, uint32_t n_
 int ss_bm25_search_sorted(ss_shard* s, uint32_t nq, const ss_bm25_query* queries, uint32_t n_sorts, const ss_result_sort* sorts, uint32_t k,
                           uint32_t n_filters, const ss_facet_filter* filters, uint32_t* out_doc, float* out_score, uint32_t* out_count,
                           uint64_t* out_total) {
-  if (!s || !queries || nq == 0 || !out_doc || !out_score || !out_count || !out_total || k == 0 || k > SS_MAX_K) return SS_EINVAL;
+  if (!s || !queries || nq == 0 || !out_doc || !out_score || !out_count || !out_total || k == 0) return SS_EINVAL;
+  if (k > SS_MAX_K) return SS_ENOTSUP;
   if (n_sorts == 0) return ss_bm25_search_filtered(s, nq, queries, k, SS_RT_TOPKCOUNT, n_filters, filters, out_doc, out_score, out_count, out_total);
   if (!sorts) return SS_EINVAL;
   if (n_sorts > SS_MAX_SORT_FIELDS) return SS_ENOTSUP;
@@ -2847,7 +2852,8 @@ int ss_bm25_search_filtered_dev(ss_shard* s, uint32_t nq, const ss_bm25_query* d
                                 uint32_t* d_out_count, uint64_t* d_out_total, void* stream) {
   if (!s || !d_q || !d_out_count || !d_out_total) return SS_EINVAL;
   if (rt > SS_RT_TOPKCOUNT) return SS_EINVAL;
-  if (rt != SS_RT_COUNT && (k == 0 || k > SS_MAX_K || !d_out_doc || !d_out_score)) return SS_EINVAL;
+  if (rt != SS_RT_COUNT && (k == 0 || !d_out_doc || !d_out_score)) return SS_EINVAL;
+  if (rt != SS_RT_COUNT && k > SS_MAX_K) return SS_ENOTSUP;
   if (!s->d_post) return SS_ESTATE;
   std::lock_guard<std::mutex> g(s->mu);
   SS_HIP(hipSetDevice(s->device));
@@ -3198,7 +3204,8 @@ static int ann_mode_ok(const ss_shard* s, const ss_ann_mode* mode) {
 int ss_vec_search_ann(ss_shard* s, uint32_t nq, const float* queries, uint32_t k, float thr, const ss_ann_mode* mode,
                       uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total, uint32_t* out_clusters) {
   if (!s || !queries || !out_doc || !out_score || !out_count || !out_total) return SS_EINVAL;
-  if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
+  if (k == 0) return SS_EINVAL;
+  if (k > SS_MAX_K) return SS_ENOTSUP;  // (deeper pages: the host's own dispatch)
   if (!s->d_X) return SS_ESTATE;
   SS_TRY(ann_mode_ok(s, mode));
   mode = ann_effective(mode);
@@ -3220,7 +3227,8 @@ int ss_vec_search_ann_dev(ss_shard* s, uint32_t nq, const float* d_queries, uint
                           uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total,
                           uint32_t* d_out_clusters, void* stream) {
   if (!s || !d_queries || !d_out_doc || !d_out_score || !d_out_count || !d_out_total) return SS_EINVAL;
-  if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
+  if (k == 0) return SS_EINVAL;
+  if (k > SS_MAX_K) return SS_ENOTSUP;  // (deeper pages: the host's own dispatch)
   if (!s->d_X) return SS_ESTATE;
   SS_TRY(ann_mode_ok(s, mode));
   mode = ann_effective(mode);
@@ -3518,7 +3526,8 @@ int ss_vec_search_i8_euclid(ss_shard* s, uint32_t nq, const int8_t* queries, con
                             uint32_t k, float thr, const ss_ann_mode* mode, uint32_t* out_doc, float* out_score, uint32_t* out_count,
                             uint64_t* out_total, uint32_t* out_clusters) {
   if (!s || !queries || !out_doc || !out_score || !out_count || !out_total) return SS_EINVAL;
-  if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
+  if (k == 0) return SS_EINVAL;
+  if (k > SS_MAX_K) return SS_ENOTSUP;  // (deeper pages: the host's own dispatch)
   if (!s->d_X8) return SS_ESTATE;
   SS_TRY(vec8_euclid_norms_ok(s, query_scale != nullptr, query_norm != nullptr));
   SS_TRY(ann_mode_ok(s, mode));
@@ -3552,7 +3561,8 @@ int ss_vec_search_i8_euclid_dev(ss_shard* s, uint32_t nq, const int8_t* d_querie
                                 uint32_t k, float thr, const ss_ann_mode* mode, uint32_t* d_out_doc, float* d_out_score,
                                 uint32_t* d_out_count, uint64_t* d_out_total, uint32_t* d_out_clusters, void* stream) {
   if (!s || !d_queries || !d_out_doc || !d_out_score || !d_out_count || !d_out_total) return SS_EINVAL;
-  if (k == 0 || k > SS_MAX_K) return SS_EINVAL;
+  if (k == 0) return SS_EINVAL;
+  if (k > SS_MAX_K) return SS_ENOTSUP;  // (deeper pages: the host's own dispatch)
   if (!s->d_X8) return SS_ESTATE;
   SS_TRY(vec8_euclid_norms_ok(s, d_query_scale != nullptr, d_query_norm != nullptr));
   SS_TRY(ann_mode_ok(s, mode));

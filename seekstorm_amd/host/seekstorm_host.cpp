@@ -276,7 +276,11 @@ int Shard::make_query(const std::vector<uint32_t>& terms, QueryType qt, ss_bm25_
   for (uint32_t t : not_terms)  // not_query_list: the "-term" operands (add_result.rs:3440-3497)
     if (std::find(uniq.begin(), uniq.end(), t) == uniq.end() && std::find(nots.begin(), nots.end(), t) == nots.end())
       nots.push_back(t);
-  if (uniq.empty() || uniq.size() + nots.size() > SS_MAX_QUERY_TERMS) return SS_EINVAL;
+  if (uniq.empty()) return SS_EINVAL;
+  // more than 32 unique terms (NOT terms included): the crate answers such a query -- union_scan_32 ranks, block by block, the 32 lists
+  // with the largest block maxima and union_count recounts (union.rs:233-259, 617-624) -- this library's query record does not hold it:
+  // the host's own dispatch keeps it (ResultObject::cpu_dispatch), it is not an invalid query
+  if (uniq.size() + nots.size() > SS_MAX_QUERY_TERMS) return SS_ENOTSUP;
   uint64_t df[SS_MAX_QUERY_TERMS];
   const int rc = ss_bm25_term_df(h_, (uint32_t)uniq.size(), uniq.data(), df);
   if (rc != SS_OK) return rc;

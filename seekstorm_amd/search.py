@@ -673,8 +673,11 @@ class Shard:
                             q["phrase_seq"][i, at + x] = N.SS_PHRASE_SKIP  # a place inside the n-gram key
                         at += len(e)
             nl = [t for t in dict.fromkeys(_flat(nl)) if t not in tl]
-            if not 1 <= len(tl) or len(tl) + len(nl) > N.SS_MAX_QUERY_TERMS:
-                raise ValueError("1..%d unique terms per query (NOT terms included)" % N.SS_MAX_QUERY_TERMS)
+            if not 1 <= len(tl):
+                raise ValueError("a query needs at least one term")
+            if len(tl) + len(nl) > N.SS_MAX_QUERY_TERMS:
+                # (not an invalid query: the crate answers it -- union.rs:233-259 -- and this library's query record does not hold it)
+                raise N.SeekStormHipError(N.SS_ENOTSUP, "more than %d unique terms (NOT terms included): the host's own dispatch" % N.SS_MAX_QUERY_TERMS)
             q["n_terms"][i] = len(tl)
             q["op"][i] = int(qt) | (len(nl) << 8) | (fmask << 16)
             for j, t in enumerate(tl):

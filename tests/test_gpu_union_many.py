@@ -106,7 +106,11 @@ def test_intersections_of_many_terms_and_the_limit(S, O, world):
         got = sh.search_lexical_batch(q, 10, S.ResultType.TopkCount, reference_shortcuts=False)
         od, os_, otot = osh.search_exhaustive(terms, O.OP_AND, 10)
         _check(O, got, 0, od, os_, otot, S.ResultType.TopkCount, S, ("and", nt))
-    # 33 terms: refused (the reference scores the first 32 by block maximum only; not modelled)
+    # 33 terms: the host's own dispatch (the reference ranks, block by block, the 32 lists with the largest block maxima and recounts,
+    # union.rs:233-259, 617-624; not modelled) -- reported as SS_ENOTSUP / cpu_dispatch, never as an empty answer or an invalid query
     assert N.SS_MAX_QUERY_TERMS == 32
-    with pytest.raises(Exception):
+    with pytest.raises(N.SeekStormHipError) as e:
         sh.make_queries([list(range(33))], S.QueryType.Union)
+    assert e.value.code == N.SS_ENOTSUP
+    ro = sh.search_lexical_shard(list(range(33)), S.QueryType.Union, 0, 10)
+    assert ro.cpu_dispatch and not ro.results
