@@ -252,6 +252,7 @@ int ss_shard_destroy(ss_shard* s) {
   if (s->h_ans) (void)hipHostFree(s->h_ans);
   if (s->d_ans_done) (void)hipFree(s->d_ans_done);
   (void)hipStreamDestroy(s->stream);
+  if (s->vev) (void)hipEventDestroy(s->vev);
   if (s->vstream) (void)hipStreamDestroy(s->vstream);
   delete s;
   return SS_OK;
@@ -2402,10 +2403,23 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
         wait_us = co.max_wait_us ? co.max_wait_us : (co.callers_est > 1 ? std::min<uint32_t>(cap, co.last_batch_us / div) : 0u);
       }
       if (wait_us) {
-        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(wait_us);
+        const auto t_in = std::chrono::steady_clock::now(), until = t_in + std::chrono::microseconds(wait_us);
+        // VECTOR passes also leave when the batch is NEARLY full and the arrivals have gone quiet: of 64 callers released together, 63 are
+        // back within ~150 us; now and then one is not (the scheduler's doing) -- waiting out the cap for it costs the 63 a quarter of a
+        // pass each (their p99: 12 - 14 ms against a p50 of 9.4, profiles/r6_tail_repeat.log), where going without it costs ONE caller a
+        // second pass.  (A hybrid caller's lexical halves come back in two or three clumps half a millisecond apart: between clumps the
+        // batch is half empty, and the rule does not fire.)
+        const uint32_t nearly = want - std::max(1u, want / 16u);
+        uint32_t have_prev = 0;
+        auto t_change = t_in;
         for (;;) {
-          { std::lock_guard<std::mutex> g(co.mu); uint32_t have = 0; for (ss_co_req* r : co.queue) have += r->nq; if (have >= want) break; }
-          if (std::chrono::steady_clock::now() >= until) break;
+          uint32_t have = 0;
+          { std::lock_guard<std::mutex> g(co.mu); for (ss_co_req* r : co.queue) have += r->nq; }
+          if (have >= want) break;
+          const auto now = std::chrono::steady_clock::now();
+          if (now >= until) break;
+          if (have != have_prev) { have_prev = have; t_change = now; }
+          if (!lexical && want >= 16u && have >= nearly && now - t_change >= std::chrono::microseconds(250)) break;
           for (int i = 0; i < 32; i++) __builtin_ia32_pause();
         }
       }
@@ -3160,8 +3174,14 @@ static int vec_search_host_lane(ss_shard* s, uint32_t nq, const void* queries, s
       SS_HIP(hipMemcpyAsync(out_doc, s->d_vdoc, (size_t)nq * k * sizeof(uint32_t), hipMemcpyDeviceToHost, s->vstream));
       SS_HIP(hipMemcpyAsync(out_score, s->d_vscore, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, s->vstream));
       SS_HIP(hipMemcpyAsync(out_total, s->d_vtotal, (size_t)nq * sizeof(uint64_t), hipMemcpyDeviceToHost, s->vstream));
+      if (!s->vev) SS_HIP(hipEventCreateWithFlags(&s->vev, hipEventDisableTiming | hipEventBlockingSync));
+      SS_HIP(hipEventRecord(s->vev, s->vstream));
     }
-    SS_HIP(hipStreamSynchronize(s->vstream));  // the pass itself: nobody waits for us but this batch's callers
+    // the pass itself: nobody waits for us but this batch's callers.  The leader SLEEPS on a blocking-sync event: hipStreamSynchronize
+    // spins, and a thread that spins through 9 ms on a box whose 64 callers share 16 CPUs uses up its time slice and is descheduled just
+    // when the pass ends -- its whole batch then comes home a scheduling quantum late (one such batch per second or two was the p99 of the
+    // T = 64 vector and hybrid callers: 17.8 / 17.0 ms against a p50 of 9.6 / 10.8, gpurun_out/r6_bench_b.json)
+    SS_HIP(hipEventSynchronize(s->vev));
     bool ovf = false;
     for (uint32_t i = 0; i < nq; i++) ovf |= out_count[i] == 0xFFFFFFFFu;
     if (!ovf) return SS_OK;  // (an adversarial row order overflowed the candidate slots: once more in safe mode)

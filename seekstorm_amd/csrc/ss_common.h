@@ -278,6 +278,7 @@ struct ss_shard {
   // vmu serialises those batches among themselves (lock order: vmu, then mu); mu is held only while a batch is ENQUEUED.
   std::mutex vmu;
   hipStream_t vstream = nullptr;
+  hipEvent_t vev = nullptr;          // behind a coalesced pass (blocking-sync: the batch's leader SLEEPS through the 9 ms instead of spinning)
   void* d_vq = nullptr; size_t vq_cap = 0;                 // staged queries (+ scales)
   uint32_t* d_vdoc = nullptr; float* d_vscore = nullptr; uint32_t* d_vcount = nullptr; uint64_t* d_vtotal = nullptr;
   size_t vout_cap = 0, vq_rows_cap = 0;
