@@ -1,4 +1,4 @@
-"""Pruned vs exhaustive strategy for unions of 4..6 lists on the C2 corpus (10 M docs)."""
+"""Pruned (round 6: the wide instances of the probe kernel) vs exhaustive strategy for unions of 5..8 lists on the C2 corpus (10 M docs)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -12,8 +12,8 @@ th = O.term_thresholds()
 sh.synth_lexical(O.LEX_SEED, 10_000_000, th, O.len_table())
 rng = np.random.default_rng(1)
 df = np.array(sh.posting_count(np.arange(4096)), np.float64) / 1e7
-bands = [np.nonzero((df >= a) & (df < b))[0] for a, b in ((0.005, 0.02), (0.02, 0.05), (0.05, 0.15), (0.002, 0.01), (0.01, 0.04), (0.03, 0.1))]
-for nt in (5, 6):
+bands = [np.nonzero((df >= a) & (df < b))[0] for a, b in ((0.005, 0.02), (0.02, 0.05), (0.05, 0.15), (0.002, 0.01), (0.01, 0.04), (0.03, 0.1), (0.1, 0.3), (0.001, 0.005))]
+for nt in (5, 6, 7, 8):
     tl = [[int(rng.choice(bands[j])) for j in range(nt)] for _ in range(500)]
     q = sh.make_queries(tl, S.QueryType.Union)
     res = {}
