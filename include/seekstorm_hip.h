@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 6
+#define SS_ABI_VERSION 7
 #define SS_NO_DOC 0xFFFFFFFFu
 /* scored + NOT terms of one query: union_docid_3 takes unions of <= 10 terms (union.rs:1308), union_blockid -> union_scan_32 those of
  * 11..32 (search.rs:3497-3520, union.rs:598-805; its 32-bit match mask is the limit) */
@@ -130,7 +130,7 @@ int ss_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen_bytes, ui
  * (pruned strategy, 16-bit scan, plain intersections, up to SS_MAX_QUERY_TERMS terms).  Its scores equal the per-field sums up to the code's
  * rounding (2^-16 relative per term, inside the 1e-4 tolerance); the image holds the postings twice.  A query WITH a field
  * filter reads the (term, field) lists: at most 32 / n_fields terms (NOT terms included), intersections of at most 8 terms.
- * SS_BM25_MERGED=0 in the environment builds the image without merged lists. */
+ * (Boosts that leave a merged weight outside the code's range build the image without merged lists: ss_bm25_fields_info.) */
 int ss_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, const uint8_t* doclen_bytes, const float* boost,
                           uint32_t n_terms, const uint64_t* term_offsets, const uint32_t* doc_ids, const uint8_t* field_ids,
                           const uint16_t* tfs);
@@ -340,6 +340,14 @@ int ss_bm25_sparse_info(ss_shard* s, uint32_t* n_lists, uint64_t* n_postings, ui
  * Searches keep running on the previous image until the new one is swapped in (the call then waits for the searches in flight). */
 int ss_bm25_append_level(ss_shard* s, uint32_t level, uint32_t n_level_docs, const uint8_t* level_doclen, uint32_t n_terms,
                          const uint64_t* term_offsets /*[n_terms+1]*/, const uint32_t* doc_ids, const uint16_t* tfs);
+/* ... of an image with SEVERAL indexed fields (ABI v7; commit.rs:142-148): the level's entries (term, doc, field, tf) sorted by (doc, field)
+ * inside a term, doc ids inside the level, and level_doclen [n_fields][n_level_docs] as ss_bm25_upload_fields takes them.  The levels are
+ * kept on the host and the image is rebuilt by the multi-field builder -- a commit costs what an upload of the shard costs (the
+ * one-field form rebuilds on the device); the answers afterwards are those of ONE ss_bm25_upload_fields of all levels, bit for bit.
+ * n_fields and boost must stay the same from level to level.  No sparse tier beside it (SS_ENOTSUP), no positions yet. */
+int ss_bm25_append_level_fields(ss_shard* s, uint32_t level, uint32_t n_level_docs, uint32_t n_fields, const uint8_t* level_doclen,
+                                const float* boost, uint32_t n_terms, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
+                                const uint16_t* tfs);
 /* ... with the postings' POSITIONS, so that phrase queries work on an image that grows by commits: positions = every posting's in CSR
  * order (ascending inside a posting), tf of them each, or npos[i] where that is not the tf (npos may be NULL) -- the component terms of
  * an n-gram key, whose own positions stand behind its FIRST component's postings (ss_bm25_upload_index_bin_positions).  Every level of

@@ -101,6 +101,7 @@ SYMBOLS = [
                                                   C.c_uint64]),
     ("ss_ref_decode_block", C.c_int, [C.c_void_p, u16p, u16p]),
     ("ss_bm25_append_level", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, u8p, C.c_uint32, u64p, u32p, u16p]),
+    ("ss_bm25_append_level_fields", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, u8p, f32p, C.c_uint32, u64p, u32p, u8p, u16p]),
     ("ss_bm25_append_level_positions", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, u8p, C.c_uint32, u64p, u32p, u16p, u16p, u16p, C.c_uint64]),
     ("ss_bm25_append_sparse_level", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, u64p, u32p, u16p, u16p, u16p, C.c_uint64]),
     ("ss_bm25_incremental_info", C.c_int, [C.c_void_p, u32p, u64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

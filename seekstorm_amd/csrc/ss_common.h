@@ -182,6 +182,17 @@ struct ss_raw_level {
   uint64_t n_pos = 0;
 };
 
+// ... of an image with SEVERAL indexed fields (ss_bm25_append_level_fields, round 6): kept on the HOST -- the multi-field image is built by
+// the host builder (per-field lists + merged lists), so a commit re-assembles the shard's postings term by term and rebuilds the image
+struct ss_raw_level_f {
+  uint32_t n_docs = 0, n_terms = 0;
+  std::vector<uint64_t> off;      // [n_terms + 1], from 0
+  std::vector<uint32_t> doc;      // shard-local doc ids; a term's entries sorted by (doc, field)
+  std::vector<uint8_t> field;
+  std::vector<uint16_t> tf;
+  std::vector<uint8_t> doclen;    // [n_fields][n_docs]
+};
+
 // Device blocks of an incremental image, recycled from commit to commit.  Every commit builds a slightly larger image beside the old
 // one; a fresh multi-GB hipMalloc now and then stalls for hundreds of milliseconds (measured: 80 ms .. 1.2 s, against 35 ms for the
 // whole rebuild), so the arrays are handed out with a quarter of headroom and the previous image's blocks serve the next commit.
@@ -386,6 +397,8 @@ struct ss_shard {
   ss_block_pool blocks;              // the image arrays of incremental images come from here
   ss_block_pool* pool = nullptr;     // set on the scratch shard a rebuild fills: its image arrays are taken from the owner's pool
   std::vector<ss_raw_level> raw;
+  std::vector<ss_raw_level_f> raw_f;  // several indexed fields: the committed levels' entries, on the host (ss_bm25_append_level_fields)
+  uint32_t raw_f_fields = 0;
   std::vector<uint8_t> h_doclen;     // the length bytes of every doc committed so far
   double raw_last_append_ms = 0.0, raw_last_rebuild_ms = 0.0;
   // bm25 workspace

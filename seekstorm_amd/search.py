@@ -412,6 +412,22 @@ class Shard:
         self.lexical_field_count = 1
         self._df_cache.clear()
 
+    def append_level_fields(self, level, level_doclen, boost, term_offsets, doc_ids, fields, tfs):
+        """one committed level of an image with SEVERAL indexed fields (ss_bm25_append_level_fields): level_doclen [n_fields][n_level_docs],
+        entries (doc, field, tf) sorted by (doc, field) inside a term"""
+        dl = np.ascontiguousarray(level_doclen, np.uint8)
+        assert dl.ndim == 2
+        off = np.ascontiguousarray(term_offsets, np.uint64)
+        d = np.ascontiguousarray(doc_ids, np.uint32)
+        f = np.ascontiguousarray(fields, np.uint8)
+        t = np.ascontiguousarray(tfs, np.uint16)
+        b = None if boost is None else np.ascontiguousarray(boost, np.float32)
+        N.check(N.lib().ss_bm25_append_level_fields(self._h, int(level), dl.shape[1], dl.shape[0], N.ptr(dl.reshape(-1), N.u8p), N.ptr(b, N.f32p), len(off) - 1,
+                                                    N.ptr(off, N.u64p), N.ptr(d, N.u32p), N.ptr(f, N.u8p), N.ptr(t, N.u16p)), "ss_bm25_append_level_fields")
+        self.indexed_doc_count = int(level) * 65536 + dl.shape[1]
+        self.lexical_field_count = dl.shape[0]
+        self._df_cache.clear()
+
     def commit_level(self, level, level_doclen, term_offsets, doc_ids, tfs, n_dense_terms=None, positions=None, npos=None):
         """one commit as the seam sees it (commit.rs:142-148): the level's postings of ALL known terms in id order --
         ids below n_dense_terms belong to the dense image (ss_bm25_append_level), the others are the sparse tier's lists

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in seekstorm_hip.h but not exported"
     bound = {s[0] for s in N.SYMBOLS}
     assert set(declared) == bound, (set(declared) ^ bound)
-    assert N.lib().ss_abi_version() == 6
+    assert N.lib().ss_abi_version() == 7
     assert N.lib().ss_strerror(-4).decode().startswith("not answered by the device path")
 
 
