@@ -2462,7 +2462,14 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
   std::vector<ss_co_req*> batch;
   for (;;) {
     if (!lead) {
-      const uint32_t v = co_wait(me, 30u);
+      // No spin before the sleep (round 6).  Rounds 3-5 spun 30 us first -- a request that arrives in the last 30 us of the batch in flight
+      // saves a futex round trip -- and at T = 64 / 256 callers that was 12.7 / 16 cores busy (290 K .. 350 K calls a second x 30 us), the
+      // whole CPU quota of the box at T = 256, throttled in 19 of 20 CFS periods.  Without it: T = 64 283 -> 297 K q/s on 4.2 cores,
+      // T = 256 345 -> 393 K on 6.7 (p99 1.5 - 2.5 ms -> 0.85), T = 8 unchanged (profiles/r6_spin.log).
+#ifndef CO_SPIN_US
+#define CO_SPIN_US 0u
+#endif
+      const uint32_t v = co_wait(me, CO_SPIN_US);
       if (v == 1u) return me->rc;
       me->state.store(0u, std::memory_order_release);  // v == 3: this thread leads the next batch (its request is the queue's front)
       lead = true;
@@ -2572,6 +2579,9 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
     // with FUTEX_WAKE(all), round 5, and a tree -- the leader wakes every 8th member, who wakes its group --, round 6: the leader's part falls
     // 47 -> 4.4 us per batch, all members run, spin and re-submit at once, and the process is throttled: T = 256 344 K -> 75 K q/s with
     // p99 = 78 ms, the CFS period; T = 64 283 K -> 220 K.  The serial wake is the pacing.  profiles/r6_tree_wake_rejected.log)
+    // (re-measured in round 6 WITHOUT the followers' spin, which had been what ran the process into its quota: the tree still loses --
+    // T = 64 299 -> 277 K q/s, T = 256 394 -> 100-140 K with 18 - 30 s of SYSTEM time per 2 s: members woken together re-submit together
+    // and fight over the queue's mutex.  The serial wake paces that too.  profiles/r6_spin_tree.log)
     bool mine = false;
     for (ss_co_req* r : batch) {
       if (r == me) mine = true;
