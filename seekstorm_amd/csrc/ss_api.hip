@@ -94,20 +94,20 @@ int ss_shard_create(int device, ss_shard** out) {
   s->device = device;
   s->co_lex.max_batch = 1024;
   s->co_vec.max_batch = SS_VEC_BATCH;
-  // ONE batch in flight per kind.  A second lane (SS_COALESCE_LANES=2: lexical batches enqueue behind each other while their leaders
-  // stage / distribute in parallel) was built and measured in round 4: the callers split over two batches of half the size, and the
-  // device's fixed cost per batch -- not the host part of a cycle -- is what bounds small batches: T = 8 54 K -> 25 K q/s, T = 64
-  // 186 K -> 156 K, T = 256 318 K -> 327 K (profiles/r4k_lanes.log).  Kept as a switch, off.
-  // Round 5, re-measured with the one-launch kernel (a batch of 32 costs 112 us against 164 us for 64): a second lane that opens only
-  // while ~32 or more callers are around (SS_COALESCE_LANES=auto) gives lexical callers T = 64 244 -> 261 K q/s (p99 356 -> 284 us) and
-  // T = 256 338 -> 341 K (p99 1.18 -> 0.78 ms) without the T = 8 collapse of two unconditional lanes (96 -> 26 K) -- but it spreads HYBRID
-  // callers' lexical halves over more, smaller batches, and a caller that misses its vector pass waits for the next (p99 15 -> 18 ms at
-  // T = 64).  One lane stays the default; =2 forces two, =auto is the adaptive form (profiles/r5_lanes.log).
+  // Lexical batches in flight: ONE, and a second lane while ~96 or more callers seem to be around (adaptive; SS_COALESCE_LANES=1 / 2 force
+  // one / two, =autoN moves the threshold).  History: two unconditional lanes halve the batches, and the device's fixed cost per batch is
+  // what bounds small ones (round 4: T = 8 54 K -> 25 K q/s; profiles/r4k_lanes.log); opening the lane from ~32 callers on gained 7 % at
+  // T = 64 and cost hybrid callers their tail (round 5, profiles/r5_lanes.log) -- while the followers' 30 us spin still ate the box's CPU
+  // quota.  Round 6, spin gone, hybrid tail fixed elsewhere: one lane against the adaptive form at a threshold of 96 -- T = 64 equal
+  // (300 - 330 K q/s), T = 128 336 - 356 K -> 535 K, T = 192 419 - 448 K -> 550 - 604 K, T = 256 404 - 425 K -> 508 - 511 K (p99 0.56 -
+  // 0.64 ms), T = 512 534 - 600 K -> 615 K; below the threshold nothing changes; a threshold of 48 halves the batches of 64 callers
+  // for nothing (profiles/r6_lanes_from.log, r6_lanes_small.log).
   {
     const char* e = getenv("SS_COALESCE_LANES");
-    const bool two = e && atoi(e) == 2, adaptive = e && strcmp(e, "auto") == 0;
-    s->co_lex.n_lanes = (two || adaptive) ? 2u : 1u;
+    const bool one = e && atoi(e) == 1, two = e && atoi(e) == 2, adaptive = !one && !two;
+    s->co_lex.n_lanes = one ? 1u : 2u;
     s->co_lex.lanes_forced = two;
+    if (adaptive && e && strncmp(e, "auto", 4) == 0 && e[4]) s->co_lex.lanes_from = (uint32_t)std::max(2, atoi(e + 4));
   }
   // the shard's stream carries the latency-bound work (lexical searches: tens of microseconds a launch) at the device's HIGHEST priority;
   // the coalesced vector scans (milliseconds a pass) run on vstream at the lowest: a lexical kernel that arrives during a scan is
@@ -2451,13 +2451,14 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
     std::lock_guard<std::mutex> g(co.mu);
     // a free lane: this thread leads a batch on it at once (nobody in flight: alone, straight away -- a lone caller pays nothing);
     // invariant: a non-empty queue always has a leader at work, or a successor already told to lead
-    lead = co.leaders < ((co.n_lanes == 2u && (co.lanes_forced || co.callers_est >= 32u)) ? 2u : 1u);
+    lead = co.leaders < ((co.n_lanes == 2u && (co.lanes_forced || co.callers_est >= co.lanes_from)) ? 2u : 1u);
     if (lead) {
       co.leaders++;
       me->lane = co.lane[0].busy ? 1u : 0u;
       co.lane[me->lane].busy = true;
     }
     co.queue.push_back(me);
+    co.queued_nq.fetch_add(me->nq, std::memory_order_relaxed);
   }
   std::vector<ss_co_req*> batch;
   for (;;) {
@@ -2506,7 +2507,7 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
         auto t_change = t_in;
         for (;;) {
           uint32_t have = 0;
-          { std::lock_guard<std::mutex> g(co.mu); for (ss_co_req* r : co.queue) have += r->nq; }
+          have = co.queued_nq.load(std::memory_order_relaxed);
           if (have >= want) break;
           const auto now = std::chrono::steady_clock::now();
           if (now >= until) break;
@@ -2526,7 +2527,7 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
       // requests ahead of it, never its own); with it every queued request that can share its batch
       ss_co_req* f = me;
       for (auto it = co.queue.begin(); it != co.queue.end(); ++it)
-        if (*it == me) { co.queue.erase(it); break; }
+        if (*it == me) { co.queue.erase(it); co.queued_nq.fetch_sub(me->nq, std::memory_order_relaxed); break; }
       batch.push_back(me);  // first, whatever else fits
       total = me->nq;
       for (auto it = co.queue.begin(); it != co.queue.end();) {
@@ -2534,6 +2535,7 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
             co_compatible(f, *it) && total + (*it)->nq <= co.max_batch) {
           total += (*it)->nq;
           batch.push_back(*it);
+          co.queued_nq.fetch_sub((*it)->nq, std::memory_order_relaxed);
           it = co.queue.erase(it);
         } else {
           ++it;

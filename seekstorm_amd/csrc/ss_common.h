@@ -148,13 +148,16 @@ struct ss_co_req {
 struct ss_coalescer {
   std::mutex mu;
   std::deque<ss_co_req*> queue;
+  std::atomic<uint32_t> queued_nq{0};  // queries of the queued requests: what a lingering leader polls WITHOUT taking mu (it used to lock mu
+                                       // every ~0.3 us of its wait, against every caller that was trying to enqueue)
   // LANES (round 4): up to n_lanes batches in flight at once.  Every lane has its own pinned staging and completion event; the device
   // work of all lanes goes to the shard's ONE stream in the order it was enqueued (so every stream synchronisation elsewhere in the
   // library still covers it), but a leader holds the shard mutex only while it enqueues and waits for its batch's event outside --
   // the next leader stages, checks and enqueues its batch while this one runs, and distributes results while the next one runs.
   uint32_t leaders = 0;             // leaders at work (<= n_lanes); invariant: a non-empty queue has a leader or a successor told to lead
   uint32_t n_lanes = 1;
-  bool lanes_forced = false;        // SS_COALESCE_LANES=2: the second lane whatever the number of callers (else: from ~32 callers on)
+  bool lanes_forced = false;        // SS_COALESCE_LANES=2: the second lane whatever the number of callers
+  uint32_t lanes_from = 96;         // adaptive: the second lane opens while this many callers seem to be around (SS_COALESCE_LANES=autoN: N)
   struct Lane { char* h_pin = nullptr; size_t h_pin_cap = 0; hipEvent_t ev = nullptr; bool busy = false; } lane[2];
   uint32_t max_batch = 0, max_wait_us = 0;
   uint64_t batches = 0, queries = 0;
