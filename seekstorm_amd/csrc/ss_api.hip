@@ -53,6 +53,7 @@ static CoTrace g_co_trace;
 // ... and of the VECTOR coalescer, batch by batch (SS_CO_TRACE: what a pass waited for and whom it left behind)
 struct CoVecBatch { uint32_t members, left_queued, linger_us, batch_us; uint64_t t_formed_us; };
 static std::vector<CoVecBatch> g_co_vec_trace;
+static std::vector<uint32_t> g_co_vec_wake_us, g_co_vec_run_us;  // per vector batch: the leader's wake loop, and the batch itself (stage .. answers scattered)
 static std::mutex g_co_vec_trace_mu;
 static const bool g_co_trace_on = getenv("SS_CO_TRACE") != nullptr;
 static inline uint64_t co_now_us() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -225,6 +226,10 @@ int ss_shard_destroy(ss_shard* s) {
     fprintf(stderr, "[co-vec] %zu batches: members p1 %u p10 %u p50 %u; linger us p50 %u p90 %u p99 %u; left queued p50 %u p90 %u p99 %u; formed-to-formed us p50 %llu p90 %llu p99 %llu\n",
             m.size(), pc(m, 0.01), pc(m, 0.10), pc(m, 0.50), pc(l, 0.50), pc(l, 0.90), pc(l, 0.99), pc(q, 0.50), pc(q, 0.90), pc(q, 0.99),
             (unsigned long long)pc64(gap, 0.50), (unsigned long long)pc64(gap, 0.90), (unsigned long long)pc64(gap, 0.99));
+    if (!g_co_vec_wake_us.empty())
+      fprintf(stderr, "[co-vec] wake loop us p50 %u p90 %u p99 %u max %u; batch (formed .. scattered) us p50 %u p99 %u max %u\n", pc(g_co_vec_wake_us, 0.5), pc(g_co_vec_wake_us, 0.9),
+              pc(g_co_vec_wake_us, 0.99), pc(g_co_vec_wake_us, 1.0), pc(g_co_vec_run_us, 0.5), pc(g_co_vec_run_us, 0.99), pc(g_co_vec_run_us, 1.0));
+    g_co_vec_wake_us.clear(); g_co_vec_run_us.clear();
     g_co_vec_trace.clear();
   }
   (void)hipSetDevice(s->device);
@@ -2487,21 +2492,30 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
         std::lock_guard<std::mutex> g(co.mu);
         // (several lanes: the callers around are shared between the batches in flight)
         want = co.max_wait_us ? co.max_batch : std::min(co.callers_est / std::max(co.leaders, 1u), co.max_batch);
-        // at most an eighth of the last batch's duration, <= 1 ms (lexical: measured at 8 / 4 / 2 / 1 on the C2 image, T = 64: 247 / 245 / 233 /
-        // 254 K q/s at batches of 39 / 48 / 62 / 64 -- a longer wait buys bigger batches and pays for them in waiting; profiles/r5_linger.log).
+        // (round 5, with the spin still there: an eighth of the last batch's duration, <= 1 ms -- measured at 8 / 4 / 2 / 1 on the C2 image,
+        // T = 64: 247 / 245 / 233 / 254 K q/s at batches of 39 / 48 / 62 / 64; profiles/r5_linger.log)
         // VECTOR passes: a quarter, <= 3 ms.  A pass costs the same 9 ms for 44 queries as for 64, so whoever misses it pays a whole pass
         // more -- and a hybrid caller comes back through its lexical half first, which at k = 100 takes 0.5 - 1.5 ms for 64 callers
         // (profiles/r6_co_vec_trace.log: with the 1 ms cap 6 % of the hybrid searches missed their pass, p99 = 2.3 x p50).
-        const uint32_t div = lexical ? 8u : 4u, cap = lexical ? 1000u : 3000u;
+        // LEXICAL, round 6 (the followers' spin gone, CPU to spare): up to the WHOLE of the last batch's duration, at most 150 us -- a
+        // one-launch batch of top-10 queries takes ~100 us, so the callers it released are all back (one futex wake each, ~1.2 us apiece)
+        // and every batch is full: T = 32 195 -> 245 K q/s, T = 64 303 -> 320 - 346 K (p99 280 -> 240 - 255 us), T = 8 p99 160 -> 94 us
+        // (profiles/r6_linger_div.log).  The cap keeps a hybrid caller's lexical half (k = 100: 0.4 - 0.8 ms a batch) from lingering its
+        // callers past their vector pass (uncapped: hybrid T = 64 p99 21 ms in one of two runs, r6_linger_div_hybrid.log).
+        const uint32_t div = lexical ? 1u : 4u, cap = lexical ? 150u : 3000u;
         wait_us = co.max_wait_us ? co.max_wait_us : (co.callers_est > 1 ? std::min<uint32_t>(cap, co.last_batch_us / div) : 0u);
       }
       if (wait_us) {
         const auto t_in = std::chrono::steady_clock::now(), until = t_in + std::chrono::microseconds(wait_us);
+        const auto hard_until = t_in + std::chrono::microseconds(std::max<uint32_t>(wait_us, std::min<uint32_t>(co.last_batch_us, 10000u)));
         // VECTOR passes also leave when the batch is NEARLY full and the arrivals have gone quiet: of 64 callers released together, 63 are
         // back within ~150 us; now and then one is not (the scheduler's doing) -- waiting out the cap for it costs the 63 a quarter of a
         // pass each (their p99: 12 - 14 ms against a p50 of 9.4, profiles/r6_tail_repeat.log), where going without it costs ONE caller a
         // second pass.  (A hybrid caller's lexical halves come back in two or three clumps half a millisecond apart: between clumps the
         // batch is half empty, and the rule does not fire.)
+#ifndef CO_VEC_QUIET_US
+#define CO_VEC_QUIET_US 700
+#endif
         const uint32_t nearly = want - std::max(1u, want / 16u);
         uint32_t have_prev = 0;
         auto t_change = t_in;
@@ -2510,9 +2524,14 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
           have = co.queued_nq.load(std::memory_order_relaxed);
           if (have >= want) break;
           const auto now = std::chrono::steady_clock::now();
-          if (now >= until) break;
+          // members of the batch before that its leader has NOT EVEN WOKEN yet are certain to come: the wake loop is 64 system calls one
+          // after the other, ~100 us as a rule -- and 6 ms now and then, when the leader loses its CPU in the middle (SS_CO_TRACE:
+          // "wake loop us p50 103 p99 572 max 6318").  The three callers it had reached used to lead the next pass without the sixty it
+          // had not (members p1 3): those paid a second pass, 19 ms.  Waited for beyond the cap, up to a pass's duration.
+          const bool pending = co.waking.load(std::memory_order_relaxed) != 0u;
+          if (now >= until && (!pending || now >= hard_until)) break;
           if (have != have_prev) { have_prev = have; t_change = now; }
-          if (!lexical && want >= 16u && have >= nearly && now - t_change >= std::chrono::microseconds(250)) break;
+          if (!lexical && !pending && want >= 16u && have >= nearly && now - t_change >= std::chrono::microseconds(CO_VEC_QUIET_US)) break;  // (longer than a lexical linger + batch: a hybrid caller's last clump)
           for (int i = 0; i < 32; i++) __builtin_ia32_pause();
         }
       }
@@ -2564,10 +2583,15 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
       uint32_t members = 0, queued = 0;
       for (ss_co_req* r : batch) members += r->nq;
       for (ss_co_req* r : co.queue) queued += r->nq;
-      // (callers seen at THIS moment miss those on their way back -- a hybrid caller is in its lexical half just now: the estimate falls by
-      // a sixteenth per batch at most, so a straggler of the last round is still waited for in this one; a lone caller: none, at once)
+      // Callers around = the most seen at the end of any of the last FOUR batches, and never less than 15/16 of the estimate before.  Callers
+      // seen at THIS moment miss those on their way back (a hybrid caller is in its lexical half just now), and one straggler's batch of ONE
+      // used to zero the estimate: the next leader then did not linger at all, took the three callers that happened to be there, and sixty
+      // paid a second pass (profiles/r6_quiet_ab.log: "members p1 3").  A lone caller is not delayed: after four batches of one the
+      // estimate is zero.
       const uint32_t seen = members + queued, floor_ = co.callers_est - std::max(1u, co.callers_est / 16u);
-      co.callers_est = batch.size() + co.queue.size() > 1 ? std::max(seen, co.callers_est > 1u ? floor_ : 0u) : 0u;
+      co.seen_ring[co.seen_at++ & 3u] = seen;
+      const uint32_t recent = std::max(std::max(co.seen_ring[0], co.seen_ring[1]), std::max(co.seen_ring[2], co.seen_ring[3]));
+      co.callers_est = recent > 1u ? std::max(recent, co.callers_est > 1u ? floor_ : 0u) : 0u;
       co.last_batch_us = (uint32_t)std::min<long long>(1000000, std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - batch_t0).count());
       // hand the lane to the queue's front unless another lane's leader already told it to lead
       for (ss_co_req* r : co.queue)
@@ -2585,11 +2609,18 @@ int co_submit(ss_shard* s, ss_coalescer& co, bool lexical, ss_co_req* me) {
     // T = 64 299 -> 277 K q/s, T = 256 394 -> 100-140 K with 18 - 30 s of SYSTEM time per 2 s: members woken together re-submit together
     // and fight over the queue's mutex.  The serial wake paces that too.  profiles/r6_spin_tree.log)
     bool mine = false;
+    co.waking.fetch_add((uint32_t)batch.size(), std::memory_order_relaxed);
     for (ss_co_req* r : batch) {
       if (r == me) mine = true;
       else co_signal(r, 1u);
+      co.waking.fetch_sub(1u, std::memory_order_relaxed);
     }
     if (g_co_trace_on && lexical && batch.size() > 1) { g_co_trace.wake += co_now_us() - tw0; g_co_trace.members += batch.size() - 1; }
+    if (g_co_trace_on && !lexical) {
+      std::lock_guard<std::mutex> gt(g_co_vec_trace_mu);
+      g_co_vec_wake_us.push_back((uint32_t)((co_now_us() - tw0) / 1000));
+      g_co_vec_run_us.push_back((uint32_t)((tw0 - trace_linger_ns) / 1000));
+    }
     if (mine) return me->rc;
     lead = false;  // (cannot happen while the leader's request is the front of its own batch; kept for safety)
   }

@@ -148,6 +148,7 @@ struct ss_co_req {
 struct ss_coalescer {
   std::mutex mu;
   std::deque<ss_co_req*> queue;
+  std::atomic<uint32_t> waking{0};     // members of finished batches whose leader has not signalled them yet (see the linger in co_submit)
   std::atomic<uint32_t> queued_nq{0};  // queries of the queued requests: what a lingering leader polls WITHOUT taking mu (it used to lock mu
                                        // every ~0.3 us of its wait, against every caller that was trying to enqueue)
   // LANES (round 4): up to n_lanes batches in flight at once.  Every lane has its own pinned staging and completion event; the device
@@ -164,6 +165,7 @@ struct ss_coalescer {
   // linger: how many callers seem to be around (members of the last batch + what was queued when it finished) and how long that
   // batch took -- the next leader gives the callers the last batch has just released a moment to come back (co_submit)
   uint32_t callers_est = 0, last_batch_us = 0;
+  uint32_t seen_ring[4] = {0, 0, 0, 0}, seen_at = 0;  // callers seen at the end of the last four batches
   // (host staging of a merged batch: PINNED, hipHostMalloc, grow-only, per lane -- the copies to and from the device are then real
   // asynchronous DMA instead of staged pageable copies; only the lane's leader of the moment touches it)
 };
