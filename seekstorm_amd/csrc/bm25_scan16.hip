@@ -56,10 +56,31 @@ constexpr uint32_t S16_SLACK = 4u;  // + NT: how far a bound can lie above score
 // since every such value carries the same upper bits 0x4B00, sums "old entry + bits" and their maxima compare like the bounds
 // themselves (a tile sum stays below 2^16: no carry).  No v_cvt, no "+ 1".  Each posting can now lie up to 2 above its product
 // (the slack of the cut counts 2 NT).
+// Round 6: one VALU operation fewer again -- the "+ BM_W_BASE" of the decode is folded into the multiplier.  BM_W_BASE = 113 << 23 only
+// moves the exponent: as_float(x + BM_W_BASE) = as_float(x) * 2^113 exactly for every x whose exponent field is not 0, so the unions
+// carry idf * scale * 2^113 (S16_WFOLD; <= 16250 * 2^113 = 1.7e38: finite) and multiply the bits of p >> 5 as they are -- the same
+// product, the same rounding.  Exponent field 0 (W19 < 2^15: weights below 2^-13, a doc some 20 000 times the average length) reads as
+// a denormal, up to 2^-13 * 16250 < 2 below the true product x.  The addend is 2^23 + 3 (the "+ 1.5" above was never representable: a
+// float of that size has no half, the literal was 2^23 + 2 all along), so a posting's bound is round(x') + 3 with x - 2 < x' <= x:
+// above x by more than 0.5 and by at most 3.5 -- the slack of the cut counts 4 per list (S16_QM_UP; the 2 NT it counted before were
+// short of the old form's 2.5 NT from five lists on).  C2 exhaustive: 1.088 -> 1.034 ms per 1000 queries (profiles/r6_qm_fold_ab.log).
 constexpr uint32_t S16_MBITS = 0x4B000000u;  // bits of 2^23
-__device__ __forceinline__ uint32_t s16_qm(uint32_t p, float fidf) {
-  return __float_as_uint(__builtin_fmaf(fidf, __uint_as_float((p >> 5) + BM_W_BASE), 8388609.5f));
+#ifndef S16_QM_FOLD
+#define S16_QM_FOLD 1  // 0: the round-2 form (experiment builds: A/B of the fold)
+#endif
+#if S16_QM_FOLD
+constexpr float S16_WFOLD = 0x1p113f;
+constexpr uint32_t S16_QM_UP = 4u;  // how far a union's bound of ONE posting can lie above idf * weight * scale
+__device__ __forceinline__ uint32_t s16_qm(uint32_t p, float fidf_fold) {
+  return __float_as_uint(__builtin_fmaf(fidf_fold, __uint_as_float(p >> 5), 8388611.0f));
 }
+#else
+constexpr float S16_WFOLD = 1.0f;
+constexpr uint32_t S16_QM_UP = 3u;
+__device__ __forceinline__ uint32_t s16_qm(uint32_t p, float fidf) {
+  return __float_as_uint(__builtin_fmaf(fidf, __uint_as_float((p >> 5) + BM_W_BASE), 8388610.0f));
+}
+#endif
 
 // one 256-posting chunk: first = the tile holds nothing of this item yet (no read), keep = read / add / write,
 // read = read / add, sums stay in registers (last term)
@@ -413,7 +434,7 @@ __device__ __forceinline__ BmTop<KPL> s16_trigger(BmTop<KPL> T, S16Cur<S16Cfg<NT
         const uint32_t mid = (lo + hi + 1u) >> 1;
         if ((uint32_t)__popcll(__ballot(lm >= mid)) >= k) lo = mid; else hi = mid - 1u;
       }
-      constexpr uint32_t SLACK = ((AND ? (uint32_t)NT : 2u * (uint32_t)NT) + S16_SLACK) << SH;
+      constexpr uint32_t SLACK = ((AND ? (uint32_t)NT : S16_QM_UP * (uint32_t)NT) + S16_SLACK) << SH;
       qcut = max(qcut, lo > SLACK ? lo - SLACK : 1u);
     } else if (KPL > 1 && k > 64u) {
       // k of 65 .. 128: more results than lanes -- the same cut over the 512 SLOTS (8 docs each, one maximum per slot): k slots holding a
@@ -430,7 +451,7 @@ __device__ __forceinline__ BmTop<KPL> s16_trigger(BmTop<KPL> T, S16Cur<S16Cfg<NT
           const uint32_t mid = (lo + hi + 1u) >> 1;
           if (slots_at(mid) >= k) lo = mid; else hi = mid - 1u;
         }
-        constexpr uint32_t SLACK2 = ((AND ? (uint32_t)NT : 2u * (uint32_t)NT) + S16_SLACK) << SH;
+        constexpr uint32_t SLACK2 = ((AND ? (uint32_t)NT : S16_QM_UP * (uint32_t)NT) + S16_SLACK) << SH;
         qcut = max(qcut, lo > SLACK2 ? lo - SLACK2 : 1u);
       }
     }
@@ -595,7 +616,7 @@ bm25_scan16_kernel(const uint32_t* __restrict__ post, const unsigned long long* 
   const uint32_t* nrowp = sub_off + (size_t)nterm * row_len;
   const float scale = (AND ? S16_QMAX_AND : EXCL ? S16_QMAX_EXCL : S16_QMAX) / (S16_WMAX * idf_sum);
 #pragma unroll
-  for (int t = 0; t < NT; t++) fidf[t] = s16_uniform(idf[t] * scale);
+  for (int t = 0; t < NT; t++) fidf[t] = s16_uniform(idf[t] * scale * (AND ? 1.0f : S16_WFOLD));  // unions: s16_qm's folded multiplier
   // wave-uniform constants of the item loop, pinned to scalar registers (left to the allocator, scale_thr went to scratch and
   // its reload brought a vmcnt(0) -- a wait for the whole prefetch -- into every item)
   const float scale_thr = s16_uniform(scale * (1.0f - 1e-5f));
@@ -975,7 +996,7 @@ __device__ __attribute__((noinline)) BmTop<KPL> s16m_trigger(BmTop<KPL> T, const
   uint32_t start = 0u;
   const bool excl = ex.nn != 0u || ex.del != nullptr;
   if (excl) s16_exclude(ex, accb, lane);
-  const uint32_t SLACK = 2u * L.nt + S16_SLACK;
+  const uint32_t SLACK = S16_QM_UP * L.nt + S16_SLACK;
   for (;;) {
     uint32_t sm[4];
 #pragma unroll
@@ -1120,7 +1141,7 @@ bm25_scan16m_kernel(const uint32_t* __restrict__ post, const unsigned long long*
   const uint32_t* __restrict__ rowp = sub_off + (size_t)term * row_len;
   S16MLists L;
   L.v_tlo = (uint32_t)taddr; L.v_thi = (uint32_t)(taddr >> 32);
-  L.v_idf = __float_as_uint(idf); L.v_fidf = __float_as_uint(idf * scale);
+  L.v_idf = __float_as_uint(idf); L.v_fidf = __float_as_uint(idf * scale * S16_WFOLD);
   L.nt = nt;
   const uint32_t s_begin = (uint32_t)(((u64)n_sub * part) / P);
   const uint32_t s_end = (uint32_t)(((u64)n_sub * (part + 1)) / P);
