@@ -776,8 +776,8 @@ int ss_bm25_search_sharded(ss_shard* s, ss_comm* c, uint32_t n_queries, const ss
                            uint32_t result_type, uint64_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total);
 
 /* The vector and the hybrid shard task of the same search (search.rs:1680-1689, 1723-1732), same conventions and the same
- * single all-gather: ss_vec_search_sharded = this shard's AnnMode::All f32 scan (host queries [n_queries][dim], n_queries <=
- * SS_VEC_BATCH) + merged top-k on every rank.  ss_hybrid_search_sharded = SearchMode::Hybrid: both shard tasks at
+ * single all-gather: ss_vec_search_sharded = this shard's AnnMode::All f32 scan (host queries [n_queries][dim]; any number of
+ * them: SS_VEC_BATCH per pass over the matrix, one all-gather for the call) + merged top-k on every rank.  ss_hybrid_search_sharded = SearchMode::Hybrid: both shard tasks at
  * k = offset + length, both lists in the one all-gather, the two cross-shard concatenations sorted, RRF over them (ranks run
  * over the whole concatenation, search.rs:1962-2035), sort / offset / length (2098-2119); out_* [n_queries][length] with
  * out_source SS_SRC_* (may be NULL); out_total = sum over the shards of max(lexical, vector) totals (1919-1921).

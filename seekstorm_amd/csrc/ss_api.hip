@@ -2700,7 +2700,7 @@ int ss_bm25_search_sharded(ss_shard* s, ss_comm* c, uint32_t nq, const ss_bm25_q
 int ss_vec_search_sharded(ss_shard* s, ss_comm* c, uint32_t nq, const float* queries, uint32_t k, float thr, uint64_t* out_doc,
                           float* out_score, uint32_t* out_count, uint64_t* out_total) {
   if (!s || !c || !queries || !out_doc || !out_score || !out_count || !out_total) return SS_EINVAL;
-  if (k == 0 || nq > SS_VEC_BATCH) return SS_EINVAL;
+  if (k == 0) return SS_EINVAL;  // (any number of queries: the scan takes them SS_VEC_BATCH per pass, one all-gather for all of them)
   if (k > SS_MAX_K) return SS_ENOTSUP;
   int dev = -1, n_ranks = 0;
   SS_TRY(ss_comm_info(c, nullptr, &n_ranks, &dev));
@@ -2722,7 +2722,7 @@ int ss_hybrid_search_sharded(ss_shard* s, ss_comm* c, uint32_t nq, const ss_bm25
                              uint32_t* out_count, uint64_t* out_total) {
   if (!s || !c || !q || !queries || !out_doc || !out_score || !out_count || !out_total) return SS_EINVAL;
   if (rt != SS_RT_TOPK && rt != SS_RT_TOPKCOUNT) return SS_EINVAL;
-  if (k == 0 || length == 0 || nq > SS_VEC_BATCH) return SS_EINVAL;
+  if (k == 0 || length == 0) return SS_EINVAL;
   if (k > SS_MAX_K) return SS_ENOTSUP;
   int dev = -1, n_ranks = 0;
   SS_TRY(ss_comm_info(c, nullptr, &n_ranks, &dev));

@@ -158,6 +158,23 @@ def test_vector_and_hybrid_sharded_single_rank(S, O, both):
             assert int(ht[i]) == max(int(lt[i]), int(vt[i])) == ro.result_count_total
     n, us = comm.profile_read()
     assert n == 2 + 2 and 0.0 < us < 5e4  # one all-gather per sharded call
+    # more queries than one pass over the matrix takes (SS_VEC_BATCH = 64): several passes, still ONE all-gather per call
+    nq2 = 150
+    qs2 = O.vec_gen(O.VECQ_SEED, 100, nq2, dim)
+    doc2, score2, cnt2, tot2 = sh.search_vector_batch(qs2, k)
+    md, ms, mc, mt = comm.search_vector_sharded(sh, qs2, k)
+    assert np.array_equal(mc, cnt2) and np.array_equal(mt, tot2)
+    for i in range(nq2):
+        assert np.array_equal(md[i, :cnt2[i]], doc2[i, :cnt2[i]].astype(np.uint64)) and np.array_equal(ms[i, :cnt2[i]], score2[i, :cnt2[i]])
+    tl2 = [tl[i % len(tl)] for i in range(nq2)]
+    q2 = sh.make_queries(tl2, S.QueryType.Union)
+    hd, hs, hsrc, hc, ht = comm.search_hybrid_sharded(sh, q2, qs2, 0, 15)
+    for i in (0, 63, 64, 65, 127, 128, nq2 - 1):
+        ro = ix.search(tl2[i], qs2[i], S.QueryType.Union, S.SearchMode.Hybrid, 0, 15, normalize_query=False)
+        assert hc[i] == len(ro.results) and hd[i, :hc[i]].tolist() == [r.doc_id for r in ro.results]
+        assert np.array_equal(hs[i, :hc[i]], np.array([r.score for r in ro.results], np.float32))
+    n, us = comm.profile_read()
+    assert n == 2  # (the counter was reset by the read above)
     comm.close()
 
 
