@@ -396,11 +396,12 @@ def test_bench_compact_line_keeps_the_contract_and_its_bound():
 
 
 def test_committed_bench_line_and_counter_file_belong_together():
-    """profiles/r5_bench_line.json is the line of the round's final run; its `traffic` figures come from profiles/pmc_traffic.json,
-    which bench.py only uses while it was collected on the kernel sources of the tree (kernel_source_hash)."""
+    """the line of the round's final run (profiles/<pmc_traffic.json's collected_as>_bench_line.json); its `traffic` figures come from
+    profiles/pmc_traffic.json, which bench.py only uses while it was collected on the kernel sources of the tree (kernel_source_hash)."""
     import json
     import bench
-    line = json.load(open(os.path.join(ROOT, "profiles", "r5_bench_line.json")))
+    tag = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["collected_as"]
+    line = json.load(open(os.path.join(ROOT, "profiles", tag + "_bench_line.json")))
     assert line["n_gpus"] == 1 and line["unit"] == "queries/s" and line["value"] > 1e6
     assert len(json.dumps(line).encode()) <= 4096
     pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
