@@ -103,6 +103,12 @@ int ss_shard_create(int device, ss_shard** out) {
   // (300 - 330 K q/s), T = 128 336 - 356 K -> 535 K, T = 192 419 - 448 K -> 550 - 604 K, T = 256 404 - 425 K -> 508 - 511 K (p99 0.56 -
   // 0.64 ms), T = 512 534 - 600 K -> 615 K; below the threshold nothing changes; a threshold of 48 halves the batches of 64 callers
   // for nothing (profiles/r6_lanes_from.log, r6_lanes_small.log).
+  // Round 6, later: all of the above was measured with both lanes feeding the shard's ONE stream -- their kernels ran one behind the other,
+  // and a second lane could only overlap host work with device work.  Each lane's one-launch kernels now run on a stream of the lane's own
+  // (ss_common.h lstream; bm25_small_try): two batches of ~22 callers overlap ON THE DEVICE, and the threshold is 32 -- T = 64 300 - 330 K ->
+  // 430 - 454 K q/s (p50 210 -> 142 us, p99 290 -> 195 us), T = 96 -> 490 - 500 K, T = 128 535 -> 570 - 720 K, T = 192 -> 570 - 620 K, T = 256 /
+  // 512 unchanged (500 / 600 K: batches of 48 queries or more fill the chip alone and share lane 0's stream), T = 8 91 -> 100 - 110 K;
+  // hybrid and vector callers unchanged (profiles/r6_lane_streams*.log).
   {
     const char* e = getenv("SS_COALESCE_LANES");
     const bool one = e && atoi(e) == 1, two = e && atoi(e) == 2, adaptive = !one && !two;
@@ -120,6 +126,20 @@ int ss_shard_create(int device, ss_shard** out) {
   *out = s;
   return SS_OK;
 }
+
+// The shard mutex, as everybody but the coalescer's lane path takes it: with the lane streams drained (ss_common.h lstream) -- whoever
+// holds it may write the lexical image or enqueue writers on s->stream, and no lane kernel is in flight to meet them.
+struct ShardLock {
+  std::unique_lock<std::mutex> g;
+  explicit ShardLock(ss_shard* s) : g(s->mu) {
+    s->main_dirty = true;  // (whatever this section enqueues on s->stream: the next lane launch waits for it)
+    if (s->lanes_inflight) {
+      for (hipStream_t st : s->lstream)
+        if (st) (void)hipStreamSynchronize(st);
+      s->lanes_inflight = false;
+    }
+  }
+};
 
 // RAII: a search on a stream other than the shard's own runs on that stream's set of scan buffers (swapped into the shard's
 // fields while the launches are enqueued -- under s->mu -- and back afterwards; buffers are allocated lazily by the scan code)
@@ -235,6 +255,8 @@ int ss_shard_destroy(ss_shard* s) {
   (void)hipSetDevice(s->device);
   (void)hipStreamSynchronize(s->stream);
   if (s->vstream) (void)hipStreamSynchronize(s->vstream);
+  for (hipStream_t st : s->lstream)
+    if (st) (void)hipStreamSynchronize(st);
   free_vec(s);
   free_bm25(s);
   for (void* p_ : {(void*)s->d_vq, (void*)s->d_vdoc, (void*)s->d_vscore, (void*)s->d_vcount, (void*)s->d_vtotal}) if (p_) (void)hipFree(p_);
@@ -255,6 +277,11 @@ int ss_shard_destroy(ss_shard* s) {
   if (s->h_bq) (void)hipHostFree(s->h_bq);
   if (s->bq_ev) (void)hipEventDestroy(s->bq_ev);
   if (s->d_small_ws) (void)hipFree(s->d_small_ws);
+  for (int i = 0; i < 2; i++) {
+    if (s->lstream[i]) { (void)hipStreamSynchronize(s->lstream[i]); (void)hipStreamDestroy(s->lstream[i]); }
+    if (s->d_small_ws_l[i]) (void)hipFree(s->d_small_ws_l[i]);
+  }
+  if (s->ev_main) (void)hipEventDestroy(s->ev_main);
   if (s->h_small) (void)hipHostFree(s->h_small);
   if (s->h_ans) (void)hipHostFree(s->h_ans);
   if (s->d_ans_done) (void)hipFree(s->d_ans_done);
@@ -270,6 +297,8 @@ int ss_shard_sync(ss_shard* s) {
   SS_HIP(hipSetDevice(s->device));
   SS_HIP(hipStreamSynchronize(s->stream));
   if (s->vstream) SS_HIP(hipStreamSynchronize(s->vstream));
+  for (hipStream_t st : s->lstream)
+    if (st) SS_HIP(hipStreamSynchronize(st));
   return SS_OK;
 }
 
@@ -326,7 +355,7 @@ int ss_bm25_upload_positions(ss_shard* s, uint64_t n_docs, const uint8_t* doclen
 // positions of the image just built (CSR order); a failure leaves no image behind
 int ssi_bm25_attach_positions(ss_shard* s, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs, const uint16_t* positions,
                               uint64_t n_positions, const uint16_t* npos) {
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   SS_HIP(hipSetDevice(s->device));
   const int rc = ssi_bm25_upload_positions(s, offs, docs, tfs, positions, n_positions, npos);
   if (rc) free_bm25(s);
@@ -380,7 +409,7 @@ int ssi_bm25_upload(ss_shard* s, uint64_t n_docs, const uint8_t* doclen, uint32_
   if (!s || !doclen || !offs || n_docs == 0 || n_terms == 0) return SS_EINVAL;
   if (offs[n_terms] && (!docs || !tfs)) return SS_EINVAL;
   if (n_docs > 0xFFFFFFFFull) return SS_ENOTSUP;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   SS_HIP(hipSetDevice(s->device));
   SS_HIP(hipStreamSynchronize(s->stream));
   free_bm25(s);
@@ -435,7 +464,7 @@ int ssi_bm25_upload_fields_positions(ss_shard* s, uint64_t n_docs, uint32_t n_fi
   int rc = ssi_bm25_upload_fields(s, n_docs, n_fields, doclen, boost, n_terms, offs, docs, fields, tfs, positions_sum);
   if (rc) return rc;
   const auto t1 = std::chrono::steady_clock::now();
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   SS_HIP(hipSetDevice(s->device));
   rc = ssi_bm25_upload_positions_fields(s, n_terms, offs, docs, fields, tfs, positions, n_positions, npos);
   if (trace) fprintf(stderr, "[load]   fields image %.0f ms, positions %.0f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
@@ -473,7 +502,7 @@ int ssi_bm25_upload_fields(ss_shard* s, uint64_t n_docs, uint32_t n_fields, cons
     });
     if (bad.load()) return SS_EINVAL;
   }
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   SS_HIP(hipSetDevice(s->device));
   SS_HIP(hipStreamSynchronize(s->stream));
   // with merged lists first; a corpus whose merged weights do not fit the weight code is built again without them
@@ -539,7 +568,7 @@ extern "C" {
 
 int ss_synth_set_partition(ss_shard* s, uint32_t shard_id, uint32_t n_shards) {
   if (!s || n_shards == 0 || shard_id >= n_shards) return SS_EINVAL;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   s->synth_stride = n_shards;
   s->synth_offset = shard_id;
   return SS_OK;
@@ -549,7 +578,7 @@ int ss_bm25_synth(ss_shard* s, uint64_t seed, uint64_t n_docs, uint32_t n_terms,
                   const uint8_t* len_table1024) {
   if (!s || !thresh32 || !len_table1024 || n_docs == 0 || n_terms == 0) return SS_EINVAL;
   if (n_docs > 0xFFFFFFFFull) return SS_ENOTSUP;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   SS_HIP(hipSetDevice(s->device));
   SS_HIP(hipStreamSynchronize(s->stream));
   free_bm25(s);
@@ -601,7 +630,7 @@ static int append_level_impl(ss_shard* s, uint32_t level, uint32_t n_level_docs,
   std::vector<uint8_t> doclen;
   uint32_t nt_old = 0;
   {
-    std::lock_guard<std::mutex> g(s->mu);
+    ShardLock g(s);
     if (s->d_post && s->raw.empty()) return SS_ESTATE;       // an image that was not built level by level
     // a sparse tier numbers its terms behind the dense ones: a grown dense vocabulary would shift them -- new terms of an image with a
     // tier join the tier (ss_bm25_append_sparse_level), whose postings must come level by level too (their tfs are kept for re-coding)
@@ -710,7 +739,7 @@ static int append_level_impl(ss_shard* s, uint32_t level, uint32_t n_level_docs,
   const double rebuild_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count();
   int rc_recode = SS_OK;
   {  // the swap: searches in flight finish on the old image, whose arrays are then released
-    std::lock_guard<std::mutex> g(s->mu);
+    ShardLock g(s);
     if (level > s->raw.size() || level + 1 < s->raw.size()) return fail(SS_ESTATE);  // another commit got in between (the caller's write lock forbids it)
     (void)hipStreamSynchronize(s->stream);
     for (auto& kv : s->bm_ws) (void)hipStreamSynchronize(kv.first);
@@ -774,7 +803,7 @@ int ss_bm25_append_level_fields(ss_shard* s, uint32_t level, uint32_t n_level_do
     const auto t_begin = std::chrono::steady_clock::now();
     std::vector<ss_raw_level_f> levels;
     {
-      std::lock_guard<std::mutex> g(s->mu);
+      ShardLock g(s);
       if ((s->d_post || !s->raw.empty()) && s->raw_f.empty()) return SS_ESTATE;  // an image that was not built this way
       if (s->sp_n) return SS_ENOTSUP;                                            // (a sparse tier beside it: upload + ss_bm25_append_sparse_fields)
       if (!s->raw_f.empty() && s->raw_f_fields != n_fields) return SS_EINVAL;
@@ -832,7 +861,7 @@ int ss_bm25_append_level_fields(ss_shard* s, uint32_t level, uint32_t n_level_do
     const auto t_build = std::chrono::steady_clock::now();
     // (the builder replaces the image in place under the shard mutex and drops every raw level: ours go back in afterwards)
     const int rc = ssi_bm25_upload_fields(s, n_docs, n_fields, dl_all.data(), boost, nt_all, off_all.data(), doc_all.data(), field_all.data(), tf_all.data(), 0);
-    std::lock_guard<std::mutex> g(s->mu);
+    ShardLock g(s);
     if (rc != SS_OK) return rc;  // (no image is left behind, and no levels: the caller starts over with an upload)
     s->raw_f.swap(levels);
     s->raw_f_fields = n_fields;
@@ -844,7 +873,7 @@ int ss_bm25_append_level_fields(ss_shard* s, uint32_t level, uint32_t n_level_do
 
 int ss_bm25_incremental_info(ss_shard* s, uint32_t* n_levels, uint64_t* raw_bytes, double* last_append_ms, double* last_rebuild_ms) {
   if (!s) return SS_EINVAL;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   uint64_t b = 0;
   for (const ss_raw_level_f& L : s->raw_f) b += L.off.size() * 8u + L.doc.size() * 7u + L.doclen.size();
   if (n_levels && !s->raw_f.empty()) { *n_levels = (uint32_t)s->raw_f.size(); n_levels = nullptr; }
@@ -867,7 +896,7 @@ int ss_set_deleted(ss_shard* s, const uint64_t* doc_ids, uint64_t n) {
     if (doc_ids[i] >= 0xFFFFFFFFull) return SS_EINVAL;
     mx = std::max(mx, doc_ids[i]);
   }
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   if (s->vstream) (void)hipStreamSynchronize(s->vstream);  // (a coalesced scan in flight reads what this call replaces; none starts while mu is ours)
   SS_HIP(hipSetDevice(s->device));
   SS_HIP(hipStreamSynchronize(s->stream));
@@ -894,7 +923,7 @@ int ss_set_deleted(ss_shard* s, const uint64_t* doc_ids, uint64_t n) {
 // bitmap standing in for the tombstone bitmap
 int ss_facet_upload(ss_shard* s, uint64_t n_docs, uint32_t record_size, const uint8_t* records) {
   if (!s || !records || n_docs == 0 || record_size == 0 || n_docs > 0xFFFFFFFEull) return SS_EINVAL;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   SS_HIP(hipSetDevice(s->device));
   SS_HIP(hipStreamSynchronize(s->stream));
   if (s->d_facets) { (void)hipFree(s->d_facets); s->d_facets = nullptr; }
@@ -911,7 +940,7 @@ int ss_facet_upload(ss_shard* s, uint64_t n_docs, uint32_t record_size, const ui
 // at 10 M docs) go to the longest lists first; a query touching a list without a row is ranked by the scan kernels.
 int ss_bm25_set_probe_budget(ss_shard* s, uint64_t max_bytes) {
   if (!s) return SS_EINVAL;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   s->probe_budget = max_bytes;
   return SS_OK;
 }
@@ -936,7 +965,7 @@ int ss_bm25_term_probed(ss_shard* s, uint32_t n, const uint32_t* terms, uint8_t*
 
 int ss_bm25_set_strategy(ss_shard* s, int strategy) {
   if (!s || strategy < SS_BM25_AUTO || strategy > SS_BM25_EXHAUSTIVE_F32) return SS_EINVAL;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   s->bm_strategy = strategy;
   return SS_OK;
 }
@@ -974,7 +1003,7 @@ int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df
 int ss_bm25_append_sparse_level(ss_shard* s, uint32_t level, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
                                 const uint16_t* npos, const uint16_t* positions, uint64_t n_positions) {
   if (!s || !offs || n_lists == 0 || (offs[n_lists] > offs[0] && (!docs || !tfs))) return SS_EINVAL;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   if (s->raw.empty()) return SS_ESTATE;  // an image that grows level by level (ss_bm25_append_level)
   SS_HIP(hipSetDevice(s->device));
   SS_HIP(hipDeviceSynchronize());  // searches on the callers' own streams may still read the arrays the level replaces
@@ -983,7 +1012,7 @@ int ss_bm25_append_sparse_level(ss_shard* s, uint32_t level, uint32_t n_lists, c
 int ss_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
                           uint32_t* first_term_id_out) {
   if (!s || !offs || (n_lists && offs[n_lists] > offs[0] && (!docs || !tfs))) return SS_EINVAL;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   SS_HIP(hipSetDevice(s->device));
   SS_HIP(hipDeviceSynchronize());  // searches on the callers' own streams may still read the arrays an append replaces
   const uint32_t first = s->bm_n_terms + s->sp_n;
@@ -994,7 +1023,7 @@ int ss_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, c
 int ss_bm25_append_sparse_fields(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint8_t* fields,
                                  const uint16_t* tfs, uint32_t* first_term_id_out) {
   if (!s || !offs || (n_lists && offs[n_lists] > offs[0] && (!docs || !fields || !tfs))) return SS_EINVAL;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   SS_HIP(hipSetDevice(s->device));
   SS_HIP(hipDeviceSynchronize());  // searches on the callers' own streams may still read the arrays an append replaces
   const uint32_t first = s->bm_n_terms / std::max<uint32_t>(s->bm_n_fields, 1) + s->sp_n;
@@ -1006,7 +1035,7 @@ int ss_bm25_append_sparse_positions(ss_shard* s, uint32_t n_lists, const uint64_
                                     const uint16_t* positions, uint64_t n_positions, const uint16_t* npos, uint32_t* first_term_id_out) {
   if (!s || !offs || (n_lists && offs[n_lists] > offs[0] && (!docs || !tfs)) || (n_positions && !positions)) return SS_EINVAL;
   static const uint16_t none = 0;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   SS_HIP(hipSetDevice(s->device));
   SS_HIP(hipDeviceSynchronize());  // searches on the callers' own streams may still read the arrays an append replaces
   const uint32_t first = s->bm_n_terms + s->sp_n;
@@ -1019,7 +1048,7 @@ int ss_bm25_append_sparse_fields_positions(ss_shard* s, uint32_t n_lists, const 
                                            uint32_t* first_term_id_out) {
   if (!s || !offs || (n_lists && offs[n_lists] > offs[0] && (!docs || !fields || !tfs)) || (n_positions && !positions)) return SS_EINVAL;
   static const uint16_t none = 0;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   SS_HIP(hipSetDevice(s->device));
   SS_HIP(hipDeviceSynchronize());  // searches on the callers' own streams may still read the arrays an append replaces
   const uint32_t first = s->bm_n_terms / std::max<uint32_t>(s->bm_n_fields, 1) + s->sp_n;
@@ -1029,7 +1058,7 @@ int ss_bm25_append_sparse_fields_positions(ss_shard* s, uint32_t n_lists, const 
 }
 int ss_bm25_sparse_info(ss_shard* s, uint32_t* n_lists, uint64_t* n_postings, uint64_t* bytes) {
   if (!s) return SS_EINVAL;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   const uint64_t np = s->h_sp_base.empty() ? 0 : s->h_sp_base.back();
   if (n_lists) *n_lists = s->sp_n;
   if (n_postings) *n_postings = np;
@@ -2035,11 +2064,42 @@ static int bm25_small_try(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint
   for (uint32_t i = 0; i < nq; i++)  // every dense list the batch reads has a probe row now, or the scans take the batch
     if (!query_lists_probed_dense(s, q[i])) return SS_OK;
   SS_HIP(hipSetDevice(s->device));
-  if (!s->d_small_ws) {
-    SS_HIP(hipMalloc(&s->d_small_ws, ssi_bm25_small_ws_bytes()));
-    SS_HIP(hipMemsetAsync(s->d_small_ws, 0, ssi_bm25_small_ws_bytes(), s->stream));
+  // slot 0 (direct calls, under ShardLock): the shard's stream and workspace.  Slots 1 / 2 (the coalescer's lanes): the lane's own
+  // (ss_common.h lstream) -- created on first use; the launch waits for whatever s->stream holds at this moment.
+  hipStream_t st = s->stream;
+  void** wsp = &s->d_small_ws;
+  if (slot != 0u) {
+    const uint32_t li = slot - 1u;
+    if (!s->ev_main) SS_HIP(hipEventCreateWithFlags(&s->ev_main, hipEventDisableTiming));
+    // a BIG batch fills the chip by itself: two of them at once only get in each other's way (T = 256: batches of 90, 415 - 490 K q/s
+    // overlapped against 490 - 510 K one behind the other) -- those queue on lane 0's stream whichever lane they come from (the workspace
+    // and the flag stay the lane's own; a lane has one batch in flight at a time)
+    static const uint32_t share_from = getenv("SS_LANE_SHARE_FROM") ? (uint32_t)atoi(getenv("SS_LANE_SHARE_FROM")) : 48u;
+    const uint32_t si = nq >= share_from ? 0u : li;
+    if (!s->lstream[si]) {
+      int pr_least = 0, pr_greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
+      SS_HIP(hipStreamCreateWithPriority(&s->lstream[si], hipStreamNonBlocking, pr_greatest));
+      s->main_dirty = true;  // (a new stream is ordered behind nothing)
+    }
+    st = s->lstream[si];
+    s->lane_last[li] = st;
+    wsp = &s->d_small_ws_l[li];
+  }
+  if (!*wsp) {
+    SS_HIP(hipMalloc(wsp, ssi_bm25_small_ws_bytes()));
+    SS_HIP(hipMemsetAsync(*wsp, 0, ssi_bm25_small_ws_bytes(), st));
   }
   SS_TRY(ssi_bm25_ensure_kth(s, s->stream));
+  if (slot != 0u) {
+    if (s->main_dirty) {  // both lanes behind the tail of s->stream as it stands (the flag is theirs together)
+      SS_HIP(hipEventRecord(s->ev_main, s->stream));
+      for (hipStream_t ls : s->lstream)
+        if (ls) SS_HIP(hipStreamWaitEvent(ls, s->ev_main, 0));
+      s->main_dirty = false;
+    }
+    s->lanes_inflight = true;
+  }
   if (!s->h_small) {
     SS_HIP(hipHostMalloc((void**)&s->h_small, SM_H_BYTES, hipHostMallocDefault));
     memset(s->h_small, 0, SM_H_BYTES);
@@ -2056,13 +2116,13 @@ static int bm25_small_try(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint
     for (uint32_t i = 0; i < n; i++) (void)small_query_fits(s, q[c0 + i], kk, &sh, &nn_max);  // this launch's own shape
     seq = ++s->small_seq ? s->small_seq : ++s->small_seq;  // never 0
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    ssi_prof_begin(s, 0, s->stream, &e0, &e1);
-    const int rc = ssi_bm25_small_launch(s, s->d_small_ws, n, q + c0, kk, sh, p_doc + (size_t)c0 * kk, p_score + (size_t)c0 * kk, p_count + c0, p_total + c0,
-                                        (uint32_t*)(s->h_small + 64 * slot), seq, s->stream);
-    ssi_prof_end(s, 0, s->stream, e0, e1);
+    ssi_prof_begin(s, 0, st, &e0, &e1);
+    const int rc = ssi_bm25_small_launch(s, *wsp, n, q + c0, kk, sh, p_doc + (size_t)c0 * kk, p_score + (size_t)c0 * kk, p_count + c0, p_total + c0,
+                                        (uint32_t*)(s->h_small + 64 * slot), seq, st);
+    ssi_prof_end(s, 0, st, e0, e1);
     if (rc != SS_OK) {  // (the per-query state may be half-way: start the next launch from zero; launches already queued finish first)
-      (void)hipStreamSynchronize(s->stream);
-      (void)hipMemsetAsync(s->d_small_ws, 0, ssi_bm25_small_ws_bytes(), s->stream);
+      (void)hipStreamSynchronize(st);
+      (void)hipMemsetAsync(*wsp, 0, ssi_bm25_small_ws_bytes(), st);
       return rc;
     }
   }
@@ -2087,7 +2147,7 @@ static int bm25_small_wait(ss_shard* s, uint32_t slot, uint32_t seq, bool mu_hel
       // pass): give the core away between looks instead of burning it
       if (dt > 300) sched_yield();
       if (dt > 2000) {  // long past any small batch: ask the runtime (a kernel that died leaves the flag untouched)
-        const hipError_t e = hipStreamQuery(s->stream);
+        const hipError_t e = hipStreamQuery(slot ? s->lane_last[slot - 1u] : s->stream);
         if (e != hipSuccess && e != hipErrorNotReady) break;
         if (e == hipSuccess) { if (__atomic_load_n((const uint32_t*)flag, __ATOMIC_ACQUIRE) == seq) return SS_OK; break; }
         if (dt > 10000000) break;
@@ -2101,10 +2161,12 @@ static int bm25_small_wait(ss_shard* s, uint32_t slot, uint32_t seq, bool mu_hel
   // ADVICE r5): without this every later one-launch batch would merge on a wrong "last arriver" or wait out the 10 s cap.
   std::unique_lock<std::mutex> g(s->mu, std::defer_lock);
   if (!mu_held) g.lock();  // (nobody enqueues another launch while the state is being zeroed)
-  (void)hipStreamSynchronize(s->stream);
-  if (s->d_small_ws) {
-    (void)hipMemsetAsync(s->d_small_ws, 0, ssi_bm25_small_ws_bytes(), s->stream);
-    (void)hipStreamSynchronize(s->stream);
+  hipStream_t st = slot ? s->lane_last[slot - 1u] : s->stream;
+  void* ws = slot ? s->d_small_ws_l[slot - 1u] : s->d_small_ws;
+  (void)hipStreamSynchronize(st);
+  if (ws) {
+    (void)hipMemsetAsync(ws, 0, ssi_bm25_small_ws_bytes(), st);
+    (void)hipStreamSynchronize(st);
   }
   return rc;
 }
@@ -2185,7 +2247,7 @@ static int bm25_answers_home(ss_shard* s, uint32_t nq, uint32_t kk, uint32_t* ou
 
 static int bm25_search_direct(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k, uint32_t rt, uint32_t n_filters,
                               const ss_facet_filter* filters, uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total) {
-  std::lock_guard<std::mutex> g(s->mu);  // before check_queries: it reads the image's host-side tables (an upload replaces them)
+  ShardLock g(s);  // before check_queries: it reads the image's host-side tables (an upload replaces them)
   if (!s->d_post) return SS_ESTATE;
   const uint32_t kk = rt == SS_RT_COUNT ? 0 : k, kw = std::max<uint32_t>(kk, 1u);
   // by shape, like a coalesced batch (bm25_search_direct_lane): the queries that fit the one-launch path take it, the staged pipeline
@@ -2281,7 +2343,7 @@ static int bm25_search_direct_lane(ss_shard* s, uint32_t nq, const ss_bm25_query
   row_of.resize(nq);
   for (uint32_t i = 0; i < nq; i++) row_of[i] = i;
   {
-    std::lock_guard<std::mutex> g(s->mu);
+    std::lock_guard<std::mutex> g(s->mu);  // (NOT ShardLock: the other lane's kernel may be in flight, that is the point)
     if (!s->d_post) return SS_ESTATE;
     const uint32_t kk = rt == SS_RT_COUNT ? 0 : k, kw = std::max<uint32_t>(kk, 1u);
     std::vector<ss_bm25_query> qs;  // the batch in the order it runs in: the fitting queries first
@@ -2635,13 +2697,13 @@ int ss_shard_set_coalescing(ss_shard* s, uint32_t max_lexical_batch, uint32_t ma
 }
 int ss_bm25_path_stats(ss_shard* s, uint64_t* one_launch_batches) {
   if (!s || !one_launch_batches) return SS_EINVAL;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   *one_launch_batches = s->small_launches;
   return SS_OK;
 }
 int ss_bm25_shape_stats(ss_shard* s, uint64_t* generic_batches) {
   if (!s || !generic_batches) return SS_EINVAL;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   *generic_batches = s->gallop_batches;
   return SS_OK;
 }
@@ -2687,7 +2749,7 @@ int ss_bm25_search_sharded(ss_shard* s, ss_comm* c, uint32_t nq, const ss_bm25_q
   if (nq == 0) return SS_OK;
   // From here on a failure is a matter of THIS shard (image missing, a query its lists cannot serve, an allocation): the rank
   // still enters the exchange, empty-handed, and every rank returns an error (ssi_comm_exchange) instead of blocking in it.
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   int rc = dev != s->device ? SS_EINVAL : !s->d_post ? SS_ESTATE : SS_OK;
   if (rc == SS_OK) rc = bm25_search_host_queries(s, nq, q, kk, rt, 0, nullptr);
   const ss_dev_list L{s->d_out_doc, s->d_out_score, s->d_out_count, kk};
@@ -2706,7 +2768,7 @@ int ss_vec_search_sharded(ss_shard* s, ss_comm* c, uint32_t nq, const float* que
   SS_TRY(ss_comm_info(c, nullptr, &n_ranks, &dev));
   if ((uint64_t)n_ranks * k > 8192) return SS_EINVAL;
   if (nq == 0) return SS_OK;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   int rc = dev != s->device ? SS_EINVAL : !s->d_X ? SS_ESTATE : SS_OK;
   std::vector<uint32_t> h_count(nq);
   if (rc == SS_OK) rc = vec_search_host_lists(s, nq, queries, sizeof(float), nullptr, k, thr, nullptr, h_count.data(), nullptr);
@@ -2728,7 +2790,7 @@ int ss_hybrid_search_sharded(ss_shard* s, ss_comm* c, uint32_t nq, const ss_bm25
   SS_TRY(ss_comm_info(c, nullptr, &n_ranks, &dev));
   if ((uint64_t)n_ranks * k * 2 > 4096) return SS_EINVAL;  // both concatenations live in the fusion kernel's LDS
   if (nq == 0) return SS_OK;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   int rc = dev != s->device ? SS_EINVAL : (!s->d_post || !s->d_X) ? SS_ESTATE : SS_OK;
   // outputs of the two searches side by side: the vector lists behind the lexical ones (reserved before either runs)
   if (rc == SS_OK && hipSetDevice(s->device) != hipSuccess) rc = SS_EDEVICE;
@@ -2755,7 +2817,7 @@ static int facet_count_impl(ss_shard* s, const ss_bm25_query* query, uint32_t n_
   if (!s->d_post) return SS_ESTATE;
   bool has_and, has_or, all_probed, any_frequent;
   uint32_t nt_max, np_max;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   SS_TRY(ssi_bm25_ensure_probe_rows(s, 1, query, s->stream));
   SS_TRY(check_queries(s, 1, query, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent));
   if (!all_probed || !s->d_probe) return SS_ENOTSUP;  // the match set comes from the probe index's bit records
@@ -2816,7 +2878,7 @@ static int facet_kth_impl(ss_shard* s, const ss_bm25_query* query, uint32_t n_fi
   if (!s->d_post) return SS_ESTATE;
   bool has_and, has_or, all_probed, any_frequent;
   uint32_t nt_max, np_max;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   SS_TRY(ssi_bm25_ensure_probe_rows(s, 1, query, s->stream));
   SS_TRY(check_queries(s, 1, query, &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent));
   if (!all_probed || !s->d_probe) return SS_ENOTSUP;
@@ -2877,7 +2939,7 @@ int ss_bm25_search_sorted(ss_shard* s, uint32_t nq, const ss_bm25_query* queries
     if (sorts[f].facet_type > SS_FACET_POINT) return SS_EINVAL;
     if (sorts[f].facet_type == SS_FACET_STRING16 || sorts[f].facet_type == SS_FACET_STRING32) return SS_ENOTSUP;  // by their strings: the host's rank column
   }
-  std::lock_guard<std::mutex> g(s->mu);  // (before the image is looked at: a commit swaps its arrays under this lock)
+  ShardLock g(s);  // (before the image is looked at: a commit swaps its arrays under this lock)
   if (!s->d_post) return SS_ESTATE;
   SS_HIP(hipSetDevice(s->device));
   if (!s->d_facets || s->facet_docs < s->bm_n_docs) return SS_ESTATE;
@@ -2961,7 +3023,7 @@ static int facet_values_impl(ss_shard* s, uint32_t n, const uint32_t* doc_ids, u
   if (!s || (n && (!doc_ids || !out_values)) || facet_type > SS_FACET_POINT) return SS_EINVAL;
   if (point && point->unit > SS_POINT_MILES) return SS_EINVAL;
   static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 2, 4, 8};
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   if (!s->d_facets || facet_offset + width[facet_type] > s->facet_record_size) return SS_ESTATE;
   if (n == 0) return SS_OK;
   SS_HIP(hipSetDevice(s->device));
@@ -2997,7 +3059,7 @@ int ss_bm25_search_filtered_dev(ss_shard* s, uint32_t nq, const ss_bm25_query* d
   if (rt != SS_RT_COUNT && (k == 0 || !d_out_doc || !d_out_score)) return SS_EINVAL;
   if (rt != SS_RT_COUNT && k > SS_MAX_K) return SS_ENOTSUP;
   if (!s->d_post) return SS_ESTATE;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   SS_HIP(hipSetDevice(s->device));
   hipStream_t st = stream ? (hipStream_t)stream : s->stream;
   if ((ops_mask & (1u << 28)) && s->sp_n) {
@@ -3069,7 +3131,7 @@ int ss_vec_upload(ss_shard* s, uint64_t n_rows, uint32_t dim, const float* rows,
     multi = std::adjacent_find(tmp.begin(), tmp.end()) != tmp.end();
     if (!tmp.empty() && tmp.back() == SS_NO_DOC) return SS_EINVAL;
   }
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   SS_HIP(hipSetDevice(s->device));
   SS_HIP(hipStreamSynchronize(s->stream));
   int rc = vec_alloc(s, n_rows, dim);
@@ -3142,7 +3204,7 @@ static int vec_bin_upload(ss_shard* s, const uint8_t* bytes, uint64_t len, uint3
   std::vector<uint32_t> tmp(ids);
   std::sort(tmp.begin(), tmp.end());
   const bool multi = std::adjacent_find(tmp.begin(), tmp.end()) != tmp.end();
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   SS_HIP(hipSetDevice(s->device));
   SS_HIP(hipStreamSynchronize(s->stream));
   int rc = i8 ? vec8_alloc(s, n_rows, dim) : vec_alloc(s, n_rows, dim);
@@ -3193,7 +3255,7 @@ int ss_vec_upload_vector_bin_i8(ss_shard* s, const uint8_t* bytes, uint64_t len,
 int ss_vec_synth(ss_shard* s, uint64_t seed, uint64_t n_rows, uint32_t dim) {
   if (!s || n_rows == 0 || dim == 0) return SS_EINVAL;
   if (n_rows > 0xFFFFFFFEull) return SS_ENOTSUP;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   SS_HIP(hipSetDevice(s->device));
   SS_HIP(hipStreamSynchronize(s->stream));
   int rc = vec_alloc(s, n_rows, dim);
@@ -3215,7 +3277,7 @@ int ss_vec_read_rows(ss_shard* s, uint64_t r0, uint64_t n, float* out) {
   if (!s || !out) return SS_EINVAL;
   if (!s->d_X) return SS_ESTATE;
   if (r0 + n > s->n_rows) return SS_EINVAL;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   SS_HIP(hipSetDevice(s->device));
   SS_HIP(hipStreamSynchronize(s->stream));
   SS_HIP(hipMemcpy2D(out, (size_t)s->dim * sizeof(float), s->d_X + r0 * s->dim_pad, (size_t)s->dim_pad * sizeof(float),
@@ -3271,7 +3333,7 @@ static int vec_search_host_lane(ss_shard* s, uint32_t nq, const void* queries, s
   std::lock_guard<std::mutex> gv(s->vmu);
   for (int attempt = 0; attempt < 2; attempt++) {
     {
-      std::lock_guard<std::mutex> g(s->mu);
+      std::lock_guard<std::mutex> g(s->mu);  // (a vector pass neither writes nor reads what the lexical lanes' kernels touch: no drain)
       SS_HIP(hipSetDevice(s->device));
       if ((elem == sizeof(float)) ? !s->d_X : !s->d_X8) return SS_ESTATE;
       const size_t qbytes = ((size_t)nq * s->dim * elem + 15) & ~(size_t)15, sbytes = query_scale ? (size_t)nq * sizeof(float) : 0;
@@ -3323,7 +3385,7 @@ static int vec_search_host(ss_shard* s, uint32_t nq, const void* queries, size_t
                            float thr, const ss_ann_mode* mode, uint32_t* out_doc, float* out_score, uint32_t* out_count,
                            uint64_t* out_total, uint32_t* out_clusters, const float* query_norm) {
   if (nq == 0) return SS_OK;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   uint32_t* d_ncl = nullptr;
   int rc = vec_search_host_lists(s, nq, queries, elem, query_scale, k, thr, mode, out_count, &d_ncl, query_norm, out_clusters != nullptr);
   if (rc == SS_OK) {
@@ -3380,7 +3442,7 @@ int ss_vec_search_ann_dev(ss_shard* s, uint32_t nq, const float* d_queries, uint
   if (!s->d_X) return SS_ESTATE;
   SS_TRY(ann_mode_ok(s, mode));
   mode = ann_effective(mode);
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   SS_HIP(hipSetDevice(s->device));
   hipStream_t st = stream ? (hipStream_t)stream : s->stream;
   VecWsBind bind(s, st);
@@ -3396,14 +3458,14 @@ int ss_vec_search_dev(ss_shard* s, uint32_t nq, const float* d_queries, uint32_t
 // ---- VectorSimilarity of the image (vector_similarity.rs:118-345): must precede the upload (layout of the f32 image)
 int ss_vec_set_similarity(ss_shard* s, int similarity) {
   if (!s || (similarity != SS_SIM_DOT && similarity != SS_SIM_EUCLIDEAN)) return SS_EINVAL;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   if ((s->d_X || s->d_X8) && similarity != s->vec_similarity) return SS_ESTATE;
   s->vec_similarity = similarity;
   return SS_OK;
 }
 int ss_vec_set_row_norms(ss_shard* s, uint64_t n_rows, const float* row_norm) {
   if (!s || !row_norm) return SS_EINVAL;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   if (s->vstream) (void)hipStreamSynchronize(s->vstream);  // (a coalesced scan in flight reads what this call replaces; none starts while mu is ours)
   SS_HIP(hipSetDevice(s->device));
   if (!s->d_X8) return SS_ESTATE;
@@ -3417,14 +3479,14 @@ int ss_vec_set_row_norms(ss_shard* s, uint64_t n_rows, const float* row_norm) {
 // ---- cluster structure of the vector image (ANN modes, vec_ann.hip)
 int ss_vec_set_clusters(ss_shard* s, uint32_t n_levels, const uint32_t* level_clusters, const uint32_t* child_count) {
   if (!s) return SS_EINVAL;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   if (s->vstream) (void)hipStreamSynchronize(s->vstream);  // (a coalesced scan in flight reads what this call replaces; none starts while mu is ours)
   SS_HIP(hipSetDevice(s->device));
   return ssi_vec_set_clusters(s, n_levels, level_clusters, child_count);
 }
 int ss_vec_set_fields(ss_shard* s, uint64_t n_rows, const uint16_t* row_field) {
   if (!s || !row_field) return SS_EINVAL;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   if (s->vstream) (void)hipStreamSynchronize(s->vstream);  // (a coalesced scan in flight reads what this call replaces; none starts while mu is ours)
   SS_HIP(hipSetDevice(s->device));
   if (!s->d_X && !s->d_X8) return SS_ESTATE;
@@ -3471,7 +3533,7 @@ int ss_vec_upload_i8(ss_shard* s, uint64_t n_rows, uint32_t dim, const int8_t* r
     multi = std::adjacent_find(tmp.begin(), tmp.end()) != tmp.end();
     if (!tmp.empty() && tmp.back() == SS_NO_DOC) return SS_EINVAL;
   }
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   SS_HIP(hipSetDevice(s->device));
   SS_HIP(hipStreamSynchronize(s->stream));
   int rc = vec8_alloc(s, n_rows, dim);
@@ -3540,7 +3602,7 @@ static int vec_grow(ss_shard* s, uint64_t new_cap, bool grow_image = true) {
 
 int ss_vec_reserve_rows(ss_shard* s, uint64_t n_rows_cap) {
   if (!s) return SS_EINVAL;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   if (s->vstream) (void)hipStreamSynchronize(s->vstream);  // (a coalesced scan in flight reads what this call replaces; none starts while mu is ours)
   SS_HIP(hipSetDevice(s->device));
   if (!s->d_X && !s->d_X8) return SS_ESTATE;
@@ -3561,7 +3623,7 @@ int ss_vec_append_rows(ss_shard* s, const ss_vec_level* lv) {
     multi = std::adjacent_find(tmp.begin(), tmp.end()) != tmp.end();
     if (tmp.back() == SS_NO_DOC) return SS_EINVAL;
   }
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   if (s->vstream) (void)hipStreamSynchronize(s->vstream);  // (a coalesced scan in flight reads what this call replaces; none starts while mu is ours)
   SS_HIP(hipSetDevice(s->device));
   if (!s->d_X && !s->d_X8) return SS_ESTATE;
@@ -3624,7 +3686,7 @@ int ss_vec_append_rows(ss_shard* s, const ss_vec_level* lv) {
 int ss_vec_synth_i8(ss_shard* s, uint64_t seed, uint64_t n_rows, uint32_t dim) {
   if (!s || n_rows == 0 || dim == 0) return SS_EINVAL;
   if (n_rows > 0xFFFFFFFEull) return SS_ENOTSUP;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   SS_HIP(hipSetDevice(s->device));
   SS_HIP(hipStreamSynchronize(s->stream));
   int rc = vec_alloc(s, n_rows, dim);  // f32 rows first ...
@@ -3650,7 +3712,7 @@ int ss_vec_read_rows_i8(ss_shard* s, uint64_t r0, uint64_t n, int8_t* out) {
   if (!s || !out) return SS_EINVAL;
   if (!s->d_X8) return SS_ESTATE;
   if (r0 + n > s->n_rows) return SS_EINVAL;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   SS_HIP(hipSetDevice(s->device));
   SS_HIP(hipStreamSynchronize(s->stream));
   if (n == 0) return SS_OK;
@@ -3715,7 +3777,7 @@ int ss_vec_search_i8_euclid_dev(ss_shard* s, uint32_t nq, const int8_t* d_querie
   SS_TRY(vec8_euclid_norms_ok(s, d_query_scale != nullptr, d_query_norm != nullptr));
   SS_TRY(ann_mode_ok(s, mode));
   mode = ann_effective(mode);
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   SS_HIP(hipSetDevice(s->device));
   hipStream_t st = stream ? (hipStream_t)stream : s->stream;
   VecWsBind bind(s, st);
@@ -3779,14 +3841,14 @@ int ss_merge_results(int mode, const uint64_t* lex_doc, const float* lex_score, 
 // ------------------------------------------------------------------ measurement hooks
 int ss_profile_enable(ss_shard* s, int on) {
   if (!s) return SS_EINVAL;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   s->prof.on = on != 0;
   return SS_OK;
 }
 
 int ss_profile_read(ss_shard* s, int kernel, uint64_t* launches, double* total_ms, int reset) {
   if (!s || kernel < 0 || kernel > 1) return SS_EINVAL;
-  std::lock_guard<std::mutex> g(s->mu);
+  ShardLock g(s);
   SS_HIP(hipSetDevice(s->device));
   for (auto& pr : s->prof.pending[kernel]) {
     SS_HIP(hipEventSynchronize(pr.second));

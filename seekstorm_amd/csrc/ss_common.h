@@ -158,7 +158,8 @@ struct ss_coalescer {
   uint32_t leaders = 0;             // leaders at work (<= n_lanes); invariant: a non-empty queue has a leader or a successor told to lead
   uint32_t n_lanes = 1;
   bool lanes_forced = false;        // SS_COALESCE_LANES=2: the second lane whatever the number of callers
-  uint32_t lanes_from = 96;         // adaptive: the second lane opens while this many callers seem to be around (SS_COALESCE_LANES=autoN: N)
+  uint32_t lanes_from = 32;         // adaptive: the second lane opens while this many callers seem to be around (SS_COALESCE_LANES=autoN: N;
+                                    // 96 while both lanes fed one stream, 32 since each has its own: ss_api.hip ss_shard_create)
   struct Lane { char* h_pin = nullptr; size_t h_pin_cap = 0; hipEvent_t ev = nullptr; bool busy = false; } lane[2];
   uint32_t max_batch = 0, max_wait_us = 0;
   uint64_t batches = 0, queries = 0;
@@ -418,6 +419,19 @@ struct ss_shard {
   void* d_small_ws = nullptr;
   char* h_small = nullptr;
   uint32_t small_seq = 0;
+  // The one-launch kernels of the coalescer's two LANES run on a stream (and a workspace) of their own each, so that two batches of
+  // ~ 20 - 30 concurrent callers overlap on the device instead of queueing on the shard's one stream (a launch of that size is a chain of
+  // dependent round trips, not a full chip).  Ordering: a lane launch waits for the tail of s->stream as it stood when it was enqueued
+  // (ev_main: uploads, commits, tombstones, probe rows built on demand -- everything that writes what the kernel reads goes through
+  // s->stream); everything ELSE that takes the shard mutex drains the lane streams first (ShardLock in ss_api.hip), so a writer never
+  // meets a lane kernel in flight.  Lane kernels only read the image; their answers go to the lanes' pinned staging.
+  hipStream_t lstream[2] = {nullptr, nullptr};
+  hipStream_t lane_last[2] = {nullptr, nullptr};  // the stream a lane's latest launch went to (big batches share lane 0's)
+  void* d_small_ws_l[2] = {nullptr, nullptr};
+  hipEvent_t ev_main = nullptr;
+  bool lanes_inflight = false;  // a lane launch since the lane streams were last drained (under mu)
+  bool main_dirty = true;       // s->stream may hold work the lane streams have not been ordered behind yet (set by every ShardLock section;
+                                // a cross-stream wait costs a launch ~ 15 us on this runtime, so it is only enqueued when there is something to wait for)
   // the STAGED pipeline's answers of a direct host-pointer call take the same road home (ss_api.hip bm25_answers_home): one kernel writes
   // them into this pinned block and raises flag slot 0 behind them -- instead of four copies into the caller's pageable arrays and a
   // stream synchronisation

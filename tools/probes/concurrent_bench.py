@@ -46,7 +46,7 @@ def cpu_stat():
 
 
 for name, mode, nq, length in LEGS:
-    for T in ((8, 64, 256) if os.environ.get("LEX_ONLY") else tuple(int(x) for x in ONLY.split(":")[1].split(",")) if ONLY else (1, 8, 64, 256, 1024)):
+    for T in (tuple(int(x) for x in os.environ["CB_T"].split(",")) if os.environ.get("CB_T") else (8, 64, 256) if os.environ.get("LEX_ONLY") else tuple(int(x) for x in ONLY.split(":")[1].split(",")) if ONLY else (1, 8, 64, 256, 1024)):
         out = (C.c_double * 5)()
         s0 = sh.coalescing_stats()
         c0, t0_ = cpu_stat(), os.times()
