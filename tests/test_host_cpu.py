@@ -27,6 +27,15 @@ def test_library_exports_every_declared_symbol():
     assert N.lib().ss_strerror(-4).decode().startswith("not answered by the device path")
 
 
+def test_driver_build_entry_point():
+    """__graft_entry__.build() is what the driver runs as its "does it build" check: it must pass on the tree as it is
+    (round 6: it still asserted the previous ABI version)."""
+    import importlib, sys
+    sys.path.insert(0, ROOT)
+    G = importlib.import_module("__graft_entry__")
+    G.build()
+
+
 def test_struct_layout_matches_header():
     import ctypes as C
     from seekstorm_amd import _native as N
