@@ -1258,7 +1258,7 @@ static inline void query_list_range(const ss_shard* s, const ss_bm25_query& q, u
 }
 static inline bool list_needs_row(const ss_shard* s, uint32_t v) { return s->h_probe_row[v] == BM_NO_PROBE_ROW && s->h_df[v] != 0; }
 
-// caller holds s->mu and synchronises st before the next call on this shard can touch the pool
+// caller holds s->mu (with or without the lane streams drained: see below)
 static int ssi_bm25_ensure_probe_rows(ss_shard* s, uint32_t nq, const ss_bm25_query* q, hipStream_t st) {
   if (s->probe_pool_rows == 0 || !s->d_probe) return SS_OK;
   const uint32_t n_lists_per_term = s->bm_n_fields, n_public = s->bm_n_terms / s->bm_n_fields;
@@ -1312,6 +1312,17 @@ static int ssi_bm25_ensure_probe_rows(ss_shard* s, uint32_t nq, const ss_bm25_qu
     stage.push_back(s->probe_pool_begin + victims[i]);
   }
   SS_HIP(hipSetDevice(s->device));
+  // Rows are about to change hands.  (1) A coalescer lane's one-launch kernel may be in flight on the lane's own stream (ss_common.h
+  // lstream) and reading a victim row -- and this call may itself come from the other lane's leader, who holds s->mu but not a ShardLock:
+  // drain the lane streams.  (2) The next lane launch has to wait for the fill on `st`: main_dirty.  (3) A lane leader does not
+  // synchronise `st` before it lets go of s->mu, so the previous fill may still be reading d_pool_stage: wait for it before overwriting.
+  s->main_dirty = true;
+  if (s->lanes_inflight) {
+    for (hipStream_t ls : s->lstream)
+      if (ls) (void)hipStreamSynchronize(ls);
+    s->lanes_inflight = false;
+  }
+  SS_HIP(hipStreamSynchronize(st));
   if (stage.size() * sizeof(uint32_t) > s->pool_stage_cap) {
     if (s->d_pool_stage) (void)hipFree(s->d_pool_stage);
     s->d_pool_stage = nullptr; s->pool_stage_cap = 0;

@@ -161,3 +161,69 @@ def test_one_launch_under_concurrent_callers(S, O, lanes, share):
         print("one-launch batches: %d (lanes %s)" % (done, lanes))
     finally:
         sh.close()
+
+
+def test_pool_rows_change_hands_under_both_lanes(S, O):
+    """A rationed vocabulary (rows for the longest lists + a pool built on demand, ss_bm25_set_probe_budget) under concurrent
+    single-query callers, two coalescer lanes: a lane leader whose batch names a row-less list builds the row on the shard's stream while
+    the OTHER lane's kernel may be in flight on its own stream -- the lane streams are drained before a row changes hands and the next lane
+    launch waits for the fill (ss_api.hip ssi_bm25_ensure_probe_rows).  Every answer equals the unrationed shard's."""
+    from test_gpu_pruned import _corpus
+    n_docs = 150_000
+    dfs = [0.2 / (1 + 0.35 * i) for i in range(56)]
+    dl, offs, docs, tfs = _corpus(O, n_docs, dfs, 23)
+    old = os.environ.get("SS_COALESCE_LANES")
+    os.environ["SS_COALESCE_LANES"] = "2"
+    try:
+        full, part = S.Shard(0), S.Shard(0)
+    finally:
+        if old is None:
+            os.environ.pop("SS_COALESCE_LANES", None)
+        else:
+            os.environ["SS_COALESCE_LANES"] = old
+    try:
+        full.upload_lexical(n_docs, dl, offs, docs, tfs)
+        n_sub = (n_docs + 4095) // 4096
+        part.set_probe_budget((40 + 1) * n_sub * 64 * 12)   # 40 rows: 30 fixed (the longest lists) + a pool of 10 for 26 row-less lists
+        part.upload_lexical(n_docs, dl, offs, docs, tfs)
+        rng = np.random.default_rng(77)
+        pool = []
+        for j in range(160):
+            nt = int(rng.integers(1, 4))
+            t = [int(rng.integers(30, 56))] + [int(x) for x in rng.choice(30, nt - 1, replace=False)]  # one row-less list per query
+            qt = S.QueryType.Intersection if j % 3 == 0 else S.QueryType.Union
+            rt = S.ResultType.TopkCount if j % 2 else S.ResultType.Topk
+            ref = full.search_lexical_batch(full.make_queries([t], qt), 10, rt, reference_shortcuts=False)
+            pool.append((part.make_queries([t], qt), rt, ref))
+        start = part.one_launch_batches()
+        errors, stop = [], threading.Event()
+
+        def caller(seed):
+            r = np.random.default_rng(seed)
+            for _ in range(1500):
+                if stop.is_set():
+                    return
+                j = int(r.integers(0, len(pool)))
+                q, rt, ref = pool[j]
+                try:
+                    got = part.search_lexical_batch(q, 10, rt, reference_shortcuts=False)
+                except Exception as e:  # noqa: BLE001
+                    errors.append((j, repr(e)))
+                    stop.set()
+                    return
+                what = _differs(S, got, ref, rt)
+                if what:
+                    errors.append((j, what, int(rt)))
+                    if len(errors) > 8:
+                        stop.set()
+
+        threads = [threading.Thread(target=caller, args=(500 + t,)) for t in range(8)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, ("answers differ from the unrationed shard's", errors[:8])
+        assert part.one_launch_batches() - start > 1000   # (the path under test ran: one-launch batches, not the staged pipeline)
+    finally:
+        full.close()
+        part.close()
