@@ -2085,7 +2085,10 @@ static int bm25_small_try(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint
     // a BIG batch fills the chip by itself: two of them at once only get in each other's way (T = 256: batches of 90, 415 - 490 K q/s
     // overlapped against 490 - 510 K one behind the other) -- those queue on lane 0's stream whichever lane they come from (the workspace
     // and the flag stay the lane's own; a lane has one batch in flight at a time)
-    static const uint32_t share_from = getenv("SS_LANE_SHARE_FROM") ? (uint32_t)atoi(getenv("SS_LANE_SHARE_FROM")) : 48u;
+#ifndef SS_LANE_SHARE_FROM
+#define SS_LANE_SHARE_FROM 48u  // (measured at 32 / 48 / 64 / never: profiles/r6_lane_streams3.log)
+#endif
+    constexpr uint32_t share_from = SS_LANE_SHARE_FROM;
     const uint32_t si = nq >= share_from ? 0u : li;
     if (!s->lstream[si]) {
       int pr_least = 0, pr_greatest = 0;

@@ -314,7 +314,8 @@ int ssh_synth_vectors(ssh_index* ix, int shard, uint64_t seed, uint64_t n_rows, 
 // The reference's REAL calling pattern, measured: n_threads host threads, each issuing ONE query per call through Index::search
 // (search.rs:1637-1743: one search per runtime worker, no batched entry point) for `seconds` of wall time.  mode: SS_MODE_*;
 // query i of the n_queries given = terms[term_off[i] .. term_off[i+1]) and / or vectors[i * dim ..]; threads draw queries round
-// robin.  Every thread's first call is a warm-up: not recorded, not counted.  out[0] = completed searches, out[1] = wall seconds, out[2] / out[3] = p50 / p99 of the per-call latency in
+// robin.  Every thread's first call is a warm-up, and so is every call begun in the first min(0.25 s, seconds / 8): not recorded, not
+// counted, outside the wall time.  out[0] = completed searches, out[1] = wall seconds, out[2] / out[3] = p50 / p99 of the per-call latency in
 // microseconds (host clock around the call), out[4] = calls that came back with an error.
 int ssh_bench_concurrent(ssh_index* ix, int mode, uint32_t n_threads, double seconds, uint32_t n_queries, const uint32_t* terms,
                          const uint32_t* term_off, const float* vectors, uint32_t query_type, uint32_t length, uint32_t result_type,
@@ -328,7 +329,7 @@ int ssh_bench_concurrent(ssh_index* ix, int mode, uint32_t n_threads, double sec
   std::vector<std::vector<float>> lat(n_threads), at(n_threads);  // per call: its latency, and when it began (us since the start)
   std::vector<std::thread> th;
   const bool hist = getenv("SSH_BENCH_HIST") != nullptr;  // diagnostics on stderr: the tail's shape and WHEN its calls happened
-  std::chrono::steady_clock::time_point w0;
+  std::chrono::steady_clock::time_point w0, t_steady;  // (both set before `go`: the threads read them after it)
   for (uint32_t t = 0; t < n_threads; t++)
     th.emplace_back([&, t] {
       lat[t].reserve(1 << 16);
@@ -348,17 +349,24 @@ int ssh_bench_concurrent(ssh_index* ix, int mode, uint32_t n_threads, double sec
         const auto t1 = std::chrono::steady_clock::now();
         if (ro.last_error || ro.results.empty()) errors.fetch_add(1, std::memory_order_relaxed);
         if (!warm) { warm = true; continue; }
+        // ... and so is every call that BEGAN in the first `warm_s` of the run: the callers reach their steady state -- all of them riding
+        // the same pass, one batch behind the other -- only after two or three passes; until then a caller arrives in the middle of
+        // somebody else's pass and waits it out before its own (hybrid, T = 64: exactly 64 calls of 20 - 29 ms, all begun in the first
+        // 100 ms, in every run: profiles/r6f_tail_repeat.log).  Not recorded, not counted; the wall time starts after them.
+        if (t0 < t_steady) continue;
         lat[t].push_back((float)std::chrono::duration<double, std::micro>(t1 - t0).count());
         if (hist) at[t].push_back((float)std::chrono::duration<double, std::micro>(t0 - w0).count());
       }
     });
+  const double warm_s = std::min(0.25, seconds / 8.0);
   w0 = std::chrono::steady_clock::now();
+  t_steady = w0 + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(warm_s));
   { std::lock_guard<std::mutex> lk(go_mu); go.store(true, std::memory_order_release); }
   go_cv.notify_all();
-  std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+  std::this_thread::sleep_for(std::chrono::duration<double>(warm_s + seconds));
   stop.store(true, std::memory_order_relaxed);
   for (auto& t : th) t.join();
-  const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+  const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_steady).count();
   std::vector<float> all;
   for (auto& l : lat) all.insert(all.end(), l.begin(), l.end());
   std::sort(all.begin(), all.end());
