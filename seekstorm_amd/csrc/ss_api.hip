@@ -249,6 +249,21 @@ int ss_shard_destroy(ss_shard* s) {
     if (!g_co_vec_wake_us.empty())
       fprintf(stderr, "[co-vec] wake loop us p50 %u p90 %u p99 %u max %u; batch (formed .. scattered) us p50 %u p99 %u max %u\n", pc(g_co_vec_wake_us, 0.5), pc(g_co_vec_wake_us, 0.9),
               pc(g_co_vec_wake_us, 0.99), pc(g_co_vec_wake_us, 1.0), pc(g_co_vec_run_us, 0.5), pc(g_co_vec_run_us, 0.99), pc(g_co_vec_run_us, 1.0));
+    // the batches that make a tail: fewer members than usual, a long pass, or a long gap to the batch before -- with their neighbours
+    if (g_co_vec_run_us.size() == g_co_vec_trace.size() && g_co_vec_wake_us.size() == g_co_vec_trace.size() && gap.size() > 8) {
+      const uint32_t m50 = pc(m, 0.5), r50 = pc(g_co_vec_run_us, 0.5);
+      const uint64_t g50 = pc64(gap, 0.5);
+      int shown = 0;
+      for (size_t i = 1; i < g_co_vec_trace.size() && shown < 24; i++) {
+        const uint64_t g = g_co_vec_trace[i].t_formed_us - g_co_vec_trace[i - 1].t_formed_us;
+        if (g_co_vec_trace[i].members * 4u >= m50 * 3u && g_co_vec_run_us[i] * 4u <= r50 * 5u && g * 10u <= g50 * 13u) continue;
+        shown++;
+        for (size_t j = i - 1; j <= std::min(i + 1, g_co_vec_trace.size() - 1); j++)
+          fprintf(stderr, "[co-vec]   %s batch %zu: members %u, left queued %u, linger %u us, formed-to-scattered %u us, wake loop %u us, since the batch before %llu us\n",
+                  j == i ? "*" : " ", j, g_co_vec_trace[j].members, g_co_vec_trace[j].left_queued, g_co_vec_trace[j].linger_us, g_co_vec_run_us[j], g_co_vec_wake_us[j],
+                  (unsigned long long)(j ? g_co_vec_trace[j].t_formed_us - g_co_vec_trace[j - 1].t_formed_us : 0));
+      }
+    }
     g_co_vec_wake_us.clear(); g_co_vec_run_us.clear();
     g_co_vec_trace.clear();
   }
