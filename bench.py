@@ -202,6 +202,31 @@ def compact_line(line):
     return out
 
 
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    """stdout carries ONE line, the result: everything else any library writes to file descriptor 1 (RCCL prints a five-line version banner
+    through C stdio when its first communicator is made) goes to stderr from here on"""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def print_line(text):
+    sys.stdout.flush()
+    try:
+        C.CDLL(None).fflush(None)  # (C stdio's buffer for fd 1 -- which is stderr by now -- before the line, not behind it)
+    except Exception:
+        pass
+    if _REAL_STDOUT is None:
+        print(text, flush=True)
+    else:
+        os.write(_REAL_STDOUT, (text + "\n").encode())
+
+
 def emit(line, world):
     """details -> bench_details.json (+ stderr); the compact line -> the LAST line of stdout"""
     text = json.dumps(line, indent=1)
@@ -213,12 +238,7 @@ def emit(line, world):
         except OSError:
             pass
     print("BENCH_DETAILS " + json.dumps(line), file=sys.stderr, flush=True)
-    sys.stdout.flush()
-    try:  # RCCL prints its version banner through C stdio, which would otherwise be flushed at exit -- BEHIND the line the driver parses
-        C.CDLL(None).fflush(None)
-    except Exception:
-        pass
-    print(json.dumps(compact_line(line)), flush=True)
+    print_line(json.dumps(compact_line(line)))
 
 
 def one_process_main(args):
@@ -286,7 +306,7 @@ def one_process_main(args):
                        "entry_point": "seekstorm_host Index::search_lexical_batch -> ss_bm25_search_sharded per shard"},
             "ms_per_call": dt / calls * 1e3, "build_s": build_s, "checksum_batch0": checksum, "shards_in_answers": shards_seen.tolist()}
     HL.ssh_index_destroy(ix)
-    print(json.dumps(_r(line)), flush=True)
+    print_line(json.dumps(_r(line)))
     return 0
 
 
@@ -326,6 +346,7 @@ def main():
                     help="the reference's OWN shape instead of one rank per GPU: ONE process, S shards on GPUs 0 .. S-1, one host thread per shard and call "
                          "(search.rs:1637-1650), the lists exchanged over RCCL communicators made by ss_comm_create_all; prints one line of the same form")
     args = ap.parse_args()
+    claim_stdout()
     if args.one_process:
         return one_process_main(args)
     if args.quick:

@@ -426,3 +426,16 @@ def test_bench_offers_the_one_process_shape():
     import subprocess, sys
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "--one-process" in out.stdout and "--gpus" in out.stdout
+
+
+def test_bench_stdout_carries_one_line():
+    """bench.py's contract is ONE JSON line on stdout: whatever a library writes to file descriptor 1 after claim_stdout() (RCCL's version
+    banner, through C stdio) lands on stderr, and print_line() puts the result on the real stdout."""
+    import subprocess, sys
+    code = ("import ctypes, os, sys; sys.path.insert(0, %r); import bench; bench.claim_stdout(); "
+            "ctypes.CDLL(None).puts(b'banner through C stdio'); os.write(1, b'raw write to fd 1\\n'); print('python print'); "
+            "bench.print_line('{\"x\": 1}')") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout == '{"x": 1}\n', repr(out.stdout)
+    assert "banner through C stdio" in out.stderr and "raw write to fd 1" in out.stderr and "python print" in out.stderr
