@@ -773,6 +773,29 @@ def main():
                     F.check_topk(mres["scan16m"][0][i], mres["scan16m"][1][i], od, os_, 1e-4, f"16-term unions, query {i}")
                 parity["union16"] = {"queries": nsm, "checked": "unions of 16 terms at full size: exact result_count_total, top-10 ids outside the tie band, scores rtol 1e-4; "
                                      "oracle = so_search_lex_ref (> 10 terms: union_scan's table walk, search_or)", "seconds": time.perf_counter() - t0}
+        # (3c'') DEEP PAGES (search.rs:1658-1659: the crate's offset + length is unbounded; SS_MAX_K = 1024 per pass behind the ABI): one
+        # C2 query -- host pointers in, the whole page on the host -- at k = 1024 (one pass), 4096, 16384; full-size parity at k = 4096.
+        deep = None
+        if not args.no_topk_count and world == 1 and not args.quick:
+            qd_np = sh.make_queries(term_lists[:4], S.QueryType.Union)
+            dms = {}
+            for kd in (1024, 4096, 16384):
+                fn = lambda kd=kd: sh.search_lexical_batch(qd_np[:1], kd, S.ResultType.TopkCount, reference_shortcuts=False)
+                n_, d_ = timed_for(fn, min_calls=20)
+                dms[str(kd)] = d_ / n_ * 1e3
+            deep = {"ms_per_query": dms, "unit": "ms", "entry_point": "ss_bm25_search (host pointers, one 3-term union of the C2 batch, TopkCount)",
+                    "note": "k > SS_MAX_K = 1024: passes of 1024 under (tombstones | the docs of the earlier passes)"}
+            if not args.no_parity:
+                t0 = time.perf_counter()
+                kd = 4096
+                dd, ds, dc, dtot = sh.search_lexical_batch(qd_np, kd, S.ResultType.TopkCount, reference_shortcuts=False)
+                dans, _, _ = F.c2_answers(args.docs, term_lists[:4], th, kd, O.OP_OR, O.RT_TOPKCOUNT, part=(rank, world))
+                for i in range(4):
+                    od, os_, otot = dans[i]
+                    assert int(dtot[i]) == otot and int(dc[i]) == len(od), f"deep page: query {i}: {int(dc[i])} of {int(dtot[i])} vs oracle {len(od)} of {otot}"
+                    F.check_topk(dd[i][:int(dc[i])], ds[i][:int(dc[i])], od, os_, 1e-4, f"deep page k = {kd}, query {i}")
+                parity["deep_page"] = {"queries": 4, "k": kd, "checked": "exact result_count_total, the 4096 ids outside the tie bands, scores rtol 1e-4",
+                                       "seconds": time.perf_counter() - t0}
         # (3d) a CLUSTERED corpus at full size (every full-size corpus was uniform-random): the same 10 M docs / 4096
         # terms, but a term's density varies 32-fold with the doc's cluster (runs of 1024 / 8192 doc ids; oracle so_lex_cluster_thresh,
         # device lex_cluster_thresh) -- doc ids in bursts, uneven block maxima, sub-blocks a term skips entirely.  Same queries.
@@ -899,7 +922,7 @@ def main():
                   latency_ms={"batch_p50": pct(lat_batch, 50), "batch_p99": pct(lat_batch, 99), "batch_samples": len(lat_batch),
                               "single_query_p50": pct(lat_one, 50), "single_query_p99": pct(lat_one, 99),
                               "single_query_samples": len(lat_one), "clock": "HIP events on the launch stream (device resident)"},
-                  end_to_end=end_to_end, intersection=inter, exhaustive_not_tombstones=excl, clustered=clustered, scale_check=scale_check, union16=many,
+                  end_to_end=end_to_end, intersection=inter, exhaustive_not_tombstones=excl, clustered=clustered, scale_check=scale_check, union16=many, deep_page=deep,
                   mean_bytes_per_query=float(bytes_q.mean()), mean_union=float(tot.mean()))
         # correctness guard inside the bench: sorted, k results
         bm_call()
@@ -1240,7 +1263,26 @@ def main():
         vec_host_call()
         ve2e = host_latencies(vec_host_call, 100)
         ve2e1 = host_latencies(lambda: vec_host_call(1), 100)
-        vec = dict(qps=B * vn / dtv, ms_per_step=dtv / vn * 1e3, calls=vn, build_s=vbuild,
+        # a DEEP page of one query (k = 4096 > SS_MAX_K: four passes under the query's exclusion bitmap); its head must be the top-kv list
+        vdeep = None
+        if not args.quick:
+            kd = 4096
+            dv_doc = np.empty((1, kd), np.uint32); dv_score = np.empty((1, kd), np.float32)
+            dv_cnt = np.empty(1, np.uint32); dv_tot = np.empty(1, np.uint64)
+
+            def vec_deep_call():
+                N.check(L.ss_vec_search(sh._h, 1, N.ptr(qv_np, N.f32p), kd, N.FLT_MIN_NEG, N.ptr(dv_doc, N.u32p), N.ptr(dv_score, N.f32p),
+                                        N.ptr(dv_cnt, N.u32p), N.ptr(dv_tot, N.u64p)), "ss_vec_search")
+            vec_host_call(1)
+            head_doc, head_score = hv_doc[0].copy(), hv_score[0].copy()
+            vec_deep_call()
+            nd_ = int(dv_cnt[0])
+            assert nd_ == min(kd, args.rows) and np.array_equal(dv_doc[0][:kv], head_doc) and np.array_equal(dv_score[0][:kv], head_score), "deep vector page: head differs"
+            assert np.all(dv_score[0][:nd_ - 1] >= dv_score[0][1:nd_]) and len(set(dv_doc[0][:nd_].tolist())) == nd_, "deep vector page: not one descending list of distinct docs"
+            vd = host_latencies(vec_deep_call, 10)
+            vdeep = {"k": kd, "single_query_ms_p50": pct(vd, 50), "samples": len(vd), "entry_point": "ss_vec_search (host pointers)",
+                     "checked": "head == the top-%d call's list bit for bit; descending, distinct docs" % kv}
+        vec = dict(qps=B * vn / dtv, ms_per_step=dtv / vn * 1e3, calls=vn, build_s=vbuild, deep_page=vdeep,
                    roofline={"bound": "mfma", "kernel": "vec_scan_kernel (+refine, all row chunks of one pass)", "achieved": ach,
                              "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": pmc_traffic("vector"),
                              "mfma_util_pmc": pmc_traffic("vector", "mfma_util"),
@@ -1549,6 +1591,8 @@ def main():
                 line["clustered"] = bm["clustered"]
             if bm.get("union16"):
                 line["union16"] = bm["union16"]
+            if bm.get("deep_page"):
+                line["deep_page"] = bm["deep_page"]
             if bm.get("scale_check"):
                 line["scale_check"] = bm["scale_check"]
             if "rationed_vocabulary" in bm:
@@ -1568,7 +1612,7 @@ def main():
                               "global_qps": vec["qps"], "ms_per_call": vec["ms_per_step"], "calls": vec["calls"], "roofline": vec["roofline"],
                               "cpu_baseline": vec.get("cpu_baseline"), "latency_ms": vec["latency_ms"], "end_to_end": vec.get("end_to_end"),
                               "build_s": vec["build_s"], "rows_per_shard": args.rows, "dim": args.dim, "hybrid": vec.get("hybrid"),
-                              "ann": vec.get("ann"), "i8": vec.get("i8")}
+                              "ann": vec.get("ann"), "i8": vec.get("i8"), "deep_page": vec.get("deep_page")}
             if vec.get("sharded"):
                 line["sharded"] = vec["sharded"]
             if vec.get("concurrent_callers"):

@@ -275,7 +275,7 @@ int ss_shard_destroy(ss_shard* s) {
   free_vec(s);
   free_bm25(s);
   for (void* p_ : {(void*)s->d_vq, (void*)s->d_vdoc, (void*)s->d_vscore, (void*)s->d_vcount, (void*)s->d_vtotal}) if (p_) (void)hipFree(p_);
-  void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_deleted, s->d_facets, s->d_filter_bits, s->d_facet_ws, s->d_pool_stage, s->d_tier_ws, s->d_tier_hold, s->d_excl_bits, s->d_sort_ws, s->d_route_ws};
+  void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_deleted, s->d_facets, s->d_filter_bits, s->d_facet_ws, s->d_pool_stage, s->d_tier_ws, s->d_tier_hold, s->d_excl_bits, s->d_sort_ws, s->d_route_ws, s->d_peel_bits};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   (void)hipDeviceSynchronize();  // searches queued on the callers' own streams may still use their workspaces
   for (auto& kv : s->bm_ws) {
@@ -2743,15 +2743,189 @@ int ss_shard_coalescing_stats(ss_shard* s, uint64_t* lexical_batches, uint64_t* 
   return SS_OK;
 }
 
+// ------------------------------------------------------------------ deep pages: offset + length beyond SS_MAX_K results
+// The crate's top_k = offset + length is unbounded (search.rs:1658-1659); the kernels' top-k structures hold SS_MAX_K.  A deeper page is
+// answered in PASSES of SS_MAX_K results: the result order is total (score descending, then doc id ascending), so the docs ranked
+// (p * SS_MAX_K, (p + 1) * SS_MAX_K] of a query are its top SS_MAX_K once the docs of the earlier passes are excluded -- and every kernel
+// family already searches under an exclusion bitmap, the tombstones' (or a facet filter's, which stands in for it).  Pass p runs the
+// ordinary search under  (what excluded docs before) | (the docs passes 0 .. p - 1 returned);  the totals are pass 0's (the first pass
+// counts exactly what a k = SS_MAX_K call counts).  Every shape the library answers at k <= SS_MAX_K is answered at any k this way, on
+// every image (both tiers, several indexed fields, phrases, composed unions); the cost is linear in k / SS_MAX_K, a page that deep is rare.
+__global__ void peel_init_kernel(uint32_t* __restrict__ bits, uint32_t words, uint32_t rows, const uint32_t* __restrict__ base, uint32_t base_words) {
+  const size_t n = (size_t)words * rows;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t w = (uint32_t)(i % words);
+    bits[i] = (base && w < base_words) ? base[w] : 0u;
+  }
+}
+// row r = blockIdx.y: the first min(counts[r], k) docs of docs[r * k ..] into bitmap r
+__global__ void peel_mark_kernel(const uint32_t* __restrict__ docs, const uint32_t* __restrict__ counts, uint32_t k, uint32_t* __restrict__ bits,
+                                 uint32_t words) {
+  const uint32_t r = blockIdx.y;
+  const uint32_t n = counts[r] < k ? counts[r] : k;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t doc = docs[(size_t)r * k + i];
+    if (doc != SS_NO_DOC && (doc >> 5) < words) atomicOr(&bits[(size_t)r * words + (doc >> 5)], 1u << (doc & 31u));
+  }
+}
+__global__ void peel_max_kernel(const uint32_t* __restrict__ v, unsigned long long n, uint32_t* __restrict__ out) {
+  uint32_t m = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = v[i] > m ? v[i] : m;
+  for (int o = 32; o > 0; o >>= 1) { const uint32_t y = __shfl_down(m, o); m = y > m ? y : m; }
+  if ((threadIdx.x & 63u) == 0) atomicMax(out, m);
+}
+
+namespace {
+// the shard's exclusion bitmap replaced by the peel bitmap for the life of the object (the caller holds the shard lock)
+struct PeelSwap {
+  ss_shard* s;
+  uint32_t* del; uint64_t dw, nd; uint32_t stride;
+  PeelSwap(ss_shard* s_, uint32_t* bits, uint64_t words, uint32_t vec_stride) : s(s_), del(s_->d_deleted), dw(s_->deleted_words), nd(s_->n_deleted), stride(s_->vec_del_stride) {
+    s->d_deleted = bits; s->deleted_words = words; s->n_deleted = 1; s->vec_del_stride = vec_stride;
+  }
+  ~PeelSwap() { s->d_deleted = del; s->deleted_words = dw; s->n_deleted = nd; s->vec_del_stride = stride; }
+};
+int peel_ensure(ss_shard* s, size_t dwords) {
+  if (dwords <= s->peel_words_cap) return SS_OK;
+  SS_HIP(hipStreamSynchronize(s->stream));
+  if (s->d_peel_bits) (void)hipFree(s->d_peel_bits);
+  s->d_peel_bits = nullptr; s->peel_words_cap = 0;
+  SS_HIP(hipMalloc(&s->d_peel_bits, dwords * sizeof(uint32_t)));
+  s->peel_words_cap = dwords;
+  return SS_OK;
+}
+}  // namespace
+
+// lexical: query by query (each pass is a single-query search of the ordinary paths).  Caller holds the shard lock; a facet filter's
+// bitmap already stands in s->d_deleted (with_facet_filter).
+static int bm25_search_deep_locked(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k, uint32_t rt, uint32_t* out_doc, float* out_score,
+                                   uint32_t* out_count, uint64_t* out_total) {
+  const uint32_t base_words = s->n_deleted ? (uint32_t)s->deleted_words : 0u;
+  const uint32_t words = std::max<uint32_t>((uint32_t)(((uint64_t)s->bm_n_docs + 31) / 32), base_words);
+  SS_HIP(hipSetDevice(s->device));
+  SS_TRY(peel_ensure(s, words));
+  const uint32_t* base = s->n_deleted ? s->d_deleted : nullptr;
+  std::vector<uint32_t> h_doc(SS_MAX_K);
+  std::vector<float> h_score(SS_MAX_K);
+  for (uint32_t i = 0; i < nq; i++) {
+    uint32_t* od = out_doc + (size_t)i * k;
+    float* os = out_score + (size_t)i * k;
+    uint32_t got = 0;
+    uint64_t total = 0;
+    peel_init_kernel<<<std::min<uint32_t>(1024u, (words + 255u) / 256u), 256, 0, s->stream>>>(s->d_peel_bits, words, 1, base, base_words);
+    SS_HIP(hipGetLastError());
+    {
+      PeelSwap sw(s, s->d_peel_bits, words, 0);
+      for (uint32_t pass = 0; got < k; pass++) {
+        const uint32_t kk = std::min<uint32_t>(SS_MAX_K, k - got);
+        SS_TRY(bm25_search_host_queries(s, 1, q + i, kk, pass == 0 ? rt : (uint32_t)SS_RT_TOPK, 0, nullptr));
+        uint32_t c = 0;
+        SS_HIP(hipMemcpyAsync(&c, s->d_out_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+        if (pass == 0) SS_HIP(hipMemcpyAsync(&total, s->d_out_total, sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
+        SS_HIP(hipMemcpyAsync(h_doc.data(), s->d_out_doc, (size_t)kk * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+        SS_HIP(hipMemcpyAsync(h_score.data(), s->d_out_score, (size_t)kk * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+        SS_HIP(hipStreamSynchronize(s->stream));
+        c = std::min(c, kk);
+        memcpy(od + got, h_doc.data(), (size_t)c * sizeof(uint32_t));
+        memcpy(os + got, h_score.data(), (size_t)c * sizeof(float));
+        got += c;
+        if (c < kk || got >= k) break;  // the list ran dry, or the page is full
+        peel_mark_kernel<<<dim3(4, 1), 256, 0, s->stream>>>(s->d_out_doc, s->d_out_count, kk, s->d_peel_bits, words);
+        SS_HIP(hipGetLastError());
+      }
+    }
+    for (uint32_t r = got; r < k; r++) { od[r] = SS_NO_DOC; os[r] = 0.f; }
+    out_count[i] = got;
+    out_total[i] = total;
+  }
+  return SS_OK;
+}
+static int bm25_search_deep(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k, uint32_t rt, uint32_t n_filters, const ss_facet_filter* filters,
+                            uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total) {
+  ShardLock g(s);
+  if (!s->d_post) return SS_ESTATE;
+  SS_HIP(hipSetDevice(s->device));
+  return with_facet_filter(s, n_filters, filters, s->stream, [&]() { return bm25_search_deep_locked(s, nq, q, k, rt, out_doc, out_score, out_count, out_total); });
+}
+
+// vectors: groups of <= SS_VEC_BATCH queries, one exclusion bitmap PER QUERY of the group (vec_refine_kernel's del_stride); a pass is one
+// scan of the group at k = SS_MAX_K.  The exclusion is by DOC (a doc of several records is returned once, by its best record).
+static int vec_search_host_deep(ss_shard* s, uint32_t nq, const void* queries, size_t elem, const float* query_scale, uint32_t k, float thr,
+                                const ss_ann_mode* mode, uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total,
+                                uint32_t* out_clusters, const float* query_norm) {
+  if (nq == 0) return SS_OK;
+  ShardLock g(s);
+  if (s->vstream) SS_HIP(hipStreamSynchronize(s->vstream));
+  SS_HIP(hipSetDevice(s->device));
+  // the largest doc id a row can stand for
+  uint64_t doc_bound = s->n_rows;
+  if (s->d_row_doc) {
+    SS_TRY(ensure_qstage(s, 256));
+    SS_HIP(hipMemsetAsync(s->d_qstage, 0, sizeof(uint32_t), s->stream));
+    peel_max_kernel<<<1024, 256, 0, s->stream>>>(s->d_row_doc, (unsigned long long)s->n_rows, (uint32_t*)s->d_qstage);
+    uint32_t mx = 0;
+    SS_HIP(hipMemcpyAsync(&mx, s->d_qstage, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    SS_HIP(hipStreamSynchronize(s->stream));
+    doc_bound = (uint64_t)mx + 1;
+  }
+  const uint32_t base_words = s->n_deleted ? (uint32_t)s->deleted_words : 0u;
+  const uint32_t words = std::max<uint32_t>((uint32_t)((doc_bound + 31) / 32), base_words);
+  const uint32_t G = (uint32_t)std::min<size_t>(nq, SS_VEC_BATCH);
+  SS_TRY(peel_ensure(s, (size_t)words * G));
+  const uint32_t* base = s->n_deleted ? s->d_deleted : nullptr;
+  const uint32_t ocw = (mode && (mode->flags & SS_ANN_REPORT_OBSERVED)) ? 3u : 1u;
+  std::vector<uint32_t> h_doc((size_t)G * SS_MAX_K), h_count(G), got(G);
+  std::vector<float> h_score((size_t)G * SS_MAX_K);
+  std::vector<uint8_t> dry(G);
+  for (uint32_t g0 = 0; g0 < nq; g0 += G) {
+    const uint32_t nb = std::min<uint32_t>(G, nq - g0);
+    peel_init_kernel<<<std::min<uint32_t>(4096u, (uint32_t)(((size_t)words * nb + 255u) / 256u)), 256, 0, s->stream>>>(s->d_peel_bits, words, nb, base, base_words);
+    SS_HIP(hipGetLastError());
+    std::fill(got.begin(), got.end(), 0u);
+    std::fill(dry.begin(), dry.end(), (uint8_t)0);
+    PeelSwap sw(s, s->d_peel_bits, words, words);
+    for (uint32_t pass = 0;; pass++) {
+      uint32_t* d_ncl = nullptr;
+      SS_TRY(vec_search_host_lists(s, nb, (const char*)queries + (size_t)g0 * s->dim * elem, elem, query_scale ? query_scale + g0 : nullptr, SS_MAX_K, thr, mode,
+                                   h_count.data(), &d_ncl, query_norm ? query_norm + g0 : nullptr, out_clusters != nullptr && pass == 0));
+      SS_HIP(hipMemcpy(h_doc.data(), s->d_out_doc, (size_t)nb * SS_MAX_K * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      SS_HIP(hipMemcpy(h_score.data(), s->d_out_score, (size_t)nb * SS_MAX_K * sizeof(float), hipMemcpyDeviceToHost));
+      if (pass == 0) {
+        SS_HIP(hipMemcpy(out_total + g0, s->d_out_total, (size_t)nb * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        if (d_ncl && out_clusters) SS_HIP(hipMemcpy(out_clusters + (size_t)g0 * ocw, d_ncl, (size_t)nb * ocw * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      }
+      bool more = false;
+      for (uint32_t i = 0; i < nb; i++) {
+        if (dry[i] || got[i] >= k) continue;
+        const uint32_t c = std::min<uint32_t>(std::min<uint32_t>(h_count[i], SS_MAX_K), k - got[i]);
+        memcpy(out_doc + (size_t)(g0 + i) * k + got[i], h_doc.data() + (size_t)i * SS_MAX_K, (size_t)c * sizeof(uint32_t));
+        memcpy(out_score + (size_t)(g0 + i) * k + got[i], h_score.data() + (size_t)i * SS_MAX_K, (size_t)c * sizeof(float));
+        got[i] += c;
+        if (h_count[i] < SS_MAX_K) dry[i] = 1;
+        more |= !dry[i] && got[i] < k;
+      }
+      if (!more) break;
+      peel_mark_kernel<<<dim3(4, nb), 256, 0, s->stream>>>(s->d_out_doc, s->d_out_count, SS_MAX_K, s->d_peel_bits, words);
+      SS_HIP(hipGetLastError());
+    }
+    for (uint32_t i = 0; i < nb; i++) {
+      for (uint32_t r = got[i]; r < k; r++) { out_doc[(size_t)(g0 + i) * k + r] = SS_NO_DOC; out_score[(size_t)(g0 + i) * k + r] = 0.f; }
+      out_count[g0 + i] = got[i];
+    }
+  }
+  return SS_OK;
+}
+
 int ss_bm25_search_filtered(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t k, uint32_t rt, uint32_t n_filters,
                             const ss_facet_filter* filters, uint32_t* out_doc, float* out_score, uint32_t* out_count,
                             uint64_t* out_total) {
   if (!s || !q || !out_count || !out_total) return SS_EINVAL;
   if (rt > SS_RT_TOPKCOUNT) return SS_EINVAL;
   if (rt != SS_RT_COUNT && (k == 0 || !out_doc || !out_score)) return SS_EINVAL;
-  if (rt != SS_RT_COUNT && k > SS_MAX_K) return SS_ENOTSUP;  // (the crate's offset + length is unbounded, search.rs:1658-1659: its own dispatch pages that deep)
   if (!s->d_post) return SS_ESTATE;
   if (nq == 0) return SS_OK;
+  // (the crate's offset + length is unbounded, search.rs:1658-1659: a page deeper than SS_MAX_K results is answered in passes)
+  if (rt != SS_RT_COUNT && k > SS_MAX_K) return bm25_search_deep(s, nq, q, k, rt, n_filters, filters, out_doc, out_score, out_count, out_total);
   if (n_filters == 0 && nq <= SS_COALESCE_MAX_REQUEST && s->co_lex.max_batch) {
     ss_co_req r;
     r.q = q; r.nq = nq; r.k = rt == SS_RT_COUNT ? 0u : k; r.rt = rt;
@@ -2959,8 +3133,8 @@ int ss_bm25_search_sorted(ss_shard* s, uint32_t nq, const ss_bm25_query* queries
                           uint32_t n_filters, const ss_facet_filter* filters, uint32_t* out_doc, float* out_score, uint32_t* out_count,
                           uint64_t* out_total) {
   if (!s || !queries || nq == 0 || !out_doc || !out_score || !out_count || !out_total || k == 0) return SS_EINVAL;
-  if (k > SS_MAX_K) return SS_ENOTSUP;
   if (n_sorts == 0) return ss_bm25_search_filtered(s, nq, queries, k, SS_RT_TOPKCOUNT, n_filters, filters, out_doc, out_score, out_count, out_total);
+  if (k > SS_MAX_K) return SS_ENOTSUP;  // (a page that deep SORTED BY A FACET: the host's own dispatch -- the select keeps k per query in LDS)
   if (!sorts) return SS_EINVAL;
   if (n_sorts > SS_MAX_SORT_FIELDS) return SS_ENOTSUP;
   static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 2, 4, 8};
@@ -3444,10 +3618,11 @@ int ss_vec_search_ann(ss_shard* s, uint32_t nq, const float* queries, uint32_t k
                       uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total, uint32_t* out_clusters) {
   if (!s || !queries || !out_doc || !out_score || !out_count || !out_total) return SS_EINVAL;
   if (k == 0) return SS_EINVAL;
-  if (k > SS_MAX_K) return SS_ENOTSUP;  // (deeper pages: the host's own dispatch)
   if (!s->d_X) return SS_ESTATE;
   SS_TRY(ann_mode_ok(s, mode));
   mode = ann_effective(mode);
+  if (k > SS_MAX_K)  // (a page deeper than SS_MAX_K results: passes under per-query exclusion bitmaps, "deep pages" above)
+    return vec_search_host_deep(s, nq, queries, sizeof(float), nullptr, k, thr, mode, out_doc, out_score, out_count, out_total, mode ? out_clusters : nullptr, nullptr);
   if (!mode && nq != 0 && nq <= SS_COALESCE_MAX_REQUEST && s->co_vec.max_batch) {  // AnnMode::All from concurrent callers: one pass serves them
     ss_co_req r;
     r.q = queries; r.nq = nq; r.k = k; r.elem = (uint32_t)sizeof(float); r.thr = thr;
@@ -3766,11 +3941,12 @@ int ss_vec_search_i8_euclid(ss_shard* s, uint32_t nq, const int8_t* queries, con
                             uint64_t* out_total, uint32_t* out_clusters) {
   if (!s || !queries || !out_doc || !out_score || !out_count || !out_total) return SS_EINVAL;
   if (k == 0) return SS_EINVAL;
-  if (k > SS_MAX_K) return SS_ENOTSUP;  // (deeper pages: the host's own dispatch)
   if (!s->d_X8) return SS_ESTATE;
   SS_TRY(vec8_euclid_norms_ok(s, query_scale != nullptr, query_norm != nullptr));
   SS_TRY(ann_mode_ok(s, mode));
   mode = ann_effective(mode);
+  if (k > SS_MAX_K)  // (deep pages)
+    return vec_search_host_deep(s, nq, queries, 1, query_scale, k, thr, mode, out_doc, out_score, out_count, out_total, mode ? out_clusters : nullptr, query_norm);
   if (!mode && !query_norm && nq != 0 && nq <= SS_COALESCE_MAX_REQUEST && s->co_vec.max_batch) {
     ss_co_req r;
     r.q = queries; r.qscale = query_scale; r.nq = nq; r.k = k; r.elem = 1; r.thr = thr;

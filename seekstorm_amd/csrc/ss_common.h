@@ -392,6 +392,11 @@ struct ss_shard {
   size_t tier_hold_cap = 0;
   uint32_t* d_excl_bits = nullptr;   // per-query exclusion bitmap of such a query: tombstones | docs of its sparse NOT lists
   size_t excl_words_cap = 0;
+  // pages deeper than SS_MAX_K results (ss_api.hip "deep pages"): the exclusion bitmap(s) of the passes -- whatever excluded docs before
+  // (tombstones, a facet filter) | the docs the earlier passes returned; one row of peel_words words per query of a vector group
+  uint32_t* d_peel_bits = nullptr;
+  size_t peel_words_cap = 0;         // dwords allocated
+  uint32_t vec_del_stride = 0;       // != 0: d_deleted holds one bitmap of that many words per query of the vector batch in flight
   // threshold seeds from OUTSIDE a batch's own lists (bm25_search_tiered: the k-th FULL score the sparse kernel found for a union whose dense
   // terms this batch carries): [ext_seed_n] floats, row i for query i of the NEXT ssi_bm25_search call of exactly ext_seed_n queries
   const float* d_ext_seed = nullptr;

@@ -423,7 +423,9 @@ constexpr int VR_THREADS = 1024;  // (256 threads measured twice as slow on the 
 __global__ void __launch_bounds__(VR_THREADS) vec_refine_kernel(VState* __restrict__ st, unsigned long long* __restrict__ cand,
                                                          uint32_t k, const uint32_t* __restrict__ row_doc /* non-null: dedup */,
                                                          const uint32_t* __restrict__ doc_map /* row -> doc, null = identity */,
-                                                         const uint32_t* __restrict__ del, uint32_t del_words) {
+                                                         const uint32_t* __restrict__ del, uint32_t del_words,
+                                                         uint32_t del_stride /* words; != 0: one bitmap per query (deep pages) */,
+                                                         uint32_t del_rows /* ... of the first del_rows queries: the batch's own */) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long* keys = (unsigned long long*)smem;
   uint32_t* docs = (uint32_t*)(smem + VS_CAP * sizeof(unsigned long long));
@@ -439,6 +441,7 @@ __global__ void __launch_bounds__(VR_THREADS) vec_refine_kernel(VState* __restri
   uint32_t np = 64;
   while (np < n) np <<= 1;
   unsigned long long* base = cand + (size_t)q * VS_CAP;
+  if (del && del_stride) del = q < del_rows ? del + (size_t)q * del_stride : nullptr;  // (slots past the batch hold no query of anybody's)
   __shared__ uint32_t live, dropped;
   if (threadIdx.x == 0) { live = 0; dropped = 0; }
   __syncthreads();
@@ -743,7 +746,7 @@ int ssi_vec_search(ss_shard* s, uint32_t nq, const void* d_queries, const float*
                                                                            s->d_Qf, nch, tile0, c, vst, cand, ann);
       vec_refine_kernel<<<SS_VEC_BATCH, VR_THREADS, VS_CAP * (sizeof(unsigned long long) + sizeof(uint32_t)), st>>>(
           vst, cand, k, s->vec_multi_record ? s->d_row_doc : nullptr, s->d_row_doc, s->n_deleted ? s->d_deleted : nullptr,
-          (uint32_t)s->deleted_words);
+          (uint32_t)s->deleted_words, s->n_deleted ? s->vec_del_stride : 0u, nb);
       tile0 += c;
     }
     ssi_prof_end(s, 1, st, e0, e1);

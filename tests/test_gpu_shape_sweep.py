@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 
 # the CPU fall-through list: (what, where the reference answers it) -- mirrored by INTEGRATION.md section 4
 CPU_FALL_THROUGH = {
-    "k_gt_1024": "offset + length beyond SS_MAX_K = 1024 results (search.rs:1658-1659: the crate's top_k is unbounded)",
+    "k_gt_1024_sorted_or_device": "offset + length beyond SS_MAX_K = 1024 results on the entries that keep their answers on the device or sort them by a facet "
+                                  "(ss_*_dev, ss_*_sharded, ss_bm25_search_sorted with sort fields; the host-pointer entries answer any k: tests/test_gpu_deep_pages.py)",
     "gt32_terms": "a query of more than 32 unique terms, NOT terms included (union.rs:233-259, 617-624: union_scan_32 over the 32 lists with the largest block maxima + union_count); refused by the mirrors' make_query, tests/test_gpu_union_many.py",
     "union_filter_gt10": "a UNION of more than 10 terms under a field filter, several indexed fields (union.rs:265-595 union_scan + add_result.rs:3124-3136)",
     "nomerged_phrase": "a phrase on an image of several indexed fields whose boosts kept the merged lists from being built (add_result.rs:3248-3386)",
@@ -307,11 +308,11 @@ def test_sweep_three_indexed_fields(S, O, with_tier):
         _expect_enotsup(S, sh, q, 10, S.ResultType.TopkCount, CPU_FALL_THROUGH["union_filter_gt10"])
         ro = sh.search_lexical_shard(_pick(rng, n, frequent + mid), S.QueryType.Union, 0, 10, field_filter=(0,))
         assert ro.cpu_dispatch and not ro.results  # the mirror says "the host's dispatch answers this", not "no hits"
-    # ... and a page deeper than SS_MAX_K results (k = 1024 itself is answered)
+    # ... a page deeper than SS_MAX_K results is answered (in passes: tests/test_gpu_deep_pages.py)
     q = sh.make_queries([_pick(rng, 2, mid)], S.QueryType.Union)
     assert int(sh.search_lexical_batch(q, 1024, S.ResultType.TopkCount, reference_shortcuts=False)[2][0]) > 0
-    _expect_enotsup(S, sh, q, 1025, S.ResultType.TopkCount, CPU_FALL_THROUGH["k_gt_1024"])
-    assert sh.search_lexical_shard(_pick(rng, 2, mid), S.QueryType.Union, 1000, 25).cpu_dispatch
+    assert int(sh.search_lexical_batch(q, 1025, S.ResultType.TopkCount, reference_shortcuts=False)[2][0]) > 0
+    assert not sh.search_lexical_shard(_pick(rng, 2, mid), S.QueryType.Union, 1000, 25).cpu_dispatch
     sh.close()
 
 
