@@ -50,6 +50,12 @@ extern "C" {
 /* scored + NOT terms of one query: union_docid_3 takes unions of <= 10 terms (union.rs:1308), union_blockid -> union_scan_32 those of
  * 11..32 (search.rs:3497-3520, union.rs:598-805; its 32-bit match mask is the limit) */
 #define SS_MAX_QUERY_TERMS 32
+/* results one PASS over the index holds.  The host-pointer searches (ss_bm25_search[_filtered], ss_vec_search*, ss_vec_search_i8*) take
+ * any k -- the crate's offset + length is unbounded (search.rs:1658-1659) -- and answer k > SS_MAX_K in passes of SS_MAX_K, every pass
+ * the ordinary search under (tombstones or the facet filter's bitmap) | (the docs of the earlier passes); totals are the first pass's.
+ * ss_bm25_search_sharded / ss_vec_search_sharded do the same before their exchange.  The entries that keep their answers on the device
+ * (ss_*_dev), fuse two lists on it (ss_hybrid_search_sharded) or sort by a facet (ss_bm25_search_sorted with sort fields) return
+ * SS_ENOTSUP beyond it. */
 #define SS_MAX_K 1024
 #define SS_VEC_BATCH 64 /* queries scanned per pass over the matrix */
 
@@ -735,7 +741,9 @@ int ss_merge_results(int mode, const uint64_t* lex_doc, const float* lex_score, 
 /* Device-side variant for the multi-GPU path: per-shard top-k lists of a whole query batch, laid out
  * [n_shards][n_queries][k] exactly as an RCCL all-gather of the ss_*_search_dev outputs leaves them, are merged
  * per query into global ids (local*S + shard), sorted by score desc (ties: shard order, as the reference's stable
- * sort of the concatenation).  Unused slots: doc = UINT64_MAX.  n_shards*k <= 8192. */
+ * sort of the concatenation).  Unused slots: doc = UINT64_MAX.  Any n_shards * k: up to 8192 keys per query are sorted in LDS; beyond
+ * that (more than 8 shards at k = 1024, a deep page) every entry finds its slot by binary searches in the other shards' lists -- the
+ * lists must then arrive sorted by score descending, as the searches leave them. */
 int ss_topk_merge_dev(int device, uint32_t n_queries, uint32_t n_shards, uint32_t k, const uint32_t* d_doc,
                       const float* d_score, const uint32_t* d_count, uint64_t* d_out_doc, float* d_out_score,
                       uint32_t* d_out_count, void* stream);
@@ -745,7 +753,7 @@ int ss_topk_merge_dev_packed(int device, uint32_t n_queries, uint32_t n_shards, 
                              uint64_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, void* stream);
 /* the WHOLE concatenation of the gathered lists, sorted: outputs [n_queries][n_shards * k] -- what the RRF ranks of a hybrid
  * search over several shards run over (search.rs:1962-2035 sorts the appended lists untruncated); feeds ss_rrf_merge_dev with
- * k_lex / k_vec = n_shards * k.  n_shards * k <= 8192. */
+ * k_lex / k_vec = n_shards * k (ss_rrf_merge_dev takes k_lex + k_vec <= 8192). */
 int ss_topk_concat_dev_packed(int device, uint32_t n_queries, uint32_t n_shards, uint32_t k, const uint32_t* d_packed,
                               uint64_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, void* stream);
 /* ---- the exchange itself, behind the ABI (RCCL over xGMI; replaces search.rs:1875-1940 + 2098-2119 for shards on different
@@ -756,7 +764,7 @@ int ss_topk_concat_dev_packed(int device, uint32_t n_queries, uint32_t n_shards,
  * ss_topk_allgather_merge: packs this shard's top-k lists of the batch (outputs of ss_*_search_dev, [n_queries][k]), ONE
  * all-gather, then ss_topk_merge_dev_packed -- every rank ends with the same merged lists.  Asynchronous on `stream`; all
  * ranks must call it with the same n_queries and k (in a single process: from one thread per rank, as Index::search runs its
- * shard tasks).  n_ranks * k <= 8192. */
+ * shard tasks).  Any n_ranks * k (see ss_topk_merge_dev). */
 #define SS_COMM_ID_BYTES 128
 typedef struct ss_comm ss_comm;
 int ss_comm_unique_id(uint8_t id_out[SS_COMM_ID_BYTES]);
@@ -781,7 +789,9 @@ int ss_bm25_search_sharded(ss_shard* s, ss_comm* c, uint32_t n_queries, const ss
  * k = offset + length, both lists in the one all-gather, the two cross-shard concatenations sorted, RRF over them (ranks run
  * over the whole concatenation, search.rs:1962-2035), sort / offset / length (2098-2119); out_* [n_queries][length] with
  * out_source SS_SRC_* (may be NULL); out_total = sum over the shards of max(lexical, vector) totals (1919-1921).
- * result_type: SS_RT_TOPK or SS_RT_TOPKCOUNT (the lexical task's).  n_ranks * k * 2 <= 4096.
+ * result_type: SS_RT_TOPK or SS_RT_TOPKCOUNT (the lexical task's).  n_ranks * k * 2 <= 8192 (the fusion kernel's LDS;
+ * SS_ENOTSUP beyond, and for k > SS_MAX_K: the host fuses such a page itself); ss_bm25_search_sharded / ss_vec_search_sharded take any k
+ * (k > SS_MAX_K: this shard's list in passes, see SS_MAX_K) and any n_ranks * k.
  * Every ss_*_search_sharded call is a collective in which a rank takes part EVEN IF its own search failed (with empty lists and
  * a status word): that rank returns its own error, every other rank SS_EPEER -- no rank is left blocking in the exchange. */
 int ss_vec_search_sharded(ss_shard* s, ss_comm* c, uint32_t n_queries, const float* queries, uint32_t k, float threshold_raw,
@@ -800,7 +810,7 @@ int ss_comm_profile_read(ss_comm* c, uint64_t* collectives, double* total_us, in
  * outputs of ss_bm25_search_dev / ss_vec_search*_dev (u32 shard-local ids, doc_ids_are_u64 = 0) or of ss_topk_merge_dev*
  * (u64 global ids, = 1), with their counts; both sorted by score descending with unique ids (the scores themselves are not
  * needed: only ranks enter the fusion).  Outputs [n_queries][length]: doc (UINT64_MAX = unused), fused score,
- * source (SS_SRC_*, may be NULL), count.  Equal fused scores: doc id ascending.  k_lex + k_vec <= 4096; k_lex = 0 or
+ * source (SS_SRC_*, may be NULL), count.  Equal fused scores: doc id ascending.  k_lex + k_vec <= 8192 (SS_ENOTSUP beyond); k_lex = 0 or
  * k_vec = 0 leaves the other list's ranks as scores. */
 int ss_rrf_merge_dev(int device, uint32_t n_queries, uint32_t k_lex, const void* d_lex_doc, const uint32_t* d_lex_count,
                      uint32_t k_vec, const void* d_vec_doc, const uint32_t* d_vec_count, int doc_ids_are_u64, uint32_t offset,

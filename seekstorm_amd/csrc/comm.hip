@@ -128,7 +128,7 @@ int ss_comm_info(const ss_comm* c, int* rank, int* n_ranks, int* device) {
 int ss_topk_allgather_merge(ss_comm* c, uint32_t n_queries, uint32_t k, const uint32_t* d_doc, const float* d_score,
                             const uint32_t* d_count, uint64_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, void* stream) {
   if (!c || !d_doc || !d_score || !d_count || !d_out_doc || !d_out_score || !d_out_count) return SS_EINVAL;
-  if (k == 0 || (uint64_t)c->n_ranks * k > 8192) return SS_EINVAL;
+  if (k == 0 || (uint64_t)c->n_ranks * k > 0xFFFFFFFFull) return SS_EINVAL;
   if (n_queries == 0) return SS_OK;
   std::lock_guard<std::mutex> g(c->mu);
   SS_HIP(hipSetDevice(c->device));

@@ -71,21 +71,82 @@ __global__ void __launch_bounds__(256) topk_merge_kernel(uint32_t nq, uint32_t S
   if (threadIdx.x == 0) out_cnt[q] = total;
 }
 
+// The same merge for ANY n_shards * k (more than the 8192 keys the kernel above sorts in LDS: deep pages, k > SS_MAX_K, or more than 8 shards at
+// k = 1024): no sort at all -- the lists arrive sorted, so every entry FINDS its rank in the merged order: its rank in its own list + for
+// every other list the number of entries that precede it there (a binary search; equal scores: concatenation order, exactly the order
+// of the keys above) -- and writes itself to that slot if it lies inside out_len.  One thread per entry; the slots no entry claims were
+// filled with (UINT64_MAX, 0) before.
+__global__ void __launch_bounds__(256) topk_merge_rank_kernel(uint32_t nq, uint32_t S, uint32_t k, const uint32_t* __restrict__ doc,
+                                                             const float* __restrict__ score, const uint32_t* __restrict__ cnt,
+                                                             size_t stride_ds, size_t stride_c, uint32_t out_len,
+                                                             u64* __restrict__ out_doc, float* __restrict__ out_score,
+                                                             uint32_t* __restrict__ out_cnt) {
+  const uint32_t q = blockIdx.y;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  auto count_of = [&](uint32_t s) -> uint32_t {
+    uint32_t c = cnt[(size_t)s * stride_c + q];
+    if (c == 0xFFFFFFFFu) c = 0;
+    return c < k ? c : k;
+  };
+  if (e == 0) {
+    u64 total = 0;
+    for (uint32_t s = 0; s < S; s++) total += count_of(s);
+    out_cnt[q] = (uint32_t)(total < out_len ? total : out_len);
+  }
+  if (e >= (size_t)S * k) return;
+  const uint32_t s = (uint32_t)(e / k), r = (uint32_t)(e % k);
+  if (r >= count_of(s)) return;
+  const size_t at = (size_t)s * stride_ds + (size_t)q * k + r;
+  const uint32_t mine = mg_f2ord(score[at]);
+  size_t rank = r;
+  for (uint32_t o = 0; o < S; o++) {
+    if (o == s) continue;
+    const float* __restrict__ ls = score + (size_t)o * stride_ds + (size_t)q * k;
+    // entries of list o that come before this one: score above it, or equal in an EARLIER list
+    uint32_t lo = 0, hi = count_of(o);
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      const uint32_t x = mg_f2ord(ls[mid]);
+      const bool before = o < s ? x >= mine : x > mine;
+      if (before) lo = mid + 1; else hi = mid;
+    }
+    rank += lo;
+  }
+  if (rank < out_len) {
+    out_doc[(size_t)q * out_len + rank] = (u64)doc[at] * S + s;  // search.rs:1671
+    out_score[(size_t)q * out_len + rank] = score[at];
+  }
+}
+
+// one launcher for both: the LDS sort up to 8192 keys, the rank merge beyond
+static int topk_merge_any(int device, uint32_t nq, uint32_t S, uint32_t k, const uint32_t* d_doc, const float* d_score, const uint32_t* d_count,
+                          size_t stride_ds, size_t stride_c, uint32_t out_len, uint64_t* d_out_doc, float* d_out_score, uint32_t* d_out_count,
+                          hipStream_t st) {
+  if (S == 0 || k == 0 || out_len == 0 || (uint64_t)out_len > (uint64_t)S * k || (uint64_t)S * k > 0xFFFFFFFFull) return SS_EINVAL;
+  if (nq == 0) return SS_OK;
+  SS_HIP(hipSetDevice(device));
+  if ((uint64_t)S * k <= 8192) {
+    uint32_t np = 64;
+    while (np < S * k) np <<= 1;
+    SS_SET_MAX_LDS(topk_merge_kernel, 8192 * 8);
+    topk_merge_kernel<<<nq, 256, np * sizeof(u64), st>>>(nq, S, k, d_doc, d_score, d_count, stride_ds, stride_c, out_len, (u64*)d_out_doc, d_out_score,
+                                                        d_out_count);
+  } else {
+    SS_HIP(hipMemsetAsync(d_out_doc, 0xFF, (size_t)nq * out_len * sizeof(u64), st));
+    SS_HIP(hipMemsetAsync(d_out_score, 0, (size_t)nq * out_len * sizeof(float), st));
+    const dim3 grid((uint32_t)(((size_t)S * k + 255) / 256), nq);
+    topk_merge_rank_kernel<<<grid, 256, 0, st>>>(nq, S, k, d_doc, d_score, d_count, stride_ds, stride_c, out_len, (u64*)d_out_doc, d_out_score, d_out_count);
+  }
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
 extern "C" int ss_topk_merge_dev(int device, uint32_t n_queries, uint32_t n_shards, uint32_t k, const uint32_t* d_doc,
                                  const float* d_score, const uint32_t* d_count, uint64_t* d_out_doc, float* d_out_score,
                                  uint32_t* d_out_count, void* stream) {
   if (!d_doc || !d_score || !d_count || !d_out_doc || !d_out_score || !d_out_count) return SS_EINVAL;
-  if (n_shards == 0 || k == 0 || (uint64_t)n_shards * k > 8192) return SS_EINVAL;
-  if (n_queries == 0) return SS_OK;
-  SS_HIP(hipSetDevice(device));
-  uint32_t np = 64;
-  while (np < n_shards * k) np <<= 1;
-  SS_SET_MAX_LDS(topk_merge_kernel, 8192 * 8);
-  topk_merge_kernel<<<n_queries, 256, np * sizeof(u64), (hipStream_t)stream>>>(n_queries, n_shards, k, d_doc, d_score, d_count,
-                                                                              (size_t)n_queries * k, (size_t)n_queries, k,
-                                                                              (u64*)d_out_doc, d_out_score, d_out_count);
-  SS_HIP(hipGetLastError());
-  return SS_OK;
+  return topk_merge_any(device, n_queries, n_shards, k, d_doc, d_score, d_count, (size_t)n_queries * k, (size_t)n_queries, k, d_out_doc, d_out_score,
+                        d_out_count, (hipStream_t)stream);
 }
 
 // The same over ONE gathered buffer: every shard contributes [nq * k doc ids | nq * k score bits | nq counts] (32-bit words),
@@ -93,34 +154,16 @@ extern "C" int ss_topk_merge_dev(int device, uint32_t n_queries, uint32_t n_shar
 extern "C" int ss_topk_merge_dev_packed(int device, uint32_t n_queries, uint32_t n_shards, uint32_t k, const uint32_t* d_packed,
                                         uint64_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, void* stream) {
   if (!d_packed || !d_out_doc || !d_out_score || !d_out_count) return SS_EINVAL;
-  if (n_shards == 0 || k == 0 || (uint64_t)n_shards * k > 8192) return SS_EINVAL;
-  if (n_queries == 0) return SS_OK;
-  SS_HIP(hipSetDevice(device));
-  uint32_t np = 64;
-  while (np < n_shards * k) np <<= 1;
-  SS_SET_MAX_LDS(topk_merge_kernel, 8192 * 8);
   const size_t nk = (size_t)n_queries * k, stride = 2 * nk + n_queries;
-  topk_merge_kernel<<<n_queries, 256, np * sizeof(u64), (hipStream_t)stream>>>(n_queries, n_shards, k, d_packed, (const float*)(d_packed + nk),
-                                                                              d_packed + 2 * nk, stride, stride, k, (u64*)d_out_doc,
-                                                                              d_out_score, d_out_count);
-  SS_HIP(hipGetLastError());
-  return SS_OK;
+  return topk_merge_any(device, n_queries, n_shards, k, d_packed, (const float*)(d_packed + nk), d_packed + 2 * nk, stride, stride, k, d_out_doc,
+                        d_out_score, d_out_count, (hipStream_t)stream);
 }
 
 // the same kernel for the sharded searches (comm.hip): lists anywhere inside the gathered buffer, out_len = k or S * k entries
 int ssi_topk_merge_launch(int device, uint32_t nq, uint32_t S, uint32_t k, const uint32_t* d_doc, const float* d_score, const uint32_t* d_count,
                           size_t stride_ds, size_t stride_c, uint32_t out_len, uint64_t* d_out_doc, float* d_out_score, uint32_t* d_out_count,
                           hipStream_t st) {
-  if (S == 0 || k == 0 || (uint64_t)S * k > 8192 || out_len == 0 || out_len > S * k) return SS_EINVAL;
-  if (nq == 0) return SS_OK;
-  SS_HIP(hipSetDevice(device));
-  uint32_t np = 64;
-  while (np < S * k) np <<= 1;
-  SS_SET_MAX_LDS(topk_merge_kernel, 8192 * 8);
-  topk_merge_kernel<<<nq, 256, np * sizeof(u64), st>>>(nq, S, k, d_doc, d_score, d_count, stride_ds, stride_c, out_len, (u64*)d_out_doc, d_out_score,
-                                                      d_out_count);
-  SS_HIP(hipGetLastError());
-  return SS_OK;
+  return topk_merge_any(device, nq, S, k, d_doc, d_score, d_count, stride_ds, stride_c, out_len, d_out_doc, d_out_score, d_out_count, st);
 }
 
 // the WHOLE concatenation, sorted: [n_queries][n_shards * k] -- what the RRF ranks of a hybrid search over several shards run
@@ -139,7 +182,7 @@ extern "C" int ss_topk_concat_dev_packed(int device, uint32_t n_queries, uint32_
 // shard searches and its answer.  score(d) = sum over the lists holding d of 1 / (0.6 + rank), rank 0-based in the list;
 // a doc of both lists is `Hybrid`, of one list keeps that list's source.  Equal fused scores: doc id ascending (the
 // reference leaves them in hash order), as ss_merge_results does.  One workgroup per query; the union of the two lists
-// (<= 4096 entries) lives in LDS: match the vector entries against the lexical ones, bitonic sort by (score desc, doc asc).
+// (<= 8192 entries) lives in LDS: match the vector entries against the lexical ones, bitonic sort by (score desc, doc asc).
 // Both lists must be sorted by score descending with unique doc ids -- what the searches and merges above produce.
 __global__ void __launch_bounds__(256) rrf_merge_kernel(uint32_t k_lex, uint32_t k_vec, const void* __restrict__ lex_doc,
                                                        const uint32_t* __restrict__ lex_cnt, const void* __restrict__ vec_doc,
@@ -228,11 +271,13 @@ extern "C" int ss_rrf_merge_dev(int device, uint32_t n_queries, uint32_t k_lex, 
                                 uint32_t* d_out_count, void* stream) {
   if ((k_lex && (!d_lex_doc || !d_lex_count)) || (k_vec && (!d_vec_doc || !d_vec_count))) return SS_EINVAL;
   if (!d_out_doc || !d_out_score || !d_out_count || length == 0) return SS_EINVAL;
-  if ((uint64_t)k_lex + k_vec == 0 || (uint64_t)k_lex + k_vec > 4096) return SS_EINVAL;
+  if ((uint64_t)k_lex + k_vec == 0) return SS_EINVAL;
+  if ((uint64_t)k_lex + k_vec > 8192) return SS_ENOTSUP;  // (the union of the two lists lives in LDS: 13 bytes an entry)
   if (n_queries == 0) return SS_OK;
   SS_HIP(hipSetDevice(device));
   uint32_t np = 64;
   while (np < k_lex + k_vec) np <<= 1;
+  SS_SET_MAX_LDS(rrf_merge_kernel, 8192 * 13);
   rrf_merge_kernel<<<n_queries, 256, (size_t)np * 13u, (hipStream_t)stream>>>(
       k_lex, k_vec, k_lex ? d_lex_doc : nullptr, d_lex_count, k_vec ? d_vec_doc : nullptr, d_vec_count, doc_ids_are_u64 ? 1 : 0,
       offset, length, (u64*)d_out_doc, d_out_score, d_out_source, d_out_count, np);

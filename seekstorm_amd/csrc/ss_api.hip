@@ -2850,11 +2850,19 @@ static int bm25_search_deep(ss_shard* s, uint32_t nq, const ss_bm25_query* q, ui
 
 // vectors: groups of <= SS_VEC_BATCH queries, one exclusion bitmap PER QUERY of the group (vec_refine_kernel's del_stride); a pass is one
 // scan of the group at k = SS_MAX_K.  The exclusion is by DOC (a doc of several records is returned once, by its best record).
+static int vec_search_deep_locked(ss_shard* s, uint32_t nq, const void* queries, size_t elem, const float* query_scale, uint32_t k, float thr,
+                                  const ss_ann_mode* mode, uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total,
+                                  uint32_t* out_clusters, const float* query_norm);
 static int vec_search_host_deep(ss_shard* s, uint32_t nq, const void* queries, size_t elem, const float* query_scale, uint32_t k, float thr,
                                 const ss_ann_mode* mode, uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total,
                                 uint32_t* out_clusters, const float* query_norm) {
   if (nq == 0) return SS_OK;
   ShardLock g(s);
+  return vec_search_deep_locked(s, nq, queries, elem, query_scale, k, thr, mode, out_doc, out_score, out_count, out_total, out_clusters, query_norm);
+}
+static int vec_search_deep_locked(ss_shard* s, uint32_t nq, const void* queries, size_t elem, const float* query_scale, uint32_t k, float thr,
+                                  const ss_ann_mode* mode, uint32_t* out_doc, float* out_score, uint32_t* out_count, uint64_t* out_total,
+                                  uint32_t* out_clusters, const float* query_norm) {
   if (s->vstream) SS_HIP(hipStreamSynchronize(s->vstream));
   SS_HIP(hipSetDevice(s->device));
   // the largest doc id a row can stand for
@@ -2944,17 +2952,27 @@ int ss_bm25_search_sharded(ss_shard* s, ss_comm* c, uint32_t nq, const ss_bm25_q
   if (!s || !c || !q || !out_total) return SS_EINVAL;
   if (rt > SS_RT_TOPKCOUNT) return SS_EINVAL;
   if (rt != SS_RT_COUNT && (k == 0 || !out_doc || !out_score || !out_count)) return SS_EINVAL;
-  if (rt != SS_RT_COUNT && k > SS_MAX_K) return SS_ENOTSUP;
   int dev = -1, n_ranks = 0;
   SS_TRY(ss_comm_info(c, nullptr, &n_ranks, &dev));
   const uint32_t kk = rt == SS_RT_COUNT ? 0 : k;
-  if ((uint64_t)n_ranks * kk > 8192) return SS_EINVAL;  // the same on every rank: nobody enters the collective
+  if ((uint64_t)n_ranks * kk > 0xFFFFFFFFull) return SS_EINVAL;  // the same on every rank: nobody enters the collective
   if (nq == 0) return SS_OK;
   // From here on a failure is a matter of THIS shard (image missing, a query its lists cannot serve, an allocation): the rank
   // still enters the exchange, empty-handed, and every rank returns an error (ssi_comm_exchange) instead of blocking in it.
   ShardLock g(s);
   int rc = dev != s->device ? SS_EINVAL : !s->d_post ? SS_ESTATE : SS_OK;
-  if (rc == SS_OK) rc = bm25_search_host_queries(s, nq, q, kk, rt, 0, nullptr);
+  if (rc == SS_OK && kk > SS_MAX_K) {  // a deep page: this shard's (0, k) list in passes ("deep pages" above), then the exchange as ever
+    std::vector<uint32_t> h_doc((size_t)nq * kk), h_cnt(nq);
+    std::vector<float> h_score((size_t)nq * kk);
+    std::vector<uint64_t> h_tot(nq);
+    rc = bm25_search_deep_locked(s, nq, q, kk, rt, h_doc.data(), h_score.data(), h_cnt.data(), h_tot.data());
+    if (rc == SS_OK) rc = ensure_out(s, nq, kk);
+    if (rc == SS_OK && (hipMemcpy(s->d_out_doc, h_doc.data(), h_doc.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                        hipMemcpy(s->d_out_score, h_score.data(), h_score.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                        hipMemcpy(s->d_out_count, h_cnt.data(), (size_t)nq * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                        hipMemcpy(s->d_out_total, h_tot.data(), (size_t)nq * 8, hipMemcpyHostToDevice) != hipSuccess))
+      rc = SS_EDEVICE;
+  } else if (rc == SS_OK) rc = bm25_search_host_queries(s, nq, q, kk, rt, 0, nullptr);
   const ss_dev_list L{s->d_out_doc, s->d_out_score, s->d_out_count, kk};
   return ssi_comm_exchange(c, nq, kk ? 1 : 0, &L, s->d_out_total, nullptr, rc, false, 0, 0, out_doc, out_score, nullptr, out_count, out_total,
                            s->stream);
@@ -2966,15 +2984,25 @@ int ss_vec_search_sharded(ss_shard* s, ss_comm* c, uint32_t nq, const float* que
                           float* out_score, uint32_t* out_count, uint64_t* out_total) {
   if (!s || !c || !queries || !out_doc || !out_score || !out_count || !out_total) return SS_EINVAL;
   if (k == 0) return SS_EINVAL;  // (any number of queries: the scan takes them SS_VEC_BATCH per pass, one all-gather for all of them)
-  if (k > SS_MAX_K) return SS_ENOTSUP;
   int dev = -1, n_ranks = 0;
   SS_TRY(ss_comm_info(c, nullptr, &n_ranks, &dev));
-  if ((uint64_t)n_ranks * k > 8192) return SS_EINVAL;
+  if ((uint64_t)n_ranks * k > 0xFFFFFFFFull) return SS_EINVAL;
   if (nq == 0) return SS_OK;
   ShardLock g(s);
   int rc = dev != s->device ? SS_EINVAL : !s->d_X ? SS_ESTATE : SS_OK;
   std::vector<uint32_t> h_count(nq);
-  if (rc == SS_OK) rc = vec_search_host_lists(s, nq, queries, sizeof(float), nullptr, k, thr, nullptr, h_count.data(), nullptr);
+  if (rc == SS_OK && k > SS_MAX_K) {  // a deep page: this shard's list in passes, then the exchange as ever
+    std::vector<uint32_t> h_doc((size_t)nq * k);
+    std::vector<float> h_score((size_t)nq * k);
+    std::vector<uint64_t> h_tot(nq);
+    rc = vec_search_deep_locked(s, nq, queries, sizeof(float), nullptr, k, thr, nullptr, h_doc.data(), h_score.data(), h_count.data(), h_tot.data(), nullptr, nullptr);
+    if (rc == SS_OK) rc = ensure_out(s, nq, k);
+    if (rc == SS_OK && (hipMemcpy(s->d_out_doc, h_doc.data(), h_doc.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                        hipMemcpy(s->d_out_score, h_score.data(), h_score.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                        hipMemcpy(s->d_out_count, h_count.data(), (size_t)nq * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                        hipMemcpy(s->d_out_total, h_tot.data(), (size_t)nq * 8, hipMemcpyHostToDevice) != hipSuccess))
+      rc = SS_EDEVICE;
+  } else if (rc == SS_OK) rc = vec_search_host_lists(s, nq, queries, sizeof(float), nullptr, k, thr, nullptr, h_count.data(), nullptr);
   const ss_dev_list L{s->d_out_doc, s->d_out_score, s->d_out_count, k};
   return ssi_comm_exchange(c, nq, 1, &L, s->d_out_total, nullptr, rc, false, 0, 0, out_doc, out_score, nullptr, out_count, out_total, s->stream);
 }
@@ -2991,7 +3019,9 @@ int ss_hybrid_search_sharded(ss_shard* s, ss_comm* c, uint32_t nq, const ss_bm25
   if (k > SS_MAX_K) return SS_ENOTSUP;
   int dev = -1, n_ranks = 0;
   SS_TRY(ss_comm_info(c, nullptr, &n_ranks, &dev));
-  if ((uint64_t)n_ranks * k * 2 > 4096) return SS_EINVAL;  // both concatenations live in the fusion kernel's LDS
+  // both concatenations live in the fusion kernel's LDS (8192 entries): a valid request beyond that is the host's own merge (SS_ENOTSUP --
+  // the same on every rank, nobody enters the collective)
+  if ((uint64_t)n_ranks * k * 2 > 8192) return SS_ENOTSUP;
   if (nq == 0) return SS_OK;
   ShardLock g(s);
   int rc = dev != s->device ? SS_EINVAL : (!s->d_post || !s->d_X) ? SS_ESTATE : SS_OK;

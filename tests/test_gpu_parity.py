@@ -507,15 +507,20 @@ def test_index_two_shards_hybrid_matches_oracle(S, O):
         sh.close()
 
 
-def test_device_merge_matches_host_merge(S, O):
-    """ss_topk_merge_dev (used after the RCCL all-gather) == ss_merge_results on the same gathered lists"""
+@pytest.mark.parametrize("Sn,nq,k,ties", [(4, 9, 100, False), (16, 5, 1024, True), (3, 4, 5000, True), (9, 3, 1000, False)])
+def test_device_merge_matches_host_merge(S, O, Sn, nq, k, ties):
+    """ss_topk_merge_dev (used after the RCCL all-gather) == ss_merge_results on the same gathered lists -- the LDS sort up to 8192 keys
+    per query, beyond that (more than 8 shards at k = 1024, a deep page) the rank merge: every entry finds its slot by binary searches in
+    the other shards' lists; equal scores in concatenation order either way"""
     import ctypes as C
     import torch
     from seekstorm_amd import distributed as D
     rng = np.random.default_rng(5)
-    Sn, nq, k = 4, 9, 100
     doc = np.stack([np.stack([rng.choice(100000, k, replace=False) for _ in range(nq)]) for _ in range(Sn)]).astype(np.int32)
-    score = np.sort(rng.standard_normal((Sn, nq, k)).astype(np.float32), axis=2)[:, :, ::-1].copy()  # negative scores too
+    score = rng.standard_normal((Sn, nq, k)).astype(np.float32)
+    if ties:
+        score = np.round(score * 8) / 8  # many equal scores, inside a list and across the lists
+    score = np.sort(score, axis=2)[:, :, ::-1].copy()  # negative scores too
     cnt = rng.integers(0, k + 1, (Sn, nq)).astype(np.int32)
     dev = torch.device("cuda", 0)
     st = torch.cuda.Stream(device=dev)

@@ -122,6 +122,14 @@ def test_search_sharded_single_rank_equals_plain_search(S, O, lex):
                 assert np.array_equal(ms[i, :cnt[i]], score[i, :cnt[i]])
         _, _, _, ct = comm.search_lexical_sharded(sh, qq, 0, result_type=int(S.ResultType.Count))
         assert np.array_equal(ct, tot)
+    # a deep page (k > SS_MAX_K): the shard's list in passes, the exchange and the merge at that k (tests/test_gpu_deep_pages.py)
+    for kd in (1500, 9000):  # (one rank x 9000 > 8192: the rank merge)
+        doc, score, cnt, tot = sh.search_lexical_batch(q, kd, reference_shortcuts=False)
+        md, ms, mc, mt = comm.search_lexical_sharded(sh, q, kd)
+        assert np.array_equal(mc, cnt) and np.array_equal(mt, tot) and int(cnt.max()) > 1024
+        for i in range(len(q)):
+            assert np.array_equal(md[i, :cnt[i]], doc[i, :cnt[i]].astype(np.uint64)) and np.array_equal(ms[i, :cnt[i]], score[i, :cnt[i]])
+            assert np.all(md[i, cnt[i]:] == np.uint64(0xFFFFFFFFFFFFFFFF))
     comm.close()
 
 
@@ -141,6 +149,12 @@ def test_vector_and_hybrid_sharded_single_rank(S, O, both):
         assert np.array_equal(mc, cnt) and np.array_equal(mt, tot)
         for i in range(nq):
             assert np.array_equal(md[i, :cnt[i]], doc[i, :cnt[i]].astype(np.uint64)) and np.array_equal(ms[i, :cnt[i]], score[i, :cnt[i]])
+    kd = 2500  # a deep vector page through the exchange
+    doc_d, score_d, cnt_d, tot_d = sh.search_vector_batch(qs, kd)
+    md, ms, mc, mt = comm.search_vector_sharded(sh, qs, kd)
+    assert np.array_equal(mc, cnt_d) and np.array_equal(mt, tot_d) and int(cnt_d.min()) > 1024
+    for i in range(nq):
+        assert np.array_equal(md[i, :cnt_d[i]], doc_d[i, :cnt_d[i]].astype(np.uint64)) and np.array_equal(ms[i, :cnt_d[i]], score_d[i, :cnt_d[i]])
     tl = [[3, 7, 9], [5, 2], [4], [1, 8, 6], [0, 9]]
     q = sh.make_queries(tl, S.QueryType.Union)
     ix = S.Index([sh])
@@ -157,7 +171,7 @@ def test_vector_and_hybrid_sharded_single_rank(S, O, both):
             assert hsrc[i, :hc[i]].tolist() == [int(r.source) for r in ro.results]
             assert int(ht[i]) == max(int(lt[i]), int(vt[i])) == ro.result_count_total
     n, us = comm.profile_read()
-    assert n == 2 + 2 and 0.0 < us < 5e4  # one all-gather per sharded call
+    assert n == 2 + 1 + 2 and 0.0 < us < 5e4  # one all-gather per sharded call
     # more queries than one pass over the matrix takes (SS_VEC_BATCH = 64): several passes, still ONE all-gather per call
     nq2 = 150
     qs2 = O.vec_gen(O.VECQ_SEED, 100, nq2, dim)
