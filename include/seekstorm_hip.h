@@ -54,8 +54,8 @@ extern "C" {
  * any k -- the crate's offset + length is unbounded (search.rs:1658-1659) -- and answer k > SS_MAX_K in passes of SS_MAX_K, every pass
  * the ordinary search under (tombstones or the facet filter's bitmap) | (the docs of the earlier passes); totals are the first pass's.
  * ss_bm25_search_sharded / ss_vec_search_sharded do the same before their exchange.  The entries that keep their answers on the device
- * (ss_*_dev), fuse two lists on it (ss_hybrid_search_sharded) or sort by a facet (ss_bm25_search_sorted with sort fields) return
- * SS_ENOTSUP beyond it. */
+ * (ss_*_dev) or fuse two lists on it (ss_hybrid_search_sharded) return SS_ENOTSUP beyond it; ss_bm25_search_sorted peels a deep page
+ * the same way (its order -- the sort fields, then score descending, then doc ascending -- is total as well). */
 #define SS_MAX_K 1024
 #define SS_VEC_BATCH 64 /* queries scanned per pass over the matrix */
 

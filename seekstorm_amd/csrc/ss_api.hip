@@ -3159,20 +3159,10 @@ int ss_bm25_facet_kth_point(ss_shard* s, const ss_bm25_query* query, uint32_t n_
 // classification -> the exclusion bitmaps -> TWO batched searches, each query inside its own doc set (the pruned kernel's filtered
 // instances take one bitmap per query) -> compose into the queries' output rows.  One synchronisation per call.  A chunk the pruned
 // kernel does not serve (k > 128, more than 4 lists per query, the exhaustive strategy) runs its searches query by query instead.
-int ss_bm25_search_sorted(ss_shard* s, uint32_t nq, const ss_bm25_query* queries, uint32_t n_sorts, const ss_result_sort* sorts, uint32_t k,
-                          uint32_t n_filters, const ss_facet_filter* filters, uint32_t* out_doc, float* out_score, uint32_t* out_count,
-                          uint64_t* out_total) {
-  if (!s || !queries || nq == 0 || !out_doc || !out_score || !out_count || !out_total || k == 0) return SS_EINVAL;
-  if (n_sorts == 0) return ss_bm25_search_filtered(s, nq, queries, k, SS_RT_TOPKCOUNT, n_filters, filters, out_doc, out_score, out_count, out_total);
-  if (k > SS_MAX_K) return SS_ENOTSUP;  // (a page that deep SORTED BY A FACET: the host's own dispatch -- the select keeps k per query in LDS)
-  if (!sorts) return SS_EINVAL;
-  if (n_sorts > SS_MAX_SORT_FIELDS) return SS_ENOTSUP;
+static int bm25_search_sorted_locked(ss_shard* s, uint32_t nq, const ss_bm25_query* queries, uint32_t n_sorts, const ss_result_sort* sorts, uint32_t k,
+                                     uint32_t n_filters, const ss_facet_filter* filters, uint32_t* out_doc, float* out_score, uint32_t* out_count,
+                                     uint64_t* out_total) {
   static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 2, 4, 8};
-  for (uint32_t f = 0; f < n_sorts; f++) {
-    if (sorts[f].facet_type > SS_FACET_POINT) return SS_EINVAL;
-    if (sorts[f].facet_type == SS_FACET_STRING16 || sorts[f].facet_type == SS_FACET_STRING32) return SS_ENOTSUP;  // by their strings: the host's rank column
-  }
-  ShardLock g(s);  // (before the image is looked at: a commit swaps its arrays under this lock)
   if (!s->d_post) return SS_ESTATE;
   SS_HIP(hipSetDevice(s->device));
   if (!s->d_facets || s->facet_docs < s->bm_n_docs) return SS_ESTATE;
@@ -3248,6 +3238,62 @@ int ss_bm25_search_sorted(ss_shard* s, uint32_t nq, const ss_bm25_query* queries
   SS_HIP(hipMemcpyAsync(out_count, W + o_oc, (size_t)nq * 4, hipMemcpyDeviceToHost, s->stream));
   SS_HIP(hipMemcpyAsync(out_total, W + o_ot, (size_t)nq * 8, hipMemcpyDeviceToHost, s->stream));
   SS_HIP(hipStreamSynchronize(s->stream));
+  return SS_OK;
+}
+
+int ss_bm25_search_sorted(ss_shard* s, uint32_t nq, const ss_bm25_query* queries, uint32_t n_sorts, const ss_result_sort* sorts, uint32_t k,
+                          uint32_t n_filters, const ss_facet_filter* filters, uint32_t* out_doc, float* out_score, uint32_t* out_count,
+                          uint64_t* out_total) {
+  if (!s || !queries || nq == 0 || !out_doc || !out_score || !out_count || !out_total || k == 0) return SS_EINVAL;
+  if (n_sorts == 0) return ss_bm25_search_filtered(s, nq, queries, k, SS_RT_TOPKCOUNT, n_filters, filters, out_doc, out_score, out_count, out_total);
+  if (!sorts) return SS_EINVAL;
+  if (n_sorts > SS_MAX_SORT_FIELDS) return SS_ENOTSUP;
+  static const uint32_t width[] = {1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 2, 4, 8};
+  for (uint32_t f = 0; f < n_sorts; f++) {
+    if (sorts[f].facet_type > SS_FACET_POINT) return SS_EINVAL;
+    if (sorts[f].facet_type == SS_FACET_STRING16 || sorts[f].facet_type == SS_FACET_STRING32) return SS_ENOTSUP;  // by their strings: the host's rank column
+  }
+  ShardLock g(s);  // (before the image is looked at: a commit swaps its arrays under this lock)
+  if (k <= SS_MAX_K) return bm25_search_sorted_locked(s, nq, queries, n_sorts, sorts, k, n_filters, filters, out_doc, out_score, out_count, out_total);
+  // a DEEP page sorted by facets: the order is total (field 1, ..., field n, score desc, doc asc), so it is peeled like any other ("deep
+  // pages" above) -- query by query, every pass the sorted search of SS_MAX_K results under (tombstones | the docs of the earlier passes);
+  // a facet filter's bitmap is built on top of that inside the pass
+  if (!s->d_post) return SS_ESTATE;
+  SS_HIP(hipSetDevice(s->device));
+  const uint32_t base_words = s->n_deleted ? (uint32_t)s->deleted_words : 0u;
+  const uint32_t words = std::max<uint32_t>((uint32_t)(((uint64_t)s->bm_n_docs + 31) / 32), base_words);
+  SS_TRY(peel_ensure(s, words));
+  const uint32_t* base = s->n_deleted ? s->d_deleted : nullptr;
+  std::vector<uint32_t> h_doc(SS_MAX_K);
+  std::vector<float> h_score(SS_MAX_K);
+  for (uint32_t i = 0; i < nq; i++) {
+    uint32_t got = 0;
+    uint64_t total = 0;
+    peel_init_kernel<<<std::min<uint32_t>(1024u, (words + 255u) / 256u), 256, 0, s->stream>>>(s->d_peel_bits, words, 1, base, base_words);
+    SS_HIP(hipGetLastError());
+    PeelSwap sw(s, s->d_peel_bits, words, 0);
+    for (uint32_t pass = 0; got < k; pass++) {
+      const uint32_t kk = std::min<uint32_t>(SS_MAX_K, k - got);
+      uint32_t c = 0;
+      uint64_t t = 0;
+      SS_TRY(bm25_search_sorted_locked(s, 1, queries + i, n_sorts, sorts, kk, n_filters, filters, h_doc.data(), h_score.data(), &c, &t));
+      if (pass == 0) total = t;
+      c = std::min(c, kk);
+      memcpy(out_doc + (size_t)i * k + got, h_doc.data(), (size_t)c * sizeof(uint32_t));
+      memcpy(out_score + (size_t)i * k + got, h_score.data(), (size_t)c * sizeof(float));
+      got += c;
+      if (c < kk || got >= k) break;
+      SS_TRY(ensure_qstage(s, (size_t)SS_MAX_K * 4 + 16));  // the pass's docs back to the device for the mark
+      SS_HIP(hipMemcpyAsync(s->d_qstage, h_doc.data(), (size_t)c * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+      SS_HIP(hipMemcpyAsync((char*)s->d_qstage + (size_t)SS_MAX_K * 4, &c, sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+      peel_mark_kernel<<<dim3(4, 1), 256, 0, s->stream>>>((const uint32_t*)s->d_qstage, (const uint32_t*)((char*)s->d_qstage + (size_t)SS_MAX_K * 4), kk, s->d_peel_bits, words);
+      SS_HIP(hipGetLastError());
+      SS_HIP(hipStreamSynchronize(s->stream));  // (h_doc and c are read by the copies)
+    }
+    for (uint32_t r = got; r < k; r++) { out_doc[(size_t)i * k + r] = SS_NO_DOC; out_score[(size_t)i * k + r] = 0.f; }
+    out_count[i] = got;
+    out_total[i] = total;
+  }
   return SS_OK;
 }
 

@@ -220,3 +220,43 @@ def test_vector_deep_pages_i8(S, O):
         assert {int(x) for x, y in zip(doc[i][:k], score[i]) if y > kth} == {int(x) for x, y in zip(od, os_) if y > kth}
         _rows_well_formed(doc[i], score[i], cnt[i], k)
     sh.close()
+
+
+def test_sorted_deep_pages(S, O):
+    """result_sort (min_heap.rs:574-1050) beyond SS_MAX_K results: the order (field 1, field 2, score desc, doc asc) is total, so a deep
+    page sorted by facets is peeled like any other; with a facet filter and tombstones on top"""
+    sh, osh, n_docs, n_terms = _single_field_world(S, O, False)
+    rng = np.random.default_rng(8)
+    rec = np.dtype([("a", "u1"), ("b", "<i2")])
+    v = np.zeros(n_docs, rec)
+    v["a"] = rng.integers(0, 12, n_docs)       # a dozen values: long tie groups, broken by the second field, then by the score
+    v["b"] = rng.integers(-400, 400, n_docs)
+    sh.upload_facets(v.view(np.uint8).reshape(n_docs, 3))
+    gone = list(range(3, n_docs, 97))
+    sh.set_deleted(gone)
+    osh.set_deleted(gone)
+    cases = [([0, 20], O.OP_OR, S.QueryType.Union), ([1, 2], O.OP_AND, S.QueryType.Intersection), ([25], O.OP_OR, S.QueryType.Union)]
+    for terms, oop, qt in cases:
+        q = sh.make_queries([terms], qt)
+        md, ms, mtot = osh.search_exhaustive(terms, oop, n_docs, [])  # every match with its score
+        for spec, flt in (([(0, "u8", False), (1, "i16", True)], None), ([(1, "i16", False)], [(0, "u8", 2, 9)])):
+            keep = np.ones(len(md), bool) if flt is None else (v["a"][md] >= 2) & (v["a"][md] < 9)
+            d_, s_ = md[keep], ms[keep]
+            keys = [d_.astype(np.int64), -s_.astype(np.float64)]  # lexsort: last key first
+            for off_, ty, desc in reversed(spec):
+                col = v["a" if off_ == 0 else "b"][d_].astype(np.int64)
+                keys.append(-col if desc else col)
+            order = np.lexsort(keys)
+            for k in (1030, 2600):
+                doc, score, tot = sh.search_lexical_sorted(q, spec, k, facet_filter=flt)
+                n = min(k, len(d_))
+                assert tot == len(d_) and len(doc) == n, (terms, spec, k, tot, len(d_), len(doc))
+                assert len(set(doc.tolist())) == n
+                want_d, want_s = d_[order][:n], s_[order][:n]
+                # the sort fields agree position by position; docs may swap only where sort fields AND scores (within tolerance) tie
+                for off_, ty, desc in spec:
+                    name = "a" if off_ == 0 else "b"
+                    assert np.array_equal(v[name][doc], v[name][want_d]), (terms, spec, k, name)
+                assert np.allclose(score, want_s, rtol=REL, atol=1e-7)
+                assert (doc == want_d).mean() > 0.98
+    sh.close()

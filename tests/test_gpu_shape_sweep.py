@@ -18,8 +18,8 @@ pytestmark = pytest.mark.gpu
 
 # the CPU fall-through list: (what, where the reference answers it) -- mirrored by INTEGRATION.md section 4
 CPU_FALL_THROUGH = {
-    "k_gt_1024_sorted_or_device": "offset + length beyond SS_MAX_K = 1024 results on the entries that keep their answers on the device, fuse two lists on it or "
-                                  "sort by a facet (ss_*_dev, ss_hybrid_search_sharded, ss_bm25_search_sorted with sort fields); the host-pointer entries and "
+    "k_gt_1024_sorted_or_device": "offset + length beyond SS_MAX_K = 1024 results on the entries that keep their answers on the device or fuse two lists on it "
+                                  "(ss_*_dev, ss_hybrid_search_sharded); the host-pointer entries (ss_bm25_search_sorted among them) and "
                                   "ss_bm25_search_sharded / ss_vec_search_sharded answer any k: tests/test_gpu_deep_pages.py, tests/test_gpu_sharded.py",
     "gt32_terms": "a query of more than 32 unique terms, NOT terms included (union.rs:233-259, 617-624: union_scan_32 over the 32 lists with the largest block maxima + union_count); refused by the mirrors' make_query, tests/test_gpu_union_many.py",
     "union_filter_gt10": "a UNION of more than 10 terms under a field filter, several indexed fields (union.rs:265-595 union_scan + add_result.rs:3124-3136)",
