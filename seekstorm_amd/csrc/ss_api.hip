@@ -275,7 +275,7 @@ int ss_shard_destroy(ss_shard* s) {
   free_vec(s);
   free_bm25(s);
   for (void* p_ : {(void*)s->d_vq, (void*)s->d_vdoc, (void*)s->d_vscore, (void*)s->d_vcount, (void*)s->d_vtotal}) if (p_) (void)hipFree(p_);
-  void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_deleted, s->d_facets, s->d_filter_bits, s->d_facet_ws, s->d_pool_stage, s->d_tier_ws, s->d_tier_hold, s->d_excl_bits, s->d_sort_ws, s->d_route_ws, s->d_peel_bits};
+  void* ptrs[] = {s->d_qstage, s->d_out_doc, s->d_out_score, s->d_out_count, s->d_out_total, s->d_bq, s->d_deleted, s->d_facets, s->d_filter_bits, s->d_facet_ws, s->d_pool_stage, s->d_tier_ws, s->d_tier_hold, s->d_excl_bits, s->d_sort_ws, s->d_route_ws, s->d_peel_bits, s->d_gate_ws};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   (void)hipDeviceSynchronize();  // searches queued on the callers' own streams may still use their workspaces
   for (auto& kv : s->bm_ws) {
@@ -1677,6 +1677,97 @@ static int bm25_search_tiered_excl(ss_shard* s, uint32_t nq, const ss_bm25_query
 // union.rs:552-553).  Rare (a rare word in a multi-word query under a field filter, or 8+ words under one); <= 10 terms -- the range
 // of union_docid_3 (search.rs:3497-3520) -- i.e. <= 1023 sub-queries in one batch (the sub-queries the specialised kernels do not take
 // run on bm25_gallop.hip); the merge is the host's.
+// A UNION of MORE than 10 terms under a field filter.  The reference leaves union_docid_3's range here (search.rs:3497-3520) and runs
+// union_blockid -> union_scan_32 (union.rs:598-805), whose candidates meet the filter inside add_result_multiterm_multifield
+// (add_result.rs:3124-3136) -- ANOTHER rule than the sub-queries' above: the loop over the doc's PRESENT terms returns at the first one
+// that stands in no listed field, so a doc is an answer iff EVERY term it holds passes the filter, and then scores with all of them (all
+// fields of each, as ever); union_scan has counted it before the filter saw it (union.rs:760-761), so result_count_total is the
+// UNFILTERED union's.  With  R = U_t { docs of t that hold t in unlisted fields only }  that is: the plain union of the merged lists under
+// the exclusion bitmap  tombstones | R.  R comes from the probe index's bit records: the match sets M_t (term t, no filter) and P_t (term
+// t under the filter) of the 2 n single-term queries in ONE ssi_bm25_match_bits call, R |= M_t & ~P_t.  Then the ordinary many-list
+// union runs under that bitmap (every kernel family honours it), its count under the tombstones alone.  Dense terms with probe rows.
+__global__ void gate_rule_bits_kernel(const unsigned long long* __restrict__ sets /*[2 n][groups]: M_0, P_0, M_1, P_1, ...*/, uint32_t n, size_t groups,
+                                      const uint32_t* __restrict__ base, uint32_t base_words, uint32_t* __restrict__ out, uint32_t words) {
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g * 2 < words; g += (size_t)gridDim.x * blockDim.x) {
+    unsigned long long r = 0ull;
+    if (g < groups)
+      for (uint32_t t = 0; t < n; t++) r |= sets[(size_t)(2 * t) * groups + g] & ~sets[(size_t)(2 * t + 1) * groups + g];
+    const size_t w0 = g * 2, w1 = g * 2 + 1;
+    out[w0] = (uint32_t)r | ((base && w0 < base_words) ? base[w0] : 0u);
+    if (w1 < words) out[w1] = (uint32_t)(r >> 32) | ((base && w1 < base_words) ? base[w1] : 0u);
+  }
+}
+static int bm25_search_gated_scan_rule(ss_shard* s, const ss_bm25_query& Q, uint32_t kk, uint32_t rt, uint32_t* a_doc, float* a_score, uint32_t* a_cnt,
+                                       unsigned long long* a_tot) {
+  const uint32_t n = Q.n_terms, nn = bm_q_nnot(Q.op), n_dense = s->bm_n_terms / s->bm_n_fields, kw = std::max<uint32_t>(kk, 1);
+  for (uint32_t t = 0; t < n + nn; t++)
+    if (Q.term[t] >= n_dense) return SS_ENOTSUP;  // (a sparse-tier term: its postings carry their fields elsewhere)
+  if (!s->bm_merged || !s->d_probe || 2 * n > 64) return SS_ENOTSUP;
+  SS_HIP(hipSetDevice(s->device));
+  std::vector<ss_bm25_query> subs(2 * (size_t)n);
+  for (uint32_t t = 0; t < n; t++)
+    for (int f = 0; f < 2; f++) {
+      ss_bm25_query& S = subs[2 * (size_t)t + f];
+      memset(&S, 0, sizeof(S));
+      S.n_terms = 1; S.term[0] = Q.term[t]; S.idf[0] = Q.idf[t];
+      S.op = SS_OP_INTERSECTION | (f ? SS_OP_FIELD_FILTER(bm_q_field_filter(Q.op)) : 0u);
+    }
+  {
+    bool has_and, has_or, all_probed, any_frequent, phrase = false, any_filter = false, uniform = false, gated = false;
+    uint32_t nt_max, np_max, nn_max = 0;
+    SS_TRY(ssi_bm25_ensure_probe_rows(s, 2 * n, subs.data(), s->stream));
+    SS_TRY(check_queries(s, 2 * n, subs.data(), &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent, &phrase, &any_filter, &uniform, &gated, &nn_max));
+    if (!all_probed) return SS_ENOTSUP;  // (a rationed vocabulary: the match sets are read from the bit records)
+  }
+  const size_t groups = (size_t)s->bm_n_sub * (BM_SUB / 64), words = ((size_t)s->bm_n_docs + 31) / 32;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t o_q = 0, o_tot = o_q + al(64 * sizeof(ss_bm25_query)), o_sets = o_tot + al(64 * 8), need = o_sets + al(2 * (size_t)n * groups * 8);
+  if (need > s->gate_ws_cap || words > s->excl_words_cap) SS_HIP(hipStreamSynchronize(s->stream));
+  if (need > s->gate_ws_cap) {
+    if (s->d_gate_ws) (void)hipFree(s->d_gate_ws);
+    s->d_gate_ws = nullptr; s->gate_ws_cap = 0;
+    SS_HIP(hipMalloc(&s->d_gate_ws, need));
+    s->gate_ws_cap = need;
+  }
+  if (words > s->excl_words_cap) {
+    if (s->d_excl_bits) (void)hipFree(s->d_excl_bits);
+    s->d_excl_bits = nullptr; s->excl_words_cap = 0;
+    SS_HIP(hipMalloc(&s->d_excl_bits, words * 4));
+    s->excl_words_cap = words;
+  }
+  char* W = (char*)s->d_gate_ws;
+  SS_HIP(hipMemcpy(W + o_q, subs.data(), subs.size() * sizeof(ss_bm25_query), hipMemcpyHostToDevice));  // (synchronous: `subs` is a local)
+  SS_TRY(ssi_bm25_match_bits(s, (const ss_bm25_query*)(W + o_q), (unsigned long long*)(W + o_sets), (unsigned long long*)(W + o_tot), s->stream, 2 * n));
+  const bool had = s->n_deleted != 0;
+  gate_rule_bits_kernel<<<(uint32_t)std::min<size_t>(2048, (words / 2 + 256) / 256), 256, 0, s->stream>>>(
+      (const unsigned long long*)(W + o_sets), n, groups, had ? s->d_deleted : nullptr, had ? (uint32_t)s->deleted_words : 0u, s->d_excl_bits, (uint32_t)words);
+  SS_HIP(hipGetLastError());
+  ss_bm25_query U = Q;  // the plain union: the filter is in the bitmap now
+  U.op = SS_OP_UNION | SS_OP_NOT_TERMS(nn);
+  *a_cnt = 0; *a_tot = 0;
+  if (kk && rt != SS_RT_COUNT) {
+    {
+      uint32_t* del = s->d_deleted;
+      const uint64_t dw = s->deleted_words, nd = s->n_deleted;
+      s->d_deleted = s->d_excl_bits; s->deleted_words = words; s->n_deleted = 1;
+      const int rc = bm25_search_host_queries(s, 1, &U, kk, SS_RT_TOPK, 0, nullptr);
+      s->d_deleted = del; s->deleted_words = dw; s->n_deleted = nd;
+      if (rc != SS_OK) return rc;
+    }
+    SS_HIP(hipStreamSynchronize(s->stream));
+    SS_HIP(hipMemcpy(a_doc, s->d_out_doc, (size_t)kw * 4, hipMemcpyDeviceToHost));
+    SS_HIP(hipMemcpy(a_score, s->d_out_score, (size_t)kw * 4, hipMemcpyDeviceToHost));
+    SS_HIP(hipMemcpy(a_cnt, s->d_out_count, 4, hipMemcpyDeviceToHost));
+    *a_tot = *a_cnt;
+  }
+  if (rt != SS_RT_TOPK) {
+    SS_TRY(bm25_search_host_queries(s, 1, &U, 0, SS_RT_COUNT, 0, nullptr));
+    SS_HIP(hipStreamSynchronize(s->stream));
+    SS_HIP(hipMemcpy(a_tot, s->d_out_total, 8, hipMemcpyDeviceToHost));
+  }
+  return SS_OK;
+}
+
 static int bm25_search_compose(ss_shard* s, uint32_t nq, const ss_bm25_query* q, uint32_t kk, uint32_t rt, const std::vector<uint32_t>& composed) {
   const uint32_t kw = std::max<uint32_t>(kk, 1), n_co = (uint32_t)composed.size();
   std::vector<uint32_t> a_doc((size_t)n_co * kw, SS_NO_DOC), a_cnt(n_co, 0);
@@ -1688,6 +1779,14 @@ static int bm25_search_compose(ss_shard* s, uint32_t nq, const ss_bm25_query* q,
     const ss_bm25_query& Q = q[composed[j]];
     const uint32_t n = Q.n_terms, nn = bm_q_nnot(Q.op);
     const uint32_t op_sub = SS_OP_INTERSECTION | SS_OP_NOT_TERMS(nn) | SS_OP_FIELD_FILTER(bm_q_field_filter(Q.op));
+    if (n > 10) {  // the reference's other rule (union_scan + the per-doc filter): above
+      SS_TRY(bm25_search_gated_scan_rule(s, Q, kk, rt, a_doc.data() + (size_t)j * kw, a_score.data() + (size_t)j * kw, &a_cnt[j], &a_tot[j]));
+      rest[composed[j]] = Q;  // keeps the row's place in the batch below; its answer is overwritten
+      rest[composed[j]].n_terms = 1;
+      for (uint32_t t = 1; t < (uint32_t)SS_MAX_QUERY_TERMS; t++) { rest[composed[j]].term[t] = 0; rest[composed[j]].idf[t] = 0.f; }
+      rest[composed[j]].op = SS_OP_INTERSECTION | SS_OP_FIELD_FILTER(bm_q_field_filter(Q.op));
+      continue;
+    }
     std::vector<ss_bm25_query> subs;
     for (uint32_t m = 1; m < (1u << n); m++) {
       ss_bm25_query S;
@@ -1834,8 +1933,8 @@ static int bm25_shape_of(const ss_shard* s, const ss_bm25_query& Q, uint32_t kk,
     return SS_OK;
   }
   if (filt && op == SS_OP_UNION && np > 1) {  // a union under a field filter: the gated scan (<= 7 dense terms), else composed
-    if (np > 10) return SS_ENOTSUP;  // the reference: union_scan + a per-doc filter, another rule
-    if (any_sparse || np > 7) *shape = SH_COMPOSE;
+    if (np > 10 && (any_sparse || !s->bm_merged)) return SS_ENOTSUP;  // (the scan rule reads the dense tier's bit records and merged lists)
+    if (any_sparse || np > 7) *shape = SH_COMPOSE;  // 8 .. 10: the reference's sub-queries; more: its other rule (bm25_search_gated_scan_rule)
     return SS_OK;
   }
   // per-field lists: under a field filter, or on an image without merged lists

@@ -396,6 +396,8 @@ struct ss_shard {
   // (tombstones, a facet filter) | the docs the earlier passes returned; one row of peel_words words per query of a vector group
   uint32_t* d_peel_bits = nullptr;
   size_t peel_words_cap = 0;         // dwords allocated
+  void* d_gate_ws = nullptr;         // match sets of a gated union's single-term queries (ss_api.hip bm25_search_gated_scan_rule), grow-only
+  size_t gate_ws_cap = 0;
   uint32_t vec_del_stride = 0;       // != 0: d_deleted holds one bitmap of that many words per query of the vector batch in flight
   // threshold seeds from OUTSIDE a batch's own lists (bm25_search_tiered: the k-th FULL score the sparse kernel found for a union whose dense
   // terms this batch carries): [ext_seed_n] floats, row i for query i of the NEXT ssi_bm25_search call of exactly ext_seed_n queries

@@ -22,7 +22,8 @@ CPU_FALL_THROUGH = {
                                   "(ss_*_dev, ss_hybrid_search_sharded); the host-pointer entries (ss_bm25_search_sorted among them) and "
                                   "ss_bm25_search_sharded / ss_vec_search_sharded answer any k: tests/test_gpu_deep_pages.py, tests/test_gpu_sharded.py",
     "gt32_terms": "a query of more than 32 unique terms, NOT terms included (union.rs:233-259, 617-624: union_scan_32 over the 32 lists with the largest block maxima + union_count); refused by the mirrors' make_query, tests/test_gpu_union_many.py",
-    "union_filter_gt10": "a UNION of more than 10 terms under a field filter, several indexed fields (union.rs:265-595 union_scan + add_result.rs:3124-3136)",
+    "union_filter_gt10_sparse": "a UNION of more than 10 terms under a field filter that names a sparse-tier term (or on a rationed vocabulary / an image without "
+                                "merged lists): union.rs:598-805 union_scan_32 + add_result.rs:3124-3136; all-dense ones are answered by that rule behind the ABI",
     "nomerged_phrase": "a phrase on an image of several indexed fields whose boosts kept the merged lists from being built (add_result.rs:3248-3386)",
     "nomerged_frequent": "all_terms_frequent on such an image (add_result.rs:1595-1607)",
     "nomerged_union_lists": "a union of more than 32 (term, field) lists on such an image (union.rs:403-805)",
@@ -231,6 +232,26 @@ def _gated_union_oracle(per_term, terms, nots, filt, gone_set, k):
     return np.array([w[0] for w in want], np.uint32), np.array([w[1] for w in want], np.float32), total
 
 
+def _gated_scan_rule_oracle(per_term, terms, nots, filt, gone_set, k):
+    """the reference's rule for a union of MORE than 10 terms under a field filter (union_blockid -> union_scan_32, union.rs:598-805, whose
+    candidates meet the filter in add_result_multiterm_multifield, add_result.rs:3124-3136: the loop over the doc's present terms returns
+    at the first one that stands in no listed field): a doc answers iff EVERY term it holds passes, and scores with all of them;
+    union_scan counted it before the filter saw it -- the total is the unfiltered union's"""
+    present = {}
+    for t in terms:
+        ts, dd, ff = per_term[t]
+        pas = set(dd[np.isin(ff, list(filt))].tolist())
+        for d in set(dd.tolist()) - gone_set:
+            e = present.setdefault(d, [True, np.float32(0)])
+            e[0] = e[0] and d in pas
+            e[1] = np.float32(e[1] + np.float32(ts[d]))
+    banned = set()
+    for t in nots:
+        banned |= set(per_term[t][1].tolist())
+    want = sorted(((d, float(e[1])) for d, e in present.items() if e[0] and d not in banned), key=lambda x: (-x[1], x[0]))[:k]
+    return np.array([w[0] for w in want], np.uint32), np.array([w[1] for w in want], np.float32), len(set(present) - banned)
+
+
 @pytest.mark.parametrize("with_tier", [False, True])
 def test_sweep_three_indexed_fields(S, O, with_tier):
     n_docs, n_fields, boost = 30_000, 3, [2.0, 1.0, 0.5]
@@ -262,9 +283,11 @@ def test_sweep_three_indexed_fields(S, O, with_tier):
             for op in ("and", "or"):
                 for n in (1, 2, 3, 5, 7, 8, 9, 10, 11, 12, 16, 24, 32):
                     for nn in (0, 2):
-                        if n + nn > 32 or (op == "or" and filt and n > 10):
+                        if n + nn > 32:
                             continue
                         for tier in (("dense", "mixed") if with_tier else ("dense",)):
+                            if op == "or" and filt and n > 10 and tier == "mixed":
+                                continue  # (CPU fall-through: a sparse-tier term in a union of more than 10 terms under a filter; below)
                             pool = frequent + mid + (rare if tier == "mixed" else [])
                             if op == "and" and n > 3:
                                 terms = _pick(rng, min(n, 12), frequent)
@@ -285,7 +308,9 @@ def test_sweep_three_indexed_fields(S, O, with_tier):
                     doc, score, cnt, tot = _run(S, sh, q, k, rt, shortcuts=False)
                     for i, (terms, nots, op) in enumerate(cells):
                         what = ("3f", with_tier, terms, nots, op, filt, k, rt, bool(deleted))
-                        if op == "or" and filt and len(terms) > 1:
+                        if op == "or" and filt and len(terms) > 10:  # the reference's other rule: union_scan + the per-doc filter
+                            od, os_, otot = _gated_scan_rule_oracle(per_term, terms, nots, filt, gone_set, k)
+                        elif op == "or" and filt and len(terms) > 1:
                             od, os_, otot = _gated_union_oracle(per_term, terms, nots, filt, gone_set, k)
                         else:
                             od, os_, otot = ex(terms, O.OP_AND if op != "or" else O.OP_OR, k, nots, deleted, filt if (op != "or" or len(terms) == 1) else ())
@@ -302,13 +327,19 @@ def test_sweep_three_indexed_fields(S, O, with_tier):
                         od, os_, otot = O.search_fields_shortcut(n_docs, dl, boost, offs, docs, fields, tfs, terms, 10, deleted)
                         _check(doc[i], score[i], cnt[i], tot[i], od, os_, otot, rt, 10, S, ("3f frequent", with_tier, terms, rt, bool(deleted)))
                 assert sh.generic_batches() > before
-    # CPU fall-through: a union of more than 10 terms under a field filter
+    # a union of more than 10 terms under a field filter: answered (all-dense: above) -- CPU fall-through only when it names a sparse-tier term
     sh.set_deleted(())
     for n in (11, 16, 30):
-        q = sh.make_queries([_pick(rng, n, frequent + mid)], S.QueryType.Union, field_filter=(0,))
-        _expect_enotsup(S, sh, q, 10, S.ResultType.TopkCount, CPU_FALL_THROUGH["union_filter_gt10"])
-        ro = sh.search_lexical_shard(_pick(rng, n, frequent + mid), S.QueryType.Union, 0, 10, field_filter=(0,))
-        assert ro.cpu_dispatch and not ro.results  # the mirror says "the host's dispatch answers this", not "no hits"
+        terms = _pick(rng, n, frequent + mid)
+        if with_tier:
+            terms[-1] = rare[0]
+            q = sh.make_queries([terms], S.QueryType.Union, field_filter=(0,))
+            _expect_enotsup(S, sh, q, 10, S.ResultType.TopkCount, CPU_FALL_THROUGH["union_filter_gt10_sparse"])
+            ro = sh.search_lexical_shard(terms, S.QueryType.Union, 0, 10, field_filter=(0,))
+            assert ro.cpu_dispatch and not ro.results  # the mirror says "the host's dispatch answers this", not "no hits"
+        else:
+            ro = sh.search_lexical_shard(terms, S.QueryType.Union, 0, 10, field_filter=(0,))
+            assert not ro.cpu_dispatch and len(ro.results) == 10
     # ... a page deeper than SS_MAX_K results is answered (in passes: tests/test_gpu_deep_pages.py)
     q = sh.make_queries([_pick(rng, 2, mid)], S.QueryType.Union)
     assert int(sh.search_lexical_batch(q, 1024, S.ResultType.TopkCount, reference_shortcuts=False)[2][0]) > 0
