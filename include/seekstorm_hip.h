@@ -406,8 +406,8 @@ int ss_bm25_term_df(ss_shard* s, uint32_t n, const uint32_t* terms, uint64_t* df
  * 3136): bits 16..31 of op, bit f = indexed field f is listed; 0 = no filter.  Intersections and single-term queries: a doc is
  * kept only if EVERY query term occurs in at least one listed field; its score still sums all fields.  A UNION of several terms
  * (<= 10, the range of union_docid_3; MORE than 10: the reference runs union_scan_32 with add_result's per-doc filter, another rule --
- * a doc answers iff EVERY term it holds stands in a listed field, and scores with all of them; answered by that rule for dense
- * terms with probe rows over merged lists, SS_ENOTSUP when such a union names a sparse-tier term):
+ * a doc answers iff EVERY term it holds stands in a listed field, and scores with all of them; answered by that rule on both tiers
+ * over merged lists, SS_ENOTSUP only when a dense list of such a union has no probe row -- a rationed vocabulary):
  * the reference filters inside union_docid_3's sub-queries (union.rs:1330-1425, 1168-1305), which comes to -- a doc's
  * score is the sum over its terms that occur in a listed field (all fields of those terms counted), a doc none of whose terms passes
  * is no result; exact count: two terms |pass(X) u pass(Y)|, more terms the UNFILTERED union (union_scan counts a doc before the

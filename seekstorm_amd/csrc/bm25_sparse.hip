@@ -402,13 +402,16 @@ __global__ void sp_excl_init_kernel(const uint32_t* __restrict__ base, uint32_t 
   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w < words) out[w] = (base && w < base_words) ? base[w] : 0u;
 }
+// unlisted != 0: only the postings that stand in NO field of that mask (several indexed fields: a sparse posting carries its fields)
 __global__ void sp_excl_mark_kernel(const unsigned long long* __restrict__ sp_base, const unsigned long long* __restrict__ sp_post, SpLists L,
-                                    uint32_t* __restrict__ out, uint32_t words) {
+                                    uint32_t* __restrict__ out, uint32_t words, uint32_t unlisted) {
   const uint32_t li = blockIdx.y;
   if (li >= L.n) return;
   const unsigned long long b0 = sp_base[L.id[li]], b1 = sp_base[L.id[li] + 1];
   for (unsigned long long x = b0 + blockIdx.x * blockDim.x + threadIdx.x; x < b1; x += (unsigned long long)gridDim.x * blockDim.x) {
-    const uint32_t doc = (uint32_t)sp_post[x];
+    const unsigned long long e = sp_post[x];
+    const uint32_t doc = (uint32_t)e;
+    if (unlisted && (((uint32_t)(e >> 32) >> BM_SP_FIELD_SHIFT) & unlisted)) continue;
     if ((doc >> 5) < words) atomicOr(out + (doc >> 5), 1u << (doc & 31u));
   }
 }
@@ -425,7 +428,20 @@ int ssi_bm25_sparse_excl_bits(const ss_shard* s, const uint32_t* d_base_bits, ui
     if (lists[i] >= s->sp_n) return SS_EINVAL;
   sp_excl_init_kernel<<<(words + 255) / 256, 256, 0, st>>>(d_base_bits, base_words, d_out, words);
   if (n_lists)
-    sp_excl_mark_kernel<<<dim3(16, n_lists), 256, 0, st>>>((const unsigned long long*)s->d_sp_base, (const unsigned long long*)s->d_sp_post, L, d_out, words);
+    sp_excl_mark_kernel<<<dim3(16, n_lists), 256, 0, st>>>((const unsigned long long*)s->d_sp_base, (const unsigned long long*)s->d_sp_post, L, d_out, words, 0u);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+// d_out |= the docs that hold a listed sparse term in fields outside `filter` only (ss_api.hip bm25_search_gated_scan_rule)
+int ssi_bm25_sparse_mark_unlisted(const ss_shard* s, const uint32_t* lists, uint32_t n_lists, uint32_t filter, uint32_t* d_out, uint32_t words, hipStream_t st) {
+  if (n_lists > (uint32_t)SS_MAX_QUERY_TERMS || filter == 0u) return SS_EINVAL;
+  if (n_lists == 0) return SS_OK;
+  SpLists L;
+  L.n = n_lists;
+  for (uint32_t i = 0; i < (uint32_t)SS_MAX_QUERY_TERMS; i++) L.id[i] = i < n_lists ? lists[i] : 0u;
+  for (uint32_t i = 0; i < n_lists; i++)
+    if (lists[i] >= s->sp_n) return SS_EINVAL;
+  sp_excl_mark_kernel<<<dim3(16, n_lists), 256, 0, st>>>((const unsigned long long*)s->d_sp_base, (const unsigned long long*)s->d_sp_post, L, d_out, words, filter);
   SS_HIP(hipGetLastError());
   return SS_OK;
 }

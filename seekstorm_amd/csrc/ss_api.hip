@@ -1700,23 +1700,27 @@ __global__ void gate_rule_bits_kernel(const unsigned long long* __restrict__ set
 static int bm25_search_gated_scan_rule(ss_shard* s, const ss_bm25_query& Q, uint32_t kk, uint32_t rt, uint32_t* a_doc, float* a_score, uint32_t* a_cnt,
                                        unsigned long long* a_tot) {
   const uint32_t n = Q.n_terms, nn = bm_q_nnot(Q.op), n_dense = s->bm_n_terms / s->bm_n_fields, kw = std::max<uint32_t>(kk, 1);
-  for (uint32_t t = 0; t < n + nn; t++)
-    if (Q.term[t] >= n_dense) return SS_ENOTSUP;  // (a sparse-tier term: its postings carry their fields elsewhere)
   if (!s->bm_merged || !s->d_probe || 2 * n > 64) return SS_ENOTSUP;
   SS_HIP(hipSetDevice(s->device));
-  std::vector<ss_bm25_query> subs(2 * (size_t)n);
-  for (uint32_t t = 0; t < n; t++)
+  // dense terms: M_t and P_t from the bit records; sparse-tier terms: their postings carry their fields (marked below)
+  std::vector<ss_bm25_query> subs;
+  uint32_t sp_lists[SS_MAX_QUERY_TERMS], n_sp = 0;
+  for (uint32_t t = 0; t < n; t++) {
+    if (Q.term[t] >= n_dense) { sp_lists[n_sp++] = Q.term[t] - n_dense; continue; }
     for (int f = 0; f < 2; f++) {
-      ss_bm25_query& S = subs[2 * (size_t)t + f];
+      ss_bm25_query S;
       memset(&S, 0, sizeof(S));
       S.n_terms = 1; S.term[0] = Q.term[t]; S.idf[0] = Q.idf[t];
       S.op = SS_OP_INTERSECTION | (f ? SS_OP_FIELD_FILTER(bm_q_field_filter(Q.op)) : 0u);
+      subs.push_back(S);
     }
-  {
+  }
+  const uint32_t nd2 = (uint32_t)subs.size();  // 2 x the dense terms
+  if (nd2) {
     bool has_and, has_or, all_probed, any_frequent, phrase = false, any_filter = false, uniform = false, gated = false;
     uint32_t nt_max, np_max, nn_max = 0;
-    SS_TRY(ssi_bm25_ensure_probe_rows(s, 2 * n, subs.data(), s->stream));
-    SS_TRY(check_queries(s, 2 * n, subs.data(), &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent, &phrase, &any_filter, &uniform, &gated, &nn_max));
+    SS_TRY(ssi_bm25_ensure_probe_rows(s, nd2, subs.data(), s->stream));
+    SS_TRY(check_queries(s, nd2, subs.data(), &has_and, &has_or, &nt_max, &np_max, &all_probed, &any_frequent, &phrase, &any_filter, &uniform, &gated, &nn_max));
     if (!all_probed) return SS_ENOTSUP;  // (a rationed vocabulary: the match sets are read from the bit records)
   }
   const size_t groups = (size_t)s->bm_n_sub * (BM_SUB / 64), words = ((size_t)s->bm_n_docs + 31) / 32;
@@ -1736,12 +1740,15 @@ static int bm25_search_gated_scan_rule(ss_shard* s, const ss_bm25_query& Q, uint
     s->excl_words_cap = words;
   }
   char* W = (char*)s->d_gate_ws;
-  SS_HIP(hipMemcpy(W + o_q, subs.data(), subs.size() * sizeof(ss_bm25_query), hipMemcpyHostToDevice));  // (synchronous: `subs` is a local)
-  SS_TRY(ssi_bm25_match_bits(s, (const ss_bm25_query*)(W + o_q), (unsigned long long*)(W + o_sets), (unsigned long long*)(W + o_tot), s->stream, 2 * n));
+  if (nd2) {
+    SS_HIP(hipMemcpy(W + o_q, subs.data(), subs.size() * sizeof(ss_bm25_query), hipMemcpyHostToDevice));  // (synchronous: `subs` is a local)
+    SS_TRY(ssi_bm25_match_bits(s, (const ss_bm25_query*)(W + o_q), (unsigned long long*)(W + o_sets), (unsigned long long*)(W + o_tot), s->stream, nd2));
+  }
   const bool had = s->n_deleted != 0;
   gate_rule_bits_kernel<<<(uint32_t)std::min<size_t>(2048, (words / 2 + 256) / 256), 256, 0, s->stream>>>(
-      (const unsigned long long*)(W + o_sets), n, groups, had ? s->d_deleted : nullptr, had ? (uint32_t)s->deleted_words : 0u, s->d_excl_bits, (uint32_t)words);
+      (const unsigned long long*)(W + o_sets), nd2 / 2, groups, had ? s->d_deleted : nullptr, had ? (uint32_t)s->deleted_words : 0u, s->d_excl_bits, (uint32_t)words);
   SS_HIP(hipGetLastError());
+  SS_TRY(ssi_bm25_sparse_mark_unlisted(s, sp_lists, n_sp, bm_q_field_filter(Q.op), s->d_excl_bits, (uint32_t)words, s->stream));
   ss_bm25_query U = Q;  // the plain union: the filter is in the bitmap now
   U.op = SS_OP_UNION | SS_OP_NOT_TERMS(nn);
   *a_cnt = 0; *a_tot = 0;
@@ -1933,7 +1940,7 @@ static int bm25_shape_of(const ss_shard* s, const ss_bm25_query& Q, uint32_t kk,
     return SS_OK;
   }
   if (filt && op == SS_OP_UNION && np > 1) {  // a union under a field filter: the gated scan (<= 7 dense terms), else composed
-    if (np > 10 && (any_sparse || !s->bm_merged)) return SS_ENOTSUP;  // (the scan rule reads the dense tier's bit records and merged lists)
+    if (np > 10 && !s->bm_merged) return SS_ENOTSUP;  // (the scan rule runs the plain union over the merged lists)
     if (any_sparse || np > 7) *shape = SH_COMPOSE;  // 8 .. 10: the reference's sub-queries; more: its other rule (bm25_search_gated_scan_rule)
     return SS_OK;
   }

@@ -622,6 +622,7 @@ int ssi_bm25_launch_sparse_seeds(uint32_t nq, uint32_t k, const uint32_t* d_dens
                                  const unsigned long long* d_keys, float* d_seed, hipStream_t st);
 int ssi_bm25_sparse_excl_bits(const ss_shard* s, const uint32_t* d_base_bits, uint32_t base_words, const uint32_t* lists, uint32_t n_lists,
                               uint32_t* d_out, uint32_t words, hipStream_t st);
+int ssi_bm25_sparse_mark_unlisted(const ss_shard* s, const uint32_t* lists, uint32_t n_lists, uint32_t filter, uint32_t* d_out, uint32_t words, hipStream_t st);
 int ssi_bm25_launch_tier_merge(uint32_t nq, uint32_t k, const uint32_t* d_dense_row, const uint32_t* d_sparse_row, const uint32_t* d_doc,
                                const float* d_score, const uint32_t* d_count, const unsigned long long* d_total, const unsigned long long* d_keys,
                                const unsigned long long* d_extra, uint32_t* o_doc, float* o_score, uint32_t* o_count, unsigned long long* o_total,

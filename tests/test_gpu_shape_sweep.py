@@ -22,8 +22,8 @@ CPU_FALL_THROUGH = {
                                   "(ss_*_dev, ss_hybrid_search_sharded); the host-pointer entries (ss_bm25_search_sorted among them) and "
                                   "ss_bm25_search_sharded / ss_vec_search_sharded answer any k: tests/test_gpu_deep_pages.py, tests/test_gpu_sharded.py",
     "gt32_terms": "a query of more than 32 unique terms, NOT terms included (union.rs:233-259, 617-624: union_scan_32 over the 32 lists with the largest block maxima + union_count); refused by the mirrors' make_query, tests/test_gpu_union_many.py",
-    "union_filter_gt10_sparse": "a UNION of more than 10 terms under a field filter that names a sparse-tier term (or on a rationed vocabulary / an image without "
-                                "merged lists): union.rs:598-805 union_scan_32 + add_result.rs:3124-3136; all-dense ones are answered by that rule behind the ABI",
+    "union_filter_gt10_no_rows": "a UNION of more than 10 terms under a field filter on a rationed vocabulary (a dense list without a probe row) or an image without "
+                                 "merged lists: union.rs:598-805 union_scan_32 + add_result.rs:3124-3136; every other one is answered by that rule behind the ABI",
     "nomerged_phrase": "a phrase on an image of several indexed fields whose boosts kept the merged lists from being built (add_result.rs:3248-3386)",
     "nomerged_frequent": "all_terms_frequent on such an image (add_result.rs:1595-1607)",
     "nomerged_union_lists": "a union of more than 32 (term, field) lists on such an image (union.rs:403-805)",
@@ -286,8 +286,6 @@ def test_sweep_three_indexed_fields(S, O, with_tier):
                         if n + nn > 32:
                             continue
                         for tier in (("dense", "mixed") if with_tier else ("dense",)):
-                            if op == "or" and filt and n > 10 and tier == "mixed":
-                                continue  # (CPU fall-through: a sparse-tier term in a union of more than 10 terms under a filter; below)
                             pool = frequent + mid + (rare if tier == "mixed" else [])
                             if op == "and" and n > 3:
                                 terms = _pick(rng, min(n, 12), frequent)
@@ -327,19 +325,14 @@ def test_sweep_three_indexed_fields(S, O, with_tier):
                         od, os_, otot = O.search_fields_shortcut(n_docs, dl, boost, offs, docs, fields, tfs, terms, 10, deleted)
                         _check(doc[i], score[i], cnt[i], tot[i], od, os_, otot, rt, 10, S, ("3f frequent", with_tier, terms, rt, bool(deleted)))
                 assert sh.generic_batches() > before
-    # a union of more than 10 terms under a field filter: answered (all-dense: above) -- CPU fall-through only when it names a sparse-tier term
+    # a union of more than 10 terms under a field filter is answered on both tiers (the cells above), through the mirror's single-query entry too
     sh.set_deleted(())
     for n in (11, 16, 30):
         terms = _pick(rng, n, frequent + mid)
         if with_tier:
             terms[-1] = rare[0]
-            q = sh.make_queries([terms], S.QueryType.Union, field_filter=(0,))
-            _expect_enotsup(S, sh, q, 10, S.ResultType.TopkCount, CPU_FALL_THROUGH["union_filter_gt10_sparse"])
-            ro = sh.search_lexical_shard(terms, S.QueryType.Union, 0, 10, field_filter=(0,))
-            assert ro.cpu_dispatch and not ro.results  # the mirror says "the host's dispatch answers this", not "no hits"
-        else:
-            ro = sh.search_lexical_shard(terms, S.QueryType.Union, 0, 10, field_filter=(0,))
-            assert not ro.cpu_dispatch and len(ro.results) == 10
+        ro = sh.search_lexical_shard(terms, S.QueryType.Union, 0, 10, field_filter=(0,))
+        assert not ro.cpu_dispatch and len(ro.results) == 10
     # ... a page deeper than SS_MAX_K results is answered (in passes: tests/test_gpu_deep_pages.py)
     q = sh.make_queries([_pick(rng, 2, mid)], S.QueryType.Union)
     assert int(sh.search_lexical_batch(q, 1024, S.ResultType.TopkCount, reference_shortcuts=False)[2][0]) > 0
