@@ -260,3 +260,76 @@ def test_sorted_deep_pages(S, O):
                 assert np.allclose(score, want_s, rtol=REL, atol=1e-7)
                 assert (doc == want_d).mean() > 0.98
     sh.close()
+
+
+def test_hybrid_deep_page_and_concurrent_callers(S, O):
+    """a deep HYBRID page through the mirror's planner (two deep shard searches + RRF on the host, search.rs:1962-2035) over two shards,
+    and deep pages issued while other threads search the same shard through the coalescer: the passes swap the shard's exclusion bitmap
+    under the shard lock -- nobody else may ever see it"""
+    import threading
+    n_docs, voc, dim = 60_000, list(range(2600, 4096, 150)), 64
+    dl = O.lex_doclen(n_docs)
+    offs, docs, tfs = O.lex_corpus(n_docs, voc)
+    rows = O.vec_gen(O.VEC_SEED, 0, n_docs, dim)
+    sh = S.Shard(0)
+    sh.upload_lexical(n_docs, dl, offs, docs, tfs)
+    sh.upload_vectors(rows)
+    qs = O.vec_gen(O.VECQ_SEED, 0, 2, dim)
+    ix = S.Index([sh])
+    terms = [3, 7, 9]
+    deep = ix.search(terms, qs[0], S.QueryType.Union, S.SearchMode.Hybrid, 2000, 30, normalize_query=False)
+    # the same page from the two deep lists fused here: RRF score of a doc = sum over the lists holding it of 1 / (0.6 + rank)
+    ld, ls, lc, lt = sh.search_lexical_batch(sh.make_queries([terms], S.QueryType.Union), 2030, reference_shortcuts=False)
+    vd, vs, vc, vt = sh.search_vector_batch(qs[:1], 2030)
+    assert int(lc[0]) == 2030 and int(vc[0]) == 2030
+    fused = {}
+    for lst in (ld[0], vd[0]):
+        for r, d in enumerate(lst.tolist()):
+            fused[d] = np.float32(fused.get(d, np.float32(0)) + np.float32(1.0) / (np.float32(0.6) + np.float32(r)))
+    want = sorted(fused.items(), key=lambda e: (-float(e[1]), e[0]))[2000:2030]
+    assert not deep.cpu_dispatch and len(deep.results) == 30
+    assert np.allclose([r.score for r in deep.results], [float(s_) for _, s_ in want], rtol=1e-6)
+    assert [r.doc_id for r in deep.results] == [d for d, _ in want]
+    # ---- concurrency: two threads page deep, four threads ask ordinary single queries of the same shard
+    q1 = sh.make_queries([[3, 7, 9]], S.QueryType.Union)
+    q2 = sh.make_queries([[5, 2]], S.QueryType.Union)
+    ref_deep = sh.search_lexical_batch(q1, 3000, reference_shortcuts=False)
+    ref_vdeep = sh.search_vector_batch(qs[1:2], 2500)
+    ref_small = [sh.search_lexical_batch(q, 10, reference_shortcuts=False) for q in (q1, q2)]
+    ref_vsmall = sh.search_vector_batch(qs[:1], 20)
+    bad, stop = [], threading.Event()
+
+    def deep_lex():
+        for _ in range(12):
+            got = sh.search_lexical_batch(q1, 3000, reference_shortcuts=False)
+            if not all(np.array_equal(a, b) for a, b in zip(got, ref_deep)):
+                bad.append("deep lexical")
+
+    def deep_vec():
+        for _ in range(6):
+            got = sh.search_vector_batch(qs[1:2], 2500)
+            if not all(np.array_equal(a, b) for a, b in zip(got[:3], ref_vdeep[:3])):
+                bad.append("deep vector")
+
+    def small(i):
+        while not stop.is_set():
+            if i == 3:
+                got = sh.search_vector_batch(qs[:1], 20)
+                if not all(np.array_equal(a, b) for a, b in zip(got[:3], ref_vsmall[:3])):
+                    bad.append("small vector")
+            else:
+                got = sh.search_lexical_batch((q1, q2)[i & 1], 10, reference_shortcuts=False)
+                if not all(np.array_equal(a, b) for a, b in zip(got, ref_small[i & 1])):
+                    bad.append("small lexical")
+
+    th = [threading.Thread(target=small, args=(i,)) for i in range(4)]
+    dth = [threading.Thread(target=deep_lex), threading.Thread(target=deep_vec)]
+    for t in th + dth:
+        t.start()
+    for t in dth:
+        t.join()
+    stop.set()
+    for t in th:
+        t.join()
+    assert not bad, sorted(set(bad))
+    sh.close()
