@@ -1435,7 +1435,10 @@ def main():
                                                ("hybrid_top100_T64", N.MODE_HYBRID, 64, B, 100), ("hybrid_top100_T256", N.MODE_HYBRID, 256, B, 100)):
                 out5 = (C.c_double * 5)()
                 st0 = sh.coalescing_stats()
-                N.check(HL.ssh_bench_concurrent(ixp, mode, T, max(args.min_seconds, 1.0), nqq, flat.ctypes.data, toff.ctypes.data, qv_np.ctypes.data,
+                # (256 callers of a 9 ms pass make ~27 calls a second each: twice the time, so that one stalled pass -- 256 calls late at once -- is
+                # not by itself the leg's p99; profiles/r6g_tail_v256.log: three isolated runs p99 / p50 1.01, 1.01 and, with ONE pass of 18 ms, 1.29)
+                leg_s = max(args.min_seconds, 1.0) * (2.0 if (T >= 256 and mode != N.MODE_LEXICAL) else 1.0)
+                N.check(HL.ssh_bench_concurrent(ixp, mode, T, leg_s, nqq, flat.ctypes.data, toff.ctypes.data, qv_np.ctypes.data,
                                                 int(S.QueryType.Union), length, N.RT_TOPK, out5), "ssh_bench_concurrent")
                 st1 = sh.coalescing_stats()
                 lb, lq, vb, vq = (st1[i] - st0[i] for i in range(4))
