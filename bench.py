@@ -1265,7 +1265,7 @@ def main():
         ve2e1 = host_latencies(lambda: vec_host_call(1), 100)
         # a DEEP page of one query (k = 4096 > SS_MAX_K: four passes under the query's exclusion bitmap); its head must be the top-kv list
         vdeep = None
-        if not args.quick:
+        if not args.quick and world == 1:
             kd = 4096
             dv_doc = np.empty((1, kd), np.uint32); dv_score = np.empty((1, kd), np.float32)
             dv_cnt = np.empty(1, np.uint32); dv_tot = np.empty(1, np.uint64)
