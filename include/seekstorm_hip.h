@@ -53,9 +53,10 @@ extern "C" {
 /* results one PASS over the index holds.  The host-pointer searches (ss_bm25_search[_filtered], ss_vec_search*, ss_vec_search_i8*) take
  * any k -- the crate's offset + length is unbounded (search.rs:1658-1659) -- and answer k > SS_MAX_K in passes of SS_MAX_K, every pass
  * the ordinary search under (tombstones or the facet filter's bitmap) | (the docs of the earlier passes); totals are the first pass's.
- * ss_bm25_search_sharded / ss_vec_search_sharded do the same before their exchange.  The entries that keep their answers on the device
- * (ss_*_dev) or fuse two lists on it (ss_hybrid_search_sharded) return SS_ENOTSUP beyond it; ss_bm25_search_sorted peels a deep page
- * the same way (its order -- the sort fields, then score descending, then doc ascending -- is total as well). */
+ * ss_bm25_search_sharded / ss_vec_search_sharded do the same before their exchange, ss_bm25_search_sorted peels a deep page the same way
+ * (its order -- the sort fields, then score descending, then doc ascending -- is total as well).  The device-pointer entries (ss_*_dev)
+ * answer a deep page too, SYNCHRONOUSLY: the passes are steered from the host, so the queries make one trip there; the page is left in
+ * the caller's device arrays.  Only ss_hybrid_search_sharded, which fuses two lists on the device, returns SS_ENOTSUP beyond it. */
 #define SS_MAX_K 1024
 #define SS_VEC_BATCH 64 /* queries scanned per pass over the matrix */
 

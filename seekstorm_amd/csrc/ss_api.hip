@@ -3442,11 +3442,29 @@ int ss_bm25_search_filtered_dev(ss_shard* s, uint32_t nq, const ss_bm25_query* d
   if (!s || !d_q || !d_out_count || !d_out_total) return SS_EINVAL;
   if (rt > SS_RT_TOPKCOUNT) return SS_EINVAL;
   if (rt != SS_RT_COUNT && (k == 0 || !d_out_doc || !d_out_score)) return SS_EINVAL;
-  if (rt != SS_RT_COUNT && k > SS_MAX_K) return SS_ENOTSUP;
   if (!s->d_post) return SS_ESTATE;
   ShardLock g(s);
   SS_HIP(hipSetDevice(s->device));
   hipStream_t st = stream ? (hipStream_t)stream : s->stream;
+  if (rt != SS_RT_COUNT && k > SS_MAX_K) {
+    // a DEEP page ("deep pages" above): the passes are steered from the host, so the queries make one trip there (like the tiered batches
+    // below) and the call is synchronous; the page is left in the caller's device arrays, ordered on `st`
+    std::vector<ss_bm25_query> hq(nq);
+    SS_HIP(hipMemcpyAsync(hq.data(), d_q, (size_t)nq * sizeof(ss_bm25_query), hipMemcpyDeviceToHost, st));
+    SS_HIP(hipStreamSynchronize(st));
+    std::vector<uint32_t> h_doc((size_t)nq * k), h_cnt(nq);
+    std::vector<float> h_score((size_t)nq * k);
+    std::vector<uint64_t> h_tot(nq);
+    SS_TRY(with_facet_filter(s, n_filters, filters, s->stream, [&]() {
+      return bm25_search_deep_locked(s, nq, hq.data(), k, rt, h_doc.data(), h_score.data(), h_cnt.data(), h_tot.data());
+    }));
+    SS_HIP(hipMemcpyAsync(d_out_doc, h_doc.data(), h_doc.size() * 4, hipMemcpyHostToDevice, st));
+    SS_HIP(hipMemcpyAsync(d_out_score, h_score.data(), h_score.size() * 4, hipMemcpyHostToDevice, st));
+    SS_HIP(hipMemcpyAsync(d_out_count, h_cnt.data(), (size_t)nq * 4, hipMemcpyHostToDevice, st));
+    SS_HIP(hipMemcpyAsync(d_out_total, h_tot.data(), (size_t)nq * 8, hipMemcpyHostToDevice, st));
+    SS_HIP(hipStreamSynchronize(st));  // (the host copies are this frame's)
+    return SS_OK;
+  }
   if ((ops_mask & (1u << 28)) && s->sp_n) {
     // the batch may name terms of the SPARSE tier: splitting it into its dense and sparse parts is host work, so the queries make
     // one trip to the host (the cost the header states); the answers are left in the caller's device arrays, ordered on `st`
@@ -3819,18 +3837,47 @@ int ss_vec_search(ss_shard* s, uint32_t nq, const float* queries, uint32_t k, fl
   return ss_vec_search_ann(s, nq, queries, k, thr, nullptr, out_doc, out_score, out_count, out_total, nullptr);
 }
 
+// a DEEP page on a device-pointer vector entry: the passes are steered from the host, so the queries (and their scales / norms) make one
+// trip there and the call is synchronous; the page is left in the caller's device arrays, ordered on `st`.  Caller holds the shard lock.
+static int vec_search_deep_dev_locked(ss_shard* s, uint32_t nq, const void* d_queries, size_t elem, const float* d_qscale, const float* d_qnorm, uint32_t k, float thr,
+                                      const ss_ann_mode* mode, uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total,
+                                      uint32_t* d_out_clusters, hipStream_t st) {
+  if (nq == 0) return SS_OK;
+  const uint32_t ocw = (mode && (mode->flags & SS_ANN_REPORT_OBSERVED)) ? 3u : 1u;
+  std::vector<char> hq((size_t)nq * s->dim * elem);
+  std::vector<float> hs(d_qscale ? nq : 0), hn(d_qnorm ? nq : 0);
+  SS_HIP(hipMemcpyAsync(hq.data(), d_queries, hq.size(), hipMemcpyDeviceToHost, st));
+  if (d_qscale) SS_HIP(hipMemcpyAsync(hs.data(), d_qscale, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+  if (d_qnorm) SS_HIP(hipMemcpyAsync(hn.data(), d_qnorm, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+  SS_HIP(hipStreamSynchronize(st));
+  std::vector<uint32_t> h_doc((size_t)nq * k), h_cnt(nq), h_ncl(d_out_clusters ? (size_t)nq * ocw : 0);
+  std::vector<float> h_score((size_t)nq * k);
+  std::vector<uint64_t> h_tot(nq);
+  SS_TRY(vec_search_deep_locked(s, nq, hq.data(), elem, d_qscale ? hs.data() : nullptr, k, thr, mode, h_doc.data(), h_score.data(), h_cnt.data(), h_tot.data(),
+                                d_out_clusters ? h_ncl.data() : nullptr, d_qnorm ? hn.data() : nullptr));
+  SS_HIP(hipMemcpyAsync(d_out_doc, h_doc.data(), h_doc.size() * 4, hipMemcpyHostToDevice, st));
+  SS_HIP(hipMemcpyAsync(d_out_score, h_score.data(), h_score.size() * 4, hipMemcpyHostToDevice, st));
+  SS_HIP(hipMemcpyAsync(d_out_count, h_cnt.data(), (size_t)nq * 4, hipMemcpyHostToDevice, st));
+  SS_HIP(hipMemcpyAsync(d_out_total, h_tot.data(), (size_t)nq * 8, hipMemcpyHostToDevice, st));
+  if (d_out_clusters) SS_HIP(hipMemcpyAsync(d_out_clusters, h_ncl.data(), h_ncl.size() * 4, hipMemcpyHostToDevice, st));
+  SS_HIP(hipStreamSynchronize(st));
+  return SS_OK;
+}
+
 int ss_vec_search_ann_dev(ss_shard* s, uint32_t nq, const float* d_queries, uint32_t k, float thr, const ss_ann_mode* mode,
                           uint32_t* d_out_doc, float* d_out_score, uint32_t* d_out_count, uint64_t* d_out_total,
                           uint32_t* d_out_clusters, void* stream) {
   if (!s || !d_queries || !d_out_doc || !d_out_score || !d_out_count || !d_out_total) return SS_EINVAL;
   if (k == 0) return SS_EINVAL;
-  if (k > SS_MAX_K) return SS_ENOTSUP;  // (deeper pages: the host's own dispatch)
   if (!s->d_X) return SS_ESTATE;
   SS_TRY(ann_mode_ok(s, mode));
   mode = ann_effective(mode);
   ShardLock g(s);
   SS_HIP(hipSetDevice(s->device));
   hipStream_t st = stream ? (hipStream_t)stream : s->stream;
+  if (k > SS_MAX_K)
+    return vec_search_deep_dev_locked(s, nq, d_queries, sizeof(float), nullptr, nullptr, k, thr, mode, d_out_doc, d_out_score, d_out_count, d_out_total,
+                                      mode ? d_out_clusters : nullptr, st);
   VecWsBind bind(s, st);
   AnnStateGuard ann_guard(s, st, mode);
   return ssi_vec_search(s, nq, d_queries, nullptr, k, thr, d_out_doc, d_out_score, d_out_count, d_out_total, st, false, mode,
@@ -4159,7 +4206,6 @@ int ss_vec_search_i8_euclid_dev(ss_shard* s, uint32_t nq, const int8_t* d_querie
                                 uint32_t* d_out_count, uint64_t* d_out_total, uint32_t* d_out_clusters, void* stream) {
   if (!s || !d_queries || !d_out_doc || !d_out_score || !d_out_count || !d_out_total) return SS_EINVAL;
   if (k == 0) return SS_EINVAL;
-  if (k > SS_MAX_K) return SS_ENOTSUP;  // (deeper pages: the host's own dispatch)
   if (!s->d_X8) return SS_ESTATE;
   SS_TRY(vec8_euclid_norms_ok(s, d_query_scale != nullptr, d_query_norm != nullptr));
   SS_TRY(ann_mode_ok(s, mode));
@@ -4167,6 +4213,9 @@ int ss_vec_search_i8_euclid_dev(ss_shard* s, uint32_t nq, const int8_t* d_querie
   ShardLock g(s);
   SS_HIP(hipSetDevice(s->device));
   hipStream_t st = stream ? (hipStream_t)stream : s->stream;
+  if (k > SS_MAX_K)
+    return vec_search_deep_dev_locked(s, nq, d_queries, 1, d_query_scale, d_query_norm, k, thr, mode, d_out_doc, d_out_score, d_out_count, d_out_total,
+                                      mode ? d_out_clusters : nullptr, st);
   VecWsBind bind(s, st);
   AnnStateGuard ann_guard(s, st, mode);
   return ssi_vec_search(s, nq, d_queries, d_query_scale, k, thr, d_out_doc, d_out_score, d_out_count, d_out_total, st, false, mode,

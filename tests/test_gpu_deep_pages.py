@@ -333,3 +333,45 @@ def test_hybrid_deep_page_and_concurrent_callers(S, O):
         t.join()
     assert not bad, sorted(set(bad))
     sh.close()
+
+
+def test_device_pointer_entries_page_deep_too(S, O):
+    """ss_bm25_search_dev / ss_vec_search_dev with k > SS_MAX_K: the passes are steered from the host (one trip of the queries there, a
+    synchronous call), the page is left in the caller's DEVICE arrays -- the same page as the host-pointer entry's"""
+    import torch
+    from seekstorm_amd import _native as N
+    sh, osh, n_docs, n_terms = _single_field_world(S, O, True)
+    dev = torch.device("cuda", 0)
+    cells = [[0, 20], [1, 16, 30], [5, 38, 45], [45]]
+    q = sh.make_queries(cells, S.QueryType.Union)
+    nq, k = len(q), 2500
+    want = sh.search_lexical_batch(q, k, S.ResultType.TopkCount, reference_shortcuts=False)
+    qd = torch.from_numpy(q.view(np.uint8).reshape(nq, -1).copy()).to(dev)
+    doc = torch.full((nq, k), -1, dtype=torch.int32, device=dev); score = torch.zeros((nq, k), dtype=torch.float32, device=dev)
+    cnt = torch.zeros((nq,), dtype=torch.int32, device=dev); tot = torch.zeros((nq,), dtype=torch.int64, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    ops = 2 | (3 << 8) | (3 << 16) | (1 << 28)  # unions, <= 3 terms, may name sparse-tier terms
+    N.check(N.lib().ss_bm25_search_dev(sh._h, nq, qd.data_ptr(), k, int(S.ResultType.TopkCount), ops, doc.data_ptr(), score.data_ptr(), cnt.data_ptr(),
+                                       tot.data_ptr(), st.cuda_stream), "ss_bm25_search_dev")
+    st.synchronize()
+    assert np.array_equal(doc.cpu().numpy().view(np.uint32), want[0]) and np.array_equal(score.cpu().numpy(), want[1])
+    assert np.array_equal(cnt.cpu().numpy().view(np.uint32), want[2]) and np.array_equal(tot.cpu().numpy().view(np.uint64), want[3])
+    assert int(want[2].max()) == k
+    sh.close()
+    # vectors
+    n_rows, dim, kv = 12_000, 64, 2100
+    rows = O.vec_gen(O.VEC_SEED, 0, n_rows, dim)
+    qs = O.vec_gen(O.VECQ_SEED, 0, 3, dim)
+    sv = S.Shard(0)
+    sv.upload_vectors(rows)
+    sv.set_deleted([5, 77, 4000])
+    wd, ws, wc, wt = sv.search_vector_batch(qs, kv)
+    tq = torch.from_numpy(qs).to(dev)
+    vdoc = torch.full((3, kv), -1, dtype=torch.int32, device=dev); vscore = torch.zeros((3, kv), dtype=torch.float32, device=dev)
+    vcnt = torch.zeros((3,), dtype=torch.int32, device=dev); vtot = torch.zeros((3,), dtype=torch.int64, device=dev)
+    N.check(N.lib().ss_vec_search_dev(sv._h, 3, tq.data_ptr(), kv, N.FLT_MIN_NEG, vdoc.data_ptr(), vscore.data_ptr(), vcnt.data_ptr(), vtot.data_ptr(),
+                                      st.cuda_stream), "ss_vec_search_dev")
+    st.synchronize()
+    assert np.array_equal(vdoc.cpu().numpy().view(np.uint32), wd) and np.array_equal(vscore.cpu().numpy(), ws)
+    assert np.array_equal(vcnt.cpu().numpy().view(np.uint32), wc) and int(wc.min()) == kv
+    sv.close()
