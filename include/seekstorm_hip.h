@@ -56,7 +56,8 @@ extern "C" {
  * ss_bm25_search_sharded / ss_vec_search_sharded do the same before their exchange, ss_bm25_search_sorted peels a deep page the same way
  * (its order -- the sort fields, then score descending, then doc ascending -- is total as well).  The device-pointer entries (ss_*_dev)
  * answer a deep page too, SYNCHRONOUSLY: the passes are steered from the host, so the queries make one trip there; the page is left in
- * the caller's device arrays.  Only ss_hybrid_search_sharded, which fuses two lists on the device, returns SS_ENOTSUP beyond it. */
+ * the caller's device arrays.  ss_hybrid_search_sharded runs both shard tasks in passes and fuses the gathered lists on the host
+ * (ss_merge_results) when the page is deep or n_ranks * k * 2 exceeds the fusion kernel's 8192 entries. */
 #define SS_MAX_K 1024
 #define SS_VEC_BATCH 64 /* queries scanned per pass over the matrix */
 
@@ -792,9 +793,9 @@ int ss_bm25_search_sharded(ss_shard* s, ss_comm* c, uint32_t n_queries, const ss
  * k = offset + length, both lists in the one all-gather, the two cross-shard concatenations sorted, RRF over them (ranks run
  * over the whole concatenation, search.rs:1962-2035), sort / offset / length (2098-2119); out_* [n_queries][length] with
  * out_source SS_SRC_* (may be NULL); out_total = sum over the shards of max(lexical, vector) totals (1919-1921).
- * result_type: SS_RT_TOPK or SS_RT_TOPKCOUNT (the lexical task's).  n_ranks * k * 2 <= 8192 (the fusion kernel's LDS;
- * SS_ENOTSUP beyond, and for k > SS_MAX_K: the host fuses such a page itself); ss_bm25_search_sharded / ss_vec_search_sharded take any k
- * (k > SS_MAX_K: this shard's list in passes, see SS_MAX_K) and any n_ranks * k.
+ * result_type: SS_RT_TOPK or SS_RT_TOPKCOUNT (the lexical task's).  Any k and any n_ranks * k on all three (k > SS_MAX_K: this
+ * shard's lists in passes, see SS_MAX_K; the hybrid fusion runs on the device while n_ranks * k * 2 <= 8192 and k <= SS_MAX_K, on the
+ * host -- the same f32 operations, ss_merge_results -- beyond).
  * Every ss_*_search_sharded call is a collective in which a rank takes part EVEN IF its own search failed (with empty lists and
  * a status word): that rank returns its own error, every other rank SS_EPEER -- no rank is left blocking in the exchange. */
 int ss_vec_search_sharded(ss_shard* s, ss_comm* c, uint32_t n_queries, const float* queries, uint32_t k, float threshold_raw,

@@ -188,9 +188,19 @@ __global__ void comm_sum_totals_kernel(uint32_t nq, uint32_t S, const uint32_t* 
 
 static inline size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
 
+int ssi_comm_exchange_hf(ss_comm* c, uint32_t nq, int n_lists, const ss_dev_list* L, const uint64_t* d_tot_a, const uint64_t* d_tot_b,
+                         int local_rc, bool hybrid, uint32_t offset, uint32_t length, uint64_t* out_doc, float* out_score,
+                         uint8_t* out_source, uint32_t* out_count, uint64_t* out_total, hipStream_t st, bool host_fuse);
 int ssi_comm_exchange(ss_comm* c, uint32_t nq, int n_lists, const ss_dev_list* L, const uint64_t* d_tot_a, const uint64_t* d_tot_b,
                       int local_rc, bool hybrid, uint32_t offset, uint32_t length, uint64_t* out_doc, float* out_score,
                       uint8_t* out_source, uint32_t* out_count, uint64_t* out_total, hipStream_t st) {
+  return ssi_comm_exchange_hf(c, nq, n_lists, L, d_tot_a, d_tot_b, local_rc, hybrid, offset, length, out_doc, out_score, out_source, out_count, out_total, st, false);
+}
+int ssi_comm_exchange_hf(ss_comm* c, uint32_t nq, int n_lists, const ss_dev_list* L, const uint64_t* d_tot_a, const uint64_t* d_tot_b,
+                         int local_rc, bool hybrid, uint32_t offset, uint32_t length, uint64_t* out_doc, float* out_score,
+                         uint8_t* out_source, uint32_t* out_count, uint64_t* out_total, hipStream_t st, bool host_fuse) {
+  // host_fuse (hybrid): the two sorted concatenations come home and ss_merge_results fuses them there -- a page deeper than SS_MAX_K, or
+  // concatenations beyond the fusion kernel's 8192 LDS entries; the same f32 operations in the same order as rrf_merge_kernel's
   if (!c || n_lists < 0 || n_lists > 2 || (hybrid && n_lists != 2)) return SS_EINVAL;
   std::lock_guard<std::mutex> g(c->mu);
   if (hipSetDevice(c->device) != hipSuccess) { (void)ncclCommAbort(c->comm); c->comm = nullptr; return SS_EDEVICE; }
@@ -260,6 +270,31 @@ int ssi_comm_exchange(ss_comm* c, uint32_t nq, int n_lists, const ss_dev_list* L
                                  (uint64_t*)(c->d_ws + o_mdoc[l]), (float*)(c->d_ws + o_msc[l]), (uint32_t*)(c->d_ws + o_mcnt[l]), st));
   }
   unsigned long long h_status = 0ull;
+  if (hybrid && host_fuse) {
+    std::vector<uint64_t> hd[2];
+    std::vector<float> hsc[2];
+    std::vector<uint32_t> hc[2];
+    for (int l = 0; l < 2; l++) {
+      hd[l].resize((size_t)nq * mlen[l]); hsc[l].resize((size_t)nq * mlen[l]); hc[l].resize(nq);
+      SS_HIP(hipMemcpyAsync(hd[l].data(), c->d_ws + o_mdoc[l], hd[l].size() * 8, hipMemcpyDeviceToHost, st));
+      SS_HIP(hipMemcpyAsync(hsc[l].data(), c->d_ws + o_msc[l], hsc[l].size() * 4, hipMemcpyDeviceToHost, st));
+      SS_HIP(hipMemcpyAsync(hc[l].data(), c->d_ws + o_mcnt[l], (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    }
+    SS_HIP(hipMemcpyAsync(out_total, d_tot, (size_t)nq * 8, hipMemcpyDeviceToHost, st));
+    SS_HIP(hipMemcpyAsync(&h_status, d_tot + nq, 8, hipMemcpyDeviceToHost, st));
+    SS_HIP(hipStreamSynchronize(st));
+    if (local_rc != SS_OK) return local_rc;
+    if (h_status) return SS_EPEER;
+    for (uint32_t i = 0; i < nq; i++) {
+      for (uint32_t r = 0; r < length; r++) { out_doc[(size_t)i * length + r] = ~0ull; out_score[(size_t)i * length + r] = 0.f; if (out_source) out_source[(size_t)i * length + r] = 0; }
+      const int w = ss_merge_results(SS_MODE_HYBRID, hd[0].data() + (size_t)i * mlen[0], hsc[0].data() + (size_t)i * mlen[0], std::min(hc[0][i], mlen[0]),
+                                     hd[1].data() + (size_t)i * mlen[1], hsc[1].data() + (size_t)i * mlen[1], std::min(hc[1][i], mlen[1]), offset, length,
+                                     out_doc + (size_t)i * length, out_score + (size_t)i * length, out_source ? out_source + (size_t)i * length : nullptr);
+      if (w < 0) return w;
+      out_count[i] = (uint32_t)w;
+    }
+    return SS_OK;
+  }
   if (hybrid) {
     SS_TRY(ss_rrf_merge_dev(c->device, nq, mlen[0], c->d_ws + o_mdoc[0], (const uint32_t*)(c->d_ws + o_mcnt[0]), mlen[1], c->d_ws + o_mdoc[1],
                             (const uint32_t*)(c->d_ws + o_mcnt[1]), 1, offset, length, (uint64_t*)(c->d_ws + o_fdoc), (float*)(c->d_ws + o_fsc),

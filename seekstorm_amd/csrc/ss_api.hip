@@ -3116,31 +3116,51 @@ int ss_vec_search_sharded(ss_shard* s, ss_comm* c, uint32_t nq, const float* que
 // SearchMode::Hybrid over shards on different GPUs: both shard tasks with (offset 0, length k = offset + length), ONE all-gather
 // of both lists, the two cross-shard concatenations sorted, RRF over them and sort / offset / length (search.rs:1962-2035,
 // 2098-2119) on the device; result_count_total = sum over the shards of max(lexical, vector) (1919-1921).
+// (comm.hip: the exchange with the hybrid fusion on the host when host_fuse)
+extern "C++" int ssi_comm_exchange_hf(ss_comm* c, uint32_t nq, int n_lists, const ss_dev_list* L, const uint64_t* d_tot_a, const uint64_t* d_tot_b,
+                         int local_rc, bool hybrid, uint32_t offset, uint32_t length, uint64_t* out_doc, float* out_score,
+                         uint8_t* out_source, uint32_t* out_count, uint64_t* out_total, hipStream_t st, bool host_fuse);
 int ss_hybrid_search_sharded(ss_shard* s, ss_comm* c, uint32_t nq, const ss_bm25_query* q, uint32_t rt, const float* queries, float thr,
                              uint32_t k, uint32_t offset, uint32_t length, uint64_t* out_doc, float* out_score, uint8_t* out_source,
                              uint32_t* out_count, uint64_t* out_total) {
   if (!s || !c || !q || !queries || !out_doc || !out_score || !out_count || !out_total) return SS_EINVAL;
   if (rt != SS_RT_TOPK && rt != SS_RT_TOPKCOUNT) return SS_EINVAL;
   if (k == 0 || length == 0) return SS_EINVAL;
-  if (k > SS_MAX_K) return SS_ENOTSUP;
   int dev = -1, n_ranks = 0;
   SS_TRY(ss_comm_info(c, nullptr, &n_ranks, &dev));
-  // both concatenations live in the fusion kernel's LDS (8192 entries): a valid request beyond that is the host's own merge (SS_ENOTSUP --
-  // the same on every rank, nobody enters the collective)
-  if ((uint64_t)n_ranks * k * 2 > 8192) return SS_ENOTSUP;
+  if ((uint64_t)n_ranks * k > 0xFFFFFFFFull) return SS_EINVAL;
+  // both concatenations live in the fusion kernel's LDS (8192 entries): beyond that, and for a page deeper than SS_MAX_K, they come home
+  // after the exchange and the host fuses them (ss_merge_results: the same f32 operations in the same order) -- the same on every rank
+  const bool host_fuse = k > SS_MAX_K || (uint64_t)n_ranks * k * 2 > 8192;
   if (nq == 0) return SS_OK;
   ShardLock g(s);
   int rc = dev != s->device ? SS_EINVAL : (!s->d_post || !s->d_X) ? SS_ESTATE : SS_OK;
   // outputs of the two searches side by side: the vector lists behind the lexical ones (reserved before either runs)
   if (rc == SS_OK && hipSetDevice(s->device) != hipSuccess) rc = SS_EDEVICE;
-  if (rc == SS_OK) rc = ensure_out(s, 2 * (size_t)nq, k);
-  if (rc == SS_OK) rc = bm25_search_host_queries(s, nq, q, k, rt, 0, nullptr);
   std::vector<uint32_t> h_count(nq);
-  if (rc == SS_OK) rc = vec_search_host_lists(s, nq, queries, sizeof(float), nullptr, k, thr, nullptr, h_count.data(), nullptr, nullptr, false, nq);
+  if (rc == SS_OK && k > SS_MAX_K) {  // both shard tasks as deep pages ("deep pages" above), then placed as the exchange expects them
+    std::vector<uint32_t> h_doc(2 * (size_t)nq * k), h_cnt(2 * (size_t)nq);
+    std::vector<float> h_score(2 * (size_t)nq * k);
+    std::vector<uint64_t> h_tot(2 * (size_t)nq);
+    rc = bm25_search_deep_locked(s, nq, q, k, rt, h_doc.data(), h_score.data(), h_cnt.data(), h_tot.data());
+    if (rc == SS_OK)
+      rc = vec_search_deep_locked(s, nq, queries, sizeof(float), nullptr, k, thr, nullptr, h_doc.data() + (size_t)nq * k, h_score.data() + (size_t)nq * k,
+                                  h_cnt.data() + nq, h_tot.data() + nq, nullptr, nullptr);
+    if (rc == SS_OK) rc = ensure_out(s, 2 * (size_t)nq, k);
+    if (rc == SS_OK && (hipMemcpy(s->d_out_doc, h_doc.data(), h_doc.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                        hipMemcpy(s->d_out_score, h_score.data(), h_score.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                        hipMemcpy(s->d_out_count, h_cnt.data(), h_cnt.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                        hipMemcpy(s->d_out_total, h_tot.data(), h_tot.size() * 8, hipMemcpyHostToDevice) != hipSuccess))
+      rc = SS_EDEVICE;
+  } else {
+    if (rc == SS_OK) rc = ensure_out(s, 2 * (size_t)nq, k);
+    if (rc == SS_OK) rc = bm25_search_host_queries(s, nq, q, k, rt, 0, nullptr);
+    if (rc == SS_OK) rc = vec_search_host_lists(s, nq, queries, sizeof(float), nullptr, k, thr, nullptr, h_count.data(), nullptr, nullptr, false, nq);
+  }
   const ss_dev_list L[2] = {{s->d_out_doc, s->d_out_score, s->d_out_count, k},
                             {s->d_out_doc + (size_t)nq * k, s->d_out_score + (size_t)nq * k, s->d_out_count + nq, k}};
-  return ssi_comm_exchange(c, nq, 2, L, s->d_out_total, s->d_out_total + nq, rc, true, offset, length, out_doc, out_score, out_source,
-                           out_count, out_total, s->stream);
+  return ssi_comm_exchange_hf(c, nq, 2, L, s->d_out_total, s->d_out_total + nq, rc, true, offset, length, out_doc, out_score, out_source,
+                              out_count, out_total, s->stream, host_fuse);
 }
 
 // Facet counts of ONE query (query_facets / facet_count, add_result.rs:484-640): histogram of a facet over the query's match

@@ -18,8 +18,6 @@ pytestmark = pytest.mark.gpu
 
 # the CPU fall-through list: (what, where the reference answers it) -- mirrored by INTEGRATION.md section 4
 CPU_FALL_THROUGH = {
-    "k_gt_1024_sorted_or_device": "offset + length beyond SS_MAX_K = 1024 results on ss_hybrid_search_sharded, which fuses two lists on the device; every other entry "
-                                  "(host-pointer, device-pointer, sorted, sharded lexical / vector) answers any k: tests/test_gpu_deep_pages.py, tests/test_gpu_sharded.py",
     "gt32_terms": "a query of more than 32 unique terms, NOT terms included (union.rs:233-259, 617-624: union_scan_32 over the 32 lists with the largest block maxima + union_count); refused by the mirrors' make_query, tests/test_gpu_union_many.py",
     "union_filter_gt10_no_rows": "a UNION of more than 10 terms under a field filter on a rationed vocabulary (a dense list without a probe row) or an image without "
                                  "merged lists: union.rs:598-805 union_scan_32 + add_result.rs:3124-3136; every other one is answered by that rule behind the ABI",

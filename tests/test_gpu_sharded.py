@@ -170,8 +170,15 @@ def test_vector_and_hybrid_sharded_single_rank(S, O, both):
             assert np.array_equal(hs[i, :hc[i]], want_sc)  # RRF scores: the same f32 operations on the device and on the host
             assert hsrc[i, :hc[i]].tolist() == [int(r.source) for r in ro.results]
             assert int(ht[i]) == max(int(lt[i]), int(vt[i])) == ro.result_count_total
+    # a deep hybrid page (k = offset + length > SS_MAX_K): both shard tasks in passes, ONE all-gather, the fusion on the host (ss_merge_results)
+    hd, hs, hsrc, hc, ht = comm.search_hybrid_sharded(sh, q, qs, 1500, 40)
+    for i in range(nq):
+        ro = ix.search(tl[i], qs[i], S.QueryType.Union, S.SearchMode.Hybrid, 1500, 40, normalize_query=False)
+        assert hc[i] == len(ro.results) == 40 and hd[i, :hc[i]].tolist() == [r.doc_id for r in ro.results]
+        assert np.array_equal(hs[i, :hc[i]], np.array([r.score for r in ro.results], np.float32))
+        assert hsrc[i, :hc[i]].tolist() == [int(r.source) for r in ro.results] and int(ht[i]) == ro.result_count_total
     n, us = comm.profile_read()
-    assert n == 2 + 1 + 2 and 0.0 < us < 5e4  # one all-gather per sharded call
+    assert n == 2 + 1 + 2 + 1 and 0.0 < us < 5e4  # one all-gather per sharded call
     # more queries than one pass over the matrix takes (SS_VEC_BATCH = 64): several passes, still ONE all-gather per call
     nq2 = 150
     qs2 = O.vec_gen(O.VECQ_SEED, 100, nq2, dim)
