@@ -56,6 +56,32 @@ __device__ __attribute__((noinline)) void pb_publish_kth_best(unsigned long long
   if (kth && lane == 0) bm_publish_tau(tau_q, __uint_as_float((uint32_t)(kth >> 32)));
 }
 
+// The same for 64 < k <= 128 (KPL = 2): every partition publishes its TWO best keys (`bests` holds [P][2]) -- 64 partitions of a query in a
+// batch of 64 then show 128 distinct docs, enough for a top-100 -- and the k-th largest of the lanes' best two is the bound (any k distinct
+// docs give one).  A reader may catch a partition between its two stores: (new best, old second) are two real docs; (old best, new second
+// = the old best) is ONE doc twice -- equal keys are the same doc, the copy is dropped.
+__device__ __attribute__((noinline)) void pb_publish_kth_best2(unsigned long long* bests, uint32_t P, uint32_t part, uint32_t k, u64 best, u64 second, uint32_t* tau_q) {
+  const int lane = __lane_id();
+  if (lane == 0) {
+    __hip_atomic_store(bests + (size_t)part * 2u, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(bests + (size_t)part * 2u + 1u, second, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const uint32_t step = (P + 255u) / 256u;
+  u64 m0 = 0ull, m1 = 0ull;  // this lane's best two
+  for (uint32_t p_ = (uint32_t)lane * step; p_ < P; p_ += 64u * step) {
+    const u64 x0 = p_ == part ? best : __hip_atomic_load(bests + (size_t)p_ * 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u64 x1 = p_ == part ? second : __hip_atomic_load(bests + (size_t)p_ * 2u + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (x1 >= x0) x1 = 0ull;  // (the same doc read twice, or a second that overtook the best it was read after)
+    if (x0 > m0) { m1 = m0 > x1 ? m0 : x1; m0 = x0; }
+    else if (x0 > m1) m1 = x0;
+  }
+  u64 kk[2] = {0ull, 0ull};
+  (void)topk_merge64<2>(kk, m0, 128u, lane);
+  (void)topk_merge64<2>(kk, m1, 128u, lane);
+  const u64 kth = k <= 64u ? rdlane64(kk[0], (int)k - 1) : rdlane64(kk[1], (int)k - 65);
+  if (kth && lane == 0) bm_publish_tau(tau_q, __uint_as_float((uint32_t)(kth >> 32)));
+}
+
 // FILT: tombstones and / or NOT terms are present (a separate instantiation: the unfiltered kernel pays nothing for them)
 // SKIP: the driver streams jump over sub-blocks whose block-max bound (qbound) lies below the threshold.  A separate
 // instantiation: the few registers the skip needs pushed the common kernel into scratch (C2: 0.55 -> 0.80 ms per 1000 queries).
@@ -135,7 +161,7 @@ __device__ __forceinline__ BmTop<KPL> pb_wave(
   T.wsc = -1.0f;
   T.matched = 0;
   uint32_t* tau_q = tau + (size_t)qi * BM_TAU_STRIDE;
-  u64 last_best = 0ull;  // (KTHB: the best key this partition has published)
+  u64 last_best = 0ull, last_second = 0ull;  // (KTHB: the best key(s) this partition has published)
   const int lane4 = lane * 4;
 
   // score in QUERY order with the exhaustive kernels' fma chain (bit-identical results)
@@ -160,6 +186,13 @@ __device__ __forceinline__ BmTop<KPL> pb_wave(
           const u64 best = rdlane64(T.keys[0], 0);
           // (intersections: the driver list is read whatever the threshold -- nothing to gain there)
           if (bests && !is_and && best != last_best) { last_best = best; pb_publish_kth_best(bests, bests_stride, P, part, k, best, tau_q); }
+        }
+        if (KTHB && KPL == 2) {  // (64 < k <= 128: the partition's best TWO keys, bests = [P][2])
+          const u64 best = rdlane64(T.keys[0], 0), second = rdlane64(T.keys[0], 1);
+          if (bests && !is_and && (best != last_best || second != last_second)) {
+            last_best = best; last_second = second;
+            pb_publish_kth_best2(bests, P, part, k, best, second, tau_q);
+          }
         }
       }
     }

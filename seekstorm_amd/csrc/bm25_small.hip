@@ -74,7 +74,7 @@ struct PbSmall {
   float* out_score;
   uint32_t* out_count;
   unsigned long long* out_total;
-  unsigned long long* bests;      // [SM_MAX_Q][SM_MAX_PB * 8] best key of every partition (zero between launches): pb_publish_kth_best
+  unsigned long long* bests;      // [SM_MAX_Q][SM_MAX_PB * 8 * 2] best key (k <= 64) / best two keys (k <= 128) of every partition (zero between launches): pb_publish_kth_best[2]
   uint32_t* flag;                 // pinned host word: = seq when every answer is in place
   // the sparse tier and (phrases) the positions of both tiers: role 3
   const unsigned long long* sp_base;
@@ -450,7 +450,8 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 4) bm25_small_kernel(const PbSm
         for (int j = 0; j < 4; j++) Q.not_[j] = FILT ? fz->q[qi].term[min(np + (uint32_t)j, 7u)] : 0u;
         T = pb_wave<NT, KPL, FILT, false, true, SM_G, true, TIER != 0>(fz->post, fz->term_base, fz->sub_off, fz->probe, fz->probe_z, fz->probe_row, fz->umax, nullptr, nullptr,
                                                    Q, fz->tau, fz->del, fz->del_words, fz->n_sub, fz->n_terms, PB * PB_WAVES, k, (fz->count & 1u) && !count_by_bits ? 1u : 0u, qi, part, w, lane, fz->q[qi].thr0,
-                                                   (fz->count & 4u) && k <= 64u && PB * PB_WAVES >= k ? fz->bests + (size_t)qi * (SM_MAX_PB * PB_WAVES) : nullptr);
+                                                   // (the partitions' best keys: one each for k <= 64, two each -- KPL = 2 -- beyond: pb_publish_kth_best[2])
+                                                   (fz->count & 4u) && PB * PB_WAVES * (uint32_t)KPL >= k && (KPL == 2 || k <= 64u) ? fz->bests + (size_t)qi * (SM_MAX_PB * PB_WAVES * 2u) : nullptr);
       }
     } else {
       // ---- role 3: a share of the sparse lists of query qi (a query without a sparse term has none: its workgroups leave, nobody
@@ -653,7 +654,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 4) bm25_small_kernel(const PbSm
     fz->tau[(size_t)qi * BM_TAU_STRIDE] = 0u;
     fz->arrive[qi] = 0u;
   }
-  for (uint32_t p_ = (uint32_t)lane; p_ < PB * PB_WAVES; p_ += 64u) fz->bests[(size_t)qi * (SM_MAX_PB * PB_WAVES) + p_] = 0ull;
+  for (uint32_t p_ = (uint32_t)lane; p_ < PB * PB_WAVES * (uint32_t)KPL; p_ += 64u) fz->bests[(size_t)qi * (SM_MAX_PB * PB_WAVES * 2u) + p_] = 0ull;
   __threadfence_system();  // the answers (host memory) before the flag
   if (lane == 0) {
     const uint32_t done = atomicAdd(&fz->arrive[SM_MAX_Q], 1u);
@@ -667,7 +668,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 4) bm25_small_kernel(const PbSm
 // ---------------------------------------------------------------- host side
 size_t ssi_bm25_small_ws_bytes() {
   return (size_t)SM_MAX_Q * SM_MAX_PB * 128u * sizeof(u64) + SM_MAX_Q * sizeof(u64) + (size_t)SM_MAX_Q * BM_TAU_STRIDE * 4u + (SM_MAX_Q + 1u) * 4u + 64u +
-         (size_t)SM_MAX_Q * SM_MAX_PB * PB_WAVES * sizeof(u64) + 8u;
+         (size_t)SM_MAX_Q * SM_MAX_PB * PB_WAVES * 2u * sizeof(u64) + 8u;
 }
 
 // can this batch take the one-launch path?  (the caller has classified its queries: ss_api.hip bm25_small_try)
@@ -768,7 +769,12 @@ int ssi_bm25_small_launch(ss_shard* s, void* ws, uint32_t nq, const ss_bm25_quer
   // bit 2: the query's threshold from the partitions' best keys (pb_publish_kth_best).  From 16 queries per call on: 64 queries 164 -> 105 us,
   // 32 queries 112 -> 87 us; a call of 1 / 8 queries -- 512 partitions per query, a handful of groups each -- pays 6 / 13 us for the
   // re-computations and gains nothing (tools/probes/small_fused.py, profiles/r5_small_kth_best.log)
-  const bool use_bests = nq >= 16u;
+  // 64 < k <= 128 (two keys a partition, pb_publish_kth_best2), C2 unions at k = 100, ms per host-pointer call without / with it:
+  // 8 queries 0.247 / 0.220, 16 0.294 / 0.192, 32 0.334 / 0.214, 64 0.449 / 0.233; one query 0.222 either way (profiles/r6i_k100_bests2.log)
+#ifndef SM_BESTS2_FROM
+#define SM_BESTS2_FROM 8u
+#endif
+  const bool use_bests = k <= 64u ? nq >= 16u : nq >= SM_BESTS2_FROM;
   a.count = (sh.want_counts ? 1u : 0u) | (use_bests ? 4u : 0u);
   a.seq = seq;
   a.out_doc = out_doc; a.out_score = out_score; a.out_count = out_count; a.out_total = (unsigned long long*)out_total; a.flag = flag;
