@@ -627,12 +627,27 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 4) bm25_small_kernel(const PbSm
 #pragma unroll
     for (int r = 0; r < KPL; r++) F.keys[r] = 0ull;
     F.worst = 0ull; F.wsc = -1.0f; F.matched = 0;
+    // Every list costs KPL full 64-key merges when most of its keys beat the running k-th -- a single query's 64 lists made 150 us of its
+    // 200 at k = 100.  The lists arrive SORTED: the k-th largest of their best two keys (<= 128 values, one list per lane) is a key k keys
+    // of the answer reach, so nothing below it needs a look -- what is left of a list is the one or two keys it really contributes.
+    // (one C2 query end to end, old / new: k = 33 130 / 109 us, 64 152 / 126, 65 200 / 160, 100 217 / 187, 128 232 / 225; the same bound in
+    // the workgroups' own merge of their eight lists gains nothing: profiles/r6j_final_merge_bound.log)
+    u64 bound = 0ull;
+    if (PB * 2u >= k) {
+      const u64* lst = lists + (size_t)min((uint32_t)lane, PB - 1u) * KS;
+      const u64 b0 = (uint32_t)lane < PB ? ldk(lst) : 0ull, b1 = (uint32_t)lane < PB ? ldk(lst + 1) : 0ull;  // ranks 0 and 1 of list `lane`
+      u64 kk2[2] = {0ull, 0ull};
+      (void)topk_merge64<2>(kk2, b0, 128u, lane);
+      (void)topk_merge64<2>(kk2, b1, 128u, lane);
+      bound = k <= 64u ? rdlane64(kk2[0], (int)k - 1) : rdlane64(kk2[1], (int)k - 65);
+    }
 #pragma unroll 1
     for (uint32_t p = 0; p < PB; p++) {  // (k > 32: the host sends no tiered query here)
 #pragma unroll
       for (int r = 0; r < KPL; r++) {
         const u64 key = ldk(lists + (size_t)p * KS + (uint32_t)r * 64u + (uint32_t)lane);
-        if (__ballot(key > F.worst)) F = bm_offer_lane_keys<KPL>(F, key > F.worst ? key : 0ull, k, nullptr);
+        const bool c = key > F.worst && key >= bound;
+        if (__ballot(c)) F = bm_offer_lane_keys<KPL>(F, c ? key : 0ull, k, nullptr);
       }
     }
 #pragma unroll
