@@ -375,3 +375,34 @@ def test_device_pointer_entries_page_deep_too(S, O):
     assert np.array_equal(vdoc.cpu().numpy().view(np.uint32), wd) and np.array_equal(vscore.cpu().numpy(), ws)
     assert np.array_equal(vcnt.cpu().numpy().view(np.uint32), wc) and int(wc.min()) == kv
     sv.close()
+
+
+def test_vector_deep_pages_under_ann_modes(S, O):
+    """Nprobe / NprobeSimilaritythreshold with k > SS_MAX_K (vector.rs:1300-1392): the passes re-select the same clusters, pass 0 reports
+    them; integer dots are exact, so the whole page is the oracle's -- including the queries whose clusters hold fewer records than k"""
+    from test_gpu_ann import clustered, queries_near
+    lc = [6, 9]
+    rows32, child = clustered(O, 77, lc, 64, lo=500, hi=1400)
+    rows = O.quantize_i8(rows32)
+    qs = O.quantize_i8(queries_near(O, rows32, 78, 6))
+    sh = S.Shard(0)
+    sh.upload_vectors_i8(rows)
+    sh.set_clusters(lc, child)
+    gone = [int(x) for x in range(7, len(rows), 301)]
+    sh.set_deleted(gone)
+    k = 2600
+    for am, kw in ((S.AnnMode.Nprobe(2), dict(n_probe=2)), (S.AnnMode.Nprobe(4), dict(n_probe=4))):
+        doc, score, cnt, tot, ncl = sh.search_vector_batch_i8(qs, k, ann_mode=am, with_clusters=True)
+        deep_seen = 0
+        for i in range(len(qs)):
+            od, os_, otot, oobs, oncl = O.vec_search_i8_ann(rows, qs[i], k, lc, child, deleted=gone, **kw)
+            assert ncl[i] == oncl and cnt[i] == len(od), (i, int(ncl[i]), oncl, int(cnt[i]), len(od))
+            assert np.array_equal(score[i][:cnt[i]], os_)
+            if len(od):
+                kth = os_[-1]
+                assert {int(x) for x, y in zip(doc[i][:cnt[i]], score[i]) if y > kth} == {int(x) for x, y in zip(od, os_) if y > kth}
+            _rows_well_formed(doc[i], score[i], cnt[i], k)
+            assert not set(map(int, doc[i][:int(cnt[i])])) & set(gone)
+            deep_seen += int(cnt[i]) > 1024
+        assert deep_seen >= 3  # (pages that really took more than one pass)
+    sh.close()
