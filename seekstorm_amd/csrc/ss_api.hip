@@ -3025,6 +3025,20 @@ static int vec_search_deep_locked(ss_shard* s, uint32_t nq, const void* queries,
     for (uint32_t i = 0; i < nb; i++) {
       for (uint32_t r = got[i]; r < k; r++) { out_doc[(size_t)(g0 + i) * k + r] = SS_NO_DOC; out_score[(size_t)(g0 + i) * k + r] = 0.f; }
       out_count[g0 + i] = got[i];
+      // f32 Euclidean: a pass is CUT by the scan's MFMA form of the distance and ordered by the rescored values (the reference's summation
+      // order) -- across a seam the last of one pass and the first of the next may stand the other way round by a rounding: one stable sort
+      if (s->vec_similarity == SS_SIM_EUCLIDEAN && elem == sizeof(float) && got[i] > SS_MAX_K) {
+        uint32_t* dd = out_doc + (size_t)(g0 + i) * k;
+        float* ss = out_score + (size_t)(g0 + i) * k;
+        std::vector<uint32_t> order(got[i]);
+        for (uint32_t r = 0; r < got[i]; r++) order[r] = r;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ss[a] > ss[b]; });
+        std::vector<uint32_t> d2(got[i]);
+        std::vector<float> s2(got[i]);
+        for (uint32_t r = 0; r < got[i]; r++) { d2[r] = dd[order[r]]; s2[r] = ss[order[r]]; }
+        memcpy(dd, d2.data(), (size_t)got[i] * 4);
+        memcpy(ss, s2.data(), (size_t)got[i] * 4);
+      }
     }
   }
   return SS_OK;

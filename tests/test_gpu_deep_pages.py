@@ -406,3 +406,20 @@ def test_vector_deep_pages_under_ann_modes(S, O):
             deep_seen += int(cnt[i]) > 1024
         assert deep_seen >= 3  # (pages that really took more than one pass)
     sh.close()
+
+
+def test_vector_deep_page_euclidean_f32(S, O):
+    """f32 Euclidean: the scan ranks by the MFMA form of the distance and the kept records are rescored in the reference's summation order
+    (vec_rescore_euclid_kernel) -- pass by pass; the page must still be one descending list and meet the oracle's within the tolerance"""
+    n_rows, dim, k = 9_000, 96, 2300
+    rows = O.vec_gen(O.VEC_SEED, 0, n_rows, dim, normalize=False) * np.float32(40.0)
+    qs = O.vec_gen(O.VECQ_SEED, 0, 3, dim, normalize=False) * np.float32(40.0)
+    sh = S.Shard(0)
+    sh.set_vector_similarity("euclidean")
+    sh.upload_vectors(rows)
+    doc, score, cnt, tot = sh.search_vector_batch(qs, k)
+    for i in range(3):
+        od, os_, *_ = O.vec_search_euclid(rows, qs[i], k, simd_order=True)
+        assert cnt[i] == len(od) == k
+        _check_vec(doc[i], score[i], cnt[i], od, os_, k, 1e-5 * 1600)
+    sh.close()
