@@ -308,8 +308,9 @@ int ss_bm25_fields_info(ss_shard* s, uint32_t* n_fields, uint32_t* merged_lists,
  * sparse list scored in full by binary-search probes of the query's other lists (north_star's galloping, intersection.rs:352-362),
  * the two lists merged per query; intersections -- the shortest sparse list drives.  Exact counts, tombstones, NOT terms
  * (a union that excludes a SPARSE term is answered on its own, under an exclusion bitmap = tombstones | the list's docs), facet
- * filters, k <= SS_MAX_K, phrases (ss_bm25_append_sparse_positions), field filters of intersections, single terms and phrases (a UNION
- * of several terms under a field filter that names a sparse term: SS_ENOTSUP).  The device-pointer entry points take
+ * filters, any k (beyond SS_MAX_K in passes), phrases (ss_bm25_append_sparse_positions), field filters of intersections, single terms,
+ * phrases and unions (a UNION of several terms under a field filter that names a sparse term is composed from the reference's own
+ * sub-queries up to 10 terms and follows its union_scan rule beyond).  The device-pointer entry points take
  * sparse terms when ops_mask bit 28 says so (one host round trip).  ss_bm25_term_df covers the sparse ids. */
 int ss_bm25_append_sparse(ss_shard* s, uint32_t n_lists, const uint64_t* offs, const uint32_t* docs, const uint16_t* tfs,
                           uint32_t* first_term_id_out);
